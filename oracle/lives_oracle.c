@@ -1,0 +1,737 @@
+/* lives_oracle.c -- CPU restatement of the LiVES per-frame hot path (see lives_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or called from the product.
+ *
+ * Written from the behaviour of the reference (file:line cited per function), not copied from it.
+ * Integer / byte work is meant to be bit-identical to the reference; the places where the reference
+ * invokes undefined behaviour are listed in DESIGN.md ("Reference quirks") with the decision taken.
+ */
+#include "lives_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * conversion tables                                      reference: src/colourspace.c:851-1105
+ * constants                                              reference: src/colourspace.h:50-63,86-131
+ * ---------------------------------------------------------------------------------------------- */
+#define SCALE 65793.            /* (2^24 - 1) / (2^8 - 1) */
+#define Y_LO 16.
+#define Y_HI 235.
+#define UV_HI 240.
+#define BIAS 128.
+
+static inline int rnd_half_away(double n) { return n >= 0. ? (int)(n + 0.5) : (int)(n - 0.5); }   /* src/maths.h:118 */
+
+static int32_t T_r2y[4][9][256], T_y2r[4][5][256];
+static int tables_ready = 0;
+
+static void build_tables(void) {
+  /* clamp factors are parenthesised constants in the reference (colourspace.h:117-118) */
+  const double cfy = (Y_HI - Y_LO) / (255. - 0.), cfuv = (UV_HI - Y_LO) / (255. - 0.);
+  for (int which = 0; which < 4; which++) {
+    const int unclamped = which & 1, hd = which & 2;
+    const double kr = hd ? 0.2126 : 0.299, kb = hd ? 0.0722 : 0.114;
+    int32_t (*f)[256] = T_r2y[which], (*b)[256] = T_y2r[which];
+    for (int i = 0; i < 256; i++) {
+      const double x = (double)i;
+      double fac;
+      if (!unclamped) {
+        f[0][i] = rnd_half_away(kr * x * cfy * SCALE);
+        f[1][i] = rnd_half_away((1. - kr - kb) * x * cfy * SCALE);
+        f[2][i] = rnd_half_away((kb * x * cfy + Y_LO) * SCALE);
+        fac = .5 / (1. - kb);
+        f[3][i] = rnd_half_away(-fac * kr * x * cfuv * SCALE);
+        f[4][i] = rnd_half_away(-fac * (1. - kb - kr) * x * cfuv * SCALE);
+        f[5][i] = rnd_half_away((0.5 * x * cfuv + BIAS) * SCALE);
+        fac = .5 / (1. - kr);
+        f[6][i] = rnd_half_away((0.5 * x * cfuv + BIAS) * SCALE);
+        f[7][i] = rnd_half_away(-fac * (1. - kb - kr) * x * cfuv * SCALE);
+        f[8][i] = rnd_half_away(-fac * kb * x * cfuv * SCALE);
+      } else {
+        f[0][i] = rnd_half_away(kr * x * SCALE);
+        f[1][i] = rnd_half_away((1. - kr - kb) * x * SCALE);
+        f[2][i] = rnd_half_away(kb * x * SCALE);
+        fac = .5 / (1. - kb);
+        f[3][i] = rnd_half_away(-fac * kr * x * SCALE);
+        f[4][i] = rnd_half_away(-fac * (1. - kb - kr) * x * SCALE);
+        f[5][i] = rnd_half_away((0.5 * x + BIAS) * SCALE);
+        fac = .5 / (1. - kr);
+        f[6][i] = rnd_half_away((0.5 * x + BIAS) * SCALE);
+        f[7][i] = rnd_half_away(-fac * (1. - kb - kr) * x * SCALE);
+        f[8][i] = rnd_half_away(-fac * kb * x * SCALE);
+      }
+    }
+    /* YUV -> RGB.  The G_Cb divisor is (1 + Kb + Kr) for YCbCr but (1 + Kb + Kb) for BT.709
+       (src/colourspace.c:1017 vs :1061) -- replicated. */
+    const double gcb_div = hd ? (1. + kb + kb) : (1. + kb + kr);
+    for (int i = 0; i < 256; i++) {
+      const double x = (double)i;
+      if (unclamped) {
+        b[0][i] = (int32_t)(i * SCALE);
+        b[1][i] = rnd_half_away(2. * (1. - kr) * (x - BIAS) * SCALE);
+        b[2][i] = rnd_half_away(-.5 / gcb_div * (x - BIAS) * SCALE);
+        b[3][i] = rnd_half_away(-.5 / (1. - kr) * (x - BIAS) * SCALE);
+        b[4][i] = rnd_half_away(2. * (1. - kb) * (x - BIAS) * SCALE);
+        continue;
+      }
+      /* luma: 0 up to 16, ramp to 234, saturate from 235 */
+      if (i <= 16) b[0][i] = 0;
+      else if (i < 235) b[0][i] = rnd_half_away((x - Y_LO) / (Y_HI - Y_LO) * 255. * SCALE);
+      else b[0][i] = (int32_t)(255 * SCALE);
+      if (i <= 16) b[1][i] = b[2][i] = b[3][i] = b[4][i] = 0;
+      else {
+        double c;
+        if (i < 240) c = ((x - Y_LO) / (UV_HI - Y_LO) * 255.) - BIAS;
+        else c = hd ? (255. - BIAS) : (((UV_HI - Y_LO) / (UV_HI - Y_LO) * 255.) - BIAS);
+        b[1][i] = rnd_half_away(2. * (1. - kr) * c * SCALE);
+        b[2][i] = rnd_half_away(-.5 / gcb_div * c * SCALE);
+        b[3][i] = rnd_half_away(-.5 / (1. - kr) * c * SCALE);
+        b[4][i] = rnd_half_away(2. * (1. - kb) * c * SCALE);
+      }
+    }
+  }
+  tables_ready = 1;
+}
+
+void orc_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb) {
+  if (!tables_ready) build_tables();
+  if (rgb2yuv) memcpy(rgb2yuv, T_r2y[which & 3], sizeof(T_r2y[0]));
+  if (yuv2rgb) memcpy(yuv2rgb, T_y2r[which & 3], sizeof(T_y2r[0]));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * gamma LUT builder                                      reference: src/colourspace.c:655-736
+ * gamma constants                                        reference: src/colourspace.h:152-185
+ * Deterministic quirks kept on purpose: X->LINEAR is the identity; the source gamma is
+ * forgotten after the first table entry; the encode branch tops out at 246.
+ * ---------------------------------------------------------------------------------------------- */
+enum { G_UNKNOWN = 0, G_LINEAR = 1, G_SRGB = 2, G_BT709 = 3, G_MONITOR = 1024 };
+typedef struct { float offs, lin, thresh, pf; } gconst_t;
+
+static gconst_t gconst_for(int gtype) {
+  gconst_t g;
+  if (gtype == G_BT709) { g.lin = 4.5; g.thresh = 0.018; g.pf = 1. / .45; }
+  else { g.lin = 12.92; g.thresh = 0.04045; g.pf = 2.4; }     /* sRGB; also used for unknown ids (index 0) */
+  g.offs = (powf((g.thresh / g.lin), (1. / g.pf)) - g.thresh) / (1. - (powf((g.thresh / g.lin), (1. / g.pf))));
+  return g;
+}
+
+static inline uint8_t clamp_int_0_255(int n) { return n < 0 ? 0 : n > 255 ? 255 : (uint8_t)n; }
+
+int orc_gamma_lut8(double fileg, int gamma_from, int gamma_to, double screen_gamma, uint8_t *lut) {
+  float inv_gamma = 0., a, x = 0.;
+  if (fileg == 1.0 && (gamma_to == gamma_from || gamma_to == G_UNKNOWN || gamma_from == G_UNKNOWN)) return 0;
+  if (gamma_to == G_MONITOR) inv_gamma = 1. / (float)screen_gamma;
+  lut[0] = 0;
+  for (int i = 1; i < 256; ++i) {
+    x = a = (float)i / 255.;
+    if (fileg != 1.0) x = powf(a, fileg);
+    if (gamma_from == G_MONITOR) { x = powf(a, screen_gamma); gamma_from = G_SRGB; }
+    if (gamma_from != G_LINEAR && !(gamma_from == G_SRGB && gamma_to == G_MONITOR)) {
+      const gconst_t g = gconst_for(gamma_from);
+      a = (a < g.thresh) ? a / g.lin : powf((a + g.offs) / (1. + g.offs), g.pf);
+      gamma_from = G_LINEAR;          /* sticks for every later entry */
+    }
+    if (gamma_to != G_LINEAR) {
+      const gconst_t g = gconst_for(gamma_to == G_MONITOR ? G_SRGB : gamma_to);
+      x = (a < (g.thresh) / g.lin) ? a * g.lin : powf((1. + g.offs) * a, 1. / g.pf) - g.offs;
+    }
+    if (gamma_to == G_MONITOR) x = powf(a, inv_gamma);
+    lut[i] = clamp_int_0_255((int)(x * 255.));
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * alpha pre-multiply tables                              reference: src/colourspace.c:1141-1160
+ * CLAMP0255f                                             reference: src/maths.h:88
+ * ---------------------------------------------------------------------------------------------- */
+static inline int clamp_round_f(float a) {
+  if (a != a) return 0;                     /* 0 * inf at alpha == 0: x86-64 gcc yields 0 (fixture-pinned) */
+  return a >= 254.5 ? 255 : a < -0.5 ? 0 : (uint8_t)(a + .5);
+}
+int orc_unal(int alpha, int v) { float al = (float)255. / (float)alpha; return clamp_round_f((float)v / al); }
+int orc_al(int alpha, int v) { float al = (float)255. / (float)alpha; return clamp_round_f((float)v * al); }
+
+void orc_alpha_premult(uint8_t *pix, int rowstride, int width, int height, int alpha_first, int un) {
+  /* src/colourspace.c:12063-12082: RGBA/BGRA colour bytes 0..2, alpha 3; ARGB colour bytes 1..3, alpha 0 */
+  const int aoffs = alpha_first ? 0 : 3, c0 = alpha_first ? 1 : 0;
+  for (int i = 0; i < height; i++) {
+    uint8_t *p = pix + (size_t)i * rowstride;
+    for (int j = 0; j < width * 4; j += 4) {
+      const int alpha = p[j + aoffs];
+      for (int c = c0; c < c0 + 3; c++) p[j + c] = (uint8_t)(un ? orc_unal(alpha, p[j + c]) : orc_al(alpha, p[j + c]));
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K1: packed RGB swizzles                                reference: src/colourspace.c:9259-10577
+ * Each op is a per-pixel byte selection; 0xFF in the selector means "constant 255" (new alpha).
+ * The gamma LUT touches colour bytes only.  swapprepost / swap4 follow the evident intent
+ * (RGBA<->ARGB rotate, BGRA<->ARGB reverse): several of the reference bodies corrupt memory or
+ * mis-order bytes (DESIGN.md quirk list).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int ibpp, obpp; uint8_t sel[4]; uint8_t is_alpha[4]; } swz_t;
+
+static swz_t swz_for(int op, int alpha_first) {
+  swz_t s; memset(&s, 0, sizeof s);
+#define SET(ib, ob, a, b, c, d) do { s.ibpp = ib; s.obpp = ob; s.sel[0] = a; s.sel[1] = b; s.sel[2] = c; s.sel[3] = d; } while (0)
+  switch (op) {
+  case ORC_SWAP3: SET(3, 3, 2, 1, 0, 0); break;
+  case ORC_SWAP4:
+    SET(4, 4, 3, 2, 1, 0);
+    if (alpha_first) s.is_alpha[3] = 1; else s.is_alpha[0] = 1;     /* in ARGB -> out BGRA ; in BGRA -> out ARGB */
+    break;
+  case ORC_SWAP3ADDPOST: SET(3, 4, 2, 1, 0, 0xFF); break;
+  case ORC_SWAP3ADDPRE: SET(3, 4, 0xFF, 2, 1, 0); break;
+  case ORC_SWAP3POSTALPHA: SET(4, 4, 2, 1, 0, 3); s.is_alpha[3] = 1; break;
+  case ORC_SWAP3PREALPHA: SET(4, 4, 0, 3, 2, 1); s.is_alpha[0] = 1; break;
+  case ORC_ADDPOST: SET(3, 4, 0, 1, 2, 0xFF); break;
+  case ORC_ADDPRE: SET(3, 4, 0xFF, 0, 1, 2); break;
+  case ORC_SWAP3DELPOST: SET(4, 3, 2, 1, 0, 0); break;
+  case ORC_DELPOST: SET(4, 3, 0, 1, 2, 0); break;
+  case ORC_DELPRE: SET(4, 3, 1, 2, 3, 0); break;
+  case ORC_SWAP3DELPRE: SET(4, 3, 3, 2, 1, 0); break;
+  case ORC_SWAPPREPOST:
+    if (alpha_first) { SET(4, 4, 1, 2, 3, 0); s.is_alpha[3] = 1; }   /* ARGB -> RGBA */
+    else { SET(4, 4, 3, 0, 1, 2); s.is_alpha[0] = 1; }               /* RGBA -> ARGB */
+    break;
+  default: s.ibpp = 0;
+  }
+#undef SET
+  return s;
+}
+
+int orc_swizzle(int op, int alpha_first, const uint8_t *src, int irow, uint8_t *dst, int orow,
+                int width, int height, const uint8_t *lut8) {
+  const swz_t s = swz_for(op, alpha_first);
+  if (!s.ibpp) return -1;
+  for (int y = 0; y < height; y++) {
+    const uint8_t *ip = src + (size_t)y * irow;
+    uint8_t *op_ = dst + (size_t)y * orow;
+    for (int x = 0; x < width; x++, ip += s.ibpp, op_ += s.obpp) {
+      uint8_t in[4] = {ip[0], ip[1], ip[2], s.ibpp == 4 ? ip[3] : 0}, out[4];
+      for (int k = 0; k < s.obpp; k++) {
+        if (s.sel[k] == 0xFF) out[k] = 255;
+        else if (s.is_alpha[k] || !lut8) out[k] = in[s.sel[k]];
+        else out[k] = lut8[in[s.sel[k]]];
+      }
+      memcpy(op_, out, s.obpp);      /* after reading: in-place safe for equal bpp */
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K6: gamma apply                                        reference: src/colourspace.c:14034-14060
+ * ---------------------------------------------------------------------------------------------- */
+void orc_gamma_apply(uint8_t *pix, int rowstride, int width, int height, int psize, int alpha_first,
+                     const uint8_t *lut8) {
+  const int ncol = psize < 3 ? psize : 3, start = alpha_first ? 1 : 0;
+  if (!lut8) return;
+  for (int y = 0; y < height; y++) {
+    uint8_t *p = pix + (size_t)y * rowstride + start;
+    for (int x = 0; x < width; x++, p += psize)
+      for (int c = 0; c < ncol; c++) p[c] = lut8[p[c]];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K2: YUV420P / YUV422P -> RGB                           reference: src/colourspace.c:3260-3904
+ * per-pixel maths                                        reference: src/colourspace.c:2351-2356, :832-843
+ * chroma clamp macros                                    reference: src/colourspace.h:19-23
+ * ---------------------------------------------------------------------------------------------- */
+static inline int clamp_uv_c(int n) {          /* CLAMP16_240 */
+  if (n < 0) return 16;
+  if (n > 255 || (n & 0xF0) == 0xF0) return 240;
+  return (n & 0xF0) ? n : 16;
+}
+static inline int clamp_uv_u(int n) { return n < 0 ? 0 : n > 255 ? 255 : n; }   /* CLAMP0_255 */
+
+static inline int fix_shift(int32_t v, int quality) {         /* _spc_rnd */
+  if (quality != 3) return v >> 16;
+  return (int32_t)((float)v / 65536.);
+}
+
+typedef struct {
+  const int32_t *ty, *rcr, *gcb, *gcr, *bcb;
+  const uint8_t *lut8;
+  int quality, opsize, order, clamped;
+} yuvctx_t;
+
+static inline void put_px(const yuvctx_t *c, uint8_t *d, int y, int u, int v) {
+  const int32_t yy = c->ty[y];
+  uint8_t r = clamp_int_0_255(fix_shift(yy + c->rcr[v], c->quality));
+  uint8_t g = clamp_int_0_255(fix_shift(yy + c->gcb[u] + c->gcr[v], c->quality));
+  uint8_t b = clamp_int_0_255(fix_shift(yy + c->bcb[u], c->quality));
+  if (c->lut8) { r = c->lut8[r]; g = c->lut8[g]; b = c->lut8[b]; }
+  switch (c->order) {
+  case 0: d[0] = r; d[1] = g; d[2] = b; if (c->opsize == 4) d[3] = 255; break;
+  case 1: d[0] = b; d[1] = g; d[2] = r; if (c->opsize == 4) d[3] = 255; break;
+  default: d[0] = 255; d[1] = r; d[2] = g; d[3] = b; break;
+  }
+}
+
+static inline int cuv(const yuvctx_t *c, int n) { return c->clamped ? clamp_uv_c(n) : clamp_uv_u(n); }
+
+/* (2a + b) / 3 and (a + 2b) / 3 on doubled sums: (int)(s / 3. + .5) == (s + 1) / 3 for s >= 0 */
+static inline void vblend(const yuvctx_t *c, int s1, int s2, int *top, int *bot) {
+  if (c->quality != 1) {
+    *top = cuv(c, (s1 + (s2 >> 1) + 1) / 3);
+    *bot = cuv(c, ((s1 >> 1) + s2 + 1) / 3);
+  } else { *top = cuv(c, s1 >> 1); *bot = cuv(c, s2 >> 1); }
+}
+
+int orc_yuv420p_to_rgb(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
+                       long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
+                       int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                       const uint8_t *lut8, int fix_edges) {
+  yuvctx_t c;
+  const int ys = istrides[0], us = istrides[1], vs = istrides[2], hw = width >> 1;
+  if (!tables_ready) build_tables();
+  if ((width & 1) || width < 2 || height < 1) return -1;
+  c.ty = T_y2r[which_tables & 3][0]; c.rcr = T_y2r[which_tables & 3][1]; c.gcb = T_y2r[which_tables & 3][2];
+  c.gcr = T_y2r[which_tables & 3][3]; c.bcb = T_y2r[which_tables & 3][4];
+  c.lut8 = lut8; c.quality = pb_quality; c.opsize = (out_order == 2) ? 4 : opsize; c.order = out_order;
+  c.clamped = !(which_tables & 1);
+  const int ops = c.opsize;
+  /* plane fetch with the index held inside the plane (the reference reads one sample past the row
+     end for the right-hand pixel of the last pair: next row's first sample, or past the plane) */
+#define PU(r, k) (u[((long)(r) * us + (k)) < u_size ? ((long)(r) * us + (k)) : u_size - 1])
+#define PV(r, k) (v[((long)(r) * vs + (k)) < v_size ? ((long)(r) * vs + (k)) : v_size - 1])
+
+  if (is_422) {
+    /* :3593-3640 (clamped) / :3858-3901 (unclamped): row i, "last/this" seeded from chroma row i>>1 */
+    for (int i = 0; i < height; i++) {
+      int lu = PU(i >> 1, 0), lv = PV(i >> 1, 0), tu = lu, tv = lv;
+      uint8_t *d = dst + (size_t)i * orow;
+      for (int k = 0; k < hw; k++) {
+        const int nu = PU(i, k + 1), nv = PV(i, k + 1);
+        put_px(&c, d + (2 * k) * ops, y[(size_t)i * ys + 2 * k], cuv(&c, (tu + lu) >> 1), cuv(&c, (tv + lv) >> 1));
+        put_px(&c, d + (2 * k + 1) * ops, y[(size_t)i * ys + 2 * k + 1], cuv(&c, (tu + nu) >> 1), cuv(&c, (tv + nv) >> 1));
+        lu = tu; lv = tv; tu = nu; tv = nv;
+      }
+    }
+    return 0;
+  }
+
+  /* row 0 (:3399-3443): left pixel of each pair averages this and previous chroma sample.  The right
+     pixel indexes the tables with an un-halved sum in the reference (undefined) -> evident intent. */
+  for (int k = 0; k < hw; k++) {
+    const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
+    put_px(&c, dst + (2 * k) * ops, y[2 * k], cuv(&c, (PU(0, k) + PU(0, kp)) >> 1), cuv(&c, (PV(0, k) + PV(0, kp)) >> 1));
+    put_px(&c, dst + (2 * k + 1) * ops, y[2 * k + 1], cuv(&c, (PU(0, k) + PU(0, kn)) >> 1), cuv(&c, (PV(0, k) + PV(0, kn)) >> 1));
+  }
+
+  /* rows 1..h-2 in pairs (i, i+1) between chroma rows r and r+1 (:3445-3554) */
+  int i;
+  for (i = 1; i < height - 1; i += 2) {
+    const int r = i >> 1;
+    uint8_t *d0 = dst + (size_t)i * orow, *d1 = d0 + orow;
+    const uint8_t *y0 = y + (size_t)i * ys, *y1 = y0 + ys;
+    for (int k = 0; k < hw; k++) {
+      int s1, s2, t, b, tv_, bv_;
+      /* left pixel: the reference builds the second-row U sum from the FIRST row (:3461), pairs V of
+         row r with the previous V of row r+1 (:3544 stores this_v2 into last_v1) and never advances
+         last_v2 from column 0 -- all deterministic, all replicated */
+      const int lu1 = k ? PU(r, k - 1) : PU(r, 0);
+      const int lv1 = k ? PV(r + 1, k - 1) : PV(r, 0);
+      const int lv2 = PV(r + 1, 0);
+      s1 = PU(r, k) + lu1; s2 = s1;
+      vblend(&c, s1, s2, &t, &b);
+      s1 = PV(r, k) + lv1; s2 = PV(r + 1, k) + lv2;
+      vblend(&c, s1, s2, &tv_, &bv_);
+      put_px(&c, d0 + (2 * k) * ops, y0[2 * k], t, tv_);
+      put_px(&c, d1 + (2 * k) * ops, y1[2 * k], b, bv_);
+      /* right pixel: this + next on both chroma rows */
+      s1 = PU(r, k) + PU(r, k + 1); s2 = PU(r + 1, k) + PU(r + 1, k + 1);
+      vblend(&c, s1, s2, &t, &b);
+      s1 = PV(r, k) + PV(r, k + 1); s2 = PV(r + 1, k) + PV(r + 1, k + 1);
+      vblend(&c, s1, s2, &tv_, &bv_);
+      put_px(&c, d0 + (2 * k + 1) * ops, y0[2 * k + 1], t, tv_);
+      put_px(&c, d1 + (2 * k + 1) * ops, y1[2 * k + 1], b, bv_);
+    }
+  }
+
+  /* trailing row (:3556-3592).  Reference, 1 thread: luma is taken from ROW 0, "next" chroma from
+     chroma row 0, the right-hand pixels land in row 0 (undefined values) and the last row's odd
+     pixels are never written.  fix_edges == 0 keeps the deterministic part of that (even x). */
+  if (i < height) {
+    const int r = i >> 1;
+    uint8_t *d = dst + (size_t)i * orow;
+    if (!fix_edges) {
+      int lu = PU(r, 0), lv = PV(r, 0), tu = lu, tv = lv;
+      for (int k = 0; k < hw; k++) {
+        const int kn = (k + 1 < hw) ? k + 1 : hw - 1;
+        put_px(&c, d + (2 * k) * ops, y[2 * k], cuv(&c, (tu + lu) >> 1), cuv(&c, (tv + lv) >> 1));
+        /* odd x: unwritten by the reference -> evident intent */
+        put_px(&c, d + (2 * k + 1) * ops, y[(size_t)i * ys + 2 * k + 1],
+               cuv(&c, (PU(r, k) + PU(r, kn)) >> 1), cuv(&c, (PV(r, k) + PV(r, kn)) >> 1));
+        lu = tu; lv = tv; tu = PU(0, k + 1); tv = PV(0, k + 1);
+      }
+    } else {
+      for (int k = 0; k < hw; k++) {
+        const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
+        put_px(&c, d + (2 * k) * ops, y[(size_t)i * ys + 2 * k],
+               cuv(&c, (PU(r, k) + PU(r, kp)) >> 1), cuv(&c, (PV(r, k) + PV(r, kp)) >> 1));
+        put_px(&c, d + (2 * k + 1) * ops, y[(size_t)i * ys + 2 * k + 1],
+               cuv(&c, (PU(r, k) + PU(r, kn)) >> 1), cuv(&c, (PV(r, k) + PV(r, kn)) >> 1));
+      }
+    }
+  }
+#undef PU
+#undef PV
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K8: letterbox                                          reference: src/colourspace.c:15343-15567
+ * black fill of `nwidth` pixels per row                  reference: src/colourspace.c:11109-11119
+ * ---------------------------------------------------------------------------------------------- */
+void orc_letterbox(const uint8_t *src, int irow, int width, int height, uint8_t *dst, int orow,
+                   int nwidth, int nheight, int psize, const uint8_t *black_pixel) {
+  const int ox = ((nwidth - width + 1) >> 1) * psize, oy = (nheight - height + 1) >> 1;
+  for (int y = 0; y < nheight; y++) {
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int x = 0; x < nwidth; x++) memcpy(d + x * psize, black_pixel, psize);
+  }
+  for (int y = 0; y < height; y++)
+    memcpy(dst + (size_t)(y + oy) * orow + ox, src + (size_t)y * irow, (size_t)width * psize);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * F1: chroma blend                    reference: lives-plugins/weed-plugins/simple_blend.c:29-33, :117-150
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint8_t mix8(int bf, int a2, int a1) { return (uint8_t)((bf * a2 + (255 - bf) * a1) >> 8); }
+
+void orc_blend_chroma(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow,
+                      int width, int height, int psize, int alpha_first, int bf) {
+  bf &= 0xFF;
+  for (int y = 0; y < height; y++) {
+    const uint8_t *a = src1 + (size_t)y * irow1, *b = src2 + (size_t)y * irow2;
+    uint8_t *d = dst + (size_t)y * orow;
+    if (psize == 3) {
+      for (int j = 0; j < width * 3; j++) d[j] = mix8(bf, b[j], a[j]);
+      continue;
+    }
+    /* 4-byte palettes: colour bytes j..j+2, "alpha" = byte j+3 of layer 2 (for ARGB, start = 1, that is the
+       NEXT pixel's alpha -- reference behaviour, kept).  dst alpha is never written. */
+    for (int j = alpha_first ? 1 : 0; j < width * 4; j += 4) {
+      const int al = b[j + 3];
+      if (al == 255) {
+        for (int c = 0; c < 3; c++) d[j + c] = mix8(bf, b[j + c], a[j + c]);
+      } else {
+        const float alpha = (float)al / 255., inv_alpha = 1. - alpha;
+        for (int c = 0; c < 3; c++)
+          d[j + c] = mix8(bf, (uint8_t)((float)b[j + c] * alpha), (uint8_t)((float)a[j + c] * inv_alpha));
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * luma of a pixel, 65536-scaled unclamped BT.601 tables  reference: libweed/weed-plugin-utils.c:879-895, :924-934
+ * ---------------------------------------------------------------------------------------------- */
+static int32_t L_r[256], L_g[256], L_b[256];
+static int luma_ready = 0;
+static void build_luma(void) {
+  for (int i = 0; i < 256; i++) {
+    L_r[i] = rnd_half_away(0.299 * (double)i * 65536.);
+    L_g[i] = rnd_half_away((1. - 0.299 - 0.114) * (double)i * 65536.);
+    L_b[i] = rnd_half_away(0.114 * (double)i * 65536.);
+  }
+  luma_ready = 1;
+}
+static inline uint8_t luma_of(const uint8_t *p, int order) {
+  switch (order) {
+  case 0: return (uint8_t)((L_r[p[0]] + L_g[p[1]] + L_b[p[2]]) >> 16);
+  case 1: return (uint8_t)((L_r[p[2]] + L_g[p[1]] + L_b[p[0]]) >> 16);
+  default: return (uint8_t)((L_r[p[1]] + L_g[p[2]] + L_b[p[3]]) >> 16);
+  }
+}
+
+/* F2: luma overlay family              reference: lives-plugins/weed-plugins/simple_blend.c:151-194
+   type 4 ("averaged luma overlay") never enters its 3x3 branch in the reference (`row` stays 0) and falls
+   through to type 1. */
+void orc_blend_luma(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst,
+                    int orow, int width, int height, int psize, int pal_order, int thresh, int inplace) {
+  const int bf = thresh & 0xFF, neg = 0xFF - bf;
+  if (!luma_ready) build_luma();
+  for (int y = 0; y < height; y++) {
+    const uint8_t *a = src1 + (size_t)y * irow1, *b = src2 + (size_t)y * irow2;
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int j = (pal_order == 2) ? 1 : 0; j < width * psize; j += psize) {
+      int take2;
+      switch (type) {
+      case 2: take2 = luma_of(b + j, pal_order) > neg; break;
+      case 3: take2 = luma_of(a + j, pal_order) > neg; break;
+      default: take2 = luma_of(a + j, pal_order) < bf; break;
+      }
+      if (take2) memcpy(d + j, b + j, 3);
+      else if (!inplace) memcpy(d + j, a + j, 3);
+    }
+  }
+}
+
+/* F3: multiply / screen / darken / lighten / overlay / dodge / burn
+                                        reference: lives-plugins/weed-plugins/multi_blends.c:24-168 */
+void orc_blend_multi(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst,
+                     int orow, int width, int height, int is_bgr, int bf) {
+  const uint8_t f = (uint8_t)bf;
+  const uint8_t b1 = (uint8_t)(f * 2), n1 = (uint8_t)(255 - f * 2), b2 = (uint8_t)((255 - f) * 2), n2 = (uint8_t)((f - 128) * 2);
+  if (!luma_ready) build_luma();
+  for (int y = 0; y < height; y++) {
+    const uint8_t *a = src1 + (size_t)y * irow1, *b = src2 + (size_t)y * irow2;
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int j = 0; j < width * 3; j += 3) {
+      uint8_t px[3];
+      int la, lb, v;
+      switch (type) {
+      case 0: for (int c = 0; c < 3; c++) px[c] = (uint8_t)((b[j + c] * a[j + c]) >> 8); break;
+      case 1: for (int c = 0; c < 3; c++) px[c] = (uint8_t)(255 - (((255 - b[j + c]) * (255 - a[j + c])) >> 8)); break;
+      case 2: la = luma_of(a + j, is_bgr); lb = luma_of(b + j, is_bgr); memcpy(px, (la <= lb) ? a + j : b + j, 3); break;
+      case 3: la = luma_of(a + j, is_bgr); lb = luma_of(b + j, is_bgr); memcpy(px, (la >= lb) ? a + j : b + j, 3); break;
+      case 4:
+        la = luma_of(a + j, is_bgr);
+        for (int c = 0; c < 3; c++)
+          px[c] = (la < 128) ? (uint8_t)((b[j + c] * a[j + c]) >> 8)
+                  : (uint8_t)(255 - (((255 - b[j + c]) * (255 - a[j + c])) >> 8));
+        break;
+      case 5:
+        for (int c = 0; c < 3; c++) {
+          if (b[j + c] == 255) px[c] = 255;
+          else { v = ((int)a[j + c] << 8) / (255 - b[j + c]); px[c] = v > 255 ? 255 : (uint8_t)v; }
+        }
+        break;
+      default:
+        for (int c = 0; c < 3; c++) {
+          if (b[j + c] == 0) px[c] = 0;
+          else { v = 255 - (255 - ((int)a[j + c] << 8)) / (int)b[j + c]; px[c] = v < 0 ? 0 : (uint8_t)v; }
+        }
+        break;
+      }
+      if (f < 128) for (int c = 0; c < 3; c++) d[j + c] = (uint8_t)((b1 * px[c] + n1 * a[j + c]) >> 8);
+      else for (int c = 0; c < 3; c++) d[j + c] = (uint8_t)((b2 * px[c] + n2 * b[j + c]) >> 8);
+    }
+  }
+}
+
+/* F4: colour key                       reference: lives-plugins/weed-plugins/scripts/colorkey.script <process> */
+void orc_colorkey(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1, uint8_t *dst, int orow,
+                  int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b,
+                  int inplace) {
+  double xdelta = delta * 2., opacx = 1. - opac;
+  int rmin, gmin, bmin, rmax, gmax, bmax;
+  delta /= 2.;
+  rmin = col_r - (int)(col_r * delta + .5);
+  gmin = col_g - (int)(col_g * xdelta + .5);
+  bmin = col_b - (int)(col_b * delta + .5);
+  xdelta *= 2.; delta *= 2.;
+  rmax = col_r + (int)((255 - col_r) * delta + .5);
+  gmax = col_g + (int)((255 - col_g) * xdelta + .5);
+  bmax = col_b + (int)((255 - col_b) * delta + .5);
+  for (int y = 0; y < height; y++) {
+    const uint8_t *a = src0 + (size_t)y * irow0, *b = src1 + (size_t)y * irow1;
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int j = 0; j < width * 3; j += 3) {
+      const int r = is_bgr ? a[j + 2] : a[j], g = a[j + 1], bl = is_bgr ? a[j] : a[j + 2];
+      if (r >= rmin && r <= rmax && g >= gmin && g <= gmax && bl >= bmin && bl <= bmax) {
+        for (int c = 0; c < 3; c++) d[j + c] = (uint8_t)(a[j + c] * opacx + b[j + c] * opac);
+      } else if (!inplace) memcpy(d + j, a + j, 3);
+    }
+  }
+}
+
+/* F5: mirrors                          reference: lives-plugins/weed-plugins/mirrors.c:26-122
+   The reference's stray writes (pixel `width` of each row for even widths, row `height`) are not
+   performed; rows / pixels it leaves unwritten in non-inplace mode get the in-place result. */
+static void mirror_x_rows(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize) {
+  const int hw = width >> 1;
+  for (int y = 0; y < height; y++) {
+    const uint8_t *s = src + (size_t)y * irow;
+    uint8_t *d = dst + (size_t)y * orow;
+    if (s != d) memcpy(d, s, (size_t)hw * psize);
+    for (int k = 0; k <= hw; k++) {
+      const int t = 2 * hw - k;
+      if (t < width) memmove(d + (size_t)t * psize, s + (size_t)k * psize, psize);
+    }
+  }
+}
+static void mirror_y_rows(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize) {
+  const int hh = height >> 1;
+  const size_t rb = (size_t)width * psize;
+  if (src != dst) for (int y = 0; y < height; y++) memcpy(dst + (size_t)y * orow, src + (size_t)y * irow, rb);
+  for (int i = 1; i < hh; i++) memcpy(dst + (size_t)(height - i) * orow, src + (size_t)i * irow, rb);
+}
+void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize) {
+  if (mode == 0) mirror_x_rows(src, irow, dst, orow, width, height, psize);
+  else if (mode == 1) mirror_y_rows(src, irow, dst, orow, width, height, psize);
+  else { mirror_y_rows(src, irow, dst, orow, width, height, psize); mirror_x_rows(dst, orow, dst, orow, width, height, psize); }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * R1: resize -- UNPINNED.  The reference hands this to FFmpeg libswscale (src/colourspace.c:14711,
+ * flags :14991-14997), which is neither vendored nor version-pinned.  Spec "lgpu-polyphase-v1"
+ * (DESIGN.md): separable polyphase FIR, horizontal then vertical, Q14 coefficients, 15-bit
+ * intermediate with 7 fractional bits, edge replicate, support widened by the downscale ratio.
+ * ---------------------------------------------------------------------------------------------- */
+static double kern_eval(int kernel, double x) {
+  x = fabs(x);
+  if (kernel == 0) {                     /* triangle */
+    return x < 1. ? 1. - x : 0.;
+  } else if (kernel == 1) {              /* cubic, B = 0, C = 0.6 */
+    const double B = 0., C = 0.6;
+    if (x < 1.) return ((12. - 9. * B - 6. * C) * x * x * x + (-18. + 12. * B + 6. * C) * x * x + (6. - 2. * B)) / 6.;
+    if (x < 2.) return ((-B - 6. * C) * x * x * x + (6. * B + 30. * C) * x * x + (-12. * B - 48. * C) * x + (8. * B + 24. * C)) / 6.;
+    return 0.;
+  } else {                               /* lanczos, a = 3 */
+    if (x < 1e-12) return 1.;
+    if (x >= 3.) return 0.;
+    const double px = M_PI * x;
+    return 3. * sin(px) * sin(px / 3.) / (px * px);
+  }
+}
+static double kern_radius(int kernel) { return kernel == 0 ? 1. : kernel == 1 ? 2. : 3.; }
+
+/* kernel: 0 triangle, 1 cubic(0, 0.6), 2 lanczos3.  pos[dstn], coef[dstn * ntaps].  returns 0 / -1 */
+int orc_make_filter(int srcn, int dstn, int kernel, int *ntaps_out, int32_t *pos, int16_t *coef, int maxtaps) {
+  const double ratio = (double)srcn / (double)dstn, scale = ratio > 1. ? ratio : 1.;
+  const double support = kern_radius(kernel) * scale;
+  const int ntaps = (int)ceil(2. * support);
+  double w[256];
+  if (ntaps > maxtaps || ntaps > 256) return -1;
+  *ntaps_out = ntaps;
+  for (int i = 0; i < dstn; i++) {
+    const double centre = ((double)i + 0.5) * ratio - 0.5;
+    const int left = (int)floor(centre - support) + 1;
+    double sum = 0.;
+    int q[256], qs = 0, big = 0;
+    for (int j = 0; j < ntaps; j++) { w[j] = kern_eval(kernel, ((double)(left + j) - centre) / scale); sum += w[j]; }
+    for (int j = 0; j < ntaps; j++) {
+      q[j] = (int)floor(w[j] / sum * 16384. + 0.5);
+      qs += q[j];
+      if (q[j] > q[big]) big = j;
+    }
+    q[big] += 16384 - qs;                /* rows sum to exactly 1.0 in Q14 */
+    pos[i] = left;
+    for (int j = 0; j < ntaps; j++) coef[(size_t)i * ntaps + j] = (int16_t)q[j];
+  }
+  return 0;
+}
+
+static int kernel_for(int interp, int upscale) {
+  /* LIVES_INTERP_BEST -> bicubic when shrinking, lanczos when enlarging; NORMAL/FAST -> bilinear
+     (src/colourspace.c:14991-14997; GdkInterpType values src/widget-helper-gtk.h:1136-1138) */
+  if (interp == ORC_INTERP_HYPER) return upscale ? 2 : 1;
+  return 0;
+}
+
+int orc_resize(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh,
+               int psize, int interp) {
+  const int kernel = kernel_for(interp, dw > sw || dh > sh);
+  int nth = 0, ntv = 0, rc = -1;
+  int32_t *hpos = malloc(sizeof(int32_t) * dw), *vpos = malloc(sizeof(int32_t) * dh);
+  int16_t *hco = malloc(sizeof(int16_t) * (size_t)dw * 256), *vco = malloc(sizeof(int16_t) * (size_t)dh * 256);
+  int16_t *tmp = malloc(sizeof(int16_t) * (size_t)sh * dw * psize);
+  if (!hpos || !vpos || !hco || !vco || !tmp) goto out;
+  if (orc_make_filter(sw, dw, kernel, &nth, hpos, hco, 256)) goto out;
+  if (orc_make_filter(sh, dh, kernel, &ntv, vpos, vco, 256)) goto out;
+  for (int y = 0; y < sh; y++) {                      /* horizontal pass */
+    const uint8_t *s = src + (size_t)y * irow;
+    int16_t *t = tmp + (size_t)y * dw * psize;
+    for (int x = 0; x < dw; x++)
+      for (int c = 0; c < psize; c++) {
+        int32_t acc = 0;
+        for (int j = 0; j < nth; j++) {
+          int sx = hpos[x] + j;
+          sx = sx < 0 ? 0 : sx >= sw ? sw - 1 : sx;
+          acc += (int32_t)hco[(size_t)x * nth + j] * s[sx * psize + c];
+        }
+        acc = (acc + 64) >> 7;
+        t[x * psize + c] = (int16_t)(acc < -32768 ? -32768 : acc > 32767 ? 32767 : acc);
+      }
+  }
+  for (int y = 0; y < dh; y++) {                      /* vertical pass */
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int x = 0; x < dw * psize; x++) {
+      int32_t acc = 0;
+      for (int j = 0; j < ntv; j++) {
+        int sy = vpos[y] + j;
+        sy = sy < 0 ? 0 : sy >= sh ? sh - 1 : sy;
+        acc += (int32_t)vco[(size_t)y * ntv + j] * tmp[(size_t)sy * dw * psize + x];
+      }
+      acc = (acc + (1 << 20)) >> 21;
+      d[x] = clamp_int_0_255(acc);
+    }
+  }
+  rc = 0;
+out:
+  free(hpos); free(vpos); free(hco); free(vco); free(tmp);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * B1: 5x5 gaussian -- UNPINNED (no reference loop).  Build-defined: [1 4 6 4 1] per axis,
+ * edge replicate, exact 12-bit row sums, one rounding: (sum + 128) >> 8.  All channels incl. alpha.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_gauss5(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize) {
+  static const int kw[5] = {1, 4, 6, 4, 1};
+  const int rowlen = width * psize;
+  uint16_t *tmp = malloc(sizeof(uint16_t) * (size_t)height * rowlen);
+  for (int y = 0; y < height; y++) {
+    const uint8_t *s = src + (size_t)y * irow;
+    for (int x = 0; x < width; x++)
+      for (int c = 0; c < psize; c++) {
+        int acc = 0;
+        for (int j = -2; j <= 2; j++) {
+          int sx = x + j; sx = sx < 0 ? 0 : sx >= width ? width - 1 : sx;
+          acc += kw[j + 2] * s[sx * psize + c];
+        }
+        tmp[(size_t)y * rowlen + x * psize + c] = (uint16_t)acc;
+      }
+  }
+  for (int y = 0; y < height; y++) {
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int x = 0; x < rowlen; x++) {
+      int acc = 0;
+      for (int j = -2; j <= 2; j++) {
+        int sy = y + j; sy = sy < 0 ? 0 : sy >= height ? height - 1 : sy;
+        acc += kw[j + 2] * tmp[(size_t)sy * rowlen + x];
+      }
+      d[x] = (uint8_t)((acc + 128) >> 8);
+    }
+  }
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the headline chain = composition of the single ops (BASELINE.json config 5 / north_star chain)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_chain(const uint8_t *src, int irow, int sw, int sh, const uint8_t *layer2, int irow2,
+              uint8_t *dst, int orow, int dw, int dh, int swap_rb, int interp, int do_blur, int bf,
+              const uint8_t *lut8) {
+  uint8_t *conv = malloc((size_t)sw * 4 * sh), *rs = malloc((size_t)dw * 4 * dh), *bl = NULL;
+  int rc = -1;
+  if (!conv || !rs) goto out;
+  if (swap_rb) orc_swizzle(ORC_SWAP3POSTALPHA, 0, src, irow, conv, sw * 4, sw, sh, NULL);
+  else for (int y = 0; y < sh; y++) memcpy(conv + (size_t)y * sw * 4, src + (size_t)y * irow, (size_t)sw * 4);
+  if (orc_resize(conv, sw * 4, sw, sh, rs, dw * 4, dw, dh, 4, interp)) goto out;
+  if (do_blur) {
+    bl = malloc((size_t)dw * 4 * dh);
+    if (!bl) goto out;
+    orc_gauss5(rs, dw * 4, bl, dw * 4, dw, dh, 4);
+  }
+  /* blend in place on the track (host "inplace" channel): dst alpha = track alpha */
+  { uint8_t *trk = bl ? bl : rs;
+    orc_blend_chroma(trk, dw * 4, layer2, irow2, trk, dw * 4, dw, dh, 4, 0, bf);
+    if (lut8) orc_gamma_apply(trk, dw * 4, dw, dh, 4, 0, lut8);
+    for (int y = 0; y < dh; y++) memcpy(dst + (size_t)y * orow, trk + (size_t)y * dw * 4, (size_t)dw * 4); }
+  rc = 0;
+out:
+  free(conv); free(rs); free(bl);
+  return rc;
+}

@@ -1,0 +1,95 @@
+/* lives_oracle.h -- CPU restatement of the LiVES per-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (lives_amd/, include/) may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it -- as the
+ * checker / the CPU number reported beside the GPU one, never as the thing shipped.
+ *
+ * Parity pin status (see DESIGN.md "Oracle"):
+ *   pinned   : tables, gamma LUT8, al/unal, K1 swizzles, YUV420P->RGB, gamma apply  -> against
+ *              oracle/_ref/libcsref.so (line-range slices of the reference's src/colourspace.c) and the
+ *              committed fixtures under tests/golden/;
+ *              chroma/luma blends, multi blends, mirrors, colour key -> against the reference's own
+ *              plugins built unmodified into oracle/_ref/ (.so files) and the committed fixtures.
+ *   UNPINNED : orc_resize (the reference calls FFmpeg libswscale, un-vendored, version unpinned --
+ *              src/colourspace.c:14711) and orc_gauss5 (no reference loop exists): both follow the
+ *              specification written in DESIGN.md.  "parity unpinned" for these two.
+ */
+#ifndef LIVES_ORACLE_H
+#define LIVES_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* which: bit0 = unclamped, bit1 = BT.709.  rgb2yuv[9][256] = Y_R Y_G Y_B Cb_R Cb_G Cb_B Cr_R Cr_G Cr_B,
+   yuv2rgb[5][256] = RGB_Y R_Cr G_Cb G_Cr B_Cb   (src/colourspace.c:851-1105) */
+void orc_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb);
+/* create_gamma_lut8 (src/colourspace.c:655-736), including its deterministic quirks */
+int orc_gamma_lut8(double fileg, int gamma_from, int gamma_to, double screen_gamma, uint8_t *lut);
+/* init_unal (src/colourspace.c:1141-1160): value of unal[alpha][v] / al[alpha][v] */
+int orc_unal(int alpha, int v);
+int orc_al(int alpha, int v);
+
+/* K1: the 13 packed RGB swizzles (src/colourspace.c:9259-10577).  op ids = order of definition. */
+enum { ORC_SWAP3, ORC_SWAP4, ORC_SWAP3ADDPOST, ORC_SWAP3ADDPRE, ORC_SWAP3POSTALPHA, ORC_SWAP3PREALPHA,
+       ORC_ADDPOST, ORC_ADDPRE, ORC_SWAP3DELPOST, ORC_DELPOST, ORC_DELPRE, ORC_SWAP3DELPRE, ORC_SWAPPREPOST };
+int orc_swizzle(int op, int alpha_first, const uint8_t *src, int irow, uint8_t *dst, int orow,
+                int width, int height, const uint8_t *lut8);
+
+/* K2: convert_yuv420p_to_rgb_frame (src/colourspace.c:3260-3904), 1-thread semantics.
+   out_order: 0 = RGB(A), 1 = BGR(A), 2 = ARGB.  u_size/v_size = readable bytes of the chroma planes.
+   fix_edges: 0 = replicate every deterministic reference behaviour (garbage last row included),
+              1 = compute the evident intent on row 0 (odd x) and on the last row. */
+int orc_yuv420p_to_rgb(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
+                       long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
+                       int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                       const uint8_t *lut8, int fix_edges);
+
+/* K6: gamma_convert_layer_thread (src/colourspace.c:14034-14060) */
+void orc_gamma_apply(uint8_t *pix, int rowstride, int width, int height, int psize, int alpha_first,
+                     const uint8_t *lut8);
+/* K9: alpha_premult packed RGBA/BGRA (aoffs 3, coffs 0) / ARGB (aoffs 0, coffs 1); un = 1: unal (REVERSE) */
+void orc_alpha_premult(uint8_t *pix, int rowstride, int width, int height, int alpha_first, int un);
+/* K8: letterbox blit into an opaque-black canvas (src/colourspace.c:15343-15567, fill :11109-11119) */
+void orc_letterbox(const uint8_t *src, int irow, int width, int height, uint8_t *dst, int orow,
+                   int nwidth, int nheight, int psize, const uint8_t *black_pixel);
+
+/* F1: "chroma blend" simple_blend.c:117-150 (psize 3 or 4; alpha_first => ARGB quirk path) */
+void orc_blend_chroma(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow,
+                      int width, int height, int psize, int alpha_first, int bf);
+/* F2: luma overlay (1) / underlay (2) / negative (3) / averaged (4 == 1 in the reference) simple_blend.c:151-194
+   pal_order: 0 = RGB.., 1 = BGR.., 2 = ARGB */
+void orc_blend_luma(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst,
+                    int orow, int width, int height, int psize, int pal_order, int thresh, int inplace);
+/* F3: multi_blends.c:68-162 (RGB24 / BGR24), type 0..6 */
+void orc_blend_multi(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst,
+                     int orow, int width, int height, int is_bgr, int bf);
+/* F4: colour key, scripts/colorkey.script <process> */
+void orc_colorkey(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1, uint8_t *dst, int orow,
+                  int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b,
+                  int inplace);
+/* F5: mirrors.c:26-122.  mode 0 = x, 1 = y, 2 = xy.  (OOB writes of the reference are not performed.) */
+void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
+
+/* R1 (UNPINNED, spec "lgpu-polyphase-v1" in DESIGN.md) */
+enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_BILINEAR = 2, ORC_INTERP_HYPER = 3 };
+int orc_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);
+int orc_resize(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh,
+               int psize, int interp);
+/* B1 (UNPINNED, build-defined): separable [1 4 6 4 1]/16 per axis, edge replicate, one rounding */
+void orc_gauss5(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
+
+/* the C5 / headline chain as the composition of the single ops above:
+   BGRA32 -> RGBA32 (swap3postalpha) -> resize (interp) -> [gauss5] -> chroma blend(bf) with layer2 -> gamma LUT */
+int orc_chain(const uint8_t *src, int irow, int sw, int sh, const uint8_t *layer2, int irow2,
+              uint8_t *dst, int orow, int dw, int dh, int swap_rb, int interp, int do_blur, int bf,
+              const uint8_t *lut8);
+
+/* row-slice threaded drivers used by bench.py's cpu_baseline leg (reference slicing rule
+   CEIL(height / n, 4), src/colourspace.c:9456-9485) */
+double orc_bench_chain(int sw, int sh, int dw, int dh, int nthreads, int nframes, int do_blur);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

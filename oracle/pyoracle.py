@@ -1,0 +1,169 @@
+"""ctypes bindings for the CPU oracle (oracle/liblives_oracle.so) and, when present, the reference
+builds under oracle/_ref/.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under lives_amd/ imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(HERE, "_ref")
+vp = ctypes.c_void_p
+ci = ctypes.c_int
+cd = ctypes.c_double
+
+OPS = ("swap3 swap4 swap3addpost swap3addpre swap3postalpha swap3prealpha addpost addpre "
+       "swap3delpost delpost delpre swap3delpre swapprepost").split()
+OP_IBPP = [3, 4, 3, 3, 4, 4, 3, 3, 4, 4, 4, 4, 4]
+OP_OBPP = [3, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 4]
+
+# weed palette ids (libweed/weed-palettes.h:48-57)
+PAL_RGB24, PAL_BGR24, PAL_RGBA32, PAL_BGRA32, PAL_ARGB32 = 1, 2, 3, 4, 5
+# weed gamma ids (libweed/weed-palettes.h) + LiVES extras (src/colourspace.h:27-29)
+GAMMA_UNKNOWN, GAMMA_LINEAR, GAMMA_SRGB, GAMMA_BT709, GAMMA_MONITOR = 0, 1, 2, 3, 1024
+
+
+def P(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def build_oracle(force=False):
+    so = os.path.join(HERE, "liblives_oracle.so")
+    srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_bench.c", "lives_oracle.h")]
+    srcs = [s for s in srcs if os.path.exists(s)]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        cs = [s for s in srcs if s.endswith(".c")]
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-shared",
+                               "-fPIC", "-o", so] + cs + ["-lm", "-lpthread"])
+    return so
+
+
+_O = None
+
+
+def oracle():
+    global _O
+    if _O is None:
+        _O = ctypes.CDLL(build_oracle())
+        _O.orc_gamma_lut8.argtypes = [cd, ci, ci, cd, vp]
+        _O.orc_yuv420p_to_rgb.argtypes = [vp, vp, vp, vp, ctypes.c_long, ctypes.c_long, vp] + [ci] * 8 + [vp, ci]
+        _O.orc_colorkey.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, cd, ci, ci, ci, ci]
+        _O.orc_swizzle.argtypes = [ci, ci, vp, ci, vp, ci, ci, ci, vp]
+        _O.orc_gamma_apply.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+        _O.orc_alpha_premult.argtypes = [vp, ci, ci, ci, ci, ci]
+        _O.orc_letterbox.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp]
+        _O.orc_blend_chroma.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci]
+        _O.orc_blend_luma.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci]
+        _O.orc_blend_multi.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci]
+        _O.orc_mirror.argtypes = [ci, vp, ci, vp, ci, ci, ci, ci]
+        _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
+        _O.orc_gauss5.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+        _O.orc_chain.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        _O.orc_make_filter.argtypes = [ci, ci, ci, vp, vp, vp, ci]
+        if hasattr(_O, "orc_bench_chain"):
+            _O.orc_bench_chain.restype = cd
+            _O.orc_bench_chain.argtypes = [ci] * 7
+    return _O
+
+
+def have_ref():
+    return all(os.path.exists(os.path.join(REFDIR, f)) for f in ("libcsref.so", "librefhost.so", "simple_blend.so"))
+
+
+_R = None
+
+
+def csref():
+    global _R
+    if _R is None:
+        _R = ctypes.CDLL(os.path.join(REFDIR, "libcsref.so"))
+        _R.csref_gamma_lut8.argtypes = [cd, ci, ci, vp]
+        _R.csref_set_prefs.argtypes = [ci, ci, cd]
+    return _R
+
+
+class RefParam(ctypes.Structure):
+    _fields_ = [("kind", ci), ("n", ci), ("ival", ci * 4), ("dval", cd)]
+
+
+def p_int(v):
+    p = RefParam(); p.kind = 0; p.ival[0] = int(v); return p
+
+
+def p_double(v):
+    p = RefParam(); p.kind = 1; p.dval = float(v); return p
+
+
+def p_rgb(r, g, b):
+    p = RefParam(); p.kind = 2; p.n = 3; p.ival[0], p.ival[1], p.ival[2] = int(r), int(g), int(b); return p
+
+
+class RefHost:
+    """Drives a weed plugin .so (the reference's, or this repo's drop-in) through oracle/ref/refhost.c."""
+
+    def __init__(self):
+        self.H = ctypes.CDLL(os.path.join(REFDIR, "librefhost.so"))
+        self.H.refhost_load.restype = vp
+        self.H.refhost_load.argtypes = [ctypes.c_char_p]
+        self.H.refhost_run.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp, ci]
+        self.H.refhost_filter_info.argtypes = [vp, ci, ctypes.c_char_p, ci, vp, ci, vp, vp, vp]
+        self.H.refhost_num_filters.argtypes = [vp]
+        self.plugins = {}
+
+    def load(self, path):
+        if path not in self.plugins:
+            h = self.H.refhost_load(path.encode())
+            if not h:
+                raise RuntimeError("cannot load weed plugin " + path)
+            self.plugins[path] = h
+        return self.plugins[path]
+
+    def filters(self, path):
+        h = self.load(path)
+        out = []
+        for i in range(self.H.refhost_num_filters(h)):
+            buf = ctypes.create_string_buffer(128)
+            pals = (ci * 16)()
+            nin, nout, npar = ci(), ci(), ci()
+            flags = self.H.refhost_filter_info(h, i, buf, 128, pals, 16, ctypes.byref(nin), ctypes.byref(nout),
+                                               ctypes.byref(npar))
+            out.append(dict(name=buf.value.decode(), flags=flags, palettes=[p for p in pals if p],
+                            n_in=nin.value, n_out=nout.value, n_params=npar.value))
+        return out
+
+    def run(self, path, fname, pal, w, h, srcs, dst, params=(), nslices=1):
+        """srcs: list of 2-D uint8 arrays (rows x rowstride); dst: 2-D uint8 array (may be srcs[0])."""
+        hdl = self.load(path)
+        n = len(srcs)
+        sp = (vp * n)(*[s.ctypes.data for s in srcs])
+        st = (ci * n)(*[s.strides[0] for s in srcs])
+        pa = (RefParam * max(1, len(params)))(*params)
+        r = self.H.refhost_run(hdl, fname.encode(), pal, w, h, n, sp, st, dst.ctypes.data, dst.strides[0],
+                               len(params), pa, nslices)
+        if r != 0:
+            raise RuntimeError("weed filter '%s' returned %d" % (fname, r))
+        return dst
+
+
+def refplugin(name):
+    return os.path.join(REFDIR, name + ".so")
+
+
+def align(n, a=32):
+    return (n + a - 1) // a * a
+
+
+def make_frame(rng, w, h, psize, stride_align=32, extra_rows=0, alpha_mix=False, pad_px=0):
+    """random packed frame with LiVES-style aligned rowstride (src/colourspace.c:11252: ALIGN_CEIL(w*psize, 32));
+    pad_px forces at least that many spare pixels at the end of each row (for reference stray writes)"""
+    stride = align((w + pad_px) * psize, stride_align)
+    a = rng.integers(0, 256, (h + extra_rows, stride), dtype=np.uint8)
+    if alpha_mix and psize == 4:
+        al = a[:, 3::4]
+        opaque = rng.random(al.shape) < 0.5
+        al[opaque] = 255
+    return a

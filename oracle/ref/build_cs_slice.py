@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Build oracle/_ref/libcsref.so from line-range slices of the REFERENCE's src/colourspace.c.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (needs /root/reference).
+
+src/colourspace.c cannot be compiled as a whole here (#include "main.h" drags in GTK / glib /
+libswscale headers that this image lacks -- SURVEY.md section 8c).  The pixel loops themselves are
+plain C, so this script concatenates the *reference's own text*, by line range, straight from
+/root/reference/src/{maths.h,colourspace.h,colourspace.c} into a scratch translation unit under
+oracle/_ref/ (git-ignored; never committed), in front of which sits a prelude that only supplies
+typedefs / attribute macros / a `prefs` struct / weed constants (no algorithmic code: rounding,
+clamping and table maths all come from the reference's lines), and after which sit thin extern
+wrappers so that ctypes can reach the `static` functions.
+
+What is exported (all call the reference's functions unmodified):
+  csref_tables(...)           conversion tables   src/colourspace.c:851-1105
+  csref_gamma_lut8(...)       create_gamma_lut8   src/colourspace.c:655-736
+  csref_unal(...)             al / unal tables    src/colourspace.c:1141-1160
+  csref_cavg(...)             cavg tables         src/colourspace.c:190-217
+  csref_yuv420p_to_rgb(...)   convert_yuv420p_to_rgb_frame   :3260-3904
+  csref_k1(...)               the 13 RGB<->RGB swizzles      :9259-10577
+  csref_gamma_apply(...)      gamma_convert_layer_thread     :14034-14060
+  csref_rgb_to_yuv420(...)    convert_rgb_to_yuv420_frame    (next-row)
+"""
+import os
+import subprocess
+import sys
+
+REF = os.environ.get("LIVES_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.normpath(os.path.join(HERE, "..", "_ref"))
+
+
+def lines(path, a, b):
+    with open(os.path.join(REF, path), "r", errors="replace") as f:
+        all_lines = f.readlines()
+    return "/* ---- %s:%d-%d ---- */\n" % (path, a, b) + "".join(all_lines[a - 1:b]) + "\n"
+
+
+PRELUDE = r'''
+/* prelude: typedefs / attributes / constants only (see build_cs_slice.py docstring) */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <unistd.h>
+typedef int boolean;
+#ifndef TRUE
+#define TRUE 1
+#define FALSE 0
+#endif
+typedef void weed_layer_t;
+#define WEED_MAXPPLANES 4
+#define LIVES_RESTRICT __restrict__
+#define LIVES_INLINE static inline
+#define LIVES_LOCAL_INLINE static inline
+#define LIVES_GLOBAL_INLINE
+#define LIVES_CONST
+#define LIVES_UNLIKELY(a) (a)
+#define LIVES_LIKELY(a) (a)
+#define LIVES_THRDATTR_PRIORITY 0
+#define USE_THREADS 1
+#define lives_calloc calloc
+#define lives_malloc malloc
+#define lives_free free
+#define lives_memcpy memcpy
+#define lives_memset memset
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+/* weed constants the loops test against: libweed/weed-palettes.h */
+#define WEED_YUV_CLAMPING_CLAMPED 0
+#define WEED_YUV_CLAMPING_UNCLAMPED 1
+#define WEED_YUV_SUBSPACE_YUV 0
+#define WEED_YUV_SUBSPACE_YCBCR 1
+#define WEED_YUV_SUBSPACE_BT709 2
+#define WEED_YUV_SAMPLING_DEFAULT 0
+#define WEED_GAMMA_UNKNOWN 0
+#define WEED_GAMMA_LINEAR 1
+#define WEED_GAMMA_SRGB 2
+#define WEED_GAMMA_BT709 3
+#define PB_QUALITY_LOW 1
+#define PB_QUALITY_MED 2
+#define PB_QUALITY_HIGH 3
+typedef struct { short pb_quality; int nfx_threads; double screen_gamma; } _prefs;
+static _prefs _the_prefs = {PB_QUALITY_MED, 1, 1.4};
+static _prefs *prefs = &_the_prefs;
+/* threads: run the slice workers synchronously on the calling thread */
+typedef int lives_thread_t;
+typedef void *(*lives_thread_func_t)(void *);
+#define lives_thread_create(thr, attr, func, arg) (*(thr) = NULL, (void)(func)(arg), 0)
+#define lives_thread_join(thr, ret) do {} while (0)
+static void swab4(const void *to, const void *from, size_t gran) {
+  /* memory.c:1501 equivalent for granularity 1: reverse 4 bytes */
+  const uint8_t *f = (const uint8_t *)from; uint8_t *t = (uint8_t *)to, tmp[4];
+  (void)gran; tmp[0] = f[3]; tmp[1] = f[2]; tmp[2] = f[1]; tmp[3] = f[0]; memcpy(t, tmp, 4);
+}
+'''
+
+THREADVAR = r'''
+static struct _conv_array _tv_conv_arrays;
+#define THREADVAR(x) _tv_##x
+'''
+
+# forward declarations for the *_frame_thread functions referenced before definition
+FWD = r'''
+static void *convert_yuv420p_to_rgb_frame_thread(void *);
+static void *convert_swap3_frame_thread(void *);
+static void *convert_swap4_frame_thread(void *);
+static void *convert_swap3addpost_frame_thread(void *);
+static void *convert_swap3addpre_frame_thread(void *);
+static void *convert_swap3postalpha_frame_thread(void *);
+static void *convert_swap3prealpha_frame_thread(void *);
+static void *convert_addpost_frame_thread(void *);
+static void *convert_addpre_frame_thread(void *);
+static void *convert_swap3delpost_frame_thread(void *);
+static void *convert_delpost_frame_thread(void *);
+static void *convert_delpre_frame_thread(void *);
+static void *convert_swap3delpre_frame_thread(void *);
+static void *convert_swapprepost_frame_thread(void *);
+static void *convert_swab_frame_thread(void *);
+'''
+
+WRAPPERS = r'''
+/* ---- extern wrappers (this repo's code; they only forward to the reference's functions) ---- */
+void csref_set_prefs(int pb_quality, int nfx_threads, double screen_gamma) {
+  prefs->pb_quality = (short)pb_quality; prefs->nfx_threads = nfx_threads; prefs->screen_gamma = screen_gamma;
+}
+static void ensure_tables(void) {
+  if (!conv_RY_inited) init_RGB_to_YUV_tables();
+  if (!conv_YR_inited) init_YUV_to_RGB_tables();
+  if (!conv_YY_inited) init_YUV_to_YUV_tables();
+  if (!avg_inited) init_average();
+  if (!unal_inited) init_unal();
+}
+/* which: 0 = YCbCr clamped, 1 = YCbCr unclamped, 2 = BT709 clamped, 3 = BT709 unclamped
+   rgb2yuv[9][256]: Y_R Y_G Y_B Cb_R Cb_G Cb_B Cr_R Cr_G Cr_B ; yuv2rgb[5][256]: RGB_Y R_Cr G_Cb G_Cr B_Cb */
+void csref_tables(int which, int *rgb2yuv, int *yuv2rgb) {
+  int clamping = (which & 1) ? WEED_YUV_CLAMPING_UNCLAMPED : WEED_YUV_CLAMPING_CLAMPED;
+  int subspace = (which & 2) ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR;
+  ensure_tables();
+  set_conversion_arrays(clamping, subspace);
+  memcpy(rgb2yuv + 0 * 256, Y_R, 1024); memcpy(rgb2yuv + 1 * 256, Y_G, 1024); memcpy(rgb2yuv + 2 * 256, Y_B, 1024);
+  memcpy(rgb2yuv + 3 * 256, Cb_R, 1024); memcpy(rgb2yuv + 4 * 256, Cb_G, 1024); memcpy(rgb2yuv + 5 * 256, Cb_B, 1024);
+  memcpy(rgb2yuv + 6 * 256, Cr_R, 1024); memcpy(rgb2yuv + 7 * 256, Cr_G, 1024); memcpy(rgb2yuv + 8 * 256, Cr_B, 1024);
+  memcpy(yuv2rgb + 0 * 256, RGB_Y, 1024); memcpy(yuv2rgb + 1 * 256, R_Cr, 1024); memcpy(yuv2rgb + 2 * 256, G_Cb, 1024);
+  memcpy(yuv2rgb + 3 * 256, G_Cr, 1024); memcpy(yuv2rgb + 4 * 256, B_Cb, 1024);
+}
+void csref_yuv_yuv_tables(uint8_t *yc2u, uint8_t *uvc2u, uint8_t *yu2c, uint8_t *uvu2c) {
+  ensure_tables();
+  memcpy(yc2u, Yclamped_to_Yunclamped, 256); memcpy(uvc2u, UVclamped_to_UVunclamped, 256);
+  memcpy(yu2c, Yunclamped_to_Yclamped, 256); memcpy(uvu2c, UVunclamped_to_UVclamped, 256);
+}
+void csref_cavg(uint8_t *c, uint8_t *u) { ensure_tables(); memcpy(c, cavgc, 65536); memcpy(u, cavgu, 65536); }
+void csref_unal(int *t_unal, int *t_al) { ensure_tables(); memcpy(t_unal, unal, 65536 * 4); memcpy(t_al, al, 65536 * 4); }
+void csref_unal_yuv(int *t_unalcy, int *t_alcy, int *t_unalcuv, int *t_alcuv) {
+  ensure_tables();
+  memcpy(t_unalcy, unalcy, 65536 * 4); memcpy(t_alcy, alcy, 65536 * 4);
+  memcpy(t_unalcuv, unalcuv, 65536 * 4); memcpy(t_alcuv, alcuv, 65536 * 4);
+}
+/* NB: call once per fresh process for a clean LUT (cache-poisoning quirk, SURVEY appendix A2) */
+int csref_gamma_lut8(double fileg, int from, int to, uint8_t *out) {
+  uint8_t *lut;
+  init_gamma_tx();
+  lut = create_gamma_lut8(fileg, from, to);
+  if (!lut) return 0;
+  memcpy(out, lut, 256);
+  return 1;
+}
+int csref_gamma_lut16(double fileg, int from, int to, uint16_t *out) {
+  uint16_t *lut;
+  init_gamma_tx();
+  lut = create_gamma_lut(fileg, from, to);
+  if (!lut) return 0;
+  memcpy(out, lut, 65536 * 2);
+  return 1;
+}
+void csref_gamma_consts(float *out8) {
+  init_gamma_tx();
+  for (int i = 0; i < N_GAMMA_TYPES; i++) {
+    out8[i * 4 + 0] = gamma_tx[i].offs; out8[i * 4 + 1] = gamma_tx[i].lin;
+    out8[i * 4 + 2] = gamma_tx[i].thresh; out8[i * 4 + 3] = gamma_tx[i].pf;
+  }
+}
+void csref_yuv420p_to_rgb(uint8_t *y, uint8_t *u, uint8_t *v, int width, int height, int *istrides,
+                          int orowstride, uint8_t *dest, int add_alpha, int is_422, int clamping, int subspace,
+                          uint16_t *lut16) {
+  uint8_t *src[3] = {y, u, v};
+  ensure_tables();
+  /* tgt_gamma = 0: an explicit LUT16 (may be NULL) is passed straight through */
+  convert_yuv420p_to_rgb_frame(src, width, height, 0, istrides, orowstride, dest, add_alpha, is_422,
+                               WEED_YUV_SAMPLING_DEFAULT, clamping, subspace, 0, 0, lut16, -1);
+}
+/* op ids follow the order of the definitions in src/colourspace.c:9259-10577 */
+int csref_k1(int op, uint8_t *src, int width, int height, int irow, int orow, uint8_t *dest, uint8_t *lut8,
+             int alpha_first) {
+  /* some threaded bodies free() the LUT they were handed (lives_gamma_lut8_free): give them a heap copy */
+  if (lut8) { uint8_t *cp = (uint8_t *)malloc(256); memcpy(cp, lut8, 256); lut8 = cp; }
+  switch (op) {
+  case 0: convert_swap3_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 1: convert_swap4_frame(src, width, height, irow, orow, dest, lut8, alpha_first, -1); break;
+  case 2: convert_swap3addpost_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 3: convert_swap3addpre_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 4: convert_swap3postalpha_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 5: convert_swap3prealpha_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 6: convert_addpost_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 7: convert_addpre_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 8: convert_swap3delpost_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 9: convert_delpost_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 10: convert_delpre_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 11: convert_swap3delpre_frame(src, width, height, irow, orow, dest, lut8, -1); break;
+  case 12: convert_swapprepost_frame(src, width, height, irow, orow, dest, lut8, alpha_first, -1); break;
+  default: return -1;
+  }
+  return 0;
+}
+void csref_gamma_apply(uint8_t *pixels, int width, int height, int rowstride, int psize, int alpha_first,
+                       int xoffset_px, uint8_t *lut8) {
+  lives_cc_params cc;
+  memset(&cc, 0, sizeof(cc));
+  cc.src = pixels; cc.hsize = width; cc.vsize = height; cc.psize = psize; cc.orowstrides[0] = rowstride;
+  cc.alpha_first = alpha_first; cc.xoffset = (size_t)xoffset_px * psize; cc.lut8 = lut8;
+  gamma_convert_layer_thread(&cc);
+}
+'''
+
+
+def find_line(path, needle, start=1):
+    with open(os.path.join(REF, path), "r", errors="replace") as f:
+        for i, l in enumerate(f, 1):
+            if i >= start and needle in l:
+                return i
+    raise SystemExit("needle not found: %s in %s" % (needle, path))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cs = "src/colourspace.c"
+    ch = "src/colourspace.h"
+    parts = [PRELUDE]
+    parts.append(lines("src/maths.h", 88, 88))      # CLAMP0255f
+    parts.append(lines("src/maths.h", 101, 104))    # CEIL, ALIGN_CEIL
+    parts.append(lines("src/maths.h", 118, 118))    # myround
+    parts.append(lines(ch, 12, 14))                 # #define USE_EXTEND (unconditional in the reference)
+    parts.append(lines(ch, 16, 29))                 # CLAMP16bit ... CLAMP0_255i, gamma ids
+    parts.append(lines(ch, 45, 47))                 # RS_ALIGN
+    parts.append(lines(ch, 50, 63))                 # FP_BITS, SCALE_FACTOR
+    parts.append(lines(ch, 65, 131))                # struct _conv_array, K*, clamp consts
+    parts.append(lines(ch, 140, 143))
+    parts.append(lines(ch, 152, 185))               # gamma_const_t, INIT_GAMMA, init_gamma_tx
+    parts.append(lines(ch, 189, 258))               # macropixels, lives_cc_params
+    parts.append(THREADVAR)
+    parts.append(lines(cs, 54, 419))                # tables, init_average, set_conversion_arrays, accessors
+    parts.append(lines(cs, 575, 575))               # unal_inited
+    parts.append(lines(cs, 592, 829))               # clamp0255f, YY tables, gamma statics, LUT builders
+    parts.append(lines(cs, 832, 843))               # spc_rnd
+    parts.append(lines(cs, 851, 1160))              # table inits, init_unal
+    parts.append(lines(cs, 2345, 2365))             # yuv2rgb_int, xyuv2rgb, SETVARS
+    parts.append(lines(cs, 2386, 2392))             # xyuv2rgb_with_gamma
+    parts.append(FWD)
+    parts.append(lines(cs, 3260, 3925))             # convert_yuv420p_to_rgb_frame (+ thread)
+    parts.append(lines(cs, 9259, 10577))            # K1 swizzle family
+    parts.append(lines(cs, 14034, 14060))           # gamma_convert_layer_thread
+    parts.append(WRAPPERS)
+    src = os.path.join(OUT, "cs_slice.c")
+    with open(src, "w") as f:
+        f.write("/* GENERATED SCRATCH FILE -- contains reference text; never commit (oracle/_ref is git-ignored) */\n")
+        f.write("".join(parts))
+    so = os.path.join(OUT, "libcsref.so")
+    cmd = ["gcc", "-shared", "-fPIC", "-O1", "-w", "-fno-strict-aliasing", "-o", so, src, "-lm"]
+    print(" ".join(cmd))
+    r = subprocess.run(cmd)
+    if r.returncode:
+        sys.exit(r.returncode)
+    print("built", so)
+
+
+if __name__ == "__main__":
+    main()
