@@ -1,0 +1,164 @@
+/* lives_gpu.h -- C ABI of liblivesgpu.so: the MI355X (gfx950) per-frame effects engine for LiVES.
+ *
+ * Frame-level entry points.  Plain pointers and sizes, no C++ / torch types.  Every `*_d` pointer is a
+ * DEVICE pointer (HBM); `stream` is a hipStream_t passed as void* (NULL = the default stream).  All
+ * calls are asynchronous on `stream`; they return LGPU_OK (0) or a negative LGPU_E_* code and never
+ * touch the frame on failure.  There is NO CPU fallback: without a HIP device every compute entry
+ * point fails with LGPU_E_NODEVICE.
+ *
+ * Each function names the reference interface it replaces (file:line under the LiVES tree).  The
+ * weed_layer_t-level seam (convert_layer_palette() & co.) that sits on top of these is declared in
+ * lives_gpu_layer.h; the weed plugin seam is lives_amd/csrc/fx_plugin.c (weed_setup).
+ *
+ * Geometry conventions are the reference's: `width` in PIXELS, rowstrides in BYTES
+ * (src/colourspace.c:11252 calc_rowstrides: ALIGN_CEIL(width * psize, 32) by default).
+ */
+#ifndef LIVES_GPU_H
+#define LIVES_GPU_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGPU_ABI_VERSION 1
+
+enum {
+  LGPU_OK = 0,
+  LGPU_E_NODEVICE = -1,   /* no HIP device / runtime error at init */
+  LGPU_E_BADARG = -2,
+  LGPU_E_UNSUPPORTED = -3,
+  LGPU_E_HIP = -4,        /* a HIP call failed; see lgpu_last_error() */
+  LGPU_E_NOMEM = -5
+};
+
+/* ---- runtime ----------------------------------------------------------------------------------- */
+int lgpu_abi_version(void);
+/* bind the calling thread to `device` and upload the conversion tables (idempotent, thread-safe) */
+int lgpu_init(int device);
+const char *lgpu_last_error(void);
+int lgpu_device_count(void);
+/* device memory + copies for hosts without their own allocator (the layer seam uses these) */
+int lgpu_malloc(void **ptr_d, size_t bytes);
+int lgpu_free(void *ptr_d);
+int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream);
+int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream);
+int lgpu_sync(void *stream);
+
+/* ---- host-side table builders (pure CPU, usable without a device) -------------------------------- */
+/* conversion tables; replaces init_RGB_to_YUV_tables / init_YUV_to_RGB_tables (src/colourspace.c:851-1105).
+   which: bit0 = unclamped, bit1 = BT.709.  rgb2yuv[9*256], yuv2rgb[5*256] (either may be NULL). */
+int lgpu_conversion_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb);
+/* replaces create_gamma_lut8 (src/colourspace.c:655-736), same return convention: 1 = LUT written,
+   0 = no conversion needed (the reference returns NULL) */
+int lgpu_gamma_lut8(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint8_t lut[256]);
+/* rowstride rule; replaces calc_rowstrides (src/colourspace.c:11252-11366) for an explicit alignment
+   (0 = RS_ALIGN_DEF 32, -1 = compact).  Returns the number of planes, fills rowstrides[4]. */
+int lgpu_calc_rowstrides(int width, int palette, int alignment, int rowstrides[4]);
+
+/* ---- K1: packed RGB <-> RGB swizzles ---------------------------------------------------------------
+   replaces convert_swap3_frame ... convert_swapprepost_frame (src/colourspace.c:9259-10577) as picked
+   by the selector tree of convert_layer_palette_full (:12370-12556). */
+enum {
+  LGPU_SWAP3, LGPU_SWAP4, LGPU_SWAP3ADDPOST, LGPU_SWAP3ADDPRE, LGPU_SWAP3POSTALPHA, LGPU_SWAP3PREALPHA,
+  LGPU_ADDPOST, LGPU_ADDPRE, LGPU_SWAP3DELPOST, LGPU_DELPOST, LGPU_DELPRE, LGPU_SWAP3DELPRE, LGPU_SWAPPREPOST
+};
+/* lut8: HOST pointer to 256 bytes or NULL (travels as a kernel argument).  src_d == dst_d is allowed
+   when input and output pixel sizes are equal. */
+int lgpu_swizzle(int op, int alpha_first, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow,
+                 int width, int height, const uint8_t *lut8, void *stream);
+
+/* ---- K6: gamma LUT apply, in place; replaces gamma_convert_layer_thread (src/colourspace.c:14034-14060)
+   on the sub-rectangle of gamma_convert_sub_layer (:14069-14143).  psize 3 or 4. */
+int lgpu_gamma_apply(uint8_t *pix_d, int rowstride, int x, int y, int width, int height, int psize,
+                     int alpha_first, const uint8_t *lut8, void *stream);
+
+/* ---- K9: alpha pre/un-multiply, in place; replaces alpha_premult (src/colourspace.c:11968-12105) for the
+   packed 4-byte RGB palettes.  un = 1 is LIVES_DIRECTION_REVERSE (the `unal` table). */
+int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int height, int alpha_first, int un,
+                       void *stream);
+
+/* ---- K2: planar YUV 4:2:0 / 4:2:2 -> packed RGB; replaces convert_yuv420p_to_rgb_frame
+   (src/colourspace.c:3260-3904; the BGR / ARGB twins :3927-5114 share the maths).
+   out_order 0 = RGB(A), 1 = BGR(A), 2 = ARGB; opsize 3 or 4; which_tables as lgpu_conversion_tables;
+   pb_quality 1 (LOW) / 2 (MED, default); HIGH (3) is LGPU_E_UNSUPPORTED.
+   lut8 (HOST, may be NULL) fuses the gamma_convert_layer() pass that follows in BASELINE config 2.
+   flags: LGPU_YUV_FIX_EDGES = write the evident intent into the last row instead of replicating the
+   reference's row-0-luma behaviour. */
+#define LGPU_YUV_FIX_EDGES 1
+int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
+                        long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
+                        int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                        const uint8_t *lut8, int flags, void *stream);
+
+/* ---- K8: letterbox; replaces the canvas fill + blit of letterbox_layer (src/colourspace.c:15343-15567;
+   fill :11109-11119).  Writes every pixel of the nwidth x nheight canvas exactly once. */
+int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow,
+                   int nwidth, int nheight, int psize, const uint8_t black_pixel[4], void *stream);
+
+/* ---- K7: resize.  Replaces the sws_scale() call of resize_layer_full (src/colourspace.c:14711, setup
+   :14940-15259).  PARITY UNPINNED: libswscale is neither vendored nor version-pinned by the reference;
+   this follows the repo's own spec "lgpu-polyphase-v1" (DESIGN.md).  interp = LiVESInterpType
+   (GdkInterpType values: 0 NEAREST/"fast", 2 BILINEAR, 3 HYPER/"best").  psize 4, 3 or 1.
+   lut8 (HOST, may be NULL) is the fused post-pass of :14718-14720. */
+int lgpu_resize(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *dst_d, int orow, int dw, int dh,
+                int psize, int interp, const uint8_t *lut8, void *stream);
+/* the filter bank the kernel uses (host, for tests / inspection): kernel 0 triangle, 1 cubic(0,.6), 2 lanczos3 */
+int lgpu_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);
+
+/* ---- B1: 5x5 separable gaussian (no reference loop exists -- BASELINE config 4; build-defined spec) */
+int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize,
+                void *stream);
+
+/* ---- F1..F5: the built-in weed effect pixel loops ----------------------------------------------------- */
+/* "chroma blend": lives-plugins/weed-plugins/simple_blend.c:117-150 */
+int lgpu_blend_chroma(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
+                      int orow, int width, int height, int psize, int alpha_first, int bf, void *stream);
+/* "luma overlay" (1) / "luma underlay" (2) / "negative luma overlay" (3) / "averaged luma overlay" (4):
+   simple_blend.c:151-194.  pal_order 0 RGB.., 1 BGR.., 2 ARGB. */
+int lgpu_blend_luma(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2,
+                    uint8_t *dst_d, int orow, int width, int height, int psize, int pal_order, int thresh,
+                    void *stream);
+/* blend_multiply .. blend_burn (type 0..6): lives-plugins/weed-plugins/multi_blends.c:24-168 */
+int lgpu_blend_multi(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2,
+                     uint8_t *dst_d, int orow, int width, int height, int is_bgr, int bf, void *stream);
+/* "colorkey": lives-plugins/weed-plugins/scripts/colorkey.script <process> */
+int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d,
+                  int orow, int width, int height, int is_bgr, double delta, double opac,
+                  int col_r, int col_g, int col_b, void *stream);
+/* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
+int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
+                int psize, void *stream);
+
+/* ---- the fused per-track chain (BASELINE config 5 / north_star headline) ------------------------------
+   convert (BGRA32 -> RGBA32 when swap_rb) -> resize -> [gauss5] -> chroma blend(bf) with layer2 -> gamma LUT,
+   one launch for a batch of independent tracks.  Bit-identical to running the single entry points in
+   that order (tests/test_chain_gpu.py).  All tracks share geometry and parameters (the shared
+   transition parameter block of SURVEY 8e); per-track pointers travel as kernel arguments. */
+#define LGPU_CHAIN_MAX_TRACKS 64
+typedef struct {
+  const uint8_t *src_d;      /* sw x sh, 4 bytes / pixel */
+  const uint8_t *layer2_d;   /* dw x dh, RGBA32 */
+  uint8_t *dst_d;            /* dw x dh, RGBA32 */
+} lgpu_chain_track;
+typedef struct {
+  int sw, sh, irow;          /* source geometry */
+  int dw, dh, irow2, orow;   /* output / layer-2 geometry */
+  int swap_rb;               /* 1: source is BGRA32 (K1 swap3postalpha fused into the load) */
+  int interp;                /* LiVESInterpType */
+  int do_blur;               /* 1: 5x5 gaussian between resize and blend */
+  int bf;                    /* chroma blend amount 0..255 */
+  int use_lut;               /* 1: apply lut8 after the blend */
+  uint8_t lut8[256];
+} lgpu_chain_params;
+int lgpu_chain(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks, void *stream);
+
+/* ---- timing helper: HIP events on `stream` around `reps` launches of the last-configured chain; used by
+   bench.py to measure the kernel's average launch duration on the stream it is launched on. */
+int lgpu_chain_timed(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks,
+                     int reps, float *ms_total, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,449 @@
+// effects.hip -- the pixel loops of the built-in weed effects (F1..F5) and the letterbox blit (K8).
+//
+//   chroma blend / luma overlays   lives-plugins/weed-plugins/simple_blend.c:58-194
+//   multiply .. burn               lives-plugins/weed-plugins/multi_blends.c:24-168
+//   colour key                     lives-plugins/weed-plugins/scripts/colorkey.script <process>
+//   mirror x / y / xy              lives-plugins/weed-plugins/mirrors.c:26-122
+//   letterbox fill + blit          src/colourspace.c:15343-15567
+//
+// All of them stream 2 frames in and 1 out with no reuse -> HBM bound.  Two-input effects share one
+// kernel skeleton: a lane loads 4 pixels of each input (16 B for 4-byte palettes, 12 B for 3-byte ones,
+// normalised to one dword per pixel by v_perm), applies a per-pixel functor and stores 4 pixels.
+#include "lgpu_common.h"
+
+namespace lgpu {
+
+// ---- 4-pixel load / store ------------------------------------------------------------------------------
+template <int PS>
+__device__ __forceinline__ void load4(const uint8_t *row, int g, bool vec, uint32_t p[4]) {
+  if (PS == 4) {
+    if (vec) { const uint4 v = *reinterpret_cast<const uint4 *>(row + (size_t)g * 16); p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+    else { const uint32_t *w = reinterpret_cast<const uint32_t *>(row + (size_t)g * 16); p[0] = w[0]; p[1] = w[1]; p[2] = w[2]; p[3] = w[3]; }
+  } else {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(row + (size_t)g * 12);
+    unpack3(w[0], w[1], w[2], p);
+  }
+}
+template <int PS>
+__device__ __forceinline__ void store4(uint8_t *row, int g, bool vec, const uint32_t q[4]) {
+  if (PS == 4) {
+    if (vec) *reinterpret_cast<uint4 *>(row + (size_t)g * 16) = make_uint4(q[0], q[1], q[2], q[3]);
+    else { uint32_t *w = reinterpret_cast<uint32_t *>(row + (size_t)g * 16); w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3]; }
+  } else {
+    uint32_t w0, w1, w2;
+    pack3(q, w0, w1, w2);
+    uint32_t *w = reinterpret_cast<uint32_t *>(row + (size_t)g * 12);
+    w[0] = w0; w[1] = w1; w[2] = w2;
+  }
+}
+template <int PS>
+__device__ __forceinline__ uint32_t load1(const uint8_t *row, int x) {
+  const uint8_t *p = row + (size_t)x * PS;
+  uint32_t v = p[0];
+  if (PS >= 3) v |= ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+  if (PS == 4) v |= (uint32_t)p[3] << 24;
+  return v;
+}
+template <int PS>
+__device__ __forceinline__ void store1(uint8_t *row, int x, uint32_t v) {
+  uint8_t *p = row + (size_t)x * PS;
+  p[0] = (uint8_t)v;
+  if (PS >= 3) { p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); }
+  if (PS == 4) p[3] = (uint8_t)(v >> 24);
+}
+
+struct Frames2 {
+  const uint8_t *s1, *s2;
+  uint8_t *dst;
+  int r1, r2, ro, width, height;
+  int vec;       // rows are 16-byte (PS 4) / 4-byte (PS 3) aligned -> vector path
+  int inplace;   // dst == s1
+};
+
+// F(p1, p2, pdst) -> output pixel dword.  pdst is only loaded when F::kNeedsDst && !inplace.
+template <int PS, class F>
+__global__ __launch_bounds__(kBlock) void k_pixel2(Frames2 f, F fn) {
+  __shared__ int32_t s_scratch[768];
+  fn.setup(s_scratch);
+  const int groups = f.width >> 2;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  const bool aligned3 = (PS == 4) || f.vec;   // 3-byte rows need 4-byte alignment for dword loads
+  for (int y = blockIdx.y; y < f.height; y += gridDim.y) {
+    const uint8_t *a = f.s1 + (size_t)y * f.r1, *b = f.s2 + (size_t)y * f.r2;
+    uint8_t *d = f.dst + (size_t)y * f.ro;
+    if (g < groups && aligned3) {
+      uint32_t p1[4], p2[4], pd[4], q[4];
+      load4<PS>(a, g, f.vec, p1);
+      load4<PS>(b, g, f.vec, p2);
+      if (F::kNeedsDst && PS == 4 && !f.inplace) load4<PS>(d, g, f.vec, pd);
+#pragma unroll
+      for (int k = 0; k < 4; k++) q[k] = fn(p1[k], p2[k], (F::kNeedsDst && PS == 4 && !f.inplace) ? pd[k] : p1[k]);
+      store4<PS>(d, g, f.vec, q);
+    } else if (g <= groups) {
+      const int x0 = aligned3 ? groups * 4 : g * 4, x1 = aligned3 ? f.width : (g * 4 + 4 < f.width ? g * 4 + 4 : f.width);
+      if (aligned3 && g != groups) continue;
+      for (int x = x0; x < x1; x++) {
+        const uint32_t p1 = load1<PS>(a, x), p2 = load1<PS>(b, x);
+        const uint32_t pd = (F::kNeedsDst && PS == 4 && !f.inplace) ? load1<PS>(d, x) : p1;
+        store1<PS>(d, x, fn(p1, p2, pd));
+      }
+    }
+  }
+}
+
+// ---- functors -------------------------------------------------------------------------------------------
+// (bf * b + (255 - bf) * a) >> 8 on two bytes at once: bytes sit in 16-bit lanes, products < 2^16
+__device__ __forceinline__ uint32_t mix_pairs(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
+  return ((b * bf + a * nbf) >> 8) & 0x00FF00FFu;
+}
+__device__ __forceinline__ uint32_t mix4(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
+  return mix_pairs(a & 0x00FF00FFu, b & 0x00FF00FFu, bf, nbf) | (mix_pairs((a >> 8) & 0x00FF00FFu, (b >> 8) & 0x00FF00FFu, bf, nbf) << 8);
+}
+
+// "chroma blend", 3-byte palettes and RGBA/BGRA (simple_blend.c:117-150).  For 4-byte pixels the output
+// alpha byte is whatever dst already holds (the reference never writes it).
+template <int PS>
+struct ChromaBlend {
+  static constexpr bool kNeedsDst = (PS == 4);
+  uint32_t bf, nbf;
+  __device__ __forceinline__ void setup(int32_t *) {}
+  __device__ __forceinline__ uint32_t operator()(uint32_t p1, uint32_t p2, uint32_t pd) const {
+    if (PS == 3) return mix4(p1, p2, bf, nbf);
+    const uint32_t al = p2 >> 24;
+    uint32_t r;
+    if (al == 255) r = mix4(p1, p2, bf, nbf);
+    else {
+      // const float alpha = (float)a / 255., inv_alpha = 1. - alpha;  (uint8_t)((float)c * alpha)
+      const float alpha = (float)((double)(float)al / 255.), inv = (float)(1. - (double)alpha);
+      uint32_t s2 = 0, s1 = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        s2 |= ((uint32_t)(int)__fmul_rn((float)((p2 >> (8 * c)) & 0xFF), alpha) & 0xFF) << (8 * c);
+        s1 |= ((uint32_t)(int)__fmul_rn((float)((p1 >> (8 * c)) & 0xFF), inv) & 0xFF) << (8 * c);
+      }
+      r = mix4(s1, s2, bf, nbf);
+    }
+    return (r & 0x00FFFFFFu) | (pd & 0xFF000000u);
+  }
+};
+
+// luma of a normalised pixel, calc_luma() (libweed/weed-plugin-utils.c:924-934); ORDER 0 RGB, 1 BGR
+struct LumaTab {
+  const int32_t *gl;   // device [3][256]
+  int32_t *s;          // LDS copy
+  __device__ __forceinline__ void stage(int32_t *lds) {
+    s = lds;
+    for (int i = threadIdx.x; i < 768; i += kBlock) lds[i] = gl[i];
+    __syncthreads();
+  }
+  __device__ __forceinline__ uint32_t luma(uint32_t p, int order) const {
+    const uint32_t c0 = p & 0xFF, c1 = (p >> 8) & 0xFF, c2 = (p >> 16) & 0xFF;
+    const int32_t v = order ? (s[c2] + s[256 + c1] + s[512 + c0]) : (s[c0] + s[256 + c1] + s[512 + c2]);
+    return (uint32_t)(v >> 16) & 0xFF;
+  }
+};
+
+// luma overlay (1, 4) / underlay (2) / negative overlay (3): copies 3 bytes from layer 2 or layer 1
+// (simple_blend.c:151-194; type 4 never reaches its 3x3 branch in the reference and is type 1)
+struct LumaBlend {
+  static constexpr bool kNeedsDst = true;   // byte 3 of 4-byte pixels is left alone
+  LumaTab t;
+  int type, order, ps;
+  uint32_t bf, neg;
+  __device__ __forceinline__ void setup(int32_t *lds) { t.stage(lds); }
+  __device__ __forceinline__ uint32_t operator()(uint32_t p1, uint32_t p2, uint32_t pd) const {
+    bool take2;
+    if (type == 2) take2 = t.luma(p2, order) > neg;
+    else if (type == 3) take2 = t.luma(p1, order) > neg;
+    else take2 = t.luma(p1, order) < bf;
+    const uint32_t c = take2 ? p2 : p1;
+    return (c & 0x00FFFFFFu) | (pd & 0xFF000000u);
+  }
+};
+
+// multi_blends.c:68-162
+struct MultiBlend {
+  static constexpr bool kNeedsDst = false;
+  LumaTab t;
+  int type, order;
+  uint32_t f, b1, n1, b2, n2;
+  __device__ __forceinline__ void setup(int32_t *lds) { t.stage(lds); }
+  __device__ __forceinline__ uint32_t operator()(uint32_t pa, uint32_t pb, uint32_t) const {
+    uint32_t px = 0;
+    if (type == 2 || type == 3) {
+      const uint32_t la = t.luma(pa, order), lb = t.luma(pb, order);
+      px = (type == 2 ? (la <= lb) : (la >= lb)) ? pa : pb;
+    } else {
+      const bool screen = (type == 1) || (type == 4 && t.luma(pa, order) >= 128);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int a = (pa >> (8 * c)) & 0xFF, b = (pb >> (8 * c)) & 0xFF;
+        int v;
+        if (type == 5) v = (b == 255) ? 255 : ((a << 8) / (255 - b) > 255 ? 255 : (a << 8) / (255 - b));
+        else if (type == 6) { if (b == 0) v = 0; else { v = 255 - (255 - (a << 8)) / b; v = v < 0 ? 0 : (v & 0xFF); } }
+        else if (screen) v = (255 - (((255 - b) * (255 - a)) >> 8)) & 0xFF;
+        else v = ((b * a) >> 8) & 0xFF;
+        px |= (uint32_t)v << (8 * c);
+      }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const uint32_t p = (px >> (8 * c)) & 0xFF, a = (pa >> (8 * c)) & 0xFF, b = (pb >> (8 * c)) & 0xFF;
+      const uint32_t v = (f < 128) ? ((b1 * p + n1 * a) >> 8) : ((b2 * p + n2 * b) >> 8);
+      out |= (v & 0xFF) << (8 * c);
+    }
+    return out;
+  }
+};
+
+// colorkey.script <process>: RGB box test on layer 0, then a double-precision lerp, truncated
+struct ColorKey {
+  static constexpr bool kNeedsDst = false;
+  int order;
+  int rmin, rmax, gmin, gmax, bmin, bmax;
+  double opac, opacx;
+  __device__ __forceinline__ void setup(int32_t *) {}
+  __device__ __forceinline__ uint32_t operator()(uint32_t p0, uint32_t p1, uint32_t) const {
+    const int c0 = p0 & 0xFF, g = (p0 >> 8) & 0xFF, c2 = (p0 >> 16) & 0xFF;
+    const int r = order ? c2 : c0, b = order ? c0 : c2;
+    if (!(r >= rmin && r <= rmax && g >= gmin && g <= gmax && b >= bmin && b <= bmax)) return p0 & 0x00FFFFFFu;
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double a = (double)((p0 >> (8 * c)) & 0xFF), bb = (double)((p1 >> (8 * c)) & 0xFF);
+      const double v = __dadd_rn(__dmul_rn(a, opacx), __dmul_rn(bb, opac));   // no FMA contraction: x86-64 baseline has none
+      out |= ((uint32_t)(int)v & 0xFF) << (8 * c);
+    }
+    return out;
+  }
+};
+
+// "chroma blend" on ARGB32: colour bytes 1..3, alpha test on the byte FOLLOWING them = the next pixel's
+// alpha (simple_blend.c:81,:128-146 with start = 1); byte 0 is never written.
+__global__ __launch_bounds__(kBlock) void k_chroma_argb(Frames2 f, uint32_t bf, uint32_t nbf) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= f.width) return;
+  for (int y = blockIdx.y; y < f.height; y += gridDim.y) {
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(f.s1 + (size_t)y * f.r1);
+    const uint8_t *brow = f.s2 + (size_t)y * f.r2;
+    const uint32_t *b = reinterpret_cast<const uint32_t *>(brow);
+    uint32_t *d = reinterpret_cast<uint32_t *>(f.dst + (size_t)y * f.ro);
+    const uint32_t p1 = a[x] >> 8, p2 = b[x] >> 8;     // colour bytes -> [c0 c1 c2 0]
+    // byte (4x + 4) of layer 2: inside the row's stride, or the next row; past the last row's stride -> opaque
+    uint32_t al = 255;
+    if (x + 1 < f.width || 4 * (x + 1) < f.r2 || y + 1 < f.height) al = brow[4 * (x + 1)];
+    uint32_t r;
+    if (al == 255) r = mix4(p1, p2, bf, nbf);
+    else {
+      const float alpha = (float)((double)(float)al / 255.), inv = (float)(1. - (double)alpha);
+      uint32_t s2 = 0, s1 = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        s2 |= ((uint32_t)(int)__fmul_rn((float)((p2 >> (8 * c)) & 0xFF), alpha) & 0xFF) << (8 * c);
+        s1 |= ((uint32_t)(int)__fmul_rn((float)((p1 >> (8 * c)) & 0xFF), inv) & 0xFF) << (8 * c);
+      }
+      r = mix4(s1, s2, bf, nbf);
+    }
+    const uint32_t keep = f.inplace ? a[x] : d[x];
+    d[x] = (keep & 0xFFu) | (r << 8);
+  }
+}
+
+// ---- mirrors ----------------------------------------------------------------------------------------------
+// result[y][x] = src[ry(y)][rx(x)], rx(x) = x <= hw ? x : 2hw - x, ry(y) = y >= h - hh + 1 ? h - y : y
+// (the in-place result of mirrors.c; its stray writes to pixel `width` / row `height` are not performed)
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_mirror(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height,
+                                                    int mx, int my, int inplace) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= width) return;
+  const int hw = width >> 1, hh = height >> 1;
+  const int sx = (mx && x > hw) ? 2 * hw - x : x;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    const int sy = (my && y >= height - hh + 1) ? height - y : y;
+    if (inplace && sx == x && sy == y) continue;
+    store1<PS>(dst + (size_t)y * orow, x, load1<PS>(src + (size_t)sy * irow, sx));
+  }
+}
+
+// ---- letterbox ------------------------------------------------------------------------------------------------
+// every canvas pixel is written exactly once: inner rectangle from src, the rest opaque black
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_letterbox(const uint8_t *src, int irow, int width, int height, uint8_t *dst, int orow,
+                                                       int nwidth, int nheight, int ox, int oy, uint32_t black, int vec) {
+  const int g = blockIdx.x * kBlock + threadIdx.x;   // group of 4 canvas pixels
+  const int x0 = g * 4;
+  if (x0 >= nwidth) return;
+  for (int y = blockIdx.y; y < nheight; y += gridDim.y) {
+    uint8_t *d = dst + (size_t)y * orow;
+    const int sy = y - oy;
+    const bool rowin = sy >= 0 && sy < height;
+    const uint8_t *s = src + (size_t)(rowin ? sy : 0) * irow;
+    if (PS == 4 && vec && x0 + 4 <= nwidth) {
+      uint32_t q[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int sx = x0 + k - ox;
+        q[k] = (rowin && sx >= 0 && sx < width) ? reinterpret_cast<const uint32_t *>(s)[sx] : black;
+      }
+      *reinterpret_cast<uint4 *>(d + (size_t)x0 * 4) = make_uint4(q[0], q[1], q[2], q[3]);
+    } else {
+      for (int x = x0; x < x0 + 4 && x < nwidth; x++) {
+        const int sx = x - ox;
+        store1<PS>(d, x, (rowin && sx >= 0 && sx < width) ? load1<PS>(s, sx) : black);
+      }
+    }
+  }
+}
+
+static inline dim3 row_grid2(unsigned items_per_row, int height) {
+  unsigned gy = (unsigned)height;
+  if (gy > 4096) gy = 4096;
+  return dim3(cdiv(items_per_row, kBlock), gy, 1);
+}
+
+static int fill_frames(Frames2 &f, const uint8_t *s1, int r1, const uint8_t *s2, int r2, uint8_t *dst, int ro, int w, int h, int ps) {
+  if (!s1 || !s2 || !dst || w <= 0 || h <= 0) { set_error("null frame or empty geometry"); return LGPU_E_BADARG; }
+  if (r1 < w * ps || r2 < w * ps || ro < w * ps) { set_error("rowstride smaller than a row"); return LGPU_E_BADARG; }
+  f.s1 = s1; f.s2 = s2; f.dst = dst; f.r1 = r1; f.r2 = r2; f.ro = ro; f.width = w; f.height = h;
+  const uintptr_t all = (uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)dst | (uintptr_t)r1 | (uintptr_t)r2 | (uintptr_t)ro;
+  if (ps == 4) {
+    if (all & 3) { set_error("4-byte pixels must be 4-byte aligned"); return LGPU_E_BADARG; }
+    f.vec = (all & 15) == 0;
+  } else f.vec = (all & 3) == 0;
+  f.inplace = (s1 == dst);
+  return LGPU_OK;
+}
+
+}  // namespace lgpu
+
+using namespace lgpu;
+
+extern "C" int lgpu_blend_chroma(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
+                                 int orow, int width, int height, int psize, int alpha_first, int bf, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  Frames2 f;
+  if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, psize))) return rc;
+  const uint32_t b = (uint32_t)bf & 0xFF, nb = 0xFF - b;
+  hipStream_t st = (hipStream_t)stream;
+  if (psize == 4 && alpha_first) {
+    hipLaunchKernelGGL(k_chroma_argb, row_grid2((unsigned)width, height), dim3(kBlock), 0, st, f, b, nb);
+  } else if (psize == 4) {
+    ChromaBlend<4> fn{b, nb};
+    hipLaunchKernelGGL((k_pixel2<4, ChromaBlend<4>>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, st, f, fn);
+  } else {
+    ChromaBlend<3> fn{b, nb};
+    hipLaunchKernelGGL((k_pixel2<3, ChromaBlend<3>>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, st, f, fn);
+  }
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_blend_luma(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
+                               int orow, int width, int height, int psize, int pal_order, int thresh, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(type >= 1 && type <= 4, "type must be 1..4");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(pal_order == 0 || pal_order == 1, "ARGB32 luma blends: use pal_order 0/1 after a swapprepost (reference ARGB path reads across pixels)");
+  Frames2 f;
+  if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, psize))) return rc;
+  LumaBlend fn;
+  fn.t.gl = device_tables()->luma; fn.t.s = nullptr;
+  fn.type = type; fn.order = pal_order; fn.ps = psize; fn.bf = (uint32_t)thresh & 0xFF; fn.neg = 0xFF - fn.bf;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = row_grid2((unsigned)(width >> 2) + 1, height);
+  if (psize == 4) hipLaunchKernelGGL((k_pixel2<4, LumaBlend>), grid, dim3(kBlock), 0, st, f, fn);
+  else hipLaunchKernelGGL((k_pixel2<3, LumaBlend>), grid, dim3(kBlock), 0, st, f, fn);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_blend_multi(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
+                                int orow, int width, int height, int is_bgr, int bf, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(type >= 0 && type <= 6, "type must be 0..6");
+  Frames2 f;
+  if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, 3))) return rc;
+  MultiBlend fn;
+  fn.t.gl = device_tables()->luma; fn.t.s = nullptr;
+  fn.type = type; fn.order = is_bgr ? 1 : 0;
+  const uint8_t ff = (uint8_t)bf;
+  fn.f = ff; fn.b1 = (uint8_t)(ff * 2); fn.n1 = (uint8_t)(255 - ff * 2); fn.b2 = (uint8_t)((255 - ff) * 2); fn.n2 = (uint8_t)((ff - 128) * 2);
+  hipLaunchKernelGGL((k_pixel2<3, MultiBlend>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, (hipStream_t)stream, f, fn);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow,
+                             int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b,
+                             void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  Frames2 f;
+  if ((rc = fill_frames(f, src0_d, irow0, src1_d, irow1, dst_d, orow, width, height, 3))) return rc;
+  ColorKey fn;
+  // parameter preparation exactly as the script does it (host side, double)
+  double xdelta = delta * 2.;
+  delta /= 2.;
+  fn.rmin = col_r - (int)(col_r * delta + .5);
+  fn.gmin = col_g - (int)(col_g * xdelta + .5);
+  fn.bmin = col_b - (int)(col_b * delta + .5);
+  xdelta *= 2.;
+  delta *= 2.;
+  fn.rmax = col_r + (int)((255 - col_r) * delta + .5);
+  fn.gmax = col_g + (int)((255 - col_g) * xdelta + .5);
+  fn.bmax = col_b + (int)((255 - col_b) * delta + .5);
+  fn.order = is_bgr ? 1 : 0; fn.opac = opac; fn.opacx = 1. - opac;
+  hipLaunchKernelGGL((k_pixel2<3, ColorKey>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, (hipStream_t)stream, f, fn);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize,
+                           void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (x), 1 (y) or 2 (xy)");
+  LGPU_REQUIRE(src_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(irow >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  const int mx = (mode == 0 || mode == 2), my = (mode == 1 || mode == 2), inplace = (src_d == dst_d);
+  const dim3 grid = row_grid2((unsigned)width, height);
+  if (psize == 4) hipLaunchKernelGGL(k_mirror<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, mx, my, inplace);
+  else hipLaunchKernelGGL(k_mirror<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, mx, my, inplace);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow, int nwidth,
+                              int nheight, int psize, const uint8_t black_pixel[4], void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && black_pixel && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 1 || psize == 3 || psize == 4, "psize must be 1, 3 or 4");
+  LGPU_REQUIRE(nwidth >= width && nheight >= height, "canvas smaller than the inner frame");
+  LGPU_REQUIRE(irow >= width * psize && orow >= nwidth * psize, "rowstride smaller than a row");
+  const int ox = (nwidth - width + 1) >> 1, oy = (nheight - height + 1) >> 1;   // src/colourspace.c:15522-15523
+  uint32_t black = black_pixel[0];
+  if (psize >= 3) black |= ((uint32_t)black_pixel[1] << 8) | ((uint32_t)black_pixel[2] << 16);
+  if (psize == 4) black |= (uint32_t)black_pixel[3] << 24;
+  const dim3 grid = row_grid2((unsigned)((nwidth + 3) >> 2), nheight);
+  hipStream_t st = (hipStream_t)stream;
+  if (psize == 4) {
+    const int vec = ((((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0) && ((((uintptr_t)src_d | (uintptr_t)irow) & 3) == 0);
+    LGPU_REQUIRE((((uintptr_t)src_d | (uintptr_t)irow | (uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0, "4-byte pixels must be 4-byte aligned");
+    hipLaunchKernelGGL(k_letterbox<4>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, vec);
+  } else if (psize == 3) {
+    hipLaunchKernelGGL(k_letterbox<3>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, 0);
+  } else {
+    // single-byte planes (Y / U / V / A of the planar palettes): 4 samples per lane
+    hipLaunchKernelGGL(k_letterbox<1>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, 0);
+  }
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

@@ -1,0 +1,94 @@
+// lgpu_common.h -- shared device helpers / launch plumbing for liblivesgpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/lives_gpu.h"
+
+namespace lgpu {
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int ensure_init();   // LGPU_OK or LGPU_E_NODEVICE
+
+#define LGPU_HIP(expr)                                                              \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      lgpu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return LGPU_E_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+#define LGPU_REQUIRE(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) { lgpu::set_error("%s: %s", __func__, msg); return LGPU_E_BADARG; } \
+  } while (0)
+
+#define LGPU_CHECK_LAUNCH()                                                         \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      lgpu::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return LGPU_E_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+// 256-byte LUT passed by value as a kernel argument (lands in the kernarg segment -> scalar loads)
+struct Lut8 {
+  uint32_t w[64];
+};
+static inline Lut8 pack_lut(const uint8_t *lut8) {
+  Lut8 l;
+  if (lut8) __builtin_memcpy(l.w, lut8, 256);
+  else for (int i = 0; i < 64; i++) { uint32_t b = 4u * i; l.w[i] = b | ((b + 1) << 8) | ((b + 2) << 16) | ((b + 3) << 24); }
+  return l;
+}
+
+// conversion tables resident in device memory (uploaded once by lgpu_init)
+struct DeviceTables {
+  int32_t *yuv2rgb[4];   // [5][256] each
+  int32_t *rgb2yuv[4];   // [9][256] each
+  int32_t *luma;         // [3][256]: 65536-scaled unclamped BT.601 luma weights (libweed/weed-plugin-utils.c:879-895)
+};
+const DeviceTables *device_tables();
+
+constexpr int kBlock = 256;   // 4 wavefronts of 64
+
+static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+#if defined(__HIPCC__)
+// ---- device helpers ---------------------------------------------------------------------------------
+// stage a kernarg LUT into LDS (256 B) -- one dword per lane for the first wave
+__device__ __forceinline__ void stage_lut(uint8_t *lds_lut, const Lut8 &lut) {
+  if (threadIdx.x < 64) reinterpret_cast<uint32_t *>(lds_lut)[threadIdx.x] = lut.w[threadIdx.x];
+}
+__device__ __forceinline__ uint32_t lut3_rgba(const uint8_t *l, uint32_t p) {   // LUT on bytes 0..2, keep byte 3
+  return (uint32_t)l[p & 0xFF] | ((uint32_t)l[(p >> 8) & 0xFF] << 8) | ((uint32_t)l[(p >> 16) & 0xFF] << 16) | (p & 0xFF000000u);
+}
+__device__ __forceinline__ uint32_t lut3_argb(const uint8_t *l, uint32_t p) {   // LUT on bytes 1..3, keep byte 0
+  return (p & 0xFFu) | ((uint32_t)l[(p >> 8) & 0xFF] << 8) | ((uint32_t)l[(p >> 16) & 0xFF] << 16) | ((uint32_t)l[p >> 24] << 24);
+}
+__device__ __forceinline__ uint32_t lut4(const uint8_t *l, uint32_t p) {
+  return (uint32_t)l[p & 0xFF] | ((uint32_t)l[(p >> 8) & 0xFF] << 8) | ((uint32_t)l[(p >> 16) & 0xFF] << 16) | ((uint32_t)l[p >> 24] << 24);
+}
+__device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+// --- per-lane 4-pixel gather / scatter ------------------------------------------------------------------
+// 3-byte pixels: 12 contiguous bytes d0 d1 d2 -> four dwords [c0 c1 c2 x]
+__device__ __forceinline__ void unpack3(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t p[4]) {
+  p[0] = d0;
+  p[1] = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);   // d0.b3 d1.b0 d1.b1
+  p[2] = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);   // d1.b2 d1.b3 d2.b0
+  p[3] = d2 >> 8;
+}
+// four dwords [o0 o1 o2 x] -> 12 contiguous bytes
+__device__ __forceinline__ void pack3(const uint32_t q[4], uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+  w0 = __builtin_amdgcn_perm(q[1], q[0], 0x04020100u);   // q0.b0 q0.b1 q0.b2 q1.b0
+  w1 = __builtin_amdgcn_perm(q[2], q[1], 0x05040201u);   // q1.b1 q1.b2 q2.b0 q2.b1
+  w2 = __builtin_amdgcn_perm(q[3], q[2], 0x06050402u);   // q2.b2 q3.b0 q3.b1 q3.b2
+}
+
+#endif
+
+}  // namespace lgpu

@@ -1,0 +1,263 @@
+// swizzle.hip -- K1 packed-RGB swizzles, K6 gamma-LUT apply, K9 alpha (un)premultiply.
+//
+// All three are pure HBM streaming kernels: 1 read + 1 write of the frame, no reuse.  One lane moves
+// 4 pixels (16 B of a 4-byte palette, 12 B of a 3-byte one) so every wavefront issues full-width,
+// contiguous global accesses; byte shuffles are v_perm_b32; the 256-byte gamma LUT rides in the
+// kernarg segment and is staged to LDS once per workgroup.
+#include "lgpu_common.h"
+
+namespace lgpu {
+
+// selector bytes: 0..3 = source byte of the (normalised) input pixel, 0x0D = constant 0xFF
+struct SwzDesc {
+  uint32_t sel;       // v_perm selector applied to {0, pixel}
+  uint32_t lutmask;   // output bytes that go through the gamma LUT (colour bytes)
+  int ibpp, obpp;
+};
+
+static bool swz_desc(int op, int alpha_first, SwzDesc *d) {
+  // out byte k <- in byte s[k]; 0xFF = new opaque alpha; a[k] = 1 when out byte k carries alpha
+  uint8_t s[4] = {0, 0, 0, 0}, a[4] = {0, 0, 0, 0};
+  auto set = [&](int ib, int ob, int s0, int s1, int s2, int s3) { d->ibpp = ib; d->obpp = ob; s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3; };
+  switch (op) {
+  case LGPU_SWAP3: set(3, 3, 2, 1, 0, 0); break;
+  case LGPU_SWAP4: set(4, 4, 3, 2, 1, 0); a[alpha_first ? 3 : 0] = 1; break;
+  case LGPU_SWAP3ADDPOST: set(3, 4, 2, 1, 0, 0xFF); break;
+  case LGPU_SWAP3ADDPRE: set(3, 4, 0xFF, 2, 1, 0); break;
+  case LGPU_SWAP3POSTALPHA: set(4, 4, 2, 1, 0, 3); a[3] = 1; break;
+  case LGPU_SWAP3PREALPHA: set(4, 4, 0, 3, 2, 1); a[0] = 1; break;
+  case LGPU_ADDPOST: set(3, 4, 0, 1, 2, 0xFF); break;
+  case LGPU_ADDPRE: set(3, 4, 0xFF, 0, 1, 2); break;
+  case LGPU_SWAP3DELPOST: set(4, 3, 2, 1, 0, 0); break;
+  case LGPU_DELPOST: set(4, 3, 0, 1, 2, 0); break;
+  case LGPU_DELPRE: set(4, 3, 1, 2, 3, 0); break;
+  case LGPU_SWAP3DELPRE: set(4, 3, 3, 2, 1, 0); break;
+  case LGPU_SWAPPREPOST:
+    if (alpha_first) { set(4, 4, 1, 2, 3, 0); a[3] = 1; } else { set(4, 4, 3, 0, 1, 2); a[0] = 1; }
+    break;
+  default: return false;
+  }
+  d->sel = 0; d->lutmask = 0;
+  for (int k = 0; k < 4; k++) {
+    const bool konst = (s[k] == 0xFF);
+    d->sel |= (uint32_t)(konst ? 0x0D : s[k]) << (8 * k);
+    if (!konst && !a[k] && k < d->obpp) d->lutmask |= 0xFFu << (8 * k);
+  }
+  return true;
+}
+
+template <int IB, int OB, bool LUT>
+__global__ __launch_bounds__(kBlock) void k_swizzle(const uint8_t *__restrict__ src, int irow, uint8_t *dst, int orow,
+                                                     int width, int height, uint32_t sel, uint32_t lutmask, Lut8 lut) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  if (LUT) { stage_lut(s_lut, lut); __syncthreads(); }
+  const int groups = width >> 2;                     // full 4-pixel groups per row
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    const uint8_t *ip = src + (size_t)y * irow;
+    uint8_t *op = dst + (size_t)y * orow;
+    if (g < groups) {
+      uint32_t p[4], q[4];
+      if (IB == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ip + (size_t)g * 16);
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+      } else {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(ip + (size_t)g * 12);
+        unpack3(w[0], w[1], w[2], p);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t t = __builtin_amdgcn_perm(0u, p[k], sel);
+        if (LUT) t = (lut4(s_lut, t) & lutmask) | (t & ~lutmask);
+        q[k] = t;
+      }
+      if (OB == 4) {
+        *reinterpret_cast<uint4 *>(op + (size_t)g * 16) = make_uint4(q[0], q[1], q[2], q[3]);
+      } else {
+        uint32_t w0, w1, w2;
+        pack3(q, w0, w1, w2);
+        uint32_t *o = reinterpret_cast<uint32_t *>(op + (size_t)g * 12);
+        o[0] = w0; o[1] = w1; o[2] = w2;
+      }
+    } else if (g == groups) {
+      // ragged tail: up to 3 pixels, byte-wise
+      for (int x = groups * 4; x < width; x++) {
+        uint32_t pin = 0;
+        for (int b = 0; b < IB; b++) pin |= (uint32_t)ip[x * IB + b] << (8 * b);
+        uint32_t t = __builtin_amdgcn_perm(0u, pin, sel);
+        if (LUT) t = (lut4(s_lut, t) & lutmask) | (t & ~lutmask);
+        for (int b = 0; b < OB; b++) op[x * OB + b] = (uint8_t)(t >> (8 * b));
+      }
+    }
+  }
+}
+
+// any alignment: one pixel per lane, byte accesses
+template <bool LUT>
+__global__ __launch_bounds__(kBlock) void k_swizzle_bytes(const uint8_t *__restrict__ src, int irow, uint8_t *dst, int orow,
+                                                           int width, int height, int ib, int ob, uint32_t sel,
+                                                           uint32_t lutmask, Lut8 lut) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  if (LUT) { stage_lut(s_lut, lut); __syncthreads(); }
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= width) return;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    const uint8_t *ip = src + (size_t)y * irow + (size_t)x * ib;
+    uint8_t *op = dst + (size_t)y * orow + (size_t)x * ob;
+    uint32_t pin = ip[0] | ((uint32_t)ip[1] << 8) | ((uint32_t)ip[2] << 16);
+    if (ib == 4) pin |= (uint32_t)ip[3] << 24;
+    uint32_t t = __builtin_amdgcn_perm(0u, pin, sel);
+    if (LUT) t = (lut4(s_lut, t) & lutmask) | (t & ~lutmask);
+    op[0] = (uint8_t)t; op[1] = (uint8_t)(t >> 8); op[2] = (uint8_t)(t >> 16);
+    if (ob == 4) op[3] = (uint8_t)(t >> 24);
+  }
+}
+
+// --- K6 -------------------------------------------------------------------------------------------------
+// The rectangle's rows are treated as byte ranges; each lane owns one 16-byte aligned chunk.  `chanmask`
+// marks the colour bytes of a dword (0x00FFFFFF RGBA/BGRA, 0xFFFFFF00 ARGB, 0xFFFFFFFF 3-byte palettes).
+__global__ __launch_bounds__(kBlock) void k_gamma_apply(uint8_t *pix, int rowstride, int byte0, int byte1, int height,
+                                                         uint32_t chanmask, Lut8 lut) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+  const int c0 = byte0 & ~15;
+  const int o = c0 + (blockIdx.x * kBlock + threadIdx.x) * 16;
+  if (o >= byte1) return;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    uint8_t *row = pix + (size_t)y * rowstride;
+    if (o >= byte0 && o + 16 <= byte1) {
+      uint4 v = *reinterpret_cast<uint4 *>(row + o);
+      v.x = (lut4(s_lut, v.x) & chanmask) | (v.x & ~chanmask);
+      v.y = (lut4(s_lut, v.y) & chanmask) | (v.y & ~chanmask);
+      v.z = (lut4(s_lut, v.z) & chanmask) | (v.z & ~chanmask);
+      v.w = (lut4(s_lut, v.w) & chanmask) | (v.w & ~chanmask);
+      *reinterpret_cast<uint4 *>(row + o) = v;
+    } else {
+      for (int b = (o < byte0 ? byte0 : o); b < o + 16 && b < byte1; b++)
+        if ((chanmask >> (8 * (b & 3))) & 0xFF) row[b] = s_lut[row[b]];
+    }
+  }
+}
+// rows that are not 16-byte aligned: one byte per lane
+__global__ __launch_bounds__(kBlock) void k_gamma_apply_bytes(uint8_t *pix, int rowstride, int byte0, int byte1, int height,
+                                                               int psize, int alpha_first, Lut8 lut) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+  const int b = byte0 + blockIdx.x * kBlock + threadIdx.x;
+  if (b >= byte1) return;
+  if (psize == 4 && ((b & 3) == (alpha_first ? 0 : 3))) return;   // rows start on a pixel boundary
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    uint8_t *p = pix + (size_t)y * rowstride + b;
+    *p = s_lut[*p];
+  }
+}
+
+// --- K9 -------------------------------------------------------------------------------------------------
+// table-free: the reference tables are al[a][v] = CLAMP0255f((float)v * (255.f / a)) and
+// unal[a][v] = CLAMP0255f((float)v / (255.f / a))  (src/colourspace.c:1141-1160); two IEEE float ops and a
+// double-precision round reproduce every one of the 2 x 65536 entries (tests/test_premult_gpu.py sweeps them).
+__device__ __forceinline__ uint32_t premult_byte(uint32_t v, float ratio, bool un) {
+  const float a = un ? __fdiv_rn((float)v, ratio) : __fmul_rn((float)v, ratio);
+  if (a != a) return 0;
+  const double d = (double)a;
+  return d >= 254.5 ? 255u : d < -0.5 ? 0u : (uint32_t)(int)(d + .5);
+}
+__global__ __launch_bounds__(kBlock) void k_premult(uint8_t *pix, int rowstride, int width, int height, int alpha_first, int un) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= width) return;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    uint32_t *pp = reinterpret_cast<uint32_t *>(pix + (size_t)y * rowstride) + x;
+    const uint32_t p = *pp;
+    const uint32_t al = alpha_first ? (p & 0xFF) : (p >> 24);
+    const float ratio = __fdiv_rn(255.f, (float)al);
+    uint32_t o;
+    if (alpha_first)
+      o = al | (premult_byte((p >> 8) & 0xFF, ratio, un) << 8) | (premult_byte((p >> 16) & 0xFF, ratio, un) << 16) |
+          (premult_byte(p >> 24, ratio, un) << 24);
+    else
+      o = premult_byte(p & 0xFF, ratio, un) | (premult_byte((p >> 8) & 0xFF, ratio, un) << 8) |
+          (premult_byte((p >> 16) & 0xFF, ratio, un) << 16) | (al << 24);
+    *pp = o;
+  }
+}
+
+static inline dim3 row_grid(unsigned items_per_row, int height) {
+  unsigned gy = (unsigned)height;
+  if (gy > 4096) gy = 4096;
+  return dim3(cdiv(items_per_row, kBlock), gy, 1);
+}
+
+}  // namespace lgpu
+
+using namespace lgpu;
+
+extern "C" int lgpu_swizzle(int op, int alpha_first, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow,
+                            int width, int height, const uint8_t *lut8, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  SwzDesc d;
+  LGPU_REQUIRE(swz_desc(op, alpha_first, &d), "unknown swizzle op");
+  LGPU_REQUIRE(src_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(irow >= width * d.ibpp && orow >= width * d.obpp, "rowstride smaller than a row");
+  LGPU_REQUIRE(src_d != dst_d || d.ibpp == d.obpp, "in-place needs equal pixel sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const Lut8 l = pack_lut(lut8);
+  const bool iv = (d.ibpp == 4) ? (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 : (((uintptr_t)src_d | (uintptr_t)irow) & 3) == 0;
+  const bool ov = (d.obpp == 4) ? (((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0 : (((uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0;
+  if (iv && ov) {
+    const dim3 grid = row_grid((unsigned)(width >> 2) + 1, height);
+#define LAUNCH(IB, OB)                                                                                                   \
+  do {                                                                                                                   \
+    if (lut8) hipLaunchKernelGGL((k_swizzle<IB, OB, true>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.sel, d.lutmask, l); \
+    else hipLaunchKernelGGL((k_swizzle<IB, OB, false>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.sel, d.lutmask, l);     \
+  } while (0)
+    if (d.ibpp == 3 && d.obpp == 3) LAUNCH(3, 3);
+    else if (d.ibpp == 3) LAUNCH(3, 4);
+    else if (d.obpp == 3) LAUNCH(4, 3);
+    else LAUNCH(4, 4);
+#undef LAUNCH
+  } else {
+    const dim3 grid = row_grid((unsigned)width, height);
+    if (lut8) hipLaunchKernelGGL((k_swizzle_bytes<true>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.ibpp, d.obpp, d.sel, d.lutmask, l);
+    else hipLaunchKernelGGL((k_swizzle_bytes<false>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.ibpp, d.obpp, d.sel, d.lutmask, l);
+  }
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_gamma_apply(uint8_t *pix_d, int rowstride, int x, int y, int width, int height, int psize,
+                                int alpha_first, const uint8_t *lut8, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(pix_d && width > 0 && height > 0 && x >= 0 && y >= 0, "null frame or empty rectangle");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(rowstride >= (x + width) * psize, "rectangle exceeds the row");
+  if (!lut8) return LGPU_OK;   // reference: no LUT -> nothing to do (src/colourspace.c:14046)
+  const Lut8 l = pack_lut(lut8);
+  uint8_t *base = pix_d + (size_t)y * rowstride;
+  const int b0 = x * psize, b1 = (x + width) * psize;
+  hipStream_t st = (hipStream_t)stream;
+  if ((((uintptr_t)base | (uintptr_t)rowstride) & 15) == 0) {
+    const uint32_t chanmask = psize == 3 ? 0xFFFFFFFFu : alpha_first ? 0xFFFFFF00u : 0x00FFFFFFu;
+    const unsigned chunks = (unsigned)((b1 - (b0 & ~15) + 15) >> 4);
+    hipLaunchKernelGGL(k_gamma_apply, row_grid(chunks, height), dim3(kBlock), 0, st, base, rowstride, b0, b1, height, chanmask, l);
+  } else {
+    hipLaunchKernelGGL(k_gamma_apply_bytes, row_grid((unsigned)(b1 - b0), height), dim3(kBlock), 0, st, base, rowstride, b0, b1,
+                       height, psize, alpha_first, l);
+  }
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int height, int alpha_first, int un, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(pix_d && width > 0 && height > 0 && rowstride >= width * 4, "bad geometry");
+  LGPU_REQUIRE((((uintptr_t)pix_d | (uintptr_t)rowstride) & 3) == 0, "4-byte pixels must be 4-byte aligned");
+  hipLaunchKernelGGL(k_premult, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width,
+                     height, alpha_first, un);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

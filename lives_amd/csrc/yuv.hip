@@ -1,0 +1,197 @@
+// yuv.hip -- K2: planar YUV 4:2:0 / 4:2:2 -> packed RGB(A) with the reference's chroma super-sampling and
+// (optionally) the gamma LUT of the gamma_convert_layer() pass fused into the store.
+//
+// Replaces convert_yuv420p_to_rgb_frame (src/colourspace.c:3260-3904).  HBM-bound: 1.5 B read + 3/4 B
+// written per pixel.  One lane owns a 2x2 output quad (one chroma column pair k of one luma row pair),
+// consecutive lanes own consecutive k, so luma loads are 2 B/lane contiguous, chroma loads hit the same
+// cache lines three times (k-1, k, k+1) and stores are 8 B/lane contiguous per row.  The five int32
+// conversion tables (5 KB) are staged in LDS once per workgroup together with the LUT.
+//
+// Reference behaviours kept bit-for-bit (see DESIGN.md, quirk list K2-a..e):
+//   - left pixel of a pair: second-row U sum rebuilt from the first row (:3461); V of row r paired with the
+//     previous V of row r+1 (:3544); "last V" of row r+1 frozen at column 0
+//   - right pixel of the last pair reads the chroma sample one past the row end
+//   - last row (1-thread reference): luma from row 0, "next" chroma from chroma row 0, even x only
+// Pixels whose reference value is undefined (row 0 odd x: out-of-bounds table index; last row odd x: never
+// written) get the evident intent.
+#include "lgpu_common.h"
+
+namespace lgpu {
+
+struct YuvArgs {
+  const uint8_t *y, *u, *v;
+  uint8_t *dst;
+  const int32_t *tables;   // [5][256] RGB_Y R_Cr G_Cb G_Cr B_Cb (device)
+  long usize, vsize;
+  int ys, us, vs, orow;
+  int width, height;
+  int opsize, order;       // order: 0 RGB(A), 1 BGR(A), 2 ARGB
+  int clamped, low_quality, fix_edges, use_lut;
+};
+
+__device__ __forceinline__ int cuv_c(int n) {   // CLAMP16_240 (src/colourspace.h:19)
+  if (n < 0) return 16;
+  if (n > 255 || (n & 0xF0) == 0xF0) return 240;
+  return (n & 0xF0) ? n : 16;
+}
+
+struct YuvCtx {
+  const int32_t *ty, *rcr, *gcb, *gcr, *bcb;
+  const uint8_t *lut;
+  bool clamped, lowq, use_lut;
+  int opsize, order;
+  __device__ __forceinline__ int cuv(int n) const { return clamped ? cuv_c(n) : (n < 0 ? 0 : n > 255 ? 255 : n); }
+  // (2a + b) / 3 and (a + 2b) / 3 on doubled sums; (int)(s / 3. + .5) == (s + 1) / 3 for s >= 0 (:3464-3469)
+  __device__ __forceinline__ void vblend(int s1, int s2, int &top, int &bot) const {
+    if (!lowq) { top = cuv((s1 + (s2 >> 1) + 1) / 3); bot = cuv(((s1 >> 1) + s2 + 1) / 3); }
+    else { top = cuv(s1 >> 1); bot = cuv(s2 >> 1); }
+  }
+  __device__ __forceinline__ uint32_t rgb(int y, int u, int v) const {   // xyuv2rgb (:2351-2356), >>16 (:832-835)
+    const int yy = ty[y];
+    uint32_t r = clamp255((yy + rcr[v]) >> 16), g = clamp255((yy + gcb[u] + gcr[v]) >> 16), b = clamp255((yy + bcb[u]) >> 16);
+    if (use_lut) { r = lut[r]; g = lut[g]; b = lut[b]; }
+    if (order == 0) return r | (g << 8) | (b << 16) | 0xFF000000u;
+    if (order == 1) return b | (g << 8) | (r << 16) | 0xFF000000u;
+    return 0xFFu | (r << 8) | (g << 16) | (b << 24);
+  }
+  __device__ __forceinline__ void store2(uint8_t *d, uint32_t p0, uint32_t p1) const {
+    if (opsize == 4) {
+      if ((reinterpret_cast<uintptr_t>(d) & 7) == 0) *reinterpret_cast<uint2 *>(d) = make_uint2(p0, p1);
+      else { reinterpret_cast<uint32_t *>(d)[0] = p0; reinterpret_cast<uint32_t *>(d)[1] = p1; }
+    } else {
+      d[0] = (uint8_t)p0; d[1] = (uint8_t)(p0 >> 8); d[2] = (uint8_t)(p0 >> 16);
+      d[3] = (uint8_t)p1; d[4] = (uint8_t)(p1 >> 8); d[5] = (uint8_t)(p1 >> 16);
+    }
+  }
+};
+
+__global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut) {
+  __shared__ int32_t s_tab[5 * 256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+
+  YuvCtx c;
+  c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
+  c.lut = s_lut; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
+
+  const int hw = a.width >> 1;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= hw) return;
+  const int ops = a.opsize;
+  const int H = a.height;
+  // units: 0 = row 0; p >= 1 = rows (2p-1, 2p) while 2p <= H-1; then (even H) the trailing row H-1
+  const int npairs = (H - 1) / 2;                      // number of full row pairs starting at row 1
+  const int nunits = 1 + npairs + (((H - 1) & 1) ? 1 : 0);
+  auto PU = [&](int r, int kk) -> int { long i = (long)r * a.us + kk; return a.u[i < a.usize ? i : a.usize - 1]; };
+  auto PV = [&](int r, int kk) -> int { long i = (long)r * a.vs + kk; return a.v[i < a.vsize ? i : a.vsize - 1]; };
+
+  for (int unit = blockIdx.y; unit < nunits; unit += gridDim.y) {
+    if (unit == 0) {
+      // row 0 (:3399-3443)
+      const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
+      const uint32_t p0 = c.rgb(a.y[2 * k], c.cuv((PU(0, k) + PU(0, kp)) >> 1), c.cuv((PV(0, k) + PV(0, kp)) >> 1));
+      const uint32_t p1 = c.rgb(a.y[2 * k + 1], c.cuv((PU(0, k) + PU(0, kn)) >> 1), c.cuv((PV(0, k) + PV(0, kn)) >> 1));
+      c.store2(a.dst + (size_t)(2 * k) * ops, p0, p1);
+    } else if (unit <= npairs) {
+      // rows (i, i+1), chroma rows r and r+1 (:3445-3554)
+      const int i = 2 * unit - 1, r = i >> 1;
+      const uint8_t *y0 = a.y + (size_t)i * a.ys + 2 * k, *y1 = y0 + a.ys;
+      uint8_t *d0 = a.dst + (size_t)i * a.orow + (size_t)(2 * k) * ops, *d1 = d0 + a.orow;
+      const int u_rk = PU(r, k), v_rk = PV(r, k), v_r1k = PV(r + 1, k);
+      int ut, ub, vt, vb;
+      // left pixel
+      const int lu1 = k ? PU(r, k - 1) : u_rk;
+      const int lv1 = k ? PV(r + 1, k - 1) : v_rk;
+      const int lv2 = PV(r + 1, 0);
+      c.vblend(u_rk + lu1, u_rk + lu1, ut, ub);
+      c.vblend(v_rk + lv1, v_r1k + lv2, vt, vb);
+      const uint32_t a0 = c.rgb(y0[0], ut, vt), b0 = c.rgb(y1[0], ub, vb);
+      // right pixel
+      c.vblend(u_rk + PU(r, k + 1), PU(r + 1, k) + PU(r + 1, k + 1), ut, ub);
+      c.vblend(v_rk + PV(r, k + 1), v_r1k + PV(r + 1, k + 1), vt, vb);
+      const uint32_t a1 = c.rgb(y0[1], ut, vt), b1 = c.rgb(y1[1], ub, vb);
+      c.store2(d0, a0, a1);
+      c.store2(d1, b0, b1);
+    } else {
+      // trailing row H-1 (:3556-3592)
+      const int i = H - 1, r = i >> 1;
+      const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
+      const uint8_t *yr = a.y + (size_t)i * a.ys;
+      uint32_t p0;
+      if (a.fix_edges) {
+        p0 = c.rgb(yr[2 * k], c.cuv((PU(r, k) + PU(r, kp)) >> 1), c.cuv((PV(r, k) + PV(r, kp)) >> 1));
+      } else {
+        // 1-thread reference: this/last walk = {row r col 0, row r col 0, row 0 col 1, row 0 col 2, ...}
+        const int tu = k ? PU(0, k) : PU(r, 0), tv = k ? PV(0, k) : PV(r, 0);
+        const int lu = (k >= 2) ? PU(0, k - 1) : PU(r, 0), lv = (k >= 2) ? PV(0, k - 1) : PV(r, 0);
+        p0 = c.rgb(a.y[2 * k], c.cuv((tu + lu) >> 1), c.cuv((tv + lv) >> 1));
+      }
+      const uint32_t p1 = c.rgb(yr[2 * k + 1], c.cuv((PU(r, k) + PU(r, kn)) >> 1), c.cuv((PV(r, k) + PV(r, kn)) >> 1));
+      c.store2(a.dst + (size_t)i * a.orow + (size_t)(2 * k) * ops, p0, p1);
+    }
+  }
+}
+
+// 4:2:2 (:3593-3640 / :3858-3901): row i, pair k; "last/this" are seeded from chroma row i>>1 (reference)
+__global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut) {
+  __shared__ int32_t s_tab[5 * 256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+  YuvCtx c;
+  c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
+  c.lut = s_lut; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
+  const int hw = a.width >> 1;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= hw) return;
+  auto PU = [&](int r, int kk) -> int { long i = (long)r * a.us + kk; return a.u[i < a.usize ? i : a.usize - 1]; };
+  auto PV = [&](int r, int kk) -> int { long i = (long)r * a.vs + kk; return a.v[i < a.vsize ? i : a.vsize - 1]; };
+  for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
+    const int tu = k ? PU(i, k) : PU(i >> 1, 0), tv = k ? PV(i, k) : PV(i >> 1, 0);
+    const int lu = (k >= 2) ? PU(i, k - 1) : PU(i >> 1, 0), lv = (k >= 2) ? PV(i, k - 1) : PV(i >> 1, 0);
+    const int nu = PU(i, k + 1), nv = PV(i, k + 1);
+    const uint8_t *yr = a.y + (size_t)i * a.ys + 2 * k;
+    const uint32_t p0 = c.rgb(yr[0], c.cuv((tu + lu) >> 1), c.cuv((tv + lv) >> 1));
+    const uint32_t p1 = c.rgb(yr[1], c.cuv((tu + nu) >> 1), c.cuv((tv + nv) >> 1));
+    c.store2(a.dst + (size_t)i * a.orow + (size_t)(2 * k) * a.opsize, p0, p1);
+  }
+}
+
+}  // namespace lgpu
+
+using namespace lgpu;
+
+extern "C" int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
+                                   long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
+                                   int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                                   const uint8_t *lut8, int flags, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(y_d && u_d && v_d && dst_d && istrides, "null plane");
+  LGPU_REQUIRE(width >= 2 && !(width & 1) && height >= 1, "width must be even and >= 2");
+  LGPU_REQUIRE(opsize == 3 || opsize == 4, "opsize must be 3 or 4");
+  LGPU_REQUIRE(out_order >= 0 && out_order <= 2, "bad out_order");
+  if (out_order == 2) opsize = 4;
+  LGPU_REQUIRE(orow >= width * opsize, "output rowstride smaller than a row");
+  LGPU_REQUIRE(opsize == 3 || (((uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0, "4-byte output must be 4-byte aligned");
+  LGPU_REQUIRE(u_size > 0 && v_size > 0, "chroma plane sizes required");
+  if (pb_quality == 3) { set_error("pb_quality HIGH (float rounding of spc_rnd) is not implemented on the GPU path"); return LGPU_E_UNSUPPORTED; }
+  const DeviceTables *t = device_tables();
+  YuvArgs a;
+  a.y = y_d; a.u = u_d; a.v = v_d; a.dst = dst_d; a.tables = t->yuv2rgb[which_tables & 3];
+  a.usize = u_size; a.vsize = v_size;
+  a.ys = istrides[0]; a.us = istrides[1]; a.vs = istrides[2]; a.orow = orow;
+  a.width = width; a.height = height; a.opsize = opsize; a.order = out_order;
+  a.clamped = !(which_tables & 1); a.low_quality = (pb_quality == 1); a.fix_edges = (flags & LGPU_YUV_FIX_EDGES) ? 1 : 0;
+  a.use_lut = lut8 ? 1 : 0;
+  const Lut8 l = pack_lut(lut8);
+  const int units = is_422 ? height : height / 2 + 1;
+  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > 2048 ? 2048 : units), 1);
+  if (is_422) hipLaunchKernelGGL(k_yuv422p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l);
+  else hipLaunchKernelGGL(k_yuv420p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

@@ -1,0 +1,100 @@
+"""ctypes view of liblivesgpu.so (the C ABI declared in include/lives_gpu.h).
+
+The product is the shared library; this module is the thinnest possible Python binding for tests and
+bench.py.  It fails loudly when the library is missing or a call returns an error -- there is no
+Python / CPU fallback for any pixel work.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "liblivesgpu.so")
+
+vp = ctypes.c_void_p
+ci = ctypes.c_int
+cl = ctypes.c_long
+cd = ctypes.c_double
+u8p = ctypes.POINTER(ctypes.c_uint8)
+
+LGPU_CHAIN_MAX_TRACKS = 64
+
+(SWAP3, SWAP4, SWAP3ADDPOST, SWAP3ADDPRE, SWAP3POSTALPHA, SWAP3PREALPHA, ADDPOST, ADDPRE, SWAP3DELPOST, DELPOST,
+ DELPRE, SWAP3DELPRE, SWAPPREPOST) = range(13)
+YUV_FIX_EDGES = 1
+
+
+class LgpuError(RuntimeError):
+    pass
+
+
+class ChainTrack(ctypes.Structure):
+    _fields_ = [("src_d", vp), ("layer2_d", vp), ("dst_d", vp)]
+
+
+class ChainParams(ctypes.Structure):
+    _fields_ = [("sw", ci), ("sh", ci), ("irow", ci), ("dw", ci), ("dh", ci), ("irow2", ci), ("orow", ci),
+                ("swap_rb", ci), ("interp", ci), ("do_blur", ci), ("bf", ci), ("use_lut", ci),
+                ("lut8", ctypes.c_uint8 * 256)]
+
+
+# name -> argtypes; every entry point include/lives_gpu.h declares must appear here (tests check both ways)
+PROTOTYPES = {
+    "lgpu_abi_version": [],
+    "lgpu_init": [ci],
+    "lgpu_device_count": [],
+    "lgpu_malloc": [ctypes.POINTER(vp), ctypes.c_size_t],
+    "lgpu_free": [vp],
+    "lgpu_upload": [vp, vp, ctypes.c_size_t, vp],
+    "lgpu_download": [vp, vp, ctypes.c_size_t, vp],
+    "lgpu_sync": [vp],
+    "lgpu_conversion_tables": [ci, vp, vp],
+    "lgpu_gamma_lut8": [cd, ci, ci, cd, vp],
+    "lgpu_calc_rowstrides": [ci, ci, ci, vp],
+    "lgpu_swizzle": [ci, ci, vp, ci, vp, ci, ci, ci, vp, vp],
+    "lgpu_gamma_apply": [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp],
+    "lgpu_alpha_premult": [vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_yuv420p_to_rgb": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
+    "lgpu_letterbox": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp],
+    "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
+    "lgpu_make_filter": [ci, ci, ci, vp, vp, vp, ci],
+    "lgpu_gauss5": [vp, ci, vp, ci, ci, ci, ci, vp],
+    "lgpu_blend_chroma": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
+    "lgpu_blend_luma": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
+    "lgpu_blend_multi": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_colorkey": [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, cd, ci, ci, ci, vp],
+    "lgpu_mirror": [ci, vp, ci, vp, ci, ci, ci, ci, vp],
+    "lgpu_chain": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci, vp],
+    "lgpu_chain_timed": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci, ci, ctypes.POINTER(ctypes.c_float), vp],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen liblivesgpu.so; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise LgpuError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(lives_amd/csrc/build.sh).  There is no CPU fallback." % SO_PATH)
+        lib = ctypes.CDLL(SO_PATH)
+        for name, args in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ci
+        lib.lgpu_last_error.restype = ctypes.c_char_p
+        lib.lgpu_last_error.argtypes = []
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().lgpu_last_error()
+        raise LgpuError("%s failed (%d): %s" % (what or "lgpu call", rc, msg.decode() if msg else ""))
+    return rc
+
+
+def call(name, *args):
+    """call an entry point and raise LgpuError on a negative return code"""
+    return check(getattr(load(), name)(*args), name)

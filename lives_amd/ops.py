@@ -1,0 +1,127 @@
+"""Torch-tensor front end over the C ABI (device memory + streams come from PyTorch-ROCm; every pixel is
+computed by liblivesgpu.so).  Frames are 2-D uint8 CUDA tensors [rows, rowstride_bytes].
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib
+
+vp = ctypes.c_void_p
+
+
+def stream_ptr():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, byte_offset=0):
+    assert t.is_cuda and t.dtype == torch.uint8
+    return vp(t.data_ptr() + byte_offset)
+
+
+def lut_ptr(lut):
+    """host LUT (numpy uint8[256] or None) -> pointer kept alive by the caller"""
+    if lut is None:
+        return None
+    lut = np.ascontiguousarray(lut, dtype=np.uint8)
+    assert lut.size == 256
+    return lut.ctypes.data_as(vp), lut
+
+
+def init(device=0):
+    torch.cuda.set_device(device)
+    lib.call("lgpu_init", device)
+
+
+def swizzle(op, src, dst, width, height, alpha_first=0, lut=None):
+    lp = lut_ptr(lut)
+    lib.call("lgpu_swizzle", op, alpha_first, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height,
+             lp[0] if lp else None, stream_ptr())
+
+
+def gamma_apply(pix, width, height, psize, lut, alpha_first=0, x=0, y=0):
+    lp = lut_ptr(lut)
+    lib.call("lgpu_gamma_apply", dptr(pix), pix.stride(0), x, y, width, height, psize, alpha_first, lp[0] if lp else None,
+             stream_ptr())
+
+
+def alpha_premult(pix, width, height, alpha_first=0, un=0):
+    lib.call("lgpu_alpha_premult", dptr(pix), pix.stride(0), width, height, alpha_first, un, stream_ptr())
+
+
+def yuv420p_to_rgb(y, u, v, dst, width, height, opsize=4, out_order=0, is_422=0, which_tables=0, pb_quality=2, lut=None,
+                   flags=0, u_size=None, v_size=None):
+    strides = (ctypes.c_int * 3)(y.stride(0), u.stride(0), v.stride(0))
+    lp = lut_ptr(lut)
+    lib.call("lgpu_yuv420p_to_rgb", dptr(y), dptr(u), dptr(v), strides, u_size if u_size is not None else u.numel(),
+             v_size if v_size is not None else v.numel(), dptr(dst), dst.stride(0), width, height, opsize, out_order, is_422,
+             which_tables, pb_quality, lp[0] if lp else None, flags, stream_ptr())
+
+
+def letterbox(src, dst, width, height, nwidth, nheight, psize, black):
+    b = (ctypes.c_uint8 * 4)(*black)
+    lib.call("lgpu_letterbox", dptr(src), src.stride(0), width, height, dptr(dst), dst.stride(0), nwidth, nheight, psize, b,
+             stream_ptr())
+
+
+def resize(src, dst, sw, sh, dw, dh, psize=4, interp=3, lut=None):
+    lp = lut_ptr(lut)
+    lib.call("lgpu_resize", dptr(src), src.stride(0), sw, sh, dptr(dst), dst.stride(0), dw, dh, psize, interp,
+             lp[0] if lp else None, stream_ptr())
+
+
+def gauss5(src, dst, width, height, psize=4):
+    lib.call("lgpu_gauss5", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
+
+
+def blend_chroma(src1, src2, dst, width, height, psize, bf, alpha_first=0):
+    lib.call("lgpu_blend_chroma", dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width,
+             height, psize, alpha_first, bf, stream_ptr())
+
+
+def blend_luma(kind, src1, src2, dst, width, height, psize, pal_order, thresh):
+    lib.call("lgpu_blend_luma", kind, dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width,
+             height, psize, pal_order, thresh, stream_ptr())
+
+
+def blend_multi(kind, src1, src2, dst, width, height, is_bgr, bf):
+    lib.call("lgpu_blend_multi", kind, dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width,
+             height, is_bgr, bf, stream_ptr())
+
+
+def colorkey(src0, src1, dst, width, height, is_bgr, delta, opac, col):
+    lib.call("lgpu_colorkey", dptr(src0), src0.stride(0), dptr(src1), src1.stride(0), dptr(dst), dst.stride(0), width, height,
+             is_bgr, float(delta), float(opac), int(col[0]), int(col[1]), int(col[2]), stream_ptr())
+
+
+def mirror(mode, src, dst, width, height, psize):
+    lib.call("lgpu_mirror", mode, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
+
+
+def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None):
+    p = lib.ChainParams()
+    p.sw, p.sh, p.irow, p.dw, p.dh, p.irow2, p.orow = sw, sh, irow, dw, dh, irow2, orow
+    p.swap_rb, p.interp, p.do_blur, p.bf = swap_rb, interp, do_blur, bf
+    p.use_lut = 1 if lut is not None else 0
+    if lut is not None:
+        ctypes.memmove(p.lut8, np.ascontiguousarray(lut, dtype=np.uint8).ctypes.data, 256)
+    return p
+
+
+def chain_tracks(srcs, layer2s, dsts):
+    n = len(srcs)
+    arr = (lib.ChainTrack * n)()
+    for i in range(n):
+        arr[i].src_d, arr[i].layer2_d, arr[i].dst_d = srcs[i].data_ptr(), layer2s[i].data_ptr(), dsts[i].data_ptr()
+    return arr
+
+
+def chain(params, tracks):
+    lib.call("lgpu_chain", ctypes.byref(params), tracks, len(tracks), stream_ptr())
+
+
+def chain_timed(params, tracks, reps):
+    ms = ctypes.c_float()
+    lib.call("lgpu_chain_timed", ctypes.byref(params), tracks, len(tracks), reps, ctypes.byref(ms), stream_ptr())
+    return ms.value

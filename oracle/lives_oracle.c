@@ -108,7 +108,8 @@ void orc_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb) {
  * Deterministic quirks kept on purpose: X->LINEAR is the identity; the source gamma is
  * forgotten after the first table entry; the encode branch tops out at 246.
  * ---------------------------------------------------------------------------------------------- */
-enum { G_UNKNOWN = 0, G_LINEAR = 1, G_SRGB = 2, G_BT709 = 3, G_MONITOR = 1024 };
+/* ids: libweed/weed-palettes.h:180-183, src/colourspace.h:27 */
+enum { G_UNKNOWN = 0, G_LINEAR = -1, G_SRGB = 1, G_BT709 = 2, G_MONITOR = 1024 };
 typedef struct { float offs, lin, thresh, pf; } gconst_t;
 
 static gconst_t gconst_for(int gtype) {

@@ -24,21 +24,46 @@ OP_OBPP = [3, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 4]
 # weed palette ids (libweed/weed-palettes.h:48-57)
 PAL_RGB24, PAL_BGR24, PAL_RGBA32, PAL_BGRA32, PAL_ARGB32 = 1, 2, 3, 4, 5
 # weed gamma ids (libweed/weed-palettes.h) + LiVES extras (src/colourspace.h:27-29)
-GAMMA_UNKNOWN, GAMMA_LINEAR, GAMMA_SRGB, GAMMA_BT709, GAMMA_MONITOR = 0, 1, 2, 3, 1024
+GAMMA_UNKNOWN, GAMMA_LINEAR, GAMMA_SRGB, GAMMA_BT709, GAMMA_MONITOR = 0, -1, 1, 2, 1024
 
 
 def P(a):
     return None if a is None else a.ctypes.data_as(vp)
 
 
-def build_oracle(force=False):
-    so = os.path.join(HERE, "liblives_oracle.so")
+def _cpu_sig():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def build_oracle(force=False, native=False):
+    """compile oracle/*.c -> liblives_oracle.so (portable x86-64-v3 code, travels with gpurun) or, with
+    native=True, liblives_oracle_native.so (-march=native, rebuilt whenever the host CPU differs: used
+    for the cpu_baseline timing so the CPU side gets the reference's --enable-turbo treatment)"""
+    so = os.path.join(HERE, "liblives_oracle_native.so" if native else "liblives_oracle.so")
+    sig = so + ".sig"
     srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_bench.c", "lives_oracle.h")]
     srcs = [s for s in srcs if os.path.exists(s)]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if native and not stale:
+        try:
+            stale = open(sig).read() != _cpu_sig()
+        except OSError:
+            stale = True
+    if stale:
         cs = [s for s in srcs if s.endswith(".c")]
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-shared",
+        march = "-march=native" if native else "-march=x86-64-v3"
+        subprocess.check_call(["gcc", "-O3", march, "-fno-fast-math", "-ffp-contract=off", "-Wall", "-shared",
                                "-fPIC", "-o", so] + cs + ["-lm", "-lpthread"])
+        if native:
+            with open(sig, "w") as f:
+                f.write(_cpu_sig())
     return so
 
 

@@ -67,17 +67,8 @@ typedef void weed_layer_t;
 #define lives_memcpy memcpy
 #define lives_memset memset
 #define MIN(a, b) ((a) < (b) ? (a) : (b))
-/* weed constants the loops test against: libweed/weed-palettes.h */
-#define WEED_YUV_CLAMPING_CLAMPED 0
-#define WEED_YUV_CLAMPING_UNCLAMPED 1
-#define WEED_YUV_SUBSPACE_YUV 0
-#define WEED_YUV_SUBSPACE_YCBCR 1
-#define WEED_YUV_SUBSPACE_BT709 2
-#define WEED_YUV_SAMPLING_DEFAULT 0
-#define WEED_GAMMA_UNKNOWN 0
-#define WEED_GAMMA_LINEAR 1
-#define WEED_GAMMA_SRGB 2
-#define WEED_GAMMA_BT709 3
+/* weed palette / clamping / gamma constants: the reference's own header */
+#include <weed/weed-palettes.h>
 #define PB_QUALITY_LOW 1
 #define PB_QUALITY_MED 2
 #define PB_QUALITY_HIGH 3
@@ -266,7 +257,7 @@ def main():
         f.write("/* GENERATED SCRATCH FILE -- contains reference text; never commit (oracle/_ref is git-ignored) */\n")
         f.write("".join(parts))
     so = os.path.join(OUT, "libcsref.so")
-    cmd = ["gcc", "-shared", "-fPIC", "-O1", "-w", "-fno-strict-aliasing", "-o", so, src, "-lm"]
+    cmd = ["gcc", "-shared", "-fPIC", "-O1", "-w", "-fno-strict-aliasing", "-I", os.path.join(OUT, "inc"), "-o", so, src, "-lm"]
     print(" ".join(cmd))
     r = subprocess.run(cmd)
     if r.returncode:

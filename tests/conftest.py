@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import pyoracle
+    return pyoracle.oracle()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """initialised GPU library; fails (does not skip) if the HIP extension is missing on a GPU box"""
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test on a box without a GPU"
+    from lives_amd import lib, ops
+    lib.load()
+    ops.init(0)
+    return ops
