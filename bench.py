@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- effect-chain frames/sec at 3840x2160 RGBA32 (BASELINE.json metric) on N MI355X GPUs.
+
+A "step" is one pass of the headline chain over one batch of synthetic tracks resident in HBM:
+   3840x2160 BGRA32 -> [convert to RGBA32] -> resize 0.5x (bicubic) -> chroma blend (bf) with a 1920x1080
+   RGBA32 layer -> gamma LUT (linear->sRGB) -> 1920x1080 RGBA32        (north_star: convert->resize->blend->gamma)
+one fused launch of liblivesgpu.so's lgpu_chain() per step, TRACKS_PER_GPU independent tracks per launch.
+Multi-GPU: one process per GPU (torch.distributed / RCCL), tracks sharded track-per-rank with no data-path
+collective; the shared transition parameter block (blend amount) is broadcast from rank 0 over RCCL every
+step and read by the kernel from device memory.  Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : algorithmic bytes / launch  divided by  the kernel's average launch duration, measured live with
+                 HIP events on the launch stream (lgpu_chain_timed), against the 8 TB/s HBM3E peak
+  cpu_baseline : the CPU oracle (a port of the reference path; oracle/) timed on this host's cores on a
+                 bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SW, SH, DW, DH = 3840, 2160, 1920, 1080
+TRACKS_PER_GPU = 16           # 16 x 33 MB sources = 531 MB per step: larger than the 256 MiB Infinity Cache
+# 33,177,600 B source + 8,294,400 B layer 2 read + 8,294,400 B written, per frame per track
+ALGO_BYTES_PER_FRAME = SW * SH * 4 + DW * DH * 4 + DW * DH * 4
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU)
+    ap.add_argument("--blur", type=int, default=0, help="1: add the 5x5 gaussian stage (BASELINE config 5 chain)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from lives_amd import lib, ops
+    ops.init(local_rank)
+
+    # ---- synthetic, device-resident inputs (seeded per rank) ----
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x11FE5 + rank)
+    T = args.tracks
+    srcs = [torch.randint(0, 256, (SH, SW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
+    l2s = [torch.randint(0, 256, (DH, DW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
+    for t in l2s:   # half of layer 2 opaque (integer blend path), half translucent (float path)
+        a = t[:, 3::4]
+        a[torch.rand(a.shape, device="cuda", generator=g) < 0.5] = 255
+    dsts = [torch.zeros((DH, DW * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+
+    from lives_amd.lib import load
+    lut = np.zeros(256, np.uint8)
+    assert load().lgpu_gamma_lut8(1.0, -1, 1, 1.4, lut.ctypes.data) == 1     # WEED_GAMMA_LINEAR -> WEED_GAMMA_SRGB
+
+    # shared transition parameter block: int32[4], [0] = blend amount; broadcast from rank 0 each step
+    pblock = torch.zeros(4, dtype=torch.int32, device="cuda")
+    schedule = torch.tensor([[(96 + 7 * s) % 256, 0, 0, 0] for s in range(args.steps + args.warmup)], dtype=torch.int32, device="cuda")
+    prm = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3, do_blur=args.blur, bf=128, lut=lut,
+                           param_block=pblock)
+    trk = ops.chain_tracks(srcs, l2s, dsts)
+
+    def step(s):
+        if rank == 0:
+            pblock.copy_(schedule[s], non_blocking=True)
+        if world > 1:
+            dist.broadcast(pblock, src=0)          # RCCL over xGMI; stream-ordered, no host sync
+        ops.chain(prm, trk)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames = world * T * args.steps
+    fps = frames / dt
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream around K launches ----
+    reps = max(10, min(args.steps, 200))
+    ms = ops.chain_timed(prm, trk, reps)
+    launch_s = ms * 1e-3 / reps
+    algo = ALGO_BYTES_PER_FRAME * T
+    achieved = algo / launch_s / 1e9
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC run of this exact workload (profiles/), if present
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pj = json.load(f)
+        if pj.get("tracks") == T and pj.get("blur") == args.blur:
+            traffic = pj.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    roof = {"bound": "hbm", "kernel": "lgpu::k_separable<8,8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "effect-chain frames/sec at 3840x2160 RGBA32", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "3840x2160 BGRA32 -> convert(RGBA32) -> bicubic resize 0.5x%s -> chroma blend with 1920x1080 RGBA32 layer -> gamma LUT (linear->sRGB)"
+                                   % (" -> 5x5 gaussian" if args.blur else ""),
+                       "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
+                       "launches_per_step": 2 if args.blur else 1},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.blur)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(blur):
+    """the oracle's threaded runner (reference row-slice rule, one thread per core) on a bounded sample"""
+    from oracle import pyoracle as po
+    import ctypes
+    so = po.build_oracle(native=True)
+    lib_ = ctypes.CDLL(so)
+    lib_.orc_bench_chain.restype = ctypes.c_double
+    lib_.orc_bench_chain.argtypes = [ctypes.c_int] * 7
+    cores = os.cpu_count() or 1
+    probe = lib_.orc_bench_chain(SW, SH, DW, DH, cores, 2, blur)
+    per = max(probe / 2, 1e-4)
+    n = int(max(4, min(400, 12.0 / per)))          # ~12 s of CPU work
+    secs = lib_.orc_bench_chain(SW, SH, DW, DH, cores, n, blur)
+    one = lib_.orc_bench_chain(SW, SH, DW, DH, 1, 2, blur) / 2
+    return {"value": round(n / secs, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same 3840x2160 chain, %d threads (reference row-slice rule), gcc -O3 -march=native" % (n, cores),
+            "single_thread_fps": round(1.0 / one, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,10 @@ typedef struct {
   int bf;                    /* chroma blend amount 0..255 */
   int use_lut;               /* 1: apply lut8 after the blend */
   uint8_t lut8[256];
+  const int32_t *param_block_d; /* optional DEVICE pointer to the shared transition parameter block
+                                   (int32[0] = blend amount); overrides `bf` when non-NULL.  This is the
+                                   block rank 0 broadcasts over RCCL/xGMI in the multi-GPU batch:
+                                   it is read by the kernel, stream-ordered, with no host round trip. */
 } lgpu_chain_params;
 int lgpu_chain(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks, void *stream);
 

@@ -24,6 +24,7 @@
 namespace lgpu {
 
 constexpr int kTileW = 64;          // output columns per workgroup == wavefront width
+constexpr int kStageMax = 6;        // 16-byte loads a thread keeps in flight while staging a window
 
 struct SepArgs {
   int sw, sh, irow;                 // source geometry
@@ -37,7 +38,9 @@ struct SepArgs {
   uint32_t src_sel;                 // v_perm selector applied to every source pixel (0x03020100 = identity)
   int blend, irow2;                 // chroma blend with layer 2 (bf / nbf below)
   uint32_t bf, nbf;
+  const int32_t *bf_d;              // optional device-resident blend amount (shared parameter block)
   int use_lut;
+  int vec;                          // source rows are 16-byte aligned: stage with 16-byte loads
   int tiles_x, tiles_y;
 };
 struct SepTracks {
@@ -93,16 +96,65 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
   const int wcols = sx1 - sx0, wrows = sy1 - sy0;     // host guarantees <= swt / sht
 
   if (a.use_lut) stage_lut(s_lut, lut);
+  uint32_t bf = a.bf, nbf = a.nbf;
+  if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
 
   // ---- 1. stage the window (edge replicate), byte swap on the fly ----
-  for (int r = threadIdx.x >> 6; r < wrows; r += kBlock >> 6) {
-    int sy = sy0 + r;
-    sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
-    const uint32_t *srow = reinterpret_cast<const uint32_t *>(src + (size_t)sy * a.irow);
-    for (int c = threadIdx.x & 63; c < wcols; c += 64) {
-      int sx = sx0 + c;
-      sx = sx < 0 ? 0 : sx >= a.sw ? a.sw - 1 : sx;
-      s_src[r * a.swt + c] = __builtin_amdgcn_perm(0u, srow[sx], a.src_sel);
+  // The window is widened to 4-pixel (16 B) columns: sx0a = sx0 rounded down to a multiple of 4.  Every
+  // thread first ISSUES all of its 16-byte loads (independent, so HBM latency is paid once per tile, not once
+  // per load), then permutes and writes them to LDS.
+  const int sx0a = sx0 & ~3;
+  const int wchunks = (sx1 - sx0a + 3) >> 2;            // 16-byte chunks per window row
+  const int nitems = wrows * wchunks;
+  if (a.vec) {
+    uint4 v[kStageMax];
+#pragma unroll
+    for (int k = 0; k < kStageMax; k++) {
+      const int it = threadIdx.x + k * kBlock;
+      if (it < nitems) {
+        const int r = it / wchunks, ch = it - r * wchunks;
+        int sy = sy0 + r;
+        sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
+        const uint8_t *srow = src + (size_t)sy * a.irow;
+        const int x = sx0a + ch * 4;
+        if (x >= 0 && x + 4 <= a.sw) v[k] = *reinterpret_cast<const uint4 *>(srow + (size_t)x * 4);
+        else {
+          const uint32_t *sp = reinterpret_cast<const uint32_t *>(srow);
+          const int m = a.sw - 1;
+          v[k] = make_uint4(sp[min(max(x, 0), m)], sp[min(max(x + 1, 0), m)], sp[min(max(x + 2, 0), m)], sp[min(max(x + 3, 0), m)]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kStageMax; k++) {
+      const int it = threadIdx.x + k * kBlock;
+      if (it < nitems) {
+        const int r = it / wchunks, ch = it - r * wchunks;
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(0u, v[k].x, a.src_sel); o.y = __builtin_amdgcn_perm(0u, v[k].y, a.src_sel);
+        o.z = __builtin_amdgcn_perm(0u, v[k].z, a.src_sel); o.w = __builtin_amdgcn_perm(0u, v[k].w, a.src_sel);
+        *reinterpret_cast<uint4 *>(s_src + r * a.swt + ch * 4) = o;
+      }
+    }
+    for (int it = threadIdx.x + kStageMax * kBlock; it < nitems; it += kBlock) {   // windows larger than the register batch
+      const int r = it / wchunks, ch = it - r * wchunks;
+      int sy = sy0 + r;
+      sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
+      const uint32_t *sp = reinterpret_cast<const uint32_t *>(src + (size_t)sy * a.irow);
+      const int m = a.sw - 1, x = sx0a + ch * 4;
+      uint32_t *d = s_src + r * a.swt + ch * 4;
+      for (int q = 0; q < 4; q++) d[q] = __builtin_amdgcn_perm(0u, sp[min(max(x + q, 0), m)], a.src_sel);
+    }
+  } else {
+    for (int r = threadIdx.x >> 6; r < wrows; r += kBlock >> 6) {
+      int sy = sy0 + r;
+      sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
+      const uint32_t *srow = reinterpret_cast<const uint32_t *>(src + (size_t)sy * a.irow);
+      for (int c = threadIdx.x & 63; c < wchunks * 4; c += 64) {
+        int sx = sx0a + c;
+        sx = sx < 0 ? 0 : sx >= a.sw ? a.sw - 1 : sx;
+        s_src[r * a.swt + c] = __builtin_amdgcn_perm(0u, srow[sx], a.src_sel);
+      }
     }
   }
   __syncthreads();
@@ -110,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
   // ---- 2. horizontal pass: lane = output column ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ox = tx0 + (lane < tw ? lane : tw - 1);
-  const int hoff = a.hpos[ox] - sx0;
+  const int hoff = a.hpos[ox] - sx0a;
   int hc[NTH ? NTH : 1];
   if (NTH) {
 #pragma unroll
@@ -170,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
                    ((uint32_t)clamp255((acc2 + a.vround) >> a.vshift) << 16) | ((uint32_t)clamp255((acc3 + a.vround) >> a.vshift) << 24);
       if (a.blend) {
         const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[tx0 + lane];
-        p = chroma_rgba(p, q, a.bf, a.nbf);
+        p = chroma_rgba(p, q, bf, nbf);
       }
       if (a.use_lut) p = lut3_rgba(s_lut, p);
       reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[tx0 + lane] = p;
@@ -290,8 +342,7 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
   a.hpos = hb->pos; a.hco = hb->co; a.nth = hb->nt;
   a.vpos = vb->pos; a.vco = vb->co; a.ntv = vb->nt;
   a.hround = hround; a.hshift = hshift; a.vround = vround; a.vshift = vshift;
-  a.swt = max_tile_span(*hb, dw, kTileW);
-  a.swt |= 1;                                      // odd row pitch: keeps column walks off a single LDS bank
+  a.swt = (max_tile_span(*hb, dw, kTileW) + 3 + 3) & ~3;   // +3: window start rounded down to a 4-pixel column
   int th = 16;
   for (;; th >>= 1) {
     a.th = th;
@@ -368,7 +419,8 @@ extern "C" int lgpu_resize(const uint8_t *src_d, int irow, int sw, int sh, uint8
   if (psize == 4 && al4) {
     SepPlan p;
     if ((rc = plan_sep(hb, vb, sw, sh, irow, dw, dh, orow, 1, 64, 7, 1 << 20, 21, &p)) == LGPU_OK) {
-      p.a.src_sel = 0x03020100u; p.a.blend = 0; p.a.irow2 = 0; p.a.bf = 0; p.a.nbf = 255; p.a.use_lut = lut8 ? 1 : 0;
+      p.a.src_sel = 0x03020100u; p.a.blend = 0; p.a.irow2 = 0; p.a.bf = 0; p.a.nbf = 255; p.a.bf_d = nullptr; p.a.use_lut = lut8 ? 1 : 0;
+      p.a.vec = (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0;
       SepTracks t;
       t.src[0] = src_d; t.l2[0] = nullptr; t.dst[0] = dst_d;
       return launch_sep(p, t, l, st);
@@ -406,7 +458,8 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
   if (psize == 4 && al4) {
     SepPlan p;
     if ((rc = plan_sep(hb, vb, width, height, irow, width, height, orow, 1, 0, 0, 128, 8, &p))) return rc;
-    p.a.src_sel = 0x03020100u; p.a.blend = 0; p.a.irow2 = 0; p.a.bf = 0; p.a.nbf = 255; p.a.use_lut = 0;
+    p.a.src_sel = 0x03020100u; p.a.blend = 0; p.a.irow2 = 0; p.a.bf = 0; p.a.nbf = 255; p.a.bf_d = nullptr; p.a.use_lut = 0;
+    p.a.vec = (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0;
     SepTracks t;
     t.src[0] = src_d; t.l2[0] = nullptr; t.dst[0] = dst_d;
     return launch_sep(p, t, l, st);
@@ -439,13 +492,16 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   const uint32_t sel = pr->swap_rb ? 0x03000102u : 0x03020100u;   // swap3postalpha: [in2 in1 in0 in3]
   const Bank *hb, *vb, *gh, *gv;
   SepTracks t;
+  uintptr_t src_bits = (uintptr_t)pr->irow;
+  for (int i = 0; i < ntracks; i++) src_bits |= (uintptr_t)tracks[i].src_d;
+  const int src_vec = (src_bits & 15) == 0;
   if (!pr->do_blur) {
     LGPU_REQUIRE(!same, "chain without resize: use lgpu_swizzle + lgpu_blend_chroma + lgpu_gamma_apply");
     if ((rc = get_bank(pr->sw, pr->dw, kernel, &hb)) || (rc = get_bank(pr->sh, pr->dh, kernel, &vb))) return rc;
     SepPlan p;
     if ((rc = plan_sep(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->orow, ntracks, 64, 7, 1 << 20, 21, &p))) return rc;
-    p.a.src_sel = sel; p.a.blend = 1; p.a.irow2 = pr->irow2; p.a.bf = (uint32_t)pr->bf & 0xFF; p.a.nbf = 0xFF - p.a.bf;
-    p.a.use_lut = pr->use_lut ? 1 : 0;
+    p.a.src_sel = sel; p.a.blend = 1; p.a.irow2 = pr->irow2; p.a.bf = (uint32_t)pr->bf & 0xFF; p.a.nbf = 0xFF - p.a.bf; p.a.bf_d = pr->param_block_d;
+    p.a.use_lut = pr->use_lut ? 1 : 0; p.a.vec = src_vec;
     for (int i = 0; i < ntracks; i++) { t.src[i] = tracks[i].src_d; t.l2[i] = tracks[i].layer2_d; t.dst[i] = tracks[i].dst_d; }
     return launch_sep(p, t, l, st);
   }
@@ -458,12 +514,13 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   if ((rc = get_bank(pr->dw, pr->dw, 100, &gh)) || (rc = get_bank(pr->dh, pr->dh, 100, &gv))) return rc;
   SepPlan p1, p2;
   if ((rc = plan_sep(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->dw * 4, ntracks, 64, 7, 1 << 20, 21, &p1))) return rc;
-  p1.a.src_sel = sel; p1.a.blend = 0; p1.a.irow2 = 0; p1.a.bf = 0; p1.a.nbf = 255; p1.a.use_lut = 0;
+  p1.a.src_sel = sel; p1.a.blend = 0; p1.a.irow2 = 0; p1.a.bf = 0; p1.a.nbf = 255; p1.a.bf_d = nullptr; p1.a.use_lut = 0; p1.a.vec = src_vec;
   for (int i = 0; i < ntracks; i++) { t.src[i] = tracks[i].src_d; t.l2[i] = nullptr; t.dst[i] = (uint8_t *)scratch + per * i; }
   if ((rc = launch_sep(p1, t, pack_lut(nullptr), st))) return rc;
   if ((rc = plan_sep(gh, gv, pr->dw, pr->dh, pr->dw * 4, pr->dw, pr->dh, pr->orow, ntracks, 0, 0, 128, 8, &p2))) return rc;
-  p2.a.src_sel = 0x03020100u; p2.a.blend = 1; p2.a.irow2 = pr->irow2; p2.a.bf = (uint32_t)pr->bf & 0xFF; p2.a.nbf = 0xFF - p2.a.bf;
+  p2.a.src_sel = 0x03020100u; p2.a.blend = 1; p2.a.irow2 = pr->irow2; p2.a.bf = (uint32_t)pr->bf & 0xFF; p2.a.nbf = 0xFF - p2.a.bf; p2.a.bf_d = pr->param_block_d;
   p2.a.use_lut = pr->use_lut ? 1 : 0;
+  p2.a.vec = ((((uintptr_t)scratch | per | (uintptr_t)(pr->dw * 4)) & 15) == 0);
   for (int i = 0; i < ntracks; i++) { t.src[i] = (uint8_t *)scratch + per * i; t.l2[i] = tracks[i].layer2_d; t.dst[i] = tracks[i].dst_d; }
   return launch_sep(p2, t, l, st);
 }

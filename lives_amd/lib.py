@@ -34,7 +34,7 @@ class ChainTrack(ctypes.Structure):
 class ChainParams(ctypes.Structure):
     _fields_ = [("sw", ci), ("sh", ci), ("irow", ci), ("dw", ci), ("dh", ci), ("irow2", ci), ("orow", ci),
                 ("swap_rb", ci), ("interp", ci), ("do_blur", ci), ("bf", ci), ("use_lut", ci),
-                ("lut8", ctypes.c_uint8 * 256)]
+                ("lut8", ctypes.c_uint8 * 256), ("param_block_d", vp)]
 
 
 # name -> argtypes; every entry point include/lives_gpu.h declares must appear here (tests check both ways)

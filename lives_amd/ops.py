@@ -99,8 +99,9 @@ def mirror(mode, src, dst, width, height, psize):
     lib.call("lgpu_mirror", mode, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
 
 
-def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None):
+def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None, param_block=None):
     p = lib.ChainParams()
+    p.param_block_d = param_block.data_ptr() if param_block is not None else None
     p.sw, p.sh, p.irow, p.dw, p.dh, p.irow2, p.orow = sw, sh, irow, dw, dh, irow2, orow
     p.swap_rb, p.interp, p.do_blur, p.bf = swap_rb, interp, do_blur, bf
     p.use_lut = 1 if lut is not None else 0

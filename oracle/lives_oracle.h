@@ -87,6 +87,9 @@ int orc_chain(const uint8_t *src, int irow, int sw, int sh, const uint8_t *layer
 
 /* row-slice threaded drivers used by bench.py's cpu_baseline leg (reference slicing rule
    CEIL(height / n, 4), src/colourspace.c:9456-9485) */
+int orc_chain_threaded(const uint8_t *src, int irow, int sw, int sh, const uint8_t *layer2, int irow2,
+                       uint8_t *dst, int orow, int dw, int dh, int swap_rb, int interp, int do_blur, int bf,
+                       const uint8_t *lut8, int nthreads);
 double orc_bench_chain(int sw, int sh, int dw, int dh, int nthreads, int nframes, int do_blur);
 
 #ifdef __cplusplus

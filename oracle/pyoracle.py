@@ -89,6 +89,7 @@ def oracle():
         _O.orc_gauss5.argtypes = [vp, ci, vp, ci, ci, ci, ci]
         _O.orc_chain.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         _O.orc_make_filter.argtypes = [ci, ci, ci, vp, vp, vp, ci]
+        _O.orc_chain_threaded.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci]
         if hasattr(_O, "orc_bench_chain"):
             _O.orc_bench_chain.restype = cd
             _O.orc_bench_chain.argtypes = [ci] * 7
