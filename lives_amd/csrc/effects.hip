@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void k_pixel2(Frames2 f, F fn) {
 // ---- functors -------------------------------------------------------------------------------------------
 // (bf * b + (255 - bf) * a) >> 8 on two bytes at once: bytes sit in 16-bit lanes, products < 2^16
 __device__ __forceinline__ uint32_t mix_pairs(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
-  return ((b * bf + a * nbf) >> 8) & 0x00FF00FFu;
+  return ((__umul24(b, bf) + __umul24(a, nbf)) >> 8) & 0x00FF00FFu;
 }
 __device__ __forceinline__ uint32_t mix4(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
   return mix_pairs(a & 0x00FF00FFu, b & 0x00FF00FFu, bf, nbf) | (mix_pairs((a >> 8) & 0x00FF00FFu, (b >> 8) & 0x00FF00FFu, bf, nbf) << 8);

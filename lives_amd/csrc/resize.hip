@@ -16,6 +16,7 @@
 // Source bytes cross HBM once (tile halos are L2 hits); intermediates never leave the CU.
 #include "lgpu_common.h"
 #include "../../include/lives_gpu_weed_abi.h"
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -50,7 +51,8 @@ struct SepTracks {
 };
 
 __device__ __forceinline__ uint32_t mix_pairs2(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
-  return ((b * bf + a * nbf) >> 8) & 0x00FF00FFu;
+  // operands are < 2^24 (two bytes in 16-bit lanes times a byte): v_mul_u32_u24 / v_mad_u32_u24, not 32/64-bit multiplies
+  return ((__umul24(b, bf) + __umul24(a, nbf)) >> 8) & 0x00FF00FFu;
 }
 __device__ __forceinline__ uint32_t mix4b(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
   return mix_pairs2(a & 0x00FF00FFu, b & 0x00FF00FFu, bf, nbf) | (mix_pairs2((a >> 8) & 0x00FF00FFu, (b >> 8) & 0x00FF00FFu, bf, nbf) << 8);
@@ -230,6 +232,272 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
   }
 }
 
+
+// =====================================================================================================================
+// k_half8 -- fast path for an exact 2:1 reduction with a uniform 8-tap filter (the headline 3840x2160 -> 1920x1080
+// bicubic case).  Same arithmetic as k_separable<8,8> (bit-identical output; tests run both), restructured because
+// the generic kernel is VALU-bound on gfx950 (profiles/r01/step1_separable_v1.md: 6.7 VALU wave-instructions per
+// output pixel, integer VOP3 ops issue at ~4.7 clk each):
+//   * the window is staged CHANNEL-PLANAR in LDS (bytes biased by -128 so they are int8),
+//   * the horizontal pass is a banded-Toeplitz product on the matrix cores: per 16 window rows x 16 output columns one
+//     v_mfma_i32_16x16x64_i8 for the high 8 bits of the Q14 taps and one for the low 6 (tap = 64 * hi + lo),
+//     A = 16 rows x 64 consecutive bytes of one channel plane, B = the constant 64 x 16 tap matrix
+//     B[k][n] = tap[k - 2n]; the C/D fragment (4 consecutive window rows per lane) packs straight into the
+//     row-pair int16 layout the vertical pass wants,
+//   * the vertical pass walks down the tile with a 4-deep register window of row pairs and v_dot2c_i32_i16,
+//   * blend + gamma epilogue as before; the per-alpha float factors of the translucent blend path come from a
+//     256-entry table instead of a double-precision divide per pixel.
+// =====================================================================================================================
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
+
+template <int TH>
+struct H8 {
+  static constexpr int kTileH = TH;                    // output rows per tile
+  static constexpr int kRows = 2 * TH + 6;             // window rows
+  static constexpr int kPairs = kRows / 2;             // row pairs
+  static constexpr int kMBlocks = (kRows + 15) / 16;   // 16-row MFMA blocks (rows past kRows are computed and dropped)
+  static constexpr int kJobsPerWave = kMBlocks;        // kMBlocks x 4 column blocks over 4 waves
+  static constexpr int kRowsPerWave = TH / 4;          // vertical pass: consecutive output rows per wave
+  static constexpr int kPlaneBytes = kRows * 160;
+  static constexpr int kSrcBytes = 4 * kPlaneBytes;
+  static constexpr int kHBytes = kPairs * kTileW * 16;
+  static constexpr int kItems = kRows * 34;
+  static constexpr int kFull = kItems / kBlock;
+  static constexpr int kTail = kItems - kFull * kBlock;
+  // planes + row-pair buffer + alpha tables + lut + slack for the fragment over-read of the padded row block
+  static constexpr size_t kLds = kSrcBytes + kHBytes + 2048 + 256 + ((kMBlocks * 16 - kRows) * 160 > kHBytes ? (kMBlocks * 16 - kRows) * 160 - kHBytes : 0) + 256;
+};
+constexpr int kH8Pitch = 160;                   // plane row pitch in bytes: conflict-free for the lane groups ds_read_b128 really uses
+                                                //   ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) and wide enough for column block 3 (bytes 96..159)
+constexpr int kH8Chunks = 34;                   // 16-byte column chunks per window row (134 px -> 33.5)
+
+struct Half8Args {
+  int sw, sh, irow, dw, dh, orow;
+  const int4v *bfrag;               // device: [2][64] B fragments (hi, lo)
+  const float *alpha_tab;           // device: [2][256] alpha, 1 - alpha (chroma blend translucent path)
+  uint32_t vc[4];                   // vertical tap pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7), 2 x int16 each
+  int swap_rb;
+  int blend, irow2;
+  uint32_t bf, nbf;
+  const int32_t *bf_d;
+  int use_lut;
+  int tiles_x, tiles_y, ntracks;
+};
+
+__device__ __forceinline__ uint32_t ld_px_clamped(const uint8_t *row, int x, int sw) {
+  x = x < 0 ? 0 : x >= sw ? sw - 1 : x;
+  return reinterpret_cast<const uint32_t *>(row)[x];
+}
+
+// per-thread staging state of one tile: up to 6 x 16-byte loads in flight
+struct H8Stage {
+  u32x4_a4 v[6];     // H8<16>: 5 full rounds + tail
+};
+
+template <int TH>
+__device__ __forceinline__ void h8_issue_loads(const Half8Args &a, const uint8_t *src, int tx0, int ty0, int tid, int wave, H8Stage &st) {
+  // item -> (window row r, 16-byte chunk ch); item + 256 -> (r + 7, ch + 18) with carry (256 = 7 * 34 + 18).
+  // Offsets are 32-bit (a frame is far below 4 GB) so the loads use the SGPR-base + VGPR-offset form.
+  constexpr int kItems = H8<TH>::kItems;                      // TH 16: 1292 = 5 * 256 + 12
+  constexpr int kFull = H8<TH>::kFull;                        // full rounds; the left-over items start at wave 0
+  const int sx0 = 2 * tx0 - 3, sy0 = 2 * ty0 - 3;
+  const bool interior = (sx0 >= 0) && (sx0 + 4 * kH8Chunks <= a.sw);   // tile-uniform: no column clamping needed
+  int r = tid / kH8Chunks, ch = tid - r * kH8Chunks;
+#pragma unroll
+  for (int k = 0; k <= kFull; k++) {
+    if (k < kFull || wave * 64 < kItems - kFull * kBlock) {
+      if (k < kFull || tid < kItems - kFull * kBlock) {
+        int sy = sy0 + r;
+        sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
+        const uint32_t rowoff = (uint32_t)sy * (uint32_t)a.irow;
+        const int x = sx0 + ch * 4;
+        if (interior) st.v[k] = *reinterpret_cast<const u32x4_a4 *>(src + (rowoff + (uint32_t)x * 4u));
+        else {
+          const uint8_t *srow = src + rowoff;
+          st.v[k].x = ld_px_clamped(srow, x, a.sw); st.v[k].y = ld_px_clamped(srow, x + 1, a.sw);
+          st.v[k].z = ld_px_clamped(srow, x + 2, a.sw); st.v[k].w = ld_px_clamped(srow, x + 3, a.sw);
+        }
+      }
+    }
+    r += 7; ch += 18;
+    if (ch >= kH8Chunks) { ch -= kH8Chunks; r += 1; }
+  }
+}
+
+template <int TH>
+__device__ __forceinline__ void h8_write_planes(const Half8Args &a, uint8_t *s_pl, int tid, int wave, const H8Stage &st) {
+  constexpr int kItems = H8<TH>::kItems;
+  constexpr int kFull = H8<TH>::kFull;
+  const int p0 = a.swap_rb ? 2 : 0, p2 = a.swap_rb ? 0 : 2;  // BGRA sources: byte 0 feeds plane 2 and vice versa
+  int r = tid / kH8Chunks, ch = tid - r * kH8Chunks;
+#pragma unroll
+  for (int k = 0; k <= kFull; k++) {
+    if (k < kFull || wave * 64 < kItems - kFull * kBlock) {
+      if (k < kFull || tid < kItems - kFull * kBlock) {
+        const u32x4_a4 v = st.v[k];
+        const uint32_t x0 = __builtin_amdgcn_perm(v.y, v.x, 0x05010400u), x1 = __builtin_amdgcn_perm(v.y, v.x, 0x07030602u);
+        const uint32_t x2 = __builtin_amdgcn_perm(v.w, v.z, 0x05010400u), x3 = __builtin_amdgcn_perm(v.w, v.z, 0x07030602u);
+        const uint32_t c0 = __builtin_amdgcn_perm(x2, x0, 0x05040100u) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(x2, x0, 0x07060302u) ^ 0x80808080u;
+        const uint32_t c2 = __builtin_amdgcn_perm(x3, x1, 0x05040100u) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(x3, x1, 0x07060302u) ^ 0x80808080u;
+        uint8_t *d = s_pl + r * kH8Pitch + ch * 4;
+        *reinterpret_cast<uint32_t *>(d + p0 * H8<TH>::kPlaneBytes) = c0;
+        *reinterpret_cast<uint32_t *>(d + 1 * H8<TH>::kPlaneBytes) = c1;
+        *reinterpret_cast<uint32_t *>(d + p2 * H8<TH>::kPlaneBytes) = c2;
+        *reinterpret_cast<uint32_t *>(d + 3 * H8<TH>::kPlaneBytes) = c3;
+      }
+    }
+    r += 7; ch += 18;
+    if (ch >= kH8Chunks) { ch -= kH8Chunks; r += 1; }
+  }
+}
+
+// Persistent workgroups: each loops over (track, tile) work items with stride gridDim.x; the next item's
+// source window is already in flight (registers) while the current one runs its horizontal and vertical passes.
+// ABL: profiling-only ablation mask (0 in production): 1 no blend/LUT epilogue, 2 no vertical dots, 4 no horizontal pass, 8 no staging
+template <int TH, int ABL>
+__global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lut8 lut) {
+  using C = H8<TH>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t *s_pl = smem;                                                   // [4][38][160] int8 planes
+  uint8_t *s_h = smem + C::kSrcBytes;                                      // [19][64][4] dwords of 2 x int16
+  float *s_alpha = reinterpret_cast<float *>(smem + C::kSrcBytes + C::kHBytes);   // [2][256]
+  uint8_t *s_lut = smem + C::kSrcBytes + C::kHBytes + 2048;                 // [256]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
+
+  if (a.use_lut) stage_lut(s_lut, lut);
+  if (a.blend) { s_alpha[tid] = a.alpha_tab[tid]; s_alpha[256 + tid] = a.alpha_tab[256 + tid]; }
+  uint32_t bf = a.bf, nbf = a.nbf;
+  if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
+
+  const int4v b_hi = a.bfrag[lane], b_lo = a.bfrag[64 + lane];
+  // accumulator preset of the low-part product: un-bias the int8 pixels (the taps sum to 16384) + the rounding of >> 7
+  const int kb = 128 * 16384 + 64;
+  const int4v cbias = {kb, kb, kb, kb};
+  const short2v vc0 = __builtin_bit_cast(short2v, a.vc[0]), vc1 = __builtin_bit_cast(short2v, a.vc[1]);
+  const short2v vc2 = __builtin_bit_cast(short2v, a.vc[2]), vc3 = __builtin_bit_cast(short2v, a.vc[3]);
+
+  // XCD-aware work list: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  Each XCD
+  // takes one contiguous eighth of the (track, tile) list and its workgroups walk it together, so the
+  // window halos shared by neighbouring tiles are hits in that XCD's own L2 instead of second HBM fetches.
+  const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3);
+  const int chunk = (nwork + 7) >> 3;
+  const int wend = min((xcd + 1) * chunk, nwork);
+  H8Stage st;
+  int work = xcd * chunk + (int)(blockIdx.x >> 3);
+  if (work < wend) {
+    const int track = work / tiles, tile = work - track * tiles;
+    if (!(ABL & 8)) h8_issue_loads<TH>(a, trk.src[track], (tile % a.tiles_x) * kTileW, (tile / a.tiles_x) * C::kTileH, tid, wave, st);
+  }
+  for (; work < wend; work += wstride) {
+    const int track = work / tiles, tile = work - track * tiles;
+    const int tx0 = (tile % a.tiles_x) * kTileW, ty0 = (tile / a.tiles_x) * C::kTileH;
+    const int tw = min(kTileW, a.dw - tx0), thh = min(C::kTileH, a.dh - ty0);
+
+    // ---- 1. transpose the staged window to int8 channel planes in LDS ----
+    if (!(ABL & 8)) h8_write_planes<TH>(a, s_pl, tid, wave, st);
+    __syncthreads();
+
+    // next work item's window: issue its loads now, they complete while this tile computes
+    {
+      const int nxt = work + wstride;
+      if (nxt < wend) {
+        const int ntrack = nxt / tiles, ntile = nxt - ntrack * tiles;
+        if (!(ABL & 8)) h8_issue_loads<TH>(a, trk.src[ntrack], (ntile % a.tiles_x) * kTileW, (ntile / a.tiles_x) * C::kTileH, tid, wave, st);
+      }
+    }
+    // layer-2 pixels of this wave's output rows (consumed in the epilogue)
+    constexpr int RPW = C::kRowsPerWave;
+    const int ly0 = wave * RPW;
+    uint32_t q2[RPW];
+    {
+      const uint8_t *l2 = trk.l2[track];
+#pragma unroll
+      for (int i = 0; i < RPW; i++) {
+        const int oy = ty0 + ly0 + i;
+        q2[i] = (a.blend && lane < tw && ly0 + i < thh) ? reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[tx0 + lane] : 0xFF000000u;
+      }
+    }
+
+    // ---- 2. horizontal pass on the matrix cores ----
+    // kMBlocks row blocks (rows past the window unused) x 4 column blocks = (mb, nb) jobs, kMBlocks per wave
+    if (!(ABL & 4)) {
+      const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < C::kJobsPerWave; j++) {
+        const int job = wave * C::kJobsPerWave + j, mb = job >> 2, nb = job & 3;
+        const uint8_t *abase = s_pl + (mb * 16 + m) * kH8Pitch + nb * 32 + g * 16;
+        uint32_t pk0[4], pk1[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int4v av = *reinterpret_cast<const int4v *>(abase + c * C::kPlaneBytes);
+          int4v zero = {0, 0, 0, 0};
+          const int4v dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_hi, zero, 0, 0, 0);
+          const int4v dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_lo, cbias, 0, 0, 0);
+          const int t0 = ((dh[0] << 6) + dl[0]) >> 7, t1 = ((dh[1] << 6) + dl[1]) >> 7;
+          const int t2 = ((dh[2] << 6) + dl[2]) >> 7, t3 = ((dh[3] << 6) + dl[3]) >> 7;
+          const short2v q0 = __builtin_amdgcn_cvt_pk_i16(t0, t1), q1 = __builtin_amdgcn_cvt_pk_i16(t2, t3);   // saturating
+          pk0[c] = __builtin_bit_cast(uint32_t, q0);
+          pk1[c] = __builtin_bit_cast(uint32_t, q1);
+        }
+        // lane holds window rows mb*16 + 4g + {0..3} = row pairs mb*8 + 2g + {0,1}, output column nb*16 + m
+        const int pr = mb * 8 + 2 * g, xcol = nb * 16 + m;
+        if (pr < C::kPairs) *reinterpret_cast<uint4 *>(s_h + ((pr)*kTileW + xcol) * 16) = make_uint4(pk0[0], pk0[1], pk0[2], pk0[3]);
+        if (pr + 1 < C::kPairs) *reinterpret_cast<uint4 *>(s_h + ((pr + 1) * kTileW + xcol) * 16) = make_uint4(pk1[0], pk1[1], pk1[2], pk1[3]);
+      }
+    }
+    __syncthreads();
+
+    // ---- 3. vertical pass (lane = column, wave = RPW consecutive output rows) + epilogue ----
+    {
+      uint8_t *dst = trk.dst[track];
+      const uint4 *col = reinterpret_cast<const uint4 *>(s_h) + lane;
+      uint4 w0 = col[(ly0 + 0) * kTileW], w1 = col[(ly0 + 1) * kTileW], w2 = col[(ly0 + 2) * kTileW];
+#pragma unroll
+      for (int i = 0; i < RPW; i++) {
+        const int ly = ly0 + i;
+        const uint4 w3 = col[(ly + 3) * kTileW];
+        if (ly < thh && lane < tw) {
+          const int vr = 1 << 20;
+          int a0 = vr, a1 = vr, a2 = vr, a3 = vr;
+#define H8_DOT(acc, fld)                                                                  \
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w0.fld), vc0, acc, false); \
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w1.fld), vc1, acc, false); \
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w2.fld), vc2, acc, false); \
+          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w3.fld), vc3, acc, false);
+          if (!(ABL & 2)) { H8_DOT(a0, x) H8_DOT(a1, y) H8_DOT(a2, z) H8_DOT(a3, w) } else { a0 = w0.x; a1 = w1.y; a2 = w2.z; a3 = w3.w; }
+#undef H8_DOT
+          uint32_t p = (uint32_t)clamp255(a0 >> 21) | ((uint32_t)clamp255(a1 >> 21) << 8) | ((uint32_t)clamp255(a2 >> 21) << 16) |
+                       ((uint32_t)clamp255(a3 >> 21) << 24);
+          if (a.blend && !(ABL & 1)) {
+            const uint32_t q = q2[i], al = q >> 24;
+            uint32_t s1 = p, s2 = q;
+            if (!__all(al == 255)) {       // wave-uniform: skip the translucent arithmetic when every layer-2 pixel is opaque
+              // (uint8_t)((float)c * alpha) with alpha = (float)a / 255., inv_alpha = 1. - alpha  (simple_blend.c:137-146)
+              const float alpha = s_alpha[al], inv = s_alpha[256 + al];
+              const uint32_t f2 = (uint32_t)__fmul_rn((float)((q >> 0) & 0xFF), alpha) | ((uint32_t)__fmul_rn((float)((q >> 8) & 0xFF), alpha) << 8) |
+                                  ((uint32_t)__fmul_rn((float)((q >> 16) & 0xFF), alpha) << 16);
+              const uint32_t f1 = (uint32_t)__fmul_rn((float)((p >> 0) & 0xFF), inv) | ((uint32_t)__fmul_rn((float)((p >> 8) & 0xFF), inv) << 8) |
+                                  ((uint32_t)__fmul_rn((float)((p >> 16) & 0xFF), inv) << 16);
+              s2 = (al == 255) ? q : f2;
+              s1 = (al == 255) ? p : f1;
+            }
+            p = (mix4b(s1, s2, bf, nbf) & 0x00FFFFFFu) | (p & 0xFF000000u);
+          }
+          if (a.use_lut && !(ABL & 1)) p = lut3_rgba(s_lut, p);
+          reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + ly) * a.orow)[tx0 + lane] = p;
+        }
+        w0 = w1; w1 = w2; w2 = w3;
+      }
+    }
+    // no barrier here: the next iteration writes only the planes (last read before the barrier above);
+    // s_h is rewritten after the next iteration's first barrier, which every wave reaches only after this pass
+  }
+}
+
 // ---- generic two-launch path: any pixel size (bytes are independent channels), global int16 scratch ----
 __global__ __launch_bounds__(kBlock) void k_hpass_generic(const uint8_t *src, int irow, int sw, int sh, int16_t *tmp, int dw,
                                                            int psize, const int32_t *pos, const int16_t *co, int nt, int round, int shift) {
@@ -276,6 +544,8 @@ struct Bank {
   int nt = 0;
   int max_span = 0;      // max over 64-column (or th-row) tiles is derived by the caller from host copies
   std::vector<int32_t> hpos;
+  std::vector<int16_t> hco;         // host copy of the taps
+  int uniform2 = 0;                 // exact 2:1, 8 identical taps per output, pos[i] = 2i - 3, taps fit 64*int8 + 6 bits
 };
 static std::mutex g_bank_mu;
 static std::map<std::tuple<int, int, int, int>, Bank> g_banks;   // (device, srcn, dstn, kernel)  kernel 100 = gauss5
@@ -300,6 +570,17 @@ static int get_bank(int srcn, int dstn, int kernel, const Bank **out) {
       int rc = lgpu_make_filter(srcn, dstn, kernel, &b.nt, b.hpos.data(), co.data(), 256);
       if (rc) { set_error("resize %d -> %d needs more than 256 taps", srcn, dstn); return rc; }
       co.resize((size_t)dstn * b.nt);
+    }
+    b.hco = co;
+    if (b.nt == 8 && srcn == 2 * dstn) {
+      b.uniform2 = 1;
+      for (int i = 0; i < dstn && b.uniform2; i++) {
+        if (b.hpos[i] != 2 * i - 3) b.uniform2 = 0;
+        for (int j = 0; j < 8; j++) {
+          const int c = co[(size_t)i * 8 + j];
+          if (c != co[j] || (c >> 6) < -128 || (c >> 6) > 127) b.uniform2 = 0;
+        }
+      }
     }
     LGPU_HIP(hipMalloc((void **)&b.pos, sizeof(int32_t) * dstn));
     LGPU_HIP(hipMalloc((void **)&b.co, sizeof(int16_t) * co.size()));
@@ -326,6 +607,95 @@ static int kernel_for_interp(int interp, bool upscale) {
   // (src/colourspace.c:14991-14997)
   if (interp == LIVES_INTERP_BEST) return upscale ? 2 : 1;
   return 0;
+}
+
+// ---- k_half8 host side ---------------------------------------------------------------------------------------
+struct Half8Const {
+  int4v *bfrag = nullptr;     // device [2][64]
+  float *alpha = nullptr;     // device [2][256]
+};
+static std::mutex g_h8_mu;
+static std::map<std::pair<int, std::vector<int16_t>>, Half8Const> g_h8;   // (device, 8 taps)
+
+static int get_half8_const(const int16_t taps[8], const Half8Const **out) {
+  int dev = 0;
+  LGPU_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_h8_mu);
+  auto key = std::make_pair(dev, std::vector<int16_t>(taps, taps + 8));
+  auto it = g_h8.find(key);
+  if (it == g_h8.end()) {
+    Half8Const c;
+    // B fragment of v_mfma_i32_16x16x64_i8: lane l supplies B[k = 16 * (l >> 4) + e][n = l & 15], e = 0..15
+    // (A uses the same k numbering; C/D: row = 4 * (l >> 4) + reg, col = l & 15 -- tools/mfma_probe.hip)
+    int8_t frag[2][64][16];
+    for (int l = 0; l < 64; l++)
+      for (int e = 0; e < 16; e++) {
+        const int k = 16 * (l >> 4) + e, n = l & 15, j = k - 2 * n;
+        const int tap = (j >= 0 && j < 8) ? taps[j] : 0;
+        frag[0][l][e] = (int8_t)(tap >> 6);        // tap = 64 * hi + lo, lo in [0, 63]
+        frag[1][l][e] = (int8_t)(tap & 63);
+      }
+    float at[512];
+    for (int al = 0; al < 256; al++) {             // simple_blend.c:137: alpha = (float)a / 255., inv_alpha = 1. - alpha
+      const float alpha = (float)al / 255., inv = 1. - alpha;
+      at[al] = alpha; at[256 + al] = inv;
+    }
+    LGPU_HIP(hipMalloc((void **)&c.bfrag, sizeof frag));
+    LGPU_HIP(hipMalloc((void **)&c.alpha, sizeof at));
+    LGPU_HIP(hipMemcpy(c.bfrag, frag, sizeof frag, hipMemcpyHostToDevice));
+    LGPU_HIP(hipMemcpy(c.alpha, at, sizeof at, hipMemcpyHostToDevice));
+    it = g_h8.emplace(key, c).first;
+  }
+  *out = &it->second;
+  return LGPU_OK;
+}
+
+// returns LGPU_OK and launches when the fast path applies; LGPU_E_UNSUPPORTED when it does not
+static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, int dw, int dh, int orow, int swap_rb, int blend,
+                     int irow2, uint32_t bf, const int32_t *bf_d, int use_lut, const SepTracks &t, int ntracks, const Lut8 &l,
+                     hipStream_t st) {
+  static const bool disabled = getenv("LGPU_DISABLE_HALF8") != nullptr;
+  if (disabled || !hb->uniform2 || !vb->uniform2) return LGPU_E_UNSUPPORTED;
+  if ((irow & 3) || (orow & 3)) return LGPU_E_UNSUPPORTED;
+  const Half8Const *hc;
+  int rc = get_half8_const(hb->hco.data(), &hc);
+  if (rc) return rc;
+  Half8Args a;
+  a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
+  a.bfrag = hc->bfrag; a.alpha_tab = hc->alpha;
+  for (int k = 0; k < 4; k++) a.vc[k] = (uint32_t)(uint16_t)vb->hco[2 * k] | ((uint32_t)(uint16_t)vb->hco[2 * k + 1] << 16);
+  a.swap_rb = swap_rb; a.blend = blend; a.irow2 = irow2; a.bf = bf; a.nbf = 0xFF - bf; a.bf_d = bf_d; a.use_lut = use_lut;
+  a.ntracks = ntracks;
+  // persistent grid: as many workgroups as stay resident, each walks the work list
+  static int g_cus = 0;
+  if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
+  static const int th_env = getenv("LGPU_HALF8_TH") ? atoi(getenv("LGPU_HALF8_TH")) : 16;
+  static const int bpc_env = getenv("LGPU_HALF8_BLOCKS_PER_CU") ? atoi(getenv("LGPU_HALF8_BLOCKS_PER_CU")) : 0;
+  const int th = (th_env == 8) ? 8 : 16;
+  a.tiles_x = (dw + kTileW - 1) / kTileW; a.tiles_y = (dh + th - 1) / th;
+  const int nwork = a.tiles_x * a.tiles_y * ntracks;
+  const size_t lds = th == 8 ? H8<8>::kLds : H8<16>::kLds;
+  int grid = g_cus * (bpc_env > 0 ? bpc_env : (int)(160 * 1024 / lds));
+  if (grid > nwork) grid = nwork;
+  grid = (grid + 7) & ~7;                      // whole workgroups per XCD
+  static const int abl = getenv("LGPU_H8_ABLATE") ? atoi(getenv("LGPU_H8_ABLATE")) : 0;   // profiling only
+#define H8_LAUNCH(TH_, ABL_)                                                                                              \
+  do {                                                                                                                    \
+    if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)k_half8<TH_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_half8<TH_, ABL_>), dim3((unsigned)grid), dim3(kBlock), lds, st, a, t, l);                       \
+  } while (0)
+  if (th == 8) H8_LAUNCH(8, 0);
+  else switch (abl) {
+    case 1: H8_LAUNCH(16, 1); break;
+    case 3: H8_LAUNCH(16, 3); break;
+    case 7: H8_LAUNCH(16, 7); break;
+    case 8: H8_LAUNCH(16, 8); break;
+    case 15: H8_LAUNCH(16, 15); break;
+    default: H8_LAUNCH(16, 0); break;
+  }
+#undef H8_LAUNCH
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
 }
 
 struct SepPlan {
@@ -418,6 +788,12 @@ extern "C" int lgpu_resize(const uint8_t *src_d, int irow, int sw, int sh, uint8
   const bool al4 = (((uintptr_t)src_d | (uintptr_t)irow | (uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0;
   if (psize == 4 && al4) {
     SepPlan p;
+    {
+      SepTracks t1;
+      t1.src[0] = src_d; t1.l2[0] = nullptr; t1.dst[0] = dst_d;
+      rc = try_half8(hb, vb, sw, sh, irow, dw, dh, orow, 0, 0, 0, 0, nullptr, lut8 ? 1 : 0, t1, 1, l, st);
+      if (rc != LGPU_E_UNSUPPORTED) return rc;
+    }
     if ((rc = plan_sep(hb, vb, sw, sh, irow, dw, dh, orow, 1, 64, 7, 1 << 20, 21, &p)) == LGPU_OK) {
       p.a.src_sel = 0x03020100u; p.a.blend = 0; p.a.irow2 = 0; p.a.bf = 0; p.a.nbf = 255; p.a.bf_d = nullptr; p.a.use_lut = lut8 ? 1 : 0;
       p.a.vec = (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0;
@@ -498,6 +874,10 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   if (!pr->do_blur) {
     LGPU_REQUIRE(!same, "chain without resize: use lgpu_swizzle + lgpu_blend_chroma + lgpu_gamma_apply");
     if ((rc = get_bank(pr->sw, pr->dw, kernel, &hb)) || (rc = get_bank(pr->sh, pr->dh, kernel, &vb))) return rc;
+    for (int i = 0; i < ntracks; i++) { t.src[i] = tracks[i].src_d; t.l2[i] = tracks[i].layer2_d; t.dst[i] = tracks[i].dst_d; }
+    rc = try_half8(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->orow, pr->swap_rb ? 1 : 0, 1, pr->irow2, (uint32_t)pr->bf & 0xFF,
+                   pr->param_block_d, pr->use_lut ? 1 : 0, t, ntracks, l, st);
+    if (rc != LGPU_E_UNSUPPORTED) return rc;
     SepPlan p;
     if ((rc = plan_sep(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->orow, ntracks, 64, 7, 1 << 20, 21, &p))) return rc;
     p.a.src_sel = sel; p.a.blend = 1; p.a.irow2 = pr->irow2; p.a.bf = (uint32_t)pr->bf & 0xFF; p.a.nbf = 0xFF - p.a.bf; p.a.bf_d = pr->param_block_d;
@@ -516,7 +896,9 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   if ((rc = plan_sep(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->dw * 4, ntracks, 64, 7, 1 << 20, 21, &p1))) return rc;
   p1.a.src_sel = sel; p1.a.blend = 0; p1.a.irow2 = 0; p1.a.bf = 0; p1.a.nbf = 255; p1.a.bf_d = nullptr; p1.a.use_lut = 0; p1.a.vec = src_vec;
   for (int i = 0; i < ntracks; i++) { t.src[i] = tracks[i].src_d; t.l2[i] = nullptr; t.dst[i] = (uint8_t *)scratch + per * i; }
-  if ((rc = launch_sep(p1, t, pack_lut(nullptr), st))) return rc;
+  rc = try_half8(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->dw * 4, pr->swap_rb ? 1 : 0, 0, 0, 0, nullptr, 0, t, ntracks, pack_lut(nullptr), st);
+  if (rc == LGPU_E_UNSUPPORTED) rc = launch_sep(p1, t, pack_lut(nullptr), st);
+  if (rc) return rc;
   if ((rc = plan_sep(gh, gv, pr->dw, pr->dh, pr->dw * 4, pr->dw, pr->dh, pr->orow, ntracks, 0, 0, 128, 8, &p2))) return rc;
   p2.a.src_sel = 0x03020100u; p2.a.blend = 1; p2.a.irow2 = pr->irow2; p2.a.bf = (uint32_t)pr->bf & 0xFF; p2.a.nbf = 0xFF - p2.a.bf; p2.a.bf_d = pr->param_block_d;
   p2.a.use_lut = pr->use_lut ? 1 : 0;

@@ -282,7 +282,7 @@ def test_mirror(gpu, orc, psize, mode):
 @pytest.mark.parametrize("psize", [4, 3, 1])
 def test_resize(gpu, orc, psize):
     rng = np.random.default_rng(1000 + psize)
-    cases = [(128, 64, 64, 32, 3), (130, 70, 64, 36, 3), (64, 32, 128, 64, 3), (100, 60, 37, 23, 3), (128, 64, 64, 32, 2),
+    cases = [(128, 64, 64, 32, 3), (200, 120, 100, 60, 3), (260, 44, 130, 22, 3), (130, 70, 64, 36, 3), (64, 32, 128, 64, 3), (100, 60, 37, 23, 3), (128, 64, 64, 32, 2),
              (64, 36, 200, 100, 2), (320, 180, 96, 54, 3), (16, 16, 4, 4, 3)]
     for (sw, sh, dw, dh, interp) in cases:
         src = frame(rng, sw, sh, psize)
@@ -310,7 +310,7 @@ def test_gauss5(gpu, orc, psize):
 def test_chain_matches_oracle_and_unfused(gpu, orc, do_blur):
     rng = np.random.default_rng(1200 + do_blur)
     lut = lut_for(rng, "l2s")
-    for (sw, sh, dw, dh) in [(128, 64, 64, 32), (384, 216, 192, 108), (200, 120, 66, 34)]:
+    for (sw, sh, dw, dh) in [(128, 64, 64, 32), (384, 216, 192, 108), (200, 120, 66, 34), (204, 76, 102, 38)]:
         for swap in (1, 0):
             for bf in (0, 128, 255):
                 ntr = 3
