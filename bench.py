@@ -54,7 +54,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from lives_amd import lib, ops
+    from lives_amd import dist as ld, lib, ops   # noqa: F401
     ops.init(local_rank)
 
     # ---- synthetic, device-resident inputs (seeded per rank) ----
@@ -73,17 +73,14 @@ def main():
     assert load().lgpu_gamma_lut8(1.0, -1, 1, 1.4, lut.ctypes.data) == 1     # WEED_GAMMA_LINEAR -> WEED_GAMMA_SRGB
 
     # shared transition parameter block: int32[4], [0] = blend amount; broadcast from rank 0 each step
-    pblock = torch.zeros(4, dtype=torch.int32, device="cuda")
+    pblock = ld.new_param_block("cuda")
     schedule = torch.tensor([[(96 + 7 * s) % 256, 0, 0, 0] for s in range(args.steps + args.warmup)], dtype=torch.int32, device="cuda")
     prm = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3, do_blur=args.blur, bf=128, lut=lut,
                            param_block=pblock)
     trk = ops.chain_tracks(srcs, l2s, dsts)
 
     def step(s):
-        if rank == 0:
-            pblock.copy_(schedule[s], non_blocking=True)
-        if world > 1:
-            dist.broadcast(pblock, src=0)          # RCCL over xGMI; stream-ordered, no host sync
+        ld.publish_params(pblock, schedule[s] if rank == 0 else None)   # RCCL broadcast over xGMI when world > 1; no host sync
         ops.chain(prm, trk)
 
     def fence():
@@ -100,10 +97,7 @@ def main():
         step(args.warmup + s)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = ld.max_over_ranks(dt, "cuda")
 
     frames = world * T * args.steps
     fps = frames / dt
@@ -122,7 +116,7 @@ def main():
             traffic = pj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roof = {"bound": "hbm", "kernel": "lgpu::k_separable<8,8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "lgpu::k_half8<16,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
 

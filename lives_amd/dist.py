@@ -1,0 +1,41 @@
+"""Multi-GPU layer of the engine: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+The path shards by independent units -- frames of live clip tracks -- so there is NO data-path collective:
+track t belongs to rank t % world.  The only exchange per frame batch is the shared transition
+parameter block (blend amount, key colour, ...), broadcast from the control rank; it stays in device memory
+and the chain kernel reads it from there (lgpu_chain_params.param_block_d), so the broadcast is stream
+ordered and needs no host round trip.
+"""
+import torch
+import torch.distributed as dist
+
+PARAM_BLOCK_INTS = 4      # int32[0] = blend amount; the rest reserved (key colour, timecode lo / hi)
+
+
+def shard_tracks(ntracks, rank, world):
+    """tracks owned by `rank`: t % world == rank"""
+    return [t for t in range(ntracks) if t % world == rank]
+
+
+def new_param_block(device):
+    return torch.zeros(PARAM_BLOCK_INTS, dtype=torch.int32, device=device)
+
+
+def publish_params(block, values=None, src=0):
+    """control rank writes `values` (sequence of ints or a tensor) into the block, everyone receives it"""
+    if values is not None and (not dist.is_initialized() or dist.get_rank() == src):
+        if torch.is_tensor(values):
+            block.copy_(values, non_blocking=True)
+        else:
+            block.copy_(torch.tensor(list(values) + [0] * (PARAM_BLOCK_INTS - len(values)), dtype=torch.int32))
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(block, src=src)
+    return block
+
+
+def max_over_ranks(seconds, device):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,46 @@
+"""CPU, world_size 2 over gloo: the multi-GPU host logic (track sharding + parameter-block broadcast)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from lives_amd import dist as ld
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = ld.shard_tracks(8, rank, world)
+    # every track owned exactly once
+    owned = torch.zeros(8, dtype=torch.int32)
+    owned[mine] = 1
+    dist.all_reduce(owned)
+    assert owned.tolist() == [1] * 8, owned
+    blk = ld.new_param_block("cpu")
+    for step in range(5):
+        ld.publish_params(blk, [96 + 7 * step, step] if rank == 0 else None)
+        assert blk.tolist() == [96 + 7 * step, step, 0, 0], (rank, blk)
+    t = ld.max_over_ranks(1.0 + rank, "cpu")
+    assert t == float(world), t
+    dist.barrier()
+    print("rank", rank, "ok", mine)
+''') % ROOT
+
+
+def test_two_rank_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok [0, 2, 4, 6]" in r.stdout and "rank 1 ok [1, 3, 5, 7]" in r.stdout, r.stdout
