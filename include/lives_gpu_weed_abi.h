@@ -157,6 +157,48 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_LEAF_YUV_CLAMPING "YUV_clamping"
 #define WEED_LEAF_YUV_SAMPLING "YUV_sampling"
 #define WEED_LEAF_YUV_SUBSPACE "YUV_subspace"
+/* plugin bootstrap (weed-effects.h:170-186, :195-230; weed.h:493-496) */
+#define WEED_LEAF_FILTERS "filters"
+#define WEED_LEAF_HOST_INFO "host_info"
+#define WEED_LEAF_VERSION "version"
+#define WEED_LEAF_PLUGIN_INFO "plugin_info"
+#define WEED_LEAF_NAME "name"
+#define WEED_LEAF_AUTHOR "author"
+#define WEED_LEAF_PALETTE_LIST "palette_list"
+#define WEED_LEAF_INIT_FUNC "init_func"
+#define WEED_LEAF_DEINIT_FUNC "deinit_func"
+#define WEED_LEAF_PROCESS_FUNC "process_func"
+#define WEED_LEAF_IN_PARAMETER_TEMPLATES "in_param_tmpls"
+#define WEED_LEAF_OUT_PARAMETER_TEMPLATES "out_param_tmpls"
+#define WEED_LEAF_IN_CHANNEL_TEMPLATES "in_chan_tmpls"
+#define WEED_LEAF_OUT_CHANNEL_TEMPLATES "out_chan_tmpls"
+#define WEED_LEAF_GUI "gui"
+#define WEED_LEAF_DEFAULT "default"
+#define WEED_LEAF_MIN "min"
+#define WEED_LEAF_MAX "max"
+#define WEED_LEAF_PARAM_TYPE "param_type"
+#define WEED_LEAF_COLORSPACE "colorspace"
+#define WEED_LEAF_IS_TRANSITION "is_transition"
+#define WEED_LEAF_LABEL "label"
+#define WEED_LEAF_USE_MNEMONIC "use_mnemonic"
+#define WEED_LEAF_DECIMALS "decimals"
+#define WEED_LEAF_FILTER_API_VERSION "filter_api_version"
+#define WEED_LEAF_WEED_API_VERSION "weed_api_version"
+#define WEED_LEAF_GET_FUNC "weed_leaf_get_func"
+#define WEED_LEAF_SET_FUNC "weed_leaf_set_func"
+#define WEED_LEAF_DELETE_FUNC "weed_leaf_delete_func"
+#define WEED_PLANT_NEW_FUNC "weed_plant_new_func"
+#define WEED_PLANT_FREE_FUNC "weed_plant_free_func"
+#define WEED_LEAF_NUM_ELEMENTS_FUNC "weed_leaf_num_elements_func"
+#define WEED_LEAF_MALLOC_FUNC "weed_malloc_func"
+#define WEED_LEAF_FREE_FUNC "weed_free_func"
+typedef weed_error_t (*weed_default_getter_f)(weed_plant_t *plant, const char *key, void *value);
+typedef weed_plant_t *(*weed_bootstrap_f)(weed_default_getter_f *, int32_t plugin_weed_min_api_version,
+                                          int32_t plugin_weed_max_api_version, int32_t plugin_filter_min_api_version,
+                                          int32_t plugin_filter_max_api_version);
+typedef weed_error_t (*weed_process_f)(weed_plant_t *filter_instance, weed_timecode_t timestamp);
+typedef weed_error_t (*weed_init_f)(weed_plant_t *filter_instance);
+typedef weed_error_t (*weed_deinit_f)(weed_plant_t *filter_instance);
 #endif
 
 #endif

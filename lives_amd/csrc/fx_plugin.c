@@ -1,0 +1,309 @@
+/* fx_plugin.c -- livesgpu_fx.so: the drop-in weed effect plugin (plugin seam of SURVEY 8b.2).
+ *
+ * Exports weed_setup(weed_bootstrap_f) (libweed/weed-effects.h:174-186) and registers filter classes with the
+ * SAME names, channel / parameter templates and palette lists as the reference plugins they replace:
+ *   "chroma blend", "luma overlay", "luma underlay", "negative luma overlay", "averaged luma overlay"
+ *                                                lives-plugins/weed-plugins/simple_blend.c:213-291
+ *   "blend_multiply" .. "blend_burn"             lives-plugins/weed-plugins/multi_blends.c:205-300
+ *   "colorkey"                                   lives-plugins/weed-plugins/scripts/colorkey.script
+ *   "mirrorx", "mirrory", "mirrorxy"             lives-plugins/weed-plugins/mirrors.c:125-160
+ * process_func uploads the host channels, runs the liblivesgpu.so kernel and downloads the result (the host
+ * owns pixel_data -- host memory; device residency across a chain is what the layer seam is for).
+ * WEED_FILTER_HINT_MAY_THREAD is deliberately NOT advertised, so the host makes one call per frame
+ * (can_thread(), src/effects-weed.c:1810); if a host slices anyway the offset / height[2] protocol of
+ * process_func_threaded (:1563-1758) is honoured.
+ *
+ * Built against include/lives_gpu_weed_abi.h only (ids + signatures of the public ABI); the core accessors
+ * are the function pointers the host hands over in weed_setup(), exactly as libweed/weed-plugin-utils.c:164-249.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdio.h>
+#include "../../include/lives_gpu_weed_abi.h"
+#include "../../include/lives_gpu.h"
+
+/* ---- host functions obtained at bootstrap ---- */
+static weed_leaf_get_f w_get;
+static weed_leaf_set_f w_set;
+static weed_plant_new_f w_new;
+static weed_leaf_num_elements_f w_nelems;
+static weed_malloc_f w_malloc;
+static weed_free_f w_free;
+
+/* ---- tiny leaf helpers ---- */
+static int g_int(weed_plant_t *p, const char *k, int idx, int dflt) { int32_t v = dflt; if (w_get(p, k, (weed_size_t)idx, &v) != WEED_SUCCESS) return dflt; return v; }
+static double g_dbl(weed_plant_t *p, const char *k, double dflt) { double v = dflt; if (w_get(p, k, 0, &v) != WEED_SUCCESS) return dflt; return v; }
+static void *g_ptr(weed_plant_t *p, const char *k, int idx) { void *v = NULL; if (w_get(p, k, (weed_size_t)idx, &v) != WEED_SUCCESS) return NULL; return v; }
+static int has(weed_plant_t *p, const char *k) { return w_nelems(p, k) > 0; }
+static void s_int(weed_plant_t *p, const char *k, int v) { int32_t x = v; w_set(p, k, WEED_SEED_INT, 1, &x); }
+static void s_bool(weed_plant_t *p, const char *k, int v) { int32_t x = v; w_set(p, k, WEED_SEED_BOOLEAN, 1, &x); }
+static void s_str(weed_plant_t *p, const char *k, const char *v) { w_set(p, k, WEED_SEED_STRING, 1, &v); }
+static void s_dbl(weed_plant_t *p, const char *k, double v) { w_set(p, k, WEED_SEED_DOUBLE, 1, &v); }
+
+static int psize_of(int pal) {
+  switch (pal) {
+  case WEED_PALETTE_RGB24: case WEED_PALETTE_BGR24: case WEED_PALETTE_YUV888: return 3;
+  case WEED_PALETTE_RGBA32: case WEED_PALETTE_BGRA32: case WEED_PALETTE_ARGB32: case WEED_PALETTE_YUVA8888:
+  case WEED_PALETTE_UYVY: case WEED_PALETTE_YUYV: return 4;
+  default: return 0;
+  }
+}
+
+/* ---- per-instance device buffers ("plugin_internal", like simple_blend.c:36-45) ---- */
+typedef struct { void *d[3]; size_t cap[3]; } fxdata_t;
+
+static fxdata_t *fx_data(weed_plant_t *inst) {
+  fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
+  if (!fx) {
+    fx = (fxdata_t *)w_malloc(sizeof(fxdata_t));
+    if (!fx) return NULL;
+    memset(fx, 0, sizeof *fx);
+    void *v = fx;
+    w_set(inst, "plugin_internal", WEED_SEED_VOIDPTR, 1, &v);
+  }
+  return fx;
+}
+static void *fx_buf(fxdata_t *fx, int i, size_t bytes) {
+  if (fx->cap[i] < bytes) {
+    if (fx->d[i]) lgpu_free(fx->d[i]);
+    fx->d[i] = NULL; fx->cap[i] = 0;
+    if (lgpu_malloc(&fx->d[i], bytes) != LGPU_OK) return NULL;
+    fx->cap[i] = bytes;
+  }
+  return fx->d[i];
+}
+static weed_error_t fx_init(weed_plant_t *inst) {
+  if (lgpu_init(0) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }   /* no GPU: refuse loudly, no CPU path */
+  return fx_data(inst) ? WEED_SUCCESS : WEED_ERROR_MEMORY_ALLOCATION;
+}
+static weed_error_t fx_deinit(weed_plant_t *inst) {
+  fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
+  if (fx) {
+    for (int i = 0; i < 3; i++) if (fx->d[i]) lgpu_free(fx->d[i]);
+    w_free(fx);
+    void *v = NULL;
+    w_set(inst, "plugin_internal", WEED_SEED_VOIDPTR, 1, &v);
+  }
+  return WEED_SUCCESS;
+}
+
+/* ---- the common frame plumbing: channels -> device -> kernel -> out channel ---- */
+typedef struct {
+  uint8_t *src[2], *dst;        /* host */
+  uint8_t *dsrc[2], *ddst;      /* device, already offset to the slice */
+  int irow[2], orow, width, height, pal, psize, nin, inplace;
+} fxframe_t;
+
+typedef int (*fx_kernel_f)(const fxframe_t *f, weed_plant_t *inst, int kind);
+
+static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f kernel, int whole_frame) {
+  fxdata_t *fx = fx_data(inst);
+  weed_plant_t *ochan = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0);
+  fxframe_t f;
+  int offset = 0, real_h, slice_h, i;
+  if (!fx || !ochan) return WEED_ERROR_FILTER_INVALID;
+  memset(&f, 0, sizeof f);
+  f.nin = nin;
+  f.pal = g_int(ochan, WEED_LEAF_CURRENT_PALETTE, 0, 0);
+  f.psize = psize_of(f.pal);
+  f.width = g_int(ochan, WEED_LEAF_WIDTH, 0, 0);
+  slice_h = g_int(ochan, WEED_LEAF_HEIGHT, 0, 0);
+  real_h = (w_nelems(ochan, WEED_LEAF_HEIGHT) > 1) ? g_int(ochan, WEED_LEAF_HEIGHT, 1, slice_h) : slice_h;
+  f.orow = g_int(ochan, WEED_LEAF_ROWSTRIDES, 0, 0);
+  f.dst = (uint8_t *)g_ptr(ochan, WEED_LEAF_PIXEL_DATA, 0);           /* pre-offset by the host when slicing */
+  if (has(ochan, WEED_LEAF_OFFSET)) offset = g_int(ochan, WEED_LEAF_OFFSET, 0, 0);
+  if (!f.psize || f.width <= 0 || slice_h <= 0 || !f.dst) return WEED_ERROR_FILTER_INVALID;
+  if (whole_frame && (offset != 0 || slice_h != real_h)) return WEED_ERROR_FILTER_INVALID;   /* mirrors need the full frame */
+  f.height = slice_h;
+  for (i = 0; i < nin; i++) {
+    weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, i);
+    if (!ic) return WEED_ERROR_FILTER_INVALID;
+    f.irow[i] = g_int(ic, WEED_LEAF_ROWSTRIDES, 0, 0);
+    f.src[i] = (uint8_t *)g_ptr(ic, WEED_LEAF_PIXEL_DATA, 0);
+    if (!f.src[i]) return WEED_ERROR_FILTER_INVALID;
+    f.src[i] += (size_t)offset * f.irow[i];                           /* inputs are NOT pre-offset (simple_blend.c:87-91) */
+  }
+  f.inplace = (f.src[0] == f.dst);
+  /* stage to the device: in rows as they are (rowstride preserved so alignment-dependent paths match) */
+  {
+    /* the ARGB chroma blend reads one byte past the last pixel of each row of layer 2 (reference quirk B1) */
+    const size_t ob = (size_t)f.orow * f.height;
+    f.ddst = (uint8_t *)fx_buf(fx, 2, ob + 16);
+    if (!f.ddst) return WEED_ERROR_MEMORY_ALLOCATION;
+    for (i = 0; i < nin; i++) {
+      const size_t ib = (size_t)f.irow[i] * f.height;
+      if (i == 0 && f.inplace) { f.dsrc[0] = f.ddst; if (lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID; continue; }
+      f.dsrc[i] = (uint8_t *)fx_buf(fx, i, ib + 16);
+      if (!f.dsrc[i]) return WEED_ERROR_MEMORY_ALLOCATION;
+      if (lgpu_upload(f.dsrc[i], f.src[i], ib, NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    }
+    if (!f.inplace && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
+    if (kernel(&f, inst, kind) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+    if (lgpu_download(f.dst, f.ddst, ob, NULL) || lgpu_sync(NULL)) return WEED_ERROR_PLUGIN_INVALID;
+  }
+  return WEED_SUCCESS;
+}
+
+static int param_int(weed_plant_t *inst, int idx, int dflt) {
+  weed_plant_t *p = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, idx);
+  return p ? g_int(p, WEED_LEAF_VALUE, 0, dflt) : dflt;
+}
+
+/* ---- kernels per filter family ---- */
+static int k_simple(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  const int v = param_int(inst, 0, 128);
+  const int af = (f->pal == WEED_PALETTE_ARGB32);
+  if (kind == 0)
+    return lgpu_blend_chroma(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize, af, v, NULL);
+  if (af) return LGPU_E_UNSUPPORTED;
+  return lgpu_blend_luma(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
+                         (f->pal == WEED_PALETTE_BGR24 || f->pal == WEED_PALETTE_BGRA32) ? 1 : 0, v, NULL);
+}
+static int k_multi(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  return lgpu_blend_multi(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height,
+                          f->pal == WEED_PALETTE_BGR24, param_int(inst, 0, 128), NULL);
+}
+static int k_ckey(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  weed_plant_t *pd = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 0), *po = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 1),
+               *pc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 2);
+  (void)kind;
+  if (!pd || !po || !pc) return LGPU_E_BADARG;
+  return lgpu_colorkey(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->pal == WEED_PALETTE_BGR24,
+                       g_dbl(pd, WEED_LEAF_VALUE, .2), g_dbl(po, WEED_LEAF_VALUE, 1.), g_int(pc, WEED_LEAF_VALUE, 0, 0),
+                       g_int(pc, WEED_LEAF_VALUE, 1, 0), g_int(pc, WEED_LEAF_VALUE, 2, 255), NULL);
+}
+static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  (void)inst;
+  return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
+}
+
+#define PROC(name, nin, kind, kern, whole) static weed_error_t name(weed_plant_t *inst, weed_timecode_t tc) { (void)tc; return fx_run(inst, nin, kind, kern, whole); }
+PROC(p_chroma, 2, 0, k_simple, 0) PROC(p_lumo, 2, 1, k_simple, 0) PROC(p_lumu, 2, 2, k_simple, 0) PROC(p_nlumo, 2, 3, k_simple, 0) PROC(p_avlumo, 2, 4, k_simple, 0)
+PROC(p_mpy, 2, 0, k_multi, 0) PROC(p_screen, 2, 1, k_multi, 0) PROC(p_darken, 2, 2, k_multi, 0) PROC(p_lighten, 2, 3, k_multi, 0)
+PROC(p_overlay, 2, 4, k_multi, 0) PROC(p_dodge, 2, 5, k_multi, 0) PROC(p_burn, 2, 6, k_multi, 0)
+PROC(p_ckey, 2, 0, k_ckey, 0)
+PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
+
+/* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
+static weed_plant_t *chantmpl(const char *name, int flags) {
+  weed_plant_t *t = w_new(WEED_PLANT_CHANNEL_TEMPLATE);
+  s_str(t, WEED_LEAF_NAME, name);
+  s_int(t, WEED_LEAF_FLAGS, flags);
+  return t;
+}
+static weed_plant_t *paramtmpl_gui(weed_plant_t *pt, const char *label) {
+  weed_plant_t *gui = w_new(WEED_PLANT_GUI);
+  w_set(pt, WEED_LEAF_GUI, WEED_SEED_PLANTPTR, 1, &gui);
+  s_str(gui, WEED_LEAF_LABEL, label);
+  s_bool(gui, WEED_LEAF_USE_MNEMONIC, WEED_TRUE);
+  return gui;
+}
+static weed_plant_t *int_param(const char *name, const char *label, int def, int mn, int mx, int transition) {
+  weed_plant_t *pt = w_new(WEED_PLANT_PARAMETER_TEMPLATE);
+  s_str(pt, WEED_LEAF_NAME, name); s_int(pt, WEED_LEAF_PARAM_TYPE, WEED_PARAM_INTEGER);
+  s_int(pt, WEED_LEAF_DEFAULT, def); s_int(pt, WEED_LEAF_MIN, mn); s_int(pt, WEED_LEAF_MAX, mx);
+  paramtmpl_gui(pt, label);
+  if (transition) s_bool(pt, WEED_LEAF_IS_TRANSITION, WEED_TRUE);
+  return pt;
+}
+static weed_plant_t *float_param(const char *name, const char *label, double def, double mn, double mx) {
+  weed_plant_t *pt = w_new(WEED_PLANT_PARAMETER_TEMPLATE), *gui;
+  s_str(pt, WEED_LEAF_NAME, name); s_int(pt, WEED_LEAF_PARAM_TYPE, WEED_PARAM_FLOAT);
+  s_dbl(pt, WEED_LEAF_DEFAULT, def); s_dbl(pt, WEED_LEAF_MIN, mn); s_dbl(pt, WEED_LEAF_MAX, mx);
+  gui = paramtmpl_gui(pt, label);
+  s_int(gui, WEED_LEAF_DECIMALS, 2);
+  return pt;
+}
+static weed_plant_t *rgb_param(const char *name, const char *label, int r, int g, int b) {
+  weed_plant_t *pt = w_new(WEED_PLANT_PARAMETER_TEMPLATE);
+  int32_t def[3] = {r, g, b};
+  s_str(pt, WEED_LEAF_NAME, name); s_int(pt, WEED_LEAF_PARAM_TYPE, WEED_PARAM_COLOR); s_int(pt, WEED_LEAF_COLORSPACE, WEED_COLORSPACE_RGB);
+  w_set(pt, WEED_LEAF_DEFAULT, WEED_SEED_INT, 3, def);
+  s_int(pt, WEED_LEAF_MIN, 0); s_int(pt, WEED_LEAF_MAX, 255);
+  paramtmpl_gui(pt, label);
+  return pt;
+}
+static void add_filter(weed_plant_t *pinfo, const char *name, int flags, const int32_t *pals, int npals, weed_process_f proc,
+                       int nin, const char *in0, const char *in1, const char *out0, weed_plant_t **params, int nparams) {
+  weed_plant_t *fc = w_new(WEED_PLANT_FILTER_CLASS), *ins[2], *outs[1], **flt;
+  const char *author = "lives-gfx950";
+  weed_init_f fi = fx_init;
+  weed_deinit_f fd = fx_deinit;
+  weed_size_t n, i;
+  s_str(fc, WEED_LEAF_NAME, name); s_str(fc, WEED_LEAF_AUTHOR, author); s_int(fc, WEED_LEAF_VERSION, 1); s_int(fc, WEED_LEAF_FLAGS, flags);
+  w_set(fc, WEED_LEAF_INIT_FUNC, WEED_SEED_FUNCPTR, 1, &fi);
+  w_set(fc, WEED_LEAF_PROCESS_FUNC, WEED_SEED_FUNCPTR, 1, &proc);
+  w_set(fc, WEED_LEAF_DEINIT_FUNC, WEED_SEED_FUNCPTR, 1, &fd);
+  ins[0] = chantmpl(in0, 0);
+  if (nin > 1) ins[1] = chantmpl(in1, 0);
+  outs[0] = chantmpl(out0, WEED_CHANNEL_CAN_DO_INPLACE);
+  w_set(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, WEED_SEED_PLANTPTR, (weed_size_t)nin, ins);
+  w_set(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, WEED_SEED_PLANTPTR, 1, outs);
+  w_set(fc, WEED_LEAF_IN_PARAMETER_TEMPLATES, WEED_SEED_PLANTPTR, (weed_size_t)nparams, nparams ? params : NULL);
+  w_set(fc, WEED_LEAF_OUT_PARAMETER_TEMPLATES, WEED_SEED_PLANTPTR, 0, NULL);
+  w_set(fc, WEED_LEAF_PALETTE_LIST, WEED_SEED_INT, (weed_size_t)npals, (void *)pals);
+  /* weed_plugin_info_add_filter_class */
+  n = has(pinfo, WEED_LEAF_FILTERS) ? w_nelems(pinfo, WEED_LEAF_FILTERS) : 0;
+  flt = (weed_plant_t **)w_malloc((n + 1) * sizeof(weed_plant_t *));
+  for (i = 0; i < n; i++) w_get(pinfo, WEED_LEAF_FILTERS, i, &flt[i]);
+  flt[n] = fc;
+  w_set(pinfo, WEED_LEAF_FILTERS, WEED_SEED_PLANTPTR, n + 1, flt);
+  w_set(fc, WEED_LEAF_PLUGIN_INFO, WEED_SEED_PLANTPTR, 1, &pinfo);
+  w_free(flt);
+}
+
+weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
+  static const int32_t rgb_all[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32};
+  static const int32_t rgb_noargb[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32};
+  static const int32_t rgb24[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24};
+  static const int32_t packed[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32,
+                                   WEED_PALETTE_YUV888, WEED_PALETTE_YUVA8888, WEED_PALETTE_UYVY, WEED_PALETTE_YUYV};
+  weed_default_getter_f dget;
+  weed_plant_t *host_info, *pinfo = NULL, *p[3];
+  int32_t filter_api = 0;
+  int i;
+  if (!weed_boot) return NULL;
+  host_info = (*weed_boot)(&dget, WEED_API_VERSION_MIN, 203, 200, WEED_FILTER_API_VERSION);
+  if (!host_info) return NULL;
+  if (dget(host_info, WEED_LEAF_GET_FUNC, (void *)&w_get) != WEED_SUCCESS) return NULL;
+  if (dget(host_info, WEED_LEAF_MALLOC_FUNC, (void *)&w_malloc) != WEED_SUCCESS) return NULL;
+  if (dget(host_info, WEED_LEAF_FREE_FUNC, (void *)&w_free) != WEED_SUCCESS) return NULL;
+  if (w_get(host_info, WEED_LEAF_SET_FUNC, 0, &w_set) != WEED_SUCCESS) return NULL;
+  if (w_get(host_info, WEED_PLANT_NEW_FUNC, 0, &w_new) != WEED_SUCCESS) return NULL;
+  if (w_get(host_info, WEED_LEAF_NUM_ELEMENTS_FUNC, 0, &w_nelems) != WEED_SUCCESS) return NULL;
+  w_get(host_info, WEED_LEAF_FILTER_API_VERSION, 0, &filter_api);
+  if (has(host_info, WEED_LEAF_PLUGIN_INFO)) w_get(host_info, WEED_LEAF_PLUGIN_INFO, 0, &pinfo);
+  if (!pinfo) pinfo = w_new(WEED_PLANT_PLUGIN_INFO);
+  if (!pinfo) return NULL;
+  w_set(pinfo, WEED_LEAF_HOST_INFO, WEED_SEED_PLANTPTR, 1, &host_info);
+
+  /* simple_blend.c:234-291 -- PREF_LINEAR_GAMMA kept where the reference asks for it; STATEFUL / MAY_THREAD dropped (no shared state, one call) */
+  p[0] = int_param("amount", "Blend _amount", 128, 0, 255, 1);
+  add_filter(pinfo, "chroma blend", WEED_FILTER_PREF_LINEAR_GAMMA, rgb_all, 5, p_chroma, 2, "in channel 0", "in channel 1", "out channel 0", p, 1);
+  {
+    static const struct { const char *n; weed_process_f f; int flags; } lum[] = {
+        {"luma overlay", p_lumo, 0}, {"luma underlay", p_lumu, 0}, {"negative luma overlay", p_nlumo, 0}, {"averaged luma overlay", p_avlumo, WEED_FILTER_PREF_LINEAR_GAMMA}};
+    for (i = 0; i < 4; i++) {
+      p[0] = int_param("threshold", "luma _threshold", 64, 0, 255, 1);
+      add_filter(pinfo, lum[i].n, lum[i].flags, rgb_noargb, 4, lum[i].f, 2, "in channel 0", "in channel 1", "out channel 0", p, 1);
+    }
+  }
+  {
+    static const struct { const char *n; weed_process_f f; } mb[] = {{"blend_multiply", p_mpy}, {"blend_screen", p_screen}, {"blend_darken", p_darken},
+        {"blend_lighten", p_lighten}, {"blend_overlay", p_overlay}, {"blend_dodge", p_dodge}, {"blend_burn", p_burn}};
+    for (i = 0; i < 7; i++) {
+      p[0] = int_param("amount", "Blend _amount", 128, 0, 255, 1);
+      add_filter(pinfo, mb[i].n, WEED_FILTER_PREF_LINEAR_GAMMA, rgb24, 2, mb[i].f, 2, "in channel 0", "in channel 1", "out channel 0", p, 1);
+    }
+  }
+  p[0] = float_param("delta", "_Delta", .2, 0., 1.);
+  p[1] = float_param("opac", "_Opacity", 1., 0., 1.);
+  p[2] = rgb_param("col", "_Colour", 0, 0, 255);
+  add_filter(pinfo, "colorkey", 0, rgb24, 2, p_ckey, 2, "in_channel0", "in_channel1", "out_channel0", p, 3);
+  add_filter(pinfo, "mirrorx", 0, packed, 9, p_mirrorx, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
+  add_filter(pinfo, "mirrory", 0, packed, 9, p_mirrory, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
+  add_filter(pinfo, "mirrorxy", 0, packed, 9, p_mirrorxy, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
+  s_int(pinfo, WEED_LEAF_VERSION, 1);
+  return pinfo;
+}

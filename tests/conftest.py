@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  Import it before anything dlopens liblivesgpu.so so
+# the process ends up with ONE HIP runtime (two runtimes in one process cannot both own the device).
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

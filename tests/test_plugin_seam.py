@@ -1,0 +1,102 @@
+"""The weed plugin seam: livesgpu_fx.so driven by a real weed host (the reference's libweed + oracle/ref/refhost.c).
+
+CPU part: bootstrap works, the filter classes mirror the reference plugins' (names, palettes, channel and
+parameter counts), and without a GPU init_func refuses loudly.  GPU part: every golden plugin record through
+weed_setup()/process_func, compared with the bytes the REFERENCE plugin produced.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OURS = os.path.join(ROOT, "lives_amd", "livesgpu_fx.so")
+needs_ref = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref (reference libweed host) not built")
+PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
+
+
+@needs_ref
+def test_filter_classes_mirror_the_reference():
+    H = po.RefHost()
+    ours = {f["name"]: f for f in H.filters(OURS)}
+    assert len(ours) == 16
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors"):
+        for rf in H.filters(po.refplugin(plug)):
+            o = ours[rf["name"]]
+            assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
+            if rf["name"].endswith("luma overlay") or rf["name"] == "luma underlay":
+                assert o["palettes"] == [1, 2, 3, 4]          # ARGB32 luma blends declined
+            else:
+                assert o["palettes"] == rf["palettes"], rf["name"]
+            assert not (o["flags"] & 64), "a GPU filter must not advertise WEED_FILTER_HINT_MAY_THREAD"
+            assert (o["flags"] & 8) == (rf["flags"] & 8), "PREF_LINEAR_GAMMA must match: " + rf["name"]
+
+
+@needs_ref
+def test_refuses_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    H = po.RefHost()
+    a = np.zeros((8, 64), np.uint8)
+    with pytest.raises(RuntimeError, match="returned 64"):       # WEED_ERROR_PLUGIN_INVALID from init_func
+        H.run(OURS, "chroma blend", 3, 16, 8, [a, a.copy()], a.copy(), [po.p_int(128)])
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_golden_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("plugins.npz")
+    n = 0
+    for rec in g["records"]:
+        rec = str(rec)
+        f = rec.split("|")
+        if f[0] == "sb":
+            fn, pal, prm = f[1], int(f[2]), int(f[3])
+            if fn != "chroma blend" and pal == 5:
+                continue
+            a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+            d = a.copy()
+            H.run(OURS, fn, pal, 18, 8, [a, b], d, [po.p_int(prm)])
+            nbytes, rows = 18 * PSIZE[pal], 8
+        elif f[0] == "mb":
+            fn, pal, prm = f[1], int(f[2]), int(f[3])
+            a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+            d = np.zeros_like(a)
+            H.run(OURS, fn, pal, 18, 8, [a, b], d, [po.p_int(prm)])
+            nbytes, rows = 54, 8
+        elif f[0] == "ck":
+            pal, delta, opac = int(f[1]), float(f[2]), float(f[3])
+            col = list(map(int, f[4].split(",")))
+            a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+            d = np.zeros_like(a)
+            H.run(OURS, "colorkey", pal, 18, 8, [a, b], d, [po.p_double(delta), po.p_double(opac), po.p_rgb(*col)])
+            nbytes, rows = 54, 8
+        else:
+            fn, pal, mw, mh = f[1], int(f[2]), int(f[3]), int(f[4])
+            a, want = g[rec + "|a"], g[rec + "|o"]
+            d = a.copy()
+            H.run(OURS, fn, pal, mw, mh, [d], d, [])
+            nbytes, rows = mw * PSIZE[pal], mh
+        assert (d[:rows, :nbytes] == want[:rows, :nbytes]).all(), rec
+        n += 1
+    assert n > 200
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_sliced_calls_equal_one_call():
+    """a host that slices anyway (process_func_threaded protocol) gets the same pixels"""
+    H = po.RefHost()
+    rng = np.random.default_rng(9)
+    w, h = 40, 24
+    s1 = po.make_frame(rng, w, h, 4, extra_rows=1, alpha_mix=True)
+    s2 = po.make_frame(rng, w, h, 4, extra_rows=1, alpha_mix=True)
+    a, b = s1.copy(), s1.copy()
+    H.run(OURS, "chroma blend", 3, w, h, [s1, s2], a, [po.p_int(140)], nslices=1)
+    H.run(OURS, "chroma blend", 3, w, h, [s1, s2], b, [po.p_int(140)], nslices=3)
+    assert (a == b).all()
