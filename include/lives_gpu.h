@@ -95,6 +95,10 @@ int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v
    fill :11109-11119).  Writes every pixel of the nwidth x nheight canvas exactly once. */
 int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow,
                    int nwidth, int nheight, int psize, const uint8_t black_pixel[4], void *stream);
+/* same with explicit offsets: the chroma planes of planar palettes sit at (int)(offs * plane_ratio) (:15553-15556) */
+int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow,
+                      int nwidth, int nheight, int psize, const uint8_t black_pixel[4], int offs_x, int offs_y,
+                      void *stream);
 
 /* ---- K7: resize.  Replaces the sws_scale() call of resize_layer_full (src/colourspace.c:14711, setup
    :14940-15259).  PARITY UNPINNED: libswscale is neither vendored nor version-pinned by the reference;

@@ -1,0 +1,86 @@
+/* lives_gpu_layer.h -- the weed_layer_t seam of liblivesgpu.so.
+ *
+ * Same prototypes, argument meaning and failure behaviour as src/colourspace.h:377-423: the layer (a weed
+ * plant of type WEED_PLANT_LAYER = 128, src/layers.h:14) is mutated IN PLACE -- pixel_data, rowstrides,
+ * width (macropixels), height, current_palette, gamma_type, YUV leaves -- old pixel memory is released
+ * with the host's allocator, and on failure the function returns FALSE and leaves the layer untouched
+ * (the memfail: contract, src/colourspace.c:13906-13927).
+ *
+ * The library never links libweed: the host hands over its accessors once with lives_gpu_bind_weed()
+ * (LiVES: the extern function pointers of libweed/weed.h:340-351 and its frame allocator).
+ *
+ * Symbols are exported as lives_gpu_<name>; define LIVES_GPU_DROP_IN before including this header to
+ * get the reference names as macros (what a LiVES build that replaces the CPU bodies would do; see
+ * INTEGRATION.md).
+ *
+ * Pixel data stays HOST memory at this seam (that is what every other part of LiVES expects): each call
+ * uploads the planes it needs, runs the gfx950 kernels and downloads into freshly allocated host memory
+ * (PCIe-bound; keeping a layer device-resident across a CONVERT chain is the next step).
+ *
+ * Coverage (anything else returns FALSE with the layer untouched, lgpu_last_error() says why):
+ *   convert_layer_palette[_full]  RGB24/BGR24/RGBA32/BGRA32/ARGB32 <-> each other (selector tree
+ *                                 src/colourspace.c:12370-12556, LUT8 gamma inline), YUV420P/YVU420P/YUV422P ->
+ *                                 those five (src/colourspace.c:13400-13560)
+ *   gamma_convert_layer / gamma_convert_sub_layer, alpha_premult, resize_layer, letterbox_layer (packed RGB
+ *   palettes and YUV420P / YVU420P / YUV422P / YUV444P planes), create_empty_pixel_data, calc_rowstrides
+ */
+#ifndef LIVES_GPU_LAYER_H
+#define LIVES_GPU_LAYER_H
+#include "lives_gpu_weed_abi.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef weed_plant_t lives_gpu_layer_t;   /* weed_layer_t */
+typedef int lives_gpu_boolean;            /* LiVES `boolean`: TRUE 1 / FALSE 0 */
+
+typedef struct {
+  weed_leaf_get_f leaf_get;
+  weed_leaf_set_f leaf_set;
+  weed_leaf_num_elements_f leaf_num_elements;
+  weed_leaf_delete_f leaf_delete;
+  void *(*pixel_alloc)(size_t bytes);     /* frame allocator (LiVES: lives_calloc_safety); NULL -> calloc */
+  void (*pixel_free)(void *);             /* LiVES: lives_free; NULL -> free */
+} lives_gpu_weed_api;
+
+/* prefs the reference reads on this path (src/preferences.h: apply_gamma, alpha_post, pb_quality, screen_gamma) */
+typedef struct {
+  int apply_gamma;      /* default 1 */
+  int alpha_post;       /* default 0 */
+  int pb_quality;       /* 1 LOW, 2 MED (default) */
+  double screen_gamma;  /* default 1.4 (DEF_SCREEN_GAMMA) */
+  int device;           /* HIP device ordinal, default 0 */
+} lives_gpu_prefs;
+
+int lives_gpu_bind_weed(const lives_gpu_weed_api *api);
+int lives_gpu_set_prefs(const lives_gpu_prefs *prefs);
+
+lives_gpu_boolean lives_gpu_convert_layer_palette(lives_gpu_layer_t *layer, int outpl, int op_clamping);
+lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
+                                                       int osubspace, int tgt_gamma);
+lives_gpu_boolean lives_gpu_gamma_convert_layer(int gamma_type, lives_gpu_layer_t *layer);
+lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y,
+                                                    int width, int height, lives_gpu_boolean may_thread);
+void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction);
+lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint);
+lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
+                                            int tpal, int tclamp);
+lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig);
+int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int *nplanes);
+
+#ifdef LIVES_GPU_DROP_IN
+#define convert_layer_palette lives_gpu_convert_layer_palette
+#define convert_layer_palette_full lives_gpu_convert_layer_palette_full
+#define gamma_convert_layer lives_gpu_gamma_convert_layer
+#define gamma_convert_sub_layer lives_gpu_gamma_convert_sub_layer
+#define alpha_premult lives_gpu_alpha_premult
+#define resize_layer lives_gpu_resize_layer
+#define letterbox_layer lives_gpu_letterbox_layer
+#define create_empty_pixel_data lives_gpu_create_empty_pixel_data
+#define calc_rowstrides lives_gpu_calc_rowstrides
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

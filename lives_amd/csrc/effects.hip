@@ -422,13 +422,20 @@ extern "C" int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *ds
 
 extern "C" int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow, int nwidth,
                               int nheight, int psize, const uint8_t black_pixel[4], void *stream) {
+  // centred: offs = (outer - inner + 1) >> 1 (src/colourspace.c:15522-15523)
+  return lgpu_letterbox_at(src_d, irow, width, height, dst_d, orow, nwidth, nheight, psize, black_pixel, (nwidth - width + 1) >> 1,
+                           (nheight - height + 1) >> 1, stream);
+}
+
+extern "C" int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow, int nwidth,
+                                 int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(src_d && dst_d && black_pixel && width > 0 && height > 0, "null frame or empty geometry");
   LGPU_REQUIRE(psize == 1 || psize == 3 || psize == 4, "psize must be 1, 3 or 4");
   LGPU_REQUIRE(nwidth >= width && nheight >= height, "canvas smaller than the inner frame");
   LGPU_REQUIRE(irow >= width * psize && orow >= nwidth * psize, "rowstride smaller than a row");
-  const int ox = (nwidth - width + 1) >> 1, oy = (nheight - height + 1) >> 1;   // src/colourspace.c:15522-15523
+  LGPU_REQUIRE(ox >= 0 && oy >= 0 && ox + width <= nwidth && oy + height <= nheight, "inner frame does not fit at that offset");
   uint32_t black = black_pixel[0];
   if (psize >= 3) black |= ((uint32_t)black_pixel[1] << 8) | ((uint32_t)black_pixel[2] << 16);
   if (psize == 4) black |= (uint32_t)black_pixel[3] << 24;

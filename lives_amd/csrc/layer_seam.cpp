@@ -1,0 +1,415 @@
+// layer_seam.cpp -- the weed_layer_t seam (include/lives_gpu_layer.h): host-side logic of
+//   convert_layer_palette_full   src/colourspace.c:12190-13928
+//   gamma_convert_sub_layer      src/colourspace.c:14069-14143
+//   alpha_premult                src/colourspace.c:11968-12105
+//   resize_layer_full            src/colourspace.c:14759-15328
+//   letterbox_layer              src/colourspace.c:15343-15567
+//   create_empty_pixel_data      src/colourspace.c:11434-11700
+//   calc_rowstrides              src/colourspace.c:11252-11366
+// re-written around the frame-level C ABI (lives_gpu.h).  All pixel work happens in the HIP kernels; this
+// file only reads / writes leaves through the accessors the host bound, moves planes over PCIe and keeps the
+// reference's bookkeeping (palette, size, rowstrides, gamma, premult flag, YUV leaves, failure = untouched layer).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../include/lives_gpu.h"
+#include "../../include/lives_gpu_layer.h"
+
+namespace {
+
+lives_gpu_weed_api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+lives_gpu_prefs g_prefs = {1, 0, 2, 1.4, 0};
+
+constexpr const char *kLeafHostFlags = "host_flags";          // LIVES_LEAF_HOST_FLAGS (src/colourspace.h:37)
+constexpr const char *kLeafContiguous = "host_contiguous";    // LIVES_LEAF_PIXEL_DATA_CONTIGUOUS (:33)
+
+bool bound() { return g_api.leaf_get && g_api.leaf_set && g_api.leaf_num_elements && g_api.leaf_delete; }
+void *palloc(size_t n) { return g_api.pixel_alloc ? g_api.pixel_alloc(n) : calloc(1, n ? n : 1); }
+void pfree(void *p) { if (!p) return; if (g_api.pixel_free) g_api.pixel_free(p); else free(p); }
+
+bool has_leaf(weed_plant_t *p, const char *k) { return g_api.leaf_num_elements(p, k) > 0; }
+int get_int(weed_plant_t *p, const char *k, int dflt, int idx = 0) {
+  int32_t v = dflt;
+  if (g_api.leaf_get(p, k, (weed_size_t)idx, &v) != WEED_SUCCESS) return dflt;
+  return v;
+}
+void set_int(weed_plant_t *p, const char *k, int v) { int32_t x = v; g_api.leaf_set(p, k, WEED_SEED_INT, 1, &x); }
+void set_bool(weed_plant_t *p, const char *k, int v) { int32_t x = v; g_api.leaf_set(p, k, WEED_SEED_BOOLEAN, 1, &x); }
+
+bool pal_is_rgb(int p) { return p >= WEED_PALETTE_RGB24 && p <= WEED_PALETTE_ARGB32; }
+bool pal_is_planar_yuv(int p) { return p == WEED_PALETTE_YUV420P || p == WEED_PALETTE_YVU420P || p == WEED_PALETTE_YUV422P || p == WEED_PALETTE_YUV444P; }
+bool pal_alpha_first(int p) { return p == WEED_PALETTE_ARGB32; }
+bool pal_alpha_last(int p) { return p == WEED_PALETTE_RGBA32 || p == WEED_PALETTE_BGRA32; }
+bool pal_has_alpha(int p) { return pal_alpha_first(p) || pal_alpha_last(p); }
+bool pal_red_first(int p) { return p == WEED_PALETTE_RGB24 || p == WEED_PALETTE_RGBA32 || p == WEED_PALETTE_ARGB32; }
+int pal_psize(int p) { return (p == WEED_PALETTE_RGB24 || p == WEED_PALETTE_BGR24) ? 3 : pal_is_rgb(p) ? 4 : pal_is_planar_yuv(p) ? 1 : 0; }
+
+// ---- a layer as this file sees it ------------------------------------------------------------------------------
+struct Layer {
+  weed_plant_t *plant;
+  int pal, width, height, nplanes;
+  int rs[4];
+  uint8_t *pd[4];
+  int clamping, subspace, sampling, gamma, flags;
+  bool contiguous;
+};
+
+int plane_w(const Layer &l, int p) { return (p == 0 || l.pal == WEED_PALETTE_YUV444P) ? l.width : l.width >> 1; }
+int plane_h(const Layer &l, int p) { return (p == 0 || l.pal == WEED_PALETTE_YUV444P || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1; }
+
+bool read_layer(weed_plant_t *plant, Layer *l) {
+  if (!plant || !bound()) return false;
+  l->plant = plant;
+  l->pal = get_int(plant, WEED_LEAF_CURRENT_PALETTE, 0);
+  l->width = get_int(plant, WEED_LEAF_WIDTH, 0);
+  l->height = get_int(plant, WEED_LEAF_HEIGHT, 0);
+  l->nplanes = (int)g_api.leaf_num_elements(plant, WEED_LEAF_PIXEL_DATA);
+  if (l->nplanes < 1 || l->nplanes > 4 || (int)g_api.leaf_num_elements(plant, WEED_LEAF_ROWSTRIDES) < l->nplanes) return false;
+  for (int i = 0; i < 4; i++) { l->rs[i] = 0; l->pd[i] = nullptr; }
+  for (int i = 0; i < l->nplanes; i++) {
+    l->rs[i] = get_int(plant, WEED_LEAF_ROWSTRIDES, 0, i);
+    void *v = nullptr;
+    g_api.leaf_get(plant, WEED_LEAF_PIXEL_DATA, (weed_size_t)i, &v);
+    l->pd[i] = (uint8_t *)v;
+  }
+  if (!l->pd[0] || l->width <= 0 || l->height <= 0) return false;
+  l->clamping = get_int(plant, WEED_LEAF_YUV_CLAMPING, -1);
+  l->subspace = get_int(plant, WEED_LEAF_YUV_SUBSPACE, WEED_YUV_SUBSPACE_YUV);
+  l->sampling = get_int(plant, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);
+  l->gamma = get_int(plant, WEED_LEAF_GAMMA_TYPE, WEED_GAMMA_UNKNOWN);
+  l->flags = get_int(plant, kLeafHostFlags, 0);
+  l->contiguous = get_int(plant, kLeafContiguous, 0) != 0;
+  return true;
+}
+
+void free_planes(const Layer &l) {
+  if (l.contiguous) pfree(l.pd[0]);
+  else for (int i = 0; i < l.nplanes; i++) pfree(l.pd[i]);
+}
+
+// new host planes for (pal, width, height) with the reference's rowstride rule; one block for planar ("contiguous")
+struct NewPlanes { int n; int rs[4]; uint8_t *pd[4]; size_t sz[4]; };
+bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np) {
+  np->n = lgpu_calc_rowstrides(width, pal, alignment, np->rs);
+  if (np->n < 1) return false;
+  size_t tot = 0;
+  for (int i = 0; i < np->n; i++) {
+    const int h = (i == 0 || pal == WEED_PALETTE_YUV444P || pal == WEED_PALETTE_YUV422P) ? height : height >> 1;
+    np->sz[i] = (size_t)np->rs[i] * h;
+    tot += np->sz[i];
+  }
+  uint8_t *blk = (uint8_t *)palloc(tot + 64);     // + EXTRA_BYTES-style slack (reference loops read a few bytes past the end)
+  if (!blk) return false;
+  size_t off = 0;
+  for (int i = 0; i < np->n; i++) { np->pd[i] = blk + off; off += np->sz[i]; }
+  return true;
+}
+void commit_planes(weed_plant_t *plant, int pal, int width, int height, const NewPlanes &np) {
+  set_int(plant, WEED_LEAF_CURRENT_PALETTE, pal);
+  set_int(plant, WEED_LEAF_WIDTH, width);
+  set_int(plant, WEED_LEAF_HEIGHT, height);
+  int32_t rs[4];
+  void *pd[4];
+  for (int i = 0; i < np.n; i++) { rs[i] = np.rs[i]; pd[i] = np.pd[i]; }
+  g_api.leaf_set(plant, WEED_LEAF_ROWSTRIDES, WEED_SEED_INT, (weed_size_t)np.n, rs);
+  g_api.leaf_set(plant, WEED_LEAF_PIXEL_DATA, WEED_SEED_VOIDPTR, (weed_size_t)np.n, pd);
+  if (np.n > 1) set_bool(plant, kLeafContiguous, WEED_TRUE); else g_api.leaf_delete(plant, kLeafContiguous);
+}
+
+// ---- device scratch (per calling thread; grown on demand) ------------------------------------------------------------
+struct Scratch {
+  void *p[8] = {nullptr};
+  size_t cap[8] = {0};
+  ~Scratch() { for (auto q : p) if (q) lgpu_free(q); }
+  uint8_t *get(int i, size_t bytes) {
+    if (cap[i] < bytes) {
+      if (p[i]) lgpu_free(p[i]);
+      p[i] = nullptr; cap[i] = 0;
+      if (lgpu_malloc(&p[i], bytes + 64) != LGPU_OK) return nullptr;
+      cap[i] = bytes;
+    }
+    return (uint8_t *)p[i];
+  }
+};
+thread_local Scratch t_scr;
+
+bool ready() { return bound() && lgpu_init(g_prefs.device) == LGPU_OK; }
+bool up(uint8_t *d, const uint8_t *h, size_t n) { return lgpu_upload(d, h, n, nullptr) == LGPU_OK; }
+bool down(uint8_t *h, const uint8_t *d, size_t n) { return lgpu_download(h, d, n, nullptr) == LGPU_OK; }
+bool sync() { return lgpu_sync(nullptr) == LGPU_OK; }
+
+int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
+  // the selector tree of src/colourspace.c:12370-12556
+  const bool swap = pal_red_first(inpl) != pal_red_first(outpl);
+  *alpha_first_arg = 0;
+  if (!pal_alpha_first(inpl)) {
+    if (!pal_alpha_last(inpl)) {                        // RGB24 / BGR24 in
+      if (!pal_alpha_first(outpl)) {
+        if (!pal_alpha_last(outpl)) return LGPU_SWAP3;
+        return swap ? LGPU_SWAP3ADDPOST : LGPU_ADDPOST;
+      }
+      return swap ? LGPU_SWAP3ADDPRE : LGPU_ADDPRE;     // -> ARGB
+    }
+    if (!pal_alpha_first(outpl)) {                      // RGBA / BGRA in
+      if (!pal_alpha_last(outpl)) return swap ? LGPU_SWAP3DELPOST : LGPU_DELPOST;
+      return LGPU_SWAP3POSTALPHA;
+    }
+    return swap ? LGPU_SWAP4 : LGPU_SWAPPREPOST;        // -> ARGB (alpha_first = FALSE)
+  }
+  *alpha_first_arg = 1;                                 // ARGB in
+  if (!pal_alpha_first(outpl)) {
+    if (!pal_alpha_last(outpl)) return swap ? LGPU_SWAP3DELPRE : LGPU_DELPRE;
+    return swap ? LGPU_SWAP4 : LGPU_SWAPPREPOST;
+  }
+  return LGPU_SWAP3PREALPHA;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lives_gpu_bind_weed(const lives_gpu_weed_api *api) {
+  if (!api || !api->leaf_get || !api->leaf_set || !api->leaf_num_elements || !api->leaf_delete) return LGPU_E_BADARG;
+  g_api = *api;
+  return LGPU_OK;
+}
+
+int lives_gpu_set_prefs(const lives_gpu_prefs *prefs) {
+  if (!prefs) return LGPU_E_BADARG;
+  g_prefs = *prefs;
+  return LGPU_OK;
+}
+
+int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int *nplanes) {
+  if (pal == WEED_PALETTE_NONE) { if (!layer || !bound()) return nullptr; pal = get_int(layer, WEED_LEAF_CURRENT_PALETTE, 0); }
+  if (!width) { if (!layer || !bound()) return nullptr; width = get_int(layer, WEED_LEAF_WIDTH, 0); }
+  int rs[4];
+  const int n = lgpu_calc_rowstrides(width, pal, 0, rs);
+  if (nplanes) *nplanes = n;
+  if (!n) return nullptr;
+  int *out = (int *)calloc((size_t)n, sizeof(int));      // caller frees with lives_free, like the reference
+  for (int i = 0; i < n; i++) out[i] = rs[i];
+  return out;
+}
+
+lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig) {
+  (void)may_contig;
+  if (!layer || !bound()) return 0;
+  const int pal = get_int(layer, WEED_LEAF_CURRENT_PALETTE, 0);
+  int width = get_int(layer, WEED_LEAF_WIDTH, 0), height = get_int(layer, WEED_LEAF_HEIGHT, 0);
+  if (width <= 0 || height <= 0 || !pal_psize(pal)) return 0;
+  if (pal == WEED_PALETTE_YUV420P || pal == WEED_PALETTE_YVU420P) { width = (width >> 1) << 1; height = (height >> 1) << 1; }   // :11601-11603
+  Layer old;
+  const bool had = read_layer(layer, &old);
+  NewPlanes np;
+  if (!alloc_planes(pal, width, height, 0, &np)) return 0;
+  if (black_fill) {
+    // opaque black: RGB 0,0,0 (alpha 255); YUV 16 (clamped) or 0, 128, 128 (src/colourspace.c:11448-11460)
+    const int clamping = get_int(layer, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED);
+    if (pal_is_planar_yuv(pal)) {
+      memset(np.pd[0], clamping == WEED_YUV_CLAMPING_CLAMPED ? 16 : 0, np.sz[0]);
+      memset(np.pd[1], 128, np.sz[1]);
+      memset(np.pd[2], 128, np.sz[2]);
+    } else if (pal_has_alpha(pal)) {
+      const int a = pal_alpha_first(pal) ? 0 : 3;
+      for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) np.pd[0][(size_t)y * np.rs[0] + x * 4 + a] = 255;
+    }
+  }
+  if (had) free_planes(old);
+  commit_planes(layer, pal, width, height, np);
+  return 1;
+}
+
+lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
+                                                       int osubspace, int tgt_gamma) {
+  (void)osampling; (void)osubspace;
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return 0;
+  const int inpl = l.pal;
+  if (inpl == outpl) return 1;                                           // :12265
+  if (!pal_is_rgb(outpl)) return 0;                                      // RGB -> YUV / YUV -> YUV: not on the GPU path yet
+  const int iclamping = l.clamping >= 0 ? l.clamping : oclamping;        // :12216-12218
+
+  // gamma decision (:12311-12332): only an explicit target changes the transfer function here
+  int new_gamma = l.gamma;
+  uint8_t lut[256];
+  const uint8_t *lutp = nullptr;
+  if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) {
+    new_gamma = tgt_gamma;
+    if (lgpu_gamma_lut8(1.0, l.gamma, new_gamma, g_prefs.screen_gamma, lut)) lutp = lut;
+  }
+  // premultiplied-alpha bookkeeping (:12290-12306)
+  int flags = l.flags;
+  if (g_prefs.alpha_post) {
+    if ((flags & LIVES_LAYER_ALPHA_PREMULT) && pal_has_alpha(inpl) && !pal_has_alpha(outpl)) {
+      lives_gpu_alpha_premult(layer, LIVES_DIRECTION_REVERSE);
+      if (!read_layer(layer, &l)) return 0;
+      flags = l.flags;
+    }
+  } else if (!pal_has_alpha(inpl) && pal_has_alpha(outpl)) flags |= LIVES_LAYER_ALPHA_PREMULT;
+  if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+
+  NewPlanes np;
+  if (!alloc_planes(outpl, l.width, l.height, 0, &np)) return 0;
+  const size_t obytes = (size_t)np.rs[0] * l.height;
+  uint8_t *d_out = t_scr.get(3, obytes);
+  bool ok = d_out != nullptr;
+  if (ok && pal_is_rgb(inpl)) {
+    int af = 0;
+    const int op = rgb_swizzle_op(inpl, outpl, &af);
+    const size_t ibytes = (size_t)l.rs[0] * l.height;
+    uint8_t *d_in = t_scr.get(0, ibytes);
+    ok = d_in && up(d_in, l.pd[0], ibytes) &&
+         lgpu_swizzle(op, af, d_in, l.rs[0], d_out, np.rs[0], l.width, l.height, lutp, nullptr) == LGPU_OK;
+  } else if (ok && (inpl == WEED_PALETTE_YUV420P || inpl == WEED_PALETTE_YVU420P || inpl == WEED_PALETTE_YUV422P)) {
+    const int iu = (inpl == WEED_PALETTE_YVU420P) ? 2 : 1, iv = (inpl == WEED_PALETTE_YVU420P) ? 1 : 2;   // swap_chroma_planes (:12353)
+    const int ch = plane_h(l, 1);
+    const size_t yb = (size_t)l.rs[0] * l.height, ub = (size_t)l.rs[iu] * ch, vb = (size_t)l.rs[iv] * ch;
+    uint8_t *dy = t_scr.get(0, yb), *du = t_scr.get(1, ub), *dv = t_scr.get(2, vb);
+    const int strides[3] = {l.rs[0], l.rs[iu], l.rs[iv]};
+    const int which = (iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | (l.subspace == WEED_YUV_SUBSPACE_BT709 ? 2 : 0);
+    const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
+    ok = dy && du && dv && up(dy, l.pd[0], yb) && up(du, l.pd[iu], ub) && up(dv, l.pd[iv], vb) &&
+         lgpu_yuv420p_to_rgb(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
+                             inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, lutp, 0, nullptr) == LGPU_OK;
+  } else ok = false;
+  ok = ok && down(np.pd[0], d_out, obytes) && sync();
+  if (!ok) { pfree(np.pd[0]); return 0; }                                  // memfail: layer untouched
+  free_planes(l);
+  commit_planes(layer, outpl, l.width, l.height, np);
+  if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
+  if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
+  g_api.leaf_delete(layer, WEED_LEAF_YUV_CLAMPING);                          // conv_done (:13881-13884)
+  g_api.leaf_delete(layer, WEED_LEAF_YUV_SUBSPACE);
+  g_api.leaf_delete(layer, WEED_LEAF_YUV_SAMPLING);
+  return 1;
+}
+
+lives_gpu_boolean lives_gpu_convert_layer_palette(lives_gpu_layer_t *layer, int outpl, int op_clamping) {
+  return lives_gpu_convert_layer_palette_full(layer, outpl, op_clamping, WEED_YUV_SAMPLING_DEFAULT, WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);   // :13931
+}
+
+lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y, int width,
+                                                    int height, lives_gpu_boolean may_thread) {
+  (void)may_thread;
+  if (!g_prefs.apply_gamma) return 1;
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return 0;
+  if (!pal_is_rgb(l.pal)) return 0;
+  if (gamma_type == l.gamma && fileg == 1.0) return 1;
+  uint8_t lut[256];
+  if (!lgpu_gamma_lut8(gamma_type == LIVES_GAMMA_VARIANT ? fileg : 1.0, l.gamma, gamma_type, g_prefs.screen_gamma, lut)) return 1;
+  if (x < 0 || y < 0 || x + width > l.width || y + height > l.height) return 0;
+  const size_t bytes = (size_t)l.rs[0] * l.height;
+  uint8_t *d = t_scr.get(0, bytes);
+  const bool ok = d && up(d, l.pd[0], bytes) &&
+                  lgpu_gamma_apply(d, l.rs[0], x, y, width, height, pal_psize(l.pal), pal_alpha_first(l.pal), lut, nullptr) == LGPU_OK &&
+                  down(l.pd[0], d, bytes) && sync();
+  if (!ok) return 0;
+  if (gamma_type != LIVES_GAMMA_VARIANT) set_int(layer, WEED_LEAF_GAMMA_TYPE, gamma_type);
+  return 1;
+}
+
+lives_gpu_boolean lives_gpu_gamma_convert_layer(int gamma_type, lives_gpu_layer_t *layer) {
+  Layer l;
+  if (!bound() || !read_layer(layer, &l)) return 0;
+  return lives_gpu_gamma_convert_sub_layer(gamma_type, 1.0, layer, 0, 0, l.width, l.height, 1);   // :14146-14155
+}
+
+void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction) {
+  Layer l;
+  if (!ready() || !read_layer(layer, &l) || !pal_has_alpha(l.pal)) return;
+  const size_t bytes = (size_t)l.rs[0] * l.height;
+  uint8_t *d = t_scr.get(0, bytes);
+  const bool ok = d && up(d, l.pd[0], bytes) &&
+                  lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK &&
+                  down(l.pd[0], d, bytes) && sync();
+  if (!ok) return;
+  int flags = l.flags;
+  if (direction == LIVES_DIRECTION_FORWARD) flags |= LIVES_LAYER_ALPHA_PREMULT; else flags &= ~LIVES_LAYER_ALPHA_PREMULT;   // :12098-12102
+  set_int(layer, kLeafHostFlags, flags);
+}
+
+// resize every plane of `l` into freshly allocated planes of (width x height); returns device-side success
+static bool resize_into(const Layer &l, int width, int height, int interp, int alignment, NewPlanes *np) {
+  if (!alloc_planes(l.pal, width, height, alignment, np)) return false;
+  bool ok = true;
+  Layer nl = l;
+  nl.width = width; nl.height = height;
+  for (int p = 0; p < np->n && ok; p++) {
+    const int ps = pal_is_planar_yuv(l.pal) ? 1 : pal_psize(l.pal);
+    const int sw = plane_w(l, p), sh = plane_h(l, p), dw = plane_w(nl, p), dh = plane_h(nl, p);
+    const size_t ib = (size_t)l.rs[p] * sh, ob = (size_t)np->rs[p] * dh;
+    uint8_t *d_in = t_scr.get(0, ib), *d_out = t_scr.get(3, ob);
+    ok = d_in && d_out && up(d_in, l.pd[p], ib) &&
+         lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, nullptr, nullptr) == LGPU_OK &&
+         down(np->pd[p], d_out, ob) && sync();
+  }
+  if (!ok) pfree(np->pd[0]);
+  return ok;
+}
+
+lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint) {
+  (void)oclamp_hint;
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return 0;
+  if (opal_hint != WEED_PALETTE_NONE && opal_hint != l.pal) return 0;     // resize + palette change in one go: not on the GPU path
+  if (!(pal_is_rgb(l.pal) || pal_is_planar_yuv(l.pal))) return 0;
+  int iwidth = (l.width >> 1) << 1, iheight = (l.height >> 1) << 1;      // :14854-14863
+  if (width < 4) width = 4;
+  if (height < 4) height = 4;
+  if (iwidth != width || iheight != height) height = (height >> 1) << 1;
+  if (iwidth == width && iheight == height) return 1;
+  if (pal_is_planar_yuv(l.pal)) width = (width >> 1) << 1;
+  Layer src = l;
+  src.width = iwidth; src.height = iheight;
+  NewPlanes np;
+  if (!resize_into(src, width, height, interp, 16, &np)) return 0;       // rowstride_alignment_hint = 16 (:14989)
+  free_planes(l);
+  commit_planes(layer, l.pal, width, height, np);
+  return 1;
+}
+
+lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
+                                            int tpal, int tclamp) {
+  if (!width || !height || !nwidth || !nheight) return 1;                 // :15377
+  if (nwidth < width) nwidth = width;
+  if (nheight < height) nheight = height;
+  if (nheight == height && nwidth == width) { lives_gpu_resize_layer(layer, width, height, interp, tpal, tclamp); return 1; }
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return 0;
+  if (l.width != width || l.height != height) {
+    if (!lives_gpu_resize_layer(layer, width, height, interp, tpal, tclamp)) return 0;
+    if (!read_layer(layer, &l)) return 0;
+  }
+  width = l.width; height = l.height;
+  if (nwidth < width || nheight < height) return 0;
+  Layer canvas = l;
+  canvas.width = nwidth; canvas.height = nheight;
+  NewPlanes np;
+  if (!alloc_planes(l.pal, nwidth, nheight, 0, &np)) return 0;
+  bool ok = true;
+  const int offs_x = (nwidth - width + 1) >> 1, offs_y = (nheight - height + 1) >> 1;     // :15522-15523
+  for (int p = 0; p < np.n && ok; p++) {
+    const int ps = pal_is_planar_yuv(l.pal) ? 1 : pal_psize(l.pal);
+    // chroma planes: offsets scaled by the plane ratio and truncated (:15553-15556)
+    const int px = (plane_w(l, p) == l.width) ? offs_x : (int)(offs_x * 0.5), py = (plane_h(l, p) == l.height) ? offs_y : (int)(offs_y * 0.5);
+    uint8_t black[4] = {0, 0, 0, 0};
+    if (pal_is_planar_yuv(l.pal)) black[0] = (p == 0) ? (l.clamping == WEED_YUV_CLAMPING_UNCLAMPED ? 0 : 16) : 128;
+    else if (pal_alpha_first(l.pal)) black[0] = 255;
+    else if (pal_alpha_last(l.pal)) black[3] = 255;
+    const int sw = plane_w(l, p), sh = plane_h(l, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
+    const size_t ib = (size_t)l.rs[p] * sh, ob = (size_t)np.rs[p] * chh;
+    uint8_t *d_in = t_scr.get(0, ib), *d_out = t_scr.get(3, ob);
+    // the canvas keeps zeroed row padding (calloc on the host side); upload it so the kernel's untouched bytes stay zero
+    ok = d_in && d_out && up(d_in, l.pd[p], ib) && up(d_out, np.pd[p], ob) &&
+         lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, nullptr) == LGPU_OK && down(np.pd[p], d_out, ob) && sync();
+  }
+  if (!ok) { pfree(np.pd[0]); return 0; }
+  free_planes(l);
+  commit_planes(layer, l.pal, nwidth, nheight, np);
+  return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""The weed_layer_t seam (include/lives_gpu_layer.h) on genuine weed plants (reference libweed as the host).
+
+Mirrors how LiVES calls these functions (src/nodemodel.c:1065-1253) on the BASELINE configs:
+  C1  640x480 RGB24 -> convert_layer_palette(BGRA32)
+  C2  YUV420P -> convert_layer_palette(RGBA32) + gamma_convert_layer(SRGB)
+  C3  RGBA32 -> resize_layer (bicubic 0.5x) -> letterbox_layer -> (plugin blend is covered in test_plugin_seam.py)
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.util import align, frame
+
+needs_ref = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref (reference libweed) not built")
+P = po.P
+RGB24, BGR24, RGBA32, BGRA32, ARGB32, YUV420P, YVU420P, YUV888 = 1, 2, 3, 4, 5, 512, 513, 588
+
+
+@pytest.fixture(scope="module")
+def seam():
+    from lives_amd import lib
+    from tests import weedhost
+    L = lib.load()
+    weedhost.bind(L)
+    return L, weedhost
+
+
+@needs_ref
+def test_host_side_functions_without_gpu(seam):
+    L, wh = seam
+    n = ctypes.c_int()
+    rs = L.lives_gpu_calc_rowstrides(640, RGB24, None, ctypes.byref(n))
+    assert n.value == 1 and rs[0] == 1920
+    rs = L.lives_gpu_calc_rowstrides(1918, YUV420P, None, ctypes.byref(n))
+    assert n.value == 3 and [rs[0], rs[1], rs[2]] == [1920, 960, 960]
+    # create_empty_pixel_data: black fill rules of src/colourspace.c:11448-11460
+    lay = wh.new_layer(RGBA32, 10, 4, [np.full((4, 64), 7, np.uint8)])
+    assert L.lives_gpu_create_empty_pixel_data(lay, 1, 1) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert rs == [64] and (planes[0][:, :40].reshape(4, 10, 4) == [0, 0, 0, 255]).all()
+    lay = wh.new_layer(YUV420P, 11, 5, [np.zeros((5, 32), np.uint8), np.zeros((2, 16), np.uint8), np.zeros((2, 16), np.uint8)], clamping=0)
+    assert L.lives_gpu_create_empty_pixel_data(lay, 1, 1) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert wh.geti(lay, "width") == 10 and wh.geti(lay, "height") == 4 and rs == [32, 16, 16]
+    assert (planes[0] == 16).all() and (planes[1] == 128).all() and (planes[2] == 128).all()
+
+
+@needs_ref
+def test_failure_leaves_layer_untouched(seam):
+    L, wh = seam
+    src = np.arange(4 * 64, dtype=np.uint8).reshape(4, 64)
+    lay = wh.new_layer(RGBA32, 10, 4, [src], gamma=1)
+    before, ptrs, _ = wh.planes_of(lay)
+    assert L.lives_gpu_convert_layer_palette(lay, YUV888, 0) == 0          # RGB -> YUV is not on the GPU path
+    after, ptrs2, _ = wh.planes_of(lay)
+    assert ptrs == ptrs2 and (before[0] == after[0]).all() and wh.geti(lay, "current_palette") == RGBA32
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_c1_rgb24_to_bgra32(seam, orc):
+    L, wh = seam
+    rng = np.random.default_rng(1)
+    w, h = 640, 480
+    src = frame(rng, w, h, 3)
+    lay = wh.new_layer(RGB24, w, h, [src], gamma=1)
+    assert L.lives_gpu_convert_layer_palette(lay, BGRA32, 0) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert (wh.geti(lay, "current_palette"), wh.geti(lay, "width"), wh.geti(lay, "height"), rs) == (BGRA32, w, h, [2560])
+    want = np.zeros((h, 2560), np.uint8)
+    orc.orc_swizzle(po.OPS.index("swap3addpost"), 0, P(src), src.strides[0], P(want), 2560, w, h, None)
+    assert (planes[0] == want).all()
+    assert wh.geti(lay, "gamma_type") == 1 and wh.geti(lay, "host_flags") == 1      # alpha added -> premult flag (:12298-12301)
+    # and every other RGB <-> RGB pair, against the oracle op the selector tree picks
+    names = {(RGB24, BGR24): "swap3", (RGB24, RGBA32): "addpost", (BGR24, RGBA32): "swap3addpost", (RGB24, ARGB32): "addpre",
+             (BGR24, ARGB32): "swap3addpre", (RGBA32, RGB24): "delpost", (RGBA32, BGR24): "swap3delpost", (RGBA32, BGRA32): "swap3postalpha",
+             (ARGB32, RGB24): "delpre", (ARGB32, BGR24): "swap3delpre", (RGBA32, ARGB32): "swapprepost", (ARGB32, RGBA32): "swapprepost",
+             (BGRA32, ARGB32): "swap4", (ARGB32, BGRA32): "swap4"}
+    psz = {RGB24: 3, BGR24: 3, RGBA32: 4, BGRA32: 4, ARGB32: 4}
+    for (ip, op_), name in names.items():
+        s = frame(rng, 66, 34, psz[ip])
+        lay = wh.new_layer(ip, 66, 34, [s])
+        assert L.lives_gpu_convert_layer_palette(lay, op_, 0) == 1, name
+        planes, _, rs = wh.planes_of(lay)
+        want = np.zeros((34, align(66 * psz[op_])), np.uint8)
+        orc.orc_swizzle(po.OPS.index(name), int(ip == ARGB32), P(s), s.strides[0], P(want), want.strides[0], 66, 34, None)
+        assert rs == [want.strides[0]] and (planes[0][:, :66 * psz[op_]] == want[:, :66 * psz[op_]]).all(), name
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(128, 72), (1920, 1080)])
+def test_c2_yuv420p_to_rgba_then_gamma(seam, orc, size):
+    L, wh = seam
+    rng = np.random.default_rng(2)
+    w, h = size
+    ys, cs = align(w), align(w) >> 1
+    Y = rng.integers(16, 236, (h, ys), dtype=np.uint8)
+    U = rng.integers(16, 241, (h // 2, cs), dtype=np.uint8)
+    V = rng.integers(16, 241, (h // 2, cs), dtype=np.uint8)
+    lay = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)       # linear gamma, clamped YCbCr
+    assert L.lives_gpu_convert_layer_palette(lay, RGBA32, 0) == 1
+    assert wh.geti(lay, "current_palette") == RGBA32 and wh.geti(lay, "YUV_clamping") is None
+    assert L.lives_gpu_gamma_convert_layer(1, lay) == 1                                   # -> WEED_GAMMA_SRGB
+    assert wh.geti(lay, "gamma_type") == 1
+    planes, _, rs = wh.planes_of(lay)
+    orow = align(w * 4)
+    want = np.zeros((h, orow), np.uint8)
+    strides = (ctypes.c_int * 3)(ys, cs, cs)
+    orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, 0, 0, 0, 2, None, 0)
+    lut = np.zeros(256, np.uint8)
+    assert orc.orc_gamma_lut8(1.0, -1, 1, 1.4, P(lut)) == 1
+    orc.orc_gamma_apply(P(want), orow, w, h, 4, 0, P(lut))
+    assert rs == [orow] and (planes[0][:, :w * 4] == want[:, :w * 4]).all()
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_c3_resize_then_letterbox(seam, orc):
+    L, wh = seam
+    rng = np.random.default_rng(3)
+    sw, sh, dw, dh, nw, nh = 384, 216, 192, 108, 192, 120
+    src = frame(rng, sw, sh, 4)
+    lay = wh.new_layer(RGBA32, sw, sh, [src])
+    assert L.lives_gpu_letterbox_layer(lay, nw, nh, dw, dh, 3, 0, 0) == 1          # LIVES_INTERP_BEST
+    planes, _, rs = wh.planes_of(lay)
+    assert (wh.geti(lay, "width"), wh.geti(lay, "height")) == (nw, nh)
+    rs_want = np.zeros((dh, dw * 4), np.uint8)
+    assert orc.orc_resize(P(src), src.strides[0], sw, sh, P(rs_want), dw * 4, dw, dh, 4, 3) == 0
+    want = np.zeros((nh, rs[0]), np.uint8)
+    orc.orc_letterbox(P(rs_want), dw * 4, dw, dh, P(want), rs[0], nw, nh, 4, P(np.array([0, 0, 0, 255], np.uint8)))
+    assert (planes[0] == want).all()
+    # planar: YUV420P resize keeps the plane geometry rules
+    Y = rng.integers(0, 256, (64, 128), dtype=np.uint8)
+    U = rng.integers(0, 256, (32, 64), dtype=np.uint8)
+    V = rng.integers(0, 256, (32, 64), dtype=np.uint8)
+    lay = wh.new_layer(YUV420P, 128, 64, [Y, U, V], clamping=0)
+    assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert rs == [64, 32, 32] and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (64, 32)
+    for pl, s, (pw, ph, qw, qh) in zip(planes, (Y, U, V), ((128, 64, 64, 32), (64, 32, 32, 16), (64, 32, 32, 16))):
+        want = np.zeros((qh, pl.shape[1]), np.uint8)
+        assert orc.orc_resize(P(s), s.strides[0], pw, ph, P(want), want.strides[0], qw, qh, 1, 3) == 0
+        assert (pl[:, :qw] == want[:, :qw]).all()
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_alpha_premult_layer(seam, orc):
+    L, wh = seam
+    rng = np.random.default_rng(4)
+    s = frame(rng, 66, 34, 4)
+    for direction, un in ((1, 0), (-1, 1)):
+        lay = wh.new_layer(RGBA32, 66, 34, [s], flags=0 if un == 0 else 1)
+        L.lives_gpu_alpha_premult(lay, direction)
+        planes, _, _ = wh.planes_of(lay)
+        want = s.copy()
+        orc.orc_alpha_premult(P(want), want.strides[0], 66, 34, 0, un)
+        assert (planes[0][:, :66 * 4] == want[:, :66 * 4]).all()
+        assert wh.geti(lay, "host_flags") == (1 if direction == 1 else 0)
