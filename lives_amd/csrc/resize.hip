@@ -59,6 +59,17 @@ __device__ __forceinline__ uint32_t mix4b(uint32_t a, uint32_t b, uint32_t bf, u
 }
 __device__ __forceinline__ int clamp_i16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
 
+// (bf * s2_c + nbf * s1_c) >> 8 for the three colour bytes with v_dot4_u32_u8: interleave the two pixels' bytes so one
+// dot4 against (bf, nbf, 0, 0) / (0, 0, bf, nbf) yields one channel; returns [r0 r1 r2 0]
+__device__ __forceinline__ uint32_t mix3_dot4(uint32_t s1, uint32_t s2, uint32_t w_lo, uint32_t w_hi) {
+  const uint32_t x01 = __builtin_amdgcn_perm(s1, s2, 0x05010400u);     // [s2.b0 s1.b0 s2.b1 s1.b1]
+  const uint32_t x2 = __builtin_amdgcn_perm(s1, s2, 0x0C0C0602u);      // [s2.b2 s1.b2 0 0]
+  const uint32_t r0 = __builtin_amdgcn_udot4(x01, w_lo, 0u, false), r1 = __builtin_amdgcn_udot4(x01, w_hi, 0u, false);
+  const uint32_t r2 = __builtin_amdgcn_udot4(x2, w_lo, 0u, false);
+  // each r < 2^16; wanted byte = bits 8..15
+  return __builtin_amdgcn_perm(r1, r0, 0x0C0C0501u) | ((r2 << 8) & 0x00FF0000u);
+}
+
 // chroma blend of one RGBA pixel pair, dst alpha = track alpha (simple_blend.c:128-146, host-inplace channel)
 __device__ __forceinline__ uint32_t chroma_rgba(uint32_t p1, uint32_t p2, uint32_t bf, uint32_t nbf) {
   const uint32_t al = p2 >> 24;
@@ -260,17 +271,16 @@ struct H8 {
   static constexpr int kMBlocks = (kRows + 15) / 16;   // 16-row MFMA blocks (rows past kRows are computed and dropped)
   static constexpr int kJobsPerWave = kMBlocks;        // kMBlocks x 4 column blocks over 4 waves
   static constexpr int kRowsPerWave = TH / 4;          // vertical pass: consecutive output rows per wave
-  static constexpr int kPlaneBytes = kRows * 160;
-  static constexpr int kSrcBytes = 4 * kPlaneBytes;
+  static constexpr int kSrcBytes = kRows * 544;        // packed RGBA window, row pitch 544 B
   static constexpr int kHBytes = kPairs * kTileW * 16;
   static constexpr int kItems = kRows * 34;
   static constexpr int kFull = kItems / kBlock;
   static constexpr int kTail = kItems - kFull * kBlock;
   // planes + row-pair buffer + alpha tables + lut + slack for the fragment over-read of the padded row block
-  static constexpr size_t kLds = kSrcBytes + kHBytes + 2048 + 256 + ((kMBlocks * 16 - kRows) * 160 > kHBytes ? (kMBlocks * 16 - kRows) * 160 - kHBytes : 0) + 256;
+  static constexpr size_t kLds = kSrcBytes + kHBytes + 256 + ((kMBlocks * 16 - kRows) * 544 > kHBytes ? (kMBlocks * 16 - kRows) * 544 - kHBytes : 0) + 256;
 };
-constexpr int kH8Pitch = 160;                   // plane row pitch in bytes: conflict-free for the lane groups ds_read_b128 really uses
-                                                //   ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) and wide enough for column block 3 (bytes 96..159)
+constexpr int kH8Pitch = 544;                   // window row pitch in bytes (136 px; 136 dwords = 8 mod 16): conflict-free for the lane
+                                                //   groups ds_read_b128 really uses ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
 constexpr int kH8Chunks = 34;                   // 16-byte column chunks per window row (134 px -> 33.5)
 
 struct Half8Args {
@@ -327,25 +337,17 @@ __device__ __forceinline__ void h8_issue_loads(const Half8Args &a, const uint8_t
 }
 
 template <int TH>
-__device__ __forceinline__ void h8_write_planes(const Half8Args &a, uint8_t *s_pl, int tid, int wave, const H8Stage &st) {
+__device__ __forceinline__ void h8_write_window(uint8_t *s_px, int tid, int wave, const H8Stage &st) {
+  // pixels stay packed (RGBA interleaved); bytes are biased by -128 so the matrix cores see int8
   constexpr int kItems = H8<TH>::kItems;
   constexpr int kFull = H8<TH>::kFull;
-  const int p0 = a.swap_rb ? 2 : 0, p2 = a.swap_rb ? 0 : 2;  // BGRA sources: byte 0 feeds plane 2 and vice versa
   int r = tid / kH8Chunks, ch = tid - r * kH8Chunks;
 #pragma unroll
   for (int k = 0; k <= kFull; k++) {
     if (k < kFull || wave * 64 < kItems - kFull * kBlock) {
       if (k < kFull || tid < kItems - kFull * kBlock) {
         const u32x4_a4 v = st.v[k];
-        const uint32_t x0 = __builtin_amdgcn_perm(v.y, v.x, 0x05010400u), x1 = __builtin_amdgcn_perm(v.y, v.x, 0x07030602u);
-        const uint32_t x2 = __builtin_amdgcn_perm(v.w, v.z, 0x05010400u), x3 = __builtin_amdgcn_perm(v.w, v.z, 0x07030602u);
-        const uint32_t c0 = __builtin_amdgcn_perm(x2, x0, 0x05040100u) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(x2, x0, 0x07060302u) ^ 0x80808080u;
-        const uint32_t c2 = __builtin_amdgcn_perm(x3, x1, 0x05040100u) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(x3, x1, 0x07060302u) ^ 0x80808080u;
-        uint8_t *d = s_pl + r * kH8Pitch + ch * 4;
-        *reinterpret_cast<uint32_t *>(d + p0 * H8<TH>::kPlaneBytes) = c0;
-        *reinterpret_cast<uint32_t *>(d + 1 * H8<TH>::kPlaneBytes) = c1;
-        *reinterpret_cast<uint32_t *>(d + p2 * H8<TH>::kPlaneBytes) = c2;
-        *reinterpret_cast<uint32_t *>(d + 3 * H8<TH>::kPlaneBytes) = c3;
+        *reinterpret_cast<uint4 *>(s_px + r * kH8Pitch + ch * 16) = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
       }
     }
     r += 7; ch += 18;
@@ -360,16 +362,14 @@ template <int TH, int ABL>
 __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lut8 lut) {
   using C = H8<TH>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t *s_pl = smem;                                                   // [4][38][160] int8 planes
+  uint8_t *s_pl = smem;                                                   // [38][136] packed pixels, int8
   uint8_t *s_h = smem + C::kSrcBytes;                                      // [19][64][4] dwords of 2 x int16
-  float *s_alpha = reinterpret_cast<float *>(smem + C::kSrcBytes + C::kHBytes);   // [2][256]
-  uint8_t *s_lut = smem + C::kSrcBytes + C::kHBytes + 2048;                 // [256]
+  uint8_t *s_lut = smem + C::kSrcBytes + C::kHBytes;                        // [256]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
 
   if (a.use_lut) stage_lut(s_lut, lut);
-  if (a.blend) { s_alpha[tid] = a.alpha_tab[tid]; s_alpha[256 + tid] = a.alpha_tab[256 + tid]; }
   uint32_t bf = a.bf, nbf = a.nbf;
   if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
 
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
     const int tw = min(kTileW, a.dw - tx0), thh = min(C::kTileH, a.dh - ty0);
 
     // ---- 1. transpose the staged window to int8 channel planes in LDS ----
-    if (!(ABL & 8)) h8_write_planes<TH>(a, s_pl, tid, wave, st);
+    if (!(ABL & 8)) h8_write_window<TH>(s_pl, tid, wave, st);
     __syncthreads();
 
     // next work item's window: issue its loads now, they complete while this tile computes
@@ -423,75 +423,92 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
     }
 
     // ---- 2. horizontal pass on the matrix cores ----
-    // kMBlocks row blocks (rows past the window unused) x 4 column blocks = (mb, nb) jobs, kMBlocks per wave
+    // A = 16 window rows x 64 bytes (16 packed pixels), B[k = (pixel, channel)][n = (column, channel)] = tap[pixel - 2 * column]
+    // on matching channels: one (mb, nb) job yields 4 output columns x 4 channels for 16 rows.  kMBlocks row blocks
+    // (rows past the window are computed and dropped) x 16 column blocks; wave w owns column blocks 4w .. 4w+3.
     if (!(ABL & 4)) {
       const int m = lane & 15, g = lane >> 4;
 #pragma unroll
-      for (int j = 0; j < C::kJobsPerWave; j++) {
-        const int job = wave * C::kJobsPerWave + j, mb = job >> 2, nb = job & 3;
-        const uint8_t *abase = s_pl + (mb * 16 + m) * kH8Pitch + nb * 32 + g * 16;
-        uint32_t pk0[4], pk1[4];
+      for (int mb = 0; mb < C::kMBlocks; mb++) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int4v av = *reinterpret_cast<const int4v *>(abase + c * C::kPlaneBytes);
+        for (int q = 0; q < 4; q++) {
+          const int nb = wave * 4 + q;
+          const int4v av = *reinterpret_cast<const int4v *>(s_pl + (mb * 16 + m) * kH8Pitch + nb * 32 + g * 16);
           int4v zero = {0, 0, 0, 0};
           const int4v dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_hi, zero, 0, 0, 0);
           const int4v dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_lo, cbias, 0, 0, 0);
           const int t0 = ((dh[0] << 6) + dl[0]) >> 7, t1 = ((dh[1] << 6) + dl[1]) >> 7;
           const int t2 = ((dh[2] << 6) + dl[2]) >> 7, t3 = ((dh[3] << 6) + dl[3]) >> 7;
           const short2v q0 = __builtin_amdgcn_cvt_pk_i16(t0, t1), q1 = __builtin_amdgcn_cvt_pk_i16(t2, t3);   // saturating
-          pk0[c] = __builtin_bit_cast(uint32_t, q0);
-          pk1[c] = __builtin_bit_cast(uint32_t, q1);
+          // lane holds window rows mb*16 + 4g + {0..3} = row pairs mb*8 + 2g + {0,1} of (column nb*4 + (m >> 2), channel m & 3)
+          const int pr = mb * 8 + 2 * g;
+          uint32_t *hp = reinterpret_cast<uint32_t *>(s_h) + (pr * kTileW + nb * 4) * 4 + m;
+          if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
+          if (pr + 1 < C::kPairs) hp[kTileW * 4] = __builtin_bit_cast(uint32_t, q1);
         }
-        // lane holds window rows mb*16 + 4g + {0..3} = row pairs mb*8 + 2g + {0,1}, output column nb*16 + m
-        const int pr = mb * 8 + 2 * g, xcol = nb * 16 + m;
-        if (pr < C::kPairs) *reinterpret_cast<uint4 *>(s_h + ((pr)*kTileW + xcol) * 16) = make_uint4(pk0[0], pk0[1], pk0[2], pk0[3]);
-        if (pr + 1 < C::kPairs) *reinterpret_cast<uint4 *>(s_h + ((pr + 1) * kTileW + xcol) * 16) = make_uint4(pk1[0], pk1[1], pk1[2], pk1[3]);
       }
     }
     __syncthreads();
 
     // ---- 3. vertical pass (lane = column, wave = RPW consecutive output rows) + epilogue ----
+    // Straight-line over the wave's RPW rows: all row-pair reads first, then all dots, then the blend, then all LUT
+    // reads, then the stores -- so LDS / VMEM latencies overlap instead of being paid once per row.
     {
       uint8_t *dst = trk.dst[track];
       const uint4 *col = reinterpret_cast<const uint4 *>(s_h) + lane;
-      uint4 w0 = col[(ly0 + 0) * kTileW], w1 = col[(ly0 + 1) * kTileW], w2 = col[(ly0 + 2) * kTileW];
+      uint4 w[RPW + 3];
+#pragma unroll
+      for (int i = 0; i < RPW + 3; i++) w[i] = col[(ly0 + i) * kTileW];
+      uint32_t px[RPW];
 #pragma unroll
       for (int i = 0; i < RPW; i++) {
-        const int ly = ly0 + i;
-        const uint4 w3 = col[(ly + 3) * kTileW];
-        if (ly < thh && lane < tw) {
-          const int vr = 1 << 20;
-          int a0 = vr, a1 = vr, a2 = vr, a3 = vr;
-#define H8_DOT(acc, fld)                                                                  \
-          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w0.fld), vc0, acc, false); \
-          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w1.fld), vc1, acc, false); \
-          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w2.fld), vc2, acc, false); \
-          acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w3.fld), vc3, acc, false);
-          if (!(ABL & 2)) { H8_DOT(a0, x) H8_DOT(a1, y) H8_DOT(a2, z) H8_DOT(a3, w) } else { a0 = w0.x; a1 = w1.y; a2 = w2.z; a3 = w3.w; }
+        const int vr = 1 << 20;
+        int a0 = vr, a1 = vr, a2 = vr, a3 = vr;
+#define H8_DOT(acc, fld)                                                                        \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i].fld), vc0, acc, false);     \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 1].fld), vc1, acc, false); \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 2].fld), vc2, acc, false); \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 3].fld), vc3, acc, false);
+        if (!(ABL & 2)) { H8_DOT(a0, x) H8_DOT(a1, y) H8_DOT(a2, z) H8_DOT(a3, w) } else { a0 = w[i].x; a1 = w[i + 1].y; a2 = w[i + 2].z; a3 = w[i + 3].w; }
 #undef H8_DOT
-          uint32_t p = (uint32_t)clamp255(a0 >> 21) | ((uint32_t)clamp255(a1 >> 21) << 8) | ((uint32_t)clamp255(a2 >> 21) << 16) |
-                       ((uint32_t)clamp255(a3 >> 21) << 24);
-          if (a.blend && !(ABL & 1)) {
-            const uint32_t q = q2[i], al = q >> 24;
-            uint32_t s1 = p, s2 = q;
-            if (!__all(al == 255)) {       // wave-uniform: skip the translucent arithmetic when every layer-2 pixel is opaque
-              // (uint8_t)((float)c * alpha) with alpha = (float)a / 255., inv_alpha = 1. - alpha  (simple_blend.c:137-146)
-              const float alpha = s_alpha[al], inv = s_alpha[256 + al];
-              const uint32_t f2 = (uint32_t)__fmul_rn((float)((q >> 0) & 0xFF), alpha) | ((uint32_t)__fmul_rn((float)((q >> 8) & 0xFF), alpha) << 8) |
-                                  ((uint32_t)__fmul_rn((float)((q >> 16) & 0xFF), alpha) << 16);
-              const uint32_t f1 = (uint32_t)__fmul_rn((float)((p >> 0) & 0xFF), inv) | ((uint32_t)__fmul_rn((float)((p >> 8) & 0xFF), inv) << 8) |
-                                  ((uint32_t)__fmul_rn((float)((p >> 16) & 0xFF), inv) << 16);
-              s2 = (al == 255) ? q : f2;
-              s1 = (al == 255) ? p : f1;
-            }
-            p = (mix4b(s1, s2, bf, nbf) & 0x00FFFFFFu) | (p & 0xFF000000u);
-          }
-          if (a.use_lut && !(ABL & 1)) p = lut3_rgba(s_lut, p);
-          reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + ly) * a.orow)[tx0 + lane] = p;
-        }
-        w0 = w1; w1 = w2; w2 = w3;
+        px[i] = (uint32_t)clamp255(a0 >> 21) | ((uint32_t)clamp255(a1 >> 21) << 8) | ((uint32_t)clamp255(a2 >> 21) << 16) |
+                ((uint32_t)clamp255(a3 >> 21) << 24);
       }
+      if (a.blend && !(ABL & 1)) {
+        const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+        bool opaque = true;
+#pragma unroll
+        for (int i = 0; i < RPW; i++) opaque = opaque && ((q2[i] >> 24) == 255);
+        if (__all(opaque)) {        // wave-uniform: no translucent layer-2 pixel in this wave's rows
+#pragma unroll
+          for (int i = 0; i < RPW; i++) px[i] = mix3_dot4(px[i], q2[i], w_lo, w_hi) | (px[i] & 0xFF000000u);
+        } else {
+          // (uint8_t)((float)c * alpha) with alpha = (float)a / 255., inv_alpha = 1. - alpha  (simple_blend.c:137-146)
+          float alpha[RPW], inv[RPW];
+#pragma unroll
+          for (int i = 0; i < RPW; i++) { const uint32_t al = q2[i] >> 24; alpha[i] = a.alpha_tab[al]; inv[i] = a.alpha_tab[256 + al]; }
+#pragma unroll
+          for (int i = 0; i < RPW; i++) {
+            const uint32_t q = q2[i], p = px[i];
+            const uint32_t f2 = (uint32_t)__fmul_rn((float)((q >> 0) & 0xFF), alpha[i]) | ((uint32_t)__fmul_rn((float)((q >> 8) & 0xFF), alpha[i]) << 8) |
+                                ((uint32_t)__fmul_rn((float)((q >> 16) & 0xFF), alpha[i]) << 16);
+            const uint32_t f1 = (uint32_t)__fmul_rn((float)((p >> 0) & 0xFF), inv[i]) | ((uint32_t)__fmul_rn((float)((p >> 8) & 0xFF), inv[i]) << 8) |
+                                ((uint32_t)__fmul_rn((float)((p >> 16) & 0xFF), inv[i]) << 16);
+            const bool op = (q >> 24) == 255;
+            px[i] = mix3_dot4(op ? p : f1, op ? q : f2, w_lo, w_hi) | (p & 0xFF000000u);
+          }
+        }
+      }
+      if (a.use_lut && !(ABL & 1)) {
+        uint32_t r[RPW], g[RPW], b[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; i++) { r[i] = s_lut[px[i] & 0xFF]; g[i] = s_lut[(px[i] >> 8) & 0xFF]; b[i] = s_lut[(px[i] >> 16) & 0xFF]; }
+#pragma unroll
+        for (int i = 0; i < RPW; i++) px[i] = r[i] | (g[i] << 8) | (b[i] << 16) | (px[i] & 0xFF000000u);
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; i++)
+        if (ly0 + i < thh && lane < tw) reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + ly0 + i) * a.orow)[tx0 + lane] = px[i];
     }
     // no barrier here: the next iteration writes only the planes (last read before the barrier above);
     // s_h is rewritten after the next iteration's first barrier, which every wave reaches only after this pass
@@ -615,23 +632,30 @@ struct Half8Const {
   float *alpha = nullptr;     // device [2][256]
 };
 static std::mutex g_h8_mu;
-static std::map<std::pair<int, std::vector<int16_t>>, Half8Const> g_h8;   // (device, 8 taps)
+static std::map<std::pair<int, std::vector<int16_t>>, Half8Const> g_h8;   // (device, 8 taps + swap flag)
 
-static int get_half8_const(const int16_t taps[8], const Half8Const **out) {
+static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const **out) {
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_h8_mu);
-  auto key = std::make_pair(dev, std::vector<int16_t>(taps, taps + 8));
+  std::vector<int16_t> kv(taps, taps + 8);
+  kv.push_back((int16_t)swap_rb);
+  auto key = std::make_pair(dev, kv);
   auto it = g_h8.find(key);
   if (it == g_h8.end()) {
     Half8Const c;
     // B fragment of v_mfma_i32_16x16x64_i8: lane l supplies B[k = 16 * (l >> 4) + e][n = l & 15], e = 0..15
-    // (A uses the same k numbering; C/D: row = 4 * (l >> 4) + reg, col = l & 15 -- tools/mfma_probe.hip)
+    // (A uses the same k numbering; C/D: row = 4 * (l >> 4) + reg, col = l & 15 -- tools/mfma_probe.hip).
+    // k = (window pixel 0..15, source byte 0..3), n = (output column 0..3, output channel 0..3):
+    // B = tap[pixel - 2 * column] where the source byte feeds that output channel (bytes 0 / 2 trade places for BGRA sources)
     int8_t frag[2][64][16];
     for (int l = 0; l < 64; l++)
       for (int e = 0; e < 16; e++) {
-        const int k = 16 * (l >> 4) + e, n = l & 15, j = k - 2 * n;
-        const int tap = (j >= 0 && j < 8) ? taps[j] : 0;
+        const int k = 16 * (l >> 4) + e, n = l & 15;
+        const int px = k >> 2, sbyte = k & 3, col = n >> 2, och = n & 3;
+        const int want = swap_rb ? (och == 0 ? 2 : och == 2 ? 0 : och) : och;
+        const int j = px - 2 * col;
+        const int tap = (sbyte == want && j >= 0 && j < 8) ? taps[j] : 0;
         frag[0][l][e] = (int8_t)(tap >> 6);        // tap = 64 * hi + lo, lo in [0, 63]
         frag[1][l][e] = (int8_t)(tap & 63);
       }
@@ -658,7 +682,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   if (disabled || !hb->uniform2 || !vb->uniform2) return LGPU_E_UNSUPPORTED;
   if ((irow & 3) || (orow & 3)) return LGPU_E_UNSUPPORTED;
   const Half8Const *hc;
-  int rc = get_half8_const(hb->hco.data(), &hc);
+  int rc = get_half8_const(hb->hco.data(), swap_rb, &hc);
   if (rc) return rc;
   Half8Args a;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
