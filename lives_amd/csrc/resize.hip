@@ -57,6 +57,17 @@ __device__ __forceinline__ uint32_t mix_pairs2(uint32_t a, uint32_t b, uint32_t 
 __device__ __forceinline__ uint32_t mix4b(uint32_t a, uint32_t b, uint32_t bf, uint32_t nbf) {
   return mix_pairs2(a & 0x00FF00FFu, b & 0x00FF00FFu, bf, nbf) | (mix_pairs2((a >> 8) & 0x00FF00FFu, (b >> 8) & 0x00FF00FFu, bf, nbf) << 8);
 }
+typedef short short2v __attribute__((ext_vector_type(2)));
+// clamp_u8(v >> 21) of four accumulators packed into one pixel: high halves (>> 16) paired by a byte permute, packed
+// arithmetic >> 5, v_sat_pk_u8_i16 (signed 16 -> unsigned 8 saturation of both halves), one permute to join
+__device__ __forceinline__ uint32_t pack_sat_shr21(int a0, int a1, int a2, int a3) {
+  const short2v h01 = __builtin_bit_cast(short2v, __builtin_amdgcn_perm((uint32_t)a1, (uint32_t)a0, 0x07060302u)) >> 5;
+  const short2v h23 = __builtin_bit_cast(short2v, __builtin_amdgcn_perm((uint32_t)a3, (uint32_t)a2, 0x07060302u)) >> 5;
+  uint32_t b01, b23;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(h01));
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(h23));
+  return __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+}
 __device__ __forceinline__ int clamp_i16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
 
 // (bf * s2_c + nbf * s1_c) >> 8 for the three colour bytes with v_dot4_u32_u8: interleave the two pixels' bytes so one
@@ -260,7 +271,6 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
 //     256-entry table instead of a double-precision divide per pixel.
 // =====================================================================================================================
 typedef int int4v __attribute__((ext_vector_type(4)));
-typedef short short2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
 
 template <int TH>
@@ -294,6 +304,7 @@ struct Half8Args {
   const int32_t *bf_d;
   int use_lut;
   int tiles_x, tiles_y, ntracks;
+  unsigned long long *dbg;          // ABL & 16 (profiling build): per-wave phase cycle sums [grid][4][8]
 };
 
 __device__ __forceinline__ uint32_t ld_px_clamped(const uint8_t *row, int x, int sw) {
@@ -374,9 +385,13 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
   if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
 
   const int4v b_hi = a.bfrag[lane], b_lo = a.bfrag[64 + lane];
-  // accumulator preset of the low-part product: un-bias the int8 pixels (the taps sum to 16384) + the rounding of >> 7
-  const int kb = 128 * 16384 + 64;
+  // The window holds px - 128 and the taps sum to 16384, so the matrix product is 128 * (t - 16384) for the spec's
+  // t = clamp_i16((h + 64) >> 7): the intermediate is kept as t' = t - 16384 (fits int16 without wrapping for the
+  // filters try_half8 admits), the clamp becomes min(t', 16383), and the vertical pass adds 16384 * sum(vc) = 2^28 back.
+  // The low-part taps are stored doubled so that t' sits in bits 8..23 of (dh << 7) + dl: a byte permute extracts it.
+  const int kb = 128;                                     // 2 * 64: the rounding of >> 7, doubled
   const int4v cbias = {kb, kb, kb, kb};
+  const short2v tmax = {16383, 16383};
   const short2v vc0 = __builtin_bit_cast(short2v, a.vc[0]), vc1 = __builtin_bit_cast(short2v, a.vc[1]);
   const short2v vc2 = __builtin_bit_cast(short2v, a.vc[2]), vc3 = __builtin_bit_cast(short2v, a.vc[3]);
 
@@ -386,20 +401,32 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
   const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3);
   const int chunk = (nwork + 7) >> 3;
   const int wend = min((xcd + 1) * chunk, nwork);
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define H8_T(i)                                                                                       \
+  if (ABL & 16) {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                     \
+    tacc[i] += now_ - tprev; tprev = now_;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
   H8Stage st;
   int work = xcd * chunk + (int)(blockIdx.x >> 3);
   if (work < wend) {
     const int track = work / tiles, tile = work - track * tiles;
     if (!(ABL & 8)) h8_issue_loads<TH>(a, trk.src[track], (tile % a.tiles_x) * kTileW, (tile / a.tiles_x) * C::kTileH, tid, wave, st);
   }
+  if (ABL & 16) tprev = __builtin_amdgcn_s_memtime();
   for (; work < wend; work += wstride) {
     const int track = work / tiles, tile = work - track * tiles;
     const int tx0 = (tile % a.tiles_x) * kTileW, ty0 = (tile / a.tiles_x) * C::kTileH;
     const int tw = min(kTileW, a.dw - tx0), thh = min(C::kTileH, a.dh - ty0);
 
     // ---- 1. transpose the staged window to int8 channel planes in LDS ----
+    H8_T(7)
     if (!(ABL & 8)) h8_write_window<TH>(s_pl, tid, wave, st);
+    H8_T(0)
     __syncthreads();
+    H8_T(1)
 
     // next work item's window: issue its loads now, they complete while this tile computes
     {
@@ -422,6 +449,7 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
       }
     }
 
+    H8_T(2)
     // ---- 2. horizontal pass on the matrix cores ----
     // A = 16 window rows x 64 bytes (16 packed pixels), B[k = (pixel, channel)][n = (column, channel)] = tap[pixel - 2 * column]
     // on matching channels: one (mb, nb) job yields 4 output columns x 4 channels for 16 rows.  kMBlocks row blocks
@@ -437,9 +465,10 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
           int4v zero = {0, 0, 0, 0};
           const int4v dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_hi, zero, 0, 0, 0);
           const int4v dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_lo, cbias, 0, 0, 0);
-          const int t0 = ((dh[0] << 6) + dl[0]) >> 7, t1 = ((dh[1] << 6) + dl[1]) >> 7;
-          const int t2 = ((dh[2] << 6) + dl[2]) >> 7, t3 = ((dh[3] << 6) + dl[3]) >> 7;
-          const short2v q0 = __builtin_amdgcn_cvt_pk_i16(t0, t1), q1 = __builtin_amdgcn_cvt_pk_i16(t2, t3);   // saturating
+          const uint32_t x0 = (uint32_t)((dh[0] << 7) + dl[0]), x1 = (uint32_t)((dh[1] << 7) + dl[1]);
+          const uint32_t x2 = (uint32_t)((dh[2] << 7) + dl[2]), x3 = (uint32_t)((dh[3] << 7) + dl[3]);
+          const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
+          const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
           // lane holds window rows mb*16 + 4g + {0..3} = row pairs mb*8 + 2g + {0,1} of (column nb*4 + (m >> 2), channel m & 3)
           const int pr = mb * 8 + 2 * g;
           uint32_t *hp = reinterpret_cast<uint32_t *>(s_h) + (pr * kTileW + nb * 4) * 4 + m;
@@ -448,7 +477,9 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
         }
       }
     }
+    H8_T(3)
     __syncthreads();
+    H8_T(4)
 
     // ---- 3. vertical pass (lane = column, wave = RPW consecutive output rows) + epilogue ----
     // Straight-line over the wave's RPW rows: all row-pair reads first, then all dots, then the blend, then all LUT
@@ -462,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
       uint32_t px[RPW];
 #pragma unroll
       for (int i = 0; i < RPW; i++) {
-        const int vr = 1 << 20;
+        const int vr = (1 << 20) + (1 << 28);     // rounding of >> 21 + the 16384 * 16384 of the t' = t - 16384 bias
         int a0 = vr, a1 = vr, a2 = vr, a3 = vr;
 #define H8_DOT(acc, fld)                                                                        \
         acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i].fld), vc0, acc, false);     \
@@ -471,9 +502,9 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
         acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 3].fld), vc3, acc, false);
         if (!(ABL & 2)) { H8_DOT(a0, x) H8_DOT(a1, y) H8_DOT(a2, z) H8_DOT(a3, w) } else { a0 = w[i].x; a1 = w[i + 1].y; a2 = w[i + 2].z; a3 = w[i + 3].w; }
 #undef H8_DOT
-        px[i] = (uint32_t)clamp255(a0 >> 21) | ((uint32_t)clamp255(a1 >> 21) << 8) | ((uint32_t)clamp255(a2 >> 21) << 16) |
-                ((uint32_t)clamp255(a3 >> 21) << 24);
+        px[i] = (ABL & 2) ? (uint32_t)(a0 ^ a1 ^ a2 ^ a3) : pack_sat_shr21(a0, a1, a2, a3);
       }
+      H8_T(5)
       if (a.blend && !(ABL & 1)) {
         const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
         bool opaque = true;
@@ -510,9 +541,404 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
       for (int i = 0; i < RPW; i++)
         if (ly0 + i < thh && lane < tw) reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + ly0 + i) * a.orow)[tx0 + lane] = px[i];
     }
+    H8_T(6)
     // no barrier here: the next iteration writes only the planes (last read before the barrier above);
     // s_h is rewritten after the next iteration's first barrier, which every wave reaches only after this pass
   }
+  if ((ABL & 16) && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tacc[i];
+  }
+#undef H8_T
+}
+
+// =====================================================================================================================
+// k_half8s: the k_half8 tile pipeline with a memory wave and LDS-DMA rings.
+// Phase timing of k_half8 (s_memtime, profiles/r01) showed its waves parked in-order on VMEM issue (window prefetch,
+// layer-2 loads, the table gather, the stores) for over half of each tile while their matrix / vector work waited
+// behind.  Here a workgroup is 4 compute waves + 1 memory wave, two workgroups per CU:
+//   memory wave : source windows by global_load_lds (no registers, no ds_write) into a 2-slot ring, issued a tile and
+//                 a half ahead; layer-2 tiles by global_load_lds into a 2-slot ring; finished tiles read back from
+//                 their ring slot and stored with 16-byte stores; edge-replicate fix-up of frame-border windows
+//   compute wave: LDS, MFMA and VALU only -- horizontal pass (pixels biased to int8 as the fragments are read),
+//                 vertical pass, blend (layer 2 from the ring slot), LUT, result into the same ring slot
+// Two workgroup barriers per tile (A(n): window n / layer-2 n landed and the row-pair buffer free, B(n): row pairs
+// complete and window slot n & 1 free), raw s_barrier so the memory wave's DMA stays in flight across them; it
+// waits with a counted vmcnt that leaves exactly the newest window outstanding.
+// =====================================================================================================================
+constexpr int kH8sThreads = 384;
+struct H8S {
+  static constexpr int kRows = 38, kPairs = 19, kMBlocks = 3, kRPW = 4, kTileH = 16;
+  static constexpr int kWinBytes = kRows * 544;        // 20672 = 20 x 1024 + 192: 21 DMA instructions, the last with 12 lanes
+  static constexpr int kRounds = 21, kTailLanes = 12;
+  static constexpr int kSplit = 11;                    // DMA instructions 0..10: memory wave 4, 11..20: memory wave 5
+  static constexpr int kOffH = 2 * kWinBytes;          // 41344
+  static constexpr int kOffQ = kOffH + kPairs * kTileW * 16;      // 60800: 2 x [16][64] pixels
+  static constexpr int kOffLut = kOffQ + 2 * 4096;     // 68992
+  static constexpr int kOffAlpha = kOffLut + 256;      // 69248: float[256]
+  static constexpr size_t kLds = kOffAlpha + 1024;     // 70272: two workgroups per CU
+};
+
+#define H8S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef const __attribute__((address_space(1))) void *h8s_gptr;
+typedef __attribute__((address_space(3))) void *h8s_lptr;
+
+// window chunk c = 64 k + lane (16 bytes, LDS offset 16 c: a row is exactly 34 chunks) <- source row sy0 + c / 34,
+// pixels sx0 + 4 (c % 34) ..+3; rows are clamped to the frame here, columns are fetched from the nearest in-frame
+// 4-pixel position and re-selected by h8s_fix_edges()
+struct H8sLaneOff { uint32_t v[H8S::kRounds]; };     // per-lane byte offset of chunk 64 k + lane inside an unclamped window
+__device__ __forceinline__ void h8s_lane_offsets(const Half8Args &a, int lane, H8sLaneOff &lo) {
+#pragma unroll
+  for (int k = 0; k < H8S::kRounds; k++) {
+    const int c = k * 64 + lane, r = (c * 241) >> 13, ch = c - r * kH8Chunks;
+    lo.v[k] = (uint32_t)r * (uint32_t)a.irow + (uint32_t)ch * 16u;
+  }
+}
+// frame-border windows (rare): rows clamped to the frame, columns fetched from the nearest in-frame 4-pixel position
+// (re-selected by h8s_fix_edges()).  Out of line and rolled: the common path must stay small in the instruction cache.
+__device__ __noinline__ void h8s_issue_window_border(int sw, int sh, int irow, const uint8_t *src, int sx0, int sy0, int lane, uint8_t *win,
+                                                     int k0, int k1) {
+  for (int k = k0; k < k1; k++) {
+    const int c = k * 64 + lane, r = (c * 241) >> 13, ch = c - r * kH8Chunks;     // c / 34 for c < 1344
+    int sy = sy0 + r;
+    sy = sy < 0 ? 0 : sy >= sh ? sh - 1 : sy;
+    int x = sx0 + ch * 4;
+    x = x < 0 ? 0 : x > sw - 4 ? sw - 4 : x;
+    const uint8_t *g = src + ((uint32_t)sy * (uint32_t)irow + (uint32_t)x * 4u);
+    if (c < H8S::kRows * kH8Chunks)
+      __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(win + k * 1024), 16, 0, 0);
+  }
+}
+template <int K0, int K1>
+__device__ __forceinline__ void h8s_issue_window(const Half8Args &a, const uint8_t *src, int tx0, int ty0, int lane, uint8_t *win,
+                                                 const H8sLaneOff &lo) {
+  const int sx0 = 2 * tx0 - 3, sy0 = 2 * ty0 - 3;
+  if (sx0 >= 0 && sx0 + 4 * kH8Chunks <= a.sw && sy0 >= 0 && sy0 + H8S::kRows <= a.sh) {
+    // window inside the frame (tile-uniform): scalar base + the precomputed lane offsets, no per-request address math
+    const uint8_t *base = src + ((uint32_t)sy0 * (uint32_t)a.irow + (uint32_t)sx0 * 4u);
+#pragma unroll
+    for (int k = K0; k < K1; k++)
+      if (k < H8S::kRounds - 1 || lane < H8S::kTailLanes)
+        __builtin_amdgcn_global_load_lds((h8s_gptr)(base + lo.v[k]), (h8s_lptr)(win + k * 1024), 16, 0, 0);
+  } else h8s_issue_window_border(a.sw, a.sh, a.irow, src, sx0, sy0, lane, win, K0, K1);
+}
+__device__ __forceinline__ uint32_t h8s_pick(const uint4 &v, int j) { return j <= 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+// frame-border windows only (tile-uniform test by the caller): re-select the pixels of the chunks that were fetched
+// from a clamped position, i.e. edge replicate.  Only the chunks that can be affected are visited (the first chunk of
+// a row at the left frame edge, the last few at the right edge), one per lane; each memory wave fixes the chunks it
+// fetched itself (c0 <= c < c1).  The LDS accesses are asm so that the compiler does not drain the DMA queue in front
+// of them: the caller's counted vmcnt has already covered this window, newer requests go to the other slot.
+__device__ __noinline__ void h8s_fix_edges(uint8_t *win, int tx0, int sw, int lane, int c0, int c1) {
+  const int sx0 = 2 * tx0 - 3;
+  const int nlo = sx0 < 0 ? (-sx0 + 3) >> 2 : 0;                               // chunks starting left of the frame
+  int chh = sw - 4 - sx0 < 0 ? 0 : ((sw - 4 - sx0) >> 2) + 1;                  // first chunk reaching past the right edge
+  if (chh < nlo) chh = nlo;
+  const int nhi = chh < kH8Chunks ? kH8Chunks - chh : 0, na = nlo + nhi;
+  for (int idx = lane; idx < H8S::kRows * na; idx += 64) {
+    const int r = idx / na, j = idx - r * na, ch = j < nlo ? j : chh + (j - nlo), c = r * kH8Chunks + ch;
+    if (c >= c0 && c < c1) {
+      const int x = sx0 + ch * 4, xl = x < 0 ? 0 : x > sw - 4 ? sw - 4 : x;
+      const uint32_t addr = (uint32_t)(uintptr_t)(h8s_lptr)(win + c * 16);
+      typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+      u32x4v fv;
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fv) : "v"(addr) : "memory");
+      const uint4 f = make_uint4(fv.x, fv.y, fv.z, fv.w);
+      const int lim = sw - 1 - xl;
+      int j0 = x - xl, j1 = j0 + 1, j2 = j0 + 2, j3 = j0 + 3;
+      j0 = j0 > lim ? lim : j0; j1 = j1 > lim ? lim : j1; j2 = j2 > lim ? lim : j2; j3 = j3 > lim ? lim : j3;
+      const u32x4v o = {h8s_pick(f, j0), h8s_pick(f, j1), h8s_pick(f, j2), h8s_pick(f, j3)};
+      asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(o) : "memory");
+    }
+  }
+}
+__device__ __forceinline__ bool h8s_border(int tx0, int sw) { const int sx0 = 2 * tx0 - 3; return sx0 < 0 || sx0 + 4 * kH8Chunks > sw; }
+
+__device__ __noinline__ void h8s_issue_q2_partial(const uint8_t *l2, int irow2, int dw, int dh, int tx0, int ty0, int lane, uint8_t *slot) {
+  const int x = min(tx0 + lane, dw - 1);              // partial-width tile: one row per request, columns clamped
+  for (int r = 0; r < 16; r++) {
+    const int oy = min(ty0 + r, dh - 1);
+    const uint8_t *g = l2 + ((uint32_t)oy * (uint32_t)irow2 + (uint32_t)x * 4u);
+    __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(slot + r * 256), 4, 0, 0);
+  }
+}
+__device__ __forceinline__ void h8s_issue_q2(const Half8Args &a, const uint8_t *l2, int tx0, int ty0, int lane, uint8_t *slot) {
+  if (tx0 + kTileW <= a.dw) {          // 4 rows x 256 B per request, LDS image lane-linear
+    const int row = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int oy = min(ty0 + k * 4 + row, a.dh - 1);
+      const uint8_t *g = l2 + ((uint32_t)oy * (uint32_t)a.irow2 + (uint32_t)(tx0 + chunk * 4) * 4u);
+      __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(slot + k * 1024), 16, 0, 0);
+    }
+  } else h8s_issue_q2_partial(l2, a.irow2, a.dw, a.dh, tx0, ty0, lane, slot);
+}
+__device__ __forceinline__ void h8s_read_tile(int lane, const uint8_t *slot, uint4 (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const uint4 *>(slot + (k * 64 + lane) * 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot may be overwritten (layer-2 DMA) from here on
+}
+__device__ __noinline__ void h8s_store_tile_partial(uint8_t *dst, int orow, int tw, int thh, int tx0, int ty0, int lane, uint4 v0, uint4 v1, uint4 v2, uint4 v3) {
+  const int row = lane >> 4, chunk = lane & 15;
+  const uint4 v[4] = {v0, v1, v2, v3};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int ly = k * 4 + row;
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + ly) * orow) + tx0 + chunk * 4;
+    if (ly < thh) {
+      if (chunk * 4 + 0 < tw) d[0] = v[k].x;
+      if (chunk * 4 + 1 < tw) d[1] = v[k].y;
+      if (chunk * 4 + 2 < tw) d[2] = v[k].z;
+      if (chunk * 4 + 3 < tw) d[3] = v[k].w;
+    }
+  }
+}
+__device__ __forceinline__ void h8s_store_tile(const Half8Args &a, uint8_t *dst, int tx0, int ty0, int lane, const uint4 (&v)[4]) {
+  const int tw = min(kTileW, a.dw - tx0), thh = min(H8S::kTileH, a.dh - ty0);
+  const int row = lane >> 4, chunk = lane & 15;
+  if (tw == kTileW && !(a.orow & 15)) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ly = k * 4 + row;
+      if (ly < thh) *reinterpret_cast<uint4 *>(dst + ((size_t)(ty0 + ly) * a.orow + (size_t)(tx0 + chunk * 4) * 4)) = v[k];
+    }
+  } else h8s_store_tile_partial(dst, a.orow, tw, thh, tx0, ty0, lane, v[0], v[1], v[2], v[3]);
+}
+
+// walks a workgroup's (track, tile) list with stride wstride without per-step divisions (all wave-uniform, SALU)
+struct H8sTile {
+  int track, tx, ty;                 // tile column / row index
+  int dq, dr, tiles_x, tiles_y;      // wstride = dq * tiles_x + dr
+  __device__ __forceinline__ void init(const Half8Args &a, int work, int wstride) {
+    tiles_x = a.tiles_x; tiles_y = a.tiles_y;
+    const int tiles = tiles_x * tiles_y;
+    track = work / tiles;
+    const int tile = work - track * tiles;
+    ty = tile / tiles_x; tx = tile - ty * tiles_x;
+    dq = wstride / tiles_x; dr = wstride - dq * tiles_x;
+  }
+  __device__ __forceinline__ void step() {
+    tx += dr; ty += dq;
+    if (tx >= tiles_x) { tx -= tiles_x; ty += 1; }
+    while (ty >= tiles_y) { ty -= tiles_y; track += 1; }
+  }
+  __device__ __forceinline__ int tx0() const { return tx * kTileW; }
+  __device__ __forceinline__ int ty0() const { return ty * H8S::kTileH; }
+};
+
+template <int DBG>
+__global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
+  using C = H8S;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define H8S_T(i)                                                                                     \
+  if (DBG) {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                     \
+    tacc[i] += now_ - tprev; tprev = now_;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t *s_win = smem;                         // 2 x [38][136] packed source pixels (raw bytes)
+  uint8_t *s_h = smem + C::kOffH;                // [19][64][4] dwords of 2 x int16
+  uint8_t *s_q = smem + C::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
+  uint8_t *s_lut = smem + C::kOffLut;
+  float *s_alpha = reinterpret_cast<float *>(smem + C::kOffAlpha);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
+  if (a.use_lut) stage_lut(s_lut, lut);
+  if (a.blend && tid < 256) s_alpha[tid] = a.alpha_tab[tid];
+
+  // XCD-aware persistent work list (see k_half8)
+  const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3);
+  const int chunk = (nwork + 7) >> 3;
+  const int wend = min((xcd + 1) * chunk, nwork);
+  int work = xcd * chunk + (int)(blockIdx.x >> 3);
+  if (work >= wend) return;                       // workgroup-uniform
+
+  if (wave >= 4) {
+    // ------------------------------------------------ memory waves ------------------------------------------------
+    // Wave 4 fetches window DMA instructions 0..10, wave 5 fetches 11..20 and also moves the layer-2 / result tiles.
+    // Window n+2 goes to slot n & 1, free after B(n) and needed at A(n+2); each wave issues the first part of its
+    // share between B(n) and A(n+1) and the rest between A(n+1) and B(n+1), so both barrier intervals carry traffic:
+    //   A(n)   | rest of window n+1; wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1
+    //   B(n)   | first part of window n+2 | wait for all but that part: window n+1 (and layer-2 n+1) have landed |
+    //          | edge fix-up of window n+1 (own chunks)
+    constexpr int K0 = 0, K1 = 6, K2 = 11, K3 = 16, K4 = 21;     // wave 4: [K0,K1) + [K1,K2); wave 5: [K2,K3) + [K3,K4)
+    const bool w5 = wave == 5;
+    H8sLaneOff lo;
+    h8s_lane_offsets(a, lane, lo);
+    H8sTile t0, t1, t2;               // tiles n, n+1, n+2
+    t0.init(a, work, wstride); t1 = t0; t1.step(); t2 = t1; t2.step();
+    const bool has1 = work + wstride < wend;
+    if (w5) {
+      if (a.blend) h8s_issue_q2(a, trk.l2[t0.track], t0.tx0(), t0.ty0(), lane, s_q);
+      h8s_issue_window<K2, K4>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
+      if (has1) { h8s_issue_window<K2, K3>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, K2 * 64, K4 * 64);
+    } else {
+      h8s_issue_window<K0, K2>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
+      if (has1) { h8s_issue_window<K0, K1>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, K0 * 64, K2 * 64);
+    }
+    H8sTile tp = t0;                  // tile n-1
+    bool has_prev = false;
+    int par = 0;
+    if (DBG) tprev = __builtin_amdgcn_s_memtime();
+    for (; work < wend; work += wstride) {
+      H8S_T(0)
+      H8S_BARRIER();                                                                   // A(n)
+      H8S_T(1)
+      const bool has_next = work + wstride < wend, has_nn = work + 2 * wstride < wend;
+      uint8_t *w1 = s_win + (par ^ 1) * C::kWinBytes;
+      if (w5) {
+        if (has_next) h8s_issue_window<K3, K4>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, w1, lo);
+        H8S_T(2)
+        uint4 ov[4];
+        if (has_prev) h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
+        if (has_next && a.blend) h8s_issue_q2(a, trk.l2[t1.track], t1.tx0(), t1.ty0(), lane, s_q + (par ^ 1) * 4096);
+        if (has_prev) h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
+      } else {
+        if (has_next) h8s_issue_window<K1, K2>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, w1, lo);
+        H8S_T(2)
+      }
+      H8S_T(3)
+      H8S_BARRIER();                                                                   // B(n): window slot n & 1 is free
+      H8S_T(4)
+      if (has_nn) {
+        uint8_t *w2 = s_win + par * C::kWinBytes;
+        if (w5) { h8s_issue_window<K2, K3>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
+        else { h8s_issue_window<K0, K1>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      H8S_T(6)
+      if (has_next && h8s_border(t1.tx0(), a.sw)) {
+        if (w5) h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K2 * 64, K4 * 64); else h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K0 * 64, K2 * 64);
+      }
+      tp = t0; has_prev = true; t0 = t1; t1 = t2; t2.step();
+      par ^= 1;
+    }
+    H8S_BARRIER();                                                                     // A(last + 1): the last tile is in its slot
+    if (w5) {
+      uint4 ov[4];
+      h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
+      h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
+    }
+    if (DBG && lane == 0)
+      for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * 6 + wave) * 8 + i] = tacc[i];
+    return;
+  }
+
+  // -------------------------------------------------- compute waves --------------------------------------------------
+  uint32_t bf = a.bf, nbf = a.nbf;
+  if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
+  const int4v b_hi = a.bfrag[lane], b_lo = a.bfrag[64 + lane];
+  const int kb = 128;                                     // see k_half8: t' = t - 16384 in bits 8..23 of (dh << 7) + dl
+  const int4v cbias = {kb, kb, kb, kb};
+  const short2v tmax = {16383, 16383};
+  const short2v vc0 = __builtin_bit_cast(short2v, a.vc[0]), vc1 = __builtin_bit_cast(short2v, a.vc[1]);
+  const short2v vc2 = __builtin_bit_cast(short2v, a.vc[2]), vc3 = __builtin_bit_cast(short2v, a.vc[3]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  constexpr int RPW = C::kRPW;
+  const int ly0 = wave * RPW;
+  const int m = lane & 15, g = lane >> 4;
+  int par = 0;
+  if (DBG) tprev = __builtin_amdgcn_s_memtime();
+  for (; work < wend; work += wstride) {
+    H8S_T(0)
+    H8S_BARRIER();                                                                     // A(n)
+    H8S_T(1)
+    // ---- horizontal pass on the matrix cores (k_half8 section 2); the window holds raw bytes, biased here ----
+    const uint8_t *s_pl = s_win + par * C::kWinBytes;
+#pragma unroll
+    for (int mb = 0; mb < C::kMBlocks; mb++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int nb = wave * 4 + q;
+        int4v av = *reinterpret_cast<const int4v *>(s_pl + (mb * 16 + m) * kH8Pitch + nb * 32 + g * 16);
+        av ^= (int)0x80808080;
+        const int4v zero = {0, 0, 0, 0};
+        const int4v dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_hi, zero, 0, 0, 0);
+        const int4v dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_lo, cbias, 0, 0, 0);
+        const uint32_t x0 = (uint32_t)((dh[0] << 7) + dl[0]), x1 = (uint32_t)((dh[1] << 7) + dl[1]);
+        const uint32_t x2 = (uint32_t)((dh[2] << 7) + dl[2]), x3 = (uint32_t)((dh[3] << 7) + dl[3]);
+        const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
+        const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
+        const int pr = mb * 8 + 2 * g;
+        uint32_t *hp = reinterpret_cast<uint32_t *>(s_h) + (pr * kTileW + nb * 4) * 4 + m;
+        if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
+        if (pr + 1 < C::kPairs) hp[kTileW * 4] = __builtin_bit_cast(uint32_t, q1);
+      }
+    }
+    H8S_T(2)
+    H8S_BARRIER();                                                                     // B(n)
+    H8S_T(3)
+    // ---- vertical pass + epilogue (k_half8 section 3); layer 2 comes from / the result goes to the ring slot ----
+    {
+      uint32_t *qs = reinterpret_cast<uint32_t *>(s_q + par * 4096) + ly0 * kTileW + lane;
+      const uint4 *col = reinterpret_cast<const uint4 *>(s_h) + lane;
+      uint4 w[RPW + 3];
+#pragma unroll
+      for (int i = 0; i < RPW + 3; i++) w[i] = col[(ly0 + i) * kTileW];
+      uint32_t q2[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; i++) q2[i] = a.blend ? qs[i * kTileW] : 0xFF000000u;
+      uint32_t px[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; i++) {
+        const int vr = (1 << 20) + (1 << 28);
+        int a0 = vr, a1 = vr, a2 = vr, a3 = vr;
+#define H8_DOT(acc, fld)                                                                        \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i].fld), vc0, acc, false);     \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 1].fld), vc1, acc, false); \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 2].fld), vc2, acc, false); \
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 3].fld), vc3, acc, false);
+        H8_DOT(a0, x) H8_DOT(a1, y) H8_DOT(a2, z) H8_DOT(a3, w)
+#undef H8_DOT
+        px[i] = pack_sat_shr21(a0, a1, a2, a3);
+      }
+      if (a.blend) {
+        const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+        bool opaque = true;
+#pragma unroll
+        for (int i = 0; i < RPW; i++) opaque = opaque && ((q2[i] >> 24) == 255);
+        if (__all(opaque)) {
+#pragma unroll
+          for (int i = 0; i < RPW; i++) px[i] = mix3_dot4(px[i], q2[i], w_lo, w_hi) | (px[i] & 0xFF000000u);
+        } else {
+          // (uint8_t)((float)c * alpha), alpha = (float)a / 255. from the table, inv_alpha = 1. - alpha: the double
+          // difference of a float in [0, 1] from 1 is exact, so its float rounding is the float subtraction
+          float alpha[RPW], inv[RPW];
+#pragma unroll
+          for (int i = 0; i < RPW; i++) { alpha[i] = s_alpha[q2[i] >> 24]; inv[i] = __fsub_rn(1.0f, alpha[i]); }
+#pragma unroll
+          for (int i = 0; i < RPW; i++) {
+            const uint32_t q = q2[i], p = px[i];
+            const uint32_t f2 = (uint32_t)__fmul_rn((float)((q >> 0) & 0xFF), alpha[i]) | ((uint32_t)__fmul_rn((float)((q >> 8) & 0xFF), alpha[i]) << 8) |
+                                ((uint32_t)__fmul_rn((float)((q >> 16) & 0xFF), alpha[i]) << 16);
+            const uint32_t f1 = (uint32_t)__fmul_rn((float)((p >> 0) & 0xFF), inv[i]) | ((uint32_t)__fmul_rn((float)((p >> 8) & 0xFF), inv[i]) << 8) |
+                                ((uint32_t)__fmul_rn((float)((p >> 16) & 0xFF), inv[i]) << 16);
+            const bool op = (q >> 24) == 255;
+            px[i] = mix3_dot4(op ? p : f1, op ? q : f2, w_lo, w_hi) | (p & 0xFF000000u);
+          }
+        }
+      }
+      if (a.use_lut) {
+        uint32_t r[RPW], gg[RPW], b[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; i++) { r[i] = s_lut[px[i] & 0xFF]; gg[i] = s_lut[(px[i] >> 8) & 0xFF]; b[i] = s_lut[(px[i] >> 16) & 0xFF]; }
+#pragma unroll
+        for (int i = 0; i < RPW; i++) px[i] = r[i] | (gg[i] << 8) | (b[i] << 16) | (px[i] & 0xFF000000u);
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; i++) qs[i * kTileW] = px[i];
+    }
+    par ^= 1;
+  }
+  H8S_BARRIER();                                                                       // A(last + 1)
+  if (DBG && lane == 0)
+    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * 6 + wave) * 8 + i] = tacc[i];
+#undef H8S_T
 }
 
 // ---- generic two-launch path: any pixel size (bytes are independent channels), global int16 scratch ----
@@ -657,7 +1083,7 @@ static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const 
         const int j = px - 2 * col;
         const int tap = (sbyte == want && j >= 0 && j < 8) ? taps[j] : 0;
         frag[0][l][e] = (int8_t)(tap >> 6);        // tap = 64 * hi + lo, lo in [0, 63]
-        frag[1][l][e] = (int8_t)(tap & 63);
+        frag[1][l][e] = (int8_t)(2 * (tap & 63));  // stored doubled (see k_half8)
       }
     float at[512];
     for (int al = 0; al < 256; al++) {             // simple_blend.c:137: alpha = (float)a / 255., inv_alpha = 1. - alpha
@@ -681,6 +1107,15 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   static const bool disabled = getenv("LGPU_DISABLE_HALF8") != nullptr;
   if (disabled || !hb->uniform2 || !vb->uniform2) return LGPU_E_UNSUPPORTED;
   if ((irow & 3) || (orow & 3)) return LGPU_E_UNSUPPORTED;
+  {   // operand ranges of the int8 / int16 forms used by the kernel
+    int hsum = 0, vsum = 0, hneg = 0;
+    for (int j = 0; j < 8; j++) {
+      const int th_ = hb->hco[j], tv = vb->hco[j];
+      if (th_ < -8192 || th_ >= 8192) return LGPU_E_UNSUPPORTED;       // tap >> 6 must fit int8
+      hsum += th_; vsum += tv; if (th_ < 0) hneg -= th_;
+    }
+    if (hsum != 16384 || vsum != 16384 || hneg > 4096) return LGPU_E_UNSUPPORTED;   // |t - 16384| <= 16384 + 2 * hneg + 1 < 2^15
+  }
   const Half8Const *hc;
   int rc = get_half8_const(hb->hco.data(), swap_rb, &hc);
   if (rc) return rc;
@@ -703,11 +1138,57 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   if (grid > nwork) grid = nwork;
   grid = (grid + 7) & ~7;                      // whole workgroups per XCD
   static const int abl = getenv("LGPU_H8_ABLATE") ? atoi(getenv("LGPU_H8_ABLATE")) : 0;   // profiling only
+  static unsigned long long *g_dbg = nullptr;
+  a.dbg = nullptr;
+  if (abl == 16) {
+    if (!g_dbg) LGPU_HIP(hipMalloc((void **)&g_dbg, sizeof(unsigned long long) * 8 * 4 * 4096));
+    a.dbg = g_dbg;
+  }
 #define H8_LAUNCH(TH_, ABL_)                                                                                              \
   do {                                                                                                                    \
     if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)k_half8<TH_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_half8<TH_, ABL_>), dim3((unsigned)grid), dim3(kBlock), lds, st, a, t, l);                       \
   } while (0)
+  static const bool classic = getenv("LGPU_H8_CLASSIC") != nullptr;
+  if (th == 16 && abl == 0 && !classic) {
+    const size_t lds_s = H8S::kLds;
+    int grid_s = g_cus * (bpc_env > 0 ? bpc_env : (int)(160 * 1024 / lds_s));
+    if (grid_s > nwork) grid_s = nwork;
+    grid_s = (grid_s + 7) & ~7;
+    static const bool dbg_s = getenv("LGPU_H8S_DEBUG") != nullptr;
+    if (dbg_s) {
+      static unsigned long long *g_dbg_s = nullptr;
+      if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * 6 * 4096));
+      a.dbg = g_dbg_s;
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      hipLaunchKernelGGL(k_half8s<1>, dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+      static int dumps = 0;
+      if (dumps++ < 3) {
+        LGPU_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)grid_s * 48);
+        LGPU_HIP(hipMemcpy(h.data(), g_dbg_s, h.size() * 8, hipMemcpyDeviceToHost));
+        double c[8] = {0}, m[8] = {0}, m5[8] = {0};
+        for (int b = 0; b < grid_s; b++)
+          for (int i = 0; i < 8; i++) {
+            for (int w = 0; w < 4; w++) c[i] += (double)h[((size_t)b * 6 + w) * 8 + i] / 4;
+            m[i] += (double)h[((size_t)b * 6 + 4) * 8 + i];
+            m5[i] += (double)h[((size_t)b * 6 + 5) * 8 + i];
+          }
+        const double it = (double)nwork;
+        fprintf(stderr, "[h8s compute wave, ticks/tile] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", c[0] / it, c[1] / it, c[2] / it, c[3] / it);
+        fprintf(stderr, "[h8s memory wave 4, ticks/tile] fix edges %.0f | wait A %.0f | dma window b %.0f | - %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
+                m[0] / it, m[1] / it, m[2] / it, m[3] / it, m[4] / it, m[5] / it, m[6] / it);
+        fprintf(stderr, "[h8s memory wave 5, ticks/tile] fix edges %.0f | wait A %.0f | dma window b %.0f | read + dma l2 + store %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
+                m5[0] / it, m5[1] / it, m5[2] / it, m5[3] / it, m5[4] / it, m5[5] / it, m5[6] / it);
+      }
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+    LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    hipLaunchKernelGGL(k_half8s<0>, dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
   if (th == 8) H8_LAUNCH(8, 0);
   else switch (abl) {
     case 1: H8_LAUNCH(16, 1); break;
@@ -715,9 +1196,23 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
     case 7: H8_LAUNCH(16, 7); break;
     case 8: H8_LAUNCH(16, 8); break;
     case 15: H8_LAUNCH(16, 15); break;
+    case 16: H8_LAUNCH(16, 16); break;
     default: H8_LAUNCH(16, 0); break;
   }
 #undef H8_LAUNCH
+  if (abl == 16) {   // phase-cycle dump (profiling build only): mean per wave over the grid
+    static int dumps = 0;
+    if (dumps++ < 3) {
+      LGPU_HIP(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h((size_t)grid * 32);
+      LGPU_HIP(hipMemcpy(h.data(), g_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      double sum[8] = {0};
+      for (int b = 0; b < grid; b++) for (int w = 0; w < 4; w++) for (int i = 1; i < 8; i++) sum[i == 7 ? 7 : i] += (double)h[((size_t)b * 4 + w) * 8 + i] , sum[0] += (i == 1 ? (double)h[((size_t)b * 4 + w) * 8] : 0);
+      const double n = (double)grid * 4, iters = (double)nwork / grid;
+      fprintf(stderr, "[h8 phases, s_memtime ticks per tile per wave] write %.0f | bar1 %.0f | issue+q2 %.0f | hpass %.0f | bar2 %.0f | vdots %.0f | epilogue %.0f | looptop %.0f\n",
+              sum[0] / n / iters, sum[1] / n / iters, sum[2] / n / iters, sum[3] / n / iters, sum[4] / n / iters, sum[5] / n / iters, sum[6] / n / iters, sum[7] / n / iters);
+    }
+  }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
