@@ -763,7 +763,7 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
     //   A(n)   | rest of window n+1; wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1
     //   B(n)   | first part of window n+2 | wait for all but that part: window n+1 (and layer-2 n+1) have landed |
     //          | edge fix-up of window n+1 (own chunks)
-    constexpr int K0 = 0, K1 = 6, K2 = 11, K3 = 16, K4 = 21;     // wave 4: [K0,K1) + [K1,K2); wave 5: [K2,K3) + [K3,K4)
+    constexpr int K0 = 0, K1 = 6, K2 = 16, K3 = 21, K4 = 21;     // wave 4: [K0,K1) after B + [K1,K2) after A; wave 5: [K2,K3) after B (+ [K3,K4) after A)
     const bool w5 = wave == 5;
     H8sLaneOff lo;
     h8s_lane_offsets(a, lane, lo);
@@ -849,25 +849,44 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
     H8S_BARRIER();                                                                     // A(n)
     H8S_T(1)
     // ---- horizontal pass on the matrix cores (k_half8 section 2); the window holds raw bytes, biased here ----
+    // Software pipelined over the three 16-row blocks: the four A fragments of block mb + 1 are read while block mb is
+    // on the matrix pipe, and a block's eight MFMAs are issued back to back before any result is consumed.
     const uint8_t *s_pl = s_win + par * C::kWinBytes;
+    {
+      const uint8_t *abase = s_pl + m * kH8Pitch + wave * 128 + g * 16;       // + mb * 16 rows + q * 32
+      uint32_t *hbase = reinterpret_cast<uint32_t *>(s_h) + wave * 64 + m;     // + pr * 256 + q * 16
+      int4v av[4], an[4];
 #pragma unroll
-    for (int mb = 0; mb < C::kMBlocks; mb++) {
+      for (int q = 0; q < 4; q++) av[q] = *reinterpret_cast<const int4v *>(abase + q * 32);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int nb = wave * 4 + q;
-        int4v av = *reinterpret_cast<const int4v *>(s_pl + (mb * 16 + m) * kH8Pitch + nb * 32 + g * 16);
-        av ^= (int)0x80808080;
+      for (int mb = 0; mb < C::kMBlocks; mb++) {
+        if (mb + 1 < C::kMBlocks) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) an[q] = *reinterpret_cast<const int4v *>(abase + (mb + 1) * 16 * kH8Pitch + q * 32);
+        }
+        int4v dh[4], dl[4];
         const int4v zero = {0, 0, 0, 0};
-        const int4v dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_hi, zero, 0, 0, 0);
-        const int4v dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_lo, cbias, 0, 0, 0);
-        const uint32_t x0 = (uint32_t)((dh[0] << 7) + dl[0]), x1 = (uint32_t)((dh[1] << 7) + dl[1]);
-        const uint32_t x2 = (uint32_t)((dh[2] << 7) + dl[2]), x3 = (uint32_t)((dh[3] << 7) + dl[3]);
-        const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
-        const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int4v ab = av[q] ^ (int)0x80808080;
+          dh[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_hi, zero, 0, 0, 0);
+          dl[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_lo, cbias, 0, 0, 0);
+        }
         const int pr = mb * 8 + 2 * g;
-        uint32_t *hp = reinterpret_cast<uint32_t *>(s_h) + (pr * kTileW + nb * 4) * 4 + m;
-        if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
-        if (pr + 1 < C::kPairs) hp[kTileW * 4] = __builtin_bit_cast(uint32_t, q1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t x0 = (uint32_t)((dh[q][0] << 7) + dl[q][0]), x1 = (uint32_t)((dh[q][1] << 7) + dl[q][1]);
+          const uint32_t x2 = (uint32_t)((dh[q][2] << 7) + dl[q][2]), x3 = (uint32_t)((dh[q][3] << 7) + dl[q][3]);
+          const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
+          const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
+          uint32_t *hp = hbase + pr * 256 + q * 16;
+          if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
+          if (pr + 1 < C::kPairs) hp[256] = __builtin_bit_cast(uint32_t, q1);
+        }
+        if (mb + 1 < C::kMBlocks) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) av[q] = an[q];
+        }
       }
     }
     H8S_T(2)
