@@ -566,17 +566,23 @@ __global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lu
 // complete and window slot n & 1 free), raw s_barrier so the memory wave's DMA stays in flight across them; it
 // waits with a counted vmcnt that leaves exactly the newest window outstanding.
 // =====================================================================================================================
-constexpr int kH8sThreads = 384;
+constexpr int kH8sCW = 4;                        // compute waves per workgroup (+ 2 memory waves)
+constexpr int kH8sThreads = (kH8sCW + 2) * 64;
 struct H8S {
-  static constexpr int kRows = 38, kPairs = 19, kMBlocks = 3, kRPW = 4, kTileH = 16;
+  static constexpr int kRows = 38, kPairs = 19, kMBlocks = 3, kTileH = 16;
+  static constexpr int kRPW = 16 / kH8sCW;             // vertical pass: output rows per compute wave
+  static constexpr int kNQ = 16 / kH8sCW;              // horizontal pass: 4-column blocks per compute wave
   static constexpr int kWinBytes = kRows * 544;        // 20672 = 20 x 1024 + 192: 21 DMA instructions, the last with 12 lanes
   static constexpr int kRounds = 21, kTailLanes = 12;
   static constexpr int kSplit = 11;                    // DMA instructions 0..10: memory wave 4, 11..20: memory wave 5
-  static constexpr int kOffH = 2 * kWinBytes;          // 41344
-  static constexpr int kOffQ = kOffH + kPairs * kTileW * 16;      // 60800: 2 x [16][64] pixels
-  static constexpr int kOffLut = kOffQ + 2 * 4096;     // 68992
-  static constexpr int kOffAlpha = kOffLut + 256;      // 69248: float[256]
-  static constexpr size_t kLds = kOffAlpha + 1024;     // 70272: two workgroups per CU
+};
+template <int NSLOT>                                    // window slots: 2 (two workgroups per CU) or 1 (three per CU)
+struct H8SL {
+  static constexpr int kOffH = NSLOT * H8S::kWinBytes;                       // 41344 / 20672
+  static constexpr int kOffQ = kOffH + H8S::kPairs * kTileW * 16;            // 2 x [16][64] pixels
+  static constexpr int kOffLut = kOffQ + 2 * 4096;
+  static constexpr int kOffAlpha = kOffLut + 256;                            // float[256]
+  static constexpr size_t kLds = kOffAlpha + 1024;                           // 70272 / 49600
 };
 
 #define H8S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -725,8 +731,8 @@ struct H8sTile {
   __device__ __forceinline__ int ty0() const { return ty * H8S::kTileH; }
 };
 
-template <int DBG>
-__global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
+template <int DBG, int NSLOT>
+__global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
   using C = H8S;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define H8S_T(i)                                                                                     \
@@ -738,10 +744,11 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
   }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t *s_win = smem;                         // 2 x [38][136] packed source pixels (raw bytes)
-  uint8_t *s_h = smem + C::kOffH;                // [19][64][4] dwords of 2 x int16
-  uint8_t *s_q = smem + C::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
-  uint8_t *s_lut = smem + C::kOffLut;
-  float *s_alpha = reinterpret_cast<float *>(smem + C::kOffAlpha);
+  using L = H8SL<NSLOT>;
+  uint8_t *s_h = smem + L::kOffH;                // [19][64][4] dwords of 2 x int16
+  uint8_t *s_q = smem + L::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
+  uint8_t *s_lut = smem + L::kOffLut;
+  float *s_alpha = reinterpret_cast<float *>(smem + L::kOffAlpha);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
@@ -755,7 +762,54 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
   int work = xcd * chunk + (int)(blockIdx.x >> 3);
   if (work >= wend) return;                       // workgroup-uniform
 
-  if (wave >= 4) {
+  if (NSLOT == 1 && wave >= kH8sCW) {
+    // -------------------------------------- memory waves, one window slot --------------------------------------
+    // three workgroups per CU hide the fetch latency by occupancy instead of a second slot:
+    //   A(n) | wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1 | B(n): the window is
+    //   free | window DMA n+1 (wave 4: requests 0..10, wave 5: 11..20) | drain | edge fix-up | A(n+1)
+    constexpr int KS = 11;
+    const bool w5 = wave == kH8sCW + 1;
+    H8sLaneOff lo;
+    h8s_lane_offsets(a, lane, lo);
+    H8sTile t0, t1;
+    t0.init(a, work, wstride); t1 = t0; t1.step();
+    if (w5) {
+      if (a.blend) h8s_issue_q2(a, trk.l2[t0.track], t0.tx0(), t0.ty0(), lane, s_q);
+      h8s_issue_window<KS, C::kRounds>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
+    } else h8s_issue_window<0, KS>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, w5 ? KS * 64 : 0, w5 ? C::kRounds * 64 : KS * 64);
+    H8sTile tp = t0;
+    bool has_prev = false;
+    int par = 0;
+    for (; work < wend; work += wstride) {
+      H8S_BARRIER();                                                                   // A(n)
+      const bool has_next = work + wstride < wend;
+      if (w5) {
+        uint4 ov[4];
+        if (has_prev) h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
+        if (has_next && a.blend) h8s_issue_q2(a, trk.l2[t1.track], t1.tx0(), t1.ty0(), lane, s_q + (par ^ 1) * 4096);
+        if (has_prev) h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
+      }
+      H8S_BARRIER();                                                                   // B(n)
+      if (has_next) {
+        if (w5) h8s_issue_window<KS, C::kRounds>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win, lo);
+        else h8s_issue_window<0, KS>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win, lo);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (has_next && h8s_border(t1.tx0(), a.sw)) h8s_fix_edges(s_win, t1.tx0(), a.sw, lane, w5 ? KS * 64 : 0, w5 ? C::kRounds * 64 : KS * 64);
+      tp = t0; has_prev = true; t0 = t1; t1.step();
+      par ^= 1;
+    }
+    H8S_BARRIER();                                                                     // A(last + 1)
+    if (w5) {
+      uint4 ov[4];
+      h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
+      h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
+    }
+    return;
+  }
+  if (wave >= kH8sCW) {
     // ------------------------------------------------ memory waves ------------------------------------------------
     // Wave 4 fetches window DMA instructions 0..10, wave 5 fetches 11..20 and also moves the layer-2 / result tiles.
     // Window n+2 goes to slot n & 1, free after B(n) and needed at A(n+2); each wave issues the first part of its
@@ -764,7 +818,7 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
     //   B(n)   | first part of window n+2 | wait for all but that part: window n+1 (and layer-2 n+1) have landed |
     //          | edge fix-up of window n+1 (own chunks)
     constexpr int K0 = 0, K1 = 6, K2 = 16, K3 = 21, K4 = 21;     // wave 4: [K0,K1) after B + [K1,K2) after A; wave 5: [K2,K3) after B (+ [K3,K4) after A)
-    const bool w5 = wave == 5;
+    const bool w5 = wave == kH8sCW + 1;
     H8sLaneOff lo;
     h8s_lane_offsets(a, lane, lo);
     H8sTile t0, t1, t2;               // tiles n, n+1, n+2
@@ -825,7 +879,7 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
       h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
     }
     if (DBG && lane == 0)
-      for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * 6 + wave) * 8 + i] = tacc[i];
+      for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * (kH8sCW + 2) + wave) * 8 + i] = tacc[i];
     return;
   }
 
@@ -851,30 +905,31 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
     // ---- horizontal pass on the matrix cores (k_half8 section 2); the window holds raw bytes, biased here ----
     // Software pipelined over the three 16-row blocks: the four A fragments of block mb + 1 are read while block mb is
     // on the matrix pipe, and a block's eight MFMAs are issued back to back before any result is consumed.
-    const uint8_t *s_pl = s_win + par * C::kWinBytes;
+    const uint8_t *s_pl = s_win + (NSLOT == 2 ? par : 0) * C::kWinBytes;
     {
-      const uint8_t *abase = s_pl + m * kH8Pitch + wave * 128 + g * 16;       // + mb * 16 rows + q * 32
-      uint32_t *hbase = reinterpret_cast<uint32_t *>(s_h) + wave * 64 + m;     // + pr * 256 + q * 16
-      int4v av[4], an[4];
+      constexpr int NQ = C::kNQ;
+      const uint8_t *abase = s_pl + m * kH8Pitch + wave * (NQ * 32) + g * 16;  // + mb * 16 rows + q * 32
+      uint32_t *hbase = reinterpret_cast<uint32_t *>(s_h) + wave * (NQ * 16) + m;   // + pr * 256 + q * 16
+      int4v av[NQ], an[NQ];
 #pragma unroll
-      for (int q = 0; q < 4; q++) av[q] = *reinterpret_cast<const int4v *>(abase + q * 32);
+      for (int q = 0; q < NQ; q++) av[q] = *reinterpret_cast<const int4v *>(abase + q * 32);
 #pragma unroll
       for (int mb = 0; mb < C::kMBlocks; mb++) {
         if (mb + 1 < C::kMBlocks) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) an[q] = *reinterpret_cast<const int4v *>(abase + (mb + 1) * 16 * kH8Pitch + q * 32);
+          for (int q = 0; q < NQ; q++) an[q] = *reinterpret_cast<const int4v *>(abase + (mb + 1) * 16 * kH8Pitch + q * 32);
         }
-        int4v dh[4], dl[4];
+        int4v dh[NQ], dl[NQ];
         const int4v zero = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NQ; q++) {
           const int4v ab = av[q] ^ (int)0x80808080;
           dh[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_hi, zero, 0, 0, 0);
           dl[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_lo, cbias, 0, 0, 0);
         }
         const int pr = mb * 8 + 2 * g;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NQ; q++) {
           const uint32_t x0 = (uint32_t)((dh[q][0] << 7) + dl[q][0]), x1 = (uint32_t)((dh[q][1] << 7) + dl[q][1]);
           const uint32_t x2 = (uint32_t)((dh[q][2] << 7) + dl[q][2]), x3 = (uint32_t)((dh[q][3] << 7) + dl[q][3]);
           const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
@@ -885,7 +940,7 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
         }
         if (mb + 1 < C::kMBlocks) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) av[q] = an[q];
+          for (int q = 0; q < NQ; q++) av[q] = an[q];
         }
       }
     }
@@ -956,7 +1011,7 @@ __global__ __launch_bounds__(kH8sThreads) void k_half8s(Half8Args a, SepTracks t
   }
   H8S_BARRIER();                                                                       // A(last + 1)
   if (DBG && lane == 0)
-    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * 6 + wave) * 8 + i] = tacc[i];
+    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * (kH8sCW + 2) + wave) * 8 + i] = tacc[i];
 #undef H8S_T
 }
 
@@ -1170,28 +1225,29 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   } while (0)
   static const bool classic = getenv("LGPU_H8_CLASSIC") != nullptr;
   if (th == 16 && abl == 0 && !classic) {
-    const size_t lds_s = H8S::kLds;
+    static const int nslot = getenv("LGPU_H8S_SLOTS") ? atoi(getenv("LGPU_H8S_SLOTS")) : 2;
+    const size_t lds_s = nslot == 1 ? H8SL<1>::kLds : H8SL<2>::kLds;
     int grid_s = g_cus * (bpc_env > 0 ? bpc_env : (int)(160 * 1024 / lds_s));
     if (grid_s > nwork) grid_s = nwork;
     grid_s = (grid_s + 7) & ~7;
     static const bool dbg_s = getenv("LGPU_H8S_DEBUG") != nullptr;
     if (dbg_s) {
       static unsigned long long *g_dbg_s = nullptr;
-      if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * 6 * 4096));
+      if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * (kH8sCW + 2) * 4096));
       a.dbg = g_dbg_s;
-      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-      hipLaunchKernelGGL(k_half8s<1>, dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      hipLaunchKernelGGL((k_half8s<1, 2>), dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
       static int dumps = 0;
       if (dumps++ < 3) {
         LGPU_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)grid_s * 48);
+        std::vector<unsigned long long> h((size_t)grid_s * 8 * (kH8sCW + 2));
         LGPU_HIP(hipMemcpy(h.data(), g_dbg_s, h.size() * 8, hipMemcpyDeviceToHost));
         double c[8] = {0}, m[8] = {0}, m5[8] = {0};
         for (int b = 0; b < grid_s; b++)
           for (int i = 0; i < 8; i++) {
-            for (int w = 0; w < 4; w++) c[i] += (double)h[((size_t)b * 6 + w) * 8 + i] / 4;
-            m[i] += (double)h[((size_t)b * 6 + 4) * 8 + i];
-            m5[i] += (double)h[((size_t)b * 6 + 5) * 8 + i];
+            for (int w = 0; w < kH8sCW; w++) c[i] += (double)h[((size_t)b * (kH8sCW + 2) + w) * 8 + i] / kH8sCW;
+            m[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW) * 8 + i];
+            m5[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW + 1) * 8 + i];
           }
         const double it = (double)nwork;
         fprintf(stderr, "[h8s compute wave, ticks/tile] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", c[0] / it, c[1] / it, c[2] / it, c[3] / it);
@@ -1203,8 +1259,13 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
-    LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    hipLaunchKernelGGL(k_half8s<0>, dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+    if (nslot == 1) {
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      hipLaunchKernelGGL((k_half8s<0, 1>), dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+    } else {
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      hipLaunchKernelGGL((k_half8s<0, 2>), dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+    }
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
