@@ -116,7 +116,7 @@ def main():
             traffic = pj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roof = {"bound": "hbm", "kernel": "lgpu::k_half8<16,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "lgpu::k_half8s<0,2>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
 
