@@ -130,6 +130,19 @@ int lgpu_blend_multi(int type, const uint8_t *src1_d, int irow1, const uint8_t *
 int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d,
                   int orow, int width, int height, int is_bgr, double delta, double opac,
                   int col_r, int col_g, int col_b, void *stream);
+/* "softlight": lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV (palette 544 YUV444P, 545 YUVA4444P,
+   522 YUV422P, 512 YUV420P, 513 YVU420P): gradient-magnitude highlight mixed into plane 0 (frame border copied), the
+   other planes are copied.  unclamped != 0: luma range 0..255, else 16..235 (the channel's YUV_clamping leaf).
+   src_d / dst_d / irow / orow: one entry per plane (3, or 4 for YUVA4444P).  Not in place (the filter is not
+   CAN_DO_INPLACE). */
+int lgpu_softlight(const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4], const int orow[4],
+                   int width, int height, int palette, int unclamped, void *stream);
+/* "edge detect": lives-plugins/weed-plugins/edge.c:129-248.  palette 1..5 (RGB24, BGR24, RGBA32, BGRA32, ARGB32);
+   mode 0 normal (edges keep the source colour) / 1 monochrome (white) / 2 supercolour (luma pass + one pass per colour
+   byte).  Gradient magnitude of the 3x3-summed central differences, global Otsu threshold over a 1017-bin histogram
+   (device-side, no host round trip), non-edges black.  dst_d may equal src_d (CAN_DO_INPLACE). */
+int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette, int mode,
+              void *stream);
 /* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
 int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
                 int psize, void *stream);

@@ -135,6 +135,7 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_FILTER_HINT_STATEFUL (1 << 2)
 #define WEED_FILTER_PREF_LINEAR_GAMMA (1 << 3)
 #define WEED_FILTER_HINT_MAY_THREAD (1 << 6)
+#define WEED_CHANNEL_REINIT_ON_SIZE_CHANGE (1 << 0)
 #define WEED_CHANNEL_CAN_DO_INPLACE (1 << 4)
 #define WEED_ERROR_PLUGIN_INVALID 64
 #define WEED_ERROR_FILTER_INVALID 65
@@ -155,6 +156,7 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_LEAF_VALUE "value"
 #define WEED_LEAF_GAMMA_TYPE "gamma_type"
 #define WEED_LEAF_YUV_CLAMPING "YUV_clamping"
+#define WEED_LEAF_CHOICES "choices"
 #define WEED_LEAF_YUV_SAMPLING "YUV_sampling"
 #define WEED_LEAF_YUV_SUBSPACE "YUV_subspace"
 /* plugin bootstrap (weed-effects.h:170-186, :195-230; weed.h:493-496) */

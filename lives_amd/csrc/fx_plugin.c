@@ -178,12 +178,64 @@ static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
 }
 
+static int k_edge(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  (void)kind;
+  return lgpu_edge(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, param_int(inst, 0, 0), NULL);
+}
+
+/* "softlight" (softlight.c:62-151): planar YUV in, planar YUV out, not in place; whole frame only */
+static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
+  fxdata_t *fx = fx_data(inst);
+  weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, 0), *oc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0);
+  const uint8_t *dsrc[4] = {0, 0, 0, 0};
+  uint8_t *ddst[4] = {0, 0, 0, 0}, *hdst[4], *base;
+  int irow[4], orow[4], ph[4], i, nplanes, pal, w, h, clamping;
+  size_t ioff[4], ooff[4], itot = 0, otot = 0;
+  (void)tc;
+  if (!fx || !ic || !oc) return WEED_ERROR_FILTER_INVALID;
+  pal = g_int(ic, WEED_LEAF_CURRENT_PALETTE, 0, 0);
+  w = g_int(ic, WEED_LEAF_WIDTH, 0, 0); h = g_int(ic, WEED_LEAF_HEIGHT, 0, 0);
+  clamping = g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED);
+  if (pal != WEED_PALETTE_YUV444P && pal != WEED_PALETTE_YUVA4444P && pal != WEED_PALETTE_YUV422P && pal != WEED_PALETTE_YUV420P &&
+      pal != WEED_PALETTE_YVU420P) return WEED_ERROR_FILTER_INVALID;
+  if (has(oc, WEED_LEAF_OFFSET) && g_int(oc, WEED_LEAF_OFFSET, 0, 0) != 0) return WEED_ERROR_FILTER_INVALID;
+  nplanes = pal == WEED_PALETTE_YUVA4444P ? 4 : 3;
+  for (i = 0; i < nplanes; i++) {
+    irow[i] = g_int(ic, WEED_LEAF_ROWSTRIDES, i, 0); orow[i] = g_int(oc, WEED_LEAF_ROWSTRIDES, i, 0);
+    ph[i] = (i == 0 || i == 3) ? h : ((pal == WEED_PALETTE_YUV420P || pal == WEED_PALETTE_YVU420P) ? h >> 1 : h);
+    ioff[i] = itot; itot += ((size_t)irow[i] * ph[i] + 15) & ~(size_t)15;
+    ooff[i] = otot; otot += ((size_t)orow[i] * ph[i] + 15) & ~(size_t)15;
+    hdst[i] = (uint8_t *)g_ptr(oc, WEED_LEAF_PIXEL_DATA, i);
+    if (!g_ptr(ic, WEED_LEAF_PIXEL_DATA, i) || !hdst[i] || irow[i] <= 0 || orow[i] <= 0) return WEED_ERROR_FILTER_INVALID;
+  }
+  base = (uint8_t *)fx_buf(fx, 0, itot);
+  if (!base) return WEED_ERROR_MEMORY_ALLOCATION;
+  for (i = 0; i < nplanes; i++) {
+    dsrc[i] = base + ioff[i];
+    if (lgpu_upload(base + ioff[i], g_ptr(ic, WEED_LEAF_PIXEL_DATA, i), (size_t)irow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
+  }
+  base = (uint8_t *)fx_buf(fx, 2, otot);
+  if (!base) return WEED_ERROR_MEMORY_ALLOCATION;
+  for (i = 0; i < nplanes; i++) {
+    ddst[i] = base + ooff[i];
+    if (lgpu_upload(ddst[i], hdst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* row padding stays as it was */
+  }
+  if (lgpu_softlight(dsrc, irow, ddst, orow, w, h, pal, clamping == WEED_YUV_CLAMPING_UNCLAMPED, NULL) != LGPU_OK) {
+    fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error());
+    return WEED_ERROR_PLUGIN_INVALID;
+  }
+  for (i = 0; i < nplanes; i++)
+    if (lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
+  return lgpu_sync(NULL) ? WEED_ERROR_PLUGIN_INVALID : WEED_SUCCESS;
+}
+
 #define PROC(name, nin, kind, kern, whole) static weed_error_t name(weed_plant_t *inst, weed_timecode_t tc) { (void)tc; return fx_run(inst, nin, kind, kern, whole); }
 PROC(p_chroma, 2, 0, k_simple, 0) PROC(p_lumo, 2, 1, k_simple, 0) PROC(p_lumu, 2, 2, k_simple, 0) PROC(p_nlumo, 2, 3, k_simple, 0) PROC(p_avlumo, 2, 4, k_simple, 0)
 PROC(p_mpy, 2, 0, k_multi, 0) PROC(p_screen, 2, 1, k_multi, 0) PROC(p_darken, 2, 2, k_multi, 0) PROC(p_lighten, 2, 3, k_multi, 0)
 PROC(p_overlay, 2, 4, k_multi, 0) PROC(p_dodge, 2, 5, k_multi, 0) PROC(p_burn, 2, 6, k_multi, 0)
 PROC(p_ckey, 2, 0, k_ckey, 0)
 PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
+PROC(p_edge, 1, 0, k_edge, 1)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -304,6 +356,28 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
   add_filter(pinfo, "mirrorx", 0, packed, 9, p_mirrorx, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
   add_filter(pinfo, "mirrory", 0, packed, 9, p_mirrory, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
   add_filter(pinfo, "mirrorxy", 0, packed, 9, p_mirrorxy, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
+  /* edge.c:251-263: "edge detect", string-list parameter "mode", in channel REINIT_ON_SIZE_CHANGE, out channel CAN_DO_INPLACE */
+  {
+    static const char *modes[] = {"normal", "monochrome", "supercolour"};
+    weed_plant_t *gui = NULL, *fc = NULL, *ict = NULL;
+    p[0] = int_param("mode", "Edge _Mode", 0, 0, 2, 0);
+    w_get(p[0], WEED_LEAF_GUI, 0, &gui);
+    if (gui) w_set(gui, WEED_LEAF_CHOICES, WEED_SEED_STRING, 3, modes);
+    add_filter(pinfo, "edge detect", WEED_FILTER_PREF_LINEAR_GAMMA, rgb_all, 5, p_edge, 1, "in channel 0", NULL, "out channel 0", p, 1);
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict);
+    if (ict) s_int(ict, WEED_LEAF_FLAGS, WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
+  }
+  /* softlight.c:160-176: planar YUV palettes, out channel NOT in place, in channel prefers unclamped luma */
+  {
+    static const int32_t yuvp[] = {WEED_PALETTE_YUV444P, WEED_PALETTE_YUVA4444P, WEED_PALETTE_YUV422P, WEED_PALETTE_YUV420P, WEED_PALETTE_YVU420P};
+    weed_plant_t *fc = NULL, *ict = NULL, *oct = NULL;
+    add_filter(pinfo, "softlight", 0, yuvp, 5, p_softlight, 1, "in channel 0", NULL, "out channel 0", NULL, 0);
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) { w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict); w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct); }
+    if (ict) s_int(ict, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED);
+    if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
+  }
   s_int(pinfo, WEED_LEAF_VERSION, 1);
   return pinfo;
 }

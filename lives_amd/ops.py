@@ -99,6 +99,22 @@ def mirror(mode, src, dst, width, height, psize):
     lib.call("lgpu_mirror", mode, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
 
 
+def softlight(src_planes, dst_planes, width, height, palette, unclamped):
+    """planar YUV softlight (softlight.c): src_planes / dst_planes are lists of 2-D uint8 device tensors, one per plane"""
+    n = len(src_planes)
+    sp = (ctypes.c_void_p * 4)(*[dptr(t) for t in src_planes])
+    dp = (ctypes.c_void_p * 4)(*[dptr(t) for t in dst_planes])
+    ss = (ctypes.c_int * 4)(*[t.stride(0) for t in src_planes])
+    ds = (ctypes.c_int * 4)(*[t.stride(0) for t in dst_planes])
+    assert n in (3, 4)
+    lib.call("lgpu_softlight", ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(dp), ctypes.addressof(ds), width, height,
+             palette, int(unclamped), stream_ptr())
+
+
+def edge(src, dst, width, height, palette, mode):
+    lib.call("lgpu_edge", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, palette, mode, stream_ptr())
+
+
 def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None, param_block=None):
     p = lib.ChainParams()
     p.param_block_d = param_block.data_ptr() if param_block is not None else None

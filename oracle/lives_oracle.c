@@ -575,6 +575,130 @@ void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * F6a: softlight                        reference: lives-plugins/weed-plugins/softlight.c:34-47 (sqrti), :62-141
+ * Per interior luma sample (the reference's own operand choice, including the two terms that differ from a
+ * textbook Sobel: row0 ends with (S[+1][+1] - S[+1][-1]) and row1 ends with the SUM S[+1][+1] + S[+1][-1]):
+ *   row0 = (S[+1][-1] - S[-1][-1]) + 2 (S[+1][0] - S[-1][0]) + (S[+1][+1] - S[+1][-1])
+ *   row1 = (S[-1][+1] - S[-1][-1]) + 2 (S[0][+1] - S[0][-1]) + (S[+1][+1] + S[+1][-1])
+ *   sum  = clamp(((3 * isqrt(row0^2 + row1^2) / 2) * 384) >> 8);  out = clamp((64 * sum + 192 * S[0][0]) >> 8)
+ * ---------------------------------------------------------------------------------------------- */
+static uint32_t isqrt_u32(uint32_t n) {            /* softlight.c:34-47, digit-by-digit floor square root */
+  uint32_t root = 0, rem = n, place = 0x40000000u, tmp;
+  while (place > rem) place >>= 2;
+  while (place) {
+    if (rem >= (tmp = root + place)) { rem -= tmp; root += place << 1; }
+    root >>= 1;
+    place >>= 2;
+  }
+  return root;
+}
+void orc_softlight_y(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int unclamped) {
+  const int ymin = unclamped ? 0 : 16, ymax = unclamped ? 255 : 235, scale = 384, mix = 192;
+  memcpy(dst, src, (size_t)width);                                                  /* :83 top scanline */
+  for (int y = 1; y < height - 1; y++) {
+    const uint8_t *s = src + (size_t)y * irow;
+    uint8_t *d = dst + (size_t)y * orow;
+    d[0] = s[0];                                                                      /* :110 */
+    for (int x = 1; x < width - 1; x++) {
+      const uint8_t *c = s + x;
+      const int row0 = (c[irow - 1] - c[-irow - 1]) + ((c[irow] - c[-irow]) << 1) + (c[irow + 1] - c[irow - 1]);
+      const int row1 = (c[-irow + 1] - c[-irow - 1]) + ((c[1] - c[-1]) << 1) + (c[irow + 1] + c[irow - 1]);
+      int sum = (int)(((3 * isqrt_u32((uint32_t)(row0 * row0 + row1 * row1)) / 2) * scale) >> 8);
+      sum = sum < ymin ? ymin : sum > ymax ? ymax : sum;
+      sum = ((256 - mix) * sum + mix * c[0]) >> 8;
+      d[x] = (uint8_t)(sum < ymin ? ymin : sum > ymax ? ymax : sum);
+    }
+    d[width - 1] = s[width - 1];                                                      /* :131 */
+  }
+  memcpy(dst + (size_t)(height - 1) * orow, src + (size_t)(height - 1) * irow, (size_t)width);   /* :141 bottom row */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * F6b: edge detect                      reference: lives-plugins/weed-plugins/edge.c:93-125 (copywalpha), :129-248
+ * Per pass (1 pass for modes 0 / 1; luma then the three colour bytes for mode 2):
+ *   l    = luma (calc_luma) or byte (pass - 1) of the pixel           -- for ARGB32 that byte index starts at A
+ *   gh   = l[x+1] - l[x-1], gv = l[y+1] - l[y-1]                       (1 <= x < w-1, 1 <= y < h-1)
+ *   v0   = gh[y-1] + gh[y] + gh[y+1], v1 = gv[x-1] + gv[x] + gv[x+1]   (2 <= x < w-2, 2 <= y < h-2)
+ *   map  = (uint16_t)(sqrtf((float)(v0*v0) + (float)(v1*v1)) * 0.94f); border cells keep their calloc'd 0
+ *   Otsu over the 1017-bin histogram in doubles; the running sums bh/nbh/bl/nbl and threshmax/difmax are
+ *   function-scope in the reference, i.e. they are NOT reset between the passes of mode 2 -- kept.
+ *   pixels with map >= thresh are painted (white / source / one channel to 255), others black on pass 0.
+ * ---------------------------------------------------------------------------------------------- */
+static void edge_paint(uint8_t *dest, size_t doffs, const uint8_t *src, size_t offs, int red, int green, int blue,
+                       int aoffs, int inplace) {   /* copywalpha, edge.c:93-125 */
+  if (aoffs == 1) {
+    if (!inplace) dest[doffs] = src[offs];
+    offs++; doffs++;
+  }
+  if (red != 3) dest[doffs] = red == 1 ? src[offs] : red == 0 ? 0 : 255;
+  if (green != 3) dest[doffs + 1] = green == 1 ? src[offs + 1] : green == 0 ? 0 : 255;
+  if (blue != 3) dest[doffs + 2] = blue == 1 ? src[offs + 2] : blue == 0 ? 0 : 255;
+  if (aoffs != 0 || inplace) return;
+  dest[doffs + 3] = src[offs + 3];
+}
+void orc_edge(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int pal, int mode,
+              int16_t *map16, int inplace) {
+  const int psize = (pal == 1 || pal == 2) ? 3 : 4;
+  const int order = pal == 1 || pal == 3 ? 0 : pal == 2 || pal == 4 ? 1 : 2;
+  const int offs = pal == 5 ? 1 : (pal == 1 || pal == 2) ? -1 : 0;
+  const int TMAX = 1017;
+  const size_t n = (size_t)width * height;
+  uint8_t *mapl = (uint8_t *)calloc(n, 1);
+  int16_t *maph = (int16_t *)calloc(n, 2), *mapv = (int16_t *)calloc(n, 2);
+  int64_t *pr = (int64_t *)malloc(1024 * sizeof(int64_t));
+  uint16_t thresh, threshmax = 0;
+  uint64_t bh = 0, bl = 0, nbh = 0, nbl = 0, nn;
+  double abl, abh, dif, difmax = 0.;
+  if (!luma_ready) build_luma();
+  for (int pass = 0; pass < 4; pass++) {
+    memset(pr, 0, 8192);
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++)
+        mapl[(size_t)y * width + x] = pass == 0 ? luma_of(src + (size_t)y * irow + x * psize, order)
+                                                : src[(size_t)y * irow + x * psize + pass - 1];
+    for (int y = 1; y < height - 1; y++)
+      for (int x = 1; x < width - 1; x++) {
+        const size_t i = (size_t)y * width + x;
+        maph[i] = (int16_t)(-mapl[i - 1] + mapl[i + 1]);
+        mapv[i] = (int16_t)(-mapl[i - width] + mapl[i + width]);
+      }
+    for (int y = 2; y < height - 2; y++)
+      for (int x = 2; x < width - 2; x++) {
+        const size_t i = (size_t)y * width + x;
+        const int16_t v0 = (int16_t)(maph[i - width] + maph[i] + maph[i + width]);
+        const int16_t v1 = (int16_t)(mapv[i - 1] + mapv[i] + mapv[i + 1]);
+        const uint16_t val = (uint16_t)(sqrtf((float)(v0 * v0) + (float)(v1 * v1)) * 0.94f);
+        map16[i] = (int16_t)val;
+        pr[val]++;
+        bh += val;
+        nbh++;
+      }
+    for (thresh = 0; thresh < TMAX; thresh++) {                                      /* :186-204 */
+      nn = (uint64_t)(pr[thresh] * thresh);
+      bl += nn; nbl += (uint64_t)pr[thresh];
+      bh -= nn; nbh -= (uint64_t)pr[thresh];
+      abh = (double)bh / (double)nbh;
+      abl = (double)bl / (double)nbl;
+      dif = (double)(nbl * nbh) * (abh - abl) * (abh - abl);
+      if (thresh > 0 && dif > difmax) { difmax = dif; threshmax = thresh; }
+    }
+    thresh = threshmax;
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++) {
+        const size_t d = (size_t)y * orow + x * psize, s = (size_t)y * irow + x * psize;
+        if ((uint16_t)map16[(size_t)y * width + x] >= thresh) {
+          if (pass == 0) { if (mode == 1) edge_paint(dst, d, src, s, 2, 2, 2, offs, inplace); else edge_paint(dst, d, src, s, 1, 1, 1, offs, inplace); }
+          else if (pass == 1) edge_paint(dst, d, src, s, 2, 3, 3, offs, inplace);
+          else if (pass == 2) edge_paint(dst, d, src, s, 3, 2, 3, offs, inplace);
+          else edge_paint(dst, d, src, s, 3, 3, 2, offs, inplace);
+        } else if (pass == 0) edge_paint(dst, d, src, s, 0, 0, 0, offs, inplace);
+      }
+    if (mode < 2) break;
+  }
+  free(mapl); free(maph); free(mapv); free(pr);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * R1: resize -- UNPINNED.  The reference hands this to FFmpeg libswscale (src/colourspace.c:14711,
  * flags :14991-14997), which is neither vendored nor version-pinned.  Spec "lgpu-polyphase-v1"
  * (DESIGN.md): separable polyphase FIR, horizontal then vertical, Q14 coefficients, 15-bit

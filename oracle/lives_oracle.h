@@ -71,6 +71,16 @@ void orc_colorkey(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1
 /* F5: mirrors.c:26-122.  mode 0 = x, 1 = y, 2 = xy.  (OOB writes of the reference are not performed.) */
 void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
 
+/* F6a: "softlight"  lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV: the stencil runs on plane 0 (rows
+   1..h-2, columns 1..w-2; the frame border is copied), the other planes are copied (:143-151).
+   unclamped != 0: output range 0..255, else 16..235 (:97-103).  Needs width, height >= 3. */
+void orc_softlight_y(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int unclamped);
+/* F6b: "edge detect"  lives-plugins/weed-plugins/edge.c:129-248.  mode 0 normal / 1 monochrome / 2 supercolour.
+   pal: WEED palette id (1 RGB24, 2 BGR24, 3 RGBA32, 4 BGRA32, 5 ARGB32).  map16: caller's int16[width*height] scratch
+   that must start zeroed (the reference's calloc'd sdata->map; its border cells are never written).  inplace: dst == src. */
+void orc_edge(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int pal, int mode,
+              int16_t *map16, int inplace);
+
 /* R1 (UNPINNED, spec "lgpu-polyphase-v1" in DESIGN.md) */
 enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_BILINEAR = 2, ORC_INTERP_HYPER = 3 };
 int orc_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);

@@ -85,6 +85,8 @@ def oracle():
         _O.orc_blend_luma.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_blend_multi.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci]
         _O.orc_mirror.argtypes = [ci, vp, ci, vp, ci, ci, ci, ci]
+        _O.orc_softlight_y.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+        _O.orc_edge.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci]
         _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
         _O.orc_gauss5.argtypes = [vp, ci, vp, ci, ci, ci, ci]
         _O.orc_chain.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -138,6 +140,7 @@ class RefHost:
         self.H.refhost_run.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp, ci]
         self.H.refhost_filter_info.argtypes = [vp, ci, ctypes.c_char_p, ci, vp, ci, vp, vp, vp]
         self.H.refhost_num_filters.argtypes = [vp]
+        self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
         self.plugins = {}
 
     def load(self, path):
@@ -160,6 +163,19 @@ class RefHost:
             out.append(dict(name=buf.value.decode(), flags=flags, palettes=[p for p in pals if p],
                             n_in=nin.value, n_out=nout.value, n_params=npar.value))
         return out
+
+    def run_planar(self, path, fname, pal, w, h, src_planes, dst_planes, clamping):
+        """src_planes / dst_planes: lists of 2-D uint8 arrays (rows x rowstride), one per plane"""
+        hdl = self.load(path)
+        n = len(src_planes)
+        sp = (vp * n)(*[a.ctypes.data for a in src_planes])
+        ss = (ci * n)(*[a.strides[0] for a in src_planes])
+        dp = (vp * n)(*[a.ctypes.data for a in dst_planes])
+        ds = (ci * n)(*[a.strides[0] for a in dst_planes])
+        r = self.H.refhost_run_planar(hdl, fname.encode(), pal, w, h, n, sp, ss, dp, ds, clamping)
+        if r != 0:
+            raise RuntimeError("weed filter '%s' returned %d" % (fname, r))
+        return dst_planes
 
     def run(self, path, fname, pal, w, h, srcs, dst, params=(), nslices=1):
         """srcs: list of 2-D uint8 arrays (rows x rowstride); dst: 2-D uint8 array (may be srcs[0])."""

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""tests/golden/stencils.npz from the reference's own softlight.c / edge.c (oracle/_ref/{softlight,edge}.so, built
+unmodified by build_ref.sh).  TEST INFRASTRUCTURE ONLY; fixtures are data (inputs + the outputs the reference
+produced).  Own seed stream so that the other fixture files stay byte-identical when this one is regenerated."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def structured(rng, w, h, ps):
+    """noise over a coarse checker so that gradients / histograms are not flat"""
+    s = po.make_frame(rng, w, h, ps)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for c in range(ps):
+        s[:, c:w * ps:ps] = ((s[:, c:w * ps:ps] >> 3) + (96 * ((xx // 5 + yy // 4 + c) % 2)).astype(np.uint8) + 40).astype(np.uint8)
+    return s
+
+
+def main():
+    assert po.have_ref(), "run oracle/ref/build_ref.sh first"
+    rng = np.random.default_rng(0x57E9C11)
+    H = po.RefHost()
+    rec, names = {}, []
+    for pal in (544, 545, 522, 512, 513):
+        for (w, h) in ((20, 10), (23, 9)):
+            if pal in (512, 513, 522) and w & 1:
+                w += 1
+            for cl in (0, 1):
+                cw = w >> 1 if pal in (512, 513, 522) else w
+                ch = h >> 1 if pal in (512, 513) else h
+                dims = [(w, h), (cw, ch), (cw, ch)] + ([(w, h)] if pal == 545 else [])
+                src = [structured(rng, a, b, 1) for (a, b) in dims]
+                dst = [np.full_like(a, 0x5A) for a in src]
+                H.run_planar(po.refplugin("softlight"), "softlight", pal, w, h, src, dst, cl)
+                key = "sl|%d|%d|%d|%d" % (pal, w, h, cl)
+                for i, a in enumerate(src):
+                    rec[key + "|i%d" % i] = a
+                    rec[key + "|o%d" % i] = dst[i]
+                names.append(key)
+    for pal in (1, 2, 3, 4, 5):
+        ps = 3 if pal <= 2 else 4
+        for mode in (0, 1, 2):
+            for inplace in (0, 1):
+                w, h = (26, 14) if inplace else (31, 12)
+                s = structured(rng, w, h, ps)
+                d0 = s.copy() if inplace else rng.integers(0, 256, s.shape, dtype=np.uint8)
+                d = d0.copy()
+                H.run(po.refplugin("edge"), "edge detect", pal, w, h, [d if inplace else s], d, [po.p_int(mode)])
+                key = "ed|%d|%d|%d|%d|%d" % (pal, mode, inplace, w, h)
+                rec[key + "|a"] = s
+                rec[key + "|d"] = d0
+                rec[key + "|o"] = d
+                names.append(key)
+    rec["records"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "stencils.npz"), **rec)
+    mpath = os.path.join(OUT, "manifest.json")
+    man = json.load(open(mpath))
+    man["groups"]["stencils.npz"] = ("reference plugins built unmodified: lives-plugins/weed-plugins/softlight.c (sl|palette|w|h|clamping(0 clamped,1 unclamped), "
+                                     "planes i<k>/o<k>), edge.c (ed|palette|mode|inplace|w|h; a = source, d = destination before, o = after); one process_func call")
+    json.dump(man, open(mpath, "w"), indent=1)
+    print("stencils.npz: %d records, %d KB" % (len(names), os.path.getsize(os.path.join(OUT, "stencils.npz")) // 1024))
+
+
+if __name__ == "__main__":
+    main()

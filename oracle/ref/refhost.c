@@ -217,3 +217,46 @@ done:
   if (iptm) free(iptm);
   return ret;
 }
+
+/* One process_func call on a PLANAR frame (softlight.c wants YUV planes): a single in and out channel with
+ * nplanes pixel_data / rowstrides entries and the YUV_clamping leaf (WEED_YUV_CLAMPING_CLAMPED 0 / UNCLAMPED 1). */
+int refhost_run_planar(void *pinfo_v, const char *fname, int pal, int w, int h, int nplanes,
+                       uint8_t **src, const int *istrides, uint8_t **dst, const int *ostrides, int clamping) {
+  weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
+  weed_plant_t *filt = find_filter(pinfo, fname);
+  weed_plant_t *inst, *inch, *outch, **ictm, **octm;
+  weed_init_f init_func;
+  weed_process_f process_func;
+  weed_deinit_f deinit_func;
+  int nict = 0, noct = 0, ret = WEED_SUCCESS;
+  if (!filt) { fprintf(stderr, "refhost: filter '%s' not found\n", fname); return -100; }
+  ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
+  octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
+  if (nict < 1 || noct < 1) return -102;
+  inst = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
+  weed_set_plantptr_value(inst, WEED_LEAF_FILTER_CLASS, filt);
+  inch = mk_channel(ictm[0], pal, w, h, istrides[0], src[0]);
+  outch = mk_channel(octm[0], pal, w, h, ostrides[0], dst[0]);
+  weed_set_voidptr_array(inch, WEED_LEAF_PIXEL_DATA, nplanes, (void **)src);
+  weed_set_int_array(inch, WEED_LEAF_ROWSTRIDES, nplanes, (int32_t *)istrides);
+  weed_set_voidptr_array(outch, WEED_LEAF_PIXEL_DATA, nplanes, (void **)dst);
+  weed_set_int_array(outch, WEED_LEAF_ROWSTRIDES, nplanes, (int32_t *)ostrides);
+  weed_set_int_value(inch, WEED_LEAF_YUV_CLAMPING, clamping);
+  weed_set_int_value(outch, WEED_LEAF_YUV_CLAMPING, clamping);
+  weed_set_plantptr_value(inst, WEED_LEAF_IN_CHANNELS, inch);
+  weed_set_plantptr_value(inst, WEED_LEAF_OUT_CHANNELS, outch);
+  init_func = (weed_init_f)weed_get_funcptr_value(filt, WEED_LEAF_INIT_FUNC, NULL);
+  process_func = (weed_process_f)weed_get_funcptr_value(filt, WEED_LEAF_PROCESS_FUNC, NULL);
+  deinit_func = (weed_deinit_f)weed_get_funcptr_value(filt, WEED_LEAF_DEINIT_FUNC, NULL);
+  if (init_func) ret = (*init_func)(inst);
+  if (ret == WEED_SUCCESS) {
+    ret = (*process_func)(inst, (weed_timecode_t)0);
+    if (deinit_func) (*deinit_func)(inst);
+  }
+  weed_plant_free(inch);
+  weed_plant_free(outch);
+  weed_plant_free(inst);
+  if (ictm) free(ictm);
+  if (octm) free(octm);
+  return ret;
+}

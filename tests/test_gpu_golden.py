@@ -124,3 +124,33 @@ def test_weed_effects_vs_reference_plugins(gpu):
             gpu.mirror(["mirrorx", "mirrory", "mirrorxy"].index(fn), dd, dd, mw, mh, ps)
             nbytes, rows = mw * ps, mh
         assert (host(dd)[:rows, :nbytes] == want[:rows, :nbytes]).all(), rec
+
+
+def test_stencils_vs_reference_plugins(gpu):
+    """softlight.c / edge.c outputs of the reference build, against lgpu_softlight / lgpu_edge directly"""
+    g = gu.load("stencils.npz")
+    n = 0
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        if f[0] == "sl":
+            pal, w, h, uncl = map(int, f[1:])
+            npl = 4 if pal == 545 else 3
+            src = [g[rec + "|i%d" % i] for i in range(npl)]
+            want = [g[rec + "|o%d" % i] for i in range(npl)]
+            dst = [dev(np.full_like(a, 0x5A)) for a in src]
+            gpu.softlight([dev(a) for a in src], dst, w, h, pal, uncl)
+            cw = w >> 1 if pal in (512, 513, 522) else w
+            ch = h >> 1 if pal in (512, 513) else h
+            dims = [(w, h), (cw, ch), (cw, ch), (w, h)]
+            for i in range(npl):
+                assert (host(dst[i])[:dims[i][1], :dims[i][0]] == want[i][:dims[i][1], :dims[i][0]]).all(), (rec, i)
+        else:
+            pal, mode, inplace, w, h = map(int, f[1:])
+            ps = 3 if pal <= 2 else 4
+            a, d0, want = g[rec + "|a"], g[rec + "|d"], g[rec + "|o"]
+            d = dev(d0)
+            gpu.edge(d if inplace else dev(a), d, w, h, pal, mode)
+            assert (host(d)[:h, :w * ps] == want[:h, :w * ps]).all(), rec
+        n += 1
+    assert n == 50
+

@@ -278,6 +278,46 @@ def test_mirror(gpu, orc, psize, mode):
             assert_same(host(d), want, w, h, psize, "mirror mode=%d %dx%d inplace=%d" % (mode, w, h, inplace))
 
 
+# ---------------------------------------------------------------------------------------------- F6 stencils
+@pytest.mark.parametrize("palette", [544, 545, 522, 512, 513])
+def test_softlight(gpu, orc, palette):
+    rng = np.random.default_rng(1500 + palette)
+    for (w, h) in [(20, 9), (64, 16), (66, 34), (130, 50), (4, 3), (258, 33)]:
+        for unclamped in (0, 1):
+            cw = w >> 1 if palette in (512, 513, 522) else w
+            ch = h >> 1 if palette in (512, 513) else h
+            dims = [(w, h), (cw, ch), (cw, ch)] + ([(w, h)] if palette == 545 else [])
+            src = [frame(rng, a, b, 1) for (a, b) in dims]
+            want = np.full_like(src[0], 0x5A)
+            orc.orc_softlight_y(P(src[0]), src[0].strides[0], P(want), want.strides[0], w, h, unclamped)
+            dst = [dev(np.full_like(a, 0x5A)) for a in src]
+            gpu.softlight([dev(a) for a in src], dst, w, h, palette, unclamped)
+            assert_same(host(dst[0]), want, w, h, 1, "softlight Y pal=%d %dx%d uncl=%d" % (palette, w, h, unclamped))
+            for i in range(1, len(dims)):      # chroma / alpha planes are copies (softlight.c:143-151)
+                assert_same(host(dst[i]), src[i], dims[i][0], dims[i][1], 1, "softlight plane %d" % i)
+
+
+@pytest.mark.parametrize("palette", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_edge(gpu, orc, palette, mode):
+    rng = np.random.default_rng(1600 + 10 * palette + mode)
+    ps = 3 if palette <= 2 else 4
+    for (w, h) in [(18, 8), (64, 16), (70, 37), (131, 50), (4, 4), (5, 5), (200, 120)]:
+        for inplace in (0, 1):
+            s = frame(rng, w, h, ps)
+            # smooth structure under the noise so that the histogram is not flat
+            yy, xx = np.mgrid[0:h, 0:w]
+            for c in range(ps):
+                s[:, c:w * ps:ps] = ((s[:, c:w * ps:ps] >> 3) + (96 * ((xx // 9 + yy // 7 + c) % 2)).astype(np.uint8) + 40).astype(np.uint8)
+            d0 = s.copy() if inplace else rng.integers(0, 256, s.shape, dtype=np.uint8)
+            want = d0.copy()
+            m16 = np.zeros(w * h, np.int16)
+            orc.orc_edge(P(want) if inplace else P(s), s.strides[0], P(want), want.strides[0], w, h, palette, mode, P(m16), inplace)
+            d = dev(d0)
+            gpu.edge(d if inplace else dev(s), d, w, h, palette, mode)
+            assert_same(host(d), want, w, h, ps, "edge pal=%d mode=%d %dx%d inplace=%d" % (palette, mode, w, h, inplace))
+
+
 # ---------------------------------------------------------------------------------------------- K7 / B1 (own spec)
 @pytest.mark.parametrize("psize", [4, 3, 1])
 def test_resize(gpu, orc, psize):

@@ -143,3 +143,36 @@ def test_weed_plugins(orc):
         assert (got[:rows, :nbytes] == want[:rows, :nbytes]).all(), rec
         n += 1
     assert n == 243
+
+
+def stencil_dims(pal, w, h):
+    cw = w >> 1 if pal in (512, 513, 522) else w
+    ch = h >> 1 if pal in (512, 513) else h
+    return [(w, h), (cw, ch), (cw, ch)] + ([(w, h)] if pal == 545 else [])
+
+
+def test_stencil_plugins(orc):
+    """softlight.c / edge.c fixtures (tests/golden/stencils.npz)"""
+    g = gu.load("stencils.npz")
+    n = 0
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        if f[0] == "sl":
+            pal, w, h, uncl = map(int, f[1:])
+            src, want = g[rec + "|i0"], g[rec + "|o0"]
+            got = np.full_like(src, 0x5A)
+            orc.orc_softlight_y(P(src), src.strides[0], P(got), got.strides[0], w, h, uncl)
+            assert (got[:h, :w] == want[:h, :w]).all(), rec
+            for i, (cw, ch) in enumerate(stencil_dims(pal, w, h)[1:], 1):
+                assert (g[rec + "|o%d" % i][:ch, :cw] == g[rec + "|i%d" % i][:ch, :cw]).all(), rec
+        else:
+            pal, mode, inplace, w, h = map(int, f[1:])
+            ps = 3 if pal <= 2 else 4
+            a, d0, want = g[rec + "|a"], g[rec + "|d"], g[rec + "|o"]
+            got = d0.copy()
+            m16 = np.zeros(w * h, np.int16)
+            orc.orc_edge(P(got) if inplace else P(a), a.strides[0], P(got), got.strides[0], w, h, pal, mode, P(m16), inplace)
+            assert (got[:h, :w * ps] == want[:h, :w * ps]).all(), rec
+        n += 1
+    assert n == 50
+

@@ -22,8 +22,8 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 16
-    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors"):
+    assert len(ours) == 18
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
@@ -100,3 +100,34 @@ def test_sliced_calls_equal_one_call():
     H.run(OURS, "chroma blend", 3, w, h, [s1, s2], a, [po.p_int(140)], nslices=1)
     H.run(OURS, "chroma blend", 3, w, h, [s1, s2], b, [po.p_int(140)], nslices=3)
     assert (a == b).all()
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_stencil_records_through_the_plugin():
+    """softlight.c / edge.c fixtures through weed_setup() / process_func of livesgpu_fx.so"""
+    H = po.RefHost()
+    g = gu.load("stencils.npz")
+    n = 0
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        if f[0] == "sl":
+            pal, w, h, uncl = map(int, f[1:])
+            npl = 4 if pal == 545 else 3
+            src = [g[rec + "|i%d" % i].copy() for i in range(npl)]
+            dst = [np.full_like(a, 0x5A) for a in src]
+            H.run_planar(OURS, "softlight", pal, w, h, src, dst, uncl)
+            cw = w >> 1 if pal in (512, 513, 522) else w
+            ch = h >> 1 if pal in (512, 513) else h
+            dims = [(w, h), (cw, ch), (cw, ch), (w, h)]
+            for i in range(npl):
+                assert (dst[i][:dims[i][1], :dims[i][0]] == g[rec + "|o%d" % i][:dims[i][1], :dims[i][0]]).all(), (rec, i)
+        else:
+            pal, mode, inplace, w, h = map(int, f[1:])
+            ps = PSIZE[pal]
+            a, d = g[rec + "|a"].copy(), g[rec + "|d"].copy()
+            H.run(OURS, "edge detect", pal, w, h, [d if inplace else a], d, [po.p_int(mode)])
+            assert (d[:h, :w * ps] == g[rec + "|o"][:h, :w * ps]).all(), rec
+        n += 1
+    assert n == 50
+
