@@ -130,6 +130,26 @@ int lgpu_blend_multi(int type, const uint8_t *src1_d, int irow1, const uint8_t *
 int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d,
                   int orow, int width, int height, int is_bgr, double delta, double opac,
                   int col_r, int col_g, int col_b, void *stream);
+/* K4: packed RGB family -> YUV family (src/colourspace.c:5129-6440; pixel maths :2119-2192), PB_QUALITY_MED rounding.
+   in_order 0 RGB, 1 BGR, 2 ARGB; in_alpha: 4-byte source pixels (implied for ARGB).
+   out_fmt  0 packed YUV888 / YUVA8888 (out_alpha)     convert_{rgb,bgr,argb}_to_yuv_frame
+            1 planar YUV444P / YUVA4444P (out_alpha)   convert_{rgb,bgr,argb}_to_yuvp_frame
+            2 UYVY, 3 YUYV                             convert_{rgb,bgr,argb}_to_{uyvy,yuyv}_frame (no gamma LUT)
+            4 YUV420P, 5 YUV422P                       convert_{rgb,bgr}_to_yuv420_frame
+   dst_d / orow: one entry per destination plane.  which_tables: bit 0 unclamped, bit 1 BT.709 (4:2:0 / 4:2:2 only --
+   the reference's other entry points are YCbCr only).  The reference's sampling is kept: U of the first and V of the
+   second pixel of a pair, YUYV without the upper chroma clamp, 4:2:0 chroma row k = avg_chroma(row 2k+2, row 2k+1).
+   LGPU_E_UNSUPPORTED for ARGB32 -> 4:2:0 / 4:2:2 (the reference reads the wrong bytes there). */
+int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
+                    uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables,
+                    void *stream);
+/* K3: YUV family -> packed RGB family (src/colourspace.c:2750-3258, :6616-7102, :7200-7498; pixel maths :2345-2459).
+   in_fmt 0 packed YUV888 / YUVA8888 (in_alpha), 1 planar YUV444P / YUVA4444P (in_alpha), 2 UYVY, 3 YUYV (width in
+   pixels); planar 4:2:0 / 4:2:2 sources: lgpu_yuv420p_to_rgb.  out_order 0 RGB, 1 BGR, 2 ARGB; out_alpha: 4-byte
+   output (implied for ARGB); alpha = source alpha or 255.  which_tables as above (BT.709 for in_fmt 0 only).
+   LGPU_E_UNSUPPORTED for planar -> ARGB32 / BGR24 (reference row arithmetic broken, :7475-7476, :7313). */
+int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                    uint8_t *dst_d, int orow, int out_order, int out_alpha, int which_tables, void *stream);
 /* "softlight": lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV (palette 544 YUV444P, 545 YUVA4444P,
    522 YUV422P, 512 YUV420P, 513 YVU420P): gradient-magnitude highlight mixed into plane 0 (frame border copied), the
    other planes are copied.  unclamped != 0: luma range 0..255, else 16..235 (the channel's YUV_clamping leaf).

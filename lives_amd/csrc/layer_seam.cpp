@@ -38,10 +38,11 @@ void set_int(weed_plant_t *p, const char *k, int v) { int32_t x = v; g_api.leaf_
 void set_bool(weed_plant_t *p, const char *k, int v) { int32_t x = v; g_api.leaf_set(p, k, WEED_SEED_BOOLEAN, 1, &x); }
 
 bool pal_is_rgb(int p) { return p >= WEED_PALETTE_RGB24 && p <= WEED_PALETTE_ARGB32; }
-bool pal_is_planar_yuv(int p) { return p == WEED_PALETTE_YUV420P || p == WEED_PALETTE_YVU420P || p == WEED_PALETTE_YUV422P || p == WEED_PALETTE_YUV444P; }
+bool pal_is_planar_yuv(int p) { return p == WEED_PALETTE_YUV420P || p == WEED_PALETTE_YVU420P || p == WEED_PALETTE_YUV422P || p == WEED_PALETTE_YUV444P || p == WEED_PALETTE_YUVA4444P; }
+bool pal_is_444(int p) { return p == WEED_PALETTE_YUV444P || p == WEED_PALETTE_YUVA4444P; }
 bool pal_alpha_first(int p) { return p == WEED_PALETTE_ARGB32; }
 bool pal_alpha_last(int p) { return p == WEED_PALETTE_RGBA32 || p == WEED_PALETTE_BGRA32; }
-bool pal_has_alpha(int p) { return pal_alpha_first(p) || pal_alpha_last(p); }
+bool pal_has_alpha(int p) { return pal_alpha_first(p) || pal_alpha_last(p) || p == WEED_PALETTE_YUVA8888 || p == WEED_PALETTE_YUVA4444P; }
 bool pal_red_first(int p) { return p == WEED_PALETTE_RGB24 || p == WEED_PALETTE_RGBA32 || p == WEED_PALETTE_ARGB32; }
 int pal_psize(int p) { return (p == WEED_PALETTE_RGB24 || p == WEED_PALETTE_BGR24) ? 3 : pal_is_rgb(p) ? 4 : pal_is_planar_yuv(p) ? 1 : 0; }
 
@@ -55,8 +56,8 @@ struct Layer {
   bool contiguous;
 };
 
-int plane_w(const Layer &l, int p) { return (p == 0 || l.pal == WEED_PALETTE_YUV444P) ? l.width : l.width >> 1; }
-int plane_h(const Layer &l, int p) { return (p == 0 || l.pal == WEED_PALETTE_YUV444P || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1; }
+int plane_w(const Layer &l, int p) { return (p == 0 || pal_is_444(l.pal)) ? l.width : l.width >> 1; }
+int plane_h(const Layer &l, int p) { return (p == 0 || pal_is_444(l.pal) || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1; }
 
 bool read_layer(weed_plant_t *plant, Layer *l) {
   if (!plant || !bound()) return false;
@@ -95,7 +96,7 @@ bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np) 
   if (np->n < 1) return false;
   size_t tot = 0;
   for (int i = 0; i < np->n; i++) {
-    const int h = (i == 0 || pal == WEED_PALETTE_YUV444P || pal == WEED_PALETTE_YUV422P) ? height : height >> 1;
+    const int h = (i == 0 || pal_is_444(pal) || pal == WEED_PALETTE_YUV422P) ? height : height >> 1;
     np->sz[i] = (size_t)np->rs[i] * h;
     tot += np->sz[i];
   }
@@ -165,6 +166,67 @@ int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
   return LGPU_SWAP3PREALPHA;
 }
 
+int k3_fmt(int pal) {
+  switch (pal) {
+  case WEED_PALETTE_YUV888: case WEED_PALETTE_YUVA8888: return 0;
+  case WEED_PALETTE_YUV444P: case WEED_PALETTE_YUVA4444P: return 1;
+  case WEED_PALETTE_UYVY: return 2;
+  case WEED_PALETTE_YUYV: return 3;
+  default: return -1;
+  }
+}
+int k4_fmt(int pal) {
+  switch (pal) {
+  case WEED_PALETTE_YUV420P: case WEED_PALETTE_YVU420P: return 4;
+  case WEED_PALETTE_YUV422P: return 5;
+  default: return k3_fmt(pal);
+  }
+}
+
+// K4 on a layer: the RGB24 / BGR24 / RGBA32 / BGRA32 / ARGB32 cases of src/colourspace.c:12559-12935 plus conv_done (:13860-13893)
+lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outpl, int oclamping, int osubspace, int tgt_gamma) {
+  const int fmt = k4_fmt(outpl);
+  if (fmt < 0) return 0;
+  if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return 0;   // LUT16 variants: CPU body
+  const int order = pal_alpha_first(l.pal) ? 2 : pal_red_first(l.pal) ? 0 : 1;
+  if (order == 2 && fmt >= 4) return 0;                                     // reference-broken (:6353), declined
+  const int in_alpha = pal_has_alpha(l.pal) ? 1 : 0, out_alpha = pal_has_alpha(outpl) ? 1 : 0;
+  int width = l.width, height = l.height;
+  if (fmt >= 2 && (width & 1)) return 0;
+  if (fmt == 4) { width = (width >> 1) << 1; height = (height >> 1) << 1; }       // create_empty_pixel_data :11601-11603
+  if (width < 2 || height < 1) return 0;
+  // subspace argument as the dispatcher passes it: some cases hand WEED_YUV_SAMPLING_DEFAULT (= 0 -> YCbCr) to the subspace slot
+  const bool use_osub = (fmt == 4 && l.pal != WEED_PALETTE_RGB24) || (fmt == 5 && l.pal == WEED_PALETTE_RGB24);
+  const int which = (oclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | ((fmt >= 4 && use_osub && osubspace == WEED_YUV_SUBSPACE_BT709) ? 2 : 0);
+  const int lwidth = (fmt == 2 || fmt == 3) ? width >> 1 : width;                   // UYVY / YUYV layers count macropixels
+  NewPlanes np;
+  if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
+  const size_t ibytes = (size_t)l.rs[0] * l.height;
+  uint8_t *d_in = t_scr.get(0, ibytes);
+  bool ok = d_in && up(d_in, l.pd[0], ibytes);
+  uint8_t *ddst[4] = {nullptr, nullptr, nullptr, nullptr};
+  int ors[4] = {0, 0, 0, 0};
+  for (int p = 0; p < np.n && ok; p++) {
+    ddst[p] = t_scr.get(3 + p, np.sz[p]);
+    ors[p] = np.rs[p];
+    ok = ddst[p] && up(ddst[p], np.pd[p], np.sz[p]);           // calloc'd padding stays as the host made it
+  }
+  ok = ok && lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr) == LGPU_OK;
+  for (int p = 0; p < np.n && ok; p++) ok = down(np.pd[p], ddst[p], np.sz[p]);
+  ok = ok && sync();
+  if (!ok) { pfree(np.pd[0]); return 0; }
+  int flags = l.flags;
+  if (in_alpha && !out_alpha) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  free_planes(l);
+  if (outpl == WEED_PALETTE_YVU420P) { uint8_t *t = np.pd[1]; np.pd[1] = np.pd[2]; np.pd[2] = t; }   // swap_chroma_planes (:13890)
+  commit_planes(layer, outpl, lwidth, height, np);
+  if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
+  set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);
+  set_int(layer, WEED_LEAF_YUV_SUBSPACE, l.gamma == WEED_GAMMA_BT709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR);
+  if (fmt >= 4 || !has_leaf(layer, WEED_LEAF_YUV_SAMPLING)) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);
+  return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,7 +290,10 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
   if (!ready() || !read_layer(layer, &l)) return 0;
   const int inpl = l.pal;
   if (inpl == outpl) return 1;                                           // :12265
-  if (!pal_is_rgb(outpl)) return 0;                                      // RGB -> YUV / YUV -> YUV: not on the GPU path yet
+  if (!pal_is_rgb(outpl)) {
+    if (pal_is_rgb(inpl)) return rgb_layer_to_yuv(layer, l, outpl, oclamping, osubspace, tgt_gamma);
+    return 0;                                                            // YUV -> YUV repacks: not on the GPU path yet
+  }
   const int iclamping = l.clamping >= 0 ? l.clamping : oclamping;        // :12216-12218
 
   // gamma decision (:12311-12332): only an explicit target changes the transfer function here
@@ -251,7 +316,8 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
   if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
 
   NewPlanes np;
-  if (!alloc_planes(outpl, l.width, l.height, 0, &np)) return 0;
+  const int owidth = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV) ? l.width * 2 : l.width;   // macropixels -> pixels (:13010)
+  if (!alloc_planes(outpl, owidth, l.height, 0, &np)) return 0;
   const size_t obytes = (size_t)np.rs[0] * l.height;
   uint8_t *d_out = t_scr.get(3, obytes);
   bool ok = d_out != nullptr;
@@ -273,11 +339,27 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     ok = dy && du && dv && up(dy, l.pd[0], yb) && up(du, l.pd[iu], ub) && up(dv, l.pd[iv], vb) &&
          lgpu_yuv420p_to_rgb(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
                              inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, lutp, 0, nullptr) == LGPU_OK;
+  } else if (ok && k3_fmt(inpl) >= 0) {
+    // K3: packed / planar 4:4:4, UYVY, YUYV -> RGB family (src/colourspace.c:12937-13860 cases); no inline gamma on these paths
+    const int fmt = k3_fmt(inpl), in_alpha = (inpl == WEED_PALETTE_YUVA8888 || inpl == WEED_PALETTE_YUVA4444P);
+    const int pxw = (fmt >= 2) ? l.width * 2 : l.width;                     // UYVY / YUYV layers count macropixels
+    const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
+    const int which = (iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | ((fmt == 0 && l.subspace == WEED_YUV_SUBSPACE_BT709) ? 2 : 0);
+    ok = !lutp && (fmt < 2 || np.rs[0] >= pxw * pal_psize(outpl));
+    const uint8_t *dsrc[4] = {nullptr, nullptr, nullptr, nullptr};
+    int irs[4] = {0, 0, 0, 0};
+    for (int p = 0; p < l.nplanes && ok; p++) {
+      const size_t b = (size_t)l.rs[p] * l.height;
+      uint8_t *d = t_scr.get(p == 0 ? 0 : p + 3, b);
+      ok = d && up(d, l.pd[p], b);
+      dsrc[p] = d; irs[p] = l.rs[p];
+    }
+    ok = ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, nullptr) == LGPU_OK;
   } else ok = false;
   ok = ok && down(np.pd[0], d_out, obytes) && sync();
   if (!ok) { pfree(np.pd[0]); return 0; }                                  // memfail: layer untouched
   free_planes(l);
-  commit_planes(layer, outpl, l.width, l.height, np);
+  commit_planes(layer, outpl, owidth, l.height, np);
   if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
   if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
   g_api.leaf_delete(layer, WEED_LEAF_YUV_CLAMPING);                          // conv_done (:13881-13884)

@@ -1,0 +1,257 @@
+// palette.hip -- the rest of the palette matrix (SURVEY 8a row P1 / 8f "next" 2):
+//   K4  packed RGB family -> YUV888 / YUVA8888 / YUV(A)444(4)P / UYVY / YUYV / YUV420P / YUV422P
+//       src/colourspace.c:5129-6440, pixel maths :2119-2192
+//   K3  YUV888 / YUVA8888 / YUV(A)444(4)P / UYVY / YUYV -> packed RGB family
+//       src/colourspace.c:2750-3258, :6616-7102, :7200-7498, pixel maths :2345-2459
+// All of it is per-pixel table arithmetic: HBM-bound byte work, lane = one pixel pair, tables staged in LDS.
+#include "lgpu_common.h"
+
+namespace lgpu {
+
+struct PalArgs {
+  const uint8_t *src[4];
+  uint8_t *dst[4];
+  int irow[4], orow[4];
+  int width, height;
+  int order, alpha_in, fmt, alpha_out;
+  int unclamped;
+  const int32_t *tables;      // rgb2yuv [9][256] or yuv2rgb [5][256] of the selected (clamping, subspace)
+};
+
+// ---- K4 -------------------------------------------------------------------------------------------------------------
+struct R2Y {
+  const int32_t *t;           // LDS [9][256]
+  int min_y, max_y, min_uv, max_uv;
+  // rgb2yuv (:2119-2127): short a = spc_rnd(sum) (>> 16 at PB_QUALITY_MED, :832-843); upper clamp first, then lower
+  __device__ __forceinline__ int Y(int r, int g, int b) const {
+    const int a = (short)((t[r] + t[256 + g] + t[512 + b]) >> 16);
+    return a > max_y ? max_y : a < min_y ? min_y : a;
+  }
+  __device__ __forceinline__ int Uraw(int r, int g, int b) const { return (short)((t[768 + r] + t[1024 + g] + t[1280 + b]) >> 16); }
+  __device__ __forceinline__ int Vraw(int r, int g, int b) const { return (short)((t[1536 + r] + t[1792 + g] + t[2048 + b]) >> 16); }
+  __device__ __forceinline__ int cuv(int a) const { return a > max_uv ? max_uv : a < min_uv ? min_uv : a; }
+};
+
+// init_average (:190-216): cavgu is integer, cavgc mixes float and double exactly as written there
+__device__ __forceinline__ int cavg(int clamped, int x, int y) {
+  if (!clamped) {
+    const int c = (((x - 128) + (y - 128)) >> 1) + 128;
+    return c > 255 ? 255 : c < 0 ? 0 : c;
+  }
+  const float fa = (float)__ddiv_rn(__dmul_rn((double)(float)(x - 128), 255.), 244.);
+  const float fb = (float)__ddiv_rn(__dmul_rn((double)(float)(y - 128), 255.), 244.);
+  const float fc = (float)__dadd_rn(__ddiv_rn(__dmul_rn((double)__fadd_rn(fa, fb), 224.), 512.), 128.);
+  return fc > 240.f ? 240 : fc < 16.f ? 16 : (int)fc;
+}
+
+__device__ __forceinline__ void load_rgb(const uint8_t *p, int order, int &r, int &g, int &b) {
+  if (order == 0) { r = p[0]; g = p[1]; b = p[2]; }
+  else if (order == 1) { r = p[2]; g = p[1]; b = p[0]; }
+  else { r = p[1]; g = p[2]; b = p[3]; }
+}
+
+template <int ORDER, int FMT>
+__global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
+  __shared__ int32_t s_t[9 * 256];
+  for (int i = threadIdx.x; i < 9 * 256; i += kBlock) s_t[i] = a.tables[i];
+  __syncthreads();
+  R2Y c;
+  c.t = s_t;
+  if (a.unclamped) { c.min_y = c.min_uv = 0; c.max_y = c.max_uv = 255; }
+  else { c.min_y = c.min_uv = 16; c.max_y = 235; c.max_uv = 240; }                 // set_conversion_arrays :361-370
+  const int ips = (ORDER == 2 || a.alpha_in) ? 4 : 3;
+  const int npairs = a.width >> 1;                                                     // an odd last pixel is never converted (:5761)
+  const int px = blockIdx.x * kBlock + threadIdx.x;
+  if (px >= npairs) return;
+  const int x = px * 2;
+  // 4:2:0 walks chroma rows (two luma rows each), everything else luma rows
+  const int nrows = FMT == 4 ? a.height >> 1 : a.height;
+  for (int yy = blockIdx.y; yy < nrows; yy += gridDim.y) {
+    if (FMT == 4) {
+      // chroma row k = avg_chroma(row 2k+2, row 2k+1); the last one is row 2k+1 alone (:6302-6315 at compact strides)
+      const int k = yy;
+      int cu1 = 0, cv1 = 0;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint8_t *s = a.src[0] + (size_t)(2 * k + j) * a.irow[0] + (size_t)x * ips;
+        int r0, g0, b0, r1, g1, b1;
+        load_rgb(s, ORDER, r0, g0, b0);
+        load_rgb(s + ips, ORDER, r1, g1, b1);
+        uint8_t *dy = a.dst[0] + (size_t)(2 * k + j) * a.orow[0] + x;
+        dy[0] = (uint8_t)c.Y(r0, g0, b0); dy[1] = (uint8_t)c.Y(r1, g1, b1);
+        if (j == 1) { cu1 = c.cuv(c.Uraw(r0, g0, b0)); cv1 = c.cuv(c.Vraw(r1, g1, b1)); }
+      }
+      if (2 * k + 2 < a.height) {
+        const uint8_t *s = a.src[0] + (size_t)(2 * k + 2) * a.irow[0] + (size_t)x * ips;
+        int r0, g0, b0, r1, g1, b1;
+        load_rgb(s, ORDER, r0, g0, b0);
+        load_rgb(s + ips, ORDER, r1, g1, b1);
+        cu1 = cavg(!a.unclamped, c.cuv(c.Uraw(r0, g0, b0)), cu1);
+        cv1 = cavg(!a.unclamped, c.cuv(c.Vraw(r1, g1, b1)), cv1);
+      }
+      a.dst[1][(size_t)k * a.orow[1] + px] = (uint8_t)cu1;
+      a.dst[2][(size_t)k * a.orow[2] + px] = (uint8_t)cv1;
+      continue;
+    }
+    const int y = yy;
+    const uint8_t *s = a.src[0] + (size_t)y * a.irow[0] + (size_t)x * ips;
+    int r0, g0, b0, r1, g1, b1;
+    load_rgb(s, ORDER, r0, g0, b0);
+    load_rgb(s + ips, ORDER, r1, g1, b1);
+    const int y0 = c.Y(r0, g0, b0), y1 = c.Y(r1, g1, b1);
+    if (FMT <= 1) {
+      const int al0 = ORDER == 2 ? s[0] : ips == 4 ? s[3] : 255, al1 = ORDER == 2 ? s[ips] : ips == 4 ? s[ips + 3] : 255;
+      const int u0 = c.cuv(c.Uraw(r0, g0, b0)), v0 = c.cuv(c.Vraw(r0, g0, b0));
+      const int u1 = c.cuv(c.Uraw(r1, g1, b1)), v1 = c.cuv(c.Vraw(r1, g1, b1));
+      if (FMT == 0) {
+        const int ops = a.alpha_out ? 4 : 3;
+        uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)x * ops;
+        d[0] = (uint8_t)y0; d[1] = (uint8_t)u0; d[2] = (uint8_t)v0;
+        if (a.alpha_out) d[3] = (uint8_t)al0;
+        d[ops] = (uint8_t)y1; d[ops + 1] = (uint8_t)u1; d[ops + 2] = (uint8_t)v1;
+        if (a.alpha_out) d[ops + 3] = (uint8_t)al1;
+      } else {
+        uint8_t *dy = a.dst[0] + (size_t)y * a.orow[0] + x, *du = a.dst[1] + (size_t)y * a.orow[1] + x, *dv = a.dst[2] + (size_t)y * a.orow[2] + x;
+        dy[0] = (uint8_t)y0; dy[1] = (uint8_t)y1; du[0] = (uint8_t)u0; du[1] = (uint8_t)u1; dv[0] = (uint8_t)v0; dv[1] = (uint8_t)v1;
+        if (a.alpha_out) { uint8_t *da = a.dst[3] + (size_t)y * a.orow[3] + x; da[0] = (uint8_t)al0; da[1] = (uint8_t)al1; }
+      }
+    } else {
+      // rgb2uyvy / rgb2yuyv (:2162-2192): U of the first pixel, V of the SECOND, no averaging
+      const int ur = c.Uraw(r0, g0, b0), vr = c.Vraw(r1, g1, b1);
+      if (FMT == 2) {
+        *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + (size_t)px * 4) =
+            (uint32_t)c.cuv(ur) | ((uint32_t)y0 << 8) | ((uint32_t)c.cuv(vr) << 16) | ((uint32_t)y1 << 24);
+      } else if (FMT == 3) {
+        // rgb2yuyv lost its `else`: only the lower chroma clamp survives (:2183-2191)
+        const uint32_t u = (uint32_t)(ur < c.min_uv ? c.min_uv : ur) & 0xFF, v = (uint32_t)(vr < c.min_uv ? c.min_uv : vr) & 0xFF;
+        *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + (size_t)px * 4) = (uint32_t)y0 | (u << 8) | ((uint32_t)y1 << 16) | (v << 24);
+      } else {       // 4:2:2 planar
+        uint8_t *dy = a.dst[0] + (size_t)y * a.orow[0] + x;
+        dy[0] = (uint8_t)y0; dy[1] = (uint8_t)y1;
+        a.dst[1][(size_t)y * a.orow[1] + px] = (uint8_t)c.cuv(ur);
+        a.dst[2][(size_t)y * a.orow[2] + px] = (uint8_t)c.cuv(vr);
+      }
+    }
+  }
+}
+
+// ---- K3 -------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_rgb(uint8_t *d, int order, int ops, const int32_t *t, int Y, int U, int V, int A) {
+  // yuv2rgb_int (:2345-2349): CLAMP0255f(spc_rnd(RGB_Y[y] + R_Cr[v])) ...
+  const int32_t yy = t[Y];
+  const int r = clamp255((yy + t[256 + V]) >> 16), g = clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = clamp255((yy + t[1024 + U]) >> 16);
+  if (order == 0) { d[0] = (uint8_t)r; d[1] = (uint8_t)g; d[2] = (uint8_t)b; if (ops == 4) d[3] = (uint8_t)A; }
+  else if (order == 1) { d[0] = (uint8_t)b; d[1] = (uint8_t)g; d[2] = (uint8_t)r; if (ops == 4) d[3] = (uint8_t)A; }
+  else { d[0] = (uint8_t)A; d[1] = (uint8_t)r; d[2] = (uint8_t)g; d[3] = (uint8_t)b; }
+}
+
+template <int FMT, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
+  __shared__ int32_t s_t[5 * 256];
+  for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
+  __syncthreads();
+  const int ops = (ORDER == 2 || a.alpha_out) ? 4 : 3;
+  const int npairs = (a.width + 1) >> 1;
+  const int px = blockIdx.x * kBlock + threadIdx.x;
+  if (px >= npairs) return;
+  const int x = px * 2;
+  const bool two = x + 1 < a.width;
+  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+    int Y0, U0, V0, A0 = 255, Y1 = 0, U1 = 0, V1 = 0, A1 = 255;
+    if (FMT == 0) {
+      const int ips = a.alpha_in ? 4 : 3;
+      const uint8_t *p = a.src[0] + (size_t)y * a.irow[0] + (size_t)x * ips;
+      Y0 = p[0]; U0 = p[1]; V0 = p[2]; if (a.alpha_in) A0 = p[3];
+      if (two) { Y1 = p[ips]; U1 = p[ips + 1]; V1 = p[ips + 2]; if (a.alpha_in) A1 = p[ips + 3]; }
+    } else if (FMT == 1) {
+      const uint8_t *py = a.src[0] + (size_t)y * a.irow[0] + x, *pu = a.src[1] + (size_t)y * a.irow[1] + x, *pv = a.src[2] + (size_t)y * a.irow[2] + x;
+      Y0 = py[0]; U0 = pu[0]; V0 = pv[0];
+      if (two) { Y1 = py[1]; U1 = pu[1]; V1 = pv[1]; }
+      if (a.alpha_in) { const uint8_t *pa = a.src[3] + (size_t)y * a.irow[3] + x; A0 = pa[0]; if (two) A1 = pa[1]; }
+    } else {
+      const uint32_t m = *reinterpret_cast<const uint32_t *>(a.src[0] + (size_t)y * a.irow[0] + (size_t)px * 4);
+      if (FMT == 2) { U0 = m & 0xFF; Y0 = (m >> 8) & 0xFF; V0 = (m >> 16) & 0xFF; Y1 = m >> 24; }      // uyvy2rgb :2410-2415
+      else { Y0 = m & 0xFF; U0 = (m >> 8) & 0xFF; Y1 = (m >> 16) & 0xFF; V0 = m >> 24; }                   // yuyv2rgb :2418-2423
+      U1 = U0; V1 = V0;
+    }
+    uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)x * ops;
+    put_rgb(d, ORDER, ops, s_t, Y0, U0, V0, A0);
+    if (two) put_rgb(d + ops, ORDER, ops, s_t, Y1, U1, V1, A1);
+  }
+}
+
+}  // namespace lgpu
+
+using namespace lgpu;
+
+extern "C" int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
+                               uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && orow && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(in_order >= 0 && in_order <= 2, "in_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
+  LGPU_REQUIRE(out_fmt >= 0 && out_fmt <= 5, "out_fmt must be 0 (packed 4:4:4), 1 (planar 4:4:4), 2 (UYVY), 3 (YUYV), 4 (4:2:0 planar), 5 (4:2:2 planar)");
+  LGPU_REQUIRE(out_fmt < 2 || !(width & 1), "subsampled targets need an even width");
+  LGPU_REQUIRE(out_fmt != 4 || !(height & 1), "4:2:0 needs an even height");
+  LGPU_REQUIRE(out_fmt >= 4 || !(which_tables & 2), "only the 4:2:0 / 4:2:2 conversions take a BT.709 subspace (the reference's other entry points are YCbCr only)");
+  if (out_fmt >= 4 && in_order == 2) { set_error("ARGB32 -> planar 4:2:0 / 4:2:2 is declined: the reference reads the wrong bytes there (src/colourspace.c:6353)"); return LGPU_E_UNSUPPORTED; }
+  PalArgs a;
+  __builtin_memset(&a, 0, sizeof a);
+  const int ips = (in_order == 2 || in_alpha) ? 4 : 3;
+  LGPU_REQUIRE(irow >= width * ips, "rowstride smaller than a row");
+  const int nplanes = out_fmt == 0 ? 1 : out_fmt == 1 ? (out_alpha ? 4 : 3) : out_fmt <= 3 ? 1 : 3;
+  for (int i = 0; i < nplanes; i++) { LGPU_REQUIRE(dst_d[i] && orow[i] > 0, "null destination plane"); a.dst[i] = dst_d[i]; a.orow[i] = orow[i]; }
+  if (out_fmt == 2 || out_fmt == 3) LGPU_REQUIRE(!(orow[0] & 3) && !(reinterpret_cast<uintptr_t>(dst_d[0]) & 3), "UYVY / YUYV rows must be 4-byte aligned");
+  a.src[0] = src_d; a.irow[0] = irow; a.width = width; a.height = height;
+  a.order = in_order; a.alpha_in = in_alpha; a.fmt = out_fmt; a.alpha_out = (out_fmt <= 1) ? out_alpha : 0;
+  a.unclamped = which_tables & 1;
+  a.tables = device_tables()->rgb2yuv[which_tables & 3];
+  const int npairs = width >> 1;
+  if (npairs == 0) return LGPU_OK;
+  const int nrows = out_fmt == 4 ? height >> 1 : height;
+  const dim3 grid(cdiv((unsigned)npairs, kBlock), (unsigned)(nrows < 2048 ? nrows : 2048));
+#define K4_CASE(O, F) case (O) * 8 + (F): hipLaunchKernelGGL((k_rgb_to_yuv<O, F>), grid, dim3(kBlock), 0, (hipStream_t)stream, a); break;
+  switch (in_order * 8 + out_fmt) {
+    K4_CASE(0, 0) K4_CASE(0, 1) K4_CASE(0, 2) K4_CASE(0, 3) K4_CASE(0, 4) K4_CASE(0, 5)
+    K4_CASE(1, 0) K4_CASE(1, 1) K4_CASE(1, 2) K4_CASE(1, 3) K4_CASE(1, 4) K4_CASE(1, 5)
+    K4_CASE(2, 0) K4_CASE(2, 1) K4_CASE(2, 2) K4_CASE(2, 3)
+  }
+#undef K4_CASE
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                               uint8_t *dst_d, int orow, int out_order, int out_alpha, int which_tables, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && irow && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(in_fmt >= 0 && in_fmt <= 3, "in_fmt must be 0 (packed 4:4:4), 1 (planar 4:4:4), 2 (UYVY) or 3 (YUYV); 4:2:0 / 4:2:2 planar: lgpu_yuv420p_to_rgb");
+  LGPU_REQUIRE(out_order >= 0 && out_order <= 2, "out_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
+  LGPU_REQUIRE(in_fmt < 2 || !(width & 1), "UYVY / YUYV need an even width");
+  LGPU_REQUIRE(in_fmt == 0 || !(which_tables & 2), "only the packed 4:4:4 conversions take a BT.709 subspace (the reference's other entry points are YCbCr only)");
+  if (in_fmt == 1 && (out_order == 2 || (out_order == 1 && !out_alpha))) {
+    set_error("planar 4:4:4 -> ARGB32 / BGR24 is declined: the reference's row arithmetic is broken there (src/colourspace.c:7475-7476, :7313)");
+    return LGPU_E_UNSUPPORTED;
+  }
+  PalArgs a;
+  __builtin_memset(&a, 0, sizeof a);
+  const int nplanes = in_fmt == 1 ? (in_alpha ? 4 : 3) : 1;
+  for (int i = 0; i < nplanes; i++) { LGPU_REQUIRE(src_d[i] && irow[i] > 0, "null source plane"); a.src[i] = src_d[i]; a.irow[i] = irow[i]; }
+  if (in_fmt >= 2) LGPU_REQUIRE(!(irow[0] & 3) && !(reinterpret_cast<uintptr_t>(src_d[0]) & 3), "UYVY / YUYV rows must be 4-byte aligned");
+  const int ops = (out_order == 2 || out_alpha) ? 4 : 3;
+  LGPU_REQUIRE(orow >= width * ops, "rowstride smaller than a row");
+  a.dst[0] = dst_d; a.orow[0] = orow; a.width = width; a.height = height;
+  a.order = out_order; a.alpha_in = (in_fmt <= 1) ? in_alpha : 0; a.fmt = in_fmt; a.alpha_out = out_alpha;
+  a.unclamped = which_tables & 1;
+  a.tables = device_tables()->yuv2rgb[which_tables & 3];
+  const dim3 grid(cdiv((unsigned)((width + 1) >> 1), kBlock), (unsigned)(height < 2048 ? height : 2048));
+#define K3_CASE(F, O) case (F) * 4 + (O): hipLaunchKernelGGL((k_yuv_to_rgb<F, O>), grid, dim3(kBlock), 0, (hipStream_t)stream, a); break;
+  switch (in_fmt * 4 + out_order) {
+    K3_CASE(0, 0) K3_CASE(0, 1) K3_CASE(0, 2) K3_CASE(1, 0) K3_CASE(1, 1) K3_CASE(2, 0) K3_CASE(2, 1) K3_CASE(2, 2)
+    K3_CASE(3, 0) K3_CASE(3, 1) K3_CASE(3, 2)
+  }
+#undef K3_CASE
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

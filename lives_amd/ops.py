@@ -99,6 +99,26 @@ def mirror(mode, src, dst, width, height, psize):
     lib.call("lgpu_mirror", mode, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
 
 
+def _plane_tables(planes):
+    n = len(planes)
+    pp = (ctypes.c_void_p * 4)(*([dptr(t) for t in planes] + [None] * (4 - n)))
+    ss = (ctypes.c_int * 4)(*([t.stride(0) for t in planes] + [0] * (4 - n)))
+    return pp, ss
+
+
+def rgb_to_yuv(src, dst_planes, width, height, in_order, in_alpha, out_fmt, out_alpha, which_tables):
+    """K4 (see include/lives_gpu.h): src 2-D uint8 device tensor, dst_planes list of 2-D uint8 device tensors"""
+    dp, ds = _plane_tables(dst_planes)
+    lib.call("lgpu_rgb_to_yuv", dptr(src), src.stride(0), width, height, in_order, int(in_alpha), ctypes.addressof(dp), ctypes.addressof(ds),
+             out_fmt, int(out_alpha), which_tables, stream_ptr())
+
+
+def yuv_to_rgb(src_planes, dst, width, height, in_fmt, in_alpha, out_order, out_alpha, which_tables):
+    sp, ss = _plane_tables(src_planes)
+    lib.call("lgpu_yuv_to_rgb", ctypes.addressof(sp), ctypes.addressof(ss), width, height, in_fmt, int(in_alpha), dptr(dst), dst.stride(0),
+             out_order, int(out_alpha), which_tables, stream_ptr())
+
+
 def softlight(src_planes, dst_planes, width, height, palette, unclamped):
     """planar YUV softlight (softlight.c): src_planes / dst_planes are lists of 2-D uint8 device tensors, one per plane"""
     n = len(src_planes)

@@ -575,6 +575,147 @@ void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * K4 / K3: the rest of the palette matrix              reference: src/colourspace.c (ranges in lives_oracle.h)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_cavg(int clamped, int x, int y) {              /* init_average, :190-216 (the non-MULT_AVG branch) */
+  if (clamped) {
+    const float fa = (float)(x - 128.) * 255. / 244., fb = (float)(y - 128.) * 255. / 244.;
+    const float fc = (fa + fb) * 224. / 512. + 128.;
+    return (uint8_t)(fc > 240. ? 240 : fc < 16. ? 16 : fc);
+  } else {
+    const short sa = (short)(x - 128), sb = (short)(y - 128);
+    const short c = (short)(((sa + sb) >> 1) + 128);
+    return (uint8_t)(c > 255 ? 255 : c < 0 ? 0 : c);
+  }
+}
+typedef struct { const int32_t (*t)[256]; int min_y, max_y, min_uv, max_uv; } r2y_t;
+static r2y_t r2y_for(int which) {
+  r2y_t c;
+  if (!tables_ready) build_tables();
+  c.t = T_r2y[which & 3];
+  if (which & 1) { c.min_y = c.min_uv = 0; c.max_y = c.max_uv = 255; }
+  else { c.min_y = c.min_uv = 16; c.max_y = 235; c.max_uv = 240; }      /* set_conversion_arrays :361-370 */
+  return c;
+}
+/* rgb2yuv (:2119-2127): short a = spc_rnd(sum); upper clamp first, then lower */
+static inline uint8_t r2y_Y(const r2y_t *c, int r, int g, int b) {
+  const short a = (short)((c->t[0][r] + c->t[1][g] + c->t[2][b]) >> 16);
+  return (uint8_t)(a > c->max_y ? c->max_y : a < c->min_y ? c->min_y : a);
+}
+static inline short r2y_Uraw(const r2y_t *c, int r, int g, int b) { return (short)((c->t[3][r] + c->t[4][g] + c->t[5][b]) >> 16); }
+static inline short r2y_Vraw(const r2y_t *c, int r, int g, int b) { return (short)((c->t[6][r] + c->t[7][g] + c->t[8][b]) >> 16); }
+static inline uint8_t r2y_clampuv(const r2y_t *c, short a) { return (uint8_t)(a > c->max_uv ? c->max_uv : a < c->min_uv ? c->min_uv : a); }
+static inline void px_rgb(const uint8_t *p, int order, int *r, int *g, int *b) {
+  switch (order) {
+  case 0: *r = p[0]; *g = p[1]; *b = p[2]; break;
+  case 1: *r = p[2]; *g = p[1]; *b = p[0]; break;
+  default: *r = p[1]; *g = p[2]; *b = p[3]; break;
+  }
+}
+int orc_rgb_to_yuv(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha,
+                   uint8_t *const dst[4], const int orow[4], int out_fmt, int out_alpha, int which_tables) {
+  const r2y_t c = r2y_for(which_tables);
+  const int ips = (in_order == 2 || in_alpha) ? 4 : 3;
+  int r, g, b;
+  if (in_order < 0 || in_order > 2 || out_fmt < 0 || out_fmt > 5 || width < 1 || height < 1) return -1;
+  if (out_fmt >= 2 && (width & 1)) return -1;
+  if (out_fmt <= 3 && (which_tables & 2)) return -1;      /* only the 4:2:0 / 4:2:2 entry points take a subspace */
+  if (out_fmt >= 4 && in_order == 2) return -1;
+  if (out_fmt == 4 && (height & 1)) return -1;
+  if (out_fmt <= 1) {
+    const int w = (width >> 1) << 1;                                    /* :5761 */
+    for (int y = 0; y < height; y++) {
+      const uint8_t *s = src + (size_t)y * irow;
+      for (int x = 0; x < w; x++) {
+        const uint8_t *p = s + x * ips;
+        const uint8_t alpha = in_order == 2 ? p[0] : ips == 4 ? p[3] : 255;
+        px_rgb(p, in_order, &r, &g, &b);
+        const uint8_t Y = r2y_Y(&c, r, g, b), U = r2y_clampuv(&c, r2y_Uraw(&c, r, g, b)), V = r2y_clampuv(&c, r2y_Vraw(&c, r, g, b));
+        if (out_fmt == 0) {
+          uint8_t *d = dst[0] + (size_t)y * orow[0] + x * (out_alpha ? 4 : 3);
+          d[0] = Y; d[1] = U; d[2] = V;
+          if (out_alpha) d[3] = alpha;
+        } else {
+          dst[0][(size_t)y * orow[0] + x] = Y; dst[1][(size_t)y * orow[1] + x] = U; dst[2][(size_t)y * orow[2] + x] = V;
+          if (out_alpha) dst[3][(size_t)y * orow[3] + x] = alpha;
+        }
+      }
+    }
+    return 0;
+  }
+  /* pair formats: rgb2uyvy / rgb2yuyv (:2162-2192): U from the first pixel, V from the second */
+  for (int y = 0; y < height; y++) {
+    const uint8_t *s = src + (size_t)y * irow;
+    for (int x = 0; x < width; x += 2) {
+      int r1, g1, b1;
+      px_rgb(s + x * ips, in_order, &r, &g, &b);
+      px_rgb(s + (x + 1) * ips, in_order, &r1, &g1, &b1);
+      const uint8_t y0 = r2y_Y(&c, r, g, b), y1 = r2y_Y(&c, r1, g1, b1);
+      const short ur = r2y_Uraw(&c, r, g, b), vr = r2y_Vraw(&c, r1, g1, b1);
+      if (out_fmt == 2) {
+        uint8_t *d = dst[0] + (size_t)y * orow[0] + x * 2;
+        d[0] = r2y_clampuv(&c, ur); d[1] = y0; d[2] = r2y_clampuv(&c, vr); d[3] = y1;
+      } else if (out_fmt == 3) {
+        uint8_t *d = dst[0] + (size_t)y * orow[0] + x * 2;                /* rgb2yuyv: the `else` is missing, the upper clamp is lost */
+        d[0] = y0; d[1] = (uint8_t)(ur < c.min_uv ? c.min_uv : ur); d[2] = y1; d[3] = (uint8_t)(vr < c.min_uv ? c.min_uv : vr);
+      } else {
+        dst[0][(size_t)y * orow[0] + x] = y0; dst[0][(size_t)y * orow[0] + x + 1] = y1;
+        const uint8_t cu = r2y_clampuv(&c, ur), cv = r2y_clampuv(&c, vr);
+        if (out_fmt == 5) { dst[1][(size_t)y * orow[1] + (x >> 1)] = cu; dst[2][(size_t)y * orow[2] + (x >> 1)] = cv; }
+        else {
+          /* :6302-6315 at compact strides: an even row k2 = 2k (k > 0) is averaged INTO chroma row k-1 (which holds luma row
+             2k-1), then overwritten by luma row 2k+1 */
+          const int k = y >> 1;
+          uint8_t *pu = dst[1] + (size_t)k * orow[1] + (x >> 1), *pv = dst[2] + (size_t)k * orow[2] + (x >> 1);
+          if (!(y & 1) && y > 0) {
+            uint8_t *qu = pu - orow[1], *qv = pv - orow[2];
+            *qu = (uint8_t)orc_cavg(!(which_tables & 1), cu, *qu);
+            *qv = (uint8_t)orc_cavg(!(which_tables & 1), cv, *qv);
+          }
+          *pu = cu; *pv = cv;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                   uint8_t *dst, int orow, int out_order, int out_alpha, int which_tables) {
+  yuvctx_t c;
+  if (!tables_ready) build_tables();
+  if (in_fmt < 0 || in_fmt > 3 || out_order < 0 || out_order > 2 || width < 1 || height < 1) return -1;
+  if (in_fmt >= 2 && (width & 1)) return -1;
+  if (in_fmt >= 1 && (which_tables & 2)) return -1;
+  if (in_fmt == 1 && out_order == 2) return -1;                 /* :7475-7476 subtracts the output stride twice */
+  if (in_fmt == 1 && out_order == 1 && !out_alpha) return -1;   /* :7313 steps 4 bytes per pixel into a BGR24 row */
+  c.ty = T_y2r[which_tables & 3][0]; c.rcr = T_y2r[which_tables & 3][1]; c.gcb = T_y2r[which_tables & 3][2];
+  c.gcr = T_y2r[which_tables & 3][3]; c.bcb = T_y2r[which_tables & 3][4];
+  c.lut8 = NULL; c.quality = 2; c.order = out_order; c.clamped = !(which_tables & 1);
+  c.opsize = (out_order == 2 || out_alpha) ? 4 : 3;
+  for (int y = 0; y < height; y++) {
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int x = 0; x < width; x++) {
+      int Y, U, V, A = 255;
+      if (in_fmt == 0) {
+        const uint8_t *p = src[0] + (size_t)y * irow[0] + x * (in_alpha ? 4 : 3);
+        Y = p[0]; U = p[1]; V = p[2]; if (in_alpha) A = p[3];
+      } else if (in_fmt == 1) {
+        Y = src[0][(size_t)y * irow[0] + x]; U = src[1][(size_t)y * irow[1] + x]; V = src[2][(size_t)y * irow[2] + x];
+        if (in_alpha) A = src[3][(size_t)y * irow[3] + x];
+      } else {
+        const uint8_t *p = src[0] + (size_t)y * irow[0] + (x >> 1) * 4;
+        if (in_fmt == 2) { U = p[0]; Y = p[1 + 2 * (x & 1)]; V = p[2]; }
+        else { Y = p[2 * (x & 1)]; U = p[1]; V = p[3]; }
+      }
+      put_px(&c, d + x * c.opsize, Y, U, V);
+      if (c.opsize == 4) d[x * 4 + (out_order == 2 ? 0 : 3)] = (uint8_t)A;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * F6a: softlight                        reference: lives-plugins/weed-plugins/softlight.c:34-47 (sqrti), :62-141
  * Per interior luma sample (the reference's own operand choice, including the two terms that differ from a
  * textbook Sobel: row0 ends with (S[+1][+1] - S[+1][-1]) and row1 ends with the SUM S[+1][+1] + S[+1][-1]):

@@ -71,6 +71,32 @@ void orc_colorkey(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1
 /* F5: mirrors.c:26-122.  mode 0 = x, 1 = y, 2 = xy.  (OOB writes of the reference are not performed.) */
 void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
 
+/* K4: packed RGB family -> YUV family (src/colourspace.c:5129-6440, pixel maths :2119-2192, 1-thread semantics).
+   in_order 0 RGB, 1 BGR, 2 ARGB; in_alpha: 4-byte source pixels (always for ARGB).
+   out_fmt  0 packed YUV888 / YUVA8888 (out_alpha)      convert_{rgb,bgr,argb}_to_yuv_frame   :5700-6144
+            1 planar YUV444P / YUVA4444P (out_alpha)    convert_{rgb,bgr,argb}_to_yuvp_frame  :5786-6239
+            2 UYVY, 3 YUYV                              convert_{rgb,bgr,argb}_to_{uyvy,yuyv}_frame :5129-5690 (no gamma LUT)
+            4 YUV420P, 5 YUV422P                        convert_{rgb,bgr}_to_yuv420_frame     :6250-6440
+   which_tables: bit 0 unclamped, bit 1 BT.709 (4:2:0 / 4:2:2 only: the other entry points always use YCbCr).
+   Packed/planar 4:4:4 leave the last pixel of an odd-width row unwritten
+   (hsize = (hsize >> 1) << 1); the subsampled formats need an even width (4:2:0: and height).
+   Reference-faithful oddities kept: UYVY/YUYV take U from the first and V from the SECOND pixel of a pair (no
+   averaging); YUYV has no upper chroma clamp (:2183-2191); 4:2:0 chroma row k is avg_chroma(row 2k+2, row 2k+1) and the
+   last chroma row is that of the last luma row alone (the in-place "average two rows" walk of :6302-6315 at compact
+   strides).  Returns -1 for combinations the reference cannot do sanely (ARGB -> 4:2:0 reads the wrong bytes, :6353). */
+int orc_rgb_to_yuv(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha,
+                   uint8_t *const dst[4], const int orow[4], int out_fmt, int out_alpha, int which_tables);
+/* K3: YUV family -> packed RGB family (src/colourspace.c:2750-3258, :6616-7102, :7200-7498; pixel maths :2345-2459).
+   in_fmt 0 packed YUV888 / YUVA8888 (in_alpha), 1 planar YUV444P / YUVA4444P (in_alpha), 2 UYVY, 3 YUYV (width in
+   pixels, even).  out_order 0 RGB, 1 BGR, 2 ARGB; out_alpha: 4-byte output (always for ARGB); alpha = source alpha
+   or 255.  The reference's UYVY / YUYV / planar entry points always use the YCbCr tables (bit 1 of which_tables must
+   be 0 for them).  Returns -1 where the reference's own row arithmetic is broken: planar -> ARGB (:7475-7476) and
+   planar -> BGR24 (:7313 always steps 4 bytes). */
+int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                   uint8_t *dst, int orow, int out_order, int out_alpha, int which_tables);
+/* init_average (src/colourspace.c:190-216): cavgc (clamped = 1) / cavgu chroma-averaging table entry */
+int orc_cavg(int clamped, int x, int y);
+
 /* F6a: "softlight"  lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV: the stencil runs on plane 0 (rows
    1..h-2, columns 1..w-2; the frame border is copied), the other planes are copied (:143-151).
    unclamped != 0: output range 0..255, else 16..235 (:97-103).  Needs width, height >= 3. */

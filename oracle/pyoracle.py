@@ -86,6 +86,9 @@ def oracle():
         _O.orc_blend_multi.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci]
         _O.orc_mirror.argtypes = [ci, vp, ci, vp, ci, ci, ci, ci]
         _O.orc_softlight_y.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+        _O.orc_rgb_to_yuv.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci]
+        _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
+        _O.orc_cavg.argtypes = [ci, ci, ci]
         _O.orc_edge.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci]
         _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
         _O.orc_gauss5.argtypes = [vp, ci, vp, ci, ci, ci, ci]
@@ -111,6 +114,8 @@ def csref():
         _R = ctypes.CDLL(os.path.join(REFDIR, "libcsref.so"))
         _R.csref_gamma_lut8.argtypes = [cd, ci, ci, vp]
         _R.csref_set_prefs.argtypes = [ci, ci, cd]
+        _R.csref_k4.argtypes = [ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, ci, ci]
+        _R.csref_k3.argtypes = [ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci]
     return _R
 
 
@@ -209,3 +214,28 @@ def make_frame(rng, w, h, psize, stride_align=32, extra_rows=0, alpha_mix=False,
         opaque = rng.random(al.shape) < 0.5
         al[opaque] = 255
     return a
+
+
+# ---- K3 / K4 helpers shared by the fixture generator and the tests --------------------------------------------------
+def k4_out_planes(rng_or_fill, w, h, out_fmt, out_alpha, compact=True):
+    """destination plane arrays for orc_rgb_to_yuv / csref_k4 (compact strides: the reference's 4:2:0 and UYVY row
+    arithmetic only works there, see lives_oracle.h)"""
+    if out_fmt == 0:
+        dims = [(w * (4 if out_alpha else 3), h)]
+    elif out_fmt == 1:
+        dims = [(w, h)] * (4 if out_alpha else 3)
+    elif out_fmt in (2, 3):
+        dims = [(w * 2, h)]
+    elif out_fmt == 4:
+        dims = [(w, h), (w >> 1, h >> 1), (w >> 1, h >> 1)]
+    else:
+        dims = [(w, h), (w >> 1, h), (w >> 1, h)]
+    return [np.full((b, a if compact else align(a, 16)), rng_or_fill, np.uint8) for (a, b) in dims], dims
+
+
+def planes_args(planes):
+    n = len(planes)
+    pp = (vp * 4)(*([a.ctypes.data for a in planes] + [0] * (4 - n)))
+    ss = (ci * 4)(*([a.strides[0] for a in planes] + [0] * (4 - n)))
+    return pp, ss
+

@@ -20,7 +20,7 @@ What is exported (all call the reference's functions unmodified):
   csref_yuv420p_to_rgb(...)   convert_yuv420p_to_rgb_frame   :3260-3904
   csref_k1(...)               the 13 RGB<->RGB swizzles      :9259-10577
   csref_gamma_apply(...)      gamma_convert_layer_thread     :14034-14060
-  csref_rgb_to_yuv420(...)    convert_rgb_to_yuv420_frame    (next-row)
+  csref_k4(...) / csref_k3(...)  the RGB -> YUV and YUV -> RGB conversions :2750-3258, :5129-6440, :6616-7498
 """
 import os
 import subprocess
@@ -57,6 +57,8 @@ typedef void weed_layer_t;
 #define LIVES_LOCAL_INLINE static inline
 #define LIVES_GLOBAL_INLINE
 #define LIVES_CONST
+#define LIVES_HOT
+#define LIVES_FLATTEN
 #define LIVES_UNLIKELY(a) (a)
 #define LIVES_LIKELY(a) (a)
 #define LIVES_THRDATTR_PRIORITY 0
@@ -204,6 +206,76 @@ int csref_k1(int op, uint8_t *src, int width, int height, int irow, int orow, ui
   }
   return 0;
 }
+/* K4: in_order 0 RGB 1 BGR 2 ARGB; out_fmt 0 packed 1 planar 2 UYVY 3 YUYV 4 420P 5 422P (see oracle/lives_oracle.h) */
+int csref_k4(int in_order, int in_alpha, int out_fmt, int out_alpha, uint8_t *src, int irow, int width, int height,
+             uint8_t **dst, int *orows, int clamping, int bt709) {
+  const int subspace = bt709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR;
+  ensure_tables();
+  avg_chromaf = avg_chromaf_fast;
+  switch (out_fmt) {
+  case 0:
+    if (in_order == 0) convert_rgb_to_yuv_frame(src, width, height, irow, orows[0], dst[0], in_alpha, out_alpha, clamping, -1);
+    else if (in_order == 1) convert_bgr_to_yuv_frame(src, width, height, irow, orows[0], dst[0], in_alpha, out_alpha, clamping, -1);
+    else convert_argb_to_yuv_frame(src, width, height, irow, orows[0], dst[0], out_alpha, clamping, -1);
+    return 0;
+  case 1:
+    if (in_order == 0) convert_rgb_to_yuvp_frame(src, width, height, irow, orows[0], dst, in_alpha, out_alpha, clamping, -1);
+    else if (in_order == 1) convert_bgr_to_yuvp_frame(src, width, height, irow, orows[0], dst, in_alpha, out_alpha, clamping, -1);
+    else convert_argb_to_yuvp_frame(src, width, height, irow, orows[0], dst, out_alpha, clamping, -1);
+    return 0;
+  case 2:
+    if (in_order == 0) convert_rgb_to_uyvy_frame(src, width, height, irow, orows[0], (uyvy_macropixel *)dst[0], in_alpha, clamping, NULL, -1);
+    else if (in_order == 1) convert_bgr_to_uyvy_frame(src, width, height, irow, orows[0], (uyvy_macropixel *)dst[0], in_alpha, clamping, NULL, -1);
+    else convert_argb_to_uyvy_frame(src, width, height, irow, orows[0], (uyvy_macropixel *)dst[0], clamping, NULL, -1);
+    return 0;
+  case 3:
+    if (in_order == 0) convert_rgb_to_yuyv_frame(src, width, height, irow, orows[0], (yuyv_macropixel *)dst[0], in_alpha, clamping, NULL, -1);
+    else if (in_order == 1) convert_bgr_to_yuyv_frame(src, width, height, irow, orows[0], (yuyv_macropixel *)dst[0], in_alpha, clamping, NULL, -1);
+    else convert_argb_to_yuyv_frame(src, width, height, irow, orows[0], (yuyv_macropixel *)dst[0], clamping, NULL, -1);
+    return 0;
+  case 4: case 5:
+    if (in_order == 0) convert_rgb_to_yuv420_frame(src, width, height, irow, orows, dst, out_fmt == 5, in_alpha, subspace, clamping);
+    else if (in_order == 1) convert_bgr_to_yuv420_frame(src, width, height, irow, orows, dst, out_fmt == 5, in_alpha, subspace, clamping);
+    else return -1;
+    return 0;
+  }
+  return -1;
+}
+/* K3: in_fmt 0 packed 1 planar 2 UYVY 3 YUYV; out_order 0 RGB 1 BGR 2 ARGB; width in pixels */
+int csref_k3(int in_fmt, int in_alpha, int out_order, int out_alpha, uint8_t **src, int *irows, int width, int height,
+             uint8_t *dst, int orow, int clamping, int bt709) {
+  const int subspace = bt709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR;
+  ensure_tables();
+  switch (in_fmt) {
+  case 0:
+    if (!in_alpha) {
+      if (out_order == 0) convert_yuv888_to_rgb_frame(src[0], width, height, irows[0], orow, dst, out_alpha, clamping, subspace, -1);
+      else if (out_order == 1) convert_yuv888_to_bgr_frame(src[0], width, height, irows[0], orow, dst, out_alpha, clamping, subspace, -1);
+      else convert_yuv888_to_argb_frame(src[0], width, height, irows[0], orow, dst, clamping, subspace, -1);
+    } else {
+      if (out_order == 0) convert_yuva8888_to_rgba_frame(src[0], width, height, irows[0], orow, dst, !out_alpha, clamping, subspace, -1);
+      else if (out_order == 1) convert_yuva8888_to_bgra_frame(src[0], width, height, irows[0], orow, dst, !out_alpha, clamping, subspace, -1);
+      else convert_yuva8888_to_argb_frame(src[0], width, height, irows[0], orow, dst, clamping, subspace, -1);
+    }
+    return 0;
+  case 1:
+    if (out_order == 0) convert_yuv_planar_to_rgb_frame(src, width, height, irows[0], orow, dst, in_alpha, out_alpha, clamping, -1);
+    else if (out_order == 1) convert_yuv_planar_to_bgr_frame(src, width, height, irows[0], orow, dst, in_alpha, out_alpha, clamping, -1);
+    else return -1;
+    return 0;
+  case 2:
+    if (out_order == 0) convert_uyvy_to_rgb_frame((uyvy_macropixel *)src[0], width >> 1, height, irows[0], orow, dst, out_alpha, clamping, subspace, -1);
+    else if (out_order == 1) convert_uyvy_to_bgr_frame((uyvy_macropixel *)src[0], width >> 1, height, irows[0], orow, dst, out_alpha, clamping, -1);
+    else convert_uyvy_to_argb_frame((uyvy_macropixel *)src[0], width >> 1, height, irows[0], orow, dst, clamping, -1);
+    return 0;
+  case 3:
+    if (out_order == 0) convert_yuyv_to_rgb_frame((yuyv_macropixel *)src[0], width >> 1, height, irows[0], orow, dst, out_alpha, clamping, -1);
+    else if (out_order == 1) convert_yuyv_to_bgr_frame((yuyv_macropixel *)src[0], width >> 1, height, irows[0], orow, dst, out_alpha, clamping, -1);
+    else convert_yuyv_to_argb_frame((yuyv_macropixel *)src[0], width >> 1, height, irows[0], orow, dst, clamping, -1);
+    return 0;
+  }
+  return -1;
+}
 void csref_gamma_apply(uint8_t *pixels, int width, int height, int rowstride, int psize, int alpha_first,
                        int xoffset_px, uint8_t *lut8) {
   lives_cc_params cc;
@@ -248,7 +320,21 @@ def main():
     parts.append(lines(cs, 2345, 2365))             # yuv2rgb_int, xyuv2rgb, SETVARS
     parts.append(lines(cs, 2386, 2392))             # xyuv2rgb_with_gamma
     parts.append(FWD)
+    parts.append(lines(cs, 1985, 2019))             # forward declarations of the K3 / K4 thread bodies
+    parts.append(lines(cs, 2040, 2070))             # forward declarations of the pixel helpers
+    parts.append(lines(cs, 2079, 2083))             # avg_chroma macros, avg_chromaf pointer
+    parts.append(lines(cs, 2097, 2101))             # avg_chromaf_fast
+    parts.append(lines(cs, 2116, 2117))             # avg_chroma_3_1f, avg_chroma_1_3f
+    parts.append(lines(cs, 2119, 2264))             # rgb2yuv, *_with_gamma, rgb2uyvy, rgb2yuyv, rgb16_2uyvy
+    parts.append(lines(cs, 2366, 2385))             # yuv2rgb_float, yuv2rgb / yuv2bgr macros, yuv2rgb_with_gamma
+    parts.append(lines(cs, 2408, 2459))             # uyvy2rgb, yuyv2rgb, yuv888_2_rgb ...
+    parts.append(lines(cs, 2750, 3258))             # K3: yuv888 / yuva8888 -> rgb / bgr / argb
     parts.append(lines(cs, 3260, 3925))             # convert_yuv420p_to_rgb_frame (+ thread)
+    parts.append(lines(cs, 5129, 5698))             # K4: rgb / bgr / argb -> uyvy / yuyv
+    parts.append(lines(cs, 5700, 6248))             # K4: rgb / bgr / argb -> yuv888 / yuva8888 / yuv(a)444p
+    parts.append(lines(cs, 6250, 6440))             # K4: rgb / argb / bgr -> yuv420p / yuv422p
+    parts.append(lines(cs, 6616, 7102))             # K3: uyvy / yuyv -> rgb / bgr / argb
+    parts.append(lines(cs, 7200, 7498))             # K3: yuv(a)444p -> rgb / bgr / argb
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family
     parts.append(lines(cs, 14034, 14060))           # gamma_convert_layer_thread
     parts.append(WRAPPERS)

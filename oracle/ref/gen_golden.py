@@ -227,6 +227,8 @@ def main():
         json.dump(manifest, f, indent=1)
     import gen_golden_stencils          # softlight.c / edge.c fixtures (own seed stream, own file)
     gen_golden_stencils.main()
+    import gen_golden_palette           # K3 / K4 conversions (own seed stream, own file)
+    gen_golden_palette.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

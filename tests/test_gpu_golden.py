@@ -154,3 +154,28 @@ def test_stencils_vs_reference_plugins(gpu):
         n += 1
     assert n == 50
 
+
+def test_k34_palette_matrix_vs_reference(gpu):
+    """lgpu_rgb_to_yuv / lgpu_yuv_to_rgb against the outputs of the reference's own conversion functions"""
+    g = gu.load("k34_palette.npz")
+    n = 0
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        a = list(map(int, f[1:]))
+        if f[0] == "k4":
+            in_order, in_alpha, out_fmt, out_alpha, which, w, h = a
+            want, dims = po.k4_out_planes(0x5A, w, h, out_fmt, out_alpha)
+            got = [dev(np.full_like(x, 0x5A)) for x in want]
+            gpu.rgb_to_yuv(dev(g[rec + "|in"]), got, w, h, in_order, in_alpha, out_fmt, out_alpha, which)
+            for i in range(len(got)):
+                assert (host(got[i]) == g[rec + "|o%d" % i]).all(), (rec, i)
+        else:
+            in_fmt, in_alpha, out_order, out_alpha, which, w, h = a
+            npl = (4 if in_alpha else 3) if in_fmt == 1 else 1
+            want = g[rec + "|out"]
+            d = dev(np.full_like(want, 0x5A))
+            gpu.yuv_to_rgb([dev(g[rec + "|i%d" % i]) for i in range(npl)], d, w, h, in_fmt, in_alpha, out_order, out_alpha, which)
+            assert (host(d) == want).all(), rec
+        n += 1
+    assert n > 150
+

@@ -278,6 +278,65 @@ def test_mirror(gpu, orc, psize, mode):
             assert_same(host(d), want, w, h, psize, "mirror mode=%d %dx%d inplace=%d" % (mode, w, h, inplace))
 
 
+# ---------------------------------------------------------------------------------------------- K4 / K3 palette matrix
+def _planes(p):
+    return po.planes_args(p)
+
+
+@pytest.mark.parametrize("in_order", [0, 1, 2])
+@pytest.mark.parametrize("out_fmt", [0, 1, 2, 3, 4, 5])
+def test_rgb_to_yuv(gpu, orc, in_order, out_fmt):
+    if out_fmt >= 4 and in_order == 2:
+        pytest.skip("ARGB32 -> 4:2:0 / 4:2:2: reference-broken, declined")
+    rng = np.random.default_rng(1700 + 10 * in_order + out_fmt)
+    sizes = [(20, 8), (66, 34), (130, 50), (258, 6)] + ([(21, 7), (1, 3)] if out_fmt <= 1 else [])
+    for (w, h) in sizes:
+        for in_alpha in ((1,) if in_order == 2 else (0, 1)):
+            for out_alpha in ((0, 1) if out_fmt <= 1 else (0,)):
+                for which in ((0, 1, 2, 3) if out_fmt >= 4 else (0, 1)):
+                    ips = 4 if (in_order == 2 or in_alpha) else 3
+                    src = frame(rng, w, h, ips)
+                    want, dims = po.k4_out_planes(0x5A, w, h, out_fmt, out_alpha, compact=False)
+                    wp, ws = _planes(want)
+                    assert orc.orc_rgb_to_yuv(P(src), src.strides[0], w, h, in_order, in_alpha, ctypes.addressof(wp), ctypes.addressof(ws),
+                                              out_fmt, out_alpha, which) == 0
+                    got = [dev(np.full_like(a, 0x5A)) for a in want]
+                    gpu.rgb_to_yuv(dev(src), got, w, h, in_order, in_alpha, out_fmt, out_alpha, which)
+                    for i, (a, b) in enumerate(dims):
+                        assert_same(host(got[i]), want[i], a, b, 1, "rgb_to_yuv order=%d alpha=%d fmt=%d oa=%d which=%d %dx%d plane %d"
+                                    % (in_order, in_alpha, out_fmt, out_alpha, which, w, h, i))
+
+
+@pytest.mark.parametrize("in_fmt", [0, 1, 2, 3])
+@pytest.mark.parametrize("out_order", [0, 1, 2])
+def test_yuv_to_rgb(gpu, orc, in_fmt, out_order):
+    rng = np.random.default_rng(1800 + 10 * in_fmt + out_order)
+    sizes = [(20, 8), (66, 34), (130, 50), (258, 6)] + ([(21, 7), (1, 3)] if in_fmt <= 1 else [])
+    n = 0
+    for (w, h) in sizes:
+        for in_alpha in ((0, 1) if in_fmt <= 1 else (0,)):
+            for out_alpha in ((1,) if out_order == 2 else (0, 1)):
+                if in_fmt == 1 and (out_order == 2 or (out_order == 1 and not out_alpha)):
+                    continue        # reference-broken, declined
+                for which in ((0, 1, 2, 3) if in_fmt == 0 else (0, 1)):
+                    if in_fmt == 0:
+                        planes = [frame(rng, w, h, 4 if in_alpha else 3)]
+                    elif in_fmt == 1:
+                        planes = [frame(rng, w, h, 1) for _ in range(4 if in_alpha else 3)]
+                    else:
+                        planes = [frame(rng, w, h, 2)]
+                    ops = 4 if (out_order == 2 or out_alpha) else 3
+                    want = np.full((h, align(w * ops)), 0x5A, np.uint8)
+                    sp, ss = _planes(planes)
+                    assert orc.orc_yuv_to_rgb(ctypes.addressof(sp), ctypes.addressof(ss), w, h, in_fmt, in_alpha, P(want), want.strides[0],
+                                              out_order, out_alpha, which) == 0
+                    d = dev(np.full_like(want, 0x5A))
+                    gpu.yuv_to_rgb([dev(a) for a in planes], d, w, h, in_fmt, in_alpha, out_order, out_alpha, which)
+                    assert_same(host(d), want, w, h, ops, "yuv_to_rgb fmt=%d ia=%d order=%d oa=%d which=%d %dx%d" % (in_fmt, in_alpha, out_order, out_alpha, which, w, h))
+                    n += 1
+    assert n > 0 or (in_fmt == 1 and out_order == 2)
+
+
 # ---------------------------------------------------------------------------------------------- F6 stencils
 @pytest.mark.parametrize("palette", [544, 545, 522, 512, 513])
 def test_softlight(gpu, orc, palette):

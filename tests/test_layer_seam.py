@@ -53,7 +53,7 @@ def test_failure_leaves_layer_untouched(seam):
     src = np.arange(4 * 64, dtype=np.uint8).reshape(4, 64)
     lay = wh.new_layer(RGBA32, 10, 4, [src], gamma=1)
     before, ptrs, _ = wh.planes_of(lay)
-    assert L.lives_gpu_convert_layer_palette(lay, YUV888, 0) == 0          # RGB -> YUV is not on the GPU path
+    assert L.lives_gpu_convert_layer_palette(lay, 595, 0) == 0             # YUV411: not on the GPU path
     after, ptrs2, _ = wh.planes_of(lay)
     assert ptrs == ptrs2 and (before[0] == after[0]).all() and wh.geti(lay, "current_palette") == RGBA32
 
@@ -160,3 +160,78 @@ def test_alpha_premult_layer(seam, orc):
         orc.orc_alpha_premult(P(want), want.strides[0], 66, 34, 0, un)
         assert (planes[0][:, :66 * 4] == want[:, :66 * 4]).all()
         assert wh.geti(lay, "host_flags") == (1 if direction == 1 else 0)
+
+
+# ---- K4 / K3 on layers: the RGB -> YUV and YUV -> RGB cases of convert_layer_palette_full (src/colourspace.c:12559-13860) ----
+K4_FMT = {588: 0, 589: 0, 544: 1, 545: 1, 564: 2, 565: 3, 512: 4, 513: 4, 522: 5}
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("inpl", [RGB24, BGR24, RGBA32, BGRA32, ARGB32])
+def test_rgb_layers_to_yuv(seam, orc, inpl):
+    L, wh = seam
+    rng = np.random.default_rng(40 + inpl)
+    w, h = 64, 16          # aligned width: the rowstrides the layer gets are compact, where the reference's 4:2:0 walk is sane
+    ips = 3 if inpl in (RGB24, BGR24) else 4
+    order = {RGB24: 0, RGBA32: 0, BGR24: 1, BGRA32: 1, ARGB32: 2}[inpl]
+    for outpl, fmt in K4_FMT.items():
+        for oclamp in (0, 1):
+            src = frame(rng, w, h, ips)
+            lay = wh.new_layer(inpl, w, h, [src], gamma=1, flags=1 if ips == 4 else 0)
+            rc = L.lives_gpu_convert_layer_palette(lay, outpl, oclamp)
+            if order == 2 and fmt >= 4:
+                assert rc == 0 and wh.geti(lay, "current_palette") == inpl       # declined (reference-broken), layer untouched
+                continue
+            assert rc == 1, (inpl, outpl)
+            planes, _, rs = wh.planes_of(lay)
+            out_alpha = 1 if outpl in (589, 545) else 0
+            want, dims = po.k4_out_planes(0, w, h, fmt, out_alpha)
+            want = [np.zeros((a.shape[0], r), np.uint8) for a, r in zip(want, rs)]
+            wp, ws = po.planes_args(want)
+            assert orc.orc_rgb_to_yuv(P(src), src.strides[0], w, h, order, int(ips == 4), ctypes.addressof(wp), ctypes.addressof(ws), fmt, out_alpha,
+                                      1 if oclamp == 1 else 0) == 0
+            if outpl == 513:
+                planes = [planes[0], planes[2], planes[1]]                       # YVU420P: chroma pointers swapped (:13890)
+            for i, (a, b) in enumerate(dims):
+                assert (planes[i][:b, :a] == want[i][:b, :a]).all(), (inpl, outpl, oclamp, i)
+            assert wh.geti(lay, "current_palette") == outpl and wh.geti(lay, "YUV_clamping") == oclamp
+            assert wh.geti(lay, "width") == (w >> 1 if fmt in (2, 3) else w) and wh.geti(lay, "YUV_subspace") == 1
+            if ips == 4 and not out_alpha:
+                assert wh.geti(lay, "host_flags") == 0                           # alpha dropped -> premult flag cleared
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("inpl", [588, 589, 544, 545, 564, 565])
+def test_yuv_layers_to_rgb(seam, orc, inpl):
+    L, wh = seam
+    rng = np.random.default_rng(60 + inpl)
+    w, h = 64, 12
+    fmt = {588: 0, 589: 0, 544: 1, 545: 1, 564: 2, 565: 3}[inpl]
+    in_alpha = 1 if inpl in (589, 545) else 0
+    for outpl in (RGB24, BGR24, RGBA32, BGRA32, ARGB32):
+        for clamp in (0, 1):
+            if fmt == 0:
+                planes = [frame(rng, w, h, 4 if in_alpha else 3)]
+            elif fmt == 1:
+                planes = [frame(rng, w, h, 1) for _ in range(4 if in_alpha else 3)]
+            else:
+                planes = [frame(rng, w, h, 2)]
+            lw = w >> 1 if fmt >= 2 else w
+            lay = wh.new_layer(inpl, lw, h, planes, clamping=clamp, subspace=1)
+            rc = L.lives_gpu_convert_layer_palette(lay, outpl, clamp)
+            order = {RGB24: 0, RGBA32: 0, BGR24: 1, BGRA32: 1, ARGB32: 2}[outpl]
+            out_alpha = 1 if outpl in (RGBA32, BGRA32, ARGB32) else 0
+            if fmt == 1 and (order == 2 or (order == 1 and not out_alpha)):
+                assert rc == 0 and wh.geti(lay, "current_palette") == inpl       # declined (reference-broken)
+                continue
+            assert rc == 1, (inpl, outpl)
+            got, _, rs = wh.planes_of(lay)
+            ops = 4 if out_alpha else 3
+            want = np.zeros((h, rs[0]), np.uint8)
+            sp, ss = po.planes_args(planes)
+            assert orc.orc_yuv_to_rgb(ctypes.addressof(sp), ctypes.addressof(ss), w, h, fmt, in_alpha, P(want), rs[0], order, out_alpha, clamp) == 0
+            assert (got[0][:, :w * ops] == want[:, :w * ops]).all(), (inpl, outpl, clamp)
+            assert wh.geti(lay, "current_palette") == outpl and wh.geti(lay, "width") == w and wh.geti(lay, "YUV_clamping") is None
+

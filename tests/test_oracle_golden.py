@@ -176,3 +176,34 @@ def test_stencil_plugins(orc):
         n += 1
     assert n == 50
 
+
+def test_k34_palette_matrix(orc):
+    """RGB <-> YUV conversions of the reference (tests/golden/k34_palette.npz)"""
+    import ctypes
+    g = gu.load("k34_palette.npz")
+    n = 0
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        a = list(map(int, f[1:]))
+        if f[0] == "k4":
+            in_order, in_alpha, out_fmt, out_alpha, which, w, h = a
+            src = g[rec + "|in"]
+            got, dims = po.k4_out_planes(0x5A, w, h, out_fmt, out_alpha)
+            gp, gs = po.planes_args(got)
+            assert orc.orc_rgb_to_yuv(P(src), src.strides[0], w, h, in_order, in_alpha, ctypes.addressof(gp), ctypes.addressof(gs), out_fmt,
+                                      out_alpha, which) == 0
+            for i in range(len(got)):
+                assert (got[i] == g[rec + "|o%d" % i]).all(), (rec, i)
+        else:
+            in_fmt, in_alpha, out_order, out_alpha, which, w, h = a
+            npl = (4 if in_alpha else 3) if in_fmt == 1 else 1
+            planes = [g[rec + "|i%d" % i] for i in range(npl)]
+            want = g[rec + "|out"]
+            got = np.full_like(want, 0x5A)
+            sp, ss = po.planes_args(planes)
+            assert orc.orc_yuv_to_rgb(ctypes.addressof(sp), ctypes.addressof(ss), w, h, in_fmt, in_alpha, P(got), got.strides[0], out_order,
+                                      out_alpha, which) == 0
+            assert (got == want).all(), rec
+        n += 1
+    assert n == len(g["records"]) and n > 150
+

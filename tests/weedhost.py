@@ -104,7 +104,7 @@ def planes_of(layer):
     pal, h = geti(layer, "current_palette"), geti(layer, "height")
     out = []
     for i in range(n.value):
-        ph = h if (i == 0 or pal in (544, 522)) else h >> 1
+        ph = h if (i == 0 or pal in (544, 545, 522)) else h >> 1
         buf = (ctypes.c_uint8 * (rs[i] * ph)).from_address(pd[i])
         out.append(np.frombuffer(buf, np.uint8).reshape(ph, rs[i]).copy())
     return out, [pd[i] for i in range(n.value)], [rs[i] for i in range(n.value)]
