@@ -199,6 +199,22 @@ int lgpu_chain(const lgpu_chain_params *params, const lgpu_chain_track *tracks, 
 int lgpu_chain_timed(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks,
                      int reps, float *ms_total, void *stream);
 
+/* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),
+   :167-189 (background, z order), :288-293 (paint loop).  One kernel: every output pixel starts from bgcol (R,G,B;
+   alpha byte 0xFF) and takes the layers that cover it in paint order -- revz == 0: the last layer first, so layer 0 ends
+   on top -- with dst.c = (uint8_t)(dst.c * (1. - alpha) + src.c * alpha) in double per colour byte.  Layers arrive
+   already scaled (lgpu_resize; the reference scales with un-vendored gdk-pixbuf) at pixel offsets
+   offs = (int)(offs_fraction * out_size).  Up to LGPU_COMP_MAX_LAYERS layers per call. */
+#define LGPU_COMP_MAX_LAYERS 16
+typedef struct {
+  const uint8_t *src_d;      /* NULL: layer disabled (compositor.c:192-195) */
+  int irow, width, height;
+  int offs_x, offs_y;        /* position of the layer's top-left pixel in the output */
+  double alpha;              /* per-layer opacity 0..1 */
+} lgpu_comp_layer;
+int lgpu_composite(uint8_t *dst_d, int orow, int owidth, int oheight, int psize, int is_bgr, const int bgcol[3],
+                   const lgpu_comp_layer *layers, int nlayers, int revz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -454,3 +454,63 @@ extern "C" int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int 
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// compositor fan-in: lives-plugins/weed-plugins/gdk/compositor.c:120-125, :167-189, :288-293
+// ---------------------------------------------------------------------------------------------------------------------
+namespace lgpu {
+struct CompArgs {
+  uint8_t *dst;
+  int orow, owidth, oheight, nlayers;
+  uint32_t bg;                       // background pixel in destination byte order, alpha 0xFF
+  lgpu_comp_layer layer[LGPU_COMP_MAX_LAYERS];   // already in paint order
+};
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_composite(CompArgs a) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= a.owidth) return;
+  for (int y = blockIdx.y; y < a.oheight; y += gridDim.y) {
+    int c0 = a.bg & 0xFF, c1 = (a.bg >> 8) & 0xFF, c2 = (a.bg >> 16) & 0xFF;
+    for (int z = 0; z < a.nlayers; z++) {
+      const lgpu_comp_layer &L = a.layer[z];
+      const int lx = x - L.offs_x, ly = y - L.offs_y;
+      if (lx < 0 || ly < 0 || lx >= L.width || ly >= L.height) continue;
+      const uint8_t *s = L.src_d + (size_t)ly * L.irow + (size_t)lx * PS;
+      const double al = L.alpha, inv = __dsub_rn(1., al);
+      // paint_pixel: dst * invalpha + src * alpha in double, truncated to a byte after every layer
+      c0 = (int)(uint8_t)__dadd_rn(__dmul_rn((double)c0, inv), __dmul_rn((double)s[0], al));
+      c1 = (int)(uint8_t)__dadd_rn(__dmul_rn((double)c1, inv), __dmul_rn((double)s[1], al));
+      c2 = (int)(uint8_t)__dadd_rn(__dmul_rn((double)c2, inv), __dmul_rn((double)s[2], al));
+    }
+    uint8_t *d = a.dst + (size_t)y * a.orow + (size_t)x * PS;
+    d[0] = (uint8_t)c0; d[1] = (uint8_t)c1; d[2] = (uint8_t)c2;
+    if (PS == 4) d[3] = 0xFF;
+  }
+}
+}  // namespace lgpu
+
+extern "C" int lgpu_composite(uint8_t *dst_d, int orow, int owidth, int oheight, int psize, int is_bgr, const int bgcol[3],
+                              const lgpu_comp_layer *layers, int nlayers, int revz, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(dst_d && bgcol && owidth > 0 && oheight > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4 (RGB24, BGR24, RGBA32, BGRA32)");
+  LGPU_REQUIRE(orow >= owidth * psize, "rowstride smaller than a row");
+  LGPU_REQUIRE(nlayers >= 0 && nlayers <= LGPU_COMP_MAX_LAYERS && (nlayers == 0 || layers), "0..LGPU_COMP_MAX_LAYERS layers");
+  lgpu::CompArgs a;
+  a.dst = dst_d; a.orow = orow; a.owidth = owidth; a.oheight = oheight; a.nlayers = 0;
+  const int r = is_bgr ? 2 : 0, b = is_bgr ? 0 : 2;
+  a.bg = (uint32_t)(bgcol[r] & 0xFF) | ((uint32_t)(bgcol[1] & 0xFF) << 8) | ((uint32_t)(bgcol[b] & 0xFF) << 16) | 0xFF000000u;
+  // paint order (compositor.c:181-189): revz == 0 walks the channels from the last to the first
+  for (int i = 0; i < nlayers; i++) {
+    const lgpu_comp_layer &L = layers[revz ? i : nlayers - 1 - i];
+    if (!L.src_d) continue;
+    LGPU_REQUIRE(L.width > 0 && L.height > 0 && L.irow >= L.width * psize, "bad layer geometry");
+    a.layer[a.nlayers++] = L;
+  }
+  const dim3 grid(cdiv((unsigned)owidth, kBlock), (unsigned)(oheight < 2048 ? oheight : 2048));
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_composite<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(lgpu::k_composite<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

@@ -39,3 +39,32 @@ def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def fan_in(local_frames, ntracks, dst=0):
+    """Compositing fan-in (SURVEY 8f "next" 1): gather the processed frames of all tracks on rank `dst`.
+
+    local_frames: this rank's frames in the order of shard_tracks(ntracks, rank, world) -- equal-shaped uint8 tensors.
+    Returns the ntracks frames in track order on `dst`, None elsewhere.  Over RCCL this is a gather on the xGMI links
+    into `dst`; every rank contributes ceil(ntracks / world) slots (short ranks pad with their last frame, dropped on
+    arrival) so that one collective moves the whole batch.
+    """
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return list(local_frames)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    slots = (ntracks + world - 1) // world
+    mine = list(local_frames)
+    assert len(mine) == len(shard_tracks(ntracks, rank, world)) and mine, "every rank must own at least one track"
+    while len(mine) < slots:
+        mine.append(mine[-1])
+    send = torch.stack(mine)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst)
+    if rank != dst:
+        return None
+    out = [None] * ntracks
+    for r in range(world):
+        for i, t in enumerate(shard_tracks(ntracks, r, world)):
+            out[t] = recv[r][i]
+    return out
+

@@ -31,6 +31,12 @@ class ChainTrack(ctypes.Structure):
     _fields_ = [("src_d", vp), ("layer2_d", vp), ("dst_d", vp)]
 
 
+class CompLayer(ctypes.Structure):
+    """lgpu_comp_layer (include/lives_gpu.h)"""
+    _fields_ = [("src_d", ctypes.c_void_p), ("irow", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int),
+                ("offs_x", ctypes.c_int), ("offs_y", ctypes.c_int), ("alpha", ctypes.c_double)]
+
+
 class ChainParams(ctypes.Structure):
     _fields_ = [("sw", ci), ("sh", ci), ("irow", ci), ("dw", ci), ("dh", ci), ("irow2", ci), ("orow", ci),
                 ("swap_rb", ci), ("interp", ci), ("do_blur", ci), ("bf", ci), ("use_lut", ci),
@@ -68,6 +74,7 @@ PROTOTYPES = {
     "lgpu_rgb_to_yuv": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp],
     "lgpu_yuv_to_rgb": [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_edge": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_composite": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp],
     "lgpu_chain": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci, vp],
     "lgpu_chain_timed": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci, ci, ctypes.POINTER(ctypes.c_float), vp],
 }

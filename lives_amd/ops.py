@@ -135,6 +135,25 @@ def edge(src, dst, width, height, palette, mode):
     lib.call("lgpu_edge", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, palette, mode, stream_ptr())
 
 
+def comp_geometry(owidth, oheight, offs_x, offs_y, scale_x, scale_y):
+    """pixel geometry of one compositor layer (compositor.c:197-212): offsets truncate, sizes round to even"""
+    return (int(offs_x * float(owidth)), int(offs_y * float(oheight)),
+            (int(owidth * scale_x + 1.) >> 1) << 1, (int(oheight * scale_y + 1.) >> 1) << 1)
+
+
+def composite(dst, owidth, oheight, psize, layers, bgcol=(0, 0, 0), is_bgr=0, revz=0):
+    """layers: list of (tensor or None, width, height, offs_x, offs_y, alpha) already scaled to their on-screen size"""
+    n = len(layers)
+    arr = (lib.CompLayer * max(1, n))()
+    for i, (t, w, h, ox, oy, al) in enumerate(layers):
+        arr[i].src_d = dptr(t) if t is not None else None
+        arr[i].irow = t.stride(0) if t is not None else 0
+        arr[i].width, arr[i].height, arr[i].offs_x, arr[i].offs_y, arr[i].alpha = w, h, ox, oy, float(al)
+    bg = (ctypes.c_int * 3)(*[int(c) for c in bgcol])
+    lib.call("lgpu_composite", dptr(dst), dst.stride(0), owidth, oheight, psize, int(is_bgr), ctypes.addressof(bg), ctypes.addressof(arr), n,
+             int(revz), stream_ptr())
+
+
 def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None, param_block=None):
     p = lib.ChainParams()
     p.param_block_d = param_block.data_ptr() if param_block is not None else None

@@ -840,6 +840,35 @@ void orc_edge(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, i
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * C1: compositor                        reference: lives-plugins/weed-plugins/gdk/compositor.c:120-125, :167-189, :288-293
+ * ---------------------------------------------------------------------------------------------- */
+void orc_composite(uint8_t *dst, int orow, int owidth, int oheight, int psize, int is_bgr, const int bgcol[3],
+                   const orc_comp_layer *layers, int nlayers, int revz) {
+  const int r = is_bgr ? 2 : 0, b = is_bgr ? 0 : 2;
+  for (int y = 0; y < oheight; y++)                                         /* :171-178 */
+    for (int x = 0; x < owidth; x++) {
+      uint8_t *d = dst + (size_t)y * orow + x * psize;
+      d[0] = (uint8_t)bgcol[r]; d[1] = (uint8_t)bgcol[1]; d[2] = (uint8_t)bgcol[b];
+      if (psize == 4) d[3] = 0xFF;
+    }
+  const int starti = revz ? 0 : nlayers - 1, endi = revz ? nlayers : -1, stepi = revz ? 1 : -1;   /* :181-189 */
+  for (int z = starti; z != endi; z += stepi) {
+    const orc_comp_layer *L = &layers[z];
+    if (!L->src) continue;
+    const double alpha = L->alpha, invalpha = 1. - alpha;
+    for (int y = L->offs_y; y < oheight && y < L->offs_y + L->height; y++)
+      for (int x = L->offs_x; x < owidth && x < L->offs_x + L->width; x++) {
+        if (x < 0 || y < 0) continue;
+        uint8_t *d = dst + (size_t)y * orow + x * psize;
+        const uint8_t *sp = L->src + (size_t)(y - L->offs_y) * L->irow + (x - L->offs_x) * psize;
+        d[0] = (uint8_t)(d[0] * invalpha + sp[0] * alpha);                  /* paint_pixel :120-125 */
+        d[1] = (uint8_t)(d[1] * invalpha + sp[1] * alpha);
+        d[2] = (uint8_t)(d[2] * invalpha + sp[2] * alpha);
+      }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * R1: resize -- UNPINNED.  The reference hands this to FFmpeg libswscale (src/colourspace.c:14711,
  * flags :14991-14997), which is neither vendored nor version-pinned.  Spec "lgpu-polyphase-v1"
  * (DESIGN.md): separable polyphase FIR, horizontal then vertical, Q14 coefficients, 15-bit

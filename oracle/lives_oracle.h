@@ -107,6 +107,15 @@ void orc_softlight_y(const uint8_t *src, int irow, uint8_t *dst, int orow, int w
 void orc_edge(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int pal, int mode,
               int16_t *map16, int inplace);
 
+/* C1: "compositor" fan-in  lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel), :167-178 (background),
+   :181-189 (z order), :288-293 (paint loop).  Layers arrive already scaled (the reference scales with gdk-pixbuf, which
+   is un-vendored: scaling is the caller's lgpu-polyphase-v1 resize).  Per layer, in paint order (revz == 0: last
+   layer first, so layer 0 ends on top): dst.c = (uint8_t)(dst.c * (1. - alpha) + src.c * alpha) in double for the
+   three colour bytes; alpha byte of 4-byte palettes stays 0xFF.  bgcol is R,G,B; is_bgr swaps where R and B land. */
+typedef struct { const uint8_t *src; int irow, width, height, offs_x, offs_y; double alpha; } orc_comp_layer;
+void orc_composite(uint8_t *dst, int orow, int owidth, int oheight, int psize, int is_bgr, const int bgcol[3],
+                   const orc_comp_layer *layers, int nlayers, int revz);
+
 /* R1 (UNPINNED, spec "lgpu-polyphase-v1" in DESIGN.md) */
 enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_BILINEAR = 2, ORC_INTERP_HYPER = 3 };
 int orc_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);

@@ -89,6 +89,7 @@ def oracle():
         _O.orc_rgb_to_yuv.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci]
         _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
         _O.orc_cavg.argtypes = [ci, ci, ci]
+        _O.orc_composite.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci]
         _O.orc_edge.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci]
         _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
         _O.orc_gauss5.argtypes = [vp, ci, vp, ci, ci, ci, ci]
@@ -117,6 +118,11 @@ def csref():
         _R.csref_k4.argtypes = [ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, ci, ci]
         _R.csref_k3.argtypes = [ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci]
     return _R
+
+
+class CompLayer(ctypes.Structure):
+    """orc_comp_layer / lgpu_comp_layer (same layout)"""
+    _fields_ = [("src", vp), ("irow", ci), ("width", ci), ("height", ci), ("offs_x", ci), ("offs_y", ci), ("alpha", cd)]
 
 
 class RefParam(ctypes.Structure):

@@ -349,6 +349,26 @@ def main():
     if r.returncode:
         sys.exit(r.returncode)
     print("built", so)
+    # compositor: only paint_pixel (lives-plugins/weed-plugins/gdk/compositor.c:120-125) is sliceable -- the rest of that
+    # plugin needs gdk-pixbuf headers.  The wrapper walks the paint loop of :288-293 over one layer.
+    comp = os.path.join(OUT, "comp_slice.c")
+    with open(comp, "w") as f:
+        f.write("/* GENERATED SCRATCH FILE -- contains reference text; never commit */\n#include <stdint.h>\n")
+        f.write(lines("lives-plugins/weed-plugins/gdk/compositor.c", 120, 125))
+        f.write('''
+void compref_paint_layer(unsigned char *dst, int orowstride, int owidth, int oheight, int psize, unsigned char *src, int irowstride,
+                         int out_width, int out_height, int myoffsx, int myoffsy, double myalpha) {
+  int x, y;
+  for (y = myoffsy; y < oheight && y < myoffsy + out_height; y++)
+    for (x = myoffsx; x < owidth && x < myoffsx + out_width; x++)
+      paint_pixel(dst, y * orowstride + x * psize, src, (y - myoffsy) * irowstride + (x - myoffsx) * psize, myalpha);
+}
+''')
+    so2 = os.path.join(OUT, "libcompref.so")
+    r = subprocess.run(["gcc", "-shared", "-fPIC", "-O2", "-w", "-o", so2, comp])
+    if r.returncode:
+        sys.exit(r.returncode)
+    print("built", so2)
 
 
 if __name__ == "__main__":

@@ -229,6 +229,8 @@ def main():
     gen_golden_stencils.main()
     import gen_golden_palette           # K3 / K4 conversions (own seed stream, own file)
     gen_golden_palette.main()
+    import gen_golden_comp              # compositor paint loop
+    gen_golden_comp.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

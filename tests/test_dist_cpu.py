@@ -26,6 +26,13 @@ WORKER = textwrap.dedent('''
         assert blk.tolist() == [96 + 7 * step, step, 0, 0], (rank, blk)
     t = ld.max_over_ranks(1.0 + rank, "cpu")
     assert t == float(world), t
+    # compositing fan-in: 5 tracks over 2 ranks (rank 1 pads one slot), frame t is filled with t + 1
+    mine5 = ld.shard_tracks(5, rank, world)
+    got = ld.fan_in([torch.full((4, 16), t + 1, dtype=torch.uint8) for t in mine5], 5, dst=0)
+    if rank == 0:
+        assert [int(g[0, 0]) for g in got] == [1, 2, 3, 4, 5] and all(g.shape == (4, 16) for g in got)
+    else:
+        assert got is None
     dist.barrier()
     os.write(1, ("rank " + str(rank) + " ok " + str(mine) + chr(10)).encode())   # one write: the two ranks share a pipe
 ''') % ROOT

@@ -179,3 +179,15 @@ def test_k34_palette_matrix_vs_reference(gpu):
         n += 1
     assert n > 150
 
+
+def test_compositor_vs_reference(gpu):
+    g = gu.load("comp.npz")
+    for rec in map(str, g["records"]):
+        ps, is_bgr, revz, ow, oh = map(int, rec.split("|")[1:])
+        geo, alphas = g[rec + "|geo"], g[rec + "|alpha"]
+        layers = [(dev(g[rec + "|l%d" % z]),) + tuple(int(v) for v in geo[z]) + (float(alphas[z]),) for z in range(4)]
+        want = g[rec + "|o"]
+        d = dev(np.full_like(want, 0x5A))
+        gpu.composite(d, ow, oh, ps, layers, bgcol=[int(v) for v in g[rec + "|bg"]], is_bgr=is_bgr, revz=revz)
+        assert (host(d)[:, :ow * ps] == want[:, :ow * ps]).all(), rec
+

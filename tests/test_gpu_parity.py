@@ -377,6 +377,36 @@ def test_edge(gpu, orc, palette, mode):
             assert_same(host(d), want, w, h, ps, "edge pal=%d mode=%d %dx%d inplace=%d" % (palette, mode, w, h, inplace))
 
 
+# ---------------------------------------------------------------------------------------------- compositor fan-in
+@pytest.mark.parametrize("psize", [3, 4])
+def test_composite(gpu, orc, psize):
+    rng = np.random.default_rng(1900 + psize)
+    for (ow, oh) in [(40, 20), (130, 50), (300, 17)]:
+        for n in (0, 1, 3, 16):
+            layers, keep = [], []
+            for z in range(n):
+                w, h = int(rng.integers(4, ow + 8)), int(rng.integers(4, oh + 8))
+                a = frame(rng, w, h, psize)
+                keep.append(a)
+                layers.append((a, w, h, int(rng.integers(0, ow)), int(rng.integers(0, oh)), float(rng.choice([0., 0.25, 0.5, 0.7312, 1.]))))
+            if n >= 3:
+                layers[1] = (None,) + layers[1][1:]                         # a disabled channel
+            bg = [int(v) for v in rng.integers(0, 256, 3)]
+            for is_bgr in (0, 1):
+                for revz in (0, 1):
+                    L = (po.CompLayer * max(1, n))()
+                    for z, (a, w, h, ox, oy, al) in enumerate(layers):
+                        L[z].src = a.ctypes.data if a is not None else None
+                        L[z].irow = a.strides[0] if a is not None else 0
+                        L[z].width, L[z].height, L[z].offs_x, L[z].offs_y, L[z].alpha = w, h, ox, oy, al
+                    want = np.full((oh, align(ow * psize)), 0x5A, np.uint8)
+                    orc.orc_composite(P(want), want.strides[0], ow, oh, psize, is_bgr, (ctypes.c_int * 3)(*bg), L, n, revz)
+                    d = dev(np.full_like(want, 0x5A))
+                    gpu.composite(d, ow, oh, psize, [(dev(a) if a is not None else None, w, h, ox, oy, al) for (a, w, h, ox, oy, al) in layers],
+                                  bgcol=bg, is_bgr=is_bgr, revz=revz)
+                    assert_same(host(d), want, ow, oh, psize, "composite ps=%d n=%d bgr=%d revz=%d %dx%d" % (psize, n, is_bgr, revz, ow, oh))
+
+
 # ---------------------------------------------------------------------------------------------- K7 / B1 (own spec)
 @pytest.mark.parametrize("psize", [4, 3, 1])
 def test_resize(gpu, orc, psize):

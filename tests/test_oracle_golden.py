@@ -207,3 +207,28 @@ def test_k34_palette_matrix(orc):
         n += 1
     assert n == len(g["records"]) and n > 150
 
+
+def comp_layers(g, rec, ptr_of):
+    geo, alphas = g[rec + "|geo"], g[rec + "|alpha"]
+    L = (po.CompLayer * 4)()
+    keep = []
+    for z in range(4):
+        a = g[rec + "|l%d" % z]
+        keep.append(a)
+        L[z].src, L[z].irow = ptr_of(a), a.strides[0]
+        L[z].width, L[z].height, L[z].offs_x, L[z].offs_y = [int(v) for v in geo[z]]
+        L[z].alpha = float(alphas[z])
+    return L, keep
+
+
+def test_compositor(orc):
+    import ctypes
+    g = gu.load("comp.npz")
+    for rec in map(str, g["records"]):
+        ps, is_bgr, revz, ow, oh = map(int, rec.split("|")[1:])
+        L, keep = comp_layers(g, rec, lambda a: a.ctypes.data)
+        want = g[rec + "|o"]
+        got = np.full_like(want, 0x5A)
+        orc.orc_composite(P(got), got.strides[0], ow, oh, ps, is_bgr, (ctypes.c_int * 3)(*[int(v) for v in g[rec + "|bg"]]), L, 4, revz)
+        assert (got[:, :ow * ps] == want[:, :ow * ps]).all(), rec
+
