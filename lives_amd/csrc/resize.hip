@@ -574,12 +574,14 @@ struct H8S {
   static constexpr int kNQ = 16 / kH8sCW;              // horizontal pass: 4-column blocks per compute wave
   static constexpr int kWinBytes = kRows * 544;        // 20672 = 20 x 1024 + 192: 21 DMA instructions, the last with 12 lanes
   static constexpr int kRounds = 21, kTailLanes = 12;
+  static constexpr int kHPitch = 264;                  // dwords per row pair of the intermediate: 256 + 8, so the four row groups of an
+                                                       //   MFMA result (pairs 2g, g = 0..3) land on different LDS banks (2 * 264 * g mod 64 = 16 g)
   static constexpr int kSplit = 11;                    // DMA instructions 0..10: memory wave 4, 11..20: memory wave 5
 };
 template <int NSLOT>                                    // window slots: 2 (two workgroups per CU) or 1 (three per CU)
 struct H8SL {
   static constexpr int kOffH = NSLOT * H8S::kWinBytes;                       // 41344 / 20672
-  static constexpr int kOffQ = kOffH + H8S::kPairs * kTileW * 16;            // 2 x [16][64] pixels
+  static constexpr int kOffQ = kOffH + H8S::kPairs * H8S::kHPitch * 4;         // 2 x [16][64] pixels
   static constexpr int kOffLut = kOffQ + 2 * 4096;
   static constexpr int kOffAlpha = kOffLut + 256;                            // float[256]
   static constexpr size_t kLds = kOffAlpha + 1024;                           // 70272 / 49600
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
     {
       constexpr int NQ = C::kNQ;
       const uint8_t *abase = s_pl + m * kH8Pitch + wave * (NQ * 32) + g * 16;  // + mb * 16 rows + q * 32
-      uint32_t *hbase = reinterpret_cast<uint32_t *>(s_h) + wave * (NQ * 16) + m;   // + pr * 256 + q * 16
+      uint32_t *hbase = reinterpret_cast<uint32_t *>(s_h) + wave * (NQ * 16) + m;   // + pr * kHPitch + q * 16
       int4v av[NQ], an[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; q++) av[q] = *reinterpret_cast<const int4v *>(abase + q * 32);
@@ -934,9 +936,9 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
           const uint32_t x2 = (uint32_t)((dh[q][2] << 7) + dl[q][2]), x3 = (uint32_t)((dh[q][3] << 7) + dl[q][3]);
           const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
           const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
-          uint32_t *hp = hbase + pr * 256 + q * 16;
+          uint32_t *hp = hbase + pr * C::kHPitch + q * 16;
           if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
-          if (pr + 1 < C::kPairs) hp[256] = __builtin_bit_cast(uint32_t, q1);
+          if (pr + 1 < C::kPairs) hp[C::kHPitch] = __builtin_bit_cast(uint32_t, q1);
         }
         if (mb + 1 < C::kMBlocks) {
 #pragma unroll
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
       const uint4 *col = reinterpret_cast<const uint4 *>(s_h) + lane;
       uint4 w[RPW + 3];
 #pragma unroll
-      for (int i = 0; i < RPW + 3; i++) w[i] = col[(ly0 + i) * kTileW];
+      for (int i = 0; i < RPW + 3; i++) w[i] = col[(ly0 + i) * (C::kHPitch / 4)];
       uint32_t q2[RPW];
 #pragma unroll
       for (int i = 0; i < RPW; i++) q2[i] = a.blend ? qs[i * kTileW] : 0xFF000000u;
