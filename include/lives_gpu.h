@@ -52,6 +52,8 @@ int lgpu_conversion_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb);
 /* replaces create_gamma_lut8 (src/colourspace.c:655-736), same return convention: 1 = LUT written,
    0 = no conversion needed (the reference returns NULL) */
 int lgpu_gamma_lut8(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint8_t lut[256]);
+/* create_gamma_lut (src/colourspace.c:738-808): 65536 x uint16; returns 1 if a LUT was produced (HOST function) */
+int lgpu_gamma_lut16(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint16_t *lut16);
 /* rowstride rule; replaces calc_rowstrides (src/colourspace.c:11252-11366) for an explicit alignment
    (0 = RS_ALIGN_DEF 32, -1 = compact).  Returns the number of planes, fills rowstrides[4]. */
 int lgpu_calc_rowstrides(int width, int palette, int alignment, int rowstrides[4]);
@@ -90,6 +92,13 @@ int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v
                         long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
                         int opsize, int out_order, int is_422, int which_tables, int pb_quality,
                         const uint8_t *lut8, int flags, void *stream);
+/* the same conversion with the reference's 16-bit indexed gamma LUT fused in, as convert_yuv420p_to_rgb_frame does when it
+   is handed a target gamma (:3274-3283; xyuv2rgb_with_gamma :2386-2390): c = lut16[CLAMP16biti(sum >> 8)] >> 8.
+   lut16_d: DEVICE pointer to 65536 uint16 (build on the host with lgpu_gamma_lut16, upload once, reuse). */
+int lgpu_yuv420p_to_rgb_lut16(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
+                              long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
+                              int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                              const uint16_t *lut16_d, int flags, void *stream);
 
 /* ---- K8: letterbox; replaces the canvas fill + blit of letterbox_layer (src/colourspace.c:15343-15567;
    fill :11109-11119).  Writes every pixel of the nwidth x nheight canvas exactly once. */

@@ -155,6 +155,35 @@ int lgpu_gamma_lut8(double file_gamma, int gamma_from, int gamma_to, double scre
   return 1;
 }
 
+// create_gamma_lut (src/colourspace.c:738-808): the 65536-entry table the reference fuses into YUV -> RGB when it is given a
+// target gamma; same evolving source-gamma state as the 8-bit builder above, CLAMP16bit (src/colourspace.h:16) at the end
+int lgpu_gamma_lut16(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint16_t *lut) {
+  if (!lut) return 0;
+  if (file_gamma == 1.0 &&
+      (gamma_to == gamma_from || gamma_to == WEED_GAMMA_UNKNOWN || gamma_from == WEED_GAMMA_UNKNOWN)) return 0;
+  const float inv_screen = (gamma_to == LIVES_GAMMA_MONITOR) ? 1. / (float)screen_gamma : 0.f;
+  int src = gamma_from;
+  lut[0] = 0;
+  for (int i = 1; i < 65536; ++i) {
+    float lin_v, enc_v;
+    lin_v = enc_v = (float)i / 65536.;
+    if (file_gamma != 1.0) enc_v = powf(lin_v, file_gamma);
+    if (src == LIVES_GAMMA_MONITOR) { enc_v = powf(lin_v, screen_gamma); src = WEED_GAMMA_SRGB; }
+    if (src != WEED_GAMMA_LINEAR && !(src == WEED_GAMMA_SRGB && gamma_to == LIVES_GAMMA_MONITOR)) {
+      const Transfer t = transfer_for(src);
+      lin_v = (lin_v < t.thresh) ? lin_v / t.lin : powf((lin_v + t.offs) / (1. + t.offs), t.pf);
+      src = WEED_GAMMA_LINEAR;
+    }
+    if (gamma_to != WEED_GAMMA_LINEAR) {
+      const Transfer t = transfer_for(gamma_to == LIVES_GAMMA_MONITOR ? WEED_GAMMA_SRGB : gamma_to);
+      enc_v = (lin_v < (t.thresh) / t.lin) ? lin_v * t.lin : powf((1. + t.offs) * lin_v, 1. / t.pf) - t.offs;
+    }
+    if (gamma_to == LIVES_GAMMA_MONITOR) enc_v = powf(lin_v, inv_screen);
+    lut[i] = enc_v >= 0.99999 ? 65535 : enc_v < 0.00001 ? 0 : (uint16_t)(enc_v * 65535.9999);
+  }
+  return 1;
+}
+
 int lgpu_calc_rowstrides(int width, int palette, int alignment, int rs[4]) {
   int nplanes = 1, bytes;
   rs[0] = rs[1] = rs[2] = rs[3] = 0;

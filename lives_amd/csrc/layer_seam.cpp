@@ -336,9 +336,17 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     const int strides[3] = {l.rs[0], l.rs[iu], l.rs[iv]};
     const int which = (iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | (l.subspace == WEED_YUV_SUBSPACE_BT709 ? 2 : 0);
     const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
-    ok = dy && du && dv && up(dy, l.pd[0], yb) && up(du, l.pd[iu], ub) && up(dv, l.pd[iv], vb) &&
-         lgpu_yuv420p_to_rgb(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
-                             inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, lutp, 0, nullptr) == LGPU_OK;
+    ok = dy && du && dv && up(dy, l.pd[0], yb) && up(du, l.pd[iu], ub) && up(dv, l.pd[iv], vb);
+    if (ok && lutp) {
+      // with a target gamma the reference fuses the 16-bit indexed LUT of create_gamma_lut into the conversion (:3274-3283)
+      static thread_local std::vector<uint16_t> h16(65536);
+      uint8_t *d16 = t_scr.get(7, 65536 * 2);
+      ok = d16 && lgpu_gamma_lut16(1.0, l.gamma, new_gamma, g_prefs.screen_gamma, h16.data()) && up(d16, (const uint8_t *)h16.data(), 65536 * 2) &&
+           lgpu_yuv420p_to_rgb_lut16(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
+                                     inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, (const uint16_t *)d16, 0, nullptr) == LGPU_OK;
+    } else if (ok)
+      ok = lgpu_yuv420p_to_rgb(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
+                               inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, nullptr, 0, nullptr) == LGPU_OK;
   } else if (ok && k3_fmt(inpl) >= 0) {
     // K3: packed / planar 4:4:4, UYVY, YUYV -> RGB family (src/colourspace.c:12937-13860 cases); no inline gamma on these paths
     const int fmt = k3_fmt(inpl), in_alpha = (inpl == WEED_PALETTE_YUVA8888 || inpl == WEED_PALETTE_YUVA4444P);

@@ -27,6 +27,7 @@ struct YuvArgs {
   int width, height;
   int opsize, order;       // order: 0 RGB(A), 1 BGR(A), 2 ARGB
   int clamped, low_quality, fix_edges, use_lut;
+  const uint16_t *lut16;   // device, 65536 entries: the fused LUT16 of xyuv2rgb_with_gamma (:2386-2390), or null
 };
 
 __device__ __forceinline__ int cuv_c(int n) {   // CLAMP16_240 (src/colourspace.h:19)
@@ -38,6 +39,7 @@ __device__ __forceinline__ int cuv_c(int n) {   // CLAMP16_240 (src/colourspace.
 struct YuvCtx {
   const int32_t *ty, *rcr, *gcb, *gcr, *bcb;
   const uint8_t *lut;
+  const uint16_t *lut16;
   bool clamped, lowq, use_lut;
   int opsize, order;
   __device__ __forceinline__ int cuv(int n) const { return clamped ? cuv_c(n) : (n < 0 ? 0 : n > 255 ? 255 : n); }
@@ -48,8 +50,16 @@ struct YuvCtx {
   }
   __device__ __forceinline__ uint32_t rgb(int y, int u, int v) const {   // xyuv2rgb (:2351-2356), >>16 (:832-835)
     const int yy = ty[y];
-    uint32_t r = clamp255((yy + rcr[v]) >> 16), g = clamp255((yy + gcb[u] + gcr[v]) >> 16), b = clamp255((yy + bcb[u]) >> 16);
-    if (use_lut) { r = lut[r]; g = lut[g]; b = lut[b]; }
+    uint32_t r, g, b;
+    if (lut16) {          // lut[CLAMP16biti(sum >> 8)] >> 8: a 128 KB table, L2 resident
+      const int ir = (yy + rcr[v]) >> 8, ig = (yy + gcb[u] + gcr[v]) >> 8, ib = (yy + bcb[u]) >> 8;
+      r = lut16[ir > 65535 ? 65535 : ir < 0 ? 0 : ir] >> 8;
+      g = lut16[ig > 65535 ? 65535 : ig < 0 ? 0 : ig] >> 8;
+      b = lut16[ib > 65535 ? 65535 : ib < 0 ? 0 : ib] >> 8;
+    } else {
+      r = clamp255((yy + rcr[v]) >> 16); g = clamp255((yy + gcb[u] + gcr[v]) >> 16); b = clamp255((yy + bcb[u]) >> 16);
+      if (use_lut) { r = lut[r]; g = lut[g]; b = lut[b]; }
+    }
     if (order == 0) return r | (g << 8) | (b << 16) | 0xFF000000u;
     if (order == 1) return b | (g << 8) | (r << 16) | 0xFF000000u;
     return 0xFFu | (r << 8) | (g << 16) | (b << 24);
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut) 
 
   YuvCtx c;
   c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
-  c.lut = s_lut; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
+  c.lut = s_lut; c.lut16 = a.lut16; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
 
   const int hw = a.width >> 1;
   const int k = blockIdx.x * kBlock + threadIdx.x;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut) 
   __syncthreads();
   YuvCtx c;
   c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
-  c.lut = s_lut; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
+  c.lut = s_lut; c.lut16 = a.lut16; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
   const int hw = a.width >> 1;
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= hw) return;
@@ -164,10 +174,10 @@ __global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut) 
 
 using namespace lgpu;
 
-extern "C" int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
-                                   long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
-                                   int opsize, int out_order, int is_422, int which_tables, int pb_quality,
-                                   const uint8_t *lut8, int flags, void *stream) {
+static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
+                               long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
+                               int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                               const uint8_t *lut8, const uint16_t *lut16_d, int flags, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(y_d && u_d && v_d && dst_d && istrides, "null plane");
@@ -187,6 +197,7 @@ extern "C" int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const
   a.width = width; a.height = height; a.opsize = opsize; a.order = out_order;
   a.clamped = !(which_tables & 1); a.low_quality = (pb_quality == 1); a.fix_edges = (flags & LGPU_YUV_FIX_EDGES) ? 1 : 0;
   a.use_lut = lut8 ? 1 : 0;
+  a.lut16 = lut16_d;
   const Lut8 l = pack_lut(lut8);
   const int units = is_422 ? height : height / 2 + 1;
   dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > 2048 ? 2048 : units), 1);
@@ -195,3 +206,21 @@ extern "C" int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+
+extern "C" int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
+                                   long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
+                                   int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                                   const uint8_t *lut8, int flags, void *stream) {
+  return yuv420p_to_rgb_impl(y_d, u_d, v_d, istrides, u_size, v_size, dst_d, orow, width, height, opsize, out_order, is_422, which_tables,
+                             pb_quality, lut8, nullptr, flags, stream);
+}
+
+extern "C" int lgpu_yuv420p_to_rgb_lut16(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
+                                         long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
+                                         int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                                         const uint16_t *lut16_d, int flags, void *stream) {
+  if (!lut16_d) { set_error("lgpu_yuv420p_to_rgb_lut16: null LUT"); return LGPU_E_BADARG; }
+  return yuv420p_to_rgb_impl(y_d, u_d, v_d, istrides, u_size, v_size, dst_d, orow, width, height, opsize, out_order, is_422, which_tables,
+                             pb_quality, nullptr, lut16_d, flags, stream);
+}
+

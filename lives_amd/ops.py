@@ -59,6 +59,14 @@ def yuv420p_to_rgb(y, u, v, dst, width, height, opsize=4, out_order=0, is_422=0,
              which_tables, pb_quality, lp[0] if lp else None, flags, stream_ptr())
 
 
+def yuv420p_to_rgb_lut16(y, u, v, dst, width, height, lut16, opsize=4, out_order=0, is_422=0, which_tables=0, pb_quality=2, flags=0):
+    """lut16: device tensor of 65536 16-bit values (the reference's fused LUT16 variant)"""
+    assert lut16.is_cuda and lut16.numel() == 65536 and lut16.element_size() == 2
+    strides = (ctypes.c_int * 3)(y.stride(0), u.stride(0), v.stride(0))
+    lib.call("lgpu_yuv420p_to_rgb_lut16", dptr(y), dptr(u), dptr(v), strides, u.numel(), v.numel(), dptr(dst), dst.stride(0), width, height,
+             opsize, out_order, is_422, which_tables, pb_quality, lut16.data_ptr(), flags, stream_ptr())
+
+
 def letterbox(src, dst, width, height, nwidth, nheight, psize, black):
     b = (ctypes.c_uint8 * 4)(*black)
     lib.call("lgpu_letterbox", dptr(src), src.stride(0), width, height, dptr(dst), dst.stride(0), nwidth, nheight, psize, b,

@@ -261,6 +261,7 @@ static inline int fix_shift(int32_t v, int quality) {         /* _spc_rnd */
 typedef struct {
   const int32_t *ty, *rcr, *gcb, *gcr, *bcb;
   const uint8_t *lut8;
+  const uint16_t *lut16;       /* xyuv2rgb_with_gamma (:2386-2390): 16-bit indexed LUT, takes precedence over lut8 */
   int quality, opsize, order, clamped;
 } yuvctx_t;
 
@@ -269,7 +270,13 @@ static inline void put_px(const yuvctx_t *c, uint8_t *d, int y, int u, int v) {
   uint8_t r = clamp_int_0_255(fix_shift(yy + c->rcr[v], c->quality));
   uint8_t g = clamp_int_0_255(fix_shift(yy + c->gcb[u] + c->gcr[v], c->quality));
   uint8_t b = clamp_int_0_255(fix_shift(yy + c->bcb[u], c->quality));
-  if (c->lut8) { r = c->lut8[r]; g = c->lut8[g]; b = c->lut8[b]; }
+  if (c->lut16) {                                   /* lut[CLAMP16biti(sum >> 8)] >> 8 */
+#define C16(n) ((n) > 65535 ? 65535 : (n) < 0 ? 0 : (n))
+    r = (uint8_t)(c->lut16[C16((yy + c->rcr[v]) >> 8)] >> 8);
+    g = (uint8_t)(c->lut16[C16((yy + c->gcb[u] + c->gcr[v]) >> 8)] >> 8);
+    b = (uint8_t)(c->lut16[C16((yy + c->bcb[u]) >> 8)] >> 8);
+#undef C16
+  } else if (c->lut8) { r = c->lut8[r]; g = c->lut8[g]; b = c->lut8[b]; }
   switch (c->order) {
   case 0: d[0] = r; d[1] = g; d[2] = b; if (c->opsize == 4) d[3] = 255; break;
   case 1: d[0] = b; d[1] = g; d[2] = r; if (c->opsize == 4) d[3] = 255; break;
@@ -287,17 +294,17 @@ static inline void vblend(const yuvctx_t *c, int s1, int s2, int *top, int *bot)
   } else { *top = cuv(c, s1 >> 1); *bot = cuv(c, s2 >> 1); }
 }
 
-int orc_yuv420p_to_rgb(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
-                       long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
-                       int opsize, int out_order, int is_422, int which_tables, int pb_quality,
-                       const uint8_t *lut8, int fix_edges) {
+static int k2_impl(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
+                   long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
+                   int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                   const uint8_t *lut8, const uint16_t *lut16, int fix_edges) {
   yuvctx_t c;
   const int ys = istrides[0], us = istrides[1], vs = istrides[2], hw = width >> 1;
   if (!tables_ready) build_tables();
   if ((width & 1) || width < 2 || height < 1) return -1;
   c.ty = T_y2r[which_tables & 3][0]; c.rcr = T_y2r[which_tables & 3][1]; c.gcb = T_y2r[which_tables & 3][2];
   c.gcr = T_y2r[which_tables & 3][3]; c.bcb = T_y2r[which_tables & 3][4];
-  c.lut8 = lut8; c.quality = pb_quality; c.opsize = (out_order == 2) ? 4 : opsize; c.order = out_order;
+  c.lut8 = lut8; c.lut16 = lut16; c.quality = pb_quality; c.opsize = (out_order == 2) ? 4 : opsize; c.order = out_order;
   c.clamped = !(which_tables & 1);
   const int ops = c.opsize;
   /* plane fetch with the index held inside the plane (the reference reads one sample past the row
@@ -387,6 +394,47 @@ int orc_yuv420p_to_rgb(const uint8_t *y, const uint8_t *u, const uint8_t *v, con
 #undef PU
 #undef PV
   return 0;
+}
+
+int orc_yuv420p_to_rgb(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
+                       long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
+                       int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                       const uint8_t *lut8, int fix_edges) {
+  return k2_impl(y, u, v, istrides, u_size, v_size, dst, orow, width, height, opsize, out_order, is_422, which_tables, pb_quality, lut8, NULL,
+                 fix_edges);
+}
+int orc_yuv420p_to_rgb_lut16(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
+                             long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
+                             int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                             const uint16_t *lut16, int fix_edges) {
+  return k2_impl(y, u, v, istrides, u_size, v_size, dst, orow, width, height, opsize, out_order, is_422, which_tables, pb_quality, NULL, lut16,
+                 fix_edges);
+}
+
+/* create_gamma_lut (src/colourspace.c:738-808): the 65536-entry sibling of create_gamma_lut8, same mutation of
+   gamma_from inside the loop; CLAMP16bit (src/colourspace.h:16) */
+int orc_gamma_lut16(double fileg, int gamma_from, int gamma_to, double screen_gamma, uint16_t *lut) {
+  float inv_gamma = 0., a, x = 0.;
+  if (fileg == 1.0 && (gamma_to == gamma_from || gamma_to == G_UNKNOWN || gamma_from == G_UNKNOWN)) return 0;
+  if (gamma_to == G_MONITOR) inv_gamma = 1. / (float)screen_gamma;
+  lut[0] = 0;
+  for (int i = 1; i < 65536; ++i) {
+    x = a = (float)i / 65536.;
+    if (fileg != 1.0) x = powf(a, fileg);
+    if (gamma_from == G_MONITOR) { x = powf(a, screen_gamma); gamma_from = G_SRGB; }
+    if (gamma_from != G_LINEAR && !(gamma_from == G_SRGB && gamma_to == G_MONITOR)) {
+      const gconst_t g = gconst_for(gamma_from);
+      a = (a < g.thresh) ? a / g.lin : powf((a + g.offs) / (1. + g.offs), g.pf);
+      gamma_from = G_LINEAR;
+    }
+    if (gamma_to != G_LINEAR) {
+      const gconst_t g = gconst_for(gamma_to == G_MONITOR ? G_SRGB : gamma_to);
+      x = (a < (g.thresh) / g.lin) ? a * g.lin : powf((1. + g.offs) * a, 1. / g.pf) - g.offs;
+    }
+    if (gamma_to == G_MONITOR) x = powf(a, inv_gamma);
+    lut[i] = (x) >= 0.99999 ? 65535 : x < 0.00001 ? 0 : (uint16_t)(x * 65535.9999);
+  }
+  return 1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -691,7 +739,7 @@ int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, in
   if (in_fmt == 1 && out_order == 1 && !out_alpha) return -1;   /* :7313 steps 4 bytes per pixel into a BGR24 row */
   c.ty = T_y2r[which_tables & 3][0]; c.rcr = T_y2r[which_tables & 3][1]; c.gcb = T_y2r[which_tables & 3][2];
   c.gcr = T_y2r[which_tables & 3][3]; c.bcb = T_y2r[which_tables & 3][4];
-  c.lut8 = NULL; c.quality = 2; c.order = out_order; c.clamped = !(which_tables & 1);
+  c.lut8 = NULL; c.lut16 = NULL; c.quality = 2; c.order = out_order; c.clamped = !(which_tables & 1);
   c.opsize = (out_order == 2 || out_alpha) ? 4 : 3;
   for (int y = 0; y < height; y++) {
     uint8_t *d = dst + (size_t)y * orow;

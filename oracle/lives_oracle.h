@@ -45,6 +45,14 @@ int orc_yuv420p_to_rgb(const uint8_t *y, const uint8_t *u, const uint8_t *v, con
                        int opsize, int out_order, int is_422, int which_tables, int pb_quality,
                        const uint8_t *lut8, int fix_edges);
 
+/* the same with the 16-bit indexed gamma LUT of create_gamma_lut (:738-808) fused in, as the reference does when it is
+   handed a target gamma (:3274-3283, xyuv2rgb_with_gamma :2386-2390): c = lut16[CLAMP16biti(sum >> 8)] >> 8 */
+int orc_yuv420p_to_rgb_lut16(const uint8_t *y, const uint8_t *u, const uint8_t *v, const int istrides[3],
+                             long u_size, long v_size, uint8_t *dst, int orow, int width, int height,
+                             int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                             const uint16_t *lut16, int fix_edges);
+int orc_gamma_lut16(double fileg, int gamma_from, int gamma_to, double screen_gamma, uint16_t *lut);
+
 /* K6: gamma_convert_layer_thread (src/colourspace.c:14034-14060) */
 void orc_gamma_apply(uint8_t *pix, int rowstride, int width, int height, int psize, int alpha_first,
                      const uint8_t *lut8);

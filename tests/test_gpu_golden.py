@@ -191,3 +191,31 @@ def test_compositor_vs_reference(gpu):
         gpu.composite(d, ow, oh, ps, layers, bgcol=[int(v) for v in g[rec + "|bg"]], is_bgr=is_bgr, revz=revz)
         assert (host(d)[:, :ow * ps] == want[:, :ow * ps]).all(), rec
 
+
+def test_k2_fused_lut16_vs_reference(gpu):
+    """lgpu_gamma_lut16 == create_gamma_lut, lgpu_yuv420p_to_rgb_lut16 == the reference with that LUT fused"""
+    import torch
+    from lives_amd.lib import load
+    g = gu.load("lut16.npz")
+    for name in map(str, g["luts"]):
+        f, t = map(int, name.split("_"))
+        mine = np.zeros(65536, np.uint16)
+        assert load().lgpu_gamma_lut16(1.0, f, t, 1.4, mine.ctypes.data) == 1
+        assert (mine == gu.lut16(g, name)).all(), name
+    d_lut = torch.from_numpy(gu.lut16(g, "-1_1").view(np.int16)).cuda()
+    for rec in g["records"]:
+        w, h, ys, cs, which, opsize, quality, is422, orow = map(int, g[rec + "_geom"])
+        chh = h if is422 else h // 2
+        Y, U, V = g[rec + "_y"], g[rec + "_u"], g[rec + "_v"]
+        d = dev(np.zeros((h, orow), np.uint8))
+        gpu.yuv420p_to_rgb_lut16(dev(Y), dev(U[:chh * cs].reshape(chh, cs)), dev(V[:chh * cs].reshape(chh, cs)), d, w, h, d_lut, opsize=opsize,
+                                 out_order=0, is_422=is422, which_tables=which, pb_quality=quality)
+        want = gu.k2_reference_pixels(g[rec + "_out"], w, h, which, opsize, is422, orow)
+        diff = (host(d)[:, :w * opsize].reshape(h, w, opsize) != want).any(axis=2) & ~gu.k2_mask(w, h, is422)
+        if (which & 1) and not is422:
+            diff[:, w - 1] = False
+            diff[1, 0] = False
+            diff[0, :] &= False
+            diff[h - 1, :] &= False
+        assert not diff.any(), "%s: %d pixels differ" % (rec, diff.sum())
+

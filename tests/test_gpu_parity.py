@@ -278,6 +278,34 @@ def test_mirror(gpu, orc, psize, mode):
             assert_same(host(d), want, w, h, psize, "mirror mode=%d %dx%d inplace=%d" % (mode, w, h, inplace))
 
 
+# ---------------------------------------------------------------------------------------------- K2 with the fused LUT16
+@pytest.mark.parametrize("is_422", [0, 1])
+def test_yuv420p_to_rgb_lut16(gpu, orc, is_422):
+    import torch
+    from lives_amd.lib import load
+    rng = np.random.default_rng(2100 + is_422)
+    for (gf, gt) in ((po.GAMMA_LINEAR, po.GAMMA_SRGB), (1, 2)):
+        want16 = np.zeros(65536, np.uint16)
+        assert orc.orc_gamma_lut16(1.0, gf, gt, 1.4, P(want16)) == 1
+        mine16 = np.zeros(65536, np.uint16)
+        assert load().lgpu_gamma_lut16(1.0, gf, gt, 1.4, mine16.ctypes.data) == 1
+        assert (mine16 == want16).all()                                       # host LUT builder == oracle (== reference, pinned on CPU)
+        d_lut = torch.from_numpy(mine16.view(np.int16)).cuda()
+        for (w, h) in [(64, 32), (66, 34), (130, 18)]:
+            for which in (0, 1, 3):
+                for order, ops in ((0, 4), (1, 3), (2, 4)):
+                    ch = h if is_422 else h // 2
+                    Y, U, V = frame(rng, w, h, 1), frame(rng, w // 2, ch, 1), frame(rng, w // 2, ch, 1)
+                    st = (ctypes.c_int * 3)(Y.strides[0], U.strides[0], V.strides[0])
+                    want = np.zeros((h, align(w * ops)), np.uint8)
+                    assert orc.orc_yuv420p_to_rgb_lut16(P(Y), P(U), P(V), st, U.size, V.size, P(want), want.strides[0], w, h, ops, order, is_422,
+                                                        which, 2, P(want16), 1) == 0
+                    d = dev(np.zeros_like(want))
+                    gpu.yuv420p_to_rgb_lut16(dev(Y), dev(U), dev(V), d, w, h, d_lut, opsize=ops, out_order=order, is_422=is_422, which_tables=which,
+                                             flags=1)
+                    assert_same(host(d), want, w, h, ops, "K2 lut16 422=%d which=%d order=%d %dx%d" % (is_422, which, order, w, h))
+
+
 # ---------------------------------------------------------------------------------------------- K4 / K3 palette matrix
 def _planes(p):
     return po.planes_args(p)

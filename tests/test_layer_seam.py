@@ -114,6 +114,16 @@ def test_c2_yuv420p_to_rgba_then_gamma(seam, orc, size):
     assert orc.orc_gamma_lut8(1.0, -1, 1, 1.4, P(lut)) == 1
     orc.orc_gamma_apply(P(want), orow, w, h, 4, 0, P(lut))
     assert rs == [orow] and (planes[0][:, :w * 4] == want[:, :w * 4]).all()
+    # convert_layer_palette_full with a target gamma: the reference fuses the 16-bit LUT into the conversion (:3274-3283)
+    lay = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette_full(lay, RGBA32, 0, 0, 1, 1) == 1
+    assert wh.geti(lay, "gamma_type") == 1
+    planes, _, rs = wh.planes_of(lay)
+    lut16 = np.zeros(65536, np.uint16)
+    assert orc.orc_gamma_lut16(1.0, -1, 1, 1.4, P(lut16)) == 1
+    want = np.zeros((h, orow), np.uint8)
+    orc.orc_yuv420p_to_rgb_lut16(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, 0, 0, 0, 2, P(lut16), 0)
+    assert (planes[0][:, :w * 4] == want[:, :w * 4]).all()
 
 
 @needs_ref

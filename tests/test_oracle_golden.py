@@ -232,3 +232,29 @@ def test_compositor(orc):
         orc.orc_composite(P(got), got.strides[0], ow, oh, ps, is_bgr, (ctypes.c_int * 3)(*[int(v) for v in g[rec + "|bg"]]), L, 4, revz)
         assert (got[:, :ow * ps] == want[:, :ow * ps]).all(), rec
 
+
+def test_lut16_and_fused_k2(orc):
+    """create_gamma_lut tables and convert_yuv420p_to_rgb_frame with a LUT16 fused (tests/golden/lut16.npz)"""
+    g = gu.load("lut16.npz")
+    for name in map(str, g["luts"]):
+        f, t = map(int, name.split("_"))
+        mine = np.zeros(65536, np.uint16)
+        assert orc.orc_gamma_lut16(1.0, f, t, 1.4, P(mine)) == 1
+        assert (mine == gu.lut16(g, name)).all(), name
+    lut = np.ascontiguousarray(gu.lut16(g, "-1_1"))
+    for rec in g["records"]:
+        w, h, ys, cs, which, opsize, quality, is422, orow = map(int, g[rec + "_geom"])
+        Y, U, V = g[rec + "_y"], g[rec + "_u"], g[rec + "_v"]
+        chh = h if is422 else h // 2
+        strides = (ctypes.c_int * 3)(ys, cs, cs)
+        got = np.zeros((h, orow), np.uint8)
+        assert orc.orc_yuv420p_to_rgb_lut16(P(Y), P(U), P(V), strides, chh * cs, chh * cs, P(got), orow, w, h, opsize, 0, is422, which, quality, P(lut), 0) == 0
+        want = gu.k2_reference_pixels(g[rec + "_out"], w, h, which, opsize, is422, orow)
+        diff = (got[:, :w * opsize].reshape(h, w, opsize) != want).any(axis=2) & ~gu.k2_mask(w, h, is422)
+        if (which & 1) and not is422:
+            diff[:, w - 1] = False
+            diff[1, 0] = False
+            diff[0, :] &= False
+            diff[h - 1, :] &= False
+        assert not diff.any(), "%s: %d pixels differ, first %s" % (rec, diff.sum(), np.argwhere(diff)[0])
+
