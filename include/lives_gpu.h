@@ -172,6 +172,18 @@ int lgpu_softlight(const uint8_t *const src_d[4], const int irow[4], uint8_t *co
    (device-side, no host round trip), non-edges black.  dst_d may equal src_d (CAN_DO_INPLACE). */
 int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette, int mode,
               void *stream);
+/* "blurzoom" (RadioacTV): lives-plugins/weed-plugins/blurzoom.c.  Stateful across frames (background luma, feedback
+   plane, snapshot frame and countdown) -> an opaque handle per filter instance, created for one frame geometry
+   (the reference's channel template is REINIT_ON_SIZE_CHANGE).  palette 3 RGBA32 / 4 BGRA32; 32 <= width < 8192.
+   mode 0 normal / 1 strobe / 2 strobe2 / 3 trigger, pattern 0 blue / 1 green / 2 red / 3 white.  Per frame: background
+   subtract + threshold, OR into the feedback plane, 4-neighbour blur (:149-168), zoom (the reference's serial pointer
+   walk :171-192 as a gather over prefix-summed step tables), saturating palette add.  Modes 1 / 2 need compact source rows
+   (the reference walks its snapshot with the source's row padding, :391-396).  Calls on one handle must be stream-ordered. */
+typedef struct lgpu_blurzoom lgpu_blurzoom;
+int lgpu_blurzoom_create(int width, int height, int palette, lgpu_blurzoom **out);
+int lgpu_blurzoom_process(lgpu_blurzoom *bz, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int mode, int pattern,
+                          void *stream);
+void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
 /* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
 int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
                 int psize, void *stream);

@@ -51,7 +51,7 @@ static int psize_of(int pal) {
 }
 
 /* ---- per-instance device buffers ("plugin_internal", like simple_blend.c:36-45) ---- */
-typedef struct { void *d[3]; size_t cap[3]; } fxdata_t;
+typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; } fxdata_t;
 
 static fxdata_t *fx_data(weed_plant_t *inst) {
   fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
@@ -81,6 +81,7 @@ static weed_error_t fx_deinit(weed_plant_t *inst) {
   fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
   if (fx) {
     for (int i = 0; i < 3; i++) if (fx->d[i]) lgpu_free(fx->d[i]);
+    if (fx->bz) lgpu_blurzoom_destroy(fx->bz);
     w_free(fx);
     void *v = NULL;
     w_set(inst, "plugin_internal", WEED_SEED_VOIDPTR, 1, &v);
@@ -229,13 +230,28 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
   return lgpu_sync(NULL) ? WEED_ERROR_PLUGIN_INVALID : WEED_SUCCESS;
 }
 
+/* "blurzoom" (blurzoom.c:345-421): stateful -- the device handle lives in plugin_internal and is rebuilt when the frame
+   geometry changes (the reference's in channel is REINIT_ON_SIZE_CHANGE) */
+static int k_blurzoom(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  fxdata_t *fx = fx_data(inst);
+  (void)kind;
+  if (!fx) return LGPU_E_NOMEM;
+  if (!fx->bz || fx->bz_w != f->width || fx->bz_h != f->height || fx->bz_pal != f->pal) {
+    if (fx->bz) lgpu_blurzoom_destroy(fx->bz);
+    fx->bz = NULL;
+    if (lgpu_blurzoom_create(f->width, f->height, f->pal, &fx->bz) != LGPU_OK) return LGPU_E_BADARG;
+    fx->bz_w = f->width; fx->bz_h = f->height; fx->bz_pal = f->pal;
+  }
+  return lgpu_blurzoom_process(fx->bz, f->dsrc[0], f->irow[0], f->ddst, f->orow, param_int(inst, 0, 0), param_int(inst, 1, 0), NULL);
+}
+
 #define PROC(name, nin, kind, kern, whole) static weed_error_t name(weed_plant_t *inst, weed_timecode_t tc) { (void)tc; return fx_run(inst, nin, kind, kern, whole); }
 PROC(p_chroma, 2, 0, k_simple, 0) PROC(p_lumo, 2, 1, k_simple, 0) PROC(p_lumu, 2, 2, k_simple, 0) PROC(p_nlumo, 2, 3, k_simple, 0) PROC(p_avlumo, 2, 4, k_simple, 0)
 PROC(p_mpy, 2, 0, k_multi, 0) PROC(p_screen, 2, 1, k_multi, 0) PROC(p_darken, 2, 2, k_multi, 0) PROC(p_lighten, 2, 3, k_multi, 0)
 PROC(p_overlay, 2, 4, k_multi, 0) PROC(p_dodge, 2, 5, k_multi, 0) PROC(p_burn, 2, 6, k_multi, 0)
 PROC(p_ckey, 2, 0, k_ckey, 0)
 PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
-PROC(p_edge, 1, 0, k_edge, 1)
+PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -367,6 +383,24 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
     if (fc) w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict);
     if (ict) s_int(ict, WEED_LEAF_FLAGS, WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
+  }
+  /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
+  {
+    static const char *modes[] = {"normal", "strobe", "strobe2", "trigger"}, *patterns[] = {"blue", "green", "red", "white"};
+    static const int32_t bzpal[] = {WEED_PALETTE_BGRA32, WEED_PALETTE_RGBA32};
+    weed_plant_t *gui = NULL, *fc = NULL, *ict = NULL, *oct = NULL;
+    p[0] = int_param("mode", "Trigger _Mode", 0, 0, 3, 0);
+    w_get(p[0], WEED_LEAF_GUI, 0, &gui);
+    if (gui) w_set(gui, WEED_LEAF_CHOICES, WEED_SEED_STRING, 4, modes);
+    p[1] = int_param("color", "_Color", 0, 0, 3, 0);
+    gui = NULL;
+    w_get(p[1], WEED_LEAF_GUI, 0, &gui);
+    if (gui) w_set(gui, WEED_LEAF_CHOICES, WEED_SEED_STRING, 4, patterns);
+    add_filter(pinfo, "blurzoom", WEED_FILTER_PREF_LINEAR_GAMMA, bzpal, 2, p_blurzoom, 1, "in channel 0", NULL, "out channel 0", p, 2);
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) { w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict); w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct); }
+    if (ict) s_int(ict, WEED_LEAF_FLAGS, WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
+    if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
   }
   /* softlight.c:160-176: planar YUV palettes, out channel NOT in place, in channel prefers unclamped luma */
   {

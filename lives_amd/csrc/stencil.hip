@@ -6,6 +6,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 namespace lgpu {
 
@@ -192,6 +193,61 @@ __global__ __launch_bounds__(kBlock) void k_edge_paint(const uint8_t *src, int i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// blurzoom (RadioacTV): lives-plugins/weed-plugins/blurzoom.c:74-101, :106-145, :149-192, :201-237, :345-421
+// ---------------------------------------------------------------------------------------------------------------------
+// background subtract + threshold (:74-101), OR of the motion mask into the feedback plane (:371-379)
+__global__ __launch_bounds__(kBlock) void k_bz_update(const uint32_t *src, int irow, int16_t *bg, uint8_t *buf, int vw, int vh, int bw, int ml,
+                                                        int threshold, int do_or) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= vw) return;
+  for (int y = blockIdx.y; y < vh; y += gridDim.y) {
+    const uint32_t p = src[(size_t)y * irow + x];
+    const int sum = (int)((p & 0xff0000) >> 15) + (int)((p & 0xff00) >> 6) + (int)(p & 0xff);
+    const int v = sum - (int)bg[(size_t)y * vw + x];
+    bg[(size_t)y * vw + x] = (int16_t)sum;
+    const uint32_t d = (uint32_t)(((v + threshold) >> 24) | ((threshold - v) >> 24)) & 0xFFu;   // 0xFF where |v| > threshold
+    if (do_or && x >= ml && x < ml + bw) buf[(size_t)y * bw + (x - ml)] |= (uint8_t)(d >> 3);
+  }
+}
+// 4-neighbour average minus one, -1 wraps to 0 (:149-168); the border of the result plane is never written
+__global__ __launch_bounds__(kBlock) void k_bz_blur(uint8_t *buf, int bw, int bh) {
+  const int x = blockIdx.x * kBlock + threadIdx.x + 1;
+  if (x >= bw - 1) return;
+  const size_t area = (size_t)bw * bh;
+  for (int y = blockIdx.y + 1; y < bh - 1; y += gridDim.y) {
+    const uint8_t *p = buf + (size_t)y * bw + x;
+    uint8_t v = (uint8_t)((p[-bw] + p[-1] + p[1] + p[bw]) / 4 - 1);
+    if (v == 255) v = 0;
+    buf[area + (size_t)y * bw + x] = v;
+  }
+}
+// the serial pointer walk of zoom() (:171-192) as a gather: row starts and inclusive column step counts are prefix sums
+__global__ __launch_bounds__(kBlock) void k_bz_zoom(uint8_t *buf, const int32_t *rowstart, const int32_t *colcum, int bw, int bh) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= bw) return;
+  const size_t area = (size_t)bw * bh;
+  const int cc = colcum[x];
+  for (int y = blockIdx.y; y < bh; y += gridDim.y) buf[(size_t)y * bw + x] = buf[area + (size_t)(rowstart[y] + cc)];
+}
+// palette add with per-byte saturation (:398-414)
+__global__ __launch_bounds__(kBlock) void k_bz_color(const uint32_t *src, int irow, uint32_t *dst, int orow, const uint8_t *buf, const uint32_t *pal,
+                                                       int vw, int vh, int bw, int ml, int pattern) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= vw) return;
+  for (int y = blockIdx.y; y < vh; y += gridDim.y) {
+    const uint32_t s = src[(size_t)y * irow + x];
+    uint32_t o = s;
+    if (x >= ml && x < ml + bw) {
+      uint32_t a = s & 0xfefeffu, b = pal[32 * pattern + buf[(size_t)y * bw + (x - ml)]];
+      a += b;
+      b = a & 0x10101u;
+      o = (s & 0xff000000u) | ((a | (b - (b >> 8))) & 0xffffffu);
+    }
+    dst[(size_t)y * orow + x] = o;
+  }
+}
+
 // per (device, stream) scratch: gradient map + state
 struct EdgeScratch { uint16_t *map = nullptr; size_t cap = 0; EdgeState *st = nullptr; };
 static std::mutex g_edge_mu;
@@ -269,3 +325,120 @@ extern "C" int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int oro
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+
+// ---- blurzoom: stateful handle ----------------------------------------------------------------------------------------
+struct lgpu_blurzoom {
+  int vw, vh, bw, bh, ml, snap_time, snap_interval, threshold, device;
+  int16_t *bg;
+  uint8_t *buf;
+  uint32_t *snap, *pal;
+  int32_t *rowstart, *colcum;
+};
+
+extern "C" void lgpu_blurzoom_destroy(lgpu_blurzoom *z) {
+  if (!z) return;
+  hipFree(z->bg); hipFree(z->buf); hipFree(z->snap); hipFree(z->pal); hipFree(z->rowstart); hipFree(z->colcum);
+  delete z;
+}
+
+extern "C" int lgpu_blurzoom_create(int width, int height, int palette, lgpu_blurzoom **out) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(out, "null result pointer");
+  LGPU_REQUIRE(width >= 32 && height >= 3 && width / 32 <= 255, "blurzoom needs 32 <= width < 8192 (blurzoom.c:262-263)");
+  LGPU_REQUIRE(palette == 3 || palette == 4, "palette must be RGBA32 (3) or BGRA32 (4)");
+  lgpu_blurzoom *z = new lgpu_blurzoom();
+  z->vw = width; z->vh = height;
+  const int blocks = width / 32;
+  z->bw = blocks * 32; z->bh = height; z->ml = (width - z->bw) / 2;
+  z->snap_time = 0; z->snap_interval = 3; z->threshold = 40 * 7;
+  LGPU_HIP(hipGetDevice(&z->device));
+  const size_t area = (size_t)z->bw * z->bh;
+  // setTable (:106-145), restated as prefix sums of the reference's own step tables
+  const double RATIO = 0.95;
+  const int HW = z->bw / 2, HH = z->bh / 2;
+  std::vector<int32_t> colcum((size_t)z->bw), rowstart((size_t)z->bh);
+  int prevptr = (int)(0.5 + RATIO * (-HW) + HW), steps = 0;
+  for (int x = 0; x < z->bw; x++) {
+    const int ptr = (int)(0.5 + RATIO * (x - HW) + HW);
+    if (ptr != prevptr) steps++;
+    prevptr = ptr;
+    colcum[(size_t)x] = steps;
+  }
+  {
+    const int tx = (int)(0.5 + RATIO * (-HW) + HW), xx = (int)(0.5 + RATIO * (z->bw - 1 - HW) + HW);
+    int ty = (int)(0.5 + RATIO * (-HH) + HH);
+    long pos = (long)ty * z->bw + tx;                 // blurzoomy[0]
+    long prev = (long)ty * z->bw + xx;
+    rowstart[0] = (int32_t)pos;
+    for (int y = 1; y < z->bh; y++) {
+      ty = (int)(0.5 + RATIO * (y - HH) + HH);
+      pos += steps;                                   // the walk ended `steps` past the row's start
+      pos += (long)ty * z->bw + tx - prev;            // blurzoomy[y]
+      prev = (long)ty * z->bw + xx;
+      rowstart[(size_t)y] = (int32_t)pos;
+    }
+  }
+  for (int y = 0; y < z->bh; y++) {                   // the walk must stay inside the result plane
+    const long lo = rowstart[(size_t)y], hi = lo + steps;
+    if (lo < 0 || hi >= (long)area) { delete z; set_error("blurzoom zoom table leaves the feedback plane"); return LGPU_E_BADARG; }
+  }
+  uint32_t P[128];
+  __builtin_memset(P, 0, sizeof P);
+  {                                                    // makePalette (:201-237)
+    const int COLORS = 32, DELTA = 255 / (COLORS / 2 - 1);
+    for (int i = 0; i < COLORS / 2; i++) {
+      const uint32_t d = (uint32_t)(i * DELTA);
+      if (palette == 3) { P[i] = d << 16; P[COLORS * 2 + i] = d; } else { P[i] = d; P[COLORS * 2 + i] = d << 16; }
+      P[COLORS + i] = d << 8;
+      if (palette == 3) { P[i + COLORS / 2] = (255u << 16) | d << 8 | d; P[COLORS * 2 + i + COLORS / 2] = 255u | d << 16 | d << 8; }
+      else { P[i + COLORS / 2] = 255u | d << 16 | d << 8; P[COLORS * 2 + i + COLORS / 2] = (255u << 16) | d << 8 | d; }
+      P[COLORS + i + COLORS / 2] = (255u << 8) | d << 16 | d;
+    }
+    for (int i = 0; i < COLORS; i++) P[COLORS * 3 + i] = (uint32_t)(255 * i / COLORS) * 0x10101u;
+    for (int i = 0; i < 128; i++) P[i] &= 0xfefeffu;
+  }
+  bool ok = hipMalloc((void **)&z->bg, sizeof(int16_t) * (size_t)width * height) == hipSuccess &&
+            hipMalloc((void **)&z->buf, area * 2) == hipSuccess && hipMalloc((void **)&z->snap, 4 * (size_t)width * height) == hipSuccess &&
+            hipMalloc((void **)&z->pal, sizeof P) == hipSuccess && hipMalloc((void **)&z->rowstart, 4 * (size_t)z->bh) == hipSuccess &&
+            hipMalloc((void **)&z->colcum, 4 * (size_t)z->bw) == hipSuccess;
+  ok = ok && hipMemset(z->bg, 0, sizeof(int16_t) * (size_t)width * height) == hipSuccess && hipMemset(z->buf, 0, area * 2) == hipSuccess &&
+       hipMemset(z->snap, 0, 4 * (size_t)width * height) == hipSuccess &&
+       hipMemcpy(z->pal, P, sizeof P, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(z->rowstart, rowstart.data(), 4 * (size_t)z->bh, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(z->colcum, colcum.data(), 4 * (size_t)z->bw, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { lgpu_blurzoom_destroy(z); set_error("blurzoom: device allocation failed"); return LGPU_E_NOMEM; }
+  *out = z;
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_blurzoom_process(lgpu_blurzoom *z, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int mode, int pattern,
+                                     void *stream) {
+  LGPU_REQUIRE(z && src_d && dst_d, "null handle or frame");
+  LGPU_REQUIRE(mode >= 0 && mode <= 3 && pattern >= 0 && pattern <= 3, "mode 0..3 (normal, strobe, strobe2, trigger), pattern 0..3 (blue, green, red, white)");
+  LGPU_REQUIRE(!(irow & 3) && !(orow & 3) && irow >= z->vw * 4 && orow >= z->vw * 4, "rowstrides must be multiples of 4 and cover a row");
+  LGPU_REQUIRE(!((reinterpret_cast<uintptr_t>(src_d) | reinterpret_cast<uintptr_t>(dst_d)) & 3), "frames must be 4-byte aligned");
+  if ((mode == 1 || mode == 2) && irow != z->vw * 4) {
+    set_error("blurzoom strobe modes read the snapshot with the source's row padding in the reference (blurzoom.c:391-396): compact rows only");
+    return LGPU_E_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(src_d);
+  const int vw = z->vw, vh = z->vh, bw = z->bw, bh = z->bh;
+  const dim3 vgrid(cdiv((unsigned)vw, kBlock), (unsigned)(vh < 1024 ? vh : 1024)), bgrid(cdiv((unsigned)bw, kBlock), (unsigned)(bh < 1024 ? bh : 1024));
+  if (mode != 2 || z->snap_time <= 0) {
+    const int feed = (mode == 0 || z->snap_time <= 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_bz_update, vgrid, dim3(kBlock), 0, st, src, irow / 4, z->bg, z->buf, vw, vh, bw, z->ml, z->threshold, feed);
+    if (feed && (mode == 1 || mode == 2))
+      LGPU_HIP(hipMemcpy2DAsync(z->snap, (size_t)vw * 4, src_d, (size_t)irow, (size_t)vw * 4, (size_t)vh, hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(k_bz_blur, bgrid, dim3(kBlock), 0, st, z->buf, bw, bh);
+  hipLaunchKernelGGL(k_bz_zoom, bgrid, dim3(kBlock), 0, st, z->buf, z->rowstart, z->colcum, bw, bh);
+  const bool from_snap = (mode == 1 || mode == 2);
+  hipLaunchKernelGGL(k_bz_color, vgrid, dim3(kBlock), 0, st, from_snap ? z->snap : src, from_snap ? vw : irow / 4, reinterpret_cast<uint32_t *>(dst_d),
+                     orow / 4, z->buf, z->pal, vw, vh, bw, z->ml, pattern);
+  LGPU_CHECK_LAUNCH();
+  if (mode == 1 || mode == 2) { z->snap_time--; if (z->snap_time < 0) z->snap_time = z->snap_interval; }
+  return LGPU_OK;
+}
+

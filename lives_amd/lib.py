@@ -76,6 +76,9 @@ PROTOTYPES = {
     "lgpu_rgb_to_yuv": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp],
     "lgpu_yuv_to_rgb": [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_edge": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_blurzoom_create": [ci, ci, ci, vp],
+    "lgpu_blurzoom_process": [vp, vp, ci, vp, ci, ci, ci, vp],
+    "lgpu_blurzoom_destroy": [vp],
     "lgpu_composite": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp],
     "lgpu_chain": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci, vp],
     "lgpu_chain_timed": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci, ci, ctypes.POINTER(ctypes.c_float), vp],

@@ -162,6 +162,23 @@ def composite(dst, owidth, oheight, psize, layers, bgcol=(0, 0, 0), is_bgr=0, re
              int(revz), stream_ptr())
 
 
+class Blurzoom:
+    """stateful blurzoom instance (lgpu_blurzoom_*): one per filter instance and frame geometry"""
+
+    def __init__(self, width, height, palette):
+        h = ctypes.c_void_p()
+        lib.call("lgpu_blurzoom_create", width, height, palette, ctypes.addressof(h))
+        self.h = h
+
+    def process(self, src, dst, mode=0, pattern=0):
+        lib.call("lgpu_blurzoom_process", self.h, dptr(src), src.stride(0), dptr(dst), dst.stride(0), mode, pattern, stream_ptr())
+
+    def close(self):
+        if self.h:
+            lib.load().lgpu_blurzoom_destroy(self.h)
+            self.h = None
+
+
 def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None, param_block=None):
     p = lib.ChainParams()
     p.param_block_d = param_block.data_ptr() if param_block is not None else None

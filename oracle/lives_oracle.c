@@ -888,6 +888,149 @@ void orc_edge(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, i
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * F6c: blurzoom                         reference: lives-plugins/weed-plugins/blurzoom.c (ranges in lives_oracle.h)
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_blurzoom {
+  int vw, vh, bw, bh, blocks, ml, mr, threshold, snap_time, snap_interval;
+  uint8_t *buf;            /* 2 * bw * bh: feedback plane, then the blur result */
+  uint32_t *zx;            /* one 32-bit step mask per block of 32 columns */
+  int *zy;                 /* per-row pointer delta */
+  int16_t *bg;
+  uint8_t *diff;
+  uint32_t *snap;
+  uint32_t pal[256];
+};
+orc_blurzoom *orc_blurzoom_new(int width, int height, int palette) {
+  orc_blurzoom *z = (orc_blurzoom *)calloc(1, sizeof *z);
+  const double RATIO = 0.95;
+  z->vw = width; z->vh = height;
+  z->blocks = width / 32; z->bw = z->blocks * 32; z->bh = height;                    /* :260-267 */
+  z->ml = (width - z->bw) / 2; z->mr = width - z->bw - z->ml;
+  z->buf = (uint8_t *)calloc((size_t)z->bw * z->bh * 2, 1);
+  z->zx = (uint32_t *)calloc((size_t)z->bw + 1, sizeof(uint32_t));
+  z->zy = (int *)calloc((size_t)z->bh + 1, sizeof(int));
+  z->bg = (int16_t *)calloc((size_t)width * height, sizeof(int16_t));
+  z->diff = (uint8_t *)calloc((size_t)width * height, 4);
+  z->snap = (uint32_t *)calloc((size_t)width * height, 4);
+  z->threshold = 40 * 7; z->snap_time = 0; z->snap_interval = 3;                     /* :288, :318-319 */
+  {                                                                                    /* setTable :106-145 */
+    const int HW = z->bw / 2, HH = z->bh / 2;
+    int prevptr = (int)(0.5 + RATIO * (-HW) + HW), ptr, tx, ty, xx;
+    for (int b = 0; b < z->blocks; b++) {
+      uint32_t bits = 0;
+      for (int x = 0; x < 32; x++) {
+        ptr = (int)(0.5 + RATIO * (b * 32 + x - HW) + HW);
+        bits >>= 1;
+        if (ptr != prevptr) bits |= 0x80000000u;
+        prevptr = ptr;
+      }
+      z->zx[b] = bits;
+    }
+    ty = (int)(0.5 + RATIO * (-HH) + HH);
+    tx = (int)(0.5 + RATIO * (-HW) + HW);
+    xx = (int)(0.5 + RATIO * (z->bw - 1 - HW) + HW);
+    z->zy[0] = ty * z->bw + tx;
+    prevptr = ty * z->bw + xx;
+    for (int y = 1; y < z->bh; y++) {
+      ty = (int)(0.5 + RATIO * (y - HH) + HH);
+      z->zy[y] = ty * z->bw + tx - prevptr;
+      prevptr = ty * z->bw + xx;
+    }
+  }
+  {                                                                                    /* makePalette :201-237 */
+    const int COLORS = 32, DELTA = 255 / (32 / 2 - 1);
+    uint32_t *P = z->pal;
+    for (int i = 0; i < COLORS / 2; i++) {
+      if (palette == 3) { P[i] = (uint32_t)(i * DELTA) << 16; P[COLORS * 2 + i] = (uint32_t)(i * DELTA); }
+      else { P[i] = (uint32_t)(i * DELTA); P[COLORS * 2 + i] = (uint32_t)(i * DELTA) << 16; }
+      P[COLORS + i] = (uint32_t)(i * DELTA) << 8;
+    }
+    for (int i = 0; i < COLORS / 2; i++) {
+      const uint32_t d = (uint32_t)(i * DELTA);
+      if (palette == 3) { P[i + COLORS / 2] = (255u << 16) | d << 8 | d; P[COLORS * 2 + i + COLORS / 2] = 255u | d << 16 | d << 8; }
+      else { P[i + COLORS / 2] = 255u | d << 16 | d << 8; P[COLORS * 2 + i + COLORS / 2] = (255u << 16) | d << 8 | d; }
+      P[COLORS + i + COLORS / 2] = (255u << 8) | d << 16 | d;
+    }
+    for (int i = 0; i < COLORS; i++) P[COLORS * 3 + i] = (uint32_t)(255 * i / COLORS) * 0x10101u;
+    for (int i = 0; i < COLORS * 4; i++) P[i] &= 0xfefeffu;
+  }
+  return z;
+}
+void orc_blurzoom_free(orc_blurzoom *z) {
+  if (!z) return;
+  free(z->buf); free(z->zx); free(z->zy); free(z->bg); free(z->diff); free(z->snap); free(z);
+}
+int orc_blurzoom_process(orc_blurzoom *z, const uint8_t *src8, int irow_b, uint8_t *dst8, int orow_b, int mode, int pattern) {
+  const int vw = z->vw, vh = z->vh, bw = z->bw, bh = z->bh;
+  const size_t area = (size_t)bw * bh;
+  if ((irow_b & 3) || (orow_b & 3) || z->blocks < 1) return -1;
+  if ((mode == 1 || mode == 2) && irow_b != vw * 4) return -1;
+  const uint32_t *src = (const uint32_t *)src8;
+  uint32_t *dst = (uint32_t *)dst8;
+  int irow = irow_b / 4;
+  const int orow = orow_b / 4;
+  if (mode != 2 || z->snap_time <= 0) {                                               /* :368 */
+    for (int y = 0; y < vh; y++)                                                       /* image_bgsubtract_update_y :74-101 */
+      for (int x = 0; x < vw; x++) {
+        const uint32_t p = src[(size_t)y * irow + x];
+        const int R = (int)((p & 0xff0000) >> (16 - 1)), G = (int)((p & 0xff00) >> (8 - 2)), B = (int)(p & 0xff);
+        const int v = (R + G + B) - (int)z->bg[(size_t)y * vw + x];
+        z->bg[(size_t)y * vw + x] = (int16_t)(R + G + B);
+        z->diff[(size_t)y * vw + x] = (uint8_t)(((v + z->threshold) >> 24) | ((z->threshold - v) >> 24));
+      }
+    if (mode == 0 || z->snap_time <= 0) {
+      for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) z->buf[(size_t)y * bw + x] |= z->diff[(size_t)y * vw + z->ml + x] >> 3;
+      if (mode == 1 || mode == 2)
+        for (int y = 0; y < vh; y++) memcpy(z->snap + (size_t)y * vw, src + (size_t)y * irow, (size_t)vw * 4);
+    }
+  }
+  {                                                                                    /* blur :149-168 */
+    const uint8_t *p = z->buf + bw + 1;
+    uint8_t *q = z->buf + area + bw + 1;
+    for (int y = bh - 2; y > 0; y--) {
+      for (int x = bw - 2; x > 0; x--) {
+        uint8_t v;
+        if ((v = (uint8_t)((p[-bw] + p[-1] + p[1] + p[bw]) / 4 - 1)) == 255) v = 0;
+        *(q++) = v;
+        p++;
+      }
+      p += 2; q += 2;
+    }
+  }
+  {                                                                                    /* zoom :171-192 */
+    const uint8_t *p = z->buf + area;
+    uint8_t *q = z->buf;
+    for (int y = 0; y < bh; y++) {
+      p += z->zy[y];
+      for (int b = 0; b < z->blocks; b++) {
+        uint32_t dx = z->zx[b];
+        for (int x = 0; x < 32; x++) { p += (dx & 1); *q++ = *p; dx >>= 1; }
+      }
+    }
+  }
+  {
+    const uint32_t *s = (mode == 1 || mode == 2) ? z->snap : src;                     /* :391-396: keeps the source's row padding */
+    const uint8_t *p = z->buf;
+    const int ipad = irow - vw, opad = orow - vw;
+    uint32_t *d = dst;
+    for (int y = 0; y < vh; y++) {
+      for (int x = 0; x < z->ml; x++) *d++ = *s++;
+      for (int x = 0; x < bw; x++) {
+        uint32_t a = *s & 0xfefeff, b = z->pal[32 * pattern + *p++];
+        a += b;
+        b = a & 0x10101;
+        *d++ = (*s++ & 0xff000000u) | ((a | (b - (b >> 8))) & 0xffffffu);
+      }
+      for (int x = 0; x < z->mr; x++) *d++ = *s++;
+      s += ipad; d += opad;
+    }
+  }
+  if (mode == 1 || mode == 2) { z->snap_time--; if (z->snap_time < 0) z->snap_time = z->snap_interval; }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * C1: compositor                        reference: lives-plugins/weed-plugins/gdk/compositor.c:120-125, :167-189, :288-293
  * ---------------------------------------------------------------------------------------------- */
 void orc_composite(uint8_t *dst, int orow, int owidth, int oheight, int psize, int is_bgr, const int bgcol[3],

@@ -115,6 +115,16 @@ void orc_softlight_y(const uint8_t *src, int irow, uint8_t *dst, int orow, int w
 void orc_edge(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int pal, int mode,
               int16_t *map16, int inplace);
 
+/* F6c: "blurzoom" (RadioacTV)  lives-plugins/weed-plugins/blurzoom.c:74-101 (background subtract), :106-145 (zoom tables),
+   :149-168 (blur), :171-192 (zoom), :201-237 (palette), :345-421 (process).  Stateful across frames: background luma,
+   feedback buffer, snapshot frame, snapshot countdown.  palette: WEED id 3 (RGBA32) or 4 (BGRA32).
+   mode 0 normal / 1 strobe / 2 strobe2 / 3 trigger; pattern 0 blue / 1 green / 2 red / 3 white.  width >= 32.
+   Modes 1 and 2 read the snapshot with the SOURCE row padding (:391-396): they need irow == 4 * width. */
+typedef struct orc_blurzoom orc_blurzoom;
+orc_blurzoom *orc_blurzoom_new(int width, int height, int palette);
+int orc_blurzoom_process(orc_blurzoom *bz, const uint8_t *src, int irow, uint8_t *dst, int orow, int mode, int pattern);
+void orc_blurzoom_free(orc_blurzoom *bz);
+
 /* C1: "compositor" fan-in  lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel), :167-178 (background),
    :181-189 (z order), :288-293 (paint loop).  Layers arrive already scaled (the reference scales with gdk-pixbuf, which
    is un-vendored: scaling is the caller's lgpu-polyphase-v1 resize).  Per layer, in paint order (revz == 0: last

@@ -91,6 +91,10 @@ def oracle():
         _O.orc_rgb_to_yuv.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci]
         _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
         _O.orc_cavg.argtypes = [ci, ci, ci]
+        _O.orc_blurzoom_new.restype = vp
+        _O.orc_blurzoom_new.argtypes = [ci, ci, ci]
+        _O.orc_blurzoom_process.argtypes = [vp, vp, ci, vp, ci, ci, ci]
+        _O.orc_blurzoom_free.argtypes = [vp]
         _O.orc_composite.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci]
         _O.orc_edge.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci]
         _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
@@ -154,6 +158,7 @@ class RefHost:
         self.H.refhost_filter_info.argtypes = [vp, ci, ctypes.c_char_p, ci, vp, ci, vp, vp, vp]
         self.H.refhost_num_filters.argtypes = [vp]
         self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
+        self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
         self.plugins = {}
 
     def load(self, path):
@@ -176,6 +181,18 @@ class RefHost:
             out.append(dict(name=buf.value.decode(), flags=flags, palettes=[p for p in pals if p],
                             n_in=nin.value, n_out=nout.value, n_params=npar.value))
         return out
+
+    def run_seq(self, path, fname, pal, w, h, srcs, dsts, params=()):
+        """one instance over a sequence of frames (stateful filters); srcs / dsts: lists of equal-stride 2-D uint8 arrays"""
+        hdl = self.load(path)
+        n = len(srcs)
+        sp = (vp * n)(*[a.ctypes.data for a in srcs])
+        dp = (vp * n)(*[a.ctypes.data for a in dsts])
+        pa = (RefParam * max(1, len(params)))(*params)
+        r = self.H.refhost_run_seq(hdl, fname.encode(), pal, w, h, n, sp, srcs[0].strides[0], dp, dsts[0].strides[0], len(params), pa)
+        if r != 0:
+            raise RuntimeError("weed filter '%s' returned %d" % (fname, r))
+        return dsts
 
     def run_planar(self, path, fname, pal, w, h, src_planes, dst_planes, clamping):
         """src_planes / dst_planes: lists of 2-D uint8 arrays (rows x rowstride), one per plane"""

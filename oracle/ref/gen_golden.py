@@ -233,6 +233,8 @@ def main():
     gen_golden_comp.main()
     import gen_golden_lut16             # create_gamma_lut + K2 with the LUT16 fused
     gen_golden_lut16.main()
+    import gen_golden_blurzoom          # stateful blurzoom over frame sequences
+    gen_golden_blurzoom.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

@@ -260,3 +260,60 @@ int refhost_run_planar(void *pinfo_v, const char *fname, int pal, int w, int h, 
   if (octm) free(octm);
   return ret;
 }
+
+/* A stateful filter over a SEQUENCE of frames on ONE instance (init once, process_func per frame, deinit once):
+ * blurzoom.c keeps its background / feedback buffers in "plugin_internal".  src[i] / dst[i]: frame i. */
+int refhost_run_seq(void *pinfo_v, const char *fname, int pal, int w, int h, int nframes,
+                    uint8_t **src, int istride, uint8_t **dst, int ostride, int nparams, const refhost_param_t *params) {
+  weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
+  weed_plant_t *filt = find_filter(pinfo, fname);
+  weed_plant_t *inst, *inch, *outch, **ictm, **octm, **iptm, *inpar[16];
+  weed_init_f init_func;
+  weed_process_f process_func;
+  weed_deinit_f deinit_func;
+  int nict = 0, noct = 0, nipt = 0, i, ret = WEED_SUCCESS;
+  if (!filt) { fprintf(stderr, "refhost: filter '%s' not found\n", fname); return -100; }
+  if (nparams > 16) return -101;
+  ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
+  octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
+  iptm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_PARAMETER_TEMPLATES, &nipt);
+  if (nict < 1 || noct < 1 || nipt < nparams) return -102;
+  inst = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
+  weed_set_plantptr_value(inst, WEED_LEAF_FILTER_CLASS, filt);
+  inch = mk_channel(ictm[0], pal, w, h, istride, src[0]);
+  outch = mk_channel(octm[0], pal, w, h, ostride, dst[0]);
+  weed_set_plantptr_value(inst, WEED_LEAF_IN_CHANNELS, inch);
+  weed_set_plantptr_value(inst, WEED_LEAF_OUT_CHANNELS, outch);
+  for (i = 0; i < nparams; i++) {
+    inpar[i] = weed_plant_new(WEED_PLANT_PARAMETER);
+    weed_set_plantptr_value(inpar[i], WEED_LEAF_TEMPLATE, iptm[i]);
+    switch (params[i].kind) {
+    case 0: weed_set_int_value(inpar[i], WEED_LEAF_VALUE, params[i].ival[0]); break;
+    case 1: weed_set_double_value(inpar[i], WEED_LEAF_VALUE, params[i].dval); break;
+    case 2: weed_set_int_array(inpar[i], WEED_LEAF_VALUE, params[i].n, (int32_t *)params[i].ival); break;
+    case 3: weed_set_boolean_value(inpar[i], WEED_LEAF_VALUE, params[i].ival[0]); break;
+    }
+  }
+  if (nparams) weed_set_plantptr_array(inst, WEED_LEAF_IN_PARAMETERS, nparams, inpar);
+  init_func = (weed_init_f)weed_get_funcptr_value(filt, WEED_LEAF_INIT_FUNC, NULL);
+  process_func = (weed_process_f)weed_get_funcptr_value(filt, WEED_LEAF_PROCESS_FUNC, NULL);
+  deinit_func = (weed_deinit_f)weed_get_funcptr_value(filt, WEED_LEAF_DEINIT_FUNC, NULL);
+  if (init_func) ret = (*init_func)(inst);
+  if (ret == WEED_SUCCESS) {
+    for (i = 0; i < nframes && ret == WEED_SUCCESS; i++) {
+      weed_set_voidptr_value(inch, WEED_LEAF_PIXEL_DATA, src[i]);
+      weed_set_voidptr_value(outch, WEED_LEAF_PIXEL_DATA, dst[i]);
+      ret = (*process_func)(inst, (weed_timecode_t)i);
+    }
+    if (deinit_func) (*deinit_func)(inst);
+  }
+  for (i = 0; i < nparams; i++) weed_plant_free(inpar[i]);
+  weed_plant_free(inch);
+  weed_plant_free(outch);
+  weed_plant_free(inst);
+  if (ictm) free(ictm);
+  if (octm) free(octm);
+  if (iptm) free(iptm);
+  return ret;
+}
+

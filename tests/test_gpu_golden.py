@@ -219,3 +219,17 @@ def test_k2_fused_lut16_vs_reference(gpu):
             diff[h - 1, :] &= False
         assert not diff.any(), "%s: %d pixels differ" % (rec, diff.sum())
 
+
+def test_blurzoom_sequences_vs_reference(gpu):
+    g = gu.load("blurzoom.npz")
+    for rec in map(str, g["records"]):
+        pal, mode, pattern, w, h, n = map(int, rec.split("|")[1:])
+        src, want = g[rec + "|in"], g[rec + "|out"]
+        z = gpu.Blurzoom(w, h, pal)
+        for f in range(n):
+            a = np.ascontiguousarray(src[f])
+            d = dev(np.full_like(a, 0x5A))
+            z.process(dev(a), d, mode, pattern)
+            assert (host(d)[:, :w * 4] == want[f][:, :w * 4]).all(), (rec, f)
+        z.close()
+

@@ -405,6 +405,36 @@ def test_edge(gpu, orc, palette, mode):
             assert_same(host(d), want, w, h, ps, "edge pal=%d mode=%d %dx%d inplace=%d" % (palette, mode, w, h, inplace))
 
 
+def bz_sequence(rng, w, h, n, compact):
+    """frames with a bright block moving over a dim noisy background, so that the background subtraction fires"""
+    out = []
+    for f in range(n):
+        a = frame(rng, w, h, 4) if not compact else rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
+        a[:, :w * 4] = (a[:, :w * 4] >> 4) + 40
+        a[2 + f % 3:6 + f % 3, ((8 + 5 * f) % (w - 20)) * 4:((24 + 5 * f) % (w - 4)) * 4] = 250
+        out.append(a)
+    return out
+
+
+@pytest.mark.parametrize("palette", [3, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_blurzoom(gpu, orc, palette, mode):
+    rng = np.random.default_rng(2200 + 10 * palette + mode)
+    for (w, h) in [(70, 12), (64, 9), (330, 40)]:
+        for pattern in (0, 3) if mode else (0, 1, 2, 3):
+            seq = bz_sequence(rng, w, h, 7, compact=mode in (1, 2))
+            z = orc.orc_blurzoom_new(w, h, palette)
+            g = gpu.Blurzoom(w, h, palette)
+            for f, a in enumerate(seq):
+                want = np.full_like(a, 0x5A)
+                assert orc.orc_blurzoom_process(z, P(a), a.strides[0], P(want), want.strides[0], mode, pattern) == 0
+                d = dev(np.full_like(a, 0x5A))
+                g.process(dev(a), d, mode, pattern)
+                assert_same(host(d), want, w, h, 4, "blurzoom pal=%d mode=%d pattern=%d %dx%d frame %d" % (palette, mode, pattern, w, h, f))
+            orc.orc_blurzoom_free(z)
+            g.close()
+
+
 # ---------------------------------------------------------------------------------------------- compositor fan-in
 @pytest.mark.parametrize("psize", [3, 4])
 def test_composite(gpu, orc, psize):

@@ -258,3 +258,17 @@ def test_lut16_and_fused_k2(orc):
             diff[h - 1, :] &= False
         assert not diff.any(), "%s: %d pixels differ, first %s" % (rec, diff.sum(), np.argwhere(diff)[0])
 
+
+def test_blurzoom_sequences(orc):
+    g = gu.load("blurzoom.npz")
+    for rec in map(str, g["records"]):
+        pal, mode, pattern, w, h, n = map(int, rec.split("|")[1:])
+        src, want = g[rec + "|in"], g[rec + "|out"]
+        z = orc.orc_blurzoom_new(w, h, pal)
+        for f in range(n):
+            a = np.ascontiguousarray(src[f])
+            got = np.full_like(a, 0x5A)
+            assert orc.orc_blurzoom_process(z, P(a), a.strides[0], P(got), got.strides[0], mode, pattern) == 0
+            assert (got[:, :w * 4] == want[f][:, :w * 4]).all(), (rec, f)
+        orc.orc_blurzoom_free(z)
+

@@ -22,8 +22,8 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 18
-    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight"):
+    assert len(ours) == 19
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
@@ -130,4 +130,19 @@ def test_stencil_records_through_the_plugin():
             assert (d[:h, :w * ps] == g[rec + "|o"][:h, :w * ps]).all(), rec
         n += 1
     assert n == 50
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_blurzoom_sequences_through_the_plugin():
+    """one filter instance over a frame sequence (stateful): weed_setup / init_func / process_func x n / deinit_func"""
+    H = po.RefHost()
+    g = gu.load("blurzoom.npz")
+    for rec in map(str, g["records"]):
+        pal, mode, pattern, w, h, n = map(int, rec.split("|")[1:])
+        srcs = [np.ascontiguousarray(a) for a in g[rec + "|in"]]
+        dsts = [np.full_like(a, 0x5A) for a in srcs]
+        H.run_seq(OURS, "blurzoom", pal, w, h, srcs, dsts, [po.p_int(mode), po.p_int(pattern)])
+        for f in range(n):
+            assert (dsts[f][:, :w * 4] == g[rec + "|out"][f][:, :w * 4]).all(), (rec, f)
 
