@@ -159,6 +159,13 @@ int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int i
    LGPU_E_UNSUPPORTED for planar -> ARGB32 / BGR24 (reference row arithmetic broken, :7475-7476, :7313). */
 int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
                     uint8_t *dst_d, int orow, int out_order, int out_alpha, int which_tables, void *stream);
+/* K5: clamped <-> unclamped switch, in place: switch_yuv_clamping_and_subspace (src/colourspace.c:10929-11090) with the
+   tables of init_YUV_to_YUV_tables (:1108-1139; one table set serves YCbCr and BT.709 -- the reference does no subspace
+   maths).  palette 588 YUV888, 589 YUVA8888 (alpha untouched), 544 / 545 / 522 / 512 / 513 planar, 564 UYVY, 565 YUYV.
+   As in the reference every byte of height * rowstride is mapped (row padding included; packed YUV888 is walked as one
+   Y,U,V stream over the whole buffer, so byte roles follow the buffer offset mod 3). */
+int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4], int palette, int height, int to_unclamped,
+                             void *stream);
 /* "softlight": lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV (palette 544 YUV444P, 545 YUVA4444P,
    522 YUV422P, 512 YUV420P, 513 YVU420P): gradient-magnitude highlight mixed into plane 0 (frame border copied), the
    other planes are copied.  unclamped != 0: luma range 0..255, else 16..235 (the channel's YUV_clamping leaf).

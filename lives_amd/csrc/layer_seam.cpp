@@ -166,6 +166,27 @@ int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
   return LGPU_SWAP3PREALPHA;
 }
 
+// K5 on a layer: switch_yuv_clamping_and_subspace (:10929-11090), in place on the layer's own planes
+bool switch_layer_clamping(weed_plant_t *layer, const Layer &l, int oclamping) {
+  uint8_t *d[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rs[4] = {0, 0, 0, 0};
+  size_t bytes[4] = {0, 0, 0, 0};
+  const bool planar = pal_is_planar_yuv(l.pal);
+  bool ok = true;
+  for (int p = 0; p < l.nplanes && ok; p++) {
+    const int ph = (!planar || p == 0 || p == 3 || pal_is_444(l.pal) || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1;
+    bytes[p] = (size_t)l.rs[p] * ph;
+    d[p] = t_scr.get(p == 0 ? 0 : p + 3, bytes[p]);
+    rs[p] = l.rs[p];
+    ok = d[p] && up(d[p], l.pd[p], bytes[p]);
+  }
+  ok = ok && lgpu_yuv_switch_clamping(d, rs, l.pal, l.height, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK;
+  for (int p = 0; p < l.nplanes && ok; p++) ok = down(l.pd[p], d[p], bytes[p]);
+  ok = ok && sync();
+  if (ok) set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);
+  return ok;
+}
+
 int k3_fmt(int pal) {
   switch (pal) {
   case WEED_PALETTE_YUV888: case WEED_PALETTE_YUVA8888: return 0;
@@ -285,10 +306,17 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
 
 lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
                                                        int osubspace, int tgt_gamma) {
-  (void)osampling; (void)osubspace;
+  (void)osampling;
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
   const int inpl = l.pal;
+  if (!pal_is_rgb(inpl) && !pal_is_rgb(outpl) && l.clamping >= 0 && (l.clamping != oclamping || l.subspace != osubspace)) {
+    // YUV -> YUV with a different range (:12241-12262): same subspace = in-place table switch; a subspace change goes through
+    // RGB in the reference -- left to the caller's CPU body
+    if (l.subspace != osubspace) return 0;
+    if (!switch_layer_clamping(layer, l, oclamping)) return 0;
+    if (!read_layer(layer, &l)) return 0;
+  }
   if (inpl == outpl) return 1;                                           // :12265
   if (!pal_is_rgb(outpl)) {
     if (pal_is_rgb(inpl)) return rgb_layer_to_yuv(layer, l, outpl, oclamping, osubspace, tgt_gamma);

@@ -180,6 +180,21 @@ __global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
   }
 }
 
+// ---- K5: clamped <-> unclamped, in place (src/colourspace.c:10929-11090) ---------------------------------------------------
+// role of a byte = position in the plane buffer modulo `period`: pattern nibbles 0 = Y table, 1 = chroma table, 2 = leave
+__global__ __launch_bounds__(kBlock) void k_clamp_switch(uint8_t *buf, size_t nbytes, int period, uint32_t pattern, Lut8 ylut, Lut8 clut) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_y[256], s_c[256];
+  stage_lut(s_y, ylut);
+  stage_lut(s_c, clut);
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nbytes; i += (size_t)gridDim.x * kBlock) {
+    const int role = (pattern >> (4 * (int)(i % (size_t)period))) & 0xF;
+    if (role == 2) continue;
+    const uint8_t v = buf[i];
+    buf[i] = role == 0 ? s_y[v] : s_c[v];
+  }
+}
+
 }  // namespace lgpu
 
 using namespace lgpu;
@@ -255,3 +270,52 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+
+// init_YUV_to_YUV_tables (src/colourspace.c:1108-1139); myround = round half away from zero (src/maths.h:118)
+static void yuv_yuv_tables(uint8_t yc2u[256], uint8_t uvc2u[256], uint8_t yu2c[256], uint8_t uvu2c[256]) {
+  auto rnd = [](double n) { return n >= 0. ? (int)(n + 0.5) : (int)(n - 0.5); };
+  int i;
+  for (i = 0; i <= 16; i++) yc2u[i] = 0;
+  for (; i < 235; i++) yc2u[i] = (uint8_t)rnd((i - 16.) * 255. / (235. - 16.));
+  for (; i < 256; i++) yc2u[i] = 255;
+  for (i = 0; i < 16; i++) uvc2u[i] = 0;
+  for (; i < 240; i++) uvc2u[i] = (uint8_t)rnd((i - 16.) * 255. / (240. - 16.));
+  for (; i < 256; i++) uvc2u[i] = 255;
+  for (i = 0; i < 256; i++) { yu2c[i] = (uint8_t)rnd((i / 255.) * (235. - 16.) + 16.); uvu2c[i] = (uint8_t)rnd((i / 255.) * (240. - 16.) + 16.); }
+}
+
+extern "C" int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4], int palette, int height, int to_unclamped,
+                                        void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(planes_d && rowstrides && planes_d[0] && rowstrides[0] > 0 && height > 0, "null plane or empty geometry");
+  uint8_t t[4][256];
+  yuv_yuv_tables(t[0], t[1], t[2], t[3]);
+  const Lut8 ly = pack_lut(to_unclamped ? t[0] : t[2]), lc = pack_lut(to_unclamped ? t[1] : t[3]);
+  const size_t n = (size_t)height * rowstrides[0];
+  hipStream_t st = (hipStream_t)stream;
+  auto launch = [&](uint8_t *buf, size_t bytes, int period, uint32_t pattern) {
+    unsigned g = cdiv((unsigned)((bytes + 7) / 8), kBlock);
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_clamp_switch, dim3(g), dim3(kBlock), 0, st, buf, bytes, period, pattern, ly, lc);
+  };
+  switch (palette) {
+  case 588: launch(planes_d[0], n, 3, 0x110u); break;                    // Y U V over the whole buffer (:10957-10968)
+  case 589: launch(planes_d[0], n, 4, 0x2110u); break;                   // Y U V A
+  case 564: launch(planes_d[0], n, 4, 0x0101u); break;                   // U Y V Y
+  case 565: launch(planes_d[0], n, 4, 0x1010u); break;                   // Y U Y V
+  case 544: case 545: case 522: case 512: case 513: {
+    LGPU_REQUIRE(planes_d[1] && planes_d[2], "null chroma plane");
+    const size_t nc = palette == 522 ? n / 2 : (palette == 512 || palette == 513) ? n / 4 : n;
+    launch(planes_d[0], n, 1, 0x0u);
+    launch(planes_d[1], nc, 1, 0x1u);
+    launch(planes_d[2], nc, 1, 0x1u);
+    break;
+  }
+  default: set_error("lgpu_yuv_switch_clamping: palette %d is not handled", palette); return LGPU_E_UNSUPPORTED;
+  }
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+

@@ -127,6 +127,11 @@ def yuv_to_rgb(src_planes, dst, width, height, in_fmt, in_alpha, out_order, out_
              out_order, int(out_alpha), which_tables, stream_ptr())
 
 
+def yuv_switch_clamping(planes, palette, height, to_unclamped):
+    pp, ss = _plane_tables(planes)
+    lib.call("lgpu_yuv_switch_clamping", ctypes.addressof(pp), ctypes.addressof(ss), palette, height, int(to_unclamped), stream_ptr())
+
+
 def softlight(src_planes, dst_planes, width, height, palette, unclamped):
     """planar YUV softlight (softlight.c): src_planes / dst_planes are lists of 2-D uint8 device tensors, one per plane"""
     n = len(src_planes)

@@ -764,6 +764,46 @@ int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, in
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * K5: clamping switch                   reference: src/colourspace.c:1108-1139, :1163-1230, :10929-11090
+ * ---------------------------------------------------------------------------------------------- */
+void orc_yuv_yuv_tables(uint8_t *yc2u, uint8_t *uvc2u, uint8_t *yu2c, uint8_t *uvu2c) {
+  int i;
+  for (i = 0; i <= 16; i++) yc2u[i] = 0;
+  for (; i < 235; i++) yc2u[i] = (uint8_t)rnd_half_away((i - 16.) * 255. / (235. - 16.));
+  for (; i < 256; i++) yc2u[i] = 255;
+  for (i = 0; i < 16; i++) uvc2u[i] = 0;
+  for (; i < 240; i++) uvc2u[i] = (uint8_t)rnd_half_away((i - 16.) * 255. / (240. - 16.));
+  for (; i < 256; i++) uvc2u[i] = 255;
+  for (i = 0; i < 256; i++) {
+    yu2c[i] = (uint8_t)rnd_half_away((i / 255.) * (235. - 16.) + 16.);
+    uvu2c[i] = (uint8_t)rnd_half_away((i / 255.) * (240. - 16.) + 16.);
+  }
+}
+int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], int palette, int height, int to_unclamped) {
+  uint8_t t[4][256];
+  orc_yuv_yuv_tables(t[0], t[1], t[2], t[3]);
+  const uint8_t *Y = to_unclamped ? t[0] : t[2], *C = to_unclamped ? t[1] : t[3];
+  const size_t n = (size_t)height * rowstrides[0];
+  uint8_t *p = planes[0];
+  switch (palette) {
+  /* packed 4:4:4: the reference walks the WHOLE buffer as one Y,U,V,... stream (:10946-10968), so with a rowstride that is
+     not a multiple of 3 the byte roles drift from row to row -- kept: role = offset in the buffer mod 3 */
+  case 588: for (size_t i = 0; i < n; i++) p[i] = (i % 3 == 0) ? Y[p[i]] : C[p[i]]; break;
+  case 589: for (size_t i = 0; i < n; i++) if ((i & 3) != 3) p[i] = ((i & 3) == 0) ? Y[p[i]] : C[p[i]]; break;
+  case 564: for (size_t i = 0; i < n; i += 4) { p[i] = C[p[i]]; p[i + 1] = Y[p[i + 1]]; p[i + 2] = C[p[i + 2]]; p[i + 3] = Y[p[i + 3]]; } break;
+  case 565: for (size_t i = 0; i < n; i += 4) { p[i] = Y[p[i]]; p[i + 1] = C[p[i + 1]]; p[i + 2] = Y[p[i + 2]]; p[i + 3] = C[p[i + 3]]; } break;
+  case 544: case 545: case 522: case 512: case 513: {
+    const size_t nc = palette == 522 ? n / 2 : (palette == 512 || palette == 513) ? n / 4 : n;
+    for (size_t i = 0; i < n; i++) p[i] = Y[p[i]];
+    for (size_t i = 0; i < nc; i++) { planes[1][i] = C[planes[1][i]]; planes[2][i] = C[planes[2][i]]; }
+    break;
+  }
+  default: return -1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * F6a: softlight                        reference: lives-plugins/weed-plugins/softlight.c:34-47 (sqrti), :62-141
  * Per interior luma sample (the reference's own operand choice, including the two terms that differ from a
  * textbook Sobel: row0 ends with (S[+1][+1] - S[+1][-1]) and row1 ends with the SUM S[+1][+1] + S[+1][-1]):

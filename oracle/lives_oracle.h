@@ -105,6 +105,14 @@ int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, in
 /* init_average (src/colourspace.c:190-216): cavgc (clamped = 1) / cavgu chroma-averaging table entry */
 int orc_cavg(int clamped, int x, int y);
 
+/* K5: clamped <-> unclamped switch, in place (src/colourspace.c:10929-11090 switch_yuv_clamping_and_subspace, tables
+   init_YUV_to_YUV_tables :1108-1139, selection :1163-1230: same table set for YCbCr and BT.709, no subspace maths).
+   Every byte of height * rowstride is mapped (row padding included, as the reference walks the whole buffer); chroma
+   planes of the subsampled planar palettes are walked for height * rowstride / 2 (4:2:2) or / 4 (4:2:0) bytes.
+   palette: 588 YUV888, 589 YUVA8888 (alpha untouched), 544 / 545 planar 4:4:4(4), 522, 512, 513, 564 UYVY, 565 YUYV. */
+void orc_yuv_yuv_tables(uint8_t *yc2u, uint8_t *uvc2u, uint8_t *yu2c, uint8_t *uvu2c);
+int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], int palette, int height, int to_unclamped);
+
 /* F6a: "softlight"  lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV: the stencil runs on plane 0 (rows
    1..h-2, columns 1..w-2; the frame border is copied), the other planes are copied (:143-151).
    unclamped != 0: output range 0..255, else 16..235 (:97-103).  Needs width, height >= 3. */

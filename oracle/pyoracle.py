@@ -91,6 +91,8 @@ def oracle():
         _O.orc_rgb_to_yuv.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci]
         _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
         _O.orc_cavg.argtypes = [ci, ci, ci]
+        _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
+        _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]
         _O.orc_blurzoom_new.restype = vp
         _O.orc_blurzoom_new.argtypes = [ci, ci, ci]
         _O.orc_blurzoom_process.argtypes = [vp, vp, ci, vp, ci, ci, ci]
@@ -121,6 +123,7 @@ def csref():
         _R = ctypes.CDLL(os.path.join(REFDIR, "libcsref.so"))
         _R.csref_gamma_lut8.argtypes = [cd, ci, ci, vp]
         _R.csref_set_prefs.argtypes = [ci, ci, cd]
+        _R.csref_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _R.csref_k4.argtypes = [ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, ci, ci]
         _R.csref_k3.argtypes = [ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci]
     return _R

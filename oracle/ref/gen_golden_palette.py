@@ -78,6 +78,9 @@ def main():
             rec[key + "|i%d" % i] = a
         rec[key + "|out"] = out
         names.append(key)
+    t = [np.zeros(256, np.uint8) for _ in range(4)]                     # K5 tables (init_YUV_to_YUV_tables, :1108-1139)
+    R.csref_yuv_yuv_tables(*[P(x) for x in t])
+    np.savez_compressed(os.path.join(OUT, "yuvyuv.npz"), yc2u=t[0], uvc2u=t[1], yu2c=t[2], uvu2c=t[3])
     rec["records"] = np.array(names)
     np.savez_compressed(os.path.join(OUT, "k34_palette.npz"), **rec)
     mpath = os.path.join(OUT, "manifest.json")
@@ -85,6 +88,7 @@ def main():
     man["groups"]["k34_palette.npz"] = ("src/colourspace.c:5129-6440 (RGB/BGR/ARGB -> YUV888, YUVA8888, YUV(A)444(4)P, UYVY, YUYV, YUV420P, YUV422P; record "
                                         "k4|in_order|in_alpha|out_fmt|out_alpha|which|w|h) and :2750-3258, :6616-7102, :7200-7498 (the reverse; record "
                                         "k3|in_fmt|in_alpha|out_order|out_alpha|which|w|h); which: bit0 unclamped, bit1 BT.709; nfx_threads = 1; compact destination strides")
+    man["groups"]["yuvyuv.npz"] = "src/colourspace.c:1108-1139 init_YUV_to_YUV_tables: Yclamped_to_Yunclamped, UVclamped_to_UVunclamped, Yunclamped_to_Yclamped, UVunclamped_to_UVclamped"
     json.dump(man, open(mpath, "w"), indent=1)
     print("k34_palette.npz: %d records, %d KB" % (len(names), os.path.getsize(os.path.join(OUT, "k34_palette.npz")) // 1024))
 

@@ -233,3 +233,13 @@ def test_blurzoom_sequences_vs_reference(gpu):
             assert (host(d)[:, :w * 4] == want[f][:, :w * 4]).all(), (rec, f)
         z.close()
 
+
+def test_clamping_switch_uses_the_reference_tables(gpu):
+    """a 0..255 ramp through lgpu_yuv_switch_clamping reproduces init_YUV_to_YUV_tables"""
+    g = gu.load("yuvyuv.npz")
+    ramp = np.arange(256, dtype=np.uint8).reshape(1, 256)
+    for to_uncl, ky, kc in ((1, "yc2u", "uvc2u"), (0, "yu2c", "uvu2c")):
+        planes = [dev(ramp.copy()), dev(ramp.copy()), dev(ramp.copy())]
+        gpu.yuv_switch_clamping(planes, 544, 1, to_uncl)
+        assert (host(planes[0])[0] == g[ky]).all() and (host(planes[1])[0] == g[kc]).all() and (host(planes[2])[0] == g[kc]).all()
+

@@ -365,6 +365,30 @@ def test_yuv_to_rgb(gpu, orc, in_fmt, out_order):
     assert n > 0 or (in_fmt == 1 and out_order == 2)
 
 
+# ---------------------------------------------------------------------------------------------- K5 clamping switch
+@pytest.mark.parametrize("palette", [588, 589, 544, 545, 522, 512, 513, 564, 565])
+def test_yuv_switch_clamping(gpu, orc, palette):
+    rng = np.random.default_rng(2300 + palette)
+    for (w, h) in [(20, 8), (66, 34), (130, 6)]:
+        for to_unclamped in (0, 1):
+            if palette in (588, 589):
+                planes = [frame(rng, w, h, 3 if palette == 588 else 4)]
+            elif palette in (564, 565):
+                planes = [frame(rng, w, h, 2)]
+            else:
+                Y = frame(rng, w, h, 1)
+                cs = Y.strides[0] if palette in (544, 545) else Y.strides[0] >> 1
+                ch = h >> 1 if palette in (512, 513) else h
+                planes = [Y] + [rng.integers(0, 256, (ch, cs), dtype=np.uint8) for _ in range(2)] + ([frame(rng, w, h, 1)] if palette == 545 else [])
+            want = [a.copy() for a in planes]
+            wp, ws = po.planes_args(want)
+            assert orc.orc_switch_yuv_clamping(ctypes.addressof(wp), ctypes.addressof(ws), palette, h, to_unclamped) == 0
+            got = [dev(a) for a in planes]
+            gpu.yuv_switch_clamping(got, palette, h, to_unclamped)
+            for i in range(len(planes)):
+                assert (host(got[i]) == want[i]).all(), (palette, w, h, to_unclamped, i)
+
+
 # ---------------------------------------------------------------------------------------------- F6 stencils
 @pytest.mark.parametrize("palette", [544, 545, 522, 512, 513])
 def test_softlight(gpu, orc, palette):

@@ -245,3 +245,32 @@ def test_yuv_layers_to_rgb(seam, orc, inpl):
             assert (got[0][:, :w * ops] == want[:, :w * ops]).all(), (inpl, outpl, clamp)
             assert wh.geti(lay, "current_palette") == outpl and wh.geti(lay, "width") == w and wh.geti(lay, "YUV_clamping") is None
 
+
+@needs_ref
+@pytest.mark.gpu
+def test_yuv_layer_clamping_switch(seam, orc):
+    """convert_layer_palette_full(layer, same palette, other clamping, same subspace) = in-place range switch (:12241-12247)"""
+    L, wh = seam
+    rng = np.random.default_rng(77)
+    w, h = 64, 8
+    for pal in (512, 544, 588, 564):
+        if pal in (588, 564):
+            planes = [frame(rng, w, h, 3 if pal == 588 else 2)]
+        else:
+            ch = h >> 1 if pal == 512 else h
+            cw = align(w) >> 1 if pal == 512 else align(w)
+            planes = [frame(rng, w, h, 1)] + [rng.integers(0, 256, (ch, cw), dtype=np.uint8) for _ in range(2)]
+        lw = w >> 1 if pal == 564 else w
+        lay = wh.new_layer(pal, lw, h, planes, clamping=0, subspace=1)
+        assert L.lives_gpu_convert_layer_palette_full(lay, pal, 1, 0, 1, 0) == 1
+        got, _, rs = wh.planes_of(lay)
+        want = [a.copy() for a in planes]
+        wp, ws = po.planes_args(want)
+        assert orc.orc_switch_yuv_clamping(ctypes.addressof(wp), ctypes.addressof(ws), pal, h, 1) == 0
+        for i in range(len(planes)):
+            assert (got[i] == want[i]).all(), (pal, i)
+        assert wh.geti(lay, "YUV_clamping") == 1 and wh.geti(lay, "current_palette") == pal
+        # a subspace change is not served on the GPU (the reference goes through RGB): FALSE, layer untouched
+        lay2 = wh.new_layer(pal, lw, h, planes, clamping=0, subspace=1)
+        assert L.lives_gpu_convert_layer_palette_full(lay2, pal, 1, 0, 2, 0) == 0 and wh.geti(lay2, "YUV_clamping") == 0
+

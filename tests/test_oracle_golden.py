@@ -272,3 +272,11 @@ def test_blurzoom_sequences(orc):
             assert (got[:, :w * 4] == want[f][:, :w * 4]).all(), (rec, f)
         orc.orc_blurzoom_free(z)
 
+
+def test_yuv_yuv_tables(orc):
+    g = gu.load("yuvyuv.npz")
+    t = [np.zeros(256, np.uint8) for _ in range(4)]
+    orc.orc_yuv_yuv_tables(*[P(x) for x in t])
+    for a, k in zip(t, ("yc2u", "uvc2u", "yu2c", "uvu2c")):
+        assert (a == g[k]).all(), k
+
