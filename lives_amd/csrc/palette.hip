@@ -181,17 +181,49 @@ __global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
 }
 
 // ---- K5: clamped <-> unclamped, in place (src/colourspace.c:10929-11090) ---------------------------------------------------
-// role of a byte = position in the plane buffer modulo `period`: pattern nibbles 0 = Y table, 1 = chroma table, 2 = leave
-__global__ __launch_bounds__(kBlock) void k_clamp_switch(uint8_t *buf, size_t nbytes, int period, uint32_t pattern, Lut8 ylut, Lut8 clut) {
+// role of a byte = position in the plane buffer modulo `period`: pattern nibbles 0 = Y table, 1 = chroma table, 2 = leave.
+// lane = 16 aligned bytes (head / tail of an unaligned buffer byte-wise by the first / last lanes)
+struct ClampPlanes { uint8_t *buf[3]; size_t nbytes[3]; uint32_t pattern[3]; };
+__global__ __launch_bounds__(kBlock) void k_clamp_switch(ClampPlanes cp, int period, Lut8 ylut, Lut8 clut) {
   __shared__ __attribute__((aligned(16))) uint8_t s_y[256], s_c[256];
   stage_lut(s_y, ylut);
   stage_lut(s_c, clut);
   __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nbytes; i += (size_t)gridDim.x * kBlock) {
-    const int role = (pattern >> (4 * (int)(i % (size_t)period))) & 0xF;
-    if (role == 2) continue;
-    const uint8_t v = buf[i];
-    buf[i] = role == 0 ? s_y[v] : s_c[v];
+  uint8_t *buf = cp.buf[blockIdx.y];                 // blockIdx.y = plane
+  const size_t nbytes = cp.nbytes[blockIdx.y];
+  const uint32_t pattern = cp.pattern[blockIdx.y];
+  if (!buf) return;
+  const size_t head = (16 - (reinterpret_cast<uintptr_t>(buf) & 15)) & 15;                     // bytes before the first aligned chunk
+  const size_t nchunks = nbytes > head ? (nbytes - head) / 16 : 0;
+  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * kBlock) {
+    const size_t off = head + c * 16;
+    uint4 v = *reinterpret_cast<uint4 *>(buf + off);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int ph = (int)(off % (size_t)period);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t byte = (w[k] >> (8 * j)) & 0xFF;
+        const int role = (pattern >> (4 * ph)) & 0xF;
+        o |= (role == 2 ? byte : role == 0 ? (uint32_t)s_y[byte] : (uint32_t)s_c[byte]) << (8 * j);
+        ph = ph + 1 == period ? 0 : ph + 1;
+      }
+      w[k] = o;
+    }
+    *reinterpret_cast<uint4 *>(buf + off) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  if (blockIdx.x == 0) {                                                                         // ragged ends
+    const size_t tail0 = head + nchunks * 16;
+    for (size_t i = threadIdx.x; i < head + (nbytes - tail0); i += kBlock) {
+      const size_t off = i < head ? i : tail0 + (i - head);
+      if (off >= nbytes) continue;
+      const int role = (pattern >> (4 * (int)(off % (size_t)period))) & 0xF;
+      if (role == 2) continue;
+      const uint8_t v = buf[off];
+      buf[off] = role == 0 ? s_y[v] : s_c[v];
+    }
   }
 }
 
@@ -294,12 +326,15 @@ extern "C" int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int ro
   const Lut8 ly = pack_lut(to_unclamped ? t[0] : t[2]), lc = pack_lut(to_unclamped ? t[1] : t[3]);
   const size_t n = (size_t)height * rowstrides[0];
   hipStream_t st = (hipStream_t)stream;
-  auto launch = [&](uint8_t *buf, size_t bytes, int period, uint32_t pattern) {
-    unsigned g = cdiv((unsigned)((bytes + 7) / 8), kBlock);
-    if (g > 8192) g = 8192;
+  auto launch3 = [&](uint8_t *b0, size_t n0, uint32_t p0, uint8_t *b1, size_t n1, uint32_t p1, uint8_t *b2, size_t n2, uint32_t p2, int period, int np) {
+    ClampPlanes cp;
+    cp.buf[0] = b0; cp.buf[1] = b1; cp.buf[2] = b2; cp.nbytes[0] = n0; cp.nbytes[1] = n1; cp.nbytes[2] = n2; cp.pattern[0] = p0; cp.pattern[1] = p1; cp.pattern[2] = p2;
+    unsigned g = cdiv((unsigned)((n0 + 15) / 16), kBlock);
+    if (g > 4096) g = 4096;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_clamp_switch, dim3(g), dim3(kBlock), 0, st, buf, bytes, period, pattern, ly, lc);
+    hipLaunchKernelGGL(k_clamp_switch, dim3(g, (unsigned)np), dim3(kBlock), 0, st, cp, period, ly, lc);
   };
+  auto launch = [&](uint8_t *buf, size_t bytes, int period, uint32_t pattern) { launch3(buf, bytes, pattern, nullptr, 0, 0, nullptr, 0, 0, period, 1); };
   switch (palette) {
   case 588: launch(planes_d[0], n, 3, 0x110u); break;                    // Y U V over the whole buffer (:10957-10968)
   case 589: launch(planes_d[0], n, 4, 0x2110u); break;                   // Y U V A
@@ -308,9 +343,7 @@ extern "C" int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int ro
   case 544: case 545: case 522: case 512: case 513: {
     LGPU_REQUIRE(planes_d[1] && planes_d[2], "null chroma plane");
     const size_t nc = palette == 522 ? n / 2 : (palette == 512 || palette == 513) ? n / 4 : n;
-    launch(planes_d[0], n, 1, 0x0u);
-    launch(planes_d[1], nc, 1, 0x1u);
-    launch(planes_d[2], nc, 1, 0x1u);
+    launch3(planes_d[0], n, 0x0u, planes_d[1], nc, 0x1u, planes_d[2], nc, 0x1u, 1, 3);
     break;
   }
   default: set_error("lgpu_yuv_switch_clamping: palette %d is not handled", palette); return LGPU_E_UNSUPPORTED;

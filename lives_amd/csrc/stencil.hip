@@ -92,11 +92,17 @@ __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int iro
   __shared__ unsigned int s_hist[1024];
   __shared__ unsigned int s_sum;
   constexpr int P = kStW + 4;
-  const int x0 = blockIdx.x * kStW, y0 = blockIdx.y * kStH;
   if (pass == 0) for (int i = threadIdx.x; i < 768; i += kBlock) s_luma[i] = gluma[i];
   for (int i = threadIdx.x; i < 1024; i += kBlock) s_hist[i] = 0;
   if (threadIdx.x == 0) s_sum = 0;
   __syncthreads();
+  // persistent over tiles: the histogram stays in LDS and is flushed once per workgroup (global atomics on 1017 hot addresses
+  // were most of this kernel's time with one flush per tile)
+  const int tiles_x = (width + kStW - 1) / kStW, ntiles = tiles_x * ((height + kStH - 1) / kStH);
+  unsigned int lsum = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int x0 = (tile % tiles_x) * kStW, y0 = (tile / tiles_x) * kStH;
+  __syncthreads();                                            // the previous tile's readers are done with `l`
   for (int i = threadIdx.x; i < (kStH + 4) * P; i += kBlock) {
     const int r = i / P, c = i - r * P;
     const int sy = y0 - 2 + r, sx = x0 - 2 + c;
@@ -114,7 +120,6 @@ __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int iro
   __syncthreads();
   const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
   const int y = y0 + ly;
-  unsigned int lsum = 0;
   if (y < height) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int iro
       map[(size_t)y * width + x] = (uint16_t)val;
     }
   }
+  }   // tiles
   if (lsum) atomicAdd(&s_sum, lsum);
   __syncthreads();
   for (int i = threadIdx.x; i < 1024; i += kBlock)
@@ -141,27 +147,55 @@ __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int iro
   if (threadIdx.x == 0 && s_sum) atomicAdd(&st->sum, (unsigned long long)s_sum);
 }
 
-// the Otsu scan of edge.c:184-205, one thread, IEEE double arithmetic in the reference's operation order
-__global__ void k_edge_otsu(EdgeState *st, unsigned long long count) {
-  if (threadIdx.x != 0) return;
-  unsigned long long bh = st->bh + st->sum, nbh = st->nbh + count, bl = st->bl, nbl = st->nbl;
-  double difmax = st->difmax;
-  unsigned int threshmax = st->threshmax;
-  for (unsigned int t = 0; t < 1017; t++) {
-    const unsigned long long pr = st->hist[t];
-    const unsigned long long nn = pr * t;
-    bl += nn; nbl += pr;
-    bh -= nn; nbh -= pr;
+// The Otsu scan of edge.c:184-205 with 1024 threads.  The reference walks t = 0..1016 serially keeping running sums and the
+// first record high of dif; here the running sums are exclusive-inclusive prefix sums of the histogram (exact in uint64),
+// every t evaluates its dif with the same IEEE double operations in the same order, and the serial "if (dif > difmax)" chain
+// is the smallest t that attains the maximum -- provided that maximum beats the difmax carried in from the previous pass.
+__global__ __launch_bounds__(1024) void k_edge_otsu(EdgeState *st, unsigned long long count) {
+  __shared__ unsigned long long s_n[1024], s_w[1024];
+  __shared__ double s_d[1024];
+  __shared__ unsigned int s_t[1024];
+  const unsigned int t = threadIdx.x;
+  const unsigned long long pr = t < 1017 ? st->hist[t] : 0ull;
+  s_n[t] = pr; s_w[t] = pr * t;
+  __syncthreads();
+  for (unsigned int off = 1; off < 1024; off <<= 1) {          // inclusive scan (Hillis-Steele): sum over 0..t
+    const unsigned long long n = t >= off ? s_n[t - off] : 0ull, w = t >= off ? s_w[t - off] : 0ull;
+    __syncthreads();
+    s_n[t] += n; s_w[t] += w;
+    __syncthreads();
+  }
+  const unsigned long long bh0 = st->bh + st->sum, nbh0 = st->nbh + count, bl0 = st->bl, nbl0 = st->nbl;
+  double dif = -1.;
+  bool valid = false;
+  if (t >= 1 && t < 1017) {
+    const unsigned long long bl = bl0 + s_w[t], nbl = nbl0 + s_n[t], bh = bh0 - s_w[t], nbh = nbh0 - s_n[t];
     const double abh = __ddiv_rn((double)bh, (double)nbh);
     const double abl = __ddiv_rn((double)bl, (double)nbl);
     const double d = __dsub_rn(abh, abl);
-    const double dif = __dmul_rn(__dmul_rn((double)(nbl * nbh), d), d);
-    if (t > 0 && dif > difmax) { difmax = dif; threshmax = t; }
+    dif = __dmul_rn(__dmul_rn((double)(nbl * nbh), d), d);
+    valid = dif == dif;                                         // a NaN never wins a `>` comparison
   }
-  st->bh = bh; st->nbh = nbh; st->bl = bl; st->nbl = nbl;
-  st->difmax = difmax; st->threshmax = threshmax; st->thresh = threshmax;
-  st->sum = 0;
-  for (int i = 0; i < 1024; i++) st->hist[i] = 0;
+  s_d[t] = valid ? dif : -1.;                                   // dif >= 0 whenever it is a number
+  s_t[t] = t;
+  __syncthreads();
+  for (unsigned int off = 512; off > 0; off >>= 1) {            // max, ties to the smaller t
+    if (t < off) {
+      const double o = s_d[t + off];
+      if (o > s_d[t] || (o == s_d[t] && s_t[t + off] < s_t[t])) { s_d[t] = o; s_t[t] = s_t[t + off]; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double difmax = st->difmax;
+    unsigned int threshmax = st->threshmax;
+    if (s_d[0] > difmax) { difmax = s_d[0]; threshmax = s_t[0]; }
+    st->bh = bh0 - s_w[1016]; st->nbh = nbh0 - s_n[1016]; st->bl = bl0 + s_w[1016]; st->nbl = nbl0 + s_n[1016];
+    st->difmax = difmax; st->threshmax = threshmax; st->thresh = threshmax;
+    st->sum = 0;
+  }
+  __syncthreads();
+  st->hist[t] = 0;
 }
 
 // copywalpha (edge.c:93-125) on every pixel: codes per colour byte 0 = black, 1 = source, 2 = white, 3 = leave
@@ -311,13 +345,14 @@ extern "C" int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int oro
     sc = e;
   }
   const unsigned long long count = (width > 4 && height > 4) ? (unsigned long long)(width - 4) * (unsigned long long)(height - 4) : 0ull;
-  const dim3 tgrid(cdiv((unsigned)width, kStW), cdiv((unsigned)height, kStH));
+  const unsigned ntiles = cdiv((unsigned)width, kStW) * cdiv((unsigned)height, kStH);
+  const dim3 tgrid(ntiles < 1024 ? ntiles : 1024);
   const dim3 pgrid(cdiv((unsigned)width, kBlock), (unsigned)(height < 1024 ? height : 1024));
   hipLaunchKernelGGL(k_edge_reset, dim3(1), dim3(256), 0, st, sc.st);
   for (int pass = 0; pass < 4; pass++) {
     if (psize == 4) hipLaunchKernelGGL(k_edge_map<4>, tgrid, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, sc.st);
     else hipLaunchKernelGGL(k_edge_map<3>, tgrid, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, sc.st);
-    hipLaunchKernelGGL(k_edge_otsu, dim3(1), dim3(64), 0, st, sc.st, count);
+    hipLaunchKernelGGL(k_edge_otsu, dim3(1), dim3(1024), 0, st, sc.st, count);
     if (psize == 4) hipLaunchKernelGGL(k_edge_paint<4>, pgrid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, pass, mode, aoffs, inplace, sc.map, sc.st);
     else hipLaunchKernelGGL(k_edge_paint<3>, pgrid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, pass, mode, aoffs, inplace, sc.map, sc.st);
     if (mode < 2) break;

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""tools/bench_ops.py -- every entry point of liblivesgpu.so at its BASELINE / SURVEY 8d size against the HBM roofline,
+with the CPU oracle (one thread, gcc -O3 -march=native) timed beside it on the same host.
+
+For each op: algorithmic bytes (compulsory reads + writes of one call), mean device time over `reps` back-to-back
+launches measured with events on the launch stream, achieved GB/s, fraction of the 8 TB/s HBM3E peak, and the oracle's
+time for the same call.  Inputs are resident in HBM; working sets are rotated over `nbuf` buffers so that one pass is
+larger than the 256 MiB Infinity Cache where the frame size allows.  Prints a markdown table (and JSON with --json).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from lives_amd import ops
+    from oracle import pyoracle as po
+    ops.init(0)
+    orc = None if args.no_cpu else ctypes.CDLL(po.build_oracle(native=True))
+    P = po.P
+    rng = np.random.default_rng(0x11FE5)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x11FE5)
+
+    def dframe(w, h, ps, n=1):
+        rs = po.align(w * ps)
+        return [torch.randint(0, 256, (h, rs), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
+
+    def hframe(w, h, ps):
+        return rng.integers(0, 256, (h, po.align(w * ps)), dtype=np.uint8)
+
+    rows = []
+
+    def timeit(fn, nbuf):
+        for i in range(3):
+            fn(i % nbuf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(args.reps):
+            fn(i % nbuf)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / args.reps
+
+    def cpu(fn):
+        if orc is None:
+            return None
+        fn()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 0.5:
+            fn()
+            n += 1
+        return (time.perf_counter() - t0) / n
+
+    def add(name, ref, size, abytes, gpu_s, cpu_s):
+        gbs = abytes / gpu_s / 1e9
+        rows.append(dict(op=name, reference=ref, size=size, algorithmic_bytes=abytes, gpu_us=round(gpu_s * 1e6, 2), gbs=round(gbs, 1),
+                         frac=round(gbs / PEAK, 4), cpu_ms=None if cpu_s is None else round(cpu_s * 1e3, 3),
+                         speedup=None if cpu_s is None else round(cpu_s / gpu_s, 1)))
+        print("  %-34s %9.2f us %8.1f GB/s  frac %.3f" % (name, gpu_s * 1e6, gbs, gbs / PEAK), file=sys.stderr, flush=True)
+
+    NB = 8
+    # ---- K1 swizzle: C1 (640x480 RGB24 -> BGRA32) and the same op at 4K -------------------------------------------------
+    for (w, h) in ((640, 480), (3840, 2160)):
+        src, dst = dframe(w, h, 3, NB), dframe(w, h, 4, NB)
+        op = po.OPS.index("swap3addpost")
+        t = timeit(lambda i: ops.swizzle(op, src[i], dst[i], w, h), NB)
+        hs, hd = hframe(w, h, 3), hframe(w, h, 4)
+        c = cpu(lambda: orc.orc_swizzle(op, 0, P(hs), hs.strides[0], P(hd), hd.strides[0], w, h, None))
+        add("swizzle RGB24->BGRA32", "colourspace.c:9445-9511", "%dx%d" % (w, h), w * h * 7, t, c)
+    # ---- K2 + fused gamma: C2 ----------------------------------------------------------------------------------------
+    w, h = 1920, 1080
+    lut = np.zeros(256, np.uint8)
+    from lives_amd.lib import load
+    load().lgpu_gamma_lut8(1.0, -1, 1, 1.4, lut.ctypes.data)
+    Y, U, V = dframe(w, h, 1, NB), dframe(w // 2, h // 2, 1, NB), dframe(w // 2, h // 2, 1, NB)
+    dst = dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.yuv420p_to_rgb(Y[i], U[i], V[i], dst[i], w, h, lut=lut), NB)
+    hy, hu, hv, hd = hframe(w, h, 1), hframe(w // 2, h // 2, 1), hframe(w // 2, h // 2, 1), hframe(w, h, 4)
+    st = (ctypes.c_int * 3)(hy.strides[0], hu.strides[0], hv.strides[0])
+    if orc:
+        orc.orc_yuv420p_to_rgb.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    c = cpu(lambda: orc.orc_yuv420p_to_rgb(P(hy), P(hu), P(hv), st, hu.size, hv.size, P(hd), hd.strides[0], w, h, 4, 0, 0, 0, 2, P(lut), 0))
+    add("yuv420p->RGBA32 + gamma LUT (C2)", "colourspace.c:3260-3904, :14034", "1920x1080", w * h * 3 // 2 + w * h * 4, t, c)
+    # ---- K6 gamma apply, K9 premult (in place) ---------------------------------------------------------------------------------
+    pix = dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.gamma_apply(pix[i], w, h, 4, lut), NB)
+    hp = hframe(w, h, 4)
+    c = cpu(lambda: orc.orc_gamma_apply(P(hp), hp.strides[0], w, h, 4, 0, P(lut)))
+    add("gamma_apply RGBA32 (in place)", "colourspace.c:14034-14060", "1920x1080", w * h * 8, t, c)
+    t = timeit(lambda i: ops.alpha_premult(pix[i], w, h), NB)
+    c = cpu(lambda: orc.orc_alpha_premult(P(hp), hp.strides[0], w, h, 0, 0))
+    add("alpha_premult RGBA32 (in place)", "colourspace.c:11968-12105", "1920x1080", w * h * 8, t, c)
+    # ---- K7 resize alone, K8 letterbox, F1 blend: C3 ----------------------------------------------------------------------------
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src, dst = dframe(sw, sh, 4, NB), dframe(dw, dh, 4, NB)
+    t = timeit(lambda i: ops.resize(src[i], dst[i], sw, sh, dw, dh), NB)
+    hs, hd = hframe(sw, sh, 4), hframe(dw, dh, 4)
+    if orc:
+        orc.orc_resize.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5
+    c = cpu(lambda: orc.orc_resize(P(hs), hs.strides[0], sw, sh, P(hd), hd.strides[0], dw, dh, 4, 3))
+    add("resize bicubic 0.5x RGBA32 (C3)", "colourspace.c:14759-15328 (own spec)", "3840x2160->1920x1080", sw * sh * 4 + dw * dh * 4, t, c)
+    canvas = dframe(1920, 1200, 4, NB)
+    black = [0, 0, 0, 255]
+    t = timeit(lambda i: ops.letterbox(dst[i], canvas[i], dw, dh, 1920, 1200, 4, black), NB)
+    hc = hframe(1920, 1200, 4)
+    blk = (ctypes.c_uint8 * 4)(*black)
+    c = cpu(lambda: orc.orc_letterbox(P(hd), hd.strides[0], dw, dh, P(hc), hc.strides[0], 1920, 1200, 4, blk))
+    add("letterbox into 1920x1200 (C3)", "colourspace.c:15343-15567", "1920x1080", dw * dh * 4 + 1920 * 1200 * 4, t, c)
+    l1, l2, lo_ = dframe(1920, 1200, 4, NB), dframe(1920, 1200, 4, NB), dframe(1920, 1200, 4, NB)
+    t = timeit(lambda i: ops.blend_chroma(l1[i], l2[i], lo_[i], 1920, 1200, 4, 128), NB)
+    h1, h2, ho = hframe(1920, 1200, 4), hframe(1920, 1200, 4), hframe(1920, 1200, 4)
+    c = cpu(lambda: orc.orc_blend_chroma(P(h1), h1.strides[0], P(h2), h2.strides[0], P(ho), ho.strides[0], 1920, 1200, 4, 0, 128))
+    add("chroma blend RGBA32 (C3)", "simple_blend.c:58-150", "1920x1200", 1920 * 1200 * 12, t, c)
+    # ---- B1 gaussian, F4 colour key: C4 --------------------------------------------------------------------------------------------
+    w, h = 3840, 2160
+    src, dst = dframe(w, h, 4, NB), dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.gauss5(src[i], dst[i], w, h), NB)
+    hs, hd = hframe(w, h, 4), hframe(w, h, 4)
+    c = cpu(lambda: orc.orc_gauss5(P(hs), hs.strides[0], P(hd), hd.strides[0], w, h, 4))
+    add("gauss5 RGBA32 (C4)", "(own spec)", "3840x2160", w * h * 8, t, c)
+    a3, b3, o3 = dframe(w, h, 3, NB), dframe(w, h, 3, NB), dframe(w, h, 3, NB)
+    t = timeit(lambda i: ops.colorkey(a3[i], b3[i], o3[i], w, h, 0, 0.2, 1.0, (0, 0, 255)), NB)
+    ha, hb, ho = hframe(w, h, 3), hframe(w, h, 3), hframe(w, h, 3)
+    if orc:
+        orc.orc_colorkey.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    c = cpu(lambda: orc.orc_colorkey(P(ha), ha.strides[0], P(hb), hb.strides[0], P(ho), ho.strides[0], w, h, 0, 0.2, 1.0, 0, 0, 255, 0))
+    add("colour key RGB24 (C4)", "scripts/colorkey.script", "3840x2160", w * h * 9, t, c)
+    t = timeit(lambda i: ops.mirror(2, src[i], dst[i], w, h, 4), NB)
+    c = cpu(lambda: orc.orc_mirror(2, P(hs), hs.strides[0], P(hd), hd.strides[0], w, h, 4))
+    add("mirrorxy RGBA32", "mirrors.c:26-122", "3840x2160", w * h * 8, t, c)
+    # ---- F6 stencils ------------------------------------------------------------------------------------------------------------
+    w, h = 1920, 1080
+    yp = [dframe(w, h, 1, NB), dframe(w // 2, h // 2, 1, NB), dframe(w // 2, h // 2, 1, NB)]
+    yo = [dframe(w, h, 1, NB), dframe(w // 2, h // 2, 1, NB), dframe(w // 2, h // 2, 1, NB)]
+    t = timeit(lambda i: ops.softlight([p[i] for p in yp], [p[i] for p in yo], w, h, 512, 1), NB)
+    hs, hd = hframe(w, h, 1), hframe(w, h, 1)
+    c = cpu(lambda: orc.orc_softlight_y(P(hs), hs.strides[0], P(hd), hd.strides[0], w, h, 1))
+    add("softlight YUV420P", "softlight.c:62-151", "1920x1080", w * h * 3, t, c)
+    src, dst = dframe(w, h, 4, NB), dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.edge(src[i], dst[i], w, h, 3, 0), NB)
+    hs, hd = hframe(w, h, 4), hframe(w, h, 4)
+    m16 = np.zeros(w * h, np.int16)
+    c = cpu(lambda: orc.orc_edge(P(hs), hs.strides[0], P(hd), hd.strides[0], w, h, 3, 0, P(m16), 0))
+    add("edge detect RGBA32 (mode 0)", "edge.c:129-248", "1920x1080", w * h * (4 + 2 + 2 + 4 + 4), t, c)
+    bz = ops.Blurzoom(w, h, 3)
+    t = timeit(lambda i: bz.process(src[i], dst[i], 0, 0), NB)
+    if orc:
+        orc.orc_blurzoom_new.restype = ctypes.c_void_p
+        orc.orc_blurzoom_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        zo = orc.orc_blurzoom_new(w, h, 3)
+    c = cpu(lambda: orc.orc_blurzoom_process(zo, P(hs), hs.strides[0], P(hd), hd.strides[0], 0, 0))
+    add("blurzoom RGBA32 (mode 0)", "blurzoom.c:345-421", "1920x1080", w * h * (4 + 4 + 4 + 4 + 1) + w * h * 6, t, c)
+    # ---- K4 / K3 / K5 -----------------------------------------------------------------------------------------------------------
+    rgba = dframe(w, h, 4, NB)
+    planes = [dframe(w, h, 1, NB), dframe(w // 2, h // 2, 1, NB), dframe(w // 2, h // 2, 1, NB)]
+    t = timeit(lambda i: ops.rgb_to_yuv(rgba[i], [p[i] for p in planes], w, h, 0, 1, 4, 0, 0), NB)
+    hs = hframe(w, h, 4)
+    hpl = [hframe(w, h, 1), hframe(w // 2, h // 2, 1), hframe(w // 2, h // 2, 1)]
+    pp, ss = po.planes_args(hpl)
+    if orc:
+        orc.orc_rgb_to_yuv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    c = cpu(lambda: orc.orc_rgb_to_yuv(P(hs), hs.strides[0], w, h, 0, 1, ctypes.addressof(pp), ctypes.addressof(ss), 4, 0, 0))
+    add("RGBA32 -> YUV420P", "colourspace.c:6250-6322", "1920x1080", w * h * 4 * 3 // 2 + w * h * 3 // 2, t, c)
+    uy = dframe(w, h, 2, NB)
+    t = timeit(lambda i: ops.yuv_to_rgb([uy[i]], rgba[i], w, h, 2, 0, 0, 1, 0), NB)
+    hu2 = hframe(w, h, 2)
+    sp, s2 = po.planes_args([hu2])
+    if orc:
+        orc.orc_yuv_to_rgb.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4
+    c = cpu(lambda: orc.orc_yuv_to_rgb(ctypes.addressof(sp), ctypes.addressof(s2), w, h, 2, 0, P(hs), hs.strides[0], 0, 1, 0))
+    add("UYVY -> RGBA32", "colourspace.c:6616-6690", "1920x1080", w * h * 6, t, c)
+    t = timeit(lambda i: ops.yuv_switch_clamping([p[i] for p in planes], 512, h, 1), NB)
+    add("clamping switch YUV420P (in place)", "colourspace.c:10929-11090", "1920x1080", w * h * 3, t, None)
+    # ---- compositor: 8 tracks 960x540 onto 1920x1080 ---------------------------------------------------------------------------------
+    lay = [dframe(960, 540, 4, 1)[0] for _ in range(8)]
+    out = dframe(w, h, 4, NB)
+    layers = [(lay[z], 960, 540, 120 * z, 60 * z, 0.75) for z in range(8)]
+    t = timeit(lambda i: ops.composite(out[i], w, h, 4, layers), NB)
+    covered = sum(max(0, min(w, 120 * z + 960) - 120 * z) * max(0, min(h, 60 * z + 540) - 60 * z) for z in range(8))
+    add("composite 8 x 960x540 layers", "compositor.c:120-293", "1920x1080", covered * 4 + w * h * 4, t, None)
+
+    print("| op | reference | size | algorithmic bytes | GPU us | GB/s | of 8 TB/s | oracle 1-thread ms | ratio |\n|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %s | `%s` | %s | %d | %.2f | %.1f | %.3f | %s | %s |" % (r["op"], r["reference"], r["size"], r["algorithmic_bytes"], r["gpu_us"], r["gbs"], r["frac"],
+                                                                      "-" if r["cpu_ms"] is None else "%.3f" % r["cpu_ms"], "-" if r["speedup"] is None else "%.0fx" % r["speedup"]))
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
