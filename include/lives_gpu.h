@@ -43,6 +43,8 @@ int lgpu_malloc(void **ptr_d, size_t bytes);
 int lgpu_free(void *ptr_d);
 int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream);
 int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream);
+int lgpu_copy(void *dst_d, const void *src_d, size_t bytes, void *stream);      /* device to device */
+int lgpu_fill(void *dst_d, int byte, size_t bytes, void *stream);
 int lgpu_sync(void *stream);
 
 /* ---- host-side table builders (pure CPU, usable without a device) -------------------------------- */

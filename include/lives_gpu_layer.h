@@ -68,6 +68,16 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
 lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig);
 int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int *nplanes);
 
+/* ---- device residency (optional): a pinned layer keeps the authoritative copy of its planes in HBM across the calls
+   above, so a chain of layer ops crosses PCIe once per direction.  Between pin and sync the HOST bytes of pixel_data are
+   stale (pointers, sizes, rowstrides and every other leaf stay exact).  The host pins a layer when it enters a run of
+   GPU-served steps (e.g. the CONVERT chain of one plan step, src/nodemodel.c:2027-2089) and syncs / unpins it before CPU
+   code reads the pixels.  State travels in the private leaf "host_gpu_resident" (host_* convention). */
+int lives_gpu_layer_pin(lives_gpu_layer_t *layer);      /* upload the planes once, mark the layer resident */
+int lives_gpu_layer_sync(lives_gpu_layer_t *layer);     /* download the current planes into pixel_data; stays pinned */
+int lives_gpu_layer_unpin(lives_gpu_layer_t *layer);    /* sync, release the device copies, clear the leaf */
+void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes);   /* PCIe bytes moved by the seam so far */
+
 #ifdef LIVES_GPU_DROP_IN
 #define convert_layer_palette lives_gpu_convert_layer_palette
 #define convert_layer_palette_full lives_gpu_convert_layer_palette_full

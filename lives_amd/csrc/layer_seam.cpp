@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "../../include/lives_gpu.h"
 #include "../../include/lives_gpu_layer.h"
@@ -23,6 +25,7 @@ lives_gpu_prefs g_prefs = {1, 0, 2, 1.4, 0};
 
 constexpr const char *kLeafHostFlags = "host_flags";          // LIVES_LEAF_HOST_FLAGS (src/colourspace.h:37)
 constexpr const char *kLeafContiguous = "host_contiguous";    // LIVES_LEAF_PIXEL_DATA_CONTIGUOUS (:33)
+constexpr const char *kLeafResident = "host_gpu_resident";    // this library's private leaf (host_* convention, src/effects-weed.h:80-119)
 
 bool bound() { return g_api.leaf_get && g_api.leaf_set && g_api.leaf_num_elements && g_api.leaf_delete; }
 void *palloc(size_t n) { return g_api.pixel_alloc ? g_api.pixel_alloc(n) : calloc(1, n ? n : 1); }
@@ -84,7 +87,32 @@ bool read_layer(weed_plant_t *plant, Layer *l) {
   return true;
 }
 
+// ---- device residency of pinned layers ---------------------------------------------------------------------------------
+// A layer the host pinned (lives_gpu_layer_pin) keeps the authoritative copy of its planes in HBM, keyed by the HOST plane
+// pointer: uploads of such a plane become device-to-device copies, downloads replace the device copy and leave the host
+// bytes stale until lives_gpu_layer_sync().  The CONVERT chain of one plan step (pconv -> gamma -> resize -> letterbox) then
+// crosses PCIe once in each direction instead of eight times.
+struct ResEntry { void *d; size_t bytes; };
+std::mutex g_res_mu;
+std::unordered_map<const void *, ResEntry> g_res;
+unsigned long long g_h2d = 0, g_d2h = 0;        // PCIe byte counters (tests check the residency contract with them)
+thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
+
+void res_drop(const void *h) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  auto it = g_res.find(h);
+  if (it == g_res.end()) return;
+  lgpu_free(it->second.d);
+  g_res.erase(it);
+}
+struct PinScope {
+  bool prev;
+  explicit PinScope(weed_plant_t *layer) : prev(t_pinned) { t_pinned = layer && bound() && has_leaf(layer, kLeafResident); }
+  ~PinScope() { t_pinned = prev; }
+};
+
 void free_planes(const Layer &l) {
+  for (int i = 0; i < l.nplanes; i++) res_drop(l.pd[i]);
   if (l.contiguous) pfree(l.pd[0]);
   else for (int i = 0; i < l.nplanes; i++) pfree(l.pd[i]);
 }
@@ -136,8 +164,35 @@ struct Scratch {
 thread_local Scratch t_scr;
 
 bool ready() { return bound() && lgpu_init(g_prefs.device) == LGPU_OK; }
-bool up(uint8_t *d, const uint8_t *h, size_t n) { return lgpu_upload(d, h, n, nullptr) == LGPU_OK; }
-bool down(uint8_t *h, const uint8_t *d, size_t n) { return lgpu_download(h, d, n, nullptr) == LGPU_OK; }
+bool up(uint8_t *d, const uint8_t *h, size_t n) {
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    auto it = g_res.find(h);
+    if (it != g_res.end() && it->second.bytes >= n) return lgpu_copy(d, it->second.d, n, nullptr) == LGPU_OK;   // resident plane: stays in HBM
+  }
+  g_h2d += n;
+  return lgpu_upload(d, h, n, nullptr) == LGPU_OK;
+}
+// a freshly allocated (zeroed) host plane that a kernel is about to fill: nothing worth sending for a pinned layer
+bool up_fresh(uint8_t *d, const uint8_t *h, size_t n) {
+  if (t_pinned) return lgpu_fill(d, 0, n, nullptr) == LGPU_OK;
+  return up(d, h, n);
+}
+bool down(uint8_t *h, const uint8_t *d, size_t n) {
+  if (t_pinned) {                       // the device copy becomes the plane; the host bytes go stale until lives_gpu_layer_sync()
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    ResEntry &e = g_res[h];
+    if (e.bytes < n) {
+      if (e.d) lgpu_free(e.d);
+      e.d = nullptr; e.bytes = 0;
+      if (lgpu_malloc(&e.d, n + 64) != LGPU_OK) { g_res.erase(h); return false; }
+      e.bytes = n;
+    }
+    return lgpu_copy(e.d, d, n, nullptr) == LGPU_OK;
+  }
+  g_d2h += n;
+  return lgpu_download(h, d, n, nullptr) == LGPU_OK;
+}
 bool sync() { return lgpu_sync(nullptr) == LGPU_OK; }
 
 int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
@@ -230,12 +285,12 @@ lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outp
   for (int p = 0; p < np.n && ok; p++) {
     ddst[p] = t_scr.get(3 + p, np.sz[p]);
     ors[p] = np.rs[p];
-    ok = ddst[p] && up(ddst[p], np.pd[p], np.sz[p]);           // calloc'd padding stays as the host made it
+    ok = ddst[p] && up_fresh(ddst[p], np.pd[p], np.sz[p]);     // calloc'd padding stays as the host made it
   }
   ok = ok && lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr) == LGPU_OK;
   for (int p = 0; p < np.n && ok; p++) ok = down(np.pd[p], ddst[p], np.sz[p]);
   ok = ok && sync();
-  if (!ok) { pfree(np.pd[0]); return 0; }
+  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }
   int flags = l.flags;
   if (in_alpha && !out_alpha) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
   free_planes(l);
@@ -307,6 +362,7 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
 lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
                                                        int osubspace, int tgt_gamma) {
   (void)osampling;
+  PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
   const int inpl = l.pal;
@@ -393,7 +449,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     ok = ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, nullptr) == LGPU_OK;
   } else ok = false;
   ok = ok && down(np.pd[0], d_out, obytes) && sync();
-  if (!ok) { pfree(np.pd[0]); return 0; }                                  // memfail: layer untouched
+  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }                                  // memfail: layer untouched
   free_planes(l);
   commit_planes(layer, outpl, owidth, l.height, np);
   if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
@@ -411,6 +467,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette(lives_gpu_layer_t *layer, int 
 lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y, int width,
                                                     int height, lives_gpu_boolean may_thread) {
   (void)may_thread;
+  PinScope pin(layer);
   if (!g_prefs.apply_gamma) return 1;
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
@@ -436,6 +493,7 @@ lives_gpu_boolean lives_gpu_gamma_convert_layer(int gamma_type, lives_gpu_layer_
 }
 
 void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction) {
+  PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l) || !pal_has_alpha(l.pal)) return;
   const size_t bytes = (size_t)l.rs[0] * l.height;
@@ -464,12 +522,13 @@ static bool resize_into(const Layer &l, int width, int height, int interp, int a
          lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, nullptr, nullptr) == LGPU_OK &&
          down(np->pd[p], d_out, ob) && sync();
   }
-  if (!ok) pfree(np->pd[0]);
+  if (!ok) { for (int q = 0; q < np->n; q++) res_drop(np->pd[q]); pfree(np->pd[0]); }
   return ok;
 }
 
 lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint) {
   (void)oclamp_hint;
+  PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
   if (opal_hint != WEED_PALETTE_NONE && opal_hint != l.pal) return 0;     // resize + palette change in one go: not on the GPU path
@@ -491,6 +550,7 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
 
 lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
                                             int tpal, int tclamp) {
+  PinScope pin(layer);
   if (!width || !height || !nwidth || !nheight) return 1;                 // :15377
   if (nwidth < width) nwidth = width;
   if (nheight < height) nheight = height;
@@ -521,13 +581,67 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
     const size_t ib = (size_t)l.rs[p] * sh, ob = (size_t)np.rs[p] * chh;
     uint8_t *d_in = t_scr.get(0, ib), *d_out = t_scr.get(3, ob);
     // the canvas keeps zeroed row padding (calloc on the host side); upload it so the kernel's untouched bytes stay zero
-    ok = d_in && d_out && up(d_in, l.pd[p], ib) && up(d_out, np.pd[p], ob) &&
+    ok = d_in && d_out && up(d_in, l.pd[p], ib) && up_fresh(d_out, np.pd[p], ob) &&
          lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, nullptr) == LGPU_OK && down(np.pd[p], d_out, ob) && sync();
   }
-  if (!ok) { pfree(np.pd[0]); return 0; }
+  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }
   free_planes(l);
   commit_planes(layer, l.pal, nwidth, nheight, np);
   return 1;
+}
+
+// ---- device residency API (seam 2) ---------------------------------------------------------------------------
+static size_t plane_bytes(const Layer &l, int p) {
+  const bool planar = pal_is_planar_yuv(l.pal);
+  const int h = (!planar || p == 0 || p == 3 || pal_is_444(l.pal) || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1;
+  return (size_t)l.rs[p] * h;
+}
+int lives_gpu_layer_pin(lives_gpu_layer_t *layer) {
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return LGPU_E_BADARG;
+  if (has_leaf(layer, kLeafResident)) return LGPU_OK;
+  for (int p = 0; p < l.nplanes; p++) {
+    const size_t n = plane_bytes(l, p);
+    void *d = nullptr;
+    if (lgpu_malloc(&d, n + 64) != LGPU_OK) { for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_NOMEM; }
+    g_h2d += n;
+    if (lgpu_upload(d, l.pd[p], n, nullptr) != LGPU_OK) { lgpu_free(d); for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_HIP; }
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    ResEntry &e = g_res[l.pd[p]];
+    if (e.d) lgpu_free(e.d);
+    e.d = d; e.bytes = n;
+  }
+  if (!sync()) return LGPU_E_HIP;
+  set_int(layer, kLeafResident, 1);
+  return LGPU_OK;
+}
+int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return LGPU_E_BADARG;
+  for (int p = 0; p < l.nplanes; p++) {
+    const size_t n = plane_bytes(l, p);
+    void *d = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_res_mu);
+      auto it = g_res.find(l.pd[p]);
+      if (it != g_res.end() && it->second.bytes >= n) d = it->second.d;
+    }
+    if (!d) continue;                                   // this plane's host bytes are current
+    g_d2h += n;
+    if (lgpu_download(l.pd[p], d, n, nullptr) != LGPU_OK) return LGPU_E_HIP;
+  }
+  return sync() ? LGPU_OK : LGPU_E_HIP;
+}
+int lives_gpu_layer_unpin(lives_gpu_layer_t *layer) {
+  const int rc = lives_gpu_layer_sync(layer);
+  Layer l;
+  if (read_layer(layer, &l)) for (int p = 0; p < l.nplanes; p++) res_drop(l.pd[p]);
+  if (bound() && layer) g_api.leaf_delete(layer, kLeafResident);
+  return rc;
+}
+void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes) {
+  if (h2d_bytes) *h2d_bytes = g_h2d;
+  if (d2h_bytes) *d2h_bytes = g_d2h;
 }
 
 }  // extern "C"

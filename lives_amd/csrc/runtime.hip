@@ -122,6 +122,20 @@ int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream) {
   return LGPU_OK;
 }
 
+int lgpu_copy(void *dst_d, const void *src_d, size_t bytes, void *stream) {
+  int rc = lgpu::ensure_init();
+  if (rc) return rc;
+  LGPU_HIP(hipMemcpyAsync(dst_d, src_d, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return LGPU_OK;
+}
+
+int lgpu_fill(void *dst_d, int byte, size_t bytes, void *stream) {
+  int rc = lgpu::ensure_init();
+  if (rc) return rc;
+  LGPU_HIP(hipMemsetAsync(dst_d, byte, bytes, (hipStream_t)stream));
+  return LGPU_OK;
+}
+
 int lgpu_sync(void *stream) {
   LGPU_HIP(hipStreamSynchronize((hipStream_t)stream));
   return LGPU_OK;

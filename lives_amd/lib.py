@@ -52,6 +52,8 @@ PROTOTYPES = {
     "lgpu_free": [vp],
     "lgpu_upload": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_download": [vp, vp, ctypes.c_size_t, vp],
+    "lgpu_copy": [vp, vp, ctypes.c_size_t, vp],
+    "lgpu_fill": [vp, ci, ctypes.c_size_t, vp],
     "lgpu_sync": [vp],
     "lgpu_conversion_tables": [ci, vp, vp],
     "lgpu_gamma_lut8": [cd, ci, ci, cd, vp],

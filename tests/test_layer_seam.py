@@ -274,3 +274,49 @@ def test_yuv_layer_clamping_switch(seam, orc):
         lay2 = wh.new_layer(pal, lw, h, planes, clamping=0, subspace=1)
         assert L.lives_gpu_convert_layer_palette_full(lay2, pal, 1, 0, 2, 0) == 0 and wh.geti(lay2, "YUV_clamping") == 0
 
+
+@needs_ref
+@pytest.mark.gpu
+def test_pinned_layer_stays_in_hbm(seam, orc):
+    """pin -> convert -> gamma -> resize -> letterbox -> sync: same pixels as the unpinned run, PCIe crossed once per direction"""
+    L, wh = seam
+
+    def stats():
+        a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        L.lives_gpu_transfer_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    rng = np.random.default_rng(11)
+    w, h = 256, 144
+    ys, cs = align(w), align(w) >> 1
+    Y = rng.integers(16, 236, (h, ys), dtype=np.uint8)
+    U = rng.integers(16, 241, (h // 2, cs), dtype=np.uint8)
+    V = rng.integers(16, 241, (h // 2, cs), dtype=np.uint8)
+
+    def chain(lay):
+        assert L.lives_gpu_convert_layer_palette(lay, RGBA32, 0) == 1
+        assert L.lives_gpu_gamma_convert_layer(1, lay) == 1
+        assert L.lives_gpu_resize_layer(lay, 128, 72, 3, 0, 0) == 1
+        assert L.lives_gpu_letterbox_layer(lay, 128, 96, 128, 72, 3, 0, 0) == 1
+
+    plain = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    h0, d0 = stats()
+    chain(plain)
+    h1, d1 = stats()
+    want, _, rs = wh.planes_of(plain)
+    pinned = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    assert L.lives_gpu_layer_pin(pinned) == 0 and wh.geti(pinned, "host_gpu_resident") == 1
+    h2, d2 = stats()
+    chain(pinned)
+    h3, d3 = stats()
+    assert (h3, d3) == (h2, d2), "a pinned layer must not cross PCIe inside the chain"
+    assert (wh.geti(pinned, "current_palette"), wh.geti(pinned, "width"), wh.geti(pinned, "height")) == (RGBA32, 128, 96)
+    assert L.lives_gpu_layer_sync(pinned) == 0
+    h4, d4 = stats()
+    got, _, rs2 = wh.planes_of(pinned)
+    assert rs2 == rs and (got[0] == want[0]).all()
+    in_bytes, out_bytes = Y.nbytes + U.nbytes + V.nbytes, got[0].nbytes
+    assert h2 - h1 == in_bytes and d4 - d3 == out_bytes                 # once in, once out
+    assert (h1 - h0) > 3 * in_bytes and (d1 - d0) > 3 * out_bytes         # the unpinned chain pays for every step
+    assert L.lives_gpu_layer_unpin(pinned) == 0 and wh.geti(pinned, "host_gpu_resident") is None
+
