@@ -9,7 +9,8 @@ Multi-GPU: one process per GPU (torch.distributed / RCCL), tracks sharded track-
 collective; the shared transition parameter block (blend amount) is broadcast from rank 0 over RCCL every
 step and read by the kernel from device memory.  Weak scaling: per-GPU work is fixed.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
+Before the W warm-up steps the device is woken up with ~60 ms of the same launch (clock / power ramp; not part of the
+schedule).  Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : algorithmic bytes / launch  divided by  the kernel's average launch duration, measured live with
                  HIP events on the launch stream (lgpu_chain_timed), against the 8 TB/s HBM3E peak
   cpu_baseline : the CPU oracle (a port of the reference path; oracle/) timed on this host's cores on a
@@ -34,8 +35,8 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU)
     ap.add_argument("--blur", type=int, default=0, help="1: add the 5x5 gaussian stage (BASELINE config 5 chain)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -79,8 +80,13 @@ def main():
                            param_block=pblock)
     trk = ops.chain_tracks(srcs, l2s, dsts)
 
+    sched_base = schedule.data_ptr()
+
     def step(s):
-        ld.publish_params(pblock, schedule[s] if rank == 0 else None)   # RCCL broadcast over xGMI when world > 1; no host sync
+        if world > 1:
+            ld.publish_params(pblock, schedule[s] if rank == 0 else None)   # RCCL broadcast over xGMI; no host sync
+        else:
+            prm.param_block_d = sched_base + 16 * s      # one GPU: nothing to exchange, the kernel reads step s of the resident schedule
         ops.chain(prm, trk)
 
     def fence():
@@ -89,6 +95,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device wake-up (not a step of the schedule): ~60 ms of the same launch so that the power / clock state is the steady one
+    # whatever --warmup says; measured: the first ~100 launches after idle run ~15 % slower
+    for _ in range(300):
+        ops.chain(prm, trk)
     for s in range(args.warmup):
         step(s)
     fence()
