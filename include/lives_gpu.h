@@ -193,6 +193,12 @@ int lgpu_blurzoom_create(int width, int height, int palette, lgpu_blurzoom **out
 int lgpu_blurzoom_process(lgpu_blurzoom *bz, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int mode, int pattern,
                           void *stream);
 void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
+/* geometric transitions: lives-plugins/weed-plugins/multi_transitions.c:86-233.  type 0 "iris rectangle", 1 "iris circle",
+   2 "4 way split"; amount = the transition parameter 0..1; packed pixels of 3 or 4 bytes.  dst_d may equal src1_d for
+   types 0 / 1 (the reference's out channel is CAN_DO_INPLACE there), not for type 2.  ("dissolve" and "rand replace" draw
+   from the host's random generator and stay on the CPU.) */
+int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
+                    int width, int height, int psize, double amount, void *stream);
 /* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
 int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
                 int psize, void *stream);

@@ -514,3 +514,74 @@ extern "C" int lgpu_composite(uint8_t *dst_d, int orow, int owidth, int oheight,
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// geometric transitions: lives-plugins/weed-plugins/multi_transitions.c:86-233 (iris rectangle, iris circle, 4 way split)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace lgpu {
+struct TransArgs {
+  const uint8_t *src1, *src2;
+  uint8_t *dst;
+  int irow1, irow2, orow, width, height, wb, type;
+  int xx, yy, ihwidth, ihheight;          // type 0: rectangle insets (bytes, rows); type 2: quadrant shifts (bytes of rows, bytes)
+  float bf, hwidth, hheight, maxradsq;
+};
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= a.width) return;
+  const int j = x * PS;
+  for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
+    const uint8_t *from;
+    if (a.type == 0) {
+      from = (j < a.xx || j >= a.wb - a.xx || i < a.yy || i >= a.height - a.yy) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
+    } else if (a.type == 1) {
+      // sqrt((xxf * xxf + yyf * yyf) / maxradsq) > bf: float terms, double square root (:185-187)
+      const float xxf = (float)(i - a.ihheight), yyf = __fdiv_rn((float)(j - a.ihwidth), (float)PS);
+      const float v = __fdiv_rn(__fadd_rn(__fmul_rn(xxf, xxf), __fmul_rn(yyf, yyf)), a.maxradsq);
+      from = (__dsqrt_rn((double)v) > (double)a.bf) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
+    } else {
+      const bool cross = __fdiv_rn(fabsf(__fsub_rn((float)i, a.hheight)), a.hheight) < a.bf ||
+                         __fdiv_rn(fabsf(__fsub_rn((float)j, a.hwidth)), a.hwidth) < a.bf || a.bf == 1.f;
+      from = cross ? a.src2 + (size_t)a.irow2 * i + j
+                   : a.src1 + (size_t)a.irow1 * i + j + (j > a.ihwidth ? -a.yy : a.yy) + (i > a.ihheight ? -(ptrdiff_t)a.xx : (ptrdiff_t)a.xx);
+    }
+    uint8_t *d = a.dst + (size_t)a.orow * i + j;
+    if (from != d) {
+#pragma unroll
+      for (int k = 0; k < PS; k++) d[k] = from[k];
+    }
+  }
+}
+}  // namespace lgpu
+
+extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
+                               int width, int height, int psize, double amount, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(type >= 0 && type <= 2, "type must be 0 (iris rectangle), 1 (iris circle) or 2 (4 way split)");
+  LGPU_REQUIRE(src1_d && src2_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(irow1 >= width * psize && irow2 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  LGPU_REQUIRE(type != 2 || src1_d != dst_d, "4 way split is not in place (multi_transitions.c:283)");
+  lgpu::TransArgs a;
+  a.src1 = src1_d; a.src2 = src2_d; a.dst = dst_d; a.irow1 = irow1; a.irow2 = irow2; a.orow = orow;
+  a.width = width; a.height = height; a.type = type;
+  // the reference's own float / double mix (:129-150)
+  float hwidth = (float)width * 0.5f;
+  const float hheight = (float)height * 0.5f;
+  a.maxradsq = (type == 1) ? ((hheight * hheight) + (hwidth * hwidth)) : 0.f;
+  a.wb = width * psize;
+  hwidth = (float)a.wb * 0.5f;
+  a.hwidth = hwidth; a.hheight = hheight; a.ihwidth = a.wb >> 1; a.ihheight = height >> 1;
+  a.bf = (float)amount;
+  const float bfneg = 1.f - a.bf;
+  a.xx = a.yy = 0;
+  if (type == 0) { a.xx = (int)((int)hwidth * bfneg + .5); a.yy = (int)((int)hheight * bfneg + .5); }
+  else if (type == 2) { a.xx = (int)(hheight * a.bf + .5) * irow1; a.yy = (int)(hwidth / (float)psize * a.bf + .5) * psize; }
+  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

@@ -174,6 +174,11 @@ static int k_ckey(const fxframe_t *f, weed_plant_t *inst, int kind) {
                        g_dbl(pd, WEED_LEAF_VALUE, .2), g_dbl(po, WEED_LEAF_VALUE, 1.), g_int(pc, WEED_LEAF_VALUE, 0, 0),
                        g_int(pc, WEED_LEAF_VALUE, 1, 0), g_int(pc, WEED_LEAF_VALUE, 2, 255), NULL);
 }
+static int k_transition(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  weed_plant_t *pa = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 0);
+  return lgpu_transition(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
+                         pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -252,6 +257,7 @@ PROC(p_overlay, 2, 4, k_multi, 0) PROC(p_dodge, 2, 5, k_multi, 0) PROC(p_burn, 2
 PROC(p_ckey, 2, 0, k_ckey, 0)
 PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
+PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -383,6 +389,23 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
     if (fc) w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict);
     if (ict) s_int(ict, WEED_LEAF_FLAGS, WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
+  }
+  /* multi_transitions.c:262-296: "iris rectangle", "iris circle" (out channel CAN_DO_INPLACE), "4 way split" (not in place);
+     float parameter "amount" flagged as the transition parameter; MAY_THREAD dropped (whole-frame geometry, one call) */
+  {
+    static const int32_t pk[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_YUV888, WEED_PALETTE_YUVA8888};
+    static const struct { const char *n; weed_process_f f; int inplace; } tr[] = {{"iris rectangle", p_irisr, 1}, {"iris circle", p_irisc, 1}, {"4 way split", p_fourw, 0}};
+    for (i = 0; i < 3; i++) {
+      weed_plant_t *fc = NULL, *oct = NULL;
+      p[0] = float_param("amount", "_Transition", 0., 0., 1.);
+      s_bool(p[0], WEED_LEAF_IS_TRANSITION, WEED_TRUE);
+      add_filter(pinfo, tr[i].n, 0, pk, 6, tr[i].f, 2, "in channel 0", "in channel 1", "out channel 0", p, 1);
+      if (!tr[i].inplace) {
+        w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+        if (fc) w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct);
+        if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
+      }
+    }
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

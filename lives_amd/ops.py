@@ -107,6 +107,11 @@ def mirror(mode, src, dst, width, height, psize):
     lib.call("lgpu_mirror", mode, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
 
 
+def transition(kind, src1, src2, dst, width, height, psize, amount):
+    lib.call("lgpu_transition", kind, dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width, height, psize,
+             float(amount), stream_ptr())
+
+
 def _plane_tables(planes):
     n = len(planes)
     pp = (ctypes.c_void_p * 4)(*([dptr(t) for t in planes] + [None] * (4 - n)))

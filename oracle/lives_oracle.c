@@ -804,6 +804,43 @@ int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], i
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * F7: geometric transitions             reference: lives-plugins/weed-plugins/multi_transitions.c:86-233
+ * ---------------------------------------------------------------------------------------------- */
+void orc_transition(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow,
+                    int width, int height, int psize, double amount) {
+  const int ihheight = height >> 1;
+  float hwidth = (float)width * 0.5f;
+  const float hheight = (float)height * 0.5f;
+  float maxradsq = 0.f;
+  if (type == 1) maxradsq = ((hheight * hheight) + (hwidth * hwidth));                   /* :137, in pixels */
+  const int wb = width * psize;                                                            /* :139: from here on width is in bytes */
+  hwidth = (float)wb * 0.5f;
+  const int ihwidth = wb >> 1;
+  const float bf = (float)amount, bfneg = 1.f - bf;
+  int xx = 0, yy = 0;
+  if (type == 2) {
+    xx = (int)(hheight * bf + .5) * irow1;
+    yy = (int)(hwidth / (float)psize * bf + .5) * psize;
+  }
+  for (int i = 0; i < height; i++)
+    for (int j = 0; j < wb; j += psize) {
+      const uint8_t *from;
+      if (type == 0) {
+        xx = (int)hwidth * bfneg + .5;
+        yy = (int)hheight * bfneg + .5;
+        from = (j < xx || j >= (wb - xx) || i < yy || i >= (height - yy)) ? src1 + (size_t)irow1 * i + j : src2 + (size_t)irow2 * i + j;
+      } else if (type == 1) {
+        const float xxf = (float)(i - ihheight), yyf = (float)(j - ihwidth) / (float)psize;
+        from = (sqrt((xxf * xxf + yyf * yyf) / maxradsq) > bf) ? src1 + (size_t)irow1 * i + j : src2 + (size_t)irow2 * i + j;
+      } else {
+        if (fabsf(i - hheight) / hheight < bf || fabsf(j - hwidth) / hwidth < bf || bf == 1.f) from = src2 + (size_t)irow2 * i + j;
+        else from = src1 + (size_t)irow1 * i + j + (j > ihwidth ? -yy : yy) + (i > ihheight ? -xx : xx);
+      }
+      memmove(dst + (size_t)orow * i + j, from, (size_t)psize);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * F6a: softlight                        reference: lives-plugins/weed-plugins/softlight.c:34-47 (sqrti), :62-141
  * Per interior luma sample (the reference's own operand choice, including the two terms that differ from a
  * textbook Sobel: row0 ends with (S[+1][+1] - S[+1][-1]) and row1 ends with the SUM S[+1][+1] + S[+1][-1]):

@@ -113,6 +113,13 @@ int orc_cavg(int clamped, int x, int y);
 void orc_yuv_yuv_tables(uint8_t *yc2u, uint8_t *uvc2u, uint8_t *yu2c, uint8_t *uvu2c);
 int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], int palette, int height, int to_unclamped);
 
+/* F7: geometric transitions  lives-plugins/weed-plugins/multi_transitions.c:86-233: type 0 "iris rectangle", 1 "iris circle",
+   2 "4 way split" (types 3 dissolve / 4 rand replace draw from the host's random generator and are not restated).
+   Packed palettes, psize bytes per pixel; amount = the transition parameter 0..1; 1-thread semantics.  In place
+   (dst == src1) is equivalent to out of place for types 0 / 1; type 2 is not in place (its out channel template says so). */
+void orc_transition(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow,
+                    int width, int height, int psize, double amount);
+
 /* F6a: "softlight"  lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV: the stencil runs on plane 0 (rows
    1..h-2, columns 1..w-2; the frame border is copied), the other planes are copied (:143-151).
    unclamped != 0: output range 0..255, else 16..235 (:97-103).  Needs width, height >= 3. */

@@ -91,6 +91,7 @@ def oracle():
         _O.orc_rgb_to_yuv.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci]
         _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
         _O.orc_cavg.argtypes = [ci, ci, ci]
+        _O.orc_transition.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]
         _O.orc_blurzoom_new.restype = vp

@@ -61,10 +61,26 @@ def main():
                 names.append(key)
     rec["records"] = np.array(names)
     np.savez_compressed(os.path.join(OUT, "stencils.npz"), **rec)
+    # geometric transitions (multi_transitions.c): own file so that stencils.npz keeps its bytes
+    tr, tnames = {}, []
+    for t, fn in enumerate(("iris rectangle", "iris circle", "4 way split")):
+        for pal, ps in ((1, 3), (4, 4)):
+            for amt in (0.0, 0.25, 0.6, 1.0):
+                w, h = 26, 11
+                s1, s2 = po.make_frame(rng, w, h, ps), po.make_frame(rng, w, h, ps)
+                d = np.full_like(s1, 0x5A)
+                H.run(po.refplugin("multi_transitions"), fn, pal, w, h, [s1, s2], d, [po.p_double(amt)])
+                key = "tr|%d|%d|%s|%d|%d" % (t, pal, amt, w, h)
+                tr[key + "|a"], tr[key + "|b"], tr[key + "|o"] = s1, s2, d
+                tnames.append(key)
+    tr["records"] = np.array(tnames)
+    np.savez_compressed(os.path.join(OUT, "transitions.npz"), **tr)
     mpath = os.path.join(OUT, "manifest.json")
     man = json.load(open(mpath))
     man["groups"]["stencils.npz"] = ("reference plugins built unmodified: lives-plugins/weed-plugins/softlight.c (sl|palette|w|h|clamping(0 clamped,1 unclamped), "
                                      "planes i<k>/o<k>), edge.c (ed|palette|mode|inplace|w|h; a = source, d = destination before, o = after); one process_func call")
+    man["groups"]["transitions.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/multi_transitions.c, filters iris rectangle (0), "
+                                        "iris circle (1), 4 way split (2); record tr|type|palette|amount|w|h; a / b sources, o result (out of place)")
     json.dump(man, open(mpath, "w"), indent=1)
     print("stencils.npz: %d records, %d KB" % (len(names), os.path.getsize(os.path.join(OUT, "stencils.npz")) // 1024))
 

@@ -243,3 +243,15 @@ def test_clamping_switch_uses_the_reference_tables(gpu):
         gpu.yuv_switch_clamping(planes, 544, 1, to_uncl)
         assert (host(planes[0])[0] == g[ky]).all() and (host(planes[1])[0] == g[kc]).all() and (host(planes[2])[0] == g[kc]).all()
 
+
+def test_transitions_vs_reference_plugin(gpu):
+    g = gu.load("transitions.npz")
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        t, pal, amt, w, h = int(f[1]), int(f[2]), float(f[3]), int(f[4]), int(f[5])
+        ps = 3 if pal <= 2 else 4
+        want = g[rec + "|o"]
+        d = dev(np.full_like(want, 0x5A))
+        gpu.transition(t, dev(g[rec + "|a"]), dev(g[rec + "|b"]), d, w, h, ps, amt)
+        assert (host(d)[:, :w * ps] == want[:, :w * ps]).all(), rec
+

@@ -365,6 +365,23 @@ def test_yuv_to_rgb(gpu, orc, in_fmt, out_order):
     assert n > 0 or (in_fmt == 1 and out_order == 2)
 
 
+# ---------------------------------------------------------------------------------------------- F7 geometric transitions
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("psize", [3, 4])
+def test_transition(gpu, orc, kind, psize):
+    rng = np.random.default_rng(2400 + 10 * kind + psize)
+    for (w, h) in [(20, 10), (33, 17), (64, 36), (7, 5), (300, 50)]:
+        for amt in (0., 0.1, 0.25, 0.5, 0.73, 0.99, 1.0):
+            for inplace in ((0, 1) if kind < 2 else (0,)):
+                s1, s2 = frame(rng, w, h, psize), frame(rng, w, h, psize)
+                want = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                orc.orc_transition(kind, P(want) if inplace else P(s1), s1.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, psize, amt)
+                d1 = dev(s1)
+                d = d1 if inplace else dev(np.full_like(s1, 0x5A))
+                gpu.transition(kind, d1, dev(s2), d, w, h, psize, amt)
+                assert_same(host(d), want, w, h, psize, "transition %d ps=%d %dx%d amount=%s inplace=%d" % (kind, psize, w, h, amt, inplace))
+
+
 # ---------------------------------------------------------------------------------------------- K5 clamping switch
 @pytest.mark.parametrize("palette", [588, 589, 544, 545, 522, 512, 513, 564, 565])
 def test_yuv_switch_clamping(gpu, orc, palette):

@@ -280,3 +280,15 @@ def test_yuv_yuv_tables(orc):
     for a, k in zip(t, ("yc2u", "uvc2u", "yu2c", "uvu2c")):
         assert (a == g[k]).all(), k
 
+
+def test_transitions(orc):
+    g = gu.load("transitions.npz")
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        t, pal, amt, w, h = int(f[1]), int(f[2]), float(f[3]), int(f[4]), int(f[5])
+        ps = 3 if pal <= 2 else 4
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        got = np.full_like(a, 0x5A)
+        orc.orc_transition(t, P(a), a.strides[0], P(b), b.strides[0], P(got), got.strides[0], w, h, ps, amt)
+        assert (got[:, :w * ps] == want[:, :w * ps]).all(), rec
+

@@ -22,7 +22,7 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 19
+    assert len(ours) == 22
     for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
@@ -145,4 +145,18 @@ def test_blurzoom_sequences_through_the_plugin():
         H.run_seq(OURS, "blurzoom", pal, w, h, srcs, dsts, [po.p_int(mode), po.p_int(pattern)])
         for f in range(n):
             assert (dsts[f][:, :w * 4] == g[rec + "|out"][f][:, :w * 4]).all(), (rec, f)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_transition_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("transitions.npz")
+    names = ["iris rectangle", "iris circle", "4 way split"]
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        t, pal, amt, w, h = int(f[1]), int(f[2]), float(f[3]), int(f[4]), int(f[5])
+        d = np.full_like(g[rec + "|o"], 0x5A)
+        H.run(OURS, names[t], pal, w, h, [g[rec + "|a"].copy(), g[rec + "|b"].copy()], d, [po.p_double(amt)])
+        assert (d[:, :w * PSIZE[pal]] == g[rec + "|o"][:, :w * PSIZE[pal]]).all(), rec
 
