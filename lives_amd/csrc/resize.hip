@@ -256,6 +256,111 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
 
 
 // =====================================================================================================================
+// k_gauss5x -- 5x5 binomial blur of RGBA32 frames (the chain's blur stage, BASELINE config 4/5, and lgpu_gauss5).
+// Same arithmetic as k_separable<5,5> with the [1 4 6 4 1] bank (bit-identical; the tests run both): exact row sums,
+// one rounding (sum + 128) >> 8, edge pixels replicated.  Because the taps are 1/4/6 the whole thing fits SWAR: a
+// pixel is split once into its even bytes and its odd bytes (two dwords holding two 16-bit lanes each); a row sum is
+// <= 16 * 255 = 4080 and a column sum of row sums <= 65280, + 128 = 65408 < 2^16, so neither pass can carry across a
+// 16-bit lane and both passes are plain 32-bit adds / shifts on four channels at a time (~8 VALU per channel-quad per
+// pass instead of 5 multiply-adds per channel).  Tile = 64 x 16 output pixels, window 68 x 20 staged with 8-byte loads.
+// =====================================================================================================================
+struct G5Args {
+  int w, h, irow, orow, irow2;
+  int blend, use_lut;
+  uint32_t bf, nbf;
+  const int32_t *bf_d;
+  int tiles_x;
+};
+constexpr int kG5W = 64, kG5H = 16, kG5WW = kG5W + 4, kG5WH = kG5H + 4;
+constexpr int kG5Sub = 4;          // sub-tiles (of kG5H rows) a workgroup walks down, prefetching the next window in registers
+
+__device__ __forceinline__ uint32_t g5_sum(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e) {
+  return a + e + ((b + d) << 2) + (c << 2) + (c << 1);   // 32-bit SWAR operands: no 24-bit multiply
+}
+
+template <bool EPI>   // EPI: chroma blend with layer 2 and / or the gamma LUT after the blur (the chain); false = plain blur
+__global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) {
+  __shared__ uint4 s_win4[kG5WH * kG5WW / 2];
+  __shared__ uint2 s_h[kG5WH * kG5W];
+  __shared__ uint8_t s_lut[256];
+  uint2 *s_win = reinterpret_cast<uint2 *>(s_win4);
+  const int tid = threadIdx.x, trk = blockIdx.y;
+  const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+  const int tx0 = tx * kG5W, ty00 = ty * (kG5H * kG5Sub);
+  const int nsub = min(kG5Sub, (a.h - ty00 + kG5H - 1) / kG5H);
+  const uint8_t *src = t.src[trk];
+  if (EPI && a.use_lut) stage_lut(s_lut, l);
+  constexpr uint32_t M = 0x00FF00FFu;
+  constexpr int kPairs = kG5WH * (kG5WW / 2), kIter = (kPairs + 255) / 256;
+  // per-lane window slots: row / pair-of-pixels index, column offsets (clamped) are the same for every sub-tile
+  int wrow[kIter], off0[kIter], off1[kIter];
+#pragma unroll
+  for (int k = 0; k < kIter; k++) {
+    const int i = tid + k * 256;
+    const int row = i / (kG5WW / 2), pr = i - row * (kG5WW / 2);
+    const int x = tx0 - 2 + 2 * pr;
+    const int x0 = x < 0 ? 0 : x >= a.w ? a.w - 1 : x, x1 = x + 1 < 0 ? 0 : x + 1 >= a.w ? a.w - 1 : x + 1;
+    wrow[k] = row; off0[k] = 4 * x0; off1[k] = 4 * x1;
+  }
+  uint2 cur[kIter];
+  auto fetch = [&](int ty0) {
+#pragma unroll
+    for (int k = 0; k < kIter; k++) {
+      if (tid + k * 256 < kPairs) {
+        int y = ty0 - 2 + wrow[k];
+        y = y < 0 ? 0 : y >= a.h ? a.h - 1 : y;
+        const uint8_t *rp = src + (size_t)y * a.irow;
+        if (off1[k] == off0[k] + 4) cur[k] = *reinterpret_cast<const uint2 *>(rp + off0[k]);
+        else cur[k] = make_uint2(*reinterpret_cast<const uint32_t *>(rp + off0[k]), *reinterpret_cast<const uint32_t *>(rp + off1[k]));
+      }
+    }
+  };
+  fetch(ty00);
+  uint32_t bf = a.bf, nbf = a.nbf;
+  if (EPI && a.blend && a.bf_d) { bf = (uint32_t)*a.bf_d & 0xFFu; nbf = 0xFFu - bf; }
+  const uint8_t *l2 = t.l2[trk];
+  uint8_t *dst = t.dst[trk];
+  const int col = tid & 63, rg = tid >> 6;
+  const int ox = tx0 + col;
+  for (int sub = 0; sub < nsub; sub++) {
+    const int ty0 = ty00 + sub * kG5H;
+#pragma unroll
+    for (int k = 0; k < kIter; k++)
+      if (tid + k * 256 < kPairs) s_win4[tid + k * 256] = make_uint4(cur[k].x & M, (cur[k].x >> 8) & M, cur[k].y & M, (cur[k].y >> 8) & M);
+    __syncthreads();
+    if (sub + 1 < nsub) fetch(ty0 + kG5H);       // next window's loads fly under this sub-tile's two passes
+    for (int i = tid; i < kG5WH * kG5W; i += 256) {
+      const int row = i >> 6, c = i & 63;
+      const uint2 *p = s_win + row * kG5WW + c;
+      const uint2 A = p[0], B = p[1], C = p[2], D = p[3], E = p[4];
+      s_h[i] = make_uint2(g5_sum(A.x, B.x, C.x, D.x, E.x), g5_sum(A.y, B.y, C.y, D.y, E.y));
+    }
+    __syncthreads();
+    if (ox < a.w) {
+      uint2 r[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = s_h[(rg * 4 + k) * kG5W + col];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int oy = ty0 + rg * 4 + j;
+        if (oy >= a.h) break;
+        const uint32_t ev = g5_sum(r[j].x, r[j + 1].x, r[j + 2].x, r[j + 3].x, r[j + 4].x) + 0x00800080u;
+        const uint32_t od = g5_sum(r[j].y, r[j + 1].y, r[j + 2].y, r[j + 3].y, r[j + 4].y) + 0x00800080u;
+        uint32_t p = __builtin_amdgcn_perm(od, ev, 0x07030501u);     // >> 8 of the four 16-bit lanes, re-interleaved
+        if (EPI) {
+          if (a.blend) {
+            const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[ox];
+            p = chroma_rgba(p, q, bf, nbf);
+          }
+          if (a.use_lut) p = lut3_rgba(s_lut, p);
+        }
+        reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[ox] = p;
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
 // k_half8 -- fast path for an exact 2:1 reduction with a uniform 8-tap filter (the headline 3840x2160 -> 1920x1080
 // bicubic case).  Same arithmetic as k_separable<8,8> (bit-identical output; tests run both), restructured because
 // the generic kernel is VALU-bound on gfx950 (profiles/r01/step1_separable_v1.md: 6.7 VALU wave-instructions per
@@ -1368,6 +1473,28 @@ static int get_scratch(size_t bytes, void **out) {
   return LGPU_OK;
 }
 
+// 5x5 binomial blur through k_gauss5x; LGPU_E_UNSUPPORTED when the frames are not 8-byte aligned (or LGPU_G5_CLASSIC
+// asks for the generic separable kernel, for A/B runs)
+static int try_gauss5x(int w, int h, int irow, int orow, int blend, int irow2, uint32_t bf, const int32_t *bf_d, int use_lut,
+                       const SepTracks &t, int ntracks, const Lut8 &l, hipStream_t st) {
+  static const bool classic = getenv("LGPU_G5_CLASSIC") != nullptr;
+  if (classic) return LGPU_E_UNSUPPORTED;
+  if (irow & 7) return LGPU_E_UNSUPPORTED;
+  for (int i = 0; i < ntracks; i++)
+    if (((uintptr_t)t.src[i] & 7) || ((uintptr_t)t.dst[i] & 3) || (blend && ((uintptr_t)t.l2[i] & 3))) return LGPU_E_UNSUPPORTED;
+  if ((orow & 3) || (blend && (irow2 & 3))) return LGPU_E_UNSUPPORTED;
+  G5Args a;
+  a.w = w; a.h = h; a.irow = irow; a.orow = orow; a.irow2 = irow2; a.blend = blend; a.use_lut = use_lut;
+  a.bf = bf & 0xFF; a.nbf = 0xFF - a.bf; a.bf_d = bf_d;
+  a.tiles_x = (w + kG5W - 1) / kG5W;
+  const int tiles_y = (h + kG5H * kG5Sub - 1) / (kG5H * kG5Sub);
+  const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)ntracks);
+  if (blend || use_lut) hipLaunchKernelGGL(k_gauss5x<true>, grid, dim3(256), 0, st, a, t, l);
+  else hipLaunchKernelGGL(k_gauss5x<false>, grid, dim3(256), 0, st, a, t, l);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
 }  // namespace lgpu
 
 using namespace lgpu;
@@ -1433,6 +1560,10 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
   const Lut8 l = pack_lut(nullptr);
   const bool al4 = (((uintptr_t)src_d | (uintptr_t)irow | (uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0;
   if (psize == 4 && al4) {
+    SepTracks tg;
+    tg.src[0] = src_d; tg.l2[0] = nullptr; tg.dst[0] = dst_d;
+    rc = try_gauss5x(width, height, irow, orow, 0, 0, 0, nullptr, 0, tg, 1, l, st);
+    if (rc != LGPU_E_UNSUPPORTED) return rc;
     SepPlan p;
     if ((rc = plan_sep(hb, vb, width, height, irow, width, height, orow, 1, 0, 0, 128, 8, &p))) return rc;
     p.a.src_sel = 0x03020100u; p.a.blend = 0; p.a.irow2 = 0; p.a.bf = 0; p.a.nbf = 255; p.a.bf_d = nullptr; p.a.use_lut = 0;
@@ -1500,6 +1631,9 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   rc = try_half8(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->dw * 4, pr->swap_rb ? 1 : 0, 0, 0, 0, nullptr, 0, t, ntracks, pack_lut(nullptr), st);
   if (rc == LGPU_E_UNSUPPORTED) rc = launch_sep(p1, t, pack_lut(nullptr), st);
   if (rc) return rc;
+  for (int i = 0; i < ntracks; i++) { t.src[i] = (uint8_t *)scratch + per * i; t.l2[i] = tracks[i].layer2_d; t.dst[i] = tracks[i].dst_d; }
+  rc = try_gauss5x(pr->dw, pr->dh, pr->dw * 4, pr->orow, 1, pr->irow2, (uint32_t)pr->bf, pr->param_block_d, pr->use_lut ? 1 : 0, t, ntracks, l, st);
+  if (rc != LGPU_E_UNSUPPORTED) return rc;
   if ((rc = plan_sep(gh, gv, pr->dw, pr->dh, pr->dw * 4, pr->dw, pr->dh, pr->orow, ntracks, 0, 0, 128, 8, &p2))) return rc;
   p2.a.src_sel = 0x03020100u; p2.a.blend = 1; p2.a.irow2 = pr->irow2; p2.a.bf = (uint32_t)pr->bf & 0xFF; p2.a.nbf = 0xFF - p2.a.bf; p2.a.bf_d = pr->param_block_d;
   p2.a.use_lut = pr->use_lut ? 1 : 0;
