@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
 
 // =====================================================================================================================
 // k_gauss5x -- 5x5 binomial blur of RGBA32 frames (the chain's blur stage, BASELINE config 4/5, and lgpu_gauss5).
-// Same arithmetic as k_separable<5,5> with the [1 4 6 4 1] bank (bit-identical; the tests run both): exact row sums,
+// Same arithmetic as k_separable<5,5> with the [1 4 6 4 1] bank (bit-identical; rows that are not 8-byte aligned still take that one): exact row sums,
 // one rounding (sum + 128) >> 8, edge pixels replicated.  Because the taps are 1/4/6 the whole thing fits SWAR: a
 // pixel is split once into its even bytes and its odd bytes (two dwords holding two 16-bit lanes each); a row sum is
 // <= 16 * 255 = 4080 and a column sum of row sums <= 65280, + 128 = 65408 < 2^16, so neither pass can carry across a
