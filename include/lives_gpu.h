@@ -199,6 +199,11 @@ void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
    from the host's random generator and stay on the CPU.) */
 int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
                     int width, int height, int psize, double amount, void *stream);
+/* "slide over": lives-plugins/weed-plugins/slide_over.c:54-146.  amount = the transition parameter 0..255; direction 1..4 as
+   sover_init stores it in "plugin_direction" (:40-51; 0 = random is drawn by the caller, :83-86); slide_lower / slide_upper =
+   the "mlower" / "mupper" switches.  Packed pixels of 3 or 4 bytes, not in place. */
+int lgpu_slide_over(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
+                    int width, int height, int psize, int amount, int direction, int slide_lower, int slide_upper, void *stream);
 /* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
 int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
                 int psize, void *stream);

@@ -136,6 +136,7 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_FILTER_PREF_LINEAR_GAMMA (1 << 3)
 #define WEED_FILTER_HINT_MAY_THREAD (1 << 6)
 #define WEED_CHANNEL_REINIT_ON_SIZE_CHANGE (1 << 0)
+#define WEED_PARAMETER_REINIT_ON_VALUE_CHANGE (1 << 0)   /* libweed/weed-effects.h:134 */
 #define WEED_CHANNEL_CAN_DO_INPLACE (1 << 4)
 #define WEED_ERROR_PLUGIN_INVALID 64
 #define WEED_ERROR_FILTER_INVALID 65
@@ -156,6 +157,7 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_LEAF_VALUE "value"
 #define WEED_LEAF_GAMMA_TYPE "gamma_type"
 #define WEED_LEAF_YUV_CLAMPING "YUV_clamping"
+#define WEED_LEAF_GROUP "group"                       /* libweed/weed-effects.h:391 */
 #define WEED_LEAF_CHOICES "choices"
 #define WEED_LEAF_YUV_SAMPLING "YUV_sampling"
 #define WEED_LEAF_YUV_SUBSPACE "YUV_subspace"

@@ -553,6 +553,33 @@ __global__ __launch_bounds__(kBlock) void k_transition(TransArgs a) {
     }
   }
 }
+
+// slide over (slide_over.c:54-146) as a gather: every output pixel comes from one of the two sources at a shifted position
+struct SlideArgs {
+  const uint8_t *src1, *src2;
+  uint8_t *dst;
+  int irow1, irow2, orow, width, height;
+  int horiz;          // 1: the bound is a column, 0: a row
+  int bound;          // outputs below the bound come from `first`, the rest from the other source
+  int first2;         // the part below the bound shows src2 (directions 2 / 4)
+  int shift_lo, shift_hi;   // coordinate shift applied below / at-or-above the bound
+};
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_slide_over(SlideArgs a) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= a.width) return;
+  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+    const int c = a.horiz ? x : y;
+    const bool lo = c < a.bound;
+    const int sc = lo ? c + a.shift_lo : c - a.bound + a.shift_hi;
+    const int sx = a.horiz ? sc : x, sy = a.horiz ? y : sc;
+    const bool from2 = lo ? a.first2 : !a.first2;
+    const uint8_t *from = from2 ? a.src2 + (size_t)a.irow2 * sy + (size_t)sx * PS : a.src1 + (size_t)a.irow1 * sy + (size_t)sx * PS;
+    uint8_t *d = a.dst + (size_t)a.orow * y + (size_t)x * PS;
+#pragma unroll
+    for (int k = 0; k < PS; k++) d[k] = from[k];
+  }
+}
 }  // namespace lgpu
 
 extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
@@ -582,6 +609,37 @@ extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const
   const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
   if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_slide_over(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
+                               int width, int height, int psize, int amount, int direction, int slide_lower, int slide_upper, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(direction >= 1 && direction <= 4, "direction must be 1..4 (slide_over.c:40-51; the host resolves 0 = random)");
+  LGPU_REQUIRE(src1_d && src2_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(irow1 >= width * psize && irow2 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  LGPU_REQUIRE(amount >= 0 && amount <= 255, "amount is 0..255");
+  LGPU_REQUIRE(dst_d != src1_d && dst_d != src2_d, "slide over is not in place");
+  const int mvl = slide_lower ? 1 : 0, mvu = slide_upper ? 1 : 0;
+  lgpu::SlideArgs a;
+  a.src1 = src1_d; a.src2 = src2_d; a.dst = dst_d; a.irow1 = irow1; a.irow2 = irow2; a.orow = orow; a.width = width; a.height = height;
+  // the reference's float / double mix for the dividing line (:93, :109, :125, :136)
+  switch (direction) {
+  case 3: a.horiz = 0; a.bound = (int)((float)height * (1. - amount / 255.)); a.first2 = 0;
+    a.shift_lo = mvu ? height - a.bound : 0; a.shift_hi = mvl ? 0 : a.bound; break;
+  case 4: a.horiz = 0; a.bound = (int)((float)height * (amount / 255.)); a.first2 = 1;
+    a.shift_lo = mvl ? height - a.bound : 0; a.shift_hi = mvu ? 0 : a.bound; break;
+  case 1: a.horiz = 1; a.bound = (int)((float)width * (1. - amount / 255.)); a.first2 = 0;
+    a.shift_lo = mvu ? width - a.bound : 0; a.shift_hi = mvl ? 0 : a.bound; break;
+  default: a.horiz = 1; a.bound = (int)((float)width * (amount / 255.)); a.first2 = 1;
+    a.shift_lo = mvl ? width - a.bound : 0; a.shift_hi = mvu ? 0 : a.bound; break;
+  }
+  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_slide_over<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(lgpu::k_slide_over<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -20,6 +20,7 @@
 #include <stddef.h>
 #include <string.h>
 #include <stdio.h>
+#include <time.h>
 #include "../../include/lives_gpu_weed_abi.h"
 #include "../../include/lives_gpu.h"
 
@@ -51,7 +52,7 @@ static int psize_of(int pal) {
 }
 
 /* ---- per-instance device buffers ("plugin_internal", like simple_blend.c:36-45) ---- */
-typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; } fxdata_t;
+typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; } fxdata_t;
 
 static fxdata_t *fx_data(weed_plant_t *inst) {
   fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
@@ -179,6 +180,31 @@ static int k_transition(const fxframe_t *f, weed_plant_t *inst, int kind) {
   return lgpu_transition(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
                          pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., NULL);
 }
+/* "slide over" (slide_over.c:40-51, :83-86): direction from the radio parameters 1..5; "random" is drawn once per instance */
+static int param_bool(weed_plant_t *inst, int idx, int dflt) {
+  weed_plant_t *p = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, idx);
+  int32_t v = dflt;
+  if (p) w_get(p, WEED_LEAF_VALUE, 0, &v);
+  return v == WEED_TRUE;
+}
+static int k_slide(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  fxdata_t *fx = fx_data(inst);
+  int dirn;
+  (void)kind;
+  if (!fx) return LGPU_E_NOMEM;
+  if (param_bool(inst, 1, WEED_TRUE)) {
+    if (!fx->slide_dir) {
+      const uint64_t seed = (uint64_t)time(NULL) ^ (uint64_t)(uintptr_t)fx;
+      fx->slide_dir = (int)(((seed * 6364136223846793005ull + 1442695040888963407ull) >> 24) & 3) + 1;
+    }
+    dirn = fx->slide_dir;
+  } else {
+    fx->slide_dir = 0;
+    dirn = param_bool(inst, 2, 0) ? 1 : param_bool(inst, 3, 0) ? 2 : param_bool(inst, 4, 0) ? 3 : 4;
+  }
+  return lgpu_slide_over(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
+                         param_int(inst, 0, 0), dirn, param_bool(inst, 6, WEED_TRUE), param_bool(inst, 7, WEED_FALSE), NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -258,6 +284,7 @@ PROC(p_ckey, 2, 0, k_ckey, 0)
 PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
+PROC(p_slide, 2, 0, k_slide, 1)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -279,6 +306,13 @@ static weed_plant_t *int_param(const char *name, const char *label, int def, int
   s_int(pt, WEED_LEAF_DEFAULT, def); s_int(pt, WEED_LEAF_MIN, mn); s_int(pt, WEED_LEAF_MAX, mx);
   paramtmpl_gui(pt, label);
   if (transition) s_bool(pt, WEED_LEAF_IS_TRANSITION, WEED_TRUE);
+  return pt;
+}
+static weed_plant_t *switch_param(const char *name, const char *label, int def) {   /* weed_switch_init, weed-plugin-utils.c:350-361 */
+  weed_plant_t *pt = w_new(WEED_PLANT_PARAMETER_TEMPLATE);
+  s_str(pt, WEED_LEAF_NAME, name); s_int(pt, WEED_LEAF_PARAM_TYPE, WEED_PARAM_SWITCH);
+  s_bool(pt, WEED_LEAF_DEFAULT, def);
+  paramtmpl_gui(pt, label);
   return pt;
 }
 static weed_plant_t *float_param(const char *name, const char *label, double def, double mn, double mx) {
@@ -334,7 +368,7 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
   static const int32_t packed[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32,
                                    WEED_PALETTE_YUV888, WEED_PALETTE_YUVA8888, WEED_PALETTE_UYVY, WEED_PALETTE_YUYV};
   weed_default_getter_f dget;
-  weed_plant_t *host_info, *pinfo = NULL, *p[3];
+  weed_plant_t *host_info, *pinfo = NULL, *p[8];
   int32_t filter_api = 0;
   int i;
   if (!weed_boot) return NULL;
@@ -406,6 +440,27 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
         if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
       }
     }
+  }
+  /* slide_over.c:148-196: "slide over": integer transition parameter, five direction radios (group 1, REINIT_ON_VALUE_CHANGE),
+     two switches; out channel not in place; packed palettes of 3 / 4 bytes */
+  {
+    static const int32_t pk[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32,
+                                 WEED_PALETTE_YUV888, WEED_PALETTE_YUVA8888, WEED_PALETTE_UYVY, WEED_PALETTE_YUYV};   /* macropixels of 4 bytes */
+    static const char *rn[] = {"dir_rand", "dir_r2l", "dir_l2r", "dir_b2t", "dir_t2b"},
+                      *rl[] = {"_Random", "_Right to left", "_Left to right", "_Bottom to top", "_Top to bottom"};
+    weed_plant_t *fc = NULL, *oct = NULL;
+    p[0] = int_param("amount", "Transition _value", 0, 0, 255, 1);
+    for (i = 0; i < 5; i++) {
+      p[1 + i] = switch_param(rn[i], rl[i], i == 0 ? WEED_TRUE : WEED_FALSE);
+      s_int(p[1 + i], WEED_LEAF_GROUP, 1);
+      s_int(p[1 + i], WEED_LEAF_FLAGS, WEED_PARAMETER_REINIT_ON_VALUE_CHANGE);
+    }
+    p[6] = switch_param("mlower", "_Slide lower clip", WEED_TRUE);
+    p[7] = switch_param("mupper", "_Slide upper clip", WEED_FALSE);
+    add_filter(pinfo, "slide over", 0, pk, 9, p_slide, 2, "in channel 0", "in channel 1", "out channel 0", p, 8);
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct);
+    if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

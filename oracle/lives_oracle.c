@@ -804,6 +804,54 @@ int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], i
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * F8: slide over                          reference: lives-plugins/weed-plugins/slide_over.c:54-146
+ * dirn 1 "left to right" .. 4 "bottom to top" (the value sover_init stores in "plugin_direction", :40-51; 0 = random is
+ * resolved by the host side); bound = the dividing line, computed in the reference's float / double mix.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_slide_over(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height,
+                    int psize, int transval, int dirn, int mvlower, int mvupper) {
+  int bound, j;
+  mvlower = !!mvlower; mvupper = !!mvupper;
+  switch (dirn) {
+  case 3:
+    bound = (float)height * (1. - transval / 255.);                                         /* :93 */
+    if (mvupper) src1 += (size_t)irow1 * (height - bound);
+    for (j = 0; j < bound; j++) {
+      memcpy(dst, src1, (size_t)width * psize);
+      src1 += irow1;
+      if (!mvlower) src2 += irow2;
+      dst += orow;
+    }
+    for (j = bound; j < height; j++) { memcpy(dst, src2, (size_t)width * psize); src2 += irow2; dst += orow; }
+    break;
+  case 4:
+    bound = (float)height * (transval / 255.);                                              /* :109 */
+    if (mvlower) src2 += (size_t)irow2 * (height - bound);
+    if (!mvupper) src1 += (size_t)irow1 * bound;
+    for (j = 0; j < bound; j++) { memcpy(dst, src2, (size_t)width * psize); src2 += irow2; dst += orow; }
+    for (j = bound; j < height; j++) { memcpy(dst, src1, (size_t)width * psize); src1 += irow1; dst += orow; }
+    break;
+  case 1:
+    bound = (float)width * (1. - transval / 255.);                                          /* :125 */
+    for (j = 0; j < height; j++) {
+      memcpy(dst, src1 + (size_t)(width - bound) * psize * mvupper, (size_t)bound * psize);
+      memcpy(dst + (size_t)bound * psize, src2 + (size_t)bound * psize * !mvlower, (size_t)(width - bound) * psize);
+      src1 += irow1; src2 += irow2; dst += orow;
+    }
+    break;
+  case 2:
+    bound = (float)width * (transval / 255.);                                               /* :136 */
+    for (j = 0; j < height; j++) {
+      memcpy(dst, src2 + (size_t)(width - bound) * psize * mvlower, (size_t)bound * psize);
+      memcpy(dst + (size_t)bound * psize, src1 + (size_t)!mvupper * bound * psize, (size_t)(width - bound) * psize);
+      src1 += irow1; src2 += irow2; dst += orow;
+    }
+    break;
+  default: break;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * F7: geometric transitions             reference: lives-plugins/weed-plugins/multi_transitions.c:86-233
  * ---------------------------------------------------------------------------------------------- */
 void orc_transition(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow,

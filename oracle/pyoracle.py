@@ -92,6 +92,7 @@ def oracle():
         _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
         _O.orc_cavg.argtypes = [ci, ci, ci]
         _O.orc_transition.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd]
+        _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]
         _O.orc_blurzoom_new.restype = vp
@@ -145,6 +146,10 @@ def p_int(v):
 
 def p_double(v):
     p = RefParam(); p.kind = 1; p.dval = float(v); return p
+
+
+def p_bool(v):
+    p = RefParam(); p.kind = 3; p.ival[0] = 1 if v else 0; return p
 
 
 def p_rgb(r, g, b):

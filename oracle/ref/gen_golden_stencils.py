@@ -75,8 +75,27 @@ def main():
                 tnames.append(key)
     tr["records"] = np.array(tnames)
     np.savez_compressed(os.path.join(OUT, "transitions.npz"), **tr)
+    # slide over (slide_over.c): direction through the radio parameters 1..5 as sover_init reads them (:40-51)
+    so, snames = {}, []
+    for dirn in (1, 2, 3, 4):
+        for pal, ps in ((1, 3), (4, 4)):
+            for tv in (0, 77, 200, 255):
+                for mvl, mvu in ((1, 0), (0, 1), (1, 1), (0, 0)):
+                    w, h = 23, 13
+                    s1, s2 = po.make_frame(rng, w, h, ps), po.make_frame(rng, w, h, ps)
+                    d = np.full_like(s1, 0x5A)
+                    radios = [po.p_bool(False)] + [po.p_bool(dirn == k) for k in (1, 2, 3)] + [po.p_bool(False)]
+                    H.run(po.refplugin("slide_over"), "slide over", pal, w, h, [s1, s2], d,
+                          [po.p_int(tv)] + radios + [po.p_bool(mvl), po.p_bool(mvu)])
+                    key = "so|%d|%d|%d|%d|%d|%d|%d" % (dirn, pal, tv, mvl, mvu, w, h)
+                    so[key + "|a"], so[key + "|b"], so[key + "|o"] = s1, s2, d
+                    snames.append(key)
+    so["records"] = np.array(snames)
+    np.savez_compressed(os.path.join(OUT, "slide_over.npz"), **so)
     mpath = os.path.join(OUT, "manifest.json")
     man = json.load(open(mpath))
+    man["groups"]["slide_over.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/slide_over.c; record "
+                                       "so|direction(1..4 as sover_init stores it)|palette|amount|slide lower|slide upper|w|h; a / b sources, o result")
     man["groups"]["stencils.npz"] = ("reference plugins built unmodified: lives-plugins/weed-plugins/softlight.c (sl|palette|w|h|clamping(0 clamped,1 unclamped), "
                                      "planes i<k>/o<k>), edge.c (ed|palette|mode|inplace|w|h; a = source, d = destination before, o = after); one process_func call")
     man["groups"]["transitions.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/multi_transitions.c, filters iris rectangle (0), "

@@ -255,3 +255,14 @@ def test_transitions_vs_reference_plugin(gpu):
         gpu.transition(t, dev(g[rec + "|a"]), dev(g[rec + "|b"]), d, w, h, ps, amt)
         assert (host(d)[:, :w * ps] == want[:, :w * ps]).all(), rec
 
+
+
+def test_slide_over_vs_reference_plugin(gpu):
+    g = gu.load("slide_over.npz")
+    for rec in map(str, g["records"]):
+        _, dirn, pal, tv, mvl, mvu, w, h = rec.split("|")
+        w, h, ps = int(w), int(h), (3 if int(pal) <= 2 else 4)
+        want = g[rec + "|o"]
+        d = dev(np.full_like(want, 0x5A))
+        gpu.slide_over(dev(g[rec + "|a"]), dev(g[rec + "|b"]), d, w, h, ps, int(tv), int(dirn), int(mvl), int(mvu))
+        assert (host(d)[:, :w * ps] == want[:, :w * ps]).all(), rec

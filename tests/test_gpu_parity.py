@@ -382,6 +382,21 @@ def test_transition(gpu, orc, kind, psize):
                 assert_same(host(d), want, w, h, psize, "transition %d ps=%d %dx%d amount=%s inplace=%d" % (kind, psize, w, h, amt, inplace))
 
 
+@pytest.mark.parametrize("psize", [3, 4])
+def test_slide_over(gpu, orc, psize):
+    rng = np.random.default_rng(2500 + psize)
+    for (w, h) in [(20, 10), (33, 17), (300, 50), (5, 3)]:
+        for dirn in (1, 2, 3, 4):
+            for tv in (0, 1, 60, 128, 254, 255):
+                for mvl, mvu in ((1, 0), (0, 1), (1, 1), (0, 0)):
+                    s1, s2 = frame(rng, w, h, psize), frame(rng, w, h, psize)
+                    want = np.full_like(s1, 0x5A)
+                    orc.orc_slide_over(P(s1), s1.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, psize, tv, dirn, mvl, mvu)
+                    d = dev(np.full_like(s1, 0x5A))
+                    gpu.slide_over(dev(s1), dev(s2), d, w, h, psize, tv, dirn, mvl, mvu)
+                    assert_same(host(d), want, w, h, psize, "slide over ps=%d %dx%d dir=%d amount=%d lower=%d upper=%d" % (psize, w, h, dirn, tv, mvl, mvu))
+
+
 # ---------------------------------------------------------------------------------------------- K5 clamping switch
 @pytest.mark.parametrize("palette", [588, 589, 544, 545, 522, 512, 513, 564, 565])
 def test_yuv_switch_clamping(gpu, orc, palette):

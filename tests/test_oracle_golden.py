@@ -292,3 +292,14 @@ def test_transitions(orc):
         orc.orc_transition(t, P(a), a.strides[0], P(b), b.strides[0], P(got), got.strides[0], w, h, ps, amt)
         assert (got[:, :w * ps] == want[:, :w * ps]).all(), rec
 
+
+
+def test_slide_over(orc):
+    g = gu.load("slide_over.npz")
+    for rec in map(str, g["records"]):
+        _, dirn, pal, tv, mvl, mvu, w, h = rec.split("|")
+        w, h, ps = int(w), int(h), (3 if int(pal) <= 2 else 4)
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        got = np.full_like(a, 0x5A)
+        orc.orc_slide_over(P(a), a.strides[0], P(b), b.strides[0], P(got), got.strides[0], w, h, ps, int(tv), int(dirn), int(mvl), int(mvu))
+        assert (got[:, :w * ps] == want[:, :w * ps]).all(), rec

@@ -22,8 +22,8 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 22
-    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom"):
+    assert len(ours) == 23
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
@@ -160,3 +160,18 @@ def test_transition_records_through_the_plugin():
         H.run(OURS, names[t], pal, w, h, [g[rec + "|a"].copy(), g[rec + "|b"].copy()], d, [po.p_double(amt)])
         assert (d[:, :w * PSIZE[pal]] == g[rec + "|o"][:, :w * PSIZE[pal]]).all(), rec
 
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_slide_over_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("slide_over.npz")
+    for rec in map(str, g["records"]):
+        _, dirn, pal, tv, mvl, mvu, w, h = rec.split("|")
+        dirn, pal, w, h = int(dirn), int(pal), int(w), int(h)
+        d = np.full_like(g[rec + "|o"], 0x5A)
+        radios = [po.p_bool(False)] + [po.p_bool(dirn == k) for k in (1, 2, 3)] + [po.p_bool(False)]
+        H.run(OURS, "slide over", pal, w, h, [g[rec + "|a"].copy(), g[rec + "|b"].copy()], d,
+              [po.p_int(int(tv))] + radios + [po.p_bool(int(mvl)), po.p_bool(int(mvu))])
+        assert (d[:, :w * PSIZE[pal]] == g[rec + "|o"][:, :w * PSIZE[pal]]).all(), rec
