@@ -168,6 +168,16 @@ int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width,
    Y,U,V stream over the whole buffer, so byte roles follow the buffer offset mod 3). */
 int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4], int palette, int height, int to_unclamped,
                              void *stream);
+/* K5b: YUV -> YUV repacks, the non-RGB half of convert_layer_palette_full's matrix (src/colourspace.c:12937-13750 dispatches
+   to :7104-7198, :7500-7753, :7800-7971, :9198-9257, :10517-10639 and the K1 addpost / delpost pair).  Palettes are
+   WEED_PALETTE_* numbers, width in pixels.  Taken: 444P / 4444P -> 888 / 8888 / 4444P / 444P / 420P / (compact rows) UYVY / YUYV;
+   888 -> 444P / 8888; 8888 -> 888; 420P -> 422P / (compact chroma) UYVY / YUYV; UYVY <-> YUYV; UYVY / YUYV -> 444P / 4444P
+   (equal plane strides) / 888 / 8888 / (compact rows) 420P.  LGPU_E_UNSUPPORTED for every other pair or layout: there the
+   reference function overruns its buffers, mixes up its strides or leaves a result that depends on what the destination
+   held before (DESIGN.md "YUV -> YUV"), and the caller keeps its CPU body.  Bytes the reference does not write are not
+   written.  clamping_unclamped picks the chroma averaging table (init_average :190-216). */
+int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4],
+                    const int orow[4], int width, int height, int clamping_unclamped, int sampling_jpeg, void *stream);
 /* "softlight": lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV (palette 544 YUV444P, 545 YUVA4444P,
    522 YUV422P, 512 YUV420P, 513 YVU420P): gradient-magnitude highlight mixed into plane 0 (frame border copied), the
    other planes are copied.  unclamped != 0: luma range 0..255, else 16..235 (the channel's YUV_clamping leaf).

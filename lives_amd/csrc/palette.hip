@@ -227,6 +227,143 @@ __global__ __launch_bounds__(kBlock) void k_clamp_switch(ClampPlanes cp, int per
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K5b: YUV -> YUV repacks (src/colourspace.c:7104-7198, :7500-7753, :7800-7971, :9198-9257, :10517-10639).  One thread per
+// 4:2:2 macropixel (two horizontally adjacent pixels) of one row, or per 2 x 2 block when the destination is 4:2:0: every
+// output byte is a gather of at most four source bytes, so the reference's serial "write, then average with what is there"
+// walks reduce to closed forms.  These are byte-granular layouts of 1-3 bytes per sample; the launches are bounded by the
+// launch floor at the sizes LiVES uses them (one 1080p frame), not by HBM.
+// ---------------------------------------------------------------------------------------------------------------------
+enum RepackKind {
+  RK_COMBINE, RK_SPLIT, RK_COPY444, RK_SWAB, RK_420_TO_PK, RK_420_TO_422P, RK_444_TO_420, RK_444_TO_PK, RK_PK_TO_444, RK_PK_TO_888,
+  RK_PK_TO_420
+};
+struct RepackArgs {
+  const uint8_t *src[4];
+  uint8_t *dst[4];
+  int irow[4], orow[4];
+  int width, height, kind;
+  int in_alpha, out_alpha;   // RK_COMBINE / RK_COPY444 / RK_PK_TO_444 / RK_PK_TO_888
+  int yuyv_in, yuyv_out;     // byte order of a packed 4:2:2 source / destination
+  int clamped;               // which averaging table (init_average, :190-216)
+  int copy_w;                // bytes per row of the plain plane copies: the width, or the whole rowstride where the reference memcpy()s the plane
+};
+
+__global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
+  const int mx = blockIdx.x * kBlock + threadIdx.x;         // macropixel column
+  const int mw = ((a.copy_w > a.width ? a.copy_w : a.width) + 1) >> 1;
+  if (mx >= mw) return;
+  const int x0 = 2 * mx;
+  if (x0 >= a.width && a.kind != RK_COPY444 && a.kind != RK_444_TO_420) return;
+  const bool two = x0 + 1 < a.width;                         // odd widths: the last column is a single pixel where the reference allows it
+  const int rows = (a.kind == RK_444_TO_420 || a.kind == RK_PK_TO_420) ? (a.height + 1) >> 1 : a.height;
+  for (int y = blockIdx.y; y < rows; y += gridDim.y) {
+    switch (a.kind) {
+    case RK_COMBINE: {
+      const int ops = a.out_alpha ? 4 : 3;
+      uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)x0 * ops;
+      for (int k = 0; k < (two ? 2 : 1); k++) {
+        const size_t si = (size_t)y * a.irow[0] + x0 + k;
+        d[k * ops] = a.src[0][si]; d[k * ops + 1] = a.src[1][si]; d[k * ops + 2] = a.src[2][si];
+        if (a.out_alpha) d[k * ops + 3] = a.in_alpha ? a.src[3][(size_t)y * a.width + x0 + k] : 255;   // alpha plane walked as compact (:7634-7638)
+      }
+      break;
+    }
+    case RK_SPLIT: {
+      const uint8_t *s = a.src[0] + (size_t)y * a.irow[0] + (size_t)x0 * 3;
+      for (int k = 0; k < (two ? 2 : 1); k++)
+        for (int p = 0; p < 3; p++) a.dst[p][(size_t)y * a.orow[p] + x0 + k] = s[3 * k + p];
+      break;
+    }
+    case RK_COPY444: {
+      for (int k = 0; k < 2; k++)
+        if (x0 + k < a.copy_w)
+          for (int p = 0; p < 3; p++) a.dst[p][(size_t)y * a.orow[0] + x0 + k] = a.src[p][(size_t)y * a.irow[0] + x0 + k];
+      break;
+    }
+    case RK_SWAB: {
+      const uint8_t *s = a.src[0] + (size_t)y * a.irow[0] + 4 * (size_t)mx;
+      uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + 4 * (size_t)mx;
+      const uint8_t b0 = s[0], b1 = s[1], b2 = s[2], b3 = s[3];
+      d[0] = b1; d[1] = b0; d[2] = b3; d[3] = b2;
+      break;
+    }
+    case RK_420_TO_PK: {
+      const uint8_t *sy = a.src[0] + (size_t)y * a.irow[0] + x0;
+      const uint8_t u = a.src[1][(size_t)(y >> 1) * a.irow[1] + mx], v = a.src[2][(size_t)(y >> 1) * a.irow[2] + mx];
+      uint8_t *d = a.dst[0] + (size_t)y * (size_t)((a.orow[0] / 4) * 4) + 4 * (size_t)mx;
+      if (a.yuyv_out) { d[0] = sy[0]; d[1] = u; d[2] = sy[1]; d[3] = v; }
+      else { d[0] = u; d[1] = sy[0]; d[2] = v; d[3] = sy[1]; }
+      break;
+    }
+    case RK_420_TO_422P: {
+      a.dst[0][(size_t)y * a.orow[0] + x0] = a.src[0][(size_t)y * a.irow[0] + x0];
+      if (two) a.dst[0][(size_t)y * a.orow[0] + x0 + 1] = a.src[0][(size_t)y * a.irow[0] + x0 + 1];
+      const int ch2 = (a.height >> 1) * 2;
+      if (y < ch2 && mx < (a.width >> 1)) {
+        for (int p = 1; p < 3; p++) {
+          int c = a.src[p][(size_t)(y >> 1) * a.irow[p] + mx];
+          if ((y & 1) && y + 1 < ch2) c = cavg(a.clamped, c, a.src[p][(size_t)((y + 1) >> 1) * a.irow[p] + mx]);
+          a.dst[p][(size_t)y * a.orow[p] + mx] = (uint8_t)c;
+        }
+      }
+      break;
+    }
+    case RK_444_TO_420: {
+      for (int r = 2 * y; r < 2 * y + 2 && r < a.height; r++)
+        for (int k = 0; k < 2; k++)
+          if (x0 + k < a.copy_w) a.dst[0][(size_t)r * a.orow[0] + x0 + k] = a.src[0][(size_t)r * a.irow[0] + x0 + k];
+      if (mx < (a.width >> 1)) {
+        for (int p = 1; p < 3; p++) {
+          const uint8_t *s0 = a.src[p] + (size_t)(2 * y) * a.irow[p] + x0;
+          int c = cavg(a.clamped, s0[0], s0[1]);
+          if (2 * y + 1 < a.height) c = cavg(a.clamped, c, cavg(a.clamped, s0[a.irow[p]], s0[a.irow[p] + 1]));
+          a.dst[p][(size_t)y * a.orow[p] + mx] = (uint8_t)c;
+        }
+      }
+      break;
+    }
+    case RK_444_TO_PK: {                                       // compact source and destination (checked by the caller)
+      const size_t si = (size_t)y * a.width + x0;
+      uint8_t *d = a.dst[0] + (size_t)y * a.width * 2 + 4 * (size_t)mx;
+      const uint8_t u = (uint8_t)cavg(a.clamped, a.src[1][si], a.src[1][si + 1]), v = (uint8_t)cavg(a.clamped, a.src[2][si], a.src[2][si + 1]);
+      if (a.yuyv_out) { d[0] = a.src[0][si]; d[1] = u; d[2] = a.src[0][si + 1]; d[3] = v; }
+      else { d[0] = u; d[1] = a.src[0][si]; d[2] = v; d[3] = a.src[0][si + 1]; }
+      break;
+    }
+    case RK_PK_TO_444: case RK_PK_TO_888: case RK_PK_TO_420: {
+      const int yo = a.yuyv_in ? 0 : 1, uo = a.yuyv_in ? 1 : 0, vo = a.yuyv_in ? 3 : 2;
+      const size_t irm = (size_t)((a.irow[0] / 4) * 4);
+      if (a.kind == RK_PK_TO_444) {
+        const uint8_t *m = a.src[0] + (size_t)y * irm + 4 * (size_t)mx;
+        const size_t di = (size_t)y * a.orow[0] + x0;
+        a.dst[0][di] = m[yo]; a.dst[0][di + 1] = m[yo + 2];
+        a.dst[1][di] = a.dst[1][di + 1] = m[uo];
+        a.dst[2][di] = a.dst[2][di + 1] = m[vo];
+      } else if (a.kind == RK_PK_TO_888) {
+        const uint8_t *m = a.src[0] + (size_t)y * irm + 4 * (size_t)mx;
+        const int ops = a.out_alpha ? 4 : 3;
+        uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)x0 * ops;
+        d[0] = m[yo]; d[1] = m[uo]; d[2] = m[vo];
+        d[ops] = m[yo + 2]; d[ops + 1] = m[uo]; d[ops + 2] = m[vo];
+        if (a.out_alpha) d[3] = d[ops + 3] = 255;
+      } else {
+        const uint8_t *m0 = a.src[0] + (size_t)(2 * y) * irm + 4 * (size_t)mx;
+        int u = m0[uo], v = m0[vo];
+        a.dst[0][(size_t)(2 * y) * a.width + x0] = m0[yo]; a.dst[0][(size_t)(2 * y) * a.width + x0 + 1] = m0[yo + 2];
+        if (2 * y + 1 < a.height) {
+          const uint8_t *m1 = m0 + irm;
+          a.dst[0][(size_t)(2 * y + 1) * a.width + x0] = m1[yo]; a.dst[0][(size_t)(2 * y + 1) * a.width + x0 + 1] = m1[yo + 2];
+          u = cavg(a.clamped, u, m1[uo]); v = cavg(a.clamped, v, m1[vo]);
+        }
+        a.dst[1][(size_t)y * (a.width >> 1) + mx] = (uint8_t)u; a.dst[2][(size_t)y * (a.width >> 1) + mx] = (uint8_t)v;
+      }
+      break;
+    }
+    }
+  }
+}
 }  // namespace lgpu
 
 using namespace lgpu;
@@ -352,3 +489,83 @@ extern "C" int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int ro
   return LGPU_OK;
 }
 
+
+static int unsupported(const char *why) { lgpu::set_error("lgpu_yuv_repack: %s", why); return LGPU_E_UNSUPPORTED; }
+
+extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4],
+                               const int orow[4], int width, int height, int clamping_unclamped, int sampling_jpeg, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  (void)sampling_jpeg;
+  enum { P_420 = 512, P_YV12 = 513, P_422 = 522, P_444 = 544, P_4444 = 545, P_UYVY = 564, P_YUYV = 565, P_888 = 588, P_8888 = 589 };
+  LGPU_REQUIRE(src_d && dst_d && irow && orow && width > 0 && height > 0, "null plane tables or empty geometry");
+  LGPU_REQUIRE(src_d[0] && dst_d[0], "null plane");
+  const bool in444 = (in_pal == P_444 || in_pal == P_4444), in420 = (in_pal == P_420 || in_pal == P_YV12);
+  const bool inpk = (in_pal == P_UYVY || in_pal == P_YUYV), outpk = (out_pal == P_UYVY || out_pal == P_YUYV);
+  hipStream_t st = (hipStream_t)stream;
+  // the K1 pair: convert_addpost_frame / convert_delpost_frame
+  if (in_pal == P_888 && out_pal == P_8888) return lgpu_swizzle(LGPU_ADDPOST, 0, src_d[0], irow[0], dst_d[0], orow[0], width, height, nullptr, stream);
+  if (in_pal == P_8888 && out_pal == P_888) return lgpu_swizzle(LGPU_DELPOST, 0, src_d[0], irow[0], dst_d[0], orow[0], width, height, nullptr, stream);
+  lgpu::RepackArgs a = {};
+  a.width = width; a.height = height; a.clamped = clamping_unclamped ? 0 : 1;
+  a.yuyv_in = (in_pal == P_YUYV); a.yuyv_out = (out_pal == P_YUYV);
+  int nin = 1, nout = 1;
+  if (in444 && (out_pal == P_888 || out_pal == P_8888)) {
+    a.kind = lgpu::RK_COMBINE; a.in_alpha = (in_pal == P_4444); a.out_alpha = (out_pal == P_8888); nin = a.in_alpha ? 4 : 3;
+  } else if (in_pal == P_888 && out_pal == P_444) {
+    a.kind = lgpu::RK_SPLIT; nout = 3;
+  } else if (in444 && (out_pal == P_444 || out_pal == P_4444) && in_pal != out_pal) {
+    a.kind = lgpu::RK_COPY444; a.out_alpha = (out_pal == P_4444); nin = 3; nout = a.out_alpha ? 4 : 3;
+    a.copy_w = (orow[0] == irow[0]) ? irow[0] : width;                     // :7658-7663 copies whole planes when the strides agree
+  } else if (inpk && outpk && in_pal != out_pal) {
+    if (width & 1) return unsupported("packed 4:2:2 needs an even width");
+    a.kind = lgpu::RK_SWAB;
+  } else if (in420 && outpk) {
+    // convert_yuv420_to_uyvy_frame steps its chroma pointers back by the rowstride (:7143-7146): compact chroma planes only
+    if (irow[1] != (width >> 1) || irow[2] != (width >> 1) || ((width | height) & 1)) return unsupported("4:2:0 -> packed 4:2:2 needs compact chroma planes and even dimensions (colourspace.c:7143)");
+    a.kind = lgpu::RK_420_TO_PK; nin = 3;
+  } else if (in420 && out_pal == P_422) {
+    if ((width | height) & 1) return unsupported("a 4:2:0 source has even width and height");
+    a.kind = lgpu::RK_420_TO_422P; nin = 3; nout = 3;
+  } else if (in444 && (out_pal == P_420 || out_pal == P_YV12)) {
+    // 4:2:0 layers have even dimensions (create_empty_pixel_data :11601-11603); with an odd one the reference writes past the planes
+    if ((width | height) & 1) return unsupported("a 4:2:0 destination needs even width and height");
+    a.kind = lgpu::RK_444_TO_420; nin = 3; nout = 3;
+    a.copy_w = (orow[0] == irow[0]) ? irow[0] : width;                     // :7711-7712
+  } else if (in444 && outpk) {
+    // only the compact branch of convert_yuv_planar_to_uyvy_frame stays inside its buffers (:7512-7524 vs :7526-7543)
+    if (irow[0] != width || orow[0] != width * 2 || (width & 1)) return unsupported("4:4:4 planar -> packed 4:2:2 needs compact rows and an even width (colourspace.c:7526)");
+    a.kind = lgpu::RK_444_TO_PK; nin = 3;
+  } else if (inpk && (out_pal == P_444 || out_pal == P_4444)) {
+    if (width & 1) return unsupported("packed 4:2:2 needs an even width");
+    if (orow[0] != orow[1] || orow[0] != orow[2]) return unsupported("packed 4:2:2 -> planar needs equal plane rowstrides (colourspace.c:7813-7816 mixes them)");
+    a.kind = lgpu::RK_PK_TO_444; nout = 3;
+  } else if (inpk && (out_pal == P_888 || out_pal == P_8888)) {
+    if (width & 1) return unsupported("packed 4:2:2 needs an even width");
+    a.kind = lgpu::RK_PK_TO_888; a.out_alpha = (out_pal == P_8888);
+  } else if (inpk && (out_pal == P_420 || out_pal == P_YV12)) {
+    if (((width | height) & 1) || irow[0] != width * 2 || orow[0] != width || orow[1] != (width >> 1) || orow[2] != (width >> 1))
+      return unsupported("packed 4:2:2 -> 4:2:0 needs compact rows on both sides (colourspace.c:7887-7927 has no strides)");
+    a.kind = lgpu::RK_PK_TO_420; nout = 3;
+  } else {
+    return unsupported("this YUV -> YUV pair is not taken (the reference function overruns, or depends on the destination's previous contents)");
+  }
+  for (int i = 0; i < nin; i++) { LGPU_REQUIRE(src_d[i], "null source plane"); a.src[i] = src_d[i]; a.irow[i] = irow[i]; }
+  for (int i = 0; i < nout; i++) { LGPU_REQUIRE(dst_d[i], "null destination plane"); a.dst[i] = dst_d[i]; a.orow[i] = orow[i]; }
+  if (a.kind == lgpu::RK_COPY444 && a.out_alpha) {
+    LGPU_REQUIRE(dst_d[3], "null alpha plane");
+    a.dst[3] = dst_d[3];
+    // memset(dest[3], 255, orowstride * height) (:7686): padding included
+    if ((rc = lgpu_fill(dst_d[3], 255, (size_t)orow[0] * height, stream))) return rc;
+  }
+  if (a.kind == lgpu::RK_PK_TO_444 && out_pal == P_4444) {
+    LGPU_REQUIRE(dst_d[3], "null alpha plane");
+    if ((rc = lgpu_fill(dst_d[3], 255, (size_t)orow[3] * height, stream))) return rc;                 // :7819
+  }
+  const int rows = (a.kind == lgpu::RK_444_TO_420 || a.kind == lgpu::RK_PK_TO_420) ? (height + 1) >> 1 : height;
+  const int span = a.copy_w > width ? a.copy_w : width;
+  const dim3 grid(cdiv((unsigned)((span + 1) >> 1), kBlock), (unsigned)(rows < 2048 ? rows : 2048));
+  hipLaunchKernelGGL(lgpu::k_yuv_repack, grid, dim3(kBlock), 0, st, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

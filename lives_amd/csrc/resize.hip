@@ -1663,7 +1663,7 @@ extern "C" int lgpu_chain_timed(const lgpu_chain_params *params, const lgpu_chai
   LGPU_HIP(hipEventRecord(e1, st));
   LGPU_HIP(hipEventSynchronize(e1));
   LGPU_HIP(hipEventElapsedTime(ms_total, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return rc;
 }

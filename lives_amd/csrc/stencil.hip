@@ -372,7 +372,7 @@ struct lgpu_blurzoom {
 
 extern "C" void lgpu_blurzoom_destroy(lgpu_blurzoom *z) {
   if (!z) return;
-  hipFree(z->bg); hipFree(z->buf); hipFree(z->snap); hipFree(z->pal); hipFree(z->rowstart); hipFree(z->colcum);
+  (void)hipFree(z->bg); (void)hipFree(z->buf); (void)hipFree(z->snap); (void)hipFree(z->pal); (void)hipFree(z->rowstart); (void)hipFree(z->colcum);
   delete z;
 }
 

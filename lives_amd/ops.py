@@ -143,6 +143,15 @@ def yuv_switch_clamping(planes, palette, height, to_unclamped):
     lib.call("lgpu_yuv_switch_clamping", ctypes.addressof(pp), ctypes.addressof(ss), palette, height, int(to_unclamped), stream_ptr())
 
 
+def yuv_repack(in_pal, out_pal, src_planes, dst_planes, width, height, unclamped=False, sampling_jpeg=False):
+    """YUV -> YUV repack (colourspace.c K5b); palettes are WEED_PALETTE_* numbers; raises LgpuError (LGPU_E_UNSUPPORTED) for pairs
+    the library does not take"""
+    sp, ss = _plane_tables(src_planes)
+    dp, ds = _plane_tables(dst_planes)
+    lib.call("lgpu_yuv_repack", in_pal, out_pal, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(dp), ctypes.addressof(ds),
+             width, height, int(bool(unclamped)), int(bool(sampling_jpeg)), stream_ptr())
+
+
 def softlight(src_planes, dst_planes, width, height, palette, unclamped):
     """planar YUV softlight (softlight.c): src_planes / dst_planes are lists of 2-D uint8 device tensors, one per plane"""
     n = len(src_planes)

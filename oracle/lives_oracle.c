@@ -1346,3 +1346,199 @@ out:
   free(conv); free(rs); free(bl);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * K5b: YUV -> YUV repacks                 reference: src/colourspace.c, the functions cited per case
+ * Palettes are the WEED_PALETTE_* numbers; width is in PIXELS (the reference's dispatcher passes pixels, and macropixels for a
+ * UYVY / YUYV source, :13130-13330).  Returns 0, or -1 for a pair / layout this restatement does not take: the reference
+ * function for it overruns its buffers, mixes up strides or leaves the result depending on the destination's previous
+ * contents (list in DESIGN.md "YUV -> YUV").  Bytes the reference does not write are not written here either.
+ * ---------------------------------------------------------------------------------------------- */
+enum { P_420 = 512, P_YV12 = 513, P_422 = 522, P_444 = 544, P_4444 = 545, P_UYVY = 564, P_YUYV = 565, P_888 = 588, P_8888 = 589 };
+
+static void copy_rows(const uint8_t *s, int irow, uint8_t *d, int orow, int nbytes, int rows) {
+  if (s == d) return;
+  for (int y = 0; y < rows; y++) memcpy(d + (size_t)y * orow, s + (size_t)y * irow, (size_t)nbytes);
+}
+
+int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const int irow[4], uint8_t *const dst[4], const int orow[4],
+                   int width, int height, int clamping_unclamped, int sampling_jpeg) {
+  const int cl = !clamping_unclamped;               /* set_conversion_arrays(clamping, YCBCR): cavg = cavgc when clamped */
+  const int in444 = (in_pal == P_444 || in_pal == P_4444), in420 = (in_pal == P_420 || in_pal == P_YV12);
+  const int inpk422 = (in_pal == P_UYVY || in_pal == P_YUYV);
+  if (width < 1 || height < 1) return -1;
+  (void)sampling_jpeg;
+
+  /* convert_combineplanes_frame :7593-7641 -- both of its branches write the same bytes */
+  if (in444 && (out_pal == P_888 || out_pal == P_8888)) {
+    const int ops = out_pal == P_8888 ? 4 : 3;
+    for (int y = 0; y < height; y++) {
+      uint8_t *d = dst[0] + (size_t)y * orow[0];
+      for (int x = 0; x < width; x++) {
+        d[x * ops + 0] = src[0][(size_t)y * irow[0] + x];
+        d[x * ops + 1] = src[1][(size_t)y * irow[0] + x];            /* one irowstride for all planes (:7624-7640) */
+        d[x * ops + 2] = src[2][(size_t)y * irow[0] + x];
+        /* the alpha pointer is never moved past the row padding (:7634-7638): the plane is walked as if it were compact */
+        if (ops == 4) d[x * ops + 3] = in_pal == P_4444 ? src[3][(size_t)y * width + x] : 255;
+      }
+    }
+    return 0;
+  }
+  /* convert_splitplanes_frame :9198-9257 -- only 888 -> 444P: with a source or destination alpha the strided branch
+     walks the alpha plane / the source with the wrong step (:9229-9233, :9236-9243) */
+  if (in_pal == P_888 && out_pal == P_444) {
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++)
+        for (int p = 0; p < 3; p++) dst[p][(size_t)y * orow[p] + x] = src[0][(size_t)y * irow[0] + x * 3 + p];
+    return 0;
+  }
+  /* convert_yuvap_to_yuvp_frame / convert_yuvp_to_yuvap_frame :7643-7688 (one rowstride in, one out) */
+  if (in444 && (out_pal == P_444 || out_pal == P_4444) && in_pal != out_pal) {
+    for (int p = 0; p < 3; p++) copy_rows(src[p], irow[0], dst[p], orow[0], orow[0] == irow[0] ? irow[0] : width, height);
+    if (out_pal == P_4444) memset(dst[3], 255, (size_t)orow[0] * height);
+    return 0;
+  }
+  /* convert_addpost_frame / convert_delpost_frame (K1 family, :9709-9837 / :10026-10113) without a LUT */
+  if (in_pal == P_888 && out_pal == P_8888) {
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++) {
+        memcpy(dst[0] + (size_t)y * orow[0] + x * 4, src[0] + (size_t)y * irow[0] + x * 3, 3);
+        dst[0][(size_t)y * orow[0] + x * 4 + 3] = 255;
+      }
+    return 0;
+  }
+  if (in_pal == P_8888 && out_pal == P_888) {
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++) memcpy(dst[0] + (size_t)y * orow[0] + x * 3, src[0] + (size_t)y * irow[0] + x * 4, 3);
+    return 0;
+  }
+  /* convert_swab_frame :10517-10575: in place in the reference (dst may equal src) */
+  if (inpk422 && (out_pal == P_UYVY || out_pal == P_YUYV) && in_pal != out_pal) {
+    if (width & 1) return -1;
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width * 2; x += 2) {
+        const uint8_t a = src[0][(size_t)y * irow[0] + x], b = src[0][(size_t)y * irow[0] + x + 1];
+        dst[0][(size_t)y * orow[0] + x] = b; dst[0][(size_t)y * orow[0] + x + 1] = a;
+      }
+    return 0;
+  }
+  /* convert_yuv420_to_uyvy_frame / _yuyv_frame :7104-7198: `i` is never advanced, so the "average with the row above"
+     step never runs; after an even row the chroma pointers go back by the ROWSTRIDE (not by the half width), which only
+     lands on the start of the same chroma row when the chroma planes are compact */
+  if (in420 && (out_pal == P_UYVY || out_pal == P_YUYV)) {
+    const int hw = width >> 1;
+    if (irow[1] != hw || irow[2] != hw || ((width | height) & 1)) return -1;
+    for (int y = 0; y < height; y++) {
+      uint8_t *d = dst[0] + (size_t)y * (orow[0] / 4) * 4;                                   /* orow / 4 macropixels (:7120) */
+      const uint8_t *sy = src[0] + (size_t)y * irow[0], *su = src[1] + (size_t)(y >> 1) * hw, *sv = src[2] + (size_t)(y >> 1) * hw;
+      for (int j = 0; j < hw; j++) {
+        if (out_pal == P_UYVY) { d[4 * j] = su[j]; d[4 * j + 1] = sy[2 * j]; d[4 * j + 2] = sv[j]; d[4 * j + 3] = sy[2 * j + 1]; }
+        else { d[4 * j] = sy[2 * j]; d[4 * j + 1] = su[j]; d[4 * j + 2] = sy[2 * j + 1]; d[4 * j + 3] = sv[j]; }
+      }
+    }
+    return 0;
+  }
+  /* 420P -> 422P: Y plane copied (weed_layer_copy_single_plane, :13593), convert_double_chroma :10612-10639 on
+     (width >> 1, height >> 1): every chroma row twice, then each odd row averaged with the even row below it */
+  if (in420 && out_pal == P_422) {
+    const int cw = width >> 1, ch = height >> 1;
+    if ((width | height) & 1) return -1;
+    copy_rows(src[0], irow[0], dst[0], orow[0], width, height);
+    for (int p = 1; p < 3; p++) {
+      int i2 = 0, chroma = 0;
+      for (int i = 0; i < ch * 2; i++) {
+        memcpy(dst[p] + (size_t)orow[p] * i, src[p] + (size_t)irow[p] * i2, (size_t)cw);
+        if (!chroma && i > 0)
+          for (int j = 0; j < cw; j++) {
+            uint8_t *q = dst[p] + (size_t)orow[p] * (i - 1) + j;
+            *q = (uint8_t)orc_cavg(cl, *q, dst[p][(size_t)orow[p] * i + j]);
+          }
+        if (chroma) i2++;
+        chroma = !chroma;
+      }
+    }
+    return 0;
+  }
+  /* convert_yuvp_to_yuv420_frame :7690-7753 (444P / 4444P -> 420P): horizontal pairs averaged, then the two rows */
+  if (in444 && (out_pal == P_420 || out_pal == P_YV12)) {
+    const int hw = width >> 1;
+    if ((width | height) & 1) return -1;             /* 4:2:0 layers are even (:11601-11603); the reference overruns otherwise */
+    if (dst[0] != src[0]) {
+      if (irow[0] == orow[0]) memcpy(dst[0], src[0], (size_t)irow[0] * height);
+      else copy_rows(src[0], irow[0], dst[0], orow[0], width, height);
+    }
+    for (int p = 1; p < 3; p++) {
+      uint8_t *d = dst[p];
+      const uint8_t *s = src[p];
+      int chroma = 0;
+      for (int i = 0; i < height; i++) {
+        for (int j = 0; j < hw; j++) {
+          const int x = orc_cavg(cl, s[j * 2], s[j * 2 + 1]);
+          d[j] = (uint8_t)(!chroma ? x : orc_cavg(cl, d[j], x));
+        }
+        if (chroma) d += orow[p];
+        chroma = !chroma;
+        s += irow[p];
+      }
+    }
+    return 0;
+  }
+  /* convert_yuv_planar_to_uyvy_frame / _yuyv_frame :7500-7591: only the compact branch stays inside its buffers (the strided
+     one runs `width` macropixels per row) */
+  if (in444 && (out_pal == P_UYVY || out_pal == P_YUYV)) {
+    if (irow[0] != width || orow[0] != width * 2 || (width & 1)) return -1;
+    const size_t n = ((size_t)width * height) >> 1;
+    for (size_t k = 0; k < n; k++) {
+      uint8_t *d = dst[0] + 4 * k;
+      const int u = orc_cavg(cl, src[1][2 * k], src[1][2 * k + 1]), v = orc_cavg(cl, src[2][2 * k], src[2][2 * k + 1]);
+      if (out_pal == P_UYVY) { d[0] = (uint8_t)u; d[1] = src[0][2 * k]; d[2] = (uint8_t)v; d[3] = src[0][2 * k + 1]; }
+      else { d[0] = src[0][2 * k]; d[1] = (uint8_t)u; d[2] = src[0][2 * k + 1]; d[3] = (uint8_t)v; }
+    }
+    return 0;
+  }
+  /* UYVY / YUYV sources (:7800-7971): chroma replicated, no interpolation */
+  if (inpk422) {
+    const int mw = width >> 1, yo = in_pal == P_UYVY ? 1 : 0, uo = in_pal == P_UYVY ? 0 : 1, vo = in_pal == P_UYVY ? 2 : 3;
+    const int irm = (irow[0] / 4) * 4;                                                        /* irow /= 4 macropixels */
+    if (width & 1) return -1;
+    if (out_pal == P_444 || out_pal == P_4444) {          /* convert_uyvy_to_yuvp_frame: plane strides are mixed up -> equal strides only */
+      if (orow[0] != orow[1] || orow[0] != orow[2]) return -1;
+      for (int k = 0; k < height; k++)
+        for (int x = 0; x < mw; x++) {
+          const uint8_t *m = src[0] + (size_t)k * irm + 4 * x;
+          dst[0][(size_t)k * orow[0] + 2 * x] = m[yo]; dst[0][(size_t)k * orow[0] + 2 * x + 1] = m[yo + 2];
+          dst[1][(size_t)k * orow[0] + 2 * x] = dst[1][(size_t)k * orow[0] + 2 * x + 1] = m[uo];
+          dst[2][(size_t)k * orow[0] + 2 * x] = dst[2][(size_t)k * orow[0] + 2 * x + 1] = m[vo];
+        }
+      if (out_pal == P_4444) memset(dst[3], 255, (size_t)orow[3] * height);
+      return 0;
+    }
+    if (out_pal == P_888 || out_pal == P_8888) {          /* convert_uyvy_to_yuv888_frame / convert_yuyv_to_yuv888_frame */
+      const int ops = out_pal == P_8888 ? 4 : 3;
+      for (int y = 0; y < height; y++)
+        for (int x = 0; x < mw; x++) {
+          const uint8_t *m = src[0] + (size_t)y * irm + 4 * x;
+          uint8_t *d = dst[0] + (size_t)y * orow[0] + (size_t)2 * x * ops;
+          d[0] = m[yo]; d[1] = m[uo]; d[2] = m[vo];
+          if (ops == 4) d[3] = 255;
+          d[ops] = m[yo + 2]; d[ops + 1] = m[uo]; d[ops + 2] = m[vo];
+          if (ops == 4) d[ops + 3] = 255;
+        }
+      return 0;
+    }
+    if (out_pal == P_420 || out_pal == P_YV12) {          /* convert_uyvy_to_yuv420_frame: no strides at all -> compact only */
+      if ((height & 1) || irow[0] != width * 2 || orow[0] != width || orow[1] != mw || orow[2] != mw) return -1;
+      for (int y = 0; y < height; y++)
+        for (int x = 0; x < mw; x++) {
+          const uint8_t *m = src[0] + (size_t)y * irm + 4 * x;
+          uint8_t *pu = dst[1] + (size_t)(y >> 1) * mw + x, *pv = dst[2] + (size_t)(y >> 1) * mw + x;
+          dst[0][(size_t)y * width + 2 * x] = m[yo]; dst[0][(size_t)y * width + 2 * x + 1] = m[yo + 2];
+          if (!(y & 1)) { *pu = m[uo]; *pv = m[vo]; }
+          else { *pu = (uint8_t)orc_cavg(cl, *pu, m[uo]); *pv = (uint8_t)orc_cavg(cl, *pv, m[vo]); }
+        }
+      return 0;
+    }
+    return -1;
+  }
+  return -1;
+}

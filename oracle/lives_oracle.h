@@ -112,6 +112,10 @@ int orc_cavg(int clamped, int x, int y);
    palette: 588 YUV888, 589 YUVA8888 (alpha untouched), 544 / 545 planar 4:4:4(4), 522, 512, 513, 564 UYVY, 565 YUYV. */
 void orc_yuv_yuv_tables(uint8_t *yc2u, uint8_t *uvc2u, uint8_t *yu2c, uint8_t *uvu2c);
 int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], int palette, int height, int to_unclamped);
+/* YUV -> YUV repacks (colourspace.c:7104-7198, :7500-7753, :7800-7971, :9198-9257, :10517-10575, :10612-10639 and the K1
+   addpost / delpost pair); WEED_PALETTE_* numbers, width in pixels; -1 = pair / layout not taken */
+int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const int irow[4], uint8_t *const dst[4], const int orow[4],
+                   int width, int height, int clamping_unclamped, int sampling_jpeg);
 
 /* F7: geometric transitions  lives-plugins/weed-plugins/multi_transitions.c:86-233: type 0 "iris rectangle", 1 "iris circle",
    2 "4 way split" (types 3 dissolve / 4 rand replace draw from the host's random generator and are not restated).

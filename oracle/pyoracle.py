@@ -92,6 +92,7 @@ def oracle():
         _O.orc_yuv_to_rgb.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci]
         _O.orc_cavg.argtypes = [ci, ci, ci]
         _O.orc_transition.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd]
+        _O.orc_yuv_repack.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci]
         _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]
@@ -128,6 +129,7 @@ def csref():
         _R.csref_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _R.csref_k4.argtypes = [ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, ci, ci]
         _R.csref_k3.argtypes = [ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci]
+        _R.csref_yuv_repack.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci]
     return _R
 
 
@@ -273,3 +275,27 @@ def planes_args(planes):
     ss = (ci * 4)(*([a.strides[0] for a in planes] + [0] * (4 - n)))
     return pp, ss
 
+
+
+# ---- K5b helpers: plane shapes of the YUV palettes (WEED_PALETTE_* numbers) ----------------------------------------
+YUV_PLANE_DIMS = {
+    512: lambda w, h: [(w, h), (w >> 1, h >> 1), (w >> 1, h >> 1)], 513: lambda w, h: [(w, h), (w >> 1, h >> 1), (w >> 1, h >> 1)],
+    522: lambda w, h: [(w, h), (w >> 1, h), (w >> 1, h)], 544: lambda w, h: [(w, h)] * 3, 545: lambda w, h: [(w, h)] * 4,
+    564: lambda w, h: [(w * 2, h)], 565: lambda w, h: [(w * 2, h)], 588: lambda w, h: [(w * 3, h)], 589: lambda w, h: [(w * 4, h)],
+}
+
+
+def yuv_planes(pal, w, h, rng=None, fill=0x5A, pad=0):
+    """list of 2-D uint8 arrays (rows x rowstride) for a frame of `pal`; pad = extra bytes per row (same for every plane)"""
+    out = []
+    for (nb, rows) in YUV_PLANE_DIMS[pal](w, h):
+        a = np.full((rows, nb + pad), fill, np.uint8) if rng is None else rng.integers(0, 256, (rows, nb + pad), dtype=np.uint8)
+        out.append(a)
+    return out
+
+
+# pairs orc_yuv_repack / lgpu_yuv_repack take, with the layouts they take them in: (in, out, padded strides allowed)
+YUV_REPACK_PAIRS = [(544, 588, 1), (544, 589, 1), (545, 588, 1), (545, 589, 1), (588, 544, 1), (545, 544, 1), (544, 545, 1),
+                    (588, 589, 1), (589, 588, 1), (564, 565, 1), (565, 564, 1), (512, 564, 0), (512, 565, 0), (512, 522, 1),
+                    (544, 512, 1), (545, 512, 1), (544, 564, 0), (544, 565, 0), (545, 564, 0), (564, 544, 1), (565, 544, 1),
+                    (564, 545, 1), (564, 588, 1), (565, 588, 1), (564, 589, 1), (565, 589, 1), (564, 512, 0), (565, 512, 0)]

@@ -241,6 +241,56 @@ int csref_k4(int in_order, int in_alpha, int out_fmt, int out_alpha, uint8_t *sr
   }
   return -1;
 }
+/* K5b: YUV -> YUV repacks with the arguments the dispatcher passes (:12937-13750); WEED_PALETTE_* numbers, width in pixels */
+int csref_yuv_repack(int in_pal, int out_pal, uint8_t **src, int *irows_in, uint8_t **dst, int *orows_in, int width, int height,
+                     int clamping, int sampling) {
+  int irows[4], orows[4];
+  const int in444 = (in_pal == 544 || in_pal == 545), in420 = (in_pal == 512 || in_pal == 513), inpk = (in_pal == 564 || in_pal == 565);
+  (void)sampling;
+  memcpy(irows, irows_in, sizeof(irows)); memcpy(orows, orows_in, sizeof(orows));
+  ensure_tables();
+  avg_chromaf = avg_chromaf_fast;
+  if (in444 && (out_pal == 588 || out_pal == 589)) { convert_combineplanes_frame(src, width, height, irows[0], orows[0], dst[0], in_pal == 545, out_pal == 589); return 0; }
+  if (in_pal == 588 && out_pal == 544) { convert_splitplanes_frame(src[0], width, height, irows[0], orows, dst, FALSE, FALSE); return 0; }
+  if (in_pal == 545 && out_pal == 544) { convert_yuvap_to_yuvp_frame(src, width, height, irows[0], orows[0], dst); return 0; }
+  if (in_pal == 544 && out_pal == 545) { convert_yuvp_to_yuvap_frame(src, width, height, irows[0], orows[0], dst); return 0; }
+  if (in_pal == 588 && out_pal == 589) { convert_addpost_frame(src[0], width, height, irows[0], orows[0], dst[0], NULL, -1); return 0; }
+  if (in_pal == 589 && out_pal == 588) { convert_delpost_frame(src[0], width, height, irows[0], orows[0], dst[0], NULL, -1); return 0; }
+  if (inpk && (out_pal == 564 || out_pal == 565) && in_pal != out_pal) {      /* in place (:13139) */
+    for (int y = 0; y < height; y++) memcpy(dst[0] + (size_t)y * orows[0], src[0] + (size_t)y * irows[0], (size_t)width * 2);
+    convert_swab_frame(dst[0], width >> 1, height, orows[0], -1);
+    return 0;
+  }
+  if (in420 && out_pal == 564) { convert_yuv420_to_uyvy_frame(src, width, height, irows, orows[0], (uyvy_macropixel *)dst[0], clamping); return 0; }
+  if (in420 && out_pal == 565) { convert_yuv420_to_yuyv_frame(src, width, height, irows, orows[0], (yuyv_macropixel *)dst[0], clamping); return 0; }
+  if (in420 && out_pal == 522) {
+    for (int y = 0; y < height; y++) memcpy(dst[0] + (size_t)y * orows[0], src[0] + (size_t)y * irows[0], (size_t)width);   /* weed_layer_copy_single_plane */
+    convert_double_chroma(src, width >> 1, height >> 1, irows, orows, dst, clamping);
+    return 0;
+  }
+  if (in444 && (out_pal == 512 || out_pal == 513)) { convert_yuvp_to_yuv420_frame(src, width, height, irows, orows, dst, clamping); return 0; }
+  if (in444 && out_pal == 564) { convert_yuv_planar_to_uyvy_frame(src, width, height, irows[0], orows[0], (uyvy_macropixel *)dst[0], clamping); return 0; }
+  if (in444 && out_pal == 565) { convert_yuv_planar_to_yuyv_frame(src, width, height, irows[0], orows[0], (yuyv_macropixel *)dst[0], clamping); return 0; }
+  if (inpk) {
+    const int mw = width >> 1;
+    if (out_pal == 544 || out_pal == 545) {
+      if (in_pal == 564) convert_uyvy_to_yuvp_frame((uyvy_macropixel *)src[0], mw, height, irows[0], orows, dst, out_pal == 545);
+      else convert_yuyv_to_yuvp_frame((yuyv_macropixel *)src[0], mw, height, irows[0], orows, dst, out_pal == 545);
+      return 0;
+    }
+    if (out_pal == 588 || out_pal == 589) {
+      if (in_pal == 564) convert_uyvy_to_yuv888_frame((uyvy_macropixel *)src[0], mw, height, irows[0], orows[0], dst[0], out_pal == 589);
+      else convert_yuyv_to_yuv888_frame((yuyv_macropixel *)src[0], mw, height, irows[0], orows[0], dst[0], out_pal == 589);
+      return 0;
+    }
+    if (out_pal == 512 || out_pal == 513) {
+      if (in_pal == 564) convert_uyvy_to_yuv420_frame((uyvy_macropixel *)src[0], mw, height, dst, clamping);
+      else convert_yuyv_to_yuv420_frame((yuyv_macropixel *)src[0], mw, height, dst, clamping);
+      return 0;
+    }
+  }
+  return -1;
+}
 /* K3: in_fmt 0 packed 1 planar 2 UYVY 3 YUYV; out_order 0 RGB 1 BGR 2 ARGB; width in pixels */
 int csref_k3(int in_fmt, int in_alpha, int out_order, int out_alpha, uint8_t **src, int *irows, int width, int height,
              uint8_t *dst, int orow, int clamping, int bt709) {
@@ -335,6 +385,11 @@ def main():
     parts.append(lines(cs, 6250, 6440))             # K4: rgb / argb / bgr -> yuv420p / yuv422p
     parts.append(lines(cs, 6616, 7102))             # K3: uyvy / yuyv -> rgb / bgr / argb
     parts.append(lines(cs, 7200, 7498))             # K3: yuv(a)444p -> rgb / bgr / argb
+    parts.append(lines(cs, 7104, 7198))             # K5b: yuv420p -> uyvy / yuyv
+    parts.append(lines(cs, 7500, 7753))             # K5b: yuv(a)444p -> uyvy / yuyv / yuv(a)888(8) / yuv(a)444p / yuv420p
+    parts.append(lines(cs, 7800, 7971))             # K5b: uyvy / yuyv -> yuv(a)444p / yuv(a)888(8) / yuv420p
+    parts.append(lines(cs, 9198, 9257))             # K5b: convert_splitplanes_frame
+    parts.append(lines(cs, 10578, 10639))           # K5b: convert_halve_chroma, convert_double_chroma
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family
     parts.append(lines(cs, 14034, 14060))           # gamma_convert_layer_thread
     parts.append(WRAPPERS)

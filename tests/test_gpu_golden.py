@@ -266,3 +266,17 @@ def test_slide_over_vs_reference_plugin(gpu):
         d = dev(np.full_like(want, 0x5A))
         gpu.slide_over(dev(g[rec + "|a"]), dev(g[rec + "|b"]), d, w, h, ps, int(tv), int(dirn), int(mvl), int(mvu))
         assert (host(d)[:, :w * ps] == want[:, :w * ps]).all(), rec
+
+
+def test_yuv_repack_vs_reference(gpu):
+    g = gu.load("yuv_repack.npz")
+    for rec in map(str, g["records"]):
+        _, ip, op, unc, pad, w, h = rec.split("|")
+        ip, op, unc, pad, w, h = int(ip), int(op), int(unc), int(pad), int(w), int(h)
+        nin, nout = len(po.YUV_PLANE_DIMS[ip](w, h)), len(po.YUV_PLANE_DIMS[op](w, h))
+        src = [dev(g[rec + "|i%d" % i]) for i in range(nin)]
+        want = [g[rec + "|o%d" % i] for i in range(nout)]
+        dst = [dev(np.full_like(a, 0x5A)) for a in want]
+        gpu.yuv_repack(ip, op, src, dst, w, h, unc)
+        for i, a in enumerate(want):
+            assert (host(dst[i]) == a).all(), "%s plane %d" % (rec, i)

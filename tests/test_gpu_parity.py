@@ -397,6 +397,40 @@ def test_slide_over(gpu, orc, psize):
                     assert_same(host(d), want, w, h, psize, "slide over ps=%d %dx%d dir=%d amount=%d lower=%d upper=%d" % (psize, w, h, dirn, tv, mvl, mvu))
 
 
+# ---------------------------------------------------------------------------------------------- K5b YUV -> YUV repacks
+@pytest.mark.parametrize("pair", po.YUV_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
+def test_yuv_repack(gpu, orc, pair):
+    import ctypes
+    ip, op, padok = pair
+    rng = np.random.default_rng(2600 + ip * 7 + op)
+    subs = {512, 513, 522, 564, 565}
+    sizes = [(16, 8), (66, 34), (130, 18), (320, 200)]
+    if ip not in subs and op not in subs:
+        sizes += [(7, 5), (33, 3)]                     # odd geometry only exists for the 4:4:4 layouts
+    for (w, h) in sizes:
+        for unc in (0, 1):
+            for pad in ((0, 24) if padok else (0,)):
+                src = po.yuv_planes(ip, w, h, rng=rng, pad=pad)
+                want = po.yuv_planes(op, w, h, fill=0x5A, pad=pad)
+                sp, ss = po.planes_args(src)
+                wp, ws = po.planes_args(want)
+                assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, unc, 0) == 0
+                dst = [dev(np.full_like(a, 0x5A)) for a in want]
+                gpu.yuv_repack(ip, op, [dev(a) for a in src], dst, w, h, unc)
+                for i, a in enumerate(want):
+                    assert (host(dst[i]) == a).all(), "repack %d->%d %dx%d unclamped=%d pad=%d plane %d" % (ip, op, w, h, unc, pad, i)
+
+
+def test_yuv_repack_declines(gpu):
+    from lives_amd.lib import LgpuError
+    w, h = 16, 8
+    for (ip, op, pad) in [(512, 564, 8), (544, 564, 8), (564, 512, 8), (522, 512, 0), (544, 522, 0), (512, 544, 0), (589, 544, 0), (588, 545, 0)]:
+        src = [dev(a) for a in po.yuv_planes(ip, w, h, fill=1, pad=pad)]
+        dst = [dev(a) for a in po.yuv_planes(op, w, h, fill=2, pad=pad)]
+        with pytest.raises(LgpuError):
+            gpu.yuv_repack(ip, op, src, dst, w, h, 0)
+
+
 # ---------------------------------------------------------------------------------------------- K5 clamping switch
 @pytest.mark.parametrize("palette", [588, 589, 544, 545, 522, 512, 513, 564, 565])
 def test_yuv_switch_clamping(gpu, orc, palette):

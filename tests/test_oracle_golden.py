@@ -303,3 +303,20 @@ def test_slide_over(orc):
         got = np.full_like(a, 0x5A)
         orc.orc_slide_over(P(a), a.strides[0], P(b), b.strides[0], P(got), got.strides[0], w, h, ps, int(tv), int(dirn), int(mvl), int(mvu))
         assert (got[:, :w * ps] == want[:, :w * ps]).all(), rec
+
+
+def test_yuv_repack(orc):
+    import ctypes
+    g = gu.load("yuv_repack.npz")
+    for rec in map(str, g["records"]):
+        _, ip, op, unc, pad, w, h = rec.split("|")
+        ip, op, unc, w, h = int(ip), int(op), int(unc), int(w), int(h)
+        nin, nout = len(po.YUV_PLANE_DIMS[ip](w, h)), len(po.YUV_PLANE_DIMS[op](w, h))
+        src = [np.ascontiguousarray(g[rec + "|i%d" % i]) for i in range(nin)]
+        want = [g[rec + "|o%d" % i] for i in range(nout)]
+        got = [np.full_like(a, 0x5A) for a in want]
+        sp, ss = po.planes_args(src)
+        gp, gs = po.planes_args(got)
+        assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(gp), ctypes.addressof(gs), w, h, unc, 0) == 0
+        for i, a in enumerate(want):
+            assert (got[i] == a).all(), "%s plane %d" % (rec, i)
