@@ -331,6 +331,58 @@ int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int
   return out;
 }
 
+// YUV -> YUV repack of a layer (:12937-13750, the non-RGB half of the dispatcher) through lgpu_yuv_repack; 0 = not taken, the
+// caller's CPU body runs (pairs / layouts listed in include/lives_gpu.h)
+lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, int outpl, int iclamping) {
+  const int inpl = l.pal;
+  const bool inpk = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV), outpk = (outpl == WEED_PALETTE_UYVY || outpl == WEED_PALETTE_YUYV);
+  const int width = inpk ? l.width * 2 : l.width, height = l.height;              // pixels
+  if (width < 1 || height < 1) return 0;
+  const int unclamped = iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0;
+  const uint8_t *dsrc[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint8_t *ddst[4] = {nullptr, nullptr, nullptr, nullptr};
+  int irs[4] = {0, 0, 0, 0}, ors[4] = {0, 0, 0, 0};
+  bool ok = true;
+  for (int p = 0; p < l.nplanes && ok; p++) {
+    const size_t b = (size_t)l.rs[p] * plane_h(l, p);
+    uint8_t *d = t_scr.get(p == 0 ? 0 : p, b);     // slots 0..2 (+ 7 for a fourth plane)
+    if (p == 3) d = t_scr.get(7, b);
+    ok = d && up(d, l.pd[p], b);
+    dsrc[p] = d; irs[p] = l.rs[p];
+  }
+  if (!ok) return 0;
+  if (inpl == WEED_PALETTE_YVU420P) { const uint8_t *t = dsrc[1]; dsrc[1] = dsrc[2]; dsrc[2] = t; const int r = irs[1]; irs[1] = irs[2]; irs[2] = r; }
+  if (inpk && outpk) {
+    // convert_swab_frame (:13139): in place, the layer keeps its pixel data
+    uint8_t *dd[4] = {const_cast<uint8_t *>(dsrc[0]), nullptr, nullptr, nullptr};
+    ok = lgpu_yuv_repack(inpl, outpl, dsrc, irs, dd, irs, width, height, unclamped, 0, nullptr) == LGPU_OK &&
+         down(l.pd[0], dd[0], (size_t)l.rs[0] * height) && sync();
+    if (!ok) return 0;
+    set_int(layer, WEED_LEAF_CURRENT_PALETTE, outpl);
+    return 1;
+  }
+  const int lwidth = outpk ? width >> 1 : width;
+  NewPlanes np;
+  if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
+  for (int p = 0; p < np.n && ok; p++) {
+    ddst[p] = t_scr.get(3 + p, np.sz[p]);
+    ors[p] = np.rs[p];
+    ok = ddst[p] && up_fresh(ddst[p], np.pd[p], np.sz[p]);
+  }
+  ok = ok && lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, 0, nullptr) == LGPU_OK;
+  for (int p = 0; p < np.n && ok; p++) ok = down(np.pd[p], ddst[p], np.sz[p]);
+  ok = ok && sync();
+  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }
+  int flags = l.flags;
+  if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  free_planes(l);
+  if (outpl == WEED_PALETTE_YVU420P) { uint8_t *t = np.pd[1]; np.pd[1] = np.pd[2]; np.pd[2] = t; }   // swap_chroma_planes (:13890)
+  commit_planes(layer, outpl, lwidth, height, np);
+  if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
+  if (outpl == WEED_PALETTE_YUV420P || outpl == WEED_PALETTE_YVU420P) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);   // :13022
+  return 1;
+}
+
 lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig) {
   (void)may_contig;
   if (!layer || !bound()) return 0;
@@ -376,7 +428,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
   if (inpl == outpl) return 1;                                           // :12265
   if (!pal_is_rgb(outpl)) {
     if (pal_is_rgb(inpl)) return rgb_layer_to_yuv(layer, l, outpl, oclamping, osubspace, tgt_gamma);
-    return 0;                                                            // YUV -> YUV repacks: not on the GPU path yet
+    return yuv_layer_repack(layer, l, outpl, l.clamping >= 0 ? l.clamping : oclamping);   // YUV -> YUV repacks (K5b)
   }
   const int iclamping = l.clamping >= 0 ? l.clamping : oclamping;        // :12216-12218
 

@@ -248,6 +248,36 @@ def test_yuv_layers_to_rgb(seam, orc, inpl):
 
 @needs_ref
 @pytest.mark.gpu
+def test_yuv_layers_repack(seam, orc):
+    """the non-RGB half of convert_layer_palette_full (:12937-13750): YUV -> YUV pairs through lgpu_yuv_repack; pairs the
+    library declines return FALSE with the layer untouched"""
+    L, wh = seam
+    rng = np.random.default_rng(88)
+    w, h = 64, 12
+    for (ip, op, _) in po.YUV_REPACK_PAIRS:
+        for clamp in (0, 1):
+            planes = po.yuv_planes(ip, w, h, rng=rng)
+            lw = w >> 1 if ip in (564, 565) else w
+            lay = wh.new_layer(ip, lw, h, [a.copy() for a in planes], clamping=clamp, subspace=1)
+            assert L.lives_gpu_convert_layer_palette_full(lay, op, clamp, 0, 1, 0) == 1, (ip, op)
+            got, _, rs = wh.planes_of(lay)
+            dims = po.YUV_PLANE_DIMS[op](w, h)
+            want = [np.zeros((b, r), np.uint8) for (a, b), r in zip(dims, rs)]
+            sp, ss = po.planes_args(planes)
+            wp, ws = po.planes_args(want)
+            assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, clamp, 0) == 0
+            for i, (a, b) in enumerate(dims):
+                assert (got[i][:b, :a] == want[i][:b, :a]).all(), (ip, op, clamp, i)
+            assert wh.geti(lay, "current_palette") == op and wh.geti(lay, "width") == (w >> 1 if op in (564, 565) else w)
+            assert wh.geti(lay, "YUV_clamping") == clamp
+    for (ip, op) in [(522, 512), (544, 522), (512, 544), (589, 544)]:          # reference functions that overrun / depend on stale bytes
+        planes = po.yuv_planes(ip, w, h, rng=rng)
+        lay = wh.new_layer(ip, w, h, planes, clamping=0, subspace=1)
+        assert L.lives_gpu_convert_layer_palette_full(lay, op, 0, 0, 1, 0) == 0 and wh.geti(lay, "current_palette") == ip
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_yuv_layer_clamping_switch(seam, orc):
     """convert_layer_palette_full(layer, same palette, other clamping, same subspace) = in-place range switch (:12241-12247)"""
     L, wh = seam
