@@ -171,8 +171,8 @@ int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4]
 /* K5b: YUV -> YUV repacks, the non-RGB half of convert_layer_palette_full's matrix (src/colourspace.c:12937-13750 dispatches
    to :7104-7198, :7500-7753, :7800-7971, :9198-9257, :10517-10639 and the K1 addpost / delpost pair).  Palettes are
    WEED_PALETTE_* numbers, width in pixels.  Taken: 444P / 4444P -> 888 / 8888 / 4444P / 444P / 420P / (compact rows) UYVY / YUYV;
-   888 -> 444P / 8888; 8888 -> 888; 420P -> 422P / (compact chroma) UYVY / YUYV; UYVY <-> YUYV; UYVY / YUYV -> 444P / 4444P
-   (equal plane strides) / 888 / 8888 / (compact rows) 420P.  LGPU_E_UNSUPPORTED for every other pair or layout: there the
+   888 -> 444P / 8888; 8888 -> 888; 888 / 8888 -> (compact destination) 420P / 422P / UYVY / YUYV; 420P -> 422P / (compact chroma) UYVY / YUYV; UYVY <-> YUYV; UYVY / YUYV -> 444P / 4444P
+   (equal plane strides) / 888 / 8888 / (compact rows) 420P / 422P.  LGPU_E_UNSUPPORTED for every other pair or layout: there the
    reference function overruns its buffers, mixes up its strides or leaves a result that depends on what the destination
    held before (DESIGN.md "YUV -> YUV"), and the caller keeps its CPU body.  Bytes the reference does not write are not
    written.  clamping_unclamped picks the chroma averaging table (init_average :190-216). */

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_clamp_switch(ClampPlanes cp, int per
 // ---------------------------------------------------------------------------------------------------------------------
 enum RepackKind {
   RK_COMBINE, RK_SPLIT, RK_COPY444, RK_SWAB, RK_420_TO_PK, RK_420_TO_422P, RK_444_TO_420, RK_444_TO_PK, RK_PK_TO_444, RK_PK_TO_888,
-  RK_PK_TO_420
+  RK_PK_TO_420, RK_888_TO_420, RK_888_TO_422, RK_PK_TO_422P
 };
 struct RepackArgs {
   const uint8_t *src[4];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
   const int x0 = 2 * mx;
   if (x0 >= a.width && a.kind != RK_COPY444 && a.kind != RK_444_TO_420) return;
   const bool two = x0 + 1 < a.width;                         // odd widths: the last column is a single pixel where the reference allows it
-  const int rows = (a.kind == RK_444_TO_420 || a.kind == RK_PK_TO_420) ? (a.height + 1) >> 1 : a.height;
+  const int rows = (a.kind == RK_444_TO_420 || a.kind == RK_PK_TO_420 || a.kind == RK_888_TO_420) ? (a.height + 1) >> 1 : a.height;
   for (int y = blockIdx.y; y < rows; y += gridDim.y) {
     switch (a.kind) {
     case RK_COMBINE: {
@@ -330,6 +330,35 @@ __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
       const uint8_t u = (uint8_t)cavg(a.clamped, a.src[1][si], a.src[1][si + 1]), v = (uint8_t)cavg(a.clamped, a.src[2][si], a.src[2][si + 1]);
       if (a.yuyv_out) { d[0] = a.src[0][si]; d[1] = u; d[2] = a.src[0][si + 1]; d[3] = v; }
       else { d[0] = u; d[1] = a.src[0][si]; d[2] = v; d[3] = a.src[0][si + 1]; }
+      break;
+    }
+    case RK_888_TO_420: case RK_888_TO_422: {                   // compact destination (checked by the caller); in_alpha = 4-byte source pixels
+      const int ips = a.in_alpha ? 4 : 3, hw = a.width >> 1;
+      if (a.kind == RK_888_TO_420) {
+        const uint8_t *s0 = a.src[0] + (size_t)(2 * y) * a.irow[0] + (size_t)x0 * ips, *s1 = s0 + a.irow[0];
+        a.dst[0][(size_t)(2 * y) * a.width + x0] = s0[0]; a.dst[0][(size_t)(2 * y) * a.width + x0 + 1] = s0[ips];
+        a.dst[0][(size_t)(2 * y + 1) * a.width + x0] = s1[0]; a.dst[0][(size_t)(2 * y + 1) * a.width + x0 + 1] = s1[ips];
+        a.dst[1][(size_t)y * hw + mx] = (uint8_t)cavg(a.clamped, cavg(a.clamped, s0[1], s0[1 + ips]), cavg(a.clamped, s1[1], s1[1 + ips]));
+        a.dst[2][(size_t)y * hw + mx] = (uint8_t)cavg(a.clamped, cavg(a.clamped, s0[2], s0[2 + ips]), cavg(a.clamped, s1[2], s1[2 + ips]));
+      } else {
+        const uint8_t *s0 = a.src[0] + (size_t)y * a.irow[0] + (size_t)x0 * ips;
+        const uint8_t u = (uint8_t)cavg(a.clamped, s0[1], s0[1 + ips]), v = (uint8_t)cavg(a.clamped, s0[2], s0[2 + ips]);
+        if (a.out_alpha) {                                        // here: planar 4:2:2 destination
+          a.dst[0][(size_t)y * a.width + x0] = s0[0]; a.dst[0][(size_t)y * a.width + x0 + 1] = s0[ips];
+          a.dst[1][(size_t)y * hw + mx] = u; a.dst[2][(size_t)y * hw + mx] = v;
+        } else {
+          uint8_t *d = a.dst[0] + (size_t)y * a.width * 2 + 4 * (size_t)mx;
+          if (a.yuyv_out) { d[0] = s0[0]; d[1] = u; d[2] = s0[ips]; d[3] = v; }
+          else { d[0] = u; d[1] = s0[0]; d[2] = v; d[3] = s0[ips]; }
+        }
+      }
+      break;
+    }
+    case RK_PK_TO_422P: {                                         // the reference never advances its source pointer (:8102-8107): macropixel 0 everywhere
+      const int yo = a.yuyv_in ? 0 : 1, uo = a.yuyv_in ? 1 : 0, vo = a.yuyv_in ? 3 : 2;
+      const uint8_t *m = a.src[0];
+      const size_t k = (size_t)y * (a.width >> 1) + mx;
+      a.dst[0][2 * k] = m[yo]; a.dst[0][2 * k + 1] = m[yo + 2]; a.dst[1][k] = m[uo]; a.dst[2][k] = m[vo];
       break;
     }
     case RK_PK_TO_444: case RK_PK_TO_888: case RK_PK_TO_420: {
@@ -536,6 +565,23 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     // only the compact branch of convert_yuv_planar_to_uyvy_frame stays inside its buffers (:7512-7524 vs :7526-7543)
     if (irow[0] != width || orow[0] != width * 2 || (width & 1)) return unsupported("4:4:4 planar -> packed 4:2:2 needs compact rows and an even width (colourspace.c:7526)");
     a.kind = lgpu::RK_444_TO_PK; nin = 3;
+  } else if ((in_pal == P_888 || in_pal == P_8888) && (out_pal == P_420 || out_pal == P_YV12 || out_pal == P_422 || outpk)) {
+    // :8035-8270: every one of these walks its destination as a compact buffer (the strided branches subtract the wrong widths)
+    a.in_alpha = (in_pal == P_8888);
+    if (width & 1) return unsupported("a subsampled destination needs an even width");
+    if (out_pal == P_420 || out_pal == P_YV12) {
+      if ((height & 1) || orow[0] != width || orow[1] != (width >> 1) || orow[2] != (width >> 1)) return unsupported("YUV888 -> 4:2:0 needs a compact destination and an even height (colourspace.c:8064-8087)");
+      a.kind = lgpu::RK_888_TO_420; nout = 3;
+    } else if (out_pal == P_422) {
+      if (irow[0] != width * (a.in_alpha ? 4 : 3) || orow[0] != width || orow[1] != (width >> 1)) return unsupported("YUV888 -> 4:2:2 planar needs compact rows on both sides (colourspace.c:8161-8178)");
+      a.kind = lgpu::RK_888_TO_422; a.out_alpha = 1; nout = 3;
+    } else {
+      if (orow[0] != width * 2) return unsupported("YUV888 -> packed 4:2:2 needs a compact destination (colourspace.c:8205-8222)");
+      a.kind = lgpu::RK_888_TO_422; a.out_alpha = 0;
+    }
+  } else if (inpk && out_pal == P_422) {
+    if ((width & 1) || irow[0] != width * 2 || orow[0] != width || orow[1] != (width >> 1) || orow[2] != (width >> 1)) return unsupported("packed 4:2:2 -> planar 4:2:2 needs compact rows on both sides (colourspace.c:8093-8126)");
+    a.kind = lgpu::RK_PK_TO_422P; nout = 3;
   } else if (inpk && (out_pal == P_444 || out_pal == P_4444)) {
     if (width & 1) return unsupported("packed 4:2:2 needs an even width");
     if (orow[0] != orow[1] || orow[0] != orow[2]) return unsupported("packed 4:2:2 -> planar needs equal plane rowstrides (colourspace.c:7813-7816 mixes them)");
@@ -562,7 +608,7 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     LGPU_REQUIRE(dst_d[3], "null alpha plane");
     if ((rc = lgpu_fill(dst_d[3], 255, (size_t)orow[3] * height, stream))) return rc;                 // :7819
   }
-  const int rows = (a.kind == lgpu::RK_444_TO_420 || a.kind == lgpu::RK_PK_TO_420) ? (height + 1) >> 1 : height;
+  const int rows = (a.kind == lgpu::RK_444_TO_420 || a.kind == lgpu::RK_PK_TO_420 || a.kind == lgpu::RK_888_TO_420) ? (height + 1) >> 1 : height;
   const int span = a.copy_w > width ? a.copy_w : width;
   const dim3 grid(cdiv((unsigned)((span + 1) >> 1), kBlock), (unsigned)(rows < 2048 ? rows : 2048));
   hipLaunchKernelGGL(lgpu::k_yuv_repack, grid, dim3(kBlock), 0, st, a);

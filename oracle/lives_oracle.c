@@ -1496,6 +1496,56 @@ int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const i
     }
     return 0;
   }
+  /* YUV888 / YUVA8888 -> subsampled (:8035-8270): horizontal pairs averaged; every one of these walks its DESTINATION as a
+     compact buffer (the strided branches of :8161-8178 / :8205-8222 / :8250-8267 subtract the wrong widths or step macropixel
+     pointers by byte counts), the packed source may have row padding */
+  if ((in_pal == P_888 || in_pal == P_8888) && (out_pal == P_420 || out_pal == P_YV12 || out_pal == P_422 || out_pal == P_UYVY || out_pal == P_YUYV)) {
+    const int ips = in_pal == P_8888 ? 4 : 3, hw = width >> 1;
+    if (width & 1) return -1;
+    if (out_pal == P_420 || out_pal == P_YV12) {                 /* convert_yuv888_to_yuv420_frame :8035-8090 */
+      if ((height & 1) || orow[0] != width || orow[1] != hw || orow[2] != hw) return -1;
+      for (int y = 0; y < height; y++) {
+        const uint8_t *s = src[0] + (size_t)y * irow[0];
+        for (int j = 0; j < hw; j++) {
+          const int xu = orc_cavg(cl, s[2 * j * ips + 1], s[2 * j * ips + 1 + ips]), xv = orc_cavg(cl, s[2 * j * ips + 2], s[2 * j * ips + 2 + ips]);
+          uint8_t *pu = dst[1] + (size_t)(y >> 1) * hw + j, *pv = dst[2] + (size_t)(y >> 1) * hw + j;
+          dst[0][(size_t)y * width + 2 * j] = s[2 * j * ips]; dst[0][(size_t)y * width + 2 * j + 1] = s[2 * j * ips + ips];
+          if (!(y & 1)) { *pu = (uint8_t)xu; *pv = (uint8_t)xv; }
+          else { *pu = (uint8_t)orc_cavg(cl, *pu, xu); *pv = (uint8_t)orc_cavg(cl, *pv, xv); }
+        }
+      }
+      return 0;
+    }
+    if (out_pal == P_422) {                                      /* convert_yuv888_to_yuv422_frame :8129-8181, compact branch */
+      if (irow[0] != width * ips || orow[0] != width || orow[1] != hw) return -1;
+    } else if (orow[0] != width * 2) return -1;                  /* convert_yuv888_to_uyvy_frame / _yuyv_frame :8184-8270 */
+    for (int y = 0; y < height; y++) {
+      const uint8_t *s = src[0] + (size_t)y * irow[0];
+      for (int j = 0; j < hw; j++) {
+        const uint8_t y0 = s[2 * j * ips], y1 = s[2 * j * ips + ips];
+        const uint8_t u = (uint8_t)orc_cavg(cl, s[2 * j * ips + 1], s[2 * j * ips + 1 + ips]), v = (uint8_t)orc_cavg(cl, s[2 * j * ips + 2], s[2 * j * ips + 2 + ips]);
+        if (out_pal == P_422) {
+          dst[0][(size_t)y * width + 2 * j] = y0; dst[0][(size_t)y * width + 2 * j + 1] = y1;
+          dst[1][(size_t)y * hw + j] = u; dst[2][(size_t)y * hw + j] = v;
+        } else {
+          uint8_t *d = dst[0] + (size_t)y * width * 2 + 4 * j;
+          if (out_pal == P_UYVY) { d[0] = u; d[1] = y0; d[2] = v; d[3] = y1; }
+          else { d[0] = y0; d[1] = u; d[2] = y1; d[3] = v; }
+        }
+      }
+    }
+    return 0;
+  }
+  /* convert_uyvy_to_yuv422_frame / convert_yuyv_to_yuv422_frame :8093-8126: flat walks, compact on both sides */
+  if (inpk422 && out_pal == P_422) {
+    const int mw = width >> 1, yo = in_pal == P_UYVY ? 1 : 0, uo = in_pal == P_UYVY ? 0 : 1, vo = in_pal == P_UYVY ? 2 : 3;
+    if ((width & 1) || irow[0] != width * 2 || orow[0] != width || orow[1] != mw || orow[2] != mw) return -1;
+    for (size_t k = 0; k < (size_t)mw * height; k++) {
+      const uint8_t *m = src[0];                                  /* the source pointer is never advanced (:8102-8107, :8120-8125) */
+      dst[0][2 * k] = m[yo]; dst[0][2 * k + 1] = m[yo + 2]; dst[1][k] = m[uo]; dst[2][k] = m[vo];
+    }
+    return 0;
+  }
   /* UYVY / YUYV sources (:7800-7971): chroma replicated, no interpolation */
   if (inpk422) {
     const int mw = width >> 1, yo = in_pal == P_UYVY ? 1 : 0, uo = in_pal == P_UYVY ? 0 : 1, vo = in_pal == P_UYVY ? 2 : 3;

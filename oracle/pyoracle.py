@@ -298,4 +298,6 @@ def yuv_planes(pal, w, h, rng=None, fill=0x5A, pad=0):
 YUV_REPACK_PAIRS = [(544, 588, 1), (544, 589, 1), (545, 588, 1), (545, 589, 1), (588, 544, 1), (545, 544, 1), (544, 545, 1),
                     (588, 589, 1), (589, 588, 1), (564, 565, 1), (565, 564, 1), (512, 564, 0), (512, 565, 0), (512, 522, 1),
                     (544, 512, 1), (545, 512, 1), (544, 564, 0), (544, 565, 0), (545, 564, 0), (564, 544, 1), (565, 544, 1),
-                    (564, 545, 1), (564, 588, 1), (565, 588, 1), (564, 589, 1), (565, 589, 1), (564, 512, 0), (565, 512, 0)]
+                    (564, 545, 1), (564, 588, 1), (565, 588, 1), (564, 589, 1), (565, 589, 1), (564, 512, 0), (565, 512, 0),
+                    (588, 512, 0), (589, 512, 0), (588, 522, 0), (589, 522, 0), (588, 564, 0), (588, 565, 0), (589, 564, 0), (589, 565, 0),
+                    (564, 522, 0), (565, 522, 0)]

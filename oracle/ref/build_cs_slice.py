@@ -271,6 +271,15 @@ int csref_yuv_repack(int in_pal, int out_pal, uint8_t **src, int *irows_in, uint
   if (in444 && (out_pal == 512 || out_pal == 513)) { convert_yuvp_to_yuv420_frame(src, width, height, irows, orows, dst, clamping); return 0; }
   if (in444 && out_pal == 564) { convert_yuv_planar_to_uyvy_frame(src, width, height, irows[0], orows[0], (uyvy_macropixel *)dst[0], clamping); return 0; }
   if (in444 && out_pal == 565) { convert_yuv_planar_to_yuyv_frame(src, width, height, irows[0], orows[0], (yuyv_macropixel *)dst[0], clamping); return 0; }
+  if ((in_pal == 588 || in_pal == 589) && (out_pal == 512 || out_pal == 513)) { convert_yuv888_to_yuv420_frame(src[0], width, height, irows[0], orows, dst, in_pal == 589, clamping); return 0; }
+  if ((in_pal == 588 || in_pal == 589) && out_pal == 522) { convert_yuv888_to_yuv422_frame(src[0], width, height, irows[0], orows, dst, in_pal == 589, clamping); return 0; }
+  if ((in_pal == 588 || in_pal == 589) && out_pal == 564) { convert_yuv888_to_uyvy_frame(src[0], width, height, irows[0], orows[0], (uyvy_macropixel *)dst[0], in_pal == 589, clamping); return 0; }
+  if ((in_pal == 588 || in_pal == 589) && out_pal == 565) { convert_yuv888_to_yuyv_frame(src[0], width, height, irows[0], orows[0], (yuyv_macropixel *)dst[0], in_pal == 589, clamping); return 0; }
+  if (inpk && out_pal == 522) {
+    if (in_pal == 564) convert_uyvy_to_yuv422_frame((uyvy_macropixel *)src[0], width >> 1, height, dst);
+    else convert_yuyv_to_yuv422_frame((yuyv_macropixel *)src[0], width >> 1, height, dst);
+    return 0;
+  }
   if (inpk) {
     const int mw = width >> 1;
     if (out_pal == 544 || out_pal == 545) {
@@ -388,6 +397,8 @@ def main():
     parts.append(lines(cs, 7104, 7198))             # K5b: yuv420p -> uyvy / yuyv
     parts.append(lines(cs, 7500, 7753))             # K5b: yuv(a)444p -> uyvy / yuyv / yuv(a)888(8) / yuv(a)444p / yuv420p
     parts.append(lines(cs, 7800, 7971))             # K5b: uyvy / yuyv -> yuv(a)444p / yuv(a)888(8) / yuv420p
+    parts.append(lines(cs, 2461, 2474))             # K5b: uyvy_2_yuv422, yuyv_2_yuv422
+    parts.append(lines(cs, 8035, 8270))             # K5b: yuv(a)888(8) -> yuv420p / yuv422p / uyvy / yuyv, uyvy / yuyv -> yuv422p
     parts.append(lines(cs, 9198, 9257))             # K5b: convert_splitplanes_frame
     parts.append(lines(cs, 10578, 10639))           # K5b: convert_halve_chroma, convert_double_chroma
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family
