@@ -209,6 +209,12 @@ void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
    from the host's random generator and stay on the CPU.) */
 int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
                     int width, int height, int psize, double amount, void *stream);
+/* "deinterlace": lives-plugins/weed-plugins/deinterlace.c:45-308.  Packed palettes (WEED_PALETTE_* 1..5, 588, 589, 564, 565;
+   width in macropixels for UYVY / YUYV); src_d == dst_d = in place (the reference's out channel is CAN_DO_INPLACE).  Rows
+   r - 1 and r are written for every odd r < height - 2, everything else is left alone (alpha of 4-byte pixels: row r only,
+   out of place).  LGPU_E_UNSUPPORTED: planar palettes, ARGB32 out of place, a width that is not a multiple of 3 with rows
+   too tight for the last partial triple. */
+int lgpu_deinterlace(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette, void *stream);
 /* "slide over": lives-plugins/weed-plugins/slide_over.c:54-146.  amount = the transition parameter 0..255; direction 1..4 as
    sover_init stores it in "plugin_direction" (:40-51; 0 = random is drawn by the caller, :83-86); slide_lower / slide_upper =
    the "mlower" / "mupper" switches.  Packed pixels of 3 or 4 bytes, not in place. */

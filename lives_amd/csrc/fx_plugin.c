@@ -205,6 +205,10 @@ static int k_slide(const fxframe_t *f, weed_plant_t *inst, int kind) {
   return lgpu_slide_over(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
                          param_int(inst, 0, 0), dirn, param_bool(inst, 6, WEED_TRUE), param_bool(inst, 7, WEED_FALSE), NULL);
 }
+static int k_deint(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  (void)inst; (void)kind;
+  return lgpu_deinterlace(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -284,7 +288,7 @@ PROC(p_ckey, 2, 0, k_ckey, 0)
 PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
-PROC(p_slide, 2, 0, k_slide, 1)
+PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -461,6 +465,13 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
     if (fc) w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct);
     if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
+  }
+  /* deinterlace.c:312-327: "deinterlace", no parameters, out channel CAN_DO_INPLACE.  The planar palettes of the reference's list are
+     left out: its loop does nothing for them (pixel_size() == 0) or crashes (YUV444P) */
+  {
+    static const int32_t pk[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_YUV888, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32,
+                                 WEED_PALETTE_YUVA8888, WEED_PALETTE_UYVY, WEED_PALETTE_YUYV};
+    add_filter(pinfo, "deinterlace", 0, pk, 9, p_deint, 1, "in channel 0", NULL, "out channel 0", p, 0);
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

@@ -287,6 +287,58 @@ struct EdgeScratch { uint16_t *map = nullptr; size_t cap = 0; EdgeState *st = nu
 static std::mutex g_edge_mu;
 static std::map<std::pair<int, void *>, EdgeScratch> g_edge;
 
+
+static std::mutex g_deint_mu;
+static std::map<std::pair<int, void *>, std::pair<uint8_t *, size_t>> g_deint;   // per (device, stream) snapshot for in-place calls
+
+// deinterlace (deinterlace.c:45-308): one thread per pixel triple of one odd row r < height - 2; writes rows r - 1 and r
+struct DeintArgs {
+  const uint8_t *src;
+  uint8_t *dst;
+  int irow, orow, ntrip, height;
+  int psize, pcpy, green, packed422, copy_alpha;
+};
+__global__ __launch_bounds__(kBlock) void k_deinterlace(DeintArgs a) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.ntrip) return;
+  const int x = t * 3 * a.psize, xc = x + 2 * a.psize;
+  const int npairs = (a.height - 2) >> 1;                                   // odd rows 1, 3, .. < height - 2
+  for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
+    const int r = 2 * pr + 1;
+    const uint8_t *r0 = a.src + (size_t)(r - 1) * a.irow, *r1 = r0 + a.irow, *r2 = r1 + a.irow, *r3 = r2 + a.irow;
+    int m1, m2, m3, m4;
+    if (a.packed422) {
+      const int yo = a.packed422 == 1 ? 1 : 0;
+      m1 = (r0[x + yo] + r0[x + yo + 2] + r0[xc + yo] + r0[xc + yo + 2]) >> 2;
+      m2 = (r2[x + yo] + r2[x + yo + 2] + r2[xc + yo] + r2[xc + yo + 2]) >> 2;
+      m3 = (r1[x + yo] + r1[x + yo + 2] + r1[xc + yo] + r1[xc + yo + 2]) >> 2;
+      m4 = (r3[x + yo] + r3[x + yo + 2] + r3[xc + yo] + r3[xc + yo + 2]) >> 2;
+    } else {
+      m1 = (r0[x + a.green] + r0[xc + a.green]) >> 1; m2 = (r2[x + a.green] + r2[xc + a.green]) >> 1;
+      m3 = (r1[x + a.green] + r1[xc + a.green]) >> 1; m4 = (r3[x + a.green] + r3[xc + a.green]) >> 1;
+    }
+    const bool mix = abs(m1 - m2) + abs(m3 - m4) < abs(m1 - m4) + abs(m3 - m2);
+    // in place the triple's own bytes are read before they are written: gather everything first
+    uint8_t top[12], bot[12], al[3] = {0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (k < a.pcpy) {
+          const int i = x + p * a.psize + k;
+          top[p * 4 + k] = r1[i];
+          bot[p * 4 + k] = mix ? (uint8_t)((r1[i] + r3[i]) >> 1) : r2[i];
+        }
+    if (a.copy_alpha) { al[0] = r1[x + 3]; al[1] = r1[x + 7]; al[2] = r1[x + 11]; }
+    uint8_t *o0 = a.dst + (size_t)(r - 1) * a.orow, *o1 = o0 + a.orow;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (k < a.pcpy) { o0[x + p * a.psize + k] = top[p * 4 + k]; o1[x + p * a.psize + k] = bot[p * 4 + k]; }
+    if (a.copy_alpha) { o1[x + 3] = al[0]; o1[x + 7] = al[1]; o1[x + 11] = al[2]; }
+  }
+}
 }  // namespace lgpu
 
 using namespace lgpu;
@@ -477,3 +529,58 @@ extern "C" int lgpu_blurzoom_process(lgpu_blurzoom *z, const uint8_t *src_d, int
   return LGPU_OK;
 }
 
+
+extern "C" int lgpu_deinterlace(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  lgpu::DeintArgs a = {};
+  const bool inplace = (src_d == dst_d);
+  switch (palette) {
+  case 1: case 2: a.psize = 3; a.pcpy = 3; a.green = 1; break;
+  case 588: a.psize = 3; a.pcpy = 3; break;
+  case 3: case 4: a.psize = 4; a.pcpy = 3; a.green = 1; a.copy_alpha = !inplace; break;
+  case 589: a.psize = 4; a.pcpy = 3; a.copy_alpha = !inplace; break;
+  case 5:
+    a.psize = 4; a.pcpy = 3; a.green = 2;
+    if (!inplace) { lgpu::set_error("lgpu_deinterlace: ARGB32 out of place is declined (deinterlace.c:119: the triple walk drifts by one byte per triple)"); return LGPU_E_UNSUPPORTED; }
+    break;
+  case 564: a.psize = 4; a.pcpy = 4; a.packed422 = 1; break;
+  case 565: a.psize = 4; a.pcpy = 4; a.packed422 = 2; break;
+  default:
+    lgpu::set_error("lgpu_deinterlace: palette %d is not taken (planar frames: the reference's pixel_size() is 0 and its loop does nothing; YUV444P dereferences an unset pointer, deinterlace.c:146)", palette);
+    return LGPU_E_UNSUPPORTED;
+  }
+  LGPU_REQUIRE(irow >= width * a.psize && orow >= width * a.psize, "rowstride smaller than a row");
+  a.ntrip = (width + 2) / 3;
+  if (a.ntrip * 3 * a.psize > irow || a.ntrip * 3 * a.psize > orow) {
+    lgpu::set_error("lgpu_deinterlace: width %d is not a multiple of 3 and the rows have no room for the last partial triple (the reference then writes into the next row)", width);
+    return LGPU_E_UNSUPPORTED;
+  }
+  a.src = src_d; a.dst = dst_d; a.irow = irow; a.orow = orow; a.height = height;
+  const int npairs = (height - 2) >> 1;
+  if (npairs < 1) return LGPU_OK;
+  if (inplace) {
+    // the serial reference reads rows r + 1, r + 2 before the next row pair overwrites them: read from a snapshot
+    int dev = 0;
+    LGPU_HIP(hipGetDevice(&dev));
+    const size_t bytes = (size_t)irow * height;
+    uint8_t *snap;
+    {
+      std::lock_guard<std::mutex> lk(g_deint_mu);
+      auto &e = g_deint[std::make_pair(dev, stream)];
+      if (e.second < bytes) {
+        if (e.first) { LGPU_HIP(hipStreamSynchronize((hipStream_t)stream)); LGPU_HIP(hipFree(e.first)); e.first = nullptr; e.second = 0; }
+        if (hipMalloc((void **)&e.first, bytes) != hipSuccess) { lgpu::set_error("lgpu_deinterlace: hipMalloc(%zu) failed", bytes); return LGPU_E_NOMEM; }
+        e.second = bytes;
+      }
+      snap = e.first;
+    }
+    LGPU_HIP(hipMemcpyAsync(snap, src_d, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    a.src = snap;
+  }
+  const dim3 grid(cdiv((unsigned)a.ntrip, kBlock), (unsigned)(npairs < 2048 ? npairs : 2048));
+  hipLaunchKernelGGL(lgpu::k_deinterlace, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

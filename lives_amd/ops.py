@@ -112,6 +112,11 @@ def transition(kind, src1, src2, dst, width, height, psize, amount):
              float(amount), stream_ptr())
 
 
+def deinterlace(src, dst, width, height, palette):
+    """deinterlace.c:45-308; src is dst = in place"""
+    lib.call("lgpu_deinterlace", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, palette, stream_ptr())
+
+
 def slide_over(src1, src2, dst, width, height, psize, amount, direction, slide_lower=True, slide_upper=False):
     """slide_over.c:54-146; direction 1..4 as sover_init stores it"""
     lib.call("lgpu_slide_over", dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width, height, psize,

@@ -1592,3 +1592,59 @@ int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const i
   }
   return -1;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F9: deinterlace                         reference: lives-plugins/weed-plugins/deinterlace.c:45-308
+ * Packed palettes only (WEED_PALETTE_* numbers 1..5 RGB family, 588 / 589, 564 / 565): for a planar frame the reference's
+ * pixel_size() is 0 and its loop does nothing (:91, :112), and YUV444P dereferences a pointer it never sets (:146).
+ * Works on pixel triples of every odd row r < height - 2: row r - 1 <- row r; row r <- the mean of rows r and r + 2 where the
+ * alternate rows differ less than the consecutive ones, else row r + 1.  Bytes the reference does not write are left alone
+ * (alpha of 4-byte pixels is copied for row r only, :271-277).  -1: ARGB32 out of place (the `x++` at :119 makes the triple
+ * walk drift by one byte per triple), or rows too tight for the last partial triple (the reference then writes into the next row).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_deinterlace(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int palette) {
+  const int inplace = (src == dst);
+  int psize, pcpy, green = 0, packed422 = 0;
+  switch (palette) {
+  case 1: case 2: psize = 3; pcpy = 3; green = 1; break;
+  case 588: psize = 3; pcpy = 3; break;
+  case 3: case 4: psize = 4; pcpy = 3; green = 1; break;
+  case 589: psize = 4; pcpy = 3; break;
+  case 5: psize = 4; pcpy = 3; green = 2; if (!inplace) return -1; break;
+  case 564: psize = 4; pcpy = 4; packed422 = 1; break;
+  case 565: psize = 4; pcpy = 4; packed422 = 2; break;
+  default: return -1;
+  }
+  const int widthx = width * psize, ntrip = (width + 2) / 3;
+  if (ntrip * 3 * psize > irow || ntrip * 3 * psize > orow) return -1;
+  for (int r = 1; r < height - 2; r += 2) {
+    const uint8_t *r0 = src + (size_t)(r - 1) * irow, *r1 = src + (size_t)r * irow, *r2 = src + (size_t)(r + 1) * irow, *r3 = src + (size_t)(r + 2) * irow;
+    uint8_t *o0 = dst + (size_t)(r - 1) * orow, *o1 = dst + (size_t)r * orow;
+    for (int x = 0; x < widthx; x += 3 * psize) {
+      const int xc = x + 2 * psize;
+      int m1, m2, m3, m4;
+      if (packed422) {
+        const int yo = packed422 == 1 ? 1 : 0;
+        m1 = (r0[x + yo] + r0[x + yo + 2] + r0[xc + yo] + r0[xc + yo + 2]) >> 2;
+        m2 = (r2[x + yo] + r2[x + yo + 2] + r2[xc + yo] + r2[xc + yo + 2]) >> 2;
+        m3 = (r1[x + yo] + r1[x + yo + 2] + r1[xc + yo] + r1[xc + yo + 2]) >> 2;
+        m4 = (r3[x + yo] + r3[x + yo + 2] + r3[xc + yo] + r3[xc + yo + 2]) >> 2;
+      } else {
+        m1 = (r0[x + green] + r0[xc + green]) >> 1; m2 = (r2[x + green] + r2[xc + green]) >> 1;
+        m3 = (r1[x + green] + r1[xc + green]) >> 1; m4 = (r3[x + green] + r3[xc + green]) >> 1;
+      }
+      const int d1 = abs(m1 - m2) + abs(m3 - m4), d2 = abs(m1 - m4) + abs(m3 - m2);
+      uint8_t top[12], bot[12];
+      for (int p = 0; p < 3; p++)
+        for (int k = 0; k < pcpy; k++) {
+          const int i = x + p * psize + k;
+          top[p * 4 + k] = r1[i];
+          bot[p * 4 + k] = (d1 < d2) ? (uint8_t)((r1[i] + r3[i]) >> 1) : r2[i];
+        }
+      for (int p = 0; p < 3; p++)
+        for (int k = 0; k < pcpy; k++) { o0[x + p * psize + k] = top[p * 4 + k]; o1[x + p * psize + k] = bot[p * 4 + k]; }
+      if (!inplace && (palette == 3 || palette == 4 || palette == 589)) { o1[x + 3] = r1[x + 3]; o1[x + 7] = r1[x + 7]; o1[x + 11] = r1[x + 11]; }
+    }
+  }
+  return 0;
+}

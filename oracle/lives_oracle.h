@@ -126,6 +126,8 @@ void orc_transition(int type, const uint8_t *src1, int irow1, const uint8_t *src
 /* slide over (slide_over.c:54-146): dirn 1..4 as stored by sover_init, transval 0..255 */
 void orc_slide_over(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height,
                     int psize, int transval, int dirn, int mvlower, int mvupper);
+/* deinterlace (deinterlace.c:45-308), packed palettes; src == dst = in place; -1 = not taken */
+int orc_deinterlace(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int palette);
 
 /* F6a: "softlight"  lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV: the stencil runs on plane 0 (rows
    1..h-2, columns 1..w-2; the frame border is copied), the other planes are copied (:143-151).

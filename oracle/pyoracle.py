@@ -93,6 +93,7 @@ def oracle():
         _O.orc_cavg.argtypes = [ci, ci, ci]
         _O.orc_transition.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd]
         _O.orc_yuv_repack.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci]
+        _O.orc_deinterlace.argtypes = [vp, ci, vp, ci, ci, ci, ci]
         _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]

@@ -92,8 +92,28 @@ def main():
                     snames.append(key)
     so["records"] = np.array(snames)
     np.savez_compressed(os.path.join(OUT, "slide_over.npz"), **so)
+    # deinterlace (deinterlace.c): packed palettes, in place and out of place (ARGB32 in place only, see lives_oracle.c)
+    de, dnames = {}, []
+    for pal, ps in ((1, 3), (2, 3), (588, 3), (3, 4), (4, 4), (589, 4), (5, 4), (564, 4), (565, 4)):
+        for (w, h) in ((12, 9), (13, 8), (6, 4)):
+            for inplace in ((1,) if pal == 5 else (0, 1)):
+                s1 = structured(rng, w, h, ps)
+                if (w + 2) // 3 * 3 * ps > s1.strides[0]:
+                    continue
+                d = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                if inplace:
+                    H.run(po.refplugin("deinterlace"), "deinterlace", pal, w, h, [d], d, [])
+                else:
+                    H.run(po.refplugin("deinterlace"), "deinterlace", pal, w, h, [s1], d, [])
+                key = "de|%d|%d|%d|%d" % (pal, inplace, w, h)
+                de[key + "|a"], de[key + "|o"] = s1, d
+                dnames.append(key)
+    de["records"] = np.array(dnames)
+    np.savez_compressed(os.path.join(OUT, "deinterlace.npz"), **de)
     mpath = os.path.join(OUT, "manifest.json")
     man = json.load(open(mpath))
+    man["groups"]["deinterlace.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/deinterlace.c; record de|palette|in place|w|h "
+                                        "(w in macropixels for 564 / 565); a source, o result (out of place: destination pre-filled with 0x5A)")
     man["groups"]["slide_over.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/slide_over.c; record "
                                        "so|direction(1..4 as sover_init stores it)|palette|amount|slide lower|slide upper|w|h; a / b sources, o result")
     man["groups"]["stencils.npz"] = ("reference plugins built unmodified: lives-plugins/weed-plugins/softlight.c (sl|palette|w|h|clamping(0 clamped,1 unclamped), "

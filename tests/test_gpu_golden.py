@@ -280,3 +280,19 @@ def test_yuv_repack_vs_reference(gpu):
         gpu.yuv_repack(ip, op, src, dst, w, h, unc)
         for i, a in enumerate(want):
             assert (host(dst[i]) == a).all(), "%s plane %d" % (rec, i)
+
+
+def test_deinterlace_vs_reference_plugin(gpu):
+    g = gu.load("deinterlace.npz")
+    for rec in map(str, g["records"]):
+        _, pal, inplace, w, h = rec.split("|")
+        a, want = g[rec + "|a"], g[rec + "|o"]
+        ps = 3 if int(pal) in (1, 2, 588) else 4
+        n = (int(w) + 2) // 3 * 3 * ps                      # the last partial triple spills into the row padding, as in the reference
+        if inplace == "1":
+            d = dev(a)
+            gpu.deinterlace(d, d, int(w), int(h), int(pal))
+        else:
+            d = dev(np.full_like(a, 0x5A))
+            gpu.deinterlace(dev(a), d, int(w), int(h), int(pal))
+        assert (host(d)[:, :n] == want[:, :n]).all(), rec

@@ -397,6 +397,38 @@ def test_slide_over(gpu, orc, psize):
                     assert_same(host(d), want, w, h, psize, "slide over ps=%d %dx%d dir=%d amount=%d lower=%d upper=%d" % (psize, w, h, dirn, tv, mvl, mvu))
 
 
+@pytest.mark.parametrize("palette", [1, 2, 588, 3, 4, 589, 5, 564, 565])
+def test_deinterlace(gpu, orc, palette):
+    from lives_amd.lib import LgpuError
+    rng = np.random.default_rng(2700 + palette)
+    ps = 3 if palette in (1, 2, 588) else 4
+    for (w, h) in [(12, 9), (30, 16), (33, 17), (300, 51), (64, 3), (9, 4), (31, 10)]:
+        for inplace in ((1,) if palette == 5 else (0, 1)):
+            s1 = frame(rng, w, h, ps)
+            # smooth vertical structure with comb rows so that both branches of the decision occur
+            s1[1::2] = (s1[1::2] >> 2) + 160
+            s1[0::2] = (s1[0::2] >> 2) + (rng.integers(0, 2, (s1[0::2].shape[0], 1), dtype=np.uint8) * 120)
+            n = (w + 2) // 3 * 3 * ps
+            if n > s1.strides[0]:
+                with pytest.raises(LgpuError):
+                    gpu.deinterlace(dev(s1), dev(s1.copy()), w, h, palette)
+                continue
+            want = s1.copy() if inplace else np.full_like(s1, 0x5A)
+            src = want if inplace else s1
+            assert orc.orc_deinterlace(P(src), src.strides[0], P(want), want.strides[0], w, h, palette) == 0
+            if inplace:
+                d = dev(s1)
+                gpu.deinterlace(d, d, w, h, palette)
+            else:
+                d = dev(np.full_like(s1, 0x5A))
+                gpu.deinterlace(dev(s1), d, w, h, palette)
+            assert (host(d)[:, :n] == want[:, :n]).all(), "deinterlace pal=%d %dx%d inplace=%d" % (palette, w, h, inplace)
+    if palette == 5:
+        a = frame(rng, 12, 8, 4)
+        with pytest.raises(LgpuError):
+            gpu.deinterlace(dev(a), dev(a.copy()), 12, 8, 5)
+
+
 # ---------------------------------------------------------------------------------------------- K5b YUV -> YUV repacks
 @pytest.mark.parametrize("pair", po.YUV_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
 def test_yuv_repack(gpu, orc, pair):

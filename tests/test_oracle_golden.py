@@ -320,3 +320,14 @@ def test_yuv_repack(orc):
         assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(gp), ctypes.addressof(gs), w, h, unc, 0) == 0
         for i, a in enumerate(want):
             assert (got[i] == a).all(), "%s plane %d" % (rec, i)
+
+
+def test_deinterlace(orc):
+    g = gu.load("deinterlace.npz")
+    for rec in map(str, g["records"]):
+        _, pal, inplace, w, h = rec.split("|")
+        a, want = g[rec + "|a"], g[rec + "|o"]
+        got = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
+        src = got if inplace == "1" else a
+        assert orc.orc_deinterlace(P(src), src.strides[0], P(got), got.strides[0], int(w), int(h), int(pal)) == 0
+        assert (got == want).all(), rec

@@ -22,13 +22,15 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 23
-    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over"):
+    assert len(ours) == 24
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
             if rf["name"].endswith("luma overlay") or rf["name"] == "luma underlay":
                 assert o["palettes"] == [1, 2, 3, 4]          # ARGB32 luma blends declined
+            elif rf["name"] == "deinterlace":
+                assert o["palettes"] == [p for p in rf["palettes"] if p not in (544, 545, 512, 513, 522)]   # planar: the reference does nothing / crashes
             else:
                 assert o["palettes"] == rf["palettes"], rf["name"]
             assert not (o["flags"] & 64), "a GPU filter must not advertise WEED_FILTER_HINT_MAY_THREAD"
@@ -175,3 +177,21 @@ def test_slide_over_records_through_the_plugin():
         H.run(OURS, "slide over", pal, w, h, [g[rec + "|a"].copy(), g[rec + "|b"].copy()], d,
               [po.p_int(int(tv))] + radios + [po.p_bool(int(mvl)), po.p_bool(int(mvu))])
         assert (d[:, :w * PSIZE[pal]] == g[rec + "|o"][:, :w * PSIZE[pal]]).all(), rec
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_deinterlace_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("deinterlace.npz")
+    for rec in map(str, g["records"]):
+        _, pal, inplace, w, h = rec.split("|")
+        a, want = g[rec + "|a"], g[rec + "|o"]
+        if inplace == "1":
+            d = a.copy()
+            H.run(OURS, "deinterlace", int(pal), int(w), int(h), [d], d, [])
+        else:
+            d = np.full_like(a, 0x5A)
+            H.run(OURS, "deinterlace", int(pal), int(w), int(h), [a.copy()], d, [])
+        n = (int(w) + 2) // 3 * 3 * (3 if int(pal) in (1, 2, 588) else 4)
+        assert (d[:, :n] == want[:, :n]).all(), rec
