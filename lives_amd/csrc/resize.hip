@@ -1456,16 +1456,20 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
   return LGPU_OK;
 }
 
-// scratch for the multi-launch paths (per device; grown on demand, never shrunk)
+// scratch for the multi-launch paths: per (device, stream), so that host threads working on their own streams never share
+// an intermediate; grown on demand, never shrunk
+// held across the launches of one multi-launch sequence: two host threads on the same stream must not interleave
+// (writer A, writer B, reader A) on the shared intermediate
+static std::mutex g_multi_mu;
 static std::mutex g_scratch_mu;
-static std::map<int, std::pair<void *, size_t>> g_scratch;
-static int get_scratch(size_t bytes, void **out) {
+static std::map<std::pair<int, hipStream_t>, std::pair<void *, size_t>> g_scratch;
+static int get_scratch(size_t bytes, hipStream_t st, void **out) {
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_scratch_mu);
-  auto &s = g_scratch[dev];
+  auto &s = g_scratch[std::make_pair(dev, st)];
   if (s.second < bytes) {
-    if (s.first) { LGPU_HIP(hipDeviceSynchronize()); LGPU_HIP(hipFree(s.first)); s.first = nullptr; s.second = 0; }
+    if (s.first) { LGPU_HIP(hipStreamSynchronize(st)); LGPU_HIP(hipFree(s.first)); s.first = nullptr; s.second = 0; }
     if (hipMalloc(&s.first, bytes) != hipSuccess) { set_error("hipMalloc(%zu) for scratch failed", bytes); return LGPU_E_NOMEM; }
     s.second = bytes;
   }
@@ -1534,7 +1538,8 @@ extern "C" int lgpu_resize(const uint8_t *src_d, int irow, int sw, int sh, uint8
   // generic: horizontal into an int16 scratch, then vertical
   void *scratch;
   const size_t need = sizeof(int16_t) * (size_t)sh * dw * psize;
-  if ((rc = get_scratch(need, &scratch))) return rc;
+  std::lock_guard<std::mutex> seq(g_multi_mu);
+  if ((rc = get_scratch(need, st, &scratch))) return rc;
   unsigned gy = (unsigned)(sh > 2048 ? 2048 : sh);
   hipLaunchKernelGGL(k_hpass_generic, dim3(cdiv((unsigned)(dw * psize), kBlock), gy), dim3(kBlock), 0, st, src_d, irow, sw, sh,
                      (int16_t *)scratch, dw, psize, hb->pos, hb->co, hb->nt, 64, 7);
@@ -1573,7 +1578,8 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
     return launch_sep(p, t, l, st);
   }
   void *scratch;
-  if ((rc = get_scratch(sizeof(int16_t) * (size_t)height * width * psize, &scratch))) return rc;
+  std::lock_guard<std::mutex> seq(g_multi_mu);
+  if ((rc = get_scratch(sizeof(int16_t) * (size_t)height * width * psize, st, &scratch))) return rc;
   unsigned gy = (unsigned)(height > 2048 ? 2048 : height);
   hipLaunchKernelGGL(k_hpass_generic, dim3(cdiv((unsigned)(width * psize), kBlock), gy), dim3(kBlock), 0, st, src_d, irow, width, height,
                      (int16_t *)scratch, width, psize, hb->pos, hb->co, 5, 0, 0);
@@ -1621,7 +1627,8 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   LGPU_REQUIRE(!same, "chain needs a resize stage");
   void *scratch;
   const size_t per = (size_t)pr->dw * 4 * pr->dh;
-  if ((rc = get_scratch(per * ntracks, &scratch))) return rc;
+  std::lock_guard<std::mutex> seq(g_multi_mu);
+  if ((rc = get_scratch(per * ntracks, st, &scratch))) return rc;
   if ((rc = get_bank(pr->sw, pr->dw, kernel, &hb)) || (rc = get_bank(pr->sh, pr->dh, kernel, &vb))) return rc;
   if ((rc = get_bank(pr->dw, pr->dw, 100, &gh)) || (rc = get_bank(pr->dh, pr->dh, 100, &gv))) return rc;
   SepPlan p1, p2;

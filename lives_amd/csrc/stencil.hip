@@ -285,6 +285,9 @@ __global__ __launch_bounds__(kBlock) void k_bz_color(const uint32_t *src, int ir
 // per (device, stream) scratch: gradient map + state
 struct EdgeScratch { uint16_t *map = nullptr; size_t cap = 0; EdgeState *st = nullptr; };
 static std::mutex g_edge_mu;
+// held across the launches of one multi-launch sequence (edge passes, in-place deinterlace): host threads that share a stream
+// must not interleave their sequences on the shared scratch
+static std::mutex g_seq_mu;
 static std::map<std::pair<int, void *>, EdgeScratch> g_edge;
 
 
@@ -382,6 +385,7 @@ extern "C" int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int oro
   hipStream_t st = (hipStream_t)stream;
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> seq(g_seq_mu);
   EdgeScratch sc;
   {
     std::lock_guard<std::mutex> lk(g_edge_mu);
@@ -560,7 +564,9 @@ extern "C" int lgpu_deinterlace(const uint8_t *src_d, int irow, uint8_t *dst_d, 
   a.src = src_d; a.dst = dst_d; a.irow = irow; a.orow = orow; a.height = height;
   const int npairs = (height - 2) >> 1;
   if (npairs < 1) return LGPU_OK;
+  std::unique_lock<std::mutex> seq(g_seq_mu, std::defer_lock);
   if (inplace) {
+    seq.lock();
     // the serial reference reads rows r + 1, r + 2 before the next row pair overwrites them: read from a snapshot
     int dev = 0;
     LGPU_HIP(hipGetDevice(&dev));
