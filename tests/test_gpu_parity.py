@@ -654,3 +654,45 @@ def test_chain_matches_oracle_and_unfused(gpu, orc, do_blur):
                 gpu.blend_chroma(rs, d_l2[i], rs, dw, dh, 4, bf)
                 gpu.gamma_apply(rs, dw, dh, 4, lut)
                 assert_same(host(rs), wants[i], dw, dh, 4, "unfused chain")
+
+
+# ---------------------------------------------------------------------------------------------- host threads
+def test_multi_launch_paths_from_two_host_threads(gpu):
+    """LiVES calls from several host threads; the multi-launch paths (chain with blur, in-place deinterlace, edge) keep their
+    intermediates per (device, stream) and enqueue each sequence atomically: results equal the single-threaded ones"""
+    import threading
+    import torch
+    rng = np.random.default_rng(2800)
+    sw, sh, dw, dh = 384, 216, 192, 108
+    jobs = []
+    for t in range(2):
+        src, l2 = frame(rng, sw, sh, 4), frame(rng, dw, dh, 4, alpha_mix=True)
+        de = frame(rng, 300, 120, 3)
+        jobs.append(dict(src=dev(src), l2=dev(l2), de=dev(de), ed=dev(frame(rng, 320, 200, 4))))
+
+    def run(j, out):
+        d = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda")
+        prm = gpu.chain_params(sw, sh, j["src"].stride(0), dw, dh, j["l2"].stride(0), d.stride(0), do_blur=1, bf=100)
+        gpu.chain(prm, gpu.chain_tracks([j["src"]], [j["l2"]], [d]))
+        x = j["de"].clone()
+        gpu.deinterlace(x, x, 300, 120, 1)
+        e = torch.zeros_like(j["ed"])
+        gpu.edge(j["ed"], e, 320, 200, 3, 2)
+        torch.cuda.synchronize()
+        out.append((host(d), host(x), host(e)))
+
+    want = []
+    for j in jobs:
+        o = []
+        run(j, o)
+        want.append(o[0])
+    for _ in range(10):
+        outs = [[], []]
+        th = [threading.Thread(target=run, args=(jobs[i], outs[i])) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for i in range(2):
+            for a, b in zip(outs[i][0], want[i]):
+                assert (a == b).all()
