@@ -85,7 +85,8 @@ int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int height, int
 /* ---- K2: planar YUV 4:2:0 / 4:2:2 -> packed RGB; replaces convert_yuv420p_to_rgb_frame
    (src/colourspace.c:3260-3904; the BGR / ARGB twins :3927-5114 share the maths).
    out_order 0 = RGB(A), 1 = BGR(A), 2 = ARGB; opsize 3 or 4; which_tables as lgpu_conversion_tables;
-   pb_quality 1 (LOW) / 2 (MED, default); HIGH (3) is LGPU_E_UNSUPPORTED.
+   pb_quality 1 (LOW) / 2 (MED, default) / 3 (HIGH, the render setting: its float rounding in _spc_rnd :832-835 is
+   bit-identical to MED once clamped, see yuv.hip).
    lut8 (HOST, may be NULL) fuses the gamma_convert_layer() pass that follows in BASELINE config 2.
    flags: LGPU_YUV_FIX_EDGES = write the evident intent into the last row instead of replicating the
    reference's row-0-luma behaviour. */

@@ -47,7 +47,7 @@ typedef struct {
 typedef struct {
   int apply_gamma;      /* default 1 */
   int alpha_post;       /* default 0 */
-  int pb_quality;       /* 1 LOW, 2 MED (default) */
+  int pb_quality;       /* 1 LOW, 2 MED (default), 3 HIGH (render; same results as MED) */
   double screen_gamma;  /* default 1.4 (DEF_SCREEN_GAMMA) */
   int device;           /* HIP device ordinal, default 0 */
 } lives_gpu_prefs;

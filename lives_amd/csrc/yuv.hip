@@ -188,7 +188,11 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   LGPU_REQUIRE(orow >= width * opsize, "output rowstride smaller than a row");
   LGPU_REQUIRE(opsize == 3 || (((uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0, "4-byte output must be 4-byte aligned");
   LGPU_REQUIRE(u_size > 0 && v_size > 0, "chroma plane sizes required");
-  if (pb_quality == 3) { set_error("pb_quality HIGH (float rounding of spc_rnd) is not implemented on the GPU path"); return LGPU_E_UNSUPPORTED; }
+  // pb_quality HIGH (3, what init_conversions() selects for rendering / transcoding, :2104-2108) only changes _spc_rnd (:832-835):
+  // (int)((float)val / 65536.) instead of val >> 16.  (float)val is exact below 2^24 and every larger sum clamps to 255 either way;
+  // for negative sums truncation and floor both end below the lower clamp: bit-identical to MED after CLAMP0255f / the Y, UV clamps
+  // (tests/test_oracle_cpu.py checks the reference slices with both settings, and the scalar identity exhaustively).
+  LGPU_REQUIRE(pb_quality >= 1 && pb_quality <= 3, "pb_quality is 1 (LOW), 2 (MED) or 3 (HIGH)");
   const DeviceTables *t = device_tables();
   YuvArgs a;
   a.y = y_d; a.u = u_d; a.v = v_d; a.dst = dst_d; a.tables = t->yuv2rgb[which_tables & 3];
@@ -200,7 +204,9 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   a.lut16 = lut16_d;
   const Lut8 l = pack_lut(lut8);
   const int units = is_422 ? height : height / 2 + 1;
-  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > 2048 ? 2048 : units), 1);
+  // every workgroup stages 5 KB of tables first: a few hundred workgroups that each walk several row pairs, not one per row pair
+  static const int gy_cap = getenv("LGPU_YUV_GY") ? atoi(getenv("LGPU_YUV_GY")) : 2048;
+  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > gy_cap ? gy_cap : units), 1);
   if (is_422) hipLaunchKernelGGL(k_yuv422p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l);
   else hipLaunchKernelGGL(k_yuv420p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l);
   LGPU_CHECK_LAUNCH();

@@ -126,7 +126,7 @@ def k2_mask(w, h, is_422):
 
 @pytest.mark.parametrize("which", range(4))
 @pytest.mark.parametrize("opsize", [3, 4])
-@pytest.mark.parametrize("quality", [1, 2])
+@pytest.mark.parametrize("quality", [1, 2, 3])      # 3 = HIGH: the oracle takes the float path of _spc_rnd, the GPU the shift
 def test_yuv420p_to_rgb(gpu, orc, which, opsize, quality):
     rng = np.random.default_rng(300 + which * 10 + opsize)
     for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 18, 160, 80), (2, 2, 32, 16), (640, 480, 640, 320)]:

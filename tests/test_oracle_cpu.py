@@ -126,3 +126,52 @@ def test_gauss5_spec_properties(orc):
     k = np.array([1, 4, 6, 4, 1])
     want = (np.outer(k, k) * 255 + 128) >> 8
     assert (dst[3:8, 3:8] == want).all() and dst.sum() == want.sum()
+
+
+def test_spc_rnd_high_equals_med_once_clamped():
+    """_spc_rnd (src/colourspace.c:832-835): pb_quality HIGH returns (int)((float)val / 65536.), everything else val >> 16.
+    After any of the clamps that follow it (0..255, 16..235, 16..240) the two agree for every 32-bit sum the tables can make."""
+    for lo in range(-2 ** 26, 2 ** 26, 2 ** 22):
+        v = np.arange(lo, lo + 2 ** 22, dtype=np.int64)
+        med = v >> 16
+        hi = np.trunc(v.astype(np.float32).astype(np.float64) / 65536.0).astype(np.int64)
+        for (a, b) in ((0, 255), (16, 235), (16, 240)):
+            assert np.array_equal(np.clip(med, a, b), np.clip(hi, a, b))
+
+
+@needs_ref
+def test_reference_slices_agree_between_pb_quality_high_and_med():
+    R = po.csref()
+    P = po.P
+
+    def run(pbq):
+        R.csref_set_prefs(pbq, 1, 1.4)
+        rng = np.random.default_rng(31)
+        outs = []
+        w, h = 64, 16
+        for in_order in (0, 1):
+            for out_fmt in range(6):
+                for which in ((0, 1, 2, 3) if out_fmt >= 4 else (0, 1)):
+                    src = rng.integers(0, 256, (h, w * 3), dtype=np.uint8)
+                    src[0, :6] = [0, 0, 0, 255, 255, 255]
+                    out, _ = po.k4_out_planes(0x5A, w, h, out_fmt, 0)
+                    op, os_ = po.planes_args(out)
+                    assert R.csref_k4(in_order, 0, out_fmt, 0, P(src), src.strides[0], w, h, ctypes.addressof(op), ctypes.addressof(os_), which & 1, which >> 1) == 0
+                    outs += [a.copy() for a in out]
+        for which in range(4):
+            planes = [rng.integers(0, 256, (h + 1, w * 3), dtype=np.uint8)[:h]]
+            sp, ss = po.planes_args(planes)
+            dst = np.zeros((h, w * 4), np.uint8)
+            assert R.csref_k3(0, 0, 0, 1, ctypes.addressof(sp), ctypes.addressof(ss), w, h, P(dst), dst.strides[0], which & 1, which >> 1) == 0
+            outs.append(dst)
+            y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            u, v = (rng.integers(0, 256, (h // 2 + 1, w // 2), dtype=np.uint8)[:h // 2] for _ in range(2))
+            ist = (ctypes.c_int * 3)(w, w // 2, w // 2)
+            dst = np.zeros((h, w * 4), np.uint8)
+            R.csref_yuv420p_to_rgb(P(y), P(u), P(v), w, h, ist, dst.strides[0], P(dst), 1, 0, which & 1, 2 if which & 2 else 1, None)
+            outs.append(dst)
+        return outs
+
+    med, high = run(2), run(3)
+    R.csref_set_prefs(2, 1, 1.4)
+    assert len(med) == len(high) and all(np.array_equal(a, b) for a, b in zip(med, high))
