@@ -1648,3 +1648,108 @@ int orc_deinterlace(const uint8_t *src, int irow, uint8_t *dst, int orow, int wi
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F10: RGBdelay / YUVdelay                reference: lives-plugins/weed-plugins/RGBdelay.c:36-431
+ * Stateful: a ring of up to 50 compact frames; per cached frame j the channels switched on are scaled through a LUT
+ * (strength normalised per channel over all enabled frames) and ADDED into the output with 8-bit wrap-around.
+ * on[3 * j + c] = the RED_ON / GREEN_ON / BLUE_ON switches, strength[j] = STRENGTH(j), for j = 0..50 (:129-132).
+ * The host-ease path (:180-183, :407-412) is not taken (no "ease_out" leaf): the cache always ramps up.
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_rgbdelay { int ccache, tcache; uint8_t *cache[51]; int is_bgr[51]; };
+
+orc_rgbdelay *orc_rgbdelay_new(void) { return (orc_rgbdelay *)calloc(1, sizeof(orc_rgbdelay)); }
+void orc_rgbdelay_free(orc_rgbdelay *s) {
+  if (!s) return;
+  for (int i = 0; i < s->tcache; i++) free(s->cache[i]);
+  free(s);
+}
+static void rgbd_make_lut(uint8_t *lut, double val, int min) {            /* make_lut :36-52 */
+  int mina = min, minb = 0;
+  double rnd = 0.5;
+  if (min < 0) { mina = 0; minb = -min; rnd += (double)minb; }
+  for (int i = 0; i < 256; i++) {
+    double rval = (double)(i - mina) * val + rnd;
+    if (rval < 0.) rval = 0.;
+    if (rval > 255.) rval = 255.;
+    lut[i] = (uint8_t)rval;
+  }
+}
+int orc_rgbdelay_process(orc_rgbdelay *s, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int palette,
+                         int yuv_clamped, int maxcache, const int *on, const double *strength) {
+  const int wb = width * 3, inplace = (src == dst);
+  const int is_bgr = (palette == 2), is_yuv = (palette == 588);
+  double tstr[3] = {0., 0., 0.}, yscale = 1., uvscale = 1.;
+  int yuvmin = 0, uvmin = 0, maxneeded = 0;
+  uint8_t lut[3][256], *tmpcache = NULL;
+  if (palette != 1 && palette != 2 && palette != 588) return -1;
+  if (maxcache < 0) maxcache = 0; else if (maxcache > 50) maxcache = 50;
+  for (int i = 1; i < maxcache; i++) if (on[3 * i] || on[3 * i + 1] || on[3 * i + 2]) maxneeded = i + 1;   /* :186-193 */
+  if (maxneeded != s->tcache) {                                                                          /* realloc_cache :54-91 */
+    for (int i = s->tcache; i > maxneeded; i--) { free(s->cache[i - 1]); s->cache[i - 1] = NULL; }
+    for (int i = s->tcache; i < maxneeded; i++) s->cache[i] = (uint8_t *)malloc((size_t)wb * height);
+    s->tcache = maxneeded;
+    if (s->ccache > s->tcache) s->ccache = s->tcache;
+  }
+  if (s->tcache > 1) tmpcache = s->cache[s->tcache - 1];
+  for (int i = s->tcache - 1; i >= 0; i--) {                                                             /* :208-228 */
+    if (i > 0) { s->cache[i] = s->cache[i - 1]; s->is_bgr[i] = s->is_bgr[i - 1]; }
+    for (int c = 0; c < 3; c++) if (on[3 * i + c]) tstr[c] += strength[i];
+  }
+  s->is_bgr[0] = is_bgr;
+  if (s->tcache > 0) {
+    for (int y = 0; y < height; y++) memcpy(tmpcache + (size_t)y * wb, src + (size_t)y * irow, (size_t)wb);
+    s->cache[0] = tmpcache;
+  }
+  for (int c = 0; c < 3; c++) if (tstr[c] < 1.) tstr[c] = 1.;
+  if (is_yuv && yuv_clamped) { yuvmin = 16; uvmin = 16; yscale = 255. / 219.; uvscale = 255. / 224.; }
+  if (s->tcache == 0) {                                                                                  /* :254-309 */
+    int b[3] = {on[0] != 0, on[1] != 0, on[2] != 0}, red = 0, blue = 2;
+    const double cstr = strength[0];
+    if (is_bgr) { const int t = b[0]; b[0] = b[2]; b[2] = t; red = 2; blue = 0; }
+    rgbd_make_lut(lut[red], cstr / tstr[0] * yscale, yuvmin);
+    rgbd_make_lut(lut[1], cstr / tstr[1] * uvscale, yuvmin);
+    rgbd_make_lut(lut[blue], cstr / tstr[2] * uvscale, yuvmin);
+    for (int y = 0; y < height; y++) {
+      const uint8_t *sp = src + (size_t)y * irow;
+      uint8_t *dp = dst + (size_t)y * orow;
+      for (int i = 0; i < wb; i += 3) {
+        if (b[0]) dp[i] = lut[0][sp[i]]; else if (inplace) dp[i] = (uint8_t)yuvmin;
+        if (b[1]) dp[i + 1] = lut[1][sp[i + 1]]; else if (inplace) dp[i + 1] = (uint8_t)uvmin;
+        if (b[2]) dp[i + 2] = lut[2][sp[i + 2]]; else if (inplace) dp[i + 2] = (uint8_t)uvmin;
+      }
+    }
+  } else {
+    memset(dst, 0, (size_t)orow * height);                                                               /* :311 */
+    for (int j = 0; j < s->tcache; j++) {
+      const int k = (j <= s->ccache) ? j : s->ccache;
+      int b[3] = {on[3 * j] != 0, on[3 * j + 1] != 0, on[3 * j + 2] != 0}, red, blue;
+      if (!b[0] && !b[1] && !b[2] && j > 0) continue;
+      const int cross = ((!is_bgr && s->is_bgr[j]) || (is_bgr && !s->is_bgr[j])) ? 2 : 0;
+      const double cstr = strength[j];
+      if (s->is_bgr[j]) { const int t = b[0]; b[0] = b[2]; b[2] = t; red = 2; blue = 0; } else { red = 0; blue = 2; }
+      rgbd_make_lut(lut[red], cstr / tstr[0] * yscale, yuvmin);
+      rgbd_make_lut(lut[1], cstr / tstr[1] * uvscale, yuvmin);
+      rgbd_make_lut(lut[blue], cstr / tstr[2] * uvscale, yuvmin);
+      for (int y = 0; y < height; y++) {
+        const uint8_t *cp = s->cache[k] + (size_t)y * wb;
+        uint8_t *dp = dst + (size_t)y * orow;
+        for (int i = 0; i < wb; i += 3) {
+          if (b[0]) dp[i] = (uint8_t)(dp[i] + lut[0][cp[i + cross]]);
+          if (b[1]) dp[i + 1] = (uint8_t)(dp[i + 1] + lut[1][cp[i + 1]]);
+          if (b[2]) dp[i + 2] = (uint8_t)(dp[i + 2] + lut[2][cp[i + 2 - cross]]);
+        }
+      }
+    }
+  }
+  if (is_yuv && yuvmin == 16) {                                                                          /* :393-403 */
+    rgbd_make_lut(lut[0], 1. / yscale, -yuvmin);
+    rgbd_make_lut(lut[1], 1. / uvscale, -yuvmin);
+    for (int y = 0; y < height; y++) {
+      uint8_t *dp = dst + (size_t)y * orow;
+      for (int i = 0; i < wb; i += 3) { dp[i] = lut[0][dp[i]]; dp[i + 1] = lut[1][dp[i + 1]]; dp[i + 2] = lut[1][dp[i + 2]]; }
+    }
+  }
+  if (s->ccache < s->tcache) s->ccache++;                                                                /* :413-416 */
+  return 0;
+}

@@ -148,6 +148,13 @@ typedef struct orc_blurzoom orc_blurzoom;
 orc_blurzoom *orc_blurzoom_new(int width, int height, int palette);
 int orc_blurzoom_process(orc_blurzoom *bz, const uint8_t *src, int irow, uint8_t *dst, int orow, int mode, int pattern);
 void orc_blurzoom_free(orc_blurzoom *bz);
+/* RGBdelay / YUVdelay (RGBdelay.c:36-431), stateful; palette 1 RGB24, 2 BGR24, 588 YUV888; on[3 * j + c] / strength[j] for the 51
+   parameter groups; src == dst = in place */
+typedef struct orc_rgbdelay orc_rgbdelay;
+orc_rgbdelay *orc_rgbdelay_new(void);
+int orc_rgbdelay_process(orc_rgbdelay *s, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int palette,
+                         int yuv_clamped, int maxcache, const int *on, const double *strength);
+void orc_rgbdelay_free(orc_rgbdelay *s);
 
 /* C1: "compositor" fan-in  lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel), :167-178 (background),
    :181-189 (z order), :288-293 (paint loop).  Layers arrive already scaled (the reference scales with gdk-pixbuf, which

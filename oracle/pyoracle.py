@@ -101,6 +101,10 @@ def oracle():
         _O.orc_blurzoom_new.argtypes = [ci, ci, ci]
         _O.orc_blurzoom_process.argtypes = [vp, vp, ci, vp, ci, ci, ci]
         _O.orc_blurzoom_free.argtypes = [vp]
+        _O.orc_rgbdelay_new.restype = vp
+        _O.orc_rgbdelay_new.argtypes = []
+        _O.orc_rgbdelay_process.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp]
+        _O.orc_rgbdelay_free.argtypes = [vp]
         _O.orc_composite.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci]
         _O.orc_edge.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci]
         _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
@@ -171,6 +175,7 @@ class RefHost:
         self.H.refhost_num_filters.argtypes = [vp]
         self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
         self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
+        self.H.refhost_set_yuv_clamping.argtypes = [ci]
         self.plugins = {}
 
     def load(self, path):

@@ -235,6 +235,10 @@ def main():
     gen_golden_lut16.main()
     import gen_golden_blurzoom          # stateful blurzoom over frame sequences
     gen_golden_blurzoom.main()
+    import gen_golden_repack            # YUV -> YUV repacks (K5b)
+    gen_golden_repack.main()
+    import gen_golden_rgbdelay          # stateful RGBdelay / YUVdelay over frame sequences
+    gen_golden_rgbdelay.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

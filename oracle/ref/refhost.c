@@ -103,6 +103,10 @@ static weed_plant_t *find_filter(weed_plant_t *pinfo, const char *fname) {
   return ret;
 }
 
+/* YUV_clamping leaf for the channels made from now on (-1 = none): "YUVdelay" reads it (RGBdelay.c:236) */
+static int g_yuv_clamping = -1;
+void refhost_set_yuv_clamping(int clamping) { g_yuv_clamping = clamping; }
+
 static weed_plant_t *mk_channel(weed_plant_t *tmpl, int pal, int w, int h, int stride, void *pd) {
   weed_plant_t *c = weed_plant_new(WEED_PLANT_CHANNEL);
   weed_set_plantptr_value(c, WEED_LEAF_TEMPLATE, tmpl);
@@ -111,6 +115,7 @@ static weed_plant_t *mk_channel(weed_plant_t *tmpl, int pal, int w, int h, int s
   weed_set_int_value(c, WEED_LEAF_CURRENT_PALETTE, pal);
   weed_set_int_value(c, WEED_LEAF_ROWSTRIDES, stride);
   weed_set_voidptr_value(c, WEED_LEAF_PIXEL_DATA, pd);
+  if (g_yuv_clamping >= 0) weed_set_int_value(c, WEED_LEAF_YUV_CLAMPING, g_yuv_clamping);
   return c;
 }
 
@@ -126,14 +131,14 @@ int refhost_run(void *pinfo_v, const char *fname, int pal, int w, int h,
                 int nparams, const refhost_param_t *params, int nslices) {
   weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
   weed_plant_t *filt = find_filter(pinfo, fname);
-  weed_plant_t *inst, *inch[4], *outch, **ictm, **octm, **iptm, *inpar[16];
+  weed_plant_t *inst, *inch[4], *outch, **ictm, **octm, **iptm, *inpar[256];
   weed_init_f init_func;
   weed_process_f process_func;
   weed_deinit_f deinit_func;
   int nict = 0, noct = 0, nipt = 0, i, ret = WEED_SUCCESS, flags;
 
   if (!filt) { fprintf(stderr, "refhost: filter '%s' not found\n", fname); return -100; }
-  if (nin > 4 || nparams > 16) return -101;
+  if (nin > 4 || nparams > 256) return -101;
 
   ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
   octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
@@ -267,13 +272,13 @@ int refhost_run_seq(void *pinfo_v, const char *fname, int pal, int w, int h, int
                     uint8_t **src, int istride, uint8_t **dst, int ostride, int nparams, const refhost_param_t *params) {
   weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
   weed_plant_t *filt = find_filter(pinfo, fname);
-  weed_plant_t *inst, *inch, *outch, **ictm, **octm, **iptm, *inpar[16];
+  weed_plant_t *inst, *inch, *outch, **ictm, **octm, **iptm, *inpar[256];
   weed_init_f init_func;
   weed_process_f process_func;
   weed_deinit_f deinit_func;
   int nict = 0, noct = 0, nipt = 0, i, ret = WEED_SUCCESS;
   if (!filt) { fprintf(stderr, "refhost: filter '%s' not found\n", fname); return -100; }
-  if (nparams > 16) return -101;
+  if (nparams > 256) return -101;
   ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
   octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
   iptm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_PARAMETER_TEMPLATES, &nipt);
