@@ -210,6 +210,16 @@ void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
    from the host's random generator and stay on the CPU.) */
 int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
                     int width, int height, int psize, double amount, void *stream);
+/* "RGBdelay" / "YUVdelay": lives-plugins/weed-plugins/RGBdelay.c:135-416, stateful: a ring of up to 50 frames stays in HBM inside the
+   handle.  palette 1 RGB24 / 2 BGR24 / 588 YUV888 (yuv_clamped = the channel's YUV_clamping leaf is CLAMPED); maxcache = parameter 0;
+   on[3 * j + c] = the R / G / B (Y / U / V) switches and strength[j] the blend strength of frame -j, j = 0..50 (parameters 4j + 1 .. 4j + 4).
+   src_d == dst_d = in place.  The host-ease branch (:180-183, :407-412) is not taken.  Calls on one handle must be stream-ordered;
+   a change of geometry restarts the ring (the reference's in channel is REINIT_ON_SIZE_CHANGE). */
+typedef struct lgpu_rgbdelay lgpu_rgbdelay;
+int lgpu_rgbdelay_create(lgpu_rgbdelay **out);
+int lgpu_rgbdelay_process(lgpu_rgbdelay *rd, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette,
+                          int yuv_clamped, int maxcache, const int *on, const double *strength, void *stream);
+void lgpu_rgbdelay_destroy(lgpu_rgbdelay *rd);
 /* "deinterlace": lives-plugins/weed-plugins/deinterlace.c:45-308.  Packed palettes (WEED_PALETTE_* 1..5, 588, 589, 564, 565;
    width in macropixels for UYVY / YUYV); src_d == dst_d = in place (the reference's out channel is CAN_DO_INPLACE).  Rows
    r - 1 and r are written for every odd r < height - 2, everything else is left alone (alpha of 4-byte pixels: row r only,

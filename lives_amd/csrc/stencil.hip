@@ -342,6 +342,76 @@ __global__ __launch_bounds__(kBlock) void k_deinterlace(DeintArgs a) {
     if (a.copy_alpha) { o1[x + 3] = al[0]; o1[x + 7] = al[1]; o1[x + 11] = al[2]; }
   }
 }
+
+// RGBdelay / YUVdelay (RGBdelay.c:135-416): the output is the 8-bit wrap-around SUM over the enabled cached frames of a
+// per-frame, per-channel LUT of the cached pixel.  One launch per processed frame: every job's three LUTs sit in LDS
+// (<= 51 x 768 B), a thread walks one pixel through all jobs (wave-uniform loop) and writes it once.
+struct RgbdJob {
+  const uint8_t *frame;      // compact cached frame (pitch = 3 * width), or the source itself in direct mode
+  uint8_t lut[3][256];
+  uint8_t b[3];              // channel enabled
+  uint8_t cross;             // 2: red / blue swapped between this cached frame and the output
+  uint8_t pad[4];
+};
+struct RgbdArgs {
+  const RgbdJob *jobs;       // device
+  int njobs;
+  uint8_t *dst;
+  int orow, width, height;
+  int direct, pitch;         // direct: no cache (tcache == 0, :254-309): one job, source pitch, untouched channels stay
+  int inplace, ymin, uvmin;
+  int reclamp;               // YUV clamped: final LUT pass (:393-403); its two tables follow the jobs
+};
+__global__ __launch_bounds__(kBlock) void k_rgbdelay(RgbdArgs a) {
+  extern __shared__ uint8_t s_rgbd[];                         // [njobs (+1 for the reclamp pair)][3][256]
+  const int nl = a.njobs + (a.reclamp ? 1 : 0);
+  for (int i = threadIdx.x; i < nl * 192; i += kBlock)
+    reinterpret_cast<uint32_t *>(s_rgbd)[i] = reinterpret_cast<const uint32_t *>(a.jobs[i / 192].lut)[i % 192];
+  __syncthreads();
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= a.width) return;
+  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+    uint8_t *d = a.dst + (size_t)y * a.orow + 3 * x;
+    if (a.direct) {
+      const RgbdJob &j = a.jobs[0];
+      const uint8_t *p = j.frame + (size_t)y * a.pitch + 3 * x;
+      const uint8_t *l = s_rgbd;
+      uint8_t v[3] = {p[0], p[1], p[2]};
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        uint8_t o;
+        bool wr = true;
+        if (j.b[c]) o = l[c * 256 + v[c]];
+        else if (a.inplace) o = (uint8_t)(c == 0 ? a.ymin : a.uvmin);
+        else { wr = false; o = 0; }
+        if (wr) {
+          if (a.reclamp) o = s_rgbd[a.njobs * 768 + (c ? 256 : 0) + o];
+          d[c] = o;
+        } else if (a.reclamp) d[c] = s_rgbd[a.njobs * 768 + (c ? 256 : 0) + d[c]];      // the final pass maps whatever the frame holds
+      }
+    } else {
+      uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+      const size_t off = (size_t)y * a.pitch + 3 * x;
+      for (int k = 0; k < a.njobs; k++) {
+        const RgbdJob &j = a.jobs[k];
+        const uint8_t *p = j.frame + off;
+        const uint8_t *l = s_rgbd + k * 768;
+        const int cr = j.cross;
+        if (j.b[0]) acc0 += l[p[cr]];
+        if (j.b[1]) acc1 += l[256 + p[1]];
+        if (j.b[2]) acc2 += l[512 + p[2 - cr]];
+      }
+      uint8_t o0 = (uint8_t)acc0, o1 = (uint8_t)acc1, o2 = (uint8_t)acc2;
+      if (a.reclamp) { const uint8_t *r = s_rgbd + a.njobs * 768; o0 = r[o0]; o1 = r[256 + o1]; o2 = r[256 + o2]; }
+      d[0] = o0; d[1] = o1; d[2] = o2;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_rgbd_snapshot(const uint8_t *src, int irow, uint8_t *frame, int wb, int height) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= wb) return;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) frame[(size_t)y * wb + x] = src[(size_t)y * irow + x];
+}
 }  // namespace lgpu
 
 using namespace lgpu;
@@ -588,5 +658,142 @@ extern "C" int lgpu_deinterlace(const uint8_t *src_d, int irow, uint8_t *dst_d, 
   const dim3 grid(cdiv((unsigned)a.ntrip, kBlock), (unsigned)(npairs < 2048 ? npairs : 2048));
   hipLaunchKernelGGL(lgpu::k_deinterlace, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+// ---- RGBdelay / YUVdelay handle: the frame ring lives in HBM, the ring bookkeeping on the host (RGBdelay.c:24-32, :54-91, :200-228) ----
+struct lgpu_rgbdelay {
+  int ccache = 0, tcache = 0, width = 0, height = 0, device = 0;
+  uint8_t *cache[51] = {nullptr};
+  int is_bgr[51] = {0};
+  lgpu::RgbdJob *jobs_d = nullptr;           // 52 slots
+  lgpu::RgbdJob *jobs_h = nullptr;           // pinned staging copy of the table; `copied` fences its reuse
+  hipEvent_t copied = nullptr;
+  bool in_flight = false;
+};
+
+extern "C" void lgpu_rgbdelay_destroy(lgpu_rgbdelay *s);
+extern "C" int lgpu_rgbdelay_create(lgpu_rgbdelay **out) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(out, "null result pointer");
+  lgpu_rgbdelay *s = new lgpu_rgbdelay();
+  LGPU_HIP(hipGetDevice(&s->device));
+  if (hipMalloc((void **)&s->jobs_d, sizeof(lgpu::RgbdJob) * 52) != hipSuccess || hipHostMalloc((void **)&s->jobs_h, sizeof(lgpu::RgbdJob) * 52) != hipSuccess ||
+      hipEventCreateWithFlags(&s->copied, hipEventDisableTiming) != hipSuccess) {
+    lgpu_rgbdelay_destroy(s);
+    lgpu::set_error("lgpu_rgbdelay_create: allocation failed");
+    return LGPU_E_NOMEM;
+  }
+  *out = s;
+  return LGPU_OK;
+}
+extern "C" void lgpu_rgbdelay_destroy(lgpu_rgbdelay *s) {
+  if (!s) return;
+  for (int i = 0; i < 51; i++) if (s->cache[i]) (void)hipFree(s->cache[i]);
+  (void)hipFree(s->jobs_d);
+  if (s->jobs_h) (void)hipHostFree(s->jobs_h);
+  if (s->copied) (void)hipEventDestroy(s->copied);
+  delete s;
+}
+static void rgbd_make_lut(uint8_t *lut, double val, int min) {            // make_lut, RGBdelay.c:36-52 (double arithmetic on the host)
+  int mina = min, minb = 0;
+  double rnd = 0.5;
+  if (min < 0) { mina = 0; minb = -min; rnd += (double)minb; }
+  for (int i = 0; i < 256; i++) {
+    double rval = (double)(i - mina) * val + rnd;
+    if (rval < 0.) rval = 0.;
+    if (rval > 255.) rval = 255.;
+    lut[i] = (uint8_t)rval;
+  }
+}
+extern "C" int lgpu_rgbdelay_process(lgpu_rgbdelay *s, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette,
+                                     int yuv_clamped, int maxcache, const int *on, const double *strength, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(s && src_d && dst_d && on && strength && width > 0 && height > 0, "null handle / frame / parameter tables or empty geometry");
+  LGPU_REQUIRE(palette == 1 || palette == 2 || palette == 588, "palette must be RGB24 (1), BGR24 (2) or YUV888 (588)");
+  LGPU_REQUIRE(irow >= width * 3 && orow >= width * 3, "rowstride smaller than a row");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> seq(g_seq_mu);
+  const int wb = width * 3, inplace = (src_d == dst_d), is_bgr = (palette == 2), is_yuv = (palette == 588);
+  if (s->width != width || s->height != height) {                 // the reference's in channel is REINIT_ON_SIZE_CHANGE: a fresh instance
+    LGPU_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 51; i++) { if (s->cache[i]) (void)hipFree(s->cache[i]); s->cache[i] = nullptr; s->is_bgr[i] = 0; }
+    s->tcache = s->ccache = 0; s->width = width; s->height = height;
+  }
+  if (maxcache < 0) maxcache = 0; else if (maxcache > 50) maxcache = 50;
+  int maxneeded = 0;
+  for (int i = 1; i < maxcache; i++) if (on[3 * i] || on[3 * i + 1] || on[3 * i + 2]) maxneeded = i + 1;
+  if (maxneeded != s->tcache) {
+    LGPU_HIP(hipStreamSynchronize(st));
+    for (int i = s->tcache; i > maxneeded; i--) { (void)hipFree(s->cache[i - 1]); s->cache[i - 1] = nullptr; }
+    for (int i = s->tcache; i < maxneeded; i++)
+      if (hipMalloc((void **)&s->cache[i], (size_t)wb * height) != hipSuccess) {
+        for (int k = s->tcache; k < i; k++) { (void)hipFree(s->cache[k]); s->cache[k] = nullptr; }
+        lgpu::set_error("lgpu_rgbdelay_process: hipMalloc of a cache frame failed");
+        return LGPU_E_NOMEM;
+      }
+    s->tcache = maxneeded;
+    if (s->ccache > s->tcache) s->ccache = s->tcache;
+  }
+  uint8_t *tmpcache = s->tcache > 1 ? s->cache[s->tcache - 1] : nullptr;
+  double tstr[3] = {0., 0., 0.}, yscale = 1., uvscale = 1.;
+  for (int i = s->tcache - 1; i >= 0; i--) {
+    if (i > 0) { s->cache[i] = s->cache[i - 1]; s->is_bgr[i] = s->is_bgr[i - 1]; }
+    for (int c = 0; c < 3; c++) if (on[3 * i + c]) tstr[c] += strength[i];
+  }
+  s->is_bgr[0] = is_bgr;
+  if (s->tcache > 0) {
+    const dim3 g(cdiv((unsigned)wb, kBlock), (unsigned)(height < 1024 ? height : 1024));
+    hipLaunchKernelGGL(lgpu::k_rgbd_snapshot, g, dim3(kBlock), 0, st, src_d, irow, tmpcache, wb, height);
+    s->cache[0] = tmpcache;
+  }
+  for (int c = 0; c < 3; c++) if (tstr[c] < 1.) tstr[c] = 1.;
+  int yuvmin = 0, uvmin = 0;
+  if (is_yuv && yuv_clamped) { yuvmin = 16; uvmin = 16; yscale = 255. / 219.; uvscale = 255. / 224.; }
+  if (s->in_flight) { LGPU_HIP(hipEventSynchronize(s->copied)); s->in_flight = false; }     // the previous table has left the staging buffer
+  lgpu::RgbdArgs a = {};
+  a.jobs = s->jobs_d; a.dst = dst_d; a.orow = orow; a.width = width; a.height = height; a.inplace = inplace; a.ymin = yuvmin; a.uvmin = uvmin;
+  int n = 0;
+  auto fill_job = [&](lgpu::RgbdJob &j, const uint8_t *frame, int frame_is_bgr, int idx, int cross) {
+    int b[3] = {on[3 * idx] != 0, on[3 * idx + 1] != 0, on[3 * idx + 2] != 0}, red = 0, blue = 2;
+    if (frame_is_bgr) { const int t = b[0]; b[0] = b[2]; b[2] = t; red = 2; blue = 0; }
+    const double cstr = strength[idx];
+    rgbd_make_lut(j.lut[red], cstr / tstr[0] * yscale, yuvmin);
+    rgbd_make_lut(j.lut[1], cstr / tstr[1] * uvscale, yuvmin);
+    rgbd_make_lut(j.lut[blue], cstr / tstr[2] * uvscale, yuvmin);
+    j.frame = frame; j.b[0] = (uint8_t)b[0]; j.b[1] = (uint8_t)b[1]; j.b[2] = (uint8_t)b[2]; j.cross = (uint8_t)cross;
+  };
+  if (s->tcache == 0) {
+    fill_job(s->jobs_h[0], src_d, is_bgr, 0, 0);
+    n = 1; a.direct = 1; a.pitch = irow;
+  } else {
+    for (int j = 0; j < s->tcache; j++) {
+      const int k = (j <= s->ccache) ? j : s->ccache;
+      if (!on[3 * j] && !on[3 * j + 1] && !on[3 * j + 2] && j > 0) continue;
+      const int cross = ((!is_bgr && s->is_bgr[j]) || (is_bgr && !s->is_bgr[j])) ? 2 : 0;
+      fill_job(s->jobs_h[n++], s->cache[k], s->is_bgr[j], j, cross);
+    }
+    a.pitch = wb;
+    if ((rc = lgpu_fill(dst_d, 0, (size_t)orow * height, stream))) return rc;      // memset(dst, 0, dframesize) :311, row padding included
+  }
+  if (is_yuv && yuvmin == 16) {
+    lgpu::RgbdJob &r = s->jobs_h[n];
+    rgbd_make_lut(r.lut[0], 1. / yscale, -yuvmin);
+    rgbd_make_lut(r.lut[1], 1. / uvscale, -yuvmin);
+    a.reclamp = 1;
+  }
+  a.njobs = n;
+  const int nl = n + a.reclamp;
+  LGPU_HIP(hipMemcpyAsync(s->jobs_d, s->jobs_h, sizeof(lgpu::RgbdJob) * nl, hipMemcpyHostToDevice, st));
+  LGPU_HIP(hipEventRecord(s->copied, st));
+  s->in_flight = true;
+  const size_t lds = (size_t)nl * 768;
+  if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)lgpu::k_rgbdelay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 1024 ? height : 1024));
+  hipLaunchKernelGGL(lgpu::k_rgbdelay, grid, dim3(kBlock), lds, st, a);
+  LGPU_CHECK_LAUNCH();
+  if (s->ccache < s->tcache) s->ccache++;
   return LGPU_OK;
 }

@@ -76,6 +76,9 @@ PROTOTYPES = {
     "lgpu_mirror": [ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_transition": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, vp],
     "lgpu_yuv_repack": [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "lgpu_rgbdelay_create": [vp],
+    "lgpu_rgbdelay_process": [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp],
+    "lgpu_rgbdelay_destroy": [vp],
     "lgpu_deinterlace": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_slide_over": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_softlight": [vp, vp, vp, vp, ci, ci, ci, ci, vp],

@@ -209,6 +209,27 @@ class Blurzoom:
             self.h = None
 
 
+class RgbDelay:
+    """stateful RGBdelay / YUVdelay instance (lgpu_rgbdelay_*): the frame ring lives in HBM inside the handle"""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        lib.call("lgpu_rgbdelay_create", ctypes.addressof(h))
+        self.h = h
+
+    def process(self, src, dst, width, height, palette, maxcache, on, strength, yuv_clamped=False):
+        on = np.ascontiguousarray(on, dtype=np.int32)
+        strength = np.ascontiguousarray(strength, dtype=np.float64)
+        assert on.size == 153 and strength.size == 51
+        lib.call("lgpu_rgbdelay_process", self.h, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, palette, int(bool(yuv_clamped)),
+                 int(maxcache), on.ctypes.data, strength.ctypes.data, stream_ptr())
+
+    def close(self):
+        if self.h:
+            lib.load().lgpu_rgbdelay_destroy(self.h)
+            self.h = None
+
+
 def chain_params(sw, sh, irow, dw, dh, irow2, orow, swap_rb=1, interp=3, do_blur=0, bf=128, lut=None, param_block=None):
     p = lib.ChainParams()
     p.param_block_d = param_block.data_ptr() if param_block is not None else None

@@ -296,3 +296,17 @@ def test_deinterlace_vs_reference_plugin(gpu):
             d = dev(np.full_like(a, 0x5A))
             gpu.deinterlace(dev(a), d, int(w), int(h), int(pal))
         assert (host(d)[:, :n] == want[:, :n]).all(), rec
+
+
+def test_rgbdelay_sequences_vs_reference_plugin(gpu):
+    g = gu.load("rgbdelay.npz")
+    for name, (fn, pal, clamp, maxcache, groups, inplace) in gu.RGBDELAY_CASES.items():
+        on, st = gu.rgbdelay_params(groups)
+        fin, fout = g[name + "|in"], g[name + "|out"]
+        rd = gpu.RgbDelay()
+        for i in range(fin.shape[0]):
+            src = dev(np.ascontiguousarray(fin[i]))
+            d = src if inplace else dev(np.full_like(fin[i], 0x5A))
+            rd.process(src, d, 10, 6, pal, maxcache, on, st, yuv_clamped=(clamp == 0))
+            assert (host(d) == fout[i]).all(), (name, i)
+        rd.close()

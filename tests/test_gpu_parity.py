@@ -429,6 +429,36 @@ def test_deinterlace(gpu, orc, palette):
             gpu.deinterlace(dev(a), dev(a.copy()), 12, 8, 5)
 
 
+@pytest.mark.parametrize("palette", [1, 2, 588])
+def test_rgbdelay_with_changing_parameters(gpu, orc, palette):
+    """a longer run than the fixtures: the parameter set changes mid-sequence (the ring grows, shrinks and empties), frames are padded"""
+    rng = np.random.default_rng(2900 + palette)
+    w, h = 70, 24
+    plans = [({0: (1, 0, 0, 1.0), 3: (0, 1, 0, 0.8), 6: (0, 0, 1, 1.0)}, 12), ({0: (1, 1, 1, 0.5), 1: (1, 1, 1, 0.5), 9: (1, 0, 1, 0.7)}, 12),
+             ({0: (0, 1, 1, 0.9)}, 20), ({0: (1, 0, 0, 1.0), 2: (0, 1, 1, 1.0)}, 2), ({0: (1, 1, 1, 1.0), 49: (1, 1, 1, 0.3)}, 50)]
+    for inplace in (0, 1):
+        s = orc.orc_rgbdelay_new()
+        rd = gpu.RgbDelay()
+        for groups, maxcache in plans:
+            on, st = gu_params(groups)
+            for _ in range(5):
+                src = frame(rng, w, h, 3)
+                want = src.copy() if inplace else np.full_like(src, 0x5A)
+                a = want if inplace else src
+                assert orc.orc_rgbdelay_process(s, P(a), a.strides[0], P(want), want.strides[0], w, h, palette, 1, maxcache, on.ctypes.data, st.ctypes.data) == 0
+                ds = dev(src)
+                d = ds if inplace else dev(np.full_like(src, 0x5A))
+                rd.process(ds, d, w, h, palette, maxcache, on, st, yuv_clamped=True)
+                assert (host(d) == want).all(), "rgbdelay pal=%d inplace=%d" % (palette, inplace)
+        orc.orc_rgbdelay_free(s)
+        rd.close()
+
+
+def gu_params(groups):
+    from tests import golden_util as gu
+    return gu.rgbdelay_params(groups)
+
+
 # ---------------------------------------------------------------------------------------------- K5b YUV -> YUV repacks
 @pytest.mark.parametrize("pair", po.YUV_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
 def test_yuv_repack(gpu, orc, pair):

@@ -331,3 +331,20 @@ def test_deinterlace(orc):
         src = got if inplace == "1" else a
         assert orc.orc_deinterlace(P(src), src.strides[0], P(got), got.strides[0], int(w), int(h), int(pal)) == 0
         assert (got == want).all(), rec
+
+
+def test_rgbdelay_sequences(orc):
+    g = gu.load("rgbdelay.npz")
+    assert sorted(map(str, g["records"])) == sorted(gu.RGBDELAY_CASES)
+    for name, (fn, pal, clamp, maxcache, groups, inplace) in gu.RGBDELAY_CASES.items():
+        on, st = gu.rgbdelay_params(groups)
+        fin, fout = g[name + "|in"], g[name + "|out"]
+        s = orc.orc_rgbdelay_new()
+        for i in range(fin.shape[0]):
+            src = np.ascontiguousarray(fin[i])
+            got = src.copy() if inplace else np.full_like(src, 0x5A)
+            a = got if inplace else src
+            assert orc.orc_rgbdelay_process(s, P(a), a.strides[0], P(got), got.strides[0], 10, 6, pal, 1 if clamp == 0 else 0, maxcache,
+                                            on.ctypes.data, st.ctypes.data) == 0
+            assert (got == fout[i]).all(), (name, i)
+        orc.orc_rgbdelay_free(s)
