@@ -52,7 +52,7 @@ static int psize_of(int pal) {
 }
 
 /* ---- per-instance device buffers ("plugin_internal", like simple_blend.c:36-45) ---- */
-typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; } fxdata_t;
+typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; lgpu_rgbdelay *rd; } fxdata_t;
 
 static fxdata_t *fx_data(weed_plant_t *inst) {
   fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
@@ -83,6 +83,7 @@ static weed_error_t fx_deinit(weed_plant_t *inst) {
   if (fx) {
     for (int i = 0; i < 3; i++) if (fx->d[i]) lgpu_free(fx->d[i]);
     if (fx->bz) lgpu_blurzoom_destroy(fx->bz);
+    if (fx->rd) lgpu_rgbdelay_destroy(fx->rd);
     w_free(fx);
     void *v = NULL;
     w_set(inst, "plugin_internal", WEED_SEED_VOIDPTR, 1, &v);
@@ -209,6 +210,26 @@ static int k_deint(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst; (void)kind;
   return lgpu_deinterlace(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, NULL);
 }
+/* "RGBdelay" / "YUVdelay" (RGBdelay.c:135-416): stateful, the frame ring lives in the device handle kept in plugin_internal */
+static double param_dbl(weed_plant_t *inst, int idx, double dflt) {
+  weed_plant_t *p = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, idx);
+  return p ? g_dbl(p, WEED_LEAF_VALUE, dflt) : dflt;
+}
+static int k_rgbdelay(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  fxdata_t *fx = fx_data(inst);
+  weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, 0);
+  int on[153], j, clamped = 0;
+  double strength[51];
+  (void)kind;
+  if (!fx) return LGPU_E_NOMEM;
+  if (!fx->rd && lgpu_rgbdelay_create(&fx->rd) != LGPU_OK) return LGPU_E_NOMEM;
+  for (j = 0; j < 51; j++) {
+    on[3 * j] = param_bool(inst, 4 * j + 1, 0); on[3 * j + 1] = param_bool(inst, 4 * j + 2, 0); on[3 * j + 2] = param_bool(inst, 4 * j + 3, 0);
+    strength[j] = param_dbl(inst, 4 * j + 4, 1.);
+  }
+  if (f->pal == WEED_PALETTE_YUV888 && ic) clamped = g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED) == WEED_YUV_CLAMPING_CLAMPED;
+  return lgpu_rgbdelay_process(fx->rd, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, clamped, param_int(inst, 0, 20), on, strength, NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -273,6 +294,7 @@ static int k_blurzoom(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (!fx) return LGPU_E_NOMEM;
   if (!fx->bz || fx->bz_w != f->width || fx->bz_h != f->height || fx->bz_pal != f->pal) {
     if (fx->bz) lgpu_blurzoom_destroy(fx->bz);
+    if (fx->rd) lgpu_rgbdelay_destroy(fx->rd);
     fx->bz = NULL;
     if (lgpu_blurzoom_create(f->width, f->height, f->pal, &fx->bz) != LGPU_OK) return LGPU_E_BADARG;
     fx->bz_w = f->width; fx->bz_h = f->height; fx->bz_pal = f->pal;
@@ -288,7 +310,7 @@ PROC(p_ckey, 2, 0, k_ckey, 0)
 PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mirrorxy, 1, 2, k_mirror, 1)
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
-PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1)
+PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1) PROC(p_rgbdelay, 1, 0, k_rgbdelay, 1)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -372,7 +394,7 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
   static const int32_t packed[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32,
                                    WEED_PALETTE_YUV888, WEED_PALETTE_YUVA8888, WEED_PALETTE_UYVY, WEED_PALETTE_YUYV};
   weed_default_getter_f dget;
-  weed_plant_t *host_info, *pinfo = NULL, *p[8];
+  weed_plant_t *host_info, *pinfo = NULL, *p[205];
   int32_t filter_api = 0;
   int i;
   if (!weed_boot) return NULL;
@@ -472,6 +494,30 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     static const int32_t pk[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_YUV888, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32,
                                  WEED_PALETTE_YUVA8888, WEED_PALETTE_UYVY, WEED_PALETTE_YUYV};
     add_filter(pinfo, "deinterlace", 0, pk, 9, p_deint, 1, "in channel 0", NULL, "out channel 0", p, 0);
+  }
+  /* RGBdelay.c:435-528: "RGBdelay" (RGB24 / BGR24) and "YUVdelay" (YUV888): parameter 0 = cache size (REINIT_ON_VALUE_CHANGE), then 51 groups of
+     three switches + one strength (defaults: R of frame 0, G of frame -4, B of frame -8); in channel REINIT_ON_SIZE_CHANGE, out channel in place */
+  {
+    static const int32_t prgb[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24}, pyuv[] = {WEED_PALETTE_YUV888};
+    int which, g, c;
+    for (which = 0; which < 2; which++) {
+      weed_plant_t *fc = NULL, *ict = NULL;
+      char label[64];
+      p[0] = int_param("fcsize", "Frame _Cache Size (max)", 20, 0, 50, 0);
+      s_int(p[0], WEED_LEAF_FLAGS, WEED_PARAMETER_REINIT_ON_VALUE_CHANGE);
+      for (g = 0; g < 51; g++) {
+        for (c = 0; c < 3; c++) {
+          const int idx = 4 * g + 1 + c;
+          if (c == 2) snprintf(label, sizeof(label), "        Frame -%-2d       ", g); else label[0] = 0;
+          p[idx] = switch_param("", label, (idx == 1 || idx == 18 || idx == 35) ? WEED_TRUE : WEED_FALSE);
+        }
+        p[4 * g + 4] = float_param("", "", 1., 0., 1.);
+      }
+      add_filter(pinfo, which ? "YUVdelay" : "RGBdelay", 0, which ? pyuv : prgb, which ? 1 : 2, p_rgbdelay, 1, "in channel 0", NULL, "out channel 0", p, 205);
+      w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+      if (fc) w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict);
+      if (ict) s_int(ict, WEED_LEAF_FLAGS, WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
+    }
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

@@ -22,8 +22,8 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 24
-    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace"):
+    assert len(ours) == 26
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace", "RGBdelay"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
@@ -195,3 +195,29 @@ def test_deinterlace_records_through_the_plugin():
             H.run(OURS, "deinterlace", int(pal), int(w), int(h), [a.copy()], d, [])
         n = (int(w) + 2) // 3 * 3 * (3 if int(pal) in (1, 2, 588) else 4)
         assert (d[:, :n] == want[:, :n]).all(), rec
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_rgbdelay_sequences_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("rgbdelay.npz")
+    for name, (fn, pal, clamp, maxcache, groups, inplace) in gu.RGBDELAY_CASES.items():
+        on, st = gu.rgbdelay_params(groups)
+        params = [po.p_int(maxcache)]
+        for j in range(51):
+            params += [po.p_bool(on[3 * j]), po.p_bool(on[3 * j + 1]), po.p_bool(on[3 * j + 2]), po.p_double(st[j])]
+        fin, fout = g[name + "|in"], g[name + "|out"]
+        frames = [np.ascontiguousarray(fin[i]) for i in range(fin.shape[0])]
+        H.H.refhost_set_yuv_clamping(clamp)
+        try:
+            if inplace:
+                out = [f.copy() for f in frames]
+                H.run_seq(OURS, fn, pal, 10, 6, out, out, params)
+            else:
+                out = [np.full_like(f, 0x5A) for f in frames]
+                H.run_seq(OURS, fn, pal, 10, 6, frames, out, params)
+        finally:
+            H.H.refhost_set_yuv_clamping(-1)
+        for i in range(len(frames)):
+            assert (out[i] == fout[i]).all(), (name, i)
