@@ -583,8 +583,15 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
   PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
-  if (opal_hint != WEED_PALETTE_NONE && opal_hint != l.pal) return 0;     // resize + palette change in one go: not on the GPU path
-  if (!(pal_is_rgb(l.pal) || pal_is_planar_yuv(l.pal))) return 0;
+  // opal_hint / oclamp_hint "may be ignored ... layer palette should be checked on return" (:14746-14751): a frame whose palette this path
+  // resizes keeps it (the caller's following convert_layer_palette does the rest); a packed-YUV frame is first taken to the hinted
+  // palette when that one is resizable and the conversion is served here
+  if (!(pal_is_rgb(l.pal) || pal_is_planar_yuv(l.pal))) {
+    if (opal_hint == WEED_PALETTE_NONE || opal_hint == l.pal || !(pal_is_rgb(opal_hint) || pal_is_planar_yuv(opal_hint))) return 0;
+    const int cl = l.clamping >= 0 ? l.clamping : WEED_YUV_CLAMPING_CLAMPED;
+    if (!lives_gpu_convert_layer_palette_full(layer, opal_hint, cl, WEED_YUV_SAMPLING_DEFAULT, l.subspace, WEED_GAMMA_UNKNOWN)) return 0;
+    if (!read_layer(layer, &l)) return 0;
+  }
   int iwidth = (l.width >> 1) << 1, iheight = (l.height >> 1) << 1;      // :14854-14863
   if (width < 4) width = 4;
   if (height < 4) height = 4;

@@ -154,6 +154,30 @@ def test_c3_resize_then_letterbox(seam, orc):
         want = np.zeros((qh, pl.shape[1]), np.uint8)
         assert orc.orc_resize(P(s), s.strides[0], pw, ph, P(want), want.strides[0], qw, qh, 1, 3) == 0
         assert (pl[:, :qw] == want[:, :qw]).all()
+    # a palette hint "may be ignored" (colourspace.c:14746-14751): the frame is resized in its own palette ...
+    src = frame(rng, sw, sh, 4)
+    lay = wh.new_layer(RGBA32, sw, sh, [src])
+    assert L.lives_gpu_resize_layer(lay, dw, dh, 3, RGB24, 0) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert wh.geti(lay, "current_palette") == RGBA32 and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (dw, dh)
+    want = np.zeros((dh, rs[0]), np.uint8)
+    assert orc.orc_resize(P(src), src.strides[0], sw, sh, P(want), rs[0], dw, dh, 4, 3) == 0
+    assert (planes[0][:, :dw * 4] == want[:, :dw * 4]).all()
+    # ... and a packed-YUV frame goes to the hinted palette first (UYVY -> RGB24 is served here), then resizes
+    uy = frame(rng, 128, 32, 2)
+    lay = wh.new_layer(564, 64, 32, [uy], clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer(lay, 64, 16, 3, RGB24, 0) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert wh.geti(lay, "current_palette") == RGB24 and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (64, 16)
+    rgb = np.zeros((32, 128 * 3), np.uint8)
+    sp, ss = po.planes_args([uy])
+    assert orc.orc_yuv_to_rgb(ctypes.addressof(sp), ctypes.addressof(ss), 128, 32, 2, 0, P(rgb), rgb.strides[0], 0, 0, 0) == 0
+    want = np.zeros((16, rs[0]), np.uint8)
+    assert orc.orc_resize(P(rgb), rgb.strides[0], 128, 32, P(want), rs[0], 64, 16, 3, 3) == 0
+    assert (planes[0][:, :64 * 3] == want[:, :64 * 3]).all()
+    # no usable hint for a packed-YUV frame: FALSE, layer untouched
+    lay = wh.new_layer(564, 64, 32, [uy], clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer(lay, 64, 16, 3, 0, 0) == 0 and wh.geti(lay, "current_palette") == 564
 
 
 @needs_ref
