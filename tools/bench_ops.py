@@ -198,6 +198,39 @@ def main():
     covered = sum(max(0, min(w, 120 * z + 960) - 120 * z) * max(0, min(h, 60 * z + 540) - 60 * z) for z in range(8))
     add("composite 8 x 960x540 layers", "compositor.c:120-293", "1920x1080", covered * 4 + w * h * 4, t, None)
 
+    # ---- K5b: the decoder hand-off repacks ------------------------------------------------------------------------------------------
+    w, h = 1920, 1080
+    Y, U, V = dframe(w, h, 1, NB), [torch.randint(0, 256, (h // 2, w // 2), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NB)], \
+        [torch.randint(0, 256, (h // 2, w // 2), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NB)]
+    pk = dframe(w, h, 2, NB)
+    t = timeit(lambda i: ops.yuv_repack(512, 564, [Y[i], U[i], V[i]], [pk[i]], w, h, 0), NB)
+    add("YUV420P -> UYVY", "colourspace.c:7104-7150", "1920x1080", w * h * 3 // 2 + w * h * 2, t, None)
+    p444 = [dframe(w, h, 1, NB) for _ in range(3)]
+    p888 = dframe(w, h, 3, NB)
+    t = timeit(lambda i: ops.yuv_repack(544, 588, [p444[0][i], p444[1][i], p444[2][i]], [p888[i]], w, h, 0), NB)
+    add("YUV444P -> YUV888", "colourspace.c:7593-7641", "1920x1080", w * h * 6, t, None)
+    # ---- more plugins: slide over, deinterlace, RGBdelay ------------------------------------------------------------------------------
+    s1, s2, d = dframe(w, h, 4, NB), dframe(w, h, 4, NB), dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.slide_over(s1[i], s2[i], d[i], w, h, 4, 100, 1), NB)
+    add("slide over RGBA32", "slide_over.c:54-146", "1920x1080", w * h * 8, t, None)
+    t = timeit(lambda i: ops.deinterlace(s1[i], d[i], w, h, 3), NB)
+    hs = hframe(w, h, 4)
+    hd2 = hs.copy()
+    if orc:
+        orc.orc_deinterlace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    c = cpu(lambda: orc.orc_deinterlace(P(hs), hs.strides[0], P(hd2), hd2.strides[0], w, h, 3))
+    add("deinterlace RGBA32", "deinterlace.c:45-308", "1920x1080", w * h * 8, t, c)
+    r24, o24 = dframe(w, h, 3, NB), dframe(w, h, 3, NB)
+    rd = ops.RgbDelay()
+    on = np.zeros(153, np.int32)
+    on[[0, 3 * 4 + 1, 3 * 8 + 2]] = 1
+    st = np.ones(51)
+    for i in range(12):
+        rd.process(r24[i % NB], o24[i % NB], w, h, 1, 20, on, st)
+    t = timeit(lambda i: rd.process(r24[i], o24[i], w, h, 1, 20, on, st), NB)
+    add("RGBdelay RGB24 (default: 3 taps of a 9-frame ring)", "RGBdelay.c:135-416", "1920x1080", w * h * 3 * (1 + 1 + 3 + 1), t, None)
+    rd.close()
+
     print("| op | reference | size | algorithmic bytes | GPU us | GB/s | of 8 TB/s | oracle 1-thread ms | ratio |\n|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         print("| %s | `%s` | %s | %d | %.2f | %.1f | %.3f | %s | %s |" % (r["op"], r["reference"], r["size"], r["algorithmic_bytes"], r["gpu_us"], r["gbs"], r["frac"],
