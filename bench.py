@@ -82,9 +82,18 @@ def main():
 
     sched_base = schedule.data_ptr()
 
+    pipe = ld.ParamPipeline("cuda")
+    nsched = args.steps + args.warmup
+    if world > 1:
+        pipe.prefetch(0, schedule[0] if rank == 0 else None)
+
     def step(s):
         if world > 1:
-            ld.publish_params(pblock, schedule[s] if rank == 0 else None)   # RCCL broadcast over xGMI; no host sync
+            # RCCL broadcast over xGMI, no host sync: the block of step s was sent while step s - 1 ran; send the next one now
+            blk = pipe.acquire(s)
+            if s + 1 < nsched:
+                pipe.prefetch(s + 1, schedule[s + 1] if rank == 0 else None)
+            prm.param_block_d = blk.data_ptr()
         else:
             prm.param_block_d = sched_base + 16 * s      # one GPU: nothing to exchange, the kernel reads step s of the resident schedule
         ops.chain(prm, trk)

@@ -33,6 +33,36 @@ def publish_params(block, values=None, src=0):
     return block
 
 
+class ParamPipeline:
+    """Double-buffered parameter block.  prefetch(s + 1) is called BEFORE the kernel of batch s is launched: the broadcast
+    is issued behind everything already on the launch stream (the kernel of batch s - 1, the last reader of that buffer)
+    and then travels over xGMI on RCCL's own stream while the kernel of batch s runs; acquire(s) makes the launch stream
+    wait for it (a stream-level wait, no host sync)."""
+
+    def __init__(self, device, src=0):
+        self.blocks = [new_param_block(device), new_param_block(device)]
+        self.pending = [None, None]
+        self.src = src
+
+    def prefetch(self, s, values):
+        b = self.blocks[s & 1]
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        if values is not None and (not multi or dist.get_rank() == self.src):
+            if torch.is_tensor(values):
+                b.copy_(values, non_blocking=True)
+            else:
+                b.copy_(torch.tensor(list(values) + [0] * (PARAM_BLOCK_INTS - len(values)), dtype=torch.int32))
+        if multi:
+            self.pending[s & 1] = dist.broadcast(b, src=self.src, async_op=True)
+
+    def acquire(self, s):
+        w = self.pending[s & 1]
+        if w is not None:
+            w.wait()
+            self.pending[s & 1] = None
+        return self.blocks[s & 1]
+
+
 def max_over_ranks(seconds, device):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return seconds

@@ -24,6 +24,14 @@ WORKER = textwrap.dedent('''
     for step in range(5):
         ld.publish_params(blk, [96 + 7 * step, step] if rank == 0 else None)
         assert blk.tolist() == [96 + 7 * step, step, 0, 0], (rank, blk)
+    # the pipelined form bench.py uses: block s + 1 is sent while step s would run; acquire(s) hands out step s' values
+    pipe = ld.ParamPipeline("cpu")
+    pipe.prefetch(0, [96, 0] if rank == 0 else None)
+    for step in range(6):
+        b = pipe.acquire(step)
+        if step + 1 < 6:
+            pipe.prefetch(step + 1, [96 + 7 * (step + 1), step + 1] if rank == 0 else None)
+        assert b.tolist() == [96 + 7 * step, step, 0, 0], (rank, step, b)
     t = ld.max_over_ranks(1.0 + rank, "cpu")
     assert t == float(world), t
     # compositing fan-in: 5 tracks over 2 ranks (rank 1 pads one slot), frame t is filled with t + 1
