@@ -1092,15 +1092,33 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
           float alpha[RPW], inv[RPW];
 #pragma unroll
           for (int i = 0; i < RPW; i++) { alpha[i] = s_alpha[q2[i] >> 24]; inv[i] = __fsub_rn(1.0f, alpha[i]); }
+          // the products are rounded to nearest as in the reference; their truncation to a byte and the packing are one
+          // v_cvt_pk_u8_f32 each, which rounds by MODE.fp_round: switched to toward-zero for exactly those instructions
+          uint32_t f1[RPW], f2[RPW];
+#pragma unroll
+          for (int i = 0; i < RPW; i += 2) {
+            float m[12];
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                m[k * 6 + c] = __fmul_rn((float)((q2[i + k] >> (8 * c)) & 0xFF), alpha[i + k]);
+                m[k * 6 + 3 + c] = __fmul_rn((float)((px[i + k] >> (8 * c)) & 0xFF), inv[i + k]);
+              }
+            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                         "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\tv_cvt_pk_u8_f32 %0, %5, 1, %0\n\tv_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                         "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                         "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\tv_cvt_pk_u8_f32 %2, %11, 1, %2\n\tv_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
+                         "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\tv_cvt_pk_u8_f32 %3, %14, 1, %3\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
+                         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                         : "=&v"(f2[i]), "=&v"(f1[i]), "=&v"(f2[i + 1]), "=&v"(f1[i + 1])
+                         : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+          }
 #pragma unroll
           for (int i = 0; i < RPW; i++) {
             const uint32_t q = q2[i], p = px[i];
-            const uint32_t f2 = (uint32_t)__fmul_rn((float)((q >> 0) & 0xFF), alpha[i]) | ((uint32_t)__fmul_rn((float)((q >> 8) & 0xFF), alpha[i]) << 8) |
-                                ((uint32_t)__fmul_rn((float)((q >> 16) & 0xFF), alpha[i]) << 16);
-            const uint32_t f1 = (uint32_t)__fmul_rn((float)((p >> 0) & 0xFF), inv[i]) | ((uint32_t)__fmul_rn((float)((p >> 8) & 0xFF), inv[i]) << 8) |
-                                ((uint32_t)__fmul_rn((float)((p >> 16) & 0xFF), inv[i]) << 16);
             const bool op = (q >> 24) == 255;
-            px[i] = mix3_dot4(op ? p : f1, op ? q : f2, w_lo, w_hi) | (p & 0xFF000000u);
+            px[i] = mix3_dot4(op ? p : f1[i], op ? q : f2[i], w_lo, w_hi) | (p & 0xFF000000u);
           }
         }
       }
