@@ -210,6 +210,12 @@ void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
    from the host's random generator and stay on the CPU.) */
 int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
                     int width, int height, int psize, double amount, void *stream);
+/* negate / posterise / ccorrect (lives-plugins/weed-plugins/scripts/{negate,posterise,ccorrect}.script): all three map every byte of a pixel
+   through a table that depends on its position in the pixel only.  lgpu_fx_luts builds the tables on the host (kind 0 negate, 1 posterise
+   with p0 = levels, 2 ccorrect with p0..p2 = red / green / blue factors; palette = WEED_PALETTE_* 1..5; returns psize, 0 = combination the
+   reference does not offer), lgpu_byte_luts applies luts[psize][256] (host pointer, travels as a kernel argument).  src_d == dst_d allowed. */
+int lgpu_fx_luts(int kind, int palette, double p0, double p1, double p2, uint8_t *luts_out);
+int lgpu_byte_luts(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, const uint8_t *luts, void *stream);
 /* "RGBdelay" / "YUVdelay": lives-plugins/weed-plugins/RGBdelay.c:135-416, stateful: a ring of up to 50 frames stays in HBM inside the
    handle.  palette 1 RGB24 / 2 BGR24 / 588 YUV888 (yuv_clamped = the channel's YUV_clamping leaf is CLAMPED); maxcache = parameter 0;
    on[3 * j + c] = the R / G / B (Y / U / V) switches and strength[j] the blend strength of frame -j, j = 0..50 (parameters 4j + 1 .. 4j + 4).

@@ -230,6 +230,15 @@ static int k_rgbdelay(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (f->pal == WEED_PALETTE_YUV888 && ic) clamped = g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED) == WEED_YUV_CLAMPING_CLAMPED;
   return lgpu_rgbdelay_process(fx->rd, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, clamped, param_int(inst, 0, 20), on, strength, NULL);
 }
+/* negate / posterise / ccorrect (scripts of those names): per-byte-position tables built on the host, one gather launch */
+static int k_scriptfx(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  uint8_t luts[4 * 256];
+  double p0 = 0., p1 = 0., p2 = 0.;
+  if (kind == 1) p0 = (double)param_int(inst, 0, 1);
+  else if (kind == 2) { p0 = param_dbl(inst, 0, 1.); p1 = param_dbl(inst, 1, 1.); p2 = param_dbl(inst, 2, 1.); }
+  if (lgpu_fx_luts(kind, f->pal, p0, p1, p2, luts) != f->psize) return LGPU_E_UNSUPPORTED;
+  return lgpu_byte_luts(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, luts, NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -311,6 +320,7 @@ PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mir
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
 PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1) PROC(p_rgbdelay, 1, 0, k_rgbdelay, 1)
+PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(p_ccorrect, 1, 2, k_scriptfx, 0)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
@@ -518,6 +528,17 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
       if (fc) w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict);
       if (ict) s_int(ict, WEED_LEAF_FLAGS, WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
     }
+  }
+  /* scripts/negate.script, posterise.script, ccorrect.script (<palette_list>, <params>): per-pixel table effects; out channel in place */
+  {
+    static const int32_t rgbx[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_ARGB32};
+    add_filter(pinfo, "negate", 0, rgbx, 5, p_negate, 1, "in_channel0", NULL, "out_channel0", p, 0);
+    p[0] = int_param("levels", "Colour _levels", 1, 1, 8, 0);
+    add_filter(pinfo, "posterise", 0, rgbx, 4, p_posterise, 1, "in_channel0", NULL, "out_channel0", p, 1);
+    p[0] = float_param("red", "_Red factor", 1., 0., 4.);
+    p[1] = float_param("green", "_Green factor", 1., 0., 4.);
+    p[2] = float_param("blue", "_Blue factor", 1., 0., 4.);
+    add_filter(pinfo, "ccorrect", 0, rgbx, 5, p_ccorrect, 1, "in_channel0", NULL, "out_channel0", p, 3);
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

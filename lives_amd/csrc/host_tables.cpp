@@ -249,3 +249,46 @@ int lgpu_make_filter(int srcn, int dstn, int kernel, int *ntaps_out, int32_t *po
 }
 
 }  // extern "C"
+
+/* the per-byte-position tables of the script effects (lives-plugins/weed-plugins/scripts/): kind 0 negate (negate.script <process>: colour
+   bytes ^ 0xFF, alpha copied), 1 posterise (posterise.script: levmask = 128 + 128 >> 1 + ..., bytes 0..2 masked, byte 3 of a 4-byte pixel
+   copied -- whatever the palette), 2 ccorrect (ccorrect.script: make_table(val): (int)(val * i + .5) capped at 255; r / g / b tables at the
+   palette's colour positions, alpha copied).  p0..p2: posterise levels in p0; ccorrect red / green / blue factors.  luts_out[psize][256]. */
+extern "C" int lgpu_fx_luts(int kind, int palette, double p0, double p1, double p2, uint8_t *luts_out) {
+  if (!luts_out || palette < 1 || palette > 5) return 0;
+  const int psize = palette <= 2 ? 3 : 4;
+  const int alpha = palette == 5 ? 0 : psize == 4 ? 3 : -1;
+  uint8_t id[256], t[3][256];
+  for (int i = 0; i < 256; i++) id[i] = (uint8_t)i;
+  if (kind == 0) {
+    for (int c = 0; c < psize; c++)
+      for (int i = 0; i < 256; i++) luts_out[c * 256 + i] = (c == alpha) ? id[i] : (uint8_t)(0xFF ^ i);
+    return psize;
+  }
+  if (kind == 1) {
+    if (palette == 5) return 0;                                  /* ALL_RGBX_PALETTES: no ARGB32 */
+    const int levels = (int)p0;
+    unsigned char levmask = 128;
+    for (int i = 1; i < levels; i++) levmask += 128 >> i;
+    for (int c = 0; c < psize; c++)
+      for (int i = 0; i < 256; i++) luts_out[c * 256 + i] = (c == 3) ? id[i] : (uint8_t)(i & levmask);
+    return psize;
+  }
+  if (kind == 2) {
+    const double val[3] = {p0, p1, p2};
+    for (int k = 0; k < 3; k++)
+      for (int i = 0; i < 256; i++) {
+        const int ival = (int)(val[k] * i + .5);
+        t[k][i] = ival > 255 ? (uint8_t)255 : (uint8_t)ival;
+      }
+    const bool bgr = (palette == 2 || palette == 4);
+    const int offs = palette == 5 ? 1 : 0;
+    for (int c = 0; c < psize; c++) {
+      const uint8_t *src = id;
+      if (c != alpha) { const int k = c - offs; src = t[bgr ? 2 - k : k]; }
+      memcpy(luts_out + c * 256, src, 256);
+    }
+    return psize;
+  }
+  return 0;
+}

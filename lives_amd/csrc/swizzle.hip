@@ -183,6 +183,37 @@ __global__ __launch_bounds__(kBlock) void k_premult(uint8_t *pix, int rowstride,
   }
 }
 
+// --- per-byte-position LUTs: negate / posterise / ccorrect (scripts/{negate,posterise,ccorrect}.script) -----------------
+// Every byte position of a pixel has its own 256-entry table (identity where the effect copies the byte); lane = 4 pixels.
+struct Luts4 { uint32_t w[4][64]; };
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_byte_luts(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, Luts4 luts) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_l[4 * 256];
+  for (int i = threadIdx.x; i < 256; i += kBlock) reinterpret_cast<uint32_t *>(s_l)[i] = luts.w[i >> 6][i & 63];
+  __syncthreads();
+  const int x4 = (blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (x4 >= width) return;
+  const int n = width - x4 < 4 ? width - x4 : 4;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    const uint8_t *s = src + (size_t)y * irow + (size_t)x4 * PS;
+    uint8_t *d = dst + (size_t)y * orow + (size_t)x4 * PS;
+    if (PS == 4 && n == 4 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+      uint4 v = *reinterpret_cast<const uint4 *>(s);
+      uint32_t *pv = &v.x;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t p = pv[k];
+        pv[k] = s_l[p & 0xFF] | ((uint32_t)s_l[256 + ((p >> 8) & 0xFF)] << 8) | ((uint32_t)s_l[512 + ((p >> 16) & 0xFF)] << 16) | ((uint32_t)s_l[768 + (p >> 24)] << 24);
+      }
+      *reinterpret_cast<uint4 *>(d) = v;
+    } else {
+      for (int k = 0; k < n; k++)
+#pragma unroll
+        for (int c = 0; c < PS; c++) d[k * PS + c] = s_l[c * 256 + s[k * PS + c]];
+    }
+  }
+}
+
 static inline dim3 row_grid(unsigned items_per_row, int height) {
   unsigned gy = (unsigned)height;
   if (gy > 4096) gy = 4096;
@@ -258,6 +289,24 @@ extern "C" int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int 
   LGPU_REQUIRE((((uintptr_t)pix_d | (uintptr_t)rowstride) & 3) == 0, "4-byte pixels must be 4-byte aligned");
   hipLaunchKernelGGL(k_premult, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width,
                      height, alpha_first, un);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_byte_luts(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, const uint8_t *luts,
+                              void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && luts && width > 0 && height > 0, "null frame / tables or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(irow >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  Luts4 l = {};
+  for (int c = 0; c < psize; c++)
+    for (int i = 0; i < 64; i++)
+      l.w[c][i] = (uint32_t)luts[c * 256 + 4 * i] | ((uint32_t)luts[c * 256 + 4 * i + 1] << 8) | ((uint32_t)luts[c * 256 + 4 * i + 2] << 16) | ((uint32_t)luts[c * 256 + 4 * i + 3] << 24);
+  const dim3 grid = row_grid((unsigned)((width + 3) / 4), height);
+  if (psize == 4) hipLaunchKernelGGL(k_byte_luts<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, l);
+  else hipLaunchKernelGGL(k_byte_luts<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, l);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "lgpu_rgbdelay_create": [vp],
     "lgpu_rgbdelay_process": [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp],
     "lgpu_rgbdelay_destroy": [vp],
+    "lgpu_fx_luts": [ci, ci, cd, cd, cd, vp],
+    "lgpu_byte_luts": [vp, ci, vp, ci, ci, ci, ci, vp, vp],
     "lgpu_deinterlace": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_slide_over": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_softlight": [vp, vp, vp, vp, ci, ci, ci, ci, vp],

@@ -112,6 +112,19 @@ def transition(kind, src1, src2, dst, width, height, psize, amount):
              float(amount), stream_ptr())
 
 
+def fx_luts(kind, palette, p0=0., p1=0., p2=0.):
+    """host tables of negate (0) / posterise (1, p0 = levels) / ccorrect (2, p0..p2 = r, g, b factors); returns uint8 [psize][256] or None"""
+    out = np.zeros((4, 256), np.uint8)
+    ps = lib.load().lgpu_fx_luts(kind, palette, float(p0), float(p1), float(p2), out.ctypes.data)
+    return out[:ps].copy() if ps else None
+
+
+def byte_luts(src, dst, width, height, psize, luts):
+    luts = np.ascontiguousarray(luts, dtype=np.uint8)
+    assert luts.shape == (psize, 256)
+    lib.call("lgpu_byte_luts", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, luts.ctypes.data, stream_ptr())
+
+
 def deinterlace(src, dst, width, height, palette):
     """deinterlace.c:45-308; src is dst = in place"""
     lib.call("lgpu_deinterlace", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, palette, stream_ptr())

@@ -1753,3 +1753,44 @@ int orc_rgbdelay_process(orc_rgbdelay *s, const uint8_t *src, int irow, uint8_t 
   if (s->ccache < s->tcache) s->ccache++;                                                                /* :413-416 */
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F11: negate / posterise / ccorrect       reference: lives-plugins/weed-plugins/scripts/{negate,posterise,ccorrect}.script
+ * All three apply a table per byte position of the pixel.  kind 0 negate (<process>: colour bytes ^ 0xFF, alpha copied),
+ * 1 posterise (levmask built as in <process>; bytes 0..2 masked, byte 3 of a 4-byte pixel copied whatever the palette; no
+ * ARGB32), 2 ccorrect (<static> make_table + <process>: r / g / b tables at the palette's colour positions, alpha copied out
+ * of place / left in place).  Returns psize, 0 for a palette the effect does not list.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_fx_luts(int kind, int palette, double p0, double p1, double p2, uint8_t *luts) {
+  if (palette < 1 || palette > 5) return 0;
+  const int psize = palette <= 2 ? 3 : 4, alpha = palette == 5 ? 0 : (psize == 4 ? 3 : -1);
+  for (int c = 0; c < psize; c++)
+    for (int i = 0; i < 256; i++) luts[c * 256 + i] = (uint8_t)i;
+  if (kind == 0) {
+    for (int c = 0; c < psize; c++)
+      if (c != alpha) for (int i = 0; i < 256; i++) luts[c * 256 + i] = (uint8_t)(0xFF ^ i);
+    return psize;
+  }
+  if (kind == 1) {
+    unsigned char levmask = 128;
+    if (palette == 5) return 0;
+    for (int i = 1; i < (int)p0; i++) levmask += 128 >> i;
+    for (int c = 0; c < 3; c++) for (int i = 0; i < 256; i++) luts[c * 256 + i] = (uint8_t)(i & levmask);
+    return psize;
+  }
+  if (kind == 2) {
+    const double val[3] = {p0, p1, p2};
+    const int bgr = (palette == 2 || palette == 4), offs = palette == 5 ? 1 : 0;
+    for (int k = 0; k < 3; k++) {
+      uint8_t *t = luts + (size_t)(offs + (bgr ? 2 - k : k)) * 256;
+      for (int i = 0; i < 256; i++) { const int ival = (val[k] * i + .5); t[i] = ival > 255 ? (uint8_t)255 : (uint8_t)ival; }
+    }
+    return psize;
+  }
+  return 0;
+}
+void orc_byte_luts(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize, const uint8_t *luts) {
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++)
+      for (int c = 0; c < psize; c++) dst[(size_t)y * orow + x * psize + c] = luts[c * 256 + src[(size_t)y * irow + x * psize + c]];
+}

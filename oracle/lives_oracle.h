@@ -128,6 +128,9 @@ void orc_slide_over(const uint8_t *src1, int irow1, const uint8_t *src2, int iro
                     int psize, int transval, int dirn, int mvlower, int mvupper);
 /* deinterlace (deinterlace.c:45-308), packed palettes; src == dst = in place; -1 = not taken */
 int orc_deinterlace(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int palette);
+/* negate / posterise / ccorrect (the three scripts of that name): per-byte-position tables + their application */
+int orc_fx_luts(int kind, int palette, double p0, double p1, double p2, uint8_t *luts);
+void orc_byte_luts(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize, const uint8_t *luts);
 
 /* F6a: "softlight"  lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV: the stencil runs on plane 0 (rows
    1..h-2, columns 1..w-2; the frame border is copied), the other planes are copied (:143-151).

@@ -93,6 +93,8 @@ def oracle():
         _O.orc_cavg.argtypes = [ci, ci, ci]
         _O.orc_transition.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd]
         _O.orc_yuv_repack.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci]
+        _O.orc_fx_luts.argtypes = [ci, ci, cd, cd, cd, vp]
+        _O.orc_byte_luts.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
         _O.orc_deinterlace.argtypes = [vp, ci, vp, ci, ci, ci, ci]
         _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]

@@ -310,3 +310,23 @@ def test_rgbdelay_sequences_vs_reference_plugin(gpu):
             rd.process(src, d, 10, 6, pal, maxcache, on, st, yuv_clamped=(clamp == 0))
             assert (host(d) == fout[i]).all(), (name, i)
         rd.close()
+
+
+def test_script_effects_vs_reference_plugins(gpu):
+    g = gu.load("scriptfx.npz")
+    for rec in map(str, g["records"]):
+        _, kind, pal, prm, inplace = rec.split("|")
+        kind, pal = int(kind), int(pal)
+        p = [float(v) for v in prm.split(",")]
+        ps = 3 if pal <= 2 else 4
+        a, want = g[rec + "|a"], g[rec + "|o"]
+        luts = gpu.fx_luts(kind, pal, *p)
+        assert luts is not None and luts.shape == (ps, 256)
+        if inplace == "1":
+            d = dev(a)
+            gpu.byte_luts(d, d, 13, 5, ps, luts)
+        else:
+            d = dev(np.full_like(a, 0x5A))
+            gpu.byte_luts(dev(a), d, 13, 5, ps, luts)
+        assert (host(d) == want).all(), rec
+    assert gpu.fx_luts(1, 5, 3) is None           # posterise lists no ARGB32

@@ -459,6 +459,28 @@ def gu_params(groups):
     return gu.rgbdelay_params(groups)
 
 
+@pytest.mark.parametrize("psize", [3, 4])
+def test_byte_luts(gpu, orc, psize):
+    rng = np.random.default_rng(3000 + psize)
+    for (w, h) in [(64, 8), (67, 5), (1, 1), (641, 33), (1920, 16)]:
+        luts = rng.integers(0, 256, (psize, 256), dtype=np.uint8)
+        for inplace in (0, 1):
+            src = frame(rng, w, h, psize)
+            want = src.copy() if inplace else np.full_like(src, 0x5A)
+            a = want if inplace else src
+            orc.orc_byte_luts(P(a), a.strides[0], P(want), want.strides[0], w, h, psize, luts.ctypes.data)
+            ds = dev(src)
+            d = ds if inplace else dev(np.full_like(src, 0x5A))
+            gpu.byte_luts(ds, d, w, h, psize, luts)
+            assert (host(d) == want).all(), "byte_luts ps=%d %dx%d inplace=%d" % (psize, w, h, inplace)
+    for kind in (0, 1, 2):
+        for pal in (1, 2, 3, 4, 5):
+            ref = np.zeros((4, 256), np.uint8)
+            n = orc.orc_fx_luts(kind, pal, 3.0, 0.6, 1.9, ref.ctypes.data)
+            got = gpu.fx_luts(kind, pal, 3.0, 0.6, 1.9)
+            assert (got is None and n == 0) or (got == ref[:n]).all()
+
+
 # ---------------------------------------------------------------------------------------------- K5b YUV -> YUV repacks
 @pytest.mark.parametrize("pair", po.YUV_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
 def test_yuv_repack(gpu, orc, pair):

@@ -348,3 +348,19 @@ def test_rgbdelay_sequences(orc):
                                             on.ctypes.data, st.ctypes.data) == 0
             assert (got == fout[i]).all(), (name, i)
         orc.orc_rgbdelay_free(s)
+
+
+def test_script_effects(orc):
+    g = gu.load("scriptfx.npz")
+    for rec in map(str, g["records"]):
+        _, kind, pal, prm, inplace = rec.split("|")
+        kind, pal = int(kind), int(pal)
+        p = [float(v) for v in prm.split(",")]
+        ps = 3 if pal <= 2 else 4
+        a, want = g[rec + "|a"], g[rec + "|o"]
+        luts = np.zeros((4, 256), np.uint8)
+        assert orc.orc_fx_luts(kind, pal, p[0], p[1], p[2], luts.ctypes.data) == ps
+        got = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
+        src = got if inplace == "1" else a
+        orc.orc_byte_luts(P(src), src.strides[0], P(got), got.strides[0], 13, 5, ps, luts.ctypes.data)
+        assert (got == want).all(), rec

@@ -22,8 +22,9 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 26
-    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace", "RGBdelay"):
+    assert len(ours) == 29
+    for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace", "RGBdelay", "negate", "posterise",
+                 "ccorrect"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
@@ -221,3 +222,24 @@ def test_rgbdelay_sequences_through_the_plugin():
             H.H.refhost_set_yuv_clamping(-1)
         for i in range(len(frames)):
             assert (out[i] == fout[i]).all(), (name, i)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_script_effect_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("scriptfx.npz")
+    names = ["negate", "posterise", "ccorrect"]
+    for rec in map(str, g["records"]):
+        _, kind, pal, prm, inplace = rec.split("|")
+        kind, pal = int(kind), int(pal)
+        p = [float(v) for v in prm.split(",")]
+        params = [] if kind == 0 else [po.p_int(int(p[0]))] if kind == 1 else [po.p_double(v) for v in p]
+        a, want = g[rec + "|a"], g[rec + "|o"]
+        if inplace == "1":
+            d = a.copy()
+            H.run(OURS, names[kind], pal, 13, 5, [d], d, params)
+        else:
+            d = np.full_like(a, 0x5A)
+            H.run(OURS, names[kind], pal, 13, 5, [a.copy()], d, params)
+        assert (d == want).all(), rec
