@@ -19,10 +19,14 @@
  *
  * Coverage (anything else returns FALSE with the layer untouched, lgpu_last_error() says why):
  *   convert_layer_palette[_full]  RGB24/BGR24/RGBA32/BGRA32/ARGB32 <-> each other (selector tree
- *                                 src/colourspace.c:12370-12556, LUT8 gamma inline), YUV420P/YVU420P/YUV422P ->
- *                                 those five (src/colourspace.c:13400-13560)
+ *                                 src/colourspace.c:12370-12556, LUT8 gamma inline); YUV420P/YVU420P/YUV422P ->
+ *                                 those five (:13400-13560, LUT16 gamma fused when a target gamma is given); RGB -> YUV888 /
+ *                                 YUVA8888 / YUV(A)444(4)P / UYVY / YUYV / YUV420P / YVU420P / YUV422P and those packed / 4:4:4
+ *                                 planar / UYVY / YUYV palettes -> RGB; the clamped <-> unclamped switch; the YUV -> YUV pairs of
+ *                                 lgpu_yuv_repack (lives_gpu.h)
  *   gamma_convert_layer / gamma_convert_sub_layer, alpha_premult, resize_layer, letterbox_layer (packed RGB
- *   palettes and YUV420P / YVU420P / YUV422P / YUV444P planes), create_empty_pixel_data, calc_rowstrides
+ *   palettes and YUV420P / YVU420P / YUV422P / YUV444P planes; palette hints see INTEGRATION.md), create_empty_pixel_data,
+ *   calc_rowstrides (with the fixed-rowstride rule when leaf_get_flags is bound)
  */
 #ifndef LIVES_GPU_LAYER_H
 #define LIVES_GPU_LAYER_H
@@ -41,6 +45,8 @@ typedef struct {
   weed_leaf_delete_f leaf_delete;
   void *(*pixel_alloc)(size_t bytes);     /* frame allocator (LiVES: lives_calloc_safety); NULL -> calloc */
   void (*pixel_free)(void *);             /* LiVES: lives_free; NULL -> free */
+  weed_leaf_get_flags_f leaf_get_flags;   /* optional (may be NULL): lets calc_rowstrides honour rowstrides flagged LIVES_FLAG_CONST_VALUE
+                                             (decoder plugins with fixed strides, src/colourspace.c:11268-11275, :11358-11363) */
 } lives_gpu_weed_api;
 
 /* prefs the reference reads on this path (src/preferences.h: apply_gamma, alpha_post, pb_quality, screen_gamma) */

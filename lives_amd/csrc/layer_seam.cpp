@@ -117,11 +117,29 @@ void free_planes(const Layer &l) {
   else for (int i = 0; i < l.nplanes; i++) pfree(l.pd[i]);
 }
 
+// fixed rowstrides (:11268-11275): a "new_rowstrides" leaf, or rowstrides flagged LIVES_FLAG_CONST_VALUE (1 << 16, src/main.h:127); taken per
+// plane when computed <= fixed < 2 * computed (the reference's integer `constrs[i] / rs[i]` between .75 and 1.25, :11358-11363)
+void apply_const_rowstrides(weed_plant_t *layer, int n, int *rs) {
+  if (!layer || !bound()) return;
+  const char *key = nullptr;
+  if (has_leaf(layer, "new_rowstrides")) key = WEED_LEAF_ROWSTRIDES;        // the reference reads the rowstrides leaf in both cases (:11269, :11273)
+  else if (g_api.leaf_get_flags && has_leaf(layer, WEED_LEAF_ROWSTRIDES) && (g_api.leaf_get_flags(layer, WEED_LEAF_ROWSTRIDES) & (1 << 16))) key = WEED_LEAF_ROWSTRIDES;
+  if (!key) return;
+  const int have = (int)g_api.leaf_num_elements(layer, key);
+  for (int i = 0; i < n && i < have; i++) {
+    int32_t c = 0;
+    if (g_api.leaf_get(layer, key, (weed_size_t)i, &c) != WEED_SUCCESS || rs[i] <= 0) continue;
+    const int q = c / rs[i];
+    if (q >= .75 && q <= 1.25) rs[i] = c;
+  }
+}
+
 // new host planes for (pal, width, height) with the reference's rowstride rule; one block for planar ("contiguous")
 struct NewPlanes { int n; int rs[4]; uint8_t *pd[4]; size_t sz[4]; };
-bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np) {
+bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np, weed_plant_t *fixed_from = nullptr) {
   np->n = lgpu_calc_rowstrides(width, pal, alignment, np->rs);
   if (np->n < 1) return false;
+  apply_const_rowstrides(fixed_from, np->n, np->rs);
   size_t tot = 0;
   for (int i = 0; i < np->n; i++) {
     const int h = (i == 0 || pal_is_444(pal) || pal == WEED_PALETTE_YUV422P) ? height : height >> 1;
@@ -326,6 +344,7 @@ int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int
   const int n = lgpu_calc_rowstrides(width, pal, 0, rs);
   if (nplanes) *nplanes = n;
   if (!n) return nullptr;
+  apply_const_rowstrides(layer, n, rs);
   int *out = (int *)calloc((size_t)n, sizeof(int));      // caller frees with lives_free, like the reference
   for (int i = 0; i < n; i++) out[i] = rs[i];
   return out;
@@ -393,7 +412,7 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
   Layer old;
   const bool had = read_layer(layer, &old);
   NewPlanes np;
-  if (!alloc_planes(pal, width, height, 0, &np)) return 0;
+  if (!alloc_planes(pal, width, height, 0, &np, layer)) return 0;
   if (black_fill) {
     // opaque black: RGB 0,0,0 (alpha 255); YUV 16 (clamped) or 0, 128, 128 (src/colourspace.c:11448-11460)
     const int clamping = get_int(layer, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED);

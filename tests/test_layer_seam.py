@@ -45,6 +45,19 @@ def test_host_side_functions_without_gpu(seam):
     planes, _, rs = wh.planes_of(lay)
     assert wh.geti(lay, "width") == 10 and wh.geti(lay, "height") == 4 and rs == [32, 16, 16]
     assert (planes[0] == 16).all() and (planes[1] == 128).all() and (planes[2] == 128).all()
+    # fixed rowstrides of a decoder plugin (src/colourspace.c:11268-11275, :11358-11363): the rowstrides leaf flagged LIVES_FLAG_CONST_VALUE
+    # (1 << 16) wins per plane while computed <= fixed < 2 * computed
+    W = wh.weed()
+    set_flags = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32)(W.fn["weed_leaf_set_flags"])
+    get_flags = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_char_p)(W.fn["weed_leaf_get_flags"])
+    lay = wh.new_layer(YUV420P, 640, 4, [np.zeros((4, 704), np.uint8), np.zeros((2, 352), np.uint8), np.zeros((2, 2048), np.uint8)], clamping=0)
+    rs = L.lives_gpu_calc_rowstrides(0, 0, lay, ctypes.byref(n))
+    assert [rs[0], rs[1], rs[2]] == [640, 320, 320]                       # not flagged: the ordinary rule
+    set_flags(lay, b"rowstrides", get_flags(lay, b"rowstrides") | (1 << 16))
+    rs = L.lives_gpu_calc_rowstrides(0, 0, lay, ctypes.byref(n))
+    assert [rs[0], rs[1], rs[2]] == [704, 352, 320]                       # 2048 >= 2 * 320: that plane keeps the computed stride
+    assert L.lives_gpu_create_empty_pixel_data(lay, 0, 1) == 1
+    assert wh.planes_of(lay)[2] == [704, 352, 320]
 
 
 @needs_ref

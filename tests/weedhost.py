@@ -36,18 +36,18 @@ def weed():
         W.weed_get_int_array_counted.restype = ctypes.POINTER(ci)
         W.weed_plant_has_leaf.argtypes = [vp, ctypes.c_char_p]
         W.plant_new = ctypes.CFUNCTYPE(vp, ctypes.c_int32)(vp.in_dll(W, "weed_plant_new").value)
-        W.fn = {n: vp.in_dll(W, n).value for n in ("weed_leaf_get", "weed_leaf_set", "weed_leaf_num_elements", "weed_leaf_delete")}
+        W.fn = {n: vp.in_dll(W, n).value for n in ("weed_leaf_get", "weed_leaf_set", "weed_leaf_num_elements", "weed_leaf_delete", "weed_leaf_get_flags", "weed_leaf_set_flags")}
         _W = W
     return _W
 
 
 class WeedApi(ctypes.Structure):
-    _fields_ = [("leaf_get", vp), ("leaf_set", vp), ("leaf_num_elements", vp), ("leaf_delete", vp), ("pixel_alloc", vp), ("pixel_free", vp)]
+    _fields_ = [("leaf_get", vp), ("leaf_set", vp), ("leaf_num_elements", vp), ("leaf_delete", vp), ("pixel_alloc", vp), ("pixel_free", vp), ("leaf_get_flags", vp)]
 
 
 def bind(L):
     W = weed()
-    api = WeedApi(W.fn["weed_leaf_get"], W.fn["weed_leaf_set"], W.fn["weed_leaf_num_elements"], W.fn["weed_leaf_delete"], None, None)
+    api = WeedApi(W.fn["weed_leaf_get"], W.fn["weed_leaf_set"], W.fn["weed_leaf_num_elements"], W.fn["weed_leaf_delete"], None, None, W.fn["weed_leaf_get_flags"])
     L.lives_gpu_bind_weed.argtypes = [ctypes.POINTER(WeedApi)]
     assert L.lives_gpu_bind_weed(ctypes.byref(api)) == 0
     for name, args in (("lives_gpu_convert_layer_palette", [vp, ci, ci]), ("lives_gpu_convert_layer_palette_full", [vp, ci, ci, ci, ci, ci]),
