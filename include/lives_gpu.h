@@ -232,6 +232,11 @@ void lgpu_rgbdelay_destroy(lgpu_rgbdelay *rd);
    out of place).  LGPU_E_UNSUPPORTED: planar palettes, ARGB32 out of place, a width that is not a multiple of 3 with rows
    too tight for the last partial triple. */
 int lgpu_deinterlace(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette, void *stream);
+/* "triple split": lives-plugins/weed-plugins/layout_blends.c:24-113, RGB24 / BGR24.  start / end / border_width are the float parameters,
+   symmetrical = "sym", split_rows = "vert", border_rgb[3] = "borderc".  src1_d == dst_d = in place (the middle band is then left alone). */
+int lgpu_triple_split(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow, int width, int height,
+                      int is_bgr, double start, int symmetrical, double end, int split_rows, double border_width, const int *border_rgb,
+                      void *stream);
 /* "slide over": lives-plugins/weed-plugins/slide_over.c:54-146.  amount = the transition parameter 0..255; direction 1..4 as
    sover_init stores it in "plugin_direction" (:40-51; 0 = random is drawn by the caller, :83-86); slide_lower / slide_upper =
    the "mlower" / "mupper" switches.  Packed pixels of 3 or 4 bytes, not in place. */

@@ -580,6 +580,34 @@ __global__ __launch_bounds__(kBlock) void k_slide_over(SlideArgs a) {
     for (int k = 0; k < PS; k++) d[k] = from[k];
   }
 }
+
+// triple split (layout_blends.c:24-113): per-pixel select between src2 (outer bands), src1 (middle band) and the border colour
+struct TsplitArgs {
+  const uint8_t *src1, *src2;
+  uint8_t *dst;
+  int irow1, irow2, orow, width, height, inplace;
+  double c_lo_out, c_hi_out, c_lo_in, c_hi_in;   // width_bytes * (xstart - bw), * (xend + bw), * (xstart + bw), * (xend - bw)
+  int tbs, tbe, bbs, bbe;
+  uint8_t bc[4];
+};
+__global__ __launch_bounds__(kBlock) void k_triple_split(TsplitArgs a) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= a.width) return;
+  const int j = 3 * x;
+  const bool col_out = (double)j < a.c_lo_out || (double)j >= a.c_hi_out;
+  const bool col_in = (double)j > a.c_lo_in && (double)j < a.c_hi_in;
+  for (int r = blockIdx.y; r < a.height; r += gridDim.y) {
+    uint8_t *d = a.dst + (size_t)r * a.orow + j;
+    if (col_out && (r <= a.tbs || r >= a.bbe)) {
+      const uint8_t *s = a.src2 + (size_t)r * a.irow2 + j;
+      d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    } else if (col_in || (r > a.tbe && r < a.bbs)) {
+      if (!a.inplace) { const uint8_t *s = a.src1 + (size_t)r * a.irow1 + j; d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+    } else {
+      d[0] = a.bc[0]; d[1] = a.bc[1]; d[2] = a.bc[2];
+    }
+  }
+}
 }  // namespace lgpu
 
 extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
@@ -640,6 +668,37 @@ extern "C" int lgpu_slide_over(const uint8_t *src1_d, int irow1, const uint8_t *
   const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
   if (psize == 4) hipLaunchKernelGGL(lgpu::k_slide_over<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(lgpu::k_slide_over<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_triple_split(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow, int width, int height,
+                                 int is_bgr, double start, int symmetrical, double end, int split_rows, double border_width, const int *border_rgb,
+                                 void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src1_d && src2_d && dst_d && border_rgb && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(irow1 >= width * 3 && irow2 >= width * 3 && orow >= width * 3, "rowstride smaller than a row");
+  LGPU_REQUIRE(dst_d != src2_d, "only the first input may be the output (layout_blends.c:36)");
+  lgpu::TsplitArgs a;
+  a.src1 = src1_d; a.src2 = src2_d; a.dst = dst_d; a.irow1 = irow1; a.irow2 = irow2; a.orow = orow; a.width = width; a.height = height;
+  a.inplace = (src1_d == dst_d);
+  // the reference's own double arithmetic (:56-83); the byte column j is compared as an int promoted to double
+  double xstart = start, xend = end;
+  const double bw = border_width;
+  if (symmetrical) { xstart /= 2.; xend = 1. - xstart; }
+  if (xstart > xend) { const double t = xend; xend = xstart; xstart = t; }
+  a.bc[0] = (uint8_t)border_rgb[is_bgr ? 2 : 0]; a.bc[1] = (uint8_t)border_rgb[1]; a.bc[2] = (uint8_t)border_rgb[is_bgr ? 0 : 2]; a.bc[3] = 0;
+  a.tbs = a.tbe = a.bbs = a.bbe = height;
+  if (split_rows) {
+    a.tbs = (int)(height * (xstart - bw) + .5); a.tbe = (int)(height * (xstart + bw) + .5);
+    a.bbs = (int)(height * (xend - bw) + .5); a.bbe = (int)(height * (xend + bw) + .5);
+    xstart = xend = -bw;
+  }
+  const int wb = width * 3;
+  a.c_lo_out = wb * (xstart - bw); a.c_hi_out = wb * (xend + bw); a.c_lo_in = wb * (xstart + bw); a.c_hi_in = wb * (xend - bw);
+  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
+  hipLaunchKernelGGL(lgpu::k_triple_split, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -239,6 +239,16 @@ static int k_scriptfx(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (lgpu_fx_luts(kind, f->pal, p0, p1, p2, luts) != f->psize) return LGPU_E_UNSUPPORTED;
   return lgpu_byte_luts(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, luts, NULL);
 }
+/* "triple split" (layout_blends.c:24-113) */
+static int k_tsplit(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  weed_plant_t *pc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 6);
+  int bc[3] = {0, 0, 0};
+  (void)kind;
+  if (pc) { bc[0] = g_int(pc, WEED_LEAF_VALUE, 0, 0); bc[1] = g_int(pc, WEED_LEAF_VALUE, 1, 0); bc[2] = g_int(pc, WEED_LEAF_VALUE, 2, 0); }
+  return lgpu_triple_split(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->pal == WEED_PALETTE_BGR24,
+                           param_dbl(inst, 0, 0.666667), param_bool(inst, 1, WEED_TRUE), param_dbl(inst, 3, 0.333333), param_bool(inst, 4, WEED_FALSE),
+                           param_dbl(inst, 5, 0.), bc, NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -320,6 +330,7 @@ PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mir
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
 PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1) PROC(p_rgbdelay, 1, 0, k_rgbdelay, 1)
+PROC(p_tsplit, 2, 0, k_tsplit, 1)
 PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(p_ccorrect, 1, 2, k_scriptfx, 0)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
@@ -539,6 +550,18 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     p[1] = float_param("green", "_Green factor", 1., 0., 4.);
     p[2] = float_param("blue", "_Blue factor", 1., 0., 4.);
     add_filter(pinfo, "ccorrect", 0, rgbx, 5, p_ccorrect, 1, "in_channel0", NULL, "out_channel0", p, 3);
+  }
+  /* layout_blends.c:121-153: "triple split", RGB24 / BGR24, seven parameters (two of them radios of group 1), out channel in place */
+  {
+    static const int32_t p24[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24};
+    p[0] = float_param("start", "_Start", 0.666667, 0., 1.);
+    p[1] = switch_param("sym", "Make s_ymmetrical", WEED_TRUE); s_int(p[1], WEED_LEAF_GROUP, 1);
+    p[2] = switch_param("usend", "Use _end value", WEED_FALSE); s_int(p[2], WEED_LEAF_GROUP, 1);
+    p[3] = float_param("end", "_End", 0.333333, 0., 1.);
+    p[4] = switch_param("vert", "Split _horizontally", WEED_FALSE);
+    p[5] = float_param("borderw", "Border _width", 0., 0., 0.5);
+    p[6] = rgb_param("borderc", "Border _colour", 0, 0, 0);
+    add_filter(pinfo, "triple split", 0, p24, 2, p_tsplit, 2, "in channel 0", "in channel 1", "out channel 0", p, 7);
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

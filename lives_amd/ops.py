@@ -130,6 +130,13 @@ def deinterlace(src, dst, width, height, palette):
     lib.call("lgpu_deinterlace", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, palette, stream_ptr())
 
 
+def triple_split(src1, src2, dst, width, height, is_bgr, start, sym, end, vert, bw, rgb):
+    """layout_blends.c:24-113; src1 is dst = in place"""
+    col = (ctypes.c_int * 3)(*[int(v) for v in rgb])
+    lib.call("lgpu_triple_split", dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width, height, int(bool(is_bgr)),
+             float(start), int(bool(sym)), float(end), int(bool(vert)), float(bw), ctypes.addressof(col), stream_ptr())
+
+
 def slide_over(src1, src2, dst, width, height, psize, amount, direction, slide_lower=True, slide_upper=False):
     """slide_over.c:54-146; direction 1..4 as sover_init stores it"""
     lib.call("lgpu_slide_over", dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width, height, psize,

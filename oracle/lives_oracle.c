@@ -1794,3 +1794,33 @@ void orc_byte_luts(const uint8_t *src, int irow, uint8_t *dst, int orow, int wid
     for (int x = 0; x < width; x++)
       for (int c = 0; c < psize; c++) dst[(size_t)y * orow + x * psize + c] = luts[c * 256 + src[(size_t)y * irow + x * psize + c]];
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F12: triple split                       reference: lives-plugins/weed-plugins/layout_blends.c:24-113
+ * RGB24 / BGR24.  The middle band shows src1, the outer bands src2, a border of colour bc between them; vert = the bands are rows.
+ * The comparisons are kept in the reference's types: byte column j (int) against width-in-bytes * double, rows as row indices
+ * (the reference compares row pointers; without `vert` all four row bounds are the end pointer).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_triple_split(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height, int is_bgr,
+                      double xstart, int sym, double xend, int vert, double bw, const int *bc_in) {
+  const int wb = width * 3, inplace = (src1 == dst);
+  int bc[3] = {bc_in[0], bc_in[1], bc_in[2]};
+  int tbs = height, tbe = height, bbs = height, bbe = height;
+  if (sym) { xstart /= 2.; xend = 1. - xstart; }
+  if (xstart > xend) { const double t = xend; xend = xstart; xstart = t; }
+  if (is_bgr) { const int t = bc[2]; bc[2] = bc[0]; bc[0] = t; }
+  if (vert) {
+    tbs = (int)(height * (xstart - bw) + .5); tbe = (int)(height * (xstart + bw) + .5);
+    bbs = (int)(height * (xend - bw) + .5); bbe = (int)(height * (xend + bw) + .5);
+    xstart = xend = -bw;
+  }
+  for (int r = 0; r < height; r++) {
+    const uint8_t *s1 = src1 + (size_t)r * irow1, *s2 = src2 + (size_t)r * irow2;
+    uint8_t *d = dst + (size_t)r * orow;
+    for (int j = 0; j < wb; j += 3) {
+      if ((j < wb * (xstart - bw) || j >= wb * (xend + bw)) && (r <= tbs || r >= bbe)) { memcpy(d + j, s2 + j, 3); continue; }
+      if ((j > wb * (xstart + bw) && j < wb * (xend - bw)) || (r > tbe && r < bbs)) { if (!inplace) memcpy(d + j, s1 + j, 3); continue; }
+      d[j] = (uint8_t)bc[0]; d[j + 1] = (uint8_t)bc[1]; d[j + 2] = (uint8_t)bc[2];
+    }
+  }
+}

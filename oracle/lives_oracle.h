@@ -126,6 +126,9 @@ void orc_transition(int type, const uint8_t *src1, int irow1, const uint8_t *src
 /* slide over (slide_over.c:54-146): dirn 1..4 as stored by sover_init, transval 0..255 */
 void orc_slide_over(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height,
                     int psize, int transval, int dirn, int mvlower, int mvupper);
+/* triple split (layout_blends.c:24-113), RGB24 / BGR24; src1 == dst = in place */
+void orc_triple_split(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height, int is_bgr,
+                      double xstart, int sym, double xend, int vert, double bw, const int *bc);
 /* deinterlace (deinterlace.c:45-308), packed palettes; src == dst = in place; -1 = not taken */
 int orc_deinterlace(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int palette);
 /* negate / posterise / ccorrect (the three scripts of that name): per-byte-position tables + their application */

@@ -96,6 +96,7 @@ def oracle():
         _O.orc_fx_luts.argtypes = [ci, ci, cd, cd, cd, vp]
         _O.orc_byte_luts.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
         _O.orc_deinterlace.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+        _O.orc_triple_split.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, ci, cd, ci, cd, vp]
         _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]

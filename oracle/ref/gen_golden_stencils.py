@@ -110,8 +110,26 @@ def main():
                 dnames.append(key)
     de["records"] = np.array(dnames)
     np.savez_compressed(os.path.join(OUT, "deinterlace.npz"), **de)
+    # triple split (layout_blends.c)
+    ts, tsn = {}, []
+    for pal in (1, 2):
+        for (start, sym, end, vert, bw) in ((0.666667, 1, 0.333333, 0, 0.), (0.3, 0, 0.8, 0, 0.05), (0.5, 1, 0.2, 1, 0.1), (0.9, 0, 0.1, 1, 0.), (0.0, 1, 0.0, 0, 0.2),
+                                            (1.0, 0, 1.0, 0, 0.03)):
+            for inplace in (0, 1):
+                w, h = 21, 12
+                s1, s2 = po.make_frame(rng, w, h, 3), po.make_frame(rng, w, h, 3)
+                d = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                prm = [po.p_double(start), po.p_bool(sym), po.p_bool(not sym), po.p_double(end), po.p_bool(vert), po.p_double(bw), po.p_rgb(200, 100, 50)]
+                H.run(po.refplugin("layout_blends"), "triple split", pal, w, h, [d if inplace else s1, s2], d, prm)
+                key = "ts|%d|%r|%d|%r|%d|%r|%d" % (pal, start, sym, end, vert, bw, inplace)
+                ts[key + "|a"], ts[key + "|b"], ts[key + "|o"] = s1, s2, d
+                tsn.append(key)
+    ts["records"] = np.array(tsn)
+    np.savez_compressed(os.path.join(OUT, "triple_split.npz"), **ts)
     mpath = os.path.join(OUT, "manifest.json")
     man = json.load(open(mpath))
+    man["groups"]["triple_split.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/layout_blends.c; record ts|palette|start|symmetrical|end|"
+                                         "split horizontally|border width|in place; border colour 200,100,50; 21x12; a / b sources, o result")
     man["groups"]["deinterlace.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/deinterlace.c; record de|palette|in place|w|h "
                                         "(w in macropixels for 564 / 565); a source, o result (out of place: destination pre-filled with 0x5A)")
     man["groups"]["slide_over.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/slide_over.c; record "

@@ -330,3 +330,14 @@ def test_script_effects_vs_reference_plugins(gpu):
             gpu.byte_luts(dev(a), d, 13, 5, ps, luts)
         assert (host(d) == want).all(), rec
     assert gpu.fx_luts(1, 5, 3) is None           # posterise lists no ARGB32
+
+
+def test_triple_split_vs_reference_plugin(gpu):
+    g = gu.load("triple_split.npz")
+    for rec in map(str, g["records"]):
+        _, pal, start, sym, end, vert, bw, inplace = rec.split("|")
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        s1 = dev(a)
+        d = s1 if inplace == "1" else dev(np.full_like(a, 0x5A))
+        gpu.triple_split(s1, dev(b), d, 21, 12, pal == "2", float(start), int(sym), float(end), int(vert), float(bw), (200, 100, 50))
+        assert (host(d) == want).all(), rec

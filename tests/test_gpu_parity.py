@@ -481,6 +481,24 @@ def test_byte_luts(gpu, orc, psize):
             assert (got is None and n == 0) or (got == ref[:n]).all()
 
 
+def test_triple_split(gpu, orc):
+    rng = np.random.default_rng(3100)
+    bc = np.array([13, 250, 77], np.int32)
+    for (w, h) in [(20, 10), (33, 17), (301, 50), (2, 2)]:
+        for is_bgr in (0, 1):
+            for (start, sym, end, vert, bw) in [(0.666667, 1, 0.333333, 0, 0.), (0.25, 0, 0.75, 0, 0.04), (0.4, 1, 0.0, 1, 0.07), (0.8, 0, 0.3, 1, 0.5),
+                                                (0.0, 0, 1.0, 0, 0.0), (0.5, 0, 0.5, 1, 0.01)]:
+                for inplace in (0, 1):
+                    s1, s2 = frame(rng, w, h, 3), frame(rng, w, h, 3)
+                    want = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                    a = want if inplace else s1
+                    orc.orc_triple_split(P(a), a.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, is_bgr, start, sym, end, vert, bw, bc.ctypes.data)
+                    d1 = dev(s1)
+                    d = d1 if inplace else dev(np.full_like(s1, 0x5A))
+                    gpu.triple_split(d1, dev(s2), d, w, h, is_bgr, start, sym, end, vert, bw, bc)
+                    assert_same(host(d), want, w, h, 3, "triple split %dx%d %r inplace=%d" % (w, h, (start, sym, end, vert, bw), inplace))
+
+
 # ---------------------------------------------------------------------------------------------- K5b YUV -> YUV repacks
 @pytest.mark.parametrize("pair", po.YUV_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
 def test_yuv_repack(gpu, orc, pair):

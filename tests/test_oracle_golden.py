@@ -364,3 +364,20 @@ def test_script_effects(orc):
         src = got if inplace == "1" else a
         orc.orc_byte_luts(P(src), src.strides[0], P(got), got.strides[0], 13, 5, ps, luts.ctypes.data)
         assert (got == want).all(), rec
+
+
+def _tsplit_cases(g):
+    for rec in map(str, g["records"]):
+        _, pal, start, sym, end, vert, bw, inplace = rec.split("|")
+        yield rec, int(pal), float(start), int(sym), float(end), int(vert), float(bw), int(inplace)
+
+
+def test_triple_split(orc):
+    g = gu.load("triple_split.npz")
+    bc = np.array([200, 100, 50], np.int32)
+    for rec, pal, start, sym, end, vert, bw, inplace in _tsplit_cases(g):
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        got = a.copy() if inplace else np.full_like(a, 0x5A)
+        s1 = got if inplace else a
+        orc.orc_triple_split(P(s1), s1.strides[0], P(b), b.strides[0], P(got), got.strides[0], 21, 12, pal == 2, start, sym, end, vert, bw, bc.ctypes.data)
+        assert (got == want).all(), rec

@@ -22,9 +22,9 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 29
+    assert len(ours) == 30
     for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace", "RGBdelay", "negate", "posterise",
-                 "ccorrect"):
+                 "ccorrect", "layout_blends"):
         for rf in H.filters(po.refplugin(plug)):
             o = ours[rf["name"]]
             assert (o["n_in"], o["n_out"], o["n_params"]) == (rf["n_in"], rf["n_out"], rf["n_params"]), rf["name"]
@@ -242,4 +242,19 @@ def test_script_effect_records_through_the_plugin():
         else:
             d = np.full_like(a, 0x5A)
             H.run(OURS, names[kind], pal, 13, 5, [a.copy()], d, params)
+        assert (d == want).all(), rec
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_triple_split_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("triple_split.npz")
+    for rec in map(str, g["records"]):
+        _, pal, start, sym, end, vert, bw, inplace = rec.split("|")
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        prm = [po.p_double(float(start)), po.p_bool(int(sym)), po.p_bool(not int(sym)), po.p_double(float(end)), po.p_bool(int(vert)), po.p_double(float(bw)),
+               po.p_rgb(200, 100, 50)]
+        d = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
+        H.run(OURS, "triple split", int(pal), 21, 12, [d if inplace == "1" else a.copy(), b.copy()], d, prm)
         assert (d == want).all(), rec
