@@ -283,8 +283,10 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
   __shared__ uint4 s_win4[kG5WH * kG5WW / 2];
   __shared__ uint2 s_h[kG5WH * kG5W];
   __shared__ uint8_t s_lut[256];
+  __shared__ float s_alpha[EPI ? 256 : 1];
   uint2 *s_win = reinterpret_cast<uint2 *>(s_win4);
   const int tid = threadIdx.x, trk = blockIdx.y;
+  if (EPI && a.blend) s_alpha[tid] = (float)((double)(float)tid / 255.);     // simple_blend.c:137 (the first barrier below publishes it)
   const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
   const int tx0 = tx * kG5W, ty00 = ty * (kG5H * kG5Sub);
   const int nsub = min(kG5Sub, (a.h - ty00 + kG5H - 1) / kG5H);
@@ -340,22 +342,66 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
       uint2 r[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) r[k] = s_h[(rg * 4 + k) * kG5W + col];
+      uint32_t px[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int oy = ty0 + rg * 4 + j;
-        if (oy >= a.h) break;
         const uint32_t ev = g5_sum(r[j].x, r[j + 1].x, r[j + 2].x, r[j + 3].x, r[j + 4].x) + 0x00800080u;
         const uint32_t od = g5_sum(r[j].y, r[j + 1].y, r[j + 2].y, r[j + 3].y, r[j + 4].y) + 0x00800080u;
-        uint32_t p = __builtin_amdgcn_perm(od, ev, 0x07030501u);     // >> 8 of the four 16-bit lanes, re-interleaved
-        if (EPI) {
-          if (a.blend) {
-            const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[ox];
-            p = chroma_rgba(p, q, bf, nbf);
-          }
-          if (a.use_lut) p = lut3_rgba(s_lut, p);
-        }
-        reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[ox] = p;
+        px[j] = __builtin_amdgcn_perm(od, ev, 0x07030501u);     // >> 8 of the four 16-bit lanes, re-interleaved
       }
+      const int oy0 = ty0 + rg * 4;
+      if (EPI) {
+        if (a.blend) {
+          // chroma blend as in k_half8s: opaque layer-2 pixels mix directly, translucent ones scale both sources first
+          // (simple_blend.c:128-146); alpha from the LDS table, products truncated + packed by v_cvt_pk_u8_f32 under RTZ
+          uint32_t q[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) q[j] = (oy0 + j < a.h) ? reinterpret_cast<const uint32_t *>(l2 + (size_t)(oy0 + j) * a.irow2)[ox] : 0xFF000000u;
+          const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+          bool opaque = true;
+#pragma unroll
+          for (int j = 0; j < 4; j++) opaque = opaque && ((q[j] >> 24) == 255);
+          if (__all(opaque)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) px[j] = mix3_dot4(px[j], q[j], w_lo, w_hi) | (px[j] & 0xFF000000u);
+          } else {
+            uint32_t f1[4], f2[4];
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              float m[12];
+#pragma unroll
+              for (int k = 0; k < 2; k++) {
+                const float alpha = s_alpha[q[i + k] >> 24], inv = __fsub_rn(1.0f, alpha);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                  m[k * 6 + c] = __fmul_rn((float)((q[i + k] >> (8 * c)) & 0xFF), alpha);
+                  m[k * 6 + 3 + c] = __fmul_rn((float)((px[i + k] >> (8 * c)) & 0xFF), inv);
+                }
+              }
+              asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                           "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\tv_cvt_pk_u8_f32 %0, %5, 1, %0\n\tv_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                           "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                           "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\tv_cvt_pk_u8_f32 %2, %11, 1, %2\n\tv_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
+                           "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\tv_cvt_pk_u8_f32 %3, %14, 1, %3\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
+                           "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                           : "=&v"(f2[i]), "=&v"(f1[i]), "=&v"(f2[i + 1]), "=&v"(f1[i + 1])
+                           : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const bool op = (q[j] >> 24) == 255;
+              px[j] = mix3_dot4(op ? px[j] : f1[j], op ? q[j] : f2[j], w_lo, w_hi) | (px[j] & 0xFF000000u);
+            }
+          }
+        }
+        if (a.use_lut) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) px[j] = lut3_rgba(s_lut, px[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (oy0 + j < a.h) reinterpret_cast<uint32_t *>(dst + (size_t)(oy0 + j) * a.orow)[ox] = px[j];
     }
   }
 }
