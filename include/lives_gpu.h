@@ -206,8 +206,8 @@ int lgpu_blurzoom_process(lgpu_blurzoom *bz, const uint8_t *src_d, int irow, uin
 void lgpu_blurzoom_destroy(lgpu_blurzoom *bz);
 /* geometric transitions: lives-plugins/weed-plugins/multi_transitions.c:86-233.  type 0 "iris rectangle", 1 "iris circle",
    2 "4 way split"; amount = the transition parameter 0..1; packed pixels of 3 or 4 bytes.  dst_d may equal src1_d for
-   types 0 / 1 (the reference's out channel is CAN_DO_INPLACE there), not for type 2.  ("dissolve" and "rand replace" draw
-   from the host's random generator and stay on the CPU.) */
+   types 0 / 1 (the reference's out channel is CAN_DO_INPLACE there), not for type 2.  ("dissolve": lgpu_dissolve below; "rand replace"
+   draws from a time-seeded global generator and stays on the CPU.) */
 int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
                     int width, int height, int psize, double amount, void *stream);
 /* negate / posterise / ccorrect (lives-plugins/weed-plugins/scripts/{negate,posterise,ccorrect}.script): all three map every byte of a pixel
@@ -242,6 +242,12 @@ int lgpu_triple_split(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, i
    the "mlower" / "mupper" switches.  Packed pixels of 3 or 4 bytes, not in place. */
 int lgpu_slide_over(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
                     int width, int height, int psize, int amount, int direction, int slide_lower, int slide_upper, void *stream);
+/* "dissolve": multi_transitions.c:41-69 (mask) and :208-212 (select).  lgpu_dissolve_mask fills width * height floats on the host from the
+   filter instance's "random_seed" (xorshift64 chain, libweed/weed-plugin-utils.c:666-704; once per instance); lgpu_dissolve shows src2 where
+   mask < (float)amount.  mask_d: the same floats in device memory.  src1_d == dst_d = in place. */
+int lgpu_dissolve_mask(uint64_t seed, int width, int height, float *mask_out);
+int lgpu_dissolve(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow, int width, int height,
+                  int psize, const float *mask_d, double amount, void *stream);
 /* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
 int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
                 int psize, void *stream);

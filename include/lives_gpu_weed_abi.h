@@ -157,6 +157,7 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_LEAF_VALUE "value"
 #define WEED_LEAF_GAMMA_TYPE "gamma_type"
 #define WEED_LEAF_YUV_CLAMPING "YUV_clamping"
+#define WEED_LEAF_RANDOM_SEED "random_seed"           /* libweed/weed-effects.h:319 */
 #define WEED_LEAF_GROUP "group"                       /* libweed/weed-effects.h:391 */
 #define WEED_LEAF_CHOICES "choices"
 #define WEED_LEAF_YUV_SAMPLING "YUV_sampling"

@@ -608,6 +608,22 @@ __global__ __launch_bounds__(kBlock) void k_triple_split(TsplitArgs a) {
     }
   }
 }
+
+// dissolve (multi_transitions.c:208-212): src2 where the per-pixel mask value is below the transition amount
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_dissolve(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width,
+                                                     int height, const float *mask, float bf, int inplace) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= width) return;
+  for (int i = blockIdx.y; i < height; i += gridDim.y) {
+    const bool two = mask[(size_t)i * width + x] < bf;
+    if (!two && inplace) continue;
+    const uint8_t *s = two ? src2 + (size_t)i * irow2 + (size_t)x * PS : src1 + (size_t)i * irow1 + (size_t)x * PS;
+    uint8_t *d = dst + (size_t)i * orow + (size_t)x * PS;
+#pragma unroll
+    for (int k = 0; k < PS; k++) d[k] = s[k];
+  }
+}
 }  // namespace lgpu
 
 extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
@@ -699,6 +715,21 @@ extern "C" int lgpu_triple_split(const uint8_t *src1_d, int irow1, const uint8_t
   a.c_lo_out = wb * (xstart - bw); a.c_hi_out = wb * (xend + bw); a.c_lo_in = wb * (xstart + bw); a.c_hi_in = wb * (xend - bw);
   const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
   hipLaunchKernelGGL(lgpu::k_triple_split, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_dissolve(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow, int width, int height,
+                             int psize, const float *mask_d, double amount, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src1_d && src2_d && dst_d && mask_d && width > 0 && height > 0, "null frame / mask or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(irow1 >= width * psize && irow2 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
+  const int inplace = (src1_d == dst_d);
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_dissolve<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, mask_d, (float)amount, inplace);
+  else hipLaunchKernelGGL(lgpu::k_dissolve<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, mask_d, (float)amount, inplace);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -52,7 +52,7 @@ static int psize_of(int pal) {
 }
 
 /* ---- per-instance device buffers ("plugin_internal", like simple_blend.c:36-45) ---- */
-typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; lgpu_rgbdelay *rd; } fxdata_t;
+typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; lgpu_rgbdelay *rd; float *mask_d; int mask_w, mask_h; int64_t mask_seed; } fxdata_t;
 
 static fxdata_t *fx_data(weed_plant_t *inst) {
   fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
@@ -84,6 +84,7 @@ static weed_error_t fx_deinit(weed_plant_t *inst) {
     for (int i = 0; i < 3; i++) if (fx->d[i]) lgpu_free(fx->d[i]);
     if (fx->bz) lgpu_blurzoom_destroy(fx->bz);
     if (fx->rd) lgpu_rgbdelay_destroy(fx->rd);
+    if (fx->mask_d) lgpu_free(fx->mask_d);
     w_free(fx);
     void *v = NULL;
     w_set(inst, "plugin_internal", WEED_SEED_VOIDPTR, 1, &v);
@@ -249,6 +250,30 @@ static int k_tsplit(const fxframe_t *f, weed_plant_t *inst, int kind) {
                            param_dbl(inst, 0, 0.666667), param_bool(inst, 1, WEED_TRUE), param_dbl(inst, 3, 0.333333), param_bool(inst, 4, WEED_FALSE),
                            param_dbl(inst, 5, 0.), bc, NULL);
 }
+/* "dissolve" (multi_transitions.c:41-69, :208-212): the mask is drawn once per instance (and geometry) from the instance's "random_seed" leaf,
+   as dissolve_init does, and kept in device memory */
+static int k_dissolve(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  fxdata_t *fx = fx_data(inst);
+  weed_plant_t *pa = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 0);
+  int64_t seed = 0;
+  (void)kind;
+  if (!fx) return LGPU_E_NOMEM;
+  if (has(inst, WEED_LEAF_RANDOM_SEED)) w_get(inst, WEED_LEAF_RANDOM_SEED, 0, &seed);
+  if (!fx->mask_d || fx->mask_w != f->width || fx->mask_h != f->height || fx->mask_seed != seed) {
+    const size_t n = (size_t)f->width * f->height;
+    float *m = (float *)w_malloc(n * sizeof(float));
+    int ok;
+    if (!m) return LGPU_E_NOMEM;
+    if (fx->mask_d) { lgpu_free(fx->mask_d); fx->mask_d = NULL; }
+    ok = lgpu_dissolve_mask((uint64_t)seed, f->width, f->height, m) == 1 && lgpu_malloc((void **)&fx->mask_d, n * sizeof(float)) == LGPU_OK &&
+         lgpu_upload(fx->mask_d, m, n * sizeof(float), NULL) == LGPU_OK && lgpu_sync(NULL) == LGPU_OK;
+    w_free(m);
+    if (!ok) return LGPU_E_NOMEM;
+    fx->mask_w = f->width; fx->mask_h = f->height; fx->mask_seed = seed;
+  }
+  return lgpu_dissolve(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize, fx->mask_d,
+                       pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -314,6 +339,7 @@ static int k_blurzoom(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (!fx->bz || fx->bz_w != f->width || fx->bz_h != f->height || fx->bz_pal != f->pal) {
     if (fx->bz) lgpu_blurzoom_destroy(fx->bz);
     if (fx->rd) lgpu_rgbdelay_destroy(fx->rd);
+    if (fx->mask_d) lgpu_free(fx->mask_d);
     fx->bz = NULL;
     if (lgpu_blurzoom_create(f->width, f->height, f->pal, &fx->bz) != LGPU_OK) return LGPU_E_BADARG;
     fx->bz_w = f->width; fx->bz_h = f->height; fx->bz_pal = f->pal;
@@ -330,7 +356,7 @@ PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mir
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
 PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1) PROC(p_rgbdelay, 1, 0, k_rgbdelay, 1)
-PROC(p_tsplit, 2, 0, k_tsplit, 1)
+PROC(p_tsplit, 2, 0, k_tsplit, 1) PROC(p_dissolve, 2, 0, k_dissolve, 1)
 PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(p_ccorrect, 1, 2, k_scriptfx, 0)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
@@ -562,6 +588,17 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     p[5] = float_param("borderw", "Border _width", 0., 0., 0.5);
     p[6] = rgb_param("borderc", "Border _colour", 0, 0, 0);
     add_filter(pinfo, "triple split", 0, p24, 2, p_tsplit, 2, "in channel 0", "in channel 1", "out channel 0", p, 7);
+  }
+  /* multi_transitions.c:298-309: "dissolve": same templates as the iris transitions, out channel in place + REINIT_ON_SIZE_CHANGE */
+  {
+    static const int32_t pk[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32, WEED_PALETTE_YUV888, WEED_PALETTE_YUVA8888};
+    weed_plant_t *fc = NULL, *oct = NULL;
+    p[0] = float_param("amount", "_Transition", 0., 0., 1.);
+    s_bool(p[0], WEED_LEAF_IS_TRANSITION, WEED_TRUE);
+    add_filter(pinfo, "dissolve", 0, pk, 6, p_dissolve, 2, "in channel 0", "in channel 1", "out channel 0", p, 1);
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct);
+    if (oct) s_int(oct, WEED_LEAF_FLAGS, WEED_CHANNEL_CAN_DO_INPLACE | WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

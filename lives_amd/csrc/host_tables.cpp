@@ -292,3 +292,17 @@ extern "C" int lgpu_fx_luts(int kind, int palette, double p0, double p1, double 
   }
   return 0;
 }
+
+/* the dissolve mask (multi_transitions.c:41-69): width * height floats drawn from xorshift64 (libweed/weed-plugin-utils.c:666) chained on the
+   instance's random seed, each (double)x / 0xFFFFFFFF / 0xFFFFFFFF rounded to float.  A serial chain: built once per instance on the host. */
+extern "C" int lgpu_dissolve_mask(uint64_t seed, int width, int height, float *mask_out) {
+  if (!mask_out || width < 1 || height < 1) return 0;
+  static const double divd = (double)(0xFFFFFFFF);
+  uint64_t x = seed;
+  for (size_t i = 0; i < (size_t)width * height; i++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const double val = (double)x / divd;
+    mask_out[i] = (float)(val / divd * 1.);
+  }
+  return 1;
+}

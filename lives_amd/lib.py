@@ -83,6 +83,8 @@ PROTOTYPES = {
     "lgpu_byte_luts": [vp, ci, vp, ci, ci, ci, ci, vp, vp],
     "lgpu_deinterlace": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_triple_split": [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, ci, cd, ci, cd, vp, vp],
+    "lgpu_dissolve_mask": [ctypes.c_uint64, ci, ci, vp],
+    "lgpu_dissolve": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, cd, vp],
     "lgpu_slide_over": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_softlight": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "lgpu_yuv_switch_clamping": [vp, vp, ci, ci, ci, vp],

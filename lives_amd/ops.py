@@ -137,6 +137,19 @@ def triple_split(src1, src2, dst, width, height, is_bgr, start, sym, end, vert, 
              float(start), int(bool(sym)), float(end), int(bool(vert)), float(bw), ctypes.addressof(col), stream_ptr())
 
 
+def dissolve_mask(seed, width, height):
+    """host float32 mask of the dissolve transition for an instance seed (multi_transitions.c:41-69)"""
+    m = np.zeros(width * height, np.float32)
+    assert lib.load().lgpu_dissolve_mask(ctypes.c_uint64(seed), width, height, m.ctypes.data) == 1
+    return m
+
+
+def dissolve(src1, src2, dst, width, height, psize, mask, amount):
+    """mask: float32 device tensor of width * height values"""
+    lib.call("lgpu_dissolve", dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width, height, psize,
+             mask.data_ptr(), float(amount), stream_ptr())
+
+
 def slide_over(src1, src2, dst, width, height, psize, amount, direction, slide_lower=True, slide_upper=False):
     """slide_over.c:54-146; direction 1..4 as sover_init stores it"""
     lib.call("lgpu_slide_over", dptr(src1), src1.stride(0), dptr(src2), src2.stride(0), dptr(dst), dst.stride(0), width, height, psize,

@@ -1824,3 +1824,30 @@ void orc_triple_split(const uint8_t *src1, int irow1, const uint8_t *src2, int i
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F7b: dissolve                           reference: multi_transitions.c:41-69 (mask), :208-212 (select);
+ *                                         RNG libweed/weed-plugin-utils.c:666, :686-704 (xorshift64 on the instance's seed leaf)
+ * mask[i] = (float)(xorshift64 chain value / 0xFFFFFFFF / 0xFFFFFFFF), seeded with the instance's "random_seed"; a pixel shows
+ * src2 where mask < (float)amount.  ("rand replace" draws from the time-seeded global generator: not reproducible, not taken.)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_dissolve_mask(uint64_t seed, int width, int height, float *mask) {
+  static const double divd = (double)(0xFFFFFFFF);
+  uint64_t x = seed;
+  for (size_t i = 0; i < (size_t)width * height; i++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const double val = (double)x / divd;
+    mask[i] = (float)(val / divd * 1.);
+  }
+}
+void orc_dissolve(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height, int psize,
+                  const float *mask, double amount) {
+  const float bf = (float)amount;
+  const int inplace = (src1 == dst);
+  for (int i = 0; i < height; i++)
+    for (int x = 0; x < width; x++) {
+      const size_t j = (size_t)x * psize;
+      if (mask[(size_t)i * width + x] < bf) memcpy(dst + (size_t)i * orow + j, src2 + (size_t)i * irow2 + j, (size_t)psize);
+      else if (!inplace) memcpy(dst + (size_t)i * orow + j, src1 + (size_t)i * irow1 + j, (size_t)psize);
+    }
+}

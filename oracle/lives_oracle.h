@@ -123,6 +123,10 @@ int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const i
    (dst == src1) is equivalent to out of place for types 0 / 1; type 2 is not in place (its out channel template says so). */
 void orc_transition(int type, const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow,
                     int width, int height, int psize, double amount);
+/* dissolve (multi_transitions.c:41-69, :208-212): mask from the instance's random seed, then a per-pixel select */
+void orc_dissolve_mask(uint64_t seed, int width, int height, float *mask);
+void orc_dissolve(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height, int psize,
+                  const float *mask, double amount);
 /* slide over (slide_over.c:54-146): dirn 1..4 as stored by sover_init, transval 0..255 */
 void orc_slide_over(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2, uint8_t *dst, int orow, int width, int height,
                     int psize, int transval, int dirn, int mvlower, int mvupper);

@@ -97,6 +97,8 @@ def oracle():
         _O.orc_byte_luts.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
         _O.orc_deinterlace.argtypes = [vp, ci, vp, ci, ci, ci, ci]
         _O.orc_triple_split.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, ci, cd, ci, cd, vp]
+        _O.orc_dissolve_mask.argtypes = [ctypes.c_uint64, ci, ci, vp]
+        _O.orc_dissolve.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, cd]
         _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_switch_yuv_clamping.argtypes = [vp, vp, ci, ci, ci]
@@ -179,6 +181,7 @@ class RefHost:
         self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
         self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
         self.H.refhost_set_yuv_clamping.argtypes = [ci]
+        self.H.refhost_set_random_seed.argtypes = [ctypes.c_int64]
         self.plugins = {}
 
     def load(self, path):

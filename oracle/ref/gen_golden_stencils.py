@@ -126,8 +126,27 @@ def main():
                 tsn.append(key)
     ts["records"] = np.array(tsn)
     np.savez_compressed(os.path.join(OUT, "triple_split.npz"), **ts)
+    # dissolve (multi_transitions.c): the instance's "random_seed" leaf is part of the record
+    ds, dsn = {}, []
+    for pal, ps in ((1, 3), (4, 4)):
+        for k, amt in enumerate((0.0, 0.2, 0.5, 0.93, 1.0)):
+            for inplace in (0, 1):
+                w, h = 17, 9
+                seed = 0x1234567ABCDEF + 977 * k + pal
+                s1, s2 = po.make_frame(rng, w, h, ps), po.make_frame(rng, w, h, ps)
+                d = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                H.H.refhost_set_random_seed(seed)
+                H.run(po.refplugin("multi_transitions"), "dissolve", pal, w, h, [d if inplace else s1, s2], d, [po.p_double(amt)])
+                H.H.refhost_set_random_seed(0)
+                key = "ds|%d|%r|%d|%d" % (pal, amt, seed, inplace)
+                ds[key + "|a"], ds[key + "|b"], ds[key + "|o"] = s1, s2, d
+                dsn.append(key)
+    ds["records"] = np.array(dsn)
+    np.savez_compressed(os.path.join(OUT, "dissolve.npz"), **ds)
     mpath = os.path.join(OUT, "manifest.json")
     man = json.load(open(mpath))
+    man["groups"]["dissolve.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/multi_transitions.c, filter dissolve; record "
+                                     "ds|palette|amount|random_seed leaf of the instance|in place; 17x9; a / b sources, o result")
     man["groups"]["triple_split.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/layout_blends.c; record ts|palette|start|symmetrical|end|"
                                          "split horizontally|border width|in place; border colour 200,100,50; 21x12; a / b sources, o result")
     man["groups"]["deinterlace.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/deinterlace.c; record de|palette|in place|w|h "

@@ -107,6 +107,10 @@ static weed_plant_t *find_filter(weed_plant_t *pinfo, const char *fname) {
 static int g_yuv_clamping = -1;
 void refhost_set_yuv_clamping(int clamping) { g_yuv_clamping = clamping; }
 
+/* "random_seed" leaf for the instances made from now on (0 = none): dissolve seeds its mask from it (multi_transitions.c:56) */
+static int64_t g_random_seed = 0;
+void refhost_set_random_seed(int64_t seed) { g_random_seed = seed; }
+
 static weed_plant_t *mk_channel(weed_plant_t *tmpl, int pal, int w, int h, int stride, void *pd) {
   weed_plant_t *c = weed_plant_new(WEED_PLANT_CHANNEL);
   weed_set_plantptr_value(c, WEED_LEAF_TEMPLATE, tmpl);
@@ -151,6 +155,7 @@ int refhost_run(void *pinfo_v, const char *fname, int pal, int w, int h,
 
   inst = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
   weed_set_plantptr_value(inst, WEED_LEAF_FILTER_CLASS, filt);
+  if (g_random_seed) weed_set_int64_value(inst, WEED_LEAF_RANDOM_SEED, g_random_seed);
   for (i = 0; i < nin; i++) inch[i] = mk_channel(ictm[i], pal, w, h, istrides[i], src[i]);
   outch = mk_channel(octm[0], pal, w, h, ostride, dst);
   weed_set_plantptr_array(inst, WEED_LEAF_IN_CHANNELS, nin, inch);
@@ -240,6 +245,7 @@ int refhost_run_planar(void *pinfo_v, const char *fname, int pal, int w, int h, 
   if (nict < 1 || noct < 1) return -102;
   inst = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
   weed_set_plantptr_value(inst, WEED_LEAF_FILTER_CLASS, filt);
+  if (g_random_seed) weed_set_int64_value(inst, WEED_LEAF_RANDOM_SEED, g_random_seed);
   inch = mk_channel(ictm[0], pal, w, h, istrides[0], src[0]);
   outch = mk_channel(octm[0], pal, w, h, ostrides[0], dst[0]);
   weed_set_voidptr_array(inch, WEED_LEAF_PIXEL_DATA, nplanes, (void **)src);
@@ -285,6 +291,7 @@ int refhost_run_seq(void *pinfo_v, const char *fname, int pal, int w, int h, int
   if (nict < 1 || noct < 1 || nipt < nparams) return -102;
   inst = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
   weed_set_plantptr_value(inst, WEED_LEAF_FILTER_CLASS, filt);
+  if (g_random_seed) weed_set_int64_value(inst, WEED_LEAF_RANDOM_SEED, g_random_seed);
   inch = mk_channel(ictm[0], pal, w, h, istride, src[0]);
   outch = mk_channel(octm[0], pal, w, h, ostride, dst[0]);
   weed_set_plantptr_value(inst, WEED_LEAF_IN_CHANNELS, inch);

@@ -341,3 +341,17 @@ def test_triple_split_vs_reference_plugin(gpu):
         d = s1 if inplace == "1" else dev(np.full_like(a, 0x5A))
         gpu.triple_split(s1, dev(b), d, 21, 12, pal == "2", float(start), int(sym), float(end), int(vert), float(bw), (200, 100, 50))
         assert (host(d) == want).all(), rec
+
+
+def test_dissolve_vs_reference_plugin(gpu):
+    import torch
+    g = gu.load("dissolve.npz")
+    for rec in map(str, g["records"]):
+        _, pal, amt, seed, inplace = rec.split("|")
+        ps = 3 if int(pal) <= 2 else 4
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        mask = torch.from_numpy(gpu.dissolve_mask(int(seed), 17, 9)).cuda()
+        s1 = dev(a)
+        d = s1 if inplace == "1" else dev(np.full_like(a, 0x5A))
+        gpu.dissolve(s1, dev(b), d, 17, 9, ps, mask, float(amt))
+        assert (host(d) == want).all(), rec

@@ -481,6 +481,29 @@ def test_byte_luts(gpu, orc, psize):
             assert (got is None and n == 0) or (got == ref[:n]).all()
 
 
+@pytest.mark.parametrize("psize", [3, 4])
+def test_dissolve(gpu, orc, psize):
+    import torch
+    rng = np.random.default_rng(3200 + psize)
+    for (w, h) in [(20, 10), (333, 47), (1, 1)]:
+        seed = 0xC0FFEE + w
+        mask = np.zeros(w * h, np.float32)
+        orc.orc_dissolve_mask(seed, w, h, mask.ctypes.data)
+        gm = gpu.dissolve_mask(seed, w, h)
+        assert (gm == mask).all()
+        dm = torch.from_numpy(gm).cuda()
+        for amt in (0.0, 0.01, 0.37, 0.5, 0.999, 1.0):
+            for inplace in (0, 1):
+                s1, s2 = frame(rng, w, h, psize), frame(rng, w, h, psize)
+                want = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                a = want if inplace else s1
+                orc.orc_dissolve(P(a), a.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, psize, mask.ctypes.data, amt)
+                d1 = dev(s1)
+                d = d1 if inplace else dev(np.full_like(s1, 0x5A))
+                gpu.dissolve(d1, dev(s2), d, w, h, psize, dm, amt)
+                assert_same(host(d), want, w, h, psize, "dissolve ps=%d %dx%d amount=%s inplace=%d" % (psize, w, h, amt, inplace))
+
+
 def test_triple_split(gpu, orc):
     rng = np.random.default_rng(3100)
     bc = np.array([13, 250, 77], np.int32)

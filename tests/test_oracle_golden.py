@@ -381,3 +381,17 @@ def test_triple_split(orc):
         s1 = got if inplace else a
         orc.orc_triple_split(P(s1), s1.strides[0], P(b), b.strides[0], P(got), got.strides[0], 21, 12, pal == 2, start, sym, end, vert, bw, bc.ctypes.data)
         assert (got == want).all(), rec
+
+
+def test_dissolve(orc):
+    g = gu.load("dissolve.npz")
+    for rec in map(str, g["records"]):
+        _, pal, amt, seed, inplace = rec.split("|")
+        ps = 3 if int(pal) <= 2 else 4
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        mask = np.zeros(17 * 9, np.float32)
+        orc.orc_dissolve_mask(int(seed), 17, 9, mask.ctypes.data)
+        got = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
+        s1 = got if inplace == "1" else a
+        orc.orc_dissolve(P(s1), s1.strides[0], P(b), b.strides[0], P(got), got.strides[0], 17, 9, ps, mask.ctypes.data, float(amt))
+        assert (got == want).all(), rec

@@ -22,7 +22,7 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 30
+    assert len(ours) == 31
     for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace", "RGBdelay", "negate", "posterise",
                  "ccorrect", "layout_blends"):
         for rf in H.filters(po.refplugin(plug)):
@@ -257,4 +257,21 @@ def test_triple_split_records_through_the_plugin():
                po.p_rgb(200, 100, 50)]
         d = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
         H.run(OURS, "triple split", int(pal), 21, 12, [d if inplace == "1" else a.copy(), b.copy()], d, prm)
+        assert (d == want).all(), rec
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dissolve_records_through_the_plugin():
+    H = po.RefHost()
+    g = gu.load("dissolve.npz")
+    for rec in map(str, g["records"]):
+        _, pal, amt, seed, inplace = rec.split("|")
+        a, b, want = g[rec + "|a"], g[rec + "|b"], g[rec + "|o"]
+        d = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
+        H.H.refhost_set_random_seed(int(seed))
+        try:
+            H.run(OURS, "dissolve", int(pal), 17, 9, [d if inplace == "1" else a.copy(), b.copy()], d, [po.p_double(float(amt))])
+        finally:
+            H.H.refhost_set_random_seed(0)
         assert (d == want).all(), rec
