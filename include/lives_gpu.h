@@ -95,6 +95,12 @@ int lgpu_yuv420p_to_rgb(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v
                         long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
                         int opsize, int out_order, int is_422, int which_tables, int pb_quality,
                         const uint8_t *lut8, int flags, void *stream);
+/* the same conversion for a batch of frames of one geometry (the frames of the live tracks of a multitrack timeline, <= LGPU_CHAIN_MAX_TRACKS)
+   in ONE launch: at 1920x1080 a single frame is bounded by the launch floor, a batch by the kernel. */
+typedef struct { const uint8_t *y_d, *u_d, *v_d; uint8_t *dst_d; } lgpu_yuv_frame;
+int lgpu_yuv420p_to_rgb_batch(int nframes, const lgpu_yuv_frame *frames, const int istrides[3], long u_size, long v_size, int orow,
+                              int width, int height, int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                              const uint8_t *lut8, int flags, void *stream);
 /* the same conversion with the reference's 16-bit indexed gamma LUT fused in, as convert_yuv420p_to_rgb_frame does when it
    is handed a target gamma (:3274-3283; xyuv2rgb_with_gamma :2386-2390): c = lut16[CLAMP16biti(sum >> 8)] >> 8.
    lut16_d: DEVICE pointer to 65536 uint16 (build on the host with lgpu_gamma_lut16, upload once, reuse). */

@@ -18,6 +18,11 @@
 
 namespace lgpu {
 
+// frames of one batch (same geometry): one launch converts them all, blockIdx.z picks the frame (tracks of a multitrack timeline)
+struct YuvBatch {
+  const uint8_t *y[LGPU_CHAIN_MAX_TRACKS], *u[LGPU_CHAIN_MAX_TRACKS], *v[LGPU_CHAIN_MAX_TRACKS];
+  uint8_t *dst[LGPU_CHAIN_MAX_TRACKS];
+};
 struct YuvArgs {
   const uint8_t *y, *u, *v;
   uint8_t *dst;
@@ -75,77 +80,139 @@ struct YuvCtx {
   }
 };
 
-__global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut) {
+// one (unit, chroma column k) cell of the 4:2:0 walk: 2 pixels of row 0, a 2 x 2 quad of a row pair, or 2 pixels of the trailing row
+// units: 0 = row 0; p >= 1 = rows (2p-1, 2p) while 2p <= H-1; then (even H) the trailing row H-1
+__device__ __forceinline__ void yuv420_cell(const YuvArgs &a, const YuvCtx &c, int unit, int k, int hw, int npairs) {
+  const int ops = a.opsize;
+  const int H = a.height;
+  auto PU = [&](int r, int kk) -> int { long i = (long)r * a.us + kk; return a.u[i < a.usize ? i : a.usize - 1]; };
+  auto PV = [&](int r, int kk) -> int { long i = (long)r * a.vs + kk; return a.v[i < a.vsize ? i : a.vsize - 1]; };
+  if (unit == 0) {
+    // row 0 (:3399-3443)
+    const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
+    const uint32_t p0 = c.rgb(a.y[2 * k], c.cuv((PU(0, k) + PU(0, kp)) >> 1), c.cuv((PV(0, k) + PV(0, kp)) >> 1));
+    const uint32_t p1 = c.rgb(a.y[2 * k + 1], c.cuv((PU(0, k) + PU(0, kn)) >> 1), c.cuv((PV(0, k) + PV(0, kn)) >> 1));
+    c.store2(a.dst + (size_t)(2 * k) * ops, p0, p1);
+  } else if (unit <= npairs) {
+    // rows (i, i+1), chroma rows r and r+1 (:3445-3554)
+    const int i = 2 * unit - 1, r = i >> 1;
+    const uint8_t *y0 = a.y + (size_t)i * a.ys + 2 * k, *y1 = y0 + a.ys;
+    uint8_t *d0 = a.dst + (size_t)i * a.orow + (size_t)(2 * k) * ops, *d1 = d0 + a.orow;
+    const int u_rk = PU(r, k), v_rk = PV(r, k), v_r1k = PV(r + 1, k);
+    int ut, ub, vt, vb;
+    // left pixel
+    const int lu1 = k ? PU(r, k - 1) : u_rk;
+    const int lv1 = k ? PV(r + 1, k - 1) : v_rk;
+    const int lv2 = PV(r + 1, 0);
+    c.vblend(u_rk + lu1, u_rk + lu1, ut, ub);
+    c.vblend(v_rk + lv1, v_r1k + lv2, vt, vb);
+    const uint32_t a0 = c.rgb(y0[0], ut, vt), b0 = c.rgb(y1[0], ub, vb);
+    // right pixel
+    c.vblend(u_rk + PU(r, k + 1), PU(r + 1, k) + PU(r + 1, k + 1), ut, ub);
+    c.vblend(v_rk + PV(r, k + 1), v_r1k + PV(r + 1, k + 1), vt, vb);
+    const uint32_t a1 = c.rgb(y0[1], ut, vt), b1 = c.rgb(y1[1], ub, vb);
+    c.store2(d0, a0, a1);
+    c.store2(d1, b0, b1);
+  } else {
+    // trailing row H-1 (:3556-3592)
+    const int i = H - 1, r = i >> 1;
+    const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
+    const uint8_t *yr = a.y + (size_t)i * a.ys;
+    uint32_t p0;
+    if (a.fix_edges) {
+      p0 = c.rgb(yr[2 * k], c.cuv((PU(r, k) + PU(r, kp)) >> 1), c.cuv((PV(r, k) + PV(r, kp)) >> 1));
+    } else {
+      // 1-thread reference: this/last walk = {row r col 0, row r col 0, row 0 col 1, row 0 col 2, ...}
+      const int tu = k ? PU(0, k) : PU(r, 0), tv = k ? PV(0, k) : PV(r, 0);
+      const int lu = (k >= 2) ? PU(0, k - 1) : PU(r, 0), lv = (k >= 2) ? PV(0, k - 1) : PV(r, 0);
+      p0 = c.rgb(a.y[2 * k], c.cuv((tu + lu) >> 1), c.cuv((tv + lv) >> 1));
+    }
+    const uint32_t p1 = c.rgb(yr[2 * k + 1], c.cuv((PU(r, k) + PU(r, kn)) >> 1), c.cuv((PV(r, k) + PV(r, kn)) >> 1));
+    c.store2(a.dst + (size_t)i * a.orow + (size_t)(2 * k) * ops, p0, p1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut, YuvBatch bt, int batched) {
+  if (batched) { a.y = bt.y[blockIdx.z]; a.u = bt.u[blockIdx.z]; a.v = bt.v[blockIdx.z]; a.dst = bt.dst[blockIdx.z]; }
   __shared__ int32_t s_tab[5 * 256];
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
   stage_lut(s_lut, lut);
   __syncthreads();
-
   YuvCtx c;
   c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
   c.lut = s_lut; c.lut16 = a.lut16; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
-
   const int hw = a.width >> 1;
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= hw) return;
-  const int ops = a.opsize;
-  const int H = a.height;
-  // units: 0 = row 0; p >= 1 = rows (2p-1, 2p) while 2p <= H-1; then (even H) the trailing row H-1
-  const int npairs = (H - 1) / 2;                      // number of full row pairs starting at row 1
-  const int nunits = 1 + npairs + (((H - 1) & 1) ? 1 : 0);
-  auto PU = [&](int r, int kk) -> int { long i = (long)r * a.us + kk; return a.u[i < a.usize ? i : a.usize - 1]; };
-  auto PV = [&](int r, int kk) -> int { long i = (long)r * a.vs + kk; return a.v[i < a.vsize ? i : a.vsize - 1]; };
+  const int npairs = (a.height - 1) / 2;                      // number of full row pairs starting at row 1
+  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
+  for (int unit = blockIdx.y; unit < nunits; unit += gridDim.y) yuv420_cell(a, c, unit, k, hw, npairs);
+}
 
+// The same walk with one lane per FOUR chroma columns (8 x 2 pixels of a row pair): the quad's luma comes in as two 8-byte loads and
+// every chroma row as three dwords (the columns left of, of and right of the group), 16 loads instead of 64 byte loads, and the two
+// output rows leave as 16-byte stores.  Only cells whose loads stay inside the planes and whose rows are aligned take this form
+// (`fast`, decided on the host per launch + per lane here); every other cell (row 0, the trailing row, the first column group, the
+// plane ends) goes through yuv420_cell above, so the result is the same bytes.
+__global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb4(YuvArgs a, Lut8 lut, YuvBatch bt, int batched) {
+  if (batched) { a.y = bt.y[blockIdx.z]; a.u = bt.u[blockIdx.z]; a.v = bt.v[blockIdx.z]; a.dst = bt.dst[blockIdx.z]; }
+  __shared__ int32_t s_tab[5 * 256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+  YuvCtx c;
+  c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
+  c.lut = s_lut; c.lut16 = a.lut16; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
+  const int hw = a.width >> 1;
+  const int k0 = 4 * (blockIdx.x * kBlock + threadIdx.x);
+  if (k0 >= hw) return;
+  const int npairs = (a.height - 1) / 2;
+  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
   for (int unit = blockIdx.y; unit < nunits; unit += gridDim.y) {
-    if (unit == 0) {
-      // row 0 (:3399-3443)
-      const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
-      const uint32_t p0 = c.rgb(a.y[2 * k], c.cuv((PU(0, k) + PU(0, kp)) >> 1), c.cuv((PV(0, k) + PV(0, kp)) >> 1));
-      const uint32_t p1 = c.rgb(a.y[2 * k + 1], c.cuv((PU(0, k) + PU(0, kn)) >> 1), c.cuv((PV(0, k) + PV(0, kn)) >> 1));
-      c.store2(a.dst + (size_t)(2 * k) * ops, p0, p1);
-    } else if (unit <= npairs) {
-      // rows (i, i+1), chroma rows r and r+1 (:3445-3554)
-      const int i = 2 * unit - 1, r = i >> 1;
-      const uint8_t *y0 = a.y + (size_t)i * a.ys + 2 * k, *y1 = y0 + a.ys;
-      uint8_t *d0 = a.dst + (size_t)i * a.orow + (size_t)(2 * k) * ops, *d1 = d0 + a.orow;
-      const int u_rk = PU(r, k), v_rk = PV(r, k), v_r1k = PV(r + 1, k);
+    const int i = 2 * unit - 1, r = i >> 1;
+    const bool fast = unit >= 1 && unit <= npairs && k0 >= 4 && k0 + 4 <= hw && (long)(r + 1) * a.us + k0 + 8 <= a.usize &&
+                      (long)(r + 1) * a.vs + k0 + 8 <= a.vsize;
+    if (!fast) {
+      for (int k = k0; k < k0 + 4 && k < hw; k++) yuv420_cell(a, c, unit, k, hw, npairs);
+      continue;
+    }
+    const uint2 ya = *reinterpret_cast<const uint2 *>(a.y + (size_t)i * a.ys + 2 * k0), yb = *reinterpret_cast<const uint2 *>(a.y + (size_t)(i + 1) * a.ys + 2 * k0);
+    const uint8_t *ur = a.u + (size_t)r * a.us + k0, *vr = a.v + (size_t)r * a.vs + k0;
+    const uint32_t u0m = *reinterpret_cast<const uint32_t *>(ur - 4), u0c = *reinterpret_cast<const uint32_t *>(ur), u0p = *reinterpret_cast<const uint32_t *>(ur + 4);
+    const uint32_t u1c = *reinterpret_cast<const uint32_t *>(ur + a.us), u1p = *reinterpret_cast<const uint32_t *>(ur + a.us + 4);
+    const uint32_t v0c = *reinterpret_cast<const uint32_t *>(vr), v0p = *reinterpret_cast<const uint32_t *>(vr + 4);
+    const uint32_t v1m = *reinterpret_cast<const uint32_t *>(vr + a.vs - 4), v1c = *reinterpret_cast<const uint32_t *>(vr + a.vs), v1p = *reinterpret_cast<const uint32_t *>(vr + a.vs + 4);
+    const int lv2 = a.v[(size_t)(r + 1) * a.vs];                            // PV(r + 1, 0): the reference's constant "last" sample
+    // samples k0-1 .. k0+4 of each row as 6-element byte strings: [m.b3, c.b0..b3, p.b0]
+    auto at6 = [](uint32_t m, uint32_t cc, uint32_t pp, int j) -> int {   // j = -1 .. 4
+      return j < 0 ? (int)(m >> 24) : j < 4 ? (int)((cc >> (8 * j)) & 0xFF) : (int)(pp & 0xFF);
+    };
+    uint32_t top[8], bot[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int u_rk = at6(0, u0c, 0, j), v_rk = at6(0, v0c, 0, j), v_r1k = at6(0, v1c, 0, j);
+      const int lu1 = at6(u0m, u0c, u0p, j - 1), lv1 = at6(v1m, v1c, v1p, j - 1);
       int ut, ub, vt, vb;
-      // left pixel
-      const int lu1 = k ? PU(r, k - 1) : u_rk;
-      const int lv1 = k ? PV(r + 1, k - 1) : v_rk;
-      const int lv2 = PV(r + 1, 0);
       c.vblend(u_rk + lu1, u_rk + lu1, ut, ub);
       c.vblend(v_rk + lv1, v_r1k + lv2, vt, vb);
-      const uint32_t a0 = c.rgb(y0[0], ut, vt), b0 = c.rgb(y1[0], ub, vb);
-      // right pixel
-      c.vblend(u_rk + PU(r, k + 1), PU(r + 1, k) + PU(r + 1, k + 1), ut, ub);
-      c.vblend(v_rk + PV(r, k + 1), v_r1k + PV(r + 1, k + 1), vt, vb);
-      const uint32_t a1 = c.rgb(y0[1], ut, vt), b1 = c.rgb(y1[1], ub, vb);
-      c.store2(d0, a0, a1);
-      c.store2(d1, b0, b1);
-    } else {
-      // trailing row H-1 (:3556-3592)
-      const int i = H - 1, r = i >> 1;
-      const int kp = k ? k - 1 : 0, kn = (k + 1 < hw) ? k + 1 : hw - 1;
-      const uint8_t *yr = a.y + (size_t)i * a.ys;
-      uint32_t p0;
-      if (a.fix_edges) {
-        p0 = c.rgb(yr[2 * k], c.cuv((PU(r, k) + PU(r, kp)) >> 1), c.cuv((PV(r, k) + PV(r, kp)) >> 1));
-      } else {
-        // 1-thread reference: this/last walk = {row r col 0, row r col 0, row 0 col 1, row 0 col 2, ...}
-        const int tu = k ? PU(0, k) : PU(r, 0), tv = k ? PV(0, k) : PV(r, 0);
-        const int lu = (k >= 2) ? PU(0, k - 1) : PU(r, 0), lv = (k >= 2) ? PV(0, k - 1) : PV(r, 0);
-        p0 = c.rgb(a.y[2 * k], c.cuv((tu + lu) >> 1), c.cuv((tv + lv) >> 1));
-      }
-      const uint32_t p1 = c.rgb(yr[2 * k + 1], c.cuv((PU(r, k) + PU(r, kn)) >> 1), c.cuv((PV(r, k) + PV(r, kn)) >> 1));
-      c.store2(a.dst + (size_t)i * a.orow + (size_t)(2 * k) * ops, p0, p1);
+      const int y00 = (int)(((j < 2 ? ya.x : ya.y) >> (16 * (j & 1))) & 0xFF), y01 = (int)(((j < 2 ? ya.x : ya.y) >> (16 * (j & 1) + 8)) & 0xFF);
+      const int y10 = (int)(((j < 2 ? yb.x : yb.y) >> (16 * (j & 1))) & 0xFF), y11 = (int)(((j < 2 ? yb.x : yb.y) >> (16 * (j & 1) + 8)) & 0xFF);
+      top[2 * j] = c.rgb(y00, ut, vt); bot[2 * j] = c.rgb(y10, ub, vb);
+      c.vblend(u_rk + at6(u0m, u0c, u0p, j + 1), at6(0, u1c, u1p, j) + at6(0, u1c, u1p, j + 1), ut, ub);
+      c.vblend(v_rk + at6(0, v0c, v0p, j + 1), v_r1k + at6(v1m, v1c, v1p, j + 1), vt, vb);
+      top[2 * j + 1] = c.rgb(y01, ut, vt); bot[2 * j + 1] = c.rgb(y11, ub, vb);
     }
+    uint4 *d0 = reinterpret_cast<uint4 *>(a.dst + (size_t)i * a.orow + (size_t)(2 * k0) * 4), *d1 = reinterpret_cast<uint4 *>(a.dst + (size_t)(i + 1) * a.orow + (size_t)(2 * k0) * 4);
+    d0[0] = make_uint4(top[0], top[1], top[2], top[3]); d0[1] = make_uint4(top[4], top[5], top[6], top[7]);
+    d1[0] = make_uint4(bot[0], bot[1], bot[2], bot[3]); d1[1] = make_uint4(bot[4], bot[5], bot[6], bot[7]);
   }
 }
 
 // 4:2:2 (:3593-3640 / :3858-3901): row i, pair k; "last/this" are seeded from chroma row i>>1 (reference)
-__global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut) {
+__global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut, YuvBatch bt, int batched) {
+  if (batched) { a.y = bt.y[blockIdx.z]; a.u = bt.u[blockIdx.z]; a.v = bt.v[blockIdx.z]; a.dst = bt.dst[blockIdx.z]; }
   __shared__ int32_t s_tab[5 * 256];
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
@@ -177,7 +244,8 @@ using namespace lgpu;
 static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
                                long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
                                int opsize, int out_order, int is_422, int which_tables, int pb_quality,
-                               const uint8_t *lut8, const uint16_t *lut16_d, int flags, void *stream) {
+                               const uint8_t *lut8, const uint16_t *lut16_d, int flags, void *stream,
+                               const YuvBatch *batch = nullptr, int nbatch = 1) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(y_d && u_d && v_d && dst_d && istrides, "null plane");
@@ -206,9 +274,25 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   const int units = is_422 ? height : height / 2 + 1;
   // every workgroup stages 5 KB of tables first: a few hundred workgroups that each walk several row pairs, not one per row pair
   static const int gy_cap = getenv("LGPU_YUV_GY") ? atoi(getenv("LGPU_YUV_GY")) : 2048;
-  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > gy_cap ? gy_cap : units), 1);
-  if (is_422) hipLaunchKernelGGL(k_yuv422p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l);
-  else hipLaunchKernelGGL(k_yuv420p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l);
+  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > gy_cap ? gy_cap : units), (unsigned)nbatch);
+  YuvBatch none = {};
+  const YuvBatch &bt = batch ? *batch : none;
+  static const bool classic = getenv("LGPU_YUV_CLASSIC") != nullptr;
+  bool wide = !is_422 && !classic && opsize == 4 && (a.ys & 7) == 0 && (a.us & 3) == 0 && (a.vs & 3) == 0 && (orow & 15) == 0;
+  for (int f = 0; f < nbatch && wide; f++) {
+    const uintptr_t py = (uintptr_t)(batch ? batch->y[f] : y_d), pu = (uintptr_t)(batch ? batch->u[f] : u_d), pv = (uintptr_t)(batch ? batch->v[f] : v_d),
+                    pd = (uintptr_t)(batch ? batch->dst[f] : dst_d);
+    wide = (py & 7) == 0 && (pu & 3) == 0 && (pv & 3) == 0 && (pd & 15) == 0;
+  }
+  // one lane per four columns means a quarter of the lanes: only worth it when the launch still fills the device (a batch of tracks, or a
+  // frame of 4K and up); a single 1080p frame keeps the one-column form (measured 13 vs 18 us)
+  const dim3 g4x(cdiv((unsigned)((width >> 1) + 3) / 4, kBlock), grid.y, grid.z);
+  if (wide && (unsigned long long)g4x.x * g4x.y * g4x.z < 2048ull && !getenv("LGPU_YUV_WIDE")) wide = false;
+  if (is_422) hipLaunchKernelGGL(k_yuv422p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
+  else if (wide) {
+    const dim3 g4(cdiv((unsigned)((width >> 1) + 3) / 4, kBlock), grid.y, grid.z);
+    hipLaunchKernelGGL(k_yuv420p_to_rgb4, g4, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
+  } else hipLaunchKernelGGL(k_yuv420p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
@@ -230,3 +314,17 @@ extern "C" int lgpu_yuv420p_to_rgb_lut16(const uint8_t *y_d, const uint8_t *u_d,
                              pb_quality, nullptr, lut16_d, flags, stream);
 }
 
+
+extern "C" int lgpu_yuv420p_to_rgb_batch(int nframes, const lgpu_yuv_frame *frames, const int istrides[3], long u_size, long v_size, int orow,
+                                         int width, int height, int opsize, int out_order, int is_422, int which_tables, int pb_quality,
+                                         const uint8_t *lut8, int flags, void *stream) {
+  if (!frames || nframes < 1 || nframes > LGPU_CHAIN_MAX_TRACKS) { set_error("lgpu_yuv420p_to_rgb_batch: 1..%d frames", LGPU_CHAIN_MAX_TRACKS); return LGPU_E_BADARG; }
+  YuvBatch b = {};
+  for (int i = 0; i < nframes; i++) {
+    if (!frames[i].y_d || !frames[i].u_d || !frames[i].v_d || !frames[i].dst_d) { set_error("lgpu_yuv420p_to_rgb_batch: null plane in frame %d", i); return LGPU_E_BADARG; }
+    b.y[i] = frames[i].y_d; b.u[i] = frames[i].u_d; b.v[i] = frames[i].v_d; b.dst[i] = frames[i].dst_d;
+    if (opsize == 4 && ((uintptr_t)frames[i].dst_d & 3)) { set_error("lgpu_yuv420p_to_rgb_batch: 4-byte output must be 4-byte aligned"); return LGPU_E_BADARG; }
+  }
+  return yuv420p_to_rgb_impl(frames[0].y_d, frames[0].u_d, frames[0].v_d, istrides, u_size, v_size, frames[0].dst_d, orow, width, height, opsize, out_order,
+                             is_422, which_tables, pb_quality, lut8, nullptr, flags, stream, &b, nframes);
+}

@@ -31,6 +31,11 @@ class ChainTrack(ctypes.Structure):
     _fields_ = [("src_d", vp), ("layer2_d", vp), ("dst_d", vp)]
 
 
+class YuvFrame(ctypes.Structure):
+    """lgpu_yuv_frame"""
+    _fields_ = [("y_d", vp), ("u_d", vp), ("v_d", vp), ("dst_d", vp)]
+
+
 class CompLayer(ctypes.Structure):
     """lgpu_comp_layer (include/lives_gpu.h)"""
     _fields_ = [("src_d", ctypes.c_void_p), ("irow", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int),
@@ -81,6 +86,7 @@ PROTOTYPES = {
     "lgpu_rgbdelay_destroy": [vp],
     "lgpu_fx_luts": [ci, ci, cd, cd, cd, vp],
     "lgpu_byte_luts": [vp, ci, vp, ci, ci, ci, ci, vp, vp],
+    "lgpu_yuv420p_to_rgb_batch": [ci, vp, vp, ctypes.c_long, ctypes.c_long, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_deinterlace": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_triple_split": [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, ci, cd, ci, cd, vp, vp],
     "lgpu_dissolve_mask": [ctypes.c_uint64, ci, ci, vp],

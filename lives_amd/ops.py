@@ -59,6 +59,19 @@ def yuv420p_to_rgb(y, u, v, dst, width, height, opsize=4, out_order=0, is_422=0,
              which_tables, pb_quality, lp[0] if lp else None, flags, stream_ptr())
 
 
+def yuv420p_to_rgb_batch(frames, width, height, opsize=4, out_order=0, is_422=0, which_tables=0, pb_quality=2, lut=None, flags=0):
+    """frames: list of (y, u, v, dst) device tensors sharing one geometry and rowstrides; one launch for all of them"""
+    n = len(frames)
+    arr = (lib.YuvFrame * n)()
+    for i, (y, u, v, d) in enumerate(frames):
+        arr[i].y_d, arr[i].u_d, arr[i].v_d, arr[i].dst_d = y.data_ptr(), u.data_ptr(), v.data_ptr(), d.data_ptr()
+    y, u, v, d = frames[0]
+    st = (ctypes.c_int * 3)(y.stride(0), u.stride(0), v.stride(0))
+    lp = lut_ptr(lut)
+    lib.call("lgpu_yuv420p_to_rgb_batch", n, arr, st, u.numel(), v.numel(), d.stride(0), width, height, opsize, out_order, is_422, which_tables,
+             pb_quality, lp[0] if lp else None, flags, stream_ptr())
+
+
 def yuv420p_to_rgb_lut16(y, u, v, dst, width, height, lut16, opsize=4, out_order=0, is_422=0, which_tables=0, pb_quality=2, flags=0):
     """lut16: device tensor of 65536 16-bit values (the reference's fused LUT16 variant)"""
     assert lut16.is_cuda and lut16.numel() == 65536 and lut16.element_size() == 2

@@ -707,6 +707,47 @@ def test_gauss5(gpu, orc, psize):
         assert_same(host(d), want, w, h, psize, "gauss5 %dx%d ps=%d" % (w, h, psize))
 
 
+def test_yuv420p_four_column_kernel(gpu, orc, monkeypatch):
+    """k_yuv420p_to_rgb4 (one lane per four chroma columns; chosen for batches / 4K frames) forced on small frames: same bytes as the oracle,
+    including the cells it hands back to the one-column walk (row 0, trailing row, first / partial column groups, plane ends)"""
+    monkeypatch.setenv("LGPU_YUV_WIDE", "1")
+    rng = np.random.default_rng(3400)
+    for which in range(4):
+        for quality in (1, 2):
+            for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 19, 160, 80), (24, 6, 32, 16), (640, 480, 640, 320)]:
+                lut = lut_for(rng, "l2s")
+                Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
+                U = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
+                V = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
+                orow = align(w * 4)
+                strides = (ctypes.c_int * 3)(ys, cs, cs)
+                want = np.full((h, orow), 0xAB, np.uint8)
+                orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, 0, 0, which, quality, P(lut), 0)
+                d = dev(np.full_like(want, 0xAB))
+                gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, which_tables=which, pb_quality=quality, lut=lut)
+                assert_same(host(d), want, w, h, 4, "yuv420p wide %dx%d which=%d q=%d" % (w, h, which, quality))
+
+
+def test_yuv420p_batch_equals_single_calls(gpu):
+    import torch
+    rng = np.random.default_rng(3300)
+    lut = lut_for(rng, "l2s")
+    for (w, h, is_422) in [(64, 32, 0), (130, 18, 0), (66, 34, 1)]:
+        frames, singles = [], []
+        for t in range(5):
+            Y = dev(rng.integers(0, 256, (h, align(w)), dtype=np.uint8))
+            ch = h if is_422 else h // 2
+            U, V = (dev(rng.integers(0, 256, (ch, align(w) // 2), dtype=np.uint8)) for _ in range(2))
+            d1 = torch.full((h, align(w * 4)), 0xAB, dtype=torch.uint8, device="cuda")
+            d2 = d1.clone()
+            gpu.yuv420p_to_rgb(Y, U, V, d1, w, h, is_422=is_422, which_tables=1, lut=lut)
+            frames.append((Y, U, V, d2))
+            singles.append(d1)
+        gpu.yuv420p_to_rgb_batch(frames, w, h, is_422=is_422, which_tables=1, lut=lut)
+        for (_, _, _, d2), d1 in zip(frames, singles):
+            assert torch.equal(d1, d2)
+
+
 # ---------------------------------------------------------------------------------------------- chain
 @pytest.mark.parametrize("do_blur", [0, 1])
 def test_chain_matches_oracle_and_unfused(gpu, orc, do_blur):

@@ -98,6 +98,11 @@ def main():
         orc.orc_yuv420p_to_rgb.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
     c = cpu(lambda: orc.orc_yuv420p_to_rgb(P(hy), P(hu), P(hv), st, hu.size, hv.size, P(hd), hd.strides[0], w, h, 4, 0, 0, 0, 2, P(lut), 0))
     add("yuv420p->RGBA32 + gamma LUT (C2)", "colourspace.c:3260-3904, :14034", "1920x1080", w * h * 3 // 2 + w * h * 4, t, c)
+    NT = 16
+    bY, bU, bV, bD = dframe(w, h, 1, NT), dframe(w // 2, h // 2, 1, NT), dframe(w // 2, h // 2, 1, NT), dframe(w, h, 4, NT)
+    bframes = list(zip(bY, bU, bV, bD))
+    t = timeit(lambda i: ops.yuv420p_to_rgb_batch(bframes, w, h, lut=lut), 1)
+    add("yuv420p->RGBA32 + gamma LUT, 16 frames / launch", "colourspace.c:3260-3904, :14034", "16 x 1920x1080", NT * (w * h * 3 // 2 + w * h * 4), t, None)
     # ---- K6 gamma apply, K9 premult (in place) ---------------------------------------------------------------------------------
     pix = dframe(w, h, 4, NB)
     t = timeit(lambda i: ops.gamma_apply(pix[i], w, h, 4, lut), NB)
