@@ -362,18 +362,25 @@ struct RgbdArgs {
   int inplace, ymin, uvmin;
   int reclamp;               // YUV clamped: final LUT pass (:393-403); its two tables follow the jobs
 };
-__global__ __launch_bounds__(kBlock) void k_rgbdelay(RgbdArgs a) {
+struct RgbdSmall { RgbdJob j[4]; };                           // up to 4 table entries travel as kernel arguments (no copy, no fence)
+template <bool SMALL>
+__global__ __launch_bounds__(kBlock) void k_rgbdelay(RgbdArgs a, RgbdSmall sm) {
   extern __shared__ uint8_t s_rgbd[];                         // [njobs (+1 for the reclamp pair)][3][256]
   const int nl = a.njobs + (a.reclamp ? 1 : 0);
+  const RgbdJob *jobs = SMALL ? sm.j : a.jobs;
   for (int i = threadIdx.x; i < nl * 192; i += kBlock)
-    reinterpret_cast<uint32_t *>(s_rgbd)[i] = reinterpret_cast<const uint32_t *>(a.jobs[i / 192].lut)[i % 192];
+    reinterpret_cast<uint32_t *>(s_rgbd)[i] = reinterpret_cast<const uint32_t *>(jobs[i / 192].lut)[i % 192];
   __syncthreads();
   const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (!a.direct && x >= a.width && 3 * x < a.orow) {          // memset(dst, 0, dframesize) (:311) reaches the row padding too
+    for (int y = blockIdx.y; y < a.height; y += gridDim.y)
+      for (int b = 3 * x; b < 3 * x + 3 && b < a.orow; b++) a.dst[(size_t)y * a.orow + b] = 0;
+  }
   if (x >= a.width) return;
   for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
     uint8_t *d = a.dst + (size_t)y * a.orow + 3 * x;
     if (a.direct) {
-      const RgbdJob &j = a.jobs[0];
+      const RgbdJob &j = jobs[0];
       const uint8_t *p = j.frame + (size_t)y * a.pitch + 3 * x;
       const uint8_t *l = s_rgbd;
       uint8_t v[3] = {p[0], p[1], p[2]};
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_rgbdelay(RgbdArgs a) {
       uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
       const size_t off = (size_t)y * a.pitch + 3 * x;
       for (int k = 0; k < a.njobs; k++) {
-        const RgbdJob &j = a.jobs[k];
+        const RgbdJob &j = jobs[k];
         const uint8_t *p = j.frame + off;
         const uint8_t *l = s_rgbd + k * 768;
         const int cr = j.cross;
@@ -775,8 +782,7 @@ extern "C" int lgpu_rgbdelay_process(lgpu_rgbdelay *s, const uint8_t *src_d, int
       const int cross = ((!is_bgr && s->is_bgr[j]) || (is_bgr && !s->is_bgr[j])) ? 2 : 0;
       fill_job(s->jobs_h[n++], s->cache[k], s->is_bgr[j], j, cross);
     }
-    a.pitch = wb;
-    if ((rc = lgpu_fill(dst_d, 0, (size_t)orow * height, stream))) return rc;      // memset(dst, 0, dframesize) :311, row padding included
+    a.pitch = wb;                                                                   // the kernel also zeroes the row padding (:311)
   }
   if (is_yuv && yuvmin == 16) {
     lgpu::RgbdJob &r = s->jobs_h[n];
@@ -786,13 +792,21 @@ extern "C" int lgpu_rgbdelay_process(lgpu_rgbdelay *s, const uint8_t *src_d, int
   }
   a.njobs = n;
   const int nl = n + a.reclamp;
-  LGPU_HIP(hipMemcpyAsync(s->jobs_d, s->jobs_h, sizeof(lgpu::RgbdJob) * nl, hipMemcpyHostToDevice, st));
-  LGPU_HIP(hipEventRecord(s->copied, st));
-  s->in_flight = true;
   const size_t lds = (size_t)nl * 768;
-  if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)lgpu::k_rgbdelay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 1024 ? height : 1024));
-  hipLaunchKernelGGL(lgpu::k_rgbdelay, grid, dim3(kBlock), lds, st, a);
+  // x covers the pixels and, in the accumulate mode, the row padding (3 bytes per lane)
+  const unsigned span = a.direct ? (unsigned)width : (unsigned)((orow + 2) / 3);
+  const dim3 grid(cdiv(span, kBlock), (unsigned)(height < 1024 ? height : 1024));
+  lgpu::RgbdSmall sm = {};
+  if (nl <= 4) {
+    for (int i = 0; i < nl; i++) sm.j[i] = s->jobs_h[i];
+    hipLaunchKernelGGL(lgpu::k_rgbdelay<true>, grid, dim3(kBlock), lds, st, a, sm);
+  } else {
+    LGPU_HIP(hipMemcpyAsync(s->jobs_d, s->jobs_h, sizeof(lgpu::RgbdJob) * nl, hipMemcpyHostToDevice, st));
+    LGPU_HIP(hipEventRecord(s->copied, st));
+    s->in_flight = true;
+    if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)lgpu::k_rgbdelay<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lgpu::k_rgbdelay<false>, grid, dim3(kBlock), lds, st, a, sm);
+  }
   LGPU_CHECK_LAUNCH();
   if (s->ccache < s->tcache) s->ccache++;
   return LGPU_OK;
