@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU)
     ap.add_argument("--blur", type=int, default=0, help="1: add the 5x5 gaussian stage (BASELINE config 5 chain)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--l2-translucent", type=float, default=0.5,
+                    help="fraction of layer-2 pixels with alpha < 255 (they take the reference's float scaling path); 0 = an opaque layer 2")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,9 +66,9 @@ def main():
     T = args.tracks
     srcs = [torch.randint(0, 256, (SH, SW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
     l2s = [torch.randint(0, 256, (DH, DW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
-    for t in l2s:   # half of layer 2 opaque (integer blend path), half translucent (float path)
+    for t in l2s:   # default: half of layer 2 opaque (integer blend path), half translucent (the reference's float scaling path), scattered per pixel
         a = t[:, 3::4]
-        a[torch.rand(a.shape, device="cuda", generator=g) < 0.5] = 255
+        a[torch.rand(a.shape, device="cuda", generator=g) >= args.l2_translucent] = 255
     dsts = [torch.zeros((DH, DW * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
 
     from lives_amd.lib import load
@@ -148,7 +150,7 @@ def main():
             "config": {"workload": "3840x2160 BGRA32 -> convert(RGBA32) -> bicubic resize 0.5x%s -> chroma blend with 1920x1080 RGBA32 layer -> gamma LUT (linear->sRGB)"
                                    % (" -> 5x5 gaussian" if args.blur else ""),
                        "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
-                       "launches_per_step": 2 if args.blur else 1},
+                       "launches_per_step": 2 if args.blur else 1, "layer2_translucent_fraction": args.l2_translucent},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu:
