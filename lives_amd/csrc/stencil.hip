@@ -414,6 +414,55 @@ __global__ __launch_bounds__(kBlock) void k_rgbdelay(RgbdArgs a, RgbdSmall sm) {
     }
   }
 }
+// the accumulate mode with one lane per FOUR pixels (12 bytes = three dwords per cached frame, three dword stores): rows of 3 * width and
+// orow bytes both multiples of 4.  Lanes past the pixels zero the row padding (memset :311).
+template <bool SMALL>
+__global__ __launch_bounds__(kBlock) void k_rgbdelay4(RgbdArgs a, RgbdSmall sm) {
+  extern __shared__ uint8_t s_rgbd[];
+  const int nl = a.njobs + (a.reclamp ? 1 : 0);
+  const RgbdJob *jobs = SMALL ? sm.j : a.jobs;
+  for (int i = threadIdx.x; i < nl * 192; i += kBlock)
+    reinterpret_cast<uint32_t *>(s_rgbd)[i] = reinterpret_cast<const uint32_t *>(jobs[i / 192].lut)[i % 192];
+  __syncthreads();
+  const int g = blockIdx.x * kBlock + threadIdx.x;            // group of 4 pixels = 12 bytes
+  const int b0 = 12 * g, wb = 3 * a.width;
+  if (b0 >= a.orow) return;
+  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+    uint32_t *d = reinterpret_cast<uint32_t *>(a.dst + (size_t)y * a.orow + b0);
+    if (b0 >= wb) {                                           // padding only
+      for (int q = 0; q < 3 && b0 + 4 * q < a.orow; q++) d[q] = 0;
+      continue;
+    }
+    uint32_t acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = 0;
+    const size_t off = (size_t)y * a.pitch + b0;
+    for (int k = 0; k < a.njobs; k++) {
+      const RgbdJob &j = jobs[k];
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(j.frame + off);
+      const uint32_t w0 = p[0], w1 = (b0 + 4 < wb) ? p[1] : 0, w2 = (b0 + 8 < wb) ? p[2] : 0;
+      const uint8_t *l = s_rgbd + k * 768;
+      const int cr = j.cross;
+      auto byte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? w0 : i < 8 ? w1 : w2; return (w >> (8 * (i & 3))) & 0xFF; };
+#pragma unroll
+      for (int px = 0; px < 4; px++) {
+        if (j.b[0]) acc[3 * px] += l[byte(3 * px + cr)];
+        if (j.b[1]) acc[3 * px + 1] += l[256 + byte(3 * px + 1)];
+        if (j.b[2]) acc[3 * px + 2] += l[512 + byte(3 * px + 2 - cr)];
+      }
+    }
+    if (a.reclamp) {
+      const uint8_t *r = s_rgbd + a.njobs * 768;
+#pragma unroll
+      for (int i = 0; i < 12; i++) acc[i] = r[((i % 3) ? 256 : 0) + (acc[i] & 0xFF)];
+    }
+    uint32_t o[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) o[q] = (acc[4 * q] & 0xFF) | ((acc[4 * q + 1] & 0xFF) << 8) | ((acc[4 * q + 2] & 0xFF) << 16) | ((acc[4 * q + 3] & 0xFF) << 24);
+    // wb % 4 == 0: a dword below wb holds pixel bytes only, one at or above it padding only
+    for (int q = 0; q < 3 && b0 + 4 * q < a.orow; q++) d[q] = (b0 + 4 * q < wb) ? o[q] : 0;
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_rgbd_snapshot(const uint8_t *src, int irow, uint8_t *frame, int wb, int height) {
   const int x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= wb) return;
@@ -797,9 +846,18 @@ extern "C" int lgpu_rgbdelay_process(lgpu_rgbdelay *s, const uint8_t *src_d, int
   const unsigned span = a.direct ? (unsigned)width : (unsigned)((orow + 2) / 3);
   const dim3 grid(cdiv(span, kBlock), (unsigned)(height < 1024 ? height : 1024));
   lgpu::RgbdSmall sm = {};
+  const bool quad = !a.direct && (wb & 3) == 0 && (orow & 3) == 0 && ((uintptr_t)dst_d & 3) == 0;
+  const dim3 grid4(cdiv((unsigned)((orow + 11) / 12), kBlock), grid.y);
   if (nl <= 4) {
     for (int i = 0; i < nl; i++) sm.j[i] = s->jobs_h[i];
-    hipLaunchKernelGGL(lgpu::k_rgbdelay<true>, grid, dim3(kBlock), lds, st, a, sm);
+    if (quad) hipLaunchKernelGGL(lgpu::k_rgbdelay4<true>, grid4, dim3(kBlock), lds, st, a, sm);
+    else hipLaunchKernelGGL(lgpu::k_rgbdelay<true>, grid, dim3(kBlock), lds, st, a, sm);
+  } else if (quad) {
+    LGPU_HIP(hipMemcpyAsync(s->jobs_d, s->jobs_h, sizeof(lgpu::RgbdJob) * nl, hipMemcpyHostToDevice, st));
+    LGPU_HIP(hipEventRecord(s->copied, st));
+    s->in_flight = true;
+    if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)lgpu::k_rgbdelay4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lgpu::k_rgbdelay4<false>, grid4, dim3(kBlock), lds, st, a, sm);
   } else {
     LGPU_HIP(hipMemcpyAsync(s->jobs_d, s->jobs_h, sizeof(lgpu::RgbdJob) * nl, hipMemcpyHostToDevice, st));
     LGPU_HIP(hipEventRecord(s->copied, st));

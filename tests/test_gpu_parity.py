@@ -433,10 +433,9 @@ def test_deinterlace(gpu, orc, palette):
 def test_rgbdelay_with_changing_parameters(gpu, orc, palette):
     """a longer run than the fixtures: the parameter set changes mid-sequence (the ring grows, shrinks and empties), frames are padded"""
     rng = np.random.default_rng(2900 + palette)
-    w, h = 70, 24
     plans = [({0: (1, 0, 0, 1.0), 3: (0, 1, 0, 0.8), 6: (0, 0, 1, 1.0)}, 12), ({0: (1, 1, 1, 0.5), 1: (1, 1, 1, 0.5), 9: (1, 0, 1, 0.7)}, 12),
              ({0: (0, 1, 1, 0.9)}, 20), ({0: (1, 0, 0, 1.0), 2: (0, 1, 1, 1.0)}, 2), ({0: (1, 1, 1, 1.0), 49: (1, 1, 1, 0.3)}, 50)]
-    for inplace in (0, 1):
+    for inplace, (w, h) in ((0, (70, 24)), (1, (70, 24)), (0, (72, 10)), (1, (132, 7))):     # 3 * width % 4 == 0 takes the four-pixel kernel
         s = orc.orc_rgbdelay_new()
         rd = gpu.RgbDelay()
         for groups, maxcache in plans:
