@@ -76,6 +76,11 @@ def main():
         print("  %-34s %9.2f us %8.1f GB/s  frac %.3f" % (name, gpu_s * 1e6, gbs, gbs / PEAK), file=sys.stderr, flush=True)
 
     NB = 8
+    # ---- the floor: a launch that moves nothing (what a dependent 1080p op cannot go below on this stream) ------------------------------------
+    tiny = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    from lives_amd.lib import call as _call
+    t = timeit(lambda i: _call("lgpu_fill", tiny.data_ptr(), 0, 64, None), 1)
+    add("launch floor (lgpu_fill of 64 bytes)", "-", "-", 64, t, None)
     # ---- K1 swizzle: C1 (640x480 RGB24 -> BGRA32) and the same op at 4K -------------------------------------------------
     for (w, h) in ((640, 480), (3840, 2160)):
         src, dst = dframe(w, h, 3, NB), dframe(w, h, 4, NB)

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""tools/fuzz_ops.py [iterations] [seed] -- randomized differential run: entry points whose geometry / stride / alignment handling has several
+code paths (resize, chain, gauss5, swizzle, K2, repacks, deinterlace, letterbox) on random sizes, strides and parameters, GPU against the CPU
+oracle, bit for bit.  TEST / DEBUG TOOL (uses oracle/); prints the first mismatch with everything needed to replay it."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import torch
+    from lives_amd import ops
+    from lives_amd.lib import LgpuError
+    from oracle import pyoracle as po
+    ops.init(0)
+    orc = po.oracle()
+    P = po.P
+    rng = np.random.default_rng(seed)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    def fr(w, h, ps, extra=None):
+        al = int(rng.choice([1, 4, 8, 16, 32]))
+        stride = (w * ps + al - 1) // al * al + (int(rng.integers(0, 3)) * al if extra is None else extra)
+        a = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        if ps == 4 and rng.random() < 0.5:
+            a[:, 3::4][rng.random((h, a[:, 3::4].shape[1])) < 0.6] = 255
+        return a
+
+    def same(got, want, nbytes, rows, what):
+        if not (got[:rows, :nbytes] == want[:rows, :nbytes]).all():
+            idx = np.argwhere(got[:rows, :nbytes] != want[:rows, :nbytes])[0]
+            print("MISMATCH", what, "first at", idx.tolist(), int(got[tuple(idx)]), int(want[tuple(idx)]), flush=True)
+            return False
+        return True
+
+    lutl = np.zeros(256, np.uint8)
+    orc.orc_gamma_lut8(1.0, po.GAMMA_LINEAR, po.GAMMA_SRGB, 1.4, P(lutl))
+    bad = 0
+    counts = {}
+    for it in range(iters):
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox"]))
+        counts[kind] = counts.get(kind, 0) + 1
+        try:
+            if kind == "resize":
+                ps = int(rng.choice([1, 3, 4]))
+                sw, sh = int(rng.integers(4, 400)), int(rng.integers(4, 200))
+                if rng.random() < 0.4:
+                    dw, dh = max(2, sw // 2), max(2, sh // 2)
+                    sw, sh = dw * 2, dh * 2
+                else:
+                    dw, dh = int(rng.integers(2, 400)), int(rng.integers(2, 200))
+                interp = int(rng.choice([1, 2, 3]))
+                src = fr(sw, sh, ps)
+                want = np.zeros((dh, (dw * ps + 31) // 32 * 32), np.uint8)
+                if orc.orc_resize(P(src), src.strides[0], sw, sh, P(want), want.strides[0], dw, dh, ps, interp) != 0:
+                    continue
+                d = dev(np.zeros_like(want))
+                ops.resize(dev(src), d, sw, sh, dw, dh, psize=ps, interp=interp)
+                ok = same(host(d), want, dw * ps, dh, "resize %dx%d->%dx%d ps=%d interp=%d stride=%d" % (sw, sh, dw, dh, ps, interp, src.strides[0]))
+            elif kind == "chain":
+                dw, dh = int(rng.integers(2, 200)), int(rng.integers(2, 120))
+                if rng.random() < 0.6:
+                    sw, sh = 2 * dw, 2 * dh
+                else:
+                    sw, sh = int(rng.integers(4, 400)), int(rng.integers(4, 240))
+                swap, blur, bf, ntr = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 256)), int(rng.integers(1, 4))
+                use_lut = rng.random() < 0.7
+                srcs = [fr(sw, sh, 4, extra=0) for _ in range(ntr)]
+                srcs = [s if s.strides[0] == srcs[0].strides[0] else np.ascontiguousarray(np.pad(s[:, :sw * 4], ((0, 0), (0, srcs[0].strides[0] - sw * 4)))) for s in srcs]
+                l2s = [fr(dw, dh, 4, extra=0) for _ in range(ntr)]
+                l2s = [s if s.strides[0] == l2s[0].strides[0] else np.ascontiguousarray(np.pad(s[:, :dw * 4], ((0, 0), (0, l2s[0].strides[0] - dw * 4)))) for s in l2s]
+                orow = (dw * 4 + 31) // 32 * 32
+                lut = lutl if use_lut else None
+                wants = []
+                for i in range(ntr):
+                    w_ = np.zeros((dh, orow), np.uint8)
+                    if orc.orc_chain(P(srcs[i]), srcs[i].strides[0], sw, sh, P(l2s[i]), l2s[i].strides[0], P(w_), orow, dw, dh, swap, 3, blur, bf, P(lut) if use_lut else None) != 0:
+                        wants = None
+                        break
+                    wants.append(w_)
+                if wants is None:
+                    continue
+                dd = [dev(np.zeros((dh, orow), np.uint8)) for _ in range(ntr)]
+                prm = ops.chain_params(sw, sh, srcs[0].strides[0], dw, dh, l2s[0].strides[0], orow, swap_rb=swap, interp=3, do_blur=blur, bf=bf, lut=lut)
+                ops.chain(prm, ops.chain_tracks([dev(s) for s in srcs], [dev(s) for s in l2s], dd))
+                ok = all(same(host(dd[i]), wants[i], dw * 4, dh, "chain %dx%d->%dx%d swap=%d blur=%d bf=%d lut=%d strides=%d/%d track %d" %
+                              (sw, sh, dw, dh, swap, blur, bf, use_lut, srcs[0].strides[0], l2s[0].strides[0], i)) for i in range(ntr))
+            elif kind == "gauss5":
+                ps = int(rng.choice([1, 3, 4]))
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 150))
+                src = fr(w, h, ps)
+                want = np.zeros_like(src)
+                orc.orc_gauss5(P(src), src.strides[0], P(want), want.strides[0], w, h, ps)
+                d = dev(np.zeros_like(src))
+                ops.gauss5(dev(src), d, w, h, psize=ps)
+                ok = same(host(d), want, w * ps, h, "gauss5 %dx%d ps=%d stride=%d" % (w, h, ps, src.strides[0]))
+            elif kind == "swizzle":
+                op = int(rng.integers(0, 13))
+                ib, ob = po.OP_IBPP[op], po.OP_OBPP[op]
+                w, h = int(rng.integers(1, 500)), int(rng.integers(1, 60))
+                src = fr(w, h, ib)
+                want = np.full((h, (w * ob + 3) // 4 * 4 + int(rng.integers(0, 3)) * 4), 0xAB, np.uint8)
+                af = int(rng.integers(0, 2)) if op in (po.OPS.index("swap4"), po.OPS.index("swapprepost")) else 0
+                lut = rng.integers(0, 256, 256, dtype=np.uint8) if rng.random() < 0.5 else None
+                orc.orc_swizzle(op, af, P(src), src.strides[0], P(want), want.strides[0], w, h, P(lut) if lut is not None else None)
+                d = dev(np.full_like(want, 0xAB))
+                ops.swizzle(op, dev(src), d, w, h, alpha_first=af, lut=lut)
+                ok = same(host(d), want, want.shape[1], h, "swizzle op=%d %dx%d af=%d lut=%d strides %d->%d" % (op, w, h, af, lut is not None, src.strides[0], want.strides[0]))
+            elif kind == "k2":
+                w, h = 2 * int(rng.integers(1, 200)), int(rng.integers(1, 100))
+                is422 = int(rng.integers(0, 2))
+                ys = (w + 7) // 8 * 8 + 8 * int(rng.integers(0, 3))
+                cs = ys // 2
+                ch = h if is422 else max(1, h // 2)
+                if not is422 and h < 2:
+                    continue
+                Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
+                U, V = (rng.integers(0, 256, (ch, cs), dtype=np.uint8) for _ in range(2))
+                opsz, which, q = int(rng.choice([3, 4])), int(rng.integers(0, 4)), int(rng.choice([1, 2, 3]))
+                os.environ["LGPU_YUV_WIDE"] = "1" if rng.random() < 0.5 else ""
+                if not os.environ["LGPU_YUV_WIDE"]:
+                    del os.environ["LGPU_YUV_WIDE"]
+                orow = (w * opsz + 15) // 16 * 16
+                st = (ctypes.c_int * 3)(ys, cs, cs)
+                want = np.full((h, orow), 0xAB, np.uint8)
+                orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), st, U.size, V.size, P(want), orow, w, h, opsz, 0, is422, which, q, P(lutl), 0)
+                d = dev(np.full_like(want, 0xAB))
+                ops.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=opsz, is_422=is422, which_tables=which, pb_quality=q, lut=lutl)
+                ok = same(host(d), want, w * opsz, h, "k2 %dx%d 422=%d ops=%d which=%d q=%d ys=%d" % (w, h, is422, opsz, which, q, ys))
+            elif kind == "repack":
+                ip, op, padok = po.YUV_REPACK_PAIRS[int(rng.integers(0, len(po.YUV_REPACK_PAIRS)))]
+                w, h = 2 * int(rng.integers(1, 150)), 2 * int(rng.integers(1, 60))
+                pad = int(rng.choice([0, 4, 24])) if padok else 0
+                unc = int(rng.integers(0, 2))
+                src = po.yuv_planes(ip, w, h, rng=rng, pad=pad)
+                want = po.yuv_planes(op, w, h, fill=0x5A, pad=pad)
+                sp, ss = po.planes_args(src)
+                wp, ws = po.planes_args(want)
+                if orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, unc, 0) != 0:
+                    continue
+                dst = [dev(np.full_like(a, 0x5A)) for a in want]
+                ops.yuv_repack(ip, op, [dev(a) for a in src], dst, w, h, unc)
+                ok = all(same(host(dst[i]), want[i], want[i].shape[1], want[i].shape[0], "repack %d->%d %dx%d pad=%d unc=%d plane %d" % (ip, op, w, h, pad, unc, i)) for i in range(len(want)))
+            elif kind == "deint":
+                pal = int(rng.choice([1, 2, 588, 3, 4, 589, 564, 565]))
+                ps = 3 if pal in (1, 2, 588) else 4
+                w, h = int(rng.integers(1, 200)), int(rng.integers(1, 80))
+                src = fr(w, h, ps)
+                inplace = int(rng.integers(0, 2))
+                want = src.copy() if inplace else np.full_like(src, 0x5A)
+                a = want if inplace else src
+                if orc.orc_deinterlace(P(a), a.strides[0], P(want), want.strides[0], w, h, pal) != 0:
+                    continue
+                ds = dev(src)
+                d = ds if inplace else dev(np.full_like(src, 0x5A))
+                ops.deinterlace(ds, d, w, h, pal)
+                n = (w + 2) // 3 * 3 * ps
+                ok = same(host(d), want, n, h, "deinterlace pal=%d %dx%d inplace=%d stride=%d" % (pal, w, h, inplace, src.strides[0]))
+            else:
+                ps = int(rng.choice([1, 3, 4]))
+                w, h = int(rng.integers(1, 200)), int(rng.integers(1, 100))
+                nw, nh = w + 2 * int(rng.integers(0, 40)), h + 2 * int(rng.integers(0, 40))
+                src = fr(w, h, ps)
+                black = rng.integers(0, 256, 4, dtype=np.uint8)
+                want = np.full((nh, (nw * ps + 31) // 32 * 32), 0x77, np.uint8)
+                orc.orc_letterbox(P(src), src.strides[0], w, h, P(want), want.strides[0], nw, nh, ps, P(black))
+                d = dev(np.full_like(want, 0x77))
+                ops.letterbox(dev(src), d, w, h, nw, nh, ps, black)
+                ok = same(host(d), want, want.shape[1], nh, "letterbox %dx%d->%dx%d ps=%d" % (w, h, nw, nh, ps))
+        except LgpuError as e:
+            print("DECLINED", kind, str(e)[:160], flush=True)
+            ok = True
+        if not ok:
+            bad += 1
+            if bad >= 10:
+                break
+    print("fuzz: %d iterations, %d mismatching cases; per kind %s" % (it + 1, bad, counts))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
