@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -167,6 +167,64 @@ def main():
                 ops.deinterlace(ds, d, w, h, pal)
                 n = (w + 2) // 3 * 3 * ps
                 ok = same(host(d), want, n, h, "deinterlace pal=%d %dx%d inplace=%d stride=%d" % (pal, w, h, inplace, src.strides[0]))
+            elif kind == "edge":
+                pal, mode = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+                ps = 3 if pal <= 2 else 4
+                w, h = int(rng.integers(4, 260)), int(rng.integers(4, 140))
+                inplace = int(rng.integers(0, 2))
+                sfr = fr(w, h, ps)
+                yy, xx = np.mgrid[0:h, 0:w]
+                for c in range(ps):
+                    sfr[:, c:w * ps:ps] = ((sfr[:, c:w * ps:ps] >> 3) + (96 * ((xx // 9 + yy // 7 + c) % 2)).astype(np.uint8) + 40).astype(np.uint8)
+                d0 = sfr.copy() if inplace else rng.integers(0, 256, sfr.shape, dtype=np.uint8)
+                want = d0.copy()
+                m16 = np.zeros(w * h, np.int16)
+                orc.orc_edge(P(want) if inplace else P(sfr), sfr.strides[0], P(want), want.strides[0], w, h, pal, mode, P(m16), inplace)
+                d = dev(d0)
+                ops.edge(d if inplace else dev(sfr), d, w, h, pal, mode)
+                ok = same(host(d), want, w * ps, h, "edge pal=%d mode=%d %dx%d inplace=%d stride=%d" % (pal, mode, w, h, inplace, sfr.strides[0]))
+            elif kind == "softlight":
+                pal = int(rng.choice([512, 513, 522, 544, 545]))
+                w, h = 2 * int(rng.integers(2, 150)), 2 * int(rng.integers(2, 70))
+                unc = int(rng.integers(0, 2))
+                cw = w >> 1 if pal in (512, 513, 522) else w
+                ch = h >> 1 if pal in (512, 513) else h
+                dims = [(w, h), (cw, ch), (cw, ch)] + ([(w, h)] if pal == 545 else [])
+                src = [fr(a, b, 1) for (a, b) in dims]
+                want = np.full_like(src[0], 0x5A)
+                orc.orc_softlight_y(P(src[0]), src[0].strides[0], P(want), want.strides[0], w, h, unc)
+                dst = [dev(np.full_like(a, 0x5A)) for a in src]
+                ops.softlight([dev(a) for a in src], dst, w, h, pal, unc)
+                ok = same(host(dst[0]), want, w, h, "softlight pal=%d %dx%d unc=%d" % (pal, w, h, unc))
+                for i in range(1, len(dims)):
+                    ok = ok and same(host(dst[i]), src[i], dims[i][0], dims[i][1], "softlight plane %d" % i)
+            elif kind == "blend":
+                pal = int(rng.integers(1, 6))
+                ps = 3 if pal <= 2 else 4
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                bf = int(rng.integers(0, 256))
+                inplace = int(rng.integers(0, 2))
+                s1, s2 = fr(w, h, ps, extra=0), fr(w, h, ps, extra=32)
+                init = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                want = init.copy()
+                a = want if inplace else s1
+                orc.orc_blend_chroma(P(a), a.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, ps, int(pal == 5), bf)
+                d1 = dev(s1)
+                d = d1 if inplace else dev(init)
+                ops.blend_chroma(d1, dev(s2), d, w, h, ps, bf, alpha_first=int(pal == 5))
+                ok = same(host(d), want, w * ps, h, "blend_chroma pal=%d %dx%d bf=%d inplace=%d" % (pal, w, h, bf, inplace))
+            elif kind == "mirror":
+                ps, mode = int(rng.choice([3, 4])), int(rng.integers(0, 3))
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 120))
+                inplace = int(rng.integers(0, 2))
+                sfr = fr(w, h, ps)
+                want = sfr.copy() if inplace else np.full_like(sfr, 0x5A)
+                a = want if inplace else sfr
+                orc.orc_mirror(mode, P(a), a.strides[0], P(want), want.strides[0], w, h, ps)
+                ds = dev(sfr)
+                d = ds if inplace else dev(np.full_like(sfr, 0x5A))
+                ops.mirror(mode, ds, d, w, h, ps)
+                ok = same(host(d), want, w * ps, h, "mirror mode=%d ps=%d %dx%d inplace=%d" % (mode, ps, w, h, inplace))
             else:
                 ps = int(rng.choice([1, 3, 4]))
                 w, h = int(rng.integers(1, 200)), int(rng.integers(1, 100))
