@@ -23,6 +23,7 @@
 #include <time.h>
 #include "../../include/lives_gpu_weed_abi.h"
 #include "../../include/lives_gpu.h"
+#include "../../include/lives_gpu_layer.h"
 
 /* ---- host functions obtained at bootstrap ---- */
 static weed_leaf_get_f w_get;
@@ -129,22 +130,30 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
     f.src[i] += (size_t)offset * f.irow[i];                           /* inputs are NOT pre-offset (simple_blend.c:87-91) */
   }
   f.inplace = (f.src[0] == f.dst);
-  /* stage to the device: in rows as they are (rowstride preserved so alignment-dependent paths match) */
+  /* stage to the device: in rows as they are (rowstride preserved so alignment-dependent paths match).  A channel whose pixel_data is the
+     plane of a pinned layer (lives_gpu_layer_pin, include/lives_gpu_layer.h) is used where it lives in HBM: no upload, and for the out
+     channel no download -- the device copy is the plane until lives_gpu_layer_sync() */
   {
     /* the ARGB chroma blend reads one byte past the last pixel of each row of layer 2 (reference quirk B1) */
     const size_t ob = (size_t)f.orow * f.height;
-    f.ddst = (uint8_t *)fx_buf(fx, 2, ob + 16);
+    uint8_t *res_dst = (uint8_t *)lives_gpu_resident_lookup(f.dst - (size_t)offset * f.orow, (size_t)f.orow * real_h);
+    if (res_dst) f.ddst = res_dst + (size_t)offset * f.orow;
+    else f.ddst = (uint8_t *)fx_buf(fx, 2, ob + 16);
     if (!f.ddst) return WEED_ERROR_MEMORY_ALLOCATION;
     for (i = 0; i < nin; i++) {
       const size_t ib = (size_t)f.irow[i] * f.height;
-      if (i == 0 && f.inplace) { f.dsrc[0] = f.ddst; if (lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID; continue; }
+      uint8_t *res_src;
+      if (i == 0 && f.inplace) { f.dsrc[0] = f.ddst; if (!res_dst && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID; continue; }
+      res_src = (uint8_t *)lives_gpu_resident_lookup(f.src[i] - (size_t)offset * f.irow[i], (size_t)f.irow[i] * real_h);
+      if (res_src) { f.dsrc[i] = res_src + (size_t)offset * f.irow[i]; continue; }
       f.dsrc[i] = (uint8_t *)fx_buf(fx, i, ib + 16);
       if (!f.dsrc[i]) return WEED_ERROR_MEMORY_ALLOCATION;
       if (lgpu_upload(f.dsrc[i], f.src[i], ib, NULL)) return WEED_ERROR_PLUGIN_INVALID;
     }
-    if (!f.inplace && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
+    if (!f.inplace && !res_dst && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
     if (kernel(&f, inst, kind) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
-    if (lgpu_download(f.dst, f.ddst, ob, NULL) || lgpu_sync(NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    if (!res_dst && lgpu_download(f.dst, f.ddst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    if (lgpu_sync(NULL)) return WEED_ERROR_PLUGIN_INVALID;
   }
   return WEED_SUCCESS;
 }

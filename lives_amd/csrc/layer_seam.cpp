@@ -717,6 +717,15 @@ int lives_gpu_layer_unpin(lives_gpu_layer_t *layer) {
   if (bound() && layer) g_api.leaf_delete(layer, kLeafResident);
   return rc;
 }
+// residency bridge for the weed plugin (same library, other seam): the device copy of a pinned layer's plane, looked up by the host plane
+// pointer the channel carries; NULL when the plane is not resident (or smaller than asked)
+void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
+  if (!host_plane) return nullptr;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  auto it = g_res.find(host_plane);
+  if (it == g_res.end() || it->second.bytes < min_bytes) return nullptr;
+  return it->second.d;
+}
 void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes) {
   if (h2d_bytes) *h2d_bytes = g_h2d;
   if (d2h_bytes) *d2h_bytes = g_d2h;

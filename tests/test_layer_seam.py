@@ -387,3 +387,50 @@ def test_pinned_layer_stays_in_hbm(seam, orc):
     assert (h1 - h0) > 3 * in_bytes and (d1 - d0) > 3 * out_bytes         # the unpinned chain pays for every step
     assert L.lives_gpu_layer_unpin(pinned) == 0 and wh.geti(pinned, "host_gpu_resident") is None
 
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_plugin_effects_on_pinned_layers_stay_in_hbm(seam, orc):
+    """both seams together: convert a pinned layer, run weed filters of livesgpu_fx.so on its planes (the channels carry the layer's host plane
+    pointers, as weed_apply_instance hands them over), sync once -- the effect results are right and nothing crossed PCIe in between"""
+    import os
+    L, wh = seam
+    H = po.RefHost()
+    OURS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lives_amd", "livesgpu_fx.so")
+
+    def stats():
+        a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        L.lives_gpu_transfer_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def view(layer):            # numpy views ON the layer's host planes (same addresses the channels would carry)
+        _, ptrs, rs = wh.planes_of(layer)
+        hh = wh.geti(layer, "height")
+        return [np.frombuffer((ctypes.c_uint8 * (rs[0] * hh)).from_address(ptrs[0]), np.uint8).reshape(hh, rs[0])]
+
+    rng = np.random.default_rng(21)
+    w, h = 64, 16
+    a_rgb, b_rgb = frame(rng, w, h, 3), frame(rng, w, h, 4, alpha_mix=True)
+    la = wh.new_layer(RGB24, w, h, [a_rgb], gamma=1)
+    lb = wh.new_layer(RGBA32, w, h, [b_rgb], gamma=1)
+    assert L.lives_gpu_layer_pin(la) == 0 and L.lives_gpu_layer_pin(lb) == 0
+    s0 = stats()
+    assert L.lives_gpu_convert_layer_palette(la, RGBA32, 0) == 1               # on the device copy
+    va, vb = view(la)[0], view(lb)[0]
+    stale = va.copy()
+    H.run(OURS, "chroma blend", RGBA32, w, h, [va, vb], va, [po.p_int(90)])     # in place on layer a, second input layer b
+    H.run(OURS, "negate", RGBA32, w, h, [va], va, [])
+    assert stats() == s0, "effects on pinned layers must not cross PCIe"
+    assert (va == stale).all(), "the host plane stays stale until the layer is synced"
+    assert L.lives_gpu_layer_sync(la) == 0
+    got = view(la)[0].copy()
+    # expected: the same steps on the oracle
+    conv = np.zeros((h, va.shape[1]), np.uint8)
+    orc.orc_swizzle(po.OPS.index("addpost"), 0, P(a_rgb), a_rgb.strides[0], P(conv), conv.strides[0], w, h, None)
+    orc.orc_blend_chroma(P(conv), conv.strides[0], P(b_rgb), b_rgb.strides[0], P(conv), conv.strides[0], w, h, 4, 0, 90)
+    luts = np.zeros((4, 256), np.uint8)
+    assert orc.orc_fx_luts(0, RGBA32, 0., 0., 0., luts.ctypes.data) == 4
+    orc.orc_byte_luts(P(conv), conv.strides[0], P(conv), conv.strides[0], w, h, 4, luts.ctypes.data)
+    assert (got[:, :w * 4] == conv[:, :w * 4]).all()
+    assert L.lives_gpu_layer_unpin(la) == 0 and L.lives_gpu_layer_unpin(lb) == 0
