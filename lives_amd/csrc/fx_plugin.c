@@ -298,7 +298,7 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
   fxdata_t *fx = fx_data(inst);
   weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, 0), *oc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0);
   const uint8_t *dsrc[4] = {0, 0, 0, 0};
-  uint8_t *ddst[4] = {0, 0, 0, 0}, *hdst[4], *base;
+  uint8_t *ddst[4] = {0, 0, 0, 0}, *rdst[4] = {0, 0, 0, 0}, *hdst[4], *base;
   int irow[4], orow[4], ph[4], i, nplanes, pal, w, h, clamping;
   size_t ioff[4], ooff[4], itot = 0, otot = 0;
   (void)tc;
@@ -320,13 +320,18 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
   }
   base = (uint8_t *)fx_buf(fx, 0, itot);
   if (!base) return WEED_ERROR_MEMORY_ALLOCATION;
-  for (i = 0; i < nplanes; i++) {
+  for (i = 0; i < nplanes; i++) {                       /* planes of a pinned layer are used where they live in HBM (see fx_run) */
+    const void *hp = g_ptr(ic, WEED_LEAF_PIXEL_DATA, i);
+    const uint8_t *res = (const uint8_t *)lives_gpu_resident_lookup(hp, (size_t)irow[i] * ph[i]);
+    if (res) { dsrc[i] = res; continue; }
     dsrc[i] = base + ioff[i];
-    if (lgpu_upload(base + ioff[i], g_ptr(ic, WEED_LEAF_PIXEL_DATA, i), (size_t)irow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    if (lgpu_upload(base + ioff[i], hp, (size_t)irow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
   }
   base = (uint8_t *)fx_buf(fx, 2, otot);
   if (!base) return WEED_ERROR_MEMORY_ALLOCATION;
   for (i = 0; i < nplanes; i++) {
+    rdst[i] = (uint8_t *)lives_gpu_resident_lookup(hdst[i], (size_t)orow[i] * ph[i]);
+    if (rdst[i]) { ddst[i] = rdst[i]; continue; }
     ddst[i] = base + ooff[i];
     if (lgpu_upload(ddst[i], hdst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* row padding stays as it was */
   }
@@ -335,7 +340,7 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
     return WEED_ERROR_PLUGIN_INVALID;
   }
   for (i = 0; i < nplanes; i++)
-    if (lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    if (!rdst[i] && lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
   return lgpu_sync(NULL) ? WEED_ERROR_PLUGIN_INVALID : WEED_SUCCESS;
 }
 
