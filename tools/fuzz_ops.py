@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -213,6 +213,74 @@ def main():
                 d = d1 if inplace else dev(init)
                 ops.blend_chroma(d1, dev(s2), d, w, h, ps, bf, alpha_first=int(pal == 5))
                 ok = same(host(d), want, w * ps, h, "blend_chroma pal=%d %dx%d bf=%d inplace=%d" % (pal, w, h, bf, inplace))
+            elif kind == "rgb2yuv":
+                in_order, out_fmt = int(rng.integers(0, 3)), int(rng.integers(0, 6))
+                if out_fmt >= 4 and in_order == 2:
+                    continue
+                in_alpha = 1 if in_order == 2 else int(rng.integers(0, 2))
+                out_alpha = int(rng.integers(0, 2)) if out_fmt <= 1 else 0
+                which = int(rng.integers(0, 4)) if out_fmt >= 4 else int(rng.integers(0, 2))
+                w, h = int(rng.integers(1, 200)), int(rng.integers(1, 80))
+                if out_fmt >= 2:
+                    w, h = 2 * max(1, w // 2), 2 * max(1, h // 2)
+                src = fr(w, h, 4 if in_alpha else 3)
+                want, dims = po.k4_out_planes(0x5A, w, h, out_fmt, out_alpha, compact=bool(rng.integers(0, 2)))
+                wp, ws = po.planes_args(want)
+                if orc.orc_rgb_to_yuv(P(src), src.strides[0], w, h, in_order, in_alpha, ctypes.addressof(wp), ctypes.addressof(ws), out_fmt, out_alpha, which) != 0:
+                    continue
+                got = [dev(np.full_like(a, 0x5A)) for a in want]
+                ops.rgb_to_yuv(dev(src), got, w, h, in_order, in_alpha, out_fmt, out_alpha, which)
+                ok = all(same(host(got[i]), want[i], a, b, "rgb2yuv order=%d ia=%d fmt=%d oa=%d which=%d %dx%d plane %d" % (in_order, in_alpha, out_fmt, out_alpha, which, w, h, i))
+                         for i, (a, b) in enumerate(dims))
+            elif kind == "yuv2rgb":
+                in_fmt, out_order = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+                in_alpha = int(rng.integers(0, 2)) if in_fmt <= 1 else 0
+                out_alpha = 1 if out_order == 2 else int(rng.integers(0, 2))
+                if in_fmt == 1 and (out_order == 2 or (out_order == 1 and not out_alpha)):
+                    continue
+                which = int(rng.integers(0, 4)) if in_fmt == 0 else int(rng.integers(0, 2))
+                w, h = int(rng.integers(1, 200)), int(rng.integers(1, 80))
+                if in_fmt >= 2:
+                    w = 2 * max(1, w // 2)
+                if in_fmt == 0:
+                    planes = [fr(w, h, 4 if in_alpha else 3)]
+                elif in_fmt == 1:
+                    planes = [fr(w, h, 1, extra=0) for _ in range(4 if in_alpha else 3)]
+                    planes = [np.ascontiguousarray(np.pad(a[:, :w], ((0, 0), (0, planes[0].strides[0] - w)))) for a in planes]
+                else:
+                    planes = [fr(w, h, 2)]
+                opsz = 4 if (out_order == 2 or out_alpha) else 3
+                want = np.full((h, (w * opsz + 31) // 32 * 32), 0x5A, np.uint8)
+                sp, ss = po.planes_args(planes)
+                if orc.orc_yuv_to_rgb(ctypes.addressof(sp), ctypes.addressof(ss), w, h, in_fmt, in_alpha, P(want), want.strides[0], out_order, out_alpha, which) != 0:
+                    continue
+                d = dev(np.full_like(want, 0x5A))
+                ops.yuv_to_rgb([dev(a) for a in planes], d, w, h, in_fmt, in_alpha, out_order, out_alpha, which)
+                ok = same(host(d), want, w * opsz, h, "yuv2rgb fmt=%d ia=%d order=%d oa=%d which=%d %dx%d" % (in_fmt, in_alpha, out_order, out_alpha, which, w, h))
+            elif kind == "transition":
+                t, ps = int(rng.integers(0, 3)), int(rng.choice([3, 4]))
+                w, h = int(rng.integers(2, 300)), int(rng.integers(2, 120))
+                amt = float(rng.choice([0., 1., float(rng.random())]))
+                s1, s2 = fr(w, h, ps), fr(w, h, ps)
+                inplace = int(rng.integers(0, 2)) if t < 2 else 0
+                want = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                a = want if inplace else s1
+                orc.orc_transition(t, P(a), a.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, ps, amt)
+                d1 = dev(s1)
+                d = d1 if inplace else dev(np.full_like(s1, 0x5A))
+                ops.transition(t, d1, dev(s2), d, w, h, ps, amt)
+                ok = same(host(d), want, w * ps, h, "transition %d ps=%d %dx%d amount=%r inplace=%d" % (t, ps, w, h, amt, inplace))
+            elif kind == "premult":
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                af, un = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                sfr = fr(w, h, 4, extra=0)
+                if sfr.strides[0] & 3:
+                    continue
+                want = sfr.copy()
+                orc.orc_alpha_premult(P(want), want.strides[0], w, h, af, un)
+                d = dev(sfr)
+                ops.alpha_premult(d, w, h, alpha_first=af, un=un)
+                ok = same(host(d), want, w * 4, h, "premult %dx%d af=%d un=%d" % (w, h, af, un))
             elif kind == "mirror":
                 ps, mode = int(rng.choice([3, 4])), int(rng.integers(0, 3))
                 w, h = int(rng.integers(1, 300)), int(rng.integers(1, 120))
