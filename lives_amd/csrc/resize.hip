@@ -1422,6 +1422,12 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
           }
         const double it = (double)nwork;
         fprintf(stderr, "[h8s compute wave, ticks/tile] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", c[0] / it, c[1] / it, c[2] / it, c[3] / it);
+        for (int w = 0; w < kH8sCW; w++) {                      // per compute wave: do the waves that share a SIMD with a memory wave run behind?
+          double cw[4] = {0, 0, 0, 0};
+          for (int b = 0; b < grid_s; b++)
+            for (int i = 0; i < 4; i++) cw[i] += (double)h[((size_t)b * (kH8sCW + 2) + w) * 8 + i];
+          fprintf(stderr, "[h8s compute wave %d] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", w, cw[0] / it, cw[1] / it, cw[2] / it, cw[3] / it);
+        }
         fprintf(stderr, "[h8s memory wave 4, ticks/tile] fix edges %.0f | wait A %.0f | dma window b %.0f | - %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
                 m[0] / it, m[1] / it, m[2] / it, m[3] / it, m[4] / it, m[5] / it, m[6] / it);
         fprintf(stderr, "[h8s memory wave 5, ticks/tile] fix edges %.0f | wait A %.0f | dma window b %.0f | read + dma l2 + store %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
