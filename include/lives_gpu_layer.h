@@ -45,8 +45,6 @@ typedef struct {
   weed_leaf_delete_f leaf_delete;
   void *(*pixel_alloc)(size_t bytes);     /* frame allocator (LiVES: lives_calloc_safety); NULL -> calloc */
   void (*pixel_free)(void *);             /* LiVES: lives_free; NULL -> free */
-  weed_leaf_get_flags_f leaf_get_flags;   /* optional (may be NULL): lets calc_rowstrides honour rowstrides flagged LIVES_FLAG_CONST_VALUE
-                                             (decoder plugins with fixed strides, src/colourspace.c:11268-11275, :11358-11363) */
 } lives_gpu_weed_api;
 
 /* prefs the reference reads on this path (src/preferences.h: apply_gamma, alpha_post, pb_quality, screen_gamma) */
@@ -60,6 +58,9 @@ typedef struct {
 
 int lives_gpu_bind_weed(const lives_gpu_weed_api *api);
 int lives_gpu_set_prefs(const lives_gpu_prefs *prefs);
+/* optional: weed_leaf_get_flags lets calc_rowstrides / create_empty_pixel_data honour rowstrides flagged LIVES_FLAG_CONST_VALUE (decoder plugins
+   with fixed strides, src/colourspace.c:11268-11275, :11358-11363); a separate call so that lives_gpu_weed_api keeps its layout */
+int lives_gpu_bind_leaf_get_flags(weed_leaf_get_flags_f leaf_get_flags);
 
 lives_gpu_boolean lives_gpu_convert_layer_palette(lives_gpu_layer_t *layer, int outpl, int op_clamping);
 lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,

@@ -20,7 +20,8 @@
 
 namespace {
 
-lives_gpu_weed_api g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+lives_gpu_weed_api g_api = {};
+weed_leaf_get_flags_f g_leaf_get_flags = nullptr;      // optional, lives_gpu_bind_leaf_get_flags
 lives_gpu_prefs g_prefs = {1, 0, 2, 1.4, 0};
 
 constexpr const char *kLeafHostFlags = "host_flags";          // LIVES_LEAF_HOST_FLAGS (src/colourspace.h:37)
@@ -123,7 +124,7 @@ void apply_const_rowstrides(weed_plant_t *layer, int n, int *rs) {
   if (!layer || !bound()) return;
   const char *key = nullptr;
   if (has_leaf(layer, "new_rowstrides")) key = WEED_LEAF_ROWSTRIDES;        // the reference reads the rowstrides leaf in both cases (:11269, :11273)
-  else if (g_api.leaf_get_flags && has_leaf(layer, WEED_LEAF_ROWSTRIDES) && (g_api.leaf_get_flags(layer, WEED_LEAF_ROWSTRIDES) & (1 << 16))) key = WEED_LEAF_ROWSTRIDES;
+  else if (g_leaf_get_flags && has_leaf(layer, WEED_LEAF_ROWSTRIDES) && (g_leaf_get_flags(layer, WEED_LEAF_ROWSTRIDES) & (1 << 16))) key = WEED_LEAF_ROWSTRIDES;
   if (!key) return;
   const int have = (int)g_api.leaf_num_elements(layer, key);
   for (int i = 0; i < n && i < have; i++) {
@@ -328,6 +329,11 @@ extern "C" {
 int lives_gpu_bind_weed(const lives_gpu_weed_api *api) {
   if (!api || !api->leaf_get || !api->leaf_set || !api->leaf_num_elements || !api->leaf_delete) return LGPU_E_BADARG;
   g_api = *api;
+  return LGPU_OK;
+}
+
+int lives_gpu_bind_leaf_get_flags(weed_leaf_get_flags_f leaf_get_flags) {
+  g_leaf_get_flags = leaf_get_flags;
   return LGPU_OK;
 }
 

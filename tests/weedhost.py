@@ -42,14 +42,16 @@ def weed():
 
 
 class WeedApi(ctypes.Structure):
-    _fields_ = [("leaf_get", vp), ("leaf_set", vp), ("leaf_num_elements", vp), ("leaf_delete", vp), ("pixel_alloc", vp), ("pixel_free", vp), ("leaf_get_flags", vp)]
+    _fields_ = [("leaf_get", vp), ("leaf_set", vp), ("leaf_num_elements", vp), ("leaf_delete", vp), ("pixel_alloc", vp), ("pixel_free", vp)]
 
 
 def bind(L):
     W = weed()
-    api = WeedApi(W.fn["weed_leaf_get"], W.fn["weed_leaf_set"], W.fn["weed_leaf_num_elements"], W.fn["weed_leaf_delete"], None, None, W.fn["weed_leaf_get_flags"])
+    api = WeedApi(W.fn["weed_leaf_get"], W.fn["weed_leaf_set"], W.fn["weed_leaf_num_elements"], W.fn["weed_leaf_delete"], None, None)
     L.lives_gpu_bind_weed.argtypes = [ctypes.POINTER(WeedApi)]
     assert L.lives_gpu_bind_weed(ctypes.byref(api)) == 0
+    L.lives_gpu_bind_leaf_get_flags.argtypes = [vp]
+    assert L.lives_gpu_bind_leaf_get_flags(W.fn["weed_leaf_get_flags"]) == 0
     for name, args in (("lives_gpu_convert_layer_palette", [vp, ci, ci]), ("lives_gpu_convert_layer_palette_full", [vp, ci, ci, ci, ci, ci]),
                        ("lives_gpu_gamma_convert_layer", [ci, vp]), ("lives_gpu_gamma_convert_sub_layer", [ci, ctypes.c_double, vp, ci, ci, ci, ci, ci]),
                        ("lives_gpu_alpha_premult", [vp, ci]), ("lives_gpu_resize_layer", [vp, ci, ci, ci, ci, ci]),
