@@ -34,6 +34,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.lgpu_abi_version() == 1
 
 
+def test_layer_seam_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "lives_gpu_layer.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(lives_gpu_[a-z0-9_]+)\s*\(", text)))
+    assert len(syms) >= 15
+    L = lib.load()
+    for s in syms:
+        assert hasattr(L, s), "include/lives_gpu_layer.h declares %s but liblivesgpu.so does not export it" % s
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
