@@ -99,11 +99,41 @@ std::unordered_map<const void *, ResEntry> g_res;
 unsigned long long g_h2d = 0, g_d2h = 0;        // PCIe byte counters (tests check the residency contract with them)
 thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
 
+// device buffers of dropped planes are recycled (hipMalloc / hipFree cost ~0.1 ms each and synchronise the device): a pinned layer going
+// through a chain of seam calls allocates a new plane per call.  Callers hold g_res_mu.  A pooled buffer is only handed out again to work that is
+// enqueued after the work that last used it (everything here runs on the null stream of the calling thread's device), so stream order protects it.
+struct PoolEntry { void *d; size_t cap; };
+std::vector<PoolEntry> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolMaxBytes = 1u << 30, kPoolMaxEntries = 32;
+void *pool_take(size_t n, size_t *cap_out) {
+  int best = -1;
+  for (int i = 0; i < (int)g_pool.size(); i++)
+    if (g_pool[i].cap >= n && g_pool[i].cap <= 2 * n + (1u << 20) && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+  if (best >= 0) {
+    void *d = g_pool[best].d;
+    *cap_out = g_pool[best].cap;
+    g_pool_bytes -= g_pool[best].cap;
+    g_pool.erase(g_pool.begin() + best);
+    return d;
+  }
+  void *d = nullptr;
+  if (lgpu_malloc(&d, n + 64) != LGPU_OK) return nullptr;
+  *cap_out = n;
+  return d;
+}
+void pool_give(void *d, size_t cap) {
+  if (!d) return;
+  if (g_pool.size() >= kPoolMaxEntries || g_pool_bytes + cap > kPoolMaxBytes) { lgpu_free(d); return; }
+  g_pool.push_back({d, cap});
+  g_pool_bytes += cap;
+}
+
 void res_drop(const void *h) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   auto it = g_res.find(h);
   if (it == g_res.end()) return;
-  lgpu_free(it->second.d);
+  pool_give(it->second.d, it->second.bytes);
   g_res.erase(it);
 }
 struct PinScope {
@@ -202,10 +232,12 @@ bool down(uint8_t *h, const uint8_t *d, size_t n) {
     std::lock_guard<std::mutex> lk(g_res_mu);
     ResEntry &e = g_res[h];
     if (e.bytes < n) {
-      if (e.d) lgpu_free(e.d);
+      pool_give(e.d, e.bytes);
       e.d = nullptr; e.bytes = 0;
-      if (lgpu_malloc(&e.d, n + 64) != LGPU_OK) { g_res.erase(h); return false; }
-      e.bytes = n;
+      size_t cap = 0;
+      e.d = pool_take(n, &cap);
+      if (!e.d) { g_res.erase(h); return false; }
+      e.bytes = cap;
     }
     return lgpu_copy(e.d, d, n, nullptr) == LGPU_OK;
   }
@@ -687,13 +719,19 @@ int lives_gpu_layer_pin(lives_gpu_layer_t *layer) {
   for (int p = 0; p < l.nplanes; p++) {
     const size_t n = plane_bytes(l, p);
     void *d = nullptr;
-    if (lgpu_malloc(&d, n + 64) != LGPU_OK) { for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_NOMEM; }
+    size_t cap = 0;
+    { std::lock_guard<std::mutex> lk(g_res_mu); d = pool_take(n, &cap); }
+    if (!d) { for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_NOMEM; }
     g_h2d += n;
-    if (lgpu_upload(d, l.pd[p], n, nullptr) != LGPU_OK) { lgpu_free(d); for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_HIP; }
+    if (lgpu_upload(d, l.pd[p], n, nullptr) != LGPU_OK) {
+      { std::lock_guard<std::mutex> lk(g_res_mu); pool_give(d, cap); }
+      for (int q = 0; q < p; q++) res_drop(l.pd[q]);
+      return LGPU_E_HIP;
+    }
     std::lock_guard<std::mutex> lk(g_res_mu);
     ResEntry &e = g_res[l.pd[p]];
-    if (e.d) lgpu_free(e.d);
-    e.d = d; e.bytes = n;
+    pool_give(e.d, e.bytes);
+    e.d = d; e.bytes = cap;
   }
   if (!sync()) return LGPU_E_HIP;
   set_int(layer, kLeafResident, 1);

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""tools/bench_seam.py -- the weed_layer_t seam on one 1080p frame: YUV420P -> RGBA32 -> gamma -> resize 0.5x -> letterbox, unpinned (every call
+crosses PCIe twice) and pinned (lives_gpu_layer_pin: one upload, one download).  Wall-clock per frame on the host, PCIe bytes from the seam's counters.
+Needs oracle/_ref/libweedall.so (the reference's libweed, built by oracle/ref/build_ref.sh) for genuine weed plants."""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from lives_amd import lib
+    from tests import weedhost as wh
+    L = lib.load()
+    wh.bind(L)
+    assert L.lgpu_init(0) == 0
+    rng = np.random.default_rng(5)
+    w, h = 1920, 1080
+    Y = rng.integers(16, 236, (h, w), dtype=np.uint8)
+    U = rng.integers(16, 241, (h // 2, w // 2), dtype=np.uint8)
+    V = rng.integers(16, 241, (h // 2, w // 2), dtype=np.uint8)
+
+    def stats():
+        a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        L.lives_gpu_transfer_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value + b.value
+
+    def chain(lay):
+        assert L.lives_gpu_convert_layer_palette(lay, 3, 0) == 1
+        assert L.lives_gpu_gamma_convert_layer(1, lay) == 1
+        assert L.lives_gpu_resize_layer(lay, 960, 540, 3, 0, 0) == 1
+        assert L.lives_gpu_letterbox_layer(lay, 960, 600, 960, 540, 3, 0, 0) == 1
+
+    for pinned in (0, 1):
+        n = 30
+        layers = [wh.new_layer(512, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1) for _ in range(n + 3)]
+        for lay in layers[:3]:                      # warm-up
+            if pinned:
+                L.lives_gpu_layer_pin(lay)
+            chain(lay)
+            if pinned:
+                L.lives_gpu_layer_unpin(lay)
+        b0 = stats()
+        t0 = time.perf_counter()
+        for lay in layers[3:]:
+            if pinned:
+                L.lives_gpu_layer_pin(lay)
+            chain(lay)
+            if pinned:
+                L.lives_gpu_layer_unpin(lay)
+        dt = (time.perf_counter() - t0) / n
+        print("%s: %.3f ms per frame (4 seam calls), %.1f MB over PCIe per frame" % ("pinned  " if pinned else "unpinned", dt * 1e3, (stats() - b0) / n / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
