@@ -43,6 +43,10 @@ int lgpu_malloc(void **ptr_d, size_t bytes);
 int lgpu_free(void *ptr_d);
 int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream);
 int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream);
+/* page-locked, zeroed host memory for frames (DMA at link rate); lgpu_upload / lgpu_download also accept pageable memory, which they move through
+   two pinned staging chunks per host thread */
+void *lgpu_pinned_calloc(size_t bytes);
+void lgpu_pinned_free(void *p);
 int lgpu_copy(void *dst_d, const void *src_d, size_t bytes, void *stream);      /* device to device */
 int lgpu_fill(void *dst_d, int byte, size_t bytes, void *stream);
 int lgpu_sync(void *stream);

@@ -83,6 +83,10 @@ int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int
 int lives_gpu_layer_pin(lives_gpu_layer_t *layer);      /* upload the planes once, mark the layer resident */
 int lives_gpu_layer_sync(lives_gpu_layer_t *layer);     /* download the current planes into pixel_data; stays pinned */
 int lives_gpu_layer_unpin(lives_gpu_layer_t *layer);    /* sync, release the device copies, clear the leaf */
+/* optional allocator pair for lives_gpu_weed_api.pixel_alloc / pixel_free: page-locked (hipHostMalloc) zeroed memory, so frames cross PCIe by DMA at
+   link rate; pageable frames still work (they go through pinned staging chunks inside lgpu_upload / lgpu_download) */
+void *lives_gpu_pinned_calloc(size_t bytes);
+void lives_gpu_pinned_free(void *p);
 /* device copy of a pinned layer's plane by its host plane pointer, or NULL (used by livesgpu_fx.so: effects on pinned layers read and write
    HBM directly, no PCIe traffic; the host bytes stay stale until lives_gpu_layer_sync()) */
 void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes);

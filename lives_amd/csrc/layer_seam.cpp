@@ -761,6 +761,11 @@ int lives_gpu_layer_unpin(lives_gpu_layer_t *layer) {
   if (bound() && layer) g_api.leaf_delete(layer, kLeafResident);
   return rc;
 }
+// optional frame allocator pair for lives_gpu_weed_api.pixel_alloc / pixel_free: page-locked, zeroed host memory, so the planes the seam creates
+// (and any frame the host allocates through it) cross PCIe by DMA at link rate instead of through the staging chunks
+void *lives_gpu_pinned_calloc(size_t bytes) { return lgpu_pinned_calloc(bytes); }
+void lives_gpu_pinned_free(void *p) { lgpu_pinned_free(p); }
+
 // residency bridge for the weed plugin (same library, other seam): the device copy of a pinned layer's plane, looked up by the host plane
 // pointer the channel carries; NULL when the plane is not resident (or smaller than asked)
 void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {

@@ -193,6 +193,19 @@ int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream) {
   return LGPU_OK;
 }
 
+void *lgpu_pinned_calloc(size_t bytes) {
+  void *p = nullptr;
+  if (lgpu::ensure_init() != LGPU_OK) return calloc(1, bytes ? bytes : 1);          // no device: plain memory, same contract
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  memset(p, 0, bytes);
+  return p;
+}
+void lgpu_pinned_free(void *p) {
+  if (!p) return;
+  if (host_is_pinned(p)) { (void)hipHostFree(p); return; }
+  free(p);
+}
+
 int lgpu_copy(void *dst_d, const void *src_d, size_t bytes, void *stream) {
   int rc = lgpu::ensure_init();
   if (rc) return rc;

@@ -87,6 +87,8 @@ PROTOTYPES = {
     "lgpu_fx_luts": [ci, ci, cd, cd, cd, vp],
     "lgpu_byte_luts": [vp, ci, vp, ci, ci, ci, ci, vp, vp],
     "lgpu_yuv420p_to_rgb_batch": [ci, vp, vp, ctypes.c_long, ctypes.c_long, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
+    "lgpu_pinned_calloc": [ctypes.c_size_t],
+    "lgpu_pinned_free": [vp],
     "lgpu_deinterlace": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_triple_split": [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, ci, cd, ci, cd, vp, vp],
     "lgpu_dissolve_mask": [ctypes.c_uint64, ci, ci, vp],
@@ -120,6 +122,8 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = ci
+        lib.lgpu_pinned_calloc.restype = vp
+        lib.lgpu_pinned_free.restype = None
         lib.lgpu_last_error.restype = ctypes.c_char_p
         lib.lgpu_last_error.argtypes = []
         _lib = lib

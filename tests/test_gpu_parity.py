@@ -865,3 +865,30 @@ def test_chain_is_graph_capturable(gpu):
         torch.cuda.synchronize()
         for t in range(T):
             assert torch.equal(dsts[t], want[t]), "graph replay differs (blur=%d track %d)" % (blur, t)
+
+
+def test_pinned_allocator_and_pageable_staging(gpu):
+    """lgpu_upload / lgpu_download on pageable memory (staged in two pinned chunks per thread, several chunks long) and on lgpu_pinned_calloc memory
+    (direct DMA) move the same bytes"""
+    import torch
+    from lives_amd.lib import load, call
+    L = load()
+    rng = np.random.default_rng(3600)
+    for n in (1000, 300 * 1024, 9 * 1024 * 1024 + 123):
+        src = rng.integers(0, 256, n, dtype=np.uint8)
+        d = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        call("lgpu_upload", d.data_ptr(), src.ctypes.data, n, None)
+        back = np.zeros(n, np.uint8)
+        call("lgpu_download", back.ctypes.data, d.data_ptr(), n, None)
+        call("lgpu_sync", None)
+        assert (back == src).all() and (d.cpu().numpy() == src).all()
+        p = L.lgpu_pinned_calloc(n)
+        assert p
+        buf = np.frombuffer((ctypes.c_uint8 * n).from_address(p), np.uint8)
+        assert not buf.any()
+        buf[:] = src[::-1]
+        call("lgpu_upload", d.data_ptr(), p, n, None)
+        call("lgpu_sync", None)
+        assert (d.cpu().numpy() == src[::-1]).all()
+        del buf
+        L.lgpu_pinned_free(p)
