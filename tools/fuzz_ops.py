@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -281,6 +281,88 @@ def main():
                 d = dev(sfr)
                 ops.alpha_premult(d, w, h, alpha_first=af, un=un)
                 ok = same(host(d), want, w * 4, h, "premult %dx%d af=%d un=%d" % (w, h, af, un))
+            elif kind == "luma":
+                pal = int(rng.integers(1, 5))
+                ps, order = (3 if pal <= 2 else 4), (0 if pal in (1, 3) else 1)
+                k2, thr, inplace = int(rng.integers(1, 5)), int(rng.integers(0, 256)), int(rng.integers(0, 2))
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                s1, s2 = fr(w, h, ps), fr(w, h, ps)
+                init = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                want = init.copy()
+                orc.orc_blend_luma(k2, P(want if inplace else s1), s1.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, ps, order, thr, inplace)
+                d1 = dev(s1)
+                d = d1 if inplace else dev(init)
+                ops.blend_luma(k2, d1, dev(s2), d, w, h, ps, order, thr)
+                ok = same(host(d), want, w * ps, h, "blend_luma kind=%d pal=%d %dx%d thr=%d inplace=%d" % (k2, pal, w, h, thr, inplace))
+            elif kind == "multi":
+                k2, is_bgr, bf = int(rng.integers(0, 7)), int(rng.integers(0, 2)), int(rng.integers(0, 256))
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                s1, s2 = fr(w, h, 3), fr(w, h, 3)
+                want = np.full_like(s1, 0x5A)
+                orc.orc_blend_multi(k2, P(s1), s1.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, is_bgr, bf)
+                d = dev(np.full_like(s1, 0x5A))
+                ops.blend_multi(k2, dev(s1), dev(s2), d, w, h, is_bgr, bf)
+                ok = same(host(d), want, w * 3, h, "blend_multi kind=%d bgr=%d bf=%d %dx%d" % (k2, is_bgr, bf, w, h))
+            elif kind == "colorkey":
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                is_bgr, delta, opac = int(rng.integers(0, 2)), float(rng.random()), float(rng.random())
+                col = [int(v) for v in rng.integers(0, 256, 3)]
+                s0, s1 = fr(w, h, 3), fr(w, h, 3)
+                s1[:, :w * 3] = np.where(rng.random((h, w * 3)) < 0.5, np.tile(np.array(col, np.uint8), w)[None, :], s1[:, :w * 3])
+                want = np.full_like(s0, 0x5A)
+                orc.orc_colorkey(P(s0), s0.strides[0], P(s1), s1.strides[0], P(want), want.strides[0], w, h, is_bgr, delta, opac, col[0], col[1], col[2], 0)
+                d = dev(np.full_like(s0, 0x5A))
+                ops.colorkey(dev(s0), dev(s1), d, w, h, is_bgr, delta, opac, col)
+                ok = same(host(d), want, w * 3, h, "colorkey %dx%d bgr=%d delta=%r opac=%r col=%s" % (w, h, is_bgr, delta, opac, col))
+            elif kind == "gamma":
+                ps = int(rng.choice([3, 4]))
+                w, h = int(rng.integers(2, 300)), int(rng.integers(2, 100))
+                x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
+                rw, rh = int(rng.integers(1, w - x + 1)), int(rng.integers(1, h - y + 1))
+                af = int(rng.integers(0, 2)) if ps == 4 else 0
+                lut = rng.integers(0, 256, 256, dtype=np.uint8)
+                pix = fr(w, h, ps)
+                want = pix.copy()
+                orc.orc_gamma_apply(ctypes.c_void_p(want.ctypes.data + y * want.strides[0] + x * ps), want.strides[0], rw, rh, ps, af, P(lut))
+                d = dev(pix)
+                ops.gamma_apply(d, rw, rh, ps, lut, alpha_first=af, x=x, y=y)
+                ok = same(host(d), want, want.shape[1], h, "gamma %dx%d ps=%d sub=(%d,%d,%d,%d) af=%d stride=%d" % (w, h, ps, x, y, rw, rh, af, pix.strides[0]))
+            elif kind == "bytelut":
+                ps = int(rng.choice([3, 4]))
+                w, h = int(rng.integers(1, 400)), int(rng.integers(1, 80))
+                luts = rng.integers(0, 256, (ps, 256), dtype=np.uint8)
+                inplace = int(rng.integers(0, 2))
+                sfr = fr(w, h, ps)
+                want = sfr.copy() if inplace else np.full_like(sfr, 0x5A)
+                a = want if inplace else sfr
+                orc.orc_byte_luts(P(a), a.strides[0], P(want), want.strides[0], w, h, ps, luts.ctypes.data)
+                ds = dev(sfr)
+                d = ds if inplace else dev(np.full_like(sfr, 0x5A))
+                ops.byte_luts(ds, d, w, h, ps, luts)
+                ok = same(host(d), want, want.shape[1], h, "byte_luts ps=%d %dx%d inplace=%d stride=%d" % (ps, w, h, inplace, sfr.strides[0]))
+            elif kind == "slide":
+                ps = int(rng.choice([3, 4]))
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                tv, dirn, mvl, mvu = int(rng.integers(0, 256)), int(rng.integers(1, 5)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                s1, s2 = fr(w, h, ps), fr(w, h, ps)
+                want = np.full_like(s1, 0x5A)
+                orc.orc_slide_over(P(s1), s1.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, ps, tv, dirn, mvl, mvu)
+                d = dev(np.full_like(s1, 0x5A))
+                ops.slide_over(dev(s1), dev(s2), d, w, h, ps, tv, dirn, mvl, mvu)
+                ok = same(host(d), want, w * ps, h, "slide ps=%d %dx%d amount=%d dir=%d lower=%d upper=%d" % (ps, w, h, tv, dirn, mvl, mvu))
+            elif kind == "tsplit":
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                start, end, bw = float(rng.random()), float(rng.random()), float(rng.random() * 0.5 * (rng.random() < 0.7))
+                sym, vert, is_bgr, inplace = (int(v) for v in rng.integers(0, 2, 4))
+                bc = np.array(rng.integers(0, 256, 3), np.int32)
+                s1, s2 = fr(w, h, 3), fr(w, h, 3)
+                want = s1.copy() if inplace else np.full_like(s1, 0x5A)
+                a = want if inplace else s1
+                orc.orc_triple_split(P(a), a.strides[0], P(s2), s2.strides[0], P(want), want.strides[0], w, h, is_bgr, start, sym, end, vert, bw, bc.ctypes.data)
+                d1 = dev(s1)
+                d = d1 if inplace else dev(np.full_like(s1, 0x5A))
+                ops.triple_split(d1, dev(s2), d, w, h, is_bgr, start, sym, end, vert, bw, bc)
+                ok = same(host(d), want, w * 3, h, "tsplit %dx%d %r sym=%d %r vert=%d bw=%r bgr=%d inplace=%d" % (w, h, start, sym, end, vert, bw, is_bgr, inplace))
             elif kind == "mirror":
                 ps, mode = int(rng.choice([3, 4])), int(rng.integers(0, 3))
                 w, h = int(rng.integers(1, 300)), int(rng.integers(1, 120))
