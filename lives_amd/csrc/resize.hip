@@ -964,6 +964,7 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
   }
   if (wave >= kH8sCW) {
     // ------------------------------------------------ memory waves ------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);     // few instructions, all of them feeding the DMA queues: let them issue ahead of the compute waves (-0.8 % per launch)
     // Wave 4 fetches window DMA instructions 0..10, wave 5 fetches 11..20 and also moves the layer-2 / result tiles.
     // Window n+2 goes to slot n & 1, free after B(n) and needed at A(n+2); each wave issues the first part of its
     // share between B(n) and A(n+1) and the rest between A(n+1) and B(n+1), so both barrier intervals carry traffic:
