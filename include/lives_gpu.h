@@ -86,6 +86,13 @@ int lgpu_gamma_apply(uint8_t *pix_d, int rowstride, int x, int y, int width, int
 int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int height, int alpha_first, int un,
                        void *stream);
 
+/* K9b: alpha_premult on YUVA8888 (589, planes_d[0]) / YUVA4444P (545, four planes), in place (src/colourspace.c:11995-12096).  clamped = the layer's
+   YUV_clamping is CLAMPED: the reference then goes through the tables unalcy / alcy / unalcuv / alcuv of init_unal (:1141-1160; lgpu_premult_yuv_tables
+   builds them on the host, each [256 alpha][256 value]); unclamped layers take the RGB arithmetic on Y, U and V. */
+int lgpu_premult_yuv_tables(uint8_t *unalcy, uint8_t *alcy, uint8_t *unalcuv, uint8_t *alcuv);
+int lgpu_alpha_premult_yuva(uint8_t *const planes_d[4], const int rowstrides[4], int width, int height, int palette, int clamped, int un,
+                            void *stream);
+
 /* ---- K2: planar YUV 4:2:0 / 4:2:2 -> packed RGB; replaces convert_yuv420p_to_rgb_frame
    (src/colourspace.c:3260-3904; the BGR / ARGB twins :3927-5114 share the maths).
    out_order 0 = RGB(A), 1 = BGR(A), 2 = ARGB; opsize 3 or 4; which_tables as lgpu_conversion_tables;

@@ -306,3 +306,20 @@ extern "C" int lgpu_dissolve_mask(uint64_t seed, int width, int height, float *m
   }
   return 1;
 }
+
+/* init_unal (src/colourspace.c:1141-1160), the four tables alpha_premult uses on CLAMPED YUVA layers, as the bytes its loops store:
+   out = unalcy, alcy, unalcuv, alcuv, each [256 alpha][256 value].  Float arithmetic as in the reference (built without -ffast-math). */
+extern "C" int lgpu_premult_yuv_tables(uint8_t *unalcy, uint8_t *alcy, uint8_t *unalcuv, uint8_t *alcuv) {
+  if (!unalcy || !alcy || !unalcuv || !alcuv) return 0;
+  auto c255f = [](double a) -> int { return a >= 254.5 ? 255 : a < -0.5 ? 0 : (uint8_t)(a + .5); };
+  for (int i = 0; i < 256; i++) {
+    const float alpha = (float)255. / (float)i;
+    for (int j = 0; j < 256; j++) {
+      unalcuv[i * 256 + j] = (uint8_t)c255f((float)(j - 16.) * alpha + 16.);
+      alcuv[i * 256 + j] = (uint8_t)c255f((float)(j - 128.) * alpha + 128.);
+      unalcy[i * 256 + j] = (uint8_t)((int)((float)j / alpha + .5) > (235. - 16.) ? (int)235. : (int)((float)(j - 16.) / alpha + 16. + .5));
+      alcy[i * 256 + j] = (uint8_t)((int)((float)j / alpha + .5) > (240. - 16.) ? (int)240. : (int)((float)(j - 16.) / alpha + 16. + .5));
+    }
+  }
+  return 1;
+}

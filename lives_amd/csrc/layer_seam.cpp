@@ -605,11 +605,29 @@ void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction) {
   PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l) || !pal_has_alpha(l.pal)) return;
-  const size_t bytes = (size_t)l.rs[0] * l.height;
-  uint8_t *d = t_scr.get(0, bytes);
-  const bool ok = d && up(d, l.pd[0], bytes) &&
-                  lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK &&
-                  down(l.pd[0], d, bytes) && sync();
+  bool ok = true;
+  if (l.pal == WEED_PALETTE_YUVA8888 || l.pal == WEED_PALETTE_YUVA4444P) {
+    // :11982, :12005-12047, :12063-12096: clamped layers go through the alcy / alcuv / unalcy / unalcuv tables, unclamped ones through al / unal
+    const int clamped = (l.clamping < 0 || l.clamping == WEED_YUV_CLAMPING_CLAMPED) ? 1 : 0;      // weed_layer_get_yuv_clamping(): CLAMPED (0) when the leaf is missing
+    uint8_t *dp[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rs[4] = {0, 0, 0, 0};
+    size_t nb[4] = {0, 0, 0, 0};
+    for (int p = 0; p < l.nplanes && ok; p++) {
+      nb[p] = (size_t)l.rs[p] * l.height;
+      dp[p] = t_scr.get(p == 3 ? 7 : p, nb[p]);
+      rs[p] = l.rs[p];
+      ok = dp[p] && up(dp[p], l.pd[p], nb[p]);
+    }
+    ok = ok && lgpu_alpha_premult_yuva(dp, rs, l.width, l.height, l.pal, clamped, direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK;
+    for (int p = 0; p < 3 && p < l.nplanes && ok; p++) ok = down(l.pd[p], dp[p], nb[p]);           // the alpha plane is only read
+    ok = ok && sync();
+  } else {
+    const size_t bytes = (size_t)l.rs[0] * l.height;
+    uint8_t *d = t_scr.get(0, bytes);
+    ok = d && up(d, l.pd[0], bytes) &&
+         lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK &&
+         down(l.pd[0], d, bytes) && sync();
+  }
   if (!ok) return;
   int flags = l.flags;
   if (direction == LIVES_DIRECTION_FORWARD) flags |= LIVES_LAYER_ALPHA_PREMULT; else flags &= ~LIVES_LAYER_ALPHA_PREMULT;   // :12098-12102

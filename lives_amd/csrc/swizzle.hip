@@ -5,6 +5,9 @@
 // contiguous global accesses; byte shuffles are v_perm_b32; the 256-byte gamma LUT rides in the
 // kernarg segment and is staged to LDS once per workgroup.
 #include "lgpu_common.h"
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace lgpu {
 
@@ -214,6 +217,56 @@ __global__ __launch_bounds__(kBlock) void k_byte_luts(const uint8_t *src, int ir
   }
 }
 
+// --- K9b: alpha_premult on YUVA8888 / YUVA4444P (src/colourspace.c:11995-12096) ------------------------------------------------
+// unclamped: the RGB arithmetic on Y, U and V; clamped: the four tables of init_unal (256 KB, device resident, L2-served)
+struct PremultYuvaArgs {
+  uint8_t *p[4];
+  int rs[4];
+  int width, height, planar, clamped, un, dword;
+  const uint8_t *cy, *cuv;       // unalcy / alcy and unalcuv / alcuv for the direction
+};
+__global__ __launch_bounds__(kBlock) void k_premult_yuva(PremultYuvaArgs a) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= a.width) return;
+  for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
+    uint8_t *py, *pu, *pv;
+    uint32_t al;
+    if (a.planar) {
+      py = a.p[0] + (size_t)i * a.rs[0] + x; pu = a.p[1] + (size_t)i * a.rs[1] + x; pv = a.p[2] + (size_t)i * a.rs[2] + x;
+      al = a.p[3][(size_t)i * a.rs[3] + x];
+    } else {
+      py = a.p[0] + (size_t)i * a.rs[0] + 4 * (size_t)x; pu = py + 1; pv = py + 2;
+      if (a.dword) {                                    // 4-byte aligned rows: one dword in, one dword out
+        const uint32_t px = *(const uint32_t *)py;
+        const uint32_t y = px & 255u, u = (px >> 8) & 255u, v = (px >> 16) & 255u;
+        al = px >> 24;
+        uint32_t ny, nu, nv;
+        if (!a.clamped) {
+          const float ratio = __fdiv_rn(255.f, (float)al);
+          ny = premult_byte(y, ratio, a.un); nu = premult_byte(u, ratio, a.un); nv = premult_byte(v, ratio, a.un);
+        } else {
+          ny = a.cy[al * 256 + y];
+          if (a.un) { nu = a.cuv[al * 256 + u]; nv = a.cuv[al * 256 + v]; }
+          else nu = nv = a.cuv[al * 256 + ny];          // the packed FORWARD loop indexes with the Y byte it has just written (:12089-12091)
+        }
+        *(uint32_t *)py = (ny & 255u) | ((nu & 255u) << 8) | ((nv & 255u) << 16) | (px & 0xff000000u);
+        continue;
+      }
+      al = py[3];
+    }
+    const uint32_t y = *py, u = *pu, v = *pv;
+    if (!a.clamped) {
+      const float ratio = __fdiv_rn(255.f, (float)al);
+      *py = (uint8_t)premult_byte(y, ratio, a.un); *pu = (uint8_t)premult_byte(u, ratio, a.un); *pv = (uint8_t)premult_byte(v, ratio, a.un);
+    } else {
+      const uint32_t ny = a.cy[al * 256 + y];
+      *py = (uint8_t)ny;
+      if (a.planar || a.un) { *pu = a.cuv[al * 256 + u]; *pv = a.cuv[al * 256 + v]; }
+      else { const uint8_t c = a.cuv[al * 256 + ny]; *pu = c; *pv = c; }        // the packed FORWARD loop indexes with the Y byte it has just written (:12089-12091)
+    }
+  }
+}
+
 static inline dim3 row_grid(unsigned items_per_row, int height) {
   unsigned gy = (unsigned)height;
   if (gy > 4096) gy = 4096;
@@ -307,6 +360,47 @@ extern "C" int lgpu_byte_luts(const uint8_t *src_d, int irow, uint8_t *dst_d, in
   const dim3 grid = row_grid((unsigned)((width + 3) / 4), height);
   if (psize == 4) hipLaunchKernelGGL(k_byte_luts<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, l);
   else hipLaunchKernelGGL(k_byte_luts<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, l);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_alpha_premult_yuva(uint8_t *const planes_d[4], const int rowstrides[4], int width, int height, int palette, int clamped, int un,
+                                       void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(planes_d && rowstrides && planes_d[0] && width > 0 && height > 0, "null planes or empty geometry");
+  LGPU_REQUIRE(palette == 589 || palette == 545, "palette must be YUVA8888 (589) or YUVA4444P (545)");
+  PremultYuvaArgs a = {};
+  a.planar = (palette == 545);
+  for (int i = 0; i < (a.planar ? 4 : 1); i++) {
+    LGPU_REQUIRE(planes_d[i] && rowstrides[i] >= width * (a.planar ? 1 : 4), "null plane or rowstride smaller than a row");
+    a.p[i] = planes_d[i]; a.rs[i] = rowstrides[i];
+  }
+  a.width = width; a.height = height; a.clamped = clamped ? 1 : 0; a.un = un ? 1 : 0;
+  a.dword = (!a.planar && (((uintptr_t)planes_d[0] | (uintptr_t)rowstrides[0]) & 3) == 0) ? 1 : 0;
+  if (a.clamped) {
+    // the four tables, built once on the host (reference arithmetic) and kept on the device
+    static std::mutex mu;
+    static std::map<int, uint8_t *> tabs;
+    int dev = 0;
+    LGPU_HIP(hipGetDevice(&dev));
+    uint8_t *t;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = tabs.find(dev);
+      if (it == tabs.end()) {
+        std::vector<uint8_t> h(4 * 65536);
+        if (!lgpu_premult_yuv_tables(h.data(), h.data() + 65536, h.data() + 2 * 65536, h.data() + 3 * 65536)) return LGPU_E_BADARG;
+        uint8_t *d = nullptr;
+        if (hipMalloc((void **)&d, h.size()) != hipSuccess) { set_error("hipMalloc of the premultiply tables failed"); return LGPU_E_NOMEM; }
+        LGPU_HIP(hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
+        it = tabs.emplace(dev, d).first;
+      }
+      t = it->second;
+    }
+    a.cy = t + (a.un ? 0 : 65536); a.cuv = t + (a.un ? 2 * 65536 : 3 * 65536);
+  }
+  hipLaunchKernelGGL(k_premult_yuva, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -89,6 +89,8 @@ PROTOTYPES = {
     "lgpu_yuv420p_to_rgb_batch": [ci, vp, vp, ctypes.c_long, ctypes.c_long, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_pinned_calloc": [ctypes.c_size_t],
     "lgpu_pinned_free": [vp],
+    "lgpu_premult_yuv_tables": [vp, vp, vp, vp],
+    "lgpu_alpha_premult_yuva": [vp, vp, ci, ci, ci, ci, ci, vp],
     "lgpu_deinterlace": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_triple_split": [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, ci, cd, ci, cd, vp, vp],
     "lgpu_dissolve_mask": [ctypes.c_uint64, ci, ci, vp],

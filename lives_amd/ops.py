@@ -50,6 +50,12 @@ def alpha_premult(pix, width, height, alpha_first=0, un=0):
     lib.call("lgpu_alpha_premult", dptr(pix), pix.stride(0), width, height, alpha_first, un, stream_ptr())
 
 
+def alpha_premult_yuva(planes, width, height, palette, clamped, un=0):
+    """K9b: YUVA8888 (589, one packed plane) / YUVA4444P (545, four planes), in place"""
+    pp, ss = _plane_tables(planes)
+    lib.call("lgpu_alpha_premult_yuva", ctypes.addressof(pp), ctypes.addressof(ss), width, height, palette, int(bool(clamped)), int(bool(un)), stream_ptr())
+
+
 def yuv420p_to_rgb(y, u, v, dst, width, height, opsize=4, out_order=0, is_422=0, which_tables=0, pb_quality=2, lut=None,
                    flags=0, u_size=None, v_size=None):
     strides = (ctypes.c_int * 3)(y.stride(0), u.stride(0), v.stride(0))

@@ -1851,3 +1851,54 @@ void orc_dissolve(const uint8_t *src1, int irow1, const uint8_t *src2, int irow2
       else if (!inplace) memcpy(dst + (size_t)i * orow + j, src1 + (size_t)i * irow1 + j, (size_t)psize);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * K9b: alpha_premult for YUVA8888 / YUVA4444P            reference: src/colourspace.c:11995-12096, tables init_unal :1141-1160
+ * Unclamped layers use the RGB tables al / unal on Y, U and V alike.  Clamped layers use alcy / alcuv (FORWARD) and unalcy / unalcuv
+ * (REVERSE): note alcy tests against the UV range and both "clamped Y" tables DIVIDE by 255 / alpha in either direction; the packed
+ * FORWARD loop (:12086-12092) indexes alcuv with the Y byte it has just written, for U and V alike.  All of it is kept.
+ * ---------------------------------------------------------------------------------------------- */
+static int k9b_c255f(double a) { return a >= 254.5 ? 255 : a < -0.5 ? 0 : (uint8_t)(a + .5); }      /* CLAMP0255f, src/maths.h:88 */
+void orc_premult_yuv_tables(uint8_t *unalcy, uint8_t *alcy, uint8_t *unalcuv, uint8_t *alcuv) {   /* each [256][256], stored as bytes the way the loops store them */
+  for (int i = 0; i < 256; i++) {
+    const float alpha = (float)255. / (float)i;
+    for (int j = 0; j < 256; j++) {
+      const int t_unalcuv = k9b_c255f((float)(j - 16.) * alpha + 16.);
+      const int t_alcuv = k9b_c255f((float)(j - 128.) * alpha + 128.);
+      const int t_unalcy = (int)((float)j / alpha + .5) > (235. - 16.) ? (int)235. : (int)((float)(j - 16.) / alpha + 16. + .5);
+      const int t_alcy = (int)((float)j / alpha + .5) > (240. - 16.) ? (int)240. : (int)((float)(j - 16.) / alpha + 16. + .5);
+      unalcuv[i * 256 + j] = (uint8_t)t_unalcuv; alcuv[i * 256 + j] = (uint8_t)t_alcuv;
+      unalcy[i * 256 + j] = (uint8_t)t_unalcy; alcy[i * 256 + j] = (uint8_t)t_alcy;
+    }
+  }
+}
+/* palette 589 YUVA8888 (planes[0] packed) or 545 YUVA4444P (four planes); clamped = the layer's YUV_clamping is CLAMPED; un = REVERSE */
+int orc_alpha_premult_yuva(uint8_t *const planes[4], const int rows[4], int width, int height, int palette, int clamped, int un) {
+  static uint8_t t[4][65536];
+  static int ready = 0;
+  if (!ready) { orc_premult_yuv_tables(t[0], t[1], t[2], t[3]); ready = 1; }
+  const uint8_t *cy = un ? t[0] : t[1], *cuv = un ? t[2] : t[3];
+  if (palette == 589) {
+    for (int i = 0; i < height; i++) {
+      uint8_t *p = planes[0] + (size_t)i * rows[0];
+      for (int j = 0; j < width * 4; j += 4) {
+        const int a = p[j + 3];
+        if (!clamped) { for (int c = 0; c < 3; c++) p[j + c] = (uint8_t)(un ? orc_unal(a, p[j + c]) : orc_al(a, p[j + c])); }
+        else if (un) { p[j] = cy[a * 256 + p[j]]; p[j + 1] = cuv[a * 256 + p[j + 1]]; p[j + 2] = cuv[a * 256 + p[j + 2]]; }
+        else { p[j] = cy[a * 256 + p[j]]; p[j + 1] = cuv[a * 256 + p[j]]; p[j + 2] = cuv[a * 256 + p[j]]; }     /* :12089-12091 */
+      }
+    }
+    return 0;
+  }
+  if (palette == 545) {
+    for (int i = 0; i < height; i++)
+      for (int j = 0; j < width; j++) {
+        const int a = planes[3][(size_t)i * rows[3] + j];
+        uint8_t *y = planes[0] + (size_t)i * rows[0] + j, *u = planes[1] + (size_t)i * rows[1] + j, *v = planes[2] + (size_t)i * rows[2] + j;
+        if (!clamped) { *y = (uint8_t)(un ? orc_unal(a, *y) : orc_al(a, *y)); *u = (uint8_t)(un ? orc_unal(a, *u) : orc_al(a, *u)); *v = (uint8_t)(un ? orc_unal(a, *v) : orc_al(a, *v)); }
+        else { *y = cy[a * 256 + *y]; *u = cuv[a * 256 + *u]; *v = cuv[a * 256 + *v]; }
+      }
+    return 0;
+  }
+  return -1;
+}

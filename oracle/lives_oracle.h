@@ -58,6 +58,9 @@ void orc_gamma_apply(uint8_t *pix, int rowstride, int width, int height, int psi
                      const uint8_t *lut8);
 /* K9: alpha_premult packed RGBA/BGRA (aoffs 3, coffs 0) / ARGB (aoffs 0, coffs 1); un = 1: unal (REVERSE) */
 void orc_alpha_premult(uint8_t *pix, int rowstride, int width, int height, int alpha_first, int un);
+/* K9b: the clamped-YUV premultiply tables of init_unal (:1141-1160) and alpha_premult for YUVA8888 (589) / YUVA4444P (545), :11995-12096 */
+void orc_premult_yuv_tables(uint8_t *unalcy, uint8_t *alcy, uint8_t *unalcuv, uint8_t *alcuv);
+int orc_alpha_premult_yuva(uint8_t *const planes[4], const int rows[4], int width, int height, int palette, int clamped, int un);
 /* K8: letterbox blit into an opaque-black canvas (src/colourspace.c:15343-15567, fill :11109-11119) */
 void orc_letterbox(const uint8_t *src, int irow, int width, int height, uint8_t *dst, int orow,
                    int nwidth, int nheight, int psize, const uint8_t *black_pixel);

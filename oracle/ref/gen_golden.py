@@ -241,6 +241,8 @@ def main():
     gen_golden_rgbdelay.main()
     import gen_golden_scriptfx          # negate / posterise / ccorrect (script-generated plugins)
     gen_golden_scriptfx.main()
+    import gen_golden_premult_yuv       # clamped-YUV premultiply tables
+    gen_golden_premult_yuv.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

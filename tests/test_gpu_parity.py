@@ -114,6 +114,49 @@ def test_alpha_premult_all_pairs(gpu, orc, af, un):
     assert_same(host(d), want, w, h, 4, "premult af=%d un=%d" % (af, un))
 
 
+def test_premult_yuv_tables_match_the_fixture(gpu):
+    from tests import golden_util as gu
+    g = gu.load("premult_yuv.npz")
+    tabs = [np.zeros((256, 256), np.uint8) for _ in range(4)]
+    gpu.lib.call("lgpu_premult_yuv_tables", *[t.ctypes.data for t in tabs])
+    for name, t in zip(("unalcy", "alcy", "unalcuv", "alcuv"), tabs):
+        assert (t == g[name]).all(), name
+
+
+@pytest.mark.parametrize("pal", [589, 545])
+@pytest.mark.parametrize("clamped", [0, 1])
+@pytest.mark.parametrize("un", [0, 1])
+def test_alpha_premult_yuva(gpu, orc, pal, clamped, un):
+    """alpha_premult on YUVA8888 / YUVA4444P (src/colourspace.c:12005-12047, :12063-12096): every (alpha, value) pair in each of Y, U, V,
+    plus a random padded frame"""
+    a = np.arange(256, dtype=np.uint8)
+    rng = np.random.default_rng(pal + 2 * clamped + un)
+    for w, h, pad, sweep in ((256, 256, 0, True), (61, 19, 12, False)):
+        if pal == 589:
+            fr = rng.integers(0, 256, (h, w * 4 + pad), dtype=np.uint8)
+            if sweep:
+                for c in range(3):
+                    fr[:, c:w * 4:4] = a[None, :]
+                fr[:, 3:w * 4:4] = a[:, None]
+            planes = [fr]
+        else:
+            planes = [rng.integers(0, 256, (h, w + pad), dtype=np.uint8) for _ in range(4)]
+            if sweep:
+                for c in range(3):
+                    planes[c][:, :w] = a[None, :]
+                planes[3][:, :w] = a[:, None]
+        want = [p.copy() for p in planes]
+        pp = (ctypes.c_void_p * 4)(*([x.ctypes.data for x in want] + [None] * (4 - len(want))))
+        ss = (ctypes.c_int * 4)(*([x.strides[0] for x in want] + [0] * (4 - len(want))))
+        orc.orc_alpha_premult_yuva(pp, ss, w, h, pal, clamped, un)
+        ds = [dev(p) for p in planes]
+        gpu.alpha_premult_yuva(ds, w, h, pal, clamped, un=un)
+        for i, (d, wt) in enumerate(zip(ds, want)):
+            bw = w * 4 if pal == 589 else w
+            assert_same(host(d), wt, bw, h, 1, "premult yuva pal=%d clamped=%d un=%d plane %d" % (pal, clamped, un, i))
+            assert (host(d)[:, bw:] == planes[i][:, bw:]).all()       # padding untouched
+
+
 # ---------------------------------------------------------------------------------------------- K2
 def k2_mask(w, h, is_422):
     m = np.zeros((h, w), bool)

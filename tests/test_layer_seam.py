@@ -209,6 +209,30 @@ def test_alpha_premult_layer(seam, orc):
         assert wh.geti(lay, "host_flags") == (1 if direction == 1 else 0)
 
 
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("pal", [589, 545])
+def test_alpha_premult_yuva_layer(seam, orc, pal):
+    """YUVA layers: the clamped tables when YUV_clamping is CLAMPED (or missing), al / unal when UNCLAMPED (src/colourspace.c:11982-12096)"""
+    L, wh = seam
+    rng = np.random.default_rng(pal)
+    w, h = 50, 22
+    for clamp_leaf in (None, 0, 1):
+        for direction, un in ((1, 0), (-1, 1)):
+            src = [frame(rng, w, h, 4)] if pal == 589 else [frame(rng, w, h, 1) for _ in range(4)]
+            lay = wh.new_layer(pal, w, h, src, clamping=clamp_leaf, flags=0 if un == 0 else 1)
+            L.lives_gpu_alpha_premult(lay, direction)
+            planes, _, _ = wh.planes_of(lay)
+            want = [s.copy() for s in src]
+            pp = (ctypes.c_void_p * 4)(*([x.ctypes.data for x in want] + [None] * (4 - len(want))))
+            ss = (ctypes.c_int * 4)(*([x.strides[0] for x in want] + [0] * (4 - len(want))))
+            orc.orc_alpha_premult_yuva(pp, ss, w, h, pal, 0 if clamp_leaf == 1 else 1, un)
+            bw = w * 4 if pal == 589 else w
+            for i in range(len(src)):
+                assert (planes[i][:, :bw] == want[i][:, :bw]).all(), (pal, clamp_leaf, direction, i)
+            assert wh.geti(lay, "host_flags") == (1 if direction == 1 else 0)
+
+
 # ---- K4 / K3 on layers: the RGB -> YUV and YUV -> RGB cases of convert_layer_palette_full (src/colourspace.c:12559-13860) ----
 K4_FMT = {588: 0, 589: 0, 544: 1, 545: 1, 564: 2, 565: 3, 512: 4, 513: 4, 522: 5}
 

@@ -34,6 +34,15 @@ def test_alpha_tables(orc):
     assert (al == g["al"]).all()
 
 
+def test_premult_yuv_tables(orc):
+    """init_unal's clamped-YUV tables (src/colourspace.c:1141-1160), as the reference slice produced them"""
+    g = gu.load("premult_yuv.npz")
+    tabs = [np.zeros((256, 256), np.uint8) for _ in range(4)]
+    orc.orc_premult_yuv_tables(*[P(t) for t in tabs])
+    for name, t in zip(("unalcy", "alcy", "unalcuv", "alcuv"), tabs):
+        assert (t == g[name]).all(), name
+
+
 def test_gamma_luts(orc):
     g = gu.load("luts.npz")
     n = 0

@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -281,6 +281,20 @@ def main():
                 d = dev(sfr)
                 ops.alpha_premult(d, w, h, alpha_first=af, un=un)
                 ok = same(host(d), want, w * 4, h, "premult %dx%d af=%d un=%d" % (w, h, af, un))
+            elif kind == "premultyuva":
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
+                pal, clamped, un = int(rng.choice([589, 545])), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                planes = [fr(w, h, 4)] if pal == 589 else [fr(w, h, 1) for _ in range(4)]
+                if pal == 589 and planes[0].strides[0] & 3:
+                    continue
+                want = [x.copy() for x in planes]
+                pp = (ctypes.c_void_p * 4)(*([x.ctypes.data for x in want] + [None] * (4 - len(want))))
+                ss = (ctypes.c_int * 4)(*([x.strides[0] for x in want] + [0] * (4 - len(want))))
+                orc.orc_alpha_premult_yuva(pp, ss, w, h, pal, clamped, un)
+                ds = [dev(x) for x in planes]
+                ops.alpha_premult_yuva(ds, w, h, pal, clamped, un=un)
+                ok = all(same(host(d), wt, w * (4 if pal == 589 else 1), h, "premult yuva %d %dx%d clamped=%d un=%d" % (pal, w, h, clamped, un))
+                         for d, wt in zip(ds, want))
             elif kind == "luma":
                 pal = int(rng.integers(1, 5))
                 ps, order = (3 if pal <= 2 else 4), (0 if pal in (1, 3) else 1)
