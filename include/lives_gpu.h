@@ -179,6 +179,14 @@ int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int i
    LGPU_E_UNSUPPORTED for planar -> ARGB32 / BGR24 (reference row arithmetic broken, :7475-7476, :7313). */
 int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
                     uint8_t *dst_d, int orow, int out_order, int out_alpha, int which_tables, void *stream);
+
+/* K3b: YUV411 (u2 y0 y1 v2 y2 y3: 4 pixels in 6 bytes) -> RGB24 / RGBA32 / BGR24 / BGRA32 / ARGB32.
+ * Replaces convert_yuv411_to_rgb_frame / _bgr_frame / _argb_frame (src/colourspace.c:8305-8620; dispatcher :13755-13795).
+ * width_mp = macropixels per row (the layer's width leaf); the source is compact rows of width_mp * 6 bytes, as the reference
+ * walks it; YCbCr subspace only.  Reference behaviour kept: the alpha byte of pixels 4j+2, 4j+3 (j < width_mp - 1)
+ * is not written; the bgr variant stores the row's first pixel and last two pixels in R,G,B order. */
+int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height, uint8_t *dst_d, int orow, int out_order, int out_alpha,
+                       int clamping_unclamped, void *stream);
 /* K5: clamped <-> unclamped switch, in place: switch_yuv_clamping_and_subspace (src/colourspace.c:10929-11090) with the
    tables of init_YUV_to_YUV_tables (:1108-1139; one table set serves YCbCr and BT.709 -- the reference does no subspace
    maths).  palette 588 YUV888, 589 YUVA8888 (alpha untouched), 544 / 545 / 522 / 512 / 513 planar, 564 UYVY, 565 YUYV.

@@ -509,7 +509,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
   if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
 
   NewPlanes np;
-  const int owidth = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV) ? l.width * 2 : l.width;   // macropixels -> pixels (:13010)
+  const int owidth = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV) ? l.width * 2 : inpl == WEED_PALETTE_YUV411 ? l.width * 4 : l.width;   // macropixels -> pixels (:13010, :13759)
   if (!alloc_planes(outpl, owidth, l.height, 0, &np)) return 0;
   const size_t obytes = (size_t)np.rs[0] * l.height;
   uint8_t *d_out = t_scr.get(3, obytes);
@@ -556,6 +556,15 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
       dsrc[p] = d; irs[p] = l.rs[p];
     }
     ok = ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, nullptr) == LGPU_OK;
+  } else if (ok && inpl == WEED_PALETTE_YUV411) {
+    // K3b (:13755-13795): the reference walks the source as compact rows of `width` macropixels and leaves some alpha bytes of the
+    // new (zeroed, create_empty_pixel_data) frame unwritten -- the device frame starts zeroed too
+    const size_t ibytes = (size_t)l.width * 6 * l.height;
+    uint8_t *d_in = t_scr.get(0, ibytes);
+    const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
+    ok = !lutp && d_in && (size_t)l.rs[0] * l.height >= ibytes && up(d_in, l.pd[0], ibytes) && lgpu_fill(d_out, 0, obytes, nullptr) == LGPU_OK &&
+         lgpu_yuv411_to_rgb(d_in, l.width, l.height, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0,
+                            iclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK;
   } else ok = false;
   ok = ok && down(np.pd[0], d_out, obytes) && sync();
   if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }                                  // memfail: layer untouched

@@ -180,6 +180,53 @@ __global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
   }
 }
 
+// ---- K3b: YUV411 -> RGB (src/colourspace.c:8305-8620) ---------------------------------------------------------------------
+// lane = one macropixel (u2 y0 y1 v2 y2 y3 -> 4 pixels).  Its first pair blends chroma with the block on the left, its second
+// pair with the block on the right (cascaded table averages, :8344-8390); the row's first and last pair use their own chroma.
+// Kept as written: the pair that opens a loop iteration never gets its alpha byte (left untouched here too), and the bgr variant
+// writes the row's first pixel and last pair in R,G,B order.
+__device__ __forceinline__ void put_colour(uint8_t *d, int bgr, const int32_t *t, int Y, int U, int V) {
+  const int32_t yy = t[Y];
+  const int r = clamp255((yy + t[256 + V]) >> 16), g = clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = clamp255((yy + t[1024 + U]) >> 16);
+  d[0] = (uint8_t)(bgr ? b : r); d[1] = (uint8_t)g; d[2] = (uint8_t)(bgr ? r : b);
+}
+__global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a) {
+  __shared__ int32_t s_t[5 * 256];
+  for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
+  __syncthreads();
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  const int wm = a.width;                                   // macropixels per row
+  if (j >= wm) return;
+  const int ps = (a.order == 2 || a.alpha_out) ? 4 : 3, coff = a.order == 2 ? 1 : 0, aoff = a.order == 2 ? 0 : 3;
+  const int bgr = a.order == 1, cl = !a.unclamped;
+  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+    const uint8_t *cb = a.src[0] + ((size_t)y * wm + j) * 6;
+    uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)j * 4 * ps;
+    const int cu = cb[0], cv = cb[3];
+    if (j == 0) {                                           // row start (:8330-8337)
+      put_colour(d + coff, 0, s_t, cb[1], cu, cv);
+      put_colour(d + ps + coff, bgr, s_t, cb[2], cu, cv);
+    } else {                                                // second half of loop iteration j (:8373-8390)
+      const int pu = cb[-6], pv = cb[-3];
+      const int qu = cavg(cl, cavg(cl, pu, cu), cu), qv = cavg(cl, cavg(cl, pv, cv), cv);
+      put_colour(d + coff, bgr, s_t, cb[1], cavg(cl, qu, pu), cavg(cl, qv, pv));
+      put_colour(d + ps + coff, bgr, s_t, cb[2], cavg(cl, qu, cu), cavg(cl, qv, cv));
+    }
+    if (ps == 4) d[aoff] = d[4 + aoff] = 255;
+    d += 2 * ps;
+    if (j == wm - 1) {                                      // row end (:8397-8406)
+      put_colour(d + coff, 0, s_t, cb[4], cu, cv);
+      put_colour(d + ps + coff, 0, s_t, cb[5], cu, cv);
+      if (ps == 4) d[aoff] = d[4 + aoff] = 255;
+    } else {                                                // first half of loop iteration j + 1 (:8344-8366): this block is "previous"
+      const int nu = cb[6], nv = cb[9];
+      const int qu = cavg(cl, cavg(cl, cu, nu), cu), qv = cavg(cl, cavg(cl, cv, nv), cv);
+      put_colour(d + coff, bgr, s_t, cb[4], cavg(cl, qu, cu), cavg(cl, qv, cv));
+      put_colour(d + ps + coff, bgr, s_t, cb[5], cavg(cl, qu, nu), cavg(cl, qv, nv));
+    }
+  }
+}
+
 // ---- K5: clamped <-> unclamped, in place (src/colourspace.c:10929-11090) ---------------------------------------------------
 // role of a byte = position in the plane buffer modulo `period`: pattern nibbles 0 = Y table, 1 = chroma table, 2 = leave.
 // lane = 16 aligned bytes (head / tail of an unaligned buffer byte-wise by the first / last lanes)
@@ -465,6 +512,25 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
     K3_CASE(3, 0) K3_CASE(3, 1) K3_CASE(3, 2)
   }
 #undef K3_CASE
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height, uint8_t *dst_d, int orow, int out_order, int out_alpha,
+                                  int clamping_unclamped, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && width_mp > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(out_order >= 0 && out_order <= 2, "out_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
+  const int ps = (out_order == 2 || out_alpha) ? 4 : 3;
+  LGPU_REQUIRE(orow >= width_mp * 4 * ps, "rowstride smaller than a row");
+  PalArgs a;
+  __builtin_memset(&a, 0, sizeof a);
+  a.src[0] = src_d; a.dst[0] = dst_d; a.orow[0] = orow; a.width = width_mp; a.height = height;
+  a.order = out_order; a.alpha_out = out_alpha; a.unclamped = clamping_unclamped ? 1 : 0;
+  a.tables = device_tables()->yuv2rgb[a.unclamped];         // set_conversion_arrays(clamping, WEED_YUV_SUBSPACE_YCBCR) (:8316)
+  const dim3 grid(cdiv((unsigned)width_mp, kBlock), (unsigned)(height < 2048 ? height : 2048));
+  hipLaunchKernelGGL(k_yuv411_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -56,6 +56,11 @@ def alpha_premult_yuva(planes, width, height, palette, clamped, un=0):
     lib.call("lgpu_alpha_premult_yuva", ctypes.addressof(pp), ctypes.addressof(ss), width, height, palette, int(bool(clamped)), int(bool(un)), stream_ptr())
 
 
+def yuv411_to_rgb(src, dst, width_mp, height, out_order=0, out_alpha=0, unclamped=0):
+    """K3b: compact YUV411 rows (width_mp * 6 bytes) -> RGB / BGR / ARGB"""
+    lib.call("lgpu_yuv411_to_rgb", dptr(src), width_mp, height, dptr(dst), dst.stride(0), out_order, out_alpha, int(bool(unclamped)), stream_ptr())
+
+
 def yuv420p_to_rgb(y, u, v, dst, width, height, opsize=4, out_order=0, is_422=0, which_tables=0, pb_quality=2, lut=None,
                    flags=0, u_size=None, v_size=None):
     strides = (ctypes.c_int * 3)(y.stride(0), u.stride(0), v.stride(0))

@@ -763,6 +763,60 @@ int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, in
   return 0;
 }
 
+/* K3b: YUV411 (u2 y0 y1 v2 y2 y3, 4 pixels in 6 bytes) -> RGB24 / RGBA32 / BGR24 / BGRA32 / ARGB32
+ * reference: src/colourspace.c:8305-8411 (rgb), :8413-8520 (bgr), :8522-8620 (argb); dispatcher :13755-13795.
+ * The source is walked as compact rows of `width_mp` macropixels (no input rowstride in the reference).  Kept as written:
+ *  - chroma of the inner pixels is a cascade of table averages (avg_chromaf = cavg of the clamping, :2099-2101) between neighbouring blocks;
+ *  - the first pair the loop writes per block boundary never gets its alpha byte (RGBA / BGRA / ARGB): those bytes keep what the
+ *    destination held;
+ *  - the bgr variant writes the row's first pixel and its last two pixels in R,G,B order (uyvy2rgb with swapped pointers only for
+ *    the second pixel of the first pair, :8445, :8515). */
+int orc_yuv411_to_rgb(const uint8_t *src, int width_mp, int height, uint8_t *dst, int orow, int out_order, int out_alpha, int unclamped) {
+  yuvctx_t c;
+  if (!tables_ready) build_tables();
+  if (!src || !dst || width_mp < 1 || height < 1 || out_order < 0 || out_order > 2) return -1;
+  const int w = unclamped ? 1 : 0, cl = !unclamped;
+  c.ty = T_y2r[w][0]; c.rcr = T_y2r[w][1]; c.gcb = T_y2r[w][2]; c.gcr = T_y2r[w][3]; c.bcb = T_y2r[w][4];
+  c.lut8 = NULL; c.lut16 = NULL; c.quality = 2; c.clamped = cl;
+  const int ps = (out_order == 2 || out_alpha) ? 4 : 3;
+  c.opsize = 3;                                                 /* colour bytes only: alpha is written (or not) below */
+  const int coff = out_order == 2 ? 1 : 0, aoff = out_order == 2 ? 0 : 3;
+  if (orow < width_mp * 4 * ps) return -1;
+  for (int i = 0; i < height; i++) {
+    const uint8_t *row = src + (size_t)i * width_mp * 6;
+    uint8_t *d = dst + (size_t)i * orow;
+    /* row start (:8330-8337): block 0's y0 y1 with its own chroma */
+    c.order = out_order == 1 ? 0 : (out_order == 2 ? 0 : 0);
+    if (ps == 4) d[aoff] = d[4 + aoff] = 255;
+    c.order = 0; put_px(&c, d + coff, row[1], row[0], row[3]);                       /* R,G,B order even in the bgr variant */
+    c.order = out_order == 1 ? 1 : 0; put_px(&c, d + ps + coff, row[2], row[0], row[3]);
+    d += 2 * ps;
+    int j;
+    for (j = 1; j < width_mp; j++) {
+      const uint8_t *pb = row + (size_t)(j - 1) * 6, *cb = row + (size_t)j * 6;
+      const int pu = pb[0], pv = pb[3], cu = cb[0], cv = cb[3];
+      const int hu = orc_cavg(cl, pu, cu), hv = orc_cavg(cl, pv, cv);
+      int qu = orc_cavg(cl, hu, pu), qv = orc_cavg(cl, hv, pv);
+      c.order = out_order == 1 ? 1 : 0;
+      put_px(&c, d + coff, pb[4], orc_cavg(cl, qu, pu), orc_cavg(cl, qv, pv));        /* y2 of the previous block; no alpha write */
+      put_px(&c, d + ps + coff, pb[5], orc_cavg(cl, qu, cu), orc_cavg(cl, qv, cv));
+      d += 2 * ps;
+      qu = orc_cavg(cl, hu, cu); qv = orc_cavg(cl, hv, cv);
+      put_px(&c, d + coff, cb[1], orc_cavg(cl, qu, pu), orc_cavg(cl, qv, pv));
+      put_px(&c, d + ps + coff, cb[2], orc_cavg(cl, qu, cu), orc_cavg(cl, qv, cv));
+      if (ps == 4) d[aoff] = d[4 + aoff] = 255;
+      d += 2 * ps;
+    }
+    /* row end (:8397-8406): the last block's y2 y3 with its own chroma, R,G,B order in the bgr variant too */
+    const uint8_t *lb = row + (size_t)(j - 1) * 6;
+    if (ps == 4) d[aoff] = d[4 + aoff] = 255;
+    c.order = 0;
+    put_px(&c, d + coff, lb[4], lb[0], lb[3]);
+    put_px(&c, d + ps + coff, lb[5], lb[0], lb[3]);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * K5: clamping switch                   reference: src/colourspace.c:1108-1139, :1163-1230, :10929-11090
  * ---------------------------------------------------------------------------------------------- */

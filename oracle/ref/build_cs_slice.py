@@ -335,6 +335,15 @@ int csref_k3(int in_fmt, int in_alpha, int out_order, int out_alpha, uint8_t **s
   }
   return -1;
 }
+/* K3b: YUV411 -> RGB; width in macropixels (what the dispatcher passes, :13755-13795) */
+int csref_yuv411_to_rgb(uint8_t *src, int width_mp, int height, uint8_t *dst, int orow, int out_order, int out_alpha, int clamping) {
+  ensure_tables();
+  avg_chromaf = avg_chromaf_fast;
+  if (out_order == 0) convert_yuv411_to_rgb_frame((yuv411_macropixel *)src, width_mp, height, orow, dst, out_alpha, clamping);
+  else if (out_order == 1) convert_yuv411_to_bgr_frame((yuv411_macropixel *)src, width_mp, height, orow, dst, out_alpha, clamping);
+  else convert_yuv411_to_argb_frame((yuv411_macropixel *)src, width_mp, height, orow, dst, clamping);
+  return 0;
+}
 void csref_gamma_apply(uint8_t *pixels, int width, int height, int rowstride, int psize, int alpha_first,
                        int xoffset_px, uint8_t *lut8) {
   lives_cc_params cc;
@@ -399,6 +408,7 @@ def main():
     parts.append(lines(cs, 7800, 7971))             # K5b: uyvy / yuyv -> yuv(a)444p / yuv(a)888(8) / yuv420p
     parts.append(lines(cs, 2461, 2474))             # K5b: uyvy_2_yuv422, yuyv_2_yuv422
     parts.append(lines(cs, 8035, 8270))             # K5b: yuv(a)888(8) -> yuv420p / yuv422p / uyvy / yuyv, uyvy / yuyv -> yuv422p
+    parts.append(lines(cs, 8305, 8620))             # K3b: yuv411 -> rgb / bgr / argb
     parts.append(lines(cs, 9198, 9257))             # K5b: convert_splitplanes_frame
     parts.append(lines(cs, 10578, 10639))           # K5b: convert_halve_chroma, convert_double_chroma
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family

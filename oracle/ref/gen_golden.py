@@ -243,6 +243,8 @@ def main():
     gen_golden_scriptfx.main()
     import gen_golden_premult_yuv       # clamped-YUV premultiply tables
     gen_golden_premult_yuv.main()
+    import gen_golden_yuv411            # YUV411 -> RGB family
+    gen_golden_yuv411.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

@@ -85,6 +85,14 @@ def test_premult_vs_reference_tables(gpu):
             assert (got[:, c::4] == tab).all(), ("un" if un else "al", c)
 
 
+def test_yuv411_vs_reference(gpu):
+    g = gu.load("yuv411.npz")
+    for n, (wm, h, order, oa, uncl, _pad) in enumerate(g["cases"].tolist()):
+        d = dev(g["init%d" % n])
+        gpu.yuv411_to_rgb(dev(g["src%d" % n]), d, wm, h, out_order=order, out_alpha=oa, unclamped=uncl)
+        assert (host(d) == g["out%d" % n]).all(), (n, wm, h, order, oa, uncl)
+
+
 def test_weed_effects_vs_reference_plugins(gpu):
     g = gu.load("plugins.npz")
     for rec in g["records"]:

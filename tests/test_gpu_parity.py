@@ -157,6 +157,23 @@ def test_alpha_premult_yuva(gpu, orc, pal, clamped, un):
             assert (host(d)[:, bw:] == planes[i][:, bw:]).all()       # padding untouched
 
 
+# ---------------------------------------------------------------------------------------------- K3b
+@pytest.mark.parametrize("order,oa", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 1)])
+@pytest.mark.parametrize("uncl", [0, 1])
+def test_yuv411_to_rgb(gpu, orc, order, oa, uncl):
+    """YUV411 -> RGB family against the oracle: ragged widths (1 macropixel too), padded rows, unwritten alpha bytes and padding kept"""
+    rng = np.random.default_rng(411 + order * 4 + oa * 2 + uncl)
+    ps = 4 if (order == 2 or oa) else 3
+    for wm, h, pad in ((1, 1, 0), (2, 5, 4), (67, 9, 8), (480, 270, 0), (257, 3, 16)):
+        src = rng.integers(0, 256, (h, wm * 6), dtype=np.uint8)
+        init = rng.integers(0, 256, (h, wm * 4 * ps + pad), dtype=np.uint8)
+        want = init.copy()
+        assert orc.orc_yuv411_to_rgb(P(src), wm, h, P(want), want.strides[0], order, oa, uncl) == 0
+        d = dev(init)
+        gpu.yuv411_to_rgb(dev(src), d, wm, h, out_order=order, out_alpha=oa, unclamped=uncl)
+        assert (host(d) == want).all(), (wm, h, pad)
+
+
 # ---------------------------------------------------------------------------------------------- K2
 def k2_mask(w, h, is_422):
     m = np.zeros((h, w), bool)

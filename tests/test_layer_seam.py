@@ -233,6 +233,28 @@ def test_alpha_premult_yuva_layer(seam, orc, pal):
             assert wh.geti(lay, "host_flags") == (1 if direction == 1 else 0)
 
 
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("outpl", [RGB24, BGR24, RGBA32, BGRA32, ARGB32])
+def test_yuv411_layer_to_rgb(seam, orc, outpl):
+    """a YUV411 layer (width leaf in macropixels, src/colourspace.c:13755-13795): new width = 4 * width, YUV leaves deleted; the alpha
+    bytes the reference leaves unwritten are those of a zeroed new frame"""
+    L, wh = seam
+    rng = np.random.default_rng(outpl)
+    wm, h = 24, 10
+    order = {RGB24: 0, RGBA32: 0, BGR24: 1, BGRA32: 1, ARGB32: 2}[outpl]
+    ps = 3 if outpl in (RGB24, BGR24) else 4
+    for clamp in (0, 1):
+        src = rng.integers(0, 256, (h, wm * 6), dtype=np.uint8)
+        lay = wh.new_layer(595, wm, h, [src], clamping=clamp, gamma=1)
+        assert L.lives_gpu_convert_layer_palette(lay, outpl, clamp) == 1
+        planes, _, rs = wh.planes_of(lay)
+        assert wh.geti(lay, "current_palette") == outpl and wh.geti(lay, "width") == wm * 4 and wh.geti(lay, "YUV_clamping") is None
+        want = np.zeros((h, rs[0]), np.uint8)
+        assert orc.orc_yuv411_to_rgb(P(src), wm, h, P(want), want.strides[0], order, 1 if ps == 4 else 0, clamp) == 0
+        assert (planes[0][:, :wm * 4 * ps] == want[:, :wm * 4 * ps]).all(), (outpl, clamp)
+
+
 # ---- K4 / K3 on layers: the RGB -> YUV and YUV -> RGB cases of convert_layer_palette_full (src/colourspace.c:12559-13860) ----
 K4_FMT = {588: 0, 589: 0, 544: 1, 545: 1, 564: 2, 565: 3, 512: 4, 513: 4, 522: 5}
 

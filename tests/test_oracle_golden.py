@@ -43,6 +43,15 @@ def test_premult_yuv_tables(orc):
         assert (t == g[name]).all(), name
 
 
+def test_yuv411_to_rgb(orc):
+    """convert_yuv411_to_rgb_frame / _bgr_frame / _argb_frame (src/colourspace.c:8305-8620)"""
+    g = gu.load("yuv411.npz")
+    for n, (wm, h, order, oa, uncl, _pad) in enumerate(g["cases"].tolist()):
+        got = g["init%d" % n].copy()
+        assert orc.orc_yuv411_to_rgb(P(np.ascontiguousarray(g["src%d" % n])), wm, h, P(got), got.strides[0], order, oa, uncl) == 0
+        assert (got == g["out%d" % n]).all(), (n, wm, h, order, oa, uncl)      # includes the alpha bytes the reference never writes
+
+
 def test_gamma_luts(orc):
     g = gu.load("luts.npz")
     n = 0

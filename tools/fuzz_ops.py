@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -295,6 +295,18 @@ def main():
                 ops.alpha_premult_yuva(ds, w, h, pal, clamped, un=un)
                 ok = all(same(host(d), wt, w * (4 if pal == 589 else 1), h, "premult yuva %d %dx%d clamped=%d un=%d" % (pal, w, h, clamped, un))
                          for d, wt in zip(ds, want))
+            elif kind == "yuv411":
+                wm, h = int(rng.integers(1, 200)), int(rng.integers(1, 60))
+                order, uncl = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+                oa = 1 if order == 2 else int(rng.integers(0, 2))
+                ps = 4 if oa else 3
+                src = rng.integers(0, 256, (h, wm * 6), dtype=np.uint8)
+                init = rng.integers(0, 256, (h, wm * 4 * ps + int(rng.integers(0, 5)) * 4), dtype=np.uint8)
+                want = init.copy()
+                orc.orc_yuv411_to_rgb(P(src), wm, h, P(want), want.strides[0], order, oa, uncl)
+                d = dev(init)
+                ops.yuv411_to_rgb(dev(src), d, wm, h, out_order=order, out_alpha=oa, unclamped=uncl)
+                ok = same(host(d), want, want.shape[1], h, "yuv411 %dx%d order=%d alpha=%d unclamped=%d" % (wm, h, order, oa, uncl))
             elif kind == "luma":
                 pal = int(rng.integers(1, 5))
                 ps, order = (3 if pal <= 2 else 4), (0 if pal in (1, 3) else 1)
