@@ -187,6 +187,12 @@ int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width,
  * is not written; the bgr variant stores the row's first pixel and last two pixels in R,G,B order. */
 int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height, uint8_t *dst_d, int orow, int out_order, int out_alpha,
                        int clamping_unclamped, void *stream);
+
+/* K4b: RGB24 / RGBA32 / BGR24 / BGRA32 / ARGB32 -> YUV411.  Replaces convert_rgb_to_yuv411_frame / _bgr_ / _argb_
+ * (src/colourspace.c:6499-6615, rgb2_411 :2322-2343; dispatcher :12627-12632, :12705, :12779, :12852, :12925).
+ * width in pixels (width % 4 pixels on the right are dropped); dst_d receives compact rows of (width >> 2) * 6 bytes. */
+int lgpu_rgb_to_yuv411(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d,
+                       int clamping_unclamped, void *stream);
 /* K5: clamped <-> unclamped switch, in place: switch_yuv_clamping_and_subspace (src/colourspace.c:10929-11090) with the
    tables of init_YUV_to_YUV_tables (:1108-1139; one table set serves YCbCr and BT.709 -- the reference does no subspace
    maths).  palette 588 YUV888, 589 YUVA8888 (alpha untouched), 544 / 545 / 522 / 512 / 513 planar, 564 UYVY, 565 YUYV.

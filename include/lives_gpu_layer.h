@@ -21,7 +21,7 @@
  *   convert_layer_palette[_full]  RGB24/BGR24/RGBA32/BGRA32/ARGB32 <-> each other (selector tree
  *                                 src/colourspace.c:12370-12556, LUT8 gamma inline); YUV420P/YVU420P/YUV422P ->
  *                                 those five (:13400-13560, LUT16 gamma fused when a target gamma is given); RGB -> YUV888 /
- *                                 YUVA8888 / YUV(A)444(4)P / UYVY / YUYV / YUV420P / YVU420P / YUV422P and those packed / 4:4:4
+ *                                 YUVA8888 / YUV(A)444(4)P / UYVY / YUYV / YUV411 / YUV420P / YVU420P / YUV422P and those packed / 4:4:4
  *                                 planar / UYVY / YUYV / YUV411 palettes -> RGB; the clamped <-> unclamped switch; the YUV -> YUV pairs of
  *                                 lgpu_yuv_repack (lives_gpu.h)
  *   gamma_convert_layer / gamma_convert_sub_layer, alpha_premult (RGB with alpha, YUVA8888, YUVA4444P), resize_layer, letterbox_layer (packed RGB

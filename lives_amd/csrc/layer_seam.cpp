@@ -311,7 +311,36 @@ int k4_fmt(int pal) {
 }
 
 // K4 on a layer: the RGB24 / BGR24 / RGBA32 / BGRA32 / ARGB32 cases of src/colourspace.c:12559-12935 plus conv_done (:13860-13893)
+// K4b on a layer (:12627-12632 and the same case under each RGB input): width leaf becomes width >> 2 macropixels, the new frame is
+// written as compact macropixel rows whatever rowstride it was given (the reference passes none)
+lives_gpu_boolean rgb_layer_to_yuv411(weed_plant_t *layer, const Layer &l, int oclamping) {
+  const int order = pal_alpha_first(l.pal) ? 2 : pal_red_first(l.pal) ? 0 : 1;
+  const int in_alpha = pal_has_alpha(l.pal) ? 1 : 0, wm = l.width >> 2;
+  if (wm < 1 || l.height < 1) return 0;
+  NewPlanes np;
+  if (!alloc_planes(WEED_PALETTE_YUV411, wm, l.height, 0, &np)) return 0;
+  const size_t ibytes = (size_t)l.rs[0] * l.height;
+  uint8_t *d_in = t_scr.get(0, ibytes), *d_out = t_scr.get(3, np.sz[0]);
+  const bool ok = d_in && d_out && up(d_in, l.pd[0], ibytes) && up_fresh(d_out, np.pd[0], np.sz[0]) &&
+                  lgpu_rgb_to_yuv411(d_in, l.rs[0], l.width, l.height, order, in_alpha, d_out, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK &&
+                  down(np.pd[0], d_out, np.sz[0]) && sync();
+  if (!ok) { res_drop(np.pd[0]); pfree(np.pd[0]); return 0; }
+  int flags = l.flags;
+  if (in_alpha) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  free_planes(l);
+  commit_planes(layer, WEED_PALETTE_YUV411, wm, l.height, np);
+  if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
+  set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);                         // conv_done, as for the other RGB -> YUV cases below
+  set_int(layer, WEED_LEAF_YUV_SUBSPACE, l.gamma == WEED_GAMMA_BT709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR);
+  if (!has_leaf(layer, WEED_LEAF_YUV_SAMPLING)) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);
+  return 1;
+}
+
 lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outpl, int oclamping, int osubspace, int tgt_gamma) {
+  if (outpl == WEED_PALETTE_YUV411) {
+    if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return 0;
+    return rgb_layer_to_yuv411(layer, l, oclamping);
+  }
   const int fmt = k4_fmt(outpl);
   if (fmt < 0) return 0;
   if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return 0;   // LUT16 variants: CPU body

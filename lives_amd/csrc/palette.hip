@@ -180,6 +180,36 @@ __global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
   }
 }
 
+// ---- K4b: RGB -> YUV411 (src/colourspace.c:6499-6615, rgb2_411 :2322-2343) -----------------------------------------------------
+// lane = four pixels -> u2 y0 y1 v2 y2 y3; chroma is the sum of the four per-pixel (>> 16) values >> 2, clamped afterwards
+__global__ __launch_bounds__(kBlock) void k_rgb_to_yuv411(PalArgs a) {
+  __shared__ int32_t s_t[9 * 256];
+  for (int i = threadIdx.x; i < 9 * 256; i += kBlock) s_t[i] = a.tables[i];
+  __syncthreads();
+  const int min_y = a.unclamped ? 0 : 16, max_y = a.unclamped ? 255 : 235, min_uv = min_y, max_uv = a.unclamped ? 255 : 240;   // :361-370
+  const int ips = (a.order == 2 || a.alpha_in) ? 4 : 3, wm = a.width >> 2;
+  const int ro = a.order == 0 ? 0 : a.order == 1 ? 2 : 1, go = a.order == 2 ? 2 : 1, bo = a.order == 0 ? 2 : a.order == 1 ? 0 : 3;
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= wm) return;
+  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+    const uint8_t *s = a.src[0] + (size_t)y * a.irow[0] + (size_t)j * 4 * ips;
+    int su = 0, sv = 0, Y[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = s[k * ips + ro], g = s[k * ips + go], b = s[k * ips + bo];
+      const int v = (s_t[r] + s_t[256 + g] + s_t[512 + b]) >> 16;
+      Y[k] = v > max_y ? max_y : v < min_y ? min_y : v;
+      su += (s_t[768 + r] + s_t[1024 + g] + s_t[1280 + b]) >> 16;
+      sv += (s_t[1536 + r] + s_t[1792 + g] + s_t[2048 + b]) >> 16;
+    }
+    su >>= 2; sv >>= 2;
+    su = su > max_uv ? max_uv : su < min_uv ? min_uv : su;
+    sv = sv > max_uv ? max_uv : sv < min_uv ? min_uv : sv;
+    uint8_t *d = a.dst[0] + ((size_t)y * wm + j) * 6;        // 2-byte aligned when the frame is
+    d[0] = (uint8_t)su; d[1] = (uint8_t)Y[0]; d[2] = (uint8_t)Y[1]; d[3] = (uint8_t)sv; d[4] = (uint8_t)Y[2]; d[5] = (uint8_t)Y[3];
+  }
+}
+
 // ---- K3b: YUV411 -> RGB (src/colourspace.c:8305-8620) ---------------------------------------------------------------------
 // lane = one macropixel (u2 y0 y1 v2 y2 y3 -> 4 pixels).  Its first pair blends chroma with the block on the left, its second
 // pair with the block on the right (cascaded table averages, :8344-8390); the row's first and last pair use their own chroma.
@@ -512,6 +542,25 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
     K3_CASE(3, 0) K3_CASE(3, 1) K3_CASE(3, 2)
   }
 #undef K3_CASE
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_rgb_to_yuv411(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d,
+                                  int clamping_unclamped, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && width >= 4 && height > 0, "null frame, or fewer than 4 pixels per row");
+  LGPU_REQUIRE(in_order >= 0 && in_order <= 2, "in_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
+  const int ips = (in_order == 2 || in_alpha) ? 4 : 3;
+  LGPU_REQUIRE(irow >= (width >> 2) * 4 * ips, "rowstride smaller than a row");
+  PalArgs a;
+  __builtin_memset(&a, 0, sizeof a);
+  a.src[0] = src_d; a.irow[0] = irow; a.dst[0] = dst_d; a.width = width; a.height = height;
+  a.order = in_order; a.alpha_in = in_alpha; a.unclamped = clamping_unclamped ? 1 : 0;
+  a.tables = device_tables()->rgb2yuv[a.unclamped];         // set_conversion_arrays(clamping, WEED_YUV_SUBSPACE_YCBCR) (:6511)
+  const dim3 grid(cdiv((unsigned)(width >> 2), kBlock), (unsigned)(height < 2048 ? height : 2048));
+  hipLaunchKernelGGL(k_rgb_to_yuv411, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

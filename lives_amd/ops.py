@@ -56,6 +56,11 @@ def alpha_premult_yuva(planes, width, height, palette, clamped, un=0):
     lib.call("lgpu_alpha_premult_yuva", ctypes.addressof(pp), ctypes.addressof(ss), width, height, palette, int(bool(clamped)), int(bool(un)), stream_ptr())
 
 
+def rgb_to_yuv411(src, dst, width, height, in_order=0, in_alpha=0, unclamped=0):
+    """K4b: RGB family -> compact YUV411 rows ((width >> 2) * 6 bytes)"""
+    lib.call("lgpu_rgb_to_yuv411", dptr(src), src.stride(0), width, height, in_order, in_alpha, dptr(dst), int(bool(unclamped)), stream_ptr())
+
+
 def yuv411_to_rgb(src, dst, width_mp, height, out_order=0, out_alpha=0, unclamped=0):
     """K3b: compact YUV411 rows (width_mp * 6 bytes) -> RGB / BGR / ARGB"""
     lib.call("lgpu_yuv411_to_rgb", dptr(src), width_mp, height, dptr(dst), dst.stride(0), out_order, out_alpha, int(bool(unclamped)), stream_ptr())

@@ -763,6 +763,36 @@ int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, in
   return 0;
 }
 
+/* K4b: RGB24 / RGBA32 / BGR24 / BGRA32 / ARGB32 -> YUV411     reference: src/colourspace.c:6499-6615, rgb2_411 :2322-2343;
+ * dispatcher :12627-12632 etc.  Four pixels -> u2 y0 y1 v2 y2 y3; chroma = (sum of the four per-pixel >> FP_BITS values) >> 2, clamped
+ * afterwards; width % 4 pixels on the right are dropped; the destination is compact rows of (width >> 2) macropixels. */
+int orc_rgb_to_yuv411(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int unclamped) {
+  const r2y_t c = r2y_for(unclamped ? 1 : 0);
+  const int ips = (in_order == 2 || in_alpha) ? 4 : 3, wm = width >> 2;
+  if (!src || !dst || in_order < 0 || in_order > 2 || wm < 1 || height < 1 || irow < wm * 4 * ips) return -1;
+  for (int y = 0; y < height; y++) {
+    const uint8_t *s = src + (size_t)y * irow;
+    uint8_t *d = dst + (size_t)y * wm * 6;
+    for (int j = 0; j < wm; j++, d += 6) {
+      int su = 0, sv = 0, Y[4];
+      for (int k = 0; k < 4; k++) {
+        int r, g, b;
+        px_rgb(s + (size_t)(4 * j + k) * ips, in_order, &r, &g, &b);
+        const int a = (c.t[0][r] + c.t[1][g] + c.t[2][b]) >> 16;
+        Y[k] = a > c.max_y ? c.max_y : a < c.min_y ? c.min_y : a;
+        su += (c.t[3][r] + c.t[4][g] + c.t[5][b]) >> 16;
+        sv += (c.t[6][r] + c.t[7][g] + c.t[8][b]) >> 16;
+      }
+      su >>= 2; sv >>= 2;
+      d[0] = (uint8_t)(su > c.max_uv ? c.max_uv : su < c.min_uv ? c.min_uv : su);
+      d[1] = (uint8_t)Y[0]; d[2] = (uint8_t)Y[1];
+      d[3] = (uint8_t)(sv > c.max_uv ? c.max_uv : sv < c.min_uv ? c.min_uv : sv);
+      d[4] = (uint8_t)Y[2]; d[5] = (uint8_t)Y[3];
+    }
+  }
+  return 0;
+}
+
 /* K3b: YUV411 (u2 y0 y1 v2 y2 y3, 4 pixels in 6 bytes) -> RGB24 / RGBA32 / BGR24 / BGRA32 / ARGB32
  * reference: src/colourspace.c:8305-8411 (rgb), :8413-8520 (bgr), :8522-8620 (argb); dispatcher :13755-13795.
  * The source is walked as compact rows of `width_mp` macropixels (no input rowstride in the reference).  Kept as written:

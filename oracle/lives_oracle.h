@@ -105,6 +105,7 @@ int orc_rgb_to_yuv(const uint8_t *src, int irow, int width, int height, int in_o
    planar -> BGR24 (:7313 always steps 4 bytes). */
 int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
                    uint8_t *dst, int orow, int out_order, int out_alpha, int which_tables);
+int orc_rgb_to_yuv411(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int unclamped);
 int orc_yuv411_to_rgb(const uint8_t *src, int width_mp, int height, uint8_t *dst, int orow, int out_order, int out_alpha, int unclamped);
 /* init_average (src/colourspace.c:190-216): cavgc (clamped = 1) / cavgu chroma-averaging table entry */
 int orc_cavg(int clamped, int x, int y);

@@ -101,6 +101,7 @@ def oracle():
         _O.orc_dissolve.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, cd]
         _O.orc_premult_yuv_tables.argtypes = [vp, vp, vp, vp]
         _O.orc_yuv411_to_rgb.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci]
+        _O.orc_rgb_to_yuv411.argtypes = [vp, ci, ci, ci, ci, ci, vp, ci]
         _O.orc_alpha_premult_yuva.argtypes = [vp, vp, ci, ci, ci, ci, ci]
         _O.orc_slide_over.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci]
         _O.orc_yuv_yuv_tables.argtypes = [vp, vp, vp, vp]

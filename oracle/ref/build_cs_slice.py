@@ -335,6 +335,14 @@ int csref_k3(int in_fmt, int in_alpha, int out_order, int out_alpha, uint8_t **s
   }
   return -1;
 }
+/* K4b: RGB -> YUV411; width in pixels (:12627-12632) */
+int csref_rgb_to_yuv411(uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int clamping) {
+  ensure_tables();
+  if (in_order == 0) convert_rgb_to_yuv411_frame(src, width, height, irow, (yuv411_macropixel *)dst, in_alpha, clamping);
+  else if (in_order == 1) convert_bgr_to_yuv411_frame(src, width, height, irow, (yuv411_macropixel *)dst, in_alpha, clamping);
+  else convert_argb_to_yuv411_frame(src, width, height, irow, (yuv411_macropixel *)dst, clamping);
+  return 0;
+}
 /* K3b: YUV411 -> RGB; width in macropixels (what the dispatcher passes, :13755-13795) */
 int csref_yuv411_to_rgb(uint8_t *src, int width_mp, int height, uint8_t *dst, int orow, int out_order, int out_alpha, int clamping) {
   ensure_tables();
@@ -408,6 +416,8 @@ def main():
     parts.append(lines(cs, 7800, 7971))             # K5b: uyvy / yuyv -> yuv(a)444p / yuv(a)888(8) / yuv420p
     parts.append(lines(cs, 2461, 2474))             # K5b: uyvy_2_yuv422, yuyv_2_yuv422
     parts.append(lines(cs, 8035, 8270))             # K5b: yuv(a)888(8) -> yuv420p / yuv422p / uyvy / yuyv, uyvy / yuyv -> yuv422p
+    parts.append(lines(cs, 2322, 2343))             # K4b: rgb2_411
+    parts.append(lines(cs, 6499, 6615))             # K4b: rgb / bgr / argb -> yuv411
     parts.append(lines(cs, 8305, 8620))             # K3b: yuv411 -> rgb / bgr / argb
     parts.append(lines(cs, 9198, 9257))             # K5b: convert_splitplanes_frame
     parts.append(lines(cs, 10578, 10639))           # K5b: convert_halve_chroma, convert_double_chroma

@@ -245,6 +245,8 @@ def main():
     gen_golden_premult_yuv.main()
     import gen_golden_yuv411            # YUV411 -> RGB family
     gen_golden_yuv411.main()
+    import gen_golden_rgb411            # RGB family -> YUV411
+    gen_golden_rgb411.main()
     tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total %d KB" % (tot // 1024))
 

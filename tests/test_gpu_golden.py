@@ -93,6 +93,14 @@ def test_yuv411_vs_reference(gpu):
         assert (host(d) == g["out%d" % n]).all(), (n, wm, h, order, oa, uncl)
 
 
+def test_rgb_to_yuv411_vs_reference(gpu):
+    g = gu.load("rgb_to_yuv411.npz")
+    for n, (w, h, order, ia, uncl, _pad) in enumerate(g["cases"].tolist()):
+        d = dev(np.full_like(g["out%d" % n], 0xA5))
+        gpu.rgb_to_yuv411(dev(g["src%d" % n]), d, w, h, in_order=order, in_alpha=ia, unclamped=uncl)
+        assert (host(d) == g["out%d" % n]).all(), (n, w, h, order, ia, uncl)
+
+
 def test_weed_effects_vs_reference_plugins(gpu):
     g = gu.load("plugins.npz")
     for rec in g["records"]:

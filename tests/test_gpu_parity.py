@@ -174,6 +174,36 @@ def test_yuv411_to_rgb(gpu, orc, order, oa, uncl):
         assert (host(d) == want).all(), (wm, h, pad)
 
 
+@pytest.mark.parametrize("order,ia", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 1)])
+@pytest.mark.parametrize("uncl", [0, 1])
+def test_rgb_to_yuv411(gpu, orc, order, ia, uncl):
+    """RGB family -> YUV411 against the oracle; widths that are not multiples of 4 lose their right edge, padded source rows"""
+    rng = np.random.default_rng(114 + order * 4 + ia * 2 + uncl)
+    ips = 4 if ia else 3
+    for w, h, pad in ((4, 1, 0), (7, 5, 4), (270, 9, 8), (1920, 270, 0), (1023, 3, 16)):
+        src = rng.integers(0, 256, (h, w * ips + pad), dtype=np.uint8)
+        want = np.full((h, (w >> 2) * 6), 0x5A, np.uint8)
+        assert orc.orc_rgb_to_yuv411(P(src), src.strides[0], w, h, order, ia, P(want), uncl) == 0
+        d = dev(np.full_like(want, 0x5A))
+        gpu.rgb_to_yuv411(dev(src), d, w, h, in_order=order, in_alpha=ia, unclamped=uncl)
+        assert (host(d) == want).all(), (w, h, pad)
+
+
+def test_yuv411_round_trip_property(gpu):
+    """size-independent property at 1080p: grey RGB -> YUV411 -> RGB returns the grey ramp within the table rounding, and chroma is neutral"""
+    w, h = 1920, 1080
+    ramp = np.repeat(np.arange(w, dtype=np.int64) * 255 // (w - 1), 3).astype(np.uint8)
+    src = np.tile(ramp, (h, 1))
+    d411 = dev(np.zeros((h, (w >> 2) * 6), np.uint8))
+    gpu.rgb_to_yuv411(dev(src), d411, w, h, unclamped=1)
+    m = host(d411).reshape(h, w >> 2, 6)
+    assert (np.abs(m[:, :, 0].astype(int) - 128) <= 1).all() and (np.abs(m[:, :, 3].astype(int) - 128) <= 1).all()
+    back = dev(np.zeros((h, w * 3), np.uint8))
+    gpu.yuv411_to_rgb(d411, back, w >> 2, h, unclamped=1)
+    assert np.abs(host(back).astype(int) - src.astype(int)).max() <= 2
+    assert (host(back) == host(back)[0]).all()                 # every row identical
+
+
 # ---------------------------------------------------------------------------------------------- K2
 def k2_mask(w, h, is_422):
     m = np.zeros((h, w), bool)

@@ -255,6 +255,27 @@ def test_yuv411_layer_to_rgb(seam, orc, outpl):
         assert (planes[0][:, :wm * 4 * ps] == want[:, :wm * 4 * ps]).all(), (outpl, clamp)
 
 
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("inpl", [RGB24, BGR24, RGBA32, BGRA32, ARGB32])
+def test_rgb_layer_to_yuv411(seam, orc, inpl):
+    L, wh = seam
+    rng = np.random.default_rng(500 + inpl)
+    w, h = 52, 9
+    order = {RGB24: 0, RGBA32: 0, BGR24: 1, BGRA32: 1, ARGB32: 2}[inpl]
+    ips = 3 if inpl in (RGB24, BGR24) else 4
+    for clamp in (0, 1):
+        src = frame(rng, w, h, ips)
+        lay = wh.new_layer(inpl, w, h, [src], gamma=1, flags=1 if ips == 4 else 0)
+        assert L.lives_gpu_convert_layer_palette(lay, 595, clamp) == 1
+        planes, _, rs = wh.planes_of(lay)
+        assert wh.geti(lay, "current_palette") == 595 and wh.geti(lay, "width") == w >> 2 and wh.geti(lay, "YUV_clamping") == clamp
+        want = np.zeros((w >> 2) * 6 * h, np.uint8)
+        assert orc.orc_rgb_to_yuv411(P(src), src.strides[0], w, h, order, 1 if ips == 4 else 0, P(want), clamp) == 0
+        assert (planes[0].reshape(-1)[:want.size] == want).all(), (inpl, clamp)     # compact rows from the start of the plane
+        assert wh.geti(lay, "host_flags", 0) == 0
+
+
 # ---- K4 / K3 on layers: the RGB -> YUV and YUV -> RGB cases of convert_layer_palette_full (src/colourspace.c:12559-13860) ----
 K4_FMT = {588: 0, 589: 0, 544: 1, 545: 1, 564: 2, 565: 3, 512: 4, 513: 4, 522: 5}
 

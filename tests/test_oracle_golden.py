@@ -52,6 +52,16 @@ def test_yuv411_to_rgb(orc):
         assert (got == g["out%d" % n]).all(), (n, wm, h, order, oa, uncl)      # includes the alpha bytes the reference never writes
 
 
+def test_rgb_to_yuv411(orc):
+    """convert_rgb_to_yuv411_frame / _bgr_ / _argb_ (src/colourspace.c:6499-6615)"""
+    g = gu.load("rgb_to_yuv411.npz")
+    for n, (w, h, order, ia, uncl, _pad) in enumerate(g["cases"].tolist()):
+        src = np.ascontiguousarray(g["src%d" % n])
+        got = np.full_like(g["out%d" % n], 0xA5)
+        assert orc.orc_rgb_to_yuv411(P(src), src.strides[0], w, h, order, ia, P(got), uncl) == 0
+        assert (got == g["out%d" % n]).all(), (n, w, h, order, ia, uncl)
+
+
 def test_gamma_luts(orc):
     g = gu.load("luts.npz")
     n = 0
