@@ -240,6 +240,16 @@ def main():
     t = timeit(lambda i: rd.process(r24[i], o24[i], w, h, 1, 20, on, st), NB)
     add("RGBdelay RGB24 (default: 3 taps of a 9-frame ring)", "RGBdelay.c:135-416", "1920x1080", w * h * 3 * (1 + 1 + 3 + 1), t, None)
     rd.close()
+    # ---- later additions: YUVA premultiply, YUV411 <-> RGB ------------------------------------------------------------------------------
+    ya = dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.alpha_premult_yuva([ya[i]], w, h, 589, 1, un=0), NB)
+    add("alpha_premult YUVA8888 clamped (in place, 64 KB tables)", "colourspace.c:12087-12096", "1920x1080", w * h * 8, t, None)
+    m411 = [torch.randint(0, 256, (h, (w >> 2) * 6), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NB)]
+    o32 = dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.yuv411_to_rgb(m411[i], o32[i], w >> 2, h, out_order=0, out_alpha=1), NB)
+    add("YUV411 -> RGBA32", "colourspace.c:8305-8411", "1920x1080", w * h * 6 // 4 + w * h * 4, t, None)
+    t = timeit(lambda i: ops.rgb_to_yuv411(o32[i], m411[i], w, h, in_order=0, in_alpha=1), NB)
+    add("RGBA32 -> YUV411", "colourspace.c:6499-6540", "1920x1080", w * h * 6 // 4 + w * h * 4, t, None)
 
     print("| op | reference | size | algorithmic bytes | GPU us | GB/s | of 8 TB/s | oracle 1-thread ms | ratio |\n|---|---|---|---|---|---|---|---|---|")
     for r in rows:
