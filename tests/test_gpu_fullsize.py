@@ -133,3 +133,31 @@ def test_involutions_at_4k(gpu):
     gpu.byte_luts(src, a, w, h, 4, neg)
     gpu.byte_luts(a, b, w, h, 4, neg)
     assert torch.equal(b, src)
+
+
+def test_yuva_premult_4k_properties(gpu, orc):
+    """alpha_premult on a 3840x2160 YUVA4444P layer: full compare with the oracle (clamped tables), and on the unclamped tables the
+    size-independent facts alpha 255 -> unchanged in both directions (the tables' ratio is 1 there; what alpha 0 gives is the reference's
+    inf / NaN conversion, left to the oracle compare)"""
+    rng = np.random.default_rng(4010)
+    w, h = 3840, 2160
+    planes = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(4)]
+    planes[3][: h // 2] = 255
+    planes[3][h // 2: h // 2 + 64] = 0
+    want = [p.copy() for p in planes]
+    pp = (ctypes.c_void_p * 4)(*[x.ctypes.data for x in want])
+    ss = (ctypes.c_int * 4)(*[x.strides[0] for x in want])
+    orc.orc_alpha_premult_yuva(pp, ss, w, h, 545, 1, 0)
+    ds = [dev(p) for p in planes]
+    gpu.alpha_premult_yuva(ds, w, h, 545, 1, un=0)
+    for i in range(4):
+        assert (host(ds[i]) == want[i]).all(), "clamped plane %d" % i
+    ds = [dev(p) for p in planes]
+    gpu.alpha_premult_yuva(ds, w, h, 545, 0, un=0)
+    for i in range(3):
+        got = host(ds[i])
+        assert (got[: h // 2] == planes[i][: h // 2]).all()
+    gpu.alpha_premult_yuva(ds, w, h, 545, 0, un=1)
+    for i in range(3):
+        assert (host(ds[i])[: h // 2] == planes[i][: h // 2]).all()
+    assert (host(ds[3]) == planes[3]).all()                      # the alpha plane is only read
