@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -307,6 +307,16 @@ def main():
                 d = dev(init)
                 ops.yuv411_to_rgb(dev(src), d, wm, h, out_order=order, out_alpha=oa, unclamped=uncl)
                 ok = same(host(d), want, want.shape[1], h, "yuv411 %dx%d order=%d alpha=%d unclamped=%d" % (wm, h, order, oa, uncl))
+            elif kind == "rgb411":
+                w, h = int(rng.integers(4, 700)), int(rng.integers(1, 60))
+                order, uncl = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+                ia = 1 if order == 2 else int(rng.integers(0, 2))
+                src = rng.integers(0, 256, (h, w * (4 if ia else 3) + int(rng.integers(0, 9))), dtype=np.uint8)
+                want = np.full((h, (w >> 2) * 6), 0x5A, np.uint8)
+                orc.orc_rgb_to_yuv411(P(src), src.strides[0], w, h, order, ia, P(want), uncl)
+                d = dev(np.full_like(want, 0x5A))
+                ops.rgb_to_yuv411(dev(src), d, w, h, in_order=order, in_alpha=ia, unclamped=uncl)
+                ok = same(host(d), want, want.shape[1], h, "rgb411 %dx%d order=%d alpha=%d unclamped=%d" % (w, h, order, ia, uncl))
             elif kind == "luma":
                 pal = int(rng.integers(1, 5))
                 ps, order = (3 if pal <= 2 else 4), (0 if pal in (1, 3) else 1)
