@@ -58,6 +58,10 @@ int lgpu_conversion_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb);
 /* replaces create_gamma_lut8 (src/colourspace.c:655-736), same return convention: 1 = LUT written,
    0 = no conversion needed (the reference returns NULL) */
 int lgpu_gamma_lut8(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint8_t lut[256]);
+/* chroma blend, translucent pixels (simple_blend.c:137-145): constants with (c * k2[a]) >> 16 == (uint8_t)((float)c * alpha)
+   and (c * k1[a]) >> 16 == (uint8_t)((float)c * (1 - alpha)) for every byte c, alpha = (float)a / 255.; proven for all
+   operand pairs while the table is built (HOST function).  a = 255: 65536 (the reference does not scale opaque pixels) */
+int lgpu_alpha_scalers(uint32_t k2[256], uint32_t k1[256]);
 /* create_gamma_lut (src/colourspace.c:738-808): 65536 x uint16; returns 1 if a LUT was produced (HOST function) */
 int lgpu_gamma_lut16(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint16_t *lut16);
 /* rowstride rule; replaces calc_rowstrides (src/colourspace.c:11252-11366) for an explicit alignment

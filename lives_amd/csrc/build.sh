@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (no v_accvgpr_read per accumulator in the VALU-bound chain kernel)
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form ${LGPU_EXTRA_FLAGS}"
 OBJ=build
 mkdir -p $OBJ
 pids=()

@@ -126,6 +126,35 @@ int lgpu_conversion_tables(int which, int32_t *rgb2yuv, int32_t *yuv2rgb) {
   return LGPU_OK;
 }
 
+// The chroma blend's scaling of translucent pixels (lives-plugins/weed-plugins/simple_blend.c:137-145):
+//   alpha = (float)a / 255., inv_alpha = 1. - alpha;  s2 = (uint8_t)((float)c2 * alpha);  s1 = (uint8_t)((float)c1 * inv_alpha)
+// as integer arithmetic: for every alpha a there is a constant K with (c * K) >> 16 == (uint8_t)((float)c * factor) for all
+// c in 0..255 (the float product truncated).  The builder evaluates the reference's expression for all 2 x 65,536 operand
+// pairs and intersects the admissible K intervals, so a table it returns is proven; LGPU_E_UNSUPPORTED if some alpha had
+// none (never on IEEE hosts).  k2[a] scales layer 2 by alpha, k1[a] scales the track by 1 - alpha; a = 255 is the opaque
+// branch of the reference (:128-131, no scaling at all): both constants are 65536, the identity.
+int lgpu_alpha_scalers(uint32_t k2[256], uint32_t k1[256]) {
+  for (int a = 0; a < 256; a++) {
+    const float alpha = (float)a / 255., inv_alpha = 1. - alpha;
+    for (int which = 0; which < 2; which++) {
+      const float f = which ? inv_alpha : alpha;
+      uint32_t *out = which ? k1 : k2;
+      if (a == 255) { out[a] = 65536u; continue; }
+      int64_t lo = 0, hi = (1 << 24) - 1;                  // 24-bit operand of v_mul_u32_u24
+      if ((uint8_t)((float)0 * f) != 0) return LGPU_E_UNSUPPORTED;
+      for (int c = 1; c < 256; c++) {
+        const int64_t t = (uint8_t)((float)c * f);
+        const int64_t l = ((t << 16) + c - 1) / c, h = (((t + 1) << 16) - 1) / c;     // t * 2^16 <= c * K < (t + 1) * 2^16
+        if (l > lo) lo = l;
+        if (h < hi) hi = h;
+      }
+      if (lo > hi) return LGPU_E_UNSUPPORTED;
+      out[a] = (uint32_t)lo;
+    }
+  }
+  return LGPU_OK;
+}
+
 int lgpu_gamma_lut8(double file_gamma, int gamma_from, int gamma_to, double screen_gamma, uint8_t lut[256]) {
   if (file_gamma == 1.0 &&
       (gamma_to == gamma_from || gamma_to == WEED_GAMMA_UNKNOWN || gamma_from == WEED_GAMMA_UNKNOWN)) return 0;

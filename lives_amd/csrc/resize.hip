@@ -407,39 +407,36 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
 }
 
 // =====================================================================================================================
-// k_half8 -- fast path for an exact 2:1 reduction with a uniform 8-tap filter (the headline 3840x2160 -> 1920x1080
-// bicubic case).  Same arithmetic as k_separable<8,8> (bit-identical output; tests run both), restructured because
-// the generic kernel is VALU-bound on gfx950 (profiles/r01/step1_separable_v1.md: 6.7 VALU wave-instructions per
-// output pixel, integer VOP3 ops issue at ~4.7 clk each):
-//   * the window is staged CHANNEL-PLANAR in LDS (bytes biased by -128 so they are int8),
-//   * the horizontal pass is a banded-Toeplitz product on the matrix cores: per 16 window rows x 16 output columns one
-//     v_mfma_i32_16x16x64_i8 for the high 8 bits of the Q14 taps and one for the low 6 (tap = 64 * hi + lo),
-//     A = 16 rows x 64 consecutive bytes of one channel plane, B = the constant 64 x 16 tap matrix
-//     B[k][n] = tap[k - 2n]; the C/D fragment (4 consecutive window rows per lane) packs straight into the
-//     row-pair int16 layout the vertical pass wants,
-//   * the vertical pass walks down the tile with a 4-deep register window of row pairs and v_dot2c_i32_i16,
-//   * blend + gamma epilogue as before; the per-alpha float factors of the translucent blend path come from a
-//     256-entry table instead of a double-precision divide per pixel.
+// k_half8s -- fast path for an exact 2:1 reduction with a uniform 8-tap filter (the headline 3840x2160 -> 1920x1080
+// bicubic case of lgpu_chain / lgpu_resize).  Same arithmetic as k_separable<8,8> (bit-identical output; the tests
+// run both), restructured because the generic kernel is VALU-bound on gfx950 (profiles/r01/step1_separable_v1.md:
+// integer VOP3 ops issue at ~4.7 clk each) and, as a one-role kernel, parked its waves on VMEM issue
+// (profiles/r01/step3_half8.md).  A workgroup is 4 compute waves + 2 memory waves, two workgroups per CU, persistent
+// and XCD-aware, walking 64 x 16 output tiles:
+//   memory waves : source windows (38 x 136 packed pixels, raw bytes) by global_load_lds into a 2-slot ring, issued a
+//                  tile and a half ahead; once a window has landed its bytes are biased to int8 IN LDS with
+//                  ds_xor_b64 (no VGPR round trip, 41 instructions per window); layer-2 tiles by global_load_lds into a
+//                  2-slot ring; finished tiles read back from their ring slot and stored with 16-byte stores;
+//                  edge-replicate fix-up of frame-border windows
+//   compute waves: LDS, MFMA and VALU only
+//     horizontal : banded-Toeplitz product on the matrix cores over packed RGBA pixels: A = 16 window rows x 64 bytes
+//                  (one ds_read_b128 per lane), v_mfma_i32_16x16x64_i8 twice (Q14 tap = 64 * hi + lo, lo stored
+//                  doubled), B[k][n] = tap[pixel - 2 * column] on matching channels (a BGRA source permutes B).  The
+//                  third 16-row block holds only window rows 32..37: its A rows are ordered so that they come out as
+//                  registers 0 / 1 of lane groups 0..2 and only those are post-processed.
+//     vertical   : lane = column, 4 consecutive output rows per wave, v_dot2c_i32_i16 on row pairs
+//     epilogue   : chroma blend with layer 2 from the ring slot, gamma LUT from LDS, result into the ring slot.  The
+//                  reference's float scaling of translucent pixels, (uint8_t)((float)c * alpha) and
+//                  (uint8_t)((float)c * (1 - alpha)) (simple_blend.c:137-145), is evaluated as (c * K[alpha]) >> 16 with
+//                  two 17-bit constants per alpha from a 2 KB LDS table (host_tables.cpp: lgpu_alpha_scalers proves
+//                  the equality for all 2 x 65,536 operand pairs when it builds the table; alpha = 255 maps to the
+//                  identity, so opaque and translucent pixels share one instruction stream).
+// Two workgroup barriers per tile (A(n): window n / layer-2 n landed and biased, the row-pair buffer free; B(n): row
+// pairs complete and window slot n & 1 free), raw s_barrier so the memory waves' DMA stays in flight across them; they
+// wait with a counted vmcnt that leaves exactly the newest window outstanding.
 // =====================================================================================================================
 typedef int int4v __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
 
-template <int TH>
-struct H8 {
-  static constexpr int kTileH = TH;                    // output rows per tile
-  static constexpr int kRows = 2 * TH + 6;             // window rows
-  static constexpr int kPairs = kRows / 2;             // row pairs
-  static constexpr int kMBlocks = (kRows + 15) / 16;   // 16-row MFMA blocks (rows past kRows are computed and dropped)
-  static constexpr int kJobsPerWave = kMBlocks;        // kMBlocks x 4 column blocks over 4 waves
-  static constexpr int kRowsPerWave = TH / 4;          // vertical pass: consecutive output rows per wave
-  static constexpr int kSrcBytes = kRows * 544;        // packed RGBA window, row pitch 544 B
-  static constexpr int kHBytes = kPairs * kTileW * 16;
-  static constexpr int kItems = kRows * 34;
-  static constexpr int kFull = kItems / kBlock;
-  static constexpr int kTail = kItems - kFull * kBlock;
-  // planes + row-pair buffer + alpha tables + lut + slack for the fragment over-read of the padded row block
-  static constexpr size_t kLds = kSrcBytes + kHBytes + 256 + ((kMBlocks * 16 - kRows) * 544 > kHBytes ? (kMBlocks * 16 - kRows) * 544 - kHBytes : 0) + 256;
-};
 constexpr int kH8Pitch = 544;                   // window row pitch in bytes (136 px; 136 dwords = 8 mod 16): conflict-free for the lane
                                                 //   groups ds_read_b128 really uses ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
 constexpr int kH8Chunks = 34;                   // 16-byte column chunks per window row (134 px -> 33.5)
@@ -447,7 +444,8 @@ constexpr int kH8Chunks = 34;                   // 16-byte column chunks per win
 struct Half8Args {
   int sw, sh, irow, dw, dh, orow;
   const int4v *bfrag;               // device: [2][64] B fragments (hi, lo)
-  const float *alpha_tab;           // device: [2][256] alpha, 1 - alpha (chroma blend translucent path)
+  const uint2 *kscale;              // device: [256] {K2, K1}: layer-2 / track colour scalers per layer-2 alpha (lgpu_alpha_scalers)
+  const float *alpha_tab;           // device: [2][256] alpha, 1 - alpha (round-1 epilogue of the A / B builds)
   uint32_t vc[4];                   // vertical tap pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7), 2 x int16 each
   int swap_rb;
   int blend, irow2;
@@ -455,268 +453,9 @@ struct Half8Args {
   const int32_t *bf_d;
   int use_lut;
   int tiles_x, tiles_y, ntracks;
-  unsigned long long *dbg;          // ABL & 16 (profiling build): per-wave phase cycle sums [grid][4][8]
+  unsigned long long *dbg;          // profiling build (LGPU_PROFILING): per-wave phase cycle sums [grid][6][8]
 };
 
-__device__ __forceinline__ uint32_t ld_px_clamped(const uint8_t *row, int x, int sw) {
-  x = x < 0 ? 0 : x >= sw ? sw - 1 : x;
-  return reinterpret_cast<const uint32_t *>(row)[x];
-}
-
-// per-thread staging state of one tile: up to 6 x 16-byte loads in flight
-struct H8Stage {
-  u32x4_a4 v[6];     // H8<16>: 5 full rounds + tail
-};
-
-template <int TH>
-__device__ __forceinline__ void h8_issue_loads(const Half8Args &a, const uint8_t *src, int tx0, int ty0, int tid, int wave, H8Stage &st) {
-  // item -> (window row r, 16-byte chunk ch); item + 256 -> (r + 7, ch + 18) with carry (256 = 7 * 34 + 18).
-  // Offsets are 32-bit (a frame is far below 4 GB) so the loads use the SGPR-base + VGPR-offset form.
-  constexpr int kItems = H8<TH>::kItems;                      // TH 16: 1292 = 5 * 256 + 12
-  constexpr int kFull = H8<TH>::kFull;                        // full rounds; the left-over items start at wave 0
-  const int sx0 = 2 * tx0 - 3, sy0 = 2 * ty0 - 3;
-  const bool interior = (sx0 >= 0) && (sx0 + 4 * kH8Chunks <= a.sw);   // tile-uniform: no column clamping needed
-  int r = tid / kH8Chunks, ch = tid - r * kH8Chunks;
-#pragma unroll
-  for (int k = 0; k <= kFull; k++) {
-    if (k < kFull || wave * 64 < kItems - kFull * kBlock) {
-      if (k < kFull || tid < kItems - kFull * kBlock) {
-        int sy = sy0 + r;
-        sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
-        const uint32_t rowoff = (uint32_t)sy * (uint32_t)a.irow;
-        const int x = sx0 + ch * 4;
-        if (interior) st.v[k] = *reinterpret_cast<const u32x4_a4 *>(src + (rowoff + (uint32_t)x * 4u));
-        else {
-          const uint8_t *srow = src + rowoff;
-          st.v[k].x = ld_px_clamped(srow, x, a.sw); st.v[k].y = ld_px_clamped(srow, x + 1, a.sw);
-          st.v[k].z = ld_px_clamped(srow, x + 2, a.sw); st.v[k].w = ld_px_clamped(srow, x + 3, a.sw);
-        }
-      }
-    }
-    r += 7; ch += 18;
-    if (ch >= kH8Chunks) { ch -= kH8Chunks; r += 1; }
-  }
-}
-
-template <int TH>
-__device__ __forceinline__ void h8_write_window(uint8_t *s_px, int tid, int wave, const H8Stage &st) {
-  // pixels stay packed (RGBA interleaved); bytes are biased by -128 so the matrix cores see int8
-  constexpr int kItems = H8<TH>::kItems;
-  constexpr int kFull = H8<TH>::kFull;
-  int r = tid / kH8Chunks, ch = tid - r * kH8Chunks;
-#pragma unroll
-  for (int k = 0; k <= kFull; k++) {
-    if (k < kFull || wave * 64 < kItems - kFull * kBlock) {
-      if (k < kFull || tid < kItems - kFull * kBlock) {
-        const u32x4_a4 v = st.v[k];
-        *reinterpret_cast<uint4 *>(s_px + r * kH8Pitch + ch * 16) = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
-      }
-    }
-    r += 7; ch += 18;
-    if (ch >= kH8Chunks) { ch -= kH8Chunks; r += 1; }
-  }
-}
-
-// Persistent workgroups: each loops over (track, tile) work items with stride gridDim.x; the next item's
-// source window is already in flight (registers) while the current one runs its horizontal and vertical passes.
-// ABL: profiling-only ablation mask (0 in production): 1 no blend/LUT epilogue, 2 no vertical dots, 4 no horizontal pass, 8 no staging
-template <int TH, int ABL>
-__global__ __launch_bounds__(kBlock) void k_half8(Half8Args a, SepTracks trk, Lut8 lut) {
-  using C = H8<TH>;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t *s_pl = smem;                                                   // [38][136] packed pixels, int8
-  uint8_t *s_h = smem + C::kSrcBytes;                                      // [19][64][4] dwords of 2 x int16
-  uint8_t *s_lut = smem + C::kSrcBytes + C::kHBytes;                        // [256]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
-
-  if (a.use_lut) stage_lut(s_lut, lut);
-  uint32_t bf = a.bf, nbf = a.nbf;
-  if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
-
-  const int4v b_hi = a.bfrag[lane], b_lo = a.bfrag[64 + lane];
-  // The window holds px - 128 and the taps sum to 16384, so the matrix product is 128 * (t - 16384) for the spec's
-  // t = clamp_i16((h + 64) >> 7): the intermediate is kept as t' = t - 16384 (fits int16 without wrapping for the
-  // filters try_half8 admits), the clamp becomes min(t', 16383), and the vertical pass adds 16384 * sum(vc) = 2^28 back.
-  // The low-part taps are stored doubled so that t' sits in bits 8..23 of (dh << 7) + dl: a byte permute extracts it.
-  const int kb = 128;                                     // 2 * 64: the rounding of >> 7, doubled
-  const int4v cbias = {kb, kb, kb, kb};
-  const short2v tmax = {16383, 16383};
-  const short2v vc0 = __builtin_bit_cast(short2v, a.vc[0]), vc1 = __builtin_bit_cast(short2v, a.vc[1]);
-  const short2v vc2 = __builtin_bit_cast(short2v, a.vc[2]), vc3 = __builtin_bit_cast(short2v, a.vc[3]);
-
-  // XCD-aware work list: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  Each XCD
-  // takes one contiguous eighth of the (track, tile) list and its workgroups walk it together, so the
-  // window halos shared by neighbouring tiles are hits in that XCD's own L2 instead of second HBM fetches.
-  const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3);
-  const int chunk = (nwork + 7) >> 3;
-  const int wend = min((xcd + 1) * chunk, nwork);
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-#define H8_T(i)                                                                                       \
-  if (ABL & 16) {                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                     \
-    tacc[i] += now_ - tprev; tprev = now_;                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-  }
-  H8Stage st;
-  int work = xcd * chunk + (int)(blockIdx.x >> 3);
-  if (work < wend) {
-    const int track = work / tiles, tile = work - track * tiles;
-    if (!(ABL & 8)) h8_issue_loads<TH>(a, trk.src[track], (tile % a.tiles_x) * kTileW, (tile / a.tiles_x) * C::kTileH, tid, wave, st);
-  }
-  if (ABL & 16) tprev = __builtin_amdgcn_s_memtime();
-  for (; work < wend; work += wstride) {
-    const int track = work / tiles, tile = work - track * tiles;
-    const int tx0 = (tile % a.tiles_x) * kTileW, ty0 = (tile / a.tiles_x) * C::kTileH;
-    const int tw = min(kTileW, a.dw - tx0), thh = min(C::kTileH, a.dh - ty0);
-
-    // ---- 1. transpose the staged window to int8 channel planes in LDS ----
-    H8_T(7)
-    if (!(ABL & 8)) h8_write_window<TH>(s_pl, tid, wave, st);
-    H8_T(0)
-    __syncthreads();
-    H8_T(1)
-
-    // next work item's window: issue its loads now, they complete while this tile computes
-    {
-      const int nxt = work + wstride;
-      if (nxt < wend) {
-        const int ntrack = nxt / tiles, ntile = nxt - ntrack * tiles;
-        if (!(ABL & 8)) h8_issue_loads<TH>(a, trk.src[ntrack], (ntile % a.tiles_x) * kTileW, (ntile / a.tiles_x) * C::kTileH, tid, wave, st);
-      }
-    }
-    // layer-2 pixels of this wave's output rows (consumed in the epilogue)
-    constexpr int RPW = C::kRowsPerWave;
-    const int ly0 = wave * RPW;
-    uint32_t q2[RPW];
-    {
-      const uint8_t *l2 = trk.l2[track];
-#pragma unroll
-      for (int i = 0; i < RPW; i++) {
-        const int oy = ty0 + ly0 + i;
-        q2[i] = (a.blend && lane < tw && ly0 + i < thh) ? reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[tx0 + lane] : 0xFF000000u;
-      }
-    }
-
-    H8_T(2)
-    // ---- 2. horizontal pass on the matrix cores ----
-    // A = 16 window rows x 64 bytes (16 packed pixels), B[k = (pixel, channel)][n = (column, channel)] = tap[pixel - 2 * column]
-    // on matching channels: one (mb, nb) job yields 4 output columns x 4 channels for 16 rows.  kMBlocks row blocks
-    // (rows past the window are computed and dropped) x 16 column blocks; wave w owns column blocks 4w .. 4w+3.
-    if (!(ABL & 4)) {
-      const int m = lane & 15, g = lane >> 4;
-#pragma unroll
-      for (int mb = 0; mb < C::kMBlocks; mb++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int nb = wave * 4 + q;
-          const int4v av = *reinterpret_cast<const int4v *>(s_pl + (mb * 16 + m) * kH8Pitch + nb * 32 + g * 16);
-          int4v zero = {0, 0, 0, 0};
-          const int4v dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_hi, zero, 0, 0, 0);
-          const int4v dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_lo, cbias, 0, 0, 0);
-          const uint32_t x0 = (uint32_t)((dh[0] << 7) + dl[0]), x1 = (uint32_t)((dh[1] << 7) + dl[1]);
-          const uint32_t x2 = (uint32_t)((dh[2] << 7) + dl[2]), x3 = (uint32_t)((dh[3] << 7) + dl[3]);
-          const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
-          const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
-          // lane holds window rows mb*16 + 4g + {0..3} = row pairs mb*8 + 2g + {0,1} of (column nb*4 + (m >> 2), channel m & 3)
-          const int pr = mb * 8 + 2 * g;
-          uint32_t *hp = reinterpret_cast<uint32_t *>(s_h) + (pr * kTileW + nb * 4) * 4 + m;
-          if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
-          if (pr + 1 < C::kPairs) hp[kTileW * 4] = __builtin_bit_cast(uint32_t, q1);
-        }
-      }
-    }
-    H8_T(3)
-    __syncthreads();
-    H8_T(4)
-
-    // ---- 3. vertical pass (lane = column, wave = RPW consecutive output rows) + epilogue ----
-    // Straight-line over the wave's RPW rows: all row-pair reads first, then all dots, then the blend, then all LUT
-    // reads, then the stores -- so LDS / VMEM latencies overlap instead of being paid once per row.
-    {
-      uint8_t *dst = trk.dst[track];
-      const uint4 *col = reinterpret_cast<const uint4 *>(s_h) + lane;
-      uint4 w[RPW + 3];
-#pragma unroll
-      for (int i = 0; i < RPW + 3; i++) w[i] = col[(ly0 + i) * kTileW];
-      uint32_t px[RPW];
-#pragma unroll
-      for (int i = 0; i < RPW; i++) {
-        const int vr = (1 << 20) + (1 << 28);     // rounding of >> 21 + the 16384 * 16384 of the t' = t - 16384 bias
-        int a0 = vr, a1 = vr, a2 = vr, a3 = vr;
-#define H8_DOT(acc, fld)                                                                        \
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i].fld), vc0, acc, false);     \
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 1].fld), vc1, acc, false); \
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 2].fld), vc2, acc, false); \
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i + 3].fld), vc3, acc, false);
-        if (!(ABL & 2)) { H8_DOT(a0, x) H8_DOT(a1, y) H8_DOT(a2, z) H8_DOT(a3, w) } else { a0 = w[i].x; a1 = w[i + 1].y; a2 = w[i + 2].z; a3 = w[i + 3].w; }
-#undef H8_DOT
-        px[i] = (ABL & 2) ? (uint32_t)(a0 ^ a1 ^ a2 ^ a3) : pack_sat_shr21(a0, a1, a2, a3);
-      }
-      H8_T(5)
-      if (a.blend && !(ABL & 1)) {
-        const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
-        bool opaque = true;
-#pragma unroll
-        for (int i = 0; i < RPW; i++) opaque = opaque && ((q2[i] >> 24) == 255);
-        if (__all(opaque)) {        // wave-uniform: no translucent layer-2 pixel in this wave's rows
-#pragma unroll
-          for (int i = 0; i < RPW; i++) px[i] = mix3_dot4(px[i], q2[i], w_lo, w_hi) | (px[i] & 0xFF000000u);
-        } else {
-          // (uint8_t)((float)c * alpha) with alpha = (float)a / 255., inv_alpha = 1. - alpha  (simple_blend.c:137-146)
-          float alpha[RPW], inv[RPW];
-#pragma unroll
-          for (int i = 0; i < RPW; i++) { const uint32_t al = q2[i] >> 24; alpha[i] = a.alpha_tab[al]; inv[i] = a.alpha_tab[256 + al]; }
-#pragma unroll
-          for (int i = 0; i < RPW; i++) {
-            const uint32_t q = q2[i], p = px[i];
-            const uint32_t f2 = (uint32_t)__fmul_rn((float)((q >> 0) & 0xFF), alpha[i]) | ((uint32_t)__fmul_rn((float)((q >> 8) & 0xFF), alpha[i]) << 8) |
-                                ((uint32_t)__fmul_rn((float)((q >> 16) & 0xFF), alpha[i]) << 16);
-            const uint32_t f1 = (uint32_t)__fmul_rn((float)((p >> 0) & 0xFF), inv[i]) | ((uint32_t)__fmul_rn((float)((p >> 8) & 0xFF), inv[i]) << 8) |
-                                ((uint32_t)__fmul_rn((float)((p >> 16) & 0xFF), inv[i]) << 16);
-            const bool op = (q >> 24) == 255;
-            px[i] = mix3_dot4(op ? p : f1, op ? q : f2, w_lo, w_hi) | (p & 0xFF000000u);
-          }
-        }
-      }
-      if (a.use_lut && !(ABL & 1)) {
-        uint32_t r[RPW], g[RPW], b[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; i++) { r[i] = s_lut[px[i] & 0xFF]; g[i] = s_lut[(px[i] >> 8) & 0xFF]; b[i] = s_lut[(px[i] >> 16) & 0xFF]; }
-#pragma unroll
-        for (int i = 0; i < RPW; i++) px[i] = r[i] | (g[i] << 8) | (b[i] << 16) | (px[i] & 0xFF000000u);
-      }
-#pragma unroll
-      for (int i = 0; i < RPW; i++)
-        if (ly0 + i < thh && lane < tw) reinterpret_cast<uint32_t *>(dst + (size_t)(ty0 + ly0 + i) * a.orow)[tx0 + lane] = px[i];
-    }
-    H8_T(6)
-    // no barrier here: the next iteration writes only the planes (last read before the barrier above);
-    // s_h is rewritten after the next iteration's first barrier, which every wave reaches only after this pass
-  }
-  if ((ABL & 16) && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tacc[i];
-  }
-#undef H8_T
-}
-
-// =====================================================================================================================
-// k_half8s: the k_half8 tile pipeline with a memory wave and LDS-DMA rings.
-// Phase timing of k_half8 (s_memtime, profiles/r01) showed its waves parked in-order on VMEM issue (window prefetch,
-// layer-2 loads, the table gather, the stores) for over half of each tile while their matrix / vector work waited
-// behind.  Here a workgroup is 4 compute waves + 1 memory wave, two workgroups per CU:
-//   memory wave : source windows by global_load_lds (no registers, no ds_write) into a 2-slot ring, issued a tile and
-//                 a half ahead; layer-2 tiles by global_load_lds into a 2-slot ring; finished tiles read back from
-//                 their ring slot and stored with 16-byte stores; edge-replicate fix-up of frame-border windows
-//   compute wave: LDS, MFMA and VALU only -- horizontal pass (pixels biased to int8 as the fragments are read),
-//                 vertical pass, blend (layer 2 from the ring slot), LUT, result into the same ring slot
-// Two workgroup barriers per tile (A(n): window n / layer-2 n landed and the row-pair buffer free, B(n): row pairs
-// complete and window slot n & 1 free), raw s_barrier so the memory wave's DMA stays in flight across them; it
-// waits with a counted vmcnt that leaves exactly the newest window outstanding.
-// =====================================================================================================================
 constexpr int kH8sCW = 4;                        // compute waves per workgroup (+ 2 memory waves)
 constexpr int kH8sThreads = (kH8sCW + 2) * 64;
 struct H8S {
@@ -727,20 +466,32 @@ struct H8S {
   static constexpr int kRounds = 21, kTailLanes = 12;
   static constexpr int kHPitch = 264;                  // dwords per row pair of the intermediate: 256 + 8, so the four row groups of an
                                                        //   MFMA result (pairs 2g, g = 0..3) land on different LDS banks (2 * 264 * g mod 64 = 16 g)
-  static constexpr int kSplit = 11;                    // DMA instructions 0..10: memory wave 4, 11..20: memory wave 5
-};
-template <int NSLOT>                                    // window slots: 2 (two workgroups per CU) or 1 (three per CU)
-struct H8SL {
-  static constexpr int kOffH = NSLOT * H8S::kWinBytes;                       // 41344 / 20672
-  static constexpr int kOffQ = kOffH + H8S::kPairs * H8S::kHPitch * 4;         // 2 x [16][64] pixels
+  static constexpr int kOffH = 2 * kWinBytes;                        // 41344: [19][264] dwords of 2 x int16
+  static constexpr int kOffQ = kOffH + kPairs * kHPitch * 4;         // 2 x [16][64] pixels: layer 2 in, finished tile out
   static constexpr int kOffLut = kOffQ + 2 * 4096;
-  static constexpr int kOffAlpha = kOffLut + 256;                            // float[256]
-  static constexpr size_t kLds = kOffAlpha + 1024;                           // 70272 / 49600
+  static constexpr int kOffK = kOffLut + 256;                        // uint2[256]
+  static constexpr size_t kLds = kOffK + 2048;                       // 71904: two workgroups per CU
 };
 
 #define H8S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef const __attribute__((address_space(1))) void *h8s_gptr;
 typedef __attribute__((address_space(3))) void *h8s_lptr;
+
+// bytes [b0, b1) of a landed window ^= 0x80 (uint8 -> int8 for the matrix cores), 8 bytes per lane and instruction,
+// executed by the LDS itself.  b0, b1 multiples of 8.  Ordered behind the caller's counted vmcnt (the DMA data is
+// there) and in front of barrier A by its lgkmcnt(0).
+template <int B0, int B1>
+__device__ __forceinline__ void h8s_bias_window(uint8_t *win, int lane) {
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  const u32x2v m = {0x80808080u, 0x80808080u};
+  const uint32_t addr = (uint32_t)(uintptr_t)(h8s_lptr)win + (uint32_t)lane * 8u;
+#pragma unroll
+  for (int off = B0; off < B1; off += 512) {
+    if (off + 512 <= B1) asm volatile("ds_xor_b64 %0, %1 offset:%2" :: "v"(addr), "v"(m), "n"(off) : "memory");
+    else if (off + lane * 8 < B1) asm volatile("ds_xor_b64 %0, %1 offset:%2" :: "v"(addr), "v"(m), "n"(off) : "memory");
+  }
+}
+
 
 // window chunk c = 64 k + lane (16 bytes, LDS offset 16 c: a row is exactly 34 chunks) <- source row sy0 + c / 34,
 // pixels sx0 + 4 (c % 34) ..+3; rows are clamped to the frame here, columns are fetched from the nearest in-frame
@@ -884,8 +635,12 @@ struct H8sTile {
   __device__ __forceinline__ int ty0() const { return ty * H8S::kTileH; }
 };
 
-template <int DBG, int NSLOT>
-__global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
+// OPT (bit mask; production = 7, the other values exist for the A / B rows of profiles/r02):
+//   1  the landed window is biased to int8 in LDS by the memory waves (else: 48 v_xor per compute wave and tile)
+//   2  third row block: only registers 0 / 1 post-processed (else: all four, half of them dropped)
+//   4  epilogue with the integer alpha scalers and the LUT gathered straight from the mix sums (else: round-1 float path)
+template <int DBG, int OPT>
+__global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
   using C = H8S;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define H8S_T(i)                                                                                     \
@@ -896,81 +651,37 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
     __builtin_amdgcn_sched_barrier(0);                                                                \
   }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t *s_win = smem;                         // 2 x [38][136] packed source pixels (raw bytes)
-  using L = H8SL<NSLOT>;
-  uint8_t *s_h = smem + L::kOffH;                // [19][64][4] dwords of 2 x int16
-  uint8_t *s_q = smem + L::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
-  uint8_t *s_lut = smem + L::kOffLut;
-  float *s_alpha = reinterpret_cast<float *>(smem + L::kOffAlpha);
+  uint8_t *s_win = smem;                         // 2 x [38][136] packed source pixels
+  uint8_t *s_h = smem + C::kOffH;                // [19][264] dwords of 2 x int16
+  uint8_t *s_q = smem + C::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
+  uint8_t *s_lut = smem + C::kOffLut;
+  uint2 *s_k = reinterpret_cast<uint2 *>(smem + C::kOffK);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
   if (a.use_lut) stage_lut(s_lut, lut);
-  if (a.blend && tid < 256) s_alpha[tid] = a.alpha_tab[tid];
+  if (a.blend && tid < 256) {
+    if (OPT & 4) s_k[tid] = a.kscale[tid];
+    else reinterpret_cast<float *>(s_k)[tid] = a.alpha_tab[tid];
+  }
 
-  // XCD-aware persistent work list (see k_half8)
+  // XCD-aware persistent work list: each XCD owns a contiguous eighth of the (track, tile) list, so that the window
+  // halos of neighbouring tiles hit that XCD's L2
   const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3);
   const int chunk = (nwork + 7) >> 3;
   const int wend = min((xcd + 1) * chunk, nwork);
   int work = xcd * chunk + (int)(blockIdx.x >> 3);
   if (work >= wend) return;                       // workgroup-uniform
 
-  if (NSLOT == 1 && wave >= kH8sCW) {
-    // -------------------------------------- memory waves, one window slot --------------------------------------
-    // three workgroups per CU hide the fetch latency by occupancy instead of a second slot:
-    //   A(n) | wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1 | B(n): the window is
-    //   free | window DMA n+1 (wave 4: requests 0..10, wave 5: 11..20) | drain | edge fix-up | A(n+1)
-    constexpr int KS = 11;
-    const bool w5 = wave == kH8sCW + 1;
-    H8sLaneOff lo;
-    h8s_lane_offsets(a, lane, lo);
-    H8sTile t0, t1;
-    t0.init(a, work, wstride); t1 = t0; t1.step();
-    if (w5) {
-      if (a.blend) h8s_issue_q2(a, trk.l2[t0.track], t0.tx0(), t0.ty0(), lane, s_q);
-      h8s_issue_window<KS, C::kRounds>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
-    } else h8s_issue_window<0, KS>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, w5 ? KS * 64 : 0, w5 ? C::kRounds * 64 : KS * 64);
-    H8sTile tp = t0;
-    bool has_prev = false;
-    int par = 0;
-    for (; work < wend; work += wstride) {
-      H8S_BARRIER();                                                                   // A(n)
-      const bool has_next = work + wstride < wend;
-      if (w5) {
-        uint4 ov[4];
-        if (has_prev) h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
-        if (has_next && a.blend) h8s_issue_q2(a, trk.l2[t1.track], t1.tx0(), t1.ty0(), lane, s_q + (par ^ 1) * 4096);
-        if (has_prev) h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
-      }
-      H8S_BARRIER();                                                                   // B(n)
-      if (has_next) {
-        if (w5) h8s_issue_window<KS, C::kRounds>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win, lo);
-        else h8s_issue_window<0, KS>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win, lo);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (has_next && h8s_border(t1.tx0(), a.sw)) h8s_fix_edges(s_win, t1.tx0(), a.sw, lane, w5 ? KS * 64 : 0, w5 ? C::kRounds * 64 : KS * 64);
-      tp = t0; has_prev = true; t0 = t1; t1.step();
-      par ^= 1;
-    }
-    H8S_BARRIER();                                                                     // A(last + 1)
-    if (w5) {
-      uint4 ov[4];
-      h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
-      h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
-    }
-    return;
-  }
   if (wave >= kH8sCW) {
     // ------------------------------------------------ memory waves ------------------------------------------------
     __builtin_amdgcn_s_setprio(3);     // few instructions, all of them feeding the DMA queues: let them issue ahead of the compute waves (-0.8 % per launch)
-    // Wave 4 fetches window DMA instructions 0..10, wave 5 fetches 11..20 and also moves the layer-2 / result tiles.
+    // Wave 4 fetches window DMA instructions 0..15, wave 5 fetches 16..20 and also moves the layer-2 / result tiles.
     // Window n+2 goes to slot n & 1, free after B(n) and needed at A(n+2); each wave issues the first part of its
     // share between B(n) and A(n+1) and the rest between A(n+1) and B(n+1), so both barrier intervals carry traffic:
     //   A(n)   | rest of window n+1; wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1
     //   B(n)   | first part of window n+2 | wait for all but that part: window n+1 (and layer-2 n+1) have landed |
-    //          | edge fix-up of window n+1 (own chunks)
+    //          | edge fix-up and int8 bias of window n+1 (own chunks)
     constexpr int K0 = 0, K1 = 6, K2 = 16, K3 = 21, K4 = 21;     // wave 4: [K0,K1) after B + [K1,K2) after A; wave 5: [K2,K3) after B (+ [K3,K4) after A)
     const bool w5 = wave == kH8sCW + 1;
     H8sLaneOff lo;
@@ -984,11 +695,13 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
       if (has1) { h8s_issue_window<K2, K3>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, K2 * 64, K4 * 64);
+      if (OPT & 1) h8s_bias_window<K2 * 1024, C::kWinBytes>(s_win, lane);
     } else {
       h8s_issue_window<K0, K2>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
       if (has1) { h8s_issue_window<K0, K1>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, K0 * 64, K2 * 64);
+      if (OPT & 1) h8s_bias_window<K0 * 1024, K2 * 1024>(s_win, lane);
     }
     H8sTile tp = t0;                  // tile n-1
     bool has_prev = false;
@@ -1020,8 +733,13 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
         else { h8s_issue_window<K0, K1>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       H8S_T(6)
-      if (has_next && h8s_border(t1.tx0(), a.sw)) {
-        if (w5) h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K2 * 64, K4 * 64); else h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K0 * 64, K2 * 64);
+      if (has_next) {
+        if (h8s_border(t1.tx0(), a.sw)) {
+          if (w5) h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K2 * 64, K4 * 64); else h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K0 * 64, K2 * 64);
+        }
+        if (OPT & 1) {
+          if (w5) h8s_bias_window<K2 * 1024, C::kWinBytes>(w1, lane); else h8s_bias_window<K0 * 1024, K2 * 1024>(w1, lane);
+        }
       }
       tp = t0; has_prev = true; t0 = t1; t1 = t2; t2.step();
       par ^= 1;
@@ -1041,56 +759,76 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
   uint32_t bf = a.bf, nbf = a.nbf;
   if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
   const int4v b_hi = a.bfrag[lane], b_lo = a.bfrag[64 + lane];
-  const int kb = 128;                                     // see k_half8: t' = t - 16384 in bits 8..23 of (dh << 7) + dl
+  // The window holds px - 128 and the taps sum to 16384, so the matrix product is 128 * (t - 16384) for the spec's
+  // t = clamp_i16((h + 64) >> 7): the intermediate is kept as t' = t - 16384 (fits int16 without wrapping for the
+  // filters try_half8 admits), the clamp becomes min(t', 16383), and the vertical pass adds 16384 * sum(vc) = 2^28 back.
+  // The low-part taps are stored doubled so that t' sits in bits 8..23 of (dh << 7) + dl: a byte permute extracts it.
+  const int kb = 128;                                     // 2 * 64: the rounding of >> 7, doubled
   const int4v cbias = {kb, kb, kb, kb};
   const short2v tmax = {16383, 16383};
   const short2v vc0 = __builtin_bit_cast(short2v, a.vc[0]), vc1 = __builtin_bit_cast(short2v, a.vc[1]);
   const short2v vc2 = __builtin_bit_cast(short2v, a.vc[2]), vc3 = __builtin_bit_cast(short2v, a.vc[3]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  constexpr int RPW = C::kRPW;
+  constexpr int RPW = C::kRPW, NQ = C::kNQ;
   const int ly0 = wave * RPW;
   const int m = lane & 15, g = lane >> 4;
+  // A fragments: lane (g, m) supplies row m, bytes 16 g .. 16 g + 15 of the block's 64-byte span.  Blocks 0 / 1 are window
+  // rows 16 mb + m.  Block 2 (OPT & 2): D register r of lane group g is row 4 g + r of the block, so with the block's row
+  // 4 g' + r' := window row 32 + 2 g' + (r' & 1) the six live rows 32..37 come out as registers 0 / 1 of groups 0..2,
+  // already paired the way the vertical pass wants them (row pair 16 + g); group 3 / registers 2, 3 are not looked at.
+  const int arow2 = (OPT & 2) ? 32 + 2 * (m >> 2) + (m & 1) : 32 + m;
+  const uint32_t aoff = (uint32_t)(m * kH8Pitch + wave * (NQ * 32) + g * 16);
+  const uint32_t aoff2 = (uint32_t)(arow2 * kH8Pitch + wave * (NQ * 32) + g * 16);
   int par = 0;
   if (DBG) tprev = __builtin_amdgcn_s_memtime();
   for (; work < wend; work += wstride) {
     H8S_T(0)
     H8S_BARRIER();                                                                     // A(n)
     H8S_T(1)
-    // ---- horizontal pass on the matrix cores (k_half8 section 2); the window holds raw bytes, biased here ----
+    // ---- horizontal pass on the matrix cores ----
     // Software pipelined over the three 16-row blocks: the four A fragments of block mb + 1 are read while block mb is
     // on the matrix pipe, and a block's eight MFMAs are issued back to back before any result is consumed.
-    const uint8_t *s_pl = s_win + (NSLOT == 2 ? par : 0) * C::kWinBytes;
+    const uint8_t *s_pl = s_win + par * C::kWinBytes;
     {
-      constexpr int NQ = C::kNQ;
-      const uint8_t *abase = s_pl + m * kH8Pitch + wave * (NQ * 32) + g * 16;  // + mb * 16 rows + q * 32
       uint32_t *hbase = reinterpret_cast<uint32_t *>(s_h) + wave * (NQ * 16) + m;   // + pr * kHPitch + q * 16
       int4v av[NQ], an[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; q++) av[q] = *reinterpret_cast<const int4v *>(abase + q * 32);
+      for (int q = 0; q < NQ; q++) av[q] = *reinterpret_cast<const int4v *>(s_pl + aoff + q * 32);
 #pragma unroll
       for (int mb = 0; mb < C::kMBlocks; mb++) {
         if (mb + 1 < C::kMBlocks) {
 #pragma unroll
-          for (int q = 0; q < NQ; q++) an[q] = *reinterpret_cast<const int4v *>(abase + (mb + 1) * 16 * kH8Pitch + q * 32);
+          for (int q = 0; q < NQ; q++)
+            an[q] = *reinterpret_cast<const int4v *>(s_pl + (mb + 1 == 2 ? aoff2 : aoff + (mb + 1) * 16 * kH8Pitch) + q * 32);
         }
         int4v dh[NQ], dl[NQ];
         const int4v zero = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-          const int4v ab = av[q] ^ (int)0x80808080;
+          const int4v ab = (OPT & 1) ? av[q] : av[q] ^ (int)0x80808080;
           dh[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_hi, zero, 0, 0, 0);
           dl[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_lo, cbias, 0, 0, 0);
         }
-        const int pr = mb * 8 + 2 * g;
+        if (mb == 2 && (OPT & 2)) {
+          const int pr = 16 + g;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const uint32_t x0 = (uint32_t)((dh[q][0] << 7) + dl[q][0]), x1 = (uint32_t)((dh[q][1] << 7) + dl[q][1]);
-          const uint32_t x2 = (uint32_t)((dh[q][2] << 7) + dl[q][2]), x3 = (uint32_t)((dh[q][3] << 7) + dl[q][3]);
-          const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
-          const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
-          uint32_t *hp = hbase + pr * C::kHPitch + q * 16;
-          if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
-          if (pr + 1 < C::kPairs) hp[C::kHPitch] = __builtin_bit_cast(uint32_t, q1);
+          for (int q = 0; q < NQ; q++) {
+            const uint32_t x0 = (uint32_t)((dh[q][0] << 7) + dl[q][0]), x1 = (uint32_t)((dh[q][1] << 7) + dl[q][1]);
+            const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
+            if (g < 3) hbase[pr * C::kHPitch + q * 16] = __builtin_bit_cast(uint32_t, q0);
+          }
+        } else {
+          const int pr = mb * 8 + 2 * g;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const uint32_t x0 = (uint32_t)((dh[q][0] << 7) + dl[q][0]), x1 = (uint32_t)((dh[q][1] << 7) + dl[q][1]);
+            const uint32_t x2 = (uint32_t)((dh[q][2] << 7) + dl[q][2]), x3 = (uint32_t)((dh[q][3] << 7) + dl[q][3]);
+            const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
+            const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
+            uint32_t *hp = hbase + pr * C::kHPitch + q * 16;
+            if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
+            if (pr + 1 < C::kPairs) hp[C::kHPitch] = __builtin_bit_cast(uint32_t, q1);
+          }
         }
         if (mb + 1 < C::kMBlocks) {
 #pragma unroll
@@ -1101,7 +839,7 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
     H8S_T(2)
     H8S_BARRIER();                                                                     // B(n)
     H8S_T(3)
-    // ---- vertical pass + epilogue (k_half8 section 3); layer 2 comes from / the result goes to the ring slot ----
+    // ---- vertical pass + epilogue; layer 2 comes from / the result goes to the ring slot ----
     {
       uint32_t *qs = reinterpret_cast<uint32_t *>(s_q + par * 4096) + ly0 * kTileW + lane;
       const uint4 *col = reinterpret_cast<const uint4 *>(s_h) + lane;
@@ -1125,56 +863,102 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
 #undef H8_DOT
         px[i] = pack_sat_shr21(a0, a1, a2, a3);
       }
-      if (a.blend) {
-        const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
-        bool opaque = true;
+      if (OPT & 4) {
+        if (a.blend) {
+          // mix sums r_c = bf * s2_c + nbf * s1_c (< 2^16, the blended byte is r_c >> 8) for the three colour channels
+          const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+          uint32_t r0[RPW], r1[RPW], r2[RPW];
+          bool opaque = true;
 #pragma unroll
-        for (int i = 0; i < RPW; i++) opaque = opaque && ((q2[i] >> 24) == 255);
-        if (__all(opaque)) {
+          for (int i = 0; i < RPW; i++) opaque = opaque && (q2[i] >= 0xFF000000u);
+          if (__all(opaque)) {           // what decoded video is: no scaling (simple_blend.c:128-131)
 #pragma unroll
-          for (int i = 0; i < RPW; i++) px[i] = mix3_dot4(px[i], q2[i], w_lo, w_hi) | (px[i] & 0xFF000000u);
-        } else {
-          // (uint8_t)((float)c * alpha), alpha = (float)a / 255. from the table, inv_alpha = 1. - alpha: the double
-          // difference of a float in [0, 1] from 1 is exact, so its float rounding is the float subtraction
-          float alpha[RPW], inv[RPW];
+            for (int i = 0; i < RPW; i++) {
+              const uint32_t x01 = __builtin_amdgcn_perm(px[i], q2[i], 0x05010400u);     // [q.b0 p.b0 q.b1 p.b1]
+              const uint32_t x2 = __builtin_amdgcn_perm(px[i], q2[i], 0x0C0C0602u);      // [q.b2 p.b2 0 0]
+              r0[i] = __builtin_amdgcn_udot4(x01, w_lo, 0u, false); r1[i] = __builtin_amdgcn_udot4(x01, w_hi, 0u, false);
+              r2[i] = __builtin_amdgcn_udot4(x2, w_lo, 0u, false);
+            }
+          } else {
+            // s2_c = (q_c * K2[alpha]) >> 16, s1_c = (p_c * K1[alpha]) >> 16: byte 2 of a 24-bit product each
+            uint2 kk[RPW];
 #pragma unroll
-          for (int i = 0; i < RPW; i++) { alpha[i] = s_alpha[q2[i] >> 24]; inv[i] = __fsub_rn(1.0f, alpha[i]); }
-          // the products are rounded to nearest as in the reference; their truncation to a byte and the packing are one
-          // v_cvt_pk_u8_f32 each, which rounds by MODE.fp_round: switched to toward-zero for exactly those instructions
-          uint32_t f1[RPW], f2[RPW];
+            for (int i = 0; i < RPW; i++) kk[i] = s_k[q2[i] >> 24];
 #pragma unroll
-          for (int i = 0; i < RPW; i += 2) {
-            float m[12];
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-              for (int c = 0; c < 3; c++) {
-                m[k * 6 + c] = __fmul_rn((float)((q2[i + k] >> (8 * c)) & 0xFF), alpha[i + k]);
-                m[k * 6 + 3 + c] = __fmul_rn((float)((px[i + k] >> (8 * c)) & 0xFF), inv[i + k]);
-              }
-            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-                         "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\tv_cvt_pk_u8_f32 %0, %5, 1, %0\n\tv_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
-                         "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
-                         "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\tv_cvt_pk_u8_f32 %2, %11, 1, %2\n\tv_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
-                         "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\tv_cvt_pk_u8_f32 %3, %14, 1, %3\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
-                         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                         : "=&v"(f2[i]), "=&v"(f1[i]), "=&v"(f2[i + 1]), "=&v"(f1[i + 1])
-                         : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+            for (int i = 0; i < RPW; i++) {
+              const uint32_t q = q2[i], p = px[i];
+              const uint32_t qa = __umul24(q & 0xFF, kk[i].x), qb = __umul24((q >> 8) & 0xFF, kk[i].x), qc = __umul24((q >> 16) & 0xFF, kk[i].x);
+              const uint32_t pa = __umul24(p & 0xFF, kk[i].y), pb = __umul24((p >> 8) & 0xFF, kk[i].y), pc = __umul24((p >> 16) & 0xFF, kk[i].y);
+              r0[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa, 0x0C0C0602u), w_lo, 0u, false);   // [s2 s1 0 0] . [bf nbf 0 0]
+              r1[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb, 0x0C0C0602u), w_lo, 0u, false);
+              r2[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc, 0x0C0C0602u), w_lo, 0u, false);
+            }
           }
+          if (a.use_lut) {
+            uint32_t o0[RPW], o1[RPW], o2[RPW];
 #pragma unroll
-          for (int i = 0; i < RPW; i++) {
-            const uint32_t q = q2[i], p = px[i];
-            const bool op = (q >> 24) == 255;
-            px[i] = mix3_dot4(op ? p : f1[i], op ? q : f2[i], w_lo, w_hi) | (p & 0xFF000000u);
+            for (int i = 0; i < RPW; i++) { o0[i] = s_lut[r0[i] >> 8]; o1[i] = s_lut[r1[i] >> 8]; o2[i] = s_lut[r2[i] >> 8]; }
+#pragma unroll
+            for (int i = 0; i < RPW; i++) px[i] = o0[i] | (o1[i] << 8) | (o2[i] << 16) | (px[i] & 0xFF000000u);
+          } else {
+#pragma unroll
+            for (int i = 0; i < RPW; i++)
+              px[i] = __builtin_amdgcn_perm(r1[i], r0[i], 0x0C0C0501u) | ((r2[i] << 8) & 0x00FF0000u) | (px[i] & 0xFF000000u);
+          }
+        } else if (a.use_lut) {
+#pragma unroll
+          for (int i = 0; i < RPW; i++) px[i] = lut3_rgba(s_lut, px[i]);
+        }
+      } else {
+        // ---- round-1 epilogue (float scaling of translucent pixels), kept for the A / B rows ----
+        const float *s_alpha = reinterpret_cast<const float *>(s_k);
+        if (a.blend) {
+          const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+          bool opaque = true;
+#pragma unroll
+          for (int i = 0; i < RPW; i++) opaque = opaque && ((q2[i] >> 24) == 255);
+          if (__all(opaque)) {
+#pragma unroll
+            for (int i = 0; i < RPW; i++) px[i] = mix3_dot4(px[i], q2[i], w_lo, w_hi) | (px[i] & 0xFF000000u);
+          } else {
+            float alpha[RPW], inv[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; i++) { alpha[i] = s_alpha[q2[i] >> 24]; inv[i] = __fsub_rn(1.0f, alpha[i]); }
+            uint32_t f1[RPW], f2[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; i += 2) {
+              float mm[12];
+#pragma unroll
+              for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                  mm[k * 6 + c] = __fmul_rn((float)((q2[i + k] >> (8 * c)) & 0xFF), alpha[i + k]);
+                  mm[k * 6 + 3 + c] = __fmul_rn((float)((px[i + k] >> (8 * c)) & 0xFF), inv[i + k]);
+                }
+              asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                           "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\tv_cvt_pk_u8_f32 %0, %5, 1, %0\n\tv_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                           "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                           "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\tv_cvt_pk_u8_f32 %2, %11, 1, %2\n\tv_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
+                           "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\tv_cvt_pk_u8_f32 %3, %14, 1, %3\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
+                           "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                           : "=&v"(f2[i]), "=&v"(f1[i]), "=&v"(f2[i + 1]), "=&v"(f1[i + 1])
+                           : "v"(mm[0]), "v"(mm[1]), "v"(mm[2]), "v"(mm[3]), "v"(mm[4]), "v"(mm[5]), "v"(mm[6]), "v"(mm[7]), "v"(mm[8]), "v"(mm[9]), "v"(mm[10]), "v"(mm[11]));
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; i++) {
+              const uint32_t q = q2[i], p = px[i];
+              const bool op = (q >> 24) == 255;
+              px[i] = mix3_dot4(op ? p : f1[i], op ? q : f2[i], w_lo, w_hi) | (p & 0xFF000000u);
+            }
           }
         }
-      }
-      if (a.use_lut) {
-        uint32_t r[RPW], gg[RPW], b[RPW];
+        if (a.use_lut) {
+          uint32_t r[RPW], gg[RPW], b[RPW];
 #pragma unroll
-        for (int i = 0; i < RPW; i++) { r[i] = s_lut[px[i] & 0xFF]; gg[i] = s_lut[(px[i] >> 8) & 0xFF]; b[i] = s_lut[(px[i] >> 16) & 0xFF]; }
+          for (int i = 0; i < RPW; i++) { r[i] = s_lut[px[i] & 0xFF]; gg[i] = s_lut[(px[i] >> 8) & 0xFF]; b[i] = s_lut[(px[i] >> 16) & 0xFF]; }
 #pragma unroll
-        for (int i = 0; i < RPW; i++) px[i] = r[i] | (gg[i] << 8) | (b[i] << 16) | (px[i] & 0xFF000000u);
+          for (int i = 0; i < RPW; i++) px[i] = r[i] | (gg[i] << 8) | (b[i] << 16) | (px[i] & 0xFF000000u);
+        }
       }
 #pragma unroll
       for (int i = 0; i < RPW; i++) qs[i * kTileW] = px[i];
@@ -1186,6 +970,7 @@ __global__ __launch_bounds__(kH8sThreads, (NSLOT == 1 ? 5 : 3)) void k_half8s(Ha
     for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * (kH8sCW + 2) + wave) * 8 + i] = tacc[i];
 #undef H8S_T
 }
+
 
 // ---- generic two-launch path: any pixel size (bytes are independent channels), global int16 scratch ----
 __global__ __launch_bounds__(kBlock) void k_hpass_generic(const uint8_t *src, int irow, int sw, int sh, int16_t *tmp, int dw,
@@ -1298,10 +1083,11 @@ static int kernel_for_interp(int interp, bool upscale) {
   return 0;
 }
 
-// ---- k_half8 host side ---------------------------------------------------------------------------------------
+// ---- k_half8s host side --------------------------------------------------------------------------------------
 struct Half8Const {
   int4v *bfrag = nullptr;     // device [2][64]
-  float *alpha = nullptr;     // device [2][256]
+  uint2 *kscale = nullptr;    // device [256]
+  float *alpha = nullptr;     // device [2][256] (round-1 epilogue of the A / B builds)
 };
 static std::mutex g_h8_mu;
 static std::map<std::pair<int, std::vector<int16_t>>, Half8Const> g_h8;   // (device, 8 taps + swap flag)
@@ -1329,16 +1115,23 @@ static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const 
         const int j = px - 2 * col;
         const int tap = (sbyte == want && j >= 0 && j < 8) ? taps[j] : 0;
         frag[0][l][e] = (int8_t)(tap >> 6);        // tap = 64 * hi + lo, lo in [0, 63]
-        frag[1][l][e] = (int8_t)(2 * (tap & 63));  // stored doubled (see k_half8)
+        frag[1][l][e] = (int8_t)(2 * (tap & 63));  // stored doubled (see k_half8s)
       }
+    uint32_t k2[256], k1[256];
+    int rc = lgpu_alpha_scalers(k2, k1);           // simple_blend.c:137-145 as (c * K) >> 16, proven while built
+    if (rc) return rc;
+    uint2 ks[256];
+    for (int al = 0; al < 256; al++) ks[al] = make_uint2(k2[al], k1[al]);
     float at[512];
     for (int al = 0; al < 256; al++) {             // simple_blend.c:137: alpha = (float)a / 255., inv_alpha = 1. - alpha
       const float alpha = (float)al / 255., inv = 1. - alpha;
       at[al] = alpha; at[256 + al] = inv;
     }
     LGPU_HIP(hipMalloc((void **)&c.bfrag, sizeof frag));
+    LGPU_HIP(hipMalloc((void **)&c.kscale, sizeof ks));
     LGPU_HIP(hipMalloc((void **)&c.alpha, sizeof at));
     LGPU_HIP(hipMemcpy(c.bfrag, frag, sizeof frag, hipMemcpyHostToDevice));
+    LGPU_HIP(hipMemcpy(c.kscale, ks, sizeof ks, hipMemcpyHostToDevice));
     LGPU_HIP(hipMemcpy(c.alpha, at, sizeof at, hipMemcpyHostToDevice));
     it = g_h8.emplace(key, c).first;
   }
@@ -1346,6 +1139,10 @@ static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const 
   return LGPU_OK;
 }
 
+static int g_h8s_opt = 7;
+#ifdef LGPU_H8S_AB
+extern "C" int lgpu_h8s_set_opt(int opt) { g_h8s_opt = opt; return LGPU_OK; }   // A / B builds only (tools/ab_h8s.py), not part of the ABI
+#endif
 // returns LGPU_OK and launches when the fast path applies; LGPU_E_UNSUPPORTED when it does not
 static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, int dw, int dh, int orow, int swap_rb, int blend,
                      int irow2, uint32_t bf, const int32_t *bf_d, int use_lut, const SepTracks &t, int ntracks, const Lut8 &l,
@@ -1367,113 +1164,71 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   if (rc) return rc;
   Half8Args a;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
-  a.bfrag = hc->bfrag; a.alpha_tab = hc->alpha;
+  a.bfrag = hc->bfrag; a.kscale = hc->kscale; a.alpha_tab = hc->alpha;
   for (int k = 0; k < 4; k++) a.vc[k] = (uint32_t)(uint16_t)vb->hco[2 * k] | ((uint32_t)(uint16_t)vb->hco[2 * k + 1] << 16);
   a.swap_rb = swap_rb; a.blend = blend; a.irow2 = irow2; a.bf = bf; a.nbf = 0xFF - bf; a.bf_d = bf_d; a.use_lut = use_lut;
   a.ntracks = ntracks;
-  // persistent grid: as many workgroups as stay resident, each walks the work list
+  a.dbg = nullptr;
+  // persistent grid: as many workgroups as stay resident (two per CU by LDS), each walks its XCD's share of the work list
   static int g_cus = 0;
   if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
-  static const int th_env = getenv("LGPU_HALF8_TH") ? atoi(getenv("LGPU_HALF8_TH")) : 16;
-  static const int bpc_env = getenv("LGPU_HALF8_BLOCKS_PER_CU") ? atoi(getenv("LGPU_HALF8_BLOCKS_PER_CU")) : 0;
-  const int th = (th_env == 8) ? 8 : 16;
-  a.tiles_x = (dw + kTileW - 1) / kTileW; a.tiles_y = (dh + th - 1) / th;
+  a.tiles_x = (dw + kTileW - 1) / kTileW; a.tiles_y = (dh + H8S::kTileH - 1) / H8S::kTileH;
   const int nwork = a.tiles_x * a.tiles_y * ntracks;
-  const size_t lds = th == 8 ? H8<8>::kLds : H8<16>::kLds;
-  int grid = g_cus * (bpc_env > 0 ? bpc_env : (int)(160 * 1024 / lds));
+  const size_t lds = H8S::kLds;
+  int grid = g_cus * (int)(160 * 1024 / lds);
   if (grid > nwork) grid = nwork;
   grid = (grid + 7) & ~7;                      // whole workgroups per XCD
-  static const int abl = getenv("LGPU_H8_ABLATE") ? atoi(getenv("LGPU_H8_ABLATE")) : 0;   // profiling only
-  static unsigned long long *g_dbg = nullptr;
-  a.dbg = nullptr;
-  if (abl == 16) {
-    if (!g_dbg) LGPU_HIP(hipMalloc((void **)&g_dbg, sizeof(unsigned long long) * 8 * 4 * 4096));
-    a.dbg = g_dbg;
-  }
-#define H8_LAUNCH(TH_, ABL_)                                                                                              \
-  do {                                                                                                                    \
-    if (lds > 48 * 1024) LGPU_HIP(hipFuncSetAttribute((const void *)k_half8<TH_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_half8<TH_, ABL_>), dim3((unsigned)grid), dim3(kBlock), lds, st, a, t, l);                       \
+  const int opt = g_h8s_opt;     // A / B builds only, see k_half8s
+#define H8S_LAUNCH(DBG_, OPT_)                                                                                          \
+  do {                                                                                                                  \
+    LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<DBG_, OPT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_half8s<DBG_, OPT_>), dim3((unsigned)grid), dim3(kH8sThreads), lds, st, a, t, l);              \
   } while (0)
-  static const bool classic = getenv("LGPU_H8_CLASSIC") != nullptr;
-  if (th == 16 && abl == 0 && !classic) {
-    static const int nslot = getenv("LGPU_H8S_SLOTS") ? atoi(getenv("LGPU_H8S_SLOTS")) : 2;
-    const size_t lds_s = nslot == 1 ? H8SL<1>::kLds : H8SL<2>::kLds;
-    int grid_s = g_cus * (bpc_env > 0 ? bpc_env : (int)(160 * 1024 / lds_s));
-    if (grid_s > nwork) grid_s = nwork;
-    grid_s = (grid_s + 7) & ~7;
-    static const bool dbg_s = getenv("LGPU_H8S_DEBUG") != nullptr;
-    if (dbg_s) {
-      static unsigned long long *g_dbg_s = nullptr;
-      if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * (kH8sCW + 2) * 4096));
-      a.dbg = g_dbg_s;
-      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-      hipLaunchKernelGGL((k_half8s<1, 2>), dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
-      static int dumps = 0;
-      if (dumps++ < 3) {
-        LGPU_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)grid_s * 8 * (kH8sCW + 2));
-        LGPU_HIP(hipMemcpy(h.data(), g_dbg_s, h.size() * 8, hipMemcpyDeviceToHost));
-        double c[8] = {0}, m[8] = {0}, m5[8] = {0};
-        for (int b = 0; b < grid_s; b++)
-          for (int i = 0; i < 8; i++) {
-            for (int w = 0; w < kH8sCW; w++) c[i] += (double)h[((size_t)b * (kH8sCW + 2) + w) * 8 + i] / kH8sCW;
-            m[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW) * 8 + i];
-            m5[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW + 1) * 8 + i];
-          }
-        const double it = (double)nwork;
-        fprintf(stderr, "[h8s compute wave, ticks/tile] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", c[0] / it, c[1] / it, c[2] / it, c[3] / it);
-        for (int w = 0; w < kH8sCW; w++) {                      // per compute wave: do the waves that share a SIMD with a memory wave run behind?
-          double cw[4] = {0, 0, 0, 0};
-          for (int b = 0; b < grid_s; b++)
-            for (int i = 0; i < 4; i++) cw[i] += (double)h[((size_t)b * (kH8sCW + 2) + w) * 8 + i];
-          fprintf(stderr, "[h8s compute wave %d] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", w, cw[0] / it, cw[1] / it, cw[2] / it, cw[3] / it);
+#ifdef LGPU_PROFILING
+  static const bool dbg_s = getenv("LGPU_H8S_DEBUG") != nullptr;
+  if (dbg_s) {     // in-kernel phase profile: s_memtime ticks between fixed points of the tile loop, per wave
+    static unsigned long long *g_dbg_s = nullptr;
+    if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * (kH8sCW + 2) * 4096));
+    a.dbg = g_dbg_s;
+    H8S_LAUNCH(1, 7);
+    static int dumps = 0;
+    if (dumps++ < 3) {
+      LGPU_HIP(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h((size_t)grid * 8 * (kH8sCW + 2));
+      LGPU_HIP(hipMemcpy(h.data(), g_dbg_s, h.size() * 8, hipMemcpyDeviceToHost));
+      double c[8] = {0}, m[8] = {0}, m5[8] = {0};
+      for (int b = 0; b < grid; b++)
+        for (int i = 0; i < 8; i++) {
+          for (int w = 0; w < kH8sCW; w++) c[i] += (double)h[((size_t)b * (kH8sCW + 2) + w) * 8 + i] / kH8sCW;
+          m[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW) * 8 + i];
+          m5[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW + 1) * 8 + i];
         }
-        fprintf(stderr, "[h8s memory wave 4, ticks/tile] fix edges %.0f | wait A %.0f | dma window b %.0f | - %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
-                m[0] / it, m[1] / it, m[2] / it, m[3] / it, m[4] / it, m[5] / it, m[6] / it);
-        fprintf(stderr, "[h8s memory wave 5, ticks/tile] fix edges %.0f | wait A %.0f | dma window b %.0f | read + dma l2 + store %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
-                m5[0] / it, m5[1] / it, m5[2] / it, m5[3] / it, m5[4] / it, m5[5] / it, m5[6] / it);
-      }
-      LGPU_CHECK_LAUNCH();
-      return LGPU_OK;
-    }
-    if (nslot == 1) {
-      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-      hipLaunchKernelGGL((k_half8s<0, 1>), dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
-    } else {
-      LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-      hipLaunchKernelGGL((k_half8s<0, 2>), dim3((unsigned)grid_s), dim3(kH8sThreads), lds_s, st, a, t, l);
+      const double it = (double)nwork;
+      fprintf(stderr, "[h8s compute wave, ticks/tile] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", c[0] / it, c[1] / it, c[2] / it, c[3] / it);
+      fprintf(stderr, "[h8s memory wave 4, ticks/tile] fix+bias %.0f | wait A %.0f | dma window b %.0f | - %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
+              m[0] / it, m[1] / it, m[2] / it, m[3] / it, m[4] / it, m[5] / it, m[6] / it);
+      fprintf(stderr, "[h8s memory wave 5, ticks/tile] fix+bias %.0f | wait A %.0f | dma window b %.0f | read + dma l2 + store %.0f | wait B %.0f | dma window a %.0f | land %.0f\n",
+              m5[0] / it, m5[1] / it, m5[2] / it, m5[3] / it, m5[4] / it, m5[5] / it, m5[6] / it);
     }
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
-  if (th == 8) H8_LAUNCH(8, 0);
-  else switch (abl) {
-    case 1: H8_LAUNCH(16, 1); break;
-    case 3: H8_LAUNCH(16, 3); break;
-    case 7: H8_LAUNCH(16, 7); break;
-    case 8: H8_LAUNCH(16, 8); break;
-    case 15: H8_LAUNCH(16, 15); break;
-    case 16: H8_LAUNCH(16, 16); break;
-    default: H8_LAUNCH(16, 0); break;
+#endif
+  switch (opt) {
+#ifdef LGPU_H8S_AB
+    case 0: H8S_LAUNCH(0, 0); break;
+    case 1: H8S_LAUNCH(0, 1); break;
+    case 3: H8S_LAUNCH(0, 3); break;
+    case 4: H8S_LAUNCH(0, 4); break;
+    case 5: H8S_LAUNCH(0, 5); break;
+#endif
+    default: H8S_LAUNCH(0, 7); break;
   }
-#undef H8_LAUNCH
-  if (abl == 16) {   // phase-cycle dump (profiling build only): mean per wave over the grid
-    static int dumps = 0;
-    if (dumps++ < 3) {
-      LGPU_HIP(hipStreamSynchronize(st));
-      std::vector<unsigned long long> h((size_t)grid * 32);
-      LGPU_HIP(hipMemcpy(h.data(), g_dbg, h.size() * 8, hipMemcpyDeviceToHost));
-      double sum[8] = {0};
-      for (int b = 0; b < grid; b++) for (int w = 0; w < 4; w++) for (int i = 1; i < 8; i++) sum[i == 7 ? 7 : i] += (double)h[((size_t)b * 4 + w) * 8 + i] , sum[0] += (i == 1 ? (double)h[((size_t)b * 4 + w) * 8] : 0);
-      const double n = (double)grid * 4, iters = (double)nwork / grid;
-      fprintf(stderr, "[h8 phases, s_memtime ticks per tile per wave] write %.0f | bar1 %.0f | issue+q2 %.0f | hpass %.0f | bar2 %.0f | vdots %.0f | epilogue %.0f | looptop %.0f\n",
-              sum[0] / n / iters, sum[1] / n / iters, sum[2] / n / iters, sum[3] / n / iters, sum[4] / n / iters, sum[5] / n / iters, sum[6] / n / iters, sum[7] / n / iters);
-    }
-  }
+#undef H8S_LAUNCH
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+
 
 struct SepPlan {
   SepArgs a;

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "lgpu_yuv420p_to_rgb": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
+    "lgpu_alpha_scalers": [vp, vp],
     "lgpu_letterbox": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp],
     "lgpu_letterbox_at": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],

@@ -879,6 +879,65 @@ def test_chain_matches_oracle_and_unfused(gpu, orc, do_blur):
                 assert_same(host(rs), wants[i], dw, dh, 4, "unfused chain")
 
 
+@pytest.mark.parametrize("do_blur", [0, 1])
+def test_chain_with_device_param_block(gpu, orc, do_blur):
+    """what bench.py times: the blend amount is read by the kernel from the device-resident shared parameter block
+    (lgpu_chain_params.param_block_d, int32[4], [0] = blend amount), a different one every step, 16 tracks per launch;
+    the kernel-argument bf is deliberately wrong so that a launch that ignores the block cannot pass"""
+    import torch
+    rng = np.random.default_rng(5100 + do_blur)
+    lut = lut_for(rng, "l2s")
+    sw, sh, dw, dh, T = 384, 216, 192, 108, 16
+    srcs = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(T)]
+    l2s = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(T)]
+    l2s[3][:, 3::4] = 255                                         # one fully opaque layer 2 (the wave-uniform integer path)
+    d_src, d_l2 = [dev(s) for s in srcs], [dev(s) for s in l2s]
+    d_dst = [dev(np.zeros((dh, align(dw * 4)), np.uint8)) for _ in range(T)]
+    schedule = torch.tensor([[b, 0, 0, 0] for b in (0, 1, 96, 128, 200, 254, 255, 256 + 77)], dtype=torch.int32, device="cuda")
+    prm = gpu.chain_params(sw, sh, srcs[0].strides[0], dw, dh, l2s[0].strides[0], d_dst[0].stride(0), swap_rb=1, interp=3, do_blur=do_blur,
+                           bf=13, lut=lut, param_block=schedule)
+    trk = gpu.chain_tracks(d_src, d_l2, d_dst)
+    for s in range(schedule.shape[0]):
+        prm.param_block_d = schedule.data_ptr() + 16 * s
+        gpu.chain(prm, trk)
+        bf = int(schedule[s, 0].item()) & 0xFF                   # the block's low byte is the amount
+        for i in (0, 3, 7, 15):
+            want = np.zeros((dh, align(dw * 4)), np.uint8)
+            assert orc.orc_chain(P(srcs[i]), srcs[i].strides[0], sw, sh, P(l2s[i]), l2s[i].strides[0], P(want), want.strides[0], dw, dh, 1, 3, do_blur, bf, P(lut)) == 0
+            assert_same(host(d_dst[i]), want, dw, dh, 4, "param block step %d (bf=%d) track %d blur=%d" % (s, bf, i, do_blur))
+
+
+@pytest.mark.parametrize("use_lut", [0, 1])
+def test_chain_every_alpha_and_colour_pair(gpu, orc, use_lut):
+    """the translucent scaling of the chroma blend (simple_blend.c:137-145) inside the fused chain, for every (layer-2 alpha, colour)
+    pair against every track colour class: layer 2 sweeps alpha along y and colour along x; the track is a flat frame per call
+    (a flat source stays flat through the resize), so one launch covers 256 x 256 (alpha, c2) pairs for a given c1"""
+    rng = np.random.default_rng(5200 + use_lut)
+    lut = lut_for(rng, "l2s") if use_lut else None
+    dw, dh = 256, 256
+    sw, sh = 2 * dw, 2 * dh
+    l2 = np.zeros((dh, dw * 4), np.uint8)
+    xs = np.arange(dw, dtype=np.uint8)
+    l2[:, 0::4] = xs[None, :]
+    l2[:, 1::4] = (255 - xs)[None, :]
+    l2[:, 2::4] = (xs * 7 + 3)[None, :]
+    l2[:, 3::4] = np.arange(dh, dtype=np.uint8)[:, None]
+    d_l2 = dev(l2)
+    for c1 in list(range(0, 256, 5)) + [1, 2, 127, 128, 254, 255]:
+        src = np.zeros((sh, sw * 4), np.uint8)
+        src[:, 0::4] = c1
+        src[:, 1::4] = 255 - c1
+        src[:, 2::4] = (c1 * 3 + 1) & 0xFF
+        src[:, 3::4] = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        for bf in (255, 0, 128, 77):
+            want = np.zeros((dh, dw * 4), np.uint8)
+            assert orc.orc_chain(P(src), sw * 4, sw, sh, P(l2), dw * 4, P(want), dw * 4, dw, dh, 0, 3, 0, bf, P(lut) if use_lut else None) == 0
+            d_dst = dev(np.zeros((dh, dw * 4), np.uint8))
+            prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=0, interp=3, do_blur=0, bf=bf, lut=lut)
+            gpu.chain(prm, gpu.chain_tracks([dev(src)], [d_l2], [d_dst]))
+            assert_same(host(d_dst), want, dw, dh, 4, "c1=%d bf=%d lut=%d" % (c1, bf, use_lut))
+
+
 # ---------------------------------------------------------------------------------------------- host threads
 def test_multi_launch_paths_from_two_host_threads(gpu):
     """LiVES calls from several host threads; the multi-launch paths (chain with blur, in-place deinterlace, edge) keep their

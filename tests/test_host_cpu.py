@@ -151,3 +151,40 @@ def test_weed_abi_constants_match_reference_headers():
         assert real[k] == v, "%s: ours %s, reference %s" % (k, v, real[k])
         checked += 1
     assert checked > 80
+
+
+def test_alpha_scalers_equal_the_reference_float_expression():
+    """lgpu_alpha_scalers: (c * k2[a]) >> 16 == (uint8_t)((float)c * alpha) and (c * k1[a]) >> 16 == (uint8_t)((float)c * inv_alpha)
+    with alpha = (float)a / 255., inv_alpha = 1. - alpha (simple_blend.c:137-145), for every byte c and every translucent alpha;
+    checked here against an independent IEEE float32 evaluation (numpy) and against the oracle's chroma blend"""
+    L = lib.load()
+    k2 = np.zeros(256, np.uint32)
+    k1 = np.zeros(256, np.uint32)
+    assert L.lgpu_alpha_scalers(P(k2), P(k1)) == 0
+    assert k2[255] == 65536 and k1[255] == 65536          # opaque pixels are not scaled (simple_blend.c:128-131)
+    a = np.arange(256)
+    alpha = (a.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32)
+    inv = (1.0 - alpha.astype(np.float64)).astype(np.float32)
+    c = np.arange(256, dtype=np.float32)
+    t2 = np.floor(c[None, :] * alpha[:, None]).astype(np.int64)        # float32 * float32 -> float32, truncated
+    t1 = np.floor(c[None, :] * inv[:, None]).astype(np.int64)
+    ci = np.arange(256, dtype=np.int64)
+    g2 = (ci[None, :] * k2.astype(np.int64)[:, None]) >> 16
+    g1 = (ci[None, :] * k1.astype(np.int64)[:, None]) >> 16
+    assert (g2[:255] == t2[:255]).all() and (g1[:255] == t1[:255]).all()
+    assert (k2 < (1 << 24)).all() and (k1 < (1 << 24)).all()          # operands of v_mul_u32_u24
+    # the oracle's chroma blend (pinned on the reference plugin) on every (alpha, colour) pair: bf = 255 keeps s2, bf = 0 keeps s1
+    o = po.oracle()
+    w, h = 256, 255
+    p2 = np.zeros((h, w * 4), np.uint8)
+    p1 = np.zeros((h, w * 4), np.uint8)
+    for ch in range(3):
+        p2[:, ch::4] = np.arange(256, dtype=np.uint8)[None, :]
+        p1[:, ch::4] = np.arange(256, dtype=np.uint8)[None, :]
+    p2[:, 3::4] = np.arange(255, dtype=np.uint8)[:, None]
+    p1[:, 3::4] = 255
+    for bf, g in ((255, g2), (0, g1)):
+        out = np.zeros_like(p1)
+        o.orc_blend_chroma(P(p1), w * 4, P(p2), w * 4, P(out), w * 4, w, h, 4, 0, bf)
+        want = (255 * g[:255]) >> 8          # blend[s2][s1] = (bf * s2 + (255 - bf) * s1) >> 8 with the other weight 0
+        assert (out[:, 0::4] == want).all(), "bf=%d" % bf
