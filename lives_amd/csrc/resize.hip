@@ -466,11 +466,13 @@ struct H8S {
   static constexpr int kRounds = 21, kTailLanes = 12;
   static constexpr int kHPitch = 264;                  // dwords per row pair of the intermediate: 256 + 8, so the four row groups of an
                                                        //   MFMA result (pairs 2g, g = 0..3) land on different LDS banks (2 * 264 * g mod 64 = 16 g)
-  static constexpr int kOffH = 2 * kWinBytes;                        // 41344: [19][264] dwords of 2 x int16
+  // LDS map; the two small tables come first so that their addresses fit the 16-bit offset field of the ds instructions
+  static constexpr int kOffLut = 0;                                  // gamma LUT, 256 bytes
+  static constexpr int kOffK = 256;                                  // uint2[256] alpha scalers
+  static constexpr int kOffWin = kOffK + 2048;                       // 2 window slots
+  static constexpr int kOffH = kOffWin + 2 * kWinBytes;              // [19][264] dwords of 2 x int16
   static constexpr int kOffQ = kOffH + kPairs * kHPitch * 4;         // 2 x [16][64] pixels: layer 2 in, finished tile out
-  static constexpr int kOffLut = kOffQ + 2 * 4096;
-  static constexpr int kOffK = kOffLut + 256;                        // uint2[256]
-  static constexpr size_t kLds = kOffK + 2048;                       // 71904: two workgroups per CU
+  static constexpr size_t kLds = kOffQ + 2 * 4096;                   // 71904: two workgroups per CU
 };
 
 #define H8S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
     __builtin_amdgcn_sched_barrier(0);                                                                \
   }
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t *s_win = smem;                         // 2 x [38][136] packed source pixels
+  uint8_t *s_win = smem + C::kOffWin;            // 2 x [38][136] packed source pixels
   uint8_t *s_h = smem + C::kOffH;                // [19][264] dwords of 2 x int16
   uint8_t *s_q = smem + C::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
   uint8_t *s_lut = smem + C::kOffLut;
@@ -883,7 +885,12 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
             // s2_c = (q_c * K2[alpha]) >> 16, s1_c = (p_c * K1[alpha]) >> 16: byte 2 of a 24-bit product each
             uint2 kk[RPW];
 #pragma unroll
-            for (int i = 0; i < RPW; i++) kk[i] = s_k[q2[i] >> 24];
+            for (int i = 0; i < RPW; i++)
+              if (OPT & 8) {
+                typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                const u32x2v t = *reinterpret_cast<const __attribute__((address_space(3))) u32x2v *>((uintptr_t)(C::kOffK + (q2[i] >> 24) * 8));
+                kk[i] = make_uint2(t.x, t.y);
+              } else kk[i] = s_k[q2[i] >> 24];
 #pragma unroll
             for (int i = 0; i < RPW; i++) {
               const uint32_t q = q2[i], p = px[i];
@@ -896,10 +903,27 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
           }
           if (a.use_lut) {
             uint32_t o0[RPW], o1[RPW], o2[RPW];
+            if (OPT & 8) {
+              // the workgroup has no static LDS, so the dynamic segment starts at LDS address 0 and a table's address is its offset:
+              // the table base folds into the ds_read offset field, the index is one shift
+              typedef const __attribute__((address_space(3))) uint8_t *lds_u8;
 #pragma unroll
-            for (int i = 0; i < RPW; i++) { o0[i] = s_lut[r0[i] >> 8]; o1[i] = s_lut[r1[i] >> 8]; o2[i] = s_lut[r2[i] >> 8]; }
+              for (int i = 0; i < RPW; i++) {
+                o0[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r0[i] >> 8)); o1[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r1[i] >> 8));
+                o2[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r2[i] >> 8));
+              }
 #pragma unroll
-            for (int i = 0; i < RPW; i++) px[i] = o0[i] | (o1[i] << 8) | (o2[i] << 16) | (px[i] & 0xFF000000u);
+              for (int i = 0; i < RPW; i++) {
+                uint32_t t = (o2[i] << 8) | o1[i];
+                t = (t << 8) | o0[i];
+                px[i] = (px[i] & 0xFF000000u) | t;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < RPW; i++) { o0[i] = s_lut[r0[i] >> 8]; o1[i] = s_lut[r1[i] >> 8]; o2[i] = s_lut[r2[i] >> 8]; }
+#pragma unroll
+              for (int i = 0; i < RPW; i++) px[i] = o0[i] | (o1[i] << 8) | (o2[i] << 16) | (px[i] & 0xFF000000u);
+            }
           } else {
 #pragma unroll
             for (int i = 0; i < RPW; i++)
@@ -1221,6 +1245,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
     case 3: H8S_LAUNCH(0, 3); break;
     case 4: H8S_LAUNCH(0, 4); break;
     case 5: H8S_LAUNCH(0, 5); break;
+    case 15: H8S_LAUNCH(0, 15); break;
 #endif
     default: H8S_LAUNCH(0, 7); break;
   }
