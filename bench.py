@@ -130,14 +130,14 @@ def main():
     algo = ALGO_BYTES_PER_FRAME * T
     achieved = algo / launch_s / 1e9
     traffic = None
-    try:   # HBM bytes per launch from the committed PMC run of this exact workload (profiles/), if present
+    try:   # HBM bytes per launch from the PMC passes of this round's build on this exact workload (tools/pmc.sh + tools/pmc_traffic.py -> profiles/pmc_traffic.json, which names the commit)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pj = json.load(f)
         if pj.get("tracks") == T and pj.get("blur") == args.blur:
             traffic = pj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roof = {"bound": "hbm", "kernel": "lgpu::k_half8s<0,2>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
 

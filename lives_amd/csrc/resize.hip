@@ -436,6 +436,8 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
 // wait with a counted vmcnt that leaves exactly the newest window outstanding.
 // =====================================================================================================================
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
 
 constexpr int kH8Pitch = 544;                   // window row pitch in bytes (136 px; 136 dwords = 8 mod 16): conflict-free for the lane
                                                 //   groups ds_read_b128 really uses ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
@@ -445,9 +447,9 @@ struct Half8Args {
   int sw, sh, irow, dw, dh, orow;
   const int4v *bfrag;               // device: [2][64] B fragments (hi, lo)
   const uint2 *kscale;              // device: [256] {K2, K1}: layer-2 / track colour scalers per layer-2 alpha (lgpu_alpha_scalers)
-  const float *alpha_tab;           // device: [2][256] alpha, 1 - alpha (round-1 epilogue of the A / B builds)
   uint32_t vc[4];                   // vertical tap pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7), 2 x int16 each
   int swap_rb;
+  int xoff;                         // 1: windows start one pixel further left (source x = 2 * tx0 - 4) so that every 16-byte request is 16-byte aligned
   int blend, irow2;
   uint32_t bf, nbf;
   const int32_t *bf_d;
@@ -469,11 +471,13 @@ struct H8S {
   // LDS map; the two small tables come first so that their addresses fit the 16-bit offset field of the ds instructions
   static constexpr int kOffLut = 0;                                  // gamma LUT, 256 bytes
   static constexpr int kOffK = 256;                                  // uint2[256] alpha scalers
-  static constexpr int kOffWin = kOffK + 2048;                       // 2 window slots
-  static constexpr int kOffH = kOffWin + 2 * kWinBytes;              // [19][264] dwords of 2 x int16
-  static constexpr int kOffQ = kOffH + kPairs * kHPitch * 4;         // 2 x [16][64] pixels: layer 2 in, finished tile out
-  static constexpr size_t kLds = kOffQ + 2 * 4096;                   // 71904: two workgroups per CU
+  static constexpr int kOffWin = kOffK + 2048;                       // window slots
 };
+struct H8SL {
+  static constexpr int kOffH = H8S::kOffWin + 2 * H8S::kWinBytes;              // [19][264] dwords of 2 x int16
+  static constexpr int kOffQ = kOffH + H8S::kPairs * H8S::kHPitch * 4;         // 2 x [16][64] pixels: layer 2 in, finished tile out
+  static constexpr size_t kLds = kOffQ + 2 * 4096;                             // 71904: two workgroups per CU (one window slot with three
+};                                                                             //   workgroups per CU measured 223-245 us against 169)
 
 #define H8S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef const __attribute__((address_space(1))) void *h8s_gptr;
@@ -521,17 +525,17 @@ __device__ __noinline__ void h8s_issue_window_border(int sw, int sh, int irow, c
       __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(win + k * 1024), 16, 0, 0);
   }
 }
-template <int K0, int K1>
+template <int K0, int K1, int AUX = 0>
 __device__ __forceinline__ void h8s_issue_window(const Half8Args &a, const uint8_t *src, int tx0, int ty0, int lane, uint8_t *win,
                                                  const H8sLaneOff &lo) {
-  const int sx0 = 2 * tx0 - 3, sy0 = 2 * ty0 - 3;
+  const int sx0 = 2 * tx0 - 3 - a.xoff, sy0 = 2 * ty0 - 3;
   if (sx0 >= 0 && sx0 + 4 * kH8Chunks <= a.sw && sy0 >= 0 && sy0 + H8S::kRows <= a.sh) {
     // window inside the frame (tile-uniform): scalar base + the precomputed lane offsets, no per-request address math
     const uint8_t *base = src + ((uint32_t)sy0 * (uint32_t)a.irow + (uint32_t)sx0 * 4u);
 #pragma unroll
     for (int k = K0; k < K1; k++)
       if (k < H8S::kRounds - 1 || lane < H8S::kTailLanes)
-        __builtin_amdgcn_global_load_lds((h8s_gptr)(base + lo.v[k]), (h8s_lptr)(win + k * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((h8s_gptr)(base + lo.v[k]), (h8s_lptr)(win + k * 1024), 16, 0, AUX);
   } else h8s_issue_window_border(a.sw, a.sh, a.irow, src, sx0, sy0, lane, win, K0, K1);
 }
 __device__ __forceinline__ uint32_t h8s_pick(const uint4 &v, int j) { return j <= 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
@@ -540,8 +544,7 @@ __device__ __forceinline__ uint32_t h8s_pick(const uint4 &v, int j) { return j <
 // a row at the left frame edge, the last few at the right edge), one per lane; each memory wave fixes the chunks it
 // fetched itself (c0 <= c < c1).  The LDS accesses are asm so that the compiler does not drain the DMA queue in front
 // of them: the caller's counted vmcnt has already covered this window, newer requests go to the other slot.
-__device__ __noinline__ void h8s_fix_edges(uint8_t *win, int tx0, int sw, int lane, int c0, int c1) {
-  const int sx0 = 2 * tx0 - 3;
+__device__ __noinline__ void h8s_fix_edges(uint8_t *win, int sx0, int sw, int lane, int c0, int c1) {
   const int nlo = sx0 < 0 ? (-sx0 + 3) >> 2 : 0;                               // chunks starting left of the frame
   int chh = sw - 4 - sx0 < 0 ? 0 : ((sw - 4 - sx0) >> 2) + 1;                  // first chunk reaching past the right edge
   if (chh < nlo) chh = nlo;
@@ -563,7 +566,7 @@ __device__ __noinline__ void h8s_fix_edges(uint8_t *win, int tx0, int sw, int la
     }
   }
 }
-__device__ __forceinline__ bool h8s_border(int tx0, int sw) { const int sx0 = 2 * tx0 - 3; return sx0 < 0 || sx0 + 4 * kH8Chunks > sw; }
+__device__ __forceinline__ bool h8s_border(int sx0, int sw) { return sx0 < 0 || sx0 + 4 * kH8Chunks > sw; }
 
 __device__ __noinline__ void h8s_issue_q2_partial(const uint8_t *l2, int irow2, int dw, int dh, int tx0, int ty0, int lane, uint8_t *slot) {
   const int x = min(tx0 + lane, dw - 1);              // partial-width tile: one row per request, columns clamped
@@ -637,13 +640,12 @@ struct H8sTile {
   __device__ __forceinline__ int ty0() const { return ty * H8S::kTileH; }
 };
 
-// OPT (bit mask; production = 7, the other values exist for the A / B rows of profiles/r02):
-//   1  the landed window is biased to int8 in LDS by the memory waves (else: 48 v_xor per compute wave and tile)
-//   2  third row block: only registers 0 / 1 post-processed (else: all four, half of them dropped)
-//   4  epilogue with the integer alpha scalers and the LUT gathered straight from the mix sums (else: round-1 float path)
-template <int DBG, int OPT>
-__global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
+// ---- compute waves (shared by both loader designs below) -------------------------------------------------------------
+// ABL (A / B builds only): 16 = barriers only (no compute), 32 = no source window loads
+template <int DBG, int ABL, int NWAVES>
+__device__ __forceinline__ void h8s_compute(const Half8Args &a, uint8_t *smem, int wave, int lane, int work, int wend, int wstride) {
   using C = H8S;
+  using L = H8SL;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define H8S_T(i)                                                                                     \
   if (DBG) {                                                                                          \
@@ -652,112 +654,10 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
     tacc[i] += now_ - tprev; tprev = now_;                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   }
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t *s_win = smem + C::kOffWin;            // 2 x [38][136] packed source pixels
-  uint8_t *s_h = smem + C::kOffH;                // [19][264] dwords of 2 x int16
-  uint8_t *s_q = smem + C::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
+  uint8_t *s_win = smem + C::kOffWin;
+  uint8_t *s_h = smem + L::kOffH;
+  uint8_t *s_q = smem + L::kOffQ;
   uint8_t *s_lut = smem + C::kOffLut;
-  uint2 *s_k = reinterpret_cast<uint2 *>(smem + C::kOffK);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles = a.tiles_x * a.tiles_y, nwork = tiles * a.ntracks;
-  if (a.use_lut) stage_lut(s_lut, lut);
-  if (a.blend && tid < 256) {
-    if (OPT & 4) s_k[tid] = a.kscale[tid];
-    else reinterpret_cast<float *>(s_k)[tid] = a.alpha_tab[tid];
-  }
-
-  // XCD-aware persistent work list: each XCD owns a contiguous eighth of the (track, tile) list, so that the window
-  // halos of neighbouring tiles hit that XCD's L2
-  const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3);
-  const int chunk = (nwork + 7) >> 3;
-  const int wend = min((xcd + 1) * chunk, nwork);
-  int work = xcd * chunk + (int)(blockIdx.x >> 3);
-  if (work >= wend) return;                       // workgroup-uniform
-
-  if (wave >= kH8sCW) {
-    // ------------------------------------------------ memory waves ------------------------------------------------
-    __builtin_amdgcn_s_setprio(3);     // few instructions, all of them feeding the DMA queues: let them issue ahead of the compute waves (-0.8 % per launch)
-    // Wave 4 fetches window DMA instructions 0..15, wave 5 fetches 16..20 and also moves the layer-2 / result tiles.
-    // Window n+2 goes to slot n & 1, free after B(n) and needed at A(n+2); each wave issues the first part of its
-    // share between B(n) and A(n+1) and the rest between A(n+1) and B(n+1), so both barrier intervals carry traffic:
-    //   A(n)   | rest of window n+1; wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1
-    //   B(n)   | first part of window n+2 | wait for all but that part: window n+1 (and layer-2 n+1) have landed |
-    //          | edge fix-up and int8 bias of window n+1 (own chunks)
-    constexpr int K0 = 0, K1 = 6, K2 = 16, K3 = 21, K4 = 21;     // wave 4: [K0,K1) after B + [K1,K2) after A; wave 5: [K2,K3) after B (+ [K3,K4) after A)
-    const bool w5 = wave == kH8sCW + 1;
-    H8sLaneOff lo;
-    h8s_lane_offsets(a, lane, lo);
-    H8sTile t0, t1, t2;               // tiles n, n+1, n+2
-    t0.init(a, work, wstride); t1 = t0; t1.step(); t2 = t1; t2.step();
-    const bool has1 = work + wstride < wend;
-    if (w5) {
-      if (a.blend) h8s_issue_q2(a, trk.l2[t0.track], t0.tx0(), t0.ty0(), lane, s_q);
-      h8s_issue_window<K2, K4>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
-      if (has1) { h8s_issue_window<K2, K3>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, K2 * 64, K4 * 64);
-      if (OPT & 1) h8s_bias_window<K2 * 1024, C::kWinBytes>(s_win, lane);
-    } else {
-      h8s_issue_window<K0, K2>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
-      if (has1) { h8s_issue_window<K0, K1>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (h8s_border(t0.tx0(), a.sw)) h8s_fix_edges(s_win, t0.tx0(), a.sw, lane, K0 * 64, K2 * 64);
-      if (OPT & 1) h8s_bias_window<K0 * 1024, K2 * 1024>(s_win, lane);
-    }
-    H8sTile tp = t0;                  // tile n-1
-    bool has_prev = false;
-    int par = 0;
-    if (DBG) tprev = __builtin_amdgcn_s_memtime();
-    for (; work < wend; work += wstride) {
-      H8S_T(0)
-      H8S_BARRIER();                                                                   // A(n)
-      H8S_T(1)
-      const bool has_next = work + wstride < wend, has_nn = work + 2 * wstride < wend;
-      uint8_t *w1 = s_win + (par ^ 1) * C::kWinBytes;
-      if (w5) {
-        if (has_next) h8s_issue_window<K3, K4>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, w1, lo);
-        H8S_T(2)
-        uint4 ov[4];
-        if (has_prev) h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
-        if (has_next && a.blend) h8s_issue_q2(a, trk.l2[t1.track], t1.tx0(), t1.ty0(), lane, s_q + (par ^ 1) * 4096);
-        if (has_prev) h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
-      } else {
-        if (has_next) h8s_issue_window<K1, K2>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, w1, lo);
-        H8S_T(2)
-      }
-      H8S_T(3)
-      H8S_BARRIER();                                                                   // B(n): window slot n & 1 is free
-      H8S_T(4)
-      if (has_nn) {
-        uint8_t *w2 = s_win + par * C::kWinBytes;
-        if (w5) { h8s_issue_window<K2, K3>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
-        else { h8s_issue_window<K0, K1>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
-      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      H8S_T(6)
-      if (has_next) {
-        if (h8s_border(t1.tx0(), a.sw)) {
-          if (w5) h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K2 * 64, K4 * 64); else h8s_fix_edges(w1, t1.tx0(), a.sw, lane, K0 * 64, K2 * 64);
-        }
-        if (OPT & 1) {
-          if (w5) h8s_bias_window<K2 * 1024, C::kWinBytes>(w1, lane); else h8s_bias_window<K0 * 1024, K2 * 1024>(w1, lane);
-        }
-      }
-      tp = t0; has_prev = true; t0 = t1; t1 = t2; t2.step();
-      par ^= 1;
-    }
-    H8S_BARRIER();                                                                     // A(last + 1): the last tile is in its slot
-    if (w5) {
-      uint4 ov[4];
-      h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
-      h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
-    }
-    if (DBG && lane == 0)
-      for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * (kH8sCW + 2) + wave) * 8 + i] = tacc[i];
-    return;
-  }
-
-  // -------------------------------------------------- compute waves --------------------------------------------------
   uint32_t bf = a.bf, nbf = a.nbf;
   if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
   const int4v b_hi = a.bfrag[lane], b_lo = a.bfrag[64 + lane];
@@ -775,18 +675,19 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
   const int ly0 = wave * RPW;
   const int m = lane & 15, g = lane >> 4;
   // A fragments: lane (g, m) supplies row m, bytes 16 g .. 16 g + 15 of the block's 64-byte span.  Blocks 0 / 1 are window
-  // rows 16 mb + m.  Block 2 (OPT & 2): D register r of lane group g is row 4 g + r of the block, so with the block's row
+  // rows 16 mb + m.  Block 2: D register r of lane group g is row 4 g + r of the block, so with the block's row
   // 4 g' + r' := window row 32 + 2 g' + (r' & 1) the six live rows 32..37 come out as registers 0 / 1 of groups 0..2,
-  // already paired the way the vertical pass wants them (row pair 16 + g); group 3 / registers 2, 3 are not looked at.
-  const int arow2 = (OPT & 2) ? 32 + 2 * (m >> 2) + (m & 1) : 32 + m;
+  // already paired the way the vertical pass wants them (row pair 16 + g); group 3 / registers 2, 3 are not looked at
+  // (rows 38 / 39 read whatever follows the slot: it is multiplied and dropped).
   const uint32_t aoff = (uint32_t)(m * kH8Pitch + wave * (NQ * 32) + g * 16);
-  const uint32_t aoff2 = (uint32_t)(arow2 * kH8Pitch + wave * (NQ * 32) + g * 16);
+  const uint32_t aoff2 = (uint32_t)((32 + 2 * (m >> 2) + (m & 1)) * kH8Pitch + wave * (NQ * 32) + g * 16);
   int par = 0;
   if (DBG) tprev = __builtin_amdgcn_s_memtime();
   for (; work < wend; work += wstride) {
     H8S_T(0)
     H8S_BARRIER();                                                                     // A(n)
     H8S_T(1)
+    if (ABL & 16) { H8S_BARRIER(); par ^= 1; continue; }
     // ---- horizontal pass on the matrix cores ----
     // Software pipelined over the three 16-row blocks: the four A fragments of block mb + 1 are read while block mb is
     // on the matrix pipe, and a block's eight MFMAs are issued back to back before any result is consumed.
@@ -807,11 +708,10 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
         const int4v zero = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-          const int4v ab = (OPT & 1) ? av[q] : av[q] ^ (int)0x80808080;
-          dh[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_hi, zero, 0, 0, 0);
-          dl[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ab, b_lo, cbias, 0, 0, 0);
+          dh[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[q], b_hi, zero, 0, 0, 0);
+          dl[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[q], b_lo, cbias, 0, 0, 0);
         }
-        if (mb == 2 && (OPT & 2)) {
+        if (mb == 2) {
           const int pr = 16 + g;
 #pragma unroll
           for (int q = 0; q < NQ; q++) {
@@ -828,8 +728,8 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
             const short2v q0 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x1, x0, 0x06050201u)), tmax);
             const short2v q1 = __builtin_elementwise_min(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(x3, x2, 0x06050201u)), tmax);
             uint32_t *hp = hbase + pr * C::kHPitch + q * 16;
-            if (pr < C::kPairs) hp[0] = __builtin_bit_cast(uint32_t, q0);
-            if (pr + 1 < C::kPairs) hp[C::kHPitch] = __builtin_bit_cast(uint32_t, q1);
+            hp[0] = __builtin_bit_cast(uint32_t, q0);
+            hp[C::kHPitch] = __builtin_bit_cast(uint32_t, q1);
           }
         }
         if (mb + 1 < C::kMBlocks) {
@@ -865,124 +765,62 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
 #undef H8_DOT
         px[i] = pack_sat_shr21(a0, a1, a2, a3);
       }
-      if (OPT & 4) {
-        if (a.blend) {
-          // mix sums r_c = bf * s2_c + nbf * s1_c (< 2^16, the blended byte is r_c >> 8) for the three colour channels
-          const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
-          uint32_t r0[RPW], r1[RPW], r2[RPW];
-          bool opaque = true;
+      // The workgroup has no static LDS, so the dynamic segment starts at LDS address 0 and a table's address is its offset:
+      // the table base folds into the ds_read offset field.
+      typedef const __attribute__((address_space(3))) uint8_t *lds_u8;
+      if (a.blend) {
+        // mix sums r_c = bf * s2_c + nbf * s1_c (< 2^16, the blended byte is r_c >> 8) for the three colour channels
+        const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+        uint32_t r0[RPW], r1[RPW], r2[RPW];
+        bool opaque = true;
 #pragma unroll
-          for (int i = 0; i < RPW; i++) opaque = opaque && (q2[i] >= 0xFF000000u);
-          if (__all(opaque)) {           // what decoded video is: no scaling (simple_blend.c:128-131)
+        for (int i = 0; i < RPW; i++) opaque = opaque && (q2[i] >= 0xFF000000u);
+        if (__all(opaque)) {           // what decoded video is: no scaling (simple_blend.c:128-131)
 #pragma unroll
-            for (int i = 0; i < RPW; i++) {
-              const uint32_t x01 = __builtin_amdgcn_perm(px[i], q2[i], 0x05010400u);     // [q.b0 p.b0 q.b1 p.b1]
-              const uint32_t x2 = __builtin_amdgcn_perm(px[i], q2[i], 0x0C0C0602u);      // [q.b2 p.b2 0 0]
-              r0[i] = __builtin_amdgcn_udot4(x01, w_lo, 0u, false); r1[i] = __builtin_amdgcn_udot4(x01, w_hi, 0u, false);
-              r2[i] = __builtin_amdgcn_udot4(x2, w_lo, 0u, false);
-            }
-          } else {
-            // s2_c = (q_c * K2[alpha]) >> 16, s1_c = (p_c * K1[alpha]) >> 16: byte 2 of a 24-bit product each
-            uint2 kk[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; i++)
-              if (OPT & 8) {
-                typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-                const u32x2v t = *reinterpret_cast<const __attribute__((address_space(3))) u32x2v *>((uintptr_t)(C::kOffK + (q2[i] >> 24) * 8));
-                kk[i] = make_uint2(t.x, t.y);
-              } else kk[i] = s_k[q2[i] >> 24];
-#pragma unroll
-            for (int i = 0; i < RPW; i++) {
-              const uint32_t q = q2[i], p = px[i];
-              const uint32_t qa = __umul24(q & 0xFF, kk[i].x), qb = __umul24((q >> 8) & 0xFF, kk[i].x), qc = __umul24((q >> 16) & 0xFF, kk[i].x);
-              const uint32_t pa = __umul24(p & 0xFF, kk[i].y), pb = __umul24((p >> 8) & 0xFF, kk[i].y), pc = __umul24((p >> 16) & 0xFF, kk[i].y);
-              r0[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa, 0x0C0C0602u), w_lo, 0u, false);   // [s2 s1 0 0] . [bf nbf 0 0]
-              r1[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb, 0x0C0C0602u), w_lo, 0u, false);
-              r2[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc, 0x0C0C0602u), w_lo, 0u, false);
-            }
+          for (int i = 0; i < RPW; i++) {
+            const uint32_t x01 = __builtin_amdgcn_perm(px[i], q2[i], 0x05010400u);     // [q.b0 p.b0 q.b1 p.b1]
+            const uint32_t x2 = __builtin_amdgcn_perm(px[i], q2[i], 0x0C0C0602u);      // [q.b2 p.b2 0 0]
+            r0[i] = __builtin_amdgcn_udot4(x01, w_lo, 0u, false); r1[i] = __builtin_amdgcn_udot4(x01, w_hi, 0u, false);
+            r2[i] = __builtin_amdgcn_udot4(x2, w_lo, 0u, false);
           }
-          if (a.use_lut) {
-            uint32_t o0[RPW], o1[RPW], o2[RPW];
-            if (OPT & 8) {
-              // the workgroup has no static LDS, so the dynamic segment starts at LDS address 0 and a table's address is its offset:
-              // the table base folds into the ds_read offset field, the index is one shift
-              typedef const __attribute__((address_space(3))) uint8_t *lds_u8;
+        } else {
+          // s2_c = (q_c * K2[alpha]) >> 16, s1_c = (p_c * K1[alpha]) >> 16: byte 2 of a 24-bit product each (simple_blend.c:137-145
+          // as integers, lgpu_alpha_scalers); alpha = 255 maps to the identity, so opaque pixels need no select
+          typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+          u32x2v kk[RPW];
 #pragma unroll
-              for (int i = 0; i < RPW; i++) {
-                o0[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r0[i] >> 8)); o1[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r1[i] >> 8));
-                o2[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r2[i] >> 8));
-              }
+          for (int i = 0; i < RPW; i++) kk[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x2v *>((uintptr_t)(C::kOffK + (q2[i] >> 24) * 8));
 #pragma unroll
-              for (int i = 0; i < RPW; i++) {
-                uint32_t t = (o2[i] << 8) | o1[i];
-                t = (t << 8) | o0[i];
-                px[i] = (px[i] & 0xFF000000u) | t;
-              }
-            } else {
-#pragma unroll
-              for (int i = 0; i < RPW; i++) { o0[i] = s_lut[r0[i] >> 8]; o1[i] = s_lut[r1[i] >> 8]; o2[i] = s_lut[r2[i] >> 8]; }
-#pragma unroll
-              for (int i = 0; i < RPW; i++) px[i] = o0[i] | (o1[i] << 8) | (o2[i] << 16) | (px[i] & 0xFF000000u);
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < RPW; i++)
-              px[i] = __builtin_amdgcn_perm(r1[i], r0[i], 0x0C0C0501u) | ((r2[i] << 8) & 0x00FF0000u) | (px[i] & 0xFF000000u);
-          }
-        } else if (a.use_lut) {
-#pragma unroll
-          for (int i = 0; i < RPW; i++) px[i] = lut3_rgba(s_lut, px[i]);
-        }
-      } else {
-        // ---- round-1 epilogue (float scaling of translucent pixels), kept for the A / B rows ----
-        const float *s_alpha = reinterpret_cast<const float *>(s_k);
-        if (a.blend) {
-          const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
-          bool opaque = true;
-#pragma unroll
-          for (int i = 0; i < RPW; i++) opaque = opaque && ((q2[i] >> 24) == 255);
-          if (__all(opaque)) {
-#pragma unroll
-            for (int i = 0; i < RPW; i++) px[i] = mix3_dot4(px[i], q2[i], w_lo, w_hi) | (px[i] & 0xFF000000u);
-          } else {
-            float alpha[RPW], inv[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; i++) { alpha[i] = s_alpha[q2[i] >> 24]; inv[i] = __fsub_rn(1.0f, alpha[i]); }
-            uint32_t f1[RPW], f2[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; i += 2) {
-              float mm[12];
-#pragma unroll
-              for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                  mm[k * 6 + c] = __fmul_rn((float)((q2[i + k] >> (8 * c)) & 0xFF), alpha[i + k]);
-                  mm[k * 6 + 3 + c] = __fmul_rn((float)((px[i + k] >> (8 * c)) & 0xFF), inv[i + k]);
-                }
-              asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-                           "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\tv_cvt_pk_u8_f32 %0, %5, 1, %0\n\tv_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
-                           "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
-                           "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\tv_cvt_pk_u8_f32 %2, %11, 1, %2\n\tv_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
-                           "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\tv_cvt_pk_u8_f32 %3, %14, 1, %3\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
-                           "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                           : "=&v"(f2[i]), "=&v"(f1[i]), "=&v"(f2[i + 1]), "=&v"(f1[i + 1])
-                           : "v"(mm[0]), "v"(mm[1]), "v"(mm[2]), "v"(mm[3]), "v"(mm[4]), "v"(mm[5]), "v"(mm[6]), "v"(mm[7]), "v"(mm[8]), "v"(mm[9]), "v"(mm[10]), "v"(mm[11]));
-            }
-#pragma unroll
-            for (int i = 0; i < RPW; i++) {
-              const uint32_t q = q2[i], p = px[i];
-              const bool op = (q >> 24) == 255;
-              px[i] = mix3_dot4(op ? p : f1[i], op ? q : f2[i], w_lo, w_hi) | (p & 0xFF000000u);
-            }
+          for (int i = 0; i < RPW; i++) {
+            const uint32_t q = q2[i], p = px[i];
+            const uint32_t qa = __umul24(q & 0xFF, kk[i].x), qb = __umul24((q >> 8) & 0xFF, kk[i].x), qc = __umul24((q >> 16) & 0xFF, kk[i].x);
+            const uint32_t pa = __umul24(p & 0xFF, kk[i].y), pb = __umul24((p >> 8) & 0xFF, kk[i].y), pc = __umul24((p >> 16) & 0xFF, kk[i].y);
+            r0[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa, 0x0C0C0602u), w_lo, 0u, false);   // [s2 s1 0 0] . [bf nbf 0 0]
+            r1[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb, 0x0C0C0602u), w_lo, 0u, false);
+            r2[i] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc, 0x0C0C0602u), w_lo, 0u, false);
           }
         }
-        if (a.use_lut) {
-          uint32_t r[RPW], gg[RPW], b[RPW];
+        if (a.use_lut) {               // the LUT is gathered straight from the mix sums: index = r_c >> 8
+          uint32_t o0[RPW], o1[RPW], o2[RPW];
 #pragma unroll
-          for (int i = 0; i < RPW; i++) { r[i] = s_lut[px[i] & 0xFF]; gg[i] = s_lut[(px[i] >> 8) & 0xFF]; b[i] = s_lut[(px[i] >> 16) & 0xFF]; }
+          for (int i = 0; i < RPW; i++) {
+            o0[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r0[i] >> 8)); o1[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r1[i] >> 8));
+            o2[i] = *(lds_u8)(uintptr_t)(C::kOffLut + (r2[i] >> 8));
+          }
 #pragma unroll
-          for (int i = 0; i < RPW; i++) px[i] = r[i] | (gg[i] << 8) | (b[i] << 16) | (px[i] & 0xFF000000u);
+          for (int i = 0; i < RPW; i++) {
+            uint32_t t = (o2[i] << 8) | o1[i];
+            t = (t << 8) | o0[i];
+            px[i] = (px[i] & 0xFF000000u) | t;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RPW; i++)
+            px[i] = __builtin_amdgcn_perm(r1[i], r0[i], 0x0C0C0501u) | ((r2[i] << 8) & 0x00FF0000u) | (px[i] & 0xFF000000u);
         }
+      } else if (a.use_lut) {
+#pragma unroll
+        for (int i = 0; i < RPW; i++) px[i] = lut3_rgba(s_lut, px[i]);
       }
 #pragma unroll
       for (int i = 0; i < RPW; i++) qs[i * kTileW] = px[i];
@@ -991,10 +829,138 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
   }
   H8S_BARRIER();                                                                       // A(last + 1)
   if (DBG && lane == 0)
-    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * (kH8sCW + 2) + wave) * 8 + i] = tacc[i];
+    for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * NWAVES + wave) * 8 + i] = tacc[i];
 #undef H8S_T
 }
 
+// shared prologue: tables into LDS, this workgroup's share of the XCD-aware persistent work list (each XCD owns a contiguous
+// eighth of the (track, tile) list, so that the window halos of neighbouring tiles hit that XCD's L2)
+__device__ __forceinline__ bool h8s_prologue(const Half8Args &a, const Lut8 &lut, uint8_t *smem, int &work, int &wend, int &wstride) {
+  const int tid = threadIdx.x;
+  if (a.use_lut) stage_lut(smem + H8S::kOffLut, lut);
+  if (a.blend && tid < 256) reinterpret_cast<uint2 *>(smem + H8S::kOffK)[tid] = a.kscale[tid];
+  const int nwork = a.tiles_x * a.tiles_y * a.ntracks;
+  const int xcd = blockIdx.x & 7;
+  wstride = (int)(gridDim.x >> 3);
+  const int chunk = (nwork + 7) >> 3;
+  wend = min((xcd + 1) * chunk, nwork);
+  work = xcd * chunk + (int)(blockIdx.x >> 3);
+  return work < wend;                              // workgroup-uniform
+}
+
+// ---- the kernel: compute waves above + two memory waves feeding the window ring by LDS-DMA (global_load_lds) ----------
+// Measured alternatives (profiles/r02/step3_*): one window slot with three workgroups per CU 223-245 us against 169; a non-temporal
+// policy on the source stream 196 against 176 (the halos live in L2); windows staged through registers by two loader waves and
+// a mover wave (two more windows in flight per workgroup, hand-counted vmcnt) 173.3 against 173.3, memory side alone 163 against
+// 161: the bytes in flight are not the limit -- with the compute waves ablated the launch moves its 818 MB at 5.0 TB/s, the
+// rate a device-to-device hipMemcpy of the same size reaches on the same box (5.17 TB/s).
+template <int DBG, int ABL>
+__global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTracks trk, Lut8 lut) {
+  using C = H8S;
+  using L = H8SL;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t *s_win = smem + C::kOffWin;            // 2 x [38][136] packed source pixels
+  uint8_t *s_q = smem + L::kOffQ;                // 2 x [16][64] pixels: layer 2 in, finished tile out
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int work, wend, wstride;
+  if (!h8s_prologue(a, lut, smem, work, wend, wstride)) return;
+  if (wave < kH8sCW) { h8s_compute<DBG, ABL, kH8sCW + 2>(a, smem, wave, lane, work, wend, wstride); return; }
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define H8S_T(i)                                                                                     \
+  if (DBG) {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                     \
+    tacc[i] += now_ - tprev; tprev = now_;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  {
+
+    // ------------------------------------------------ memory waves ------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);     // few instructions, all of them feeding the DMA queues: let them issue ahead of the compute waves (-0.8 % per launch)
+    // Wave 4 fetches window DMA instructions 0..15, wave 5 fetches 16..20 and also moves the layer-2 / result tiles.
+    // Window n+2 goes to slot n & 1, free after B(n) and needed at A(n+2); each wave issues the first part of its
+    // share between B(n) and A(n+1) and the rest between A(n+1) and B(n+1), so both barrier intervals carry traffic:
+    //   A(n)   | rest of window n+1; wave 5: read tile n-1 from its ring slot, layer-2 DMA n+1 into it, store tile n-1
+    //   B(n)   | first part of window n+2 | wait for all but that part: window n+1 (and layer-2 n+1) have landed |
+    //          | edge fix-up and int8 bias of window n+1 (own chunks)
+    constexpr int WAUX = 0;                                      // cache policy of the source stream (non-temporal measured 196 us against 176: the halos live in L2)
+    constexpr int K2 = (ABL & 64) ? 11 : 16;                     // A / B: balanced split of a window between the two waves
+    constexpr int K0 = 0, K1 = (ABL & 128) ? K2 : 6, K3 = 21, K4 = 21;     // wave 4: [K0,K1) after B + [K1,K2) after A; wave 5: [K2,K3) after B (+ [K3,K4) after A)
+    const bool w5 = wave == kH8sCW + 1;
+    H8sLaneOff lo;
+    h8s_lane_offsets(a, lane, lo);
+    H8sTile t0, t1, t2;               // tiles n, n+1, n+2
+    t0.init(a, work, wstride); t1 = t0; t1.step(); t2 = t1; t2.step();
+    const bool has1 = work + wstride < wend;
+    if (w5) {
+      if (a.blend) h8s_issue_q2(a, trk.l2[t0.track], t0.tx0(), t0.ty0(), lane, s_q);
+      if (!(ABL & 32)) h8s_issue_window<K2, K4, WAUX>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
+      if (has1) { if (!(ABL & 32)) h8s_issue_window<K2, K3, WAUX>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (h8s_border(2 * t0.tx0() - 3 - a.xoff, a.sw)) h8s_fix_edges(s_win, 2 * t0.tx0() - 3 - a.xoff, a.sw, lane, K2 * 64, K4 * 64);
+      h8s_bias_window<K2 * 1024, C::kWinBytes>(s_win, lane);
+    } else {
+      if (!(ABL & 32)) h8s_issue_window<K0, K2, WAUX>(a, trk.src[t0.track], t0.tx0(), t0.ty0(), lane, s_win, lo);
+      if (has1) { if (!(ABL & 32)) h8s_issue_window<K0, K1, WAUX>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, s_win + C::kWinBytes, lo); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (h8s_border(2 * t0.tx0() - 3 - a.xoff, a.sw)) h8s_fix_edges(s_win, 2 * t0.tx0() - 3 - a.xoff, a.sw, lane, K0 * 64, K2 * 64);
+      h8s_bias_window<K0 * 1024, K2 * 1024>(s_win, lane);
+    }
+    H8sTile tp = t0;                  // tile n-1
+    bool has_prev = false;
+    int par = 0;
+    if (DBG) tprev = __builtin_amdgcn_s_memtime();
+    for (; work < wend; work += wstride) {
+      H8S_T(0)
+      H8S_BARRIER();                                                                   // A(n)
+      H8S_T(1)
+      const bool has_next = work + wstride < wend, has_nn = work + 2 * wstride < wend;
+      uint8_t *w1 = s_win + (par ^ 1) * C::kWinBytes;
+      if (w5) {
+        if (has_next) if (!(ABL & 32)) h8s_issue_window<K3, K4, WAUX>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, w1, lo);
+        H8S_T(2)
+        uint4 ov[4];
+        if (has_prev) h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
+        if (has_next && a.blend) h8s_issue_q2(a, trk.l2[t1.track], t1.tx0(), t1.ty0(), lane, s_q + (par ^ 1) * 4096);
+        if (has_prev) h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
+      } else {
+        if (has_next) if (!(ABL & 32)) h8s_issue_window<K1, K2, WAUX>(a, trk.src[t1.track], t1.tx0(), t1.ty0(), lane, w1, lo);
+        H8S_T(2)
+      }
+      H8S_T(3)
+      H8S_BARRIER();                                                                   // B(n): window slot n & 1 is free
+      H8S_T(4)
+      if (has_nn) {
+        uint8_t *w2 = s_win + par * C::kWinBytes;
+        if (w5) { if (!(ABL & 32)) h8s_issue_window<K2, K3, WAUX>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K3 - K2) : "memory"); }
+        else { if (!(ABL & 32)) h8s_issue_window<K0, K1, WAUX>(a, trk.src[t2.track], t2.tx0(), t2.ty0(), lane, w2, lo); H8S_T(5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1 - K0) : "memory"); }
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      H8S_T(6)
+      if (has_next) {
+        const int sx1 = 2 * t1.tx0() - 3 - a.xoff;
+        if (h8s_border(sx1, a.sw)) {
+          if (w5) h8s_fix_edges(w1, sx1, a.sw, lane, K2 * 64, K4 * 64); else h8s_fix_edges(w1, sx1, a.sw, lane, K0 * 64, K2 * 64);
+        }
+        {
+          if (w5) h8s_bias_window<K2 * 1024, C::kWinBytes>(w1, lane); else h8s_bias_window<K0 * 1024, K2 * 1024>(w1, lane);
+        }
+      }
+      tp = t0; has_prev = true; t0 = t1; t1 = t2; t2.step();
+      par ^= 1;
+    }
+    H8S_BARRIER();                                                                     // A(last + 1): the last tile is in its slot
+    if (w5) {
+      uint4 ov[4];
+      h8s_read_tile(lane, s_q + (par ^ 1) * 4096, ov);
+      h8s_store_tile(a, trk.dst[tp.track], tp.tx0(), tp.ty0(), lane, ov);
+    }
+    if (DBG && lane == 0)
+      for (int i = 0; i < 8; i++) a.dbg[((size_t)blockIdx.x * (kH8sCW + 2) + wave) * 8 + i] = tacc[i];
+    return;
+  
+  }
+#undef H8S_T
+}
 
 // ---- generic two-launch path: any pixel size (bytes are independent channels), global int16 scratch ----
 __global__ __launch_bounds__(kBlock) void k_hpass_generic(const uint8_t *src, int irow, int sw, int sh, int16_t *tmp, int dw,
@@ -1111,17 +1077,16 @@ static int kernel_for_interp(int interp, bool upscale) {
 struct Half8Const {
   int4v *bfrag = nullptr;     // device [2][64]
   uint2 *kscale = nullptr;    // device [256]
-  float *alpha = nullptr;     // device [2][256] (round-1 epilogue of the A / B builds)
 };
 static std::mutex g_h8_mu;
 static std::map<std::pair<int, std::vector<int16_t>>, Half8Const> g_h8;   // (device, 8 taps + swap flag)
 
-static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const **out) {
+static int get_half8_const(const int16_t taps[8], int swap_rb, int xoff, const Half8Const **out) {
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_h8_mu);
   std::vector<int16_t> kv(taps, taps + 8);
-  kv.push_back((int16_t)swap_rb);
+  kv.push_back((int16_t)(swap_rb | (xoff << 1)));
   auto key = std::make_pair(dev, kv);
   auto it = g_h8.find(key);
   if (it == g_h8.end()) {
@@ -1136,7 +1101,7 @@ static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const 
         const int k = 16 * (l >> 4) + e, n = l & 15;
         const int px = k >> 2, sbyte = k & 3, col = n >> 2, och = n & 3;
         const int want = swap_rb ? (och == 0 ? 2 : och == 2 ? 0 : och) : och;
-        const int j = px - 2 * col;
+        const int j = px - 2 * col - xoff;
         const int tap = (sbyte == want && j >= 0 && j < 8) ? taps[j] : 0;
         frag[0][l][e] = (int8_t)(tap >> 6);        // tap = 64 * hi + lo, lo in [0, 63]
         frag[1][l][e] = (int8_t)(2 * (tap & 63));  // stored doubled (see k_half8s)
@@ -1146,24 +1111,17 @@ static int get_half8_const(const int16_t taps[8], int swap_rb, const Half8Const 
     if (rc) return rc;
     uint2 ks[256];
     for (int al = 0; al < 256; al++) ks[al] = make_uint2(k2[al], k1[al]);
-    float at[512];
-    for (int al = 0; al < 256; al++) {             // simple_blend.c:137: alpha = (float)a / 255., inv_alpha = 1. - alpha
-      const float alpha = (float)al / 255., inv = 1. - alpha;
-      at[al] = alpha; at[256 + al] = inv;
-    }
     LGPU_HIP(hipMalloc((void **)&c.bfrag, sizeof frag));
     LGPU_HIP(hipMalloc((void **)&c.kscale, sizeof ks));
-    LGPU_HIP(hipMalloc((void **)&c.alpha, sizeof at));
     LGPU_HIP(hipMemcpy(c.bfrag, frag, sizeof frag, hipMemcpyHostToDevice));
     LGPU_HIP(hipMemcpy(c.kscale, ks, sizeof ks, hipMemcpyHostToDevice));
-    LGPU_HIP(hipMemcpy(c.alpha, at, sizeof at, hipMemcpyHostToDevice));
     it = g_h8.emplace(key, c).first;
   }
   *out = &it->second;
   return LGPU_OK;
 }
 
-static int g_h8s_opt = 7;
+static int g_h8s_opt = 0;
 #ifdef LGPU_H8S_AB
 extern "C" int lgpu_h8s_set_opt(int opt) { g_h8s_opt = opt; return LGPU_OK; }   // A / B builds only (tools/ab_h8s.py), not part of the ABI
 #endif
@@ -1183,12 +1141,18 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
     }
     if (hsum != 16384 || vsum != 16384 || hneg > 4096) return LGPU_E_UNSUPPORTED;   // |t - 16384| <= 16384 + 2 * hneg + 1 < 2^15
   }
+  // 16-byte aligned requests when every source row starts 16-byte aligned: the window then starts at source x = 2 * tx0 - 4
+  // (a multiple of four pixels) and the tap matrix is shifted by one pixel instead
+  int xoff = ((irow & 15) == 0) ? 1 : 0;
+  for (int i = 0; i < ntracks; i++) if ((uintptr_t)t.src[i] & 15) xoff = 0;
+  if (g_h8s_opt & 256) xoff = 0;                   // A / B builds
   const Half8Const *hc;
-  int rc = get_half8_const(hb->hco.data(), swap_rb, &hc);
+  int rc = get_half8_const(hb->hco.data(), swap_rb, xoff, &hc);
   if (rc) return rc;
   Half8Args a;
+  a.xoff = xoff;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
-  a.bfrag = hc->bfrag; a.kscale = hc->kscale; a.alpha_tab = hc->alpha;
+  a.bfrag = hc->bfrag; a.kscale = hc->kscale;
   for (int k = 0; k < 4; k++) a.vc[k] = (uint32_t)(uint16_t)vb->hco[2 * k] | ((uint32_t)(uint16_t)vb->hco[2 * k + 1] << 16);
   a.swap_rb = swap_rb; a.blend = blend; a.irow2 = irow2; a.bf = bf; a.nbf = 0xFF - bf; a.bf_d = bf_d; a.use_lut = use_lut;
   a.ntracks = ntracks;
@@ -1198,34 +1162,34 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
   a.tiles_x = (dw + kTileW - 1) / kTileW; a.tiles_y = (dh + H8S::kTileH - 1) / H8S::kTileH;
   const int nwork = a.tiles_x * a.tiles_y * ntracks;
-  const size_t lds = H8S::kLds;
+  const int mode = g_h8s_opt & 255;                // A / B builds (tools/ab_h8s.py): ablations of k_half8s
+  const size_t lds = H8SL::kLds;
   int grid = g_cus * (int)(160 * 1024 / lds);
   if (grid > nwork) grid = nwork;
   grid = (grid + 7) & ~7;                      // whole workgroups per XCD
-  const int opt = g_h8s_opt;     // A / B builds only, see k_half8s
-#define H8S_LAUNCH(DBG_, OPT_)                                                                                          \
+#define H8S_LAUNCH(DBG_, ABL_)                                                                                          \
   do {                                                                                                                  \
-    LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<DBG_, OPT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_half8s<DBG_, OPT_>), dim3((unsigned)grid), dim3(kH8sThreads), lds, st, a, t, l);              \
+    LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<DBG_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_half8s<DBG_, ABL_>), dim3((unsigned)grid), dim3(kH8sThreads), lds, st, a, t, l);              \
   } while (0)
 #ifdef LGPU_PROFILING
   static const bool dbg_s = getenv("LGPU_H8S_DEBUG") != nullptr;
   if (dbg_s) {     // in-kernel phase profile: s_memtime ticks between fixed points of the tile loop, per wave
     static unsigned long long *g_dbg_s = nullptr;
-    if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * (kH8sCW + 2) * 4096));
+    constexpr int nw = kH8sCW + 2;
+    if (!g_dbg_s) LGPU_HIP(hipMalloc((void **)&g_dbg_s, sizeof(unsigned long long) * 8 * nw * 4096));
     a.dbg = g_dbg_s;
-    H8S_LAUNCH(1, 7);
+    H8S_LAUNCH(1, 0);
     static int dumps = 0;
     if (dumps++ < 3) {
       LGPU_HIP(hipStreamSynchronize(st));
-      std::vector<unsigned long long> h((size_t)grid * 8 * (kH8sCW + 2));
+      std::vector<unsigned long long> h((size_t)grid * 8 * nw);
       LGPU_HIP(hipMemcpy(h.data(), g_dbg_s, h.size() * 8, hipMemcpyDeviceToHost));
       double c[8] = {0}, m[8] = {0}, m5[8] = {0};
       for (int b = 0; b < grid; b++)
         for (int i = 0; i < 8; i++) {
-          for (int w = 0; w < kH8sCW; w++) c[i] += (double)h[((size_t)b * (kH8sCW + 2) + w) * 8 + i] / kH8sCW;
-          m[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW) * 8 + i];
-          m5[i] += (double)h[((size_t)b * (kH8sCW + 2) + kH8sCW + 1) * 8 + i];
+          for (int w = 0; w < kH8sCW; w++) c[i] += (double)h[((size_t)b * nw + w) * 8 + i] / kH8sCW;
+          m[i] += (double)h[((size_t)b * nw + kH8sCW) * 8 + i]; m5[i] += (double)h[((size_t)b * nw + kH8sCW + 1) * 8 + i];
         }
       const double it = (double)nwork;
       fprintf(stderr, "[h8s compute wave, ticks/tile] V+epilogue %.0f | wait A %.0f | H %.0f | wait B %.0f\n", c[0] / it, c[1] / it, c[2] / it, c[3] / it);
@@ -1238,16 +1202,14 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
     return LGPU_OK;
   }
 #endif
-  switch (opt) {
+  switch (mode) {
 #ifdef LGPU_H8S_AB
-    case 0: H8S_LAUNCH(0, 0); break;
-    case 1: H8S_LAUNCH(0, 1); break;
-    case 3: H8S_LAUNCH(0, 3); break;
-    case 4: H8S_LAUNCH(0, 4); break;
-    case 5: H8S_LAUNCH(0, 5); break;
-    case 15: H8S_LAUNCH(0, 15); break;
+    case 16: H8S_LAUNCH(0, 16); break;      // no compute: memory waves and barriers only
+    case 32: H8S_LAUNCH(0, 32); break;      // no source window DMA: compute, layer 2 and stores only
+    case 2: H8S_LAUNCH(0, 128); break;      // wave 4 issues its whole share of a window right after B
+    case 3: H8S_LAUNCH(0, 192); break;      // the same with an 11 / 10 split of the DMA rounds
 #endif
-    default: H8S_LAUNCH(0, 7); break;
+    default: H8S_LAUNCH(0, 0); break;
   }
 #undef H8S_LAUNCH
   LGPU_CHECK_LAUNCH();
