@@ -40,6 +40,9 @@ const char *lgpu_last_error(void);
 int lgpu_device_count(void);
 /* device memory + copies for hosts without their own allocator (the layer seam uses these) */
 int lgpu_malloc(void **ptr_d, size_t bytes);
+/* diagnostics: the nth lgpu_malloc from now (1 = the next one) fails with LGPU_E_NOMEM; 0 disarms.  Used by the tests of the
+   "failure leaves the layer untouched" contract (memfail:, src/colourspace.c:13906-13927) to fail a call after it has started. */
+int lgpu_debug_fail_alloc(int nth);
 int lgpu_free(void *ptr_d);
 int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream);
 int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream);
@@ -50,6 +53,11 @@ void lgpu_pinned_free(void *p);
 int lgpu_copy(void *dst_d, const void *src_d, size_t bytes, void *stream);      /* device to device */
 int lgpu_fill(void *dst_d, int byte, size_t bytes, void *stream);
 int lgpu_sync(void *stream);
+/* rows of row_bytes bytes between two pitched device buffers (what compact_rowstrides :14439 and the cut of unletterbox_layer :15612-15615 do) */
+int lgpu_copy_rows(void *dst_d, int orow, const void *src_d, int irow, int row_bytes, int rows, void *stream);
+/* n repetitions of a plen-byte (1..8) pattern at the start of every row: a palette's black as blank_pixel / blank_row paint it
+   (src/colourspace.c:11123-11210), for weed_layer_clear_pixel_data on device-resident planes */
+int lgpu_fill_pattern(void *dst_d, int rowstride, const uint8_t *pattern, int plen, int n, int rows, void *stream);
 
 /* ---- host-side table builders (pure CPU, usable without a device) -------------------------------- */
 /* conversion tables; replaces init_RGB_to_YUV_tables / init_YUV_to_RGB_tables (src/colourspace.c:851-1105).

@@ -14,8 +14,15 @@
  * INTEGRATION.md).
  *
  * Pixel data stays HOST memory at this seam (that is what every other part of LiVES expects): each call
- * uploads the planes it needs, runs the gfx950 kernels and downloads into freshly allocated host memory
- * (PCIe-bound; keeping a layer device-resident across a CONVERT chain is the next step).
+ * uploads the planes it needs, runs the gfx950 kernels, downloads into freshly allocated host memory and
+ * synchronises once before it returns (PCIe-bound).  A layer pinned with lives_gpu_layer_pin() keeps its planes
+ * in HBM instead: the same calls then only enqueue kernels on the resident buffers -- no copy, no
+ * synchronisation -- until lives_gpu_layer_sync() / _unpin() brings the pixels home.
+ *
+ * A call this library does not serve returns FALSE with the layer's pixels untouched and the caller's CPU
+ * body takes over; a PINNED layer is first synchronised and unpinned in that case, so the CPU body reads
+ * current bytes.  The reference's own first steps of convert_layer_palette_full (range switch, un-premultiply)
+ * may already have run by then: the layer is in the state the reference has after them.
  *
  * Coverage (anything else returns FALSE with the layer untouched, lgpu_last_error() says why):
  *   convert_layer_palette[_full]  RGB24/BGR24/RGBA32/BGRA32/ARGB32 <-> each other (selector tree
@@ -24,9 +31,14 @@
  *                                 YUVA8888 / YUV(A)444(4)P / UYVY / YUYV / YUV411 / YUV420P / YVU420P / YUV422P and those packed / 4:4:4
  *                                 planar / UYVY / YUYV / YUV411 palettes -> RGB; the clamped <-> unclamped switch; the YUV -> YUV pairs of
  *                                 lgpu_yuv_repack (lives_gpu.h)
- *   gamma_convert_layer / gamma_convert_sub_layer, alpha_premult (RGB with alpha, YUVA8888, YUVA4444P), resize_layer, letterbox_layer (packed RGB
- *   palettes and YUV420P / YVU420P / YUV422P / YUV444P planes; palette hints see INTEGRATION.md), create_empty_pixel_data,
- *   calc_rowstrides (with the fixed-rowstride rule when leaf_get_flags is bound)
+ *   gamma_convert_layer / _variant / gamma_convert_sub_layer, alpha_premult (RGB with alpha, YUVA8888, YUVA4444P), resize_layer / resize_layer_full
+ *   (tgt_gamma = the fused LUT8 post-pass), letterbox_layer, unletterbox_layer (packed RGB palettes and YUV420P / YVU420P / YUV422P / YUV444P
+ *   planes; palette hints see INTEGRATION.md), compact_rowstrides, create_empty_pixel_data, weed_layer_clear_pixel_data, calc_rowstrides (with the
+ *   fixed-rowstride rule when leaf_get_flags is bound)
+ *
+ * The reference NAMES (convert_layer_palette, resize_layer_full, ...) are exported as real symbols by the small shim
+ * lives_amd/liblivesgpu_dropin.so (csrc/dropin.c: one forwarding function per name), kept out of liblivesgpu.so itself so that a process
+ * which also carries the CPU bodies (LiVES during a staged migration, the parity tests) has no duplicate symbols.
  */
 #ifndef LIVES_GPU_LAYER_H
 #define LIVES_GPU_LAYER_H
@@ -65,13 +77,21 @@ int lives_gpu_bind_leaf_get_flags(weed_leaf_get_flags_f leaf_get_flags);
 lives_gpu_boolean lives_gpu_convert_layer_palette(lives_gpu_layer_t *layer, int outpl, int op_clamping);
 lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
                                                        int osubspace, int tgt_gamma);
+lives_gpu_boolean lives_gpu_convert_layer_palette_with_sampling(lives_gpu_layer_t *layer, int outpl, int out_sampling);   /* colourspace.h:397 */
 lives_gpu_boolean lives_gpu_gamma_convert_layer(int gamma_type, lives_gpu_layer_t *layer);
+lives_gpu_boolean lives_gpu_gamma_convert_layer_variant(double file_gamma, int tgt_gamma, lives_gpu_layer_t *layer);      /* colourspace.h:392 */
 lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y,
                                                     int width, int height, lives_gpu_boolean may_thread);
 void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction);
 lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint);
+/* colourspace.h:409-411; tgt_gamma: the LUT8 post-pass fused into the resize (src/colourspace.c:14718-14720, :15119-15127) */
+lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
+                                              int osamp_hint, int osubs_hint, int tgt_gamma);
 lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
                                             int tpal, int tclamp);
+lives_gpu_boolean lives_gpu_unletterbox_layer(lives_gpu_layer_t *layer, int opwidth, int opheight, int top, int bottom, int left, int right);   /* colourspace.h:418 */
+lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer);                     /* colourspace.h:420 */
+lives_gpu_boolean lives_gpu_weed_layer_clear_pixel_data(lives_gpu_layer_t *layer);            /* colourspace.h:399 */
 lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig);
 int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int *nplanes);
 
@@ -83,6 +103,10 @@ int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int
 int lives_gpu_layer_pin(lives_gpu_layer_t *layer);      /* upload the planes once, mark the layer resident */
 int lives_gpu_layer_sync(lives_gpu_layer_t *layer);     /* download the current planes into pixel_data; stays pinned */
 int lives_gpu_layer_unpin(lives_gpu_layer_t *layer);    /* sync, release the device copies, clear the leaf */
+/* the host is about to free or replace the pixel_data of a pinned layer itself (weed_layer_pixel_data_free, an error path): release the
+   device copies without a download and clear the leaf.  Device copies are keyed by host plane pointer, so this (or unpin) MUST precede
+   any release of a pinned layer's planes that does not go through this library. */
+int lives_gpu_layer_forget(lives_gpu_layer_t *layer);
 /* optional allocator pair for lives_gpu_weed_api.pixel_alloc / pixel_free: page-locked (hipHostMalloc) zeroed memory, so frames cross PCIe by DMA at
    link rate; pageable frames still work (they go through pinned staging chunks inside lgpu_upload / lgpu_download) */
 void *lives_gpu_pinned_calloc(size_t bytes);
@@ -95,6 +119,12 @@ void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long 
 #ifdef LIVES_GPU_DROP_IN
 #define convert_layer_palette lives_gpu_convert_layer_palette
 #define convert_layer_palette_full lives_gpu_convert_layer_palette_full
+#define convert_layer_palette_with_sampling lives_gpu_convert_layer_palette_with_sampling
+#define gamma_convert_layer_variant lives_gpu_gamma_convert_layer_variant
+#define resize_layer_full lives_gpu_resize_layer_full
+#define unletterbox_layer lives_gpu_unletterbox_layer
+#define compact_rowstrides lives_gpu_compact_rowstrides
+#define weed_layer_clear_pixel_data lives_gpu_weed_layer_clear_pixel_data
 #define gamma_convert_layer lives_gpu_gamma_convert_layer
 #define gamma_convert_sub_layer lives_gpu_gamma_convert_sub_layer
 #define alpha_premult lives_gpu_alpha_premult

@@ -15,6 +15,7 @@
 
 #ifndef WEED_PALETTE_END   /* ---- palettes: weed-palettes.h:43-102 ---- */
 #define WEED_PALETTE_NONE 0
+#define WEED_PALETTE_ANY -1          /* libweed/weed-palettes.h:41 */
 #define WEED_PALETTE_END 0
 #define WEED_PALETTE_RGB24 1
 #define WEED_PALETTE_BGR24 2

@@ -6,12 +6,22 @@
 //   letterbox_layer              src/colourspace.c:15343-15567
 //   create_empty_pixel_data      src/colourspace.c:11434-11700
 //   calc_rowstrides              src/colourspace.c:11252-11366
+//   weed_layer_clear_pixel_data  src/colourspace.c:11229-11244
+//   compact_rowstrides           src/colourspace.c:14439-14496
+//   unletterbox_layer            src/colourspace.c:15570-15628
 // re-written around the frame-level C ABI (lives_gpu.h).  All pixel work happens in the HIP kernels; this
 // file only reads / writes leaves through the accessors the host bound, moves planes over PCIe and keeps the
 // reference's bookkeeping (palette, size, rowstrides, gamma, premult flag, YUV leaves, failure = untouched layer).
+//
+// Data movement (struct Work below): an ordinary layer's planes are uploaded into per-thread scratch, the kernels run,
+// the results are downloaded into freshly allocated host planes and the call synchronises ONCE before it returns (host
+// bytes must be valid then).  A pinned layer (lives_gpu_layer_pin) keeps its planes in HBM: the kernels read and write
+// the resident buffers directly, new planes are pool buffers registered under the new host pointer, nothing is copied and
+// nothing synchronises -- the calls of a chain only enqueue work, the one synchronisation is lives_gpu_layer_sync().
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -96,7 +106,7 @@ bool read_layer(weed_plant_t *plant, Layer *l) {
 struct ResEntry { void *d; size_t bytes; };
 std::mutex g_res_mu;
 std::unordered_map<const void *, ResEntry> g_res;
-unsigned long long g_h2d = 0, g_d2h = 0;        // PCIe byte counters (tests check the residency contract with them)
+std::atomic<unsigned long long> g_h2d{0}, g_d2h{0};   // PCIe byte counters (tests check the residency contract with them)
 thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
 
 // device buffers of dropped planes are recycled (hipMalloc / hipFree cost ~0.1 ms each and synchronise the device): a pinned layer going
@@ -196,10 +206,10 @@ void commit_planes(weed_plant_t *plant, int pal, int width, int height, const Ne
 }
 
 // ---- device scratch (per calling thread; grown on demand) ------------------------------------------------------------
+// Not freed at thread exit: a thread_local destructor of the main thread runs after the HIP runtime has been torn down.
 struct Scratch {
   void *p[8] = {nullptr};
   size_t cap[8] = {0};
-  ~Scratch() { for (auto q : p) if (q) lgpu_free(q); }
   uint8_t *get(int i, size_t bytes) {
     if (cap[i] < bytes) {
       if (p[i]) lgpu_free(p[i]);
@@ -213,38 +223,90 @@ struct Scratch {
 thread_local Scratch t_scr;
 
 bool ready() { return bound() && lgpu_init(g_prefs.device) == LGPU_OK; }
-bool up(uint8_t *d, const uint8_t *h, size_t n) {
-  {
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    auto it = g_res.find(h);
-    if (it != g_res.end() && it->second.bytes >= n) return lgpu_copy(d, it->second.d, n, nullptr) == LGPU_OK;   // resident plane: stays in HBM
-  }
-  g_h2d += n;
-  return lgpu_upload(d, h, n, nullptr) == LGPU_OK;
-}
-// a freshly allocated (zeroed) host plane that a kernel is about to fill: nothing worth sending for a pinned layer
-bool up_fresh(uint8_t *d, const uint8_t *h, size_t n) {
-  if (t_pinned) return lgpu_fill(d, 0, n, nullptr) == LGPU_OK;
-  return up(d, h, n);
-}
-bool down(uint8_t *h, const uint8_t *d, size_t n) {
-  if (t_pinned) {                       // the device copy becomes the plane; the host bytes go stale until lives_gpu_layer_sync()
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    ResEntry &e = g_res[h];
-    if (e.bytes < n) {
-      pool_give(e.d, e.bytes);
-      e.d = nullptr; e.bytes = 0;
-      size_t cap = 0;
-      e.d = pool_take(n, &cap);
-      if (!e.d) { g_res.erase(h); return false; }
-      e.bytes = cap;
-    }
-    return lgpu_copy(e.d, d, n, nullptr) == LGPU_OK;
-  }
-  g_d2h += n;
-  return lgpu_download(h, d, n, nullptr) == LGPU_OK;
-}
 bool sync() { return lgpu_sync(nullptr) == LGPU_OK; }
+
+// resident device copy of a plane of the layer the call in progress works on (only pinned layers have one: the table is
+// keyed by host pointer, and a host pointer proves nothing about a layer that was never pinned)
+uint8_t *resident(const void *h, size_t n) {
+  if (!t_pinned || !h) return nullptr;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  auto it = g_res.find(h);
+  return (it != g_res.end() && it->second.bytes >= n) ? (uint8_t *)it->second.d : nullptr;
+}
+
+// One seam call's device-side work.  in(): the current bytes of an existing plane.  out(): a plane the call creates (for a new
+// host plane).  inout(): a plane modified in place.  finish() makes the results the planes' contents: downloads + ONE sync for an
+// ordinary layer; for a pinned layer the pool buffers the kernels wrote become the resident copies, nothing moves, nothing waits.
+// A Work that is dropped without finish() (any failure) gives its buffers back: the layer is as it was.
+struct Work {
+  struct Out { uint8_t *host, *dev; size_t n, cap; bool pooled; };
+  Out outs[8];
+  int nout = 0;
+  bool ok = true, done = false;
+  const uint8_t *in(const uint8_t *h, size_t n, int slot) {
+    if (!ok) return nullptr;
+    if (uint8_t *r = resident(h, n)) return r;
+    uint8_t *d = t_scr.get(slot, n);
+    g_h2d += n;
+    ok = d && lgpu_upload(d, h, n, nullptr) == LGPU_OK;
+    return ok ? d : nullptr;
+  }
+  // zero: the kernel does not write every byte (row padding, skipped alpha bytes): start from the zeros of the fresh host plane
+  uint8_t *out(uint8_t *h, size_t n, int slot, bool zero) {
+    if (!ok || nout >= 8) { ok = false; return nullptr; }
+    Out o = {h, nullptr, n, 0, false};
+    if (t_pinned) {
+      std::lock_guard<std::mutex> lk(g_res_mu);
+      o.dev = (uint8_t *)pool_take(n, &o.cap);
+      o.pooled = true;
+    } else o.dev = t_scr.get(slot, n);
+    ok = o.dev && (!zero || lgpu_fill(o.dev, 0, n, nullptr) == LGPU_OK);
+    if (o.dev) outs[nout++] = o;
+    return ok ? o.dev : nullptr;
+  }
+  uint8_t *inout(uint8_t *h, size_t n, int slot) {
+    if (!ok || nout >= 8) { ok = false; return nullptr; }
+    if (uint8_t *r = resident(h, n)) return r;               // modified where it lives
+    uint8_t *d = const_cast<uint8_t *>(in(h, n, slot));
+    if (d) outs[nout++] = Out{h, d, n, 0, false};
+    return d;
+  }
+  bool finish() {
+    if (!ok) return false;
+    bool moved = false;
+    for (int i = 0; i < nout && ok; i++) {
+      Out &o = outs[i];
+      if (o.pooled) {                                         // the buffer becomes the resident copy of the new host plane
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        ResEntry &e = g_res[o.host];
+        pool_give(e.d, e.bytes);
+        e.d = o.dev; e.bytes = o.cap;
+        o.dev = nullptr;
+      } else {
+        g_d2h += o.n;
+        ok = lgpu_download(o.host, o.dev, o.n, nullptr) == LGPU_OK;
+        moved = true;
+      }
+    }
+    if (ok && moved) ok = sync();
+    done = ok;
+    return ok;
+  }
+  ~Work() {
+    if (done) return;
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    for (int i = 0; i < nout; i++) if (outs[i].pooled && outs[i].dev) pool_give(outs[i].dev, outs[i].cap);
+  }
+};
+
+// A call that this library does not serve returns FALSE and the caller's CPU body takes over.  The host bytes of a
+// pinned layer are stale by contract, so a pinned layer is first brought home and unpinned: the CPU body then sees the current
+// pixels, and no stale device copy survives it.
+int lives_gpu_layer_unpin_impl(weed_plant_t *layer);
+lives_gpu_boolean decline(weed_plant_t *layer) {
+  if (t_pinned && layer) lives_gpu_layer_unpin_impl(layer);
+  return 0;
+}
 
 int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
   // the selector tree of src/colourspace.c:12370-12556
@@ -274,23 +336,19 @@ int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
 
 // K5 on a layer: switch_yuv_clamping_and_subspace (:10929-11090), in place on the layer's own planes
 bool switch_layer_clamping(weed_plant_t *layer, const Layer &l, int oclamping) {
+  Work w;
   uint8_t *d[4] = {nullptr, nullptr, nullptr, nullptr};
   int rs[4] = {0, 0, 0, 0};
-  size_t bytes[4] = {0, 0, 0, 0};
   const bool planar = pal_is_planar_yuv(l.pal);
-  bool ok = true;
-  for (int p = 0; p < l.nplanes && ok; p++) {
+  for (int p = 0; p < l.nplanes; p++) {
     const int ph = (!planar || p == 0 || p == 3 || pal_is_444(l.pal) || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1;
-    bytes[p] = (size_t)l.rs[p] * ph;
-    d[p] = t_scr.get(p == 0 ? 0 : p + 3, bytes[p]);
+    d[p] = w.inout(l.pd[p], (size_t)l.rs[p] * ph, p == 0 ? 0 : p + 3);
     rs[p] = l.rs[p];
-    ok = d[p] && up(d[p], l.pd[p], bytes[p]);
   }
-  ok = ok && lgpu_yuv_switch_clamping(d, rs, l.pal, l.height, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK;
-  for (int p = 0; p < l.nplanes && ok; p++) ok = down(l.pd[p], d[p], bytes[p]);
-  ok = ok && sync();
-  if (ok) set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);
-  return ok;
+  if (!w.ok || lgpu_yuv_switch_clamping(d, rs, l.pal, l.height, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) != LGPU_OK) return false;
+  if (!w.finish()) return false;
+  set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);
+  return true;
 }
 
 int k3_fmt(int pal) {
@@ -310,23 +368,23 @@ int k4_fmt(int pal) {
   }
 }
 
-// K4 on a layer: the RGB24 / BGR24 / RGBA32 / BGRA32 / ARGB32 cases of src/colourspace.c:12559-12935 plus conv_done (:13860-13893)
+void drop_new_planes(const NewPlanes &np) { pfree(np.pd[0]); }       // one block (alloc_planes)
+
 // K4b on a layer (:12627-12632 and the same case under each RGB input): width leaf becomes width >> 2 macropixels, the new frame is
-// written as compact macropixel rows whatever rowstride it was given (the reference passes none)
-lives_gpu_boolean rgb_layer_to_yuv411(weed_plant_t *layer, const Layer &l, int oclamping) {
+// written as compact macropixel rows whatever rowstride it was given (the reference passes none).  `flags` = host_flags after the
+// reference's premultiplied-alpha bookkeeping (:12290-12306), done by the caller for every palette pair.
+lives_gpu_boolean rgb_layer_to_yuv411(weed_plant_t *layer, const Layer &l, int oclamping, int flags) {
   const int order = pal_alpha_first(l.pal) ? 2 : pal_red_first(l.pal) ? 0 : 1;
   const int in_alpha = pal_has_alpha(l.pal) ? 1 : 0, wm = l.width >> 2;
-  if (wm < 1 || l.height < 1) return 0;
+  if (wm < 1 || l.height < 1) return decline(layer);
   NewPlanes np;
   if (!alloc_planes(WEED_PALETTE_YUV411, wm, l.height, 0, &np)) return 0;
-  const size_t ibytes = (size_t)l.rs[0] * l.height;
-  uint8_t *d_in = t_scr.get(0, ibytes), *d_out = t_scr.get(3, np.sz[0]);
-  const bool ok = d_in && d_out && up(d_in, l.pd[0], ibytes) && up_fresh(d_out, np.pd[0], np.sz[0]) &&
-                  lgpu_rgb_to_yuv411(d_in, l.rs[0], l.width, l.height, order, in_alpha, d_out, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK &&
-                  down(np.pd[0], d_out, np.sz[0]) && sync();
-  if (!ok) { res_drop(np.pd[0]); pfree(np.pd[0]); return 0; }
-  int flags = l.flags;
-  if (in_alpha) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  Work w;
+  const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
+  uint8_t *d_out = w.out(np.pd[0], np.sz[0], 3, true);
+  const bool ok = w.ok && lgpu_rgb_to_yuv411(d_in, l.rs[0], l.width, l.height, order, in_alpha, d_out, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK &&
+                  w.finish();
+  if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
   commit_planes(layer, WEED_PALETTE_YUV411, wm, l.height, np);
   if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
@@ -336,43 +394,33 @@ lives_gpu_boolean rgb_layer_to_yuv411(weed_plant_t *layer, const Layer &l, int o
   return 1;
 }
 
-lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outpl, int oclamping, int osubspace, int tgt_gamma) {
-  if (outpl == WEED_PALETTE_YUV411) {
-    if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return 0;
-    return rgb_layer_to_yuv411(layer, l, oclamping);
-  }
+// K4 on a layer: the RGB24 / BGR24 / RGBA32 / BGRA32 / ARGB32 cases of src/colourspace.c:12559-12935 plus conv_done (:13860-13893)
+lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outpl, int oclamping, int osubspace, int tgt_gamma, int flags) {
+  // the LUT16 variants of these entry points (a target gamma that differs from the layer's) stay with the CPU body
+  if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return decline(layer);
+  if (outpl == WEED_PALETTE_YUV411) return rgb_layer_to_yuv411(layer, l, oclamping, flags);
   const int fmt = k4_fmt(outpl);
-  if (fmt < 0) return 0;
-  if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return 0;   // LUT16 variants: CPU body
+  if (fmt < 0) return decline(layer);
   const int order = pal_alpha_first(l.pal) ? 2 : pal_red_first(l.pal) ? 0 : 1;
-  if (order == 2 && fmt >= 4) return 0;                                     // reference-broken (:6353), declined
+  if (order == 2 && fmt >= 4) return decline(layer);                        // reference-broken (:6353)
   const int in_alpha = pal_has_alpha(l.pal) ? 1 : 0, out_alpha = pal_has_alpha(outpl) ? 1 : 0;
   int width = l.width, height = l.height;
-  if (fmt >= 2 && (width & 1)) return 0;
+  if (fmt >= 2 && (width & 1)) return decline(layer);
   if (fmt == 4) { width = (width >> 1) << 1; height = (height >> 1) << 1; }       // create_empty_pixel_data :11601-11603
-  if (width < 2 || height < 1) return 0;
+  if (width < 2 || height < 1) return decline(layer);
   // subspace argument as the dispatcher passes it: some cases hand WEED_YUV_SAMPLING_DEFAULT (= 0 -> YCbCr) to the subspace slot
   const bool use_osub = (fmt == 4 && l.pal != WEED_PALETTE_RGB24) || (fmt == 5 && l.pal == WEED_PALETTE_RGB24);
   const int which = (oclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | ((fmt >= 4 && use_osub && osubspace == WEED_YUV_SUBSPACE_BT709) ? 2 : 0);
   const int lwidth = (fmt == 2 || fmt == 3) ? width >> 1 : width;                   // UYVY / YUYV layers count macropixels
   NewPlanes np;
   if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
-  const size_t ibytes = (size_t)l.rs[0] * l.height;
-  uint8_t *d_in = t_scr.get(0, ibytes);
-  bool ok = d_in && up(d_in, l.pd[0], ibytes);
+  Work w;
+  const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
   uint8_t *ddst[4] = {nullptr, nullptr, nullptr, nullptr};
   int ors[4] = {0, 0, 0, 0};
-  for (int p = 0; p < np.n && ok; p++) {
-    ddst[p] = t_scr.get(3 + p, np.sz[p]);
-    ors[p] = np.rs[p];
-    ok = ddst[p] && up_fresh(ddst[p], np.pd[p], np.sz[p]);     // calloc'd padding stays as the host made it
-  }
-  ok = ok && lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr) == LGPU_OK;
-  for (int p = 0; p < np.n && ok; p++) ok = down(np.pd[p], ddst[p], np.sz[p]);
-  ok = ok && sync();
-  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }
-  int flags = l.flags;
-  if (in_alpha && !out_alpha) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }   // calloc'd padding stays as the host made it
+  const bool ok = w.ok && lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr) == LGPU_OK && w.finish();
+  if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
   if (outpl == WEED_PALETTE_YVU420P) { uint8_t *t = np.pd[1]; np.pd[1] = np.pd[2]; np.pd[2] = t; }   // swap_chroma_planes (:13890)
   commit_planes(layer, outpl, lwidth, height, np);
@@ -381,6 +429,24 @@ lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outp
   set_int(layer, WEED_LEAF_YUV_SUBSPACE, l.gamma == WEED_GAMMA_BT709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR);
   if (fmt >= 4 || !has_leaf(layer, WEED_LEAF_YUV_SAMPLING)) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);
   return 1;
+}
+
+// a pinned layer's LUT16 (create_gamma_lut, 65536 x uint16) per (from, to, screen gamma): built once per device, not per frame
+struct Lut16Key { int from, to; double screen; bool operator==(const Lut16Key &o) const { return from == o.from && to == o.to && screen == o.screen; } };
+std::mutex g_l16_mu;
+std::vector<std::pair<Lut16Key, void *>> g_l16;
+const uint16_t *device_lut16(int from, int to) {
+  const Lut16Key k = {from, to, g_prefs.screen_gamma};
+  std::lock_guard<std::mutex> lk(g_l16_mu);
+  for (auto &e : g_l16) if (e.first == k) return (const uint16_t *)e.second;
+  std::vector<uint16_t> h(65536);
+  if (!lgpu_gamma_lut16(1.0, from, to, g_prefs.screen_gamma, h.data())) return nullptr;
+  void *d = nullptr;
+  if (lgpu_malloc(&d, 65536 * 2) != LGPU_OK) return nullptr;
+  if (lgpu_upload(d, h.data(), 65536 * 2, nullptr) != LGPU_OK || lgpu_sync(nullptr) != LGPU_OK) { lgpu_free(d); return nullptr; }
+  if (g_l16.size() >= 16) { lgpu_free(g_l16.front().second); g_l16.erase(g_l16.begin()); }
+  g_l16.push_back({k, d});
+  return (const uint16_t *)d;
 }
 
 }  // namespace
@@ -419,54 +485,54 @@ int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int
 
 // YUV -> YUV repack of a layer (:12937-13750, the non-RGB half of the dispatcher) through lgpu_yuv_repack; 0 = not taken, the
 // caller's CPU body runs (pairs / layouts listed in include/lives_gpu.h)
-lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, int outpl, int iclamping) {
+static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, int outpl, int iclamping, int flags) {
   const int inpl = l.pal;
   const bool inpk = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV), outpk = (outpl == WEED_PALETTE_UYVY || outpl == WEED_PALETTE_YUYV);
   const int width = inpk ? l.width * 2 : l.width, height = l.height;              // pixels
-  if (width < 1 || height < 1) return 0;
+  if (width < 1 || height < 1) return decline(layer);
   const int unclamped = iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0;
   const uint8_t *dsrc[4] = {nullptr, nullptr, nullptr, nullptr};
   uint8_t *ddst[4] = {nullptr, nullptr, nullptr, nullptr};
   int irs[4] = {0, 0, 0, 0}, ors[4] = {0, 0, 0, 0};
-  bool ok = true;
-  for (int p = 0; p < l.nplanes && ok; p++) {
-    const size_t b = (size_t)l.rs[p] * plane_h(l, p);
-    uint8_t *d = t_scr.get(p == 0 ? 0 : p, b);     // slots 0..2 (+ 7 for a fourth plane)
-    if (p == 3) d = t_scr.get(7, b);
-    ok = d && up(d, l.pd[p], b);
-    dsrc[p] = d; irs[p] = l.rs[p];
-  }
-  if (!ok) return 0;
-  if (inpl == WEED_PALETTE_YVU420P) { const uint8_t *t = dsrc[1]; dsrc[1] = dsrc[2]; dsrc[2] = t; const int r = irs[1]; irs[1] = irs[2]; irs[2] = r; }
+  Work w;
   if (inpk && outpk) {
     // convert_swab_frame (:13139): in place, the layer keeps its pixel data
-    uint8_t *dd[4] = {const_cast<uint8_t *>(dsrc[0]), nullptr, nullptr, nullptr};
-    ok = lgpu_yuv_repack(inpl, outpl, dsrc, irs, dd, irs, width, height, unclamped, 0, nullptr) == LGPU_OK &&
-         down(l.pd[0], dd[0], (size_t)l.rs[0] * height) && sync();
-    if (!ok) return 0;
+    uint8_t *dd[4] = {w.inout(l.pd[0], (size_t)l.rs[0] * height, 0), nullptr, nullptr, nullptr};
+    dsrc[0] = dd[0]; irs[0] = l.rs[0];
+    if (!w.ok) return 0;
+    const int rc = lgpu_yuv_repack(inpl, outpl, dsrc, irs, dd, irs, width, height, unclamped, 0, nullptr);
+    if (rc == LGPU_E_UNSUPPORTED) return decline(layer);
+    if (rc != LGPU_OK || !w.finish()) return 0;
     set_int(layer, WEED_LEAF_CURRENT_PALETTE, outpl);
     return 1;
   }
+  for (int p = 0; p < l.nplanes; p++) { dsrc[p] = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p == 3 ? 7 : p); irs[p] = l.rs[p]; }
+  if (!w.ok) return 0;
+  if (inpl == WEED_PALETTE_YVU420P) { const uint8_t *t = dsrc[1]; dsrc[1] = dsrc[2]; dsrc[2] = t; const int r = irs[1]; irs[1] = irs[2]; irs[2] = r; }
   const int lwidth = outpk ? width >> 1 : width;
   NewPlanes np;
   if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
-  for (int p = 0; p < np.n && ok; p++) {
-    ddst[p] = t_scr.get(3 + p, np.sz[p]);
-    ors[p] = np.rs[p];
-    ok = ddst[p] && up_fresh(ddst[p], np.pd[p], np.sz[p]);
-  }
-  ok = ok && lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, 0, nullptr) == LGPU_OK;
-  for (int p = 0; p < np.n && ok; p++) ok = down(np.pd[p], ddst[p], np.sz[p]);
-  ok = ok && sync();
-  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }
-  int flags = l.flags;
-  if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }
+  const int rc = w.ok ? lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, 0, nullptr) : LGPU_E_NOMEM;
+  if (rc == LGPU_E_UNSUPPORTED) { drop_new_planes(np); return decline(layer); }
+  if (rc != LGPU_OK || !w.finish()) { drop_new_planes(np); return 0; }
   free_planes(l);
   if (outpl == WEED_PALETTE_YVU420P) { uint8_t *t = np.pd[1]; np.pd[1] = np.pd[2]; np.pd[2] = t; }   // swap_chroma_planes (:13890)
   commit_planes(layer, outpl, lwidth, height, np);
   if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
   if (outpl == WEED_PALETTE_YUV420P || outpl == WEED_PALETTE_YVU420P) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);   // :13022
   return 1;
+}
+
+// black of a palette as the reference paints it (blank_pixel / blank_row, src/colourspace.c:11123-11210) into a HOST plane set
+static void host_black_fill(int pal, int width, int height, int clamping, const NewPlanes &np) {
+  const uint8_t yb = clamping == WEED_YUV_CLAMPING_UNCLAMPED ? 0 : 16;
+  if (pal_is_planar_yuv(pal)) {
+    for (int p = 0; p < np.n; p++) memset(np.pd[p], p == 0 ? yb : p == 3 ? 255 : 128, np.sz[p]);
+  } else if (pal_has_alpha(pal)) {
+    const int a = pal_alpha_first(pal) ? 0 : 3;
+    for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) np.pd[0][(size_t)y * np.rs[0] + x * 4 + a] = 255;
+  }
 }
 
 lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig) {
@@ -480,18 +546,8 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
   const bool had = read_layer(layer, &old);
   NewPlanes np;
   if (!alloc_planes(pal, width, height, 0, &np, layer)) return 0;
-  if (black_fill) {
-    // opaque black: RGB 0,0,0 (alpha 255); YUV 16 (clamped) or 0, 128, 128 (src/colourspace.c:11448-11460)
-    const int clamping = get_int(layer, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED);
-    if (pal_is_planar_yuv(pal)) {
-      memset(np.pd[0], clamping == WEED_YUV_CLAMPING_CLAMPED ? 16 : 0, np.sz[0]);
-      memset(np.pd[1], 128, np.sz[1]);
-      memset(np.pd[2], 128, np.sz[2]);
-    } else if (pal_has_alpha(pal)) {
-      const int a = pal_alpha_first(pal) ? 0 : 3;
-      for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) np.pd[0][(size_t)y * np.rs[0] + x * 4 + a] = 255;
-    }
-  }
+  // opaque black: RGB 0,0,0 (alpha 255); YUV 16 (clamped) or 0, 128, 128 (src/colourspace.c:11448-11460)
+  if (black_fill) host_black_fill(pal, width, height, get_int(layer, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED), np);
   if (had) free_planes(old);
   commit_planes(layer, pal, width, height, np);
   return 1;
@@ -499,22 +555,40 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
 
 lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
                                                        int osubspace, int tgt_gamma) {
-  (void)osampling;
   PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
   const int inpl = l.pal;
+  // The reference's own first steps (range switch :12241-12262, un-premultiply :12290-12306) are done first here too.  If the
+  // conversion proper is then declined, the layer is in the state the reference has at that point and its CPU body continues from
+  // there (both steps are no-ops the second time: the leaves they test have been updated).
   if (!pal_is_rgb(inpl) && !pal_is_rgb(outpl) && l.clamping >= 0 && (l.clamping != oclamping || l.subspace != osubspace)) {
-    // YUV -> YUV with a different range (:12241-12262): same subspace = in-place table switch; a subspace change goes through
-    // RGB in the reference -- left to the caller's CPU body
-    if (l.subspace != osubspace) return 0;
+    // YUV -> YUV with a different range: same subspace = in-place table switch; a subspace change goes through RGB in the reference
+    if (l.subspace != osubspace) return decline(layer);
     if (!switch_layer_clamping(layer, l, oclamping)) return 0;
     if (!read_layer(layer, &l)) return 0;
   }
-  if (inpl == outpl) return 1;                                           // :12265
+  if (inpl == outpl) {                                                     // :12265
+    // 4:2:0 JPEG <-> MPEG chroma siting is switch_yuv_sampling (:10876-10925) in the reference: not served here
+    if ((inpl == WEED_PALETTE_YUV420P || inpl == WEED_PALETTE_YVU420P) && l.sampling != osampling &&
+        (l.sampling == WEED_YUV_SAMPLING_JPEG || l.sampling == WEED_YUV_SAMPLING_MPEG) &&
+        (osampling == WEED_YUV_SAMPLING_JPEG || osampling == WEED_YUV_SAMPLING_MPEG)) return decline(layer);
+    return 1;
+  }
+  // premultiplied-alpha bookkeeping (:12290-12306), for every in / out palette pair
+  int flags = l.flags;
+  if (g_prefs.alpha_post) {
+    if ((flags & LIVES_LAYER_ALPHA_PREMULT) && pal_has_alpha(inpl) && !pal_has_alpha(outpl)) {
+      lives_gpu_alpha_premult(layer, LIVES_DIRECTION_REVERSE);
+      if (!read_layer(layer, &l)) return 0;
+      flags = l.flags;
+    }
+  } else if (!pal_has_alpha(inpl) && pal_has_alpha(outpl)) flags |= LIVES_LAYER_ALPHA_PREMULT;
+  if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+
   if (!pal_is_rgb(outpl)) {
-    if (pal_is_rgb(inpl)) return rgb_layer_to_yuv(layer, l, outpl, oclamping, osubspace, tgt_gamma);
-    return yuv_layer_repack(layer, l, outpl, l.clamping >= 0 ? l.clamping : oclamping);   // YUV -> YUV repacks (K5b)
+    if (pal_is_rgb(inpl)) return rgb_layer_to_yuv(layer, l, outpl, oclamping, osubspace, tgt_gamma, flags);
+    return yuv_layer_repack(layer, l, outpl, l.clamping >= 0 ? l.clamping : oclamping, flags);   // YUV -> YUV repacks (K5b)
   }
   const int iclamping = l.clamping >= 0 ? l.clamping : oclamping;        // :12216-12218
 
@@ -526,77 +600,65 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     new_gamma = tgt_gamma;
     if (lgpu_gamma_lut8(1.0, l.gamma, new_gamma, g_prefs.screen_gamma, lut)) lutp = lut;
   }
-  // premultiplied-alpha bookkeeping (:12290-12306)
-  int flags = l.flags;
-  if (g_prefs.alpha_post) {
-    if ((flags & LIVES_LAYER_ALPHA_PREMULT) && pal_has_alpha(inpl) && !pal_has_alpha(outpl)) {
-      lives_gpu_alpha_premult(layer, LIVES_DIRECTION_REVERSE);
-      if (!read_layer(layer, &l)) return 0;
-      flags = l.flags;
-    }
-  } else if (!pal_has_alpha(inpl) && pal_has_alpha(outpl)) flags |= LIVES_LAYER_ALPHA_PREMULT;
-  if (pal_has_alpha(inpl) && !pal_has_alpha(outpl)) flags &= ~LIVES_LAYER_ALPHA_PREMULT;
+  const bool in_planar_sub = (inpl == WEED_PALETTE_YUV420P || inpl == WEED_PALETTE_YVU420P || inpl == WEED_PALETTE_YUV422P);
+  if (!pal_is_rgb(inpl) && !in_planar_sub && k3_fmt(inpl) < 0 && inpl != WEED_PALETTE_YUV411) return decline(layer);
+  if (lutp && !pal_is_rgb(inpl) && !in_planar_sub) return decline(layer);   // no inline gamma on the K3 / 4:1:1 paths
 
   NewPlanes np;
   const int owidth = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV) ? l.width * 2 : inpl == WEED_PALETTE_YUV411 ? l.width * 4 : l.width;   // macropixels -> pixels (:13010, :13759)
   if (!alloc_planes(outpl, owidth, l.height, 0, &np)) return 0;
   const size_t obytes = (size_t)np.rs[0] * l.height;
-  uint8_t *d_out = t_scr.get(3, obytes);
-  bool ok = d_out != nullptr;
-  if (ok && pal_is_rgb(inpl)) {
+  Work w;
+  bool ok = true;
+  if (pal_is_rgb(inpl)) {
     int af = 0;
     const int op = rgb_swizzle_op(inpl, outpl, &af);
-    const size_t ibytes = (size_t)l.rs[0] * l.height;
-    uint8_t *d_in = t_scr.get(0, ibytes);
-    ok = d_in && up(d_in, l.pd[0], ibytes) &&
-         lgpu_swizzle(op, af, d_in, l.rs[0], d_out, np.rs[0], l.width, l.height, lutp, nullptr) == LGPU_OK;
-  } else if (ok && (inpl == WEED_PALETTE_YUV420P || inpl == WEED_PALETTE_YVU420P || inpl == WEED_PALETTE_YUV422P)) {
+    const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
+    uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
+    ok = w.ok && lgpu_swizzle(op, af, d_in, l.rs[0], d_out, np.rs[0], l.width, l.height, lutp, nullptr) == LGPU_OK;
+  } else if (in_planar_sub) {
     const int iu = (inpl == WEED_PALETTE_YVU420P) ? 2 : 1, iv = (inpl == WEED_PALETTE_YVU420P) ? 1 : 2;   // swap_chroma_planes (:12353)
     const int ch = plane_h(l, 1);
     const size_t yb = (size_t)l.rs[0] * l.height, ub = (size_t)l.rs[iu] * ch, vb = (size_t)l.rs[iv] * ch;
-    uint8_t *dy = t_scr.get(0, yb), *du = t_scr.get(1, ub), *dv = t_scr.get(2, vb);
+    const uint8_t *dy = w.in(l.pd[0], yb, 0), *du = w.in(l.pd[iu], ub, 1), *dv = w.in(l.pd[iv], vb, 2);
+    uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
     const int strides[3] = {l.rs[0], l.rs[iu], l.rs[iv]};
     const int which = (iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | (l.subspace == WEED_YUV_SUBSPACE_BT709 ? 2 : 0);
     const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
-    ok = dy && du && dv && up(dy, l.pd[0], yb) && up(du, l.pd[iu], ub) && up(dv, l.pd[iv], vb);
+    ok = w.ok;
     if (ok && lutp) {
       // with a target gamma the reference fuses the 16-bit indexed LUT of create_gamma_lut into the conversion (:3274-3283)
-      static thread_local std::vector<uint16_t> h16(65536);
-      uint8_t *d16 = t_scr.get(7, 65536 * 2);
-      ok = d16 && lgpu_gamma_lut16(1.0, l.gamma, new_gamma, g_prefs.screen_gamma, h16.data()) && up(d16, (const uint8_t *)h16.data(), 65536 * 2) &&
-           lgpu_yuv420p_to_rgb_lut16(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
-                                     inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, (const uint16_t *)d16, 0, nullptr) == LGPU_OK;
+      const uint16_t *d16 = device_lut16(l.gamma, new_gamma);
+      ok = d16 && lgpu_yuv420p_to_rgb_lut16(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
+                                            inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, d16, 0, nullptr) == LGPU_OK;
     } else if (ok)
       ok = lgpu_yuv420p_to_rgb(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
                                inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, nullptr, 0, nullptr) == LGPU_OK;
-  } else if (ok && k3_fmt(inpl) >= 0) {
+  } else if (k3_fmt(inpl) >= 0) {
     // K3: packed / planar 4:4:4, UYVY, YUYV -> RGB family (src/colourspace.c:12937-13860 cases); no inline gamma on these paths
     const int fmt = k3_fmt(inpl), in_alpha = (inpl == WEED_PALETTE_YUVA8888 || inpl == WEED_PALETTE_YUVA4444P);
     const int pxw = (fmt >= 2) ? l.width * 2 : l.width;                     // UYVY / YUYV layers count macropixels
     const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
     const int which = (iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | ((fmt == 0 && l.subspace == WEED_YUV_SUBSPACE_BT709) ? 2 : 0);
-    ok = !lutp && (fmt < 2 || np.rs[0] >= pxw * pal_psize(outpl));
+    if (fmt >= 2 && np.rs[0] < pxw * pal_psize(outpl)) { drop_new_planes(np); return decline(layer); }
     const uint8_t *dsrc[4] = {nullptr, nullptr, nullptr, nullptr};
     int irs[4] = {0, 0, 0, 0};
-    for (int p = 0; p < l.nplanes && ok; p++) {
-      const size_t b = (size_t)l.rs[p] * l.height;
-      uint8_t *d = t_scr.get(p == 0 ? 0 : p + 3, b);
-      ok = d && up(d, l.pd[p], b);
-      dsrc[p] = d; irs[p] = l.rs[p];
-    }
-    ok = ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, nullptr) == LGPU_OK;
-  } else if (ok && inpl == WEED_PALETTE_YUV411) {
-    // K3b (:13755-13795): the reference walks the source as compact rows of `width` macropixels and leaves some alpha bytes of the
+    for (int p = 0; p < l.nplanes; p++) { dsrc[p] = w.in(l.pd[p], (size_t)l.rs[p] * l.height, p == 0 ? 0 : p + 3); irs[p] = l.rs[p]; }
+    uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
+    ok = w.ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, nullptr) == LGPU_OK;
+  } else {
+    // K3b, YUV411 (:13755-13795): the reference walks the source as compact rows of `width` macropixels and leaves some alpha bytes of the
     // new (zeroed, create_empty_pixel_data) frame unwritten -- the device frame starts zeroed too
     const size_t ibytes = (size_t)l.width * 6 * l.height;
-    uint8_t *d_in = t_scr.get(0, ibytes);
     const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
-    ok = !lutp && d_in && (size_t)l.rs[0] * l.height >= ibytes && up(d_in, l.pd[0], ibytes) && lgpu_fill(d_out, 0, obytes, nullptr) == LGPU_OK &&
-         lgpu_yuv411_to_rgb(d_in, l.width, l.height, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0,
-                            iclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK;
-  } else ok = false;
-  ok = ok && down(np.pd[0], d_out, obytes) && sync();
-  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }                                  // memfail: layer untouched
+    if ((size_t)l.rs[0] * l.height < ibytes) { drop_new_planes(np); return decline(layer); }
+    const uint8_t *d_in = w.in(l.pd[0], ibytes, 0);
+    uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
+    ok = w.ok && lgpu_yuv411_to_rgb(d_in, l.width, l.height, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0,
+                                   iclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK;
+  }
+  ok = ok && w.finish();
+  if (!ok) { drop_new_planes(np); return 0; }                                // memfail: layer untouched
   free_planes(l);
   commit_planes(layer, outpl, owidth, l.height, np);
   if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
@@ -611,6 +673,11 @@ lives_gpu_boolean lives_gpu_convert_layer_palette(lives_gpu_layer_t *layer, int 
   return lives_gpu_convert_layer_palette_full(layer, outpl, op_clamping, WEED_YUV_SAMPLING_DEFAULT, WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);   // :13931
 }
 
+// src/colourspace.c:13935-13938
+lives_gpu_boolean lives_gpu_convert_layer_palette_with_sampling(lives_gpu_layer_t *layer, int outpl, int out_sampling) {
+  return lives_gpu_convert_layer_palette_full(layer, outpl, WEED_YUV_CLAMPING_UNCLAMPED, out_sampling, WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);
+}
+
 lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y, int width,
                                                     int height, lives_gpu_boolean may_thread) {
   (void)may_thread;
@@ -618,16 +685,14 @@ lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg
   if (!g_prefs.apply_gamma) return 1;
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
-  if (!pal_is_rgb(l.pal)) return 0;
+  if (!pal_is_rgb(l.pal)) return decline(layer);
   if (gamma_type == l.gamma && fileg == 1.0) return 1;
   uint8_t lut[256];
   if (!lgpu_gamma_lut8(gamma_type == LIVES_GAMMA_VARIANT ? fileg : 1.0, l.gamma, gamma_type, g_prefs.screen_gamma, lut)) return 1;
   if (x < 0 || y < 0 || x + width > l.width || y + height > l.height) return 0;
-  const size_t bytes = (size_t)l.rs[0] * l.height;
-  uint8_t *d = t_scr.get(0, bytes);
-  const bool ok = d && up(d, l.pd[0], bytes) &&
-                  lgpu_gamma_apply(d, l.rs[0], x, y, width, height, pal_psize(l.pal), pal_alpha_first(l.pal), lut, nullptr) == LGPU_OK &&
-                  down(l.pd[0], d, bytes) && sync();
+  Work w;
+  uint8_t *d = w.inout(l.pd[0], (size_t)l.rs[0] * l.height, 0);
+  const bool ok = w.ok && lgpu_gamma_apply(d, l.rs[0], x, y, width, height, pal_psize(l.pal), pal_alpha_first(l.pal), lut, nullptr) == LGPU_OK && w.finish();
   if (!ok) return 0;
   if (gamma_type != LIVES_GAMMA_VARIANT) set_int(layer, WEED_LEAF_GAMMA_TYPE, gamma_type);
   return 1;
@@ -639,60 +704,68 @@ lives_gpu_boolean lives_gpu_gamma_convert_layer(int gamma_type, lives_gpu_layer_
   return lives_gpu_gamma_convert_sub_layer(gamma_type, 1.0, layer, 0, 0, l.width, l.height, 1);   // :14146-14155
 }
 
+// gamma_convert_layer_variant (src/colourspace.c:14157-14168): the layer is tagged LINEAR, then taken to tgt_gamma through
+// gamma_convert_sub_layer(tgt_gamma, file_gamma, ...): as there, file_gamma enters the table only when tgt_gamma is WEED_GAMMA_VARIANT
+// (:14099-14102) -- kept
+lives_gpu_boolean lives_gpu_gamma_convert_layer_variant(double file_gamma, int tgt_gamma, lives_gpu_layer_t *layer) {
+  Layer l;
+  if (!bound() || !read_layer(layer, &l)) return 0;
+  set_int(layer, WEED_LEAF_GAMMA_TYPE, WEED_GAMMA_LINEAR);
+  return lives_gpu_gamma_convert_sub_layer(tgt_gamma, file_gamma, layer, 0, 0, l.width, l.height, 1);
+}
+
 void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction) {
   PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l) || !pal_has_alpha(l.pal)) return;
+  Work w;
   bool ok = true;
   if (l.pal == WEED_PALETTE_YUVA8888 || l.pal == WEED_PALETTE_YUVA4444P) {
     // :11982, :12005-12047, :12063-12096: clamped layers go through the alcy / alcuv / unalcy / unalcuv tables, unclamped ones through al / unal
     const int clamped = (l.clamping < 0 || l.clamping == WEED_YUV_CLAMPING_CLAMPED) ? 1 : 0;      // weed_layer_get_yuv_clamping(): CLAMPED (0) when the leaf is missing
     uint8_t *dp[4] = {nullptr, nullptr, nullptr, nullptr};
     int rs[4] = {0, 0, 0, 0};
-    size_t nb[4] = {0, 0, 0, 0};
-    for (int p = 0; p < l.nplanes && ok; p++) {
-      nb[p] = (size_t)l.rs[p] * l.height;
-      dp[p] = t_scr.get(p == 3 ? 7 : p, nb[p]);
+    for (int p = 0; p < l.nplanes; p++) {
+      const size_t nb = (size_t)l.rs[p] * l.height;
+      dp[p] = (p == 3) ? const_cast<uint8_t *>(w.in(l.pd[p], nb, 7)) : w.inout(l.pd[p], nb, p);           // the alpha plane is only read
       rs[p] = l.rs[p];
-      ok = dp[p] && up(dp[p], l.pd[p], nb[p]);
     }
-    ok = ok && lgpu_alpha_premult_yuva(dp, rs, l.width, l.height, l.pal, clamped, direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK;
-    for (int p = 0; p < 3 && p < l.nplanes && ok; p++) ok = down(l.pd[p], dp[p], nb[p]);           // the alpha plane is only read
-    ok = ok && sync();
+    ok = w.ok && lgpu_alpha_premult_yuva(dp, rs, l.width, l.height, l.pal, clamped, direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK;
   } else {
-    const size_t bytes = (size_t)l.rs[0] * l.height;
-    uint8_t *d = t_scr.get(0, bytes);
-    ok = d && up(d, l.pd[0], bytes) &&
-         lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK &&
-         down(l.pd[0], d, bytes) && sync();
+    uint8_t *d = w.inout(l.pd[0], (size_t)l.rs[0] * l.height, 0);
+    ok = w.ok && lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK;
   }
-  if (!ok) return;
+  if (!ok || !w.finish()) return;
   int flags = l.flags;
   if (direction == LIVES_DIRECTION_FORWARD) flags |= LIVES_LAYER_ALPHA_PREMULT; else flags &= ~LIVES_LAYER_ALPHA_PREMULT;   // :12098-12102
   set_int(layer, kLeafHostFlags, flags);
 }
 
-// resize every plane of `l` into freshly allocated planes of (width x height); returns device-side success
-static bool resize_into(const Layer &l, int width, int height, int interp, int alignment, NewPlanes *np) {
+// resize every plane of `l` into freshly allocated planes of (width x height); lut8: the fused post-pass of :14718-14720 (RGB only)
+static bool resize_into(const Layer &l, int width, int height, int interp, int alignment, const uint8_t *lut8, NewPlanes *np) {
   if (!alloc_planes(l.pal, width, height, alignment, np)) return false;
-  bool ok = true;
+  Work w;
   Layer nl = l;
   nl.width = width; nl.height = height;
+  bool ok = true;
   for (int p = 0; p < np->n && ok; p++) {
     const int ps = pal_is_planar_yuv(l.pal) ? 1 : pal_psize(l.pal);
     const int sw = plane_w(l, p), sh = plane_h(l, p), dw = plane_w(nl, p), dh = plane_h(nl, p);
-    const size_t ib = (size_t)l.rs[p] * sh, ob = (size_t)np->rs[p] * dh;
-    uint8_t *d_in = t_scr.get(0, ib), *d_out = t_scr.get(3, ob);
-    ok = d_in && d_out && up(d_in, l.pd[p], ib) &&
-         lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, nullptr, nullptr) == LGPU_OK &&
-         down(np->pd[p], d_out, ob) && sync();
+    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
+    uint8_t *d_out = w.out(np->pd[p], (size_t)np->rs[p] * dh, 3 + p, true);
+    ok = w.ok && lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, lut8, nullptr) == LGPU_OK;
   }
-  if (!ok) { for (int q = 0; q < np->n; q++) res_drop(np->pd[q]); pfree(np->pd[0]); }
+  ok = ok && w.finish();
+  if (!ok) drop_new_planes(*np);
   return ok;
 }
 
-lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint) {
-  (void)oclamp_hint;
+// resize_layer_full (src/colourspace.c:14759-15328).  osamp_hint / osubs_hint only parameterise the reference's swscale colourspace
+// details for conversions done inside the scaler; this path never converts inside the resize (the layer keeps its palette, "layer palette
+// should be checked on return", :14746-14751), so they take part in the target-gamma decision only (:14890-14899).
+lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
+                                              int osamp_hint, int osubs_hint, int tgt_gamma) {
+  (void)oclamp_hint; (void)osamp_hint;
   PinScope pin(layer);
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
@@ -700,7 +773,7 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
   // resizes keeps it (the caller's following convert_layer_palette does the rest); a packed-YUV frame is first taken to the hinted
   // palette when that one is resizable and the conversion is served here
   if (!(pal_is_rgb(l.pal) || pal_is_planar_yuv(l.pal))) {
-    if (opal_hint == WEED_PALETTE_NONE || opal_hint == l.pal || !(pal_is_rgb(opal_hint) || pal_is_planar_yuv(opal_hint))) return 0;
+    if (opal_hint == WEED_PALETTE_NONE || opal_hint == l.pal || !(pal_is_rgb(opal_hint) || pal_is_planar_yuv(opal_hint))) return decline(layer);
     const int cl = l.clamping >= 0 ? l.clamping : WEED_YUV_CLAMPING_CLAMPED;
     if (!lives_gpu_convert_layer_palette_full(layer, opal_hint, cl, WEED_YUV_SAMPLING_DEFAULT, l.subspace, WEED_GAMMA_UNKNOWN)) return 0;
     if (!read_layer(layer, &l)) return 0;
@@ -711,13 +784,31 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
   if (iwidth != width || iheight != height) height = (height >> 1) << 1;
   if (iwidth == width && iheight == height) return 1;
   if (pal_is_planar_yuv(l.pal)) width = (width >> 1) << 1;
+  // target gamma (:14890-14899, :15119-15127): applied as a LUT8 after the scaler when the output is RGB and the layer's gamma is known
+  const int opal = (opal_hint == WEED_PALETTE_NONE || opal_hint == WEED_PALETTE_ANY) ? l.pal : opal_hint;
+  if (tgt_gamma == WEED_GAMMA_UNKNOWN && !pal_is_rgb(opal) && osubs_hint == WEED_YUV_SUBSPACE_BT709) tgt_gamma = WEED_GAMMA_BT709;
+  if (tgt_gamma == WEED_GAMMA_UNKNOWN && pal_is_rgb(l.pal) && !pal_is_rgb(opal)) tgt_gamma = WEED_GAMMA_SRGB;       // get_tgt_gamma :14733
+  if (tgt_gamma == WEED_GAMMA_UNKNOWN) tgt_gamma = l.gamma;
+  uint8_t lut[256];
+  const uint8_t *lutp = nullptr;
+  int new_gamma = l.gamma;
+  if (tgt_gamma != WEED_GAMMA_UNKNOWN && pal_is_rgb(opal) && pal_is_rgb(l.pal)) {
+    if (l.gamma != WEED_GAMMA_UNKNOWN && l.gamma != tgt_gamma && lgpu_gamma_lut8(1.0, l.gamma, tgt_gamma, g_prefs.screen_gamma, lut)) lutp = lut;
+    new_gamma = tgt_gamma;
+  }
   Layer src = l;
   src.width = iwidth; src.height = iheight;
   NewPlanes np;
-  if (!resize_into(src, width, height, interp, 16, &np)) return 0;       // rowstride_alignment_hint = 16 (:14989)
+  if (!resize_into(src, width, height, interp, 16, lutp, &np)) return 0;       // rowstride_alignment_hint = 16 (:14989)
   free_planes(l);
   commit_planes(layer, l.pal, width, height, np);
+  if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
   return 1;
+}
+
+lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint) {
+  return lives_gpu_resize_layer_full(layer, width, height, interp, opal_hint, oclamp_hint, WEED_YUV_SAMPLING_DEFAULT,
+                                     WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);                          // :15331-15334
 }
 
 lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
@@ -739,6 +830,7 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
   canvas.width = nwidth; canvas.height = nheight;
   NewPlanes np;
   if (!alloc_planes(l.pal, nwidth, nheight, 0, &np)) return 0;
+  Work w;
   bool ok = true;
   const int offs_x = (nwidth - width + 1) >> 1, offs_y = (nheight - height + 1) >> 1;     // :15522-15523
   for (int p = 0; p < np.n && ok; p++) {
@@ -750,15 +842,131 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
     else if (pal_alpha_first(l.pal)) black[0] = 255;
     else if (pal_alpha_last(l.pal)) black[3] = 255;
     const int sw = plane_w(l, p), sh = plane_h(l, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
-    const size_t ib = (size_t)l.rs[p] * sh, ob = (size_t)np.rs[p] * chh;
-    uint8_t *d_in = t_scr.get(0, ib), *d_out = t_scr.get(3, ob);
-    // the canvas keeps zeroed row padding (calloc on the host side); upload it so the kernel's untouched bytes stay zero
-    ok = d_in && d_out && up(d_in, l.pd[p], ib) && up_fresh(d_out, np.pd[p], ob) &&
-         lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, nullptr) == LGPU_OK && down(np.pd[p], d_out, ob) && sync();
+    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
+    uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, true);     // the canvas keeps its zeroed row padding
+    ok = w.ok && lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, nullptr) == LGPU_OK;
   }
-  if (!ok) { for (int q = 0; q < np.n; q++) res_drop(np.pd[q]); pfree(np.pd[0]); return 0; }
+  ok = ok && w.finish();
+  if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
   commit_planes(layer, l.pal, nwidth, nheight, np);
+  return 1;
+}
+
+// unletterbox_layer (src/colourspace.c:15570-15628): cut the borders off, then resize to (opwidth, opheight) (0 = keep, -1 = the outer
+// size).  Packed palettes only, as in the reference.  Quirk U1: the reference's row copy moves `xwidth` BYTES, not pixels
+// (:15614), so only the first xwidth / psize pixels of every row arrive and the rest of the new (black, opaque) frame stays black: kept.
+lives_gpu_boolean lives_gpu_unletterbox_layer(lives_gpu_layer_t *layer, int opwidth, int opheight, int top, int bottom, int left, int right) {
+  PinScope pin(layer);
+  Layer l;
+  if (!layer || !ready() || !read_layer(layer, &l)) return 0;
+  if (top < 0) top = 0;
+  if (bottom < 0) bottom = 0;
+  if (left < 0) left = 0;
+  if (right < 0) right = 0;
+  if (!pal_is_rgb(l.pal)) return decline(layer);
+  const int width = l.width, height = l.height, ps = pal_psize(l.pal);
+  const int xwidth = width - left - right, xheight = height - top - bottom;
+  if ((xwidth == width && xheight == height) || xwidth <= 0 || xheight <= 0) return 1;
+  NewPlanes np;
+  if (!alloc_planes(l.pal, xwidth, xheight, 0, &np)) return 0;
+  uint8_t black[4] = {0, 0, 0, 0};
+  if (pal_alpha_first(l.pal)) black[0] = 255; else if (pal_alpha_last(l.pal)) black[3] = 255;
+  {
+    Work w;
+    const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * height, 0);
+    uint8_t *d_out = w.out(np.pd[0], np.sz[0], 3, true);
+    // the copied part of a row is xwidth bytes = xwidth / ps whole pixels (+ xwidth % ps bytes of the next one: a byte-granular blit)
+    const bool ok = w.ok && lgpu_fill_pattern(d_out, np.rs[0], black, ps, xwidth, xheight, nullptr) == LGPU_OK &&          // create_empty_pixel_data(black_fill)
+                    lgpu_copy_rows(d_out, np.rs[0], d_in + (size_t)top * l.rs[0] + (size_t)left * ps, l.rs[0], xwidth, xheight, nullptr) == LGPU_OK && w.finish();
+    if (!ok) { drop_new_planes(np); return 0; }
+  }
+  free_planes(l);
+  commit_planes(layer, l.pal, xwidth, xheight, np);
+  if (opwidth == -1) opwidth = width; else if (!opwidth) opwidth = xwidth;
+  if (opheight == -1) opheight = height; else if (!opheight) opheight = xheight;
+  if (opwidth == xwidth && opheight == xheight) return 1;
+  return lives_gpu_resize_layer(layer, opwidth, opheight, LIVES_INTERP_BEST, WEED_PALETTE_ANY, WEED_YUV_CLAMPING_UNCLAMPED);
+}
+
+// compact_rowstrides (src/colourspace.c:14439-14496): new pixel data whose rowstrides are exactly width * bytes per (macro)pixel * plane ratio
+lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer) {
+  PinScope pin(layer);
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return 0;
+  int bpm = pal_psize(l.pal);                                               // bytes per macropixel of plane 0
+  if (l.pal == WEED_PALETTE_UYVY || l.pal == WEED_PALETTE_YUYV || l.pal == WEED_PALETTE_YUVA8888) bpm = 4;
+  else if (l.pal == WEED_PALETTE_YUV888) bpm = 3;
+  else if (l.pal == WEED_PALETTE_YUV411) bpm = 6;
+  if (!bpm) return decline(layer);
+  NewPlanes np;
+  np.n = l.nplanes;
+  bool change = false;
+  size_t tot = 0;
+  for (int p = 0; p < l.nplanes; p++) {
+    np.rs[p] = plane_w(l, p) * bpm;
+    np.sz[p] = (size_t)np.rs[p] * plane_h(l, p);
+    tot += np.sz[p];
+    if (np.rs[p] != l.rs[p]) change = true;
+  }
+  if (!change) return 1;
+  uint8_t *blk = (uint8_t *)palloc(tot + 64);
+  if (!blk) return 0;
+  size_t off = 0;
+  for (int p = 0; p < np.n; p++) { np.pd[p] = blk + off; off += np.sz[p]; }
+  {
+    Work w;
+    bool ok = true;
+    for (int p = 0; p < np.n && ok; p++) {
+      const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p);
+      uint8_t *d_out = w.out(np.pd[p], np.sz[p], 3 + p, false);
+      ok = w.ok && lgpu_copy_rows(d_out, np.rs[p], d_in, l.rs[p], np.rs[p], plane_h(l, p), nullptr) == LGPU_OK;
+    }
+    if (!ok || !w.finish()) { pfree(blk); return 0; }
+  }
+  free_planes(l);
+  commit_planes(layer, l.pal, l.width, l.height, np);
+  return 1;
+}
+
+// weed_layer_clear_pixel_data (src/colourspace.c:11229-11244): the frame painted black in place (blank_frame :11212-11226): host
+// bytes of an ordinary layer (a fill of host memory is the host's business), the resident planes of a pinned one.  Packed palettes
+// keep the reference's per-pixel pattern (opaque alpha); YUYV keeps its quirk (blank_pixel :11150-11154 never advances: only the first
+// macropixel of a row is written).
+lives_gpu_boolean lives_gpu_weed_layer_clear_pixel_data(lives_gpu_layer_t *layer) {
+  PinScope pin(layer);
+  Layer l;
+  if (!layer || !bound() || !read_layer(layer, &l)) return 0;
+  const int clamping = l.clamping >= 0 ? l.clamping : WEED_YUV_CLAMPING_CLAMPED;       // weed_layer_get_palette_yuv: CLAMPED when the leaf is missing
+  const uint8_t yb = clamping == WEED_YUV_CLAMPING_UNCLAMPED ? 0 : 16;
+  uint8_t pat[8];
+  int plen = 0, nmp = l.width;                    // pattern of one (macro)pixel of plane 0, macropixels per row
+  switch (l.pal) {
+  case WEED_PALETTE_RGB24: case WEED_PALETTE_BGR24: pat[0] = pat[1] = pat[2] = 0; plen = 3; break;
+  case WEED_PALETTE_RGBA32: case WEED_PALETTE_BGRA32: pat[0] = pat[1] = pat[2] = 0; pat[3] = 255; plen = 4; break;
+  case WEED_PALETTE_ARGB32: pat[0] = 255; pat[1] = pat[2] = pat[3] = 0; plen = 4; break;
+  case WEED_PALETTE_UYVY: pat[0] = pat[2] = 128; pat[1] = pat[3] = yb; plen = 4; break;
+  case WEED_PALETTE_YUYV: pat[0] = pat[2] = yb; pat[1] = pat[3] = 128; plen = 4; nmp = 1; break;
+  case WEED_PALETTE_YUV888: pat[0] = yb; pat[1] = pat[2] = 128; plen = 3; break;
+  case WEED_PALETTE_YUVA8888: pat[0] = yb; pat[1] = pat[2] = 128; pat[3] = 255; plen = 4; break;
+  case WEED_PALETTE_YUV411: pat[0] = pat[3] = 128; pat[1] = pat[2] = pat[4] = pat[5] = yb; plen = 6; break;
+  default: break;
+  }
+  if (!plen && !pal_is_planar_yuv(l.pal)) return 0;
+  const bool on_device = t_pinned && ready();
+  for (int p = 0; p < l.nplanes; p++) {
+    const int ph = plane_h(l, p), pw = plane_w(l, p);
+    uint8_t one[1] = {(uint8_t)(p == 0 ? yb : p == 3 ? 255 : 128)};
+    const uint8_t *pp = plen ? pat : one;
+    const int pl = plen ? plen : 1, n = plen ? nmp : pw;
+    uint8_t *d = on_device ? resident(l.pd[p], (size_t)l.rs[p] * ph) : nullptr;
+    if (d) { if (lgpu_fill_pattern(d, l.rs[p], pp, pl, n, ph, nullptr) != LGPU_OK) return 0; continue; }
+    for (int y = 0; y < ph; y++) {
+      uint8_t *row = l.pd[p] + (size_t)y * l.rs[p];
+      if (pl == 1) memset(row, pp[0], (size_t)n);
+      else for (int x = 0; x < n; x++) memcpy(row + (size_t)x * pl, pp, (size_t)pl);
+    }
+  }
   return 1;
 }
 
@@ -789,13 +997,14 @@ int lives_gpu_layer_pin(lives_gpu_layer_t *layer) {
     pool_give(e.d, e.bytes);
     e.d = d; e.bytes = cap;
   }
-  if (!sync()) return LGPU_E_HIP;
+  if (!sync()) return LGPU_E_HIP;             // the host may change or free its bytes once pin returns
   set_int(layer, kLeafResident, 1);
   return LGPU_OK;
 }
 int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return LGPU_E_BADARG;
+  if (!has_leaf(layer, kLeafResident)) return LGPU_OK;          // never pinned: the host bytes are the planes
   for (int p = 0; p < l.nplanes; p++) {
     const size_t n = plane_bytes(l, p);
     void *d = nullptr;
@@ -810,20 +1019,37 @@ int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
   }
   return sync() ? LGPU_OK : LGPU_E_HIP;
 }
-int lives_gpu_layer_unpin(lives_gpu_layer_t *layer) {
+}  // extern "C"
+namespace {
+int lives_gpu_layer_unpin_impl(weed_plant_t *layer) {
   const int rc = lives_gpu_layer_sync(layer);
   Layer l;
   if (read_layer(layer, &l)) for (int p = 0; p < l.nplanes; p++) res_drop(l.pd[p]);
   if (bound() && layer) g_api.leaf_delete(layer, kLeafResident);
   return rc;
 }
+}  // namespace
+extern "C" {
+int lives_gpu_layer_unpin(lives_gpu_layer_t *layer) { return lives_gpu_layer_unpin_impl(layer); }
+// the host is about to free or replace this layer's pixel_data itself (weed_layer_pixel_data_free, an error path, a CPU body that
+// allocates new planes): drop the device copies WITHOUT bringing them home.  After this no table entry refers to the layer's host
+// pointers, so a later allocation at the same address cannot be mistaken for a resident plane.
+int lives_gpu_layer_forget(lives_gpu_layer_t *layer) {
+  Layer l;
+  if (!bound() || !layer) return LGPU_E_BADARG;
+  if (read_layer(layer, &l)) for (int p = 0; p < l.nplanes; p++) res_drop(l.pd[p]);
+  g_api.leaf_delete(layer, kLeafResident);
+  return LGPU_OK;
+}
 // optional frame allocator pair for lives_gpu_weed_api.pixel_alloc / pixel_free: page-locked, zeroed host memory, so the planes the seam creates
-// (and any frame the host allocates through it) cross PCIe by DMA at link rate instead of through the staging chunks
+// (and any frame the host allocates through it) cross PCIe by DMA at link rate instead of through the staging chunks.  Freeing a plane through it
+// also drops a device copy registered under that address.
 void *lives_gpu_pinned_calloc(size_t bytes) { return lgpu_pinned_calloc(bytes); }
-void lives_gpu_pinned_free(void *p) { lgpu_pinned_free(p); }
+void lives_gpu_pinned_free(void *p) { res_drop(p); lgpu_pinned_free(p); }
 
 // residency bridge for the weed plugin (same library, other seam): the device copy of a pinned layer's plane, looked up by the host plane
-// pointer the channel carries; NULL when the plane is not resident (or smaller than asked)
+// pointer the channel carries; NULL when the plane is not resident (or smaller than asked).  Entries exist only between lives_gpu_layer_pin
+// and unpin / forget / the release of the plane through this library (free_planes, lives_gpu_pinned_free).
 void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
   if (!host_plane) return nullptr;
   std::lock_guard<std::mutex> lk(g_res_mu);
@@ -832,8 +1058,8 @@ void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
   return it->second.d;
 }
 void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes) {
-  if (h2d_bytes) *h2d_bytes = g_h2d;
-  if (d2h_bytes) *d2h_bytes = g_d2h;
+  if (h2d_bytes) *h2d_bytes = g_h2d.load();
+  if (d2h_bytes) *d2h_bytes = g_d2h.load();
 }
 
 }  // extern "C"

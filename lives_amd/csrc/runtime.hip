@@ -1,6 +1,7 @@
 // runtime.hip -- device init, error string, memory helpers, resident conversion tables.
 #include "lgpu_common.h"
 #include <stdarg.h>
+#include <atomic>
 #include <mutex>
 #include <string.h>
 
@@ -8,7 +9,7 @@ namespace lgpu {
 
 static thread_local char g_err[512] = "";
 static std::mutex g_mu;
-static bool g_inited[64];
+static std::atomic<bool> g_inited[64];     // release after the tables are published, acquire before they are read
 static DeviceTables g_tables[64];
 
 void set_error(const char *fmt, ...) {
@@ -33,7 +34,7 @@ static int init_device(int dev) {
   }
   if (dev < 0 || dev >= n || dev >= 64) { set_error("device %d out of range (%d devices)", dev, n); return LGPU_E_BADARG; }
   LGPU_HIP(hipSetDevice(dev));
-  if (g_inited[dev]) return LGPU_OK;
+  if (g_inited[dev].load(std::memory_order_acquire)) return LGPU_OK;
   hipDeviceProp_t prop;
   LGPU_HIP(hipGetDeviceProperties(&prop, dev));
   if (!strstr(prop.gcnArchName, "gfx950")) {
@@ -59,7 +60,7 @@ static int init_device(int dev) {
     LGPU_HIP(hipMalloc((void **)&g_tables[dev].luma, sizeof lw));
     LGPU_HIP(hipMemcpy(g_tables[dev].luma, lw, sizeof lw, hipMemcpyHostToDevice));
   }
-  g_inited[dev] = true;
+  g_inited[dev].store(true, std::memory_order_release);
   return LGPU_OK;
 }
 
@@ -69,13 +70,13 @@ int ensure_init() {
     set_error("no HIP device available (this library has no CPU fallback)");
     return LGPU_E_NODEVICE;
   }
-  if (d < 64 && g_inited[d]) return LGPU_OK;
+  if (d < 64 && g_inited[d].load(std::memory_order_acquire)) return LGPU_OK;
   return init_device(d);
 }
 
 const DeviceTables *device_tables() {
   int d = current_device();
-  return (d >= 0 && d < 64 && g_inited[d]) ? &g_tables[d] : nullptr;
+  return (d >= 0 && d < 64 && g_inited[d].load(std::memory_order_acquire)) ? &g_tables[d] : nullptr;
 }
 
 }  // namespace lgpu
@@ -94,10 +95,15 @@ int lgpu_device_count(void) {
   return n;
 }
 
+// fault injection for the failure-contract tests: the n-th lgpu_malloc from now fails as if the device were out of memory
+static std::atomic<int> g_fail_alloc{0};
+int lgpu_debug_fail_alloc(int nth) { g_fail_alloc.store(nth > 0 ? nth : 0); return LGPU_OK; }
+
 int lgpu_malloc(void **ptr_d, size_t bytes) {
   int rc = lgpu::ensure_init();
   if (rc) return rc;
   if (!ptr_d) return LGPU_E_BADARG;
+  if (g_fail_alloc.load() > 0 && g_fail_alloc.fetch_sub(1) == 1) { *ptr_d = nullptr; lgpu::set_error("hipMalloc(%zu) failed (injected)", bytes); return LGPU_E_NOMEM; }
   if (hipMalloc(ptr_d, bytes ? bytes : 1) != hipSuccess) { lgpu::set_error("hipMalloc(%zu) failed", bytes); return LGPU_E_NOMEM; }
   return LGPU_OK;
 }
@@ -217,6 +223,42 @@ int lgpu_fill(void *dst_d, int byte, size_t bytes, void *stream) {
   int rc = lgpu::ensure_init();
   if (rc) return rc;
   LGPU_HIP(hipMemsetAsync(dst_d, byte, bytes, (hipStream_t)stream));
+  return LGPU_OK;
+}
+
+// rows of row_bytes bytes between two pitched device buffers (compact_rowstrides, the cut of unletterbox_layer)
+int lgpu_copy_rows(void *dst_d, int orow, const void *src_d, int irow, int row_bytes, int rows, void *stream) {
+  int rc = lgpu::ensure_init();
+  if (rc) return rc;
+  if (!dst_d || !src_d || row_bytes < 0 || rows < 0 || orow < row_bytes || irow < row_bytes) { lgpu::set_error("lgpu_copy_rows: bad geometry"); return LGPU_E_BADARG; }
+  if (!row_bytes || !rows) return LGPU_OK;
+  LGPU_HIP(hipMemcpy2DAsync(dst_d, (size_t)orow, src_d, (size_t)irow, (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return LGPU_OK;
+}
+
+namespace lgpu {
+struct Pat8 { uint8_t b[8]; };
+__global__ __launch_bounds__(kBlock) void k_fill_pattern(uint8_t *dst, int rowstride, Pat8 pat, int plen, int nbytes, int rows) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;            // byte within the row
+  if (x >= nbytes) return;
+  const uint8_t v = pat.b[x % plen];
+  for (int y = blockIdx.y; y < rows; y += gridDim.y) dst[(size_t)y * rowstride + x] = v;
+}
+}  // namespace lgpu
+
+// n repetitions of a plen-byte (1..8) pattern at the start of every row: the black of a palette (blank_pixel / blank_row,
+// src/colourspace.c:11123-11210) on device-resident planes; bytes past n * plen in a row are left alone
+int lgpu_fill_pattern(void *dst_d, int rowstride, const uint8_t *pattern, int plen, int n, int rows, void *stream) {
+  int rc = lgpu::ensure_init();
+  if (rc) return rc;
+  if (!dst_d || !pattern || plen < 1 || plen > 8 || n < 0 || rows < 0 || (long)n * plen > rowstride) { lgpu::set_error("lgpu_fill_pattern: bad geometry"); return LGPU_E_BADARG; }
+  if (!n || !rows) return LGPU_OK;
+  lgpu::Pat8 p = {};
+  for (int i = 0; i < plen; i++) p.b[i] = pattern[i];
+  const int nbytes = n * plen;
+  dim3 grid(lgpu::cdiv((unsigned)nbytes, lgpu::kBlock), (unsigned)(rows > 512 ? 512 : rows));
+  hipLaunchKernelGGL(lgpu::k_fill_pattern, grid, dim3(lgpu::kBlock), 0, (hipStream_t)stream, (uint8_t *)dst_d, rowstride, p, plen, nbytes, rows);
+  LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
 

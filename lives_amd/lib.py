@@ -55,11 +55,14 @@ PROTOTYPES = {
     "lgpu_device_count": [],
     "lgpu_malloc": [ctypes.POINTER(vp), ctypes.c_size_t],
     "lgpu_free": [vp],
+    "lgpu_debug_fail_alloc": [ci],
     "lgpu_upload": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_download": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_copy": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_fill": [vp, ci, ctypes.c_size_t, vp],
     "lgpu_sync": [vp],
+    "lgpu_copy_rows": [vp, ci, vp, ci, ci, ci, vp],
+    "lgpu_fill_pattern": [vp, ci, vp, ci, ci, ci, vp],
     "lgpu_conversion_tables": [ci, vp, vp],
     "lgpu_gamma_lut8": [cd, ci, ci, cd, vp],
     "lgpu_calc_rowstrides": [ci, ci, ci, vp],

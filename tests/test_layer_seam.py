@@ -62,13 +62,73 @@ def test_host_side_functions_without_gpu(seam):
 
 @needs_ref
 def test_failure_leaves_layer_untouched(seam):
+    """no device (this box) or a declined conversion: FALSE, same planes, same leaves"""
     L, wh = seam
     src = np.arange(4 * 64, dtype=np.uint8).reshape(4, 64)
-    lay = wh.new_layer(RGBA32, 10, 4, [src], gamma=1)
+    lay = wh.new_layer(ARGB32, 10, 4, [src], gamma=1)
     before, ptrs, _ = wh.planes_of(lay)
-    assert L.lives_gpu_convert_layer_palette(lay, 595, 0) == 0             # YUV411: not on the GPU path
+    assert L.lives_gpu_convert_layer_palette(lay, YUV420P, 0) == 0            # ARGB32 -> 4:2:0: reference-broken (K4-d), declined everywhere
     after, ptrs2, _ = wh.planes_of(lay)
-    assert ptrs == ptrs2 and (before[0] == after[0]).all() and wh.geti(lay, "current_palette") == RGBA32
+    assert ptrs == ptrs2 and (before[0] == after[0]).all() and wh.geti(lay, "current_palette") == ARGB32
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_declines_and_device_failures_leave_the_layer_untouched(seam, orc):
+    """the memfail: contract (src/colourspace.c:13906-13927) on a real device: (1) conversions this library declines, (2) calls that fail
+    AFTER they have started -- a device allocation fails half way (lgpu_debug_fail_alloc) -- return FALSE with the same plane
+    pointers, the same bytes and the same leaves; the same call then succeeds"""
+    L, wh = seam
+    rng = np.random.default_rng(77)
+    L.lgpu_debug_fail_alloc.argtypes = [ctypes.c_int]
+
+    def snapshot(lay):
+        planes, ptrs, rs = wh.planes_of(lay)
+        return ([p.copy() for p in planes], ptrs, rs, wh.geti(lay, "current_palette"), wh.geti(lay, "width"), wh.geti(lay, "height"),
+                wh.geti(lay, "gamma_type"), wh.geti(lay, "host_flags"))
+
+    def same(a, b):
+        return a[1:] == b[1:] and all((x == y).all() for x, y in zip(a[0], b[0]))
+
+    # (1) declined pairs: ARGB32 -> 4:2:0 (K4-d), 4:2:2 planar -> YUV888 (reads past its chroma rows), a subspace change between YUV palettes
+    src = frame(rng, 64, 32, 4)
+    lay = wh.new_layer(ARGB32, 64, 32, [src], gamma=1)
+    s0 = snapshot(lay)
+    assert L.lives_gpu_convert_layer_palette(lay, YUV420P, 0) == 0 and same(s0, snapshot(lay))
+    Y, U, V = frame(rng, 64, 32, 1), frame(rng, 32, 32, 1), frame(rng, 32, 32, 1)
+    lay = wh.new_layer(522, 64, 32, [Y, U, V], clamping=0, subspace=1)
+    s0 = snapshot(lay)
+    assert L.lives_gpu_convert_layer_palette(lay, YUV888, 0) == 0 and same(s0, snapshot(lay))
+    lay = wh.new_layer(YUV888, 64, 32, [frame(rng, 64, 32, 3)], clamping=0, subspace=1)
+    s0 = snapshot(lay)
+    assert L.lives_gpu_convert_layer_palette_full(lay, 589, 0, 0, 2, 0) == 0 and same(s0, snapshot(lay))        # YCbCr -> BT.709: through RGB in the reference
+    # (2) injected allocation failures inside calls that are served: sizes nobody used before, so every call has to allocate
+    for nth, (bw, bh) in ((1, (2303, 1301)), (2, (2603, 1501))):     # larger than any frame so far: both scratch slots have to grow in each round
+        big = frame(rng, bw, bh, 4)
+        lay = wh.new_layer(RGBA32, bw, bh, [big], gamma=1)
+        s0 = snapshot(lay)
+        L.lgpu_debug_fail_alloc(nth)
+        rc = L.lives_gpu_convert_layer_palette(lay, BGR24, 0)
+        L.lgpu_debug_fail_alloc(0)
+        assert rc == 0 and same(s0, snapshot(lay)), "failed allocation %d" % nth
+        assert L.lives_gpu_convert_layer_palette(lay, BGR24, 0) == 1 and wh.geti(lay, "current_palette") == BGR24
+    big = frame(rng, 2811, 1607, 4)
+    lay = wh.new_layer(RGBA32, 2811, 1607, [big])
+    s0 = snapshot(lay)
+    L.lgpu_debug_fail_alloc(1)
+    rc = L.lives_gpu_resize_layer(lay, 1404, 802, 3, 0, 0)
+    L.lgpu_debug_fail_alloc(0)
+    assert rc == 0 and same(s0, snapshot(lay))
+    assert L.lives_gpu_resize_layer(lay, 1404, 802, 3, 0, 0) == 1
+    # a pinned layer: the failure happens when the new resident plane is taken from the pool
+    lay = wh.new_layer(RGBA32, 3011, 1693, [frame(rng, 3011, 1693, 4)], gamma=1)
+    assert L.lives_gpu_layer_pin(lay) == 0
+    s0 = snapshot(lay)
+    L.lgpu_debug_fail_alloc(1)
+    rc = L.lives_gpu_convert_layer_palette(lay, BGR24, 0)
+    L.lgpu_debug_fail_alloc(0)
+    assert rc == 0 and same(s0, snapshot(lay)) and wh.geti(lay, "host_gpu_resident") == 1
+    assert L.lives_gpu_convert_layer_palette(lay, BGR24, 0) == 1 and L.lives_gpu_layer_unpin(lay) == 0
 
 
 @needs_ref

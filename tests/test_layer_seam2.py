@@ -1,0 +1,246 @@
+"""The rest of the layer-op seam (src/colourspace.h:377-423) on genuine weed plants: resize_layer_full with its fused gamma pass,
+unletterbox_layer, compact_rowstrides, weed_layer_clear_pixel_data, the _with_sampling / _variant wrappers, the premultiplied-alpha
+bookkeeping with prefs->alpha_post, and the residency rules (a declined call unpins, forget + a new allocation at the same address)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.util import align, frame
+
+needs_ref = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref (reference libweed) not built")
+pytestmark = [needs_ref, pytest.mark.gpu]
+P = po.P
+RGB24, BGR24, RGBA32, BGRA32, ARGB32, YUV420P, YUV422P, YUV444P, UYVY, YUYV, YUV888, YUVA8888, YUV411 = 1, 2, 3, 4, 5, 512, 522, 544, 564, 565, 588, 589, 595
+
+
+@pytest.fixture(scope="module")
+def seam():
+    from lives_amd import lib
+    from tests import weedhost
+    L = lib.load()
+    weedhost.bind(L)
+    return L, weedhost
+
+
+class Prefs(ctypes.Structure):
+    _fields_ = [("apply_gamma", ctypes.c_int), ("alpha_post", ctypes.c_int), ("pb_quality", ctypes.c_int), ("screen_gamma", ctypes.c_double), ("device", ctypes.c_int)]
+
+
+def test_resize_layer_full_fuses_the_target_gamma(seam, orc):
+    """tgt_gamma != layer gamma on an RGB layer: the LUT8 of create_gamma_lut8(layer gamma -> target) runs over the scaled frame
+    (src/colourspace.c:14718-14720, :15119-15127) and the layer is tagged with the target"""
+    L, wh = seam
+    rng = np.random.default_rng(41)
+    sw, sh, dw, dh = 384, 216, 192, 108
+    src = frame(rng, sw, sh, 4)
+    lay = wh.new_layer(RGBA32, sw, sh, [src], gamma=-1)                     # WEED_GAMMA_LINEAR
+    assert L.lives_gpu_resize_layer_full(lay, dw, dh, 3, RGBA32, 0, 0, 0, 1) == 1      # -> WEED_GAMMA_SRGB
+    planes, _, rs = wh.planes_of(lay)
+    assert (wh.geti(lay, "width"), wh.geti(lay, "height"), wh.geti(lay, "gamma_type")) == (dw, dh, 1)
+    want = np.zeros((dh, rs[0]), np.uint8)
+    assert orc.orc_resize(P(src), src.strides[0], sw, sh, P(want), rs[0], dw, dh, 4, 3) == 0
+    lut = np.zeros(256, np.uint8)
+    assert orc.orc_gamma_lut8(1.0, -1, 1, 1.4, P(lut)) == 1
+    orc.orc_gamma_apply(P(want), rs[0], dw, dh, 4, 0, P(lut))
+    assert (planes[0][:, :dw * 4] == want[:, :dw * 4]).all()
+    # unknown target: the layer's own gamma, no LUT; the six-argument form is the same call
+    a = wh.new_layer(RGBA32, sw, sh, [src], gamma=1)
+    b = wh.new_layer(RGBA32, sw, sh, [src], gamma=1)
+    assert L.lives_gpu_resize_layer_full(a, dw, dh, 3, 0, 0, 0, 0, 0) == 1 and L.lives_gpu_resize_layer(b, dw, dh, 3, 0, 0) == 1
+    assert (wh.planes_of(a)[0][0] == wh.planes_of(b)[0][0]).all() and wh.geti(a, "gamma_type") == 1
+
+
+def test_unletterbox_layer(seam, orc):
+    """borders cut off (src/colourspace.c:15570-15628); quirk U1: the reference's row copy moves xwidth BYTES (:15614), the rest of each
+    row of the new opaque-black frame stays black"""
+    L, wh = seam
+    rng = np.random.default_rng(42)
+    w, h, top, bottom, left, right = 96, 64, 6, 10, 8, 12
+    for pal, ps, black in ((RGBA32, 4, [0, 0, 0, 255]), (RGB24, 3, [0, 0, 0]), (ARGB32, 4, [255, 0, 0, 0])):
+        src = frame(rng, w, h, ps)
+        lay = wh.new_layer(pal, w, h, [src])
+        assert L.lives_gpu_unletterbox_layer(lay, 0, 0, top, bottom, left, right) == 1
+        xw, xh = w - left - right, h - top - bottom
+        planes, _, rs = wh.planes_of(lay)
+        assert (wh.geti(lay, "width"), wh.geti(lay, "height"), rs) == (xw, xh, [align(xw * ps)])
+        want = np.zeros((xh, rs[0]), np.uint8)
+        want[:, :xw * ps] = np.tile(np.array(black, np.uint8), xw)[None, :]
+        want[:, :xw] = src[top:top + xh, left * ps:left * ps + xw]
+        assert (planes[0] == want).all(), pal
+    # with an output size: the cut frame is resized (LIVES_INTERP_BEST)
+    src = frame(rng, w, h, 4)
+    lay = wh.new_layer(RGBA32, w, h, [src])
+    assert L.lives_gpu_unletterbox_layer(lay, -1, -1, top, bottom, left, right) == 1
+    assert (wh.geti(lay, "width"), wh.geti(lay, "height")) == (w, h)
+    # nothing to cut: TRUE, same planes
+    lay = wh.new_layer(RGBA32, w, h, [src])
+    _, ptrs, _ = wh.planes_of(lay)
+    assert L.lives_gpu_unletterbox_layer(lay, 0, 0, 0, 0, -3, 0) == 1 and wh.planes_of(lay)[1] == ptrs
+
+
+def test_compact_rowstrides(seam):
+    L, wh = seam
+    rng = np.random.default_rng(43)
+    src = frame(rng, 50, 20, 3, stride=192)
+    lay = wh.new_layer(RGB24, 50, 20, [src])
+    assert L.lives_gpu_compact_rowstrides(lay) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert rs == [150] and (planes[0] == src[:, :150]).all()
+    Y, U, V = frame(rng, 50, 20, 1, stride=64), frame(rng, 25, 10, 1, stride=32), frame(rng, 25, 10, 1, stride=32)
+    lay = wh.new_layer(YUV420P, 50, 20, [Y, U, V], clamping=0)
+    assert L.lives_gpu_compact_rowstrides(lay) == 1
+    planes, _, rs = wh.planes_of(lay)
+    assert rs == [50, 25, 25] and (planes[0] == Y[:, :50]).all() and (planes[1] == U[:, :25]).all() and (planes[2] == V[:, :25]).all()
+    _, ptrs, _ = wh.planes_of(lay)
+    assert L.lives_gpu_compact_rowstrides(lay) == 1 and wh.planes_of(lay)[1] == ptrs      # already compact: untouched
+
+
+def test_weed_layer_clear_pixel_data(seam):
+    """blank_frame (src/colourspace.c:11212-11226) in place: the palette's black over the pixels, row padding untouched; host bytes of an
+    ordinary layer, the resident planes of a pinned one"""
+    L, wh = seam
+    rng = np.random.default_rng(44)
+    cases = [(RGB24, 3, [0, 0, 0], None), (RGBA32, 4, [0, 0, 0, 255], None), (ARGB32, 4, [255, 0, 0, 0], None), (YUV888, 3, [16, 128, 128], 0),
+             (YUVA8888, 4, [0, 128, 128, 255], 1), (UYVY, 4, [128, 16, 128, 16], 0), (YUV411, 6, [128, 16, 16, 128, 16, 16], 0)]
+    for pinned in (0, 1):
+        for pal, ps, black, clamping in cases:
+            w, h = 40, 12
+            src = frame(rng, w, h, ps)
+            lay = wh.new_layer(pal, w, h, [src], clamping=clamping)
+            if pinned:
+                assert L.lives_gpu_layer_pin(lay) == 0
+            _, ptrs, _ = wh.planes_of(lay)
+            assert L.lives_gpu_weed_layer_clear_pixel_data(lay) == 1
+            if pinned:
+                assert L.lives_gpu_layer_unpin(lay) == 0
+            planes, ptrs2, _ = wh.planes_of(lay)
+            want = src.copy()
+            want[:, :w * ps] = np.tile(np.array(black, np.uint8), w)[None, :]
+            assert ptrs2 == ptrs and (planes[0] == want).all(), (pal, pinned)
+        # YUYV: blank_pixel never advances (:11150-11154): only the first macropixel of every row is painted
+        src = frame(rng, 40, 12, 4)
+        lay = wh.new_layer(YUYV, 40, 12, [src], clamping=0)
+        if pinned:
+            assert L.lives_gpu_layer_pin(lay) == 0
+        assert L.lives_gpu_weed_layer_clear_pixel_data(lay) == 1
+        if pinned:
+            assert L.lives_gpu_layer_unpin(lay) == 0
+        want = src.copy()
+        want[:, :4] = [16, 128, 16, 128]
+        assert (wh.planes_of(lay)[0][0] == want).all()
+        # planar 4:2:0: Y 16 (clamped), chroma 128
+        Y, U, V = frame(rng, 64, 16, 1), frame(rng, 32, 8, 1), frame(rng, 32, 8, 1)
+        lay = wh.new_layer(YUV420P, 64, 16, [Y, U, V], clamping=0)
+        if pinned:
+            assert L.lives_gpu_layer_pin(lay) == 0
+        assert L.lives_gpu_weed_layer_clear_pixel_data(lay) == 1
+        if pinned:
+            assert L.lives_gpu_layer_unpin(lay) == 0
+        planes, _, _ = wh.planes_of(lay)
+        assert (planes[0][:, :64] == 16).all() and (planes[1][:, :32] == 128).all() and (planes[2][:, :32] == 128).all()
+
+
+def test_wrappers_with_sampling_and_variant(seam, orc):
+    L, wh = seam
+    rng = np.random.default_rng(45)
+    src = frame(rng, 66, 34, 3)
+    a, b = wh.new_layer(RGB24, 66, 34, [src]), wh.new_layer(RGB24, 66, 34, [src])
+    assert L.lives_gpu_convert_layer_palette_with_sampling(a, YUV888, 0) == 1                 # (unclamped, default subspace, no gamma) :13935
+    assert L.lives_gpu_convert_layer_palette_full(b, YUV888, 1, 0, 0, 0) == 1
+    assert (wh.planes_of(a)[0][0] == wh.planes_of(b)[0][0]).all() and wh.geti(a, "YUV_clamping") == 1
+    # gamma_convert_layer_variant (:14157-14168): the layer is tagged LINEAR first, then converted to the target; the file gamma enters the
+    # table only for the target WEED_GAMMA_VARIANT (2048), which leaves the tag alone (:14137-14138)
+    src = frame(rng, 66, 34, 4)
+    for tgt, fg in ((1, 1.8), (2048, 1.8)):
+        lay = wh.new_layer(RGBA32, 66, 34, [src], gamma=1)
+        assert L.lives_gpu_gamma_convert_layer_variant(fg, tgt, lay) == 1
+        lut = np.zeros(256, np.uint8)
+        assert orc.orc_gamma_lut8(fg if tgt == 2048 else 1.0, -1, tgt, 1.4, P(lut)) == 1
+        want = src.copy()
+        orc.orc_gamma_apply(P(want), want.strides[0], 66, 34, 4, 0, P(lut))
+        assert (wh.planes_of(lay)[0][0] == want).all() and wh.geti(lay, "gamma_type") == (1 if tgt == 1 else -1), tgt
+
+
+def test_premult_bookkeeping_applies_to_every_palette_pair(seam, orc):
+    """src/colourspace.c:12290-12306 runs before the palette dispatch: with prefs->alpha_post a PREMULT RGBA layer that loses its alpha
+    to a YUV palette is un-premultiplied first; without it, RGB24 -> YUVA8888 gains the PREMULT flag"""
+    L, wh = seam
+    rng = np.random.default_rng(46)
+    L.lives_gpu_set_prefs.argtypes = [ctypes.POINTER(Prefs)]
+    src = frame(rng, 64, 32, 4, alpha_mix=True)
+    try:
+        assert L.lives_gpu_set_prefs(ctypes.byref(Prefs(1, 1, 2, 1.4, 0))) == 0
+        lay = wh.new_layer(RGBA32, 64, 32, [src], flags=1)                                  # LIVES_LAYER_ALPHA_PREMULT
+        assert L.lives_gpu_convert_layer_palette(lay, YUV888, 0) == 1
+        un = src.copy()
+        orc.orc_alpha_premult(P(un), un.strides[0], 64, 32, 0, 1)
+        want = np.zeros((32, align(64 * 3)), np.uint8)
+        dp, ds = po.planes_args([want])
+        assert orc.orc_rgb_to_yuv(P(un), un.strides[0], 64, 32, 0, 1, ctypes.addressof(dp), ctypes.addressof(ds), 0, 0, 0) == 0
+        assert (wh.planes_of(lay)[0][0][:, :64 * 3] == want[:, :64 * 3]).all() and (wh.geti(lay, "host_flags") or 0) & 1 == 0
+    finally:
+        assert L.lives_gpu_set_prefs(ctypes.byref(Prefs(1, 0, 2, 1.4, 0))) == 0
+    rgb = frame(rng, 64, 32, 3)
+    lay = wh.new_layer(RGB24, 64, 32, [rgb])
+    assert L.lives_gpu_convert_layer_palette(lay, YUVA8888, 0) == 1 and (wh.geti(lay, "host_flags") or 0) & 1 == 1
+
+
+def test_a_declined_call_brings_a_pinned_layer_home(seam):
+    """FALSE means the caller's CPU body runs next; the host bytes of a pinned layer are stale by contract, so the
+    decline synchronises and unpins it first"""
+    L, wh = seam
+    rng = np.random.default_rng(47)
+    src = frame(rng, 64, 32, 4)
+    lay = wh.new_layer(RGBA32, 64, 32, [src], gamma=-1)
+    assert L.lives_gpu_layer_pin(lay) == 0
+    assert L.lives_gpu_gamma_convert_layer(1, lay) == 1                    # device copy changes, host bytes are stale now
+    stale, _, _ = wh.planes_of(lay)
+    assert (stale[0] == src).all()
+    assert L.lives_gpu_convert_layer_palette(lay, YUV420P, 0) == 1          # served: still pinned
+    assert wh.geti(lay, "host_gpu_resident") == 1
+    lay2 = wh.new_layer(ARGB32, 64, 32, [src], gamma=-1)
+    assert L.lives_gpu_layer_pin(lay2) == 0 and L.lives_gpu_gamma_convert_layer(1, lay2) == 1
+    want = wh.new_layer(ARGB32, 64, 32, [src], gamma=-1)
+    assert L.lives_gpu_gamma_convert_layer(1, want) == 1
+    assert L.lives_gpu_convert_layer_palette(lay2, YUV420P, 0) == 0         # ARGB32 -> 4:2:0 is declined ...
+    assert wh.geti(lay2, "host_gpu_resident") is None                      # ... and the layer came home first
+    assert (wh.planes_of(lay2)[0][0] == wh.planes_of(want)[0][0]).all()
+    assert L.lives_gpu_layer_unpin(lay) == 0
+
+
+def test_forget_drops_the_device_copy(seam):
+    """the table of device copies is keyed by host plane pointer: a host that frees a pinned layer's planes itself calls
+    lives_gpu_layer_forget() first; a new layer that lands on the same address is then an ordinary layer"""
+    L, wh = seam
+    rng = np.random.default_rng(48)
+    L.lives_gpu_resident_lookup.restype = ctypes.c_void_p
+    L.lives_gpu_resident_lookup.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    a = frame(rng, 64, 32, 4)
+    lay = wh.new_layer(RGBA32, 64, 32, [a], gamma=-1)
+    _, ptrs, _ = wh.planes_of(lay)
+    assert L.lives_gpu_layer_pin(lay) == 0 and L.lives_gpu_resident_lookup(ptrs[0], a.nbytes)
+    assert L.lives_gpu_layer_forget(lay) == 0
+    assert not L.lives_gpu_resident_lookup(ptrs[0], a.nbytes) and wh.geti(lay, "host_gpu_resident") is None
+    # the host reuses the memory for another frame (same address, never pinned): the seam must read the HOST bytes
+    b = frame(rng, 64, 32, 4)
+    ctypes.memmove(ptrs[0], b.ctypes.data, b.nbytes)
+    assert L.lives_gpu_convert_layer_palette(lay, BGRA32, 0) == 1
+    got = wh.planes_of(lay)[0][0]
+    assert (got[:, 0::4] == b[:, 2::4]).all() and (got[:, 2::4] == b[:, 0::4]).all()
+    # an unpinned layer never consults the table, even if an entry with its address existed
+    lay1 = wh.new_layer(RGBA32, 64, 32, [a], gamma=-1)
+    assert L.lives_gpu_layer_pin(lay1) == 0
+    _, p1, _ = wh.planes_of(lay1)
+    assert L.lives_gpu_gamma_convert_layer(1, lay1) == 1                    # device copy differs from the host bytes
+    W = wh.weed()
+    lay_alias = W.plant_new(128)                                           # a second, unpinned layer over the same host memory
+    for k, v in (("current_palette", RGBA32), ("width", 64), ("height", 32), ("gamma_type", -1)):
+        W.weed_set_int_value(lay_alias, k.encode(), v)
+    W.weed_set_int_array(lay_alias, b"rowstrides", 1, (ctypes.c_int * 1)(a.strides[0]))
+    W.weed_set_voidptr_array(lay_alias, b"pixel_data", 1, (ctypes.c_void_p * 1)(p1[0]))
+    ref = wh.new_layer(RGBA32, 64, 32, [a], gamma=-1)
+    assert L.lives_gpu_gamma_convert_layer(1, lay_alias) == 1 and L.lives_gpu_gamma_convert_layer(1, ref) == 1
+    assert L.lives_gpu_layer_forget(lay1) == 0
+    assert (wh.planes_of(lay_alias)[0][0] == wh.planes_of(ref)[0][0]).all()

@@ -56,7 +56,11 @@ def bind(L):
                        ("lives_gpu_gamma_convert_layer", [ci, vp]), ("lives_gpu_gamma_convert_sub_layer", [ci, ctypes.c_double, vp, ci, ci, ci, ci, ci]),
                        ("lives_gpu_alpha_premult", [vp, ci]), ("lives_gpu_resize_layer", [vp, ci, ci, ci, ci, ci]),
                        ("lives_gpu_letterbox_layer", [vp, ci, ci, ci, ci, ci, ci, ci]), ("lives_gpu_create_empty_pixel_data", [vp, ci, ci]),
-                       ("lives_gpu_layer_pin", [vp]), ("lives_gpu_layer_sync", [vp]), ("lives_gpu_layer_unpin", [vp]), ("lives_gpu_transfer_stats", [vp, vp])):
+                       ("lives_gpu_layer_pin", [vp]), ("lives_gpu_layer_sync", [vp]), ("lives_gpu_layer_unpin", [vp]), ("lives_gpu_layer_forget", [vp]),
+                       ("lives_gpu_transfer_stats", [vp, vp]), ("lives_gpu_convert_layer_palette_with_sampling", [vp, ci, ci]),
+                       ("lives_gpu_gamma_convert_layer_variant", [ctypes.c_double, ci, vp]), ("lives_gpu_resize_layer_full", [vp, ci, ci, ci, ci, ci, ci, ci, ci]),
+                       ("lives_gpu_unletterbox_layer", [vp, ci, ci, ci, ci, ci, ci]), ("lives_gpu_compact_rowstrides", [vp]),
+                       ("lives_gpu_weed_layer_clear_pixel_data", [vp])):
         getattr(L, name).argtypes = args
     L.lives_gpu_calc_rowstrides.argtypes = [ci, ci, vp, vp]
     L.lives_gpu_calc_rowstrides.restype = ctypes.POINTER(ci)
