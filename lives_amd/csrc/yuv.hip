@@ -210,6 +210,142 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb4(YuvArgs a, Lut8 lut,
   }
 }
 
+// ---- the same cells for launches that fill the device (batches of tracks, 4K frames): k_yuv420p_to_rgb16 ---------------------------
+// profiles/r02/k2_pmc.md: k_yuv420p_to_rgb4 on the 16-frame batch spends 58 VALU operations and 9.3 LDS gathers per pixel, 53 % of its
+// LDS cycles are bank conflicts (random indices into 256-entry tables: ~3.5 lanes of every 32 meet on a bank).  This kernel keeps the
+// cell arithmetic (same bytes) and changes what is around it:
+//   * tables in SIXTEEN interleaved copies (entry i of copy c at slot 16 i + c; lane uses copy lane & 15): a copy owns 2 of the 32
+//     banks and is used by 2 lanes of a half-wave, so a gather costs at most 2 LDS cycles per half instead of ~3.5;
+//   * {R_Cr, G_Cr}[v] and {G_Cb, B_Cb}[u] as 8-byte entries: 3 table gathers per pixel instead of 5 (the left pixels of a quad share
+//     their U pair: 11 per 2 x 2 quad);
+//   * CLAMP0255f + gamma LUT as ONE table indexed by (sum >> 16) + kY16Bias (RGB_Y carries the bias): no clamp instructions;
+//   * CLAMP16_240 / the 0..255 clamp as one v_med3, / 3 as a multiply-shift, chroma bytes taken by SDWA operands.
+// 139 KB of tables per workgroup, so a workgroup is 1024 threads, one per CU, persistent over the cells (4 row pairs x 256 column groups
+// per step).  Cells near the frame edges go through yuv420_cell() as before.
+constexpr int kY16Bias = 320, kY16Lut = 896;        // (sum >> 16) of every table set lies in [-320, 575] (checked on the host per launch)
+constexpr int kY16OffLut = 0, kY16OffTy = kY16Lut * 64, kY16OffRG = kY16OffTy + 16384, kY16OffGB = kY16OffRG + 32768, kY16OffTab = kY16OffGB + 32768,
+              kY16OffLut8 = kY16OffTab + 5 * 1024, kY16Lds = kY16OffLut8 + 256;     // the table bases travel in the per-lane copy offsets, the LUT sits at 0
+template <int ORDER>
+__global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, YuvBatch bt, int nframes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t *s_ty = reinterpret_cast<uint32_t *>(smem + kY16OffTy);
+  uint2 *s_rg = reinterpret_cast<uint2 *>(smem + kY16OffRG), *s_gb = reinterpret_cast<uint2 *>(smem + kY16OffGB);
+  uint32_t *s_lx = reinterpret_cast<uint32_t *>(smem + kY16OffLut);
+  int32_t *s_tab = reinterpret_cast<int32_t *>(smem + kY16OffTab);
+  uint8_t *s_lut = smem + kY16OffLut8;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 5 * 256; i += 1024) s_tab[i] = a.tables[i];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+  const int clo = a.clamped ? 16 : 0, chi = a.clamped ? 240 : 255;
+  for (int i = tid; i < 256 * 16; i += 1024) {
+    const int e = i >> 4;
+    s_ty[i] = (uint32_t)(s_tab[e] + (kY16Bias << 16));
+    const int ec = e < clo ? clo : e > chi ? chi : e;                                   // CLAMP16_240 / 0..255 of the blended chroma, folded into the index
+    s_rg[i] = make_uint2((uint32_t)s_tab[256 + ec], (uint32_t)s_tab[768 + ec]);        // R_Cr, G_Cr (indexed by V)
+    s_gb[i] = make_uint2((uint32_t)s_tab[512 + ec], (uint32_t)s_tab[1024 + ec]);       // G_Cb, B_Cb (indexed by U)
+  }
+  for (int i = tid; i < kY16Lut * 16; i += 1024) {
+    const int e = (i >> 4) - kY16Bias, cl = e < 0 ? 0 : e > 255 ? 255 : e;
+    s_lx[i] = a.use_lut ? s_lut[cl] : (uint32_t)cl;
+  }
+  __syncthreads();
+  YuvCtx c;
+  c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
+  c.lut = s_lut; c.lut16 = nullptr; c.clamped = a.clamped; c.lowq = false; c.use_lut = a.use_lut; c.opsize = 4; c.order = ORDER;
+  const int hw = a.width >> 1, ncg = (hw + 3) >> 2;
+  const int npairs = (a.height - 1) / 2;
+  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
+  const int total = nunits * nframes;
+  const uint32_t c4 = (uint32_t)(tid & 15) * 4u, c4y = c4 + kY16OffTy, c8v = c4 * 2u + kY16OffRG, c8u = c4 * 2u + kY16OffGB;
+  typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) u32x2v *lds_u64;
+  // A workgroup step covers 4 linear units (frame, row-pair unit) x 256 column groups; a thread walks its cells (unit, column group)
+  // with the loads of the NEXT cell issued before the arithmetic of the current one (16 waves per CU hide little latency by themselves).
+  struct Cell { uint2 ya, yb; uint32_t u0m, u0c, u0p, u1c, u1p, v0c, v0p, v1m, v1c, v1p, lv2; int z, unit, k0; bool valid, fast; };
+  auto fetch = [&](int ul, int cg) -> Cell {
+    Cell q;
+    q.valid = ul < total;
+    q.fast = false;
+    if (!q.valid) return q;
+    q.z = ul / nunits; q.unit = ul - q.z * nunits; q.k0 = 4 * cg;
+    const int i = 2 * q.unit - 1, r = i >> 1;
+    q.fast = q.unit >= 1 && q.unit <= npairs && q.k0 + 4 <= hw && (long)(r + 1) * a.us + q.k0 + 8 <= a.usize &&
+             (long)(r + 1) * a.vs + q.k0 + 8 <= a.vsize;
+    if (!q.fast) return q;
+    const uint8_t *py = bt.y[q.z], *pu = bt.u[q.z], *pv = bt.v[q.z];
+    q.ya = *reinterpret_cast<const uint2 *>(py + (size_t)i * a.ys + 2 * q.k0); q.yb = *reinterpret_cast<const uint2 *>(py + (size_t)(i + 1) * a.ys + 2 * q.k0);
+    const uint8_t *ur = pu + (size_t)r * a.us + q.k0, *vr = pv + (size_t)r * a.vs + q.k0;
+    q.u0c = *reinterpret_cast<const uint32_t *>(ur); q.u0p = *reinterpret_cast<const uint32_t *>(ur + 4);
+    q.u1c = *reinterpret_cast<const uint32_t *>(ur + a.us); q.u1p = *reinterpret_cast<const uint32_t *>(ur + a.us + 4);
+    q.v0c = *reinterpret_cast<const uint32_t *>(vr); q.v0p = *reinterpret_cast<const uint32_t *>(vr + 4);
+    q.v1c = *reinterpret_cast<const uint32_t *>(vr + a.vs); q.v1p = *reinterpret_cast<const uint32_t *>(vr + a.vs + 4);
+    // the sample left of the group: column k0 - 1, or for the first group the reference's k == 0 case: lu1 = U[r][0], lv1 = V[r][0] (:3447-3452)
+    if (q.k0) { q.u0m = *reinterpret_cast<const uint32_t *>(ur - 4); q.v1m = *reinterpret_cast<const uint32_t *>(vr + a.vs - 4); }
+    else { q.u0m = q.u0c << 24; q.v1m = q.v0c << 24; }
+    q.lv2 = pv[(size_t)(r + 1) * a.vs];                                     // PV(r + 1, 0): the reference's constant "last" sample
+    return q;
+  };
+  // sample j = -1 .. 4 of a chroma row held as [m.b3 | c.b0..b3 | p.b0]
+  auto at6 = [](uint32_t m, uint32_t cc, uint32_t pp, int j) -> uint32_t { return j < 0 ? (m >> 24) : j < 4 ? ((cc >> (8 * j)) & 0xFF) : (pp & 0xFF); };
+  // (2a + b) / 3 resp. (a + 2b) / 3 on doubled sums, clamped, as the byte offset of the 8-byte table entry: (int)(s / 3. + .5) == (s + 1) / 3
+  // -> LDS byte address of the 8-byte table entry (the clamp lives in the table, the copy and table offsets in cbase)
+  auto blend = [&](uint32_t s1, uint32_t s2, uint32_t cbase) -> uint32_t { return ((__umul24(s1 + (s2 >> 1) + 1u, 43691u) >> 17) << 7) + cbase; };
+  auto pixel = [&](uint32_t yv, uint32_t ua, uint32_t va) -> uint32_t {
+    const uint32_t yy = *(lds_u32)(uintptr_t)((yv << 6) + c4y);
+    const u32x2v rg = *(lds_u64)(uintptr_t)va, gb = *(lds_u64)(uintptr_t)ua;
+    const uint32_t sr = yy + rg.x, sg = yy + gb.x + rg.y, sb = yy + gb.y;
+    const uint32_t r_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sr >> 10) & 0xFFC0u) | c4));
+    const uint32_t g_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sg >> 10) & 0xFFC0u) | c4));
+    const uint32_t b_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sb >> 10) & 0xFFC0u) | c4));
+    // two byte permutes per pixel (selector 0x0C = 0x00, 0x0D = 0xFF: the alpha byte costs nothing)
+    if (ORDER == 0) return __builtin_amdgcn_perm(b_, __builtin_amdgcn_perm(g_, r_, 0x0C0C0400u), 0x0D040100u);
+    if (ORDER == 1) return __builtin_amdgcn_perm(r_, __builtin_amdgcn_perm(g_, b_, 0x0C0C0400u), 0x0D040100u);
+    return __builtin_amdgcn_perm(b_, __builtin_amdgcn_perm(g_, r_, 0x0C04000Du), 0x04020100u);
+  };
+  int ul = blockIdx.x * 4 + (tid >> 8), cg = tid & 255;
+  const int ustep = (int)gridDim.x * 4;
+  if (cg >= ncg) return;
+  Cell cur = fetch(ul, cg);
+  while (cur.valid) {
+    cg += 256;
+    if (cg >= ncg) { cg = tid & 255; ul += ustep; }
+    const Cell nxt = fetch(ul, cg);
+    if (!cur.fast) {
+      YuvArgs f = a;
+      f.y = bt.y[cur.z]; f.u = bt.u[cur.z]; f.v = bt.v[cur.z]; f.dst = bt.dst[cur.z];
+      for (int k = cur.k0; k < cur.k0 + 4 && k < hw; k++) yuv420_cell(f, c, cur.unit, k, hw, npairs);
+    } else {
+      const int i = 2 * cur.unit - 1;
+      uint32_t top[8], bot[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t u_rk = at6(0, cur.u0c, 0, j), v_rk = at6(0, cur.v0c, 0, j), v_r1k = at6(0, cur.v1c, 0, j);
+        const uint32_t yw0 = j < 2 ? cur.ya.x : cur.ya.y, yw1 = j < 2 ? cur.yb.x : cur.yb.y;
+        const uint32_t y00 = (yw0 >> (16 * (j & 1))) & 0xFF, y01 = (yw0 >> (16 * (j & 1) + 8)) & 0xFF;
+        const uint32_t y10 = (yw1 >> (16 * (j & 1))) & 0xFF, y11 = (yw1 >> (16 * (j & 1) + 8)) & 0xFF;
+        // left pixel: U row pair (s, s) -> top == bottom (:3461); V of row r with the previous V of row r + 1, the "last V" frozen at column 0 (:3544)
+        const uint32_t su = u_rk + at6(cur.u0m, cur.u0c, cur.u0p, j - 1);
+        const uint32_t uleft = blend(su, su, c8u);
+        const uint32_t s1v = v_rk + at6(cur.v1m, cur.v1c, cur.v1p, j - 1), s2v = v_r1k + cur.lv2;
+        top[2 * j] = pixel(y00, uleft, blend(s1v, s2v, c8v));
+        bot[2 * j] = pixel(y10, uleft, blend(s2v, s1v, c8v));
+        // right pixel
+        const uint32_t s1u = u_rk + at6(cur.u0m, cur.u0c, cur.u0p, j + 1), s2u = at6(0, cur.u1c, cur.u1p, j) + at6(0, cur.u1c, cur.u1p, j + 1);
+        const uint32_t s1w = v_rk + at6(0, cur.v0c, cur.v0p, j + 1), s2w = v_r1k + at6(cur.v1m, cur.v1c, cur.v1p, j + 1);
+        top[2 * j + 1] = pixel(y01, blend(s1u, s2u, c8u), blend(s1w, s2w, c8v));
+        bot[2 * j + 1] = pixel(y11, blend(s2u, s1u, c8u), blend(s2w, s1w, c8v));
+      }
+      uint8_t *dst = bt.dst[cur.z];
+      uint4 *d0 = reinterpret_cast<uint4 *>(dst + (size_t)i * a.orow + (size_t)(2 * cur.k0) * 4), *d1 = reinterpret_cast<uint4 *>(dst + (size_t)(i + 1) * a.orow + (size_t)(2 * cur.k0) * 4);
+      d0[0] = make_uint4(top[0], top[1], top[2], top[3]); d0[1] = make_uint4(top[4], top[5], top[6], top[7]);
+      d1[0] = make_uint4(bot[0], bot[1], bot[2], bot[3]); d1[1] = make_uint4(bot[4], bot[5], bot[6], bot[7]);
+    }
+    cur = nxt;
+  }
+}
+
 // 4:2:2 (:3593-3640 / :3858-3901): row i, pair k; "last/this" are seeded from chroma row i>>1 (reference)
 __global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut, YuvBatch bt, int batched) {
   if (batched) { a.y = bt.y[blockIdx.z]; a.u = bt.u[blockIdx.z]; a.v = bt.v[blockIdx.z]; a.dst = bt.dst[blockIdx.z]; }
@@ -287,7 +423,56 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   // one lane per four columns means a quarter of the lanes: only worth it when the launch still fills the device (a batch of tracks, or a
   // frame of 4K and up); a single 1080p frame keeps the one-column form (measured 13 vs 18 us)
   const dim3 g4x(cdiv((unsigned)((width >> 1) + 3) / 4, kBlock), grid.y, grid.z);
-  if (wide && (unsigned long long)g4x.x * g4x.y * g4x.z < 2048ull && !getenv("LGPU_YUV_WIDE")) wide = false;
+  if (wide && (unsigned long long)g4x.x * g4x.y * g4x.z < 2048ull && !getenv("LGPU_YUV_WIDE") && !getenv("LGPU_YUV_FORCE16")) wide = false;
+  // launches that fill the device take the 16-copy-table kernel (one 1024-thread workgroup per CU, 139 KB of tables each)
+  static const bool no16 = getenv("LGPU_YUV_NO16") != nullptr;
+  const bool force16 = getenv("LGPU_YUV_FORCE16") != nullptr;            // tests: the 16-copy kernel at any size
+  if (wide && !no16 && !lut16_d && !a.low_quality && (force16 || (unsigned long long)g4x.x * g4x.y * g4x.z * kBlock >= 256ull * 1024ull)) {
+    // the clamp + LUT table covers (sum >> 16) in [-kY16Bias, kY16Lut - kY16Bias): true for the reference's four table sets, checked here
+    static int range_ok[4] = {0, 0, 0, 0};          // 0 unknown, 1 ok, -1 no
+    const int w4 = which_tables & 3;
+    if (!range_ok[w4]) {
+      int32_t rgb2yuv[9 * 256], t5[5 * 256];
+      lgpu_conversion_tables(w4, rgb2yuv, t5);
+      long lo = 0, hi = 0;
+      for (int y = 0; y < 256; y++)
+        for (int cidx = 0; cidx < 256; cidx++) {
+          const long yy = t5[y];
+          const long s[4] = {yy + t5[256 + cidx], yy + t5[1024 + cidx], yy + t5[512 + cidx] + t5[768], yy + t5[512 + cidx] + t5[768 + 255]};
+          for (long v : s) { if ((v >> 16) < lo) lo = v >> 16; if ((v >> 16) > hi) hi = v >> 16; }
+        }
+      long gmin = 0, gmax = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+      for (int cidx = 0; cidx < 256; cidx++) {
+        if (t5[512 + cidx] < a2) a2 = t5[512 + cidx];
+        if (t5[512 + cidx] > b2) b2 = t5[512 + cidx];
+        if (t5[768 + cidx] < a3) a3 = t5[768 + cidx];
+        if (t5[768 + cidx] > b3) b3 = t5[768 + cidx];
+      }
+      gmin = (a2 + a3) >> 16; gmax = ((long)t5[255] + b2 + b3) >> 16;
+      if (gmin < lo) lo = gmin;
+      if (gmax > hi) hi = gmax;
+      range_ok[w4] = (lo >= -kY16Bias && hi < kY16Lut - kY16Bias) ? 1 : -1;
+    }
+    if (range_ok[w4] == 1) {
+      static int g_cus = 0;
+      if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
+      YuvBatch one = {};
+      if (!batch) { one.y[0] = y_d; one.u[0] = u_d; one.v[0] = v_d; one.dst[0] = dst_d; }
+      const YuvBatch &b16 = batch ? *batch : one;
+      const int total = units * nbatch;
+      int g16 = (total + 3) / 4;
+      if (g16 > g_cus) g16 = g_cus;
+#define Y16_LAUNCH(ORDER_)                                                                                                             \
+      do {                                                                                                                             \
+        LGPU_HIP(hipFuncSetAttribute((const void *)k_yuv420p_to_rgb16<ORDER_>, hipFuncAttributeMaxDynamicSharedMemorySize, kY16Lds));  \
+        hipLaunchKernelGGL((k_yuv420p_to_rgb16<ORDER_>), dim3((unsigned)g16), dim3(1024), kY16Lds, (hipStream_t)stream, a, l, b16, nbatch); \
+      } while (0)
+      if (out_order == 0) Y16_LAUNCH(0); else if (out_order == 1) Y16_LAUNCH(1); else Y16_LAUNCH(2);
+#undef Y16_LAUNCH
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
   if (is_422) hipLaunchKernelGGL(k_yuv422p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
   else if (wide) {
     const dim3 g4(cdiv((unsigned)((width >> 1) + 3) / 4, kBlock), grid.y, grid.z);

@@ -817,6 +817,60 @@ def test_yuv420p_four_column_kernel(gpu, orc, monkeypatch):
                 assert_same(host(d), want, w, h, 4, "yuv420p wide %dx%d which=%d q=%d" % (w, h, which, quality))
 
 
+def test_yuv420p_sixteen_copy_table_kernel(gpu, orc, monkeypatch):
+    """k_yuv420p_to_rgb16 (what batches of tracks and 4K frames take: tables in 16 interleaved LDS copies, clamp + LUT as one table,
+    8-byte chroma entries) forced on small frames: same bytes as the oracle for the four table sets, the three byte orders, with and
+    without the gamma LUT, unaligned plane ends, and for a batch of frames in one launch"""
+    monkeypatch.setenv("LGPU_YUV_FORCE16", "1")
+    rng = np.random.default_rng(3450)
+    for which in range(4):
+        for order in (0, 1, 2):
+            for use_lut in (0, 1):
+                for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 19, 160, 80), (24, 6, 32, 16), (640, 480, 640, 320), (1920, 64, 1920, 960)]:
+                    lut = lut_for(rng, "l2s") if use_lut else None
+                    Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
+                    U = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
+                    V = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
+                    orow = align(w * 4)
+                    strides = (ctypes.c_int * 3)(ys, cs, cs)
+                    want = np.full((h, orow), 0xAB, np.uint8)
+                    orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, order, 0, which, 2, P(lut) if use_lut else None, 0)
+                    d = dev(np.full_like(want, 0xAB))
+                    gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, out_order=order, which_tables=which, pb_quality=2, lut=lut)
+                    assert_same(host(d), want, w, h, 4, "yuv420p 16-copy %dx%d which=%d order=%d lut=%d" % (w, h, which, order, use_lut))
+    # extreme samples: every (y, u, v) corner reaches the ends of the clamp + LUT table
+    w, h = 64, 32
+    for which in range(4):
+        for yv in (0, 16, 235, 255):
+            for uv in (0, 16, 128, 240, 255):
+                Y = np.full((h, w), yv, np.uint8)
+                U = np.full((h // 2, w // 2), uv, np.uint8)
+                V = np.full((h // 2, w // 2), 255 - uv if uv not in (0, 255) else uv, np.uint8)
+                strides = (ctypes.c_int * 3)(w, w // 2, w // 2)
+                want = np.zeros((h, w * 4), np.uint8)
+                orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), w * 4, w, h, 4, 0, 0, which, 2, None, 0)
+                d = dev(np.zeros_like(want))
+                gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, which_tables=which)
+                assert_same(host(d), want, w, h, 4, "corner y=%d u=%d which=%d" % (yv, uv, which))
+    # a batch in one launch == the same frames one by one through the one-column kernel
+    import torch
+    w, h, n = 256, 96, 5
+    lut = lut_for(rng, "l2s")
+    frames = []
+    for _ in range(n):
+        Y = dev(rng.integers(0, 256, (h, w), dtype=np.uint8))
+        U = dev(rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8))
+        V = dev(rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8))
+        frames.append((Y, U, V, torch.zeros((h, w * 4), dtype=torch.uint8, device="cuda")))
+    gpu.yuv420p_to_rgb_batch(frames, w, h, lut=lut)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("LGPU_YUV_FORCE16")             # frames of this size take the one-column kernel on their own
+    for (Y, U, V, d) in frames:
+        one = torch.zeros_like(d)
+        gpu.yuv420p_to_rgb(Y, U, V, one, w, h, lut=lut)
+        assert torch.equal(one, d)
+
+
 def test_yuv420p_batch_equals_single_calls(gpu):
     import torch
     rng = np.random.default_rng(3300)
