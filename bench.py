@@ -7,7 +7,9 @@ A "step" is one pass of the headline chain over one batch of synthetic tracks re
 one fused launch of liblivesgpu.so's lgpu_chain() per step, TRACKS_PER_GPU independent tracks per launch.
 Multi-GPU: one process per GPU (torch.distributed / RCCL), tracks sharded track-per-rank with no data-path
 collective; the shared transition parameter block (blend amount) is broadcast from rank 0 over RCCL every
-step and read by the kernel from device memory.  Weak scaling: per-GPU work is fixed.
+step (lgpu_params_broadcast, the library's C entry point, on its own communicator) and read by the kernel from
+device memory.  Weak scaling: per-GPU work is fixed.  `--tracks 1` is BASELINE config 5's shape
+(one 4K frame per GPU per step); the default keeps 16 tracks per GPU so that one step exceeds the Infinity Cache.
 
 Before the W warm-up steps the device is woken up with ~60 ms of the same launch (clock / power ramp; not part of the
 schedule).  Prints ONE JSON line on rank 0 (contract in the task statement), including
@@ -84,7 +86,10 @@ def main():
 
     sched_base = schedule.data_ptr()
 
-    pipe = ld.ParamPipeline("cuda")
+    # N > 1: the library's own RCCL communicator (lgpu_dist_comm_create; torch.distributed only carries its 128-byte id) and the C entry
+    # point lgpu_params_broadcast for the per-step exchange, on a side stream, double buffered
+    comm = ld.RcclComm("cuda") if world > 1 else None
+    pipe = ld.ParamPipeline("cuda", comm=comm)
     nsched = args.steps + args.warmup
     if world > 1:
         pipe.prefetch(0, schedule[0] if rank == 0 else None)
@@ -157,6 +162,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.blur)
     if world > 1:
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

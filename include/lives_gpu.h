@@ -327,6 +327,23 @@ int lgpu_chain(const lgpu_chain_params *params, const lgpu_chain_track *tracks, 
 int lgpu_chain_timed(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks,
                      int reps, float *ms_total, void *stream);
 
+/* ---- multi-GPU exchange: one process per GPU, tracks sharded track t -> rank t % world, no data-path collective.  What the
+   ranks exchange goes over RCCL (xGMI), bound at run time (dlopen of librccl.so.1: no link-time dependency, a single-GPU host never loads
+   it).  The communicator is RCCL's own: rank 0 makes the id, the host ships its 128 bytes to the other ranks by whatever channel it has,
+   every rank calls lgpu_dist_comm_create.  All calls below are stream ordered and never synchronise the host. */
+#define LGPU_DIST_ID_BYTES 128
+int lgpu_dist_bind(const char *rccl_path);                                  /* optional: an explicit library path (NULL: the process's copy, then the system's) */
+int lgpu_dist_unique_id(uint8_t id[LGPU_DIST_ID_BYTES]);                    /* ncclGetUniqueId */
+int lgpu_dist_comm_create(const uint8_t id[LGPU_DIST_ID_BYTES], int rank, int world, void **comm);   /* ncclCommInitRank on the current device */
+int lgpu_dist_comm_destroy(void *comm);
+/* the shared transition parameter block (lgpu_chain_params.param_block_d: int32[4] in device memory) from `root` to every rank, in place */
+int lgpu_params_broadcast(void *comm, int root, int32_t *param_block_d, void *stream);
+/* max of a device status word over the ranks: the optional completion / error barrier */
+int lgpu_status_allreduce(void *comm, int32_t *status_d, void *stream);
+/* compositing fan-in: each rank's processed frames (nlocal = its share of ntracks, frame_bytes each, contiguous) to `root`, which gets the
+   ntracks frames in track order in gathered_d; point-to-point sends inside one RCCL group */
+int lgpu_fan_in(void *comm, int root, int rank, int world, int ntracks, const uint8_t *frames_d, size_t frame_bytes, uint8_t *gathered_d, void *stream);
+
 /* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),
    :167-189 (background, z order), :288-293 (paint loop).  One kernel: every output pixel starts from bgcol (R,G,B;
    alpha byte 0xFF) and takes the layers that cover it in paint order -- revz == 0: the last layer first, so layer 0 ends

@@ -14,12 +14,12 @@ for f in runtime swizzle yuv effects resize stencil palette; do
     pids+=($!)
   fi
 done
-for f in host_tables layer_seam; do
+for f in host_tables layer_seam dist; do
   if [ -f $f.cpp ] && { [ ! -f $OBJ/$f.o ] || [ $f.cpp -nt $OBJ/$f.o ] || [ ../../include/lives_gpu.h -nt $OBJ/$f.o ]; }; then
     g++ -O2 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wall -c $f.cpp -o $OBJ/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblivesgpu.so $OBJ/*.o -Wl,-soname,liblivesgpu.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblivesgpu.so $OBJ/*.o -ldl -Wl,-soname,liblivesgpu.so
 echo "built $(cd .. && pwd)/liblivesgpu.so"

@@ -61,6 +61,13 @@ PROTOTYPES = {
     "lgpu_copy": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_fill": [vp, ci, ctypes.c_size_t, vp],
     "lgpu_sync": [vp],
+    "lgpu_dist_bind": [ctypes.c_char_p],
+    "lgpu_dist_unique_id": [vp],
+    "lgpu_dist_comm_create": [vp, ci, ci, ctypes.POINTER(vp)],
+    "lgpu_dist_comm_destroy": [vp],
+    "lgpu_params_broadcast": [vp, ci, vp, vp],
+    "lgpu_status_allreduce": [vp, vp, vp],
+    "lgpu_fan_in": [vp, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp],
     "lgpu_copy_rows": [vp, ci, vp, ci, ci, ci, vp],
     "lgpu_fill_pattern": [vp, ci, vp, ci, ci, ci, vp],
     "lgpu_conversion_tables": [ci, vp, vp],

@@ -1095,3 +1095,41 @@ def test_pinned_allocator_and_pageable_staging(gpu):
         assert (d.cpu().numpy() == src[::-1]).all()
         del buf
         L.lgpu_pinned_free(p)
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU C entry points
+def test_rccl_entry_points_on_a_one_rank_communicator(gpu):
+    """include/lives_gpu.h "multi-GPU exchange": RCCL bound at run time, a communicator from the 128-byte id, the parameter block
+    broadcast in place, the status max and the compositing fan-in -- on the one GPU of this box as a world of one rank (the
+    two-rank protocol is covered over gloo in tests/test_dist_cpu.py; N > 1 runs on the driver's 8-GPU node through bench.py)"""
+    import torch
+    from lives_amd import dist as ld
+    comm = ld.RcclComm("cuda")
+    assert (comm.rank, comm.world) == (0, 1)
+    blk = torch.tensor([107, 1, 2, 3], dtype=torch.int32, device="cuda")
+    comm.broadcast_params(blk)
+    st = torch.tensor([5], dtype=torch.int32, device="cuda")
+    comm.status_max(st)
+    frames = torch.arange(3 * 64, dtype=torch.int32, device="cuda").to(torch.uint8).reshape(3, 64).contiguous()
+    out = torch.zeros((3, 64), dtype=torch.uint8, device="cuda")
+    comm.fan_in(frames, 3, 64, out)
+    torch.cuda.synchronize()
+    assert blk.tolist() == [107, 1, 2, 3] and st.item() == 5 and torch.equal(out, frames)
+    # the pipelined parameter block on the C path drives the kernel: same frames as the kernel-argument amount
+    rng = np.random.default_rng(6100)
+    sw, sh, dw, dh = 256, 144, 128, 72
+    src, l2 = dev(frame(rng, sw, sh, 4)), dev(frame(rng, dw, dh, 4, alpha_mix=True))
+    pipe = ld.ParamPipeline("cuda", comm=comm)
+    pipe.prefetch(0, [41, 0])
+    for s in range(4):
+        b = pipe.acquire(s)
+        if s + 1 < 4:
+            pipe.prefetch(s + 1, [41 + 50 * (s + 1), 0])
+        d1, d2 = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda"), torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda")
+        prm = gpu.chain_params(sw, sh, src.stride(0), dw, dh, l2.stride(0), dw * 4, bf=13, param_block=b)
+        gpu.chain(prm, gpu.chain_tracks([src], [l2], [d1]))
+        prm2 = gpu.chain_params(sw, sh, src.stride(0), dw, dh, l2.stride(0), dw * 4, bf=41 + 50 * s)
+        gpu.chain(prm2, gpu.chain_tracks([src], [l2], [d2]))
+        torch.cuda.synchronize()
+        assert torch.equal(d1, d2), s
+    comm.close()
