@@ -43,6 +43,10 @@ struct SepArgs {
   int use_lut;
   int vec;                          // source rows are 16-byte aligned: stage with 16-byte loads
   int tiles_x, tiles_y;
+  // k_sep2: taps as packed int16 pairs.  hco2[dst][nph] = (tap 2j, tap 2j+1); vco2[dst][npv] = the row's taps laid over EVEN-aligned
+  // source row pairs: (v0, v1), (v2, v3) ... when vpos is even, (0, v0), (v1, v2) ... when it is odd
+  const uint32_t *hco2, *vco2;
+  int nph, npv;
 };
 struct SepTracks {
   const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
@@ -254,6 +258,151 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
   }
 }
 
+
+// k_sep2: the same separable filter for RGBA32 with both passes on v_dot2_i32_i16 (two multiply-adds per operation):
+//   horizontal: per window row pair and tap pair, one v_perm per channel builds (pixel j, pixel j+1) as two 16-bit lanes, one dot2 against the
+//               packed tap pair accumulates them: one VALU operation per multiply-add (k_separable: byte extract + v_mad = two), and the rounding
+//               rides in the accumulator seed; v_cvt_pk_i16_i32 clamps and packs two rows' results;
+//   vertical  : the intermediate is stored as EVEN-aligned row pairs (one uint4 = 4 channels x 2 rows per column), the taps of an output row
+//               arrive packed over such pairs (vco2), so a row pair costs four dot2 = half an operation per multiply-add.
+// Same arithmetic as the oracle's orc_resize (bit-identical; the tests run every path against it).  Measured on the ratios k_half8s does not
+// take: profiles/r02/resize_ratios.md.
+template <int NPH>
+__global__ __launch_bounds__(kBlock) void k_sep2(SepArgs a, SepTracks trk, Lut8 lut) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t *s_src = reinterpret_cast<uint32_t *>(smem);                               // [sht][swt]
+  uint4 *s_p = reinterpret_cast<uint4 *>(smem + (size_t)a.sht * a.swt * 4);           // [sht / 2][64]: 4 channels x (row 2k, row 2k+1) int16
+  uint8_t *s_lut = smem + (size_t)a.sht * a.swt * 4 + (size_t)(a.sht >> 1) * kTileW * 16;
+  uint32_t *s_vc = reinterpret_cast<uint32_t *>(s_lut + 256);                           // [th][npv + 1]: first row pair, then the packed taps of the row
+
+  const int tile = blockIdx.x, track = blockIdx.y;
+  const int tx0 = (tile % a.tiles_x) * kTileW, ty0 = (tile / a.tiles_x) * a.th;
+  const int tw = min(kTileW, a.dw - tx0), thh = min(a.th, a.dh - ty0);
+  const uint8_t *src = trk.src[track];
+  // the vertical taps of this tile's rows go to LDS once (a scalar load per tap inside the row loop costs its latency per row)
+  for (int i = threadIdx.x; i < thh * (a.npv + 1); i += kBlock) {
+    const int ly = i / (a.npv + 1), j = i - ly * (a.npv + 1);
+    s_vc[i] = j ? a.vco2[(size_t)(ty0 + ly) * a.npv + (j - 1)] : (uint32_t)(a.vpos[ty0 + ly] >> 1);
+  }
+  const int sx0 = a.hpos[tx0], sx1 = a.hpos[tx0 + tw - 1] + 2 * NPH;       // padded taps read one pixel further
+  const int sy0 = a.vpos[ty0] & ~1, sy1 = a.vpos[ty0 + thh - 1] + a.ntv;   // window rows start on an even source row
+  const int wrows = (sy1 - sy0 + 1) & ~1, npairs = wrows >> 1;
+  if (a.use_lut) stage_lut(s_lut, lut);
+  uint32_t bf = a.bf, nbf = a.nbf;
+  if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
+
+  // ---- 1. stage the window (edge replicate), byte swap on the fly: as k_separable ----
+  const int sx0a = sx0 & ~3;
+  const int wchunks = (sx1 - sx0a + 3) >> 2;
+  const int nitems = wrows * wchunks;
+  if (a.vec) {
+    for (int base = 0; base < nitems; base += kStageMax * kBlock) {
+      uint4 v[kStageMax];
+#pragma unroll
+      for (int k = 0; k < kStageMax; k++) {
+        const int it = base + threadIdx.x + k * kBlock;
+        if (it < nitems) {
+          const int r = it / wchunks, ch = it - r * wchunks;
+          int sy = sy0 + r;
+          sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
+          const uint8_t *srow = src + (size_t)sy * a.irow;
+          const int x = sx0a + ch * 4;
+          if (x >= 0 && x + 4 <= a.sw) v[k] = *reinterpret_cast<const uint4 *>(srow + (size_t)x * 4);
+          else {
+            const uint32_t *sp = reinterpret_cast<const uint32_t *>(srow);
+            const int m = a.sw - 1;
+            v[k] = make_uint4(sp[min(max(x, 0), m)], sp[min(max(x + 1, 0), m)], sp[min(max(x + 2, 0), m)], sp[min(max(x + 3, 0), m)]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kStageMax; k++) {
+        const int it = base + threadIdx.x + k * kBlock;
+        if (it < nitems) {
+          const int r = it / wchunks, ch = it - r * wchunks;
+          uint4 o;
+          o.x = __builtin_amdgcn_perm(0u, v[k].x, a.src_sel); o.y = __builtin_amdgcn_perm(0u, v[k].y, a.src_sel);
+          o.z = __builtin_amdgcn_perm(0u, v[k].z, a.src_sel); o.w = __builtin_amdgcn_perm(0u, v[k].w, a.src_sel);
+          *reinterpret_cast<uint4 *>(s_src + r * a.swt + ch * 4) = o;
+        }
+      }
+    }
+  } else {
+    for (int r = threadIdx.x >> 6; r < wrows; r += kBlock >> 6) {
+      int sy = sy0 + r;
+      sy = sy < 0 ? 0 : sy >= a.sh ? a.sh - 1 : sy;
+      const uint32_t *srow = reinterpret_cast<const uint32_t *>(src + (size_t)sy * a.irow);
+      for (int c = threadIdx.x & 63; c < wchunks * 4; c += 64) {
+        int sx = sx0a + c;
+        sx = sx < 0 ? 0 : sx >= a.sw ? a.sw - 1 : sx;
+        s_src[r * a.swt + c] = __builtin_amdgcn_perm(0u, srow[sx], a.src_sel);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. horizontal pass: lane = output column, a wave takes window row pairs ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ox = tx0 + (lane < tw ? lane : tw - 1);
+  const int hoff = a.hpos[ox] - sx0a;
+  short2v hc2[NPH];
+#pragma unroll
+  for (int j = 0; j < NPH; j++) hc2[j] = __builtin_bit_cast(short2v, a.hco2[(size_t)ox * NPH + j]);
+  for (int k = wave; k < npairs; k += kBlock >> 6) {
+    const uint32_t *r0 = s_src + (2 * k) * a.swt + hoff, *r1 = r0 + a.swt;
+    int e0 = a.hround, e1 = a.hround, e2 = a.hround, e3 = a.hround, o0 = a.hround, o1 = a.hround, o2 = a.hround, o3 = a.hround;
+#pragma unroll
+    for (int j = 0; j < NPH; j++) {
+      const uint32_t p0 = r0[2 * j], p1 = r0[2 * j + 1], q0 = r1[2 * j], q1 = r1[2 * j + 1];
+      // (pixel 2j, pixel 2j+1) of one channel as two 16-bit lanes: selector bytes [c, 0, 4 + c, 0]
+      e0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, 0x0C040C00u)), hc2[j], e0, false);
+      e1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, 0x0C050C01u)), hc2[j], e1, false);
+      e2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, 0x0C060C02u)), hc2[j], e2, false);
+      e3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, 0x0C070C03u)), hc2[j], e3, false);
+      o0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, 0x0C040C00u)), hc2[j], o0, false);
+      o1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, 0x0C050C01u)), hc2[j], o1, false);
+      o2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, 0x0C060C02u)), hc2[j], o2, false);
+      o3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, 0x0C070C03u)), hc2[j], o3, false);
+    }
+    // clamp_i16(acc >> hshift) of (even row, odd row) packed by one v_cvt_pk_i16_i32 per channel
+    uint4 pk;
+    pk.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e0 >> a.hshift, o0 >> a.hshift));
+    pk.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e1 >> a.hshift, o1 >> a.hshift));
+    pk.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e2 >> a.hshift, o2 >> a.hshift));
+    pk.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e3 >> a.hshift, o3 >> a.hshift));
+    s_p[k * kTileW + lane] = pk;
+  }
+  __syncthreads();
+
+  // ---- 3. vertical pass + epilogue: wave = output row, lane = output column ----
+  uint8_t *dst = trk.dst[track];
+  const uint8_t *l2 = trk.l2[track];
+  for (int ly = wave; ly < thh; ly += kBlock >> 6) {
+    const int oy = ty0 + ly;
+    const uint32_t *vc2 = s_vc + ly * (a.npv + 1);                  // LDS, the same address for every lane (broadcast)
+    const int kp = (int)vc2[0] - (sy0 >> 1);                        // first row pair
+    int acc0 = a.vround, acc1 = a.vround, acc2 = a.vround, acc3 = a.vround;
+    const uint4 *col = s_p + kp * kTileW + lane;
+    for (int j = 0; j < a.npv; j++) {
+      const uint4 t = col[j * kTileW];
+      const short2v cf = __builtin_bit_cast(short2v, vc2[1 + j]);
+      acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, t.x), cf, acc0, false);
+      acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, t.y), cf, acc1, false);
+      acc2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, t.z), cf, acc2, false);
+      acc3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, t.w), cf, acc3, false);
+    }
+    if (lane < tw) {
+      uint32_t p = (uint32_t)clamp255(acc0 >> a.vshift) | ((uint32_t)clamp255(acc1 >> a.vshift) << 8) |
+                   ((uint32_t)clamp255(acc2 >> a.vshift) << 16) | ((uint32_t)clamp255(acc3 >> a.vshift) << 24);
+      if (a.blend) {
+        const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[tx0 + lane];
+        p = chroma_rgba(p, q, bf, nbf);
+      }
+      if (a.use_lut) p = lut3_rgba(s_lut, p);
+      reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[tx0 + lane] = p;
+    }
+  }
+}
 
 // =====================================================================================================================
 // k_gauss5x -- 5x5 binomial blur of RGBA32 frames (the chain's blur stage, BASELINE config 4/5, and lgpu_gauss5).
@@ -1010,6 +1159,8 @@ struct Bank {
   std::vector<int32_t> hpos;
   std::vector<int16_t> hco;         // host copy of the taps
   int uniform2 = 0;                 // exact 2:1, 8 identical taps per output, pos[i] = 2i - 3, taps fit 64*int8 + 6 bits
+  uint32_t *co2h = nullptr, *co2v = nullptr;   // k_sep2: taps as packed pairs, [dst][nph] resp. [dst][npv] (see SepArgs)
+  int nph = 0, npv = 0;
 };
 static std::mutex g_bank_mu;
 static std::map<std::tuple<int, int, int, int>, Bank> g_banks;   // (device, srcn, dstn, kernel)  kernel 100 = gauss5
@@ -1045,6 +1196,24 @@ static int get_bank(int srcn, int dstn, int kernel, const Bank **out) {
           if (c != co[j] || (c >> 6) < -128 || (c >> 6) > 127) b.uniform2 = 0;
         }
       }
+    }
+    {
+      b.nph = (b.nt + 1) / 2; b.npv = b.nt / 2 + 1;
+      std::vector<uint32_t> h2((size_t)dstn * b.nph), v2((size_t)dstn * b.npv);
+      auto pk = [](int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); };
+      for (int i = 0; i < dstn; i++) {
+        const int16_t *c = co.data() + (size_t)i * b.nt;
+        for (int j = 0; j < b.nph; j++) h2[(size_t)i * b.nph + j] = pk(c[2 * j], 2 * j + 1 < b.nt ? c[2 * j + 1] : 0);
+        const int odd = b.hpos[i] & 1;                                  // first tap on the second row of its (even-aligned) pair
+        for (int j = 0; j < b.npv; j++) {
+          const int t0 = 2 * j - odd, t1 = t0 + 1;
+          v2[(size_t)i * b.npv + j] = pk(t0 >= 0 && t0 < b.nt ? c[t0] : 0, t1 >= 0 && t1 < b.nt ? c[t1] : 0);
+        }
+      }
+      LGPU_HIP(hipMalloc((void **)&b.co2h, sizeof(uint32_t) * h2.size()));
+      LGPU_HIP(hipMalloc((void **)&b.co2v, sizeof(uint32_t) * v2.size()));
+      LGPU_HIP(hipMemcpy(b.co2h, h2.data(), sizeof(uint32_t) * h2.size(), hipMemcpyHostToDevice));
+      LGPU_HIP(hipMemcpy(b.co2v, v2.data(), sizeof(uint32_t) * v2.size(), hipMemcpyHostToDevice));
     }
     LGPU_HIP(hipMalloc((void **)&b.pos, sizeof(int32_t) * dstn));
     LGPU_HIP(hipMalloc((void **)&b.co, sizeof(int16_t) * co.size()));
@@ -1245,6 +1414,45 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
   p->grid = dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)ntracks, 1);
   p->variant = (a.nth == 8 && a.ntv == 8) ? 1 : (a.nth == 5 && a.ntv == 5) ? 2 : (a.nth == 4 && a.ntv == 4) ? 3 :
                (a.nth == 2 && a.ntv == 2) ? 4 : (a.nth == 6 && a.ntv == 6) ? 5 : 0;
+  // k_sep2 (dot2 on both passes): tap pair counts with an instantiation, windows that leave two workgroups per CU
+  static const bool no_sep2 = getenv("LGPU_NO_SEP2") != nullptr;
+  const int nph = hb->nph;
+  if (!no_sep2 && (nph == 1 || nph == 2 || nph == 3 || nph == 4 || nph == 6 || nph == 8 || nph == 12) && vb->nt <= 64) {
+    SepArgs b = a;
+    b.hco2 = hb->co2h; b.vco2 = vb->co2v; b.nph = nph; b.npv = vb->npv;
+    // the padded last tap pair reads one pixel further, rows come in even-aligned pairs
+    int swt2 = 0;
+    for (int t0 = 0; t0 < dw; t0 += kTileW) {
+      const int t1 = (t0 + kTileW < dw ? t0 + kTileW : dw) - 1;
+      const int span = hb->hpos[t1] + 2 * nph - (hb->hpos[t0] & ~3);
+      if (span > swt2) swt2 = span;
+    }
+    b.swt = (swt2 + 3) & ~3;
+    // tile height: 16 rows, 32 when enlarging (small windows: taller tiles amortise a workgroup's three phases; measured 29.8 against 33.9 us for
+    // 1080p -> 4K, profiles/r02/resize_ratios.md)
+    for (int th2 = dh > sh ? 32 : 16;; th2 >>= 1) {
+      int sht2 = 0;
+      for (int t0 = 0; t0 < dh; t0 += th2) {
+        const int t1 = (t0 + th2 < dh ? t0 + th2 : dh) - 1;
+        const int span = ((vb->hpos[t1] + vb->nt - (vb->hpos[t0] & ~1)) + 1) & ~1;
+        if (span > sht2) sht2 = span;
+      }
+      // the parity-shifted tap layout may touch one row pair past the last tap
+      sht2 += 2;
+      const size_t lds2 = (size_t)sht2 * b.swt * 4 + (size_t)(sht2 >> 1) * kTileW * 16 + 256 + (size_t)th2 * (vb->npv + 1) * 4;
+      if (lds2 <= 80 * 1024 || th2 == 1) {
+        if (lds2 <= 160 * 1024) {
+          b.th = th2; b.sht = sht2;
+          b.tiles_y = (dh + th2 - 1) / th2;
+          a = b;
+          p->lds = lds2;
+          p->grid = dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)ntracks, 1);
+          p->variant = 100 + nph;
+        }
+        break;
+      }
+    }
+  }
   return LGPU_OK;
 }
 
@@ -1256,7 +1464,20 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
       LGPU_HIP(hipFuncSetAttribute((const void *)k_separable<H, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
     hipLaunchKernelGGL((k_separable<H, V>), p.grid, blk, p.lds, st, p.a, t, l);                              \
   } while (0)
+#define SEP2_LAUNCH(N)                                                                                       \
+  do {                                                                                                       \
+    if (p.lds > 48 * 1024)                                                                                   \
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
+    hipLaunchKernelGGL((k_sep2<N>), p.grid, blk, p.lds, st, p.a, t, l);                                      \
+  } while (0)
   switch (p.variant) {
+  case 101: SEP2_LAUNCH(1); break;
+  case 102: SEP2_LAUNCH(2); break;
+  case 103: SEP2_LAUNCH(3); break;
+  case 104: SEP2_LAUNCH(4); break;
+  case 106: SEP2_LAUNCH(6); break;
+  case 108: SEP2_LAUNCH(8); break;
+  case 112: SEP2_LAUNCH(12); break;
   case 1: SEP_LAUNCH(8, 8); break;
   case 2: SEP_LAUNCH(5, 5); break;
   case 3: SEP_LAUNCH(4, 4); break;
@@ -1265,6 +1486,7 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
   default: SEP_LAUNCH(0, 0); break;
   }
 #undef SEP_LAUNCH
+#undef SEP2_LAUNCH
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""tools/bench_resize.py -- lgpu_resize on the ratios the headline kernel does not cover (everything but the exact 2:1 bicubic case), RGBA32,
+HIP events around back-to-back launches on rotating buffers; algorithmic bytes = source read + destination written."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch   # noqa: E402
+from lives_amd import ops   # noqa: E402
+
+CASES = [("3840x2160 -> 1280x720 bicubic", 3840, 2160, 1280, 720, 3), ("1920x1080 -> 3840x2160 lanczos (BEST, enlarging)", 1920, 1080, 3840, 2160, 3),
+         ("3840x2160 -> 1920x1080 bicubic (k_half8s)", 3840, 2160, 1920, 1080, 3), ("3840x2160 -> 1706x960 bicubic (letterbox inner size)", 3840, 2160, 1706, 960, 3),
+         ("1920x1080 -> 1280x720 bicubic", 1920, 1080, 1280, 720, 3), ("3840x2160 -> 1920x1080 bilinear", 3840, 2160, 1920, 1080, 2)]
+
+
+def main():
+    ops.init(0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    reps, nb = 30, 6
+    for name, sw, sh, dw, dh, interp in CASES:
+        srcs = [torch.randint(0, 256, (sh, sw * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(nb)]
+        dsts = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        for i in range(3):
+            ops.resize(srcs[i], dsts[i], sw, sh, dw, dh, psize=4, interp=interp)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            ops.resize(srcs[i % nb], dsts[i % nb], sw, sh, dw, dh, psize=4, interp=interp)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        ab = sw * sh * 4 + dw * dh * 4
+        print(json.dumps({"op": name, "us": round(us, 2), "algorithmic_bytes": ab, "GBs": round(ab / us / 1e3, 1), "frac_of_8TBs": round(ab / us / 1e3 / 8000, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
