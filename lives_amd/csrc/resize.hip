@@ -62,6 +62,7 @@ __device__ __forceinline__ uint32_t mix4b(uint32_t a, uint32_t b, uint32_t bf, u
   return mix_pairs2(a & 0x00FF00FFu, b & 0x00FF00FFu, bf, nbf) | (mix_pairs2((a >> 8) & 0x00FF00FFu, (b >> 8) & 0x00FF00FFu, bf, nbf) << 8);
 }
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
 // clamp_u8(v >> 21) of four accumulators packed into one pixel: high halves (>> 16) paired by a byte permute, packed
 // arithmetic >> 5, v_sat_pk_u8_i16 (signed 16 -> unsigned 8 saturation of both halves), one permute to join
 __device__ __forceinline__ uint32_t pack_sat_shr21(int a0, int a1, int a2, int a3) {
@@ -419,6 +420,7 @@ struct G5Args {
   uint32_t bf, nbf;
   const int32_t *bf_d;
   int tiles_x;
+  const uint2 *kscale;      // device [256] {K2, K1}: lgpu_alpha_scalers (the chroma blend's translucent scaling as integers)
 };
 constexpr int kG5W = 64, kG5H = 16, kG5WW = kG5W + 4, kG5WH = kG5H + 4;
 constexpr int kG5Sub = 4;          // sub-tiles (of kG5H rows) a workgroup walks down, prefetching the next window in registers
@@ -427,15 +429,22 @@ __device__ __forceinline__ uint32_t g5_sum(uint32_t a, uint32_t b, uint32_t c, u
   return a + e + ((b + d) << 2) + (c << 2) + (c << 1);   // 32-bit SWAR operands: no 24-bit multiply
 }
 
-template <bool EPI>   // EPI: chroma blend with layer 2 and / or the gamma LUT after the blur (the chain); false = plain blur
+// MH (measurement variant, LGPU_G5_MFMA=1): the horizontal pass as a banded-Toeplitz product on the matrix cores, the form BASELINE config 4
+// names ("MFMA row/col").  The window is kept as packed pixels biased to int8; A = 16 window rows x 16 pixels (one ds_read_b128 per lane),
+// B[k = (pixel, byte)][n = (column, channel)] = {1 4 6 4 1}[pixel - column] on matching channels; 16 source pixels give 12 output columns
+// = three v_mfma_i32_16x16x64_i8 per A fragment, six fragments per 64 columns, two row blocks (rows 0..15 and 4..19) per 20-row window:
+// 36 MFMAs per tile.  Every D register is one channel of one column: it is un-biased (+ 16 * 128) and written as a 16-bit lane of the
+// SWAR layout the vertical pass reads.  Same bytes as the SWAR pass; the timing is in profiles/r02/gauss5_mfma.md.
+constexpr int kG5MPitch = 76 * 4;        // bytes per window row of the MFMA variant: 6 fragments x 12 pixels + 4
+template <bool EPI, bool MH = false>   // EPI: chroma blend with layer 2 and / or the gamma LUT after the blur (the chain); false = plain blur
 __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) {
-  __shared__ uint4 s_win4[kG5WH * kG5WW / 2];
+  __shared__ uint4 s_win4[MH ? (kG5WH * kG5MPitch + 64) / 16 : kG5WH * kG5WW / 2];
   __shared__ uint2 s_h[kG5WH * kG5W];
   __shared__ uint8_t s_lut[256];
-  __shared__ float s_alpha[EPI ? 256 : 1];
+  __shared__ uint2 s_k[EPI ? 256 : 1];
   uint2 *s_win = reinterpret_cast<uint2 *>(s_win4);
   const int tid = threadIdx.x, trk = blockIdx.y;
-  if (EPI && a.blend) s_alpha[tid] = (float)((double)(float)tid / 255.);     // simple_blend.c:137 (the first barrier below publishes it)
+  if (EPI && a.blend) s_k[tid] = a.kscale[tid];          // simple_blend.c:137-145 as (c * K) >> 16 (the first barrier below publishes it)
   const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
   const int tx0 = tx * kG5W, ty00 = ty * (kG5H * kG5Sub);
   const int nsub = min(kG5Sub, (a.h - ty00 + kG5H - 1) / kG5H);
@@ -475,16 +484,70 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
   const int ox = tx0 + col;
   for (int sub = 0; sub < nsub; sub++) {
     const int ty0 = ty00 + sub * kG5H;
+    if (!MH) {
 #pragma unroll
-    for (int k = 0; k < kIter; k++)
-      if (tid + k * 256 < kPairs) s_win4[tid + k * 256] = make_uint4(cur[k].x & M, (cur[k].x >> 8) & M, cur[k].y & M, (cur[k].y >> 8) & M);
+      for (int k = 0; k < kIter; k++)
+        if (tid + k * 256 < kPairs) s_win4[tid + k * 256] = make_uint4(cur[k].x & M, (cur[k].x >> 8) & M, cur[k].y & M, (cur[k].y >> 8) & M);
+    } else {
+      uint8_t *s_raw = reinterpret_cast<uint8_t *>(s_win4);
+#pragma unroll
+      for (int k = 0; k < kIter; k++) {
+        const int i = tid + k * 256;
+        if (i < kPairs) {
+          const int row = i / (kG5WW / 2), pr = i - row * (kG5WW / 2);
+          *reinterpret_cast<uint2 *>(s_raw + row * kG5MPitch + pr * 8) = make_uint2(cur[k].x ^ 0x80808080u, cur[k].y ^ 0x80808080u);
+        }
+      }
+    }
     __syncthreads();
     if (sub + 1 < nsub) fetch(ty0 + kG5H);       // next window's loads fly under this sub-tile's two passes
-    for (int i = tid; i < kG5WH * kG5W; i += 256) {
-      const int row = i >> 6, c = i & 63;
-      const uint2 *p = s_win + row * kG5WW + c;
-      const uint2 A = p[0], B = p[1], C = p[2], D = p[3], E = p[4];
-      s_h[i] = make_uint2(g5_sum(A.x, B.x, C.x, D.x, E.x), g5_sum(A.y, B.y, C.y, D.y, E.y));
+    if (!MH) {
+      for (int i = tid; i < kG5WH * kG5W; i += 256) {
+        const int row = i >> 6, c = i & 63;
+        const uint2 *p = s_win + row * kG5WW + c;
+        const uint2 A = p[0], B = p[1], C = p[2], D = p[3], E = p[4];
+        s_h[i] = make_uint2(g5_sum(A.x, B.x, C.x, D.x, E.x), g5_sum(A.y, B.y, C.y, D.y, E.y));
+      }
+    } else {
+      const uint8_t *s_raw = reinterpret_cast<const uint8_t *>(s_win4);
+      const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+      // B fragments of the three 4-column groups of a 16-pixel span: lane (g, n) supplies k = 16 g + e, e = 0..15
+      int4v bfr[3];
+#pragma unroll
+      for (int nb = 0; nb < 3; nb++) {
+        uint32_t w4[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int e4 = 0; e4 < 4; e4++) {
+            const int k = 16 * g + 4 * d + e4, px = k >> 2, ch = k & 3, col = 4 * nb + (m >> 2), och = m & 3, j = px - col;
+            const int tap = (ch == och && j >= 0 && j <= 4) ? (j == 0 || j == 4 ? 1 : j == 2 ? 6 : 4) : 0;
+            v |= (uint32_t)tap << (8 * e4);
+          }
+          w4[d] = v;
+        }
+        bfr[nb] = int4v{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
+      }
+      uint16_t *s_h16 = reinterpret_cast<uint16_t *>(s_h);
+      const int slot = (m & 1) * 2 + ((m >> 1) & 1);                 // 16-bit lane of channel m & 3 in the uint2 {ch0 | ch2 << 16, ch1 | ch3 << 16}
+      // 12 (row block, fragment) jobs over the four waves
+      for (int job = wave; job < 12; job += 4) {
+        const int blk = job / 6, fj = job - blk * 6;
+        const int row0 = blk * 4;                                      // block 1 covers rows 4..19 and delivers rows 16..19
+        const int4v afr = *reinterpret_cast<const int4v *>(s_raw + (row0 + m) * kG5MPitch + fj * 48 + g * 16);
+        const int4v zero = {0, 0, 0, 0};
+#pragma unroll
+        for (int nb = 0; nb < 3; nb++) {
+          const int4v d = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr, bfr[nb], zero, 0, 0, 0);
+          const int col = fj * 12 + nb * 4 + (m >> 2);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = row0 + 4 * g + r;
+            if (col < kG5W && (blk == 0 || row >= 16)) s_h16[(row * kG5W + col) * 4 + slot] = (uint16_t)(d[r] + 2048);
+          }
+        }
+      }
     }
     __syncthreads();
     if (ox < a.w) {
@@ -501,49 +564,44 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
       const int oy0 = ty0 + rg * 4;
       if (EPI) {
         if (a.blend) {
-          // chroma blend as in k_half8s: opaque layer-2 pixels mix directly, translucent ones scale both sources first
-          // (simple_blend.c:128-146); alpha from the LDS table, products truncated + packed by v_cvt_pk_u8_f32 under RTZ
+          // chroma blend + gamma LUT as in k_half8s: mix sums r_c = bf * s2_c + nbf * s1_c from v_dot4, translucent layer-2 pixels scale both
+          // sources first by the integer scalers of lgpu_alpha_scalers (alpha = 255 -> identity), the LUT is gathered from r_c >> 8
           uint32_t q[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) q[j] = (oy0 + j < a.h) ? reinterpret_cast<const uint32_t *>(l2 + (size_t)(oy0 + j) * a.irow2)[ox] : 0xFF000000u;
           const uint32_t w_lo = bf | (nbf << 8), w_hi = w_lo << 16;
+          uint32_t r0[4], r1[4], r2[4];
           bool opaque = true;
 #pragma unroll
-          for (int j = 0; j < 4; j++) opaque = opaque && ((q[j] >> 24) == 255);
+          for (int j = 0; j < 4; j++) opaque = opaque && (q[j] >= 0xFF000000u);
           if (__all(opaque)) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) px[j] = mix3_dot4(px[j], q[j], w_lo, w_hi) | (px[j] & 0xFF000000u);
-          } else {
-            uint32_t f1[4], f2[4];
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-              float m[12];
-#pragma unroll
-              for (int k = 0; k < 2; k++) {
-                const float alpha = s_alpha[q[i + k] >> 24], inv = __fsub_rn(1.0f, alpha);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                  m[k * 6 + c] = __fmul_rn((float)((q[i + k] >> (8 * c)) & 0xFF), alpha);
-                  m[k * 6 + 3 + c] = __fmul_rn((float)((px[i + k] >> (8 * c)) & 0xFF), inv);
-                }
-              }
-              asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-                           "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\tv_cvt_pk_u8_f32 %0, %5, 1, %0\n\tv_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
-                           "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
-                           "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\tv_cvt_pk_u8_f32 %2, %11, 1, %2\n\tv_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
-                           "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\tv_cvt_pk_u8_f32 %3, %14, 1, %3\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
-                           "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                           : "=&v"(f2[i]), "=&v"(f1[i]), "=&v"(f2[i + 1]), "=&v"(f1[i + 1])
-                           : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+            for (int j = 0; j < 4; j++) {
+              const uint32_t x01 = __builtin_amdgcn_perm(px[j], q[j], 0x05010400u), x2 = __builtin_amdgcn_perm(px[j], q[j], 0x0C0C0602u);
+              r0[j] = __builtin_amdgcn_udot4(x01, w_lo, 0u, false); r1[j] = __builtin_amdgcn_udot4(x01, w_hi, 0u, false);
+              r2[j] = __builtin_amdgcn_udot4(x2, w_lo, 0u, false);
             }
+          } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              const bool op = (q[j] >> 24) == 255;
-              px[j] = mix3_dot4(op ? px[j] : f1[j], op ? q[j] : f2[j], w_lo, w_hi) | (px[j] & 0xFF000000u);
+              const uint2 kk = s_k[q[j] >> 24];
+              const uint32_t qq = q[j], p = px[j];
+              const uint32_t qa = __umul24(qq & 0xFF, kk.x), qb = __umul24((qq >> 8) & 0xFF, kk.x), qc = __umul24((qq >> 16) & 0xFF, kk.x);
+              const uint32_t pa = __umul24(p & 0xFF, kk.y), pb = __umul24((p >> 8) & 0xFF, kk.y), pc = __umul24((p >> 16) & 0xFF, kk.y);
+              r0[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa, 0x0C0C0602u), w_lo, 0u, false);
+              r1[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb, 0x0C0C0602u), w_lo, 0u, false);
+              r2[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc, 0x0C0C0602u), w_lo, 0u, false);
             }
           }
-        }
-        if (a.use_lut) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (a.use_lut) {
+              uint32_t tq = ((uint32_t)s_lut[r2[j] >> 8] << 8) | s_lut[r1[j] >> 8];
+              tq = (tq << 8) | s_lut[r0[j] >> 8];
+              px[j] = (px[j] & 0xFF000000u) | tq;
+            } else px[j] = __builtin_amdgcn_perm(r1[j], r0[j], 0x0C0C0501u) | ((r2[j] << 8) & 0x00FF0000u) | (px[j] & 0xFF000000u);
+          }
+        } else if (a.use_lut) {
 #pragma unroll
           for (int j = 0; j < 4; j++) px[j] = lut3_rgba(s_lut, px[j]);
         }
@@ -584,7 +642,6 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
 // pairs complete and window slot n & 1 free), raw s_barrier so the memory waves' DMA stays in flight across them; they
 // wait with a counted vmcnt that leaves exactly the newest window outstanding.
 // =====================================================================================================================
-typedef int int4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
 
@@ -1242,10 +1299,32 @@ static int kernel_for_interp(int interp, bool upscale) {
   return 0;
 }
 
+// the chroma blend's alpha scalers (lgpu_alpha_scalers, proven while built) as one device table per device: {K2, K1} per layer-2 alpha
+static std::mutex g_ks_mu;
+static std::map<int, uint2 *> g_ks;
+static int get_kscale(const uint2 **out) {
+  int dev = 0;
+  LGPU_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_ks_mu);
+  auto it = g_ks.find(dev);
+  if (it == g_ks.end()) {
+    uint32_t k2[256], k1[256];
+    int rc = lgpu_alpha_scalers(k2, k1);           // simple_blend.c:137-145 as (c * K) >> 16
+    if (rc) return rc;
+    uint2 ks[256];
+    for (int al = 0; al < 256; al++) ks[al] = make_uint2(k2[al], k1[al]);
+    uint2 *d = nullptr;
+    LGPU_HIP(hipMalloc((void **)&d, sizeof ks));
+    LGPU_HIP(hipMemcpy(d, ks, sizeof ks, hipMemcpyHostToDevice));
+    it = g_ks.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return LGPU_OK;
+}
+
 // ---- k_half8s host side --------------------------------------------------------------------------------------
 struct Half8Const {
   int4v *bfrag = nullptr;     // device [2][64]
-  uint2 *kscale = nullptr;    // device [256]
 };
 static std::mutex g_h8_mu;
 static std::map<std::pair<int, std::vector<int16_t>>, Half8Const> g_h8;   // (device, 8 taps + swap flag)
@@ -1275,15 +1354,8 @@ static int get_half8_const(const int16_t taps[8], int swap_rb, int xoff, const H
         frag[0][l][e] = (int8_t)(tap >> 6);        // tap = 64 * hi + lo, lo in [0, 63]
         frag[1][l][e] = (int8_t)(2 * (tap & 63));  // stored doubled (see k_half8s)
       }
-    uint32_t k2[256], k1[256];
-    int rc = lgpu_alpha_scalers(k2, k1);           // simple_blend.c:137-145 as (c * K) >> 16, proven while built
-    if (rc) return rc;
-    uint2 ks[256];
-    for (int al = 0; al < 256; al++) ks[al] = make_uint2(k2[al], k1[al]);
     LGPU_HIP(hipMalloc((void **)&c.bfrag, sizeof frag));
-    LGPU_HIP(hipMalloc((void **)&c.kscale, sizeof ks));
     LGPU_HIP(hipMemcpy(c.bfrag, frag, sizeof frag, hipMemcpyHostToDevice));
-    LGPU_HIP(hipMemcpy(c.kscale, ks, sizeof ks, hipMemcpyHostToDevice));
     it = g_h8.emplace(key, c).first;
   }
   *out = &it->second;
@@ -1319,9 +1391,10 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   int rc = get_half8_const(hb->hco.data(), swap_rb, xoff, &hc);
   if (rc) return rc;
   Half8Args a;
+  if ((rc = get_kscale(&a.kscale))) return rc;
   a.xoff = xoff;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
-  a.bfrag = hc->bfrag; a.kscale = hc->kscale;
+  a.bfrag = hc->bfrag;
   for (int k = 0; k < 4; k++) a.vc[k] = (uint32_t)(uint16_t)vb->hco[2 * k] | ((uint32_t)(uint16_t)vb->hco[2 * k + 1] << 16);
   a.swap_rb = swap_rb; a.blend = blend; a.irow2 = irow2; a.bf = bf; a.nbf = 0xFF - bf; a.bf_d = bf_d; a.use_lut = use_lut;
   a.ntracks = ntracks;
@@ -1525,10 +1598,16 @@ static int try_gauss5x(int w, int h, int irow, int orow, int blend, int irow2, u
   G5Args a;
   a.w = w; a.h = h; a.irow = irow; a.orow = orow; a.irow2 = irow2; a.blend = blend; a.use_lut = use_lut;
   a.bf = bf & 0xFF; a.nbf = 0xFF - a.bf; a.bf_d = bf_d;
+  a.kscale = nullptr;
+  if (blend) { int rc = get_kscale(&a.kscale); if (rc) return rc; }
   a.tiles_x = (w + kG5W - 1) / kG5W;
   const int tiles_y = (h + kG5H * kG5Sub - 1) / (kG5H * kG5Sub);
   const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)ntracks);
-  if (blend || use_lut) hipLaunchKernelGGL(k_gauss5x<true>, grid, dim3(256), 0, st, a, t, l);
+  static const bool mfma_h = getenv("LGPU_G5_MFMA") != nullptr;       // measurement variant, see k_gauss5x
+  if (mfma_h) {
+    if (blend || use_lut) hipLaunchKernelGGL((k_gauss5x<true, true>), grid, dim3(256), 0, st, a, t, l);
+    else hipLaunchKernelGGL((k_gauss5x<false, true>), grid, dim3(256), 0, st, a, t, l);
+  } else if (blend || use_lut) hipLaunchKernelGGL(k_gauss5x<true>, grid, dim3(256), 0, st, a, t, l);
   else hipLaunchKernelGGL(k_gauss5x<false>, grid, dim3(256), 0, st, a, t, l);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
