@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU)
     ap.add_argument("--blur", type=int, default=0, help="1: add the 5x5 gaussian stage (BASELINE config 5 chain)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--sets", type=int, default=2,
+                    help="independent buffer sets (sources, layer 2, destinations) the steps rotate through; with 2, consecutive steps share no byte, "
+                         "so nothing a step reads can still sit in the 256 MiB Infinity Cache from the step before")
     ap.add_argument("--l2-translucent", type=float, default=0.5,
                     help="fraction of layer-2 pixels with alpha < 255 (they take the reference's float scaling path); 0 = an opaque layer 2")
     args = ap.parse_args()
@@ -66,12 +69,17 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(0x11FE5 + rank)
     T = args.tracks
-    srcs = [torch.randint(0, 256, (SH, SW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
-    l2s = [torch.randint(0, 256, (DH, DW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
-    for t in l2s:   # default: half of layer 2 opaque (integer blend path), half translucent (the reference's float scaling path), scattered per pixel
-        a = t[:, 3::4]
-        a[torch.rand(a.shape, device="cuda", generator=g) >= args.l2_translucent] = 255
-    dsts = [torch.zeros((DH, DW * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    nsets = max(1, args.sets)
+    keep, trks = [], []
+    for _ in range(nsets):
+        srcs = [torch.randint(0, 256, (SH, SW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
+        l2s = [torch.randint(0, 256, (DH, DW * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(T)]
+        for t in l2s:   # default: half of layer 2 opaque (integer blend path), half translucent (the reference's float scaling path), scattered per pixel
+            a = t[:, 3::4]
+            a[torch.rand(a.shape, device="cuda", generator=g) >= args.l2_translucent] = 255
+        dsts = [torch.zeros((DH, DW * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+        keep.append((srcs, l2s, dsts))
+        trks.append(ops.chain_tracks(srcs, l2s, dsts))
 
     from lives_amd.lib import load
     lut = np.zeros(256, np.uint8)
@@ -82,7 +90,7 @@ def main():
     schedule = torch.tensor([[(96 + 7 * s) % 256, 0, 0, 0] for s in range(args.steps + args.warmup)], dtype=torch.int32, device="cuda")
     prm = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3, do_blur=args.blur, bf=128, lut=lut,
                            param_block=pblock)
-    trk = ops.chain_tracks(srcs, l2s, dsts)
+    trk = trks[0]
 
     sched_base = schedule.data_ptr()
 
@@ -103,7 +111,7 @@ def main():
             prm.param_block_d = blk.data_ptr()
         else:
             prm.param_block_d = sched_base + 16 * s      # one GPU: nothing to exchange, the kernel reads step s of the resident schedule
-        ops.chain(prm, trk)
+        ops.chain(prm, trks[s % nsets])
 
     def fence():
         torch.cuda.synchronize()
@@ -113,8 +121,8 @@ def main():
 
     # device wake-up (not a step of the schedule): ~60 ms of the same launch so that the power / clock state is the steady one
     # whatever --warmup says; measured: the first ~100 launches after idle run ~15 % slower
-    for _ in range(300):
-        ops.chain(prm, trk)
+    for i in range(300):
+        ops.chain(prm, trks[i % nsets])
     for s in range(args.warmup):
         step(s)
     fence()
@@ -130,7 +138,17 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around K launches ----
     reps = max(10, min(args.steps, 200))
-    ms = ops.chain_timed(prm, trk, reps)
+    if nsets == 1:
+        ms = ops.chain_timed(prm, trk, reps)       # the library's own event pair (hipEventRecord on the launch stream around `reps` launches)
+    else:                                          # the same, around launches that rotate through the buffer sets: ops.chain launches on torch's current stream,
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)    # which is the stream these events are recorded on
+        prm.param_block_d = sched_base if world == 1 else pblock.data_ptr()
+        e0.record()
+        for i in range(reps):
+            ops.chain(prm, trks[i % nsets])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
     launch_s = ms * 1e-3 / reps
     algo = ALGO_BYTES_PER_FRAME * T
     achieved = algo / launch_s / 1e9
@@ -155,7 +173,7 @@ def main():
             "config": {"workload": "3840x2160 BGRA32 -> convert(RGBA32) -> bicubic resize 0.5x%s -> chroma blend with 1920x1080 RGBA32 layer -> gamma LUT (linear->sRGB)"
                                    % (" -> 5x5 gaussian" if args.blur else ""),
                        "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
-                       "launches_per_step": 2 if args.blur else 1, "layer2_translucent_fraction": args.l2_translucent},
+                       "launches_per_step": 2 if args.blur else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu:

@@ -94,6 +94,11 @@ lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer);       
 lives_gpu_boolean lives_gpu_weed_layer_clear_pixel_data(lives_gpu_layer_t *layer);            /* colourspace.h:399 */
 lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, lives_gpu_boolean black_fill, lives_gpu_boolean may_contig);
 int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int *nplanes);
+/* THREADVAR(rowstride_alignment_hint) of the calling thread (src/colourspace.c:11285-11297; set by src/player.c:1355-1356, src/transcode.c:42,:369,
+   src/effects-weed.c:2005-2007): a value >= 4 is the alignment of the NEXT plane allocation of this thread, -1 = compact rows until reset, 0 = default (32).
+   A host that keeps the CPU bodies beside the GPU ones forwards its thread variable before a seam call and reads it back after. */
+void lives_gpu_set_rowstride_alignment_hint(int hint);
+int lives_gpu_get_rowstride_alignment_hint(void);
 
 /* ---- device residency (optional): a pinned layer keeps the authoritative copy of its planes in HBM across the calls
    above, so a chain of layer ops crosses PCIe once per direction.  Between pin and sync the HOST bytes of pixel_data are

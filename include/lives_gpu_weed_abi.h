@@ -3,8 +3,8 @@
  * A LiVES build includes the real <weed/weed.h>, <weed/weed-palettes.h>, <weed/weed-effects.h>; this
  * header exists so that the library builds without the LiVES tree.  It only restates numeric ids,
  * leaf-name strings and function-pointer signatures of the public ABI (libweed/weed.h:150-262,:373-465;
- * libweed/weed-palettes.h:43-185; libweed/weed-effects.h:44-400).  tests/test_weed_abi.py checks every
- * value below against the reference headers when /root/reference is present.
+ * libweed/weed-palettes.h:43-185; libweed/weed-effects.h:44-400).  tests/test_host_cpu.py
+ * (test_weed_abi_constants_match_reference_headers) checks every value below against the reference headers when /root/reference is present.
  *
  * If the real weed headers were included first, nothing here is redefined.
  */

@@ -177,8 +177,19 @@ void apply_const_rowstrides(weed_plant_t *layer, int n, int *rs) {
 
 // new host planes for (pal, width, height) with the reference's rowstride rule; one block for planar ("contiguous")
 struct NewPlanes { int n; int rs[4]; uint8_t *pd[4]; size_t sz[4]; };
+// THREADVAR(rowstride_alignment_hint) of the calling thread as calc_rowstrides consumes it (:11285-11297): a value >= 4 applies to the next
+// allocation only, -1 (compact rows: what v1 playback plugins and the transcoder ask for, src/player.c:1355-1356, src/transcode.c:42) stays until
+// the caller resets it.  The host forwards its own thread variable with lives_gpu_set_rowstride_alignment_hint(); the reference also remembers
+// the last alignment used as the thread's new default (:11295) -- not mirrored: that default belongs to LiVES' own allocations.
+thread_local int t_rs_hint = 0;
+int take_alignment(int forced) {
+  if (forced) { t_rs_hint = 0; return forced; }      // resize_layer overwrites the hint with 16 and the allocation consumes it (:14989)
+  const int h = t_rs_hint;
+  if (h != -1) t_rs_hint = 0;
+  return h;
+}
 bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np, weed_plant_t *fixed_from = nullptr) {
-  np->n = lgpu_calc_rowstrides(width, pal, alignment, np->rs);
+  np->n = lgpu_calc_rowstrides(width, pal, take_alignment(alignment), np->rs);
   if (np->n < 1) return false;
   apply_const_rowstrides(fixed_from, np->n, np->rs);
   size_t tot = 0;
@@ -470,11 +481,14 @@ int lives_gpu_set_prefs(const lives_gpu_prefs *prefs) {
   return LGPU_OK;
 }
 
+void lives_gpu_set_rowstride_alignment_hint(int hint) { t_rs_hint = hint; }
+int lives_gpu_get_rowstride_alignment_hint(void) { return t_rs_hint; }
+
 int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int *nplanes) {
   if (pal == WEED_PALETTE_NONE) { if (!layer || !bound()) return nullptr; pal = get_int(layer, WEED_LEAF_CURRENT_PALETTE, 0); }
   if (!width) { if (!layer || !bound()) return nullptr; width = get_int(layer, WEED_LEAF_WIDTH, 0); }
   int rs[4];
-  const int n = lgpu_calc_rowstrides(width, pal, 0, rs);
+  const int n = lgpu_calc_rowstrides(width, pal, take_alignment(0), rs);
   if (nplanes) *nplanes = n;
   if (!n) return nullptr;
   apply_const_rowstrides(layer, n, rs);

@@ -41,7 +41,12 @@ def main():
     R = po.csref()
     R.csref_set_prefs(2, 1, 1.4)
     manifest = {"reference": "salsaman/LiVES @ /root/reference", "prefs": {"pb_quality": "PB_QUALITY_MED", "screen_gamma": 1.4},
-                "groups": {}}
+                "groups": {},
+                "unpinned": {
+                 "lgpu_swizzle ops swap4, swapprepost, delpre without LUT": "reference-broken in every mode (DESIGN.md K1-b); checked GPU == oracle only",
+                 "lgpu_resize / lgpu_chain resize stage": "libswscale is not in the image; own spec lgpu-polyphase-v1 (DESIGN.md section 5), GPU == oracle + properties; tests/test_swscale_info.py prints PSNR against a libswscale found at run time, never gating",
+                 "lgpu_gauss5": "no reference loop exists (BASELINE config 4 names the op only); own spec, GPU == oracle + properties"
+                }}
 
     # ---- conversion tables, alpha tables -----------------------------------------------------------------
     tabs = {}
@@ -115,7 +120,7 @@ def main():
     R.csref_set_prefs(2, 1, 1.4)
     manifest["groups"]["k1_swizzle.npz"] = ("src/colourspace.c:9259-10577; record <op>_lut<0|1>_t<nfx_threads>; swap3/swap3postalpha/swap3prealpha in place "
                                             "(as convert_layer_palette_full calls them); swap4, swapprepost and delpre-without-LUT are broken in the "
-                                            "reference in every mode and have no fixture")
+                                            "reference in every mode and have no fixture: UNPINNED (GPU == oracle == the evident permutation; no reference output exists to compare with)")
 
     # ---- K2 yuv420p / 422p -> rgb --------------------------------------------------------------------------------
     k2 = {}

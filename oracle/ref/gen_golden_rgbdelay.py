@@ -78,7 +78,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "rgbdelay.npz"), **rec)
     mpath = os.path.join(OUT, "manifest.json")
     man = json.load(open(mpath))
-    man["groups"]["rgbdelay.npz"] = ("reference plugin built unmodified: lives-plugins/weed-plugins/RGBdelay.c (filters RGBdelay, YUVdelay); one instance over 12 frames "
+    man["groups"]["rgbdelay.npz"] = ("reference SOURCE unmodified, but compiled with clang -ftrivial-auto-var-init=zero (oracle/ref/build_ref.sh): that flag changes what the reference's "
+                                     "uninitialised-int read in weed_param_get_value_boolean does (quirk R1 in DESIGN.md: a plain gcc build reads every switch as off), so these records "
+                                     "pin the plugin's evident intent, not a stock build: lives-plugins/weed-plugins/RGBdelay.c (filters RGBdelay, YUVdelay); one instance over 12 frames "
                                      "of 10x6; parameter sets = CASES in oracle/ref/gen_golden_rgbdelay.py (name -> filter, palette, YUV_clamping leaf, cache size, "
                                      "{frame: r, g, b switches + strength}, in place); <name>|in / <name>|out = stacked frames (out of place: destination pre-filled 0x5A)")
     json.dump(man, open(mpath, "w"), indent=1)

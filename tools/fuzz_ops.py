@@ -92,10 +92,17 @@ def main():
                 if wants is None:
                     continue
                 dd = [dev(np.zeros((dh, orow), np.uint8)) for _ in range(ntr)]
-                prm = ops.chain_params(sw, sh, srcs[0].strides[0], dw, dh, l2s[0].strides[0], orow, swap_rb=swap, interp=3, do_blur=blur, bf=bf, lut=lut)
+                # half of the cases hand the blend amount over the way bench.py does: in a device-resident parameter block (int32[4], [0] = bf) that the
+                # kernel reads, with a decoy value in the kernarg field
+                via_block = rng.random() < 0.5
+                if via_block:
+                    counts["chain(param_block)"] = counts.get("chain(param_block)", 0) + 1
+                pb = torch.tensor([bf, 0, 0, 0], dtype=torch.int32, device="cuda") if via_block else None
+                prm = ops.chain_params(sw, sh, srcs[0].strides[0], dw, dh, l2s[0].strides[0], orow, swap_rb=swap, interp=3, do_blur=blur,
+                                       bf=(bf * 7 + 13) % 256 if via_block else bf, lut=lut, param_block=pb)
                 ops.chain(prm, ops.chain_tracks([dev(s) for s in srcs], [dev(s) for s in l2s], dd))
-                ok = all(same(host(dd[i]), wants[i], dw * 4, dh, "chain %dx%d->%dx%d swap=%d blur=%d bf=%d lut=%d strides=%d/%d track %d" %
-                              (sw, sh, dw, dh, swap, blur, bf, use_lut, srcs[0].strides[0], l2s[0].strides[0], i)) for i in range(ntr))
+                ok = all(same(host(dd[i]), wants[i], dw * 4, dh, "chain %dx%d->%dx%d swap=%d blur=%d bf=%d lut=%d strides=%d/%d track %d param_block=%d" %
+                              (sw, sh, dw, dh, swap, blur, bf, use_lut, srcs[0].strides[0], l2s[0].strides[0], i, via_block)) for i in range(ntr))
             elif kind == "gauss5":
                 ps = int(rng.choice([1, 3, 4]))
                 w, h = int(rng.integers(1, 300)), int(rng.integers(1, 150))
