@@ -583,10 +583,9 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     if (!read_layer(layer, &l)) return 0;
   }
   if (inpl == outpl) {                                                     // :12265
-    // 4:2:0 JPEG <-> MPEG chroma siting is switch_yuv_sampling (:10876-10925) in the reference: not served here
-    if ((inpl == WEED_PALETTE_YUV420P || inpl == WEED_PALETTE_YVU420P) && l.sampling != osampling &&
-        (l.sampling == WEED_YUV_SAMPLING_JPEG || l.sampling == WEED_YUV_SAMPLING_MPEG) &&
-        (osampling == WEED_YUV_SAMPLING_JPEG || osampling == WEED_YUV_SAMPLING_MPEG)) return decline(layer);
+    // Nothing left to do, exactly as in the reference: its 4:2:0 JPEG <-> MPEG chroma-siting pass (switch_yuv_sampling, :10876-10925) is called
+    // from inside `if (isampling == osampling && ...)` under the condition `isampling != osampling` (:12268-12274), i.e. never (quirk SS1): a request
+    // that differs in sampling only returns TRUE with the pixels and the YUV_sampling leaf as they were.
     return 1;
   }
   // premultiplied-alpha bookkeeping (:12290-12306), for every in / out palette pair

@@ -999,8 +999,9 @@ void orc_softlight_y(const uint8_t *src, int irow, uint8_t *dst, int orow, int w
     d[0] = s[0];                                                                      /* :110 */
     for (int x = 1; x < width - 1; x++) {
       const uint8_t *c = s + x;
-      const int row0 = (c[irow - 1] - c[-irow - 1]) + ((c[irow] - c[-irow]) << 1) + (c[irow + 1] - c[irow - 1]);
-      const int row1 = (c[-irow + 1] - c[-irow - 1]) + ((c[1] - c[-1]) << 1) + (c[irow + 1] + c[irow - 1]);
+      /* `* 2`: the reference writes `<< 1` on differences that can be negative (softlight.c:119-123); same value with gcc, but not UB */
+      const int row0 = (c[irow - 1] - c[-irow - 1]) + ((c[irow] - c[-irow]) * 2) + (c[irow + 1] - c[irow - 1]);
+      const int row1 = (c[-irow + 1] - c[-irow - 1]) + ((c[1] - c[-1]) * 2) + (c[irow + 1] + c[irow - 1]);
       int sum = (int)(((3 * isqrt_u32((uint32_t)(row0 * row0 + row1 * row1)) / 2) * scale) >> 8);
       sum = sum < ymin ? ymin : sum > ymax ? ymax : sum;
       sum = ((256 - mix) * sum + mix * c[0]) >> 8;

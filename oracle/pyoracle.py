@@ -46,7 +46,8 @@ def build_oracle(force=False, native=False):
     """compile oracle/*.c -> liblives_oracle.so (portable x86-64-v3 code, travels with gpurun) or, with
     native=True, liblives_oracle_native.so (-march=native, rebuilt whenever the host CPU differs: used
     for the cpu_baseline timing so the CPU side gets the reference's --enable-turbo treatment)"""
-    so = os.path.join(HERE, "liblives_oracle_native.so" if native else "liblives_oracle.so")
+    ubsan = bool(os.environ.get("LGPU_ORACLE_UBSAN")) and not native          # tools/oracle_ubsan.sh: the restatement under -fsanitize=undefined
+    so = os.path.join(HERE, "liblives_oracle_native.so" if native else "liblives_oracle_ubsan.so" if ubsan else "liblives_oracle.so")
     sig = so + ".sig"
     srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_bench.c", "lives_oracle.h")]
     srcs = [s for s in srcs if os.path.exists(s)]
@@ -59,8 +60,9 @@ def build_oracle(force=False, native=False):
     if stale:
         cs = [s for s in srcs if s.endswith(".c")]
         march = "-march=native" if native else "-march=x86-64-v3"
-        subprocess.check_call(["gcc", "-O3", march, "-fno-fast-math", "-ffp-contract=off", "-Wall", "-shared",
-                               "-fPIC", "-o", so] + cs + ["-lm", "-lpthread"])
+        san = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"] if ubsan else []
+        subprocess.check_call(["gcc", "-O1" if ubsan else "-O3", march, "-fno-fast-math", "-ffp-contract=off", "-Wall", "-shared",
+                               "-fPIC", "-o", so] + san + cs + ["-lm", "-lpthread"])
         if native:
             with open(sig, "w") as f:
                 f.write(_cpu_sig())

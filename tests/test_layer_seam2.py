@@ -163,6 +163,28 @@ def test_wrappers_with_sampling_and_variant(seam, orc):
         assert (wh.planes_of(lay)[0][0] == want).all() and wh.geti(lay, "gamma_type") == (1 if tgt == 1 else -1), tgt
 
 
+def test_a_sampling_only_request_is_a_no_op_as_in_the_reference(seam):
+    """src/colourspace.c:12265-12274: switch_yuv_sampling (:10876-10925) sits behind `isampling == osampling` and asks for `isampling != osampling`:
+    it is never called.  A 4:2:0 layer asked to change its chroma siting only comes back TRUE, pixels, pointers and the YUV_sampling leaf untouched."""
+    L, wh = seam
+    W = wh.weed()
+    rng = np.random.default_rng(47)
+    Y, U, V = frame(rng, 64, 32, 1), frame(rng, 32, 16, 1), frame(rng, 32, 16, 1)
+    for pinned in (0, 1):
+        for isamp, osamp in ((1, 0), (0, 1)):
+            lay = wh.new_layer(YUV420P, 64, 32, [Y, U, V], clamping=0, subspace=1)
+            W.weed_set_int_value(lay, b"YUV_sampling", isamp)
+            if pinned:
+                assert L.lives_gpu_layer_pin(lay) == 0
+            _, ptrs, _ = wh.planes_of(lay)
+            assert L.lives_gpu_convert_layer_palette_full(lay, YUV420P, 0, osamp, 1, 0) == 1
+            if pinned:
+                assert wh.geti(lay, "host_gpu_resident") == 1 and L.lives_gpu_layer_unpin(lay) == 0      # not a decline: the layer stayed resident
+            planes, ptrs2, _ = wh.planes_of(lay)
+            assert ptrs2 == ptrs and wh.geti(lay, "YUV_sampling") == isamp
+            assert (planes[0] == Y).all() and (planes[1] == U).all() and (planes[2] == V).all()
+
+
 def test_premult_bookkeeping_applies_to_every_palette_pair(seam, orc):
     """src/colourspace.c:12290-12306 runs before the palette dispatch: with prefs->alpha_post a PREMULT RGBA layer that loses its alpha
     to a YUV palette is un-premultiplied first; without it, RGB24 -> YUVA8888 gains the PREMULT flag"""
