@@ -47,6 +47,8 @@ struct SepArgs {
   // source row pairs: (v0, v1), (v2, v3) ... when vpos is even, (0, v0), (v1, v2) ... when it is odd
   const uint32_t *hco2, *vco2;
   int nph, npv;
+  int ntracks;                      // k_sep2p: tracks of the launch (the tile list is tiles_x * tiles_y * ntracks long)
+  unsigned long long *dbg;          // k_sep2p, LGPU_S2P_DEBUG=1: per-wave phase cycle sums [grid][6][8] (nullptr otherwise)
 };
 struct SepTracks {
   const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
@@ -393,8 +395,9 @@ __global__ __launch_bounds__(kBlock) void k_sep2(SepArgs a, SepTracks trk, Lut8 
       acc3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, t.w), cf, acc3, false);
     }
     if (lane < tw) {
-      uint32_t p = (uint32_t)clamp255(acc0 >> a.vshift) | ((uint32_t)clamp255(acc1 >> a.vshift) << 8) |
-                   ((uint32_t)clamp255(acc2 >> a.vshift) << 16) | ((uint32_t)clamp255(acc3 >> a.vshift) << 24);
+      uint32_t p = a.vshift == 21 ? pack_sat_shr21(acc0, acc1, acc2, acc3)
+                                  : (uint32_t)clamp255(acc0 >> a.vshift) | ((uint32_t)clamp255(acc1 >> a.vshift) << 8) |
+                                        ((uint32_t)clamp255(acc2 >> a.vshift) << 16) | ((uint32_t)clamp255(acc3 >> a.vshift) << 24);
       if (a.blend) {
         const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[tx0 + lane];
         p = chroma_rgba(p, q, bf, nbf);
@@ -1168,6 +1171,288 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
 #undef H8S_T
 }
 
+// =====================================================================================================================
+// k_sep2p -- k_sep2's arithmetic (bit-identical) in the shape that made the 2:1 case fast: persistent, XCD-aware workgroups of
+// 4 compute waves + 2 memory waves.  k_sep2 runs its three phases (stage window - horizontal - vertical) back to back with nothing in flight
+// across them; here the source window of tile n+1 / n+2 travels by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a
+// two-slot ring while the compute waves work on tile n, and the compute waves never touch global memory except for the result
+// stores: the per-column taps / offsets and the per-row vertical taps of the next tile are fetched by the memory waves too and
+// handed over through LDS.  Memory wave m owns the tiles i = m (mod 2) of the workgroup's list, so "my window has landed" is a
+// plain vmcnt(0).  Per tile i:
+//     A(i)  | compute: horizontal pass window i -> row pairs | wave (i+1)&1: wait for window i+1, edge fix-up, tables of tile i+1
+//     B(i)  | compute: vertical pass + epilogue + stores     | wave i&1: issue window i+2 into slot i&1
+// Every window has the plan's maximal shape [sht][swt]; rows are clamped to the frame by address, column chunks outside the frame
+// are fetched from the nearest in-frame chunk and overwritten with the edge pixel after landing (source width % 4 == 0 required, so a
+// 16-byte chunk is inside or outside as a whole).  The BGRA byte swap moves from staging into the horizontal pass's selectors.
+// =====================================================================================================================
+constexpr int kS2pCW = 4, kS2pThreads = (kS2pCW + 2) * 64, kS2pMaxReq = 48, kS2pMaxNpv = 8;
+struct S2pTile {
+  int track, tx0, ty0;
+  __device__ __forceinline__ void set(const SepArgs &a, int work) {
+    const int tiles = a.tiles_x * a.tiles_y;
+    track = work / tiles;
+    const int tile = work - track * tiles, ty = tile / a.tiles_x;
+    tx0 = (tile - ty * a.tiles_x) * kTileW; ty0 = ty * a.th;
+  }
+};
+struct S2pLds {       // byte offsets into the dynamic LDS block
+  int win, p, lut, vc, hc, hdr, vcslot, hcslot;
+  size_t total;
+  __host__ __device__ S2pLds(int sht, int swt, int th, int npv, int nph) {
+    win = sht * swt * 4;
+    p = 2 * win;
+    lut = p + (sht >> 1) * kTileW * 16;
+    vc = lut + 256;
+    vcslot = th * (npv + 1) * 4;
+    hc = vc + 2 * vcslot;
+    hcslot = (nph + 1) * 256;
+    hdr = hc + 2 * hcslot;
+    total = (size_t)hdr;
+  }
+};
+__device__ __noinline__ void s2p_issue_border(int sw, int sh, int irow, int swt, const uint8_t *src, int sx0a, int sy0, int lane, uint8_t *win, int nreq,
+                                              int nchunks, uint32_t mcpr) {     // scalars, not the argument struct: a reference would force a stack copy of it
+  const int cpr = swt >> 2;
+  for (int k = 0; k < nreq; k++) {
+    const int c = k * 64 + lane, r = (int)(((uint32_t)c * mcpr) >> 20), ch = c - r * cpr;
+    int sy = sy0 + r;
+    sy = sy < 0 ? 0 : sy >= sh ? sh - 1 : sy;
+    int x = sx0a + ch * 4;
+    x = x < 0 ? 0 : x > sw - 4 ? sw - 4 : x;
+    const uint8_t *g = src + ((uint32_t)sy * (uint32_t)irow + (uint32_t)x * 4u);
+    if (c < nchunks) __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(win + k * 1024), 16, 0, 0);
+  }
+}
+__device__ __noinline__ void s2p_fix_edges(uint8_t *win, int sx0a, int sw, int swt, int sht, int lane) {
+  const int cpr = swt >> 2;
+  const int nlo = sx0a < 0 ? (-sx0a) >> 2 : 0;                 // chunks left of the frame (sx0a is a multiple of 4)
+  int chh = (sw - sx0a) >> 2;                                  // first chunk right of the frame
+  if (chh > cpr) chh = cpr;
+  const int na = nlo + (cpr - chh);
+  uint32_t *w = reinterpret_cast<uint32_t *>(win);
+  for (int idx = lane; idx < sht * na; idx += 64) {
+    const int r = idx / na, j = idx - r * na;
+    const int ch = j < nlo ? j : chh + (j - nlo);
+    const uint32_t v = w[r * swt + (j < nlo ? -sx0a : sw - 1 - sx0a)];
+    *reinterpret_cast<uint4 *>(w + r * swt + ch * 4) = make_uint4(v, v, v, v);
+  }
+}
+
+template <int NPH>
+__device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &trk, uint8_t *smem, const S2pLds &L, int wave, int lane,
+                                            int work, int wend, int wstride) {
+  uint4 *s_p = reinterpret_cast<uint4 *>(smem + L.p);
+  const uint8_t *s_lut = smem + L.lut;
+  uint32_t bf = a.bf, nbf = a.nbf;
+  if (a.blend && a.bf_d) { bf = (uint32_t)a.bf_d[0] & 0xFF; nbf = 0xFF - bf; }
+  // selector of channel c: bytes [b, 0, 4 + b, 0] with b = the source byte that feeds output channel c (identity or the R <-> B swap)
+  uint32_t sel[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) sel[c] = 0x0C040C00u + ((a.src_sel >> (8 * c)) & 3u) * 0x00010001u;
+  int par = 0;
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define S2P_T(i) if (a.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
+  for (; work < wend; work += wstride, par ^= 1) {
+    S2pTile t;
+    t.set(a, work);
+    const int tw = min(kTileW, a.dw - t.tx0), thh = min(a.th, a.dh - t.ty0);
+    S2P_T(3)
+    H8S_BARRIER();                                                                   // A(i): window i, tables i in place; row pairs free
+    S2P_T(0)
+    const uint32_t *s_src = reinterpret_cast<const uint32_t *>(smem + par * L.win);
+    const uint32_t *s_hc = reinterpret_cast<const uint32_t *>(smem + L.hc + par * L.hcslot);
+    const uint32_t *s_vc = reinterpret_cast<const uint32_t *>(smem + L.vc + par * L.vcslot);
+    // the tables arrive raw: hpos of the lane's column, vpos of the rows; the window origin is (hpos[first column] & ~3, vpos[first row] & ~1)
+    const int sx0a = (int)s_hc[0] & ~3, sy0 = (int)s_vc[0] & ~1;
+    const int npairs = (((int)s_vc[(thh - 1) * (a.npv + 1)] + a.ntv - sy0 + 1) & ~1) >> 1;
+    // ---- horizontal pass: lane = output column, a wave takes window row pairs ----
+    const int hoff = (int)s_hc[lane] - sx0a;
+    short2v hc2[NPH];
+#pragma unroll
+    for (int j = 0; j < NPH; j++) hc2[j] = __builtin_bit_cast(short2v, s_hc[(1 + j) * 64 + lane]);
+    for (int k = wave; k < npairs; k += kS2pCW) {
+      const uint32_t *r0 = s_src + (2 * k) * a.swt + hoff, *r1 = r0 + a.swt;
+      int e0 = a.hround, e1 = a.hround, e2 = a.hround, e3 = a.hround, o0 = a.hround, o1 = a.hround, o2 = a.hround, o3 = a.hround;
+#pragma unroll
+      for (int j = 0; j < NPH; j++) {
+        const uint32_t p0 = r0[2 * j], p1 = r0[2 * j + 1], q0 = r1[2 * j], q1 = r1[2 * j + 1];
+        e0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, sel[0])), hc2[j], e0, false);
+        e1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, sel[1])), hc2[j], e1, false);
+        e2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, sel[2])), hc2[j], e2, false);
+        e3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(p1, p0, sel[3])), hc2[j], e3, false);
+        o0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, sel[0])), hc2[j], o0, false);
+        o1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, sel[1])), hc2[j], o1, false);
+        o2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, sel[2])), hc2[j], o2, false);
+        o3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(q1, q0, sel[3])), hc2[j], o3, false);
+      }
+      uint4 pk;
+      pk.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e0 >> a.hshift, o0 >> a.hshift));
+      pk.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e1 >> a.hshift, o1 >> a.hshift));
+      pk.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e2 >> a.hshift, o2 >> a.hshift));
+      pk.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e3 >> a.hshift, o3 >> a.hshift));
+      s_p[k * kTileW + lane] = pk;
+    }
+    S2P_T(1)
+    H8S_BARRIER();                                                                   // B(i): row pairs complete, window slot i & 1 free
+    S2P_T(2)
+    // ---- vertical pass + epilogue: wave = output row, lane = output column ----
+    uint8_t *dst = trk.dst[t.track];
+    const uint8_t *l2 = trk.l2[t.track];
+    // four output rows of the wave at a time: their row-pair / tap-pair reads are requested together, so the LDS latency of the (run-time long)
+    // pair loop is paid once per four rows (one row at a time measured 900 cycles per row, mostly waiting)
+    for (int lyb = wave; lyb < thh; lyb += 4 * kS2pCW) {
+      const uint32_t *vc2[4];
+      const uint4 *col[4];
+      int acc[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ly = min(lyb + r * kS2pCW, thh - 1);               // rows past the tile repeat the last one (not stored)
+        vc2[r] = s_vc + ly * (a.npv + 1);                           // the same address for every lane (broadcast)
+        acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = a.vround;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) col[r] = s_p + (((int)vc2[r][0] >> 1) - (sy0 >> 1)) * kTileW + lane;       // first row pair, window relative
+      for (int j = 0; j < a.npv; j++) {
+        uint4 tt[4];
+        uint32_t cf[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { tt[r] = col[r][j * kTileW]; cf[r] = vc2[r][1 + j]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const short2v c2 = __builtin_bit_cast(short2v, cf[r]);
+          acc[r][0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].x), c2, acc[r][0], false);
+          acc[r][1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].y), c2, acc[r][1], false);
+          acc[r][2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].z), c2, acc[r][2], false);
+          acc[r][3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].w), c2, acc[r][3], false);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ly = lyb + r * kS2pCW, oy = t.ty0 + ly;
+        if (ly < thh && lane < tw) {
+          uint32_t p = a.vshift == 21 ? pack_sat_shr21(acc[r][0], acc[r][1], acc[r][2], acc[r][3])
+                                      : (uint32_t)clamp255(acc[r][0] >> a.vshift) | ((uint32_t)clamp255(acc[r][1] >> a.vshift) << 8) |
+                                            ((uint32_t)clamp255(acc[r][2] >> a.vshift) << 16) | ((uint32_t)clamp255(acc[r][3] >> a.vshift) << 24);
+          if (a.blend) {
+            const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[t.tx0 + lane];
+            p = chroma_rgba(p, q, bf, nbf);
+          }
+          if (a.use_lut) p = lut3_rgba(s_lut, p);
+          reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[t.tx0 + lane] = p;
+        }
+      }
+    }
+  }
+  S2P_T(3)
+  if (a.dbg && lane == 0)          // [0] waiting at A, [1] horizontal pass, [2] waiting at B, [3] vertical pass + stores
+    for (int i = 0; i < 4; i++) a.dbg[((size_t)blockIdx.x * (kS2pCW + 2) + wave) * 8 + i] = tacc[i];
+#undef S2P_T
+}
+
+template <int NPH>
+__global__ __launch_bounds__(kS2pThreads, 3) void k_sep2p(SepArgs a, SepTracks trk, Lut8 lut) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const S2pLds L(a.sht, a.swt, a.th, a.npv, NPH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.use_lut) stage_lut(smem + L.lut, lut);
+  const int nwork = a.tiles_x * a.tiles_y * a.ntracks;
+  const int xcd = blockIdx.x & 7, wstride = (int)(gridDim.x >> 3), chunk = (nwork + 7) >> 3;
+  const int wend = min((xcd + 1) * chunk, nwork);
+  int work = xcd * chunk + (int)(blockIdx.x >> 3);
+  if (work >= wend) return;                                     // workgroup-uniform
+  if (wave < kS2pCW) { s2p_compute<NPH>(a, trk, smem, L, wave, lane, work, wend, wstride); return; }
+
+  // ------------------------------------------------ memory waves ------------------------------------------------
+  __builtin_amdgcn_s_setprio(3);
+  const int m = wave - kS2pCW;
+  const int cpr = a.swt >> 2, nchunks = a.sht * cpr, nreq = (nchunks + 63) >> 6;
+  const uint32_t mcpr = ((1u << 20) + (uint32_t)cpr - 1u) / (uint32_t)cpr;          // c / cpr == (c * mcpr) >> 20 for c < 3072, cpr >= 4
+  const uint32_t mnpv = ((1u << 16) + (uint32_t)a.npv) / (uint32_t)(a.npv + 1);     // i / (npv + 1) likewise for i < 256
+  // chunk 64 k + lane of an unclamped window sits at byte offset r * irow + 16 ch; stepping k by one moves (r, ch) by (64 / cpr, 64 % cpr)
+  const uint32_t r_l = ((uint32_t)lane * mcpr) >> 20, ch_l = (uint32_t)lane - r_l * (uint32_t)cpr;
+  const uint32_t off_l = r_l * (uint32_t)a.irow + ch_l * 16u;
+  const uint32_t dr = 64u / (uint32_t)cpr, dch = 64u - dr * (uint32_t)cpr;
+  const uint32_t doff = dr * (uint32_t)a.irow + dch * 16u, dwrap = (uint32_t)a.irow - (uint32_t)cpr * 16u;
+  // Everything a tile needs travels by LDS-DMA -- the window (16 bytes per lane and request) and its tables as RAW words (4 bytes per lane and
+  // request: hpos / tap pairs of the lane's column, vpos / tap pairs of the rows) -- so no load result lives in a register between the issue and
+  // the barrier that follows and the compiler has nothing to wait for there; the compute waves derive offsets from the raw words.  The window
+  // origin of the NEXT tile this wave will issue is fetched one step ahead (gx, gy).
+  int sx0a_f = 0;
+  auto geom = [&](int wk, int &gx, int &gy) {
+    S2pTile t;
+    t.set(a, wk);
+    gx = a.hpos[t.tx0]; gy = a.vpos[t.ty0];
+  };
+  auto issue = [&](int wk, int slot, int gx, int gy) {
+    S2pTile t;
+    t.set(a, wk);
+    const int tw = min(kTileW, a.dw - t.tx0), thh = min(a.th, a.dh - t.ty0);
+    const int sx0a = gx & ~3, sy0 = gy & ~1;
+    uint8_t *win = smem + slot * L.win;
+    const uint8_t *src = trk.src[t.track];
+    const bool inside = sx0a >= 0 && sx0a + a.swt <= a.sw && sy0 >= 0 && sy0 + a.sht <= a.sh;
+    if (inside) {
+      const uint8_t *base = src + ((uint32_t)sy0 * (uint32_t)a.irow + (uint32_t)sx0a * 4u);
+      uint32_t off = off_l, ch = ch_l;
+      for (int k = 0; k < nreq; k++) {
+        if (k * 64 + lane < nchunks) __builtin_amdgcn_global_load_lds((h8s_gptr)(base + off), (h8s_lptr)(win + k * 1024), 16, 0, 0);
+        ch += dch; off += doff;
+        if (ch >= (uint32_t)cpr) { ch -= (uint32_t)cpr; off += dwrap; }
+      }
+    } else s2p_issue_border(a.sw, a.sh, a.irow, a.swt, src, sx0a, sy0, lane, win, nreq, nchunks, mcpr);
+    const int ox = t.tx0 + (lane < tw ? lane : tw - 1);
+    uint8_t *hc = smem + L.hc + slot * L.hcslot, *vc = smem + L.vc + slot * L.vcslot;
+    __builtin_amdgcn_global_load_lds((h8s_gptr)(a.hpos + ox), (h8s_lptr)hc, 4, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NPH; j++) __builtin_amdgcn_global_load_lds((h8s_gptr)(a.hco2 + ((size_t)ox * NPH + j)), (h8s_lptr)(hc + (1 + j) * 256), 4, 0, 0);
+    const int nvc = thh * (a.npv + 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q * 64 < nvc) {                                        // wave-uniform
+        const int i = q * 64 + lane;
+        const int ly = (int)(((uint32_t)i * mnpv) >> 16), j = i - ly * (a.npv + 1);
+        const uint32_t *g = j ? a.vco2 + ((size_t)(t.ty0 + ly) * a.npv + (j - 1)) : reinterpret_cast<const uint32_t *>(a.vpos + (t.ty0 + ly));
+        if (i < nvc) __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(vc + q * 256), 4, 0, 0);
+      }
+    }
+    sx0a_f = sx0a;
+  };
+  auto land = [&](int slot) {                                    // my window in flight has to be complete before the barrier that publishes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sx0a_f < 0 || sx0a_f + a.swt > a.sw) s2p_fix_edges(smem + slot * L.win, sx0a_f, a.sw, a.swt, a.sht, lane);
+  };
+
+  // wave m starts on tile m of the list; wave 0 publishes tile 0 before A(0)
+  const int first = work + m * wstride;
+  int gx = 0, gy = 0;
+  if (first < wend) {
+    geom(first, gx, gy);
+    issue(first, m, gx, gy);
+    if (first + 2 * wstride < wend) geom(first + 2 * wstride, gx, gy);
+  }
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define S2P_T(i) if (a.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
+  if (m == 0) land(0);
+  S2P_T(1)
+  int i = 0;
+  for (; work < wend; work += wstride, i++) {
+    H8S_BARRIER();                                                                   // A(i)
+    S2P_T(0)
+    if (((i + 1) & 1) == m && work + wstride < wend) land((i + 1) & 1);
+    S2P_T(1)
+    H8S_BARRIER();                                                                   // B(i)
+    S2P_T(2)
+    if ((i & 1) == m && work + 2 * wstride < wend) {
+      issue(work + 2 * wstride, i & 1, gx, gy);
+      if (work + 4 * wstride < wend) geom(work + 4 * wstride, gx, gy);
+    }
+    S2P_T(3)
+  }
+  if (a.dbg && lane == 0)          // [0] waiting at A, [1] waiting for the window + fix-up, [2] waiting at B, [3] issuing
+    for (int k = 0; k < 4; k++) a.dbg[((size_t)blockIdx.x * (kS2pCW + 2) + wave) * 8 + k] = tacc[k];
+#undef S2P_T
+}
+
 // ---- generic two-launch path: any pixel size (bytes are independent channels), global int16 scratch ----
 __global__ __launch_bounds__(kBlock) void k_hpass_generic(const uint8_t *src, int irow, int sw, int sh, int16_t *tmp, int dw,
                                                            int psize, const int32_t *pos, const int16_t *co, int nt, int round, int shift) {
@@ -1463,12 +1748,18 @@ struct SepPlan {
   SepArgs a;
   size_t lds;
   dim3 grid;
-  int variant;   // 0 generic taps, 1 = (8,8), 2 = (5,5), 3 = (4,4), 4 = (2,2), 5 = (6,6)
+  int variant;   // 0 generic taps, 1 = (8,8), 2 = (5,5), 3 = (4,4), 4 = (2,2), 5 = (6,6); 100 + nph: k_sep2
+  // k_sep2p (persistent workgroups, prefetched windows) for the same taps: its own tile height / window rows; taken at launch when the source rows
+  // are 16-byte aligned
+  bool pers = false;
+  int p_th = 0, p_sht = 0, p_tiles_y = 0;
+  size_t p_lds = 0;
 };
 
 static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, int dw, int dh, int orow, int ntracks,
                     int hround, int hshift, int vround, int vshift, SepPlan *p) {
   SepArgs &a = p->a;
+  a.dbg = nullptr; a.ntracks = ntracks; a.hco2 = a.vco2 = nullptr; a.nph = a.npv = 0;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
   a.hpos = hb->pos; a.hco = hb->co; a.nth = hb->nt;
   a.vpos = vb->pos; a.vco = vb->co; a.ntv = vb->nt;
@@ -1490,7 +1781,7 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
   // k_sep2 (dot2 on both passes): tap pair counts with an instantiation, windows that leave two workgroups per CU
   static const bool no_sep2 = getenv("LGPU_NO_SEP2") != nullptr;
   const int nph = hb->nph;
-  if (!no_sep2 && (nph == 1 || nph == 2 || nph == 3 || nph == 4 || nph == 6 || nph == 8 || nph == 12) && vb->nt <= 64) {
+  if (!no_sep2 && (nph == 1 || nph == 2 || nph == 3 || nph == 4 || nph == 5 || nph == 6 || nph == 7 || nph == 8 || nph == 10 || nph == 12) && vb->nt <= 64) {
     SepArgs b = a;
     b.hco2 = hb->co2h; b.vco2 = vb->co2v; b.nph = nph; b.npv = vb->npv;
     // the padded last tap pair reads one pixel further, rows come in even-aligned pairs
@@ -1501,17 +1792,19 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
       if (span > swt2) swt2 = span;
     }
     b.swt = (swt2 + 3) & ~3;
-    // tile height: 16 rows, 32 when enlarging (small windows: taller tiles amortise a workgroup's three phases; measured 29.8 against 33.9 us for
-    // 1080p -> 4K, profiles/r02/resize_ratios.md)
-    for (int th2 = dh > sh ? 32 : 16;; th2 >>= 1) {
+    auto window_rows = [&](int th2) {
       int sht2 = 0;
       for (int t0 = 0; t0 < dh; t0 += th2) {
         const int t1 = (t0 + th2 < dh ? t0 + th2 : dh) - 1;
         const int span = ((vb->hpos[t1] + vb->nt - (vb->hpos[t0] & ~1)) + 1) & ~1;
         if (span > sht2) sht2 = span;
       }
-      // the parity-shifted tap layout may touch one row pair past the last tap
-      sht2 += 2;
+      return sht2 + 2;       // the parity-shifted tap layout may touch one row pair past the last tap
+    };
+    // tile height: 16 rows, 32 when enlarging (small windows: taller tiles amortise a workgroup's three phases; measured 29.8 against 33.9 us for
+    // 1080p -> 4K, profiles/r02/resize_ratios.md)
+    for (int th2 = dh > sh ? 32 : 16;; th2 >>= 1) {
+      const int sht2 = window_rows(th2);
       const size_t lds2 = (size_t)sht2 * b.swt * 4 + (size_t)(sht2 >> 1) * kTileW * 16 + 256 + (size_t)th2 * (vb->npv + 1) * 4;
       if (lds2 <= 80 * 1024 || th2 == 1) {
         if (lds2 <= 160 * 1024) {
@@ -1523,6 +1816,19 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
           p->variant = 100 + nph;
         }
         break;
+      }
+    }
+    // k_sep2p: two window slots + double-buffered tables must leave two workgroups per CU; a window is at most kS2pMaxReq DMA requests
+    const bool no_sep2p = getenv("LGPU_NO_SEP2P") != nullptr;
+    static const int th_force = getenv("LGPU_SEP2P_TH") ? atoi(getenv("LGPU_SEP2P_TH")) : 0;
+    if (p->variant >= 100 && !no_sep2p && (sw & 3) == 0) {
+      for (int th2 = th_force ? th_force : dh > sh ? 32 : 16; th2 >= 1; th2 >>= 1) {
+        const int sht2 = window_rows(th2);
+        const S2pLds L(sht2, a.swt, th2, vb->npv, nph);
+        if (L.total <= 80 * 1024 && sht2 * (a.swt >> 2) <= kS2pMaxReq * 64 && th2 * (vb->npv + 1) <= 256 && vb->npv <= kS2pMaxNpv) {
+          p->pers = true; p->p_th = th2; p->p_sht = sht2; p->p_tiles_y = (dh + th2 - 1) / th2; p->p_lds = L.total;
+          break;
+        }
       }
     }
   }
@@ -1543,13 +1849,65 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
       LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
     hipLaunchKernelGGL((k_sep2<N>), p.grid, blk, p.lds, st, p.a, t, l);                                      \
   } while (0)
+  const bool s2p_force = getenv("LGPU_SEP2P_FORCE") != nullptr;          // tests: the persistent kernel on small frames
+  // k_sep2p pays when a workgroup gets a few tiles to pipeline and the windows are the heavy part (shrinking); measured in profiles/r02/resize_ratios.md
+  if (p.pers && p.a.vec && p.variant >= 100 &&
+      (s2p_force || (p.a.dh < p.a.sh && (long)p.a.tiles_x * p.p_tiles_y * (long)p.grid.y >= 3L * 512))) {
+    SepArgs ap = p.a;
+    ap.th = p.p_th; ap.sht = p.p_sht; ap.tiles_y = p.p_tiles_y; ap.ntracks = (int)p.grid.y;
+    static int g_cus = 0;
+    if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
+    const int nwork = ap.tiles_x * ap.tiles_y * ap.ntracks;
+    int g = (nwork + 7) & ~7;
+    if (g > 2 * g_cus) g = (2 * g_cus) & ~7;
+    if (g < 8) g = 8;
+    static const bool s2p_dbg = getenv("LGPU_S2P_DEBUG") != nullptr;
+    ap.dbg = nullptr;
+    if (s2p_dbg) { LGPU_HIP(hipMalloc((void **)&ap.dbg, (size_t)g * 6 * 8 * 8)); LGPU_HIP(hipMemsetAsync(ap.dbg, 0, (size_t)g * 6 * 8 * 8, st)); }
+#define SEP2P_LAUNCH(N)                                                                                      \
+  do {                                                                                                       \
+    if (p.p_lds > 48 * 1024)                                                                                 \
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2p<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.p_lds)); \
+    hipLaunchKernelGGL((k_sep2p<N>), dim3((unsigned)g), dim3(kS2pThreads), p.p_lds, st, ap, t, l);            \
+  } while (0)
+    switch (p.variant) {
+    case 101: SEP2P_LAUNCH(1); break;
+    case 102: SEP2P_LAUNCH(2); break;
+    case 103: SEP2P_LAUNCH(3); break;
+    case 104: SEP2P_LAUNCH(4); break;
+    case 105: SEP2P_LAUNCH(5); break;
+    case 106: SEP2P_LAUNCH(6); break;
+    case 107: SEP2P_LAUNCH(7); break;
+    case 108: SEP2P_LAUNCH(8); break;
+    case 110: SEP2P_LAUNCH(10); break;
+    default: SEP2P_LAUNCH(12); break;
+    }
+#undef SEP2P_LAUNCH
+    LGPU_CHECK_LAUNCH();
+    if (s2p_dbg) {           // debugging aid: mean cycles (100 MHz s_memtime ticks) per phase over the workgroups, compute wave 0 and the two memory waves
+      std::vector<unsigned long long> h((size_t)g * 48);
+      LGPU_HIP(hipStreamSynchronize(st));
+      LGPU_HIP(hipMemcpy(h.data(), ap.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      LGPU_HIP(hipFree(ap.dbg));
+      double acc[3][4] = {{0}};
+      for (int b = 0; b < g; b++)
+        for (int k = 0; k < 4; k++) { acc[0][k] += (double)h[((size_t)b * 6 + 0) * 8 + k]; acc[1][k] += (double)h[((size_t)b * 6 + 4) * 8 + k]; acc[2][k] += (double)h[((size_t)b * 6 + 5) * 8 + k]; }
+      fprintf(stderr, "k_sep2p<%d> grid %d th %d sht %d swt %d tiles %d lds %zu | compute w0: A %.0f H %.0f B %.0f V %.0f | mem w4: A %.0f land %.0f B %.0f issue %.0f | mem w5: A %.0f land %.0f B %.0f issue %.0f (ticks of 10 ns, mean per workgroup)\n",
+              p.variant - 100, g, ap.th, ap.sht, ap.swt, nwork, p.p_lds, acc[0][0] / g, acc[0][1] / g, acc[0][2] / g, acc[0][3] / g, acc[1][0] / g, acc[1][1] / g, acc[1][2] / g,
+              acc[1][3] / g, acc[2][0] / g, acc[2][1] / g, acc[2][2] / g, acc[2][3] / g);
+    }
+    return LGPU_OK;
+  }
   switch (p.variant) {
   case 101: SEP2_LAUNCH(1); break;
   case 102: SEP2_LAUNCH(2); break;
   case 103: SEP2_LAUNCH(3); break;
   case 104: SEP2_LAUNCH(4); break;
+  case 105: SEP2_LAUNCH(5); break;
   case 106: SEP2_LAUNCH(6); break;
+  case 107: SEP2_LAUNCH(7); break;
   case 108: SEP2_LAUNCH(8); break;
+  case 110: SEP2_LAUNCH(10); break;
   case 112: SEP2_LAUNCH(12); break;
   case 1: SEP_LAUNCH(8, 8); break;
   case 2: SEP_LAUNCH(5, 5); break;

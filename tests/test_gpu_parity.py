@@ -784,6 +784,39 @@ def test_resize(gpu, orc, psize):
         assert_same(host(d), want, dw, dh, psize, "resize %dx%d->%dx%d interp=%d ps=%d" % (sw, sh, dw, dh, interp, psize))
 
 
+def test_resize_persistent_kernel(gpu, orc, monkeypatch):
+    """k_sep2p (persistent workgroups, windows and tables prefetched by LDS-DMA; taken by default for large shrinking launches) forced on small
+    frames: same bytes as the oracle for shrinking, enlarging and mixed ratios, windows that cross every frame border, partial tiles, one tile
+    per workgroup and several, and -- through the chain -- several tracks per launch with the byte swap, the blend and the gamma LUT"""
+    monkeypatch.setenv("LGPU_SEP2P_FORCE", "1")
+    rng = np.random.default_rng(1050)
+    cases = [(384, 216, 128, 72, 3), (256, 144, 512, 288, 3), (192, 108, 128, 72, 3), (640, 360, 212, 120, 3), (128, 64, 64, 32, 2), (400, 300, 100, 75, 3),
+             (1920, 1080, 1280, 720, 3), (1280, 720, 1920, 1080, 3), (3840, 2160, 1280, 720, 3), (64, 32, 128, 64, 3), (100, 60, 36, 24, 3), (16, 16, 4, 4, 3),
+             (3840, 40, 480, 8, 3), (64, 2160, 16, 720, 2)]
+    for (sw, sh, dw, dh, interp) in cases:
+        src = frame(rng, sw, sh, 4)
+        want = np.zeros((dh, align(dw * 4)), np.uint8)
+        assert orc.orc_resize(P(src), src.strides[0], sw, sh, P(want), want.strides[0], dw, dh, 4, interp) == 0
+        d = dev(np.zeros_like(want))
+        gpu.resize(dev(src), d, sw, sh, dw, dh, psize=4, interp=interp)
+        assert_same(host(d), want, dw, dh, 4, "resize (k_sep2p) %dx%d->%dx%d interp=%d" % (sw, sh, dw, dh, interp))
+    lut = lut_for(rng, "l2s")
+    for (sw, sh, dw, dh, swap, bf, ntr, use_lut) in [(384, 216, 128, 72, 1, 90, 3, 1), (320, 200, 200, 120, 0, 255, 2, 0), (200, 120, 320, 200, 1, 17, 5, 1)]:
+        srcs = [frame(rng, sw, sh, 4) for _ in range(ntr)]
+        l2s = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(ntr)]
+        orow = align(dw * 4)
+        wants = []
+        for i in range(ntr):
+            w_ = np.zeros((dh, orow), np.uint8)
+            assert orc.orc_chain(P(srcs[i]), srcs[i].strides[0], sw, sh, P(l2s[i]), l2s[i].strides[0], P(w_), orow, dw, dh, swap, 3, 0, bf, P(lut) if use_lut else None) == 0
+            wants.append(w_)
+        dd = [dev(np.zeros((dh, orow), np.uint8)) for _ in range(ntr)]
+        prm = gpu.chain_params(sw, sh, srcs[0].strides[0], dw, dh, l2s[0].strides[0], orow, swap_rb=swap, interp=3, do_blur=0, bf=bf, lut=lut if use_lut else None)
+        gpu.chain(prm, gpu.chain_tracks([dev(s_) for s_ in srcs], [dev(s_) for s_ in l2s], dd))
+        for i in range(ntr):
+            assert_same(host(dd[i]), wants[i], dw, dh, 4, "chain (k_sep2p) %dx%d->%dx%d track %d" % (sw, sh, dw, dh, i))
+
+
 @pytest.mark.parametrize("psize", [4, 3, 1])
 def test_gauss5(gpu, orc, psize):
     rng = np.random.default_rng(1100 + psize)
