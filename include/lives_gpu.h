@@ -219,7 +219,13 @@ int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4]
    (equal plane strides) / 888 / 8888 / (compact rows) 420P / 422P.  LGPU_E_UNSUPPORTED for every other pair or layout: there the
    reference function overruns its buffers, mixes up its strides or leaves a result that depends on what the destination
    held before (DESIGN.md "YUV -> YUV"), and the caller keeps its CPU body.  Bytes the reference does not write are not
-   written.  clamping_unclamped picks the chroma averaging table (init_average :190-216). */
+   written.  clamping_unclamped picks the chroma averaging table (init_average :190-216).
+   K5c, the 4:1:1 pairs (palette 595; width in pixels, a multiple of 4): YUV411 -> 888 / 8888 / 444P / 4444P / UYVY / YUYV / 422P / 420P / YVU420P
+   (src/colourspace.c:8622-9146) and 444P / 4444P / UYVY / YUYV / 888 / 8888 / 420P / 422P -> YUV411 (:7755-7798, :7973-8033, :8272-8303, :9148-9196).
+   The reference functions take no destination rowstride and walk their 4:1:1 side as one stream: here too both sides are COMPACT STREAMS from the
+   start of each plane and irow / orow are ignored, except irow[0] for the planar / packed 4:4:4 sources whose functions take one.  Their quirks
+   are kept (DESIGN.md K5c-*): 4:4:4 planar -> 4:1:1 leaves only the frame's last macropixel, in the first slot; packed 4:4:4 -> 4:1:1 converts the rows
+   that begin within the first width * height bytes; YUV411 -> 4:2:0 leaves all chroma in chroma row 0. */
 int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4],
                     const int orow[4], int width, int height, int clamping_unclamped, int sampling_jpeg, void *stream);
 /* "softlight": lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV (palette 544 YUV444P, 545 YUVA4444P,

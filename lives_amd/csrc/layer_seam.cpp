@@ -502,7 +502,8 @@ int *lives_gpu_calc_rowstrides(int width, int pal, lives_gpu_layer_t *layer, int
 static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, int outpl, int iclamping, int flags) {
   const int inpl = l.pal;
   const bool inpk = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV), outpk = (outpl == WEED_PALETTE_UYVY || outpl == WEED_PALETTE_YUYV);
-  const int width = inpk ? l.width * 2 : l.width, height = l.height;              // pixels
+  const bool in411 = inpl == WEED_PALETTE_YUV411, out411 = outpl == WEED_PALETTE_YUV411;
+  const int width = inpk ? l.width * 2 : in411 ? l.width * 4 : l.width, height = l.height;              // pixels
   if (width < 1 || height < 1) return decline(layer);
   const int unclamped = iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0;
   const uint8_t *dsrc[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -523,7 +524,11 @@ static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, i
   for (int p = 0; p < l.nplanes; p++) { dsrc[p] = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p == 3 ? 7 : p); irs[p] = l.rs[p]; }
   if (!w.ok) return 0;
   if (inpl == WEED_PALETTE_YVU420P) { const uint8_t *t = dsrc[1]; dsrc[1] = dsrc[2]; dsrc[2] = t; const int r = irs[1]; irs[1] = irs[2]; irs[2] = r; }
-  const int lwidth = outpk ? width >> 1 : width;
+  // K5c, the 4:1:1 pairs (:13024-13029 ..., :13793-13846): the new layer gets its ordinary (aligned, zeroed) planes and the reference functions then walk
+  // them as compact streams; lgpu_yuv_repack does the same
+  if ((in411 || out411) && (width & 3)) return decline(layer);
+  if (in411 && (outpl == WEED_PALETTE_YUV420P || outpl == WEED_PALETTE_YVU420P) && (height & 1)) return decline(layer);
+  const int lwidth = outpk ? width >> 1 : out411 ? width >> 2 : width;
   NewPlanes np;
   if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
   for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }
@@ -534,7 +539,7 @@ static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, i
   if (outpl == WEED_PALETTE_YVU420P) { uint8_t *t = np.pd[1]; np.pd[1] = np.pd[2]; np.pd[2] = t; }   // swap_chroma_planes (:13890)
   commit_planes(layer, outpl, lwidth, height, np);
   if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
-  if (outpl == WEED_PALETTE_YUV420P || outpl == WEED_PALETTE_YVU420P) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);   // :13022
+  if ((outpl == WEED_PALETTE_YUV420P || outpl == WEED_PALETTE_YVU420P) && !in411) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);   // :13022
   return 1;
 }
 

@@ -327,6 +327,145 @@ enum RepackKind {
   RK_COMBINE, RK_SPLIT, RK_COPY444, RK_SWAB, RK_420_TO_PK, RK_420_TO_422P, RK_444_TO_420, RK_444_TO_PK, RK_PK_TO_444, RK_PK_TO_888,
   RK_PK_TO_420, RK_888_TO_420, RK_888_TO_422, RK_PK_TO_422P
 };
+// ---- K5c: YUV411 <-> the other YUV palettes (src/colourspace.c:7755-7798, :7973-8033, :8272-8303, :8622-9196) ---------------------------------
+// Every one of the reference functions walks its 4:1:1 side -- and, where it takes no rowstride, the other side too -- as ONE compact stream from
+// the start of the plane; so do these (what that means for a layer with padded rows is the reference's behaviour, byte for byte).  Closed forms of
+// the serial walks; quirks kept: the duplicated lumas of the planar 4:4:4 / packed 4:2:2 targets, all chroma rows of the 4:2:0 target landing in
+// chroma row 0 whose first sample folds a whole row, planar 4:4:4 -> 4:1:1 overwriting its first macropixel, packed 4:4:4 -> 4:1:1 stopping after
+// width * height BYTES.  Macropixel bytes: u2 y0 y1 v2 y2 y3.
+enum { K411_TO_888 = 1, K411_TO_444, K411_TO_PK, K411_TO_422P, K411_TO_420, K411_FROM_PK, K411_FROM_888, K411_FROM_420, K411_FROM_444 };
+struct R411Args {
+  const uint8_t *src[4];
+  uint8_t *dst[4];
+  int irow;                  // source rowstride where the reference function takes one (planar / packed 4:4:4 sources)
+  int width, height, kind;   // width in pixels
+  int alpha;                 // 4-byte packed pixels / alpha plane on the non-4:1:1 side
+  int yuyv;                  // byte order of the packed 4:2:2 side
+  int is422;                 // K411_FROM_420: the source is 4:2:2 planar
+  int clamped;
+  int rows;                  // K411_FROM_888: rows that begin before byte width * height
+};
+// chroma of the two output pixels of block j that lean on the PREVIOUS block (pixels 4j, 4j+1) / on the NEXT block (4j+2, 4j+3): the
+// three-deep cascade of :8650-8716 (h = the blocks' mean, q = h re-averaged with the nearer block, then with either block)
+__device__ __forceinline__ void c411_fine_pair(int cl, int a, int b, int near_b, int &o0, int &o1) {   // a = block j-1 (or j), b = block j (or j+1)
+  const int q = cavg(cl, cavg(cl, a, b), near_b ? b : a);
+  o0 = cavg(cl, q, a); o1 = cavg(cl, q, b);
+}
+__global__ __launch_bounds__(kBlock) void k_yuv411_repack(R411Args a) {
+  const int wm = a.width >> 2, cl = a.clamped;
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (a.kind == K411_FROM_444) {                             // one macropixel: the last one of the frame, written over the first
+    if (j || blockIdx.y) return;
+    const int r = a.height - 1, jj = wm - 1;
+    const uint8_t *sy = a.src[0] + (size_t)r * a.width + 4 * jj, *su = a.src[1] + (size_t)r * a.irow + 4 * jj, *sv = a.src[2] + (size_t)r * a.irow + 4 * jj;
+    uint8_t *m = a.dst[0];
+    m[0] = (uint8_t)cavg(cl, cavg(cl, su[0], su[1]), cavg(cl, su[2], su[3])); m[1] = sy[0]; m[2] = sy[1];
+    m[3] = (uint8_t)cavg(cl, cavg(cl, sv[0], sv[1]), cavg(cl, sv[2], sv[3])); m[4] = sy[2]; m[5] = sy[3];
+    return;
+  }
+  if (j >= wm) return;
+  for (int r = blockIdx.y; r < a.height; r += gridDim.y) {
+    if (a.kind >= K411_FROM_PK) {                            // ---- something -> 4:1:1: lane = destination macropixel (r, j)
+      uint8_t *m = a.dst[0] + ((size_t)r * wm + j) * 6;
+      if (a.kind == K411_FROM_PK) {
+        const uint8_t *p = a.src[0] + ((size_t)r * wm + j) * 8, *q = p + 4;
+        const int uo = a.yuyv ? 1 : 0, vo = a.yuyv ? 3 : 2, ya = a.yuyv ? 0 : 1, yb = a.yuyv ? 2 : 3;
+        m[0] = (uint8_t)cavg(cl, p[uo], q[uo]); m[1] = p[ya]; m[2] = p[yb];
+        m[3] = (uint8_t)cavg(cl, p[vo], q[vo]); m[4] = q[ya]; m[5] = q[yb];
+      } else if (a.kind == K411_FROM_888) {
+        if (r >= a.rows) return;
+        const int ips = a.alpha ? 4 : 3;
+        const uint8_t *p = a.src[0] + (size_t)r * a.irow + (size_t)4 * j * ips;
+        m[0] = (uint8_t)((p[1] + p[ips + 1] + p[2 * ips + 1] + p[3 * ips + 1]) >> 2); m[1] = p[0]; m[2] = p[ips];
+        m[3] = (uint8_t)((p[2] + p[ips + 2] + p[2 * ips + 2] + p[3 * ips + 2]) >> 2); m[4] = p[2 * ips]; m[5] = p[3 * ips];
+      } else {                                               // K411_FROM_420 (compact planes)
+        const int hw = a.width >> 1;
+        const uint8_t *sy = a.src[0] + (size_t)r * a.width + 4 * j;
+        const size_t c0 = (size_t)(a.is422 ? r : r >> 1) * hw + 2 * j;
+        int u = cavg(cl, a.src[1][c0], a.src[1][c0 + 1]), v = cavg(cl, a.src[2][c0], a.src[2][c0 + 1]);
+        if (!a.is422 && (r & 1) && r + 1 < a.height) {       // odd rows below the last take the mean with the row that follows (:9179-9182)
+          const size_t c1 = (size_t)((r + 1) >> 1) * hw + 2 * j;
+          u = cavg(cl, u, cavg(cl, a.src[1][c1], a.src[1][c1 + 1])); v = cavg(cl, v, cavg(cl, a.src[2][c1], a.src[2][c1 + 1]));
+        }
+        m[0] = (uint8_t)u; m[1] = sy[0]; m[2] = sy[1]; m[3] = (uint8_t)v; m[4] = sy[2]; m[5] = sy[3];
+      }
+      continue;
+    }
+    // ---- 4:1:1 -> something: lane = source block j of row r, it owns output pixels 4j .. 4j+3 (macropixels 2j, 2j+1)
+    const uint8_t *cb = a.src[0] + ((size_t)r * wm + j) * 6;
+    const int cu = cb[0], cv = cb[3];
+    const int y0 = cb[1], y1 = cb[2], y2 = cb[4], y3 = cb[5];
+    const bool first = j == 0, last = j == wm - 1;
+    const int pu = first ? cu : cb[-6], pv = first ? cv : cb[-3], nu = last ? cu : cb[6], nv = last ? cv : cb[9];
+    if (a.kind == K411_TO_888 || a.kind == K411_TO_444) {
+      int u[4], v[4];
+      if (first) { u[0] = u[1] = cu; v[0] = v[1] = cv; }
+      else { c411_fine_pair(cl, pu, cu, 1, u[0], u[1]); c411_fine_pair(cl, pv, cv, 1, v[0], v[1]); }
+      if (last) { u[2] = u[3] = cu; v[2] = v[3] = cv; }
+      else { c411_fine_pair(cl, cu, nu, 0, u[2], u[3]); c411_fine_pair(cl, cv, nv, 0, v[2], v[3]); }
+      if (a.kind == K411_TO_888) {
+        const int ps = a.alpha ? 4 : 3;
+        uint8_t *d = a.dst[0] + ((size_t)r * a.width + 4 * j) * ps;
+        const int yy[4] = {y0, y1, y2, y3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { d[k * ps] = (uint8_t)yy[k]; d[k * ps + 1] = (uint8_t)u[k]; d[k * ps + 2] = (uint8_t)v[k]; if (ps == 4) d[k * ps + 3] = 255; }
+      } else {
+        const size_t o = (size_t)r * a.width + 4 * j;
+        const int yy[4] = {y0, y0, y2, last ? y3 : y2};        // :8751-8756, :8789-8818: the second luma of a pair repeats the first, except in the row's last pair
+        const uint32_t yw = (uint32_t)yy[0] | ((uint32_t)yy[1] << 8) | ((uint32_t)yy[2] << 16) | ((uint32_t)yy[3] << 24);
+        const uint32_t uw = (uint32_t)u[0] | ((uint32_t)u[1] << 8) | ((uint32_t)u[2] << 16) | ((uint32_t)u[3] << 24);
+        const uint32_t vw = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        if (first && !last) {}                                  // (nothing special: block 0's first pair is y0 y0 as well, :8751-8756)
+        uint8_t *dy = a.dst[0] + o, *du = a.dst[1] + o, *dv = a.dst[2] + o;
+        for (int k = 0; k < 4; k++) { dy[k] = (uint8_t)(yw >> (8 * k)); du[k] = (uint8_t)(uw >> (8 * k)); dv[k] = (uint8_t)(vw >> (8 * k)); }
+        if (a.alpha) { uint8_t *da = a.dst[3] + o; da[0] = da[1] = da[2] = da[3] = 255; }
+      }
+      continue;
+    }
+    // the two-deep chroma of the 4:2:2 / 4:2:0 targets: macropixel 2j leans on the previous block, 2j+1 on the next
+    const int u0 = first ? cu : cavg(cl, cavg(cl, pu, cu), cu), v0 = first ? cv : cavg(cl, cavg(cl, pv, cv), cv);
+    const int u1 = last ? cu : cavg(cl, cavg(cl, cu, nu), cu), v1 = last ? cv : cavg(cl, cavg(cl, cv, nv), cv);
+    if (a.kind == K411_TO_PK) {
+      uint8_t *d = a.dst[0] + ((size_t)r * wm + j) * 8;
+      const int a0 = y0, b0 = first ? y1 : y0, a1 = y2, b1 = last ? y3 : y2;      // inner macropixels carry one luma twice (:8875-8878, :8893-8896)
+      if (!a.yuyv) { d[0] = (uint8_t)u0; d[1] = (uint8_t)a0; d[2] = (uint8_t)v0; d[3] = (uint8_t)b0; d[4] = (uint8_t)u1; d[5] = (uint8_t)a1; d[6] = (uint8_t)v1; d[7] = (uint8_t)b1; }
+      else { d[0] = (uint8_t)a0; d[1] = (uint8_t)u0; d[2] = (uint8_t)b0; d[3] = (uint8_t)v0; d[4] = (uint8_t)a1; d[5] = (uint8_t)u1; d[6] = (uint8_t)b1; d[7] = (uint8_t)v1; }
+      continue;
+    }
+    uint8_t *dy = a.dst[0] + (size_t)r * a.width + 4 * j;
+    dy[0] = (uint8_t)y0; dy[1] = (uint8_t)y1; dy[2] = (uint8_t)y2; dy[3] = (uint8_t)y3;
+    if (a.kind == K411_TO_422P) {
+      uint8_t *du = a.dst[1] + (size_t)r * 2 * wm + 2 * j, *dv = a.dst[2] + (size_t)r * 2 * wm + 2 * j;
+      du[0] = (uint8_t)u0; du[1] = (uint8_t)u1; dv[0] = (uint8_t)v0; dv[1] = (uint8_t)v1;
+    } else if (r == ((a.height - 1) & ~1)) {
+      // K411_TO_420 (:9062-9141): every even row is written to chroma row 0 and the pointers step back, so only the last even row survives
+      // there (its first sample is then folded with the whole last odd row by k_yuv411_420_fold)
+      a.dst[1][2 * j] = (uint8_t)u0; a.dst[1][2 * j + 1] = (uint8_t)u1; a.dst[2][2 * j] = (uint8_t)v0; a.dst[2][2 * j + 1] = (uint8_t)v1;
+    }
+  }
+}
+// YUV411 -> 4:2:0, the odd row after the last even one: each of its 2 wm chroma samples is averaged INTO THE FIRST sample of chroma row 0, in order
+// (the destination pointer is not advanced on odd rows, :9071-9073, :9096-9098, :9113-9115, :9134-9136).  A serial fold by one lane per plane.
+__global__ void k_yuv411_420_fold(const uint8_t *src, int wm, int row, uint8_t *du, uint8_t *dv, int cl) {
+  const int off = threadIdx.x ? 3 : 0;                     // lane 0: U, lane 1: V
+  uint8_t *d = threadIdx.x ? dv : du;
+  if (threadIdx.x > 1) return;
+  const uint8_t *rp = src + (size_t)row * wm * 6;
+  int acc = d[0];
+  for (int m = 0; m < 2 * wm; m++) {
+    int c;
+    if (m == 0) c = rp[off];
+    else if (m == 2 * wm - 1) c = rp[(size_t)(wm - 1) * 6 + off];
+    else {
+      const int j = (m + 1) >> 1, k = (m + 1) & 1;
+      const int p = rp[(size_t)(j - 1) * 6 + off], q = rp[(size_t)j * 6 + off];
+      c = cavg(cl, cavg(cl, p, q), k ? q : p);
+    }
+    acc = cavg(cl, acc, c);
+  }
+  d[0] = (uint8_t)acc;
+}
+
 struct RepackArgs {
   const uint8_t *src[4];
   uint8_t *dst[4];
@@ -687,6 +826,52 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
   // the K1 pair: convert_addpost_frame / convert_delpost_frame
   if (in_pal == P_888 && out_pal == P_8888) return lgpu_swizzle(LGPU_ADDPOST, 0, src_d[0], irow[0], dst_d[0], orow[0], width, height, nullptr, stream);
   if (in_pal == P_8888 && out_pal == P_888) return lgpu_swizzle(LGPU_DELPOST, 0, src_d[0], irow[0], dst_d[0], orow[0], width, height, nullptr, stream);
+  if (in_pal == 595 || out_pal == 595) {
+    // K5c: the 4:1:1 pairs (compact streams on both sides, see k_yuv411_repack)
+    if (in_pal == out_pal) return unsupported("nothing to convert");
+    if (width < 4 || (width & 3)) return unsupported("YUV411 pairs need a width that is a multiple of 4 pixels");
+    lgpu::R411Args r = {};
+    r.width = width; r.height = height; r.clamped = clamping_unclamped ? 0 : 1; r.irow = irow[0];
+    const int other = in_pal == 595 ? out_pal : in_pal;
+    int nin = 1, nout = 1;
+    r.yuyv = (other == P_YUYV); r.alpha = (other == P_8888 || other == P_4444);
+    if (in_pal == 595) {
+      switch (out_pal) {
+      case P_888: case P_8888: r.kind = lgpu::K411_TO_888; break;
+      case P_444: case P_4444: r.kind = lgpu::K411_TO_444; nout = r.alpha ? 4 : 3; break;
+      case P_UYVY: case P_YUYV: r.kind = lgpu::K411_TO_PK; break;
+      case P_422: r.kind = lgpu::K411_TO_422P; nout = 3; break;
+      case P_420: case P_YV12: r.kind = lgpu::K411_TO_420; nout = 3; break;
+      default: return unsupported("YUV411 -> this palette does not exist in the reference either");
+      }
+    } else {
+      switch (in_pal) {
+      case P_444: case P_4444: r.kind = lgpu::K411_FROM_444; nin = 3; break;
+      case P_UYVY: case P_YUYV: r.kind = lgpu::K411_FROM_PK; break;
+      case P_888: case P_8888: {
+        r.kind = lgpu::K411_FROM_888;
+        LGPU_REQUIRE(irow[0] >= width * (r.alpha ? 4 : 3), "source rowstride smaller than a row");
+        const size_t lim = (size_t)width * height;               // the end pointer is width * height BYTES past the start (:8277)
+        r.rows = (int)((lim + (size_t)irow[0] - 1) / (size_t)irow[0]);
+        if (r.rows > height) r.rows = height;
+        break;
+      }
+      case P_420: case P_YV12: case P_422:
+        if (in_pal != P_422 && (height & 1)) return unsupported("a 4:2:0 source has an even height");
+        r.kind = lgpu::K411_FROM_420; r.is422 = (in_pal == P_422); nin = 3; break;
+      default: return unsupported("this palette -> YUV411 does not exist in the reference either");
+      }
+    }
+    for (int i = 0; i < nin; i++) { LGPU_REQUIRE(src_d[i], "null source plane"); r.src[i] = src_d[i]; }
+    for (int i = 0; i < nout; i++) { LGPU_REQUIRE(dst_d[i], "null destination plane"); r.dst[i] = dst_d[i]; }
+    if (out_pal == P_YV12) { uint8_t *t = r.dst[1]; r.dst[1] = r.dst[2]; r.dst[2] = t; }       // is_yvu (:9055-9061)
+    const dim3 grid(cdiv((unsigned)(width >> 2), kBlock), (unsigned)(height < 2048 ? height : 2048));
+    hipLaunchKernelGGL(lgpu::k_yuv411_repack, grid, dim3(kBlock), 0, st, r);
+    if (r.kind == lgpu::K411_TO_420 && height >= 2 && !(height & 1))
+      hipLaunchKernelGGL(lgpu::k_yuv411_420_fold, dim3(1), dim3(64), 0, st, r.src[0], width >> 2, height - 1, r.dst[1], r.dst[2], r.clamped);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
   lgpu::RepackArgs a = {};
   a.width = width; a.height = height; a.clamped = clamping_unclamped ? 0 : 1;
   a.yuyv_in = (in_pal == P_YUYV); a.yuyv_out = (out_pal == P_YUYV);

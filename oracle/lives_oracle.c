@@ -1446,9 +1446,166 @@ static void copy_rows(const uint8_t *s, int irow, uint8_t *d, int orow, int nbyt
   for (int y = 0; y < rows; y++) memcpy(d + (size_t)y * orow, s + (size_t)y * irow, (size_t)nbytes);
 }
 
+/* ---- YUV411 <-> the other YUV palettes (src/colourspace.c:7755-7796, :7973-8033, :8272-8303, :8622-9146, :9148-9196; dispatcher :13024-13029,
+ * :13223-13228, :13323-13328, :13416-13421, :13508-13513, :13636-13641, :13743-13748, :13793-13846).  `width` is in PIXELS (a multiple of 4).
+ * Every one of these walks its 4:1:1 side -- and, where it has no rowstride argument, the other side too -- as one compact stream from the start of
+ * the plane, whatever rowstride the layer has: restated the same way (a strided destination "drifts" exactly like the reference's).  Bytes the
+ * reference does not write are not written here.  Macropixel bytes: u2 y0 y1 v2 y2 y3. */
+enum { P_411 = 595 };
+/* chroma of output pixel p (0 .. 4 wm - 1) of one row: the three-deep average cascade between neighbouring blocks (:8650-8716) */
+static int c411_fine(int cl, const uint8_t *row, int wm, int p, int off) {
+  if (p < 2) return row[off];
+  if (p >= 4 * wm - 2) return row[(size_t)(wm - 1) * 6 + off];
+  const int j = (p + 2) >> 2, k = (p + 2) & 3;
+  const int pu = row[(size_t)(j - 1) * 6 + off], cu = row[(size_t)j * 6 + off];
+  const int h = orc_cavg(cl, pu, cu), q = orc_cavg(cl, h, k < 2 ? pu : cu);
+  return orc_cavg(cl, q, (k & 1) ? cu : pu);
+}
+/* chroma of output macropixel m (0 .. 2 wm - 1): the two-deep form of the 4:2:2 targets (:8860-8895, :9001-9024) */
+static int c411_half(int cl, const uint8_t *row, int wm, int m, int off) {
+  if (m == 0) return row[off];
+  if (m == 2 * wm - 1) return row[(size_t)(wm - 1) * 6 + off];
+  const int j = (m + 1) >> 1, k = (m + 1) & 1;
+  const int pu = row[(size_t)(j - 1) * 6 + off], cu = row[(size_t)j * 6 + off];
+  return orc_cavg(cl, orc_cavg(cl, pu, cu), k ? cu : pu);
+}
+static int y411(const uint8_t *row, int p) { static const int yo[4] = {1, 2, 4, 5}; return row[(size_t)(p >> 2) * 6 + yo[p & 3]]; }
+
+static int orc_yuv411_repack(int in_pal, int out_pal, const uint8_t *const src[4], const int irow[4], uint8_t *const dst[4], int width, int height, int cl) {
+  if (width < 4 || (width & 3) || height < 1) return -1;
+  const int wm = width >> 2;
+  if (in_pal == P_411) {
+    const uint8_t *s = src[0];
+    if (out_pal == P_888 || out_pal == P_8888) {                 /* convert_yuv411_to_yuv888_frame :8622-8736 */
+      const int ps = out_pal == P_8888 ? 4 : 3;
+      for (int r = 0; r < height; r++) {
+        const uint8_t *row = s + (size_t)r * wm * 6;
+        uint8_t *d = dst[0] + (size_t)r * width * ps;
+        for (int p = 0; p < width; p++) {
+          d[p * ps] = (uint8_t)y411(row, p); d[p * ps + 1] = (uint8_t)c411_fine(cl, row, wm, p, 0); d[p * ps + 2] = (uint8_t)c411_fine(cl, row, wm, p, 3);
+          if (ps == 4) d[p * ps + 3] = 255;
+        }
+      }
+      return 0;
+    }
+    if (out_pal == P_444 || out_pal == P_4444) {                 /* convert_yuv411_to_yuvp_frame :8739-8838: the second luma of every pair but the last is the first one again */
+      for (int r = 0; r < height; r++) {
+        const uint8_t *row = s + (size_t)r * wm * 6;
+        const size_t o = (size_t)r * width;
+        for (int p = 0; p < width; p++) {
+          dst[0][o + p] = (uint8_t)y411(row, p >= width - 2 ? p : (p & ~1));
+          dst[1][o + p] = (uint8_t)c411_fine(cl, row, wm, p, 0); dst[2][o + p] = (uint8_t)c411_fine(cl, row, wm, p, 3);
+          if (out_pal == P_4444) dst[3][o + p] = 255;
+        }
+      }
+      return 0;
+    }
+    if (out_pal == P_UYVY || out_pal == P_YUYV) {                /* :8842-8979: inner macropixels carry one luma twice */
+      for (int r = 0; r < height; r++) {
+        const uint8_t *row = s + (size_t)r * wm * 6;
+        uint8_t *d = dst[0] + (size_t)r * width * 2;
+        for (int m = 0; m < 2 * wm; m++) {
+          const int inner = m > 0 && m < 2 * wm - 1;
+          const int ya = y411(row, 2 * m), yb = inner ? ya : y411(row, 2 * m + 1);
+          const int u = c411_half(cl, row, wm, m, 0), v = c411_half(cl, row, wm, m, 3);
+          if (out_pal == P_UYVY) { d[4 * m] = (uint8_t)u; d[4 * m + 1] = (uint8_t)ya; d[4 * m + 2] = (uint8_t)v; d[4 * m + 3] = (uint8_t)yb; }
+          else { d[4 * m] = (uint8_t)ya; d[4 * m + 1] = (uint8_t)u; d[4 * m + 2] = (uint8_t)yb; d[4 * m + 3] = (uint8_t)v; }
+        }
+      }
+      return 0;
+    }
+    if (out_pal == P_422) {                                      /* convert_yuv411_to_yuv422_frame :8982-9036 */
+      for (int r = 0; r < height; r++) {
+        const uint8_t *row = s + (size_t)r * wm * 6;
+        for (int p = 0; p < width; p++) dst[0][(size_t)r * width + p] = (uint8_t)y411(row, p);
+        for (int m = 0; m < 2 * wm; m++) {
+          dst[1][(size_t)r * 2 * wm + m] = (uint8_t)c411_half(cl, row, wm, m, 0);
+          dst[2][(size_t)r * 2 * wm + m] = (uint8_t)c411_half(cl, row, wm, m, 3);
+        }
+      }
+      return 0;
+    }
+    if (out_pal == P_420 || out_pal == P_YV12) {
+      /* convert_yuv411_to_yuv420_frame :9039-9146: after an even row the chroma pointers go back to where they were, and on the odd row every
+         sample is averaged into *d_u WITHOUT advancing it: all rows land in chroma row 0, whose first sample collects the whole odd row */
+      uint8_t *du = dst[out_pal == P_YV12 ? 2 : 1], *dv = dst[out_pal == P_YV12 ? 1 : 2];
+      for (int r = 0; r < height; r++) {
+        const uint8_t *row = s + (size_t)r * wm * 6;
+        for (int p = 0; p < width; p++) dst[0][(size_t)r * width + p] = (uint8_t)y411(row, p);
+        for (int m = 0; m < 2 * wm; m++) {
+          const int u = c411_half(cl, row, wm, m, 0), v = c411_half(cl, row, wm, m, 3);
+          if (!(r & 1)) { du[m] = (uint8_t)u; dv[m] = (uint8_t)v; }
+          else { du[0] = (uint8_t)orc_cavg(cl, du[0], u); dv[0] = (uint8_t)orc_cavg(cl, dv[0], v); }
+        }
+      }
+      return 0;
+    }
+    return -1;
+  }
+  if (out_pal != P_411) return -1;
+  uint8_t *d = dst[0];
+  if (in_pal == P_444 || in_pal == P_4444) {
+    /* convert_yuvp_to_yuv411_frame :7755-7796: the destination pointer is never advanced, so every macropixel is written over the FIRST one and the
+       frame ends up holding only the last one there; the Y pointer never skips the row padding either */
+    const int r = height - 1, j = wm - 1;
+    const uint8_t *sy = src[0] + (size_t)r * width + 4 * j, *su = src[1] + (size_t)r * irow[0] + 4 * j, *sv = src[2] + (size_t)r * irow[0] + 4 * j;
+    d[0] = (uint8_t)orc_cavg(cl, orc_cavg(cl, su[0], su[1]), orc_cavg(cl, su[2], su[3]));
+    d[1] = sy[0]; d[2] = sy[1];
+    d[3] = (uint8_t)orc_cavg(cl, orc_cavg(cl, sv[0], sv[1]), orc_cavg(cl, sv[2], sv[3]));
+    d[4] = sy[2]; d[5] = sy[3];
+    return 0;
+  }
+  if (in_pal == P_UYVY || in_pal == P_YUYV) {                    /* :7973-8033: no rowstride argument, the source is one stream */
+    const int uo = in_pal == P_UYVY ? 0 : 1, vo = in_pal == P_UYVY ? 2 : 3, ya = in_pal == P_UYVY ? 1 : 0, yb = in_pal == P_UYVY ? 3 : 2;
+    for (size_t k = 0; k < (size_t)wm * height; k++) {
+      const uint8_t *a = src[0] + k * 8, *b = a + 4;
+      uint8_t *m = d + k * 6;
+      m[0] = (uint8_t)orc_cavg(cl, a[uo], b[uo]); m[1] = a[ya]; m[2] = a[yb];
+      m[3] = (uint8_t)orc_cavg(cl, a[vo], b[vo]); m[4] = b[ya]; m[5] = b[yb];
+    }
+    return 0;
+  }
+  if (in_pal == P_888 || in_pal == P_8888) {
+    /* convert_yuv888_to_yuv411_frame :8272-8303: the end pointer is width * height BYTES past the start, tested once per row: only the rows that
+       begin before it are converted; chroma is the plain mean of the four samples (no table) */
+    const int ips = in_pal == P_8888 ? 4 : 3;
+    for (int r = 0; (size_t)r * irow[0] < (size_t)width * height && r < height; r++)
+      for (int j = 0; j < wm; j++) {
+        const uint8_t *p = src[0] + (size_t)r * irow[0] + (size_t)4 * j * ips;
+        uint8_t *m = d + ((size_t)r * wm + j) * 6;
+        m[0] = (uint8_t)((p[1] + p[ips + 1] + p[2 * ips + 1] + p[3 * ips + 1]) >> 2);
+        m[1] = p[0]; m[2] = p[ips];
+        m[3] = (uint8_t)((p[2] + p[ips + 2] + p[2 * ips + 2] + p[3 * ips + 2]) >> 2);
+        m[4] = p[2 * ips]; m[5] = p[3 * ips];
+      }
+    return 0;
+  }
+  if (in_pal == P_420 || in_pal == P_YV12 || in_pal == P_422) {
+    /* convert_yuv420_to_yuv411_frame :9148-9196 (compact planes): chroma = average of two neighbouring samples of the row's chroma row; for 4:2:0 every
+       odd row below the last is then averaged with the row that follows it (:9179-9182) */
+    const int is422 = in_pal == P_422, hw = width >> 1;
+    const uint8_t *pu = src[1], *pv = src[2];              /* a YVU420P layer arrives with its chroma pointers swapped by the caller, like every 4:2:0 source */
+    for (int r = 0; r < height; r++)
+      for (int j = 0; j < wm; j++) {
+        const uint8_t *sy = src[0] + (size_t)r * width + 4 * j;
+        const size_t c0 = (size_t)(is422 ? r : r >> 1) * hw + 2 * j;
+        int u = orc_cavg(cl, pu[c0], pu[c0 + 1]), v = orc_cavg(cl, pv[c0], pv[c0 + 1]);
+        if (!is422 && (r & 1) && r + 1 < height) {
+          const size_t c1 = (size_t)((r + 1) >> 1) * hw + 2 * j;
+          u = orc_cavg(cl, u, orc_cavg(cl, pu[c1], pu[c1 + 1])); v = orc_cavg(cl, v, orc_cavg(cl, pv[c1], pv[c1 + 1]));
+        }
+        uint8_t *m = d + ((size_t)r * wm + j) * 6;
+        m[0] = (uint8_t)u; m[1] = sy[0]; m[2] = sy[1]; m[3] = (uint8_t)v; m[4] = sy[2]; m[5] = sy[3];
+      }
+    return 0;
+  }
+  return -1;
+}
+
 int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const int irow[4], uint8_t *const dst[4], const int orow[4],
                    int width, int height, int clamping_unclamped, int sampling_jpeg) {
   const int cl = !clamping_unclamped;               /* set_conversion_arrays(clamping, YCBCR): cavg = cavgc when clamped */
+  if (in_pal == P_411 || out_pal == P_411) return orc_yuv411_repack(in_pal, out_pal, src, irow, dst, width, height, cl);
   const int in444 = (in_pal == P_444 || in_pal == P_4444), in420 = (in_pal == P_420 || in_pal == P_YV12);
   const int inpk422 = (in_pal == P_UYVY || in_pal == P_YUYV);
   if (width < 1 || height < 1) return -1;

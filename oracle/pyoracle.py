@@ -300,6 +300,7 @@ YUV_PLANE_DIMS = {
     512: lambda w, h: [(w, h), (w >> 1, h >> 1), (w >> 1, h >> 1)], 513: lambda w, h: [(w, h), (w >> 1, h >> 1), (w >> 1, h >> 1)],
     522: lambda w, h: [(w, h), (w >> 1, h), (w >> 1, h)], 544: lambda w, h: [(w, h)] * 3, 545: lambda w, h: [(w, h)] * 4,
     564: lambda w, h: [(w * 2, h)], 565: lambda w, h: [(w * 2, h)], 588: lambda w, h: [(w * 3, h)], 589: lambda w, h: [(w * 4, h)],
+    595: lambda w, h: [((w >> 2) * 6, h)],
 }
 
 
@@ -319,3 +320,7 @@ YUV_REPACK_PAIRS = [(544, 588, 1), (544, 589, 1), (545, 588, 1), (545, 589, 1), 
                     (564, 545, 1), (564, 588, 1), (565, 588, 1), (564, 589, 1), (565, 589, 1), (564, 512, 0), (565, 512, 0),
                     (588, 512, 0), (589, 512, 0), (588, 522, 0), (589, 522, 0), (588, 564, 0), (588, 565, 0), (589, 564, 0), (589, 565, 0),
                     (564, 522, 0), (565, 522, 0)]
+# the 4:1:1 pairs (width in pixels, a multiple of 4): every one of them walks its buffers as compact streams; padded rows are allowed where the reference
+# function takes a source rowstride (planar 4:4:4 and packed 4:4:4 sources)
+YUV411_REPACK_PAIRS = [(595, 588, 0), (595, 589, 0), (595, 544, 0), (595, 545, 0), (595, 564, 0), (595, 565, 0), (595, 522, 0), (595, 512, 0), (595, 513, 0),
+                       (544, 595, 1), (545, 595, 1), (564, 595, 0), (565, 595, 0), (588, 595, 1), (589, 595, 1), (512, 595, 0), (522, 595, 0)]

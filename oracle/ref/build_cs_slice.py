@@ -250,6 +250,36 @@ int csref_yuv_repack(int in_pal, int out_pal, uint8_t **src, int *irows_in, uint
   memcpy(irows, irows_in, sizeof(irows)); memcpy(orows, orows_in, sizeof(orows));
   ensure_tables();
   avg_chromaf = avg_chromaf_fast;
+  /* K5c: the 4:1:1 pairs; width in pixels, the dispatcher hands macropixels (:13793-13846) resp. pixels (:13024-13029 ...) */
+  if (in_pal == 595) {
+    yuv411_macropixel *s = (yuv411_macropixel *)src[0];
+    const int wm = width >> 2;
+    switch (out_pal) {
+    case 588: convert_yuv411_to_yuv888_frame(s, wm, height, dst[0], FALSE, clamping); return 0;
+    case 589: convert_yuv411_to_yuv888_frame(s, wm, height, dst[0], TRUE, clamping); return 0;
+    case 544: convert_yuv411_to_yuvp_frame(s, wm, height, dst, FALSE, clamping); return 0;
+    case 545: convert_yuv411_to_yuvp_frame(s, wm, height, dst, TRUE, clamping); return 0;
+    case 564: convert_yuv411_to_uyvy_frame(s, wm, height, (uyvy_macropixel *)dst[0], clamping); return 0;
+    case 565: convert_yuv411_to_yuyv_frame(s, wm, height, (yuyv_macropixel *)dst[0], clamping); return 0;
+    case 522: convert_yuv411_to_yuv422_frame(s, wm, height, dst, clamping); return 0;
+    case 512: convert_yuv411_to_yuv420_frame(s, wm, height, dst, FALSE, clamping); return 0;
+    case 513: convert_yuv411_to_yuv420_frame(s, wm, height, dst, TRUE, clamping); return 0;
+    }
+    return -1;
+  }
+  if (out_pal == 595) {
+    yuv411_macropixel *d = (yuv411_macropixel *)dst[0];
+    if (in444) { convert_yuvp_to_yuv411_frame(src, width, height, irows[0], d, clamping); return 0; }
+    if (in_pal == 564) { convert_uyvy_to_yuv411_frame((uyvy_macropixel *)src[0], width >> 1, height, d, clamping); return 0; }
+    if (in_pal == 565) { convert_yuyv_to_yuv411_frame((yuyv_macropixel *)src[0], width >> 1, height, d, clamping); return 0; }
+    if (in_pal == 588 || in_pal == 589) {
+      set_conversion_arrays(clamping, WEED_YUV_SUBSPACE_YCBCR);
+      convert_yuv888_to_yuv411_frame(src[0], width, height, irows[0], d, in_pal == 589);
+      return 0;
+    }
+    if (in420 || in_pal == 522) { convert_yuv420_to_yuv411_frame(src, width, height, d, in_pal == 522, clamping); return 0; }
+    return -1;
+  }
   if (in444 && (out_pal == 588 || out_pal == 589)) { convert_combineplanes_frame(src, width, height, irows[0], orows[0], dst[0], in_pal == 545, out_pal == 589); return 0; }
   if (in_pal == 588 && out_pal == 544) { convert_splitplanes_frame(src[0], width, height, irows[0], orows, dst, FALSE, FALSE); return 0; }
   if (in_pal == 545 && out_pal == 544) { convert_yuvap_to_yuvp_frame(src, width, height, irows[0], orows[0], dst); return 0; }
@@ -419,6 +449,10 @@ def main():
     parts.append(lines(cs, 2322, 2343))             # K4b: rgb2_411
     parts.append(lines(cs, 6499, 6615))             # K4b: rgb / bgr / argb -> yuv411
     parts.append(lines(cs, 8305, 8620))             # K3b: yuv411 -> rgb / bgr / argb
+    parts.append(lines(cs, 7755, 7798))             # K5c: yuv(a)444p -> yuv411
+    parts.append(lines(cs, 7973, 8033))             # K5c: uyvy / yuyv -> yuv411
+    parts.append(lines(cs, 8272, 8303))             # K5c: yuv(a)888(8) -> yuv411
+    parts.append(lines(cs, 8622, 9196))             # K5c: yuv411 -> yuv(a)888(8) / yuv(a)444p / uyvy / yuyv / yuv422p / yuv420p, yuv420p / yuv422p -> yuv411
     parts.append(lines(cs, 9198, 9257))             # K5b: convert_splitplanes_frame
     parts.append(lines(cs, 10578, 10639))           # K5b: convert_halve_chroma, convert_double_chroma
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family

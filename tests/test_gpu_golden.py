@@ -298,6 +298,20 @@ def test_yuv_repack_vs_reference(gpu):
             assert (host(dst[i]) == a).all(), "%s plane %d" % (rec, i)
 
 
+def test_yuv411_repack_vs_reference(gpu):
+    g = gu.load("yuv411_repack.npz")
+    for rec in map(str, g["records"]):
+        _, ip, op, unc, pad, w, h = rec.split("|")
+        ip, op, unc, pad, w, h = int(ip), int(op), int(unc), int(pad), int(w), int(h)
+        nin, nout = len(po.YUV_PLANE_DIMS[ip](w, h)), len(po.YUV_PLANE_DIMS[op](w, h))
+        src = [dev(g[rec + "|i%d" % i]) for i in range(nin)]
+        want = [g[rec + "|o%d" % i] for i in range(nout)]
+        dst = [dev(np.full_like(a, 0x5A)) for a in want]
+        gpu.yuv_repack(ip, op, src, dst, w, h, unc)
+        for i, a in enumerate(want):
+            assert (host(dst[i]) == a).all(), "%s plane %d" % (rec, i)
+
+
 def test_deinterlace_vs_reference_plugin(gpu):
     g = gu.load("deinterlace.npz")
     for rec in map(str, g["records"]):

@@ -635,6 +635,30 @@ def test_yuv_repack(gpu, orc, pair):
                     assert (host(dst[i]) == a).all(), "repack %d->%d %dx%d unclamped=%d pad=%d plane %d" % (ip, op, w, h, unc, pad, i)
 
 
+@pytest.mark.parametrize("pair", po.YUV411_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
+def test_yuv411_repack(gpu, orc, pair):
+    """K5c: YUV411 <-> YUV888 / YUVA8888 / YUV444P / YUVA4444P / UYVY / YUYV / YUV422P / YUV420P / YVU420P (:7755-7798, :7973-8033, :8272-8303,
+    :8622-9196), compact streams on both sides as in the reference, at sizes from one macropixel per row to 1080p"""
+    import ctypes
+    ip, op, padok = pair
+    rng = np.random.default_rng(2700 + ip * 7 + op)
+    sizes = [(4, 2), (8, 6), (64, 34), (132, 18), (320, 200), (1920, 1080)]
+    if op in (512, 513):
+        sizes += [(16, 5), (16, 1)]                     # odd heights: the last even row has no odd row to fold
+    for (w, h) in sizes:
+        for unc in (0, 1):
+            for pad in ((0, 24) if padok else (0,)):
+                src = po.yuv_planes(ip, w, h, rng=rng, pad=pad)
+                want = po.yuv_planes(op, w, h + ((h & 1) if op in (512, 513) else 0), fill=0x5A, pad=0)
+                sp, ss = po.planes_args(src)
+                wp, ws = po.planes_args(want)
+                assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, unc, 0) == 0
+                dst = [dev(np.full_like(a, 0x5A)) for a in want]
+                gpu.yuv_repack(ip, op, [dev(a) for a in src], dst, w, h, unc)
+                for i, a in enumerate(want):
+                    assert (host(dst[i]) == a).all(), "repack %d->%d %dx%d unclamped=%d pad=%d plane %d" % (ip, op, w, h, unc, pad, i)
+
+
 def test_yuv_repack_declines(gpu):
     from lives_amd.lib import LgpuError
     w, h = 16, 8

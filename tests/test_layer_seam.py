@@ -442,6 +442,43 @@ def test_yuv_layers_repack(seam, orc):
 
 @needs_ref
 @pytest.mark.gpu
+@pytest.mark.parametrize("w", [64, 72])
+def test_yuv411_layers_repack(seam, orc, w):
+    """K5c through the layer seam (:13024-13029 ..., :13793-13846): YUV411 <-> the other YUV palettes.  The reference allocates the new layer with its ordinary
+    aligned rowstrides and then walks it -- and the 4:1:1 side -- as compact streams; with w = 72 neither side's rows are compact, so the rows "drift"
+    exactly as they do there (the oracle is handed the same strided, zeroed planes and writes the same stream)"""
+    L, wh = seam
+    rng = np.random.default_rng(89 + w)
+    h = 12
+    for (ip, op, _) in po.YUV411_REPACK_PAIRS:
+        for clamp in (0, 1):
+            dims_in = po.YUV_PLANE_DIMS[ip](w, h)
+            planes = [rng.integers(0, 256, (b, align(a)), dtype=np.uint8) for (a, b) in dims_in]
+            if ip in (512, 513, 522):
+                planes[1] = planes[1][:, :align(dims_in[0][0]) >> 1].copy(); planes[2] = planes[2][:, :align(dims_in[0][0]) >> 1].copy()   # rs[1] = rs[0] >> 1
+            lw = w >> 1 if ip in (564, 565) else w >> 2 if ip == 595 else w
+            lay = wh.new_layer(ip, lw, h, [a.copy() for a in planes], clamping=clamp, subspace=1)
+            assert L.lives_gpu_convert_layer_palette_full(lay, op, clamp, 0, 1, 0) == 1, (ip, op)
+            got, _, rs = wh.planes_of(lay)
+            dims = po.YUV_PLANE_DIMS[op](w, h)
+            want = [np.zeros((b, r), np.uint8) for (a, b), r in zip(dims, rs)]
+            sp, ss = po.planes_args(planes)
+            wp, ws = po.planes_args(want)
+            assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, clamp, 0) == 0
+            if op == 513:
+                got = [got[0], got[2], got[1]]              # swap_chroma_planes (:13890) after the is_yvu walk
+            for i in range(len(dims)):
+                assert (got[i] == want[i]).all(), (ip, op, clamp, i)
+            assert wh.geti(lay, "current_palette") == op and wh.geti(lay, "YUV_clamping") == clamp
+            assert wh.geti(lay, "width") == (w >> 1 if op in (564, 565) else w >> 2 if op == 595 else w) and wh.geti(lay, "height") == h
+    lay = wh.new_layer(595, 5, h, [rng.integers(0, 256, (h, 32), dtype=np.uint8)], clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette_full(lay, 512, 0, 0, 1, 0) == 1        # 5 macropixels = 20 pixels: still a multiple of 4
+    lay = wh.new_layer(595, 4, 7, [rng.integers(0, 256, (7, 32), dtype=np.uint8)], clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette_full(lay, 512, 0, 0, 1, 0) == 0 and wh.geti(lay, "current_palette") == 595      # odd height: declined
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_yuv_layer_clamping_switch(seam, orc):
     """convert_layer_palette_full(layer, same palette, other clamping, same subspace) = in-place range switch (:12241-12247)"""
     L, wh = seam

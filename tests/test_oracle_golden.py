@@ -350,6 +350,24 @@ def test_yuv_repack(orc):
             assert (got[i] == a).all(), "%s plane %d" % (rec, i)
 
 
+def test_yuv411_repack(orc):
+    """YUV411 <-> the other YUV palettes against the reference slice fixtures (:7755-7798, :7973-8033, :8272-8303, :8622-9196)"""
+    import ctypes
+    g = gu.load("yuv411_repack.npz")
+    for rec in map(str, g["records"]):
+        _, ip, op, unc, pad, w, h = rec.split("|")
+        ip, op, unc, w, h = int(ip), int(op), int(unc), int(w), int(h)
+        nin, nout = len(po.YUV_PLANE_DIMS[ip](w, h)), len(po.YUV_PLANE_DIMS[op](w, h))
+        src = [np.ascontiguousarray(g[rec + "|i%d" % i]) for i in range(nin)]
+        want = [g[rec + "|o%d" % i] for i in range(nout)]
+        got = [np.full_like(a, 0x5A) for a in want]
+        sp, ss = po.planes_args(src)
+        gp, gs = po.planes_args(got)
+        assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(gp), ctypes.addressof(gs), w, h, unc, 0) == 0
+        for i, a in enumerate(want):
+            assert (got[i] == a).all(), "%s plane %d" % (rec, i)
+
+
 def test_deinterlace(orc):
     g = gu.load("deinterlace.npz")
     for rec in map(str, g["records"]):

@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -159,6 +159,22 @@ def main():
                 dst = [dev(np.full_like(a, 0x5A)) for a in want]
                 ops.yuv_repack(ip, op, [dev(a) for a in src], dst, w, h, unc)
                 ok = all(same(host(dst[i]), want[i], want[i].shape[1], want[i].shape[0], "repack %d->%d %dx%d pad=%d unc=%d plane %d" % (ip, op, w, h, pad, unc, i)) for i in range(len(want)))
+            elif kind == "repack411":
+                ip, op, padok = po.YUV411_REPACK_PAIRS[int(rng.integers(0, len(po.YUV411_REPACK_PAIRS)))]
+                w, h = 4 * int(rng.integers(1, 120)), int(rng.integers(1, 80))
+                if ip in (512, 513):
+                    h += h & 1
+                pad = int(rng.choice([0, 4, 24])) if padok else 0
+                unc = int(rng.integers(0, 2))
+                src = po.yuv_planes(ip, w, h, rng=rng, pad=pad)
+                want = po.yuv_planes(op, w, h + ((h & 1) if op in (512, 513) else 0), fill=0x5A, pad=0)
+                sp, ss = po.planes_args(src)
+                wp, ws = po.planes_args(want)
+                if orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, unc, 0) != 0:
+                    continue
+                dst = [dev(np.full_like(a, 0x5A)) for a in want]
+                ops.yuv_repack(ip, op, [dev(a) for a in src], dst, w, h, unc)
+                ok = all(same(host(dst[i]), want[i], want[i].shape[1], want[i].shape[0], "repack411 %d->%d %dx%d pad=%d unc=%d plane %d" % (ip, op, w, h, pad, unc, i)) for i in range(len(want)))
             elif kind == "deint":
                 pal = int(rng.choice([1, 2, 588, 3, 4, 589, 564, 565]))
                 ps = 3 if pal in (1, 2, 588) else 4
