@@ -184,6 +184,11 @@ int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int i
 int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
                     uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables,
                     void *stream);
+/* the same for out_fmt 2 (UYVY) / 3 (YUYV) with the 16-bit gamma LUT inline: rgb2uyvy_with_gamma / rgb2yuyv_with_gamma (src/colourspace.c:2146-2159, :2194-2207), what
+   those entry points run when convert_layer_palette_full changes the gamma on the way (:12565-12580, :12646-12660, :12722-12736, :12796-12810, :12869-12883).
+   lut16_d: the 65536 entries of lgpu_gamma_lut16() in device memory.  YCbCr tables only, as in the reference. */
+int lgpu_rgb_to_yuv_lut16(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d, int orow, int out_fmt,
+                          int clamping_unclamped, const uint16_t *lut16_d, void *stream);
 /* K3: YUV family -> packed RGB family (src/colourspace.c:2750-3258, :6616-7102, :7200-7498; pixel maths :2345-2459).
    in_fmt 0 packed YUV888 / YUVA8888 (in_alpha), 1 planar YUV444P / YUVA4444P (in_alpha), 2 UYVY, 3 YUYV (width in
    pixels); planar 4:2:0 / 4:2:2 sources: lgpu_yuv420p_to_rgb.  out_order 0 RGB, 1 BGR, 2 ARGB; out_alpha: 4-byte
@@ -220,6 +225,9 @@ int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4]
    reference function overruns its buffers, mixes up its strides or leaves a result that depends on what the destination
    held before (DESIGN.md "YUV -> YUV"), and the caller keeps its CPU body.  Bytes the reference does not write are not
    written.  clamping_unclamped picks the chroma averaging table (init_average :190-216).
+   K5d: 420P / YVU420P (chroma pointers in U, V order) / 422P -> 888 / 8888 (convert_quad_chroma_packed :10715-10808, convert_double_chroma_packed :10811-10873): the
+   only pairs that read `sampling` (the source's WEED_YUV_SAMPLING_*: 0 = JPEG / default -> plain means, else the 3:1 / 1:3 forms).  The destination must be the zeroed
+   frame create_empty_pixel_data() hands the reference: the last odd row's chroma and several alpha bytes are never written.  Even height for 4:2:0.
    K5c, the 4:1:1 pairs (palette 595; width in pixels, a multiple of 4): YUV411 -> 888 / 8888 / 444P / 4444P / UYVY / YUYV / 422P / 420P / YVU420P
    (src/colourspace.c:8622-9146) and 444P / 4444P / UYVY / YUYV / 888 / 8888 / 420P / 422P -> YUV411 (:7755-7798, :7973-8033, :8272-8303, :9148-9196).
    The reference functions take no destination rowstride and walk their 4:1:1 side as one stream: here too both sides are COMPACT STREAMS from the
@@ -227,7 +235,7 @@ int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int rowstrides[4]
    are kept (DESIGN.md K5c-*): 4:4:4 planar -> 4:1:1 leaves only the frame's last macropixel, in the first slot; packed 4:4:4 -> 4:1:1 converts the rows
    that begin within the first width * height bytes; YUV411 -> 4:2:0 leaves all chroma in chroma row 0. */
 int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4],
-                    const int orow[4], int width, int height, int clamping_unclamped, int sampling_jpeg, void *stream);
+                    const int orow[4], int width, int height, int clamping_unclamped, int sampling, void *stream);
 /* "softlight": lives-plugins/weed-plugins/softlight.c:62-141.  Planar YUV (palette 544 YUV444P, 545 YUVA4444P,
    522 YUV422P, 512 YUV420P, 513 YVU420P): gradient-magnitude highlight mixed into plane 0 (frame border copied), the
    other planes are copied.  unclamped != 0: luma range 0..255, else 16..235 (the channel's YUV_clamping leaf).

@@ -29,8 +29,9 @@
  *                                 src/colourspace.c:12370-12556, LUT8 gamma inline); YUV420P/YVU420P/YUV422P ->
  *                                 those five (:13400-13560, LUT16 gamma fused when a target gamma is given); RGB -> YUV888 /
  *                                 YUVA8888 / YUV(A)444(4)P / UYVY / YUYV / YUV411 / YUV420P / YVU420P / YUV422P and those packed / 4:4:4
- *                                 planar / UYVY / YUYV / YUV411 palettes -> RGB; the clamped <-> unclamped switch; the YUV -> YUV pairs of
- *                                 lgpu_yuv_repack (lives_gpu.h), YUV411 to and from the other YUV palettes included
+ *                                 planar / UYVY / YUYV / YUV411 palettes -> RGB (RGB -> YUV changes the gamma on the way as :12311-12332 decides: the 16-bit LUT inline for
+ *                                 UYVY / YUYV, a gamma pass first for the others); the clamped <-> unclamped switch; the YUV -> YUV pairs of
+ *                                 lgpu_yuv_repack (lives_gpu.h), YUV411 to and from the other YUV palettes and 4:2:0 / 4:2:2 planar -> YUV888 / YUVA8888 included
  *   gamma_convert_layer / _variant / gamma_convert_sub_layer, alpha_premult (RGB with alpha, YUVA8888, YUVA4444P), resize_layer / resize_layer_full
  *   (tgt_gamma = the fused LUT8 post-pass), letterbox_layer, unletterbox_layer (packed RGB palettes and YUV420P / YVU420P / YUV422P / YUV444P
  *   planes; palette hints see INTEGRATION.md), compact_rowstrides, create_empty_pixel_data, weed_layer_clear_pixel_data, calc_rowstrides (with the

@@ -406,9 +406,25 @@ lives_gpu_boolean rgb_layer_to_yuv411(weed_plant_t *layer, const Layer &l, int o
 }
 
 // K4 on a layer: the RGB24 / BGR24 / RGBA32 / BGRA32 / ARGB32 cases of src/colourspace.c:12559-12935 plus conv_done (:13860-13893)
-lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outpl, int oclamping, int osubspace, int tgt_gamma, int flags) {
-  // the LUT16 variants of these entry points (a target gamma that differs from the layer's) stay with the CPU body
-  if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != WEED_GAMMA_UNKNOWN && tgt_gamma != l.gamma) return decline(layer);
+const uint16_t *device_lut16(int from, int to);
+lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l_in, int outpl, int oclamping, int osubspace, int tgt_gamma, int flags) {
+  // gamma on the way (:12311-12332): an RGB layer of known gamma that goes to YUV ends up SRGB (BT709 for a BT.709 target subspace) unless the caller names a
+  // target.  The UYVY / YUYV entry points take the 16-bit LUT inline (can_inline_gamma :12136-12142, rgb2uyvy_with_gamma); for every other YUV palette the
+  // reference converts the layer's gamma first (gamma_convert_layer, :12326-12329) and then the palette
+  Layer l = l_in;
+  int new_gamma = WEED_GAMMA_UNKNOWN;
+  const bool inline_gamma = (outpl == WEED_PALETTE_UYVY || outpl == WEED_PALETTE_YUYV);
+  const uint16_t *lut16 = nullptr;
+  if (g_prefs.apply_gamma && l.gamma != WEED_GAMMA_UNKNOWN) {
+    new_gamma = tgt_gamma != WEED_GAMMA_UNKNOWN ? tgt_gamma : osubspace == WEED_YUV_SUBSPACE_BT709 ? WEED_GAMMA_BT709 : WEED_GAMMA_SRGB;
+    if (!inline_gamma) {
+      if (new_gamma != l.gamma && !lives_gpu_gamma_convert_layer(new_gamma, layer)) return decline(layer);
+      if (!read_layer(layer, &l)) return 0;
+      new_gamma = l.gamma;
+    } else if (new_gamma != l.gamma) {
+      lut16 = device_lut16(l.gamma, new_gamma);          // nullptr when create_gamma_lut makes none for the pair: the plain entry point runs, as in the reference
+    }
+  }
   if (outpl == WEED_PALETTE_YUV411) return rgb_layer_to_yuv411(layer, l, oclamping, flags);
   const int fmt = k4_fmt(outpl);
   if (fmt < 0) return decline(layer);
@@ -430,14 +446,19 @@ lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l, int outp
   uint8_t *ddst[4] = {nullptr, nullptr, nullptr, nullptr};
   int ors[4] = {0, 0, 0, 0};
   for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }   // calloc'd padding stays as the host made it
-  const bool ok = w.ok && lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr) == LGPU_OK && w.finish();
+  const bool ok = w.ok &&
+                  (lut16 ? lgpu_rgb_to_yuv_lut16(d_in, l.rs[0], width, height, order, in_alpha, ddst[0], ors[0], fmt, which & 1, lut16, nullptr)
+                         : lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr)) == LGPU_OK &&
+                  w.finish();
   if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
   if (outpl == WEED_PALETTE_YVU420P) { uint8_t *t = np.pd[1]; np.pd[1] = np.pd[2]; np.pd[2] = t; }   // swap_chroma_planes (:13890)
   commit_planes(layer, outpl, lwidth, height, np);
   if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
   set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);
-  set_int(layer, WEED_LEAF_YUV_SUBSPACE, l.gamma == WEED_GAMMA_BT709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR);
+  int final_gamma = l.gamma;
+  if (inline_gamma && new_gamma != WEED_GAMMA_UNKNOWN) { set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma); final_gamma = new_gamma; }      // :13873-13876
+  set_int(layer, WEED_LEAF_YUV_SUBSPACE, final_gamma == WEED_GAMMA_BT709 ? WEED_YUV_SUBSPACE_BT709 : WEED_YUV_SUBSPACE_YCBCR);              // :13884-13888
   if (fmt >= 4 || !has_leaf(layer, WEED_LEAF_YUV_SAMPLING)) set_int(layer, WEED_LEAF_YUV_SAMPLING, WEED_YUV_SAMPLING_DEFAULT);
   return 1;
 }
@@ -532,7 +553,7 @@ static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, i
   NewPlanes np;
   if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
   for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }
-  const int rc = w.ok ? lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, 0, nullptr) : LGPU_E_NOMEM;
+  const int rc = w.ok ? lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, l.sampling, nullptr) : LGPU_E_NOMEM;   // isampling: read by K5d only
   if (rc == LGPU_E_UNSUPPORTED) { drop_new_planes(np); return decline(layer); }
   if (rc != LGPU_OK || !w.finish()) { drop_new_planes(np); return 0; }
   free_planes(l);

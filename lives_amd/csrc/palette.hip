@@ -17,6 +17,7 @@ struct PalArgs {
   int order, alpha_in, fmt, alpha_out;
   int unclamped;
   const int32_t *tables;      // rgb2yuv [9][256] or yuv2rgb [5][256] of the selected (clamping, subspace)
+  const uint16_t *lut16;      // k_rgb_to_yuv, UYVY / YUYV only: create_gamma_lut's 65536 entries, applied inline (rgb2uyvy_with_gamma)
 };
 
 // ---- K4 -------------------------------------------------------------------------------------------------------------
@@ -31,6 +32,13 @@ struct R2Y {
   __device__ __forceinline__ int Uraw(int r, int g, int b) const { return (short)((t[768 + r] + t[1024 + g] + t[1280 + b]) >> 16); }
   __device__ __forceinline__ int Vraw(int r, int g, int b) const { return (short)((t[1536 + r] + t[1792 + g] + t[2048 + b]) >> 16); }
   __device__ __forceinline__ int cuv(int a) const { return a > max_uv ? max_uv : a < min_uv ? min_uv : a; }
+  // rgb2uyvy_with_gamma (:2146-2159): the table sum's top 16 bits index the LUT, the LUT's high byte is the sample
+  __device__ __forceinline__ int Yg(const uint16_t *l, int r, int g, int b) const {
+    const int a = l[((uint32_t)(t[r] + t[256 + g] + t[512 + b]) >> 8) & 0xFFFF] >> 8;
+    return a > max_y ? max_y : a < min_y ? min_y : a;
+  }
+  __device__ __forceinline__ int Ug(const uint16_t *l, int r, int g, int b) const { return cuv(l[((uint32_t)(t[768 + r] + t[1024 + g] + t[1280 + b]) >> 8) & 0xFFFF] >> 8); }
+  __device__ __forceinline__ int Vg(const uint16_t *l, int r, int g, int b) const { return cuv(l[((uint32_t)(t[1536 + r] + t[1792 + g] + t[2048 + b]) >> 8) & 0xFFFF] >> 8); }
 };
 
 // init_average (:190-216): cavgu is integer, cavgc mixes float and double exactly as written there
@@ -108,6 +116,14 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
     int r0, g0, b0, r1, g1, b1;
     load_rgb(s, ORDER, r0, g0, b0);
     load_rgb(s + ips, ORDER, r1, g1, b1);
+    if ((FMT == 2 || FMT == 3) && a.lut16) {
+      // the gamma twins clamp properly in both byte orders (rgb2yuyv_with_gamma :2194-2207 has the `else` rgb2yuyv lost)
+      const uint32_t gy0 = (uint32_t)c.Yg(a.lut16, r0, g0, b0), gy1 = (uint32_t)c.Yg(a.lut16, r1, g1, b1);
+      const uint32_t gu = (uint32_t)c.Ug(a.lut16, r0, g0, b0), gv = (uint32_t)c.Vg(a.lut16, r1, g1, b1);
+      *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + (size_t)px * 4) =
+          FMT == 2 ? (gu | (gy0 << 8) | (gv << 16) | (gy1 << 24)) : (gy0 | (gu << 8) | (gy1 << 16) | (gv << 24));
+      continue;
+    }
     const int y0 = c.Y(r0, g0, b0), y1 = c.Y(r1, g1, b1);
     if (FMT <= 1) {
       const int al0 = ORDER == 2 ? s[0] : ips == 4 ? s[3] : 255, al1 = ORDER == 2 ? s[ips] : ips == 4 ? s[ips + 3] : 255;
@@ -466,6 +482,61 @@ __global__ void k_yuv411_420_fold(const uint8_t *src, int wm, int row, uint8_t *
   d[0] = (uint8_t)acc;
 }
 
+// ---- K5d: 4:2:0 / 4:2:2 planar -> YUV888 / YUVA8888 (convert_quad_chroma_packed :10715-10808, convert_double_chroma_packed :10811-10873) -------------
+// lane = one pixel pair of one row.  Chroma is supersampled from the neighbouring samples of the row's chroma row (JPEG / default siting: plain means;
+// otherwise the 3:1 / 1:3 forms); the pair's second pixel reads sample k + 1 even for the row's last pair (the next chroma row's first sample; for the plane's
+// last row the index is clamped to the plane -- the reference reads past it).  4:2:0: even rows as above; odd row i (i <= height - 3) = mean of the even rows
+// around it, i.e. of two such supersampled values; the LAST odd row's chroma and the alpha of every odd row are not written.  4:2:2: the second pixel of
+// a pair never gets its alpha.  Bytes the reference does not write are not written.
+struct ChromaUpArgs {
+  const uint8_t *src[3];
+  uint8_t *dst;
+  int irow[3], orow;
+  int width, height;
+  int is420, alpha, jpeg, clamped;
+  unsigned ulast, vlast;       // last valid byte index of the chroma planes
+};
+__device__ __forceinline__ void chroma_up_pair(const ChromaUpArgs &a, int cr, int k, int &u_a, int &v_a, int &u_b, int &v_b) {
+  const int cl = a.clamped;
+  const unsigned ub = (unsigned)cr * (unsigned)a.irow[1] + (unsigned)k, vb = (unsigned)cr * (unsigned)a.irow[2] + (unsigned)k;
+  const int u0 = a.src[1][min(ub, a.ulast)], v0 = a.src[2][min(vb, a.vlast)], u1 = a.src[1][min(ub + 1, a.ulast)], v1 = a.src[2][min(vb + 1, a.vlast)];
+  if (k > 0) {
+    const int um = a.src[1][ub - 1], vm = a.src[2][vb - 1];
+    u_a = a.jpeg ? cavg(cl, um, u0) : cavg(cl, um, cavg(cl, um, u0));        // avg_chroma_3_1f
+    v_a = a.jpeg ? cavg(cl, vm, v0) : cavg(cl, cavg(cl, vm, v0), v0);        // avg_chroma_1_3f
+  } else { u_a = u0; v_a = v0; }
+  if (a.is420) {
+    u_b = a.jpeg ? cavg(cl, u0, u1) : cavg(cl, cavg(cl, u0, u1), u1);        // 1_3 for U, 3_1 for V (:10756-10757)
+    v_b = a.jpeg ? cavg(cl, v0, v1) : cavg(cl, v0, cavg(cl, v0, v1));
+  } else {
+    u_b = a.jpeg ? cavg(cl, u0, u1) : cavg(cl, u0, cavg(cl, u0, u1));        // the first pixel's forms again (:10862-10863)
+    v_b = a.jpeg ? cavg(cl, v0, v1) : cavg(cl, cavg(cl, v0, v1), v1);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_chroma_up_packed(ChromaUpArgs a) {
+  const int k = blockIdx.x * kBlock + threadIdx.x, hw = a.width >> 1, ps = a.alpha ? 4 : 3, cl = a.clamped;
+  if (k >= hw) return;
+  for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
+    uint8_t *p = a.dst + (size_t)i * a.orow + (size_t)2 * k * ps;
+    const uint8_t *sy = a.src[0] + (size_t)i * a.irow[0] + 2 * k;
+    p[0] = sy[0]; p[ps] = sy[1];
+    if (a.is420 && (i & 1)) {
+      if (i + 2 < a.height) {                                // mean of the even rows around it (:10766-10777)
+        int ua, va, ub, vb, uc, vc, ud, vd;
+        chroma_up_pair(a, (i - 1) >> 1, k, ua, va, ub, vb);
+        chroma_up_pair(a, (i + 1) >> 1, k, uc, vc, ud, vd);
+        p[1] = (uint8_t)cavg(cl, uc, ua); p[2] = (uint8_t)cavg(cl, vc, va);
+        p[ps + 1] = (uint8_t)cavg(cl, ud, ub); p[ps + 2] = (uint8_t)cavg(cl, vd, vb);
+      }
+      continue;
+    }
+    int ua, va, ub, vb;
+    chroma_up_pair(a, a.is420 ? i >> 1 : i, k, ua, va, ub, vb);
+    p[1] = (uint8_t)ua; p[2] = (uint8_t)va; p[ps + 1] = (uint8_t)ub; p[ps + 2] = (uint8_t)vb;
+    if (a.alpha) { p[3] = 255; if (a.is420) p[ps + 3] = 255; }
+  }
+}
+
 struct RepackArgs {
   const uint8_t *src[4];
   uint8_t *dst[4];
@@ -644,8 +715,8 @@ static int ensure_cavgc() {
   return LGPU_OK;
 }
 
-extern "C" int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
-                               uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, void *stream) {
+static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
+                           uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, const uint16_t *lut16_d, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   if ((rc = ensure_cavgc())) return rc;
@@ -667,6 +738,7 @@ extern "C" int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int he
   a.order = in_order; a.alpha_in = in_alpha; a.fmt = out_fmt; a.alpha_out = (out_fmt <= 1) ? out_alpha : 0;
   a.unclamped = which_tables & 1;
   a.tables = device_tables()->rgb2yuv[which_tables & 3];
+  a.lut16 = lut16_d;
   const int npairs = width >> 1;
   if (npairs == 0) return LGPU_OK;
   const int nrows = out_fmt == 4 ? height >> 1 : height;
@@ -680,6 +752,18 @@ extern "C" int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int he
 #undef K4_CASE
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+extern "C" int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
+                               uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, void *stream) {
+  return rgb_to_yuv_impl(src_d, irow, width, height, in_order, in_alpha, dst_d, orow, out_fmt, out_alpha, which_tables, nullptr, stream);
+}
+extern "C" int lgpu_rgb_to_yuv_lut16(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d, int orow, int out_fmt,
+                                     int clamping_unclamped, const uint16_t *lut16_d, void *stream) {
+  LGPU_REQUIRE(lut16_d, "null LUT");
+  LGPU_REQUIRE(out_fmt == 2 || out_fmt == 3, "only the UYVY (2) and YUYV (3) entry points take a gamma LUT (rgb2uyvy_with_gamma, rgb2yuyv_with_gamma)");
+  uint8_t *const dd[4] = {dst_d, nullptr, nullptr, nullptr};
+  const int oo[4] = {orow, 0, 0, 0};
+  return rgb_to_yuv_impl(src_d, irow, width, height, in_order, in_alpha, dd, oo, out_fmt, 0, clamping_unclamped ? 1 : 0, lut16_d, stream);
 }
 
 extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
@@ -812,11 +896,10 @@ extern "C" int lgpu_yuv_switch_clamping(uint8_t *const planes_d[4], const int ro
 static int unsupported(const char *why) { lgpu::set_error("lgpu_yuv_repack: %s", why); return LGPU_E_UNSUPPORTED; }
 
 extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4],
-                               const int orow[4], int width, int height, int clamping_unclamped, int sampling_jpeg, void *stream) {
+                               const int orow[4], int width, int height, int clamping_unclamped, int sampling, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   if ((rc = ensure_cavgc())) return rc;
-  (void)sampling_jpeg;
   enum { P_420 = 512, P_YV12 = 513, P_422 = 522, P_444 = 544, P_4444 = 545, P_UYVY = 564, P_YUYV = 565, P_888 = 588, P_8888 = 589 };
   LGPU_REQUIRE(src_d && dst_d && irow && orow && width > 0 && height > 0, "null plane tables or empty geometry");
   LGPU_REQUIRE(src_d[0] && dst_d[0], "null plane");
@@ -869,6 +952,21 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     hipLaunchKernelGGL(lgpu::k_yuv411_repack, grid, dim3(kBlock), 0, st, r);
     if (r.kind == lgpu::K411_TO_420 && height >= 2 && !(height & 1))
       hipLaunchKernelGGL(lgpu::k_yuv411_420_fold, dim3(1), dim3(64), 0, st, r.src[0], width >> 2, height - 1, r.dst[1], r.dst[2], r.clamped);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
+  if ((in420 || in_pal == P_422) && (out_pal == P_888 || out_pal == P_8888)) {
+    // K5d: convert_quad_chroma_packed / convert_double_chroma_packed
+    if (width & 1) return unsupported("a subsampled source has an even width");
+    if (in420 && ((height & 1) || height < 2)) return unsupported("4:2:0 -> packed 4:4:4 needs an even height (the reference's trailing loop reads the row after the frame, colourspace.c:10798)");
+    lgpu::ChromaUpArgs c = {};
+    for (int i = 0; i < 3; i++) { LGPU_REQUIRE(src_d[i] && irow[i] > 0, "null source plane"); c.src[i] = src_d[i]; c.irow[i] = irow[i]; }
+    c.dst = dst_d[0]; c.orow = orow[0]; c.width = width; c.height = height;
+    c.is420 = in420 ? 1 : 0; c.alpha = (out_pal == P_8888); c.jpeg = (sampling == 0); c.clamped = clamping_unclamped ? 0 : 1;
+    const int crows = in420 ? height >> 1 : height;
+    c.ulast = (unsigned)irow[1] * (unsigned)crows - 1u; c.vlast = (unsigned)irow[2] * (unsigned)crows - 1u;
+    const dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(height < 2048 ? height : 2048));
+    hipLaunchKernelGGL(lgpu::k_chroma_up_packed, grid, dim3(kBlock), 0, st, c);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }

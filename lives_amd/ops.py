@@ -199,6 +199,13 @@ def rgb_to_yuv(src, dst_planes, width, height, in_order, in_alpha, out_fmt, out_
              out_fmt, int(out_alpha), which_tables, stream_ptr())
 
 
+def rgb_to_yuv_lut16(src, dst, width, height, in_order, in_alpha, out_fmt, unclamped, lut16):
+    """K4 with the 16-bit gamma LUT inline (UYVY / YUYV only); lut16: device tensor of 65536 16-bit entries"""
+    assert lut16.is_cuda and lut16.numel() == 65536 and lut16.element_size() == 2
+    lib.call("lgpu_rgb_to_yuv_lut16", dptr(src), src.stride(0), width, height, in_order, int(in_alpha), dptr(dst), dst.stride(0), out_fmt,
+             int(bool(unclamped)), lut16.data_ptr(), stream_ptr())
+
+
 def yuv_to_rgb(src_planes, dst, width, height, in_fmt, in_alpha, out_order, out_alpha, which_tables):
     sp, ss = _plane_tables(src_planes)
     lib.call("lgpu_yuv_to_rgb", ctypes.addressof(sp), ctypes.addressof(ss), width, height, in_fmt, int(in_alpha), dptr(dst), dst.stride(0),
@@ -210,13 +217,13 @@ def yuv_switch_clamping(planes, palette, height, to_unclamped):
     lib.call("lgpu_yuv_switch_clamping", ctypes.addressof(pp), ctypes.addressof(ss), palette, height, int(to_unclamped), stream_ptr())
 
 
-def yuv_repack(in_pal, out_pal, src_planes, dst_planes, width, height, unclamped=False, sampling_jpeg=False):
+def yuv_repack(in_pal, out_pal, src_planes, dst_planes, width, height, unclamped=False, sampling=0):
     """YUV -> YUV repack (colourspace.c K5b); palettes are WEED_PALETTE_* numbers; raises LgpuError (LGPU_E_UNSUPPORTED) for pairs
     the library does not take"""
     sp, ss = _plane_tables(src_planes)
     dp, ds = _plane_tables(dst_planes)
     lib.call("lgpu_yuv_repack", in_pal, out_pal, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(dp), ctypes.addressof(ds),
-             width, height, int(bool(unclamped)), int(bool(sampling_jpeg)), stream_ptr())
+             width, height, int(bool(unclamped)), int(sampling), stream_ptr())
 
 
 def softlight(src_planes, dst_planes, width, height, palette, unclamped):

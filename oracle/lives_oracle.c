@@ -766,6 +766,33 @@ int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, in
 /* K4b: RGB24 / RGBA32 / BGR24 / BGRA32 / ARGB32 -> YUV411     reference: src/colourspace.c:6499-6615, rgb2_411 :2322-2343;
  * dispatcher :12627-12632 etc.  Four pixels -> u2 y0 y1 v2 y2 y3; chroma = (sum of the four per-pixel >> FP_BITS values) >> 2, clamped
  * afterwards; width % 4 pixels on the right are dropped; the destination is compact rows of (width >> 2) macropixels. */
+/* K4 with the 16-bit gamma LUT inline: rgb2uyvy_with_gamma / rgb2yuyv_with_gamma (src/colourspace.c:2146-2159, :2194-2207), what the UYVY / YUYV entry points run
+ * when convert_layer_palette_full changes the gamma on the way (:12565-12580, :12646-12660 ...: create_gamma_lut(1.0, gamma_type, new_gamma_type)).  Each table sum
+ * indexes the LUT by its top 16 bits (>> 8), the LUT's high byte is the sample; both forms clamp properly here (the missing `else` of rgb2yuyv is not in
+ * its gamma twin).  out_fmt 2 UYVY, 3 YUYV; U from the first pixel, V from the second. */
+int orc_rgb_to_yuv_lut16(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int orow, int out_fmt,
+                         int unclamped, const uint16_t *lut16) {
+  const r2y_t c = r2y_for(unclamped ? 1 : 0);
+  const int ips = (in_order == 2 || in_alpha) ? 4 : 3;
+  if (!src || !dst || !lut16 || in_order < 0 || in_order > 2 || (out_fmt != 2 && out_fmt != 3) || width < 2 || (width & 1) || height < 1) return -1;
+  for (int y = 0; y < height; y++) {
+    const uint8_t *s = src + (size_t)y * irow;
+    uint8_t *d = dst + (size_t)y * orow;          /* the reference's row step (:5206) only works for compact rows; any rowstride is honoured here, as in orc_rgb_to_yuv */
+    for (int x = 0; x < width; x += 2, d += 4) {
+      int r0, g0, b0, r1, g1, b1;
+      px_rgb(s + (size_t)x * ips, in_order, &r0, &g0, &b0);
+      px_rgb(s + (size_t)(x + 1) * ips, in_order, &r1, &g1, &b1);
+      const int y0 = lut16[((uint32_t)(c.t[0][r0] + c.t[1][g0] + c.t[2][b0]) >> 8) & 0xFFFF] >> 8, y1 = lut16[((uint32_t)(c.t[0][r1] + c.t[1][g1] + c.t[2][b1]) >> 8) & 0xFFFF] >> 8;
+      const int u = lut16[((uint32_t)(c.t[3][r0] + c.t[4][g0] + c.t[5][b0]) >> 8) & 0xFFFF] >> 8, v = lut16[((uint32_t)(c.t[6][r1] + c.t[7][g1] + c.t[8][b1]) >> 8) & 0xFFFF] >> 8;
+      const uint8_t Y0 = (uint8_t)(y0 > c.max_y ? c.max_y : y0 < c.min_y ? c.min_y : y0), Y1 = (uint8_t)(y1 > c.max_y ? c.max_y : y1 < c.min_y ? c.min_y : y1);
+      const uint8_t U = (uint8_t)(u > c.max_uv ? c.max_uv : u < c.min_uv ? c.min_uv : u), V = (uint8_t)(v > c.max_uv ? c.max_uv : v < c.min_uv ? c.min_uv : v);
+      if (out_fmt == 2) { d[0] = U; d[1] = Y0; d[2] = V; d[3] = Y1; }
+      else { d[0] = Y0; d[1] = U; d[2] = Y1; d[3] = V; }
+    }
+  }
+  return 0;
+}
+
 int orc_rgb_to_yuv411(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int unclamped) {
   const r2y_t c = r2y_for(unclamped ? 1 : 0);
   const int ips = (in_order == 2 || in_alpha) ? 4 : 3, wm = width >> 2;
@@ -1603,13 +1630,12 @@ static int orc_yuv411_repack(int in_pal, int out_pal, const uint8_t *const src[4
 }
 
 int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const int irow[4], uint8_t *const dst[4], const int orow[4],
-                   int width, int height, int clamping_unclamped, int sampling_jpeg) {
+                   int width, int height, int clamping_unclamped, int sampling) {
   const int cl = !clamping_unclamped;               /* set_conversion_arrays(clamping, YCBCR): cavg = cavgc when clamped */
   if (in_pal == P_411 || out_pal == P_411) return orc_yuv411_repack(in_pal, out_pal, src, irow, dst, width, height, cl);
   const int in444 = (in_pal == P_444 || in_pal == P_4444), in420 = (in_pal == P_420 || in_pal == P_YV12);
   const int inpk422 = (in_pal == P_UYVY || in_pal == P_YUYV);
   if (width < 1 || height < 1) return -1;
-  (void)sampling_jpeg;
 
   /* convert_combineplanes_frame :7593-7641 -- both of its branches write the same bytes */
   if (in444 && (out_pal == P_888 || out_pal == P_8888)) {
@@ -1662,6 +1688,62 @@ int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const i
         const uint8_t a = src[0][(size_t)y * irow[0] + x], b = src[0][(size_t)y * irow[0] + x + 1];
         dst[0][(size_t)y * orow[0] + x] = b; dst[0][(size_t)y * orow[0] + x + 1] = a;
       }
+    return 0;
+  }
+  /* convert_quad_chroma_packed :10715-10808 (4:2:0 planar -> YUV888 / YUVA8888) and convert_double_chroma_packed :10811-10873 (4:2:2 planar -> the same).
+     Chroma is supersampled horizontally from the neighbouring samples (JPEG / default siting: plain averages; other sitings: the 3:1 / 1:3 forms);
+     the second pixel of a row's last pair reads the sample one past the chroma row (the next row's first; for the plane's last row one past the plane:
+     clamped to the plane here, the tests mask that pixel when the planes are compact).
+     4:2:0: even rows are computed, on every odd row i >= 3 the chroma of row i - 2 becomes the mean of its even neighbours; the LAST odd row's chroma and
+     the alpha of all odd rows are never written (the caller's zeroed frame shows through).  Even heights only: with an odd one the trailing loop (:10798-10807)
+     reads the row after the frame.  4:2:2: the second pixel of every pair never gets its alpha byte (:10857-10870). */
+  if ((in420 || in_pal == P_422) && (out_pal == P_888 || out_pal == P_8888)) {
+    const int ps = out_pal == P_8888 ? 4 : 3, jpeg = sampling == 0, is420 = in420;
+    const int hw = width >> 1, crows = is420 ? height >> 1 : height;
+    if ((width & 1) || (is420 && ((height & 1) || height < 2))) return -1;
+    const size_t ulast = (size_t)irow[1] * crows - 1, vlast = (size_t)irow[2] * crows - 1;
+    #define CH_U(cr, k) src[1][((size_t)(cr) * irow[1] + (k)) > ulast ? ulast : ((size_t)(cr) * irow[1] + (k))]
+    #define CH_V(cr, k) src[2][((size_t)(cr) * irow[2] + (k)) > vlast ? vlast : ((size_t)(cr) * irow[2] + (k))]
+    for (int i = 0; i < height; i++) {
+      uint8_t *d = dst[0] + (size_t)i * orow[0];
+      const uint8_t *sy = src[0] + (size_t)i * irow[0];
+      if (is420 && (i & 1)) {
+        for (int x = 0; x < width; x++) d[x * ps] = sy[x];
+        continue;
+      }
+      const int cr = is420 ? i >> 1 : i;
+      for (int k = 0; k < hw; k++) {
+        const int u0 = CH_U(cr, k), v0 = CH_V(cr, k), u1 = CH_U(cr, k + 1), v1 = CH_V(cr, k + 1);
+        uint8_t *p = d + (size_t)2 * k * ps;
+        p[0] = sy[2 * k];
+        if (k > 0) {
+          const int um = CH_U(cr, k - 1), vm = CH_V(cr, k - 1);
+          p[1] = (uint8_t)(jpeg ? orc_cavg(cl, um, u0) : orc_cavg(cl, um, orc_cavg(cl, um, u0)));          /* avg_chroma_3_1f */
+          p[2] = (uint8_t)(jpeg ? orc_cavg(cl, vm, v0) : orc_cavg(cl, orc_cavg(cl, vm, v0), v0));          /* avg_chroma_1_3f */
+        } else { p[1] = (uint8_t)u0; p[2] = (uint8_t)v0; }
+        if (ps == 4) p[3] = 255;
+        p += ps;
+        p[0] = sy[2 * k + 1];
+        if (is420) {
+          p[1] = (uint8_t)(jpeg ? orc_cavg(cl, u0, u1) : orc_cavg(cl, orc_cavg(cl, u0, u1), u1));          /* 1_3 for U, 3_1 for V (:10756-10757) */
+          p[2] = (uint8_t)(jpeg ? orc_cavg(cl, v0, v1) : orc_cavg(cl, v0, orc_cavg(cl, v0, v1)));
+          if (ps == 4) p[3] = 255;
+        } else {
+          p[1] = (uint8_t)(jpeg ? orc_cavg(cl, u0, u1) : orc_cavg(cl, u0, orc_cavg(cl, u0, u1)));          /* the same 3_1 / 1_3 as the first pixel (:10862-10863) */
+          p[2] = (uint8_t)(jpeg ? orc_cavg(cl, v0, v1) : orc_cavg(cl, orc_cavg(cl, v0, v1), v1));
+        }
+      }
+    }
+    if (is420)
+      for (int i = 1; i + 2 < height; i += 2) {                   /* row i = mean of rows i - 1 and i + 1, written while row i + 2 is walked (:10766-10777) */
+        uint8_t *d = dst[0] + (size_t)i * orow[0];
+        for (int x = 0; x < hw * 2; x++) {
+          d[x * ps + 1] = (uint8_t)orc_cavg(cl, d[x * ps + 1 + orow[0]], d[x * ps + 1 - orow[0]]);
+          d[x * ps + 2] = (uint8_t)orc_cavg(cl, d[x * ps + 2 + orow[0]], d[x * ps + 2 - orow[0]]);
+        }
+      }
+    #undef CH_U
+    #undef CH_V
     return 0;
   }
   /* convert_yuv420_to_uyvy_frame / _yuyv_frame :7104-7198: `i` is never advanced, so the "average with the row above"

@@ -105,6 +105,8 @@ int orc_rgb_to_yuv(const uint8_t *src, int irow, int width, int height, int in_o
    planar -> BGR24 (:7313 always steps 4 bytes). */
 int orc_yuv_to_rgb(const uint8_t *const src[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
                    uint8_t *dst, int orow, int out_order, int out_alpha, int which_tables);
+int orc_rgb_to_yuv_lut16(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int orow, int out_fmt,
+                         int unclamped, const uint16_t *lut16);
 int orc_rgb_to_yuv411(const uint8_t *src, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst, int unclamped);
 int orc_yuv411_to_rgb(const uint8_t *src, int width_mp, int height, uint8_t *dst, int orow, int out_order, int out_alpha, int unclamped);
 /* init_average (src/colourspace.c:190-216): cavgc (clamped = 1) / cavgu chroma-averaging table entry */
@@ -120,7 +122,7 @@ int orc_switch_yuv_clamping(uint8_t *const planes[4], const int rowstrides[4], i
 /* YUV -> YUV repacks (colourspace.c:7104-7198, :7500-7753, :7800-7971, :9198-9257, :10517-10575, :10612-10639 and the K1
    addpost / delpost pair); WEED_PALETTE_* numbers, width in pixels; -1 = pair / layout not taken */
 int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const int irow[4], uint8_t *const dst[4], const int orow[4],
-                   int width, int height, int clamping_unclamped, int sampling_jpeg);
+                   int width, int height, int clamping_unclamped, int sampling);
 
 /* F7: geometric transitions  lives-plugins/weed-plugins/multi_transitions.c:86-233: type 0 "iris rectangle", 1 "iris circle",
    2 "4 way split" (types 3 dissolve / 4 rand replace draw from the host's random generator and are not restated).

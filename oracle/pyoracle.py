@@ -320,6 +320,23 @@ YUV_REPACK_PAIRS = [(544, 588, 1), (544, 589, 1), (545, 588, 1), (545, 589, 1), 
                     (564, 545, 1), (564, 588, 1), (565, 588, 1), (564, 589, 1), (565, 589, 1), (564, 512, 0), (565, 512, 0),
                     (588, 512, 0), (589, 512, 0), (588, 522, 0), (589, 522, 0), (588, 564, 0), (588, 565, 0), (589, 564, 0), (589, 565, 0),
                     (564, 522, 0), (565, 522, 0)]
+# 4:2:0 / 4:2:2 planar -> packed 4:4:4 (convert_quad_chroma_packed / convert_double_chroma_packed, :10715-10873)
+CHROMA_UP_PAIRS = [(512, 588), (512, 589), (522, 588), (522, 589)]
+
+
+def chroma_up_mask(ip, op, w, h, pad, shape):
+    """1 where the result is defined: with compact chroma planes the last pixel of the rows fed by the LAST chroma row takes its chroma from one sample past
+    the plane (undefined in the reference): the last even row and -- through the vertical mean -- the odd row above it for 4:2:0, the last row for 4:2:2"""
+    m = np.ones(shape, np.uint8)
+    if pad == 0:
+        ps = 4 if op == 589 else 3
+        rows = [h - 2, h - 3] if ip in (512, 513) else [h - 1]
+        for r in rows:
+            if r >= 0:
+                m[r, (w - 1) * ps + 1:(w - 1) * ps + 3] = 0
+    return m
+
+
 # the 4:1:1 pairs (width in pixels, a multiple of 4): every one of them walks its buffers as compact streams; padded rows are allowed where the reference
 # function takes a source rowstride (planar 4:4:4 and packed 4:4:4 sources)
 YUV411_REPACK_PAIRS = [(595, 588, 0), (595, 589, 0), (595, 544, 0), (595, 545, 0), (595, 564, 0), (595, 565, 0), (595, 522, 0), (595, 512, 0), (595, 513, 0),

@@ -241,12 +241,29 @@ int csref_k4(int in_order, int in_alpha, int out_fmt, int out_alpha, uint8_t *sr
   }
   return -1;
 }
+/* K4 with a 16-bit gamma LUT (rgb2uyvy_with_gamma / rgb2yuyv_with_gamma): out_fmt 2 UYVY, 3 YUYV.  The frame functions take ownership of nothing here:
+   with one thread they never free the LUT */
+int csref_k4_lut16(int in_order, int in_alpha, uint8_t *src, int width, int height, int irow, int out_fmt, uint8_t *dst, int orow, int clamping, uint16_t *lut) {
+  ensure_tables();
+  if (out_fmt == 2) {
+    if (in_order == 0) convert_rgb_to_uyvy_frame(src, width, height, irow, orow, (uyvy_macropixel *)dst, in_alpha, clamping, lut, -1);
+    else if (in_order == 1) convert_bgr_to_uyvy_frame(src, width, height, irow, orow, (uyvy_macropixel *)dst, in_alpha, clamping, lut, -1);
+    else convert_argb_to_uyvy_frame(src, width, height, irow, orow, (uyvy_macropixel *)dst, clamping, lut, -1);
+    return 0;
+  }
+  if (out_fmt == 3) {
+    if (in_order == 0) convert_rgb_to_yuyv_frame(src, width, height, irow, orow, (yuyv_macropixel *)dst, in_alpha, clamping, lut, -1);
+    else if (in_order == 1) convert_bgr_to_yuyv_frame(src, width, height, irow, orow, (yuyv_macropixel *)dst, in_alpha, clamping, lut, -1);
+    else convert_argb_to_yuyv_frame(src, width, height, irow, orow, (yuyv_macropixel *)dst, clamping, lut, -1);
+    return 0;
+  }
+  return -1;
+}
 /* K5b: YUV -> YUV repacks with the arguments the dispatcher passes (:12937-13750); WEED_PALETTE_* numbers, width in pixels */
 int csref_yuv_repack(int in_pal, int out_pal, uint8_t **src, int *irows_in, uint8_t **dst, int *orows_in, int width, int height,
                      int clamping, int sampling) {
   int irows[4], orows[4];
   const int in444 = (in_pal == 544 || in_pal == 545), in420 = (in_pal == 512 || in_pal == 513), inpk = (in_pal == 564 || in_pal == 565);
-  (void)sampling;
   memcpy(irows, irows_in, sizeof(irows)); memcpy(orows, orows_in, sizeof(orows));
   ensure_tables();
   avg_chromaf = avg_chromaf_fast;
@@ -291,6 +308,8 @@ int csref_yuv_repack(int in_pal, int out_pal, uint8_t **src, int *irows_in, uint
     convert_swab_frame(dst[0], width >> 1, height, orows[0], -1);
     return 0;
   }
+  if (in420 && (out_pal == 588 || out_pal == 589)) { convert_quad_chroma_packed(src, width, height, irows, orows[0], dst[0], out_pal == 589, sampling, clamping); return 0; }
+  if (in_pal == 522 && (out_pal == 588 || out_pal == 589)) { convert_double_chroma_packed(src, width, height, irows, orows[0], dst[0], out_pal == 589, sampling, clamping); return 0; }
   if (in420 && out_pal == 564) { convert_yuv420_to_uyvy_frame(src, width, height, irows, orows[0], (uyvy_macropixel *)dst[0], clamping); return 0; }
   if (in420 && out_pal == 565) { convert_yuv420_to_yuyv_frame(src, width, height, irows, orows[0], (yuyv_macropixel *)dst[0], clamping); return 0; }
   if (in420 && out_pal == 522) {
@@ -455,6 +474,7 @@ def main():
     parts.append(lines(cs, 8622, 9196))             # K5c: yuv411 -> yuv(a)888(8) / yuv(a)444p / uyvy / yuyv / yuv422p / yuv420p, yuv420p / yuv422p -> yuv411
     parts.append(lines(cs, 9198, 9257))             # K5b: convert_splitplanes_frame
     parts.append(lines(cs, 10578, 10639))           # K5b: convert_halve_chroma, convert_double_chroma
+    parts.append(lines(cs, 10715, 10873))           # K5d: convert_quad_chroma_packed, convert_double_chroma_packed
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family
     parts.append(lines(cs, 14034, 14060))           # gamma_convert_layer_thread
     parts.append(WRAPPERS)

@@ -312,6 +312,33 @@ def test_yuv411_repack_vs_reference(gpu):
             assert (host(dst[i]) == a).all(), "%s plane %d" % (rec, i)
 
 
+def test_chroma_up_packed_vs_reference(gpu):
+    g = gu.load("chroma_up.npz")
+    for rec in map(str, g["records"]):
+        _, ip, op, unc, sampling, pad, w, h = rec.split("|")
+        ip, op, unc, sampling, w, h = int(ip), int(op), int(unc), int(sampling), int(w), int(h)
+        src = [dev(g[rec + "|i%d" % i]) for i in range(3)]
+        want, mask = g[rec + "|o0"], g[rec + "|m"]
+        d = dev(np.full_like(want, 0x5A))
+        gpu.yuv_repack(ip, op, src, [d], w, h, unc, sampling)
+        assert (host(d) * mask == want).all(), rec
+
+
+def test_k4_lut16_vs_reference(gpu):
+    import torch
+    g, L = gu.load("k4_lut16.npz"), gu.load("lut16.npz")
+    luts = {}
+    for rec in map(str, g["records"]):
+        _, lname, order, alpha, fmt, unc, w, h, pad = rec.split("|")
+        order, alpha, fmt, unc, w, h = int(order), int(alpha), int(fmt), int(unc), int(w), int(h)
+        if lname not in luts:
+            luts[lname] = torch.from_numpy(gu.lut16(L, lname).view(np.int16)).cuda()
+        want = g[rec + "|o"]
+        d = dev(np.full_like(want, 0x5A))
+        gpu.rgb_to_yuv_lut16(dev(g[rec + "|i"]), d, w, h, order, alpha, fmt, unc, luts[lname])
+        assert (host(d) == want).all(), rec
+
+
 def test_deinterlace_vs_reference_plugin(gpu):
     g = gu.load("deinterlace.npz")
     for rec in map(str, g["records"]):

@@ -659,10 +659,52 @@ def test_yuv411_repack(gpu, orc, pair):
                     assert (host(dst[i]) == a).all(), "repack %d->%d %dx%d unclamped=%d pad=%d plane %d" % (ip, op, w, h, unc, pad, i)
 
 
+@pytest.mark.parametrize("order,alpha", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 1)])
+def test_rgb_to_packed_422_with_gamma_lut16(gpu, orc, order, alpha):
+    """K4 with the 16-bit LUT inline (rgb2uyvy_with_gamma / rgb2yuyv_with_gamma): every table sum's top 16 bits index create_gamma_lut's table"""
+    import torch
+    rng = np.random.default_rng(2900 + order * 2 + alpha)
+    ips = 4 if alpha else 3
+    for (gf, gt) in ((po.GAMMA_LINEAR, po.GAMMA_SRGB), (po.GAMMA_SRGB, po.GAMMA_LINEAR), (po.GAMMA_SRGB, po.GAMMA_BT709)):
+        lut = np.zeros(65536, np.uint16)
+        assert orc.orc_gamma_lut16(1.0, gf, gt, 1.4, P(lut)) == 1
+        d_lut = torch.from_numpy(lut.view(np.int16)).cuda()
+        for (w, h) in [(2, 1), (64, 16), (130, 9), (1920, 1080)]:
+            for fmt in (2, 3):
+                for unc in (0, 1):
+                    src = frame(rng, w, h, ips)
+                    want = np.full((h, align(w * 2)), 0x5A, np.uint8)
+                    assert orc.orc_rgb_to_yuv_lut16(P(src), src.strides[0], w, h, order, alpha, P(want), want.strides[0], fmt, unc, P(lut)) == 0
+                    d = dev(np.full_like(want, 0x5A))
+                    gpu.rgb_to_yuv_lut16(dev(src), d, w, h, order, alpha, fmt, unc, d_lut)
+                    assert (host(d) == want).all(), "rgb -> %s lut16 %dx%d order=%d alpha=%d unclamped=%d" % ("UYVY" if fmt == 2 else "YUYV", w, h, order, alpha, unc)
+
+
+@pytest.mark.parametrize("pair", po.CHROMA_UP_PAIRS, ids=lambda p: "%d-%d" % p)
+def test_chroma_up_packed(gpu, orc, pair):
+    """K5d: YUV420P / YUV422P -> YUV888 / YUVA8888 (convert_quad_chroma_packed / convert_double_chroma_packed, :10715-10873): both chroma sitings, padded and compact planes
+    (the clamped out-of-plane read is the oracle's rule too), bytes the reference leaves alone stay 0x5A"""
+    import ctypes
+    ip, op = pair
+    rng = np.random.default_rng(2800 + ip + op)
+    for (w, h) in [(4, 2), (16, 8), (66, 34), (130, 18), (320, 200), (1920, 1080)]:
+        for unc in (0, 1):
+            for sampling in (0, 1):
+                for pad in (0, 24):
+                    src = po.yuv_planes(ip, w, h, rng=rng, pad=pad)
+                    want = po.yuv_planes(op, w, h, fill=0x5A, pad=pad)
+                    sp, ss = po.planes_args(src)
+                    wp, ws = po.planes_args(want)
+                    assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, unc, sampling) == 0
+                    d = dev(np.full_like(want[0], 0x5A))
+                    gpu.yuv_repack(ip, op, [dev(a) for a in src], [d], w, h, unc, sampling)
+                    assert (host(d) == want[0]).all(), "chroma up %d->%d %dx%d unclamped=%d sampling=%d pad=%d" % (ip, op, w, h, unc, sampling, pad)
+
+
 def test_yuv_repack_declines(gpu):
     from lives_amd.lib import LgpuError
     w, h = 16, 8
-    for (ip, op, pad) in [(512, 564, 8), (544, 564, 8), (564, 512, 8), (522, 512, 0), (544, 522, 0), (512, 544, 0), (589, 544, 0), (588, 545, 0)]:
+    for (ip, op, pad) in [(512, 564, 8), (544, 564, 8), (564, 512, 8), (522, 512, 0), (544, 522, 0), (512, 544, 0), (589, 544, 0), (588, 545, 0), (512, 545, 0), (522, 544, 0)]:
         src = [dev(a) for a in po.yuv_planes(ip, w, h, fill=1, pad=pad)]
         dst = [dev(a) for a in po.yuv_planes(op, w, h, fill=2, pad=pad)]
         with pytest.raises(LgpuError):

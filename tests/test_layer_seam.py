@@ -434,10 +434,85 @@ def test_yuv_layers_repack(seam, orc):
                 assert (got[i][:b, :a] == want[i][:b, :a]).all(), (ip, op, clamp, i)
             assert wh.geti(lay, "current_palette") == op and wh.geti(lay, "width") == (w >> 1 if op in (564, 565) else w)
             assert wh.geti(lay, "YUV_clamping") == clamp
-    for (ip, op) in [(522, 512), (544, 522), (512, 544), (589, 544)]:          # reference functions that overrun / depend on stale bytes
+    for (ip, op) in [(522, 512), (544, 522), (512, 544), (589, 544), (512, 545)]:          # reference functions that overrun / depend on stale bytes
         planes = po.yuv_planes(ip, w, h, rng=rng)
         lay = wh.new_layer(ip, w, h, planes, clamping=0, subspace=1)
         assert L.lives_gpu_convert_layer_palette_full(lay, op, 0, 0, 1, 0) == 0 and wh.geti(lay, "current_palette") == ip
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_rgb_layers_to_yuv_change_gamma_on_the_way(seam, orc):
+    """src/colourspace.c:12311-12332: an RGB layer of known gamma that goes to YUV becomes SRGB (BT709 for a BT.709 target subspace, or the caller's target);
+    UYVY / YUYV take the 16-bit LUT inline (rgb2uyvy_with_gamma), every other YUV palette gets gamma_convert_layer() first"""
+    L, wh = seam
+    rng = np.random.default_rng(91)
+    w, h = 64, 10
+    LIN, SRGB, BT709 = -1, 1, 2
+    for (inpl, ips, order) in ((RGBA32, 4, 0), (BGR24, 3, 1)):
+        for (tgt, osub, want_gamma) in ((0, 1, SRGB), (BT709, 1, BT709), (0, 2, BT709)):      # (tgt_gamma, osubspace (1 YCbCr, 2 BT.709), resulting gamma)
+            src = frame(rng, w, h, ips)
+            # UYVY: the LUT inline
+            lay = wh.new_layer(inpl, w, h, [src.copy()], gamma=LIN, flags=0)
+            assert L.lives_gpu_convert_layer_palette_full(lay, 564, 0, 0, osub, tgt) == 1
+            got, _, rs = wh.planes_of(lay)
+            lut16 = np.zeros(65536, np.uint16)
+            assert orc.orc_gamma_lut16(1.0, LIN, want_gamma, 1.4, P(lut16)) == 1
+            want = np.zeros((h, rs[0]), np.uint8)
+            assert orc.orc_rgb_to_yuv_lut16(P(src), src.strides[0], w, h, order, int(ips == 4), P(want), rs[0], 2, 0, P(lut16)) == 0
+            assert (got[0] == want).all(), (inpl, tgt, osub)
+            assert wh.geti(lay, "gamma_type") == want_gamma and wh.geti(lay, "YUV_subspace") == (2 if want_gamma == BT709 else 1)
+            # YUV888: gamma first (LUT8 over the RGB frame), then the palette
+            lay = wh.new_layer(inpl, w, h, [src.copy()], gamma=LIN, flags=0)
+            assert L.lives_gpu_convert_layer_palette_full(lay, 588, 0, 0, osub, tgt) == 1
+            got, _, rs = wh.planes_of(lay)
+            lut8 = np.zeros(256, np.uint8)
+            assert orc.orc_gamma_lut8(1.0, LIN, want_gamma, 1.4, P(lut8)) == 1
+            g = src.copy()
+            orc.orc_gamma_apply(P(g), g.strides[0], w, h, ips, 0, P(lut8))
+            want = [np.zeros((h, rs[0]), np.uint8)]
+            wp, ws = po.planes_args(want)
+            assert orc.orc_rgb_to_yuv(P(g), g.strides[0], w, h, order, int(ips == 4), ctypes.addressof(wp), ctypes.addressof(ws), 0, 0, 0) == 0
+            assert (got[0] == want[0]).all(), (inpl, tgt, osub, "888")
+            assert wh.geti(lay, "gamma_type") == want_gamma
+    # a layer that is already SRGB: nothing changes on the way (the plain entry points)
+    src = frame(rng, w, h, 4)
+    lay = wh.new_layer(RGBA32, w, h, [src.copy()], gamma=SRGB, flags=0)
+    assert L.lives_gpu_convert_layer_palette_full(lay, 565, 0, 0, 1, 0) == 1
+    got, _, rs = wh.planes_of(lay)
+    want = [np.zeros((h, rs[0]), np.uint8)]
+    wp, ws = po.planes_args(want)
+    assert orc.orc_rgb_to_yuv(P(src), src.strides[0], w, h, 0, 1, ctypes.addressof(wp), ctypes.addressof(ws), 3, 0, 0) == 0
+    assert (got[0] == want[0]).all() and wh.geti(lay, "gamma_type") == SRGB
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_planar_layers_to_packed_444(seam, orc):
+    """K5d through the layer seam (:13624-13635, :13731-13742): YUV420P / YVU420P / YUV422P -> YUV888 / YUVA8888, reading the layer's YUV_sampling leaf; the new
+    frame starts zeroed as create_empty_pixel_data() leaves it, so the bytes the reference never writes (last odd row's chroma, skipped alpha) are zero"""
+    L, wh = seam
+    W = wh.weed()
+    rng = np.random.default_rng(90)
+    w, h = 72, 12
+    for ip in (512, 513, 522):
+        for op in (588, 589):
+            for sampling in (0, 1):
+                dims_in = po.YUV_PLANE_DIMS[ip](w, h)
+                planes = [rng.integers(0, 256, (dims_in[0][1], align(w)), dtype=np.uint8)] + [rng.integers(0, 256, (b, align(w) >> 1), dtype=np.uint8) for (a, b) in dims_in[1:]]
+                lay = wh.new_layer(ip, w, h, [a.copy() for a in planes], clamping=0, subspace=1)
+                W.weed_set_int_value(lay, b"YUV_sampling", sampling)
+                assert L.lives_gpu_convert_layer_palette_full(lay, op, 0, sampling, 1, 0) == 1, (ip, op)
+                got, _, rs = wh.planes_of(lay)
+                want = [np.zeros((h, rs[0]), np.uint8)]
+                src = planes if ip != 513 else [planes[0], planes[2], planes[1]]          # the dispatcher swaps the chroma pointers of a YVU layer first
+                sp, ss = po.planes_args(src)
+                wp, ws = po.planes_args(want)
+                assert orc.orc_yuv_repack(512 if ip == 513 else ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(wp), ctypes.addressof(ws), w, h, 0, sampling) == 0
+                assert (got[0] == want[0]).all(), (ip, op, sampling)
+                assert wh.geti(lay, "current_palette") == op and wh.geti(lay, "width") == w
+    lay = wh.new_layer(512, w, 11, [rng.integers(0, 256, (11, 96), dtype=np.uint8), rng.integers(0, 256, (5, 48), dtype=np.uint8), rng.integers(0, 256, (5, 48), dtype=np.uint8)], clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette_full(lay, 588, 0, 0, 1, 0) == 0 and wh.geti(lay, "current_palette") == 512      # odd height: the reference overruns, declined
 
 
 @needs_ref

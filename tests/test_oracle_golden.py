@@ -368,6 +368,35 @@ def test_yuv411_repack(orc):
             assert (got[i] == a).all(), "%s plane %d" % (rec, i)
 
 
+def test_chroma_up_packed(orc):
+    """4:2:0 / 4:2:2 planar -> YUV888 / YUVA8888 against the reference slice fixtures (:10715-10873); m = 0 where the reference reads past a compact plane"""
+    import ctypes
+    g = gu.load("chroma_up.npz")
+    for rec in map(str, g["records"]):
+        _, ip, op, unc, sampling, pad, w, h = rec.split("|")
+        ip, op, unc, sampling, w, h = int(ip), int(op), int(unc), int(sampling), int(w), int(h)
+        src = [np.ascontiguousarray(g[rec + "|i%d" % i]) for i in range(3)]
+        want, mask = g[rec + "|o0"], g[rec + "|m"]
+        got = [np.full_like(want, 0x5A)]
+        sp, ss = po.planes_args(src)
+        gp, gs = po.planes_args(got)
+        assert orc.orc_yuv_repack(ip, op, ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(gp), ctypes.addressof(gs), w, h, unc, sampling) == 0
+        assert (got[0] * mask == want).all(), rec
+
+
+def test_k4_lut16(orc):
+    """RGB family -> UYVY / YUYV with the 16-bit gamma LUT inline against the reference slice fixtures (rgb2uyvy_with_gamma / rgb2yuyv_with_gamma)"""
+    g, L = gu.load("k4_lut16.npz"), gu.load("lut16.npz")
+    for rec in map(str, g["records"]):
+        _, lname, order, alpha, fmt, unc, w, h, pad = rec.split("|")
+        order, alpha, fmt, unc, w, h = int(order), int(alpha), int(fmt), int(unc), int(w), int(h)
+        lut = np.ascontiguousarray(gu.lut16(L, lname))
+        src, want = np.ascontiguousarray(g[rec + "|i"]), g[rec + "|o"]
+        got = np.full_like(want, 0x5A)
+        assert orc.orc_rgb_to_yuv_lut16(P(src), src.strides[0], w, h, order, alpha, P(got), got.strides[0], fmt, unc, P(lut)) == 0
+        assert (got == want).all(), rec
+
+
 def test_deinterlace(orc):
     g = gu.load("deinterlace.npz")
     for rec in map(str, g["records"]):
