@@ -220,8 +220,8 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb4(YuvArgs a, Lut8 lut,
 //     their U pair: 11 per 2 x 2 quad);
 //   * CLAMP0255f + gamma LUT as ONE table indexed by (sum >> 16) + kY16Bias (RGB_Y carries the bias): no clamp instructions;
 //   * CLAMP16_240 / the 0..255 clamp as one v_med3, / 3 as a multiply-shift, chroma bytes taken by SDWA operands.
-// 139 KB of tables per workgroup, so a workgroup is 1024 threads, one per CU, persistent over the cells (4 row pairs x 256 column groups
-// per step).  Cells near the frame edges go through yuv420_cell() as before.
+// 139 KB of tables per workgroup, so a workgroup is 1024 threads, one per CU, persistent over the cells (dealt out round-robin over the whole grid).
+// Cells near the frame edges go through yuv420_cell() as before.
 constexpr int kY16Bias = 320, kY16Lut = 896;        // (sum >> 16) of every table set lies in [-320, 575] (checked on the host per launch)
 constexpr int kY16OffLut = 0, kY16OffTy = kY16Lut * 64, kY16OffRG = kY16OffTy + 16384, kY16OffGB = kY16OffRG + 32768, kY16OffTab = kY16OffGB + 32768,
               kY16OffLut8 = kY16OffTab + 5 * 1024, kY16Lds = kY16OffLut8 + 256;     // the table bases travel in the per-lane copy offsets, the LUT sits at 0
@@ -257,19 +257,24 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, 
   const int npairs = (a.height - 1) / 2;
   const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
   const int total = nunits * nframes;
+  const uint32_t zmagic = (uint32_t)(((1ull << 32) + (uint32_t)nunits - 1u) / (uint32_t)nunits);   // ul / nunits == umulhi(ul, zmagic) for ul < 64 * nunits, 2 <= nunits < 8192
   const uint32_t c4 = (uint32_t)(tid & 15) * 4u, c4y = c4 + kY16OffTy, c8v = c4 * 2u + kY16OffRG, c8u = c4 * 2u + kY16OffGB;
   typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
   typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) u32x2v *lds_u64;
-  // A workgroup step covers 4 linear units (frame, row-pair unit) x 256 column groups; a thread walks its cells (unit, column group)
-  // with the loads of the NEXT cell issued before the arithmetic of the current one (16 waves per CU hide little latency by themselves).
+  // A thread walks its cells with the loads of the NEXT cell issued before the arithmetic of the current one (16 waves per CU hide little latency by themselves).
+  // Cells (unit, column group) are numbered linearly over the whole launch and dealt out round-robin to ALL threads of the grid: with a static
+  // (unit -> workgroup quarter, column group -> lane) split 16 of every 256 lanes had no column group at 1080p (96 of 256 at 1280 wide) and the workgroups
+  // got 8 or 9 units.  At 16 x 1080p both splits measure the same (53.2 us, A / B on one box): the launch is bound by the LDS gathers, not by lane-time.
   struct Cell { uint2 ya, yb; uint32_t u0m, u0c, u0p, u1c, u1p, v0c, v0p, v1m, v1c, v1p, lv2; int z, unit, k0; bool valid, fast; };
+  const uint32_t cstep = gridDim.x * 1024u;
+  const int dul = (int)(cstep / (uint32_t)ncg), dcg = (int)(cstep - (uint32_t)dul * (uint32_t)ncg);      // one step of a thread in (unit, column group) terms
   auto fetch = [&](int ul, int cg) -> Cell {
     Cell q;
     q.valid = ul < total;
     q.fast = false;
     if (!q.valid) return q;
-    q.z = ul / nunits; q.unit = ul - q.z * nunits; q.k0 = 4 * cg;
+    q.z = (int)__umulhi((uint32_t)ul, zmagic); q.unit = ul - q.z * nunits; q.k0 = 4 * cg;
     const int i = 2 * q.unit - 1, r = i >> 1;
     q.fast = q.unit >= 1 && q.unit <= npairs && q.k0 + 4 <= hw && (long)(r + 1) * a.us + q.k0 + 8 <= a.usize &&
              (long)(r + 1) * a.vs + q.k0 + 8 <= a.vsize;
@@ -304,13 +309,12 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, 
     if (ORDER == 1) return __builtin_amdgcn_perm(r_, __builtin_amdgcn_perm(g_, b_, 0x0C0C0400u), 0x0D040100u);
     return __builtin_amdgcn_perm(b_, __builtin_amdgcn_perm(g_, r_, 0x0C04000Du), 0x04020100u);
   };
-  int ul = blockIdx.x * 4 + (tid >> 8), cg = tid & 255;
-  const int ustep = (int)gridDim.x * 4;
-  if (cg >= ncg) return;
+  const uint32_t idx0 = blockIdx.x * 1024u + (uint32_t)tid;
+  int ul = (int)(idx0 / (uint32_t)ncg), cg = (int)(idx0 - (uint32_t)ul * (uint32_t)ncg);
   Cell cur = fetch(ul, cg);
   while (cur.valid) {
-    cg += 256;
-    if (cg >= ncg) { cg = tid & 255; ul += ustep; }
+    ul += dul; cg += dcg;
+    if (cg >= ncg) { cg -= ncg; ul++; }
     const Cell nxt = fetch(ul, cg);
     if (!cur.fast) {
       YuvArgs f = a;
@@ -427,7 +431,7 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   // launches that fill the device take the 16-copy-table kernel (one 1024-thread workgroup per CU, 139 KB of tables each)
   static const bool no16 = getenv("LGPU_YUV_NO16") != nullptr;
   const bool force16 = getenv("LGPU_YUV_FORCE16") != nullptr;            // tests: the 16-copy kernel at any size
-  if (wide && !no16 && !lut16_d && !a.low_quality && (force16 || (unsigned long long)g4x.x * g4x.y * g4x.z * kBlock >= 256ull * 1024ull)) {
+  if (wide && !no16 && !lut16_d && !a.low_quality && units >= 2 && units < 8192 && nbatch <= 64 && (force16 || (unsigned long long)g4x.x * g4x.y * g4x.z * kBlock >= 256ull * 1024ull)) {
     // the clamp + LUT table covers (sum >> 16) in [-kY16Bias, kY16Lut - kY16Bias): true for the reference's four table sets, checked here
     static int range_ok[4] = {0, 0, 0, 0};          // 0 unknown, 1 ok, -1 no
     const int w4 = which_tables & 3;

@@ -46,9 +46,13 @@ def main():
     rows = []
 
     def timeit(fn, nbuf):
-        for i in range(3):
-            fn(i % nbuf)
-        torch.cuda.synchronize()
+        t_end = time.perf_counter() + 0.06          # ~60 ms of the same launch first (clock / power state of a running pipeline, as bench.py does)
+        i = 0
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                fn(i % nbuf)
+                i += 1
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(args.reps):
