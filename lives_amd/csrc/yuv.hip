@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb4(YuvArgs a, Lut8 lut,
 constexpr int kY16Bias = 320, kY16Lut = 896;        // (sum >> 16) of every table set lies in [-320, 575] (checked on the host per launch)
 constexpr int kY16OffLut = 0, kY16OffTy = kY16Lut * 64, kY16OffRG = kY16OffTy + 16384, kY16OffGB = kY16OffRG + 32768, kY16OffTab = kY16OffGB + 32768,
               kY16OffLut8 = kY16OffTab + 5 * 1024, kY16Lds = kY16OffLut8 + 256;     // the table bases travel in the per-lane copy offsets, the LUT sits at 0
-template <int ORDER>
+template <int ORDER, bool LUT>
 __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, YuvBatch bt, int nframes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *s_ty = reinterpret_cast<uint32_t *>(smem + kY16OffTy);
@@ -301,9 +301,16 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, 
     const uint32_t yy = *(lds_u32)(uintptr_t)((yv << 6) + c4y);
     const u32x2v rg = *(lds_u64)(uintptr_t)va, gb = *(lds_u64)(uintptr_t)ua;
     const uint32_t sr = yy + rg.x, sg = yy + gb.x + rg.y, sb = yy + gb.y;
-    const uint32_t r_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sr >> 10) & 0xFFC0u) | c4));
-    const uint32_t g_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sg >> 10) & 0xFFC0u) | c4));
-    const uint32_t b_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sb >> 10) & 0xFFC0u) | c4));
+    uint32_t r_, g_, b_;
+    if (LUT) {
+      r_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sr >> 10) & 0xFFC0u) | c4));
+      g_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sg >> 10) & 0xFFC0u) | c4));
+      b_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sb >> 10) & 0xFFC0u) | c4));
+    } else {            // no gamma LUT: CLAMP0255f alone is one v_med3 per channel instead of an LDS gather (half of the kernel's gathers)
+      r_ = (uint32_t)min(max((int)(sr >> 16) - kY16Bias, 0), 255);
+      g_ = (uint32_t)min(max((int)(sg >> 16) - kY16Bias, 0), 255);
+      b_ = (uint32_t)min(max((int)(sb >> 16) - kY16Bias, 0), 255);
+    }
     // two byte permutes per pixel (selector 0x0C = 0x00, 0x0D = 0xFF: the alpha byte costs nothing)
     if (ORDER == 0) return __builtin_amdgcn_perm(b_, __builtin_amdgcn_perm(g_, r_, 0x0C0C0400u), 0x0D040100u);
     if (ORDER == 1) return __builtin_amdgcn_perm(r_, __builtin_amdgcn_perm(g_, b_, 0x0C0C0400u), 0x0D040100u);
@@ -468,8 +475,13 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
       if (g16 > g_cus) g16 = g_cus;
 #define Y16_LAUNCH(ORDER_)                                                                                                             \
       do {                                                                                                                             \
-        LGPU_HIP(hipFuncSetAttribute((const void *)k_yuv420p_to_rgb16<ORDER_>, hipFuncAttributeMaxDynamicSharedMemorySize, kY16Lds));  \
-        hipLaunchKernelGGL((k_yuv420p_to_rgb16<ORDER_>), dim3((unsigned)g16), dim3(1024), kY16Lds, (hipStream_t)stream, a, l, b16, nbatch); \
+        if (a.use_lut) {                                                                                                             \
+          LGPU_HIP(hipFuncSetAttribute((const void *)k_yuv420p_to_rgb16<ORDER_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kY16Lds));  \
+          hipLaunchKernelGGL((k_yuv420p_to_rgb16<ORDER_, true>), dim3((unsigned)g16), dim3(1024), kY16Lds, (hipStream_t)stream, a, l, b16, nbatch); \
+        } else {                                                                                                                     \
+          LGPU_HIP(hipFuncSetAttribute((const void *)k_yuv420p_to_rgb16<ORDER_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kY16Lds));  \
+          hipLaunchKernelGGL((k_yuv420p_to_rgb16<ORDER_, false>), dim3((unsigned)g16), dim3(1024), kY16Lds, (hipStream_t)stream, a, l, b16, nbatch); \
+        }                                                                                                                            \
       } while (0)
       if (out_order == 0) Y16_LAUNCH(0); else if (out_order == 1) Y16_LAUNCH(1); else Y16_LAUNCH(2);
 #undef Y16_LAUNCH

@@ -16,6 +16,7 @@ from lives_amd.lib import load   # noqa: E402
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    with_lut = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0        # 0: plain palette conversion, no gamma on the way
     ops.init(0)
     w, h = 1920, 1080
     g = torch.Generator(device="cuda")
@@ -30,17 +31,17 @@ def main():
     t_end = time.perf_counter() + 0.08              # ~80 ms of the same launch first: clock / power state of a running pipeline
     while time.perf_counter() < t_end:
         for _ in range(20):
-            ops.yuv420p_to_rgb_batch(frames, w, h, lut=lut)
+            ops.yuv420p_to_rgb_batch(frames, w, h, lut=lut if with_lut else None)
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.yuv420p_to_rgb_batch(frames, w, h, lut=lut)
+        ops.yuv420p_to_rgb_batch(frames, w, h, lut=lut if with_lut else None)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     ab = nt * (w * h * 3 // 2 + w * h * 4)
-    print(json.dumps({"op": "yuv420p -> RGBA32 + gamma LUT, %d x 1080p per launch" % nt, "us_per_launch": round(us, 2), "algorithmic_bytes": ab,
+    print(json.dumps({"op": "yuv420p -> RGBA32%s, %d x 1080p per launch" % (" + gamma LUT" if with_lut else "", nt), "us_per_launch": round(us, 2), "algorithmic_bytes": ab,
                       "GBs": round(ab / us / 1e3, 1), "frac_of_8TBs": round(ab / us / 1e3 / 8000, 4)}))
 
 
