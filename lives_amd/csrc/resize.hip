@@ -1500,7 +1500,8 @@ struct Bank {
   int max_span = 0;      // max over 64-column (or th-row) tiles is derived by the caller from host copies
   std::vector<int32_t> hpos;
   std::vector<int16_t> hco;         // host copy of the taps
-  int uniform2 = 0;                 // exact 2:1, 8 identical taps per output, pos[i] = 2i - 3, taps fit 64*int8 + 6 bits
+  int uniform2 = 0;                 // exact 2:1, the same <= 8 taps for every output, centred like the 8-tap case (taps8 = zero padded to pos[i] = 2i - 3), taps fit 64*int8 + 6 bits
+  int16_t taps8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t *co2h = nullptr, *co2v = nullptr;   // k_sep2: taps as packed pairs, [dst][nph] resp. [dst][npv] (see SepArgs)
   int nph = 0, npv = 0;
 };
@@ -1529,15 +1530,18 @@ static int get_bank(int srcn, int dstn, int kernel, const Bank **out) {
       co.resize((size_t)dstn * b.nt);
     }
     b.hco = co;
-    if (b.nt == 8 && srcn == 2 * dstn) {
+    if (b.nt <= 8 && !(b.nt & 1) && srcn == 2 * dstn && kernel != 100) {
+      // k_half8s takes any uniform 2:1 filter that embeds into its 8-tap window: bicubic (8 taps) and, zero padded on both sides, bilinear (4 taps)
+      const int pad = (8 - b.nt) / 2;
       b.uniform2 = 1;
       for (int i = 0; i < dstn && b.uniform2; i++) {
-        if (b.hpos[i] != 2 * i - 3) b.uniform2 = 0;
-        for (int j = 0; j < 8; j++) {
-          const int c = co[(size_t)i * 8 + j];
+        if (b.hpos[i] != 2 * i - 3 + pad) b.uniform2 = 0;
+        for (int j = 0; j < b.nt; j++) {
+          const int c = co[(size_t)i * b.nt + j];
           if (c != co[j] || (c >> 6) < -128 || (c >> 6) > 127) b.uniform2 = 0;
         }
       }
+      if (b.uniform2) for (int j = 0; j < b.nt; j++) b.taps8[pad + j] = co[j];
     }
     {
       b.nph = (b.nt + 1) / 2; b.npv = b.nt / 2 + 1;
@@ -1661,7 +1665,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   {   // operand ranges of the int8 / int16 forms used by the kernel
     int hsum = 0, vsum = 0, hneg = 0;
     for (int j = 0; j < 8; j++) {
-      const int th_ = hb->hco[j], tv = vb->hco[j];
+      const int th_ = hb->taps8[j], tv = vb->taps8[j];
       if (th_ < -8192 || th_ >= 8192) return LGPU_E_UNSUPPORTED;       // tap >> 6 must fit int8
       hsum += th_; vsum += tv; if (th_ < 0) hneg -= th_;
     }
@@ -1673,14 +1677,14 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   for (int i = 0; i < ntracks; i++) if ((uintptr_t)t.src[i] & 15) xoff = 0;
   if (g_h8s_opt & 256) xoff = 0;                   // A / B builds
   const Half8Const *hc;
-  int rc = get_half8_const(hb->hco.data(), swap_rb, xoff, &hc);
+  int rc = get_half8_const(hb->taps8, swap_rb, xoff, &hc);
   if (rc) return rc;
   Half8Args a;
   if ((rc = get_kscale(&a.kscale))) return rc;
   a.xoff = xoff;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
   a.bfrag = hc->bfrag;
-  for (int k = 0; k < 4; k++) a.vc[k] = (uint32_t)(uint16_t)vb->hco[2 * k] | ((uint32_t)(uint16_t)vb->hco[2 * k + 1] << 16);
+  for (int k = 0; k < 4; k++) a.vc[k] = (uint32_t)(uint16_t)vb->taps8[2 * k] | ((uint32_t)(uint16_t)vb->taps8[2 * k + 1] << 16);
   a.swap_rb = swap_rb; a.blend = blend; a.irow2 = irow2; a.bf = bf; a.nbf = 0xFF - bf; a.bf_d = bf_d; a.use_lut = use_lut;
   a.ntracks = ntracks;
   a.dbg = nullptr;
