@@ -96,7 +96,16 @@ def main():
 
     # N > 1: the library's own RCCL communicator (lgpu_dist_comm_create; torch.distributed only carries its 128-byte id) and the C entry
     # point lgpu_params_broadcast for the per-step exchange, on a side stream, double buffered
-    comm = ld.RcclComm("cuda") if world > 1 else None
+    comm = None
+    if world > 1 and not os.environ.get("LGPU_BENCH_TORCH_DIST"):
+        # every rank first checks that it can bind RCCL at all (dlopen + symbols); the communicator is only created when ALL can, so that no rank
+        # waits in ncclCommInitRank for one that gave up -- otherwise the parameter block falls back to torch.distributed's broadcast
+        can = torch.tensor([1 if load().lgpu_dist_bind(None) == 0 else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if int(can.item()) == 1:
+            comm = ld.RcclComm("cuda")
+        elif rank == 0:
+            print("bench.py: librccl could not be bound on every rank; the parameter block goes through torch.distributed", file=sys.stderr)
     pipe = ld.ParamPipeline("cuda", comm=comm)
     nsched = args.steps + args.warmup
     if world > 1:
@@ -173,6 +182,9 @@ def main():
             "config": {"workload": "3840x2160 BGRA32 -> convert(RGBA32) -> bicubic resize 0.5x%s -> chroma blend with 1920x1080 RGBA32 layer -> gamma LUT (linear->sRGB)"
                                    % (" -> 5x5 gaussian" if args.blur else ""),
                        "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
+                       "param_exchange": ("none (one GPU: the kernel reads step s of the resident schedule)" if world == 1 else
+                                          "lgpu_params_broadcast (RCCL, the library's C entry point), pipelined on a side stream" if comm is not None else
+                                          "torch.distributed broadcast (fallback)"),
                        "launches_per_step": 2 if args.blur else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
             "roofline": roof,
         }
@@ -180,7 +192,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.blur)
     if world > 1:
         dist.barrier()
-        comm.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

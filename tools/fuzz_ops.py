@@ -66,8 +66,15 @@ def main():
                 if orc.orc_resize(P(src), src.strides[0], sw, sh, P(want), want.strides[0], dw, dh, ps, interp) != 0:
                     continue
                 d = dev(np.zeros_like(want))
-                ops.resize(dev(src), d, sw, sh, dw, dh, psize=ps, interp=interp)
-                ok = same(host(d), want, dw * ps, dh, "resize %dx%d->%dx%d ps=%d interp=%d stride=%d" % (sw, sh, dw, dh, ps, interp, src.strides[0]))
+                forced = rng.random() < 0.35            # the persistent general-ratio kernel (k_sep2p) on small frames too
+                if forced:
+                    os.environ["LGPU_SEP2P_FORCE"] = "1"
+                    counts["resize(k_sep2p forced)"] = counts.get("resize(k_sep2p forced)", 0) + 1
+                try:
+                    ops.resize(dev(src), d, sw, sh, dw, dh, psize=ps, interp=interp)
+                finally:
+                    os.environ.pop("LGPU_SEP2P_FORCE", None)
+                ok = same(host(d), want, dw * ps, dh, "resize %dx%d->%dx%d ps=%d interp=%d stride=%d forced=%d" % (sw, sh, dw, dh, ps, interp, src.strides[0], forced))
             elif kind == "chain":
                 dw, dh = int(rng.integers(2, 200)), int(rng.integers(2, 120))
                 if rng.random() < 0.6:
@@ -100,7 +107,13 @@ def main():
                 pb = torch.tensor([bf, 0, 0, 0], dtype=torch.int32, device="cuda") if via_block else None
                 prm = ops.chain_params(sw, sh, srcs[0].strides[0], dw, dh, l2s[0].strides[0], orow, swap_rb=swap, interp=3, do_blur=blur,
                                        bf=(bf * 7 + 13) % 256 if via_block else bf, lut=lut, param_block=pb)
-                ops.chain(prm, ops.chain_tracks([dev(s) for s in srcs], [dev(s) for s in l2s], dd))
+                forced = rng.random() < 0.35
+                if forced:
+                    os.environ["LGPU_SEP2P_FORCE"] = "1"
+                try:
+                    ops.chain(prm, ops.chain_tracks([dev(s) for s in srcs], [dev(s) for s in l2s], dd))
+                finally:
+                    os.environ.pop("LGPU_SEP2P_FORCE", None)
                 ok = all(same(host(dd[i]), wants[i], dw * 4, dh, "chain %dx%d->%dx%d swap=%d blur=%d bf=%d lut=%d strides=%d/%d track %d param_block=%d" %
                               (sw, sh, dw, dh, swap, blur, bf, use_lut, srcs[0].strides[0], l2s[0].strides[0], i, via_block)) for i in range(ntr))
             elif kind == "gauss5":
