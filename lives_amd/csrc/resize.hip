@@ -49,6 +49,10 @@ struct SepArgs {
   int nph, npv;
   int ntracks;                      // k_sep2p: tracks of the launch (the tile list is tiles_x * tiles_y * ntracks long)
   unsigned long long *dbg;          // k_sep2p, LGPU_S2P_DEBUG=1: per-wave phase cycle sums [grid][6][8] (nullptr otherwise)
+  // k_sep2p with the horizontal pass on the matrix cores (uniform integer ratio r: every output column has the same taps and starts r pixels after
+  // its neighbour): B fragments [KB][hi, lo][64 lanes] of v_mfma_i32_16x16x64_i8, see sep2p_bfrag()
+  const void *bfrag;
+  int mh_r;
 };
 struct SepTracks {
   const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
@@ -1185,7 +1189,8 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
 // are fetched from the nearest in-frame chunk and overwritten with the edge pixel after landing (source width % 4 == 0 required, so a
 // 16-byte chunk is inside or outside as a whole).  The BGRA byte swap moves from staging into the horizontal pass's selectors.
 // =====================================================================================================================
-constexpr int kS2pCW = 4, kS2pThreads = (kS2pCW + 2) * 64, kS2pMaxReq = 48, kS2pMaxNpv = 8;
+constexpr int kS2pMhCW = 4;       // 8 compute waves per workgroup measured 36 us against 24 for 4K -> 720p: two 10-wave workgroups do not run concurrently on a CU
+constexpr int kS2pMaxReq = 48, kS2pMaxNpv = 8;       // compute waves per workgroup: template parameter CW (4 for the dot2 pass, 8 for the matrix-core pass), + 2 memory waves
 struct S2pTile {
   int track, tx0, ty0;
   __device__ __forceinline__ void set(const SepArgs &a, int work) {
@@ -1238,7 +1243,51 @@ __device__ __noinline__ void s2p_fix_edges(uint8_t *win, int sx0a, int sw, int s
   }
 }
 
-template <int NPH>
+// The horizontal pass of k_sep2p on the matrix cores, for launches whose horizontal filter is the same for every output column at an integer ratio r
+// (4K -> 720p, 4K -> 960x540, 2:1 with more than 8 taps): a banded-Toeplitz product as in k_half8s.  The landed window is flipped to int8 in LDS by
+// its memory wave (^ 0x80).  Work item = (16 window rows, 4 output columns): A = the rows' 64 bytes starting at pixel 4 r q (16-byte aligned) per K block,
+// B[k][n] = tap[pixel - (c0 + r * column)] where the source byte feeds the output channel (Q14 tap = 64 hi + lo, two fragments), KB K blocks of 16
+// pixels cover c0 + 3 r + ntaps pixels.  D = 64 Dh + Dl = sum - 2^21 (the -128 bias times the tap sum 16384), so the accumulator starts at 2^21 + 64 and
+// t = D >> 7 is the spec's (sum + 64) >> 7; v_cvt_pk_i16_i32 clamps and packs two rows.  Lane (g = l >> 4, n = l & 15) holds rows 4 g .. 4 g + 3 of
+// (column n >> 2, channel n & 3): two 4-byte stores into the row-pair buffer the vertical pass reads.  Same bytes as the dot2 pass.
+template <int KB, int CW>
+__device__ __forceinline__ void s2p_hpass_mfma(const SepArgs &a, const uint8_t *win, uint32_t *s_p32, int npairs, int wave, int lane, const int4v (&bh)[KB], const int4v (&bl)[KB]) {
+  const int pitch = a.swt * 4, nrb = (2 * npairs + 15) >> 4, cap = a.sht >> 1;
+  const int4v zero = {0, 0, 0, 0}, cinit = {(1 << 21) + 64, (1 << 21) + 64, (1 << 21) + 64, (1 << 21) + 64};
+  const int g = lane >> 4, n = lane & 15;
+  // a wave owns NQ = 16 / CW neighbouring column blocks and walks the row blocks; the NQ products of a row block are independent chains (loads first,
+  // then the matrix instructions interleaved): one item at a time measured no faster than the dot2 pass -- LDS and MFMA latency
+  constexpr int NQ = 16 / CW;
+  for (int R = 0; R < nrb; R++) {
+    const int row = min(R * 16 + n, a.sht - 1);                          // A: lane supplies row (l & 15), bytes 16 (l >> 4) .. + 15 of the K block
+    const uint8_t *ap = win + row * pitch + (NQ * wave) * (16 * a.mh_r) + g * 16;
+    int4v av[NQ][KB], dh[NQ], dl[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; u++)
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) av[u][kb] = *reinterpret_cast<const int4v *>(ap + u * (16 * a.mh_r) + kb * 64);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) { dh[u] = zero; dl[u] = cinit; }
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+      for (int u = 0; u < NQ; u++) {
+        dh[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[u][kb], bh[kb], dh[u], 0, 0, 0);
+        dl[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[u][kb], bl[kb], dl[u], 0, 0, 0);
+      }
+    const int pr = R * 8 + 2 * g;                                        // row pairs (4 g, 4 g + 1) and (4 g + 2, 4 g + 3) of this block
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+      const int q = NQ * wave + u;
+      const int t0 = ((dh[u].x << 6) + dl[u].x) >> 7, t1 = ((dh[u].y << 6) + dl[u].y) >> 7, t2 = ((dh[u].z << 6) + dl[u].z) >> 7, t3 = ((dh[u].w << 6) + dl[u].w) >> 7;
+      uint32_t *d = s_p32 + ((size_t)pr * kTileW + 4 * q + (n >> 2)) * 4 + (n & 3);
+      if (pr < cap) d[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(t0, t1));
+      if (pr + 1 < cap) d[kTileW * 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(t2, t3));
+    }
+  }
+}
+
+template <int NPH, int KB, int CW>
 __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &trk, uint8_t *smem, const S2pLds &L, int wave, int lane,
                                             int work, int wend, int wstride) {
   uint4 *s_p = reinterpret_cast<uint4 *>(smem + L.p);
@@ -1250,6 +1299,14 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
 #pragma unroll
   for (int c = 0; c < 4; c++) sel[c] = 0x0C040C00u + ((a.src_sel >> (8 * c)) & 3u) * 0x00010001u;
   int par = 0;
+  int4v bh[KB ? KB : 1], bl[KB ? KB : 1];
+  if (KB) {
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      bh[kb] = reinterpret_cast<const int4v *>(a.bfrag)[(kb * 2 + 0) * 64 + lane];
+      bl[kb] = reinterpret_cast<const int4v *>(a.bfrag)[(kb * 2 + 1) * 64 + lane];
+    }
+  }
   unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
 #define S2P_T(i) if (a.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
   for (; work < wend; work += wstride, par ^= 1) {
@@ -1265,12 +1322,15 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
     // the tables arrive raw: hpos of the lane's column, vpos of the rows; the window origin is (hpos[first column] & ~3, vpos[first row] & ~1)
     const int sx0a = (int)s_hc[0] & ~3, sy0 = (int)s_vc[0] & ~1;
     const int npairs = (((int)s_vc[(thh - 1) * (a.npv + 1)] + a.ntv - sy0 + 1) & ~1) >> 1;
+    if (KB) {
+      s2p_hpass_mfma<(KB ? KB : 1), CW>(a, reinterpret_cast<const uint8_t *>(s_src), reinterpret_cast<uint32_t *>(s_p), npairs, wave, lane, bh, bl);
+    } else {
     // ---- horizontal pass: lane = output column, a wave takes window row pairs ----
     const int hoff = (int)s_hc[lane] - sx0a;
     short2v hc2[NPH];
 #pragma unroll
     for (int j = 0; j < NPH; j++) hc2[j] = __builtin_bit_cast(short2v, s_hc[(1 + j) * 64 + lane]);
-    for (int k = wave; k < npairs; k += kS2pCW) {
+    for (int k = wave; k < npairs; k += CW) {
       const uint32_t *r0 = s_src + (2 * k) * a.swt + hoff, *r1 = r0 + a.swt;
       int e0 = a.hround, e1 = a.hround, e2 = a.hround, e3 = a.hround, o0 = a.hround, o1 = a.hround, o2 = a.hround, o3 = a.hround;
 #pragma unroll
@@ -1292,65 +1352,70 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
       pk.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e3 >> a.hshift, o3 >> a.hshift));
       s_p[k * kTileW + lane] = pk;
     }
+    }
     S2P_T(1)
     H8S_BARRIER();                                                                   // B(i): row pairs complete, window slot i & 1 free
     S2P_T(2)
     // ---- vertical pass + epilogue: wave = output row, lane = output column ----
     uint8_t *dst = trk.dst[t.track];
     const uint8_t *l2 = trk.l2[t.track];
-    // four output rows of the wave at a time: their row-pair / tap-pair reads are requested together, so the LDS latency of the (run-time long)
-    // pair loop is paid once per four rows (one row at a time measured 900 cycles per row, mostly waiting)
-    for (int lyb = wave; lyb < thh; lyb += 4 * kS2pCW) {
-      const uint32_t *vc2[4];
-      const uint4 *col[4];
-      int acc[4][4];
+    // NB output rows of the wave at a time (4 when the tile gives a wave more than two rows, else 2): their row-pair / tap-pair reads are requested
+    // together, so the LDS latency of the (run-time long) pair loop is paid once per batch (one row at a time measured 900 cycles per row, mostly waiting)
+    auto vrows = [&](auto nb_tag) {
+      constexpr int NB = decltype(nb_tag)::value;
+      for (int lyb = wave; lyb < thh; lyb += NB * CW) {
+        const uint32_t *vc2[NB];
+        const uint4 *col[NB];
+        int acc[NB][4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ly = min(lyb + r * kS2pCW, thh - 1);               // rows past the tile repeat the last one (not stored)
-        vc2[r] = s_vc + ly * (a.npv + 1);                           // the same address for every lane (broadcast)
-        acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = a.vround;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) col[r] = s_p + (((int)vc2[r][0] >> 1) - (sy0 >> 1)) * kTileW + lane;       // first row pair, window relative
-      for (int j = 0; j < a.npv; j++) {
-        uint4 tt[4];
-        uint32_t cf[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { tt[r] = col[r][j * kTileW]; cf[r] = vc2[r][1 + j]; }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const short2v c2 = __builtin_bit_cast(short2v, cf[r]);
-          acc[r][0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].x), c2, acc[r][0], false);
-          acc[r][1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].y), c2, acc[r][1], false);
-          acc[r][2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].z), c2, acc[r][2], false);
-          acc[r][3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].w), c2, acc[r][3], false);
+        for (int r = 0; r < NB; r++) {
+          const int ly = min(lyb + r * CW, thh - 1);                  // rows past the tile repeat the last one (not stored)
+          vc2[r] = s_vc + ly * (a.npv + 1);                           // the same address for every lane (broadcast)
+          acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = a.vround;
         }
-      }
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ly = lyb + r * kS2pCW, oy = t.ty0 + ly;
-        if (ly < thh && lane < tw) {
-          uint32_t p = a.vshift == 21 ? pack_sat_shr21(acc[r][0], acc[r][1], acc[r][2], acc[r][3])
-                                      : (uint32_t)clamp255(acc[r][0] >> a.vshift) | ((uint32_t)clamp255(acc[r][1] >> a.vshift) << 8) |
-                                            ((uint32_t)clamp255(acc[r][2] >> a.vshift) << 16) | ((uint32_t)clamp255(acc[r][3] >> a.vshift) << 24);
-          if (a.blend) {
-            const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[t.tx0 + lane];
-            p = chroma_rgba(p, q, bf, nbf);
+        for (int r = 0; r < NB; r++) col[r] = s_p + (((int)vc2[r][0] >> 1) - (sy0 >> 1)) * kTileW + lane;       // first row pair, window relative
+        for (int j = 0; j < a.npv; j++) {
+          uint4 tt[NB];
+          uint32_t cf[NB];
+#pragma unroll
+          for (int r = 0; r < NB; r++) { tt[r] = col[r][j * kTileW]; cf[r] = vc2[r][1 + j]; }
+#pragma unroll
+          for (int r = 0; r < NB; r++) {
+            const short2v c2 = __builtin_bit_cast(short2v, cf[r]);
+            acc[r][0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].x), c2, acc[r][0], false);
+            acc[r][1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].y), c2, acc[r][1], false);
+            acc[r][2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].z), c2, acc[r][2], false);
+            acc[r][3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, tt[r].w), c2, acc[r][3], false);
           }
-          if (a.use_lut) p = lut3_rgba(s_lut, p);
-          reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[t.tx0 + lane] = p;
+        }
+#pragma unroll
+        for (int r = 0; r < NB; r++) {
+          const int ly = lyb + r * CW, oy = t.ty0 + ly;
+          if (ly < thh && lane < tw) {
+            uint32_t p = a.vshift == 21 ? pack_sat_shr21(acc[r][0], acc[r][1], acc[r][2], acc[r][3])
+                                        : (uint32_t)clamp255(acc[r][0] >> a.vshift) | ((uint32_t)clamp255(acc[r][1] >> a.vshift) << 8) |
+                                              ((uint32_t)clamp255(acc[r][2] >> a.vshift) << 16) | ((uint32_t)clamp255(acc[r][3] >> a.vshift) << 24);
+            if (a.blend) {
+              const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[t.tx0 + lane];
+              p = chroma_rgba(p, q, bf, nbf);
+            }
+            if (a.use_lut) p = lut3_rgba(s_lut, p);
+            reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[t.tx0 + lane] = p;
+          }
         }
       }
-    }
+    };
+    if (a.th > 2 * CW) vrows(std::integral_constant<int, 4>()); else vrows(std::integral_constant<int, 2>());
   }
   S2P_T(3)
   if (a.dbg && lane == 0)          // [0] waiting at A, [1] horizontal pass, [2] waiting at B, [3] vertical pass + stores
-    for (int i = 0; i < 4; i++) a.dbg[((size_t)blockIdx.x * (kS2pCW + 2) + wave) * 8 + i] = tacc[i];
+    for (int i = 0; i < 4; i++) a.dbg[((size_t)blockIdx.x * (CW + 2) + wave) * 8 + i] = tacc[i];
 #undef S2P_T
 }
 
-template <int NPH>
-__global__ __launch_bounds__(kS2pThreads, 3) void k_sep2p(SepArgs a, SepTracks trk, Lut8 lut) {
+template <int NPH, int KB, int CW>
+__global__ __launch_bounds__((CW + 2) * 64, (CW + 2) / 2) void k_sep2p(SepArgs a, SepTracks trk, Lut8 lut) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const S2pLds L(a.sht, a.swt, a.th, a.npv, NPH);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1360,11 +1425,11 @@ __global__ __launch_bounds__(kS2pThreads, 3) void k_sep2p(SepArgs a, SepTracks t
   const int wend = min((xcd + 1) * chunk, nwork);
   int work = xcd * chunk + (int)(blockIdx.x >> 3);
   if (work >= wend) return;                                     // workgroup-uniform
-  if (wave < kS2pCW) { s2p_compute<NPH>(a, trk, smem, L, wave, lane, work, wend, wstride); return; }
+  if (wave < CW) { s2p_compute<NPH, KB, CW>(a, trk, smem, L, wave, lane, work, wend, wstride); return; }
 
   // ------------------------------------------------ memory waves ------------------------------------------------
   __builtin_amdgcn_s_setprio(3);
-  const int m = wave - kS2pCW;
+  const int m = wave - CW;
   const int cpr = a.swt >> 2, nchunks = a.sht * cpr, nreq = (nchunks + 63) >> 6;
   const uint32_t mcpr = ((1u << 20) + (uint32_t)cpr - 1u) / (uint32_t)cpr;          // c / cpr == (c * mcpr) >> 20 for c < 3072, cpr >= 4
   const uint32_t mnpv = ((1u << 16) + (uint32_t)a.npv) / (uint32_t)(a.npv + 1);     // i / (npv + 1) likewise for i < 256
@@ -1420,6 +1485,14 @@ __global__ __launch_bounds__(kS2pThreads, 3) void k_sep2p(SepArgs a, SepTracks t
   auto land = [&](int slot) {                                    // my window in flight has to be complete before the barrier that publishes it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (sx0a_f < 0 || sx0a_f + a.swt > a.sw) s2p_fix_edges(smem + slot * L.win, sx0a_f, a.sw, a.swt, a.sht, lane);
+    if (KB) {                                                    // uint8 -> int8 for the matrix cores
+      uint4 *w = reinterpret_cast<uint4 *>(smem + slot * L.win);
+      for (int i = lane; i < (L.win >> 4); i += 64) {
+        uint4 v = w[i];
+        v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+        w[i] = v;
+      }
+    }
   };
 
   // wave m starts on tile m of the list; wave 0 publishes tile 0 before A(0)
@@ -1449,7 +1522,7 @@ __global__ __launch_bounds__(kS2pThreads, 3) void k_sep2p(SepArgs a, SepTracks t
     S2P_T(3)
   }
   if (a.dbg && lane == 0)          // [0] waiting at A, [1] waiting for the window + fix-up, [2] waiting at B, [3] issuing
-    for (int k = 0; k < 4; k++) a.dbg[((size_t)blockIdx.x * (kS2pCW + 2) + wave) * 8 + k] = tacc[k];
+    for (int k = 0; k < 4; k++) a.dbg[((size_t)blockIdx.x * (CW + 2) + wave) * 8 + k] = tacc[k];
 #undef S2P_T
 }
 
@@ -1758,12 +1831,15 @@ struct SepPlan {
   bool pers = false;
   int p_th = 0, p_sht = 0, p_tiles_y = 0;
   size_t p_lds = 0;
+  // ... and its horizontal pass on the matrix cores when every output column has the same taps at an integer ratio (mh_r > 0)
+  int mh_r = 0, mh_c0 = 0, mh_kb = 0, mh_nt = 0;
+  int16_t mh_taps[32];
 };
 
 static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, int dw, int dh, int orow, int ntracks,
                     int hround, int hshift, int vround, int vshift, SepPlan *p) {
   SepArgs &a = p->a;
-  a.dbg = nullptr; a.ntracks = ntracks; a.hco2 = a.vco2 = nullptr; a.nph = a.npv = 0;
+  a.dbg = nullptr; a.ntracks = ntracks; a.hco2 = a.vco2 = nullptr; a.nph = a.npv = 0; a.bfrag = nullptr; a.mh_r = 0;
   a.sw = sw; a.sh = sh; a.irow = irow; a.dw = dw; a.dh = dh; a.orow = orow;
   a.hpos = hb->pos; a.hco = hb->co; a.nth = hb->nt;
   a.vpos = vb->pos; a.vco = vb->co; a.ntv = vb->nt;
@@ -1835,7 +1911,59 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
         }
       }
     }
+    // the horizontal pass as a matrix product: same taps for every column, integer ratio, taps that split into int8 hi / 6-bit lo, at most two K blocks
+    p->mh_r = 0;
+    const bool no_mh = getenv("LGPU_NO_SEP2P_MFMA") != nullptr;
+    if (p->pers && !no_mh && dw >= 1 && sw % dw == 0 && sw / dw >= 2 && hb->nt <= 32 && hround == 64 && hshift == 7) {
+      const int r = sw / dw, c0 = hb->hpos[0] & 3, nt = hb->nt;
+      bool ok = (c0 + 3 * r + nt) <= 32;
+      for (int c = 0; c < dw && ok; c++) {
+        if (hb->hpos[c] != hb->hpos[0] + r * c) ok = false;
+        for (int j = 0; j < nt && ok; j++) {
+          const int tp = hb->hco[(size_t)c * nt + j];
+          if (tp != hb->hco[j] || tp < -8192 || tp >= 8192) ok = false;
+        }
+      }
+      if (ok) {
+        p->mh_r = r; p->mh_c0 = c0; p->mh_nt = nt; p->mh_kb = (c0 + 3 * r + nt + 15) / 16;
+        for (int j = 0; j < 32; j++) p->mh_taps[j] = j < nt ? hb->hco[j] : 0;
+      }
+    }
   }
+  return LGPU_OK;
+}
+
+// B fragments of the matrix-core horizontal pass (s2p_hpass_mfma), cached per (device, taps, ratio, first-column offset, byte order).
+// Lane l supplies B[k = 16 (l >> 4) + e][n = l & 15], e = 0..15, of K block kb: k = (window pixel 16 kb + (k >> 2), source byte k & 3),
+// n = (output column n >> 2, output channel n & 3); value = tap[pixel - (c0 + r column)] where the source byte feeds the channel (src_sel), as 64 hi + lo.
+static std::mutex g_s2pb_mu;
+static std::map<std::vector<int>, void *> g_s2pb;
+static int sep2p_bfrag(const SepPlan &p, const void **out) {
+  int dev = 0;
+  LGPU_HIP(hipGetDevice(&dev));
+  std::vector<int> key = {dev, p.mh_r, p.mh_c0, p.mh_nt, p.mh_kb, (int)p.a.src_sel};
+  for (int j = 0; j < p.mh_nt; j++) key.push_back(p.mh_taps[j]);
+  std::lock_guard<std::mutex> lk(g_s2pb_mu);
+  auto it = g_s2pb.find(key);
+  if (it == g_s2pb.end()) {
+    std::vector<int8_t> frag((size_t)p.mh_kb * 2 * 64 * 16);
+    for (int kb = 0; kb < p.mh_kb; kb++)
+      for (int l = 0; l < 64; l++)
+        for (int e = 0; e < 16; e++) {
+          const int k = 16 * (l >> 4) + e, n = l & 15;
+          const int px = 16 * kb + (k >> 2), sbyte = k & 3, col = n >> 2, och = n & 3;
+          const int want = (int)((p.a.src_sel >> (8 * och)) & 3u);
+          const int j = px - (p.mh_c0 + p.mh_r * col);
+          const int tap = (sbyte == want && j >= 0 && j < p.mh_nt) ? p.mh_taps[j] : 0;
+          frag[(((size_t)kb * 2 + 0) * 64 + l) * 16 + e] = (int8_t)(tap >> 6);
+          frag[(((size_t)kb * 2 + 1) * 64 + l) * 16 + e] = (int8_t)(tap & 63);
+        }
+    void *d = nullptr;
+    LGPU_HIP(hipMalloc(&d, frag.size()));
+    LGPU_HIP(hipMemcpy(d, frag.data(), frag.size(), hipMemcpyHostToDevice));
+    it = g_s2pb.emplace(key, d).first;
+  }
+  *out = it->second;
   return LGPU_OK;
 }
 
@@ -1856,24 +1984,40 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
   const bool s2p_force = getenv("LGPU_SEP2P_FORCE") != nullptr;          // tests: the persistent kernel on small frames
   // k_sep2p pays when a workgroup gets a few tiles to pipeline and the windows are the heavy part (shrinking); measured in profiles/r02/resize_ratios.md
   if (p.pers && p.a.vec && p.variant >= 100 &&
-      (s2p_force || (p.a.dh < p.a.sh && (long)p.a.tiles_x * p.p_tiles_y * (long)p.grid.y >= 3L * 512))) {
+      (s2p_force || p.mh_r || (p.a.dh < p.a.sh && (long)p.a.tiles_x * p.p_tiles_y * (long)p.grid.y >= 3L * 512))) {
     SepArgs ap = p.a;
     ap.th = p.p_th; ap.sht = p.p_sht; ap.tiles_y = p.p_tiles_y; ap.ntracks = (int)p.grid.y;
+    ap.bfrag = nullptr; ap.mh_r = p.mh_r;
+    size_t lds_launch = p.p_lds;
+    if (p.mh_r) {
+      int rc = sep2p_bfrag(p, &ap.bfrag);
+      if (rc) return rc;
+      lds_launch = S2pLds(ap.sht, ap.swt, ap.th, ap.npv, 1).total;
+    }
     static int g_cus = 0;
     if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
     const int nwork = ap.tiles_x * ap.tiles_y * ap.ntracks;
     int g = (nwork + 7) & ~7;
-    if (g > 2 * g_cus) g = (2 * g_cus) & ~7;
+    if (g > 2 * g_cus) g = (2 * g_cus) & ~7;          // two workgroups per CU by LDS (three or four smaller ones measured slower: 38 / 48 us against 24 for 4K -> 720p)
     if (g < 8) g = 8;
     static const bool s2p_dbg = getenv("LGPU_S2P_DEBUG") != nullptr;
     ap.dbg = nullptr;
-    if (s2p_dbg) { LGPU_HIP(hipMalloc((void **)&ap.dbg, (size_t)g * 6 * 8 * 8)); LGPU_HIP(hipMemsetAsync(ap.dbg, 0, (size_t)g * 6 * 8 * 8, st)); }
+    const int nwv = (p.mh_r ? kS2pMhCW : 4) + 2;
+    if (s2p_dbg) { LGPU_HIP(hipMalloc((void **)&ap.dbg, (size_t)g * nwv * 8 * 8)); LGPU_HIP(hipMemsetAsync(ap.dbg, 0, (size_t)g * nwv * 8 * 8, st)); }
 #define SEP2P_LAUNCH(N)                                                                                      \
   do {                                                                                                       \
     if (p.p_lds > 48 * 1024)                                                                                 \
-      LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2p<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.p_lds)); \
-    hipLaunchKernelGGL((k_sep2p<N>), dim3((unsigned)g), dim3(kS2pThreads), p.p_lds, st, ap, t, l);            \
+      LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2p<N, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.p_lds)); \
+    hipLaunchKernelGGL((k_sep2p<N, 0, 4>), dim3((unsigned)g), dim3(6 * 64), p.p_lds, st, ap, t, l);           \
   } while (0)
+    if (p.mh_r) {
+      if (lds_launch > 48 * 1024) {
+        LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2p<1, 1, kS2pMhCW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
+        LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2p<1, 2, kS2pMhCW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
+      }
+      if (p.mh_kb == 1) hipLaunchKernelGGL((k_sep2p<1, 1, kS2pMhCW>), dim3((unsigned)g), dim3((kS2pMhCW + 2) * 64), lds_launch, st, ap, t, l);
+      else hipLaunchKernelGGL((k_sep2p<1, 2, kS2pMhCW>), dim3((unsigned)g), dim3((kS2pMhCW + 2) * 64), lds_launch, st, ap, t, l);
+    } else
     switch (p.variant) {
     case 101: SEP2P_LAUNCH(1); break;
     case 102: SEP2P_LAUNCH(2); break;
@@ -1889,15 +2033,18 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
 #undef SEP2P_LAUNCH
     LGPU_CHECK_LAUNCH();
     if (s2p_dbg) {           // debugging aid: mean cycles (100 MHz s_memtime ticks) per phase over the workgroups, compute wave 0 and the two memory waves
-      std::vector<unsigned long long> h((size_t)g * 48);
+      std::vector<unsigned long long> h((size_t)g * nwv * 8);
       LGPU_HIP(hipStreamSynchronize(st));
       LGPU_HIP(hipMemcpy(h.data(), ap.dbg, h.size() * 8, hipMemcpyDeviceToHost));
       LGPU_HIP(hipFree(ap.dbg));
       double acc[3][4] = {{0}};
       for (int b = 0; b < g; b++)
-        for (int k = 0; k < 4; k++) { acc[0][k] += (double)h[((size_t)b * 6 + 0) * 8 + k]; acc[1][k] += (double)h[((size_t)b * 6 + 4) * 8 + k]; acc[2][k] += (double)h[((size_t)b * 6 + 5) * 8 + k]; }
-      fprintf(stderr, "k_sep2p<%d> grid %d th %d sht %d swt %d tiles %d lds %zu | compute w0: A %.0f H %.0f B %.0f V %.0f | mem w4: A %.0f land %.0f B %.0f issue %.0f | mem w5: A %.0f land %.0f B %.0f issue %.0f (ticks of 10 ns, mean per workgroup)\n",
-              p.variant - 100, g, ap.th, ap.sht, ap.swt, nwork, p.p_lds, acc[0][0] / g, acc[0][1] / g, acc[0][2] / g, acc[0][3] / g, acc[1][0] / g, acc[1][1] / g, acc[1][2] / g,
+        for (int k = 0; k < 4; k++) { acc[0][k] += (double)h[((size_t)b * nwv + 0) * 8 + k]; acc[1][k] += (double)h[((size_t)b * nwv + nwv - 2) * 8 + k]; acc[2][k] += (double)h[((size_t)b * nwv + nwv - 1) * 8 + k]; }
+      int occ = -1;
+      if (p.mh_r) { if (p.mh_kb == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sep2p<1, 1, kS2pMhCW>, (kS2pMhCW + 2) * 64, lds_launch); else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sep2p<1, 2, kS2pMhCW>, (kS2pMhCW + 2) * 64, lds_launch); }
+      fprintf(stderr, "occupancy (workgroups per CU by the runtime's calculator): %d\n", occ);
+      fprintf(stderr, "k_sep2p<%d>%s grid %d th %d sht %d swt %d tiles %d lds %zu | compute w0: A %.0f H %.0f B %.0f V %.0f | mem w4: A %.0f land %.0f B %.0f issue %.0f | mem w5: A %.0f land %.0f B %.0f issue %.0f (ticks of 10 ns, mean per workgroup)\n",
+              p.variant - 100, p.mh_r ? " (matrix-core horizontal pass)" : "", g, ap.th, ap.sht, ap.swt, nwork, lds_launch, acc[0][0] / g, acc[0][1] / g, acc[0][2] / g, acc[0][3] / g, acc[1][0] / g, acc[1][1] / g, acc[1][2] / g,
               acc[1][3] / g, acc[2][0] / g, acc[2][1] / g, acc[2][2] / g, acc[2][3] / g);
     }
     return LGPU_OK;
