@@ -23,17 +23,46 @@ __device__ __forceinline__ uint32_t isqrt24(uint32_t n) {
   return r;
 }
 
+// the planes that are only copied (softlight.c:143-151) ride in the same launch: blockIdx.z = 1 .. ncopy copies 64 x 16 tiles of plane z
+struct SoftCopy { const uint8_t *src[3]; uint8_t *dst[3]; int irow[3], orow[3], w, h, n; };
 __global__ __launch_bounds__(kBlock) void k_softlight(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height,
-                                                        int ymin, int ymax) {
-  __shared__ uint8_t s[(kStH + 2) * (kStW + 8)];              // rows y0-1 .. y0+kStH, columns x0-4 .. x0+kStW+3
+                                                        int ymin, int ymax, SoftCopy cp) {
+  __shared__ __attribute__((aligned(4))) uint8_t s[(kStH + 2) * (kStW + 8)];              // rows y0-1 .. y0+kStH, columns x0-4 .. x0+kStW+3
   constexpr int P = kStW + 8;
   const int x0 = blockIdx.x * kStW, y0 = blockIdx.y * kStH;
-  for (int i = threadIdx.x; i < (kStH + 2) * P; i += kBlock) {
-    const int r = i / P, c = i - r * P;
-    int sy = y0 - 1 + r, sx = x0 - 4 + c;
-    sy = sy < 0 ? 0 : sy >= height ? height - 1 : sy;          // clamped fetches only feed border outputs, which are copies
-    sx = sx < 0 ? 0 : sx >= width ? width - 1 : sx;
-    s[i] = src[(size_t)sy * irow + sx];
+  if (blockIdx.z) {
+    const int pz = blockIdx.z - 1, ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4, y = y0 + ly, x = x0 + lx;
+    if (y >= cp.h || x >= cp.w) return;
+    const uint8_t *ps = cp.src[pz] + (size_t)y * cp.irow[pz] + x;
+    uint8_t *pd = cp.dst[pz] + (size_t)y * cp.orow[pz] + x;
+    if (x + 4 <= cp.w && (((uintptr_t)ps | (uintptr_t)pd) & 3) == 0) *reinterpret_cast<uint32_t *>(pd) = *reinterpret_cast<const uint32_t *>(ps);
+    else for (int j = 0; j < 4 && x + j < cp.w; j++) pd[j] = ps[j];
+    return;
+  }
+  // window as dwords, both of a thread's requests issued before the first is stored (a rolled byte loop paid five dependent round trips per tile)
+  {
+    constexpr int DW = P / 4, ND = (kStH + 2) * DW, NI = (ND + kBlock - 1) / kBlock;        // 18 dwords per row, 324 per window, 2 per thread
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)irow) & 3) == 0;
+    uint32_t v[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+      const int i = threadIdx.x + k * kBlock, r = i / DW, c = i - r * DW;
+      int sy = y0 - 1 + r;
+      const int sx = x0 - 4 + 4 * c;
+      sy = sy < 0 ? 0 : sy >= height ? height - 1 : sy;        // clamped fetches only feed border outputs, which are copies
+      v[k] = 0;
+      if (i < ND) {
+        const uint8_t *row = src + (size_t)sy * irow;
+        if (al && sx >= 0 && sx + 4 <= width) v[k] = *reinterpret_cast<const uint32_t *>(row + sx);
+        else
+          for (int j = 0; j < 4; j++) { int xx = sx + j; xx = xx < 0 ? 0 : xx >= width ? width - 1 : xx; v[k] |= (uint32_t)row[xx] << (8 * j); }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+      const int i = threadIdx.x + k * kBlock;
+      if (i < ND) reinterpret_cast<uint32_t *>(s)[i] = v[k];
+    }
   }
   __syncthreads();
   const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
@@ -77,16 +106,13 @@ struct EdgeState {            // the function-scope accumulators of edge_process
   unsigned int hist[1024];
 };
 
-__global__ void k_edge_reset(EdgeState *st) {
-  const int i = threadIdx.x;
-  if (i == 0) { st->bh = st->bl = st->nbh = st->nbl = 0; st->difmax = 0.; st->threshmax = 0; st->thresh = 0; st->sum = 0; }
   for (int k = i; k < 1024; k += blockDim.x) st->hist[k] = 0;
 }
 
 // luma (pass 0) or byte pass-1 of the pixel; gradient magnitude map + histogram
 template <int PS>
 __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int irow, int width, int height, int order, int pass,
-                                                       const int32_t *gluma, uint16_t *map, EdgeState *st) {
+                                                       const int32_t *gluma, uint16_t *map, unsigned int *slices, int vec) {
   __shared__ uint8_t l[(kStH + 4) * (kStW + 4)];
   __shared__ int32_t s_luma[768];
   __shared__ unsigned int s_hist[1024];
@@ -103,6 +129,33 @@ __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int iro
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int x0 = (tile % tiles_x) * kStW, y0 = (tile / tiles_x) * kStH;
   __syncthreads();                                            // the previous tile's readers are done with `l`
+  if (PS == 4 && vec) {
+    // one dword per pixel, and all of a thread's window pixels requested before the first is used: the rolled loop below pays a global round trip
+    // per pixel (five to six per tile and thread), which was most of this kernel's 37 us
+    constexpr int NI = ((kStH + 4) * P + kBlock - 1) / kBlock;
+    uint32_t px[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+      const int i = threadIdx.x + k * kBlock, r = i / P, c = i - r * P;
+      const int sy = y0 - 2 + r, sx = x0 - 2 + c;
+      px[k] = 0;
+      if (i < (kStH + 4) * P && sy >= 0 && sy < height && sx >= 0 && sx < width) px[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)sy * irow + (size_t)sx * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+      const int i = threadIdx.x + k * kBlock, r = i / P, c = i - r * P;
+      const int sy = y0 - 2 + r, sx = x0 - 2 + c;
+      uint8_t v = 0;
+      if (sy >= 0 && sy < height && sx >= 0 && sx < width) {
+        if (pass == 0) {        // calc_luma(), libweed/weed-plugin-utils.c:924-934
+          const int c0 = (px[k] >> (order == 2 ? 8 : 0)) & 0xFF, c1 = (px[k] >> (order == 2 ? 16 : 8)) & 0xFF, c2 = (px[k] >> (order == 2 ? 24 : 16)) & 0xFF;
+          const int32_t t = order == 1 ? (s_luma[c2] + s_luma[256 + c1] + s_luma[512 + c0]) : (s_luma[c0] + s_luma[256 + c1] + s_luma[512 + c2]);
+          v = (uint8_t)(t >> 16);
+        } else v = (uint8_t)(px[k] >> (8 * (pass - 1)));
+      }
+      if (i < (kStH + 4) * P) l[i] = v;
+    }
+  } else
   for (int i = threadIdx.x; i < (kStH + 4) * P; i += kBlock) {
     const int r = i / P, c = i - r * P;
     const int sy = y0 - 2 + r, sx = x0 - 2 + c;
@@ -142,16 +195,36 @@ __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int iro
   }   // tiles
   if (lsum) atomicAdd(&s_sum, lsum);
   __syncthreads();
-  for (int i = threadIdx.x; i < 1024; i += kBlock)
-    if (s_hist[i]) atomicAdd(&st->hist[i], s_hist[i]);
-  if (threadIdx.x == 0 && s_sum) atomicAdd(&st->sum, (unsigned long long)s_sum);
+  // the workgroup's histogram goes to its own slice, plain stores: k_edge_hist_reduce adds the slices up.  (Every workgroup adding its 1017 bins
+  // to the same 1017 global counters cost more than the map itself: 54 us per frame with 1024 workgroups, 79 with 2048, 47 with 512.)
+  unsigned int *sl = slices + (size_t)blockIdx.x * 1025;
+  for (int i = threadIdx.x; i < 1024; i += kBlock) sl[i] = s_hist[i];
+  if (threadIdx.x == 0) sl[1024] = s_sum;
+}
+// slices -> EdgeState: workgroup = (256 bins, one 64th of the slices: at most 16 per thread, all requested before they are added -- with 16 chunks and a rolled
+// loop this kernel took 25.6 us, every load a round trip of its own)
+constexpr int kEdgeChunks = 64;
+__global__ __launch_bounds__(256) void k_edge_hist_reduce(const unsigned int *slices, int nslices, EdgeState *st) {
+  const int bin = (blockIdx.x & 3) * 256 + threadIdx.x, chunk = blockIdx.x >> 2;
+  unsigned int v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { const int sidx = chunk + k * kEdgeChunks; v[k] = sidx < nslices ? slices[(size_t)sidx * 1025 + bin] : 0u; }
+  unsigned int acc = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc += v[k];
+  if (acc) atomicAdd(&st->hist[bin], acc);
+  if ((blockIdx.x & 3) == 0 && threadIdx.x < 16) {
+    const int sidx = chunk + (int)threadIdx.x * kEdgeChunks;
+    const unsigned int t = sidx < nslices ? slices[(size_t)sidx * 1025 + 1024] : 0u;
+    if (t) atomicAdd(&st->sum, (unsigned long long)t);
+  }
 }
 
 // The Otsu scan of edge.c:184-205 with 1024 threads.  The reference walks t = 0..1016 serially keeping running sums and the
 // first record high of dif; here the running sums are exclusive-inclusive prefix sums of the histogram (exact in uint64),
 // every t evaluates its dif with the same IEEE double operations in the same order, and the serial "if (dif > difmax)" chain
 // is the smallest t that attains the maximum -- provided that maximum beats the difmax carried in from the previous pass.
-__global__ __launch_bounds__(1024) void k_edge_otsu(EdgeState *st, unsigned long long count) {
+__global__ __launch_bounds__(1024) void k_edge_otsu(EdgeState *st, unsigned long long count, int first) {
   __shared__ unsigned long long s_n[1024], s_w[1024];
   __shared__ double s_d[1024];
   __shared__ unsigned int s_t[1024];
@@ -165,7 +238,9 @@ __global__ __launch_bounds__(1024) void k_edge_otsu(EdgeState *st, unsigned long
     s_n[t] += n; s_w[t] += w;
     __syncthreads();
   }
-  const unsigned long long bh0 = st->bh + st->sum, nbh0 = st->nbh + count, bl0 = st->bl, nbl0 = st->nbl;
+  // first pass of a frame: the carried accumulators start from zero (edge.c:146-149 are function-scope locals); this replaces a reset launch per frame --
+  // the histogram and the sum are left zeroed by the previous scan (below) and by the allocation
+  const unsigned long long bh0 = (first ? 0ull : st->bh) + st->sum, nbh0 = (first ? 0ull : st->nbh) + count, bl0 = first ? 0ull : st->bl, nbl0 = first ? 0ull : st->nbl;
   double dif = -1.;
   bool valid = false;
   if (t >= 1 && t < 1017) {
@@ -187,8 +262,8 @@ __global__ __launch_bounds__(1024) void k_edge_otsu(EdgeState *st, unsigned long
     __syncthreads();
   }
   if (t == 0) {
-    double difmax = st->difmax;
-    unsigned int threshmax = st->threshmax;
+    double difmax = first ? 0. : st->difmax;
+    unsigned int threshmax = first ? 0u : st->threshmax;
     if (s_d[0] > difmax) { difmax = s_d[0]; threshmax = s_t[0]; }
     st->bh = bh0 - s_w[1016]; st->nbh = nbh0 - s_n[1016]; st->bl = bl0 + s_w[1016]; st->nbl = nbl0 + s_n[1016];
     st->difmax = difmax; st->threshmax = threshmax; st->thresh = threshmax;
@@ -202,7 +277,7 @@ __global__ __launch_bounds__(1024) void k_edge_otsu(EdgeState *st, unsigned long
 template <int PS>
 __global__ __launch_bounds__(kBlock) void k_edge_paint(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height,
                                                          int pass, int mode, int aoffs, int inplace, const uint16_t *map,
-                                                         const EdgeState *st) {
+                                                         const EdgeState *st, int vec) {
   const int x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= width) return;
   const unsigned int thresh = st->thresh;
@@ -210,6 +285,21 @@ __global__ __launch_bounds__(kBlock) void k_edge_paint(const uint8_t *src, int i
     const uint8_t *s = src + (size_t)y * irow + (size_t)x * PS;
     uint8_t *d = dst + (size_t)y * orow + (size_t)x * PS;
     const bool edge = map[(size_t)y * width + x] >= thresh;
+    if (PS == 4 && vec) {
+      // the same byte rules on one dword: colour bytes = source / black / white (pass 0) or one channel forced to 255 (passes 1..3, edges only);
+      // the alpha byte is the source's (copied when out of place, already there when in place)
+      const uint32_t sp = *reinterpret_cast<const uint32_t *>(s);
+      const uint32_t cmask = aoffs == 1 ? 0xFFFFFF00u : 0x00FFFFFFu;
+      if (pass == 0) {
+        const uint32_t colour = edge ? (mode == 1 ? cmask : (sp & cmask)) : 0u;
+        *reinterpret_cast<uint32_t *>(d) = colour | (sp & ~cmask);
+      } else if (edge) {
+        const uint32_t old_ = *reinterpret_cast<const uint32_t *>(d);
+        const uint32_t forced = 0xFFu << (8 * ((aoffs == 1 ? 1 : 0) + pass - 1));
+        *reinterpret_cast<uint32_t *>(d) = ((old_ | forced) & cmask) | ((inplace ? old_ : sp) & ~cmask);
+      }
+      continue;
+    }
     int code[3];
     if (edge) {
       if (pass == 0) code[0] = code[1] = code[2] = (mode == 1 ? 2 : 1);
@@ -283,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_bz_color(const uint32_t *src, int ir
 }
 
 // per (device, stream) scratch: gradient map + state
-struct EdgeScratch { uint16_t *map = nullptr; size_t cap = 0; EdgeState *st = nullptr; };
+struct EdgeScratch { uint16_t *map = nullptr; size_t cap = 0; EdgeState *st = nullptr; unsigned int *slices = nullptr; };
 static std::mutex g_edge_mu;
 // held across the launches of one multi-launch sequence (edge passes, in-place deinterlace): host threads that share a stream
 // must not interleave their sequences on the shared scratch
@@ -484,15 +574,16 @@ extern "C" int lgpu_softlight(const uint8_t *const src_d[4], const int irow[4], 
   for (int i = 0; i < nplanes; i++) LGPU_REQUIRE(src_d[i] && dst_d[i] && src_d[i] != dst_d[i], "null plane, or in place (the filter is not CAN_DO_INPLACE)");
   LGPU_REQUIRE(irow[0] >= width && orow[0] >= width, "rowstride smaller than a row");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(cdiv((unsigned)width, kStW), cdiv((unsigned)height, kStH));
+  // the other planes are copied (softlight.c:143-151) by extra blocks of the same launch; alpha of YUVA4444P has the chroma geometry of 4:4:4
+  SoftCopy cp = {};
+  cp.w = (palette == 512 || palette == 513 || palette == 522) ? width >> 1 : width;
+  cp.h = (palette == 512 || palette == 513) ? height >> 1 : height;
+  cp.n = nplanes - 1;
+  for (int i = 1; i < nplanes; i++) { cp.src[i - 1] = src_d[i]; cp.dst[i - 1] = dst_d[i]; cp.irow[i - 1] = irow[i]; cp.orow[i - 1] = orow[i]; }
+  const dim3 grid(cdiv((unsigned)width, kStW), cdiv((unsigned)height, kStH), (unsigned)nplanes);
   hipLaunchKernelGGL(k_softlight, grid, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16,
-                     unclamped ? 255 : 235);
+                     unclamped ? 255 : 235, cp);
   LGPU_CHECK_LAUNCH();
-  // the other planes are copied (softlight.c:143-151); alpha of YUVA4444P has the chroma geometry of 4:4:4
-  const int cw = (palette == 512 || palette == 513 || palette == 522) ? width >> 1 : width;
-  const int chh = (palette == 512 || palette == 513) ? height >> 1 : height;
-  for (int i = 1; i < nplanes; i++)
-    LGPU_HIP(hipMemcpy2DAsync(dst_d[i], (size_t)orow[i], src_d[i], (size_t)irow[i], (size_t)cw, (size_t)chh, hipMemcpyDeviceToDevice, st));
   return LGPU_OK;
 }
 
@@ -523,20 +614,22 @@ extern "C" int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int oro
       if (hipMalloc((void **)&e.map, need) != hipSuccess) { set_error("hipMalloc(%zu) for the edge map failed", need); return LGPU_E_NOMEM; }
       e.cap = need;
     }
-    if (!e.st) LGPU_HIP(hipMalloc((void **)&e.st, sizeof(EdgeState)));
+    if (!e.st) { LGPU_HIP(hipMalloc((void **)&e.st, sizeof(EdgeState))); LGPU_HIP(hipMemset(e.st, 0, sizeof(EdgeState))); }
+    if (!e.slices) LGPU_HIP(hipMalloc((void **)&e.slices, (size_t)1024 * 1025 * sizeof(unsigned int)));      // one histogram slice per map workgroup
     sc = e;
   }
   const unsigned long long count = (width > 4 && height > 4) ? (unsigned long long)(width - 4) * (unsigned long long)(height - 4) : 0ull;
   const unsigned ntiles = cdiv((unsigned)width, kStW) * cdiv((unsigned)height, kStH);
-  const dim3 tgrid(ntiles < 1024 ? ntiles : 1024);
+  const dim3 tgrid(ntiles < 1024u ? ntiles : 1024u);
   const dim3 pgrid(cdiv((unsigned)width, kBlock), (unsigned)(height < 1024 ? height : 1024));
-  hipLaunchKernelGGL(k_edge_reset, dim3(1), dim3(256), 0, st, sc.st);
+  const int vec4 = (psize == 4 && ((((uintptr_t)src_d | (uintptr_t)dst_d | (uintptr_t)irow | (uintptr_t)orow) & 3) == 0)) ? 1 : 0;
   for (int pass = 0; pass < 4; pass++) {
-    if (psize == 4) hipLaunchKernelGGL(k_edge_map<4>, tgrid, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, sc.st);
-    else hipLaunchKernelGGL(k_edge_map<3>, tgrid, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, sc.st);
-    hipLaunchKernelGGL(k_edge_otsu, dim3(1), dim3(1024), 0, st, sc.st, count);
-    if (psize == 4) hipLaunchKernelGGL(k_edge_paint<4>, pgrid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, pass, mode, aoffs, inplace, sc.map, sc.st);
-    else hipLaunchKernelGGL(k_edge_paint<3>, pgrid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, pass, mode, aoffs, inplace, sc.map, sc.st);
+    if (psize == 4) hipLaunchKernelGGL(k_edge_map<4>, tgrid, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, sc.slices, vec4);
+    else hipLaunchKernelGGL(k_edge_map<3>, tgrid, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, sc.slices, 0);
+    hipLaunchKernelGGL(k_edge_hist_reduce, dim3(4 * kEdgeChunks), dim3(256), 0, st, sc.slices, (int)tgrid.x, sc.st);      // tgrid.x <= 1024 = 16 * kEdgeChunks slices
+    hipLaunchKernelGGL(k_edge_otsu, dim3(1), dim3(1024), 0, st, sc.st, count, pass == 0 ? 1 : 0);
+    if (psize == 4) hipLaunchKernelGGL(k_edge_paint<4>, pgrid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, pass, mode, aoffs, inplace, sc.map, sc.st, vec4);
+    else hipLaunchKernelGGL(k_edge_paint<3>, pgrid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, pass, mode, aoffs, inplace, sc.map, sc.st, 0);
     if (mode < 2) break;
   }
   LGPU_CHECK_LAUNCH();
