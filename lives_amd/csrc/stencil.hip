@@ -106,9 +106,6 @@ struct EdgeState {            // the function-scope accumulators of edge_process
   unsigned int hist[1024];
 };
 
-  for (int k = i; k < 1024; k += blockDim.x) st->hist[k] = 0;
-}
-
 // luma (pass 0) or byte pass-1 of the pixel; gradient magnitude map + histogram
 template <int PS>
 __global__ __launch_bounds__(kBlock) void k_edge_map(const uint8_t *src, int irow, int width, int height, int order, int pass,
