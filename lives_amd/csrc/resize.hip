@@ -1769,6 +1769,9 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   const int mode = g_h8s_opt & 255;                // A / B builds (tools/ab_h8s.py): ablations of k_half8s
   const size_t lds = H8SL::kLds;
   int grid = g_cus * (int)(160 * 1024 / lds);
+  // multi-GPU hosts: leave a few workgroup slots (one per XCD) free, so that a kernel with a large LDS footprint enqueued on another stream -- RCCL's
+  // broadcast of the next parameter block -- finds a CU while this persistent kernel runs (tools/corun_probe.py, profiles/r02/corun_probe.txt)
+  if (const char *sp = getenv("LGPU_CHAIN_SPARE_WGS")) { const int n = atoi(sp); if (n > 0 && n < grid / 2) grid -= n; }
   if (grid > nwork) grid = nwork;
   grid = (grid + 7) & ~7;                      // whole workgroups per XCD
 #define H8S_LAUNCH(DBG_, ABL_)                                                                                          \
