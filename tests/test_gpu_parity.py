@@ -1060,6 +1060,31 @@ def test_chain_with_device_param_block(gpu, orc, do_blur):
             assert_same(host(d_dst[i]), want, dw, dh, 4, "param block step %d (bf=%d) track %d blur=%d" % (s, bf, i, do_blur))
 
 
+def test_chain_with_spare_workgroup_slots(gpu, monkeypatch):
+    """multi-GPU hosts run the persistent chain kernel with a few workgroup slots left free (LGPU_CHAIN_SPARE_WGS, for RCCL's broadcast): another grid size
+    and tile-list stride, the same bytes -- at the bench's geometry, one 4K track"""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src = torch.randint(0, 256, (sh, sw * 4), dtype=torch.uint8, device="cuda", generator=g)
+    l2 = torch.randint(0, 256, (dh, dw * 4), dtype=torch.uint8, device="cuda", generator=g)
+    lut = lut_for(np.random.default_rng(1), "l2s")
+    outs = []
+    for spare in (None, "8", "16", "100"):
+        if spare is None:
+            monkeypatch.delenv("LGPU_CHAIN_SPARE_WGS", raising=False)
+        else:
+            monkeypatch.setenv("LGPU_CHAIN_SPARE_WGS", spare)
+        d = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda")
+        prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3, do_blur=0, bf=99, lut=lut)
+        gpu.chain(prm, gpu.chain_tracks([src], [l2], [d]))
+        torch.cuda.synchronize()
+        outs.append(d)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 @pytest.mark.parametrize("use_lut", [0, 1])
 def test_chain_every_alpha_and_colour_pair(gpu, orc, use_lut):
     """the translucent scaling of the chroma blend (simple_blend.c:137-145) inside the fused chain, for every (layer-2 alpha, colour)
