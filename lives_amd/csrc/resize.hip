@@ -1774,6 +1774,17 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   if (const char *sp = getenv("LGPU_CHAIN_SPARE_WGS")) { const int n = atoi(sp); if (n > 0 && n < grid / 2) grid -= n; }
   if (grid > nwork) grid = nwork;
   grid = (grid + 7) & ~7;                      // whole workgroups per XCD
+  // An XCD's workgroups walk its share of the tile list with a stride of grid / 8 tiles.  When that stride shares a large factor with the number of tiles per
+  // row the workgroups march down fixed tile columns in lockstep and the launch takes up to 1.7x as long (measured: 4096 x 2160 sources, 32 tiles per row,
+  // stride 64: 283 us against 180 with stride 62; 24 tiles per row: 185 against 161; profiles/r02/chain_stride.md): take the largest stride whose gcd with
+  // the row length is at most 2.
+  if (grid >= 64) {
+    auto gcd = [](int x, int y) { while (y) { const int t_ = x % y; x = y; y = t_; } return x; };
+    int w = grid >> 3;
+    for (int k = 0; k < 6 && w - k >= 8; k++)
+      if (gcd(w - k, a.tiles_x) <= 2) { w -= k; break; }
+    grid = w << 3;
+  }
 #define H8S_LAUNCH(DBG_, ABL_)                                                                                          \
   do {                                                                                                                  \
     LGPU_HIP(hipFuncSetAttribute((const void *)k_half8s<DBG_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -2003,6 +2014,13 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
     int g = (nwork + 7) & ~7;
     if (g > 2 * g_cus) g = (2 * g_cus) & ~7;          // two workgroups per CU by LDS (three or four smaller ones measured slower: 38 / 48 us against 24 for 4K -> 720p)
     if (g < 8) g = 8;
+    if (g >= 64) {                                     // the tile-list stride (g / 8) must not share a large factor with the tiles per row (see try_half8)
+      auto gcd = [](int x, int y) { while (y) { const int t_ = x % y; x = y; y = t_; } return x; };
+      int w = g >> 3;
+      for (int k = 0; k < 6 && w - k >= 8; k++)
+        if (gcd(w - k, ap.tiles_x) <= 2) { w -= k; break; }
+      g = w << 3;
+    }
     static const bool s2p_dbg = getenv("LGPU_S2P_DEBUG") != nullptr;
     ap.dbg = nullptr;
     const int nwv = (p.mh_r ? kS2pMhCW : 4) + 2;

@@ -18,7 +18,7 @@ def main():
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     with_lut = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0        # 0: plain palette conversion, no gamma on the way
     ops.init(0)
-    w, h = 1920, 1080
+    w, h = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1920, 1080)
     g = torch.Generator(device="cuda")
     g.manual_seed(0x11FE5)
 
@@ -41,7 +41,7 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     ab = nt * (w * h * 3 // 2 + w * h * 4)
-    print(json.dumps({"op": "yuv420p -> RGBA32%s, %d x 1080p per launch" % (" + gamma LUT" if with_lut else "", nt), "us_per_launch": round(us, 2), "algorithmic_bytes": ab,
+    print(json.dumps({"op": "yuv420p -> RGBA32%s, %d x %dx%d per launch" % (" + gamma LUT" if with_lut else "", nt, w, h), "us_per_launch": round(us, 2), "algorithmic_bytes": ab,
                       "GBs": round(ab / us / 1e3, 1), "frac_of_8TBs": round(ab / us / 1e3 / 8000, 4)}))
 
 
