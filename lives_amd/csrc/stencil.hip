@@ -387,6 +387,7 @@ struct DeintArgs {
   uint8_t *dst;
   int irow, orow, ntrip, height;
   int psize, pcpy, green, packed422, copy_alpha;
+  int dword, inplace;       // 4-byte pixels (not packed 4:2:2) in 4-byte aligned rows: the triple as three dwords per row
 };
 __global__ __launch_bounds__(kBlock) void k_deinterlace(DeintArgs a) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
@@ -396,6 +397,31 @@ __global__ __launch_bounds__(kBlock) void k_deinterlace(DeintArgs a) {
   for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
     const int r = 2 * pr + 1;
     const uint8_t *r0 = a.src + (size_t)(r - 1) * a.irow, *r1 = r0 + a.irow, *r2 = r1 + a.irow, *r3 = r2 + a.irow;
+    if (a.dword) {
+      // the same byte rules on dwords: colour bytes 0..2 of the three pixels come from row r (top, written to row r - 1) and from row r + 1 or the byte-wise
+      // mean of rows r and r + 2 (bottom, written to row r); byte 3 of the top pixels is not written (in place: what the snapshot holds; out of place: what the
+      // destination holds), byte 3 of the bottom pixels is row r's when out of place, untouched in place
+      const uint32_t *q0 = reinterpret_cast<const uint32_t *>(r0) + 3 * t, *q1 = reinterpret_cast<const uint32_t *>(r1) + 3 * t;
+      const uint32_t *q2 = reinterpret_cast<const uint32_t *>(r2) + 3 * t, *q3 = reinterpret_cast<const uint32_t *>(r3) + 3 * t;
+      uint32_t *o0 = reinterpret_cast<uint32_t *>(a.dst + (size_t)(r - 1) * a.orow) + 3 * t, *o1 = reinterpret_cast<uint32_t *>(a.dst + (size_t)r * a.orow) + 3 * t;
+      uint32_t p0[3], p1[3], p2[3], p3[3], keep[3];
+#pragma unroll
+      for (int p = 0; p < 3; p++) { p0[p] = q0[p]; p1[p] = q1[p]; p2[p] = q2[p]; p3[p] = q3[p]; }
+#pragma unroll
+      for (int p = 0; p < 3; p++) keep[p] = a.inplace ? p0[p] : o0[p];
+      const int sh = 8 * a.green;
+      const int m1 = (int)(((p0[0] >> sh) & 0xFF) + ((p0[2] >> sh) & 0xFF)) >> 1, m2 = (int)(((p2[0] >> sh) & 0xFF) + ((p2[2] >> sh) & 0xFF)) >> 1;
+      const int m3 = (int)(((p1[0] >> sh) & 0xFF) + ((p1[2] >> sh) & 0xFF)) >> 1, m4 = (int)(((p3[0] >> sh) & 0xFF) + ((p3[2] >> sh) & 0xFF)) >> 1;
+      const bool mixd = abs(m1 - m2) + abs(m3 - m4) < abs(m1 - m4) + abs(m3 - m2);
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        const uint32_t avg = (p1[p] & p3[p]) + (((p1[p] ^ p3[p]) & 0xFEFEFEFEu) >> 1);          // (x + y) >> 1 per byte
+        const uint32_t bot = mixd ? avg : p2[p];
+        o0[p] = (p1[p] & 0x00FFFFFFu) | (keep[p] & 0xFF000000u);
+        o1[p] = (bot & 0x00FFFFFFu) | (p1[p] & 0xFF000000u);          // out of place: row r's byte 3 (copy_alpha); in place: the byte that is there already (the same one)
+      }
+      continue;
+    }
     int m1, m2, m3, m4;
     if (a.packed422) {
       const int yo = a.packed422 == 1 ? 1 : 0;
@@ -801,6 +827,10 @@ extern "C" int lgpu_deinterlace(const uint8_t *src_d, int irow, uint8_t *dst_d, 
     LGPU_HIP(hipMemcpyAsync(snap, src_d, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     a.src = snap;
   }
+  a.inplace = inplace ? 1 : 0;
+  // whole triples only (width a multiple of 3: a partial last triple keeps the byte walk), 4-byte pixels whose copied bytes are 0..2
+  a.dword = (a.psize == 4 && !a.packed422 && a.pcpy == 3 && (width % 3) == 0 && ((((uintptr_t)a.src | (uintptr_t)dst_d | (uintptr_t)irow | (uintptr_t)orow) & 3) == 0) &&
+             (inplace || a.copy_alpha)) ? 1 : 0;
   const dim3 grid(cdiv((unsigned)a.ntrip, kBlock), (unsigned)(npairs < 2048 ? npairs : 2048));
   hipLaunchKernelGGL(lgpu::k_deinterlace, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
