@@ -210,6 +210,9 @@ int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height, uint8_t *
  * width in pixels (width % 4 pixels on the right are dropped); dst_d receives compact rows of (width >> 2) * 6 bytes. */
 int lgpu_rgb_to_yuv411(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d,
                        int clamping_unclamped, void *stream);
+/* diagnostics: cavgc, the clamped chroma-average table of init_average (src/colourspace.c:190-216), as this device computes it (the kernels use
+   fmaf(fa[x] + fa[y], 0.4375f, 128.f) with fa(x) = (float)((x - 128) * 255. / 244.): one rounding of the reference's exactly representable double) */
+int lgpu_chroma_average_table(uint8_t out[65536]);
 /* K5: clamped <-> unclamped switch, in place: switch_yuv_clamping_and_subspace (src/colourspace.c:10929-11090) with the
    tables of init_YUV_to_YUV_tables (:1108-1139; one table set serves YCbCr and BT.709 -- the reference does no subspace
    maths).  palette 588 YUV888, 589 YUVA8888 (alpha untouched), 544 / 545 / 522 / 512 / 513 planar, 564 UYVY, 565 YUYV.

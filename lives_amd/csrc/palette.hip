@@ -55,12 +55,33 @@ __device__ __forceinline__ int cavg_arith(int clamped, int x, int y) {
 
 // The clamped average costs three double divisions per sample; like the reference (cavgc, a 64 KB table filled once by init_average) the
 // kernels read it from a table: built per device, on the device, with the arithmetic above (so the bytes are the ones it produced before).
-__device__ const uint8_t *d_cavgc = nullptr;
-__global__ __launch_bounds__(256) void k_build_cavgc(uint8_t *t) { t[blockIdx.x * 256 + threadIdx.x] = (uint8_t)cavg_arith(1, blockIdx.x, threadIdx.x); }
-__device__ __forceinline__ int cavg(int clamped, int x, int y) {       // x, y are bytes (the reference indexes cavg[(x << 8) + y])
-  if (!clamped) return cavg_arith(0, x, y);
-  return d_cavgc[((x & 255) << 8) | (y & 255)];
+// The clamped average without the double divisions: fa(x) = (float)((x - 128) * 255. / 244.) is a 256-entry table (built per workgroup with the formula above),
+// and (float)((double)(fa + fb) * 224. / 512. + 128.) is ONE rounding of an exactly representable double (a 24-bit sum times 7 / 16 plus 128), i.e. fmaf(fa + fb, 0.4375f, 128.f).
+__device__ __forceinline__ float cavg_fa(int x) { return (float)__ddiv_rn(__dmul_rn((double)(float)(x - 128), 255.), 244.); }
+__device__ __forceinline__ int cavg_lds(int clamped, const float *s_fa, int x, int y) {
+  if (!clamped) {
+    const int c = (((x - 128) + (y - 128)) >> 1) + 128;
+    return c > 255 ? 255 : c < 0 ? 0 : c;
+  }
+  const float fc = __fmaf_rn(__fadd_rn(s_fa[x], s_fa[y]), 0.4375f, 128.f);
+  return fc > 240.f ? 240 : fc < 16.f ? 16 : (int)fc;
 }
+__device__ const uint8_t *d_cavgc = nullptr;
+// built with the fma form (cavg_lds) the kernels use; tests/test_gpu_parity.py::test_chroma_average_table compares all 65,536 entries with the reference's table
+__global__ __launch_bounds__(256) void k_build_cavgc(uint8_t *t) {
+  __shared__ float s_fa[256];
+  s_fa[threadIdx.x] = cavg_fa((int)threadIdx.x);
+  __syncthreads();
+  t[blockIdx.x * 256 + threadIdx.x] = (uint8_t)cavg_lds(1, s_fa, blockIdx.x, threadIdx.x);
+}
+// the kernels' average: the fma form on a per-workgroup fa table in LDS.  Every kernel that calls cavg() runs cavg_init() first, before any thread returns.
+// (Round 1 gathered from a 64 KB table in global memory; the table is still built, for the test that compares it with the reference's.)
+__shared__ float s_cavg_fa[256];
+__device__ __forceinline__ void cavg_init() {
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_cavg_fa[i] = cavg_fa(i);
+  __syncthreads();
+}
+__device__ __forceinline__ int cavg(int clamped, int x, int y) { return cavg_lds(clamped, s_cavg_fa, x & 255, y & 255); }   // x, y are bytes (the reference indexes cavg[(x << 8) + y])
 
 __device__ __forceinline__ void load_rgb(const uint8_t *p, int order, int &r, int &g, int &b) {
   if (order == 0) { r = p[0]; g = p[1]; b = p[2]; }
@@ -70,6 +91,7 @@ __device__ __forceinline__ void load_rgb(const uint8_t *p, int order, int &r, in
 
 template <int ORDER, int FMT>
 __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
+  cavg_init();
   __shared__ int32_t s_t[9 * 256];
   for (int i = threadIdx.x; i < 9 * 256; i += kBlock) s_t[i] = a.tables[i];
   __syncthreads();
@@ -247,9 +269,16 @@ __device__ __forceinline__ void put_colour(uint8_t *d, int bgr, const int32_t *t
   const int r = clamp255((yy + t[256 + V]) >> 16), g = clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = clamp255((yy + t[1024 + U]) >> 16);
   d[0] = (uint8_t)(bgr ? b : r); d[1] = (uint8_t)g; d[2] = (uint8_t)(bgr ? r : b);
 }
+__device__ __forceinline__ uint32_t colour24(int bgr, const int32_t *t, int Y, int U, int V) {       // put_colour's three bytes as bits 0..23
+  const int32_t yy = t[Y];
+  const uint32_t r = (uint32_t)clamp255((yy + t[256 + V]) >> 16), g = (uint32_t)clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = (uint32_t)clamp255((yy + t[1024 + U]) >> 16);
+  return bgr ? (b | (g << 8) | (r << 16)) : (r | (g << 8) | (b << 16));
+}
 __global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a) {
   __shared__ int32_t s_t[5 * 256];
+  __shared__ float s_fa[256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
+  s_fa[threadIdx.x] = cavg_fa((int)threadIdx.x);             // kBlock == 256
   __syncthreads();
   const int j = blockIdx.x * kBlock + threadIdx.x;
   const int wm = a.width;                                   // macropixels per row
@@ -260,14 +289,42 @@ __global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a) {
     const uint8_t *cb = a.src[0] + ((size_t)y * wm + j) * 6;
     uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)j * 4 * ps;
     const int cu = cb[0], cv = cb[3];
+    if (ps == 4 && ((reinterpret_cast<uintptr_t>(d) & 15) == 0)) {
+      // four-byte pixels: the block's four pixels leave as one 16-byte store instead of 14 .. 16 byte stores; the two alpha bytes the reference never writes
+      // (pixels 4j + 2, 4j + 3 of every block but the row's last, quirk K3b) are taken from what the destination holds
+      const bool first = j == 0, last = j == wm - 1;
+      uint32_t c0, c1, c2, c3;
+      if (first) { c0 = colour24(0, s_t, cb[1], cu, cv); c1 = colour24(bgr, s_t, cb[2], cu, cv); }
+      else {
+        const int pu = cb[-6], pv = cb[-3];
+        const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pu, cu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pv, cv), cv);
+        c0 = colour24(bgr, s_t, cb[1], cavg_lds(cl, s_fa, qu, pu), cavg_lds(cl, s_fa, qv, pv));
+        c1 = colour24(bgr, s_t, cb[2], cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
+      }
+      uint32_t a2 = 0xFFu, a3 = 0xFFu;
+      if (last) { c2 = colour24(0, s_t, cb[4], cu, cv); c3 = colour24(0, s_t, cb[5], cu, cv); }
+      else {
+        const int nu = cb[6], nv = cb[9];
+        const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cu, nu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cv, nv), cv);
+        c2 = colour24(bgr, s_t, cb[4], cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
+        c3 = colour24(bgr, s_t, cb[5], cavg_lds(cl, s_fa, qu, nu), cavg_lds(cl, s_fa, qv, nv));
+        const uint2 old_ = *reinterpret_cast<const uint2 *>(d + 8);
+        a2 = aoff ? old_.x >> 24 : old_.x & 0xFF; a3 = aoff ? old_.y >> 24 : old_.y & 0xFF;
+      }
+      uint4 o;
+      if (aoff) { o.x = c0 | 0xFF000000u; o.y = c1 | 0xFF000000u; o.z = c2 | (a2 << 24); o.w = c3 | (a3 << 24); }
+      else { o.x = (c0 << 8) | 0xFFu; o.y = (c1 << 8) | 0xFFu; o.z = (c2 << 8) | a2; o.w = (c3 << 8) | a3; }
+      *reinterpret_cast<uint4 *>(d) = o;
+      continue;
+    }
     if (j == 0) {                                           // row start (:8330-8337)
       put_colour(d + coff, 0, s_t, cb[1], cu, cv);
       put_colour(d + ps + coff, bgr, s_t, cb[2], cu, cv);
     } else {                                                // second half of loop iteration j (:8373-8390)
       const int pu = cb[-6], pv = cb[-3];
-      const int qu = cavg_arith(cl, cavg_arith(cl, pu, cu), cu), qv = cavg_arith(cl, cavg_arith(cl, pv, cv), cv);
-      put_colour(d + coff, bgr, s_t, cb[1], cavg_arith(cl, qu, pu), cavg_arith(cl, qv, pv));
-      put_colour(d + ps + coff, bgr, s_t, cb[2], cavg_arith(cl, qu, cu), cavg_arith(cl, qv, cv));
+      const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pu, cu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pv, cv), cv);
+      put_colour(d + coff, bgr, s_t, cb[1], cavg_lds(cl, s_fa, qu, pu), cavg_lds(cl, s_fa, qv, pv));
+      put_colour(d + ps + coff, bgr, s_t, cb[2], cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
     }
     if (ps == 4) d[aoff] = d[4 + aoff] = 255;
     d += 2 * ps;
@@ -277,9 +334,9 @@ __global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a) {
       if (ps == 4) d[aoff] = d[4 + aoff] = 255;
     } else {                                                // first half of loop iteration j + 1 (:8344-8366): this block is "previous"
       const int nu = cb[6], nv = cb[9];
-      const int qu = cavg_arith(cl, cavg_arith(cl, cu, nu), cu), qv = cavg_arith(cl, cavg_arith(cl, cv, nv), cv);
-      put_colour(d + coff, bgr, s_t, cb[4], cavg_arith(cl, qu, cu), cavg_arith(cl, qv, cv));
-      put_colour(d + ps + coff, bgr, s_t, cb[5], cavg_arith(cl, qu, nu), cavg_arith(cl, qv, nv));
+      const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cu, nu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cv, nv), cv);
+      put_colour(d + coff, bgr, s_t, cb[4], cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
+      put_colour(d + ps + coff, bgr, s_t, cb[5], cavg_lds(cl, s_fa, qu, nu), cavg_lds(cl, s_fa, qv, nv));
     }
   }
 }
@@ -368,6 +425,7 @@ __device__ __forceinline__ void c411_fine_pair(int cl, int a, int b, int near_b,
   o0 = cavg(cl, q, a); o1 = cavg(cl, q, b);
 }
 __global__ __launch_bounds__(kBlock) void k_yuv411_repack(R411Args a) {
+  cavg_init();
   const int wm = a.width >> 2, cl = a.clamped;
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (a.kind == K411_FROM_444) {                             // one macropixel: the last one of the frame, written over the first
@@ -463,6 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv411_repack(R411Args a) {
 // YUV411 -> 4:2:0, the odd row after the last even one: each of its 2 wm chroma samples is averaged INTO THE FIRST sample of chroma row 0, in order
 // (the destination pointer is not advanced on odd rows, :9071-9073, :9096-9098, :9113-9115, :9134-9136).  A serial fold by one lane per plane.
 __global__ void k_yuv411_420_fold(const uint8_t *src, int wm, int row, uint8_t *du, uint8_t *dv, int cl) {
+  cavg_init();
   const int off = threadIdx.x ? 3 : 0;                     // lane 0: U, lane 1: V
   uint8_t *d = threadIdx.x ? dv : du;
   if (threadIdx.x > 1) return;
@@ -514,6 +573,7 @@ __device__ __forceinline__ void chroma_up_pair(const ChromaUpArgs &a, int cr, in
   }
 }
 __global__ __launch_bounds__(kBlock) void k_chroma_up_packed(ChromaUpArgs a) {
+  cavg_init();
   const int k = blockIdx.x * kBlock + threadIdx.x, hw = a.width >> 1, ps = a.alpha ? 4 : 3, cl = a.clamped;
   if (k >= hw) return;
   for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
@@ -549,6 +609,7 @@ struct RepackArgs {
 };
 
 __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
+  cavg_init();
   const int mx = blockIdx.x * kBlock + threadIdx.x;         // macropixel column
   const int mw = ((a.copy_w > a.width ? a.copy_w : a.width) + 1) >> 1;
   if (mx >= mw) return;
@@ -712,6 +773,18 @@ static int ensure_cavgc() {
     return LGPU_E_HIP;
   }
   tab[dev] = d;
+  return LGPU_OK;
+}
+
+// diagnostics: the device's clamped chroma-average table (init_average, src/colourspace.c:190-216) as the kernels compute it
+extern "C" int lgpu_chroma_average_table(uint8_t out[65536]) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if ((rc = ensure_cavgc())) return rc;
+  LGPU_REQUIRE(out, "null result buffer");
+  const uint8_t *d = nullptr;
+  LGPU_HIP(hipMemcpyFromSymbol(&d, HIP_SYMBOL(d_cavgc), sizeof d));
+  LGPU_HIP(hipMemcpy(out, d, 65536, hipMemcpyDeviceToHost));
   return LGPU_OK;
 }
 

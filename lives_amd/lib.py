@@ -110,6 +110,7 @@ PROTOTYPES = {
     "lgpu_softlight": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "lgpu_yuv_switch_clamping": [vp, vp, ci, ci, ci, vp],
     "lgpu_rgb_to_yuv": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp],
+    "lgpu_chroma_average_table": [vp],
     "lgpu_rgb_to_yuv_lut16": [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp],
     "lgpu_yuv_to_rgb": [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_rgb_to_yuv411": [vp, ci, ci, ci, ci, ci, vp, ci, vp],

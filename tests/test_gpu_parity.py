@@ -635,6 +635,18 @@ def test_yuv_repack(gpu, orc, pair):
                     assert (host(dst[i]) == a).all(), "repack %d->%d %dx%d unclamped=%d pad=%d plane %d" % (ip, op, w, h, unc, pad, i)
 
 
+def test_chroma_average_table(gpu, orc):
+    """the clamped chroma average (init_average, src/colourspace.c:190-216) as the kernels compute it -- fmaf(fa[x] + fa[y], 0.4375f, 128.f) on a 256-entry float table
+    instead of the reference's float / double chain -- for ALL 65,536 pairs against the oracle's table (itself pinned on the reference's cavgc)"""
+    from lives_amd.lib import load
+    t = np.zeros(65536, np.uint8)
+    assert load().lgpu_chroma_average_table(t.ctypes.data) == 0
+    want = np.array([[orc.orc_cavg(1, x, y) for y in range(256)] for x in range(256)], np.uint8)
+    assert (t.reshape(256, 256) == want).all()
+    from tests import golden_util as gu
+    assert (t.reshape(256, 256) == gu.load("cavg.npz")["cavgc"]).all()            # ... and against the reference's own table
+
+
 @pytest.mark.parametrize("pair", po.YUV411_REPACK_PAIRS, ids=lambda p: "%d-%d" % (p[0], p[1]))
 def test_yuv411_repack(gpu, orc, pair):
     """K5c: YUV411 <-> YUV888 / YUVA8888 / YUV444P / YUVA4444P / UYVY / YUYV / YUV422P / YUV420P / YVU420P (:7755-7798, :7973-8033, :8272-8303,

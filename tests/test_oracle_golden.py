@@ -368,6 +368,14 @@ def test_yuv411_repack(orc):
             assert (got[i] == a).all(), "%s plane %d" % (rec, i)
 
 
+def test_chroma_average_tables(orc):
+    """orc_cavg against the reference's cavgc / cavgu (init_average, src/colourspace.c:190-216), all 2 x 65,536 entries"""
+    g = gu.load("cavg.npz")
+    for cl, key in ((1, "cavgc"), (0, "cavgu")):
+        got = np.array([[orc.orc_cavg(cl, x, y) for y in range(256)] for x in range(256)], np.uint8)
+        assert (got == g[key]).all(), key
+
+
 def test_chroma_up_packed(orc):
     """4:2:0 / 4:2:2 planar -> YUV888 / YUVA8888 against the reference slice fixtures (:10715-10873); m = 0 where the reference reads past a compact plane"""
     import ctypes
