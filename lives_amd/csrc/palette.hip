@@ -41,20 +41,8 @@ struct R2Y {
   __device__ __forceinline__ int Vg(const uint16_t *l, int r, int g, int b) const { return cuv(l[((uint32_t)(t[1536 + r] + t[1792 + g] + t[2048 + b]) >> 8) & 0xFFFF] >> 8); }
 };
 
-// init_average (:190-216): cavgu is integer, cavgc mixes float and double exactly as written there
-__device__ __forceinline__ int cavg_arith(int clamped, int x, int y) {
-  if (!clamped) {
-    const int c = (((x - 128) + (y - 128)) >> 1) + 128;
-    return c > 255 ? 255 : c < 0 ? 0 : c;
-  }
-  const float fa = (float)__ddiv_rn(__dmul_rn((double)(float)(x - 128), 255.), 244.);
-  const float fb = (float)__ddiv_rn(__dmul_rn((double)(float)(y - 128), 255.), 244.);
-  const float fc = (float)__dadd_rn(__ddiv_rn(__dmul_rn((double)__fadd_rn(fa, fb), 224.), 512.), 128.);
-  return fc > 240.f ? 240 : fc < 16.f ? 16 : (int)fc;
-}
-
-// The clamped average costs three double divisions per sample; like the reference (cavgc, a 64 KB table filled once by init_average) the
-// kernels read it from a table: built per device, on the device, with the arithmetic above (so the bytes are the ones it produced before).
+// init_average (:190-216): cavgu is the integer mean; cavgc mixes float and double exactly as written there:
+//   fa = (float)((double)(float)(x - 128) * 255. / 244.), fb likewise, fc = (float)((double)(fa + fb) * 224. / 512. + 128.), clamped to 16 .. 240 and truncated.
 // The clamped average without the double divisions: fa(x) = (float)((x - 128) * 255. / 244.) is a 256-entry table (built per workgroup with the formula above),
 // and (float)((double)(fa + fb) * 224. / 512. + 128.) is ONE rounding of an exactly representable double (a 24-bit sum times 7 / 16 plus 128), i.e. fmaf(fa + fb, 0.4375f, 128.f).
 __device__ __forceinline__ float cavg_fa(int x) { return (float)__ddiv_rn(__dmul_rn((double)(float)(x - 128), 255.), 244.); }
