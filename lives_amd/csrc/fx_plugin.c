@@ -283,6 +283,23 @@ static int k_dissolve(const fxframe_t *f, weed_plant_t *inst, int kind) {
   return lgpu_dissolve(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize, fx->mask_d,
                        pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., NULL);
 }
+/* "rand replace" (multi_transitions.c:96-112, :213-220): per frame ONE draw of a uniform number decides whether the whole frame is the second input
+   (draw < amount) or the first; in place and "first" means nothing to do.  The reference draws from libweed's time-seeded global generator
+   (fastrnd_dbl, weed-plugin-utils.c): no sequence to reproduce, so this is an xorshift64* seeded from the clock the same way; the frame copy is the device work */
+static uint64_t g_rr_state;
+static double rr_draw(void) {
+  if (!g_rr_state) { g_rr_state = ((uint64_t)time(NULL) << 20) ^ (uint64_t)clock() ^ 0x9E3779B97F4A7C15ull; }
+  g_rr_state ^= g_rr_state >> 12; g_rr_state ^= g_rr_state << 25; g_rr_state ^= g_rr_state >> 27;
+  return (double)((g_rr_state * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);       /* [0, 1) */
+}
+static int k_rreplace(const fxframe_t *f, weed_plant_t *inst, int kind) {
+  weed_plant_t *pa = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 0);
+  const double bfd = pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0.;
+  const int cpy0 = rr_draw() < bfd;
+  (void)kind;
+  if (f->inplace && !cpy0) return LGPU_OK;
+  return lgpu_copy_rows(f->ddst, f->orow, cpy0 ? f->dsrc[1] : f->dsrc[0], cpy0 ? f->irow[1] : f->irow[0], f->width * f->psize, f->height, NULL);
+}
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
   return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
@@ -370,7 +387,7 @@ PROC(p_mirrorx, 1, 0, k_mirror, 0) PROC(p_mirrory, 1, 1, k_mirror, 1) PROC(p_mir
 PROC(p_edge, 1, 0, k_edge, 1) PROC(p_blurzoom, 1, 0, k_blurzoom, 1)
 PROC(p_irisr, 2, 0, k_transition, 1) PROC(p_irisc, 2, 1, k_transition, 1) PROC(p_fourw, 2, 2, k_transition, 1)
 PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1) PROC(p_rgbdelay, 1, 0, k_rgbdelay, 1)
-PROC(p_tsplit, 2, 0, k_tsplit, 1) PROC(p_dissolve, 2, 0, k_dissolve, 1)
+PROC(p_tsplit, 2, 0, k_tsplit, 1) PROC(p_dissolve, 2, 0, k_dissolve, 1) PROC(p_rreplace, 2, 0, k_rreplace, 1)
 PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(p_ccorrect, 1, 2, k_scriptfx, 0)
 
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
@@ -613,6 +630,14 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
     if (fc) w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct);
     if (oct) s_int(oct, WEED_LEAF_FLAGS, WEED_CHANNEL_CAN_DO_INPLACE | WEED_CHANNEL_REINIT_ON_SIZE_CHANGE);
+    /* multi_transitions.c:314-326: "rand replace", the fifth class of that plugin: same templates, out channel in place */
+    p[0] = float_param("amount", "_Transition", 0., 0., 1.);
+    s_bool(p[0], WEED_LEAF_IS_TRANSITION, WEED_TRUE);
+    add_filter(pinfo, "rand replace", 0, pk, 6, p_rreplace, 2, "in channel 0", "in channel 1", "out channel 0", p, 1);
+    fc = NULL; oct = NULL;
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct);
+    if (oct) s_int(oct, WEED_LEAF_FLAGS, WEED_CHANNEL_CAN_DO_INPLACE);
   }
   /* blurzoom.c:424-446: "blurzoom" by effectTV, string-list parameters "mode" and "color", BGRA32 / RGBA32, out channel NOT in place */
   {

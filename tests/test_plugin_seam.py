@@ -22,7 +22,7 @@ PSIZE = {1: 3, 2: 3, 3: 4, 4: 4, 5: 4}
 def test_filter_classes_mirror_the_reference():
     H = po.RefHost()
     ours = {f["name"]: f for f in H.filters(OURS)}
-    assert len(ours) == 31
+    assert len(ours) == 32
     for plug in ("simple_blend", "multi_blends", "colorkey", "mirrors", "edge", "softlight", "blurzoom", "slide_over", "deinterlace", "RGBdelay", "negate", "posterise",
                  "ccorrect", "layout_blends"):
         for rf in H.filters(po.refplugin(plug)):
@@ -258,6 +258,34 @@ def test_triple_split_records_through_the_plugin():
         d = a.copy() if inplace == "1" else np.full_like(a, 0x5A)
         H.run(OURS, "triple split", int(pal), 21, 12, [d if inplace == "1" else a.copy(), b.copy()], d, prm)
         assert (d == want).all(), rec
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_rand_replace_through_the_plugin():
+    """"rand replace" (multi_transitions.c:96-112, :213-220): one uniform draw per frame picks the second input (draw < amount) or the first.  The reference draws from a
+    time-seeded global generator, so the sequence cannot be pinned; the two ends of the parameter are deterministic in both, and the reference plugin run on the same
+    frames gives the same bytes there; in between the share of frames taken from the second input follows the amount"""
+    H = po.RefHost()
+    rng = np.random.default_rng(77)
+    for pal in (1, 3, 4):
+        ps = PSIZE[pal]
+        a, b = rng.integers(0, 256, (9, po.align(17 * ps)), dtype=np.uint8), rng.integers(0, 256, (9, po.align(17 * ps)), dtype=np.uint8)
+        for amt, src in ((0.0, a), (1.0, b)):
+            for inplace in (0, 1):
+                outs = []
+                for so in (OURS, po.refplugin("multi_transitions")):
+                    d = a.copy() if inplace else np.full_like(a, 0x5A)
+                    H.run(so, "rand replace", pal, 17, 9, [d if inplace else a.copy(), b.copy()], d, [po.p_double(amt)])
+                    outs.append(d)
+                assert (outs[0][:, :17 * ps] == src[:, :17 * ps]).all() and (outs[0][:, :17 * ps] == outs[1][:, :17 * ps]).all(), (pal, amt, inplace)
+    a, b = np.zeros((9, po.align(17 * 4)), np.uint8), np.full((9, po.align(17 * 4)), 200, np.uint8)
+    n = 0
+    for _ in range(400):
+        d = np.zeros_like(a)
+        H.run(OURS, "rand replace", 3, 17, 9, [a.copy(), b.copy()], d, [po.p_double(0.3)])
+        n += int(d[0, 0] == 200)
+    assert 70 <= n <= 170, n          # 400 draws at 0.3: 120 +- 5 sigma
 
 
 @needs_ref
