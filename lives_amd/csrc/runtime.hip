@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <atomic>
 #include <mutex>
+#include <vector>
 #include <string.h>
 
 namespace lgpu {
@@ -41,25 +42,24 @@ static int init_device(int dev) {
     set_error("device %d is %s; this build carries gfx950 (MI355X) code objects only", dev, prop.gcnArchName);
     return LGPU_E_NODEVICE;
   }
-  for (int which = 0; which < 4; which++) {
-    int32_t r2y[9 * 256], y2r[5 * 256];
-    lgpu_conversion_tables(which, r2y, y2r);
-    LGPU_HIP(hipMalloc((void **)&g_tables[dev].rgb2yuv[which], sizeof r2y));
-    LGPU_HIP(hipMalloc((void **)&g_tables[dev].yuv2rgb[which], sizeof y2r));
-    LGPU_HIP(hipMemcpy(g_tables[dev].rgb2yuv[which], r2y, sizeof r2y, hipMemcpyHostToDevice));
-    LGPU_HIP(hipMemcpy(g_tables[dev].yuv2rgb[which], y2r, sizeof y2r, hipMemcpyHostToDevice));
-  }
+  // all tables in ONE allocation: a failure part of the way through leaves nothing behind
+  constexpr size_t kR2Y = 9 * 256, kY2R = 5 * 256, kLuma = 3 * 256, kTotal = 4 * (kR2Y + kY2R) + kLuma;
+  std::vector<int32_t> host(kTotal);
+  for (int which = 0; which < 4; which++) lgpu_conversion_tables(which, host.data() + which * (kR2Y + kY2R), host.data() + which * (kR2Y + kY2R) + kR2Y);
   {
     // luma weights of calc_luma(): myround(k * i * 65536.) per channel
-    int32_t lw[3 * 256];
+    int32_t *lw = host.data() + 4 * (kR2Y + kY2R);
     for (int i = 0; i < 256; i++) {
       const double v = (double)i;
       const double r = 0.299 * v * 65536., g = (1. - 0.299 - 0.114) * v * 65536., b = 0.114 * v * 65536.;
       lw[i] = (int32_t)(r + 0.5); lw[256 + i] = (int32_t)(g + 0.5); lw[512 + i] = (int32_t)(b + 0.5);
     }
-    LGPU_HIP(hipMalloc((void **)&g_tables[dev].luma, sizeof lw));
-    LGPU_HIP(hipMemcpy(g_tables[dev].luma, lw, sizeof lw, hipMemcpyHostToDevice));
   }
+  int32_t *d = nullptr;
+  if (hipMalloc((void **)&d, kTotal * sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc of the conversion tables failed"); return LGPU_E_NOMEM; }
+  if (hipMemcpy(d, host.data(), kTotal * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); set_error("upload of the conversion tables failed"); return LGPU_E_HIP; }
+  for (int which = 0; which < 4; which++) { g_tables[dev].rgb2yuv[which] = d + which * (kR2Y + kY2R); g_tables[dev].yuv2rgb[which] = d + which * (kR2Y + kY2R) + kR2Y; }
+  g_tables[dev].luma = d + 4 * (kR2Y + kY2R);
   g_inited[dev].store(true, std::memory_order_release);
   return LGPU_OK;
 }
