@@ -475,6 +475,28 @@ def test_rgb_layers_to_yuv_change_gamma_on_the_way(seam, orc):
             assert orc.orc_rgb_to_yuv(P(g), g.strides[0], w, h, order, int(ips == 4), ctypes.addressof(wp), ctypes.addressof(ws), 0, 0, 0) == 0
             assert (got[0] == want[0]).all(), (inpl, tgt, osub, "888")
             assert wh.geti(lay, "gamma_type") == want_gamma
+    # the same on a pinned layer: both steps run on the resident planes, the bytes come home at the sync
+    src = frame(rng, w, h, 4)
+    for outpl, fmt in ((564, 2), (588, 0)):
+        lay = wh.new_layer(RGBA32, w, h, [src.copy()], gamma=LIN, flags=0)
+        assert L.lives_gpu_layer_pin(lay) == 0
+        assert L.lives_gpu_convert_layer_palette_full(lay, outpl, 0, 0, 1, 0) == 1
+        assert wh.geti(lay, "host_gpu_resident") == 1 and L.lives_gpu_layer_unpin(lay) == 0
+        got, _, rs = wh.planes_of(lay)
+        want = np.zeros((h, rs[0]), np.uint8)
+        if fmt == 2:
+            lut16 = np.zeros(65536, np.uint16)
+            assert orc.orc_gamma_lut16(1.0, LIN, SRGB, 1.4, P(lut16)) == 1
+            assert orc.orc_rgb_to_yuv_lut16(P(src), src.strides[0], w, h, 0, 1, P(want), rs[0], 2, 0, P(lut16)) == 0
+        else:
+            lut8 = np.zeros(256, np.uint8)
+            assert orc.orc_gamma_lut8(1.0, LIN, SRGB, 1.4, P(lut8)) == 1
+            g = src.copy()
+            orc.orc_gamma_apply(P(g), g.strides[0], w, h, 4, 0, P(lut8))
+            wl = [want]
+            wp, ws = po.planes_args(wl)
+            assert orc.orc_rgb_to_yuv(P(g), g.strides[0], w, h, 0, 1, ctypes.addressof(wp), ctypes.addressof(ws), 0, 0, 0) == 0
+        assert (got[0] == want).all() and wh.geti(lay, "gamma_type") == SRGB, outpl
     # a layer that is already SRGB: nothing changes on the way (the plain entry points)
     src = frame(rng, w, h, 4)
     lay = wh.new_layer(RGBA32, w, h, [src.copy()], gamma=SRGB, flags=0)
@@ -533,7 +555,12 @@ def test_yuv411_layers_repack(seam, orc, w):
                 planes[1] = planes[1][:, :align(dims_in[0][0]) >> 1].copy(); planes[2] = planes[2][:, :align(dims_in[0][0]) >> 1].copy()   # rs[1] = rs[0] >> 1
             lw = w >> 1 if ip in (564, 565) else w >> 2 if ip == 595 else w
             lay = wh.new_layer(ip, lw, h, [a.copy() for a in planes], clamping=clamp, subspace=1)
+            pinned = clamp == 1                          # half of the cases on resident planes
+            if pinned:
+                assert L.lives_gpu_layer_pin(lay) == 0
             assert L.lives_gpu_convert_layer_palette_full(lay, op, clamp, 0, 1, 0) == 1, (ip, op)
+            if pinned:
+                assert wh.geti(lay, "host_gpu_resident") == 1 and L.lives_gpu_layer_unpin(lay) == 0
             got, _, rs = wh.planes_of(lay)
             dims = po.YUV_PLANE_DIMS[op](w, h)
             want = [np.zeros((b, r), np.uint8) for (a, b), r in zip(dims, rs)]
