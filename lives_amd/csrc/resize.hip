@@ -1200,13 +1200,15 @@ struct S2pTile {
     tx0 = (tile - ty * a.tiles_x) * kTileW; ty0 = ty * a.th;
   }
 };
+constexpr int kS2pPitch = kTileW + 2;   // row-pair buffer of k_sep2p: uint4 per column, two spare columns per row pair so that the matrix-core pass's four
+                                        // row-pair groups (2 g pairs apart) land in different banks (a pitch of 64 uint4 put all four on the same 16)
 struct S2pLds {       // byte offsets into the dynamic LDS block
   int win, p, lut, vc, hc, hdr, vcslot, hcslot;
   size_t total;
   __host__ __device__ S2pLds(int sht, int swt, int th, int npv, int nph) {
     win = sht * swt * 4;
     p = 2 * win;
-    lut = p + (sht >> 1) * kTileW * 16;
+    lut = p + (sht >> 1) * kS2pPitch * 16;
     vc = lut + 256;
     vcslot = th * (npv + 1) * 4;
     hc = vc + 2 * vcslot;
@@ -1280,9 +1282,9 @@ __device__ __forceinline__ void s2p_hpass_mfma(const SepArgs &a, const uint8_t *
     for (int u = 0; u < NQ; u++) {
       const int q = NQ * wave + u;
       const int t0 = ((dh[u].x << 6) + dl[u].x) >> 7, t1 = ((dh[u].y << 6) + dl[u].y) >> 7, t2 = ((dh[u].z << 6) + dl[u].z) >> 7, t3 = ((dh[u].w << 6) + dl[u].w) >> 7;
-      uint32_t *d = s_p32 + ((size_t)pr * kTileW + 4 * q + (n >> 2)) * 4 + (n & 3);
+      uint32_t *d = s_p32 + ((size_t)pr * kS2pPitch + 4 * q + (n >> 2)) * 4 + (n & 3);
       if (pr < cap) d[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(t0, t1));
-      if (pr + 1 < cap) d[kTileW * 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(t2, t3));
+      if (pr + 1 < cap) d[kS2pPitch * 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(t2, t3));
     }
   }
 }
@@ -1313,6 +1315,18 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
     S2pTile t;
     t.set(a, work);
     const int tw = min(kTileW, a.dw - t.tx0), thh = min(a.th, a.dh - t.ty0);
+    uint8_t *dst = trk.dst[t.track];
+    const uint8_t *l2 = trk.l2[t.track];
+    // the second layer's pixels of the wave's first batch of output rows are requested here, a whole horizontal pass before they are blended in
+    // (requested next to their use they cost a full memory latency per tile: 5,800 cycles of vertical pass against 2,650 without the blend)
+    uint32_t qpre[4] = {0, 0, 0, 0};
+    if (a.blend) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ly = wave + r * CW;
+        if (ly < thh && lane < tw) qpre[r] = reinterpret_cast<const uint32_t *>(l2 + (size_t)(t.ty0 + ly) * a.irow2)[t.tx0 + lane];
+      }
+    }
     S2P_T(3)
     H8S_BARRIER();                                                                   // A(i): window i, tables i in place; row pairs free
     S2P_T(0)
@@ -1350,15 +1364,13 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
       pk.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e1 >> a.hshift, o1 >> a.hshift));
       pk.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e2 >> a.hshift, o2 >> a.hshift));
       pk.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(e3 >> a.hshift, o3 >> a.hshift));
-      s_p[k * kTileW + lane] = pk;
+      s_p[k * kS2pPitch + lane] = pk;
     }
     }
     S2P_T(1)
     H8S_BARRIER();                                                                   // B(i): row pairs complete, window slot i & 1 free
     S2P_T(2)
     // ---- vertical pass + epilogue: wave = output row, lane = output column ----
-    uint8_t *dst = trk.dst[t.track];
-    const uint8_t *l2 = trk.l2[t.track];
     // NB output rows of the wave at a time (4 when the tile gives a wave more than two rows, else 2): their row-pair / tap-pair reads are requested
     // together, so the LDS latency of the (run-time long) pair loop is paid once per batch (one row at a time measured 900 cycles per row, mostly waiting)
     auto vrows = [&](auto nb_tag) {
@@ -1367,6 +1379,13 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
         const uint32_t *vc2[NB];
         const uint4 *col[NB];
         int acc[NB][4];
+        if (a.blend && lyb != wave) {                                 // later batches of a tall tile: requested before the taps are read
+#pragma unroll
+          for (int r = 0; r < NB; r++) {
+            const int ly = lyb + r * CW;
+            if (ly < thh && lane < tw) qpre[r] = reinterpret_cast<const uint32_t *>(l2 + (size_t)(t.ty0 + ly) * a.irow2)[t.tx0 + lane];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < NB; r++) {
           const int ly = min(lyb + r * CW, thh - 1);                  // rows past the tile repeat the last one (not stored)
@@ -1374,12 +1393,12 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
           acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = a.vround;
         }
 #pragma unroll
-        for (int r = 0; r < NB; r++) col[r] = s_p + (((int)vc2[r][0] >> 1) - (sy0 >> 1)) * kTileW + lane;       // first row pair, window relative
+        for (int r = 0; r < NB; r++) col[r] = s_p + (((int)vc2[r][0] >> 1) - (sy0 >> 1)) * kS2pPitch + lane;       // first row pair, window relative
         for (int j = 0; j < a.npv; j++) {
           uint4 tt[NB];
           uint32_t cf[NB];
 #pragma unroll
-          for (int r = 0; r < NB; r++) { tt[r] = col[r][j * kTileW]; cf[r] = vc2[r][1 + j]; }
+          for (int r = 0; r < NB; r++) { tt[r] = col[r][j * kS2pPitch]; cf[r] = vc2[r][1 + j]; }
 #pragma unroll
           for (int r = 0; r < NB; r++) {
             const short2v c2 = __builtin_bit_cast(short2v, cf[r]);
@@ -1396,10 +1415,7 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
             uint32_t p = a.vshift == 21 ? pack_sat_shr21(acc[r][0], acc[r][1], acc[r][2], acc[r][3])
                                         : (uint32_t)clamp255(acc[r][0] >> a.vshift) | ((uint32_t)clamp255(acc[r][1] >> a.vshift) << 8) |
                                               ((uint32_t)clamp255(acc[r][2] >> a.vshift) << 16) | ((uint32_t)clamp255(acc[r][3] >> a.vshift) << 24);
-            if (a.blend) {
-              const uint32_t q = reinterpret_cast<const uint32_t *>(l2 + (size_t)oy * a.irow2)[t.tx0 + lane];
-              p = chroma_rgba(p, q, bf, nbf);
-            }
+            if (a.blend) p = chroma_rgba(p, qpre[r], bf, nbf);
             if (a.use_lut) p = lut3_rgba(s_lut, p);
             reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[t.tx0 + lane] = p;
           }
@@ -1912,23 +1928,13 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
         break;
       }
     }
-    // k_sep2p: two window slots + double-buffered tables must leave two workgroups per CU; a window is at most kS2pMaxReq DMA requests
-    const bool no_sep2p = getenv("LGPU_NO_SEP2P") != nullptr;
-    static const int th_force = getenv("LGPU_SEP2P_TH") ? atoi(getenv("LGPU_SEP2P_TH")) : 0;
-    if (p->variant >= 100 && !no_sep2p && (sw & 3) == 0) {
-      for (int th2 = th_force ? th_force : dh > sh ? 32 : 16; th2 >= 1; th2 >>= 1) {
-        const int sht2 = window_rows(th2);
-        const S2pLds L(sht2, a.swt, th2, vb->npv, nph);
-        if (L.total <= 80 * 1024 && sht2 * (a.swt >> 2) <= kS2pMaxReq * 64 && th2 * (vb->npv + 1) <= 256 && vb->npv <= kS2pMaxNpv) {
-          p->pers = true; p->p_th = th2; p->p_sht = sht2; p->p_tiles_y = (dh + th2 - 1) / th2; p->p_lds = L.total;
-          break;
-        }
-      }
-    }
     // the horizontal pass as a matrix product: same taps for every column, integer ratio, taps that split into int8 hi / 6-bit lo, at most two K blocks
+    // (decided before the tile height: such a launch carries no per-column tap tables in LDS)
     p->mh_r = 0;
+    const bool no_sep2p = getenv("LGPU_NO_SEP2P") != nullptr;
     const bool no_mh = getenv("LGPU_NO_SEP2P_MFMA") != nullptr;
-    if (p->pers && !no_mh && dw >= 1 && sw % dw == 0 && sw / dw >= 2 && hb->nt <= 32 && hround == 64 && hshift == 7) {
+    const bool pers_ok = p->variant >= 100 && !no_sep2p && (sw & 3) == 0;
+    if (pers_ok && !no_mh && dw >= 1 && sw % dw == 0 && sw / dw >= 2 && hb->nt <= 32 && hround == 64 && hshift == 7) {
       const int r = sw / dw, c0 = hb->hpos[0] & 3, nt = hb->nt;
       bool ok = (c0 + 3 * r + nt) <= 32;
       for (int c = 0; c < dw && ok; c++) {
@@ -1943,6 +1949,19 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
         for (int j = 0; j < 32; j++) p->mh_taps[j] = j < nt ? hb->hco[j] : 0;
       }
     }
+    // k_sep2p: two window slots + double-buffered tables must leave two workgroups per CU; a window is at most kS2pMaxReq DMA requests
+    static const int th_force = getenv("LGPU_SEP2P_TH") ? atoi(getenv("LGPU_SEP2P_TH")) : 0;
+    if (pers_ok) {
+      for (int th2 = th_force ? th_force : dh > sh ? 32 : 16; th2 >= 1; th2 >>= 1) {
+        const int sht2 = window_rows(th2);
+        const S2pLds L(sht2, a.swt, th2, vb->npv, p->mh_r ? 1 : nph);
+        if (L.total <= 80 * 1024 && sht2 * (a.swt >> 2) <= kS2pMaxReq * 64 && th2 * (vb->npv + 1) <= 256 && vb->npv <= kS2pMaxNpv) {
+          p->pers = true; p->p_th = th2; p->p_sht = sht2; p->p_tiles_y = (dh + th2 - 1) / th2; p->p_lds = L.total;
+          break;
+        }
+      }
+    }
+    if (!p->pers) p->mh_r = 0;
   }
   return LGPU_OK;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/bench_chain_geom.py <sw> <sh> [tracks] -- the fused chain (2:1) at another geometry: us per launch and fraction of the 8 TB/s roofline; used to look at
+"""tools/bench_chain_geom.py <sw> <sh> [tracks [dw dh]] -- the fused chain (2:1 unless dw dh are given) at another geometry: us per launch and fraction of the 8 TB/s roofline; used to look at
 how the persistent kernel's tile-list stride interacts with the number of tiles per row"""
 import json
 import os
@@ -17,7 +17,7 @@ from lives_amd.lib import load   # noqa: E402
 def main():
     sw, sh = int(sys.argv[1]), int(sys.argv[2])
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-    dw, dh = sw // 2, sh // 2
+    dw, dh = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (sw // 2, sh // 2)
     ops.init(0)
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     sets = []
