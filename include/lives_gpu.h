@@ -44,6 +44,11 @@ int lgpu_malloc(void **ptr_d, size_t bytes);
    "failure leaves the layer untouched" contract (memfail:, src/colourspace.c:13906-13927) to fail a call after it has started. */
 int lgpu_debug_fail_alloc(int nth);
 int lgpu_free(void *ptr_d);
+/* stream-ordered allocation from the device's default pool (hipMallocAsync / hipFreeAsync): the block may be used by work enqueued on `stream` after the
+   call, and is handed out again only to work enqueued after the free.  No device synchronisation on either side (hipFree waits for the device to drain);
+   what the layer seam's resident planes come from.  lgpu_debug_fail_alloc counts these too. */
+int lgpu_malloc_ordered(void **ptr_d, size_t bytes, void *stream);
+int lgpu_free_ordered(void *ptr_d, void *stream);
 int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream);
 int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream);
 /* page-locked, zeroed host memory for frames (DMA at link rate); lgpu_upload / lgpu_download also accept pageable memory, which they move through

@@ -39,7 +39,13 @@ constexpr const char *kLeafContiguous = "host_contiguous";    // LIVES_LEAF_PIXE
 constexpr const char *kLeafResident = "host_gpu_resident";    // this library's private leaf (host_* convention, src/effects-weed.h:80-119)
 
 bool bound() { return g_api.leaf_get && g_api.leaf_set && g_api.leaf_num_elements && g_api.leaf_delete; }
-void *palloc(size_t n) { return g_api.pixel_alloc ? g_api.pixel_alloc(n) : calloc(1, n ? n : 1); }
+// zeroed = false: every byte of the block is about to be overwritten (a download of whole planes, or -- pinned layer -- the bytes are stale by contract
+// until lives_gpu_layer_sync() writes whole planes): glibc's calloc memsets recycled heap memory, ~60 us for a 1080p RGBA plane, which was the largest
+// single item of a seam call's host time (tools/bench_seam.py; profiles/r02/seam_bench.txt)
+void *palloc(size_t n, bool zeroed = true) {
+  if (g_api.pixel_alloc) return g_api.pixel_alloc(n);
+  return zeroed ? calloc(1, n ? n : 1) : malloc(n ? n : 1);
+}
 void pfree(void *p) { if (!p) return; if (g_api.pixel_free) g_api.pixel_free(p); else free(p); }
 
 bool has_leaf(weed_plant_t *p, const char *k) { return g_api.leaf_num_elements(p, k) > 0; }
@@ -109,9 +115,11 @@ std::unordered_map<const void *, ResEntry> g_res;
 std::atomic<unsigned long long> g_h2d{0}, g_d2h{0};   // PCIe byte counters (tests check the residency contract with them)
 thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
 
-// device buffers of dropped planes are recycled (hipMalloc / hipFree cost ~0.1 ms each and synchronise the device): a pinned layer going
-// through a chain of seam calls allocates a new plane per call.  Callers hold g_res_mu.  A pooled buffer is only handed out again to work that is
-// enqueued after the work that last used it (everything here runs on the null stream of the calling thread's device), so stream order protects it.
+// Device buffers of resident planes: a pinned layer going through a chain of seam calls takes a new plane per call and drops the old one, and neither
+// side may wait for the device.  First level: a small list of dropped buffers (a hit costs nothing; callers hold g_res_mu).  Behind it the device's
+// stream-ordered pool (lgpu_malloc_ordered: hipMallocAsync / hipFreeAsync on the null stream, which is the stream every seam call enqueues on; ~7 us a
+// pair, no synchronisation -- hipMalloc costs ~0.1 ms and hipFree waits for the device to drain, tools/alloc_probe.hip).  Either way a buffer is only
+// handed out again to work enqueued after the work that last used it, so stream order protects work still in flight that reads it.
 struct PoolEntry { void *d; size_t cap; };
 std::vector<PoolEntry> g_pool;
 size_t g_pool_bytes = 0;
@@ -128,13 +136,13 @@ void *pool_take(size_t n, size_t *cap_out) {
     return d;
   }
   void *d = nullptr;
-  if (lgpu_malloc(&d, n + 64) != LGPU_OK) return nullptr;
+  if (lgpu_malloc_ordered(&d, n + 64, nullptr) != LGPU_OK) return nullptr;
   *cap_out = n;
   return d;
 }
 void pool_give(void *d, size_t cap) {
   if (!d) return;
-  if (g_pool.size() >= kPoolMaxEntries || g_pool_bytes + cap > kPoolMaxBytes) { lgpu_free(d); return; }
+  if (g_pool.size() >= kPoolMaxEntries || g_pool_bytes + cap > kPoolMaxBytes) { lgpu_free_ordered(d, nullptr); return; }
   g_pool.push_back({d, cap});
   g_pool_bytes += cap;
 }
@@ -188,7 +196,7 @@ int take_alignment(int forced) {
   if (h != -1) t_rs_hint = 0;
   return h;
 }
-bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np, weed_plant_t *fixed_from = nullptr) {
+bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np, weed_plant_t *fixed_from = nullptr, bool zeroed = false) {
   np->n = lgpu_calc_rowstrides(width, pal, take_alignment(alignment), np->rs);
   if (np->n < 1) return false;
   apply_const_rowstrides(fixed_from, np->n, np->rs);
@@ -198,8 +206,9 @@ bool alloc_planes(int pal, int width, int height, int alignment, NewPlanes *np, 
     np->sz[i] = (size_t)np->rs[i] * h;
     tot += np->sz[i];
   }
-  uint8_t *blk = (uint8_t *)palloc(tot + 64);     // + EXTRA_BYTES-style slack (reference loops read a few bytes past the end)
+  uint8_t *blk = (uint8_t *)palloc(tot + 64, zeroed);     // + EXTRA_BYTES-style slack (reference loops read a few bytes past the end)
   if (!blk) return false;
+  if (!zeroed) memset(blk + tot, 0, 64);
   size_t off = 0;
   for (int i = 0; i < np->n; i++) { np->pd[i] = blk + off; off += np->sz[i]; }
   return true;
@@ -585,7 +594,7 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
   Layer old;
   const bool had = read_layer(layer, &old);
   NewPlanes np;
-  if (!alloc_planes(pal, width, height, 0, &np, layer)) return 0;
+  if (!alloc_planes(pal, width, height, 0, &np, layer, true)) return 0;
   // opaque black: RGB 0,0,0 (alpha 255); YUV 16 (clamped) or 0, 128, 128 (src/colourspace.c:11448-11460)
   if (black_fill) host_black_fill(pal, width, height, get_int(layer, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED), np);
   if (had) free_planes(old);
@@ -949,8 +958,9 @@ lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer) {
     if (np.rs[p] != l.rs[p]) change = true;
   }
   if (!change) return 1;
-  uint8_t *blk = (uint8_t *)palloc(tot + 64);
+  uint8_t *blk = (uint8_t *)palloc(tot + 64, false);
   if (!blk) return 0;
+  memset(blk + tot, 0, 64);
   size_t off = 0;
   for (int p = 0; p < np.n; p++) { np.pd[p] = blk + off; off += np.sz[p]; }
   {

@@ -55,6 +55,8 @@ PROTOTYPES = {
     "lgpu_device_count": [],
     "lgpu_malloc": [ctypes.POINTER(vp), ctypes.c_size_t],
     "lgpu_free": [vp],
+    "lgpu_malloc_ordered": [ctypes.POINTER(vp), ctypes.c_size_t, vp],
+    "lgpu_free_ordered": [vp, vp],
     "lgpu_debug_fail_alloc": [ci],
     "lgpu_upload": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_download": [vp, vp, ctypes.c_size_t, vp],

@@ -1269,3 +1269,40 @@ def test_rccl_entry_points_on_a_one_rank_communicator(gpu):
         torch.cuda.synchronize()
         assert torch.equal(d1, d2), s
     comm.close()
+
+
+@pytest.mark.gpu
+def test_stream_ordered_allocation():
+    """lgpu_malloc_ordered / lgpu_free_ordered (what the layer seam's resident planes come from): blocks of the device's stream-ordered pool are usable by
+    work enqueued after the call, freed blocks come back without a device synchronisation, and lgpu_debug_fail_alloc counts these allocations too"""
+    from lives_amd import lib
+    L = lib.load()
+    assert L.lgpu_init(0) == 0
+    ptrs = []
+    for i, n in enumerate((1 << 20, 2400000, 8294400)):
+        p = ctypes.c_void_p()
+        assert L.lgpu_malloc_ordered(ctypes.byref(p), n, None) == 0 and p.value
+        assert L.lgpu_fill(p, 17 + i, n, None) == 0
+        ptrs.append((p, n, 17 + i))
+    for p, n, v in ptrs:
+        back = np.zeros(n, np.uint8)
+        assert L.lgpu_download(back.ctypes.data, p, n, None) == 0 and L.lgpu_sync(None) == 0
+        assert (back == v).all()
+        assert L.lgpu_free_ordered(p, None) == 0
+    assert L.lgpu_free_ordered(None, None) == 0
+    # a freed block is handed out again to later work (no sync in between), and holds whatever that work writes
+    for k in range(8):
+        p = ctypes.c_void_p()
+        assert L.lgpu_malloc_ordered(ctypes.byref(p), 2400000, None) == 0
+        assert L.lgpu_fill(p, k, 2400000, None) == 0
+        back = np.zeros(16, np.uint8)
+        assert L.lgpu_download(back.ctypes.data, ctypes.c_void_p(p.value + 2400000 - 16), 16, None) == 0
+        assert L.lgpu_free_ordered(p, None) == 0
+        assert L.lgpu_sync(None) == 0 and (back == k).all()
+    L.lgpu_debug_fail_alloc.argtypes = [ctypes.c_int]
+    L.lgpu_debug_fail_alloc(1)
+    p = ctypes.c_void_p(1)
+    rc = L.lgpu_malloc_ordered(ctypes.byref(p), 4096, None)
+    L.lgpu_debug_fail_alloc(0)
+    assert rc == -5 and not p.value
+    assert L.lgpu_malloc_ordered(ctypes.byref(p), 4096, None) == 0 and L.lgpu_free_ordered(p, None) == 0

@@ -30,11 +30,20 @@ def main():
         L.lives_gpu_transfer_stats(ctypes.byref(a), ctypes.byref(b))
         return a.value + b.value
 
+    per_call = [0.0, 0.0, 0.0, 0.0]
+
     def chain(lay):
+        t = [time.perf_counter()]
         assert L.lives_gpu_convert_layer_palette(lay, 3, 0) == 1
+        t.append(time.perf_counter())
         assert L.lives_gpu_gamma_convert_layer(1, lay) == 1
+        t.append(time.perf_counter())
         assert L.lives_gpu_resize_layer(lay, 960, 540, 3, 0, 0) == 1
+        t.append(time.perf_counter())
         assert L.lives_gpu_letterbox_layer(lay, 960, 600, 960, 540, 3, 0, 0) == 1
+        t.append(time.perf_counter())
+        for i in range(4):
+            per_call[i] += t[i + 1] - t[i]
 
     for pinned in (0, 1):
         n = 30
@@ -46,6 +55,7 @@ def main():
             if pinned:
                 L.lives_gpu_layer_unpin(lay)
         b0 = stats()
+        per_call[:] = [0.0, 0.0, 0.0, 0.0]
         t_pin = t_chain = t_sync = 0.0
         t0 = time.perf_counter()
         for lay in layers[3:]:
@@ -64,12 +74,31 @@ def main():
         if pinned:
             print("          of which pin (upload 3.1 MB + sync) %.3f ms | the four calls (enqueue only, no synchronisation) %.3f ms | unpin (wait for the kernels, download 2.3 MB) %.3f ms"
                   % (t_pin / n * 1e3, t_chain / n * 1e3, t_sync / n * 1e3), flush=True)
+            print("          per call, us: convert %.1f | gamma %.1f | resize %.1f | letterbox %.1f" % tuple(x / n * 1e6 for x in per_call), flush=True)
+    # the host allocator's share: the convert call frees the decoder's three planes (3.1 MB the host wrote) with the bound pixel_free -- libc's free here,
+    # i.e. an munmap of ~760 touched pages; LiVES' own frames come from its bigblock pool (src/memory.c) and cost nothing to release
+    libc = ctypes.CDLL("libc.so.6")
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    blocks = []
+    for _ in range(20):
+        pm = libc.malloc(Y.nbytes + U.nbytes + V.nbytes + 64)
+        ctypes.memmove(pm, Y.ctypes.data, Y.nbytes)
+        ctypes.memmove(pm + Y.nbytes, U.ctypes.data, U.nbytes)
+        ctypes.memmove(pm + Y.nbytes + U.nbytes, V.ctypes.data, V.nbytes)
+        blocks.append(pm)
+    t0 = time.perf_counter()
+    for pm in blocks:
+        libc.free(pm)
+    print("          (libc free() of one decoder frame's touched 3.1 MB, which the convert call includes: %.1f us)" % ((time.perf_counter() - t0) / 20 * 1e6), flush=True)
     # a resident chain as a render loop runs it: layers pinned once (decoder output uploaded), the chain enqueued for a batch of frames, one wait at the end
     n = 30
     layers = [wh.new_layer(512, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1) for _ in range(n)]
     for lay in layers:
         L.lives_gpu_layer_pin(lay)
     L.lgpu_sync(None)
+    per_call[:] = [0.0, 0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for lay in layers:
         chain(lay)
@@ -77,6 +106,7 @@ def main():
     L.lgpu_sync(None)
     t2 = time.perf_counter()
     print("resident : %.3f ms per frame host time for the four calls, %.3f ms per frame until the device has finished all %d frames" % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3, n), flush=True)
+    print("          per call, us: convert %.1f | gamma %.1f | resize %.1f | letterbox %.1f" % tuple(x / n * 1e6 for x in per_call), flush=True)
     for lay in layers:
         L.lives_gpu_layer_unpin(lay)
 
