@@ -49,6 +49,16 @@ int lgpu_free(void *ptr_d);
    what the layer seam's resident planes come from.  lgpu_debug_fail_alloc counts these too. */
 int lgpu_malloc_ordered(void **ptr_d, size_t bytes, void *stream);
 int lgpu_free_ordered(void *ptr_d, void *stream);
+/* streams and events for hosts that enqueue from several threads.  Every entry point below takes a `stream` (NULL = the null stream).  nonblocking = 0:
+   the stream is ordered against work on the null stream (and every launch on it pays for that); 1: it is not, and the caller orders hand-overs with
+   events.  The layer seam (lives_gpu_layer.h) gives every host thread a non-blocking stream of its own and orders work on a resident plane across
+   threads -- and against the null stream the weed plugin uses -- with an event at each hand-over (LiVES' plan steps run on pool threads: src/threading.c). */
+int lgpu_stream_create(void **stream_out, int nonblocking);
+int lgpu_stream_destroy(void *stream);
+int lgpu_event_create(void **event_out);
+int lgpu_event_destroy(void *event);
+int lgpu_event_record(void *event, void *stream);
+int lgpu_stream_wait_event(void *stream, void *event);
 int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream);
 int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream);
 /* page-locked, zeroed host memory for frames (DMA at link rate); lgpu_upload / lgpu_download also accept pageable memory, which they move through

@@ -20,6 +20,7 @@
 // nothing synchronises -- the calls of a chain only enqueue work, the one synchronisation is lives_gpu_layer_sync().
 #include <stdint.h>
 #include <stdlib.h>
+#include <sched.h>
 #include <string.h>
 #include <atomic>
 #include <mutex>
@@ -109,50 +110,134 @@ bool read_layer(weed_plant_t *plant, Layer *l) {
 // pointer: uploads of such a plane become device-to-device copies, downloads replace the device copy and leave the host
 // bytes stale until lives_gpu_layer_sync().  The CONVERT chain of one plan step (pconv -> gamma -> resize -> letterbox) then
 // crosses PCIe once in each direction instead of eight times.
-struct ResEntry { void *d; size_t bytes; };
-std::mutex g_res_mu;
-std::unordered_map<const void *, ResEntry> g_res;
+// Streams: every host thread enqueues on a stream of its own (LiVES runs plan steps and conversions on pool threads, src/threading.c; one shared
+// stream would run the small kernels of different tracks one after the other).  Non-blocking streams: a launch on a blocking one costs twice the host
+// time (ordering against the null stream is checked per launch).  The null stream's users -- the weed plugin through lives_gpu_resident_lookup -- are
+// ordered at that hand-over like any other stream.  Never destroyed: a thread_local destructor of the main thread runs after HIP's teardown.
+thread_local void *t_stream = nullptr;
+thread_local bool t_stream_tried = false;
+void *S() {
+  if (!t_stream_tried) {
+    t_stream_tried = true;
+    if (lgpu_stream_create(&t_stream, 1) != LGPU_OK) t_stream = nullptr;        // the null stream then: everything is ordered, nothing overlaps
+  }
+  return t_stream;
+}
+
+// A device buffer and the stream its last use was enqueued on.  Ownership of a resident plane moves from call to call; a call on ANOTHER thread's
+// stream orders itself behind the previous owner by recording an event on that stream at the moment of the hand-over (everything enqueued there
+// so far, which includes the buffer's last use) and waiting for it -- nothing is recorded while a layer stays on one thread (an event per plane and
+// call measured 4 - 8 us each on these streams: 9 -> 17 us per seam call).
+struct Dev { void *d = nullptr; size_t bytes = 0; void *stream = nullptr; };
+static char g_idle_tag;
+void *const kIdle = &g_idle_tag;                  // Dev::stream of a buffer whose last use is known to be complete (the stream was synchronised since)
+// The table lock: a dozen sub-microsecond critical sections per seam call.  A futex mutex here made sixteen host threads run slower than one (every
+// contended acquisition a sleep / wake cycle, ~10 us; tools/bench_seam_mt.py: 500 us per call at 16 threads against 10 us alone), so: spin briefly, then yield.
+struct SpinLock {
+  std::atomic<bool> held{false};
+  void lock() {
+    for (int spins = 0;; spins++) {
+      if (!held.load(std::memory_order_relaxed) && !held.exchange(true, std::memory_order_acquire)) return;
+      if (spins < 4000) __builtin_ia32_pause(); else { sched_yield(); spins = 0; }
+    }
+  }
+  void unlock() { held.store(false, std::memory_order_release); }
+};
+SpinLock g_res_mu;                                // guards g_res, g_pool and the Dev records in them
+std::unordered_map<const void *, Dev> g_res;      // resident planes by HOST plane pointer
 std::atomic<unsigned long long> g_h2d{0}, g_d2h{0};   // PCIe byte counters (tests check the residency contract with them)
 thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
+thread_local void *t_event = nullptr;           // this thread's hand-over event (re-recorded at every hand-over; a wait holds the record it saw)
+
+// No HIP call is made under g_res_mu: the functions below copy what they need out of the tables and do the stream work afterwards.
+// The calling thread's stream waits for everything enqueued so far on the stream of the buffer's last use, if that is another stream.
+void await(const Dev &b) {
+  if (!b.d || b.stream == S() || b.stream == kIdle) return;
+  if (!t_event && lgpu_event_create(&t_event) != LGPU_OK) t_event = nullptr;
+  if (t_event && lgpu_event_record(t_event, b.stream) == LGPU_OK && lgpu_stream_wait_event(S(), t_event) == LGPU_OK) return;
+  lgpu_sync(b.stream);                            // no event to be had: wait for that stream on the host instead
+}
 
 // Device buffers of resident planes: a pinned layer going through a chain of seam calls takes a new plane per call and drops the old one, and neither
-// side may wait for the device.  First level: a small list of dropped buffers (a hit costs nothing; callers hold g_res_mu).  Behind it the device's
-// stream-ordered pool (lgpu_malloc_ordered: hipMallocAsync / hipFreeAsync on the null stream, which is the stream every seam call enqueues on; ~7 us a
-// pair, no synchronisation -- hipMalloc costs ~0.1 ms and hipFree waits for the device to drain, tools/alloc_probe.hip).  Either way a buffer is only
-// handed out again to work enqueued after the work that last used it, so stream order protects work still in flight that reads it.
-struct PoolEntry { void *d; size_t cap; };
-std::vector<PoolEntry> g_pool;
+// side may wait for the device.  First level: a list of dropped buffers (a hit costs nothing).  Behind it the device's stream-ordered pool
+// (lgpu_malloc_ordered: hipMallocAsync / hipFreeAsync on the calling thread's stream; ~10 us each, no synchronisation -- hipMalloc costs ~0.1 ms
+// and hipFree waits for the device to drain, tools/alloc_probe.hip).  A buffer from the list carries the stream of its last use; a taker on another
+// stream waits for that one.
+// Buffers come in size classes ({1, 1.25, 1.5, 1.75} x 2^k, at least 64 KB): planes of similar size -- a 960 x 540 frame and its 960 x 600 letterboxed
+// canvas -- recycle each other's buffers instead of each going to the device pool.  The list keeps up to 8 GB (a 288 GB device; what a few dozen 4K
+// layers in flight hand back and forth) and is bucketed by class, so in steady state no call reaches hipMallocAsync / hipFreeAsync at all: under
+// sixteen host threads those two were where the seam calls queued (tools/bench_seam_mt.py).
+std::unordered_map<size_t, std::vector<Dev>> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t kPoolMaxBytes = 1u << 30, kPoolMaxEntries = 32;
-void *pool_take(size_t n, size_t *cap_out) {
-  int best = -1;
-  for (int i = 0; i < (int)g_pool.size(); i++)
-    if (g_pool[i].cap >= n && g_pool[i].cap <= 2 * n + (1u << 20) && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
-  if (best >= 0) {
-    void *d = g_pool[best].d;
-    *cap_out = g_pool[best].cap;
-    g_pool_bytes -= g_pool[best].cap;
-    g_pool.erase(g_pool.begin() + best);
-    return d;
-  }
-  void *d = nullptr;
-  if (lgpu_malloc_ordered(&d, n + 64, nullptr) != LGPU_OK) return nullptr;
-  *cap_out = n;
-  return d;
+constexpr size_t kPoolMaxBytes = 8ull << 30;
+size_t pool_class(size_t n) {
+  if (n <= (64u << 10)) return 64u << 10;
+  size_t base = 64u << 10;
+  while (base * 2 <= n) base *= 2;
+  const size_t step = base / 4;
+  return base + (n - base + step - 1) / step * step;
 }
-void pool_give(void *d, size_t cap) {
-  if (!d) return;
-  if (g_pool.size() >= kPoolMaxEntries || g_pool_bytes + cap > kPoolMaxBytes) { lgpu_free_ordered(d, nullptr); return; }
-  g_pool.push_back({d, cap});
-  g_pool_bytes += cap;
+bool pool_take(size_t n, Dev *out) {
+  const size_t cls = pool_class(n + 64);
+  bool hit = false;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    auto it = g_pool.find(cls);
+    if (it != g_pool.end() && !it->second.empty()) {
+      std::vector<Dev> &v = it->second;
+      int best = (int)v.size() - 1;                                // newest first; one whose last use needs no cross-stream wait if there is one near the top
+      for (int i = best, k = 0; i >= 0 && k < 8; i--, k++)
+        if (v[i].stream == S() || v[i].stream == kIdle) { best = i; break; }
+      *out = v[best];
+      v[best] = v.back();
+      v.pop_back();
+      g_pool_bytes -= cls;
+      hit = true;
+    }
+  }
+  if (hit) { await(*out); out->stream = S(); return true; }
+  Dev b;
+  if (lgpu_malloc_ordered(&b.d, cls, S()) != LGPU_OK) return false;
+  b.bytes = cls; b.stream = S();
+  *out = b;
+  return true;
+}
+void pool_give(Dev b) {
+  if (!b.d) return;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    if (g_pool_bytes + b.bytes <= kPoolMaxBytes) {
+      g_pool[b.bytes].push_back(b);
+      g_pool_bytes += b.bytes;
+      return;
+    }
+  }
+  await(b);                                       // the free is ordered on this thread's stream, which first waits for the last use
+  lgpu_free_ordered(b.d, S());
+}
+// the resident copy registered under host plane h becomes b (last used on the calling thread's stream); whatever was there goes back to the pool
+void res_put(const void *h, Dev b) {
+  Dev old;
+  b.stream = S();
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    Dev &e = g_res[h];
+    old = e;
+    e = b;
+  }
+  pool_give(old);
 }
 
 void res_drop(const void *h) {
-  std::lock_guard<std::mutex> lk(g_res_mu);
-  auto it = g_res.find(h);
-  if (it == g_res.end()) return;
-  pool_give(it->second.d, it->second.bytes);
-  g_res.erase(it);
+  Dev b;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    auto it = g_res.find(h);
+    if (it == g_res.end()) return;
+    b = it->second;
+    g_res.erase(it);
+  }
+  pool_give(b);
 }
 struct PinScope {
   bool prev;
@@ -243,53 +328,78 @@ struct Scratch {
 thread_local Scratch t_scr;
 
 bool ready() { return bound() && lgpu_init(g_prefs.device) == LGPU_OK; }
-bool sync() { return lgpu_sync(nullptr) == LGPU_OK; }
+bool sync() { return lgpu_sync(S()) == LGPU_OK; }
 
 // resident device copy of a plane of the layer the call in progress works on (only pinned layers have one: the table is
-// keyed by host pointer, and a host pointer proves nothing about a layer that was never pinned)
+// keyed by host pointer, and a host pointer proves nothing about a layer that was never pinned), ready for work on the calling
+// thread's stream.  The caller marks the plane (touch_done) once its work is enqueued.
 uint8_t *resident(const void *h, size_t n) {
   if (!t_pinned || !h) return nullptr;
-  std::lock_guard<std::mutex> lk(g_res_mu);
+  Dev b;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    auto it = g_res.find(h);
+    if (it == g_res.end() || it->second.bytes < n) return nullptr;
+    b = it->second;
+    it->second.stream = S();                     // this thread's stream is where its next use is enqueued (behind the wait below)
+  }
+  await(b);
+  return (uint8_t *)b.d;
+}
+void touch_done(const void *h) {
+  std::lock_guard<SpinLock> lk(g_res_mu);
   auto it = g_res.find(h);
-  return (it != g_res.end() && it->second.bytes >= n) ? (uint8_t *)it->second.d : nullptr;
+  if (it != g_res.end()) it->second.stream = S();
 }
 
-// One seam call's device-side work.  in(): the current bytes of an existing plane.  out(): a plane the call creates (for a new
-// host plane).  inout(): a plane modified in place.  finish() makes the results the planes' contents: downloads + ONE sync for an
-// ordinary layer; for a pinned layer the pool buffers the kernels wrote become the resident copies, nothing moves, nothing waits.
-// A Work that is dropped without finish() (any failure) gives its buffers back: the layer is as it was.
+// One seam call's device-side work, enqueued on the calling thread's stream.  in(): the current bytes of an existing plane.  out(): a plane
+// the call creates (for a new host plane).  inout(): a plane modified in place.  finish() makes the results the planes' contents: downloads + ONE
+// sync for an ordinary layer; for a pinned layer the pool buffers the kernels wrote become the resident copies, nothing moves, nothing waits.
+// A Work that is dropped without finish() (any failure) gives its buffers back: the layer is as it was.  Either way every resident plane the
+// call touched is marked with the calling thread's stream, which is what a later call on another thread's stream orders itself behind.
 struct Work {
-  struct Out { uint8_t *host, *dev; size_t n, cap; bool pooled; };
+  struct Out { uint8_t *host; Dev b; size_t n; bool pooled; };
   Out outs[8];
-  int nout = 0;
+  const void *touched[12];
+  int nout = 0, ntouched = 0;
   bool ok = true, done = false;
+  uint8_t *use(const void *h, size_t n) {
+    uint8_t *r = resident(h, n);
+    if (r && ntouched < 12) touched[ntouched++] = h;
+    else if (r) { touch_done(h); }                            // cannot happen with <= 4 planes in and out; marked early rather than lost
+    return r;
+  }
   const uint8_t *in(const uint8_t *h, size_t n, int slot) {
     if (!ok) return nullptr;
-    if (uint8_t *r = resident(h, n)) return r;
+    if (uint8_t *r = use(h, n)) return r;
     uint8_t *d = t_scr.get(slot, n);
     g_h2d += n;
-    ok = d && lgpu_upload(d, h, n, nullptr) == LGPU_OK;
+    ok = d && lgpu_upload(d, h, n, S()) == LGPU_OK;
     return ok ? d : nullptr;
   }
   // zero: the kernel does not write every byte (row padding, skipped alpha bytes): start from the zeros of the fresh host plane
   uint8_t *out(uint8_t *h, size_t n, int slot, bool zero) {
     if (!ok || nout >= 8) { ok = false; return nullptr; }
-    Out o = {h, nullptr, n, 0, false};
+    Out o;
+    o.host = h; o.n = n; o.pooled = false;
     if (t_pinned) {
-      std::lock_guard<std::mutex> lk(g_res_mu);
-      o.dev = (uint8_t *)pool_take(n, &o.cap);
+      if (!pool_take(n, &o.b)) { ok = false; return nullptr; }
       o.pooled = true;
-    } else o.dev = t_scr.get(slot, n);
-    ok = o.dev && (!zero || lgpu_fill(o.dev, 0, n, nullptr) == LGPU_OK);
-    if (o.dev) outs[nout++] = o;
-    return ok ? o.dev : nullptr;
+    } else o.b.d = t_scr.get(slot, n);
+    ok = o.b.d && (!zero || lgpu_fill(o.b.d, 0, n, S()) == LGPU_OK);
+    if (o.b.d) outs[nout++] = o;
+    return ok ? (uint8_t *)o.b.d : nullptr;
   }
   uint8_t *inout(uint8_t *h, size_t n, int slot) {
     if (!ok || nout >= 8) { ok = false; return nullptr; }
-    if (uint8_t *r = resident(h, n)) return r;               // modified where it lives
+    if (uint8_t *r = use(h, n)) return r;                    // modified where it lives
     uint8_t *d = const_cast<uint8_t *>(in(h, n, slot));
-    if (d) outs[nout++] = Out{h, d, n, 0, false};
+    if (d) { Out o; o.host = h; o.b.d = d; o.n = n; o.pooled = false; outs[nout++] = o; }
     return d;
+  }
+  void mark_touched() {
+    for (int i = 0; i < ntouched; i++) touch_done(touched[i]);
+    ntouched = 0;
   }
   bool finish() {
     if (!ok) return false;
@@ -297,25 +407,24 @@ struct Work {
     for (int i = 0; i < nout && ok; i++) {
       Out &o = outs[i];
       if (o.pooled) {                                         // the buffer becomes the resident copy of the new host plane
-        std::lock_guard<std::mutex> lk(g_res_mu);
-        ResEntry &e = g_res[o.host];
-        pool_give(e.d, e.bytes);
-        e.d = o.dev; e.bytes = o.cap;
-        o.dev = nullptr;
+        res_put(o.host, o.b);
+        o.b = Dev();
       } else {
         g_d2h += o.n;
-        ok = lgpu_download(o.host, o.dev, o.n, nullptr) == LGPU_OK;
+        ok = lgpu_download(o.host, o.b.d, o.n, S()) == LGPU_OK;
         moved = true;
       }
     }
+    mark_touched();
     if (ok && moved) ok = sync();
     done = ok;
     return ok;
   }
   ~Work() {
     if (done) return;
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    for (int i = 0; i < nout; i++) if (outs[i].pooled && outs[i].dev) pool_give(outs[i].dev, outs[i].cap);
+    mark_touched();
+    for (int i = 0; i < nout; i++)
+      if (outs[i].pooled && outs[i].b.d) { outs[i].b.stream = S(); pool_give(outs[i].b); }
   }
 };
 
@@ -365,7 +474,7 @@ bool switch_layer_clamping(weed_plant_t *layer, const Layer &l, int oclamping) {
     d[p] = w.inout(l.pd[p], (size_t)l.rs[p] * ph, p == 0 ? 0 : p + 3);
     rs[p] = l.rs[p];
   }
-  if (!w.ok || lgpu_yuv_switch_clamping(d, rs, l.pal, l.height, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) != LGPU_OK) return false;
+  if (!w.ok || lgpu_yuv_switch_clamping(d, rs, l.pal, l.height, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, S()) != LGPU_OK) return false;
   if (!w.finish()) return false;
   set_int(layer, WEED_LEAF_YUV_CLAMPING, oclamping);
   return true;
@@ -402,7 +511,7 @@ lives_gpu_boolean rgb_layer_to_yuv411(weed_plant_t *layer, const Layer &l, int o
   Work w;
   const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
   uint8_t *d_out = w.out(np.pd[0], np.sz[0], 3, true);
-  const bool ok = w.ok && lgpu_rgb_to_yuv411(d_in, l.rs[0], l.width, l.height, order, in_alpha, d_out, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK &&
+  const bool ok = w.ok && lgpu_rgb_to_yuv411(d_in, l.rs[0], l.width, l.height, order, in_alpha, d_out, oclamping == WEED_YUV_CLAMPING_UNCLAMPED, S()) == LGPU_OK &&
                   w.finish();
   if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
@@ -456,8 +565,8 @@ lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l_in, int o
   int ors[4] = {0, 0, 0, 0};
   for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }   // calloc'd padding stays as the host made it
   const bool ok = w.ok &&
-                  (lut16 ? lgpu_rgb_to_yuv_lut16(d_in, l.rs[0], width, height, order, in_alpha, ddst[0], ors[0], fmt, which & 1, lut16, nullptr)
-                         : lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, nullptr)) == LGPU_OK &&
+                  (lut16 ? lgpu_rgb_to_yuv_lut16(d_in, l.rs[0], width, height, order, in_alpha, ddst[0], ors[0], fmt, which & 1, lut16, S())
+                         : lgpu_rgb_to_yuv(d_in, l.rs[0], width, height, order, in_alpha, ddst, ors, fmt, out_alpha, which, S())) == LGPU_OK &&
                   w.finish();
   if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
@@ -545,7 +654,7 @@ static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, i
     uint8_t *dd[4] = {w.inout(l.pd[0], (size_t)l.rs[0] * height, 0), nullptr, nullptr, nullptr};
     dsrc[0] = dd[0]; irs[0] = l.rs[0];
     if (!w.ok) return 0;
-    const int rc = lgpu_yuv_repack(inpl, outpl, dsrc, irs, dd, irs, width, height, unclamped, 0, nullptr);
+    const int rc = lgpu_yuv_repack(inpl, outpl, dsrc, irs, dd, irs, width, height, unclamped, 0, S());
     if (rc == LGPU_E_UNSUPPORTED) return decline(layer);
     if (rc != LGPU_OK || !w.finish()) return 0;
     set_int(layer, WEED_LEAF_CURRENT_PALETTE, outpl);
@@ -562,7 +671,7 @@ static lives_gpu_boolean yuv_layer_repack(weed_plant_t *layer, const Layer &l, i
   NewPlanes np;
   if (!alloc_planes(outpl, lwidth, height, 0, &np)) return 0;
   for (int p = 0; p < np.n; p++) { ddst[p] = w.out(np.pd[p], np.sz[p], 3 + p, true); ors[p] = np.rs[p]; }
-  const int rc = w.ok ? lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, l.sampling, nullptr) : LGPU_E_NOMEM;   // isampling: read by K5d only
+  const int rc = w.ok ? lgpu_yuv_repack(inpl, outpl, dsrc, irs, ddst, ors, width, height, unclamped, l.sampling, S()) : LGPU_E_NOMEM;   // isampling: read by K5d only
   if (rc == LGPU_E_UNSUPPORTED) { drop_new_planes(np); return decline(layer); }
   if (rc != LGPU_OK || !w.finish()) { drop_new_planes(np); return 0; }
   free_planes(l);
@@ -663,7 +772,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     const int op = rgb_swizzle_op(inpl, outpl, &af);
     const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
     uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
-    ok = w.ok && lgpu_swizzle(op, af, d_in, l.rs[0], d_out, np.rs[0], l.width, l.height, lutp, nullptr) == LGPU_OK;
+    ok = w.ok && lgpu_swizzle(op, af, d_in, l.rs[0], d_out, np.rs[0], l.width, l.height, lutp, S()) == LGPU_OK;
   } else if (in_planar_sub) {
     const int iu = (inpl == WEED_PALETTE_YVU420P) ? 2 : 1, iv = (inpl == WEED_PALETTE_YVU420P) ? 1 : 2;   // swap_chroma_planes (:12353)
     const int ch = plane_h(l, 1);
@@ -678,10 +787,10 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
       // with a target gamma the reference fuses the 16-bit indexed LUT of create_gamma_lut into the conversion (:3274-3283)
       const uint16_t *d16 = device_lut16(l.gamma, new_gamma);
       ok = d16 && lgpu_yuv420p_to_rgb_lut16(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
-                                            inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, d16, 0, nullptr) == LGPU_OK;
+                                            inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, d16, 0, S()) == LGPU_OK;
     } else if (ok)
       ok = lgpu_yuv420p_to_rgb(dy, du, dv, strides, (long)ub, (long)vb, d_out, np.rs[0], l.width, l.height, pal_psize(outpl), order,
-                               inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, nullptr, 0, nullptr) == LGPU_OK;
+                               inpl == WEED_PALETTE_YUV422P, which, g_prefs.pb_quality, nullptr, 0, S()) == LGPU_OK;
   } else if (k3_fmt(inpl) >= 0) {
     // K3: packed / planar 4:4:4, UYVY, YUYV -> RGB family (src/colourspace.c:12937-13860 cases); no inline gamma on these paths
     const int fmt = k3_fmt(inpl), in_alpha = (inpl == WEED_PALETTE_YUVA8888 || inpl == WEED_PALETTE_YUVA4444P);
@@ -693,7 +802,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     int irs[4] = {0, 0, 0, 0};
     for (int p = 0; p < l.nplanes; p++) { dsrc[p] = w.in(l.pd[p], (size_t)l.rs[p] * l.height, p == 0 ? 0 : p + 3); irs[p] = l.rs[p]; }
     uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
-    ok = w.ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, nullptr) == LGPU_OK;
+    ok = w.ok && lgpu_yuv_to_rgb(dsrc, irs, pxw, l.height, fmt, in_alpha, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0, which, S()) == LGPU_OK;
   } else {
     // K3b, YUV411 (:13755-13795): the reference walks the source as compact rows of `width` macropixels and leaves some alpha bytes of the
     // new (zeroed, create_empty_pixel_data) frame unwritten -- the device frame starts zeroed too
@@ -703,7 +812,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     const uint8_t *d_in = w.in(l.pd[0], ibytes, 0);
     uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
     ok = w.ok && lgpu_yuv411_to_rgb(d_in, l.width, l.height, d_out, np.rs[0], order, pal_has_alpha(outpl) ? 1 : 0,
-                                   iclamping == WEED_YUV_CLAMPING_UNCLAMPED, nullptr) == LGPU_OK;
+                                   iclamping == WEED_YUV_CLAMPING_UNCLAMPED, S()) == LGPU_OK;
   }
   ok = ok && w.finish();
   if (!ok) { drop_new_planes(np); return 0; }                                // memfail: layer untouched
@@ -740,7 +849,7 @@ lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg
   if (x < 0 || y < 0 || x + width > l.width || y + height > l.height) return 0;
   Work w;
   uint8_t *d = w.inout(l.pd[0], (size_t)l.rs[0] * l.height, 0);
-  const bool ok = w.ok && lgpu_gamma_apply(d, l.rs[0], x, y, width, height, pal_psize(l.pal), pal_alpha_first(l.pal), lut, nullptr) == LGPU_OK && w.finish();
+  const bool ok = w.ok && lgpu_gamma_apply(d, l.rs[0], x, y, width, height, pal_psize(l.pal), pal_alpha_first(l.pal), lut, S()) == LGPU_OK && w.finish();
   if (!ok) return 0;
   if (gamma_type != LIVES_GAMMA_VARIANT) set_int(layer, WEED_LEAF_GAMMA_TYPE, gamma_type);
   return 1;
@@ -778,10 +887,10 @@ void lives_gpu_alpha_premult(lives_gpu_layer_t *layer, int direction) {
       dp[p] = (p == 3) ? const_cast<uint8_t *>(w.in(l.pd[p], nb, 7)) : w.inout(l.pd[p], nb, p);           // the alpha plane is only read
       rs[p] = l.rs[p];
     }
-    ok = w.ok && lgpu_alpha_premult_yuva(dp, rs, l.width, l.height, l.pal, clamped, direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK;
+    ok = w.ok && lgpu_alpha_premult_yuva(dp, rs, l.width, l.height, l.pal, clamped, direction == LIVES_DIRECTION_REVERSE, S()) == LGPU_OK;
   } else {
     uint8_t *d = w.inout(l.pd[0], (size_t)l.rs[0] * l.height, 0);
-    ok = w.ok && lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, nullptr) == LGPU_OK;
+    ok = w.ok && lgpu_alpha_premult(d, l.rs[0], l.width, l.height, pal_alpha_first(l.pal), direction == LIVES_DIRECTION_REVERSE, S()) == LGPU_OK;
   }
   if (!ok || !w.finish()) return;
   int flags = l.flags;
@@ -801,7 +910,7 @@ static bool resize_into(const Layer &l, int width, int height, int interp, int a
     const int sw = plane_w(l, p), sh = plane_h(l, p), dw = plane_w(nl, p), dh = plane_h(nl, p);
     const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
     uint8_t *d_out = w.out(np->pd[p], (size_t)np->rs[p] * dh, 3 + p, true);
-    ok = w.ok && lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, lut8, nullptr) == LGPU_OK;
+    ok = w.ok && lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, lut8, S()) == LGPU_OK;
   }
   ok = ok && w.finish();
   if (!ok) drop_new_planes(*np);
@@ -892,7 +1001,7 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
     const int sw = plane_w(l, p), sh = plane_h(l, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
     const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
     uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, true);     // the canvas keeps its zeroed row padding
-    ok = w.ok && lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, nullptr) == LGPU_OK;
+    ok = w.ok && lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, S()) == LGPU_OK;
   }
   ok = ok && w.finish();
   if (!ok) { drop_new_planes(np); return 0; }
@@ -925,8 +1034,8 @@ lives_gpu_boolean lives_gpu_unletterbox_layer(lives_gpu_layer_t *layer, int opwi
     const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * height, 0);
     uint8_t *d_out = w.out(np.pd[0], np.sz[0], 3, true);
     // the copied part of a row is xwidth bytes = xwidth / ps whole pixels (+ xwidth % ps bytes of the next one: a byte-granular blit)
-    const bool ok = w.ok && lgpu_fill_pattern(d_out, np.rs[0], black, ps, xwidth, xheight, nullptr) == LGPU_OK &&          // create_empty_pixel_data(black_fill)
-                    lgpu_copy_rows(d_out, np.rs[0], d_in + (size_t)top * l.rs[0] + (size_t)left * ps, l.rs[0], xwidth, xheight, nullptr) == LGPU_OK && w.finish();
+    const bool ok = w.ok && lgpu_fill_pattern(d_out, np.rs[0], black, ps, xwidth, xheight, S()) == LGPU_OK &&          // create_empty_pixel_data(black_fill)
+                    lgpu_copy_rows(d_out, np.rs[0], d_in + (size_t)top * l.rs[0] + (size_t)left * ps, l.rs[0], xwidth, xheight, S()) == LGPU_OK && w.finish();
     if (!ok) { drop_new_planes(np); return 0; }
   }
   free_planes(l);
@@ -969,7 +1078,7 @@ lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer) {
     for (int p = 0; p < np.n && ok; p++) {
       const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p);
       uint8_t *d_out = w.out(np.pd[p], np.sz[p], 3 + p, false);
-      ok = w.ok && lgpu_copy_rows(d_out, np.rs[p], d_in, l.rs[p], np.rs[p], plane_h(l, p), nullptr) == LGPU_OK;
+      ok = w.ok && lgpu_copy_rows(d_out, np.rs[p], d_in, l.rs[p], np.rs[p], plane_h(l, p), S()) == LGPU_OK;
     }
     if (!ok || !w.finish()) { pfree(blk); return 0; }
   }
@@ -1009,7 +1118,12 @@ lives_gpu_boolean lives_gpu_weed_layer_clear_pixel_data(lives_gpu_layer_t *layer
     const uint8_t *pp = plen ? pat : one;
     const int pl = plen ? plen : 1, n = plen ? nmp : pw;
     uint8_t *d = on_device ? resident(l.pd[p], (size_t)l.rs[p] * ph) : nullptr;
-    if (d) { if (lgpu_fill_pattern(d, l.rs[p], pp, pl, n, ph, nullptr) != LGPU_OK) return 0; continue; }
+    if (d) {
+      const int rc = lgpu_fill_pattern(d, l.rs[p], pp, pl, n, ph, S());
+      touch_done(l.pd[p]);
+      if (rc != LGPU_OK) return 0;
+      continue;
+    }
     for (int y = 0; y < ph; y++) {
       uint8_t *row = l.pd[p] + (size_t)y * l.rs[p];
       if (pl == 1) memset(row, pp[0], (size_t)n);
@@ -1025,28 +1139,32 @@ static size_t plane_bytes(const Layer &l, int p) {
   const int h = (!planar || p == 0 || p == 3 || pal_is_444(l.pal) || l.pal == WEED_PALETTE_YUV422P) ? l.height : l.height >> 1;
   return (size_t)l.rs[p] * h;
 }
+// this thread's stream has just been synchronised: planes whose last use was enqueued on it have no work pending, whoever touches them next need not wait
+static void settle(const Layer &l) {
+  std::lock_guard<SpinLock> lk(g_res_mu);
+  for (int p = 0; p < l.nplanes; p++) {
+    auto it = g_res.find(l.pd[p]);
+    if (it != g_res.end() && it->second.stream == S()) it->second.stream = kIdle;
+  }
+}
 int lives_gpu_layer_pin(lives_gpu_layer_t *layer) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return LGPU_E_BADARG;
   if (has_leaf(layer, kLeafResident)) return LGPU_OK;
   for (int p = 0; p < l.nplanes; p++) {
     const size_t n = plane_bytes(l, p);
-    void *d = nullptr;
-    size_t cap = 0;
-    { std::lock_guard<std::mutex> lk(g_res_mu); d = pool_take(n, &cap); }
-    if (!d) { for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_NOMEM; }
+    Dev b;
+    if (!pool_take(n, &b)) { for (int q = 0; q < p; q++) res_drop(l.pd[q]); return LGPU_E_NOMEM; }
     g_h2d += n;
-    if (lgpu_upload(d, l.pd[p], n, nullptr) != LGPU_OK) {
-      { std::lock_guard<std::mutex> lk(g_res_mu); pool_give(d, cap); }
+    if (lgpu_upload(b.d, l.pd[p], n, S()) != LGPU_OK) {
+      pool_give(b);
       for (int q = 0; q < p; q++) res_drop(l.pd[q]);
       return LGPU_E_HIP;
     }
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    ResEntry &e = g_res[l.pd[p]];
-    pool_give(e.d, e.bytes);
-    e.d = d; e.bytes = cap;
+    res_put(l.pd[p], b);
   }
   if (!sync()) return LGPU_E_HIP;             // the host may change or free its bytes once pin returns
+  settle(l);
   set_int(layer, kLeafResident, 1);
   return LGPU_OK;
 }
@@ -1056,17 +1174,20 @@ int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
   if (!has_leaf(layer, kLeafResident)) return LGPU_OK;          // never pinned: the host bytes are the planes
   for (int p = 0; p < l.nplanes; p++) {
     const size_t n = plane_bytes(l, p);
-    void *d = nullptr;
+    Dev b;
     {
-      std::lock_guard<std::mutex> lk(g_res_mu);
+      std::lock_guard<SpinLock> lk(g_res_mu);
       auto it = g_res.find(l.pd[p]);
-      if (it != g_res.end() && it->second.bytes >= n) d = it->second.d;
+      if (it != g_res.end() && it->second.bytes >= n) { b = it->second; it->second.stream = S(); }
     }
-    if (!d) continue;                                   // this plane's host bytes are current
+    if (!b.d) continue;                                 // this plane's host bytes are current
+    await(b);                                           // behind the work of whichever thread touched it last
     g_d2h += n;
-    if (lgpu_download(l.pd[p], d, n, nullptr) != LGPU_OK) return LGPU_E_HIP;
+    if (lgpu_download(l.pd[p], b.d, n, S()) != LGPU_OK) return LGPU_E_HIP;
   }
-  return sync() ? LGPU_OK : LGPU_E_HIP;
+  if (!sync()) return LGPU_E_HIP;
+  settle(l);
+  return LGPU_OK;
 }
 }  // extern "C"
 namespace {
@@ -1101,10 +1222,21 @@ void lives_gpu_pinned_free(void *p) { res_drop(p); lgpu_pinned_free(p); }
 // and unpin / forget / the release of the plane through this library (free_planes, lives_gpu_pinned_free).
 void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
   if (!host_plane) return nullptr;
-  std::lock_guard<std::mutex> lk(g_res_mu);
-  auto it = g_res.find(host_plane);
-  if (it == g_res.end() || it->second.bytes < min_bytes) return nullptr;
-  return it->second.d;
+  Dev b;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    auto it = g_res.find(host_plane);
+    if (it == g_res.end() || it->second.bytes < min_bytes) return nullptr;
+    b = it->second;
+    it->second.stream = nullptr;
+  }
+  // the caller works on the NULL stream: hand the plane over to it (the null stream waits for the plane's last use; the next seam call on a thread's
+  // stream will in turn wait for the null stream)
+  if (b.stream != nullptr && b.stream != kIdle) {
+    if (!t_event && lgpu_event_create(&t_event) != LGPU_OK) t_event = nullptr;
+    if (!(t_event && lgpu_event_record(t_event, b.stream) == LGPU_OK && lgpu_stream_wait_event(nullptr, t_event) == LGPU_OK)) lgpu_sync(b.stream);
+  }
+  return b.d;
 }
 void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes) {
   if (h2d_bytes) *h2d_bytes = g_h2d.load();

@@ -57,6 +57,12 @@ PROTOTYPES = {
     "lgpu_free": [vp],
     "lgpu_malloc_ordered": [ctypes.POINTER(vp), ctypes.c_size_t, vp],
     "lgpu_free_ordered": [vp, vp],
+    "lgpu_stream_create": [ctypes.POINTER(vp), ctypes.c_int],
+    "lgpu_stream_destroy": [vp],
+    "lgpu_event_create": [ctypes.POINTER(vp)],
+    "lgpu_event_destroy": [vp],
+    "lgpu_event_record": [vp, vp],
+    "lgpu_stream_wait_event": [vp, vp],
     "lgpu_debug_fail_alloc": [ci],
     "lgpu_upload": [vp, vp, ctypes.c_size_t, vp],
     "lgpu_download": [vp, vp, ctypes.c_size_t, vp],

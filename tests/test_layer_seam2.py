@@ -266,3 +266,71 @@ def test_forget_drops_the_device_copy(seam):
     assert L.lives_gpu_gamma_convert_layer(1, lay_alias) == 1 and L.lives_gpu_gamma_convert_layer(1, ref) == 1
     assert L.lives_gpu_layer_forget(lay1) == 0
     assert (wh.planes_of(lay_alias)[0][0] == wh.planes_of(ref)[0][0]).all()
+
+
+def _chain_bytes(L, wh, Y, U, V, w, h):
+    """convert -> gamma -> resize -> letterbox on one thread, unpinned: the reference result for the threaded runs below"""
+    lay = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette(lay, RGBA32, 0) == 1
+    assert L.lives_gpu_gamma_convert_layer(1, lay) == 1
+    assert L.lives_gpu_resize_layer(lay, w // 2, h // 2, 3, 0, 0) == 1
+    assert L.lives_gpu_letterbox_layer(lay, w // 2, h // 2 + 24, w // 2, h // 2, 3, 0, 0) == 1
+    return wh.planes_of(lay)[0][0].copy()
+
+
+def test_host_threads_enqueue_on_their_own_streams(seam):
+    """LiVES runs plan steps on pool threads (src/threading.c; the seam's threading rule): every host thread enqueues on a stream of its own,
+    a resident plane carries an event behind its last use and a call on another thread's stream waits for it.  (1) eight threads, each its own pinned
+    layers through the four-call chain; (2) ONE layer handed from thread to thread between the calls (pin | convert | gamma | resize | letterbox | unpin,
+    six different threads, no synchronisation in between but the hand-over itself).  Same bytes as the single-threaded unpinned chain."""
+    import threading
+    L, wh = seam
+    w, h = 320, 180
+    rng = np.random.default_rng(4242)
+    frames = []
+    for _ in range(8):
+        Y = rng.integers(16, 236, (h, w), dtype=np.uint8)
+        U = rng.integers(16, 241, (h // 2, w // 2), dtype=np.uint8)
+        V = rng.integers(16, 241, (h // 2, w // 2), dtype=np.uint8)
+        frames.append((Y, U, V, _chain_bytes(L, wh, Y, U, V, w, h)))
+    errors = []
+
+    def own_layers(i):
+        try:
+            Y, U, V, want = frames[i]
+            for _ in range(6):
+                lay = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+                assert L.lives_gpu_layer_pin(lay) == 0
+                assert L.lives_gpu_convert_layer_palette(lay, RGBA32, 0) == 1
+                assert L.lives_gpu_gamma_convert_layer(1, lay) == 1
+                assert L.lives_gpu_resize_layer(lay, w // 2, h // 2, 3, 0, 0) == 1
+                assert L.lives_gpu_letterbox_layer(lay, w // 2, h // 2 + 24, w // 2, h // 2, 3, 0, 0) == 1
+                assert L.lives_gpu_layer_unpin(lay) == 0
+                assert (wh.planes_of(lay)[0][0] == want).all(), "thread %d" % i
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=own_layers, args=(i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+    # (2) one layer, a different thread per step
+    def run_on_new_thread(fn):
+        box = []
+        t = threading.Thread(target=lambda: box.append(fn()))
+        t.start()
+        t.join()
+        return box[0]
+
+    for Y, U, V, want in frames[:4]:
+        lay = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+        assert run_on_new_thread(lambda: L.lives_gpu_layer_pin(lay)) == 0
+        assert run_on_new_thread(lambda: L.lives_gpu_convert_layer_palette(lay, RGBA32, 0)) == 1
+        assert run_on_new_thread(lambda: L.lives_gpu_gamma_convert_layer(1, lay)) == 1
+        assert run_on_new_thread(lambda: L.lives_gpu_resize_layer(lay, w // 2, h // 2, 3, 0, 0)) == 1
+        assert run_on_new_thread(lambda: L.lives_gpu_letterbox_layer(lay, w // 2, h // 2 + 24, w // 2, h // 2, 3, 0, 0)) == 1
+        assert run_on_new_thread(lambda: L.lives_gpu_layer_unpin(lay)) == 0
+        assert (wh.planes_of(lay)[0][0] == want).all()
