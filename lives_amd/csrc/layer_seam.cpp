@@ -778,7 +778,7 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer,
     const int ch = plane_h(l, 1);
     const size_t yb = (size_t)l.rs[0] * l.height, ub = (size_t)l.rs[iu] * ch, vb = (size_t)l.rs[iv] * ch;
     const uint8_t *dy = w.in(l.pd[0], yb, 0), *du = w.in(l.pd[iu], ub, 1), *dv = w.in(l.pd[iv], vb, 2);
-    uint8_t *d_out = w.out(np.pd[0], obytes, 3, true);
+    uint8_t *d_out = w.out(np.pd[0], obytes, 3, np.rs[0] != l.width * pal_psize(outpl));     // the kernel writes every byte of every pixel: only row padding needs the zeros
     const int strides[3] = {l.rs[0], l.rs[iu], l.rs[iv]};
     const int which = (iclamping == WEED_YUV_CLAMPING_UNCLAMPED ? 1 : 0) | (l.subspace == WEED_YUV_SUBSPACE_BT709 ? 2 : 0);
     const int order = pal_alpha_first(outpl) ? 2 : pal_red_first(outpl) ? 0 : 1;
@@ -909,7 +909,7 @@ static bool resize_into(const Layer &l, int width, int height, int interp, int a
     const int ps = pal_is_planar_yuv(l.pal) ? 1 : pal_psize(l.pal);
     const int sw = plane_w(l, p), sh = plane_h(l, p), dw = plane_w(nl, p), dh = plane_h(nl, p);
     const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
-    uint8_t *d_out = w.out(np->pd[p], (size_t)np->rs[p] * dh, 3 + p, true);
+    uint8_t *d_out = w.out(np->pd[p], (size_t)np->rs[p] * dh, 3 + p, np->rs[p] != dw * ps);          // zeros for the row padding only
     ok = w.ok && lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, lut8, S()) == LGPU_OK;
   }
   ok = ok && w.finish();
@@ -1000,7 +1000,7 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
     else if (pal_alpha_last(l.pal)) black[3] = 255;
     const int sw = plane_w(l, p), sh = plane_h(l, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
     const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
-    uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, true);     // the canvas keeps its zeroed row padding
+    uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, np.rs[p] != cw * ps);     // the canvas keeps its zeroed row padding (the kernel paints every pixel)
     ok = w.ok && lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, S()) == LGPU_OK;
   }
   ok = ok && w.finish();
