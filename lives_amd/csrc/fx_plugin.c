@@ -152,8 +152,9 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
     }
     if (!f.inplace && !res_dst && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
     if (kernel(&f, inst, kind) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
-    if (!res_dst && lgpu_download(f.dst, f.ddst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;
-    if (lgpu_sync(NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    /* an out channel on a pinned layer: the effect is enqueued and the call returns (stream order carries it to whatever reads the plane next; the host
+       bytes are stale by the pinning contract).  Otherwise the result is brought home and has to be complete on return. */
+    if (!res_dst && (lgpu_download(f.dst, f.ddst, ob, NULL) || lgpu_sync(NULL))) return WEED_ERROR_PLUGIN_INVALID;
   }
   return WEED_SUCCESS;
 }
@@ -356,9 +357,13 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
     fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error());
     return WEED_ERROR_PLUGIN_INVALID;
   }
-  for (i = 0; i < nplanes; i++)
-    if (!rdst[i] && lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
-  return lgpu_sync(NULL) ? WEED_ERROR_PLUGIN_INVALID : WEED_SUCCESS;
+  {
+    int home = 0;
+    for (i = 0; i < nplanes; i++)
+      if (!rdst[i]) { home = 1; if (lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID; }
+    if (home && lgpu_sync(NULL)) return WEED_ERROR_PLUGIN_INVALID;           /* planes of a pinned layer: enqueued, not waited for (see fx_run) */
+  }
+  return WEED_SUCCESS;
 }
 
 /* "blurzoom" (blurzoom.c:345-421): stateful -- the device handle lives in plugin_internal and is rebuilt when the frame
