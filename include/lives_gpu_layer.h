@@ -120,6 +120,16 @@ void lives_gpu_pinned_free(void *p);
 /* device copy of a pinned layer's plane by its host plane pointer, or NULL (used by livesgpu_fx.so: effects on pinned layers read and write
    HBM directly, no PCIe traffic; the host bytes stay stale until lives_gpu_layer_sync()) */
 void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes);
+/* The same for code that enqueues on the calling thread's stream instead of the null stream (every host thread that enters the seam has a stream of its
+   own; livesgpu_fx.so runs its effects there, so effects of different tracks overlap on the device like the seam's own calls):
+   acquire = the device copy, with the calling thread's stream ordered behind the plane's last writer (write != 0: and behind every reader since);
+   release = tell the table that a read / a write of the plane has been enqueued on that stream.  Between the two the caller enqueues its work on
+   lives_gpu_thread_stream().  lives_gpu_stream_follow(s) orders the calling thread's stream behind everything enqueued so far on s (NULL = the null
+   stream): for state a caller keeps on the device across calls that may arrive on different threads. */
+void *lives_gpu_thread_stream(void);
+void lives_gpu_stream_follow(void *other_stream);
+void *lives_gpu_resident_acquire(const void *host_plane, size_t min_bytes, int write);
+void lives_gpu_resident_release(const void *host_plane, int write);
 void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes);   /* PCIe bytes moved by the seam so far */
 
 #ifdef LIVES_GPU_DROP_IN

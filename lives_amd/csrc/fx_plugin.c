@@ -53,8 +53,21 @@ static int psize_of(int pal) {
 }
 
 /* ---- per-instance device buffers ("plugin_internal", like simple_blend.c:36-45) ---- */
-typedef struct { void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; lgpu_rgbdelay *rd; float *mask_d; int mask_w, mask_h; int64_t mask_seed; } fxdata_t;
+typedef struct { void *last_stream; int has_stream; void *d[3]; size_t cap[3]; lgpu_blurzoom *bz; int bz_w, bz_h, bz_pal; int slide_dir; lgpu_rgbdelay *rd; float *mask_d; int mask_w, mask_h; int64_t mask_seed; } fxdata_t;
 
+/* The effects are enqueued on the CALLING THREAD's stream (lives_gpu_thread_stream: the one the layer seam uses for this host thread; NULL -- the null stream --
+   when the host has not bound the layer seam), so effects of different tracks, applied by different pool threads, overlap on the device.  An instance keeps
+   device state across calls (staging buffers, the blurzoom / RGBdelay rings): when a call arrives on another thread than the previous one, this thread's stream
+   first waits for everything the previous one enqueued. */
+static __thread void *fx_stream_;
+#define FXS fx_stream_
+static fxdata_t *fx_data(weed_plant_t *inst);
+static void fx_enter(fxdata_t *fx) {
+  FXS = lives_gpu_thread_stream();
+  if (!fx) return;
+  if (fx->has_stream && fx->last_stream != FXS) lives_gpu_stream_follow(fx->last_stream);
+  fx->last_stream = FXS; fx->has_stream = 1;
+}
 static fxdata_t *fx_data(weed_plant_t *inst) {
   fxdata_t *fx = (fxdata_t *)g_ptr(inst, "plugin_internal", 0);
   if (!fx) {
@@ -108,6 +121,7 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
   fxframe_t f;
   int offset = 0, real_h, slice_h, i;
   if (!fx || !ochan) return WEED_ERROR_FILTER_INVALID;
+  fx_enter(fx);
   memset(&f, 0, sizeof f);
   f.nin = nin;
   f.pal = g_int(ochan, WEED_LEAF_CURRENT_PALETTE, 0, 0);
@@ -136,25 +150,31 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
   {
     /* the ARGB chroma blend reads one byte past the last pixel of each row of layer 2 (reference quirk B1) */
     const size_t ob = (size_t)f.orow * f.height;
-    uint8_t *res_dst = (uint8_t *)lives_gpu_resident_lookup(f.dst - (size_t)offset * f.orow, (size_t)f.orow * real_h);
+    const void *rel[3] = {NULL, NULL, NULL};         /* resident planes to release once the effect is enqueued: [0] the out channel (write), [1..] in channels (read) */
+    uint8_t *res_dst = (uint8_t *)lives_gpu_resident_acquire(f.dst - (size_t)offset * f.orow, (size_t)f.orow * real_h, 1);
+    if (res_dst) rel[0] = f.dst - (size_t)offset * f.orow;
     if (res_dst) f.ddst = res_dst + (size_t)offset * f.orow;
     else f.ddst = (uint8_t *)fx_buf(fx, 2, ob + 16);
     if (!f.ddst) return WEED_ERROR_MEMORY_ALLOCATION;
     for (i = 0; i < nin; i++) {
       const size_t ib = (size_t)f.irow[i] * f.height;
       uint8_t *res_src;
-      if (i == 0 && f.inplace) { f.dsrc[0] = f.ddst; if (!res_dst && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID; continue; }
-      res_src = (uint8_t *)lives_gpu_resident_lookup(f.src[i] - (size_t)offset * f.irow[i], (size_t)f.irow[i] * real_h);
-      if (res_src) { f.dsrc[i] = res_src + (size_t)offset * f.irow[i]; continue; }
+      if (i == 0 && f.inplace) { f.dsrc[0] = f.ddst; if (!res_dst && lgpu_upload(f.ddst, f.dst, ob, FXS)) return WEED_ERROR_PLUGIN_INVALID; continue; }
+      res_src = (uint8_t *)lives_gpu_resident_acquire(f.src[i] - (size_t)offset * f.irow[i], (size_t)f.irow[i] * real_h, 0);
+      if (res_src) { rel[1 + i] = f.src[i] - (size_t)offset * f.irow[i]; f.dsrc[i] = res_src + (size_t)offset * f.irow[i]; continue; }
       f.dsrc[i] = (uint8_t *)fx_buf(fx, i, ib + 16);
       if (!f.dsrc[i]) return WEED_ERROR_MEMORY_ALLOCATION;
-      if (lgpu_upload(f.dsrc[i], f.src[i], ib, NULL)) return WEED_ERROR_PLUGIN_INVALID;
+      if (lgpu_upload(f.dsrc[i], f.src[i], ib, FXS)) return WEED_ERROR_PLUGIN_INVALID;
     }
-    if (!f.inplace && !res_dst && lgpu_upload(f.ddst, f.dst, ob, NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
-    if (kernel(&f, inst, kind) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+    if (!f.inplace && !res_dst && lgpu_upload(f.ddst, f.dst, ob, FXS)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
+    {
+      const int krc = kernel(&f, inst, kind);
+      lives_gpu_resident_release(rel[0], 1); lives_gpu_resident_release(rel[1], 0); lives_gpu_resident_release(rel[2], 0);
+      if (krc != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+    }
     /* an out channel on a pinned layer: the effect is enqueued and the call returns (stream order carries it to whatever reads the plane next; the host
        bytes are stale by the pinning contract).  Otherwise the result is brought home and has to be complete on return. */
-    if (!res_dst && (lgpu_download(f.dst, f.ddst, ob, NULL) || lgpu_sync(NULL))) return WEED_ERROR_PLUGIN_INVALID;
+    if (!res_dst && (lgpu_download(f.dst, f.ddst, ob, FXS) || lgpu_sync(FXS))) return WEED_ERROR_PLUGIN_INVALID;
   }
   return WEED_SUCCESS;
 }
@@ -169,14 +189,14 @@ static int k_simple(const fxframe_t *f, weed_plant_t *inst, int kind) {
   const int v = param_int(inst, 0, 128);
   const int af = (f->pal == WEED_PALETTE_ARGB32);
   if (kind == 0)
-    return lgpu_blend_chroma(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize, af, v, NULL);
+    return lgpu_blend_chroma(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize, af, v, FXS);
   if (af) return LGPU_E_UNSUPPORTED;
   return lgpu_blend_luma(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
-                         (f->pal == WEED_PALETTE_BGR24 || f->pal == WEED_PALETTE_BGRA32) ? 1 : 0, v, NULL);
+                         (f->pal == WEED_PALETTE_BGR24 || f->pal == WEED_PALETTE_BGRA32) ? 1 : 0, v, FXS);
 }
 static int k_multi(const fxframe_t *f, weed_plant_t *inst, int kind) {
   return lgpu_blend_multi(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height,
-                          f->pal == WEED_PALETTE_BGR24, param_int(inst, 0, 128), NULL);
+                          f->pal == WEED_PALETTE_BGR24, param_int(inst, 0, 128), FXS);
 }
 static int k_ckey(const fxframe_t *f, weed_plant_t *inst, int kind) {
   weed_plant_t *pd = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 0), *po = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 1),
@@ -185,12 +205,12 @@ static int k_ckey(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (!pd || !po || !pc) return LGPU_E_BADARG;
   return lgpu_colorkey(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->pal == WEED_PALETTE_BGR24,
                        g_dbl(pd, WEED_LEAF_VALUE, .2), g_dbl(po, WEED_LEAF_VALUE, 1.), g_int(pc, WEED_LEAF_VALUE, 0, 0),
-                       g_int(pc, WEED_LEAF_VALUE, 1, 0), g_int(pc, WEED_LEAF_VALUE, 2, 255), NULL);
+                       g_int(pc, WEED_LEAF_VALUE, 1, 0), g_int(pc, WEED_LEAF_VALUE, 2, 255), FXS);
 }
 static int k_transition(const fxframe_t *f, weed_plant_t *inst, int kind) {
   weed_plant_t *pa = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, 0);
   return lgpu_transition(kind, f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
-                         pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., NULL);
+                         pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., FXS);
 }
 /* "slide over" (slide_over.c:40-51, :83-86): direction from the radio parameters 1..5; "random" is drawn once per instance */
 static int param_bool(weed_plant_t *inst, int idx, int dflt) {
@@ -215,11 +235,11 @@ static int k_slide(const fxframe_t *f, weed_plant_t *inst, int kind) {
     dirn = param_bool(inst, 2, 0) ? 1 : param_bool(inst, 3, 0) ? 2 : param_bool(inst, 4, 0) ? 3 : 4;
   }
   return lgpu_slide_over(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize,
-                         param_int(inst, 0, 0), dirn, param_bool(inst, 6, WEED_TRUE), param_bool(inst, 7, WEED_FALSE), NULL);
+                         param_int(inst, 0, 0), dirn, param_bool(inst, 6, WEED_TRUE), param_bool(inst, 7, WEED_FALSE), FXS);
 }
 static int k_deint(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst; (void)kind;
-  return lgpu_deinterlace(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, NULL);
+  return lgpu_deinterlace(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, FXS);
 }
 /* "RGBdelay" / "YUVdelay" (RGBdelay.c:135-416): stateful, the frame ring lives in the device handle kept in plugin_internal */
 static double param_dbl(weed_plant_t *inst, int idx, double dflt) {
@@ -239,7 +259,7 @@ static int k_rgbdelay(const fxframe_t *f, weed_plant_t *inst, int kind) {
     strength[j] = param_dbl(inst, 4 * j + 4, 1.);
   }
   if (f->pal == WEED_PALETTE_YUV888 && ic) clamped = g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED) == WEED_YUV_CLAMPING_CLAMPED;
-  return lgpu_rgbdelay_process(fx->rd, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, clamped, param_int(inst, 0, 20), on, strength, NULL);
+  return lgpu_rgbdelay_process(fx->rd, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, clamped, param_int(inst, 0, 20), on, strength, FXS);
 }
 /* negate / posterise / ccorrect (scripts of those names): per-byte-position tables built on the host, one gather launch */
 static int k_scriptfx(const fxframe_t *f, weed_plant_t *inst, int kind) {
@@ -248,7 +268,7 @@ static int k_scriptfx(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (kind == 1) p0 = (double)param_int(inst, 0, 1);
   else if (kind == 2) { p0 = param_dbl(inst, 0, 1.); p1 = param_dbl(inst, 1, 1.); p2 = param_dbl(inst, 2, 1.); }
   if (lgpu_fx_luts(kind, f->pal, p0, p1, p2, luts) != f->psize) return LGPU_E_UNSUPPORTED;
-  return lgpu_byte_luts(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, luts, NULL);
+  return lgpu_byte_luts(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, luts, FXS);
 }
 /* "triple split" (layout_blends.c:24-113) */
 static int k_tsplit(const fxframe_t *f, weed_plant_t *inst, int kind) {
@@ -258,7 +278,7 @@ static int k_tsplit(const fxframe_t *f, weed_plant_t *inst, int kind) {
   if (pc) { bc[0] = g_int(pc, WEED_LEAF_VALUE, 0, 0); bc[1] = g_int(pc, WEED_LEAF_VALUE, 1, 0); bc[2] = g_int(pc, WEED_LEAF_VALUE, 2, 0); }
   return lgpu_triple_split(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->pal == WEED_PALETTE_BGR24,
                            param_dbl(inst, 0, 0.666667), param_bool(inst, 1, WEED_TRUE), param_dbl(inst, 3, 0.333333), param_bool(inst, 4, WEED_FALSE),
-                           param_dbl(inst, 5, 0.), bc, NULL);
+                           param_dbl(inst, 5, 0.), bc, FXS);
 }
 /* "dissolve" (multi_transitions.c:41-69, :208-212): the mask is drawn once per instance (and geometry) from the instance's "random_seed" leaf,
    as dissolve_init does, and kept in device memory */
@@ -276,13 +296,13 @@ static int k_dissolve(const fxframe_t *f, weed_plant_t *inst, int kind) {
     if (!m) return LGPU_E_NOMEM;
     if (fx->mask_d) { lgpu_free(fx->mask_d); fx->mask_d = NULL; }
     ok = lgpu_dissolve_mask((uint64_t)seed, f->width, f->height, m) == 1 && lgpu_malloc((void **)&fx->mask_d, n * sizeof(float)) == LGPU_OK &&
-         lgpu_upload(fx->mask_d, m, n * sizeof(float), NULL) == LGPU_OK && lgpu_sync(NULL) == LGPU_OK;
+         lgpu_upload(fx->mask_d, m, n * sizeof(float), FXS) == LGPU_OK && lgpu_sync(FXS) == LGPU_OK;
     w_free(m);
     if (!ok) return LGPU_E_NOMEM;
     fx->mask_w = f->width; fx->mask_h = f->height; fx->mask_seed = seed;
   }
   return lgpu_dissolve(f->dsrc[0], f->irow[0], f->dsrc[1], f->irow[1], f->ddst, f->orow, f->width, f->height, f->psize, fx->mask_d,
-                       pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., NULL);
+                       pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0., FXS);
 }
 /* "rand replace" (multi_transitions.c:96-112, :213-220): per frame ONE draw of a uniform number decides whether the whole frame is the second input
    (draw < amount) or the first; in place and "first" means nothing to do.  The reference draws from libweed's time-seeded global generator
@@ -299,16 +319,16 @@ static int k_rreplace(const fxframe_t *f, weed_plant_t *inst, int kind) {
   const int cpy0 = rr_draw() < bfd;
   (void)kind;
   if (f->inplace && !cpy0) return LGPU_OK;
-  return lgpu_copy_rows(f->ddst, f->orow, cpy0 ? f->dsrc[1] : f->dsrc[0], cpy0 ? f->irow[1] : f->irow[0], f->width * f->psize, f->height, NULL);
+  return lgpu_copy_rows(f->ddst, f->orow, cpy0 ? f->dsrc[1] : f->dsrc[0], cpy0 ? f->irow[1] : f->irow[0], f->width * f->psize, f->height, FXS);
 }
 static int k_mirror(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)inst;
-  return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, NULL);
+  return lgpu_mirror(kind, f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->psize, FXS);
 }
 
 static int k_edge(const fxframe_t *f, weed_plant_t *inst, int kind) {
   (void)kind;
-  return lgpu_edge(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, param_int(inst, 0, 0), NULL);
+  return lgpu_edge(f->dsrc[0], f->irow[0], f->ddst, f->orow, f->width, f->height, f->pal, param_int(inst, 0, 0), FXS);
 }
 
 /* "softlight" (softlight.c:62-151): planar YUV in, planar YUV out, not in place; whole frame only */
@@ -317,10 +337,12 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
   weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, 0), *oc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0);
   const uint8_t *dsrc[4] = {0, 0, 0, 0};
   uint8_t *ddst[4] = {0, 0, 0, 0}, *rdst[4] = {0, 0, 0, 0}, *hdst[4], *base;
+  int rsrc[4] = {0, 0, 0, 0};
   int irow[4], orow[4], ph[4], i, nplanes, pal, w, h, clamping;
   size_t ioff[4], ooff[4], itot = 0, otot = 0;
   (void)tc;
   if (!fx || !ic || !oc) return WEED_ERROR_FILTER_INVALID;
+  fx_enter(fx);
   pal = g_int(ic, WEED_LEAF_CURRENT_PALETTE, 0, 0);
   w = g_int(ic, WEED_LEAF_WIDTH, 0, 0); h = g_int(ic, WEED_LEAF_HEIGHT, 0, 0);
   clamping = g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED);
@@ -340,28 +362,35 @@ static weed_error_t p_softlight(weed_plant_t *inst, weed_timecode_t tc) {
   if (!base) return WEED_ERROR_MEMORY_ALLOCATION;
   for (i = 0; i < nplanes; i++) {                       /* planes of a pinned layer are used where they live in HBM (see fx_run) */
     const void *hp = g_ptr(ic, WEED_LEAF_PIXEL_DATA, i);
-    const uint8_t *res = (const uint8_t *)lives_gpu_resident_lookup(hp, (size_t)irow[i] * ph[i]);
-    if (res) { dsrc[i] = res; continue; }
+    const uint8_t *res = (const uint8_t *)lives_gpu_resident_acquire(hp, (size_t)irow[i] * ph[i], 0);
+    if (res) { dsrc[i] = res; rsrc[i] = 1; continue; }
     dsrc[i] = base + ioff[i];
-    if (lgpu_upload(base + ioff[i], hp, (size_t)irow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;
+    if (lgpu_upload(base + ioff[i], hp, (size_t)irow[i] * ph[i], FXS)) return WEED_ERROR_PLUGIN_INVALID;
   }
   base = (uint8_t *)fx_buf(fx, 2, otot);
   if (!base) return WEED_ERROR_MEMORY_ALLOCATION;
   for (i = 0; i < nplanes; i++) {
-    rdst[i] = (uint8_t *)lives_gpu_resident_lookup(hdst[i], (size_t)orow[i] * ph[i]);
+    rdst[i] = (uint8_t *)lives_gpu_resident_acquire(hdst[i], (size_t)orow[i] * ph[i], 1);
     if (rdst[i]) { ddst[i] = rdst[i]; continue; }
     ddst[i] = base + ooff[i];
-    if (lgpu_upload(ddst[i], hdst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID;   /* row padding stays as it was */
+    if (lgpu_upload(ddst[i], hdst[i], (size_t)orow[i] * ph[i], FXS)) return WEED_ERROR_PLUGIN_INVALID;   /* row padding stays as it was */
   }
-  if (lgpu_softlight(dsrc, irow, ddst, orow, w, h, pal, clamping == WEED_YUV_CLAMPING_UNCLAMPED, NULL) != LGPU_OK) {
-    fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error());
-    return WEED_ERROR_PLUGIN_INVALID;
+  {
+    const int krc = lgpu_softlight(dsrc, irow, ddst, orow, w, h, pal, clamping == WEED_YUV_CLAMPING_UNCLAMPED, FXS);
+    for (i = 0; i < nplanes; i++) {                       /* the planes of pinned layers: a read / a write has been enqueued on this thread's stream */
+      if (rsrc[i]) lives_gpu_resident_release(g_ptr(ic, WEED_LEAF_PIXEL_DATA, i), 0);
+      if (rdst[i]) lives_gpu_resident_release(hdst[i], 1);
+    }
+    if (krc != LGPU_OK) {
+      fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error());
+      return WEED_ERROR_PLUGIN_INVALID;
+    }
   }
   {
     int home = 0;
     for (i = 0; i < nplanes; i++)
-      if (!rdst[i]) { home = 1; if (lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], NULL)) return WEED_ERROR_PLUGIN_INVALID; }
-    if (home && lgpu_sync(NULL)) return WEED_ERROR_PLUGIN_INVALID;           /* planes of a pinned layer: enqueued, not waited for (see fx_run) */
+      if (!rdst[i]) { home = 1; if (lgpu_download(hdst[i], ddst[i], (size_t)orow[i] * ph[i], FXS)) return WEED_ERROR_PLUGIN_INVALID; }
+    if (home && lgpu_sync(FXS)) return WEED_ERROR_PLUGIN_INVALID;           /* planes of a pinned layer: enqueued, not waited for (see fx_run) */
   }
   return WEED_SUCCESS;
 }
@@ -380,7 +409,7 @@ static int k_blurzoom(const fxframe_t *f, weed_plant_t *inst, int kind) {
     if (lgpu_blurzoom_create(f->width, f->height, f->pal, &fx->bz) != LGPU_OK) return LGPU_E_BADARG;
     fx->bz_w = f->width; fx->bz_h = f->height; fx->bz_pal = f->pal;
   }
-  return lgpu_blurzoom_process(fx->bz, f->dsrc[0], f->irow[0], f->ddst, f->orow, param_int(inst, 0, 0), param_int(inst, 1, 0), NULL);
+  return lgpu_blurzoom_process(fx->bz, f->dsrc[0], f->irow[0], f->ddst, f->orow, param_int(inst, 0, 0), param_int(inst, 1, 0), FXS);
 }
 
 #define PROC(name, nin, kind, kern, whole) static weed_error_t name(weed_plant_t *inst, weed_timecode_t tc) { (void)tc; return fx_run(inst, nin, kind, kern, whole); }

@@ -128,7 +128,9 @@ void *S() {
 // stream orders itself behind the previous owner by recording an event on that stream at the moment of the hand-over (everything enqueued there
 // so far, which includes the buffer's last use) and waiting for it -- nothing is recorded while a layer stays on one thread (an event per plane and
 // call measured 4 - 8 us each on these streams: 9 -> 17 us per seam call).
-struct Dev { void *d = nullptr; size_t bytes = 0; void *stream = nullptr; };
+// `stream` is where the last WRITE (or exclusive use) was enqueued; `rs` are other streams that have enqueued READS since (two effect instances on two pool
+// threads may read one layer at the same time): a reader waits for the writer only, a writer for the writer and all readers.
+struct Dev { void *d = nullptr; size_t bytes = 0; void *stream = nullptr; void *rs[4] = {nullptr, nullptr, nullptr, nullptr}; int nr = 0; };
 static char g_idle_tag;
 void *const kIdle = &g_idle_tag;                  // Dev::stream of a buffer whose last use is known to be complete (the stream was synchronised since)
 // The table lock: a dozen sub-microsecond critical sections per seam call.  A futex mutex here made sixteen host threads run slower than one (every
@@ -151,11 +153,25 @@ thread_local void *t_event = nullptr;           // this thread's hand-over event
 
 // No HIP call is made under g_res_mu: the functions below copy what they need out of the tables and do the stream work afterwards.
 // The calling thread's stream waits for everything enqueued so far on the stream of the buffer's last use, if that is another stream.
-void await(const Dev &b) {
-  if (!b.d || b.stream == S() || b.stream == kIdle) return;
+void follow(void *other) {                        // other: a stream (nullptr = the null stream) or kIdle
+  if (other == S() || other == kIdle) return;
   if (!t_event && lgpu_event_create(&t_event) != LGPU_OK) t_event = nullptr;
-  if (t_event && lgpu_event_record(t_event, b.stream) == LGPU_OK && lgpu_stream_wait_event(S(), t_event) == LGPU_OK) return;
-  lgpu_sync(b.stream);                            // no event to be had: wait for that stream on the host instead
+  if (t_event && lgpu_event_record(t_event, other) == LGPU_OK && lgpu_stream_wait_event(S(), t_event) == LGPU_OK) return;
+  lgpu_sync(other);                               // no event to be had: wait for that stream on the host instead
+}
+void await(const Dev &b, bool write = true) {
+  if (!b.d) return;
+  follow(b.stream);
+  if (write) for (int i = 0; i < b.nr; i++) follow(b.rs[i]);
+}
+// (g_res_mu held) the calling thread's stream has enqueued a read / a write of the buffer
+void note_use(Dev &e, bool write) {
+  void *s = S();
+  if (write) { e.stream = s; e.nr = 0; return; }
+  if (e.stream == s) return;
+  for (int i = 0; i < e.nr; i++) if (e.rs[i] == s) return;
+  if (e.nr < 4) e.rs[e.nr++] = s;
+  else e.rs[0] = s;                               // a fifth concurrent reader stream of one plane: not tracked (LiVES copies a layer that fans out)
 }
 
 // Device buffers of resident planes: a pinned layer going through a chain of seam calls takes a new plane per call and drops the old one, and neither
@@ -187,7 +203,7 @@ bool pool_take(size_t n, Dev *out) {
       std::vector<Dev> &v = it->second;
       int best = (int)v.size() - 1;                                // newest first; one whose last use needs no cross-stream wait if there is one near the top
       for (int i = best, k = 0; i >= 0 && k < 8; i--, k++)
-        if (v[i].stream == S() || v[i].stream == kIdle) { best = i; break; }
+        if ((v[i].stream == S() || v[i].stream == kIdle) && v[i].nr == 0) { best = i; break; }
       *out = v[best];
       v[best] = v.back();
       v.pop_back();
@@ -195,7 +211,7 @@ bool pool_take(size_t n, Dev *out) {
       hit = true;
     }
   }
-  if (hit) { await(*out); out->stream = S(); return true; }
+  if (hit) { await(*out); out->stream = S(); out->nr = 0; return true; }
   Dev b;
   if (lgpu_malloc_ordered(&b.d, cls, S()) != LGPU_OK) return false;
   b.bytes = cls; b.stream = S();
@@ -218,7 +234,7 @@ void pool_give(Dev b) {
 // the resident copy registered under host plane h becomes b (last used on the calling thread's stream); whatever was there goes back to the pool
 void res_put(const void *h, Dev b) {
   Dev old;
-  b.stream = S();
+  b.stream = S(); b.nr = 0;
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     Dev &e = g_res[h];
@@ -333,23 +349,25 @@ bool sync() { return lgpu_sync(S()) == LGPU_OK; }
 // resident device copy of a plane of the layer the call in progress works on (only pinned layers have one: the table is
 // keyed by host pointer, and a host pointer proves nothing about a layer that was never pinned), ready for work on the calling
 // thread's stream.  The caller marks the plane (touch_done) once its work is enqueued.
-uint8_t *resident(const void *h, size_t n) {
-  if (!t_pinned || !h) return nullptr;
+uint8_t *acquire(const void *h, size_t n, bool write) {
   Dev b;
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     auto it = g_res.find(h);
     if (it == g_res.end() || it->second.bytes < n) return nullptr;
     b = it->second;
-    it->second.stream = S();                     // this thread's stream is where its next use is enqueued (behind the wait below)
   }
-  await(b);
+  await(b, write);
   return (uint8_t *)b.d;
 }
-void touch_done(const void *h) {
+uint8_t *resident(const void *h, size_t n, bool write) {
+  if (!t_pinned || !h) return nullptr;
+  return acquire(h, n, write);
+}
+void touch_done(const void *h, bool write) {
   std::lock_guard<SpinLock> lk(g_res_mu);
   auto it = g_res.find(h);
-  if (it != g_res.end()) it->second.stream = S();
+  if (it != g_res.end()) note_use(it->second, write);
 }
 
 // One seam call's device-side work, enqueued on the calling thread's stream.  in(): the current bytes of an existing plane.  out(): a plane
@@ -361,17 +379,18 @@ struct Work {
   struct Out { uint8_t *host; Dev b; size_t n; bool pooled; };
   Out outs[8];
   const void *touched[12];
+  bool twrite[12];
   int nout = 0, ntouched = 0;
   bool ok = true, done = false;
-  uint8_t *use(const void *h, size_t n) {
-    uint8_t *r = resident(h, n);
-    if (r && ntouched < 12) touched[ntouched++] = h;
-    else if (r) { touch_done(h); }                            // cannot happen with <= 4 planes in and out; marked early rather than lost
+  uint8_t *use(const void *h, size_t n, bool write) {
+    uint8_t *r = resident(h, n, write);
+    if (r && ntouched < 12) { touched[ntouched] = h; twrite[ntouched++] = write; }
+    else if (r) { touch_done(h, true); }                      // cannot happen with <= 4 planes in and out; marked early (as a write) rather than lost
     return r;
   }
   const uint8_t *in(const uint8_t *h, size_t n, int slot) {
     if (!ok) return nullptr;
-    if (uint8_t *r = use(h, n)) return r;
+    if (uint8_t *r = use(h, n, false)) return r;
     uint8_t *d = t_scr.get(slot, n);
     g_h2d += n;
     ok = d && lgpu_upload(d, h, n, S()) == LGPU_OK;
@@ -392,13 +411,13 @@ struct Work {
   }
   uint8_t *inout(uint8_t *h, size_t n, int slot) {
     if (!ok || nout >= 8) { ok = false; return nullptr; }
-    if (uint8_t *r = use(h, n)) return r;                    // modified where it lives
+    if (uint8_t *r = use(h, n, true)) return r;              // modified where it lives
     uint8_t *d = const_cast<uint8_t *>(in(h, n, slot));
     if (d) { Out o; o.host = h; o.b.d = d; o.n = n; o.pooled = false; outs[nout++] = o; }
     return d;
   }
   void mark_touched() {
-    for (int i = 0; i < ntouched; i++) touch_done(touched[i]);
+    for (int i = 0; i < ntouched; i++) touch_done(touched[i], twrite[i]);
     ntouched = 0;
   }
   bool finish() {
@@ -424,7 +443,7 @@ struct Work {
     if (done) return;
     mark_touched();
     for (int i = 0; i < nout; i++)
-      if (outs[i].pooled && outs[i].b.d) { outs[i].b.stream = S(); pool_give(outs[i].b); }
+      if (outs[i].pooled && outs[i].b.d) { outs[i].b.stream = S(); outs[i].b.nr = 0; pool_give(outs[i].b); }
   }
 };
 
@@ -1117,10 +1136,10 @@ lives_gpu_boolean lives_gpu_weed_layer_clear_pixel_data(lives_gpu_layer_t *layer
     uint8_t one[1] = {(uint8_t)(p == 0 ? yb : p == 3 ? 255 : 128)};
     const uint8_t *pp = plen ? pat : one;
     const int pl = plen ? plen : 1, n = plen ? nmp : pw;
-    uint8_t *d = on_device ? resident(l.pd[p], (size_t)l.rs[p] * ph) : nullptr;
+    uint8_t *d = on_device ? resident(l.pd[p], (size_t)l.rs[p] * ph, true) : nullptr;
     if (d) {
       const int rc = lgpu_fill_pattern(d, l.rs[p], pp, pl, n, ph, S());
-      touch_done(l.pd[p]);
+      touch_done(l.pd[p], true);
       if (rc != LGPU_OK) return 0;
       continue;
     }
@@ -1144,7 +1163,12 @@ static void settle(const Layer &l) {
   std::lock_guard<SpinLock> lk(g_res_mu);
   for (int p = 0; p < l.nplanes; p++) {
     auto it = g_res.find(l.pd[p]);
-    if (it != g_res.end() && it->second.stream == S()) it->second.stream = kIdle;
+    if (it == g_res.end()) continue;
+    Dev &e = it->second;
+    if (e.stream == S()) e.stream = kIdle;
+    int k = 0;
+    for (int i = 0; i < e.nr; i++) if (e.rs[i] != S()) e.rs[k++] = e.rs[i];
+    e.nr = k;
   }
 }
 int lives_gpu_layer_pin(lives_gpu_layer_t *layer) {
@@ -1178,10 +1202,10 @@ int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
     {
       std::lock_guard<SpinLock> lk(g_res_mu);
       auto it = g_res.find(l.pd[p]);
-      if (it != g_res.end() && it->second.bytes >= n) { b = it->second; it->second.stream = S(); }
+      if (it != g_res.end() && it->second.bytes >= n) { b = it->second; note_use(it->second, false); }
     }
     if (!b.d) continue;                                 // this plane's host bytes are current
-    await(b);                                           // behind the work of whichever thread touched it last
+    await(b, false);                                    // behind the work of whichever thread wrote it last
     g_d2h += n;
     if (lgpu_download(l.pd[p], b.d, n, S()) != LGPU_OK) return LGPU_E_HIP;
   }
@@ -1228,15 +1252,28 @@ void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
     auto it = g_res.find(host_plane);
     if (it == g_res.end() || it->second.bytes < min_bytes) return nullptr;
     b = it->second;
-    it->second.stream = nullptr;
+    it->second.stream = nullptr; it->second.nr = 0;
   }
-  // the caller works on the NULL stream: hand the plane over to it (the null stream waits for the plane's last use; the next seam call on a thread's
-  // stream will in turn wait for the null stream)
-  if (b.stream != nullptr && b.stream != kIdle) {
+  // the caller works on the NULL stream: hand the plane over to it (the null stream waits for the plane's writer and readers; the next seam call on a
+  // thread's stream will in turn wait for the null stream)
+  void *users[5] = {b.stream, b.rs[0], b.rs[1], b.rs[2], b.rs[3]};
+  for (int i = 0; i < 1 + b.nr; i++) {
+    if (users[i] == nullptr || users[i] == kIdle) continue;
     if (!t_event && lgpu_event_create(&t_event) != LGPU_OK) t_event = nullptr;
-    if (!(t_event && lgpu_event_record(t_event, b.stream) == LGPU_OK && lgpu_stream_wait_event(nullptr, t_event) == LGPU_OK)) lgpu_sync(b.stream);
+    if (!(t_event && lgpu_event_record(t_event, users[i]) == LGPU_OK && lgpu_stream_wait_event(nullptr, t_event) == LGPU_OK)) lgpu_sync(users[i]);
   }
   return b.d;
+}
+// The same for callers that enqueue on the CALLING THREAD's stream (lives_gpu_thread_stream; what livesgpu_fx.so does): acquire orders that stream behind the
+// plane's writer (and, for a write, its readers), release records the use once the caller's work is enqueued.
+void *lives_gpu_thread_stream(void) { return ready() ? S() : nullptr; }
+void lives_gpu_stream_follow(void *other) { if (ready()) follow(other); }
+void *lives_gpu_resident_acquire(const void *host_plane, size_t min_bytes, int write) {
+  if (!host_plane || !ready()) return nullptr;
+  return acquire(host_plane, min_bytes, write != 0);
+}
+void lives_gpu_resident_release(const void *host_plane, int write) {
+  if (host_plane) touch_done(host_plane, write != 0);
 }
 void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long *d2h_bytes) {
   if (h2d_bytes) *h2d_bytes = g_h2d.load();

@@ -334,3 +334,67 @@ def test_host_threads_enqueue_on_their_own_streams(seam):
         assert run_on_new_thread(lambda: L.lives_gpu_letterbox_layer(lay, w // 2, h // 2 + 24, w // 2, h // 2, 3, 0, 0)) == 1
         assert run_on_new_thread(lambda: L.lives_gpu_layer_unpin(lay)) == 0
         assert (wh.planes_of(lay)[0][0] == want).all()
+
+
+def test_effects_and_seam_calls_from_several_threads(seam):
+    """both seams from pool threads: livesgpu_fx.so enqueues its effects on the calling thread's stream as well (lives_gpu_resident_acquire / _release),
+    so a plan step = seam call -> effect -> effect -> seam call stays on one stream, and the same layer handed to another thread between the steps is
+    ordered by the hand-over events.  Result bytes against the same steps run on the main thread."""
+    import os
+    import threading
+    L, wh = seam
+    OURS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lives_amd", "livesgpu_fx.so")
+    w, h = 192, 96
+    rng = np.random.default_rng(77)
+
+    def view(layer):
+        _, ptrs, rs = wh.planes_of(layer)
+        hh = wh.geti(layer, "height")
+        return np.frombuffer((ctypes.c_uint8 * (rs[0] * hh)).from_address(ptrs[0]), np.uint8).reshape(hh, rs[0])
+
+    def steps(H, la, lb):
+        yield lambda: L.lives_gpu_layer_pin(la) == 0 and L.lives_gpu_layer_pin(lb) == 0
+        yield lambda: L.lives_gpu_convert_layer_palette(la, RGBA32, 0) == 1
+        yield lambda: H.run(OURS, "chroma blend", RGBA32, w, h, [view(la), view(lb)], view(la), [po.p_int(90)]) is not None     # in place on layer a
+        yield lambda: H.run(OURS, "negate", RGBA32, w, h, [view(la)], view(la), []) is not None
+        yield lambda: L.lives_gpu_gamma_convert_layer(2, la) == 1
+        yield lambda: L.lives_gpu_layer_unpin(la) == 0 and L.lives_gpu_layer_unpin(lb) == 0
+
+    def new_pair(i):
+        r = np.random.default_rng(1000 + i)
+        return wh.new_layer(RGB24, w, h, [frame(r, w, h, 3)], gamma=1), wh.new_layer(RGBA32, w, h, [frame(r, w, h, 4, alpha_mix=True)], gamma=1)
+
+    def run_all(i, out, hop):
+        try:
+            H = po.RefHost()
+            la, lb = new_pair(i)
+            for st in steps(H, la, lb):
+                if hop:                          # every step on a thread of its own
+                    ok = []
+                    t = threading.Thread(target=lambda: ok.append(st()))
+                    t.start(); t.join()
+                    assert ok and ok[0]
+                else:
+                    assert st()
+            out[i] = view(la)[:, :w * 4].copy()
+        except BaseException as e:              # noqa: BLE001
+            out[i] = repr(e)
+
+    want = {}
+    for i in range(4):
+        run_all(i, want, False)
+        assert isinstance(want[i], np.ndarray), want[i]
+    got = {}
+    ts = [threading.Thread(target=run_all, args=(i, got, False)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(4):
+        assert isinstance(got[i], np.ndarray), got[i]
+        assert (got[i] == want[i]).all(), "thread %d" % i
+    hopped = {}
+    run_all(0, hopped, True)
+    assert isinstance(hopped[0], np.ndarray), hopped[0]
+    assert (hopped[0] == want[0]).all()
+    del rng
