@@ -75,6 +75,34 @@ def main():
             print("          of which pin (upload 3.1 MB + sync) %.3f ms | the four calls (enqueue only, no synchronisation) %.3f ms | unpin (wait for the kernels, download 2.3 MB) %.3f ms"
                   % (t_pin / n * 1e3, t_chain / n * 1e3, t_sync / n * 1e3), flush=True)
             print("          per call, us: convert %.1f | gamma %.1f | resize %.1f | letterbox %.1f" % tuple(x / n * 1e6 for x in per_call), flush=True)
+    # the same unpinned chain when the host's frames are page-locked: lives_gpu_pinned_calloc / _free bound as the seam's pixel_alloc / pixel_free, the decoder's
+    # planes from it too -- every plane then crosses PCIe by DMA straight from / to its own memory instead of through the 4 MB staging chunks
+    L.lives_gpu_pinned_calloc.restype = ctypes.c_void_p
+    L.lives_gpu_pinned_calloc.argtypes = [ctypes.c_size_t]
+    W = wh.weed()
+    api = wh.WeedApi(W.fn["weed_leaf_get"], W.fn["weed_leaf_set"], W.fn["weed_leaf_num_elements"], W.fn["weed_leaf_delete"],
+                     ctypes.cast(L.lives_gpu_pinned_calloc, ctypes.c_void_p).value, ctypes.cast(L.lives_gpu_pinned_free, ctypes.c_void_p).value)
+    assert L.lives_gpu_bind_weed(ctypes.byref(api)) == 0
+    keep_malloc_copy = wh.malloc_copy
+
+    def pinned_copy(arr):
+        pm = L.lives_gpu_pinned_calloc(arr.nbytes + 64)
+        ctypes.memmove(pm, arr.ctypes.data, arr.nbytes)
+        return pm
+    wh.malloc_copy = pinned_copy
+    n = 12
+    layers = [wh.new_layer(512, w, h, [Y, U, V], gamma=-1, clamping=0, subspace=1) for _ in range(n + 2)]
+    for lay in layers[:2]:
+        chain(lay)
+    b0 = stats()
+    t0 = time.perf_counter()
+    for lay in layers[2:]:
+        chain(lay)
+    dt = (time.perf_counter() - t0) / n
+    print("unpinned, page-locked frames (lives_gpu_pinned_calloc as the frame allocator; one hipHostMalloc + memset per new plane -- a host would pool them): %.3f ms per frame (4 seam calls), %.1f MB over PCIe per frame"
+          % (dt * 1e3, (stats() - b0) / n / 1e6), flush=True)
+    wh.malloc_copy = keep_malloc_copy
+    wh.bind(L)
     # the host allocator's share: the convert call frees the decoder's three planes (3.1 MB the host wrote) with the bound pixel_free -- libc's free here,
     # i.e. an munmap of ~760 touched pages; LiVES' own frames come from its bigblock pool (src/memory.c) and cost nothing to release
     libc = ctypes.CDLL("libc.so.6")
