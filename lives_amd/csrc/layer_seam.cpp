@@ -112,8 +112,8 @@ bool read_layer(weed_plant_t *plant, Layer *l) {
 // crosses PCIe once in each direction instead of eight times.
 // Streams: every host thread enqueues on a stream of its own (LiVES runs plan steps and conversions on pool threads, src/threading.c; one shared
 // stream would run the small kernels of different tracks one after the other).  Non-blocking streams: a launch on a blocking one costs twice the host
-// time (ordering against the null stream is checked per launch).  The null stream's users -- the weed plugin through lives_gpu_resident_lookup -- are
-// ordered at that hand-over like any other stream.  Never destroyed: a thread_local destructor of the main thread runs after HIP's teardown.
+// time (ordering against the null stream is checked per launch).  livesgpu_fx.so enqueues on the same per-thread streams (lives_gpu_resident_acquire /
+// _release); a caller on the null stream is ordered at its hand-over (lives_gpu_resident_lookup) like any other stream.  Never destroyed: a thread_local destructor of the main thread runs after HIP's teardown.
 thread_local void *t_stream = nullptr;
 thread_local bool t_stream_tried = false;
 void *S() {
