@@ -185,9 +185,10 @@ int lgpu_stream_wait_event(void *stream, void *event) {
   return LGPU_OK;
 }
 
-// Pageable host memory (what LiVES' frame allocator hands out) crosses PCIe at ~2 GB/s through hipMemcpyAsync.  Frames therefore go through two
-// pinned staging chunks per host thread: the CPU copies chunk k + 1 into one while the DMA engine moves chunk k out of the other (measured on
-// 1080p planes: 1.8 -> ~9 GB/s).  Memory the host pinned or registered itself takes the direct path.
+// Pageable host memory (what LiVES' frame allocator hands out) goes TO the device at ~2.7 GB/s through hipMemcpyAsync.  Uploads therefore go through two
+// pinned staging chunks per host thread: the CPU copies chunk k + 1 into one while the DMA engine moves chunk k out of the other (8.3 MB: 3.1 ms plain,
+// 0.37 ms staged = 22 GB/s; hipHostRegister around a direct DMA costs 0.33 - 0.5 ms for the registration alone; tools/pcie_probe.hip).  Memory the host
+// pinned or registered itself takes the direct path.
 namespace {
 constexpr size_t kStageChunk = 4u << 20, kStageMin = 256u << 10;
 struct Stage {
@@ -239,34 +240,13 @@ int lgpu_upload(void *dst_d, const void *src_h, size_t bytes, void *stream) {
   return LGPU_OK;
 }
 
+// Downloads go straight to the destination, pageable or not: the runtime's own pageable path moves 8.3 MB in 157 us into memory the host has touched
+// (53 GB/s) and in 0.8 ms into a fresh block -- the new host plane of a seam call -- where the staging-chunk scheme above took 2.6 ms, most of it first-touch
+// page faults of the CPU copy out of the chunk (tools/pcie_probe.hip).  Only the UPLOAD direction is slow for pageable memory (2.7 GB/s plain, 22 GB/s staged).
 int lgpu_download(void *dst_h, const void *src_d, size_t bytes, void *stream) {
   int rc = lgpu::ensure_init();
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  int dev = 0;
-  if (bytes >= kStageMin && hipGetDevice(&dev) == hipSuccess && !host_is_pinned(dst_h) && t_stage.ready(dev)) {
-    const size_t nch = (bytes + kStageChunk - 1) / kStageChunk;
-    auto issue = [&](size_t c) -> int {
-      const int k = (int)(c & 1);
-      const size_t off = c * kStageChunk, n = bytes - off < kStageChunk ? bytes - off : kStageChunk;
-      if (t_stage.busy[k]) LGPU_HIP(hipEventSynchronize(t_stage.ev[k]));
-      LGPU_HIP(hipMemcpyAsync(t_stage.buf[k], (const char *)src_d + off, n, hipMemcpyDeviceToHost, st));
-      LGPU_HIP(hipEventRecord(t_stage.ev[k], st));
-      t_stage.busy[k] = true;
-      return LGPU_OK;
-    };
-    if ((rc = issue(0))) return rc;
-    for (size_t c = 0; c < nch; c++) {
-      const int k = (int)(c & 1);
-      const size_t off = c * kStageChunk, n = bytes - off < kStageChunk ? bytes - off : kStageChunk;
-      if (c + 1 < nch && (rc = issue(c + 1))) return rc;                     // chunk c + 1 is in flight while chunk c is copied out
-      LGPU_HIP(hipEventSynchronize(t_stage.ev[k]));
-      t_stage.busy[k] = false;
-      memcpy((char *)dst_h + off, t_stage.buf[k], n);
-    }
-    return LGPU_OK;                                     // complete on return, like a pageable device-to-host copy
-  }
-  LGPU_HIP(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, st));
+  LGPU_HIP(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return LGPU_OK;
 }
 
