@@ -927,7 +927,7 @@ static bool resize_into(const Layer &l, int width, int height, int interp, int a
   for (int p = 0; p < np->n && ok; p++) {
     const int ps = pal_is_planar_yuv(l.pal) ? 1 : pal_psize(l.pal);
     const int sw = plane_w(l, p), sh = plane_h(l, p), dw = plane_w(nl, p), dh = plane_h(nl, p);
-    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
+    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p == 3 ? 7 : p);          // scratch slots (ordinary layers): planes in 0, 1, 2, 7; planes out 3 .. 6
     uint8_t *d_out = w.out(np->pd[p], (size_t)np->rs[p] * dh, 3 + p, np->rs[p] != dw * ps);          // zeros for the row padding only
     ok = w.ok && lgpu_resize(d_in, l.rs[p], sw, sh, d_out, np->rs[p], dw, dh, ps, interp, lut8, S()) == LGPU_OK;
   }
@@ -1018,7 +1018,7 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
     else if (pal_alpha_first(l.pal)) black[0] = 255;
     else if (pal_alpha_last(l.pal)) black[3] = 255;
     const int sw = plane_w(l, p), sh = plane_h(l, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
-    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p);
+    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p == 3 ? 7 : p);
     uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, np.rs[p] != cw * ps);     // the canvas keeps its zeroed row padding (the kernel paints every pixel)
     ok = w.ok && lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, S()) == LGPU_OK;
   }
@@ -1095,7 +1095,7 @@ lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer) {
     Work w;
     bool ok = true;
     for (int p = 0; p < np.n && ok; p++) {
-      const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p);
+      const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p == 3 ? 7 : p);
       uint8_t *d_out = w.out(np.pd[p], np.sz[p], 3 + p, false);
       ok = w.ok && lgpu_copy_rows(d_out, np.rs[p], d_in, l.rs[p], np.rs[p], plane_h(l, p), S()) == LGPU_OK;
     }

@@ -398,3 +398,121 @@ def test_effects_and_seam_calls_from_several_threads(seam):
     assert isinstance(hopped[0], np.ndarray), hopped[0]
     assert (hopped[0] == want[0]).all()
     del rng
+
+
+def _planes_for(rng, pal, w, h):
+    """random planes of a w x h (pixels) frame in palette pal, rows 32-byte aligned like the reference's allocator; returns (planes, width leaf)"""
+    def plane(pw, ph, lo=0, hi=256):
+        a = np.zeros((ph, align(pw)), np.uint8)
+        a[:, :pw] = rng.integers(lo, hi, (ph, pw), dtype=np.uint8)
+        return a
+    if pal in (RGB24, BGR24, YUV888):
+        return [plane(w * 3, h)], w
+    if pal in (RGBA32, BGRA32, ARGB32, YUVA8888):
+        return [plane(w * 4, h)], w
+    if pal in (UYVY, YUYV):
+        return [plane(w * 2, h, 16, 236)], w // 2
+    if pal == YUV411:
+        return [plane((w // 4) * 6, h, 16, 236)], w // 4
+    if pal in (YUV420P, 513):
+        return [plane(w, h, 16, 236), plane(w // 2, h // 2, 16, 241), plane(w // 2, h // 2, 16, 241)], w
+    if pal == YUV422P:
+        return [plane(w, h, 16, 236), plane(w // 2, h, 16, 241), plane(w // 2, h, 16, 241)], w
+    if pal == YUV444P:
+        return [plane(w, h, 16, 236), plane(w, h, 16, 241), plane(w, h, 16, 241)], w
+    if pal == 545:                                                          # YUVA4444P
+        return [plane(w, h, 16, 236), plane(w, h, 16, 241), plane(w, h, 16, 241), plane(w, h)], w
+    raise AssertionError(pal)
+
+
+def test_every_palette_pair_pinned_and_unpinned_agree(seam):
+    """the whole convert_layer_palette matrix, differential: the same request on an ordinary layer (upload - kernel - download) and on a pinned one (resident
+    planes, result brought home by unpin) must return the same value and leave the same leaves and the same bytes -- including the declined pairs, which
+    must leave both layers as they were.  16 palettes x 16 targets x 2 clampings, two sizes."""
+    L, wh = seam
+    pals = [RGB24, BGR24, RGBA32, BGRA32, ARGB32, YUV420P, 513, YUV422P, YUV444P, 545, UYVY, YUYV, YUV888, YUVA8888, YUV411]
+    rng = np.random.default_rng(20260928)
+    served = declined = 0
+    for (w, h) in ((64, 32), (136, 50)):
+        for inpl in pals:
+            for outpl in pals:
+                for oclamp in (0, 1):
+                    planes, wl = _planes_for(rng, inpl, w, h)
+                    kw = dict(gamma=1) if inpl <= ARGB32 else dict(clamping=0, subspace=1)
+                    a = wh.new_layer(inpl, wl, h, planes, **kw)
+                    b = wh.new_layer(inpl, wl, h, planes, **kw)
+                    ra = L.lives_gpu_convert_layer_palette(a, outpl, oclamp)
+                    assert L.lives_gpu_layer_pin(b) == 0
+                    rb = L.lives_gpu_convert_layer_palette(b, outpl, oclamp)
+                    assert L.lives_gpu_layer_unpin(b) == 0
+                    assert ra == rb, (inpl, outpl, oclamp, w, h, ra, rb)
+                    pa, _, rsa = wh.planes_of(a)
+                    pb, _, rsb = wh.planes_of(b)
+                    la = [wh.geti(a, k) for k in ("current_palette", "width", "height", "YUV_clamping", "YUV_subspace", "YUV_sampling", "gamma_type")]
+                    lb = [wh.geti(b, k) for k in ("current_palette", "width", "height", "YUV_clamping", "YUV_subspace", "YUV_sampling", "gamma_type")]
+                    assert la == lb and rsa == rsb, (inpl, outpl, oclamp, la, lb)
+                    for x, y in zip(pa, pb):
+                        assert (x == y).all(), (inpl, outpl, oclamp, w, h)
+                    if ra:
+                        served += 1
+                    else:
+                        declined += 1
+                        assert la[0] == inpl
+    assert served > 300 and declined > 0
+
+
+def test_every_layer_op_pinned_and_unpinned_agree(seam):
+    """the other seam entry points, same differential: gamma, premultiply, resize (three interpolations, shrinking and enlarging), letterbox, unletterbox,
+    compact_rowstrides, weed_layer_clear_pixel_data on every palette they take -- ordinary layer against pinned layer, return value, leaves and bytes"""
+    L, wh = seam
+    pals = [RGB24, BGR24, RGBA32, BGRA32, ARGB32, YUV420P, 513, YUV422P, YUV444P, 545, UYVY, YUYV, YUV888, YUVA8888, YUV411]
+    rng = np.random.default_rng(5150)
+    ops = [("gamma", lambda lay: L.lives_gpu_gamma_convert_layer(2, lay)),
+           ("premult", lambda lay: (L.lives_gpu_alpha_premult(lay, 0), 1)[1]),
+           ("unpremult", lambda lay: (L.lives_gpu_alpha_premult(lay, 1), 1)[1]),
+           ("resize-bicubic-down", lambda lay: L.lives_gpu_resize_layer(lay, 72, 40, 3, 0, 0)),
+           ("resize-half", lambda lay: L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0)),
+           ("resize-bilinear-up", lambda lay: L.lives_gpu_resize_layer(lay, 200, 96, 2, 0, 0)),
+           ("resize-nearest", lambda lay: L.lives_gpu_resize_layer(lay, 96, 48, 0, 0, 0)),
+           ("letterbox", lambda lay: L.lives_gpu_letterbox_layer(lay, 160, 100, 96, 48, 3, 0, 0)),
+           ("unletterbox", lambda lay: L.lives_gpu_unletterbox_layer(lay, 0, 0, 4, 6, 8, 12)),
+           ("compact", lambda lay: L.lives_gpu_compact_rowstrides(lay)),
+           ("clear", lambda lay: L.lives_gpu_weed_layer_clear_pixel_data(lay))]
+    keys = ("current_palette", "width", "height", "YUV_clamping", "YUV_subspace", "gamma_type", "host_flags")
+    n = 0
+    for pal in pals:
+        for name, op in ops:
+            w, h = 128, 64
+            planes, wl = _planes_for(rng, pal, w, h)
+            kw = dict(gamma=1) if pal <= ARGB32 else dict(clamping=0, subspace=1)
+            a = wh.new_layer(pal, wl, h, planes, **kw)
+            b = wh.new_layer(pal, wl, h, planes, **kw)
+            ra = op(a)
+            assert L.lives_gpu_layer_pin(b) == 0
+            rb = op(b)
+            assert L.lives_gpu_layer_unpin(b) == 0
+            assert ra == rb, (pal, name, ra, rb)
+            pa, _, rsa = wh.planes_of(a)
+            pb, _, rsb = wh.planes_of(b)
+            assert [wh.geti(a, k) for k in keys] == [wh.geti(b, k) for k in keys] and rsa == rsb, (pal, name)
+            for x, y in zip(pa, pb):
+                assert (x == y).all(), (pal, name)
+            n += 1
+    assert n == len(pals) * len(ops)
+
+
+def test_four_plane_layers_resize_plane_by_plane(seam, orc):
+    """YUVA4444P through resize_layer on an ORDINARY layer: four planes in, four planes out, every plane the oracle's resize of that plane (the differential test above
+    found the alpha plane's upload landing in the scratch slot that held the new Y plane; scratch slots are now planes-in 0, 1, 2, 7 / planes-out 3 .. 6)"""
+    L, wh = seam
+    rng = np.random.default_rng(545)
+    w, h, dw, dh = 128, 64, 72, 40
+    planes, wl = _planes_for(rng, 545, w, h)
+    lay = wh.new_layer(545, wl, h, planes, clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer(lay, dw, dh, 3, 0, 0) == 1
+    got, _, rs = wh.planes_of(lay)
+    assert len(got) == 4 and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (dw, dh)
+    for p in range(4):
+        want = np.zeros((dh, rs[p]), np.uint8)
+        assert orc.orc_resize(P(planes[p]), planes[p].strides[0], w, h, P(want), rs[p], dw, dh, 1, 3) == 0
+        assert (got[p][:, :dw] == want[:, :dw]).all(), p
