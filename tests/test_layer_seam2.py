@@ -516,3 +516,44 @@ def test_four_plane_layers_resize_plane_by_plane(seam, orc):
         want = np.zeros((dh, rs[p]), np.uint8)
         assert orc.orc_resize(P(planes[p]), planes[p].strides[0], w, h, P(want), rs[p], dw, dh, 1, 3) == 0
         assert (got[p][:, :dw] == want[:, :dw]).all(), p
+
+
+def test_every_filter_class_on_pinned_planes(seam):
+    """the plugin seam's residency path, differential over the filter classes of livesgpu_fx.so: channels that carry ordinary host memory (upload - effect - download)
+    against channels that carry the planes of pinned layers (effect on the resident copies, on the calling thread's stream, bytes home at unpin).  Default parameters,
+    RGBA32 / RGB24 as the class takes them; stateful and random classes run one frame from a fresh instance either way."""
+    import os
+    L, wh = seam
+    H = po.RefHost()
+    OURS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lives_amd", "livesgpu_fx.so")
+    H.H.refhost_set_random_seed(12345)
+    w, h = 96, 48
+    rng = np.random.default_rng(31)
+    ran = 0
+    for f in H.filters(OURS):
+        pal = RGBA32 if RGBA32 in f["palettes"] else RGB24 if RGB24 in f["palettes"] else None
+        if pal is None or f["n_in"] < 1 or f["n_in"] > 2 or f["n_out"] != 1 or f["name"] in ("rand replace",):
+            continue
+        ps = 4 if pal == RGBA32 else 3
+        srcs = [frame(rng, w, h, ps, alpha_mix=(ps == 4)) for _ in range(f["n_in"])]
+        # ordinary memory, in place on input 0 (what LiVES does for these classes)
+        plain = [s.copy() for s in srcs]
+        try:
+            H.H.refhost_set_random_seed(12345)
+            H.run(OURS, f["name"], pal, w, h, plain, plain[0], [])
+        except RuntimeError:
+            continue                                     # a class that wants parameters / geometry this harness does not give it
+        layers = [wh.new_layer(pal, w, h, [s], gamma=1) for s in srcs]
+        for lay in layers:
+            assert L.lives_gpu_layer_pin(lay) == 0
+        views = []
+        for lay in layers:
+            _, ptrs, rs = wh.planes_of(lay)
+            views.append(np.frombuffer((ctypes.c_uint8 * (rs[0] * h)).from_address(ptrs[0]), np.uint8).reshape(h, rs[0]))
+        H.H.refhost_set_random_seed(12345)
+        H.run(OURS, f["name"], pal, w, h, views, views[0], [])
+        for lay in layers:
+            assert L.lives_gpu_layer_unpin(lay) == 0
+        assert (views[0][:, :w * ps] == plain[0][:, :w * ps]).all(), f["name"]
+        ran += 1
+    assert ran >= 20, ran
