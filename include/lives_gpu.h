@@ -156,6 +156,10 @@ int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int height, uint8_
 int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow,
                       int nwidth, int nheight, int psize, const uint8_t black_pixel[4], int offs_x, int offs_y,
                       void *stream);
+/* the bars alone: black on every canvas pixel outside the width x height rectangle at (ox, oy) -- for callers that let lgpu_resize write the inner frame
+   straight into the canvas (dst_d + oy * orow + ox * psize), so that the resized frame never exists on its own (what lives_gpu_letterbox_layer does) */
+int lgpu_letterbox_bars(uint8_t *dst_d, int orow, int nwidth, int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, int width,
+                        int height, void *stream);
 
 /* ---- K7: resize.  Replaces the sws_scale() call of resize_layer_full (src/colourspace.c:14711, setup
    :14940-15259).  PARITY UNPINNED: libswscale is neither vendored nor version-pinned by the reference;

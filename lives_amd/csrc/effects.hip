@@ -297,6 +297,22 @@ __global__ __launch_bounds__(kBlock) void k_letterbox(const uint8_t *src, int ir
   }
 }
 
+// the bars alone: every canvas pixel OUTSIDE the inner rectangle gets the palette's black (letterbox_layer when the inner frame is written in place by the
+// scaler, so the resized frame never exists on its own)
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_letterbox_bars(uint8_t *dst, int orow, int nwidth, int nheight, int ox, int oy, int width, int height, uint32_t black) {
+  const int g = blockIdx.x * kBlock + threadIdx.x;   // group of 4 canvas pixels
+  const int x0 = g * 4;
+  if (x0 >= nwidth) return;
+  for (int y = blockIdx.y; y < nheight; y += gridDim.y) {
+    uint8_t *d = dst + (size_t)y * orow;
+    const bool rowin = y >= oy && y < oy + height;
+    if (rowin && x0 >= ox && x0 + 4 <= ox + width) continue;                        // wholly inside: the scaler's
+    for (int x = x0; x < x0 + 4 && x < nwidth; x++)
+      if (!(rowin && x >= ox && x < ox + width)) store1<PS>(d, x, black);
+  }
+}
+
 static inline dim3 row_grid2(unsigned items_per_row, int height) {
   unsigned gy = (unsigned)height;
   if (gy > 4096) gy = 4096;
@@ -451,6 +467,27 @@ extern "C" int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int 
     // single-byte planes (Y / U / V / A of the planar palettes): 4 samples per lane
     hipLaunchKernelGGL(k_letterbox<1>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, 0);
   }
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+extern "C" int lgpu_letterbox_bars(uint8_t *dst_d, int orow, int nwidth, int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, int width,
+                                   int height, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(dst_d && black_pixel && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 1 || psize == 3 || psize == 4, "psize must be 1, 3 or 4");
+  LGPU_REQUIRE(orow >= nwidth * psize, "rowstride smaller than a row");
+  LGPU_REQUIRE(ox >= 0 && oy >= 0 && ox + width <= nwidth && oy + height <= nheight, "inner frame does not fit at that offset");
+  LGPU_REQUIRE(psize != 4 || (((uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0, "4-byte pixels must be 4-byte aligned");
+  uint32_t black = black_pixel[0];
+  if (psize >= 3) black |= ((uint32_t)black_pixel[1] << 8) | ((uint32_t)black_pixel[2] << 16);
+  if (psize == 4) black |= (uint32_t)black_pixel[3] << 24;
+  const dim3 grid = row_grid2((unsigned)((nwidth + 3) >> 2), nheight);
+  hipStream_t st = (hipStream_t)stream;
+  if (psize == 4) hipLaunchKernelGGL(k_letterbox_bars<4>, grid, dim3(kBlock), 0, st, dst_d, orow, nwidth, nheight, ox, oy, width, height, black);
+  else if (psize == 3) hipLaunchKernelGGL(k_letterbox_bars<3>, grid, dim3(kBlock), 0, st, dst_d, orow, nwidth, nheight, ox, oy, width, height, black);
+  else hipLaunchKernelGGL(k_letterbox_bars<1>, grid, dim3(kBlock), 0, st, dst_d, orow, nwidth, nheight, ox, oy, width, height, black);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

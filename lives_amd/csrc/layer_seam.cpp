@@ -936,20 +936,19 @@ static bool resize_into(const Layer &l, int width, int height, int interp, int a
   return ok;
 }
 
-// resize_layer_full (src/colourspace.c:14759-15328).  osamp_hint / osubs_hint only parameterise the reference's swscale colourspace
-// details for conversions done inside the scaler; this path never converts inside the resize (the layer keeps its palette, "layer palette
-// should be checked on return", :14746-14751), so they take part in the target-gamma decision only (:14890-14899).
-lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
-                                              int osamp_hint, int osubs_hint, int tgt_gamma) {
-  (void)oclamp_hint; (void)osamp_hint;
-  PinScope pin(layer);
-  Layer l;
+// What resize_layer_full decides before it scales (shared with letterbox_layer, which scales straight into its canvas): the layer converted to a resizable
+// palette if need be, the even source size, the adjusted target size, the fused gamma table.  Returns 1 = scale, 0 = failed / declined (*rc says which
+// value the seam call returns), 2 = nothing to do.
+struct ResizePlan { Layer l, src; int width, height, new_gamma; bool use_lut; uint8_t lut[256]; };
+static int plan_resize(weed_plant_t *layer, int width, int height, int opal_hint, int osubs_hint, int tgt_gamma, ResizePlan *rp, int *rc) {
+  Layer &l = rp->l;
+  *rc = 0;
   if (!ready() || !read_layer(layer, &l)) return 0;
   // opal_hint / oclamp_hint "may be ignored ... layer palette should be checked on return" (:14746-14751): a frame whose palette this path
   // resizes keeps it (the caller's following convert_layer_palette does the rest); a packed-YUV frame is first taken to the hinted
   // palette when that one is resizable and the conversion is served here
   if (!(pal_is_rgb(l.pal) || pal_is_planar_yuv(l.pal))) {
-    if (opal_hint == WEED_PALETTE_NONE || opal_hint == l.pal || !(pal_is_rgb(opal_hint) || pal_is_planar_yuv(opal_hint))) return decline(layer);
+    if (opal_hint == WEED_PALETTE_NONE || opal_hint == l.pal || !(pal_is_rgb(opal_hint) || pal_is_planar_yuv(opal_hint))) { *rc = decline(layer); return 0; }
     const int cl = l.clamping >= 0 ? l.clamping : WEED_YUV_CLAMPING_CLAMPED;
     if (!lives_gpu_convert_layer_palette_full(layer, opal_hint, cl, WEED_YUV_SAMPLING_DEFAULT, l.subspace, WEED_GAMMA_UNKNOWN)) return 0;
     if (!read_layer(layer, &l)) return 0;
@@ -958,27 +957,40 @@ lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int widt
   if (width < 4) width = 4;
   if (height < 4) height = 4;
   if (iwidth != width || iheight != height) height = (height >> 1) << 1;
-  if (iwidth == width && iheight == height) return 1;
+  if (iwidth == width && iheight == height) { *rc = 1; return 2; }
   if (pal_is_planar_yuv(l.pal)) width = (width >> 1) << 1;
   // target gamma (:14890-14899, :15119-15127): applied as a LUT8 after the scaler when the output is RGB and the layer's gamma is known
   const int opal = (opal_hint == WEED_PALETTE_NONE || opal_hint == WEED_PALETTE_ANY) ? l.pal : opal_hint;
   if (tgt_gamma == WEED_GAMMA_UNKNOWN && !pal_is_rgb(opal) && osubs_hint == WEED_YUV_SUBSPACE_BT709) tgt_gamma = WEED_GAMMA_BT709;
   if (tgt_gamma == WEED_GAMMA_UNKNOWN && pal_is_rgb(l.pal) && !pal_is_rgb(opal)) tgt_gamma = WEED_GAMMA_SRGB;       // get_tgt_gamma :14733
   if (tgt_gamma == WEED_GAMMA_UNKNOWN) tgt_gamma = l.gamma;
-  uint8_t lut[256];
-  const uint8_t *lutp = nullptr;
-  int new_gamma = l.gamma;
+  rp->use_lut = false;
+  rp->new_gamma = l.gamma;
   if (tgt_gamma != WEED_GAMMA_UNKNOWN && pal_is_rgb(opal) && pal_is_rgb(l.pal)) {
-    if (l.gamma != WEED_GAMMA_UNKNOWN && l.gamma != tgt_gamma && lgpu_gamma_lut8(1.0, l.gamma, tgt_gamma, g_prefs.screen_gamma, lut)) lutp = lut;
-    new_gamma = tgt_gamma;
+    if (l.gamma != WEED_GAMMA_UNKNOWN && l.gamma != tgt_gamma && lgpu_gamma_lut8(1.0, l.gamma, tgt_gamma, g_prefs.screen_gamma, rp->lut)) rp->use_lut = true;
+    rp->new_gamma = tgt_gamma;
   }
-  Layer src = l;
-  src.width = iwidth; src.height = iheight;
+  rp->src = l;
+  rp->src.width = iwidth; rp->src.height = iheight;
+  rp->width = width; rp->height = height;
+  return 1;
+}
+
+// resize_layer_full (src/colourspace.c:14759-15328).  osamp_hint / osubs_hint only parameterise the reference's swscale colourspace
+// details for conversions done inside the scaler; this path never converts inside the resize (the layer keeps its palette, "layer palette
+// should be checked on return", :14746-14751), so they take part in the target-gamma decision only (:14890-14899).
+lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
+                                              int osamp_hint, int osubs_hint, int tgt_gamma) {
+  (void)oclamp_hint; (void)osamp_hint;
+  PinScope pin(layer);
+  ResizePlan rp;
+  int rc;
+  if (plan_resize(layer, width, height, opal_hint, osubs_hint, tgt_gamma, &rp, &rc) != 1) return rc;
   NewPlanes np;
-  if (!resize_into(src, width, height, interp, 16, lutp, &np)) return 0;       // rowstride_alignment_hint = 16 (:14989)
-  free_planes(l);
-  commit_planes(layer, l.pal, width, height, np);
-  if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
+  if (!resize_into(rp.src, rp.width, rp.height, interp, 16, rp.use_lut ? rp.lut : nullptr, &np)) return 0;       // rowstride_alignment_hint = 16 (:14989)
+  free_planes(rp.l);
+  commit_planes(layer, rp.l.pal, rp.width, rp.height, np);
+  if (rp.new_gamma != rp.l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, rp.new_gamma);
   return 1;
 }
 
@@ -994,15 +1006,30 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
   if (nwidth < width) nwidth = width;
   if (nheight < height) nheight = height;
   if (nheight == height && nwidth == width) { lives_gpu_resize_layer(layer, width, height, interp, tpal, tclamp); return 1; }
-  Layer l;
-  if (!ready() || !read_layer(layer, &l)) return 0;
-  if (l.width != width || l.height != height) {
-    if (!lives_gpu_resize_layer(layer, width, height, interp, tpal, tclamp)) return 0;
-    if (!read_layer(layer, &l)) return 0;
+  // The inner frame: what resize_layer(layer, width, height, interp, tpal, tclamp) would leave (:15389) -- scaled STRAIGHT INTO the canvas when it has to
+  // be scaled (the resized frame never exists on its own: one plane-sized write and read less per plane), blitted when it already has its size.
+  ResizePlan rp;
+  int rc, todo = 2;
+  if (!ready() || !read_layer(layer, &rp.l)) return 0;
+  if (rp.l.width != width || rp.l.height != height) {                                     // resize_layer is only called for a frame of another size
+    todo = plan_resize(layer, width, height, tpal, WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN, &rp, &rc);
+    if (todo == 0) return rc;
   }
-  width = l.width; height = l.height;
-  if (nwidth < width || nheight < height) return 0;
-  Layer canvas = l;
+  const Layer &l = rp.l;
+  Layer inner = l;                                       // the frame as it sits in the canvas
+  if (todo == 1) { inner.width = rp.width; inner.height = rp.height; }
+  width = inner.width; height = inner.height;
+  if (nwidth < width || nheight < height) {              // cannot hold it (the reference asserts its sizes earlier): leave the layer resized, as the two calls did
+    if (todo == 1) {
+      NewPlanes rnp;
+      if (!resize_into(rp.src, rp.width, rp.height, interp, 16, rp.use_lut ? rp.lut : nullptr, &rnp)) return 0;
+      free_planes(l);
+      commit_planes(layer, l.pal, rp.width, rp.height, rnp);
+      if (rp.new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, rp.new_gamma);
+    }
+    return 0;
+  }
+  Layer canvas = inner;
   canvas.width = nwidth; canvas.height = nheight;
   NewPlanes np;
   if (!alloc_planes(l.pal, nwidth, nheight, 0, &np)) return 0;
@@ -1012,20 +1039,28 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
   for (int p = 0; p < np.n && ok; p++) {
     const int ps = pal_is_planar_yuv(l.pal) ? 1 : pal_psize(l.pal);
     // chroma planes: offsets scaled by the plane ratio and truncated (:15553-15556)
-    const int px = (plane_w(l, p) == l.width) ? offs_x : (int)(offs_x * 0.5), py = (plane_h(l, p) == l.height) ? offs_y : (int)(offs_y * 0.5);
+    const int px = (plane_w(inner, p) == inner.width) ? offs_x : (int)(offs_x * 0.5), py = (plane_h(inner, p) == inner.height) ? offs_y : (int)(offs_y * 0.5);
     uint8_t black[4] = {0, 0, 0, 0};
     if (pal_is_planar_yuv(l.pal)) black[0] = (p == 0) ? (l.clamping == WEED_YUV_CLAMPING_UNCLAMPED ? 0 : 16) : 128;
     else if (pal_alpha_first(l.pal)) black[0] = 255;
     else if (pal_alpha_last(l.pal)) black[3] = 255;
-    const int sw = plane_w(l, p), sh = plane_h(l, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
-    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * sh, p == 3 ? 7 : p);
-    uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, np.rs[p] != cw * ps);     // the canvas keeps its zeroed row padding (the kernel paints every pixel)
-    ok = w.ok && lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, S()) == LGPU_OK;
+    const int iw = plane_w(inner, p), ih = plane_h(inner, p), cw = plane_w(canvas, p), chh = plane_h(canvas, p);
+    const Layer &from = todo == 1 ? rp.src : l;
+    const int sw = plane_w(from, p), sh = plane_h(from, p);
+    const uint8_t *d_in = w.in(l.pd[p], (size_t)l.rs[p] * plane_h(l, p), p == 3 ? 7 : p);
+    uint8_t *d_out = w.out(np.pd[p], (size_t)np.rs[p] * chh, 3 + p, np.rs[p] != cw * ps);     // the canvas keeps its zeroed row padding (the kernels paint every pixel)
+    if (!w.ok) { ok = false; break; }
+    if (todo == 1)
+      ok = lgpu_letterbox_bars(d_out, np.rs[p], cw, chh, ps, black, px, py, iw, ih, S()) == LGPU_OK &&
+           lgpu_resize(d_in, l.rs[p], sw, sh, d_out + (size_t)py * np.rs[p] + (size_t)px * ps, np.rs[p], iw, ih, ps, interp, rp.use_lut ? rp.lut : nullptr, S()) == LGPU_OK;
+    else
+      ok = lgpu_letterbox_at(d_in, l.rs[p], sw, sh, d_out, np.rs[p], cw, chh, ps, black, px, py, S()) == LGPU_OK;
   }
   ok = ok && w.finish();
   if (!ok) { drop_new_planes(np); return 0; }
   free_planes(l);
   commit_planes(layer, l.pal, nwidth, nheight, np);
+  if (todo == 1 && rp.new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, rp.new_gamma);
   return 1;
 }
 

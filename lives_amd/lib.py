@@ -90,6 +90,7 @@ PROTOTYPES = {
     "lgpu_alpha_scalers": [vp, vp],
     "lgpu_letterbox": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp],
     "lgpu_letterbox_at": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, ci, vp],
+    "lgpu_letterbox_bars": [vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
     "lgpu_make_filter": [ci, ci, ci, vp, vp, vp, ci],
     "lgpu_gauss5": [vp, ci, vp, ci, ci, ci, ci, vp],
