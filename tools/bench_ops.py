@@ -137,6 +137,16 @@ def main():
     blk = (ctypes.c_uint8 * 4)(*black)
     c = cpu(lambda: orc.orc_letterbox(P(hd), hd.strides[0], dw, dh, P(hc), hc.strides[0], 1920, 1200, 4, blk))
     add("letterbox into 1920x1200 (C3)", "colourspace.c:15343-15567", "1920x1080", dw * dh * 4 + 1920 * 1200 * 4, t, c)
+    # what letterbox_layer does with a frame of another size: the scaler writes the inner frame straight into the canvas, the bars by their own kernel
+    from lives_amd import lib as _lib
+    blk4 = (ctypes.c_uint8 * 4)(*black)
+
+    def fused(i):
+        cv = canvas[i]
+        _lib.call("lgpu_letterbox_bars", ops.dptr(cv), cv.stride(0), 1920, 1200, 4, blk4, 0, 60, dw, dh, ops.stream_ptr())
+        _lib.call("lgpu_resize", ops.dptr(src[i]), src[i].stride(0), sw, sh, ops.dptr(cv, 60 * cv.stride(0)), cv.stride(0), dw, dh, 4, 3, None, ops.stream_ptr())
+    t = timeit(fused, NB)
+    add("resize 0.5x straight into the 1920x1200 canvas + bars (C3, letterbox_layer)", "colourspace.c:15343-15567", "3840x2160->1920x1200", sw * sh * 4 + 1920 * 1200 * 4, t, None)
     l1, l2, lo_ = dframe(1920, 1200, 4, NB), dframe(1920, 1200, 4, NB), dframe(1920, 1200, 4, NB)
     t = timeit(lambda i: ops.blend_chroma(l1[i], l2[i], lo_[i], 1920, 1200, 4, 128), NB)
     h1, h2, ho = hframe(1920, 1200, 4), hframe(1920, 1200, 4), hframe(1920, 1200, 4)
