@@ -25,6 +25,23 @@ __global__ __launch_bounds__(512) void k_stream(const uint8_t *src, size_t bytes
         if (k >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
         __builtin_amdgcn_global_load_lds((gptr)(src + (r << 10) + lane * 16), (lptr)(ring + (k % DEPTH) * 1024), 16, 0, 0);
       }
+    } else if (pattern == 4) {
+      // 128-column x 8-row tiles: windows of 22 rows x 1,056 bytes (66 chunks a row), the same bytes per tile as 64 x 16 with twice as long row segments
+      const int tx4 = 15, ty4 = 135, ntiles = tx4 * ty4 * nframes;
+      const int xcd = blockIdx.x & 7, stride = (gridDim.x >> 3) * nw, chunk = (ntiles + 7) >> 3;
+      const int wend = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
+      int k = 0;
+      for (int t = xcd * chunk + (blockIdx.x >> 3) * nw + wave; t < wend; t += stride) {
+        const int f = t / (tx4 * ty4), tt = t - f * tx4 * ty4, ty = tt / tx4, tx = tt - ty * tx4;
+        const uint8_t *base = src + (size_t)f * irow * 2160;
+        for (int q = 0; q < 23; q++, k++) {
+          const int c = q * 64 + lane, r = c / 66, ch = c - r * 66;
+          int sy = 16 * ty - 3 + r; sy = sy < 0 ? 0 : sy > 2159 ? 2159 : sy;
+          int x = 1024 * tx - 16 + ch * 16; x = x < 0 ? 0 : x > irow - 16 ? irow - 16 : x;
+          if (k >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+          if (c < 22 * 66) __builtin_amdgcn_global_load_lds((gptr)(base + (size_t)sy * irow + x), (lptr)(ring + (k % DEPTH) * 1024), 16, 0, 0);
+        }
+      }
     } else if (pattern >= 2) {
       // pattern 2: every loader wave walks DOWN 64-column strips over a contiguous run of the column-major tile list (k_half8r): 17 requests (32 rows) per tile;
       // pattern 3: the same, but every wave takes whole strips (68 tiles), so that waves on neighbouring strips read the same source rows at the same time
@@ -66,9 +83,24 @@ __global__ __launch_bounds__(512) void k_stream(const uint8_t *src, size_t bytes
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else if (writer && wave == nw) {
-    // the result stream: a quarter of the source bytes, 16-byte stores, spread like the readers
-    const size_t n16 = (bytes >> 2) >> 4;
-    for (size_t i = (size_t)blockIdx.x * 64 + lane; i < n16; i += (size_t)gridDim.x * 64) reinterpret_cast<uint4 *>(dst)[i] = make_uint4(1, 2, 3, 4);
+    if (writer == 1) {
+      // the result stream: a quarter of the source bytes, 16-byte stores, linear
+      const size_t n16 = (bytes >> 2) >> 4;
+      for (size_t i = (size_t)blockIdx.x * 64 + lane; i < n16; i += (size_t)gridDim.x * 64) reinterpret_cast<uint4 *>(dst)[i] = make_uint4(1, 2, 3, 4);
+    } else {
+      // writer 2: as k_half8s stores its tiles -- 64 x 16 result pixels per tile, a request = 4 rows x 256 bytes, rows 7,680 bytes apart, tiles in the readers' order
+      const int ntiles = tiles_x * tiles_y * nframes;
+      const int xcd = blockIdx.x & 7, stride = (gridDim.x >> 3), chunk = (ntiles + 7) >> 3;
+      const int wend = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
+      for (int t = xcd * chunk + (blockIdx.x >> 3); t < wend; t += stride) {
+        const int f = t / (tiles_x * tiles_y), tt = t - f * tiles_x * tiles_y, ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        uint8_t *base = dst + (size_t)f * 7680 * 1080;
+        for (int k2 = 0; k2 < 4; k2++) {
+          int oy = 16 * ty + k2 * 4 + (lane >> 4); oy = oy > 1079 ? 1079 : oy;
+          *reinterpret_cast<uint4 *>(base + (size_t)oy * 7680 + (size_t)tx * 256 + (lane & 15) * 16) = make_uint4(1, 2, 3, 4);
+        }
+      }
+    }
   }
 }
 
@@ -80,8 +112,8 @@ int main(int argc, char **argv) {
   hipMemset(src, 1, bytes * 2);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   printf("pattern waves/WG WGs depth writer : us per pass, read GB/s (+ write GB/s)\n");
-  for (int pattern = 1; pattern < 4; pattern++)
-    for (int writer = 0; writer < 2; writer++)
+  for (int pattern : {1})
+    for (int writer = 0; writer < 3; writer++)
       for (int nw : {2})
         for (int wgs : {512})
           for (int depth : {16}) {
@@ -100,7 +132,7 @@ int main(int argc, char **argv) {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double us = ms * 1e3 / reps;
-            const double rbytes = pattern == 0 ? (double)bytes : pattern == 1 ? 30.0 * 68 * nframes * 38 * 544 : 30.0 * 68 * nframes * 32 * 544;
+            const double rbytes = pattern == 0 ? (double)bytes : pattern == 1 ? 30.0 * 68 * nframes * 38 * 544 : pattern == 4 ? 15.0 * 135 * nframes * 22 * 1056 : 30.0 * 68 * nframes * 32 * 544;
             printf("%d %d %d %d %d : %.1f us, %.0f GB/s%s\n", pattern, nw, wgs, depth, writer, us, rbytes / us / 1e3, writer ? " + write" : "");
             if (writer) printf("        (+ %.0f GB/s written; read + write %.0f GB/s)\n", bytes / 4.0 / us / 1e3, (rbytes + bytes / 4.0) / us / 1e3);
           }
