@@ -796,7 +796,7 @@ __device__ __forceinline__ void h8s_issue_q2(const Half8Args &a, const uint8_t *
     for (int k = 0; k < 4; k++) {
       const int oy = min(ty0 + k * 4 + row, a.dh - 1);
       const uint8_t *g = l2 + ((uint32_t)oy * (uint32_t)a.irow2 + (uint32_t)(tx0 + chunk * 4) * 4u);
-      __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(slot + k * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((h8s_gptr)g, (h8s_lptr)(slot + k * 1024), 16, 0, 2);      // nt: layer 2 is read once (no halo, unlike the source windows)
     }
   } else h8s_issue_q2_partial(l2, a.irow2, a.dw, a.dh, tx0, ty0, lane, slot);
 }
@@ -827,7 +827,12 @@ __device__ __forceinline__ void h8s_store_tile(const Half8Args &a, uint8_t *dst,
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int ly = k * 4 + row;
-      if (ly < thh) *reinterpret_cast<uint4 *>(dst + ((size_t)(ty0 + ly) * a.orow + (size_t)(tx0 + chunk * 4) * 4)) = v[k];
+      // non-temporal: the result stream is written once and not read back by this launch; with the default policy its 133 MB cost ~40 us next to 98 us
+      // of source reads in a free-running probe, with `nt` ~27 us (tools/dma_ceiling.hip, profiles/r02/ring_experiment.md)
+      if (ly < thh) {
+        const u32x4v o = {v[k].x, v[k].y, v[k].z, v[k].w};
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4v *>(dst + ((size_t)(ty0 + ly) * a.orow + (size_t)(tx0 + chunk * 4) * 4)));
+      }
     }
   } else h8s_store_tile_partial(dst, a.orow, tw, thh, tx0, ty0, lane, v[0], v[1], v[2], v[3]);
 }

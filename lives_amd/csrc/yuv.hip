@@ -350,8 +350,12 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, 
       }
       uint8_t *dst = bt.dst[cur.z];
       uint4 *d0 = reinterpret_cast<uint4 *>(dst + (size_t)i * a.orow + (size_t)(2 * cur.k0) * 4), *d1 = reinterpret_cast<uint4 *>(dst + (size_t)(i + 1) * a.orow + (size_t)(2 * cur.k0) * 4);
-      d0[0] = make_uint4(top[0], top[1], top[2], top[3]); d0[1] = make_uint4(top[4], top[5], top[6], top[7]);
-      d1[0] = make_uint4(bot[0], bot[1], bot[2], bot[3]); d1[1] = make_uint4(bot[4], bot[5], bot[6], bot[7]);
+      // non-temporal: written once, not read back by this launch (the same change bought 1.3 % on the chain kernel, profiles/r02/ring_experiment.md)
+      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+      u32x4s *e0 = reinterpret_cast<u32x4s *>(d0), *e1 = reinterpret_cast<u32x4s *>(d1);
+      const u32x4s t0 = {top[0], top[1], top[2], top[3]}, t1 = {top[4], top[5], top[6], top[7]}, b0 = {bot[0], bot[1], bot[2], bot[3]}, b1 = {bot[4], bot[5], bot[6], bot[7]};
+      __builtin_nontemporal_store(t0, e0); __builtin_nontemporal_store(t1, e0 + 1);
+      __builtin_nontemporal_store(b0, e1); __builtin_nontemporal_store(b1, e1 + 1);
     }
     cur = nxt;
   }

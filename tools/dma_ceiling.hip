@@ -97,7 +97,13 @@ __global__ __launch_bounds__(512) void k_stream(const uint8_t *src, size_t bytes
         uint8_t *base = dst + (size_t)f * 7680 * 1080;
         for (int k2 = 0; k2 < 4; k2++) {
           int oy = 16 * ty + k2 * 4 + (lane >> 4); oy = oy > 1079 ? 1079 : oy;
-          *reinterpret_cast<uint4 *>(base + (size_t)oy * 7680 + (size_t)tx * 256 + (lane & 15) * 16) = make_uint4(1, 2, 3, 4);
+          uint4 *wp = reinterpret_cast<uint4 *>(base + (size_t)oy * 7680 + (size_t)tx * 256 + (lane & 15) * 16);
+          typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+          const u32x4w val = {1, 2, 3, 4};
+          if (writer == 2) *wp = make_uint4(1, 2, 3, 4);
+          else if (writer == 3) __builtin_nontemporal_store(val, reinterpret_cast<u32x4w *>(wp));
+          else if (writer == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(wp), "v"(val) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(wp), "v"(val) : "memory");
         }
       }
     }
@@ -113,7 +119,7 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   printf("pattern waves/WG WGs depth writer : us per pass, read GB/s (+ write GB/s)\n");
   for (int pattern : {1})
-    for (int writer = 0; writer < 3; writer++)
+    for (int writer : {0, 2, 3, 4, 5})
       for (int nw : {2})
         for (int wgs : {512})
           for (int depth : {16}) {
