@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
         p = chroma_rgba(p, q, bf, nbf);
       }
       if (a.use_lut) p = lut3_rgba(s_lut, p);
-      reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[tx0 + lane] = p;
+      __builtin_nontemporal_store(p, reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow) + tx0 + lane);      // written once, not read back
     }
   }
 }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_sep2(SepArgs a, SepTracks trk, Lut8 
         p = chroma_rgba(p, q, bf, nbf);
       }
       if (a.use_lut) p = lut3_rgba(s_lut, p);
-      reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[tx0 + lane] = p;
+      __builtin_nontemporal_store(p, reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow) + tx0 + lane);      // written once, not read back
     }
   }
 }
@@ -1422,7 +1422,7 @@ __device__ __forceinline__ void s2p_compute(const SepArgs &a, const SepTracks &t
                                               ((uint32_t)clamp255(acc[r][2] >> a.vshift) << 16) | ((uint32_t)clamp255(acc[r][3] >> a.vshift) << 24);
             if (a.blend) p = chroma_rgba(p, qpre[r], bf, nbf);
             if (a.use_lut) p = lut3_rgba(s_lut, p);
-            reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow)[t.tx0 + lane] = p;
+            __builtin_nontemporal_store(p, reinterpret_cast<uint32_t *>(dst + (size_t)oy * a.orow) + t.tx0 + lane);      // written once, not read back
           }
         }
       }
