@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_gauss5x(G5Args a, SepTracks t, Lut8 l) 
       }
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        if (oy0 + j < a.h) reinterpret_cast<uint32_t *>(dst + (size_t)(oy0 + j) * a.orow)[ox] = px[j];
+        if (oy0 + j < a.h) __builtin_nontemporal_store(px[j], reinterpret_cast<uint32_t *>(dst + (size_t)(oy0 + j) * a.orow) + ox);      // written once, not read back
     }
   }
 }
