@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(kH8sThreads, 3) void k_half8s(Half8Args a, SepTrack
 // 16-byte chunk is inside or outside as a whole).  The BGRA byte swap moves from staging into the horizontal pass's selectors.
 // =====================================================================================================================
 constexpr int kS2pMhCW = 4;       // 8 compute waves per workgroup measured 36 us against 24 for 4K -> 720p: two 10-wave workgroups do not run concurrently on a CU
-constexpr int kS2pMaxReq = 48, kS2pMaxNpv = 8;       // compute waves per workgroup: template parameter CW (4 for the dot2 pass, 8 for the matrix-core pass), + 2 memory waves
+constexpr int kS2pMaxReq = 48, kS2pMaxNpv = 12;       // compute waves per workgroup: template parameter CW (4 for the dot2 pass, 8 for the matrix-core pass), + 2 memory waves
 struct S2pTile {
   int track, tx0, ty0;
   __device__ __forceinline__ void set(const SepArgs &a, int work) {
@@ -2022,10 +2022,11 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
       LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
     hipLaunchKernelGGL((k_sep2<N>), p.grid, blk, p.lds, st, p.a, t, l);                                      \
   } while (0)
+  if (getenv("LGPU_PLAN_DEBUG")) fprintf(stderr, "plan: %dx%d -> %dx%d variant %d lds %zu th %d sht %d swt %d | pers %d vec %d mh_r %d p_th %d p_sht %d p_lds %zu npv %d nth %d\n", p.a.sw, p.a.sh, p.a.dw, p.a.dh, p.variant, p.lds, p.a.th, p.a.sht, p.a.swt, (int)p.pers, p.a.vec, p.mh_r, p.p_th, p.p_sht, p.p_lds, p.a.npv, p.a.nth);
   const bool s2p_force = getenv("LGPU_SEP2P_FORCE") != nullptr;          // tests: the persistent kernel on small frames
   // k_sep2p pays when a workgroup gets a few tiles to pipeline and the windows are the heavy part (shrinking); measured in profiles/r02/resize_ratios.md
   if (p.pers && p.a.vec && p.variant >= 100 &&
-      (s2p_force || p.mh_r || (p.a.dh < p.a.sh && (long)p.a.tiles_x * p.p_tiles_y * (long)p.grid.y >= 3L * 512))) {
+      (s2p_force || (p.p_th >= 4 && (p.mh_r || (p.a.dh < p.a.sh && (long)p.a.tiles_x * p.p_tiles_y * (long)p.grid.y >= 3L * 512))))) {      // 2-row tiles (4:1: 498 against 470 us for 16 x 4K -> 960 x 540) lose to k_sep2
     SepArgs ap = p.a;
     ap.th = p.p_th; ap.sht = p.p_sht; ap.tiles_y = p.p_tiles_y; ap.ntracks = (int)p.grid.y;
     ap.bfrag = nullptr; ap.mh_r = p.mh_r;

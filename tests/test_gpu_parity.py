@@ -870,7 +870,7 @@ def test_resize_persistent_kernel(gpu, orc, monkeypatch):
     rng = np.random.default_rng(1050)
     cases = [(384, 216, 128, 72, 3), (256, 144, 512, 288, 3), (192, 108, 128, 72, 3), (640, 360, 212, 120, 3), (128, 64, 64, 32, 2), (400, 300, 100, 75, 3),
              (1920, 1080, 1280, 720, 3), (1280, 720, 1920, 1080, 3), (3840, 2160, 1280, 720, 3), (64, 32, 128, 64, 3), (100, 60, 36, 24, 3), (16, 16, 4, 4, 3),
-             (3840, 40, 480, 8, 3), (64, 2160, 16, 720, 2)]
+             (3840, 40, 480, 8, 3), (64, 2160, 16, 720, 2), (3840, 2160, 960, 540, 3), (1920, 1080, 480, 270, 3)]
     for (sw, sh, dw, dh, interp) in cases:
         src = frame(rng, sw, sh, 4)
         want = np.zeros((dh, align(dw * 4)), np.uint8)
