@@ -113,16 +113,37 @@ bool read_layer(weed_plant_t *plant, Layer *l) {
 // Streams: every host thread enqueues on a stream of its own (LiVES runs plan steps and conversions on pool threads, src/threading.c; one shared
 // stream would run the small kernels of different tracks one after the other).  Non-blocking streams: a launch on a blocking one costs twice the host
 // time (ordering against the null stream is checked per launch).  livesgpu_fx.so enqueues on the same per-thread streams (lives_gpu_resident_acquire /
-// _release); a caller on the null stream is ordered at its hand-over (lives_gpu_resident_lookup) like any other stream.  Never destroyed: a thread_local destructor of the main thread runs after HIP's teardown.
-thread_local void *t_stream = nullptr;
-thread_local bool t_stream_tried = false;
-void *S() {
-  if (!t_stream_tried) {
-    t_stream_tried = true;
-    if (lgpu_stream_create(&t_stream, 1) != LGPU_OK) t_stream = nullptr;        // the null stream then: everything is ordered, nothing overlaps
+// _release); a caller on the null stream is ordered at its hand-over (lives_gpu_resident_lookup) like any other stream.  Never destroyed (a thread_local destructor of the main thread runs after HIP's teardown), but recycled:
+// A thread that ends hands its stream (and its hand-over event) to a spare list, and a new thread takes one from there before it creates one: a host that
+// runs short-lived threads does not pile up streams.  No HIP call in the destructor (it may run after HIP's teardown); the list itself is never destroyed.
+struct SpareGpuObjects { std::atomic<bool> held{false}; std::vector<void *> streams, events; };
+SpareGpuObjects &spares() { static SpareGpuObjects *p = new SpareGpuObjects; return *p; }
+struct ThreadGpu {
+  void *stream = nullptr, *event = nullptr;
+  bool tried = false;
+  ~ThreadGpu() {
+    if (!stream && !event) return;
+    SpareGpuObjects &sp = spares();
+    while (sp.held.exchange(true, std::memory_order_acquire)) sched_yield();
+    if (stream) sp.streams.push_back(stream);
+    if (event) sp.events.push_back(event);
+    sp.held.store(false, std::memory_order_release);
   }
-  return t_stream;
+};
+thread_local ThreadGpu t_gpu;
+void *S() {
+  if (!t_gpu.tried) {
+    t_gpu.tried = true;
+    SpareGpuObjects &sp = spares();
+    while (sp.held.exchange(true, std::memory_order_acquire)) sched_yield();
+    if (!sp.streams.empty()) { t_gpu.stream = sp.streams.back(); sp.streams.pop_back(); }
+    if (!sp.events.empty()) { t_gpu.event = sp.events.back(); sp.events.pop_back(); }
+    sp.held.store(false, std::memory_order_release);
+    if (!t_gpu.stream && lgpu_stream_create(&t_gpu.stream, 1) != LGPU_OK) t_gpu.stream = nullptr;     // the null stream then: everything is ordered, nothing overlaps
+  }
+  return t_gpu.stream;
 }
+#define t_event (t_gpu.event)
 
 // A device buffer and the stream its last use was enqueued on.  Ownership of a resident plane moves from call to call; a call on ANOTHER thread's
 // stream orders itself behind the previous owner by recording an event on that stream at the moment of the hand-over (everything enqueued there
@@ -149,7 +170,7 @@ SpinLock g_res_mu;                                // guards g_res, g_pool and th
 std::unordered_map<const void *, Dev> g_res;      // resident planes by HOST plane pointer
 std::atomic<unsigned long long> g_h2d{0}, g_d2h{0};   // PCIe byte counters (tests check the residency contract with them)
 thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
-thread_local void *t_event = nullptr;           // this thread's hand-over event (re-recorded at every hand-over; a wait holds the record it saw)
+// t_gpu.event: this thread's hand-over event (re-recorded at every hand-over; a wait holds the record it saw)
 
 // No HIP call is made under g_res_mu: the functions below copy what they need out of the tables and do the stream work afterwards.
 // The calling thread's stream waits for everything enqueued so far on the stream of the buffer's last use, if that is another stream.
@@ -327,11 +348,25 @@ void commit_planes(weed_plant_t *plant, int pal, int width, int height, const Ne
 }
 
 // ---- device scratch (per calling thread; grown on demand) ------------------------------------------------------------
-// Not freed at thread exit: a thread_local destructor of the main thread runs after the HIP runtime has been torn down.
+// A thread that ends leaves its buffers on a spare list (no HIP call in a thread_local destructor: the main thread's runs after HIP's teardown) and the next
+// new thread starts from them.
+struct ScratchSet { void *p[8]; size_t cap[8]; };
+struct SpareScratch { std::mutex mu; std::vector<ScratchSet> sets; };
+SpareScratch &spare_scratch() { static SpareScratch *sp = new SpareScratch; return *sp; }
 struct Scratch {
   void *p[8] = {nullptr};
   size_t cap[8] = {0};
+  bool adopted = false;
   uint8_t *get(int i, size_t bytes) {
+    if (!adopted) {
+      adopted = true;
+      SpareScratch &sp = spare_scratch();
+      std::lock_guard<std::mutex> lk(sp.mu);
+      if (!sp.sets.empty()) {
+        for (int k = 0; k < 8; k++) { p[k] = sp.sets.back().p[k]; cap[k] = sp.sets.back().cap[k]; }
+        sp.sets.pop_back();
+      }
+    }
     if (cap[i] < bytes) {
       if (p[i]) lgpu_free(p[i]);
       p[i] = nullptr; cap[i] = 0;
@@ -339,6 +374,16 @@ struct Scratch {
       cap[i] = bytes;
     }
     return (uint8_t *)p[i];
+  }
+  ~Scratch() {
+    bool any = false;
+    for (int k = 0; k < 8; k++) any = any || p[k];
+    if (!any) return;
+    SpareScratch &sp = spare_scratch();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    ScratchSet st;
+    for (int k = 0; k < 8; k++) { st.p[k] = p[k]; st.cap[k] = cap[k]; }
+    sp.sets.push_back(st);
   }
 };
 thread_local Scratch t_scr;

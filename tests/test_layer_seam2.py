@@ -557,3 +557,36 @@ def test_every_filter_class_on_pinned_planes(seam):
         assert (views[0][:, :w * ps] == plain[0][:, :w * ps]).all(), f["name"]
         ran += 1
     assert ran >= 20, ran
+
+
+def test_short_lived_threads_do_not_pile_up_device_objects(seam):
+    """a host that makes its seam calls from threads that come and go: a finished thread's stream, staging chunks and device scratch go to spare lists and the
+    next new thread starts from them -- 300 threads one after the other, each with an un-pinned and a pinned call, leave the device's free memory where it was"""
+    import threading
+    import torch
+    L, wh = seam
+    w, h = 640, 360
+    rng = np.random.default_rng(9)
+    src = frame(rng, w, h, 4)
+
+    def one():
+        a = wh.new_layer(RGBA32, w, h, [src], gamma=1)
+        assert L.lives_gpu_convert_layer_palette(a, BGR24, 0) == 1
+        b = wh.new_layer(RGBA32, w, h, [src], gamma=1)
+        assert L.lives_gpu_layer_pin(b) == 0 and L.lives_gpu_convert_layer_palette(b, BGR24, 0) == 1 and L.lives_gpu_layer_unpin(b) == 0
+        assert (wh.planes_of(a)[0][0] == wh.planes_of(b)[0][0]).all()
+
+    def run(n):
+        errs = []
+        for _ in range(n):
+            t = threading.Thread(target=lambda: (one(), None) if True else None)
+            t.start(); t.join()
+        return errs
+
+    run(20)                                              # warm: pools, spare lists
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    run(300)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), "device memory shrank by %d MB over 300 short-lived threads" % ((free0 - free1) >> 20)
