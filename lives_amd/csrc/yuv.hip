@@ -136,18 +136,47 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut, 
   if (batched) { a.y = bt.y[blockIdx.z]; a.u = bt.u[blockIdx.z]; a.v = bt.v[blockIdx.z]; a.dst = bt.dst[blockIdx.z]; }
   __shared__ int32_t s_tab[5 * 256];
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  const int hw = a.width >> 1;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  const int npairs = (a.height - 1) / 2;                      // number of full row pairs starting at row 1
+  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
+  // A single 1080p frame is one cell per lane: the workgroup's 5 KB of tables and the cell's fifteen samples are both a memory latency away.  The samples of the
+  // first cell are requested BEFORE the tables are staged (interior cells of a row pair only -- everything else walks yuv420_cell as before), so the two
+  // latencies overlap instead of adding up.
+  const int unit0 = blockIdx.y;
+  const int i0 = 2 * unit0 - 1, r0 = i0 >> 1;
+  const bool pre = k >= 1 && k + 1 < hw && unit0 >= 1 && unit0 <= npairs && (long)(r0 + 1) * a.us + k + 2 <= a.usize && (long)(r0 + 1) * a.vs + k + 2 <= a.vsize;
+  int py00 = 0, py01 = 0, py10 = 0, py11 = 0, u_l = 0, u_c = 0, u_n = 0, u1_c = 0, u1_n = 0, v_c = 0, v_n = 0, v1_l = 0, v1_c = 0, v1_n = 0, v1_0 = 0;
+  if (pre) {
+    const uint8_t *y0 = a.y + (size_t)i0 * a.ys + 2 * k, *y1 = y0 + a.ys;
+    const uint8_t *ur = a.u + (size_t)r0 * a.us + k, *vr = a.v + (size_t)r0 * a.vs + k;
+    py00 = y0[0]; py01 = y0[1]; py10 = y1[0]; py11 = y1[1];
+    u_l = ur[-1]; u_c = ur[0]; u_n = ur[1]; u1_c = ur[a.us]; u1_n = ur[a.us + 1];
+    v_c = vr[0]; v_n = vr[1]; v1_l = vr[a.vs - 1]; v1_c = vr[a.vs]; v1_n = vr[a.vs + 1]; v1_0 = a.v[(size_t)(r0 + 1) * a.vs];
+  }
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
   stage_lut(s_lut, lut);
   __syncthreads();
   YuvCtx c;
   c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
   c.lut = s_lut; c.lut16 = a.lut16; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
-  const int hw = a.width >> 1;
-  const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= hw) return;
-  const int npairs = (a.height - 1) / 2;                      // number of full row pairs starting at row 1
-  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
-  for (int unit = blockIdx.y; unit < nunits; unit += gridDim.y) yuv420_cell(a, c, unit, k, hw, npairs);
+  int unit = unit0;
+  if (pre) {
+    // the row-pair branch of yuv420_cell on the samples already here (same expressions, :3445-3554)
+    uint8_t *d0 = a.dst + (size_t)i0 * a.orow + (size_t)(2 * k) * a.opsize, *d1 = d0 + a.orow;
+    int ut, ub, vt, vb;
+    c.vblend(u_c + u_l, u_c + u_l, ut, ub);
+    c.vblend(v_c + v1_l, v1_c + v1_0, vt, vb);
+    const uint32_t a0 = c.rgb(py00, ut, vt), b0 = c.rgb(py10, ub, vb);
+    c.vblend(u_c + u_n, u1_c + u1_n, ut, ub);
+    c.vblend(v_c + v_n, v1_c + v1_n, vt, vb);
+    const uint32_t a1 = c.rgb(py01, ut, vt), b1 = c.rgb(py11, ub, vb);
+    c.store2(d0, a0, a1);
+    c.store2(d1, b0, b1);
+    unit += gridDim.y;
+  }
+  for (; unit < nunits; unit += gridDim.y) yuv420_cell(a, c, unit, k, hw, npairs);
 }
 
 // The same walk with one lane per FOUR chroma columns (8 x 2 pixels of a row pair): the quad's luma comes in as two 8-byte loads and
