@@ -597,7 +597,8 @@ struct RepackArgs {
 };
 
 __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
-  cavg_init();
+  // the chroma-average table costs a workgroup a round of LDS writes and a barrier: only the kinds that average build it (kernel-uniform)
+  if (a.kind > RK_420_TO_PK) cavg_init();              // RK_COMBINE .. RK_420_TO_PK are permutations
   const int mx = blockIdx.x * kBlock + threadIdx.x;         // macropixel column
   const int mw = ((a.copy_w > a.width ? a.copy_w : a.width) + 1) >> 1;
   if (mx >= mw) return;
@@ -610,6 +611,31 @@ __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
     case RK_COMBINE: {
       const int ops = a.out_alpha ? 4 : 3;
       uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)x0 * ops;
+      if (a.out_alpha && two && ((uintptr_t)d & 7) == 0) {        // two YUVA pixels = one 8-byte store
+        const size_t si = (size_t)y * a.irow[0] + x0;
+        const uint32_t a0 = a.in_alpha ? a.src[3][(size_t)y * a.width + x0] : 255u, a1 = a.in_alpha ? a.src[3][(size_t)y * a.width + x0 + 1] : 255u;
+        const uint32_t p0 = a.src[0][si] | ((uint32_t)a.src[1][si] << 8) | ((uint32_t)a.src[2][si] << 16) | (a0 << 24);
+        const uint32_t p1 = a.src[0][si + 1] | ((uint32_t)a.src[1][si + 1] << 8) | ((uint32_t)a.src[2][si + 1] << 16) | (a1 << 24);
+        *reinterpret_cast<uint2 *>(d) = make_uint2(p0, p1);
+        break;
+      }
+      if (!a.out_alpha) {
+        // four pixels at a time on the even lanes (3 dword loads, 3 dword stores instead of 12 + 12 byte accesses on two lanes) where rows and pointers allow it
+        const int xq = x0 & ~3;
+        const bool quad = xq + 3 < a.width && (a.irow[0] & 3) == 0 && (a.orow[0] & 3) == 0 &&
+                          ((((uintptr_t)a.src[0] | (uintptr_t)a.src[1] | (uintptr_t)a.src[2] | (uintptr_t)a.dst[0]) & 3) == 0);
+        if (quad) {
+          if (mx & 1) break;                                   // the even lane of the pair does all four
+          const size_t si = (size_t)y * a.irow[0] + xq;
+          const uint32_t Y4 = *reinterpret_cast<const uint32_t *>(a.src[0] + si), U4 = *reinterpret_cast<const uint32_t *>(a.src[1] + si), V4 = *reinterpret_cast<const uint32_t *>(a.src[2] + si);
+          uint32_t *dq = reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + (size_t)xq * 3);
+          // bytes out: Y0 U0 V0 Y1 | U1 V1 Y2 U2 | V2 Y3 U3 V3
+          dq[0] = (Y4 & 0xFF) | ((U4 & 0xFF) << 8) | ((V4 & 0xFF) << 16) | ((Y4 & 0xFF00) << 16);
+          dq[1] = ((U4 >> 8) & 0xFF) | (V4 & 0xFF00) | (Y4 & 0xFF0000) | ((U4 & 0xFF0000) << 8);
+          dq[2] = ((V4 >> 16) & 0xFF) | ((Y4 >> 16) & 0xFF00) | ((U4 >> 8) & 0xFF0000) | (V4 & 0xFF000000u);
+          break;
+        }
+      }
       for (int k = 0; k < (two ? 2 : 1); k++) {
         const size_t si = (size_t)y * a.irow[0] + x0 + k;
         d[k * ops] = a.src[0][si]; d[k * ops + 1] = a.src[1][si]; d[k * ops + 2] = a.src[2][si];
@@ -640,8 +666,10 @@ __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
       const uint8_t *sy = a.src[0] + (size_t)y * a.irow[0] + x0;
       const uint8_t u = a.src[1][(size_t)(y >> 1) * a.irow[1] + mx], v = a.src[2][(size_t)(y >> 1) * a.irow[2] + mx];
       uint8_t *d = a.dst[0] + (size_t)y * (size_t)((a.orow[0] / 4) * 4) + 4 * (size_t)mx;
-      if (a.yuyv_out) { d[0] = sy[0]; d[1] = u; d[2] = sy[1]; d[3] = v; }
-      else { d[0] = u; d[1] = sy[0]; d[2] = v; d[3] = sy[1]; }
+      const uint32_t y0_ = sy[0], y1_ = sy[1];
+      const uint32_t mp = a.yuyv_out ? (y0_ | ((uint32_t)u << 8) | (y1_ << 16) | ((uint32_t)v << 24)) : ((uint32_t)u | (y0_ << 8) | ((uint32_t)v << 16) | (y1_ << 24));
+      if (((uintptr_t)d & 3) == 0) *reinterpret_cast<uint32_t *>(d) = mp;                  // one macropixel = one dword store instead of four byte stores
+      else { d[0] = (uint8_t)mp; d[1] = (uint8_t)(mp >> 8); d[2] = (uint8_t)(mp >> 16); d[3] = (uint8_t)(mp >> 24); }
       break;
     }
     case RK_420_TO_422P: {
