@@ -167,22 +167,31 @@ __device__ __forceinline__ uint32_t premult_byte(uint32_t v, float ratio, bool u
   const double d = (double)a;
   return d >= 254.5 ? 255u : d < -0.5 ? 0u : (uint32_t)(int)(d + .5);
 }
+__device__ __forceinline__ uint32_t premult_pixel(uint32_t p, int alpha_first, int un, const float *s_ratio) {
+  const uint32_t al = alpha_first ? (p & 0xFF) : (p >> 24);
+  const float ratio = s_ratio[al];                 // 255.f / alpha, the correctly rounded quotient, from the workgroup's table instead of a division per pixel
+  if (alpha_first)
+    return al | (premult_byte((p >> 8) & 0xFF, ratio, un) << 8) | (premult_byte((p >> 16) & 0xFF, ratio, un) << 16) | (premult_byte(p >> 24, ratio, un) << 24);
+  return premult_byte(p & 0xFF, ratio, un) | (premult_byte((p >> 8) & 0xFF, ratio, un) << 8) | (premult_byte((p >> 16) & 0xFF, ratio, un) << 16) | (al << 24);
+}
+// VEC: four pixels per lane, 16-byte loads and stores (rows and base 16-byte aligned, decided on the host)
+template <bool VEC>
 __global__ __launch_bounds__(kBlock) void k_premult(uint8_t *pix, int rowstride, int width, int height, int alpha_first, int un) {
-  const int x = blockIdx.x * kBlock + threadIdx.x;
+  __shared__ float s_ratio[256];
+  for (int i = threadIdx.x; i < 256; i += kBlock) s_ratio[i] = __fdiv_rn(255.f, (float)i);
+  __syncthreads();
+  const int x = (blockIdx.x * kBlock + threadIdx.x) * (VEC ? 4 : 1);
   if (x >= width) return;
   for (int y = blockIdx.y; y < height; y += gridDim.y) {
     uint32_t *pp = reinterpret_cast<uint32_t *>(pix + (size_t)y * rowstride) + x;
-    const uint32_t p = *pp;
-    const uint32_t al = alpha_first ? (p & 0xFF) : (p >> 24);
-    const float ratio = __fdiv_rn(255.f, (float)al);
-    uint32_t o;
-    if (alpha_first)
-      o = al | (premult_byte((p >> 8) & 0xFF, ratio, un) << 8) | (premult_byte((p >> 16) & 0xFF, ratio, un) << 16) |
-          (premult_byte(p >> 24, ratio, un) << 24);
-    else
-      o = premult_byte(p & 0xFF, ratio, un) | (premult_byte((p >> 8) & 0xFF, ratio, un) << 8) |
-          (premult_byte((p >> 16) & 0xFF, ratio, un) << 16) | (al << 24);
-    *pp = o;
+    if (VEC && x + 4 <= width) {
+      uint4 v = *reinterpret_cast<const uint4 *>(pp);
+      v.x = premult_pixel(v.x, alpha_first, un, s_ratio); v.y = premult_pixel(v.y, alpha_first, un, s_ratio);
+      v.z = premult_pixel(v.z, alpha_first, un, s_ratio); v.w = premult_pixel(v.w, alpha_first, un, s_ratio);
+      *reinterpret_cast<uint4 *>(pp) = v;
+    } else {
+      for (int k = 0; k < (VEC ? 4 : 1) && x + k < width; k++) pp[k] = premult_pixel(pp[k], alpha_first, un, s_ratio);
+    }
   }
 }
 
@@ -340,8 +349,10 @@ extern "C" int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int 
   if (rc) return rc;
   LGPU_REQUIRE(pix_d && width > 0 && height > 0 && rowstride >= width * 4, "bad geometry");
   LGPU_REQUIRE((((uintptr_t)pix_d | (uintptr_t)rowstride) & 3) == 0, "4-byte pixels must be 4-byte aligned");
-  hipLaunchKernelGGL(k_premult, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width,
-                     height, alpha_first, un);
+  if ((((uintptr_t)pix_d | (uintptr_t)rowstride) & 15) == 0)
+    hipLaunchKernelGGL(k_premult<true>, row_grid((unsigned)((width + 3) >> 2), height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width, height, alpha_first, un);
+  else
+    hipLaunchKernelGGL(k_premult<false>, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width, height, alpha_first, un);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
