@@ -77,9 +77,28 @@ __device__ __forceinline__ void load_rgb(const uint8_t *p, int order, int &r, in
   else { r = p[1]; g = p[2]; b = p[3]; }
 }
 
+// a pair of neighbouring pixels: one 8-byte load when they are 4-byte pixels at an 8-byte aligned address (the usual RGBA32 / BGRA32 / ARGB32 row), byte loads otherwise
+__device__ __forceinline__ void load_rgb_pair(const uint8_t *s, int ips, int order, int &r0, int &g0, int &b0, int &r1, int &g1, int &b1) {
+  if (ips == 4 && (reinterpret_cast<uintptr_t>(s) & 7) == 0) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(s);
+    const int sh = order == 2 ? 8 : 0;                     // ARGB: colours in bytes 1..3
+    const int c0a = (v.x >> sh) & 0xFF, c1a = (v.x >> (sh + 8)) & 0xFF, c2a = (v.x >> (sh + 16)) & 0xFF;
+    const int c0b = (v.y >> sh) & 0xFF, c1b = (v.y >> (sh + 8)) & 0xFF, c2b = (v.y >> (sh + 16)) & 0xFF;
+    if (order == 1) { r0 = c2a; g0 = c1a; b0 = c0a; r1 = c2b; g1 = c1b; b1 = c0b; }
+    else { r0 = c0a; g0 = c1a; b0 = c2a; r1 = c0b; g1 = c1b; b1 = c2b; }
+    return;
+  }
+  load_rgb(s, order, r0, g0, b0);
+  load_rgb(s + ips, order, r1, g1, b1);
+}
+__device__ __forceinline__ void store_y_pair(uint8_t *dy, int y0, int y1) {
+  if ((reinterpret_cast<uintptr_t>(dy) & 1) == 0) *reinterpret_cast<uint16_t *>(dy) = (uint16_t)((y0 & 0xFF) | ((y1 & 0xFF) << 8));
+  else { dy[0] = (uint8_t)y0; dy[1] = (uint8_t)y1; }
+}
+
 template <int ORDER, int FMT>
 __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
-  cavg_init();
+  if (FMT == 4) cavg_init();                              // only the 4:2:0 walk averages
   __shared__ int32_t s_t[9 * 256];
   for (int i = threadIdx.x; i < 9 * 256; i += kBlock) s_t[i] = a.tables[i];
   __syncthreads();
@@ -103,17 +122,14 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
       for (int j = 0; j < 2; j++) {
         const uint8_t *s = a.src[0] + (size_t)(2 * k + j) * a.irow[0] + (size_t)x * ips;
         int r0, g0, b0, r1, g1, b1;
-        load_rgb(s, ORDER, r0, g0, b0);
-        load_rgb(s + ips, ORDER, r1, g1, b1);
-        uint8_t *dy = a.dst[0] + (size_t)(2 * k + j) * a.orow[0] + x;
-        dy[0] = (uint8_t)c.Y(r0, g0, b0); dy[1] = (uint8_t)c.Y(r1, g1, b1);
+        load_rgb_pair(s, ips, ORDER, r0, g0, b0, r1, g1, b1);
+        store_y_pair(a.dst[0] + (size_t)(2 * k + j) * a.orow[0] + x, c.Y(r0, g0, b0), c.Y(r1, g1, b1));
         if (j == 1) { cu1 = c.cuv(c.Uraw(r0, g0, b0)); cv1 = c.cuv(c.Vraw(r1, g1, b1)); }
       }
       if (2 * k + 2 < a.height) {
         const uint8_t *s = a.src[0] + (size_t)(2 * k + 2) * a.irow[0] + (size_t)x * ips;
         int r0, g0, b0, r1, g1, b1;
-        load_rgb(s, ORDER, r0, g0, b0);
-        load_rgb(s + ips, ORDER, r1, g1, b1);
+        load_rgb_pair(s, ips, ORDER, r0, g0, b0, r1, g1, b1);
         cu1 = cavg(!a.unclamped, c.cuv(c.Uraw(r0, g0, b0)), cu1);
         cv1 = cavg(!a.unclamped, c.cuv(c.Vraw(r1, g1, b1)), cv1);
       }
@@ -124,8 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
     const int y = yy;
     const uint8_t *s = a.src[0] + (size_t)y * a.irow[0] + (size_t)x * ips;
     int r0, g0, b0, r1, g1, b1;
-    load_rgb(s, ORDER, r0, g0, b0);
-    load_rgb(s + ips, ORDER, r1, g1, b1);
+    load_rgb_pair(s, ips, ORDER, r0, g0, b0, r1, g1, b1);
     if ((FMT == 2 || FMT == 3) && a.lut16) {
       // the gamma twins clamp properly in both byte orders (rgb2yuyv_with_gamma :2194-2207 has the `else` rgb2yuyv lost)
       const uint32_t gy0 = (uint32_t)c.Yg(a.lut16, r0, g0, b0), gy1 = (uint32_t)c.Yg(a.lut16, r1, g1, b1);
@@ -162,8 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
         const uint32_t u = (uint32_t)(ur < c.min_uv ? c.min_uv : ur) & 0xFF, v = (uint32_t)(vr < c.min_uv ? c.min_uv : vr) & 0xFF;
         *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + (size_t)px * 4) = (uint32_t)y0 | (u << 8) | ((uint32_t)y1 << 16) | (v << 24);
       } else {       // 4:2:2 planar
-        uint8_t *dy = a.dst[0] + (size_t)y * a.orow[0] + x;
-        dy[0] = (uint8_t)y0; dy[1] = (uint8_t)y1;
+        store_y_pair(a.dst[0] + (size_t)y * a.orow[0] + x, y0, y1);
         a.dst[1][(size_t)y * a.orow[1] + px] = (uint8_t)c.cuv(ur);
         a.dst[2][(size_t)y * a.orow[2] + px] = (uint8_t)c.cuv(vr);
       }
