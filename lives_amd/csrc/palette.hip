@@ -190,6 +190,11 @@ __device__ __forceinline__ void put_rgb(uint8_t *d, int order, int ops, const in
   // yuv2rgb_int (:2345-2349): CLAMP0255f(spc_rnd(RGB_Y[y] + R_Cr[v])) ...
   const int32_t yy = t[Y];
   const int r = clamp255((yy + t[256 + V]) >> 16), g = clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = clamp255((yy + t[1024 + U]) >> 16);
+  if (ops == 4 && (reinterpret_cast<uintptr_t>(d) & 3) == 0) {           // a 4-byte pixel at a 4-byte aligned address: one store
+    const uint32_t R = (uint32_t)r, G = (uint32_t)g, B = (uint32_t)b, AA = (uint32_t)A & 0xFF;
+    *reinterpret_cast<uint32_t *>(d) = order == 0 ? (R | (G << 8) | (B << 16) | (AA << 24)) : order == 1 ? (B | (G << 8) | (R << 16) | (AA << 24)) : (AA | (R << 8) | (G << 16) | (B << 24));
+    return;
+  }
   if (order == 0) { d[0] = (uint8_t)r; d[1] = (uint8_t)g; d[2] = (uint8_t)b; if (ops == 4) d[3] = (uint8_t)A; }
   else if (order == 1) { d[0] = (uint8_t)b; d[1] = (uint8_t)g; d[2] = (uint8_t)r; if (ops == 4) d[3] = (uint8_t)A; }
   else { d[0] = (uint8_t)A; d[1] = (uint8_t)r; d[2] = (uint8_t)g; d[3] = (uint8_t)b; }
