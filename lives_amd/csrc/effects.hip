@@ -613,6 +613,10 @@ __global__ __launch_bounds__(kBlock) void k_slide_over(SlideArgs a) {
     const bool from2 = lo ? a.first2 : !a.first2;
     const uint8_t *from = from2 ? a.src2 + (size_t)a.irow2 * sy + (size_t)sx * PS : a.src1 + (size_t)a.irow1 * sy + (size_t)sx * PS;
     uint8_t *d = a.dst + (size_t)a.orow * y + (size_t)x * PS;
+    if (PS == 4 && ((reinterpret_cast<uintptr_t>(from) | reinterpret_cast<uintptr_t>(d)) & 3) == 0) {      // a 4-byte pixel: one load, one store
+      *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(from);
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < PS; k++) d[k] = from[k];
   }
