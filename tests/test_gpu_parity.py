@@ -1306,3 +1306,44 @@ def test_stream_ordered_allocation():
     L.lgpu_debug_fail_alloc(0)
     assert rc == -5 and not p.value
     assert L.lgpu_malloc_ordered(ctypes.byref(p), 4096, None) == 0 and L.lgpu_free_ordered(p, None) == 0
+
+
+@pytest.mark.gpu
+def test_entry_points_run_on_the_stream_they_are_given(gpu):
+    """every frame-level entry point takes a stream: work given to a side stream must be complete when THAT stream has been synchronised (nothing may have been
+    launched on the null stream instead) and must equal the same calls on the null stream.  A large fill keeps the side stream busy first, so a kernel that went to
+    another stream would overtake it and be visible as a mismatch; the ops with internal scratch (3-byte resize, the blur chain, gauss5, K2) are the ones that matter."""
+    import torch
+    rng = np.random.default_rng(4711)
+    sw, sh, dw, dh = 640, 360, 320, 180
+    src4, src3 = dev(frame(rng, sw, sh, 4)), dev(frame(rng, sw, sh, 3))
+    l2 = dev(frame(rng, dw, dh, 4, alpha_mix=True))
+    Y = dev(rng.integers(16, 236, (sh, sw), dtype=np.uint8)); U = dev(rng.integers(16, 241, (sh // 2, sw // 2), dtype=np.uint8)); V = dev(rng.integers(16, 241, (sh // 2, sw // 2), dtype=np.uint8))
+    lut = np.arange(255, -1, -1, dtype=np.uint8)
+    big = torch.zeros(512 << 20, dtype=torch.uint8, device="cuda")
+
+    def run_all():
+        outs = []
+        o = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda"); gpu.resize(src4, o, sw, sh, dw, dh, psize=4, interp=3); outs.append(o)
+        o = torch.zeros((dh, align(dw * 3)), dtype=torch.uint8, device="cuda"); gpu.resize(src3, o, sw, sh, dw, dh, psize=3, interp=3); outs.append(o)
+        o = torch.zeros((200, 300 * 4), dtype=torch.uint8, device="cuda"); gpu.resize(src4, o, sw, sh, 300, 200, psize=4, interp=2); outs.append(o)
+        o = torch.zeros_like(src4); gpu.gauss5(src4, o, sw, sh, psize=4); outs.append(o)
+        o = torch.zeros((sh, sw * 4), dtype=torch.uint8, device="cuda"); gpu.yuv420p_to_rgb(Y, U, V, o, sw, sh, lut=lut); outs.append(o)
+        for blur in (0, 1):
+            o = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda")
+            prm = gpu.chain_params(sw, sh, src4.stride(0), dw, dh, l2.stride(0), dw * 4, swap_rb=1, interp=3, do_blur=blur, bf=77, lut=lut)
+            gpu.chain(prm, gpu.chain_tracks([src4], [l2], [o])); outs.append(o)
+        o = torch.zeros_like(src4); gpu.mirror(2, src4, o, sw, sh, 4); outs.append(o)
+        return outs
+
+    want = run_all()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            big.fill_(1)                                   # ~0.4 ms of work in front on the side stream
+        got = run_all()
+    side.synchronize()                                     # this stream only
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()
