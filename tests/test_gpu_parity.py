@@ -1334,6 +1334,11 @@ def test_entry_points_run_on_the_stream_they_are_given(gpu):
             prm = gpu.chain_params(sw, sh, src4.stride(0), dw, dh, l2.stride(0), dw * 4, swap_rb=1, interp=3, do_blur=blur, bf=77, lut=lut)
             gpu.chain(prm, gpu.chain_tracks([src4], [l2], [o])); outs.append(o)
         o = torch.zeros_like(src4); gpu.mirror(2, src4, o, sw, sh, 4); outs.append(o)
+        # effects with device state of their own (edge: map + histogram scratch per stream; deinterlace: snapshot per stream for in-place calls)
+        o = torch.zeros_like(src4); gpu.edge(src4, o, sw, sh, 3, 0); outs.append(o)
+        o = src4.clone(); gpu.deinterlace(o, o, 636, sh, 3); outs.append(o)          # the reference wants width % 3 == 0 here
+        o = torch.zeros_like(src4); gpu.blend_chroma(src4, src4.flip(0).contiguous(), o, sw, sh, 4, 99); outs.append(o)
+        o = torch.zeros_like(src4); gpu.slide_over(src4, src4.flip(0).contiguous(), o, sw, sh, 4, 0.4, 2); outs.append(o)
         return outs
 
     want = run_all()
