@@ -1352,3 +1352,27 @@ def test_entry_points_run_on_the_stream_they_are_given(gpu):
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("psize", [1, 3, 4])
+def test_letterbox_bars_paint_everything_but_the_inner_frame(gpu, psize):
+    """lgpu_letterbox_bars (what letterbox_layer uses when the scaler writes the inner frame straight into the canvas): black outside the rectangle, not one byte inside,
+    row padding untouched; odd offsets and sizes, rectangles that touch the canvas edges"""
+    from lives_amd import lib
+    import torch
+    rng = np.random.default_rng(60 + psize)
+    black = {1: [16, 0, 0, 0], 3: [1, 2, 3, 0], 4: [0, 0, 0, 255]}[psize]
+    for (nw, nh, ox, oy, w, h) in ((96, 64, 10, 7, 50, 33), (64, 48, 0, 6, 64, 36), (61, 37, 5, 0, 51, 37), (40, 40, 0, 0, 40, 40), (33, 9, 32, 8, 1, 1)):
+        canvas = frame(rng, nw, nh, psize)
+        want = canvas.copy()
+        px = np.array(black[:psize], np.uint8)
+        for y in range(nh):
+            for x in range(nw):
+                if not (oy <= y < oy + h and ox <= x < ox + w):
+                    want[y, x * psize:(x + 1) * psize] = px
+        d = dev(canvas)
+        b = (ctypes.c_uint8 * 4)(*black)
+        lib.call("lgpu_letterbox_bars", d.data_ptr(), d.stride(0), nw, nh, psize, b, ox, oy, w, h, None)
+        torch.cuda.synchronize()
+        assert (host(d) == want).all(), (psize, nw, nh, ox, oy, w, h)
