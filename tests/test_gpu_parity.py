@@ -1376,3 +1376,28 @@ def test_letterbox_bars_paint_everything_but_the_inner_frame(gpu, psize):
         lib.call("lgpu_letterbox_bars", d.data_ptr(), d.stride(0), nw, nh, psize, b, ox, oy, w, h, None)
         torch.cuda.synchronize()
         assert (host(d) == want).all(), (psize, nw, nh, ox, oy, w, h)
+
+
+@pytest.mark.gpu
+def test_stream_and_event_entry_points():
+    """lgpu_stream_create / lgpu_event_*: two streams of the library, work ordered from one to the other by an event (what the layer seam does at a cross-thread
+    hand-over), both the blocking and the non-blocking kind"""
+    from lives_amd import lib
+    L = lib.load()
+    assert L.lgpu_init(0) == 0
+    n = 64 << 20
+    for nonblocking in (0, 1):
+        sa, sb, ev, buf = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert L.lgpu_stream_create(ctypes.byref(sa), nonblocking) == 0 and L.lgpu_stream_create(ctypes.byref(sb), nonblocking) == 0
+        assert L.lgpu_event_create(ctypes.byref(ev)) == 0
+        assert L.lgpu_malloc_ordered(ctypes.byref(buf), n, sa) == 0
+        for v in (1, 2, 3, 4, 5, 6, 7, 8):
+            assert L.lgpu_fill(buf, v, n, sa) == 0                      # a queue of fills on stream a, the last one wins
+        assert L.lgpu_event_record(ev, sa) == 0 and L.lgpu_stream_wait_event(sb, ev) == 0
+        back = np.zeros(4096, np.uint8)
+        assert L.lgpu_download(back.ctypes.data, ctypes.c_void_p(buf.value + n - 4096), 4096, sb) == 0      # on stream b, behind the event
+        assert L.lgpu_sync(sb) == 0
+        assert (back == 8).all()
+        assert L.lgpu_free_ordered(buf, sb) == 0 and L.lgpu_sync(sb) == 0 and L.lgpu_sync(sa) == 0
+        assert L.lgpu_event_destroy(ev) == 0 and L.lgpu_stream_destroy(sa) == 0 and L.lgpu_stream_destroy(sb) == 0
+    assert L.lgpu_event_record(None, None) < 0 and L.lgpu_stream_wait_event(None, None) < 0
