@@ -168,6 +168,17 @@ int lgpu_letterbox_bars(uint8_t *dst_d, int orow, int nwidth, int nheight, int p
    lut8 (HOST, may be NULL) is the fused post-pass of :14718-14720. */
 int lgpu_resize(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *dst_d, int orow, int dw, int dh,
                 int psize, int interp, const uint8_t *lut8, void *stream);
+/* ---- K7, pixbuf arithmetic: the reference's OTHER resize body -- resize_layer_full without swscale scales through
+   lives_pixbuf_scale_simple == gdk_pixbuf_scale_simple (src/colourspace.c:15262-15322, call :15295), and the compositor scales its layers with the
+   same call (lives-plugins/weed-plugins/gdk/compositor.c:263-265).  PINNED: bit-exact to gdk-pixbuf 2.42.8's output (tests/golden/pixbuf_scale.npz,
+   made from the runtime library by oracle/ref/gen_golden_pixbuf.py).  channels 3 = pixbuf without alpha (RGB24 / BGR24 / YUV888 layers), 4 = with
+   alpha (RGBA32 / BGRA32 / YUVA8888: colours are weighted by alpha, colourspace.c:14219-14225).  interp = LiVESInterpType: 0 NEAREST, 2 BILINEAR,
+   3 HYPER.  Same size = plain copy, as the library does.  LGPU_E_UNSUPPORTED for reductions beyond ~30:1 (the library's two-step scaler). */
+int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *dst_d, int orow, int dw, int dh, int channels, int interp,
+                      void *stream);
+/* the per-phase integer weight tables that call uses (host, for tests / inspection): table = [16 y phases][16 x phases][n_y][n_x], each summing to
+   65536; xoff / yoff = 16.16 position of destination pixel 0.  table may be NULL to query the sizes. */
+int lgpu_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff, int32_t *table, size_t table_ints);
 /* the filter bank the kernel uses (host, for tests / inspection): kernel 0 triangle, 1 cubic(0,.6), 2 lanczos3 */
 int lgpu_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);
 

@@ -92,6 +92,8 @@ PROTOTYPES = {
     "lgpu_letterbox_at": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, ci, vp],
     "lgpu_letterbox_bars": [vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
+    "lgpu_pixbuf_scale": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_pixbuf_weights": [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_size_t],
     "lgpu_make_filter": [ci, ci, ci, vp, vp, vp, ci],
     "lgpu_gauss5": [vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_blend_chroma": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],

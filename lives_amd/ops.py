@@ -108,6 +108,10 @@ def resize(src, dst, sw, sh, dw, dh, psize=4, interp=3, lut=None):
              lp[0] if lp else None, stream_ptr())
 
 
+def pixbuf_scale(src, dst, sw, sh, dw, dh, channels=4, interp=3):
+    lib.call("lgpu_pixbuf_scale", dptr(src), src.stride(0), sw, sh, dptr(dst), dst.stride(0), dw, dh, channels, interp, stream_ptr())
+
+
 def gauss5(src, dst, width, height, psize=4):
     lib.call("lgpu_gauss5", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
 

@@ -187,6 +187,11 @@ enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_BILINEAR = 2, ORC_INTERP_HYPER = 3 };
 int orc_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);
 int orc_resize(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh,
                int psize, int interp);
+/* R1, pixbuf backend (PINNED on the gdk-pixbuf runtime library the reference's non-swscale resize body calls, src/colourspace.c:15295;
+   oracle/orc_pixbuf.c).  channels 3 (no alpha) or 4 (alpha-weighted); interp as above.  0 ok, -1 bad args, -2 ratio not covered. */
+int orc_pixbuf_scale(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int channels, int interp);
+int *orc_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff);
+void orc_pixbuf_free(void *p);
 /* B1 (UNPINNED, build-defined): separable [1 4 6 4 1]/16 per axis, edge replicate, one rounding */
 void orc_gauss5(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
 

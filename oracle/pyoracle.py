@@ -49,7 +49,7 @@ def build_oracle(force=False, native=False):
     ubsan = bool(os.environ.get("LGPU_ORACLE_UBSAN")) and not native          # tools/oracle_ubsan.sh: the restatement under -fsanitize=undefined
     so = os.path.join(HERE, "liblives_oracle_native.so" if native else "liblives_oracle_ubsan.so" if ubsan else "liblives_oracle.so")
     sig = so + ".sig"
-    srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_bench.c", "lives_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_pixbuf.c", "orc_bench.c", "lives_oracle.h")]
     srcs = [s for s in srcs if os.path.exists(s)]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if native and not stale:
@@ -121,6 +121,10 @@ def oracle():
         _O.orc_resize.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
         _O.orc_gauss5.argtypes = [vp, ci, vp, ci, ci, ci, ci]
         _O.orc_chain.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        _O.orc_pixbuf_scale.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci]
+        _O.orc_pixbuf_weights.restype = ctypes.POINTER(ctypes.c_int)
+        _O.orc_pixbuf_weights.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp]
+        _O.orc_pixbuf_free.argtypes = [vp]
         _O.orc_make_filter.argtypes = [ci, ci, ci, vp, vp, vp, ci]
         _O.orc_chain_threaded.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci]
         if hasattr(_O, "orc_bench_chain"):

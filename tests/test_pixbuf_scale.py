@@ -1,0 +1,206 @@
+"""R1 on its pinnable reference: gdk_pixbuf_scale_simple, the scaler resize_layer_full calls without swscale (src/colourspace.c:15295) and the
+compositor calls for its layers (compositor.c:263-265).
+
+CPU (-m "not gpu"): the restatement oracle/orc_pixbuf.c == the committed library outputs tests/golden/pixbuf_scale.npz == the live
+libgdk_pixbuf-2.0.so.0 where it loads; the product's host tables == the oracle's; and the measured gap between the repo's own polyphase spec
+(lgpu-polyphase-v1, orc_resize) and the library (informational: printed, bounded only loosely).
+GPU (-m gpu): lgpu_pixbuf_scale == the fixtures and == the oracle, bit for bit.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+
+from golden_util import load
+from oracle import pyoracle as po
+from oracle.ref import pixbuf_ref as pr
+from oracle.ref.gen_golden_pixbuf import band_crcs, make_src
+from util import align, dev, host
+
+P = po.P
+
+
+def records():
+    g = load("pixbuf_scale.npz")
+    out = []
+    for key in g.files:
+        kind, ch, interp, s, d, am, seed = key.split("|")
+        sw, sh = (int(v) for v in s.split("x"))
+        dw, dh = (int(v) for v in d.split("x"))
+        out.append((kind, int(ch), int(interp), sw, sh, dw, dh, int(am), int(seed), g[key]))
+    return out
+
+
+def orc_scale(orc, src, sw, sh, dw, dh, ch, interp):
+    got = np.zeros((dh, dw * ch), np.uint8)
+    assert orc.orc_pixbuf_scale(P(src), src.strides[0], sw, sh, P(got), got.strides[0], dw, dh, ch, interp) == 0
+    return got
+
+
+def test_oracle_equals_the_library_fixtures(orc):
+    n = 0
+    for (kind, ch, interp, sw, sh, dw, dh, am, seed, want) in records():
+        got = orc_scale(orc, make_src(seed, sw, sh, ch, am), sw, sh, dw, dh, ch, interp)
+        if kind == "pb":
+            bad = np.argwhere(got != want)
+            assert len(bad) == 0, "%dch interp %d %dx%d->%dx%d alpha mode %d: %d bytes differ, first %s" % (ch, interp, sw, sh, dw, dh, am, len(bad), bad[0].tolist())
+        else:
+            assert (band_crcs(got) == want).all(), "%dch interp %d %dx%d->%dx%d: band CRCs differ" % (ch, interp, sw, sh, dw, dh)
+        n += 1
+    assert n >= 200
+
+
+@pytest.mark.skipif(not pr.available(), reason="libgdk_pixbuf-2.0.so.0 not on this box")
+def test_oracle_equals_the_live_library(orc):
+    """random geometry, strides, alpha mixes -- a few hundred cases straight against the library"""
+    rng = np.random.default_rng(0x9DB)
+    for it in range(400):
+        sw, sh = int(rng.integers(1, 120)), int(rng.integers(1, 80))
+        dw, dh = int(rng.integers(1, 160)), int(rng.integers(1, 100))
+        ch, interp = int(rng.choice([3, 4])), int(rng.choice([0, 2, 3]))
+        src = rng.integers(0, 256, (sh, sw * ch + int(rng.integers(0, 9))), dtype=np.uint8)
+        if ch == 4:
+            a = src[:, 3:sw * 4:4]
+            mode = it % 3
+            if mode == 1:
+                a[:] = 255
+            elif mode == 2:
+                a[rng.random(a.shape) < 0.4] = 0
+        got = np.zeros((dh, dw * ch), np.uint8)
+        rc = orc.orc_pixbuf_scale(P(src), src.strides[0], sw, sh, P(got), got.strides[0], dw, dh, ch, interp)
+        if rc == -2:
+            continue
+        assert rc == 0
+        want = pr.scale_simple(src, sw, ch, dw, dh, interp)
+        assert (got == want).all(), "case %d: %dch interp %d %dx%d->%dx%d" % (it, ch, interp, sw, sh, dw, dh)
+
+
+def test_strong_reductions_are_declined(orc):
+    """beyond n_x * n_y = 1000 taps the library pre-shrinks in a first step (measured: equal up to 989, different from 1015); not covered"""
+    src = np.zeros((120, 120 * 3), np.uint8)
+    out = np.zeros((2, 6), np.uint8)
+    assert orc.orc_pixbuf_scale(P(src), 360, 120, 120, P(out), 6, 2, 2, 3, 3) == -2
+
+
+def test_product_host_tables_equal_the_oracle(orc):
+    from lives_amd import lib
+    L = lib.load()
+    for (interp, sw, sh, dw, dh) in [(3, 3840, 2160, 1920, 1080), (2, 3840, 2160, 1920, 1080), (3, 64, 32, 43, 21), (2, 64, 32, 96, 48), (3, 100, 60, 37, 91),
+                                      (2, 17, 13, 40, 7), (3, 3840, 2160, 1706, 960), (3, 1920, 1080, 3840, 2160)]:
+        nx, ny, xo, yo = (ctypes.c_int() for _ in range(4))
+        t = orc.orc_pixbuf_weights(interp, sw, sh, dw, dh, ctypes.byref(nx), ctypes.byref(ny), ctypes.byref(xo), ctypes.byref(yo))
+        want = np.ctypeslib.as_array(t, shape=(256 * nx.value * ny.value,)).copy()
+        orc.orc_pixbuf_free(t)
+        assert want.reshape(256, -1).sum(axis=1).tolist() == [65536] * 256
+        mx, my, px, py = (ctypes.c_int() for _ in range(4))
+        got = np.zeros_like(want)
+        assert L.lgpu_pixbuf_weights(interp, sw, sh, dw, dh, ctypes.byref(mx), ctypes.byref(my), ctypes.byref(px), ctypes.byref(py), got.ctypes.data, got.size) == 0
+        assert (mx.value, my.value, px.value, py.value) == (nx.value, ny.value, xo.value, yo.value)
+        assert (got == want).all()
+
+
+def test_gap_between_the_polyphase_spec_and_the_library(orc, capsys):
+    """the first real number for "how far is lgpu-polyphase-v1 from a scaler the reference calls": per fixture, max |diff| and PSNR of orc_resize
+    (the spec the default lgpu_resize / lgpu_chain follow) against gdk-pixbuf's output.  Informational -- the two are different filters
+    (bicubic(0, .6) / lanczos against pixops' box-integrated bilinear), so only a loose sanity bound is asserted on smooth content."""
+    rows = []
+    for (kind, ch, interp, sw, sh, dw, dh, am, seed, want) in records():
+        if kind != "pb" or (ch == 4 and am != 1) or (sw, sh) == (dw, dh) or min(sw, sh, dw, dh) < 8:
+            continue        # the spec does not weight colours by alpha: compare opaque / 3-byte records only
+        src = make_src(seed, sw, sh, ch, am)
+        got = np.zeros((dh, dw * ch), np.uint8)
+        assert orc.orc_resize(P(src), src.strides[0], sw, sh, P(got), got.strides[0], dw, dh, ch, interp) == 0
+        d = got.astype(np.int32) - want.astype(np.int32)
+        mse = float((d * d).mean())
+        rows.append((ch, interp, sw, sh, dw, dh, int(np.abs(d).max()), 99.0 if mse == 0 else 10 * np.log10(255 * 255 / mse)))
+    # smooth content: a gradient, where any two sane filters agree closely
+    sw, sh, dw, dh = 128, 64, 64, 32
+    yy, xx = np.mgrid[0:sh, 0:sw]
+    smooth = np.stack([xx * 2 % 256, yy * 4 % 256, (xx + yy) % 256, np.full_like(xx, 255)], axis=2).astype(np.uint8).reshape(sh, sw * 4)
+    smooth = np.ascontiguousarray(smooth)
+    a = np.zeros((dh, dw * 4), np.uint8)
+    assert orc.orc_resize(P(smooth), sw * 4, sw, sh, P(a), dw * 4, dw, dh, 4, 3) == 0
+    b = orc_scale(orc, smooth, sw, sh, dw, dh, 4, 3)
+    # compare away from the wrap-around lines of the sawtooth
+    core = np.abs(a.astype(int) - b.astype(int)).reshape(dh, dw, 4)
+    with capsys.disabled():
+        print("\n  lgpu-polyphase-v1 (orc_resize) against gdk-pixbuf 2.42.8 fixtures, uniform random bytes (worst case for any filter pair):")
+        print("  ch interp   src -> dst        max|d|  PSNR dB")
+        for r in rows:
+            print("   %d    %d   %3dx%-3d -> %3dx%-3d   %4d   %6.2f" % r)
+        print("  smooth 128x64 -> 64x32 HYPER vs bicubic: median |d| %d, 90th percentile %d" % (int(np.median(core)), int(np.percentile(core, 90))))
+    assert np.median(core) <= 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+gpu_mark = pytest.mark.gpu
+
+
+def gpu_scale(gpu, src, sw, sh, dw, dh, ch, interp, orow=None):
+    orow = orow or align(dw * ch, 4)
+    d = dev(np.full((dh + 1, orow), 0xA5, np.uint8))
+    gpu.pixbuf_scale(dev(src), d, sw, sh, dw, dh, channels=ch, interp=interp)
+    out = host(d)
+    assert (out[dh] == 0xA5).all(), "row past the frame was written"
+    assert (out[:dh, dw * ch:] == 0xA5).all(), "row padding was written"
+    return out[:dh, :dw * ch]
+
+
+@gpu_mark
+def test_gpu_equals_the_library_fixtures(gpu):
+    for (kind, ch, interp, sw, sh, dw, dh, am, seed, want) in records():
+        src = make_src(seed, sw, sh, ch, am)
+        if ch == 3 and (sw * 3) % 4:
+            src = np.ascontiguousarray(np.pad(src, ((0, 0), (0, 4 - (sw * 3) % 4))))
+        got = gpu_scale(gpu, src, sw, sh, dw, dh, ch, interp)
+        if kind == "pb":
+            bad = np.argwhere(got != want)
+            assert len(bad) == 0, "%dch interp %d %dx%d->%dx%d alpha mode %d: %d bytes differ, first %s" % (ch, interp, sw, sh, dw, dh, am, len(bad), bad[0].tolist())
+        else:
+            assert (band_crcs(np.ascontiguousarray(got)) == want).all(), "%dch interp %d %dx%d->%dx%d: band CRCs differ" % (ch, interp, sw, sh, dw, dh)
+
+
+@gpu_mark
+def test_gpu_equals_the_oracle_on_random_geometry(gpu, orc):
+    rng = np.random.default_rng(0x9DB1)
+    n = 0
+    for it in range(300):
+        sw, sh = int(rng.integers(1, 400)), int(rng.integers(1, 200))
+        dw, dh = int(rng.integers(1, 500)), int(rng.integers(1, 260))
+        ch, interp = int(rng.choice([3, 4])), int(rng.choice([0, 2, 3]))
+        irow = align(sw * ch + int(rng.integers(0, 3)) * 4, 4)
+        src = rng.integers(0, 256, (sh, irow), dtype=np.uint8)
+        if ch == 4:
+            a = src[:, 3:sw * 4:4]
+            if it % 3 == 1:
+                a[:] = 255
+            elif it % 3 == 2:
+                a[rng.random(a.shape) < 0.4] = 0
+        want = np.zeros((dh, dw * ch), np.uint8)
+        rc = orc.orc_pixbuf_scale(P(src), irow, sw, sh, P(want), want.strides[0], dw, dh, ch, interp)
+        if rc == -2:
+            continue
+        assert rc == 0
+        got = gpu_scale(gpu, src, sw, sh, dw, dh, ch, interp)
+        assert (got == want).all(), "case %d: %dch interp %d %dx%d->%dx%d: %d bytes differ" % (it, ch, interp, sw, sh, dw, dh, int((got != want).sum()))
+        n += 1
+    assert n > 250
+
+
+@gpu_mark
+def test_gpu_strong_reductions(gpu, orc):
+    """windows too large for LDS take the direct kernel; ratios past the library's one-step range are refused, the frame untouched"""
+    from lives_amd import lib
+    rng = np.random.default_rng(0x9DB2)
+    for (sw, sh, dw, dh, ch, interp) in [(3000, 64, 100, 8, 4, 3), (64, 1500, 16, 50, 3, 2), (2048, 512, 70, 18, 4, 2), (1200, 900, 41, 300, 3, 3)]:
+        src = rng.integers(0, 256, (sh, sw * ch), dtype=np.uint8)
+        want = np.zeros((dh, dw * ch), np.uint8)
+        assert orc.orc_pixbuf_scale(P(src), sw * ch, sw, sh, P(want), dw * ch, dw, dh, ch, interp) == 0
+        got = gpu_scale(gpu, src, sw, sh, dw, dh, ch, interp)
+        assert (got == want).all(), "%dx%d->%dx%d" % (sw, sh, dw, dh)
+    src = dev(np.zeros((120, 480), np.uint8))
+    d = dev(np.full((2, 8), 7, np.uint8))
+    with pytest.raises(lib.LgpuError):
+        gpu.pixbuf_scale(src, d, 120, 120, 2, 2, channels=4, interp=3)
+    assert (host(d) == 7).all()
