@@ -47,7 +47,13 @@ def main():
                          "so nothing a step reads can still sit in the 256 MiB Infinity Cache from the step before")
     ap.add_argument("--l2-translucent", type=float, default=0.5,
                     help="fraction of layer-2 pixels with alpha < 255 (they take the reference's float scaling path); 0 = an opaque layer 2")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / reduce / print path only, on the gloo backend with no GPU work (tests/test_dist_cpu.py runs this on a CPU box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run plainly: become the launcher -- one rank per GPU under torch.distributed.run on this node, same arguments
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -56,7 +62,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or unset WORLD_SIZE and let bench.py launch itself" % (
+        args.gpus, world, args.gpus)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -202,6 +211,38 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def self_launch(n):
+    """re-exec under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on 127.0.0.1 with a free port; the ranks inherit the arguments,
+    rank 0 prints the one JSON line"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """everything around the GPU work: rendezvous (gloo), the track sharding, the max-over-ranks reduction, rank 0's one line"""
+    import torch.distributed as dist
+    from lives_amd import dist as ld
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    mine = ld.shard_tracks(world * args.tracks, rank, world)
+    dt = ld.max_over_ranks(1e-3 * (rank + 1), "cpu")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "effect-chain frames/sec at 3840x2160 RGBA32", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "tracks_of_rank0": mine, "max_over_ranks_s": dt}))
 
 
 def cpu_baseline(blur):

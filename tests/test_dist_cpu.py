@@ -59,3 +59,18 @@ def test_two_rank_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok [0, 2, 4, 6]" in r.stdout and "rank 1 ok [1, 3, 5, 7]" in r.stdout, r.stdout
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus 2` run plainly (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run with one rank per GPU;
+    --dry-run keeps the GPU work out so that the spawn, the rendezvous on 127.0.0.1, the sharding, the max-over-ranks reduction and rank 0's
+    single JSON line run on a CPU box"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--tracks", "1"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["tracks_of_rank0"] == [0] and abs(j["max_over_ranks_s"] - 2e-3) < 1e-9
