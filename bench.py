@@ -47,6 +47,9 @@ def main():
                          "so nothing a step reads can still sit in the 256 MiB Infinity Cache from the step before")
     ap.add_argument("--l2-translucent", type=float, default=0.5,
                     help="fraction of layer-2 pixels with alpha < 255 (they take the reference's float scaling path); 0 = an opaque layer 2")
+    ap.add_argument("--resize-backend", choices=["polyphase", "pixbuf"], default="polyphase",
+                    help="arithmetic of the resize stage: the repo's polyphase spec in the swscale body's place (bicubic; parity unpinned, libswscale is not in the "
+                         "image) or the reference's gdk-pixbuf body (GDK_INTERP_HYPER, alpha-weighted; bit-exact to gdk-pixbuf 2.42.8)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce / print path only, on the gloo backend with no GPU work (tests/test_dist_cpu.py runs this on a CPU box)")
     args = ap.parse_args()
@@ -97,7 +100,7 @@ def main():
     # shared transition parameter block: int32[4], [0] = blend amount; broadcast from rank 0 each step
     pblock = ld.new_param_block("cuda")
     schedule = torch.tensor([[(96 + 7 * s) % 256, 0, 0, 0] for s in range(args.steps + args.warmup)], dtype=torch.int32, device="cuda")
-    prm = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3, do_blur=args.blur, bf=128, lut=lut,
+    prm = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3 | (0x100 if args.resize_backend == "pixbuf" else 0), do_blur=args.blur, bf=128, lut=lut,
                            param_block=pblock)
     trk = trks[0]
 
@@ -183,7 +186,7 @@ def main():
             traffic = pj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roof = {"bound": "hbm", "kernel": "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "lgpu::k_pb_half<1>" if args.resize_backend == "pixbuf" else "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
 
@@ -193,8 +196,9 @@ def main():
             "metric": "effect-chain frames/sec at 3840x2160 RGBA32", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "3840x2160 BGRA32 -> convert(RGBA32) -> bicubic resize 0.5x%s -> chroma blend with 1920x1080 RGBA32 layer -> gamma LUT (linear->sRGB)"
-                                   % (" -> 5x5 gaussian" if args.blur else ""),
+            "config": {"workload": "3840x2160 BGRA32 -> convert(RGBA32) -> %s resize 0.5x%s -> chroma blend with 1920x1080 RGBA32 layer -> gamma LUT (linear->sRGB)"
+                                   % ("gdk-pixbuf HYPER (alpha-weighted, pinned)" if args.resize_backend == "pixbuf" else "bicubic", " -> 5x5 gaussian" if args.blur else ""),
+                       "resize_backend": args.resize_backend,
                        "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
                        "param_exchange": ("none (one GPU: the kernel reads step s of the resident schedule)" if world == 1 else
                                           "lgpu_params_broadcast (RCCL, the library's C entry point), pipelined on a side stream" if comm is not None else

@@ -349,6 +349,7 @@ int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int or
    that order (tests/test_chain_gpu.py).  All tracks share geometry and parameters (the shared
    transition parameter block of SURVEY 8e); per-track pointers travel as kernel arguments. */
 #define LGPU_CHAIN_MAX_TRACKS 64
+#define LGPU_INTERP_PIXBUF 0x100
 typedef struct {
   const uint8_t *src_d;      /* sw x sh, 4 bytes / pixel */
   const uint8_t *layer2_d;   /* dw x dh, RGBA32 */
@@ -358,7 +359,8 @@ typedef struct {
   int sw, sh, irow;          /* source geometry */
   int dw, dh, irow2, orow;   /* output / layer-2 geometry */
   int swap_rb;               /* 1: source is BGRA32 (K1 swap3postalpha fused into the load) */
-  int interp;                /* LiVESInterpType */
+  int interp;                /* LiVESInterpType; | LGPU_INTERP_PIXBUF: the resize stage follows the reference's gdk-pixbuf body (lgpu_pixbuf_scale, 4 channels with
+                                alpha) instead of the polyphase spec -- pinned arithmetic; the exact aligned 2:1 case is one fused launch */
   int do_blur;               /* 1: 5x5 gaussian between resize and blend */
   int bf;                    /* chroma blend amount 0..255 */
   int use_lut;               /* 1: apply lut8 after the blend */
@@ -396,7 +398,8 @@ int lgpu_fan_in(void *comm, int root, int rank, int world, int ntracks, const ui
    :167-189 (background, z order), :288-293 (paint loop).  One kernel: every output pixel starts from bgcol (R,G,B;
    alpha byte 0xFF) and takes the layers that cover it in paint order -- revz == 0: the last layer first, so layer 0 ends
    on top -- with dst.c = (uint8_t)(dst.c * (1. - alpha) + src.c * alpha) in double per colour byte.  Layers arrive
-   already scaled (lgpu_resize; the reference scales with un-vendored gdk-pixbuf) at pixel offsets
+   already scaled -- by lgpu_pixbuf_scale, bit-exact to the gdk_pixbuf_scale_simple call of compositor.c:262-266 (GDK_INTERP_HYPER when either side grows,
+   GDK_INTERP_BILINEAR otherwise; 4-byte palettes with alpha) -- at pixel offsets
    offs = (int)(offs_fraction * out_size).  Up to LGPU_COMP_MAX_LAYERS layers per call. */
 #define LGPU_COMP_MAX_LAYERS 16
 typedef struct {

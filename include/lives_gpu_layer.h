@@ -88,6 +88,15 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
 /* colourspace.h:409-411; tgt_gamma: the LUT8 post-pass fused into the resize (src/colourspace.c:14718-14720, :15119-15127) */
 lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
                                               int osamp_hint, int osubs_hint, int tgt_gamma);
+/* which of the reference's two resize bodies resize_layer / resize_layer_full (and the scaling inside letterbox_layer / unletterbox_layer) follow:
+   LIVES_GPU_RESIZE_POLYPHASE (default) -- the swscale body's place (src/colourspace.c:14940-15259); libswscale is un-vendored and unpinned, so the
+     arithmetic is this library's own spec "lgpu-polyphase-v1" (DESIGN.md section 5), every palette, fused target gamma;
+   LIVES_GPU_RESIZE_PIXBUF -- the gdk-pixbuf body (:15262-15322), bit-exact to gdk_pixbuf_scale_simple 2.42.8 for the palettes of its switch (RGB24, BGR24,
+     RGBA32, BGRA32, YUV888, YUVA8888): alpha-weighted colours on 4-byte palettes, rowstride ALIGN4(width * channels), RGB layers come back tagged
+     WEED_GAMMA_SRGB, no gamma pass; other palettes keep the polyphase body.  A separate call so that lives_gpu_prefs keeps its layout.  Returns 0, -1 on a bad value. */
+enum { LIVES_GPU_RESIZE_POLYPHASE = 0, LIVES_GPU_RESIZE_PIXBUF = 1 };
+int lives_gpu_set_resize_backend(int backend);
+int lives_gpu_get_resize_backend(void);
 lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
                                             int tpal, int tclamp);
 lives_gpu_boolean lives_gpu_unletterbox_layer(lives_gpu_layer_t *layer, int opwidth, int opheight, int top, int bottom, int left, int right);   /* colourspace.h:418 */

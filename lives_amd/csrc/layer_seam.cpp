@@ -276,10 +276,18 @@ void res_drop(const void *h) {
   }
   pool_give(b);
 }
+int lives_gpu_layer_unpin_impl(weed_plant_t *layer);
 struct PinScope {
   bool prev;
-  explicit PinScope(weed_plant_t *layer) : prev(t_pinned) { t_pinned = layer && bound() && has_leaf(layer, kLeafResident); }
+  weed_plant_t *layer;
+  explicit PinScope(weed_plant_t *layer_) : prev(t_pinned), layer(layer_) { t_pinned = layer && bound() && has_leaf(layer, kLeafResident); }
   ~PinScope() { t_pinned = prev; }
+  // every FALSE a seam call returns on a PINNED layer -- declined, or failed after it started (allocation, launch, copy) -- leaves the layer
+  // synchronised and unpinned (lives_gpu_layer.h: "the CPU body reads current bytes"); decline() does the same on the paths that know they decline
+  int settle(int rc) {
+    if (!rc && t_pinned && layer && has_leaf(layer, kLeafResident)) lives_gpu_layer_unpin_impl(layer);
+    return rc;
+  }
 };
 
 void free_planes(const Layer &l) {
@@ -775,9 +783,13 @@ lives_gpu_boolean lives_gpu_create_empty_pixel_data(lives_gpu_layer_t *layer, li
   return 1;
 }
 
+static lives_gpu_boolean convert_layer_palette_full_body(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling, int osubspace, int tgt_gamma);
 lives_gpu_boolean lives_gpu_convert_layer_palette_full(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling,
                                                        int osubspace, int tgt_gamma) {
   PinScope pin(layer);
+  return pin.settle(convert_layer_palette_full_body(layer, outpl, oclamping, osampling, osubspace, tgt_gamma));
+}
+static lives_gpu_boolean convert_layer_palette_full_body(lives_gpu_layer_t *layer, int outpl, int oclamping, int osampling, int osubspace, int tgt_gamma) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
   const int inpl = l.pal;
@@ -899,10 +911,14 @@ lives_gpu_boolean lives_gpu_convert_layer_palette_with_sampling(lives_gpu_layer_
   return lives_gpu_convert_layer_palette_full(layer, outpl, WEED_YUV_CLAMPING_UNCLAMPED, out_sampling, WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);
 }
 
+static lives_gpu_boolean gamma_convert_sub_layer_body(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y, int width, int height);
 lives_gpu_boolean lives_gpu_gamma_convert_sub_layer(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y, int width,
                                                     int height, lives_gpu_boolean may_thread) {
   (void)may_thread;
   PinScope pin(layer);
+  return pin.settle(gamma_convert_sub_layer_body(gamma_type, fileg, layer, x, y, width, height));
+}
+static lives_gpu_boolean gamma_convert_sub_layer_body(int gamma_type, double fileg, lives_gpu_layer_t *layer, int x, int y, int width, int height) {
   if (!g_prefs.apply_gamma) return 1;
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
@@ -1021,13 +1037,77 @@ static int plan_resize(weed_plant_t *layer, int width, int height, int opal_hint
   return 1;
 }
 
+// ---- resize backend ------------------------------------------------------------------------------------------------------------------
+// resize_layer_full has two bodies in the reference: the swscale one (:14940-15259; un-vendored, version unpinned -> this library's own
+// polyphase spec) and the gdk-pixbuf one (:15262-15322: layer_to_pixbuf, lives_pixbuf_scale_simple, pixbuf_to_layer).
+// The second is pinned byte for byte (pixbuf.hip); a host that wants the reference's pinned arithmetic selects it here.
+static std::atomic<int> g_resize_backend{LIVES_GPU_RESIZE_POLYPHASE};
+int lives_gpu_set_resize_backend(int backend) {
+  if (backend != LIVES_GPU_RESIZE_POLYPHASE && backend != LIVES_GPU_RESIZE_PIXBUF) return -1;
+  g_resize_backend.store(backend);
+  return 0;
+}
+int lives_gpu_get_resize_backend(void) { return g_resize_backend.load(); }
+
+static bool pal_is_pixbuf(int pal) {      // the cases of the switch at :15275-15290 (3 or 4 channels, alpha last)
+  return pal == WEED_PALETTE_RGB24 || pal == WEED_PALETTE_BGR24 || pal == WEED_PALETTE_RGBA32 || pal == WEED_PALETTE_BGRA32 ||
+         pal == WEED_PALETTE_YUV888 || pal == WEED_PALETTE_YUVA8888;
+}
+
+// The pixbuf body.  Returns -1 when this body does not apply (palette outside the switch: the reference prints "resizing unknown palette" and fails;
+// this library serves those through the polyphase body instead), else the value resize_layer_full returns.
+//   * size rules of the common prologue (:14854-14868): even source size only for the "nothing to do" test, width / height >= 4, even target height
+//   * clamped YUV888 / YUVA8888 is first switched to unclamped (:15277-15284)
+//   * the WHOLE layer (odd sizes included: the sizes are re-read at :15263-15264) is scaled; 4-byte palettes weight colours by alpha
+//   * the new frame has the pixbuf's rowstride, ALIGN4(width * channels), and RGB layers come back tagged WEED_GAMMA_SRGB (pixbuf_to_layer :14378-14379,
+//     :14405-14406), whatever they were tagged before; no gamma LUT runs in this body
+static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int interp) {
+  Layer l;
+  if (!ready() || !read_layer(layer, &l)) return 0;
+  if (!pal_is_pixbuf(l.pal) || (interp != LIVES_INTERP_FAST && interp != LIVES_INTERP_NORMAL && interp != LIVES_INTERP_BEST)) return -1;
+  if (width <= 0 || height <= 0) return 0;
+  const int iwidth = (l.width >> 1) << 1, iheight = (l.height >> 1) << 1;
+  if (width < 4) width = 4;
+  if (height < 4) height = 4;
+  if (iwidth != width || iheight != height) height = (height >> 1) << 1;
+  if (iwidth == width && iheight == height) return 1;
+  if ((l.pal == WEED_PALETTE_YUV888 || l.pal == WEED_PALETTE_YUVA8888) && l.clamping != WEED_YUV_CLAMPING_UNCLAMPED) {
+    if (!lives_gpu_convert_layer_palette(layer, l.pal, WEED_YUV_CLAMPING_UNCLAMPED)) return 0;
+    if (!read_layer(layer, &l)) return 0;
+  }
+  if (l.width == width && l.height == height) return 1;
+  const int ch = (l.pal == WEED_PALETTE_RGB24 || l.pal == WEED_PALETTE_BGR24 || l.pal == WEED_PALETTE_YUV888) ? 3 : 4;
+  NewPlanes np;
+  if (!alloc_planes(l.pal, width, height, 4, &np)) return 0;
+  Work w;
+  const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
+  uint8_t *d_out = w.out(np.pd[0], (size_t)np.rs[0] * height, 3, np.rs[0] != width * ch);
+  const int rc = w.ok ? lgpu_pixbuf_scale(d_in, l.rs[0], l.width, l.height, d_out, np.rs[0], width, height, ch, interp, S()) : LGPU_E_HIP;
+  if (rc != LGPU_OK || !w.finish()) {
+    drop_new_planes(np);
+    return rc == LGPU_E_UNSUPPORTED ? decline(layer) : 0;      // reductions past the library's one-step range: the host's own body takes them
+  }
+  free_planes(l);
+  commit_planes(layer, l.pal, width, height, np);
+  if (pal_is_rgb(l.pal) && l.gamma != WEED_GAMMA_SRGB) set_int(layer, WEED_LEAF_GAMMA_TYPE, WEED_GAMMA_SRGB);
+  return 1;
+}
+
 // resize_layer_full (src/colourspace.c:14759-15328).  osamp_hint / osubs_hint only parameterise the reference's swscale colourspace
 // details for conversions done inside the scaler; this path never converts inside the resize (the layer keeps its palette, "layer palette
 // should be checked on return", :14746-14751), so they take part in the target-gamma decision only (:14890-14899).
+static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int osubs_hint, int tgt_gamma);
 lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
                                               int osamp_hint, int osubs_hint, int tgt_gamma) {
   (void)oclamp_hint; (void)osamp_hint;
   PinScope pin(layer);
+  return pin.settle(resize_layer_full_body(layer, width, height, interp, opal_hint, osubs_hint, tgt_gamma));
+}
+static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int osubs_hint, int tgt_gamma) {
+  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF) {
+    const int done = resize_pixbuf_body(layer, width, height, interp);
+    if (done >= 0) return done;
+  }
   ResizePlan rp;
   int rc;
   if (plan_resize(layer, width, height, opal_hint, osubs_hint, tgt_gamma, &rp, &rc) != 1) return rc;
@@ -1044,9 +1124,13 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
                                      WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);                          // :15331-15334
 }
 
+static lives_gpu_boolean letterbox_layer_body(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp, int tpal, int tclamp);
 lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
                                             int tpal, int tclamp) {
   PinScope pin(layer);
+  return pin.settle(letterbox_layer_body(layer, nwidth, nheight, width, height, interp, tpal, tclamp));
+}
+static lives_gpu_boolean letterbox_layer_body(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp, int tpal, int tclamp) {
   if (!width || !height || !nwidth || !nheight) return 1;                 // :15377
   if (nwidth < width) nwidth = width;
   if (nheight < height) nheight = height;
@@ -1056,6 +1140,13 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
   ResizePlan rp;
   int rc, todo = 2;
   if (!ready() || !read_layer(layer, &rp.l)) return 0;
+  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF && pal_is_pixbuf(rp.l.pal) && (rp.l.width != width || rp.l.height != height)) {
+    // the pixbuf body as the reference runs it: resize_layer first (:15389), then the blit of the frame it left
+    if (!lives_gpu_resize_layer(layer, width, height, interp, tpal, tclamp)) return 0;
+    if (!read_layer(layer, &rp.l)) return 0;
+    width = rp.l.width; height = rp.l.height;
+  }
+  if (!(pal_is_rgb(rp.l.pal) || pal_is_planar_yuv(rp.l.pal)) && pal_psize(rp.l.pal) == 0) return decline(layer);   // packed YUV the blit has no pixel size for
   if (rp.l.width != width || rp.l.height != height) {                                     // resize_layer is only called for a frame of another size
     todo = plan_resize(layer, width, height, tpal, WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN, &rp, &rc);
     if (todo == 0) return rc;
@@ -1112,8 +1203,12 @@ lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth
 // unletterbox_layer (src/colourspace.c:15570-15628): cut the borders off, then resize to (opwidth, opheight) (0 = keep, -1 = the outer
 // size).  Packed palettes only, as in the reference.  Quirk U1: the reference's row copy moves `xwidth` BYTES, not pixels
 // (:15614), so only the first xwidth / psize pixels of every row arrive and the rest of the new (black, opaque) frame stays black: kept.
+static lives_gpu_boolean unletterbox_layer_body(lives_gpu_layer_t *layer, int opwidth, int opheight, int top, int bottom, int left, int right);
 lives_gpu_boolean lives_gpu_unletterbox_layer(lives_gpu_layer_t *layer, int opwidth, int opheight, int top, int bottom, int left, int right) {
   PinScope pin(layer);
+  return pin.settle(unletterbox_layer_body(layer, opwidth, opheight, top, bottom, left, right));
+}
+static lives_gpu_boolean unletterbox_layer_body(lives_gpu_layer_t *layer, int opwidth, int opheight, int top, int bottom, int left, int right) {
   Layer l;
   if (!layer || !ready() || !read_layer(layer, &l)) return 0;
   if (top < 0) top = 0;
@@ -1146,8 +1241,12 @@ lives_gpu_boolean lives_gpu_unletterbox_layer(lives_gpu_layer_t *layer, int opwi
 }
 
 // compact_rowstrides (src/colourspace.c:14439-14496): new pixel data whose rowstrides are exactly width * bytes per (macro)pixel * plane ratio
+static lives_gpu_boolean compact_rowstrides_body(lives_gpu_layer_t *layer);
 lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer) {
   PinScope pin(layer);
+  return pin.settle(compact_rowstrides_body(layer));
+}
+static lives_gpu_boolean compact_rowstrides_body(lives_gpu_layer_t *layer) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
   int bpm = pal_psize(l.pal);                                               // bytes per macropixel of plane 0
@@ -1190,8 +1289,12 @@ lives_gpu_boolean lives_gpu_compact_rowstrides(lives_gpu_layer_t *layer) {
 // bytes of an ordinary layer (a fill of host memory is the host's business), the resident planes of a pinned one.  Packed palettes
 // keep the reference's per-pixel pattern (opaque alpha); YUYV keeps its quirk (blank_pixel :11150-11154 never advances: only the first
 // macropixel of a row is written).
+static lives_gpu_boolean weed_layer_clear_pixel_data_body(lives_gpu_layer_t *layer);
 lives_gpu_boolean lives_gpu_weed_layer_clear_pixel_data(lives_gpu_layer_t *layer) {
   PinScope pin(layer);
+  return pin.settle(weed_layer_clear_pixel_data_body(layer));
+}
+static lives_gpu_boolean weed_layer_clear_pixel_data_body(lives_gpu_layer_t *layer) {
   Layer l;
   if (!layer || !bound() || !read_layer(layer, &l)) return 0;
   const int clamping = l.clamping >= 0 ? l.clamping : WEED_YUV_CLAMPING_CLAMPED;       // weed_layer_get_palette_yuv: CLAMPED when the leaf is missing

@@ -146,6 +146,168 @@ __global__ __launch_bounds__(256) void k_pb_nearest(const uint8_t *src, int irow
   else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
 }
 
+// =====================================================================================================================================================
+// k_pb_half -- the exact 2:1 reduction of 4-byte pixels (the headline 3840x2160 -> 1920x1080 case), HYPER or BILINEAR, optionally with the rest of the
+// chain fused behind it (chroma blend with layer 2, gamma LUT).  For this ratio every destination pixel has phase (0, 0) and the library's table is an
+// exact outer product -- HYPER: 256 * [1 7 7 1]^T [1 7 7 1] on source pixels 2X-1 .. 2X+2 (the 5th row / column is zero), BILINEAR: 16384 * ones(2, 2)
+// on 2X, 2X+1 (the host verifies that against the table it built) -- so the alpha-weighted sums separate exactly:
+//     P_c = alpha * q_c (< 2^16),  H_c = vo * (P[2X-1] + P[2X+2]) + vi * (P[2X] + P[2X+1]) (< 2^20),  V_c = the same down the rows (< 2^24),
+//     colour = (uint8_t)((double)V_c * (1.0 / (double)V_alpha)),  alpha' = (scale * V_alpha) >> 16      (the common power of two drops out of the quotient)
+// No LDS, no matrix cores: a wave owns a strip of 124 output columns and walks down `th` output rows.  A lane loads 4 source pixels per row with one
+// 16-byte load, premultiplies them into 16-bit pairs, takes the one neighbour pixel it needs on each side from the adjacent lanes (DPP wave shifts; lanes
+// 0 and 63 only feed their neighbours), forms its two H columns with v_dot2_u32_u16 and keeps the last two H rows in registers; every second source row
+// one output row (two pixels per lane, 8-byte stores) leaves.  HBM-bound: source read once (+ 2 of 2 th + 2 rows re-read at band seams, + 4 of 252 columns).
+// =====================================================================================================================================================
+struct PbHalfArgs {
+  int sw, sh, irow, dw, dh, orow;
+  uint32_t vin2, vout2;          // inner / outer tap as (v | v << 16)
+  int ashift;                    // alpha' = V_alpha >> ashift   (HYPER 8, BILINEAR 2)
+  int swap_rb, blend, irow2, use_lut;
+  uint32_t bf;
+  const int32_t *bf_d;
+  int strips, bands, th, ntracks;
+  int nt_out;
+};
+struct PbTracks {
+  const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
+  const uint8_t *l2[LGPU_CHAIN_MAX_TRACKS];
+  uint8_t *dst[LGPU_CHAIN_MAX_TRACKS];
+};
+typedef unsigned short pb_us2 __attribute__((ext_vector_type(2)));
+typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pb_dot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(pb_us2, a), __builtin_bit_cast(pb_us2, b), c, false);
+}
+// one source row of a lane: 4 pixels -> the two H columns of its 4 channels (h[c] = column 2k, h[4 + c] = column 2k + 1)
+__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t vin2, uint32_t vout2, uint32_t h[8]) {
+  const uint32_t a01 = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u), a23 = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);     // alpha pairs as 2 x u16
+  uint32_t A[4], B[4];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    // (alpha * q_c) of both pixels of a pair: colour bytes spread to 16-bit lanes, packed multiply (products < 2^16)
+    const uint32_t sel = 0x0C040C00u + 0x00010001u * c;
+    const pb_us2 c01 = __builtin_bit_cast(pb_us2, __builtin_amdgcn_perm(q.y, q.x, sel)), c23 = __builtin_bit_cast(pb_us2, __builtin_amdgcn_perm(q.w, q.z, sel));
+    A[c] = __builtin_bit_cast(uint32_t, c01 * __builtin_bit_cast(pb_us2, a01));
+    B[c] = __builtin_bit_cast(uint32_t, c23 * __builtin_bit_cast(pb_us2, a23));
+  }
+  A[3] = a01; B[3] = a23;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B[c], 0x138, 0xF, 0xF, false);     // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1])
+    const uint32_t ar = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A[c], 0x130, 0xF, 0xF, false);     // wave_shl:1 -- the right lane's (P[4k+4], P[4k+5])
+    const uint32_t o0 = __builtin_amdgcn_alignbit(B[c], bl, 16);      // (P[4k-1], P[4k+2])
+    const uint32_t o1 = __builtin_amdgcn_alignbit(ar, A[c], 16);      // (P[4k+1], P[4k+4])
+    h[c] = pb_dot2(o0, vout2, pb_dot2(A[c], vin2, 0u));
+    h[4 + c] = pb_dot2(o1, vout2, pb_dot2(B[c], vin2, 0u));
+  }
+}
+__device__ __forceinline__ uint32_t pb_half_pixel(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t va, int ashift, int swap_rb) {
+  if (!va) return 0u;
+  const double ia = 1.0 / (double)va;
+  const uint32_t c0 = (uint32_t)(uint8_t)((double)v0 * ia), c1 = (uint32_t)(uint8_t)((double)v1 * ia), c2 = (uint32_t)(uint8_t)((double)v2 * ia);
+  return (swap_rb ? (c2 | (c0 << 16)) : (c0 | (c2 << 16))) | (c1 << 8) | ((va >> ashift) << 24);
+}
+
+__device__ __forceinline__ uint32_t pb_chroma_rgba(uint32_t p1, uint32_t p2, uint32_t bf, uint32_t nbf) {
+  // chroma blend of simple_blend.c:117-146 on an RGBA pair: opaque layer-2 pixels through the integer table expression, translucent ones through
+  // the reference's float scaling of both sources first; dst alpha = the track's alpha
+  const uint32_t al = p2 >> 24;
+  uint32_t s1 = p1, s2 = p2;
+  if (al != 255) {
+    const float alpha = (float)((double)(float)al / 255.), inv = (float)(1. - (double)alpha);
+    s1 = 0; s2 = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      s2 |= ((uint32_t)(int)__fmul_rn((float)((p2 >> (8 * c)) & 0xFF), alpha) & 0xFF) << (8 * c);
+      s1 |= ((uint32_t)(int)__fmul_rn((float)((p1 >> (8 * c)) & 0xFF), inv) & 0xFF) << (8 * c);
+    }
+  }
+  const uint32_t lo = ((__umul24(s2 & 0x00FF00FFu, bf) + __umul24(s1 & 0x00FF00FFu, nbf)) >> 8) & 0x00FF00FFu;
+  const uint32_t hi = ((__umul24((s2 >> 8) & 0xFFu, bf) + __umul24((s1 >> 8) & 0xFFu, nbf))) & 0x0000FF00u;
+  return lo | hi | (p1 & 0xFF000000u);
+}
+
+template <int CHAIN>
+__global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
+  __shared__ uint8_t s_lut[256];
+  if (CHAIN) { stage_lut(s_lut, lut); __syncthreads(); }
+  const int lane = threadIdx.x & 63;
+  int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int per_track = A.strips * A.bands;
+  if (item >= per_track * A.ntracks) return;
+  const int track = item / per_track;
+  item -= track * per_track;
+  const int band = item / A.strips, strip = item - band * A.strips;
+  const int k = strip * 62 - 1 + lane;                    // this lane's source quad: pixels 4k .. 4k + 3
+  const int kmax = (A.sw >> 2) - 1;
+  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
+  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
+  const uint8_t *src = T.src[track] + 16 * (size_t)kc;
+  const bool out_lane = lane >= 1 && lane <= 62 && k <= kmax;
+  uint32_t bf = A.bf;
+  if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
+  const uint32_t nbf = 255u - bf;
+
+  auto load_row = [&](int sy) -> pb_u4 {
+    sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
+    pb_u4 q = *reinterpret_cast<const pb_u4 *>(src + (size_t)sy * A.irow);
+    if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
+    if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }       // right of the frame: the last pixel repeated
+    return q;
+  };
+  uint32_t hp[8], hq[8], hr[8], hs[8];
+  const int sy0 = 2 * y0 - 1;
+  pb_half_hrow(load_row(sy0), A.vin2, A.vout2, hp);
+  pb_half_hrow(load_row(sy0 + 1), A.vin2, A.vout2, hq);
+  pb_u4 qa = load_row(sy0 + 2), qb = load_row(sy0 + 3);
+  const uint32_t vi = A.vin2 & 0xFFFFu, vo = A.vout2 & 0xFFFFu;
+  for (int r = 0; r < rows; r++) {
+    const pb_u4 na = load_row(sy0 + 2 * r + 4), nb = load_row(sy0 + 2 * r + 5);       // the next output row's new source rows, in flight during this row's arithmetic
+    pb_half_hrow(qa, A.vin2, A.vout2, hr);
+    pb_half_hrow(qb, A.vin2, A.vout2, hs);
+    uint32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = __umul24(hq[i] + hr[i], vi) + __umul24(hp[i] + hs[i], vo);
+    uint32_t px0 = pb_half_pixel(v[0], v[1], v[2], v[3], A.ashift, A.swap_rb), px1 = pb_half_pixel(v[4], v[5], v[6], v[7], A.ashift, A.swap_rb);
+    const int y = y0 + r;
+    if (out_lane) {
+      if (CHAIN) {
+        if (A.blend) {
+          const uint2 l2 = *reinterpret_cast<const uint2 *>(T.l2[track] + (size_t)y * A.irow2 + 8 * (size_t)k);
+          px0 = pb_chroma_rgba(px0, l2.x, bf, nbf);
+          px1 = pb_chroma_rgba(px1, l2.y, bf, nbf);
+        }
+        if (A.use_lut) { px0 = lut3_rgba(s_lut, px0); px1 = lut3_rgba(s_lut, px1); }
+      }
+      typedef unsigned pb_u2 __attribute__((ext_vector_type(2)));
+      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)y * A.orow + 8 * (size_t)k);
+      pb_u2 o;
+      o.x = px0; o.y = px1;
+      if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { hp[i] = hr[i]; hq[i] = hs[i]; }
+    qa = na; qb = nb;
+  }
+}
+
+// the rest of the chain behind a resize that was not fused: [R <-> B] -> chroma blend with layer 2 -> gamma LUT, one RGBA pixel per thread
+__global__ __launch_bounds__(256) void k_pb_epilogue(const uint8_t *trk, int irow, const uint8_t *l2, int irow2, uint8_t *dst, int orow, int width, int height,
+                                                     int swap_rb, uint32_t bf, const int32_t *bf_d, int use_lut, const Lut8 lut) {
+  __shared__ uint8_t s_lut[256];
+  stage_lut(s_lut, lut);
+  __syncthreads();
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= width || y >= height) return;
+  if (bf_d) bf = (uint32_t)bf_d[0] & 0xFF;
+  uint32_t p = reinterpret_cast<const uint32_t *>(trk + (size_t)y * irow)[x];
+  if (swap_rb) p = __builtin_amdgcn_perm(p, p, 0x03000102u);
+  p = pb_chroma_rgba(p, reinterpret_cast<const uint32_t *>(l2 + (size_t)y * irow2)[x], bf, 255u - bf);
+  if (use_lut) p = lut3_rgba(s_lut, p);
+  reinterpret_cast<uint32_t *>(dst + (size_t)y * orow)[x] = p;
+}
+
 // ---- host: the per-phase weight tables ----------------------------------------------------------------------------------------------------
 struct PbDim { int n; double offset; std::vector<double> w; };   // w[phase * n + tap]
 
@@ -234,6 +396,84 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, const PbTable **
   return it->second->table_d ? LGPU_OK : LGPU_E_UNSUPPORTED;
 }
 
+
+// the exact-2:1 fast path: geometry, alignment, and the table really being the outer product the kernel evaluates
+static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int dh, uintptr_t src_bits, uintptr_t dst_bits, uint32_t *vin, uint32_t *vout, int *ashift) {
+  if (sw != 2 * dw || sh != 2 * dh || (sw & 3) || (src_bits & 15) || (dst_bits & 7)) return false;
+  const int vi = interp == 3 ? 7 : 1, vo = interp == 3 ? 1 : 0, scale = interp == 3 ? 256 : 16384, first = interp == 3 ? 0 : 1;
+  if (t->xoff != (interp == 3 ? -65536 : 0) || t->yoff != t->xoff) return false;
+  const int *w = t->host.data();                       // phase (0, 0)
+  for (int ty = 0; ty < t->n_y; ty++)
+    for (int tx = 0; tx < t->n_x; tx++) {
+      const int ky = ty + first, kx = tx + first;      // position in the 4-tap vector [vo vi vi vo] that starts at source pixel 2X - 1
+      const int wy = (ky < 0 || ky > 3) ? 0 : (ky == 0 || ky == 3) ? vo : vi, wx = (kx < 0 || kx > 3) ? 0 : (kx == 0 || kx == 3) ? vo : vi;
+      if (w[ty * t->n_x + tx] != scale * wy * wx) return false;
+    }
+  *vin = (uint32_t)vi * 0x00010001u; *vout = (uint32_t)vo * 0x00010001u; *ashift = interp == 3 ? 8 : 2;
+  return true;
+}
+
+static void pb_half_geometry(PbHalfArgs *a, int ntracks) {
+  a->strips = (int)cdiv((unsigned)a->dw, 124);
+  a->th = 32;
+  while (a->th > 8 && (long long)a->strips * cdiv((unsigned)a->dh, (unsigned)a->th) * ntracks < 3000) a->th >>= 1;
+  a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
+  a->ntracks = ntracks;
+}
+
+// the fused chain on the pixbuf arithmetic (lgpu_chain with LGPU_INTERP_PIXBUF): convert -> gdk-pixbuf 2:1 scale -> chroma blend -> gamma LUT in one launch.
+// LGPU_E_UNSUPPORTED when the geometry is not the exact aligned 2:1 case (the caller then runs the stages one by one).
+int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+  const int interp = pr->interp & 0xFF;
+  if (interp != 2 && interp != 3) return LGPU_E_UNSUPPORTED;
+  const PbTable *t;
+  int rc = pb_table(interp, pr->sw, pr->sh, pr->dw, pr->dh, &t);
+  if (rc) return rc;
+  uintptr_t sb = (uintptr_t)pr->irow, db = (uintptr_t)pr->orow | (uintptr_t)pr->irow2;
+  for (int i = 0; i < ntracks; i++) { sb |= (uintptr_t)tracks[i].src_d; db |= (uintptr_t)tracks[i].dst_d | (uintptr_t)tracks[i].layer2_d; }
+  PbHalfArgs a;
+  if (!pb_half_ok(t, interp, pr->sw, pr->sh, pr->dw, pr->dh, sb, db, &a.vin2, &a.vout2, &a.ashift)) return LGPU_E_UNSUPPORTED;
+  a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
+  a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
+  a.nt_out = 1;
+  pb_half_geometry(&a, ntracks);
+  PbTracks T;
+  for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
+  const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
+  hipLaunchKernelGGL(k_pb_half<1>, dim3(cdiv((unsigned)(a.strips * a.bands * ntracks), 4)), dim3(256), 0, st, a, T, l);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+// lgpu_chain with LGPU_INTERP_PIXBUF.  One fused launch for the exact aligned 2:1 case; otherwise (and with the blur stage) the stages run one after
+// the other through stream-ordered scratch frames: pixbuf scale -> [5x5 gaussian] -> [R <-> B] + chroma blend + gamma LUT.  The channel swap commutes with the
+// scaler and the gaussian (both treat the three colour bytes alike), so it rides in the last kernel.
+int pb_chain(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+  int rc;
+  if (!pr->do_blur) {
+    rc = pb_chain_half(pr, tracks, ntracks, st);
+    if (rc != LGPU_E_UNSUPPORTED) return rc;
+  }
+  const int interp = pr->interp & 0xFF;
+  const size_t per = (size_t)pr->dw * 4 * pr->dh;
+  void *sa = nullptr, *sb = nullptr;
+  if ((rc = lgpu_malloc_ordered(&sa, per, st))) return rc;
+  if (pr->do_blur && (rc = lgpu_malloc_ordered(&sb, per, st))) { lgpu_free_ordered(sa, st); return rc; }
+  const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
+  for (int i = 0; i < ntracks && !rc; i++) {
+    rc = lgpu_pixbuf_scale(tracks[i].src_d, pr->irow, pr->sw, pr->sh, (uint8_t *)sa, pr->dw * 4, pr->dw, pr->dh, 4, interp, st);
+    const uint8_t *trk = (const uint8_t *)sa;
+    if (!rc && pr->do_blur) { rc = lgpu_gauss5((const uint8_t *)sa, pr->dw * 4, (uint8_t *)sb, pr->dw * 4, pr->dw, pr->dh, 4, st); trk = (const uint8_t *)sb; }
+    if (rc) break;
+    hipLaunchKernelGGL(k_pb_epilogue, dim3(cdiv((unsigned)pr->dw, 64), cdiv((unsigned)pr->dh, 4)), dim3(256), 0, st, trk, pr->dw * 4, tracks[i].layer2_d, pr->irow2,
+                       tracks[i].dst_d, pr->orow, pr->dw, pr->dh, pr->swap_rb ? 1 : 0, (uint32_t)pr->bf & 0xFF, pr->param_block_d, pr->use_lut ? 1 : 0, l);
+    if (hipGetLastError() != hipSuccess) { set_error("k_pb_epilogue launch failed"); rc = LGPU_E_HIP; }
+  }
+  lgpu_free_ordered(sa, st);
+  if (sb) lgpu_free_ordered(sb, st);
+  return rc;
+}
+
 }  // namespace lgpu
 
 using namespace lgpu;
@@ -278,6 +518,19 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   if ((rc = pb_table(interp, sw, sh, dw, dh, &t))) {
     if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d needs %d x %d taps; the library's two-step scaler is not covered", sw, sh, dw, dh, t->n_x, t->n_y);
     return rc;
+  }
+  if (channels == 4) {
+    PbHalfArgs h;
+    if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.vin2, &h.vout2, &h.ashift)) {
+      h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0;
+      pb_half_geometry(&h, 1);
+      PbTracks T;
+      T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
+      hipLaunchKernelGGL(k_pb_half<0>, dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
   }
   PbArgs a;
   a.src = src_d; a.dst = dst_d; a.irow = irow; a.orow = orow; a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;

@@ -1442,7 +1442,9 @@ int orc_chain(const uint8_t *src, int irow, int sw, int sh, const uint8_t *layer
   if (!conv || !rs) goto out;
   if (swap_rb) orc_swizzle(ORC_SWAP3POSTALPHA, 0, src, irow, conv, sw * 4, sw, sh, NULL);
   else for (int y = 0; y < sh; y++) memcpy(conv + (size_t)y * sw * 4, src + (size_t)y * irow, (size_t)sw * 4);
-  if (orc_resize(conv, sw * 4, sw, sh, rs, dw * 4, dw, dh, 4, interp)) goto out;
+  if (interp & 0x100) {      /* LGPU_INTERP_PIXBUF: the resize stage is the reference's gdk-pixbuf body (orc_pixbuf.c), 4 channels with alpha */
+    if (orc_pixbuf_scale(conv, sw * 4, sw, sh, rs, dw * 4, dw, dh, 4, interp & 0xFF)) goto out;
+  } else if (orc_resize(conv, sw * 4, sw, sh, rs, dw * 4, dw, dh, 4, interp)) goto out;
   if (do_blur) {
     bl = malloc((size_t)dw * 4 * dh);
     if (!bl) goto out;

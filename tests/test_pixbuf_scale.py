@@ -204,3 +204,96 @@ def test_gpu_strong_reductions(gpu, orc):
     with pytest.raises(lib.LgpuError):
         gpu.pixbuf_scale(src, d, 120, 120, 2, 2, channels=4, interp=3)
     assert (host(d) == 7).all()
+
+
+@gpu_mark
+@pytest.mark.parametrize("psize", [3, 4])
+def test_compositor_flow_scales_its_layers_as_the_reference_does(gpu, orc, psize):
+    """lives-plugins/weed-plugins/gdk/compositor.c:225-282: every in channel becomes a pixbuf (with alpha for 4-byte palettes, :83-90), is scaled to its
+    on-screen size by gdk_pixbuf_scale_simple -- GDK_INTERP_HYPER when either side grows, GDK_INTERP_BILINEAR otherwise (:154-155, :262-266) -- and painted
+    by paint_pixel.  GPU: lgpu_pixbuf_scale + lgpu_composite against the pinned restatement of both (and the live library where it loads)."""
+    rng = np.random.default_rng(0x9DB9 + psize)
+    ow, oh = 160, 90
+    layers_o, layers_g, keep = [], [], []
+    geo = [(64, 36, 100, 56, 10, 8, 0.75), (200, 120, 80, 48, 70, 30, 1.0), (50, 40, 50, 70, 0, 20, 0.5), (96, 54, 96, 54, 60, 36, 0.3)]
+    for (iw, ih, w, h, ox, oy, al) in geo:
+        src = rng.integers(0, 256, (ih, align(iw * psize, 4)), dtype=np.uint8)
+        interp = 3 if (w > iw or h > ih) else 2
+        scaled = np.zeros((h, align(w * psize, 4)), np.uint8)
+        assert orc.orc_pixbuf_scale(P(src), src.strides[0], iw, ih, P(scaled), scaled.strides[0], w, h, psize, interp) == 0
+        if pr.available():
+            assert (pr.scale_simple(src, iw, psize, w, h, interp) == scaled[:, :w * psize]).all()
+        d_scaled = dev(np.zeros_like(scaled))
+        gpu.pixbuf_scale(dev(src), d_scaled, iw, ih, w, h, channels=psize, interp=interp)
+        keep.append(scaled)
+        layers_o.append((scaled, w, h, ox, oy, al))
+        layers_g.append((d_scaled, w, h, ox, oy, al))
+    L = (po.CompLayer * len(geo))()
+    for z, (a, w, h, ox, oy, al) in enumerate(layers_o):
+        L[z].src, L[z].irow, L[z].width, L[z].height, L[z].offs_x, L[z].offs_y, L[z].alpha = a.ctypes.data, a.strides[0], w, h, ox, oy, al
+    bg = [12, 200, 99]
+    for revz in (0, 1):
+        want = np.zeros((oh, align(ow * psize, 4)), np.uint8)
+        orc.orc_composite(P(want), want.strides[0], ow, oh, psize, 0, (ctypes.c_int * 3)(*bg), L, len(geo), revz)
+        d = dev(np.zeros_like(want))
+        gpu.composite(d, ow, oh, psize, layers_g, bgcol=bg, is_bgr=0, revz=revz)
+        assert (host(d)[:, :ow * psize] == want[:, :ow * psize]).all(), "revz %d" % revz
+
+
+@gpu_mark
+def test_chain_on_the_pixbuf_arithmetic(gpu, orc):
+    """lgpu_chain with LGPU_INTERP_PIXBUF: convert -> gdk-pixbuf scale (4 channels, alpha-weighted) -> chroma blend -> gamma LUT == the oracle's composition
+    of the pinned single stages.  The exact aligned 2:1 cases take the one-launch kernel k_pb_half (HYPER and BILINEAR, several tracks, strips that end
+    inside the frame, bands of every height); the others the staged path (other ratios, the blur stage, unaligned rowstrides)."""
+    PIXBUF = 0x100
+    rng = np.random.default_rng(0x9DBA)
+    lut = np.zeros(256, np.uint8)
+    assert orc.orc_gamma_lut8(1.0, -1, 1, 1.4, P(lut)) == 1
+    cases = [  # sw, sh, dw, dh, interp, swap, bf, ntracks, use_lut, blur, src pad, dst pad
+        (256, 144, 128, 72, 3, 1, 128, 1, 1, 0, 0, 0), (512, 40, 256, 20, 3, 0, 77, 3, 0, 0, 0, 0), (1000, 132, 500, 66, 3, 1, 255, 2, 1, 0, 16, 8),
+        (256, 144, 128, 72, 2, 1, 100, 2, 1, 0, 0, 0), (8, 4, 4, 2, 3, 0, 9, 1, 1, 0, 0, 0), (3840, 64, 1920, 32, 3, 1, 200, 1, 1, 0, 0, 0),
+        (248, 1000, 124, 500, 3, 1, 33, 1, 0, 0, 0, 0), (252, 66, 126, 33, 2, 0, 0, 1, 1, 0, 0, 0),
+        (258, 66, 129, 33, 3, 1, 128, 1, 1, 0, 0, 0),            # sw % 4 != 0: staged
+        (256, 144, 128, 72, 3, 1, 128, 1, 1, 0, 4, 4),            # rowstrides not multiples of 16 / 8: staged
+        (300, 200, 128, 72, 3, 1, 90, 2, 1, 0, 0, 0), (128, 72, 256, 144, 3, 0, 90, 1, 1, 0, 0, 0), (256, 144, 128, 72, 3, 1, 128, 2, 1, 1, 0, 0)]
+    for (sw, sh, dw, dh, interp, swap, bf, ntr, use_lut, blur, spad, dpad) in cases:
+        irow, orow = sw * 4 + spad, dw * 4 + dpad
+        srcs = [rng.integers(0, 256, (sh, irow), dtype=np.uint8) for _ in range(ntr)]
+        for s_ in srcs:
+            a = s_[:, 3:sw * 4:4]
+            a[rng.random(a.shape) < 0.3] = 255
+            a[rng.random(a.shape) < 0.15] = 0
+        l2s = [rng.integers(0, 256, (dh, orow), dtype=np.uint8) for _ in range(ntr)]
+        for l_ in l2s:
+            a = l_[:, 3:dw * 4:4]
+            a[rng.random(a.shape) < 0.5] = 255
+        wants = []
+        for i in range(ntr):
+            w_ = np.zeros((dh, orow), np.uint8)
+            assert orc.orc_chain(P(srcs[i]), irow, sw, sh, P(l2s[i]), orow, P(w_), orow, dw, dh, swap, interp | PIXBUF, blur, bf, P(lut) if use_lut else None) == 0
+            wants.append(w_)
+        dd = [dev(np.zeros((dh, orow), np.uint8)) for _ in range(ntr)]
+        prm = gpu.chain_params(sw, sh, irow, dw, dh, orow, orow, swap_rb=swap, interp=interp | PIXBUF, do_blur=blur, bf=bf, lut=lut if use_lut else None)
+        gpu.chain(prm, gpu.chain_tracks([dev(s_) for s_ in srcs], [dev(s_) for s_ in l2s], dd))
+        for i in range(ntr):
+            got = host(dd[i])
+            bad = np.argwhere(got[:, :dw * 4] != wants[i][:, :dw * 4])
+            assert len(bad) == 0, "chain(pixbuf) %dx%d->%dx%d interp %d track %d: %d bytes differ, first %s" % (sw, sh, dw, dh, interp, i, len(bad), bad[0].tolist())
+            assert (got[:, dw * 4:] == 0).all(), "row padding written"
+
+
+@gpu_mark
+def test_chain_pixbuf_reads_the_device_parameter_block(gpu, orc):
+    import torch
+    PIXBUF = 0x100
+    rng = np.random.default_rng(0x9DBB)
+    for (sw, sh, dw, dh) in [(256, 144, 128, 72), (300, 200, 128, 72)]:
+        src = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)
+        l2 = rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8)
+        want = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_chain(P(src), sw * 4, sw, sh, P(l2), dw * 4, P(want), dw * 4, dw, dh, 1, 3 | PIXBUF, 0, 201, None) == 0
+        block = torch.tensor([201, 0, 0, 0], dtype=torch.int32, device="cuda")
+        d = dev(np.zeros_like(want))
+        prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=5, lut=None, param_block=block)
+        gpu.chain(prm, gpu.chain_tracks([dev(src)], [dev(l2)], [d]))
+        assert (host(d) == want).all()
