@@ -23,12 +23,15 @@
 // two-dimensional (rounded and corrected per phase), not separable.
 #include "lgpu_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
 #include <vector>
 
 namespace lgpu {
+
+int get_kscale(const uint2 **out);      // resize.hip: the chroma blend's alpha scalers as a device table
 
 struct PbArgs {
   const uint8_t *src;
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(256) void k_pb_nearest(const uint8_t *src, int irow
 // =====================================================================================================================================================
 struct PbHalfArgs {
   int sw, sh, irow, dw, dh, orow;
-  uint32_t vin2, vout2;          // inner / outer tap as (v | v << 16)
+  int hyper;                     // 1: [1 7 7 1] (GDK_INTERP_HYPER), 0: [0 1 1 0] (GDK_INTERP_BILINEAR)
+  const uint2 *kscale;           // device [256] {K2, K1}: the chroma blend's translucent scalers (lgpu_alpha_scalers)
   int ashift;                    // alpha' = V_alpha >> ashift   (HYPER 8, BILINEAR 2)
   int swap_rb, blend, irow2, use_lut;
   uint32_t bf;
@@ -175,43 +179,182 @@ struct PbTracks {
 };
 typedef unsigned short pb_us2 __attribute__((ext_vector_type(2)));
 typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned pb_u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pb_dot2(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_udot2(__builtin_bit_cast(pb_us2, a), __builtin_bit_cast(pb_us2, b), c, false);
 }
-// one source row of a lane: 4 pixels -> the two H columns of its 4 channels (h[c] = column 2k, h[4 + c] = column 2k + 1)
-__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t vin2, uint32_t vout2, uint32_t h[8]) {
-  const uint32_t a01 = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u), a23 = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);     // alpha pairs as 2 x u16
-  uint32_t A[4], B[4];
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    // (alpha * q_c) of both pixels of a pair: colour bytes spread to 16-bit lanes, packed multiply (products < 2^16)
-    const uint32_t sel = 0x0C040C00u + 0x00010001u * c;
-    const pb_us2 c01 = __builtin_bit_cast(pb_us2, __builtin_amdgcn_perm(q.y, q.x, sel)), c23 = __builtin_bit_cast(pb_us2, __builtin_amdgcn_perm(q.w, q.z, sel));
-    A[c] = __builtin_bit_cast(uint32_t, c01 * __builtin_bit_cast(pb_us2, a01));
-    B[c] = __builtin_bit_cast(uint32_t, c23 * __builtin_bit_cast(pb_us2, a23));
+// (alpha * byte C) of two pixels as a 16-bit pair, straight from the packed pixels: SDWA multiplies select the bytes and place the 16-bit product
+template <int C>
+__device__ __forceinline__ uint32_t pb_premul_pair(uint32_t q0, uint32_t q1) {
+  uint32_t d;
+  if (C == 0) {
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(d) : "v"(q0));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0" : "+v"(d) : "v"(q1));
+  } else if (C == 1) {
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(d) : "v"(q0));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_1" : "+v"(d) : "v"(q1));
+  } else {
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(d) : "v"(q0));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2" : "+v"(d) : "v"(q1));
   }
-  A[3] = a01; B[3] = a23;
+  return d;
+}
+__device__ __forceinline__ uint32_t pb_add_hi_lo(uint32_t x, uint32_t y) {      // x.hi16 + y.lo16
+  uint32_t d;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+// one source row of a lane: 4 pixels -> the two H columns of its 4 channels (h[c] = column 2k, h[4 + c] = column 2k + 1)
+template <int HYPER>
+__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8]) {
+  uint32_t A[4], B[4];
+  A[0] = pb_premul_pair<0>(q.x, q.y); B[0] = pb_premul_pair<0>(q.z, q.w);
+  A[1] = pb_premul_pair<1>(q.x, q.y); B[1] = pb_premul_pair<1>(q.z, q.w);
+  A[2] = pb_premul_pair<2>(q.x, q.y); B[2] = pb_premul_pair<2>(q.z, q.w);
+  A[3] = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u); B[3] = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);       // the alpha pairs
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    const uint32_t bl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B[c], 0x138, 0xF, 0xF, false);     // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1])
-    const uint32_t ar = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A[c], 0x130, 0xF, 0xF, false);     // wave_shl:1 -- the right lane's (P[4k+4], P[4k+5])
-    const uint32_t o0 = __builtin_amdgcn_alignbit(B[c], bl, 16);      // (P[4k-1], P[4k+2])
-    const uint32_t o1 = __builtin_amdgcn_alignbit(ar, A[c], 16);      // (P[4k+1], P[4k+4])
-    h[c] = pb_dot2(o0, vout2, pb_dot2(A[c], vin2, 0u));
-    h[4 + c] = pb_dot2(o1, vout2, pb_dot2(B[c], vin2, 0u));
+    if (HYPER) {
+#if defined(PBH_VARIANT) && (PBH_VARIANT & 2)
+      const uint32_t bl = B[c] ^ 1u, ar = A[c] ^ 1u;       // timing probe only: no lane exchange
+#else
+      const uint32_t bl = (uint32_t)__builtin_amdgcn_mov_dpp((int)B[c], 0x138, 0xF, 0xF, true);     // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1])
+      const uint32_t ar = (uint32_t)__builtin_amdgcn_mov_dpp((int)A[c], 0x130, 0xF, 0xF, true);     // wave_shl:1 -- the right lane's (P[4k+4], P[4k+5])
+#endif
+      h[c] = pb_dot2(A[c], 0x00070007u, pb_add_hi_lo(bl, B[c]));          // P[4k-1] + 7 P[4k] + 7 P[4k+1] + P[4k+2]
+      h[4 + c] = pb_dot2(B[c], 0x00070007u, pb_add_hi_lo(A[c], ar));      // P[4k+1] + 7 P[4k+2] + 7 P[4k+3] + P[4k+4]
+    } else {
+      h[c] = pb_dot2(A[c], 0x00010001u, 0u);
+      h[4 + c] = pb_dot2(B[c], 0x00010001u, 0u);
+    }
   }
 }
-__device__ __forceinline__ uint32_t pb_half_pixel(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t va, int ashift, int swap_rb) {
-  if (!va) return 0u;
+// V_c * fl(1 / V_alpha), truncated, for the three colours of one pixel
+__device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t va, uint32_t c[3]) {
+#if defined(PBH_VARIANT) && (PBH_VARIANT & 4)
+  c[0] = (v0 >> 16) + (va & 1); c[1] = v1 >> 16; c[2] = v2 >> 16;       // timing probe only: no division
+#else
   const double ia = 1.0 / (double)va;
-  const uint32_t c0 = (uint32_t)(uint8_t)((double)v0 * ia), c1 = (uint32_t)(uint8_t)((double)v1 * ia), c2 = (uint32_t)(uint8_t)((double)v2 * ia);
-  return (swap_rb ? (c2 | (c0 << 16)) : (c0 | (c2 << 16))) | (c1 << 8) | ((va >> ashift) << 24);
+  c[0] = (uint32_t)(int)((double)v0 * ia); c[1] = (uint32_t)(int)((double)v1 * ia); c[2] = (uint32_t)(int)((double)v2 * ia);
+#endif
 }
 
+template <int CHAIN, int HYPER>
+__global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
+  __shared__ uint8_t s_lut[256];
+  __shared__ pb_u2 s_k[256];
+  if (CHAIN) {
+    stage_lut(s_lut, lut);
+    if (A.blend) {
+      const uint2 kk = A.kscale[threadIdx.x];
+      pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
+      s_k[threadIdx.x] = kv;
+    }
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
+  const int per_track = A.strips * A.bands;
+  if (item >= per_track * A.ntracks) return;
+  const int track = item / per_track;
+  item -= track * per_track;
+  const int band = item / A.strips, strip = item - band * A.strips;
+  const int k = strip * 62 - 1 + lane;                    // this lane's source quad: pixels 4k .. 4k + 3
+  const int kmax = (A.sw >> 2) - 1;
+  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
+  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
+  const uint8_t *rowbase = T.src[track];          // uniform
+  const uint32_t lane_off = 16u * (uint32_t)kc;
+  const bool out_lane = lane >= 1 && lane <= 62 && k <= kmax;
+  const bool edge_strip = strip == 0 || (strip + 1) * 62 >= kmax;        // wave-uniform: some lanes of this strip lie outside the frame
+  uint32_t bf = A.bf;
+  if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
+  const uint32_t w_lo = bf | ((255u - bf) << 8);
+
+  auto load_row = [&](int sy) -> pb_u4 {
+    sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
+#if defined(PBH_VARIANT) && (PBH_VARIANT & 1)
+    return __builtin_nontemporal_load(reinterpret_cast<const pb_u4 *>(rowbase + (size_t)sy * A.irow + lane_off));
+#else
+    return *reinterpret_cast<const pb_u4 *>(rowbase + (size_t)sy * A.irow + lane_off);      // plain loads: measured faster than non-temporal ones (band seams and strip halos re-read through L2)
+#endif
+  };
+  // lanes outside the frame (edge strips only, a wave-uniform test) repeat the border pixel; applied when a row is consumed, so that no load is waited for early
+  auto fix = [&](pb_u4 q) -> pb_u4 {
+    if (edge_strip) {
+      if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
+      if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }       // right of the frame: the last pixel repeated
+    }
+    return q;
+  };
+  const uint8_t *l2base = (CHAIN && A.blend) ? T.l2[track] : nullptr;
+  const uint32_t l2_off = 8u * (uint32_t)kc;
+  auto load_l2 = [&](int y) -> pb_u2 {
+    y = y > A.dh - 1 ? A.dh - 1 : y;
+    return __builtin_nontemporal_load(reinterpret_cast<const pb_u2 *>(l2base + (size_t)y * A.irow2 + l2_off));
+  };
+  // carry[i] = (outer tap) * H[2Y-1] + (inner tap) * H[2Y]: the half of output row Y that is known before its last two source rows arrive
+  uint32_t carry[8], hr[8], hs[8];
+  const int sy0 = 2 * y0 - 1;
+  pb_u4 q0 = load_row(sy0), q1 = load_row(sy0 + 1), qa = load_row(sy0 + 2), qb = load_row(sy0 + 3);
+  pb_u2 l2;
+  l2.x = 0; l2.y = 0;
+  if (CHAIN && A.blend) l2 = load_l2(y0);
+  pb_half_hrow<HYPER>(fix(q0), hr);
+  pb_half_hrow<HYPER>(fix(q1), hs);
+#pragma unroll
+  for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
+  for (int r = 0; r < rows; r++) {
+    // the next output row's two new source rows and its layer-2 pixels: in flight during this row's arithmetic
+    const pb_u4 na = load_row(sy0 + 2 * r + 4), nb = load_row(sy0 + 2 * r + 5);
+    pb_u2 nl2;
+    nl2.x = 0; nl2.y = 0;
+    if (CHAIN && A.blend) nl2 = load_l2(y0 + r + 1);
+    pb_half_hrow<HYPER>(fix(qa), hr);
+    pb_half_hrow<HYPER>(fix(qb), hs);
+    uint32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
+      else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
+    }
+    const int y = y0 + r;
+    uint32_t px[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t va = v[4 * j + 3];
+      uint32_t c[3];
+      pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, c);       // V_alpha == 0 makes every V_c 0 too: 0 * fl(1 / 1) = 0, the library's all-zero pixel
+      if (A.swap_rb) { const uint32_t t = c[0]; c[0] = c[2]; c[2] = t; }
+      const uint32_t al = (va >> A.ashift) << 24;
+      if (CHAIN && A.blend) {
+        // chroma blend (simple_blend.c:117-146) on the colours while they are still apart: s2 = (layer-2 colour * K2[alpha2]) >> 16, s1 = (track colour * K1[alpha2]) >> 16
+        // (the reference's float scaling of translucent pixels as integers, lgpu_alpha_scalers; alpha 255 = identity), then (bf * s2 + (255 - bf) * s1) >> 8
+        const uint32_t q = j ? l2.y : l2.x;
+        const pb_u2 kk = s_k[q >> 24];
+        const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
+        const uint32_t pa = __umul24(c[0], kk.y), pb = __umul24(c[1], kk.y), pc = __umul24(c[2], kk.y);
+        c[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+        c[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+        c[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      }
+      if (CHAIN && A.use_lut) { c[0] = s_lut[c[0]]; c[1] = s_lut[c[1]]; c[2] = s_lut[c[2]]; }
+      px[j] = c[0] | (c[1] << 8) | (c[2] << 16) | al;
+    }
+    if (out_lane) {
+      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)y * A.orow + 8 * (size_t)k);
+      pb_u2 o;
+      o.x = px[0]; o.y = px[1];
+      if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
+    }
+    qa = na; qb = nb; l2 = nl2;
+  }
+}
+
+// chroma blend of simple_blend.c:117-146 on an RGBA pair (the staged path's form): opaque layer-2 pixels through the integer table expression, translucent ones
+// through the reference's float scaling of both sources first; dst alpha = the track's alpha
 __device__ __forceinline__ uint32_t pb_chroma_rgba(uint32_t p1, uint32_t p2, uint32_t bf, uint32_t nbf) {
-  // chroma blend of simple_blend.c:117-146 on an RGBA pair: opaque layer-2 pixels through the integer table expression, translucent ones through
-  // the reference's float scaling of both sources first; dst alpha = the track's alpha
   const uint32_t al = p2 >> 24;
   uint32_t s1 = p1, s2 = p2;
   if (al != 255) {
@@ -226,70 +369,6 @@ __device__ __forceinline__ uint32_t pb_chroma_rgba(uint32_t p1, uint32_t p2, uin
   const uint32_t lo = ((__umul24(s2 & 0x00FF00FFu, bf) + __umul24(s1 & 0x00FF00FFu, nbf)) >> 8) & 0x00FF00FFu;
   const uint32_t hi = ((__umul24((s2 >> 8) & 0xFFu, bf) + __umul24((s1 >> 8) & 0xFFu, nbf))) & 0x0000FF00u;
   return lo | hi | (p1 & 0xFF000000u);
-}
-
-template <int CHAIN>
-__global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
-  __shared__ uint8_t s_lut[256];
-  if (CHAIN) { stage_lut(s_lut, lut); __syncthreads(); }
-  const int lane = threadIdx.x & 63;
-  int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int per_track = A.strips * A.bands;
-  if (item >= per_track * A.ntracks) return;
-  const int track = item / per_track;
-  item -= track * per_track;
-  const int band = item / A.strips, strip = item - band * A.strips;
-  const int k = strip * 62 - 1 + lane;                    // this lane's source quad: pixels 4k .. 4k + 3
-  const int kmax = (A.sw >> 2) - 1;
-  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
-  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
-  const uint8_t *src = T.src[track] + 16 * (size_t)kc;
-  const bool out_lane = lane >= 1 && lane <= 62 && k <= kmax;
-  uint32_t bf = A.bf;
-  if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
-  const uint32_t nbf = 255u - bf;
-
-  auto load_row = [&](int sy) -> pb_u4 {
-    sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
-    pb_u4 q = *reinterpret_cast<const pb_u4 *>(src + (size_t)sy * A.irow);
-    if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
-    if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }       // right of the frame: the last pixel repeated
-    return q;
-  };
-  uint32_t hp[8], hq[8], hr[8], hs[8];
-  const int sy0 = 2 * y0 - 1;
-  pb_half_hrow(load_row(sy0), A.vin2, A.vout2, hp);
-  pb_half_hrow(load_row(sy0 + 1), A.vin2, A.vout2, hq);
-  pb_u4 qa = load_row(sy0 + 2), qb = load_row(sy0 + 3);
-  const uint32_t vi = A.vin2 & 0xFFFFu, vo = A.vout2 & 0xFFFFu;
-  for (int r = 0; r < rows; r++) {
-    const pb_u4 na = load_row(sy0 + 2 * r + 4), nb = load_row(sy0 + 2 * r + 5);       // the next output row's new source rows, in flight during this row's arithmetic
-    pb_half_hrow(qa, A.vin2, A.vout2, hr);
-    pb_half_hrow(qb, A.vin2, A.vout2, hs);
-    uint32_t v[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = __umul24(hq[i] + hr[i], vi) + __umul24(hp[i] + hs[i], vo);
-    uint32_t px0 = pb_half_pixel(v[0], v[1], v[2], v[3], A.ashift, A.swap_rb), px1 = pb_half_pixel(v[4], v[5], v[6], v[7], A.ashift, A.swap_rb);
-    const int y = y0 + r;
-    if (out_lane) {
-      if (CHAIN) {
-        if (A.blend) {
-          const uint2 l2 = *reinterpret_cast<const uint2 *>(T.l2[track] + (size_t)y * A.irow2 + 8 * (size_t)k);
-          px0 = pb_chroma_rgba(px0, l2.x, bf, nbf);
-          px1 = pb_chroma_rgba(px1, l2.y, bf, nbf);
-        }
-        if (A.use_lut) { px0 = lut3_rgba(s_lut, px0); px1 = lut3_rgba(s_lut, px1); }
-      }
-      typedef unsigned pb_u2 __attribute__((ext_vector_type(2)));
-      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)y * A.orow + 8 * (size_t)k);
-      pb_u2 o;
-      o.x = px0; o.y = px1;
-      if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { hp[i] = hr[i]; hq[i] = hs[i]; }
-    qa = na; qb = nb;
-  }
 }
 
 // the rest of the chain behind a resize that was not fused: [R <-> B] -> chroma blend with layer 2 -> gamma LUT, one RGBA pixel per thread
@@ -398,7 +477,7 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, const PbTable **
 
 
 // the exact-2:1 fast path: geometry, alignment, and the table really being the outer product the kernel evaluates
-static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int dh, uintptr_t src_bits, uintptr_t dst_bits, uint32_t *vin, uint32_t *vout, int *ashift) {
+static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int dh, uintptr_t src_bits, uintptr_t dst_bits, int *hyper, int *ashift) {
   if (sw != 2 * dw || sh != 2 * dh || (sw & 3) || (src_bits & 15) || (dst_bits & 7)) return false;
   const int vi = interp == 3 ? 7 : 1, vo = interp == 3 ? 1 : 0, scale = interp == 3 ? 256 : 16384, first = interp == 3 ? 0 : 1;
   if (t->xoff != (interp == 3 ? -65536 : 0) || t->yoff != t->xoff) return false;
@@ -409,14 +488,17 @@ static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int
       const int wy = (ky < 0 || ky > 3) ? 0 : (ky == 0 || ky == 3) ? vo : vi, wx = (kx < 0 || kx > 3) ? 0 : (kx == 0 || kx == 3) ? vo : vi;
       if (w[ty * t->n_x + tx] != scale * wy * wx) return false;
     }
-  *vin = (uint32_t)vi * 0x00010001u; *vout = (uint32_t)vo * 0x00010001u; *ashift = interp == 3 ? 8 : 2;
+  *hyper = interp == 3; *ashift = interp == 3 ? 8 : 2;
   return true;
 }
 
 static void pb_half_geometry(PbHalfArgs *a, int ntracks) {
   a->strips = (int)cdiv((unsigned)a->dw, 124);
-  a->th = 32;
-  while (a->th > 8 && (long long)a->strips * cdiv((unsigned)a->dh, (unsigned)a->th) * ntracks < 3000) a->th >>= 1;
+  // measured (profiles/r03/pbh_sweep.txt): short bands win even when the device is full -- 8 rows at 16 tracks (170 us against 184 at 16 rows), 4 rows when a
+  // launch has fewer than ~8k waves (one 4K frame: 11.5 us against 12.4 at 8 rows, 15.7 at 16)
+  a->th = 8;
+  if ((long long)a->strips * cdiv((unsigned)a->dh, 8u) * ntracks < 8192) a->th = 4;
+  if (const char *e = getenv("LGPU_PBH_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
   a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
   a->ntracks = ntracks;
 }
@@ -432,7 +514,8 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
   uintptr_t sb = (uintptr_t)pr->irow, db = (uintptr_t)pr->orow | (uintptr_t)pr->irow2;
   for (int i = 0; i < ntracks; i++) { sb |= (uintptr_t)tracks[i].src_d; db |= (uintptr_t)tracks[i].dst_d | (uintptr_t)tracks[i].layer2_d; }
   PbHalfArgs a;
-  if (!pb_half_ok(t, interp, pr->sw, pr->sh, pr->dw, pr->dh, sb, db, &a.vin2, &a.vout2, &a.ashift)) return LGPU_E_UNSUPPORTED;
+  if (!pb_half_ok(t, interp, pr->sw, pr->sh, pr->dw, pr->dh, sb, db, &a.hyper, &a.ashift)) return LGPU_E_UNSUPPORTED;
+  if ((rc = get_kscale(&a.kscale))) return rc;
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
   a.nt_out = 1;
@@ -440,7 +523,8 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
   PbTracks T;
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
-  hipLaunchKernelGGL(k_pb_half<1>, dim3(cdiv((unsigned)(a.strips * a.bands * ntracks), 4)), dim3(256), 0, st, a, T, l);
+  if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1>), dim3(cdiv((unsigned)(a.strips * a.bands * ntracks), 4)), dim3(256), 0, st, a, T, l);
+  else hipLaunchKernelGGL((k_pb_half<1, 0>), dim3(cdiv((unsigned)(a.strips * a.bands * ntracks), 4)), dim3(256), 0, st, a, T, l);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
@@ -521,13 +605,15 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   }
   if (channels == 4) {
     PbHalfArgs h;
-    if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.vin2, &h.vout2, &h.ashift)) {
+    if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
       h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0;
       pb_half_geometry(&h, 1);
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
-      hipLaunchKernelGGL(k_pb_half<0>, dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      h.kscale = nullptr;
+      if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      else hipLaunchKernelGGL((k_pb_half<0, 0>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }

@@ -1687,7 +1687,7 @@ static int kernel_for_interp(int interp, bool upscale) {
 // the chroma blend's alpha scalers (lgpu_alpha_scalers, proven while built) as one device table per device: {K2, K1} per layer-2 alpha
 static std::mutex g_ks_mu;
 static std::map<int, uint2 *> g_ks;
-static int get_kscale(const uint2 **out) {
+int get_kscale(const uint2 **out) {
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_ks_mu);

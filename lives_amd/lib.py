@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "liblivesgpu.so")
+SO_PATH = os.environ.get("LGPU_SO") or os.path.join(HERE, "liblivesgpu.so")      # LGPU_SO: a profiling build of the same library (tools/)
 
 vp = ctypes.c_void_p
 ci = ctypes.c_int

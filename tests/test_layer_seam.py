@@ -127,8 +127,9 @@ def test_declines_and_device_failures_leave_the_layer_untouched(seam, orc):
     L.lgpu_debug_fail_alloc(1)
     rc = L.lives_gpu_convert_layer_palette(lay, BGR24, 0)
     L.lgpu_debug_fail_alloc(0)
-    assert rc == 0 and same(s0, snapshot(lay)) and wh.geti(lay, "host_gpu_resident") == 1
-    assert L.lives_gpu_convert_layer_palette(lay, BGR24, 0) == 1 and L.lives_gpu_layer_unpin(lay) == 0
+    # FALSE on a pinned layer, whatever the cause: the layer comes back synchronised and unpinned, so that the host's CPU body reads current bytes
+    assert rc == 0 and same(s0, snapshot(lay)) and wh.geti(lay, "host_gpu_resident") is None
+    assert L.lives_gpu_convert_layer_palette(lay, BGR24, 0) == 1
 
 
 @needs_ref

@@ -124,16 +124,16 @@ def test_a_false_on_a_pinned_layer_always_brings_it_home(seam):
     for a call that fails after it started (allocation failure injected)"""
     L, wh = seam
     rng = np.random.default_rng(0x9DB8)
-    y, u, v = frame(rng, 64, 32, 1), frame(rng, 32, 16, 1), frame(rng, 32, 16, 1)
-    lay = wh.new_layer(YUV420P, 64, 32, [y, u, v], clamping=0, subspace=1)
+    src = frame(rng, 32, 32, 4)                                                       # UYVY: 64 pixels = 32 macropixels of 4 bytes
+    lay = wh.new_layer(UYVY, 32, 32, [src], clamping=0, subspace=1)
     assert L.lives_gpu_layer_pin(lay) == 0
-    assert L.lives_gpu_convert_layer_palette(lay, UYVY, 0) == 1                      # resident UYVY now; the host planes were never written
-    ref = wh.new_layer(YUV420P, 64, 32, [y, u, v], clamping=0, subspace=1)
-    assert L.lives_gpu_convert_layer_palette(ref, UYVY, 0) == 1
-    assert wh.geti(lay, "host_gpu_resident") == 1
+    assert L.lives_gpu_convert_layer_palette_full(lay, UYVY, 1, 0, 1, 0) == 1        # clamped -> unclamped on the device; the host planes are stale now
+    ref = wh.new_layer(UYVY, 32, 32, [src], clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette_full(ref, UYVY, 1, 0, 1, 0) == 1
+    assert wh.geti(lay, "host_gpu_resident") == 1 and (wh.planes_of(lay)[0][0] == src).all()
     assert L.lives_gpu_letterbox_layer(lay, 80, 40, 64, 32, 3, 0, 0) == 0
     assert wh.geti(lay, "host_gpu_resident") is None
-    assert (wh.planes_of(lay)[0][0] == wh.planes_of(ref)[0][0]).all()
+    assert (wh.planes_of(lay)[0][0] == wh.planes_of(ref)[0][0]).all() and not (wh.planes_of(ref)[0][0] == src).all()
     # a failure after the call has started: the second allocation of a resize fails
     src = frame(rng, 128, 64, 4)
     lay = wh.new_layer(RGBA32, 128, 64, [src], gamma=-1)
