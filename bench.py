@@ -109,26 +109,34 @@ def main():
     # N > 1: the library's own RCCL communicator (lgpu_dist_comm_create; torch.distributed only carries its 128-byte id) and the C entry
     # point lgpu_params_broadcast for the per-step exchange, on a side stream, double buffered
     comm = None
-    if world > 1:
+    multi = world > 1 or bool(os.environ.get("LGPU_BENCH_FORCE_EXCHANGE"))     # FORCE: the N > 1 host path (one-rank RCCL communicator, C stepper, config-5 leg) on one GPU
+    if multi:
         # the chain kernel is persistent and fills every CU with two 71.9 KB workgroups; a kernel with a large LDS footprint on another stream -- RCCL's
         # broadcast -- would wait for it to end (tools/corun_probe.py: 164 us instead of 20).  Sixteen free workgroup slots (two per XCD) cost 1 % of the
         # launch and let the broadcast of the next parameter block run beside it (profiles/r02/corun_probe.txt)
         os.environ.setdefault("LGPU_CHAIN_SPARE_WGS", "16")
-    if world > 1 and not os.environ.get("LGPU_BENCH_TORCH_DIST"):
+    if multi and not os.environ.get("LGPU_BENCH_TORCH_DIST"):
         # every rank first checks that it can bind RCCL at all (dlopen + symbols); the communicator is only created when ALL can, so that no rank
         # waits in ncclCommInitRank for one that gave up -- otherwise the parameter block falls back to torch.distributed's broadcast
         can = torch.tensor([1 if load().lgpu_dist_bind(None) == 0 else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if world > 1:
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)
         if int(can.item()) == 1:
             comm = ld.RcclComm("cuda")
         elif rank == 0:
             print("bench.py: librccl could not be bound on every rank; the parameter block goes through torch.distributed", file=sys.stderr)
-    pipe = ld.ParamPipeline("cuda", comm=comm)
     nsched = args.steps + args.warmup
-    if world > 1:
+    sched_host = [[(96 + 7 * s) % 256, 0, 0, 0] for s in range(nsched)]
+    # N > 1 with RCCL bound: the whole per-step host path is ONE C call, lgpu_chain_step (wait for this step's block, exchange the next on a side stream, launch)
+    stepper = ld.Stepper(comm, sched_host[0]) if comm is not None else None
+    pipe = ld.ParamPipeline("cuda", comm=None) if (world > 1 and comm is None) else None
+    if pipe is not None:
         pipe.prefetch(0, schedule[0] if rank == 0 else None)
 
     def step(s):
+        if stepper is not None:
+            stepper.step(sched_host[s + 1] if s + 1 < nsched else None, prm, trks[s % nsets])
+            return
         if world > 1:
             # RCCL broadcast over xGMI, no host sync: the block of step s was sent while step s - 1 ran; send the next one now
             blk = pipe.acquire(s)
@@ -161,6 +169,26 @@ def main():
 
     frames = world * T * args.steps
     fps = frames / dt
+
+    # N > 1: BASELINE config 5's own shape as well -- ONE 4K frame per GPU per step, the exchange on -- through the same C step
+    config5 = None
+    if multi and stepper is not None:
+        stepper.close()
+        stepper = None
+        one = [ops.chain_tracks([k[0][0]], [k[1][0]], [k[2][0]]) for k in keep]
+        n5 = max(args.steps, 200)
+        st5 = ld.Stepper(comm, sched_host[0])
+        for s in range(50):
+            st5.step(sched_host[(s + 1) % nsched], prm, one[s % nsets])
+        fence()
+        t5 = time.perf_counter()
+        for s in range(n5):
+            st5.step(sched_host[(s + 1) % nsched] if s + 1 < n5 else None, prm, one[s % nsets])
+        fence()
+        d5 = ld.max_over_ranks(time.perf_counter() - t5, "cuda")
+        st5.close()
+        config5 = {"config5_fps": round(world * n5 / d5, 1), "config5_ms_per_step": round(d5 / n5 * 1e3, 4), "config5_steps": n5,
+                   "config5_shape": "one 3840x2160 frame per GPU per step, lgpu_chain_step (C) with the RCCL parameter exchange on"}
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around K launches ----
     reps = max(10, min(args.steps, 200))
@@ -200,18 +228,21 @@ def main():
                                    % ("gdk-pixbuf HYPER (alpha-weighted, pinned)" if args.resize_backend == "pixbuf" else "bicubic", " -> 5x5 gaussian" if args.blur else ""),
                        "resize_backend": args.resize_backend,
                        "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
-                       "param_exchange": ("none (one GPU: the kernel reads step s of the resident schedule)" if world == 1 else
-                                          "lgpu_params_broadcast (RCCL, the library's C entry point), pipelined on a side stream" if comm is not None else
+                       "param_exchange": ("none (one GPU: the kernel reads step s of the resident schedule)" if not multi else
+                                          "lgpu_chain_step (C): lgpu_params_set + lgpu_params_broadcast (RCCL) on a side stream, one step ahead of the kernel" if comm is not None else
                                           "torch.distributed broadcast (fallback)"),
                        "launches_per_step": 2 if args.blur else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
             "roofline": roof,
         }
+        if config5:
+            out["config"].update(config5)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.blur)
+    if comm is not None:
+        if world > 1:
+            dist.barrier()
+        comm.close()
     if world > 1:
-        dist.barrier()
-        if comm is not None:
-            comm.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

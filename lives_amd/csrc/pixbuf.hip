@@ -39,6 +39,7 @@ struct PbArgs {
   int irow, orow, sw, sh, dw, dh;
   int x_step, y_step, xoff, yoff;
   int n_x, n_y;
+  int tx0, tx1, ty0, ty1;   // the taps that are non-zero for some destination pixel of this call: [tx0, tx1) x [ty0, ty1)
   const int *table;     // device: [16][16][n_y][n_x]
   unsigned rnd;         // 3-byte interior rounding term
   int tile_h, win_w, win_h;
@@ -108,12 +109,14 @@ __global__ __launch_bounds__(256) void k_pb_window(const PbArgs A) {
     if (j < A.dw) {
       if (UNIFORM_X) {
         const int *wt = A.table + (size_t)__builtin_amdgcn_readfirstlane((yph * 16 + xph) * nn);
-        for (int ty = 0; ty < A.n_y; ty++, wp += A.win_w, wt += A.n_x)
-          for (int tx = 0; tx < A.n_x; tx++) pb_tap<CH>(wp[tx], (unsigned)wt[tx], r, g, b, a);
+        wp += A.ty0 * A.win_w; wt += A.ty0 * A.n_x;
+        for (int ty = A.ty0; ty < A.ty1; ty++, wp += A.win_w, wt += A.n_x)
+          for (int tx = A.tx0; tx < A.tx1; tx++) pb_tap<CH>(wp[tx], (unsigned)wt[tx], r, g, b, a);
       } else {
-        const int *wt = A.table + (size_t)(yph * 16 + xph) * nn;
-        for (int ty = 0; ty < A.n_y; ty++, wp += A.win_w, wt += A.n_x)
-          for (int tx = 0; tx < A.n_x; tx++) pb_tap<CH>(wp[tx], (unsigned)wt[tx], r, g, b, a);
+        const int *wt = A.table + (size_t)(yph * 16 + xph) * nn + A.ty0 * A.n_x;
+        wp += A.ty0 * A.win_w;
+        for (int ty = A.ty0; ty < A.ty1; ty++, wp += A.win_w, wt += A.n_x)
+          for (int tx = A.tx0; tx < A.tx1; tx++) pb_tap<CH>(wp[tx], (unsigned)wt[tx], r, g, b, a);
       }
       pb_finish<CH>(A.dst + (size_t)i * A.orow + (size_t)j * CH, r, g, b, a, edge, A.rnd);
     }
@@ -130,9 +133,10 @@ __global__ __launch_bounds__(256) void k_pb_direct(const PbArgs A) {
   const bool edge = xs < 0 || xs + A.n_x > A.sw;
   const int *wt = A.table + (size_t)(yph * 16 + xph) * A.n_x * A.n_y;
   unsigned r = 0, g = 0, b = 0, a = 0;
-  for (int ty = 0; ty < A.n_y; ty++, wt += A.n_x) {
+  wt += A.ty0 * A.n_x;
+  for (int ty = A.ty0; ty < A.ty1; ty++, wt += A.n_x) {
     const uint8_t *row = A.src + (size_t)pb_clamp(ys + ty, A.sh - 1) * A.irow;
-    for (int tx = 0; tx < A.n_x; tx++) pb_tap<CH>(pb_load_px<CH>(row, pb_clamp(xs + tx, A.sw - 1)), (unsigned)wt[tx], r, g, b, a);
+    for (int tx = A.tx0; tx < A.tx1; tx++) pb_tap<CH>(pb_load_px<CH>(row, pb_clamp(xs + tx, A.sw - 1)), (unsigned)wt[tx], r, g, b, a);
   }
   pb_finish<CH>(A.dst + (size_t)i * A.orow + (size_t)j * CH, r, g, b, a, edge, A.rnd);
 }
@@ -476,6 +480,24 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, const PbTable **
 }
 
 
+// zero taps are common (the 5th row / column of an integer-ratio HYPER table, the far taps of most phases): only the phases this call's destination pixels
+// take are looked at, and the tap loops run over the bounding box of their non-zero weights
+static void pb_used_taps(const PbTable *t, int x_step, int y_step, int dw, int dh, PbArgs *a) {
+  bool xp[16] = {false}, yp[16] = {false};
+  for (int j = 0; j < dw; j++) xp[(((long long)j * x_step + t->xoff) >> 12) & 15] = true;
+  for (int i = 0; i < dh; i++) yp[(((long long)i * y_step + t->yoff) >> 12) & 15] = true;
+  int tx0 = t->n_x, tx1 = 0, ty0 = t->n_y, ty1 = 0;
+  for (int y = 0; y < 16; y++)
+    for (int x = 0; x < 16; x++) {
+      if (!xp[x] || !yp[y]) continue;
+      const int *w = t->host.data() + (size_t)(y * 16 + x) * t->n_x * t->n_y;
+      for (int ty = 0; ty < t->n_y; ty++)
+        for (int tx = 0; tx < t->n_x; tx++)
+          if (w[ty * t->n_x + tx]) { tx0 = tx < tx0 ? tx : tx0; tx1 = tx + 1 > tx1 ? tx + 1 : tx1; ty0 = ty < ty0 ? ty : ty0; ty1 = ty + 1 > ty1 ? ty + 1 : ty1; }
+    }
+  a->tx0 = tx0; a->tx1 = tx1; a->ty0 = ty0; a->ty1 = ty1;
+}
+
 // the exact-2:1 fast path: geometry, alignment, and the table really being the outer product the kernel evaluates
 static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int dh, uintptr_t src_bits, uintptr_t dst_bits, int *hyper, int *ashift) {
   if (sw != 2 * dw || sh != 2 * dh || (sw & 3) || (src_bits & 15) || (dst_bits & 7)) return false;
@@ -622,6 +644,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   a.src = src_d; a.dst = dst_d; a.irow = irow; a.orow = orow; a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
   a.x_step = x_step; a.y_step = y_step; a.xoff = t->xoff; a.yoff = t->yoff; a.n_x = t->n_x; a.n_y = t->n_y; a.table = t->table_d;
   a.rnd = (t->n_x == 2 && t->n_y == 2 && channels == 3) ? 0x8000u : 0xffffu;
+  pb_used_taps(t, x_step, y_step, dw, dh, &a);
   a.win_w = (int)((63LL * x_step + 65535) >> 16) + t->n_x;
   a.tile_h = 0;
   for (int th = 16; th >= 1; th >>= 1) {

@@ -313,6 +313,7 @@ int lgpu_copy_rows(void *dst_d, int orow, const void *src_d, int irow, int row_b
 
 namespace lgpu {
 struct Pat8 { uint8_t b[8]; };
+__global__ void k_set4(int32_t *blk, int32_t a, int32_t b, int32_t c, int32_t d) { if (threadIdx.x == 0) { blk[0] = a; blk[1] = b; blk[2] = c; blk[3] = d; } }
 __global__ __launch_bounds__(kBlock) void k_fill_pattern(uint8_t *dst, int rowstride, Pat8 pat, int plen, int nbytes, int rows) {
   const int x = blockIdx.x * kBlock + threadIdx.x;            // byte within the row
   if (x >= nbytes) return;
@@ -339,6 +340,17 @@ int lgpu_fill_pattern(void *dst_d, int rowstride, const uint8_t *pattern, int pl
 
 int lgpu_sync(void *stream) {
   LGPU_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return LGPU_OK;
+}
+
+// the control rank writes the shared transition parameter block (int32[4], device memory) from four host values: they travel as kernel arguments, so
+// the call costs one launch and no host -> device copy (a 16-byte hipMemcpyAsync from pageable memory stages and blocks)
+int lgpu_params_set(int32_t *param_block_d, const int32_t values[4], void *stream) {
+  int rc = lgpu::ensure_init();
+  if (rc) return rc;
+  if (!param_block_d || !values) { lgpu::set_error("lgpu_params_set: null argument"); return LGPU_E_BADARG; }
+  hipLaunchKernelGGL(lgpu::k_set4, dim3(1), dim3(64), 0, (hipStream_t)stream, param_block_d, values[0], values[1], values[2], values[3]);
+  LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
 

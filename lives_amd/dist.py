@@ -75,6 +75,37 @@ class RcclComm:
             self.comm = None
 
 
+class Stepper:
+    """lgpu_stepper (include/lives_gpu.h): the per-step host path in C -- wait for this step's parameter block, exchange the next one on a side
+    stream beside the kernel, launch the chain -- as one ctypes call.  comm: RcclComm or None (one GPU, nothing to exchange)."""
+
+    def __init__(self, comm, first_values, root=0, stream=None):
+        import ctypes
+        from . import lib
+        self.lib, self.ct = lib, ctypes
+        self.h = ctypes.c_void_p()
+        vals = (ctypes.c_int32 * 4)(*(list(first_values) + [0] * 4)[:4])
+        lib.call("lgpu_stepper_create", comm.comm if comm is not None else None, root, comm.rank if comm is not None else 0, _sp(stream), vals, ctypes.byref(self.h))
+        self._vals = (ctypes.c_int32 * 4)()
+
+    def step(self, next_values, params, tracks):
+        """next_values: the block of the following step (used on the root), None after the last one"""
+        nv = None
+        if next_values is not None:
+            for i in range(4):
+                self._vals[i] = int(next_values[i]) if i < len(next_values) else 0
+            nv = self._vals
+        self.lib.call("lgpu_chain_step", self.h, nv, self.ct.byref(params), tracks, len(tracks))
+
+    def block_ptr(self, which):
+        return self.lib.load().lgpu_stepper_block(self.h, which)
+
+    def close(self):
+        if self.h:
+            self.lib.call("lgpu_stepper_destroy", self.h)
+            self.h = None
+
+
 def _sp(stream):
     if stream is not None:
         return stream.cuda_stream

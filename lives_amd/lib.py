@@ -76,6 +76,11 @@ PROTOTYPES = {
     "lgpu_params_broadcast": [vp, ci, vp, vp],
     "lgpu_status_allreduce": [vp, vp, vp],
     "lgpu_fan_in": [vp, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp],
+    "lgpu_params_set": [vp, vp, vp],
+    "lgpu_stepper_create": [vp, ci, ci, vp, vp, ctypes.POINTER(vp)],
+    "lgpu_chain_step": [vp, vp, vp, vp, ci],
+    "lgpu_stepper_block": [vp, ci],
+    "lgpu_stepper_destroy": [vp],
     "lgpu_copy_rows": [vp, ci, vp, ci, ci, ci, vp],
     "lgpu_fill_pattern": [vp, ci, vp, ci, ci, ci, vp],
     "lgpu_conversion_tables": [ci, vp, vp],
@@ -151,6 +156,7 @@ def load():
             fn.argtypes = args
             fn.restype = ci
         lib.lgpu_pinned_calloc.restype = vp
+        lib.lgpu_stepper_block.restype = vp
         lib.lgpu_pinned_free.restype = None
         lib.lgpu_last_error.restype = ctypes.c_char_p
         lib.lgpu_last_error.argtypes = []

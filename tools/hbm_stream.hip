@@ -1,0 +1,102 @@
+// tools/hbm_stream.hip -- what this box's memory system delivers to hand-written streams of the chain kernel's shape (tools/, not product).
+//
+//   read   : pure read stream, global_load_dwordx4 per lane, 4 loads in flight per lane, xor-reduced so that nothing is elided
+//   copy   : 1 read : 1 write (the guide's float4 copy: 6.29 TB/s on its box)
+//   mix5   : 5 reads : 1 write in 16-byte units -- the byte mix of one lgpu_chain launch (33.2 MB source + 8.3 MB layer 2 read, 8.3 MB written per frame)
+// each as plain / non-temporal accesses, over a working set the size of the bench's step (~800 MB, 3x the 256 MiB Infinity Cache), on two rotating
+// buffer sets.  Output: GB/s of bytes moved (read + written), to be compared with roofline.achieved of bench.py on the same box.
+//
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/_hbm_stream tools/hbm_stream.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int NT>
+__device__ __forceinline__ u4 ld(const u4 *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <int NT>
+__device__ __forceinline__ void st(u4 *p, u4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// grid-stride over 16-byte units; UNROLL independent loads per lane before the first use
+template <int NT, int UNROLL>
+__global__ __launch_bounds__(256) void k_read(const u4 *src, size_t n, u4 *sink) {
+  u4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    u4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) v[u] = ld<NT>(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) acc ^= v[u];
+  }
+  for (; i < n; i += stride) acc ^= ld<NT>(src + i);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc;       // never true for the random fill; keeps the loads
+}
+
+template <int NT, int UNROLL>
+__global__ __launch_bounds__(256) void k_copy(const u4 *src, u4 *dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    u4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) v[u] = ld<NT>(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) st<NT>(dst + i + u * stride, v[u]);
+  }
+  for (; i < n; i += stride) st<NT>(dst + i, ld<NT>(src + i));
+}
+
+// 5 reads (4 from the big stream + 1 from a second stream) : 1 write
+template <int NT>
+__global__ __launch_bounds__(256) void k_mix5(const u4 *big, const u4 *small, u4 *dst, size_t nout) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nout; i += stride) {
+    const u4 a = ld<NT>(big + i), b = ld<NT>(big + nout + i), c = ld<NT>(big + 2 * nout + i), d = ld<NT>(big + 3 * nout + i), e = ld<NT>(small + i);
+    st<NT>(dst + i, a ^ b ^ c ^ d ^ e);
+  }
+}
+
+static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
+
+int main(int argc, char **argv) {
+  const size_t out_units = (size_t)16 * 1920 * 1080 * 4 / 16;          // 16 frames of 1920x1080x4 in 16-byte units = 132.7 MB
+  const size_t big_units = 4 * out_units;                              // 530.8 MB
+  const int sets = 2, reps = 40;
+  u4 *big[2], *small[2], *dst[2], *sink;
+  for (int s = 0; s < sets; s++) {
+    CK(hipMalloc(&big[s], big_units * 16)); CK(hipMalloc(&small[s], out_units * 16)); CK(hipMalloc(&dst[s], big_units * 16));
+    CK(hipMemset(big[s], 0x5A + s, big_units * 16)); CK(hipMemset(small[s], 0x33 + s, out_units * 16)); CK(hipMemset(dst[s], 0, big_units * 16));
+  }
+  CK(hipMalloc(&sink, 16));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  int dev = 0, cus = 256;
+  CK(hipGetDevice(&dev));
+  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grids[] = {cus * 4, cus * 8, cus * 16, cus * 32};
+  printf("# %d CUs; working set per launch: read %.1f MB / copy %.1f MB / mix5 %.1f MB; %d launches each on %d rotating buffer sets\n", cus, big_units * 16 / 1e6,
+         2 * big_units * 16 / 1e6, 6 * out_units * 16 / 1e6, reps, sets);
+  auto run = [&](const char *name, double bytes, auto launch) {
+    for (int g : grids) {
+      for (int w = 0; w < 6; w++) launch(g, w & 1);
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; r++) launch(g, r & 1);
+      CK(hipEventRecord(e1, 0));
+      const float ms = time_ms(e0, e1) / reps;
+      printf("%-22s grid %6d  %8.2f us  %8.1f GB/s\n", name, g, ms * 1e3, bytes / (ms * 1e-3) / 1e9);
+    }
+  };
+  run("read plain x4", big_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_read<0, 4>), dim3(g), dim3(256), 0, 0, big[s], big_units, sink); });
+  run("read nt x4", big_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_read<1, 4>), dim3(g), dim3(256), 0, 0, big[s], big_units, sink); });
+  run("read plain x8", big_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_read<0, 8>), dim3(g), dim3(256), 0, 0, big[s], big_units, sink); });
+  run("copy plain x4", 2 * big_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_copy<0, 4>), dim3(g), dim3(256), 0, 0, big[s], dst[s], big_units); });
+  run("copy nt x4", 2 * big_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_copy<1, 4>), dim3(g), dim3(256), 0, 0, big[s], dst[s], big_units); });
+  run("mix5 (5R:1W) plain", 6 * out_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_mix5<0>), dim3(g), dim3(256), 0, 0, big[s], small[s], dst[s], out_units); });
+  run("mix5 (5R:1W) nt", 6 * out_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_mix5<1>), dim3(g), dim3(256), 0, 0, big[s], small[s], dst[s], out_units); });
+  return 0;
+}

@@ -1,0 +1,94 @@
+/* tools/worker.c -- the render-worker loop of one rank in plain C on liblivesgpu.so's C ABI (north_star: "host code stays C"):
+ *
+ *     for every frame batch:  lgpu_chain_step()  =  wait for this batch's parameter block, send the next one beside the kernel, launch the chain
+ *
+ * One process per GPU.  World size 1 runs the whole host path -- RCCL communicator, side stream, events, broadcast -- on a single GPU (a one-rank
+ * communicator), which is what the pool's one-GPU boxes can measure: host microseconds per step and frames / s at one 4K frame per step
+ * (BASELINE config 5's per-GPU shape) with the exchange ON.  With WORLD_SIZE > 1 (RANK, LOCAL_RANK, LGPU_ID_FILE in the environment) rank 0
+ * writes the 128-byte communicator id to LGPU_ID_FILE and the others read it: no Python, no MPI.
+ *
+ * build: gcc -O2 -o tools/_worker tools/worker.c -Iinclude -Llives_amd -llivesgpu -Wl,-rpath,$PWD/lives_amd
+ * run  : tools/_worker [--tracks 1] [--steps 2000] [--exchange 1] [--pixbuf 0]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include "lives_gpu.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s failed: %d (%s)\n", #x, rc_, lgpu_last_error()); exit(1); } } while (0)
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static int envi(const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; }
+
+int main(int argc, char **argv) {
+  int tracks = 1, steps = 2000, exchange = 1, pixbuf = 0;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--tracks")) tracks = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--exchange")) exchange = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--pixbuf")) pixbuf = atoi(argv[i + 1]);
+  }
+  const int rank = envi("RANK", 0), world = envi("WORLD_SIZE", 1), local = envi("LOCAL_RANK", rank);
+  const int SW = 3840, SH = 2160, DW = 1920, DH = 1080, NSETS = 2;
+  CHECK(lgpu_init(local));
+  void *stream;
+  CHECK(lgpu_stream_create(&stream, 1));
+
+  /* device-resident synthetic tracks, two rotating sets */
+  lgpu_chain_track *trk = calloc((size_t)NSETS * tracks, sizeof *trk);
+  for (int i = 0; i < NSETS * tracks; i++) {
+    void *s, *l, *d;
+    CHECK(lgpu_malloc(&s, (size_t)SW * SH * 4)); CHECK(lgpu_malloc(&l, (size_t)DW * DH * 4)); CHECK(lgpu_malloc(&d, (size_t)DW * DH * 4));
+    CHECK(lgpu_fill(s, 0x40 + i, (size_t)SW * SH * 4, stream)); CHECK(lgpu_fill(l, 0xC0 - i, (size_t)DW * DH * 4, stream));
+    trk[i].src_d = s; trk[i].layer2_d = l; trk[i].dst_d = d;
+  }
+  lgpu_chain_params prm;
+  memset(&prm, 0, sizeof prm);
+  prm.sw = SW; prm.sh = SH; prm.irow = SW * 4; prm.dw = DW; prm.dh = DH; prm.irow2 = DW * 4; prm.orow = DW * 4;
+  prm.swap_rb = 1; prm.interp = 3 | (pixbuf ? LGPU_INTERP_PIXBUF : 0); prm.bf = 128; prm.use_lut = 1;
+  if (lgpu_gamma_lut8(1.0, -1, 1, 1.4, prm.lut8) != 1) { fprintf(stderr, "no gamma LUT\n"); return 1; }
+
+  void *comm = NULL;
+  if (exchange) {
+    uint8_t id[LGPU_DIST_ID_BYTES];
+    const char *idf = getenv("LGPU_ID_FILE");
+    if (rank == 0) {
+      CHECK(lgpu_dist_unique_id(id));
+      if (world > 1) { FILE *f = fopen(idf, "wb"); fwrite(id, 1, sizeof id, f); fclose(f); char done[512]; snprintf(done, sizeof done, "%s.ok", idf); f = fopen(done, "w"); fclose(f); }
+    } else {
+      char done[512]; snprintf(done, sizeof done, "%s.ok", idf);
+      while (access(done, F_OK)) usleep(1000);
+      FILE *f = fopen(idf, "rb"); if (fread(id, 1, sizeof id, f) != sizeof id) return 1; fclose(f);
+    }
+    CHECK(lgpu_dist_comm_create(id, rank, world, &comm));
+  }
+  int32_t v[4] = {96, 0, 0, 0};
+  lgpu_stepper *st;
+  CHECK(lgpu_stepper_create(comm, 0, rank, stream, v, &st));
+  for (int s = 0; s < 300; s++) { v[0] = (96 + 7 * s) & 255; CHECK(lgpu_chain_step(st, v, &prm, trk + (s % NSETS) * tracks, tracks)); }   /* device wake-up */
+  CHECK(lgpu_sync(stream));
+  const double t0 = now();
+  for (int s = 0; s < steps; s++) { v[0] = (96 + 7 * s) & 255; CHECK(lgpu_chain_step(st, v, &prm, trk + (s % NSETS) * tracks, tracks)); }
+  const double t_enq = now();
+  CHECK(lgpu_sync(stream));
+  const double t1 = now();
+  /* host cost alone: the same calls with the stream left to drain in between (enqueue never blocks on a full queue) */
+  double host = 0;
+  for (int s = 0; s < 200; s++) {
+    v[0] = s & 255;
+    const double a = now();
+    CHECK(lgpu_chain_step(st, v, &prm, trk + (s % NSETS) * tracks, tracks));
+    host += now() - a;
+    if ((s & 15) == 15) CHECK(lgpu_sync(stream));
+  }
+  CHECK(lgpu_sync(stream));
+  if (rank == 0)
+    printf("{\"tool\": \"worker.c\", \"world\": %d, \"tracks_per_step\": %d, \"exchange\": \"%s\", \"resize\": \"%s\", \"steps\": %d, \"us_per_step\": %.2f, "
+           "\"frames_per_s_per_gpu\": %.0f, \"enqueue_us_per_step\": %.2f, \"host_us_per_step_idle_queue\": %.2f}\n",
+           world, tracks, exchange ? (world > 1 ? "rccl broadcast" : "rccl broadcast (one-rank communicator)") : "none", pixbuf ? "pixbuf" : "polyphase", steps,
+           (t1 - t0) / steps * 1e6, tracks * steps / (t1 - t0), (t_enq - t0) / steps * 1e6, host / 200 * 1e6);
+  CHECK(lgpu_stepper_destroy(st));
+  if (comm) CHECK(lgpu_dist_comm_destroy(comm));
+  return 0;
+}
