@@ -397,13 +397,13 @@ int lgpu_fan_in(void *comm, int root, int rank, int world, int ntracks, const ui
 /* the control rank's write of the block (four host values as kernel arguments: one tiny launch, no host -> device copy) */
 int lgpu_params_set(int32_t *param_block_d, const int32_t values[4], void *stream);
 /* ---- one step of the batch from C (north_star "host code stays C"): the chain over this rank's tracks with the step's parameter block, while the
-   block of the NEXT step is exchanged on a side stream (two device blocks, one event each; the launch stream never waits for xGMI, the host never synchronises).
+   block of the NEXT step is exchanged on a side stream (a ring of 16 device blocks, one event each; the launch stream never waits for xGMI, the host never synchronises).
    comm == NULL: one GPU, nothing to exchange -- the block is written on the launch stream.  tools/worker.c is the render-worker loop on top of it. */
 typedef struct lgpu_stepper lgpu_stepper;
 int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, const int32_t first_values[4], lgpu_stepper **out);
 /* next_values: the block of the following step (read on the root only), NULL on every rank for the last step.  params->param_block_d is replaced by the stepper's block. */
 int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks);
-const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* the two device blocks (tests) */
+const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 16 (tests) */
 int lgpu_stepper_destroy(lgpu_stepper *s);
 
 /* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),

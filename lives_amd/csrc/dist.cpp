@@ -138,24 +138,28 @@ int lgpu_fan_in(void *comm, int root, int rank, int world, int ntracks, const ui
 // A render worker runs, per frame batch: [parameter block of this batch has arrived] -> chain kernel.  The block of batch s + 1 is broadcast on a
 // side stream while the kernel of batch s runs (two device blocks, one event each), so the launch stream never waits for xGMI and the host never
 // synchronises: lgpu_chain_step = stream wait + event record + (root: one tiny launch) + ncclBroadcast + event record + the chain launch.
+enum { kStepRing = 16, kStepFence = kStepRing / 2 };
 struct lgpu_stepper {
   void *comm;                 // RCCL communicator, or NULL: one GPU, nothing to exchange (the block is written on the launch stream)
   int root, rank;
   void *launch, *side;        // hipStream_t
-  void *ready[2], *tail;      // events: block s & 1 has arrived / the launch stream's tail when the exchange was enqueued
-  int32_t *blk[2];
+  void *ready[kStepRing], *tail;      // events: block s % ring has arrived / the launch stream's tail at the last fence
+  int32_t *blk[kStepRing];
   long step;
 };
 
+// The exchange of step `step` on the side stream.  Its block, ring slot step % 16, was last read by the kernel of step - 16; every 8th step the side stream is
+// ordered behind the launch stream's tail (which then has passed the kernel of step - 2 at least), so the slot is free when it is rewritten, and the two
+// cross-stream calls of that ordering are paid once per 8 steps instead of every step (they cost more host time than the rest of the step together when every
+// launch sits behind a fresh cross-stream barrier: tools/worker.c, profiles/r03/worker_step.md).
 static int stepper_prefetch(lgpu_stepper *s, long step, const int32_t values[4]) {
   int rc;
-  int32_t *b = s->blk[step & 1];
+  int32_t *b = s->blk[step % kStepRing];
   if (!s->comm) return lgpu_params_set(b, values, s->launch);            // stream order does the rest
-  // behind everything already on the launch stream -- the last reader of this block is two kernels back -- then beside the next kernel
-  if ((rc = lgpu_event_record(s->tail, s->launch)) || (rc = lgpu_stream_wait_event(s->side, s->tail))) return rc;
+  if (step % kStepFence == 0 && ((rc = lgpu_event_record(s->tail, s->launch)) || (rc = lgpu_stream_wait_event(s->side, s->tail)))) return rc;
   if (s->rank == s->root && (rc = lgpu_params_set(b, values, s->side))) return rc;
   if ((rc = lgpu_params_broadcast(s->comm, s->root, b, s->side))) return rc;
-  return lgpu_event_record(s->ready[step & 1], s->side);
+  return lgpu_event_record(s->ready[step % kStepRing], s->side);
 }
 
 int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, const int32_t first_values[4], lgpu_stepper **out) {
@@ -164,11 +168,11 @@ int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, con
   s->comm = comm; s->root = root; s->rank = rank; s->launch = launch_stream; s->step = 0;
   int rc = LGPU_OK;
   void *p = nullptr;
-  if ((rc = lgpu_malloc(&p, 2 * 4 * sizeof(int32_t)))) { delete s; return rc; }
-  s->blk[0] = (int32_t *)p; s->blk[1] = s->blk[0] + 4;
+  if ((rc = lgpu_malloc(&p, kStepRing * 4 * sizeof(int32_t)))) { delete s; return rc; }
+  for (int i = 0; i < kStepRing; i++) s->blk[i] = (int32_t *)p + 4 * i;
   if (comm) {
     if (!rc) rc = lgpu_stream_create(&s->side, 1);
-    for (int i = 0; i < 2 && !rc; i++) rc = lgpu_event_create(&s->ready[i]);
+    for (int i = 0; i < kStepRing && !rc; i++) rc = lgpu_event_create(&s->ready[i]);
     if (!rc) rc = lgpu_event_create(&s->tail);
   }
   if (!rc) rc = stepper_prefetch(s, 0, first_values);
@@ -183,21 +187,21 @@ int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_ch
   if (!s || !params) { lgpu::set_error("lgpu_chain_step: null argument"); return LGPU_E_BADARG; }
   static const int32_t zero[4] = {0, 0, 0, 0};
   int rc;
-  if (s->comm && (rc = lgpu_stream_wait_event(s->launch, s->ready[s->step & 1]))) return rc;
+  if (s->comm && (rc = lgpu_stream_wait_event(s->launch, s->ready[s->step % kStepRing]))) return rc;
   if (next_values && (rc = stepper_prefetch(s, s->step + 1, s->rank == s->root ? next_values : zero))) return rc;
   lgpu_chain_params p = *params;
-  p.param_block_d = s->blk[s->step & 1];
+  p.param_block_d = s->blk[s->step % kStepRing];
   s->step++;
   return lgpu_chain(&p, tracks, ntracks, s->launch);
 }
 
-const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which) { return s ? s->blk[which & 1] : nullptr; }
+const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which) { return s ? s->blk[which % kStepRing] : nullptr; }
 
 int lgpu_stepper_destroy(lgpu_stepper *s) {
   if (!s) return LGPU_OK;
   if (s->launch || true) lgpu_sync(s->launch);
   if (s->side) { lgpu_sync(s->side); lgpu_stream_destroy(s->side); }
-  for (int i = 0; i < 2; i++) if (s->ready[i]) lgpu_event_destroy(s->ready[i]);
+  for (int i = 0; i < kStepRing; i++) if (s->ready[i]) lgpu_event_destroy(s->ready[i]);
   if (s->tail) lgpu_event_destroy(s->tail);
   if (s->blk[0]) lgpu_free(s->blk[0]);
   delete s;

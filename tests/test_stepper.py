@@ -18,7 +18,7 @@ def test_steps_use_the_block_of_their_own_step(gpu, orc, exchange):
     sw, sh, dw, dh = 256, 144, 128, 72
     srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(2)]
     l2s = [rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8) for _ in range(2)]
-    schedule = [17, 200, 0, 255, 96, 131, 64]
+    schedule = [17, 200, 0, 255, 96, 131, 64] + [int(v) for v in rng.integers(0, 256, 38)]      # 45 steps: the 16-slot block ring wraps twice, 5 fences
     comm = ld.RcclComm("cuda") if exchange else None
     d_srcs, d_l2s = [dev(s) for s in srcs], [dev(s) for s in l2s]
     outs = [[dev(np.zeros((dh, dw * 4), np.uint8)) for _ in range(2)] for _ in schedule]

@@ -37,10 +37,15 @@ int main(int argc, char **argv) {
 
   /* device-resident synthetic tracks, two rotating sets */
   lgpu_chain_track *trk = calloc((size_t)NSETS * tracks, sizeof *trk);
+  uint64_t *hostbuf = malloc((size_t)SW * SH * 4), rng = 0x11FE5ull + (uint64_t)rank;
   for (int i = 0; i < NSETS * tracks; i++) {
     void *s, *l, *d;
     CHECK(lgpu_malloc(&s, (size_t)SW * SH * 4)); CHECK(lgpu_malloc(&l, (size_t)DW * DH * 4)); CHECK(lgpu_malloc(&d, (size_t)DW * DH * 4));
-    CHECK(lgpu_fill(s, 0x40 + i, (size_t)SW * SH * 4, stream)); CHECK(lgpu_fill(l, 0xC0 - i, (size_t)DW * DH * 4, stream));
+    /* uniform random bytes (xorshift64), half of layer 2 opaque -- bench.py's synthetic frames; constant fills run measurably faster and are not used */
+    for (size_t k = 0; k < (size_t)SW * SH / 2; k++) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; hostbuf[k] = rng; }
+    CHECK(lgpu_upload(s, hostbuf, (size_t)SW * SH * 4, stream)); CHECK(lgpu_sync(stream));
+    for (size_t k = 0; k < (size_t)DW * DH / 2; k++) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; hostbuf[k] = rng | ((rng & 0x100) ? 0xFF000000FF000000ull : 0); }
+    CHECK(lgpu_upload(l, hostbuf, (size_t)DW * DH * 4, stream)); CHECK(lgpu_sync(stream));
     trk[i].src_d = s; trk[i].layer2_d = l; trk[i].dst_d = d;
   }
   lgpu_chain_params prm;
@@ -62,6 +67,27 @@ int main(int argc, char **argv) {
       FILE *f = fopen(idf, "rb"); if (fread(id, 1, sizeof id, f) != sizeof id) return 1; fclose(f);
     }
     CHECK(lgpu_dist_comm_create(id, rank, world, &comm));
+  }
+  if (getenv("LGPU_WORKER_PROBE") && comm) {      /* host cost of the primitives a step is made of (idle queue, 1000 calls each) */
+    void *side, *ev, *blk;
+    int32_t pv[4] = {1, 2, 3, 4};
+    CHECK(lgpu_stream_create(&side, 1)); CHECK(lgpu_event_create(&ev)); CHECK(lgpu_malloc(&blk, 16));
+    const char *names[] = {"lgpu_event_record", "lgpu_stream_wait_event", "lgpu_params_set", "lgpu_params_broadcast", "lgpu_chain (1 track)"};
+    for (int what = 0; what < 5; what++) {
+      CHECK(lgpu_sync(stream)); CHECK(lgpu_sync(side));
+      double acc = 0;
+      for (int i = 0; i < 1000; i++) {
+        const double a = now();
+        if (what == 0) CHECK(lgpu_event_record(ev, stream));
+        else if (what == 1) CHECK(lgpu_stream_wait_event(side, ev));
+        else if (what == 2) CHECK(lgpu_params_set(blk, pv, side));
+        else if (what == 3) CHECK(lgpu_params_broadcast(comm, 0, blk, side));
+        else CHECK(lgpu_chain(&prm, trk, 1, stream));
+        acc += now() - a;
+        if ((i & 31) == 31) { CHECK(lgpu_sync(stream)); CHECK(lgpu_sync(side)); }
+      }
+      printf("probe %-24s %.2f us per call\n", names[what], acc / 1000 * 1e6);
+    }
   }
   int32_t v[4] = {96, 0, 0, 0};
   lgpu_stepper *st;
