@@ -2,8 +2,10 @@
 """bench.py -- effect-chain frames/sec at 3840x2160 RGBA32 (BASELINE.json metric) on N MI355X GPUs.
 
 A "step" is one pass of the headline chain over one batch of synthetic tracks resident in HBM:
-   3840x2160 BGRA32 -> [convert to RGBA32] -> resize 0.5x (bicubic) -> chroma blend (bf) with a 1920x1080
+   3840x2160 BGRA32 -> [convert to RGBA32] -> resize 0.5x (LIVES_INTERP_BEST) -> chroma blend (bf) with a 1920x1080
    RGBA32 layer -> gamma LUT (linear->sRGB) -> 1920x1080 RGBA32        (north_star: convert->resize->blend->gamma)
+The resize stage runs on the reference's gdk-pixbuf arithmetic by default (--resize-backend pixbuf: GDK_INTERP_HYPER, alpha-weighted, bit-exact to
+gdk_pixbuf_scale_simple 2.42.8 -- the pinned parity path); --resize-backend polyphase is the repo's own bicubic spec standing in for libswscale.
 one fused launch of liblivesgpu.so's lgpu_chain() per step, TRACKS_PER_GPU independent tracks per launch.
 Multi-GPU: one process per GPU (torch.distributed / RCCL), tracks sharded track-per-rank with no data-path
 collective; the shared transition parameter block (blend amount) is broadcast from rank 0 over RCCL every
@@ -47,7 +49,7 @@ def main():
                          "so nothing a step reads can still sit in the 256 MiB Infinity Cache from the step before")
     ap.add_argument("--l2-translucent", type=float, default=0.5,
                     help="fraction of layer-2 pixels with alpha < 255 (they take the reference's float scaling path); 0 = an opaque layer 2")
-    ap.add_argument("--resize-backend", choices=["polyphase", "pixbuf"], default="polyphase",
+    ap.add_argument("--resize-backend", choices=["polyphase", "pixbuf"], default="pixbuf",
                     help="arithmetic of the resize stage: the repo's polyphase spec in the swscale body's place (bicubic; parity unpinned, libswscale is not in the "
                          "image) or the reference's gdk-pixbuf body (GDK_INTERP_HYPER, alpha-weighted; bit-exact to gdk-pixbuf 2.42.8)")
     ap.add_argument("--dry-run", action="store_true",
@@ -208,13 +210,13 @@ def main():
     achieved = algo / launch_s / 1e9
     traffic = None
     try:   # HBM bytes per launch from the PMC passes of this round's build on this exact workload (tools/pmc.sh + tools/pmc_traffic.py -> profiles/pmc_traffic.json, which names the commit)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_pixbuf.json" if args.resize_backend == "pixbuf" else "pmc_traffic.json")) as f:
             pj = json.load(f)
         if pj.get("tracks") == T and pj.get("blur") == args.blur:
             traffic = pj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roof = {"bound": "hbm", "kernel": "lgpu::k_pb_half<1>" if args.resize_backend == "pixbuf" else "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": ("lgpu::k_pb_half<1,1,%d>" % args.blur) if args.resize_backend == "pixbuf" else "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
 
@@ -231,7 +233,7 @@ def main():
                        "param_exchange": ("none (one GPU: the kernel reads step s of the resident schedule)" if not multi else
                                           "lgpu_chain_step (C): lgpu_params_set + lgpu_params_broadcast (RCCL) on a side stream, one step ahead of the kernel" if comm is not None else
                                           "torch.distributed broadcast (fallback)"),
-                       "launches_per_step": 2 if args.blur else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
+                       "launches_per_step": 2 if (args.blur and args.resize_backend != "pixbuf") else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
             "roofline": roof,
         }
         if config5:

@@ -244,34 +244,31 @@ __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32
 #endif
 }
 
-template <int CHAIN, int HYPER>
+// BLUR (chain only): BASELINE config 5's 5x5 gaussian ([1 4 6 4 1] / 16 per axis, edge replicate, one rounding: (sum + 128) >> 8) between the scaler and the
+// blend, in the same launch.  The scaled row of a lane (two RGBA pixels) is blurred horizontally with its neighbours' pixels (four more DPP moves; bytes in
+// 16-bit lanes, so one 32-bit operation serves two channels), the last five blurred rows stay in registers and every new one completes an output row.  A strip
+// then yields 120 columns (lanes 2 .. 61) and a band computes 4 more scaled rows than it stores.
+template <int CHAIN, int HYPER, int BLUR>
 __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
   __shared__ uint8_t s_lut[256];
   __shared__ pb_u2 s_k[256];
-  if (CHAIN) {
-    stage_lut(s_lut, lut);
-    if (A.blend) {
-      const uint2 kk = A.kscale[threadIdx.x];
-      pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
-      s_k[threadIdx.x] = kv;
-    }
-    __syncthreads();
-  }
+  constexpr int kHalo = BLUR ? 2 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
   const int lane = threadIdx.x & 63;
   int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
   const int per_track = A.strips * A.bands;
-  if (item >= per_track * A.ntracks) return;
+  const bool spare = item >= per_track * A.ntracks;           // a wave past the last item of the last workgroup: walks the last item again, stores nothing
+  if (spare) item = per_track * A.ntracks - 1;
   const int track = item / per_track;
   item -= track * per_track;
   const int band = item / A.strips, strip = item - band * A.strips;
-  const int k = strip * 62 - 1 + lane;                    // this lane's source quad: pixels 4k .. 4k + 3
+  const int k = strip * kCols - kHalo + lane;             // this lane's source quad: pixels 4k .. 4k + 3 -> output columns 2k, 2k + 1
   const int kmax = (A.sw >> 2) - 1;
   const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
   const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
   const uint8_t *rowbase = T.src[track];          // uniform
   const uint32_t lane_off = 16u * (uint32_t)kc;
-  const bool out_lane = lane >= 1 && lane <= 62 && k <= kmax;
-  const bool edge_strip = strip == 0 || (strip + 1) * 62 >= kmax;        // wave-uniform: some lanes of this strip lie outside the frame
+  const bool out_lane = lane >= kHalo && lane < 64 - kHalo && k <= kmax && !spare;
+  const bool edge_strip = strip == 0 || (strip + 1) * kCols + kHalo >= kmax;        // wave-uniform: some lanes of this strip lie outside the frame
   uint32_t bf = A.bf;
   if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
   const uint32_t w_lo = bf | ((255u - bf) << 8);
@@ -295,64 +292,135 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const uint8_t *l2base = (CHAIN && A.blend) ? T.l2[track] : nullptr;
   const uint32_t l2_off = 8u * (uint32_t)kc;
   auto load_l2 = [&](int y) -> pb_u2 {
-    y = y > A.dh - 1 ? A.dh - 1 : y;
+    y = y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y;
     return __builtin_nontemporal_load(reinterpret_cast<const pb_u2 *>(l2base + (size_t)y * A.irow2 + l2_off));
   };
-  // carry[i] = (outer tap) * H[2Y-1] + (inner tap) * H[2Y]: the half of output row Y that is known before its last two source rows arrive
+  // the rest of the chain on one pixel whose colours are still apart, and the store
+  auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
+    if (CHAIN && A.blend) {
+      // chroma blend (simple_blend.c:117-146): s2 = (layer-2 colour * K2[alpha2]) >> 16, s1 = (track colour * K1[alpha2]) >> 16 (the reference's float scaling of
+      // translucent pixels as integers, lgpu_alpha_scalers; alpha 255 = identity), then (bf * s2 + (255 - bf) * s1) >> 8
+      const pb_u2 kk = s_k[q >> 24];
+      const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
+      const uint32_t pa = __umul24(c0, kk.y), pb = __umul24(c1, kk.y), pc = __umul24(c2, kk.y);
+      c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+    }
+    if (CHAIN && A.use_lut) { c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2]; }
+    return c0 | (c1 << 8) | (c2 << 16) | al;
+  };
+  auto store_row = [&](int y, uint32_t p0, uint32_t p1) {
+    if (out_lane) {
+      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)y * A.orow + 8 * (size_t)k);
+      pb_u2 o;
+      o.x = p0; o.y = p1;
+      if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
+    }
+  };
+
+  // scaled rows this band has to produce: its own, plus two above and below for the blur (clamped to the frame: the gaussian replicates the border rows)
+  const int vr0 = BLUR ? y0 - 2 : y0, vr1 = BLUR ? y0 + rows + 1 : y0 + rows - 1;
+  const int ylo = vr0 < 0 ? 0 : vr0;
+  // carry[i] = (outer tap) * H[2Y-1] + (inner tap) * H[2Y]: the half of scaled row Y that is known before its last two source rows arrive
   uint32_t carry[8], hr[8], hs[8];
-  const int sy0 = 2 * y0 - 1;
+  const int sy0 = 2 * ylo - 1;
   pb_u4 q0 = load_row(sy0), q1 = load_row(sy0 + 1), qa = load_row(sy0 + 2), qb = load_row(sy0 + 3);
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
   if (CHAIN && A.blend) l2 = load_l2(y0);
+  if (CHAIN) {        // the two small tables are staged while the first source rows are in flight
+    stage_lut(s_lut, lut);
+    if (A.blend) {
+      const uint2 kk = A.kscale[threadIdx.x];
+      pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
+      s_k[threadIdx.x] = kv;
+    }
+    __syncthreads();
+  }
   pb_half_hrow<HYPER>(fix(q0), hr);
   pb_half_hrow<HYPER>(fix(q1), hs);
 #pragma unroll
   for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
-  for (int r = 0; r < rows; r++) {
-    // the next output row's two new source rows and its layer-2 pixels: in flight during this row's arithmetic
-    const pb_u4 na = load_row(sy0 + 2 * r + 4), nb = load_row(sy0 + 2 * r + 5);
+  int produced = ylo - 1;                 // the last scaled row that exists
+  uint32_t cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, al[2] = {0, 0};      // the current scaled row of this lane: colours apart, alpha in place (<< 24)
+  uint32_t ring[5][4];                     // BLUR: horizontally blurred rows, newest last; [row][column * 2 + (0: bytes 0 and 2, 1: bytes 1 and 3)] in 16-bit lanes
+  if (BLUR) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { ring[i][0] = 0; ring[i][1] = 0; ring[i][2] = 0; ring[i][3] = 0; }
+  }
+  for (int vr = vr0; vr <= vr1; vr++) {
+    const int yy = vr < 0 ? 0 : vr > A.dh - 1 ? A.dh - 1 : vr;
     pb_u2 nl2;
     nl2.x = 0; nl2.y = 0;
-    if (CHAIN && A.blend) nl2 = load_l2(y0 + r + 1);
-    pb_half_hrow<HYPER>(fix(qa), hr);
-    pb_half_hrow<HYPER>(fix(qb), hs);
-    uint32_t v[8];
+    if (yy > produced) {
+      // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
+      const int r = yy - ylo;
+      const pb_u4 na = load_row(sy0 + 2 * r + 4), nb = load_row(sy0 + 2 * r + 5);
+      if (CHAIN && A.blend) nl2 = load_l2(BLUR ? vr - 1 : yy + 1);
+      pb_half_hrow<HYPER>(fix(qa), hr);
+      pb_half_hrow<HYPER>(fix(qb), hs);
+      uint32_t v[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
-      else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
-    }
-    const int y = y0 + r;
-    uint32_t px[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const uint32_t va = v[4 * j + 3];
-      uint32_t c[3];
-      pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, c);       // V_alpha == 0 makes every V_c 0 too: 0 * fl(1 / 1) = 0, the library's all-zero pixel
-      if (A.swap_rb) { const uint32_t t = c[0]; c[0] = c[2]; c[2] = t; }
-      const uint32_t al = (va >> A.ashift) << 24;
-      if (CHAIN && A.blend) {
-        // chroma blend (simple_blend.c:117-146) on the colours while they are still apart: s2 = (layer-2 colour * K2[alpha2]) >> 16, s1 = (track colour * K1[alpha2]) >> 16
-        // (the reference's float scaling of translucent pixels as integers, lgpu_alpha_scalers; alpha 255 = identity), then (bf * s2 + (255 - bf) * s1) >> 8
-        const uint32_t q = j ? l2.y : l2.x;
-        const pb_u2 kk = s_k[q >> 24];
-        const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
-        const uint32_t pa = __umul24(c[0], kk.y), pb = __umul24(c[1], kk.y), pc = __umul24(c[2], kk.y);
-        c[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-        c[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-        c[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      for (int i = 0; i < 8; i++) {
+        if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
+        else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
       }
-      if (CHAIN && A.use_lut) { c[0] = s_lut[c[0]]; c[1] = s_lut[c[1]]; c[2] = s_lut[c[2]]; }
-      px[j] = c[0] | (c[1] << 8) | (c[2] << 16) | al;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t va = v[4 * j + 3];
+        pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, cc[j]);       // V_alpha == 0 makes every V_c 0 too: 0 * fl(1 / 1) = 0, the library's all-zero pixel
+        if (A.swap_rb) { const uint32_t t = cc[j][0]; cc[j][0] = cc[j][2]; cc[j][2] = t; }
+        al[j] = (va >> A.ashift) << 24;
+      }
+      qa = na; qb = nb;
+      produced = yy;
+      if (BLUR) {
+        // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
+        uint32_t e[6], o[6];
+        e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
+        e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
+        e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
+        e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
+        e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
+        if (edge_strip) {       // the gaussian replicates the frame's first / last column
+          if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
+          if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
+        ring[4][0] = e[0] + e[4] + 4u * (e[1] + e[3]) + 6u * e[2]; ring[4][1] = o[0] + o[4] + 4u * (o[1] + o[3]) + 6u * o[2];
+        ring[4][2] = e[1] + e[5] + 4u * (e[2] + e[4]) + 6u * e[3]; ring[4][3] = o[1] + o[5] + 4u * (o[2] + o[4]) + 6u * o[3];
+      }
+    } else if (BLUR) {          // a row beyond the frame's first / last: the border row again
+      if (CHAIN && A.blend) nl2 = load_l2(vr - 1);
+      const uint32_t t0 = ring[4][0], t1 = ring[4][1], t2 = ring[4][2], t3 = ring[4][3];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
+      ring[4][0] = t0; ring[4][1] = t1; ring[4][2] = t2; ring[4][3] = t3;
     }
-    if (out_lane) {
-      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)y * A.orow + 8 * (size_t)k);
-      pb_u2 o;
-      o.x = px[0]; o.y = px[1];
-      if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
+    if (BLUR) {
+      if (vr == vr0 && vr0 < 0) {           // the band starts above the frame: rows -2 and -1 are row 0, which has just been made -- fill the ring behind it
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ring[i][0] = ring[4][0]; ring[i][1] = ring[4][1]; ring[i][2] = ring[4][2]; ring[i][3] = ring[4][3]; }
+      }
+      if (vr >= y0 + 2) {
+        const int y = vr - 2;
+        uint32_t pxo[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
+          const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
+          // bytes 1 and 3 of each 16-bit lane are the blurred values: (ve >> 8) & 0x00FF00FF = (c0, c2), (vo >> 8) & 0x00FF00FF = (c1, alpha)
+          pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
+        }
+        store_row(y, pxo[0], pxo[1]);
+      }
+      if (vr >= y0 + 1) l2 = nl2;
+    } else {
+      store_row(yy, finish(cc[0][0], cc[0][1], cc[0][2], al[0], l2.x), finish(cc[1][0], cc[1][1], cc[1][2], al[1], l2.y));
+      l2 = nl2;
     }
-    qa = na; qb = nb; l2 = nl2;
   }
 }
 
@@ -514,12 +582,13 @@ static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int
   return true;
 }
 
-static void pb_half_geometry(PbHalfArgs *a, int ntracks) {
-  a->strips = (int)cdiv((unsigned)a->dw, 124);
+static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
+  a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : 124);
   // measured (profiles/r03/pbh_sweep.txt): short bands win even when the device is full -- 8 rows at 16 tracks (170 us against 184 at 16 rows), 4 rows when a
   // launch has fewer than ~8k waves (one 4K frame: 11.5 us against 12.4 at 8 rows, 15.7 at 16)
   a->th = 8;
   if ((long long)a->strips * cdiv((unsigned)a->dh, 8u) * ntracks < 8192) a->th = 4;
+  if (blur) a->th = (long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 8 : 16;      // a band computes th + 4 scaled rows: taller bands, (th + 4) / th of the arithmetic
   if (const char *e = getenv("LGPU_PBH_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
   a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
   a->ntracks = ntracks;
@@ -541,12 +610,18 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
   a.nt_out = 1;
-  pb_half_geometry(&a, ntracks);
+  pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
   PbTracks T;
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
-  if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1>), dim3(cdiv((unsigned)(a.strips * a.bands * ntracks), 4)), dim3(256), 0, st, a, T, l);
-  else hipLaunchKernelGGL((k_pb_half<1, 0>), dim3(cdiv((unsigned)(a.strips * a.bands * ntracks), 4)), dim3(256), 0, st, a, T, l);
+  const dim3 grid(cdiv((unsigned)(a.strips * a.bands * ntracks), 4));
+  if (pr->do_blur) {
+    if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 1>), grid, dim3(256), 0, st, a, T, l);
+    else hipLaunchKernelGGL((k_pb_half<1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
+  } else {
+    if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 0>), grid, dim3(256), 0, st, a, T, l);
+    else hipLaunchKernelGGL((k_pb_half<1, 0, 0>), grid, dim3(256), 0, st, a, T, l);
+  }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
@@ -556,10 +631,8 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
 // scaler and the gaussian (both treat the three colour bytes alike), so it rides in the last kernel.
 int pb_chain(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
   int rc;
-  if (!pr->do_blur) {
-    rc = pb_chain_half(pr, tracks, ntracks, st);
-    if (rc != LGPU_E_UNSUPPORTED) return rc;
-  }
+  rc = pb_chain_half(pr, tracks, ntracks, st);         // one launch, the blur stage included
+  if (rc != LGPU_E_UNSUPPORTED) return rc;
   const int interp = pr->interp & 0xFF;
   const size_t per = (size_t)pr->dw * 4 * pr->dh;
   void *sa = nullptr, *sb = nullptr;
@@ -634,8 +707,8 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
       h.kscale = nullptr;
-      if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
-      else hipLaunchKernelGGL((k_pb_half<0, 0>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      else hipLaunchKernelGGL((k_pb_half<0, 0, 0>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }

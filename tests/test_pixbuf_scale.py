@@ -255,7 +255,11 @@ def test_chain_on_the_pixbuf_arithmetic(gpu, orc):
         (248, 1000, 124, 500, 3, 1, 33, 1, 0, 0, 0, 0), (252, 66, 126, 33, 2, 0, 0, 1, 1, 0, 0, 0),
         (258, 66, 129, 33, 3, 1, 128, 1, 1, 0, 0, 0),            # sw % 4 != 0: staged
         (256, 144, 128, 72, 3, 1, 128, 1, 1, 0, 4, 4),            # rowstrides not multiples of 16 / 8: staged
-        (300, 200, 128, 72, 3, 1, 90, 2, 1, 0, 0, 0), (128, 72, 256, 144, 3, 0, 90, 1, 1, 0, 0, 0), (256, 144, 128, 72, 3, 1, 128, 2, 1, 1, 0, 0)]
+        (300, 200, 128, 72, 3, 1, 90, 2, 1, 0, 0, 0), (128, 72, 256, 144, 3, 0, 90, 1, 1, 0, 0, 0), (256, 144, 128, 72, 3, 1, 128, 2, 1, 1, 0, 0),
+        # the blur stage in the same launch (k_pb_half<.., BLUR>): bands that start above / end below the frame, strips of 120 columns, both interps
+        (512, 40, 256, 20, 3, 0, 77, 3, 0, 1, 0, 0), (1000, 132, 500, 66, 2, 1, 255, 2, 1, 1, 0, 0), (8, 4, 4, 2, 3, 0, 9, 1, 1, 1, 0, 0),
+        (248, 1000, 124, 500, 3, 1, 33, 1, 0, 1, 0, 0), (244, 36, 122, 18, 3, 1, 50, 1, 1, 1, 0, 0), (3840, 80, 1920, 40, 3, 1, 128, 1, 1, 1, 0, 0),
+        (300, 200, 128, 72, 3, 1, 90, 1, 1, 1, 0, 0)]
     for (sw, sh, dw, dh, interp, swap, bf, ntr, use_lut, blur, spad, dpad) in cases:
         irow, orow = sw * 4 + spad, dw * 4 + dpad
         srcs = [rng.integers(0, 256, (sh, irow), dtype=np.uint8) for _ in range(ntr)]

@@ -20,7 +20,7 @@ fetch = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"])
 write = sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"])
 out = {"source": "tools/pmc.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes around `python bench.py --steps 10 --warmup 2 --no-cpu`; "
                  "FETCH_SIZE x 2 (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md), both counters in KB",
-       "commit": commit, "kernel": pat, "tracks": 16, "blur": 0, "dispatches": len(agg["FETCH_SIZE"]),
+       "commit": commit, "kernel": pat, "tracks": 16, "blur": int(os.environ.get("PMC_BLUR", "0")), "dispatches": len(agg["FETCH_SIZE"]),
        "fetch_size_kb": round(fetch, 1), "write_size_kb": round(write, 1),
        "hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024))}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
