@@ -173,7 +173,7 @@ struct PbHalfArgs {
   int swap_rb, blend, irow2, use_lut;
   uint32_t bf;
   const int32_t *bf_d;
-  int strips, bands, th, ntracks;
+  int strips, cgroups, bands, th, ntracks;     // cgroups = ceil(strips / 4): workgroups per band
   int nt_out;
 };
 struct PbTracks {
@@ -254,13 +254,23 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   __shared__ pb_u2 s_k[256];
   constexpr int kHalo = BLUR ? 2 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
   const int lane = threadIdx.x & 63;
-  int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
-  const int per_track = A.strips * A.bands;
-  const bool spare = item >= per_track * A.ntracks;           // a wave past the last item of the last workgroup: walks the last item again, stores nothing
-  if (spare) item = per_track * A.ntracks - 1;
-  const int track = item / per_track;
-  item -= track * per_track;
-  const int band = item / A.strips, strip = item - band * A.strips;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
+  // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its
+  // own L2; two bands that follow each other vertically share two source rows.  So every XCD gets a CONTIGUOUS run of the sequence (track, column group, band) and
+  // walks it band by band: the shared rows are fetched once and hit that XCD's L2 the second time (PMC: 999 MB -> see profiles/r03 per 16-track launch).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nseq = A.cgroups * A.bands * A.ntracks, per_xcd = (nseq + 7) >> 3;
+  int seq = xcd * per_xcd + slot;
+  int strip = 0, band = 0, track = 0;
+  bool spare = seq >= nseq || slot >= per_xcd;
+  if (!spare) {
+    const int cg = seq / A.bands;
+    band = seq - cg * A.bands;
+    track = cg / A.cgroups;
+    strip = (cg - track * A.cgroups) * 4 + wave;
+    spare = strip >= A.strips;
+  }
+  if (spare) { strip = 0; band = 0; track = 0; }           // a wave without work walks item 0 again and stores nothing (it still takes part in the barrier)
   const int k = strip * kCols - kHalo + lane;             // this lane's source quad: pixels 4k .. 4k + 3 -> output columns 2k, 2k + 1
   const int kmax = (A.sw >> 2) - 1;
   const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
@@ -319,16 +329,20 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     }
   };
 
-  // scaled rows this band has to produce: its own, plus two above and below for the blur (clamped to the frame: the gaussian replicates the border rows)
+  // scaled rows this band has to produce: its own, plus two above and below for the blur (clamped to the frame: the gaussian replicates the border rows).
+  // Odd bands walk UPWARDS (both filters are symmetric, so only the row addresses change): a band and its lower neighbour then reach the two source rows
+  // they share at the same time -- both at their end, or both at their start -- and the second read hits the XCD's L2 instead of HBM.
   const int vr0 = BLUR ? y0 - 2 : y0, vr1 = BLUR ? y0 + rows + 1 : y0 + rows - 1;
-  const int ylo = vr0 < 0 ? 0 : vr0;
-  // carry[i] = (outer tap) * H[2Y-1] + (inner tap) * H[2Y]: the half of scaled row Y that is known before its last two source rows arrive
+  const int ylo = vr0 < 0 ? 0 : vr0, yhi = vr1 > A.dh - 1 ? A.dh - 1 : vr1;
+  const int d = (band & 1) ? -1 : 1;
+  const int ystart = d > 0 ? ylo : yhi, vstart = d > 0 ? vr0 : vr1;
+  const int S0 = d > 0 ? 2 * ylo - 1 : 2 * yhi + 2;           // source rows are consumed in the order S0, S0 + d, S0 + 2 d, ...
+  // carry[i] = (outer tap) * H[first row] + (inner tap) * H[second row] of a scaled row: the half that is known before its last two source rows arrive
   uint32_t carry[8], hr[8], hs[8];
-  const int sy0 = 2 * ylo - 1;
-  pb_u4 q0 = load_row(sy0), q1 = load_row(sy0 + 1), qa = load_row(sy0 + 2), qb = load_row(sy0 + 3);
+  pb_u4 q0 = load_row(S0), q1 = load_row(S0 + d), qa = load_row(S0 + 2 * d), qb = load_row(S0 + 3 * d);
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
-  if (CHAIN && A.blend) l2 = load_l2(y0);
+  if (CHAIN && A.blend) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
   if (CHAIN) {        // the two small tables are staged while the first source rows are in flight
     stage_lut(s_lut, lut);
     if (A.blend) {
@@ -342,22 +356,24 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   pb_half_hrow<HYPER>(fix(q1), hs);
 #pragma unroll
   for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
-  int produced = ylo - 1;                 // the last scaled row that exists
+  int produced = ystart - d;              // the last scaled row that exists
   uint32_t cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, al[2] = {0, 0};      // the current scaled row of this lane: colours apart, alpha in place (<< 24)
   uint32_t ring[5][4];                     // BLUR: horizontally blurred rows, newest last; [row][column * 2 + (0: bytes 0 and 2, 1: bytes 1 and 3)] in 16-bit lanes
   if (BLUR) {
 #pragma unroll
     for (int i = 0; i < 5; i++) { ring[i][0] = 0; ring[i][1] = 0; ring[i][2] = 0; ring[i][3] = 0; }
   }
-  for (int vr = vr0; vr <= vr1; vr++) {
+  const int nsteps = vr1 - vr0 + 1;
+  for (int step = 0; step < nsteps; step++) {
+    const int vr = vstart + d * step;
     const int yy = vr < 0 ? 0 : vr > A.dh - 1 ? A.dh - 1 : vr;
     pb_u2 nl2;
     nl2.x = 0; nl2.y = 0;
-    if (yy > produced) {
+    if (yy != produced) {
       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
-      const int r = yy - ylo;
-      const pb_u4 na = load_row(sy0 + 2 * r + 4), nb = load_row(sy0 + 2 * r + 5);
-      if (CHAIN && A.blend) nl2 = load_l2(BLUR ? vr - 1 : yy + 1);
+      const int r = d > 0 ? yy - ystart : ystart - yy;
+      const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
+      if (CHAIN && A.blend) nl2 = load_l2(BLUR ? vr - d : yy + d);
       pb_half_hrow<HYPER>(fix(qa), hr);
       pb_half_hrow<HYPER>(fix(qb), hs);
       uint32_t v[8];
@@ -393,30 +409,26 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
         ring[4][2] = e[1] + e[5] + 4u * (e[2] + e[4]) + 6u * e[3]; ring[4][3] = o[1] + o[5] + 4u * (o[2] + o[4]) + 6u * o[3];
       }
     } else if (BLUR) {          // a row beyond the frame's first / last: the border row again
-      if (CHAIN && A.blend) nl2 = load_l2(vr - 1);
+      if (CHAIN && A.blend) nl2 = load_l2(vr - d);
       const uint32_t t0 = ring[4][0], t1 = ring[4][1], t2 = ring[4][2], t3 = ring[4][3];
 #pragma unroll
       for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
       ring[4][0] = t0; ring[4][1] = t1; ring[4][2] = t2; ring[4][3] = t3;
     }
     if (BLUR) {
-      if (vr == vr0 && vr0 < 0) {           // the band starts above the frame: rows -2 and -1 are row 0, which has just been made -- fill the ring behind it
-#pragma unroll
-        for (int i = 0; i < 4; i++) { ring[i][0] = ring[4][0]; ring[i][1] = ring[4][1]; ring[i][2] = ring[4][2]; ring[i][3] = ring[4][3]; }
-      }
-      if (vr >= y0 + 2) {
-        const int y = vr - 2;
+      if (step >= 4) {                    // the ring holds the five rows around output row vr - 2 d
+        const int y = vr - 2 * d;
         uint32_t pxo[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
           const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
-          // bytes 1 and 3 of each 16-bit lane are the blurred values: (ve >> 8) & 0x00FF00FF = (c0, c2), (vo >> 8) & 0x00FF00FF = (c1, alpha)
+          // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
           pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
         }
         store_row(y, pxo[0], pxo[1]);
       }
-      if (vr >= y0 + 1) l2 = nl2;
+      if (step >= 3) l2 = nl2;
     } else {
       store_row(yy, finish(cc[0][0], cc[0][1], cc[0][2], al[0], l2.x), finish(cc[1][0], cc[1][1], cc[1][2], al[1], l2.y));
       l2 = nl2;
@@ -584,15 +596,17 @@ static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int
 
 static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : 124);
-  // measured (profiles/r03/pbh_sweep.txt): short bands win even when the device is full -- 8 rows at 16 tracks (170 us against 184 at 16 rows), 4 rows when a
-  // launch has fewer than ~8k waves (one 4K frame: 11.5 us against 12.4 at 8 rows, 15.7 at 16)
-  a->th = 8;
-  if ((long long)a->strips * cdiv((unsigned)a->dh, 8u) * ntracks < 8192) a->th = 4;
+  // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full -- with neighbouring bands walking towards each other, 4 rows: 167 us at
+  // 16 tracks (174 at 8 rows, 175 at 16), one 4K frame 11.0 us (11.6 / 14.7)
+  a->th = 4;
   if (blur) a->th = (long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 8 : 16;      // a band computes th + 4 scaled rows: taller bands, (th + 4) / th of the arithmetic
   if (const char *e = getenv("LGPU_PBH_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
   a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
+  a->cgroups = (a->strips + 3) / 4;
   a->ntracks = ntracks;
 }
+
+static unsigned pb_half_grid(const PbHalfArgs &a) { return 8u * cdiv((unsigned)(a.cgroups * a.bands * a.ntracks), 8u); }
 
 // the fused chain on the pixbuf arithmetic (lgpu_chain with LGPU_INTERP_PIXBUF): convert -> gdk-pixbuf 2:1 scale -> chroma blend -> gamma LUT in one launch.
 // LGPU_E_UNSUPPORTED when the geometry is not the exact aligned 2:1 case (the caller then runs the stages one by one).
@@ -614,7 +628,7 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
   PbTracks T;
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
-  const dim3 grid(cdiv((unsigned)(a.strips * a.bands * ntracks), 4));
+  const dim3 grid(pb_half_grid(a));
   if (pr->do_blur) {
     if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 1>), grid, dim3(256), 0, st, a, T, l);
     else hipLaunchKernelGGL((k_pb_half<1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
@@ -707,8 +721,8 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
       h.kscale = nullptr;
-      if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
-      else hipLaunchKernelGGL((k_pb_half<0, 0, 0>), dim3(cdiv((unsigned)(h.strips * h.bands), 4)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      else hipLaunchKernelGGL((k_pb_half<0, 0, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
