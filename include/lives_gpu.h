@@ -371,6 +371,11 @@ typedef struct {
                                    it is read by the kernel, stream-ordered, with no host round trip. */
 } lgpu_chain_params;
 int lgpu_chain(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks, void *stream);
+/* the same chain with letterbox_layer (src/colourspace.c:15343-15567) between the resize and the blend -- BASELINE config 3: the scaled dw x dh frame sits at
+   (offs_x, offs_y) of an nwidth x nheight canvas of opaque black (LiVES centres it: offs = (n - size + 1) >> 1, :15522-15523); layer 2 and the destination are
+   canvas-sized (irow2 / orow are their strides).  One launch on the pixbuf arithmetic for the exact aligned 2:1 case with an even offs_x; staged otherwise. */
+typedef struct { int nwidth, nheight, offs_x, offs_y; } lgpu_canvas;
+int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream);
 
 /* ---- timing helper: HIP events on `stream` around `reps` launches of the last-configured chain; used by
    bench.py to measure the kernel's average launch duration on the stream it is launched on. */

@@ -174,6 +174,8 @@ struct PbHalfArgs {
   uint32_t bf;
   const int32_t *bf_d;
   int strips, cgroups, bands, th, ntracks;     // cgroups = ceil(strips / 4): workgroups per band
+  int cw, ch, ox, oy;            // letterbox canvas (cw == 0: none): dst / layer 2 are cw x ch, the scaled frame sits at (ox, oy), the rest is opaque black under the blend
+  int main_blocks, bar_blocks;   // workgroups of the frame proper / per track of the bars (1024 canvas pixels each)
   int nt_out;
 };
 struct PbTracks {
@@ -253,6 +255,41 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   __shared__ uint8_t s_lut[256];
   __shared__ pb_u2 s_k[256];
   constexpr int kHalo = BLUR ? 2 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
+  if (CHAIN && blockIdx.x >= (unsigned)A.main_blocks) {
+    // letterbox bars (letterbox_layer's black canvas, src/colourspace.c:15417-15503, under the rest of the chain): opaque black -> chroma blend with layer 2 -> LUT
+    stage_lut(s_lut, lut);
+    if (A.blend) {
+      const uint2 kk = A.kscale[threadIdx.x];
+      pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
+      s_k[threadIdx.x] = kv;
+    }
+    __syncthreads();
+    const int b = blockIdx.x - A.main_blocks, track = b / A.bar_blocks, chunk = b - track * A.bar_blocks;
+    uint32_t bf = A.bf;
+    if (A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
+    const uint32_t w_lo = bf | ((255u - bf) << 8);
+    const int top = A.oy * A.cw, bottom = (A.ch - A.oy - A.dh) * A.cw, sw_ = A.cw - A.dw, total = top + bottom + A.dh * sw_;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int p = chunk * 1024 + i * 256 + threadIdx.x, x, y;
+      if (p >= total) break;
+      if (p < top) { y = p / A.cw; x = p - y * A.cw; }
+      else if (p < top + bottom) { p -= top; y = p / A.cw; x = p - y * A.cw; y += A.oy + A.dh; }
+      else { p -= top + bottom; y = p / sw_; x = p - y * sw_; y += A.oy; if (x >= A.ox) x += A.dw; }
+      uint32_t c0 = 0, c1 = 0, c2 = 0;
+      if (A.blend) {
+        const uint32_t q = reinterpret_cast<const uint32_t *>(T.l2[track] + (size_t)y * A.irow2)[x];
+        const pb_u2 kk = s_k[q >> 24];
+        const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
+        c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+        c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+        c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      }
+      if (A.use_lut) { c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2]; }
+      reinterpret_cast<uint32_t *>(T.dst[track] + (size_t)y * A.orow)[x] = c0 | (c1 << 8) | (c2 << 16) | 0xFF000000u;
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
   // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its
@@ -300,10 +337,10 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     return q;
   };
   const uint8_t *l2base = (CHAIN && A.blend) ? T.l2[track] : nullptr;
-  const uint32_t l2_off = 8u * (uint32_t)kc;
+  const uint32_t l2_off = 8u * (uint32_t)kc + 4u * (uint32_t)A.ox;
   auto load_l2 = [&](int y) -> pb_u2 {
     y = y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y;
-    return __builtin_nontemporal_load(reinterpret_cast<const pb_u2 *>(l2base + (size_t)y * A.irow2 + l2_off));
+    return __builtin_nontemporal_load(reinterpret_cast<const pb_u2 *>(l2base + (size_t)(y + A.oy) * A.irow2 + l2_off));
   };
   // the rest of the chain on one pixel whose colours are still apart, and the store
   auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
@@ -322,7 +359,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   };
   auto store_row = [&](int y, uint32_t p0, uint32_t p1) {
     if (out_lane) {
-      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)y * A.orow + 8 * (size_t)k);
+      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)(y + A.oy) * A.orow + 8 * (size_t)k + 4 * (size_t)A.ox);
       pb_u2 o;
       o.x = p0; o.y = p1;
       if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
@@ -610,7 +647,7 @@ static unsigned pb_half_grid(const PbHalfArgs &a) { return 8u * cdiv((unsigned)(
 
 // the fused chain on the pixbuf arithmetic (lgpu_chain with LGPU_INTERP_PIXBUF): convert -> gdk-pixbuf 2:1 scale -> chroma blend -> gamma LUT in one launch.
 // LGPU_E_UNSUPPORTED when the geometry is not the exact aligned 2:1 case (the caller then runs the stages one by one).
-int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
   const int interp = pr->interp & 0xFF;
   if (interp != 2 && interp != 3) return LGPU_E_UNSUPPORTED;
   const PbTable *t;
@@ -619,16 +656,20 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
   uintptr_t sb = (uintptr_t)pr->irow, db = (uintptr_t)pr->orow | (uintptr_t)pr->irow2;
   for (int i = 0; i < ntracks; i++) { sb |= (uintptr_t)tracks[i].src_d; db |= (uintptr_t)tracks[i].dst_d | (uintptr_t)tracks[i].layer2_d; }
   PbHalfArgs a;
+  if (cv && (cv->offs_x & 1)) return LGPU_E_UNSUPPORTED;        // 8-byte stores: the frame must start on an even canvas column
   if (!pb_half_ok(t, interp, pr->sw, pr->sh, pr->dw, pr->dh, sb, db, &a.hyper, &a.ashift)) return LGPU_E_UNSUPPORTED;
   if ((rc = get_kscale(&a.kscale))) return rc;
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
   a.nt_out = 1;
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
+  a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
+  if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
+  a.main_blocks = (int)pb_half_grid(a);
   PbTracks T;
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
-  const dim3 grid(pb_half_grid(a));
+  const dim3 grid((unsigned)(a.main_blocks + a.bar_blocks * ntracks));
   if (pr->do_blur) {
     if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 1>), grid, dim3(256), 0, st, a, T, l);
     else hipLaunchKernelGGL((k_pb_half<1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
@@ -640,26 +681,34 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, i
   return LGPU_OK;
 }
 
-// lgpu_chain with LGPU_INTERP_PIXBUF.  One fused launch for the exact aligned 2:1 case; otherwise (and with the blur stage) the stages run one after
-// the other through stream-ordered scratch frames: pixbuf scale -> [5x5 gaussian] -> [R <-> B] + chroma blend + gamma LUT.  The channel swap commutes with the
-// scaler and the gaussian (both treat the three colour bytes alike), so it rides in the last kernel.
-int pb_chain(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+// lgpu_chain / lgpu_chain_canvas.  One fused launch for the exact aligned 2:1 case on the pixbuf arithmetic (blur stage and letterbox canvas included); otherwise the
+// stages run one after the other through stream-ordered scratch frames: [bars] -> scale (into the canvas) -> [5x5 gaussian] -> [R <-> B] + chroma blend + gamma LUT.
+// The channel swap commutes with the scalers and the gaussian (all treat the three colour bytes alike), so it rides in the last kernel.
+int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
   int rc;
-  rc = pb_chain_half(pr, tracks, ntracks, st);         // one launch, the blur stage included
-  if (rc != LGPU_E_UNSUPPORTED) return rc;
+  const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0;
+  if (pixbuf && !(cv && pr->do_blur)) {
+    rc = pb_chain_half(pr, cv, tracks, ntracks, st);         // one launch
+    if (rc != LGPU_E_UNSUPPORTED) return rc;
+  }
   const int interp = pr->interp & 0xFF;
-  const size_t per = (size_t)pr->dw * 4 * pr->dh;
+  const int cw = cv ? cv->nwidth : pr->dw, ch = cv ? cv->nheight : pr->dh, ox = cv ? cv->offs_x : 0, oy = cv ? cv->offs_y : 0;
+  const size_t per = (size_t)cw * 4 * ch;
   void *sa = nullptr, *sb = nullptr;
   if ((rc = lgpu_malloc_ordered(&sa, per, st))) return rc;
   if (pr->do_blur && (rc = lgpu_malloc_ordered(&sb, per, st))) { lgpu_free_ordered(sa, st); return rc; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
+  const uint8_t black[4] = {0, 0, 0, 255};
   for (int i = 0; i < ntracks && !rc; i++) {
-    rc = lgpu_pixbuf_scale(tracks[i].src_d, pr->irow, pr->sw, pr->sh, (uint8_t *)sa, pr->dw * 4, pr->dw, pr->dh, 4, interp, st);
+    uint8_t *inner = (uint8_t *)sa + (size_t)oy * cw * 4 + (size_t)ox * 4;
+    if (cv) rc = lgpu_letterbox_bars((uint8_t *)sa, cw * 4, cw, ch, 4, black, ox, oy, pr->dw, pr->dh, st);
+    if (!rc) rc = pixbuf ? lgpu_pixbuf_scale(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp, st)
+                         : lgpu_resize(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp, nullptr, st);
     const uint8_t *trk = (const uint8_t *)sa;
-    if (!rc && pr->do_blur) { rc = lgpu_gauss5((const uint8_t *)sa, pr->dw * 4, (uint8_t *)sb, pr->dw * 4, pr->dw, pr->dh, 4, st); trk = (const uint8_t *)sb; }
+    if (!rc && pr->do_blur) { rc = lgpu_gauss5((const uint8_t *)sa, cw * 4, (uint8_t *)sb, cw * 4, cw, ch, 4, st); trk = (const uint8_t *)sb; }
     if (rc) break;
-    hipLaunchKernelGGL(k_pb_epilogue, dim3(cdiv((unsigned)pr->dw, 64), cdiv((unsigned)pr->dh, 4)), dim3(256), 0, st, trk, pr->dw * 4, tracks[i].layer2_d, pr->irow2,
-                       tracks[i].dst_d, pr->orow, pr->dw, pr->dh, pr->swap_rb ? 1 : 0, (uint32_t)pr->bf & 0xFF, pr->param_block_d, pr->use_lut ? 1 : 0, l);
+    hipLaunchKernelGGL(k_pb_epilogue, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4)), dim3(256), 0, st, trk, cw * 4, tracks[i].layer2_d, pr->irow2,
+                       tracks[i].dst_d, pr->orow, cw, ch, pr->swap_rb ? 1 : 0, (uint32_t)pr->bf & 0xFF, pr->param_block_d, pr->use_lut ? 1 : 0, l);
     if (hipGetLastError() != hipSuccess) { set_error("k_pb_epilogue launch failed"); rc = LGPU_E_HIP; }
   }
   lgpu_free_ordered(sa, st);
@@ -720,7 +769,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       pb_half_geometry(&h, 1);
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
-      h.kscale = nullptr;
+      h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.main_blocks = (int)pb_half_grid(h);
       if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       else hipLaunchKernelGGL((k_pb_half<0, 0, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       LGPU_CHECK_LAUNCH();
@@ -755,4 +804,23 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+
+// resize -> letterbox -> blend (-> gamma) as one call: BASELINE config 3's chain.  letterbox_layer (src/colourspace.c:15343-15567) centres the scaled frame on an
+// opaque black canvas; here the canvas never exists on its own: the scaled frame is blended and stored at its place, the bars are blended black.
+extern "C" int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(params && canvas && tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
+  LGPU_REQUIRE(params->sw > 0 && params->sh > 0 && params->dw > 0 && params->dh > 0, "empty geometry");
+  LGPU_REQUIRE(canvas->nwidth >= params->dw && canvas->nheight >= params->dh && canvas->offs_x >= 0 && canvas->offs_y >= 0 &&
+               canvas->offs_x + params->dw <= canvas->nwidth && canvas->offs_y + params->dh <= canvas->nheight, "the scaled frame must lie inside the canvas");
+  LGPU_REQUIRE(params->irow >= params->sw * 4 && params->orow >= canvas->nwidth * 4 && params->irow2 >= canvas->nwidth * 4, "rowstride smaller than a row");
+  LGPU_REQUIRE(((params->irow | params->orow | params->irow2) & 3) == 0, "rowstrides must be multiples of 4");
+  LGPU_REQUIRE(!(params->sw == params->dw && params->sh == params->dh), "chain needs a resize stage");
+  for (int i = 0; i < ntracks; i++) {
+    LGPU_REQUIRE(tracks[i].src_d && tracks[i].layer2_d && tracks[i].dst_d, "null track pointer");
+    LGPU_REQUIRE((((uintptr_t)tracks[i].src_d | (uintptr_t)tracks[i].layer2_d | (uintptr_t)tracks[i].dst_d) & 3) == 0, "frames must be 4-byte aligned");
+  }
+  return pb_chain(params, canvas, tracks, ntracks, (hipStream_t)stream);
 }

@@ -2262,7 +2262,7 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
   return LGPU_OK;
 }
 
-namespace lgpu { int pb_chain(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st); }
+namespace lgpu { int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st); }
 static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
   int rc;
   LGPU_REQUIRE(pr && tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
@@ -2276,7 +2276,7 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   const bool same = (pr->sw == pr->dw && pr->sh == pr->dh);
   if (pr->interp & LGPU_INTERP_PIXBUF) {                 // the resize stage on the reference's gdk-pixbuf arithmetic (pixbuf.hip)
     LGPU_REQUIRE(!same, "chain needs a resize stage");
-    return pb_chain(pr, tracks, ntracks, st);
+    return pb_chain(pr, nullptr, tracks, ntracks, st);
   }
   const int kernel = kernel_for_interp(pr->interp, pr->dw > pr->sw || pr->dh > pr->sh);
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);

@@ -42,6 +42,11 @@ class CompLayer(ctypes.Structure):
                 ("offs_x", ctypes.c_int), ("offs_y", ctypes.c_int), ("alpha", ctypes.c_double)]
 
 
+class Canvas(ctypes.Structure):
+    """lgpu_canvas"""
+    _fields_ = [("nwidth", ci), ("nheight", ci), ("offs_x", ci), ("offs_y", ci)]
+
+
 class ChainParams(ctypes.Structure):
     _fields_ = [("sw", ci), ("sh", ci), ("irow", ci), ("dw", ci), ("dh", ci), ("irow2", ci), ("orow", ci),
                 ("swap_rb", ci), ("interp", ci), ("do_blur", ci), ("bf", ci), ("use_lut", ci),
@@ -98,6 +103,7 @@ PROTOTYPES = {
     "lgpu_letterbox_bars": [vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
     "lgpu_pixbuf_scale": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_chain_canvas": [vp, vp, vp, ci, vp],
     "lgpu_pixbuf_weights": [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_size_t],
     "lgpu_make_filter": [ci, ci, ci, vp, vp, vp, ci],
     "lgpu_gauss5": [vp, ci, vp, ci, ci, ci, ci, vp],

@@ -326,6 +326,11 @@ def chain(params, tracks):
     lib.call("lgpu_chain", ctypes.byref(params), tracks, len(tracks), stream_ptr())
 
 
+def chain_canvas(params, tracks, nwidth, nheight, offs_x, offs_y):
+    cv = lib.Canvas(nwidth, nheight, offs_x, offs_y)
+    lib.call("lgpu_chain_canvas", ctypes.byref(params), ctypes.byref(cv), tracks, len(tracks), stream_ptr())
+
+
 def chain_timed(params, tracks, reps):
     ms = ctypes.c_float()
     lib.call("lgpu_chain_timed", ctypes.byref(params), tracks, len(tracks), reps, ctypes.byref(ms), stream_ptr())

@@ -301,3 +301,70 @@ def test_chain_pixbuf_reads_the_device_parameter_block(gpu, orc):
         prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=5, lut=None, param_block=block)
         gpu.chain(prm, gpu.chain_tracks([dev(src)], [dev(l2)], [d]))
         assert (host(d) == want).all()
+
+
+def _want_canvas(orc, src, irow, sw, sh, l2, irow2, dw, dh, nw, nh, ox, oy, swap, interp_flags, bf, lut):
+    """the oracle's single stages in the chain's order: convert -> scale -> letterbox at (ox, oy) -> chroma blend -> gamma LUT"""
+    conv = np.zeros((sh, sw * 4), np.uint8)
+    if swap:
+        assert orc.orc_swizzle(4, 0, P(src), irow, P(conv), sw * 4, sw, sh, None) == 0            # ORC_SWAP3POSTALPHA
+    else:
+        conv[:] = src[:, :sw * 4]
+    rs = np.zeros((dh, dw * 4), np.uint8)
+    if interp_flags & 0x100:
+        assert orc.orc_pixbuf_scale(P(conv), sw * 4, sw, sh, P(rs), dw * 4, dw, dh, 4, interp_flags & 0xFF) == 0
+    else:
+        assert orc.orc_resize(P(conv), sw * 4, sw, sh, P(rs), dw * 4, dw, dh, 4, interp_flags) == 0
+    cv = np.zeros((nh, nw, 4), np.uint8)
+    cv[..., 3] = 255
+    cv[oy:oy + dh, ox:ox + dw] = rs.reshape(dh, dw, 4)
+    cv = np.ascontiguousarray(cv.reshape(nh, nw * 4))
+    orc.orc_blend_chroma(P(cv), nw * 4, P(l2), irow2, P(cv), nw * 4, nw, nh, 4, 0, bf)
+    if lut is not None:
+        orc.orc_gamma_apply(P(cv), nw * 4, nw, nh, 4, 0, P(lut))
+    return cv
+
+
+@gpu_mark
+def test_chain_with_a_letterbox_canvas(gpu, orc):
+    """lgpu_chain_canvas (BASELINE config 3: resize -> letterbox -> blend): one launch on the pixbuf arithmetic (frame + blended bars), staged for the polyphase
+    backend, odd offsets and other ratios"""
+    rng = np.random.default_rng(0x9DBC)
+    lut = np.zeros(256, np.uint8)
+    assert orc.orc_gamma_lut8(1.0, -1, 1, 1.4, P(lut)) == 1
+    cases = [  # sw, sh, dw, dh, nw, nh, ox, oy, interp flags, swap, bf, use lut, tracks
+        (256, 144, 128, 72, 128, 80, 0, 4, 0x103, 0, 128, 0, 1), (256, 144, 128, 72, 160, 100, 16, 14, 0x103, 1, 77, 1, 2), (512, 40, 256, 20, 300, 21, 44, 1, 0x102, 1, 200, 1, 1),
+        (256, 144, 128, 72, 131, 75, 3, 2, 0x103, 1, 99, 1, 1),          # odd offs_x: staged
+        (300, 200, 128, 72, 160, 90, 16, 9, 0x103, 0, 128, 1, 1),         # not 2:1: staged
+        (256, 144, 128, 72, 160, 100, 16, 14, 3, 1, 77, 1, 2)]            # polyphase backend: staged
+    for (sw, sh, dw, dh, nw, nh, ox, oy, itp, swap, bf, use_lut, ntr) in cases:
+        srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(ntr)]
+        l2s = [rng.integers(0, 256, (nh, nw * 4), dtype=np.uint8) for _ in range(ntr)]
+        for l_ in l2s:
+            a = l_[:, 3::4]
+            a[rng.random(a.shape) < 0.5] = 255
+        dd = [dev(np.zeros((nh, nw * 4), np.uint8)) for _ in range(ntr)]
+        prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, nw * 4, nw * 4, swap_rb=swap, interp=itp, do_blur=0, bf=bf, lut=lut if use_lut else None)
+        gpu.chain_canvas(prm, gpu.chain_tracks([dev(s_) for s_ in srcs], [dev(s_) for s_ in l2s], dd), nw, nh, ox, oy)
+        for i in range(ntr):
+            want = _want_canvas(orc, srcs[i], sw * 4, sw, sh, l2s[i], nw * 4, dw, dh, nw, nh, ox, oy, swap, itp, bf, lut if use_lut else None)
+            got = host(dd[i])
+            bad = np.argwhere(got != want)
+            assert len(bad) == 0, "canvas chain %s track %d: %d bytes differ, first %s" % ((sw, sh, dw, dh, nw, nh, ox, oy, hex(itp)), i, len(bad), bad[0].tolist())
+
+
+@gpu_mark
+def test_c3_at_size_in_one_launch(gpu, orc):
+    """BASELINE config 3 at its size: 3840x2160 RGBA32 -> 0.5x -> letterbox into 1920x1200 (offs_y = 60) -> chroma blend bf = 128 with a 1920x1200 layer"""
+    rng = np.random.default_rng(0x9DBD)
+    sw, sh, dw, dh, nw, nh = 3840, 2160, 1920, 1080, 1920, 1200
+    ox, oy = (nw - dw + 1) >> 1, (nh - dh + 1) >> 1
+    src = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)
+    src[:, 3::4][rng.random((sh, sw)) < 0.5] = 255
+    l2 = rng.integers(0, 256, (nh, nw * 4), dtype=np.uint8)
+    l2[:, 3::4][rng.random((nh, nw)) < 0.5] = 255
+    d = dev(np.zeros((nh, nw * 4), np.uint8))
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, nw * 4, nw * 4, swap_rb=0, interp=0x103, do_blur=0, bf=128, lut=None)
+    gpu.chain_canvas(prm, gpu.chain_tracks([dev(src)], [dev(l2)], [d]), nw, nh, ox, oy)
+    want = _want_canvas(orc, src, sw * 4, sw, sh, l2, nw * 4, dw, dh, nw, nh, ox, oy, 0, 0x103, 128, None)
+    assert (host(d) == want).all()

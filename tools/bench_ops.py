@@ -179,6 +179,22 @@ def main():
     h1, h2, ho = hframe(1920, 1200, 4), hframe(1920, 1200, 4), hframe(1920, 1200, 4)
     c = cpu(lambda: orc.orc_blend_chroma(P(h1), h1.strides[0], P(h2), h2.strides[0], P(ho), ho.strides[0], 1920, 1200, 4, 0, 128))
     add("chroma blend RGBA32 (C3)", "simple_blend.c:58-150", "1920x1200", 1920 * 1200 * 12, t, c)
+    # BASELINE config 3 as ONE launch on the pinned (gdk-pixbuf) arithmetic: resize 0.5x -> letterbox into 1920x1200 -> chroma blend bf = 128 (lgpu_chain_canvas)
+    c3d = dframe(1920, 1200, 4, NB)
+    for t_ in l2:
+        a_ = t_[:, 3::4]
+        a_[torch.rand(a_.shape, device="cuda", generator=g) < 0.5] = 255
+    prm3 = ops.chain_params(sw, sh, src[0].stride(0), dw, dh, l2[0].stride(0), c3d[0].stride(0), swap_rb=0, interp=3 | 0x100, do_blur=0, bf=128, lut=None)
+    trk3 = [ops.chain_tracks([src[i]], [l2[i]], [c3d[i]]) for i in range(NB)]
+    t = timeit(lambda i: ops.chain_canvas(prm3, trk3[i], 1920, 1200, 0, 60), NB)
+    add("C3 in one launch: resize 0.5x (gdk-pixbuf HYPER) -> letterbox 1920x1200 -> chroma blend (lgpu_chain_canvas)", "colourspace.c:15262-15322, :15343-15567, simple_blend.c:58-150",
+        "3840x2160->1920x1200", sw * sh * 4 + 2 * 1920 * 1200 * 4, t, None)
+    pbd = dframe(dw, dh, 4, NB)
+    t = timeit(lambda i: ops.pixbuf_scale(src[i], pbd[i], sw, sh, dw, dh, channels=4, interp=3), NB)
+    if orc:
+        orc.orc_pixbuf_scale.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5
+    c = cpu(lambda: orc.orc_pixbuf_scale(P(hs), hs.strides[0], sw, sh, P(hd), hd.strides[0], dw, dh, 4, 3))
+    add("resize 0.5x RGBA32, gdk-pixbuf HYPER (lgpu_pixbuf_scale, pinned)", "colourspace.c:15262-15322", "3840x2160->1920x1080", sw * sh * 4 + dw * dh * 4, t, c)
     # ---- B1 gaussian, F4 colour key: C4 --------------------------------------------------------------------------------------------
     w, h = 3840, 2160
     src, dst = dframe(w, h, 4, NB), dframe(w, h, 4, NB)
