@@ -339,6 +339,11 @@ int lgpu_slide_over(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int
 int lgpu_dissolve_mask(uint64_t seed, int width, int height, float *mask_out);
 int lgpu_dissolve(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow, int width, int height,
                   int psize, const float *mask_d, double amount, void *stream);
+/* BASELINE config 4 in one launch: lgpu_gauss5 of frame 0, then lgpu_colorkey of the blurred frame against frame 1 -- the blurred frame never exists in memory.
+   psize 3 (RGB24 / BGR24, the reference's palettes) or 4 (RGBA32 / BGRA32: the extension SURVEY 8d names for the headline size; the alpha byte stays the blurred
+   frame's).  LGPU_E_UNSUPPORTED when width % 4 != 0 or a frame / rowstride is not 4- (psize 3) or 16-byte (psize 4) aligned: run the two entry points then. */
+int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow, int width, int height, int psize,
+                         int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, void *stream);
 /* mirrorx (0) / mirrory (1) / mirrorxy (2): lives-plugins/weed-plugins/mirrors.c:26-122.  src_d may equal dst_d. */
 int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height,
                 int psize, void *stream);

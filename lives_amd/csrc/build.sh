@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 OBJ=build
 mkdir -p $OBJ
 pids=()
-for f in runtime swizzle yuv effects resize stencil palette pixbuf; do
+for f in runtime swizzle yuv effects resize stencil palette pixbuf fused; do
   if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ lgpu_common.h -nt $OBJ/$f.o ] || [ ../../include/lives_gpu.h -nt $OBJ/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o $OBJ/$f.o &
     pids+=($!)

@@ -1,0 +1,198 @@
+// fused.hip -- BASELINE config 4 as one launch: 5x5 separable gaussian -> colour-key composite against a second frame.
+//
+//   gaussian   : no reference loop exists (BASELINE names the op only); the repo's spec, identical to lgpu_gauss5: [1 4 6 4 1] / 16 per axis, border
+//                replicated, 16-bit intermediate, one rounding (sum + 128) >> 8, every byte of the pixel alike
+//   colour key : lives-plugins/weed-plugins/scripts/colorkey.script <process> -- box test on R, G, B against [min, max] per channel (green's box is built from
+//                2 x delta), matching pixels become (uint8_t)(a * (1 - opac) + b * opac) per colour byte in double, others keep the first frame's pixel.
+//                RGB24 / BGR24 as in the reference; RGBA32 / BGRA32 is the extension SURVEY 8d names for the headline size (the alpha byte stays the blurred
+//                frame's).
+//
+// k_gauss5_colorkey: no LDS.  A wave owns a strip of 248 columns (62 lanes x 4 pixels; lanes 0 and 63 only feed their neighbours) and walks a band of rows.
+// Per source row a lane loads its 4 pixels (16 or 12 bytes), takes the two pixels it needs on each side from the adjacent lanes (DPP wave shifts), blurs
+// horizontally with the bytes spread to 16-bit lanes (one 32-bit operation = two channels) and keeps the last five blurred rows in registers; every new row
+// completes one output row, which is keyed against the second frame's pixels (loaded a row ahead) and stored.  Odd bands walk upwards, so that the four source
+// rows two neighbouring bands share are read at the same time and the second read hits L2 (same scheme as k_pb_half).  HBM-bound: 3 frames of traffic.
+#include "lgpu_common.h"
+#include <cmath>
+
+namespace lgpu {
+
+struct GckArgs {
+  const uint8_t *src0, *src1;
+  uint8_t *dst;
+  int irow0, irow1, orow, width, height;
+  int strips, cgroups, bands, th;
+  int rmin, rmax, gmin, gmax, bmin, bmax, order;      // order 1: BGR(A)
+  double opac, opacx;
+  int key;                                            // 0: blur only
+};
+typedef unsigned gk_u4 __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(4))) gk_u3 { uint32_t x, y, z; };          // 12 bytes at a 4-byte aligned address: global_load / store_dwordx3
+
+template <int PS>
+__global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-contiguous order: (column group, band) runs, band-minor (see k_pb_half)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nseq = A.cgroups * A.bands, per_xcd = (nseq + 7) >> 3;
+  const int seq = xcd * per_xcd + slot;
+  if (seq >= nseq || slot >= per_xcd) return;
+  const int cg = seq / A.bands, band = seq - cg * A.bands, strip = cg * 4 + wave;
+  if (strip >= A.strips) return;
+  const int k = strip * 62 - 1 + lane, kmax = (A.width >> 2) - 1;        // this lane's pixels: 4k .. 4k + 3
+  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
+  const bool out_lane = lane >= 1 && lane <= 62 && k <= kmax;
+  const bool edge_strip = strip == 0 || (strip + 1) * 62 + 1 >= kmax;
+  const int y0 = band * A.th, rows = min(A.th, A.height - y0);
+  const uint32_t off = (uint32_t)(4 * PS) * (uint32_t)kc;
+
+  auto load4 = [&](const uint8_t *base, int irow, int y) -> gk_u4 {
+    y = y < 0 ? 0 : y > A.height - 1 ? A.height - 1 : y;
+    const uint8_t *p = base + (size_t)y * irow + off;
+    if (PS == 4) return *reinterpret_cast<const gk_u4 *>(p);
+    const gk_u3 t = *reinterpret_cast<const gk_u3 *>(p);
+    uint32_t q[4];
+    unpack3(t.x, t.y, t.z, q);
+    gk_u4 r;
+    r.x = q[0]; r.y = q[1]; r.z = q[2]; r.w = q[3];
+    return r;
+  };
+  auto fix = [&](gk_u4 q) -> gk_u4 {          // the gaussian replicates the frame's first / last column
+    if (edge_strip) {
+      if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }
+      if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }
+    }
+    return q;
+  };
+  // horizontal pass of one row: h[2 j] = (byte 0, byte 2), h[2 j + 1] = (byte 1, byte 3) sums of pixel j, in 16-bit lanes
+  auto hrow = [&](gk_u4 q, uint32_t h[8]) {
+    uint32_t p[8];
+    p[2] = q.x; p[3] = q.y; p[4] = q.z; p[5] = q.w;
+    p[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.z, 0x138, 0xF, 0xF, true); p[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.w, 0x138, 0xF, 0xF, true);   // wave_shr:1
+    p[6] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.x, 0x130, 0xF, 0xF, true); p[7] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.y, 0x130, 0xF, 0xF, true);   // wave_shl:1
+    uint32_t e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { e[i] = p[i] & 0x00FF00FFu; o[i] = (p[i] >> 8) & 0x00FF00FFu; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      h[2 * j] = e[j] + e[j + 4] + 4u * (e[j + 1] + e[j + 3]) + 6u * e[j + 2];
+      h[2 * j + 1] = o[j] + o[j + 4] + 4u * (o[j + 1] + o[j + 3]) + 6u * o[j + 2];
+    }
+  };
+
+  const int vr0 = y0 - 2, vr1 = y0 + rows + 1;
+  const int ylo = vr0 < 0 ? 0 : vr0, yhi = vr1 > A.height - 1 ? A.height - 1 : vr1;
+  const int d = (band & 1) ? -1 : 1;
+  const int ystart = d > 0 ? ylo : yhi, vstart = d > 0 ? vr0 : vr1;
+  gk_u4 qn = load4(A.src0, A.irow0, ystart);
+  gk_u4 b4 = {0, 0, 0, 0};
+  if (A.key) b4 = load4(A.src1, A.irow1, d > 0 ? y0 : y0 + rows - 1);
+  uint32_t ring[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) ring[i][j] = 0;
+  int produced = ystart - d;
+  const int nsteps = vr1 - vr0 + 1;
+  for (int step = 0; step < nsteps; step++) {
+    const int vr = vstart + d * step;
+    const int yy = vr < 0 ? 0 : vr > A.height - 1 ? A.height - 1 : vr;
+    gk_u4 nb = {0, 0, 0, 0};
+    if (A.key) nb = load4(A.src1, A.irow1, vr - d);              // the second frame's pixels of the NEXT output row
+    uint32_t h[8];
+    if (yy != produced) {
+      const gk_u4 q = qn;
+      qn = load4(A.src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic
+      hrow(fix(q), h);
+      produced = yy;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) h[j] = ring[4][j];               // a row beyond the frame: the border row again
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) ring[i][j] = ring[i + 1][j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ring[4][j] = h[j];
+    if (step >= 4) {
+      const int y = vr - 2 * d;
+      uint32_t px[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
+        const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
+        uint32_t a = ((ve >> 8) & 0x00FF00FFu) | (vo & 0xFF00FF00u);
+        if (A.key) {
+          const uint32_t b = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+          const int c0 = a & 0xFF, c1 = (a >> 8) & 0xFF, c2 = (a >> 16) & 0xFF;
+          const int r = A.order ? c2 : c0, bl = A.order ? c0 : c2;
+          if (r >= A.rmin && r <= A.rmax && c1 >= A.gmin && c1 <= A.gmax && bl >= A.bmin && bl <= A.bmax) {
+            const uint32_t m0 = (uint32_t)(uint8_t)((double)c0 * A.opacx + (double)(b & 0xFF) * A.opac);
+            const uint32_t m1 = (uint32_t)(uint8_t)((double)c1 * A.opacx + (double)((b >> 8) & 0xFF) * A.opac);
+            const uint32_t m2 = (uint32_t)(uint8_t)((double)c2 * A.opacx + (double)((b >> 16) & 0xFF) * A.opac);
+            a = m0 | (m1 << 8) | (m2 << 16) | (a & 0xFF000000u);
+          }
+        }
+        px[j] = a;
+      }
+      if (out_lane) {
+        uint8_t *dp = A.dst + (size_t)y * A.orow + (size_t)(4 * PS) * (size_t)k;
+        if (PS == 4) {
+          gk_u4 o4;
+          o4.x = px[0]; o4.y = px[1]; o4.z = px[2]; o4.w = px[3];
+          __builtin_nontemporal_store(o4, reinterpret_cast<gk_u4 *>(dp));
+        } else {
+          gk_u3 o3;
+          uint32_t w0, w1, w2;
+          pack3(px, w0, w1, w2);
+          o3.x = w0; o3.y = w1; o3.z = w2;
+          *reinterpret_cast<gk_u3 *>(dp) = o3;
+        }
+      }
+    }
+    if (step >= 3) b4 = nb;
+  }
+}
+
+}  // namespace lgpu
+
+using namespace lgpu;
+
+// 5x5 gaussian of frame 0, then the colour key of the blurred frame against frame 1, in one launch.  psize 3 (RGB24 / BGR24: the reference's palettes) or 4
+// (RGBA32 / BGRA32: extension, alpha = the blurred frame's).  LGPU_E_UNSUPPORTED when the width is not a multiple of 4 or a frame is not 4- (psize 3) / 16-byte
+// (psize 4) aligned: the caller then runs lgpu_gauss5 and lgpu_colorkey one after the other.
+extern "C" int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow, int width, int height, int psize,
+                                    int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src0_d && src1_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(irow0 >= width * psize && irow1 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  LGPU_REQUIRE(src0_d != dst_d, "the blur cannot run in place");
+  const uintptr_t bits = (uintptr_t)src0_d | (uintptr_t)src1_d | (uintptr_t)dst_d | (uintptr_t)irow0 | (uintptr_t)irow1 | (uintptr_t)orow;
+  if ((width & 3) || (bits & (psize == 4 ? 15 : 3))) { set_error("lgpu_gauss5_colorkey: width %% 4 or alignment outside the fused kernel's range"); return LGPU_E_UNSUPPORTED; }
+  GckArgs a;
+  a.src0 = src0_d; a.src1 = src1_d; a.dst = dst_d; a.irow0 = irow0; a.irow1 = irow1; a.orow = orow; a.width = width; a.height = height;
+  a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
+  a.th = 16;
+  if ((long long)a.cgroups * 4 * cdiv((unsigned)height, 16u) < 4096) a.th = 8;
+  a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
+  // parameter preparation exactly as the script does it (host side, double)
+  double xdelta = delta * 2.;
+  delta /= 2.;
+  a.rmin = col_r - (int)(col_r * delta + .5);
+  a.gmin = col_g - (int)(col_g * xdelta + .5);
+  a.bmin = col_b - (int)(col_b * delta + .5);
+  xdelta *= 2.;
+  delta *= 2.;
+  a.rmax = col_r + (int)((255 - col_r) * delta + .5);
+  a.gmax = col_g + (int)((255 - col_g) * xdelta + .5);
+  a.bmax = col_b + (int)((255 - col_b) * delta + .5);
+  a.order = is_bgr ? 1 : 0; a.opac = opac; a.opacx = 1. - opac; a.key = 1;
+  const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u));
+  if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}

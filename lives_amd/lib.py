@@ -111,6 +111,7 @@ PROTOTYPES = {
     "lgpu_blend_luma": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_blend_multi": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp],
     "lgpu_colorkey": [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, cd, ci, ci, ci, vp],
+    "lgpu_gauss5_colorkey": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, cd, cd, ci, ci, ci, vp],
     "lgpu_mirror": [ci, vp, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_transition": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, vp],
     "lgpu_yuv_repack": [ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp],

@@ -108,6 +108,11 @@ def resize(src, dst, sw, sh, dw, dh, psize=4, interp=3, lut=None):
              lp[0] if lp else None, stream_ptr())
 
 
+def gauss5_colorkey(src0, src1, dst, width, height, psize, is_bgr, delta, opac, col):
+    lib.call("lgpu_gauss5_colorkey", dptr(src0), src0.stride(0), dptr(src1), src1.stride(0), dptr(dst), dst.stride(0), width, height, psize, int(is_bgr),
+             float(delta), float(opac), int(col[0]), int(col[1]), int(col[2]), stream_ptr())
+
+
 def pixbuf_scale(src, dst, sw, sh, dw, dh, channels=4, interp=3):
     lib.call("lgpu_pixbuf_scale", dptr(src), src.stride(0), sw, sh, dptr(dst), dst.stride(0), dw, dh, channels, interp, stream_ptr())
 

@@ -595,6 +595,32 @@ void orc_colorkey(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1
   }
 }
 
+/* the same key on 4-byte pixels (RGBA32 / BGRA32) -- an EXTENSION (the reference filter takes RGB24 / BGR24 only): the three colour bytes as above, the alpha
+   byte is the first frame's.  Used for BASELINE config 4's "RGBA32 extension for the headline" (SURVEY 8d); own spec, unpinned. */
+void orc_colorkey4(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1, uint8_t *dst, int orow,
+                   int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b) {
+  double xdelta = delta * 2., opacx = 1. - opac;
+  int rmin, gmin, bmin, rmax, gmax, bmax;
+  delta /= 2.;
+  rmin = col_r - (int)(col_r * delta + .5);
+  gmin = col_g - (int)(col_g * xdelta + .5);
+  bmin = col_b - (int)(col_b * delta + .5);
+  xdelta *= 2.; delta *= 2.;
+  rmax = col_r + (int)((255 - col_r) * delta + .5);
+  gmax = col_g + (int)((255 - col_g) * xdelta + .5);
+  bmax = col_b + (int)((255 - col_b) * delta + .5);
+  for (int y = 0; y < height; y++) {
+    const uint8_t *a = src0 + (size_t)y * irow0, *b = src1 + (size_t)y * irow1;
+    uint8_t *d = dst + (size_t)y * orow;
+    for (int j = 0; j < width * 4; j += 4) {
+      const int r = is_bgr ? a[j + 2] : a[j], g = a[j + 1], bl = is_bgr ? a[j] : a[j + 2];
+      memcpy(d + j, a + j, 4);
+      if (r >= rmin && r <= rmax && g >= gmin && g <= gmax && bl >= bmin && bl <= bmax)
+        for (int c = 0; c < 3; c++) d[j + c] = (uint8_t)(a[j + c] * opacx + b[j + c] * opac);
+    }
+  }
+}
+
 /* F5: mirrors                          reference: lives-plugins/weed-plugins/mirrors.c:26-122
    The reference's stray writes (pixel `width` of each row for even widths, row `height`) are not
    performed; rows / pixels it leaves unwritten in non-inplace mode get the in-place result. */

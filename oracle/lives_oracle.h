@@ -79,6 +79,9 @@ void orc_blend_multi(int type, const uint8_t *src1, int irow1, const uint8_t *sr
 void orc_colorkey(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1, uint8_t *dst, int orow,
                   int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b,
                   int inplace);
+/* extension: the key on 4-byte pixels, alpha from the first frame (own spec; BASELINE config 4's RGBA32 form) */
+void orc_colorkey4(const uint8_t *src0, int irow0, const uint8_t *src1, int irow1, uint8_t *dst, int orow,
+                   int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b);
 /* F5: mirrors.c:26-122.  mode 0 = x, 1 = y, 2 = xy.  (OOB writes of the reference are not performed.) */
 void orc_mirror(int mode, const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
 

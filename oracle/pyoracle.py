@@ -81,6 +81,7 @@ def oracle():
         _O.orc_yuv420p_to_rgb_lut16.argtypes = [vp, vp, vp, vp, ctypes.c_long, ctypes.c_long, vp] + [ci] * 8 + [vp, ci]
         _O.orc_gamma_lut16.argtypes = [cd, ci, ci, cd, vp]
         _O.orc_colorkey.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, cd, ci, ci, ci, ci]
+        _O.orc_colorkey4.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, cd, cd, ci, ci, ci]
         _O.orc_swizzle.argtypes = [ci, ci, vp, ci, vp, ci, ci, ci, vp]
         _O.orc_gamma_apply.argtypes = [vp, ci, ci, ci, ci, ci, vp]
         _O.orc_alpha_premult.argtypes = [vp, ci, ci, ci, ci, ci]

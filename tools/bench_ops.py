@@ -202,7 +202,13 @@ def main():
     hs, hd = hframe(w, h, 4), hframe(w, h, 4)
     c = cpu(lambda: orc.orc_gauss5(P(hs), hs.strides[0], P(hd), hd.strides[0], w, h, 4))
     add("gauss5 RGBA32 (C4)", "(own spec)", "3840x2160", w * h * 8, t, c)
+    # BASELINE config 4 as ONE launch: gaussian -> colour key, RGBA32 (the extension SURVEY 8d names: 2 x 33.2 MB read + 33.2 MB written) and RGB24 (the reference's palette)
+    k2 = dframe(w, h, 4, NB)
+    t = timeit(lambda i: ops.gauss5_colorkey(src[i], k2[i], dst[i], w, h, 4, 0, 0.3, 0.8, (128, 128, 128)), NB)
+    add("C4 in one launch: gauss5 -> colour key RGBA32 (lgpu_gauss5_colorkey)", "colorkey.script + own spec", "3840x2160", w * h * 12, t, None)
     a3, b3, o3 = dframe(w, h, 3, NB), dframe(w, h, 3, NB), dframe(w, h, 3, NB)
+    t = timeit(lambda i: ops.gauss5_colorkey(a3[i], b3[i], o3[i], w, h, 3, 0, 0.3, 0.8, (128, 128, 128)), NB)
+    add("C4 in one launch: gauss5 -> colour key RGB24 (lgpu_gauss5_colorkey)", "colorkey.script + own spec", "3840x2160", w * h * 9, t, None)
     t = timeit(lambda i: ops.colorkey(a3[i], b3[i], o3[i], w, h, 0, 0.2, 1.0, (0, 0, 255)), NB)
     ha, hb, ho = hframe(w, h, 3), hframe(w, h, 3), hframe(w, h, 3)
     if orc:
