@@ -239,7 +239,7 @@ def main():
         if config5:
             out["config"].update(config5)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.blur)
+            out["cpu_baseline"] = cpu_baseline(args.blur, args.resize_backend == "pixbuf")
     if comm is not None:
         if world > 1:
             dist.barrier()
@@ -282,22 +282,23 @@ def dry_run(args, rank, world):
                           "tracks_of_rank0": mine, "max_over_ranks_s": dt}))
 
 
-def cpu_baseline(blur):
+def cpu_baseline(blur, pixbuf=True):
     """the oracle's threaded runner (reference row-slice rule, one thread per core) on a bounded sample"""
     from oracle import pyoracle as po
     import ctypes
     so = po.build_oracle(native=True)
     lib_ = ctypes.CDLL(so)
-    lib_.orc_bench_chain.restype = ctypes.c_double
-    lib_.orc_bench_chain.argtypes = [ctypes.c_int] * 7
+    lib_.orc_bench_chain2.restype = ctypes.c_double
+    lib_.orc_bench_chain2.argtypes = [ctypes.c_int] * 8
+    interp = 3 | (0x100 if pixbuf else 0)          # the same resize arithmetic as the GPU leg
     cores = os.cpu_count() or 1
-    probe = lib_.orc_bench_chain(SW, SH, DW, DH, cores, 2, blur)
+    probe = lib_.orc_bench_chain2(SW, SH, DW, DH, cores, 2, blur, interp)
     per = max(probe / 2, 1e-4)
     n = int(max(4, min(400, 12.0 / per)))          # ~12 s of CPU work
-    secs = lib_.orc_bench_chain(SW, SH, DW, DH, cores, n, blur)
-    one = lib_.orc_bench_chain(SW, SH, DW, DH, 1, 2, blur) / 2
+    secs = lib_.orc_bench_chain2(SW, SH, DW, DH, cores, n, blur, interp)
+    one = lib_.orc_bench_chain2(SW, SH, DW, DH, 1, 2, blur, interp) / 2
     return {"value": round(n / secs, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same 3840x2160 chain, %d threads (reference row-slice rule), gcc -O3 -march=native" % (n, cores),
+            "sample": "%d frames of the same 3840x2160 chain (%s resize), %d threads (reference row-slice rule), gcc -O3 -march=native" % (n, "gdk-pixbuf HYPER" if pixbuf else "polyphase bicubic", cores),
             "single_thread_fps": round(1.0 / one, 2)}
 
 

@@ -193,6 +193,7 @@ int orc_resize(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int o
 /* R1, pixbuf backend (PINNED on the gdk-pixbuf runtime library the reference's non-swscale resize body calls, src/colourspace.c:15295;
    oracle/orc_pixbuf.c).  channels 3 (no alpha) or 4 (alpha-weighted); interp as above.  0 ok, -1 bad args, -2 ratio not covered. */
 int orc_pixbuf_scale(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int channels, int interp);
+int orc_pixbuf_scale_rows(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int channels, int interp, int y0, int y1);
 int *orc_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff);
 void orc_pixbuf_free(void *p);
 /* B1 (UNPINNED, build-defined): separable [1 4 6 4 1]/16 per axis, edge replicate, one rounding */

@@ -14,7 +14,7 @@
 typedef struct {
   const uint8_t *src, *l2;
   uint8_t *dst;
-  int irow, irow2, orow, sw, sh, dw, dh, swap_rb, do_blur, bf;
+  int irow, irow2, orow, sw, sh, dw, dh, swap_rb, do_blur, bf, pixbuf_interp;      /* pixbuf_interp >= 0: the resize stage on gdk-pixbuf's arithmetic (orc_pixbuf.c) */
   const uint8_t *lut8;
   int nth, ntv;
   const int32_t *hpos, *vpos;
@@ -27,6 +27,12 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? 
 /* resized rows [ry0, ry1) of the (swapped) source into out (row pitch dw*4); exact orc_resize arithmetic */
 static void resize_rows(const job_t *j, int ry0, int ry1, uint8_t *out) {
   const int dw = j->dw, sw = j->sw, sh = j->sh;
+  if (j->pixbuf_interp >= 0) {          /* LGPU_INTERP_PIXBUF: rows [ry0, ry1) by the pinned scaler; the R <-> B swap commutes with it and is done on its output */
+    orc_pixbuf_scale_rows(j->src, j->irow, sw, sh, out, dw * 4, dw, j->dh, 4, j->pixbuf_interp, ry0, ry1);
+    if (j->swap_rb)
+      for (size_t i = 0; i < (size_t)(ry1 - ry0) * dw; i++) { const uint8_t t = out[4 * i]; out[4 * i] = out[4 * i + 2]; out[4 * i + 2] = t; }
+    return;
+  }
   const int s0 = j->vpos[ry0], s1 = j->vpos[ry1 - 1] + j->ntv;      /* unclamped source row span */
   const int nrows = s1 - s0;
   int16_t *tmp = malloc(sizeof(int16_t) * (size_t)nrows * dw * 4);
@@ -108,6 +114,8 @@ static void *run_slice(void *arg) {
 int orc_chain_threaded(const uint8_t *src, int irow, int sw, int sh, const uint8_t *layer2, int irow2,
                        uint8_t *dst, int orow, int dw, int dh, int swap_rb, int interp, int do_blur, int bf,
                        const uint8_t *lut8, int nthreads) {
+  const int pixbuf_interp = (interp & 0x100) ? (interp & 0xFF) : -1;
+  interp &= 0xFF;
   const int kernel = (interp == ORC_INTERP_HYPER) ? ((dw > sw || dh > sh) ? 2 : 1) : 0;
   int32_t *hpos = malloc(sizeof(int32_t) * dw), *vpos = malloc(sizeof(int32_t) * dh);
   int16_t *hco = malloc(sizeof(int16_t) * (size_t)dw * 256), *vco = malloc(sizeof(int16_t) * (size_t)dh * 256);
@@ -126,6 +134,7 @@ int orc_chain_threaded(const uint8_t *src, int irow, int sw, int sh, const uint8
       job_t *j = &jobs[i];
       j->src = src; j->l2 = layer2; j->dst = dst; j->irow = irow; j->irow2 = irow2; j->orow = orow;
       j->sw = sw; j->sh = sh; j->dw = dw; j->dh = dh; j->swap_rb = swap_rb; j->do_blur = do_blur; j->bf = bf; j->lut8 = lut8;
+      j->pixbuf_interp = pixbuf_interp;
       j->nth = nth; j->ntv = ntv; j->hpos = hpos; j->vpos = vpos; j->hco = hco; j->vco = vco;
       j->y0 = i * per; j->y1 = (i + 1) * per > dh ? dh : (i + 1) * per;
       if (j->y0 >= dh) break;
@@ -141,10 +150,14 @@ out:
   return rc;
 }
 
+double orc_bench_chain2(int sw, int sh, int dw, int dh, int nthreads, int nframes, int do_blur, int interp);
 static uint32_t xs32(uint32_t *s) { uint32_t x = *s; x ^= x << 13; x ^= x >> 17; x ^= x << 5; return *s = x; }
 
 /* times `nframes` passes of the chain on synthetic frames (seed 0x11FE5); returns seconds, or < 0 */
-double orc_bench_chain(int sw, int sh, int dw, int dh, int nthreads, int nframes, int do_blur) {
+double orc_bench_chain(int sw, int sh, int dw, int dh, int nthreads, int nframes, int do_blur) { return orc_bench_chain2(sw, sh, dw, dh, nthreads, nframes, do_blur, ORC_INTERP_HYPER); }
+
+/* interp may carry 0x100 (LGPU_INTERP_PIXBUF) */
+double orc_bench_chain2(int sw, int sh, int dw, int dh, int nthreads, int nframes, int do_blur, int interp) {
   const size_t sb = (size_t)sw * 4 * sh, db = (size_t)dw * 4 * dh;
   uint8_t *src = malloc(sb), *l2 = malloc(db), *dst = malloc(db), lut[256];
   uint32_t seed = 0x11FE5;
@@ -154,10 +167,10 @@ double orc_bench_chain(int sw, int sh, int dw, int dh, int nthreads, int nframes
   for (size_t i = 0; i < db; i++) l2[i] = (uint8_t)(xs32(&seed) >> 24);
   for (size_t i = 3; i < db; i += 8) l2[i] = 255;          /* half of layer 2 opaque */
   orc_gamma_lut8(1.0, -1, 1, 1.4, lut);
-  orc_chain_threaded(src, sw * 4, sw, sh, l2, dw * 4, dst, dw * 4, dw, dh, 1, ORC_INTERP_HYPER, do_blur, 128, lut, nthreads);  /* warm-up */
+  orc_chain_threaded(src, sw * 4, sw, sh, l2, dw * 4, dst, dw * 4, dw, dh, 1, interp, do_blur, 128, lut, nthreads);  /* warm-up */
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int f = 0; f < nframes; f++)
-    if (orc_chain_threaded(src, sw * 4, sw, sh, l2, dw * 4, dst, dw * 4, dw, dh, 1, ORC_INTERP_HYPER, do_blur, 128 + (f & 1), lut, nthreads)) return -1.;
+    if (orc_chain_threaded(src, sw * 4, sw, sh, l2, dw * 4, dst, dw * 4, dw, dh, 1, interp, do_blur, 128 + (f & 1), lut, nthreads)) return -1.;
   clock_gettime(CLOCK_MONOTONIC, &t1);
   free(src); free(l2); free(dst);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);

@@ -148,14 +148,15 @@ static inline int pb_clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi
 
 /* GDK_INTERP_NEAREST: sample at the 16.16 position of the destination pixel centre, truncated */
 static void pb_nearest(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int ch,
-                       double scale_x, double scale_y) {
+                       double scale_x, double scale_y, int y0, int y1) {
   const int x_step = (int)((1 << PB_SCALE_SHIFT) / scale_x);
   const int y_step = (int)((1 << PB_SCALE_SHIFT) / scale_y);
-  for (int i = 0; i < dh; i++) {
+  (void)dh;
+  for (int i = y0; i < y1; i++) {
     int y_pos = (int)(((int64_t)i * y_step + y_step / 2) >> PB_SCALE_SHIFT);
     y_pos = pb_clampi(y_pos, 0, sh - 1);
     const uint8_t *s = src + (size_t)y_pos * irow;
-    uint8_t *d = dst + (size_t)i * orow;
+    uint8_t *d = dst + (size_t)(i - y0) * orow;
     int64_t x = x_step / 2;
     for (int j = 0; j < dw; j++, x += x_step) {
       int xp = (int)(x >> PB_SCALE_SHIFT);
@@ -171,13 +172,18 @@ static int pb_two_step(int n_x, int n_y) { return (int64_t)n_x * n_y > 1000; }
 /* src: 3 channels (no alpha) or 4 channels (has alpha); dst the same channel count.  interp: 0 NEAREST, 2 BILINEAR, 3 HYPER.
    returns 0, -1 on bad arguments / allocation, -2 for ratios this restatement does not cover. */
 int orc_pixbuf_scale(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int channels, int interp) {
-  if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || (channels != 3 && channels != 4)) return -1;
+  return orc_pixbuf_scale_rows(src, irow, sw, sh, dst, orow, dw, dh, channels, interp, 0, dh);
+}
+
+/* destination rows [y0, y1) only; dst points at row y0 (the row-sliced CPU baseline runner uses this) */
+int orc_pixbuf_scale_rows(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int channels, int interp, int y0, int y1) {
+  if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || (channels != 3 && channels != 4) || y0 < 0 || y1 > dh || y0 > y1) return -1;
   if (dw == sw && dh == sh) {            /* gdk_pixbuf_scale_simple returns a plain copy */
-    for (int y = 0; y < sh; y++) memcpy(dst + (size_t)y * orow, src + (size_t)y * irow, (size_t)sw * channels);
+    for (int y = y0; y < y1; y++) memcpy(dst + (size_t)(y - y0) * orow, src + (size_t)y * irow, (size_t)sw * channels);
     return 0;
   }
   const double scale_x = (double)dw / sw, scale_y = (double)dh / sh;
-  if (interp == 0) { pb_nearest(src, irow, sw, sh, dst, orow, dw, dh, channels, scale_x, scale_y); return 0; }
+  if (interp == 0) { pb_nearest(src, irow, sw, sh, dst, orow, dw, dh, channels, scale_x, scale_y, y0, y1); return 0; }
   if (interp != 2 && interp != 3) return -1;
   int n_x, n_y, xoff, yoff;
   int *table = orc_pixbuf_weights(interp, sw, sh, dw, dh, &n_x, &n_y, &xoff, &yoff);
@@ -188,11 +194,11 @@ int orc_pixbuf_scale(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst,
   if (x_step == 0 || y_step == 0) { free(table); return -2; }
   /* the library's 2 x 2, 3 -> 3 channel line function rounds to nearest; every other case rounds up */
   const unsigned rnd = (n_x == 2 && n_y == 2 && channels == 3) ? 0x8000u : 0xffffu;
-  int64_t y = yoff;
-  for (int i = 0; i < dh; i++, y += y_step) {
+  int64_t y = yoff + (int64_t)y0 * y_step;
+  for (int i = y0; i < y1; i++, y += y_step) {
     const int y_start = (int)(y >> PB_SCALE_SHIFT);
     const int *run = table + (size_t)((y >> (PB_SCALE_SHIFT - PB_SUB_BITS)) & PB_SUB_MASK) * n_x * n_y * PB_SUB;
-    uint8_t *d = dst + (size_t)i * orow;
+    uint8_t *d = dst + (size_t)(i - y0) * orow;
     int64_t x = xoff;
     for (int j = 0; j < dw; j++, x += x_step, d += channels) {
       const int x_start = (int)(x >> PB_SCALE_SHIFT);

@@ -85,6 +85,11 @@ def test_threaded_chain_equals_serial(orc):
                 assert orc.orc_chain(P(src), sw * 4, sw, sh, P(l2), dw * 4, P(a), dw * 4, dw, dh, 1, 3, blur, 100, P(lut)) == 0
                 assert orc.orc_chain_threaded(P(src), sw * 4, sw, sh, P(l2), dw * 4, P(b), dw * 4, dw, dh, 1, 3, blur, 100, P(lut), nt) == 0
                 assert (a == b).all(), (sw, sh, blur, nt)
+                # the same on the pinned resize arithmetic (LGPU_INTERP_PIXBUF = 0x100): what bench.py's cpu_baseline times by default
+                src[:, 3::4][rng.random((sh, sw)) < 0.4] = 255
+                assert orc.orc_chain(P(src), sw * 4, sw, sh, P(l2), dw * 4, P(a), dw * 4, dw, dh, 1, 3 | 0x100, blur, 100, P(lut)) == 0
+                assert orc.orc_chain_threaded(P(src), sw * 4, sw, sh, P(l2), dw * 4, P(b), dw * 4, dw, dh, 1, 3 | 0x100, blur, 100, P(lut), nt) == 0
+                assert (a == b).all(), ("pixbuf", sw, sh, blur, nt)
 
 
 def test_resize_spec_properties(orc):
