@@ -633,9 +633,9 @@ static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int
 
 static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : 124);
-  // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full -- with neighbouring bands walking towards each other, 4 rows: 167 us at
-  // 16 tracks (174 at 8 rows, 175 at 16), one 4K frame 11.0 us (11.6 / 14.7)
-  a->th = 4;
+  // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
+  // 16 tracks 170 / 167 us at 4 rows, 166 at 6, 165 / 174 at 8, 175 at 16; one 4K frame 11.0-11.2 us at 4 rows, 9.9 at 6, 11.7 at 8, 14.7 at 16
+  a->th = 6;
   if (blur) a->th = (long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 8 : 16;      // a band computes th + 4 scaled rows: taller bands, (th + 4) / th of the arithmetic
   if (const char *e = getenv("LGPU_PBH_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
   a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
