@@ -60,7 +60,8 @@ __device__ __forceinline__ void pb_finish(uint8_t *d, unsigned r, unsigned g, un
   if (CH == 4) {
     uint32_t o = 0;
     if (a) {
-      const double ia = 1.0 / (double)a;
+      // every tap opaque (the common frame): a = 255 * 65536 and fl(1 / a) is a constant -- the same double the division returns, without the division
+      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : 1.0 / (double)a;
       o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
     }
     *reinterpret_cast<uint32_t *>(d) = o;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void pb_tap(uint32_t q, unsigned w, unsigned &r, unsi
 template <int CH, int UNIFORM_X>
 __global__ __launch_bounds__(256) void k_pb_window(const PbArgs A) {
   extern __shared__ uint32_t win[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
   const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
   const int x0 = (int)(((long long)j0 * A.x_step + A.xoff) >> 16), y0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16);
   for (int wy = wave; wy < A.win_h; wy += 4) {
@@ -508,6 +509,90 @@ __global__ __launch_bounds__(256) void k_pb_epilogue(const uint8_t *trk, int iro
   reinterpret_cast<uint32_t *>(dst + (size_t)y * orow)[x] = p;
 }
 
+// =====================================================================================================================================================
+// k_pb_pairs -- every ratio whose per-phase weights fit 16 bits (all but tables with a single 65536 tap): two taps per v_dot2_u32_u16.
+// The window sits in LDS as premultiplied 16-bit values on ALIGNED pixel pairs: per pair 16 bytes = (P_c[2p] | P_c[2p+1] << 16) for c = 0, 1, 2 and the alpha pair
+// (3-byte pixels: P = the byte itself, no alpha).  A destination pixel's taps start at an even or odd source pixel; the weight rows are stored for both parities
+// as pairs aligned the same way (a zero weight pads the odd end), [y phase][x phase][parity][tap row][pair], so a tap row costs one ds_read_b128 per pair, one
+// weight dword per pair (read four at a time) and four dot2 -- about 2 VALU per tap and channel instead of 9 in k_pb_window.
+// =====================================================================================================================================================
+struct PbPairArgs {
+  const uint8_t *src;
+  uint8_t *dst;
+  int irow, orow, sw, sh, dw, dh;
+  int x_step, y_step, xoff, yoff;
+  int n_x, tx0, ty0, ny_eff, nq;       // nq: groups of four pairs per tap row
+  const uint32_t *pairs;               // device: [16][16][2][ny_eff][4 nq]
+  unsigned rnd;
+  int tile_h, wpairs, win_h;
+};
+
+// NPC: pairs per tap row when there are at most four (compile time: no work on the padding of the weight row), 0: any count, four at a time
+template <int CH, int NPC>
+__global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
+  extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
+  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
+  const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~1;          // the window starts on an even source pixel
+  const int ys0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;
+  for (int wy = wave; wy < A.win_h; wy += 4) {
+    const uint8_t *row = A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow;
+    pb_u4 *wr = winp + wy * A.wpairs;
+    for (int p = lane; p < A.wpairs; p += 64) {
+      const uint32_t q0 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p, A.sw - 1)), q1 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p + 1, A.sw - 1));
+      pb_u4 v;
+      if (CH == 4) {
+        v.x = pb_premul_pair<0>(q0, q1); v.y = pb_premul_pair<1>(q0, q1); v.z = pb_premul_pair<2>(q0, q1); v.w = __builtin_amdgcn_perm(q1, q0, 0x0C070C03u);
+      } else {
+        v.x = __builtin_amdgcn_perm(q1, q0, 0x0C040C00u); v.y = __builtin_amdgcn_perm(q1, q0, 0x0C050C01u); v.z = __builtin_amdgcn_perm(q1, q0, 0x0C060C02u); v.w = 0u;
+      }
+      wr[p] = v;
+    }
+  }
+  __syncthreads();
+  const int j = j0 + lane;
+  const long long x = (long long)j * A.x_step + A.xoff;
+  const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15;
+  const bool edge = xs < 0 || xs + A.n_x > A.sw;
+  const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
+  const int rowlen = 4 * A.nq;
+  // (loading a destination row's weight vectors a row ahead into registers was built and measured: 30 -> 42 us at 4K -> 1706x960 -- the predicated register arrays
+  // cost more than the exposed loads, which eight waves per SIMD already cover)
+  for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
+    const int i = i0 + r_;
+    if (i >= A.dh) break;
+    if (j >= A.dw) continue;
+    const long long y = (long long)i * A.y_step + A.yoff;
+    const int ys = (int)(y >> 16), yph = (int)(y >> 12) & 15;
+    const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
+    const pb_u4 *wt = reinterpret_cast<const pb_u4 *>(A.pairs + (size_t)(((yph * 16 + xph) * 2 + par) * A.ny_eff) * rowlen);
+    unsigned r = 0, g = 0, b = 0, a = 0;
+    for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
+      if (NPC) {
+        const pb_u4 w = wt[ty];
+        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < NPC; k++) {
+          const pb_u4 dd = wp[k];
+          r = pb_dot2(dd.x, wv[k], r); g = pb_dot2(dd.y, wv[k], g); b = pb_dot2(dd.z, wv[k], b);
+          if (CH == 4) a = pb_dot2(dd.w, wv[k], a);
+        }
+        continue;
+      }
+      for (int qd = 0; qd < A.nq; qd++) {
+        const pb_u4 w = wt[ty * A.nq + qd];
+        const pb_u4 d0 = wp[4 * qd], d1 = wp[4 * qd + 1], d2 = wp[4 * qd + 2], d3 = wp[4 * qd + 3];
+        r = pb_dot2(d0.x, w.x, r); g = pb_dot2(d0.y, w.x, g); b = pb_dot2(d0.z, w.x, b);
+        r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
+        r = pb_dot2(d2.x, w.z, r); g = pb_dot2(d2.y, w.z, g); b = pb_dot2(d2.z, w.z, b);
+        r = pb_dot2(d3.x, w.w, r); g = pb_dot2(d3.y, w.w, g); b = pb_dot2(d3.z, w.w, b);
+        if (CH == 4) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
+      }
+    }
+    pb_finish<CH>(A.dst + (size_t)i * A.orow + (size_t)j * CH, r, g, b, a, edge, A.rnd);
+  }
+}
+
 // ---- host: the per-phase weight tables ----------------------------------------------------------------------------------------------------
 struct PbDim { int n; double offset; std::vector<double> w; };   // w[phase * n + tap]
 
@@ -550,7 +635,8 @@ static void pb_fix_sum(int *w, int count, int total) {
       }
 }
 
-struct PbTable { int n_x, n_y, xoff, yoff, uniform_x; int *table_d; std::vector<int> host; };
+struct PbTable { int n_x, n_y, xoff, yoff, uniform_x; int *table_d; std::vector<int> host;
+                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0, nq = 0; uint32_t *pairs_d = nullptr; };      // pairs_d: the k_pb_pairs form of the table (nullptr: a weight needs 17 bits)
 static std::mutex g_pb_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, PbTable *> g_pb_tables;   // (device, interp, sw, sh, dw, dh); entries live as long as the library
 
@@ -576,6 +662,46 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
   if (upload) {
     LGPU_HIP(hipMalloc((void **)&t->table_d, t->host.size() * sizeof(int)));
     LGPU_HIP(hipMemcpy(t->table_d, t->host.data(), t->host.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  // the phases this geometry's destination pixels take, the bounding box of their non-zero taps, and -- when every weight of those phases fits 16 bits -- the
+  // table again as aligned tap PAIRS for both start parities (k_pb_pairs)
+  const int x_step = (int)(65536 / ((double)dw / sw)), y_step = (int)(65536 / ((double)dh / sh));
+  if (x_step > 0 && y_step > 0) {
+    bool xp[16] = {false}, yp[16] = {false};
+    for (int j = 0; j < dw; j++) xp[(((long long)j * x_step + t->xoff) >> 12) & 15] = true;
+    for (int i = 0; i < dh; i++) yp[(((long long)i * y_step + t->yoff) >> 12) & 15] = true;
+    int tx0 = t->n_x, tx1 = 0, ty0 = t->n_y, ty1 = 0, wmax = 0;
+    for (int y = 0; y < 16; y++)
+      for (int x = 0; x < 16; x++) {
+        if (!xp[x] || !yp[y]) continue;
+        const int *w = t->host.data() + (size_t)(y * 16 + x) * nn;
+        for (int ty = 0; ty < t->n_y; ty++)
+          for (int tx = 0; tx < t->n_x; tx++)
+            if (w[ty * t->n_x + tx]) {
+              tx0 = tx < tx0 ? tx : tx0; tx1 = tx + 1 > tx1 ? tx + 1 : tx1; ty0 = ty < ty0 ? ty : ty0; ty1 = ty + 1 > ty1 ? ty + 1 : ty1;
+              wmax = w[ty * t->n_x + tx] > wmax ? w[ty * t->n_x + tx] : wmax;
+            }
+      }
+    t->tx0 = tx0; t->tx1 = tx1; t->ty0 = ty0; t->ty1 = ty1;
+    if (upload && wmax < 65536 && tx1 > tx0) {
+      const int n_eff = tx1 - tx0, ny_eff = ty1 - ty0, np = (n_eff + 2) / 2, nq = (np + 3) / 4, rowlen = 4 * nq;
+      std::vector<uint32_t> pr((size_t)16 * 16 * 2 * ny_eff * rowlen, 0u);
+      for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++)
+          for (int par = 0; par < 2; par++) {
+            const int *w = t->host.data() + (size_t)(y * 16 + x) * nn;
+            uint32_t *o = pr.data() + (size_t)(((y * 16 + x) * 2 + par) * ny_eff) * rowlen;
+            for (int ty = 0; ty < ny_eff; ty++)
+              for (int i = 0; i < np; i++) {
+                const int t0 = tx0 + 2 * i - par, t1 = t0 + 1;        // the two taps of aligned pair i when the first tap sits on an even (par 0) / odd (par 1) source pixel
+                const uint32_t w0 = (t0 >= tx0 && t0 < tx1) ? (uint32_t)w[(ty0 + ty) * t->n_x + t0] : 0u, w1 = (t1 >= tx0 && t1 < tx1) ? (uint32_t)w[(ty0 + ty) * t->n_x + t1] : 0u;
+                o[ty * rowlen + i] = w0 | (w1 << 16);
+              }
+          }
+      LGPU_HIP(hipMalloc((void **)&t->pairs_d, pr.size() * sizeof(uint32_t)));
+      LGPU_HIP(hipMemcpy(t->pairs_d, pr.data(), pr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      t->nq = nq;
+    }
   }
   return LGPU_OK;
 }
@@ -772,6 +898,40 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.main_blocks = (int)pb_half_grid(h);
       if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       else hipLaunchKernelGGL((k_pb_half<0, 0, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
+  const bool no_pairs = getenv("LGPU_PB_NO_PAIRS") != nullptr;        // tests: the one-tap-per-operation kernels at any ratio
+  if (t->pairs_d && !no_pairs) {
+    PbPairArgs pa;
+    pa.src = src_d; pa.dst = dst_d; pa.irow = irow; pa.orow = orow; pa.sw = sw; pa.sh = sh; pa.dw = dw; pa.dh = dh;
+    pa.x_step = x_step; pa.y_step = y_step; pa.xoff = t->xoff; pa.yoff = t->yoff; pa.n_x = t->n_x; pa.tx0 = t->tx0; pa.ty0 = t->ty0; pa.ny_eff = t->ty1 - t->ty0; pa.nq = t->nq;
+    pa.pairs = t->pairs_d;
+    pa.rnd = (t->n_x == 2 && t->n_y == 2 && channels == 3) ? 0x8000u : 0xffffu;
+    // pairs per window row: the span of 64 destination pixels' first taps, the taps of the last one (padded to whole groups of four pairs), one pair of alignment slack
+    pa.wpairs = (int)((((63LL * x_step + 65535) >> 16) + 1) / 2) + 4 * t->nq + 2;
+    pa.tile_h = 0;
+    size_t lds_cap = 24 * 1024;                         // 6 workgroups per CU: the per-lane weight loads want occupancy more than the window wants rows (profiles/r03/pb_pairs_lds_sweep.txt)
+    if (const char *e = getenv("LGPU_PB_LDS_KB")) { const int v = atoi(e); if (v >= 4 && v <= 64) lds_cap = (size_t)v * 1024; }      // tuning probe
+    for (int th = 16; th >= 1; th >>= 1) {
+      const int wh = (int)(((long long)(th - 1) * y_step + 65535) >> 16) + pa.ny_eff + 1;
+      if ((size_t)pa.wpairs * wh * 16 <= lds_cap) { pa.tile_h = th; pa.win_h = wh; break; }
+    }
+    if (pa.tile_h) {
+      const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h));
+      const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
+      const int np = (t->tx1 - t->tx0 + 2) / 2;
+#define PB_PAIRS(CHN)                                                                                   \
+      switch (np <= 4 ? np : 0) {                                                                       \
+        case 1: hipLaunchKernelGGL((k_pb_pairs<CHN, 1>), g, block, lds, st, pa); break;                 \
+        case 2: hipLaunchKernelGGL((k_pb_pairs<CHN, 2>), g, block, lds, st, pa); break;                 \
+        case 3: hipLaunchKernelGGL((k_pb_pairs<CHN, 3>), g, block, lds, st, pa); break;                 \
+        case 4: hipLaunchKernelGGL((k_pb_pairs<CHN, 4>), g, block, lds, st, pa); break;                 \
+        default: hipLaunchKernelGGL((k_pb_pairs<CHN, 0>), g, block, lds, st, pa); break;                \
+      }
+      if (channels == 4) { PB_PAIRS(4) } else { PB_PAIRS(3) }
+#undef PB_PAIRS
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }

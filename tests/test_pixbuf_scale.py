@@ -189,6 +189,18 @@ def test_gpu_equals_the_oracle_on_random_geometry(gpu, orc):
 
 
 @gpu_mark
+def test_gpu_one_tap_kernels_at_every_ratio(gpu, orc, monkeypatch):
+    """k_pb_window / k_pb_direct (what ratios with a 17-bit weight and windows too large for LDS take) forced onto the ratios k_pb_pairs normally serves"""
+    monkeypatch.setenv("LGPU_PB_NO_PAIRS", "1")
+    rng = np.random.default_rng(0x9DBE)
+    for (sw, sh, dw, dh, ch, interp) in [(384, 216, 171, 96, 4, 3), (200, 120, 300, 180, 4, 3), (200, 120, 133, 80, 3, 2), (64, 36, 200, 100, 3, 3), (320, 180, 96, 54, 4, 2)]:
+        src = rng.integers(0, 256, (sh, align(sw * ch, 4)), dtype=np.uint8)
+        want = np.zeros((dh, dw * ch), np.uint8)
+        assert orc.orc_pixbuf_scale(P(src), src.strides[0], sw, sh, P(want), dw * ch, dw, dh, ch, interp) == 0
+        assert (gpu_scale(gpu, src, sw, sh, dw, dh, ch, interp) == want).all(), (sw, sh, dw, dh, ch, interp)
+
+
+@gpu_mark
 def test_gpu_strong_reductions(gpu, orc):
     """windows too large for LDS take the direct kernel; ratios past the library's one-step range are refused, the frame untouched"""
     from lives_amd import lib

@@ -29,8 +29,11 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
     reps, nb = 200, 6
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for case in (PIXBUF_CASES if pixbuf else CASES):
         name, sw, sh, dw, dh, interp = case[:6]
+        if only and not any(o in name for o in only):
+            continue
         ch = case[6] if pixbuf else 4
         srcs = [torch.randint(0, 256, (sh, sw * ch), dtype=torch.uint8, device="cuda", generator=g) for _ in range(nb)]
         dsts = [torch.zeros((dh, dw * ch), dtype=torch.uint8, device="cuda") for _ in range(nb)]
