@@ -160,6 +160,16 @@ typedef void *(*weed_memmove_f)(void *, const void *, size_t);
 #define WEED_LEAF_YUV_CLAMPING "YUV_clamping"
 #define WEED_LEAF_RANDOM_SEED "random_seed"           /* libweed/weed-effects.h:319 */
 #define WEED_LEAF_GROUP "group"                       /* libweed/weed-effects.h:391 */
+/* the compositor class (lives-plugins/weed-plugins/gdk/compositor.c:295-351): libweed/weed-effects.h:113, :135-136, :204, :279, :304, :339, :362, :390 */
+#define WEED_FILTER_CHANNEL_SIZES_MAY_VARY (1 << 8)
+#define WEED_PARAMETER_VARIABLE_SIZE (1 << 1)
+#define WEED_PARAMETER_VALUE_PER_CHANNEL (1 << 2)
+#define WEED_LEAF_DESCRIPTION "description"
+#define WEED_LEAF_INNER_SIZE "inner_size"
+#define WEED_LEAF_LAYOUT_SCHEME "layout_scheme"
+#define WEED_LEAF_MAX_REPEATS "max_repeats"
+#define WEED_LEAF_DISABLED "disabled"
+#define WEED_LEAF_NEW_DEFAULT "new_default"
 #define WEED_LEAF_CHOICES "choices"
 #define WEED_LEAF_YUV_SAMPLING "YUV_sampling"
 #define WEED_LEAF_YUV_SUBSPACE "YUV_subspace"

@@ -7,6 +7,7 @@
  *   "blend_multiply" .. "blend_burn"             lives-plugins/weed-plugins/multi_blends.c:205-300
  *   "colorkey"                                   lives-plugins/weed-plugins/scripts/colorkey.script
  *   "mirrorx", "mirrory", "mirrorxy"             lives-plugins/weed-plugins/mirrors.c:125-160
+ *   "compositor"                                 lives-plugins/weed-plugins/gdk/compositor.c:127-351 (scaler: gdk_pixbuf_scale_simple, pinned -- pixbuf.hip)
  * process_func uploads the host channels, runs the liblivesgpu.so kernel and downloads the result (the host
  * owns pixel_data -- host memory; device residency across a chain is what the layer seam is for).
  * WEED_FILTER_HINT_MAY_THREAD is deliberately NOT advertised, so the host makes one call per frame
@@ -424,6 +425,97 @@ PROC(p_slide, 2, 0, k_slide, 1) PROC(p_deint, 1, 0, k_deint, 1) PROC(p_rgbdelay,
 PROC(p_tsplit, 2, 0, k_tsplit, 1) PROC(p_dissolve, 2, 0, k_dissolve, 1) PROC(p_rreplace, 2, 0, k_rreplace, 1)
 PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(p_ccorrect, 1, 2, k_scriptfx, 0)
 
+/* ---- "compositor" (lives-plugins/weed-plugins/gdk/compositor.c:127-292) -----------------------------------------------------------------------------
+   any number of in channels of any size (WEED_FILTER_CHANNEL_SIZES_MAY_VARY, in channel template with max_repeats 0); per-channel x / y offset, x / y
+   scale and alpha (variable-size parameters, one value per channel), background colour, z order.  Every enabled channel becomes a pixbuf (with alpha
+   for 4-byte palettes, :83-90), is scaled to (((int)(owidth * scalex + 1.)) >> 1) << 1 by the same rule for the height (:218-219) with
+   gdk_pixbuf_scale_simple -- GDK_INTERP_HYPER when a side grows, GDK_INTERP_BILINEAR otherwise (:262-266) -- and painted at (int)(offs * out size) by
+   paint_pixel (:120-125).  Here: lgpu_pixbuf_scale (bit-exact to that library call) per channel into stream-ordered device frames, then ONE
+   lgpu_composite launch.  A channel with an "inner_size" leaf is cropped first as :228-258 do.  At most LGPU_COMP_MAX_LAYERS enabled channels. */
+static double g_dbl_at(weed_plant_t *p, const char *k, int idx, double dflt) { double v = dflt; if (w_get(p, k, (weed_size_t)idx, &v) != WEED_SUCCESS) return dflt; return v; }
+static weed_error_t p_compositor(weed_plant_t *inst, weed_timecode_t tc) {
+  fxdata_t *fx = fx_data(inst);
+  weed_plant_t *ochan = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0), *par[7];
+  lgpu_comp_layer layers[LGPU_COMP_MAX_LAYERS];
+  void *tofree[2 * LGPU_COMP_MAX_LAYERS + 1];
+  int nfree = 0, nin, z, i, owidth, oheight, pal, psize, orow, bg[3], revz, rc = LGPU_OK;
+  uint8_t *dst, *ddst = NULL;
+  (void)tc;
+  if (!fx || !ochan) return WEED_ERROR_FILTER_INVALID;
+  fx_enter(fx);
+  nin = (int)w_nelems(inst, WEED_LEAF_IN_CHANNELS);
+  owidth = g_int(ochan, WEED_LEAF_WIDTH, 0, 0); oheight = g_int(ochan, WEED_LEAF_HEIGHT, 0, 0);
+  pal = g_int(ochan, WEED_LEAF_CURRENT_PALETTE, 0, 0); psize = psize_of(pal);
+  orow = g_int(ochan, WEED_LEAF_ROWSTRIDES, 0, 0);
+  dst = (uint8_t *)g_ptr(ochan, WEED_LEAF_PIXEL_DATA, 0);
+  if (!dst || owidth <= 0 || oheight <= 0 || !(pal == WEED_PALETTE_RGB24 || pal == WEED_PALETTE_BGR24 || pal == WEED_PALETTE_RGBA32 || pal == WEED_PALETTE_BGRA32)) return WEED_ERROR_FILTER_INVALID;
+  if (nin > LGPU_COMP_MAX_LAYERS) { fprintf(stderr, "livesgpu_fx: compositor: more than %d in channels\n", LGPU_COMP_MAX_LAYERS); return WEED_ERROR_FILTER_INVALID; }
+  for (i = 0; i < 7; i++) if (!(par[i] = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_PARAMETERS, i))) return WEED_ERROR_FILTER_INVALID;
+  for (i = 0; i < 3; i++) bg[i] = g_int(par[5], WEED_LEAF_VALUE, i, 0);
+  revz = g_int(par[6], WEED_LEAF_VALUE, 0, WEED_FALSE) == WEED_TRUE;
+  memset(layers, 0, sizeof layers);
+  for (z = 0; z < nin && rc == LGPU_OK; z++) {
+    weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, z);
+    const uint8_t *src;
+    int in_width, in_height, irow, out_width, out_height, cutleft = 0, cuttop = 0, interp, srow;
+    double scx, scy;
+    void *dsrc = NULL, *dscaled = NULL;
+    if (!ic || g_int(ic, WEED_LEAF_DISABLED, 0, WEED_FALSE) == WEED_TRUE) continue;                 /* :192-193 */
+    src = (const uint8_t *)g_ptr(ic, WEED_LEAF_PIXEL_DATA, 0);
+    if (!src) continue;
+    scx = z < (int)w_nelems(par[2], WEED_LEAF_VALUE) ? g_dbl_at(par[2], WEED_LEAF_VALUE, z, 1.) : 1.;
+    scy = z < (int)w_nelems(par[3], WEED_LEAF_VALUE) ? g_dbl_at(par[3], WEED_LEAF_VALUE, z, 1.) : 1.;
+    out_width = (((int)(owidth * scx + 1.)) >> 1) << 1;
+    out_height = (((int)(oheight * scy + 1.)) >> 1) << 1;
+    if (out_width * out_height < 16) continue;                                                        /* :221 */
+    in_width = g_int(ic, WEED_LEAF_WIDTH, 0, 0); in_height = g_int(ic, WEED_LEAF_HEIGHT, 0, 0); irow = g_int(ic, WEED_LEAF_ROWSTRIDES, 0, 0);
+    if (in_width <= 0 || in_height <= 0 || irow < in_width * psize) { rc = LGPU_E_BADARG; break; }
+    if (w_nelems(ic, WEED_LEAF_INNER_SIZE) >= 4) {                                                  /* letterboxed channel: :228-258 */
+      const int lbx = g_int(ic, WEED_LEAF_INNER_SIZE, 0, 0), lby = g_int(ic, WEED_LEAF_INNER_SIZE, 1, 0);
+      const int lbw = g_int(ic, WEED_LEAF_INNER_SIZE, 2, in_width), lbh = g_int(ic, WEED_LEAF_INNER_SIZE, 3, in_height);
+      const int lbwidth = (int)(lbw / scx), lbheight = (int)(lbh / scy);
+      if (lbwidth < in_width) {
+        const int totlbw = in_width - lbw;
+        const double lbscale = (double)(in_width - lbwidth) / (double)totlbw;
+        const int extra = (int)((double)(in_width - lbx - lbw) * lbscale + .5);
+        cutleft = (int)((double)lbx * (1. - lbscale) + .5);
+        in_width = lbx - cutleft + lbw + extra;
+      } else { cutleft = lbx; in_width = lbw; }
+      if (lbheight < in_height) {
+        const int totlbh = in_height - lbh;
+        const double lbscale = ((double)in_height - (double)lbheight) / (double)totlbh;
+        const int extra = (int)((double)(in_height - lby - lbh) * lbscale + .5);
+        cuttop = (int)((double)lby * (1. - lbscale) + .5);
+        in_height = lby - cuttop + lbh + extra;
+      } else { cuttop = lby; in_height = lbh; }
+      if (in_width <= 0 || in_height <= 0) continue;
+    }
+    interp = (out_width > in_width || out_height > in_height) ? LIVES_INTERP_BEST : LIVES_INTERP_NORMAL;   /* up_interp HYPER / down_interp BILINEAR, :154-155 */
+    srow = (out_width * psize + 3) & ~3;                                                               /* the scaled pixbuf's rowstride */
+    if ((rc = lgpu_malloc_ordered(&dsrc, (size_t)irow * in_height + 16, FXS))) break;
+    tofree[nfree++] = dsrc;
+    if ((rc = lgpu_upload(dsrc, src + (size_t)cuttop * irow, (size_t)irow * in_height, FXS))) break;
+    if ((rc = lgpu_malloc_ordered(&dscaled, (size_t)srow * out_height + 16, FXS))) break;
+    tofree[nfree++] = dscaled;
+    if ((rc = lgpu_pixbuf_scale((const uint8_t *)dsrc + (size_t)cutleft * psize, irow, in_width, in_height, (uint8_t *)dscaled, srow, out_width, out_height, psize, interp, FXS))) break;
+    layers[z].src_d = (const uint8_t *)dscaled; layers[z].irow = srow; layers[z].width = out_width; layers[z].height = out_height;
+    layers[z].offs_x = z < (int)w_nelems(par[0], WEED_LEAF_VALUE) ? (int)(g_dbl_at(par[0], WEED_LEAF_VALUE, z, 0.) * (double)owidth) : 0;
+    layers[z].offs_y = z < (int)w_nelems(par[1], WEED_LEAF_VALUE) ? (int)(g_dbl_at(par[1], WEED_LEAF_VALUE, z, 0.) * (double)oheight) : 0;
+    layers[z].alpha = z < (int)w_nelems(par[4], WEED_LEAF_VALUE) ? g_dbl_at(par[4], WEED_LEAF_VALUE, z, 1.) : 1.;
+  }
+  if (rc == LGPU_OK) rc = lgpu_malloc_ordered((void **)&ddst, (size_t)orow * oheight + 16, FXS);
+  if (rc == LGPU_OK) {
+    tofree[nfree++] = ddst;
+    if (orow != owidth * psize) rc = lgpu_upload(ddst, dst, (size_t)orow * oheight, FXS);           /* row padding keeps the host's bytes */
+  }
+  if (rc == LGPU_OK) rc = lgpu_composite(ddst, orow, owidth, oheight, psize, pal == WEED_PALETTE_BGR24 || pal == WEED_PALETTE_BGRA32, bg, layers, nin, revz, FXS);
+  if (rc == LGPU_OK) rc = lgpu_download(dst, ddst, (size_t)orow * oheight, FXS);
+  if (rc == LGPU_OK) rc = lgpu_sync(FXS);
+  for (i = 0; i < nfree; i++) lgpu_free_ordered(tofree[i], FXS);
+  if (rc != LGPU_OK) { fprintf(stderr, "livesgpu_fx: compositor: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+  return WEED_SUCCESS;
+}
+
 /* ---- class construction (same leaves as weed_filter_class_init & friends, weed-plugin-utils.c:258-420) ---- */
 static weed_plant_t *chantmpl(const char *name, int flags) {
   weed_plant_t *t = w_new(WEED_PLANT_CHANNEL_TEMPLATE);
@@ -700,6 +792,33 @@ weed_plant_t *weed_setup(weed_bootstrap_f weed_boot) {
     if (fc) { w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict); w_get(fc, WEED_LEAF_OUT_CHANNEL_TEMPLATES, 0, &oct); }
     if (ict) s_int(ict, WEED_LEAF_YUV_CLAMPING, WEED_YUV_CLAMPING_UNCLAMPED);
     if (oct) s_int(oct, WEED_LEAF_FLAGS, 0);
+  }
+  /* gdk/compositor.c:295-351: "compositor": one in channel template repeated without limit (max_repeats 0), five per-channel float parameters
+     (VARIABLE_SIZE | VALUE_PER_CHANNEL, new_default), background colour, z switch; WEED_FILTER_CHANNEL_SIZES_MAY_VARY.  The palette list is the reference's
+     (RGBA32 twice there; BGRA32 is what its paint loop's r / b swap is for and is accepted here too) */
+  {
+    static const int32_t pk[] = {WEED_PALETTE_RGB24, WEED_PALETTE_BGR24, WEED_PALETTE_RGBA32, WEED_PALETTE_BGRA32};
+    static const char *rfx[] = {"layout|p6|", "layout|p0|p1|", "layout|p2|p3|", "layout|p4|", "layout|hseparator|", "layout|p5|", "special|framedraw|multirect|0|1|2|3|4|"};
+    static const double nd[5] = {0., 0., 1., 1., 1.};
+    weed_plant_t *fc = NULL, *ict = NULL, *gui;
+    p[0] = float_param("xoffs", "_X offset", 0., 0., 1.); p[1] = float_param("yoffs", "_Y offset", 0., 0., 1.);
+    p[2] = float_param("scalex", "Scale _width", 1., 0., 1.); p[3] = float_param("scaley", "Scale _height", 1., 0., 1.);
+    p[4] = float_param("alpha", "_Alpha", 1.0, 0.0, 1.0);
+    p[5] = rgb_param("bgcol", "_Background color", 0, 0, 0);
+    p[6] = switch_param("revz", "Invert _Z Index", WEED_FALSE);
+    for (i = 0; i < 5; i++) { s_int(p[i], WEED_LEAF_FLAGS, WEED_PARAMETER_VARIABLE_SIZE | WEED_PARAMETER_VALUE_PER_CHANNEL); s_dbl(p[i], WEED_LEAF_NEW_DEFAULT, nd[i]); }
+    s_str(p[6], WEED_LEAF_DESCRIPTION, "If checked, the rear frames overlay the front ones.");
+    add_filter(pinfo, "compositor", WEED_FILTER_CHANNEL_SIZES_MAY_VARY, pk, 4, p_compositor, 1, "in channel 0", NULL, "out channel 0", p, 7);
+    w_get(pinfo, WEED_LEAF_FILTERS, w_nelems(pinfo, WEED_LEAF_FILTERS) - 1, &fc);
+    if (fc) {
+      w_get(fc, WEED_LEAF_IN_CHANNEL_TEMPLATES, 0, &ict);
+      if (ict) s_int(ict, WEED_LEAF_MAX_REPEATS, 0);
+      gui = w_new(WEED_PLANT_GUI);
+      w_set(fc, WEED_LEAF_GUI, WEED_SEED_PLANTPTR, 1, &gui);
+      s_str(gui, WEED_LEAF_LAYOUT_SCHEME, "RFX");
+      s_str(gui, "layout_rfx_delim", "|");
+      w_set(gui, "layout_rfx_strings", WEED_SEED_STRING, 7, rfx);
+    }
   }
   s_int(pinfo, WEED_LEAF_VERSION, 1);
   return pinfo;

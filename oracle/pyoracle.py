@@ -191,6 +191,7 @@ class RefHost:
         self.H.refhost_num_filters.argtypes = [vp]
         self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
         self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
+        self.H.refhost_run_compositor.argtypes = [vp, ctypes.c_char_p, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci]
         self.H.refhost_set_yuv_clamping.argtypes = [ci]
         self.H.refhost_set_random_seed.argtypes = [ctypes.c_int64]
         self.plugins = {}
@@ -240,6 +241,19 @@ class RefHost:
         if r != 0:
             raise RuntimeError("weed filter '%s' returned %d" % (fname, r))
         return dst_planes
+
+    def run_compositor(self, path, pal, srcs, sizes, disabled, dst, ow, oh, offsx, offsy, scalex, scaley, alpha, bgcol, revz):
+        """the "compositor" class: in channels of their own sizes (srcs[i]: rows x rowstride, sizes[i] = (w, h)), per-channel parameter arrays"""
+        hdl = self.load(path)
+        n = len(srcs)
+        sp = (vp * n)(*[a.ctypes.data for a in srcs])
+        ia = lambda v: (ci * len(v))(*[int(x) for x in v])
+        da = lambda v: (cd * len(v))(*[float(x) for x in v])
+        r = self.H.refhost_run_compositor(hdl, b"compositor", pal, n, sp, ia([s[0] for s in sizes]), ia([s[1] for s in sizes]), ia([a.strides[0] for a in srcs]),
+                                          ia(disabled), dst.ctypes.data, ow, oh, dst.strides[0], da(offsx), da(offsy), da(scalex), da(scaley), da(alpha), ia(bgcol), int(revz))
+        if r != 0:
+            raise RuntimeError("weed filter 'compositor' returned %d" % r)
+        return dst
 
     def run(self, path, fname, pal, w, h, srcs, dst, params=(), nslices=1):
         """srcs: list of 2-D uint8 arrays (rows x rowstride); dst: 2-D uint8 array (may be srcs[0])."""

@@ -272,6 +272,60 @@ int refhost_run_planar(void *pinfo_v, const char *fname, int pal, int w, int h, 
   return ret;
 }
 
+/* The compositor class: nin in channels of their own sizes, all instances of in channel template 0 (max_repeats 0), some possibly disabled by the host;
+ * parameters 0-4 are double arrays with one value per channel, 5 = int[3] colour, 6 = switch.  One process call on the whole frame. */
+int refhost_run_compositor(void *pinfo_v, const char *fname, int pal, int nin, uint8_t **src, const int *ws, const int *hs, const int *istrides, const int *disabled,
+                           uint8_t *dst, int ow, int oh, int ostride, const double *offsx, const double *offsy, const double *scalex, const double *scaley,
+                           const double *alpha, const int *bgcol, int revz) {
+  weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
+  weed_plant_t *filt = find_filter(pinfo, fname);
+  weed_plant_t *inst, *inch[64], *outch, **ictm, **octm, **iptm, *inpar[7];
+  weed_init_f init_func;
+  weed_process_f process_func;
+  weed_deinit_f deinit_func;
+  const double *arrs[5] = {offsx, offsy, scalex, scaley, alpha};
+  int nict = 0, noct = 0, nipt = 0, i, ret = WEED_SUCCESS;
+  if (!filt) return -100;
+  if (nin > 64) return -101;
+  ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
+  octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
+  iptm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_PARAMETER_TEMPLATES, &nipt);
+  if (nict < 1 || noct < 1 || nipt < 7) return -102;
+  inst = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
+  weed_set_plantptr_value(inst, WEED_LEAF_FILTER_CLASS, filt);
+  for (i = 0; i < nin; i++) {
+    inch[i] = mk_channel(ictm[0], pal, ws[i], hs[i], istrides[i], src[i]);
+    if (disabled[i]) weed_set_boolean_value(inch[i], WEED_LEAF_DISABLED, WEED_TRUE);
+  }
+  outch = mk_channel(octm[0], pal, ow, oh, ostride, dst);
+  weed_set_plantptr_array(inst, WEED_LEAF_IN_CHANNELS, nin, inch);
+  weed_set_plantptr_value(inst, WEED_LEAF_OUT_CHANNELS, outch);
+  for (i = 0; i < 7; i++) {
+    inpar[i] = weed_plant_new(WEED_PLANT_PARAMETER);
+    weed_set_plantptr_value(inpar[i], WEED_LEAF_TEMPLATE, iptm[i]);
+    if (i < 5) weed_set_double_array(inpar[i], WEED_LEAF_VALUE, nin, (double *)arrs[i]);
+    else if (i == 5) weed_set_int_array(inpar[i], WEED_LEAF_VALUE, 3, (int32_t *)bgcol);
+    else weed_set_boolean_value(inpar[i], WEED_LEAF_VALUE, revz ? WEED_TRUE : WEED_FALSE);
+  }
+  weed_set_plantptr_array(inst, WEED_LEAF_IN_PARAMETERS, 7, inpar);
+  init_func = (weed_init_f)weed_get_funcptr_value(filt, WEED_LEAF_INIT_FUNC, NULL);
+  process_func = (weed_process_f)weed_get_funcptr_value(filt, WEED_LEAF_PROCESS_FUNC, NULL);
+  deinit_func = (weed_deinit_f)weed_get_funcptr_value(filt, WEED_LEAF_DEINIT_FUNC, NULL);
+  if (init_func) ret = (*init_func)(inst);
+  if (ret == WEED_SUCCESS) {
+    ret = (*process_func)(inst, (weed_timecode_t)0);
+    if (deinit_func) (*deinit_func)(inst);
+  }
+  for (i = 0; i < 7; i++) weed_plant_free(inpar[i]);
+  for (i = 0; i < nin; i++) weed_plant_free(inch[i]);
+  weed_plant_free(outch);
+  weed_plant_free(inst);
+  if (ictm) free(ictm);
+  if (octm) free(octm);
+  if (iptm) free(iptm);
+  return ret;
+}
+
 /* A stateful filter over a SEQUENCE of frames on ONE instance (init once, process_func per frame, deinit once):
  * blurzoom.c keeps its background / feedback buffers in "plugin_internal".  src[i] / dst[i]: frame i. */
 int refhost_run_seq(void *pinfo_v, const char *fname, int pal, int w, int h, int nframes,
