@@ -49,7 +49,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411"]))
+        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411", "pixbuf", "pixbuf", "chainpb", "chainpb", "canvas", "c4"]))
         counts[kind] = counts.get(kind, 0) + 1
         try:
             if kind == "resize":
@@ -116,6 +116,127 @@ def main():
                     os.environ.pop("LGPU_SEP2P_FORCE", None)
                 ok = all(same(host(dd[i]), wants[i], dw * 4, dh, "chain %dx%d->%dx%d swap=%d blur=%d bf=%d lut=%d strides=%d/%d track %d param_block=%d" %
                               (sw, sh, dw, dh, swap, blur, bf, use_lut, srcs[0].strides[0], l2s[0].strides[0], i, via_block)) for i in range(ntr))
+            elif kind == "pixbuf":
+                # gdk-pixbuf arithmetic (pinned): every interp, 3 / 4 channels, ratios from 1:12 to 12:1, exact 2:1 (k_pb_half) in a third of the cases
+                ch, interp = int(rng.choice([3, 4])), int(rng.choice([0, 2, 3]))
+                sw, sh = int(rng.integers(1, 500)), int(rng.integers(1, 260))
+                if rng.random() < 0.33:
+                    dw, dh = max(1, sw // 2), max(1, sh // 2)
+                    sw, sh = 2 * dw, 2 * dh
+                else:
+                    dw, dh = int(rng.integers(1, 600)), int(rng.integers(1, 300))
+                al = 16 if rng.random() < 0.5 else 4
+                irow = (sw * ch + al - 1) // al * al
+                src = rng.integers(0, 256, (sh, irow), dtype=np.uint8)
+                if ch == 4:
+                    am = rng.random()
+                    a = src[:, 3:sw * 4:4]
+                    if am < 0.3:
+                        a[:] = 255
+                    elif am < 0.7:
+                        a[rng.random(a.shape) < 0.4] = 0
+                        a[rng.random(a.shape) < 0.3] = 255
+                orow = (dw * ch + al - 1) // al * al
+                want = np.zeros((dh, orow), np.uint8)
+                rc = orc.orc_pixbuf_scale(P(src), irow, sw, sh, P(want), orow, dw, dh, ch, interp)
+                if rc == -2:
+                    continue
+                d = dev(np.zeros((dh, orow), np.uint8))
+                if rng.random() < 0.15:
+                    os.environ["LGPU_PB_NO_PAIRS"] = "1"
+                try:
+                    ops.pixbuf_scale(dev(src), d, sw, sh, dw, dh, channels=ch, interp=interp)
+                finally:
+                    os.environ.pop("LGPU_PB_NO_PAIRS", None)
+                ok = same(host(d), want, dw * ch, dh, "pixbuf %dx%d->%dx%d ch=%d interp=%d strides %d/%d" % (sw, sh, dw, dh, ch, interp, irow, orow))
+            elif kind in ("chainpb", "canvas"):
+                # the chain on the pinned arithmetic: fused (exact aligned 2:1: k_pb_half, with and without the blur stage, with a letterbox canvas) and staged
+                dw, dh = int(rng.integers(2, 260)) & ~1, int(rng.integers(2, 140))
+                dw = max(dw, 2)
+                if rng.random() < 0.7:
+                    sw, sh = 2 * dw, 2 * dh
+                else:
+                    sw, sh = int(rng.integers(4, 500)), int(rng.integers(4, 260))
+                interp = int(rng.choice([2, 3])) | 0x100
+                swap, bf, ntr = int(rng.integers(0, 2)), int(rng.integers(0, 256)), int(rng.integers(1, 4))
+                use_lut = rng.random() < 0.7
+                blur = int(rng.integers(0, 2)) if kind == "chainpb" else 0
+                if kind == "canvas":
+                    nw, nh = dw + int(rng.integers(0, 40)), dh + int(rng.integers(0, 30))
+                    ox, oy = int(rng.integers(0, nw - dw + 1)), int(rng.integers(0, nh - dh + 1))
+                    if rng.random() < 0.7:
+                        ox &= ~1
+                else:
+                    nw, nh, ox, oy = dw, dh, 0, 0
+                al = 16 if rng.random() < 0.7 else 4
+                irow, crow = (sw * 4 + al - 1) // al * al, (nw * 4 + al - 1) // al * al
+                srcs = [rng.integers(0, 256, (sh, irow), dtype=np.uint8) for _ in range(ntr)]
+                for s_ in srcs:
+                    a = s_[:, 3:sw * 4:4]
+                    a[rng.random(a.shape) < 0.4] = 255
+                    a[rng.random(a.shape) < 0.1] = 0
+                l2s = [rng.integers(0, 256, (nh, crow), dtype=np.uint8) for _ in range(ntr)]
+                for l_ in l2s:
+                    l_[:, 3:nw * 4:4][rng.random((nh, nw)) < 0.5] = 255
+                lut = lutl if use_lut else None
+                wants = []
+                for i in range(ntr):
+                    if kind == "chainpb":
+                        w_ = np.zeros((dh, crow), np.uint8)
+                        if orc.orc_chain(P(srcs[i]), irow, sw, sh, P(l2s[i]), crow, P(w_), crow, dw, dh, swap, interp, blur, bf, P(lut) if use_lut else None) != 0:
+                            wants = None            # a reduction past gdk-pixbuf's one-step range
+                            break
+                    else:
+                        conv = np.zeros((sh, sw * 4), np.uint8)
+                        if swap:
+                            orc.orc_swizzle(4, 0, P(srcs[i]), irow, P(conv), sw * 4, sw, sh, None)
+                        else:
+                            conv[:] = srcs[i][:, :sw * 4]
+                        rs = np.zeros((dh, dw * 4), np.uint8)
+                        if orc.orc_pixbuf_scale(P(conv), sw * 4, sw, sh, P(rs), dw * 4, dw, dh, 4, interp & 0xFF) != 0:
+                            wants = None
+                            break
+                        cv = np.zeros((nh, nw, 4), np.uint8)
+                        cv[..., 3] = 255
+                        cv[oy:oy + dh, ox:ox + dw] = rs.reshape(dh, dw, 4)
+                        w_ = np.zeros((nh, crow), np.uint8)
+                        w_[:, :nw * 4] = cv.reshape(nh, nw * 4)
+                        orc.orc_blend_chroma(P(w_), crow, P(l2s[i]), crow, P(w_), crow, nw, nh, 4, 0, bf)
+                        if use_lut:
+                            orc.orc_gamma_apply(P(w_), crow, nw, nh, 4, 0, P(lut))
+                    wants.append(w_)
+                if wants is None:
+                    continue
+                dd = [dev(np.zeros((nh, crow), np.uint8)) for _ in range(ntr)]
+                via_block = rng.random() < 0.4
+                pb = torch.tensor([bf, 0, 0, 0], dtype=torch.int32, device="cuda") if via_block else None
+                prm = ops.chain_params(sw, sh, irow, dw, dh, crow, crow, swap_rb=swap, interp=interp, do_blur=blur, bf=(bf * 7 + 13) % 256 if via_block else bf, lut=lut, param_block=pb)
+                trk = ops.chain_tracks([dev(s_) for s_ in srcs], [dev(s_) for s_ in l2s], dd)
+                if kind == "canvas":
+                    ops.chain_canvas(prm, trk, nw, nh, ox, oy)
+                else:
+                    ops.chain(prm, trk)
+                ok = all(same(host(dd[i]), wants[i], nw * 4, nh, "%s %dx%d->%dx%d in %dx%d at (%d,%d) interp=%x swap=%d blur=%d bf=%d lut=%d strides %d/%d track %d block=%d" %
+                              (kind, sw, sh, dw, dh, nw, nh, ox, oy, interp, swap, blur, bf, use_lut, irow, crow, i, via_block)) for i in range(ntr))
+            elif kind == "c4":
+                ps = int(rng.choice([3, 4]))
+                w, h = 4 * int(rng.integers(1, 130)), int(rng.integers(1, 120))
+                rs_ = (w * ps + 15) // 16 * 16
+                a = rng.integers(0, 256, (h, rs_), dtype=np.uint8)
+                b = rng.integers(0, 256, (h, rs_), dtype=np.uint8)
+                a[:, :(w // 2) * ps] = rng.integers(90, 170, (h, (w // 2) * ps), dtype=np.uint8)
+                is_bgr, delta, opac = int(rng.integers(0, 2)), float(rng.random()), float(rng.random())
+                col = [int(v) for v in rng.integers(100, 160, 3)]
+                bl = np.zeros_like(a)
+                orc.orc_gauss5(P(a), rs_, P(bl), rs_, w, h, ps)
+                want = np.zeros_like(a)
+                if ps == 3:
+                    orc.orc_colorkey(P(bl), rs_, P(b), rs_, P(want), rs_, w, h, is_bgr, delta, opac, col[0], col[1], col[2], 0)
+                else:
+                    orc.orc_colorkey4(P(bl), rs_, P(b), rs_, P(want), rs_, w, h, is_bgr, delta, opac, col[0], col[1], col[2])
+                d = dev(np.zeros_like(a))
+                ops.gauss5_colorkey(dev(a), dev(b), d, w, h, ps, is_bgr, delta, opac, col)
+                ok = same(host(d), want, w * ps, h, "c4 %dx%d ps=%d bgr=%d delta=%r opac=%r col=%s" % (w, h, ps, is_bgr, delta, opac, col))
             elif kind == "gauss5":
                 ps = int(rng.choice([1, 3, 4]))
                 w, h = int(rng.integers(1, 300)), int(rng.integers(1, 150))
