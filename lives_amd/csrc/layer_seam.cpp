@@ -276,6 +276,19 @@ void res_drop(const void *h) {
   }
   pool_give(b);
 }
+// every resident plane whose host pointer lies inside [base, base + bytes): a contiguous planar block is freed through its base pointer, but its planes 1..3
+// are registered under interior pointers and must not survive it (a later block at the same address would otherwise inherit their device copies)
+void res_drop_range(const void *base, size_t bytes) {
+  std::vector<Dev> gone;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    for (auto it = g_res.begin(); it != g_res.end();) {
+      const uintptr_t h = (uintptr_t)it->first;
+      if (h >= (uintptr_t)base && h < (uintptr_t)base + bytes) { gone.push_back(it->second); it = g_res.erase(it); } else ++it;
+    }
+  }
+  for (auto &b : gone) pool_give(b);
+}
 int lives_gpu_layer_unpin_impl(weed_plant_t *layer);
 struct PinScope {
   bool prev;
@@ -653,20 +666,22 @@ lives_gpu_boolean rgb_layer_to_yuv(weed_plant_t *layer, const Layer &l_in, int o
   return 1;
 }
 
-// a pinned layer's LUT16 (create_gamma_lut, 65536 x uint16) per (from, to, screen gamma): built once per device, not per frame
-struct Lut16Key { int from, to; double screen; bool operator==(const Lut16Key &o) const { return from == o.from && to == o.to && screen == o.screen; } };
+// a pinned layer's LUT16 (create_gamma_lut, 65536 x uint16) per (device, from, to, screen gamma): built once, not per frame.  Entries are never evicted -- a
+// pointer handed to one host thread may not yet be in a launch when another thread asks for a seventeenth table -- and there are few of them: the gamma pairs
+// LiVES uses times the screen gammas a session sets, 128 KB each (a cap of 256 entries = 32 MB is a failure, not an eviction).
+struct Lut16Key { int dev, from, to; double screen; bool operator==(const Lut16Key &o) const { return dev == o.dev && from == o.from && to == o.to && screen == o.screen; } };
 std::mutex g_l16_mu;
 std::vector<std::pair<Lut16Key, void *>> g_l16;
 const uint16_t *device_lut16(int from, int to) {
-  const Lut16Key k = {from, to, g_prefs.screen_gamma};
+  const Lut16Key k = {g_prefs.device, from, to, g_prefs.screen_gamma};
   std::lock_guard<std::mutex> lk(g_l16_mu);
   for (auto &e : g_l16) if (e.first == k) return (const uint16_t *)e.second;
+  if (g_l16.size() >= 256) return nullptr;
   std::vector<uint16_t> h(65536);
   if (!lgpu_gamma_lut16(1.0, from, to, g_prefs.screen_gamma, h.data())) return nullptr;
   void *d = nullptr;
   if (lgpu_malloc(&d, 65536 * 2) != LGPU_OK) return nullptr;
-  if (lgpu_upload(d, h.data(), 65536 * 2, nullptr) != LGPU_OK || lgpu_sync(nullptr) != LGPU_OK) { lgpu_free(d); return nullptr; }
-  if (g_l16.size() >= 16) { lgpu_free(g_l16.front().second); g_l16.erase(g_l16.begin()); }
+  if (lgpu_upload(d, h.data(), 65536 * 2, S()) != LGPU_OK || lgpu_sync(S()) != LGPU_OK) { lgpu_free(d); return nullptr; }     // the calling thread's stream; complete before the pointer is shared
   g_l16.push_back({k, d});
   return (const uint16_t *)d;
 }
@@ -1421,8 +1436,23 @@ int lives_gpu_layer_forget(lives_gpu_layer_t *layer) {
 // optional frame allocator pair for lives_gpu_weed_api.pixel_alloc / pixel_free: page-locked, zeroed host memory, so the planes the seam creates
 // (and any frame the host allocates through it) cross PCIe by DMA at link rate instead of through the staging chunks.  Freeing a plane through it
 // also drops a device copy registered under that address.
-void *lives_gpu_pinned_calloc(size_t bytes) { return lgpu_pinned_calloc(bytes); }
-void lives_gpu_pinned_free(void *p) { res_drop(p); lgpu_pinned_free(p); }
+static std::mutex g_pinned_mu;
+static std::unordered_map<const void *, size_t> g_pinned_blocks;      // blocks handed out by lives_gpu_pinned_calloc: base -> bytes (for the range drop on free)
+void *lives_gpu_pinned_calloc(size_t bytes) {
+  void *p = lgpu_pinned_calloc(bytes);
+  if (p) { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned_blocks[p] = bytes ? bytes : 1; }
+  return p;
+}
+void lives_gpu_pinned_free(void *p) {
+  size_t bytes = 1;
+  if (p) {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto it = g_pinned_blocks.find(p);
+    if (it != g_pinned_blocks.end()) { bytes = it->second; g_pinned_blocks.erase(it); }
+  }
+  if (p) res_drop_range(p, bytes);
+  lgpu_pinned_free(p);
+}
 
 // residency bridge for the weed plugin (same library, other seam): the device copy of a pinned layer's plane, looked up by the host plane
 // pointer the channel carries; NULL when the plane is not resident (or smaller than asked).  Entries exist only between lives_gpu_layer_pin

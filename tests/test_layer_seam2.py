@@ -590,3 +590,39 @@ def test_short_lived_threads_do_not_pile_up_device_objects(seam):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (64 << 20), "device memory shrank by %d MB over 300 short-lived threads" % ((free0 - free1) >> 20)
+
+
+def test_freeing_a_contiguous_block_drops_every_plane_inside_it(seam):
+    """lives_gpu_pinned_free(base) of a contiguous planar block (planes 1 and 2 are interior pointers of it): no resident entry inside the block may
+    survive, or a later block at the same address would inherit a stale device copy"""
+    L, wh = seam
+    W = wh.weed()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.lives_gpu_pinned_calloc.restype = vp
+    L.lives_gpu_pinned_calloc.argtypes = [ctypes.c_size_t]
+    L.lives_gpu_pinned_free.argtypes = [vp]
+    L.lives_gpu_resident_acquire.restype = vp
+    L.lives_gpu_resident_acquire.argtypes = [vp, ctypes.c_size_t, ci]
+    L.lives_gpu_resident_release.argtypes = [vp, ci]
+    api = wh.WeedApi(W.fn["weed_leaf_get"], W.fn["weed_leaf_set"], W.fn["weed_leaf_num_elements"], W.fn["weed_leaf_delete"],
+                     ctypes.cast(L.lives_gpu_pinned_calloc, vp), ctypes.cast(L.lives_gpu_pinned_free, vp))
+    assert L.lives_gpu_bind_weed(ctypes.byref(api)) == 0
+    try:
+        rng = np.random.default_rng(48)
+        lay = wh.new_layer(RGBA32, 64, 32, [frame(rng, 64, 32, 4)], gamma=1)
+        assert L.lives_gpu_layer_pin(lay) == 0
+        assert L.lives_gpu_convert_layer_palette(lay, YUV420P, 0) == 1              # new planes: one page-locked block, three resident planes
+        _, ptrs, rs = wh.planes_of(lay)
+        assert ptrs[1] == ptrs[0] + rs[0] * 32 and ptrs[2] == ptrs[1] + rs[1] * 16, "one contiguous block (may_contig allocation, colourspace.c:11601-11664)"
+        for pl in range(3):
+            d = L.lives_gpu_resident_acquire(ptrs[pl], 16, 0)
+            assert d, "plane %d is resident" % pl
+            L.lives_gpu_resident_release(ptrs[pl], 0)
+        L.lives_gpu_pinned_free(ptrs[0])                                            # the host frees the block itself
+        for pl in range(3):
+            assert not L.lives_gpu_resident_acquire(ptrs[pl], 16, 0), "plane %d outlived its block" % pl
+        leaf_delete = ctypes.CFUNCTYPE(ci, vp, ctypes.c_char_p)(W.fn["weed_leaf_delete"])
+        leaf_delete(lay, b"pixel_data")
+        leaf_delete(lay, b"host_gpu_resident")
+    finally:
+        wh.bind(L)
