@@ -151,6 +151,7 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
   {
     /* the ARGB chroma blend reads one byte past the last pixel of each row of layer 2 (reference quirk B1) */
     const size_t ob = (size_t)f.orow * f.height;
+    int uploaded = 0;
     const void *rel[3] = {NULL, NULL, NULL};         /* resident planes to release once the effect is enqueued: [0] the out channel (write), [1..] in channels (read) */
     uint8_t *res_dst = (uint8_t *)lives_gpu_resident_acquire(f.dst - (size_t)offset * f.orow, (size_t)f.orow * real_h, 1);
     if (res_dst) rel[0] = f.dst - (size_t)offset * f.orow;
@@ -166,6 +167,7 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
       f.dsrc[i] = (uint8_t *)fx_buf(fx, i, ib + 16);
       if (!f.dsrc[i]) return WEED_ERROR_MEMORY_ALLOCATION;
       if (lgpu_upload(f.dsrc[i], f.src[i], ib, FXS)) return WEED_ERROR_PLUGIN_INVALID;
+      uploaded = 1;
     }
     if (!f.inplace && !res_dst && lgpu_upload(f.ddst, f.dst, ob, FXS)) return WEED_ERROR_PLUGIN_INVALID;   /* bytes the effect leaves alone */
     {
@@ -176,6 +178,9 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
     /* an out channel on a pinned layer: the effect is enqueued and the call returns (stream order carries it to whatever reads the plane next; the host
        bytes are stale by the pinning contract).  Otherwise the result is brought home and has to be complete on return. */
     if (!res_dst && (lgpu_download(f.dst, f.ddst, ob, FXS) || lgpu_sync(FXS))) return WEED_ERROR_PLUGIN_INVALID;
+    /* resident out channel, but an input came from host memory: from a page-locked frame that is an asynchronous DMA out of the host's plane, which the host may
+       reuse as soon as this call returns -- wait for the uploads (the effect itself stays enqueued) */
+    if (res_dst && uploaded && lgpu_sync(FXS)) return WEED_ERROR_PLUGIN_INVALID;
   }
   return WEED_SUCCESS;
 }
