@@ -179,7 +179,7 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
        bytes are stale by the pinning contract).  Otherwise the result is brought home and has to be complete on return. */
     if (!res_dst && (lgpu_download(f.dst, f.ddst, ob, FXS) || lgpu_sync(FXS))) return WEED_ERROR_PLUGIN_INVALID;
     /* resident out channel, but an input came from host memory: from a page-locked frame that is an asynchronous DMA out of the host's plane, which the host may
-       reuse as soon as this call returns -- wait for the uploads (the effect itself stays enqueued) */
+       reuse as soon as this call returns -- wait for the stream (uploads and, on this mixed path, the effect behind them) */
     if (res_dst && uploaded && lgpu_sync(FXS)) return WEED_ERROR_PLUGIN_INVALID;
   }
   return WEED_SUCCESS;
