@@ -371,23 +371,32 @@ void commit_planes(weed_plant_t *plant, int pal, int width, int height, const Ne
 // ---- device scratch (per calling thread; grown on demand) ------------------------------------------------------------
 // A thread that ends leaves its buffers on a spare list (no HIP call in a thread_local destructor: the main thread's runs after HIP's teardown) and the next
 // new thread starts from them.
-struct ScratchSet { void *p[8]; size_t cap[8]; };
+struct ScratchSet { void *p[8]; size_t cap[8]; void *stream; };      // stream: where the thread that owned the set enqueued its last use
 struct SpareScratch { std::mutex mu; std::vector<ScratchSet> sets; };
 SpareScratch &spare_scratch() { static SpareScratch *sp = new SpareScratch; return *sp; }
 struct Scratch {
   void *p[8] = {nullptr};
   size_t cap[8] = {0};
   bool adopted = false;
+  void *last_stream = nullptr;
   uint8_t *get(int i, size_t bytes) {
     if (!adopted) {
       adopted = true;
-      SpareScratch &sp = spare_scratch();
-      std::lock_guard<std::mutex> lk(sp.mu);
-      if (!sp.sets.empty()) {
-        for (int k = 0; k < 8; k++) { p[k] = sp.sets.back().p[k]; cap[k] = sp.sets.back().cap[k]; }
-        sp.sets.pop_back();
+      void *prev = kIdle;
+      {
+        SpareScratch &sp = spare_scratch();
+        std::lock_guard<std::mutex> lk(sp.mu);
+        if (!sp.sets.empty()) {
+          for (int k = 0; k < 8; k++) { p[k] = sp.sets.back().p[k]; cap[k] = sp.sets.back().cap[k]; }
+          prev = sp.sets.back().stream;
+          sp.sets.pop_back();
+        }
       }
+      // the set's previous owner never synchronised on a pinned layer: its last kernels may still read these buffers on ITS stream, which some third thread may
+      // have adopted meanwhile -- this thread's stream orders itself behind that stream once, at adoption
+      follow(prev);
     }
+    last_stream = S();
     if (cap[i] < bytes) {
       if (p[i]) lgpu_free(p[i]);
       p[i] = nullptr; cap[i] = 0;
@@ -404,6 +413,7 @@ struct Scratch {
     std::lock_guard<std::mutex> lk(sp.mu);
     ScratchSet st;
     for (int k = 0; k < 8; k++) { st.p[k] = p[k]; st.cap[k] = cap[k]; }
+    st.stream = last_stream;
     sp.sets.push_back(st);
   }
 };

@@ -15,6 +15,7 @@
 // Pixels whose reference value is undefined (row 0 odd x: out-of-bounds table index; last row odd x: never
 // written) get the evident intent.
 #include "lgpu_common.h"
+#include <atomic>
 
 namespace lgpu {
 
@@ -473,7 +474,7 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   const bool force16 = getenv("LGPU_YUV_FORCE16") != nullptr;            // tests: the 16-copy kernel at any size
   if (wide && !no16 && !lut16_d && !a.low_quality && units >= 2 && units < 8192 && nbatch <= 64 && (force16 || (unsigned long long)g4x.x * g4x.y * g4x.z * kBlock >= 256ull * 1024ull)) {
     // the clamp + LUT table covers (sum >> 16) in [-kY16Bias, kY16Lut - kY16Bias): true for the reference's four table sets, checked here
-    static int range_ok[4] = {0, 0, 0, 0};          // 0 unknown, 1 ok, -1 no
+    static std::atomic<int> range_ok[4];            // 0 unknown, 1 ok, -1 no (host threads race to the same answer: a pure function of the table set)
     const int w4 = which_tables & 3;
     if (!range_ok[w4]) {
       int32_t rgb2yuv[9 * 256], t5[5 * 256];
@@ -498,8 +499,11 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
       range_ok[w4] = (lo >= -kY16Bias && hi < kY16Lut - kY16Bias) ? 1 : -1;
     }
     if (range_ok[w4] == 1) {
-      static int g_cus = 0;
-      if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
+      static std::atomic<int> g_cus_dev[16];          // CU count per device ordinal
+      int dev = 0;
+      LGPU_HIP(hipGetDevice(&dev));
+      int g_cus = g_cus_dev[dev & 15].load();
+      if (!g_cus) { hipDeviceProp_t prop; LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; g_cus_dev[dev & 15].store(g_cus); }
       YuvBatch one = {};
       if (!batch) { one.y[0] = y_d; one.u[0] = u_d; one.v[0] = v_d; one.dst[0] = dst_d; }
       const YuvBatch &b16 = batch ? *batch : one;
