@@ -253,11 +253,13 @@ __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32
 // then yields 120 columns (lanes 2 .. 61) and a band computes 4 more scaled rows than it stores.
 template <int CHAIN, int HYPER, int BLUR>
 __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
-  __shared__ uint8_t s_lut[256];
-  __shared__ pb_u2 s_k[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut_all[4][256];       // the gamma LUT and the blend's alpha scalers, one private copy per wave: a wave stages its
+  __shared__ pb_u2 s_k_all[4][256];                                        //   own and never waits for the other three (no workgroup barrier on the frame path)
   constexpr int kHalo = BLUR ? 2 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
   if (CHAIN && blockIdx.x >= (unsigned)A.main_blocks) {
     // letterbox bars (letterbox_layer's black canvas, src/colourspace.c:15417-15503, under the rest of the chain): opaque black -> chroma blend with layer 2 -> LUT
+    uint8_t *s_lut = s_lut_all[0];
+    pb_u2 *s_k = s_k_all[0];
     stage_lut(s_lut, lut);
     if (A.blend) {
       const uint2 kk = A.kscale[threadIdx.x];
@@ -293,6 +295,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
+  uint8_t *s_lut = s_lut_all[wave];
+  pb_u2 *s_k = s_k_all[wave];
   // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its
   // own L2; two bands that follow each other vertically share two source rows.  So every XCD gets a CONTIGUOUS run of the sequence (track, column group, band) and
   // walks it band by band: the shared rows are fetched once and hit that XCD's L2 the second time (PMC: 999 MB -> see profiles/r03 per 16-track launch).
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     strip = (cg - track * A.cgroups) * 4 + wave;
     spare = strip >= A.strips;
   }
-  if (spare) { strip = 0; band = 0; track = 0; }           // a wave without work walks item 0 again and stores nothing (it still takes part in the barrier)
+  if (spare) return;                                        // no workgroup barrier on this path: a wave without work simply ends
   const int k = strip * kCols - kHalo + lane;             // this lane's source quad: pixels 4k .. 4k + 3 -> output columns 2k, 2k + 1
   const int kmax = (A.sw >> 2) - 1;
   const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
@@ -381,14 +385,18 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
   if (CHAIN && A.blend) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
-  if (CHAIN) {        // the two small tables are staged while the first source rows are in flight
-    stage_lut(s_lut, lut);
+  if (CHAIN) {        // this wave's copy of the two small tables, requested while the first source rows are in flight; first read an output row later
+    reinterpret_cast<uint32_t *>(s_lut)[lane] = lut.w[lane];
     if (A.blend) {
-      const uint2 kk = A.kscale[threadIdx.x];
-      pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
-      s_k[threadIdx.x] = kv;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint2 kk = A.kscale[lane + 64 * i];
+        pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
+        s_k[lane + 64 * i] = kv;
+      }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   pb_half_hrow<HYPER>(fix(q0), hr);
   pb_half_hrow<HYPER>(fix(q1), hs);
