@@ -1921,10 +1921,12 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
     };
     // tile height: 16 rows, 32 when enlarging (small windows: taller tiles amortise a workgroup's three phases; measured 29.8 against 33.9 us for
     // 1080p -> 4K, profiles/r02/resize_ratios.md)
+    size_t sep2_lds_cap = 80 * 1024;
+    if (const char *e = getenv("LGPU_SEP2_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) sep2_lds_cap = (size_t)v * 1024; }      // tuning probe
     for (int th2 = dh > sh ? 32 : 16;; th2 >>= 1) {
       const int sht2 = window_rows(th2);
       const size_t lds2 = (size_t)sht2 * b.swt * 4 + (size_t)(sht2 >> 1) * kTileW * 16 + 256 + (size_t)th2 * (vb->npv + 1) * 4;
-      if (lds2 <= 80 * 1024 || th2 == 1) {
+      if (lds2 <= sep2_lds_cap || th2 == 1) {
         if (lds2 <= 160 * 1024) {
           b.th = th2; b.sht = sht2;
           b.tiles_y = (dh + th2 - 1) / th2;
