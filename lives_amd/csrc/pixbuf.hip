@@ -533,28 +533,49 @@ struct PbPairArgs {
   const uint32_t *pairs;               // device: [16][16][2][ny_eff][4 nq]
   unsigned rnd;
   int tile_h, wpairs, win_h;
+  int no_quad;                         // tuning probe: stage pixel pairs one by one
 };
 
-// NPC: pairs per tap row when there are at most four (compile time: no work on the padding of the weight row), 0: any count, four at a time
-template <int CH, int NPC>
+// NPC: pairs per tap row when there are at most four (compile time: no work on the padding of the weight row), 0: any count, four at a time.
+// NY: tap rows when known at compile time (then a destination pixel's weight vectors are requested together, before the first tap, instead of one exposed load
+// per tap row), 0: any count.  Measured (profiles/r03/pb_pairs_ab.txt): a gain for 2-3 tap rows (enlarging: 29.3 -> 27.3 us), a loss for 5-6 (4K -> 1706x960: 24.6 -> 37.2 us;
+// the 24 weight registers cost more than the exposed loads), so only the short filters are instantiated that way.
+template <int CH, int NPC, int NY>
 __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
   extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
   const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
-  const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~1;          // the window starts on an even source pixel
+  const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~3;          // the window starts on a source pixel that is a multiple of 4: aligned pairs, 16-byte loads
   const int ys0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;
-  for (int wy = wave; wy < A.win_h; wy += 4) {
-    const uint8_t *row = A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow;
-    pb_u4 *wr = winp + wy * A.wpairs;
-    for (int p = lane; p < A.wpairs; p += 64) {
-      const uint32_t q0 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p, A.sw - 1)), q1 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p + 1, A.sw - 1));
-      pb_u4 v;
-      if (CH == 4) {
-        v.x = pb_premul_pair<0>(q0, q1); v.y = pb_premul_pair<1>(q0, q1); v.z = pb_premul_pair<2>(q0, q1); v.w = __builtin_amdgcn_perm(q1, q0, 0x0C070C03u);
-      } else {
-        v.x = __builtin_amdgcn_perm(q1, q0, 0x0C040C00u); v.y = __builtin_amdgcn_perm(q1, q0, 0x0C050C01u); v.z = __builtin_amdgcn_perm(q1, q0, 0x0C060C02u); v.w = 0u;
+  // ---- the window: premultiplied pairs.  4-byte pixels whose window lies inside the row (uniform per workgroup) come four at a time, one 16-byte load -> two pairs
+  const bool inside = CH == 4 && !A.no_quad && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && (wx0 & 3) == 0 && ((uintptr_t)A.src & 15) == 0 && (A.irow & 15) == 0 && (A.wpairs & 1) == 0;
+  if (inside) {
+    const int wq = A.wpairs >> 1;                       // quads per window row
+    for (int wy = wave; wy < A.win_h; wy += 4) {
+      const pb_u4 *row = reinterpret_cast<const pb_u4 *>(A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow + 4 * (size_t)wx0);
+      pb_u4 *wr = winp + wy * A.wpairs;
+      for (int qd = lane; qd < wq; qd += 64) {
+        const pb_u4 q = row[qd];
+        pb_u4 v0, v1;
+        v0.x = pb_premul_pair<0>(q.x, q.y); v0.y = pb_premul_pair<1>(q.x, q.y); v0.z = pb_premul_pair<2>(q.x, q.y); v0.w = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u);
+        v1.x = pb_premul_pair<0>(q.z, q.w); v1.y = pb_premul_pair<1>(q.z, q.w); v1.z = pb_premul_pair<2>(q.z, q.w); v1.w = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);
+        wr[2 * qd] = v0; wr[2 * qd + 1] = v1;
       }
-      wr[p] = v;
+    }
+  } else {
+    for (int wy = wave; wy < A.win_h; wy += 4) {
+      const uint8_t *row = A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow;
+      pb_u4 *wr = winp + wy * A.wpairs;
+      for (int p = lane; p < A.wpairs; p += 64) {
+        const uint32_t q0 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p, A.sw - 1)), q1 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p + 1, A.sw - 1));
+        pb_u4 v;
+        if (CH == 4) {
+          v.x = pb_premul_pair<0>(q0, q1); v.y = pb_premul_pair<1>(q0, q1); v.z = pb_premul_pair<2>(q0, q1); v.w = __builtin_amdgcn_perm(q1, q0, 0x0C070C03u);
+        } else {
+          v.x = __builtin_amdgcn_perm(q1, q0, 0x0C040C00u); v.y = __builtin_amdgcn_perm(q1, q0, 0x0C050C01u); v.z = __builtin_amdgcn_perm(q1, q0, 0x0C060C02u); v.w = 0u;
+        }
+        wr[p] = v;
+      }
     }
   }
   __syncthreads();
@@ -564,8 +585,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
   const bool edge = xs < 0 || xs + A.n_x > A.sw;
   const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
   const int rowlen = 4 * A.nq;
-  // (loading a destination row's weight vectors a row ahead into registers was built and measured: 30 -> 42 us at 4K -> 1706x960 -- the predicated register arrays
-  // cost more than the exposed loads, which eight waves per SIMD already cover)
+  const pb_u4 *pairs4 = reinterpret_cast<const pb_u4 *>(A.pairs);      // uniform base, 32-bit per-lane index: scalar-base addressing
   for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
     const int i = i0 + r_;
     if (i >= A.dh) break;
@@ -573,28 +593,44 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
     const long long y = (long long)i * A.y_step + A.yoff;
     const int ys = (int)(y >> 16), yph = (int)(y >> 12) & 15;
     const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
-    const pb_u4 *wt = reinterpret_cast<const pb_u4 *>(A.pairs + (size_t)(((yph * 16 + xph) * 2 + par) * A.ny_eff) * rowlen);
+    const uint32_t wi = (uint32_t)(((yph * 16 + xph) * 2 + par) * A.ny_eff) * (uint32_t)A.nq;
     unsigned r = 0, g = 0, b = 0, a = 0;
-    for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
-      if (NPC) {
-        const pb_u4 w = wt[ty];
-        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+    if (NPC && NY) {
+      pb_u4 wv[NY ? NY : 1];
+#pragma unroll
+      for (int ty = 0; ty < NY; ty++) wv[ty] = pairs4[wi + ty];
+#pragma unroll
+      for (int ty = 0; ty < NY; ty++) {
+        const uint32_t wq[4] = {wv[ty].x, wv[ty].y, wv[ty].z, wv[ty].w};
 #pragma unroll
         for (int k = 0; k < NPC; k++) {
-          const pb_u4 dd = wp[k];
-          r = pb_dot2(dd.x, wv[k], r); g = pb_dot2(dd.y, wv[k], g); b = pb_dot2(dd.z, wv[k], b);
-          if (CH == 4) a = pb_dot2(dd.w, wv[k], a);
+          const pb_u4 dd = wp[ty * A.wpairs + k];
+          r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
+          if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
         }
-        continue;
       }
-      for (int qd = 0; qd < A.nq; qd++) {
-        const pb_u4 w = wt[ty * A.nq + qd];
-        const pb_u4 d0 = wp[4 * qd], d1 = wp[4 * qd + 1], d2 = wp[4 * qd + 2], d3 = wp[4 * qd + 3];
-        r = pb_dot2(d0.x, w.x, r); g = pb_dot2(d0.y, w.x, g); b = pb_dot2(d0.z, w.x, b);
-        r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
-        r = pb_dot2(d2.x, w.z, r); g = pb_dot2(d2.y, w.z, g); b = pb_dot2(d2.z, w.z, b);
-        r = pb_dot2(d3.x, w.w, r); g = pb_dot2(d3.y, w.w, g); b = pb_dot2(d3.z, w.w, b);
-        if (CH == 4) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
+    } else {
+      for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
+        if (NPC) {
+          const pb_u4 w = pairs4[wi + ty];
+          const uint32_t wq[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int k = 0; k < (NPC ? NPC : 1); k++) {
+            const pb_u4 dd = wp[k];
+            r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
+            if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
+          }
+          continue;
+        }
+        for (int qd = 0; qd < A.nq; qd++) {
+          const pb_u4 w = pairs4[wi + ty * A.nq + qd];
+          const pb_u4 d0 = wp[4 * qd], d1 = wp[4 * qd + 1], d2 = wp[4 * qd + 2], d3 = wp[4 * qd + 3];
+          r = pb_dot2(d0.x, w.x, r); g = pb_dot2(d0.y, w.x, g); b = pb_dot2(d0.z, w.x, b);
+          r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
+          r = pb_dot2(d2.x, w.z, r); g = pb_dot2(d2.y, w.z, g); b = pb_dot2(d2.z, w.z, b);
+          r = pb_dot2(d3.x, w.w, r); g = pb_dot2(d3.y, w.w, g); b = pb_dot2(d3.z, w.w, b);
+          if (CH == 4) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
+        }
       }
     }
     pb_finish<CH>(A.dst + (size_t)i * A.orow + (size_t)j * CH, r, g, b, a, edge, A.rnd);
@@ -920,7 +956,8 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     pa.pairs = t->pairs_d;
     pa.rnd = (t->n_x == 2 && t->n_y == 2 && channels == 3) ? 0x8000u : 0xffffu;
     // pairs per window row: the span of 64 destination pixels' first taps, the taps of the last one (padded to whole groups of four pairs), one pair of alignment slack
-    pa.wpairs = (int)((((63LL * x_step + 65535) >> 16) + 1) / 2) + 4 * t->nq + 2;
+    pa.wpairs = ((int)((((63LL * x_step + 65535) >> 16) + 1) / 2) + 4 * t->nq + 3 + 3) & ~3;       // whole quads of pairs, and wx0 is rounded down to a multiple of 4 below
+
     pa.tile_h = 0;
     size_t lds_cap = 24 * 1024;                         // 6 workgroups per CU: the per-lane weight loads want occupancy more than the window wants rows (profiles/r03/pb_pairs_lds_sweep.txt)
     if (const char *e = getenv("LGPU_PB_LDS_KB")) { const int v = atoi(e); if (v >= 4 && v <= 64) lds_cap = (size_t)v * 1024; }      // tuning probe
@@ -932,14 +969,16 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h));
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
-#define PB_PAIRS(CHN)                                                                                   \
-      switch (np <= 4 ? np : 0) {                                                                       \
-        case 1: hipLaunchKernelGGL((k_pb_pairs<CHN, 1>), g, block, lds, st, pa); break;                 \
-        case 2: hipLaunchKernelGGL((k_pb_pairs<CHN, 2>), g, block, lds, st, pa); break;                 \
-        case 3: hipLaunchKernelGGL((k_pb_pairs<CHN, 3>), g, block, lds, st, pa); break;                 \
-        case 4: hipLaunchKernelGGL((k_pb_pairs<CHN, 4>), g, block, lds, st, pa); break;                 \
-        default: hipLaunchKernelGGL((k_pb_pairs<CHN, 0>), g, block, lds, st, pa); break;                \
-      }
+#define PB_PAIRS(CHN)                                                                                                     \
+      { const int ny = getenv("LGPU_PB_NO_NY") ? 0 : t->ty1 - t->ty0; pa.no_quad = getenv("LGPU_PB_NO_QUAD") ? 1 : 0;                                                                                   \
+        if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa);                       \
+        else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa);                  \
+        else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa);                  \
+        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0>), g, block, lds, st, pa);                             \
+        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0>), g, block, lds, st, pa);                             \
+        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0>), g, block, lds, st, pa);                             \
+        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0>), g, block, lds, st, pa);                             \
+        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0>), g, block, lds, st, pa); }
       if (channels == 4) { PB_PAIRS(4) } else { PB_PAIRS(3) }
 #undef PB_PAIRS
       LGPU_CHECK_LAUNCH();
