@@ -54,7 +54,20 @@ __device__ __forceinline__ uint32_t pb_load_px(const uint8_t *row, int x) {
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
 }
 
-// the accumulators of one destination pixel -> its bytes
+// the accumulators of one destination pixel -> its bytes, packed c0 | c1 << 8 | c2 << 16 | alpha << 24
+template <int CH>
+__device__ __forceinline__ uint32_t pb_finish_px(unsigned r, unsigned g, unsigned b, unsigned a, bool edge, unsigned rnd) {
+  if (CH == 4) {
+    uint32_t o = 0;
+    if (a) {
+      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : 1.0 / (double)a;      // every tap opaque (the common frame): fl(1 / a) is a constant, no division
+      o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
+    }
+    return o;
+  }
+  if (edge) return ((r * 255u + 0xffffffu) >> 24) | (((g * 255u + 0xffffffu) >> 24) << 8) | (((b * 255u + 0xffffffu) >> 24) << 16);
+  return (((r + rnd) >> 16) & 0xFFu) | ((((g + rnd) >> 16) & 0xFFu) << 8) | ((((b + rnd) >> 16) & 0xFFu) << 16);
+}
 template <int CH>
 __device__ __forceinline__ void pb_finish(uint8_t *d, unsigned r, unsigned g, unsigned b, unsigned a, bool edge, unsigned rnd) {
   if (CH == 4) {
@@ -482,6 +495,104 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   }
 }
 
+// k_pb_half3 -- the same exact 2:1 reduction for 3-byte pixels (RGB24 / BGR24 / YUV888: a pixbuf WITHOUT alpha), standalone form only.  No alpha weighting:
+// P = the byte, colour = (scale * V + 0xffff) >> 16 inside the row, (255 * scale * V + 0xffffff) >> 24 on the columns whose taps leave it (the library's
+// per-pixel path: column 0 for HYPER, the last column for both).  A lane loads 12 bytes (4 pixels) per row and makes 2 output pixels; lanes pair up (DPP inside
+// the quad) so that two lanes' 12 output bytes leave as three dword stores.  Strips of 120 columns (lanes 2 .. 61 store; the pairing needs even lanes on even quads).
+struct __attribute__((aligned(4))) pb_u3 { uint32_t x, y, z; };
+template <int HYPER>
+__global__ __launch_bounds__(256) void k_pb_half3(const PbHalfArgs A, const uint8_t *src_, uint8_t *dst_) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nseq = A.cgroups * A.bands, per_xcd = (nseq + 7) >> 3;
+  const int seq = xcd * per_xcd + slot;
+  if (seq >= nseq || slot >= per_xcd) return;
+  const int cg = seq / A.bands, band = seq - cg * A.bands, strip = cg * 4 + wave;
+  if (strip >= A.strips) return;
+  const int k = strip * 60 - 2 + lane, kmax = (A.sw >> 2) - 1;
+  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
+  const bool out_lane = lane >= 2 && lane <= 61 && k <= kmax;
+  const bool edge_strip = strip == 0 || (strip + 1) * 60 + 2 >= kmax;
+  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
+  const uint32_t lane_off = 12u * (uint32_t)kc;
+  auto load_row = [&](int sy) -> pb_u4 {
+    sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
+    const pb_u3 t = *reinterpret_cast<const pb_u3 *>(src_ + (size_t)sy * A.irow + lane_off);
+    uint32_t q[4];
+    unpack3(t.x, t.y, t.z, q);
+    pb_u4 r;
+    r.x = q[0]; r.y = q[1]; r.z = q[2]; r.w = q[3];
+    return r;
+  };
+  auto fix = [&](pb_u4 q) -> pb_u4 {
+    if (edge_strip) {
+      if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }
+      if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }
+    }
+    return q;
+  };
+  auto hrow = [&](pb_u4 q, uint32_t h[6]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const uint32_t sel = 0x0C040C00u + 0x00010001u * c;
+      const uint32_t Ap = __builtin_amdgcn_perm(q.y, q.x, sel), Bp = __builtin_amdgcn_perm(q.w, q.z, sel);      // (byte c of pixel 0 | of pixel 1 << 16), (pixel 2 | pixel 3)
+      if (HYPER) {
+        const uint32_t bl = (uint32_t)__builtin_amdgcn_mov_dpp((int)Bp, 0x138, 0xF, 0xF, true), ar = (uint32_t)__builtin_amdgcn_mov_dpp((int)Ap, 0x130, 0xF, 0xF, true);
+        h[c] = pb_dot2(Ap, 0x00070007u, pb_add_hi_lo(bl, Bp));
+        h[3 + c] = pb_dot2(Bp, 0x00070007u, pb_add_hi_lo(Ap, ar));
+      } else {
+        h[c] = pb_dot2(Ap, 0x00010001u, 0u);
+        h[3 + c] = pb_dot2(Bp, 0x00010001u, 0u);
+      }
+    }
+  };
+  const int ylo = y0, yhi = y0 + rows - 1;
+  const int d = (band & 1) ? -1 : 1;
+  const int ystart = d > 0 ? ylo : yhi;
+  const int S0 = d > 0 ? 2 * ylo - 1 : 2 * yhi + 2;
+  uint32_t carry[6], hr[6], hs[6];
+  pb_u4 q0 = load_row(S0), q1 = load_row(S0 + d), qa = load_row(S0 + 2 * d), qb = load_row(S0 + 3 * d);
+  hrow(fix(q0), hr);
+  hrow(fix(q1), hs);
+#pragma unroll
+  for (int i = 0; i < 6; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
+  const uint32_t scale = HYPER ? 256u : 16384u;
+  const int X0 = 2 * k;                                                   // this lane's output columns X0, X0 + 1
+  const bool e0 = HYPER && X0 == 0, e1 = X0 + 1 == A.dw - 1;              // columns whose taps leave the row
+  for (int r = 0; r < rows; r++) {
+    const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
+    hrow(fix(qa), hr);
+    hrow(fix(qb), hs);
+    uint32_t px[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      uint32_t c[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int t = 3 * j + i;
+        uint32_t v;
+        if (HYPER) { v = carry[t] + __umul24(hr[t], 7u) + hs[t]; carry[t] = __umul24(hs[t], 7u) + hr[t]; }
+        else { v = carry[t] + hr[t]; carry[t] = hs[t]; }
+        const uint32_t rr = v * scale;                                      // the library's r: <= 255 * 65536
+        c[i] = (j ? e1 : e0) ? (rr * 255u + 0xffffffu) >> 24 : (rr + 0xffffu) >> 16;
+      }
+      px[j] = c[0] | (c[1] << 8) | (c[2] << 16);
+    }
+    // two lanes' four pixels -> three dwords: lanes 2m (columns X, X + 1) and 2m + 1 (X + 2, X + 3) of a quad
+    uint32_t q[4], w0, w1, w2;
+    q[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px[0], 0xA0, 0xF, 0xF, true); q[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px[1], 0xA0, 0xF, 0xF, true);     // quad_perm [0, 0, 2, 2]
+    q[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px[0], 0xF5, 0xF, 0xF, true); q[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px[1], 0xF5, 0xF, 0xF, true);     // quad_perm [1, 1, 3, 3]
+    pack3(q, w0, w1, w2);
+    const int y = d > 0 ? ystart + r : ystart - r;
+    if (out_lane) {
+      uint32_t *dp = reinterpret_cast<uint32_t *>(dst_ + (size_t)y * A.orow) + 3 * (k >> 1);
+      if (lane & 1) dp[1] = w1; else { dp[0] = w0; dp[2] = w2; }
+    }
+    qa = na; qb = nb;
+  }
+}
+
 // chroma blend of simple_blend.c:117-146 on an RGBA pair (the staged path's form): opaque layer-2 pixels through the integer table expression, translucent ones
 // through the reference's float scaling of both sources first; dst alpha = the track's alpha
 __device__ __forceinline__ uint32_t pb_chroma_rgba(uint32_t p1, uint32_t p2, uint32_t bf, uint32_t nbf) {
@@ -562,6 +673,21 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
         wr[2 * qd] = v0; wr[2 * qd + 1] = v1;
       }
     }
+  } else if (CH == 3 && !A.no_quad && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && 3 * (wx0 + 2 * A.wpairs) + 8 <= A.irow && ((uintptr_t)A.src & 3) == 0 && (A.irow & 3) == 0) {
+    // 3-byte pixels, window inside the row with a few spare bytes behind it: a pair's 6 bytes out of three aligned dwords (v_alignbyte) instead of six byte loads
+    for (int wy = wave; wy < A.win_h; wy += 4) {
+      const uint8_t *row = A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow;
+      pb_u4 *wr = winp + wy * A.wpairs;
+      for (int p = lane; p < A.wpairs; p += 64) {
+        const uint32_t bo = 3u * (uint32_t)(wx0 + 2 * p);
+        const uint32_t *dp = reinterpret_cast<const uint32_t *>(row + (bo & ~3u));
+        const uint32_t d0 = dp[0], d1 = dp[1], d2 = dp[2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, bo & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, bo & 3u);     // bytes bo .. bo + 7
+        pb_u4 v;
+        v.x = __builtin_amdgcn_perm(lo, lo, 0x0C030C00u); v.y = __builtin_amdgcn_perm(hi, lo, 0x0C040C01u); v.z = __builtin_amdgcn_perm(hi, lo, 0x0C050C02u); v.w = 0u;
+        wr[p] = v;
+      }
+    }
   } else {
     for (int wy = wave; wy < A.win_h; wy += 4) {
       const uint8_t *row = A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow;
@@ -586,6 +712,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
   const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
   const int rowlen = 4 * A.nq;
   const pb_u4 *pairs4 = reinterpret_cast<const pb_u4 *>(A.pairs);      // uniform base, 32-bit per-lane index: scalar-base addressing
+  const bool quads3 = CH == 3 && (((uintptr_t)A.dst | (uintptr_t)A.orow) & 3) == 0;
   for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
     const int i = i0 + r_;
     if (i >= A.dh) break;
@@ -633,7 +760,19 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
         }
       }
     }
-    pb_finish<CH>(A.dst + (size_t)i * A.orow + (size_t)j * CH, r, g, b, a, edge, A.rnd);
+    const uint32_t px = pb_finish_px<CH>(r, g, b, a, edge, A.rnd);
+    uint8_t *drow = A.dst + (size_t)i * A.orow;
+    if (CH == 4) reinterpret_cast<uint32_t *>(drow)[j] = px;
+    else if (quads3 && (j | 3) < A.dw) {
+      // four lanes' 3-byte pixels = three dwords: every lane reads its quad's four values (DPP quad_perm broadcasts), packs them, and lanes 0..2 of the quad
+      // store one dword each -- coalesced dword stores instead of three byte stores per pixel
+      uint32_t q[4], w0, w1, w2;
+      q[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0x00, 0xF, 0xF, true); q[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0x55, 0xF, 0xF, true);
+      q[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xAA, 0xF, 0xF, true); q[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xFF, 0xF, 0xF, true);
+      pack3(q, w0, w1, w2);
+      const int l = lane & 3;
+      if (l < 3) reinterpret_cast<uint32_t *>(drow)[3 * (j >> 2) + l] = l == 0 ? w0 : l == 1 ? w1 : w2;
+    } else { uint8_t *d = drow + 3 * (size_t)j; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
   }
 }
 
@@ -932,6 +1071,19 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   if ((rc = pb_table(interp, sw, sh, dw, dh, &t))) {
     if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d needs %d x %d taps; the library's two-step scaler is not covered", sw, sh, dw, dh, t->n_x, t->n_y);
     return rc;
+  }
+  if (channels == 3 && sw == 2 * dw && sh == 2 * dh && (sw & 7) == 0 && ((((uintptr_t)src_d | (uintptr_t)dst_d) | (unsigned)irow | (unsigned)orow) & 3) == 0 && !getenv("LGPU_PB_NO_HALF3")) {
+    PbHalfArgs h;
+    // the same table check as the 4-byte kernel (alignment arguments that always pass: this kernel's own are checked above)
+    if (pb_half_ok(t, interp, sw, sh, dw, dh, 0, 0, &h.hyper, &h.ashift)) {
+      h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
+      h.strips = (int)cdiv((unsigned)dw, 120); h.cgroups = (h.strips + 3) / 4; h.th = 6; h.bands = (int)cdiv((unsigned)dh, 6u); h.ntracks = 1;
+      const dim3 g3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u));
+      if (h.hyper) hipLaunchKernelGGL(k_pb_half3<1>, g3, dim3(256), 0, st, h, src_d, dst_d);
+      else hipLaunchKernelGGL(k_pb_half3<0>, g3, dim3(256), 0, st, h, src_d, dst_d);
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
   }
   if (channels == 4) {
     PbHalfArgs h;

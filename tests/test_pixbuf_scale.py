@@ -380,3 +380,18 @@ def test_c3_at_size_in_one_launch(gpu, orc):
     gpu.chain_canvas(prm, gpu.chain_tracks([dev(src)], [dev(l2)], [d]), nw, nh, ox, oy)
     want = _want_canvas(orc, src, sw * 4, sw, sh, l2, nw * 4, dw, dh, nw, nh, ox, oy, 0, 0x103, 128, None)
     assert (host(d) == want).all()
+
+
+@gpu_mark
+def test_exact_halving_of_3_byte_pixels(gpu, orc):
+    """k_pb_half3 (RGB24 / BGR24 / YUV888 at exactly 2:1, widths that are multiples of 8): both interps, strips that end inside the frame, bands of every
+    height, the two columns whose taps leave the row (the library's per-pixel rounding), padded rowstrides"""
+    rng = np.random.default_rng(0x9DBF)
+    for (sw, sh, interp, pad) in [(64, 32, 3, 0), (64, 32, 2, 0), (248, 10, 3, 4), (488, 26, 3, 0), (1000, 64, 2, 8), (3840, 24, 3, 0), (8, 2, 3, 0), (16, 4, 2, 0), (968, 1000, 3, 0)]:
+        dw, dh = sw // 2, sh // 2
+        src = rng.integers(0, 256, (sh, sw * 3 + pad), dtype=np.uint8)
+        want = np.zeros((dh, dw * 3), np.uint8)
+        assert orc.orc_pixbuf_scale(P(src), src.strides[0], sw, sh, P(want), dw * 3, dw, dh, 3, interp) == 0
+        got = gpu_scale(gpu, src, sw, sh, dw, dh, 3, interp)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, "%dx%d interp %d: %d bytes differ, first %s" % (sw, sh, interp, len(bad), bad[0].tolist())
