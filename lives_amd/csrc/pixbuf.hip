@@ -593,6 +593,83 @@ __global__ __launch_bounds__(256) void k_pb_half3(const PbHalfArgs A, const uint
   }
 }
 
+// k_pb_double -- the exact 1:2 enlargement of 4-byte pixels (1080p -> 4K), HYPER or BILINEAR: both tables are exactly 4096 * [1 3] x [1 3] outer products on the two
+// nearest source pixels per axis (host-checked), so with P = alpha * q:  out(2i) = P[i-1] + 3 P[i],  out(2i+1) = 3 P[i] + P[i+1]  along a row, the same down the
+// rows, colour = (uint8_t)((double)V_c * (1.0 / (double)V_alpha)), alpha' = V_alpha >> 4 (the common 4096 drops out).  A lane owns two source pixels (one 8-byte load per
+// source row, the neighbours by DPP), i.e. four output columns, and every new source row completes two output rows (16-byte stores).  The arithmetic that is left is
+// the library's double division, once per output pixel; frames that are opaque where they are sampled take the constant reciprocal.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_pb_double(const PbHalfArgs A, const uint8_t *src_, uint8_t *dst_) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nseq = A.cgroups * A.bands, per_xcd = (nseq + 7) >> 3;
+  const int seq = xcd * per_xcd + slot;
+  if (seq >= nseq || slot >= per_xcd) return;
+  const int cg = seq / A.bands, band = seq - cg * A.bands, strip = cg * 4 + wave;
+  if (strip >= A.strips) return;
+  const int k = strip * 62 - 1 + lane, kmax = (A.sw >> 1) - 1;            // this lane's source pixels 2k, 2k + 1 -> output columns 4k .. 4k + 3
+  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
+  const bool out_lane = lane >= 1 && lane <= 62 && k <= kmax;
+  const bool edge_strip = strip == 0 || (strip + 1) * 62 + 1 >= kmax;
+  const int r0 = band * A.th, nrows = min(A.th, A.sh - r0);               // source rows r0 .. r0 + nrows - 1 -> output rows 2 r0 .. 2 (r0 + nrows) - 1
+  const uint32_t lane_off = 8u * (uint32_t)kc;
+  auto load_row = [&](int sy) -> pb_u2 {
+    sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
+    return *reinterpret_cast<const pb_u2 *>(src_ + (size_t)sy * A.irow + lane_off);
+  };
+  // one source row of a lane -> its four H columns per channel: h[4 * col + c]
+  auto hrow = [&](pb_u2 q, uint32_t h[16]) {
+    if (edge_strip) {
+      if (k < 0) q.y = q.x;              // left of the frame: pixel 0 again (only its right pixel is ever read by lane k = 0)
+      if (k > kmax) q.x = q.y;           // right of the frame: the last pixel again
+    }
+    uint32_t pr[4];
+    pr[0] = pb_premul_pair<0>(q.x, q.y); pr[1] = pb_premul_pair<1>(q.x, q.y); pr[2] = pb_premul_pair<2>(q.x, q.y); pr[3] = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t left = (uint32_t)__builtin_amdgcn_mov_dpp((int)pr[c], 0x138, 0xF, 0xF, true) >> 16;       // P[2k - 1]: the left lane's second pixel
+      const uint32_t right = (uint32_t)__builtin_amdgcn_mov_dpp((int)pr[c], 0x130, 0xF, 0xF, true) & 0xFFFFu;   // P[2k + 2]: the right lane's first pixel
+      const uint32_t p0 = pr[c] & 0xFFFFu, p1 = pr[c] >> 16;
+      h[c] = left + 3u * p0; h[4 + c] = 3u * p0 + p1; h[8 + c] = p0 + 3u * p1; h[12 + c] = 3u * p1 + right;
+    }
+  };
+  auto emit = [&](int oy, const uint32_t a3[16], const uint32_t b1[16]) {     // output row oy = 3 * a3 + b1
+    pb_u4 o;
+    uint32_t px[4];
+#pragma unroll
+    for (int col = 0; col < 4; col++) {
+      const uint32_t va = 3u * a3[4 * col + 3] + b1[4 * col + 3];
+      uint32_t p = 0;
+      if (va) {
+        const double ia = (va == 4080u) ? (1.0 / 4080.0) : 1.0 / (double)va;
+        const uint32_t c0 = (uint32_t)(int)((double)(3u * a3[4 * col] + b1[4 * col]) * ia), c1 = (uint32_t)(int)((double)(3u * a3[4 * col + 1] + b1[4 * col + 1]) * ia),
+                       c2 = (uint32_t)(int)((double)(3u * a3[4 * col + 2] + b1[4 * col + 2]) * ia);
+        p = c0 | (c1 << 8) | (c2 << 16) | ((va >> 4) << 24);
+      }
+      px[col] = p;
+    }
+    o.x = px[0]; o.y = px[1]; o.z = px[2]; o.w = px[3];
+    if (out_lane) __builtin_nontemporal_store(o, reinterpret_cast<pb_u4 *>(dst_ + (size_t)oy * A.orow + 16 * (size_t)k));
+  };
+  uint32_t hp[16], hc[16];
+  pb_u2 qn = load_row(r0);
+  hrow(load_row(r0 - 1), hp);
+  hrow(qn, hc);
+  qn = load_row(r0 + 1);
+  for (int r = 0; r < nrows; r++) {
+    // rows r0 + r - 1 (hp), r0 + r (hc) are here; r0 + r + 1 arrives: output rows 2 (r0 + r) = hp + 3 hc and 2 (r0 + r) + 1 = 3 hc + hn
+    const pb_u2 q = qn;
+    qn = load_row(r0 + r + 2);
+    uint32_t hn[16];
+    hrow(q, hn);
+    emit(2 * (r0 + r), hc, hp);
+    emit(2 * (r0 + r) + 1, hc, hn);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { hp[i] = hc[i]; hc[i] = hn[i]; }
+  }
+}
+
 // chroma blend of simple_blend.c:117-146 on an RGBA pair (the staged path's form): opaque layer-2 pixels through the integer table expression, translucent ones
 // through the reference's float scaling of both sources first; dst alpha = the track's alpha
 __device__ __forceinline__ uint32_t pb_chroma_rgba(uint32_t p1, uint32_t p2, uint32_t bf, uint32_t nbf) {
@@ -940,6 +1017,27 @@ static bool pb_half_ok(const PbTable *t, int interp, int sw, int sh, int dw, int
   return true;
 }
 
+// the exact 1:2 enlargement: every phase the destination pixels take must be 4096 * [wy0 wy1] x [wx0 wx1] with (1, 3) or (3, 1) on two adjacent taps, placed so that
+// out(2i) = P[i-1] + 3 P[i] and out(2i+1) = 3 P[i] + P[i+1] (what k_pb_double evaluates); anything else keeps the general kernels
+static bool pb_double_ok(const PbTable *t, int x_step, int y_step) {
+  if (x_step != 32768 || y_step != 32768) return false;
+  for (int jy = 0; jy < 2; jy++)
+    for (int jx = 0; jx < 2; jx++) {
+      const long long x = (long long)jx * x_step + t->xoff, y = (long long)jy * y_step + t->yoff;
+      const int xs = (int)(x >> 16), ys = (int)(y >> 16), xph = (int)(x >> 12) & 15, yph = (int)(y >> 12) & 15;
+      const int *w = t->host.data() + (size_t)(yph * 16 + xph) * t->n_x * t->n_y;
+      // destination pixel jx (0: even column, 1: odd) must weight source pixels (jx == 0 ? -1, 0 : 0, 1) with (1, 3) / (3, 1); same vertically
+      for (int ty = 0; ty < t->n_y; ty++)
+        for (int tx = 0; tx < t->n_x; tx++) {
+          const int sx = xs + tx, sy = ys + ty;
+          const int wx = jx == 0 ? (sx == -1 ? 1 : sx == 0 ? 3 : 0) : (sx == 0 ? 3 : sx == 1 ? 1 : 0);
+          const int wy = jy == 0 ? (sy == -1 ? 1 : sy == 0 ? 3 : 0) : (sy == 0 ? 3 : sy == 1 ? 1 : 0);
+          if (w[ty * t->n_x + tx] != 4096 * wx * wy) return false;
+        }
+    }
+  return true;
+}
+
 static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : 124);
   // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
@@ -1071,6 +1169,18 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   if ((rc = pb_table(interp, sw, sh, dw, dh, &t))) {
     if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d needs %d x %d taps; the library's two-step scaler is not covered", sw, sh, dw, dh, t->n_x, t->n_y);
     return rc;
+  }
+  if (channels == 4 && dw == 2 * sw && dh == 2 * sh && (sw & 1) == 0 && (((uintptr_t)src_d | (unsigned)irow) & 7) == 0 && (((uintptr_t)dst_d | (unsigned)orow) & 15) == 0 &&
+      pb_double_ok(t, x_step, y_step) && !getenv("LGPU_PB_NO_DOUBLE")) {
+    PbHalfArgs h;
+    h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
+    h.strips = (int)cdiv((unsigned)sw, 124); h.cgroups = (h.strips + 3) / 4;
+    h.th = 4;                      // measured (1080p -> 4K): 18.2 us at 4 source rows per band, 22.8 at 8, 33.4 at 16, 52.7 at 32 -- per-wave latency, as in k_pb_half
+    if (const char *e = getenv("LGPU_PBD_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) h.th = v; }
+    h.bands = (int)cdiv((unsigned)sh, (unsigned)h.th); h.ntracks = 1;
+    hipLaunchKernelGGL(k_pb_double<0>, dim3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u)), dim3(256), 0, st, h, src_d, dst_d);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
   }
   if (channels == 3 && sw == 2 * dw && sh == 2 * dh && (sw & 7) == 0 && ((((uintptr_t)src_d | (uintptr_t)dst_d) | (unsigned)irow | (unsigned)orow) & 3) == 0 && !getenv("LGPU_PB_NO_HALF3")) {
     PbHalfArgs h;

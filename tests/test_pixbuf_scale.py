@@ -395,3 +395,24 @@ def test_exact_halving_of_3_byte_pixels(gpu, orc):
         got = gpu_scale(gpu, src, sw, sh, dw, dh, 3, interp)
         bad = np.argwhere(got != want)
         assert len(bad) == 0, "%dx%d interp %d: %d bytes differ, first %s" % (sw, sh, interp, len(bad), bad[0].tolist())
+
+
+@gpu_mark
+def test_exact_doubling_of_4_byte_pixels(gpu, orc):
+    """k_pb_double (1:2, both interps -- their tables are the same 4096 * [1 3] x [1 3] products): translucent, opaque (the constant-reciprocal path) and
+    all-zero alpha, strips that end inside the frame, bands of every height, both frame borders"""
+    rng = np.random.default_rng(0x9DC0)
+    for (sw, sh, interp, amode) in [(64, 32, 3, 0), (64, 32, 2, 1), (248, 9, 3, 2), (250, 17, 3, 0), (500, 40, 2, 0), (1920, 12, 3, 1), (2, 1, 3, 0), (126, 130, 3, 2)]:
+        dw, dh = 2 * sw, 2 * sh
+        src = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)
+        a = src[:, 3::4]
+        if amode == 1:
+            a[:] = 255
+        elif amode == 2:
+            a[rng.random(a.shape) < 0.4] = 0
+            a[rng.random(a.shape) < 0.4] = 255
+        want = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_pixbuf_scale(P(src), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, interp) == 0
+        got = gpu_scale(gpu, src, sw, sh, dw, dh, 4, interp, orow=dw * 4)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, "%dx%d interp %d alpha mode %d: %d bytes differ, first %s" % (sw, sh, interp, amode, len(bad), bad[0].tolist())

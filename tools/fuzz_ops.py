@@ -120,9 +120,13 @@ def main():
                 # gdk-pixbuf arithmetic (pinned): every interp, 3 / 4 channels, ratios from 1:12 to 12:1, exact 2:1 (k_pb_half) in a third of the cases
                 ch, interp = int(rng.choice([3, 4])), int(rng.choice([0, 2, 3]))
                 sw, sh = int(rng.integers(1, 500)), int(rng.integers(1, 260))
-                if rng.random() < 0.33:
+                u = rng.random()
+                if u < 0.33:
                     dw, dh = max(1, sw // 2), max(1, sh // 2)
                     sw, sh = 2 * dw, 2 * dh
+                elif u < 0.5:                     # exact 1:2 (k_pb_double)
+                    sw, sh = max(2, (sw // 2) & ~1), max(1, sh // 2)
+                    dw, dh = 2 * sw, 2 * sh
                 else:
                     dw, dh = int(rng.integers(1, 600)), int(rng.integers(1, 300))
                 al = 16 if rng.random() < 0.5 else 4
