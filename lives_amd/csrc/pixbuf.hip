@@ -653,14 +653,16 @@ __global__ __launch_bounds__(256) void k_pb_double(const PbHalfArgs A, const uin
     if (out_lane) __builtin_nontemporal_store(o, reinterpret_cast<pb_u4 *>(dst_ + (size_t)oy * A.orow + 16 * (size_t)k));
   };
   uint32_t hp[16], hc[16];
-  pb_u2 qn = load_row(r0);
-  hrow(load_row(r0 - 1), hp);
-  hrow(qn, hc);
-  qn = load_row(r0 + 1);
+  // a lane's row is 8 bytes: the next three source rows are always in flight (a band is short and its loads are a dependent chain otherwise)
+  const pb_u2 qm = load_row(r0 - 1), q0 = load_row(r0);
+  pb_u2 qn = load_row(r0 + 1), qn2 = load_row(r0 + 2), qn3 = load_row(r0 + 3);
+  hrow(qm, hp);
+  hrow(q0, hc);
   for (int r = 0; r < nrows; r++) {
     // rows r0 + r - 1 (hp), r0 + r (hc) are here; r0 + r + 1 arrives: output rows 2 (r0 + r) = hp + 3 hc and 2 (r0 + r) + 1 = 3 hc + hn
     const pb_u2 q = qn;
-    qn = load_row(r0 + r + 2);
+    qn = qn2; qn2 = qn3;
+    qn3 = load_row(r0 + r + 4);
     uint32_t hn[16];
     hrow(q, hn);
     emit(2 * (r0 + r), hc, hp);
@@ -1175,7 +1177,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     PbHalfArgs h;
     h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
     h.strips = (int)cdiv((unsigned)sw, 124); h.cgroups = (h.strips + 3) / 4;
-    h.th = 4;                      // measured (1080p -> 4K): 18.2 us at 4 source rows per band, 22.8 at 8, 33.4 at 16, 52.7 at 32 -- per-wave latency, as in k_pb_half
+    h.th = 3;                      // measured (1080p -> 4K): 16.5 us at 2-3 source rows per band, 18.2 us at 4, 22.8 at 8, 33.4 at 16, 52.7 at 32 -- per-wave latency, as in k_pb_half
     if (const char *e = getenv("LGPU_PBD_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) h.th = v; }
     h.bands = (int)cdiv((unsigned)sh, (unsigned)h.th); h.ntracks = 1;
     hipLaunchKernelGGL(k_pb_double<0>, dim3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u)), dim3(256), 0, st, h, src_d, dst_d);

@@ -36,6 +36,10 @@ def main():
             continue
         ch = case[6] if pixbuf else 4
         srcs = [torch.randint(0, 256, (sh, sw * ch), dtype=torch.uint8, device="cuda", generator=g) for _ in range(nb)]
+        if pixbuf and ch == 4 and "--opaque" in sys.argv:
+            for t_ in srcs:
+                t_[:, 3::4] = 255           # the common frame: no translucency anywhere
+            name += " (opaque)"
         dsts = [torch.zeros((dh, dw * ch), dtype=torch.uint8, device="cuda") for _ in range(nb)]
         if pixbuf:
             def run(s_, d_):
