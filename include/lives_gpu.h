@@ -140,6 +140,10 @@ typedef struct { const uint8_t *y_d, *u_d, *v_d; uint8_t *dst_d; } lgpu_yuv_fram
 int lgpu_yuv420p_to_rgb_batch(int nframes, const lgpu_yuv_frame *frames, const int istrides[3], long u_size, long v_size, int orow,
                               int width, int height, int opsize, int out_order, int is_422, int which_tables, int pb_quality,
                               const uint8_t *lut8, int flags, void *stream);
+/* launch shape of the 4:2:0 kernel for aligned rows (yuv.hip, k_yuv420p_to_rgb_s): chroma columns per lane cell (1, 2 or 4; 0 sends every launch
+   through the one-column kernel), threads per workgroup (256 / 512 / 1024), resident groups of 256 threads per CU; -1 keeps a value.  Results do not
+   depend on it (tests walk every setting); process-wide, not meant to change while conversions are in flight. */
+int lgpu_yuv420_tuning(int cell_columns, int block, int groups_per_cu);
 /* the same conversion with the reference's 16-bit indexed gamma LUT fused in, as convert_yuv420p_to_rgb_frame does when it
    is handed a target gamma (:3274-3283; xyuv2rgb_with_gamma :2386-2390): c = lut16[CLAMP16biti(sum >> 8)] >> 8.
    lut16_d: DEVICE pointer to 65536 uint16 (build on the host with lgpu_gamma_lut16, upload once, reuse). */

@@ -789,7 +789,6 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
   const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15;
   const bool edge = xs < 0 || xs + A.n_x > A.sw;
   const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
-  const int rowlen = 4 * A.nq;
   const pb_u4 *pairs4 = reinterpret_cast<const pb_u4 *>(A.pairs);      // uniform base, 32-bit per-lane index: scalar-base addressing
   const bool quads3 = CH == 3 && (((uintptr_t)A.dst | (uintptr_t)A.orow) & 3) == 0;
   for (int r_ = wave; r_ < A.tile_h; r_ += 4) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_separable(SepArgs a, SepTracks trk, 
   // source window of this tile (unclamped coordinates)
   const int sx0 = a.hpos[tx0], sx1 = a.hpos[tx0 + tw - 1] + nth;
   const int sy0 = a.vpos[ty0], sy1 = a.vpos[ty0 + thh - 1] + ntv;
-  const int wcols = sx1 - sx0, wrows = sy1 - sy0;     // host guarantees <= swt / sht
+  const int wrows = sy1 - sy0;                         // host guarantees <= sht (and sx1 - sx0 <= swt)
 
   if (a.use_lut) stage_lut(s_lut, lut);
   uint32_t bf = a.bf, nbf = a.nbf;

@@ -193,7 +193,7 @@ namespace {
 constexpr size_t kStageChunk = 4u << 20, kStageMin = 256u << 10;
 struct StageSet { void *buf[2]; hipEvent_t ev[2]; bool busy[2]; int dev; };
 struct SpareStages { std::mutex mu; std::vector<StageSet> sets; };
-SpareStages &spare_stages() { static SpareStages *p = new SpareStages; return *p; }      // never destroyed: thread destructors may run late
+extern "C++" SpareStages &spare_stages() { static SpareStages *p = new SpareStages; return *p; }      // never destroyed: thread destructors may run late
 struct Stage {
   void *buf[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};

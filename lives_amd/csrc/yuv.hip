@@ -15,7 +15,9 @@
 // Pixels whose reference value is undefined (row 0 odd x: out-of-bounds table index; last row odd x: never
 // written) get the evident intent.
 #include "lgpu_common.h"
+#include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 namespace lgpu {
 
@@ -48,6 +50,7 @@ struct YuvCtx {
   const uint16_t *lut16;
   bool clamped, lowq, use_lut;
   int opsize, order;
+  int cs = 1;              // stride of the four chroma tables (2 where they are interleaved in pairs)
   __device__ __forceinline__ int cuv(int n) const { return clamped ? cuv_c(n) : (n < 0 ? 0 : n > 255 ? 255 : n); }
   // (2a + b) / 3 and (a + 2b) / 3 on doubled sums; (int)(s / 3. + .5) == (s + 1) / 3 for s >= 0 (:3464-3469)
   __device__ __forceinline__ void vblend(int s1, int s2, int &top, int &bot) const {
@@ -58,12 +61,12 @@ struct YuvCtx {
     const int yy = ty[y];
     uint32_t r, g, b;
     if (lut16) {          // lut[CLAMP16biti(sum >> 8)] >> 8: a 128 KB table, L2 resident
-      const int ir = (yy + rcr[v]) >> 8, ig = (yy + gcb[u] + gcr[v]) >> 8, ib = (yy + bcb[u]) >> 8;
+      const int ir = (yy + rcr[v * cs]) >> 8, ig = (yy + gcb[u * cs] + gcr[v * cs]) >> 8, ib = (yy + bcb[u * cs]) >> 8;
       r = lut16[ir > 65535 ? 65535 : ir < 0 ? 0 : ir] >> 8;
       g = lut16[ig > 65535 ? 65535 : ig < 0 ? 0 : ig] >> 8;
       b = lut16[ib > 65535 ? 65535 : ib < 0 ? 0 : ib] >> 8;
     } else {
-      r = clamp255((yy + rcr[v]) >> 16); g = clamp255((yy + gcb[u] + gcr[v]) >> 16); b = clamp255((yy + bcb[u]) >> 16);
+      r = clamp255((yy + rcr[v * cs]) >> 16); g = clamp255((yy + gcb[u * cs] + gcr[v * cs]) >> 16); b = clamp255((yy + bcb[u * cs]) >> 16);
       if (use_lut) { r = lut[r]; g = lut[g]; b = lut[b]; }
     }
     if (order == 0) return r | (g << 8) | (b << 16) | 0xFF000000u;
@@ -180,212 +183,140 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut, 
   for (; unit < nunits; unit += gridDim.y) yuv420_cell(a, c, unit, k, hw, npairs);
 }
 
-// The same walk with one lane per FOUR chroma columns (8 x 2 pixels of a row pair): the quad's luma comes in as two 8-byte loads and
-// every chroma row as three dwords (the columns left of, of and right of the group), 16 loads instead of 64 byte loads, and the two
-// output rows leave as 16-byte stores.  Only cells whose loads stay inside the planes and whose rows are aligned take this form
-// (`fast`, decided on the host per launch + per lane here); every other cell (row 0, the trailing row, the first column group, the
-// plane ends) goes through yuv420_cell above, so the result is the same bytes.
-__global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb4(YuvArgs a, Lut8 lut, YuvBatch bt, int batched) {
-  if (batched) { a.y = bt.y[blockIdx.z]; a.u = bt.u[blockIdx.z]; a.v = bt.v[blockIdx.z]; a.dst = bt.dst[blockIdx.z]; }
-  __shared__ int32_t s_tab[5 * 256];
-  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
-  for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_tab[i] = a.tables[i];
-  stage_lut(s_lut, lut);
-  __syncthreads();
-  YuvCtx c;
-  c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
-  c.lut = s_lut; c.lut16 = a.lut16; c.clamped = a.clamped; c.lowq = a.low_quality; c.use_lut = a.use_lut; c.opsize = a.opsize; c.order = a.order;
-  const int hw = a.width >> 1;
-  const int k0 = 4 * (blockIdx.x * kBlock + threadIdx.x);
-  if (k0 >= hw) return;
+// ---- every launch whose rows are aligned: k_yuv420p_to_rgb_s --------------------------------------------------------------------------
+// profiles/r03/k2_single_pmc.md: the one-cell-per-lane kernel above spends 269 VALU + 179 SALU + 34 LDS instructions per wave on 256 pixels, 8,656 waves in
+// two generations of 2,164 workgroups that each stage 5.4 KB of tables (one 1080p frame: 11.6 us).  This form:
+//   * {R_Cr, G_Cr}[v] and {G_Cb, B_Cb}[u] as 8-byte LDS entries with CLAMP16_240 / the 0..255 clamp folded into the index: 3 table gathers per pixel, no
+//     chroma clamp instructions; / 3 as a multiply-shift; CLAMP0255f as one v_med3; two byte permutes assemble the pixel (26.6 VALU per pixel);
+//   * cells of NC chroma columns (2 NC x 2 pixels) numbered linearly over the frame (no idle lanes at 960 chroma columns); every chroma row of a cell is ONE
+//     unaligned load of the NC + 2 samples the cell needs;
+//   * the samples of a thread's first cell are requested before the tables are staged, those of its next cell before the arithmetic of the current one
+//     (launches with more cells than resident threads walk them with a grid stride: the tables are staged once per workgroup, not once per cell);
+//   * edge cells (row 0, the trailing row, plane ends) walk yuv420_cell() on the same LDS tables.
+// One 1080p frame: 11.6 -> 6.5 us; 16 x 1080p: 47.9 us (the 16-copy-table kernel of round 2, removed) -> 40 us (profiles/r03/k2_forms.txt).
+constexpr int kYsOffTy = 0, kYsOffRG = 1024, kYsOffGB = 3072, kYsOffLut = 5120, kYsLds = 5376;
+template <int NC, int ORDER, bool LUT>
+__global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, YuvBatch bt, int batched, uint32_t cgmagic) {
+  if (batched) { a.y = bt.y[blockIdx.y]; a.u = bt.u[blockIdx.y]; a.v = bt.v[blockIdx.y]; a.dst = bt.dst[blockIdx.y]; }
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kYsLds];
+  typedef typename std::conditional<NC == 4, uint64_t, uint32_t>::type win_t;      // NC + 2 chroma samples of a row (NC = 1 reads one byte more than it uses)
+  typedef typename std::conditional<NC == 4, uint64_t, typename std::conditional<NC == 2, uint32_t, uint16_t>::type>::type ywin_t;      // 2 NC luma samples
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int hw = a.width >> 1, ncg = (hw + NC - 1) / NC;
   const int npairs = (a.height - 1) / 2;
   const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
-  for (int unit = blockIdx.y; unit < nunits; unit += gridDim.y) {
-    const int i = 2 * unit - 1, r = i >> 1;
-    const bool fast = unit >= 1 && unit <= npairs && k0 >= 4 && k0 + 4 <= hw && (long)(r + 1) * a.us + k0 + 8 <= a.usize &&
-                      (long)(r + 1) * a.vs + k0 + 8 <= a.vsize;
-    if (!fast) {
-      for (int k = k0; k < k0 + 4 && k < hw; k++) yuv420_cell(a, c, unit, k, hw, npairs);
-      continue;
-    }
-    const uint2 ya = *reinterpret_cast<const uint2 *>(a.y + (size_t)i * a.ys + 2 * k0), yb = *reinterpret_cast<const uint2 *>(a.y + (size_t)(i + 1) * a.ys + 2 * k0);
-    const uint8_t *ur = a.u + (size_t)r * a.us + k0, *vr = a.v + (size_t)r * a.vs + k0;
-    const uint32_t u0m = *reinterpret_cast<const uint32_t *>(ur - 4), u0c = *reinterpret_cast<const uint32_t *>(ur), u0p = *reinterpret_cast<const uint32_t *>(ur + 4);
-    const uint32_t u1c = *reinterpret_cast<const uint32_t *>(ur + a.us), u1p = *reinterpret_cast<const uint32_t *>(ur + a.us + 4);
-    const uint32_t v0c = *reinterpret_cast<const uint32_t *>(vr), v0p = *reinterpret_cast<const uint32_t *>(vr + 4);
-    const uint32_t v1m = *reinterpret_cast<const uint32_t *>(vr + a.vs - 4), v1c = *reinterpret_cast<const uint32_t *>(vr + a.vs), v1p = *reinterpret_cast<const uint32_t *>(vr + a.vs + 4);
-    const int lv2 = a.v[(size_t)(r + 1) * a.vs];                            // PV(r + 1, 0): the reference's constant "last" sample
-    // samples k0-1 .. k0+4 of each row as 6-element byte strings: [m.b3, c.b0..b3, p.b0]
-    auto at6 = [](uint32_t m, uint32_t cc, uint32_t pp, int j) -> int {   // j = -1 .. 4
-      return j < 0 ? (int)(m >> 24) : j < 4 ? (int)((cc >> (8 * j)) & 0xFF) : (int)(pp & 0xFF);
-    };
-    uint32_t top[8], bot[8];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int u_rk = at6(0, u0c, 0, j), v_rk = at6(0, v0c, 0, j), v_r1k = at6(0, v1c, 0, j);
-      const int lu1 = at6(u0m, u0c, u0p, j - 1), lv1 = at6(v1m, v1c, v1p, j - 1);
-      int ut, ub, vt, vb;
-      c.vblend(u_rk + lu1, u_rk + lu1, ut, ub);
-      c.vblend(v_rk + lv1, v_r1k + lv2, vt, vb);
-      const int y00 = (int)(((j < 2 ? ya.x : ya.y) >> (16 * (j & 1))) & 0xFF), y01 = (int)(((j < 2 ? ya.x : ya.y) >> (16 * (j & 1) + 8)) & 0xFF);
-      const int y10 = (int)(((j < 2 ? yb.x : yb.y) >> (16 * (j & 1))) & 0xFF), y11 = (int)(((j < 2 ? yb.x : yb.y) >> (16 * (j & 1) + 8)) & 0xFF);
-      top[2 * j] = c.rgb(y00, ut, vt); bot[2 * j] = c.rgb(y10, ub, vb);
-      c.vblend(u_rk + at6(u0m, u0c, u0p, j + 1), at6(0, u1c, u1p, j) + at6(0, u1c, u1p, j + 1), ut, ub);
-      c.vblend(v_rk + at6(0, v0c, v0p, j + 1), v_r1k + at6(v1m, v1c, v1p, j + 1), vt, vb);
-      top[2 * j + 1] = c.rgb(y01, ut, vt); bot[2 * j + 1] = c.rgb(y11, ub, vb);
-    }
-    uint4 *d0 = reinterpret_cast<uint4 *>(a.dst + (size_t)i * a.orow + (size_t)(2 * k0) * 4), *d1 = reinterpret_cast<uint4 *>(a.dst + (size_t)(i + 1) * a.orow + (size_t)(2 * k0) * 4);
-    d0[0] = make_uint4(top[0], top[1], top[2], top[3]); d0[1] = make_uint4(top[4], top[5], top[6], top[7]);
-    d1[0] = make_uint4(bot[0], bot[1], bot[2], bot[3]); d1[1] = make_uint4(bot[4], bot[5], bot[6], bot[7]);
-  }
-}
-
-// ---- the same cells for launches that fill the device (batches of tracks, 4K frames): k_yuv420p_to_rgb16 ---------------------------
-// profiles/r02/k2_pmc.md: k_yuv420p_to_rgb4 on the 16-frame batch spends 58 VALU operations and 9.3 LDS gathers per pixel, 53 % of its
-// LDS cycles are bank conflicts (random indices into 256-entry tables: ~3.5 lanes of every 32 meet on a bank).  This kernel keeps the
-// cell arithmetic (same bytes) and changes what is around it:
-//   * tables in SIXTEEN interleaved copies (entry i of copy c at slot 16 i + c; lane uses copy lane & 15): a copy owns 2 of the 32
-//     banks and is used by 2 lanes of a half-wave, so a gather costs at most 2 LDS cycles per half instead of ~3.5;
-//   * {R_Cr, G_Cr}[v] and {G_Cb, B_Cb}[u] as 8-byte entries: 3 table gathers per pixel instead of 5 (the left pixels of a quad share
-//     their U pair: 11 per 2 x 2 quad);
-//   * CLAMP0255f + gamma LUT as ONE table indexed by (sum >> 16) + kY16Bias (RGB_Y carries the bias): no clamp instructions;
-//   * CLAMP16_240 / the 0..255 clamp as one v_med3, / 3 as a multiply-shift, chroma bytes taken by SDWA operands.
-// 139 KB of tables per workgroup, so a workgroup is 1024 threads, one per CU, persistent over the cells (dealt out round-robin over the whole grid).
-// Cells near the frame edges go through yuv420_cell() as before.
-constexpr int kY16Bias = 320, kY16Lut = 896;        // (sum >> 16) of every table set lies in [-320, 575] (checked on the host per launch)
-constexpr int kY16OffLut = 0, kY16OffTy = kY16Lut * 64, kY16OffRG = kY16OffTy + 16384, kY16OffGB = kY16OffRG + 32768, kY16OffTab = kY16OffGB + 32768,
-              kY16OffLut8 = kY16OffTab + 5 * 1024, kY16Lds = kY16OffLut8 + 256;     // the table bases travel in the per-lane copy offsets, the LUT sits at 0
-template <int ORDER, bool LUT>
-__global__ __launch_bounds__(1024) void k_yuv420p_to_rgb16(YuvArgs a, Lut8 lut, YuvBatch bt, int nframes) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t *s_ty = reinterpret_cast<uint32_t *>(smem + kY16OffTy);
-  uint2 *s_rg = reinterpret_cast<uint2 *>(smem + kY16OffRG), *s_gb = reinterpret_cast<uint2 *>(smem + kY16OffGB);
-  uint32_t *s_lx = reinterpret_cast<uint32_t *>(smem + kY16OffLut);
-  int32_t *s_tab = reinterpret_cast<int32_t *>(smem + kY16OffTab);
-  uint8_t *s_lut = smem + kY16OffLut8;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 5 * 256; i += 1024) s_tab[i] = a.tables[i];
-  stage_lut(s_lut, lut);
-  __syncthreads();
-  const int clo = a.clamped ? 16 : 0, chi = a.clamped ? 240 : 255;
-  for (int i = tid; i < 256 * 16; i += 1024) {
-    const int e = i >> 4;
-    s_ty[i] = (uint32_t)(s_tab[e] + (kY16Bias << 16));
-    const int ec = e < clo ? clo : e > chi ? chi : e;                                   // CLAMP16_240 / 0..255 of the blended chroma, folded into the index
-    s_rg[i] = make_uint2((uint32_t)s_tab[256 + ec], (uint32_t)s_tab[768 + ec]);        // R_Cr, G_Cr (indexed by V)
-    s_gb[i] = make_uint2((uint32_t)s_tab[512 + ec], (uint32_t)s_tab[1024 + ec]);       // G_Cb, B_Cb (indexed by U)
-  }
-  for (int i = tid; i < kY16Lut * 16; i += 1024) {
-    const int e = (i >> 4) - kY16Bias, cl = e < 0 ? 0 : e > 255 ? 255 : e;
-    s_lx[i] = a.use_lut ? s_lut[cl] : (uint32_t)cl;
-  }
-  __syncthreads();
-  YuvCtx c;
-  c.ty = s_tab; c.rcr = s_tab + 256; c.gcb = s_tab + 512; c.gcr = s_tab + 768; c.bcb = s_tab + 1024;
-  c.lut = s_lut; c.lut16 = nullptr; c.clamped = a.clamped; c.lowq = false; c.use_lut = a.use_lut; c.opsize = 4; c.order = ORDER;
-  const int hw = a.width >> 1, ncg = (hw + 3) >> 2;
-  const int npairs = (a.height - 1) / 2;
-  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
-  const int total = nunits * nframes;
-  const uint32_t zmagic = (uint32_t)(((1ull << 32) + (uint32_t)nunits - 1u) / (uint32_t)nunits);   // ul / nunits == umulhi(ul, zmagic) for ul < 64 * nunits, 2 <= nunits < 8192
-  const uint32_t c4 = (uint32_t)(tid & 15) * 4u, c4y = c4 + kY16OffTy, c8v = c4 * 2u + kY16OffRG, c8u = c4 * 2u + kY16OffGB;
-  typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
-  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-  typedef const __attribute__((address_space(3))) u32x2v *lds_u64;
-  // A thread walks its cells with the loads of the NEXT cell issued before the arithmetic of the current one (16 waves per CU hide little latency by themselves).
-  // Cells (unit, column group) are numbered linearly over the whole launch and dealt out round-robin to ALL threads of the grid: with a static
-  // (unit -> workgroup quarter, column group -> lane) split 16 of every 256 lanes had no column group at 1080p (96 of 256 at 1280 wide) and the workgroups
-  // got 8 or 9 units.  At 16 x 1080p both splits measure the same (53.2 us, A / B on one box): the launch is bound by the LDS gathers, not by lane-time.
-  struct Cell { uint2 ya, yb; uint32_t u0m, u0c, u0p, u1c, u1p, v0c, v0p, v1m, v1c, v1p, lv2; int z, unit, k0; bool valid, fast; };
-  const uint32_t cstep = gridDim.x * 1024u;
-  const int dul = (int)(cstep / (uint32_t)ncg), dcg = (int)(cstep - (uint32_t)dul * (uint32_t)ncg);      // one step of a thread in (unit, column group) terms
-  auto fetch = [&](int ul, int cg) -> Cell {
+  struct Cell { ywin_t ya, yb; win_t u0, u1, v0, v1; uint32_t lv2; int unit, k0; bool valid, fast; };
+  auto fetch = [&](uint32_t idx) -> Cell {
     Cell q;
-    q.valid = ul < total;
-    q.fast = false;
-    if (!q.valid) return q;
-    q.z = (int)__umulhi((uint32_t)ul, zmagic); q.unit = ul - q.z * nunits; q.k0 = 4 * cg;
+    uint32_t unit = __umulhi(idx, cgmagic);                  // floor magic: the quotient or one less
+    uint32_t cg = idx - unit * (uint32_t)ncg;
+    if (cg >= (uint32_t)ncg) { cg -= ncg; unit++; }
+    q.unit = (int)unit; q.k0 = NC * (int)cg;
+    q.valid = unit < (uint32_t)nunits;
     const int i = 2 * q.unit - 1, r = i >> 1;
-    q.fast = q.unit >= 1 && q.unit <= npairs && q.k0 + 4 <= hw && (long)(r + 1) * a.us + q.k0 + 8 <= a.usize &&
-             (long)(r + 1) * a.vs + q.k0 + 8 <= a.vsize;
-    if (!q.fast) return q;
-    const uint8_t *py = bt.y[q.z], *pu = bt.u[q.z], *pv = bt.v[q.z];
-    q.ya = *reinterpret_cast<const uint2 *>(py + (size_t)i * a.ys + 2 * q.k0); q.yb = *reinterpret_cast<const uint2 *>(py + (size_t)(i + 1) * a.ys + 2 * q.k0);
-    const uint8_t *ur = pu + (size_t)r * a.us + q.k0, *vr = pv + (size_t)r * a.vs + q.k0;
-    q.u0c = *reinterpret_cast<const uint32_t *>(ur); q.u0p = *reinterpret_cast<const uint32_t *>(ur + 4);
-    q.u1c = *reinterpret_cast<const uint32_t *>(ur + a.us); q.u1p = *reinterpret_cast<const uint32_t *>(ur + a.us + 4);
-    q.v0c = *reinterpret_cast<const uint32_t *>(vr); q.v0p = *reinterpret_cast<const uint32_t *>(vr + 4);
-    q.v1c = *reinterpret_cast<const uint32_t *>(vr + a.vs); q.v1p = *reinterpret_cast<const uint32_t *>(vr + a.vs + 4);
-    // the sample left of the group: column k0 - 1, or for the first group the reference's k == 0 case: lu1 = U[r][0], lv1 = V[r][0] (:3447-3452)
-    if (q.k0) { q.u0m = *reinterpret_cast<const uint32_t *>(ur - 4); q.v1m = *reinterpret_cast<const uint32_t *>(vr + a.vs - 4); }
-    else { q.u0m = q.u0c << 24; q.v1m = q.v0c << 24; }
-    q.lv2 = pv[(size_t)(r + 1) * a.vs];                                     // PV(r + 1, 0): the reference's constant "last" sample
+    q.fast = q.valid && q.unit >= 1 && q.unit <= npairs && q.k0 + NC <= hw && (long)(r + 1) * a.us + q.k0 + (long)sizeof(win_t) <= a.usize &&
+             (long)(r + 1) * a.vs + q.k0 + (long)sizeof(win_t) <= a.vsize;
+    q.ya = q.yb = 0; q.u0 = q.u1 = q.v0 = q.v1 = 0; q.lv2 = 0;
+    if (q.fast) {
+      auto ld = [](const uint8_t *p) -> win_t { win_t w; __builtin_memcpy(&w, p, sizeof(win_t)); return w; };
+      q.ya = *reinterpret_cast<const ywin_t *>(a.y + (size_t)i * a.ys + 2 * q.k0); q.yb = *reinterpret_cast<const ywin_t *>(a.y + (size_t)(i + 1) * a.ys + 2 * q.k0);
+      const uint8_t *ur = a.u + (size_t)r * a.us + q.k0, *vr = a.v + (size_t)r * a.vs + q.k0;
+      const int o = q.k0 ? 1 : 0;                             // the first group has no sample on its left: fixed up where the cell is computed
+      q.u0 = ld(ur - o); q.u1 = ld(ur + a.us - o); q.v0 = ld(vr - o); q.v1 = ld(vr + a.vs - o);
+      q.lv2 = a.v[(size_t)(r + 1) * a.vs];                    // PV(r + 1, 0): the reference's constant "last" sample
+    }
     return q;
   };
-  // sample j = -1 .. 4 of a chroma row held as [m.b3 | c.b0..b3 | p.b0]
-  auto at6 = [](uint32_t m, uint32_t cc, uint32_t pp, int j) -> uint32_t { return j < 0 ? (m >> 24) : j < 4 ? ((cc >> (8 * j)) & 0xFF) : (pp & 0xFF); };
-  // (2a + b) / 3 resp. (a + 2b) / 3 on doubled sums, clamped, as the byte offset of the 8-byte table entry: (int)(s / 3. + .5) == (s + 1) / 3
-  // -> LDS byte address of the 8-byte table entry (the clamp lives in the table, the copy and table offsets in cbase)
-  auto blend = [&](uint32_t s1, uint32_t s2, uint32_t cbase) -> uint32_t { return ((__umul24(s1 + (s2 >> 1) + 1u, 43691u) >> 17) << 7) + cbase; };
+  const uint32_t stride = gridDim.x * (uint32_t)nth;
+  uint32_t idx = blockIdx.x * (uint32_t)nth + (uint32_t)tid;
+  Cell cur = fetch(idx);
+  // tables: RGB_Y as is, {R_Cr, G_Cr}[v] and {G_Cb, B_Cb}[u] as 8-byte entries indexed by the UNCLAMPED blended chroma
+  {
+    uint32_t *s_ty = reinterpret_cast<uint32_t *>(smem + kYsOffTy);
+    uint2 *s_rg = reinterpret_cast<uint2 *>(smem + kYsOffRG), *s_gb = reinterpret_cast<uint2 *>(smem + kYsOffGB);
+    const int clo = a.clamped ? 16 : 0, chi = a.clamped ? 240 : 255;
+    // 256 entries x 3 tables over the workgroup's groups of 256 threads; every load of a thread is issued before its first LDS write
+    const int e = tid & 255, grp = tid >> 8, ngr = nth >> 8;
+    const int ec = e < clo ? clo : e > chi ? chi : e;       // CLAMP16_240 (16 below 16, 240 from 0xF0 up) / 0..255; the blend itself never leaves 0..255
+    const bool d0 = grp == 0, d1 = grp == 1 % ngr, d2 = grp == 2 % ngr;
+    uint32_t t_y = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+    if (d0) t_y = (uint32_t)a.tables[e];
+    if (d1) { t_a = (uint32_t)a.tables[256 + ec]; t_b = (uint32_t)a.tables[768 + ec]; }
+    if (d2) { t_c = (uint32_t)a.tables[512 + ec]; t_d = (uint32_t)a.tables[1024 + ec]; }
+    if (d0) s_ty[e] = t_y;
+    if (d1) s_rg[e] = make_uint2(t_a, t_b);
+    if (d2) s_gb[e] = make_uint2(t_c, t_d);
+    if (LUT) { const int t2 = nth - 1 - tid; if (t2 < 64) reinterpret_cast<uint32_t *>(smem + kYsOffLut)[t2] = lut.w[t2]; }
+  }
+  __syncthreads();
+  typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+  typedef const __attribute__((address_space(3))) uint8_t *lds_u8;
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) u32x2v *lds_u64;
+  const uint32_t sbase = (uint32_t)(uintptr_t)smem;
+  // sample j = -1 .. NC of a chroma row window, luma byte j = 0 .. 2 NC - 1
+  auto at = [](win_t w, int j) -> uint32_t { return (uint32_t)(w >> (8 * (j + 1))) & 0xFFu; };
+  auto yat = [](ywin_t w, int j) -> uint32_t { return (uint32_t)(w >> (8 * j)) & 0xFFu; };
+  // (2a + b) / 3 on doubled sums, (int)(s / 3. + .5) == (s + 1) / 3 == (s + 1) * 43691 >> 17 for s < 2^15, as the LDS address of the 8-byte table entry
+  auto blend = [&](uint32_t s1, uint32_t s2, uint32_t base) -> uint32_t { return ((__umul24(s1 + (s2 >> 1) + 1u, 43691u) >> 17) << 3) + base; };
+  const uint32_t bu = sbase + kYsOffGB, bv = sbase + kYsOffRG;
   auto pixel = [&](uint32_t yv, uint32_t ua, uint32_t va) -> uint32_t {
-    const uint32_t yy = *(lds_u32)(uintptr_t)((yv << 6) + c4y);
+    const uint32_t yy = *(lds_u32)(uintptr_t)(sbase + kYsOffTy + (yv << 2));
     const u32x2v rg = *(lds_u64)(uintptr_t)va, gb = *(lds_u64)(uintptr_t)ua;
-    const uint32_t sr = yy + rg.x, sg = yy + gb.x + rg.y, sb = yy + gb.y;
-    uint32_t r_, g_, b_;
+    const int sr = (int)(yy + rg.x), sg = (int)(yy + gb.x + rg.y), sb = (int)(yy + gb.y);
+    uint32_t r_ = (uint32_t)min(max(sr >> 16, 0), 255), g_ = (uint32_t)min(max(sg >> 16, 0), 255), b_ = (uint32_t)min(max(sb >> 16, 0), 255);
     if (LUT) {
-      r_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sr >> 10) & 0xFFC0u) | c4));
-      g_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sg >> 10) & 0xFFC0u) | c4));
-      b_ = *(lds_u32)(uintptr_t)(kY16OffLut + (((sb >> 10) & 0xFFC0u) | c4));
-    } else {            // no gamma LUT: CLAMP0255f alone is one v_med3 per channel instead of an LDS gather (half of the kernel's gathers)
-      r_ = (uint32_t)min(max((int)(sr >> 16) - kY16Bias, 0), 255);
-      g_ = (uint32_t)min(max((int)(sg >> 16) - kY16Bias, 0), 255);
-      b_ = (uint32_t)min(max((int)(sb >> 16) - kY16Bias, 0), 255);
+      r_ = *(lds_u8)(uintptr_t)(sbase + kYsOffLut + r_); g_ = *(lds_u8)(uintptr_t)(sbase + kYsOffLut + g_); b_ = *(lds_u8)(uintptr_t)(sbase + kYsOffLut + b_);
     }
     // two byte permutes per pixel (selector 0x0C = 0x00, 0x0D = 0xFF: the alpha byte costs nothing)
     if (ORDER == 0) return __builtin_amdgcn_perm(b_, __builtin_amdgcn_perm(g_, r_, 0x0C0C0400u), 0x0D040100u);
     if (ORDER == 1) return __builtin_amdgcn_perm(r_, __builtin_amdgcn_perm(g_, b_, 0x0C0C0400u), 0x0D040100u);
     return __builtin_amdgcn_perm(b_, __builtin_amdgcn_perm(g_, r_, 0x0C04000Du), 0x04020100u);
   };
-  const uint32_t idx0 = blockIdx.x * 1024u + (uint32_t)tid;
-  int ul = (int)(idx0 / (uint32_t)ncg), cg = (int)(idx0 - (uint32_t)ul * (uint32_t)ncg);
-  Cell cur = fetch(ul, cg);
   while (cur.valid) {
-    ul += dul; cg += dcg;
-    if (cg >= ncg) { cg -= ncg; ul++; }
-    const Cell nxt = fetch(ul, cg);
+    idx += stride;
+    const Cell nxt = fetch(idx);
     if (!cur.fast) {
-      YuvArgs f = a;
-      f.y = bt.y[cur.z]; f.u = bt.u[cur.z]; f.v = bt.v[cur.z]; f.dst = bt.dst[cur.z];
-      for (int k = cur.k0; k < cur.k0 + 4 && k < hw; k++) yuv420_cell(f, c, cur.unit, k, hw, npairs);
+      // the paired tables hold tables[clamp(e)]: the cell clamps its index before the lookup, and the clamp is idempotent
+      YuvCtx c;
+      const int32_t *t32 = reinterpret_cast<const int32_t *>(smem);
+      c.ty = t32 + kYsOffTy / 4; c.rcr = t32 + kYsOffRG / 4; c.gcr = t32 + kYsOffRG / 4 + 1; c.gcb = t32 + kYsOffGB / 4; c.bcb = t32 + kYsOffGB / 4 + 1; c.cs = 2;
+      c.lut = smem + kYsOffLut; c.lut16 = nullptr; c.clamped = a.clamped; c.lowq = false; c.use_lut = LUT; c.opsize = 4; c.order = ORDER;
+      for (int k = cur.k0; k < cur.k0 + NC && k < hw; k++) yuv420_cell(a, c, cur.unit, k, hw, npairs);
     } else {
-      const int i = 2 * cur.unit - 1;
-      uint32_t top[8], bot[8];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t u_rk = at6(0, cur.u0c, 0, j), v_rk = at6(0, cur.v0c, 0, j), v_r1k = at6(0, cur.v1c, 0, j);
-        const uint32_t yw0 = j < 2 ? cur.ya.x : cur.ya.y, yw1 = j < 2 ? cur.yb.x : cur.yb.y;
-        const uint32_t y00 = (yw0 >> (16 * (j & 1))) & 0xFF, y01 = (yw0 >> (16 * (j & 1) + 8)) & 0xFF;
-        const uint32_t y10 = (yw1 >> (16 * (j & 1))) & 0xFF, y11 = (yw1 >> (16 * (j & 1) + 8)) & 0xFF;
-        // left pixel: U row pair (s, s) -> top == bottom (:3461); V of row r with the previous V of row r + 1, the "last V" frozen at column 0 (:3544)
-        const uint32_t su = u_rk + at6(cur.u0m, cur.u0c, cur.u0p, j - 1);
-        const uint32_t uleft = blend(su, su, c8u);
-        const uint32_t s1v = v_rk + at6(cur.v1m, cur.v1c, cur.v1p, j - 1), s2v = v_r1k + cur.lv2;
-        top[2 * j] = pixel(y00, uleft, blend(s1v, s2v, c8v));
-        bot[2 * j] = pixel(y10, uleft, blend(s2v, s1v, c8v));
-        // right pixel
-        const uint32_t s1u = u_rk + at6(cur.u0m, cur.u0c, cur.u0p, j + 1), s2u = at6(0, cur.u1c, cur.u1p, j) + at6(0, cur.u1c, cur.u1p, j + 1);
-        const uint32_t s1w = v_rk + at6(0, cur.v0c, cur.v0p, j + 1), s2w = v_r1k + at6(cur.v1m, cur.v1c, cur.v1p, j + 1);
-        top[2 * j + 1] = pixel(y01, blend(s1u, s2u, c8u), blend(s1w, s2w, c8v));
-        bot[2 * j + 1] = pixel(y11, blend(s2u, s1u, c8u), blend(s2w, s1w, c8v));
+      win_t u0 = cur.u0, u1 = cur.u1, v0 = cur.v0, v1 = cur.v1;
+      if (!cur.k0) {
+        // first group: the reference's k == 0 case takes U[r][0] / V[r][0] as the samples left of the group (:3447-3452)
+        u0 = (u0 << 8) | (u0 & 0xFF); u1 = u1 << 8; v1 = (v1 << 8) | (v0 & 0xFF); v0 = v0 << 8;
       }
-      uint8_t *dst = bt.dst[cur.z];
-      uint4 *d0 = reinterpret_cast<uint4 *>(dst + (size_t)i * a.orow + (size_t)(2 * cur.k0) * 4), *d1 = reinterpret_cast<uint4 *>(dst + (size_t)(i + 1) * a.orow + (size_t)(2 * cur.k0) * 4);
-      // non-temporal: written once, not read back by this launch (the same change bought 1.3 % on the chain kernel, profiles/r02/ring_experiment.md)
-      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-      u32x4s *e0 = reinterpret_cast<u32x4s *>(d0), *e1 = reinterpret_cast<u32x4s *>(d1);
-      const u32x4s t0 = {top[0], top[1], top[2], top[3]}, t1 = {top[4], top[5], top[6], top[7]}, b0 = {bot[0], bot[1], bot[2], bot[3]}, b1 = {bot[4], bot[5], bot[6], bot[7]};
-      __builtin_nontemporal_store(t0, e0); __builtin_nontemporal_store(t1, e0 + 1);
-      __builtin_nontemporal_store(b0, e1); __builtin_nontemporal_store(b1, e1 + 1);
+      uint32_t top[2 * NC], bot[2 * NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        const uint32_t u_rk = at(u0, j), v_rk = at(v0, j), v_r1k = at(v1, j);
+        // left pixel: U row pair (s, s) -> top == bottom (:3461); V of row r with the previous V of row r + 1, the "last V" frozen at column 0 (:3544)
+        const uint32_t su = u_rk + at(u0, j - 1);
+        const uint32_t uleft = blend(su, su, bu);
+        const uint32_t s1v = v_rk + at(v1, j - 1), s2v = v_r1k + cur.lv2;
+        top[2 * j] = pixel(yat(cur.ya, 2 * j), uleft, blend(s1v, s2v, bv));
+        bot[2 * j] = pixel(yat(cur.yb, 2 * j), uleft, blend(s2v, s1v, bv));
+        // right pixel
+        const uint32_t s1u = u_rk + at(u0, j + 1), s2u = at(u1, j) + at(u1, j + 1);
+        const uint32_t s1w = v_rk + at(v0, j + 1), s2w = v_r1k + at(v1, j + 1);
+        top[2 * j + 1] = pixel(yat(cur.ya, 2 * j + 1), blend(s1u, s2u, bu), blend(s1w, s2w, bv));
+        bot[2 * j + 1] = pixel(yat(cur.yb, 2 * j + 1), blend(s2u, s1u, bu), blend(s2w, s1w, bv));
+      }
+      uint8_t *d0 = a.dst + (size_t)(2 * cur.unit - 1) * a.orow + (size_t)(2 * cur.k0) * 4, *d1 = d0 + a.orow;
+      if (NC == 1) {
+        *reinterpret_cast<uint2 *>(d0) = make_uint2(top[0], top[1]); *reinterpret_cast<uint2 *>(d1) = make_uint2(bot[0], bot[1]);
+      } else {
+        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+        u32x4s *e0 = reinterpret_cast<u32x4s *>(d0), *e1 = reinterpret_cast<u32x4s *>(d1);
+#pragma unroll
+        for (int q = 0; q < NC / 2; q++) {
+          const u32x4s t = {top[4 * q], top[4 * q + 1], top[4 * q + 2], top[4 * q + 3]}, b = {bot[4 * q], bot[4 * q + 1], bot[4 * q + 2], bot[4 * q + 3]};
+          e0[q] = t; e1[q] = b;
+        }
+      }
     }
     cur = nxt;
   }
@@ -422,6 +353,32 @@ __global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut, 
 
 using namespace lgpu;
 
+// launch shape of k_yuv420p_to_rgb_s: chroma columns per cell (1, 2, 4; 0 = never take that form), threads per workgroup, resident 256-thread groups per CU.
+// Defaults from profiles/r03/k2_forms.txt; LGPU_YUV_S_NC / _BLOCK / _WGS at first use or lgpu_yuv420_tuning() (tests walk every cell width) override them.
+struct YuvTuning { std::atomic<int> nc{2}, block{512}, wgs{8}; };
+static YuvTuning &yuv_tuning() {
+  static YuvTuning t;
+  static std::atomic<bool> init{false};
+  if (!init.load()) {
+    const char *e;
+    if ((e = getenv("LGPU_YUV_S_NC"))) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) t.nc = v; }
+    if ((e = getenv("LGPU_YUV_S_BLOCK"))) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.block = v; }
+    if ((e = getenv("LGPU_YUV_S_WGS"))) { const int v = atoi(e); if (v >= 1) t.wgs = v; }
+    init = true;
+  }
+  return t;
+}
+extern "C" int lgpu_yuv420_tuning(int cell_columns, int block, int groups_per_cu) {
+  YuvTuning &t = yuv_tuning();
+  LGPU_REQUIRE(cell_columns == -1 || cell_columns == 0 || cell_columns == 1 || cell_columns == 2 || cell_columns == 4, "cell_columns is 0 (off), 1, 2 or 4 (-1 keeps it)");
+  LGPU_REQUIRE(block == -1 || block == 256 || block == 512 || block == 1024, "block is 256, 512 or 1024 (-1 keeps it)");
+  LGPU_REQUIRE(groups_per_cu == -1 || groups_per_cu >= 1, "groups_per_cu >= 1 (-1 keeps it)");
+  if (cell_columns >= 0) t.nc = cell_columns;
+  if (block > 0) t.block = block;
+  if (groups_per_cu > 0) t.wgs = groups_per_cu;
+  return LGPU_OK;
+}
+
 static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uint8_t *v_d, const int istrides[3],
                                long u_size, long v_size, uint8_t *dst_d, int orow, int width, int height,
                                int opsize, int out_order, int is_422, int which_tables, int pb_quality,
@@ -454,83 +411,48 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   const Lut8 l = pack_lut(lut8);
   const int units = is_422 ? height : height / 2 + 1;
   // every workgroup stages 5 KB of tables first: a few hundred workgroups that each walk several row pairs, not one per row pair
-  static const int gy_cap = getenv("LGPU_YUV_GY") ? atoi(getenv("LGPU_YUV_GY")) : 2048;
-  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > gy_cap ? gy_cap : units), (unsigned)nbatch);
+  dim3 grid(cdiv((unsigned)(width >> 1), kBlock), (unsigned)(units > 2048 ? 2048 : units), (unsigned)nbatch);
   YuvBatch none = {};
   const YuvBatch &bt = batch ? *batch : none;
-  static const bool classic = getenv("LGPU_YUV_CLASSIC") != nullptr;
-  bool wide = !is_422 && !classic && opsize == 4 && (a.ys & 7) == 0 && (a.us & 3) == 0 && (a.vs & 3) == 0 && (orow & 15) == 0;
-  for (int f = 0; f < nbatch && wide; f++) {
-    const uintptr_t py = (uintptr_t)(batch ? batch->y[f] : y_d), pu = (uintptr_t)(batch ? batch->u[f] : u_d), pv = (uintptr_t)(batch ? batch->v[f] : v_d),
-                    pd = (uintptr_t)(batch ? batch->dst[f] : dst_d);
-    wide = (py & 7) == 0 && (pu & 3) == 0 && (pv & 3) == 0 && (pd & 15) == 0;
+  // aligned rows, 4-byte pixels, no LUT16, not the LOW quality setting: the paired-table form; everything else the one-cell-per-lane kernels
+  const YuvTuning &tn = yuv_tuning();
+  const int s_nc = tn.nc.load(), s_block = tn.block.load(), s_wgs = tn.wgs.load();
+  bool form_s = !is_422 && s_nc && opsize == 4 && !lut16_d && !a.low_quality && (a.ys & (2 * s_nc - 1)) == 0 && (orow & (s_nc == 1 ? 7 : 15)) == 0 && nbatch <= 65535;
+  for (int f = 0; f < nbatch && form_s; f++) {
+    const uintptr_t py = (uintptr_t)(batch ? batch->y[f] : y_d), pd = (uintptr_t)(batch ? batch->dst[f] : dst_d);
+    form_s = (py & (2 * s_nc - 1)) == 0 && (pd & (s_nc == 1 ? 7 : 15)) == 0;
   }
-  // one lane per four columns means a quarter of the lanes: only worth it when the launch still fills the device (a batch of tracks, or a
-  // frame of 4K and up); a single 1080p frame keeps the one-column form (measured 13 vs 18 us)
-  const dim3 g4x(cdiv((unsigned)((width >> 1) + 3) / 4, kBlock), grid.y, grid.z);
-  if (wide && (unsigned long long)g4x.x * g4x.y * g4x.z < 2048ull && !getenv("LGPU_YUV_WIDE") && !getenv("LGPU_YUV_FORCE16")) wide = false;
-  // launches that fill the device take the 16-copy-table kernel (one 1024-thread workgroup per CU, 139 KB of tables each)
-  static const bool no16 = getenv("LGPU_YUV_NO16") != nullptr;
-  const bool force16 = getenv("LGPU_YUV_FORCE16") != nullptr;            // tests: the 16-copy kernel at any size
-  if (wide && !no16 && !lut16_d && !a.low_quality && units >= 2 && units < 8192 && nbatch <= 64 && (force16 || (unsigned long long)g4x.x * g4x.y * g4x.z * kBlock >= 256ull * 1024ull)) {
-    // the clamp + LUT table covers (sum >> 16) in [-kY16Bias, kY16Lut - kY16Bias): true for the reference's four table sets, checked here
-    static std::atomic<int> range_ok[4];            // 0 unknown, 1 ok, -1 no (host threads race to the same answer: a pure function of the table set)
-    const int w4 = which_tables & 3;
-    if (!range_ok[w4]) {
-      int32_t rgb2yuv[9 * 256], t5[5 * 256];
-      lgpu_conversion_tables(w4, rgb2yuv, t5);
-      long lo = 0, hi = 0;
-      for (int y = 0; y < 256; y++)
-        for (int cidx = 0; cidx < 256; cidx++) {
-          const long yy = t5[y];
-          const long s[4] = {yy + t5[256 + cidx], yy + t5[1024 + cidx], yy + t5[512 + cidx] + t5[768], yy + t5[512 + cidx] + t5[768 + 255]};
-          for (long v : s) { if ((v >> 16) < lo) lo = v >> 16; if ((v >> 16) > hi) hi = v >> 16; }
-        }
-      long gmin = 0, gmax = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
-      for (int cidx = 0; cidx < 256; cidx++) {
-        if (t5[512 + cidx] < a2) a2 = t5[512 + cidx];
-        if (t5[512 + cidx] > b2) b2 = t5[512 + cidx];
-        if (t5[768 + cidx] < a3) a3 = t5[768 + cidx];
-        if (t5[768 + cidx] > b3) b3 = t5[768 + cidx];
-      }
-      gmin = (a2 + a3) >> 16; gmax = ((long)t5[255] + b2 + b3) >> 16;
-      if (gmin < lo) lo = gmin;
-      if (gmax > hi) hi = gmax;
-      range_ok[w4] = (lo >= -kY16Bias && hi < kY16Lut - kY16Bias) ? 1 : -1;
-    }
-    if (range_ok[w4] == 1) {
-      static std::atomic<int> g_cus_dev[16];          // CU count per device ordinal
+  if (form_s) {
+    const int hw = width >> 1, ncg = (hw + s_nc - 1) / s_nc;
+    const int npairs_h = (height - 1) / 2, nunits_h = 1 + npairs_h + (((height - 1) & 1) ? 1 : 0);
+    const unsigned long long cells = (unsigned long long)ncg * nunits_h;
+    if (cells < (1ull << 31)) {
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ncg - (ncg == 1 ? 1 : 0));
+      // at most s_wgs x 256 threads per CU over the whole launch: a thread walks its cells with a grid stride
+      static std::atomic<int> s_cus_dev[16];
       int dev = 0;
       LGPU_HIP(hipGetDevice(&dev));
-      int g_cus = g_cus_dev[dev & 15].load();
-      if (!g_cus) { hipDeviceProp_t prop; LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; g_cus_dev[dev & 15].store(g_cus); }
-      YuvBatch one = {};
-      if (!batch) { one.y[0] = y_d; one.u[0] = u_d; one.v[0] = v_d; one.dst[0] = dst_d; }
-      const YuvBatch &b16 = batch ? *batch : one;
-      const int total = units * nbatch;
-      int g16 = (total + 3) / 4;
-      if (g16 > g_cus) g16 = g_cus;
-#define Y16_LAUNCH(ORDER_)                                                                                                             \
+      int cus = s_cus_dev[dev & 15].load();
+      if (!cus) { hipDeviceProp_t prop; LGPU_HIP(hipGetDeviceProperties(&prop, dev)); cus = prop.multiProcessorCount; s_cus_dev[dev & 15].store(cus); }
+      unsigned gx = (unsigned)((cells + s_block - 1) / s_block);
+      const unsigned cap = (unsigned)std::max(1, (int)((long)cus * s_wgs * 256 / s_block / nbatch));
+      if (gx > cap) gx = cap;
+      const dim3 gs(gx, (unsigned)nbatch);
+#define YS_LAUNCH(NC_, ORDER_)                                                                                                          \
       do {                                                                                                                             \
-        if (a.use_lut) {                                                                                                             \
-          LGPU_HIP(hipFuncSetAttribute((const void *)k_yuv420p_to_rgb16<ORDER_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kY16Lds));  \
-          hipLaunchKernelGGL((k_yuv420p_to_rgb16<ORDER_, true>), dim3((unsigned)g16), dim3(1024), kY16Lds, (hipStream_t)stream, a, l, b16, nbatch); \
-        } else {                                                                                                                     \
-          LGPU_HIP(hipFuncSetAttribute((const void *)k_yuv420p_to_rgb16<ORDER_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kY16Lds));  \
-          hipLaunchKernelGGL((k_yuv420p_to_rgb16<ORDER_, false>), dim3((unsigned)g16), dim3(1024), kY16Lds, (hipStream_t)stream, a, l, b16, nbatch); \
-        }                                                                                                                            \
+        if (a.use_lut) hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, true>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);  \
+        else hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, false>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);        \
       } while (0)
-      if (out_order == 0) Y16_LAUNCH(0); else if (out_order == 1) Y16_LAUNCH(1); else Y16_LAUNCH(2);
-#undef Y16_LAUNCH
+      if (s_nc == 4) { if (out_order == 0) YS_LAUNCH(4, 0); else if (out_order == 1) YS_LAUNCH(4, 1); else YS_LAUNCH(4, 2); }
+      else if (s_nc == 1) { if (out_order == 0) YS_LAUNCH(1, 0); else if (out_order == 1) YS_LAUNCH(1, 1); else YS_LAUNCH(1, 2); }
+      else { if (out_order == 0) YS_LAUNCH(2, 0); else if (out_order == 1) YS_LAUNCH(2, 1); else YS_LAUNCH(2, 2); }
+#undef YS_LAUNCH
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
   }
   if (is_422) hipLaunchKernelGGL(k_yuv422p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
-  else if (wide) {
-    const dim3 g4(cdiv((unsigned)((width >> 1) + 3) / 4, kBlock), grid.y, grid.z);
-    hipLaunchKernelGGL(k_yuv420p_to_rgb4, g4, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
-  } else hipLaunchKernelGGL(k_yuv420p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
+  else hipLaunchKernelGGL(k_yuv420p_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

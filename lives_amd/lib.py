@@ -95,6 +95,7 @@ PROTOTYPES = {
     "lgpu_gamma_apply": [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp],
     "lgpu_alpha_premult": [vp, ci, ci, ci, ci, ci, vp],
     "lgpu_yuv420p_to_rgb": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
+    "lgpu_yuv420_tuning": [ci, ci, ci],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
     "lgpu_alpha_scalers": [vp, vp],

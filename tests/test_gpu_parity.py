@@ -907,49 +907,41 @@ def test_gauss5(gpu, orc, psize):
         assert_same(host(d), want, w, h, psize, "gauss5 %dx%d ps=%d" % (w, h, psize))
 
 
-def test_yuv420p_four_column_kernel(gpu, orc, monkeypatch):
-    """k_yuv420p_to_rgb4 (one lane per four chroma columns; chosen for batches / 4K frames) forced on small frames: same bytes as the oracle,
-    including the cells it hands back to the one-column walk (row 0, trailing row, first / partial column groups, plane ends)"""
-    monkeypatch.setenv("LGPU_YUV_WIDE", "1")
-    rng = np.random.default_rng(3400)
-    for which in range(4):
-        for quality in (1, 2):
-            for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 19, 160, 80), (24, 6, 32, 16), (640, 480, 640, 320)]:
-                lut = lut_for(rng, "l2s")
-                Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
-                U = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
-                V = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
-                orow = align(w * 4)
-                strides = (ctypes.c_int * 3)(ys, cs, cs)
-                want = np.full((h, orow), 0xAB, np.uint8)
-                orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, 0, 0, which, quality, P(lut), 0)
-                d = dev(np.full_like(want, 0xAB))
-                gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, which_tables=which, pb_quality=quality, lut=lut)
-                assert_same(host(d), want, w, h, 4, "yuv420p wide %dx%d which=%d q=%d" % (w, h, which, quality))
+@pytest.fixture
+def yuv_tuning():
+    from lives_amd.lib import load
+    lib = load()
+    yield lambda nc=-1, block=-1, wgs=-1: lib.lgpu_yuv420_tuning(nc, block, wgs)
+    lib.lgpu_yuv420_tuning(2, 512, 8)
 
 
-def test_yuv420p_sixteen_copy_table_kernel(gpu, orc, monkeypatch):
-    """k_yuv420p_to_rgb16 (what batches of tracks and 4K frames take: tables in 16 interleaved LDS copies, clamp + LUT as one table,
-    8-byte chroma entries) forced on small frames: same bytes as the oracle for the four table sets, the three byte orders, with and
-    without the gamma LUT, unaligned plane ends, and for a batch of frames in one launch"""
-    monkeypatch.setenv("LGPU_YUV_FORCE16", "1")
-    rng = np.random.default_rng(3450)
-    for which in range(4):
-        for order in (0, 1, 2):
-            for use_lut in (0, 1):
-                for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 19, 160, 80), (24, 6, 32, 16), (640, 480, 640, 320), (1920, 64, 1920, 960)]:
-                    lut = lut_for(rng, "l2s") if use_lut else None
-                    Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
-                    U = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
-                    V = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
-                    orow = align(w * 4)
-                    strides = (ctypes.c_int * 3)(ys, cs, cs)
-                    want = np.full((h, orow), 0xAB, np.uint8)
-                    orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, order, 0, which, 2, P(lut) if use_lut else None, 0)
-                    d = dev(np.full_like(want, 0xAB))
-                    gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, out_order=order, which_tables=which, pb_quality=2, lut=lut)
-                    assert_same(host(d), want, w, h, 4, "yuv420p 16-copy %dx%d which=%d order=%d lut=%d" % (w, h, which, order, use_lut))
-    # extreme samples: every (y, u, v) corner reaches the ends of the clamp + LUT table
+@pytest.mark.parametrize("nc", [0, 1, 2, 4])
+def test_yuv420p_every_cell_width(gpu, orc, yuv_tuning, nc):
+    """k_yuv420p_to_rgb_s with cells of 1 / 2 / 4 chroma columns (and switched off: the one-column kernel for everything), three workgroup sizes,
+    a grid capped at one group per CU (every thread walks several cells): same bytes as the oracle for the four table sets, the three byte orders,
+    with and without the gamma LUT, including the cells handed to the one-column walk (row 0, the trailing row, partial column groups, plane ends)"""
+    rng = np.random.default_rng(3400 + nc)
+    for (block, wgs) in [(256, 8), (512, 1), (1024, 1)]:
+        assert yuv_tuning(nc, block, wgs) == 0
+        for which in range(4):
+            for order in (0, 1, 2):
+                for use_lut in (0, 1):
+                    for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 19, 160, 80), (24, 6, 32, 16), (2, 2, 8, 4), (6, 3, 8, 4), (640, 480, 640, 320), (1920, 64, 1920, 960)]:
+                        if (which, order, use_lut) != (0, 0, 1) and (w, block) not in ((66, 256), (130, 512), (24, 1024)):
+                            continue                    # the full size list once per shape, three sizes for every table set / order / LUT
+                        lut = lut_for(rng, "l2s") if use_lut else None
+                        Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
+                        U = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
+                        V = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
+                        orow = align(w * 4)
+                        strides = (ctypes.c_int * 3)(ys, cs, cs)
+                        want = np.full((h, orow), 0xAB, np.uint8)
+                        orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, order, 0, which, 2, P(lut) if use_lut else None, 0)
+                        d = dev(np.full_like(want, 0xAB))
+                        gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, out_order=order, which_tables=which, pb_quality=2, lut=lut)
+                        assert_same(host(d), want, w, h, 4, "yuv420p nc=%d block=%d %dx%d which=%d order=%d lut=%d" % (nc, block, w, h, which, order, use_lut))
+    # extreme samples: every (y, u, v) corner reaches the ends of the clamps
+    yuv_tuning(nc, 512, 8)
     w, h = 64, 32
     for which in range(4):
         for yv in (0, 16, 235, 255):
@@ -975,7 +967,7 @@ def test_yuv420p_sixteen_copy_table_kernel(gpu, orc, monkeypatch):
         frames.append((Y, U, V, torch.zeros((h, w * 4), dtype=torch.uint8, device="cuda")))
     gpu.yuv420p_to_rgb_batch(frames, w, h, lut=lut)
     torch.cuda.synchronize()
-    monkeypatch.delenv("LGPU_YUV_FORCE16")             # frames of this size take the one-column kernel on their own
+    yuv_tuning(0)
     for (Y, U, V, d) in frames:
         one = torch.zeros_like(d)
         gpu.yuv420p_to_rgb(Y, U, V, one, w, h, lut=lut)

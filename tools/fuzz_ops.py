@@ -17,7 +17,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     import torch
     from lives_amd import ops
-    from lives_amd.lib import LgpuError
+    from lives_amd.lib import LgpuError, load
+    lib = load()
     from oracle import pyoracle as po
     ops.init(0)
     orc = po.oracle()
@@ -273,9 +274,7 @@ def main():
                 Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
                 U, V = (rng.integers(0, 256, (ch, cs), dtype=np.uint8) for _ in range(2))
                 opsz, which, q = int(rng.choice([3, 4])), int(rng.integers(0, 4)), int(rng.choice([1, 2, 3]))
-                os.environ["LGPU_YUV_WIDE"] = "1" if rng.random() < 0.5 else ""
-                if not os.environ["LGPU_YUV_WIDE"]:
-                    del os.environ["LGPU_YUV_WIDE"]
+                lib.lgpu_yuv420_tuning(int(rng.choice([0, 1, 2, 4])), int(rng.choice([256, 512, 1024])), int(rng.choice([1, 8])))
                 orow = (w * opsz + 15) // 16 * 16
                 st = (ctypes.c_int * 3)(ys, cs, cs)
                 want = np.full((h, orow), 0xAB, np.uint8)

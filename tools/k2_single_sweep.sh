@@ -1,8 +1,8 @@
 #!/bin/bash
-# K2 on ONE 1080p frame (BASELINE config 2): back-to-back launch interval against the number of row-pair units a lane walks (LGPU_YUV_GY caps grid.y), then
+# K2 on ONE 1080p frame (BASELINE config 2): back-to-back launch interval of the one-column kernel and of the default form, then
 # rocprofv3 kernel stats + counters of the single-frame kernel
 cd $GRAFT_REPO_ROOT
-for gy in 34 68 136 271 541; do echo "LGPU_YUV_GY=$gy: $(LGPU_YUV_GY=$gy python tools/prof_k2_single.py 2>/dev/null | tail -1)"; done
+echo "one-column kernel (LGPU_YUV_S_NC=0): $(LGPU_YUV_S_NC=0 python tools/prof_k2_single.py 2>/dev/null | tail -1)"
 echo "default: $(python tools/prof_k2_single.py 2>/dev/null | tail -1)"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_k2s; mkdir -p $O
