@@ -52,6 +52,7 @@ struct DeviceTables {
   int32_t *luma;         // [3][256]: 65536-scaled unclamped BT.601 luma weights (libweed/weed-plugin-utils.c:879-895)
 };
 const DeviceTables *device_tables();
+int device_cus();      // CUs of the current device
 
 constexpr int kBlock = 256;   // 4 wavefronts of 64
 

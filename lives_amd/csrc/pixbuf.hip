@@ -854,6 +854,75 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
   }
 }
 
+// =====================================================================================================================================================
+// k_pb_gather -- 4-byte pixels at INTEGER reduction ratios other than 2:1 (3:1, 4:1, ...: one phase for the whole frame), no LDS window and no barrier: a lane
+// owns one destination pixel and reads its taps where they lie (one or two 4-byte-aligned vector loads per tap row; neighbouring lanes' windows overlap in
+// L1), premultiplies them as 16-bit pairs (SDWA) and accumulates two taps per v_dot2_u32_u16 with weight pairs aligned on the FIRST tap.  The weights are
+// wave-uniform: scalar loads, SGPR operands of the dot products.  The loads of tap row t + 1 are issued before the arithmetic of row t.
+// profiles/r03/pb_gather_ab.txt: 4K -> 720p HYPER 18.8 -> 13.3 us, BILINEAR 12.4 -> 8.7, 4K -> 960x540 16.7 -> 11.0 against k_pb_pairs.  With per-lane weights
+// (ratios with several phases; from device memory or from an LDS copy of the table, both built and measured) the same kernel LOSES to the LDS window
+// (4K -> 1706x960 31.4 / 25.6 against 24.7 us, 1080p -> 720p 13.7 / 14.3 against 10.1, enlargements 15-40 % slower): every source pixel is premultiplied once per
+// destination pixel that uses it, and the taps come through L1 at half the LDS rate -- those ratios keep k_pb_pairs.
+// =====================================================================================================================================================
+struct PbGatherArgs {
+  const uint8_t *src;
+  uint8_t *dst;
+  int irow, orow, sw, sh, dw, dh;
+  int x_step, y_step, xoff, yoff;
+  int tx0, ty0, ny_eff;
+};                                     // + gp, device: [16][16][ny_eff][RL] weight pairs (tap tx0 + 2k | tap tx0 + 2k + 1 << 16), zero padded
+typedef pb_u4 pb_u4a __attribute__((aligned(4)));
+typedef pb_u2 pb_u2a __attribute__((aligned(4)));
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A, const uint32_t *__restrict__ gp) {
+  constexpr int RL = NP <= 2 ? 2 : 4;                  // weight dwords per tap row
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + lane, i = blockIdx.y * 4 + wave;
+  if (i >= A.dh) return;
+  const bool live = j < A.dw;
+  const long long x = (long long)(live ? j : A.dw - 1) * A.x_step + A.xoff, y = (long long)i * A.y_step + A.yoff;
+  const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15, ys = (int)(y >> 16) + A.ty0, yph = (int)(y >> 12) & 15;
+  const int p0 = xs + A.tx0;
+  const bool fast = p0 >= 0 && p0 + 2 * NP <= A.sw;
+  const uint32_t *wrow = gp + (uint32_t)((yph * 16 + __builtin_amdgcn_readfirstlane(xph)) * A.ny_eff) * RL;      // the same phase in every lane (host-checked)
+  struct Row { uint32_t q[2 * NP]; uint32_t w[RL]; };
+  auto fetch = [&](int ty) -> Row {
+    Row R;
+    const uint8_t *row = A.src + (size_t)pb_clamp(ys + ty, A.sh - 1) * A.irow;
+    if (fast) {
+      const uint8_t *p = row + 4 * (size_t)p0;
+      if (NP == 1) { const pb_u2 v = *reinterpret_cast<const pb_u2a *>(p); R.q[0] = v.x; R.q[1] = v.y; }
+      else {
+        const pb_u4 v = *reinterpret_cast<const pb_u4a *>(p);
+        R.q[0] = v.x; R.q[1] = v.y; R.q[2] = v.z; R.q[3] = v.w;
+        if (NP == 3) { const pb_u2 u = *reinterpret_cast<const pb_u2a *>(p + 16); R.q[4 % (2 * NP)] = u.x; R.q[5 % (2 * NP)] = u.y; }
+        if (NP == 4) { const pb_u4 u = *reinterpret_cast<const pb_u4a *>(p + 16); R.q[4 % (2 * NP)] = u.x; R.q[5 % (2 * NP)] = u.y; R.q[6 % (2 * NP)] = u.z; R.q[7 % (2 * NP)] = u.w; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2 * NP; k++) R.q[k] = reinterpret_cast<const uint32_t *>(row)[pb_clamp(p0 + k, A.sw - 1)];
+    }
+    if (RL == 2) { const pb_u2 v = *reinterpret_cast<const pb_u2 *>(wrow + ty * RL); R.w[0] = v.x; R.w[1] = v.y; }
+    else { const pb_u4 v = *reinterpret_cast<const pb_u4 *>(wrow + ty * RL); R.w[0] = v.x; R.w[1] = v.y; R.w[2 % RL] = v.z; R.w[3 % RL] = v.w; }
+    return R;
+  };
+  unsigned r = 0, g = 0, b = 0, a = 0;
+  Row cur = fetch(0);
+  for (int ty = 0; ty < A.ny_eff; ty++) {
+    Row nxt = cur;
+    if (ty + 1 < A.ny_eff) nxt = fetch(ty + 1);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const uint32_t q0 = cur.q[2 * k], q1 = cur.q[2 * k + 1], w = cur.w[k];
+      r = pb_dot2(pb_premul_pair<0>(q0, q1), w, r); g = pb_dot2(pb_premul_pair<1>(q0, q1), w, g); b = pb_dot2(pb_premul_pair<2>(q0, q1), w, b);
+      a = pb_dot2(__builtin_amdgcn_perm(q1, q0, 0x0C070C03u), w, a);
+    }
+    cur = nxt;
+  }
+  if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_finish_px<4>(r, g, b, a, false, 0u);
+}
+
 // ---- host: the per-phase weight tables ----------------------------------------------------------------------------------------------------
 struct PbDim { int n; double offset; std::vector<double> w; };   // w[phase * n + tap]
 
@@ -897,7 +966,7 @@ static void pb_fix_sum(int *w, int count, int total) {
 }
 
 struct PbTable { int n_x, n_y, xoff, yoff, uniform_x; int *table_d; std::vector<int> host;
-                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0, nq = 0; uint32_t *pairs_d = nullptr; };      // pairs_d: the k_pb_pairs form of the table (nullptr: a weight needs 17 bits)
+                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0, nq = 0; uint32_t *pairs_d = nullptr; uint32_t *gpairs_d = nullptr; };      // pairs_d: the k_pb_pairs form of the table (nullptr: a weight needs 17 bits)
 static std::mutex g_pb_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, PbTable *> g_pb_tables;   // (device, interp, sw, sh, dw, dh); entries live as long as the library
 
@@ -962,6 +1031,23 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
       LGPU_HIP(hipMalloc((void **)&t->pairs_d, pr.size() * sizeof(uint32_t)));
       LGPU_HIP(hipMemcpy(t->pairs_d, pr.data(), pr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       t->nq = nq;
+      // the same weights as pairs aligned on the first used tap (k_pb_gather: one form, no parity), rows of 2 or 4 dwords
+      const int gnp = (n_eff + 1) / 2;
+      if (gnp <= 4) {
+        const int rl = gnp <= 2 ? 2 : 4;
+        std::vector<uint32_t> gp((size_t)256 * ny_eff * rl, 0u);
+        for (int ph = 0; ph < 256; ph++) {
+          const int *w = t->host.data() + (size_t)ph * nn;
+          for (int ty = 0; ty < ny_eff; ty++)
+            for (int i = 0; i < gnp; i++) {
+              const int t0 = tx0 + 2 * i, t1 = t0 + 1;
+              const uint32_t w0 = (uint32_t)w[(ty0 + ty) * t->n_x + t0], w1 = t1 < tx1 ? (uint32_t)w[(ty0 + ty) * t->n_x + t1] : 0u;
+              gp[((size_t)ph * ny_eff + ty) * rl + i] = w0 | (w1 << 16);
+            }
+        }
+        LGPU_HIP(hipMalloc((void **)&t->gpairs_d, gp.size() * sizeof(uint32_t)));
+        LGPU_HIP(hipMemcpy(t->gpairs_d, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      }
     }
   }
   return LGPU_OK;
@@ -1212,6 +1298,21 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     }
   }
   const bool no_pairs = getenv("LGPU_PB_NO_PAIRS") != nullptr;        // tests: the one-tap-per-operation kernels at any ratio
+  static const bool no_gather = getenv("LGPU_PB_NO_GATHER") != nullptr;
+  // integer reductions (one phase for the whole frame): the barrier-free kernel with scalar weights; every other ratio keeps the LDS window
+  if (channels == 4 && t->gpairs_d && !no_pairs && !no_gather && (x_step & 0xFFFF) == 0 && (y_step & 0xFFFF) == 0) {
+    PbGatherArgs ga;
+    ga.src = src_d; ga.dst = dst_d; ga.irow = irow; ga.orow = orow; ga.sw = sw; ga.sh = sh; ga.dw = dw; ga.dh = dh;
+    ga.x_step = x_step; ga.y_step = y_step; ga.xoff = t->xoff; ga.yoff = t->yoff; ga.tx0 = t->tx0; ga.ty0 = t->ty0; ga.ny_eff = t->ty1 - t->ty0;
+    const int gnp = (t->tx1 - t->tx0 + 1) / 2;
+    const uint32_t *gp = t->gpairs_d;
+    if (gnp == 1) hipLaunchKernelGGL(k_pb_gather<1>, grid, block, 0, st, ga, gp);
+    else if (gnp == 2) hipLaunchKernelGGL(k_pb_gather<2>, grid, block, 0, st, ga, gp);
+    else if (gnp == 3) hipLaunchKernelGGL(k_pb_gather<3>, grid, block, 0, st, ga, gp);
+    else hipLaunchKernelGGL(k_pb_gather<4>, grid, block, 0, st, ga, gp);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
   if (t->pairs_d && !no_pairs) {
     PbPairArgs pa;
     pa.src = src_d; pa.dst = dst_d; pa.irow = irow; pa.orow = orow; pa.sw = sw; pa.sh = sh; pa.dw = dw; pa.dh = dh;

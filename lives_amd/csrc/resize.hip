@@ -1786,8 +1786,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   a.dbg = nullptr;
   a.nt_out = nt_out;
   // persistent grid: as many workgroups as stay resident (two per CU by LDS), each walks its XCD's share of the work list
-  static int g_cus = 0;
-  if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
+  const int g_cus = device_cus();
   a.tiles_x = (dw + kTileW - 1) / kTileW; a.tiles_y = (dh + H8S::kTileH - 1) / H8S::kTileH;
   const int nwork = a.tiles_x * a.tiles_y * ntracks;
   const int mode = g_h8s_opt & 255;                // A / B builds (tools/ab_h8s.py): ablations of k_half8s
@@ -2038,8 +2037,7 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
       if (rc) return rc;
       lds_launch = S2pLds(ap.sht, ap.swt, ap.th, ap.npv, 1).total;
     }
-    static int g_cus = 0;
-    if (!g_cus) { hipDeviceProp_t prop; int dev = 0; LGPU_HIP(hipGetDevice(&dev)); LGPU_HIP(hipGetDeviceProperties(&prop, dev)); g_cus = prop.multiProcessorCount; }
+    const int g_cus = device_cus();
     const int nwork = ap.tiles_x * ap.tiles_y * ap.ntracks;
     int g = (nwork + 7) & ~7;
     if (g > 2 * g_cus) g = (2 * g_cus) & ~7;          // two workgroups per CU by LDS (three or four smaller ones measured slower: 38 / 48 us against 24 for 4K -> 720p)

@@ -90,6 +90,20 @@ const DeviceTables *device_tables() {
   return (d >= 0 && d < 64 && g_inited[d].load(std::memory_order_acquire)) ? &g_tables[d] : nullptr;
 }
 
+// CUs of the current device (persistent grids are sized from it); one property query per device and process
+int device_cus() {
+  static std::atomic<int> cus[64];
+  const int d = current_device();
+  if (d < 0 || d >= 64) return 256;
+  int c = cus[d].load(std::memory_order_relaxed);
+  if (!c) {
+    hipDeviceProp_t prop;
+    c = hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus[d].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
 }  // namespace lgpu
 
 extern "C" {

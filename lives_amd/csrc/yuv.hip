@@ -429,11 +429,7 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
     if (cells < (1ull << 31)) {
       const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ncg - (ncg == 1 ? 1 : 0));
       // at most s_wgs x 256 threads per CU over the whole launch: a thread walks its cells with a grid stride
-      static std::atomic<int> s_cus_dev[16];
-      int dev = 0;
-      LGPU_HIP(hipGetDevice(&dev));
-      int cus = s_cus_dev[dev & 15].load();
-      if (!cus) { hipDeviceProp_t prop; LGPU_HIP(hipGetDeviceProperties(&prop, dev)); cus = prop.multiProcessorCount; s_cus_dev[dev & 15].store(cus); }
+      const int cus = device_cus();
       unsigned gx = (unsigned)((cells + s_block - 1) / s_block);
       const unsigned cap = (unsigned)std::max(1, (int)((long)cus * s_wgs * 256 / s_block / nbatch));
       if (gx > cap) gx = cap;

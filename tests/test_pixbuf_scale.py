@@ -201,6 +201,27 @@ def test_gpu_one_tap_kernels_at_every_ratio(gpu, orc, monkeypatch):
 
 
 @gpu_mark
+def test_gpu_integer_reductions(gpu, orc):
+    """k_pb_gather (4-byte pixels at 3:1, 4:1, ... -- one phase for the whole frame, scalar weights, taps read where they lie): both filters, widths that end
+    inside a wave, frames narrower than a tap row (every lane on the clamped path), mixed integer ratios, translucent / opaque / zero alpha, unaligned halving
+    (what k_pb_half declines)"""
+    rng = np.random.default_rng(0x9DB7)
+    for (sw, sh, dw, dh) in [(384, 216, 128, 72), (390, 219, 130, 73), (1920, 96, 640, 32), (256, 256, 64, 64), (640, 100, 128, 20), (300, 240, 100, 60), (12, 9, 4, 3),
+                             (6, 6, 2, 2), (3, 3, 1, 1), (402, 198, 201, 99), (384, 216, 64, 72)]:
+        for interp in (2, 3):
+            for amode in (0, 1, 2):
+                src = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)
+                if amode == 1:
+                    src[:, 3::4] = 255
+                elif amode == 2:
+                    src[:, 3::4] = rng.choice(np.array([0, 255, 7], np.uint8), (sh, sw))
+                want = np.zeros((dh, dw * 4), np.uint8)
+                assert orc.orc_pixbuf_scale(P(src), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, interp) == 0
+                got = gpu_scale(gpu, src, sw, sh, dw, dh, 4, interp)
+                assert (got == want).all(), "%dx%d->%dx%d interp %d alpha mode %d" % (sw, sh, dw, dh, interp, amode)
+
+
+@gpu_mark
 def test_gpu_strong_reductions(gpu, orc):
     """windows too large for LDS take the direct kernel; ratios past the library's one-step range are refused, the frame untouched"""
     from lives_amd import lib

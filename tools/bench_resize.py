@@ -20,7 +20,10 @@ PIXBUF_CASES = [("pixbuf 3840x2160 -> 1920x1080 HYPER rgba", 3840, 2160, 1920, 1
                 ("pixbuf 3840x2160 -> 1920x1080 NEAREST rgba", 3840, 2160, 1920, 1080, 0, 4), ("pixbuf 3840x2160 -> 1920x1080 HYPER rgb24", 3840, 2160, 1920, 1080, 3, 3),
                 ("pixbuf 3840x2160 -> 1706x960 HYPER rgba", 3840, 2160, 1706, 960, 3, 4), ("pixbuf 3840x2160 -> 1280x720 HYPER rgba", 3840, 2160, 1280, 720, 3, 4),
                 ("pixbuf 1920x1080 -> 3840x2160 HYPER rgba", 1920, 1080, 3840, 2160, 3, 4), ("pixbuf 1920x1080 -> 3840x2160 BILINEAR rgba", 1920, 1080, 3840, 2160, 2, 4),
-                ("pixbuf 1920x1080 -> 1280x720 HYPER rgba", 1920, 1080, 1280, 720, 3, 4)]
+                ("pixbuf 1920x1080 -> 1280x720 HYPER rgba", 1920, 1080, 1280, 720, 3, 4), ("pixbuf 3840x2160 -> 1280x720 BILINEAR rgba", 3840, 2160, 1280, 720, 2, 4),
+                ("pixbuf 1280x720 -> 1920x1080 HYPER rgba", 1280, 720, 1920, 1080, 3, 4), ("pixbuf 1280x720 -> 1920x1080 BILINEAR rgba", 1280, 720, 1920, 1080, 2, 4),
+                ("pixbuf 1920x1080 -> 2560x1440 HYPER rgba", 1920, 1080, 2560, 1440, 3, 4), ("pixbuf 3840x2160 -> 960x540 HYPER rgba", 3840, 2160, 960, 540, 3, 4),
+                ("pixbuf 1280x720 -> 3840x2160 HYPER rgba", 1280, 720, 3840, 2160, 3, 4), ("pixbuf 1280x720 -> 3840x2160 BILINEAR rgba", 1280, 720, 3840, 2160, 2, 4)]
 
 
 def main():

@@ -128,6 +128,10 @@ def main():
                 elif u < 0.5:                     # exact 1:2 (k_pb_double)
                     sw, sh = max(2, (sw // 2) & ~1), max(1, sh // 2)
                     dw, dh = 2 * sw, 2 * sh
+                elif u < 0.65:                    # integer reductions (k_pb_gather)
+                    fx, fy = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+                    dw, dh = max(1, sw // fx), max(1, sh // fy)
+                    sw, sh = fx * dw, fy * dh
                 else:
                     dw, dh = int(rng.integers(1, 600)), int(rng.integers(1, 300))
                 al = 16 if rng.random() < 0.5 else 4
