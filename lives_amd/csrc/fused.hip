@@ -10,7 +10,8 @@
 // k_gauss5_colorkey: no LDS.  A wave owns a strip of 248 columns (62 lanes x 4 pixels; lanes 0 and 63 only feed their neighbours) and walks a band of rows.
 // Per source row a lane loads its 4 pixels (16 or 12 bytes), takes the two pixels it needs on each side from the adjacent lanes (DPP wave shifts), blurs
 // horizontally with the bytes spread to 16-bit lanes (one 32-bit operation = two channels) and keeps the last five blurred rows in registers; every new row
-// completes one output row, which is keyed against the second frame's pixels (loaded a row ahead) and stored.  Odd bands walk upwards, so that the four source
+// completes one output row, which is keyed against the second frame's pixels (loaded a row ahead) and stored.  The key's box test runs on two 16-bit lanes per
+// operation; its two double products come from 256-entry tables the workgroup computes once (the same IEEE products, one f64 add + one conversion per byte).  Odd bands walk upwards, so that the four source
 // rows two neighbouring bands share are read at the same time and the second read hits L2 (same scheme as k_pb_half).  HBM-bound: 3 frames of traffic.
 #include "lgpu_common.h"
 #include <cmath>
@@ -22,7 +23,7 @@ struct GckArgs {
   uint8_t *dst;
   int irow0, irow1, orow, width, height;
   int strips, cgroups, bands, th;
-  int rmin, rmax, gmin, gmax, bmin, bmax, order;      // order 1: BGR(A)
+  uint32_t mn_e, mx_e, mn_o, mx_o;                    // the key's box on (byte 0, byte 2) and (byte 1, byte 3) as 16-bit lanes; the max words carry 0x8000 per lane
   double opac, opacx;
   int key;                                            // 0: blur only
 };
@@ -32,6 +33,9 @@ struct __attribute__((aligned(4))) gk_u3 { uint32_t x, y, z; };          // 12 b
 template <int PS>
 __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ double s_ta[256], s_tb[256];               // a * (1 - opac), b * opac for every byte value: the script's two products
+  if (A.key) { s_ta[threadIdx.x] = (double)(int)threadIdx.x * A.opacx; s_tb[threadIdx.x] = (double)(int)threadIdx.x * A.opac; }
+  __syncthreads();
   // XCD-contiguous order: (column group, band) runs, band-minor (see k_pb_half)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int nseq = A.cgroups * A.bands, per_xcd = (nseq + 7) >> 3;
@@ -94,64 +98,66 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
     for (int j = 0; j < 8; j++) ring[i][j] = 0;
   int produced = ystart - d;
   const int nsteps = vr1 - vr0 + 1;
-  for (int step = 0; step < nsteps; step++) {
-    const int vr = vstart + d * step;
-    const int yy = vr < 0 ? 0 : vr > A.height - 1 ? A.height - 1 : vr;
-    gk_u4 nb = {0, 0, 0, 0};
-    if (A.key) nb = load4(A.src1, A.irow1, vr - d);              // the second frame's pixels of the NEXT output row
-    uint32_t h[8];
-    if (yy != produced) {
-      const gk_u4 q = qn;
-      qn = load4(A.src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic
-      hrow(fix(q), h);
-      produced = yy;
-    } else {
+  // the ring rotates by slot index, five steps per trip of the outer loop: slot u takes the new row, (u + 1) % 5 is the oldest -- no register moves
+  for (int step0 = 0; step0 < nsteps; step0 += 5) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) h[j] = ring[4][j];               // a row beyond the frame: the border row again
-    }
+    for (int u = 0; u < 5; u++) {
+      const int step = step0 + u;
+      if (step >= nsteps) break;
+      const int vr = vstart + d * step;
+      const int yy = vr < 0 ? 0 : vr > A.height - 1 ? A.height - 1 : vr;
+      gk_u4 nb = {0, 0, 0, 0};
+      if (A.key) nb = load4(A.src1, A.irow1, vr - d);              // the second frame's pixels of the NEXT output row
+      if (yy != produced) {
+        const gk_u4 q = qn;
+        qn = load4(A.src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic
+        hrow(fix(q), ring[u]);
+        produced = yy;
+      } else {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 8; j++) ring[u][j] = ring[(u + 4) % 5][j];   // a row beyond the frame: the border row again
+      }
+      if (step >= 4) {
+        const int y = vr - 2 * d;
+        const uint32_t *r0 = ring[(u + 1) % 5], *r1 = ring[(u + 2) % 5], *r2 = ring[(u + 3) % 5], *r3 = ring[(u + 4) % 5], *r4 = ring[u];
+        uint32_t px[4];
 #pragma unroll
-      for (int j = 0; j < 8; j++) ring[i][j] = ring[i + 1][j];
-#pragma unroll
-    for (int j = 0; j < 8; j++) ring[4][j] = h[j];
-    if (step >= 4) {
-      const int y = vr - 2 * d;
-      uint32_t px[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
-        const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
-        uint32_t a = ((ve >> 8) & 0x00FF00FFu) | (vo & 0xFF00FF00u);
-        if (A.key) {
-          const uint32_t b = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
-          const int c0 = a & 0xFF, c1 = (a >> 8) & 0xFF, c2 = (a >> 16) & 0xFF;
-          const int r = A.order ? c2 : c0, bl = A.order ? c0 : c2;
-          if (r >= A.rmin && r <= A.rmax && c1 >= A.gmin && c1 <= A.gmax && bl >= A.bmin && bl <= A.bmax) {
-            const uint32_t m0 = (uint32_t)(uint8_t)((double)c0 * A.opacx + (double)(b & 0xFF) * A.opac);
-            const uint32_t m1 = (uint32_t)(uint8_t)((double)c1 * A.opacx + (double)((b >> 8) & 0xFF) * A.opac);
-            const uint32_t m2 = (uint32_t)(uint8_t)((double)c2 * A.opacx + (double)((b >> 16) & 0xFF) * A.opac);
-            a = m0 | (m1 << 8) | (m2 << 16) | (a & 0xFF000000u);
+        for (int j = 0; j < 4; j++) {
+          const uint32_t ve = r0[2 * j] + r4[2 * j] + 4u * (r1[2 * j] + r3[2 * j]) + 6u * r2[2 * j] + 0x00800080u;
+          const uint32_t vo = r0[2 * j + 1] + r4[2 * j + 1] + 4u * (r1[2 * j + 1] + r3[2 * j + 1]) + 6u * r2[2 * j + 1] + 0x00800080u;
+          uint32_t a = ((ve >> 8) & 0x00FF00FFu) | (vo & 0xFF00FF00u);
+          if (A.key) {
+            // the box test on both 16-bit lanes at once: x >= min <=> bit 15 of (x | 0x8000) - min, x <= max <=> bit 15 of (max | 0x8000) - x (the alpha lane's box is 0 .. 255)
+            const uint32_t e = (ve >> 8) & 0x00FF00FFu, o = (vo >> 8) & 0x00FF00FFu;
+            const uint32_t t = ((e | 0x80008000u) - A.mn_e) & (A.mx_e - e) & ((o | 0x80008000u) - A.mn_o) & (A.mx_o - o) & 0x80008000u;
+            if (t == 0x80008000u) {
+              // (uint8_t)(a * (1 - opac) + b * opac) in double, the products from the workgroup's two 256-entry tables: one f64 add and one conversion per byte
+              const uint32_t b = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+              const uint32_t m0 = (uint32_t)(uint8_t)(s_ta[a & 0xFF] + s_tb[b & 0xFF]);
+              const uint32_t m1 = (uint32_t)(uint8_t)(s_ta[(a >> 8) & 0xFF] + s_tb[(b >> 8) & 0xFF]);
+              const uint32_t m2 = (uint32_t)(uint8_t)(s_ta[(a >> 16) & 0xFF] + s_tb[(b >> 16) & 0xFF]);
+              a = m0 | (m1 << 8) | (m2 << 16) | (a & 0xFF000000u);
+            }
+          }
+          px[j] = a;
+        }
+        if (out_lane) {
+          uint8_t *dp = A.dst + (size_t)y * A.orow + (size_t)(4 * PS) * (size_t)k;
+          if (PS == 4) {
+            gk_u4 o4;
+            o4.x = px[0]; o4.y = px[1]; o4.z = px[2]; o4.w = px[3];
+            __builtin_nontemporal_store(o4, reinterpret_cast<gk_u4 *>(dp));
+          } else {
+            gk_u3 o3;
+            uint32_t w0, w1, w2;
+            pack3(px, w0, w1, w2);
+            o3.x = w0; o3.y = w1; o3.z = w2;
+            *reinterpret_cast<gk_u3 *>(dp) = o3;
           }
         }
-        px[j] = a;
       }
-      if (out_lane) {
-        uint8_t *dp = A.dst + (size_t)y * A.orow + (size_t)(4 * PS) * (size_t)k;
-        if (PS == 4) {
-          gk_u4 o4;
-          o4.x = px[0]; o4.y = px[1]; o4.z = px[2]; o4.w = px[3];
-          __builtin_nontemporal_store(o4, reinterpret_cast<gk_u4 *>(dp));
-        } else {
-          gk_u3 o3;
-          uint32_t w0, w1, w2;
-          pack3(px, w0, w1, w2);
-          o3.x = w0; o3.y = w1; o3.z = w2;
-          *reinterpret_cast<gk_u3 *>(dp) = o3;
-        }
-      }
+      if (step >= 3) b4 = nb;
     }
-    if (step >= 3) b4 = nb;
   }
 }
 
@@ -175,21 +181,33 @@ extern "C" int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint
   GckArgs a;
   a.src0 = src0_d; a.src1 = src1_d; a.dst = dst_d; a.irow0 = irow0; a.irow1 = irow1; a.orow = orow; a.width = width; a.height = height;
   a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
-  a.th = 16;
-  if ((long long)a.cgroups * 4 * cdiv((unsigned)height, 16u) < 4096) a.th = 8;
+  // short bands: the launch is bound by the time a wave needs for its rows, not by the rows the bands share (profiles/r03/c4_band_sweep.txt: 4K RGBA32 27 us at 6 rows,
+  // 28 at 8, 32 at 16, 45 at 32)
+  a.th = psize == 4 ? 6 : 8;
+  if (const char *e = getenv("LGPU_GCK_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a.th = v; }      // tuning probe
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   // parameter preparation exactly as the script does it (host side, double)
   double xdelta = delta * 2.;
   delta /= 2.;
-  a.rmin = col_r - (int)(col_r * delta + .5);
-  a.gmin = col_g - (int)(col_g * xdelta + .5);
-  a.bmin = col_b - (int)(col_b * delta + .5);
+  const int rmin = col_r - (int)(col_r * delta + .5);
+  const int gmin = col_g - (int)(col_g * xdelta + .5);
+  const int bmin = col_b - (int)(col_b * delta + .5);
   xdelta *= 2.;
   delta *= 2.;
-  a.rmax = col_r + (int)((255 - col_r) * delta + .5);
-  a.gmax = col_g + (int)((255 - col_g) * xdelta + .5);
-  a.bmax = col_b + (int)((255 - col_b) * delta + .5);
-  a.order = is_bgr ? 1 : 0; a.opac = opac; a.opacx = 1. - opac; a.key = 1;
+  const int rmax = col_r + (int)((255 - col_r) * delta + .5);
+  const int gmax = col_g + (int)((255 - col_g) * xdelta + .5);
+  const int bmax = col_b + (int)((255 - col_b) * delta + .5);
+  // the box as packed 16-bit lanes in memory byte order (byte 0 / byte 2 = red / blue or blue / red); bounds outside 0 .. 255 are clamped where that keeps the
+  // test's meaning, a box no byte can enter switches the key off (the blurred frame alone is the result then)
+  auto lo = [](int v) { return (uint32_t)(v < 0 ? 0 : v); };
+  auto hi = [](int v) { return (uint32_t)(v > 255 ? 255 : v); };
+  const bool empty = rmin > 255 || gmin > 255 || bmin > 255 || rmax < 0 || gmax < 0 || bmax < 0 || rmin > rmax || gmin > gmax || bmin > bmax;
+  const int c0min = is_bgr ? bmin : rmin, c0max = is_bgr ? bmax : rmax, c2min = is_bgr ? rmin : bmin, c2max = is_bgr ? rmax : bmax;
+  if (!empty) {
+    a.mn_e = lo(c0min) | (lo(c2min) << 16); a.mx_e = (hi(c0max) | (hi(c2max) << 16)) | 0x80008000u;
+    a.mn_o = lo(gmin); a.mx_o = (hi(gmax) | (255u << 16)) | 0x80008000u;
+  } else { a.mn_e = a.mx_e = a.mn_o = a.mx_o = 0; }
+  a.opac = opac; a.opacx = 1. - opac; a.key = empty ? 0 : 1;
   const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u));
   if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
