@@ -923,6 +923,103 @@ __global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A, const u
   if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_finish_px<4>(r, g, b, a, false, 0u);
 }
 
+// =====================================================================================================================================================
+// k_pb_up -- 4-byte pixels, both sides enlarged (any ratio but the exact 1:2 of k_pb_double): a destination pixel needs at most 4 x 4 taps, consecutive
+// destination rows share their source rows, and sixteen phases per axis are all the weights there are.  A lane owns ONE destination column and walks a band of
+// destination rows with its tap window in REGISTERS (NY source rows x NP premultiplied pixel pairs): a source row is read (one 4-byte-aligned vector load where
+// the taps lie, the next row always in flight) and premultiplied once per lane and band, when the walk crosses into it, instead of once per destination row; the
+// pair table of all 256 phases sits in LDS (8 KB at 4 x 4 taps), so a destination pixel costs two ds_read_b128, NY x NP x 4 dot products and the library's
+// double-precision un-premultiply.  k_pb_pairs on the same frames is LDS-bound (8 window reads + 4 weight vectors from device memory per destination pixel).
+// =====================================================================================================================================================
+struct PbUpArgs {
+  const uint8_t *src;
+  uint8_t *dst;
+  int irow, orow, sw, sh, dw, dh;
+  int x_step, y_step, xoff, yoff;
+  int tx0, ty0, rb;                    // rb: destination rows per band
+};
+
+template <int NP, int NY>
+__global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A, const uint32_t *__restrict__ gp) {
+  constexpr int RL = 2, PW = NY * RL;                  // dwords per tap row / per phase of the pair table (rows of 2 dwords for NP <= 2)
+  __shared__ __attribute__((aligned(16))) uint32_t s_w[256 * PW];
+  for (int e = threadIdx.x; e < 256 * PW; e += 256) s_w[e] = gp[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cb = blockIdx.x * 4 + wave;
+  if (cb * 64 >= A.dw) return;
+  const int j = cb * 64 + lane;
+  const bool live = j < A.dw;
+  const long long x = (long long)(live ? j : A.dw - 1) * A.x_step + A.xoff;
+  const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15;
+  const int p0 = xs + A.tx0;
+  const bool fast = p0 >= 0 && p0 + 2 * NP <= A.sw;
+  struct Raw { uint32_t q[2 * NP]; };
+  auto load_raw = [&](int v) -> Raw {                  // the taps of virtual source row v (rows beyond the frame repeat its first / last row)
+    Raw R;
+    const uint8_t *row = A.src + (size_t)pb_clamp(v, A.sh - 1) * A.irow;
+    if (fast) {
+      const uint8_t *p = row + 4 * (size_t)p0;
+      if (NP == 1) { const pb_u2 t = *reinterpret_cast<const pb_u2a *>(p); R.q[0] = t.x; R.q[1] = t.y; }
+      else { const pb_u4 t = *reinterpret_cast<const pb_u4a *>(p); R.q[0] = t.x; R.q[1] = t.y; R.q[2 % (2 * NP)] = t.z; R.q[3 % (2 * NP)] = t.w; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2 * NP; k++) R.q[k] = reinterpret_cast<const uint32_t *>(row)[pb_clamp(p0 + k, A.sw - 1)];
+    }
+    return R;
+  };
+  uint32_t win[NY][4 * NP];
+  auto premul = [&](const Raw &R, uint32_t *o) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      o[4 * k] = pb_premul_pair<0>(R.q[2 * k], R.q[2 * k + 1]); o[4 * k + 1] = pb_premul_pair<1>(R.q[2 * k], R.q[2 * k + 1]);
+      o[4 * k + 2] = pb_premul_pair<2>(R.q[2 * k], R.q[2 * k + 1]); o[4 * k + 3] = __builtin_amdgcn_perm(R.q[2 * k + 1], R.q[2 * k], 0x0C070C03u);
+    }
+  };
+  const int i0 = blockIdx.y * A.rb, i1 = min(i0 + A.rb, A.dh);
+  int cur = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;          // virtual source row of win[0]
+  {
+    Raw r0[NY];
+#pragma unroll
+    for (int t = 0; t < NY; t++) r0[t] = load_raw(cur + t);
+#pragma unroll
+    for (int t = 0; t < NY; t++) premul(r0[t], win[t]);
+  }
+  Raw nxt = load_raw(cur + NY);
+  const uint32_t *wbase = s_w + xph * PW;
+  for (int i = i0; i < i1; i++) {
+    const long long y = (long long)i * A.y_step + A.yoff;
+    const int vs = (int)(y >> 16) + A.ty0, yph = (int)(y >> 12) & 15;
+    if (vs != cur) {                                   // wave-uniform; the walk enters the next source row (a step <= 1 never skips one)
+#pragma unroll
+      for (int t = 0; t + 1 < NY; t++)
+#pragma unroll
+        for (int c = 0; c < 4 * NP; c++) win[t][c] = win[t + 1][c];
+      premul(nxt, win[NY - 1]);
+      cur = vs;
+      nxt = load_raw(cur + NY);
+    }
+    const uint32_t *w = wbase + yph * 16 * PW;
+    uint32_t wv[PW];
+    if (PW % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < PW / 4; c++) { const pb_u4 t = reinterpret_cast<const pb_u4 *>(w)[c]; wv[4 * c] = t.x; wv[4 * c + 1] = t.y; wv[4 * c + 2] = t.z; wv[4 * c + 3] = t.w; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < PW / 2; c++) { const pb_u2 t = reinterpret_cast<const pb_u2 *>(w)[c]; wv[2 * c] = t.x; wv[2 * c + 1] = t.y; }
+    }
+    unsigned r = 0, g = 0, b = 0, a = 0;
+#pragma unroll
+    for (int t = 0; t < NY; t++)
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const uint32_t ww = wv[t * RL + k];
+        r = pb_dot2(win[t][4 * k], ww, r); g = pb_dot2(win[t][4 * k + 1], ww, g); b = pb_dot2(win[t][4 * k + 2], ww, b); a = pb_dot2(win[t][4 * k + 3], ww, a);
+      }
+    if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_finish_px<4>(r, g, b, a, false, 0u);
+  }
+}
+
 // ---- host: the per-phase weight tables ----------------------------------------------------------------------------------------------------
 struct PbDim { int n; double offset; std::vector<double> w; };   // w[phase * n + tap]
 
@@ -1299,6 +1396,26 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   }
   const bool no_pairs = getenv("LGPU_PB_NO_PAIRS") != nullptr;        // tests: the one-tap-per-operation kernels at any ratio
   static const bool no_gather = getenv("LGPU_PB_NO_GATHER") != nullptr;
+  // both sides enlarged: the register-window walk
+  static const bool no_up = getenv("LGPU_PB_NO_UP") != nullptr;
+  if (channels == 4 && t->gpairs_d && !no_pairs && !no_up && x_step <= 65536 && y_step <= 65536) {
+    const int unp = (t->tx1 - t->tx0 + 1) / 2, uny = t->ty1 - t->ty0;
+    if (unp >= 1 && unp <= 2 && uny >= 1 && uny <= 4) {
+      PbUpArgs ua;
+      ua.src = src_d; ua.dst = dst_d; ua.irow = irow; ua.orow = orow; ua.sw = sw; ua.sh = sh; ua.dw = dw; ua.dh = dh;
+      ua.x_step = x_step; ua.y_step = y_step; ua.xoff = t->xoff; ua.yoff = t->yoff; ua.tx0 = t->tx0; ua.ty0 = t->ty0;
+      ua.rb = (long long)dw * dh >= 6000000 ? 8 : 6;      // per-wave time rules (profiles/r03/pb_up_ab.txt: 720p -> 1080p 11.6 us at 6 rows per band, 15.3 at 16, 38 at 64)
+      if (const char *e = getenv("LGPU_PB_UP_RB")) { const int v = atoi(e); if (v >= 1 && v <= 4096) ua.rb = v; }      // tuning probe
+      const dim3 gu(cdiv(cdiv((unsigned)dw, 64), 4), cdiv((unsigned)dh, (unsigned)ua.rb));
+      const uint32_t *gp = t->gpairs_d;
+#define PB_UP(NP_, NY_) hipLaunchKernelGGL((k_pb_up<NP_, NY_>), gu, block, 0, st, ua, gp)
+      if (unp == 1) { if (uny == 1) PB_UP(1, 1); else if (uny == 2) PB_UP(1, 2); else if (uny == 3) PB_UP(1, 3); else PB_UP(1, 4); }
+      else { if (uny == 1) PB_UP(2, 1); else if (uny == 2) PB_UP(2, 2); else if (uny == 3) PB_UP(2, 3); else PB_UP(2, 4); }
+#undef PB_UP
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
   // integer reductions (one phase for the whole frame): the barrier-free kernel with scalar weights; every other ratio keeps the LDS window
   if (channels == 4 && t->gpairs_d && !no_pairs && !no_gather && (x_step & 0xFFFF) == 0 && (y_step & 0xFFFF) == 0) {
     PbGatherArgs ga;

@@ -222,6 +222,30 @@ def test_gpu_integer_reductions(gpu, orc):
 
 
 @gpu_mark
+def test_gpu_enlargements(gpu, orc, monkeypatch):
+    """k_pb_up (4-byte pixels, both sides enlarged: register tap window walked down a band of destination rows, pair table in LDS): both filters, ratios from 1.01 to 9,
+    one side kept (step exactly 1), frames narrower than a tap row, widths that end inside a wave, heights that end inside a band, band heights 1 and 5, three alpha mixes"""
+    rng = np.random.default_rng(0x9DB8)
+    cases = [(128, 72, 192, 108), (100, 60, 101, 61), (64, 36, 200, 100), (30, 20, 270, 180), (96, 54, 96, 108), (96, 54, 200, 54), (3, 2, 100, 70), (1, 1, 9, 9),
+             (640, 360, 1280, 720), (642, 361, 1284, 722), (200, 120, 300, 180), (500, 9, 1000, 10)]
+    for rb in (None, "1", "5"):
+        if rb:
+            monkeypatch.setenv("LGPU_PB_UP_RB", rb)
+        for (sw, sh, dw, dh) in cases if rb is None else cases[:5]:
+            for interp in (2, 3):
+                for amode in (0, 1, 2):
+                    src = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)
+                    if amode == 1:
+                        src[:, 3::4] = 255
+                    elif amode == 2:
+                        src[:, 3::4] = rng.choice(np.array([0, 255, 7], np.uint8), (sh, sw))
+                    want = np.zeros((dh, dw * 4), np.uint8)
+                    assert orc.orc_pixbuf_scale(P(src), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, interp) == 0
+                    got = gpu_scale(gpu, src, sw, sh, dw, dh, 4, interp)
+                    assert (got == want).all(), "%dx%d->%dx%d interp %d alpha mode %d band %s" % (sw, sh, dw, dh, interp, amode, rb)
+
+
+@gpu_mark
 def test_gpu_strong_reductions(gpu, orc):
     """windows too large for LDS take the direct kernel; ratios past the library's one-step range are refused, the frame untouched"""
     from lives_amd import lib
