@@ -216,7 +216,7 @@ def main():
             traffic = pj.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roof = {"bound": "hbm", "kernel": ("lgpu::k_pb_half<1,1,%d>" % args.blur) if args.resize_backend == "pixbuf" else "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": pixbuf_kernel_name(args) if args.resize_backend == "pixbuf" else "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
 
@@ -280,6 +280,15 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "effect-chain frames/sec at 3840x2160 RGBA32", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "tracks_of_rank0": mine, "max_over_ranks_s": dt}))
+
+
+def pixbuf_kernel_name(args):
+    """the instantiation pb_half_geometry() (pixbuf.hip) picks for this launch, as rocprofv3 prints it: <CHAIN, HYPER, BLUR, ALIGNED>; strips of 64 storing lanes
+    when the launch fills the device and there is no blur stage"""
+    aligned = (not args.blur) and ((1920 + 127) // 128) * (1080 // 6) * args.tracks >= 8192
+    if os.environ.get("LGPU_PBH_ALIGNED") is not None and not args.blur:
+        aligned = os.environ["LGPU_PBH_ALIGNED"] not in ("", "0")
+    return "lgpu::k_pb_half<1, 1, %d, %d>" % (args.blur, 1 if aligned else 0)
 
 
 def cpu_baseline(blur, pixbuf=True):

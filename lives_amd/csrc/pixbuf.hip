@@ -191,6 +191,7 @@ struct PbHalfArgs {
   int cw, ch, ox, oy;            // letterbox canvas (cw == 0: none): dst / layer 2 are cw x ch, the scaled frame sits at (ox, oy), the rest is opaque black under the blend
   int main_blocks, bar_blocks;   // workgroups of the frame proper / per track of the bars (1024 canvas pixels each)
   int nt_out;
+  int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
 };
 struct PbTracks {
   const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
@@ -226,8 +227,10 @@ __device__ __forceinline__ uint32_t pb_add_hi_lo(uint32_t x, uint32_t y) {      
   return d;
 }
 // one source row of a lane: 4 pixels -> the two H columns of its 4 channels (h[c] = column 2k, h[4 + c] = column 2k + 1)
-template <int HYPER>
-__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8]) {
+// e (ALIGNED strips only, otherwise 0): lane 0 holds pixel P[4k-1] there, lane 63 pixel P[4k+4] (clamped into the row), every other lane 0 -- the two taps the
+// wave shifts cannot deliver.
+template <int HYPER, int ALIGNED = 0>
+__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u) {
   uint32_t A[4], B[4];
   A[0] = pb_premul_pair<0>(q.x, q.y); B[0] = pb_premul_pair<0>(q.z, q.w);
   A[1] = pb_premul_pair<1>(q.x, q.y); B[1] = pb_premul_pair<1>(q.z, q.w);
@@ -249,6 +252,20 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8]) {
       h[4 + c] = pb_dot2(B[c], 0x00010001u, 0u);
     }
   }
+  if (HYPER && ALIGNED) {
+    // e is non-zero in lanes 0 and 63 only; a DPP row mask splits it: lanes 0-15 keep it as the left pixel, lanes 48-63 as the right one (0 premultiplies to 0)
+    const uint32_t el = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0xE4, 0x1, 0xF, false), er = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0xE4, 0x8, 0xF, false);
+    uint32_t xl[4], xr[4];
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(xl[0]) : "v"(el));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(xl[1]) : "v"(el));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(xl[2]) : "v"(el));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(xr[0]) : "v"(er));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(xr[1]) : "v"(er));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(xr[2]) : "v"(er));
+    xl[3] = el >> 24; xr[3] = er >> 24;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { h[c] += xl[c]; h[4 + c] += xr[c]; }
+  }
 }
 // V_c * fl(1 / V_alpha), truncated, for the three colours of one pixel
 __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t va, uint32_t c[3]) {
@@ -264,11 +281,13 @@ __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32
 // blend, in the same launch.  The scaled row of a lane (two RGBA pixels) is blurred horizontally with its neighbours' pixels (four more DPP moves; bytes in
 // 16-bit lanes, so one 32-bit operation serves two channels), the last five blurred rows stay in registers and every new one completes an output row.  A strip
 // then yields 120 columns (lanes 2 .. 61) and a band computes 4 more scaled rows than it stores.
-template <int CHAIN, int HYPER, int BLUR>
+template <int CHAIN, int HYPER, int BLUR, int ALIGNED = 0>
 __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
   __shared__ __attribute__((aligned(16))) uint8_t s_lut_all[4][256];       // the gamma LUT and the blend's alpha scalers, one private copy per wave: a wave stages its
   __shared__ pb_u2 s_k_all[4][256];                                        //   own and never waits for the other three (no workgroup barrier on the frame path)
-  constexpr int kHalo = BLUR ? 2 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
+  // ALIGNED (no blur): strips of 64 quads, no feeder lanes -- a wave's row is 1024 source bytes and 512 result bytes on 128-byte lines; the two taps beyond the
+  // strip come from one extra 4-byte load per source row in lanes 0 and 63
+  constexpr int kHalo = BLUR ? 2 : ALIGNED ? 0 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
   if (CHAIN && blockIdx.x >= (unsigned)A.main_blocks) {
     // letterbox bars (letterbox_layer's black canvas, src/colourspace.c:15417-15503, under the rest of the chain): opaque black -> chroma blend with layer 2 -> LUT
     uint8_t *s_lut = s_lut_all[0];
@@ -346,6 +365,18 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     return *reinterpret_cast<const pb_u4 *>(rowbase + (size_t)sy * A.irow + lane_off);      // plain loads: measured faster than non-temporal ones (band seams and strip halos re-read through L2)
 #endif
   };
+  // ALIGNED: the pixel left of the strip (lane 0) / right of it (lane 63), clamped into the row -- which is the library's edge rule at the frame's two ends
+  const bool e_lane = HYPER && ALIGNED && (lane == 0 || lane == 63);
+  const int e_x = lane == 0 ? 4 * k - 1 : 4 * k + 4;
+  const uint32_t e_off = 4u * (uint32_t)(e_x < 0 ? 0 : e_x > A.sw - 1 ? A.sw - 1 : e_x);
+  auto load_e = [&](int sy) -> uint32_t {
+    uint32_t e = 0u;
+    if (e_lane) {
+      sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
+      e = *reinterpret_cast<const uint32_t *>(rowbase + (size_t)sy * A.irow + e_off);
+    }
+    return e;
+  };
   // lanes outside the frame (edge strips only, a wave-uniform test) repeat the border pixel; applied when a row is consumed, so that no load is waited for early
   auto fix = [&](pb_u4 q) -> pb_u4 {
     if (edge_strip) {
@@ -395,6 +426,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   // carry[i] = (outer tap) * H[first row] + (inner tap) * H[second row] of a scaled row: the half that is known before its last two source rows arrive
   uint32_t carry[8], hr[8], hs[8];
   pb_u4 q0 = load_row(S0), q1 = load_row(S0 + d), qa = load_row(S0 + 2 * d), qb = load_row(S0 + 3 * d);
+  uint32_t e0 = load_e(S0), e1 = load_e(S0 + d), ea = load_e(S0 + 2 * d), eb = load_e(S0 + 3 * d);
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
   if (CHAIN && A.blend) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
@@ -411,8 +443,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  pb_half_hrow<HYPER>(fix(q0), hr);
-  pb_half_hrow<HYPER>(fix(q1), hs);
+  pb_half_hrow<HYPER, ALIGNED>(fix(q0), hr, e0);
+  pb_half_hrow<HYPER, ALIGNED>(fix(q1), hs, e1);
 #pragma unroll
   for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
   int produced = ystart - d;              // the last scaled row that exists
@@ -432,9 +464,10 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
       const int r = d > 0 ? yy - ystart : ystart - yy;
       const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
+      const uint32_t nea = load_e(S0 + d * (2 * r + 4)), neb = load_e(S0 + d * (2 * r + 5));
       if (CHAIN && A.blend) nl2 = load_l2(BLUR ? vr - d : yy + d);
-      pb_half_hrow<HYPER>(fix(qa), hr);
-      pb_half_hrow<HYPER>(fix(qb), hs);
+      pb_half_hrow<HYPER, ALIGNED>(fix(qa), hr, ea);
+      pb_half_hrow<HYPER, ALIGNED>(fix(qb), hs, eb);
       uint32_t v[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -449,6 +482,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
         al[j] = (va >> A.ashift) << 24;
       }
       qa = na; qb = nb;
+      ea = nea; eb = neb;
       produced = yy;
       if (BLUR) {
         // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
@@ -1223,7 +1257,11 @@ static bool pb_double_ok(const PbTable *t, int x_step, int y_step) {
 }
 
 static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
-  a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : 124);
+  // strips of 64 storing lanes on 128-byte lines when the launch fills the device (16 tracks: 173.7 -> 169.5 us, interleaved A / B in profiles/r03/pbh_aligned_ab.txt);
+  // one frame keeps the 62 + 2 form (14.3 against 15.8 us: the extra load and its arithmetic lengthen every wave's row step)
+  a->aligned = !blur && (long long)cdiv((unsigned)a->dw, 128) * cdiv((unsigned)a->dh, 6u) * ntracks >= 8192;
+  if (!blur) { if (const char *e = getenv("LGPU_PBH_ALIGNED")) a->aligned = atoi(e) ? 1 : 0; }       // tests: either form at any size
+  a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : a->aligned ? 128 : 124);
   // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
   // 16 tracks 170 / 167 us at 4 rows, 166 at 6, 165 / 174 at 8, 175 at 16; one 4K frame 11.0-11.2 us at 4 rows, 9.9 at 6, 11.7 at 8, 14.7 at 16
   a->th = 6;
@@ -1267,7 +1305,10 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
     if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 1>), grid, dim3(256), 0, st, a, T, l);
     else hipLaunchKernelGGL((k_pb_half<1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
   } else {
-    if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 0>), grid, dim3(256), 0, st, a, T, l);
+    if (a.aligned) {
+      if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
+      else hipLaunchKernelGGL((k_pb_half<1, 0, 0, 1>), grid, dim3(256), 0, st, a, T, l);
+    } else if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 0>), grid, dim3(256), 0, st, a, T, l);
     else hipLaunchKernelGGL((k_pb_half<1, 0, 0>), grid, dim3(256), 0, st, a, T, l);
   }
   LGPU_CHECK_LAUNCH();
@@ -1388,7 +1429,10 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
       h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.main_blocks = (int)pb_half_grid(h);
-      if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      if (h.aligned) {
+        if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0, 1>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+        else hipLaunchKernelGGL((k_pb_half<0, 0, 0, 1>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
+      } else if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       else hipLaunchKernelGGL((k_pb_half<0, 0, 0>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;

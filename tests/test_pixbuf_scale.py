@@ -298,15 +298,19 @@ def test_compositor_flow_scales_its_layers_as_the_reference_does(gpu, orc, psize
 
 
 @gpu_mark
-def test_chain_on_the_pixbuf_arithmetic(gpu, orc):
-    """lgpu_chain with LGPU_INTERP_PIXBUF: convert -> gdk-pixbuf scale (4 channels, alpha-weighted) -> chroma blend -> gamma LUT == the oracle's composition
+@pytest.mark.parametrize("strips64", [0, 1])
+def test_chain_on_the_pixbuf_arithmetic(gpu, orc, monkeypatch, strips64):
+    """(both strip forms of k_pb_half: 62 storing lanes + 2 feeder lanes, and 64 storing lanes with the two outer taps from an extra load -- what full-device launches take)
+    lgpu_chain with LGPU_INTERP_PIXBUF: convert -> gdk-pixbuf scale (4 channels, alpha-weighted) -> chroma blend -> gamma LUT == the oracle's composition
     of the pinned single stages.  The exact aligned 2:1 cases take the one-launch kernel k_pb_half (HYPER and BILINEAR, several tracks, strips that end
     inside the frame, bands of every height); the others the staged path (other ratios, the blur stage, unaligned rowstrides)."""
+    monkeypatch.setenv("LGPU_PBH_ALIGNED", str(strips64))
     PIXBUF = 0x100
     rng = np.random.default_rng(0x9DBA)
     lut = np.zeros(256, np.uint8)
     assert orc.orc_gamma_lut8(1.0, -1, 1, 1.4, P(lut)) == 1
     cases = [  # sw, sh, dw, dh, interp, swap, bf, ntracks, use_lut, blur, src pad, dst pad
+        (1024, 48, 512, 24, 3, 1, 128, 2, 1, 0, 0, 0), (772, 36, 386, 18, 3, 0, 60, 1, 1, 0, 0, 0), (260, 36, 130, 18, 3, 0, 60, 1, 0, 0, 0, 0),
         (256, 144, 128, 72, 3, 1, 128, 1, 1, 0, 0, 0), (512, 40, 256, 20, 3, 0, 77, 3, 0, 0, 0, 0), (1000, 132, 500, 66, 3, 1, 255, 2, 1, 0, 16, 8),
         (256, 144, 128, 72, 2, 1, 100, 2, 1, 0, 0, 0), (8, 4, 4, 2, 3, 0, 9, 1, 1, 0, 0, 0), (3840, 64, 1920, 32, 3, 1, 200, 1, 1, 0, 0, 0),
         (248, 1000, 124, 500, 3, 1, 33, 1, 0, 0, 0, 0), (252, 66, 126, 33, 2, 0, 0, 1, 1, 0, 0, 0),

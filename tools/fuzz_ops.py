@@ -52,6 +52,7 @@ def main():
     for it in range(iters):
         kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411", "pixbuf", "pixbuf", "chainpb", "chainpb", "canvas", "c4"]))
         counts[kind] = counts.get(kind, 0) + 1
+        os.environ["LGPU_PBH_ALIGNED"] = "1" if rng.random() < 0.5 else "0"          # both strip forms of k_pb_half at every size
         try:
             if kind == "resize":
                 ps = int(rng.choice([1, 3, 4]))
