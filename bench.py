@@ -283,11 +283,9 @@ def dry_run(args, rank, world):
 
 
 def pixbuf_kernel_name(args):
-    """the instantiation pb_half_geometry() (pixbuf.hip) picks for this launch, as rocprofv3 prints it: <CHAIN, HYPER, BLUR, ALIGNED>; strips of 64 storing lanes
-    when the launch fills the device and there is no blur stage"""
-    aligned = (not args.blur) and ((1920 + 127) // 128) * (1080 // 6) * args.tracks >= 8192
-    if os.environ.get("LGPU_PBH_ALIGNED") is not None and not args.blur:
-        aligned = os.environ["LGPU_PBH_ALIGNED"] not in ("", "0")
+    """the instantiation pb_half_geometry() (pixbuf.hip) picks for this launch, as rocprofv3 prints it: <CHAIN, HYPER, BLUR, ALIGNED>; ALIGNED (strips of 64 storing lanes)
+    is opt-in through LGPU_PBH_ALIGNED=1"""
+    aligned = (not args.blur) and os.environ.get("LGPU_PBH_ALIGNED", "0") not in ("", "0")
     return "lgpu::k_pb_half<1, 1, %d, %d>" % (args.blur, 1 if aligned else 0)
 
 

@@ -230,7 +230,7 @@ __device__ __forceinline__ uint32_t pb_add_hi_lo(uint32_t x, uint32_t y) {      
 // e (ALIGNED strips only, otherwise 0): lane 0 holds pixel P[4k-1] there, lane 63 pixel P[4k+4] (clamped into the row), every other lane 0 -- the two taps the
 // wave shifts cannot deliver.
 template <int HYPER, int ALIGNED = 0>
-__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u) {
+__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u, uint32_t ml = 0u, uint32_t mr = 0u) {
   uint32_t A[4], B[4];
   A[0] = pb_premul_pair<0>(q.x, q.y); B[0] = pb_premul_pair<0>(q.z, q.w);
   A[1] = pb_premul_pair<1>(q.x, q.y); B[1] = pb_premul_pair<1>(q.z, q.w);
@@ -253,18 +253,14 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
     }
   }
   if (HYPER && ALIGNED) {
-    // e is non-zero in lanes 0 and 63 only; a DPP row mask splits it: lanes 0-15 keep it as the left pixel, lanes 48-63 as the right one (0 premultiplies to 0)
-    const uint32_t el = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0xE4, 0x1, 0xF, false), er = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0xE4, 0x8, 0xF, false);
-    uint32_t xl[4], xr[4];
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(xl[0]) : "v"(el));
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(xl[1]) : "v"(el));
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(xl[2]) : "v"(el));
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(xr[0]) : "v"(er));
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(xr[1]) : "v"(er));
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(xr[2]) : "v"(er));
-    xl[3] = el >> 24; xr[3] = er >> 24;
+    // e is non-zero in lanes 0 and 63 only; ml / mr (1 in lane 0 / lane 63, else 0) steer its premultiplied bytes into column 2k or 2k + 1: 4 + 8 operations per row
+    uint32_t x[4];
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(x[0]) : "v"(e));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(x[1]) : "v"(e));
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(x[2]) : "v"(e));
+    x[3] = e >> 24;
 #pragma unroll
-    for (int c = 0; c < 4; c++) { h[c] += xl[c]; h[4 + c] += xr[c]; }
+    for (int c = 0; c < 4; c++) { h[c] = __umul24(x[c], ml) + h[c]; h[4 + c] = __umul24(x[c], mr) + h[4 + c]; }
   }
 }
 // V_c * fl(1 / V_alpha), truncated, for the three colours of one pixel
@@ -380,7 +376,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   // lanes outside the frame (edge strips only, a wave-uniform test) repeat the border pixel; applied when a row is consumed, so that no load is waited for early
   auto fix = [&](pb_u4 q) -> pb_u4 {
     if (edge_strip) {
-      if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
+      if (!ALIGNED && k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
       if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }       // right of the frame: the last pixel repeated
     }
     return q;
@@ -443,8 +439,10 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  pb_half_hrow<HYPER, ALIGNED>(fix(q0), hr, e0);
-  pb_half_hrow<HYPER, ALIGNED>(fix(q1), hs, e1);
+  uint32_t e_ml = lane == 0 ? 1u : 0u, e_mr = lane == 63 ? 1u : 0u;
+  asm volatile("" : "+v"(e_ml), "+v"(e_mr));          // opaque to the optimiser: it would turn the multiply-adds below into select + add pairs
+  pb_half_hrow<HYPER, ALIGNED>(fix(q0), hr, e0, e_ml, e_mr);
+  pb_half_hrow<HYPER, ALIGNED>(fix(q1), hs, e1, e_ml, e_mr);
 #pragma unroll
   for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
   int produced = ystart - d;              // the last scaled row that exists
@@ -466,8 +464,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
       const uint32_t nea = load_e(S0 + d * (2 * r + 4)), neb = load_e(S0 + d * (2 * r + 5));
       if (CHAIN && A.blend) nl2 = load_l2(BLUR ? vr - d : yy + d);
-      pb_half_hrow<HYPER, ALIGNED>(fix(qa), hr, ea);
-      pb_half_hrow<HYPER, ALIGNED>(fix(qb), hs, eb);
+      pb_half_hrow<HYPER, ALIGNED>(fix(qa), hr, ea, e_ml, e_mr);
+      pb_half_hrow<HYPER, ALIGNED>(fix(qb), hs, eb, e_ml, e_mr);
       uint32_t v[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -1257,10 +1255,11 @@ static bool pb_double_ok(const PbTable *t, int x_step, int y_step) {
 }
 
 static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
-  // strips of 64 storing lanes on 128-byte lines when the launch fills the device (16 tracks: 173.7 -> 169.5 us, interleaved A / B in profiles/r03/pbh_aligned_ab.txt);
-  // one frame keeps the 62 + 2 form (14.3 against 15.8 us: the extra load and its arithmetic lengthen every wave's row step)
-  a->aligned = !blur && (long long)cdiv((unsigned)a->dw, 128) * cdiv((unsigned)a->dh, 6u) * ntracks >= 8192;
-  if (!blur) { if (const char *e = getenv("LGPU_PBH_ALIGNED")) a->aligned = atoi(e) ? 1 : 0; }       // tests: either form at any size
+  // strips of 64 storing lanes on 128-byte lines (k_pb_half<.., ALIGNED>): 3 % less traffic for 13 % more arithmetic.  On a box that has been under load for a
+  // minute (memory side slower) the 16-track launch gains 2.4 % (173.7 -> 169.5 us), on a fresh box it loses 2 % (161 -> 165 us), one frame per launch loses 10 %
+  // (profiles/r03/pbh_aligned_ab.txt: five interleaved A / B runs on four boxes) -- so it is opt-in: LGPU_PBH_ALIGNED=1
+  a->aligned = 0;
+  if (!blur) { if (const char *e = getenv("LGPU_PBH_ALIGNED")) a->aligned = atoi(e) ? 1 : 0; }
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : a->aligned ? 128 : 124);
   // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
   // 16 tracks 170 / 167 us at 4 rows, 166 at 6, 165 / 174 at 8, 175 at 16; one 4K frame 11.0-11.2 us at 4 rows, 9.9 at 6, 11.7 at 8, 14.7 at 16
