@@ -353,12 +353,18 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
   const uint32_t w_lo = bf | ((255u - bf) << 8);
 
+  // a row's address as a scalar base (the SGPR pair of a global_load ... saddr) + this lane's 32-bit offset: no 64-bit multiply-add per lane and row
+  typedef const __attribute__((address_space(1))) uint8_t *gptr_t;      // rebuilt from an integer, the pointer must say "global" itself (else: flat loads)
+  auto urow = [](const uint8_t *base, int y, int pitch) -> gptr_t {
+    const uint64_t a = (uint64_t)base + (uint64_t)((int64_t)y * pitch);
+    return (gptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+  };
   auto load_row = [&](int sy) -> pb_u4 {
-    sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
+    sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);      // uniform by construction; said so, the row address is a scalar base + a 32-bit lane offset
 #if defined(PBH_VARIANT) && (PBH_VARIANT & 1)
-    return __builtin_nontemporal_load(reinterpret_cast<const pb_u4 *>(rowbase + (size_t)sy * A.irow + lane_off));
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) pb_u4 *)(urow(rowbase, sy, A.irow) + lane_off));
 #else
-    return *reinterpret_cast<const pb_u4 *>(rowbase + (size_t)sy * A.irow + lane_off);      // plain loads: measured faster than non-temporal ones (band seams and strip halos re-read through L2)
+    return *(const __attribute__((address_space(1))) pb_u4 *)(urow(rowbase, sy, A.irow) + lane_off);      // plain loads: measured faster than non-temporal ones (band seams and strip halos re-read through L2)
 #endif
   };
   // ALIGNED: the pixel left of the strip (lane 0) / right of it (lane 63), clamped into the row -- which is the library's edge rule at the frame's two ends
@@ -368,14 +374,15 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   auto load_e = [&](int sy) -> uint32_t {
     uint32_t e = 0u;
     if (e_lane) {
-      sy = sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy;
-      e = *reinterpret_cast<const uint32_t *>(rowbase + (size_t)sy * A.irow + e_off);
+      sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
+      e = *(const __attribute__((address_space(1))) uint32_t *)(urow(rowbase, sy, A.irow) + e_off);
     }
     return e;
   };
   // lanes outside the frame (edge strips only, a wave-uniform test) repeat the border pixel; applied when a row is consumed, so that no load is waited for early
   auto fix = [&](pb_u4 q) -> pb_u4 {
     if (edge_strip) {
+      asm volatile("" ::: "memory");                            // keeps this a (wave-uniform) branch: as selects it costs every strip six operations per source row
       if (!ALIGNED && k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
       if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }       // right of the frame: the last pixel repeated
     }
@@ -384,8 +391,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const uint8_t *l2base = (CHAIN && A.blend) ? T.l2[track] : nullptr;
   const uint32_t l2_off = 8u * (uint32_t)kc + 4u * (uint32_t)A.ox;
   auto load_l2 = [&](int y) -> pb_u2 {
-    y = y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y;
-    return __builtin_nontemporal_load(reinterpret_cast<const pb_u2 *>(l2base + (size_t)(y + A.oy) * A.irow2 + l2_off));
+    y = __builtin_amdgcn_readfirstlane(y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y);
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) pb_u2 *)(urow(l2base, y + A.oy, A.irow2) + l2_off));
   };
   // the rest of the chain on one pixel whose colours are still apart, and the store
   auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
