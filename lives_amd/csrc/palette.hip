@@ -185,6 +185,67 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
   }
 }
 
+// RGBA32 / BGRA32 -> YUV420P for aligned frames (the sink hand-off of a 1080p frame): the arithmetic of k_rgb_to_yuv<.., 4> in the shape that paid off for K2
+// (yuv.hip, k_yuv420p_to_rgb_s).  A lane owns a cell of 4 x 2 pixels -- luma rows 2u + 1 and 2u + 2, whose chroma the reference averages into chroma row u
+// (:6302-6315; row 0 is luma only, the last chroma row has row 2u + 1 alone) -- so every source row is read once (16 bytes per lane), luma leaves as dwords and
+// chroma as 16-bit pairs; cells are numbered linearly over the frame, the first cell's pixels are requested before the tables (9 KB + the chroma-average table) are
+// staged, and a 512-thread workgroup stages them once for 2,048 cells.  k_rgb_to_yuv<.., 4>: one workgroup of 256 pixel pairs per chroma row, the second row of every
+// pair of rows read twice.
+template <int ORDER>
+__global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gmagic) {
+  __shared__ int32_t s_t[9 * 256];
+  typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+  const int ngr = a.width >> 2, hc = a.height >> 1, nunits = hc + 1;      // unit 0: row 0 alone; unit u + 1: rows 2u + 1, 2u + 2 -> chroma row u
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t unit = __umulhi(idx, gmagic);                                     // floor magic: the quotient or one less
+  uint32_t gx = idx - unit * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; unit++; }
+  const bool valid = unit < (uint32_t)nunits;
+  const int ra = unit ? 2 * (int)unit - 1 : 0, rb = ra + 1;                  // the cell's rows; rb unused for unit 0
+  const bool has_b = valid && unit && rb < a.height;
+  pu4 qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
+  if (valid) qa = *reinterpret_cast<const pu4 *>(a.src[0] + (size_t)ra * a.irow[0] + 16 * (size_t)gx);
+  if (has_b) qb = *reinterpret_cast<const pu4 *>(a.src[0] + (size_t)rb * a.irow[0] + 16 * (size_t)gx);
+  for (int i = threadIdx.x; i < 9 * 256; i += blockDim.x) s_t[i] = a.tables[i];
+  cavg_init();                                                               // ends with the workgroup barrier
+  if (!valid) return;
+  R2Y c;
+  c.t = s_t;
+  if (a.unclamped) { c.min_y = c.min_uv = 0; c.max_y = c.max_uv = 255; }
+  else { c.min_y = c.min_uv = 16; c.max_y = 235; c.max_uv = 240; }
+  auto rgb = [](uint32_t p, int &r, int &g, int &b) {
+    const int c0 = p & 0xFF, c1 = (p >> 8) & 0xFF, c2 = (p >> 16) & 0xFF;
+    if (ORDER == 1) { r = c2; g = c1; b = c0; } else { r = c0; g = c1; b = c2; }
+  };
+  // one row of the cell: four luma samples, U of pixels 0 and 2, V of pixels 1 and 3 (rgb2yuv's pairing, :6250-6322)
+  auto row = [&](pu4 q, uint32_t &yy, int u[2], int v[2], bool chroma) {
+    const uint32_t px[4] = {q.x, q.y, q.z, q.w};
+    yy = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int r, g, b;
+      rgb(px[i], r, g, b);
+      yy |= (uint32_t)c.Y(r, g, b) << (8 * i);
+      if (chroma) { if (i & 1) v[i >> 1] = c.cuv(c.Vraw(r, g, b)); else u[i >> 1] = c.cuv(c.Uraw(r, g, b)); }
+    }
+  };
+  const int ylim = 2 * hc;                                                   // luma rows the reference writes (an odd last row is read for its chroma only)
+  uint32_t ya, yb;
+  int ua[2] = {0, 0}, va[2] = {0, 0}, ub[2] = {0, 0}, vb[2] = {0, 0};
+  row(qa, ya, ua, va, unit != 0);
+  if (ra < ylim) *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)ra * a.orow[0] + 4 * (size_t)gx) = ya;
+  if (!unit) return;
+  if (has_b) {
+    row(qb, yb, ub, vb, true);
+    if (rb < ylim) *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)rb * a.orow[0] + 4 * (size_t)gx) = yb;
+#pragma unroll
+    for (int i = 0; i < 2; i++) { ua[i] = cavg(!a.unclamped, ub[i], ua[i]); va[i] = cavg(!a.unclamped, vb[i], va[i]); }
+  }
+  const int k = (int)unit - 1;
+  *reinterpret_cast<uint16_t *>(a.dst[1] + (size_t)k * a.orow[1] + 2 * (size_t)gx) = (uint16_t)((ua[0] & 0xFF) | ((ua[1] & 0xFF) << 8));
+  *reinterpret_cast<uint16_t *>(a.dst[2] + (size_t)k * a.orow[2] + 2 * (size_t)gx) = (uint16_t)((va[0] & 0xFF) | ((va[1] & 0xFF) << 8));
+}
+
 // ---- K3 -------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void put_rgb(uint8_t *d, int order, int ops, const int32_t *t, int Y, int U, int V, int A) {
   // yuv2rgb_int (:2345-2349): CLAMP0255f(spc_rnd(RGB_Y[y] + R_Cr[v])) ...
@@ -858,6 +919,22 @@ static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height
   a.lut16 = lut16_d;
   const int npairs = width >> 1;
   if (npairs == 0) return LGPU_OK;
+  // aligned 4-byte pixels -> 4:2:0: the cell form
+  static const bool no_s420 = getenv("LGPU_RGB2YUV_NO_S") != nullptr;
+  if (out_fmt == 4 && ips == 4 && in_order <= 1 && !no_s420 && (width & 3) == 0 && height >= 2 &&
+      (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 && (((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 3) == 0 &&
+      (((uintptr_t)dst_d[1] | (uintptr_t)orow[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[2]) & 1) == 0) {
+    const int ngr = width >> 2, nunits = (height >> 1) + 1;
+    const unsigned long long cells = (unsigned long long)ngr * nunits;
+    if (cells < (1ull << 31)) {
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+      const dim3 gs((unsigned)((cells + 511) / 512));
+      if (in_order == 0) hipLaunchKernelGGL(k_rgb_to_yuv420_s<0>, gs, dim3(512), 0, (hipStream_t)stream, a, magic);
+      else hipLaunchKernelGGL(k_rgb_to_yuv420_s<1>, gs, dim3(512), 0, (hipStream_t)stream, a, magic);
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
   const int nrows = out_fmt == 4 ? height >> 1 : height;
   const dim3 grid(cdiv((unsigned)npairs, kBlock), (unsigned)(nrows < 2048 ? nrows : 2048));
 #define K4_CASE(O, F) case (O) * 8 + (F): hipLaunchKernelGGL((k_rgb_to_yuv<O, F>), grid, dim3(kBlock), 0, (hipStream_t)stream, a); break;
