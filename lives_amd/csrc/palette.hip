@@ -296,6 +296,53 @@ __global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
   }
 }
 
+// UYVY / YUYV -> 4-byte RGB on aligned frames (a live-capture frame on its way into the chain): the cell shape of k_yuv420p_to_rgb_s / k_rgb_to_yuv420_s.
+// A lane owns two macropixels (8 bytes in, four pixels = 16 bytes out), cells are numbered linearly over the frame, the macropixels are requested before the tables
+// are staged, and the two chroma terms that share an index sit in one 8-byte LDS entry ({R_Cr, G_Cr}[v], {G_Cb, B_Cb}[u]): 1 + 2 / 2 gathers per pixel instead of 5.
+// Same arithmetic as put_rgb() above: CLAMP0255f((RGB_Y[y] + ...) >> 16), alpha 255.
+template <int FMT, int ORDER>
+__global__ __launch_bounds__(512) void k_uyvy_to_rgb_s(PalArgs a, uint32_t gmagic) {
+  __shared__ int32_t s_ty[256];
+  __shared__ uint2 s_rg[256], s_gb[256];
+  const int ngr = a.width >> 2;                          // cells per row
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);                    // floor magic: the quotient or one less
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  const bool valid = y < (uint32_t)a.height;
+  uint2 m = make_uint2(0u, 0u);
+  if (valid) m = *reinterpret_cast<const uint2 *>(a.src[0] + (size_t)y * a.irow[0] + 8 * (size_t)gx);
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    s_ty[e] = a.tables[e];
+    s_rg[e] = make_uint2((uint32_t)a.tables[256 + e], (uint32_t)a.tables[768 + e]);       // R_Cr, G_Cr (indexed by V)
+    s_gb[e] = make_uint2((uint32_t)a.tables[512 + e], (uint32_t)a.tables[1024 + e]);      // G_Cb, B_Cb (indexed by U)
+  }
+  __syncthreads();
+  if (!valid) return;
+  uint32_t px[4];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const uint32_t w = h ? m.y : m.x;
+    uint32_t Y0, Y1, U, V;
+    if (FMT == 2) { U = w & 0xFF; Y0 = (w >> 8) & 0xFF; V = (w >> 16) & 0xFF; Y1 = w >> 24; }      // uyvy2rgb :2410-2415
+    else { Y0 = w & 0xFF; U = (w >> 8) & 0xFF; Y1 = (w >> 16) & 0xFF; V = w >> 24; }                 // yuyv2rgb :2418-2423
+    const uint2 rg = s_rg[V], gb = s_gb[U];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int32_t yy = s_ty[i ? Y1 : Y0];
+      const uint32_t r = (uint32_t)clamp255((yy + (int32_t)rg.x) >> 16), g = (uint32_t)clamp255((yy + (int32_t)gb.x + (int32_t)rg.y) >> 16), b = (uint32_t)clamp255((yy + (int32_t)gb.y) >> 16);
+      // two byte permutes per pixel (selector 0x0C = 0x00, 0x0D = 0xFF); also keeps the compiler from fusing shift + clamp + pack into v_ashr_pk_u8_i32, whose
+      // upper result half it takes for zero (seen wrong on gfx950 with ROCm 7.2: the blue byte came out OR-ed with leftovers)
+      px[2 * h + i] = ORDER == 0 ? __builtin_amdgcn_perm(b, __builtin_amdgcn_perm(g, r, 0x0C0C0400u), 0x0D040100u)
+                    : ORDER == 1 ? __builtin_amdgcn_perm(r, __builtin_amdgcn_perm(g, b, 0x0C0C0400u), 0x0D040100u)
+                                 : __builtin_amdgcn_perm(b, __builtin_amdgcn_perm(g, r, 0x0C04000Du), 0x04020100u);
+    }
+  }
+  typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+  const pu4 o = {px[0], px[1], px[2], px[3]};
+  *reinterpret_cast<pu4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = o;
+}
+
 // ---- K4b: RGB -> YUV411 (src/colourspace.c:6499-6615, rgb2_411 :2322-2343) -----------------------------------------------------
 // lane = four pixels -> u2 y0 y1 v2 y2 y3; chroma is the sum of the four per-pixel (>> 16) values >> 2, clamped afterwards
 __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv411(PalArgs a) {
@@ -985,6 +1032,21 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
   a.order = out_order; a.alpha_in = (in_fmt <= 1) ? in_alpha : 0; a.fmt = in_fmt; a.alpha_out = out_alpha;
   a.unclamped = which_tables & 1;
   a.tables = device_tables()->yuv2rgb[which_tables & 3];
+  // UYVY / YUYV -> 4-byte pixels on aligned frames: the cell form
+  static const bool no_s = getenv("LGPU_UYVY_NO_S") != nullptr;
+  if (in_fmt >= 2 && ops == 4 && !no_s && (width & 3) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 && (((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0) {
+    const int ngr = width >> 2;
+    const unsigned long long cells = (unsigned long long)ngr * height;
+    if (cells < (1ull << 31)) {
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+      const dim3 gs((unsigned)((cells + 511) / 512));
+#define K3S_CASE(F, O) case (F) * 4 + (O): hipLaunchKernelGGL((k_uyvy_to_rgb_s<F, O>), gs, dim3(512), 0, (hipStream_t)stream, a, magic); break;
+      switch (in_fmt * 4 + out_order) { K3S_CASE(2, 0) K3S_CASE(2, 1) K3S_CASE(2, 2) K3S_CASE(3, 0) K3S_CASE(3, 1) K3S_CASE(3, 2) }
+#undef K3S_CASE
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
   const dim3 grid(cdiv((unsigned)((width + 1) >> 1), kBlock), (unsigned)(height < 2048 ? height : 2048));
 #define K3_CASE(F, O) case (F) * 4 + (O): hipLaunchKernelGGL((k_yuv_to_rgb<F, O>), grid, dim3(kBlock), 0, (hipStream_t)stream, a); break;
   switch (in_fmt * 4 + out_order) {

@@ -431,7 +431,7 @@ def test_rgb_to_yuv(gpu, orc, in_order, out_fmt):
 @pytest.mark.parametrize("out_order", [0, 1, 2])
 def test_yuv_to_rgb(gpu, orc, in_fmt, out_order):
     rng = np.random.default_rng(1800 + 10 * in_fmt + out_order)
-    sizes = [(20, 8), (66, 34), (130, 50), (258, 6)] + ([(21, 7), (1, 3)] if in_fmt <= 1 else [])
+    sizes = [(20, 8), (66, 34), (130, 50), (258, 6)] + ([(21, 7), (1, 3)] if in_fmt <= 1 else [(64, 32), (4, 1), (2048, 3), (516, 9)])       # in_fmt >= 2: widths the cell kernel takes
     n = 0
     for (w, h) in sizes:
         for in_alpha in ((0, 1) if in_fmt <= 1 else (0,)):
