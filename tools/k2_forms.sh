@@ -1,5 +1,6 @@
 #!/bin/bash
-# K2 kernel forms against the launch size: the one-copy form (k_yuv420p_to_rgb_s), the 16-copy form (k_yuv420p_to_rgb16) and the older kernels, rocprofv3 kernel time
+# K2 launch shapes of k_yuv420p_to_rgb_s against the launch size (cell width, workgroup size, resident groups per CU), rocprofv3 kernel time.
+# (profiles/r03/k2_forms.txt was made by an earlier version of this script, when the 16-copy-table and four-column kernels still existed.)
 cd $GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/k2forms; mkdir -p $O
@@ -21,9 +22,9 @@ P
 for geo in "1 1920 1080" "4 1920 1080" "16 1920 1080" "1 3840 2160"; do
   for wgs in 4 8 16 100000; do
     for blk in 256 512 1024; do
-      run "w$wgs b$blk" $geo LGPU_YUV_NO16=1 LGPU_YUV_S_WGS=$wgs LGPU_YUV_S_BLOCK=$blk
+      run "w$wgs b$blk" $geo LGPU_YUV_S_WGS=$wgs LGPU_YUV_S_BLOCK=$blk
     done
   done
-  run "nc1 w8 b512" $geo LGPU_YUV_NO16=1 LGPU_YUV_S_WGS=8 LGPU_YUV_S_BLOCK=512 LGPU_YUV_S_NC=1
-  run "nc4 w8 b512" $geo LGPU_YUV_NO16=1 LGPU_YUV_S_WGS=8 LGPU_YUV_S_BLOCK=512 LGPU_YUV_S_NC=4
+  run "nc1 w8 b512" $geo LGPU_YUV_S_WGS=8 LGPU_YUV_S_BLOCK=512 LGPU_YUV_S_NC=1
+  run "nc4 w8 b512" $geo LGPU_YUV_S_WGS=8 LGPU_YUV_S_BLOCK=512 LGPU_YUV_S_NC=4
 done

@@ -16,7 +16,7 @@ for r in csv.DictReader(open(f[0])):
 P
 }
 for rep in 1 2; do
-run "classic" LGPU_YUV_NO_S=1
+run "classic" LGPU_YUV_S_NC=0
 run "s nc1 b256" LGPU_YUV_S_NC=1 LGPU_YUV_S_BLOCK=256
 run "s nc1 b512" LGPU_YUV_S_NC=1 LGPU_YUV_S_BLOCK=512
 run "s nc1 b1024" LGPU_YUV_S_NC=1 LGPU_YUV_S_BLOCK=1024
