@@ -183,6 +183,20 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut, 
   for (; unit < nunits; unit += gridDim.y) yuv420_cell(a, c, unit, k, hw, npairs);
 }
 
+// one (row i, chroma column k) cell of the 4:2:2 walk (:3593-3640 / :3858-3901): "last / this" are seeded from chroma row i >> 1 (reference), so the first pair of a
+// row takes its left samples from there
+__device__ __forceinline__ void yuv422_cell(const YuvArgs &a, const YuvCtx &c, int i, int k) {
+  auto PU = [&](int r, int kk) -> int { long q = (long)r * a.us + kk; return a.u[q < a.usize ? q : a.usize - 1]; };
+  auto PV = [&](int r, int kk) -> int { long q = (long)r * a.vs + kk; return a.v[q < a.vsize ? q : a.vsize - 1]; };
+  const int tu = k ? PU(i, k) : PU(i >> 1, 0), tv = k ? PV(i, k) : PV(i >> 1, 0);
+  const int lu = (k >= 2) ? PU(i, k - 1) : PU(i >> 1, 0), lv = (k >= 2) ? PV(i, k - 1) : PV(i >> 1, 0);
+  const int nu = PU(i, k + 1), nv = PV(i, k + 1);
+  const uint8_t *yr = a.y + (size_t)i * a.ys + 2 * k;
+  const uint32_t p0 = c.rgb(yr[0], c.cuv((tu + lu) >> 1), c.cuv((tv + lv) >> 1));
+  const uint32_t p1 = c.rgb(yr[1], c.cuv((tu + nu) >> 1), c.cuv((tv + nv) >> 1));
+  c.store2(a.dst + (size_t)i * a.orow + (size_t)(2 * k) * a.opsize, p0, p1);
+}
+
 // ---- every launch whose rows are aligned: k_yuv420p_to_rgb_s --------------------------------------------------------------------------
 // profiles/r03/k2_single_pmc.md: the one-cell-per-lane kernel above spends 269 VALU + 179 SALU + 34 LDS instructions per wave on 256 pixels, 8,656 waves in
 // two generations of 2,164 workgroups that each stage 5.4 KB of tables (one 1080p frame: 11.6 us).  This form:
@@ -195,7 +209,8 @@ __global__ __launch_bounds__(kBlock) void k_yuv420p_to_rgb(YuvArgs a, Lut8 lut, 
 //   * edge cells (row 0, the trailing row, plane ends) walk yuv420_cell() on the same LDS tables.
 // One 1080p frame: 11.6 -> 6.5 us; 16 x 1080p: 47.9 us (the 16-copy-table kernel of round 2, removed) -> 40 us (profiles/r03/k2_forms.txt).
 constexpr int kYsOffTy = 0, kYsOffRG = 1024, kYsOffGB = 3072, kYsOffLut = 5120, kYsLds = 5376;
-template <int NC, int ORDER, bool LUT>
+// V422: planar 4:2:2 (one luma row per cell, chroma averaged along the row only; the first column group of a row goes through yuv422_cell())
+template <int NC, int ORDER, bool LUT, bool V422 = false>
 __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, YuvBatch bt, int batched, uint32_t cgmagic) {
   if (batched) { a.y = bt.y[blockIdx.y]; a.u = bt.u[blockIdx.y]; a.v = bt.v[blockIdx.y]; a.dst = bt.dst[blockIdx.y]; }
   __shared__ __attribute__((aligned(16))) uint8_t smem[kYsLds];
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, 
   const int tid = threadIdx.x, nth = blockDim.x;
   const int hw = a.width >> 1, ncg = (hw + NC - 1) / NC;
   const int npairs = (a.height - 1) / 2;
-  const int nunits = 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
+  const int nunits = V422 ? a.height : 1 + npairs + (((a.height - 1) & 1) ? 1 : 0);
   struct Cell { ywin_t ya, yb; win_t u0, u1, v0, v1; uint32_t lv2; int unit, k0; bool valid, fast; };
   auto fetch = [&](uint32_t idx) -> Cell {
     Cell q;
@@ -213,10 +228,21 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, 
     if (cg >= (uint32_t)ncg) { cg -= ncg; unit++; }
     q.unit = (int)unit; q.k0 = NC * (int)cg;
     q.valid = unit < (uint32_t)nunits;
+    q.ya = q.yb = 0; q.u0 = q.u1 = q.v0 = q.v1 = 0; q.lv2 = 0;
+    if (V422) {
+      // row q.unit; columns k0 >= 2 only (the first pairs of a row take their left samples from chroma row i >> 1), the window k0 - 1 .. inside the plane
+      const int i2 = q.unit;
+      q.fast = q.valid && q.k0 >= 2 && q.k0 + NC <= hw && (long)i2 * a.us + q.k0 - 1 + (long)sizeof(win_t) <= a.usize && (long)i2 * a.vs + q.k0 - 1 + (long)sizeof(win_t) <= a.vsize;
+      if (q.fast) {
+        auto ld = [](const uint8_t *p) -> win_t { win_t w; __builtin_memcpy(&w, p, sizeof(win_t)); return w; };
+        q.ya = *reinterpret_cast<const ywin_t *>(a.y + (size_t)i2 * a.ys + 2 * q.k0);
+        q.u0 = ld(a.u + (size_t)i2 * a.us + q.k0 - 1); q.v0 = ld(a.v + (size_t)i2 * a.vs + q.k0 - 1);
+      }
+      return q;
+    }
     const int i = 2 * q.unit - 1, r = i >> 1;
     q.fast = q.valid && q.unit >= 1 && q.unit <= npairs && q.k0 + NC <= hw && (long)(r + 1) * a.us + q.k0 + (long)sizeof(win_t) <= a.usize &&
              (long)(r + 1) * a.vs + q.k0 + (long)sizeof(win_t) <= a.vsize;
-    q.ya = q.yb = 0; q.u0 = q.u1 = q.v0 = q.v1 = 0; q.lv2 = 0;
     if (q.fast) {
       auto ld = [](const uint8_t *p) -> win_t { win_t w; __builtin_memcpy(&w, p, sizeof(win_t)); return w; };
       q.ya = *reinterpret_cast<const ywin_t *>(a.y + (size_t)i * a.ys + 2 * q.k0); q.yb = *reinterpret_cast<const ywin_t *>(a.y + (size_t)(i + 1) * a.ys + 2 * q.k0);
@@ -282,7 +308,22 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, 
       const int32_t *t32 = reinterpret_cast<const int32_t *>(smem);
       c.ty = t32 + kYsOffTy / 4; c.rcr = t32 + kYsOffRG / 4; c.gcr = t32 + kYsOffRG / 4 + 1; c.gcb = t32 + kYsOffGB / 4; c.bcb = t32 + kYsOffGB / 4 + 1; c.cs = 2;
       c.lut = smem + kYsOffLut; c.lut16 = nullptr; c.clamped = a.clamped; c.lowq = false; c.use_lut = LUT; c.opsize = 4; c.order = ORDER;
-      for (int k = cur.k0; k < cur.k0 + NC && k < hw; k++) yuv420_cell(a, c, cur.unit, k, hw, npairs);
+      for (int k = cur.k0; k < cur.k0 + NC && k < hw; k++) { if (V422) yuv422_cell(a, c, cur.unit, k); else yuv420_cell(a, c, cur.unit, k, hw, npairs); }
+    } else if (V422) {
+      uint32_t px[2 * NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        const uint32_t tu = at(cur.u0, j), tv = at(cur.v0, j);
+        px[2 * j] = pixel(yat(cur.ya, 2 * j), (((tu + at(cur.u0, j - 1)) >> 1) << 3) + bu, (((tv + at(cur.v0, j - 1)) >> 1) << 3) + bv);
+        px[2 * j + 1] = pixel(yat(cur.ya, 2 * j + 1), (((tu + at(cur.u0, j + 1)) >> 1) << 3) + bu, (((tv + at(cur.v0, j + 1)) >> 1) << 3) + bv);
+      }
+      uint8_t *d0 = a.dst + (size_t)cur.unit * a.orow + (size_t)(2 * cur.k0) * 4;
+      if (NC == 1) *reinterpret_cast<uint2 *>(d0) = make_uint2(px[0], px[1]);
+      else {
+        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < NC / 2; q++) { const u32x4s t = {px[4 * q], px[4 * q + 1], px[4 * q + 2], px[4 * q + 3]}; reinterpret_cast<u32x4s *>(d0)[q] = t; }
+      }
     } else {
       win_t u0 = cur.u0, u1 = cur.u1, v0 = cur.v0, v1 = cur.v1;
       if (!cur.k0) {
@@ -336,17 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv422p_to_rgb(YuvArgs a, Lut8 lut, 
   const int hw = a.width >> 1;
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= hw) return;
-  auto PU = [&](int r, int kk) -> int { long i = (long)r * a.us + kk; return a.u[i < a.usize ? i : a.usize - 1]; };
-  auto PV = [&](int r, int kk) -> int { long i = (long)r * a.vs + kk; return a.v[i < a.vsize ? i : a.vsize - 1]; };
-  for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
-    const int tu = k ? PU(i, k) : PU(i >> 1, 0), tv = k ? PV(i, k) : PV(i >> 1, 0);
-    const int lu = (k >= 2) ? PU(i, k - 1) : PU(i >> 1, 0), lv = (k >= 2) ? PV(i, k - 1) : PV(i >> 1, 0);
-    const int nu = PU(i, k + 1), nv = PV(i, k + 1);
-    const uint8_t *yr = a.y + (size_t)i * a.ys + 2 * k;
-    const uint32_t p0 = c.rgb(yr[0], c.cuv((tu + lu) >> 1), c.cuv((tv + lv) >> 1));
-    const uint32_t p1 = c.rgb(yr[1], c.cuv((tu + nu) >> 1), c.cuv((tv + nv) >> 1));
-    c.store2(a.dst + (size_t)i * a.orow + (size_t)(2 * k) * a.opsize, p0, p1);
-  }
+  for (int i = blockIdx.y; i < a.height; i += gridDim.y) yuv422_cell(a, c, i, k);
 }
 
 }  // namespace lgpu
@@ -417,14 +448,14 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   // aligned rows, 4-byte pixels, no LUT16, not the LOW quality setting: the paired-table form; everything else the one-cell-per-lane kernels
   const YuvTuning &tn = yuv_tuning();
   const int s_nc = tn.nc.load(), s_block = tn.block.load(), s_wgs = tn.wgs.load();
-  bool form_s = !is_422 && s_nc && opsize == 4 && !lut16_d && !a.low_quality && (a.ys & (2 * s_nc - 1)) == 0 && (orow & (s_nc == 1 ? 7 : 15)) == 0 && nbatch <= 65535;
+  bool form_s = s_nc && opsize == 4 && !lut16_d && !a.low_quality && (a.ys & (2 * s_nc - 1)) == 0 && (orow & (s_nc == 1 ? 7 : 15)) == 0 && nbatch <= 65535;
   for (int f = 0; f < nbatch && form_s; f++) {
     const uintptr_t py = (uintptr_t)(batch ? batch->y[f] : y_d), pd = (uintptr_t)(batch ? batch->dst[f] : dst_d);
     form_s = (py & (2 * s_nc - 1)) == 0 && (pd & (s_nc == 1 ? 7 : 15)) == 0;
   }
   if (form_s) {
     const int hw = width >> 1, ncg = (hw + s_nc - 1) / s_nc;
-    const int npairs_h = (height - 1) / 2, nunits_h = 1 + npairs_h + (((height - 1) & 1) ? 1 : 0);
+    const int npairs_h = (height - 1) / 2, nunits_h = is_422 ? height : 1 + npairs_h + (((height - 1) & 1) ? 1 : 0);
     const unsigned long long cells = (unsigned long long)ncg * nunits_h;
     if (cells < (1ull << 31)) {
       const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ncg - (ncg == 1 ? 1 : 0));
@@ -436,7 +467,10 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
       const dim3 gs(gx, (unsigned)nbatch);
 #define YS_LAUNCH(NC_, ORDER_)                                                                                                          \
       do {                                                                                                                             \
-        if (a.use_lut) hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, true>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);  \
+        if (is_422) {                                                                                                                  \
+          if (a.use_lut) hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, true, true>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);  \
+          else hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, false, true>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);        \
+        } else if (a.use_lut) hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, true>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);  \
         else hipLaunchKernelGGL((k_yuv420p_to_rgb_s<NC_, ORDER_, false>), gs, dim3(s_block), 0, (hipStream_t)stream, a, l, bt, batch ? 1 : 0, magic);        \
       } while (0)
       if (s_nc == 4) { if (out_order == 0) YS_LAUNCH(4, 0); else if (out_order == 1) YS_LAUNCH(4, 1); else YS_LAUNCH(4, 2); }

@@ -931,17 +931,18 @@ def test_yuv420p_every_cell_width(gpu, orc, yuv_tuning, nc):
                     for (w, h, ys, cs) in [(64, 32, 64, 32), (66, 34, 96, 48), (130, 19, 160, 80), (24, 6, 32, 16), (2, 2, 8, 4), (6, 3, 8, 4), (640, 480, 640, 320), (1920, 64, 1920, 960)]:
                         if (which, order, use_lut) != (0, 0, 1) and (w, block) not in ((66, 256), (130, 512), (24, 1024)):
                             continue                    # the full size list once per shape, three sizes for every table set / order / LUT
-                        lut = lut_for(rng, "l2s") if use_lut else None
-                        Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
-                        U = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
-                        V = rng.integers(0, 256, (h // 2, cs), dtype=np.uint8)
-                        orow = align(w * 4)
-                        strides = (ctypes.c_int * 3)(ys, cs, cs)
-                        want = np.full((h, orow), 0xAB, np.uint8)
-                        orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, order, 0, which, 2, P(lut) if use_lut else None, 0)
-                        d = dev(np.full_like(want, 0xAB))
-                        gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, out_order=order, which_tables=which, pb_quality=2, lut=lut)
-                        assert_same(host(d), want, w, h, 4, "yuv420p nc=%d block=%d %dx%d which=%d order=%d lut=%d" % (nc, block, w, h, which, order, use_lut))
+                        for is422 in (0, 1):             # planar 4:2:2 rides the same kernel (one luma row per cell)
+                            lut = lut_for(rng, "l2s") if use_lut else None
+                            Y = rng.integers(0, 256, (h, ys), dtype=np.uint8)
+                            U = rng.integers(0, 256, (h if is422 else h // 2, cs), dtype=np.uint8)
+                            V = rng.integers(0, 256, (h if is422 else h // 2, cs), dtype=np.uint8)
+                            orow = align(w * 4)
+                            strides = (ctypes.c_int * 3)(ys, cs, cs)
+                            want = np.full((h, orow), 0xAB, np.uint8)
+                            orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(want), orow, w, h, 4, order, is422, which, 2, P(lut) if use_lut else None, 0)
+                            d = dev(np.full_like(want, 0xAB))
+                            gpu.yuv420p_to_rgb(dev(Y), dev(U), dev(V), d, w, h, opsize=4, out_order=order, is_422=is422, which_tables=which, pb_quality=2, lut=lut)
+                            assert_same(host(d), want, w, h, 4, "yuv42%dp nc=%d block=%d %dx%d which=%d order=%d lut=%d" % (2 if is422 else 0, nc, block, w, h, which, order, use_lut))
     # extreme samples: every (y, u, v) corner reaches the ends of the clamps
     yuv_tuning(nc, 512, 8)
     w, h = 64, 32

@@ -139,6 +139,9 @@ def main():
     bframes = list(zip(bY, bU, bV, bD))
     t = timeit(lambda i: ops.yuv420p_to_rgb_batch(bframes, w, h, lut=lut), 1)
     add("yuv420p->RGBA32 + gamma LUT, 16 frames / launch", "colourspace.c:3260-3904, :14034", "16 x 1920x1080", NT * (w * h * 3 // 2 + w * h * 4), t, None)
+    U2, V2 = dframe(w // 2, h, 1, NB), dframe(w // 2, h, 1, NB)
+    t = timeit(lambda i: ops.yuv420p_to_rgb(Y[i], U2[i], V2[i], dst[i], w, h, is_422=1, lut=lut), NB)
+    add("yuv422p->RGBA32 + gamma LUT", "colourspace.c:3593-3640, :14034", "1920x1080", w * h * 2 + w * h * 4, t, None)
     # ---- K6 gamma apply, K9 premult (in place) ---------------------------------------------------------------------------------
     pix = dframe(w, h, 4, NB)
     t = timeit(lambda i: ops.gamma_apply(pix[i], w, h, 4, lut), NB)
