@@ -246,6 +246,49 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gma
   *reinterpret_cast<uint16_t *>(a.dst[2] + (size_t)k * a.orow[2] + 2 * (size_t)gx) = (uint16_t)((va[0] & 0xFF) | ((va[1] & 0xFF) << 8));
 }
 
+// RGBA32 / BGRA32 -> UYVY / YUYV / YUV422P on aligned frames: the same cell shape, one row per cell (rgb2uyvy / rgb2yuyv :2162-2192: U of a pair's first pixel,
+// V of its second, no averaging; the YUYV form keeps only the lower chroma clamp, as the reference does).  FMT as in k_rgb_to_yuv: 2 UYVY, 3 YUYV, 5 planar 4:2:2.
+template <int ORDER, int FMT>
+__global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gmagic) {
+  __shared__ int32_t s_t[9 * 256];
+  typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+  const int ngr = a.width >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);                                        // floor magic: the quotient or one less
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  const bool valid = y < (uint32_t)a.height;
+  pu4 q = {0, 0, 0, 0};
+  if (valid) q = *reinterpret_cast<const pu4 *>(a.src[0] + (size_t)y * a.irow[0] + 16 * (size_t)gx);
+  for (int i = threadIdx.x; i < 9 * 256; i += blockDim.x) s_t[i] = a.tables[i];
+  __syncthreads();
+  if (!valid) return;
+  R2Y c;
+  c.t = s_t;
+  if (a.unclamped) { c.min_y = c.min_uv = 0; c.max_y = c.max_uv = 255; }
+  else { c.min_y = c.min_uv = 16; c.max_y = 235; c.max_uv = 240; }
+  const uint32_t px[4] = {q.x, q.y, q.z, q.w};
+  uint32_t yy[4], uu[2], vv[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c0 = px[i] & 0xFF, c1 = (px[i] >> 8) & 0xFF, c2 = (px[i] >> 16) & 0xFF;
+    const int r = ORDER == 1 ? c2 : c0, g = c1, b = ORDER == 1 ? c0 : c2;
+    yy[i] = (uint32_t)c.Y(r, g, b);
+    if (i & 1) { const int vr = c.Vraw(r, g, b); vv[i >> 1] = FMT == 3 ? ((uint32_t)(vr < c.min_uv ? c.min_uv : vr) & 0xFF) : (uint32_t)c.cuv(vr); }
+    else { const int ur = c.Uraw(r, g, b); uu[i >> 1] = FMT == 3 ? ((uint32_t)(ur < c.min_uv ? c.min_uv : ur) & 0xFF) : (uint32_t)c.cuv(ur); }
+  }
+  if (FMT == 5) {
+    *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + 4 * (size_t)gx) = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
+    *reinterpret_cast<uint16_t *>(a.dst[1] + (size_t)y * a.orow[1] + 2 * (size_t)gx) = (uint16_t)(uu[0] | (uu[1] << 8));
+    *reinterpret_cast<uint16_t *>(a.dst[2] + (size_t)y * a.orow[2] + 2 * (size_t)gx) = (uint16_t)(vv[0] | (vv[1] << 8));
+  } else {
+    uint2 o;
+    if (FMT == 2) { o.x = uu[0] | (yy[0] << 8) | (vv[0] << 16) | (yy[1] << 24); o.y = uu[1] | (yy[2] << 8) | (vv[1] << 16) | (yy[3] << 24); }
+    else { o.x = yy[0] | (uu[0] << 8) | (yy[1] << 16) | (vv[0] << 24); o.y = yy[2] | (uu[1] << 8) | (yy[3] << 16) | (vv[1] << 24); }
+    *reinterpret_cast<uint2 *>(a.dst[0] + (size_t)y * a.orow[0] + 8 * (size_t)gx) = o;
+  }
+}
+
 // ---- K3 -------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void put_rgb(uint8_t *d, int order, int ops, const int32_t *t, int Y, int U, int V, int A) {
   // yuv2rgb_int (:2345-2349): CLAMP0255f(spc_rnd(RGB_Y[y] + R_Cr[v])) ...
@@ -978,6 +1021,23 @@ static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height
       const dim3 gs((unsigned)((cells + 511) / 512));
       if (in_order == 0) hipLaunchKernelGGL(k_rgb_to_yuv420_s<0>, gs, dim3(512), 0, (hipStream_t)stream, a, magic);
       else hipLaunchKernelGGL(k_rgb_to_yuv420_s<1>, gs, dim3(512), 0, (hipStream_t)stream, a, magic);
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
+  // aligned 4-byte pixels -> packed / planar 4:2:2 without a gamma LUT: the cell form
+  if ((out_fmt == 2 || out_fmt == 3 || out_fmt == 5) && ips == 4 && in_order <= 1 && !lut16_d && !no_s420 && (width & 3) == 0 &&
+      (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 &&
+      (out_fmt == 5 ? ((((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 3) == 0 && (((uintptr_t)dst_d[1] | (uintptr_t)orow[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[2]) & 1) == 0)
+                    : ((((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 7) == 0))) {
+    const int ngr = width >> 2;
+    const unsigned long long cells = (unsigned long long)ngr * height;
+    if (cells < (1ull << 31)) {
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+      const dim3 gs((unsigned)((cells + 511) / 512));
+#define K4S_CASE(O, F) case (O) * 8 + (F): hipLaunchKernelGGL((k_rgb_to_yuv422_s<O, F>), gs, dim3(512), 0, (hipStream_t)stream, a, magic); break;
+      switch (in_order * 8 + out_fmt) { K4S_CASE(0, 2) K4S_CASE(0, 3) K4S_CASE(0, 5) K4S_CASE(1, 2) K4S_CASE(1, 3) K4S_CASE(1, 5) }
+#undef K4S_CASE
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }

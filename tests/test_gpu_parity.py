@@ -408,6 +408,8 @@ def test_rgb_to_yuv(gpu, orc, in_order, out_fmt):
         pytest.skip("ARGB32 -> 4:2:0 / 4:2:2: reference-broken, declined")
     rng = np.random.default_rng(1700 + 10 * in_order + out_fmt)
     sizes = [(20, 8), (66, 34), (130, 50), (258, 6)] + ([(21, 7), (1, 3)] if out_fmt <= 1 else [])
+    if out_fmt in (2, 3, 5):
+        sizes += [(64, 32), (4, 1), (2048, 3), (516, 9)]       # widths the one-row cell kernel takes (k_rgb_to_yuv422_s)
     if out_fmt == 4:
         sizes += [(64, 32), (128, 8), (4, 2), (256, 2), (2048, 4), (516, 10)]       # widths the 4 x 2 cell kernel takes (k_rgb_to_yuv420_s), one chroma row, a partial last workgroup
     for (w, h) in sizes:

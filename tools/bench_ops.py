@@ -256,6 +256,9 @@ def main():
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int]
     c = cpu(lambda: orc.orc_rgb_to_yuv(P(hs), hs.strides[0], w, h, 0, 1, ctypes.addressof(pp), ctypes.addressof(ss), 4, 0, 0))
     add("RGBA32 -> YUV420P", "colourspace.c:6250-6322", "1920x1080", w * h * 4 * 3 // 2 + w * h * 3 // 2, t, c)
+    uy = dframe(w // 2, h, 4, NB)
+    t = timeit(lambda i: ops.rgb_to_yuv(rgba[i], [uy[i]], w, h, 0, 1, 2, 0, 0), NB)
+    add("RGBA32 -> UYVY", "colourspace.c:5761-5830, :2162-2176", "1920x1080", w * h * 4 + w * h * 2, t, None)
     uy = dframe(w, h, 2, NB)
     t = timeit(lambda i: ops.yuv_to_rgb([uy[i]], rgba[i], w, h, 2, 0, 0, 1, 0), NB)
     hu2 = hframe(w, h, 2)
