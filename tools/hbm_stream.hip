@@ -61,6 +61,42 @@ __global__ __launch_bounds__(256) void k_mix5(const u4 *big, const u4 *small, u4
   }
 }
 
+// rows: the chain kernel's own access shape -- 16 frames of 3840 x 2160 x 4 (pitch 15,360 B) in one buffer; a wave owns a strip of LPL KB of a band of 12 rows and
+// walks it row by row (LPL 16-byte loads per lane and row, the next row requested before the current one is consumed), plus one 8-byte read and one 8-byte write
+// per lane and PAIR of rows from / to two 1920 x 1080 x 4 frames (layer 2, destination): the launch's 5 : 1 : 1 byte mix with its 2-D locality instead of a
+// linear stream.  Work order: wave w -> (frame, strip, band), band-minor, as k_pb_half numbers it.
+template <int LPL, int NT>
+__global__ __launch_bounds__(256) void k_rows(const u4 *src, const uint2 *l2, uint2 *dst, int nwaves) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wave >= nwaves) return;
+  const int strips = 15360 / (1024 * LPL), bands = 180;
+  const int band = wave % bands, strip = (wave / bands) % strips, frame = wave / (bands * strips);
+  const size_t fbase = (size_t)frame * 2160 * 15360 / 16;
+  const u4 *p = src + fbase + (size_t)(band * 12) * (15360 / 16) + (size_t)strip * (64 * LPL) + lane;
+  u4 acc = {0, 0, 0, 0};
+  u4 cur[LPL], nxt[LPL];
+#pragma unroll
+  for (int u = 0; u < LPL; u++) cur[u] = ld<NT>(p + 64 * u);
+  for (int r = 0; r < 12; r++) {
+    const u4 *q = p + (size_t)(r + 1) * (15360 / 16);
+#pragma unroll
+    for (int u = 0; u < LPL; u++) nxt[u] = r + 1 < 12 ? ld<NT>(q + 64 * u) : cur[u];
+#pragma unroll
+    for (int u = 0; u < LPL; u++) acc ^= cur[u];
+    if (r & 1) {
+      const size_t o = (size_t)frame * 1080 * 960 + (size_t)(band * 6 + (r >> 1)) * 960 + (size_t)strip * (64 * LPL) + lane;      // 8-byte units: a 1920 x 4 row has 960
+#pragma unroll
+      for (int u = 0; u < LPL; u++) {
+        const uint2 a = l2[o + 64 * u];
+        uint2 w; w.x = a.x ^ acc.x ^ acc.z; w.y = a.y ^ acc.y ^ acc.w;
+        dst[o + 64 * u] = w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LPL; u++) cur[u] = nxt[u];
+  }
+}
+
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
 int main(int argc, char **argv) {
@@ -98,5 +134,22 @@ int main(int argc, char **argv) {
   run("copy nt x4", 2 * big_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_copy<1, 4>), dim3(g), dim3(256), 0, 0, big[s], dst[s], big_units); });
   run("mix5 (5R:1W) plain", 6 * out_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_mix5<0>), dim3(g), dim3(256), 0, 0, big[s], small[s], dst[s], out_units); });
   run("mix5 (5R:1W) nt", 6 * out_units * 16.0, [&](int g, int s) { hipLaunchKernelGGL((k_mix5<1>), dim3(g), dim3(256), 0, 0, big[s], small[s], dst[s], out_units); });
+  // the chain kernel's 2-D shape: strips of 1 / 2 / 4 KB per wave and row
+  {
+    const double bytes = 16.0 * (3840.0 * 2160 * 4 + 2 * 1920.0 * 1080 * 4);
+    auto rows = [&](const char *name, int lpl, auto launch) {
+      const int nwaves = 16 * (15360 / (1024 * lpl)) * 180;
+      for (int w = 0; w < 6; w++) launch((nwaves + 3) / 4, w & 1, nwaves);
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; r++) launch((nwaves + 3) / 4, r & 1, nwaves);
+      CK(hipEventRecord(e1, 0));
+      const float ms = time_ms(e0, e1) / reps;
+      printf("%-22s waves %6d  %8.2f us  %8.1f GB/s\n", name, nwaves, ms * 1e3, bytes / (ms * 1e-3) / 1e9);
+    };
+    rows("rows 1 KB strips", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<1, 0>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+    rows("rows 2 KB strips", 2, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<2, 0>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+    rows("rows 4 KB strips", 4, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<4, 0>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+    rows("rows 1 KB strips nt", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<1, 1>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+  }
   return 0;
 }
