@@ -65,12 +65,17 @@ __global__ __launch_bounds__(256) void k_mix5(const u4 *big, const u4 *small, u4
 // walks it row by row (LPL 16-byte loads per lane and row, the next row requested before the current one is consumed), plus one 8-byte read and one 8-byte write
 // per lane and PAIR of rows from / to two 1920 x 1080 x 4 frames (layer 2, destination): the launch's 5 : 1 : 1 byte mix with its 2-D locality instead of a
 // linear stream.  Work order: wave w -> (frame, strip, band), band-minor, as k_pb_half numbers it.
-template <int LPL, int NT>
+template <int LPL, int NT, int MAP = 0>
 __global__ __launch_bounds__(256) void k_rows(const u4 *src, const uint2 *l2, uint2 *dst, int nwaves) {
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wave >= nwaves) return;
   const int strips = 15360 / (1024 * LPL), bands = 180;
-  const int band = wave % bands, strip = (wave / bands) % strips, frame = wave / (bands * strips);
+  int band = wave % bands, strip = (wave / bands) % strips, frame = wave / (bands * strips);
+  if (MAP == 1) {                                  // a workgroup = four adjacent strips of one band, workgroups band-minor: k_pb_half's own numbering
+    const int cgroups = (strips + 3) / 4, wg = blockIdx.x, w = threadIdx.x >> 6;
+    band = wg % bands; strip = ((wg / bands) % cgroups) * 4 + w; frame = wg / (bands * cgroups);
+    if (strip >= strips || frame >= 16) return;
+  }
   const size_t fbase = (size_t)frame * 2160 * 15360 / 16;
   const u4 *p = src + fbase + (size_t)(band * 12) * (15360 / 16) + (size_t)strip * (64 * LPL) + lane;
   u4 acc = {0, 0, 0, 0};
@@ -94,6 +99,32 @@ __global__ __launch_bounds__(256) void k_rows(const u4 *src, const uint2 *l2, ui
     }
 #pragma unroll
     for (int u = 0; u < LPL; u++) cur[u] = nxt[u];
+  }
+}
+
+// the same 1 KB strips with PF rows requested ahead instead of one (registers instead of waves as the place where bytes wait)
+template <int PF>
+__global__ __launch_bounds__(256) void k_rows_pf(const u4 *src, const uint2 *l2, uint2 *dst, int nwaves) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wave >= nwaves) return;
+  const int strips = 15, bands = 180;
+  const int band = wave % bands, strip = (wave / bands) % strips, frame = wave / (bands * strips);
+  const u4 *p = src + (size_t)frame * 2160 * 15360 / 16 + (size_t)(band * 12) * (15360 / 16) + (size_t)strip * 64 + lane;
+  u4 acc = {0, 0, 0, 0};
+  u4 q[PF];
+#pragma unroll
+  for (int u = 0; u < PF; u++) q[u] = *(p + (size_t)u * (15360 / 16));
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    const u4 cur = q[r % PF];
+    if (r + PF < 12) q[r % PF] = *(p + (size_t)(r + PF) * (15360 / 16));
+    acc ^= cur;
+    if (r & 1) {
+      const size_t o = (size_t)frame * 1080 * 960 + (size_t)(band * 6 + (r >> 1)) * 960 + (size_t)strip * 64 + lane;
+      const uint2 a = l2[o];
+      uint2 w; w.x = a.x ^ acc.x ^ acc.z; w.y = a.y ^ acc.y ^ acc.w;
+      dst[o] = w;
+    }
   }
 }
 
@@ -149,6 +180,18 @@ int main(int argc, char **argv) {
     rows("rows 1 KB strips", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<1, 0>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
     rows("rows 2 KB strips", 2, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<2, 0>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
     rows("rows 4 KB strips", 4, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<4, 0>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+    {
+      const int nwg = 16 * 4 * 180;               // 16 frames x ceil(15 / 4) strip groups x 180 bands
+      for (int w = 0; w < 6; w++) hipLaunchKernelGGL((k_rows<1, 0, 1>), dim3(nwg), dim3(256), 0, 0, big[w & 1], (const uint2 *)small[w & 1], (uint2 *)dst[w & 1], 1 << 30);
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; r++) hipLaunchKernelGGL((k_rows<1, 0, 1>), dim3(nwg), dim3(256), 0, 0, big[r & 1], (const uint2 *)small[r & 1], (uint2 *)dst[r & 1], 1 << 30);
+      CK(hipEventRecord(e1, 0));
+      const float ms = time_ms(e0, e1) / reps;
+      printf("%-22s wgs   %6d  %8.2f us  %8.1f GB/s\n", "rows 1 KB, wg = 4 adjacent strips", nwg, ms * 1e3, bytes / (ms * 1e-3) / 1e9);
+    }
+    rows("rows 1 KB, 2 rows ahead", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows_pf<2>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+    rows("rows 1 KB, 4 rows ahead", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows_pf<4>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
+    rows("rows 1 KB, 12 rows ahead", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows_pf<12>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
     rows("rows 1 KB strips nt", 1, [&](int g, int s, int n) { hipLaunchKernelGGL((k_rows<1, 1>), dim3(g), dim3(256), 0, 0, big[s], (const uint2 *)small[s], (uint2 *)dst[s], n); });
   }
   return 0;
