@@ -165,6 +165,27 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
 
 using namespace lgpu;
 
+// the gaussian alone through the same kernel (key off): what lgpu_gauss5 takes for aligned 3- and 4-byte frames.  LGPU_E_UNSUPPORTED: the caller's other kernels.
+namespace lgpu {
+int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, hipStream_t st) {
+  const uintptr_t bits = (uintptr_t)src_d | (uintptr_t)dst_d | (uintptr_t)irow | (uintptr_t)orow;
+  if ((psize != 3 && psize != 4) || (width & 3) || (bits & (psize == 4 ? 15 : 3))) return LGPU_E_UNSUPPORTED;
+  GckArgs a;
+  __builtin_memset(&a, 0, sizeof a);
+  a.src0 = src_d; a.src1 = nullptr; a.dst = dst_d; a.irow0 = irow; a.irow1 = 0; a.orow = orow; a.width = width; a.height = height;
+  a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
+  a.th = psize == 4 ? 6 : 8;
+  if (const char *e = getenv("LGPU_GCK_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a.th = v; }
+  a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
+  a.key = 0;
+  const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u));
+  if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, st, a);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+}  // namespace lgpu
+
 // 5x5 gaussian of frame 0, then the colour key of the blurred frame against frame 1, in one launch.  psize 3 (RGB24 / BGR24: the reference's palettes) or 4
 // (RGBA32 / BGRA32: extension, alpha = the blurred frame's).  LGPU_E_UNSUPPORTED when the width is not a multiple of 4 or a frame is not 4- (psize 3) / 16-byte
 // (psize 4) aligned: the caller then runs lgpu_gauss5 and lgpu_colorkey one after the other.

@@ -2223,6 +2223,7 @@ extern "C" int lgpu_resize(const uint8_t *src_d, int irow, int sw, int sh, uint8
   return LGPU_OK;
 }
 
+namespace lgpu { int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, hipStream_t st); }
 extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
@@ -2235,6 +2236,12 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
   if ((rc = get_bank(height, height, 100, &vb))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const Lut8 l = pack_lut(nullptr);
+  // aligned 3- / 4-byte frames: the register-pipelined row walk of fused.hip (the same arithmetic; profiles/r03/ops_roofline.md)
+  static const bool no_rows = getenv("LGPU_GAUSS5_NO_ROWS") != nullptr;
+  if (!no_rows && (psize == 3 || psize == 4)) {
+    rc = lgpu::gauss5_rows(src_d, irow, dst_d, orow, width, height, psize, st);
+    if (rc != LGPU_E_UNSUPPORTED) return rc;
+  }
   const bool al4 = (((uintptr_t)src_d | (uintptr_t)irow | (uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0;
   if (psize == 4 && al4) {
     SepTracks tg;
