@@ -1271,8 +1271,6 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
   // 16 tracks 170 / 167 us at 4 rows, 166 at 6, 165 / 174 at 8, 175 at 16; one 4K frame 11.0-11.2 us at 4 rows, 9.9 at 6, 11.7 at 8, 14.7 at 16
   a->th = 6;                     // (8 rows are 0.6 % faster on a full device, interleaved on two boxes -- profiles/r03/pbh_th_interleaved.txt; kept at 6: the round's evidence files were made with it)
-  // a full device: 8 rows (interleaved on two boxes, profiles/r03/pbh_th_interleaved.txt + pbh_sweep4_fine.txt: 0.5-0.7 % under 6 rows, 10 / 12 / 16 / 24 rows at or above)
-  if (!blur && (long long)a->strips * cdiv((unsigned)a->dh, 6u) * ntracks >= 8192) a->th = 8;
   // with the blur a band computes th + 4 scaled rows: a full device wants tall bands (16 tracks: 280 us at 4 rows, 241 at 6, 222 at 8, 204 at 12, 197 at 16, 194 at 24),
   // one frame short ones (24.7 / 21.3 / 24.0 / 23.2 / 27.6 / 28.6 us) -- profiles/r03/blur_band_sweep.txt
   if (blur) a->th = (long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6 : 24;
