@@ -61,6 +61,25 @@ def test_two_rank_gloo(tmp_path):
     assert "rank 0 ok [0, 2, 4, 6]" in r.stdout and "rank 1 ok [1, 3, 5, 7]" in r.stdout, r.stdout
 
 
+def test_bench_as_the_driver_launches_it_for_8_gpus():
+    """the driver's own command line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` -- with
+    --dry-run (gloo, no GPU work): eight ranks rendezvous, shard 8 x 2 tracks `t % world`, reduce the maximum and rank 0 alone prints the line"""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1", "--tracks", "2"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["dry_run"] is True and j["tracks_of_rank0"] == [0, 8], j
+
+
 def test_bench_launches_itself_for_n_gpus():
     """`python bench.py --gpus 2` run plainly (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run with one rank per GPU;
     --dry-run keeps the GPU work out so that the spawn, the rendezvous on 127.0.0.1, the sharding, the max-over-ranks reduction and rank 0's
