@@ -775,6 +775,29 @@ struct RepackArgs {
   int copy_w;                // bytes per row of the plain plane copies: the width, or the whole rowstride where the reference memcpy()s the plane
 };
 
+// 4:2:0 -> UYVY / YUYV on aligned frames (the playback plugin's packed 4:2:2 from a decoder's planes): a permutation, so the whole cost is the shape -- cells of four
+// macropixels (8 + 4 + 4 bytes in, 16 out) numbered linearly over the frame instead of one macropixel per lane and one 256-lane workgroup per row segment
+__global__ __launch_bounds__(512) void k_420_to_packed_s(RepackArgs a, uint32_t gmagic) {
+  const int ngr = a.width >> 3;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);                    // floor magic: the quotient or one less
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)a.height) return;
+  const uint2 y8 = *reinterpret_cast<const uint2 *>(a.src[0] + (size_t)y * a.irow[0] + 8 * (size_t)gx);
+  const uint32_t u4 = *reinterpret_cast<const uint32_t *>(a.src[1] + (size_t)(y >> 1) * a.irow[1] + 4 * (size_t)gx), v4 = *reinterpret_cast<const uint32_t *>(a.src[2] + (size_t)(y >> 1) * a.irow[2] + 4 * (size_t)gx);
+  uint32_t mpx[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t yw = k < 2 ? y8.x : y8.y;
+    const uint32_t y0_ = (yw >> (16 * (k & 1))) & 0xFF, y1_ = (yw >> (16 * (k & 1) + 8)) & 0xFF, u = (u4 >> (8 * k)) & 0xFF, v = (v4 >> (8 * k)) & 0xFF;
+    mpx[k] = a.yuyv_out ? (y0_ | (u << 8) | (y1_ << 16) | (v << 24)) : (u | (y0_ << 8) | (v << 16) | (y1_ << 24));
+  }
+  typedef unsigned rk_u4 __attribute__((ext_vector_type(4)));
+  const rk_u4 o = {mpx[0], mpx[1], mpx[2], mpx[3]};
+  *reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * (size_t)((a.orow[0] / 4) * 4) + 16 * (size_t)gx) = o;
+}
+
 __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
   // the chroma-average table costs a workgroup a round of LDS writes and a barrier: only the kinds that average build it (kernel-uniform)
   if (a.kind > RK_420_TO_PK) cavg_init();              // RK_COMBINE .. RK_420_TO_PK are permutations
@@ -1358,6 +1381,16 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
   if (a.kind == lgpu::RK_PK_TO_444 && out_pal == P_4444) {
     LGPU_REQUIRE(dst_d[3], "null alpha plane");
     if ((rc = lgpu_fill(dst_d[3], 255, (size_t)orow[3] * height, stream))) return rc;                 // :7819
+  }
+  static const bool no_s = getenv("LGPU_REPACK_NO_S") != nullptr;
+  if (a.kind == lgpu::RK_420_TO_PK && !no_s && (width & 7) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 && (((uintptr_t)src_d[1] | (uintptr_t)src_d[2]) & 3) == 0 &&
+      (((uintptr_t)dst_d[0] | (uintptr_t)((orow[0] / 4) * 4)) & 15) == 0 && (unsigned long long)(width >> 3) * height < (1ull << 31)) {
+    const int ngr = width >> 3;
+    const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+    const unsigned long long cells = (unsigned long long)ngr * height;
+    hipLaunchKernelGGL(lgpu::k_420_to_packed_s, dim3((unsigned)((cells + 511) / 512)), dim3(512), 0, st, a, magic);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
   }
   const int rows = (a.kind == lgpu::RK_444_TO_420 || a.kind == lgpu::RK_PK_TO_420 || a.kind == lgpu::RK_888_TO_420) ? (height + 1) >> 1 : height;
   const int span = a.copy_w > width ? a.copy_w : width;
