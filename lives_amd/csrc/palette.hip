@@ -798,6 +798,21 @@ __global__ __launch_bounds__(512) void k_420_to_packed_s(RepackArgs a, uint32_t 
   *reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * (size_t)((a.orow[0] / 4) * 4) + 16 * (size_t)gx) = o;
 }
 
+// UYVY <-> YUYV on aligned frames: swap the bytes of every 16-bit half, four macropixels per lane, linear cells
+__global__ __launch_bounds__(512) void k_swab_s(RepackArgs a, uint32_t gmagic) {
+  const int ngr = a.width >> 3;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)a.height) return;
+  typedef unsigned rk_u4 __attribute__((ext_vector_type(4)));
+  rk_u4 v = *reinterpret_cast<const rk_u4 *>(a.src[0] + (size_t)y * a.irow[0] + 16 * (size_t)gx);
+  v.x = __builtin_amdgcn_perm(0u, v.x, 0x02030001u); v.y = __builtin_amdgcn_perm(0u, v.y, 0x02030001u);
+  v.z = __builtin_amdgcn_perm(0u, v.z, 0x02030001u); v.w = __builtin_amdgcn_perm(0u, v.w, 0x02030001u);
+  *reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = v;
+}
+
 __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
   // the chroma-average table costs a workgroup a round of LDS writes and a barrier: only the kinds that average build it (kernel-uniform)
   if (a.kind > RK_420_TO_PK) cavg_init();              // RK_COMBINE .. RK_420_TO_PK are permutations
@@ -1389,6 +1404,14 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
     const unsigned long long cells = (unsigned long long)ngr * height;
     hipLaunchKernelGGL(lgpu::k_420_to_packed_s, dim3((unsigned)((cells + 511) / 512)), dim3(512), 0, st, a, magic);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
+  if (a.kind == lgpu::RK_SWAB && !no_s && (width & 7) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0] | (uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 15) == 0 &&
+      (unsigned long long)(width >> 3) * height < (1ull << 31)) {
+    const int ngr = width >> 3;
+    const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+    hipLaunchKernelGGL(lgpu::k_swab_s, dim3((unsigned)(((unsigned long long)ngr * height + 511) / 512)), dim3(512), 0, st, a, magic);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
