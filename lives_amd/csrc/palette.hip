@@ -798,6 +798,35 @@ __global__ __launch_bounds__(512) void k_420_to_packed_s(RepackArgs a, uint32_t 
   *reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * (size_t)((a.orow[0] / 4) * 4) + 16 * (size_t)gx) = o;
 }
 
+// planar 4:4:4 (+ alpha plane) -> packed YUV888 / YUVA8888 on aligned frames: four pixels per lane (three or four dword loads, 12 or 16 bytes out), linear cells.
+// The alpha plane is walked as a compact buffer, as the reference does (:7634-7638).
+__global__ __launch_bounds__(512) void k_combine_s(RepackArgs a, uint32_t gmagic) {
+  const int ngr = a.width >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)a.height) return;
+  const size_t si = (size_t)y * a.irow[0] + 4 * (size_t)gx;
+  const uint32_t Y4 = *reinterpret_cast<const uint32_t *>(a.src[0] + si), U4 = *reinterpret_cast<const uint32_t *>(a.src[1] + si), V4 = *reinterpret_cast<const uint32_t *>(a.src[2] + si);
+  if (a.out_alpha) {
+    const uint32_t A4 = a.in_alpha ? *reinterpret_cast<const uint32_t *>(a.src[3] + (size_t)y * a.width + 4 * (size_t)gx) : 0xFFFFFFFFu;
+    typedef unsigned rk_u4 __attribute__((ext_vector_type(4)));
+    rk_u4 o;
+    o.x = (Y4 & 0xFF) | ((U4 & 0xFF) << 8) | ((V4 & 0xFF) << 16) | ((A4 & 0xFF) << 24);
+    o.y = ((Y4 >> 8) & 0xFF) | (U4 & 0xFF00) | ((V4 & 0xFF00) << 8) | ((A4 & 0xFF00) << 16);
+    o.z = ((Y4 >> 16) & 0xFF) | ((U4 >> 8) & 0xFF00) | (V4 & 0xFF0000) | ((A4 & 0xFF0000) << 8);
+    o.w = (Y4 >> 24) | ((U4 >> 16) & 0xFF00) | ((V4 >> 8) & 0xFF0000) | (A4 & 0xFF000000u);
+    *reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = o;
+  } else {
+    uint32_t *dq = reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + 12 * (size_t)gx);
+    // bytes out: Y0 U0 V0 Y1 | U1 V1 Y2 U2 | V2 Y3 U3 V3
+    dq[0] = (Y4 & 0xFF) | ((U4 & 0xFF) << 8) | ((V4 & 0xFF) << 16) | ((Y4 & 0xFF00) << 16);
+    dq[1] = ((U4 >> 8) & 0xFF) | (V4 & 0xFF00) | (Y4 & 0xFF0000) | ((U4 & 0xFF0000) << 8);
+    dq[2] = ((V4 >> 16) & 0xFF) | ((Y4 >> 16) & 0xFF00) | ((U4 >> 8) & 0xFF0000) | (V4 & 0xFF000000u);
+  }
+}
+
 // UYVY <-> YUYV on aligned frames: swap the bytes of every 16-bit half, four macropixels per lane, linear cells
 __global__ __launch_bounds__(512) void k_swab_s(RepackArgs a, uint32_t gmagic) {
   const int ngr = a.width >> 3;
@@ -1404,6 +1433,15 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
     const unsigned long long cells = (unsigned long long)ngr * height;
     hipLaunchKernelGGL(lgpu::k_420_to_packed_s, dim3((unsigned)((cells + 511) / 512)), dim3(512), 0, st, a, magic);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
+  if (a.kind == lgpu::RK_COMBINE && !no_s && (width & 3) == 0 && ((irow[0] | irow[1] | irow[2]) & 3) == 0 && irow[0] == irow[1] && irow[0] == irow[2] &&
+      (((uintptr_t)src_d[0] | (uintptr_t)src_d[1] | (uintptr_t)src_d[2]) & 3) == 0 && (!a.in_alpha || !a.out_alpha || (((uintptr_t)src_d[3]) & 3) == 0) &&
+      (((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & (a.out_alpha ? 15 : 3)) == 0 && (unsigned long long)(width >> 2) * height < (1ull << 31)) {
+    const int ngr = width >> 2;
+    const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+    hipLaunchKernelGGL(lgpu::k_combine_s, dim3((unsigned)(((unsigned long long)ngr * height + 511) / 512)), dim3(512), 0, st, a, magic);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
