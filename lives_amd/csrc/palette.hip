@@ -827,6 +827,24 @@ __global__ __launch_bounds__(512) void k_combine_s(RepackArgs a, uint32_t gmagic
   }
 }
 
+// packed YUV888 -> planar 4:4:4 on aligned frames: four pixels per lane (12 bytes in, one dword into each plane), linear cells
+__global__ __launch_bounds__(512) void k_split_s(RepackArgs a, uint32_t gmagic) {
+  const int ngr = a.width >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)a.height) return;
+  const uint32_t *sp = reinterpret_cast<const uint32_t *>(a.src[0] + (size_t)y * a.irow[0] + 12 * (size_t)gx);
+  const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2];              // Y0 U0 V0 Y1 | U1 V1 Y2 U2 | V2 Y3 U3 V3
+  const uint32_t Y4 = (w0 & 0xFF) | ((w0 >> 16) & 0xFF00) | (w1 & 0xFF0000) | ((w2 << 16) & 0xFF000000u);
+  const uint32_t U4 = ((w0 >> 8) & 0xFF) | ((w1 << 8) & 0xFF00) | ((w1 >> 8) & 0xFF0000) | ((w2 << 8) & 0xFF000000u);
+  const uint32_t V4 = ((w0 >> 16) & 0xFF) | (w1 & 0xFF00) | ((w2 << 16) & 0xFF0000) | (w2 & 0xFF000000u);
+  *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + 4 * (size_t)gx) = Y4;
+  *reinterpret_cast<uint32_t *>(a.dst[1] + (size_t)y * a.orow[1] + 4 * (size_t)gx) = U4;
+  *reinterpret_cast<uint32_t *>(a.dst[2] + (size_t)y * a.orow[2] + 4 * (size_t)gx) = V4;
+}
+
 // UYVY <-> YUYV on aligned frames: swap the bytes of every 16-bit half, four macropixels per lane, linear cells
 __global__ __launch_bounds__(512) void k_swab_s(RepackArgs a, uint32_t gmagic) {
   const int ngr = a.width >> 3;
@@ -1442,6 +1460,15 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     const int ngr = width >> 2;
     const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
     hipLaunchKernelGGL(lgpu::k_combine_s, dim3((unsigned)(((unsigned long long)ngr * height + 511) / 512)), dim3(512), 0, st, a, magic);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
+  if (a.kind == lgpu::RK_SPLIT && !no_s && (width & 3) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 3) == 0 &&
+      (((uintptr_t)dst_d[0] | (uintptr_t)dst_d[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[0] | (uintptr_t)orow[1] | (uintptr_t)orow[2]) & 3) == 0 &&
+      (unsigned long long)(width >> 2) * height < (1ull << 31)) {
+    const int ngr = width >> 2;
+    const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+    hipLaunchKernelGGL(lgpu::k_split_s, dim3((unsigned)(((unsigned long long)ngr * height + 511) / 512)), dim3(512), 0, st, a, magic);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
