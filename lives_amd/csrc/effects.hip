@@ -585,8 +585,11 @@ __global__ __launch_bounds__(kBlock) void k_transition(TransArgs a) {
     }
     uint8_t *d = a.dst + (size_t)a.orow * i + j;
     if (from != d) {
+      if (PS == 4 && (((uintptr_t)from | (uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(from);      // a 4-byte pixel at an aligned address: one load, one store
+      else {
 #pragma unroll
-      for (int k = 0; k < PS; k++) d[k] = from[k];
+        for (int k = 0; k < PS; k++) d[k] = from[k];
+      }
     }
   }
 }
