@@ -116,7 +116,8 @@ def main():
         # the chain kernel is persistent and fills every CU with two 71.9 KB workgroups; a kernel with a large LDS footprint on another stream -- RCCL's
         # broadcast -- would wait for it to end (tools/corun_probe.py: 164 us instead of 20).  Sixteen free workgroup slots (two per XCD) cost 1 % of the
         # launch and let the broadcast of the next parameter block run beside it (profiles/r02/corun_probe.txt)
-        os.environ.setdefault("LGPU_CHAIN_SPARE_WGS", "16")
+        if load().lgpu_tuning_get(b"CHAIN_SPARE_WGS") < 0:
+            load().lgpu_tuning_set(b"CHAIN_SPARE_WGS", 16)
     if multi and not os.environ.get("LGPU_BENCH_TORCH_DIST"):
         # every rank first checks that it can bind RCCL at all (dlopen + symbols); the communicator is only created when ALL can, so that no rank
         # waits in ncclCommInitRank for one that gave up -- otherwise the parameter block falls back to torch.distributed's broadcast

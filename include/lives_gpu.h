@@ -144,6 +144,12 @@ int lgpu_yuv420p_to_rgb_batch(int nframes, const lgpu_yuv_frame *frames, const i
    through the one-column kernel), threads per workgroup (256 / 512 / 1024), resident groups of 256 threads per CU; -1 keeps a value.  Results do not
    depend on it (tests walk every setting); process-wide, not meant to change while conversions are in flight. */
 int lgpu_yuv420_tuning(int cell_columns, int block, int groups_per_cu);
+/* Launch-shape / ablation switches by name ("PBH_TH", "PBH_ALIGNED", "PB_NO_PAIRS", "GCK_TH", "CHAIN_SPARE_WGS", ...: the LGPU_<NAME> environment variables
+   without the prefix).  The environment is read ONCE, at the library's first launch; afterwards only this call changes a switch (value < 0 clears it), so no
+   launch path ever calls getenv() beside a host that calls setenv().  Results do not depend on any of them (the tests walk them).  lgpu_tuning_get: the
+   current value, -1 when unset or unknown. */
+int lgpu_tuning_set(const char *name, int value);
+int lgpu_tuning_get(const char *name);
 /* the same conversion with the reference's 16-bit indexed gamma LUT fused in, as convert_yuv420p_to_rgb_frame does when it
    is handed a target gamma (:3274-3283; xyuv2rgb_with_gamma :2386-2390): c = lut16[CLAMP16biti(sum >> 8)] >> 8.
    lut16_d: DEVICE pointer to 65536 uint16 (build on the host with lgpu_gamma_lut16, upload once, reuse). */

@@ -175,7 +175,7 @@ int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int wi
   a.src0 = src_d; a.src1 = nullptr; a.dst = dst_d; a.irow0 = irow; a.irow1 = 0; a.orow = orow; a.width = width; a.height = height;
   a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
   a.th = psize == 4 ? 6 : 8;
-  if (const char *e = getenv("LGPU_GCK_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a.th = v; }
+  { const int v = tune(TUNE_GCK_TH); if (v >= 1 && v <= 1024) a.th = v; }
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   a.key = 0;
   const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u));
@@ -205,7 +205,7 @@ extern "C" int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint
   // short bands: the launch is bound by the time a wave needs for its rows, not by the rows the bands share (profiles/r03/c4_band_sweep.txt: 4K RGBA32 27 us at 6 rows,
   // 28 at 8, 32 at 16, 45 at 32)
   a.th = psize == 4 ? 6 : 8;
-  if (const char *e = getenv("LGPU_GCK_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a.th = v; }      // tuning probe
+  { const int v = tune(TUNE_GCK_TH); if (v >= 1 && v <= 1024) a.th = v; }      // tuning probe
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   // parameter preparation exactly as the script does it (host side, double)
   double xdelta = delta * 2.;

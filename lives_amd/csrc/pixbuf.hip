@@ -1266,7 +1266,7 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   // minute (memory side slower) the 16-track launch gains 2.4 % (173.7 -> 169.5 us), on a fresh box it loses 2 % (161 -> 165 us), one frame per launch loses 10 %
   // (profiles/r03/pbh_aligned_ab.txt: five interleaved A / B runs on four boxes) -- so it is opt-in: LGPU_PBH_ALIGNED=1
   a->aligned = 0;
-  if (!blur) { if (const char *e = getenv("LGPU_PBH_ALIGNED")) a->aligned = atoi(e) ? 1 : 0; }
+  if (!blur && tune(TUNE_PBH_ALIGNED) >= 0) a->aligned = tune(TUNE_PBH_ALIGNED) ? 1 : 0;
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : a->aligned ? 128 : 124);
   // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
   // 16 tracks 170 / 167 us at 4 rows, 166 at 6, 165 / 174 at 8, 175 at 16; one 4K frame 11.0-11.2 us at 4 rows, 9.9 at 6, 11.7 at 8, 14.7 at 16
@@ -1274,7 +1274,7 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   // with the blur a band computes th + 4 scaled rows: a full device wants tall bands (16 tracks: 280 us at 4 rows, 241 at 6, 222 at 8, 204 at 12, 197 at 16, 194 at 24),
   // one frame short ones (24.7 / 21.3 / 24.0 / 23.2 / 27.6 / 28.6 us) -- profiles/r03/blur_band_sweep.txt
   if (blur) a->th = (long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6 : 24;
-  if (const char *e = getenv("LGPU_PBH_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
+  { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
   a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
   a->cgroups = (a->strips + 3) / 4;
   a->ntracks = ntracks;
@@ -1402,18 +1402,18 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     return rc;
   }
   if (channels == 4 && dw == 2 * sw && dh == 2 * sh && (sw & 1) == 0 && (((uintptr_t)src_d | (unsigned)irow) & 7) == 0 && (((uintptr_t)dst_d | (unsigned)orow) & 15) == 0 &&
-      pb_double_ok(t, x_step, y_step) && !getenv("LGPU_PB_NO_DOUBLE")) {
+      pb_double_ok(t, x_step, y_step) && !tune_on(TUNE_PB_NO_DOUBLE)) {
     PbHalfArgs h;
     h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
     h.strips = (int)cdiv((unsigned)sw, 124); h.cgroups = (h.strips + 3) / 4;
     h.th = 3;                      // measured (1080p -> 4K): 16.5 us at 2-3 source rows per band, 18.2 us at 4, 22.8 at 8, 33.4 at 16, 52.7 at 32 -- per-wave latency, as in k_pb_half
-    if (const char *e = getenv("LGPU_PBD_TH")) { const int v = atoi(e); if (v >= 1 && v <= 1024) h.th = v; }
+    { const int v = tune(TUNE_PBD_TH); if (v >= 1 && v <= 1024) h.th = v; }
     h.bands = (int)cdiv((unsigned)sh, (unsigned)h.th); h.ntracks = 1;
     hipLaunchKernelGGL(k_pb_double<0>, dim3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u)), dim3(256), 0, st, h, src_d, dst_d);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
-  if (channels == 3 && sw == 2 * dw && sh == 2 * dh && (sw & 7) == 0 && ((((uintptr_t)src_d | (uintptr_t)dst_d) | (unsigned)irow | (unsigned)orow) & 3) == 0 && !getenv("LGPU_PB_NO_HALF3")) {
+  if (channels == 3 && sw == 2 * dw && sh == 2 * dh && (sw & 7) == 0 && ((((uintptr_t)src_d | (uintptr_t)dst_d) | (unsigned)irow | (unsigned)orow) & 3) == 0 && !tune_on(TUNE_PB_NO_HALF3)) {
     PbHalfArgs h;
     // the same table check as the 4-byte kernel (alignment arguments that always pass: this kernel's own are checked above)
     if (pb_half_ok(t, interp, sw, sh, dw, dh, 0, 0, &h.hyper, &h.ashift)) {
@@ -1444,10 +1444,10 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       return LGPU_OK;
     }
   }
-  const bool no_pairs = getenv("LGPU_PB_NO_PAIRS") != nullptr;        // tests: the one-tap-per-operation kernels at any ratio
-  static const bool no_gather = getenv("LGPU_PB_NO_GATHER") != nullptr;
+  const bool no_pairs = tune_on(TUNE_PB_NO_PAIRS);        // tests: the one-tap-per-operation kernels at any ratio
+  const bool no_gather = tune_on(TUNE_PB_NO_GATHER);
   // both sides enlarged: the register-window walk
-  static const bool no_up = getenv("LGPU_PB_NO_UP") != nullptr;
+  const bool no_up = tune_on(TUNE_PB_NO_UP);
   if (channels == 4 && t->gpairs_d && !no_pairs && !no_up && x_step <= 65536 && y_step <= 65536) {
     const int unp = (t->tx1 - t->tx0 + 1) / 2, uny = t->ty1 - t->ty0;
     if (unp >= 1 && unp <= 2 && uny >= 1 && uny <= 4) {
@@ -1455,7 +1455,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       ua.src = src_d; ua.dst = dst_d; ua.irow = irow; ua.orow = orow; ua.sw = sw; ua.sh = sh; ua.dw = dw; ua.dh = dh;
       ua.x_step = x_step; ua.y_step = y_step; ua.xoff = t->xoff; ua.yoff = t->yoff; ua.tx0 = t->tx0; ua.ty0 = t->ty0;
       ua.rb = (long long)dw * dh >= 6000000 ? 8 : 6;      // per-wave time rules (profiles/r03/pb_up_ab.txt: 720p -> 1080p 11.6 us at 6 rows per band, 15.3 at 16, 38 at 64)
-      if (const char *e = getenv("LGPU_PB_UP_RB")) { const int v = atoi(e); if (v >= 1 && v <= 4096) ua.rb = v; }      // tuning probe
+      { const int v = tune(TUNE_PB_UP_RB); if (v >= 1 && v <= 4096) ua.rb = v; }      // tuning probe
       const dim3 gu(cdiv(cdiv((unsigned)dw, 64), 4), cdiv((unsigned)dh, (unsigned)ua.rb));
       const uint32_t *gp = t->gpairs_d;
 #define PB_UP(NP_, NY_) hipLaunchKernelGGL((k_pb_up<NP_, NY_>), gu, block, 0, st, ua, gp)
@@ -1491,7 +1491,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
 
     pa.tile_h = 0;
     size_t lds_cap = 24 * 1024;                         // 6 workgroups per CU: the per-lane weight loads want occupancy more than the window wants rows (profiles/r03/pb_pairs_lds_sweep.txt)
-    if (const char *e = getenv("LGPU_PB_LDS_KB")) { const int v = atoi(e); if (v >= 4 && v <= 64) lds_cap = (size_t)v * 1024; }      // tuning probe
+    { const int v = tune(TUNE_PB_LDS_KB); if (v >= 4 && v <= 64) lds_cap = (size_t)v * 1024; }      // tuning probe
     for (int th = 16; th >= 1; th >>= 1) {
       const int wh = (int)(((long long)(th - 1) * y_step + 65535) >> 16) + pa.ny_eff + 1;
       if ((size_t)pa.wpairs * wh * 16 <= lds_cap) { pa.tile_h = th; pa.win_h = wh; break; }
@@ -1501,7 +1501,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
 #define PB_PAIRS(CHN)                                                                                                     \
-      { const int ny = getenv("LGPU_PB_NO_NY") ? 0 : t->ty1 - t->ty0; pa.no_quad = getenv("LGPU_PB_NO_QUAD") ? 1 : 0;                                                                                   \
+      { const int ny = tune_on(TUNE_PB_NO_NY) ? 0 : t->ty1 - t->ty0; pa.no_quad = tune_on(TUNE_PB_NO_QUAD) ? 1 : 0;                                                                                   \
         if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa);                       \
         else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa);                  \
         else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa);                  \

@@ -1794,7 +1794,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
   int grid = g_cus * (int)(160 * 1024 / lds);
   // multi-GPU hosts: leave a few workgroup slots (one per XCD) free, so that a kernel with a large LDS footprint enqueued on another stream -- RCCL's
   // broadcast of the next parameter block -- finds a CU while this persistent kernel runs (tools/corun_probe.py, profiles/r02/corun_probe.txt)
-  if (const char *sp = getenv("LGPU_CHAIN_SPARE_WGS")) { const int n = atoi(sp); if (n > 0 && n < grid / 2) grid -= n; }
+  { const int n = tune(TUNE_CHAIN_SPARE_WGS); if (n > 0 && n < grid / 2) grid -= n; }
   if (grid > nwork) grid = nwork;
   grid = (grid + 7) & ~7;                      // whole workgroups per XCD
   // An XCD's workgroups walk its share of the tile list with a stride of grid / 8 tiles.  When that stride shares a large factor with the number of tiles per
@@ -1921,7 +1921,7 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
     // tile height: 16 rows, 32 when enlarging (small windows: taller tiles amortise a workgroup's three phases; measured 29.8 against 33.9 us for
     // 1080p -> 4K, profiles/r02/resize_ratios.md)
     size_t sep2_lds_cap = 80 * 1024;
-    if (const char *e = getenv("LGPU_SEP2_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) sep2_lds_cap = (size_t)v * 1024; }      // tuning probe
+    { const int v = tune(TUNE_SEP2_LDS_KB); if (v >= 8 && v <= 160) sep2_lds_cap = (size_t)v * 1024; }      // tuning probe
     for (int th2 = dh > sh ? 32 : 16;; th2 >>= 1) {
       const int sht2 = window_rows(th2);
       const size_t lds2 = (size_t)sht2 * b.swt * 4 + (size_t)(sht2 >> 1) * kTileW * 16 + 256 + (size_t)th2 * (vb->npv + 1) * 4;
@@ -1940,8 +1940,8 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
     // the horizontal pass as a matrix product: same taps for every column, integer ratio, taps that split into int8 hi / 6-bit lo, at most two K blocks
     // (decided before the tile height: such a launch carries no per-column tap tables in LDS)
     p->mh_r = 0;
-    const bool no_sep2p = getenv("LGPU_NO_SEP2P") != nullptr;
-    const bool no_mh = getenv("LGPU_NO_SEP2P_MFMA") != nullptr;
+    const bool no_sep2p = tune_on(TUNE_NO_SEP2P);
+    const bool no_mh = tune_on(TUNE_NO_SEP2P_MFMA);
     const bool pers_ok = p->variant >= 100 && !no_sep2p && (sw & 3) == 0;
     if (pers_ok && !no_mh && dw >= 1 && sw % dw == 0 && sw / dw >= 2 && hb->nt <= 32 && hround == 64 && hshift == 7) {
       const int r = sw / dw, c0 = hb->hpos[0] & 3, nt = hb->nt;
@@ -2023,8 +2023,8 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
       LGPU_HIP(hipFuncSetAttribute((const void *)k_sep2<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
     hipLaunchKernelGGL((k_sep2<N>), p.grid, blk, p.lds, st, p.a, t, l);                                      \
   } while (0)
-  if (getenv("LGPU_PLAN_DEBUG")) fprintf(stderr, "plan: %dx%d -> %dx%d variant %d lds %zu th %d sht %d swt %d | pers %d vec %d mh_r %d p_th %d p_sht %d p_lds %zu npv %d nth %d\n", p.a.sw, p.a.sh, p.a.dw, p.a.dh, p.variant, p.lds, p.a.th, p.a.sht, p.a.swt, (int)p.pers, p.a.vec, p.mh_r, p.p_th, p.p_sht, p.p_lds, p.a.npv, p.a.nth);
-  const bool s2p_force = getenv("LGPU_SEP2P_FORCE") != nullptr;          // tests: the persistent kernel on small frames
+  if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "plan: %dx%d -> %dx%d variant %d lds %zu th %d sht %d swt %d | pers %d vec %d mh_r %d p_th %d p_sht %d p_lds %zu npv %d nth %d\n", p.a.sw, p.a.sh, p.a.dw, p.a.dh, p.variant, p.lds, p.a.th, p.a.sht, p.a.swt, (int)p.pers, p.a.vec, p.mh_r, p.p_th, p.p_sht, p.p_lds, p.a.npv, p.a.nth);
+  const bool s2p_force = tune_on(TUNE_SEP2P_FORCE);          // tests: the persistent kernel on small frames
   // k_sep2p pays when a workgroup gets a few tiles to pipeline and the windows are the heavy part (shrinking); measured in profiles/r02/resize_ratios.md
   if (p.pers && p.a.vec && p.variant >= 100 &&
       (s2p_force || (p.p_th >= 4 && (p.mh_r || (p.a.dh < p.a.sh && (long)p.a.tiles_x * p.p_tiles_y * (long)p.grid.y >= 3L * 512))))) {      // 2-row tiles (4:1: 498 against 470 us for 16 x 4K -> 960 x 540) lose to k_sep2

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 namespace lgpu {
 
@@ -104,9 +105,46 @@ int device_cus() {
   return c;
 }
 
+static const char *const kTuneNames[TUNE_COUNT] = {
+  "PBH_ALIGNED", "PBH_TH", "PBH_LOADER", "PB_NO_DOUBLE", "PBD_TH", "PB_NO_HALF3", "PB_NO_PAIRS", "PB_NO_GATHER", "PB_NO_UP", "PB_UP_RB",
+  "PB_LDS_KB", "PB_NO_NY", "PB_NO_QUAD", "GCK_TH", "CHAIN_SPARE_WGS", "SEP2_LDS_KB", "NO_SEP2P", "NO_SEP2P_MFMA", "PLAN_DEBUG",
+  "SEP2P_FORCE", "PB_CACHE_MAX", "K2_WGS"};
+static std::atomic<int> g_tune[TUNE_COUNT];
+static std::once_flag g_tune_once;
+static void tune_init() {
+  std::call_once(g_tune_once, [] {
+    for (int i = 0; i < TUNE_COUNT; i++) {
+      char name[64];
+      snprintf(name, sizeof name, "LGPU_%s", kTuneNames[i]);
+      const char *e = getenv(name);           // once per process, before the first launch this library makes
+      g_tune[i].store(e ? (*e ? atoi(e) : 1) : -1, std::memory_order_relaxed);
+    }
+  });
+}
+int tune(Tune t) {
+  tune_init();
+  return g_tune[t].load(std::memory_order_relaxed);
+}
+
 }  // namespace lgpu
 
 extern "C" {
+
+// launch-shape / ablation switches by name (the LGPU_<NAME> environment variables without the prefix); value < 0 clears a switch.  Results never depend on them.
+int lgpu_tuning_set(const char *name, int value) {
+  if (!name) { lgpu::set_error("lgpu_tuning_set: null name"); return LGPU_E_BADARG; }
+  lgpu::tune_init();
+  for (int i = 0; i < lgpu::TUNE_COUNT; i++)
+    if (!strcmp(name, lgpu::kTuneNames[i])) { lgpu::g_tune[i].store(value < 0 ? -1 : value, std::memory_order_relaxed); return LGPU_OK; }
+  lgpu::set_error("lgpu_tuning_set: unknown switch %s", name);
+  return LGPU_E_BADARG;
+}
+int lgpu_tuning_get(const char *name) {
+  if (!name) return -1;
+  for (int i = 0; i < lgpu::TUNE_COUNT; i++)
+    if (!strcmp(name, lgpu::kTuneNames[i])) return lgpu::tune((lgpu::Tune)i);
+  return -1;
+}
 
 int lgpu_abi_version(void) { return LGPU_ABI_VERSION; }
 

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "lgpu_alpha_premult": [vp, ci, ci, ci, ci, ci, vp],
     "lgpu_yuv420p_to_rgb": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_yuv420_tuning": [ci, ci, ci],
+    "lgpu_tuning_set": [ctypes.c_char_p, ci],
+    "lgpu_tuning_get": [ctypes.c_char_p],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
     "lgpu_alpha_scalers": [vp, vp],

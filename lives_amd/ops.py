@@ -34,6 +34,14 @@ def init(device=0):
     lib.call("lgpu_init", device)
 
 
+def tuning(name, value):
+    """a launch-shape / ablation switch by name (lgpu_tuning_set; value < 0 or None clears it); returns the previous value (-1: unset)"""
+    L = lib.load()
+    old = L.lgpu_tuning_get(name.encode())
+    assert L.lgpu_tuning_set(name.encode(), -1 if value is None else int(value)) == 0, lib.last_error()
+    return old
+
+
 def swizzle(op, src, dst, width, height, alpha_first=0, lut=None):
     lp = lut_ptr(lut)
     lib.call("lgpu_swizzle", op, alpha_first, dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height,

@@ -31,3 +31,17 @@ def gpu():
     lib.load()
     ops.init(0)
     return ops
+
+
+@pytest.fixture
+def tune():
+    """set launch-shape switches of the library for one test (lgpu_tuning_set); every switch touched is restored afterwards"""
+    from lives_amd import ops
+    saved = {}
+
+    def set_(name, value):
+        old = ops.tuning(name, value)
+        saved.setdefault(name, old)
+    yield set_
+    for name, old in saved.items():
+        ops.tuning(name, old)

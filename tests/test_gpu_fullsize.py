@@ -89,24 +89,35 @@ def test_c4_gauss5_and_colorkey_4k(gpu, orc):
     assert_same(host(dk), wk, w, h, 3, "C4 colour key")
 
 
+PIXBUF = 0x100      # LGPU_INTERP_PIXBUF: the resize stage on gdk-pixbuf's arithmetic (the pinned one, and what bench.py launches by default)
+
+
+def _c5_batch(rng, T):
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    base = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(2)]
+    l2b = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(2)]
+    # tracks 0 / 1 distinct, the others alternate between the two: same input -> same output whatever the slot
+    return base, l2b, [dev(base[t & 1]) for t in range(T)], [dev(l2b[t & 1]) for t in range(T)]
+
+
+@pytest.mark.parametrize("interp", [3, 3 | PIXBUF], ids=["polyphase", "pixbuf"])
 @pytest.mark.parametrize("do_blur", [0, 1])
-def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur):
+def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur, interp):
+    """the launch bench.py times -- 16 x 3840x2160 BGRA32 tracks, swap + scale 0.5x + [blur] + blend + LUT in ONE launch -- on both resize backends.  With the
+    pixbuf backend this is k_pb_half<1, 1, BLUR> at full device size: do_blur = 1 reaches the 24-row bands pb_half_geometry() only picks for >= 8 4K tracks.
+    Reference: src/colourspace.c:15262-15322 (the gdk-pixbuf body of resize_layer_full), simple_blend.c:117-146"""
     import torch
     rng = np.random.default_rng(4005 + do_blur)
     sw, sh, dw, dh, T = 3840, 2160, 1920, 1080, 16
     lut = l2s_lut()
-    base = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(2)]
-    l2b = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(2)]
-    # tracks 0 / 1 distinct, the other 14 alternate between the two: same input -> same output whatever the slot
-    src_d = [dev(base[t & 1]) for t in range(T)]
-    l2_d = [dev(l2b[t & 1]) for t in range(T)]
+    base, l2b, src_d, l2_d = _c5_batch(rng, T)
     dst_d = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
-    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3, do_blur=do_blur, bf=107, lut=lut)
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=interp, do_blur=do_blur, bf=107, lut=lut)
     gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, dst_d))
     for i in range(2):
         want = np.zeros((dh, dw * 4), np.uint8)
-        assert orc.orc_chain(P(base[i]), sw * 4, sw, sh, P(l2b[i]), dw * 4, P(want), dw * 4, dw, dh, 1, 3, do_blur, 107, P(lut)) == 0
-        assert_same(host(dst_d[i]), want, dw, dh, 4, "C5 track %d blur=%d" % (i, do_blur))
+        assert orc.orc_chain(P(base[i]), sw * 4, sw, sh, P(l2b[i]), dw * 4, P(want), dw * 4, dw, dh, 1, interp, do_blur, 107, P(lut)) == 0
+        assert_same(host(dst_d[i]), want, dw, dh, 4, "C5 track %d blur=%d interp=%#x" % (i, do_blur, interp))
     for t in range(2, T):
         assert torch.equal(dst_d[t], dst_d[t & 1]), "track %d differs from track %d with the same input" % (t, t & 1)
     # a permuted batch gives the permuted result
@@ -115,6 +126,79 @@ def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur):
     gpu.chain(prm, gpu.chain_tracks([src_d[p] for p in perm], [l2_d[p] for p in perm], dst2))
     for t in range(T):
         assert torch.equal(dst2[t], dst_d[perm[t]])
+
+
+@pytest.mark.parametrize("shape", ["aligned", "th8"])
+def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
+    """the same 16-track launch in the shapes the switches select (64-lane strips, another band height): same bytes as the default shape,
+    which test_c5_sixteen_track_4k_chain compares with the oracle -- and track 0 against the oracle here as well"""
+    import torch
+    rng = np.random.default_rng(4015)
+    sw, sh, dw, dh, T = 3840, 2160, 1920, 1080, 16
+    lut = l2s_lut()
+    base, l2b, src_d, l2_d = _c5_batch(rng, T)
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=31, lut=lut)
+    ref = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, ref))
+    if shape == "aligned":
+        tune("PBH_ALIGNED", 1)
+    else:
+        tune("PBH_TH", 8)
+    got = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, got))
+    for t in range(T):
+        assert torch.equal(got[t], ref[t]), "track %d: shape %s differs from the default shape" % (t, shape)
+    want = np.zeros((dh, dw * 4), np.uint8)
+    assert orc.orc_chain(P(base[0]), sw * 4, sw, sh, P(l2b[0]), dw * 4, P(want), dw * 4, dw, dh, 1, 3 | PIXBUF, 0, 31, P(lut)) == 0
+    assert_same(host(got[0]), want, dw, dh, 4, "C5 %s" % shape)
+
+
+@pytest.mark.parametrize("do_blur", [0, 1])
+def test_c5_through_the_c_stepper_with_a_device_parameter_block(gpu, orc, do_blur):
+    """lgpu_chain_step (the per-step host path of the N > 1 bench, dist.cpp): 16 tracks per step, the blend amount read by the kernel from the stepper's device
+    block -- a different value every step, and params.bf deliberately wrong"""
+    import torch
+    from lives_amd import dist as ld
+    rng = np.random.default_rng(4025 + do_blur)
+    sw, sh, dw, dh, T = 3840, 2160, 1920, 1080, 16
+    lut = l2s_lut()
+    base, l2b, src_d, l2_d = _c5_batch(rng, T)
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=do_blur, bf=5, lut=lut)
+    bfs = [201, 17, 128]
+    outs = [[torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)] for _ in bfs]
+    st = ld.Stepper(None, [bfs[0], 0, 0, 0])
+    for s, o in enumerate(outs):
+        st.step([bfs[s + 1], 0, 0, 0] if s + 1 < len(bfs) else None, prm, gpu.chain_tracks(src_d, l2_d, o))
+    torch.cuda.synchronize()
+    st.close()
+    for s, bf in enumerate(bfs):
+        for i in range(2):
+            want = np.zeros((dh, dw * 4), np.uint8)
+            assert orc.orc_chain(P(base[i]), sw * 4, sw, sh, P(l2b[i]), dw * 4, P(want), dw * 4, dw, dh, 1, 3 | PIXBUF, do_blur, bf, P(lut)) == 0
+            assert_same(host(outs[s][i]), want, dw, dh, 4, "C5 step %d (bf %d) track %d blur=%d" % (s, bf, i, do_blur))
+        for t in range(2, T):
+            assert torch.equal(outs[s][t], outs[s][t & 1])
+
+
+@pytest.mark.parametrize("th", [24, 7, 1])
+def test_blur_chain_band_seams_at_forced_heights(gpu, orc, tune, th):
+    """k_pb_half<.., BLUR> with the band height forced (24 rows = what full-device launches take; 7: bands that end inside the frame; 1: every row a seam) on frames
+    small enough for a full compare on every run: several bands, bands walking up and down, the frame's last band shorter than the others"""
+    tune("PBH_TH", th)
+    rng = np.random.default_rng(4040 + th)
+    lut = l2s_lut()
+    for (sw, sh, dw, dh, interp, ntr) in [(512, 200, 256, 100, 3, 2), (1000, 132, 500, 66, 2, 1), (3840, 160, 1920, 80, 3, 1), (248, 1000, 124, 500, 3, 1)]:
+        srcs = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(ntr)]
+        l2s = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(ntr)]
+        irow, orow = srcs[0].strides[0], l2s[0].strides[0]
+        dd = [dev(np.zeros((dh, orow), np.uint8)) for _ in range(ntr)]
+        for blur in (1, 0):
+            prm = gpu.chain_params(sw, sh, irow, dw, dh, orow, orow, swap_rb=1, interp=interp | PIXBUF, do_blur=blur, bf=77, lut=lut)
+            gpu.chain(prm, gpu.chain_tracks([dev(s_) for s_ in srcs], [dev(s_) for s_ in l2s], dd))
+            for i in range(ntr):
+                want = np.zeros((dh, orow), np.uint8)
+                assert orc.orc_chain(P(srcs[i]), irow, sw, sh, P(l2s[i]), orow, P(want), orow, dw, dh, 1, interp | PIXBUF, blur, 77, P(lut)) == 0
+                assert_same(host(dd[i]), want, dw, dh, 4, "th=%d %dx%d blur=%d track %d" % (th, sw, sh, blur, i))
 
 
 def test_involutions_at_4k(gpu):

@@ -866,11 +866,11 @@ def test_resize(gpu, orc, psize):
         assert_same(host(d), want, dw, dh, psize, "resize %dx%d->%dx%d interp=%d ps=%d" % (sw, sh, dw, dh, interp, psize))
 
 
-def test_resize_persistent_kernel(gpu, orc, monkeypatch):
+def test_resize_persistent_kernel(gpu, orc, tune):
     """k_sep2p (persistent workgroups, windows and tables prefetched by LDS-DMA; taken by default for large shrinking launches) forced on small
     frames: same bytes as the oracle for shrinking, enlarging and mixed ratios, windows that cross every frame border, partial tiles, one tile
     per workgroup and several, and -- through the chain -- several tracks per launch with the byte swap, the blend and the gamma LUT"""
-    monkeypatch.setenv("LGPU_SEP2P_FORCE", "1")
+    tune("SEP2P_FORCE", 1)
     rng = np.random.default_rng(1050)
     cases = [(384, 216, 128, 72, 3), (256, 144, 512, 288, 3), (192, 108, 128, 72, 3), (640, 360, 212, 120, 3), (128, 64, 64, 32, 2), (400, 300, 100, 75, 3),
              (1920, 1080, 1280, 720, 3), (1280, 720, 1920, 1080, 3), (3840, 2160, 1280, 720, 3), (64, 32, 128, 64, 3), (100, 60, 36, 24, 3), (16, 16, 4, 4, 3),
@@ -1069,7 +1069,7 @@ def test_chain_with_device_param_block(gpu, orc, do_blur):
             assert_same(host(d_dst[i]), want, dw, dh, 4, "param block step %d (bf=%d) track %d blur=%d" % (s, bf, i, do_blur))
 
 
-def test_chain_with_spare_workgroup_slots(gpu, monkeypatch):
+def test_chain_with_spare_workgroup_slots(gpu, tune):
     """multi-GPU hosts run the persistent chain kernel with a few workgroup slots left free (LGPU_CHAIN_SPARE_WGS, for RCCL's broadcast): another grid size
     and tile-list stride, the same bytes -- at the bench's geometry, one 4K track"""
     import torch
@@ -1081,10 +1081,7 @@ def test_chain_with_spare_workgroup_slots(gpu, monkeypatch):
     lut = lut_for(np.random.default_rng(1), "l2s")
     outs = []
     for spare in (None, "8", "16", "100"):
-        if spare is None:
-            monkeypatch.delenv("LGPU_CHAIN_SPARE_WGS", raising=False)
-        else:
-            monkeypatch.setenv("LGPU_CHAIN_SPARE_WGS", spare)
+        tune("CHAIN_SPARE_WGS", None if spare is None else int(spare))
         d = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda")
         prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3, do_blur=0, bf=99, lut=lut)
         gpu.chain(prm, gpu.chain_tracks([src], [l2], [d]))

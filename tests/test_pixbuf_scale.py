@@ -189,9 +189,9 @@ def test_gpu_equals_the_oracle_on_random_geometry(gpu, orc):
 
 
 @gpu_mark
-def test_gpu_one_tap_kernels_at_every_ratio(gpu, orc, monkeypatch):
+def test_gpu_one_tap_kernels_at_every_ratio(gpu, orc, tune):
     """k_pb_window / k_pb_direct (what ratios with a 17-bit weight and windows too large for LDS take) forced onto the ratios k_pb_pairs normally serves"""
-    monkeypatch.setenv("LGPU_PB_NO_PAIRS", "1")
+    tune("PB_NO_PAIRS", 1)
     rng = np.random.default_rng(0x9DBE)
     for (sw, sh, dw, dh, ch, interp) in [(384, 216, 171, 96, 4, 3), (200, 120, 300, 180, 4, 3), (200, 120, 133, 80, 3, 2), (64, 36, 200, 100, 3, 3), (320, 180, 96, 54, 4, 2)]:
         src = rng.integers(0, 256, (sh, align(sw * ch, 4)), dtype=np.uint8)
@@ -222,7 +222,7 @@ def test_gpu_integer_reductions(gpu, orc):
 
 
 @gpu_mark
-def test_gpu_enlargements(gpu, orc, monkeypatch):
+def test_gpu_enlargements(gpu, orc, tune):
     """k_pb_up (4-byte pixels, both sides enlarged: register tap window walked down a band of destination rows, pair table in LDS): both filters, ratios from 1.01 to 9,
     one side kept (step exactly 1), frames narrower than a tap row, widths that end inside a wave, heights that end inside a band, band heights 1 and 5, three alpha mixes"""
     rng = np.random.default_rng(0x9DB8)
@@ -230,7 +230,7 @@ def test_gpu_enlargements(gpu, orc, monkeypatch):
              (640, 360, 1280, 720), (642, 361, 1284, 722), (200, 120, 300, 180), (500, 9, 1000, 10)]
     for rb in (None, "1", "5"):
         if rb:
-            monkeypatch.setenv("LGPU_PB_UP_RB", rb)
+            tune("PB_UP_RB", int(rb))
         for (sw, sh, dw, dh) in cases if rb is None else cases[:5]:
             for interp in (2, 3):
                 for amode in (0, 1, 2):
@@ -299,12 +299,12 @@ def test_compositor_flow_scales_its_layers_as_the_reference_does(gpu, orc, psize
 
 @gpu_mark
 @pytest.mark.parametrize("strips64", [0, 1])
-def test_chain_on_the_pixbuf_arithmetic(gpu, orc, monkeypatch, strips64):
+def test_chain_on_the_pixbuf_arithmetic(gpu, orc, tune, strips64):
     """(both strip forms of k_pb_half: 62 storing lanes + 2 feeder lanes, and 64 storing lanes with the two outer taps from an extra load -- what full-device launches take)
     lgpu_chain with LGPU_INTERP_PIXBUF: convert -> gdk-pixbuf scale (4 channels, alpha-weighted) -> chroma blend -> gamma LUT == the oracle's composition
     of the pinned single stages.  The exact aligned 2:1 cases take the one-launch kernel k_pb_half (HYPER and BILINEAR, several tracks, strips that end
     inside the frame, bands of every height); the others the staged path (other ratios, the blur stage, unaligned rowstrides)."""
-    monkeypatch.setenv("LGPU_PBH_ALIGNED", str(strips64))
+    tune("PBH_ALIGNED", strips64)
     PIXBUF = 0x100
     rng = np.random.default_rng(0x9DBA)
     lut = np.zeros(256, np.uint8)

@@ -52,7 +52,7 @@ def main():
     for it in range(iters):
         kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411", "pixbuf", "pixbuf", "chainpb", "chainpb", "canvas", "c4"]))
         counts[kind] = counts.get(kind, 0) + 1
-        os.environ["LGPU_PBH_ALIGNED"] = "1" if rng.random() < 0.5 else "0"          # both strip forms of k_pb_half at every size
+        ops.tuning("PBH_ALIGNED", 1 if rng.random() < 0.5 else 0)          # both strip forms of k_pb_half at every size
         try:
             if kind == "resize":
                 ps = int(rng.choice([1, 3, 4]))
@@ -70,12 +70,12 @@ def main():
                 d = dev(np.zeros_like(want))
                 forced = rng.random() < 0.35            # the persistent general-ratio kernel (k_sep2p) on small frames too
                 if forced:
-                    os.environ["LGPU_SEP2P_FORCE"] = "1"
+                    ops.tuning("SEP2P_FORCE", 1)
                     counts["resize(k_sep2p forced)"] = counts.get("resize(k_sep2p forced)", 0) + 1
                 try:
                     ops.resize(dev(src), d, sw, sh, dw, dh, psize=ps, interp=interp)
                 finally:
-                    os.environ.pop("LGPU_SEP2P_FORCE", None)
+                    ops.tuning("SEP2P_FORCE", None)
                 ok = same(host(d), want, dw * ps, dh, "resize %dx%d->%dx%d ps=%d interp=%d stride=%d forced=%d" % (sw, sh, dw, dh, ps, interp, src.strides[0], forced))
             elif kind == "chain":
                 dw, dh = int(rng.integers(2, 200)), int(rng.integers(2, 120))
@@ -111,11 +111,11 @@ def main():
                                        bf=(bf * 7 + 13) % 256 if via_block else bf, lut=lut, param_block=pb)
                 forced = rng.random() < 0.35
                 if forced:
-                    os.environ["LGPU_SEP2P_FORCE"] = "1"
+                    ops.tuning("SEP2P_FORCE", 1)
                 try:
                     ops.chain(prm, ops.chain_tracks([dev(s) for s in srcs], [dev(s) for s in l2s], dd))
                 finally:
-                    os.environ.pop("LGPU_SEP2P_FORCE", None)
+                    ops.tuning("SEP2P_FORCE", None)
                 ok = all(same(host(dd[i]), wants[i], dw * 4, dh, "chain %dx%d->%dx%d swap=%d blur=%d bf=%d lut=%d strides=%d/%d track %d param_block=%d" %
                               (sw, sh, dw, dh, swap, blur, bf, use_lut, srcs[0].strides[0], l2s[0].strides[0], i, via_block)) for i in range(ntr))
             elif kind == "pixbuf":
@@ -153,11 +153,11 @@ def main():
                     continue
                 d = dev(np.zeros((dh, orow), np.uint8))
                 if rng.random() < 0.15:
-                    os.environ["LGPU_PB_NO_PAIRS"] = "1"
+                    ops.tuning("PB_NO_PAIRS", 1)
                 try:
                     ops.pixbuf_scale(dev(src), d, sw, sh, dw, dh, channels=ch, interp=interp)
                 finally:
-                    os.environ.pop("LGPU_PB_NO_PAIRS", None)
+                    ops.tuning("PB_NO_PAIRS", None)
                 ok = same(host(d), want, dw * ch, dh, "pixbuf %dx%d->%dx%d ch=%d interp=%d strides %d/%d" % (sw, sh, dw, dh, ch, interp, irow, orow))
             elif kind in ("chainpb", "canvas"):
                 # the chain on the pinned arithmetic: fused (exact aligned 2:1: k_pb_half, with and without the blur stage, with a letterbox canvas) and staged
