@@ -150,6 +150,9 @@ int lgpu_yuv420_tuning(int cell_columns, int block, int groups_per_cu);
    current value, -1 when unset or unknown. */
 int lgpu_tuning_set(const char *name, int value);
 int lgpu_tuning_get(const char *name);
+/* test hook: the scaler's five-operation reciprocal (pixbuf.hip: pb_recip) against the IEEE division 1.0 / (double)a for every integer a of [lo, hi), hi <= 2^24;
+   *mismatches = how many differ (0 over the whole range: tests/test_pixbuf_scale.py) */
+int lgpu_debug_recip_check(uint32_t lo, uint32_t hi, unsigned long long *mismatches);
 /* the same conversion with the reference's 16-bit indexed gamma LUT fused in, as convert_yuv420p_to_rgb_frame does when it
    is handed a target gamma (:3274-3283; xyuv2rgb_with_gamma :2386-2390): c = lut16[CLAMP16biti(sum >> 8)] >> 8.
    lut16_d: DEVICE pointer to 65536 uint16 (build on the host with lgpu_gamma_lut16, upload once, reuse). */

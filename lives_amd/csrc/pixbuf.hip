@@ -198,6 +198,11 @@ struct PbTracks {
   const uint8_t *l2[LGPU_CHAIN_MAX_TRACKS];
   uint8_t *dst[LGPU_CHAIN_MAX_TRACKS];
 };
+#if defined(PBH_VARIANT) && (PBH_VARIANT & 1)
+#define PBH_LOAD_AUX 2          // timing probe: non-temporal source loads
+#else
+#define PBH_LOAD_AUX 0
+#endif
 typedef unsigned short pb_us2 __attribute__((ext_vector_type(2)));
 typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned pb_u2 __attribute__((ext_vector_type(2)));
@@ -228,13 +233,14 @@ __device__ __forceinline__ uint32_t pb_add_hi_lo(uint32_t x, uint32_t y) {      
 }
 // one source row of a lane: 4 pixels -> the two H columns of its 4 channels (h[c] = column 2k, h[4 + c] = column 2k + 1)
 // e (ALIGNED strips only, otherwise 0): lane 0 holds pixel P[4k-1] there, lane 63 pixel P[4k+4] (clamped into the row), every other lane 0 -- the two taps the
-// wave shifts cannot deliver.
-template <int HYPER, int ALIGNED = 0>
+// wave shifts cannot deliver.  SWAP: channel 0 is fed from byte 2 and channel 2 from byte 0 (the R <-> B conversion of the chain costs nothing: the three colours
+// are treated alike until they are stored).
+template <int HYPER, int ALIGNED = 0, int SWAP = 0>
 __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u, uint32_t ml = 0u, uint32_t mr = 0u) {
   uint32_t A[4], B[4];
-  A[0] = pb_premul_pair<0>(q.x, q.y); B[0] = pb_premul_pair<0>(q.z, q.w);
+  A[0] = pb_premul_pair<SWAP ? 2 : 0>(q.x, q.y); B[0] = pb_premul_pair<SWAP ? 2 : 0>(q.z, q.w);
   A[1] = pb_premul_pair<1>(q.x, q.y); B[1] = pb_premul_pair<1>(q.z, q.w);
-  A[2] = pb_premul_pair<2>(q.x, q.y); B[2] = pb_premul_pair<2>(q.z, q.w);
+  A[2] = pb_premul_pair<SWAP ? 0 : 2>(q.x, q.y); B[2] = pb_premul_pair<SWAP ? 0 : 2>(q.z, q.w);
   A[3] = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u); B[3] = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);       // the alpha pairs
 #pragma unroll
   for (int c = 0; c < 4; c++) {
@@ -255,20 +261,48 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
   if (HYPER && ALIGNED) {
     // e is non-zero in lanes 0 and 63 only; ml / mr (1 in lane 0 / lane 63, else 0) steer its premultiplied bytes into column 2k or 2k + 1: 4 + 8 operations per row
     uint32_t x[4];
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(x[0]) : "v"(e));
+    if (SWAP) {
+      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(x[0]) : "v"(e));
+      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(x[2]) : "v"(e));
+    } else {
+      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(x[0]) : "v"(e));
+      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(x[2]) : "v"(e));
+    }
     asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(x[1]) : "v"(e));
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(x[2]) : "v"(e));
     x[3] = e >> 24;
 #pragma unroll
     for (int c = 0; c < 4; c++) { h[c] = __umul24(x[c], ml) + h[c]; h[4 + c] = __umul24(x[c], mr) + h[4 + c]; }
   }
 }
+
+// fl(1.0 / (double)a) for an integer 1 <= a < 2^24 -- the library's `1.0 / (double)a`, correctly rounded -- in five operations instead of the eleven of the compiler's
+// IEEE division (scale, fix-up and the denormal / overflow handling are not needed for this range): the hardware estimate (2^-26 or better) and two Newton steps
+// in fused multiply-adds.  Why the last step rounds correctly: e1 = 1 - a y1 is exact (a y1 has at most 77 bits and differs from 1 by ~2^-50), so the fma rounds
+// the REAL number (1 / a)(1 - e1^2) once; and 1 / a for a 24-bit integer a that is not a power of two lies at least 2^-25 ulp away from every rounding boundary,
+// far more than e1^2 ~ 2^-100.  Checked against the division for every a of the range on the device (lgpu_debug_recip_check, tests/test_pixbuf_scale.py).
+__device__ __forceinline__ double pb_recip(uint32_t a) {
+  const double x = (double)a;
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__global__ void k_pb_recip_check(uint32_t lo, uint32_t hi, unsigned long long *bad) {
+  const uint32_t a = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < lo || a >= hi || a == 0) return;
+  const double want = 1.0 / (double)a;
+  if (__builtin_bit_cast(unsigned long long, pb_recip(a)) != __builtin_bit_cast(unsigned long long, want)) atomicAdd(bad, 1ull);
+}
 // V_c * fl(1 / V_alpha), truncated, for the three colours of one pixel
 __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t va, uint32_t c[3]) {
 #if defined(PBH_VARIANT) && (PBH_VARIANT & 4)
   c[0] = (v0 >> 16) + (va & 1); c[1] = v1 >> 16; c[2] = v2 >> 16;       // timing probe only: no division
+#elif defined(PBH_VARIANT) && (PBH_VARIANT & 8)
+  const double ia = 1.0 / (double)va;                                    // timing probe only: the compiler's IEEE division
+  c[0] = (uint32_t)(int)((double)v0 * ia); c[1] = (uint32_t)(int)((double)v1 * ia); c[2] = (uint32_t)(int)((double)v2 * ia);
 #else
-  const double ia = 1.0 / (double)va;
+  const double ia = pb_recip(va);
   c[0] = (uint32_t)(int)((double)v0 * ia); c[1] = (uint32_t)(int)((double)v1 * ia); c[2] = (uint32_t)(int)((double)v2 * ia);
 #endif
 }
@@ -277,19 +311,23 @@ __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32
 // blend, in the same launch.  The scaled row of a lane (two RGBA pixels) is blurred horizontally with its neighbours' pixels (four more DPP moves; bytes in
 // 16-bit lanes, so one 32-bit operation serves two channels), the last five blurred rows stay in registers and every new one completes an output row.  A strip
 // then yields 120 columns (lanes 2 .. 61) and a band computes 4 more scaled rows than it stores.
-template <int CHAIN, int HYPER, int BLUR, int ALIGNED = 0>
+//
+// Memory operations are buffer loads / stores: one 128-bit descriptor per frame in SGPRs (built once per wave from uniform values), the row as the scalar offset,
+// the lane's place in the row as a constant 32-bit VGPR offset -- no address arithmetic on the vector unit at all; lanes that must not store carry an offset beyond
+// the descriptor's range and the hardware drops their store (no exec-mask branch per row).
+template <int CHAIN, int HYPER, int BLUR, int ALIGNED = 0, int SWAP = 0>
 __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_lut_all[4][256];       // the gamma LUT and the blend's alpha scalers, one private copy per wave: a wave stages its
-  __shared__ pb_u2 s_k_all[4][256];                                        //   own and never waits for the other three (no workgroup barrier on the frame path)
+  // the gamma LUT and the blend's alpha scalers.  ONE copy per workgroup, but no workgroup barrier on the frame path: every wave writes the whole of both tables
+  // itself (the same bytes) and reads them after its own writes have landed; a slower wave writing the same bytes again changes nothing
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  __shared__ pb_u2 s_k[256];
   // ALIGNED (no blur): strips of 64 quads, no feeder lanes -- a wave's row is 1024 source bytes and 512 result bytes on 128-byte lines; the two taps beyond the
   // strip come from one extra 4-byte load per source row in lanes 0 and 63
   constexpr int kHalo = BLUR ? 2 : ALIGNED ? 0 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
   if (CHAIN && blockIdx.x >= (unsigned)A.main_blocks) {
     // letterbox bars (letterbox_layer's black canvas, src/colourspace.c:15417-15503, under the rest of the chain): opaque black -> chroma blend with layer 2 -> LUT
-    uint8_t *s_lut = s_lut_all[0];
-    pb_u2 *s_k = s_k_all[0];
     stage_lut(s_lut, lut);
-    if (A.blend) {
+    {
       const uint2 kk = A.kscale[threadIdx.x];
       pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
       s_k[threadIdx.x] = kv;
@@ -307,24 +345,19 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       if (p < top) { y = p / A.cw; x = p - y * A.cw; }
       else if (p < top + bottom) { p -= top; y = p / A.cw; x = p - y * A.cw; y += A.oy + A.dh; }
       else { p -= top + bottom; y = p / sw_; x = p - y * sw_; y += A.oy; if (x >= A.ox) x += A.dw; }
-      uint32_t c0 = 0, c1 = 0, c2 = 0;
-      if (A.blend) {
-        const uint32_t q = reinterpret_cast<const uint32_t *>(T.l2[track] + (size_t)y * A.irow2)[x];
-        const pb_u2 kk = s_k[q >> 24];
-        const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
-        c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-        c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-        c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-      }
-      if (A.use_lut) { c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2]; }
+      const uint32_t q = reinterpret_cast<const uint32_t *>(T.l2[track] + (size_t)y * A.irow2)[x];
+      const pb_u2 kk = s_k[q >> 24];
+      const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
+      uint32_t c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      uint32_t c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      uint32_t c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(0u, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2];
       reinterpret_cast<uint32_t *>(T.dst[track] + (size_t)y * A.orow)[x] = c0 | (c1 << 8) | (c2 << 16) | 0xFF000000u;
     }
     return;
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
-  uint8_t *s_lut = s_lut_all[wave];
-  pb_u2 *s_k = s_k_all[wave];
   // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its
   // own L2; two bands that follow each other vertically share two source rows.  So every XCD gets a CONTIGUOUS run of the sequence (track, column group, band) and
   // walks it band by band: the shared rows are fetched once and hit that XCD's L2 the second time (PMC: 999 MB -> see profiles/r03 per 16-track launch).
@@ -345,27 +378,27 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const int kmax = (A.sw >> 2) - 1;
   const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
   const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
-  const uint8_t *rowbase = T.src[track];          // uniform
-  const uint32_t lane_off = 16u * (uint32_t)kc;
-  const bool out_lane = lane >= kHalo && lane < 64 - kHalo && k <= kmax && !spare;
+  const bool out_lane = lane >= kHalo && lane < 64 - kHalo && k <= kmax;
   const bool edge_strip = strip == 0 || (strip + 1) * kCols + kHalo >= kmax;        // wave-uniform: some lanes of this strip lie outside the frame
   uint32_t bf = A.bf;
   if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
   const uint32_t w_lo = bf | ((255u - bf) << 8);
 
-  // a row's address as a scalar base (the SGPR pair of a global_load ... saddr) + this lane's 32-bit offset: no 64-bit multiply-add per lane and row
-  typedef const __attribute__((address_space(1))) uint8_t *gptr_t;      // rebuilt from an integer, the pointer must say "global" itself (else: flat loads)
-  auto urow = [](const uint8_t *base, int y, int pitch) -> gptr_t {
-    const uint64_t a = (uint64_t)base + (uint64_t)((int64_t)y * pitch);
-    return (gptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+  // descriptors: base pointers made provably uniform (readfirstlane of both halves), range = the whole frame
+  auto srd = [](const void *p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    void *u = (void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+    return __builtin_amdgcn_make_buffer_rsrc(u, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
   };
+  const int out_rows = A.cw ? A.ch : A.dh;
+  const __amdgpu_buffer_rsrc_t r_src = srd(T.src[track], (uint32_t)A.sh * (uint32_t)A.irow);
+  const __amdgpu_buffer_rsrc_t r_dst = srd(T.dst[track], (uint32_t)out_rows * (uint32_t)A.orow);
+  const __amdgpu_buffer_rsrc_t r_l2 = srd(CHAIN ? (const void *)T.l2[track] : (const void *)T.src[track], CHAIN ? (uint32_t)out_rows * (uint32_t)A.irow2 : 16u);
+  const uint32_t lane_off = 16u * (uint32_t)kc;
   auto load_row = [&](int sy) -> pb_u4 {
-    sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);      // uniform by construction; said so, the row address is a scalar base + a 32-bit lane offset
-#if defined(PBH_VARIANT) && (PBH_VARIANT & 1)
-    return __builtin_nontemporal_load((const __attribute__((address_space(1))) pb_u4 *)(urow(rowbase, sy, A.irow) + lane_off));
-#else
-    return *(const __attribute__((address_space(1))) pb_u4 *)(urow(rowbase, sy, A.irow) + lane_off);      // plain loads: measured faster than non-temporal ones (band seams and strip halos re-read through L2)
-#endif
+    sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);      // uniform by construction; said so, the row offset stays scalar
+    // plain loads: measured faster than non-temporal ones (band seams and strip halos are re-read through L2)
+    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow, (PBH_LOAD_AUX));
   };
   // ALIGNED: the pixel left of the strip (lane 0) / right of it (lane 63), clamped into the row -- which is the library's edge rule at the frame's two ends
   const bool e_lane = HYPER && ALIGNED && (lane == 0 || lane == 63);
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     uint32_t e = 0u;
     if (e_lane) {
       sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
-      e = *(const __attribute__((address_space(1))) uint32_t *)(urow(rowbase, sy, A.irow) + e_off);
+      e = __builtin_amdgcn_raw_buffer_load_b32(r_src, (int)e_off, sy * A.irow, 0);
     }
     return e;
   };
@@ -388,34 +421,33 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     }
     return q;
   };
-  const uint8_t *l2base = (CHAIN && A.blend) ? T.l2[track] : nullptr;
   const uint32_t l2_off = 8u * (uint32_t)kc + 4u * (uint32_t)A.ox;
   auto load_l2 = [&](int y) -> pb_u2 {
     y = __builtin_amdgcn_readfirstlane(y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y);
-    return __builtin_nontemporal_load((const __attribute__((address_space(1))) pb_u2 *)(urow(l2base, y + A.oy, A.irow2) + l2_off));
+    return __builtin_amdgcn_raw_buffer_load_b64(r_l2, (int)l2_off, (y + A.oy) * A.irow2, 2);      // read once: non-temporal
   };
-  // the rest of the chain on one pixel whose colours are still apart, and the store
+  // the rest of the chain on one pixel whose colours are still apart: chroma blend (simple_blend.c:117-146): s2 = (layer-2 colour * K2[alpha2]) >> 16,
+  // s1 = (track colour * K1[alpha2]) >> 16 (the reference's float scaling of translucent pixels as integers, lgpu_alpha_scalers; alpha 255 = identity), then
+  // (bf * s2 + (255 - bf) * s1) >> 8, then the gamma LUT (the identity table when the chain has none)
   auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
-    if (CHAIN && A.blend) {
-      // chroma blend (simple_blend.c:117-146): s2 = (layer-2 colour * K2[alpha2]) >> 16, s1 = (track colour * K1[alpha2]) >> 16 (the reference's float scaling of
-      // translucent pixels as integers, lgpu_alpha_scalers; alpha 255 = identity), then (bf * s2 + (255 - bf) * s1) >> 8
+    if (CHAIN) {
       const pb_u2 kk = s_k[q >> 24];
       const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
       const uint32_t pa = __umul24(c0, kk.y), pb = __umul24(c1, kk.y), pc = __umul24(c2, kk.y);
       c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
       c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
       c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+      c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2];
     }
-    if (CHAIN && A.use_lut) { c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2]; }
     return c0 | (c1 << 8) | (c2 << 16) | al;
   };
+  const uint32_t st_off = out_lane ? 8u * (uint32_t)k + 4u * (uint32_t)A.ox : 0xFFFFFFF0u;      // beyond the descriptor's range: the hardware drops the store
   auto store_row = [&](int y, uint32_t p0, uint32_t p1) {
-    if (out_lane) {
-      pb_u2 *d = reinterpret_cast<pb_u2 *>(T.dst[track] + (size_t)(y + A.oy) * A.orow + 8 * (size_t)k + 4 * (size_t)A.ox);
-      pb_u2 o;
-      o.x = p0; o.y = p1;
-      if (A.nt_out) __builtin_nontemporal_store(o, d); else *d = o;
-    }
+    pb_u2 o;
+    o.x = p0; o.y = p1;
+    const int so = __builtin_amdgcn_readfirstlane((y + A.oy) * A.orow);
+    if (CHAIN) __builtin_amdgcn_raw_buffer_store_b64(o, r_dst, (int)st_off, so, 2);       // results are not read again by this launch: non-temporal
+    else __builtin_amdgcn_raw_buffer_store_b64(o, r_dst, (int)st_off, so, 0);
   };
 
   // scaled rows this band has to produce: its own, plus two above and below for the blur (clamped to the frame: the gaussian replicates the border rows).
@@ -432,33 +464,75 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   uint32_t e0 = load_e(S0), e1 = load_e(S0 + d), ea = load_e(S0 + 2 * d), eb = load_e(S0 + 3 * d);
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
-  if (CHAIN && A.blend) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
-  if (CHAIN) {        // this wave's copy of the two small tables, requested while the first source rows are in flight; first read an output row later
+  if (CHAIN) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
+  if (CHAIN) {        // the two small tables, requested while the first source rows are in flight; first read an output row later
     reinterpret_cast<uint32_t *>(s_lut)[lane] = lut.w[lane];
-    if (A.blend) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const uint2 kk = A.kscale[lane + 64 * i];
-        pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
-        s_k[lane + 64 * i] = kv;
-      }
+    for (int i = 0; i < 4; i++) {
+      const uint2 kk = A.kscale[lane + 64 * i];
+      pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
+      s_k[lane + 64 * i] = kv;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   uint32_t e_ml = lane == 0 ? 1u : 0u, e_mr = lane == 63 ? 1u : 0u;
   asm volatile("" : "+v"(e_ml), "+v"(e_mr));          // opaque to the optimiser: it would turn the multiply-adds below into select + add pairs
-  pb_half_hrow<HYPER, ALIGNED>(fix(q0), hr, e0, e_ml, e_mr);
-  pb_half_hrow<HYPER, ALIGNED>(fix(q1), hs, e1, e_ml, e_mr);
+  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q0), hr, e0, e_ml, e_mr);
+  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q1), hs, e1, e_ml, e_mr);
 #pragma unroll
   for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
-  int produced = ystart - d;              // the last scaled row that exists
-  uint32_t cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, al[2] = {0, 0};      // the current scaled row of this lane: colours apart, alpha in place (<< 24)
-  uint32_t ring[5][4];                     // BLUR: horizontally blurred rows, newest last; [row][column * 2 + (0: bytes 0 and 2, 1: bytes 1 and 3)] in 16-bit lanes
-  if (BLUR) {
+
+  // one scaled row from its last two source rows (the first two are in `carry`): colours apart in cc, alpha in place (<< 24) in al
+  auto scale_row = [&](const pb_u4 &ra, const pb_u4 &rb, uint32_t xa, uint32_t xb, uint32_t cc[2][3], uint32_t al[2]) __attribute__((always_inline)) {
+    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(ra), hr, xa, e_ml, e_mr);
+    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(rb), hs, xb, e_ml, e_mr);
+    uint32_t v[8];
 #pragma unroll
-    for (int i = 0; i < 5; i++) { ring[i][0] = 0; ring[i][1] = 0; ring[i][2] = 0; ring[i][3] = 0; }
+    for (int i = 0; i < 8; i++) {
+      if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
+      else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t va = v[4 * j + 3];
+      pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, cc[j]);       // V_alpha == 0 makes every V_c 0 too: 0 * fl(1 / 1) = 0, the library's all-zero pixel
+      al[j] = (va >> A.ashift) << 24;
+    }
+  };
+
+  if (!BLUR) {
+    // two scaled rows per trip, the source rows of one in (qa, qb), of the other in (na, nb): a row's loads land in the registers its arithmetic reads, issued a whole
+    // row of arithmetic earlier, and nothing is moved between registers
+    pb_u4 na = qa, nb = qb;
+    uint32_t nea = 0, neb = 0;
+    pb_u2 nl2;
+    nl2.x = 0; nl2.y = 0;
+    auto one = [&](int r, pb_u4 &ca, pb_u4 &cb, uint32_t &cea, uint32_t &ceb, pb_u2 &cl2, pb_u4 &xa, pb_u4 &xb, uint32_t &xea, uint32_t &xeb, pb_u2 &xl2) __attribute__((always_inline)) {
+      const int yy = d > 0 ? ystart + r : ystart - r;
+      if (r + 1 < rows) {       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
+        xa = load_row(S0 + d * (2 * r + 4)); xb = load_row(S0 + d * (2 * r + 5));
+        xea = load_e(S0 + d * (2 * r + 4)); xeb = load_e(S0 + d * (2 * r + 5));
+        if (CHAIN) xl2 = load_l2(yy + d);
+      }
+      uint32_t cc[2][3], al[2];
+      scale_row(ca, cb, cea, ceb, cc, al);
+      store_row(yy, finish(cc[0][0], cc[0][1], cc[0][2], al[0], cl2.x), finish(cc[1][0], cc[1][1], cc[1][2], al[1], cl2.y));
+    };
+    int r = 0;
+    for (; r + 1 < rows; r += 2) {
+      one(r, qa, qb, ea, eb, l2, na, nb, nea, neb, nl2);
+      one(r + 1, na, nb, nea, neb, nl2, qa, qb, ea, eb, l2);
+    }
+    if (r < rows) one(r, qa, qb, ea, eb, l2, na, nb, nea, neb, nl2);
+    return;
   }
+
+  int produced = ystart - d;              // the last scaled row that exists
+  uint32_t cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, al[2] = {0, 0};      // the current scaled row of this lane
+  uint32_t ring[5][4];                     // horizontally blurred rows, newest last; [row][column * 2 + (0: bytes 0 and 2, 1: bytes 1 and 3)] in 16-bit lanes
+#pragma unroll
+  for (int i = 0; i < 5; i++) { ring[i][0] = 0; ring[i][1] = 0; ring[i][2] = 0; ring[i][3] = 0; }
   const int nsteps = vr1 - vr0 + 1;
   for (int step = 0; step < nsteps; step++) {
     const int vr = vstart + d * step;
@@ -469,69 +543,210 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
       const int r = d > 0 ? yy - ystart : ystart - yy;
       const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
-      const uint32_t nea = load_e(S0 + d * (2 * r + 4)), neb = load_e(S0 + d * (2 * r + 5));
-      if (CHAIN && A.blend) nl2 = load_l2(BLUR ? vr - d : yy + d);
-      pb_half_hrow<HYPER, ALIGNED>(fix(qa), hr, ea, e_ml, e_mr);
-      pb_half_hrow<HYPER, ALIGNED>(fix(qb), hs, eb, e_ml, e_mr);
-      uint32_t v[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
-        else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const uint32_t va = v[4 * j + 3];
-        pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, cc[j]);       // V_alpha == 0 makes every V_c 0 too: 0 * fl(1 / 1) = 0, the library's all-zero pixel
-        if (A.swap_rb) { const uint32_t t = cc[j][0]; cc[j][0] = cc[j][2]; cc[j][2] = t; }
-        al[j] = (va >> A.ashift) << 24;
-      }
+      if (CHAIN) nl2 = load_l2(vr - d);
+      scale_row(qa, qb, 0u, 0u, cc, al);
       qa = na; qb = nb;
-      ea = nea; eb = neb;
       produced = yy;
-      if (BLUR) {
-        // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
-        uint32_t e[6], o[6];
-        e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
-        e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
-        e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
-        e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
-        e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
-        if (edge_strip) {       // the gaussian replicates the frame's first / last column
-          if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
-          if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
-        ring[4][0] = e[0] + e[4] + 4u * (e[1] + e[3]) + 6u * e[2]; ring[4][1] = o[0] + o[4] + 4u * (o[1] + o[3]) + 6u * o[2];
-        ring[4][2] = e[1] + e[5] + 4u * (e[2] + e[4]) + 6u * e[3]; ring[4][3] = o[1] + o[5] + 4u * (o[2] + o[4]) + 6u * o[3];
+      // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
+      uint32_t e[6], o[6];
+      e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
+      e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
+      e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
+      e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
+      e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
+      if (edge_strip) {       // the gaussian replicates the frame's first / last column
+        if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
+        if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
       }
-    } else if (BLUR) {          // a row beyond the frame's first / last: the border row again
-      if (CHAIN && A.blend) nl2 = load_l2(vr - d);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
+      ring[4][0] = e[0] + e[4] + 4u * (e[1] + e[3]) + 6u * e[2]; ring[4][1] = o[0] + o[4] + 4u * (o[1] + o[3]) + 6u * o[2];
+      ring[4][2] = e[1] + e[5] + 4u * (e[2] + e[4]) + 6u * e[3]; ring[4][3] = o[1] + o[5] + 4u * (o[2] + o[4]) + 6u * o[3];
+    } else {          // a row beyond the frame's first / last: the border row again
+      if (CHAIN) nl2 = load_l2(vr - d);
       const uint32_t t0 = ring[4][0], t1 = ring[4][1], t2 = ring[4][2], t3 = ring[4][3];
 #pragma unroll
       for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
       ring[4][0] = t0; ring[4][1] = t1; ring[4][2] = t2; ring[4][3] = t3;
     }
-    if (BLUR) {
-      if (step >= 4) {                    // the ring holds the five rows around output row vr - 2 d
-        const int y = vr - 2 * d;
-        uint32_t pxo[2];
+    if (step >= 4) {                    // the ring holds the five rows around output row vr - 2 d
+      const int y = vr - 2 * d;
+      uint32_t pxo[2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
-          const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
-          // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
-          pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
-        }
-        store_row(y, pxo[0], pxo[1]);
+      for (int j = 0; j < 2; j++) {
+        const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
+        const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
+        // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
+        pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
       }
-      if (step >= 3) l2 = nl2;
-    } else {
-      store_row(yy, finish(cc[0][0], cc[0][1], cc[0][2], al[0], l2.x), finish(cc[1][0], cc[1][1], cc[1][2], al[1], l2.y));
-      l2 = nl2;
+      store_row(y, pxo[0], pxo[1]);
     }
+    if (step >= 3) l2 = nl2;
   }
+}
+
+// =====================================================================================================================================================
+// k_pb_half_ld -- the chain form of k_pb_half (no blur, no canvas) with the HBM stream taken out of the arithmetic waves: a workgroup is FOUR compute waves (the four
+// adjacent strips of a band, today's arithmetic unchanged) and ONE loader wave.  The loader requests every source row of the band ONCE, as one burst of four
+// back-to-back 1 KB requests (250 quads = 4000 contiguous bytes: what the four strips and their two feeder quads cover), straight into an LDS ring by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write); the compute waves read their 16 bytes per lane and row with ds_read_b128.  Why: the same bytes
+// stream 15 % faster when ONE wave asks for 4 KB of a row at a stretch than when four waves ask for 1 KB each at their own pace (profiles/r03/chain_sides.txt:
+// DRAM pages stay open), and the compute waves no longer queue behind their own loads; bands can be tall (the ring, not the register file, holds the rows in
+// flight), so the two seam rows a band shares with its neighbour weigh 2 / (2 th + 2) of the source traffic at th = 16 instead of th = 6.
+// Ring: NP slots of one ROW PAIR (2 x 4096 bytes).  One raw s_barrier per scaled row: B(p) says "pair p has landed" (the loader waited for it with a counted
+// vmcnt before arriving) and "pair p - 1 has been read" (the compute waves arrive after their ds_reads of it returned), so the loader refills slot (p - 1) % NP
+// right after B(p) with pair p - 1 + NP.
+// =====================================================================================================================================================
+#define PB_LD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef const __attribute__((address_space(1))) void *pb_gptr;
+typedef __attribute__((address_space(3))) void *pb_lptr;
+template <int HYPER, int SWAP, int NP>
+__global__ __launch_bounds__(320) void k_pb_half_ld(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
+  constexpr int kRowB = 4096;                                           // LDS pitch of a row segment (4000 bytes used)
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[NP * 2 * kRowB];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+  __shared__ pb_u2 s_k[256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0 .. 3 compute, 4 loader
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nseq = A.cgroups * A.bands * A.ntracks, per_xcd = (nseq + 7) >> 3;
+  const int seq = xcd * per_xcd + slot;
+  if (seq >= nseq || slot >= per_xcd) return;                            // the whole workgroup
+  const int cg_ = seq / A.bands, band = seq - cg_ * A.bands, track = cg_ / A.cgroups, cg = cg_ - track * A.cgroups;
+  const int kmax = (A.sw >> 2) - 1;
+  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
+  const int d = (band & 1) ? -1 : 1;
+  const int ystart = d > 0 ? y0 : y0 + rows - 1;
+  const int S0 = d > 0 ? 2 * y0 - 1 : 2 * (y0 + rows - 1) + 2;           // source rows are consumed in the order S0, S0 + d, ...: pair p = rows S0 + 2 p d, S0 + (2 p + 1) d
+  const int npairs = rows + 1;
+
+  if (wave == 4) {
+    // ---- loader: 8 requests per pair (2 rows x 4 rounds of 64 quads; the last round 58), rows and quads clamped into the frame (the compute waves re-select the
+    // border pixels as before)
+    const uint64_t a64 = (uint64_t)T.src[track];
+    const uint8_t *src = (const uint8_t *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a64));
+    const int q0 = cg * 248 - 1;
+    uint32_t off[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int q = q0 + 64 * j + lane; off[j] = 16u * (uint32_t)(q < 0 ? 0 : q > kmax ? kmax : q); }
+    auto issue = [&](int p) __attribute__((always_inline)) {
+      uint8_t *sl = s_ring + (p % NP) * 2 * kRowB;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int sy = S0 + d * (2 * p + h);
+        sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
+        const uint8_t *g = src + (size_t)sy * A.irow;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < 3 || lane < 58) __builtin_amdgcn_global_load_lds((pb_gptr)(g + off[j]), (pb_lptr)(sl + h * kRowB + j * 1024), 16, 0, 0);
+      }
+    };
+    for (int p = 0; p < NP && p < npairs; p++) issue(p);
+    for (int p = 0; p < npairs; p++) {
+      // pairs requested after pair p at this point: up to NP - 2 (NP - 1 for p = 0; taken as NP - 2 as well), fewer at the band's end
+      const int after = min(NP - 2, npairs - 1 - p);
+      if (NP >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (NP >= 3 && after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PB_LD_BARRIER();                                                   // B(p)
+      if (p >= 1 && p - 1 + NP < npairs) issue(p - 1 + NP);
+    }
+    return;
+  }
+
+  // ---- compute waves
+  const int strip = cg * 4 + wave;
+  const bool active = strip < A.strips;                                  // wave-uniform; an idle wave still meets every barrier
+  const int k = strip * 62 - 1 + lane;
+  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
+  const bool out_lane = lane >= 1 && lane < 63 && k <= kmax && active;
+  const bool edge_strip = strip == 0 || (strip + 1) * 62 + 1 >= kmax;
+  uint32_t bf = A.bf;
+  if (A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
+  const uint32_t w_lo = bf | ((255u - bf) << 8);
+  auto srd = [](const void *p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    void *u = (void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+    return __builtin_amdgcn_make_buffer_rsrc(u, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t r_dst = srd(T.dst[track], (uint32_t)A.dh * (uint32_t)A.orow);
+  const __amdgpu_buffer_rsrc_t r_l2 = srd(T.l2[track], (uint32_t)A.dh * (uint32_t)A.irow2);
+  const uint32_t l2_off = 8u * (uint32_t)kc;
+  auto load_l2 = [&](int y) -> pb_u2 {
+    y = __builtin_amdgcn_readfirstlane(y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y);
+    return __builtin_amdgcn_raw_buffer_load_b64(r_l2, (int)l2_off, y * A.irow2, 2);
+  };
+  auto fix = [&](pb_u4 q) -> pb_u4 {
+    if (edge_strip) {
+      asm volatile("" ::: "memory");
+      if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }
+      if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }
+    }
+    return q;
+  };
+  auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
+    const pb_u2 kk = s_k[q >> 24];
+    const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
+    const uint32_t pa = __umul24(c0, kk.y), pb = __umul24(c1, kk.y), pc = __umul24(c2, kk.y);
+    c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+    c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+    c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
+    c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2];
+    return c0 | (c1 << 8) | (c2 << 16) | al;
+  };
+  const uint32_t st_off = out_lane ? 8u * (uint32_t)k : 0xFFFFFFF0u;
+  const uint8_t *ring_lane = s_ring + 16 * (wave * 62 + lane);
+  auto ring_row = [&](int p, int h) -> pb_u4 { return *reinterpret_cast<const pb_u4 *>(ring_lane + ((p % NP) * 2 + h) * kRowB); };
+
+  pb_u2 l2, nl2;
+  l2.x = 0; l2.y = 0; nl2 = l2;
+  if (active) l2 = load_l2(ystart);
+  reinterpret_cast<uint32_t *>(s_lut)[lane] = lut.w[lane];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint2 kk = A.kscale[lane + 64 * i];
+    pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
+    s_k[lane + 64 * i] = kv;
+  }
+  uint32_t carry[8], hr[8], hs[8];
+  PB_LD_BARRIER();                                                       // B(0)
+  {
+    const pb_u4 q0 = ring_row(0, 0), q1 = ring_row(0, 1);
+    pb_half_hrow<HYPER, 0, SWAP>(fix(q0), hr);
+    pb_half_hrow<HYPER, 0, SWAP>(fix(q1), hs);
+#pragma unroll
+    for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
+  }
+  auto one = [&](int r, pb_u2 &cl2, pb_u2 &xl2) __attribute__((always_inline)) {
+    const int yy = d > 0 ? ystart + r : ystart - r;
+    if (active && r + 1 < rows) xl2 = load_l2(yy + d);
+    PB_LD_BARRIER();                                                     // B(r + 1)
+    if (!active) return;
+    const pb_u4 ra = ring_row(r + 1, 0), rb = ring_row(r + 1, 1);
+    pb_half_hrow<HYPER, 0, SWAP>(fix(ra), hr);
+    pb_half_hrow<HYPER, 0, SWAP>(fix(rb), hs);
+    uint32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
+      else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
+    }
+    uint32_t px[2];
+    const uint32_t lq[2] = {cl2.x, cl2.y};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t va = v[4 * j + 3];
+      uint32_t c[3];
+      pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, c);
+      px[j] = finish(c[0], c[1], c[2], (va >> A.ashift) << 24, lq[j]);
+    }
+    pb_u2 o;
+    o.x = px[0]; o.y = px[1];
+    __builtin_amdgcn_raw_buffer_store_b64(o, r_dst, (int)st_off, __builtin_amdgcn_readfirstlane(yy * A.orow), 2);
+  };
+  int r = 0;
+  for (; r + 1 < rows; r += 2) { one(r, l2, nl2); one(r + 1, nl2, l2); }
+  if (r < rows) one(r, l2, nl2);
 }
 
 // k_pb_half3 -- the same exact 2:1 reduction for 3-byte pixels (RGB24 / BGR24 / YUV888: a pixbuf WITHOUT alpha), standalone form only.  No alpha weighting:
@@ -1307,16 +1522,33 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
   const dim3 grid((unsigned)(a.main_blocks + a.bar_blocks * ntracks));
-  if (pr->do_blur) {
-    if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 1>), grid, dim3(256), 0, st, a, T, l);
-    else hipLaunchKernelGGL((k_pb_half<1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
-  } else {
-    if (a.aligned) {
-      if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 0, 1>), grid, dim3(256), 0, st, a, T, l);
-      else hipLaunchKernelGGL((k_pb_half<1, 0, 0, 1>), grid, dim3(256), 0, st, a, T, l);
-    } else if (a.hyper) hipLaunchKernelGGL((k_pb_half<1, 1, 0>), grid, dim3(256), 0, st, a, T, l);
-    else hipLaunchKernelGGL((k_pb_half<1, 0, 0>), grid, dim3(256), 0, st, a, T, l);
+  // the loader-wave form (k_pb_half_ld): full-device launches of the plain chain
+  if (!pr->do_blur && !cv && tune(TUNE_PBH_LOADER) > 0) {
+    const int np = tune(TUNE_PBH_LOADER);
+    a.aligned = 0;
+    a.strips = (int)cdiv((unsigned)a.dw, 124); a.cgroups = (a.strips + 3) / 4;
+    a.th = 16;
+    { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) a.th = v; }
+    a.bands = (int)cdiv((unsigned)a.dh, (unsigned)a.th);
+    const dim3 g(pb_half_grid(a));
+#define PBH_LD(HY, SW) do { if (np == 3) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 3>), g, dim3(320), 0, st, a, T, l); else if (np >= 6) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 6>), g, dim3(320), 0, st, a, T, l); else hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 4>), g, dim3(320), 0, st, a, T, l); } while (0)
+    if (a.hyper) { if (a.swap_rb) PBH_LD(1, 1); else PBH_LD(1, 0); }
+    else { if (a.swap_rb) PBH_LD(0, 1); else PBH_LD(0, 0); }
+#undef PBH_LD
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
   }
+#define PBH_LAUNCH(HY, BL, AL, SW) hipLaunchKernelGGL((k_pb_half<1, HY, BL, AL, SW>), grid, dim3(256), 0, st, a, T, l)
+#define PBH_SWAP(HY, BL, AL) do { if (a.swap_rb) PBH_LAUNCH(HY, BL, AL, 1); else PBH_LAUNCH(HY, BL, AL, 0); } while (0)
+  if (pr->do_blur) {
+    if (a.hyper) PBH_SWAP(1, 1, 0); else PBH_SWAP(0, 1, 0);
+  } else if (a.aligned) {
+    if (a.hyper) PBH_SWAP(1, 0, 1); else PBH_SWAP(0, 0, 1);
+  } else {
+    if (a.hyper) PBH_SWAP(1, 0, 0); else PBH_SWAP(0, 0, 0);
+  }
+#undef PBH_SWAP
+#undef PBH_LAUNCH
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
@@ -1359,6 +1591,21 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
 }  // namespace lgpu
 
 using namespace lgpu;
+
+// test hook: how many integers a of [lo, hi) give pb_recip(a) != 1.0 / (double)a on the device (0 for the whole 24-bit range, tests/test_pixbuf_scale.py)
+extern "C" int lgpu_debug_recip_check(uint32_t lo, uint32_t hi, unsigned long long *mismatches) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(mismatches && hi > lo && hi <= (1u << 24), "range must lie inside [0, 2^24)");
+  unsigned long long *d = nullptr;
+  LGPU_HIP(hipMalloc((void **)&d, sizeof *d));
+  LGPU_HIP(hipMemset(d, 0, sizeof *d));
+  hipLaunchKernelGGL(k_pb_recip_check, dim3(cdiv(hi - lo, 256u)), dim3(256), 0, 0, lo, hi, d);
+  const hipError_t e = hipMemcpy(mismatches, d, sizeof *d, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_error("lgpu_debug_recip_check: %s", hipGetErrorString(e)); return LGPU_E_HIP; }
+  return LGPU_OK;
+}
 
 extern "C" int lgpu_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff, int32_t *table, size_t table_ints) {
   if ((interp != 2 && interp != 3) || sw < 1 || sh < 1 || dw < 1 || dh < 1 || !n_x || !n_y || !xoff || !yoff) return LGPU_E_BADARG;

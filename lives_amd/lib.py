@@ -98,6 +98,7 @@ PROTOTYPES = {
     "lgpu_yuv420_tuning": [ci, ci, ci],
     "lgpu_tuning_set": [ctypes.c_char_p, ci],
     "lgpu_tuning_get": [ctypes.c_char_p],
+    "lgpu_debug_recip_check": [ctypes.c_uint32, ctypes.c_uint32, vp],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
     "lgpu_alpha_scalers": [vp, vp],

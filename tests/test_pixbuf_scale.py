@@ -348,6 +348,17 @@ def test_chain_on_the_pixbuf_arithmetic(gpu, orc, tune, strips64):
 
 
 @gpu_mark
+def test_reciprocal_equals_the_division_for_every_24_bit_integer(gpu):
+    """the scaler's `1.0 / (double)a` is computed as the hardware estimate + two Newton steps (pb_recip, five operations): the same double as the IEEE division
+    for EVERY a a sum of alpha weights can take (1 .. 2^24 - 1), checked on the device"""
+    import ctypes
+    from lives_amd import lib
+    bad = ctypes.c_ulonglong(123)
+    lib.call("lgpu_debug_recip_check", 1, 1 << 24, ctypes.byref(bad))
+    assert bad.value == 0, "%d reciprocals differ from the division" % bad.value
+
+
+@gpu_mark
 def test_chain_pixbuf_reads_the_device_parameter_block(gpu, orc):
     import torch
     PIXBUF = 0x100
