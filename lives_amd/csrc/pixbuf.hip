@@ -188,6 +188,7 @@ struct PbHalfArgs {
   uint32_t bf;
   const int32_t *bf_d;
   int strips, cgroups, bands, th, ntracks;     // cgroups = ceil(strips / 4): workgroups per band
+  int rem;                       // k_pb_half / k_pb_half_ld: the first `rem` bands are th + 1 rows tall, the others th (bands * th + rem == dh: band heights differ by one row at most)
   int cw, ch, ox, oy;            // letterbox canvas (cw == 0: none): dst / layer 2 are cw x ch, the scaled frame sits at (ox, oy), the rest is opaque black under the blend
   int main_blocks, bar_blocks;   // workgroups of the frame proper / per track of the bars (1024 canvas pixels each)
   int nt_out;
@@ -236,20 +237,37 @@ __device__ __forceinline__ uint32_t pb_add_hi_lo(uint32_t x, uint32_t y) {      
 // wave shifts cannot deliver.  SWAP: channel 0 is fed from byte 2 and channel 2 from byte 0 (the R <-> B conversion of the chain costs nothing: the three colours
 // are treated alike until they are stored).
 template <int HYPER, int ALIGNED = 0, int SWAP = 0>
-__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u, uint32_t ml = 0u, uint32_t mr = 0u) {
+__device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u, uint32_t em = 0u) {
   uint32_t A[4], B[4];
   A[0] = pb_premul_pair<SWAP ? 2 : 0>(q.x, q.y); B[0] = pb_premul_pair<SWAP ? 2 : 0>(q.z, q.w);
   A[1] = pb_premul_pair<1>(q.x, q.y); B[1] = pb_premul_pair<1>(q.z, q.w);
   A[2] = pb_premul_pair<SWAP ? 0 : 2>(q.x, q.y); B[2] = pb_premul_pair<SWAP ? 0 : 2>(q.z, q.w);
   A[3] = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u); B[3] = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);       // the alpha pairs
+  // ALIGNED: the one pixel beyond the strip, premultiplied and already in the half of the dword where the wave shift would have delivered it -- em = 65536 in
+  // lane 0 (P[4k-1] belongs in the high half of the left neighbour's pair), 1 in lane 63 (P[4k+4] in the low half of the right neighbour's), 0 elsewhere; it then
+  // rides into the lane exchange as the value the shift leaves in lanes that have no source lane (DPP without bound_ctrl keeps the destination): 5 operations per row
+  uint32_t xe[4] = {0u, 0u, 0u, 0u};
+  if (HYPER && ALIGNED) {
+    const uint32_t am = __umul24(e >> 24, em);                           // alpha * {65536, 1, 0} <= 0xFF0000: a 24-bit operand
+    if (SWAP) {
+      asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(xe[0]) : "v"(am), "v"(e));
+      asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(xe[2]) : "v"(am), "v"(e));
+    } else {
+      asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(xe[0]) : "v"(am), "v"(e));
+      asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(xe[2]) : "v"(am), "v"(e));
+    }
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(xe[1]) : "v"(am), "v"(e));
+    xe[3] = am;
+  }
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     if (HYPER) {
 #if defined(PBH_VARIANT) && (PBH_VARIANT & 2)
       const uint32_t bl = B[c] ^ 1u, ar = A[c] ^ 1u;       // timing probe only: no lane exchange
 #else
-      const uint32_t bl = (uint32_t)__builtin_amdgcn_mov_dpp((int)B[c], 0x138, 0xF, 0xF, true);     // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1])
-      const uint32_t ar = (uint32_t)__builtin_amdgcn_mov_dpp((int)A[c], 0x130, 0xF, 0xF, true);     // wave_shl:1 -- the right lane's (P[4k+4], P[4k+5])
+      // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1]);  wave_shl:1 -- the right lane's (P[4k+4], P[4k+5]);  lanes 0 / 63 keep xe (0 in strips with feeder lanes)
+      const uint32_t bl = ALIGNED ? (uint32_t)__builtin_amdgcn_update_dpp((int)xe[c], (int)B[c], 0x138, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_mov_dpp((int)B[c], 0x138, 0xF, 0xF, true);
+      const uint32_t ar = ALIGNED ? (uint32_t)__builtin_amdgcn_update_dpp((int)xe[c], (int)A[c], 0x130, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_mov_dpp((int)A[c], 0x130, 0xF, 0xF, true);
 #endif
       h[c] = pb_dot2(A[c], 0x00070007u, pb_add_hi_lo(bl, B[c]));          // P[4k-1] + 7 P[4k] + 7 P[4k+1] + P[4k+2]
       h[4 + c] = pb_dot2(B[c], 0x00070007u, pb_add_hi_lo(A[c], ar));      // P[4k+1] + 7 P[4k+2] + 7 P[4k+3] + P[4k+4]
@@ -257,21 +275,6 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
       h[c] = pb_dot2(A[c], 0x00010001u, 0u);
       h[4 + c] = pb_dot2(B[c], 0x00010001u, 0u);
     }
-  }
-  if (HYPER && ALIGNED) {
-    // e is non-zero in lanes 0 and 63 only; ml / mr (1 in lane 0 / lane 63, else 0) steer its premultiplied bytes into column 2k or 2k + 1: 4 + 8 operations per row
-    uint32_t x[4];
-    if (SWAP) {
-      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(x[0]) : "v"(e));
-      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(x[2]) : "v"(e));
-    } else {
-      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(x[0]) : "v"(e));
-      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(x[2]) : "v"(e));
-    }
-    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(x[1]) : "v"(e));
-    x[3] = e >> 24;
-#pragma unroll
-    for (int c = 0; c < 4; c++) { h[c] = __umul24(x[c], ml) + h[c]; h[4 + c] = __umul24(x[c], mr) + h[4 + c]; }
   }
 }
 
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const int k = strip * kCols - kHalo + lane;             // this lane's source quad: pixels 4k .. 4k + 3 -> output columns 2k, 2k + 1
   const int kmax = (A.sw >> 2) - 1;
   const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
-  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
+  const int y0 = band * A.th + min(band, A.rem), rows = A.th + (band < A.rem ? 1 : 0);
   const bool out_lane = lane >= kHalo && lane < 64 - kHalo && k <= kmax;
   const bool edge_strip = strip == 0 || (strip + 1) * kCols + kHalo >= kmax;        // wave-uniform: some lanes of this strip lie outside the frame
   uint32_t bf = A.bf;
@@ -476,17 +479,16 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  uint32_t e_ml = lane == 0 ? 1u : 0u, e_mr = lane == 63 ? 1u : 0u;
-  asm volatile("" : "+v"(e_ml), "+v"(e_mr));          // opaque to the optimiser: it would turn the multiply-adds below into select + add pairs
-  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q0), hr, e0, e_ml, e_mr);
-  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q1), hs, e1, e_ml, e_mr);
+  const uint32_t e_m = lane == 0 ? 65536u : lane == 63 ? 1u : 0u;
+  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q0), hr, e0, e_m);
+  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q1), hs, e1, e_m);
 #pragma unroll
   for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
 
   // one scaled row from its last two source rows (the first two are in `carry`): colours apart in cc, alpha in place (<< 24) in al
   auto scale_row = [&](const pb_u4 &ra, const pb_u4 &rb, uint32_t xa, uint32_t xb, uint32_t cc[2][3], uint32_t al[2]) __attribute__((always_inline)) {
-    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(ra), hr, xa, e_ml, e_mr);
-    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(rb), hs, xb, e_ml, e_mr);
+    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(ra), hr, xa, e_m);
+    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(rb), hs, xb, e_m);
     uint32_t v[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
 #define PB_LD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef const __attribute__((address_space(1))) void *pb_gptr;
 typedef __attribute__((address_space(3))) void *pb_lptr;
-template <int HYPER, int SWAP, int NP>
+template <int HYPER, int SWAP, int NP, int NT = 0>
 __global__ __launch_bounds__(320) void k_pb_half_ld(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
   constexpr int kRowB = 4096;                                           // LDS pitch of a row segment (4000 bytes used)
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[NP * 2 * kRowB];
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(320) void k_pb_half_ld(const PbHalfArgs A, const Pb
   if (seq >= nseq || slot >= per_xcd) return;                            // the whole workgroup
   const int cg_ = seq / A.bands, band = seq - cg_ * A.bands, track = cg_ / A.cgroups, cg = cg_ - track * A.cgroups;
   const int kmax = (A.sw >> 2) - 1;
-  const int y0 = band * A.th, rows = min(A.th, A.dh - y0);
+  const int y0 = band * A.th + min(band, A.rem), rows = A.th + (band < A.rem ? 1 : 0);
   const int d = (band & 1) ? -1 : 1;
   const int ystart = d > 0 ? y0 : y0 + rows - 1;
   const int S0 = d > 0 ? 2 * y0 - 1 : 2 * (y0 + rows - 1) + 2;           // source rows are consumed in the order S0, S0 + d, ...: pair p = rows S0 + 2 p d, S0 + (2 p + 1) d
@@ -638,7 +640,11 @@ __global__ __launch_bounds__(320) void k_pb_half_ld(const PbHalfArgs A, const Pb
         const uint8_t *g = src + (size_t)sy * A.irow;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (j < 3 || lane < 58) __builtin_amdgcn_global_load_lds((pb_gptr)(g + off[j]), (pb_lptr)(sl + h * kRowB + j * 1024), 16, 0, 0);
+          if (j < 3 || lane < 58) {
+            // NT: a band's own rows are read once (non-temporal); its first and last pair are shared with the neighbouring bands and stay in L2's normal policy
+            if (NT && p > 0 && p < npairs - 1) __builtin_amdgcn_global_load_lds((pb_gptr)(g + off[j]), (pb_lptr)(sl + h * kRowB + j * 1024), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((pb_gptr)(g + off[j]), (pb_lptr)(sl + h * kRowB + j * 1024), 16, 0, 0);
+          }
       }
     };
     for (int p = 0; p < NP && p < npairs; p++) issue(p);
@@ -1476,23 +1482,41 @@ static bool pb_double_ok(const PbTable *t, int x_step, int y_step) {
   return true;
 }
 
+// bands of th or th + 1 rows that cover dh exactly
+static void pb_half_bands(PbHalfArgs *a, int bands) {
+  if (bands < 1) bands = 1;
+  if (bands > a->dh) bands = a->dh;
+  a->bands = bands; a->th = a->dh / bands; a->rem = a->dh - a->th * bands;
+}
+
 static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
-  // strips of 64 storing lanes on 128-byte lines (k_pb_half<.., ALIGNED>): 3 % less traffic for 13 % more arithmetic.  On a box that has been under load for a
-  // minute (memory side slower) the 16-track launch gains 2.4 % (173.7 -> 169.5 us), on a fresh box it loses 2 % (161 -> 165 us), one frame per launch loses 10 %
-  // (profiles/r03/pbh_aligned_ab.txt: five interleaved A / B runs on four boxes) -- so it is opt-in: LGPU_PBH_ALIGNED=1
-  a->aligned = 0;
+  // strips of 64 storing lanes on 128-byte lines (k_pb_half<.., ALIGNED>; the two outer taps of a strip from one extra 4-byte load in lanes 0 and 63, which ride into
+  // the lane exchange for free).  Round 3 measured them 3 % lighter on traffic and 13 % heavier on arithmetic: a draw.  With round 4's arithmetic (buffer addressing,
+  // five-operation reciprocal, no register moves, the edge taps through DPP's kept destination) they win clearly: 16 tracks 166.5 -> 155.0 us, 8 tracks 85.7 -> 81.1,
+  // one frame equal (profiles/r04/al_ab1.txt, interleaved).  LGPU_PBH_ALIGNED=0 keeps the feeder-lane strips.
+  a->aligned = blur ? 0 : 1;
   if (!blur && tune(TUNE_PBH_ALIGNED) >= 0) a->aligned = tune(TUNE_PBH_ALIGNED) ? 1 : 0;
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : a->aligned ? 128 : 124);
-  // measured (profiles/r03/pbh_sweep*.txt): short bands win even when the device is full.  With neighbouring bands walking towards each other, over two boxes:
-  // 16 tracks 170 / 167 us at 4 rows, 166 at 6, 165 / 174 at 8, 175 at 16; one 4K frame 11.0-11.2 us at 4 rows, 9.9 at 6, 11.7 at 8, 14.7 at 16
-  a->th = 6;                     // (8 rows are 0.6 % faster on a full device, interleaved on two boxes -- profiles/r03/pbh_th_interleaved.txt; kept at 6: the round's evidence files were made with it)
-  // with the blur a band computes th + 4 scaled rows: a full device wants tall bands (16 tracks: 280 us at 4 rows, 241 at 6, 222 at 8, 204 at 12, 197 at 16, 194 at 24),
-  // one frame short ones (24.7 / 21.3 / 24.0 / 23.2 / 27.6 / 28.6 us) -- profiles/r03/blur_band_sweep.txt
-  if (blur) a->th = (long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6 : 24;
-  { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) a->th = v; }       // tuning probe
-  a->bands = (int)cdiv((unsigned)a->dh, (unsigned)a->th);
   a->cgroups = (a->strips + 3) / 4;
   a->ntracks = ntracks;
+  // Band height.  Short bands win (profiles/r03/pbh_sweep*.txt, r04/al_ab1.txt: 4-6 rows within 1 %, 8 rows 5 % behind, 12 rows further), but with ~6 rows a
+  // full-device launch is only five or six generations of workgroups and the last, partly filled generation costs up to 6 % (16 tracks at 6 rows: 11,520 workgroups
+  // on 2,048 resident ones = 5.6 generations).  So when a launch does not fit into one generation, the number of bands per column is chosen -- between 5 and 7.5 rows
+  // per band, heights differing by one row at most -- so that the workgroups fill whole generations: the cheapest of generations x (rows per band + 1.5), the 1.5
+  // standing for a band's two extra source rows and its start-up.  With the blur a band computes th + 4 scaled rows, a full device wants tall bands, one frame short ones
+  // (profiles/r03/blur_band_sweep.txt).
+  const int per_cu = blur ? 6 : 8;                       // resident workgroups per CU (80 / <= 64 VGPRs)
+  const long long slots = (long long)device_cus() * per_cu, cols = (long long)a->cgroups * ntracks;
+  int bands = (int)cdiv((unsigned)a->dh, blur ? ((long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6u : 24u) : 6u);
+  if (!blur && cols * bands > slots) {
+    double best = 1e30;
+    for (int b = (int)cdiv(2u * (unsigned)a->dh, 15u); b <= (int)cdiv((unsigned)a->dh, 5u); b++) {
+      const double cost = (double)((cols * b + slots - 1) / slots) * ((double)a->dh / b + 1.5);
+      if (cost < best) { best = cost; bands = b; }
+    }
+  }
+  { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) bands = (int)cdiv((unsigned)a->dh, (unsigned)v); }       // tuning probe / tests: bands of (about) v rows
+  pb_half_bands(a, bands);
 }
 
 static unsigned pb_half_grid(const PbHalfArgs &a) { return 8u * cdiv((unsigned)(a.cgroups * a.bands * a.ntracks), 8u); }
@@ -1524,14 +1548,12 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   const dim3 grid((unsigned)(a.main_blocks + a.bar_blocks * ntracks));
   // the loader-wave form (k_pb_half_ld): full-device launches of the plain chain
   if (!pr->do_blur && !cv && tune(TUNE_PBH_LOADER) > 0) {
-    const int np = tune(TUNE_PBH_LOADER);
+    const int np = tune(TUNE_PBH_LOADER) & 15, nt = tune(TUNE_PBH_LOADER) >> 4;          // ring depth in row pairs; + 16: non-temporal loads of a band's inner rows
     a.aligned = 0;
     a.strips = (int)cdiv((unsigned)a.dw, 124); a.cgroups = (a.strips + 3) / 4;
-    a.th = 16;
-    { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) a.th = v; }
-    a.bands = (int)cdiv((unsigned)a.dh, (unsigned)a.th);
+    { const int v = tune(TUNE_PBH_TH); pb_half_bands(&a, (int)cdiv((unsigned)a.dh, v >= 1 && v <= 1024 ? (unsigned)v : 12u)); }
     const dim3 g(pb_half_grid(a));
-#define PBH_LD(HY, SW) do { if (np == 3) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 3>), g, dim3(320), 0, st, a, T, l); else if (np >= 6) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 6>), g, dim3(320), 0, st, a, T, l); else hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 4>), g, dim3(320), 0, st, a, T, l); } while (0)
+#define PBH_LD(HY, SW) do { if (np == 3) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 3>), g, dim3(320), 0, st, a, T, l); else if (np >= 6) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 6>), g, dim3(320), 0, st, a, T, l); else if (nt) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 4, 1>), g, dim3(320), 0, st, a, T, l); else hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 4>), g, dim3(320), 0, st, a, T, l); } while (0)
     if (a.hyper) { if (a.swap_rb) PBH_LD(1, 1); else PBH_LD(1, 0); }
     else { if (a.swap_rb) PBH_LD(0, 1); else PBH_LD(0, 0); }
 #undef PBH_LD

@@ -128,9 +128,9 @@ def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur, interp):
         assert torch.equal(dst2[t], dst_d[perm[t]])
 
 
-@pytest.mark.parametrize("shape", ["aligned", "th8"])
+@pytest.mark.parametrize("shape", ["aligned", "th8", "loader3", "loader4", "loader6", "loader4_th5"])
 def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
-    """the same 16-track launch in the shapes the switches select (64-lane strips, another band height): same bytes as the default shape,
+    """the same 16-track launch in the shapes the switches select (64-lane strips, another band height, the loader-wave form k_pb_half_ld with rings of 3 / 4 / 6 row pairs and a band height that leaves a short last band): same bytes as the default shape,
     which test_c5_sixteen_track_4k_chain compares with the oracle -- and track 0 against the oracle here as well"""
     import torch
     rng = np.random.default_rng(4015)
@@ -142,8 +142,12 @@ def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
     gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, ref))
     if shape == "aligned":
         tune("PBH_ALIGNED", 1)
-    else:
+    elif shape == "th8":
         tune("PBH_TH", 8)
+    else:
+        tune("PBH_LOADER", int(shape[6]))
+        if shape.endswith("th5"):
+            tune("PBH_TH", 5)
     got = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
     gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, got))
     for t in range(T):
