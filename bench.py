@@ -128,6 +128,16 @@ def main():
             comm = ld.RcclComm("cuda")
         elif rank == 0:
             print("bench.py: librccl could not be bound on every rank; the parameter block goes through torch.distributed", file=sys.stderr)
+    rccl_preflight = None
+    if comm is not None and world > 1:
+        # the exchanges of the path with the ranks of this job before anything is timed: broadcast with real peers, fan-in slots for 2 * world + 1 tracks, 20 steps of
+        # the C stepper against plain launches.  A failure does not kill the job: the parameter block then goes through torch.distributed and the line says so
+        rccl_preflight = ld.preflight(comm, "cuda", ops=ops)
+        if rccl_preflight != "ok":
+            if rank == 0:
+                print("bench.py: RCCL preflight %s; the parameter block goes through torch.distributed" % rccl_preflight, file=sys.stderr)
+            comm.close()
+            comm = None
     nsched = args.steps + args.warmup
     sched_host = [[(96 + 7 * s) % 256, 0, 0, 0] for s in range(nsched)]
     # N > 1 with RCCL bound: the whole per-step host path is ONE C call, lgpu_chain_step (wait for this step's block, exchange the next on a side stream, launch)
@@ -136,9 +146,15 @@ def main():
     if pipe is not None:
         pipe.prefetch(0, schedule[0] if rank == 0 else None)
 
+    AHEAD = 16          # parameter blocks per exchange (lgpu_stepper_feed): the schedule of a render is known ahead
+    fed = [1]           # blocks handed to the stepper so far (the first one by its constructor)
+
     def step(s):
         if stepper is not None:
-            stepper.step(sched_host[s + 1] if s + 1 < nsched else None, prm, trks[s % nsets])
+            if fed[0] == s + 1 and fed[0] < nsched:
+                stepper.feed(sched_host[fed[0]:fed[0] + AHEAD])
+                fed[0] = min(nsched, fed[0] + AHEAD)
+            stepper.step(None, prm, trks[s % nsets])
             return
         if world > 1:
             # RCCL broadcast over xGMI, no host sync: the block of step s was sent while step s - 1 ran; send the next one now
@@ -181,17 +197,26 @@ def main():
         one = [ops.chain_tracks([k[0][0]], [k[1][0]], [k[2][0]]) for k in keep]
         n5 = max(args.steps, 200)
         st5 = ld.Stepper(comm, sched_host[0])
-        for s in range(50):
-            st5.step(sched_host[(s + 1) % nsched], prm, one[s % nsets])
+        tot5, f5 = 50 + n5, 1
+
+        def step5(i):
+            nonlocal f5
+            if f5 == i + 1 and f5 < tot5:
+                k = min(AHEAD, tot5 - f5)
+                st5.feed([sched_host[(f5 + j) % nsched] for j in range(k)])
+                f5 += k
+            st5.step(None, prm, one[i % nsets])
+        for i in range(50):
+            step5(i)
         fence()
         t5 = time.perf_counter()
-        for s in range(n5):
-            st5.step(sched_host[(s + 1) % nsched] if s + 1 < n5 else None, prm, one[s % nsets])
+        for i in range(50, tot5):
+            step5(i)
         fence()
         d5 = ld.max_over_ranks(time.perf_counter() - t5, "cuda")
         st5.close()
         config5 = {"config5_fps": round(world * n5 / d5, 1), "config5_ms_per_step": round(d5 / n5 * 1e3, 4), "config5_steps": n5,
-                   "config5_shape": "one 3840x2160 frame per GPU per step, lgpu_chain_step (C) with the RCCL parameter exchange on"}
+                   "config5_shape": "one 3840x2160 frame per GPU per step, lgpu_chain_step (C) with the RCCL parameter exchange on (%d blocks per exchange, lgpu_stepper_feed)" % AHEAD}
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around K launches ----
     reps = max(10, min(args.steps, 200))
@@ -209,17 +234,48 @@ def main():
     launch_s = ms * 1e-3 / reps
     algo = ALGO_BYTES_PER_FRAME * T
     achieved = algo / launch_s / 1e9
-    traffic = None
-    try:   # HBM bytes per launch from the PMC passes of this round's build on this exact workload (tools/pmc.sh + tools/pmc_traffic.py -> profiles/pmc_traffic.json, which names the commit)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_pixbuf.json" if args.resize_backend == "pixbuf" else "pmc_traffic.json")) as f:
+    traffic, traffic_source = None, None
+    try:   # HBM bytes per launch from the PMC passes of this round's build on this exact workload (tools/pmc.sh + tools/pmc_traffic.py -> profiles/pmc_traffic*.json, which names the commit)
+        tf = "pmc_traffic_pixbuf.json" if args.resize_backend == "pixbuf" else "pmc_traffic.json"
+        with open(os.path.join(ROOT, "profiles", tf)) as f:
             pj = json.load(f)
         if pj.get("tracks") == T and pj.get("blur") == args.blur:
             traffic = pj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/%s@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of that commit's build; not measured in this run)" % (tf, pj.get("commit"))
     except (OSError, ValueError):
         pass
+
+    # the denominator of "aggregate at 8 GPUs on an 8-track batch": the same 8 tracks as ONE launch on ONE GPU (every rank measures its own; rank 0's is printed)
+    batch8 = None
+    if T >= 8:
+        prm.param_block_d = sched_base if world == 1 else pblock.data_ptr()
+        t8 = [ops.chain_tracks(k[0][:8], k[1][:8], k[2][:8]) for k in keep]
+        for i in range(20):
+            ops.chain(prm, t8[i % nsets])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n8 = max(20, min(args.steps, 200))
+        e0.record()
+        for i in range(n8):
+            ops.chain(prm, t8[i % nsets])
+        e1.record()
+        torch.cuda.synchronize()
+        us8 = e0.elapsed_time(e1) * 1e3 / n8
+        batch8 = {"batch8_1gpu_fps": round(8e6 / us8, 1), "batch8_1gpu_us_per_step": round(us8, 2)}
+
+    # what this box's memory system gives the launch's own algorithmic bytes as a bare stream (no arithmetic, no re-reads): tells a slow box from a regression
+    box = None
+    if True:
+        try:
+            ops.stream_probe(prm, trks[0], 3)
+            sp = sum(ops.stream_probe(prm, trks[i % nsets], 5) for i in range(2)) / 10.0 * 1e3      # 10 launches over both buffer sets, us per launch
+            box = {"stream_probe_us": round(sp, 2), "stream_probe_GBps": round(algo / sp / 1e3, 1), "kernel_over_stream": round(launch_s * 1e6 / sp, 3),
+                   "class": "fast-stream" if algo / sp / 1e3 >= 5600.0 else "slow-stream",
+                   "what": "lgpu_debug_stream_probe: the launch's algorithmic bytes (every source / layer-2 byte read once, every result byte written once, 16-byte non-temporal accesses, no arithmetic)"}
+        except Exception as e:      # noqa: BLE001 -- a measurement aid, never fatal
+            box = {"error": str(e)}
     roof = {"bound": "hbm", "kernel": pixbuf_kernel_name(args) if args.resize_backend == "pixbuf" else "lgpu::k_half8s<0,0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2)}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": algo, "launch_us": round(launch_s * 1e6, 2), "box_class": box}
 
     out = None
     if rank == 0:
@@ -232,13 +288,20 @@ def main():
                        "resize_backend": args.resize_backend,
                        "tracks_per_gpu": T, "frames_per_step": world * T, "inputs": "HBM-resident", "parallelism": "track-per-gpu x%d" % world,
                        "param_exchange": ("none (one GPU: the kernel reads step s of the resident schedule)" if not multi else
-                                          "lgpu_chain_step (C): lgpu_params_set + lgpu_params_broadcast (RCCL) on a side stream, one step ahead of the kernel" if comm is not None else
+                                          "lgpu_stepper_feed + lgpu_chain_step (C): the blocks of 16 steps per lgpu_params_set_n + ncclBroadcast on a side stream, ahead of the kernels that read them" if comm is not None else
                                           "torch.distributed broadcast (fallback)"),
                        "launches_per_step": 2 if (args.blur and args.resize_backend != "pixbuf") else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
             "roofline": roof,
         }
+        if batch8:
+            out["config"].update(batch8)
         if config5:
             out["config"].update(config5)
+            if batch8:       # what 8 GPUs with one frame each would make of the 8-track batch that one GPU runs as one launch
+                out["config"]["projected_batch8_speedup"] = round(batch8["batch8_1gpu_us_per_step"] / (config5["config5_ms_per_step"] * 1e3), 2)
+        if world > 1:
+            out["config"]["rccl_ranks"] = world if comm is not None else 0
+            out["config"]["rccl_preflight"] = rccl_preflight if rccl_preflight is not None else "not run (librccl could not be bound on every rank)"
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.blur, args.resize_backend == "pixbuf")
     if comm is not None:
@@ -274,13 +337,14 @@ def dry_run(args, rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
     mine = ld.shard_tracks(world * args.tracks, rank, world)
+    pf = ld.preflight(ld.TorchComm(), "cpu") if world > 1 else "ok"          # the preflight's plumbing (verdict shared by every rank) on gloo; the C stepper part needs a GPU
     dt = ld.max_over_ranks(1e-3 * (rank + 1), "cpu")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "effect-chain frames/sec at 3840x2160 RGBA32", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "tracks_of_rank0": mine, "max_over_ranks_s": dt}))
+                          "tracks_of_rank0": mine, "max_over_ranks_s": dt, "rccl_preflight": pf}))
 
 
 def pixbuf_kernel_name(args):

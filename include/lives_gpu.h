@@ -400,6 +400,11 @@ int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas
 int lgpu_chain_timed(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks,
                      int reps, float *ms_total, void *stream);
 
+/* measurement hook (bench.py: roofline.box_class): the chain's own algorithmic bytes as a bare stream on the same frames -- every source and layer-2 byte read once
+   (16-byte non-temporal loads), every destination byte written once (non-temporal stores), no arithmetic, no re-reads; HIP events on `stream` around `reps` launches.
+   Compact frames only; the destination frames are left dirty. */
+int lgpu_debug_stream_probe(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks, int reps, float *ms_total, void *stream);
+
 /* ---- multi-GPU exchange: one process per GPU, tracks sharded track t -> rank t % world, no data-path collective.  What the
    ranks exchange goes over RCCL (xGMI), bound at run time (dlopen of librccl.so.1: no link-time dependency, a single-GPU host never loads
    it).  The communicator is RCCL's own: rank 0 makes the id, the host ships its 128 bytes to the other ranks by whatever channel it has,
@@ -419,14 +424,24 @@ int lgpu_fan_in(void *comm, int root, int rank, int world, int ntracks, const ui
 
 /* the control rank's write of the block (four host values as kernel arguments: one tiny launch, no host -> device copy) */
 int lgpu_params_set(int32_t *param_block_d, const int32_t values[4], void *stream);
-/* ---- one step of the batch from C (north_star "host code stays C"): the chain over this rank's tracks with the step's parameter block, while the
-   block of the NEXT step is exchanged on a side stream (a ring of 16 device blocks, one event each; the launch stream never waits for xGMI, the host never synchronises).
-   comm == NULL: one GPU, nothing to exchange -- the block is written on the launch stream.  tools/worker.c is the render-worker loop on top of it. */
+/* the same for nblocks consecutive blocks: one launch / one ncclBroadcast of nblocks x 16 bytes */
+int lgpu_params_set_n(int32_t *param_blocks_d, const int32_t *values, int nblocks, void *stream);
+int lgpu_params_broadcast_n(void *comm, int root, int32_t *param_blocks_d, int nblocks, void *stream);
+/* ---- one step of the batch from C (north_star "host code stays C"): the chain over this rank's tracks with the step's parameter block; the blocks
+   travel AHEAD of the kernels on a side stream into a ring of 64 device blocks (the launch stream never waits for xGMI, the host never synchronises).
+   lgpu_stepper_feed hands over the blocks of the next n steps in ONE exchange (root: one tiny launch + one ncclBroadcast of n x 16 bytes; every rank calls it with
+   the same n; values = n x 4 ints, read on the root only): a render knows its schedule ahead, and a live parameter is one feed of latency either way -- per step
+   the host then pays the chain launch and 1 / n of an exchange.  lgpu_chain_step with next_values != NULL is the one-block-ahead form of the same thing.
+   comm == NULL: one GPU, nothing to exchange -- the blocks are written on the launch stream.  tools/worker.c is the render-worker loop on top of it.
+   Errors: LGPU_E_BADARG from argument checks leaves the stepper untouched (repeat the call); any other error leaves this rank out of step with its peers -- every
+   later call fails, destroy the stepper. */
 typedef struct lgpu_stepper lgpu_stepper;
 int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, const int32_t first_values[4], lgpu_stepper **out);
-/* next_values: the block of the following step (read on the root only), NULL on every rank for the last step.  params->param_block_d is replaced by the stepper's block. */
+int lgpu_stepper_feed(lgpu_stepper *s, const int32_t *values, int n);
+/* next_values: the block of the following step (read on the root only) when no feed has brought it yet; NULL on every rank after the last step or when
+   lgpu_stepper_feed is used.  params->param_block_d is replaced by the stepper's block. */
 int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks);
-const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 16 (tests) */
+const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 64 (tests); NULL for a negative index */
 int lgpu_stepper_destroy(lgpu_stepper *s);
 
 /* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),

@@ -134,76 +134,121 @@ int lgpu_fan_in(void *comm, int root, int rank, int world, int ntracks, const ui
 }
 
 
+// the same for `nblocks` consecutive blocks in one exchange (the schedule of a render is known ahead: lgpu_stepper_feed)
+int lgpu_params_broadcast_n(void *comm, int root, int32_t *param_blocks_d, int nblocks, void *stream) {
+  if (!comm || !param_blocks_d || nblocks < 1) { lgpu::set_error("lgpu_params_broadcast_n: bad argument"); return LGPU_E_BADARG; }
+  if (!g_r.h) return LGPU_E_BADARG;
+  return check(g_r.Broadcast(param_blocks_d, param_blocks_d, 4 * (size_t)nblocks, ncclInt32, root, (ncclComm_t)comm, stream), "ncclBroadcast");
+}
+
 // ---- the per-step host path of the multi-GPU batch as ONE C call (north_star: "host code stays C") -------------------------------------------
-// A render worker runs, per frame batch: [parameter block of this batch has arrived] -> chain kernel.  The block of batch s + 1 is broadcast on a
-// side stream while the kernel of batch s runs (two device blocks, one event each), so the launch stream never waits for xGMI and the host never
-// synchronises: lgpu_chain_step = stream wait + event record + (root: one tiny launch) + ncclBroadcast + event record + the chain launch.
-enum { kStepRing = 16, kStepFence = kStepRing / 2 };
+// A render worker runs, per frame batch: [parameter block of this batch has arrived] -> chain kernel.  Blocks travel AHEAD of the kernels that read them, on a
+// side stream, into a ring of 64 device blocks: lgpu_stepper_feed() hands over the blocks of the next n steps (a render knows its schedule; a live parameter
+// is one feed of latency either way) -- on the root one tiny launch that writes them, then ONE ncclBroadcast of n x 16 bytes, one event.  lgpu_chain_step()
+// = [stream wait on the feed that brought this step's block, the first time a step of that feed comes up] + the chain launch: per step the host pays the
+// launch and 1 / n of an exchange; the launch stream never waits for xGMI and the host never synchronises.  lgpu_chain_step with next_values is the n = 1 form.
+enum { kStepRing = 64 };
 struct lgpu_stepper {
-  void *comm;                 // RCCL communicator, or NULL: one GPU, nothing to exchange (the block is written on the launch stream)
+  void *comm;                 // RCCL communicator, or NULL: one GPU, nothing to exchange (blocks are written on the launch stream)
   int root, rank;
   void *launch, *side;        // hipStream_t
-  void *ready[kStepRing], *tail;      // events: block s % ring has arrived / the launch stream's tail at the last fence
-  int32_t *blk[kStepRing];
-  long step;
+  void *ev[kStepRing];        // event of feed f at ev[f % ring] (a ring slot holds at most one unconsumed feed: feeds carry >= 1 block each and <= ring blocks are unconsumed)
+  void *tail;                 // the launch stream's tail at the last fence
+  int32_t *blk;               // ring of kStepRing blocks
+  long fed, step, feeds;      // blocks handed over / consumed by a launch, feeds so far
+  long feed_of[kStepRing];    // which feed brought the block in ring slot i
+  long waited;                // the newest feed the launch stream has been ordered behind
+  long fenced;                // every launch of a step < fenced is ordered before what the side stream does next
+  int failed;                 // a step or feed failed half way: the stepper is out of step with its peers and refuses further calls
 };
 
-// The exchange of step `step` on the side stream.  Its block, ring slot step % 16, was last read by the kernel of step - 16; every 8th step the side stream is
-// ordered behind the launch stream's tail (which then has passed the kernel of step - 2 at least), so the slot is free when it is rewritten, and the two
-// cross-stream calls of that ordering are paid once per 8 steps instead of every step (they cost more host time than the rest of the step together when every
-// launch sits behind a fresh cross-stream barrier: tools/worker.c, profiles/r03/worker_step.md).
-static int stepper_prefetch(lgpu_stepper *s, long step, const int32_t values[4]) {
-  int rc;
-  int32_t *b = s->blk[step % kStepRing];
-  if (!s->comm) return lgpu_params_set(b, values, s->launch);            // stream order does the rest
-  if (step % kStepFence == 0 && ((rc = lgpu_event_record(s->tail, s->launch)) || (rc = lgpu_stream_wait_event(s->side, s->tail)))) return rc;
-  if (s->rank == s->root && (rc = lgpu_params_set(b, values, s->side))) return rc;
-  if ((rc = lgpu_params_broadcast(s->comm, s->root, b, s->side))) return rc;
-  return lgpu_event_record(s->ready[step % kStepRing], s->side);
+// n >= 1 blocks for steps fed .. fed + n - 1 (values: n x 4 ints, read on the root only; NULL elsewhere is fine).  Every rank calls it with the same n.
+int lgpu_stepper_feed(lgpu_stepper *s, const int32_t *values, int n) {
+  if (!s || n < 1 || n > kStepRing) { lgpu::set_error("lgpu_stepper_feed: bad arguments"); return LGPU_E_BADARG; }
+  if (s->failed) { lgpu::set_error("lgpu_stepper_feed: an earlier call failed half way; the stepper is out of step with its peers: destroy it"); return LGPU_E_BADARG; }
+  if (s->fed + n - s->step > kStepRing) { lgpu::set_error("lgpu_stepper_feed: %ld blocks are waiting for their steps; the ring holds %d", s->fed - s->step, (int)kStepRing); return LGPU_E_BADARG; }
+  const bool is_root = s->rank == s->root;
+  if (is_root && !values) { lgpu::set_error("lgpu_stepper_feed: the root needs values"); return LGPU_E_BADARG; }
+  int rc = LGPU_OK;
+  void *st = s->comm ? s->side : s->launch;
+  // the ring slots of blocks fed .. fed + n - 1 were last read by the kernels of steps fed - ring .. fed + n - 1 - ring: the side stream must be behind them.  A fence
+  // orders it behind EVERY launch made so far, so one is due only about once per ring (two host calls, paid every ~60 steps instead of every step)
+  if (s->comm && s->fenced < s->fed + n - kStepRing) {
+    if ((rc = lgpu_event_record(s->tail, s->launch)) || (rc = lgpu_stream_wait_event(s->side, s->tail))) return rc;        // nothing has changed yet: the call can be repeated
+    s->fenced = s->step;
+  }
+  for (int done = 0; done < n && !rc;) {        // at most two contiguous runs (the ring wraps)
+    const long first = s->fed + done;
+    const int slot = (int)(first % kStepRing), run = n - done < kStepRing - slot ? n - done : kStepRing - slot;
+    if (is_root) rc = lgpu_params_set_n(s->blk + 4 * slot, values + 4 * done, run, st);
+    if (!rc && s->comm) rc = lgpu_params_broadcast_n(s->comm, s->root, s->blk + 4 * slot, run, st);
+    done += run;
+  }
+  if (!rc && s->comm) rc = lgpu_event_record(s->ev[s->feeds % kStepRing], s->side);
+  if (rc) { s->failed = 1; return rc; }          // part of the exchange may be enqueued: this rank can no longer stay in step
+  for (int i = 0; i < n; i++) s->feed_of[(s->fed + i) % kStepRing] = s->feeds;
+  s->fed += n;
+  s->feeds++;
+  return LGPU_OK;
 }
 
 int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, const int32_t first_values[4], lgpu_stepper **out) {
-  if (!out || !first_values || root < 0 || rank < 0) { lgpu::set_error("lgpu_stepper_create: bad arguments"); return LGPU_E_BADARG; }
+  if (!out || root < 0 || rank < 0) { lgpu::set_error("lgpu_stepper_create: bad arguments"); return LGPU_E_BADARG; }
+  if (rank == root && !first_values) { lgpu::set_error("lgpu_stepper_create: the root needs the first block"); return LGPU_E_BADARG; }
   lgpu_stepper *s = new lgpu_stepper();
-  s->comm = comm; s->root = root; s->rank = rank; s->launch = launch_stream; s->step = 0;
+  memset(s, 0, sizeof *s);
+  s->comm = comm; s->root = root; s->rank = rank; s->launch = launch_stream; s->waited = -1;
   int rc = LGPU_OK;
   void *p = nullptr;
   if ((rc = lgpu_malloc(&p, kStepRing * 4 * sizeof(int32_t)))) { delete s; return rc; }
-  for (int i = 0; i < kStepRing; i++) s->blk[i] = (int32_t *)p + 4 * i;
+  s->blk = (int32_t *)p;
   if (comm) {
     if (!rc) rc = lgpu_stream_create(&s->side, 1);
-    for (int i = 0; i < kStepRing && !rc; i++) rc = lgpu_event_create(&s->ready[i]);
+    for (int i = 0; i < kStepRing && !rc; i++) rc = lgpu_event_create(&s->ev[i]);
     if (!rc) rc = lgpu_event_create(&s->tail);
   }
-  if (!rc) rc = stepper_prefetch(s, 0, first_values);
+  if (!rc) rc = lgpu_stepper_feed(s, first_values, 1);
   if (rc) { lgpu_stepper_destroy(s); return rc; }
   *out = s;
   return LGPU_OK;
 }
 
-// one batch: the chain over `tracks` with the parameter block of this step (params->param_block_d is ignored: the stepper's block is used), and -- unless this
-// is the last step (next_values == NULL on every rank) -- the exchange of the next step's block enqueued beside it.  next_values matters on the root only.
+// one batch: the chain over `tracks` with the parameter block of this step (params->param_block_d is ignored: the stepper's block is used).  next_values != NULL:
+// the block of the following step is fed first (the one-block-ahead form; NULL on every rank when the blocks come through lgpu_stepper_feed or after the last step;
+// the values matter on the root only).  Arguments are checked BEFORE anything is enqueued: a call that returns LGPU_E_BADARG has changed nothing and may be repeated.
 int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks) {
-  if (!s || !params) { lgpu::set_error("lgpu_chain_step: null argument"); return LGPU_E_BADARG; }
+  if (!s || !params || !tracks || ntracks < 1 || ntracks > LGPU_CHAIN_MAX_TRACKS) { lgpu::set_error("lgpu_chain_step: bad arguments"); return LGPU_E_BADARG; }
+  if (s->failed) { lgpu::set_error("lgpu_chain_step: an earlier call failed half way; the stepper is out of step with its peers: destroy it"); return LGPU_E_BADARG; }
+  if (params->sw <= 0 || params->sh <= 0 || params->dw <= 0 || params->dh <= 0 || params->irow < params->sw * 4 || params->orow < params->dw * 4 ||
+      params->irow2 < params->dw * 4 || ((params->irow | params->orow | params->irow2) & 3)) { lgpu::set_error("lgpu_chain_step: bad geometry"); return LGPU_E_BADARG; }
+  for (int i = 0; i < ntracks; i++)
+    if (!tracks[i].src_d || !tracks[i].layer2_d || !tracks[i].dst_d) { lgpu::set_error("lgpu_chain_step: null track pointer"); return LGPU_E_BADARG; }
+  if (s->step >= s->fed) { lgpu::set_error("lgpu_chain_step: no parameter block has been fed for step %ld", s->step); return LGPU_E_BADARG; }
   static const int32_t zero[4] = {0, 0, 0, 0};
   int rc;
-  if (s->comm && (rc = lgpu_stream_wait_event(s->launch, s->ready[s->step % kStepRing]))) return rc;
-  if (next_values && (rc = stepper_prefetch(s, s->step + 1, s->rank == s->root ? next_values : zero))) return rc;
+  if (next_values && s->fed == s->step + 1 && (rc = lgpu_stepper_feed(s, s->rank == s->root ? next_values : zero, 1))) return rc;
+  const long f = s->feed_of[s->step % kStepRing];
+  if (s->comm && f > s->waited) {
+    if ((rc = lgpu_stream_wait_event(s->launch, s->ev[f % kStepRing]))) { s->failed = 1; return rc; }
+    s->waited = f;
+  }
   lgpu_chain_params p = *params;
-  p.param_block_d = s->blk[s->step % kStepRing];
+  p.param_block_d = s->blk + 4 * (s->step % kStepRing);
+  rc = lgpu_chain(&p, tracks, ntracks, s->launch);
+  if (rc) { s->failed = 1; return rc; }          // the exchange for this step has happened on every rank; this rank's launch has not
   s->step++;
-  return lgpu_chain(&p, tracks, ntracks, s->launch);
+  return LGPU_OK;
 }
 
-const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which) { return s ? s->blk[which % kStepRing] : nullptr; }
+const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which) { return (s && which >= 0) ? s->blk + 4 * (which % kStepRing) : nullptr; }
 
 int lgpu_stepper_destroy(lgpu_stepper *s) {
   if (!s) return LGPU_OK;
-  if (s->launch || true) lgpu_sync(s->launch);
+  lgpu_sync(s->launch);
   if (s->side) { lgpu_sync(s->side); lgpu_stream_destroy(s->side); }
-  for (int i = 0; i < kStepRing; i++) if (s->ready[i]) lgpu_event_destroy(s->ready[i]);
+  for (int i = 0; i < kStepRing; i++) if (s->ev[i]) lgpu_event_destroy(s->ev[i]);
   if (s->tail) lgpu_event_destroy(s->tail);
-  if (s->blk[0]) lgpu_free(s->blk[0]);
+  if (s->blk) lgpu_free(s->blk);
   delete s;
   return LGPU_OK;
 }

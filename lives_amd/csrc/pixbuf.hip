@@ -1614,6 +1614,45 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
 
 using namespace lgpu;
 
+// measurement hook (bench.py's roofline.box_class): the chain's own ALGORITHMIC bytes as a bare stream -- every source and layer-2 byte of the tracks read once with
+// 16-byte loads, every destination byte written once with non-temporal 16-byte stores (an XOR fold of what was read, so nothing can be elided) -- timed with HIP events
+// on `stream` around `reps` launches.  What this box's memory system gives this read : write mix with no arithmetic and no re-reads; the destinations are left dirty.
+__global__ __launch_bounds__(256) void k_chain_stream_probe(const PbTracks T, int ntracks, unsigned src_q, unsigned dst_q) {      // sizes in 16-byte quads per track
+  const unsigned per = dst_q, nthreads = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int t = 0; t < ntracks; t++) {
+    const pb_u4 *s = reinterpret_cast<const pb_u4 *>(T.src[t]), *l = reinterpret_cast<const pb_u4 *>(T.l2[t]);
+    pb_u4 *d = reinterpret_cast<pb_u4 *>(T.dst[t]);
+    for (unsigned i = tid; i < per; i += nthreads) {
+      pb_u4 a = __builtin_nontemporal_load(l + i);
+      const unsigned n = src_q / dst_q;          // 4 source quads per destination quad at 2:1
+      for (unsigned j = 0; j < n; j++) { const pb_u4 b = __builtin_nontemporal_load(s + (size_t)j * per + i); a.x ^= b.x; a.y ^= b.y; a.z ^= b.z; a.w ^= b.w; }
+      __builtin_nontemporal_store(a, d + i);
+    }
+  }
+}
+extern "C" int lgpu_debug_stream_probe(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, int reps, float *ms_total, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(pr && tracks && ms_total && reps > 0 && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "bad arguments");
+  const size_t sb = (size_t)pr->irow * pr->sh, db = (size_t)pr->orow * pr->dh;
+  LGPU_REQUIRE(pr->irow == pr->sw * 4 && pr->orow == pr->dw * 4 && pr->irow2 == pr->orow && db % 16 == 0 && sb % db == 0, "compact frames whose source is a whole multiple of the destination");
+  PbTracks T;
+  for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  LGPU_HIP(hipEventCreate(&e0));
+  LGPU_HIP(hipEventCreate(&e1));
+  LGPU_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_chain_stream_probe, dim3((unsigned)device_cus() * 8u), dim3(256), 0, st, T, ntracks, (unsigned)(sb / 16), (unsigned)(db / 16));
+  LGPU_HIP(hipEventRecord(e1, st));
+  LGPU_HIP(hipEventSynchronize(e1));
+  LGPU_HIP(hipEventElapsedTime(ms_total, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
 // test hook: how many integers a of [lo, hi) give pb_recip(a) != 1.0 / (double)a on the device (0 for the whole 24-bit range, tests/test_pixbuf_scale.py)
 extern "C" int lgpu_debug_recip_check(uint32_t lo, uint32_t hi, unsigned long long *mismatches) {
   int rc = ensure_init();

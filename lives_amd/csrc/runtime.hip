@@ -365,6 +365,8 @@ int lgpu_copy_rows(void *dst_d, int orow, const void *src_d, int irow, int row_b
 
 namespace lgpu {
 struct Pat8 { uint8_t b[8]; };
+struct Set64 { int32_t w[64]; };
+__global__ void k_set64(int32_t *dst, const Set64 v, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = v.w[threadIdx.x]; }
 __global__ void k_set4(int32_t *blk, int32_t a, int32_t b, int32_t c, int32_t d) { if (threadIdx.x == 0) { blk[0] = a; blk[1] = b; blk[2] = c; blk[3] = d; } }
 __global__ __launch_bounds__(kBlock) void k_fill_pattern(uint8_t *dst, int rowstride, Pat8 pat, int plen, int nbytes, int rows) {
   const int x = blockIdx.x * kBlock + threadIdx.x;            // byte within the row
@@ -397,6 +399,21 @@ int lgpu_sync(void *stream) {
 
 // the control rank writes the shared transition parameter block (int32[4], device memory) from four host values: they travel as kernel arguments, so
 // the call costs one launch and no host -> device copy (a 16-byte hipMemcpyAsync from pageable memory stages and blocks)
+int lgpu_params_set_n(int32_t *param_blocks_d, const int32_t *values, int nblocks, void *stream) {
+  int rc = lgpu::ensure_init();
+  if (rc) return rc;
+  if (!param_blocks_d || !values || nblocks < 1) { lgpu::set_error("lgpu_params_set_n: bad argument"); return LGPU_E_BADARG; }
+  for (int i = 0; i < nblocks; i += 16) {        // up to 16 blocks (256 bytes) per launch, as kernel arguments
+    lgpu::Set64 v;
+    const int n = nblocks - i < 16 ? nblocks - i : 16;
+    memset(&v, 0, sizeof v);
+    memcpy(v.w, values + 4 * i, (size_t)n * 16);
+    hipLaunchKernelGGL(lgpu::k_set64, dim3(1), dim3(64), 0, (hipStream_t)stream, param_blocks_d + 4 * i, v, 4 * n);
+    LGPU_CHECK_LAUNCH();
+  }
+  return LGPU_OK;
+}
+
 int lgpu_params_set(int32_t *param_block_d, const int32_t values[4], void *stream) {
   int rc = lgpu::ensure_init();
   if (rc) return rc;

@@ -97,6 +97,15 @@ class Stepper:
             nv = self._vals
         self.lib.call("lgpu_chain_step", self.h, nv, self.ct.byref(params), tracks, len(tracks))
 
+    def feed(self, rows):
+        """lgpu_stepper_feed: the blocks of the next len(rows) steps in one exchange (rows: lists of up to 4 ints; read on the root only)"""
+        n = len(rows)
+        flat = (self.ct.c_int32 * (4 * n))()
+        for i, r in enumerate(rows):
+            for j in range(min(4, len(r))):
+                flat[4 * i + j] = int(r[j])
+        self.lib.call("lgpu_stepper_feed", self.h, flat, n)
+
     def block_ptr(self, which):
         return self.lib.load().lgpu_stepper_block(self.h, which)
 
@@ -158,6 +167,118 @@ class ParamPipeline:
                 w.wait()
             self.pending[s & 1] = None
         return self.blocks[s & 1]
+
+
+class TorchComm:
+    """the same three exchanges on torch.distributed (gloo on CPU boxes): what preflight() runs on when there is no GPU, and the shape of the fallback"""
+
+    def __init__(self):
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def broadcast_params(self, block, root=0, stream=None):
+        if self.world > 1:
+            dist.broadcast(block, src=root)
+
+    def status_max(self, status, stream=None):
+        if self.world > 1:
+            dist.all_reduce(status, op=dist.ReduceOp.MAX)
+
+    def fan_in(self, frames, ntracks, frame_bytes, gathered, root=0, stream=None):
+        mine = shard_tracks(ntracks, self.rank, self.world)
+        got = fan_in([frames[i * frame_bytes:(i + 1) * frame_bytes] for i in range(len(mine))], ntracks, dst=root)
+        if got is not None and gathered is not None:
+            for t, f in enumerate(got):
+                gathered[t * frame_bytes:(t + 1) * frame_bytes] = f
+
+    def close(self):
+        pass
+
+
+def preflight(comm, device="cuda", ops=None, steps=20):
+    """The exchanges of the path with the ranks of THIS job, before anything is timed (bench.py, N > 1): the parameter block from the root arrives on every rank,
+    the status word is the maximum over the ranks, lgpu_fan_in puts 2 * world + 1 tracks into track order on the root, and -- with a GPU (`ops`) -- `steps` steps of the
+    C stepper use the ROOT's value on every rank (oracle-free: each step's output equals a plain lgpu_chain launch of the same frame with that value).
+    The ranks agree on a verdict after EVERY stage (through torch.distributed, not through the communicator under test), so a rank that fails a check never leaves
+    the others inside the next collective.  Every rank returns the same string: "ok", or "failed: rank r: <reason>" for the lowest failing rank of the first
+    failing stage.  A rank that hangs inside RCCL is not caught."""
+    rank, world = comm.rank, comm.world
+
+    def stage_broadcast():
+        blk = torch.tensor([123 + world, 45, 6, 7] if rank == 0 else [0, 0, 0, 0], dtype=torch.int32, device=device)
+        comm.broadcast_params(blk, root=0)
+        if blk.cpu().tolist() != [123 + world, 45, 6, 7]:
+            raise RuntimeError("broadcast: rank %d holds %s" % (rank, blk.cpu().tolist()))
+
+    def stage_status():
+        st = torch.tensor([rank + 1], dtype=torch.int32, device=device)
+        comm.status_max(st)
+        if int(st.cpu().item()) != world:
+            raise RuntimeError("status word: %d instead of %d" % (int(st.cpu().item()), world))
+
+    def stage_fan_in():
+        ntracks, fb = 2 * world + 1, 4096
+        mine = shard_tracks(ntracks, rank, world)
+        frames = torch.cat([torch.full((fb,), (t + 1) & 255, dtype=torch.uint8, device=device) for t in mine])
+        gathered = torch.zeros(ntracks * fb, dtype=torch.uint8, device=device) if rank == 0 else None
+        comm.fan_in(frames, ntracks, fb, gathered, root=0)
+        if rank == 0:
+            g = gathered.cpu().view(ntracks, fb)
+            for t in range(ntracks):
+                if not bool((g[t] == ((t + 1) & 255)).all()):
+                    raise RuntimeError("fan-in: slot %d holds track %d" % (t, int(g[t, 0]) - 1))
+
+    def stage_stepper():
+        g_ = torch.Generator(device=device)
+        g_.manual_seed(0x2C1 + rank)
+        sw, sh, dw, dh = 256, 144, 128, 72
+        src = torch.randint(0, 256, (sh, sw * 4), dtype=torch.uint8, device=device, generator=g_)
+        l2 = torch.randint(0, 256, (dh, dw * 4), dtype=torch.uint8, device=device, generator=g_)
+        schedule = [(37 * s + 11) & 255 for s in range(steps)]                 # the same list on every rank; only the root hands it to the stepper
+        outs = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device=device) for _ in schedule]
+        prm = ops.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | 0x100, do_blur=0, bf=1, lut=None)
+        stp = Stepper(comm, [schedule[0]] if rank == 0 else [0])
+        try:
+            fed = 1
+            for s in range(steps):
+                if fed == s + 1 and fed < steps:             # blocks of up to 8 steps per exchange
+                    rows = [[v if rank == 0 else 0, 0, 0, 0] for v in schedule[fed:fed + 8]]
+                    stp.feed(rows)
+                    fed += len(rows)
+                stp.step(None, prm, ops.chain_tracks([src], [l2], [outs[s]]))
+            torch.cuda.synchronize()
+        finally:
+            stp.close()
+        ref = torch.zeros((dh, dw * 4), dtype=torch.uint8, device=device)
+        for s, bf in enumerate(schedule):
+            p2 = ops.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | 0x100, do_blur=0, bf=bf, lut=None)
+            ops.chain(p2, ops.chain_tracks([src], [l2], [ref]))
+            torch.cuda.synchronize()
+            if not torch.equal(ref, outs[s]):
+                raise RuntimeError("stepper: step %d did not blend with the root's amount %d" % (s, bf))
+
+    def agree(why):          # one verdict for all
+        if not (dist.is_initialized() and world > 1):
+            return "failed: rank 0: " + why if why else None
+        bad = torch.tensor([rank if why else world], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.MIN)
+        first = int(bad.item())
+        if first >= world:
+            return None
+        msg = [why if rank == first else None]
+        dist.broadcast_object_list(msg, src=first)
+        return "failed: rank %d: %s" % (first, msg[0])
+
+    for stage in [stage_broadcast, stage_status, stage_fan_in] + ([stage_stepper] if ops is not None else []):
+        why = ""
+        try:
+            stage()
+        except Exception as e:          # noqa: BLE001 -- whatever went wrong, the job goes on without the C exchange and says so
+            why = "%s: %s" % (type(e).__name__, e)
+        verdict = agree(why)
+        if verdict:
+            return verdict
+    return "ok"
 
 
 def max_over_ranks(seconds, device):

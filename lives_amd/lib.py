@@ -84,6 +84,9 @@ PROTOTYPES = {
     "lgpu_params_set": [vp, vp, vp],
     "lgpu_stepper_create": [vp, ci, ci, vp, vp, ctypes.POINTER(vp)],
     "lgpu_chain_step": [vp, vp, vp, vp, ci],
+    "lgpu_stepper_feed": [vp, vp, ci],
+    "lgpu_params_set_n": [vp, vp, ci, vp],
+    "lgpu_params_broadcast_n": [vp, ci, vp, ci, vp],
     "lgpu_stepper_block": [vp, ci],
     "lgpu_stepper_destroy": [vp],
     "lgpu_copy_rows": [vp, ci, vp, ci, ci, ci, vp],
@@ -99,6 +102,7 @@ PROTOTYPES = {
     "lgpu_tuning_set": [ctypes.c_char_p, ci],
     "lgpu_tuning_get": [ctypes.c_char_p],
     "lgpu_debug_recip_check": [ctypes.c_uint32, ctypes.c_uint32, vp],
+    "lgpu_debug_stream_probe": [vp, vp, ci, ci, vp, vp],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
     "lgpu_alpha_scalers": [vp, vp],

@@ -344,6 +344,13 @@ def chain_canvas(params, tracks, nwidth, nheight, offs_x, offs_y):
     lib.call("lgpu_chain_canvas", ctypes.byref(params), ctypes.byref(cv), tracks, len(tracks), stream_ptr())
 
 
+def stream_probe(params, tracks, reps):
+    """lgpu_debug_stream_probe: the chain's algorithmic bytes as a bare stream on the same frames, ms for `reps` launches (destinations left dirty)"""
+    ms = ctypes.c_float()
+    lib.call("lgpu_debug_stream_probe", ctypes.byref(params), tracks, len(tracks), reps, ctypes.byref(ms), stream_ptr())
+    return ms.value
+
+
 def chain_timed(params, tracks, reps):
     ms = ctypes.c_float()
     lib.call("lgpu_chain_timed", ctypes.byref(params), tracks, len(tracks), reps, ctypes.byref(ms), stream_ptr())

@@ -5,6 +5,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent('''
@@ -78,6 +80,7 @@ def test_bench_as_the_driver_launches_it_for_8_gpus():
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
     j = json.loads(lines[0])
     assert j["n_gpus"] == 8 and j["dry_run"] is True and j["tracks_of_rank0"] == [0, 8], j
+    assert j["rccl_preflight"] == "ok", j            # the preflight's own plumbing (broadcast, status word, fan-in of 17 tracks over 8 ranks, one verdict for all) on gloo
 
 
 def test_bench_launches_itself_for_n_gpus():
@@ -93,3 +96,41 @@ def test_bench_launches_itself_for_n_gpus():
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["dry_run"] is True and j["tracks_of_rank0"] == [0] and abs(j["max_over_ranks_s"] - 2e-3) < 1e-9
+
+
+def _preflight_worker(rank, world, port, q, break_it):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from lives_amd import dist as ld
+    comm = ld.TorchComm()
+    if break_it and rank == 1:
+        real = comm.status_max
+        comm.status_max = lambda st, stream=None: (real(st), st.zero_())          # rank 1 takes part in the exchange and then "loses" its result
+    q.put((rank, ld.preflight(comm, "cpu")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_it", [False, True])
+def test_preflight_gives_every_rank_the_same_verdict(break_it):
+    """lives_amd.dist.preflight (what bench.py runs before timing when N > 1) on 2 gloo ranks: "ok" on both, and when one rank's exchange is broken every
+    rank learns which rank failed and why -- the bench then falls back to torch.distributed instead of dying"""
+    import torch.multiprocessing as mp
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_preflight_worker, args=(r, 2, port, q, break_it)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    if break_it:
+        assert got[0] == got[1] and got[0].startswith("failed: rank 1: RuntimeError: status word"), got
+    else:
+        assert got == {0: "ok", 1: "ok"}, got

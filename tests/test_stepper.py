@@ -10,31 +10,71 @@ P = po.P
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("ahead", [1, 5, 16])
 @pytest.mark.parametrize("exchange", [0, 1])
-def test_steps_use_the_block_of_their_own_step(gpu, orc, exchange):
+def test_steps_use_the_block_of_their_own_step(gpu, orc, exchange, ahead):
     import torch
     from lives_amd import dist as ld
     rng = np.random.default_rng(0x57E9 + exchange)
     sw, sh, dw, dh = 256, 144, 128, 72
     srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(2)]
     l2s = [rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8) for _ in range(2)]
-    schedule = [17, 200, 0, 255, 96, 131, 64] + [int(v) for v in rng.integers(0, 256, 38)]      # 45 steps: the 16-slot block ring wraps twice, 5 fences
+    schedule = [17, 200, 0, 255, 96, 131, 64] + [int(v) for v in rng.integers(0, 256, 143)]      # 150 steps: the 64-slot block ring wraps twice, with fences
+    # ahead == 1: one block ahead through lgpu_chain_step's next_values; otherwise lgpu_stepper_feed hands over the blocks of the next `ahead` steps in one exchange
     comm = ld.RcclComm("cuda") if exchange else None
     d_srcs, d_l2s = [dev(s) for s in srcs], [dev(s) for s in l2s]
-    outs = [[dev(np.zeros((dh, dw * 4), np.uint8)) for _ in range(2)] for _ in schedule]
+    outs = [[dev(np.zeros((dh, dw * 4), np.uint8)) for _ in range(2)] for _ in range(32)]
+    wants = {}
+    for bf in set(schedule):
+        for i in range(2):
+            w_ = np.zeros((dh, dw * 4), np.uint8)
+            assert orc.orc_chain(P(srcs[i]), sw * 4, sw, sh, P(l2s[i]), dw * 4, P(w_), dw * 4, dw, dh, 1, 3, 0, bf, None) == 0
+            wants[(bf, i)] = w_
     prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3, do_blur=0, bf=1, lut=None)      # bf = 1 must never be used
     st = ld.Stepper(comm, [schedule[0]])
     try:
+        fed = 1
         for s, bf in enumerate(schedule):
             nxt = [schedule[s + 1], 0, 0, 0] if s + 1 < len(schedule) else None
-            st.step(nxt, prm, gpu.chain_tracks(d_srcs, d_l2s, outs[s]))
+            if ahead > 1:
+                nxt = None
+                if fed == s + 1 and fed < len(schedule):
+                    rows = [[v, 0, 0, 0] for v in schedule[fed:fed + ahead]]
+                    st.feed(rows)
+                    fed += len(rows)
+            st.step(nxt, prm, gpu.chain_tracks(d_srcs, d_l2s, outs[s % 32]))
+            if s % 32 == 31 or s == len(schedule) - 1:         # compare in groups of 32 steps (the output buffers are reused)
+                torch.cuda.synchronize()
+                for t in range(s - s % 32, s + 1):
+                    for i in range(2):
+                        assert (host(outs[t % 32][i]) == wants[(schedule[t], i)]).all(), "step %d (blend amount %d) track %d" % (t, schedule[t], i)
         torch.cuda.synchronize()
     finally:
         st.close()
         if comm is not None:
             comm.close()
-    for s, bf in enumerate(schedule):
-        for i in range(2):
-            want = np.zeros((dh, dw * 4), np.uint8)
-            assert orc.orc_chain(P(srcs[i]), sw * 4, sw, sh, P(l2s[i]), dw * 4, P(want), dw * 4, dw, dh, 1, 3, 0, bf, None) == 0
-            assert (host(outs[s][i]) == want).all(), "step %d (blend amount %d) track %d" % (s, bf, i)
+
+
+def test_stepper_refuses_what_would_put_it_out_of_step(gpu):
+    """argument errors are found before anything is enqueued (the call can be repeated); a step without a block, a feed beyond the ring and a negative ring index are refused"""
+    import ctypes
+    from lives_amd import dist as ld, lib
+    L = lib.load()
+    rng = np.random.default_rng(5)
+    sw, sh, dw, dh = 64, 32, 32, 16
+    d_src, d_l2, d_out = dev(rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)), dev(rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8)), dev(np.zeros((dh, dw * 4), np.uint8))
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=0, interp=3, do_blur=0, bf=1, lut=None)
+    trk = gpu.chain_tracks([d_src], [d_l2], [d_out])
+    st = ld.Stepper(None, [10])
+    try:
+        assert L.lgpu_stepper_block(st.h, -1) is None
+        bad = gpu.chain_params(sw, sh, sw * 4 - 4, dw, dh, dw * 4, dw * 4, swap_rb=0, interp=3, do_blur=0, bf=1, lut=None)      # rowstride smaller than a row
+        assert L.lgpu_chain_step(st.h, None, ctypes.byref(bad), trk, 1) == -2          # LGPU_E_BADARG, nothing changed ...
+        st.step(None, prm, trk)                                                          # ... so the same step goes through afterwards
+        assert L.lgpu_chain_step(st.h, None, ctypes.byref(prm), trk, 1) == -2          # no block for step 1
+        st.feed([[v] for v in range(64)])                                                # a whole ring
+        assert L.lgpu_stepper_feed(st.h, (ctypes.c_int32 * 4)(), 1) == -2               # one more does not fit
+        for _ in range(64):
+            st.step(None, prm, trk)
+    finally:
+        st.close()
