@@ -311,7 +311,10 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # librccl prints its version banner through C stdio, which a pipe buffers until exit: out with it BEFORE the one JSON line
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def self_launch(n):
