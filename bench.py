@@ -304,6 +304,8 @@ def main():
             out["config"]["rccl_preflight"] = rccl_preflight if rccl_preflight is not None else "not run (librccl could not be bound on every rank)"
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.blur, args.resize_backend == "pixbuf")
+    import ctypes
+    ctypes.CDLL(None).fflush(None)          # every rank: whatever librccl left in C stdio's buffer goes out now, not at exit behind rank 0's line
     if comm is not None:
         if world > 1:
             dist.barrier()
