@@ -150,6 +150,8 @@ int lgpu_yuv420_tuning(int cell_columns, int block, int groups_per_cu);
    current value, -1 when unset or unknown. */
 int lgpu_tuning_set(const char *name, int value);
 int lgpu_tuning_get(const char *name);
+/* test hook: entries in the scaler's table cache (bounded: LGPU_PB_CACHE_MAX / lgpu_tuning_set("PB_CACHE_MAX", n), default 64; least recently used goes first) */
+int lgpu_debug_pixbuf_cache_entries(void);
 /* test hook: the scaler's five-operation reciprocal (pixbuf.hip: pb_recip) against the IEEE division 1.0 / (double)a for every integer a of [lo, hi), hi <= 2^24;
    *mismatches = how many differ (0 over the whole range: tests/test_pixbuf_scale.py) */
 int lgpu_debug_recip_check(uint32_t lo, uint32_t hi, unsigned long long *mismatches);

@@ -443,8 +443,9 @@ static weed_error_t p_compositor(weed_plant_t *inst, weed_timecode_t tc) {
   weed_plant_t *ochan = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0), *par[7];
   lgpu_comp_layer layers[LGPU_COMP_MAX_LAYERS];
   void *tofree[2 * LGPU_COMP_MAX_LAYERS + 1];
-  int nfree = 0, nin, z, i, owidth, oheight, pal, psize, orow, bg[3], revz, rc = LGPU_OK;
-  uint8_t *dst, *ddst = NULL;
+  const void *rel_in[LGPU_COMP_MAX_LAYERS];        /* resident in planes to release (read) once the work is enqueued */
+  int nfree = 0, nrel = 0, uploaded = 0, nin, z, i, owidth, oheight, pal, psize, orow, bg[3], revz, rc = LGPU_OK;
+  uint8_t *dst, *ddst = NULL, *res_dst = NULL;
   (void)tc;
   if (!fx || !ochan) return WEED_ERROR_FILTER_INVALID;
   fx_enter(fx);
@@ -461,8 +462,8 @@ static weed_error_t p_compositor(weed_plant_t *inst, weed_timecode_t tc) {
   memset(layers, 0, sizeof layers);
   for (z = 0; z < nin && rc == LGPU_OK; z++) {
     weed_plant_t *ic = (weed_plant_t *)g_ptr(inst, WEED_LEAF_IN_CHANNELS, z);
-    const uint8_t *src;
-    int in_width, in_height, irow, out_width, out_height, cutleft = 0, cuttop = 0, interp, srow;
+    const uint8_t *src, *frame_d;
+    int in_width, in_height, full_height, irow, out_width, out_height, cutleft = 0, cuttop = 0, interp, srow;
     double scx, scy;
     void *dsrc = NULL, *dscaled = NULL;
     if (!ic || g_int(ic, WEED_LEAF_DISABLED, 0, WEED_FALSE) == WEED_TRUE) continue;                 /* :192-193 */
@@ -475,6 +476,7 @@ static weed_error_t p_compositor(weed_plant_t *inst, weed_timecode_t tc) {
     if (out_width * out_height < 16) continue;                                                        /* :221 */
     in_width = g_int(ic, WEED_LEAF_WIDTH, 0, 0); in_height = g_int(ic, WEED_LEAF_HEIGHT, 0, 0); irow = g_int(ic, WEED_LEAF_ROWSTRIDES, 0, 0);
     if (in_width <= 0 || in_height <= 0 || irow < in_width * psize) { rc = LGPU_E_BADARG; break; }
+    full_height = in_height;
     if (w_nelems(ic, WEED_LEAF_INNER_SIZE) >= 4) {                                                  /* letterboxed channel: :228-258 */
       const int lbx = g_int(ic, WEED_LEAF_INNER_SIZE, 0, 0), lby = g_int(ic, WEED_LEAF_INNER_SIZE, 1, 0);
       const int lbw = g_int(ic, WEED_LEAF_INNER_SIZE, 2, in_width), lbh = g_int(ic, WEED_LEAF_INNER_SIZE, 3, in_height);
@@ -497,25 +499,43 @@ static weed_error_t p_compositor(weed_plant_t *inst, weed_timecode_t tc) {
     }
     interp = (out_width > in_width || out_height > in_height) ? LIVES_INTERP_BEST : LIVES_INTERP_NORMAL;   /* up_interp HYPER / down_interp BILINEAR, :154-155 */
     srow = (out_width * psize + 3) & ~3;                                                               /* the scaled pixbuf's rowstride */
-    if ((rc = lgpu_malloc_ordered(&dsrc, (size_t)irow * in_height + 16, FXS))) break;
-    tofree[nfree++] = dsrc;
-    if ((rc = lgpu_upload(dsrc, src + (size_t)cuttop * irow, (size_t)irow * in_height, FXS))) break;
+    /* the plane of a pinned layer (lives_gpu_layer_pin) is scaled from where it lives in HBM -- its host bytes are stale by the pinning contract; otherwise the
+       host plane is uploaded */
+    frame_d = (const uint8_t *)lives_gpu_resident_acquire(src, (size_t)irow * full_height, 0);
+    if (frame_d) { rel_in[nrel++] = src; frame_d += (size_t)cuttop * irow; }
+    else {
+      if ((rc = lgpu_malloc_ordered(&dsrc, (size_t)irow * in_height + 16, FXS))) break;
+      tofree[nfree++] = dsrc;
+      if ((rc = lgpu_upload(dsrc, src + (size_t)cuttop * irow, (size_t)irow * in_height, FXS))) break;
+      uploaded = 1;
+      frame_d = (const uint8_t *)dsrc;
+    }
     if ((rc = lgpu_malloc_ordered(&dscaled, (size_t)srow * out_height + 16, FXS))) break;
     tofree[nfree++] = dscaled;
-    if ((rc = lgpu_pixbuf_scale((const uint8_t *)dsrc + (size_t)cutleft * psize, irow, in_width, in_height, (uint8_t *)dscaled, srow, out_width, out_height, psize, interp, FXS))) break;
+    if ((rc = lgpu_pixbuf_scale(frame_d + (size_t)cutleft * psize, irow, in_width, in_height, (uint8_t *)dscaled, srow, out_width, out_height, psize, interp, FXS))) break;
     layers[z].src_d = (const uint8_t *)dscaled; layers[z].irow = srow; layers[z].width = out_width; layers[z].height = out_height;
     layers[z].offs_x = z < (int)w_nelems(par[0], WEED_LEAF_VALUE) ? (int)(g_dbl_at(par[0], WEED_LEAF_VALUE, z, 0.) * (double)owidth) : 0;
     layers[z].offs_y = z < (int)w_nelems(par[1], WEED_LEAF_VALUE) ? (int)(g_dbl_at(par[1], WEED_LEAF_VALUE, z, 0.) * (double)oheight) : 0;
     layers[z].alpha = z < (int)w_nelems(par[4], WEED_LEAF_VALUE) ? g_dbl_at(par[4], WEED_LEAF_VALUE, z, 1.) : 1.;
   }
-  if (rc == LGPU_OK) rc = lgpu_malloc_ordered((void **)&ddst, (size_t)orow * oheight + 16, FXS);
+  /* the out channel: composited into the device copy when its layer is pinned (no download: the device copy IS the plane until lives_gpu_layer_sync()) */
+  if (rc == LGPU_OK) res_dst = (uint8_t *)lives_gpu_resident_acquire(dst, (size_t)orow * oheight, 1);
   if (rc == LGPU_OK) {
-    tofree[nfree++] = ddst;
-    if (orow != owidth * psize) rc = lgpu_upload(ddst, dst, (size_t)orow * oheight, FXS);           /* row padding keeps the host's bytes */
+    if (res_dst) ddst = res_dst;
+    else {
+      rc = lgpu_malloc_ordered((void **)&ddst, (size_t)orow * oheight + 16, FXS);
+      if (rc == LGPU_OK) {
+        tofree[nfree++] = ddst;
+        if (orow != owidth * psize) rc = lgpu_upload(ddst, dst, (size_t)orow * oheight, FXS);           /* row padding keeps the host's bytes */
+      }
+    }
   }
   if (rc == LGPU_OK) rc = lgpu_composite(ddst, orow, owidth, oheight, psize, pal == WEED_PALETTE_BGR24 || pal == WEED_PALETTE_BGRA32, bg, layers, nin, revz, FXS);
-  if (rc == LGPU_OK) rc = lgpu_download(dst, ddst, (size_t)orow * oheight, FXS);
-  if (rc == LGPU_OK) rc = lgpu_sync(FXS);
+  for (i = 0; i < nrel; i++) lives_gpu_resident_release(rel_in[i], 0);
+  if (res_dst) lives_gpu_resident_release(dst, 1);
+  if (rc == LGPU_OK && !res_dst) rc = lgpu_download(dst, ddst, (size_t)orow * oheight, FXS);
+  /* the result has to be home on return unless it lives on the device; uploads out of host planes have to be over either way (the host may reuse them) */
+  if (rc == LGPU_OK && (!res_dst || uploaded)) rc = lgpu_sync(FXS);
   for (i = 0; i < nfree; i++) lgpu_free_ordered(tofree[i], FXS);
   if (rc != LGPU_OK) { fprintf(stderr, "livesgpu_fx: compositor: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
   return WEED_SUCCESS;

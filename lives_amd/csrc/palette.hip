@@ -1445,7 +1445,8 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     if ((rc = lgpu_fill(dst_d[3], 255, (size_t)orow[3] * height, stream))) return rc;                 // :7819
   }
   static const bool no_s = getenv("LGPU_REPACK_NO_S") != nullptr;
-  if (a.kind == lgpu::RK_420_TO_PK && !no_s && (width & 7) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 && (((uintptr_t)src_d[1] | (uintptr_t)src_d[2]) & 3) == 0 &&
+  if (a.kind == lgpu::RK_420_TO_PK && !no_s && (width & 7) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 &&
+      (((uintptr_t)src_d[1] | (uintptr_t)src_d[2] | (uintptr_t)irow[1] | (uintptr_t)irow[2]) & 3) == 0 &&        // dword loads on EVERY chroma row
       (((uintptr_t)dst_d[0] | (uintptr_t)((orow[0] / 4) * 4)) & 15) == 0 && (unsigned long long)(width >> 3) * height < (1ull << 31)) {
     const int ngr = width >> 3;
     const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));

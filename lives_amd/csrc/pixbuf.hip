@@ -1323,11 +1323,54 @@ static void pb_fix_sum(int *w, int count, int total) {
 }
 
 struct PbTable { int n_x, n_y, xoff, yoff, uniform_x; int *table_d; std::vector<int> host;
-                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0, nq = 0; uint32_t *pairs_d = nullptr; uint32_t *gpairs_d = nullptr; };      // pairs_d: the k_pb_pairs form of the table (nullptr: a weight needs 17 bits)
+                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0, nq = 0; uint32_t *pairs_d = nullptr; uint32_t *gpairs_d = nullptr;      // pairs_d: the k_pb_pairs form of the table (nullptr: a weight needs 17 bits)
+                 // cache bookkeeping (under g_pb_mu): the event behind the uploads, the streams that have launched with this table, calls between lookup and launch, age
+                 hipEvent_t ready = nullptr; std::vector<hipStream_t> users; int pins = 0; unsigned long long stamp = 0; };
+// The tables of a geometry are cached per (device, interp, sw, sh, dw, dh) -- but BOUNDED: a compositor that animates its layers' scale or an interactive zoom asks
+// for a new geometry every frame.  At most LGPU_PB_CACHE_MAX entries (64) stay; the least recently used one that no call holds is retired.  Device memory comes
+// from the stream-ordered pool on the CALLING stream (no null-stream copy, no device-wide synchronisation in the frame path); an entry built on one stream is
+// waited for (one event) by the first launch from another; a retired entry's memory is freed stream-ordered behind the last launch of every stream that used it.
+// A table is built outside the lock.
 static std::mutex g_pb_mu;
-static std::map<std::tuple<int, int, int, int, int, int>, PbTable *> g_pb_tables;   // (device, interp, sw, sh, dw, dh); entries live as long as the library
+static std::map<std::tuple<int, int, int, int, int, int>, PbTable *> g_pb_tables;
+static unsigned long long g_pb_clock = 0;
 
-static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool upload) {
+static void pb_free_device(PbTable *t, hipStream_t st) {
+  if (t->table_d) (void)hipFreeAsync(t->table_d, st);
+  if (t->pairs_d) (void)hipFreeAsync(t->pairs_d, st);
+  if (t->gpairs_d) (void)hipFreeAsync(t->gpairs_d, st);
+  t->table_d = nullptr; t->pairs_d = nullptr; t->gpairs_d = nullptr;
+  (void)hipGetLastError();
+}
+// an entry no longer in the map and held by no call: its memory goes back behind everything its users have enqueued
+static void pb_retire(PbTable *t) {
+  hipStream_t home = t->users.empty() ? nullptr : t->users[0];
+  for (size_t i = 1; i < t->users.size(); i++) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(e, t->users[i]) == hipSuccess) (void)hipStreamWaitEvent(home, e, 0);       // a stream that is gone by now has finished its work: nothing to wait for
+      (void)hipEventDestroy(e);
+    }
+    (void)hipGetLastError();
+  }
+  pb_free_device(t, home);
+  if (t->ready) (void)hipEventDestroy(t->ready);
+  delete t;
+}
+static int pb_upload(const void *host, size_t bytes, hipStream_t st, void **out) {
+  *out = nullptr;
+  int rc = lgpu_malloc_ordered(out, bytes, st);
+  if (rc) return rc;
+  if (hipMemcpyAsync(*out, host, bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+    set_error("upload of a scaler table failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFreeAsync(*out, st);
+    *out = nullptr;
+    return LGPU_E_HIP;
+  }
+  return LGPU_OK;
+}
+
+static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool upload, hipStream_t st = nullptr) {
   const PbDim fx = pb_dimension(interp, (double)dw / sw), fy = pb_dimension(interp, (double)dh / sh);
   t->n_x = fx.n; t->n_y = fy.n;
   t->xoff = (int)floor(fx.offset * 65536); t->yoff = (int)floor(fy.offset * 65536);
@@ -1346,10 +1389,8 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
         }
       pb_fix_sum(pw, nn, total);
     }
-  if (upload) {
-    LGPU_HIP(hipMalloc((void **)&t->table_d, t->host.size() * sizeof(int)));
-    LGPU_HIP(hipMemcpy(t->table_d, t->host.data(), t->host.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
+  int rc;
+  if (upload && (rc = pb_upload(t->host.data(), t->host.size() * sizeof(int), st, (void **)&t->table_d))) return rc;
   // the phases this geometry's destination pixels take, the bounding box of their non-zero taps, and -- when every weight of those phases fits 16 bits -- the
   // table again as aligned tap PAIRS for both start parities (k_pb_pairs)
   const int x_step = (int)(65536 / ((double)dw / sw)), y_step = (int)(65536 / ((double)dh / sh));
@@ -1385,8 +1426,8 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
                 o[ty * rowlen + i] = w0 | (w1 << 16);
               }
           }
-      LGPU_HIP(hipMalloc((void **)&t->pairs_d, pr.size() * sizeof(uint32_t)));
-      LGPU_HIP(hipMemcpy(t->pairs_d, pr.data(), pr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      if ((rc = pb_upload(pr.data(), pr.size() * sizeof(uint32_t), st, (void **)&t->pairs_d))) { pb_free_device(t, st); return rc; }
+      (void)hipStreamSynchronize(st);          // pr is a local: its bytes must have left before it goes (a new geometry only; the frame path re-uses the entry)
       t->nq = nq;
       // the same weights as pairs aligned on the first used tap (k_pb_gather: one form, no parity), rows of 2 or 4 dwords
       const int gnp = (n_eff + 1) / 2;
@@ -1402,28 +1443,83 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
               gp[((size_t)ph * ny_eff + ty) * rl + i] = w0 | (w1 << 16);
             }
         }
-        LGPU_HIP(hipMalloc((void **)&t->gpairs_d, gp.size() * sizeof(uint32_t)));
-        LGPU_HIP(hipMemcpy(t->gpairs_d, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if ((rc = pb_upload(gp.data(), gp.size() * sizeof(uint32_t), st, (void **)&t->gpairs_d))) { pb_free_device(t, st); return rc; }
+        (void)hipStreamSynchronize(st);
       }
     }
   }
   return LGPU_OK;
 }
 
-static int pb_table(int interp, int sw, int sh, int dw, int dh, const PbTable **out) {
+// lookup (or build) + pin: the caller launches on `st` and then lets go with pb_unpin() -- or simply lets a PbPin go out of scope
+static void pb_unpin(const PbTable *t) {
+  if (!t) return;
+  std::lock_guard<std::mutex> lk(g_pb_mu);
+  const_cast<PbTable *>(t)->pins--;
+}
+struct PbPin {
+  const PbTable *t = nullptr;
+  ~PbPin() { pb_unpin(t); }
+};
+static int pb_table(int interp, int sw, int sh, int dw, int dh, hipStream_t st, PbPin *pin) {
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_pb_mu);
   const auto key = std::make_tuple(dev, interp, sw, sh, dw, dh);
-  auto it = g_pb_tables.find(key);
-  if (it == g_pb_tables.end()) {
-    PbTable *t = new PbTable();
-    const int rc = pb_build(interp, sw, sh, dw, dh, t, true);
-    if (rc != LGPU_OK && rc != LGPU_E_UNSUPPORTED) { delete t; return rc; }
-    it = g_pb_tables.emplace(key, t).first;
+  auto take = [&](PbTable *t, hipEvent_t *wait) {          // under the lock
+    t->pins++;
+    t->stamp = ++g_pb_clock;
+    bool known = false;
+    for (hipStream_t u : t->users) known = known || u == st;
+    if (!known) { t->users.push_back(st); *wait = t->ready; }
+    pin->t = t;
+  };
+  hipEvent_t wait = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pb_mu);
+    auto it = g_pb_tables.find(key);
+    if (it != g_pb_tables.end()) take(it->second, &wait);
   }
-  *out = it->second;
-  return it->second->table_d ? LGPU_OK : LGPU_E_UNSUPPORTED;
+  if (!pin->t) {
+    PbTable *t = new PbTable();
+    int rc = pb_build(interp, sw, sh, dw, dh, t, true, st);          // outside the lock
+    if (rc != LGPU_OK && rc != LGPU_E_UNSUPPORTED) { delete t; return rc; }
+    if (t->table_d && (hipEventCreateWithFlags(&t->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(t->ready, st) != hipSuccess)) {
+      set_error("scaler table: event failed");
+      pb_free_device(t, st);
+      if (t->ready) (void)hipEventDestroy(t->ready);
+      delete t;
+      return LGPU_E_HIP;
+    }
+    t->users.push_back(st);
+    std::vector<PbTable *> out_;
+    {
+      std::lock_guard<std::mutex> lk(g_pb_mu);
+      auto it = g_pb_tables.find(key);
+      if (it != g_pb_tables.end()) { out_.push_back(t); take(it->second, &wait); }       // another thread was faster: its entry is the one
+      else {
+        g_pb_tables.emplace(key, t);
+        t->pins = 1; t->stamp = ++g_pb_clock;
+        pin->t = t;
+        int cap = tune(TUNE_PB_CACHE_MAX);
+        if (cap < 1) cap = 64;
+        while ((int)g_pb_tables.size() > cap) {           // the least recently used entry nobody holds
+          auto victim = g_pb_tables.end();
+          for (auto j = g_pb_tables.begin(); j != g_pb_tables.end(); ++j)
+            if (j->second->pins == 0 && (victim == g_pb_tables.end() || j->second->stamp < victim->second->stamp)) victim = j;
+          if (victim == g_pb_tables.end()) break;
+          out_.push_back(victim->second);
+          g_pb_tables.erase(victim);
+        }
+      }
+    }
+    for (PbTable *o : out_) pb_retire(o);                  // outside the lock
+  }
+  if (wait && hipStreamWaitEvent(st, wait, 0) != hipSuccess) { (void)hipGetLastError(); set_error("scaler table: stream wait failed"); return LGPU_E_HIP; }
+  return pin->t->table_d ? LGPU_OK : LGPU_E_UNSUPPORTED;
+}
+extern "C" int lgpu_debug_pixbuf_cache_entries(void) {
+  std::lock_guard<std::mutex> lk(g_pb_mu);
+  return (int)g_pb_tables.size();
 }
 
 
@@ -1526,9 +1622,10 @@ static unsigned pb_half_grid(const PbHalfArgs &a) { return 8u * cdiv((unsigned)(
 int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
   const int interp = pr->interp & 0xFF;
   if (interp != 2 && interp != 3) return LGPU_E_UNSUPPORTED;
-  const PbTable *t;
-  int rc = pb_table(interp, pr->sw, pr->sh, pr->dw, pr->dh, &t);
+  PbPin pin;
+  int rc = pb_table(interp, pr->sw, pr->sh, pr->dw, pr->dh, st, &pin);
   if (rc) return rc;
+  const PbTable *t = pin.t;
   uintptr_t sb = (uintptr_t)pr->irow, db = (uintptr_t)pr->orow | (uintptr_t)pr->irow2;
   for (int i = 0; i < ntracks; i++) { sb |= (uintptr_t)tracks[i].src_d; db |= (uintptr_t)tracks[i].dst_d | (uintptr_t)tracks[i].layer2_d; }
   PbHalfArgs a;
@@ -1704,8 +1801,10 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
-  const PbTable *t;
-  if ((rc = pb_table(interp, sw, sh, dw, dh, &t))) {
+  PbPin pin;
+  rc = pb_table(interp, sw, sh, dw, dh, st, &pin);
+  const PbTable *t = pin.t;
+  if (rc) {
     if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d needs %d x %d taps; the library's two-step scaler is not covered", sw, sh, dw, dh, t->n_x, t->n_y);
     return rc;
   }

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "lgpu_tuning_get": [ctypes.c_char_p],
     "lgpu_debug_recip_check": [ctypes.c_uint32, ctypes.c_uint32, vp],
     "lgpu_debug_stream_probe": [vp, vp, ci, ci, vp, vp],
+    "lgpu_debug_pixbuf_cache_entries": [],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
     "lgpu_alpha_scalers": [vp, vp],

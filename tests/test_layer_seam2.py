@@ -559,6 +559,45 @@ def test_every_filter_class_on_pinned_planes(seam):
     assert ran >= 20, ran
 
 
+def test_compositor_class_on_pinned_planes(seam):
+    """the compositor class (fx_plugin.c: p_compositor) through the residency bridge: in channels and the out channel on planes of PINNED layers -- whose host bytes are
+    stale by contract and are scribbled over here after pinning -- give what ordinary memory gives; a mixed call (one in channel in host memory) too; and the next
+    effect on the out layer sees the composite, not an older device copy"""
+    import os
+    L, wh = seam
+    H = po.RefHost()
+    OURS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lives_amd", "livesgpu_fx.so")
+    rng = np.random.default_rng(77)
+    ow, oh, pal, ps = 160, 90, RGBA32, 4
+    sizes = [(64, 36), (200, 120), (96, 54)]
+    offsx, offsy, scx, scy, alpha = [0.06, 0.44, 0.3], [0.09, 0.33, 0.4], [0.625, 0.5, 0.6], [0.62, 0.53, 0.6], [0.75, 1.0, 0.3]
+    srcs = [frame(rng, w_, h_, ps, alpha_mix=True) for (w_, h_) in sizes]
+    plain = np.zeros((oh, po.align(ow * ps, 32)), np.uint8)
+    H.run_compositor(OURS, pal, [s_.copy() for s_ in srcs], sizes, [0, 0, 0], plain, ow, oh, offsx, offsy, scx, scy, alpha, [12, 200, 99], 0)
+    for mixed in (0, 1):
+        layers = [wh.new_layer(pal, w_, h_, [s_], gamma=1) for (w_, h_), s_ in zip(sizes, srcs)]
+        out_layer = wh.new_layer(pal, ow, oh, [np.zeros_like(plain)], gamma=1)
+        pinned = layers[:2] if mixed else layers
+        for lay in pinned + [out_layer]:
+            assert L.lives_gpu_layer_pin(lay) == 0
+        views = []
+        for lay, (w_, h_) in zip(layers, sizes):
+            _, ptrs, rs = wh.planes_of(lay)
+            views.append(np.frombuffer((ctypes.c_uint8 * (rs[0] * h_)).from_address(ptrs[0]), np.uint8).reshape(h_, rs[0]))
+        for v in views[:len(pinned)]:
+            v[:] = 0x5A                                     # the host bytes of a pinned plane are stale: whoever reads them composites garbage
+        _, optrs, ors = wh.planes_of(out_layer)
+        oview = np.frombuffer((ctypes.c_uint8 * (ors[0] * oh)).from_address(optrs[0]), np.uint8).reshape(oh, ors[0])
+        H.run_compositor(OURS, pal, views, sizes, [0, 0, 0], oview, ow, oh, offsx, offsy, scx, scy, alpha, [12, 200, 99], 0)
+        # the next effect on the out layer (negate, in place) must see the composite
+        H.run(OURS, "negate", pal, ow, oh, [oview], oview, [])
+        for lay in pinned + [out_layer]:
+            assert L.lives_gpu_layer_unpin(lay) == 0
+        want = plain.copy()
+        H.run(OURS, "negate", pal, ow, oh, [want], want, [])
+        assert (oview[:, :ow * ps] == want[:, :ow * ps]).all(), "mixed=%d" % mixed
+
+
 def test_short_lived_threads_do_not_pile_up_device_objects(seam):
     """a host that makes its seam calls from threads that come and go: a finished thread's stream, staging chunks and device scratch go to spare lists and the
     next new thread starts from them -- 300 threads one after the other, each with an un-pinned and a pinned call, leave the device's free memory where it was"""

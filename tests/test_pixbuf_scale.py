@@ -352,6 +352,38 @@ def test_chain_on_the_pixbuf_arithmetic(gpu, orc, tune, strips64):
 
 
 @gpu_mark
+def test_table_cache_stays_bounded_and_serves_several_streams(gpu, orc, tune):
+    """a host that animates a layer's scale asks for a new geometry every frame (compositor.c:229-266, an interactive zoom through resize_layer): the cache of
+    per-geometry tables keeps at most PB_CACHE_MAX entries (least recently used first out, memory freed stream-ordered behind the launches that used it), results
+    stay right while entries come and go, and an entry built on one stream serves a launch from another at once"""
+    import torch
+    from lives_amd import lib
+    tune("PB_CACHE_MAX", 6)
+    rng = np.random.default_rng(0x9DC0)
+    sw, sh = 200, 120
+    src = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8)
+    d_src = dev(src)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    checks = []
+    for i in range(60):
+        dw, dh = 60 + 3 * i, 40 + 2 * i                 # 60 geometries, reductions and enlargements
+        d = torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda")
+        d2 = torch.zeros_like(d)
+        with torch.cuda.stream(streams[i % 3]):
+            gpu.pixbuf_scale(d_src, d, sw, sh, dw, dh, channels=4, interp=3)
+        with torch.cuda.stream(streams[(i + 1) % 3]):   # the same geometry from another stream straight away: waits for the entry's upload, not for the host
+            gpu.pixbuf_scale(d_src, d2, sw, sh, dw, dh, channels=4, interp=3)
+        assert lib.load().lgpu_debug_pixbuf_cache_entries() <= 6
+        if i % 7 == 0:
+            checks.append((dw, dh, d, d2))
+    torch.cuda.synchronize()
+    for (dw, dh, d, d2) in checks:
+        want = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_pixbuf_scale(P(src), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, 3) == 0
+        assert (d.cpu().numpy() == want).all() and (d2.cpu().numpy() == want).all(), (dw, dh)
+
+
+@gpu_mark
 def test_reciprocal_equals_the_division_for_every_24_bit_integer(gpu):
     """the scaler's `1.0 / (double)a` is computed as the hardware estimate + two Newton steps (pb_recip, five operations): the same double as the IEEE division
     for EVERY a a sum of alpha weights can take (1 .. 2^24 - 1), checked on the device"""
