@@ -150,6 +150,9 @@ int lgpu_yuv420_tuning(int cell_columns, int block, int groups_per_cu);
    current value, -1 when unset or unknown. */
 int lgpu_tuning_set(const char *name, int value);
 int lgpu_tuning_get(const char *name);
+/* test hook: the four clamped YUVA premultiply tables (order of lgpu_premult_yuv_tables, 4 x 65,536 bytes) as the DEVICE arithmetic of lgpu_alpha_premult_yuva evaluates
+   them -- the kernel is table-free; tests compare this with the host tables byte for byte */
+int lgpu_debug_premult_yuv_tables_device(uint8_t *out_host);
 /* test hook: entries in the scaler's table cache (bounded: LGPU_PB_CACHE_MAX / lgpu_tuning_set("PB_CACHE_MAX", n), default 64; least recently used goes first) */
 int lgpu_debug_pixbuf_cache_entries(void);
 /* test hook: the scaler's five-operation reciprocal (pixbuf.hip: pb_recip) against the IEEE division 1.0 / (double)a for every integer a of [lo, hi), hi <= 2^24;

@@ -441,40 +441,48 @@ __device__ __forceinline__ uint32_t colour24(int bgr, const int32_t *t, int Y, i
   const uint32_t r = (uint32_t)clamp255((yy + t[256 + V]) >> 16), g = (uint32_t)clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = (uint32_t)clamp255((yy + t[1024 + U]) >> 16);
   return bgr ? (b | (g << 8) | (r << 16)) : (r | (g << 8) | (b << 16));
 }
-__global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a) {
+// Launch shape (round 4): macropixels are numbered linearly over the frame and walked with a grid stride by at most two 256-thread workgroups per CU -- the first
+// form started one workgroup per 256 macropixels of a row (2,160 for a 1080p frame, each staging 6 KB of tables for 1.5 KB of pixels) and read its ten bytes one by
+// one; now a macropixel is one dword + one halfword, its neighbours' chroma one unaligned dword each (11.2 -> see profiles/r04/ops_roofline.md).
+__global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a, uint32_t gmagic, uint32_t ncells) {
   __shared__ int32_t s_t[5 * 256];
   __shared__ float s_fa[256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
   s_fa[threadIdx.x] = cavg_fa((int)threadIdx.x);             // kBlock == 256
   __syncthreads();
-  const int j = blockIdx.x * kBlock + threadIdx.x;
   const int wm = a.width;                                   // macropixels per row
-  if (j >= wm) return;
   const int ps = (a.order == 2 || a.alpha_out) ? 4 : 3, coff = a.order == 2 ? 1 : 0, aoff = a.order == 2 ? 0 : 3;
   const int bgr = a.order == 1, cl = !a.unclamped;
-  for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+  for (uint32_t cell = blockIdx.x * kBlock + threadIdx.x; cell < ncells; cell += gridDim.x * kBlock) {
+    uint32_t y = __umulhi(cell, gmagic);                     // floor magic: the quotient or one less
+    uint32_t jj = cell - y * (uint32_t)wm;
+    if (jj >= (uint32_t)wm) { jj -= wm; y++; }
+    const int j = (int)jj;
     const uint8_t *cb = a.src[0] + ((size_t)y * wm + j) * 6;
     uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + (size_t)j * 4 * ps;
-    const int cu = cb[0], cv = cb[3];
-    if (ps == 4 && ((reinterpret_cast<uintptr_t>(d) & 15) == 0)) {
+    if (ps == 4 && ((reinterpret_cast<uintptr_t>(d) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cb) & 1) == 0)) {
       // four-byte pixels: the block's four pixels leave as one 16-byte store instead of 14 .. 16 byte stores; the two alpha bytes the reference never writes
       // (pixels 4j + 2, 4j + 3 of every block but the row's last, quirk K3b) are taken from what the destination holds
       const bool first = j == 0, last = j == wm - 1;
+      const uint32_t w0 = *reinterpret_cast<const uint32_t *>(cb), w1 = *reinterpret_cast<const uint16_t *>(cb + 4);      // u y0 y1 v | y2 y3
+      const int cu = w0 & 0xFF, cv = w0 >> 24, y0_ = (w0 >> 8) & 0xFF, y1_ = (w0 >> 16) & 0xFF, y2_ = w1 & 0xFF, y3_ = w1 >> 8;
       uint32_t c0, c1, c2, c3;
-      if (first) { c0 = colour24(0, s_t, cb[1], cu, cv); c1 = colour24(bgr, s_t, cb[2], cu, cv); }
+      if (first) { c0 = colour24(0, s_t, y0_, cu, cv); c1 = colour24(bgr, s_t, y1_, cu, cv); }
       else {
-        const int pu = cb[-6], pv = cb[-3];
+        const uint32_t pw = *reinterpret_cast<const uint32_t *>(cb - 6);          // the block on the left: u at byte 0, v at byte 3
+        const int pu = pw & 0xFF, pv = pw >> 24;
         const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pu, cu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pv, cv), cv);
-        c0 = colour24(bgr, s_t, cb[1], cavg_lds(cl, s_fa, qu, pu), cavg_lds(cl, s_fa, qv, pv));
-        c1 = colour24(bgr, s_t, cb[2], cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
+        c0 = colour24(bgr, s_t, y0_, cavg_lds(cl, s_fa, qu, pu), cavg_lds(cl, s_fa, qv, pv));
+        c1 = colour24(bgr, s_t, y1_, cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
       }
       uint32_t a2 = 0xFFu, a3 = 0xFFu;
-      if (last) { c2 = colour24(0, s_t, cb[4], cu, cv); c3 = colour24(0, s_t, cb[5], cu, cv); }
+      if (last) { c2 = colour24(0, s_t, y2_, cu, cv); c3 = colour24(0, s_t, y3_, cu, cv); }
       else {
-        const int nu = cb[6], nv = cb[9];
+        const uint32_t nw = *reinterpret_cast<const uint32_t *>(cb + 6);          // the block on the right
+        const int nu = nw & 0xFF, nv = nw >> 24;
         const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cu, nu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cv, nv), cv);
-        c2 = colour24(bgr, s_t, cb[4], cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
-        c3 = colour24(bgr, s_t, cb[5], cavg_lds(cl, s_fa, qu, nu), cavg_lds(cl, s_fa, qv, nv));
+        c2 = colour24(bgr, s_t, y2_, cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
+        c3 = colour24(bgr, s_t, y3_, cavg_lds(cl, s_fa, qu, nu), cavg_lds(cl, s_fa, qv, nv));
         const uint2 old_ = *reinterpret_cast<const uint2 *>(d + 8);
         a2 = aoff ? old_.x >> 24 : old_.x & 0xFF; a3 = aoff ? old_.y >> 24 : old_.y & 0xFF;
       }
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a) {
       *reinterpret_cast<uint4 *>(d) = o;
       continue;
     }
+    const int cu = cb[0], cv = cb[3];
     if (j == 0) {                                           // row start (:8330-8337)
       put_colour(d + coff, 0, s_t, cb[1], cu, cv);
       put_colour(d + ps + coff, bgr, s_t, cb[2], cu, cv);
@@ -1237,8 +1246,11 @@ extern "C" int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height
   a.src[0] = src_d; a.dst[0] = dst_d; a.orow[0] = orow; a.width = width_mp; a.height = height;
   a.order = out_order; a.alpha_out = out_alpha; a.unclamped = clamping_unclamped ? 1 : 0;
   a.tables = device_tables()->yuv2rgb[a.unclamped];         // set_conversion_arrays(clamping, WEED_YUV_SUBSPACE_YCBCR) (:8316)
-  const dim3 grid(cdiv((unsigned)width_mp, kBlock), (unsigned)(height < 2048 ? height : 2048));
-  hipLaunchKernelGGL(k_yuv411_to_rgb, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  LGPU_REQUIRE((unsigned long long)width_mp * height < (1ull << 31), "frame too large");
+  const uint32_t ncells = (uint32_t)width_mp * (uint32_t)height;
+  const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)width_mp - (width_mp == 1 ? 1 : 0));
+  unsigned wgs = cdiv(ncells, kBlock), cap = (unsigned)device_cus() * (unsigned)(tune(TUNE_K2_WGS) > 0 ? tune(TUNE_K2_WGS) : 8);
+  hipLaunchKernelGGL(k_yuv411_to_rgb, dim3(wgs < cap ? wgs : cap), dim3(kBlock), 0, (hipStream_t)stream, a, magic, ncells);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -191,6 +191,7 @@ struct PbHalfArgs {
   int rem;                       // k_pb_half / k_pb_half_ld: the first `rem` bands are th + 1 rows tall, the others th (bands * th + rem == dh: band heights differ by one row at most)
   int cw, ch, ox, oy;            // letterbox canvas (cw == 0: none): dst / layer 2 are cw x ch, the scaled frame sits at (ox, oy), the rest is opaque black under the blend
   int main_blocks, bar_blocks;   // workgroups of the frame proper / per track of the bars (1024 canvas pixels each)
+  int bar_first;                 // the bars' workgroups come FIRST in the grid (a multiple of 8, so the frame's workgroups keep their XCD): they run while the frame's first loads are in flight
   int nt_out;
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
 };
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   // ALIGNED (no blur): strips of 64 quads, no feeder lanes -- a wave's row is 1024 source bytes and 512 result bytes on 128-byte lines; the two taps beyond the
   // strip come from one extra 4-byte load per source row in lanes 0 and 63
   constexpr int kHalo = BLUR ? 2 : ALIGNED ? 0 : 1, kCols = 64 - 2 * kHalo;      // lanes that only feed their neighbours on each side / lanes that store
-  if (CHAIN && blockIdx.x >= (unsigned)A.main_blocks) {
+  if (CHAIN && blockIdx.x < (unsigned)A.bar_first) {
     // letterbox bars (letterbox_layer's black canvas, src/colourspace.c:15417-15503, under the rest of the chain): opaque black -> chroma blend with layer 2 -> LUT
     stage_lut(s_lut, lut);
     {
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       s_k[threadIdx.x] = kv;
     }
     __syncthreads();
-    const int b = blockIdx.x - A.main_blocks, track = b / A.bar_blocks, chunk = b - track * A.bar_blocks;
+    const int b = blockIdx.x, track = b / A.bar_blocks, chunk = b - track * A.bar_blocks;
+    if (track >= A.ntracks) return;                       // padding up to a multiple of 8
     uint32_t bf = A.bf;
     if (A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
     const uint32_t w_lo = bf | ((255u - bf) << 8);
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its
   // own L2; two bands that follow each other vertically share two source rows.  So every XCD gets a CONTIGUOUS run of the sequence (track, column group, band) and
   // walks it band by band: the shared rows are fetched once and hit that XCD's L2 the second time (PMC: 999 MB -> see profiles/r03 per 16-track launch).
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const unsigned bid = blockIdx.x - (CHAIN ? (unsigned)A.bar_first : 0u);
+  const int xcd = bid & 7, slot = bid >> 3;
   const int nseq = A.cgroups * A.bands * A.ntracks, per_xcd = (nseq + 7) >> 3;
   int seq = xcd * per_xcd + slot;
   int strip = 0, band = 0, track = 0;
@@ -1324,13 +1327,13 @@ static void pb_fix_sum(int *w, int count, int total) {
 
 struct PbTable { int n_x, n_y, xoff, yoff, uniform_x; int *table_d; std::vector<int> host;
                  int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0, nq = 0; uint32_t *pairs_d = nullptr; uint32_t *gpairs_d = nullptr;      // pairs_d: the k_pb_pairs form of the table (nullptr: a weight needs 17 bits)
-                 // cache bookkeeping (under g_pb_mu): the event behind the uploads, the streams that have launched with this table, calls between lookup and launch, age
-                 hipEvent_t ready = nullptr; std::vector<hipStream_t> users; int pins = 0; unsigned long long stamp = 0; };
+                 // cache bookkeeping (under g_pb_mu): the streams that have launched with this table, calls between lookup and launch, age
+                 std::vector<hipStream_t> users; int pins = 0; unsigned long long stamp = 0; };
 // The tables of a geometry are cached per (device, interp, sw, sh, dw, dh) -- but BOUNDED: a compositor that animates its layers' scale or an interactive zoom asks
 // for a new geometry every frame.  At most LGPU_PB_CACHE_MAX entries (64) stay; the least recently used one that no call holds is retired.  Device memory comes
-// from the stream-ordered pool on the CALLING stream (no null-stream copy, no device-wide synchronisation in the frame path); an entry built on one stream is
-// waited for (one event) by the first launch from another; a retired entry's memory is freed stream-ordered behind the last launch of every stream that used it.
-// A table is built outside the lock.
+// from the stream-ordered pool on the CALLING stream (no null-stream copy, no device-wide synchronisation); the builder waits for its own uploads before the entry
+// becomes visible (a new geometry only -- and no cross-stream event waits later, which a stream under graph capture cannot take); a retired entry's memory is freed
+// stream-ordered behind the last launch of every stream that used it.  A table is built outside the lock.
 static std::mutex g_pb_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, PbTable *> g_pb_tables;
 static unsigned long long g_pb_clock = 0;
@@ -1354,7 +1357,6 @@ static void pb_retire(PbTable *t) {
     (void)hipGetLastError();
   }
   pb_free_device(t, home);
-  if (t->ready) (void)hipEventDestroy(t->ready);
   delete t;
 }
 static int pb_upload(const void *host, size_t bytes, hipStream_t st, void **out) {
@@ -1427,7 +1429,7 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
               }
           }
       if ((rc = pb_upload(pr.data(), pr.size() * sizeof(uint32_t), st, (void **)&t->pairs_d))) { pb_free_device(t, st); return rc; }
-      (void)hipStreamSynchronize(st);          // pr is a local: its bytes must have left before it goes (a new geometry only; the frame path re-uses the entry)
+      (void)hipStreamSynchronize(st);          // pr is a local: its bytes must have left before it goes
       t->nq = nq;
       // the same weights as pairs aligned on the first used tap (k_pb_gather: one form, no parity), rows of 2 or 4 dwords
       const int gnp = (n_eff + 1) / 2;
@@ -1465,28 +1467,26 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, hipStream_t st, 
   int dev = 0;
   LGPU_HIP(hipGetDevice(&dev));
   const auto key = std::make_tuple(dev, interp, sw, sh, dw, dh);
-  auto take = [&](PbTable *t, hipEvent_t *wait) {          // under the lock
+  auto take = [&](PbTable *t) {          // under the lock
     t->pins++;
     t->stamp = ++g_pb_clock;
     bool known = false;
     for (hipStream_t u : t->users) known = known || u == st;
-    if (!known) { t->users.push_back(st); *wait = t->ready; }
+    if (!known) t->users.push_back(st);
     pin->t = t;
   };
-  hipEvent_t wait = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_pb_mu);
     auto it = g_pb_tables.find(key);
-    if (it != g_pb_tables.end()) take(it->second, &wait);
+    if (it != g_pb_tables.end()) take(it->second);
   }
   if (!pin->t) {
     PbTable *t = new PbTable();
     int rc = pb_build(interp, sw, sh, dw, dh, t, true, st);          // outside the lock
     if (rc != LGPU_OK && rc != LGPU_E_UNSUPPORTED) { delete t; return rc; }
-    if (t->table_d && (hipEventCreateWithFlags(&t->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(t->ready, st) != hipSuccess)) {
-      set_error("scaler table: event failed");
+    if (t->table_d && hipStreamSynchronize(st) != hipSuccess) {        // the uploads are over before anybody else can find the entry
+      set_error("scaler table: upload failed: %s", hipGetErrorString(hipGetLastError()));
       pb_free_device(t, st);
-      if (t->ready) (void)hipEventDestroy(t->ready);
       delete t;
       return LGPU_E_HIP;
     }
@@ -1495,7 +1495,7 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, hipStream_t st, 
     {
       std::lock_guard<std::mutex> lk(g_pb_mu);
       auto it = g_pb_tables.find(key);
-      if (it != g_pb_tables.end()) { out_.push_back(t); take(it->second, &wait); }       // another thread was faster: its entry is the one
+      if (it != g_pb_tables.end()) { out_.push_back(t); take(it->second); }       // another thread was faster: its entry is the one
       else {
         g_pb_tables.emplace(key, t);
         t->pins = 1; t->stamp = ++g_pb_clock;
@@ -1514,7 +1514,6 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, hipStream_t st, 
     }
     for (PbTable *o : out_) pb_retire(o);                  // outside the lock
   }
-  if (wait && hipStreamWaitEvent(st, wait, 0) != hipSuccess) { (void)hipGetLastError(); set_error("scaler table: stream wait failed"); return LGPU_E_HIP; }
   return pin->t->table_d ? LGPU_OK : LGPU_E_UNSUPPORTED;
 }
 extern "C" int lgpu_debug_pixbuf_cache_entries(void) {
@@ -1639,10 +1638,11 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
   a.main_blocks = (int)pb_half_grid(a);
+  a.bar_first = (a.bar_blocks * ntracks + 7) & ~7;
   PbTracks T;
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
-  const dim3 grid((unsigned)(a.main_blocks + a.bar_blocks * ntracks));
+  const dim3 grid((unsigned)(a.main_blocks + a.bar_first));
   // the loader-wave form (k_pb_half_ld): full-device launches of the plain chain
   if (!pr->do_blur && !cv && tune(TUNE_PBH_LOADER) > 0) {
     const int np = tune(TUNE_PBH_LOADER) & 15, nt = tune(TUNE_PBH_LOADER) >> 4;          // ring depth in row pairs; + 16: non-temporal loads of a band's inner rows
@@ -1680,6 +1680,7 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
   const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0;
   if (pixbuf && !(cv && pr->do_blur)) {
     rc = pb_chain_half(pr, cv, tracks, ntracks, st);         // one launch
+    if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: one-launch form rc %d (%s)\n", rc, rc ? lgpu_last_error() : "ok");
     if (rc != LGPU_E_UNSUPPORTED) return rc;
   }
   const int interp = pr->interp & 0xFF;
@@ -1841,7 +1842,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       pb_half_geometry(&h, 1);
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
-      h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.main_blocks = (int)pb_half_grid(h);
+      h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.bar_first = 0; h.main_blocks = (int)pb_half_grid(h);
       if (h.aligned) {
         if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0, 1>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
         else hipLaunchKernelGGL((k_pb_half<0, 0, 0, 1>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));

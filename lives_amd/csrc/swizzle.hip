@@ -227,15 +227,50 @@ __global__ __launch_bounds__(kBlock) void k_byte_luts(const uint8_t *src, int ir
 }
 
 // --- K9b: alpha_premult on YUVA8888 / YUVA4444P (src/colourspace.c:11995-12096) ------------------------------------------------
-// unclamped: the RGB arithmetic on Y, U and V; clamped: the four tables of init_unal (256 KB, device resident, L2-served)
+// unclamped: the RGB arithmetic on Y, U and V.  clamped: the four tables of init_unal (:1141-1160; 4 x 64 KB) -- evaluated, not gathered: three byte gathers per
+// pixel from 64 KB tables cost a wave up to 3 x 64 cache lines (12.3 us per 1080p frame); the entries are
+//   alcy / unalcy [i][j] = (int)((float)j / alpha + .5) > lim ? cap : (int)((float)(j - 16.) / alpha + 16. + .5)        alpha = 255.f / i, (lim, cap) = (224, 240) / (219, 235)
+//     = floor((2 j i + 255) / 510) > lim ? cap : floor((2 (j - 16) i + 8415) / 510)   EXACTLY: 2 x i + 255 is odd and 510 even, so no quotient is nearer than 1 / 510 to the
+//       rounding boundary, four orders of magnitude more than the float error -- all 2 x 65,536 entries equal the integer form (tests/test_host_cpu.py), row 0 included;
+//   alcuv / unalcuv [i][j] = c255f((float)(j - off) * alpha + off), off = 128 / 16: here the real value does land on boundaries (2,154 + 2,188 entries) and 26 of them go the
+//       other way in float, so the float product is kept: __fmul_rn with alpha from a 256-entry table of correctly rounded quotients (one per lane and workgroup), the
+//       rest in exact double steps; alpha = inf (i = 0) gives the reference's 0 / 255 / (NaN ->) 0 through the saturating conversion.
 struct PremultYuvaArgs {
   uint8_t *p[4];
   int rs[4];
   int width, height, planar, clamped, un, dword;
-  const uint8_t *cy, *cuv;       // unalcy / alcy and unalcuv / alcuv for the direction
 };
+__device__ __forceinline__ uint32_t pm_div510(uint32_t n) { return __umulhi(n, 2155905153u) >> 8; }       // floor(n / 510) for every 32-bit n (510 * 2155905153 - 2^40 = 254 <= 2^8)
+template <int UN>
+__device__ __forceinline__ uint32_t pm_cy(uint32_t y, uint32_t al) {
+  const uint32_t t = pm_div510(2u * y * al + 255u);
+  const uint32_t m = pm_div510((uint32_t)(2 * ((int)y - 16) * (int)al + 8415));          // 255 .. 130,305: never negative
+  return t > (UN ? 219u : 224u) ? (UN ? 235u : 240u) : m;
+}
+template <int UN>
+__device__ __forceinline__ uint32_t pm_cuv(uint32_t v, float alpha) {
+  const int off = UN ? 16 : 128;
+  const float p = __fmul_rn((float)((int)v - off), alpha);
+  const int r = (int)((double)p + ((double)off + .5));                    // p + off and + .5 are exact in double; NaN -> 0, +-inf saturate
+  return (uint32_t)min(max(r, 0), 255);
+}
+template <int UN, int PLANAR>
+__device__ __forceinline__ uint32_t pm_clamped_px(uint32_t px, const float *s_ratio) {        // packed Y U V A pixel
+  const uint32_t al = px >> 24;
+  const float alpha = s_ratio[al];
+  const uint32_t ny = pm_cy<UN>(px & 255u, al);
+  uint32_t nu, nv;
+  if (UN || PLANAR) { nu = pm_cuv<UN>((px >> 8) & 255u, alpha); nv = pm_cuv<UN>((px >> 16) & 255u, alpha); }
+  else nu = nv = pm_cuv<0>(ny, alpha);                 // the packed FORWARD loop indexes alcuv with the Y byte it has just written (:12089-12091)
+  return ny | (nu << 8) | (nv << 16) | (px & 0xff000000u);
+}
+// 4 pixels per lane on 16-byte aligned packed rows (VEC), one otherwise; planar layers: one sample of each plane per lane
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_premult_yuva(PremultYuvaArgs a) {
-  const int x = blockIdx.x * kBlock + threadIdx.x;
+  __shared__ float s_ratio[256];
+  for (int i = threadIdx.x; i < 256; i += kBlock) s_ratio[i] = __fdiv_rn(255.f, (float)i);
+  __syncthreads();
+  const int x = (blockIdx.x * kBlock + threadIdx.x) * (VEC ? 4 : 1);
   if (x >= a.width) return;
   for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
     uint8_t *py, *pu, *pv;
@@ -245,35 +280,44 @@ __global__ __launch_bounds__(kBlock) void k_premult_yuva(PremultYuvaArgs a) {
       al = a.p[3][(size_t)i * a.rs[3] + x];
     } else {
       py = a.p[0] + (size_t)i * a.rs[0] + 4 * (size_t)x; pu = py + 1; pv = py + 2;
+      if (VEC) {                                          // (width % 4 == 0 on this path)
+        uint4 q = *reinterpret_cast<const uint4 *>(py);
+        if (a.un) { q.x = pm_clamped_px<1, 0>(q.x, s_ratio); q.y = pm_clamped_px<1, 0>(q.y, s_ratio); q.z = pm_clamped_px<1, 0>(q.z, s_ratio); q.w = pm_clamped_px<1, 0>(q.w, s_ratio); }
+        else { q.x = pm_clamped_px<0, 0>(q.x, s_ratio); q.y = pm_clamped_px<0, 0>(q.y, s_ratio); q.z = pm_clamped_px<0, 0>(q.z, s_ratio); q.w = pm_clamped_px<0, 0>(q.w, s_ratio); }
+        *reinterpret_cast<uint4 *>(py) = q;
+        continue;
+      }
       if (a.dword) {                                    // 4-byte aligned rows: one dword in, one dword out
         const uint32_t px = *(const uint32_t *)py;
-        const uint32_t y = px & 255u, u = (px >> 8) & 255u, v = (px >> 16) & 255u;
-        al = px >> 24;
-        uint32_t ny, nu, nv;
+        uint32_t o;
         if (!a.clamped) {
-          const float ratio = __fdiv_rn(255.f, (float)al);
-          ny = premult_byte(y, ratio, a.un); nu = premult_byte(u, ratio, a.un); nv = premult_byte(v, ratio, a.un);
-        } else {
-          ny = a.cy[al * 256 + y];
-          if (a.un) { nu = a.cuv[al * 256 + u]; nv = a.cuv[al * 256 + v]; }
-          else nu = nv = a.cuv[al * 256 + ny];          // the packed FORWARD loop indexes with the Y byte it has just written (:12089-12091)
-        }
-        *(uint32_t *)py = (ny & 255u) | ((nu & 255u) << 8) | ((nv & 255u) << 16) | (px & 0xff000000u);
+          const float ratio = s_ratio[px >> 24];
+          o = (premult_byte(px & 255u, ratio, a.un) & 255u) | ((premult_byte((px >> 8) & 255u, ratio, a.un) & 255u) << 8) | ((premult_byte((px >> 16) & 255u, ratio, a.un) & 255u) << 16) | (px & 0xff000000u);
+        } else o = a.un ? pm_clamped_px<1, 0>(px, s_ratio) : pm_clamped_px<0, 0>(px, s_ratio);
+        *(uint32_t *)py = o;
         continue;
       }
       al = py[3];
     }
     const uint32_t y = *py, u = *pu, v = *pv;
     if (!a.clamped) {
-      const float ratio = __fdiv_rn(255.f, (float)al);
+      const float ratio = s_ratio[al];
       *py = (uint8_t)premult_byte(y, ratio, a.un); *pu = (uint8_t)premult_byte(u, ratio, a.un); *pv = (uint8_t)premult_byte(v, ratio, a.un);
     } else {
-      const uint32_t ny = a.cy[al * 256 + y];
-      *py = (uint8_t)ny;
-      if (a.planar || a.un) { *pu = a.cuv[al * 256 + u]; *pv = a.cuv[al * 256 + v]; }
-      else { const uint8_t c = a.cuv[al * 256 + ny]; *pu = c; *pv = c; }        // the packed FORWARD loop indexes with the Y byte it has just written (:12089-12091)
+      const uint32_t px = y | (u << 8) | (v << 16) | (al << 24);
+      const uint32_t o = a.planar ? (a.un ? pm_clamped_px<1, 1>(px, s_ratio) : pm_clamped_px<0, 1>(px, s_ratio)) : (a.un ? pm_clamped_px<1, 0>(px, s_ratio) : pm_clamped_px<0, 0>(px, s_ratio));
+      *py = (uint8_t)o; *pu = (uint8_t)(o >> 8); *pv = (uint8_t)(o >> 16);
     }
   }
+}
+// test hook: the four tables as the device arithmetic gives them ([unalcy, alcy, unalcuv, alcuv][256][256]), to be compared with lgpu_premult_yuv_tables byte for byte
+__global__ __launch_bounds__(256) void k_premult_yuv_tables(uint8_t *out) {
+  const uint32_t al = blockIdx.x, j = threadIdx.x;
+  const float alpha = __fdiv_rn(255.f, (float)al);
+  out[0 * 65536 + al * 256 + j] = (uint8_t)pm_cy<1>(j, al);
+  out[1 * 65536 + al * 256 + j] = (uint8_t)pm_cy<0>(j, al);
+  out[2 * 65536 + al * 256 + j] = (uint8_t)pm_cuv<1>(j, alpha);
+  out[3 * 65536 + al * 256 + j] = (uint8_t)pm_cuv<0>(j, alpha);
 }
 
 static inline dim3 row_grid(unsigned items_per_row, int height) {
@@ -389,29 +433,24 @@ extern "C" int lgpu_alpha_premult_yuva(uint8_t *const planes_d[4], const int row
   }
   a.width = width; a.height = height; a.clamped = clamped ? 1 : 0; a.un = un ? 1 : 0;
   a.dword = (!a.planar && (((uintptr_t)planes_d[0] | (uintptr_t)rowstrides[0]) & 3) == 0) ? 1 : 0;
-  if (a.clamped) {
-    // the four tables, built once on the host (reference arithmetic) and kept on the device
-    static std::mutex mu;
-    static std::map<int, uint8_t *> tabs;
-    int dev = 0;
-    LGPU_HIP(hipGetDevice(&dev));
-    uint8_t *t;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      auto it = tabs.find(dev);
-      if (it == tabs.end()) {
-        std::vector<uint8_t> h(4 * 65536);
-        if (!lgpu_premult_yuv_tables(h.data(), h.data() + 65536, h.data() + 2 * 65536, h.data() + 3 * 65536)) return LGPU_E_BADARG;
-        uint8_t *d = nullptr;
-        if (hipMalloc((void **)&d, h.size()) != hipSuccess) { set_error("hipMalloc of the premultiply tables failed"); return LGPU_E_NOMEM; }
-        LGPU_HIP(hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
-        it = tabs.emplace(dev, d).first;
-      }
-      t = it->second;
-    }
-    a.cy = t + (a.un ? 0 : 65536); a.cuv = t + (a.un ? 2 * 65536 : 3 * 65536);
-  }
-  hipLaunchKernelGGL(k_premult_yuva, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, a);
+  // clamped packed layers on 16-byte aligned rows: four pixels per lane
+  if (a.clamped && !a.planar && (width & 3) == 0 && (((uintptr_t)planes_d[0] | (uintptr_t)rowstrides[0]) & 15) == 0)
+    hipLaunchKernelGGL(k_premult_yuva<1>, row_grid((unsigned)width / 4, height), dim3(kBlock), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_premult_yuva<0>, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, a);
   LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+// test hook: the four clamped premultiply tables as the DEVICE arithmetic of k_premult_yuva evaluates them, 4 x 65,536 bytes in the order of lgpu_premult_yuv_tables
+extern "C" int lgpu_debug_premult_yuv_tables_device(uint8_t *out_host) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(out_host, "null output");
+  uint8_t *d = nullptr;
+  LGPU_HIP(hipMalloc((void **)&d, 4 * 65536));
+  hipLaunchKernelGGL(k_premult_yuv_tables, dim3(256), dim3(256), 0, 0, d);
+  const hipError_t e = hipMemcpy(out_host, d, 4 * 65536, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_error("lgpu_debug_premult_yuv_tables_device: %s", hipGetErrorString(e)); return LGPU_E_HIP; }
   return LGPU_OK;
 }

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "lgpu_debug_recip_check": [ctypes.c_uint32, ctypes.c_uint32, vp],
     "lgpu_debug_stream_probe": [vp, vp, ci, ci, vp, vp],
     "lgpu_debug_pixbuf_cache_entries": [],
+    "lgpu_debug_premult_yuv_tables_device": [vp],
     "lgpu_yuv420p_to_rgb_lut16": [vp, vp, vp, vp, cl, cl, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
     "lgpu_gamma_lut16": [cd, ci, ci, cd, vp],
     "lgpu_alpha_scalers": [vp, vp],

@@ -123,6 +123,18 @@ def test_premult_yuv_tables_match_the_fixture(gpu):
         assert (t == g[name]).all(), name
 
 
+def test_premult_yuv_tables_as_the_device_evaluates_them(gpu):
+    """lgpu_alpha_premult_yuva is table-free since round 4: the integer form of alcy / unalcy and the float product of alcuv / unalcuv, evaluated by the kernel's own
+    device functions for all 4 x 65,536 (alpha, value) pairs, against the reference's tables (fixture made from the colourspace.c slice)"""
+    from tests import golden_util as gu
+    g = gu.load("premult_yuv.npz")
+    out = np.zeros((4, 256, 256), np.uint8)
+    gpu.lib.call("lgpu_debug_premult_yuv_tables_device", out.ctypes.data)
+    for k, name in enumerate(("unalcy", "alcy", "unalcuv", "alcuv")):
+        bad = np.argwhere(out[k] != g[name])
+        assert len(bad) == 0, "%s: %d entries differ, first (alpha, value) = %s" % (name, len(bad), bad[0].tolist())
+
+
 @pytest.mark.parametrize("pal", [589, 545])
 @pytest.mark.parametrize("clamped", [0, 1])
 @pytest.mark.parametrize("un", [0, 1])

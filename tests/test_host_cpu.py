@@ -188,3 +188,23 @@ def test_alpha_scalers_equal_the_reference_float_expression():
         o.orc_blend_chroma(P(p1), w * 4, P(p2), w * 4, P(out), w * 4, w, h, 4, 0, bf)
         want = (255 * g[:255]) >> 8          # blend[s2][s1] = (bf * s2 + (255 - bf) * s1) >> 8 with the other weight 0
         assert (out[:, 0::4] == want).all(), "bf=%d" % bf
+
+
+def test_clamped_luma_premultiply_tables_have_an_exact_integer_form():
+    """what k_premult_yuva evaluates instead of gathering from init_unal's 64 KB tables (src/colourspace.c:1141-1160): alcy / unalcy[i][j] ==
+    floor((2 j i + 255) / 510) > lim ? cap : floor((2 (j - 16) i + 8415) / 510) for every (alpha, value) pair -- 2 j i + 255 is odd and 510 even, so the float
+    arithmetic of the reference never sits on a rounding boundary; and floor(n / 510) == (n * 2155905153) >> 40 over the whole range"""
+    import ctypes
+    import numpy as np
+    from lives_amd import lib
+    L = lib.load()
+    t = [np.zeros((256, 256), np.uint8) for _ in range(4)]
+    L.lgpu_premult_yuv_tables.argtypes = [ctypes.c_void_p] * 4
+    assert L.lgpu_premult_yuv_tables(*[x.ctypes.data for x in t]) == 1
+    i = np.arange(256, dtype=np.int64)[:, None]
+    j = np.arange(256, dtype=np.int64)[None, :]
+    n = np.arange(0, 140000, dtype=np.int64)
+    assert ((n * 2155905153 >> 40) == n // 510).all()
+    for tab, lim, cap in ((t[0], 219, 235), (t[1], 224, 240)):
+        cand = np.where((2 * j * i + 255) // 510 > lim, cap, (2 * (j - 16) * i + 8415) // 510)
+        assert (cand == tab).all()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""tools/bench_one.py <op> [<op> ...] -- device time per launch of single entry points (the cases of tools/prof_one.py) by HIP-graph replay over rotating buffers:
+no host time between the kernels.  Prints one line per op: us, GB/s of algorithmic bytes, fraction of 8 TB/s.  LGPU_* switches apply (read once per process)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch         # noqa: E402
+from lives_amd import ops   # noqa: E402
+import prof_one      # noqa: E402
+
+
+def main():
+    ops.init(0)
+    for op in sys.argv[1:]:
+        fn, nbytes = prof_one.case(op)
+        for i in range(60):
+            fn(i)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        per = 4 * prof_one.NB
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for i in range(per):
+                    fn(i)
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / (20 * per))
+        print("%-28s %7.2f us  %7.1f GB/s  %.3f of 8 TB/s" % (op, best, nbytes / best / 1e3, nbytes / best / 1e3 / 8000.0), flush=True)
+
+
+if __name__ == "__main__":
+    main()

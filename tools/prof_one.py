@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/prof_one.py <op> -- one entry point in a loop for rocprofv3 --kernel-trace --stats (which kernels a multi-launch op spends its time in)"""
+"""tools/prof_one.py <op> -- one entry point in a loop for rocprofv3 (--kernel-trace --stats / --pmc); tools/bench_one.py times the same cases by HIP-graph replay.
+ops: edge softlight yuv411 premult_yuva composite k2 c3 c4rgb24 c4rgba pb:SWxSH:DWxDH:interp"""
 import os
 import sys
 
@@ -9,23 +10,78 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 from lives_amd import ops   # noqa: E402
 
+NB = 6        # rotating buffer sets: consecutive launches do not read what the one before left in the caches
+
+
+def case(op):
+    """-> (fn(i), algorithmic bytes per launch): fn launches the op on buffer set i % NB"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    w, h = 1920, 1080
+
+    def rnd(rows, cols):
+        return [torch.randint(0, 256, (rows, cols), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NB)]
+    if op == "edge":
+        src, dst = rnd(h, w * 4), rnd(h, w * 4)
+        return (lambda i: ops.edge(src[i % NB], dst[i % NB], w, h, 3, 0)), w * h * 16
+    if op == "softlight":
+        pl = [[a, b, c] for a, b, c in zip(rnd(h, w), rnd(h // 2, w // 2), rnd(h // 2, w // 2))]
+        dl = [[torch.zeros_like(t) for t in p] for p in pl]
+        return (lambda i: ops.softlight(pl[i % NB], dl[i % NB], w, h, 512, 0)), w * h * 3
+    if op == "yuv411":
+        m, o = rnd(h, (w >> 2) * 6), rnd(h, w * 4)
+        return (lambda i: ops.yuv411_to_rgb(m[i % NB], o[i % NB], w >> 2, h, out_order=0, out_alpha=1)), w * h * 6 // 4 + w * h * 4
+    if op == "premult_yuva":
+        ya = rnd(h, w * 4)
+        return (lambda i: ops.alpha_premult_yuva([ya[i % NB]], w, h, 589, 1, un=0)), w * h * 8
+    if op == "composite":
+        lay = [torch.randint(0, 256, (540, 960 * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(8)]
+        out = rnd(h, w * 4)
+        layers = [(lay[z], 960, 540, 120 * z, 60 * z, 0.75) for z in range(8)]
+        return (lambda i: ops.composite(out[i % NB], w, h, 4, layers)), 8 * 960 * 540 * 4 + w * h * 4
+    if op == "k2":
+        Y, U, V, o = rnd(h, w), rnd(h // 2, w // 2), rnd(h // 2, w // 2), rnd(h, w * 4)
+        lut = np.arange(256, dtype=np.uint8)[::-1].copy()
+        return (lambda i: ops.yuv420p_to_rgb(Y[i % NB], U[i % NB], V[i % NB], o[i % NB], w, h, lut=lut)), w * h * 3 // 2 + w * h * 4
+    if op in ("c3", "c4rgb24", "c4rgba"):
+        W, H = 3840, 2160
+        if op == "c3":
+            src, l2 = rnd(H, W * 4), rnd(1200, 1920 * 4)
+            d = [torch.zeros_like(t) for t in l2]
+            prm = ops.chain_params(W, H, W * 4, 1920, 1080, 1920 * 4, 1920 * 4, swap_rb=int(os.environ.get('C3_SWAP', '0')), interp=3 | 0x100, do_blur=0, bf=128, lut=None)
+            trk = [ops.chain_tracks([src[i]], [l2[i]], [d[i]]) for i in range(NB)]
+            return (lambda i, keep=(src, l2, d): ops.chain_canvas(prm, trk[i % NB], 1920, 1200, 0, 60)), W * H * 4 + 2 * 1920 * 1200 * 4      # keep: the tracks hold raw pointers
+        ps = 3 if op == "c4rgb24" else 4
+        a, b = rnd(H, W * ps), rnd(H, W * ps)
+        o = [torch.zeros_like(t) for t in a]
+        return (lambda i: ops.gauss5_colorkey(a[i % NB], b[i % NB], o[i % NB], W, H, ps, 0, 0.3, 0.8, (128, 128, 128))), W * H * ps * 3
+    if op.startswith("chain"):         # chainN: the headline chain on N tracks per launch
+        n = int(op[5:] or 1)
+        W, H = 3840, 2160
+        nb = 2
+        sets = []
+        for _ in range(nb):
+            srcs = [torch.randint(0, 256, (H, W * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
+            l2s = [torch.randint(0, 256, (1080, 1920 * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
+            ds = [torch.zeros_like(t) for t in l2s]
+            sets.append((srcs, l2s, ds, ops.chain_tracks(srcs, l2s, ds)))
+        prm = ops.chain_params(W, H, W * 4, 1920, 1080, 1920 * 4, 1920 * 4, swap_rb=int(os.environ.get('C3_SWAP', '1')), interp=3 | 0x100, do_blur=0, bf=128, lut=np.arange(256, dtype=np.uint8))
+        return (lambda i: ops.chain(prm, sets[i % nb][3])), n * (W * H * 4 + 2 * 1920 * 1080 * 4)
+    if op.startswith("pb:"):           # pb:SWxSH:DWxDH:interp  -- one gdk-pixbuf ratio
+        _, a_, b_, it = op.split(":")
+        sw, sh = (int(v) for v in a_.split("x"))
+        dw, dh = (int(v) for v in b_.split("x"))
+        src, dst = rnd(sh, sw * 4), rnd(dh, dw * 4)
+        return (lambda i: ops.pixbuf_scale(src[i % NB], dst[i % NB], sw, sh, dw, dh, channels=4, interp=int(it))), sw * sh * 4 + dw * dh * 4
+    raise SystemExit("unknown op " + op)
+
 
 def main():
     op = sys.argv[1] if len(sys.argv) > 1 else "edge"
     ops.init(0)
-    g = torch.Generator(device="cuda")
-    g.manual_seed(3)
-    w, h = 1920, 1080
-    if op == "edge":
-        src = torch.randint(0, 256, (h, w * 4), dtype=torch.uint8, device="cuda", generator=g)
-        dst = torch.zeros_like(src)
-        for _ in range(200):
-            ops.edge(src, dst, w, h, 3, 0)
-    elif op == "softlight":
-        pl = [torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda", generator=g)] + [torch.randint(0, 256, (h // 2, w // 2), dtype=torch.uint8, device="cuda", generator=g) for _ in range(2)]
-        dl = [torch.zeros_like(t) for t in pl]
-        for _ in range(200):
-            ops.softlight(pl, dl, w, h, 512, 0)
+    fn, _ = case(op)
+    for i in range(200):
+        fn(i)
     torch.cuda.synchronize()
 
 
