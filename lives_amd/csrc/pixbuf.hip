@@ -54,13 +54,26 @@ __device__ __forceinline__ uint32_t pb_load_px(const uint8_t *row, int x) {
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
 }
 
+// fl(1.0 / (double)a) for an integer 1 <= a < 2^24 -- the library's `1.0 / (double)a`, correctly rounded -- in five operations instead of the eleven of the compiler's
+// IEEE division (scale, fix-up and the denormal / overflow handling are not needed for this range): the hardware estimate (2^-26 or better) and two Newton steps
+// in fused multiply-adds.  Why the last step rounds correctly: e1 = 1 - a y1 is exact (a y1 has at most 77 bits and differs from 1 by ~2^-50), so the fma rounds
+// the REAL number (1 / a)(1 - e1^2) once; and 1 / a for a 24-bit integer a that is not a power of two lies at least 2^-25 ulp away from every rounding boundary,
+// far more than e1^2 ~ 2^-100.  Checked against the division for every a of the range on the device (lgpu_debug_recip_check, tests/test_pixbuf_scale.py).
+__device__ __forceinline__ double pb_recip(uint32_t a) {
+  const double x = (double)a;
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
 // the accumulators of one destination pixel -> its bytes, packed c0 | c1 << 8 | c2 << 16 | alpha << 24
 template <int CH>
 __device__ __forceinline__ uint32_t pb_finish_px(unsigned r, unsigned g, unsigned b, unsigned a, bool edge, unsigned rnd) {
   if (CH == 4) {
     uint32_t o = 0;
     if (a) {
-      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : 1.0 / (double)a;      // every tap opaque (the common frame): fl(1 / a) is a constant, no division
+      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : pb_recip(a);      // every tap opaque (the common frame): fl(1 / a) is a constant; otherwise the five-operation reciprocal (a <= 0xFF0000)
       o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
     }
     return o;
@@ -74,7 +87,7 @@ __device__ __forceinline__ void pb_finish(uint8_t *d, unsigned r, unsigned g, un
     uint32_t o = 0;
     if (a) {
       // every tap opaque (the common frame): a = 255 * 65536 and fl(1 / a) is a constant -- the same double the division returns, without the division
-      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : 1.0 / (double)a;
+      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : pb_recip(a);
       o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
     }
     *reinterpret_cast<uint32_t *>(d) = o;
@@ -279,19 +292,6 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
   }
 }
 
-// fl(1.0 / (double)a) for an integer 1 <= a < 2^24 -- the library's `1.0 / (double)a`, correctly rounded -- in five operations instead of the eleven of the compiler's
-// IEEE division (scale, fix-up and the denormal / overflow handling are not needed for this range): the hardware estimate (2^-26 or better) and two Newton steps
-// in fused multiply-adds.  Why the last step rounds correctly: e1 = 1 - a y1 is exact (a y1 has at most 77 bits and differs from 1 by ~2^-50), so the fma rounds
-// the REAL number (1 / a)(1 - e1^2) once; and 1 / a for a 24-bit integer a that is not a power of two lies at least 2^-25 ulp away from every rounding boundary,
-// far more than e1^2 ~ 2^-100.  Checked against the division for every a of the range on the device (lgpu_debug_recip_check, tests/test_pixbuf_scale.py).
-__device__ __forceinline__ double pb_recip(uint32_t a) {
-  const double x = (double)a;
-  double y = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-x, y, 1.0);
-  return __builtin_fma(y, e, y);
-}
 __global__ void k_pb_recip_check(uint32_t lo, uint32_t hi, unsigned long long *bad) {
   const uint32_t a = lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (a < lo || a >= hi || a == 0) return;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void k_pb_double(const PbHalfArgs A, const uin
       const uint32_t va = 3u * a3[4 * col + 3] + b1[4 * col + 3];
       uint32_t p = 0;
       if (va) {
-        const double ia = (va == 4080u) ? (1.0 / 4080.0) : 1.0 / (double)va;
+        const double ia = (va == 4080u) ? (1.0 / 4080.0) : pb_recip(va);
         const uint32_t c0 = (uint32_t)(int)((double)(3u * a3[4 * col] + b1[4 * col]) * ia), c1 = (uint32_t)(int)((double)(3u * a3[4 * col + 1] + b1[4 * col + 1]) * ia),
                        c2 = (uint32_t)(int)((double)(3u * a3[4 * col + 2] + b1[4 * col + 2]) * ia);
         p = c0 | (c1 << 8) | (c2 << 16) | ((va >> 4) << 24);
