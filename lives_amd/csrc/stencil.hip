@@ -95,6 +95,91 @@ __global__ __launch_bounds__(kBlock) void k_softlight(const uint8_t *src, int ir
     for (int j = 0; j < 4 && j < n; j++) d[j] = out[j];
 }
 
+// k_softlight_s -- the same filter on 4-aligned luma planes without LDS and without a barrier (round 4).  A lane owns FOUR columns (one dword of luma) and a wave a band
+// of RB rows: the RB + 2 rows the band needs are requested up front, a row's left / right neighbours come from the adjacent lanes (DPP wave shifts + v_alignbyte; lanes
+// 0 and 63 only feed their neighbours), the 3 x 3 sums run on pixel PAIRS in packed 16-bit lanes (|row0| <= 765, |row1| <= 1275), row0^2 + row1^2 is one
+// v_dot2_i32_i16, the integer square root is the truncated float square root (exact for n < 2.3 M: checked exhaustively on the host, tests/test_host_cpu.py), and
+// (64 s + 192 v) >> 8 == (s + 3 v) >> 2.  57 -> ~22 vector operations per pixel; one 1080p 4:2:0 frame 6.2 -> see profiles/r04/ops_roofline.md.
+typedef short sl_s2 __attribute__((ext_vector_type(2)));
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_softlight_s(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int ymin, int ymax, SoftCopy cp) {
+  if (blockIdx.z) {          // the planes that are only copied: 256 x 16 tiles of plane z - 1, sixteen bytes per thread
+    const int pz = blockIdx.z - 1, ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 16, y = blockIdx.y * 16 + ly, x = blockIdx.x * 256 + lx;
+    if (y >= cp.h || x >= cp.w) return;
+    const uint8_t *ps = cp.src[pz] + (size_t)y * cp.irow[pz] + x;
+    uint8_t *pd = cp.dst[pz] + (size_t)y * cp.orow[pz] + x;
+    if (x + 16 <= cp.w && (((uintptr_t)ps | (uintptr_t)pd) & 15) == 0) *reinterpret_cast<uint4 *>(pd) = *reinterpret_cast<const uint4 *>(ps);
+    else for (int j = 0; j < 16 && x + j < cp.w; j++) pd[j] = ps[j];
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nq = width >> 2;                                       // dwords per row (width % 4 == 0 on this path)
+  if ((int)blockIdx.x * 62 >= nq) return;                          // the grid is as wide as the widest plane wants it
+  const int q = blockIdx.x * 62 - 1 + lane;                        // this lane's dword; lanes 0 and 63 are feeders
+  const int qc = q < 0 ? 0 : q >= nq ? nq - 1 : q;
+  const int y0 = (blockIdx.y * 4 + wave) * RB;
+  if (y0 >= height) return;
+  const int rows = min(RB, height - y0);
+  const bool out_lane = lane >= 1 && lane <= 62 && q < nq;
+  uint32_t in[RB + 2];
+#pragma unroll
+  for (int r = 0; r < RB + 2; r++) {
+    int sy = y0 - 1 + r;
+    sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy >= height ? height - 1 : sy);      // clamped rows only feed border rows, which are copies
+    in[r] = reinterpret_cast<const uint32_t *>(src + (size_t)sy * irow)[qc];
+  }
+  // per source row: the row shifted right / left by one pixel, then everything as pixel pairs in 16-bit lanes: e = (pixel 0, pixel 2), o = (pixel 1, pixel 3)
+  uint32_t Le[RB + 2], Lo[RB + 2], Ce[RB + 2], Co[RB + 2], Re[RB + 2], Ro[RB + 2];
+#pragma unroll
+  for (int r = 0; r < RB + 2; r++) {
+    const uint32_t c = in[r];
+    const uint32_t ql = (uint32_t)__builtin_amdgcn_mov_dpp((int)c, 0x138, 0xF, 0xF, true), qr = (uint32_t)__builtin_amdgcn_mov_dpp((int)c, 0x130, 0xF, 0xF, true);
+    const uint32_t l = __builtin_amdgcn_alignbyte(c, ql, 3), rr = __builtin_amdgcn_alignbyte(qr, c, 1);      // byte k = pixel k - 1 / pixel k + 1
+    Le[r] = l & 0x00FF00FFu; Lo[r] = (l >> 8) & 0x00FF00FFu;
+    Ce[r] = c & 0x00FF00FFu; Co[r] = (c >> 8) & 0x00FF00FFu;
+    Re[r] = rr & 0x00FF00FFu; Ro[r] = (rr >> 8) & 0x00FF00FFu;
+  }
+  // frame-border pixels keep their value: byte mask of this lane's border columns
+  const uint32_t xmask = (q == 0 ? 0x000000FFu : 0u) | (q == nq - 1 ? 0xFF000000u : 0u);
+  auto pk = [](uint32_t v) -> sl_s2 { return __builtin_bit_cast(sl_s2, v); };
+  auto un = [](sl_s2 v) -> uint32_t { return __builtin_bit_cast(uint32_t, v); };
+#pragma unroll
+  for (int r = 0; r < RB; r++) {
+    if (r >= rows) break;
+    const int y = y0 + r;
+    uint32_t out = in[r + 1];
+    if (y > 0 && y < height - 1) {                                  // uniform
+      uint32_t res[4];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {                                 // h = 0: pixels 0 and 2, h = 1: pixels 1 and 3
+        const sl_s2 AL = pk(h ? Lo[r] : Le[r]), AC = pk(h ? Co[r] : Ce[r]), AR = pk(h ? Ro[r] : Re[r]);
+        const sl_s2 CL = pk(h ? Lo[r + 1] : Le[r + 1]), CC = pk(h ? Co[r + 1] : Ce[r + 1]), CR = pk(h ? Ro[r + 1] : Re[r + 1]);
+        const sl_s2 BL = pk(h ? Lo[r + 2] : Le[r + 2]), BC = pk(h ? Co[r + 2] : Ce[r + 2]), BR = pk(h ? Ro[r + 2] : Re[r + 2]);
+        // softlight.c:115-120 as written: row0 = (S[+1][-1] - S[-1][-1]) + 2 (S[+1][0] - S[-1][0]) + (S[+1][+1] - S[+1][-1]); row1's third term is a SUM
+        const sl_s2 row0 = (BC - AC) * (short)2 + (BR - AL);
+        const sl_s2 row1 = (CR - CL) * (short)2 + (AR - AL) + (BR + BL);
+        const uint32_t r0 = un(row0), r1 = un(row1);
+        const uint32_t xa = __builtin_amdgcn_perm(r1, r0, 0x05040100u), xb = __builtin_amdgcn_perm(r1, r0, 0x07060302u);      // (row0, row1) of the pair's first / second pixel
+        const uint32_t cc = un(CC);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          const uint32_t xx = p ? xb : xa;
+          const uint32_t n = (uint32_t)__builtin_amdgcn_sdot2(pk(xx), pk(xx), 0, false);
+          const uint32_t sq = (uint32_t)__fsqrt_rn((float)n);
+          int sum = (int)((((3u * sq) >> 1) * 3u) >> 1);            // ((3 sq / 2) * 384) >> 8
+          sum = sum < ymin ? ymin : sum > ymax ? ymax : sum;
+          const int v = (int)((p ? cc >> 16 : cc) & 0xFFFFu);
+          sum = (sum + 3 * v) >> 2;                                  // (64 sum + 192 v) >> 8
+          res[2 * p + h] = (uint32_t)(sum < ymin ? ymin : sum > ymax ? ymax : sum);
+        }
+      }
+      const uint32_t calc = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+      out = (calc & ~xmask) | (out & xmask);
+    }
+    if (out_lane) reinterpret_cast<uint32_t *>(dst + (size_t)y * orow)[q] = out;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // edge detect
 // ---------------------------------------------------------------------------------------------------------------------
@@ -603,6 +688,18 @@ extern "C" int lgpu_softlight(const uint8_t *const src_d[4], const int irow[4], 
   cp.h = (palette == 512 || palette == 513) ? height >> 1 : height;
   cp.n = nplanes - 1;
   for (int i = 1; i < nplanes; i++) { cp.src[i - 1] = src_d[i]; cp.dst[i - 1] = dst_d[i]; cp.irow[i - 1] = irow[i]; cp.orow[i - 1] = orow[i]; }
+  // 4-aligned luma planes: the register form (k_softlight_s); everything else the LDS tile kernel
+  if ((width & 3) == 0 && width >= 8 && ((((uintptr_t)src_d[0] | (uintptr_t)dst_d[0]) | (unsigned)irow[0] | (unsigned)orow[0]) & 3) == 0 && !tune_on(TUNE_SOFT_NO_S)) {
+    const int rbt = tune(TUNE_SOFT_RB), rb = (rbt & 15) == 4 ? 4 : 2;
+    const unsigned strips = cdiv((unsigned)(width >> 2), 62u), bands = cdiv((unsigned)height, (unsigned)(4 * rb));
+    const unsigned cx = cdiv((unsigned)cp.w, 256u), cy = cdiv((unsigned)cp.h, 16u);     // the copy planes' tiles must fit the same grid
+    dim3 gs(strips > cx ? strips : cx, bands > cy ? bands : cy, (unsigned)nplanes);
+    if (rbt >= 16) gs = dim3(strips, bands, 1);          // probe: luma only
+    if (rb == 4) hipLaunchKernelGGL(k_softlight_s<4>, gs, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
+    else hipLaunchKernelGGL(k_softlight_s<2>, gs, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
   const dim3 grid(cdiv((unsigned)width, kStW), cdiv((unsigned)height, kStH), (unsigned)nplanes);
   hipLaunchKernelGGL(k_softlight, grid, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16,
                      unclamped ? 255 : 235, cp);

@@ -764,10 +764,17 @@ def test_yuv_switch_clamping(gpu, orc, palette):
 
 
 # ---------------------------------------------------------------------------------------------- F6 stencils
+@pytest.mark.parametrize("shape", ["rb2", "rb4", "tiles"])
 @pytest.mark.parametrize("palette", [544, 545, 522, 512, 513])
-def test_softlight(gpu, orc, palette):
+def test_softlight(gpu, orc, tune, palette, shape):
+    """4-aligned planes take the register form k_softlight_s (bands of 2 or 4 rows per wave, strips of 248 columns: widths that end inside a strip, several strips,
+    heights that end inside a band), everything else -- and everything when the switch says so -- the LDS tile kernel"""
+    if shape == "rb4":
+        tune("SOFT_RB", 4)
+    elif shape == "tiles":
+        tune("SOFT_NO_S", 1)
     rng = np.random.default_rng(1500 + palette)
-    for (w, h) in [(20, 9), (64, 16), (66, 34), (130, 50), (4, 3), (258, 33)]:
+    for (w, h) in [(20, 9), (64, 16), (66, 34), (130, 50), (4, 3), (258, 33), (256, 40), (1000, 21), (1920, 30), (252, 7), (8, 3), (496, 11), (500, 5)]:
         for unclamped in (0, 1):
             cw = w >> 1 if palette in (512, 513, 522) else w
             ch = h >> 1 if palette in (512, 513) else h

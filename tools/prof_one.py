@@ -21,6 +21,11 @@ def case(op):
 
     def rnd(rows, cols):
         return [torch.randint(0, 256, (rows, cols), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NB)]
+    if op.startswith("copy"):          # copyN: a plain copy of a 1920 x 1080 frame of N-byte pixels -- the floor of a single-frame launch by this measurement
+        n = int(op[4:] or 1)
+        from lives_amd import lib
+        a_, b_ = rnd(h, w * n), rnd(h, w * n)
+        return (lambda i: lib.call("lgpu_copy_rows", b_[i % NB].data_ptr(), w * n, a_[i % NB].data_ptr(), w * n, w * n, h, ops.stream_ptr())), 2 * w * h * n
     if op == "edge":
         src, dst = rnd(h, w * 4), rnd(h, w * 4)
         return (lambda i: ops.edge(src[i % NB], dst[i % NB], w, h, 3, 0)), w * h * 16
