@@ -446,6 +446,9 @@ int lgpu_stepper_feed(lgpu_stepper *s, const int32_t *values, int n);
 /* next_values: the block of the following step (read on the root only) when no feed has brought it yet; NULL on every rank after the last step or when
    lgpu_stepper_feed is used.  params->param_block_d is replaced by the stepper's block. */
 int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks);
+/* a second launch stream: odd steps go there, so that the drain of one frame's launch overlaps the ramp-up of the next (frames of consecutive steps are independent).
+   NULL switches it off.  The caller synchronises both streams before reading results. */
+int lgpu_stepper_overlap(lgpu_stepper *s, void *second_launch_stream);
 const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 64 (tests); NULL for a negative index */
 int lgpu_stepper_destroy(lgpu_stepper *s);
 

@@ -206,6 +206,7 @@ struct PbHalfArgs {
   int main_blocks, bar_blocks;   // workgroups of the frame proper / per track of the bars (1024 canvas pixels each)
   int bar_first;                 // the bars' workgroups come FIRST in the grid (a multiple of 8, so the frame's workgroups keep their XCD): they run while the frame's first loads are in flight
   int nt_out;
+  int nt_in;                     // probe (LGPU_PBH_NT_IN): non-temporal loads for a band's inner source rows
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
 };
 struct PbTracks {
@@ -406,6 +407,10 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     // plain loads: measured faster than non-temporal ones (band seams and strip halos are re-read through L2)
     return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow, (PBH_LOAD_AUX));
   };
+  auto load_row_nt = [&](int sy) -> pb_u4 {      // probe (A.nt_in): a band's INNER rows are read once by this launch; the two pairs it shares with its neighbours stay in L2's normal policy
+    sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
+    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow, 2);
+  };
   // ALIGNED: the pixel left of the strip (lane 0) / right of it (lane 63), clamped into the row -- which is the library's edge rule at the frame's two ends
   const bool e_lane = HYPER && ALIGNED && (lane == 0 || lane == 63);
   const int e_x = lane == 0 ? 4 * k - 1 : 4 * k + 4;
@@ -516,7 +521,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     auto one = [&](int r, pb_u4 &ca, pb_u4 &cb, uint32_t &cea, uint32_t &ceb, pb_u2 &cl2, pb_u4 &xa, pb_u4 &xb, uint32_t &xea, uint32_t &xeb, pb_u2 &xl2) __attribute__((always_inline)) {
       const int yy = d > 0 ? ystart + r : ystart - r;
       if (r + 1 < rows) {       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
-        xa = load_row(S0 + d * (2 * r + 4)); xb = load_row(S0 + d * (2 * r + 5));
+        if (A.nt_in && r + 2 < rows) { xa = load_row_nt(S0 + d * (2 * r + 4)); xb = load_row_nt(S0 + d * (2 * r + 5)); }       // uniform
+        else { xa = load_row(S0 + d * (2 * r + 4)); xb = load_row(S0 + d * (2 * r + 5)); }
         xea = load_e(S0 + d * (2 * r + 4)); xeb = load_e(S0 + d * (2 * r + 5));
         if (CHAIN) xl2 = load_l2(yy + d);
       }
@@ -1634,6 +1640,14 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
   a.nt_out = 1;
+  // non-temporal loads for a band's inner source rows: measured by tracks per launch on 4K sources (profiles/r04/nt_inner_rows_by_tracks.txt, interleaved): 2-4 tracks
+  // +1-4 % (slower), 6 / 8 / 10 tracks -11 / -13 / -11 %, 12 tracks -3 %, 16 tracks +2 %: a gain where the launch's source bytes are about 0.6-1.8 x the 256 MiB
+  // Infinity Cache (streaming reads then no longer push layer 2 and the other rotating frames out of it), a small loss where they are far below or above it
+  {
+    const unsigned long long src_bytes = (unsigned long long)pr->irow * pr->sh * ntracks;
+    a.nt_in = (src_bytes >= 160ull << 20 && src_bytes <= 460ull << 20) ? 1 : 0;
+    if (tune(TUNE_PBH_NT_IN) >= 0) a.nt_in = tune(TUNE_PBH_NT_IN) ? 1 : 0;
+  }
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
@@ -1838,7 +1852,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     PbHalfArgs h;
     if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
-      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0;
       pb_half_geometry(&h, 1);
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;

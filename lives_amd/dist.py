@@ -106,6 +106,11 @@ class Stepper:
                 flat[4 * i + j] = int(r[j])
         self.lib.call("lgpu_stepper_feed", self.h, flat, n)
 
+    def overlap(self, second_stream):
+        """lgpu_stepper_overlap: odd steps on a second launch stream (a torch.cuda.Stream, or None to switch it off); synchronise both before reading results"""
+        self.lib.call("lgpu_stepper_overlap", self.h, second_stream.cuda_stream if second_stream is not None else None)
+        self._second = second_stream
+
     def block_ptr(self, which):
         return self.lib.load().lgpu_stepper_block(self.h, which)
 

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "lgpu_stepper_create": [vp, ci, ci, vp, vp, ctypes.POINTER(vp)],
     "lgpu_chain_step": [vp, vp, vp, vp, ci],
     "lgpu_stepper_feed": [vp, vp, ci],
+    "lgpu_stepper_overlap": [vp, vp],
     "lgpu_params_set_n": [vp, vp, ci, vp],
     "lgpu_params_broadcast_n": [vp, ci, vp, ci, vp],
     "lgpu_stepper_block": [vp, ci],

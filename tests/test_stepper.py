@@ -10,9 +10,10 @@ P = po.P
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("ahead", [1, 5, 16])
 @pytest.mark.parametrize("exchange", [0, 1])
-def test_steps_use_the_block_of_their_own_step(gpu, orc, exchange, ahead):
+def test_steps_use_the_block_of_their_own_step(gpu, orc, exchange, ahead, overlap):
     import torch
     from lives_amd import dist as ld
     rng = np.random.default_rng(0x57E9 + exchange)
@@ -32,6 +33,8 @@ def test_steps_use_the_block_of_their_own_step(gpu, orc, exchange, ahead):
             wants[(bf, i)] = w_
     prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3, do_blur=0, bf=1, lut=None)      # bf = 1 must never be used
     st = ld.Stepper(comm, [schedule[0]])
+    if overlap:                         # odd steps on a second launch stream (lgpu_stepper_overlap)
+        st.overlap(torch.cuda.Stream())
     try:
         fed = 1
         for s, bf in enumerate(schedule):

@@ -8,7 +8,7 @@
  * writes the 128-byte communicator id to LGPU_ID_FILE and the others read it: no Python, no MPI.
  *
  * build: gcc -O2 -o tools/_worker tools/worker.c -Iinclude -Llives_amd -llivesgpu -Wl,-rpath,$PWD/lives_amd
- * run  : tools/_worker [--tracks 1] [--steps 2000] [--exchange 1] [--pixbuf 1] [--ahead 16]      (--ahead n: the blocks of n steps per exchange, lgpu_stepper_feed;
+ * run  : tools/_worker [--tracks 1] [--steps 2000] [--exchange 1] [--pixbuf 1] [--ahead 16] [--overlap 1]      (--ahead n: the blocks of n steps per exchange, lgpu_stepper_feed;
  *                                                                                                  1 = one block ahead, through lgpu_chain_step's next_values)
  */
 #include <stdio.h>
@@ -23,19 +23,23 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 static int envi(const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; }
 
 int main(int argc, char **argv) {
-  int tracks = 1, steps = 2000, exchange = 1, pixbuf = 1, ahead = 16;
+  int tracks = 1, steps = 2000, exchange = 1, pixbuf = 1, ahead = 16, overlap = 1;
   for (int i = 1; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--tracks")) tracks = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--exchange")) exchange = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--pixbuf")) pixbuf = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--ahead")) ahead = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--overlap")) overlap = atoi(argv[i + 1]);
   }
   const int rank = envi("RANK", 0), world = envi("WORLD_SIZE", 1), local = envi("LOCAL_RANK", rank);
   const int SW = 3840, SH = 2160, DW = 1920, DH = 1080, NSETS = 2;
   CHECK(lgpu_init(local));
-  void *stream;
+  void *stream, *stream2 = NULL;
   CHECK(lgpu_stream_create(&stream, 1));
+  /* the second launch stream right behind the first: HIP deals its few hardware queues out to streams in creation order, and two launch streams that end up on
+     the same queue do not overlap (measured: created after the communicator's streams they shared one) */
+  if (overlap) CHECK(lgpu_stream_create(&stream2, 1));
 
   /* device-resident synthetic tracks, two rotating sets */
   lgpu_chain_track *trk = calloc((size_t)NSETS * tracks, sizeof *trk);
@@ -96,6 +100,8 @@ int main(int argc, char **argv) {
   if (ahead > 32) ahead = 32;
   lgpu_stepper *st;
   CHECK(lgpu_stepper_create(comm, 0, rank, stream, v, &st));
+  if (overlap) CHECK(lgpu_stepper_overlap(st, stream2));      /* odd steps on the second launch stream */
+#define SYNC() do { CHECK(lgpu_sync(stream)); if (stream2) CHECK(lgpu_sync(stream2)); } while (0)
   long fed = 1;                                  /* blocks handed over so far (the first one by lgpu_stepper_create) */
   int32_t sched[32 * 4];
   /* one step: feed the blocks of the next `ahead` steps when the last fed one is about to be used, then launch */
@@ -105,11 +111,11 @@ int main(int argc, char **argv) {
     CHECK(lgpu_chain_step(st, ahead > 1 ? NULL : v, &prm, trk + ((s_) % NSETS) * tracks, tracks)); } while (0)
   long s = 0;
   for (; s < 300; s++) STEP(s);                  /* device wake-up */
-  CHECK(lgpu_sync(stream));
+  SYNC();
   const double t0 = now();
   for (; s < 300 + steps; s++) STEP(s);
   const double t_enq = now();
-  CHECK(lgpu_sync(stream));
+  SYNC();
   const double t1 = now();
   /* host cost alone: the same calls with the stream left to drain in between (enqueue never blocks on a full queue) */
   double host = 0;
@@ -117,13 +123,13 @@ int main(int argc, char **argv) {
     const double a = now();
     STEP(s);
     host += now() - a;
-    if ((i & 15) == 15) CHECK(lgpu_sync(stream));
+    if ((i & 15) == 15) SYNC();
   }
-  CHECK(lgpu_sync(stream));
+  SYNC();
   if (rank == 0)
-    printf("{\"tool\": \"worker.c\", \"world\": %d, \"tracks_per_step\": %d, \"exchange\": \"%s\", \"resize\": \"%s\", \"blocks_per_exchange\": %d, \"steps\": %d, \"us_per_step\": %.2f, "
+    printf("{\"tool\": \"worker.c\", \"world\": %d, \"tracks_per_step\": %d, \"exchange\": \"%s\", \"resize\": \"%s\", \"blocks_per_exchange\": %d, \"launch_streams\": %d, \"steps\": %d, \"us_per_step\": %.2f, "
            "\"frames_per_s_per_gpu\": %.0f, \"enqueue_us_per_step\": %.2f, \"host_us_per_step_idle_queue\": %.2f}\n",
-           world, tracks, exchange ? (world > 1 ? "rccl broadcast" : "rccl broadcast (one-rank communicator)") : "none", pixbuf ? "pixbuf" : "polyphase", ahead, steps,
+           world, tracks, exchange ? (world > 1 ? "rccl broadcast" : "rccl broadcast (one-rank communicator)") : "none", pixbuf ? "pixbuf" : "polyphase", ahead, overlap ? 2 : 1, steps,
            (t1 - t0) / steps * 1e6, tracks * steps / (t1 - t0), (t_enq - t0) / steps * 1e6, host / 256 * 1e6);
   CHECK(lgpu_stepper_destroy(st));
   if (comm) CHECK(lgpu_dist_comm_destroy(comm));
