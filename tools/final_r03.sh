@@ -3,7 +3,7 @@
 # chain / the polyphase chain / tools/bench_ops.py, the op table, the resize tables, the HBM streams, the C worker
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
-C=$(cat gpurun_out/.commit 2>/dev/null || echo unknown)
+C=$(cat tools/_commit 2>/dev/null || echo unknown)
 # first, on the fresh box: the profiled run (its own bench line sits in trace.log) and right behind it the plain default bench
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_first -o t -- python bench.py --no-cpu > $O/bench_line_inside_the_rocprofv3_run.log 2>&1

@@ -3,7 +3,7 @@
 # the launch, PMC passes + traffic json of the current build, bench lines of the other shapes, the forced-exchange N > 1 host path, the C worker, the op timings
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final_r04; mkdir -p $O
-C=$(cat gpurun_out/.commit 2>/dev/null || echo unknown)
+C=$(cat tools/_commit 2>/dev/null || echo unknown)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_first -o t -- python bench.py --no-cpu > $O/bench_line_inside_the_rocprofv3_run.log 2>&1
 cp $O/trace_first/t_kernel_stats.csv $O/final_kernel_stats.csv
