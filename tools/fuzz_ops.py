@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None        # optional: restrict the run to these kinds
     import torch
     from lives_amd import ops
     from lives_amd.lib import LgpuError, load
@@ -51,8 +52,13 @@ def main():
     counts = {}
     for it in range(iters):
         kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411", "pixbuf", "pixbuf", "chainpb", "chainpb", "canvas", "c4"]))
+        if only and kind not in only:
+            continue
         counts[kind] = counts.get(kind, 0) + 1
         ops.tuning("PBH_ALIGNED", 1 if rng.random() < 0.5 else 0)          # both strip forms of k_pb_half at every size
+        ops.tuning("PBH_LOADER", int(rng.choice([0, 0, 3, 4, 6, 20])))      # the loader-wave form, rings of 3 / 4 / 6 row pairs, non-temporal inner rows
+        ops.tuning("PBH_NT_IN", int(rng.choice([0, 1])))                    # non-temporal inner rows in the register form
+        ops.tuning("PBH_TH", int(rng.choice([1, 2, 3, 5, 6, 7, 12, 24])) if rng.random() < 0.5 else None)       # forced band heights
         try:
             if kind == "resize":
                 ps = int(rng.choice([1, 3, 4]))
