@@ -105,6 +105,14 @@ def main():
         keep.append((srcs, l2s, dsts))
         trks.append(ops.chain_tracks(srcs, l2s, dsts))
 
+    def groups_of(n):
+        """The frames of all buffer sets as launches of n tracks each (the 8-track and one-frame legs rotate through ALL of them, like the 16-track steps do)."""
+        out = []
+        for srcs, l2s, dsts in keep:
+            for i in range(0, T - n + 1, n):
+                out.append(ops.chain_tracks(srcs[i:i + n], l2s[i:i + n], dsts[i:i + n]))
+        return out
+
     from lives_amd.lib import load
     lut = np.zeros(256, np.uint8)
     assert load().lgpu_gamma_lut8(1.0, -1, 1, 1.4, lut.ctypes.data) == 1     # WEED_GAMMA_LINEAR -> WEED_GAMMA_SRGB
@@ -204,7 +212,7 @@ def main():
     if multi and stepper is not None:
         stepper.close()
         stepper = None
-        one = [ops.chain_tracks([k[0][0]], [k[1][0]], [k[2][0]]) for k in keep]
+        one = groups_of(1)                    # every frame of every buffer set in turn: the one-frame launches, too, see buffers the memory-side cache has long lost
         n5 = max(args.steps, 200)
         st5 = ld.Stepper(comm, sched_host[0], stream=launch_a)
         st5.overlap(launch_b)                 # odd steps on the second launch stream: consecutive frames are independent, the drain of one launch overlaps the ramp-up of the next
@@ -216,7 +224,7 @@ def main():
                 k = min(AHEAD, tot5 - f5)
                 st5.feed([sched_host[(f5 + j) % nsched] for j in range(k)])
                 f5 += k
-            st5.step(None, prm, one[i % nsets])
+            st5.step(None, prm, one[i % len(one)])
         for i in range(50):
             step5(i)
         fence()
@@ -261,18 +269,18 @@ def main():
     batch8 = None
     if T >= 8:
         prm.param_block_d = sched_base if world == 1 else pblock.data_ptr()
-        t8 = [ops.chain_tracks(k[0][:8], k[1][:8], k[2][:8]) for k in keep]
-        for i in range(10):
-            ops.chain(prm, t8[i % nsets])
+        t8 = groups_of(8)                     # 16 tracks x 2 sets = four 8-track groups, 1.6 GB: with two groups the 256 MiB memory-side cache still holds part of a group when its turn
+        for i in range(10):                   # comes again (tools/sets_ab.sh, profiles/r04/sets_ab.txt: 8 tracks 69 us over two groups, 82 us over four or more; 16 tracks 156 us either way)
+            ops.chain(prm, t8[i % len(t8)])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n8 = 20          # few launches: they carry the same kernel name as the 16-track launch in a rocprofv3 --stats run (30 of ~1,600: the average moves by < 1 %)
         e0.record()
         for i in range(n8):
-            ops.chain(prm, t8[i % nsets])
+            ops.chain(prm, t8[i % len(t8)])
         e1.record()
         torch.cuda.synchronize()
         us8 = e0.elapsed_time(e1) * 1e3 / n8
-        batch8 = {"batch8_1gpu_fps": round(8e6 / us8, 1), "batch8_1gpu_us_per_step": round(us8, 2)}
+        batch8 = {"batch8_1gpu_fps": round(8e6 / us8, 1), "batch8_1gpu_us_per_step": round(us8, 2), "batch8_groups_rotated": len(t8)}
 
     # what this box's memory system gives the launch's own algorithmic bytes as a bare stream (no arithmetic, no re-reads): tells a slow box from a regression
     box = None

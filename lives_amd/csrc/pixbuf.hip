@@ -1640,14 +1640,11 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
   a.nt_out = 1;
-  // non-temporal loads for a band's inner source rows: measured by tracks per launch on 4K sources (profiles/r04/nt_inner_rows_by_tracks.txt, interleaved): 2-4 tracks
-  // +1-4 % (slower), 6 / 8 / 10 tracks -11 / -13 / -11 %, 12 tracks -3 %, 16 tracks +2 %: a gain where the launch's source bytes are about 0.6-1.8 x the 256 MiB
-  // Infinity Cache (streaming reads then no longer push layer 2 and the other rotating frames out of it), a small loss where they are far below or above it
-  {
-    const unsigned long long src_bytes = (unsigned long long)pr->irow * pr->sh * ntracks;
-    a.nt_in = (src_bytes >= 160ull << 20 && src_bytes <= 460ull << 20) ? 1 : 0;
-    if (tune(TUNE_PBH_NT_IN) >= 0) a.nt_in = tune(TUNE_PBH_NT_IN) ? 1 : 0;
-  }
+  // non-temporal loads for a band's inner source rows: OFF unless LGPU_PBH_NT_IN / lgpu_tuning_set asks.  Mid-round they were on for 160-460 MiB of source per launch
+  // (profiles/r04/nt_inner_rows_by_tracks.txt: 6-10 tracks 11-13 % faster) -- measured on TWO rotating buffer sets, where the 256 MiB memory-side cache still held part
+  // of a set when its turn came again and streaming reads pushed less of it out.  On buffers that cache has long lost (four or more sets: a frame that was just uploaded)
+  // they cost 1-2 % at every track count (profiles/r04/nt_cold_ab.txt), and that is the case a host presents
+  a.nt_in = tune(TUNE_PBH_NT_IN) > 0 ? 1 : 0;
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """tools/bench_one.py <op> [<op> ...] -- device time per launch of single entry points (the cases of tools/prof_one.py) by HIP-graph replay over rotating buffers:
-no host time between the kernels.  Prints one line per op: us, GB/s of algorithmic bytes, fraction of 8 TB/s.  LGPU_* switches apply (read once per process)."""
+no host time between the kernels.  Prints one line per op: us, GB/s of algorithmic bytes, fraction of 8 TB/s.  LGPU_* switches apply (read once per process).
+--cold (first argument): as many buffer sets per op as make 1.6 GB -- every launch then reads bytes the 256 MiB memory-side cache has long lost; the default six
+sets of a 1080p op (under 100 MB together) stay inside that cache from one replay to the next, which a frame that has just been uploaded does not."""
 import os
 import sys
 
@@ -14,7 +16,18 @@ import prof_one      # noqa: E402
 
 def main():
     ops.init(0)
-    for op in sys.argv[1:]:
+    names = sys.argv[1:]
+    cold = bool(names) and names[0] == "--cold"
+    if cold:
+        names = names[1:]
+    for op in names:
+        prof_one.NB = 6
+        if cold:
+            prof_one.NB = 1
+            _, nbytes = prof_one.case(op)
+            prof_one.NB = max(4, int(1.6e9 / nbytes) + 1)
+            prof_one.COLD = True
+            torch.cuda.empty_cache()
         fn, nbytes = prof_one.case(op)
         for i in range(60):
             fn(i)
@@ -22,7 +35,7 @@ def main():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
-        per = 4 * prof_one.NB
+        per = 4 * prof_one.NB if prof_one.NB <= 8 else prof_one.NB
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
                 for i in range(per):
@@ -39,7 +52,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / (20 * per))
-        print("%-28s %7.2f us  %7.1f GB/s  %.3f of 8 TB/s" % (op, best, nbytes / best / 1e3, nbytes / best / 1e3 / 8000.0), flush=True)
+        print("%-28s %7.2f us  %7.1f GB/s  %.3f of 8 TB/s%s" % (op, best, nbytes / best / 1e3, nbytes / best / 1e3 / 8000.0, "   (cold: %d buffer sets)" % prof_one.NB if cold else ""), flush=True)
+        del fn, graph
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ import torch         # noqa: E402
 from lives_amd import ops   # noqa: E402
 
 NB = 6        # rotating buffer sets: consecutive launches do not read what the one before left in the caches
+COLD = False  # tools/bench_one.py --cold: NB is then as many sets as make 1.6 GB
 
 
 def case(op):
@@ -63,7 +64,7 @@ def case(op):
     if op.startswith("chain"):         # chainN: the headline chain on N tracks per launch
         n = int(op[5:] or 1)
         W, H = 3840, 2160
-        nb = 2
+        nb = NB if COLD else 2             # sets of n tracks
         sets = []
         for _ in range(nb):
             srcs = [torch.randint(0, 256, (H, W * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
