@@ -8,7 +8,7 @@
  * writes the 128-byte communicator id to LGPU_ID_FILE and the others read it: no Python, no MPI.
  *
  * build: gcc -O2 -o tools/_worker tools/worker.c -Iinclude -Llives_amd -llivesgpu -Wl,-rpath,$PWD/lives_amd
- * run  : tools/_worker [--tracks 1] [--steps 2000] [--exchange 1] [--pixbuf 1] [--ahead 16] [--overlap 1]      (--ahead n: the blocks of n steps per exchange, lgpu_stepper_feed;
+ * run  : tools/_worker [--tracks 1] [--steps 2000] [--exchange 1] [--pixbuf 1] [--ahead 16] [--overlap 1] [--sets N]      (--ahead n: the blocks of n steps per exchange, lgpu_stepper_feed;
  *                                                                                                  1 = one block ahead, through lgpu_chain_step's next_values)
  */
 #include <stdio.h>
@@ -23,7 +23,7 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 static int envi(const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; }
 
 int main(int argc, char **argv) {
-  int tracks = 1, steps = 2000, exchange = 1, pixbuf = 1, ahead = 16, overlap = 1;
+  int tracks = 1, steps = 2000, exchange = 1, pixbuf = 1, ahead = 16, overlap = 1, sets = 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--tracks")) tracks = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
@@ -31,9 +31,13 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--pixbuf")) pixbuf = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--ahead")) ahead = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--overlap")) overlap = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--sets")) sets = atoi(argv[i + 1]);
   }
   const int rank = envi("RANK", 0), world = envi("WORLD_SIZE", 1), local = envi("LOCAL_RANK", rank);
-  const int SW = 3840, SH = 2160, DW = 1920, DH = 1080, NSETS = 2;
+  const int SW = 3840, SH = 2160, DW = 1920, DH = 1080;
+  /* rotating buffer sets: 32 frames of each kind in all (1.6 GB) unless --sets says otherwise -- with two sets of one frame every byte stays in the 256 MiB memory-side cache
+     from one step to the next (8.8 instead of 10.2 us per one-frame step), which a frame that was just uploaded does not (profiles/r04/sets_ab.txt) */
+  const int NSETS = sets > 0 ? sets : (32 / tracks > 2 ? 32 / tracks : 2);
   CHECK(lgpu_init(local));
   void *stream, *stream2 = NULL;
   CHECK(lgpu_stream_create(&stream, 1));
@@ -41,7 +45,7 @@ int main(int argc, char **argv) {
      the same queue do not overlap (measured: created after the communicator's streams they shared one) */
   if (overlap) CHECK(lgpu_stream_create(&stream2, 1));
 
-  /* device-resident synthetic tracks, two rotating sets */
+  /* device-resident synthetic tracks, NSETS rotating sets */
   lgpu_chain_track *trk = calloc((size_t)NSETS * tracks, sizeof *trk);
   uint64_t *hostbuf = malloc((size_t)SW * SH * 4), rng = 0x11FE5ull + (uint64_t)rank;
   for (int i = 0; i < NSETS * tracks; i++) {
@@ -127,9 +131,9 @@ int main(int argc, char **argv) {
   }
   SYNC();
   if (rank == 0)
-    printf("{\"tool\": \"worker.c\", \"world\": %d, \"tracks_per_step\": %d, \"exchange\": \"%s\", \"resize\": \"%s\", \"blocks_per_exchange\": %d, \"launch_streams\": %d, \"steps\": %d, \"us_per_step\": %.2f, "
+    printf("{\"tool\": \"worker.c\", \"world\": %d, \"tracks_per_step\": %d, \"exchange\": \"%s\", \"resize\": \"%s\", \"blocks_per_exchange\": %d, \"launch_streams\": %d, \"buffer_sets\": %d, \"steps\": %d, \"us_per_step\": %.2f, "
            "\"frames_per_s_per_gpu\": %.0f, \"enqueue_us_per_step\": %.2f, \"host_us_per_step_idle_queue\": %.2f}\n",
-           world, tracks, exchange ? (world > 1 ? "rccl broadcast" : "rccl broadcast (one-rank communicator)") : "none", pixbuf ? "pixbuf" : "polyphase", ahead, overlap ? 2 : 1, steps,
+           world, tracks, exchange ? (world > 1 ? "rccl broadcast" : "rccl broadcast (one-rank communicator)") : "none", pixbuf ? "pixbuf" : "polyphase", ahead, overlap ? 2 : 1, NSETS, steps,
            (t1 - t0) / steps * 1e6, tracks * steps / (t1 - t0), (t_enq - t0) / steps * 1e6, host / 256 * 1e6);
   CHECK(lgpu_stepper_destroy(st));
   if (comm) CHECK(lgpu_dist_comm_destroy(comm));
