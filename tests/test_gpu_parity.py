@@ -810,6 +810,50 @@ def test_edge(gpu, orc, palette, mode):
             assert_same(host(d), want, w, h, ps, "edge pal=%d mode=%d %dx%d inplace=%d" % (palette, mode, w, h, inplace))
 
 
+@pytest.mark.parametrize("palette", [3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_edge_by_quads(gpu, orc, palette, mode, tune):
+    """the three-launch form for 4-byte pixels on 16-byte aligned rows (k_edge_map4 / k_edge_reduce_otsu / k_edge_paint4): whole and partial 128 x 32 tiles, more
+    tiles than the map's 1,024 workgroups, frames of one quad column group, in place and out of place; a smooth and a noisy frame (few / all histogram bins)"""
+    rng = np.random.default_rng(2600 + 10 * palette + mode)
+    for (w, h, noisy) in [(8, 5, 0), (128, 32, 0), (132, 33, 1), (260, 70, 0), (516, 131, 1), (1920, 1080, 0), (4096, 1100, 1)]:
+        if w >= 1920 and (mode == 1 or palette == 4):
+            continue
+        for inplace in (0, 1):
+            s = frame(rng, w, h, 4)
+            if not noisy:
+                yy, xx = np.mgrid[0:h, 0:w]
+                for c in range(4):
+                    s[:, c:w * 4:4] = ((s[:, c:w * 4:4] >> 3) + (96 * ((xx // 9 + yy // 7 + c) % 2)).astype(np.uint8) + 40).astype(np.uint8)
+            d0 = s.copy() if inplace else rng.integers(0, 256, s.shape, dtype=np.uint8)
+            want = d0.copy()
+            m16 = np.zeros(w * h, np.int16)
+            orc.orc_edge(P(want) if inplace else P(s), s.strides[0], P(want), want.strides[0], w, h, palette, mode, P(m16), inplace)
+            for eh in ((0,) if w >= 1920 else (16, 32)):      # both tile heights of the map kernel (0: the library's choice)
+                tune("EDGE_TH", eh)
+                d = dev(d0)
+                gpu.edge(d if inplace else dev(s), d, w, h, palette, mode)
+                assert_same(host(d), want, w, h, 4, "edge by quads pal=%d mode=%d %dx%d inplace=%d tile rows %d" % (palette, mode, w, h, inplace, eh))
+                assert_padding_untouched(host(d), d0, w, h, 4, "edge by quads %dx%d" % (w, h))
+
+
+def test_edge_forms_agree(gpu, tune):
+    """the quad form against the general kernels (EDGE_NO_S) on the same frames, state carried over consecutive calls on one stream"""
+    import torch
+    rng = np.random.default_rng(77)
+    for (w, h) in [(640, 360), (1280, 720)]:
+        s = dev(frame(rng, w, h, 4))
+        outs = []
+        for off in (1, 0, 1, 0):
+            tune("EDGE_NO_S", off)
+            for mode in (0, 2):
+                o = torch.zeros_like(s)
+                gpu.edge(s, o, w, h, 3, mode)
+                outs.append(host(o).copy())
+        for i in range(2, len(outs)):
+            assert (outs[i] == outs[i % 2]).all(), "edge forms differ (%dx%d, call %d)" % (w, h, i)
+
+
 def bz_sequence(rng, w, h, n, compact):
     """frames with a bright block moving over a dim noisy background, so that the background subtraction fires"""
     out = []
