@@ -980,7 +980,8 @@ __global__ __launch_bounds__(256) void k_pb_epilogue(const uint8_t *trk, int iro
 // k_pb_pairs -- every ratio whose per-phase weights fit 16 bits (all but tables with a single 65536 tap): two taps per v_dot2_u32_u16.
 // The window sits in LDS as premultiplied 16-bit values on ALIGNED pixel pairs: per pair 16 bytes = (P_c[2p] | P_c[2p+1] << 16) for c = 0, 1, 2 and the alpha pair
 // (3-byte pixels: P = the byte itself, no alpha).  A destination pixel's taps start at an even or odd source pixel; the weight rows are stored for both parities
-// as pairs aligned the same way (a zero weight pads the odd end), [y phase][x phase][parity][tap row][pair], so a tap row costs one ds_read_b128 per pair, one
+// as pairs aligned the same way (a zero weight pads the odd end), [y phase][tap row][x phase][parity][pair] (the 64 vectors a wave requests for one tap row then
+// lie in 512 bytes instead of being spread over 3 KB: 24 cache lines per request became 4), so a tap row costs one ds_read_b128 per pair, one
 // weight dword per pair (read four at a time) and four dot2 -- about 2 VALU per tap and channel instead of 9 in k_pb_window.
 // =====================================================================================================================================================
 struct PbPairArgs {
@@ -989,7 +990,7 @@ struct PbPairArgs {
   int irow, orow, sw, sh, dw, dh;
   int x_step, y_step, xoff, yoff;
   int n_x, tx0, ty0, ny_eff, nq;       // nq: groups of four pairs per tap row
-  const uint32_t *pairs;               // device: [16][16][2][ny_eff][4 nq]
+  const uint32_t *pairs;               // device: [16 y phases][ny_eff][16 x phases][2 parities][4 nq]
   unsigned rnd;
   int tile_h, wpairs, win_h;
   int no_quad;                         // tuning probe: stage pixel pairs one by one
@@ -1067,12 +1068,12 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
     const long long y = (long long)i * A.y_step + A.yoff;
     const int ys = (int)(y >> 16), yph = (int)(y >> 12) & 15;
     const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
-    const uint32_t wi = (uint32_t)(((yph * 16 + xph) * 2 + par) * A.ny_eff) * (uint32_t)A.nq;
+    const uint32_t wi = (uint32_t)(yph * A.ny_eff * 32 + xph * 2 + par);       // [y phase][tap row][x phase][parity]: a wave's 64 vectors of one tap row lie within 512 nq bytes
     unsigned r = 0, g = 0, b = 0, a = 0;
     if (NPC && NY) {
       pb_u4 wv[NY ? NY : 1];
 #pragma unroll
-      for (int ty = 0; ty < NY; ty++) wv[ty] = pairs4[wi + ty];
+      for (int ty = 0; ty < NY; ty++) wv[ty] = pairs4[wi + 32 * ty];
 #pragma unroll
       for (int ty = 0; ty < NY; ty++) {
         const uint32_t wq[4] = {wv[ty].x, wv[ty].y, wv[ty].z, wv[ty].w};
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
     } else {
       for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
         if (NPC) {
-          const pb_u4 w = pairs4[wi + ty];
+          const pb_u4 w = pairs4[wi + 32 * ty];
           const uint32_t wq[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
           for (int k = 0; k < (NPC ? NPC : 1); k++) {
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
           continue;
         }
         for (int qd = 0; qd < A.nq; qd++) {
-          const pb_u4 w = pairs4[wi + ty * A.nq + qd];
+          const pb_u4 w = pairs4[(wi + 32 * ty) * A.nq + qd];
           const pb_u4 d0 = wp[4 * qd], d1 = wp[4 * qd + 1], d2 = wp[4 * qd + 2], d3 = wp[4 * qd + 3];
           r = pb_dot2(d0.x, w.x, r); g = pb_dot2(d0.y, w.x, g); b = pb_dot2(d0.z, w.x, b);
           r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
@@ -1426,12 +1427,12 @@ static int pb_build(int interp, int sw, int sh, int dw, int dh, PbTable *t, bool
         for (int x = 0; x < 16; x++)
           for (int par = 0; par < 2; par++) {
             const int *w = t->host.data() + (size_t)(y * 16 + x) * nn;
-            uint32_t *o = pr.data() + (size_t)(((y * 16 + x) * 2 + par) * ny_eff) * rowlen;
+
             for (int ty = 0; ty < ny_eff; ty++)
               for (int i = 0; i < np; i++) {
                 const int t0 = tx0 + 2 * i - par, t1 = t0 + 1;        // the two taps of aligned pair i when the first tap sits on an even (par 0) / odd (par 1) source pixel
                 const uint32_t w0 = (t0 >= tx0 && t0 < tx1) ? (uint32_t)w[(ty0 + ty) * t->n_x + t0] : 0u, w1 = (t1 >= tx0 && t1 < tx1) ? (uint32_t)w[(ty0 + ty) * t->n_x + t1] : 0u;
-                o[ty * rowlen + i] = w0 | (w1 << 16);
+                pr[((size_t)(y * ny_eff + ty) * 32 + x * 2 + par) * rowlen + i] = w0 | (w1 << 16);
               }
           }
       if ((rc = pb_upload(pr.data(), pr.size() * sizeof(uint32_t), st, (void **)&t->pairs_d))) { pb_free_device(t, st); return rc; }
