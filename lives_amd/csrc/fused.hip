@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
     for (int i = 0; i < 8; i++) { e[i] = p[i] & 0x00FF00FFu; o[i] = (p[i] >> 8) & 0x00FF00FFu; }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      h[2 * j] = e[j] + e[j + 4] + 4u * (e[j + 1] + e[j + 3]) + 6u * e[j + 2];
-      h[2 * j + 1] = o[j] + o[j + 4] + 4u * (o[j + 1] + o[j + 3]) + 6u * o[j + 2];
+      h[2 * j] = gauss5_taps(e[j], e[j + 1], e[j + 2], e[j + 3], e[j + 4]);
+      h[2 * j + 1] = gauss5_taps(o[j], o[j + 1], o[j + 2], o[j + 3], o[j + 4]);
     }
   };
 
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
       if (A.key) nb = load4(A.src1, A.irow1, vr - d);              // the second frame's pixels of the NEXT output row
       if (yy != produced) {
         const gk_u4 q = qn;
-        qn = load4(A.src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic
+        qn = load4(A.src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic (two rows ahead: 26.4 -> 28.8 us, the registers cost a wave per SIMD)
         hrow(fix(q), ring[u]);
         produced = yy;
       } else {
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
         uint32_t px[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const uint32_t ve = r0[2 * j] + r4[2 * j] + 4u * (r1[2 * j] + r3[2 * j]) + 6u * r2[2 * j] + 0x00800080u;
-          const uint32_t vo = r0[2 * j + 1] + r4[2 * j + 1] + 4u * (r1[2 * j + 1] + r3[2 * j + 1]) + 6u * r2[2 * j + 1] + 0x00800080u;
+          const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
+          const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
           uint32_t a = ((ve >> 8) & 0x00FF00FFu) | (vo & 0xFF00FF00u);
           if (A.key) {
             // the box test on both 16-bit lanes at once: x >= min <=> bit 15 of (x | 0x8000) - min, x <= max <=> bit 15 of (max | 0x8000) - x (the alpha lane's box is 0 .. 255)

@@ -85,6 +85,9 @@ __device__ __forceinline__ uint32_t lut4(const uint8_t *l, uint32_t p) {
   return (uint32_t)l[p & 0xFF] | ((uint32_t)l[(p >> 8) & 0xFF] << 8) | ((uint32_t)l[(p >> 16) & 0xFF] << 16) | ((uint32_t)l[p >> 24] << 24);
 }
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+// [1 4 6 4 1] on packed 16-bit lanes, a + e + 4 (b + d) + 6 c + k, without a 32-bit multiply: the operands of the vertical pass exceed 24 bits, so `6u * c` became
+// v_mul_lo_u32 (a quarter of the vector rate); ((b + c + d) << 2) + (c << 1) + (a + e + k) is two v_add3 and two v_lshl_add
+__device__ __forceinline__ uint32_t gauss5_taps(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t k = 0u) { return ((b + c + d) << 2) + (c << 1) + (a + e + k); }
 
 // --- per-lane 4-pixel gather / scatter ------------------------------------------------------------------
 // 3-byte pixels: 12 contiguous bytes d0 d1 d2 -> four dwords [c0 c1 c2 x]

@@ -571,8 +571,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
-      ring[4][0] = e[0] + e[4] + 4u * (e[1] + e[3]) + 6u * e[2]; ring[4][1] = o[0] + o[4] + 4u * (o[1] + o[3]) + 6u * o[2];
-      ring[4][2] = e[1] + e[5] + 4u * (e[2] + e[4]) + 6u * e[3]; ring[4][3] = o[1] + o[5] + 4u * (o[2] + o[4]) + 6u * o[3];
+      ring[4][0] = gauss5_taps(e[0], e[1], e[2], e[3], e[4]); ring[4][1] = gauss5_taps(o[0], o[1], o[2], o[3], o[4]);
+      ring[4][2] = gauss5_taps(e[1], e[2], e[3], e[4], e[5]); ring[4][3] = gauss5_taps(o[1], o[2], o[3], o[4], o[5]);
     } else {          // a row beyond the frame's first / last: the border row again
       if (CHAIN) nl2 = load_l2(vr - d);
       const uint32_t t0 = ring[4][0], t1 = ring[4][1], t2 = ring[4][2], t3 = ring[4][3];
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       uint32_t pxo[2];
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        const uint32_t ve = ring[0][2 * j] + ring[4][2 * j] + 4u * (ring[1][2 * j] + ring[3][2 * j]) + 6u * ring[2][2 * j] + 0x00800080u;
-        const uint32_t vo = ring[0][2 * j + 1] + ring[4][2 * j + 1] + 4u * (ring[1][2 * j + 1] + ring[3][2 * j + 1]) + 6u * ring[2][2 * j + 1] + 0x00800080u;
+        const uint32_t ve = gauss5_taps(ring[0][2 * j], ring[1][2 * j], ring[2][2 * j], ring[3][2 * j], ring[4][2 * j], 0x00800080u);
+        const uint32_t vo = gauss5_taps(ring[0][2 * j + 1], ring[1][2 * j + 1], ring[2][2 * j + 1], ring[3][2 * j + 1], ring[4][2 * j + 1], 0x00800080u);
         // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
         pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
       }
