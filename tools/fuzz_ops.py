@@ -342,6 +342,9 @@ def main():
                 pal, mode = int(rng.integers(1, 6)), int(rng.integers(0, 3))
                 ps = 3 if pal <= 2 else 4
                 w, h = int(rng.integers(4, 260)), int(rng.integers(4, 140))
+                if rng.random() < 0.5:        # whole quads, sometimes several 128 x 32 tiles: with a 16-byte multiple as rowstride these take the quad form (k_edge_map4 / _reduce_otsu / _paint4)
+                    w, h = 4 * int(rng.integers(2, 175)), int(rng.integers(4, 300))
+                    ops.tuning("EDGE_TH", int(rng.choice([16, 32])))
                 inplace = int(rng.integers(0, 2))
                 sfr = fr(w, h, ps)
                 yy, xx = np.mgrid[0:h, 0:w]
