@@ -232,24 +232,29 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, 
     if (V422) {
       // row q.unit; columns k0 >= 2 only (the first pairs of a row take their left samples from chroma row i >> 1), the window k0 - 1 .. inside the plane
       const int i2 = q.unit;
-      q.fast = q.valid && q.k0 >= 2 && q.k0 + NC <= hw && (long)i2 * a.us + q.k0 - 1 + (long)sizeof(win_t) <= a.usize && (long)i2 * a.vs + q.k0 - 1 + (long)sizeof(win_t) <= a.vsize;
+      // plane offsets are 32-bit products of 24-bit operands (the host sends larger planes to the general kernel): v_mul_u32_u24 instead of 64-bit multiply-adds at a quarter of the rate
+      const uint32_t ou = __umul24((uint32_t)i2, (uint32_t)a.us) + (uint32_t)q.k0 - 1u, ov = __umul24((uint32_t)i2, (uint32_t)a.vs) + (uint32_t)q.k0 - 1u;
+      q.fast = q.valid && q.k0 >= 2 && q.k0 + NC <= hw && (long)ou + (long)sizeof(win_t) <= a.usize && (long)ov + (long)sizeof(win_t) <= a.vsize;
       if (q.fast) {
         auto ld = [](const uint8_t *p) -> win_t { win_t w; __builtin_memcpy(&w, p, sizeof(win_t)); return w; };
-        q.ya = *reinterpret_cast<const ywin_t *>(a.y + (size_t)i2 * a.ys + 2 * q.k0);
-        q.u0 = ld(a.u + (size_t)i2 * a.us + q.k0 - 1); q.v0 = ld(a.v + (size_t)i2 * a.vs + q.k0 - 1);
+        q.ya = *reinterpret_cast<const ywin_t *>(a.y + (__umul24((uint32_t)i2, (uint32_t)a.ys) + 2u * (uint32_t)q.k0));
+        q.u0 = ld(a.u + ou); q.v0 = ld(a.v + ov);
       }
       return q;
     }
     const int i = 2 * q.unit - 1, r = i >> 1;
-    q.fast = q.valid && q.unit >= 1 && q.unit <= npairs && q.k0 + NC <= hw && (long)(r + 1) * a.us + q.k0 + (long)sizeof(win_t) <= a.usize &&
-             (long)(r + 1) * a.vs + q.k0 + (long)sizeof(win_t) <= a.vsize;
+    // 32-bit plane offsets from 24-bit operands (see above); the edge units (unit 0, the trailing row) never take this path, so i >= 1 and r >= 0 here
+    const uint32_t ru = __umul24((uint32_t)(r + 1), (uint32_t)a.us), rv = __umul24((uint32_t)(r + 1), (uint32_t)a.vs);      // row r + 1 of the chroma planes
+    q.fast = q.valid && q.unit >= 1 && q.unit <= npairs && q.k0 + NC <= hw && (long)ru + q.k0 + (long)sizeof(win_t) <= a.usize &&
+             (long)rv + q.k0 + (long)sizeof(win_t) <= a.vsize;
     if (q.fast) {
       auto ld = [](const uint8_t *p) -> win_t { win_t w; __builtin_memcpy(&w, p, sizeof(win_t)); return w; };
-      q.ya = *reinterpret_cast<const ywin_t *>(a.y + (size_t)i * a.ys + 2 * q.k0); q.yb = *reinterpret_cast<const ywin_t *>(a.y + (size_t)(i + 1) * a.ys + 2 * q.k0);
-      const uint8_t *ur = a.u + (size_t)r * a.us + q.k0, *vr = a.v + (size_t)r * a.vs + q.k0;
+      const uint32_t oy = __umul24((uint32_t)i, (uint32_t)a.ys) + 2u * (uint32_t)q.k0;
+      q.ya = *reinterpret_cast<const ywin_t *>(a.y + oy); q.yb = *reinterpret_cast<const ywin_t *>(a.y + (oy + (uint32_t)a.ys));
       const int o = q.k0 ? 1 : 0;                             // the first group has no sample on its left: fixed up where the cell is computed
-      q.u0 = ld(ur - o); q.u1 = ld(ur + a.us - o); q.v0 = ld(vr - o); q.v1 = ld(vr + a.vs - o);
-      q.lv2 = a.v[(size_t)(r + 1) * a.vs];                    // PV(r + 1, 0): the reference's constant "last" sample
+      const uint32_t cu = ru + (uint32_t)q.k0 - (uint32_t)o, cv = rv + (uint32_t)q.k0 - (uint32_t)o;      // the window in chroma row r + 1; row r is one stride back
+      q.u0 = ld(a.u + (cu - (uint32_t)a.us)); q.u1 = ld(a.u + cu); q.v0 = ld(a.v + (cv - (uint32_t)a.vs)); q.v1 = ld(a.v + cv);
+      q.lv2 = a.v[rv];                                        // PV(r + 1, 0): the reference's constant "last" sample
     }
     return q;
   };
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, 
         px[2 * j] = pixel(yat(cur.ya, 2 * j), (((tu + at(cur.u0, j - 1)) >> 1) << 3) + bu, (((tv + at(cur.v0, j - 1)) >> 1) << 3) + bv);
         px[2 * j + 1] = pixel(yat(cur.ya, 2 * j + 1), (((tu + at(cur.u0, j + 1)) >> 1) << 3) + bu, (((tv + at(cur.v0, j + 1)) >> 1) << 3) + bv);
       }
-      uint8_t *d0 = a.dst + (size_t)cur.unit * a.orow + (size_t)(2 * cur.k0) * 4;
+      uint8_t *d0 = a.dst + (__umul24((uint32_t)cur.unit, (uint32_t)a.orow) + 8u * (uint32_t)cur.k0);
       if (NC == 1) *reinterpret_cast<uint2 *>(d0) = make_uint2(px[0], px[1]);
       else {
         typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(1024) void k_yuv420p_to_rgb_s(YuvArgs a, Lut8 lut, 
         top[2 * j + 1] = pixel(yat(cur.ya, 2 * j + 1), blend(s1u, s2u, bu), blend(s1w, s2w, bv));
         bot[2 * j + 1] = pixel(yat(cur.yb, 2 * j + 1), blend(s2u, s1u, bu), blend(s2w, s1w, bv));
       }
-      uint8_t *d0 = a.dst + (size_t)(2 * cur.unit - 1) * a.orow + (size_t)(2 * cur.k0) * 4, *d1 = d0 + a.orow;
+      uint8_t *d0 = a.dst + (__umul24((uint32_t)(2 * cur.unit - 1), (uint32_t)a.orow) + 8u * (uint32_t)cur.k0), *d1 = d0 + a.orow;
       if (NC == 1) {
         *reinterpret_cast<uint2 *>(d0) = make_uint2(top[0], top[1]); *reinterpret_cast<uint2 *>(d1) = make_uint2(bot[0], bot[1]);
       } else {
@@ -448,7 +453,11 @@ static int yuv420p_to_rgb_impl(const uint8_t *y_d, const uint8_t *u_d, const uin
   // aligned rows, 4-byte pixels, no LUT16, not the LOW quality setting: the paired-table form; everything else the one-cell-per-lane kernels
   const YuvTuning &tn = yuv_tuning();
   const int s_nc = tn.nc.load(), s_block = tn.block.load(), s_wgs = tn.wgs.load();
-  bool form_s = s_nc && opsize == 4 && !lut16_d && !a.low_quality && (a.ys & (2 * s_nc - 1)) == 0 && (orow & (s_nc == 1 ? 7 : 15)) == 0 && nbatch <= 65535;
+  // ... and planes whose byte offsets fit 31 bits with strides and row counts below 2^24 (the kernel multiplies them as 24-bit operands)
+  const long long lim31 = 1ll << 31;
+  bool form_s = s_nc && opsize == 4 && !lut16_d && !a.low_quality && (a.ys & (2 * s_nc - 1)) == 0 && (orow & (s_nc == 1 ? 7 : 15)) == 0 && nbatch <= 65535 &&
+                height < (1 << 23) && a.ys < (1 << 24) && a.us < (1 << 24) && a.vs < (1 << 24) && orow < (1 << 24) && a.us > 0 && a.vs > 0 &&
+                (long long)a.ys * (height + 1) < lim31 && (long long)a.us * (height + 2) < lim31 && (long long)a.vs * (height + 2) < lim31 && (long long)orow * (height + 1) < lim31;
   for (int f = 0; f < nbatch && form_s; f++) {
     const uintptr_t py = (uintptr_t)(batch ? batch->y[f] : y_d), pd = (uintptr_t)(batch ? batch->dst[f] : dst_d);
     form_s = (py & (2 * s_nc - 1)) == 0 && (pd & (s_nc == 1 ? 7 : 15)) == 0;
