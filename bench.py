@@ -217,36 +217,46 @@ def main():
     frames = world * T * args.steps
     fps = frames / dt
 
-    # N > 1: BASELINE config 5's own shape as well -- ONE 4K frame per GPU per step, the exchange on -- through the same C step
+    # N > 1: BASELINE config 5's own shape as well -- ONE 4K frame per GPU per step, the exchange on -- through the same C step: once on the chain of the headline
+    # (north_star's convert -> resize -> blend -> gamma) and once with config 5's 5x5 gaussian between the scaler and the blend
+    prm_blur = prm if args.blur else ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3 | (0x100 if args.resize_backend == "pixbuf" else 0), do_blur=1, bf=128, lut=lut,
+                                                      param_block=pblock)
     config5 = None
     if multi and stepper is not None:
         stepper.close()
         stepper = None
         one = groups_of(1)                    # every frame of every buffer set in turn: the one-frame launches, too, see buffers the memory-side cache has long lost
         n5 = max(args.steps, 200)
-        st5 = ld.Stepper(comm, sched_host[0], stream=launch_a)
-        st5.overlap(launch_b)                 # odd steps on the second launch stream: consecutive frames are independent, the drain of one launch overlaps the ramp-up of the next
-        tot5, f5 = 50 + n5, 1
 
-        def step5(i):
-            nonlocal f5
-            if f5 == i + 1 and f5 < tot5:
-                k = min(AHEAD, tot5 - f5)
-                st5.feed([sched_host[(f5 + j) % nsched] for j in range(k)])
-                f5 += k
-            st5.step(None, prm, one[i % len(one)])
-        for i in range(50):
-            step5(i)
-        fence()
-        t5 = time.perf_counter()
-        for i in range(50, tot5):
-            step5(i)
-        fence()
-        d5 = ld.max_over_ranks(time.perf_counter() - t5, "cuda")
-        st5.close()
+        def one_frame_leg(p5):
+            st5 = ld.Stepper(comm, sched_host[0], stream=launch_a)
+            st5.overlap(launch_b)             # odd steps on the second launch stream: consecutive frames are independent, the drain of one launch overlaps the ramp-up of the next
+            tot5, f5 = 50 + n5, 1
+
+            def step5(i):
+                nonlocal f5
+                if f5 == i + 1 and f5 < tot5:
+                    k = min(AHEAD, tot5 - f5)
+                    st5.feed([sched_host[(f5 + j) % nsched] for j in range(k)])
+                    f5 += k
+                st5.step(None, p5, one[i % len(one)])
+            for i in range(50):
+                step5(i)
+            fence()
+            t5 = time.perf_counter()
+            for i in range(50, tot5):
+                step5(i)
+            fence()
+            d5 = ld.max_over_ranks(time.perf_counter() - t5, "cuda")
+            st5.close()
+            return d5
+        d5 = one_frame_leg(prm)
         config5 = {"config5_fps": round(world * n5 / d5, 1), "config5_ms_per_step": round(d5 / n5 * 1e3, 4), "config5_steps": n5,
                    "config5_shape": "one 3840x2160 frame per GPU per step, lgpu_chain_step (C) with the RCCL parameter exchange on (%d blocks per exchange, lgpu_stepper_feed), "
                                     "steps alternating between two launch streams (lgpu_stepper_overlap)" % AHEAD}
+        if args.resize_backend == "pixbuf" and not args.blur:
+            d5b = one_frame_leg(prm_blur)
+            config5.update({"config5_blur_fps": round(world * n5 / d5b, 1), "config5_blur_ms_per_step": round(d5b / n5 * 1e3, 4)})
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around K launches ----
     reps = max(10, min(args.steps, 200))
@@ -291,6 +301,17 @@ def main():
         torch.cuda.synchronize()
         us8 = e0.elapsed_time(e1) * 1e3 / n8
         batch8 = {"batch8_1gpu_fps": round(8e6 / us8, 1), "batch8_1gpu_us_per_step": round(us8, 2), "batch8_groups_rotated": len(t8)}
+        if args.resize_backend == "pixbuf" and not args.blur:      # the same with config 5's gaussian in the chain
+            prm_blur.param_block_d = prm.param_block_d
+            for i in range(6):
+                ops.chain(prm_blur, t8[i % len(t8)])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n8):
+                ops.chain(prm_blur, t8[i % len(t8)])
+            e1.record()
+            torch.cuda.synchronize()
+            batch8["batch8_blur_1gpu_us_per_step"] = round(e0.elapsed_time(e1) * 1e3 / n8, 2)
 
     # what this box's memory system gives the launch's own algorithmic bytes as a bare stream (no arithmetic, no re-reads): tells a slow box from a regression
     box = None
@@ -333,6 +354,8 @@ def main():
             out["config"].update(config5)
             if batch8:       # what 8 GPUs with one frame each would make of the 8-track batch that one GPU runs as one launch
                 out["config"]["projected_batch8_speedup"] = round(batch8["batch8_1gpu_us_per_step"] / (config5["config5_ms_per_step"] * 1e3), 2)
+                if "config5_blur_ms_per_step" in config5 and "batch8_blur_1gpu_us_per_step" in batch8:
+                    out["config"]["projected_batch8_blur_speedup"] = round(batch8["batch8_blur_1gpu_us_per_step"] / (config5["config5_blur_ms_per_step"] * 1e3), 2)
         if world > 1:
             out["config"]["rccl_ranks"] = world if comm is not None else 0
             out["config"]["rccl_preflight"] = rccl_preflight if rccl_preflight is not None else "not run (librccl could not be bound on every rank)"
