@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU)
     ap.add_argument("--blur", type=int, default=0, help="1: add the 5x5 gaussian stage (BASELINE config 5 chain)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--launch-streams", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive steps alternate between two launch streams (independent buffer sets; needs an even --sets): 4-6 %% more frames/s, "
+                         "but a profiler then sees pairs of overlapping launches of about twice the duration each")
     ap.add_argument("--sets", type=int, default=2,
                     help="independent buffer sets (sources, layer 2, destinations) the steps rotate through; with 2, consecutive steps share no byte, "
                          "so nothing a step reads can still sit in the 256 MiB Infinity Cache from the step before")
@@ -162,7 +165,10 @@ def main():
     # Consecutive steps work on different buffer sets and are independent, so they alternate between two launch streams: the last workgroups of one launch drain while
     # the first of the next ramp up (tools/worker_overlap16.sh, profiles/r04/worker_overlap16.txt: 145 -> 136.5 us per 16-track step, 76 -> 70 per 8-track step).  Step s
     # and step s + 2 share a stream and a buffer set, so every buffer has one stream; with an odd number of sets the steps stay on one stream.
-    two_streams = nsets % 2 == 0 and not os.environ.get("LGPU_BENCH_ONE_STREAM")
+    # OFF by default: two launches that are in flight together share the device from their first workgroup on (the dispatcher serves both queues), so each lasts
+    # about twice as long while a pair takes less than two -- rocprofv3's per-kernel average then reads ~250 us beside a 156 us `roofline.launch_us`
+    # (profiles/r04/box_c/README).  The default bench keeps one stream, so that its profile and its line say the same thing; `--launch-streams 2` is the faster host.
+    two_streams = args.launch_streams == 2 and nsets % 2 == 0
     stepper = ld.Stepper(comm, sched_host[0], stream=launch_a) if comm is not None else None
     if stepper is not None and two_streams:
         stepper.overlap(launch_b)

@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_first -o t -- python bench.py --no-cpu > $O/bench_line_inside_the_rocprofv3_run.log 2>&1
 cp $O/trace_first/t_kernel_stats.csv $O/final_kernel_stats.csv
 python bench.py > $O/bench_default.json 2>$O/bench_default.err
+python bench.py --no-cpu --launch-streams 2 2>/dev/null | grep "^{" > $O/bench_two_streams.json
 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep "^{" > $O/bench_driver_shape.json
 # power / clocks beside 30 s of back-to-back launches
 python bench.py --no-cpu --steps 150000 --warmup 100 > $O/clock_probe_bench.json 2>/dev/null &
@@ -24,11 +25,12 @@ for a in "--tracks 1" "--tracks 8" "--blur 1" "--blur 1 --tracks 1" "--resize-ba
 done
 LGPU_BENCH_FORCE_EXCHANGE=1 python bench.py --no-cpu 2>/dev/null | grep "^{" > $O/bench_forced_exchange.json
 gcc -O2 -o tools/_worker tools/worker.c -Iinclude -Llives_amd -llivesgpu -Wl,-rpath,$PWD/lives_amd
-for a in "--tracks 1 --exchange 1 --ahead 16" "--tracks 1 --exchange 1 --ahead 1" "--tracks 1 --exchange 0 --ahead 16" "--tracks 16 --exchange 1 --ahead 16 --steps 500"; do LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:$LD_LIBRARY_PATH tools/_worker $a 2>&1 | grep tool >> $O/worker.jsonl; done
+for a in "--tracks 1 --exchange 1 --ahead 16" "--tracks 1 --exchange 1 --ahead 16 --sets 2" "--tracks 1 --exchange 1 --ahead 1" "--tracks 1 --exchange 0 --ahead 16" "--tracks 8 --exchange 1 --steps 600" "--tracks 16 --exchange 1 --ahead 16 --steps 500" "--tracks 16 --exchange 1 --overlap 0 --steps 500"; do LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:$LD_LIBRARY_PATH tools/_worker $a 2>&1 | grep tool >> $O/worker.jsonl; done
 tools/pmc.sh gpurun_out/pmc_final_r04 > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_final_r04 k_pb_half > $O/final_pmc_pixbuf_chain.md
 python tools/pmc_traffic.py gpurun_out/pmc_final_r04 $C k_pb_half > $O/pmc_traffic_pixbuf.json
 cp gpurun_out/pmc_final_r04/trace/t_kernel_stats.csv $O/kernel_stats_late_in_the_call.csv
-python tools/bench_one.py chain1 chain8 chain16 c3 c4rgba c4rgb24 k2 premult_yuva yuv411 composite softlight pb:3840x2160:1920x1080:3 pb:1920x1080:1280x720:3 pb:1280x720:1920x1080:3 pb:3840x2160:1706x960:3 pb:1920x1080:2560x1440:3 pb:1280x720:3840x2160:3 > $O/op_timings.txt 2>/dev/null
+bash tools/cold_ops.sh > $O/op_timings.txt 2>/dev/null
+bash tools/edge_ab.sh 2>/dev/null | head -6 > $O/edge_timings.txt
 rm -rf $O/trace_first gpurun_out/pmc_final_r04/*/*.db
-cat $O/bench_default.json | head -c 1500; echo; cat $O/power_clock_samples.txt | tail -3; cat $O/pmc_traffic_pixbuf.json; cat $O/op_timings.txt
+cat $O/bench_default.json | head -c 1500; echo; cat $O/power_clock_samples.txt | tail -3; cat $O/pmc_traffic_pixbuf.json; head -22 $O/op_timings.txt
