@@ -162,9 +162,9 @@ def main():
     nsched = args.steps + args.warmup
     sched_host = [[(96 + 7 * s) % 256, 0, 0, 0] for s in range(nsched)]
     # N > 1 with RCCL bound: the whole per-step host path is ONE C call, lgpu_chain_step (wait for this step's block, exchange the next on a side stream, launch)
-    # Consecutive steps work on different buffer sets and are independent, so they alternate between two launch streams: the last workgroups of one launch drain while
-    # the first of the next ramp up (tools/worker_overlap16.sh, profiles/r04/worker_overlap16.txt: 145 -> 136.5 us per 16-track step, 76 -> 70 per 8-track step).  Step s
-    # and step s + 2 share a stream and a buffer set, so every buffer has one stream; with an odd number of sets the steps stay on one stream.
+    # Consecutive steps work on different buffer sets and are independent, so they MAY alternate between two launch streams (tools/worker_overlap16.sh,
+    # profiles/r04/worker_overlap16.txt: 145 -> 136.5 us per 16-track step, 76 -> 70 per 8-track step).  Step s and step s + 2 share a stream and a buffer set, so
+    # every buffer has one stream; with an odd number of sets the steps stay on one stream.
     # OFF by default: two launches that are in flight together share the device from their first workgroup on (the dispatcher serves both queues), so each lasts
     # about twice as long while a pair takes less than two -- rocprofv3's per-kernel average then reads ~250 us beside a 156 us `roofline.launch_us`
     # (profiles/r04/box_c/README).  The default bench keeps one stream, so that its profile and its line say the same thing; `--launch-streams 2` is the faster host.
