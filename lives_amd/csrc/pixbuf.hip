@@ -207,6 +207,7 @@ struct PbHalfArgs {
   int bar_first;                 // the bars' workgroups come FIRST in the grid (a multiple of 8, so the frame's workgroups keep their XCD): they run while the frame's first loads are in flight
   int nt_out;
   int nt_in;                     // probe (LGPU_PBH_NT_IN): non-temporal loads for a band's inner source rows
+  int row_major;                 // work order within a track: column groups fastest (1, default) or bands fastest (0, PBH_ORDER)
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
 };
 struct PbTracks {
@@ -374,10 +375,18 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   int strip = 0, band = 0, track = 0;
   bool spare = seq >= nseq || slot >= per_xcd;
   if (!spare) {
-    const int cg = seq / A.bands;
-    band = seq - cg * A.bands;
-    track = cg / A.cgroups;
-    strip = (cg - track * A.cgroups) * 4 + wave;
+    if (A.row_major) {                                      // column groups fastest: consecutive workgroups of an XCD read one band across the whole row (contiguous 15 KB per source row)
+      const int per_track = A.cgroups * A.bands;
+      track = seq / per_track;
+      const int idx = seq - track * per_track;
+      band = idx / A.cgroups;
+      strip = (idx - band * A.cgroups) * 4 + wave;
+    } else {
+      const int cg = seq / A.bands;
+      band = seq - cg * A.bands;
+      track = cg / A.cgroups;
+      strip = (cg - track * A.cgroups) * 4 + wave;
+    }
     spare = strip >= A.strips;
   }
   if (spare) return;                                        // no workgroup barrier on this path: a wave without work simply ends
@@ -1646,6 +1655,8 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   // of a set when its turn came again and streaming reads pushed less of it out.  On buffers that cache has long lost (four or more sets: a frame that was just uploaded)
   // they cost 1-2 % at every track count (profiles/r04/nt_cold_ab.txt), and that is the case a host presents
   a.nt_in = tune(TUNE_PBH_NT_IN) > 0 ? 1 : 0;
+  // work order: profiles/r04/order_ab.txt -- 16 tracks 146-157 -> 144-145 us, 8 tracks 79.9 -> 76.6, one frame equal
+  a.row_major = tune(TUNE_PBH_ORDER) == 0 ? 0 : 1;      // (every XCD starting at another height of its frame on top of it: no difference, order_ab.txt)
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
@@ -1850,7 +1861,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     PbHalfArgs h;
     if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
-      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) == 0 ? 0 : 1;
       pb_half_geometry(&h, 1);
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
