@@ -207,7 +207,7 @@ struct PbHalfArgs {
   int bar_first;                 // the bars' workgroups come FIRST in the grid (a multiple of 8, so the frame's workgroups keep their XCD): they run while the frame's first loads are in flight
   int nt_out;
   int nt_in;                     // probe (LGPU_PBH_NT_IN): non-temporal loads for a band's inner source rows
-  int row_major;                 // work order within a track: column groups fastest (1, default) or bands fastest (0, PBH_ORDER)
+  int row_major;                 // work order (PBH_ORDER): 0 bands fastest, 1 column groups fastest, 2 that with the bands dealt round robin to the XCDs
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
 };
 struct PbTracks {
@@ -365,17 +365,29 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and the compiler is told so: scalar row / track arithmetic
-  // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its
-  // own L2; two bands that follow each other vertically share two source rows.  So every XCD gets a CONTIGUOUS run of the sequence (track, column group, band) and
-  // walks it band by band: the shared rows are fetched once and hit that XCD's L2 the second time (PMC: 999 MB -> see profiles/r03 per 16-track launch).
+  // Work order.  A workgroup = the 4 adjacent strips of one band of one track (a "column group").  Workgroups reach the 8 XCDs round robin, each XCD with its own L2;
+  // two bands that follow each other vertically share two source rows (ten with the gaussian), and odd bands walk upwards so that the pair reaches them together.
+  // A.row_major picks how (track, band, column group) map to (XCD, slot): 0 -- every XCD a contiguous run of the sequence, a column group's bands one after the other
+  // (rounds 3 / 4: the shared rows hit that XCD's L2, 999 -> 883 MB per 16-track launch); 1 -- the same runs, the column groups of a band one after the other
+  // (consecutive workgroups read a band across the whole row); 2 -- the bands of a track dealt round robin to the XCDs, column groups fastest: the whole device
+  // sweeps one frame at a time, as a linear stream of the same bytes would.  Measured in pb_chain_half()'s comment.
   const unsigned bid = blockIdx.x - (CHAIN ? (unsigned)A.bar_first : 0u);
   const int xcd = bid & 7, slot = bid >> 3;
   const int nseq = A.cgroups * A.bands * A.ntracks, per_xcd = (nseq + 7) >> 3;
   int seq = xcd * per_xcd + slot;
   int strip = 0, band = 0, track = 0;
-  bool spare = seq >= nseq || slot >= per_xcd;
+  bool spare = (seq >= nseq || slot >= per_xcd) && A.row_major != 2;
   if (!spare) {
-    if (A.row_major) {                                      // column groups fastest: consecutive workgroups of an XCD read one band across the whole row (contiguous 15 KB per source row)
+    if (A.row_major == 2) {                                 // the bands of a track dealt round robin to the XCDs, column groups fastest: all XCDs sweep ONE frame together
+      const int nb = (A.bands + 7 - xcd) >> 3, per_track = nb * A.cgroups;
+      spare = per_track == 0 || slot >= per_track * A.ntracks;
+      if (!spare) {
+        track = slot / per_track;
+        const int idx = slot - track * per_track, bi = idx / A.cgroups;
+        band = xcd + 8 * bi;
+        strip = (idx - bi * A.cgroups) * 4 + wave;
+      }
+    } else if (A.row_major) {                                      // column groups fastest: consecutive workgroups of an XCD read one band across the whole row (contiguous 15 KB per source row)
       const int per_track = A.cgroups * A.bands;
       track = seq / per_track;
       const int idx = seq - track * per_track;
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       track = cg / A.cgroups;
       strip = (cg - track * A.cgroups) * 4 + wave;
     }
-    spare = strip >= A.strips;
+    spare = spare || strip >= A.strips;
   }
   if (spare) return;                                        // no workgroup barrier on this path: a wave without work simply ends
   const int k = strip * kCols - kHalo + lane;             // this lane's source quad: pixels 4k .. 4k + 3 -> output columns 2k, 2k + 1
@@ -1630,7 +1642,7 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   pb_half_bands(a, bands);
 }
 
-static unsigned pb_half_grid(const PbHalfArgs &a) { return 8u * cdiv((unsigned)(a.cgroups * a.bands * a.ntracks), 8u); }
+static unsigned pb_half_grid(const PbHalfArgs &a) { return a.row_major == 2 ? 8u * (unsigned)(a.cgroups * a.ntracks) * cdiv((unsigned)a.bands, 8u) : 8u * cdiv((unsigned)(a.cgroups * a.bands * a.ntracks), 8u); }
 
 // the fused chain on the pixbuf arithmetic (lgpu_chain with LGPU_INTERP_PIXBUF): convert -> gdk-pixbuf 2:1 scale -> chroma blend -> gamma LUT in one launch.
 // LGPU_E_UNSUPPORTED when the geometry is not the exact aligned 2:1 case (the caller then runs the stages one by one).
@@ -1655,8 +1667,11 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   // of a set when its turn came again and streaming reads pushed less of it out.  On buffers that cache has long lost (four or more sets: a frame that was just uploaded)
   // they cost 1-2 % at every track count (profiles/r04/nt_cold_ab.txt), and that is the case a host presents
   a.nt_in = tune(TUNE_PBH_NT_IN) > 0 ? 1 : 0;
-  // work order: profiles/r04/order_ab.txt -- 16 tracks 146-157 -> 144-145 us, 8 tracks 79.9 -> 76.6, one frame equal
-  a.row_major = tune(TUNE_PBH_ORDER) == 0 ? 0 : 1;      // (every XCD starting at another height of its frame on top of it: no difference, order_ab.txt)
+  // Work order (PBH_ORDER; profiles/r04/order_ab.txt, interleaved on cold buffers).  0: a column group's bands one after the other, an XCD owning a contiguous run (rounds 3 / 4);
+  // 1: the column groups of a band one after the other -- consecutive workgroups read a band across the whole row: 16 tracks 147.5 -> 142.3 us on one box, 152 -> 146 on another;
+  // 2: that, with the bands of a track dealt round robin to the XCDs, so that the whole device sweeps ONE frame at a time like a linear stream does: 151-152 -> 144.2, 8 tracks
+  // 76.8 -> 74.3.  With the 5x5 gaussian in the chain neighbouring bands share ten source rows instead of two and want the same L2: 186 us with 1, 189 with 2 -- it keeps 1.
+  a.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : (pr->do_blur ? 1 : 2);
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
@@ -1861,7 +1876,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     PbHalfArgs h;
     if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
-      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) == 0 ? 0 : 1;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 2;
       pb_half_geometry(&h, 1);
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;

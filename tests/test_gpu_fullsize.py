@@ -128,7 +128,7 @@ def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur, interp):
         assert torch.equal(dst2[t], dst_d[perm[t]])
 
 
-@pytest.mark.parametrize("shape", ["aligned", "th8", "bands_fastest", "loader3", "loader4", "loader6", "loader4_th5"])
+@pytest.mark.parametrize("shape", ["aligned", "th8", "bands_fastest", "xcd_runs", "loader3", "loader4", "loader6", "loader4_th5"])
 def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
     """the same 16-track launch in the shapes the switches select (64-lane strips, another band height, the loader-wave form k_pb_half_ld with rings of 3 / 4 / 6 row pairs and a band height that leaves a short last band): same bytes as the default shape,
     which test_c5_sixteen_track_4k_chain compares with the oracle -- and track 0 against the oracle here as well"""
@@ -144,8 +144,10 @@ def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
         tune("PBH_ALIGNED", 1)
     elif shape == "th8":
         tune("PBH_TH", 8)
-    elif shape == "bands_fastest":      # the work order of rounds 3 / 4 (the default now walks the column groups of a band first)
+    elif shape == "bands_fastest":      # the work order of rounds 3 / 4 (the default now deals a track's bands round robin to the XCDs, column groups fastest)
         tune("PBH_ORDER", 0)
+    elif shape == "xcd_runs":           # column groups fastest, every XCD a contiguous run of the sequence (what the blur chain keeps)
+        tune("PBH_ORDER", 1)
     else:
         tune("PBH_LOADER", int(shape[6]))
         if shape.endswith("th5"):

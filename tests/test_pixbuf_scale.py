@@ -298,7 +298,7 @@ def test_compositor_flow_scales_its_layers_as_the_reference_does(gpu, orc, psize
 
 
 @gpu_mark
-@pytest.mark.parametrize("strips64", [0, 1, 2, 3])
+@pytest.mark.parametrize("strips64", [0, 1, 2, 3, 4])
 def test_chain_on_the_pixbuf_arithmetic(gpu, orc, tune, strips64):
     """(both strip forms of k_pb_half: 62 storing lanes + 2 feeder lanes, and 64 storing lanes with the two outer taps from an extra load -- what full-device launches take)
     lgpu_chain with LGPU_INTERP_PIXBUF: convert -> gdk-pixbuf scale (4 channels, alpha-weighted) -> chroma blend -> gamma LUT == the oracle's composition
@@ -307,9 +307,9 @@ def test_chain_on_the_pixbuf_arithmetic(gpu, orc, tune, strips64):
     if strips64 == 2:           # the loader-wave form (k_pb_half_ld) on every plain 2:1 case, bands of 3 rows
         tune("PBH_LOADER", 4)
         tune("PBH_TH", 3)
-    elif strips64 == 3:         # 64-lane strips in the other work order (bands fastest)
+    elif strips64 >= 3:         # 64-lane strips in the other work orders (3: bands fastest, 4: column groups fastest in contiguous runs per XCD; the default deals bands round robin)
         tune("PBH_ALIGNED", 1)
-        tune("PBH_ORDER", 0)
+        tune("PBH_ORDER", strips64 - 3)
     else:
         tune("PBH_ALIGNED", strips64)
     PIXBUF = 0x100
