@@ -1622,23 +1622,16 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   a->strips = (int)cdiv((unsigned)a->dw, blur ? 120 : a->aligned ? 128 : 124);
   a->cgroups = (a->strips + 3) / 4;
   a->ntracks = ntracks;
-  // Band height.  Short bands win (profiles/r03/pbh_sweep*.txt, r04/al_ab1.txt: 4-6 rows within 1 %, 8 rows 5 % behind, 12 rows further), but with ~6 rows a
-  // full-device launch is only five or six generations of workgroups and the last, partly filled generation costs up to 6 % (16 tracks at 6 rows: 11,520 workgroups
-  // on 2,048 resident ones = 5.6 generations).  So when a launch does not fit into one generation, the number of bands per column is chosen -- between 5 and 7.5 rows
-  // per band, heights differing by one row at most -- so that the workgroups fill whole generations: the cheapest of generations x (rows per band + 1.5), the 1.5
-  // standing for a band's two extra source rows and its start-up.  With the blur a band computes th + 4 scaled rows, a full device wants tall bands, one frame short ones
+  // Band height.  Short bands win (profiles/r03/pbh_sweep*.txt, r04/al_ab1.txt: 4-6 rows within 1 %, 8 rows 5 % behind, 12 rows further).  One frame: 6 rows.  A launch of
+  // more than one generation of workgroups: 5 rows -- under the round-robin work order (pb_chain_half) the band count that fills whole generations no longer matters and
+  // finer bands sweep the frame more evenly (profiles/r04/band_count_sweep.txt: 16 tracks 160 bands 143.6-144.4 us, 192 142.2-142.7, **216 141.6**, 256 143.4, 288 143.1;
+  // rounds 3 / 4 chose 160 = whole generations).  With the blur a band computes th + 4 scaled rows, a full device wants tall bands, one frame short ones
   // (profiles/r03/blur_band_sweep.txt).
   const int per_cu = blur ? 6 : 8;                       // resident workgroups per CU (80 / <= 64 VGPRs)
   const long long slots = (long long)device_cus() * per_cu, cols = (long long)a->cgroups * ntracks;
   int bands = (int)cdiv((unsigned)a->dh, blur ? ((long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6u : 24u) : 6u);
-  if (!blur && cols * bands > slots) {
-    double best = 1e30;
-    for (int b = (int)cdiv(2u * (unsigned)a->dh, 15u); b <= (int)cdiv((unsigned)a->dh, 5u); b++) {
-      const double cost = (double)((cols * b + slots - 1) / slots) * ((double)a->dh / b + 1.5);
-      if (cost < best) { best = cost; bands = b; }
-    }
-  }
-  { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) bands = (int)cdiv((unsigned)a->dh, (unsigned)v); }       // tuning probe / tests: bands of (about) v rows
+  if (!blur && cols * bands > slots) bands = (a->dh + 2) / 5;
+  { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) bands = (int)cdiv((unsigned)a->dh, (unsigned)v); else if (v > 100000) bands = v - 100000; }       // tuning probe / tests: bands of (about) v rows, or 100000 + the number of bands
   pb_half_bands(a, bands);
 }
 
