@@ -1688,7 +1688,13 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
-#define PBH_LAUNCH(HY, BL, AL, SW) hipLaunchKernelGGL((k_pb_half<1, HY, BL, AL, SW>), grid, dim3(256), 0, st, a, T, l)
+  // Workgroups per CU (PBH_OCC): a launch of more than one generation runs FIVE workgroups per CU instead of the eight its registers allow -- unused dynamic LDS is what
+  // holds the others back.  Fewer bands in flight = a narrower window of the frames being streamed at any moment (profiles/r04/occupancy_sweep.txt: 8 / 7 / 6 / 5 / 4 / 3
+  // per CU 142.3 / 142.2 / 141.4 / 139.2 / 142.3 / 180 us per 16-track launch, 8 tracks 74.1 -> 72.8; with the gaussian 184 -> 187, so that chain keeps its six).
+  int occ = (!pr->do_blur && (long long)a.cgroups * a.bands * ntracks > (long long)device_cus() * 8) ? 5 : 0;
+  if (tune(TUNE_PBH_OCC) >= 0) occ = tune(TUNE_PBH_OCC);
+  const size_t occ_lds = occ > 0 && occ < 16 ? (size_t)(160 * 1024) / (size_t)occ - 3072 : 0;
+#define PBH_LAUNCH(HY, BL, AL, SW) hipLaunchKernelGGL((k_pb_half<1, HY, BL, AL, SW>), grid, dim3(256), occ_lds, st, a, T, l)
 #define PBH_SWAP(HY, BL, AL) do { if (a.swap_rb) PBH_LAUNCH(HY, BL, AL, 1); else PBH_LAUNCH(HY, BL, AL, 0); } while (0)
   if (pr->do_blur) {
     if (a.hyper) PBH_SWAP(1, 1, 0); else PBH_SWAP(0, 1, 0);
