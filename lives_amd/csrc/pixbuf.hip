@@ -207,6 +207,7 @@ struct PbHalfArgs {
   int bar_first;                 // the bars' workgroups come FIRST in the grid (a multiple of 8, so the frame's workgroups keep their XCD): they run while the frame's first loads are in flight
   int nt_out;
   int nt_in;                     // probe (LGPU_PBH_NT_IN): non-temporal loads for a band's inner source rows
+  int bgroup;                    // order 2: neighbouring bands per XCD turn (PBH_GROUP)
   int row_major;                 // work order (PBH_ORDER): 0 bands fastest, 1 column groups fastest, 2 that with the bands dealt round robin to the XCDs
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
 };
@@ -378,14 +379,15 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   int strip = 0, band = 0, track = 0;
   bool spare = (seq >= nseq || slot >= per_xcd) && A.row_major != 2;
   if (!spare) {
-    if (A.row_major == 2) {                                 // the bands of a track dealt round robin to the XCDs, column groups fastest: all XCDs sweep ONE frame together
-      const int nb = (A.bands + 7 - xcd) >> 3, per_track = nb * A.cgroups;
+    if (A.row_major == 2) {                                 // groups of A.bgroup neighbouring bands dealt round robin to the XCDs, column groups fastest: all XCDs sweep ONE frame together
+      const int G = A.bgroup, ngroups = (A.bands + G - 1) / G, ng_x = (ngroups + 7 - xcd) >> 3, per_track = ng_x * G * A.cgroups;
       spare = per_track == 0 || slot >= per_track * A.ntracks;
       if (!spare) {
         track = slot / per_track;
-        const int idx = slot - track * per_track, bi = idx / A.cgroups;
-        band = xcd + 8 * bi;
+        const int idx = slot - track * per_track, bi = idx / A.cgroups, gi = bi / G;
+        band = G * (xcd + 8 * gi) + (bi - gi * G);
         strip = (idx - bi * A.cgroups) * 4 + wave;
+        spare = band >= A.bands;
       }
     } else if (A.row_major) {                                      // column groups fastest: consecutive workgroups of an XCD read one band across the whole row (contiguous 15 KB per source row)
       const int per_track = A.cgroups * A.bands;
@@ -1630,12 +1632,13 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   const int per_cu = blur ? 6 : 8;                       // resident workgroups per CU (80 / <= 64 VGPRs)
   const long long slots = (long long)device_cus() * per_cu, cols = (long long)a->cgroups * ntracks;
   int bands = (int)cdiv((unsigned)a->dh, blur ? ((long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6u : 24u) : 6u);
-  if (!blur && cols * bands > slots) bands = (a->dh + 2) / 5;
+  if (blur && cols * bands > slots) bands = 8 * std::max(1, (bands + 4) / 8);            // a multiple of 8 here too (16 tracks: 45 bands 179-181 us, 48 bands 177)
+  if (!blur && cols * bands > slots) bands = 8 * std::max(1, (a->dh + 20) / 40);       // ~5 rows per band, a multiple of 8: every XCD then owns the same number of bands (pb_chain_half)
   { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) bands = (int)cdiv((unsigned)a->dh, (unsigned)v); else if (v > 100000) bands = v - 100000; }       // tuning probe / tests: bands of (about) v rows, or 100000 + the number of bands
   pb_half_bands(a, bands);
 }
 
-static unsigned pb_half_grid(const PbHalfArgs &a) { return a.row_major == 2 ? 8u * (unsigned)(a.cgroups * a.ntracks) * cdiv((unsigned)a.bands, 8u) : 8u * cdiv((unsigned)(a.cgroups * a.bands * a.ntracks), 8u); }
+static unsigned pb_half_grid(const PbHalfArgs &a) { return a.row_major == 2 ? 8u * (unsigned)(a.cgroups * a.ntracks * a.bgroup) * cdiv(cdiv((unsigned)a.bands, (unsigned)a.bgroup), 8u) : 8u * cdiv((unsigned)(a.cgroups * a.bands * a.ntracks), 8u); }
 
 // the fused chain on the pixbuf arithmetic (lgpu_chain with LGPU_INTERP_PIXBUF): convert -> gdk-pixbuf 2:1 scale -> chroma blend -> gamma LUT in one launch.
 // LGPU_E_UNSUPPORTED when the geometry is not the exact aligned 2:1 case (the caller then runs the stages one by one).
@@ -1665,7 +1668,13 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   // 2: that, with the bands of a track dealt round robin to the XCDs, so that the whole device sweeps ONE frame at a time like a linear stream does: 151-152 -> 144.2, 8 tracks
   // 76.8 -> 74.3.  With the 5x5 gaussian in the chain neighbouring bands share ten source rows instead of two and want the same L2: 186 us with 1, 189 with 2 -- it keeps 1.
   a.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : (pr->do_blur ? 1 : 2);
+  // ... in groups of `bgroup` neighbouring bands per XCD turn.  What matters is that every XCD gets the SAME number of bands of a track (profiles/r04/group_ab.txt: 216 bands
+  // in groups of 1 / 3 / 9 / 27 -- 27 / 9 / 3 / 1 turns per XCD -- 138.2-140.3 us; groups of 2 / 4 / 5 / 13 / 25, which leave some XCDs a turn short, 143 / 143 / 152 / 166 / 194);
+  // among the balanced ones the largest group re-reads least: L2 -> fabric reads 769.5 / 698.8 / 675.2 / 667.3 MB per launch against 663.6 MB of source + layer 2.
+  // So: an eighth of the track's bands per XCD when the band count is a multiple of 8 (pb_half_geometry makes it one for full-device launches), else band by band.
+  a.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
+  if (a.bgroup <= 0) a.bgroup = (a.bands % 8 == 0) ? a.bands / 8 : 1;
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
   a.main_blocks = (int)pb_half_grid(a);
@@ -1875,8 +1884,9 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     PbHalfArgs h;
     if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
-      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 2;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 2; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
       pb_half_geometry(&h, 1);
+      if (h.bgroup <= 0) h.bgroup = (h.bands % 8 == 0) ? h.bands / 8 : 1;
       PbTracks T;
       T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
       h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.bar_first = 0; h.main_blocks = (int)pb_half_grid(h);
