@@ -128,7 +128,7 @@ def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur, interp):
         assert torch.equal(dst2[t], dst_d[perm[t]])
 
 
-@pytest.mark.parametrize("shape", ["aligned", "th8", "bands_fastest", "xcd_runs", "loader3", "loader4", "loader6", "loader4_th5"])
+@pytest.mark.parametrize("shape", ["aligned", "th8", "bands_fastest", "xcd_runs", "bands_one_by_one", "groups_of_5", "eight_per_cu", "loader3", "loader4", "loader6", "loader4_th5"])
 def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
     """the same 16-track launch in the shapes the switches select (64-lane strips, another band height, the loader-wave form k_pb_half_ld with rings of 3 / 4 / 6 row pairs and a band height that leaves a short last band): same bytes as the default shape,
     which test_c5_sixteen_track_4k_chain compares with the oracle -- and track 0 against the oracle here as well"""
@@ -148,6 +148,12 @@ def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
         tune("PBH_ORDER", 0)
     elif shape == "xcd_runs":           # column groups fastest, every XCD a contiguous run of the sequence (what the blur chain keeps)
         tune("PBH_ORDER", 1)
+    elif shape == "bands_one_by_one":   # all XCDs on one track, the bands dealt one by one instead of by eighths
+        tune("PBH_GROUP", 1)
+    elif shape == "groups_of_5":        # a group size that leaves some XCDs a turn short (216 bands = 44 groups: the padding slots of the grid must stay idle)
+        tune("PBH_GROUP", 5)
+    elif shape == "eight_per_cu":       # no dynamic-LDS cap on the workgroups per CU
+        tune("PBH_OCC", 0)
     else:
         tune("PBH_LOADER", int(shape[6]))
         if shape.endswith("th5"):
