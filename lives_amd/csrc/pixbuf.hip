@@ -568,54 +568,58 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
 #pragma unroll
   for (int i = 0; i < 5; i++) { ring[i][0] = 0; ring[i][1] = 0; ring[i][2] = 0; ring[i][3] = 0; }
   const int nsteps = vr1 - vr0 + 1;
-  for (int step = 0; step < nsteps; step++) {
-    const int vr = vstart + d * step;
-    const int yy = vr < 0 ? 0 : vr > A.dh - 1 ? A.dh - 1 : vr;
-    pb_u2 nl2;
-    nl2.x = 0; nl2.y = 0;
-    if (yy != produced) {
-      // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
-      const int r = d > 0 ? yy - ystart : ystart - yy;
-      const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
-      if (CHAIN) nl2 = load_l2(vr - d);
-      scale_row(qa, qb, 0u, 0u, cc, al);
-      qa = na; qb = nb;
-      produced = yy;
-      // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
-      uint32_t e[6], o[6];
-      e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
-      e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
-      e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
-      e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
-      e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
-      if (edge_strip) {       // the gaussian replicates the frame's first / last column
-        if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
-        if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
+  // the ring rotates by slot index, five steps per trip of the outer loop: slot u takes the new row, (u + 1) % 5 is the oldest -- no register moves (the rolled loop
+  // shifted the ring down every step: 16 moves per scaled row)
+  for (int step0 = 0; step0 < nsteps; step0 += 5) {
+#pragma unroll
+    for (int u = 0; u < 5; u++) {
+      const int step = step0 + u;
+      if (step >= nsteps) break;
+      const int vr = vstart + d * step;
+      const int yy = vr < 0 ? 0 : vr > A.dh - 1 ? A.dh - 1 : vr;
+      pb_u2 nl2;
+      nl2.x = 0; nl2.y = 0;
+      if (yy != produced) {
+        // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
+        const int r = d > 0 ? yy - ystart : ystart - yy;
+        const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
+        if (CHAIN) nl2 = load_l2(vr - d);
+        scale_row(qa, qb, 0u, 0u, cc, al);
+        qa = na; qb = nb;
+        produced = yy;
+        // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
+        uint32_t e[6], o[6];
+        e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
+        e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
+        e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
+        e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
+        e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
+        if (edge_strip) {       // the gaussian replicates the frame's first / last column
+          if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
+          if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
+        }
+        ring[u][0] = gauss5_taps(e[0], e[1], e[2], e[3], e[4]); ring[u][1] = gauss5_taps(o[0], o[1], o[2], o[3], o[4]);
+        ring[u][2] = gauss5_taps(e[1], e[2], e[3], e[4], e[5]); ring[u][3] = gauss5_taps(o[1], o[2], o[3], o[4], o[5]);
+      } else {          // a row beyond the frame's first / last: the border row again
+        if (CHAIN) nl2 = load_l2(vr - d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) ring[u][i] = ring[(u + 4) % 5][i];
       }
+      if (step >= 4) {                    // the ring holds the five rows around output row vr - 2 d: oldest (u + 1) % 5 ... newest u
+        const int y = vr - 2 * d;
+        const uint32_t *r0 = ring[(u + 1) % 5], *r1 = ring[(u + 2) % 5], *r2 = ring[(u + 3) % 5], *r3 = ring[(u + 4) % 5], *r4 = ring[u];
+        uint32_t pxo[2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
-      ring[4][0] = gauss5_taps(e[0], e[1], e[2], e[3], e[4]); ring[4][1] = gauss5_taps(o[0], o[1], o[2], o[3], o[4]);
-      ring[4][2] = gauss5_taps(e[1], e[2], e[3], e[4], e[5]); ring[4][3] = gauss5_taps(o[1], o[2], o[3], o[4], o[5]);
-    } else {          // a row beyond the frame's first / last: the border row again
-      if (CHAIN) nl2 = load_l2(vr - d);
-      const uint32_t t0 = ring[4][0], t1 = ring[4][1], t2 = ring[4][2], t3 = ring[4][3];
-#pragma unroll
-      for (int i = 0; i < 4; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
-      ring[4][0] = t0; ring[4][1] = t1; ring[4][2] = t2; ring[4][3] = t3;
-    }
-    if (step >= 4) {                    // the ring holds the five rows around output row vr - 2 d
-      const int y = vr - 2 * d;
-      uint32_t pxo[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const uint32_t ve = gauss5_taps(ring[0][2 * j], ring[1][2 * j], ring[2][2 * j], ring[3][2 * j], ring[4][2 * j], 0x00800080u);
-        const uint32_t vo = gauss5_taps(ring[0][2 * j + 1], ring[1][2 * j + 1], ring[2][2 * j + 1], ring[3][2 * j + 1], ring[4][2 * j + 1], 0x00800080u);
-        // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
-        pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
+        for (int j = 0; j < 2; j++) {
+          const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
+          const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
+          // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
+          pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
+        }
+        store_row(y, pxo[0], pxo[1]);
       }
-      store_row(y, pxo[0], pxo[1]);
+      if (step >= 3) l2 = nl2;
     }
-    if (step >= 3) l2 = nl2;
   }
 }
 
