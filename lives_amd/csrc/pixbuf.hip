@@ -1671,13 +1671,16 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   // 1: the column groups of a band one after the other -- consecutive workgroups read a band across the whole row: 16 tracks 147.5 -> 142.3 us on one box, 152 -> 146 on another;
   // 2: that, with the bands of a track dealt round robin to the XCDs, so that the whole device sweeps ONE frame at a time like a linear stream does: 151-152 -> 144.2, 8 tracks
   // 76.8 -> 74.3.  With the 5x5 gaussian in the chain neighbouring bands share ten source rows instead of two and want the same L2: 186 us with 1, 189 with 2 -- it keeps 1.
-  a.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : (pr->do_blur ? 1 : 2);
+  a.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : -1;       // -1: decided below, once the geometry is known
   // ... in groups of `bgroup` neighbouring bands per XCD turn.  What matters is that every XCD gets the SAME number of bands of a track (profiles/r04/group_ab.txt: 216 bands
   // in groups of 1 / 3 / 9 / 27 -- 27 / 9 / 3 / 1 turns per XCD -- 138.2-140.3 us; groups of 2 / 4 / 5 / 13 / 25, which leave some XCDs a turn short, 143 / 143 / 152 / 166 / 194);
   // among the balanced ones the largest group re-reads least: L2 -> fabric reads 769.5 / 698.8 / 675.2 / 667.3 MB per launch against 663.6 MB of source + layer 2.
   // So: an eighth of the track's bands per XCD when the band count is a multiple of 8 (pb_half_geometry makes it one for full-device launches), else band by band.
   a.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
+  // a launch that fits one generation of workgroups (one or two 4K tracks) is a matter of latency, not of streaming order: order 1 there (graph replay, one frame 12.09 us
+  // against 12.45 with order 2 and 12.24 with order 0; config 3 12.19 / 12.62 / 12.33; two tracks 20.0 / 21.05 / 20.5)
+  if (a.row_major < 0) a.row_major = (!pr->do_blur && (long long)a.cgroups * a.bands * ntracks > (long long)device_cus() * 8) ? 2 : 1;
   if (a.bgroup <= 0) a.bgroup = (a.bands % 8 == 0) ? a.bands / 8 : 1;
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
@@ -1888,7 +1891,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     PbHalfArgs h;
     if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
-      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 2; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 1; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
       pb_half_geometry(&h, 1);
       if (h.bgroup <= 0) h.bgroup = (h.bands % 8 == 0) ? h.bands / 8 : 1;
       PbTracks T;
