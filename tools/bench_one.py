@@ -18,11 +18,15 @@ def main():
     ops.init(0)
     names = sys.argv[1:]
     cold = two = False
+    nstreams = 2
     while names and names[0].startswith("--"):
         if names[0] == "--cold":
             cold = True
         elif names[0] == "--two-streams":      # launches alternate between two streams inside the graph (independent buffer sets): the drain of one overlaps the ramp-up of the next
             two = True
+        elif names[0].startswith("--streams="):      # the same over N streams (buffer sets a multiple of N)
+            two = True
+            nstreams = int(names[0].split("=")[1])
         names = names[1:]
     for op in names:
         prof_one.NB = 6
@@ -30,32 +34,35 @@ def main():
             prof_one.NB = 1
             _, nbytes = prof_one.case(op)
             prof_one.NB = max(4, int(1.6e9 / nbytes) + 1)
-            prof_one.NB += prof_one.NB % 2
+            prof_one.NB += (-prof_one.NB) % (nstreams if two else 2)
             prof_one.COLD = True
             torch.cuda.empty_cache()
         fn, nbytes = prof_one.case(op)
         for i in range(60):
             fn(i)
         torch.cuda.synchronize()
-        side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+        side = torch.cuda.Stream()
+        others = [torch.cuda.Stream() for _ in range(nstreams - 1)]
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
         per = 4 * prof_one.NB if prof_one.NB <= 8 else prof_one.NB
-        per -= per % 2 if two else 0
-        if two and prof_one.NB % 2:
-            raise SystemExit("--two-streams needs an even number of buffer sets (a set stays on one stream)")
+        per -= per % nstreams if two else 0
+        if two and prof_one.NB % nstreams:
+            raise SystemExit("N streams need a multiple of N buffer sets (a set stays on one stream)")
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
                 if two:
-                    side2.wait_stream(side)
+                    for o in others:
+                        o.wait_stream(side)
                 for i in range(per):
-                    if two and (i & 1):
-                        with torch.cuda.stream(side2):
+                    if two and (i % nstreams):
+                        with torch.cuda.stream(others[i % nstreams - 1]):
                             fn(i)
                     else:
                         fn(i)
                 if two:
-                    side.wait_stream(side2)
+                    for o in others:
+                        side.wait_stream(o)
         for _ in range(5):
             graph.replay()
         torch.cuda.synchronize()
@@ -68,7 +75,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / (20 * per))
-        print("%-28s %7.2f us  %7.1f GB/s  %.3f of 8 TB/s%s" % (op, best, nbytes / best / 1e3, nbytes / best / 1e3 / 8000.0, ("   (cold: %d buffer sets)" % prof_one.NB if cold else "") + ("   (two streams)" if two else "")), flush=True)
+        print("%-28s %7.2f us  %7.1f GB/s  %.3f of 8 TB/s%s" % (op, best, nbytes / best / 1e3, nbytes / best / 1e3 / 8000.0, ("   (cold: %d buffer sets)" % prof_one.NB if cold else "") + ("   (%d streams)" % nstreams if two else "")), flush=True)
         del fn, graph
         torch.cuda.empty_cache()
 
