@@ -89,11 +89,13 @@ lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, in
 lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
                                               int osamp_hint, int osubs_hint, int tgt_gamma);
 /* which of the reference's two resize bodies resize_layer / resize_layer_full (and the scaling inside letterbox_layer / unletterbox_layer) follow:
-   LIVES_GPU_RESIZE_POLYPHASE (default) -- the swscale body's place (src/colourspace.c:14940-15259); libswscale is un-vendored and unpinned, so the
-     arithmetic is this library's own spec "lgpu-polyphase-v1" (DESIGN.md section 5), every palette, fused target gamma;
-   LIVES_GPU_RESIZE_PIXBUF -- the gdk-pixbuf body (:15262-15322), bit-exact to gdk_pixbuf_scale_simple 2.42.8 for the palettes of its switch (RGB24, BGR24,
-     RGBA32, BGRA32, YUV888, YUVA8888): alpha-weighted colours on 4-byte palettes, rowstride ALIGN4(width * channels), RGB layers come back tagged
-     WEED_GAMMA_SRGB, no gamma pass; other palettes keep the polyphase body.  A separate call so that lives_gpu_prefs keeps its layout.  Returns 0, -1 on a bad value. */
+   LIVES_GPU_RESIZE_PIXBUF (default) -- the gdk-pixbuf body (src/colourspace.c:15262-15322), bit-exact to gdk_pixbuf_scale_simple 2.42.8 for the palettes of
+     its switch (RGB24, BGR24, RGBA32, BGRA32, YUV888, YUVA8888): alpha-weighted colours on 4-byte palettes, rowstride ALIGN4(width * channels), RGB layers
+     come back tagged WEED_GAMMA_SRGB, no gamma pass.  A palette outside the switch that needs scaling fails as that body does (:15303-15307: the warning on
+     stderr, FALSE, the layer as it came -- a pinned one synchronised and unpinned), so the caller's own CPU body or the other backend takes it;
+   LIVES_GPU_RESIZE_POLYPHASE -- the swscale body's place (:14940-15259), the choice of a host "built with USE_SWSCALE"; libswscale is un-vendored and
+     unpinned, so the arithmetic is this library's own spec "lgpu-polyphase-v1" (DESIGN.md), every palette, fused target gamma.
+   A separate call so that lives_gpu_prefs keeps its layout.  Returns 0, -1 on a bad value. */
 enum { LIVES_GPU_RESIZE_POLYPHASE = 0, LIVES_GPU_RESIZE_PIXBUF = 1 };
 int lives_gpu_set_resize_backend(int backend);
 int lives_gpu_get_resize_backend(void);

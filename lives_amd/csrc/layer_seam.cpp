@@ -19,6 +19,7 @@
 // the resident buffers directly, new planes are pool buffers registered under the new host pointer, nothing is copied and
 // nothing synchronises -- the calls of a chain only enqueue work, the one synchronisation is lives_gpu_layer_sync().
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <sched.h>
 #include <string.h>
@@ -1065,8 +1066,9 @@ static int plan_resize(weed_plant_t *layer, int width, int height, int opal_hint
 // ---- resize backend ------------------------------------------------------------------------------------------------------------------
 // resize_layer_full has two bodies in the reference: the swscale one (:14940-15259; un-vendored, version unpinned -> this library's own
 // polyphase spec) and the gdk-pixbuf one (:15262-15322: layer_to_pixbuf, lives_pixbuf_scale_simple, pixbuf_to_layer).
-// The second is pinned byte for byte (pixbuf.hip); a host that wants the reference's pinned arithmetic selects it here.
-static std::atomic<int> g_resize_backend{LIVES_GPU_RESIZE_POLYPHASE};
+// The second is pinned byte for byte (pixbuf.hip) and is the DEFAULT: a host that links the seam and calls resize_layer / letterbox_layer as the
+// reference does gets arithmetic a reference binary pins.  The polyphase body is the opt-in of a host "built with USE_SWSCALE".
+static std::atomic<int> g_resize_backend{LIVES_GPU_RESIZE_PIXBUF};
 int lives_gpu_set_resize_backend(int backend) {
   if (backend != LIVES_GPU_RESIZE_POLYPHASE && backend != LIVES_GPU_RESIZE_PIXBUF) return -1;
   g_resize_backend.store(backend);
@@ -1079,23 +1081,31 @@ static bool pal_is_pixbuf(int pal) {      // the cases of the switch at :15275-1
          pal == WEED_PALETTE_YUV888 || pal == WEED_PALETTE_YUVA8888;
 }
 
-// The pixbuf body.  Returns -1 when this body does not apply (palette outside the switch: the reference prints "resizing unknown palette" and fails;
-// this library serves those through the polyphase body instead), else the value resize_layer_full returns.
+// The pixbuf body: the value resize_layer_full returns.  A palette outside the switch fails as the reference's body does (:15303-15307: the warning, FALSE,
+// the layer as it came); a host that wants those palettes scaled on the device selects the polyphase backend, one that keeps its CPU bodies runs its own.
 //   * size rules of the common prologue (:14854-14868): even source size only for the "nothing to do" test, width / height >= 4, even target height
 //   * clamped YUV888 / YUVA8888 is first switched to unclamped (:15277-15284)
 //   * the WHOLE layer (odd sizes included: the sizes are re-read at :15263-15264) is scaled; 4-byte palettes weight colours by alpha
 //   * the new frame has the pixbuf's rowstride, ALIGN4(width * channels), and RGB layers come back tagged WEED_GAMMA_SRGB (pixbuf_to_layer :14378-14379,
 //     :14405-14406), whatever they were tagged before; no gamma LUT runs in this body
+static int width_pixels(const Layer &l) {       // weed_layer_get_width_pixels: the width leaf counts macropixels
+  return (l.pal == WEED_PALETTE_UYVY || l.pal == WEED_PALETTE_YUYV) ? l.width * 2 : l.pal == WEED_PALETTE_YUV411 ? l.width * 4 : l.width;
+}
 static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int interp) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
-  if (!pal_is_pixbuf(l.pal) || (interp != LIVES_INTERP_FAST && interp != LIVES_INTERP_NORMAL && interp != LIVES_INTERP_BEST)) return -1;
   if (width <= 0 || height <= 0) return 0;
-  const int iwidth = (l.width >> 1) << 1, iheight = (l.height >> 1) << 1;
+  const int iwidth = (width_pixels(l) >> 1) << 1, iheight = (l.height >> 1) << 1;
   if (width < 4) width = 4;
   if (height < 4) height = 4;
   if (iwidth != width || iheight != height) height = (height >> 1) << 1;
   if (iwidth == width && iheight == height) return 1;
+  if (width_pixels(l) == width && l.height == height) return 1;                     // "no resize needed" (:15265-15270) comes before the switch, for every palette
+  if (!pal_is_pixbuf(l.pal) || (interp != LIVES_INTERP_FAST && interp != LIVES_INTERP_NORMAL && interp != LIVES_INTERP_BEST)) {
+    if (!pal_is_pixbuf(l.pal)) fprintf(stderr, "Warning: resizing unknown palette %d\n", l.pal);
+    fprintf(stderr, "unable to scale layer to %d x %d for palette %d\n", width, height, l.pal);
+    return decline(layer);
+  }
   if ((l.pal == WEED_PALETTE_YUV888 || l.pal == WEED_PALETTE_YUVA8888) && l.clamping != WEED_YUV_CLAMPING_UNCLAMPED) {
     if (!lives_gpu_convert_layer_palette(layer, l.pal, WEED_YUV_CLAMPING_UNCLAMPED)) return 0;
     if (!read_layer(layer, &l)) return 0;
@@ -1129,10 +1139,7 @@ lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int widt
   return pin.settle(resize_layer_full_body(layer, width, height, interp, opal_hint, osubs_hint, tgt_gamma));
 }
 static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int osubs_hint, int tgt_gamma) {
-  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF) {
-    const int done = resize_pixbuf_body(layer, width, height, interp);
-    if (done >= 0) return done;
-  }
+  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF) return resize_pixbuf_body(layer, width, height, interp);
   ResizePlan rp;
   int rc;
   if (plan_resize(layer, width, height, opal_hint, osubs_hint, tgt_gamma, &rp, &rc) != 1) return rc;
@@ -1165,7 +1172,7 @@ static lives_gpu_boolean letterbox_layer_body(lives_gpu_layer_t *layer, int nwid
   ResizePlan rp;
   int rc, todo = 2;
   if (!ready() || !read_layer(layer, &rp.l)) return 0;
-  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF && pal_is_pixbuf(rp.l.pal) && (rp.l.width != width || rp.l.height != height)) {
+  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF && (width_pixels(rp.l) != width || rp.l.height != height)) {
     // the pixbuf body as the reference runs it: resize_layer first (:15389), then the blit of the frame it left
     if (!lives_gpu_resize_layer(layer, width, height, interp, tpal, tclamp)) return 0;
     if (!read_layer(layer, &rp.l)) return 0;

@@ -82,11 +82,6 @@ typedef int lives_thread_t;
 typedef void *(*lives_thread_func_t)(void *);
 #define lives_thread_create(thr, attr, func, arg) (*(thr) = NULL, (void)(func)(arg), 0)
 #define lives_thread_join(thr, ret) do {} while (0)
-static void swab4(const void *to, const void *from, size_t gran) {
-  /* memory.c:1501 equivalent for granularity 1: reverse 4 bytes */
-  const uint8_t *f = (const uint8_t *)from; uint8_t *t = (uint8_t *)to, tmp[4];
-  (void)gran; tmp[0] = f[3]; tmp[1] = f[2]; tmp[2] = f[1]; tmp[3] = f[0]; memcpy(t, tmp, 4);
-}
 '''
 
 THREADVAR = r'''
@@ -425,6 +420,9 @@ def main():
     cs = "src/colourspace.c"
     ch = "src/colourspace.h"
     parts = [PRELUDE]
+    parts.append(lines("src/memory.c", 1481, 1484))   # union split4
+    parts.append(lines("src/memory.c", 1491, 1498))   # swab2 (over libc's swab)
+    parts.append(lines("src/memory.c", 1501, 1522))   # swab4: the byte reversal the K1 swap4 family calls -- the prelude carries no pixel code
     parts.append(lines("src/maths.h", 88, 88))      # CLAMP0255f
     parts.append(lines("src/maths.h", 101, 104))    # CEIL, ALIGN_CEIL
     parts.append(lines("src/maths.h", 118, 118))    # myround

@@ -24,7 +24,11 @@ def seam():
     from tests import weedhost
     L = lib.load()
     weedhost.bind(L)
-    return L, weedhost
+    # this module exercises the swscale body's stand-in ("host built with USE_SWSCALE"): every palette, fused target gamma, the library's own polyphase spec.
+    # The seam's default is the pinned gdk-pixbuf body (tests/test_layer_seam_pixbuf.py, tests/test_dropin.py).
+    assert L.lives_gpu_set_resize_backend(0) == 0
+    yield L, weedhost
+    assert L.lives_gpu_set_resize_backend(1) == 0
 
 
 @needs_ref

@@ -26,10 +26,9 @@ def seam():
 @pytest.fixture()
 def pixbuf_backend(seam):
     L, _ = seam
-    assert L.lives_gpu_get_resize_backend() == POLYPHASE
-    assert L.lives_gpu_set_resize_backend(7) == -1 and L.lives_gpu_set_resize_backend(PIXBUF) == 0
+    assert L.lives_gpu_get_resize_backend() == PIXBUF, "the pinned body is the seam's default"
+    assert L.lives_gpu_set_resize_backend(7) == -1 and L.lives_gpu_get_resize_backend() == PIXBUF
     yield
-    assert L.lives_gpu_set_resize_backend(POLYPHASE) == 0
 
 
 def want_scaled(orc, src, sw, sh, dw, dh, ch, interp):
@@ -78,16 +77,42 @@ def test_size_rules_of_the_common_prologue(seam, orc, pixbuf_backend):
     assert (wh.planes_of(lay)[0][0][:20, :16] == want).all()
 
 
-def test_palettes_outside_the_pixbuf_switch_keep_the_polyphase_body(seam, orc, pixbuf_backend):
+def test_palettes_outside_the_pixbuf_switch_fail_as_the_reference_body_does(seam, orc, pixbuf_backend):
+    """src/colourspace.c:15303-15307: "Warning: resizing unknown palette", retval FALSE, the layer as it came (a pinned one synchronised and unpinned); the
+    nothing-to-do tests (:14854-14868, :15265-15270) come before the switch and answer TRUE for every palette; the polyphase backend is the opt-in that scales them"""
     L, wh = seam
     rng = np.random.default_rng(0x9DB5)
     src = frame(rng, 128, 64, 4)
-    lay = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
-    assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1
-    planes, _, rs = wh.planes_of(lay)
-    want = np.zeros((32, rs[0]), np.uint8)
-    assert orc.orc_resize(P(src), src.strides[0], 128, 64, P(want), rs[0], 64, 32, 4, 3) == 0
-    assert (planes[0][:, :256] == want[:, :256]).all()
+    for pinned in (0, 1):
+        lay = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
+        if pinned:
+            assert L.lives_gpu_layer_pin(lay) == 0
+        assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 0
+        assert wh.geti(lay, "host_gpu_resident") is None
+        assert (wh.geti(lay, "width"), wh.geti(lay, "height"), wh.geti(lay, "current_palette")) == (128, 64, ARGB32)
+        assert (wh.planes_of(lay)[0][0] == src).all()
+        assert L.lives_gpu_resize_layer(lay, 128, 64, 3, 0, 0) == 1                       # no resize needed
+        assert L.lives_gpu_letterbox_layer(lay, 160, 80, 64, 32, 3, 0, 0) == 0           # the inner resize fails first (:15389)
+        assert (wh.geti(lay, "width"), wh.geti(lay, "height")) == (128, 64)
+    ys = align(128)
+    Y, U, V = frame(rng, 128, 64, 1), frame(rng, 64, 32, 1), frame(rng, 64, 32, 1)
+    lay = wh.new_layer(YUV420P, 128, 64, [Y, U, V], clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 0 and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (128, 64)
+    uy = frame(rng, 32, 32, 4)                                                            # UYVY: 32 macropixels = 64 pixels
+    lay = wh.new_layer(UYVY, 32, 32, [uy], clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1                            # width in PIXELS equals the layer's: nothing to do
+    assert L.lives_gpu_resize_layer(lay, 32, 32, 3, 0, 0) == 0 and wh.geti(lay, "width") == 32
+    # the opt-in: a host "built with USE_SWSCALE"
+    assert L.lives_gpu_set_resize_backend(POLYPHASE) == 0
+    try:
+        lay = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
+        assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1
+        planes, _, rs = wh.planes_of(lay)
+        want = np.zeros((32, rs[0]), np.uint8)
+        assert orc.orc_resize(P(src), src.strides[0], 128, 64, P(want), rs[0], 64, 32, 4, 3) == 0
+        assert (planes[0][:, :256] == want[:, :256]).all()
+    finally:
+        assert L.lives_gpu_set_resize_backend(PIXBUF) == 0
 
 
 def test_reductions_past_the_one_step_range_are_declined(seam, pixbuf_backend):
