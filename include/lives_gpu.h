@@ -29,7 +29,8 @@ enum {
   LGPU_E_BADARG = -2,
   LGPU_E_UNSUPPORTED = -3,
   LGPU_E_HIP = -4,        /* a HIP call failed; see lgpu_last_error() */
-  LGPU_E_NOMEM = -5
+  LGPU_E_NOMEM = -5,
+  LGPU_E_STATE = -6       /* the object is out of step after an earlier half-done call (lgpu_stepper): destroy it */
 };
 
 /* ---- runtime ----------------------------------------------------------------------------------- */
@@ -438,8 +439,10 @@ int lgpu_params_broadcast_n(void *comm, int root, int32_t *param_blocks_d, int n
    the same n; values = n x 4 ints, read on the root only): a render knows its schedule ahead, and a live parameter is one feed of latency either way -- per step
    the host then pays the chain launch and 1 / n of an exchange.  lgpu_chain_step with next_values != NULL is the one-block-ahead form of the same thing.
    comm == NULL: one GPU, nothing to exchange -- the blocks are written on the launch stream.  tools/worker.c is the render-worker loop on top of it.
-   Errors: LGPU_E_BADARG from argument checks leaves the stepper untouched (repeat the call); any other error leaves this rank out of step with its peers -- every
-   later call fails, destroy the stepper. */
+   Errors: LGPU_E_BADARG comes from argument checks only -- EVERY check lgpu_chain makes on the same arguments is made before anything is fed or enqueued -- and
+   leaves the stepper untouched (repeat the call); any other error leaves this rank out of step with its peers: lgpu_stepper_failed() turns 1, every later call
+   returns LGPU_E_STATE, destroy the stepper.  lgpu_stepper_timeout_ms: how long a rank waits inside an exchange for its peers before it reports which call hung
+   (0 = for ever, the default); a timed-out stepper is failed like any other. */
 typedef struct lgpu_stepper lgpu_stepper;
 int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, const int32_t first_values[4], lgpu_stepper **out);
 int lgpu_stepper_feed(lgpu_stepper *s, const int32_t *values, int n);
@@ -449,6 +452,8 @@ int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_ch
 /* a second launch stream: odd steps go there, so that the drain of one frame's launch overlaps the ramp-up of the next (frames of consecutive steps are independent).
    NULL switches it off.  The caller synchronises both streams before reading results. */
 int lgpu_stepper_overlap(lgpu_stepper *s, void *second_launch_stream);
+int lgpu_chain_check(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks);     /* lgpu_chain's argument checks alone (no device work): LGPU_OK or LGPU_E_BADARG */
+int lgpu_stepper_failed(const lgpu_stepper *s);                           /* 1 after a half-done call, else 0 */
 const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 64 (tests); NULL for a negative index */
 int lgpu_stepper_destroy(lgpu_stepper *s);
 

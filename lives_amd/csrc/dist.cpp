@@ -166,7 +166,7 @@ struct lgpu_stepper {
 // n >= 1 blocks for steps fed .. fed + n - 1 (values: n x 4 ints, read on the root only; NULL elsewhere is fine).  Every rank calls it with the same n.
 int lgpu_stepper_feed(lgpu_stepper *s, const int32_t *values, int n) {
   if (!s || n < 1 || n > kStepRing) { lgpu::set_error("lgpu_stepper_feed: bad arguments"); return LGPU_E_BADARG; }
-  if (s->failed) { lgpu::set_error("lgpu_stepper_feed: an earlier call failed half way; the stepper is out of step with its peers: destroy it"); return LGPU_E_BADARG; }
+  if (s->failed) { lgpu::set_error("lgpu_stepper_feed: an earlier call failed half way; the stepper is out of step with its peers: destroy it"); return LGPU_E_STATE; }
   if (s->fed + n - s->step > kStepRing) { lgpu::set_error("lgpu_stepper_feed: %ld blocks are waiting for their steps; the ring holds %d", s->fed - s->step, (int)kStepRing); return LGPU_E_BADARG; }
   const bool is_root = s->rank == s->root;
   if (is_root && !values) { lgpu::set_error("lgpu_stepper_feed: the root needs values"); return LGPU_E_BADARG; }
@@ -227,11 +227,9 @@ int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, con
 // the values matter on the root only).  Arguments are checked BEFORE anything is enqueued: a call that returns LGPU_E_BADARG has changed nothing and may be repeated.
 int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks) {
   if (!s || !params || !tracks || ntracks < 1 || ntracks > LGPU_CHAIN_MAX_TRACKS) { lgpu::set_error("lgpu_chain_step: bad arguments"); return LGPU_E_BADARG; }
-  if (s->failed) { lgpu::set_error("lgpu_chain_step: an earlier call failed half way; the stepper is out of step with its peers: destroy it"); return LGPU_E_BADARG; }
-  if (params->sw <= 0 || params->sh <= 0 || params->dw <= 0 || params->dh <= 0 || params->irow < params->sw * 4 || params->orow < params->dw * 4 ||
-      params->irow2 < params->dw * 4 || ((params->irow | params->orow | params->irow2) & 3)) { lgpu::set_error("lgpu_chain_step: bad geometry"); return LGPU_E_BADARG; }
-  for (int i = 0; i < ntracks; i++)
-    if (!tracks[i].src_d || !tracks[i].layer2_d || !tracks[i].dst_d) { lgpu::set_error("lgpu_chain_step: null track pointer"); return LGPU_E_BADARG; }
+  if (s->failed) { lgpu::set_error("lgpu_chain_step: an earlier call failed half way; the stepper is out of step with its peers: destroy it"); return LGPU_E_STATE; }
+  // every argument check of lgpu_chain BEFORE anything is fed or enqueued (lgpu_chain_check is the list lgpu_chain itself runs): BADARG then really means "untouched"
+  { const int bad = lgpu_chain_check(params, tracks, ntracks); if (bad) return bad; }
   if (s->step >= s->fed) { lgpu::set_error("lgpu_chain_step: no parameter block has been fed for step %ld", s->step); return LGPU_E_BADARG; }
   static const int32_t zero[4] = {0, 0, 0, 0};
   int rc;
@@ -247,7 +245,7 @@ int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_ch
   lgpu_chain_params p = *params;
   p.param_block_d = s->blk + 4 * (s->step % kStepRing);
   rc = lgpu_chain(&p, tracks, ntracks, st);
-  if (rc) { s->failed = 1; return rc; }          // the exchange for this step has happened on every rank; this rank's launch has not
+  if (rc) { s->failed = 1; return rc == LGPU_E_BADARG ? LGPU_E_STATE : rc; }          // the exchange for this step has happened on every rank; this rank's launch has not (never BADARG: that code means "untouched")
   s->step++;
   return LGPU_OK;
 }
@@ -258,10 +256,16 @@ int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_ch
 // The caller synchronises BOTH streams (or destroys the stepper) before it reads results.
 int lgpu_stepper_overlap(lgpu_stepper *s, void *second_launch_stream) {
   if (!s) { lgpu::set_error("lgpu_stepper_overlap: null stepper"); return LGPU_E_BADARG; }
-  if (s->failed) return LGPU_E_BADARG;
+  if (s->failed) { lgpu::set_error("lgpu_stepper_overlap: the stepper is out of step: destroy it"); return LGPU_E_STATE; }
   int rc = LGPU_OK;
   if (second_launch_stream && !s->tail2 && (rc = lgpu_event_create(&s->tail2))) return rc;
   if (second_launch_stream && !s->tail && (rc = lgpu_event_create(&s->tail))) return rc;
+  if (s->launch2 && s->launch2 != second_launch_stream) {
+    // the stream being dropped (or replaced) may still run odd steps that read ring slots: the first launch stream -- and the side stream, which rewrites the slots when
+    // there is a communicator -- go behind it now, since no later fence will look at it
+    if ((rc = lgpu_event_record(s->tail2, s->launch2)) || (rc = lgpu_stream_wait_event(s->launch, s->tail2))) return rc;
+    if (s->comm && (rc = lgpu_stream_wait_event(s->side, s->tail2))) return rc;
+  }
   if (second_launch_stream) {
     // everything fed so far is visible to the new stream: order it behind the stream the blocks were written / received on
     void *from = s->comm ? s->side : s->launch;
@@ -271,6 +275,8 @@ int lgpu_stepper_overlap(lgpu_stepper *s, void *second_launch_stream) {
   s->launch2 = second_launch_stream;
   return LGPU_OK;
 }
+
+int lgpu_stepper_failed(const lgpu_stepper *s) { return s && s->failed ? 1 : 0; }
 
 const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which) { return (s && which >= 0) ? s->blk + 4 * (which % kStepRing) : nullptr; }
 

@@ -1372,25 +1372,36 @@ static std::mutex g_pb_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, PbTable *> g_pb_tables;
 static unsigned long long g_pb_clock = 0;
 
-static void pb_free_device(PbTable *t, hipStream_t st) {
-  if (t->table_d) (void)hipFreeAsync(t->table_d, st);
-  if (t->pairs_d) (void)hipFreeAsync(t->pairs_d, st);
-  if (t->gpairs_d) (void)hipFreeAsync(t->gpairs_d, st);
+// `ordered` false: the caller could not order `st` behind every user of the table (or st itself is gone) -- the device is drained first, then the blocks are freed outright
+static void pb_free_device(PbTable *t, hipStream_t st, bool ordered = true) {
+  void *blocks[3] = {t->table_d, t->pairs_d, t->gpairs_d};
+  for (void *b : blocks) {
+    if (!b) continue;
+    if (ordered && hipFreeAsync(b, st) == hipSuccess) continue;
+    (void)hipGetLastError();
+    if (ordered) { (void)hipDeviceSynchronize(); ordered = false; }       // a destroyed home stream (hipFreeAsync failed): everything it and the others launched is over after this
+    (void)hipFree(b);
+  }
   t->table_d = nullptr; t->pairs_d = nullptr; t->gpairs_d = nullptr;
   (void)hipGetLastError();
 }
 // an entry no longer in the map and held by no call: its memory goes back behind everything its users have enqueued
 static void pb_retire(PbTable *t) {
+  // (entries are only ever retired on their own device: the eviction loop in pb_table looks at the current device's keys alone, so the events below are
+  // created where the streams live)
   hipStream_t home = t->users.empty() ? nullptr : t->users[0];
+  bool ordered = true;
   for (size_t i = 1; i < t->users.size(); i++) {
     hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
-      if (hipEventRecord(e, t->users[i]) == hipSuccess) (void)hipStreamWaitEvent(home, e, 0);       // a stream that is gone by now has finished its work: nothing to wait for
-      (void)hipEventDestroy(e);
-    }
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ordered = false; (void)hipGetLastError(); continue; }
+    if (hipEventRecord(e, t->users[i]) == hipSuccess) {
+      if (hipStreamWaitEvent(home, e, 0) != hipSuccess) ordered = false;       // the home stream is gone, or the wait could not be placed: drain instead
+    }                                                                          // (a USER stream that is gone has finished its work: nothing to wait for)
+    (void)hipEventDestroy(e);
     (void)hipGetLastError();
   }
-  pb_free_device(t, home);
+  if (!ordered) (void)hipDeviceSynchronize();
+  pb_free_device(t, home, ordered);
   delete t;
 }
 static int pb_upload(const void *host, size_t bytes, hipStream_t st, void **out) {
@@ -1538,8 +1549,8 @@ static int pb_table(int interp, int sw, int sh, int dw, int dh, hipStream_t st, 
         if (cap < 1) cap = 64;
         while ((int)g_pb_tables.size() > cap) {           // the least recently used entry nobody holds
           auto victim = g_pb_tables.end();
-          for (auto j = g_pb_tables.begin(); j != g_pb_tables.end(); ++j)
-            if (j->second->pins == 0 && (victim == g_pb_tables.end() || j->second->stamp < victim->second->stamp)) victim = j;
+          for (auto j = g_pb_tables.begin(); j != g_pb_tables.end(); ++j)       // of THIS device: its streams and pool are the current ones here
+            if (std::get<0>(j->first) == std::get<0>(key) && j->second->pins == 0 && (victim == g_pb_tables.end() || j->second->stamp < victim->second->stamp)) victim = j;
           if (victim == g_pb_tables.end()) break;
           out_.push_back(victim->second);
           g_pb_tables.erase(victim);
@@ -1658,6 +1669,12 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   PbHalfArgs a;
   if (cv && (cv->offs_x & 1)) return LGPU_E_UNSUPPORTED;        // 8-byte stores: the frame must start on an even canvas column
   if (!pb_half_ok(t, interp, pr->sw, pr->sh, pr->dw, pr->dh, sb, db, &a.hyper, &a.ashift)) return LGPU_E_UNSUPPORTED;
+  {
+    // k_pb_half addresses its frames through 32-bit buffer offsets (row * rowstride as a scalar offset): a plane of 2 GiB or more -- a sub-rectangle of a huge atlas
+    // with its rowstride -- keeps the general kernels and their 64-bit row addresses
+    const long long out_rows = cv ? cv->nheight : pr->dh, lim = 1ll << 31;
+    if ((long long)pr->sh * pr->irow >= lim || out_rows * pr->orow >= lim || out_rows * pr->irow2 >= lim) return LGPU_E_UNSUPPORTED;
+  }
   if ((rc = get_kscale(&a.kscale))) return rc;
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
@@ -1889,7 +1906,8 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   }
   if (channels == 4) {
     PbHalfArgs h;
-    if (pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
+    if ((long long)sh * irow < (1ll << 31) && (long long)dh * orow < (1ll << 31) &&        // 32-bit buffer offsets in k_pb_half (see pb_chain_half)
+        pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
       h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 1; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
       pb_half_geometry(&h, 1);

@@ -2270,8 +2270,8 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
 }
 
 namespace lgpu { int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st); }
-static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
-  int rc;
+// every LGPU_E_BADARG lgpu_chain can answer, and nothing else: pure argument checks, no device work.  lgpu_chain_step runs them before it feeds or enqueues anything.
+extern "C" int lgpu_chain_check(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks) {
   LGPU_REQUIRE(pr && tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
   LGPU_REQUIRE(pr->sw > 0 && pr->sh > 0 && pr->dw > 0 && pr->dh > 0, "empty geometry");
   LGPU_REQUIRE(pr->irow >= pr->sw * 4 && pr->orow >= pr->dw * 4 && pr->irow2 >= pr->dw * 4, "rowstride smaller than a row");
@@ -2279,10 +2279,21 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   for (int i = 0; i < ntracks; i++) {
     LGPU_REQUIRE(tracks[i].src_d && tracks[i].layer2_d && tracks[i].dst_d, "null track pointer");
     LGPU_REQUIRE((((uintptr_t)tracks[i].src_d | (uintptr_t)tracks[i].layer2_d | (uintptr_t)tracks[i].dst_d) & 3) == 0, "frames must be 4-byte aligned");
+    LGPU_REQUIRE(tracks[i].src_d != tracks[i].dst_d, "the chain cannot run in place");
   }
-  const bool same = (pr->sw == pr->dw && pr->sh == pr->dh);
+  LGPU_REQUIRE(!(pr->sw == pr->dw && pr->sh == pr->dh), "the chain needs a resize stage (same size: lgpu_swizzle + lgpu_blend_chroma + lgpu_gamma_apply)");
+  if (pr->interp & LGPU_INTERP_PIXBUF) {
+    const int ip = pr->interp & 0xFF;
+    LGPU_REQUIRE(ip == 0 || ip == 2 || ip == 3, "interp must be 0 (NEAREST), 2 (BILINEAR) or 3 (HYPER) on the gdk-pixbuf arithmetic");
+    LGPU_REQUIRE(pr->sw < 32768 && pr->sh < 32768 && pr->dw < 32768 && pr->dh < 32768, "frame sides must stay below 32768 (16.16 positions)");
+  }
+  return LGPU_OK;
+}
+
+static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+  int rc;
+  if ((rc = lgpu_chain_check(pr, tracks, ntracks))) return rc;
   if (pr->interp & LGPU_INTERP_PIXBUF) {                 // the resize stage on the reference's gdk-pixbuf arithmetic (pixbuf.hip)
-    LGPU_REQUIRE(!same, "chain needs a resize stage");
     return pb_chain(pr, nullptr, tracks, ntracks, st);
   }
   const int kernel = kernel_for_interp(pr->interp, pr->dw > pr->sw || pr->dh > pr->sh);
@@ -2294,7 +2305,6 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   for (int i = 0; i < ntracks; i++) src_bits |= (uintptr_t)tracks[i].src_d;
   const int src_vec = (src_bits & 15) == 0;
   if (!pr->do_blur) {
-    LGPU_REQUIRE(!same, "chain without resize: use lgpu_swizzle + lgpu_blend_chroma + lgpu_gamma_apply");
     if ((rc = get_bank(pr->sw, pr->dw, kernel, &hb)) || (rc = get_bank(pr->sh, pr->dh, kernel, &vb))) return rc;
     for (int i = 0; i < ntracks; i++) { t.src[i] = tracks[i].src_d; t.l2[i] = tracks[i].layer2_d; t.dst[i] = tracks[i].dst_d; }
     rc = try_half8(hb, vb, pr->sw, pr->sh, pr->irow, pr->dw, pr->dh, pr->orow, pr->swap_rb ? 1 : 0, 1, pr->irow2, (uint32_t)pr->bf & 0xFF,
@@ -2308,7 +2318,6 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
     return launch_sep(p, t, l, st);
   }
   // with blur: resize into scratch (per track), then gaussian with the blend + gamma epilogue
-  LGPU_REQUIRE(!same, "chain needs a resize stage");
   void *scratch;
   const size_t per = (size_t)pr->dw * 4 * pr->dh;
   std::lock_guard<std::mutex> seq(g_multi_mu);

@@ -413,7 +413,10 @@ constexpr int kEmW = 128, kEmQ = kEmW / 4 + 2;       // 34 quads = 136 luma byte
 // each behind its own s_waitcnt).  Frame offsets are 32-bit (the host checks height * rowstride < 2^31).
 template <int EH>
 __global__ __launch_bounds__(kBlock) void k_edge_map4(const uint8_t *src, int irow, int width, int height, int order, int pass,
-                                                        const int32_t *gluma, uint16_t *map, int mpitch, unsigned int *slices) {
+                                                        const int32_t *gluma, uint16_t *map, int mpitch, unsigned int *slices, unsigned int *ticket) {
+  // the first map launch of a call clears the reduce kernel's ticket (ordered before that launch by the stream): a launch that died half way in an EARLIER call
+  // cannot leave the persistent state with a count that picks the wrong "last" workgroup for ever after
+  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(ticket, 0u);
   constexpr int RT = EH / 8;                                 // rows per thread
   constexpr int NQ = (EH + 2) * kEmQ, NI = (NQ + kBlock - 1) / kBlock;       // quads of a window, per thread: all requested before the first is used
   __shared__ __attribute__((aligned(16))) uint32_t l[NI * kBlock];           // (EH + 2) rows of kEmQ dwords, padded to whole rounds of the workgroup
@@ -532,7 +535,10 @@ __global__ __launch_bounds__(256) void k_edge_reduce_otsu(const unsigned int *sl
     for (int k = 0; k < 16; k++) acc += v[k];
     // Every read-modify-write below is a device-scope atomic that RETURNS its old value: the value comes back from the place the operation was performed, so once
     // a thread holds it the addition is done as far as any later device-scope atomic is concerned.  That is all the ticket needs -- no device-scope fence, which on
-    // this part writes the whole L2 back (the map kernel has just left 4 MB of dirty lines there: 23 us per launch with __threadfence() here, measured)
+    // this part writes the whole L2 back (the map kernel has just left 4 MB of dirty lines there: 23 us per launch with __threadfence() here, measured).
+    // HARDWARE ASSUMPTION (gfx950, the only target build.sh compiles for): agent-scope returning RMWs are performed at the memory side, in issue order per
+    // wave, so "old value returned" implies "performed" for every later agent-scope atomic.  Formally (C++ memory model) these relaxed atomics do not
+    // synchronise; on another part or compiler, use __hip_atomic_fetch_add(&st->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) and pay the fence.
     unsigned int r0 = 0;
     unsigned long long r1 = 0;
     if (acc) r0 = atomicAdd(&st->hist[bin], acc);
@@ -1001,8 +1007,8 @@ extern "C" int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int oro
       const unsigned pcap = (unsigned)device_cus() * 8u, pneed = (unsigned)((quads + kBlock - 1) / kBlock);
       const dim3 pg(pneed < pcap ? pneed : pcap);
       for (int pass = 0; pass < 4; pass++) {
-        if (eh == 16) hipLaunchKernelGGL(k_edge_map4<16>, g4, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, width, sc.slices);
-        else hipLaunchKernelGGL(k_edge_map4<32>, g4, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, width, sc.slices);
+        if (eh == 16) hipLaunchKernelGGL(k_edge_map4<16>, g4, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, width, sc.slices, &sc.st->ticket);
+        else hipLaunchKernelGGL(k_edge_map4<32>, g4, dim3(kBlock), 0, st, src_d, irow, width, height, order, pass, device_tables()->luma, sc.map, width, sc.slices, &sc.st->ticket);
         hipLaunchKernelGGL(k_edge_reduce_otsu, dim3(4 * kEdgeChunks), dim3(256), 0, st, sc.slices, (int)g4.x, sc.st, count, pass == 0 ? 1 : 0);
         hipLaunchKernelGGL(k_edge_paint4, pg, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, (int)wq, height, pass, mode, aoffs, inplace, sc.map, width, sc.st, qmagic);
         if (mode < 2) break;

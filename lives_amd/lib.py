@@ -86,6 +86,8 @@ PROTOTYPES = {
     "lgpu_chain_step": [vp, vp, vp, vp, ci],
     "lgpu_stepper_feed": [vp, vp, ci],
     "lgpu_stepper_overlap": [vp, vp],
+    "lgpu_stepper_failed": [vp],
+    "lgpu_chain_check": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci],
     "lgpu_params_set_n": [vp, vp, ci, vp],
     "lgpu_params_broadcast_n": [vp, ci, vp, ci, vp],
     "lgpu_stepper_block": [vp, ci],

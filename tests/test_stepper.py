@@ -73,6 +73,18 @@ def test_stepper_refuses_what_would_put_it_out_of_step(gpu):
         assert L.lgpu_stepper_block(st.h, -1) is None
         bad = gpu.chain_params(sw, sh, sw * 4 - 4, dw, dh, dw * 4, dw * 4, swap_rb=0, interp=3, do_blur=0, bf=1, lut=None)      # rowstride smaller than a row
         assert L.lgpu_chain_step(st.h, None, ctypes.byref(bad), trk, 1) == -2          # LGPU_E_BADARG, nothing changed ...
+        # every check lgpu_chain makes is made before the next block is fed: a misaligned frame, a chain without a resize stage, an interp value the pixbuf
+        # arithmetic does not have -- each with next_values given, none of them may feed it
+        mis = gpu.chain_tracks([d_src], [d_l2], [d_out])
+        mis[0].src_d = d_src.data_ptr() + 2
+        nxt = (ctypes.c_int32 * 4)(77, 0, 0, 0)
+        same = gpu.chain_params(sw, sh, sw * 4, sw, sh, sw * 4, sw * 4, swap_rb=0, interp=3, do_blur=0, bf=1, lut=None)
+        tiles = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=0, interp=1 | 0x100, do_blur=0, bf=1, lut=None)
+        assert L.lgpu_chain_step(st.h, nxt, ctypes.byref(prm), mis, 1) == -2
+        assert L.lgpu_chain_step(st.h, nxt, ctypes.byref(same), trk, 1) == -2
+        assert L.lgpu_chain_step(st.h, nxt, ctypes.byref(tiles), trk, 1) == -2
+        assert L.lgpu_chain_check(ctypes.byref(tiles), trk, 1) == -2 and L.lgpu_chain_check(ctypes.byref(prm), trk, 1) == 0
+        assert L.lgpu_stepper_failed(st.h) == 0
         st.step(None, prm, trk)                                                          # ... so the same step goes through afterwards
         assert L.lgpu_chain_step(st.h, None, ctypes.byref(prm), trk, 1) == -2          # no block for step 1
         st.feed([[v] for v in range(64)])                                                # a whole ring
