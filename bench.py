@@ -199,7 +199,11 @@ def main():
                 return
         ops.chain(prm, trks[s % nsets])
 
+    STEP_TIMEOUT_MS = int(os.environ.get("LGPU_STEP_TIMEOUT_MS", "120000"))
+
     def fence():
+        if stepper is not None:
+            stepper.wait(STEP_TIMEOUT_MS)      # a peer that never arrives ends the job with a message (which rank waited for what), not with a hang in the synchronise below
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -217,8 +221,9 @@ def main():
     for s in range(args.steps):
         step(args.warmup + s)
     fence()
-    dt = time.perf_counter() - t0
-    dt = ld.max_over_ranks(dt, "cuda")
+    dt_own = time.perf_counter() - t0
+    dt = ld.max_over_ranks(dt_own, "cuda")
+    dt_all = ld.all_over_ranks(dt_own, "cuda")          # every rank's own clock around the same K steps (value uses the max)
 
     frames = world * T * args.steps
     fps = frames / dt
@@ -228,8 +233,9 @@ def main():
     prm_blur = prm if args.blur else ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3 | (0x100 if args.resize_backend == "pixbuf" else 0), do_blur=1, bf=128, lut=lut,
                                                       param_block=pblock)
     config5 = None
-    if multi and stepper is not None:
-        stepper.close()
+    if stepper is not None or not multi:      # every rank count: at N = 1 the same C step without a communicator (nothing to exchange: the blocks are written on the launch stream)
+        if stepper is not None:
+            stepper.close()
         stepper = None
         one = groups_of(1)                    # every frame of every buffer set in turn: the one-frame launches, too, see buffers the memory-side cache has long lost
         n5 = max(args.steps, 200)
@@ -248,18 +254,20 @@ def main():
                 st5.step(None, p5, one[i % len(one)])
             for i in range(50):
                 step5(i)
+            st5.wait(STEP_TIMEOUT_MS)
             fence()
             t5 = time.perf_counter()
             for i in range(50, tot5):
                 step5(i)
+            st5.wait(STEP_TIMEOUT_MS)
             fence()
             d5 = ld.max_over_ranks(time.perf_counter() - t5, "cuda")
             st5.close()
             return d5
         d5 = one_frame_leg(prm)
         config5 = {"config5_fps": round(world * n5 / d5, 1), "config5_ms_per_step": round(d5 / n5 * 1e3, 4), "config5_steps": n5,
-                   "config5_shape": "one 3840x2160 frame per GPU per step, lgpu_chain_step (C) with the RCCL parameter exchange on (%d blocks per exchange, lgpu_stepper_feed), "
-                                    "steps alternating between two launch streams (lgpu_stepper_overlap)" % AHEAD}
+                   "config5_shape": "one 3840x2160 frame per GPU per step, lgpu_chain_step (C) with %s (%d blocks per lgpu_stepper_feed), "
+                                    "steps alternating between two launch streams (lgpu_stepper_overlap)" % ("the RCCL parameter exchange on" if comm is not None else "no communicator (one GPU)", AHEAD)}
         if args.resize_backend == "pixbuf" and not args.blur:
             d5b = one_frame_leg(prm_blur)
             config5.update({"config5_blur_fps": round(world * n5 / d5b, 1), "config5_blur_ms_per_step": round(d5b / n5 * 1e3, 4)})
@@ -362,9 +370,14 @@ def main():
                 out["config"]["projected_batch8_speedup"] = round(batch8["batch8_1gpu_us_per_step"] / (config5["config5_ms_per_step"] * 1e3), 2)
                 if "config5_blur_ms_per_step" in config5 and "batch8_blur_1gpu_us_per_step" in batch8:
                     out["config"]["projected_batch8_blur_speedup"] = round(batch8["batch8_blur_1gpu_us_per_step"] / (config5["config5_blur_ms_per_step"] * 1e3), 2)
-        if world > 1:
-            out["config"]["rccl_ranks"] = world if comm is not None else 0
-            out["config"]["rccl_preflight"] = rccl_preflight if rccl_preflight is not None else "not run (librccl could not be bound on every rank)"
+        out["per_rank_ms_per_step"] = {"min": round(min(dt_all) / args.steps * 1e3, 4), "max": round(max(dt_all) / args.steps * 1e3, 4), "ranks": len(dt_all)}
+        if multi:
+            # the ranks the communicator really has (ncclCommCount), not what the launcher promised: a line that says N GPUs over a smaller communicator is refused
+            nr = comm.count() if comm is not None else 0
+            assert comm is None or nr == world, "the RCCL communicator has %d ranks, the job %d" % (nr, world)
+            out["config"]["rccl_ranks"] = nr
+            if world > 1:
+                out["config"]["rccl_preflight"] = rccl_preflight if rccl_preflight is not None else "not run (librccl could not be bound on every rank)"
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.blur, args.resize_backend == "pixbuf")
     ctypes.CDLL(None).fflush(None)          # every rank: whatever librccl left in C stdio's buffer goes out now, not at exit behind rank 0's line
@@ -405,12 +418,13 @@ def dry_run(args, rank, world):
     mine = ld.shard_tracks(world * args.tracks, rank, world)
     pf = ld.preflight(ld.TorchComm(), "cpu") if world > 1 else "ok"          # the preflight's plumbing (verdict shared by every rank) on gloo; the C stepper part needs a GPU
     dt = ld.max_over_ranks(1e-3 * (rank + 1), "cpu")
+    dts = ld.all_over_ranks(1e-3 * (rank + 1), "cpu")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "effect-chain frames/sec at 3840x2160 RGBA32", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "tracks_of_rank0": mine, "max_over_ranks_s": dt, "rccl_preflight": pf}))
+                          "tracks_of_rank0": mine, "max_over_ranks_s": dt, "all_over_ranks_s": dts, "rccl_preflight": pf}))
 
 
 def pixbuf_kernel_name(args):

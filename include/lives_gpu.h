@@ -30,7 +30,8 @@ enum {
   LGPU_E_UNSUPPORTED = -3,
   LGPU_E_HIP = -4,        /* a HIP call failed; see lgpu_last_error() */
   LGPU_E_NOMEM = -5,
-  LGPU_E_STATE = -6       /* the object is out of step after an earlier half-done call (lgpu_stepper): destroy it */
+  LGPU_E_STATE = -6,      /* the object is out of step after an earlier half-done call (lgpu_stepper): destroy it */
+  LGPU_E_TIMEOUT = -7     /* a peer did not arrive in time (lgpu_dist_comm_create_timeout, lgpu_stepper_wait); lgpu_last_error() says what was being waited for */
 };
 
 /* ---- runtime ----------------------------------------------------------------------------------- */
@@ -39,6 +40,8 @@ int lgpu_abi_version(void);
 int lgpu_init(int device);
 const char *lgpu_last_error(void);
 int lgpu_device_count(void);
+int lgpu_current_device(int *device);     /* hipGetDevice / hipSetDevice of the calling thread */
+int lgpu_set_device(int device);
 /* device memory + copies for hosts without their own allocator (the layer seam uses these) */
 int lgpu_malloc(void **ptr_d, size_t bytes);
 /* diagnostics: the nth lgpu_malloc from now (1 = the next one) fails with LGPU_E_NOMEM; 0 disarms.  Used by the tests of the
@@ -70,6 +73,7 @@ void lgpu_pinned_free(void *p);
 int lgpu_copy(void *dst_d, const void *src_d, size_t bytes, void *stream);      /* device to device */
 int lgpu_fill(void *dst_d, int byte, size_t bytes, void *stream);
 int lgpu_sync(void *stream);
+int lgpu_stream_query(void *stream);      /* 1 = everything enqueued so far has completed, 0 = not yet (never blocks), < 0 = error */
 /* rows of row_bytes bytes between two pitched device buffers (what compact_rowstrides :14439 and the cut of unletterbox_layer :15612-15615 do) */
 int lgpu_copy_rows(void *dst_d, int orow, const void *src_d, int irow, int row_bytes, int rows, void *stream);
 /* n repetitions of a plen-byte (1..8) pattern at the start of every row: a palette's black as blank_pixel / blank_row paint it
@@ -197,6 +201,12 @@ int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *d
                       void *stream);
 /* the per-phase integer weight tables that call uses (host, for tests / inspection): table = [16 y phases][16 x phases][n_y][n_x], each summing to
    65536; xoff / yoff = 16.16 position of destination pixel 0.  table may be NULL to query the sizes. */
+/* the same for nframes (1 .. LGPU_CHAIN_MAX_TRACKS) frames of ONE geometry in ONE launch: src_d / dst_d are host arrays of device pointers.  The unit of work of the
+   path is a batch of independent frames, one per live clip track (src/effects-weed.c:1850-2425 runs an instance once per track per tick; compositor.c:262-266
+   scales every layer of a frame): the weight tables, the per-launch cost of thousands of small workgroups and the launch itself are paid once.  Results are those
+   of nframes single calls, bit for bit.  Alignment requirements apply to the least aligned frame. */
+int lgpu_pixbuf_scale_batch(const uint8_t *const *src_d, uint8_t *const *dst_d, int nframes, int irow, int sw, int sh, int orow, int dw, int dh, int channels,
+                            int interp, void *stream);
 int lgpu_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff, int32_t *table, size_t table_ints);
 /* the filter bank the kernel uses (host, for tests / inspection): kernel 0 triangle, 1 cubic(0,.6), 2 lanczos3 */
 int lgpu_make_filter(int srcn, int dstn, int kernel, int *ntaps, int32_t *pos, int16_t *coef, int maxtaps);
@@ -419,6 +429,11 @@ int lgpu_debug_stream_probe(const lgpu_chain_params *params, const lgpu_chain_tr
 int lgpu_dist_bind(const char *rccl_path);                                  /* optional: an explicit library path (NULL: the process's copy, then the system's) */
 int lgpu_dist_unique_id(uint8_t id[LGPU_DIST_ID_BYTES]);                    /* ncclGetUniqueId */
 int lgpu_dist_comm_create(const uint8_t id[LGPU_DIST_ID_BYTES], int rank, int world, void **comm);   /* ncclCommInitRank on the current device */
+/* the same with a limit: ncclCommInitRank blocks for ever when a rank of the job never arrives; here the call returns LGPU_E_TIMEOUT after timeout_ms
+   (lgpu_last_error(): which rank of how many waited how long) and the process can report and exit -- the abandoned initialisation is left behind, do not reuse the id.
+   timeout_ms <= 0: no limit */
+int lgpu_dist_comm_create_timeout(const uint8_t id[LGPU_DIST_ID_BYTES], int rank, int world, int timeout_ms, void **comm);
+int lgpu_dist_comm_count(void *comm);                                       /* ncclCommCount: the ranks of the communicator, or a negative LGPU_E_* */
 int lgpu_dist_comm_destroy(void *comm);
 /* the shared transition parameter block (lgpu_chain_params.param_block_d: int32[4] in device memory) from `root` to every rank, in place */
 int lgpu_params_broadcast(void *comm, int root, int32_t *param_block_d, void *stream);
@@ -441,8 +456,10 @@ int lgpu_params_broadcast_n(void *comm, int root, int32_t *param_blocks_d, int n
    comm == NULL: one GPU, nothing to exchange -- the blocks are written on the launch stream.  tools/worker.c is the render-worker loop on top of it.
    Errors: LGPU_E_BADARG comes from argument checks only -- EVERY check lgpu_chain makes on the same arguments is made before anything is fed or enqueued -- and
    leaves the stepper untouched (repeat the call); any other error leaves this rank out of step with its peers: lgpu_stepper_failed() turns 1, every later call
-   returns LGPU_E_STATE, destroy the stepper.  lgpu_stepper_timeout_ms: how long a rank waits inside an exchange for its peers before it reports which call hung
-   (0 = for ever, the default); a timed-out stepper is failed like any other. */
+   returns LGPU_E_STATE, destroy the stepper.
+   lgpu_stepper_wait(s, timeout_ms): the host-side wait a worker uses INSTEAD of a bare stream synchronise -- until everything fed and launched so far has
+   completed, or LGPU_E_TIMEOUT after timeout_ms (0 = for ever) with lgpu_last_error() naming what hangs (the exchange on the side stream = a peer that never
+   entered the same feed, or a launch) and the step / feed counters of this rank; a timed-out stepper is failed like any other. */
 typedef struct lgpu_stepper lgpu_stepper;
 int lgpu_stepper_create(void *comm, int root, int rank, void *launch_stream, const int32_t first_values[4], lgpu_stepper **out);
 int lgpu_stepper_feed(lgpu_stepper *s, const int32_t *values, int n);
@@ -453,9 +470,24 @@ int lgpu_chain_step(lgpu_stepper *s, const int32_t next_values[4], const lgpu_ch
    NULL switches it off.  The caller synchronises both streams before reading results. */
 int lgpu_stepper_overlap(lgpu_stepper *s, void *second_launch_stream);
 int lgpu_chain_check(const lgpu_chain_params *params, const lgpu_chain_track *tracks, int ntracks);     /* lgpu_chain's argument checks alone (no device work): LGPU_OK or LGPU_E_BADARG */
+int lgpu_stepper_wait(lgpu_stepper *s, int timeout_ms);
 int lgpu_stepper_failed(const lgpu_stepper *s);                           /* 1 after a half-done call, else 0 */
 const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 64 (tests); NULL for a negative index */
 int lgpu_stepper_destroy(lgpu_stepper *s);
+
+/* ---- batched effects: ONE launch for the instances of one filter on the live tracks of a tick (weed_apply_instance runs once per track per tick,
+   src/effects-weed.c:1850-2425).  The frames share geometry, rowstrides and parameters; only the planes differ.  Results are those of nframes single calls, bit
+   for bit.  ops and their fields (everything else ignored):
+     LGPU_FX_SOFTLIGHT      in0 / out: the 3 (4: YUVA4444P) planes; irow0[], orow[], width, height, palette; ip[0] = unclamped          (lgpu_softlight)
+     LGPU_FX_TRANSITION     in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = type, ip[1] = psize, dp[0] = amount   (lgpu_transition)
+     LGPU_FX_YUV411_TO_RGB  in0[0], out[0]; width = macropixels, height, orow[0]; ip[0] = out_order, ip[1] = out_alpha, ip[2] = unclamped      (lgpu_yuv411_to_rgb)
+   The scaler has its own batch entry (lgpu_pixbuf_scale_batch), the palette conversion K2 lgpu_yuv420p_to_rgb_batch, the chain takes its tracks directly.  The
+   compositor (lgpu_composite) IS the fan-in of a tick's tracks into one frame: a tick has one of it, there is nothing to batch. */
+#define LGPU_FX_MAX_FRAMES 16
+enum { LGPU_FX_SOFTLIGHT = 1, LGPU_FX_TRANSITION = 2, LGPU_FX_YUV411_TO_RGB = 3 };
+typedef struct { const uint8_t *in0[4]; const uint8_t *in1[4]; uint8_t *out[4]; } lgpu_fx_frame;
+typedef struct { int op, width, height, palette; int irow0[4], irow1[4], orow[4]; int ip[4]; double dp[2]; } lgpu_fx_params;
+int lgpu_fx_batch(const lgpu_fx_params *params, const lgpu_fx_frame *frames, int nframes, void *stream);
 
 /* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),
    :167-189 (background, z order), :288-293 (paint loop).  One kernel: every output pixel starts from bgcol (R,G,B;

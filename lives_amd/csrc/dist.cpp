@@ -9,7 +9,11 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include "../../include/lives_gpu.h"
 
 namespace lgpu { void set_error(const char *fmt, ...); }
@@ -32,6 +36,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;       // optional
 };
 Rccl g_r;
 std::mutex g_mu;
@@ -51,6 +56,7 @@ int bind_rccl(const char *path) {
   SYM(AllReduce, "ncclAllReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
   SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+  *(void **)(&r.CommCount) = dlsym(h, "ncclCommCount");
   g_r = r;
   return LGPU_OK;
 }
@@ -85,6 +91,45 @@ int lgpu_dist_comm_create(const uint8_t id[LGPU_DIST_ID_BYTES], int rank, int wo
   if ((rc = check(g_r.CommInitRank(&c, world, u, rank), "ncclCommInitRank"))) return rc;
   *comm = c;
   return LGPU_OK;
+}
+
+// ncclCommInitRank on a helper thread, the caller waits for it with a limit: version-independent (no ncclConfig_t, whose layout moves between RCCL releases)
+int lgpu_dist_comm_create_timeout(const uint8_t id[LGPU_DIST_ID_BYTES], int rank, int world, int timeout_ms, void **comm) {
+  if (timeout_ms <= 0) return lgpu_dist_comm_create(id, rank, world, comm);
+  int rc = bind_rccl(nullptr);
+  if (rc) return rc;
+  if (!id || !comm || world < 1 || rank < 0 || rank >= world) { lgpu::set_error("lgpu_dist_comm_create_timeout: bad arguments"); return LGPU_E_BADARG; }
+  int dev = 0;
+  if ((rc = lgpu_current_device(&dev))) return rc;
+  struct Job { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t res = 0; ncclComm_t c = nullptr; };
+  auto job = std::make_shared<Job>();
+  ncclUniqueId u;
+  memcpy(u.internal, id, sizeof u.internal);
+  std::thread([job, u, rank, world, dev]() {
+    (void)lgpu_set_device(dev);                          // the communicator belongs to the caller's device
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = g_r.CommInitRank(&c, world, u, rank);
+    std::lock_guard<std::mutex> lk(job->mu);
+    job->res = r; job->c = c; job->done = true;
+    job->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(job->mu);
+  if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
+    lgpu::set_error("lgpu_dist_comm_create_timeout: rank %d of %d waited %d ms in ncclCommInitRank: a rank of the job has not arrived (not started, crashed before its "
+                    "rendezvous, or another id / world size)", rank, world, timeout_ms);
+    return LGPU_E_TIMEOUT;
+  }
+  if ((rc = check(job->res, "ncclCommInitRank"))) return rc;
+  *comm = job->c;
+  return LGPU_OK;
+}
+
+int lgpu_dist_comm_count(void *comm) {
+  if (!comm || !g_r.h) { lgpu::set_error("lgpu_dist_comm_count: no communicator"); return LGPU_E_BADARG; }
+  if (!g_r.CommCount) { lgpu::set_error("lgpu_dist_comm_count: ncclCommCount missing in librccl"); return LGPU_E_UNSUPPORTED; }
+  int n = 0;
+  const int rc = check(g_r.CommCount((ncclComm_t)comm, &n), "ncclCommCount");
+  return rc ? rc : n;
 }
 
 int lgpu_dist_comm_destroy(void *comm) {
@@ -277,6 +322,34 @@ int lgpu_stepper_overlap(lgpu_stepper *s, void *second_launch_stream) {
 }
 
 int lgpu_stepper_failed(const lgpu_stepper *s) { return s && s->failed ? 1 : 0; }
+
+// host-side wait with a limit (what a worker calls instead of a bare stream synchronise): polls the streams, never blocks inside the runtime
+int lgpu_stepper_wait(lgpu_stepper *s, int timeout_ms) {
+  if (!s) { lgpu::set_error("lgpu_stepper_wait: null stepper"); return LGPU_E_BADARG; }
+  if (s->failed) { lgpu::set_error("lgpu_stepper_wait: the stepper is out of step: destroy it"); return LGPU_E_STATE; }
+  const auto t0 = std::chrono::steady_clock::now();
+  void *streams[3] = {s->comm ? s->side : nullptr, s->launch, s->launch2};
+  const char *names[3] = {"the parameter exchange (side stream): a peer has not entered the same lgpu_stepper_feed / lgpu_chain_step", "a chain launch (first launch stream)",
+                          "a chain launch (second launch stream)"};
+  for (unsigned spin = 0;; spin++) {
+    int busy = -1;
+    for (int i = 0; i < 3 && busy < 0; i++) {
+      if (!streams[i]) continue;
+      const int q = lgpu_stream_query(streams[i]);
+      if (q < 0) { s->failed = 1; return q; }
+      if (q == 0) busy = i;
+    }
+    if (busy < 0) return LGPU_OK;
+    const long waited = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (timeout_ms > 0 && waited >= timeout_ms) {
+      s->failed = 1;
+      lgpu::set_error("lgpu_stepper_wait: rank %d (root %d) waited %ld ms for %s; %ld blocks fed in %ld feeds, %ld steps launched", s->rank, s->root, waited, names[busy],
+                      s->fed, s->feeds, s->step);
+      return LGPU_E_TIMEOUT;
+    }
+    if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
 
 const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which) { return (s && which >= 0) ? s->blk + 4 * (which % kStepRing) : nullptr; }
 

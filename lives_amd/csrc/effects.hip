@@ -581,14 +581,15 @@ extern "C" int lgpu_composite(uint8_t *dst_d, int orow, int owidth, int oheight,
 // ---------------------------------------------------------------------------------------------------------------------
 namespace lgpu {
 struct TransArgs {
-  const uint8_t *src1, *src2;
+  const uint8_t *src1, *src2;      // filled in the kernel from the frame table (blockIdx.z)
   uint8_t *dst;
   int irow1, irow2, orow, width, height, wb, type;
   int xx, yy, ihwidth, ihheight;          // type 0: rectangle insets (bytes, rows); type 2: quadrant shifts (bytes of rows, bytes)
   float bf, hwidth, hheight, maxradsq;
 };
 template <int PS>
-__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a) {
+__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFrames F) {
+  a.src1 = F.in0[blockIdx.z][0]; a.src2 = F.in1[blockIdx.z][0]; a.dst = F.out[blockIdx.z][0];
   const int x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= a.width) return;
   const int j = x * PS;
@@ -694,17 +695,17 @@ __global__ __launch_bounds__(kBlock) void k_dissolve(const uint8_t *src1, int ir
 }
 }  // namespace lgpu
 
-extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
-                               int width, int height, int psize, double amount, void *stream) {
-  int rc = ensure_init();
-  if (rc) return rc;
+int lgpu::transition_n(const FxFrames &F, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, double amount, hipStream_t st) {
   LGPU_REQUIRE(type >= 0 && type <= 2, "type must be 0 (iris rectangle), 1 (iris circle) or 2 (4 way split)");
-  LGPU_REQUIRE(src1_d && src2_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(width > 0 && height > 0, "empty geometry");
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
   LGPU_REQUIRE(irow1 >= width * psize && irow2 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
-  LGPU_REQUIRE(type != 2 || src1_d != dst_d, "4 way split is not in place (multi_transitions.c:283)");
+  for (int f = 0; f < nframes; f++) {
+    LGPU_REQUIRE(F.in0[f][0] && F.in1[f][0] && F.out[f][0], "null frame");
+    LGPU_REQUIRE(type != 2 || F.in0[f][0] != F.out[f][0], "4 way split is not in place (multi_transitions.c:283)");
+  }
   lgpu::TransArgs a;
-  a.src1 = src1_d; a.src2 = src2_d; a.dst = dst_d; a.irow1 = irow1; a.irow2 = irow2; a.orow = orow;
+  a.src1 = nullptr; a.src2 = nullptr; a.dst = nullptr; a.irow1 = irow1; a.irow2 = irow2; a.orow = orow;
   a.width = width; a.height = height; a.type = type;
   // the reference's own float / double mix (:129-150)
   float hwidth = (float)width * 0.5f;
@@ -718,11 +719,38 @@ extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const
   a.xx = a.yy = 0;
   if (type == 0) { a.xx = (int)((int)hwidth * bfneg + .5); a.yy = (int)((int)hheight * bfneg + .5); }
   else if (type == 2) { a.xx = (int)(hheight * a.bf + .5) * irow1; a.yy = (int)(hwidth / (float)psize * a.bf + .5) * psize; }
-  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048));
-  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048), (unsigned)nframes);
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, st, a, F);
+  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, st, a, F);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+
+extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,
+                               int width, int height, int psize, double amount, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  FxFrames F = {};
+  F.in0[0][0] = src1_d; F.in1[0][0] = src2_d; F.out[0][0] = dst_d;
+  return transition_n(F, 1, type, irow1, irow2, orow, width, height, psize, amount, (hipStream_t)stream);
+}
+
+// One launch for the instances of ONE filter on the live tracks of a tick (src/effects-weed.c:1850-2425 runs weed_apply_instance once per track): the frames share
+// geometry, rowstrides and parameters; only the planes differ.  Results are those of nframes single calls.
+extern "C" int lgpu_fx_batch(const lgpu_fx_params *p, const lgpu_fx_frame *frames, int nframes, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(p && frames && nframes >= 1 && nframes <= LGPU_FX_MAX_FRAMES, "1..LGPU_FX_MAX_FRAMES frames");
+  FxFrames F = {};
+  for (int f = 0; f < nframes; f++)
+    for (int k = 0; k < 4; k++) { F.in0[f][k] = frames[f].in0[k]; F.in1[f][k] = frames[f].in1[k]; F.out[f][k] = frames[f].out[k]; }
+  hipStream_t st = (hipStream_t)stream;
+  switch (p->op) {
+  case LGPU_FX_SOFTLIGHT: return softlight_n(F, nframes, p->irow0, p->orow, p->width, p->height, p->palette, p->ip[0], st);
+  case LGPU_FX_TRANSITION: return transition_n(F, nframes, p->ip[0], p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[1], p->dp[0], st);
+  case LGPU_FX_YUV411_TO_RGB: return yuv411_to_rgb_n(F, nframes, p->width, p->height, p->orow[0], p->ip[0], p->ip[1], p->ip[2], st);
+  default: set_error("lgpu_fx_batch: unknown op %d", p->op); return LGPU_E_BADARG;
+  }
 }
 
 extern "C" int lgpu_slide_over(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d, int orow,

@@ -45,6 +45,18 @@ static inline Lut8 pack_lut(const uint8_t *lut8) {
   return l;
 }
 
+// The frames of one batched effect launch (lgpu_fx_batch): planes of the first input, of the second input (transitions) and of the output of every frame; the
+// kernels take the frame from the grid (z index, or y where the grid is one-dimensional).  A single-frame entry point passes a table with one frame.
+struct FxFrames {
+  const uint8_t *in0[LGPU_FX_MAX_FRAMES][4];
+  const uint8_t *in1[LGPU_FX_MAX_FRAMES][4];
+  uint8_t *out[LGPU_FX_MAX_FRAMES][4];
+};
+// the batched forms behind the single-frame entry points and lgpu_fx_batch (argument checks included; ensure_init() is the caller's)
+int softlight_n(const FxFrames &F, int nframes, const int irow[4], const int orow[4], int width, int height, int palette, int unclamped, hipStream_t st);
+int transition_n(const FxFrames &F, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, double amount, hipStream_t st);
+int yuv411_to_rgb_n(const FxFrames &F, int nframes, int width_mp, int height, int orow, int out_order, int out_alpha, int clamping_unclamped, hipStream_t st);
+
 // conversion tables resident in device memory (uploaded once by lgpu_init)
 struct DeviceTables {
   int32_t *yuv2rgb[4];   // [5][256] each

@@ -444,7 +444,8 @@ __device__ __forceinline__ uint32_t colour24(int bgr, const int32_t *t, int Y, i
 // Launch shape (round 4): macropixels are numbered linearly over the frame and walked with a grid stride by at most two 256-thread workgroups per CU -- the first
 // form started one workgroup per 256 macropixels of a row (2,160 for a 1080p frame, each staging 6 KB of tables for 1.5 KB of pixels) and read its ten bytes one by
 // one; now a macropixel is one dword + one halfword, its neighbours' chroma one unaligned dword each (11.2 -> see profiles/r04/ops_roofline.md).
-__global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a, uint32_t gmagic, uint32_t ncells) {
+__global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a, uint32_t gmagic, uint32_t ncells, const FxFrames F) {
+  a.src[0] = F.in0[blockIdx.y][0]; a.dst[0] = F.out[blockIdx.y][0];      // blockIdx.y: the frame of a batched launch
   __shared__ int32_t s_t[5 * 256];
   __shared__ float s_fa[256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
@@ -1232,27 +1233,35 @@ extern "C" int lgpu_rgb_to_yuv411(const uint8_t *src_d, int irow, int width, int
   return LGPU_OK;
 }
 
-extern "C" int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height, uint8_t *dst_d, int orow, int out_order, int out_alpha,
-                                  int clamping_unclamped, void *stream) {
-  int rc = ensure_init();
-  if (rc) return rc;
+int lgpu::yuv411_to_rgb_n(const FxFrames &F, int nframes, int width_mp, int height, int orow, int out_order, int out_alpha, int clamping_unclamped, hipStream_t st) {
+  int rc;
   if ((rc = ensure_cavgc())) return rc;
-  LGPU_REQUIRE(src_d && dst_d && width_mp > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(width_mp > 0 && height > 0, "empty geometry");
+  for (int f = 0; f < nframes; f++) LGPU_REQUIRE(F.in0[f][0] && F.out[f][0], "null frame");
   LGPU_REQUIRE(out_order >= 0 && out_order <= 2, "out_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
   const int ps = (out_order == 2 || out_alpha) ? 4 : 3;
   LGPU_REQUIRE(orow >= width_mp * 4 * ps, "rowstride smaller than a row");
   PalArgs a;
   __builtin_memset(&a, 0, sizeof a);
-  a.src[0] = src_d; a.dst[0] = dst_d; a.orow[0] = orow; a.width = width_mp; a.height = height;
+  a.orow[0] = orow; a.width = width_mp; a.height = height;
   a.order = out_order; a.alpha_out = out_alpha; a.unclamped = clamping_unclamped ? 1 : 0;
   a.tables = device_tables()->yuv2rgb[a.unclamped];         // set_conversion_arrays(clamping, WEED_YUV_SUBSPACE_YCBCR) (:8316)
   LGPU_REQUIRE((unsigned long long)width_mp * height < (1ull << 31), "frame too large");
   const uint32_t ncells = (uint32_t)width_mp * (uint32_t)height;
   const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)width_mp - (width_mp == 1 ? 1 : 0));
-  unsigned wgs = cdiv(ncells, kBlock), cap = (unsigned)device_cus() * (unsigned)(tune(TUNE_K2_WGS) > 0 ? tune(TUNE_K2_WGS) : 8);
-  hipLaunchKernelGGL(k_yuv411_to_rgb, dim3(wgs < cap ? wgs : cap), dim3(kBlock), 0, (hipStream_t)stream, a, magic, ncells);
+  unsigned wgs = cdiv(ncells, kBlock), cap = cdiv((unsigned)device_cus() * (unsigned)(tune(TUNE_K2_WGS) > 0 ? tune(TUNE_K2_WGS) : 8), (unsigned)nframes);
+  hipLaunchKernelGGL(k_yuv411_to_rgb, dim3(wgs < cap ? wgs : cap, (unsigned)nframes), dim3(kBlock), 0, st, a, magic, ncells, F);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+
+extern "C" int lgpu_yuv411_to_rgb(const uint8_t *src_d, int width_mp, int height, uint8_t *dst_d, int orow, int out_order, int out_alpha,
+                                  int clamping_unclamped, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  FxFrames F = {};
+  F.in0[0][0] = src_d; F.out[0][0] = dst_d;
+  return yuv411_to_rgb_n(F, 1, width_mp, height, orow, out_order, out_alpha, clamping_unclamped, (hipStream_t)stream);
 }
 
 // init_YUV_to_YUV_tables (src/colourspace.c:1108-1139); myround = round half away from zero (src/maths.h:118)

@@ -109,8 +109,18 @@ __device__ __forceinline__ void pb_tap(uint32_t q, unsigned w, unsigned &r, unsi
 }
 
 // 64 x tile_h output pixels per workgroup (4 waves, a wave per output row), clamped source window in LDS
+// The frames of one launch: every scaler kernel below serves up to LGPU_CHAIN_MAX_TRACKS frames of ONE geometry (lgpu_pixbuf_scale_batch: the frames of the live
+// tracks of one plan step) -- the grid's z index is the frame, the tables, the weight vectors and the launch are paid once.  The pointers in the argument
+// structs are frame 0's (what a single-frame call passes).
+struct PbFrames {
+  const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
+  uint8_t *dst[LGPU_CHAIN_MAX_TRACKS];
+};
+#define PB_FRAME_ARGS(TYPE) TYPE A = A_; A.src = F.src[blockIdx.z]; A.dst = F.dst[blockIdx.z]
+
 template <int CH, int UNIFORM_X>
-__global__ __launch_bounds__(256) void k_pb_window(const PbArgs A) {
+__global__ __launch_bounds__(256) void k_pb_window(const PbArgs A_, const PbFrames F) {
+  PB_FRAME_ARGS(PbArgs);
   extern __shared__ uint32_t win[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
   const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
@@ -152,7 +162,8 @@ __global__ __launch_bounds__(256) void k_pb_window(const PbArgs A) {
 
 // any ratio: a thread per destination pixel, taps straight from memory
 template <int CH>
-__global__ __launch_bounds__(256) void k_pb_direct(const PbArgs A) {
+__global__ __launch_bounds__(256) void k_pb_direct(const PbArgs A_, const PbFrames F) {
+  PB_FRAME_ARGS(PbArgs);
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (j >= A.dw || i >= A.dh) return;
   const long long x = (long long)j * A.x_step + A.xoff, y = (long long)i * A.y_step + A.yoff;
@@ -169,7 +180,9 @@ __global__ __launch_bounds__(256) void k_pb_direct(const PbArgs A) {
 }
 
 template <int CH>
-__global__ __launch_bounds__(256) void k_pb_nearest(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int x_step, int y_step) {
+__global__ __launch_bounds__(256) void k_pb_nearest(const PbFrames F, int irow, int sw, int sh, int orow, int dw, int dh, int x_step, int y_step) {
+  const uint8_t *src = F.src[blockIdx.z];
+  uint8_t *dst = F.dst[blockIdx.z];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (j >= dw || i >= dh) return;
   const int ys = pb_clamp((int)(((long long)i * y_step + y_step / 2) >> 16), sh - 1);
@@ -797,7 +810,9 @@ __global__ __launch_bounds__(320) void k_pb_half_ld(const PbHalfArgs A, const Pb
 // the quad) so that two lanes' 12 output bytes leave as three dword stores.  Strips of 120 columns (lanes 2 .. 61 store; the pairing needs even lanes on even quads).
 struct __attribute__((aligned(4))) pb_u3 { uint32_t x, y, z; };
 template <int HYPER>
-__global__ __launch_bounds__(256) void k_pb_half3(const PbHalfArgs A, const uint8_t *src_, uint8_t *dst_) {
+__global__ __launch_bounds__(256) void k_pb_half3(const PbHalfArgs A, const PbFrames F) {
+  const uint8_t *src_ = F.src[blockIdx.z];
+  uint8_t *dst_ = F.dst[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -895,7 +910,9 @@ __global__ __launch_bounds__(256) void k_pb_half3(const PbHalfArgs A, const uint
 // source row, the neighbours by DPP), i.e. four output columns, and every new source row completes two output rows (16-byte stores).  The arithmetic that is left is
 // the library's double division, once per output pixel; frames that are opaque where they are sampled take the constant reciprocal.
 template <int DUMMY>
-__global__ __launch_bounds__(256) void k_pb_double(const PbHalfArgs A, const uint8_t *src_, uint8_t *dst_) {
+__global__ __launch_bounds__(256) void k_pb_double(const PbHalfArgs A, const PbFrames F) {
+  const uint8_t *src_ = F.src[blockIdx.z];
+  uint8_t *dst_ = F.dst[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1028,7 +1045,8 @@ struct PbPairArgs {
 // per tap row), 0: any count.  Measured (profiles/r03/pb_pairs_ab.txt): a gain for 2-3 tap rows (enlarging: 29.3 -> 27.3 us), a loss for 5-6 (4K -> 1706x960: 24.6 -> 37.2 us;
 // the 24 weight registers cost more than the exposed loads), so only the short filters are instantiated that way.
 template <int CH, int NPC, int NY>
-__global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A) {
+__global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbFrames F) {
+  PB_FRAME_ARGS(PbPairArgs);
   extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
   const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
@@ -1172,7 +1190,8 @@ typedef pb_u4 pb_u4a __attribute__((aligned(4)));
 typedef pb_u2 pb_u2a __attribute__((aligned(4)));
 
 template <int NP>
-__global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A, const uint32_t *__restrict__ gp) {
+__global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A_, const uint32_t *__restrict__ gp, const PbFrames F) {
+  PB_FRAME_ARGS(PbGatherArgs);
   constexpr int RL = NP <= 2 ? 2 : 4;                  // weight dwords per tap row
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = blockIdx.x * 64 + lane, i = blockIdx.y * 4 + wave;
@@ -1237,7 +1256,8 @@ struct PbUpArgs {
 };
 
 template <int NP, int NY>
-__global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A, const uint32_t *__restrict__ gp) {
+__global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t *__restrict__ gp, const PbFrames F) {
+  PB_FRAME_ARGS(PbUpArgs);
   constexpr int RL = 2, PW = NY * RL;                  // dwords per tap row / per phase of the pair table (rows of 2 dwords for NP <= 2)
   __shared__ __attribute__((aligned(16))) uint32_t s_w[256 * PW];
   for (int e = threadIdx.x; e < 256 * PW; e += 256) s_w[e] = gp[e];
@@ -1849,26 +1869,39 @@ extern "C" int lgpu_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, i
   return LGPU_OK;
 }
 
-extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *dst_d, int orow, int dw, int dh, int channels, int interp,
-                                 void *stream) {
+// n frames of one geometry in one launch of whichever kernel the geometry selects (n == 1: lgpu_pixbuf_scale)
+static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int irow, int sw, int sh, int orow, int dw, int dh, int channels, int interp, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(src_d && dst_d && sw > 0 && sh > 0 && dw > 0 && dh > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(srcs && dsts && n >= 1 && n <= LGPU_CHAIN_MAX_TRACKS, "1..64 frames");
+  LGPU_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, "empty geometry");
+  PbFrames F;
+  uintptr_t sbits = 0, dbits = 0;                       // alignment of the launch = of its least aligned frame
+  for (int i = 0; i < n; i++) {
+    LGPU_REQUIRE(srcs[i] && dsts[i], "null frame");
+    LGPU_REQUIRE(srcs[i] != dsts[i], "scaling cannot run in place");
+    F.src[i] = srcs[i]; F.dst[i] = dsts[i];
+    sbits |= (uintptr_t)srcs[i]; dbits |= (uintptr_t)dsts[i];
+  }
+  const uint8_t *const src_d = srcs[0];
+  uint8_t *const dst_d = dsts[0];
   LGPU_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (no alpha) or 4 (alpha)");
   LGPU_REQUIRE(interp == 0 || interp == 2 || interp == 3, "interp must be 0 (NEAREST), 2 (BILINEAR) or 3 (HYPER)");
   LGPU_REQUIRE(irow >= sw * channels && orow >= dw * channels, "rowstride smaller than a row");
-  LGPU_REQUIRE(src_d != dst_d, "scaling cannot run in place");
   LGPU_REQUIRE(sw < 32768 && sh < 32768 && dw < 32768 && dh < 32768, "frame sides must stay below 32768 (16.16 positions)");
-  if (channels == 4) LGPU_REQUIRE((((uintptr_t)src_d | (uintptr_t)dst_d | (unsigned)irow | (unsigned)orow) & 3) == 0, "4-byte pixels must be 4-byte aligned");
+  if (channels == 4) LGPU_REQUIRE(((sbits | dbits | (unsigned)irow | (unsigned)orow) & 3) == 0, "4-byte pixels must be 4-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dw == sw && dh == sh) return lgpu_copy_rows(dst_d, orow, src_d, irow, sw * channels, sh, stream);   // gdk_pixbuf_scale_simple: a plain copy
+  if (dw == sw && dh == sh) {                           // gdk_pixbuf_scale_simple: a plain copy
+    for (int i = 0; i < n && !rc; i++) rc = lgpu_copy_rows(dsts[i], orow, srcs[i], irow, sw * channels, sh, stream);
+    return rc;
+  }
   const double scale_x = (double)dw / sw, scale_y = (double)dh / sh;
   const int x_step = (int)(65536 / scale_x), y_step = (int)(65536 / scale_y);
   if (x_step == 0 || y_step == 0) { set_error("lgpu_pixbuf_scale: enlargement beyond 65536x"); return LGPU_E_UNSUPPORTED; }
-  const dim3 grid(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, 4)), block(256);
+  const dim3 grid(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, 4), (unsigned)n), block(256);
   if (interp == 0) {
-    if (channels == 4) hipLaunchKernelGGL(k_pb_nearest<4>, grid, block, 0, st, src_d, irow, sw, sh, dst_d, orow, dw, dh, x_step, y_step);
-    else hipLaunchKernelGGL(k_pb_nearest<3>, grid, block, 0, st, src_d, irow, sw, sh, dst_d, orow, dw, dh, x_step, y_step);
+    if (channels == 4) hipLaunchKernelGGL(k_pb_nearest<4>, grid, block, 0, st, F, irow, sw, sh, orow, dw, dh, x_step, y_step);
+    else hipLaunchKernelGGL(k_pb_nearest<3>, grid, block, 0, st, F, irow, sw, sh, orow, dw, dh, x_step, y_step);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
@@ -1879,7 +1912,7 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d needs %d x %d taps; the library's two-step scaler is not covered", sw, sh, dw, dh, t->n_x, t->n_y);
     return rc;
   }
-  if (channels == 4 && dw == 2 * sw && dh == 2 * sh && (sw & 1) == 0 && (((uintptr_t)src_d | (unsigned)irow) & 7) == 0 && (((uintptr_t)dst_d | (unsigned)orow) & 15) == 0 &&
+  if (channels == 4 && dw == 2 * sw && dh == 2 * sh && (sw & 1) == 0 && ((sbits | (unsigned)irow) & 7) == 0 && ((dbits | (unsigned)orow) & 15) == 0 &&
       pb_double_ok(t, x_step, y_step) && !tune_on(TUNE_PB_NO_DOUBLE)) {
     PbHalfArgs h;
     h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
@@ -1887,19 +1920,19 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     h.th = 3;                      // measured (1080p -> 4K): 16.5 us at 2-3 source rows per band, 18.2 us at 4, 22.8 at 8, 33.4 at 16, 52.7 at 32 -- per-wave latency, as in k_pb_half
     { const int v = tune(TUNE_PBD_TH); if (v >= 1 && v <= 1024) h.th = v; }
     h.bands = (int)cdiv((unsigned)sh, (unsigned)h.th); h.ntracks = 1;
-    hipLaunchKernelGGL(k_pb_double<0>, dim3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u)), dim3(256), 0, st, h, src_d, dst_d);
+    hipLaunchKernelGGL(k_pb_double<0>, dim3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u), 1, (unsigned)n), dim3(256), 0, st, h, F);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
-  if (channels == 3 && sw == 2 * dw && sh == 2 * dh && (sw & 7) == 0 && ((((uintptr_t)src_d | (uintptr_t)dst_d) | (unsigned)irow | (unsigned)orow) & 3) == 0 && !tune_on(TUNE_PB_NO_HALF3)) {
+  if (channels == 3 && sw == 2 * dw && sh == 2 * dh && (sw & 7) == 0 && ((sbits | dbits | (unsigned)irow | (unsigned)orow) & 3) == 0 && !tune_on(TUNE_PB_NO_HALF3)) {
     PbHalfArgs h;
     // the same table check as the 4-byte kernel (alignment arguments that always pass: this kernel's own are checked above)
     if (pb_half_ok(t, interp, sw, sh, dw, dh, 0, 0, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
       h.strips = (int)cdiv((unsigned)dw, 120); h.cgroups = (h.strips + 3) / 4; h.th = 6; h.bands = (int)cdiv((unsigned)dh, 6u); h.ntracks = 1;
-      const dim3 g3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u));
-      if (h.hyper) hipLaunchKernelGGL(k_pb_half3<1>, g3, dim3(256), 0, st, h, src_d, dst_d);
-      else hipLaunchKernelGGL(k_pb_half3<0>, g3, dim3(256), 0, st, h, src_d, dst_d);
+      const dim3 g3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u), 1, (unsigned)n);
+      if (h.hyper) hipLaunchKernelGGL(k_pb_half3<1>, g3, dim3(256), 0, st, h, F);
+      else hipLaunchKernelGGL(k_pb_half3<0>, g3, dim3(256), 0, st, h, F);
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
@@ -1907,13 +1940,14 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   if (channels == 4) {
     PbHalfArgs h;
     if ((long long)sh * irow < (1ll << 31) && (long long)dh * orow < (1ll << 31) &&        // 32-bit buffer offsets in k_pb_half (see pb_chain_half)
-        pb_half_ok(t, interp, sw, sh, dw, dh, (uintptr_t)src_d | (uintptr_t)irow, (uintptr_t)dst_d | (uintptr_t)orow, &h.hyper, &h.ashift)) {
+        pb_half_ok(t, interp, sw, sh, dw, dh, sbits | (uintptr_t)irow, dbits | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
       h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 1; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
-      pb_half_geometry(&h, 1);
+      pb_half_geometry(&h, n);
+      if (tune(TUNE_PBH_ORDER) < 0 && (long long)h.cgroups * h.bands * n > (long long)device_cus() * 8) h.row_major = 2;      // more than one generation: the chain's sweep order (pb_chain_half)
       if (h.bgroup <= 0) h.bgroup = (h.bands % 8 == 0) ? h.bands / 8 : 1;
       PbTracks T;
-      T.src[0] = src_d; T.l2[0] = nullptr; T.dst[0] = dst_d;
+      for (int i = 0; i < n; i++) { T.src[i] = srcs[i]; T.l2[i] = nullptr; T.dst[i] = dsts[i]; }
       h.kscale = nullptr; h.cw = h.ch = h.ox = h.oy = 0; h.bar_blocks = 0; h.bar_first = 0; h.main_blocks = (int)pb_half_grid(h);
       if (h.aligned) {
         if (h.hyper) hipLaunchKernelGGL((k_pb_half<0, 1, 0, 1>), dim3(pb_half_grid(h)), dim3(256), 0, st, h, T, pack_lut(nullptr));
@@ -1936,9 +1970,9 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       ua.x_step = x_step; ua.y_step = y_step; ua.xoff = t->xoff; ua.yoff = t->yoff; ua.tx0 = t->tx0; ua.ty0 = t->ty0;
       ua.rb = (long long)dw * dh >= 6000000 ? 8 : 6;      // per-wave time rules (profiles/r03/pb_up_ab.txt: 720p -> 1080p 11.6 us at 6 rows per band, 15.3 at 16, 38 at 64)
       { const int v = tune(TUNE_PB_UP_RB); if (v >= 1 && v <= 4096) ua.rb = v; }      // tuning probe
-      const dim3 gu(cdiv(cdiv((unsigned)dw, 64), 4), cdiv((unsigned)dh, (unsigned)ua.rb));
+      const dim3 gu(cdiv(cdiv((unsigned)dw, 64), 4), cdiv((unsigned)dh, (unsigned)ua.rb), (unsigned)n);
       const uint32_t *gp = t->gpairs_d;
-#define PB_UP(NP_, NY_) hipLaunchKernelGGL((k_pb_up<NP_, NY_>), gu, block, 0, st, ua, gp)
+#define PB_UP(NP_, NY_) hipLaunchKernelGGL((k_pb_up<NP_, NY_>), gu, block, 0, st, ua, gp, F)
       if (unp == 1) { if (uny == 1) PB_UP(1, 1); else if (uny == 2) PB_UP(1, 2); else if (uny == 3) PB_UP(1, 3); else PB_UP(1, 4); }
       else { if (uny == 1) PB_UP(2, 1); else if (uny == 2) PB_UP(2, 2); else if (uny == 3) PB_UP(2, 3); else PB_UP(2, 4); }
 #undef PB_UP
@@ -1953,10 +1987,10 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
     ga.x_step = x_step; ga.y_step = y_step; ga.xoff = t->xoff; ga.yoff = t->yoff; ga.tx0 = t->tx0; ga.ty0 = t->ty0; ga.ny_eff = t->ty1 - t->ty0;
     const int gnp = (t->tx1 - t->tx0 + 1) / 2;
     const uint32_t *gp = t->gpairs_d;
-    if (gnp == 1) hipLaunchKernelGGL(k_pb_gather<1>, grid, block, 0, st, ga, gp);
-    else if (gnp == 2) hipLaunchKernelGGL(k_pb_gather<2>, grid, block, 0, st, ga, gp);
-    else if (gnp == 3) hipLaunchKernelGGL(k_pb_gather<3>, grid, block, 0, st, ga, gp);
-    else hipLaunchKernelGGL(k_pb_gather<4>, grid, block, 0, st, ga, gp);
+    if (gnp == 1) hipLaunchKernelGGL(k_pb_gather<1>, grid, block, 0, st, ga, gp, F);
+    else if (gnp == 2) hipLaunchKernelGGL(k_pb_gather<2>, grid, block, 0, st, ga, gp, F);
+    else if (gnp == 3) hipLaunchKernelGGL(k_pb_gather<3>, grid, block, 0, st, ga, gp, F);
+    else hipLaunchKernelGGL(k_pb_gather<4>, grid, block, 0, st, ga, gp, F);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
@@ -1977,19 +2011,19 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
       if ((size_t)pa.wpairs * wh * 16 <= lds_cap) { pa.tile_h = th; pa.win_h = wh; break; }
     }
     if (pa.tile_h) {
-      const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h));
+      const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h), (unsigned)n);
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
 #define PB_PAIRS(CHN)                                                                                                     \
       { const int ny = tune_on(TUNE_PB_NO_NY) ? 0 : t->ty1 - t->ty0; pa.no_quad = tune_on(TUNE_PB_NO_QUAD) ? 1 : 0;                                                                                   \
-        if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa);                       \
-        else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa);                  \
-        else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa);                  \
-        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0>), g, block, lds, st, pa);                             \
-        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0>), g, block, lds, st, pa);                             \
-        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0>), g, block, lds, st, pa);                             \
-        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0>), g, block, lds, st, pa);                             \
-        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0>), g, block, lds, st, pa); }
+        if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa, F);                       \
+        else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa, F);                  \
+        else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa, F);                  \
+        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0>), g, block, lds, st, pa, F);                             \
+        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0>), g, block, lds, st, pa, F);                             \
+        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0>), g, block, lds, st, pa, F);                             \
+        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0>), g, block, lds, st, pa, F);                             \
+        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0>), g, block, lds, st, pa, F); }
       if (channels == 4) { PB_PAIRS(4) } else { PB_PAIRS(3) }
 #undef PB_PAIRS
       LGPU_CHECK_LAUNCH();
@@ -2009,21 +2043,32 @@ extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh,
   }
   const bool uniform = (x_step & 0xFFFF) == 0;
   if (a.tile_h) {
-    const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)a.tile_h));
+    const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)a.tile_h), (unsigned)n);
     const size_t lds = (size_t)a.win_w * a.win_h * 4;
     if (channels == 4) {
-      if (uniform) hipLaunchKernelGGL((k_pb_window<4, 1>), g, block, lds, st, a);
-      else hipLaunchKernelGGL((k_pb_window<4, 0>), g, block, lds, st, a);
+      if (uniform) hipLaunchKernelGGL((k_pb_window<4, 1>), g, block, lds, st, a, F);
+      else hipLaunchKernelGGL((k_pb_window<4, 0>), g, block, lds, st, a, F);
     } else {
-      if (uniform) hipLaunchKernelGGL((k_pb_window<3, 1>), g, block, lds, st, a);
-      else hipLaunchKernelGGL((k_pb_window<3, 0>), g, block, lds, st, a);
+      if (uniform) hipLaunchKernelGGL((k_pb_window<3, 1>), g, block, lds, st, a, F);
+      else hipLaunchKernelGGL((k_pb_window<3, 0>), g, block, lds, st, a, F);
     }
   } else {
-    if (channels == 4) hipLaunchKernelGGL(k_pb_direct<4>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(k_pb_direct<3>, grid, block, 0, st, a);
+    if (channels == 4) hipLaunchKernelGGL(k_pb_direct<4>, grid, block, 0, st, a, F);
+    else hipLaunchKernelGGL(k_pb_direct<3>, grid, block, 0, st, a, F);
   }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+
+extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *dst_d, int orow, int dw, int dh, int channels, int interp,
+                                 void *stream) {
+  return pb_scale_n(&src_d, &dst_d, 1, irow, sw, sh, orow, dw, dh, channels, interp, stream);
+}
+// lgpu_pixbuf_scale for nframes frames of one geometry (the layers of the live tracks of one plan step: src/effects-weed.c:1850-2425 runs one instance per track per
+// tick; compositor.c:262-266 scales every layer of a frame): ONE launch
+extern "C" int lgpu_pixbuf_scale_batch(const uint8_t *const *src_d, uint8_t *const *dst_d, int nframes, int irow, int sw, int sh, int orow, int dw, int dh, int channels,
+                                       int interp, void *stream) {
+  return pb_scale_n(src_d, dst_d, nframes, irow, sw, sh, orow, dw, dh, channels, interp, stream);
 }
 
 // resize -> letterbox -> blend (-> gamma) as one call: BASELINE config 3's chain.  letterbox_layer (src/colourspace.c:15343-15567) centres the scaled frame on an

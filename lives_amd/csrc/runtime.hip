@@ -397,6 +397,26 @@ int lgpu_sync(void *stream) {
   return LGPU_OK;
 }
 
+// the calling thread's current HIP device (helper threads of this library take their creator's)
+int lgpu_current_device(int *device) {
+  if (!device) return LGPU_E_BADARG;
+  LGPU_HIP(hipGetDevice(device));
+  return LGPU_OK;
+}
+int lgpu_set_device(int device) {
+  LGPU_HIP(hipSetDevice(device));
+  return LGPU_OK;
+}
+
+// 1: everything enqueued on the stream so far has completed, 0: not yet, negative: a HIP error (no blocking: hipStreamQuery)
+int lgpu_stream_query(void *stream) {
+  const hipError_t e = hipStreamQuery((hipStream_t)stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  lgpu::set_error("hipStreamQuery failed: %s", hipGetErrorString(e));
+  return LGPU_E_HIP;
+}
+
 // the control rank writes the shared transition parameter block (int32[4], device memory) from four host values: they travel as kernel arguments, so
 // the call costs one launch and no host -> device copy (a 16-byte hipMemcpyAsync from pageable memory stages and blocks)
 int lgpu_params_set_n(int32_t *param_blocks_d, const int32_t *values, int nblocks, void *stream) {

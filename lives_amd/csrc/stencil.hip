@@ -24,17 +24,21 @@ __device__ __forceinline__ uint32_t isqrt24(uint32_t n) {
 }
 
 // the planes that are only copied (softlight.c:143-151) ride in the same launch: blockIdx.z = 1 .. ncopy copies 64 x 16 tiles of plane z
-struct SoftCopy { const uint8_t *src[3]; uint8_t *dst[3]; int irow[3], orow[3], w, h, n; };
-__global__ __launch_bounds__(kBlock) void k_softlight(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height,
+// batched (lgpu_fx_batch): blockIdx.z = frame * (n + 1) + plane, the frame's planes from the table
+struct SoftCopy { int irow[3], orow[3], w, h, n; };
+__global__ __launch_bounds__(kBlock) void k_softlight(const FxFrames F, int irow, int orow, int width, int height,
                                                         int ymin, int ymax, SoftCopy cp) {
+  const int frame = blockIdx.z / (cp.n + 1), plane = blockIdx.z - frame * (cp.n + 1);
+  const uint8_t *src = F.in0[frame][0];
+  uint8_t *dst = F.out[frame][0];
   __shared__ __attribute__((aligned(4))) uint8_t s[(kStH + 2) * (kStW + 8)];              // rows y0-1 .. y0+kStH, columns x0-4 .. x0+kStW+3
   constexpr int P = kStW + 8;
   const int x0 = blockIdx.x * kStW, y0 = blockIdx.y * kStH;
-  if (blockIdx.z) {
-    const int pz = blockIdx.z - 1, ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4, y = y0 + ly, x = x0 + lx;
+  if (plane) {
+    const int pz = plane - 1, ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4, y = y0 + ly, x = x0 + lx;
     if (y >= cp.h || x >= cp.w) return;
-    const uint8_t *ps = cp.src[pz] + (size_t)y * cp.irow[pz] + x;
-    uint8_t *pd = cp.dst[pz] + (size_t)y * cp.orow[pz] + x;
+    const uint8_t *ps = F.in0[frame][plane] + (size_t)y * cp.irow[pz] + x;
+    uint8_t *pd = F.out[frame][plane] + (size_t)y * cp.orow[pz] + x;
     if (x + 4 <= cp.w && (((uintptr_t)ps | (uintptr_t)pd) & 3) == 0) *reinterpret_cast<uint32_t *>(pd) = *reinterpret_cast<const uint32_t *>(ps);
     else for (int j = 0; j < 4 && x + j < cp.w; j++) pd[j] = ps[j];
     return;
@@ -102,12 +106,15 @@ __global__ __launch_bounds__(kBlock) void k_softlight(const uint8_t *src, int ir
 // (64 s + 192 v) >> 8 == (s + 3 v) >> 2.  57 -> ~22 vector operations per pixel; one 1080p 4:2:0 frame 6.2 -> see profiles/r04/ops_roofline.md.
 typedef short sl_s2 __attribute__((ext_vector_type(2)));
 template <int RB>
-__global__ __launch_bounds__(kBlock) void k_softlight_s(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int ymin, int ymax, SoftCopy cp) {
-  if (blockIdx.z) {          // the planes that are only copied: 256 x 16 tiles of plane z - 1, sixteen bytes per thread
-    const int pz = blockIdx.z - 1, ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 16, y = blockIdx.y * 16 + ly, x = blockIdx.x * 256 + lx;
+__global__ __launch_bounds__(kBlock) void k_softlight_s(const FxFrames F, int irow, int orow, int width, int height, int ymin, int ymax, SoftCopy cp) {
+  const int frame = blockIdx.z / (cp.n + 1), plane = blockIdx.z - frame * (cp.n + 1);
+  const uint8_t *src = F.in0[frame][0];
+  uint8_t *dst = F.out[frame][0];
+  if (plane) {          // the planes that are only copied: 256 x 16 tiles of plane `plane`, sixteen bytes per thread
+    const int pz = plane - 1, ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 16, y = blockIdx.y * 16 + ly, x = blockIdx.x * 256 + lx;
     if (y >= cp.h || x >= cp.w) return;
-    const uint8_t *ps = cp.src[pz] + (size_t)y * cp.irow[pz] + x;
-    uint8_t *pd = cp.dst[pz] + (size_t)y * cp.orow[pz] + x;
+    const uint8_t *ps = F.in0[frame][plane] + (size_t)y * cp.irow[pz] + x;
+    uint8_t *pd = F.out[frame][plane] + (size_t)y * cp.orow[pz] + x;
     if (x + 16 <= cp.w && (((uintptr_t)ps | (uintptr_t)pd) & 15) == 0) *reinterpret_cast<uint4 *>(pd) = *reinterpret_cast<const uint4 *>(ps);
     else for (int j = 0; j < 16 && x + j < cp.w; j++) pd[j] = ps[j];
     return;
@@ -920,41 +927,53 @@ __global__ __launch_bounds__(kBlock) void k_rgbd_snapshot(const uint8_t *src, in
 
 using namespace lgpu;
 
-extern "C" int lgpu_softlight(const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4], const int orow[4],
-                              int width, int height, int palette, int unclamped, void *stream) {
-  int rc = ensure_init();
-  if (rc) return rc;
-  LGPU_REQUIRE(src_d && dst_d && irow && orow, "null plane tables");
+// nframes frames of one geometry (lgpu_softlight: one; lgpu_fx_batch: the instances of the filter on the live tracks of a tick) in ONE launch
+int lgpu::softlight_n(const FxFrames &F, int nframes, const int irow[4], const int orow[4], int width, int height, int palette, int unclamped, hipStream_t st) {
+  LGPU_REQUIRE(irow && orow, "null rowstride tables");
   LGPU_REQUIRE(palette == 544 || palette == 545 || palette == 522 || palette == 512 || palette == 513,
                "palette must be YUV444P, YUVA4444P, YUV422P, YUV420P or YVU420P (softlight.c:162-164)");
   LGPU_REQUIRE(width >= 3 && height >= 3, "softlight needs at least 3 x 3 samples");
   const int nplanes = palette == 545 ? 4 : 3;
-  for (int i = 0; i < nplanes; i++) LGPU_REQUIRE(src_d[i] && dst_d[i] && src_d[i] != dst_d[i], "null plane, or in place (the filter is not CAN_DO_INPLACE)");
+  uintptr_t bits = 0;
+  for (int f = 0; f < nframes; f++)
+    for (int i = 0; i < nplanes; i++) {
+      LGPU_REQUIRE(F.in0[f][i] && F.out[f][i] && F.in0[f][i] != F.out[f][i], "null plane, or in place (the filter is not CAN_DO_INPLACE)");
+      if (i == 0) bits |= (uintptr_t)F.in0[f][0] | (uintptr_t)F.out[f][0];
+    }
   LGPU_REQUIRE(irow[0] >= width && orow[0] >= width, "rowstride smaller than a row");
-  hipStream_t st = (hipStream_t)stream;
   // the other planes are copied (softlight.c:143-151) by extra blocks of the same launch; alpha of YUVA4444P has the chroma geometry of 4:4:4
   SoftCopy cp = {};
   cp.w = (palette == 512 || palette == 513 || palette == 522) ? width >> 1 : width;
   cp.h = (palette == 512 || palette == 513) ? height >> 1 : height;
   cp.n = nplanes - 1;
-  for (int i = 1; i < nplanes; i++) { cp.src[i - 1] = src_d[i]; cp.dst[i - 1] = dst_d[i]; cp.irow[i - 1] = irow[i]; cp.orow[i - 1] = orow[i]; }
+  for (int i = 1; i < nplanes; i++) { cp.irow[i - 1] = irow[i]; cp.orow[i - 1] = orow[i]; }
   // 4-aligned luma planes: the register form (k_softlight_s); everything else the LDS tile kernel
-  if ((width & 3) == 0 && width >= 8 && ((((uintptr_t)src_d[0] | (uintptr_t)dst_d[0]) | (unsigned)irow[0] | (unsigned)orow[0]) & 3) == 0 && !tune_on(TUNE_SOFT_NO_S)) {
+  if ((width & 3) == 0 && width >= 8 && ((bits | (unsigned)irow[0] | (unsigned)orow[0]) & 3) == 0 && !tune_on(TUNE_SOFT_NO_S)) {
     const int rbt = tune(TUNE_SOFT_RB), rb = (rbt & 15) == 4 ? 4 : 2;
     const unsigned strips = cdiv((unsigned)(width >> 2), 62u), bands = cdiv((unsigned)height, (unsigned)(4 * rb));
     const unsigned cx = cdiv((unsigned)cp.w, 256u), cy = cdiv((unsigned)cp.h, 16u);     // the copy planes' tiles must fit the same grid
-    dim3 gs(strips > cx ? strips : cx, bands > cy ? bands : cy, (unsigned)nplanes);
-    if (rbt >= 16) gs = dim3(strips, bands, 1);          // probe: luma only
-    if (rb == 4) hipLaunchKernelGGL(k_softlight_s<4>, gs, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
-    else hipLaunchKernelGGL(k_softlight_s<2>, gs, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
+    dim3 gs(strips > cx ? strips : cx, bands > cy ? bands : cy, (unsigned)(nplanes * nframes));
+    if (rbt >= 16) { gs = dim3(strips, bands, (unsigned)nframes); cp.n = 0; }          // probe: luma only
+    if (rb == 4) hipLaunchKernelGGL(k_softlight_s<4>, gs, dim3(kBlock), 0, st, F, irow[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
+    else hipLaunchKernelGGL(k_softlight_s<2>, gs, dim3(kBlock), 0, st, F, irow[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
-  const dim3 grid(cdiv((unsigned)width, kStW), cdiv((unsigned)height, kStH), (unsigned)nplanes);
-  hipLaunchKernelGGL(k_softlight, grid, dim3(kBlock), 0, st, src_d[0], irow[0], dst_d[0], orow[0], width, height, unclamped ? 0 : 16,
-                     unclamped ? 255 : 235, cp);
+  const dim3 grid(cdiv((unsigned)width, kStW), cdiv((unsigned)height, kStH), (unsigned)(nplanes * nframes));
+  hipLaunchKernelGGL(k_softlight, grid, dim3(kBlock), 0, st, F, irow[0], orow[0], width, height, unclamped ? 0 : 16, unclamped ? 255 : 235, cp);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+
+extern "C" int lgpu_softlight(const uint8_t *const src_d[4], const int irow[4], uint8_t *const dst_d[4], const int orow[4],
+                              int width, int height, int palette, int unclamped, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(src_d && dst_d && irow && orow, "null plane tables");
+  FxFrames F = {};
+  const int nplanes = palette == 545 ? 4 : 3;
+  for (int i = 0; i < nplanes; i++) { F.in0[0][i] = src_d[i]; F.out[0][i] = dst_d[i]; }
+  return softlight_n(F, 1, irow, orow, width, height, palette, unclamped, (hipStream_t)stream);
 }
 
 extern "C" int lgpu_edge(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int palette, int mode,

@@ -8,6 +8,8 @@ ordered and needs no host round trip.  On GPUs the exchange runs through the lib
 lgpu_params_broadcast / lgpu_fan_in, RCCL called directly); the torch.distributed forms below remain for the CPU (gloo) tests
 of the protocol and as the id side channel.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -55,8 +57,13 @@ class RcclComm:
             dist.broadcast(t, src=0)
             idbuf = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
         c = ctypes.c_void_p()
-        lib.call("lgpu_dist_comm_create", idbuf, self.rank, self.world, ctypes.byref(c))
+        # a rank of the job that never arrives must not hang the others for ever: LGPU_E_TIMEOUT after LGPU_COMM_TIMEOUT_MS (default 120 s) names the rank that waited
+        lib.call("lgpu_dist_comm_create_timeout", idbuf, self.rank, self.world, int(os.environ.get("LGPU_COMM_TIMEOUT_MS", "120000")), ctypes.byref(c))
         self.comm = c
+
+    def count(self):
+        """ncclCommCount: the ranks this communicator really has"""
+        return int(self.lib.load().lgpu_dist_comm_count(self.comm))
 
     def broadcast_params(self, block, root=0, stream=None):
         self.lib.call("lgpu_params_broadcast", self.comm, root, block.data_ptr(), _sp(stream))
@@ -110,6 +117,13 @@ class Stepper:
         """lgpu_stepper_overlap: odd steps on a second launch stream (a torch.cuda.Stream, or None to switch it off); synchronise both before reading results"""
         self.lib.call("lgpu_stepper_overlap", self.h, second_stream.cuda_stream if second_stream is not None else None)
         self._second = second_stream
+
+    def wait(self, timeout_ms=0):
+        """lgpu_stepper_wait: everything fed and launched so far has completed, or LgpuError (LGPU_E_TIMEOUT) naming what hangs"""
+        self.lib.call("lgpu_stepper_wait", self.h, int(timeout_ms))
+
+    def failed(self):
+        return bool(self.lib.load().lgpu_stepper_failed(self.h))
 
     def block_ptr(self, which):
         return self.lib.load().lgpu_stepper_block(self.h, which)
@@ -292,6 +306,16 @@ def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_over_ranks(seconds, device):
+    """every rank's value, in rank order (a list of one without a process group)"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [seconds]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = seconds
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
 
 
 def fan_in(local_frames, ntracks, dst=0):

@@ -53,11 +53,22 @@ class ChainParams(ctypes.Structure):
                 ("lut8", ctypes.c_uint8 * 256), ("param_block_d", vp)]
 
 
+class FxFrame(ctypes.Structure):
+    _fields_ = [("in0", vp * 4), ("in1", vp * 4), ("out", vp * 4)]
+
+
+class FxParams(ctypes.Structure):
+    _fields_ = [("op", ci), ("width", ci), ("height", ci), ("palette", ci), ("irow0", ci * 4), ("irow1", ci * 4), ("orow", ci * 4), ("ip", ci * 4), ("dp", ctypes.c_double * 2)]
+
+
 # name -> argtypes; every entry point include/lives_gpu.h declares must appear here (tests check both ways)
 PROTOTYPES = {
     "lgpu_abi_version": [],
     "lgpu_init": [ci],
     "lgpu_device_count": [],
+    "lgpu_current_device": [vp],
+    "lgpu_set_device": [ci],
+    "lgpu_stream_query": [vp],
     "lgpu_malloc": [ctypes.POINTER(vp), ctypes.c_size_t],
     "lgpu_free": [vp],
     "lgpu_malloc_ordered": [ctypes.POINTER(vp), ctypes.c_size_t, vp],
@@ -77,6 +88,8 @@ PROTOTYPES = {
     "lgpu_dist_bind": [ctypes.c_char_p],
     "lgpu_dist_unique_id": [vp],
     "lgpu_dist_comm_create": [vp, ci, ci, ctypes.POINTER(vp)],
+    "lgpu_dist_comm_create_timeout": [vp, ci, ci, ci, ctypes.POINTER(vp)],
+    "lgpu_dist_comm_count": [vp],
     "lgpu_dist_comm_destroy": [vp],
     "lgpu_params_broadcast": [vp, ci, vp, vp],
     "lgpu_status_allreduce": [vp, vp, vp],
@@ -87,6 +100,7 @@ PROTOTYPES = {
     "lgpu_stepper_feed": [vp, vp, ci],
     "lgpu_stepper_overlap": [vp, vp],
     "lgpu_stepper_failed": [vp],
+    "lgpu_stepper_wait": [vp, ci],
     "lgpu_chain_check": [ctypes.POINTER(ChainParams), ctypes.POINTER(ChainTrack), ci],
     "lgpu_params_set_n": [vp, vp, ci, vp],
     "lgpu_params_broadcast_n": [vp, ci, vp, ci, vp],
@@ -116,6 +130,8 @@ PROTOTYPES = {
     "lgpu_letterbox_bars": [vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
     "lgpu_pixbuf_scale": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_pixbuf_scale_batch": [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "lgpu_fx_batch": [ctypes.POINTER(FxParams), ctypes.POINTER(FxFrame), ci, vp],
     "lgpu_chain_canvas": [vp, vp, vp, ci, vp],
     "lgpu_pixbuf_weights": [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_size_t],
     "lgpu_make_filter": [ci, ci, ci, vp, vp, vp, ci],

@@ -125,6 +125,15 @@ def pixbuf_scale(src, dst, sw, sh, dw, dh, channels=4, interp=3):
     lib.call("lgpu_pixbuf_scale", dptr(src), src.stride(0), sw, sh, dptr(dst), dst.stride(0), dw, dh, channels, interp, stream_ptr())
 
 
+def ptr_array(tensors):
+    """host array of device pointers (what the *_batch entry points take)"""
+    return (ctypes.c_void_p * len(tensors))(*[dptr(t) for t in tensors])
+
+
+def pixbuf_scale_batch(srcs, dsts, sw, sh, dw, dh, channels=4, interp=3):
+    lib.call("lgpu_pixbuf_scale_batch", ptr_array(srcs), ptr_array(dsts), len(srcs), srcs[0].stride(0), sw, sh, dsts[0].stride(0), dw, dh, channels, interp, stream_ptr())
+
+
 def gauss5(src, dst, width, height, psize=4):
     lib.call("lgpu_gauss5", dptr(src), src.stride(0), dptr(dst), dst.stride(0), width, height, psize, stream_ptr())
 
@@ -253,6 +262,34 @@ def softlight(src_planes, dst_planes, width, height, palette, unclamped):
     assert n in (3, 4)
     lib.call("lgpu_softlight", ctypes.addressof(sp), ctypes.addressof(ss), ctypes.addressof(dp), ctypes.addressof(ds), width, height,
              palette, int(unclamped), stream_ptr())
+
+
+FX_SOFTLIGHT, FX_TRANSITION, FX_YUV411_TO_RGB = 1, 2, 3
+
+
+def fx_batch(op, ins0, outs, width, height, ins1=None, palette=0, ip=(0, 0, 0, 0), dp=(0., 0.)):
+    """lgpu_fx_batch: ins0 / ins1 / outs are lists (one entry per frame) of lists of plane tensors; strides are taken from frame 0"""
+    n = len(ins0)
+    frames = (lib.FxFrame * n)()
+    for f in range(n):
+        for k, t in enumerate(ins0[f]):
+            frames[f].in0[k] = dptr(t)
+        for k, t in enumerate(ins1[f] if ins1 else []):
+            frames[f].in1[k] = dptr(t)
+        for k, t in enumerate(outs[f]):
+            frames[f].out[k] = dptr(t)
+    prm = lib.FxParams()
+    prm.op, prm.width, prm.height, prm.palette = op, width, height, palette
+    for k, t in enumerate(ins0[0]):
+        prm.irow0[k] = t.stride(0)
+    for k, t in enumerate(ins1[0] if ins1 else []):
+        prm.irow1[k] = t.stride(0)
+    for k, t in enumerate(outs[0]):
+        prm.orow[k] = t.stride(0)
+    for k in range(4):
+        prm.ip[k] = int(ip[k]) if k < len(ip) else 0
+    prm.dp[0], prm.dp[1] = float(dp[0]), float(dp[1]) if len(dp) > 1 else 0.
+    lib.call("lgpu_fx_batch", ctypes.byref(prm), frames, n, stream_ptr())
 
 
 def edge(src, dst, width, height, palette, mode):

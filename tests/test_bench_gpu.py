@@ -43,3 +43,63 @@ def test_bench_multi_gpu_host_path_on_one_gpu():
         assert c[k] > 0, k
     assert c["config5_blur_ms_per_step"] > c["config5_ms_per_step"]
     assert c["projected_batch8_speedup"] > 3.0
+    assert c["rccl_ranks"] == 1 and j["per_rank_ms_per_step"]["ranks"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_under_the_drivers_launcher_agrees_with_the_plain_run():
+    """The driver's N = 1 leg of the scaling run is `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`: the same workload, a value within 5 %
+    of the plain run's, the per-rank clocks and the config-5 figures present at every rank count."""
+    import socket
+    plain = run_bench(["--steps", "200", "--warmup", "50"])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu", "--steps", "200", "--warmup", "50"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["config"]["workload"] == plain["config"]["workload"] and j["config"]["tracks_per_gpu"] == plain["config"]["tracks_per_gpu"] and j["n_gpus"] == 1
+    assert abs(j["value"] - plain["value"]) <= 0.05 * plain["value"], (j["value"], plain["value"])
+    for line in (j, plain):
+        assert line["per_rank_ms_per_step"]["ranks"] == 1 and abs(line["per_rank_ms_per_step"]["max"] - line["ms_per_step"]) < 1e-3
+        assert line["config"]["config5_ms_per_step"] > 0 and line["config"]["config5_blur_ms_per_step"] > line["config"]["config5_ms_per_step"]
+
+
+@pytest.mark.gpu
+def test_a_missing_peer_ends_with_a_message_not_a_hang(gpu):
+    """lgpu_dist_comm_create_timeout: rank 0 of a two-rank job whose rank 1 never starts gets LGPU_E_TIMEOUT and a message naming the rank that waited;
+    lgpu_stepper_wait: a launch stream that does not drain within the limit fails the stepper with what it was waiting for"""
+    import ctypes
+    import time
+    import numpy as np
+    import torch
+    from lives_amd import dist as ld, lib
+    L = lib.load()
+    idbuf = (ctypes.c_uint8 * 128)()
+    if L.lgpu_dist_bind(None) == 0:
+        assert L.lgpu_dist_unique_id(idbuf) == 0
+        c = ctypes.c_void_p()
+        t0 = time.time()
+        rc = L.lgpu_dist_comm_create_timeout(idbuf, 0, 2, 1500, ctypes.byref(c))
+        assert rc == -7 and 1.0 < time.time() - t0 < 30.0
+        assert b"rank 0 of 2" in L.lgpu_last_error()
+    # a stepper whose launch stream is held up by a host callback that sleeps past the limit
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+    nap = CB(lambda _: time.sleep(1.5))
+    own = torch.cuda.Stream()
+    st = ld.Stepper(None, [10], stream=own)
+    try:
+        st.wait(2000)                                       # nothing outstanding: returns at once
+        assert hip.hipLaunchHostFunc(ctypes.c_void_p(own.cuda_stream), nap, None) == 0
+        with pytest.raises(lib.LgpuError) as ei:
+            st.wait(200)
+        assert "waited" in str(ei.value) and "launch" in str(ei.value) and st.failed()
+        torch.cuda.synchronize()
+    finally:
+        st.close()

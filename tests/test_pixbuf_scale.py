@@ -515,3 +515,61 @@ def test_exact_doubling_of_4_byte_pixels(gpu, orc):
         got = gpu_scale(gpu, src, sw, sh, dw, dh, 4, interp, orow=dw * 4)
         bad = np.argwhere(got != want)
         assert len(bad) == 0, "%dx%d interp %d alpha mode %d: %d bytes differ, first %s" % (sw, sh, interp, amode, len(bad), bad[0].tolist())
+
+
+@gpu_mark
+def test_batch_equals_single_calls_and_the_oracle(gpu, orc, tune):
+    """lgpu_pixbuf_scale_batch: N frames of one geometry in ONE launch of whichever kernel the geometry selects.  Every frame against the oracle (so: against N single
+    calls too, which the tests above pin), frames in a shuffled slot order, guard rows / row padding of every destination untouched, the least aligned frame decides
+    the kernel.  Geometries: one per kernel -- pairs (non-integer reduction), gather (3:1), up (enlargement), double (1:2), half (2:1, 4 bytes), half3 (2:1, 3 bytes),
+    nearest, the LDS-window and direct kernels (forced), a same-size copy."""
+    from lives_amd import lib
+    rng = np.random.default_rng(0x9DC1)
+    cases = [(384, 216, 171, 96, 4, 3, None), (384, 216, 171, 96, 3, 2, None), (390, 219, 130, 73, 4, 3, None), (128, 72, 192, 108, 4, 3, None), (128, 72, 256, 144, 4, 3, None),
+             (512, 64, 256, 32, 4, 3, None), (512, 64, 256, 32, 4, 2, None), (256, 64, 128, 32, 3, 3, None), (200, 120, 133, 80, 4, 0, None), (200, 120, 133, 80, 3, 0, None),
+             (384, 216, 171, 96, 4, 3, "PB_NO_PAIRS"), (3000, 64, 100, 8, 4, 3, None), (64, 36, 64, 36, 4, 3, None)]
+    for (sw, sh, dw, dh, ch, interp, sw_off) in cases:
+        if sw_off:
+            tune(sw_off, 1)
+        for n in (1, 2, 5, 16):
+            irow, orow = align(sw * ch, 16), align(dw * ch, 16)
+            srcs = [rng.integers(0, 256, (sh, irow), dtype=np.uint8) for _ in range(n)]
+            if ch == 4:
+                for k, s_ in enumerate(srcs):
+                    if k % 3 == 1:
+                        s_[:, 3::4] = 255
+                    elif k % 3 == 2:
+                        s_[:, 3::4][rng.random((sh, irow // 4)) < 0.4] = 0
+            wants = []
+            for s_ in srcs:
+                w_ = np.zeros((dh, dw * ch), np.uint8)
+                assert orc.orc_pixbuf_scale(P(s_), irow, sw, sh, P(w_), dw * ch, dw, dh, ch, interp) == 0
+                wants.append(w_)
+            d_srcs = [dev(s_) for s_ in srcs]
+            d_dsts = [dev(np.full((dh + 1, orow), 0xA5, np.uint8)) for _ in range(n)]
+            order = list(rng.permutation(n))
+            gpu.pixbuf_scale_batch([d_srcs[i] for i in order], [d_dsts[i] for i in order], sw, sh, dw, dh, channels=ch, interp=interp)
+            for i in range(n):
+                out = host(d_dsts[i])
+                assert (out[dh] == 0xA5).all() and (out[:dh, dw * ch:] == 0xA5).all(), "guard bytes of frame %d" % i
+                assert (out[:dh, :dw * ch] == wants[i]).all(), "%dx%d->%dx%d %dch interp %d: frame %d of %d differs" % (sw, sh, dw, dh, ch, interp, i, n)
+        if sw_off:
+            tune(sw_off, 0)
+    # one frame of the batch on a 4-byte instead of a 16-byte boundary: the whole launch takes the kernel that frame needs, results unchanged
+    sw, sh, dw, dh = 512, 64, 256, 32
+    srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(3)]
+    slab = dev(np.zeros(sh * sw * 4 + 16, np.uint8))
+    odd = slab[4:4 + sh * sw * 4].view(sh, sw * 4)
+    odd.copy_(dev(srcs[1]))
+    d_srcs = [dev(srcs[0]), odd, dev(srcs[2])]
+    d_dsts = [dev(np.zeros((dh, dw * 4), np.uint8)) for _ in range(3)]
+    gpu.pixbuf_scale_batch(d_srcs, d_dsts, sw, sh, dw, dh, channels=4, interp=3)
+    for i in range(3):
+        w_ = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_pixbuf_scale(P(srcs[i]), sw * 4, sw, sh, P(w_), dw * 4, dw, dh, 4, 3) == 0
+        assert (host(d_dsts[i]) == w_).all()
+    # argument errors: no frame, too many, a null frame, in place
+    with pytest.raises(lib.LgpuError):
+        gpu.pixbuf_scale_batch(d_srcs[:1] * 65, d_dsts[:1] * 65, sw, sh, dw, dh, channels=4, interp=3)
+    with pytest.raises(lib.LgpuError):
+        gpu.pixbuf_scale_batch([d_srcs[0], d_dsts[1]], [d_dsts[0], d_dsts[1]], sw, sh, dw, dh, channels=4, interp=3)

@@ -73,6 +73,37 @@ def case(op):
             sets.append((srcs, l2s, ds, ops.chain_tracks(srcs, l2s, ds)))
         prm = ops.chain_params(W, H, W * 4, 1920, 1080, 1920 * 4, 1920 * 4, swap_rb=int(os.environ.get('C3_SWAP', '1')), interp=3 | 0x100, do_blur=0, bf=128, lut=np.arange(256, dtype=np.uint8))
         return (lambda i: ops.chain(prm, sets[i % nb][3])), n * (W * H * 4 + 2 * 1920 * 1080 * 4)
+    if op.startswith("fx") and ":" in op:       # fxN:softlight | fxN:yuv411 | fxN:transition -- N frames per launch through lgpu_fx_batch
+        n = int(op[2:op.index(":")])
+        kind = op.split(":")[1]
+        nb = 2 if not COLD else max(2, NB // n + 1)
+
+        def frames(rows, cols):
+            return [[torch.randint(0, 256, (rows, cols), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)] for _ in range(nb)]
+        if kind == "softlight":
+            Y, U, V = frames(h, w), frames(h // 2, w // 2), frames(h // 2, w // 2)
+            ins = [[[Y[s][f], U[s][f], V[s][f]] for f in range(n)] for s in range(nb)]
+            outs = [[[torch.zeros_like(t) for t in fr] for fr in st_] for st_ in ins]
+            return (lambda i: ops.fx_batch(ops.FX_SOFTLIGHT, ins[i % nb], outs[i % nb], w, h, palette=512, ip=(0,))), n * w * h * 3
+        if kind == "yuv411":
+            m, o = frames(h, (w >> 2) * 6), frames(h, w * 4)
+            return (lambda i: ops.fx_batch(ops.FX_YUV411_TO_RGB, [[t] for t in m[i % nb]], [[t] for t in o[i % nb]], w >> 2, h, ip=(0, 1, 0))), n * (w * h * 6 // 4 + w * h * 4)
+        if kind == "transition":
+            a_, b_, o = frames(h, w * 4), frames(h, w * 4), frames(h, w * 4)
+            return (lambda i: ops.fx_batch(ops.FX_TRANSITION, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], w, h, ins1=[[t] for t in b_[i % nb]], ip=(1, 4), dp=(0.5,))), n * w * h * 8
+        raise SystemExit("unknown fx batch " + op)
+    if op.startswith("pb") and op[2:op.index(":")].isdigit():      # pbN:SWxSH:DWxDH:interp -- N frames of one geometry per launch (lgpu_pixbuf_scale_batch)
+        head, a_, b_, it = op.split(":")
+        n = int(head[2:])
+        sw, sh = (int(v) for v in a_.split("x"))
+        dw, dh = (int(v) for v in b_.split("x"))
+        nb = NB if COLD else 2
+        if COLD:
+            nb = max(2, NB // n + 1)
+            nb += nb % 2
+        sets = [([torch.randint(0, 256, (sh, sw * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)],
+                 [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(n)]) for _ in range(nb)]
+        return (lambda i: ops.pixbuf_scale_batch(sets[i % nb][0], sets[i % nb][1], sw, sh, dw, dh, channels=4, interp=int(it))), n * (sw * sh * 4 + dw * dh * 4)
     if op.startswith("pb:"):           # pb:SWxSH:DWxDH:interp  -- one gdk-pixbuf ratio
         _, a_, b_, it = op.split(":")
         sw, sh = (int(v) for v in a_.split("x"))
