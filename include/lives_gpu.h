@@ -481,10 +481,12 @@ int lgpu_stepper_destroy(lgpu_stepper *s);
      LGPU_FX_SOFTLIGHT      in0 / out: the 3 (4: YUVA4444P) planes; irow0[], orow[], width, height, palette; ip[0] = unclamped          (lgpu_softlight)
      LGPU_FX_TRANSITION     in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = type, ip[1] = psize, dp[0] = amount   (lgpu_transition)
      LGPU_FX_YUV411_TO_RGB  in0[0], out[0]; width = macropixels, height, orow[0]; ip[0] = out_order, ip[1] = out_alpha, ip[2] = unclamped      (lgpu_yuv411_to_rgb)
+     LGPU_FX_GAUSS5_COLORKEY in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = psize, ip[1] = is_bgr, ip[2] = key colour r | g << 8 | b << 16,
+                            dp[0] = delta, dp[1] = opacity  (lgpu_gauss5_colorkey: BASELINE config 4 in one launch; LGPU_E_UNSUPPORTED outside its alignment range)
    The scaler has its own batch entry (lgpu_pixbuf_scale_batch), the palette conversion K2 lgpu_yuv420p_to_rgb_batch, the chain takes its tracks directly.  The
    compositor (lgpu_composite) IS the fan-in of a tick's tracks into one frame: a tick has one of it, there is nothing to batch. */
 #define LGPU_FX_MAX_FRAMES 16
-enum { LGPU_FX_SOFTLIGHT = 1, LGPU_FX_TRANSITION = 2, LGPU_FX_YUV411_TO_RGB = 3 };
+enum { LGPU_FX_SOFTLIGHT = 1, LGPU_FX_TRANSITION = 2, LGPU_FX_YUV411_TO_RGB = 3, LGPU_FX_GAUSS5_COLORKEY = 4 };
 typedef struct { const uint8_t *in0[4]; const uint8_t *in1[4]; uint8_t *out[4]; } lgpu_fx_frame;
 typedef struct { int op, width, height, palette; int irow0[4], irow1[4], orow[4]; int ip[4]; double dp[2]; } lgpu_fx_params;
 int lgpu_fx_batch(const lgpu_fx_params *params, const lgpu_fx_frame *frames, int nframes, void *stream);

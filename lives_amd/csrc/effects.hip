@@ -749,6 +749,8 @@ extern "C" int lgpu_fx_batch(const lgpu_fx_params *p, const lgpu_fx_frame *frame
   case LGPU_FX_SOFTLIGHT: return softlight_n(F, nframes, p->irow0, p->orow, p->width, p->height, p->palette, p->ip[0], st);
   case LGPU_FX_TRANSITION: return transition_n(F, nframes, p->ip[0], p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[1], p->dp[0], st);
   case LGPU_FX_YUV411_TO_RGB: return yuv411_to_rgb_n(F, nframes, p->width, p->height, p->orow[0], p->ip[0], p->ip[1], p->ip[2], st);
+  case LGPU_FX_GAUSS5_COLORKEY: return gauss5_colorkey_n(F, nframes, p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[0], p->ip[1], p->dp[0], p->dp[1], p->ip[2] & 0xFF,
+                                                         (p->ip[2] >> 8) & 0xFF, (p->ip[2] >> 16) & 0xFF, st);
   default: set_error("lgpu_fx_batch: unknown op %d", p->op); return LGPU_E_BADARG;
   }
 }

@@ -23,7 +23,7 @@ struct GckArgs {
   uint8_t *dst;
   int irow0, irow1, orow, width, height;
   int strips, cgroups, bands, th;
-  uint32_t mn_e, mx_e, mn_o, mx_o;                    // the key's box on (byte 0, byte 2) and (byte 1, byte 3) as 16-bit lanes; the max words carry 0x8000 per lane
+  uint32_t mn_e, mx_e, mn_o, mx_o;                    // the key's box on (byte 0, byte 2) and (byte 1, byte 3) as 16-bit lanes: mn = 0x8000 - min, mx = max | 0x8000 per lane
   double opac, opacx;
   int key;                                            // 0: blur only
 };
@@ -31,7 +31,9 @@ typedef unsigned gk_u4 __attribute__((ext_vector_type(4)));
 struct __attribute__((aligned(4))) gk_u3 { uint32_t x, y, z; };          // 12 bytes at a 4-byte aligned address: global_load / store_dwordx3
 
 template <int PS>
-__global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
+__global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A_, const FxFrames F) {
+  GckArgs A = A_;                                       // blockIdx.y: the frame of a batched launch (lgpu_fx_batch)
+  A.src0 = F.in0[blockIdx.y][0]; A.src1 = F.in1[blockIdx.y][0]; A.dst = F.out[blockIdx.y][0];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __shared__ double s_ta[256], s_tb[256];               // a * (1 - opac), b * opac for every byte value: the script's two products
   if (A.key) { s_ta[threadIdx.x] = (double)(int)threadIdx.x * A.opacx; s_tb[threadIdx.x] = (double)(int)threadIdx.x * A.opac; }
@@ -50,17 +52,28 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
   const int y0 = band * A.th, rows = min(A.th, A.height - y0);
   const uint32_t off = (uint32_t)(4 * PS) * (uint32_t)kc;
 
-  auto load4 = [&](const uint8_t *base, int irow, int y) -> gk_u4 {
-    y = y < 0 ? 0 : y > A.height - 1 ? A.height - 1 : y;
-    const uint8_t *p = base + (size_t)y * irow + off;
-    if (PS == 4) return *reinterpret_cast<const gk_u4 *>(p);
-    const gk_u3 t = *reinterpret_cast<const gk_u3 *>(p);
+  // buffer loads / stores: one descriptor per frame in SGPRs, the row as the scalar offset, the lane's place in the row as a constant VGPR offset -- no 64-bit
+  // address arithmetic on the vector unit (it was a v_mad_i64_i32 per access); lanes that must not store carry an offset beyond the descriptor's range
+  auto srd = [](const void *p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    void *u = (void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+    return __builtin_amdgcn_make_buffer_rsrc(u, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t r_src0 = srd(A.src0, (uint32_t)A.height * (uint32_t)A.irow0);
+  const __amdgpu_buffer_rsrc_t r_src1 = srd(A.key ? A.src1 : A.src0, A.key ? (uint32_t)A.height * (uint32_t)A.irow1 : 16u);
+  const __amdgpu_buffer_rsrc_t r_dst = srd(A.dst, (uint32_t)A.height * (uint32_t)A.orow);
+  auto load4 = [&](const __amdgpu_buffer_rsrc_t &r, int irow, int y) -> gk_u4 {
+    y = __builtin_amdgcn_readfirstlane(y < 0 ? 0 : y > A.height - 1 ? A.height - 1 : y);
+    if (PS == 4) return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, y * irow, 0);
+    typedef unsigned gk_v3 __attribute__((ext_vector_type(3)));
+    const gk_v3 t = __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, y * irow, 0);
     uint32_t q[4];
     unpack3(t.x, t.y, t.z, q);
-    gk_u4 r;
-    r.x = q[0]; r.y = q[1]; r.z = q[2]; r.w = q[3];
-    return r;
+    gk_u4 r4;
+    r4.x = q[0]; r4.y = q[1]; r4.z = q[2]; r4.w = q[3];
+    return r4;
   };
+  const uint32_t st_off = out_lane ? (uint32_t)(4 * PS) * (uint32_t)k : 0xFFFFFFF0u;
   auto fix = [&](gk_u4 q) -> gk_u4 {          // the gaussian replicates the frame's first / last column
     if (edge_strip) {
       if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }
@@ -70,13 +83,16 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
   };
   // horizontal pass of one row: h[2 j] = (byte 0, byte 2), h[2 j + 1] = (byte 1, byte 3) sums of pixel j, in 16-bit lanes
   auto hrow = [&](gk_u4 q, uint32_t h[8]) {
-    uint32_t p[8];
-    p[2] = q.x; p[3] = q.y; p[4] = q.z; p[5] = q.w;
-    p[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.z, 0x138, 0xF, 0xF, true); p[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.w, 0x138, 0xF, 0xF, true);   // wave_shr:1
-    p[6] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.x, 0x130, 0xF, 0xF, true); p[7] = (uint32_t)__builtin_amdgcn_mov_dpp((int)q.y, 0x130, 0xF, 0xF, true);   // wave_shl:1
+    // the lane's own four pixels are spread to 16-bit lanes first (one AND for bytes 0 / 2, one byte permute for bytes 1 / 3), and the SPREAD values travel to the
+    // neighbours: 8 + 8 operations per row instead of 4 lane moves + 24 to spread eight raw pixels
     uint32_t e[8], o[8];
+    const uint32_t own[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int i = 0; i < 8; i++) { e[i] = p[i] & 0x00FF00FFu; o[i] = (p[i] >> 8) & 0x00FF00FFu; }
+    for (int i = 0; i < 4; i++) { e[2 + i] = own[i] & 0x00FF00FFu; o[2 + i] = __builtin_amdgcn_perm(0u, own[i], 0x0C030C01u); }
+    e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[4], 0x138, 0xF, 0xF, true); e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[5], 0x138, 0xF, 0xF, true);   // wave_shr:1: the left lane's pixels 2, 3
+    o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[4], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[5], 0x138, 0xF, 0xF, true);
+    e[6] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); e[7] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true);   // wave_shl:1: the right lane's pixels 0, 1
+    o[6] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true); o[7] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       h[2 * j] = gauss5_taps(e[j], e[j + 1], e[j + 2], e[j + 3], e[j + 4]);
@@ -88,9 +104,8 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
   const int ylo = vr0 < 0 ? 0 : vr0, yhi = vr1 > A.height - 1 ? A.height - 1 : vr1;
   const int d = (band & 1) ? -1 : 1;
   const int ystart = d > 0 ? ylo : yhi, vstart = d > 0 ? vr0 : vr1;
-  gk_u4 qn = load4(A.src0, A.irow0, ystart);
-  gk_u4 b4 = {0, 0, 0, 0};
-  if (A.key) b4 = load4(A.src1, A.irow1, d > 0 ? y0 : y0 + rows - 1);
+  gk_u4 qn = load4(r_src0, A.irow0, ystart);
+  gk_u4 b4 = {0, 0, 0, 0};      // the second frame's pixels of the current output row: taken over from `nb` at the end of every step (step 3 loads the first output row's)
   uint32_t ring[5][8];
 #pragma unroll
   for (int i = 0; i < 5; i++)
@@ -107,10 +122,10 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
       const int vr = vstart + d * step;
       const int yy = vr < 0 ? 0 : vr > A.height - 1 ? A.height - 1 : vr;
       gk_u4 nb = {0, 0, 0, 0};
-      if (A.key) nb = load4(A.src1, A.irow1, vr - d);              // the second frame's pixels of the NEXT output row
+      if (A.key) nb = load4(r_src1, A.irow1, vr - d);              // the second frame's pixels of the NEXT output row
       if (yy != produced) {
         const gk_u4 q = qn;
-        qn = load4(A.src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic (two rows ahead: 26.4 -> 28.8 us, the registers cost a wave per SIMD)
+        qn = load4(r_src0, A.irow0, yy + d);                         // the next source row, in flight during this row's arithmetic (two rows ahead: 26.4 -> 28.8 us, the registers cost a wave per SIMD)
         hrow(fix(q), ring[u]);
         produced = yy;
       } else {
@@ -125,11 +140,12 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
         for (int j = 0; j < 4; j++) {
           const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
           const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
-          uint32_t a = ((ve >> 8) & 0x00FF00FFu) | (vo & 0xFF00FF00u);
+          uint32_t a = __builtin_amdgcn_perm(vo, ve, 0x07030501u);         // the high byte of every 16-bit lane is the blurred value: (ve.1, vo.1, ve.3, vo.3) in one byte permute
           if (A.key) {
-            // the box test on both 16-bit lanes at once: x >= min <=> bit 15 of (x | 0x8000) - min, x <= max <=> bit 15 of (max | 0x8000) - x (the alpha lane's box is 0 .. 255)
-            const uint32_t e = (ve >> 8) & 0x00FF00FFu, o = (vo >> 8) & 0x00FF00FFu;
-            const uint32_t t = ((e | 0x80008000u) - A.mn_e) & (A.mx_e - e) & ((o | 0x80008000u) - A.mn_o) & (A.mx_o - o) & 0x80008000u;
+            // the box test on both 16-bit lanes at once: x >= min <=> bit 15 of x + (0x8000 - min), x <= max <=> bit 15 of (max | 0x8000) - x (the alpha lane's box is
+            // 0 .. 255); the constants come ready from the host, the adds / subtracts / ANDs are the vector unit's cheap class
+            const uint32_t e = a & 0x00FF00FFu, o = __builtin_amdgcn_perm(0u, a, 0x0C030C01u);
+            const uint32_t t = (e + A.mn_e) & (A.mx_e - e) & (o + A.mn_o) & (A.mx_o - o) & 0x80008000u;
             if (t == 0x80008000u) {
               // (uint8_t)(a * (1 - opac) + b * opac) in double, the products from the workgroup's two 256-entry tables: one f64 add and one conversion per byte
               const uint32_t b = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
@@ -141,22 +157,23 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A) {
           }
           px[j] = a;
         }
-        if (out_lane) {
-          uint8_t *dp = A.dst + (size_t)y * A.orow + (size_t)(4 * PS) * (size_t)k;
+        {
+          const int so = __builtin_amdgcn_readfirstlane(y * A.orow);
           if (PS == 4) {
             gk_u4 o4;
             o4.x = px[0]; o4.y = px[1]; o4.z = px[2]; o4.w = px[3];
-            __builtin_nontemporal_store(o4, reinterpret_cast<gk_u4 *>(dp));
+            __builtin_amdgcn_raw_buffer_store_b128(o4, r_dst, (int)st_off, so, 2);       // not read again by this launch: non-temporal
           } else {
-            gk_u3 o3;
+            typedef unsigned gk_v3 __attribute__((ext_vector_type(3)));
+            gk_v3 o3;
             uint32_t w0, w1, w2;
             pack3(px, w0, w1, w2);
             o3.x = w0; o3.y = w1; o3.z = w2;
-            *reinterpret_cast<gk_u3 *>(dp) = o3;
+            __builtin_amdgcn_raw_buffer_store_b96(o3, r_dst, (int)st_off, so, 0);
           }
         }
       }
-      if (step >= 3) b4 = nb;
+      b4 = nb;                    // unconditionally: as a select on (step >= 3) it was four v_cndmask per step
     }
   }
 }
@@ -170,6 +187,7 @@ namespace lgpu {
 int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, hipStream_t st) {
   const uintptr_t bits = (uintptr_t)src_d | (uintptr_t)dst_d | (uintptr_t)irow | (uintptr_t)orow;
   if ((psize != 3 && psize != 4) || (width & 3) || (bits & (psize == 4 ? 15 : 3))) return LGPU_E_UNSUPPORTED;
+  if ((long long)height * irow >= (1ll << 31) || (long long)height * orow >= (1ll << 31)) return LGPU_E_UNSUPPORTED;      // 32-bit buffer offsets in the kernel
   GckArgs a;
   __builtin_memset(&a, 0, sizeof a);
   a.src0 = src_d; a.src1 = nullptr; a.dst = dst_d; a.irow0 = irow; a.irow1 = 0; a.orow = orow; a.width = width; a.height = height;
@@ -179,8 +197,10 @@ int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int wi
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   a.key = 0;
   const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u));
-  if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, st, a);
+  FxFrames F = {};
+  F.in0[0][0] = src_d; F.out[0][0] = dst_d;
+  if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, st, a, F);
+  else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, st, a, F);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
@@ -189,22 +209,29 @@ int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int wi
 // 5x5 gaussian of frame 0, then the colour key of the blurred frame against frame 1, in one launch.  psize 3 (RGB24 / BGR24: the reference's palettes) or 4
 // (RGBA32 / BGRA32: extension, alpha = the blurred frame's).  LGPU_E_UNSUPPORTED when the width is not a multiple of 4 or a frame is not 4- (psize 3) / 16-byte
 // (psize 4) aligned: the caller then runs lgpu_gauss5 and lgpu_colorkey one after the other.
-extern "C" int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow, int width, int height, int psize,
-                                    int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, void *stream) {
-  int rc = ensure_init();
-  if (rc) return rc;
-  LGPU_REQUIRE(src0_d && src1_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+int lgpu::gauss5_colorkey_n(const FxFrames &F, int nframes, int irow0, int irow1, int orow, int width, int height, int psize,
+                            int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, hipStream_t stream) {
+  LGPU_REQUIRE(width > 0 && height > 0, "empty geometry");
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
   LGPU_REQUIRE(irow0 >= width * psize && irow1 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
-  LGPU_REQUIRE(src0_d != dst_d, "the blur cannot run in place");
-  const uintptr_t bits = (uintptr_t)src0_d | (uintptr_t)src1_d | (uintptr_t)dst_d | (uintptr_t)irow0 | (uintptr_t)irow1 | (uintptr_t)orow;
+  uintptr_t bits = (uintptr_t)irow0 | (uintptr_t)irow1 | (uintptr_t)orow;
+  for (int f = 0; f < nframes; f++) {
+    LGPU_REQUIRE(F.in0[f][0] && F.in1[f][0] && F.out[f][0], "null frame");
+    LGPU_REQUIRE(F.in0[f][0] != F.out[f][0], "the blur cannot run in place");
+    bits |= (uintptr_t)F.in0[f][0] | (uintptr_t)F.in1[f][0] | (uintptr_t)F.out[f][0];
+  }
   if ((width & 3) || (bits & (psize == 4 ? 15 : 3))) { set_error("lgpu_gauss5_colorkey: width %% 4 or alignment outside the fused kernel's range"); return LGPU_E_UNSUPPORTED; }
+  if ((long long)height * irow0 >= (1ll << 31) || (long long)height * irow1 >= (1ll << 31) || (long long)height * orow >= (1ll << 31)) {
+    set_error("lgpu_gauss5_colorkey: a plane of 2 GiB or more is outside the fused kernel's 32-bit buffer offsets"); return LGPU_E_UNSUPPORTED; }
   GckArgs a;
-  a.src0 = src0_d; a.src1 = src1_d; a.dst = dst_d; a.irow0 = irow0; a.irow1 = irow1; a.orow = orow; a.width = width; a.height = height;
+  a.src0 = nullptr; a.src1 = nullptr; a.dst = nullptr; a.irow0 = irow0; a.irow1 = irow1; a.orow = orow; a.width = width; a.height = height;
   a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
   // short bands: the launch is bound by the time a wave needs for its rows, not by the rows the bands share (profiles/r03/c4_band_sweep.txt: 4K RGBA32 27 us at 6 rows,
   // 28 at 8, 32 at 16, 45 at 32)
   a.th = psize == 4 ? 6 : 8;
+  // a launch of more than one generation of workgroups (several frames: lgpu_fx_batch) is no longer a matter of one wave's latency: taller bands, fewer rows
+  // blurred twice (profiles/r05: 8 x 4K RGBA32 164 us at 6 rows, 155 at 8, 162 at 12; RGB24 173 at 8, 168 at 12, 167 at 16)
+  if ((long long)a.cgroups * cdiv((unsigned)height, (unsigned)a.th) * nframes > (long long)device_cus() * 8) a.th = psize == 4 ? 8 : 12;
   { const int v = tune(TUNE_GCK_TH); if (v >= 1 && v <= 1024) a.th = v; }      // tuning probe
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   // parameter preparation exactly as the script does it (host side, double)
@@ -225,13 +252,22 @@ extern "C" int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint
   const bool empty = rmin > 255 || gmin > 255 || bmin > 255 || rmax < 0 || gmax < 0 || bmax < 0 || rmin > rmax || gmin > gmax || bmin > bmax;
   const int c0min = is_bgr ? bmin : rmin, c0max = is_bgr ? bmax : rmax, c2min = is_bgr ? rmin : bmin, c2max = is_bgr ? rmax : bmax;
   if (!empty) {
-    a.mn_e = lo(c0min) | (lo(c2min) << 16); a.mx_e = (hi(c0max) | (hi(c2max) << 16)) | 0x80008000u;
-    a.mn_o = lo(gmin); a.mx_o = (hi(gmax) | (255u << 16)) | 0x80008000u;
+    a.mn_e = (0x8000u - lo(c0min)) | ((0x8000u - lo(c2min)) << 16); a.mx_e = (hi(c0max) | (hi(c2max) << 16)) | 0x80008000u;       // mn_*: 0x8000 - min per lane (the kernel ADDS it)
+    a.mn_o = (0x8000u - lo(gmin)) | (0x8000u << 16); a.mx_o = (hi(gmax) | (255u << 16)) | 0x80008000u;
   } else { a.mn_e = a.mx_e = a.mn_o = a.mx_o = 0; }
   a.opac = opac; a.opacx = 1. - opac; a.key = empty ? 0 : 1;
-  const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u));
-  if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(8u * cdiv((unsigned)(a.cgroups * a.bands), 8u), (unsigned)nframes);
+  if (psize == 4) hipLaunchKernelGGL(k_gauss5_colorkey<4>, grid, dim3(256), 0, stream, a, F);
+  else hipLaunchKernelGGL(k_gauss5_colorkey<3>, grid, dim3(256), 0, stream, a, F);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+
+extern "C" int lgpu_gauss5_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow, int width, int height, int psize,
+                                    int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  FxFrames F = {};
+  F.in0[0][0] = src0_d; F.in1[0][0] = src1_d; F.out[0][0] = dst_d;
+  return gauss5_colorkey_n(F, 1, irow0, irow1, orow, width, height, psize, is_bgr, delta, opac, col_r, col_g, col_b, (hipStream_t)stream);
 }

@@ -65,3 +65,24 @@ def test_unaligned_frames_are_refused(gpu):
     a = dev(np.zeros((8, 48), np.uint8))
     with pytest.raises(lib.LgpuError):
         gpu.gauss5_colorkey(a, a, dev(np.zeros((8, 48), np.uint8)), 10, 8, 4, 0, 0.3, 0.8, (1, 2, 3))      # width % 4 != 0
+
+
+@pytest.mark.parametrize("ps", [3, 4])
+def test_gauss5_colorkey_batch(gpu, orc, ps):
+    """config 4 for the frames of several tracks in ONE launch (lgpu_fx_batch, LGPU_FX_GAUSS5_COLORKEY): every frame against the oracle, slots shuffled"""
+    rng = np.random.default_rng(0xC40 + ps)
+    w, h, is_bgr, delta, opac, col = 504, 37, 1, 0.4, 0.7, (128, 120, 135)
+    rs = align(w * ps, 16)
+    for n in (1, 3, 16):
+        a = [rng.integers(64, 192, (h, rs), dtype=np.uint8) for _ in range(n)]
+        b = [rng.integers(0, 256, (h, rs), dtype=np.uint8) for _ in range(n)]
+        da, db = [dev(x) for x in a], [dev(x) for x in b]
+        outs = [dev(np.full((h + 1, rs), 0x5A, np.uint8)) for _ in range(n)]
+        order = list(rng.permutation(n))
+        gpu.fx_batch(gpu.FX_GAUSS5_COLORKEY, [[da[i]] for i in order], [[outs[i]] for i in order], w, h, ins1=[[db[i]] for i in order],
+                     ip=(ps, is_bgr, col[0] | (col[1] << 8) | (col[2] << 16)), dp=(delta, opac))
+        for f in range(n):
+            want = want_c4(orc, a[f], b[f], w, h, ps, is_bgr, delta, opac, col)
+            got = host(outs[f])
+            assert (got[:h, :w * ps] == want[:, :w * ps]).all(), "frame %d of %d" % (f, n)
+            assert (got[h] == 0x5A).all() and (got[:h, w * ps:] == 0x5A).all()

@@ -60,7 +60,8 @@ def case(op):
         ps = 3 if op == "c4rgb24" else 4
         a, b = rnd(H, W * ps), rnd(H, W * ps)
         o = [torch.zeros_like(t) for t in a]
-        return (lambda i: ops.gauss5_colorkey(a[i % NB], b[i % NB], o[i % NB], W, H, ps, 0, 0.3, 0.8, (128, 128, 128))), W * H * ps * 3
+        delta = float(os.environ.get("C4_DELTA", "0.3"))
+        return (lambda i: ops.gauss5_colorkey(a[i % NB], b[i % NB], o[i % NB], W, H, ps, 0, delta, 0.8, (128, 128, 128))), W * H * ps * 3
     if op.startswith("chain"):         # chainN: the headline chain on N tracks per launch
         n = int(op[5:] or 1)
         W, H = 3840, 2160
@@ -91,6 +92,13 @@ def case(op):
         if kind == "transition":
             a_, b_, o = frames(h, w * 4), frames(h, w * 4), frames(h, w * 4)
             return (lambda i: ops.fx_batch(ops.FX_TRANSITION, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], w, h, ins1=[[t] for t in b_[i % nb]], ip=(1, 4), dp=(0.5,))), n * w * h * 8
+        if kind in ("c4rgba", "c4rgb24"):
+            W, H, ps = 3840, 2160, (4 if kind == "c4rgba" else 3)
+            a_ = [[torch.randint(0, 256, (H, W * ps), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)] for _ in range(nb)]
+            b_ = [[torch.randint(0, 256, (H, W * ps), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)] for _ in range(nb)]
+            o = [[torch.zeros_like(t) for t in st_] for st_ in a_]
+            return (lambda i: ops.fx_batch(ops.FX_GAUSS5_COLORKEY, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], W, H, ins1=[[t] for t in b_[i % nb]],
+                                           ip=(ps, 0, 128 | (128 << 8) | (128 << 16)), dp=(0.3, 0.8))), n * W * H * ps * 3
         raise SystemExit("unknown fx batch " + op)
     if op.startswith("pb") and op[2:op.index(":")].isdigit():      # pbN:SWxSH:DWxDH:interp -- N frames of one geometry per launch (lgpu_pixbuf_scale_batch)
         head, a_, b_, it = op.split(":")
