@@ -423,6 +423,10 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const int y0 = band * A.th + min(band, A.rem), rows = A.th + (band < A.rem ? 1 : 0);
   const bool out_lane = lane >= kHalo && lane < 64 - kHalo && k <= kmax;
   const bool edge_strip = strip == 0 || (strip + 1) * kCols + kHalo >= kmax;        // wave-uniform: some lanes of this strip lie outside the frame
+  // BLUR: a band whose scaled rows (its own and the two above / below) keep clear of the frame's first and last row walks in straight-line code (further down).  There
+  // every source row index lies in [1, sh - 2], and the lanes outside the frame read the ONE pixel their neighbour wants from them where it lies -- the lane left of
+  // the frame gets P[0] as its fourth pixel (12 bytes before the row), the lane right of it P[sw - 1] as its first -- so no pixel has to be fixed up after it arrived
+  const bool fastp = BLUR && y0 - 2 >= 1 && y0 + rows + 1 <= A.dh - 2;
   uint32_t bf = A.bf;
   if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
   const uint32_t w_lo = bf | ((255u - bf) << 8);
@@ -437,15 +441,16 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const __amdgpu_buffer_rsrc_t r_src = srd(T.src[track], (uint32_t)A.sh * (uint32_t)A.irow);
   const __amdgpu_buffer_rsrc_t r_dst = srd(T.dst[track], (uint32_t)out_rows * (uint32_t)A.orow);
   const __amdgpu_buffer_rsrc_t r_l2 = srd(CHAIN ? (const void *)T.l2[track] : (const void *)T.src[track], CHAIN ? (uint32_t)out_rows * (uint32_t)A.irow2 : 16u);
-  const uint32_t lane_off = 16u * (uint32_t)kc;
+  const uint32_t lane_off = fastp ? (k < 0 ? 4u : k > kmax ? 16u * (uint32_t)(kmax + 1) + 12u : 16u * (uint32_t)(k + 1)) : 16u * (uint32_t)kc;
+  const int row_adj = __builtin_amdgcn_readfirstlane(fastp ? -16 : 0);      // fastp: the lane offsets are written against 16 bytes before the row
   auto load_row = [&](int sy) -> pb_u4 {
     sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);      // uniform by construction; said so, the row offset stays scalar
     // plain loads: measured faster than non-temporal ones (band seams and strip halos are re-read through L2)
-    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow, (PBH_LOAD_AUX));
+    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow + row_adj, (PBH_LOAD_AUX));
   };
   auto load_row_nt = [&](int sy) -> pb_u4 {      // probe (A.nt_in): a band's INNER rows are read once by this launch; the two pairs it shares with its neighbours stay in L2's normal policy
     sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
-    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow, 2);
+    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow + row_adj, 2);
   };
   // ALIGNED: the pixel left of the strip (lane 0) / right of it (lane 63), clamped into the row -- which is the library's edge rule at the frame's two ends
   const bool e_lane = HYPER && ALIGNED && (lane == 0 || lane == 63);
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   };
   // lanes outside the frame (edge strips only, a wave-uniform test) repeat the border pixel; applied when a row is consumed, so that no load is waited for early
   auto fix = [&](pb_u4 q) -> pb_u4 {
-    if (edge_strip) {
+    if (edge_strip && !fastp) {
       asm volatile("" ::: "memory");                            // keeps this a (wave-uniform) branch: as selects it costs every strip six operations per source row
       if (!ALIGNED && k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }           // left of the frame: pixel 0 repeated (only P[-1] is ever used)
       if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }       // right of the frame: the last pixel repeated
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   uint32_t e0 = load_e(S0), e1 = load_e(S0 + d), ea = load_e(S0 + 2 * d), eb = load_e(S0 + 3 * d);
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
-  if (CHAIN) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
+  if (CHAIN && !fastp) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
   if (CHAIN) {        // the two small tables, requested while the first source rows are in flight; first read an output row later
     reinterpret_cast<uint32_t *>(s_lut)[lane] = lut.w[lane];
 #pragma unroll
@@ -575,14 +580,95 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     return;
   }
 
+  // horizontal gaussian of one scaled row on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
+  auto hblur = [&](const uint32_t cc[2][3], const uint32_t al[2], uint32_t slot[4]) __attribute__((always_inline)) {
+    uint32_t e[6], o[6];
+    e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
+    e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
+    e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
+    e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
+    e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
+    if (edge_strip) {       // the gaussian replicates the frame's first / last column
+      if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
+      if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
+    }
+    slot[0] = gauss5_taps(e[0], e[1], e[2], e[3], e[4]); slot[1] = gauss5_taps(o[0], o[1], o[2], o[3], o[4]);
+    slot[2] = gauss5_taps(e[1], e[2], e[3], e[4], e[5]); slot[3] = gauss5_taps(o[1], o[2], o[3], o[4], o[5]);
+  };
+  // vertical gaussian over five ring rows (oldest first), blend with the layer-2 pixels, LUT, store
+  auto vblur_store = [&](int y, const uint32_t *r0, const uint32_t *r1, const uint32_t *r2, const uint32_t *r3, const uint32_t *r4, const pb_u2 &lp) __attribute__((always_inline)) {
+    uint32_t pxo[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
+      const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
+      // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
+      pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? lp.y : lp.x);
+    }
+    store_row(y, pxo[0], pxo[1]);
+  };
+  uint32_t ring[5][4];                     // horizontally blurred rows; [row][column * 2 + (0: bytes 0 and 2, 1: bytes 1 and 3)] in 16-bit lanes
+  const int nsteps = vr1 - vr0 + 1;
+
+  if (fastp) {
+    // Every step scales a NEW row; the two source rows of step s + 1 are requested during step s INTO the registers that held step s's rows, each as soon as its
+    // horizontal pass has read it (no second pair of row registers, no copies), the layer-2 pixels of a step's own output row at its top: each is read almost a step
+    // of arithmetic later, and no wait sits between a store and the next loads.  (The general loop below copies the new rows right behind the scaler and the
+    // layer-2 pixels behind the store: a step then waits for the loads it has just issued and for its own store -- profiles/r05/blur_investigation.md.)
+    uint32_t cc[2][3], al[2];
+    auto scale_refill = [&](int s, bool more) __attribute__((always_inline)) {
+      pb_half_hrow<HYPER, ALIGNED, SWAP>(qa, hr, 0u, e_m);
+      if (more) qa = load_row(S0 + d * (2 * s + 4));
+      pb_half_hrow<HYPER, ALIGNED, SWAP>(qb, hs, 0u, e_m);
+      if (more) qb = load_row(S0 + d * (2 * s + 5));
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
+        else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t va = v[4 * j + 3];
+        pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, cc[j]);
+        al[j] = (va >> A.ashift) << 24;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < 4; s++) {            // the four rows above (below) the band's first output row: no output yet (nsteps >= 5: a next step exists)
+      scale_refill(s, true);
+      hblur(cc, al, ring[s]);
+    }
+    constexpr int kSlot[5] = {4, 0, 1, 2, 3};          // ring slot of step 4 + u (= step % 5); the oldest of the five rows is the slot after it
+    int s0 = 4;
+    for (; s0 + 5 < nsteps; s0 += 5) {       // whole groups of five steps, each with a step behind it: no conditions inside
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int s = s0 + u, t = kSlot[u];
+        l2 = load_l2(vstart + d * (s - 2));                // this step's output row
+        scale_refill(s, true);
+        hblur(cc, al, ring[t]);
+        vblur_store(vstart + d * (s - 2), ring[(t + 1) % 5], ring[(t + 2) % 5], ring[(t + 3) % 5], ring[(t + 4) % 5], ring[t], l2);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; u++) {            // the last one to five steps
+      const int s = s0 + u, t = kSlot[u];
+      if (s >= nsteps) break;
+      l2 = load_l2(vstart + d * (s - 2));
+      scale_refill(s, s + 1 < nsteps);
+      hblur(cc, al, ring[t]);
+      vblur_store(vstart + d * (s - 2), ring[(t + 1) % 5], ring[(t + 2) % 5], ring[(t + 3) % 5], ring[(t + 4) % 5], ring[t], l2);
+    }
+    return;
+  }
+
   int produced = ystart - d;              // the last scaled row that exists
   uint32_t cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, al[2] = {0, 0};      // the current scaled row of this lane
-  uint32_t ring[5][4];                     // horizontally blurred rows, newest last; [row][column * 2 + (0: bytes 0 and 2, 1: bytes 1 and 3)] in 16-bit lanes
 #pragma unroll
   for (int i = 0; i < 5; i++) { ring[i][0] = 0; ring[i][1] = 0; ring[i][2] = 0; ring[i][3] = 0; }
-  const int nsteps = vr1 - vr0 + 1;
-  // the ring rotates by slot index, five steps per trip of the outer loop: slot u takes the new row, (u + 1) % 5 is the oldest -- no register moves (the rolled loop
-  // shifted the ring down every step: 16 moves per scaled row)
+  // the first and the last band of a frame: rows beyond the frame repeat the border row.  The ring rotates by slot index, five steps per trip of the outer loop:
+  // slot u takes the new row, (u + 1) % 5 is the oldest -- no register moves
   for (int step0 = 0; step0 < nsteps; step0 += 5) {
 #pragma unroll
     for (int u = 0; u < 5; u++) {
@@ -595,42 +681,18 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       if (yy != produced) {
         // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
         const int r = d > 0 ? yy - ystart : ystart - yy;
-        const pb_u4 na = load_row(S0 + d * (2 * r + 4)), nb = load_row(S0 + d * (2 * r + 5));
         if (CHAIN) nl2 = load_l2(vr - d);
         scale_row(qa, qb, 0u, 0u, cc, al);
-        qa = na; qb = nb;
+        qa = load_row(S0 + d * (2 * r + 4)); qb = load_row(S0 + d * (2 * r + 5));       // into the registers just read (these two bands per track are not where the time goes)
         produced = yy;
-        // horizontal pass on bytes in 16-bit lanes: e = (byte 0, byte 2), o = (byte 1, byte 3) of a pixel; columns 2k-2 .. 2k+3 around this lane's two
-        uint32_t e[6], o[6];
-        e[2] = cc[0][0] | (cc[0][2] << 16); o[2] = cc[0][1] | (al[0] >> 8); e[3] = cc[1][0] | (cc[1][2] << 16); o[3] = cc[1][1] | (al[1] >> 8);
-        e[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x138, 0xF, 0xF, true); o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x138, 0xF, 0xF, true);
-        e[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x138, 0xF, 0xF, true); o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x138, 0xF, 0xF, true);
-        e[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[2], 0x130, 0xF, 0xF, true); o[4] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[2], 0x130, 0xF, 0xF, true);
-        e[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)e[3], 0x130, 0xF, 0xF, true); o[5] = (uint32_t)__builtin_amdgcn_mov_dpp((int)o[3], 0x130, 0xF, 0xF, true);
-        if (edge_strip) {       // the gaussian replicates the frame's first / last column
-          if (k == 0) { e[0] = e[2]; e[1] = e[2]; o[0] = o[2]; o[1] = o[2]; }
-          if (k == kmax) { e[4] = e[3]; e[5] = e[3]; o[4] = o[3]; o[5] = o[3]; }
-        }
-        ring[u][0] = gauss5_taps(e[0], e[1], e[2], e[3], e[4]); ring[u][1] = gauss5_taps(o[0], o[1], o[2], o[3], o[4]);
-        ring[u][2] = gauss5_taps(e[1], e[2], e[3], e[4], e[5]); ring[u][3] = gauss5_taps(o[1], o[2], o[3], o[4], o[5]);
+        hblur(cc, al, ring[u]);
       } else {          // a row beyond the frame's first / last: the border row again
         if (CHAIN) nl2 = load_l2(vr - d);
 #pragma unroll
         for (int i = 0; i < 4; i++) ring[u][i] = ring[(u + 4) % 5][i];
       }
-      if (step >= 4) {                    // the ring holds the five rows around output row vr - 2 d: oldest (u + 1) % 5 ... newest u
-        const int y = vr - 2 * d;
-        const uint32_t *r0 = ring[(u + 1) % 5], *r1 = ring[(u + 2) % 5], *r2 = ring[(u + 3) % 5], *r3 = ring[(u + 4) % 5], *r4 = ring[u];
-        uint32_t pxo[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
-          const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
-          // the high byte of each 16-bit lane is the blurred value: ve -> (c0, c2), vo -> (c1, alpha)
-          pxo[j] = finish((ve >> 8) & 0xFF, (vo >> 8) & 0xFF, ve >> 24, vo & 0xFF000000u, j ? l2.y : l2.x);
-        }
-        store_row(y, pxo[0], pxo[1]);
-      }
+      if (step >= 4)                      // the ring holds the five rows around output row vr - 2 d: oldest (u + 1) % 5 ... newest u
+        vblur_store(vr - 2 * d, ring[(u + 1) % 5], ring[(u + 2) % 5], ring[(u + 3) % 5], ring[(u + 4) % 5], ring[u], l2);
       if (step >= 3) l2 = nl2;
     }
   }
