@@ -107,12 +107,74 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A_, const
   gk_u4 qn = load4(r_src0, A.irow0, ystart);
   gk_u4 b4 = {0, 0, 0, 0};      // the second frame's pixels of the current output row: taken over from `nb` at the end of every step (step 3 loads the first output row's)
   uint32_t ring[5][8];
+  // one output row from the five ring rows around it (oldest first), keyed against the second frame's pixels, stored
+  auto finish_row = [&](int y, const uint32_t *r0, const uint32_t *r1, const uint32_t *r2, const uint32_t *r3, const uint32_t *r4, const gk_u4 &bb) __attribute__((always_inline)) {
+    uint32_t px[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
+      const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
+      uint32_t a = __builtin_amdgcn_perm(vo, ve, 0x07030501u);         // the high byte of every 16-bit lane is the blurred value: (ve.1, vo.1, ve.3, vo.3) in one byte permute
+      if (A.key) {
+        // the box test on both 16-bit lanes at once: x >= min <=> bit 15 of x + (0x8000 - min), x <= max <=> bit 15 of (max | 0x8000) - x (the alpha lane's box is
+        // 0 .. 255); the constants come ready from the host, the adds / subtracts / ANDs are the vector unit's cheap class
+        const uint32_t e = a & 0x00FF00FFu, o = __builtin_amdgcn_perm(0u, a, 0x0C030C01u);
+        const uint32_t t = (e + A.mn_e) & (A.mx_e - e) & (o + A.mn_o) & (A.mx_o - o) & 0x80008000u;
+        if (t == 0x80008000u) {
+          // (uint8_t)(a * (1 - opac) + b * opac) in double, the products from the workgroup's two 256-entry tables: one f64 add and one conversion per byte
+          const uint32_t b = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;
+          const uint32_t m0 = (uint32_t)(uint8_t)(s_ta[a & 0xFF] + s_tb[b & 0xFF]);
+          const uint32_t m1 = (uint32_t)(uint8_t)(s_ta[(a >> 8) & 0xFF] + s_tb[(b >> 8) & 0xFF]);
+          const uint32_t m2 = (uint32_t)(uint8_t)(s_ta[(a >> 16) & 0xFF] + s_tb[(b >> 16) & 0xFF]);
+          a = m0 | (m1 << 8) | (m2 << 16) | (a & 0xFF000000u);
+        }
+      }
+      px[j] = a;
+    }
+    const int so = __builtin_amdgcn_readfirstlane(y * A.orow);
+    if (PS == 4) {
+      gk_u4 o4;
+      o4.x = px[0]; o4.y = px[1]; o4.z = px[2]; o4.w = px[3];
+      __builtin_amdgcn_raw_buffer_store_b128(o4, r_dst, (int)st_off, so, 2);       // not read again by this launch: non-temporal
+    } else {
+      typedef unsigned gk_v3 __attribute__((ext_vector_type(3)));
+      gk_v3 o3;
+      uint32_t w0, w1, w2;
+      pack3(px, w0, w1, w2);
+      o3.x = w0; o3.y = w1; o3.z = w2;
+      __builtin_amdgcn_raw_buffer_store_b96(o3, r_dst, (int)st_off, so, 0);
+    }
+  };
+  const int nsteps = vr1 - vr0 + 1;
+  if (vr0 >= 0 && vr1 <= A.height - 1) {
+    // Bands clear of the frame's first / last rows: every step blurs a NEW row, so the walk is straight-line code.  The next source row is requested INTO the
+    // registers of the row the horizontal pass has just read, the second frame's pixels of a step's output row at the top of that step; both are read most of a
+    // step later and no wait sits behind a store.  (The general loop below took the new row over at the top of the next step, behind the store: s_waitcnt vmcnt(0)
+    // there made every step wait for its own store and for the load it had just issued -- the same finding as in k_pb_half, profiles/r05/blur_investigation.md.)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      hrow(fix(qn), ring[s]);
+      qn = load4(r_src0, A.irow0, vstart + d * (s + 1));             // nsteps >= 5: the row exists
+    }
+    constexpr int kSlot[5] = {4, 0, 1, 2, 3};
+    for (int s0 = 4; s0 < nsteps; s0 += 5) {
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int s = s0 + u, t = kSlot[u];
+        if (s >= nsteps) break;
+        if (A.key) b4 = load4(r_src1, A.irow1, vstart + d * (s - 2));      // this step's output row
+        hrow(fix(qn), ring[t]);
+        if (s + 1 < nsteps) qn = load4(r_src0, A.irow0, vstart + d * (s + 1));
+        finish_row(vstart + d * (s - 2), ring[(t + 1) % 5], ring[(t + 2) % 5], ring[(t + 3) % 5], ring[(t + 4) % 5], ring[t], b4);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 5; i++)
 #pragma unroll
     for (int j = 0; j < 8; j++) ring[i][j] = 0;
   int produced = ystart - d;
-  const int nsteps = vr1 - vr0 + 1;
   // the ring rotates by slot index, five steps per trip of the outer loop: slot u takes the new row, (u + 1) % 5 is the oldest -- no register moves
   for (int step0 = 0; step0 < nsteps; step0 += 5) {
 #pragma unroll
@@ -132,47 +194,7 @@ __global__ __launch_bounds__(256) void k_gauss5_colorkey(const GckArgs A_, const
 #pragma unroll
         for (int j = 0; j < 8; j++) ring[u][j] = ring[(u + 4) % 5][j];   // a row beyond the frame: the border row again
       }
-      if (step >= 4) {
-        const int y = vr - 2 * d;
-        const uint32_t *r0 = ring[(u + 1) % 5], *r1 = ring[(u + 2) % 5], *r2 = ring[(u + 3) % 5], *r3 = ring[(u + 4) % 5], *r4 = ring[u];
-        uint32_t px[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t ve = gauss5_taps(r0[2 * j], r1[2 * j], r2[2 * j], r3[2 * j], r4[2 * j], 0x00800080u);
-          const uint32_t vo = gauss5_taps(r0[2 * j + 1], r1[2 * j + 1], r2[2 * j + 1], r3[2 * j + 1], r4[2 * j + 1], 0x00800080u);
-          uint32_t a = __builtin_amdgcn_perm(vo, ve, 0x07030501u);         // the high byte of every 16-bit lane is the blurred value: (ve.1, vo.1, ve.3, vo.3) in one byte permute
-          if (A.key) {
-            // the box test on both 16-bit lanes at once: x >= min <=> bit 15 of x + (0x8000 - min), x <= max <=> bit 15 of (max | 0x8000) - x (the alpha lane's box is
-            // 0 .. 255); the constants come ready from the host, the adds / subtracts / ANDs are the vector unit's cheap class
-            const uint32_t e = a & 0x00FF00FFu, o = __builtin_amdgcn_perm(0u, a, 0x0C030C01u);
-            const uint32_t t = (e + A.mn_e) & (A.mx_e - e) & (o + A.mn_o) & (A.mx_o - o) & 0x80008000u;
-            if (t == 0x80008000u) {
-              // (uint8_t)(a * (1 - opac) + b * opac) in double, the products from the workgroup's two 256-entry tables: one f64 add and one conversion per byte
-              const uint32_t b = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
-              const uint32_t m0 = (uint32_t)(uint8_t)(s_ta[a & 0xFF] + s_tb[b & 0xFF]);
-              const uint32_t m1 = (uint32_t)(uint8_t)(s_ta[(a >> 8) & 0xFF] + s_tb[(b >> 8) & 0xFF]);
-              const uint32_t m2 = (uint32_t)(uint8_t)(s_ta[(a >> 16) & 0xFF] + s_tb[(b >> 16) & 0xFF]);
-              a = m0 | (m1 << 8) | (m2 << 16) | (a & 0xFF000000u);
-            }
-          }
-          px[j] = a;
-        }
-        {
-          const int so = __builtin_amdgcn_readfirstlane(y * A.orow);
-          if (PS == 4) {
-            gk_u4 o4;
-            o4.x = px[0]; o4.y = px[1]; o4.z = px[2]; o4.w = px[3];
-            __builtin_amdgcn_raw_buffer_store_b128(o4, r_dst, (int)st_off, so, 2);       // not read again by this launch: non-temporal
-          } else {
-            typedef unsigned gk_v3 __attribute__((ext_vector_type(3)));
-            gk_v3 o3;
-            uint32_t w0, w1, w2;
-            pack3(px, w0, w1, w2);
-            o3.x = w0; o3.y = w1; o3.z = w2;
-            __builtin_amdgcn_raw_buffer_store_b96(o3, r_dst, (int)st_off, so, 0);
-          }
-        }
-      }
+      if (step >= 4) finish_row(vr - 2 * d, ring[(u + 1) % 5], ring[(u + 2) % 5], ring[(u + 3) % 5], ring[(u + 4) % 5], ring[u], b4);
       b4 = nb;                    // unconditionally: as a select on (step >= 3) it was four v_cndmask per step
     }
   }
@@ -192,7 +214,7 @@ int gauss5_rows(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int wi
   __builtin_memset(&a, 0, sizeof a);
   a.src0 = src_d; a.src1 = nullptr; a.dst = dst_d; a.irow0 = irow; a.irow1 = 0; a.orow = orow; a.width = width; a.height = height;
   a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
-  a.th = psize == 4 ? 6 : 8;
+  a.th = 8;
   { const int v = tune(TUNE_GCK_TH); if (v >= 1 && v <= 1024) a.th = v; }
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   a.key = 0;
@@ -228,10 +250,10 @@ int lgpu::gauss5_colorkey_n(const FxFrames &F, int nframes, int irow0, int irow1
   a.strips = (int)cdiv((unsigned)width, 248); a.cgroups = (a.strips + 3) / 4;
   // short bands: the launch is bound by the time a wave needs for its rows, not by the rows the bands share (profiles/r03/c4_band_sweep.txt: 4K RGBA32 27 us at 6 rows,
   // 28 at 8, 32 at 16, 45 at 32)
-  a.th = psize == 4 ? 6 : 8;
+  a.th = 8;            // one frame: 4,320 waves, one generation at five workgroups per CU (82 / 86 VGPRs); 6-row bands would need a second generation for their last 640
   // a launch of more than one generation of workgroups (several frames: lgpu_fx_batch) is no longer a matter of one wave's latency: taller bands, fewer rows
   // blurred twice (profiles/r05: 8 x 4K RGBA32 164 us at 6 rows, 155 at 8, 162 at 12; RGB24 173 at 8, 168 at 12, 167 at 16)
-  if ((long long)a.cgroups * cdiv((unsigned)height, (unsigned)a.th) * nframes > (long long)device_cus() * 8) a.th = psize == 4 ? 8 : 12;
+  if ((long long)a.cgroups * cdiv((unsigned)height, (unsigned)a.th) * nframes > (long long)device_cus() * 5) a.th = psize == 4 ? 8 : 12;
   { const int v = tune(TUNE_GCK_TH); if (v >= 1 && v <= 1024) a.th = v; }      // tuning probe
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   // parameter preparation exactly as the script does it (host side, double)
