@@ -432,8 +432,6 @@ def pixbuf_kernel_name(args):
     is the default (round 4); the last argument is SWAP (BGRA -> RGBA)"""
     from lives_amd.lib import load
     aligned = (not args.blur) and load().lgpu_tuning_get(b"PBH_ALIGNED") != 0        # the default since round 4; LGPU_PBH_ALIGNED=0 keeps the feeder-lane strips
-    if (not args.blur) and load().lgpu_tuning_get(b"PBH_LOADER") > 0:
-        return "lgpu::k_pb_half_ld<1, 1, %d, %d>" % (load().lgpu_tuning_get(b"PBH_LOADER") & 15, load().lgpu_tuning_get(b"PBH_LOADER") >> 4)
     return "lgpu::k_pb_half<1, 1, %d, %d, 1>" % (args.blur, 1 if aligned else 0)
 
 

@@ -1105,7 +1105,7 @@ static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height
   const int npairs = width >> 1;
   if (npairs == 0) return LGPU_OK;
   // aligned 4-byte pixels -> 4:2:0: the cell form
-  static const bool no_s420 = getenv("LGPU_RGB2YUV_NO_S") != nullptr;
+  const bool no_s420 = tune_on(TUNE_RGB2YUV_NO_S);
   if (out_fmt == 4 && ips == 4 && in_order <= 1 && !no_s420 && (width & 3) == 0 && height >= 2 &&
       (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 && (((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 3) == 0 &&
       (((uintptr_t)dst_d[1] | (uintptr_t)orow[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[2]) & 1) == 0) {
@@ -1188,7 +1188,7 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
   a.unclamped = which_tables & 1;
   a.tables = device_tables()->yuv2rgb[which_tables & 3];
   // UYVY / YUYV -> 4-byte pixels on aligned frames: the cell form
-  static const bool no_s = getenv("LGPU_UYVY_NO_S") != nullptr;
+  const bool no_s = tune_on(TUNE_UYVY_NO_S);
   if (in_fmt >= 2 && ops == 4 && !no_s && (width & 3) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 && (((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0) {
     const int ngr = width >> 2;
     const unsigned long long cells = (unsigned long long)ngr * height;
@@ -1465,7 +1465,7 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     LGPU_REQUIRE(dst_d[3], "null alpha plane");
     if ((rc = lgpu_fill(dst_d[3], 255, (size_t)orow[3] * height, stream))) return rc;                 // :7819
   }
-  static const bool no_s = getenv("LGPU_REPACK_NO_S") != nullptr;
+  const bool no_s = tune_on(TUNE_REPACK_NO_S);
   if (a.kind == lgpu::RK_420_TO_PK && !no_s && (width & 7) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 &&
       (((uintptr_t)src_d[1] | (uintptr_t)src_d[2] | (uintptr_t)irow[1] | (uintptr_t)irow[2]) & 3) == 0 &&        // dword loads on EVERY chroma row
       (((uintptr_t)dst_d[0] | (uintptr_t)((orow[0] / 4) * 4)) & 15) == 0 && (unsigned long long)(width >> 3) * height < (1ull << 31)) {

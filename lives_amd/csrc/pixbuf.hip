@@ -214,12 +214,11 @@ struct PbHalfArgs {
   uint32_t bf;
   const int32_t *bf_d;
   int strips, cgroups, bands, th, ntracks;     // cgroups = ceil(strips / 4): workgroups per band
-  int rem;                       // k_pb_half / k_pb_half_ld: the first `rem` bands are th + 1 rows tall, the others th (bands * th + rem == dh: band heights differ by one row at most)
+  int rem;                       // the first `rem` bands are th + 1 rows tall, the others th (bands * th + rem == dh: band heights differ by one row at most)
   int cw, ch, ox, oy;            // letterbox canvas (cw == 0: none): dst / layer 2 are cw x ch, the scaled frame sits at (ox, oy), the rest is opaque black under the blend
   int main_blocks, bar_blocks;   // workgroups of the frame proper / per track of the bars (1024 canvas pixels each)
   int bar_first;                 // the bars' workgroups come FIRST in the grid (a multiple of 8, so the frame's workgroups keep their XCD): they run while the frame's first loads are in flight
   int nt_out;
-  int nt_in;                     // probe (LGPU_PBH_NT_IN): non-temporal loads for a band's inner source rows
   int bgroup;                    // order 2: neighbouring bands per XCD turn (PBH_GROUP)
   int row_major;                 // work order (PBH_ORDER): 0 bands fastest, 1 column groups fastest, 2 that with the bands dealt round robin to the XCDs
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
@@ -229,11 +228,6 @@ struct PbTracks {
   const uint8_t *l2[LGPU_CHAIN_MAX_TRACKS];
   uint8_t *dst[LGPU_CHAIN_MAX_TRACKS];
 };
-#if defined(PBH_VARIANT) && (PBH_VARIANT & 1)
-#define PBH_LOAD_AUX 2          // timing probe: non-temporal source loads
-#else
-#define PBH_LOAD_AUX 0
-#endif
 typedef unsigned short pb_us2 __attribute__((ext_vector_type(2)));
 typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned pb_u2 __attribute__((ext_vector_type(2)));
@@ -292,13 +286,9 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     if (HYPER) {
-#if defined(PBH_VARIANT) && (PBH_VARIANT & 2)
-      const uint32_t bl = B[c] ^ 1u, ar = A[c] ^ 1u;       // timing probe only: no lane exchange
-#else
       // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1]);  wave_shl:1 -- the right lane's (P[4k+4], P[4k+5]);  lanes 0 / 63 keep xe (0 in strips with feeder lanes)
       const uint32_t bl = ALIGNED ? (uint32_t)__builtin_amdgcn_update_dpp((int)xe[c], (int)B[c], 0x138, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_mov_dpp((int)B[c], 0x138, 0xF, 0xF, true);
       const uint32_t ar = ALIGNED ? (uint32_t)__builtin_amdgcn_update_dpp((int)xe[c], (int)A[c], 0x130, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_mov_dpp((int)A[c], 0x130, 0xF, 0xF, true);
-#endif
       h[c] = pb_dot2(A[c], 0x00070007u, pb_add_hi_lo(bl, B[c]));          // P[4k-1] + 7 P[4k] + 7 P[4k+1] + P[4k+2]
       h[4 + c] = pb_dot2(B[c], 0x00070007u, pb_add_hi_lo(A[c], ar));      // P[4k+1] + 7 P[4k+2] + 7 P[4k+3] + P[4k+4]
     } else {
@@ -316,15 +306,8 @@ __global__ void k_pb_recip_check(uint32_t lo, uint32_t hi, unsigned long long *b
 }
 // V_c * fl(1 / V_alpha), truncated, for the three colours of one pixel
 __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t va, uint32_t c[3]) {
-#if defined(PBH_VARIANT) && (PBH_VARIANT & 4)
-  c[0] = (v0 >> 16) + (va & 1); c[1] = v1 >> 16; c[2] = v2 >> 16;       // timing probe only: no division
-#elif defined(PBH_VARIANT) && (PBH_VARIANT & 8)
-  const double ia = 1.0 / (double)va;                                    // timing probe only: the compiler's IEEE division
-  c[0] = (uint32_t)(int)((double)v0 * ia); c[1] = (uint32_t)(int)((double)v1 * ia); c[2] = (uint32_t)(int)((double)v2 * ia);
-#else
   const double ia = pb_recip(va);
   c[0] = (uint32_t)(int)((double)v0 * ia); c[1] = (uint32_t)(int)((double)v1 * ia); c[2] = (uint32_t)(int)((double)v2 * ia);
-#endif
 }
 
 // BLUR (chain only): BASELINE config 5's 5x5 gaussian ([1 4 6 4 1] / 16 per axis, edge replicate, one rounding: (sum + 128) >> 8) between the scaler and the
@@ -402,17 +385,12 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
         strip = (idx - bi * A.cgroups) * 4 + wave;
         spare = band >= A.bands;
       }
-    } else if (A.row_major) {                                      // column groups fastest: consecutive workgroups of an XCD read one band across the whole row (contiguous 15 KB per source row)
+    } else {                                      // column groups fastest: consecutive workgroups of an XCD read one band across the whole row (contiguous 15 KB per source row)
       const int per_track = A.cgroups * A.bands;
       track = seq / per_track;
       const int idx = seq - track * per_track;
       band = idx / A.cgroups;
       strip = (idx - band * A.cgroups) * 4 + wave;
-    } else {
-      const int cg = seq / A.bands;
-      band = seq - cg * A.bands;
-      track = cg / A.cgroups;
-      strip = (cg - track * A.cgroups) * 4 + wave;
     }
     spare = spare || strip >= A.strips;
   }
@@ -446,11 +424,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   auto load_row = [&](int sy) -> pb_u4 {
     sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);      // uniform by construction; said so, the row offset stays scalar
     // plain loads: measured faster than non-temporal ones (band seams and strip halos are re-read through L2)
-    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow + row_adj, (PBH_LOAD_AUX));
-  };
-  auto load_row_nt = [&](int sy) -> pb_u4 {      // probe (A.nt_in): a band's INNER rows are read once by this launch; the two pairs it shares with its neighbours stay in L2's normal policy
-    sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
-    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow + row_adj, 2);
+    return __builtin_amdgcn_raw_buffer_load_b128(r_src, (int)lane_off, sy * A.irow + row_adj, 0);
   };
   // ALIGNED: the pixel left of the strip (lane 0) / right of it (lane 63), clamped into the row -- which is the library's edge rule at the frame's two ends
   const bool e_lane = HYPER && ALIGNED && (lane == 0 || lane == 63);
@@ -562,8 +536,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     auto one = [&](int r, pb_u4 &ca, pb_u4 &cb, uint32_t &cea, uint32_t &ceb, pb_u2 &cl2, pb_u4 &xa, pb_u4 &xb, uint32_t &xea, uint32_t &xeb, pb_u2 &xl2) __attribute__((always_inline)) {
       const int yy = d > 0 ? ystart + r : ystart - r;
       if (r + 1 < rows) {       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
-        if (A.nt_in && r + 2 < rows) { xa = load_row_nt(S0 + d * (2 * r + 4)); xb = load_row_nt(S0 + d * (2 * r + 5)); }       // uniform
-        else { xa = load_row(S0 + d * (2 * r + 4)); xb = load_row(S0 + d * (2 * r + 5)); }
+        xa = load_row(S0 + d * (2 * r + 4)); xb = load_row(S0 + d * (2 * r + 5));
         xea = load_e(S0 + d * (2 * r + 4)); xeb = load_e(S0 + d * (2 * r + 5));
         if (CHAIN) xl2 = load_l2(yy + d);
       }
@@ -699,173 +672,6 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
 }
 
 // =====================================================================================================================================================
-// k_pb_half_ld -- the chain form of k_pb_half (no blur, no canvas) with the HBM stream taken out of the arithmetic waves: a workgroup is FOUR compute waves (the four
-// adjacent strips of a band, today's arithmetic unchanged) and ONE loader wave.  The loader requests every source row of the band ONCE, as one burst of four
-// back-to-back 1 KB requests (250 quads = 4000 contiguous bytes: what the four strips and their two feeder quads cover), straight into an LDS ring by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write); the compute waves read their 16 bytes per lane and row with ds_read_b128.  Why: the same bytes
-// stream 15 % faster when ONE wave asks for 4 KB of a row at a stretch than when four waves ask for 1 KB each at their own pace (profiles/r03/chain_sides.txt:
-// DRAM pages stay open), and the compute waves no longer queue behind their own loads; bands can be tall (the ring, not the register file, holds the rows in
-// flight), so the two seam rows a band shares with its neighbour weigh 2 / (2 th + 2) of the source traffic at th = 16 instead of th = 6.
-// Ring: NP slots of one ROW PAIR (2 x 4096 bytes).  One raw s_barrier per scaled row: B(p) says "pair p has landed" (the loader waited for it with a counted
-// vmcnt before arriving) and "pair p - 1 has been read" (the compute waves arrive after their ds_reads of it returned), so the loader refills slot (p - 1) % NP
-// right after B(p) with pair p - 1 + NP.
-// =====================================================================================================================================================
-#define PB_LD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-typedef const __attribute__((address_space(1))) void *pb_gptr;
-typedef __attribute__((address_space(3))) void *pb_lptr;
-template <int HYPER, int SWAP, int NP, int NT = 0>
-__global__ __launch_bounds__(320) void k_pb_half_ld(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
-  constexpr int kRowB = 4096;                                           // LDS pitch of a row segment (4000 bytes used)
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[NP * 2 * kRowB];
-  __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
-  __shared__ pb_u2 s_k[256];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0 .. 3 compute, 4 loader
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int nseq = A.cgroups * A.bands * A.ntracks, per_xcd = (nseq + 7) >> 3;
-  const int seq = xcd * per_xcd + slot;
-  if (seq >= nseq || slot >= per_xcd) return;                            // the whole workgroup
-  const int cg_ = seq / A.bands, band = seq - cg_ * A.bands, track = cg_ / A.cgroups, cg = cg_ - track * A.cgroups;
-  const int kmax = (A.sw >> 2) - 1;
-  const int y0 = band * A.th + min(band, A.rem), rows = A.th + (band < A.rem ? 1 : 0);
-  const int d = (band & 1) ? -1 : 1;
-  const int ystart = d > 0 ? y0 : y0 + rows - 1;
-  const int S0 = d > 0 ? 2 * y0 - 1 : 2 * (y0 + rows - 1) + 2;           // source rows are consumed in the order S0, S0 + d, ...: pair p = rows S0 + 2 p d, S0 + (2 p + 1) d
-  const int npairs = rows + 1;
-
-  if (wave == 4) {
-    // ---- loader: 8 requests per pair (2 rows x 4 rounds of 64 quads; the last round 58), rows and quads clamped into the frame (the compute waves re-select the
-    // border pixels as before)
-    const uint64_t a64 = (uint64_t)T.src[track];
-    const uint8_t *src = (const uint8_t *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a64));
-    const int q0 = cg * 248 - 1;
-    uint32_t off[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const int q = q0 + 64 * j + lane; off[j] = 16u * (uint32_t)(q < 0 ? 0 : q > kmax ? kmax : q); }
-    auto issue = [&](int p) __attribute__((always_inline)) {
-      uint8_t *sl = s_ring + (p % NP) * 2 * kRowB;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        int sy = S0 + d * (2 * p + h);
-        sy = __builtin_amdgcn_readfirstlane(sy < 0 ? 0 : sy > A.sh - 1 ? A.sh - 1 : sy);
-        const uint8_t *g = src + (size_t)sy * A.irow;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (j < 3 || lane < 58) {
-            // NT: a band's own rows are read once (non-temporal); its first and last pair are shared with the neighbouring bands and stay in L2's normal policy
-            if (NT && p > 0 && p < npairs - 1) __builtin_amdgcn_global_load_lds((pb_gptr)(g + off[j]), (pb_lptr)(sl + h * kRowB + j * 1024), 16, 0, 2);
-            else __builtin_amdgcn_global_load_lds((pb_gptr)(g + off[j]), (pb_lptr)(sl + h * kRowB + j * 1024), 16, 0, 0);
-          }
-      }
-    };
-    for (int p = 0; p < NP && p < npairs; p++) issue(p);
-    for (int p = 0; p < npairs; p++) {
-      // pairs requested after pair p at this point: up to NP - 2 (NP - 1 for p = 0; taken as NP - 2 as well), fewer at the band's end
-      const int after = min(NP - 2, npairs - 1 - p);
-      if (NP >= 4 && after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (NP >= 3 && after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PB_LD_BARRIER();                                                   // B(p)
-      if (p >= 1 && p - 1 + NP < npairs) issue(p - 1 + NP);
-    }
-    return;
-  }
-
-  // ---- compute waves
-  const int strip = cg * 4 + wave;
-  const bool active = strip < A.strips;                                  // wave-uniform; an idle wave still meets every barrier
-  const int k = strip * 62 - 1 + lane;
-  const int kc = k < 0 ? 0 : k > kmax ? kmax : k;
-  const bool out_lane = lane >= 1 && lane < 63 && k <= kmax && active;
-  const bool edge_strip = strip == 0 || (strip + 1) * 62 + 1 >= kmax;
-  uint32_t bf = A.bf;
-  if (A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
-  const uint32_t w_lo = bf | ((255u - bf) << 8);
-  auto srd = [](const void *p, uint32_t bytes) {
-    const uint64_t a = (uint64_t)p;
-    void *u = (void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
-    return __builtin_amdgcn_make_buffer_rsrc(u, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-  };
-  const __amdgpu_buffer_rsrc_t r_dst = srd(T.dst[track], (uint32_t)A.dh * (uint32_t)A.orow);
-  const __amdgpu_buffer_rsrc_t r_l2 = srd(T.l2[track], (uint32_t)A.dh * (uint32_t)A.irow2);
-  const uint32_t l2_off = 8u * (uint32_t)kc;
-  auto load_l2 = [&](int y) -> pb_u2 {
-    y = __builtin_amdgcn_readfirstlane(y < 0 ? 0 : y > A.dh - 1 ? A.dh - 1 : y);
-    return __builtin_amdgcn_raw_buffer_load_b64(r_l2, (int)l2_off, y * A.irow2, 2);
-  };
-  auto fix = [&](pb_u4 q) -> pb_u4 {
-    if (edge_strip) {
-      asm volatile("" ::: "memory");
-      if (k < 0) { q.y = q.x; q.z = q.x; q.w = q.x; }
-      if (k > kmax) { q.x = q.w; q.y = q.w; q.z = q.w; }
-    }
-    return q;
-  };
-  auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
-    const pb_u2 kk = s_k[q >> 24];
-    const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
-    const uint32_t pa = __umul24(c0, kk.y), pb = __umul24(c1, kk.y), pc = __umul24(c2, kk.y);
-    c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-    c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-    c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-    c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2];
-    return c0 | (c1 << 8) | (c2 << 16) | al;
-  };
-  const uint32_t st_off = out_lane ? 8u * (uint32_t)k : 0xFFFFFFF0u;
-  const uint8_t *ring_lane = s_ring + 16 * (wave * 62 + lane);
-  auto ring_row = [&](int p, int h) -> pb_u4 { return *reinterpret_cast<const pb_u4 *>(ring_lane + ((p % NP) * 2 + h) * kRowB); };
-
-  pb_u2 l2, nl2;
-  l2.x = 0; l2.y = 0; nl2 = l2;
-  if (active) l2 = load_l2(ystart);
-  reinterpret_cast<uint32_t *>(s_lut)[lane] = lut.w[lane];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint2 kk = A.kscale[lane + 64 * i];
-    pb_u2 kv; kv.x = kk.x; kv.y = kk.y;
-    s_k[lane + 64 * i] = kv;
-  }
-  uint32_t carry[8], hr[8], hs[8];
-  PB_LD_BARRIER();                                                       // B(0)
-  {
-    const pb_u4 q0 = ring_row(0, 0), q1 = ring_row(0, 1);
-    pb_half_hrow<HYPER, 0, SWAP>(fix(q0), hr);
-    pb_half_hrow<HYPER, 0, SWAP>(fix(q1), hs);
-#pragma unroll
-    for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
-  }
-  auto one = [&](int r, pb_u2 &cl2, pb_u2 &xl2) __attribute__((always_inline)) {
-    const int yy = d > 0 ? ystart + r : ystart - r;
-    if (active && r + 1 < rows) xl2 = load_l2(yy + d);
-    PB_LD_BARRIER();                                                     // B(r + 1)
-    if (!active) return;
-    const pb_u4 ra = ring_row(r + 1, 0), rb = ring_row(r + 1, 1);
-    pb_half_hrow<HYPER, 0, SWAP>(fix(ra), hr);
-    pb_half_hrow<HYPER, 0, SWAP>(fix(rb), hs);
-    uint32_t v[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
-      else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
-    }
-    uint32_t px[2];
-    const uint32_t lq[2] = {cl2.x, cl2.y};
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const uint32_t va = v[4 * j + 3];
-      uint32_t c[3];
-      pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, c);
-      px[j] = finish(c[0], c[1], c[2], (va >> A.ashift) << 24, lq[j]);
-    }
-    pb_u2 o;
-    o.x = px[0]; o.y = px[1];
-    __builtin_amdgcn_raw_buffer_store_b64(o, r_dst, (int)st_off, __builtin_amdgcn_readfirstlane(yy * A.orow), 2);
-  };
-  int r = 0;
-  for (; r + 1 < rows; r += 2) { one(r, l2, nl2); one(r + 1, nl2, l2); }
-  if (r < rows) one(r, l2, nl2);
-}
-
 // k_pb_half3 -- the same exact 2:1 reduction for 3-byte pixels (RGB24 / BGR24 / YUV888: a pixbuf WITHOUT alpha), standalone form only.  No alpha weighting:
 // P = the byte, colour = (scale * V + 0xffff) >> 16 inside the row, (255 * scale * V + 0xffffff) >> 24 on the columns whose taps leave it (the library's
 // per-pixel path: column 0 for HYPER, the last column for both).  A lane loads 12 bytes (4 pixels) per row and makes 2 output pixels; lanes pair up (DPP inside
@@ -1099,7 +905,6 @@ struct PbPairArgs {
   const uint32_t *pairs;               // device: [16 y phases][ny_eff][16 x phases][2 parities][4 nq]
   unsigned rnd;
   int tile_h, wpairs, win_h;
-  int no_quad;                         // tuning probe: stage pixel pairs one by one
 };
 
 // NPC: pairs per tap row when there are at most four (compile time: no work on the padding of the weight row), 0: any count, four at a time.
@@ -1115,7 +920,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~3;          // the window starts on a source pixel that is a multiple of 4: aligned pairs, 16-byte loads
   const int ys0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;
   // ---- the window: premultiplied pairs.  4-byte pixels whose window lies inside the row (uniform per workgroup) come four at a time, one 16-byte load -> two pairs
-  const bool inside = CH == 4 && !A.no_quad && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && (wx0 & 3) == 0 && ((uintptr_t)A.src & 15) == 0 && (A.irow & 15) == 0 && (A.wpairs & 1) == 0;
+  const bool inside = CH == 4 && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && (wx0 & 3) == 0 && ((uintptr_t)A.src & 15) == 0 && (A.irow & 15) == 0 && (A.wpairs & 1) == 0;
   if (inside) {
     const int wq = A.wpairs >> 1;                       // quads per window row
     for (int wy = wave; wy < A.win_h; wy += 4) {
@@ -1129,7 +934,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
         wr[2 * qd] = v0; wr[2 * qd + 1] = v1;
       }
     }
-  } else if (CH == 3 && !A.no_quad && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && 3 * (wx0 + 2 * A.wpairs) + 8 <= A.irow && ((uintptr_t)A.src & 3) == 0 && (A.irow & 3) == 0) {
+  } else if (CH == 3 && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && 3 * (wx0 + 2 * A.wpairs) + 8 <= A.irow && ((uintptr_t)A.src & 3) == 0 && (A.irow & 3) == 0) {
     // 3-byte pixels, window inside the row with a few spare bytes behind it: a pair's 6 bytes out of three aligned dwords (v_alignbyte) instead of six byte loads
     for (int wy = wave; wy < A.win_h; wy += 4) {
       const uint8_t *row = A.src + (size_t)pb_clamp(ys0 + wy, A.sh - 1) * A.irow;
@@ -1761,11 +1566,7 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
   a.nt_out = 1;
-  // non-temporal loads for a band's inner source rows: OFF unless LGPU_PBH_NT_IN / lgpu_tuning_set asks.  Mid-round they were on for 160-460 MiB of source per launch
-  // (profiles/r04/nt_inner_rows_by_tracks.txt: 6-10 tracks 11-13 % faster) -- measured on TWO rotating buffer sets, where the 256 MiB memory-side cache still held part
-  // of a set when its turn came again and streaming reads pushed less of it out.  On buffers that cache has long lost (four or more sets: a frame that was just uploaded)
-  // they cost 1-2 % at every track count (profiles/r04/nt_cold_ab.txt), and that is the case a host presents
-  a.nt_in = tune(TUNE_PBH_NT_IN) > 0 ? 1 : 0;
+  // (non-temporal loads for a band's inner source rows were measured and dropped: a gain only on buffers the memory-side cache still holds, profiles/r04/nt_cold_ab.txt)
   // Work order (PBH_ORDER; profiles/r04/order_ab.txt, interleaved on cold buffers).  0: a column group's bands one after the other, an XCD owning a contiguous run (rounds 3 / 4);
   // 1: the column groups of a band one after the other -- consecutive workgroups read a band across the whole row: 16 tracks 147.5 -> 142.3 us on one box, 152 -> 146 on another;
   // 2: that, with the bands of a track dealt round robin to the XCDs, so that the whole device sweeps ONE frame at a time like a linear stream does: 151-152 -> 144.2, 8 tracks
@@ -1789,20 +1590,6 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
   const dim3 grid((unsigned)(a.main_blocks + a.bar_first));
-  // the loader-wave form (k_pb_half_ld): full-device launches of the plain chain
-  if (!pr->do_blur && !cv && tune(TUNE_PBH_LOADER) > 0) {
-    const int np = tune(TUNE_PBH_LOADER) & 15, nt = tune(TUNE_PBH_LOADER) >> 4;          // ring depth in row pairs; + 16: non-temporal loads of a band's inner rows
-    a.aligned = 0;
-    a.strips = (int)cdiv((unsigned)a.dw, 124); a.cgroups = (a.strips + 3) / 4;
-    { const int v = tune(TUNE_PBH_TH); pb_half_bands(&a, (int)cdiv((unsigned)a.dh, v >= 1 && v <= 1024 ? (unsigned)v : 12u)); }
-    const dim3 g(pb_half_grid(a));
-#define PBH_LD(HY, SW) do { if (np == 3) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 3>), g, dim3(320), 0, st, a, T, l); else if (np >= 6) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 6>), g, dim3(320), 0, st, a, T, l); else if (nt) hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 4, 1>), g, dim3(320), 0, st, a, T, l); else hipLaunchKernelGGL((k_pb_half_ld<HY, SW, 4>), g, dim3(320), 0, st, a, T, l); } while (0)
-    if (a.hyper) { if (a.swap_rb) PBH_LD(1, 1); else PBH_LD(1, 0); }
-    else { if (a.swap_rb) PBH_LD(0, 1); else PBH_LD(0, 0); }
-#undef PBH_LD
-    LGPU_CHECK_LAUNCH();
-    return LGPU_OK;
-  }
   // Workgroups per CU (PBH_OCC): a launch of more than one generation runs FIVE workgroups per CU instead of the eight its registers allow -- unused dynamic LDS is what
   // holds the others back.  Fewer bands in flight = a narrower window of the frames being streamed at any moment (profiles/r04/occupancy_sweep.txt: 8 / 7 / 6 / 5 / 4 / 3
   // per CU 142.3 / 142.2 / 141.4 / 139.2 / 142.3 / 180 us per 16-track launch, 8 tracks 74.1 -> 72.8; with the gaussian 184 -> 187, so that chain keeps its six).
@@ -1980,7 +1767,6 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
     h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
     h.strips = (int)cdiv((unsigned)sw, 124); h.cgroups = (h.strips + 3) / 4;
     h.th = 3;                      // measured (1080p -> 4K): 16.5 us at 2-3 source rows per band, 18.2 us at 4, 22.8 at 8, 33.4 at 16, 52.7 at 32 -- per-wave latency, as in k_pb_half
-    { const int v = tune(TUNE_PBD_TH); if (v >= 1 && v <= 1024) h.th = v; }
     h.bands = (int)cdiv((unsigned)sh, (unsigned)h.th); h.ntracks = 1;
     hipLaunchKernelGGL(k_pb_double<0>, dim3(8u * cdiv((unsigned)(h.cgroups * h.bands), 8u), 1, (unsigned)n), dim3(256), 0, st, h, F);
     LGPU_CHECK_LAUNCH();
@@ -2004,7 +1790,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
     if ((long long)sh * irow < (1ll << 31) && (long long)dh * orow < (1ll << 31) &&        // 32-bit buffer offsets in k_pb_half (see pb_chain_half)
         pb_half_ok(t, interp, sw, sh, dw, dh, sbits | (uintptr_t)irow, dbits | (uintptr_t)orow, &h.hyper, &h.ashift)) {
       h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
-      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.nt_in = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 1; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
+      h.swap_rb = 0; h.blend = 0; h.irow2 = 0; h.use_lut = 0; h.bf = 0; h.bf_d = nullptr; h.nt_out = 0; h.row_major = tune(TUNE_PBH_ORDER) >= 0 && tune(TUNE_PBH_ORDER) <= 2 ? tune(TUNE_PBH_ORDER) : 1; h.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
       pb_half_geometry(&h, n);
       if (tune(TUNE_PBH_ORDER) < 0 && (long long)h.cgroups * h.bands * n > (long long)device_cus() * 8) h.row_major = 2;      // more than one generation: the chain's sweep order (pb_chain_half)
       if (h.bgroup <= 0) h.bgroup = (h.bands % 8 == 0) ? h.bands / 8 : 1;
@@ -2067,7 +1853,6 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
 
     pa.tile_h = 0;
     size_t lds_cap = 24 * 1024;                         // 6 workgroups per CU: the per-lane weight loads want occupancy more than the window wants rows (profiles/r03/pb_pairs_lds_sweep.txt)
-    { const int v = tune(TUNE_PB_LDS_KB); if (v >= 4 && v <= 64) lds_cap = (size_t)v * 1024; }      // tuning probe
     for (int th = 16; th >= 1; th >>= 1) {
       const int wh = (int)(((long long)(th - 1) * y_step + 65535) >> 16) + pa.ny_eff + 1;
       if ((size_t)pa.wpairs * wh * 16 <= lds_cap) { pa.tile_h = th; pa.win_h = wh; break; }
@@ -2077,7 +1862,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
 #define PB_PAIRS(CHN)                                                                                                     \
-      { const int ny = tune_on(TUNE_PB_NO_NY) ? 0 : t->ty1 - t->ty0; pa.no_quad = tune_on(TUNE_PB_NO_QUAD) ? 1 : 0;                                                                                   \
+      { const int ny = t->ty1 - t->ty0;                                                                                   \
         if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa, F);                       \
         else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa, F);                  \
         else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa, F);                  \

@@ -1755,7 +1755,7 @@ extern "C" int lgpu_h8s_set_opt(int opt) { g_h8s_opt = opt; return LGPU_OK; }   
 static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, int dw, int dh, int orow, int swap_rb, int blend,
                      int irow2, uint32_t bf, const int32_t *bf_d, int use_lut, const SepTracks &t, int ntracks, const Lut8 &l,
                      hipStream_t st, int nt_out = 1) {
-  static const bool disabled = getenv("LGPU_DISABLE_HALF8") != nullptr;
+  const bool disabled = tune_on(TUNE_DISABLE_HALF8);
   if (disabled || !hb->uniform2 || !vb->uniform2) return LGPU_E_UNSUPPORTED;
   if ((irow & 3) || (orow & 3)) return LGPU_E_UNSUPPORTED;
   {   // operand ranges of the int8 / int16 forms used by the kernel
@@ -1814,7 +1814,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
     hipLaunchKernelGGL((k_half8s<DBG_, ABL_>), dim3((unsigned)grid), dim3(kH8sThreads), lds, st, a, t, l);              \
   } while (0)
 #ifdef LGPU_PROFILING
-  static const bool dbg_s = getenv("LGPU_H8S_DEBUG") != nullptr;
+  const bool dbg_s = tune_on(TUNE_PLAN_DEBUG);
   if (dbg_s) {     // in-kernel phase profile: s_memtime ticks between fixed points of the tile loop, per wave
     static unsigned long long *g_dbg_s = nullptr;
     constexpr int nw = kH8sCW + 2;
@@ -1896,7 +1896,7 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
   p->variant = (a.nth == 8 && a.ntv == 8) ? 1 : (a.nth == 5 && a.ntv == 5) ? 2 : (a.nth == 4 && a.ntv == 4) ? 3 :
                (a.nth == 2 && a.ntv == 2) ? 4 : (a.nth == 6 && a.ntv == 6) ? 5 : 0;
   // k_sep2 (dot2 on both passes): tap pair counts with an instantiation, windows that leave two workgroups per CU
-  static const bool no_sep2 = getenv("LGPU_NO_SEP2") != nullptr;
+  const bool no_sep2 = tune_on(TUNE_NO_SEP2);
   const int nph = hb->nph;
   if (!no_sep2 && (nph == 1 || nph == 2 || nph == 3 || nph == 4 || nph == 5 || nph == 6 || nph == 7 || nph == 8 || nph == 10 || nph == 12) && vb->nt <= 64) {
     SepArgs b = a;
@@ -1959,7 +1959,7 @@ static int plan_sep(const Bank *hb, const Bank *vb, int sw, int sh, int irow, in
       }
     }
     // k_sep2p: two window slots + double-buffered tables must leave two workgroups per CU; a window is at most kS2pMaxReq DMA requests
-    static const int th_force = getenv("LGPU_SEP2P_TH") ? atoi(getenv("LGPU_SEP2P_TH")) : 0;
+    const int th_force = tune(TUNE_SEP2P_TH) > 0 ? tune(TUNE_SEP2P_TH) : 0;
     if (pers_ok) {
       for (int th2 = th_force ? th_force : dh > sh ? 32 : 16; th2 >= 1; th2 >>= 1) {
         const int sht2 = window_rows(th2);
@@ -2049,7 +2049,7 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
         if (gcd(w - k, ap.tiles_x) <= 2) { w -= k; break; }
       g = w << 3;
     }
-    static const bool s2p_dbg = getenv("LGPU_S2P_DEBUG") != nullptr;
+    const bool s2p_dbg = tune_on(TUNE_PLAN_DEBUG);
     ap.dbg = nullptr;
     const int nwv = (p.mh_r ? kS2pMhCW : 4) + 2;
     if (s2p_dbg) { LGPU_HIP(hipMalloc((void **)&ap.dbg, (size_t)g * nwv * 8 * 8)); LGPU_HIP(hipMemsetAsync(ap.dbg, 0, (size_t)g * nwv * 8 * 8, st)); }
@@ -2147,7 +2147,7 @@ static int get_scratch(size_t bytes, hipStream_t st, void **out) {
 // asks for the generic separable kernel, for A/B runs)
 static int try_gauss5x(int w, int h, int irow, int orow, int blend, int irow2, uint32_t bf, const int32_t *bf_d, int use_lut,
                        const SepTracks &t, int ntracks, const Lut8 &l, hipStream_t st) {
-  static const bool classic = getenv("LGPU_G5_CLASSIC") != nullptr;
+  const bool classic = tune_on(TUNE_G5_CLASSIC);
   if (classic) return LGPU_E_UNSUPPORTED;
   if (irow & 7) return LGPU_E_UNSUPPORTED;
   for (int i = 0; i < ntracks; i++)
@@ -2161,7 +2161,7 @@ static int try_gauss5x(int w, int h, int irow, int orow, int blend, int irow2, u
   a.tiles_x = (w + kG5W - 1) / kG5W;
   const int tiles_y = (h + kG5H * kG5Sub - 1) / (kG5H * kG5Sub);
   const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)ntracks);
-  static const bool mfma_h = getenv("LGPU_G5_MFMA") != nullptr;       // measurement variant, see k_gauss5x
+  const bool mfma_h = tune_on(TUNE_G5_MFMA);       // the matrix-core form of the horizontal pass (north_star names it; measured slower: profiles/r02/gauss5_mfma.md), LGPU_G5_MFMA / lgpu_tuning_set
   if (mfma_h) {
     if (blend || use_lut) hipLaunchKernelGGL((k_gauss5x<true, true>), grid, dim3(256), 0, st, a, t, l);
     else hipLaunchKernelGGL((k_gauss5x<false, true>), grid, dim3(256), 0, st, a, t, l);
@@ -2237,7 +2237,7 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
   hipStream_t st = (hipStream_t)stream;
   const Lut8 l = pack_lut(nullptr);
   // aligned 3- / 4-byte frames: the register-pipelined row walk of fused.hip (the same arithmetic; profiles/r03/ops_roofline.md)
-  static const bool no_rows = getenv("LGPU_GAUSS5_NO_ROWS") != nullptr;
+  const bool no_rows = tune_on(TUNE_GAUSS5_NO_ROWS);
   if (!no_rows && (psize == 3 || psize == 4)) {
     rc = lgpu::gauss5_rows(src_d, irow, dst_d, orow, width, height, psize, st);
     if (rc != LGPU_E_UNSUPPORTED) return rc;

@@ -128,10 +128,11 @@ def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur, interp):
         assert torch.equal(dst2[t], dst_d[perm[t]])
 
 
-@pytest.mark.parametrize("shape", ["aligned", "th8", "bands_fastest", "xcd_runs", "bands_one_by_one", "groups_of_5", "eight_per_cu", "loader3", "loader4", "loader6", "loader4_th5"])
+@pytest.mark.parametrize("shape", ["feeder_lanes", "th8", "xcd_runs", "bands_one_by_one", "groups_of_5", "eight_per_cu"])
 def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
-    """the same 16-track launch in the shapes the switches select (64-lane strips, another band height, the loader-wave form k_pb_half_ld with rings of 3 / 4 / 6 row pairs and a band height that leaves a short last band): same bytes as the default shape,
-    which test_c5_sixteen_track_4k_chain compares with the oracle -- and track 0 against the oracle here as well"""
+    """the same 16-track launch in the shapes that ship behind the launch-shape switches (strips with feeder lanes instead of 64 storing lanes, another band height, the
+    contiguous-run work order the blur chain keeps, other band groupings, eight workgroups per CU): every shape must give the bytes of the default shape, which
+    test_c5_sixteen_track_4k_chain compares with the oracle -- and track 0 against the oracle here as well"""
     import torch
     rng = np.random.default_rng(4015)
     sw, sh, dw, dh, T = 3840, 2160, 1920, 1080, 16
@@ -140,24 +141,18 @@ def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
     prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=31, lut=lut)
     ref = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
     gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, ref))
-    if shape == "aligned":
-        tune("PBH_ALIGNED", 1)
+    if shape == "feeder_lanes":
+        tune("PBH_ALIGNED", 0)
     elif shape == "th8":
         tune("PBH_TH", 8)
-    elif shape == "bands_fastest":      # the work order of rounds 3 / 4 (the default now deals a track's bands round robin to the XCDs, column groups fastest)
-        tune("PBH_ORDER", 0)
     elif shape == "xcd_runs":           # column groups fastest, every XCD a contiguous run of the sequence (what the blur chain keeps)
         tune("PBH_ORDER", 1)
     elif shape == "bands_one_by_one":   # all XCDs on one track, the bands dealt one by one instead of by eighths
         tune("PBH_GROUP", 1)
     elif shape == "groups_of_5":        # a group size that leaves some XCDs a turn short (216 bands = 44 groups: the padding slots of the grid must stay idle)
         tune("PBH_GROUP", 5)
-    elif shape == "eight_per_cu":       # no dynamic-LDS cap on the workgroups per CU
+    else:                               # eight_per_cu: no dynamic-LDS cap on the workgroups per CU
         tune("PBH_OCC", 0)
-    else:
-        tune("PBH_LOADER", int(shape[6]))
-        if shape.endswith("th5"):
-            tune("PBH_TH", 5)
     got = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
     gpu.chain(prm, gpu.chain_tracks(src_d, l2_d, got))
     for t in range(T):

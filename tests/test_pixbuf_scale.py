@@ -298,18 +298,17 @@ def test_compositor_flow_scales_its_layers_as_the_reference_does(gpu, orc, psize
 
 
 @gpu_mark
-@pytest.mark.parametrize("strips64", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("strips64", [0, 1, 2, 3])
 def test_chain_on_the_pixbuf_arithmetic(gpu, orc, tune, strips64):
     """(both strip forms of k_pb_half: 62 storing lanes + 2 feeder lanes, and 64 storing lanes with the two outer taps from an extra load -- what full-device launches take)
     lgpu_chain with LGPU_INTERP_PIXBUF: convert -> gdk-pixbuf scale (4 channels, alpha-weighted) -> chroma blend -> gamma LUT == the oracle's composition
     of the pinned single stages.  The exact aligned 2:1 cases take the one-launch kernel k_pb_half (HYPER and BILINEAR, several tracks, strips that end
     inside the frame, bands of every height); the others the staged path (other ratios, the blur stage, unaligned rowstrides)."""
-    if strips64 == 2:           # the loader-wave form (k_pb_half_ld) on every plain 2:1 case, bands of 3 rows
-        tune("PBH_LOADER", 4)
+    if strips64 == 2:           # bands of 3 rows
         tune("PBH_TH", 3)
-    elif strips64 >= 3:         # 64-lane strips in the other work orders (3: bands fastest, 4: column groups fastest in contiguous runs per XCD; the default deals bands round robin)
+    elif strips64 == 3:         # 64-lane strips, column groups fastest in contiguous runs per XCD (the default for launches of several generations deals bands round robin)
         tune("PBH_ALIGNED", 1)
-        tune("PBH_ORDER", strips64 - 3)
+        tune("PBH_ORDER", 1)
     else:
         tune("PBH_ALIGNED", strips64)
     PIXBUF = 0x100

@@ -56,9 +56,7 @@ def main():
             continue
         counts[kind] = counts.get(kind, 0) + 1
         ops.tuning("PBH_ALIGNED", 1 if rng.random() < 0.5 else 0)          # both strip forms of k_pb_half at every size
-        ops.tuning("PBH_LOADER", int(rng.choice([0, 0, 3, 4, 6, 20])))      # the loader-wave form, rings of 3 / 4 / 6 row pairs, non-temporal inner rows
-        ops.tuning("PBH_NT_IN", int(rng.choice([0, 1])))                    # non-temporal inner rows in the register form
-        ops.tuning("PBH_ORDER", int(rng.choice([0, 1, 2])))                 # the three work orders of k_pb_half
+        ops.tuning("PBH_ORDER", int(rng.choice([1, 2])))                    # the two work orders of k_pb_half
         ops.tuning("PBH_GROUP", int(rng.choice([1, 2, 3, 5, 8])) if rng.random() < 0.5 else None)      # bands an XCD takes per turn (None: an eighth of the track's when that is whole)
         ops.tuning("PBH_OCC", int(rng.choice([0, 2, 5])) if rng.random() < 0.3 else None)               # workgroups per CU
         ops.tuning("PBH_TH", int(rng.choice([1, 2, 3, 5, 6, 7, 12, 24])) if rng.random() < 0.5 else None)       # forced band heights

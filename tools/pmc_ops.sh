@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: counters of the single-frame kernels the review lists (softlight, edge, YUV411 -> RGBA, YUVA premultiply, composite, K2, C3, C4 RGB24) and of the gdk-pixbuf ratios off 2:1
+# counters of the single-frame kernels (softlight, edge, YUV411 -> RGBA, YUVA premultiply, composite, K2, C3, C4) and of the gdk-pixbuf ratios off 2:1: tools/pmc_ops.sh <case> ...
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04/pmc
 run() { name=$1; pat=$2; shift 2; bash tools/pmc_case.sh gpurun_out/r04/pmc/$name "$pat" python tools/prof_one.py "$@" > gpurun_out/r04/pmc_$name.md 2>&1; rm -rf gpurun_out/r04/pmc/$name; }

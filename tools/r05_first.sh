@@ -12,7 +12,7 @@ python tools/pmc_summary.py gpurun_out/r05/pmc_blur16 k_pb_half > $O/pmc_pb_half
 tools/pmc.sh gpurun_out/r05/pmc_blur8 --blur 1 --tracks 8 > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/r05/pmc_blur8 k_pb_half > $O/pmc_pb_half_blur_8tracks.md
 mkdir -p gpurun_out/r04/pmc
-bash tools/pmc_r04.sh c4rgb24 pb3 pb1 composite
+bash tools/pmc_ops.sh c4rgb24 pb3 pb1 composite
 bash tools/pmc_case.sh gpurun_out/r05/pmc_c4rgba k_gauss5_colorkey python tools/prof_one.py c4rgba > $O/pmc_c4rgba.md 2>&1
 cp gpurun_out/r04/pmc_c4rgb24.md gpurun_out/r04/pmc_pb_4k_to_1706x960.md gpurun_out/r04/pmc_pb_1080p_to_720p.md gpurun_out/r04/pmc_composite.md $O/ 2>/dev/null
 bash tools/cold_ops.sh > $O/op_timings.txt 2>/dev/null
