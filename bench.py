@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU)
     ap.add_argument("--blur", type=int, default=0, help="1: add the 5x5 gaussian stage (BASELINE config 5 chain)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--config5", action="store_true", help="N = 1 without a launcher: run the one-frame-per-step legs (config5_*) as well; launched jobs always do")
     ap.add_argument("--launch-streams", type=int, default=1, choices=[1, 2],
                     help="2: consecutive steps alternate between two launch streams (independent buffer sets; needs an even --sets): 4-6 %% more frames/s, "
                          "but a profiler then sees pairs of overlapping launches of about twice the duration each")
@@ -233,7 +234,10 @@ def main():
     prm_blur = prm if args.blur else ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3 | (0x100 if args.resize_backend == "pixbuf" else 0), do_blur=1, bf=128, lut=lut,
                                                       param_block=pblock)
     config5 = None
-    if stepper is not None or not multi:      # every rank count: at N = 1 the same C step without a communicator (nothing to exchange: the blocks are written on the launch stream)
+    # every rank count of a launched job (the driver's scaling run starts N = 1 under torch.distributed.run as well): at N = 1 the same C step without a communicator.
+    # NOT in the plain `python bench.py`: its ~2,000 one-frame launches carry the 16-track launch's kernel name and would drag the average rocprofv3 --stats prints for it
+    # away from roofline.launch_us (`--config5` asks for the leg there)
+    if stepper is not None or (not multi and (args.config5 or "WORLD_SIZE" in os.environ)):
         if stepper is not None:
             stepper.close()
         stepper = None
