@@ -586,6 +586,7 @@ struct TransArgs {
   int irow1, irow2, orow, width, height, wb, type;
   int xx, yy, ihwidth, ihheight;          // type 0: rectangle insets (bytes, rows); type 2: quadrant shifts (bytes of rows, bytes)
   float bf, hwidth, hheight, maxradsq;
+  float uthr;                             // type 1: the largest float u with sqrt((double)(u / maxradsq)) <= bf (host, bisection over the floats): the test is u > uthr
 };
 template <int PS>
 __global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFrames F) {
@@ -600,8 +601,10 @@ __global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFram
     } else if (a.type == 1) {
       // sqrt((xxf * xxf + yyf * yyf) / maxradsq) > bf: float terms, double square root (:185-187)
       const float xxf = (float)(i - a.ihheight), yyf = __fdiv_rn((float)(j - a.ihwidth), (float)PS);
-      const float v = __fdiv_rn(__fadd_rn(__fmul_rn(xxf, xxf), __fmul_rn(yyf, yyf)), a.maxradsq);
-      from = (__dsqrt_rn((double)v) > (double)a.bf) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
+      // the float division by maxradsq and the double square root are monotone in u = xxf^2 + yyf^2, so "sqrt(u / maxradsq) > bf" is "u > uthr" for the one float
+      // uthr the host finds with the same IEEE operations (exact: every float u falls on the same side); a division and a square root per pixel less
+      const float u = __fadd_rn(__fmul_rn(xxf, xxf), __fmul_rn(yyf, yyf));
+      from = (u > a.uthr) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
     } else {
       const bool cross = __fdiv_rn(fabsf(__fsub_rn((float)i, a.hheight)), a.hheight) < a.bf ||
                          __fdiv_rn(fabsf(__fsub_rn((float)j, a.hwidth)), a.hwidth) < a.bf || a.bf == 1.f;
@@ -715,6 +718,17 @@ int lgpu::transition_n(const FxFrames &F, int nframes, int type, int irow1, int 
   hwidth = (float)a.wb * 0.5f;
   a.hwidth = hwidth; a.hheight = hheight; a.ihwidth = a.wb >> 1; a.ihheight = height >> 1;
   a.bf = (float)amount;
+  a.uthr = 0.f;
+  if (type == 1) {
+    auto pred = [&](uint32_t bits) { float u; __builtin_memcpy(&u, &bits, 4); const volatile float q = u / a.maxradsq; return sqrt((double)q) > (double)a.bf; };
+    if (pred(0u)) a.uthr = -1.f;                                   // true for every u >= 0
+    else {
+      uint32_t lo = 0u, hi = 0x7F7FFFFFu;                          // pred(lo) false; the largest finite float
+      if (!pred(hi)) lo = hi;
+      else while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (pred(mid)) hi = mid; else lo = mid; }
+      __builtin_memcpy(&a.uthr, &lo, 4);
+    }
+  }
   const float bfneg = 1.f - a.bf;
   a.xx = a.yy = 0;
   if (type == 0) { a.xx = (int)((int)hwidth * bfneg + .5); a.yy = (int)((int)hheight * bfneg + .5); }
