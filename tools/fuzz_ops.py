@@ -51,7 +51,7 @@ def main():
     bad = 0
     counts = {}
     for it in range(iters):
-        kind = str(rng.choice(["resize", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411", "pixbuf", "pixbuf", "chainpb", "chainpb", "canvas", "c4"]))
+        kind = str(rng.choice(["resize", "pbbatch", "fxbatch", "chain", "gauss5", "swizzle", "k2", "repack", "deint", "letterbox", "edge", "softlight", "blend", "mirror", "rgb2yuv", "yuv2rgb", "transition", "premult", "premultyuva", "yuv411", "rgb411", "luma", "multi", "colorkey", "gamma", "bytelut", "slide", "tsplit", "repack411", "pixbuf", "pixbuf", "chainpb", "chainpb", "canvas", "c4"]))
         if only and kind not in only:
             continue
         counts[kind] = counts.get(kind, 0) + 1
@@ -445,6 +445,42 @@ def main():
                 d = d1 if inplace else dev(np.full_like(s1, 0x5A))
                 ops.transition(t, d1, dev(s2), d, w, h, ps, amt)
                 ok = same(host(d), want, w * ps, h, "transition %d ps=%d %dx%d amount=%r inplace=%d" % (t, ps, w, h, amt, inplace))
+            elif kind == "pbbatch":
+                # lgpu_pixbuf_scale_batch: 1 .. 6 frames of one random geometry in one launch, every frame against the oracle
+                ch, interp, n = int(rng.choice([3, 4])), int(rng.choice([0, 2, 3])), int(rng.integers(1, 7))
+                sw, sh, dw, dh = int(rng.integers(1, 300)), int(rng.integers(1, 160)), int(rng.integers(1, 400)), int(rng.integers(1, 200))
+                if rng.random() < 0.3:
+                    dw, dh = max(1, sw // 2), max(1, sh // 2)
+                    sw, sh = 2 * dw, 2 * dh
+                irow, orow = (sw * ch + 15) // 16 * 16, (dw * ch + 15) // 16 * 16
+                srcs = [rng.integers(0, 256, (sh, irow), dtype=np.uint8) for _ in range(n)]
+                wants, skip = [], False
+                for s_ in srcs:
+                    w_ = np.zeros((dh, dw * ch), np.uint8)
+                    if orc.orc_pixbuf_scale(P(s_), irow, sw, sh, P(w_), dw * ch, dw, dh, ch, interp) != 0:
+                        skip = True
+                    wants.append(w_)
+                ok = True
+                if not skip:
+                    dd = [dev(np.full((dh, orow), 0x5A, np.uint8)) for _ in range(n)]
+                    ops.pixbuf_scale_batch([dev(s_) for s_ in srcs], dd, sw, sh, dw, dh, channels=ch, interp=interp)
+                    for f in range(n):
+                        ok = ok and same(host(dd[f]), wants[f], dw * ch, dh, "pbbatch frame %d of %d: %dch interp %d %dx%d->%dx%d" % (f, n, ch, interp, sw, sh, dw, dh))
+            elif kind == "fxbatch":
+                # lgpu_fx_batch, transitions: 1 .. 6 frames in one launch against the oracle
+                t, ps, n = int(rng.integers(0, 3)), int(rng.choice([3, 4])), int(rng.integers(1, 7))
+                w, h = int(rng.integers(2, 300)), int(rng.integers(2, 120))
+                amt = float(rng.choice([0., 1., float(rng.random())]))
+                stride = (w * ps + 15) // 16 * 16
+                s1 = [rng.integers(0, 256, (h, stride), dtype=np.uint8) for _ in range(n)]
+                s2 = [rng.integers(0, 256, (h, stride), dtype=np.uint8) for _ in range(n)]
+                dd = [dev(np.full((h, stride), 0x5A, np.uint8)) for _ in range(n)]
+                ops.fx_batch(ops.FX_TRANSITION, [[dev(a)] for a in s1], [[d_] for d_ in dd], w, h, ins1=[[dev(a)] for a in s2], ip=(t, ps), dp=(amt,))
+                ok = True
+                for f in range(n):
+                    want = np.full((h, stride), 0x5A, np.uint8)
+                    orc.orc_transition(t, P(s1[f]), stride, P(s2[f]), stride, P(want), stride, w, h, ps, amt)
+                    ok = ok and same(host(dd[f]), want, w * ps, h, "fxbatch transition %d ps=%d %dx%d amount=%r frame %d of %d" % (t, ps, w, h, amt, f, n))
             elif kind == "premult":
                 w, h = int(rng.integers(1, 300)), int(rng.integers(1, 100))
                 af, un = int(rng.integers(0, 2)), int(rng.integers(0, 2))
