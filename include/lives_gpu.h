@@ -479,7 +479,7 @@ int lgpu_stepper_destroy(lgpu_stepper *s);
    src/effects-weed.c:1850-2425).  The frames share geometry, rowstrides and parameters; only the planes differ.  Results are those of nframes single calls, bit
    for bit.  ops and their fields (everything else ignored):
      LGPU_FX_SOFTLIGHT      in0 / out: the 3 (4: YUVA4444P) planes; irow0[], orow[], width, height, palette; ip[0] = unclamped          (lgpu_softlight)
-     LGPU_FX_TRANSITION     in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = type, ip[1] = psize, dp[0] = amount   (lgpu_transition)
+     LGPU_FX_TRANSITION     in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = type, ip[1] = psize, dp[0] = amount, or frame_dp0[f] = the amount of frame f   (lgpu_transition)
      LGPU_FX_YUV411_TO_RGB  in0[0], out[0]; width = macropixels, height, orow[0]; ip[0] = out_order, ip[1] = out_alpha, ip[2] = unclamped      (lgpu_yuv411_to_rgb)
      LGPU_FX_GAUSS5_COLORKEY in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = psize, ip[1] = is_bgr, ip[2] = key colour r | g << 8 | b << 16,
                             dp[0] = delta, dp[1] = opacity  (lgpu_gauss5_colorkey: BASELINE config 4 in one launch; LGPU_E_UNSUPPORTED outside its alignment range)
@@ -488,7 +488,8 @@ int lgpu_stepper_destroy(lgpu_stepper *s);
 #define LGPU_FX_MAX_FRAMES 16
 enum { LGPU_FX_SOFTLIGHT = 1, LGPU_FX_TRANSITION = 2, LGPU_FX_YUV411_TO_RGB = 3, LGPU_FX_GAUSS5_COLORKEY = 4 };
 typedef struct { const uint8_t *in0[4]; const uint8_t *in1[4]; uint8_t *out[4]; } lgpu_fx_frame;
-typedef struct { int op, width, height, palette; int irow0[4], irow1[4], orow[4]; int ip[4]; double dp[2]; } lgpu_fx_params;
+typedef struct { int op, width, height, palette; int irow0[4], irow1[4], orow[4]; int ip[4]; double dp[2];
+                 const double *frame_dp0; /* NULL, or nframes values that replace dp[0] frame by frame (LGPU_FX_TRANSITION; BADARG for the other ops) */ } lgpu_fx_params;
 int lgpu_fx_batch(const lgpu_fx_params *params, const lgpu_fx_frame *frames, int nframes, void *stream);
 
 /* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),

@@ -588,9 +588,12 @@ struct TransArgs {
   float bf, hwidth, hheight, maxradsq;
   float uthr;                             // type 1: the largest float u with sqrt((double)(u / maxradsq)) <= bf (host, bisection over the floats): the test is u > uthr
 };
+struct TransAmt { int xx, yy; float bf, uthr; };      // what the transition amount decides: per frame of a batch
+struct TransAmts { TransAmt v[LGPU_FX_MAX_FRAMES]; };
 template <int PS>
-__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFrames F) {
+__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFrames F, const TransAmts A) {
   a.src1 = F.in0[blockIdx.z][0]; a.src2 = F.in1[blockIdx.z][0]; a.dst = F.out[blockIdx.z][0];
+  a.xx = A.v[blockIdx.z].xx; a.yy = A.v[blockIdx.z].yy; a.bf = A.v[blockIdx.z].bf; a.uthr = A.v[blockIdx.z].uthr;
   const int x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= a.width) return;
   const int j = x * PS;
@@ -698,16 +701,18 @@ __global__ __launch_bounds__(kBlock) void k_dissolve(const uint8_t *src1, int ir
 }
 }  // namespace lgpu
 
-int lgpu::transition_n(const FxFrames &F, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, double amount, hipStream_t st) {
+int lgpu::transition_n(const FxFrames &F, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, const double *amounts, hipStream_t st) {
   LGPU_REQUIRE(type >= 0 && type <= 2, "type must be 0 (iris rectangle), 1 (iris circle) or 2 (4 way split)");
   LGPU_REQUIRE(width > 0 && height > 0, "empty geometry");
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
   LGPU_REQUIRE(irow1 >= width * psize && irow2 >= width * psize && orow >= width * psize, "rowstride smaller than a row");
+  LGPU_REQUIRE(amounts && nframes >= 1 && nframes <= LGPU_FX_MAX_FRAMES, "1..LGPU_FX_MAX_FRAMES frames, an amount each");
   for (int f = 0; f < nframes; f++) {
     LGPU_REQUIRE(F.in0[f][0] && F.in1[f][0] && F.out[f][0], "null frame");
     LGPU_REQUIRE(type != 2 || F.in0[f][0] != F.out[f][0], "4 way split is not in place (multi_transitions.c:283)");
   }
   lgpu::TransArgs a;
+  lgpu::TransAmts A = {};
   a.src1 = nullptr; a.src2 = nullptr; a.dst = nullptr; a.irow1 = irow1; a.irow2 = irow2; a.orow = orow;
   a.width = width; a.height = height; a.type = type;
   // the reference's own float / double mix (:129-150)
@@ -717,25 +722,29 @@ int lgpu::transition_n(const FxFrames &F, int nframes, int type, int irow1, int 
   a.wb = width * psize;
   hwidth = (float)a.wb * 0.5f;
   a.hwidth = hwidth; a.hheight = hheight; a.ihwidth = a.wb >> 1; a.ihheight = height >> 1;
-  a.bf = (float)amount;
-  a.uthr = 0.f;
-  if (type == 1) {
-    auto pred = [&](uint32_t bits) { float u; __builtin_memcpy(&u, &bits, 4); const volatile float q = u / a.maxradsq; return sqrt((double)q) > (double)a.bf; };
-    if (pred(0u)) a.uthr = -1.f;                                   // true for every u >= 0
-    else {
-      uint32_t lo = 0u, hi = 0x7F7FFFFFu;                          // pred(lo) false; the largest finite float
-      if (!pred(hi)) lo = hi;
-      else while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (pred(mid)) hi = mid; else lo = mid; }
-      __builtin_memcpy(&a.uthr, &lo, 4);
+  a.bf = 0.f; a.uthr = 0.f; a.xx = a.yy = 0;                       // per frame: the kernel takes them from A
+  for (int f = 0; f < nframes; f++) {
+    lgpu::TransAmt &m = A.v[f];
+    m.bf = (float)amounts[f];
+    m.uthr = 0.f;
+    if (type == 1) {
+      auto pred = [&](uint32_t bits) { float u; __builtin_memcpy(&u, &bits, 4); const volatile float q = u / a.maxradsq; return sqrt((double)q) > (double)m.bf; };
+      if (pred(0u)) m.uthr = -1.f;                                 // true for every u >= 0
+      else {
+        uint32_t lo = 0u, hi = 0x7F7FFFFFu;                        // pred(lo) false; the largest finite float
+        if (!pred(hi)) lo = hi;
+        else while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (pred(mid)) hi = mid; else lo = mid; }
+        __builtin_memcpy(&m.uthr, &lo, 4);
+      }
     }
+    const float bfneg = 1.f - m.bf;
+    m.xx = m.yy = 0;
+    if (type == 0) { m.xx = (int)((int)hwidth * bfneg + .5); m.yy = (int)((int)hheight * bfneg + .5); }
+    else if (type == 2) { m.xx = (int)(hheight * m.bf + .5) * irow1; m.yy = (int)(hwidth / (float)psize * m.bf + .5) * psize; }
   }
-  const float bfneg = 1.f - a.bf;
-  a.xx = a.yy = 0;
-  if (type == 0) { a.xx = (int)((int)hwidth * bfneg + .5); a.yy = (int)((int)hheight * bfneg + .5); }
-  else if (type == 2) { a.xx = (int)(hheight * a.bf + .5) * irow1; a.yy = (int)(hwidth / (float)psize * a.bf + .5) * psize; }
   const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048), (unsigned)nframes);
-  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, st, a, F);
-  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, st, a, F);
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, st, a, F, A);
+  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, st, a, F, A);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
@@ -746,7 +755,7 @@ extern "C" int lgpu_transition(int type, const uint8_t *src1_d, int irow1, const
   if (rc) return rc;
   FxFrames F = {};
   F.in0[0][0] = src1_d; F.in1[0][0] = src2_d; F.out[0][0] = dst_d;
-  return transition_n(F, 1, type, irow1, irow2, orow, width, height, psize, amount, (hipStream_t)stream);
+  return transition_n(F, 1, type, irow1, irow2, orow, width, height, psize, &amount, (hipStream_t)stream);
 }
 
 // One launch for the instances of ONE filter on the live tracks of a tick (src/effects-weed.c:1850-2425 runs weed_apply_instance once per track): the frames share
@@ -759,9 +768,14 @@ extern "C" int lgpu_fx_batch(const lgpu_fx_params *p, const lgpu_fx_frame *frame
   for (int f = 0; f < nframes; f++)
     for (int k = 0; k < 4; k++) { F.in0[f][k] = frames[f].in0[k]; F.in1[f][k] = frames[f].in1[k]; F.out[f][k] = frames[f].out[k]; }
   hipStream_t st = (hipStream_t)stream;
+  LGPU_REQUIRE(!p->frame_dp0 || p->op == LGPU_FX_TRANSITION, "frame_dp0 (a value per frame) is taken by LGPU_FX_TRANSITION only");
   switch (p->op) {
   case LGPU_FX_SOFTLIGHT: return softlight_n(F, nframes, p->irow0, p->orow, p->width, p->height, p->palette, p->ip[0], st);
-  case LGPU_FX_TRANSITION: return transition_n(F, nframes, p->ip[0], p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[1], p->dp[0], st);
+  case LGPU_FX_TRANSITION: {
+    double am[LGPU_FX_MAX_FRAMES];
+    for (int f = 0; f < nframes; f++) am[f] = p->frame_dp0 ? p->frame_dp0[f] : p->dp[0];
+    return transition_n(F, nframes, p->ip[0], p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[1], am, st);
+  }
   case LGPU_FX_YUV411_TO_RGB: return yuv411_to_rgb_n(F, nframes, p->width, p->height, p->orow[0], p->ip[0], p->ip[1], p->ip[2], st);
   case LGPU_FX_GAUSS5_COLORKEY: return gauss5_colorkey_n(F, nframes, p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[0], p->ip[1], p->dp[0], p->dp[1], p->ip[2] & 0xFF,
                                                          (p->ip[2] >> 8) & 0xFF, (p->ip[2] >> 16) & 0xFF, st);

@@ -437,6 +437,115 @@ PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(
    gdk_pixbuf_scale_simple -- GDK_INTERP_HYPER when a side grows, GDK_INTERP_BILINEAR otherwise (:262-266) -- and painted at (int)(offs * out size) by
    paint_pixel (:120-125).  Here: lgpu_pixbuf_scale (bit-exact to that library call) per channel into stream-ordered device frames, then ONE
    lgpu_composite launch.  A channel with an "inner_size" leaf is cropped first as :228-258 do.  At most LGPU_COMP_MAX_LAYERS enabled channels. */
+/* ---- several instances of one filter class in ONE launch (an extension of this plugin, not of the weed API; a host finds it with dlsym) ----
+   The reference applies the effects of a plan step one instance after another (src/effects-weed.c:1563-1758 per instance), and a 640x360 frame is a
+   ramp-and-drain bound launch on 256 CUs: n instances of the same class on frames of one geometry go out as one lgpu_fx_batch launch (include/lives_gpu.h).
+   Batched today: the three transitions of multi_transitions.c ("iris rectangle", "iris circle", "4 way split"), each instance with its own "amount";
+   any other class, mixed classes, mixed geometry, sliced channels or more than LGPU_FX_MAX_FRAMES instances fall back to process_func per instance, so the
+   result is the same either way.  Channels on pinned layers are used where they live (no copy, no wait), the others are staged as fx_run does. */
+static int batch_kind(weed_plant_t *inst) {
+  weed_plant_t *fc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_FILTER_CLASS, 0);
+  weed_process_f pf = NULL;
+  if (!fc || w_get(fc, WEED_LEAF_PROCESS_FUNC, 0, &pf) != WEED_SUCCESS) return -1;
+  return pf == p_irisr ? 0 : pf == p_irisc ? 1 : pf == p_fourw ? 2 : -1;
+}
+static weed_error_t batch_fallback(weed_plant_t **insts, int n, weed_timecode_t tc) {
+  weed_error_t ret = WEED_SUCCESS;
+  for (int i = 0; i < n; i++) {
+    weed_plant_t *fc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_FILTER_CLASS, 0);
+    weed_process_f pf = NULL;
+    weed_error_t r;
+    if (!fc || w_get(fc, WEED_LEAF_PROCESS_FUNC, 0, &pf) != WEED_SUCCESS || !pf) return WEED_ERROR_FILTER_INVALID;
+    r = (*pf)(insts[i], tc);
+    if (r != WEED_SUCCESS) ret = r;
+  }
+  return ret;
+}
+weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecode_t tc) {
+  lgpu_fx_frame fr[LGPU_FX_MAX_FRAMES];
+  lgpu_fx_params P;
+  const void *rel[LGPU_FX_MAX_FRAMES][3];
+  uint8_t *hdst[LGPU_FX_MAX_FRAMES], *ddst[LGPU_FX_MAX_FRAMES];
+  int kind, i, c, w = 0, h = 0, pal = 0, irow[2] = {0, 0}, orow = 0, psize, home = 0, uploaded = 0, krc;
+  double amounts[LGPU_FX_MAX_FRAMES];
+  weed_error_t ret = WEED_SUCCESS;
+  if (!insts || n <= 0) return WEED_ERROR_FILTER_INVALID;
+  for (i = 0; i < n; i++) if (!insts[i]) return WEED_ERROR_FILTER_INVALID;
+  kind = batch_kind(insts[0]);
+  if (kind < 0 || n > LGPU_FX_MAX_FRAMES || n == 1) return batch_fallback(insts, n, tc);
+  for (i = 0; i < n; i++) {
+    weed_plant_t *oc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0), *pa = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_PARAMETERS, 0);
+    amounts[i] = pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0.;
+    if (batch_kind(insts[i]) != kind || !oc || has(oc, WEED_LEAF_OFFSET) || w_nelems(oc, WEED_LEAF_HEIGHT) > 1) return batch_fallback(insts, n, tc);
+    if (i == 0) {
+      w = g_int(oc, WEED_LEAF_WIDTH, 0, 0); h = g_int(oc, WEED_LEAF_HEIGHT, 0, 0); pal = g_int(oc, WEED_LEAF_CURRENT_PALETTE, 0, 0);
+      orow = g_int(oc, WEED_LEAF_ROWSTRIDES, 0, 0);
+    } else if (w != g_int(oc, WEED_LEAF_WIDTH, 0, 0) || h != g_int(oc, WEED_LEAF_HEIGHT, 0, 0) || pal != g_int(oc, WEED_LEAF_CURRENT_PALETTE, 0, 0) ||
+               orow != g_int(oc, WEED_LEAF_ROWSTRIDES, 0, 0)) return batch_fallback(insts, n, tc);
+    if (!g_ptr(oc, WEED_LEAF_PIXEL_DATA, 0)) return WEED_ERROR_FILTER_INVALID;
+    for (c = 0; c < 2; c++) {
+      weed_plant_t *ic = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_CHANNELS, c);
+      if (!ic || !g_ptr(ic, WEED_LEAF_PIXEL_DATA, 0)) return WEED_ERROR_FILTER_INVALID;
+      if (i == 0) irow[c] = g_int(ic, WEED_LEAF_ROWSTRIDES, 0, 0);
+      else if (irow[c] != g_int(ic, WEED_LEAF_ROWSTRIDES, 0, 0)) return batch_fallback(insts, n, tc);
+    }
+  }
+  psize = psize_of(pal);
+  if (!psize || w <= 0 || h <= 0) return WEED_ERROR_FILTER_INVALID;
+  if (lgpu_init(0) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+  memset(fr, 0, sizeof fr); memset(rel, 0, sizeof rel);
+  for (i = 0; i < n && ret == WEED_SUCCESS; i++) {
+    fxdata_t *fx = fx_data(insts[i]);
+    weed_plant_t *oc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0);
+    const size_t ob = (size_t)orow * h;
+    uint8_t *src0 = NULL;
+    if (!fx) { ret = WEED_ERROR_MEMORY_ALLOCATION; break; }
+    fx_enter(fx);
+    hdst[i] = (uint8_t *)g_ptr(oc, WEED_LEAF_PIXEL_DATA, 0);
+    ddst[i] = (uint8_t *)lives_gpu_resident_acquire(hdst[i], ob, 1);
+    if (ddst[i]) rel[i][0] = hdst[i];
+    else { ddst[i] = (uint8_t *)fx_buf(fx, 2, ob + 16); home = 1; }
+    if (!ddst[i]) { ret = WEED_ERROR_MEMORY_ALLOCATION; break; }
+    for (c = 0; c < 2; c++) {
+      weed_plant_t *ic = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_CHANNELS, c);
+      uint8_t *hs = (uint8_t *)g_ptr(ic, WEED_LEAF_PIXEL_DATA, 0), *ds;
+      const size_t ib = (size_t)irow[c] * h;
+      if (c == 0) src0 = hs;
+      if (c == 0 && hs == hdst[i]) {                    /* in place (the two iris classes may be) */
+        if (!rel[i][0] && lgpu_upload(ddst[i], hs, ob, FXS)) ret = WEED_ERROR_PLUGIN_INVALID;
+        fr[i].in0[0] = ddst[i];
+        continue;
+      }
+      ds = (uint8_t *)lives_gpu_resident_acquire(hs, ib, 0);
+      if (ds) rel[i][1 + c] = hs;
+      else {
+        ds = (uint8_t *)fx_buf(fx, c, ib + 16);
+        if (!ds) { ret = WEED_ERROR_MEMORY_ALLOCATION; break; }
+        if (lgpu_upload(ds, hs, ib, FXS)) ret = WEED_ERROR_PLUGIN_INVALID;
+        uploaded = 1;
+      }
+      if (c == 0) fr[i].in0[0] = ds; else fr[i].in1[0] = ds;
+    }
+    if (src0 != hdst[i] && !rel[i][0] && ret == WEED_SUCCESS && lgpu_upload(ddst[i], hdst[i], ob, FXS)) ret = WEED_ERROR_PLUGIN_INVALID;   /* row padding */
+    fr[i].out[0] = ddst[i];
+  }
+  krc = LGPU_OK;
+  if (ret == WEED_SUCCESS) {
+    memset(&P, 0, sizeof P);
+    P.op = LGPU_FX_TRANSITION; P.width = w; P.height = h;
+    P.irow0[0] = irow[0]; P.irow1[0] = irow[1]; P.orow[0] = orow;
+    P.ip[0] = kind; P.ip[1] = psize; P.frame_dp0 = amounts;
+    krc = lgpu_fx_batch(&P, fr, n, FXS);
+  }
+  for (i = 0; i < n; i++) { lives_gpu_resident_release(rel[i][0], 1); lives_gpu_resident_release(rel[i][1], 0); lives_gpu_resident_release(rel[i][2], 0); }
+  if (ret != WEED_SUCCESS) return ret;
+  if (krc != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+  for (i = 0; i < n; i++)
+    if (!rel[i][0] && lgpu_download(hdst[i], ddst[i], (size_t)orow * h, FXS)) return WEED_ERROR_PLUGIN_INVALID;
+  if ((home || uploaded) && lgpu_sync(FXS)) return WEED_ERROR_PLUGIN_INVALID;    /* as fx_run: host planes are complete / reusable on return */
+  return WEED_SUCCESS;
+}
+
 static double g_dbl_at(weed_plant_t *p, const char *k, int idx, double dflt) { double v = dflt; if (w_get(p, k, (weed_size_t)idx, &v) != WEED_SUCCESS) return dflt; return v; }
 static weed_error_t p_compositor(weed_plant_t *inst, weed_timecode_t tc) {
   fxdata_t *fx = fx_data(inst);

@@ -58,7 +58,8 @@ class FxFrame(ctypes.Structure):
 
 
 class FxParams(ctypes.Structure):
-    _fields_ = [("op", ci), ("width", ci), ("height", ci), ("palette", ci), ("irow0", ci * 4), ("irow1", ci * 4), ("orow", ci * 4), ("ip", ci * 4), ("dp", ctypes.c_double * 2)]
+    _fields_ = [("op", ci), ("width", ci), ("height", ci), ("palette", ci), ("irow0", ci * 4), ("irow1", ci * 4), ("orow", ci * 4), ("ip", ci * 4), ("dp", ctypes.c_double * 2),
+                ("frame_dp0", ctypes.POINTER(ctypes.c_double))]
 
 
 # name -> argtypes; every entry point include/lives_gpu.h declares must appear here (tests check both ways)

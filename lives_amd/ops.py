@@ -267,8 +267,9 @@ def softlight(src_planes, dst_planes, width, height, palette, unclamped):
 FX_SOFTLIGHT, FX_TRANSITION, FX_YUV411_TO_RGB, FX_GAUSS5_COLORKEY = 1, 2, 3, 4
 
 
-def fx_batch(op, ins0, outs, width, height, ins1=None, palette=0, ip=(0, 0, 0, 0), dp=(0., 0.)):
-    """lgpu_fx_batch: ins0 / ins1 / outs are lists (one entry per frame) of lists of plane tensors; strides are taken from frame 0"""
+def fx_batch(op, ins0, outs, width, height, ins1=None, palette=0, ip=(0, 0, 0, 0), dp=(0., 0.), frame_dp0=None):
+    """lgpu_fx_batch: ins0 / ins1 / outs are lists (one entry per frame) of lists of plane tensors; strides are taken from frame 0;
+    frame_dp0: a value per frame in place of dp[0] (transitions: the amount)"""
     n = len(ins0)
     frames = (lib.FxFrame * n)()
     for f in range(n):
@@ -289,6 +290,9 @@ def fx_batch(op, ins0, outs, width, height, ins1=None, palette=0, ip=(0, 0, 0, 0
     for k in range(4):
         prm.ip[k] = int(ip[k]) if k < len(ip) else 0
     prm.dp[0], prm.dp[1] = float(dp[0]), float(dp[1]) if len(dp) > 1 else 0.
+    if frame_dp0 is not None:
+        per_frame = (ctypes.c_double * n)(*[float(v) for v in frame_dp0])
+        prm.frame_dp0 = ctypes.cast(per_frame, ctypes.POINTER(ctypes.c_double))
     lib.call("lgpu_fx_batch", ctypes.byref(prm), frames, n, stream_ptr())
 
 

@@ -192,6 +192,7 @@ class RefHost:
         self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
         self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
         self.H.refhost_run_compositor.argtypes = [vp, ctypes.c_char_p, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci]
+        self.H.refhost_run_batch.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, vp]
         self.H.refhost_set_yuv_clamping.argtypes = [ci]
         self.H.refhost_set_random_seed.argtypes = [ctypes.c_int64]
         self.plugins = {}
@@ -254,6 +255,21 @@ class RefHost:
         if r != 0:
             raise RuntimeError("weed filter 'compositor' returned %d" % r)
         return dst
+
+    def run_batch(self, path, fname, pal, w, h, srcs1, srcs2, dsts, amounts, hook=None):
+        """n instances of one transition class (a frame pair and an amount each): process_func per instance, or one call of the plugin's
+        batch hook (hook = the symbol's name in the plugin, e.g. "livesgpu_fx_process_batch")"""
+        hdl = self.load(path)
+        n = len(dsts)
+        arr = lambda fr: (vp * n)(*[a.ctypes.data for a in fr])
+        fn = None
+        if hook:
+            fn = ctypes.cast(getattr(ctypes.CDLL(path), hook), vp)
+        r = self.H.refhost_run_batch(hdl, fname.encode(), pal, w, h, n, arr(srcs1), srcs1[0].strides[0], arr(srcs2), srcs2[0].strides[0],
+                                     arr(dsts), dsts[0].strides[0], (cd * n)(*[float(a) for a in amounts]), fn)
+        if r != 0:
+            raise RuntimeError("weed filter '%s' (batch of %d) returned %d" % (fname, n, r))
+        return dsts
 
     def run(self, path, fname, pal, w, h, srcs, dst, params=(), nslices=1):
         """srcs: list of 2-D uint8 arrays (rows x rowstride); dst: 2-D uint8 array (may be srcs[0])."""

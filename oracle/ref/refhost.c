@@ -383,3 +383,55 @@ int refhost_run_seq(void *pinfo_v, const char *fname, int pal, int w, int h, int
   return ret;
 }
 
+
+/* n instances of one two-input filter class with one double parameter each (the transitions), as a plan step holds them for n tracks:
+ * init each, then either process_func per instance (batch_hook NULL) or ONE call of the plugin's batch hook
+ *   weed_error_t hook(weed_plant_t **instances, int n, weed_timecode_t tc)
+ * (this repo's livesgpu_fx.so exports livesgpu_fx_process_batch; the reference's plugins have none), then deinit each.
+ * src1[i] / src2[i] / dst[i]: the planes of instance i (dst[i] may alias src1[i]). */
+typedef weed_error_t (*refhost_batch_f)(weed_plant_t **, int, weed_timecode_t);
+int refhost_run_batch(void *pinfo_v, const char *fname, int pal, int w, int h, int n, uint8_t **src1, int istride1, uint8_t **src2, int istride2,
+                      uint8_t **dst, int ostride, const double *amounts, void *batch_hook) {
+  weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
+  weed_plant_t *filt = find_filter(pinfo, fname);
+  weed_plant_t *inst[64], *in1[64], *in2[64], *outc[64], *par[64], **ictm, **octm, **iptm;
+  weed_init_f init_func;
+  weed_process_f process_func;
+  weed_deinit_f deinit_func;
+  int nict = 0, noct = 0, nipt = 0, i, ninit = 0, ret = WEED_SUCCESS;
+  if (!filt) { fprintf(stderr, "refhost: filter '%s' not found\n", fname); return -100; }
+  if (n < 1 || n > 64) return -101;
+  ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
+  octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
+  iptm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_PARAMETER_TEMPLATES, &nipt);
+  if (nict < 2 || noct < 1 || nipt < 1) return -102;
+  init_func = (weed_init_f)weed_get_funcptr_value(filt, WEED_LEAF_INIT_FUNC, NULL);
+  process_func = (weed_process_f)weed_get_funcptr_value(filt, WEED_LEAF_PROCESS_FUNC, NULL);
+  deinit_func = (weed_deinit_f)weed_get_funcptr_value(filt, WEED_LEAF_DEINIT_FUNC, NULL);
+  for (i = 0; i < n; i++) {
+    weed_plant_t *ch[2];
+    inst[i] = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
+    weed_set_plantptr_value(inst[i], WEED_LEAF_FILTER_CLASS, filt);
+    ch[0] = in1[i] = mk_channel(ictm[0], pal, w, h, istride1, src1[i]);
+    ch[1] = in2[i] = mk_channel(ictm[1], pal, w, h, istride2, src2[i]);
+    outc[i] = mk_channel(octm[0], pal, w, h, ostride, dst[i]);
+    weed_set_plantptr_array(inst[i], WEED_LEAF_IN_CHANNELS, 2, ch);
+    weed_set_plantptr_value(inst[i], WEED_LEAF_OUT_CHANNELS, outc[i]);
+    par[i] = weed_plant_new(WEED_PLANT_PARAMETER);
+    weed_set_plantptr_value(par[i], WEED_LEAF_TEMPLATE, iptm[0]);
+    weed_set_double_value(par[i], WEED_LEAF_VALUE, amounts[i]);
+    weed_set_plantptr_value(inst[i], WEED_LEAF_IN_PARAMETERS, par[i]);
+  }
+  for (ninit = 0; ninit < n && ret == WEED_SUCCESS; ninit++)
+    if (init_func) { ret = (*init_func)(inst[ninit]); if (ret != WEED_SUCCESS) break; }
+  if (ret == WEED_SUCCESS) {
+    if (batch_hook) ret = (*(refhost_batch_f)batch_hook)(inst, n, (weed_timecode_t)0);
+    else for (i = 0; i < n; i++) { int r = (*process_func)(inst[i], (weed_timecode_t)0); if (r != WEED_SUCCESS) ret = r; }
+  }
+  for (i = 0; i < ninit; i++) if (deinit_func) (*deinit_func)(inst[i]);
+  for (i = 0; i < n; i++) { weed_plant_free(par[i]); weed_plant_free(in1[i]); weed_plant_free(in2[i]); weed_plant_free(outc[i]); weed_plant_free(inst[i]); }
+  if (ictm) free(ictm);
+  if (octm) free(octm);
+  if (iptm) free(iptm);
+  return ret;
+}

@@ -65,6 +65,18 @@ def test_transition_batch(gpu, orc, kind, psize):
             got = host(outs[f])
             assert (got[:h, :w * psize] == want[:, :w * psize]).all(), "frame %d of %d" % (f, n)
             assert (got[h] == 0xA5).all() and (got[:h, w * psize:] == 0xA5).all()
+    # an amount per frame (frame_dp0): what the plugin's batch hook passes for the instances of a plan step
+    n = 9
+    amts = [0., 1.] + list(rng.random(n - 2))
+    stride = align(w * psize, 16)
+    s1 = [rng.integers(0, 256, (h, stride), dtype=np.uint8) for _ in range(n)]
+    s2 = [rng.integers(0, 256, (h, stride), dtype=np.uint8) for _ in range(n)]
+    outs = [guarded(h, stride) for _ in range(n)]
+    gpu.fx_batch(gpu.FX_TRANSITION, [[dev(a)] for a in s1], [[o] for o in outs], w, h, ins1=[[dev(a)] for a in s2], ip=(kind, psize), dp=(0.123,), frame_dp0=amts)
+    for f in range(n):
+        want = np.full((h, stride), 0xA5, np.uint8)
+        orc.orc_transition(kind, P(s1[f]), stride, P(s2[f]), stride, P(want), stride, w, h, psize, amts[f])
+        assert (host(outs[f])[:h] == want).all(), "frame %d, amount %r" % (f, amts[f])
 
 
 @pytest.mark.parametrize("order,oa", [(0, 0), (0, 1), (1, 1), (2, 0)])
@@ -99,3 +111,5 @@ def test_fx_batch_refuses_bad_arguments(gpu):
         gpu.fx_batch(gpu.FX_TRANSITION, [[t]] * 17, [[t]] * 17, 8, 8, ins1=[[t]] * 17, ip=(0, 4), dp=(0.5,))
     with pytest.raises(lib.LgpuError):
         gpu.fx_batch(gpu.FX_TRANSITION, [[t]], [[t]], 8, 8, ins1=[[t]], ip=(2, 4), dp=(0.5,))          # 4 way split in place
+    with pytest.raises(lib.LgpuError):
+        gpu.fx_batch(gpu.FX_SOFTLIGHT, [[t, t, t]], [[t, t, t]], 8, 8, palette=544, frame_dp0=[0.5])   # a value per frame: transitions only

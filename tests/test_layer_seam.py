@@ -705,3 +705,48 @@ def test_plugin_effects_on_pinned_layers_stay_in_hbm(seam, orc):
     orc.orc_byte_luts(P(conv), conv.strides[0], P(conv), conv.strides[0], w, h, 4, luts.ctypes.data)
     assert (got[:, :w * 4] == conv[:, :w * 4]).all()
     assert L.lives_gpu_layer_unpin(la) == 0 and L.lives_gpu_layer_unpin(lb) == 0
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_plugin_batch_hook_on_pinned_layers(seam):
+    """the plan step of n tracks: n transition instances whose channels are planes of pinned layers go through livesgpu_fx_process_batch as one launch
+    on the planes where they live -- nothing crosses PCIe until the layers are synced, and the results are the reference plugin's"""
+    import os
+    L, wh = seam
+    H = po.RefHost()
+    OURS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lives_amd", "livesgpu_fx.so")
+
+    def stats():
+        a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        L.lives_gpu_transfer_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def view(layer):
+        _, ptrs, rs = wh.planes_of(layer)
+        hh = wh.geti(layer, "height")
+        return np.frombuffer((ctypes.c_uint8 * (rs[0] * hh)).from_address(ptrs[0]), np.uint8).reshape(hh, rs[0])
+
+    rng = np.random.default_rng(23)
+    w, h, n = 128, 36, 6
+    fa = [frame(rng, w, h, 4) for _ in range(n)]
+    fb = [frame(rng, w, h, 4) for _ in range(n)]
+    amounts = [0.05 + 0.15 * i for i in range(n)]
+    want = [np.zeros_like(x) for x in fa]
+    H.run_batch(po.refplugin("multi_transitions"), "iris circle", RGBA32, w, h, fa, fb, want, amounts)
+    la = [wh.new_layer(RGBA32, w, h, [x.copy()], gamma=1) for x in fa]
+    lb = [wh.new_layer(RGBA32, w, h, [x.copy()], gamma=1) for x in fb]
+    lo = [wh.new_layer(RGBA32, w, h, [np.zeros_like(x)], gamma=1) for x in fa]
+    for lay in la + lb + lo:
+        assert L.lives_gpu_layer_pin(lay) == 0
+    va, vb, vo = [view(x) for x in la], [view(x) for x in lb], [view(x) for x in lo]
+    s0 = stats()
+    H.run_batch(OURS, "iris circle", RGBA32, w, h, va, vb, vo, amounts, hook="livesgpu_fx_process_batch")
+    assert stats() == s0, "a batch on pinned layers must not cross PCIe"
+    assert all((v == 0).all() for v in vo), "the host planes stay stale until the layers are synced"
+    for lay in lo:
+        assert L.lives_gpu_layer_sync(lay) == 0
+    for i in range(n):
+        assert (view(lo[i])[:, :w * 4] == want[i][:, :w * 4]).all(), i
+    for lay in la + lb + lo:
+        assert L.lives_gpu_layer_unpin(lay) == 0

@@ -169,6 +169,41 @@ def test_transition_records_through_the_plugin():
 
 @needs_ref
 @pytest.mark.gpu
+def test_batch_hook_one_launch_for_the_instances_of_a_plan_step():
+    """livesgpu_fx_process_batch (this plugin's extension): n instances of one transition class, an amount each, in ONE launch -- the golden records of a class
+    as one batch, then 7 and 17 (> LGPU_FX_MAX_FRAMES: per instance behind the same call) random instances against the REFERENCE plugin run one by one"""
+    H = po.RefHost()
+    g = gu.load("transitions.npz")
+    names = ["iris rectangle", "iris circle", "4 way split"]
+    groups = {}
+    for rec in map(str, g["records"]):
+        f = rec.split("|")
+        groups.setdefault((int(f[1]), int(f[2]), int(f[4]), int(f[5])), []).append((rec, float(f[3])))
+    for (t, pal, w, h), recs in groups.items():
+        a = [g[r + "|a"].copy() for r, _ in recs]
+        b = [g[r + "|b"].copy() for r, _ in recs]
+        d = [np.full_like(g[r + "|o"], 0x5A) for r, _ in recs]
+        H.run_batch(OURS, names[t], pal, w, h, a, b, d, [amt for _, amt in recs], hook="livesgpu_fx_process_batch")
+        for (r, _), got in zip(recs, d):
+            assert (got[:, :w * PSIZE[pal]] == g[r + "|o"][:, :w * PSIZE[pal]]).all(), r
+    rng = np.random.default_rng(77)
+    ref = po.refplugin("multi_transitions")
+    for t, pal, w, h, n, inplace in ((0, 1, 640, 360, 7, False), (1, 3, 640, 360, 7, True), (2, 3, 322, 121, 7, False), (1, 1, 97, 33, 17, False), (0, 4, 64, 40, 1, False)):
+        ps = PSIZE[pal]
+        a = [po.make_frame(rng, w, h, ps) for _ in range(n)]
+        b = [po.make_frame(rng, w, h, ps) for _ in range(n)]
+        amounts = list(rng.random(n))
+        amounts[0], amounts[-1] = 0., 1.
+        want = [x.copy() if inplace else np.full_like(x, 0x33) for x in a]
+        H.run_batch(ref, names[t], pal, w, h, want if inplace else a, b, want, amounts)
+        got = [x.copy() if inplace else np.full_like(x, 0x33) for x in a]
+        H.run_batch(OURS, names[t], pal, w, h, got if inplace else a, b, got, amounts, hook="livesgpu_fx_process_batch")
+        for i in range(n):
+            assert (got[i] == want[i]).all(), (t, pal, w, h, i)          # the row padding too: it stays as it was
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_slide_over_records_through_the_plugin():
     H = po.RefHost()
     g = gu.load("slide_over.npz")
