@@ -590,38 +590,75 @@ struct TransArgs {
 };
 struct TransAmt { int xx, yy; float bf, uthr; };      // what the transition amount decides: per frame of a batch
 struct TransAmts { TransAmt v[LGPU_FX_MAX_FRAMES]; };
+// where pixel (i, j / PS) comes from (multi_transitions.c:152-205), the reference's own float / double mix
 template <int PS>
-__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFrames F, const TransAmts A) {
-  a.src1 = F.in0[blockIdx.z][0]; a.src2 = F.in1[blockIdx.z][0]; a.dst = F.out[blockIdx.z][0];
-  a.xx = A.v[blockIdx.z].xx; a.yy = A.v[blockIdx.z].yy; a.bf = A.v[blockIdx.z].bf; a.uthr = A.v[blockIdx.z].uthr;
-  const int x = blockIdx.x * kBlock + threadIdx.x;
-  if (x >= a.width) return;
-  const int j = x * PS;
-  for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
-    const uint8_t *from;
-    if (a.type == 0) {
-      from = (j < a.xx || j >= a.wb - a.xx || i < a.yy || i >= a.height - a.yy) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
-    } else if (a.type == 1) {
-      // sqrt((xxf * xxf + yyf * yyf) / maxradsq) > bf: float terms, double square root (:185-187)
-      const float xxf = (float)(i - a.ihheight), yyf = __fdiv_rn((float)(j - a.ihwidth), (float)PS);
-      // the float division by maxradsq and the double square root are monotone in u = xxf^2 + yyf^2, so "sqrt(u / maxradsq) > bf" is "u > uthr" for the one float
-      // uthr the host finds with the same IEEE operations (exact: every float u falls on the same side); a division and a square root per pixel less
-      const float u = __fadd_rn(__fmul_rn(xxf, xxf), __fmul_rn(yyf, yyf));
-      from = (u > a.uthr) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
-    } else {
-      const bool cross = __fdiv_rn(fabsf(__fsub_rn((float)i, a.hheight)), a.hheight) < a.bf ||
-                         __fdiv_rn(fabsf(__fsub_rn((float)j, a.hwidth)), a.hwidth) < a.bf || a.bf == 1.f;
-      from = cross ? a.src2 + (size_t)a.irow2 * i + j
-                   : a.src1 + (size_t)a.irow1 * i + j + (j > a.ihwidth ? -a.yy : a.yy) + (i > a.ihheight ? -(ptrdiff_t)a.xx : (ptrdiff_t)a.xx);
-    }
-    uint8_t *d = a.dst + (size_t)a.orow * i + j;
-    if (from != d) {
-      if (PS == 4 && (((uintptr_t)from | (uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(from);      // a 4-byte pixel at an aligned address: one load, one store
-      else {
+__device__ __forceinline__ const uint8_t *trans_from(const TransArgs &a, int i, int j) {
+  if (a.type == 0)
+    return (j < a.xx || j >= a.wb - a.xx || i < a.yy || i >= a.height - a.yy) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
+  if (a.type == 1) {
+    // sqrt((xxf * xxf + yyf * yyf) / maxradsq) > bf: float terms, double square root (:185-187)
+    const float xxf = (float)(i - a.ihheight), yyf = __fdiv_rn((float)(j - a.ihwidth), (float)PS);
+    // the float division by maxradsq and the double square root are monotone in u = xxf^2 + yyf^2, so "sqrt(u / maxradsq) > bf" is "u > uthr" for the one float
+    // uthr the host finds with the same IEEE operations (exact: every float u falls on the same side); a division and a square root per pixel less
+    const float u = __fadd_rn(__fmul_rn(xxf, xxf), __fmul_rn(yyf, yyf));
+    return (u > a.uthr) ? a.src1 + (size_t)a.irow1 * i + j : a.src2 + (size_t)a.irow2 * i + j;
+  }
+  const bool cross = __fdiv_rn(fabsf(__fsub_rn((float)i, a.hheight)), a.hheight) < a.bf ||
+                     __fdiv_rn(fabsf(__fsub_rn((float)j, a.hwidth)), a.hwidth) < a.bf || a.bf == 1.f;
+  return cross ? a.src2 + (size_t)a.irow2 * i + j
+               : a.src1 + (size_t)a.irow1 * i + j + (j > a.ihwidth ? -a.yy : a.yy) + (i > a.ihheight ? -(ptrdiff_t)a.xx : (ptrdiff_t)a.xx);
+}
+template <int PS>
+__device__ __forceinline__ void trans_copy_px(uint8_t *d, const uint8_t *from) {
+  if (from == d) return;
+  if (PS == 4 && (((uintptr_t)from | (uintptr_t)d) & 3) == 0) { *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(from); return; }      // a 4-byte pixel at an aligned address: one load, one store
 #pragma unroll
-        for (int k = 0; k < PS; k++) d[k] = from[k];
-      }
+  for (int k = 0; k < PS; k++) d[k] = from[k];
+}
+// A thread owns FOUR neighbouring pixels of a row (16 or 12 bytes).  The transitions are selects between two frames (the 4 way split: a shifted copy of the first): when
+// the four sources are neighbours too -- everywhere but on the outline of the figure -- they move as one 16-byte (three 4-byte) load and store; the outline's groups
+// go pixel by pixel.  In place (the iris classes): a group that stays what it is is not touched.
+typedef uint32_t tr_u4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t tr_u3 __attribute__((ext_vector_type(3), aligned(4)));
+template <int PS>
+__global__ __launch_bounds__(kBlock) void k_transition(TransArgs a, const FxFrames F, const TransAmts A, int qpr, unsigned total, unsigned half) {
+  a.src1 = F.in0[blockIdx.y][0]; a.src2 = F.in1[blockIdx.y][0]; a.dst = F.out[blockIdx.y][0];
+  a.xx = A.v[blockIdx.y].xx; a.yy = A.v[blockIdx.y].yy; a.bf = A.v[blockIdx.y].bf; a.uthr = A.v[blockIdx.y].uthr;
+  // two groups per thread, half a frame apart: both loads are on their way before the first store
+  const unsigned t0 = blockIdx.x * kBlock + threadIdx.x;
+  if (t0 >= half) return;
+  const uint8_t *from[2][4];
+  uint8_t *d[2];
+  int npx[2];
+  bool run[2];
+  tr_u4 v4[2];
+  tr_u3 v3[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const unsigned t = t0 + (unsigned)g * half;
+    npx[g] = 0; run[g] = false; d[g] = nullptr;
+    if (t >= total) continue;
+    const int i = (int)(t / (unsigned)qpr), x0 = 4 * (int)(t - (unsigned)i * (unsigned)qpr);
+    d[g] = a.dst + (size_t)a.orow * i + (size_t)x0 * PS;
+    npx[g] = min(4, a.width - x0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) from[g][k] = trans_from<PS>(a, i, (x0 + (k < npx[g] ? k : 0)) * PS);
+    run[g] = npx[g] == 4 && from[g][1] == from[g][0] + PS && from[g][2] == from[g][0] + 2 * PS && from[g][3] == from[g][0] + 3 * PS &&
+             (((uintptr_t)from[g][0] | (uintptr_t)d[g]) & 3) == 0;
+    if (run[g] && from[g][0] != d[g]) {
+      if (PS == 4) v4[g] = *reinterpret_cast<const tr_u4 *>(from[g][0]);
+      else v3[g] = *reinterpret_cast<const tr_u3 *>(from[g][0]);
     }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    if (run[g]) {
+      if (from[g][0] == d[g]) continue;
+      if (PS == 4) *reinterpret_cast<tr_u4 *>(d[g]) = v4[g];
+      else *reinterpret_cast<tr_u3 *>(d[g]) = v3[g];
+      continue;
+    }
+    for (int k = 0; k < npx[g]; k++) trans_copy_px<PS>(d[g] + k * PS, from[g][k]);
   }
 }
 
@@ -742,9 +779,13 @@ int lgpu::transition_n(const FxFrames &F, int nframes, int type, int irow1, int 
     if (type == 0) { m.xx = (int)((int)hwidth * bfneg + .5); m.yy = (int)((int)hheight * bfneg + .5); }
     else if (type == 2) { m.xx = (int)(hheight * m.bf + .5) * irow1; m.yy = (int)(hwidth / (float)psize * m.bf + .5) * psize; }
   }
-  const dim3 grid(cdiv((unsigned)width, kBlock), (unsigned)(height < 2048 ? height : 2048), (unsigned)nframes);
-  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, st, a, F, A);
-  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, st, a, F, A);
+  const int qpr = (width + 3) / 4;                                  // groups of four pixels per row
+  LGPU_REQUIRE((long long)qpr * height < (1ll << 31), "frame too large");
+  const unsigned total = (unsigned)qpr * (unsigned)height;
+  const unsigned half = (total + 1) / 2;
+  const dim3 grid(cdiv(half, kBlock), (unsigned)nframes);
+  if (psize == 4) hipLaunchKernelGGL(lgpu::k_transition<4>, grid, dim3(kBlock), 0, st, a, F, A, qpr, total, half);
+  else hipLaunchKernelGGL(lgpu::k_transition<3>, grid, dim3(kBlock), 0, st, a, F, A, qpr, total, half);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }

@@ -919,6 +919,22 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
   const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~3;          // the window starts on a source pixel that is a multiple of 4: aligned pairs, 16-byte loads
   const int ys0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;
+  const int j = j0 + lane;
+  const long long x = (long long)j * A.x_step + A.xoff;
+  const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15;
+  const bool edge = xs < 0 || xs + A.n_x > A.sw;
+  const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
+  const pb_u4 *pairs4 = reinterpret_cast<const pb_u4 *>(A.pairs);      // uniform base, 32-bit per-lane index: scalar-base addressing
+  // tap rows known at compile time: the weight vectors of the wave's first destination row are requested BEFORE the window (they land while it is staged: the
+  // in-order vector-memory counter makes the window's wait cover them), the following rows' during the taps of the row before -- no exposed load per tap row
+  pb_u4 wv[(NPC && NY) ? NY : 1];
+  if (NPC && NY) {
+    const int i = min(i0 + wave, A.dh - 1), jc = min(j, A.dw - 1);
+    const long long xc = (long long)jc * A.x_step + A.xoff;
+    const uint32_t wi0 = (uint32_t)(((int)(((long long)i * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + ((int)(xc >> 12) & 15) * 2 + (((int)(xc >> 16) + A.tx0) & 1));
+#pragma unroll
+    for (int ty = 0; ty < NY; ty++) wv[ty] = pairs4[wi0 + 32 * ty];
+  }
   // ---- the window: premultiplied pairs.  4-byte pixels whose window lies inside the row (uniform per workgroup) come four at a time, one 16-byte load -> two pairs
   const bool inside = CH == 4 && wx0 >= 0 && wx0 + 2 * A.wpairs <= A.sw && (wx0 & 3) == 0 && ((uintptr_t)A.src & 15) == 0 && (A.irow & 15) == 0 && (A.wpairs & 1) == 0;
   if (inside) {
@@ -966,12 +982,6 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
     }
   }
   __syncthreads();
-  const int j = j0 + lane;
-  const long long x = (long long)j * A.x_step + A.xoff;
-  const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15;
-  const bool edge = xs < 0 || xs + A.n_x > A.sw;
-  const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
-  const pb_u4 *pairs4 = reinterpret_cast<const pb_u4 *>(A.pairs);      // uniform base, 32-bit per-lane index: scalar-base addressing
   const bool quads3 = CH == 3 && (((uintptr_t)A.dst | (uintptr_t)A.orow) & 3) == 0;
   for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
     const int i = i0 + r_;
@@ -983,9 +993,14 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
     const uint32_t wi = (uint32_t)(yph * A.ny_eff * 32 + xph * 2 + par);       // [y phase][tap row][x phase][parity]: a wave's 64 vectors of one tap row lie within 512 nq bytes
     unsigned r = 0, g = 0, b = 0, a = 0;
     if (NPC && NY) {
-      pb_u4 wv[NY ? NY : 1];
+      // this row's vectors are in wv (requested before the window was staged, or during the previous row's taps); the next row's go out now
+      pb_u4 wn[NY ? NY : 1];
+      const bool more = r_ + 4 < A.tile_h && i + 4 < A.dh;
+      if (more) {
+        const uint32_t win = (uint32_t)(((int)(((long long)(i + 4) * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + xph * 2 + par);
 #pragma unroll
-      for (int ty = 0; ty < NY; ty++) wv[ty] = pairs4[wi + 32 * ty];
+        for (int ty = 0; ty < NY; ty++) wn[ty] = pairs4[win + 32 * ty];
+      }
 #pragma unroll
       for (int ty = 0; ty < NY; ty++) {
         const uint32_t wq[4] = {wv[ty].x, wv[ty].y, wv[ty].z, wv[ty].w};
@@ -995,6 +1010,13 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
           r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
           if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
         }
+        // long filters: a tap row's window reads stay next to its taps.  Left alone the compiler runs the alpha sums of all rows first and sinks the colour sums behind
+        // the alpha test of pb_finish_px: every window vector stays live (4 x 6 x 4 = 96 registers) and the occupancy goes from 8 waves to 3
+        if (NY >= 3) { asm volatile("" : "+v"(r), "+v"(g), "+v"(b), "+v"(a)); __builtin_amdgcn_sched_barrier(0); }
+      }
+      if (more) {
+#pragma unroll
+        for (int ty = 0; ty < NY; ty++) wv[ty] = wn[ty];
       }
     } else {
       for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
@@ -1852,7 +1874,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
     pa.wpairs = ((int)((((63LL * x_step + 65535) >> 16) + 1) / 2) + 4 * t->nq + 3 + 3) & ~3;       // whole quads of pairs, and wx0 is rounded down to a multiple of 4 below
 
     pa.tile_h = 0;
-    size_t lds_cap = 24 * 1024;                         // 6 workgroups per CU: the per-lane weight loads want occupancy more than the window wants rows (profiles/r03/pb_pairs_lds_sweep.txt)
+    size_t lds_cap = (tune(TUNE_PB_LDS_KB) > 0 ? (size_t)tune(TUNE_PB_LDS_KB) : 24) * 1024;     // 6 workgroups per CU: the per-lane weight loads want occupancy more than the window wants rows (profiles/r03/pb_pairs_lds_sweep.txt)
     for (int th = 16; th >= 1; th >>= 1) {
       const int wh = (int)(((long long)(th - 1) * y_step + 65535) >> 16) + pa.ny_eff + 1;
       if ((size_t)pa.wpairs * wh * 16 <= lds_cap) { pa.tile_h = th; pa.win_h = wh; break; }
@@ -1863,9 +1885,13 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       const int np = (t->tx1 - t->tx0 + 2) / 2;
 #define PB_PAIRS(CHN)                                                                                                     \
       { const int ny = t->ty1 - t->ty0;                                                                                   \
+        const bool pre = !tune_on(TUNE_PB_NO_PRE);                                                                          \
         if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa, F);                       \
         else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa, F);                  \
         else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa, F);                  \
+        else if (pre && np == 3 && ny == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 4>), g, block, lds, st, pa, F);           \
+        else if (pre && np == 3 && ny == 5) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 5>), g, block, lds, st, pa, F);           \
+        else if (pre && np == 4 && ny == 6) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 6>), g, block, lds, st, pa, F);           \
         else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0>), g, block, lds, st, pa, F);                             \
         else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0>), g, block, lds, st, pa, F);                             \
         else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0>), g, block, lds, st, pa, F);                             \
