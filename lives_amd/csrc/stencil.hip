@@ -23,6 +23,13 @@ __device__ __forceinline__ uint32_t isqrt24(uint32_t n) {
   return r;
 }
 
+// lo <= x <= hi as ONE v_med3_i32.  Written as two selects the compiler emits a compare, a v_cndmask_b32_e32 on vcc and a v_min per clamp, and that v_cndmask form
+// issues at less than a quarter of the rate of the other vector operations on gfx950 (tools/valu_rates2.hip): the two clamps were a quarter of this kernel's time
+__device__ __forceinline__ int sl_clamp(int x, int lo, int hi) {
+  int d;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(lo), "v"(hi));
+  return d;
+}
 // the planes that are only copied (softlight.c:143-151) ride in the same launch: blockIdx.z = 1 .. ncopy copies 64 x 16 tiles of plane z
 // batched (lgpu_fx_batch): blockIdx.z = frame * (n + 1) + plane, the frame's planes from the table
 struct SoftCopy { int irow[3], orow[3], w, h, n; };
@@ -85,9 +92,9 @@ __global__ __launch_bounds__(kBlock) void k_softlight(const FxFrames F, int irow
       const int row0 = (c[P - 1] - c[-P - 1]) + ((c[P] - c[-P]) << 1) + (c[P + 1] - c[P - 1]);
       const int row1 = (c[-P + 1] - c[-P - 1]) + ((c[1] - c[-1]) << 1) + (c[P + 1] + c[P - 1]);
       int sum = (int)(((3 * isqrt24((uint32_t)(row0 * row0 + row1 * row1)) / 2) * 384u) >> 8);
-      sum = sum < ymin ? ymin : sum > ymax ? ymax : sum;
+      sum = sl_clamp(sum, ymin, ymax);
       sum = (64 * sum + 192 * v) >> 8;
-      v = sum < ymin ? ymin : sum > ymax ? ymax : sum;
+      v = sl_clamp(sum, ymin, ymax);
     }
     out[j] = (uint8_t)v;
   }
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_softlight(const FxFrames F, int irow
 // v_dot2_i32_i16, the integer square root is the truncated float square root (exact for n < 2.3 M: checked exhaustively on the host, tests/test_host_cpu.py), and
 // (64 s + 192 v) >> 8 == (s + 3 v) >> 2.  57 -> ~22 vector operations per pixel; one 1080p 4:2:0 frame 6.2 -> see profiles/r04/ops_roofline.md.
 typedef short sl_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short sl_u2 __attribute__((ext_vector_type(2)));
 template <int RB>
 __global__ __launch_bounds__(kBlock) void k_softlight_s(const FxFrames F, int irow, int orow, int width, int height, int ymin, int ymax, SoftCopy cp) {
   const int frame = blockIdx.z / (cp.n + 1), plane = blockIdx.z - frame * (cp.n + 1);
@@ -150,13 +158,14 @@ __global__ __launch_bounds__(kBlock) void k_softlight_s(const FxFrames F, int ir
   const uint32_t xmask = (q == 0 ? 0x000000FFu : 0u) | (q == nq - 1 ? 0xFF000000u : 0u);
   auto pk = [](uint32_t v) -> sl_s2 { return __builtin_bit_cast(sl_s2, v); };
   auto un = [](sl_s2 v) -> uint32_t { return __builtin_bit_cast(uint32_t, v); };
+  const sl_u2 lo2 = {(unsigned short)ymin, (unsigned short)ymin}, hi2 = {(unsigned short)ymax, (unsigned short)ymax};
 #pragma unroll
   for (int r = 0; r < RB; r++) {
     if (r >= rows) break;
     const int y = y0 + r;
     uint32_t out = in[r + 1];
     if (y > 0 && y < height - 1) {                                  // uniform
-      uint32_t res[4];
+      uint32_t res2[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {                                 // h = 0: pixels 0 and 2, h = 1: pixels 1 and 3
         const sl_s2 AL = pk(h ? Lo[r] : Le[r]), AC = pk(h ? Co[r] : Ce[r]), AR = pk(h ? Ro[r] : Re[r]);
@@ -167,20 +176,18 @@ __global__ __launch_bounds__(kBlock) void k_softlight_s(const FxFrames F, int ir
         const sl_s2 row1 = (CR - CL) * (short)2 + (AR - AL) + (BR + BL);
         const uint32_t r0 = un(row0), r1 = un(row1);
         const uint32_t xa = __builtin_amdgcn_perm(r1, r0, 0x05040100u), xb = __builtin_amdgcn_perm(r1, r0, 0x07060302u);      // (row0, row1) of the pair's first / second pixel
-        const uint32_t cc = un(CC);
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-          const uint32_t xx = p ? xb : xa;
-          const uint32_t n = (uint32_t)__builtin_amdgcn_sdot2(pk(xx), pk(xx), 0, false);
-          const uint32_t sq = (uint32_t)__fsqrt_rn((float)n);
-          int sum = (int)((((3u * sq) >> 1) * 3u) >> 1);            // ((3 sq / 2) * 384) >> 8
-          sum = sum < ymin ? ymin : sum > ymax ? ymax : sum;
-          const int v = (int)((p ? cc >> 16 : cc) & 0xFFFFu);
-          sum = (sum + 3 * v) >> 2;                                  // (64 sum + 192 v) >> 8
-          res[2 * p + h] = (uint32_t)(sum < ymin ? ymin : sum > ymax ? ymax : sum);
-        }
+        // the two square roots one by one, everything after them on the pair in packed 16-bit lanes (sq <= 1660: 3 sq, (3 sq / 2) 3 and sum + 3 v all fit 16 bits)
+        const uint32_t n0 = (uint32_t)__builtin_amdgcn_sdot2(pk(xa), pk(xa), 0, false), n1 = (uint32_t)__builtin_amdgcn_sdot2(pk(xb), pk(xb), 0, false);
+        const uint32_t sq0 = (uint32_t)__fsqrt_rn((float)n0), sq1 = (uint32_t)__fsqrt_rn((float)n1);
+        sl_u2 t = __builtin_bit_cast(sl_u2, sq0 | (sq1 << 16));
+        t = (t * (unsigned short)3) >> (unsigned short)1;             // 3 sq / 2
+        t = (t * (unsigned short)3) >> (unsigned short)1;             // (.. * 384) >> 8
+        t = __builtin_elementwise_min(__builtin_elementwise_max(t, lo2), hi2);
+        t = (t + __builtin_bit_cast(sl_u2, CC) * (unsigned short)3) >> (unsigned short)2;      // (64 sum + 192 v) >> 8
+        t = __builtin_elementwise_min(__builtin_elementwise_max(t, lo2), hi2);
+        res2[h] = __builtin_bit_cast(uint32_t, t);
       }
-      const uint32_t calc = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+      const uint32_t calc = res2[0] | (res2[1] << 8);                // pixels (0, 2) | pixels (1, 3) << 8
       out = (calc & ~xmask) | (out & xmask);
     }
     if (out_lane) reinterpret_cast<uint32_t *>(dst + (size_t)y * orow)[q] = out;

@@ -58,6 +58,11 @@
 #define A_OR(i) "v_or_b32 %" #i ", %8, %" #i "\n"
 #define A_CNDMASK(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define A_CNDSGPR(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
+#define A_CNDE64VCC(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define A_BFI(i) "v_bfi_b32 %" #i ", %8, %9, %" #i "\n"
+#define A_MED3(i) "v_med3_i32 %" #i ", %" #i ", %8, %9\n"
+#define A_CMPCND(i) "v_cmp_gt_i32 vcc, %8, %" #i "\nv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
+#define A_CMPCNDS(i) "v_cmp_gt_i32 s[10:11], %8, %" #i "\nv_cndmask_b32_e64 %" #i ", %" #i ", %9, s[10:11]\n"
 #define A_FFBL(i) "v_ffbl_b32 %" #i ", %" #i "\n"
 #define A_PERM(i) "v_perm_b32 %" #i ", %8, %" #i ", %9\n"
 #define A_MAXU(i) "v_max_u32 %" #i ", %8, %" #i "\n"
@@ -79,7 +84,7 @@
 BODY32(add_u32, A_ADD) BODY32(mov_b32, A_MOV) BODY32(mad_u32_u24, A_MADU24) BODY32(mul_u32_u24, A_MULU24) BODY32(dpp_wave_shr, A_DPPSHR) BODY32(dpp_quad_perm, A_DPPQUAD)
 BODY32(dpp_row_shr, A_DPPROWSHR) BODY32(add_u32_sdwa, A_ADDSDWA) BODY32(dot2_u32_u16, A_DOT2U) BODY32(dot4_u32_u8, A_DOT4U) BODY32(lshl_or, A_LSHLOR) BODY32(and_or, A_ANDOR)
 BODY32(or3, A_OR3) BODY32(add3, A_ADD3) BODY32(add_lshl, A_ADDLSHL) BODY32(lshl_add, A_LSHLADD) BODY32(lshlrev, A_LSHL) BODY32(lshrrev, A_LSHR) BODY32(or_b32, A_OR)
-BODY32(cndmask, A_CNDMASK) BODY32(cndmask_sgpr, A_CNDSGPR) BODY32(ffbl, A_FFBL) BODY32(perm, A_PERM) BODY32(max_u32, A_MAXU) BODY32(pk_add_u16, A_PKADD) BODY32(pk_mad_u16, A_PKMAD) BODY32(pk_lshlrev_b16, A_PKLSHL)
+BODY32(cndmask, A_CNDMASK) BODY32(cndmask_sgpr, A_CNDSGPR) BODY32(cndmask_e64_vcc, A_CNDE64VCC) BODY32(bfi, A_BFI) BODY32(med3_i32, A_MED3) BODY32(cmp_cndmask_vcc_pair, A_CMPCND) BODY32(cmp_cndmask_sgpr_pair, A_CMPCNDS) BODY32(ffbl, A_FFBL) BODY32(perm, A_PERM) BODY32(max_u32, A_MAXU) BODY32(pk_add_u16, A_PKADD) BODY32(pk_mad_u16, A_PKMAD) BODY32(pk_lshlrev_b16, A_PKLSHL)
 BODY32(mul_u24_sdwa_preserve, A_MULSDWA) BODY32(fma_f32, A_FMAF32) BODY32(cvt_f32_u32, A_CVTF32U) BODY32(rcp_f32, A_RCPF32) BODY32(mul_hi_u32, A_MULHI)
 BODY64(fma_f64, D_FMA) BODY64(mul_f64, D_MUL) BODY64(add_f64, D_ADD) BODY64(rcp_f64, D_RCP)
 
@@ -116,7 +121,7 @@ int main(int argc, char **argv) {
   std::vector<Ent> ents = {
 #define E(n) {#n, k_##n}
       E(add_u32), E(mov_b32), E(mad_u32_u24), E(mul_u32_u24), E(dpp_wave_shr), E(dpp_quad_perm), E(dpp_row_shr), E(add_u32_sdwa), E(dot2_u32_u16), E(dot4_u32_u8),
-      E(lshl_or), E(and_or), E(or3), E(add3), E(add_lshl), E(lshl_add), E(lshlrev), E(lshrrev), E(or_b32), E(cndmask), E(cndmask_sgpr), E(ffbl), E(perm), E(max_u32), E(pk_add_u16), E(pk_mad_u16),
+      E(lshl_or), E(and_or), E(or3), E(add3), E(add_lshl), E(lshl_add), E(lshlrev), E(lshrrev), E(or_b32), E(cndmask), E(cndmask_sgpr), E(cndmask_e64_vcc), E(bfi), E(med3_i32), E(cmp_cndmask_vcc_pair), E(cmp_cndmask_sgpr_pair), E(ffbl), E(perm), E(max_u32), E(pk_add_u16), E(pk_mad_u16),
       E(pk_lshlrev_b16), E(mul_u24_sdwa_preserve), E(fma_f32), E(cvt_f32_u32), E(rcp_f32), E(mul_hi_u32), E(fma_f64), E(mul_f64), E(add_f64), E(rcp_f64), E(cvt_f64_u32), E(cvt_i32_f64)};
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
