@@ -483,13 +483,17 @@ int lgpu_stepper_destroy(lgpu_stepper *s);
      LGPU_FX_YUV411_TO_RGB  in0[0], out[0]; width = macropixels, height, orow[0]; ip[0] = out_order, ip[1] = out_alpha, ip[2] = unclamped      (lgpu_yuv411_to_rgb)
      LGPU_FX_GAUSS5_COLORKEY in0[0], in1[0], out[0]; irow0[0], irow1[0], orow[0], width, height; ip[0] = psize, ip[1] = is_bgr, ip[2] = key colour r | g << 8 | b << 16,
                             dp[0] = delta, dp[1] = opacity  (lgpu_gauss5_colorkey: BASELINE config 4 in one launch; LGPU_E_UNSUPPORTED outside its alignment range)
+     LGPU_FX_BLEND_CHROMA   in0[0], in1[0], out[0] (out may be in0: in place); irow0[0], irow1[0], orow[0], width, height; ip[0] = psize, ip[1] = 0 (ARGB32: lgpu_blend_chroma),
+                            dp[0] = blend amount, or frame_dp0[f]   (lgpu_blend_chroma)
+     LGPU_FX_BLEND_LUMA     as above; ip[0] = type 1..4, ip[1] = psize, ip[2] = pal_order; dp[0] / frame_dp0[f] = threshold   (lgpu_blend_luma)
+     LGPU_FX_BLEND_MULTI    as above, 3-byte pixels; ip[0] = type 0..6, ip[1] = is_bgr; dp[0] / frame_dp0[f] = blend amount   (lgpu_blend_multi)
    The scaler has its own batch entry (lgpu_pixbuf_scale_batch), the palette conversion K2 lgpu_yuv420p_to_rgb_batch, the chain takes its tracks directly.  The
    compositor (lgpu_composite) IS the fan-in of a tick's tracks into one frame: a tick has one of it, there is nothing to batch. */
 #define LGPU_FX_MAX_FRAMES 16
-enum { LGPU_FX_SOFTLIGHT = 1, LGPU_FX_TRANSITION = 2, LGPU_FX_YUV411_TO_RGB = 3, LGPU_FX_GAUSS5_COLORKEY = 4 };
+enum { LGPU_FX_SOFTLIGHT = 1, LGPU_FX_TRANSITION = 2, LGPU_FX_YUV411_TO_RGB = 3, LGPU_FX_GAUSS5_COLORKEY = 4, LGPU_FX_BLEND_CHROMA = 5, LGPU_FX_BLEND_LUMA = 6, LGPU_FX_BLEND_MULTI = 7 };
 typedef struct { const uint8_t *in0[4]; const uint8_t *in1[4]; uint8_t *out[4]; } lgpu_fx_frame;
 typedef struct { int op, width, height, palette; int irow0[4], irow1[4], orow[4]; int ip[4]; double dp[2];
-                 const double *frame_dp0; /* NULL, or nframes values that replace dp[0] frame by frame (LGPU_FX_TRANSITION; BADARG for the other ops) */ } lgpu_fx_params;
+                 const double *frame_dp0; /* NULL, or nframes values that replace dp[0] frame by frame (the transitions and the blends; BADARG for the other ops) */ } lgpu_fx_params;
 int lgpu_fx_batch(const lgpu_fx_params *params, const lgpu_fx_frame *frames, int nframes, void *stream);
 
 /* ---- compositor fan-in (SURVEY 8f "next" 1): lives-plugins/weed-plugins/gdk/compositor.c:120-125 (paint_pixel),

@@ -60,10 +60,19 @@ struct Frames2 {
   int inplace;   // dst == s1
 };
 
+// the frames of one launch (blockIdx.z): the planes and the functor -- i.e. the parameters -- of each; geometry, rowstrides and alignment class are shared (Frames2)
+template <class F>
+struct Pix2Batch {
+  const uint8_t *s1[LGPU_FX_MAX_FRAMES], *s2[LGPU_FX_MAX_FRAMES];
+  uint8_t *dst[LGPU_FX_MAX_FRAMES];
+  F fn[LGPU_FX_MAX_FRAMES];
+};
 // F(p1, p2, pdst) -> output pixel dword.  pdst is only loaded when F::kNeedsDst && !inplace.
 template <int PS, class F>
-__global__ __launch_bounds__(kBlock) void k_pixel2(Frames2 f, F fn) {
+__global__ __launch_bounds__(kBlock) void k_pixel2(Frames2 f, const Pix2Batch<F> B) {
   __shared__ int32_t s_scratch[768];
+  f.s1 = B.s1[blockIdx.z]; f.s2 = B.s2[blockIdx.z]; f.dst = B.dst[blockIdx.z]; f.inplace = f.s1 == f.dst;
+  F fn = B.fn[blockIdx.z];
   fn.setup(s_scratch);
   const int groups = f.width >> 2;
   const int g = blockIdx.x * kBlock + threadIdx.x;
@@ -336,63 +345,104 @@ static int fill_frames(Frames2 &f, const uint8_t *s1, int r1, const uint8_t *s2,
 
 using namespace lgpu;
 
+// nframes frames of one geometry through k_pixel2: the frame table of a launch, the alignment class over ALL frames
+template <int PS, class F>
+static int pixel2_launch(const FxFrames &X, int nframes, const F *fns, int r1, int r2, int ro, int width, int height, hipStream_t st) {
+  LGPU_REQUIRE(nframes >= 1 && nframes <= LGPU_FX_MAX_FRAMES, "1..LGPU_FX_MAX_FRAMES frames");
+  Frames2 f;
+  Pix2Batch<F> B = {};
+  int vec = 1;
+  for (int k = 0; k < nframes; k++) {
+    Frames2 one;
+    int rc = fill_frames(one, X.in0[k][0], r1, X.in1[k][0], r2, X.out[k][0], ro, width, height, PS);
+    if (rc) return rc;
+    vec &= one.vec;
+    f = one;
+    B.s1[k] = one.s1; B.s2[k] = one.s2; B.dst[k] = one.dst; B.fn[k] = fns[k];
+  }
+  f.vec = vec; f.s1 = f.s2 = nullptr; f.dst = nullptr; f.inplace = 0;        // per frame: the kernel takes them from the table
+  dim3 g = row_grid2((unsigned)(width >> 2) + 1, height);
+  g.z = (unsigned)nframes;
+  hipLaunchKernelGGL((k_pixel2<PS, F>), g, dim3(kBlock), 0, st, f, B);
+  LGPU_CHECK_LAUNCH();
+  return LGPU_OK;
+}
+
+int lgpu::blend_chroma_n(const FxFrames &X, int nframes, int irow1, int irow2, int orow, int width, int height, int psize, const int *bf, hipStream_t st) {
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(bf && nframes >= 1 && nframes <= LGPU_FX_MAX_FRAMES, "1..LGPU_FX_MAX_FRAMES frames, a blend amount each");
+  if (psize == 4) {
+    ChromaBlend<4> fn[LGPU_FX_MAX_FRAMES];
+    for (int k = 0; k < nframes; k++) { const uint32_t b = (uint32_t)bf[k] & 0xFF; fn[k] = ChromaBlend<4>{b, 0xFF - b}; }
+    return pixel2_launch<4>(X, nframes, fn, irow1, irow2, orow, width, height, st);
+  }
+  ChromaBlend<3> fn[LGPU_FX_MAX_FRAMES];
+  for (int k = 0; k < nframes; k++) { const uint32_t b = (uint32_t)bf[k] & 0xFF; fn[k] = ChromaBlend<3>{b, 0xFF - b}; }
+  return pixel2_launch<3>(X, nframes, fn, irow1, irow2, orow, width, height, st);
+}
+
 extern "C" int lgpu_blend_chroma(const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
                                  int orow, int width, int height, int psize, int alpha_first, int bf, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
-  Frames2 f;
-  if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, psize))) return rc;
-  const uint32_t b = (uint32_t)bf & 0xFF, nb = 0xFF - b;
   hipStream_t st = (hipStream_t)stream;
   if (psize == 4 && alpha_first) {
+    Frames2 f;
+    if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, psize))) return rc;
+    const uint32_t b = (uint32_t)bf & 0xFF, nb = 0xFF - b;
     hipLaunchKernelGGL(k_chroma_argb, row_grid2((unsigned)width, height), dim3(kBlock), 0, st, f, b, nb);
-  } else if (psize == 4) {
-    ChromaBlend<4> fn{b, nb};
-    hipLaunchKernelGGL((k_pixel2<4, ChromaBlend<4>>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, st, f, fn);
-  } else {
-    ChromaBlend<3> fn{b, nb};
-    hipLaunchKernelGGL((k_pixel2<3, ChromaBlend<3>>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, st, f, fn);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
   }
-  LGPU_CHECK_LAUNCH();
-  return LGPU_OK;
+  FxFrames X = {};
+  X.in0[0][0] = src1_d; X.in1[0][0] = src2_d; X.out[0][0] = dst_d;
+  return blend_chroma_n(X, 1, irow1, irow2, orow, width, height, psize, &bf, st);
+}
+
+int lgpu::blend_luma_n(const FxFrames &X, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, int pal_order, const int *thresh, hipStream_t st) {
+  LGPU_REQUIRE(type >= 1 && type <= 4, "type must be 1..4");
+  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
+  LGPU_REQUIRE(pal_order == 0 || pal_order == 1, "ARGB32 luma blends: use pal_order 0/1 after a swapprepost (reference ARGB path reads across pixels)");
+  LGPU_REQUIRE(thresh && nframes >= 1 && nframes <= LGPU_FX_MAX_FRAMES, "1..LGPU_FX_MAX_FRAMES frames, a threshold each");
+  LumaBlend fn[LGPU_FX_MAX_FRAMES];
+  for (int k = 0; k < nframes; k++) {
+    fn[k].t.gl = device_tables()->luma; fn[k].t.s = nullptr;
+    fn[k].type = type; fn[k].order = pal_order; fn[k].ps = psize; fn[k].bf = (uint32_t)thresh[k] & 0xFF; fn[k].neg = 0xFF - fn[k].bf;
+  }
+  if (psize == 4) return pixel2_launch<4>(X, nframes, fn, irow1, irow2, orow, width, height, st);
+  return pixel2_launch<3>(X, nframes, fn, irow1, irow2, orow, width, height, st);
 }
 
 extern "C" int lgpu_blend_luma(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
                                int orow, int width, int height, int psize, int pal_order, int thresh, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(type >= 1 && type <= 4, "type must be 1..4");
-  LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
-  LGPU_REQUIRE(pal_order == 0 || pal_order == 1, "ARGB32 luma blends: use pal_order 0/1 after a swapprepost (reference ARGB path reads across pixels)");
-  Frames2 f;
-  if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, psize))) return rc;
-  LumaBlend fn;
-  fn.t.gl = device_tables()->luma; fn.t.s = nullptr;
-  fn.type = type; fn.order = pal_order; fn.ps = psize; fn.bf = (uint32_t)thresh & 0xFF; fn.neg = 0xFF - fn.bf;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid = row_grid2((unsigned)(width >> 2) + 1, height);
-  if (psize == 4) hipLaunchKernelGGL((k_pixel2<4, LumaBlend>), grid, dim3(kBlock), 0, st, f, fn);
-  else hipLaunchKernelGGL((k_pixel2<3, LumaBlend>), grid, dim3(kBlock), 0, st, f, fn);
-  LGPU_CHECK_LAUNCH();
-  return LGPU_OK;
+  FxFrames X = {};
+  X.in0[0][0] = src1_d; X.in1[0][0] = src2_d; X.out[0][0] = dst_d;
+  return blend_luma_n(X, 1, type, irow1, irow2, orow, width, height, psize, pal_order, &thresh, (hipStream_t)stream);
+}
+
+int lgpu::blend_multi_n(const FxFrames &X, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int is_bgr, const int *bf, hipStream_t st) {
+  LGPU_REQUIRE(type >= 0 && type <= 6, "type must be 0..6");
+  LGPU_REQUIRE(bf && nframes >= 1 && nframes <= LGPU_FX_MAX_FRAMES, "1..LGPU_FX_MAX_FRAMES frames, a blend amount each");
+  MultiBlend fn[LGPU_FX_MAX_FRAMES];
+  for (int k = 0; k < nframes; k++) {
+    fn[k].t.gl = device_tables()->luma; fn[k].t.s = nullptr;
+    fn[k].type = type; fn[k].order = is_bgr ? 1 : 0;
+    const uint8_t ff = (uint8_t)bf[k];
+    fn[k].f = ff; fn[k].b1 = (uint8_t)(ff * 2); fn[k].n1 = (uint8_t)(255 - ff * 2); fn[k].b2 = (uint8_t)((255 - ff) * 2); fn[k].n2 = (uint8_t)((ff - 128) * 2);
+  }
+  return pixel2_launch<3>(X, nframes, fn, irow1, irow2, orow, width, height, st);
 }
 
 extern "C" int lgpu_blend_multi(int type, const uint8_t *src1_d, int irow1, const uint8_t *src2_d, int irow2, uint8_t *dst_d,
                                 int orow, int width, int height, int is_bgr, int bf, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(type >= 0 && type <= 6, "type must be 0..6");
-  Frames2 f;
-  if ((rc = fill_frames(f, src1_d, irow1, src2_d, irow2, dst_d, orow, width, height, 3))) return rc;
-  MultiBlend fn;
-  fn.t.gl = device_tables()->luma; fn.t.s = nullptr;
-  fn.type = type; fn.order = is_bgr ? 1 : 0;
-  const uint8_t ff = (uint8_t)bf;
-  fn.f = ff; fn.b1 = (uint8_t)(ff * 2); fn.n1 = (uint8_t)(255 - ff * 2); fn.b2 = (uint8_t)((255 - ff) * 2); fn.n2 = (uint8_t)((ff - 128) * 2);
-  hipLaunchKernelGGL((k_pixel2<3, MultiBlend>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, (hipStream_t)stream, f, fn);
-  LGPU_CHECK_LAUNCH();
-  return LGPU_OK;
+  FxFrames X = {};
+  X.in0[0][0] = src1_d; X.in1[0][0] = src2_d; X.out[0][0] = dst_d;
+  return blend_multi_n(X, 1, type, irow1, irow2, orow, width, height, is_bgr, &bf, (hipStream_t)stream);
 }
 
 extern "C" int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow,
@@ -415,9 +465,9 @@ extern "C" int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *sr
   fn.gmax = col_g + (int)((255 - col_g) * xdelta + .5);
   fn.bmax = col_b + (int)((255 - col_b) * delta + .5);
   fn.order = is_bgr ? 1 : 0; fn.opac = opac; fn.opacx = 1. - opac;
-  hipLaunchKernelGGL((k_pixel2<3, ColorKey>), row_grid2((unsigned)(width >> 2) + 1, height), dim3(kBlock), 0, (hipStream_t)stream, f, fn);
-  LGPU_CHECK_LAUNCH();
-  return LGPU_OK;
+  FxFrames X = {};
+  X.in0[0][0] = src0_d; X.in1[0][0] = src1_d; X.out[0][0] = dst_d;
+  return pixel2_launch<3>(X, 1, &fn, irow0, irow1, orow, width, height, (hipStream_t)stream);
 }
 
 extern "C" int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize,
@@ -809,7 +859,8 @@ extern "C" int lgpu_fx_batch(const lgpu_fx_params *p, const lgpu_fx_frame *frame
   for (int f = 0; f < nframes; f++)
     for (int k = 0; k < 4; k++) { F.in0[f][k] = frames[f].in0[k]; F.in1[f][k] = frames[f].in1[k]; F.out[f][k] = frames[f].out[k]; }
   hipStream_t st = (hipStream_t)stream;
-  LGPU_REQUIRE(!p->frame_dp0 || p->op == LGPU_FX_TRANSITION, "frame_dp0 (a value per frame) is taken by LGPU_FX_TRANSITION only");
+  LGPU_REQUIRE(!p->frame_dp0 || p->op == LGPU_FX_TRANSITION || p->op == LGPU_FX_BLEND_CHROMA || p->op == LGPU_FX_BLEND_LUMA || p->op == LGPU_FX_BLEND_MULTI,
+               "frame_dp0 (a value per frame) is taken by the transitions and the blends only");
   switch (p->op) {
   case LGPU_FX_SOFTLIGHT: return softlight_n(F, nframes, p->irow0, p->orow, p->width, p->height, p->palette, p->ip[0], st);
   case LGPU_FX_TRANSITION: {
@@ -820,6 +871,16 @@ extern "C" int lgpu_fx_batch(const lgpu_fx_params *p, const lgpu_fx_frame *frame
   case LGPU_FX_YUV411_TO_RGB: return yuv411_to_rgb_n(F, nframes, p->width, p->height, p->orow[0], p->ip[0], p->ip[1], p->ip[2], st);
   case LGPU_FX_GAUSS5_COLORKEY: return gauss5_colorkey_n(F, nframes, p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[0], p->ip[1], p->dp[0], p->dp[1], p->ip[2] & 0xFF,
                                                          (p->ip[2] >> 8) & 0xFF, (p->ip[2] >> 16) & 0xFF, st);
+  case LGPU_FX_BLEND_CHROMA: case LGPU_FX_BLEND_LUMA: case LGPU_FX_BLEND_MULTI: {
+    int v[LGPU_FX_MAX_FRAMES];
+    for (int f = 0; f < nframes; f++) v[f] = (int)(p->frame_dp0 ? p->frame_dp0[f] : p->dp[0]);
+    if (p->op == LGPU_FX_BLEND_CHROMA) {
+      LGPU_REQUIRE(!p->ip[1], "ARGB32 (alpha first) is served by lgpu_blend_chroma frame by frame");
+      return blend_chroma_n(F, nframes, p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[0], v, st);
+    }
+    if (p->op == LGPU_FX_BLEND_LUMA) return blend_luma_n(F, nframes, p->ip[0], p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[1], p->ip[2], v, st);
+    return blend_multi_n(F, nframes, p->ip[0], p->irow0[0], p->irow1[0], p->orow[0], p->width, p->height, p->ip[1], v, st);
+  }
   default: set_error("lgpu_fx_batch: unknown op %d", p->op); return LGPU_E_BADARG;
   }
 }

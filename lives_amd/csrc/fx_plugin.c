@@ -440,14 +440,25 @@ PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(
 /* ---- several instances of one filter class in ONE launch (an extension of this plugin, not of the weed API; a host finds it with dlsym) ----
    The reference applies the effects of a plan step one instance after another (src/effects-weed.c:1563-1758 per instance), and a 640x360 frame is a
    ramp-and-drain bound launch on 256 CUs: n instances of the same class on frames of one geometry go out as one lgpu_fx_batch launch (include/lives_gpu.h).
-   Batched today: the three transitions of multi_transitions.c ("iris rectangle", "iris circle", "4 way split"), each instance with its own "amount";
+   Batched today: the three transitions of multi_transitions.c ("iris rectangle", "iris circle", "4 way split"), the five blends of simple_blend.c and the seven of
+   multi_blends.c (ARGB32 frames excepted), each instance with its own amount / threshold;
    any other class, mixed classes, mixed geometry, sliced channels or more than LGPU_FX_MAX_FRAMES instances fall back to process_func per instance, so the
    result is the same either way.  Channels on pinned layers are used where they live (no copy, no wait), the others are staged as fx_run does. */
-static int batch_kind(weed_plant_t *inst) {
+/* the classes with a batch kernel: op of lgpu_fx_batch, its `kind`, and whether parameter 0 (the one value an instance adds to the launch) is an integer */
+typedef struct { int op, kind, int_param, two_in; } batch_class_t;
+static int batch_class(weed_plant_t *inst, batch_class_t *bc) {
+  static const struct { weed_process_f f; batch_class_t c; } tab[] = {
+    {p_irisr, {LGPU_FX_TRANSITION, 0, 0, 1}}, {p_irisc, {LGPU_FX_TRANSITION, 1, 0, 1}}, {p_fourw, {LGPU_FX_TRANSITION, 2, 0, 1}},
+    {p_chroma, {LGPU_FX_BLEND_CHROMA, 0, 1, 1}},
+    {p_lumo, {LGPU_FX_BLEND_LUMA, 1, 1, 1}}, {p_lumu, {LGPU_FX_BLEND_LUMA, 2, 1, 1}}, {p_nlumo, {LGPU_FX_BLEND_LUMA, 3, 1, 1}}, {p_avlumo, {LGPU_FX_BLEND_LUMA, 4, 1, 1}},
+    {p_mpy, {LGPU_FX_BLEND_MULTI, 0, 1, 1}}, {p_screen, {LGPU_FX_BLEND_MULTI, 1, 1, 1}}, {p_darken, {LGPU_FX_BLEND_MULTI, 2, 1, 1}}, {p_lighten, {LGPU_FX_BLEND_MULTI, 3, 1, 1}},
+    {p_overlay, {LGPU_FX_BLEND_MULTI, 4, 1, 1}}, {p_dodge, {LGPU_FX_BLEND_MULTI, 5, 1, 1}}, {p_burn, {LGPU_FX_BLEND_MULTI, 6, 1, 1}},
+  };
   weed_plant_t *fc = (weed_plant_t *)g_ptr(inst, WEED_LEAF_FILTER_CLASS, 0);
   weed_process_f pf = NULL;
-  if (!fc || w_get(fc, WEED_LEAF_PROCESS_FUNC, 0, &pf) != WEED_SUCCESS) return -1;
-  return pf == p_irisr ? 0 : pf == p_irisc ? 1 : pf == p_fourw ? 2 : -1;
+  if (!fc || w_get(fc, WEED_LEAF_PROCESS_FUNC, 0, &pf) != WEED_SUCCESS) return 0;
+  for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++) if (tab[i].f == pf) { *bc = tab[i].c; return 1; }
+  return 0;
 }
 static weed_error_t batch_fallback(weed_plant_t **insts, int n, weed_timecode_t tc) {
   weed_error_t ret = WEED_SUCCESS;
@@ -466,17 +477,17 @@ weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecod
   lgpu_fx_params P;
   const void *rel[LGPU_FX_MAX_FRAMES][3];
   uint8_t *hdst[LGPU_FX_MAX_FRAMES], *ddst[LGPU_FX_MAX_FRAMES];
-  int kind, i, c, w = 0, h = 0, pal = 0, irow[2] = {0, 0}, orow = 0, psize, home = 0, uploaded = 0, krc;
+  batch_class_t bc, bci;
+  int i, c, w = 0, h = 0, pal = 0, irow[2] = {0, 0}, orow = 0, psize, home = 0, uploaded = 0, krc;
   double amounts[LGPU_FX_MAX_FRAMES];
   weed_error_t ret = WEED_SUCCESS;
   if (!insts || n <= 0) return WEED_ERROR_FILTER_INVALID;
   for (i = 0; i < n; i++) if (!insts[i]) return WEED_ERROR_FILTER_INVALID;
-  kind = batch_kind(insts[0]);
-  if (kind < 0 || n > LGPU_FX_MAX_FRAMES || n == 1) return batch_fallback(insts, n, tc);
+  if (!batch_class(insts[0], &bc) || n > LGPU_FX_MAX_FRAMES || n == 1) return batch_fallback(insts, n, tc);
   for (i = 0; i < n; i++) {
     weed_plant_t *oc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0), *pa = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_PARAMETERS, 0);
-    amounts[i] = pa ? g_dbl(pa, WEED_LEAF_VALUE, 0.) : 0.;
-    if (batch_kind(insts[i]) != kind || !oc || has(oc, WEED_LEAF_OFFSET) || w_nelems(oc, WEED_LEAF_HEIGHT) > 1) return batch_fallback(insts, n, tc);
+    amounts[i] = !pa ? (bc.int_param ? 128. : 0.) : bc.int_param ? (double)g_int(pa, WEED_LEAF_VALUE, 0, 128) : g_dbl(pa, WEED_LEAF_VALUE, 0.);
+    if (!batch_class(insts[i], &bci) || bci.op != bc.op || bci.kind != bc.kind || !oc || has(oc, WEED_LEAF_OFFSET) || w_nelems(oc, WEED_LEAF_HEIGHT) > 1) return batch_fallback(insts, n, tc);
     if (i == 0) {
       w = g_int(oc, WEED_LEAF_WIDTH, 0, 0); h = g_int(oc, WEED_LEAF_HEIGHT, 0, 0); pal = g_int(oc, WEED_LEAF_CURRENT_PALETTE, 0, 0);
       orow = g_int(oc, WEED_LEAF_ROWSTRIDES, 0, 0);
@@ -492,6 +503,7 @@ weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecod
   }
   psize = psize_of(pal);
   if (!psize || w <= 0 || h <= 0) return WEED_ERROR_FILTER_INVALID;
+  if (bc.op != LGPU_FX_TRANSITION && (pal == WEED_PALETTE_ARGB32 || (bc.op == LGPU_FX_BLEND_MULTI && psize != 3))) return batch_fallback(insts, n, tc);   /* as k_simple / k_multi serve them */
   if (lgpu_init(0) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
   memset(fr, 0, sizeof fr); memset(rel, 0, sizeof rel);
   for (i = 0; i < n && ret == WEED_SUCCESS; i++) {
@@ -532,9 +544,13 @@ weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecod
   krc = LGPU_OK;
   if (ret == WEED_SUCCESS) {
     memset(&P, 0, sizeof P);
-    P.op = LGPU_FX_TRANSITION; P.width = w; P.height = h;
+    P.op = bc.op; P.width = w; P.height = h;
     P.irow0[0] = irow[0]; P.irow1[0] = irow[1]; P.orow[0] = orow;
-    P.ip[0] = kind; P.ip[1] = psize; P.frame_dp0 = amounts;
+    P.frame_dp0 = amounts;
+    if (bc.op == LGPU_FX_TRANSITION) { P.ip[0] = bc.kind; P.ip[1] = psize; }
+    else if (bc.op == LGPU_FX_BLEND_CHROMA) { P.ip[0] = psize; P.ip[1] = 0; }
+    else if (bc.op == LGPU_FX_BLEND_LUMA) { P.ip[0] = bc.kind; P.ip[1] = psize; P.ip[2] = (pal == WEED_PALETTE_BGR24 || pal == WEED_PALETTE_BGRA32) ? 1 : 0; }
+    else { P.ip[0] = bc.kind; P.ip[1] = pal == WEED_PALETTE_BGR24; }
     krc = lgpu_fx_batch(&P, fr, n, FXS);
   }
   for (i = 0; i < n; i++) { lives_gpu_resident_release(rel[i][0], 1); lives_gpu_resident_release(rel[i][1], 0); lives_gpu_resident_release(rel[i][2], 0); }

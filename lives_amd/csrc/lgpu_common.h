@@ -54,6 +54,9 @@ struct FxFrames {
 };
 // the batched forms behind the single-frame entry points and lgpu_fx_batch (argument checks included; ensure_init() is the caller's)
 int softlight_n(const FxFrames &F, int nframes, const int irow[4], const int orow[4], int width, int height, int palette, int unclamped, hipStream_t st);
+int blend_chroma_n(const FxFrames &X, int nframes, int irow1, int irow2, int orow, int width, int height, int psize, const int *bf, hipStream_t st);
+int blend_luma_n(const FxFrames &X, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, int pal_order, const int *thresh, hipStream_t st);
+int blend_multi_n(const FxFrames &X, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int is_bgr, const int *bf, hipStream_t st);
 int transition_n(const FxFrames &F, int nframes, int type, int irow1, int irow2, int orow, int width, int height, int psize, const double *amounts, hipStream_t st);
 int gauss5_colorkey_n(const FxFrames &F, int nframes, int irow0, int irow1, int orow, int width, int height, int psize, int is_bgr, double delta, double opac,
                       int col_r, int col_g, int col_b, hipStream_t st);

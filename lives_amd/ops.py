@@ -264,7 +264,7 @@ def softlight(src_planes, dst_planes, width, height, palette, unclamped):
              palette, int(unclamped), stream_ptr())
 
 
-FX_SOFTLIGHT, FX_TRANSITION, FX_YUV411_TO_RGB, FX_GAUSS5_COLORKEY = 1, 2, 3, 4
+FX_SOFTLIGHT, FX_TRANSITION, FX_YUV411_TO_RGB, FX_GAUSS5_COLORKEY, FX_BLEND_CHROMA, FX_BLEND_LUMA, FX_BLEND_MULTI = 1, 2, 3, 4, 5, 6, 7
 
 
 def fx_batch(op, ins0, outs, width, height, ins1=None, palette=0, ip=(0, 0, 0, 0), dp=(0., 0.), frame_dp0=None):

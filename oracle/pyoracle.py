@@ -192,7 +192,7 @@ class RefHost:
         self.H.refhost_run_planar.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, vp, vp, vp, ci]
         self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
         self.H.refhost_run_compositor.argtypes = [vp, ctypes.c_char_p, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci]
-        self.H.refhost_run_batch.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, vp]
+        self.H.refhost_run_batch.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
         self.H.refhost_set_yuv_clamping.argtypes = [ci]
         self.H.refhost_set_random_seed.argtypes = [ctypes.c_int64]
         self.plugins = {}
@@ -256,7 +256,7 @@ class RefHost:
             raise RuntimeError("weed filter 'compositor' returned %d" % r)
         return dst
 
-    def run_batch(self, path, fname, pal, w, h, srcs1, srcs2, dsts, amounts, hook=None):
+    def run_batch(self, path, fname, pal, w, h, srcs1, srcs2, dsts, amounts, hook=None, int_param=False):
         """n instances of one transition class (a frame pair and an amount each): process_func per instance, or one call of the plugin's
         batch hook (hook = the symbol's name in the plugin, e.g. "livesgpu_fx_process_batch")"""
         hdl = self.load(path)
@@ -266,7 +266,7 @@ class RefHost:
         if hook:
             fn = ctypes.cast(getattr(ctypes.CDLL(path), hook), vp)
         r = self.H.refhost_run_batch(hdl, fname.encode(), pal, w, h, n, arr(srcs1), srcs1[0].strides[0], arr(srcs2), srcs2[0].strides[0],
-                                     arr(dsts), dsts[0].strides[0], (cd * n)(*[float(a) for a in amounts]), fn)
+                                     arr(dsts), dsts[0].strides[0], (cd * n)(*[float(a) for a in amounts]), int(int_param), fn)
         if r != 0:
             raise RuntimeError("weed filter '%s' (batch of %d) returned %d" % (fname, n, r))
         return dsts

@@ -391,7 +391,7 @@ int refhost_run_seq(void *pinfo_v, const char *fname, int pal, int w, int h, int
  * src1[i] / src2[i] / dst[i]: the planes of instance i (dst[i] may alias src1[i]). */
 typedef weed_error_t (*refhost_batch_f)(weed_plant_t **, int, weed_timecode_t);
 int refhost_run_batch(void *pinfo_v, const char *fname, int pal, int w, int h, int n, uint8_t **src1, int istride1, uint8_t **src2, int istride2,
-                      uint8_t **dst, int ostride, const double *amounts, void *batch_hook) {
+                      uint8_t **dst, int ostride, const double *amounts, int int_param, void *batch_hook) {
   weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
   weed_plant_t *filt = find_filter(pinfo, fname);
   weed_plant_t *inst[64], *in1[64], *in2[64], *outc[64], *par[64], **ictm, **octm, **iptm;
@@ -419,7 +419,8 @@ int refhost_run_batch(void *pinfo_v, const char *fname, int pal, int w, int h, i
     weed_set_plantptr_value(inst[i], WEED_LEAF_OUT_CHANNELS, outc[i]);
     par[i] = weed_plant_new(WEED_PLANT_PARAMETER);
     weed_set_plantptr_value(par[i], WEED_LEAF_TEMPLATE, iptm[0]);
-    weed_set_double_value(par[i], WEED_LEAF_VALUE, amounts[i]);
+    if (int_param) weed_set_int_value(par[i], WEED_LEAF_VALUE, (int)amounts[i]);
+    else weed_set_double_value(par[i], WEED_LEAF_VALUE, amounts[i]);
     weed_set_plantptr_value(inst[i], WEED_LEAF_IN_PARAMETERS, par[i]);
   }
   for (ninit = 0; ninit < n && ret == WEED_SUCCESS; ninit++)

@@ -79,6 +79,43 @@ def test_transition_batch(gpu, orc, kind, psize):
         assert (host(outs[f])[:h] == want).all(), "frame %d, amount %r" % (f, amts[f])
 
 
+@pytest.mark.parametrize("fam", ["chroma3", "chroma4", "luma", "multi"])
+def test_blend_batches(gpu, orc, fam):
+    """the two-input blends of simple_blend.c / multi_blends.c, n frames with an amount each in one launch (k_pixel2's frame table), out of place and in place"""
+    rng = np.random.default_rng(0xB300 + len(fam))
+    w, h = 133, 37
+    cases = {"chroma3": [(gpu.FX_BLEND_CHROMA, 3, (3, 0))], "chroma4": [(gpu.FX_BLEND_CHROMA, 4, (4, 0))],
+             "luma": [(gpu.FX_BLEND_LUMA, ps, (t, ps, o)) for t in (1, 2, 3, 4) for ps, o in ((3, 0), (4, 1))],
+             "multi": [(gpu.FX_BLEND_MULTI, 3, (t, t & 1)) for t in range(7)]}[fam]
+    for op, ps, ip in cases:
+        for n, inplace in ((1, False), (5, False), (16, True)):
+            stride = align(w * ps, 16)
+            s1 = [rng.integers(0, 256, (h, stride), dtype=np.uint8) for _ in range(n)]
+            s2 = [rng.integers(0, 256, (h, stride), dtype=np.uint8) for _ in range(n)]
+            if ps == 4:
+                for a in s2:
+                    a[:, 3::4][rng.random((h, stride // 4)) < 0.5] = 255
+            amts = [int(v) for v in rng.integers(0, 256, n)]
+            amts[0] = 255
+            pre = [rng.integers(0, 256, (h + 1, stride), dtype=np.uint8) for _ in range(n)]      # the chroma blend leaves the destination's alpha byte as it is
+            d1, d2 = [dev(a) for a in s1], [dev(a) for a in s2]
+            outs = d1 if inplace else [dev(a) for a in pre]
+            gpu.fx_batch(op, [[t] for t in d1], [[t] for t in outs], w, h, ins1=[[t] for t in d2], ip=ip, dp=(77.,), frame_dp0=amts)
+            for f in range(n):
+                want = s1[f].copy() if inplace else pre[f][:h].copy()
+                src1 = want if inplace else s1[f]
+                if op == gpu.FX_BLEND_CHROMA:
+                    orc.orc_blend_chroma(P(src1), stride, P(s2[f]), stride, P(want), stride, w, h, ps, 0, amts[f])
+                elif op == gpu.FX_BLEND_LUMA:
+                    orc.orc_blend_luma(ip[0], P(src1), stride, P(s2[f]), stride, P(want), stride, w, h, ps, ip[2], amts[f], int(inplace))
+                else:
+                    orc.orc_blend_multi(ip[0], P(src1), stride, P(s2[f]), stride, P(want), stride, w, h, ip[1], amts[f])
+                got = host(outs[f])
+                assert (got[:h, :w * ps] == want[:, :w * ps]).all(), (fam, ip, n, inplace, f)
+                if not inplace:
+                    assert (got[h] == pre[f][h]).all() and (got[:h, w * ps:] == pre[f][:h, w * ps:]).all()
+
+
 @pytest.mark.parametrize("order,oa", [(0, 0), (0, 1), (1, 1), (2, 0)])
 def test_yuv411_to_rgb_batch(gpu, orc, order, oa):
     rng = np.random.default_rng(0xB200 + order * 2 + oa)

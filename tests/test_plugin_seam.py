@@ -200,6 +200,22 @@ def test_batch_hook_one_launch_for_the_instances_of_a_plan_step():
         H.run_batch(OURS, names[t], pal, w, h, got if inplace else a, b, got, amounts, hook="livesgpu_fx_process_batch")
         for i in range(n):
             assert (got[i] == want[i]).all(), (t, pal, w, h, i)          # the row padding too: it stays as it was
+    # the blends of simple_blend.c / multi_blends.c: an integer amount per instance
+    for name, plug, pal, n, inplace in (("chroma blend", "simple_blend", 3, 6, True), ("chroma blend", "simple_blend", 1, 4, False), ("luma overlay", "simple_blend", 4, 5, False),
+                                        ("averaged luma overlay", "simple_blend", 2, 3, True), ("blend_screen", "multi_blends", 1, 7, False), ("blend_burn", "multi_blends", 2, 16, True),
+                                        ("chroma blend", "simple_blend", 5, 3, False)):          # ARGB32: per instance behind the same call
+        ps, w, h = PSIZE[pal], 200, 44
+        names = {f["name"] for f in H.filters(OURS)}
+        assert name in names, sorted(names)
+        a = [po.make_frame(rng, w, h, ps, alpha_mix=True) for _ in range(n)]
+        b = [po.make_frame(rng, w, h, ps, alpha_mix=True, pad_px=1) for _ in range(n)]
+        amounts = [int(v) for v in rng.integers(0, 256, n)]
+        want = [x.copy() if inplace else np.full_like(x, 0x33) for x in a]
+        H.run_batch(po.refplugin(plug), name, pal, w, h, want if inplace else a, b, want, amounts, int_param=True)
+        got = [x.copy() if inplace else np.full_like(x, 0x33) for x in a]
+        H.run_batch(OURS, name, pal, w, h, got if inplace else a, b, got, amounts, hook="livesgpu_fx_process_batch", int_param=True)
+        for i in range(n):
+            assert (got[i][:, :w * ps] == want[i][:, :w * ps]).all(), (name, pal, i)
 
 
 @needs_ref

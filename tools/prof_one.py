@@ -74,7 +74,7 @@ def case(op):
             sets.append((srcs, l2s, ds, ops.chain_tracks(srcs, l2s, ds)))
         prm = ops.chain_params(W, H, W * 4, 1920, 1080, 1920 * 4, 1920 * 4, swap_rb=int(os.environ.get('C3_SWAP', '1')), interp=3 | 0x100, do_blur=0, bf=128, lut=np.arange(256, dtype=np.uint8))
         return (lambda i: ops.chain(prm, sets[i % nb][3])), n * (W * H * 4 + 2 * 1920 * 1080 * 4)
-    if op.startswith("fx") and ":" in op:       # fxN:softlight | fxN:yuv411 | fxN:transition -- N frames per launch through lgpu_fx_batch
+    if op.startswith("fx") and ":" in op:       # fxN:softlight | fxN:yuv411 | fxN:transition | fxN:chroma | fxN:luma | fxN:multi -- N frames per launch through lgpu_fx_batch
         n = int(op[2:op.index(":")])
         kind = op.split(":")[1]
         nb = 2 if not COLD else max(2, NB // n + 1)
@@ -92,6 +92,12 @@ def case(op):
         if kind == "transition":
             a_, b_, o = frames(h, w * 4), frames(h, w * 4), frames(h, w * 4)
             return (lambda i: ops.fx_batch(ops.FX_TRANSITION, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], w, h, ins1=[[t] for t in b_[i % nb]], ip=(1, 4), dp=(0.5,))), n * w * h * 8
+        if kind in ("chroma", "luma", "multi"):        # the two-input blends: bytes = two frames read, one written
+            ps = 3 if kind == "multi" else 4
+            a_, b_, o = frames(h, w * ps), frames(h, w * ps), frames(h, w * ps)
+            op, ip = {"chroma": (ops.FX_BLEND_CHROMA, (4, 0)), "luma": (ops.FX_BLEND_LUMA, (1, 4, 0)), "multi": (ops.FX_BLEND_MULTI, (1, 0))}[kind]
+            amts = [40 + 10 * f for f in range(n)]
+            return (lambda i: ops.fx_batch(op, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], w, h, ins1=[[t] for t in b_[i % nb]], ip=ip, frame_dp0=amts)), n * w * h * ps * 3
         if kind in ("c4rgba", "c4rgb24"):
             W, H, ps = 3840, 2160, (4 if kind == "c4rgba" else 3)
             a_ = [[torch.randint(0, 256, (H, W * ps), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)] for _ in range(nb)]
