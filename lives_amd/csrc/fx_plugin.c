@@ -501,6 +501,16 @@ weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecod
       else if (irow[c] != g_int(ic, WEED_LEAF_ROWSTRIDES, 0, 0)) return batch_fallback(insts, n, tc);
     }
   }
+  /* one launch has no order between its frames: an instance that reads (or writes) the plane another one writes keeps the sequence of the per-instance loop */
+  for (i = 0; i < n; i++) {
+    const void *oi = g_ptr((weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0), WEED_LEAF_PIXEL_DATA, 0);
+    for (c = 0; c < n; c++) {
+      if (c == i) continue;
+      if (oi == g_ptr((weed_plant_t *)g_ptr(insts[c], WEED_LEAF_OUT_CHANNELS, 0), WEED_LEAF_PIXEL_DATA, 0) ||
+          oi == g_ptr((weed_plant_t *)g_ptr(insts[c], WEED_LEAF_IN_CHANNELS, 0), WEED_LEAF_PIXEL_DATA, 0) ||
+          oi == g_ptr((weed_plant_t *)g_ptr(insts[c], WEED_LEAF_IN_CHANNELS, 1), WEED_LEAF_PIXEL_DATA, 0)) return batch_fallback(insts, n, tc);
+    }
+  }
   psize = psize_of(pal);
   if (!psize || w <= 0 || h <= 0) return WEED_ERROR_FILTER_INVALID;
   if (bc.op != LGPU_FX_TRANSITION && (pal == WEED_PALETTE_ARGB32 || (bc.op == LGPU_FX_BLEND_MULTI && psize != 3))) return batch_fallback(insts, n, tc);   /* as k_simple / k_multi serve them */

@@ -200,6 +200,14 @@ def test_batch_hook_one_launch_for_the_instances_of_a_plan_step():
         H.run_batch(OURS, names[t], pal, w, h, got if inplace else a, b, got, amounts, hook="livesgpu_fx_process_batch")
         for i in range(n):
             assert (got[i] == want[i]).all(), (t, pal, w, h, i)          # the row padding too: it stays as it was
+    # a chain inside the batch (instance 1 reads what instance 0 writes): the hook keeps the sequence of the per-instance loop
+    a = [po.make_frame(rng, 96, 20, 4) for _ in range(3)]
+    b = [po.make_frame(rng, 96, 20, 4) for _ in range(3)]
+    outs = [np.zeros_like(a[0]) for _ in range(3)]
+    H.run_batch(OURS, "iris circle", 3, 96, 20, [a[0], outs[0], a[2]], b, outs, [0.3, 0.6, 0.9], hook="livesgpu_fx_process_batch")
+    want = [np.zeros_like(a[0]) for _ in range(3)]
+    H.run_batch(ref, "iris circle", 3, 96, 20, [a[0], want[0], a[2]], b, want, [0.3, 0.6, 0.9])
+    assert all((outs[i][:, :96 * 4] == want[i][:, :96 * 4]).all() for i in range(3))
     # the blends of simple_blend.c / multi_blends.c: an integer amount per instance
     for name, plug, pal, n, inplace in (("chroma blend", "simple_blend", 3, 6, True), ("chroma blend", "simple_blend", 1, 4, False), ("luma overlay", "simple_blend", 4, 5, False),
                                         ("averaged luma overlay", "simple_blend", 2, 3, True), ("blend_screen", "multi_blends", 1, 7, False), ("blend_burn", "multi_blends", 2, 16, True),
