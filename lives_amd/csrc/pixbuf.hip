@@ -1551,12 +1551,21 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
   // Band height.  Short bands win (profiles/r03/pbh_sweep*.txt, r04/al_ab1.txt: 4-6 rows within 1 %, 8 rows 5 % behind, 12 rows further).  One frame: 6 rows.  A launch of
   // more than one generation of workgroups: 5 rows -- under the round-robin work order (pb_chain_half) the band count that fills whole generations no longer matters and
   // finer bands sweep the frame more evenly (profiles/r04/band_count_sweep.txt: 16 tracks 160 bands 143.6-144.4 us, 192 142.2-142.7, **216 141.6**, 256 143.4, 288 143.1;
-  // rounds 3 / 4 chose 160 = whole generations).  With the blur a band computes th + 4 scaled rows, a full device wants tall bands, one frame short ones
-  // (profiles/r03/blur_band_sweep.txt).
-  const int per_cu = blur ? 6 : 8;                       // resident workgroups per CU (80 / <= 64 VGPRs)
+  // rounds 3 / 4 chose 160 = whole generations).  With the blur a band computes th + 4 scaled rows: its own rule below.
+  const int per_cu = blur ? 4 : 8;                       // resident workgroups per CU (98 / <= 64 VGPRs)
   const long long slots = (long long)device_cus() * per_cu, cols = (long long)a->cgroups * ntracks;
-  int bands = (int)cdiv((unsigned)a->dh, blur ? ((long long)a->strips * cdiv((unsigned)a->dh, 16u) * ntracks < 8192 ? 6u : 24u) : 6u);
-  if (blur && cols * bands > slots) bands = 8 * std::max(1, (bands + 4) / 8);            // a multiple of 8 here too (16 tracks: 45 bands 179-181 us, 48 bands 177)
+  int bands = (int)cdiv((unsigned)a->dh, 6u);
+  if (blur) {
+    // The straight-line walk (round 5) runs at four workgroups per CU (98 registers).  ONE workgroup per CU and track (two for a single frame) is what every track count
+    // from 1 to 16 wants: 1920 wide = 4 column groups x 64 bands of ~17 rows, four tracks = one whole generation.  Against the 48 / 184 bands of before (bands of 22 rows
+    // for full-device launches, 6 rows below): 1 track 17.5 -> 16.8 us, 2 28.7 -> 26.2, 3 38.8 -> 34.1, 4 49.4 -> 42.2, 6 72 -> 67, 8 92.0 -> 86.3, 12 134.0 -> 126.1,
+    // 16 169.3 -> 165.2; more bands (80 .. 128) and fewer (32 .. 48) lose at every count (profiles/r05/late/blur_generations.txt).  A multiple of 8: every XCD the same
+    // number of a track's bands.  Bands of 6 .. 34 rows.
+    const int per_track = device_cus() * (ntracks == 1 ? 2 : 1);
+    bands = std::max(8, per_track / std::max(1, a->cgroups) / 8 * 8);
+    bands = std::min(bands, std::max(1, a->dh / 6));
+    bands = std::max(bands, (int)cdiv((unsigned)a->dh, 34u));
+  }
   if (!blur && cols * bands > slots) bands = 8 * std::max(1, (a->dh + 20) / 40);       // ~5 rows per band, a multiple of 8: every XCD then owns the same number of bands (pb_chain_half)
   { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) bands = (int)cdiv((unsigned)a->dh, (unsigned)v); else if (v > 100000) bands = v - 100000; }       // tuning probe / tests: bands of (about) v rows, or 100000 + the number of bands
   pb_half_bands(a, bands);
