@@ -253,7 +253,20 @@ int lgpu::gauss5_colorkey_n(const FxFrames &F, int nframes, int irow0, int irow1
   a.th = 8;            // one frame: 4,320 waves, one generation at five workgroups per CU (82 / 86 VGPRs); 6-row bands would need a second generation for their last 640
   // a launch of more than one generation of workgroups (several frames: lgpu_fx_batch) is no longer a matter of one wave's latency: taller bands, fewer rows
   // blurred twice (profiles/r05: 8 x 4K RGBA32 164 us at 6 rows, 155 at 8, 162 at 12; RGB24 173 at 8, 168 at 12, 167 at 16)
-  if ((long long)a.cgroups * cdiv((unsigned)height, (unsigned)a.th) * nframes > (long long)device_cus() * 5) a.th = psize == 4 ? 8 : 12;
+  if ((long long)a.cgroups * cdiv((unsigned)height, (unsigned)a.th) * nframes > (long long)device_cus() * 5) {
+    a.th = psize == 4 ? 8 : 12;
+    if (psize == 3) {
+      // 3-byte pixels: of 12 / 15 / 18 rows the height whose LAST generation of workgroups (five per CU) is fullest -- 8 x 4K: 18 rows = three whole generations,
+      // 157.6 -> 152.8 us (4-byte pixels are flat from 8 to 9 rows and lose above: profiles/r05/late/c4_generations.txt)
+      const long long slots = (long long)device_cus() * 5;
+      double best = 0.;
+      for (int th = 12; th <= 18; th += 3) {
+        const long long wgs = (long long)a.cgroups * cdiv((unsigned)height, (unsigned)th) * nframes;
+        const double fill = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+        if (fill > best + 1e-9) { best = fill; a.th = th; }
+      }
+    }
+  }
   { const int v = tune(TUNE_GCK_TH); if (v >= 1 && v <= 1024) a.th = v; }      // tuning probe
   a.bands = (int)cdiv((unsigned)height, (unsigned)a.th);
   // parameter preparation exactly as the script does it (host side, double)
