@@ -911,7 +911,9 @@ struct PbPairArgs {
 // NY: tap rows when known at compile time (then a destination pixel's weight vectors are requested together, before the first tap, instead of one exposed load
 // per tap row), 0: any count.  Measured (profiles/r03/pb_pairs_ab.txt): a gain for 2-3 tap rows (enlarging: 29.3 -> 27.3 us), a loss for 5-6 (4K -> 1706x960: 24.6 -> 37.2 us;
 // the 24 weight registers cost more than the exposed loads), so only the short filters are instantiated that way.
-template <int CH, int NPC, int NY>
+// ONE: tiles of at most four rows -- a wave has ONE destination row, and the code that requests and takes over the next row's weight vectors (24 register moves per row that the
+// compiler does not branch around) is not there
+template <int CH, int NPC, int NY, int ONE = 0>
 __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbFrames F) {
   PB_FRAME_ARGS(PbPairArgs);
   extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
@@ -983,65 +985,8 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   }
   __syncthreads();
   const bool quads3 = CH == 3 && (((uintptr_t)A.dst | (uintptr_t)A.orow) & 3) == 0;
-  for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
-    const int i = i0 + r_;
-    if (i >= A.dh) break;
-    if (j >= A.dw) continue;
-    const long long y = (long long)i * A.y_step + A.yoff;
-    const int ys = (int)(y >> 16), yph = (int)(y >> 12) & 15;
-    const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
-    const uint32_t wi = (uint32_t)(yph * A.ny_eff * 32 + xph * 2 + par);       // [y phase][tap row][x phase][parity]: a wave's 64 vectors of one tap row lie within 512 nq bytes
-    unsigned r = 0, g = 0, b = 0, a = 0;
-    if (NPC && NY) {
-      // this row's vectors are in wv (requested before the window was staged, or during the previous row's taps); the next row's go out now
-      pb_u4 wn[NY ? NY : 1];
-      const bool more = r_ + 4 < A.tile_h && i + 4 < A.dh;
-      if (more) {
-        const uint32_t win = (uint32_t)(((int)(((long long)(i + 4) * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + xph * 2 + par);
-#pragma unroll
-        for (int ty = 0; ty < NY; ty++) wn[ty] = pairs4[win + 32 * ty];
-      }
-#pragma unroll
-      for (int ty = 0; ty < NY; ty++) {
-        const uint32_t wq[4] = {wv[ty].x, wv[ty].y, wv[ty].z, wv[ty].w};
-#pragma unroll
-        for (int k = 0; k < NPC; k++) {
-          const pb_u4 dd = wp[ty * A.wpairs + k];
-          r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
-          if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
-        }
-        // long filters: a tap row's window reads stay next to its taps.  Left alone the compiler runs the alpha sums of all rows first and sinks the colour sums behind
-        // the alpha test of pb_finish_px: every window vector stays live (4 x 6 x 4 = 96 registers) and the occupancy goes from 8 waves to 3
-        if (NY >= 3) { asm volatile("" : "+v"(r), "+v"(g), "+v"(b), "+v"(a)); __builtin_amdgcn_sched_barrier(0); }
-      }
-      if (more) {
-#pragma unroll
-        for (int ty = 0; ty < NY; ty++) wv[ty] = wn[ty];
-      }
-    } else {
-      for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
-        if (NPC) {
-          const pb_u4 w = pairs4[wi + 32 * ty];
-          const uint32_t wq[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-          for (int k = 0; k < (NPC ? NPC : 1); k++) {
-            const pb_u4 dd = wp[k];
-            r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
-            if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
-          }
-          continue;
-        }
-        for (int qd = 0; qd < A.nq; qd++) {
-          const pb_u4 w = pairs4[(wi + 32 * ty) * A.nq + qd];
-          const pb_u4 d0 = wp[4 * qd], d1 = wp[4 * qd + 1], d2 = wp[4 * qd + 2], d3 = wp[4 * qd + 3];
-          r = pb_dot2(d0.x, w.x, r); g = pb_dot2(d0.y, w.x, g); b = pb_dot2(d0.z, w.x, b);
-          r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
-          r = pb_dot2(d2.x, w.z, r); g = pb_dot2(d2.y, w.z, g); b = pb_dot2(d2.z, w.z, b);
-          r = pb_dot2(d3.x, w.w, r); g = pb_dot2(d3.y, w.w, g); b = pb_dot2(d3.z, w.w, b);
-          if (CH == 4) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
-        }
-      }
-    }
+  // the accumulators of destination pixel (i, j) -> its bytes, stored
+  auto emit = [&](int i, unsigned r, unsigned g, unsigned b, unsigned a) {
     const uint32_t px = pb_finish_px<CH>(r, g, b, a, edge, A.rnd);
     uint8_t *drow = A.dst + (size_t)i * A.orow;
     if (CH == 4) reinterpret_cast<uint32_t *>(drow)[j] = px;
@@ -1055,6 +1000,78 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
       const int l = lane & 3;
       if (l < 3) reinterpret_cast<uint32_t *>(drow)[3 * (j >> 2) + l] = l == 0 ? w0 : l == 1 ? w1 : w2;
     } else { uint8_t *d = drow + 3 * (size_t)j; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
+  };
+  if (NPC && NY) {
+    // tap rows known at compile time: this row's weight vectors are in `cur` (requested before the window was staged, or during the previous row's taps); the next
+    // row's go out into `nxt` before the taps.  The two register sets change roles from row to row (no take-over copies)
+    pb_u4 wn[(NPC && NY) ? NY : 1];
+    auto do_row = [&](int r_, const pb_u4 *cur, pb_u4 *nxt) {
+      const int i = i0 + r_;
+      const long long y = (long long)i * A.y_step + A.yoff;
+      const int ys = (int)(y >> 16);
+      const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
+      if (!ONE && r_ + 4 < A.tile_h && i + 4 < A.dh) {
+        const uint32_t win = (uint32_t)(((int)(((long long)(i + 4) * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + xph * 2 + par);
+#pragma unroll
+        for (int ty = 0; ty < NY; ty++) nxt[ty] = pairs4[win + 32 * ty];
+      }
+      unsigned r = 0, g = 0, b = 0, a = 0;
+#pragma unroll
+      for (int ty = 0; ty < NY; ty++) {
+        const uint32_t wq[4] = {cur[ty].x, cur[ty].y, cur[ty].z, cur[ty].w};
+#pragma unroll
+        for (int k = 0; k < NPC; k++) {
+          const pb_u4 dd = wp[ty * A.wpairs + k];
+          r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
+          if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
+        }
+        // long filters: a tap row's window reads stay next to its taps.  Left alone the compiler runs the alpha sums of all rows first and sinks the colour sums behind
+        // the alpha test of pb_finish_px: every window vector stays live (4 x 6 x 4 = 96 registers) and the occupancy goes from 8 waves to 3
+        if (NY >= 3) { asm volatile("" : "+v"(r), "+v"(g), "+v"(b), "+v"(a)); __builtin_amdgcn_sched_barrier(0); }
+      }
+      emit(i, r, g, b, a);
+    };
+    if (j < A.dw) {
+      for (int r_ = wave; r_ < A.tile_h && i0 + r_ < A.dh; r_ += 8) {
+        do_row(r_, wv, wn);
+        if (ONE || r_ + 4 >= A.tile_h || i0 + r_ + 4 >= A.dh) break;
+        do_row(r_ + 4, wn, wv);
+      }
+    }
+    return;
+  }
+  for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
+    const int i = i0 + r_;
+    if (i >= A.dh) break;
+    if (j >= A.dw) continue;
+    const long long y = (long long)i * A.y_step + A.yoff;
+    const int ys = (int)(y >> 16), yph = (int)(y >> 12) & 15;
+    const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
+    const uint32_t wi = (uint32_t)(yph * A.ny_eff * 32 + xph * 2 + par);       // [y phase][tap row][x phase][parity]: a wave's 64 vectors of one tap row lie within 512 nq bytes
+    unsigned r = 0, g = 0, b = 0, a = 0;
+    for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
+      if (NPC) {
+        const pb_u4 w = pairs4[wi + 32 * ty];
+        const uint32_t wq[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < (NPC ? NPC : 1); k++) {
+          const pb_u4 dd = wp[k];
+          r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
+          if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
+        }
+        continue;
+      }
+      for (int qd = 0; qd < A.nq; qd++) {
+        const pb_u4 w = pairs4[(wi + 32 * ty) * A.nq + qd];
+        const pb_u4 d0 = wp[4 * qd], d1 = wp[4 * qd + 1], d2 = wp[4 * qd + 2], d3 = wp[4 * qd + 3];
+        r = pb_dot2(d0.x, w.x, r); g = pb_dot2(d0.y, w.x, g); b = pb_dot2(d0.z, w.x, b);
+        r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
+        r = pb_dot2(d2.x, w.z, r); g = pb_dot2(d2.y, w.z, g); b = pb_dot2(d2.z, w.z, b);
+        r = pb_dot2(d3.x, w.w, r); g = pb_dot2(d3.y, w.w, g); b = pb_dot2(d3.z, w.w, b);
+        if (CH == 4) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
+      }
+    }
+    emit(i, r, g, b, a);
   }
 }
 
@@ -1892,15 +1909,16 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h), (unsigned)n);
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
+#define PB_PRE(CHN, NP_, NY_) { if (pa.tile_h <= 4) hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 1>), g, block, lds, st, pa, F); else hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 0>), g, block, lds, st, pa, F); }
 #define PB_PAIRS(CHN)                                                                                                     \
       { const int ny = t->ty1 - t->ty0;                                                                                   \
         const bool pre = !tune_on(TUNE_PB_NO_PRE);                                                                          \
-        if (np == 2 && ny == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 2>), g, block, lds, st, pa, F);                       \
-        else if (np == 2 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 3>), g, block, lds, st, pa, F);                  \
-        else if (np == 3 && ny == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 3>), g, block, lds, st, pa, F);                  \
-        else if (pre && np == 3 && ny == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 4>), g, block, lds, st, pa, F);           \
-        else if (pre && np == 3 && ny == 5) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 5>), g, block, lds, st, pa, F);           \
-        else if (pre && np == 4 && ny == 6) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 6>), g, block, lds, st, pa, F);           \
+        if (np == 2 && ny == 2) PB_PRE(CHN, 2, 2)                                                                            \
+        else if (np == 2 && ny == 3) PB_PRE(CHN, 2, 3)                                                                       \
+        else if (np == 3 && ny == 3) PB_PRE(CHN, 3, 3)                                                                       \
+        else if (pre && np == 3 && ny == 4) PB_PRE(CHN, 3, 4)                                                                \
+        else if (pre && np == 3 && ny == 5) PB_PRE(CHN, 3, 5)                                                                \
+        else if (pre && np == 4 && ny == 6) PB_PRE(CHN, 4, 6)                                                                \
         else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0>), g, block, lds, st, pa, F);                             \
         else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0>), g, block, lds, st, pa, F);                             \
         else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0>), g, block, lds, st, pa, F);                             \
@@ -1908,6 +1926,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
         else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0>), g, block, lds, st, pa, F); }
       if (channels == 4) { PB_PAIRS(4) } else { PB_PAIRS(3) }
 #undef PB_PAIRS
+#undef PB_PRE
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
