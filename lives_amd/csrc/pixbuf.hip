@@ -71,12 +71,12 @@ __device__ __forceinline__ double pb_recip(uint32_t a) {
 template <int CH>
 __device__ __forceinline__ uint32_t pb_finish_px(unsigned r, unsigned g, unsigned b, unsigned a, bool edge, unsigned rnd) {
   if (CH == 4) {
-    uint32_t o = 0;
-    if (a) {
-      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : pb_recip(a);      // every tap opaque (the common frame): fl(1 / a) is a constant; otherwise the five-operation reciprocal (a <= 0xFF0000)
-      o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
-    }
-    return o;
+    // every tap of every lane opaque (the common frame): fl(1 / a) is a constant -- a WAVE-UNIFORM test, so the choice is a scalar branch; otherwise every lane runs the
+    // five-operation reciprocal (a <= 0xFF0000; a == 0 computes on 1 and is zeroed below).  Per-lane tests of both cases made this a web of exec-mask branches.
+    const bool opaque = __builtin_amdgcn_ballot_w64(a != 0xFF0000u) == 0;
+    const double ia = opaque ? (1.0 / 16711680.0) : pb_recip(a ? a : 1u);
+    const uint32_t o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
+    return a ? o : 0u;
   }
   if (edge) return ((r * 255u + 0xffffffu) >> 24) | (((g * 255u + 0xffffffu) >> 24) << 8) | (((b * 255u + 0xffffffu) >> 24) << 16);
   return (((r + rnd) >> 16) & 0xFFu) | ((((g + rnd) >> 16) & 0xFFu) << 8) | ((((b + rnd) >> 16) & 0xFFu) << 16);
@@ -84,13 +84,7 @@ __device__ __forceinline__ uint32_t pb_finish_px(unsigned r, unsigned g, unsigne
 template <int CH>
 __device__ __forceinline__ void pb_finish(uint8_t *d, unsigned r, unsigned g, unsigned b, unsigned a, bool edge, unsigned rnd) {
   if (CH == 4) {
-    uint32_t o = 0;
-    if (a) {
-      // every tap opaque (the common frame): a = 255 * 65536 and fl(1 / a) is a constant -- the same double the division returns, without the division
-      const double ia = (a == 0xFF0000u) ? (1.0 / 16711680.0) : pb_recip(a);
-      o = (uint32_t)(uint8_t)((double)r * ia) | ((uint32_t)(uint8_t)((double)g * ia) << 8) | ((uint32_t)(uint8_t)((double)b * ia) << 16) | ((a >> 16) << 24);
-    }
-    *reinterpret_cast<uint32_t *>(d) = o;
+    *reinterpret_cast<uint32_t *>(d) = pb_finish_px<4>(r, g, b, a, edge, rnd);
   } else if (edge) {
     d[0] = (uint8_t)((r * 255u + 0xffffffu) >> 24); d[1] = (uint8_t)((g * 255u + 0xffffffu) >> 24); d[2] = (uint8_t)((b * 255u + 0xffffffu) >> 24);
   } else {
