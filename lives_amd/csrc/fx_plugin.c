@@ -441,7 +441,7 @@ PROC(p_negate, 1, 0, k_scriptfx, 0) PROC(p_posterise, 1, 1, k_scriptfx, 0) PROC(
    The reference applies the effects of a plan step one instance after another (src/effects-weed.c:1563-1758 per instance), and a 640x360 frame is a
    ramp-and-drain bound launch on 256 CUs: n instances of the same class on frames of one geometry go out as one lgpu_fx_batch launch (include/lives_gpu.h).
    Batched today: the three transitions of multi_transitions.c ("iris rectangle", "iris circle", "4 way split"), the five blends of simple_blend.c and the seven of
-   multi_blends.c (ARGB32 frames excepted), each instance with its own amount / threshold;
+   multi_blends.c (ARGB32 frames excepted), each instance with its own amount / threshold, and "softlight" (planar YUV);
    any other class, mixed classes, mixed geometry, sliced channels or more than LGPU_FX_MAX_FRAMES instances fall back to process_func per instance, so the
    result is the same either way.  Channels on pinned layers are used where they live (no copy, no wait), the others are staged as fx_run does. */
 /* the classes with a batch kernel: op of lgpu_fx_batch, its `kind`, and whether parameter 0 (the one value an instance adds to the launch) is an integer */
@@ -472,6 +472,90 @@ static weed_error_t batch_fallback(weed_plant_t **insts, int n, weed_timecode_t 
   }
   return ret;
 }
+/* "softlight" (planar YUV, one in channel): the planes of n instances through ONE lgpu_fx_batch launch; staging per instance as p_softlight does it */
+static weed_error_t batch_softlight(weed_plant_t **insts, int n, weed_timecode_t tc) {
+  lgpu_fx_frame fr[LGPU_FX_MAX_FRAMES];
+  lgpu_fx_params P;
+  uint8_t *hdst[LGPU_FX_MAX_FRAMES][4], *ddst[LGPU_FX_MAX_FRAMES][4];
+  const void *hsrc[LGPU_FX_MAX_FRAMES][4];
+  int rsrc[LGPU_FX_MAX_FRAMES][4], rdst[LGPU_FX_MAX_FRAMES][4];
+  int irow[4] = {0, 0, 0, 0}, orow[4] = {0, 0, 0, 0}, ph[4] = {0, 0, 0, 0}, i, k, nplanes = 0, pal = 0, w = 0, h = 0, clamping = 0, home = 0, uploaded = 0, krc;
+  size_t ioff[4], ooff[4], itot = 0, otot = 0;
+  weed_error_t ret = WEED_SUCCESS;
+  for (i = 0; i < n; i++) {
+    weed_plant_t *ic = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_CHANNELS, 0), *oc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0);
+    if (!ic || !oc) return WEED_ERROR_FILTER_INVALID;
+    if (has(oc, WEED_LEAF_OFFSET) || w_nelems(oc, WEED_LEAF_HEIGHT) > 1) return batch_fallback(insts, n, tc);
+    if (i == 0) {
+      pal = g_int(ic, WEED_LEAF_CURRENT_PALETTE, 0, 0); w = g_int(ic, WEED_LEAF_WIDTH, 0, 0); h = g_int(ic, WEED_LEAF_HEIGHT, 0, 0);
+      clamping = g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED);
+      if (pal != WEED_PALETTE_YUV444P && pal != WEED_PALETTE_YUVA4444P && pal != WEED_PALETTE_YUV422P && pal != WEED_PALETTE_YUV420P && pal != WEED_PALETTE_YVU420P)
+        return batch_fallback(insts, n, tc);
+      nplanes = pal == WEED_PALETTE_YUVA4444P ? 4 : 3;
+      for (k = 0; k < nplanes; k++) {
+        irow[k] = g_int(ic, WEED_LEAF_ROWSTRIDES, k, 0); orow[k] = g_int(oc, WEED_LEAF_ROWSTRIDES, k, 0);
+        ph[k] = (k == 0 || k == 3) ? h : ((pal == WEED_PALETTE_YUV420P || pal == WEED_PALETTE_YVU420P) ? h >> 1 : h);
+        ioff[k] = itot; itot += ((size_t)irow[k] * ph[k] + 15) & ~(size_t)15;
+        ooff[k] = otot; otot += ((size_t)orow[k] * ph[k] + 15) & ~(size_t)15;
+        if (irow[k] <= 0 || orow[k] <= 0) return WEED_ERROR_FILTER_INVALID;
+      }
+    } else if (pal != g_int(ic, WEED_LEAF_CURRENT_PALETTE, 0, 0) || w != g_int(ic, WEED_LEAF_WIDTH, 0, 0) || h != g_int(ic, WEED_LEAF_HEIGHT, 0, 0) ||
+               clamping != g_int(ic, WEED_LEAF_YUV_CLAMPING, 0, WEED_YUV_CLAMPING_CLAMPED)) return batch_fallback(insts, n, tc);
+    for (k = 0; k < nplanes; k++) {
+      if (irow[k] != g_int(ic, WEED_LEAF_ROWSTRIDES, k, 0) || orow[k] != g_int(oc, WEED_LEAF_ROWSTRIDES, k, 0)) return batch_fallback(insts, n, tc);
+      hsrc[i][k] = g_ptr(ic, WEED_LEAF_PIXEL_DATA, k); hdst[i][k] = (uint8_t *)g_ptr(oc, WEED_LEAF_PIXEL_DATA, k);
+      if (!hsrc[i][k] || !hdst[i][k]) return WEED_ERROR_FILTER_INVALID;
+    }
+  }
+  for (i = 0; i < n; i++)                                  /* independent instances only (see the caller) */
+    for (k = 0; k < n; k++)
+      if (k != i && (hdst[i][0] == hdst[k][0] || (const void *)hdst[i][0] == hsrc[k][0])) return batch_fallback(insts, n, tc);
+  if (lgpu_init(0) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+  memset(fr, 0, sizeof fr); memset(rsrc, 0, sizeof rsrc); memset(rdst, 0, sizeof rdst);
+  for (i = 0; i < n && ret == WEED_SUCCESS; i++) {
+    fxdata_t *fx = fx_data(insts[i]);
+    uint8_t *ibase, *obase;
+    if (!fx) { ret = WEED_ERROR_MEMORY_ALLOCATION; break; }
+    fx_enter(fx);
+    ibase = (uint8_t *)fx_buf(fx, 0, itot); obase = (uint8_t *)fx_buf(fx, 2, otot);
+    if (!ibase || !obase) { ret = WEED_ERROR_MEMORY_ALLOCATION; break; }
+    for (k = 0; k < nplanes; k++) {
+      const uint8_t *res = (const uint8_t *)lives_gpu_resident_acquire(hsrc[i][k], (size_t)irow[k] * ph[k], 0);
+      if (res) { fr[i].in0[k] = res; rsrc[i][k] = 1; }
+      else {
+        fr[i].in0[k] = ibase + ioff[k];
+        if (lgpu_upload(ibase + ioff[k], hsrc[i][k], (size_t)irow[k] * ph[k], FXS)) ret = WEED_ERROR_PLUGIN_INVALID;
+        uploaded = 1;
+      }
+      ddst[i][k] = (uint8_t *)lives_gpu_resident_acquire(hdst[i][k], (size_t)orow[k] * ph[k], 1);
+      if (ddst[i][k]) rdst[i][k] = 1;
+      else {
+        ddst[i][k] = obase + ooff[k]; home = 1;
+        if (lgpu_upload(ddst[i][k], hdst[i][k], (size_t)orow[k] * ph[k], FXS)) ret = WEED_ERROR_PLUGIN_INVALID;      /* row padding stays as it was */
+      }
+      fr[i].out[k] = ddst[i][k];
+    }
+  }
+  krc = LGPU_OK;
+  if (ret == WEED_SUCCESS) {
+    memset(&P, 0, sizeof P);
+    P.op = LGPU_FX_SOFTLIGHT; P.width = w; P.height = h; P.palette = pal; P.ip[0] = clamping == WEED_YUV_CLAMPING_UNCLAMPED;
+    for (k = 0; k < nplanes; k++) { P.irow0[k] = irow[k]; P.orow[k] = orow[k]; }
+    krc = lgpu_fx_batch(&P, fr, n, FXS);
+  }
+  for (i = 0; i < n; i++)
+    for (k = 0; k < nplanes; k++) {
+      if (rsrc[i][k]) lives_gpu_resident_release(hsrc[i][k], 0);
+      if (rdst[i][k]) lives_gpu_resident_release(hdst[i][k], 1);
+    }
+  if (ret != WEED_SUCCESS) return ret;
+  if (krc != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
+  for (i = 0; i < n; i++)
+    for (k = 0; k < nplanes; k++)
+      if (!rdst[i][k] && lgpu_download(hdst[i][k], ddst[i][k], (size_t)orow[k] * ph[k], FXS)) return WEED_ERROR_PLUGIN_INVALID;
+  if ((home || uploaded) && lgpu_sync(FXS)) return WEED_ERROR_PLUGIN_INVALID;
+  return WEED_SUCCESS;
+}
 weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecode_t tc) {
   lgpu_fx_frame fr[LGPU_FX_MAX_FRAMES];
   lgpu_fx_params P;
@@ -483,6 +567,18 @@ weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecod
   weed_error_t ret = WEED_SUCCESS;
   if (!insts || n <= 0) return WEED_ERROR_FILTER_INVALID;
   for (i = 0; i < n; i++) if (!insts[i]) return WEED_ERROR_FILTER_INVALID;
+  if (n > 1 && n <= LGPU_FX_MAX_FRAMES) {
+    weed_plant_t *fc0 = (weed_plant_t *)g_ptr(insts[0], WEED_LEAF_FILTER_CLASS, 0);
+    weed_process_f pf0 = NULL;
+    if (fc0 && w_get(fc0, WEED_LEAF_PROCESS_FUNC, 0, &pf0) == WEED_SUCCESS && pf0 == p_softlight) {
+      for (i = 1; i < n; i++) {
+        weed_plant_t *fci = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_FILTER_CLASS, 0);
+        weed_process_f pfi = NULL;
+        if (!fci || w_get(fci, WEED_LEAF_PROCESS_FUNC, 0, &pfi) != WEED_SUCCESS || pfi != p_softlight) return batch_fallback(insts, n, tc);
+      }
+      return batch_softlight(insts, n, tc);
+    }
+  }
   if (!batch_class(insts[0], &bc) || n > LGPU_FX_MAX_FRAMES || n == 1) return batch_fallback(insts, n, tc);
   for (i = 0; i < n; i++) {
     weed_plant_t *oc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0), *pa = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_PARAMETERS, 0);

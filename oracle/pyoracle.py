@@ -193,6 +193,7 @@ class RefHost:
         self.H.refhost_run_seq.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]
         self.H.refhost_run_compositor.argtypes = [vp, ctypes.c_char_p, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci]
         self.H.refhost_run_batch.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
+        self.H.refhost_run_planar_batch.argtypes = [vp, ctypes.c_char_p, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp]
         self.H.refhost_set_yuv_clamping.argtypes = [ci]
         self.H.refhost_set_random_seed.argtypes = [ctypes.c_int64]
         self.plugins = {}
@@ -242,6 +243,20 @@ class RefHost:
         if r != 0:
             raise RuntimeError("weed filter '%s' returned %d" % (fname, r))
         return dst_planes
+
+    def run_planar_batch(self, path, fname, pal, w, h, srcs, dsts, clamping, hook=None):
+        """n instances of a planar one-input class: srcs / dsts are lists (one per instance) of plane lists; process_func per instance, or one call of the plugin's batch hook"""
+        hdl = self.load(path)
+        n, npl = len(srcs), len(srcs[0])
+        sp = (vp * (n * npl))(*[a.ctypes.data for fr in srcs for a in fr])
+        dp = (vp * (n * npl))(*[a.ctypes.data for fr in dsts for a in fr])
+        ss = (ci * npl)(*[a.strides[0] for a in srcs[0]])
+        ds = (ci * npl)(*[a.strides[0] for a in dsts[0]])
+        fn = ctypes.cast(getattr(ctypes.CDLL(path), hook), vp) if hook else None
+        r = self.H.refhost_run_planar_batch(hdl, fname.encode(), pal, w, h, npl, n, sp, ss, dp, ds, clamping, fn)
+        if r != 0:
+            raise RuntimeError("weed filter '%s' (batch of %d) returned %d" % (fname, n, r))
+        return dsts
 
     def run_compositor(self, path, pal, srcs, sizes, disabled, dst, ow, oh, offsx, offsy, scalex, scaley, alpha, bgcol, revz):
         """the "compositor" class: in channels of their own sizes (srcs[i]: rows x rowstride, sizes[i] = (w, h)), per-channel parameter arrays"""

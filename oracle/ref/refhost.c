@@ -436,3 +436,49 @@ int refhost_run_batch(void *pinfo_v, const char *fname, int pal, int w, int h, i
   if (iptm) free(iptm);
   return ret;
 }
+
+/* n instances of a one-input PLANAR class (softlight.c): planes laid out frame after frame in src / dst ([i * nplanes + p]), one rowstride set for all.
+ * batch_hook as in refhost_run_batch. */
+int refhost_run_planar_batch(void *pinfo_v, const char *fname, int pal, int w, int h, int nplanes, int n,
+                             uint8_t **src, const int *istrides, uint8_t **dst, const int *ostrides, int clamping, void *batch_hook) {
+  weed_plant_t *pinfo = (weed_plant_t *)pinfo_v;
+  weed_plant_t *filt = find_filter(pinfo, fname);
+  weed_plant_t *inst[64], *inch[64], *outch[64], **ictm, **octm;
+  weed_init_f init_func;
+  weed_process_f process_func;
+  weed_deinit_f deinit_func;
+  int nict = 0, noct = 0, i, ninit, ret = WEED_SUCCESS;
+  if (!filt) { fprintf(stderr, "refhost: filter '%s' not found\n", fname); return -100; }
+  if (n < 1 || n > 64) return -101;
+  ictm = weed_get_plantptr_array_counted(filt, WEED_LEAF_IN_CHANNEL_TEMPLATES, &nict);
+  octm = weed_get_plantptr_array_counted(filt, WEED_LEAF_OUT_CHANNEL_TEMPLATES, &noct);
+  if (nict < 1 || noct < 1) return -102;
+  init_func = (weed_init_f)weed_get_funcptr_value(filt, WEED_LEAF_INIT_FUNC, NULL);
+  process_func = (weed_process_f)weed_get_funcptr_value(filt, WEED_LEAF_PROCESS_FUNC, NULL);
+  deinit_func = (weed_deinit_f)weed_get_funcptr_value(filt, WEED_LEAF_DEINIT_FUNC, NULL);
+  for (i = 0; i < n; i++) {
+    inst[i] = weed_plant_new(WEED_PLANT_FILTER_INSTANCE);
+    weed_set_plantptr_value(inst[i], WEED_LEAF_FILTER_CLASS, filt);
+    inch[i] = mk_channel(ictm[0], pal, w, h, istrides[0], src[i * nplanes]);
+    outch[i] = mk_channel(octm[0], pal, w, h, ostrides[0], dst[i * nplanes]);
+    weed_set_voidptr_array(inch[i], WEED_LEAF_PIXEL_DATA, nplanes, (void **)(src + i * nplanes));
+    weed_set_int_array(inch[i], WEED_LEAF_ROWSTRIDES, nplanes, (int32_t *)istrides);
+    weed_set_voidptr_array(outch[i], WEED_LEAF_PIXEL_DATA, nplanes, (void **)(dst + i * nplanes));
+    weed_set_int_array(outch[i], WEED_LEAF_ROWSTRIDES, nplanes, (int32_t *)ostrides);
+    weed_set_int_value(inch[i], WEED_LEAF_YUV_CLAMPING, clamping);
+    weed_set_int_value(outch[i], WEED_LEAF_YUV_CLAMPING, clamping);
+    weed_set_plantptr_value(inst[i], WEED_LEAF_IN_CHANNELS, inch[i]);
+    weed_set_plantptr_value(inst[i], WEED_LEAF_OUT_CHANNELS, outch[i]);
+  }
+  for (ninit = 0; ninit < n; ninit++)
+    if (init_func) { ret = (*init_func)(inst[ninit]); if (ret != WEED_SUCCESS) break; }
+  if (ret == WEED_SUCCESS) {
+    if (batch_hook) ret = (*(refhost_batch_f)batch_hook)(inst, n, (weed_timecode_t)0);
+    else for (i = 0; i < n; i++) { int r = (*process_func)(inst[i], (weed_timecode_t)0); if (r != WEED_SUCCESS) ret = r; }
+  }
+  for (i = 0; i < ninit; i++) if (deinit_func) (*deinit_func)(inst[i]);
+  for (i = 0; i < n; i++) { weed_plant_free(inch[i]); weed_plant_free(outch[i]); weed_plant_free(inst[i]); }
+  if (ictm) free(ictm);
+  if (octm) free(octm);
+  return ret;
+}

@@ -208,6 +208,21 @@ def test_batch_hook_one_launch_for_the_instances_of_a_plan_step():
     want = [np.zeros_like(a[0]) for _ in range(3)]
     H.run_batch(ref, "iris circle", 3, 96, 20, [a[0], want[0], a[2]], b, want, [0.3, 0.6, 0.9])
     assert all((outs[i][:, :96 * 4] == want[i][:, :96 * 4]).all() for i in range(3))
+    # "softlight": planar frames, n instances in one launch, against the reference plugin run per instance
+    for pal, w, h, n, uncl in ((512, 96, 40, 5, 0), (544, 70, 33, 16, 1), (545, 64, 20, 3, 0), (522, 128, 18, 2, 1), (512, 96, 40, 17, 0)):
+        npl = 4 if pal == 545 else 3
+        cw = w >> 1 if pal in (512, 513, 522) else w
+        ch = h >> 1 if pal in (512, 513) else h
+        dims = [(w, h), (cw, ch), (cw, ch), (w, h)][:npl]
+        srcs = [[rng.integers(0, 256, (dh_, (dw_ + 15) // 16 * 16), dtype=np.uint8) for dw_, dh_ in dims] for _ in range(n)]
+        want = [[np.full_like(a, 0x5A) for a in fr] for fr in srcs]
+        H.run_planar_batch(po.refplugin("softlight"), "softlight", pal, w, h, srcs, want, uncl)
+        got = [[np.full_like(a, 0x5A) for a in fr] for fr in srcs]
+        H.run_planar_batch(OURS, "softlight", pal, w, h, srcs, got, uncl, hook="livesgpu_fx_process_batch")
+        for i in range(n):
+            for k, (dw_, dh_) in enumerate(dims):
+                assert (got[i][k][:dh_, :dw_] == want[i][k][:dh_, :dw_]).all(), (pal, i, k)
+                assert (got[i][k][:, dw_:] == 0x5A).all(), "row padding stays as it was"
     # the blends of simple_blend.c / multi_blends.c: an integer amount per instance
     for name, plug, pal, n, inplace in (("chroma blend", "simple_blend", 3, 6, True), ("chroma blend", "simple_blend", 1, 4, False), ("luma overlay", "simple_blend", 4, 5, False),
                                         ("averaged luma overlay", "simple_blend", 2, 3, True), ("blend_screen", "multi_blends", 1, 7, False), ("blend_burn", "multi_blends", 2, 16, True),
