@@ -1622,7 +1622,9 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
   // a launch that fits one generation of workgroups (one or two 4K tracks) is a matter of latency, not of streaming order: order 1 there (graph replay, one frame 12.09 us
   // against 12.45 with order 2 and 12.24 with order 0; config 3 12.19 / 12.62 / 12.33; two tracks 20.0 / 21.05 / 20.5)
-  if (a.row_major < 0) a.row_major = (!pr->do_blur && (long long)a.cgroups * a.bands * ntracks > (long long)device_cus() * 8) ? 2 : 1;
+  // With the gaussian (four resident workgroups per CU, one per CU and track): order 2 from a whole generation on -- 4 tracks 42.3 -> 41.9 us, 8 88.7 -> 86.9, 16 166.5 -> 164.5;
+  // one and two tracks keep order 1 (16.9 / 26.4 against 17.1 / 27.2).  Round 4's kernel, with its taller bands, had it the other way round.
+  if (a.row_major < 0) a.row_major = ((long long)a.cgroups * a.bands * ntracks >= (long long)device_cus() * (pr->do_blur ? 4 : 8) + (pr->do_blur ? 0 : 1)) ? 2 : 1;
   if (a.bgroup <= 0) a.bgroup = (a.bands % 8 == 0) ? a.bands / 8 : 1;
   a.cw = a.ch = a.ox = a.oy = 0; a.bar_blocks = 0;
   if (cv) { a.cw = cv->nwidth; a.ch = cv->nheight; a.ox = cv->offs_x; a.oy = cv->offs_y; a.bar_blocks = (int)cdiv((unsigned)(a.cw * a.ch - a.dw * a.dh), 1024u); }
