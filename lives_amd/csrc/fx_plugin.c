@@ -25,6 +25,7 @@
 #include "../../include/lives_gpu_weed_abi.h"
 #include "../../include/lives_gpu.h"
 #include "../../include/lives_gpu_layer.h"
+#include "../../include/livesgpu_fx.h"
 
 /* ---- host functions obtained at bootstrap ---- */
 static weed_leaf_get_f w_get;

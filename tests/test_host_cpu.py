@@ -44,6 +44,25 @@ def test_layer_seam_exports_every_declared_symbol():
         assert hasattr(L, s), "include/lives_gpu_layer.h declares %s but liblivesgpu.so does not export it" % s
 
 
+def test_plugin_exports_what_its_header_declares():
+    """include/livesgpu_fx.h: weed_setup and the batch hook are real exported symbols of livesgpu_fx.so, and the header compiles as C beside the layer header"""
+    import ctypes
+    import subprocess
+    import tempfile
+    text = open(os.path.join(ROOT, "include", "livesgpu_fx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(weed_setup|livesgpu_fx_[a-z0-9_]+)\s*\(", text)))
+    assert syms == ["livesgpu_fx_process_batch", "weed_setup"]
+    so = os.path.join(ROOT, "lives_amd", "livesgpu_fx.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(syms) <= exported, exported
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "lives_gpu_layer.h"\n#include "livesgpu_fx.h"\nint main(void) { return (int)sizeof(&livesgpu_fx_process_batch) == 0; }\n')
+        subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src], check=True)
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
