@@ -54,13 +54,28 @@ __device__ __forceinline__ int cavg_lds(int clamped, const float *s_fa, int x, i
   const float fc = __fmaf_rn(__fadd_rn(s_fa[x], s_fa[y]), 0.4375f, 128.f);
   return (int)__builtin_amdgcn_fmed3f(fc, 16.f, 240.f);       // > 240 -> 240, < 16 -> 16, else truncated: one v_med3_f32 instead of two compares and two v_cndmask_b32_e32 (which issue at 1 / 4.6 rate)
 }
+// fa(x) WITHOUT the table: d = x - 128 is exact in float, 255 / 244 = KHI + KLO to 48 bits, and fmaf(d, KHI, d * KLO) rounds the exact d * KHI + fl(d * KLO) once --
+// for all 256 bytes the float the double division gives (k_build_cavgc compares the two forms entry by entry; tests/test_gpu_parity.py::test_chroma_average_table).
+// Four vector operations instead of an LDS gather: for kernels whose LDS pipe is full of table gathers (YUV411 -> RGB: 67 % bank-conflict cycles).
+__device__ __forceinline__ float cavg_fa_arith(float d) { return __fmaf_rn(d, 0x1.0b8a7ep+0f, __fmul_rn(d, -0x1.92e2ap-28f)); }
+__device__ __forceinline__ int cavg_arith(int clamped, int x, int y) {
+  if (!clamped) {
+    const int c = (((x - 128) + (y - 128)) >> 1) + 128;
+    return c > 255 ? 255 : c < 0 ? 0 : c;
+  }
+  const float fc = __fmaf_rn(__fadd_rn(cavg_fa_arith((float)(x - 128)), cavg_fa_arith((float)(y - 128))), 0.4375f, 128.f);
+  return (int)__builtin_amdgcn_fmed3f(fc, 16.f, 240.f);
+}
+__device__ unsigned int d_cavg_forms_differ = 0;
 __device__ const uint8_t *d_cavgc = nullptr;
 // built with the fma form (cavg_lds) the kernels use; tests/test_gpu_parity.py::test_chroma_average_table compares all 65,536 entries with the reference's table
 __global__ __launch_bounds__(256) void k_build_cavgc(uint8_t *t) {
   __shared__ float s_fa[256];
   s_fa[threadIdx.x] = cavg_fa((int)threadIdx.x);
   __syncthreads();
-  t[blockIdx.x * 256 + threadIdx.x] = (uint8_t)cavg_lds(1, s_fa, blockIdx.x, threadIdx.x);
+  const int v = cavg_lds(1, s_fa, blockIdx.x, threadIdx.x);
+  t[blockIdx.x * 256 + threadIdx.x] = (uint8_t)v;
+  if (cavg_arith(1, blockIdx.x, threadIdx.x) != v) atomicAdd(&d_cavg_forms_differ, 1u);      // the table-free form must say the same for every pair
 }
 // the kernels' average: the fma form on a per-workgroup fa table in LDS.  Every kernel that calls cavg() runs cavg_init() first, before any thread returns.
 // (Round 1 gathered from a 64 KB table in global memory; the table is still built, for the test that compares it with the reference's.)
@@ -436,6 +451,14 @@ __device__ __forceinline__ void put_colour(uint8_t *d, int bgr, const int32_t *t
   const int r = clamp255((yy + t[256 + V]) >> 16), g = clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = clamp255((yy + t[1024 + U]) >> 16);
   d[0] = (uint8_t)(bgr ? b : r); d[1] = (uint8_t)g; d[2] = (uint8_t)(bgr ? r : b);
 }
+// the same from PAIRED tables -- {R_V, G_V}[v] and {G_U, B_U}[u] as 8-byte entries: three LDS gathers per pixel instead of five (the kernel is bound by them)
+__device__ __forceinline__ int clamp255m(int v) { int d; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(d) : "v"(v), "v"(255)); return d; }
+__device__ __forceinline__ uint32_t colour24p(int bgr, const int32_t *ty, const int2 *tv, const int2 *tu, int Y, int U, int V) {
+  const int32_t yy = ty[Y];
+  const int2 vv = tv[V], uu = tu[U];
+  const uint32_t r = (uint32_t)clamp255m((yy + vv.x) >> 16), g = (uint32_t)clamp255m((yy + uu.x + vv.y) >> 16), b = (uint32_t)clamp255m((yy + uu.y) >> 16);
+  return bgr ? (b | (g << 8) | (r << 16)) : (r | (g << 8) | (b << 16));
+}
 __device__ __forceinline__ uint32_t colour24(int bgr, const int32_t *t, int Y, int U, int V) {       // put_colour's three bytes as bits 0..23
   const int32_t yy = t[Y];
   const uint32_t r = (uint32_t)clamp255((yy + t[256 + V]) >> 16), g = (uint32_t)clamp255((yy + t[512 + U] + t[768 + V]) >> 16), b = (uint32_t)clamp255((yy + t[1024 + U]) >> 16);
@@ -447,8 +470,11 @@ __device__ __forceinline__ uint32_t colour24(int bgr, const int32_t *t, int Y, i
 __global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a, uint32_t gmagic, uint32_t ncells, const FxFrames F) {
   a.src[0] = F.in0[blockIdx.y][0]; a.dst[0] = F.out[blockIdx.y][0];      // blockIdx.y: the frame of a batched launch
   __shared__ int32_t s_t[5 * 256];
+  __shared__ int2 s_v2[256], s_u2[256];
   __shared__ float s_fa[256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
+  s_v2[threadIdx.x] = make_int2(a.tables[256 + threadIdx.x], a.tables[768 + threadIdx.x]);       // {R_V, G_V}
+  s_u2[threadIdx.x] = make_int2(a.tables[512 + threadIdx.x], a.tables[1024 + threadIdx.x]);      // {G_U, B_U}
   s_fa[threadIdx.x] = cavg_fa((int)threadIdx.x);             // kBlock == 256
   __syncthreads();
   const int wm = a.width;                                   // macropixels per row
@@ -468,22 +494,22 @@ __global__ __launch_bounds__(kBlock) void k_yuv411_to_rgb(PalArgs a, uint32_t gm
       const uint32_t w0 = *reinterpret_cast<const uint32_t *>(cb), w1 = *reinterpret_cast<const uint16_t *>(cb + 4);      // u y0 y1 v | y2 y3
       const int cu = w0 & 0xFF, cv = w0 >> 24, y0_ = (w0 >> 8) & 0xFF, y1_ = (w0 >> 16) & 0xFF, y2_ = w1 & 0xFF, y3_ = w1 >> 8;
       uint32_t c0, c1, c2, c3;
-      if (first) { c0 = colour24(0, s_t, y0_, cu, cv); c1 = colour24(bgr, s_t, y1_, cu, cv); }
+      if (first) { c0 = colour24p(0, s_t, s_v2, s_u2, y0_, cu, cv); c1 = colour24p(bgr, s_t, s_v2, s_u2, y1_, cu, cv); }
       else {
         const uint32_t pw = *reinterpret_cast<const uint32_t *>(cb - 6);          // the block on the left: u at byte 0, v at byte 3
         const int pu = pw & 0xFF, pv = pw >> 24;
-        const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pu, cu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, pv, cv), cv);
-        c0 = colour24(bgr, s_t, y0_, cavg_lds(cl, s_fa, qu, pu), cavg_lds(cl, s_fa, qv, pv));
-        c1 = colour24(bgr, s_t, y1_, cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
+        const int qu = cavg_arith(cl, cavg_arith(cl, pu, cu), cu), qv = cavg_arith(cl, cavg_arith(cl, pv, cv), cv);
+        c0 = colour24p(bgr, s_t, s_v2, s_u2, y0_, cavg_arith(cl, qu, pu), cavg_arith(cl, qv, pv));
+        c1 = colour24p(bgr, s_t, s_v2, s_u2, y1_, cavg_arith(cl, qu, cu), cavg_arith(cl, qv, cv));
       }
       uint32_t a2 = 0xFFu, a3 = 0xFFu;
-      if (last) { c2 = colour24(0, s_t, y2_, cu, cv); c3 = colour24(0, s_t, y3_, cu, cv); }
+      if (last) { c2 = colour24p(0, s_t, s_v2, s_u2, y2_, cu, cv); c3 = colour24p(0, s_t, s_v2, s_u2, y3_, cu, cv); }
       else {
         const uint32_t nw = *reinterpret_cast<const uint32_t *>(cb + 6);          // the block on the right
         const int nu = nw & 0xFF, nv = nw >> 24;
-        const int qu = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cu, nu), cu), qv = cavg_lds(cl, s_fa, cavg_lds(cl, s_fa, cv, nv), cv);
-        c2 = colour24(bgr, s_t, y2_, cavg_lds(cl, s_fa, qu, cu), cavg_lds(cl, s_fa, qv, cv));
-        c3 = colour24(bgr, s_t, y3_, cavg_lds(cl, s_fa, qu, nu), cavg_lds(cl, s_fa, qv, nv));
+        const int qu = cavg_arith(cl, cavg_arith(cl, cu, nu), cu), qv = cavg_arith(cl, cavg_arith(cl, cv, nv), cv);
+        c2 = colour24p(bgr, s_t, s_v2, s_u2, y2_, cavg_arith(cl, qu, cu), cavg_arith(cl, qv, cv));
+        c3 = colour24p(bgr, s_t, s_v2, s_u2, y3_, cavg_arith(cl, qu, nu), cavg_arith(cl, qv, nv));
         const uint2 old_ = *reinterpret_cast<const uint2 *>(d + 8);
         a2 = aoff ? old_.x >> 24 : old_.x & 0xFF; a3 = aoff ? old_.y >> 24 : old_.y & 0xFF;
       }
@@ -1075,6 +1101,9 @@ extern "C" int lgpu_chroma_average_table(uint8_t out[65536]) {
   const uint8_t *d = nullptr;
   LGPU_HIP(hipMemcpyFromSymbol(&d, HIP_SYMBOL(d_cavgc), sizeof d));
   LGPU_HIP(hipMemcpy(out, d, 65536, hipMemcpyDeviceToHost));
+  unsigned int differ = 0;
+  LGPU_HIP(hipMemcpyFromSymbol(&differ, HIP_SYMBOL(d_cavg_forms_differ), sizeof differ));
+  if (differ) { set_error("the table-free chroma average differs from the table form for %u pairs", differ); return LGPU_E_HIP; }
   return LGPU_OK;
 }
 
