@@ -378,7 +378,12 @@ def main():
         if multi:
             # the ranks the communicator really has (ncclCommCount), not what the launcher promised: a line that says N GPUs over a smaller communicator is refused
             nr = comm.count() if comm is not None else 0
-            assert comm is None or nr == world, "the RCCL communicator has %d ranks, the job %d" % (nr, world)
+            if nr < 0:           # ncclCommCount is bound as optional: a librccl without it (or a failed call) is "unknown", not a reason to lose the measurement
+                from lives_amd import lib as _lib
+                msg = _lib.load().lgpu_last_error()
+                nr = "unavailable (%s)" % (msg.decode() if msg else "error %d" % nr)
+            else:
+                assert comm is None or nr == world, "the RCCL communicator has %d ranks, the job %d" % (nr, world)
             out["config"]["rccl_ranks"] = nr
             if world > 1:
                 out["config"]["rccl_preflight"] = rccl_preflight if rccl_preflight is not None else "not run (librccl could not be bound on every rank)"

@@ -91,12 +91,27 @@ lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int widt
 /* which of the reference's two resize bodies resize_layer / resize_layer_full (and the scaling inside letterbox_layer / unletterbox_layer) follow:
    LIVES_GPU_RESIZE_PIXBUF (default) -- the gdk-pixbuf body (src/colourspace.c:15262-15322), bit-exact to gdk_pixbuf_scale_simple 2.42.8 for the palettes of
      its switch (RGB24, BGR24, RGBA32, BGRA32, YUV888, YUVA8888): alpha-weighted colours on 4-byte palettes, rowstride ALIGN4(width * channels), RGB layers
-     come back tagged WEED_GAMMA_SRGB, no gamma pass.  A palette outside the switch that needs scaling fails as that body does (:15303-15307: the warning on
-     stderr, FALSE, the layer as it came -- a pinned one synchronised and unpinned), so the caller's own CPU body or the other backend takes it;
+     come back tagged WEED_GAMMA_SRGB, no gamma pass.  In front of it runs the reference's palette resolution (get_resizable + the pre-conversion,
+     :14869-14912; see lives_gpu_get_resizable below): a frame in a palette outside the switch is first converted -- YUV420P with an RGBA32 hint becomes RGBA32,
+     ARGB32 with an RGBA32 hint becomes RGBA32 -- and then scaled; FALSE (the layer as the failed step left it, a pinned one synchronised and unpinned)
+     only where the reference has no route either (e.g. YUV420P with a YUV420P hint: its LIVES_FATAL) or where its own post-check fails (:14916-14923);
    LIVES_GPU_RESIZE_POLYPHASE -- the swscale body's place (:14940-15259), the choice of a host "built with USE_SWSCALE"; libswscale is un-vendored and
      unpinned, so the arithmetic is this library's own spec "lgpu-polyphase-v1" (DESIGN.md), every palette, fused target gamma.
    A separate call so that lives_gpu_prefs keeps its layout.  Returns 0, -1 on a bad value. */
 enum { LIVES_GPU_RESIZE_POLYPHASE = 0, LIVES_GPU_RESIZE_PIXBUF = 1 };
+/* The planner's capability queries of the same header range (src/colourspace.h:400-407; callers src/nodemodel.c:131, :143, :210, :2961), answered for the
+   bodies of THIS library so that a host which swapped the bodies plans for what will run:
+   get_resizable (src/colourspace.c:14577-14669) -- the palette a frame is scaled in, with weed_palette_is_resizable() = the switch of the resize body in force
+     (PIXBUF: RGB24 / BGR24 / RGBA32 / BGRA32 / YUV888 / YUVA8888, the reference's own rule without swscale, :2619-2643; POLYPHASE: packed RGB and planar YUV).
+     Returns LIVES_RESULT_SUCCESS 1 / LIVES_RESULT_FAIL 0 (also where the reference ends in LIVES_FATAL: no resizable route).  resize_layer_full runs it in front
+     of the body exactly as the reference does (:14869-14912): a YUV420P frame with an RGBA32 hint is converted, then scaled;
+   get_tgt_gamma (:14736-14740); can_inline_gamma (:12128-12145) -- TRUE where this library folds the target gamma into the conversion kernel (RGB <-> RGB,
+     4:2:0 / 4:2:2 planar -> RGB, RGB -> UYVY / YUYV); pconv_can_inplace (:12148-12157) -- TRUE where the conversion keeps the layer's pixel_data (UYVY <-> YUYV only:
+     every other conversion of this library writes new planes). */
+int lives_gpu_get_resizable(int *ppalette, int *pxpal, int *oclamp_hint, int *opal, int *pxopal, lives_gpu_boolean upscale);
+int lives_gpu_get_tgt_gamma(int ipal, int opal);
+lives_gpu_boolean lives_gpu_can_inline_gamma(int inpl, int opal);
+lives_gpu_boolean lives_gpu_pconv_can_inplace(int inpl, int outpl);
 int lives_gpu_set_resize_backend(int backend);
 int lives_gpu_get_resize_backend(void);
 lives_gpu_boolean lives_gpu_letterbox_layer(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp,
@@ -159,6 +174,10 @@ void lives_gpu_transfer_stats(unsigned long long *h2d_bytes, unsigned long long 
 #define letterbox_layer lives_gpu_letterbox_layer
 #define create_empty_pixel_data lives_gpu_create_empty_pixel_data
 #define calc_rowstrides lives_gpu_calc_rowstrides
+#define get_resizable lives_gpu_get_resizable
+#define get_tgt_gamma lives_gpu_get_tgt_gamma
+#define can_inline_gamma lives_gpu_can_inline_gamma
+#define pconv_can_inplace lives_gpu_pconv_can_inplace
 #endif
 
 #ifdef __cplusplus

@@ -328,13 +328,16 @@ int lgpu_stepper_wait(lgpu_stepper *s, int timeout_ms) {
   if (!s) { lgpu::set_error("lgpu_stepper_wait: null stepper"); return LGPU_E_BADARG; }
   if (s->failed) { lgpu::set_error("lgpu_stepper_wait: the stepper is out of step: destroy it"); return LGPU_E_STATE; }
   const auto t0 = std::chrono::steady_clock::now();
-  void *streams[3] = {s->comm ? s->side : nullptr, s->launch, s->launch2};
+  // which streams take part is a matter of state, not of pointer values: the first launch stream may be the NULL stream (lgpu_stepper_create accepts it, and
+  // hipStreamQuery(NULL) is a valid query of it); the side stream only carries work with a communicator, the second launch stream only while the overlap is on
+  void *streams[3] = {s->side, s->launch, s->launch2};
+  const bool used[3] = {s->comm != nullptr && s->side != nullptr, true, s->launch2 != nullptr};
   const char *names[3] = {"the parameter exchange (side stream): a peer has not entered the same lgpu_stepper_feed / lgpu_chain_step", "a chain launch (first launch stream)",
                           "a chain launch (second launch stream)"};
   for (unsigned spin = 0;; spin++) {
     int busy = -1;
     for (int i = 0; i < 3 && busy < 0; i++) {
-      if (!streams[i]) continue;
+      if (!used[i]) continue;
       const int q = lgpu_stream_query(streams[i]);
       if (q < 0) { s->failed = 1; return q; }
       if (q == 0) busy = i;

@@ -37,3 +37,10 @@ EXPORT boolean compact_rowstrides(weed_layer_t *l) { return lives_gpu_compact_ro
 EXPORT boolean create_empty_pixel_data(weed_layer_t *l, boolean black_fill, boolean may_contig) { return lives_gpu_create_empty_pixel_data(l, black_fill, may_contig); }
 EXPORT boolean weed_layer_clear_pixel_data(weed_layer_t *l) { return lives_gpu_weed_layer_clear_pixel_data(l); }
 EXPORT int *calc_rowstrides(int width, int pal, weed_layer_t *l, int *nplanes) { return lives_gpu_calc_rowstrides(width, pal, l, nplanes); }
+/* the planner's queries of the same header range (src/colourspace.h:400-407) */
+EXPORT int get_resizable(int *ppalette, int *pxpal, int *oclamp_hint, int *opal, int *pxopal, boolean upscale) {
+  return lives_gpu_get_resizable(ppalette, pxpal, oclamp_hint, opal, pxopal, upscale);
+}
+EXPORT int get_tgt_gamma(int ipal, int opal) { return lives_gpu_get_tgt_gamma(ipal, opal); }
+EXPORT boolean can_inline_gamma(int inpl, int opal) { return lives_gpu_can_inline_gamma(inpl, opal); }
+EXPORT boolean pconv_can_inplace(int inpl, int outpl) { return lives_gpu_pconv_can_inplace(inpl, outpl); }

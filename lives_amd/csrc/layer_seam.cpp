@@ -61,6 +61,9 @@ void set_bool(weed_plant_t *p, const char *k, int v) { int32_t x = v; g_api.leaf
 
 bool pal_is_rgb(int p) { return p >= WEED_PALETTE_RGB24 && p <= WEED_PALETTE_ARGB32; }
 bool pal_is_planar_yuv(int p) { return p == WEED_PALETTE_YUV420P || p == WEED_PALETTE_YVU420P || p == WEED_PALETTE_YUV422P || p == WEED_PALETTE_YUV444P || p == WEED_PALETTE_YUVA4444P; }
+bool pal_is_yuv(int p) {
+  return pal_is_planar_yuv(p) || p == WEED_PALETTE_UYVY || p == WEED_PALETTE_YUYV || p == WEED_PALETTE_YUV888 || p == WEED_PALETTE_YUVA8888 || p == WEED_PALETTE_YUV411;
+}
 bool pal_is_444(int p) { return p == WEED_PALETTE_YUV444P || p == WEED_PALETTE_YUVA4444P; }
 bool pal_alpha_first(int p) { return p == WEED_PALETTE_ARGB32; }
 bool pal_alpha_last(int p) { return p == WEED_PALETTE_RGBA32 || p == WEED_PALETTE_BGRA32; }
@@ -822,9 +825,13 @@ static lives_gpu_boolean convert_layer_palette_full_body(lives_gpu_layer_t *laye
   // The reference's own first steps (range switch :12241-12262, un-premultiply :12290-12306) are done first here too.  If the
   // conversion proper is then declined, the layer is in the state the reference has at that point and its CPU body continues from
   // there (both steps are no-ops the second time: the leaves they test have been updated).
-  if (!pal_is_rgb(inpl) && !pal_is_rgb(outpl) && l.clamping >= 0 && (l.clamping != oclamping || l.subspace != osubspace)) {
-    // YUV -> YUV with a different range: same subspace = in-place table switch; a subspace change goes through RGB in the reference
-    if (l.subspace != osubspace) return decline(layer);
+  if (pal_is_yuv(inpl) && pal_is_yuv(outpl) && ((l.clamping >= 0 && l.clamping != oclamping) || l.subspace != osubspace)) {      // :12241 (iclamping = oclamping without the leaf, :12216-12218)
+    // YUV -> YUV with a different range: same subspace = in-place table switch (:12242-12247); a subspace change goes through RGB(A) (:12248-12262) -- the
+    // frame is taken to RGB24 / RGBA32 with its own tables and converted from there with the target's range and subspace, as the reference does it
+    if (l.subspace != osubspace) {
+      if (!lives_gpu_convert_layer_palette(layer, pal_has_alpha(inpl) ? WEED_PALETTE_RGBA32 : WEED_PALETTE_RGB24, 0)) return 0;
+      return convert_layer_palette_full_body(layer, outpl, oclamping, osampling, osubspace, tgt_gamma);
+    }
     if (!switch_layer_clamping(layer, l, oclamping)) return 0;
     if (!read_layer(layer, &l)) return 0;
   }
@@ -1081,32 +1088,141 @@ static bool pal_is_pixbuf(int pal) {      // the cases of the switch at :15275-1
          pal == WEED_PALETTE_YUV888 || pal == WEED_PALETTE_YUVA8888;
 }
 
-// The pixbuf body: the value resize_layer_full returns.  A palette outside the switch fails as the reference's body does (:15303-15307: the warning, FALSE,
-// the layer as it came); a host that wants those palettes scaled on the device selects the polyphase backend, one that keeps its CPU bodies runs its own.
-//   * size rules of the common prologue (:14854-14868): even source size only for the "nothing to do" test, width / height >= 4, even target height
-//   * clamped YUV888 / YUVA8888 is first switched to unclamped (:15277-15284)
+// ---- the palette resolution in front of the resize bodies, and the planner's capability queries (src/colourspace.h:400-407) ------------------------------
+// The reference answers these from its CPU rules; exported under the reference's names by liblivesgpu_dropin.so, they describe the bodies of THIS library, so
+// that a planner which swapped the bodies plans for what will run (callers: src/nodemodel.c:131, :143, :210, :2961).
+// weed_palette_is_resizable (:2647-2654) for the body in force.  PIXBUF: the switch of a build without swscale (weed_palette_conv_resizable, :2619-2643), which is
+// also the switch of the gdk-pixbuf body itself (:15275-15290).  POLYPHASE: what that body scales as it comes (packed RGB, planar YUV).
+static bool pal_resizable(int pal) {
+  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF) return pal_is_pixbuf(pal);
+  return pal_is_rgb(pal) || pal_is_planar_yuv(pal);
+}
+static int masq_pal(int pal) {                                         // get_masq_pal (:14500-14513)
+  if (g_resize_backend.load() != LIVES_GPU_RESIZE_PIXBUF) return WEED_PALETTE_NONE;      // the polyphase body scales a palette as what it is or not at all
+  if (pal == WEED_PALETTE_RGBA32 || pal == WEED_PALETTE_BGRA32 || pal == WEED_PALETTE_YUVA8888) return WEED_PALETTE_RGBA32;
+  if (pal == WEED_PALETTE_RGB24 || pal == WEED_PALETTE_BGR24 || pal == WEED_PALETTE_YUV888) return WEED_PALETTE_RGB24;
+  if (pal == WEED_PALETTE_YVU420P) return WEED_PALETTE_YUV420P;
+  return WEED_PALETTE_NONE;
+}
+static int inter_pal(int inpal, int outpal, bool upscale) {            // get_inter_pal (:14516-14575)
+  const bool both_alpha = pal_has_alpha(inpal) && pal_has_alpha(outpal), any_planar = pal_is_planar_yuv(inpal) || pal_is_planar_yuv(outpal);
+  const int rgb = both_alpha ? WEED_PALETTE_RGBA32 : WEED_PALETTE_RGB24;
+  const int yuv = any_planar ? (both_alpha ? WEED_PALETTE_YUVA4444P : WEED_PALETTE_YUV444P) : (both_alpha ? WEED_PALETTE_YUVA8888 : WEED_PALETTE_YUV888);
+  if (pal_is_rgb(inpal) && pal_is_rgb(outpal)) return rgb;
+  if (pal_is_yuv(inpal) && pal_is_yuv(outpal)) return yuv;
+  // rgb <-> yuv (or a hint that is neither: ANY): convert before an upscale, after a downscale
+  if (pal_is_rgb(inpal)) return upscale ? yuv : rgb;
+  return upscale ? rgb : yuv;
+}
+// get_resizable (:14577-14669).  LIVES_RESULT_SUCCESS = 1, LIVES_RESULT_FAIL = 0 (src/defs.h:211-212).  Where the reference ends in LIVES_FATAL ("Unable to
+// convert from palette ...": neither the intermediate palette nor a masquerade of it is resizable) this returns FAIL with the arguments as they came.
+int lives_gpu_get_resizable(int *ppalette, int *pxpal, int *oclamp_hint, int *opal, int *pxopal, lives_gpu_boolean upscale) {
+  if (!ppalette || !opal) return 0;
+  int resolved = WEED_PALETTE_NONE;
+  const int palette = *ppalette;
+  int xpalette = palette, opal_hint = *opal, xopal_hint = opal_hint;
+  const bool in_resizable = pal_resizable(palette), out_resizable = pal_resizable(opal_hint);
+  if (in_resizable) {
+    if (opal_hint != WEED_PALETTE_ANY) {
+      if (out_resizable) resolved = palette;
+      else if (upscale) {
+        const int omasq = masq_pal(opal_hint);
+        if (omasq != WEED_PALETTE_NONE) { resolved = opal_hint; xpalette = xopal_hint = omasq; }
+      }
+    }
+    if (resolved == WEED_PALETTE_NONE) resolved = xopal_hint = opal_hint = xpalette = palette;
+  } else if (out_resizable) {
+    if (!upscale || opal_hint == WEED_PALETTE_ANY) {
+      const int imasq = masq_pal(palette);
+      if (imasq) { resolved = opal_hint = palette; xpalette = xopal_hint = imasq; }
+    }
+    if (resolved == WEED_PALETTE_NONE) resolved = xpalette = xopal_hint = opal_hint;
+  } else {
+    int imasq = resolved = inter_pal(palette, opal_hint, upscale != 0);
+    if (resolved == WEED_PALETTE_NONE || !pal_resizable(resolved)) {
+      if (resolved != WEED_PALETTE_NONE) imasq = masq_pal(resolved);
+      if (imasq == WEED_PALETTE_NONE) return 0;                        // LIVES_FATAL in the reference
+    }
+    opal_hint = resolved;
+    xpalette = xopal_hint = imasq;
+  }
+  if (resolved == WEED_PALETTE_NONE) return 0;
+  *ppalette = resolved;
+  *opal = opal_hint;
+  if (pxpal) *pxpal = xpalette;
+  if (pxopal) *pxopal = xopal_hint;
+  if (oclamp_hint && pal_is_yuv(resolved) && pal_is_rgb(xpalette)) *oclamp_hint = WEED_YUV_CLAMPING_UNCLAMPED;
+  return 1;
+}
+int lives_gpu_get_tgt_gamma(int ipal, int opal) { return (pal_is_rgb(ipal) && pal_is_yuv(opal)) ? WEED_GAMMA_SRGB : WEED_GAMMA_UNKNOWN; }      // :14736-14740
+// can_inline_gamma (:12128-12145) for the conversions of this library: a target gamma is folded into the conversion kernel for RGB <-> RGB (LUT8 in the
+// swizzle), 4:2:0 / 4:2:2 planar -> RGB (the 16-bit LUT of :3274-3283) and RGB -> UYVY / YUYV; every other pair takes its gamma as a separate pass (the
+// reference's rule answers TRUE for more pairs than its own conversions honour).
+lives_gpu_boolean lives_gpu_can_inline_gamma(int inpl, int opal) {
+  if (pal_is_rgb(inpl) && pal_is_rgb(opal)) return 1;
+  if ((inpl == WEED_PALETTE_YUV420P || inpl == WEED_PALETTE_YVU420P || inpl == WEED_PALETTE_YUV422P) && pal_is_rgb(opal)) return 1;
+  if (pal_is_rgb(inpl) && (opal == WEED_PALETTE_UYVY || opal == WEED_PALETTE_YUYV)) return 1;
+  return 0;
+}
+// pconv_can_inplace (:12148-12157): TRUE where the conversion leaves the layer's pixel_data where it is.  Here every conversion writes new planes (the old ones go
+// back through the host's allocator) except the byte swap between the two packed 4:2:2 orders; the planner books one more frame for the others (src/nodemodel.c:2961).
+lives_gpu_boolean lives_gpu_pconv_can_inplace(int inpl, int outpl) {
+  return (inpl == WEED_PALETTE_UYVY && outpl == WEED_PALETTE_YUYV) || (inpl == WEED_PALETTE_YUYV && outpl == WEED_PALETTE_UYVY);
+}
+
+// The gdk-pixbuf form of resize_layer_full (src/colourspace.c:14759-14937 + :15262-15322): the value it returns.
+//   * size rules (:14854-14868): even source size only for the "nothing to do" test, width / height >= 4, even target height
+//   * the palette resolution every build runs BEFORE its body (:14869-14912): get_resizable picks the palette the frame is scaled in -- a palette outside the body's
+//     switch is first converted (to the hinted palette when that one is resizable, else to an intermediate one), with the target-gamma decision of :14890-14899
+//     handed to that conversion; the call ends FALSE where the reference does: no resizable route (its LIVES_FATAL), or the layer does not have the resolved
+//     palette / the hinted clamping afterwards (:14916-14923).  Quirk R2 (docs/QUIRKS.md): weed_layer_get_yuv_clamping() answers 0 = CLAMPED for a layer
+//     without the leaf, which is every RGB layer, so an RGB frame with oclamp_hint UNCLAMPED fails that test -- as in the reference (unletterbox_layer :15628 passes
+//     exactly that)
+//   * clamped YUV888 / YUVA8888 is switched to unclamped inside the body (:15277-15284)
 //   * the WHOLE layer (odd sizes included: the sizes are re-read at :15263-15264) is scaled; 4-byte palettes weight colours by alpha
 //   * the new frame has the pixbuf's rowstride, ALIGN4(width * channels), and RGB layers come back tagged WEED_GAMMA_SRGB (pixbuf_to_layer :14378-14379,
 //     :14405-14406), whatever they were tagged before; no gamma LUT runs in this body
 static int width_pixels(const Layer &l) {       // weed_layer_get_width_pixels: the width leaf counts macropixels
   return (l.pal == WEED_PALETTE_UYVY || l.pal == WEED_PALETTE_YUYV) ? l.width * 2 : l.pal == WEED_PALETTE_YUV411 ? l.width * 4 : l.width;
 }
-static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int interp) {
+static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint, int osamp_hint, int osubs_hint, int tgt_gamma) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
+  if (opal_hint == WEED_PALETTE_NONE) opal_hint = WEED_PALETTE_ANY;                  // :14822
   if (width <= 0 || height <= 0) return 0;
-  const int iwidth = (width_pixels(l) >> 1) << 1, iheight = (l.height >> 1) << 1;
+  int iwidth = (width_pixels(l) >> 1) << 1, iheight = (l.height >> 1) << 1;
   if (width < 4) width = 4;
   if (height < 4) height = 4;
   if (iwidth != width || iheight != height) height = (height >> 1) << 1;
   if (iwidth == width && iheight == height) return 1;
+  const int palette = l.pal;
+  int iclamping = l.clamping < 0 ? 0 : l.clamping;                                   // weed_layer_get_yuv_clamping: 0 without the leaf
+  int resolved = palette, xpalette, xopal_hint;
+  const int upscale = (long)width * height > (long)iwidth * iheight;
+  if (!lives_gpu_get_resizable(&resolved, &xpalette, &oclamp_hint, &opal_hint, &xopal_hint, upscale)) {
+    fprintf(stderr, "Unable to convert from palette %d to palette %d\n", palette, opal_hint);
+    return decline(layer);
+  }
+  if (tgt_gamma == WEED_GAMMA_UNKNOWN && pal_is_yuv(opal_hint) && osubs_hint == WEED_YUV_SUBSPACE_BT709) tgt_gamma = WEED_GAMMA_BT709;      // :14890-14899
+  if (tgt_gamma == WEED_GAMMA_UNKNOWN) tgt_gamma = lives_gpu_get_tgt_gamma(palette, opal_hint);
+  if (tgt_gamma == WEED_GAMMA_UNKNOWN) tgt_gamma = l.gamma;
+  if (tgt_gamma == WEED_GAMMA_BT709 && pal_is_yuv(opal_hint)) osubs_hint = WEED_YUV_SUBSPACE_BT709;
+  if (resolved != palette || oclamp_hint != iclamping) {
+    lives_gpu_convert_layer_palette_full(layer, resolved, oclamp_hint, osamp_hint, osubs_hint, tgt_gamma);      // :14907 (its value is not looked at there either)
+    if (!read_layer(layer, &l)) return 0;
+  }
+  iclamping = l.clamping < 0 ? 0 : l.clamping;
+  if (l.pal != resolved || iclamping != oclamp_hint) return decline(layer);          // :14916-14923
+  iwidth = (width_pixels(l) >> 1) << 1; iheight = (l.height >> 1) << 1;
+  if (iwidth == width && iheight == height) return 1;
+  // ---- the body (:15262-15322)
   if (width_pixels(l) == width && l.height == height) return 1;                     // "no resize needed" (:15265-15270) comes before the switch, for every palette
   if (!pal_is_pixbuf(l.pal) || (interp != LIVES_INTERP_FAST && interp != LIVES_INTERP_NORMAL && interp != LIVES_INTERP_BEST)) {
     if (!pal_is_pixbuf(l.pal)) fprintf(stderr, "Warning: resizing unknown palette %d\n", l.pal);
     fprintf(stderr, "unable to scale layer to %d x %d for palette %d\n", width, height, l.pal);
     return decline(layer);
   }
-  if ((l.pal == WEED_PALETTE_YUV888 || l.pal == WEED_PALETTE_YUVA8888) && l.clamping != WEED_YUV_CLAMPING_UNCLAMPED) {
+  if ((l.pal == WEED_PALETTE_YUV888 || l.pal == WEED_PALETTE_YUVA8888) && iclamping == WEED_YUV_CLAMPING_CLAMPED) {
     if (!lives_gpu_convert_layer_palette(layer, l.pal, WEED_YUV_CLAMPING_UNCLAMPED)) return 0;
     if (!read_layer(layer, &l)) return 0;
   }
@@ -1128,18 +1244,18 @@ static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int in
   return 1;
 }
 
-// resize_layer_full (src/colourspace.c:14759-15328).  osamp_hint / osubs_hint only parameterise the reference's swscale colourspace
-// details for conversions done inside the scaler; this path never converts inside the resize (the layer keeps its palette, "layer palette
-// should be checked on return", :14746-14751), so they take part in the target-gamma decision only (:14890-14899).
-static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int osubs_hint, int tgt_gamma);
+// resize_layer_full (src/colourspace.c:14759-15328).  PIXBUF backend: the reference's own sequence (palette resolution, pre-conversion, gdk-pixbuf body).
+// POLYPHASE backend (the opt-in standing where the swscale body stands): the layer keeps its palette when the scaler takes it as it is (packed RGB, planar YUV;
+// "layer palette should be checked on return", :14746-14751), a packed-YUV frame is first taken to the hinted palette, and osamp_hint / osubs_hint take part in
+// the target-gamma decision only (:14890-14899).
+static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint, int osamp_hint, int osubs_hint, int tgt_gamma);
 lives_gpu_boolean lives_gpu_resize_layer_full(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint,
                                               int osamp_hint, int osubs_hint, int tgt_gamma) {
-  (void)oclamp_hint; (void)osamp_hint;
   PinScope pin(layer);
-  return pin.settle(resize_layer_full_body(layer, width, height, interp, opal_hint, osubs_hint, tgt_gamma));
+  return pin.settle(resize_layer_full_body(layer, width, height, interp, opal_hint, oclamp_hint, osamp_hint, osubs_hint, tgt_gamma));
 }
-static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int osubs_hint, int tgt_gamma) {
-  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF) return resize_pixbuf_body(layer, width, height, interp);
+static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint, int osamp_hint, int osubs_hint, int tgt_gamma) {
+  if (g_resize_backend.load() == LIVES_GPU_RESIZE_PIXBUF) return resize_pixbuf_body(layer, width, height, interp, opal_hint, oclamp_hint, osamp_hint, osubs_hint, tgt_gamma);
   ResizePlan rp;
   int rc;
   if (plan_resize(layer, width, height, opal_hint, osubs_hint, tgt_gamma, &rp, &rc) != 1) return rc;
@@ -1153,7 +1269,7 @@ static lives_gpu_boolean resize_layer_full_body(lives_gpu_layer_t *layer, int wi
 
 lives_gpu_boolean lives_gpu_resize_layer(lives_gpu_layer_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint) {
   return lives_gpu_resize_layer_full(layer, width, height, interp, opal_hint, oclamp_hint, WEED_YUV_SAMPLING_DEFAULT,
-                                     WEED_YUV_SUBSPACE_YUV, WEED_GAMMA_UNKNOWN);                          // :15331-15334
+                                     WEED_YUV_SUBSPACE_YCBCR, WEED_GAMMA_UNKNOWN);                        // :15331-15335
 }
 
 static lives_gpu_boolean letterbox_layer_body(lives_gpu_layer_t *layer, int nwidth, int nheight, int width, int height, int interp, int tpal, int tclamp);

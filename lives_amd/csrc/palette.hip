@@ -1088,6 +1088,14 @@ static int ensure_cavgc() {
     set_error("building the chroma average table failed");
     return LGPU_E_HIP;
   }
+  // the kernels average chroma WITHOUT the table (cavg_arith: fmaf with split constants); k_build_cavgc has just compared that form with the table form for all
+  // 65,536 pairs.  A compiler or target change that moved the arithmetic would otherwise give wrong 4:1:1 bytes with no error at run time: fail here instead.
+  unsigned int differ = 0;
+  if (hipMemcpyFromSymbol(&differ, HIP_SYMBOL(d_cavg_forms_differ), sizeof differ) != hipSuccess || differ) {
+    (void)hipFree(d);
+    set_error("the table-free chroma average differs from the table form for %u of 65536 pairs: this build's arithmetic is not the reference's", differ);
+    return LGPU_E_HIP;
+  }
   tab[dev] = d;
   return LGPU_OK;
 }

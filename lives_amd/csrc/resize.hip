@@ -1814,7 +1814,7 @@ static int try_half8(const Bank *hb, const Bank *vb, int sw, int sh, int irow, i
     hipLaunchKernelGGL((k_half8s<DBG_, ABL_>), dim3((unsigned)grid), dim3(kH8sThreads), lds, st, a, t, l);              \
   } while (0)
 #ifdef LGPU_PROFILING
-  const bool dbg_s = tune_on(TUNE_PLAN_DEBUG);
+  const bool dbg_s = tune_on(TUNE_PHASE_PROFILE);      // LGPU_PLAN_DEBUG only prints: the run being diagnosed keeps its timing and captures into graphs
   if (dbg_s) {     // in-kernel phase profile: s_memtime ticks between fixed points of the tile loop, per wave
     static unsigned long long *g_dbg_s = nullptr;
     constexpr int nw = kH8sCW + 2;
@@ -2049,7 +2049,7 @@ static int launch_sep(const SepPlan &p, const SepTracks &t, const Lut8 &l, hipSt
         if (gcd(w - k, ap.tiles_x) <= 2) { w -= k; break; }
       g = w << 3;
     }
-    const bool s2p_dbg = tune_on(TUNE_PLAN_DEBUG);
+    const bool s2p_dbg = tune_on(TUNE_PHASE_PROFILE);      // the instrumented kernel path (allocates, synchronises): its own switch, not LGPU_PLAN_DEBUG
     ap.dbg = nullptr;
     const int nwv = (p.mh_r ? kS2pMhCW : 4) + 2;
     if (s2p_dbg) { LGPU_HIP(hipMalloc((void **)&ap.dbg, (size_t)g * nwv * 8 * 8)); LGPU_HIP(hipMemsetAsync(ap.dbg, 0, (size_t)g * nwv * 8 * 8, st)); }

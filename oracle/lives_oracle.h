@@ -196,6 +196,12 @@ int orc_pixbuf_scale(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst,
 int orc_pixbuf_scale_rows(const uint8_t *src, int irow, int sw, int sh, uint8_t *dst, int orow, int dw, int dh, int channels, int interp, int y0, int y1);
 int *orc_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff);
 void orc_pixbuf_free(void *p);
+/* the palette resolution in front of resize_layer_full's body and the planner's queries (oracle/orc_resizable.c; src/colourspace.c:14500-14669, :14736-14740,
+   :12128-12157), for a build without swscale; pinned by tests/golden/resizable.npz */
+int orc_get_resizable(int *io);
+int orc_get_tgt_gamma(int ipal, int opal);
+int orc_can_inline_gamma(int inpl, int opal);
+int orc_pconv_can_inplace(int inpl, int outpl);
 /* B1 (UNPINNED, build-defined): separable [1 4 6 4 1]/16 per axis, edge replicate, one rounding */
 void orc_gauss5(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height, int psize);
 

@@ -49,7 +49,7 @@ def build_oracle(force=False, native=False):
     ubsan = bool(os.environ.get("LGPU_ORACLE_UBSAN")) and not native          # tools/oracle_ubsan.sh: the restatement under -fsanitize=undefined
     so = os.path.join(HERE, "liblives_oracle_native.so" if native else "liblives_oracle_ubsan.so" if ubsan else "liblives_oracle.so")
     sig = so + ".sig"
-    srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_pixbuf.c", "orc_bench.c", "lives_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("lives_oracle.c", "orc_pixbuf.c", "orc_bench.c", "orc_resizable.c", "lives_oracle.h")]
     srcs = [s for s in srcs if os.path.exists(s)]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if native and not stale:

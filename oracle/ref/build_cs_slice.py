@@ -29,6 +29,8 @@ import sys
 REF = os.environ.get("LIVES_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.normpath(os.path.join(HERE, "..", "_ref"))
+# scratch translation units and the include-path symlinks stay outside the repo (build_ref.sh sets LIVES_REF_WORK); only the .so lands in oracle/_ref
+WORK = os.environ.get("LIVES_REF_WORK", os.path.join(os.environ.get("TMPDIR", "/tmp"), "lives_ref_work"))
 
 
 def lines(path, a, b):
@@ -417,6 +419,7 @@ def find_line(path, needle, start=1):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    os.makedirs(WORK, exist_ok=True)
     cs = "src/colourspace.c"
     ch = "src/colourspace.h"
     parts = [PRELUDE]
@@ -476,12 +479,12 @@ def main():
     parts.append(lines(cs, 9259, 10577))            # K1 swizzle family
     parts.append(lines(cs, 14034, 14060))           # gamma_convert_layer_thread
     parts.append(WRAPPERS)
-    src = os.path.join(OUT, "cs_slice.c")
+    src = os.path.join(WORK, "cs_slice.c")
     with open(src, "w") as f:
         f.write("/* GENERATED SCRATCH FILE -- contains reference text; never commit (oracle/_ref is git-ignored) */\n")
         f.write("".join(parts))
     so = os.path.join(OUT, "libcsref.so")
-    cmd = ["gcc", "-shared", "-fPIC", "-O1", "-w", "-fno-strict-aliasing", "-I", os.path.join(OUT, "inc"), "-o", so, src, "-lm"]
+    cmd = ["gcc", "-shared", "-fPIC", "-O1", "-w", "-fno-strict-aliasing", "-I", os.path.join(WORK, "inc"), "-o", so, src, "-lm"]
     print(" ".join(cmd))
     r = subprocess.run(cmd)
     if r.returncode:
@@ -489,7 +492,7 @@ def main():
     print("built", so)
     # compositor: only paint_pixel (lives-plugins/weed-plugins/gdk/compositor.c:120-125) is sliceable -- the rest of that
     # plugin needs gdk-pixbuf headers.  The wrapper walks the paint loop of :288-293 over one layer.
-    comp = os.path.join(OUT, "comp_slice.c")
+    comp = os.path.join(WORK, "comp_slice.c")
     with open(comp, "w") as f:
         f.write("/* GENERATED SCRATCH FILE -- contains reference text; never commit */\n#include <stdint.h>\n")
         f.write(lines("lives-plugins/weed-plugins/gdk/compositor.c", 120, 125))

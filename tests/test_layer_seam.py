@@ -102,10 +102,14 @@ def test_declines_and_device_failures_leave_the_layer_untouched(seam, orc):
     Y, U, V = frame(rng, 64, 32, 1), frame(rng, 32, 32, 1), frame(rng, 32, 32, 1)
     lay = wh.new_layer(522, 64, 32, [Y, U, V], clamping=0, subspace=1)
     s0 = snapshot(lay)
-    assert L.lives_gpu_convert_layer_palette(lay, YUV888, 0) == 0 and same(s0, snapshot(lay))
-    lay = wh.new_layer(YUV888, 64, 32, [frame(rng, 64, 32, 3)], clamping=0, subspace=1)
-    s0 = snapshot(lay)
-    assert L.lives_gpu_convert_layer_palette_full(lay, 589, 0, 0, 2, 0) == 0 and same(s0, snapshot(lay))        # YCbCr -> BT.709: through RGB in the reference
+    assert L.lives_gpu_convert_layer_palette_full(lay, YUV888, 0, 0, 1, 0) == 0 and same(s0, snapshot(lay))
+    # a subspace change between YUV palettes goes through RGB(A) as in the reference (src/colourspace.c:12248-12262): equal to the two conversions done by hand
+    for (pal, planes, outpl, osub) in ((522, [Y, U, V], YUV888, 0), (YUV888, [frame(rng, 64, 32, 3)], 589, 2)):
+        lay = wh.new_layer(pal, 64, 32, planes, clamping=0, subspace=1)
+        assert L.lives_gpu_convert_layer_palette_full(lay, outpl, 0, 0, osub, 0) == 1
+        twin = wh.new_layer(pal, 64, 32, planes, clamping=0, subspace=1)
+        assert L.lives_gpu_convert_layer_palette(twin, RGB24, 0) == 1 and L.lives_gpu_convert_layer_palette_full(twin, outpl, 0, 0, osub, 0) == 1
+        assert same(snapshot(lay), snapshot(twin)) and wh.geti(lay, "current_palette") == outpl
     # (2) injected allocation failures inside calls that are served: sizes nobody used before, so every call has to allocate
     for nth, (bw, bh) in ((1, (2303, 1301)), (2, (2603, 1501))):     # larger than any frame so far: both scratch slots have to grow in each round
         big = frame(rng, bw, bh, 4)
@@ -608,9 +612,15 @@ def test_yuv_layer_clamping_switch(seam, orc):
         for i in range(len(planes)):
             assert (got[i] == want[i]).all(), (pal, i)
         assert wh.geti(lay, "YUV_clamping") == 1 and wh.geti(lay, "current_palette") == pal
-        # a subspace change is not served on the GPU (the reference goes through RGB): FALSE, layer untouched
+        # a subspace change goes through RGB as in the reference (:12248-12262): the layer comes back in the same palette with the target's range and subspace
         lay2 = wh.new_layer(pal, lw, h, planes, clamping=0, subspace=1)
-        assert L.lives_gpu_convert_layer_palette_full(lay2, pal, 1, 0, 2, 0) == 0 and wh.geti(lay2, "YUV_clamping") == 0
+        twin = wh.new_layer(pal, lw, h, planes, clamping=0, subspace=1)
+        ok = L.lives_gpu_convert_layer_palette_full(lay2, pal, 1, 0, 2, 0)
+        assert L.lives_gpu_convert_layer_palette(twin, 1, 0) == 1
+        assert ok == L.lives_gpu_convert_layer_palette_full(twin, pal, 1, 0, 2, 0)
+        if ok:
+            assert (wh.geti(lay2, "YUV_clamping"), wh.geti(lay2, "current_palette")) == (1, pal)
+            assert all((a == b).all() for a, b in zip(wh.planes_of(lay2)[0], wh.planes_of(twin)[0]))
 
 
 @needs_ref

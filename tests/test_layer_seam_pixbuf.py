@@ -77,42 +77,153 @@ def test_size_rules_of_the_common_prologue(seam, orc, pixbuf_backend):
     assert (wh.planes_of(lay)[0][0][:20, :16] == want).all()
 
 
-def test_palettes_outside_the_pixbuf_switch_fail_as_the_reference_body_does(seam, orc, pixbuf_backend):
-    """src/colourspace.c:15303-15307: "Warning: resizing unknown palette", retval FALSE, the layer as it came (a pinned one synchronised and unpinned); the
-    nothing-to-do tests (:14854-14868, :15265-15270) come before the switch and answer TRUE for every palette; the polyphase backend is the opt-in that scales them"""
+def yuv420_planes(rng, w, h):
+    ys, cs = align(w), align(w) >> 1
+    return (rng.integers(16, 236, (h, ys), dtype=np.uint8), rng.integers(16, 241, (h // 2, cs), dtype=np.uint8), rng.integers(16, 241, (h // 2, cs), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("pinned", [0, 1])
+@pytest.mark.parametrize("geom", [(128, 64, 64, 32), (130, 74, 200, 112)])
+def test_yuv420p_with_the_hint_res_substep_passes_is_converted_then_scaled(seam, orc, pixbuf_backend, pinned, geom):
+    """src/nodemodel.c:1187 calls resize_layer(layer, w, h, interp, opalette, oclamping); for a decoder's YUV420P frame and an RGBA32 hint get_resizable resolves
+    RGBA32 (src/colourspace.c:14625-14637), convert_layer_palette_full runs (:14907) and the gdk-pixbuf body scales the result.  Expected side: orc_yuv420p_to_rgb ->
+    orc_pixbuf_scale, nothing of the library (quirk A4's undefined pixels of the first stage are taken from a separately converted twin, as in test_dropin.py)"""
     L, wh = seam
-    rng = np.random.default_rng(0x9DB5)
-    src = frame(rng, 128, 64, 4)
+    w, h, dw, dh = geom
+    rng = np.random.default_rng(0x9DC0 + w)
+    Y, U, V = yuv420_planes(rng, w, h)
+    lay = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=1, clamping=0, subspace=1)
+    if pinned:
+        assert L.lives_gpu_layer_pin(lay) == 0
+    assert L.lives_gpu_resize_layer(lay, dw, dh, 3, RGBA32, 0) == 1
+    if pinned:
+        assert wh.geti(lay, "host_gpu_resident") == 1 and L.lives_gpu_layer_unpin(lay) == 0
+    got, _, rs = wh.planes_of(lay)
+    assert (wh.geti(lay, "current_palette"), wh.geti(lay, "width"), wh.geti(lay, "height")) == (RGBA32, dw, dh) and rs[0] == dw * 4
+    assert wh.geti(lay, "YUV_clamping") is None and wh.geti(lay, "gamma_type") == 1
+    import ctypes
+    strides = (ctypes.c_int * 3)(Y.strides[0], U.strides[0], V.strides[0])
+    rgba = np.zeros((h, align(w * 4)), np.uint8)
+    orc.orc_yuv420p_to_rgb(P(Y), P(U), P(V), strides, U.size, V.size, P(rgba), rgba.strides[0], w, h, 4, 0, 0, 0, 2, None, 0)
+    twin = wh.new_layer(YUV420P, w, h, [Y, U, V], gamma=1, clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette(twin, RGBA32, 0) == 1
+    first = wh.planes_of(twin)[0][0][:, :w * 4].reshape(h, w, 4)
+    a4 = np.zeros((h, w), bool)
+    a4[0, 1::2] = True
+    a4[h - 1, 1::2] = True
+    view = rgba[:, :w * 4].reshape(h, w, 4)
+    assert (first[~a4] == view[~a4]).all()
+    view[a4] = first[a4]
+    want = want_scaled(orc, rgba, w, h, dw, dh, 4, 3)
+    assert (got[0][:dh, :dw * 4] == want).all()
+
+
+def scaled_twin(L, wh, orc, pal, w, h, planes, kw, to_pal, clamp, dw, dh, ch, interp):
+    """the expected side of a resolved resize: the library's own (separately oracle-tested) conversion of a twin layer, then the ORACLE's gdk-pixbuf scale"""
+    twin = wh.new_layer(pal, w, h, planes, **kw)
+    assert L.lives_gpu_convert_layer_palette_full(twin, to_pal, clamp, 0, 1, 0) == 1
+    tp, _, trs = wh.planes_of(twin)
+    tw = wh.geti(twin, "width")
+    return want_scaled(orc, np.ascontiguousarray(tp[0]), tw, h, dw, dh, ch, interp), twin
+
+
+def test_palettes_outside_the_switch_take_the_route_get_resizable_resolves(seam, orc, pixbuf_backend):
+    """ARGB32 with an RGBA32 hint -> RGBA32 (get_inter_pal, :14516-14521); without a hint RGB24 when reducing and YUV888 when enlarging (:14539-14557: "if upscaling,
+    better to convert yuv / rgb now"); UYVY with an RGB24 hint -> RGB24 in both directions.  Each: TRUE, the resolved palette, the pixels = conversion then scale;
+    pinned == unpinned"""
+    L, wh = seam
+    rng = np.random.default_rng(0x9DC5)
+    src = frame(rng, 128, 64, 4, alpha_mix=True)
+    uy = frame(rng, 64, 64, 4)                                                            # UYVY: 64 macropixels = 128 pixels
+    uy[:] = np.clip(uy, 16, 235)
+    for (pal, planes, kw, hint, dw, dh, res, ch, interp) in (
+            (ARGB32, [src], dict(gamma=1), RGBA32, 64, 32, RGBA32, 4, 3), (ARGB32, [src], dict(gamma=1), 0, 64, 32, RGB24, 3, 3),
+            (ARGB32, [src], dict(gamma=1), RGBA32, 200, 100, RGBA32, 4, 2),
+            (UYVY, [uy], dict(clamping=0, subspace=1), RGB24, 64, 32, RGB24, 3, 3), (UYVY, [uy], dict(clamping=0, subspace=1), RGB24, 200, 96, RGB24, 3, 2)):
+        w = 128
+        want, _ = scaled_twin(L, wh, orc, pal, planes[0].shape[1] // 4 if pal == UYVY else w, 64, planes, kw, res, 0, dw, dh, ch, interp)
+        outs = []
+        for pinned in (0, 1):
+            lay = wh.new_layer(pal, planes[0].shape[1] // 4 if pal == UYVY else w, 64, planes, **kw)
+            if pinned:
+                assert L.lives_gpu_layer_pin(lay) == 0
+            assert L.lives_gpu_resize_layer(lay, dw, dh, interp, hint, 0) == 1, (pal, hint, dw, dh)
+            if pinned:
+                assert wh.geti(lay, "host_gpu_resident") == 1 and L.lives_gpu_layer_unpin(lay) == 0
+            assert (wh.geti(lay, "current_palette"), wh.geti(lay, "width"), wh.geti(lay, "height")) == (res, dw, dh), (pal, hint)
+            outs.append(wh.planes_of(lay)[0][0][:dh, :dw * ch])
+            assert (outs[-1] == want).all(), (pal, hint, dw, dh, pinned)
+    # ARGB32 enlarged without a hint: through YUV888 -- converted with the clamping the caller hinted (CLAMPED), switched to UNCLAMPED inside the body (:15277-15284)
+    lay = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
+    assert L.lives_gpu_resize_layer(lay, 200, 100, 3, 0, 0) == 1
+    assert (wh.geti(lay, "current_palette"), wh.geti(lay, "width"), wh.geti(lay, "height"), wh.geti(lay, "YUV_clamping")) == (YUV888, 200, 100, 1)
+    twin = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
+    assert L.lives_gpu_convert_layer_palette_full(twin, YUV888, 0, 0, 1, 1) == 1 and L.lives_gpu_convert_layer_palette(twin, YUV888, 1) == 1
+    want = want_scaled(orc, np.ascontiguousarray(wh.planes_of(twin)[0][0]), 128, 64, 200, 100, 3, 3)
+    assert (wh.planes_of(lay)[0][0][:100, :600] == want).all()
+
+
+def test_where_the_reference_has_no_route_the_call_fails_and_the_layer_is_as_it_came(seam, orc, pixbuf_backend):
+    """YUV420P with a YUV420P hint or, reducing, without one: get_inter_pal answers YUV444P, which neither scales nor masquerades -- the reference's LIVES_FATAL
+    (:14641-14650); here FALSE, the layer untouched, a pinned one synchronised and unpinned.  The nothing-to-do tests (:14854-14868) still come first."""
+    L, wh = seam
+    rng = np.random.default_rng(0x9DC6)
+    Y, U, V = yuv420_planes(rng, 128, 64)
     for pinned in (0, 1):
-        lay = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
-        if pinned:
-            assert L.lives_gpu_layer_pin(lay) == 0
-        assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 0
-        assert wh.geti(lay, "host_gpu_resident") is None
-        assert (wh.geti(lay, "width"), wh.geti(lay, "height"), wh.geti(lay, "current_palette")) == (128, 64, ARGB32)
-        assert (wh.planes_of(lay)[0][0] == src).all()
-        assert L.lives_gpu_resize_layer(lay, 128, 64, 3, 0, 0) == 1                       # no resize needed
-        assert L.lives_gpu_letterbox_layer(lay, 160, 80, 64, 32, 3, 0, 0) == 0           # the inner resize fails first (:15389)
-        assert (wh.geti(lay, "width"), wh.geti(lay, "height")) == (128, 64)
-    ys = align(128)
-    Y, U, V = frame(rng, 128, 64, 1), frame(rng, 64, 32, 1), frame(rng, 64, 32, 1)
+        for hint in (YUV420P, 0):
+            lay = wh.new_layer(YUV420P, 128, 64, [Y, U, V], clamping=0, subspace=1)
+            if pinned:
+                assert L.lives_gpu_layer_pin(lay) == 0
+            assert L.lives_gpu_resize_layer(lay, 128, 64, 3, hint, 0) == 1                # no resize needed
+            assert L.lives_gpu_resize_layer(lay, 64, 32, 3, hint, 0) == 0
+            assert wh.geti(lay, "host_gpu_resident") is None
+            assert (wh.geti(lay, "width"), wh.geti(lay, "height"), wh.geti(lay, "current_palette")) == (128, 64, YUV420P)
+            got = wh.planes_of(lay)[0]
+            assert (got[0] == Y).all() and (got[1] == U).all() and (got[2] == V).all()
+            assert L.lives_gpu_letterbox_layer(lay, 160, 80, 64, 32, 3, hint, 0) == 0      # the inner resize fails first (:15389)
+    # enlarging without a hint has a route: RGB24 first (:14559-14563)
     lay = wh.new_layer(YUV420P, 128, 64, [Y, U, V], clamping=0, subspace=1)
-    assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 0 and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (128, 64)
-    uy = frame(rng, 32, 32, 4)                                                            # UYVY: 32 macropixels = 64 pixels
-    lay = wh.new_layer(UYVY, 32, 32, [uy], clamping=0, subspace=1)
-    assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1                            # width in PIXELS equals the layer's: nothing to do
-    assert L.lives_gpu_resize_layer(lay, 32, 32, 3, 0, 0) == 0 and wh.geti(lay, "width") == 32
-    # the opt-in: a host "built with USE_SWSCALE"
+    assert L.lives_gpu_resize_layer(lay, 256, 128, 2, 0, 0) == 1 and wh.geti(lay, "current_palette") == RGB24
+    # the opt-in: a host "built with USE_SWSCALE" scales the planes as they are
     assert L.lives_gpu_set_resize_backend(POLYPHASE) == 0
     try:
-        lay = wh.new_layer(ARGB32, 128, 64, [src], gamma=1)
-        assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1
-        planes, _, rs = wh.planes_of(lay)
-        want = np.zeros((32, rs[0]), np.uint8)
-        assert orc.orc_resize(P(src), src.strides[0], 128, 64, P(want), rs[0], 64, 32, 4, 3) == 0
-        assert (planes[0][:, :256] == want[:, :256]).all()
+        lay = wh.new_layer(YUV420P, 128, 64, [Y, U, V], clamping=0, subspace=1)
+        assert L.lives_gpu_resize_layer(lay, 64, 32, 3, 0, 0) == 1 and wh.geti(lay, "current_palette") == YUV420P
     finally:
         assert L.lives_gpu_set_resize_backend(PIXBUF) == 0
+
+
+def test_quirk_r2_an_rgb_layer_with_an_unclamped_hint_fails_the_post_check(seam, orc, pixbuf_backend):
+    """:14916-14923 compares weed_layer_get_yuv_clamping(layer) -- 0 = CLAMPED for a layer without the leaf, i.e. every RGB layer -- with oclamp_hint: an RGB frame
+    with the hint UNCLAMPED fails although nothing about it is YUV.  unletterbox_layer passes exactly that hint (:15628): its cut happens, its final resize does not."""
+    L, wh = seam
+    rng = np.random.default_rng(0x9DC7)
+    src = frame(rng, 96, 64, 4)
+    lay = wh.new_layer(RGBA32, 96, 64, [src], gamma=1)
+    assert L.lives_gpu_resize_layer(lay, 48, 32, 3, RGBA32, 1) == 0 and (wh.geti(lay, "width"), wh.geti(lay, "height")) == (96, 64)
+    assert (wh.planes_of(lay)[0][0] == src).all()
+    assert L.lives_gpu_resize_layer(lay, 48, 32, 3, RGBA32, 0) == 1
+    lay = wh.new_layer(RGBA32, 96, 64, [src], gamma=1)
+    assert L.lives_gpu_unletterbox_layer(lay, -1, -1, 6, 10, 8, 12) == 0
+    assert (wh.geti(lay, "width"), wh.geti(lay, "height")) == (76, 48), "the borders are gone, the frame was not scaled back"
+    lay = wh.new_layer(RGBA32, 96, 64, [src], gamma=1)
+    assert L.lives_gpu_unletterbox_layer(lay, 0, 0, 6, 10, 8, 12) == 1
+
+
+def test_the_target_gamma_goes_into_the_pre_conversion(seam, orc, pixbuf_backend):
+    """:14890-14907: tgt_gamma is handed to convert_layer_palette_full, which fuses it (LUT16 for 4:2:0 -> RGB); then the body tags the RGB frame SRGB whatever it was"""
+    L, wh = seam
+    rng = np.random.default_rng(0x9DC8)
+    Y, U, V = yuv420_planes(rng, 128, 64)
+    lay = wh.new_layer(YUV420P, 128, 64, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer_full(lay, 64, 32, 3, RGBA32, 0, 0, 1, 1) == 1
+    twin = wh.new_layer(YUV420P, 128, 64, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    assert L.lives_gpu_convert_layer_palette_full(twin, RGBA32, 0, 0, 1, 1) == 1 and wh.geti(twin, "gamma_type") == 1
+    want = want_scaled(orc, np.ascontiguousarray(wh.planes_of(twin)[0][0]), 128, 64, 64, 32, 4, 3)
+    assert (wh.planes_of(lay)[0][0][:32, :256] == want).all() and wh.geti(lay, "gamma_type") == 1
+    plain = wh.new_layer(YUV420P, 128, 64, [Y, U, V], gamma=-1, clamping=0, subspace=1)
+    assert L.lives_gpu_resize_layer(plain, 64, 32, 3, RGBA32, 0) == 1
+    assert not (wh.planes_of(plain)[0][0][:32, :256] == want).all(), "without a target the LINEAR frame is converted as it is"
 
 
 def test_reductions_past_the_one_step_range_are_declined(seam, pixbuf_backend):

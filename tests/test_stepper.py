@@ -93,3 +93,29 @@ def test_stepper_refuses_what_would_put_it_out_of_step(gpu):
             st.step(None, prm, trk)
     finally:
         st.close()
+
+
+def test_wait_covers_a_stepper_on_the_null_stream(gpu):
+    """lgpu_stepper_create accepts the NULL stream as its launch stream (torch's default stream IS handle 0): lgpu_stepper_wait has to poll it like any other --
+    it returns only once the launches are complete (queried right after it, with no other synchronisation), not after a look at the side stream alone"""
+    import torch
+    from lives_amd import dist as ld, lib
+    L = lib.load()
+    rng = np.random.default_rng(6)
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    d_src = dev(rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8))
+    d_l2, d_out = dev(rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8)), dev(np.zeros((dh, dw * 4), np.uint8))
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | 0x100, do_blur=1, bf=1, lut=None)
+    trk = gpu.chain_tracks([d_src] * 8, [d_l2] * 8, [d_out] * 8)
+    assert torch.cuda.current_stream().cuda_stream == 0
+    torch.cuda.synchronize()
+    st = ld.Stepper(None, [10])                      # stream=None -> torch's current stream = the NULL stream
+    try:
+        st.feed([[v] for v in range(1, 40)])
+        for _ in range(40):                           # ~40 x 8 tracks x 20 us: a few milliseconds of queued work
+            st.step(None, prm, trk)
+        assert L.lgpu_stream_query(None) == 0, "the launches are still running when the host gets here"
+        st.wait(20000)
+        assert L.lgpu_stream_query(None) == 1, "lgpu_stepper_wait came back while its launch stream was busy"
+    finally:
+        st.close()
