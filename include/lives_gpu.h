@@ -205,6 +205,8 @@ int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *d
    path is a batch of independent frames, one per live clip track (src/effects-weed.c:1850-2425 runs an instance once per track per tick; compositor.c:262-266
    scales every layer of a frame): the weight tables, the per-launch cost of thousands of small workgroups and the launch itself are paid once.  Results are those
    of nframes single calls, bit for bit.  Alignment requirements apply to the least aligned frame. */
+/* what lgpu_pixbuf_scale would answer for this geometry, nothing launched (the weight table is built and cached): LGPU_OK / LGPU_E_BADARG / LGPU_E_UNSUPPORTED */
+int lgpu_pixbuf_scale_check(int sw, int sh, int dw, int dh, int channels, int interp, void *stream);
 int lgpu_pixbuf_scale_batch(const uint8_t *const *src_d, uint8_t *const *dst_d, int nframes, int irow, int sw, int sh, int orow, int dw, int dh, int channels,
                             int interp, void *stream);
 int lgpu_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, int *n_x, int *n_y, int *xoff, int *yoff, int32_t *table, size_t table_ints);

@@ -135,6 +135,24 @@ int lives_gpu_get_rowstride_alignment_hint(void);
 int lives_gpu_layer_pin(lives_gpu_layer_t *layer);      /* upload the planes once, mark the layer resident */
 int lives_gpu_layer_sync(lives_gpu_layer_t *layer);     /* download the current planes into pixel_data; stays pinned */
 int lives_gpu_layer_unpin(lives_gpu_layer_t *layer);    /* sync, release the device copies, clear the leaf */
+/* A layer whose planes ALREADY lie in device memory the caller owns (a hardware decoder's output surfaces, a frame an earlier pass left in HBM): pinned with
+   those buffers as its resident planes -- no upload, no copy.  The library reads them in place (in-place seam calls write them), never frees them; keep them
+   valid until the layer's pixel_data has been replaced by a seam call or the layer is synchronised / unpinned / forgotten.  producer_stream: where their
+   contents were produced (NULL = the null stream); producer_done != 0: that work is known to be complete, nobody has to wait for it. */
+int lives_gpu_layer_pin_device(lives_gpu_layer_t *layer, const void *const *planes_d, int nplanes, void *producer_stream, int producer_done);
+/* ---- deferred execution on pinned layers (on by default).  The host bytes of a pinned layer are stale until lives_gpu_layer_sync(), so the seam calls of one
+   track's plan step on an RGBA32 / BGRA32 frame -- convert_layer_palette (R <-> B), resize_layer[_full] (gdk-pixbuf body), letterbox_layer, livesgpu_fx.so's
+   "chroma blend" in place, gamma_convert_layer -- are RECORDED on the plane (every leaf changes as in the eager call) and run as ONE launch of the fused chain
+   kernel: by themselves when anyone needs the pixels (another seam call, an effect, sync / unpin), or for all tracks of a tick together when the host calls
+   lives_gpu_layers_flush(layers, n) after its plan steps have returned (programs of equal shape share the launch: this is lgpu_chain, reached through the
+   reference's own calls).  Results are those of the eager calls, bit for bit (tests/test_deferred.py).  What a stage can refuse is checked when it is recorded;
+   device failures at run time surface at the flush / sync that runs the program.  lives_gpu_set_deferred(0) launches every call by itself (returns the old value). */
+int lives_gpu_set_deferred(int on);
+int lives_gpu_layers_flush(lives_gpu_layer_t *const *layers, int nlayers);
+/* counters since load: [0] stages recorded, [1] fused chain launches made for pending programs, [2] programs (tracks) those carried, [3] programs run stage by stage */
+void lives_gpu_deferred_stats(unsigned long long out[4]);
+/* (for livesgpu_fx.so) record an in-place "chroma blend" of the pending plane dst_host with the resident plane layer2_host; 1 = recorded, 0 = run the kernel */
+int lives_gpu_deferred_blend_chroma(const void *dst_host, int orow, int width, int height, int palette, const void *layer2_host, int irow2, int bf);
 /* the host is about to free or replace the pixel_data of a pinned layer itself (weed_layer_pixel_data_free, an error path): release the
    device copies without a download and clear the leaf.  Device copies are keyed by host plane pointer, so this (or unpin) MUST precede
    any release of a pinned layer's planes that does not go through this library. */

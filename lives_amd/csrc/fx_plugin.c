@@ -117,6 +117,8 @@ typedef struct {
 
 typedef int (*fx_kernel_f)(const fxframe_t *f, weed_plant_t *inst, int kind);
 
+static int k_simple(const fxframe_t *f, weed_plant_t *inst, int kind);
+static int param_int(weed_plant_t *inst, int idx, int dflt);
 static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f kernel, int whole_frame) {
   fxdata_t *fx = fx_data(inst);
   weed_plant_t *ochan = (weed_plant_t *)g_ptr(inst, WEED_LEAF_OUT_CHANNELS, 0);
@@ -146,6 +148,10 @@ static weed_error_t fx_run(weed_plant_t *inst, int nin, int kind, fx_kernel_f ke
     f.src[i] += (size_t)offset * f.irow[i];                           /* inputs are NOT pre-offset (simple_blend.c:87-91) */
   }
   f.inplace = (f.src[0] == f.dst);
+  /* "chroma blend" in place on a pinned layer whose plane is still a pending program of the layer seam (convert -> resize -> ... recorded, not yet run): the
+     blend joins the program and the whole chain runs as one launch when the host flushes its tracks or needs the pixels (include/lives_gpu_layer.h) */
+  if (kernel == k_simple && kind == 0 && nin == 2 && f.inplace && offset == 0 && slice_h == real_h &&
+      lives_gpu_deferred_blend_chroma(f.dst, f.orow, f.width, f.height, f.pal, f.src[1], f.irow[1], param_int(inst, 0, 128))) return WEED_SUCCESS;
   /* stage to the device: in rows as they are (rowstride preserved so alignment-dependent paths match).  A channel whose pixel_data is the
      plane of a pinned layer (lives_gpu_layer_pin, include/lives_gpu_layer.h) is used where it lives in HBM: no upload, and for the out
      channel no download -- the device copy is the plane until lives_gpu_layer_sync() */

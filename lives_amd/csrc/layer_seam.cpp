@@ -155,7 +155,12 @@ void *S() {
 // call measured 4 - 8 us each on these streams: 9 -> 17 us per seam call).
 // `stream` is where the last WRITE (or exclusive use) was enqueued; `rs` are other streams that have enqueued READS since (two effect instances on two pool
 // threads may read one layer at the same time): a reader waits for the writer only, a writer for the writer and all readers.
-struct Dev { void *d = nullptr; size_t bytes = 0; void *stream = nullptr; void *rs[4] = {nullptr, nullptr, nullptr, nullptr}; int nr = 0; };
+struct Lazy;
+// lazy: the plane is not computed yet -- it stands for a pending program (deferred execution, below; d is null then).  external: caller-owned device memory
+// (lives_gpu_layer_pin_device) that never enters the pool.  lazy_readers: pending programs of OTHER planes read this one (their layer 2): they run before it is
+// written, replaced or dropped.
+struct Dev { void *d = nullptr; size_t bytes = 0; void *stream = nullptr; void *rs[4] = {nullptr, nullptr, nullptr, nullptr}; int nr = 0;
+             Lazy *lazy = nullptr; bool external = false; int lazy_readers = 0; };
 static char g_idle_tag;
 void *const kIdle = &g_idle_tag;                  // Dev::stream of a buffer whose last use is known to be complete (the stream was synchronised since)
 // The table lock: a dozen sub-microsecond critical sections per seam call.  A futex mutex here made sixteen host threads run slower than one (every
@@ -243,8 +248,11 @@ bool pool_take(size_t n, Dev *out) {
   *out = b;
   return true;
 }
+void lazy_discard(Lazy *z);
+void lazy_run_readers_of(const void *h);
 void pool_give(Dev b) {
-  if (!b.d) return;
+  if (b.lazy) { lazy_discard(b.lazy); return; }       // a pending program nobody will ever look at: its source frame goes back, nothing runs
+  if (!b.d || b.external) return;
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     if (g_pool_bytes + b.bytes <= kPoolMaxBytes) {
@@ -260,6 +268,7 @@ void pool_give(Dev b) {
 void res_put(const void *h, Dev b) {
   Dev old;
   b.stream = S(); b.nr = 0;
+  lazy_run_readers_of(h);
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     Dev &e = g_res[h];
@@ -271,6 +280,7 @@ void res_put(const void *h, Dev b) {
 
 void res_drop(const void *h) {
   Dev b;
+  lazy_run_readers_of(h);
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     auto it = g_res.find(h);
@@ -284,6 +294,14 @@ void res_drop(const void *h) {
 // are registered under interior pointers and must not survive it (a later block at the same address would otherwise inherit their device copies)
 void res_drop_range(const void *base, size_t bytes) {
   std::vector<Dev> gone;
+  {
+    std::vector<const void *> read;
+    {
+      std::lock_guard<SpinLock> lk(g_res_mu);
+      for (auto &kv : g_res) if ((uintptr_t)kv.first >= (uintptr_t)base && (uintptr_t)kv.first < (uintptr_t)base + bytes && kv.second.lazy_readers > 0) read.push_back(kv.first);
+    }
+    for (const void *h : read) lazy_run_readers_of(h);
+  }
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     for (auto it = g_res.begin(); it != g_res.end();) {
@@ -429,13 +447,20 @@ bool sync() { return lgpu_sync(S()) == LGPU_OK; }
 // resident device copy of a plane of the layer the call in progress works on (only pinned layers have one: the table is
 // keyed by host pointer, and a host pointer proves nothing about a layer that was never pinned), ready for work on the calling
 // thread's stream.  The caller marks the plane (touch_done) once its work is enqueued.
+bool lazy_materialise(const void *h);
 uint8_t *acquire(const void *h, size_t n, bool write) {
   Dev b;
-  {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    auto it = g_res.find(h);
-    if (it == g_res.end() || it->second.bytes < n) return nullptr;
-    b = it->second;
+  for (int pass = 0;; pass++) {
+    {
+      std::lock_guard<SpinLock> lk(g_res_mu);
+      auto it = g_res.find(h);
+      if (it == g_res.end() || it->second.bytes < n) return nullptr;
+      b = it->second;
+    }
+    if (!b.lazy && !(write && b.lazy_readers > 0)) break;
+    if (pass > 3) return nullptr;
+    if (b.lazy && !lazy_materialise(h)) return nullptr;       // whoever needs the pixels themselves gets them: the pending program runs now, on this thread's stream
+    if (write && b.lazy_readers > 0) lazy_run_readers_of(h);    // programs that still read this plane see it as it is now
   }
   await(b, write);
   return (uint8_t *)b.d;
@@ -534,6 +559,244 @@ int lives_gpu_layer_unpin_impl(weed_plant_t *layer);
 lives_gpu_boolean decline(weed_plant_t *layer) {
   if (t_pinned && layer) lives_gpu_layer_unpin_impl(layer);
   return 0;
+}
+
+// ---- deferred execution on pinned layers ------------------------------------------------------------------------------------------------
+// The host bytes of a pinned layer are stale by contract until lives_gpu_layer_sync(), so nothing obliges a seam call on a pinned layer to have RUN when it
+// returns -- only to have happened, in order, before anybody sees the pixels.  The calls of one track's plan step (src/nodemodel.c:1065-1253: pconv, resize,
+// letterbox substeps; src/effects-weed.c:1850-2425: the filter instance; the gamma substep) on an RGBA32 / BGRA32 frame are therefore RECORDED on the plane
+// instead of launched one by one: R <-> B swizzle, gdk-pixbuf scale, letterbox canvas, "chroma blend" with a second layer, gamma LUT -- in that order, each at
+// most once.  Every leaf of the layer changes exactly as in the eager call (palette, size, rowstrides, a fresh host plane, gamma tag); the plane's entry in the
+// residency table holds the program instead of pixels.  A program runs
+//   * when someone needs the pixels (any other seam call or effect on the plane, lives_gpu_layer_sync / _unpin: through acquire()), by itself;
+//   * when lives_gpu_layers_flush() is handed the layers of a tick: programs of equal shape become ONE launch of the fused chain kernel (lgpu_chain /
+//     lgpu_chain_canvas, one track per layer) -- the launch bench.py times, reached through the reference's own calls;
+//   * before a plane it reads (layer 2 of its blend) is written, replaced or released.
+// What a stage could refuse is checked when it is recorded (palette, geometry, the scaler's range), so a recorded call cannot turn into a FALSE later; a device
+// failure at run time (allocation, launch) surfaces at the flush / sync that runs the program, which then stays pending.
+// lives_gpu_set_deferred(0) switches the recording off (every call launches its own kernels, as before round 6); tests compare the two.
+enum { LZ_NONE = 0, LZ_SWAP = 1, LZ_SCALE = 2, LZ_CANVAS = 3, LZ_BLEND = 4, LZ_LUT = 5 };
+struct Lazy {
+  Dev src;                          // the frame the program starts from (owned: goes back to the pool when the program has run, unless external)
+  int sw = 0, sh = 0, srs = 0;
+  int stage = LZ_NONE;              // the last stage recorded
+  bool swap = false;
+  bool scale = false; int dw = 0, dh = 0, interp = 0;
+  bool canvas = false; int nw = 0, nh = 0, ox = 0, oy = 0;
+  bool blend = false; int bf = 0; const void *l2h = nullptr; Dev l2; int l2rs = 0;
+  bool lut = false; uint8_t lut8[256];
+  int w = 0, h = 0, rs = 0;         // the plane the program stands for
+};
+std::atomic<int> g_deferred{1};
+std::atomic<unsigned long long> g_lz_recorded{0}, g_lz_chain_launches{0}, g_lz_chain_tracks{0}, g_lz_staged{0};      // lives_gpu_deferred_stats
+std::mutex g_lazy_mu;               // one program (group) runs at a time; never taken with g_res_mu held
+bool lazy_pal(int pal) { return pal == WEED_PALETTE_RGBA32 || pal == WEED_PALETTE_BGRA32; }
+
+void lazy_unread(Lazy *z) {          // (no lock held) the program no longer reads its layer 2
+  if (!z->blend || !z->l2h) return;
+  std::lock_guard<SpinLock> lk(g_res_mu);
+  auto it = g_res.find(z->l2h);
+  if (it != g_res.end() && it->second.lazy_readers > 0) it->second.lazy_readers--;
+  z->l2h = nullptr;
+}
+void lazy_discard(Lazy *z) {
+  if (!z) return;
+  lazy_unread(z);
+  Dev src = z->src;
+  delete z;
+  pool_give(src);
+}
+bool lazy_same_shape(const Lazy *a, const Lazy *b) {
+  return a->sw == b->sw && a->sh == b->sh && a->srs == b->srs && a->swap == b->swap && a->scale == b->scale && a->dw == b->dw && a->dh == b->dh &&
+         a->interp == b->interp && a->canvas == b->canvas && a->nw == b->nw && a->nh == b->nh && a->ox == b->ox && a->oy == b->oy && a->blend == b->blend &&
+         a->bf == b->bf && a->l2rs == b->l2rs && a->lut == b->lut && (!a->lut || !memcmp(a->lut8, b->lut8, 256)) && a->w == b->w && a->h == b->h && a->rs == b->rs;
+}
+// one program, stage by stage through stream-ordered scratch frames, into out (the plane's rowstride)
+int lazy_run_staged(const Lazy *z, uint8_t *out) {
+  const uint8_t *cur = (const uint8_t *)z->src.d;
+  int cw = z->sw, ch = z->sh, crs = z->srs, rc = LGPU_OK;
+  void *tmp[3] = {nullptr, nullptr, nullptr};
+  int nt = 0;
+  const int last_geo = z->canvas ? LZ_CANVAS : z->scale ? LZ_SCALE : LZ_SWAP;
+  auto target = [&](int stage, int w, int h, uint8_t **dst, int *drs) -> int {       // where a geometric stage writes: the plane itself for the last one
+    if (stage == last_geo) { *dst = out; *drs = z->rs; return LGPU_OK; }
+    const int r = lgpu_malloc_ordered(&tmp[nt], (size_t)w * 4 * h + 64, S());
+    if (r) return r;
+    *dst = (uint8_t *)tmp[nt++]; *drs = w * 4;
+    return LGPU_OK;
+  };
+  uint8_t *dst = nullptr;
+  int drs = 0;
+  if (!z->swap && !z->scale && !z->canvas) rc = lgpu_copy_rows(out, z->rs, cur, crs, cw * 4, ch, S());      // no geometric stage: the in-place stages work on a copy
+  if (!rc && z->swap) {
+    if (!(rc = target(LZ_SWAP, cw, ch, &dst, &drs))) rc = lgpu_swizzle(LGPU_SWAP3POSTALPHA, 0, cur, crs, dst, drs, cw, ch, nullptr, S());
+    cur = dst; crs = drs;
+  }
+  if (!rc && z->scale) {
+    if (!(rc = target(LZ_SCALE, z->dw, z->dh, &dst, &drs))) rc = lgpu_pixbuf_scale(cur, crs, cw, ch, dst, drs, z->dw, z->dh, 4, z->interp, S());
+    cur = dst; crs = drs; cw = z->dw; ch = z->dh;
+  }
+  if (!rc && z->canvas) {
+    const uint8_t black[4] = {0, 0, 0, 255};
+    if (!(rc = target(LZ_CANVAS, z->nw, z->nh, &dst, &drs))) rc = lgpu_letterbox_at(cur, crs, cw, ch, dst, drs, z->nw, z->nh, 4, black, z->ox, z->oy, S());
+    cur = dst; crs = drs; cw = z->nw; ch = z->nh;
+  }
+  if (!rc && z->blend) rc = lgpu_blend_chroma(out, z->rs, (const uint8_t *)z->l2.d, z->l2rs, out, z->rs, z->w, z->h, 4, 0, z->bf, S());
+  if (!rc && z->lut) rc = lgpu_gamma_apply(out, z->rs, 0, 0, z->w, z->h, 4, 0, z->lut8, S());
+  for (int i = 0; i < nt; i++) lgpu_free_ordered(tmp[i], S());
+  return rc;
+}
+// run n pending programs of ONE shape (g_lazy_mu held by the caller; hs[i]: the host plane zs[i] is registered under).  Afterwards the planes are ordinary
+// resident planes whose last writer is the calling thread's stream.
+int lazy_run_group(Lazy *const *zs, const void *const *hs, int n) {
+  const Lazy *z0 = zs[0];
+  const size_t bytes = (size_t)z0->rs * z0->h;
+  std::vector<Dev> outs((size_t)n);
+  int rc = LGPU_OK;
+  for (int i = 0; i < n; i++)
+    if (!pool_take(bytes, &outs[(size_t)i])) { for (int k = 0; k < i; k++) pool_give(outs[(size_t)k]); return LGPU_E_NOMEM; }
+  for (int i = 0; i < n; i++) {
+    await(zs[i]->src, false);
+    if (zs[i]->blend) await(zs[i]->l2, false);
+    if (z0->rs != z0->w * 4) rc = rc ? rc : lgpu_fill(outs[(size_t)i].d, 0, bytes, S());      // the row padding of a fresh plane is zero (calloc in the eager path)
+  }
+  bool done = false;
+  if (!rc && z0->scale && z0->blend && !(z0->dw == z0->sw && z0->dh == z0->sh) && n <= LGPU_CHAIN_MAX_TRACKS) {
+    lgpu_chain_params pr;
+    memset(&pr, 0, sizeof pr);
+    pr.sw = z0->sw; pr.sh = z0->sh; pr.irow = z0->srs; pr.dw = z0->dw; pr.dh = z0->dh; pr.irow2 = z0->l2rs; pr.orow = z0->rs;
+    pr.swap_rb = z0->swap ? 1 : 0; pr.interp = z0->interp | LGPU_INTERP_PIXBUF; pr.do_blur = 0; pr.bf = z0->bf; pr.use_lut = z0->lut ? 1 : 0;
+    if (z0->lut) memcpy(pr.lut8, z0->lut8, 256);
+    std::vector<lgpu_chain_track> tr((size_t)n);
+    for (int i = 0; i < n; i++) { tr[(size_t)i].src_d = (const uint8_t *)zs[i]->src.d; tr[(size_t)i].layer2_d = (const uint8_t *)zs[i]->l2.d; tr[(size_t)i].dst_d = (uint8_t *)outs[(size_t)i].d; }
+    int crc;
+    if (z0->canvas) { const lgpu_canvas cv = {z0->nw, z0->nh, z0->ox, z0->oy}; crc = lgpu_chain_canvas(&pr, &cv, tr.data(), n, S()); }
+    else crc = lgpu_chain(&pr, tr.data(), n, S());
+    if (crc == LGPU_OK) { done = true; g_lz_chain_launches++; g_lz_chain_tracks += (unsigned long long)n; }
+    else if (crc != LGPU_E_BADARG && crc != LGPU_E_UNSUPPORTED) rc = crc;          // a shape the fused kernel does not take runs stage by stage below
+  }
+  if (!rc && !done)
+    for (int i = 0; i < n && !rc; i++) { rc = lazy_run_staged(zs[i], (uint8_t *)outs[(size_t)i].d); g_lz_staged++; }
+  if (rc) {                                                                            // the programs stay pending; what was enqueued wrote scratch only
+    for (int i = 0; i < n; i++) { outs[(size_t)i].stream = S(); pool_give(outs[(size_t)i]); }
+    return rc;
+  }
+  for (int i = 0; i < n; i++) {
+    Lazy *z = zs[i];
+    {
+      std::lock_guard<SpinLock> lk(g_res_mu);
+      auto it = g_res.find(hs[i]);
+      if (it != g_res.end() && it->second.lazy == z) {
+        Dev &e = it->second;
+        const int readers = e.lazy_readers;
+        e = outs[(size_t)i];
+        e.stream = S(); e.nr = 0; e.lazy = nullptr; e.lazy_readers = readers;
+        outs[(size_t)i] = Dev();
+      }
+      if (z->blend && z->l2h) {
+        auto l2 = g_res.find(z->l2h);
+        if (l2 != g_res.end()) { note_use(l2->second, false); if (l2->second.lazy_readers > 0) l2->second.lazy_readers--; }
+        z->l2h = nullptr;
+      }
+    }
+    if (outs[(size_t)i].d) { outs[(size_t)i].stream = S(); pool_give(outs[(size_t)i]); }          // (the plane vanished meanwhile: cannot happen under the host's own ordering)
+    Dev src = z->src;
+    src.stream = S(); src.nr = 0;                                                       // its last use is the launch just enqueued
+    delete z;
+    pool_give(src);
+  }
+  return LGPU_OK;
+}
+// the pending program of plane h, if any, runs now (on the calling thread's stream)
+bool lazy_materialise(const void *h) {
+  std::lock_guard<std::mutex> run(g_lazy_mu);
+  Lazy *z = nullptr;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    auto it = g_res.find(h);
+    if (it == g_res.end()) return false;
+    z = it->second.lazy;
+  }
+  if (!z) return true;                      // somebody else ran it meanwhile
+  return lazy_run_group(&z, &h, 1) == LGPU_OK;
+}
+// programs that read plane h as their layer 2 run before h changes
+void lazy_run_readers_of(const void *h) {
+  for (int guard = 0; guard < 64; guard++) {
+    const void *reader = nullptr;
+    {
+      std::lock_guard<SpinLock> lk(g_res_mu);
+      auto it = g_res.find(h);
+      if (it == g_res.end() || it->second.lazy_readers <= 0) return;
+      for (auto &kv : g_res) if (kv.second.lazy && kv.second.lazy->blend && kv.second.lazy->l2h == h) { reader = kv.first; break; }
+      if (!reader) { it->second.lazy_readers = 0; return; }
+    }
+    if (!lazy_materialise(reader)) return;
+  }
+}
+// The plane of layer l becomes (or stays) the subject of a pending program that can still take `stage`.  Returns the program DETACHED from the table (the caller
+// records its stage and registers it under the layer's new host plane with lazy_attach, or puts it back under the old one on failure), or nullptr: not deferrable.
+Lazy *lazy_detach(const Layer &l, int stage) {
+  if (!g_deferred.load(std::memory_order_relaxed) || !t_pinned || !lazy_pal(l.pal) || l.nplanes != 1 || (l.rs[0] & 3) || ((uintptr_t)l.pd[0] & 3)) return nullptr;
+  const size_t n = (size_t)l.rs[0] * l.height;
+  for (int pass = 0; pass < 2; pass++) {
+    Dev e;
+    bool need_run = false;
+    {
+      std::lock_guard<SpinLock> lk(g_res_mu);
+      auto it = g_res.find(l.pd[0]);
+      if (it == g_res.end() || it->second.bytes < n) return nullptr;
+      if (it->second.lazy_readers > 0) return nullptr;                     // someone's layer 2: it keeps its pixels
+      if (it->second.lazy && it->second.lazy->stage >= stage) need_run = true;
+      else { e = it->second; g_res.erase(it); }
+    }
+    if (need_run) { if (!lazy_materialise(l.pd[0])) return nullptr; continue; }    // the recorded program cannot take this stage: it runs, a new one starts from its result
+    if (e.lazy) return e.lazy;
+    Lazy *z = new Lazy;
+    z->src = e; z->sw = l.width; z->sh = l.height; z->srs = l.rs[0];
+    z->w = l.width; z->h = l.height; z->rs = l.rs[0];
+    return z;
+  }
+  return nullptr;
+}
+bool plane_is_lazy(const void *h) {
+  std::lock_guard<SpinLock> lk(g_res_mu);
+  auto it = g_res.find(h);
+  return it != g_res.end() && it->second.lazy != nullptr;
+}
+void lazy_attach(const void *h, Lazy *z) {
+  Dev e;
+  g_lz_recorded++;
+  e.lazy = z; e.bytes = (size_t)z->rs * z->h; e.stream = kIdle;
+  Dev old;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    Dev &slot = g_res[h];
+    old = slot;
+    slot = e;
+  }
+  if (old.d || old.lazy) pool_give(old);
+}
+// put a detached program / plane back under the host plane it came from (a stage could not be recorded after all)
+void lazy_reattach(const void *h, Lazy *z) {
+  if (z->stage == LZ_NONE) {              // it was an ordinary resident plane
+    Dev e = z->src;
+    delete z;
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    g_res[h] = e;
+    return;
+  }
+  lazy_attach(h, z);
+}
+// new host plane(s) for the plane a recorded stage produces; the old host plane is released, the program moves under the new pointer
+bool lazy_commit(weed_plant_t *layer, const Layer &l, Lazy *z, int pal, int width, int height, int alignment) {
+  NewPlanes np;
+  if (!alloc_planes(pal, width, height, alignment, &np)) return false;
+  z->w = width; z->h = height; z->rs = np.rs[0];
+  lazy_attach(np.pd[0], z);
+  if (l.contiguous) pfree(l.pd[0]); else for (int i = 0; i < l.nplanes; i++) pfree(l.pd[i]);      // free_planes without the table (the entry has moved)
+  commit_planes(layer, pal, width, height, np);
+  return true;
 }
 
 int rgb_swizzle_op(int inpl, int outpl, int *alpha_first_arg) {
@@ -870,6 +1133,20 @@ static lives_gpu_boolean convert_layer_palette_full_body(lives_gpu_layer_t *laye
   if (!pal_is_rgb(inpl) && !in_planar_sub && k3_fmt(inpl) < 0 && inpl != WEED_PALETTE_YUV411) return decline(layer);
   if (lutp && !pal_is_rgb(inpl) && !in_planar_sub) return decline(layer);   // no inline gamma on the K3 / 4:1:1 paths
 
+  if (!lutp && lazy_pal(inpl) && lazy_pal(outpl)) {
+    // RGBA32 <-> BGRA32 on a pinned layer: recorded, not launched (deferred execution, above)
+    if (Lazy *z = lazy_detach(l, LZ_SWAP)) {
+      const int prev = z->stage;
+      z->swap = true; z->stage = LZ_SWAP;
+      if (!lazy_commit(layer, l, z, outpl, l.width, l.height, 0)) { z->swap = false; z->stage = prev; lazy_reattach(l.pd[0], z); return 0; }
+      if (new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, new_gamma);
+      if (flags != l.flags) set_int(layer, kLeafHostFlags, flags);
+      g_api.leaf_delete(layer, WEED_LEAF_YUV_CLAMPING);
+      g_api.leaf_delete(layer, WEED_LEAF_YUV_SUBSPACE);
+      g_api.leaf_delete(layer, WEED_LEAF_YUV_SAMPLING);
+      return 1;
+    }
+  }
   NewPlanes np;
   const int owidth = (inpl == WEED_PALETTE_UYVY || inpl == WEED_PALETTE_YUYV) ? l.width * 2 : inpl == WEED_PALETTE_YUV411 ? l.width * 4 : l.width;   // macropixels -> pixels (:13010, :13759)
   if (!alloc_planes(outpl, owidth, l.height, 0, &np)) return 0;
@@ -960,6 +1237,18 @@ static lives_gpu_boolean gamma_convert_sub_layer_body(int gamma_type, double fil
   uint8_t lut[256];
   if (!lgpu_gamma_lut8(gamma_type == LIVES_GAMMA_VARIANT ? fileg : 1.0, l.gamma, gamma_type, g_prefs.screen_gamma, lut)) return 1;
   if (x < 0 || y < 0 || x + width > l.width || y + height > l.height) return 0;
+  if (x == 0 && y == 0 && width == l.width && height == l.height && lazy_pal(l.pal) && plane_is_lazy(l.pd[0])) {
+    // the whole frame of a plane that is still a pending program: the table becomes its last stage
+    if (Lazy *z = lazy_detach(l, LZ_LUT)) {
+      if (z->stage != LZ_NONE) {
+        z->lut = true; memcpy(z->lut8, lut, 256); z->stage = LZ_LUT;
+        lazy_attach(l.pd[0], z);
+        if (gamma_type != LIVES_GAMMA_VARIANT) set_int(layer, WEED_LEAF_GAMMA_TYPE, gamma_type);
+        return 1;
+      }
+      lazy_reattach(l.pd[0], z);          // the program had a table already and has run: a table pass alone is one kernel, in place, below
+    }
+  }
   Work w;
   uint8_t *d = w.inout(l.pd[0], (size_t)l.rs[0] * l.height, 0);
   const bool ok = w.ok && lgpu_gamma_apply(d, l.rs[0], x, y, width, height, pal_psize(l.pal), pal_alpha_first(l.pal), lut, S()) == LGPU_OK && w.finish();
@@ -1228,6 +1517,19 @@ static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int in
   }
   if (l.width == width && l.height == height) return 1;
   const int ch = (l.pal == WEED_PALETTE_RGB24 || l.pal == WEED_PALETTE_BGR24 || l.pal == WEED_PALETTE_YUV888) ? 3 : 4;
+  if (lazy_pal(l.pal)) {
+    // a pinned RGBA32 / BGRA32 frame: the scale is recorded (deferred execution) once the scaler has said it takes the geometry
+    if (Lazy *z = lazy_detach(l, LZ_SCALE)) {
+      if (lgpu_pixbuf_scale_check(l.width, l.height, width, height, 4, interp, S()) == LGPU_OK) {
+        const int prev = z->stage;
+        z->scale = true; z->dw = width; z->dh = height; z->interp = interp; z->stage = LZ_SCALE;
+        if (!lazy_commit(layer, l, z, l.pal, width, height, 4)) { z->scale = false; z->stage = prev; lazy_reattach(l.pd[0], z); return 0; }
+        if (l.gamma != WEED_GAMMA_SRGB) set_int(layer, WEED_LEAF_GAMMA_TYPE, WEED_GAMMA_SRGB);
+        return 1;
+      }
+      lazy_reattach(l.pd[0], z);          // the eager path below answers (and declines what the scaler does not cover)
+    }
+  }
   NewPlanes np;
   if (!alloc_planes(l.pal, width, height, 4, &np)) return 0;
   Work w;
@@ -1312,6 +1614,15 @@ static lives_gpu_boolean letterbox_layer_body(lives_gpu_layer_t *layer, int nwid
       if (rp.new_gamma != l.gamma) set_int(layer, WEED_LEAF_GAMMA_TYPE, rp.new_gamma);
     }
     return 0;
+  }
+  if (todo == 2 && lazy_pal(l.pal) && plane_is_lazy(l.pd[0])) {
+    // the frame is a pending program (it has just been scaled): the canvas becomes its next stage
+    if (Lazy *z = lazy_detach(l, LZ_CANVAS)) {
+      const int prev = z->stage;
+      z->canvas = true; z->nw = nwidth; z->nh = nheight; z->ox = (nwidth - width + 1) >> 1; z->oy = (nheight - height + 1) >> 1; z->stage = LZ_CANVAS;
+      if (!lazy_commit(layer, l, z, l.pal, nwidth, nheight, 0)) { z->canvas = false; z->stage = prev; lazy_reattach(l.pd[0], z); return 0; }
+      return 1;
+    }
   }
   Layer canvas = inner;
   canvas.width = nwidth; canvas.height = nheight;
@@ -1523,6 +1834,100 @@ int lives_gpu_layer_pin(lives_gpu_layer_t *layer) {
   set_int(layer, kLeafResident, 1);
   return LGPU_OK;
 }
+// A layer whose planes ALREADY are in device memory the caller owns (a hardware decoder's output surfaces, the frame a previous pass left in HBM): the layer is
+// pinned with those buffers as its resident planes -- no upload, no copy.  The library reads them where they lie (in-place calls write them) and never frees them;
+// they must stay valid until the layer's pixel_data has been replaced by a seam call, or the layer is synchronised / unpinned / forgotten.  producer_stream: the
+// stream their contents were produced on (NULL = the null stream; pass lives_gpu_thread_stream() or any stream already synchronised for "complete").
+int lives_gpu_layer_pin_device(lives_gpu_layer_t *layer, const void *const *planes_d, int nplanes, void *producer_stream, int producer_done) {
+  Layer l;
+  if (!ready() || !read_layer(layer, &l) || !planes_d || nplanes != l.nplanes) return LGPU_E_BADARG;
+  if (has_leaf(layer, kLeafResident)) return LGPU_E_BADARG;
+  for (int p = 0; p < l.nplanes; p++) if (!planes_d[p]) return LGPU_E_BADARG;
+  for (int p = 0; p < l.nplanes; p++) {
+    Dev b;
+    b.d = const_cast<void *>(planes_d[p]); b.bytes = plane_bytes(l, p); b.external = true;
+    b.stream = producer_done ? kIdle : producer_stream;
+    lazy_run_readers_of(l.pd[p]);
+    Dev old;
+    {
+      std::lock_guard<SpinLock> lk(g_res_mu);
+      Dev &slot = g_res[l.pd[p]];
+      old = slot;
+      slot = b;
+    }
+    if (old.d || old.lazy) pool_give(old);
+  }
+  set_int(layer, kLeafResident, 1);
+  return LGPU_OK;
+}
+// deferred execution (see "deferred execution on pinned layers" above): on (default) / off; returns the previous setting
+int lives_gpu_set_deferred(int on) { return g_deferred.exchange(on ? 1 : 0); }
+// counters since the library was loaded: [0] stages recorded, [1] fused chain launches made for pending programs, [2] tracks (programs) those launches carried,
+// [3] programs run stage by stage (shapes the fused kernel does not take)
+void lives_gpu_deferred_stats(unsigned long long out[4]) {
+  if (!out) return;
+  out[0] = g_lz_recorded.load(); out[1] = g_lz_chain_launches.load(); out[2] = g_lz_chain_tracks.load(); out[3] = g_lz_staged.load();
+}
+// Run the pending programs of these layers now, on the calling thread's stream: programs of equal shape (the tracks of one plan step) share ONE launch of the
+// fused chain kernel.  The layers stay pinned, nothing is downloaded, the host does not wait.  What a host calls once per tick when the plan steps of its tracks
+// have returned (src/nodemodel.c:2027-2101 runs them on pool threads and collects them); without it every program still runs, by itself, when its pixels are needed.
+int lives_gpu_layers_flush(lives_gpu_layer_t *const *layers, int nlayers) {
+  if (!ready() || (nlayers > 0 && !layers)) return LGPU_E_BADARG;
+  std::vector<const void *> hs;
+  for (int i = 0; i < nlayers; i++) {
+    Layer l;
+    if (!layers[i] || !read_layer(layers[i], &l)) continue;
+    for (int p = 0; p < l.nplanes; p++) hs.push_back(l.pd[p]);
+  }
+  std::lock_guard<std::mutex> run(g_lazy_mu);
+  std::vector<Lazy *> zs(hs.size(), nullptr);
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    for (size_t i = 0; i < hs.size(); i++) { auto it = g_res.find(hs[i]); if (it != g_res.end()) zs[i] = it->second.lazy; }
+  }
+  int rc = LGPU_OK;
+  std::vector<char> done(hs.size(), 0);
+  for (size_t i = 0; i < hs.size(); i++) {
+    if (!zs[i] || done[i]) continue;
+    std::vector<Lazy *> gz;
+    std::vector<const void *> gh;
+    for (size_t k = i; k < hs.size() && (int)gz.size() < LGPU_CHAIN_MAX_TRACKS; k++)
+      if (zs[k] && !done[k] && lazy_same_shape(zs[i], zs[k])) {
+        bool dup = false;
+        for (Lazy *q : gz) dup = dup || q == zs[k];
+        done[k] = 1;
+        if (!dup) { gz.push_back(zs[k]); gh.push_back(hs[k]); }
+      }
+    const int r = lazy_run_group(gz.data(), gh.data(), (int)gz.size());
+    if (r && !rc) rc = r;
+  }
+  return rc;
+}
+// livesgpu_fx.so's "chroma blend" on a plane that is a pending program (in place: out channel = in channel 0): the blend with layer 2 is recorded as the program's
+// next stage.  1 = recorded, the effect has nothing left to do; 0 = not applicable, the effect runs its kernel (acquiring the planes runs what is pending).
+int lives_gpu_deferred_blend_chroma(const void *dst_host, int orow, int width, int height, int palette, const void *layer2_host, int irow2, int bf) {
+  if (!g_deferred.load(std::memory_order_relaxed) || !dst_host || !layer2_host || dst_host == layer2_host || !lazy_pal(palette) || (irow2 & 3) || !ready()) return 0;
+  {
+    std::lock_guard<SpinLock> lk(g_res_mu);
+    auto it = g_res.find(dst_host);
+    if (it == g_res.end() || !it->second.lazy || it->second.lazy_readers > 0) return 0;
+    const Lazy *z = it->second.lazy;
+    if (z->stage >= LZ_BLEND || z->w != width || z->h != height || z->rs != orow) return 0;
+  }
+  const size_t n2 = (size_t)irow2 * height;
+  uint8_t *l2d = acquire(layer2_host, n2, false);          // layer 2 itself may be pending: it runs; this thread's stream is behind its writer
+  if (!l2d) return 0;
+  std::lock_guard<SpinLock> lk(g_res_mu);
+  auto it = g_res.find(dst_host);
+  auto l2 = g_res.find(layer2_host);
+  if (it == g_res.end() || !it->second.lazy || l2 == g_res.end() || !l2->second.d) return 0;
+  Lazy *z = it->second.lazy;
+  if (z->stage >= LZ_BLEND) return 0;
+  g_lz_recorded++;
+  z->blend = true; z->bf = bf & 0xFF; z->l2h = layer2_host; z->l2 = l2->second; z->l2rs = irow2; z->stage = LZ_BLEND;
+  l2->second.lazy_readers++;
+  return 1;
+}
 int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return LGPU_E_BADARG;
@@ -1530,6 +1935,7 @@ int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
   for (int p = 0; p < l.nplanes; p++) {
     const size_t n = plane_bytes(l, p);
     Dev b;
+    if (plane_is_lazy(l.pd[p]) && !lazy_materialise(l.pd[p])) return LGPU_E_HIP;        // a pending program runs now
     {
       std::lock_guard<SpinLock> lk(g_res_mu);
       auto it = g_res.find(l.pd[p]);
@@ -1593,6 +1999,8 @@ void lives_gpu_pinned_free(void *p) {
 void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
   if (!host_plane) return nullptr;
   Dev b;
+  if (plane_is_lazy(host_plane) && !lazy_materialise(host_plane)) return nullptr;
+  lazy_run_readers_of(host_plane);                    // the caller may write the plane
   {
     std::lock_guard<SpinLock> lk(g_res_mu);
     auto it = g_res.find(host_plane);

@@ -1957,6 +1957,25 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
   return LGPU_OK;
 }
 
+// what lgpu_pixbuf_scale would answer for this geometry, without launching anything (the weight table is built and cached on the way, so the scale that follows
+// finds it): LGPU_OK, LGPU_E_BADARG, or LGPU_E_UNSUPPORTED for a reduction past the library's one-step range.  The layer seam asks before it records a scale
+// for later (deferred execution, layer_seam.cpp): a recorded call must not turn into a refusal.
+extern "C" int lgpu_pixbuf_scale_check(int sw, int sh, int dw, int dh, int channels, int interp, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(sw > 0 && sh > 0 && dw > 0 && dh > 0, "empty geometry");
+  LGPU_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (no alpha) or 4 (alpha)");
+  LGPU_REQUIRE(interp == 0 || interp == 2 || interp == 3, "interp must be 0 (NEAREST), 2 (BILINEAR) or 3 (HYPER)");
+  LGPU_REQUIRE(sw < 32768 && sh < 32768 && dw < 32768 && dh < 32768, "frame sides must stay below 32768 (16.16 positions)");
+  if (dw == sw && dh == sh) return LGPU_OK;
+  const double scale_x = (double)dw / sw, scale_y = (double)dh / sh;
+  if ((int)(65536 / scale_x) == 0 || (int)(65536 / scale_y) == 0) { set_error("lgpu_pixbuf_scale: enlargement beyond 65536x"); return LGPU_E_UNSUPPORTED; }
+  if (interp == 0) return LGPU_OK;
+  PbPin pin;
+  rc = pb_table(interp, sw, sh, dw, dh, (hipStream_t)stream, &pin);
+  if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d: the library's two-step scaler is not covered", sw, sh, dw, dh);
+  return rc;
+}
 extern "C" int lgpu_pixbuf_scale(const uint8_t *src_d, int irow, int sw, int sh, uint8_t *dst_d, int orow, int dw, int dh, int channels, int interp,
                                  void *stream) {
   return pb_scale_n(&src_d, &dst_d, 1, irow, sw, sh, orow, dw, dh, channels, interp, stream);

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "lgpu_letterbox_bars": [vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
     "lgpu_pixbuf_scale": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_pixbuf_scale_check": [ci, ci, ci, ci, ci, ci, vp],
     "lgpu_pixbuf_scale_batch": [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_fx_batch": [ctypes.POINTER(FxParams), ctypes.POINTER(FxFrame), ci, vp],
     "lgpu_chain_canvas": [vp, vp, vp, ci, vp],

@@ -51,7 +51,8 @@ def test_resize_layer_follows_the_pixbuf_body(seam, orc, pixbuf_backend, pinned)
         lay = wh.new_layer(pal, sw, sh, [src], gamma=-1 if pal < 10 else None, clamping=1 if pal > 10 else None)
         if pinned:
             assert L.lives_gpu_layer_pin(lay) == 0
-        assert L.lives_gpu_resize_layer(lay, dw, dh, interp, 0, 0) == 1, (pal, sw, sh, dw, dh)
+        # oclamp_hint: the layer's own clamping for the YUV frames (UNCLAMPED) -- with another one the frame is first switched to it (:14901-14908, next test)
+        assert L.lives_gpu_resize_layer(lay, dw, dh, interp, 0, 1 if pal > 10 else 0) == 1, (pal, sw, sh, dw, dh)
         if pinned:
             assert wh.geti(lay, "host_gpu_resident") == 1 and L.lives_gpu_layer_unpin(lay) == 0
         planes, _, rs = wh.planes_of(lay)
@@ -61,6 +62,23 @@ def test_resize_layer_follows_the_pixbuf_body(seam, orc, pixbuf_backend, pinned)
         assert (planes[0][:dh, :dw * ch] == want).all(), (pal, sw, sh, dw, dh, interp)
         if pal < 10:
             assert wh.geti(lay, "gamma_type") == 1, "pixbuf_to_layer tags RGB layers WEED_GAMMA_SRGB (:14378-14379)"
+
+
+def test_a_clamping_hint_that_differs_is_applied_before_the_body(seam, orc, pixbuf_backend):
+    """:14901-14908: `resolved != palette || oclamp_hint != iclamping` -> convert_layer_palette_full(layer, resolved, oclamp_hint, ...) -- an UNCLAMPED YUV888 frame
+    with the hint CLAMPED is switched to clamped, and the body switches it back to unclamped before it scales (:15277-15284): both table passes show in the pixels"""
+    L, wh = seam
+    rng = np.random.default_rng(0x9DB9)
+    src = frame(rng, 128, 72, 3)
+    lay = wh.new_layer(YUV888, 128, 72, [src], clamping=1, subspace=1)
+    assert L.lives_gpu_resize_layer(lay, 64, 36, 3, 0, 0) == 1 and wh.geti(lay, "YUV_clamping") == 1
+    twin = wh.new_layer(YUV888, 128, 72, [src], clamping=1, subspace=1)
+    # the body's call is convert_layer_palette(layer, YUV888, UNCLAMPED) = subspace argument WEED_YUV_SUBSPACE_YUV (:13931): for a frame tagged YCbCr that is a
+    # "subspace change", which the reference takes through RGB24 (:12248-12262) -- kept
+    assert L.lives_gpu_convert_layer_palette_full(twin, YUV888, 0, 0, 1, 0) == 1 and L.lives_gpu_convert_layer_palette(twin, YUV888, 1) == 1
+    there_and_back = np.ascontiguousarray(wh.planes_of(twin)[0][0])
+    assert not (there_and_back == src).all()
+    assert (wh.planes_of(lay)[0][0][:36, :192] == want_scaled(orc, there_and_back, 128, 72, 64, 36, 3, 3)).all()
 
 
 def test_size_rules_of_the_common_prologue(seam, orc, pixbuf_backend):
