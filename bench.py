@@ -331,6 +331,16 @@ def main():
             torch.cuda.synchronize()
             batch8["batch8_blur_1gpu_us_per_step"] = round(e0.elapsed_time(e1) * 1e3 / n8, 2)
 
+    # ---- the same chain through the REFERENCE's API (N = 1, outside the timed region of `value`): the tracks as pinned weed_layer_t's, one host thread per track,
+    # convert_layer_palette -> resize_layer -> "chroma blend" process_func -> gamma_convert_layer by the reference names (liblivesgpu_dropin.so + livesgpu_fx.so),
+    # lives_gpu_layers_flush once per tick: the calls are recorded on the planes and become ONE lgpu_chain launch (tools/seam_host.c; include/lives_gpu_layer.h)
+    seam = None
+    if world == 1 and not args.blur and args.resize_backend == "pixbuf" and not args.dry_run:
+        try:
+            seam = seam_chain_leg(keep[0][0], keep[0][1], ops, fps, T)
+        except Exception as e:      # noqa: BLE001 -- a second measurement, never fatal for the line
+            seam = {"error": str(e)}
+
     # what this box's memory system gives the launch's own algorithmic bytes as a bare stream (no arithmetic, no re-reads): tells a slow box from a regression
     box = None
     if True:
@@ -366,6 +376,8 @@ def main():
                        "launches_per_step": 2 if (args.blur and args.resize_backend != "pixbuf") else 1, "layer2_translucent_fraction": args.l2_translucent, "buffer_sets_rotated": nsets},
             "roofline": roof,
         }
+        if seam:
+            out["seam_chain"] = seam
         if batch8:
             out["config"].update(batch8)
         if config5:
@@ -400,6 +412,59 @@ def main():
         ctypes.CDLL(None).fflush(None)      # librccl prints its version banner through C stdio, which a pipe buffers until exit: out with it BEFORE the one JSON line
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def seam_chain_leg(srcs, l2s, ops, value_fps, T, ticks=150, warm=30):
+    """the headline chain through the two seams by the reference's names, from C host threads (tools/libseam_host.so)"""
+    import numpy as np
+    import torch
+    from lives_amd import lib
+    L = lib.load()
+    so = os.path.join(ROOT, "tools", "libseam_host.so")
+    if not os.path.exists(so):
+        raise RuntimeError("tools/libseam_host.so is missing: run __graft_entry__.build()")
+    Hs = ctypes.CDLL(so)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    Hs.seam_host_run.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(vp), ctypes.POINTER(ci)]
+    if Hs.seam_host_init(os.path.join(ROOT, "lives_amd", "livesgpu_fx.so").encode()) != 0:
+        raise RuntimeError("seam_host_init failed")
+    L.lives_gpu_deferred_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    L.lives_gpu_deferred_stats.restype = None
+    sp = (vp * T)(*[t.data_ptr() for t in srcs])
+    lp = (vp * T)(*[t.data_ptr() for t in l2s])
+    BT709 = 2
+    res = {}
+    for threads in (1, 0):
+        st0, st1 = (ctypes.c_ulonglong * 4)(), (ctypes.c_ulonglong * 4)()
+        ms, outs, orow = ctypes.c_double(), (vp * T)(), ci()
+        L.lives_gpu_deferred_stats(st0)
+        rc = Hs.seam_host_run(T, SW, SH, DW, DH, sp, lp, 128, BT709, ticks, warm, threads, ctypes.byref(ms), outs, ctypes.byref(orow))
+        L.lives_gpu_deferred_stats(st1)
+        if rc:
+            raise RuntimeError("seam_host_run failed at step %d" % rc)
+        n = ticks + warm
+        res[threads] = (ms.value, (st1[1] - st0[1], st1[2] - st0[2], st1[3] - st0[3]), n)
+        if threads:      # the bytes of the last tick against the same frames through lgpu_chain directly (same table, same amount)
+            lut = np.zeros(256, np.uint8)
+            assert L.lgpu_gamma_lut8(1.0, 1, BT709, 1.4, lut.ctypes.data) == 1
+            ref = torch.zeros((DH, DW * 4), dtype=torch.uint8, device="cuda")
+            prm = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3 | 0x100, do_blur=0, bf=128, lut=lut)
+            ops.chain(prm, ops.chain_tracks([srcs[T - 1]], [l2s[T - 1]], [ref]))
+            torch.cuda.synchronize()
+            got = torch.empty_like(ref)
+            lib.call("lgpu_copy_rows", got.data_ptr(), DW * 4, outs[T - 1], orow.value, DW * 4, DH, None)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(got, ref))
+        Hs.seam_host_release()
+    ms_t, (launches, tracks, staged), n = res[1]
+    fps = T * ticks / (ms_t * 1e-3)
+    return {"fps": round(fps, 1), "frac_of_value": round(fps / value_fps, 3), "ms_per_tick": round(ms_t / ticks, 4), "tracks": T, "host_threads": T, "ticks": ticks,
+            "one_host_thread_fps": round(T * ticks / (res[0][0] * 1e-3), 1),
+            "chain_launches_per_tick": round(launches / n, 3), "tracks_per_launch": round(tracks / max(1, launches), 2), "programs_run_stage_by_stage": staged,
+            "same_bytes_as_lgpu_chain": same,
+            "what": "per tick and track, on one host thread per track: a BGRA32 weed layer whose frame is already in HBM (lives_gpu_layer_pin_device) -> convert_layer_palette(RGBA32) -> "
+                    "resize_layer(1920x1080, LIVES_INTERP_BEST) -> process_func of livesgpu_fx.so's \"chroma blend\" (in place, amount 128) -> gamma_convert_layer(WEED_GAMMA_BT709), by the "
+                    "reference's names out of liblivesgpu_dropin.so; then lives_gpu_layers_flush(layers, n) once per tick.  Wall clock over the ticks, host work included."}
 
 
 def self_launch(n):

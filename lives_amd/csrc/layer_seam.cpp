@@ -1235,7 +1235,17 @@ static lives_gpu_boolean gamma_convert_sub_layer_body(int gamma_type, double fil
   if (!pal_is_rgb(l.pal)) return decline(layer);
   if (gamma_type == l.gamma && fileg == 1.0) return 1;
   uint8_t lut[256];
-  if (!lgpu_gamma_lut8(gamma_type == LIVES_GAMMA_VARIANT ? fileg : 1.0, l.gamma, gamma_type, g_prefs.screen_gamma, lut)) return 1;
+  {
+    // the calling thread's last table is kept, as the reference keeps its last one (:664-670): 255 powf pairs per call otherwise
+    thread_local struct { double fg, sg; int from, to, made; uint8_t t[256]; } memo = {0., 0., 0, 0, -1, {0}};
+    const double fg = gamma_type == LIVES_GAMMA_VARIANT ? fileg : 1.0;
+    if (!(memo.made >= 0 && memo.fg == fg && memo.sg == g_prefs.screen_gamma && memo.from == l.gamma && memo.to == gamma_type)) {
+      memo.made = lgpu_gamma_lut8(fg, l.gamma, gamma_type, g_prefs.screen_gamma, memo.t);
+      memo.fg = fg; memo.sg = g_prefs.screen_gamma; memo.from = l.gamma; memo.to = gamma_type;
+    }
+    if (!memo.made) return 1;
+    memcpy(lut, memo.t, 256);
+  }
   if (x < 0 || y < 0 || x + width > l.width || y + height > l.height) return 0;
   if (x == 0 && y == 0 && width == l.width && height == l.height && lazy_pal(l.pal) && plane_is_lazy(l.pd[0])) {
     // the whole frame of a plane that is still a pending program: the table becomes its last stage
@@ -1474,6 +1484,15 @@ lives_gpu_boolean lives_gpu_pconv_can_inplace(int inpl, int outpl) {
 static int width_pixels(const Layer &l) {       // weed_layer_get_width_pixels: the width leaf counts macropixels
   return (l.pal == WEED_PALETTE_UYVY || l.pal == WEED_PALETTE_YUYV) ? l.width * 2 : l.pal == WEED_PALETTE_YUV411 ? l.width * 4 : l.width;
 }
+// lgpu_pixbuf_scale_check with the calling thread's last positive answer remembered: the tracks of a render ask for the same geometry tick after tick, and
+// sixteen host threads queueing for the scaler's table cache lock every tick is what the answer would otherwise cost
+static bool scale_is_served(int sw, int sh, int dw, int dh, int interp) {
+  thread_local int last[5] = {0, 0, 0, 0, -1};
+  if (last[0] == sw && last[1] == sh && last[2] == dw && last[3] == dh && last[4] == interp) return true;
+  if (lgpu_pixbuf_scale_check(sw, sh, dw, dh, 4, interp, S()) != LGPU_OK) return false;
+  last[0] = sw; last[1] = sh; last[2] = dw; last[3] = dh; last[4] = interp;
+  return true;
+}
 static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int interp, int opal_hint, int oclamp_hint, int osamp_hint, int osubs_hint, int tgt_gamma) {
   Layer l;
   if (!ready() || !read_layer(layer, &l)) return 0;
@@ -1520,7 +1539,7 @@ static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int in
   if (lazy_pal(l.pal)) {
     // a pinned RGBA32 / BGRA32 frame: the scale is recorded (deferred execution) once the scaler has said it takes the geometry
     if (Lazy *z = lazy_detach(l, LZ_SCALE)) {
-      if (lgpu_pixbuf_scale_check(l.width, l.height, width, height, 4, interp, S()) == LGPU_OK) {
+      if (scale_is_served(l.width, l.height, width, height, interp)) {
         const int prev = z->stage;
         z->scale = true; z->dw = width; z->dh = height; z->interp = interp; z->stage = LZ_SCALE;
         if (!lazy_commit(layer, l, z, l.pal, width, height, 4)) { z->scale = false; z->stage = prev; lazy_reattach(l.pd[0], z); return 0; }
