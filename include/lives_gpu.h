@@ -477,6 +477,27 @@ int lgpu_stepper_failed(const lgpu_stepper *s);                           /* 1 a
 const int32_t *lgpu_stepper_block(const lgpu_stepper *s, int which);      /* ring slot which % 64 (tests); NULL for a negative index */
 int lgpu_stepper_destroy(lgpu_stepper *s);
 
+/* ---- batch forms of the CONVERT-step kernels and of the single-plane effects: nframes (1..LGPU_FX_MAX_FRAMES) frames of ONE geometry -- the same substep of the
+   live tracks of a tick (src/nodemodel.c:1093 pconv, :1138 gamma, :1253 letterbox run once per track per tick, exactly like the effects) -- as ONE launch: the frame
+   is the grid's z index, the frame pointers travel in the kernarg segment.  Arguments are those of the single-frame entry point with frame tables in place of the
+   frame pointers; the results are those of nframes single calls, bit for bit (tests/test_batch_forms.py).  The vector forms are taken when EVERY frame is aligned.
+   (K2 has lgpu_yuv420p_to_rgb_batch, the scaler lgpu_pixbuf_scale_batch, the two-input effects lgpu_fx_batch, the chain its tracks.) */
+int lgpu_swizzle_batch(int op, int alpha_first, const uint8_t *const *src_d, int irow, uint8_t *const *dst_d, int orow, int width, int height,
+                       const uint8_t *lut8, int nframes, void *stream);
+int lgpu_gamma_apply_batch(uint8_t *const *pix_d, int rowstride, int x, int y, int width, int height, int psize, int alpha_first, const uint8_t *lut8,
+                           int nframes, void *stream);
+int lgpu_alpha_premult_batch(uint8_t *const *pix_d, int rowstride, int width, int height, int alpha_first, int un, int nframes, void *stream);
+int lgpu_mirror_batch(int mode, const uint8_t *const *src_d, int irow, uint8_t *const *dst_d, int orow, int width, int height, int psize, int nframes, void *stream);
+int lgpu_letterbox_batch(const uint8_t *const *src_d, int irow, int width, int height, uint8_t *const *dst_d, int orow, int nwidth, int nheight, int psize,
+                         const uint8_t black_pixel[4], int nframes, void *stream);          /* centred, as lgpu_letterbox */
+int lgpu_colorkey_batch(const uint8_t *const *src0_d, int irow0, const uint8_t *const *src1_d, int irow1, uint8_t *const *dst_d, int orow, int width, int height,
+                        int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, int nframes, void *stream);
+/* K4 / K3 (lgpu_rgb_to_yuv / lgpu_yuv_to_rgb): the planar side's table holds nframes x 4 plane pointers, [frame * 4 + plane] */
+int lgpu_rgb_to_yuv_batch(const uint8_t *const *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *const *dst_d, const int orow[4],
+                          int out_fmt, int out_alpha, int which_tables, int nframes, void *stream);
+int lgpu_yuv_to_rgb_batch(const uint8_t *const *src_d, const int irow[4], int width, int height, int in_fmt, int in_alpha, uint8_t *const *dst_d, int orow,
+                          int out_order, int out_alpha, int which_tables, int nframes, void *stream);
+
 /* ---- batched effects: ONE launch for the instances of one filter on the live tracks of a tick (weed_apply_instance runs once per track per tick,
    src/effects-weed.c:1850-2425).  The frames share geometry, rowstrides and parameters; only the planes differ.  Results are those of nframes single calls, bit
    for bit.  ops and their fields (everything else ignored):

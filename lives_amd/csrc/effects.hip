@@ -263,8 +263,11 @@ __global__ __launch_bounds__(kBlock) void k_chroma_argb(Frames2 f, uint32_t bf, 
 // result[y][x] = src[ry(y)][rx(x)], rx(x) = x <= hw ? x : 2hw - x, ry(y) = y >= h - hh + 1 ? h - y : y
 // (the in-place result of mirrors.c; its stray writes to pixel `width` / row `height` are not performed)
 template <int PS>
-__global__ __launch_bounds__(kBlock) void k_mirror(const uint8_t *src, int irow, uint8_t *dst, int orow, int width, int height,
-                                                    int mx, int my, int inplace) {
+__global__ __launch_bounds__(kBlock) void k_mirror(const FrameTab T, int irow, int orow, int width, int height,
+                                                    int mx, int my) {
+  const uint8_t *src = T.src[blockIdx.z];          // the frame is the grid's z index (lgpu_mirror_batch)
+  uint8_t *dst = T.dst[blockIdx.z];
+  const int inplace = src == dst;
   const int x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= width) return;
   const int hw = width >> 1, hh = height >> 1;
@@ -279,8 +282,10 @@ __global__ __launch_bounds__(kBlock) void k_mirror(const uint8_t *src, int irow,
 // ---- letterbox ------------------------------------------------------------------------------------------------
 // every canvas pixel is written exactly once: inner rectangle from src, the rest opaque black
 template <int PS>
-__global__ __launch_bounds__(kBlock) void k_letterbox(const uint8_t *src, int irow, int width, int height, uint8_t *dst, int orow,
+__global__ __launch_bounds__(kBlock) void k_letterbox(const FrameTab T, int irow, int width, int height, int orow,
                                                        int nwidth, int nheight, int ox, int oy, uint32_t black, int vec) {
+  const uint8_t *src = T.src[blockIdx.z];
+  uint8_t *dst = T.dst[blockIdx.z];
   const int g = blockIdx.x * kBlock + threadIdx.x;   // group of 4 canvas pixels
   const int x0 = g * 4;
   if (x0 >= nwidth) return;
@@ -445,13 +450,11 @@ extern "C" int lgpu_blend_multi(int type, const uint8_t *src1_d, int irow1, cons
   return blend_multi_n(X, 1, type, irow1, irow2, orow, width, height, is_bgr, &bf, (hipStream_t)stream);
 }
 
-extern "C" int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow,
-                             int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b,
-                             void *stream) {
+static int colorkey_n(const uint8_t *const *src0_d, int irow0, const uint8_t *const *src1_d, int irow1, uint8_t *const *dst_d, int orow,
+                      int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, int n, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  Frames2 f;
-  if ((rc = fill_frames(f, src0_d, irow0, src1_d, irow1, dst_d, orow, width, height, 3))) return rc;
+  LGPU_REQUIRE(src0_d && src1_d && dst_d && n >= 1 && n <= LGPU_FX_MAX_FRAMES, "null frame table or not 1..16 frames");
   ColorKey fn;
   // parameter preparation exactly as the script does it (host side, double)
   double xdelta = delta * 2.;
@@ -466,24 +469,44 @@ extern "C" int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *sr
   fn.bmax = col_b + (int)((255 - col_b) * delta + .5);
   fn.order = is_bgr ? 1 : 0; fn.opac = opac; fn.opacx = 1. - opac;
   FxFrames X = {};
-  X.in0[0][0] = src0_d; X.in1[0][0] = src1_d; X.out[0][0] = dst_d;
-  return pixel2_launch<3>(X, 1, &fn, irow0, irow1, orow, width, height, (hipStream_t)stream);
+  ColorKey fns[LGPU_FX_MAX_FRAMES];
+  for (int i = 0; i < n; i++) { X.in0[i][0] = src0_d[i]; X.in1[i][0] = src1_d[i]; X.out[i][0] = dst_d[i]; fns[i] = fn; }
+  return pixel2_launch<3>(X, n, fns, irow0, irow1, orow, width, height, (hipStream_t)stream);
+}
+extern "C" int lgpu_colorkey(const uint8_t *src0_d, int irow0, const uint8_t *src1_d, int irow1, uint8_t *dst_d, int orow,
+                             int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b,
+                             void *stream) {
+  return colorkey_n(&src0_d, irow0, &src1_d, irow1, &dst_d, orow, width, height, is_bgr, delta, opac, col_r, col_g, col_b, 1, stream);
+}
+extern "C" int lgpu_colorkey_batch(const uint8_t *const *src0_d, int irow0, const uint8_t *const *src1_d, int irow1, uint8_t *const *dst_d, int orow,
+                                   int width, int height, int is_bgr, double delta, double opac, int col_r, int col_g, int col_b, int nframes, void *stream) {
+  return colorkey_n(src0_d, irow0, src1_d, irow1, dst_d, orow, width, height, is_bgr, delta, opac, col_r, col_g, col_b, nframes, stream);
 }
 
-extern "C" int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize,
-                           void *stream) {
+static int mirror_n(int mode, const uint8_t *const *src_d, int irow, uint8_t *const *dst_d, int orow, int width, int height, int psize, int n, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (x), 1 (y) or 2 (xy)");
-  LGPU_REQUIRE(src_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(src_d && dst_d && n >= 1 && n <= LGPU_FX_MAX_FRAMES && width > 0 && height > 0, "null frame table, 1..16 frames, or empty geometry");
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
   LGPU_REQUIRE(irow >= width * psize && orow >= width * psize, "rowstride smaller than a row");
-  const int mx = (mode == 0 || mode == 2), my = (mode == 1 || mode == 2), inplace = (src_d == dst_d);
-  const dim3 grid = row_grid2((unsigned)width, height);
-  if (psize == 4) hipLaunchKernelGGL(k_mirror<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, mx, my, inplace);
-  else hipLaunchKernelGGL(k_mirror<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, src_d, irow, dst_d, orow, width, height, mx, my, inplace);
+  FrameTab T = {};
+  for (int i = 0; i < n; i++) { LGPU_REQUIRE(src_d[i] && dst_d[i], "null frame"); T.src[i] = src_d[i]; T.dst[i] = dst_d[i]; }
+  const int mx = (mode == 0 || mode == 2), my = (mode == 1 || mode == 2);
+  dim3 grid = row_grid2((unsigned)width, height);
+  grid.z = (unsigned)n;
+  if (psize == 4) hipLaunchKernelGGL(k_mirror<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, T, irow, orow, width, height, mx, my);
+  else hipLaunchKernelGGL(k_mirror<3>, grid, dim3(kBlock), 0, (hipStream_t)stream, T, irow, orow, width, height, mx, my);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+extern "C" int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize,
+                           void *stream) {
+  return mirror_n(mode, &src_d, irow, &dst_d, orow, width, height, psize, 1, stream);
+}
+extern "C" int lgpu_mirror_batch(int mode, const uint8_t *const *src_d, int irow, uint8_t *const *dst_d, int orow, int width, int height, int psize,
+                                 int nframes, void *stream) {
+  return mirror_n(mode, src_d, irow, dst_d, orow, width, height, psize, nframes, stream);
 }
 
 extern "C" int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow, int nwidth,
@@ -493,11 +516,14 @@ extern "C" int lgpu_letterbox(const uint8_t *src_d, int irow, int width, int hei
                            (nheight - height + 1) >> 1, stream);
 }
 
-extern "C" int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow, int nwidth,
-                                 int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, void *stream) {
+static int letterbox_n(const uint8_t *const *srcs, int irow, int width, int height, uint8_t *const *dsts, int orow, int nwidth,
+                       int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, int n, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(src_d && dst_d && black_pixel && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(srcs && dsts && n >= 1 && n <= LGPU_FX_MAX_FRAMES && black_pixel && width > 0 && height > 0, "null frame table, 1..16 frames, or empty geometry");
+  FrameTab T = {};
+  uintptr_t sbits = (uintptr_t)irow, dbits = (uintptr_t)orow;
+  for (int i = 0; i < n; i++) { LGPU_REQUIRE(srcs[i] && dsts[i], "null frame"); T.src[i] = srcs[i]; T.dst[i] = dsts[i]; sbits |= (uintptr_t)srcs[i]; dbits |= (uintptr_t)dsts[i]; }
   LGPU_REQUIRE(psize == 1 || psize == 3 || psize == 4, "psize must be 1, 3 or 4");
   LGPU_REQUIRE(nwidth >= width && nheight >= height, "canvas smaller than the inner frame");
   LGPU_REQUIRE(irow >= width * psize && orow >= nwidth * psize, "rowstride smaller than a row");
@@ -505,20 +531,30 @@ extern "C" int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int 
   uint32_t black = black_pixel[0];
   if (psize >= 3) black |= ((uint32_t)black_pixel[1] << 8) | ((uint32_t)black_pixel[2] << 16);
   if (psize == 4) black |= (uint32_t)black_pixel[3] << 24;
-  const dim3 grid = row_grid2((unsigned)((nwidth + 3) >> 2), nheight);
+  dim3 grid = row_grid2((unsigned)((nwidth + 3) >> 2), nheight);
+  grid.z = (unsigned)n;
   hipStream_t st = (hipStream_t)stream;
   if (psize == 4) {
-    const int vec = ((((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0) && ((((uintptr_t)src_d | (uintptr_t)irow) & 3) == 0);
-    LGPU_REQUIRE((((uintptr_t)src_d | (uintptr_t)irow | (uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0, "4-byte pixels must be 4-byte aligned");
-    hipLaunchKernelGGL(k_letterbox<4>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, vec);
+    const int vec = ((dbits & 15) == 0) && ((sbits & 3) == 0);
+    LGPU_REQUIRE(((sbits | dbits) & 3) == 0, "4-byte pixels must be 4-byte aligned");
+    hipLaunchKernelGGL(k_letterbox<4>, grid, dim3(kBlock), 0, st, T, irow, width, height, orow, nwidth, nheight, ox, oy, black, vec);
   } else if (psize == 3) {
-    hipLaunchKernelGGL(k_letterbox<3>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, 0);
+    hipLaunchKernelGGL(k_letterbox<3>, grid, dim3(kBlock), 0, st, T, irow, width, height, orow, nwidth, nheight, ox, oy, black, 0);
   } else {
     // single-byte planes (Y / U / V / A of the planar palettes): 4 samples per lane
-    hipLaunchKernelGGL(k_letterbox<1>, grid, dim3(kBlock), 0, st, src_d, irow, width, height, dst_d, orow, nwidth, nheight, ox, oy, black, 0);
+    hipLaunchKernelGGL(k_letterbox<1>, grid, dim3(kBlock), 0, st, T, irow, width, height, orow, nwidth, nheight, ox, oy, black, 0);
   }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+extern "C" int lgpu_letterbox_at(const uint8_t *src_d, int irow, int width, int height, uint8_t *dst_d, int orow, int nwidth,
+                                 int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, void *stream) {
+  return letterbox_n(&src_d, irow, width, height, &dst_d, orow, nwidth, nheight, psize, black_pixel, ox, oy, 1, stream);
+}
+// nframes frames of one geometry into their canvases, centred as letterbox_layer centres them (src/colourspace.c:15522-15523): one launch
+extern "C" int lgpu_letterbox_batch(const uint8_t *const *src_d, int irow, int width, int height, uint8_t *const *dst_d, int orow, int nwidth,
+                                    int nheight, int psize, const uint8_t black_pixel[4], int nframes, void *stream) {
+  return letterbox_n(src_d, irow, width, height, dst_d, orow, nwidth, nheight, psize, black_pixel, (nwidth - width + 1) >> 1, (nheight - height + 1) >> 1, nframes, stream);
 }
 
 extern "C" int lgpu_letterbox_bars(uint8_t *dst_d, int orow, int nwidth, int nheight, int psize, const uint8_t black_pixel[4], int ox, int oy, int width,

@@ -73,6 +73,9 @@ int device_cus();      // CUs of the current device
 
 constexpr int kBlock = 256;   // 4 wavefronts of 64
 
+// frames of one geometry for the batch forms of the single-plane kernels (lgpu_*_batch): the frame is the grid's z index; travels in the kernarg segment
+struct FrameTab { const uint8_t *src[16]; uint8_t *dst[16]; };        // 16 = LGPU_FX_MAX_FRAMES
+
 // ---- launch-shape / ablation switches ------------------------------------------------------------------
 // Every switch the launch paths consult lives in ONE process-wide table of atomics: filled once from the environment (LGPU_<NAME>) at first use, changed
 // afterwards only through lgpu_tuning_set() (tests, sweeps).  No launch path calls getenv(): the host (LiVES) calls setenv() at run time from other threads.

@@ -20,6 +20,12 @@ struct PalArgs {
   const uint16_t *lut16;      // k_rgb_to_yuv, UYVY / YUYV only: create_gamma_lut's 65536 entries, applied inline (rgb2uyvy_with_gamma)
 };
 
+// the frame of a batched launch (lgpu_rgb_to_yuv_batch / lgpu_yuv_to_rgb_batch): planes by the grid's z index; a single-frame call passes a table of one
+__device__ __forceinline__ void pal_frame(PalArgs &a, const FxFrames &F) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) { a.src[k] = F.in0[blockIdx.z][k]; a.dst[k] = F.out[blockIdx.z][k]; }
+}
+
 // ---- K4 -------------------------------------------------------------------------------------------------------------
 struct R2Y {
   const int32_t *t;           // LDS [9][256]
@@ -112,7 +118,8 @@ __device__ __forceinline__ void store_y_pair(uint8_t *dy, int y0, int y1) {
 }
 
 template <int ORDER, int FMT>
-__global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
+__global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a, const FxFrames F) {
+  pal_frame(a, F);
   if (FMT == 4) cavg_init();                              // only the 4:2:0 walk averages
   __shared__ int32_t s_t[9 * 256];
   for (int i = threadIdx.x; i < 9 * 256; i += kBlock) s_t[i] = a.tables[i];
@@ -207,7 +214,8 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a) {
 // staged, and a 512-thread workgroup stages them once for 2,048 cells.  k_rgb_to_yuv<.., 4>: one workgroup of 256 pixel pairs per chroma row, the second row of every
 // pair of rows read twice.
 template <int ORDER>
-__global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gmagic) {
+__global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
+  pal_frame(a, F);
   __shared__ int32_t s_t[9 * 256];
   typedef unsigned pu4 __attribute__((ext_vector_type(4)));
   const int ngr = a.width >> 2, hc = a.height >> 1, nunits = hc + 1;      // unit 0: row 0 alone; unit u + 1: rows 2u + 1, 2u + 2 -> chroma row u
@@ -264,7 +272,8 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gma
 // RGBA32 / BGRA32 -> UYVY / YUYV / YUV422P on aligned frames: the same cell shape, one row per cell (rgb2uyvy / rgb2yuyv :2162-2192: U of a pair's first pixel,
 // V of its second, no averaging; the YUYV form keeps only the lower chroma clamp, as the reference does).  FMT as in k_rgb_to_yuv: 2 UYVY, 3 YUYV, 5 planar 4:2:2.
 template <int ORDER, int FMT>
-__global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gmagic) {
+__global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
+  pal_frame(a, F);
   __shared__ int32_t s_t[9 * 256];
   typedef unsigned pu4 __attribute__((ext_vector_type(4)));
   const int ngr = a.width >> 2;
@@ -320,7 +329,8 @@ __device__ __forceinline__ void put_rgb(uint8_t *d, int order, int ops, const in
 }
 
 template <int FMT, int ORDER>
-__global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
+__global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a, const FxFrames F) {
+  pal_frame(a, F);
   __shared__ int32_t s_t[5 * 256];
   for (int i = threadIdx.x; i < 5 * 256; i += kBlock) s_t[i] = a.tables[i];
   __syncthreads();
@@ -359,7 +369,8 @@ __global__ __launch_bounds__(kBlock) void k_yuv_to_rgb(PalArgs a) {
 // are staged, and the two chroma terms that share an index sit in one 8-byte LDS entry ({R_Cr, G_Cr}[v], {G_Cb, B_Cb}[u]): 1 + 2 / 2 gathers per pixel instead of 5.
 // Same arithmetic as put_rgb() above: CLAMP0255f((RGB_Y[y] + ...) >> 16), alpha 255.
 template <int FMT, int ORDER>
-__global__ __launch_bounds__(512) void k_uyvy_to_rgb_s(PalArgs a, uint32_t gmagic) {
+__global__ __launch_bounds__(512) void k_uyvy_to_rgb_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
+  pal_frame(a, F);
   __shared__ int32_t s_ty[256];
   __shared__ uint2 s_rg[256], s_gb[256];
   const int ngr = a.width >> 2;                          // cells per row
@@ -1115,12 +1126,16 @@ extern "C" int lgpu_chroma_average_table(uint8_t out[65536]) {
   return LGPU_OK;
 }
 
-static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
-                           uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, const uint16_t *lut16_d, void *stream) {
+// nfr frames of one geometry (srcs[f], dsts[f][plane]) as one launch: the frame is the grid's z index; the cell forms need EVERY frame aligned
+static int rgb_to_yuv_impl_n(const uint8_t *const *srcs, int irow, int width, int height, int in_order, int in_alpha,
+                             uint8_t *const (*dsts)[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, const uint16_t *lut16_d, int nfr, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   if ((rc = ensure_cavgc())) return rc;
-  LGPU_REQUIRE(src_d && dst_d && orow && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(srcs && dsts && orow && nfr >= 1 && nfr <= LGPU_FX_MAX_FRAMES && width > 0 && height > 0, "null frame table, 1..16 frames, or empty geometry");
+  const uint8_t *const src_d = srcs[0];
+  uint8_t *const *const dst_d = dsts[0];
+  LGPU_REQUIRE(src_d, "null frame");
   LGPU_REQUIRE(in_order >= 0 && in_order <= 2, "in_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
   LGPU_REQUIRE(out_fmt >= 0 && out_fmt <= 5, "out_fmt must be 0 (packed 4:4:4), 1 (planar 4:4:4), 2 (UYVY), 3 (YUYV), 4 (4:2:0 planar), 5 (4:2:2 planar)");
   LGPU_REQUIRE(out_fmt < 2 || !(width & 1), "subsampled targets need an even width");
@@ -1139,35 +1154,43 @@ static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height
   a.unclamped = which_tables & 1;
   a.tables = device_tables()->rgb2yuv[which_tables & 3];
   a.lut16 = lut16_d;
+  FxFrames F = {};
+  uintptr_t sbits = (uintptr_t)irow, d0bits = (uintptr_t)orow[0], d12bits = 0;
+  for (int f = 0; f < nfr; f++) {
+    LGPU_REQUIRE(srcs[f], "null frame");
+    F.in0[f][0] = srcs[f]; sbits |= (uintptr_t)srcs[f];
+    for (int i = 0; i < nplanes; i++) { LGPU_REQUIRE(dsts[f][i], "null destination plane"); F.out[f][i] = dsts[f][i]; }
+    d0bits |= (uintptr_t)dsts[f][0];
+    if (nplanes >= 3) d12bits |= (uintptr_t)dsts[f][1] | (uintptr_t)dsts[f][2] | (uintptr_t)orow[1] | (uintptr_t)orow[2];
+    if (out_fmt == 2 || out_fmt == 3) LGPU_REQUIRE(!((uintptr_t)dsts[f][0] & 3), "UYVY / YUYV rows must be 4-byte aligned");
+  }
   const int npairs = width >> 1;
   if (npairs == 0) return LGPU_OK;
   // aligned 4-byte pixels -> 4:2:0: the cell form
   const bool no_s420 = tune_on(TUNE_RGB2YUV_NO_S);
   if (out_fmt == 4 && ips == 4 && in_order <= 1 && !no_s420 && (width & 3) == 0 && height >= 2 &&
-      (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 && (((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 3) == 0 &&
-      (((uintptr_t)dst_d[1] | (uintptr_t)orow[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[2]) & 1) == 0) {
+      (sbits & 15) == 0 && (d0bits & 3) == 0 && (d12bits & 1) == 0) {
     const int ngr = width >> 2, nunits = (height >> 1) + 1;
     const unsigned long long cells = (unsigned long long)ngr * nunits;
     if (cells < (1ull << 31)) {
       const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
-      const dim3 gs((unsigned)((cells + 511) / 512));
-      if (in_order == 0) hipLaunchKernelGGL(k_rgb_to_yuv420_s<0>, gs, dim3(512), 0, (hipStream_t)stream, a, magic);
-      else hipLaunchKernelGGL(k_rgb_to_yuv420_s<1>, gs, dim3(512), 0, (hipStream_t)stream, a, magic);
+      const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
+      if (in_order == 0) hipLaunchKernelGGL(k_rgb_to_yuv420_s<0>, gs, dim3(512), 0, (hipStream_t)stream, a, magic, F);
+      else hipLaunchKernelGGL(k_rgb_to_yuv420_s<1>, gs, dim3(512), 0, (hipStream_t)stream, a, magic, F);
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
   }
   // aligned 4-byte pixels -> packed / planar 4:2:2 without a gamma LUT: the cell form
   if ((out_fmt == 2 || out_fmt == 3 || out_fmt == 5) && ips == 4 && in_order <= 1 && !lut16_d && !no_s420 && (width & 3) == 0 &&
-      (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 &&
-      (out_fmt == 5 ? ((((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 3) == 0 && (((uintptr_t)dst_d[1] | (uintptr_t)orow[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[2]) & 1) == 0)
-                    : ((((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 7) == 0))) {
+      (sbits & 15) == 0 &&
+      (out_fmt == 5 ? ((d0bits & 3) == 0 && (d12bits & 1) == 0) : ((d0bits & 7) == 0))) {
     const int ngr = width >> 2;
     const unsigned long long cells = (unsigned long long)ngr * height;
     if (cells < (1ull << 31)) {
       const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
-      const dim3 gs((unsigned)((cells + 511) / 512));
-#define K4S_CASE(O, F) case (O) * 8 + (F): hipLaunchKernelGGL((k_rgb_to_yuv422_s<O, F>), gs, dim3(512), 0, (hipStream_t)stream, a, magic); break;
+      const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
+#define K4S_CASE(O, FM) case (O) * 8 + (FM): hipLaunchKernelGGL((k_rgb_to_yuv422_s<O, FM>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
       switch (in_order * 8 + out_fmt) { K4S_CASE(0, 2) K4S_CASE(0, 3) K4S_CASE(0, 5) K4S_CASE(1, 2) K4S_CASE(1, 3) K4S_CASE(1, 5) }
 #undef K4S_CASE
       LGPU_CHECK_LAUNCH();
@@ -1175,8 +1198,8 @@ static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height
     }
   }
   const int nrows = out_fmt == 4 ? height >> 1 : height;
-  const dim3 grid(cdiv((unsigned)npairs, kBlock), (unsigned)(nrows < 2048 ? nrows : 2048));
-#define K4_CASE(O, F) case (O) * 8 + (F): hipLaunchKernelGGL((k_rgb_to_yuv<O, F>), grid, dim3(kBlock), 0, (hipStream_t)stream, a); break;
+  const dim3 grid(cdiv((unsigned)npairs, kBlock), (unsigned)(nrows < 2048 ? nrows : 2048), (unsigned)nfr);
+#define K4_CASE(O, FM) case (O) * 8 + (FM): hipLaunchKernelGGL((k_rgb_to_yuv<O, FM>), grid, dim3(kBlock), 0, (hipStream_t)stream, a, F); break;
   switch (in_order * 8 + out_fmt) {
     K4_CASE(0, 0) K4_CASE(0, 1) K4_CASE(0, 2) K4_CASE(0, 3) K4_CASE(0, 4) K4_CASE(0, 5)
     K4_CASE(1, 0) K4_CASE(1, 1) K4_CASE(1, 2) K4_CASE(1, 3) K4_CASE(1, 4) K4_CASE(1, 5)
@@ -1186,9 +1209,21 @@ static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+static int rgb_to_yuv_impl(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
+                           uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, const uint16_t *lut16_d, void *stream) {
+  LGPU_REQUIRE(dst_d, "null destination table");
+  uint8_t *const one[1][4] = {{dst_d[0], dst_d[1], dst_d[2], dst_d[3]}};
+  return rgb_to_yuv_impl_n(&src_d, irow, width, height, in_order, in_alpha, one, orow, out_fmt, out_alpha, which_tables, lut16_d, 1, stream);
+}
 extern "C" int lgpu_rgb_to_yuv(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha,
                                uint8_t *const dst_d[4], const int orow[4], int out_fmt, int out_alpha, int which_tables, void *stream) {
   return rgb_to_yuv_impl(src_d, irow, width, height, in_order, in_alpha, dst_d, orow, out_fmt, out_alpha, which_tables, nullptr, stream);
+}
+// nframes frames of one geometry: dst_d[f * 4 + plane]
+extern "C" int lgpu_rgb_to_yuv_batch(const uint8_t *const *src_d, int irow, int width, int height, int in_order, int in_alpha,
+                                     uint8_t *const *dst_d, const int orow[4], int out_fmt, int out_alpha, int which_tables, int nframes, void *stream) {
+  LGPU_REQUIRE(dst_d, "null destination table");
+  return rgb_to_yuv_impl_n(src_d, irow, width, height, in_order, in_alpha, reinterpret_cast<uint8_t *const (*)[4]>(dst_d), orow, out_fmt, out_alpha, which_tables, nullptr, nframes, stream);
 }
 extern "C" int lgpu_rgb_to_yuv_lut16(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d, int orow, int out_fmt,
                                      int clamping_unclamped, const uint16_t *lut16_d, void *stream) {
@@ -1199,12 +1234,15 @@ extern "C" int lgpu_rgb_to_yuv_lut16(const uint8_t *src_d, int irow, int width, 
   return rgb_to_yuv_impl(src_d, irow, width, height, in_order, in_alpha, dd, oo, out_fmt, 0, clamping_unclamped ? 1 : 0, lut16_d, stream);
 }
 
-extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
-                               uint8_t *dst_d, int orow, int out_order, int out_alpha, int which_tables, void *stream) {
+static int yuv_to_rgb_n(const uint8_t *const (*srcs)[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                        uint8_t *const *dsts, int orow, int out_order, int out_alpha, int which_tables, int nfr, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   if ((rc = ensure_cavgc())) return rc;
-  LGPU_REQUIRE(src_d && irow && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(srcs && irow && dsts && nfr >= 1 && nfr <= LGPU_FX_MAX_FRAMES && width > 0 && height > 0, "null frame table, 1..16 frames, or empty geometry");
+  const uint8_t *const *const src_d = srcs[0];
+  uint8_t *const dst_d = dsts[0];
+  LGPU_REQUIRE(dst_d, "null frame");
   LGPU_REQUIRE(in_fmt >= 0 && in_fmt <= 3, "in_fmt must be 0 (packed 4:4:4), 1 (planar 4:4:4), 2 (UYVY) or 3 (YUYV); 4:2:0 / 4:2:2 planar: lgpu_yuv420p_to_rgb");
   LGPU_REQUIRE(out_order >= 0 && out_order <= 2, "out_order must be 0 (RGB), 1 (BGR) or 2 (ARGB)");
   LGPU_REQUIRE(in_fmt < 2 || !(width & 1), "UYVY / YUYV need an even width");
@@ -1224,23 +1262,32 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
   a.order = out_order; a.alpha_in = (in_fmt <= 1) ? in_alpha : 0; a.fmt = in_fmt; a.alpha_out = out_alpha;
   a.unclamped = which_tables & 1;
   a.tables = device_tables()->yuv2rgb[which_tables & 3];
+  FxFrames F = {};
+  uintptr_t sbits = (uintptr_t)irow[0], dbits = (uintptr_t)orow;
+  for (int f = 0; f < nfr; f++) {
+    LGPU_REQUIRE(dsts[f], "null frame");
+    F.out[f][0] = dsts[f]; dbits |= (uintptr_t)dsts[f];
+    for (int i = 0; i < nplanes; i++) { LGPU_REQUIRE(srcs[f][i], "null source plane"); F.in0[f][i] = srcs[f][i]; }
+    sbits |= (uintptr_t)srcs[f][0];
+    if (in_fmt >= 2) LGPU_REQUIRE(!((uintptr_t)srcs[f][0] & 3), "UYVY / YUYV rows must be 4-byte aligned");
+  }
   // UYVY / YUYV -> 4-byte pixels on aligned frames: the cell form
   const bool no_s = tune_on(TUNE_UYVY_NO_S);
-  if (in_fmt >= 2 && ops == 4 && !no_s && (width & 3) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & 7) == 0 && (((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0) {
+  if (in_fmt >= 2 && ops == 4 && !no_s && (width & 3) == 0 && (sbits & 7) == 0 && (dbits & 15) == 0) {
     const int ngr = width >> 2;
     const unsigned long long cells = (unsigned long long)ngr * height;
     if (cells < (1ull << 31)) {
       const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
-      const dim3 gs((unsigned)((cells + 511) / 512));
-#define K3S_CASE(F, O) case (F) * 4 + (O): hipLaunchKernelGGL((k_uyvy_to_rgb_s<F, O>), gs, dim3(512), 0, (hipStream_t)stream, a, magic); break;
+      const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
+#define K3S_CASE(FM, O) case (FM) * 4 + (O): hipLaunchKernelGGL((k_uyvy_to_rgb_s<FM, O>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
       switch (in_fmt * 4 + out_order) { K3S_CASE(2, 0) K3S_CASE(2, 1) K3S_CASE(2, 2) K3S_CASE(3, 0) K3S_CASE(3, 1) K3S_CASE(3, 2) }
 #undef K3S_CASE
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
   }
-  const dim3 grid(cdiv((unsigned)((width + 1) >> 1), kBlock), (unsigned)(height < 2048 ? height : 2048));
-#define K3_CASE(F, O) case (F) * 4 + (O): hipLaunchKernelGGL((k_yuv_to_rgb<F, O>), grid, dim3(kBlock), 0, (hipStream_t)stream, a); break;
+  const dim3 grid(cdiv((unsigned)((width + 1) >> 1), kBlock), (unsigned)(height < 2048 ? height : 2048), (unsigned)nfr);
+#define K3_CASE(FM, O) case (FM) * 4 + (O): hipLaunchKernelGGL((k_yuv_to_rgb<FM, O>), grid, dim3(kBlock), 0, (hipStream_t)stream, a, F); break;
   switch (in_fmt * 4 + out_order) {
     K3_CASE(0, 0) K3_CASE(0, 1) K3_CASE(0, 2) K3_CASE(1, 0) K3_CASE(1, 1) K3_CASE(2, 0) K3_CASE(2, 1) K3_CASE(2, 2)
     K3_CASE(3, 0) K3_CASE(3, 1) K3_CASE(3, 2)
@@ -1248,6 +1295,18 @@ extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4],
 #undef K3_CASE
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+extern "C" int lgpu_yuv_to_rgb(const uint8_t *const src_d[4], const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                               uint8_t *dst_d, int orow, int out_order, int out_alpha, int which_tables, void *stream) {
+  LGPU_REQUIRE(src_d, "null source table");
+  const uint8_t *const one[1][4] = {{src_d[0], src_d[1], src_d[2], src_d[3]}};
+  return yuv_to_rgb_n(one, irow, width, height, in_fmt, in_alpha, &dst_d, orow, out_order, out_alpha, which_tables, 1, stream);
+}
+// nframes frames of one geometry: src_d[f * 4 + plane]
+extern "C" int lgpu_yuv_to_rgb_batch(const uint8_t *const *src_d, const int irow[4], int width, int height, int in_fmt, int in_alpha,
+                                     uint8_t *const *dst_d, int orow, int out_order, int out_alpha, int which_tables, int nframes, void *stream) {
+  LGPU_REQUIRE(src_d, "null source table");
+  return yuv_to_rgb_n(reinterpret_cast<const uint8_t *const (*)[4]>(src_d), irow, width, height, in_fmt, in_alpha, dst_d, orow, out_order, out_alpha, which_tables, nframes, stream);
 }
 
 extern "C" int lgpu_rgb_to_yuv411(const uint8_t *src_d, int irow, int width, int height, int in_order, int in_alpha, uint8_t *dst_d,

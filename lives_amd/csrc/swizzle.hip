@@ -50,10 +50,12 @@ static bool swz_desc(int op, int alpha_first, SwzDesc *d) {
 }
 
 template <int IB, int OB, bool LUT>
-__global__ __launch_bounds__(kBlock) void k_swizzle(const uint8_t *__restrict__ src, int irow, uint8_t *dst, int orow,
+__global__ __launch_bounds__(kBlock) void k_swizzle(const FrameTab F, int irow, int orow,
                                                      int width, int height, uint32_t sel, uint32_t lutmask, Lut8 lut) {
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
   if (LUT) { stage_lut(s_lut, lut); __syncthreads(); }
+  const uint8_t *__restrict__ src = F.src[blockIdx.z];          // the frame is the grid's z index (lgpu_swizzle_batch)
+  uint8_t *dst = F.dst[blockIdx.z];
   const int groups = width >> 2;                     // full 4-pixel groups per row
   const int g = blockIdx.x * kBlock + threadIdx.x;
   for (int y = blockIdx.y; y < height; y += gridDim.y) {
@@ -97,11 +99,13 @@ __global__ __launch_bounds__(kBlock) void k_swizzle(const uint8_t *__restrict__ 
 
 // any alignment: one pixel per lane, byte accesses
 template <bool LUT>
-__global__ __launch_bounds__(kBlock) void k_swizzle_bytes(const uint8_t *__restrict__ src, int irow, uint8_t *dst, int orow,
+__global__ __launch_bounds__(kBlock) void k_swizzle_bytes(const FrameTab F, int irow, int orow,
                                                            int width, int height, int ib, int ob, uint32_t sel,
                                                            uint32_t lutmask, Lut8 lut) {
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
   if (LUT) { stage_lut(s_lut, lut); __syncthreads(); }
+  const uint8_t *__restrict__ src = F.src[blockIdx.z];
+  uint8_t *dst = F.dst[blockIdx.z];
   const int x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= width) return;
   for (int y = blockIdx.y; y < height; y += gridDim.y) {
@@ -119,11 +123,12 @@ __global__ __launch_bounds__(kBlock) void k_swizzle_bytes(const uint8_t *__restr
 // --- K6 -------------------------------------------------------------------------------------------------
 // The rectangle's rows are treated as byte ranges; each lane owns one 16-byte aligned chunk.  `chanmask`
 // marks the colour bytes of a dword (0x00FFFFFF RGBA/BGRA, 0xFFFFFF00 ARGB, 0xFFFFFFFF 3-byte palettes).
-__global__ __launch_bounds__(kBlock) void k_gamma_apply(uint8_t *pix, int rowstride, int byte0, int byte1, int height,
+__global__ __launch_bounds__(kBlock) void k_gamma_apply(const FrameTab F, int rowstride, int byte0, int byte1, int height,
                                                          uint32_t chanmask, Lut8 lut) {
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
   stage_lut(s_lut, lut);
   __syncthreads();
+  uint8_t *pix = F.dst[blockIdx.z];
   const int c0 = byte0 & ~15;
   const int o = c0 + (blockIdx.x * kBlock + threadIdx.x) * 16;
   if (o >= byte1) return;
@@ -143,11 +148,12 @@ __global__ __launch_bounds__(kBlock) void k_gamma_apply(uint8_t *pix, int rowstr
   }
 }
 // rows that are not 16-byte aligned: one byte per lane
-__global__ __launch_bounds__(kBlock) void k_gamma_apply_bytes(uint8_t *pix, int rowstride, int byte0, int byte1, int height,
+__global__ __launch_bounds__(kBlock) void k_gamma_apply_bytes(const FrameTab F, int rowstride, int byte0, int byte1, int height,
                                                                int psize, int alpha_first, Lut8 lut) {
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
   stage_lut(s_lut, lut);
   __syncthreads();
+  uint8_t *pix = F.dst[blockIdx.z];
   const int b = byte0 + blockIdx.x * kBlock + threadIdx.x;
   if (b >= byte1) return;
   if (psize == 4 && ((b & 3) == (alpha_first ? 0 : 3))) return;   // rows start on a pixel boundary
@@ -176,7 +182,8 @@ __device__ __forceinline__ uint32_t premult_pixel(uint32_t p, int alpha_first, i
 }
 // VEC: four pixels per lane, 16-byte loads and stores (rows and base 16-byte aligned, decided on the host)
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void k_premult(uint8_t *pix, int rowstride, int width, int height, int alpha_first, int un) {
+__global__ __launch_bounds__(kBlock) void k_premult(const FrameTab F, int rowstride, int width, int height, int alpha_first, int un) {
+  uint8_t *pix = F.dst[blockIdx.z];
   __shared__ float s_ratio[256];
   for (int i = threadIdx.x; i < 256; i += kBlock) s_ratio[i] = __fdiv_rn(255.f, (float)i);
   __syncthreads();
@@ -330,25 +337,33 @@ static inline dim3 row_grid(unsigned items_per_row, int height) {
 
 using namespace lgpu;
 
-extern "C" int lgpu_swizzle(int op, int alpha_first, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow,
-                            int width, int height, const uint8_t *lut8, void *stream) {
+// frames of one geometry as ONE launch (the frame is the grid's z index); n = 1 is the single-frame entry point.  The vector forms need every frame aligned.
+static dim3 with_frames(dim3 g, int n) { g.z = (unsigned)n; return g; }
+static int swizzle_n(int op, int alpha_first, const uint8_t *const *src_d, int irow, uint8_t *const *dst_d, int orow, int width, int height, const uint8_t *lut8, int n, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
   SwzDesc d;
   LGPU_REQUIRE(swz_desc(op, alpha_first, &d), "unknown swizzle op");
-  LGPU_REQUIRE(src_d && dst_d && width > 0 && height > 0, "null frame or empty geometry");
+  LGPU_REQUIRE(src_d && dst_d && n >= 1 && n <= LGPU_FX_MAX_FRAMES && width > 0 && height > 0, "null frame table, 1..16 frames, or empty geometry");
   LGPU_REQUIRE(irow >= width * d.ibpp && orow >= width * d.obpp, "rowstride smaller than a row");
-  LGPU_REQUIRE(src_d != dst_d || d.ibpp == d.obpp, "in-place needs equal pixel sizes");
+  FrameTab F = {};
+  uintptr_t sb = (uintptr_t)irow, db = (uintptr_t)orow;
+  for (int i = 0; i < n; i++) {
+    LGPU_REQUIRE(src_d[i] && dst_d[i], "null frame");
+    LGPU_REQUIRE(src_d[i] != dst_d[i] || d.ibpp == d.obpp, "in-place needs equal pixel sizes");
+    F.src[i] = src_d[i]; F.dst[i] = dst_d[i];
+    sb |= (uintptr_t)src_d[i]; db |= (uintptr_t)dst_d[i];
+  }
   hipStream_t st = (hipStream_t)stream;
   const Lut8 l = pack_lut(lut8);
-  const bool iv = (d.ibpp == 4) ? (((uintptr_t)src_d | (uintptr_t)irow) & 15) == 0 : (((uintptr_t)src_d | (uintptr_t)irow) & 3) == 0;
-  const bool ov = (d.obpp == 4) ? (((uintptr_t)dst_d | (uintptr_t)orow) & 15) == 0 : (((uintptr_t)dst_d | (uintptr_t)orow) & 3) == 0;
+  const bool iv = (d.ibpp == 4) ? (sb & 15) == 0 : (sb & 3) == 0;
+  const bool ov = (d.obpp == 4) ? (db & 15) == 0 : (db & 3) == 0;
   if (iv && ov) {
-    const dim3 grid = row_grid((unsigned)(width >> 2) + 1, height);
+    const dim3 grid = with_frames(row_grid((unsigned)(width >> 2) + 1, height), n);
 #define LAUNCH(IB, OB)                                                                                                   \
   do {                                                                                                                   \
-    if (lut8) hipLaunchKernelGGL((k_swizzle<IB, OB, true>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.sel, d.lutmask, l); \
-    else hipLaunchKernelGGL((k_swizzle<IB, OB, false>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.sel, d.lutmask, l);     \
+    if (lut8) hipLaunchKernelGGL((k_swizzle<IB, OB, true>), grid, dim3(kBlock), 0, st, F, irow, orow, width, height, d.sel, d.lutmask, l); \
+    else hipLaunchKernelGGL((k_swizzle<IB, OB, false>), grid, dim3(kBlock), 0, st, F, irow, orow, width, height, d.sel, d.lutmask, l);     \
   } while (0)
     if (d.ibpp == 3 && d.obpp == 3) LAUNCH(3, 3);
     else if (d.ibpp == 3) LAUNCH(3, 4);
@@ -356,49 +371,76 @@ extern "C" int lgpu_swizzle(int op, int alpha_first, const uint8_t *src_d, int i
     else LAUNCH(4, 4);
 #undef LAUNCH
   } else {
-    const dim3 grid = row_grid((unsigned)width, height);
-    if (lut8) hipLaunchKernelGGL((k_swizzle_bytes<true>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.ibpp, d.obpp, d.sel, d.lutmask, l);
-    else hipLaunchKernelGGL((k_swizzle_bytes<false>), grid, dim3(kBlock), 0, st, src_d, irow, dst_d, orow, width, height, d.ibpp, d.obpp, d.sel, d.lutmask, l);
+    const dim3 grid = with_frames(row_grid((unsigned)width, height), n);
+    if (lut8) hipLaunchKernelGGL((k_swizzle_bytes<true>), grid, dim3(kBlock), 0, st, F, irow, orow, width, height, d.ibpp, d.obpp, d.sel, d.lutmask, l);
+    else hipLaunchKernelGGL((k_swizzle_bytes<false>), grid, dim3(kBlock), 0, st, F, irow, orow, width, height, d.ibpp, d.obpp, d.sel, d.lutmask, l);
   }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+extern "C" int lgpu_swizzle(int op, int alpha_first, const uint8_t *src_d, int irow, uint8_t *dst_d, int orow,
+                            int width, int height, const uint8_t *lut8, void *stream) {
+  return swizzle_n(op, alpha_first, &src_d, irow, &dst_d, orow, width, height, lut8, 1, stream);
+}
+extern "C" int lgpu_swizzle_batch(int op, int alpha_first, const uint8_t *const *src_d, int irow, uint8_t *const *dst_d, int orow,
+                                  int width, int height, const uint8_t *lut8, int nframes, void *stream) {
+  return swizzle_n(op, alpha_first, src_d, irow, dst_d, orow, width, height, lut8, nframes, stream);
+}
 
-extern "C" int lgpu_gamma_apply(uint8_t *pix_d, int rowstride, int x, int y, int width, int height, int psize,
-                                int alpha_first, const uint8_t *lut8, void *stream) {
+static int gamma_apply_n(uint8_t *const *pix_d, int rowstride, int x, int y, int width, int height, int psize, int alpha_first, const uint8_t *lut8, int n, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(pix_d && width > 0 && height > 0 && x >= 0 && y >= 0, "null frame or empty rectangle");
+  LGPU_REQUIRE(pix_d && n >= 1 && n <= LGPU_FX_MAX_FRAMES && width > 0 && height > 0 && x >= 0 && y >= 0, "null frame table, 1..16 frames, or empty rectangle");
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
   LGPU_REQUIRE(rowstride >= (x + width) * psize, "rectangle exceeds the row");
+  for (int i = 0; i < n; i++) LGPU_REQUIRE(pix_d[i], "null frame");
   if (!lut8) return LGPU_OK;   // reference: no LUT -> nothing to do (src/colourspace.c:14046)
   const Lut8 l = pack_lut(lut8);
-  uint8_t *base = pix_d + (size_t)y * rowstride;
+  FrameTab F = {};
+  uintptr_t bits = (uintptr_t)rowstride;
+  for (int i = 0; i < n; i++) { F.dst[i] = pix_d[i] + (size_t)y * rowstride; bits |= (uintptr_t)F.dst[i]; }
   const int b0 = x * psize, b1 = (x + width) * psize;
   hipStream_t st = (hipStream_t)stream;
-  if ((((uintptr_t)base | (uintptr_t)rowstride) & 15) == 0) {
+  if ((bits & 15) == 0) {
     const uint32_t chanmask = psize == 3 ? 0xFFFFFFFFu : alpha_first ? 0xFFFFFF00u : 0x00FFFFFFu;
     const unsigned chunks = (unsigned)((b1 - (b0 & ~15) + 15) >> 4);
-    hipLaunchKernelGGL(k_gamma_apply, row_grid(chunks, height), dim3(kBlock), 0, st, base, rowstride, b0, b1, height, chanmask, l);
+    hipLaunchKernelGGL(k_gamma_apply, with_frames(row_grid(chunks, height), n), dim3(kBlock), 0, st, F, rowstride, b0, b1, height, chanmask, l);
   } else {
-    hipLaunchKernelGGL(k_gamma_apply_bytes, row_grid((unsigned)(b1 - b0), height), dim3(kBlock), 0, st, base, rowstride, b0, b1,
+    hipLaunchKernelGGL(k_gamma_apply_bytes, with_frames(row_grid((unsigned)(b1 - b0), height), n), dim3(kBlock), 0, st, F, rowstride, b0, b1,
                        height, psize, alpha_first, l);
   }
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
 }
+extern "C" int lgpu_gamma_apply(uint8_t *pix_d, int rowstride, int x, int y, int width, int height, int psize,
+                                int alpha_first, const uint8_t *lut8, void *stream) {
+  return gamma_apply_n(&pix_d, rowstride, x, y, width, height, psize, alpha_first, lut8, 1, stream);
+}
+extern "C" int lgpu_gamma_apply_batch(uint8_t *const *pix_d, int rowstride, int x, int y, int width, int height, int psize,
+                                      int alpha_first, const uint8_t *lut8, int nframes, void *stream) {
+  return gamma_apply_n(pix_d, rowstride, x, y, width, height, psize, alpha_first, lut8, nframes, stream);
+}
 
-extern "C" int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int height, int alpha_first, int un, void *stream) {
+static int alpha_premult_n(uint8_t *const *pix_d, int rowstride, int width, int height, int alpha_first, int un, int n, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(pix_d && width > 0 && height > 0 && rowstride >= width * 4, "bad geometry");
-  LGPU_REQUIRE((((uintptr_t)pix_d | (uintptr_t)rowstride) & 3) == 0, "4-byte pixels must be 4-byte aligned");
-  if ((((uintptr_t)pix_d | (uintptr_t)rowstride) & 15) == 0)
-    hipLaunchKernelGGL(k_premult<true>, row_grid((unsigned)((width + 3) >> 2), height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width, height, alpha_first, un);
+  LGPU_REQUIRE(pix_d && n >= 1 && n <= LGPU_FX_MAX_FRAMES && width > 0 && height > 0 && rowstride >= width * 4, "bad geometry or frame table");
+  FrameTab F = {};
+  uintptr_t bits = (uintptr_t)rowstride;
+  for (int i = 0; i < n; i++) { LGPU_REQUIRE(pix_d[i], "null frame"); F.dst[i] = pix_d[i]; bits |= (uintptr_t)pix_d[i]; }
+  LGPU_REQUIRE((bits & 3) == 0, "4-byte pixels must be 4-byte aligned");
+  if ((bits & 15) == 0)
+    hipLaunchKernelGGL(k_premult<true>, with_frames(row_grid((unsigned)((width + 3) >> 2), height), n), dim3(kBlock), 0, (hipStream_t)stream, F, rowstride, width, height, alpha_first, un);
   else
-    hipLaunchKernelGGL(k_premult<false>, row_grid((unsigned)width, height), dim3(kBlock), 0, (hipStream_t)stream, pix_d, rowstride, width, height, alpha_first, un);
+    hipLaunchKernelGGL(k_premult<false>, with_frames(row_grid((unsigned)width, height), n), dim3(kBlock), 0, (hipStream_t)stream, F, rowstride, width, height, alpha_first, un);
   LGPU_CHECK_LAUNCH();
   return LGPU_OK;
+}
+extern "C" int lgpu_alpha_premult(uint8_t *pix_d, int rowstride, int width, int height, int alpha_first, int un, void *stream) {
+  return alpha_premult_n(&pix_d, rowstride, width, height, alpha_first, un, 1, stream);
+}
+extern "C" int lgpu_alpha_premult_batch(uint8_t *const *pix_d, int rowstride, int width, int height, int alpha_first, int un, int nframes, void *stream) {
+  return alpha_premult_n(pix_d, rowstride, width, height, alpha_first, un, nframes, stream);
 }
 
 extern "C" int lgpu_byte_luts(const uint8_t *src_d, int irow, uint8_t *dst_d, int orow, int width, int height, int psize, const uint8_t *luts,

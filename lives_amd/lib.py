@@ -131,6 +131,14 @@ PROTOTYPES = {
     "lgpu_letterbox_bars": [vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp],
     "lgpu_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp],
     "lgpu_pixbuf_scale": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_swizzle_batch": [ci, ci, vp, ci, vp, ci, ci, ci, vp, ci, vp],
+    "lgpu_gamma_apply_batch": [vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp],
+    "lgpu_alpha_premult_batch": [vp, ci, ci, ci, ci, ci, ci, vp],
+    "lgpu_mirror_batch": [ci, vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_letterbox_batch": [vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, vp],
+    "lgpu_colorkey_batch": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double, ci, ci, ci, ci, vp],
+    "lgpu_rgb_to_yuv_batch": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp],
+    "lgpu_yuv_to_rgb_batch": [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
     "lgpu_pixbuf_scale_check": [ci, ci, ci, ci, ci, ci, vp],
     "lgpu_pixbuf_scale_batch": [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_fx_batch": [ctypes.POINTER(FxParams), ctypes.POINTER(FxFrame), ci, vp],
