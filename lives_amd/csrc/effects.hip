@@ -262,6 +262,38 @@ __global__ __launch_bounds__(kBlock) void k_chroma_argb(Frames2 f, uint32_t bf, 
 // ---- mirrors ----------------------------------------------------------------------------------------------
 // result[y][x] = src[ry(y)][rx(x)], rx(x) = x <= hw ? x : 2hw - x, ry(y) = y >= h - hh + 1 ? h - y : y
 // (the in-place result of mirrors.c; its stray writes to pixel `width` / row `height` are not performed)
+// 4-byte pixels on 16-byte aligned frames: a lane moves FOUR neighbouring pixels with one 16-byte load and one 16-byte store -- a group wholly inside the
+// reflected half reads its four source pixels as one (dword-aligned) run and reverses them.  One pixel per lane (below) left the launch bound by its 138,000
+// one-kilobyte workgroups: 16 x 1080p 73.6 us, 0.45 of the roofline.
+__global__ __launch_bounds__(kBlock) void k_mirror_v4(const FrameTab T, int irow, int orow, int width, int height, int mx, int my) {
+  const uint8_t *src = T.src[blockIdx.z];
+  uint8_t *dst = T.dst[blockIdx.z];
+  const int inplace = src == dst;
+  const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (x0 >= width) return;
+  const int hw = width >> 1, hh = height >> 1;
+  const bool whole = x0 + 4 <= width;
+  const bool plain = whole && (!mx || x0 + 3 <= hw), flipped = whole && mx && x0 > hw;
+  for (int y = blockIdx.y; y < height; y += gridDim.y) {
+    const int sy = (my && y >= height - hh + 1) ? height - y : y;
+    const uint32_t *srow = reinterpret_cast<const uint32_t *>(src + (size_t)sy * irow);
+    uint32_t *drow = reinterpret_cast<uint32_t *>(dst + (size_t)y * orow);
+    if (plain) {
+      if (inplace && sy == y) continue;
+      *reinterpret_cast<uint4 *>(drow + x0) = *reinterpret_cast<const uint4 *>(srow + x0);
+    } else if (flipped) {
+      uint32_t v[4];
+      __builtin_memcpy(v, srow + (2 * hw - x0 - 3), 16);          // source pixels 2hw - x0 - 3 .. 2hw - x0: dword aligned, one load
+      *reinterpret_cast<uint4 *>(drow + x0) = make_uint4(v[3], v[2], v[1], v[0]);
+    } else {
+      for (int x = x0; x < x0 + 4 && x < width; x++) {
+        const int sx = (mx && x > hw) ? 2 * hw - x : x;
+        if (inplace && sx == x && sy == y) continue;
+        drow[x] = srow[sx];
+      }
+    }
+  }
+}
 template <int PS>
 __global__ __launch_bounds__(kBlock) void k_mirror(const FrameTab T, int irow, int orow, int width, int height,
                                                     int mx, int my) {
@@ -491,8 +523,16 @@ static int mirror_n(int mode, const uint8_t *const *src_d, int irow, uint8_t *co
   LGPU_REQUIRE(psize == 3 || psize == 4, "psize must be 3 or 4");
   LGPU_REQUIRE(irow >= width * psize && orow >= width * psize, "rowstride smaller than a row");
   FrameTab T = {};
-  for (int i = 0; i < n; i++) { LGPU_REQUIRE(src_d[i] && dst_d[i], "null frame"); T.src[i] = src_d[i]; T.dst[i] = dst_d[i]; }
+  uintptr_t bits = (uintptr_t)irow | (uintptr_t)orow;
+  for (int i = 0; i < n; i++) { LGPU_REQUIRE(src_d[i] && dst_d[i], "null frame"); T.src[i] = src_d[i]; T.dst[i] = dst_d[i]; bits |= (uintptr_t)src_d[i] | (uintptr_t)dst_d[i]; }
   const int mx = (mode == 0 || mode == 2), my = (mode == 1 || mode == 2);
+  if (psize == 4 && (bits & 15) == 0) {
+    dim3 g4 = row_grid2((unsigned)((width + 3) >> 2), height);
+    g4.z = (unsigned)n;
+    hipLaunchKernelGGL(k_mirror_v4, g4, dim3(kBlock), 0, (hipStream_t)stream, T, irow, orow, width, height, mx, my);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
+  }
   dim3 grid = row_grid2((unsigned)width, height);
   grid.z = (unsigned)n;
   if (psize == 4) hipLaunchKernelGGL(k_mirror<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, T, irow, orow, width, height, mx, my);

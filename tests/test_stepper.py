@@ -119,3 +119,16 @@ def test_wait_covers_a_stepper_on_the_null_stream(gpu):
         assert L.lgpu_stream_query(None) == 1, "lgpu_stepper_wait came back while its launch stream was busy"
     finally:
         st.close()
+
+
+def test_every_exchange_of_the_path_runs_against_self(gpu):
+    """a ONE-RANK RCCL communicator on the GPU: the parameter broadcast, the status all-reduce, the compositing fan-in (lgpu_fan_in: its Send / Recv slots inside one
+    RCCL group, 2 * world + 1 tracks) and 20 steps of the C stepper -- the whole of lives_amd.dist.preflight, which bench.py runs with real peers before it times
+    anything.  Until a multi-GPU node exists this is as close to hardware as the three exchanges get."""
+    from lives_amd import dist as ld
+    comm = ld.RcclComm("cuda")
+    try:
+        assert comm.count() in (1,) or comm.count() < 0          # 1, or a negative LGPU_E_* where the bound librccl has no ncclCommCount
+        assert ld.preflight(comm, "cuda", ops=gpu) == "ok"
+    finally:
+        comm.close()

@@ -49,6 +49,15 @@ def case(op):
         Y, U, V, o = rnd(h, w), rnd(h // 2, w // 2), rnd(h // 2, w // 2), rnd(h, w * 4)
         lut = np.arange(256, dtype=np.uint8)[::-1].copy()
         return (lambda i: ops.yuv420p_to_rgb(Y[i % NB], U[i % NB], V[i % NB], o[i % NB], w, h, lut=lut)), w * h * 3 // 2 + w * h * 4
+    if op.startswith("k2b"):           # k2bN: N 1080p frames per launch (lgpu_yuv420p_to_rgb_batch)
+        n = int(op[3:])
+        nb = 2 if not COLD else max(2, NB // n + 1)
+        lut = np.arange(256, dtype=np.uint8)[::-1].copy()
+        sets = []
+        for _ in range(nb):
+            sets.append([(torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda", generator=g), torch.randint(0, 256, (h // 2, w // 2), dtype=torch.uint8, device="cuda", generator=g),
+                          torch.randint(0, 256, (h // 2, w // 2), dtype=torch.uint8, device="cuda", generator=g), torch.zeros((h, w * 4), dtype=torch.uint8, device="cuda")) for _ in range(n)])
+        return (lambda i: ops.yuv420p_to_rgb_batch(sets[i % nb], w, h, lut=lut)), n * (w * h * 3 // 2 + w * h * 4)
     if op in ("c3", "c4rgb24", "c4rgba"):
         W, H = 3840, 2160
         if op == "c3":
@@ -92,9 +101,14 @@ def case(op):
         if kind == "transition":
             a_, b_, o = frames(h, w * 4), frames(h, w * 4), frames(h, w * 4)
             return (lambda i: ops.fx_batch(ops.FX_TRANSITION, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], w, h, ins1=[[t] for t in b_[i % nb]], ip=(1, 4), dp=(0.5,))), n * w * h * 8
+        inplace = kind.endswith("_ip")          # chroma_ip / luma_ip: out channel = in channel 0 (what a host does with CHANNEL_CAN_DO_INPLACE): two reads, one write;
+        if inplace:                              # out of place the 4-byte blends also READ the destination, whose alpha byte the reference never writes
+            kind = kind[:-3]
         if kind in ("chroma", "luma", "multi"):        # the two-input blends: bytes = two frames read, one written
             ps = 3 if kind == "multi" else 4
             a_, b_, o = frames(h, w * ps), frames(h, w * ps), frames(h, w * ps)
+            if inplace:
+                o = a_
             op, ip = {"chroma": (ops.FX_BLEND_CHROMA, (4, 0)), "luma": (ops.FX_BLEND_LUMA, (1, 4, 0)), "multi": (ops.FX_BLEND_MULTI, (1, 0))}[kind]
             amts = [40 + 10 * f for f in range(n)]
             return (lambda i: ops.fx_batch(op, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], w, h, ins1=[[t] for t in b_[i % nb]], ip=ip, frame_dp0=amts)), n * w * h * ps * 3
@@ -106,6 +120,80 @@ def case(op):
             return (lambda i: ops.fx_batch(ops.FX_GAUSS5_COLORKEY, [[t] for t in a_[i % nb]], [[t] for t in o[i % nb]], W, H, ins1=[[t] for t in b_[i % nb]],
                                            ip=(ps, 0, 128 | (128 << 8) | (128 << 16)), dp=(0.3, 0.8))), n * W * H * ps * 3
         raise SystemExit("unknown fx batch " + op)
+    if op.startswith("b") and ":" in op and op[1:op.index(":")].isdigit():
+        # bN:<kernel> -- N frames of 1920 x 1080 per launch through the batch forms of the CONVERT-step kernels and single-plane effects (include/lives_gpu.h, round 6):
+        # swz (BGRA32 -> RGBA32), swz34 (RGB24 -> BGRA32), gamma, premult, mirror, letterbox (-> 1920 x 1200), colorkey, r2y420 / r2uyvy / r2y888 (RGBA32 -> ...), y8882rgb / uyvy2rgb (-> RGBA32)
+        import ctypes
+        from lives_amd import lib
+        n = int(op[1:op.index(":")])
+        kind = op.split(":")[1]
+        nb = 2 if not COLD else max(2, NB // n + 1)
+        vp = ctypes.c_void_p
+
+        def frames(rows, cols):
+            return [[torch.randint(0, 256, (rows, cols), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)] for _ in range(nb)]
+
+        def tab(sets):
+            return [(vp * n)(*[t.data_ptr() for t in st_]) for st_ in sets]
+        lut = np.arange(256, dtype=np.uint8)[::-1].copy()
+        sp = ops.stream_ptr
+        if kind in ("swz", "swz34"):
+            ib = 4 if kind == "swz" else 3
+            a_, o = frames(h, w * ib), frames(h, w * 4)
+            ta, to = tab(a_), tab(o)
+            opi = 4 if kind == "swz" else 2          # LGPU_SWAP3POSTALPHA / LGPU_SWAP3ADDPOST
+            return (lambda i, keep=(a_, o): lib.call("lgpu_swizzle_batch", opi, 0, ta[i % nb], w * ib, to[i % nb], w * 4, w, h, None, n, sp())), n * w * h * (ib + 4)
+        if kind == "gamma":
+            a_ = frames(h, w * 4)
+            ta = tab(a_)
+            return (lambda i, keep=a_: lib.call("lgpu_gamma_apply_batch", ta[i % nb], w * 4, 0, 0, w, h, 4, 0, lut.ctypes.data, n, sp())), n * w * h * 8
+        if kind == "premult":
+            a_ = frames(h, w * 4)
+            ta = tab(a_)
+            return (lambda i, keep=a_: lib.call("lgpu_alpha_premult_batch", ta[i % nb], w * 4, w, h, 0, 0, n, sp())), n * w * h * 8
+        if kind == "mirror":
+            a_, o = frames(h, w * 4), frames(h, w * 4)
+            ta, to = tab(a_), tab(o)
+            return (lambda i, keep=(a_, o): lib.call("lgpu_mirror_batch", 2, ta[i % nb], w * 4, to[i % nb], w * 4, w, h, 4, n, sp())), n * w * h * 8
+        if kind == "letterbox":
+            a_, o = frames(h, w * 4), frames(1200, w * 4)
+            ta, to = tab(a_), tab(o)
+            black = (ctypes.c_uint8 * 4)(0, 0, 0, 255)
+            return (lambda i, keep=(a_, o): lib.call("lgpu_letterbox_batch", ta[i % nb], w * 4, w, h, to[i % nb], w * 4, w, 1200, 4, black, n, sp())), n * (w * h * 4 + w * 1200 * 4)
+        if kind == "colorkey":
+            a_, b_, o = frames(h, w * 3), frames(h, w * 3), frames(h, w * 3)
+            ta, tb, to = tab(a_), tab(b_), tab(o)
+            return (lambda i, keep=(a_, b_, o): lib.call("lgpu_colorkey_batch", ta[i % nb], w * 3, tb[i % nb], w * 3, to[i % nb], w * 3, w, h, 0, 0.3, 0.8, 128, 128, 128, n, sp())), n * w * h * 9
+        if kind in ("r2y420", "r2uyvy", "r2y888"):
+            fmt = {"r2y420": 4, "r2uyvy": 2, "r2y888": 0}[kind]
+            a_ = frames(h, w * 4)
+            dims = {4: [(h, w), (h // 2, w // 2), (h // 2, w // 2)], 2: [(h, w * 2)], 0: [(h, w * 3)]}[fmt]
+            o = [[[torch.zeros(d, dtype=torch.uint8, device="cuda") for d in dims] for _ in range(n)] for _ in range(nb)]
+            ta = tab(a_)
+            to = []
+            for st_ in o:
+                t_ = (vp * (4 * n))()
+                for f in range(n):
+                    for k, pl in enumerate(st_[f]):
+                        t_[4 * f + k] = pl.data_ptr()
+                to.append(t_)
+            orow = (ctypes.c_int * 4)(*([d[1] for d in dims] + [0] * (4 - len(dims))))
+            ob = sum(d[0] * d[1] for d in dims)
+            return (lambda i, keep=(a_, o): lib.call("lgpu_rgb_to_yuv_batch", ta[i % nb], w * 4, w, h, 0, 1, to[i % nb], orow, fmt, 0, 0, n, sp())), n * (w * h * 4 + ob)
+        if kind in ("y8882rgb", "uyvy2rgb"):
+            fmt = 0 if kind == "y8882rgb" else 2
+            ib = 3 if fmt == 0 else 2
+            a_, o = frames(h, w * ib), frames(h, w * 4)
+            ta = []
+            for st_ in a_:
+                t_ = (vp * (4 * n))()
+                for f in range(n):
+                    t_[4 * f] = st_[f].data_ptr()
+                ta.append(t_)
+            to = tab(o)
+            irow = (ctypes.c_int * 4)(w * ib, 0, 0, 0)
+            return (lambda i, keep=(a_, o): lib.call("lgpu_yuv_to_rgb_batch", ta[i % nb], irow, w, h, fmt, 0, to[i % nb], w * 4, 0, 1, 0, n, sp())), n * w * h * (ib + 4)
+        raise SystemExit("unknown batch form " + op)
     if op.startswith("pb") and op[2:op.index(":")].isdigit():      # pbN:SWxSH:DWxDH:interp -- N frames of one geometry per launch (lgpu_pixbuf_scale_batch)
         head, a_, b_, it = op.split(":")
         n = int(head[2:])
