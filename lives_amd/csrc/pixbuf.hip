@@ -21,6 +21,7 @@
 // loads when the x phase is the same for every pixel -- integer ratios -- and per-lane loads otherwise), k_pb_direct (any ratio, source through
 // the caches), k_pb_nearest.  HBM-bound work with an integer MAC per tap and channel; no matrix-core formulation: the per-phase tables are
 // two-dimensional (rounded and corrected per phase), not separable.
+#include <atomic>
 #include "lgpu_common.h"
 #include <cmath>
 #include <cstdlib>
@@ -250,17 +251,37 @@ __device__ __forceinline__ uint32_t pb_add_hi_lo(uint32_t x, uint32_t y) {      
   asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "=v"(d) : "v"(x), "v"(y));
   return d;
 }
+// a * 7 + c as ONE 24-bit multiply-add whatever the compiler has learnt about the operands: with the all-opaque form's known-zero high bytes it otherwise turns
+// __umul24 into a plain multiply and selects v_mad_u64_u32 / v_mul_lo_u32 (quarter rate) for it
+__device__ __forceinline__ uint32_t pb_mad7(uint32_t a, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u24 %0, %1, 7, %2" : "=v"(d) : "v"(a), "v"(c));
+  return d;
+}
 // one source row of a lane: 4 pixels -> the two H columns of its 4 channels (h[c] = column 2k, h[4 + c] = column 2k + 1)
 // e (ALIGNED strips only, otherwise 0): lane 0 holds pixel P[4k-1] there, lane 63 pixel P[4k+4] (clamped into the row), every other lane 0 -- the two taps the
 // wave shifts cannot deliver.  SWAP: channel 0 is fed from byte 2 and channel 2 from byte 0 (the R <-> B conversion of the chain costs nothing: the three colours
 // are treated alike until they are stored).
-template <int HYPER, int ALIGNED = 0, int SWAP = 0>
+// OPAQUE (the caller states that every source pixel has alpha 255 -- decoded video, a frame that has just been given its alpha channel): alpha * colour is 255 * colour
+// for every tap, the 255 and the library's reciprocal cancel EXACTLY (trunc(255 T * fl(1 / 65280)) == T >> 8 for every T the 256 weight units can make of bytes, and
+// the bilinear twin with 1020 and >> 2: checked for all of them when the kernel's tables are built, pb_opaque_check), so the colours go through as plain bytes: one
+// v_perm per channel pair instead of two SDWA multiplies, three channels instead of four, a shift instead of the reciprocal and three double-precision products.
+template <int HYPER, int ALIGNED = 0, int SWAP = 0, int OPAQUE = 0>
 __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e = 0u, uint32_t em = 0u) {
+  static_assert(!(OPAQUE && ALIGNED), "the all-opaque form exists for the strips with feeder lanes (the gaussian chain)");
   uint32_t A[4], B[4];
+  if (OPAQUE) {
+    constexpr uint32_t s0 = SWAP ? 0x0C060C02u : 0x0C040C00u, s2 = SWAP ? 0x0C040C00u : 0x0C060C02u;
+    A[0] = __builtin_amdgcn_perm(q.y, q.x, s0); B[0] = __builtin_amdgcn_perm(q.w, q.z, s0);
+    A[1] = __builtin_amdgcn_perm(q.y, q.x, 0x0C050C01u); B[1] = __builtin_amdgcn_perm(q.w, q.z, 0x0C050C01u);
+    A[2] = __builtin_amdgcn_perm(q.y, q.x, s2); B[2] = __builtin_amdgcn_perm(q.w, q.z, s2);
+    A[3] = 0u; B[3] = 0u;
+  } else {
   A[0] = pb_premul_pair<SWAP ? 2 : 0>(q.x, q.y); B[0] = pb_premul_pair<SWAP ? 2 : 0>(q.z, q.w);
   A[1] = pb_premul_pair<1>(q.x, q.y); B[1] = pb_premul_pair<1>(q.z, q.w);
   A[2] = pb_premul_pair<SWAP ? 0 : 2>(q.x, q.y); B[2] = pb_premul_pair<SWAP ? 0 : 2>(q.z, q.w);
   A[3] = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u); B[3] = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);       // the alpha pairs
+  }
   // ALIGNED: the one pixel beyond the strip, premultiplied and already in the half of the dword where the wave shift would have delivered it -- em = 65536 in
   // lane 0 (P[4k-1] belongs in the high half of the left neighbour's pair), 1 in lane 63 (P[4k+4] in the low half of the right neighbour's), 0 elsewhere; it then
   // rides into the lane exchange as the value the shift leaves in lanes that have no source lane (DPP without bound_ctrl keeps the destination): 5 operations per row
@@ -278,7 +299,7 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
     xe[3] = am;
   }
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
+  for (int c = 0; c < (OPAQUE ? 3 : 4); c++) {
     if (HYPER) {
       // wave_shr:1 -- the left lane's (P[4k-2], P[4k-1]);  wave_shl:1 -- the right lane's (P[4k+4], P[4k+5]);  lanes 0 / 63 keep xe (0 in strips with feeder lanes)
       const uint32_t bl = ALIGNED ? (uint32_t)__builtin_amdgcn_update_dpp((int)xe[c], (int)B[c], 0x138, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_mov_dpp((int)B[c], 0x138, 0xF, 0xF, true);
@@ -292,6 +313,35 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
   }
 }
 
+// the all-opaque forms replace the library's (uint8_t)((double)V_c * (1.0 / (double)V_alpha)) by a shift: V_c = 255 T, V_alpha = 255 * 256 (HYPER: T = the 256 weight
+// units on bytes, T <= 65280) or 255 * 4 (BILINEAR: T <= 1020).  Every T is compared on the device in the library's own double arithmetic before the first such launch.
+__global__ void k_pb_opaque_check(unsigned int *bad) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= 65280u) {
+    const double ia = pb_recip(65280u);
+    if ((uint32_t)(int)((double)(255u * t) * ia) != (t >> 8)) atomicAdd(bad, 1u);
+  }
+  if (t <= 1020u) {
+    const double ib = pb_recip(1020u);
+    if ((uint32_t)(int)((double)(255u * t) * ib) != (t >> 2)) atomicAdd(bad, 1u);
+  }
+}
+static int pb_opaque_check() {
+  static std::atomic<int> state{0};          // 0 not run, 1 good, -1 bad
+  int st = state.load();
+  if (st == 0) {
+    unsigned int *d = nullptr, h = 1;
+    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) { set_error("pb_opaque_check: hipMalloc failed"); return LGPU_E_NOMEM; }
+    (void)hipMemset(d, 0, sizeof h);
+    hipLaunchKernelGGL(k_pb_opaque_check, dim3(256), dim3(256), 0, (hipStream_t)0, d);
+    const bool ok = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    st = (ok && h == 0) ? 1 : -1;
+    state.store(st);
+  }
+  if (st < 0) { set_error("the all-opaque shift differs from the library's double-precision un-premultiply on this build: LGPU_INTERP_OPAQUE is refused"); return LGPU_E_HIP; }
+  return LGPU_OK;
+}
 __global__ void k_pb_recip_check(uint32_t lo, uint32_t hi, unsigned long long *bad) {
   const uint32_t a = lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (a < lo || a >= hi || a == 0) return;
@@ -312,7 +362,7 @@ __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32
 // Memory operations are buffer loads / stores: one 128-bit descriptor per frame in SGPRs (built once per wave from uniform values), the row as the scalar offset,
 // the lane's place in the row as a constant 32-bit VGPR offset -- no address arithmetic on the vector unit at all; lanes that must not store carry an offset beyond
 // the descriptor's range and the hardware drops their store (no exec-mask branch per row).
-template <int CHAIN, int HYPER, int BLUR, int ALIGNED = 0, int SWAP = 0>
+template <int CHAIN, int HYPER, int BLUR, int ALIGNED = 0, int SWAP = 0, int OPAQUE = 0>
 __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
   // the gamma LUT and the blend's alpha scalers.  ONE copy per workgroup, but no workgroup barrier on the frame path: every wave writes the whole of both tables
   // itself (the same bytes) and reads them after its own writes have landed; a slower wave writing the same bytes again changes nothing
@@ -497,23 +547,26 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     __builtin_amdgcn_wave_barrier();
   }
   const uint32_t e_m = lane == 0 ? 65536u : lane == 63 ? 1u : 0u;
-  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q0), hr, e0, e_m);
-  pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(q1), hs, e1, e_m);
+  pb_half_hrow<HYPER, ALIGNED, SWAP, OPAQUE>(fix(q0), hr, e0, e_m);
+  pb_half_hrow<HYPER, ALIGNED, SWAP, OPAQUE>(fix(q1), hs, e1, e_m);
 #pragma unroll
-  for (int i = 0; i < 8; i++) carry[i] = HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
+  for (int i = 0; i < 8; i++) if (!OPAQUE || (i & 3) != 3) carry[i] = (HYPER && OPAQUE) ? pb_mad7(hs[i], hr[i]) : HYPER ? __umul24(hs[i], 7u) + hr[i] : hs[i];
 
   // one scaled row from its last two source rows (the first two are in `carry`): colours apart in cc, alpha in place (<< 24) in al
   auto scale_row = [&](const pb_u4 &ra, const pb_u4 &rb, uint32_t xa, uint32_t xb, uint32_t cc[2][3], uint32_t al[2]) __attribute__((always_inline)) {
-    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(ra), hr, xa, e_m);
-    pb_half_hrow<HYPER, ALIGNED, SWAP>(fix(rb), hs, xb, e_m);
+    pb_half_hrow<HYPER, ALIGNED, SWAP, OPAQUE>(fix(ra), hr, xa, e_m);
+    pb_half_hrow<HYPER, ALIGNED, SWAP, OPAQUE>(fix(rb), hs, xb, e_m);
     uint32_t v[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+      if (OPAQUE && (i & 3) == 3) { v[i] = 0u; continue; }          // no alpha sums: the alpha is 255 by the caller's word
+      if (HYPER && OPAQUE) { v[i] = pb_mad7(hr[i], carry[i] + hs[i]); carry[i] = pb_mad7(hs[i], hr[i]); continue; }
       if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
       else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
     }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
+      if (OPAQUE) { cc[j][0] = v[4 * j] >> (HYPER ? 8 : 2); cc[j][1] = v[4 * j + 1] >> (HYPER ? 8 : 2); cc[j][2] = v[4 * j + 2] >> (HYPER ? 8 : 2); al[j] = 0xFF000000u; continue; }
       const uint32_t va = v[4 * j + 3];
       pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, cc[j]);       // V_alpha == 0 makes every V_c 0 too: 0 * fl(1 / 1) = 0, the library's all-zero pixel
       al[j] = (va >> A.ashift) << 24;
@@ -584,18 +637,21 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     // layer-2 pixels behind the store: a step then waits for the loads it has just issued and for its own store -- profiles/r05/blur_investigation.md.)
     uint32_t cc[2][3], al[2];
     auto scale_refill = [&](int s, bool more) __attribute__((always_inline)) {
-      pb_half_hrow<HYPER, ALIGNED, SWAP>(qa, hr, 0u, e_m);
+      pb_half_hrow<HYPER, ALIGNED, SWAP, OPAQUE>(qa, hr, 0u, e_m);
       if (more) qa = load_row(S0 + d * (2 * s + 4));
-      pb_half_hrow<HYPER, ALIGNED, SWAP>(qb, hs, 0u, e_m);
+      pb_half_hrow<HYPER, ALIGNED, SWAP, OPAQUE>(qb, hs, 0u, e_m);
       if (more) qb = load_row(S0 + d * (2 * s + 5));
       uint32_t v[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
+        if (OPAQUE && (i & 3) == 3) { v[i] = 0u; continue; }
+        if (HYPER && OPAQUE) { v[i] = pb_mad7(hr[i], carry[i] + hs[i]); carry[i] = pb_mad7(hs[i], hr[i]); continue; }
         if (HYPER) { v[i] = carry[i] + __umul24(hr[i], 7u) + hs[i]; carry[i] = __umul24(hs[i], 7u) + hr[i]; }
         else { v[i] = carry[i] + hr[i]; carry[i] = hs[i]; }
       }
 #pragma unroll
       for (int j = 0; j < 2; j++) {
+        if (OPAQUE) { cc[j][0] = v[4 * j] >> (HYPER ? 8 : 2); cc[j][1] = v[4 * j + 1] >> (HYPER ? 8 : 2); cc[j][2] = v[4 * j + 2] >> (HYPER ? 8 : 2); al[j] = 0xFF000000u; continue; }
         const uint32_t va = v[4 * j + 3];
         pb_half_colours(v[4 * j], v[4 * j + 1], v[4 * j + 2], va ? va : 1u, cc[j]);
         al[j] = (va >> A.ashift) << 24;
@@ -1642,13 +1698,20 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   const size_t occ_lds = occ > 0 && occ < 16 ? (size_t)(160 * 1024) / (size_t)occ - 3072 : 0;
 #define PBH_LAUNCH(HY, BL, AL, SW) hipLaunchKernelGGL((k_pb_half<1, HY, BL, AL, SW>), grid, dim3(256), occ_lds, st, a, T, l)
 #define PBH_SWAP(HY, BL, AL) do { if (a.swap_rb) PBH_LAUNCH(HY, BL, AL, 1); else PBH_LAUNCH(HY, BL, AL, 0); } while (0)
-  if (pr->do_blur) {
+#define PBH_OPAQUE(HY, SW) hipLaunchKernelGGL((k_pb_half<1, HY, 1, 0, SW, 1>), grid, dim3(256), occ_lds, st, a, T, l)
+  if (pr->do_blur && (pr->interp & LGPU_INTERP_OPAQUE)) {
+    // the caller's word that every source pixel is opaque: the vector-bound gaussian chain sheds a quarter of its instructions (pb_half_hrow)
+    if ((rc = pb_opaque_check())) return rc;
+    if (a.hyper) { if (a.swap_rb) PBH_OPAQUE(1, 1); else PBH_OPAQUE(1, 0); }
+    else { if (a.swap_rb) PBH_OPAQUE(0, 1); else PBH_OPAQUE(0, 0); }
+  } else if (pr->do_blur) {
     if (a.hyper) PBH_SWAP(1, 1, 0); else PBH_SWAP(0, 1, 0);
   } else if (a.aligned) {
     if (a.hyper) PBH_SWAP(1, 0, 1); else PBH_SWAP(0, 0, 1);
   } else {
     if (a.hyper) PBH_SWAP(1, 0, 0); else PBH_SWAP(0, 0, 0);
   }
+#undef PBH_OPAQUE
 #undef PBH_SWAP
 #undef PBH_LAUNCH
   LGPU_CHECK_LAUNCH();

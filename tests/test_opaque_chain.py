@@ -1,0 +1,60 @@
+"""LGPU_INTERP_OPAQUE: the caller's word that every source pixel has alpha 255 lets the gaussian chain run its lighter instantiation (pixbuf.hip, pb_half_hrow<.., OPAQUE>):
+the bytes must be those of the general kernel and of the oracle's chain (orc_chain: swizzle -> gdk-pixbuf scale -> gauss5 -> chroma blend -> LUT), HYPER and BILINEAR,
+with and without the R <-> B swap, on small frames with edge strips and at BASELINE's 3840 x 2160."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.util import dev, host
+
+pytestmark = pytest.mark.gpu
+P = po.P
+PIXBUF, OPAQUE = 0x100, 0x200
+
+
+@pytest.mark.parametrize("interp", [3, 2])
+@pytest.mark.parametrize("swap", [1, 0])
+@pytest.mark.parametrize("geom", [(256, 144), (1000, 600), (3840, 2160)])
+def test_opaque_chain_equals_the_general_kernel_and_the_oracle(gpu, orc, geom, swap, interp):
+    sw, sh = geom
+    dw, dh = sw // 2, sh // 2
+    rng = np.random.default_rng(0x0FA0 + sw + swap * 2 + interp)
+    n = 1 if sw > 2000 else 3
+    srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(n)]
+    for s in srcs:
+        s[:, 3::4] = 255
+    l2s = [rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8) for _ in range(n)]
+    for t in l2s:
+        a = t[:, 3::4]
+        a[rng.random(a.shape) < 0.5] = 255
+    lut = rng.permutation(256).astype(np.uint8)
+    d_s, d_l = [dev(a) for a in srcs], [dev(a) for a in l2s]
+    outs = {}
+    for flag in (OPAQUE, 0):
+        d_o = [dev(np.zeros((dh, dw * 4), np.uint8)) for _ in range(n)]
+        prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=swap, interp=interp | PIXBUF | flag, do_blur=1, bf=113, lut=lut)
+        gpu.chain(prm, gpu.chain_tracks(d_s, d_l, d_o))
+        outs[flag] = [host(t) for t in d_o]
+    for i in range(n):
+        assert (outs[OPAQUE][i] == outs[0][i]).all(), "track %d: the all-opaque instantiation differs from the general kernel" % i
+    if sw <= 1000:
+        for i in range(n):
+            want = np.zeros((dh, dw * 4), np.uint8)
+            assert orc.orc_chain(P(srcs[i]), sw * 4, sw, sh, P(l2s[i]), dw * 4, P(want), dw * 4, dw, dh, swap, interp | PIXBUF, 1, 113, P(lut)) == 0
+            assert (outs[OPAQUE][i] == want).all(), i
+
+
+def test_the_flag_changes_nothing_where_there_is_no_lighter_form(gpu):
+    """without the gaussian, or off the exact 2:1 case, LGPU_INTERP_OPAQUE is ignored: same bytes, translucent sources included"""
+    rng = np.random.default_rng(0x0FA9)
+    for (sw, sh, dw, dh, blur) in ((256, 144, 128, 72, 0), (262, 150, 128, 72, 1)):
+        src, l2 = rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8), rng.integers(0, 256, (dh, dw * 4), dtype=np.uint8)
+        if blur:
+            src[:, 3::4] = 255
+        res = []
+        for flag in (OPAQUE, 0):
+            d_o = dev(np.zeros((dh, dw * 4), np.uint8))
+            prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF | flag, do_blur=blur, bf=90, lut=None)
+            gpu.chain(prm, gpu.chain_tracks([dev(src)], [dev(l2)], [d_o]))
+            res.append(host(d_o))
+        assert (res[0] == res[1]).all()

@@ -71,17 +71,23 @@ def case(op):
         o = [torch.zeros_like(t) for t in a]
         delta = float(os.environ.get("C4_DELTA", "0.3"))
         return (lambda i: ops.gauss5_colorkey(a[i % NB], b[i % NB], o[i % NB], W, H, ps, 0, delta, 0.8, (128, 128, 128))), W * H * ps * 3
-    if op.startswith("chain"):         # chainN: the headline chain on N tracks per launch
-        n = int(op[5:] or 1)
+    if op.startswith("chain"):         # chainN: the headline chain on N tracks per launch; chainblurN: with config 5's gaussian; chainbluropN: that, all-opaque sources + LGPU_INTERP_OPAQUE
+        blur = op.startswith("chainblur")
+        opaque = op.startswith("chainblurop")
+        n = int(op[len("chainblurop" if opaque else "chainblur" if blur else "chain"):] or 1)
         W, H = 3840, 2160
         nb = NB if COLD else 2             # sets of n tracks
         sets = []
         for _ in range(nb):
             srcs = [torch.randint(0, 256, (H, W * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
+            if opaque:
+                for t_ in srcs:
+                    t_[:, 3::4] = 255
             l2s = [torch.randint(0, 256, (1080, 1920 * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
             ds = [torch.zeros_like(t) for t in l2s]
             sets.append((srcs, l2s, ds, ops.chain_tracks(srcs, l2s, ds)))
-        prm = ops.chain_params(W, H, W * 4, 1920, 1080, 1920 * 4, 1920 * 4, swap_rb=int(os.environ.get('C3_SWAP', '1')), interp=3 | 0x100, do_blur=0, bf=128, lut=np.arange(256, dtype=np.uint8))
+        prm = ops.chain_params(W, H, W * 4, 1920, 1080, 1920 * 4, 1920 * 4, swap_rb=int(os.environ.get('C3_SWAP', '1')), interp=3 | 0x100 | (0x200 if opaque else 0), do_blur=1 if blur else 0, bf=128,
+                               lut=np.arange(256, dtype=np.uint8))
         return (lambda i: ops.chain(prm, sets[i % nb][3])), n * (W * H * 4 + 2 * 1920 * 1080 * 4)
     if op.startswith("fx") and ":" in op:       # fxN:softlight | fxN:yuv411 | fxN:transition | fxN:chroma | fxN:luma | fxN:multi -- N frames per launch through lgpu_fx_batch
         n = int(op[2:op.index(":")])
