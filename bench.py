@@ -330,6 +330,26 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             batch8["batch8_blur_1gpu_us_per_step"] = round(e0.elapsed_time(e1) * 1e3 / n8, 2)
+            # ... and on frames whose alpha is 255 everywhere (decoded video), with the caller's word for it (LGPU_INTERP_OPAQUE): the lighter instantiation, same bytes
+            opq = []
+            for srcs, l2s, dsts in keep:
+                for i in range(0, T - 7, 8):
+                    o_s = [t.clone() for t in srcs[i:i + 8]]
+                    for t in o_s:
+                        t[:, 3::4] = 255
+                    opq.append((o_s, ops.chain_tracks(o_s, l2s[i:i + 8], dsts[i:i + 8])))
+            prm_op = ops.chain_params(SW, SH, SW * 4, DW, DH, DW * 4, DW * 4, swap_rb=1, interp=3 | 0x100 | 0x200, do_blur=1, bf=128, lut=lut, param_block=pblock)
+            prm_op.param_block_d = prm.param_block_d
+            for i in range(6):
+                ops.chain(prm_op, opq[i % len(opq)][1])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n8):
+                ops.chain(prm_op, opq[i % len(opq)][1])
+            e1.record()
+            torch.cuda.synchronize()
+            batch8["batch8_blur_opaque_sources_1gpu_us_per_step"] = round(e0.elapsed_time(e1) * 1e3 / n8, 2)
+            del opq
 
     # ---- the same chain through the REFERENCE's API (N = 1, outside the timed region of `value`): the tracks as pinned weed_layer_t's, one host thread per track,
     # convert_layer_palette -> resize_layer -> "chroma blend" process_func -> gamma_convert_layer by the reference names (liblivesgpu_dropin.so + livesgpu_fx.so),

@@ -1605,7 +1605,7 @@ static void pb_half_bands(PbHalfArgs *a, int bands) {
   a->bands = bands; a->th = a->dh / bands; a->rem = a->dh - a->th * bands;
 }
 
-static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
+static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0, int opaque = 0) {
   // strips of 64 storing lanes on 128-byte lines (k_pb_half<.., ALIGNED>; the two outer taps of a strip from one extra 4-byte load in lanes 0 and 63, which ride into
   // the lane exchange for free).  Round 3 measured them 3 % lighter on traffic and 13 % heavier on arithmetic: a draw.  With round 4's arithmetic (buffer addressing,
   // five-operation reciprocal, no register moves, the edge taps through DPP's kept destination) they win clearly: 16 tracks 166.5 -> 155.0 us, 8 tracks 85.7 -> 81.1,
@@ -1632,6 +1632,11 @@ static void pb_half_geometry(PbHalfArgs *a, int ntracks, int blur = 0) {
     bands = std::max(8, per_track / std::max(1, a->cgroups) / 8 * 8);
     bands = std::min(bands, std::max(1, a->dh / 6));
     bands = std::max(bands, (int)cdiv((unsigned)a->dh, 34u));
+    // The all-opaque instantiation (170 vector instructions per step instead of 232, 82 registers) is no longer bound by its arithmetic: shorter bands -- more waves
+    // in flight, four halo rows or not -- win.  16 tracks: 64 bands 160.8 us, 80 155.9, 112 154.3, **120 152.1 / 136 151.8**, 144 156.1, 184 157.3; 8 tracks 84.0 /
+    // 81.1 / 81.8 / **79.2** / 79.6 / 81.9 / 81.5; one frame 21.1 (64) .. 16.9 (120) .. **14.9 (184)** (profiles/r06/blur_opaque_bands.txt).  The general kernel
+    // (arithmetic-bound) loses with them: 171.6 us at 120 bands against 162.2 at 64.
+    if (opaque) bands = ntracks == 1 ? std::max(8, a->dh / 6 / 8 * 8) : std::max(8, a->dh / 9 / 8 * 8);
   }
   if (!blur && cols * bands > slots) bands = 8 * std::max(1, (a->dh + 20) / 40);       // ~5 rows per band, a multiple of 8: every XCD then owns the same number of bands (pb_chain_half)
   { const int v = tune(TUNE_PBH_TH); if (v >= 1 && v <= 1024) bands = (int)cdiv((unsigned)a->dh, (unsigned)v); else if (v > 100000) bands = v - 100000; }       // tuning probe / tests: bands of (about) v rows, or 100000 + the number of bands
@@ -1675,7 +1680,7 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   // among the balanced ones the largest group re-reads least: L2 -> fabric reads 769.5 / 698.8 / 675.2 / 667.3 MB per launch against 663.6 MB of source + layer 2.
   // So: an eighth of the track's bands per XCD when the band count is a multiple of 8 (pb_half_geometry makes it one for full-device launches), else band by band.
   a.bgroup = tune(TUNE_PBH_GROUP) >= 1 && tune(TUNE_PBH_GROUP) <= 4096 ? tune(TUNE_PBH_GROUP) : 0;
-  pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0);
+  pb_half_geometry(&a, ntracks, pr->do_blur ? 1 : 0, (pr->do_blur && (pr->interp & LGPU_INTERP_OPAQUE)) ? 1 : 0);
   // a launch that fits one generation of workgroups (one or two 4K tracks) is a matter of latency, not of streaming order: order 1 there (graph replay, one frame 12.09 us
   // against 12.45 with order 2 and 12.24 with order 0; config 3 12.19 / 12.62 / 12.33; two tracks 20.0 / 21.05 / 20.5)
   // With the gaussian (four resident workgroups per CU, one per CU and track): order 2 from a whole generation on -- 4 tracks 42.3 -> 41.9 us, 8 88.7 -> 86.9, 16 166.5 -> 164.5;

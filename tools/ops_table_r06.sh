@@ -14,6 +14,8 @@ python tools/bench_one.py --cold fx1:chroma_ip fx8:chroma_ip fx16:chroma_ip fx8:
 python tools/bench_one.py --cold softlight fx8:softlight fx16:softlight yuv411 fx8:yuv411 fx16:yuv411 c4rgba fx8:c4rgba c4rgb24 fx8:c4rgb24 2>/dev/null
 echo "== K2 (lgpu_yuv420p_to_rgb[_batch]) and the chain (lgpu_chain, 4K tracks)"
 python tools/bench_one.py --cold k2 k2b8 k2b16 chain1 chain8 chain16 c3 2>/dev/null
+echo "   (with config 5's gaussian; chainbluropN: sources whose alpha is 255 everywhere + LGPU_INTERP_OPAQUE)"
+python tools/bench_one.py --cold chainblur1 chainblur4 chainblur8 chainblur16 chainblurop1 chainblurop4 chainblurop8 chainblurop16 2>/dev/null
 echo "== gdk-pixbuf scaler (lgpu_pixbuf_scale[_batch])"
 for r in 3840x2160:1920x1080 1920x1080:1280x720 1280x720:1920x1080 3840x2160:1706x960 1920x1080:2560x1440 1280x720:3840x2160; do python tools/bench_one.py --cold pb:$r:3 pb8:$r:3 pb16:$r:3 2>/dev/null; done
 echo "== single-frame entry points without a batch form"
