@@ -387,8 +387,10 @@ int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int or
 #define LGPU_CHAIN_MAX_TRACKS 64
 #define LGPU_INTERP_PIXBUF 0x100
 #define LGPU_INTERP_OPAQUE 0x200   /* with LGPU_INTERP_PIXBUF: the caller STATES that every source pixel has alpha 255 (decoded video, a frame that has just been given
-                                      its alpha channel).  The alpha weighting then cancels exactly and the gaussian chain (do_blur, exact 2:1) runs a lighter
-                                      instantiation with the same bytes; ignored elsewhere.  A frame that is not opaque gets wrong colours: state it only when known. */
+                                      its alpha channel).  The alpha weighting then cancels exactly (checked on the device for every sum the weights can make) and
+                                      lighter instantiations with the same bytes run: the gaussian chain (do_blur, exact 2:1; lgpu_chain) and the two-dimensional
+                                      filters of every other ratio (lgpu_pixbuf_scale[_batch], channels 4: pass interp | LGPU_INTERP_OPAQUE); ignored elsewhere.
+                                      A frame that is not opaque gets wrong colours: state it only when known. */
 typedef struct {
   const uint8_t *src_d;      /* sw x sh, 4 bytes / pixel */
   const uint8_t *layer2_d;   /* dw x dh, RGBA32 */

@@ -317,6 +317,13 @@ __device__ __forceinline__ void pb_half_hrow(pb_u4 q, uint32_t h[8], uint32_t e 
 // units on bytes, T <= 65280) or 255 * 4 (BILINEAR: T <= 1020).  Every T is compared on the device in the library's own double arithmetic before the first such launch.
 __global__ void k_pb_opaque_check(unsigned int *bad) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  {      // the general ratios: T = the 65536 weight units on bytes, T <= 65536 * 255 < 2^24; a thread takes 256 of them
+    const double ic = pb_recip(255u * 65536u);
+    for (uint32_t k = 0; k < 256u; k++) {
+      const uint32_t T = t * 256u + k;
+      if (T <= 65536u * 255u && (uint32_t)(int)((double)(255ull * T) * ic) != (T >> 16)) atomicAdd(bad, 1u);
+    }
+  }
   if (t <= 65280u) {
     const double ia = pb_recip(65280u);
     if ((uint32_t)(int)((double)(255u * t) * ia) != (t >> 8)) atomicAdd(bad, 1u);
@@ -963,8 +970,12 @@ struct PbPairArgs {
 // the 24 weight registers cost more than the exposed loads), so only the short filters are instantiated that way.
 // ONE: tiles of at most four rows -- a wave has ONE destination row, and the code that requests and takes over the next row's weight vectors (24 register moves per row that the
 // compiler does not branch around) is not there
-template <int CH, int NPC, int NY, int ONE = 0>
+// OPQ (4-byte pixels; lgpu_pixbuf_scale with LGPU_INTERP_OPAQUE: the caller states that every source pixel has alpha 255): the window holds the colour BYTES as 16-bit
+// pairs (one v_perm per pair and channel, no alpha product), the alpha sums are not formed (three dot products per pair instead of four), and the library's
+// (uint8_t)((double)(255 T) * fl(1 / (255 * 65536))) is T >> 16 -- equal for every T < 2^24, checked on the device before the first such launch (pb_opaque_check)
+template <int CH, int NPC, int NY, int ONE = 0, int OPQ = 0>
 __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbFrames F) {
+  static_assert(!OPQ || CH == 4, "the all-opaque form is a form of the 4-byte kernel");
   PB_FRAME_ARGS(PbPairArgs);
   extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
@@ -997,8 +1008,13 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
       for (int qd = lane; qd < wq; qd += 64) {
         const pb_u4 q = row[qd];
         pb_u4 v0, v1;
+        if (OPQ) {
+          v0.x = __builtin_amdgcn_perm(q.y, q.x, 0x0C040C00u); v0.y = __builtin_amdgcn_perm(q.y, q.x, 0x0C050C01u); v0.z = __builtin_amdgcn_perm(q.y, q.x, 0x0C060C02u); v0.w = 0u;
+          v1.x = __builtin_amdgcn_perm(q.w, q.z, 0x0C040C00u); v1.y = __builtin_amdgcn_perm(q.w, q.z, 0x0C050C01u); v1.z = __builtin_amdgcn_perm(q.w, q.z, 0x0C060C02u); v1.w = 0u;
+        } else {
         v0.x = pb_premul_pair<0>(q.x, q.y); v0.y = pb_premul_pair<1>(q.x, q.y); v0.z = pb_premul_pair<2>(q.x, q.y); v0.w = __builtin_amdgcn_perm(q.y, q.x, 0x0C070C03u);
         v1.x = pb_premul_pair<0>(q.z, q.w); v1.y = pb_premul_pair<1>(q.z, q.w); v1.z = pb_premul_pair<2>(q.z, q.w); v1.w = __builtin_amdgcn_perm(q.w, q.z, 0x0C070C03u);
+        }
         wr[2 * qd] = v0; wr[2 * qd + 1] = v1;
       }
     }
@@ -1024,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
       for (int p = lane; p < A.wpairs; p += 64) {
         const uint32_t q0 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p, A.sw - 1)), q1 = pb_load_px<CH>(row, pb_clamp(wx0 + 2 * p + 1, A.sw - 1));
         pb_u4 v;
-        if (CH == 4) {
+        if (CH == 4 && !OPQ) {
           v.x = pb_premul_pair<0>(q0, q1); v.y = pb_premul_pair<1>(q0, q1); v.z = pb_premul_pair<2>(q0, q1); v.w = __builtin_amdgcn_perm(q1, q0, 0x0C070C03u);
         } else {
           v.x = __builtin_amdgcn_perm(q1, q0, 0x0C040C00u); v.y = __builtin_amdgcn_perm(q1, q0, 0x0C050C01u); v.z = __builtin_amdgcn_perm(q1, q0, 0x0C060C02u); v.w = 0u;
@@ -1037,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   const bool quads3 = CH == 3 && (((uintptr_t)A.dst | (uintptr_t)A.orow) & 3) == 0;
   // the accumulators of destination pixel (i, j) -> its bytes, stored
   auto emit = [&](int i, unsigned r, unsigned g, unsigned b, unsigned a) {
-    const uint32_t px = pb_finish_px<CH>(r, g, b, a, edge, A.rnd);
+    const uint32_t px = OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<CH>(r, g, b, a, edge, A.rnd);
     uint8_t *drow = A.dst + (size_t)i * A.orow;
     if (CH == 4) reinterpret_cast<uint32_t *>(drow)[j] = px;
     else if (quads3 && (j | 3) < A.dw) {
@@ -1073,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
         for (int k = 0; k < NPC; k++) {
           const pb_u4 dd = wp[ty * A.wpairs + k];
           r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
-          if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
+          if (CH == 4 && !OPQ) a = pb_dot2(dd.w, wq[k], a);
         }
         // long filters: a tap row's window reads stay next to its taps.  Left alone the compiler runs the alpha sums of all rows first and sinks the colour sums behind
         // the alpha test of pb_finish_px: every window vector stays live (4 x 6 x 4 = 96 registers) and the occupancy goes from 8 waves to 3
@@ -1107,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
         for (int k = 0; k < (NPC ? NPC : 1); k++) {
           const pb_u4 dd = wp[k];
           r = pb_dot2(dd.x, wq[k], r); g = pb_dot2(dd.y, wq[k], g); b = pb_dot2(dd.z, wq[k], b);
-          if (CH == 4) a = pb_dot2(dd.w, wq[k], a);
+          if (CH == 4 && !OPQ) a = pb_dot2(dd.w, wq[k], a);
         }
         continue;
       }
@@ -1118,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
         r = pb_dot2(d1.x, w.y, r); g = pb_dot2(d1.y, w.y, g); b = pb_dot2(d1.z, w.y, b);
         r = pb_dot2(d2.x, w.z, r); g = pb_dot2(d2.y, w.z, g); b = pb_dot2(d2.z, w.z, b);
         r = pb_dot2(d3.x, w.w, r); g = pb_dot2(d3.y, w.w, g); b = pb_dot2(d3.z, w.w, b);
-        if (CH == 4) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
+        if (CH == 4 && !OPQ) { a = pb_dot2(d0.w, w.x, a); a = pb_dot2(d1.w, w.y, a); a = pb_dot2(d2.w, w.z, a); a = pb_dot2(d3.w, w.w, a); }
       }
     }
     emit(i, r, g, b, a);
@@ -1745,7 +1761,7 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
   for (int i = 0; i < ntracks && !rc; i++) {
     uint8_t *inner = (uint8_t *)sa + (size_t)oy * cw * 4 + (size_t)ox * 4;
     if (cv) rc = lgpu_letterbox_bars((uint8_t *)sa, cw * 4, cw, ch, 4, black, ox, oy, pr->dw, pr->dh, st);
-    if (!rc) rc = pixbuf ? lgpu_pixbuf_scale(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp, st)
+    if (!rc) rc = pixbuf ? lgpu_pixbuf_scale(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp | (pr->interp & LGPU_INTERP_OPAQUE), st)
                          : lgpu_resize(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp, nullptr, st);
     const uint8_t *trk = (const uint8_t *)sa;
     if (!rc && pr->do_blur) { rc = lgpu_gauss5((const uint8_t *)sa, cw * 4, (uint8_t *)sb, cw * 4, cw, ch, 4, st); trk = (const uint8_t *)sb; }
@@ -1847,6 +1863,8 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
   const uint8_t *const src_d = srcs[0];
   uint8_t *const dst_d = dsts[0];
   LGPU_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (no alpha) or 4 (alpha)");
+  const bool opaque = (interp & LGPU_INTERP_OPAQUE) != 0;          // the caller's word that every source pixel has alpha 255: the pair kernel's lighter form (k_pb_pairs<.., OPQ>)
+  interp &= ~LGPU_INTERP_OPAQUE;
   LGPU_REQUIRE(interp == 0 || interp == 2 || interp == 3, "interp must be 0 (NEAREST), 2 (BILINEAR) or 3 (HYPER)");
   LGPU_REQUIRE(irow >= sw * channels && orow >= dw * channels, "rowstride smaller than a row");
   LGPU_REQUIRE(sw < 32768 && sh < 32768 && dw < 32768 && dh < 32768, "frame sides must stay below 32768 (16.16 positions)");
@@ -1973,22 +1991,22 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h), (unsigned)n);
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
-#define PB_PRE(CHN, NP_, NY_) { if (pa.tile_h <= 4) hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 1>), g, block, lds, st, pa, F); else hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 0>), g, block, lds, st, pa, F); }
-#define PB_PAIRS(CHN)                                                                                                     \
+#define PB_PRE(CHN, NP_, NY_, OQ) { if (pa.tile_h <= 4) hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 1, OQ>), g, block, lds, st, pa, F); else hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 0, OQ>), g, block, lds, st, pa, F); }
+#define PB_PAIRS(CHN, OQ)                                                                                                 \
       { const int ny = t->ty1 - t->ty0;                                                                                   \
         const bool pre = !tune_on(TUNE_PB_NO_PRE);                                                                          \
-        if (np == 2 && ny == 2) PB_PRE(CHN, 2, 2)                                                                            \
-        else if (np == 2 && ny == 3) PB_PRE(CHN, 2, 3)                                                                       \
-        else if (np == 3 && ny == 3) PB_PRE(CHN, 3, 3)                                                                       \
-        else if (pre && np == 3 && ny == 4) PB_PRE(CHN, 3, 4)                                                                \
-        else if (pre && np == 3 && ny == 5) PB_PRE(CHN, 3, 5)                                                                \
-        else if (pre && np == 4 && ny == 6) PB_PRE(CHN, 4, 6)                                                                \
-        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0>), g, block, lds, st, pa, F);                             \
-        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0>), g, block, lds, st, pa, F);                             \
-        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0>), g, block, lds, st, pa, F);                             \
-        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0>), g, block, lds, st, pa, F);                             \
-        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0>), g, block, lds, st, pa, F); }
-      if (channels == 4) { PB_PAIRS(4) } else { PB_PAIRS(3) }
+        if (np == 2 && ny == 2) PB_PRE(CHN, 2, 2, OQ)                                                                        \
+        else if (np == 2 && ny == 3) PB_PRE(CHN, 2, 3, OQ)                                                                   \
+        else if (np == 3 && ny == 3) PB_PRE(CHN, 3, 3, OQ)                                                                   \
+        else if (pre && np == 3 && ny == 4) PB_PRE(CHN, 3, 4, OQ)                                                            \
+        else if (pre && np == 3 && ny == 5) PB_PRE(CHN, 3, 5, OQ)                                                            \
+        else if (pre && np == 4 && ny == 6) PB_PRE(CHN, 4, 6, OQ)                                                            \
+        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
+        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
+        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
+        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
+        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0, 0, OQ>), g, block, lds, st, pa, F); }
+      if (channels == 4 && opaque) { if ((rc = pb_opaque_check())) return rc; PB_PAIRS(4, 1) } else if (channels == 4) { PB_PAIRS(4, 0) } else { PB_PAIRS(3, 0) }
 #undef PB_PAIRS
 #undef PB_PRE
       LGPU_CHECK_LAUNCH();

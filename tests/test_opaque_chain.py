@@ -58,3 +58,32 @@ def test_the_flag_changes_nothing_where_there_is_no_lighter_form(gpu):
             gpu.chain(prm, gpu.chain_tracks([dev(src)], [dev(l2)], [d_o]))
             res.append(host(d_o))
         assert (res[0] == res[1]).all()
+
+
+@pytest.mark.parametrize("interp", [3, 2])
+@pytest.mark.parametrize("geom", [(384, 216, 171, 96), (200, 120, 133, 80), (128, 72, 200, 112), (96, 54, 320, 180), (1920, 1080, 1280, 720), (300, 200, 100, 50), (131, 77, 64, 36)])
+def test_opaque_scaler_equals_the_general_kernels_and_the_oracle(gpu, orc, geom, interp):
+    """lgpu_pixbuf_scale[_batch] with interp | LGPU_INTERP_OPAQUE on frames whose alpha is 255 everywhere: the pair kernel's lighter form (and, where another kernel
+    serves the ratio, the flag ignored) -- the bytes of the general path and of the oracle's gdk-pixbuf restatement, alpha 255 out"""
+    sw, sh, dw, dh = geom
+    rng = np.random.default_rng(0x0FB0 + sw + dw + interp)
+    n = 3
+    srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(n)]
+    for s in srcs:
+        s[:, 3::4] = 255
+    d_s = [dev(a) for a in srcs]
+    outs = {}
+    for flag in (OPAQUE, 0):
+        d_o = [dev(np.full((dh + 1, dw * 4), 0xA5, np.uint8)) for _ in range(n)]
+        gpu.pixbuf_scale_batch(d_s, d_o, sw, sh, dw, dh, channels=4, interp=interp | flag)
+        one = dev(np.full((dh + 1, dw * 4), 0xA5, np.uint8))
+        gpu.pixbuf_scale(d_s[1], one, sw, sh, dw, dh, channels=4, interp=interp | flag)
+        outs[flag] = [host(t) for t in d_o]
+        assert (host(one) == outs[flag][1]).all()
+    for i in range(n):
+        assert (outs[OPAQUE][i] == outs[0][i]).all(), i
+        assert (outs[OPAQUE][i][dh] == 0xA5).all()
+    if sw <= 400:
+        want = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_pixbuf_scale(P(srcs[0]), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, interp) == 0
+        assert (outs[OPAQUE][0][:dh] == want).all()

@@ -202,6 +202,8 @@ def case(op):
         raise SystemExit("unknown batch form " + op)
     if op.startswith("pb") and op[2:op.index(":")].isdigit():      # pbN:SWxSH:DWxDH:interp -- N frames of one geometry per launch (lgpu_pixbuf_scale_batch)
         head, a_, b_, it = op.split(":")
+        opq = it.endswith("o")          # pbN:...:3o -- sources whose alpha is 255 everywhere, interp | LGPU_INTERP_OPAQUE
+        it = str(int(it.rstrip("o")) | (0x200 if opq else 0))
         n = int(head[2:])
         sw, sh = (int(v) for v in a_.split("x"))
         dw, dh = (int(v) for v in b_.split("x"))
@@ -211,12 +213,21 @@ def case(op):
             nb += nb % 2
         sets = [([torch.randint(0, 256, (sh, sw * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)],
                  [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(n)]) for _ in range(nb)]
+        if opq:
+            for st_ in sets:
+                for t_ in st_[0]:
+                    t_[:, 3::4] = 255
         return (lambda i: ops.pixbuf_scale_batch(sets[i % nb][0], sets[i % nb][1], sw, sh, dw, dh, channels=4, interp=int(it))), n * (sw * sh * 4 + dw * dh * 4)
     if op.startswith("pb:"):           # pb:SWxSH:DWxDH:interp  -- one gdk-pixbuf ratio
         _, a_, b_, it = op.split(":")
+        opq = it.endswith("o")
+        it = str(int(it.rstrip("o")) | (0x200 if opq else 0))
         sw, sh = (int(v) for v in a_.split("x"))
         dw, dh = (int(v) for v in b_.split("x"))
         src, dst = rnd(sh, sw * 4), rnd(dh, dw * 4)
+        if opq:
+            for t_ in src:
+                t_[:, 3::4] = 255
         return (lambda i: ops.pixbuf_scale(src[i % NB], dst[i % NB], sw, sh, dw, dh, channels=4, interp=int(it))), sw * sh * 4 + dw * dh * 4
     raise SystemExit("unknown op " + op)
 
