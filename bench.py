@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--resize-backend", choices=["polyphase", "pixbuf"], default="pixbuf",
                     help="arithmetic of the resize stage: the repo's polyphase spec in the swscale body's place (bicubic; parity unpinned, libswscale is not in the "
                          "image) or the reference's gdk-pixbuf body (GDK_INTERP_HYPER, alpha-weighted; bit-exact to gdk-pixbuf 2.42.8)")
+    ap.add_argument("--no-seam", action="store_true", help="skip the seam_chain leg (a profiled run then holds the launches behind `value` only under the headline kernel's name)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce / print path only, on the gloo backend with no GPU work (tests/test_dist_cpu.py runs this on a CPU box)")
     args = ap.parse_args()
@@ -355,7 +356,7 @@ def main():
     # convert_layer_palette -> resize_layer -> "chroma blend" process_func -> gamma_convert_layer by the reference names (liblivesgpu_dropin.so + livesgpu_fx.so),
     # lives_gpu_layers_flush once per tick: the calls are recorded on the planes and become ONE lgpu_chain launch (tools/seam_host.c; include/lives_gpu_layer.h)
     seam = None
-    if world == 1 and not args.blur and args.resize_backend == "pixbuf" and not args.dry_run:
+    if world == 1 and not args.blur and args.resize_backend == "pixbuf" and not args.dry_run and not args.no_seam:
         try:
             seam = seam_chain_leg(keep[0][0], keep[0][1], ops, fps, T)
         except Exception as e:      # noqa: BLE001 -- a second measurement, never fatal for the line
@@ -526,7 +527,7 @@ def pixbuf_kernel_name(args):
     is the default (round 4); the last argument is SWAP (BGRA -> RGBA)"""
     from lives_amd.lib import load
     aligned = (not args.blur) and load().lgpu_tuning_get(b"PBH_ALIGNED") != 0        # the default since round 4; LGPU_PBH_ALIGNED=0 keeps the feeder-lane strips
-    return "lgpu::k_pb_half<1, 1, %d, %d, 1>" % (args.blur, 1 if aligned else 0)
+    return "lgpu::k_pb_half<1, 1, %d, %d, 1, 0>" % (args.blur, 1 if aligned else 0)          # <CHAIN, HYPER, BLUR, ALIGNED, SWAP, OPAQUE>
 
 
 def cpu_baseline(blur, pixbuf=True):

@@ -6,14 +6,14 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/final_r06; mkdir -p $O
 C=$(cat tools/_commit 2>/dev/null || echo unknown)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_first -o t -- python bench.py --no-cpu > $O/bench_line_inside_the_rocprofv3_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_first -o t -- python bench.py --no-cpu --no-seam > $O/bench_line_inside_the_rocprofv3_run.log 2>&1
 cp $O/trace_first/t_kernel_stats.csv $O/final_kernel_stats.csv
 python bench.py > $O/bench_default.json 2>$O/bench_default.err
 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep "^{" > $O/bench_driver_shape.json
 for a in "--tracks 1" "--tracks 8" "--blur 1" "--blur 1 --tracks 8" "--blur 1 --tracks 1"; do
   timeout 300 python bench.py --no-cpu $a 2>/dev/null | grep "^{" >> $O/final_bench.jsonl
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_blur -o t -- python bench.py --no-cpu --blur 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_blur -o t -- python bench.py --no-cpu --no-seam --blur 1 > /dev/null 2>&1
 cp $O/trace_blur/t_kernel_stats.csv $O/blur_kernel_stats.csv
 python tools/seam_profile.py 2>&1 | grep -v amdgpu.ids > $O/seam_host_profile.txt
 bash tools/ops_table_r06.sh > $O/ops_roofline.md 2>$O/ops_roofline.err

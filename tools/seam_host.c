@@ -112,10 +112,14 @@ static int track_step(int t) {
 
 /* Pool threads SLEEP between ticks (futex), as LiVES' do (src/threading.c): a host that spins seventeen threads at 100 % starves itself wherever the process has a
    CPU quota -- measured on the pool's boxes: every seam call 50-400 x slower, tools/seam_profile.py -- and a render host has other work for its cores anyway.
-   A short spin first: the next tick usually follows within microseconds. */
+   No spin first (g_spin below). */
 static long futex(atomic_int *addr, int op, int val) { return syscall(SYS_futex, addr, op, val, NULL, NULL, 0); }
+/* SEAM_SPIN: pause iterations before a waiter parks.  0 = park at once, the default: measured on the pool's boxes (16 CPUs by quota, 17 threads here plus the
+   interpreter's) 0 -> 101-107 k frames/s, 200 -> 87-104 k, 2000 -> 65 k, 10000 -> 72-82 k, 50000 -> 61-66 k (profiles/r06/seam_spin_sweep.txt): every waiter that
+   spins is a runnable thread that can push the holder of the library's table lock off its CPU */
+static int g_spin = 0;
 static void wait_change(atomic_int *addr, int seen) {
-  for (int i = 0; i < 200; i++) { if (atomic_load_explicit(addr, memory_order_acquire) != seen) return; __builtin_ia32_pause(); }
+  for (int i = 0; i < g_spin; i++) { if (atomic_load_explicit(addr, memory_order_acquire) != seen) return; __builtin_ia32_pause(); }
   while (atomic_load_explicit(addr, memory_order_acquire) == seen) futex(addr, FUTEX_WAIT_PRIVATE, seen);
 }
 static void *worker(void *arg) {
@@ -144,6 +148,7 @@ static weed_plant_t *find_filter(const char *name) {
 
 /* bind the layer seam to this host's plants, load the plugin through weed_setup(weed_bootstrap) as load_weed_plugin does (src/effects-weed.c:4468-4568) */
 int seam_host_init(const char *fx_so_path) {
+  if (getenv("SEAM_SPIN")) g_spin = atoi(getenv("SEAM_SPIN"));
   lives_gpu_weed_api api = {mw_leaf_get, mw_leaf_set, mw_leaf_num_elements, mw_leaf_delete, pix_alloc, pix_free};
   if (lives_gpu_bind_weed(&api) != 0) return -1;          /* every time: a test process may have bound another weed host in between */
   if (g_pinfo) return 0;
