@@ -175,13 +175,19 @@ struct SpinLock {
   }
   void unlock() { held.store(false, std::memory_order_release); }
 };
-SpinLock g_res_mu;                                // guards g_res, g_pool and the Dev records in them
-std::unordered_map<const void *, Dev> g_res;      // resident planes by HOST plane pointer
+// Resident planes by HOST plane pointer, in 64 SHARDS with a lock each (round 6): sixteen host threads, one per track, each enter the table ~15 times per plan step
+// of their track -- behind ONE lock a recorded seam call cost 6-30 us instead of 0.4 (tools/seam_profile.py); the tracks' planes are different allocations and
+// land in different shards.  No function holds two shard locks at once.  The buffer pool has a lock of its own.
+struct alignas(128) ResShard { SpinLock mu; std::unordered_map<const void *, Dev> m; };
+constexpr int kResShards = 64;
+ResShard g_shards[kResShards];
+ResShard &shard_of(const void *h) { const uintptr_t a = (uintptr_t)h; return g_shards[((a >> 12) ^ (a >> 18) ^ (a >> 25)) & (kResShards - 1)]; }
+SpinLock g_pool_mu;                               // guards g_pool
 std::atomic<unsigned long long> g_h2d{0}, g_d2h{0};   // PCIe byte counters (tests check the residency contract with them)
 thread_local bool t_pinned = false;             // the call in progress works on a pinned layer
 // t_gpu.event: this thread's hand-over event (re-recorded at every hand-over; a wait holds the record it saw)
 
-// No HIP call is made under g_res_mu: the functions below copy what they need out of the tables and do the stream work afterwards.
+// No HIP call is made under a table lock: the functions below copy what they need out of the tables and do the stream work afterwards.
 // The calling thread's stream waits for everything enqueued so far on the stream of the buffer's last use, if that is another stream.
 void follow(void *other) {                        // other: a stream (nullptr = the null stream) or kIdle
   if (other == S() || other == kIdle) return;
@@ -194,7 +200,7 @@ void await(const Dev &b, bool write = true) {
   follow(b.stream);
   if (write) for (int i = 0; i < b.nr; i++) follow(b.rs[i]);
 }
-// (g_res_mu held) the calling thread's stream has enqueued a read / a write of the buffer
+// (the plane's shard lock held) the calling thread's stream has enqueued a read / a write of the buffer
 void note_use(Dev &e, bool write) {
   void *s = S();
   if (write) { e.stream = s; e.nr = 0; return; }
@@ -227,7 +233,7 @@ bool pool_take(size_t n, Dev *out) {
   const size_t cls = pool_class(n + 64);
   bool hit = false;
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
+    std::lock_guard<SpinLock> lk(g_pool_mu);
     auto it = g_pool.find(cls);
     if (it != g_pool.end() && !it->second.empty()) {
       std::vector<Dev> &v = it->second;
@@ -254,7 +260,7 @@ void pool_give(Dev b) {
   if (b.lazy) { lazy_discard(b.lazy); return; }       // a pending program nobody will ever look at: its source frame goes back, nothing runs
   if (!b.d || b.external) return;
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
+    std::lock_guard<SpinLock> lk(g_pool_mu);
     if (g_pool_bytes + b.bytes <= kPoolMaxBytes) {
       g_pool[b.bytes].push_back(b);
       g_pool_bytes += b.bytes;
@@ -270,8 +276,9 @@ void res_put(const void *h, Dev b) {
   b.stream = S(); b.nr = 0;
   lazy_run_readers_of(h);
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    Dev &e = g_res[h];
+    ResShard &sh = shard_of(h);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    Dev &e = sh.m[h];
     old = e;
     e = b;
   }
@@ -282,11 +289,12 @@ void res_drop(const void *h) {
   Dev b;
   lazy_run_readers_of(h);
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    auto it = g_res.find(h);
-    if (it == g_res.end()) return;
+    ResShard &sh = shard_of(h);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(h);
+    if (it == sh.m.end()) return;
     b = it->second;
-    g_res.erase(it);
+    sh.m.erase(it);
   }
   pool_give(b);
 }
@@ -296,17 +304,17 @@ void res_drop_range(const void *base, size_t bytes) {
   std::vector<Dev> gone;
   {
     std::vector<const void *> read;
-    {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      for (auto &kv : g_res) if ((uintptr_t)kv.first >= (uintptr_t)base && (uintptr_t)kv.first < (uintptr_t)base + bytes && kv.second.lazy_readers > 0) read.push_back(kv.first);
+    for (ResShard &sh : g_shards) {
+      std::lock_guard<SpinLock> lk(sh.mu);
+      for (auto &kv : sh.m) if ((uintptr_t)kv.first >= (uintptr_t)base && (uintptr_t)kv.first < (uintptr_t)base + bytes && kv.second.lazy_readers > 0) read.push_back(kv.first);
     }
     for (const void *h : read) lazy_run_readers_of(h);
   }
-  {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    for (auto it = g_res.begin(); it != g_res.end();) {
+  for (ResShard &sh : g_shards) {
+    std::lock_guard<SpinLock> lk(sh.mu);
+    for (auto it = sh.m.begin(); it != sh.m.end();) {
       const uintptr_t h = (uintptr_t)it->first;
-      if (h >= (uintptr_t)base && h < (uintptr_t)base + bytes) { gone.push_back(it->second); it = g_res.erase(it); } else ++it;
+      if (h >= (uintptr_t)base && h < (uintptr_t)base + bytes) { gone.push_back(it->second); it = sh.m.erase(it); } else ++it;
     }
   }
   for (auto &b : gone) pool_give(b);
@@ -452,9 +460,10 @@ uint8_t *acquire(const void *h, size_t n, bool write) {
   Dev b;
   for (int pass = 0;; pass++) {
     {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      auto it = g_res.find(h);
-      if (it == g_res.end() || it->second.bytes < n) return nullptr;
+      ResShard &sh = shard_of(h);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto it = sh.m.find(h);
+      if (it == sh.m.end() || it->second.bytes < n) return nullptr;
       b = it->second;
     }
     if (!b.lazy && !(write && b.lazy_readers > 0)) break;
@@ -470,9 +479,10 @@ uint8_t *resident(const void *h, size_t n, bool write) {
   return acquire(h, n, write);
 }
 void touch_done(const void *h, bool write) {
-  std::lock_guard<SpinLock> lk(g_res_mu);
-  auto it = g_res.find(h);
-  if (it != g_res.end()) note_use(it->second, write);
+  ResShard &sh = shard_of(h);
+  std::lock_guard<SpinLock> lk(sh.mu);
+  auto it = sh.m.find(h);
+  if (it != sh.m.end()) note_use(it->second, write);
 }
 
 // One seam call's device-side work, enqueued on the calling thread's stream.  in(): the current bytes of an existing plane.  out(): a plane
@@ -589,14 +599,15 @@ struct Lazy {
 };
 std::atomic<int> g_deferred{1};
 std::atomic<unsigned long long> g_lz_recorded{0}, g_lz_chain_launches{0}, g_lz_chain_tracks{0}, g_lz_staged{0};      // lives_gpu_deferred_stats
-std::mutex g_lazy_mu;               // one program (group) runs at a time; never taken with g_res_mu held
+std::mutex g_lazy_mu;               // one program (group) runs at a time; never taken with a table lock held
 bool lazy_pal(int pal) { return pal == WEED_PALETTE_RGBA32 || pal == WEED_PALETTE_BGRA32; }
 
 void lazy_unread(Lazy *z) {          // (no lock held) the program no longer reads its layer 2
   if (!z->blend || !z->l2h) return;
-  std::lock_guard<SpinLock> lk(g_res_mu);
-  auto it = g_res.find(z->l2h);
-  if (it != g_res.end() && it->second.lazy_readers > 0) it->second.lazy_readers--;
+  ResShard &sh = shard_of(z->l2h);
+  std::lock_guard<SpinLock> lk(sh.mu);
+  auto it = sh.m.find(z->l2h);
+  if (it != sh.m.end() && it->second.lazy_readers > 0) it->second.lazy_readers--;
   z->l2h = nullptr;
 }
 void lazy_discard(Lazy *z) {
@@ -684,20 +695,23 @@ int lazy_run_group(Lazy *const *zs, const void *const *hs, int n) {
   for (int i = 0; i < n; i++) {
     Lazy *z = zs[i];
     {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      auto it = g_res.find(hs[i]);
-      if (it != g_res.end() && it->second.lazy == z) {
+      ResShard &sh = shard_of(hs[i]);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto it = sh.m.find(hs[i]);
+      if (it != sh.m.end() && it->second.lazy == z) {
         Dev &e = it->second;
         const int readers = e.lazy_readers;
         e = outs[(size_t)i];
         e.stream = S(); e.nr = 0; e.lazy = nullptr; e.lazy_readers = readers;
         outs[(size_t)i] = Dev();
       }
-      if (z->blend && z->l2h) {
-        auto l2 = g_res.find(z->l2h);
-        if (l2 != g_res.end()) { note_use(l2->second, false); if (l2->second.lazy_readers > 0) l2->second.lazy_readers--; }
-        z->l2h = nullptr;
-      }
+    }
+    if (z->blend && z->l2h) {
+      ResShard &sh = shard_of(z->l2h);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto l2 = sh.m.find(z->l2h);
+      if (l2 != sh.m.end()) { note_use(l2->second, false); if (l2->second.lazy_readers > 0) l2->second.lazy_readers--; }
+      z->l2h = nullptr;
     }
     if (outs[(size_t)i].d) { outs[(size_t)i].stream = S(); pool_give(outs[(size_t)i]); }          // (the plane vanished meanwhile: cannot happen under the host's own ordering)
     Dev src = z->src;
@@ -712,9 +726,10 @@ bool lazy_materialise(const void *h) {
   std::lock_guard<std::mutex> run(g_lazy_mu);
   Lazy *z = nullptr;
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    auto it = g_res.find(h);
-    if (it == g_res.end()) return false;
+    ResShard &sh = shard_of(h);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(h);
+    if (it == sh.m.end()) return false;
     z = it->second.lazy;
   }
   if (!z) return true;                      // somebody else ran it meanwhile
@@ -725,11 +740,22 @@ void lazy_run_readers_of(const void *h) {
   for (int guard = 0; guard < 64; guard++) {
     const void *reader = nullptr;
     {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      auto it = g_res.find(h);
-      if (it == g_res.end() || it->second.lazy_readers <= 0) return;
-      for (auto &kv : g_res) if (kv.second.lazy && kv.second.lazy->blend && kv.second.lazy->l2h == h) { reader = kv.first; break; }
-      if (!reader) { it->second.lazy_readers = 0; return; }
+      ResShard &sh = shard_of(h);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto it = sh.m.find(h);
+      if (it == sh.m.end() || it->second.lazy_readers <= 0) return;
+    }
+    for (ResShard &sh : g_shards) {                  // (rare: a plane that pending programs read is about to change) look for one of them, shard by shard
+      std::lock_guard<SpinLock> lk(sh.mu);
+      for (auto &kv : sh.m) if (kv.second.lazy && kv.second.lazy->blend && kv.second.lazy->l2h == h) { reader = kv.first; break; }
+      if (reader) break;
+    }
+    if (!reader) {
+      ResShard &sh = shard_of(h);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto it = sh.m.find(h);
+      if (it != sh.m.end()) it->second.lazy_readers = 0;
+      return;
     }
     if (!lazy_materialise(reader)) return;
   }
@@ -743,12 +769,13 @@ Lazy *lazy_detach(const Layer &l, int stage) {
     Dev e;
     bool need_run = false;
     {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      auto it = g_res.find(l.pd[0]);
-      if (it == g_res.end() || it->second.bytes < n) return nullptr;
+      ResShard &sh = shard_of(l.pd[0]);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto it = sh.m.find(l.pd[0]);
+      if (it == sh.m.end() || it->second.bytes < n) return nullptr;
       if (it->second.lazy_readers > 0) return nullptr;                     // someone's layer 2: it keeps its pixels
       if (it->second.lazy && it->second.lazy->stage >= stage) need_run = true;
-      else { e = it->second; g_res.erase(it); }
+      else { e = it->second; sh.m.erase(it); }
     }
     if (need_run) { if (!lazy_materialise(l.pd[0])) return nullptr; continue; }    // the recorded program cannot take this stage: it runs, a new one starts from its result
     if (e.lazy) return e.lazy;
@@ -760,9 +787,10 @@ Lazy *lazy_detach(const Layer &l, int stage) {
   return nullptr;
 }
 bool plane_is_lazy(const void *h) {
-  std::lock_guard<SpinLock> lk(g_res_mu);
-  auto it = g_res.find(h);
-  return it != g_res.end() && it->second.lazy != nullptr;
+  ResShard &sh = shard_of(h);
+  std::lock_guard<SpinLock> lk(sh.mu);
+  auto it = sh.m.find(h);
+  return it != sh.m.end() && it->second.lazy != nullptr;
 }
 void lazy_attach(const void *h, Lazy *z) {
   Dev e;
@@ -770,8 +798,9 @@ void lazy_attach(const void *h, Lazy *z) {
   e.lazy = z; e.bytes = (size_t)z->rs * z->h; e.stream = kIdle;
   Dev old;
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    Dev &slot = g_res[h];
+    ResShard &sh = shard_of(h);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    Dev &slot = sh.m[h];
     old = slot;
     slot = e;
   }
@@ -782,8 +811,9 @@ void lazy_reattach(const void *h, Lazy *z) {
   if (z->stage == LZ_NONE) {              // it was an ordinary resident plane
     Dev e = z->src;
     delete z;
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    g_res[h] = e;
+    ResShard &sh = shard_of(h);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    sh.m[h] = e;
     return;
   }
   lazy_attach(h, z);
@@ -1821,10 +1851,11 @@ static size_t plane_bytes(const Layer &l, int p) {
 }
 // this thread's stream has just been synchronised: planes whose last use was enqueued on it have no work pending, whoever touches them next need not wait
 static void settle(const Layer &l) {
-  std::lock_guard<SpinLock> lk(g_res_mu);
   for (int p = 0; p < l.nplanes; p++) {
-    auto it = g_res.find(l.pd[p]);
-    if (it == g_res.end()) continue;
+    ResShard &sh = shard_of(l.pd[p]);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(l.pd[p]);
+    if (it == sh.m.end()) continue;
     Dev &e = it->second;
     if (e.stream == S()) e.stream = kIdle;
     int k = 0;
@@ -1869,8 +1900,9 @@ int lives_gpu_layer_pin_device(lives_gpu_layer_t *layer, const void *const *plan
     lazy_run_readers_of(l.pd[p]);
     Dev old;
     {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      Dev &slot = g_res[l.pd[p]];
+      ResShard &sh = shard_of(l.pd[p]);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      Dev &slot = sh.m[l.pd[p]];
       old = slot;
       slot = b;
     }
@@ -1900,9 +1932,11 @@ int lives_gpu_layers_flush(lives_gpu_layer_t *const *layers, int nlayers) {
   }
   std::lock_guard<std::mutex> run(g_lazy_mu);
   std::vector<Lazy *> zs(hs.size(), nullptr);
-  {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    for (size_t i = 0; i < hs.size(); i++) { auto it = g_res.find(hs[i]); if (it != g_res.end()) zs[i] = it->second.lazy; }
+  for (size_t i = 0; i < hs.size(); i++) {
+    ResShard &sh = shard_of(hs[i]);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(hs[i]);
+    if (it != sh.m.end()) zs[i] = it->second.lazy;
   }
   int rc = LGPU_OK;
   std::vector<char> done(hs.size(), 0);
@@ -1927,24 +1961,46 @@ int lives_gpu_layers_flush(lives_gpu_layer_t *const *layers, int nlayers) {
 int lives_gpu_deferred_blend_chroma(const void *dst_host, int orow, int width, int height, int palette, const void *layer2_host, int irow2, int bf) {
   if (!g_deferred.load(std::memory_order_relaxed) || !dst_host || !layer2_host || dst_host == layer2_host || !lazy_pal(palette) || (irow2 & 3) || !ready()) return 0;
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    auto it = g_res.find(dst_host);
-    if (it == g_res.end() || !it->second.lazy || it->second.lazy_readers > 0) return 0;
+    ResShard &sh = shard_of(dst_host);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(dst_host);
+    if (it == sh.m.end() || !it->second.lazy || it->second.lazy_readers > 0) return 0;
     const Lazy *z = it->second.lazy;
     if (z->stage >= LZ_BLEND || z->w != width || z->h != height || z->rs != orow) return 0;
   }
   const size_t n2 = (size_t)irow2 * height;
   uint8_t *l2d = acquire(layer2_host, n2, false);          // layer 2 itself may be pending: it runs; this thread's stream is behind its writer
   if (!l2d) return 0;
-  std::lock_guard<SpinLock> lk(g_res_mu);
-  auto it = g_res.find(dst_host);
-  auto l2 = g_res.find(layer2_host);
-  if (it == g_res.end() || !it->second.lazy || l2 == g_res.end() || !l2->second.d) return 0;
-  Lazy *z = it->second.lazy;
-  if (z->stage >= LZ_BLEND) return 0;
-  g_lz_recorded++;
-  z->blend = true; z->bf = bf & 0xFF; z->l2h = layer2_host; z->l2 = l2->second; z->l2rs = irow2; z->stage = LZ_BLEND;
-  l2->second.lazy_readers++;
+  // layer 2 first (its own shard): it becomes a plane a pending program reads; then the program takes the stage -- or, should the plane have changed hands in
+  // between (it cannot under the host's own ordering), layer 2 is let go again
+  Dev l2copy;
+  {
+    ResShard &sh = shard_of(layer2_host);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto l2 = sh.m.find(layer2_host);
+    if (l2 == sh.m.end() || !l2->second.d) return 0;
+    l2copy = l2->second;
+    l2->second.lazy_readers++;
+  }
+  bool taken = false;
+  {
+    ResShard &sh = shard_of(dst_host);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(dst_host);
+    if (it != sh.m.end() && it->second.lazy && it->second.lazy->stage < LZ_BLEND) {
+      Lazy *z = it->second.lazy;
+      g_lz_recorded++;
+      z->blend = true; z->bf = bf & 0xFF; z->l2h = layer2_host; z->l2 = l2copy; z->l2rs = irow2; z->stage = LZ_BLEND;
+      taken = true;
+    }
+  }
+  if (!taken) {
+    ResShard &sh = shard_of(layer2_host);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto l2 = sh.m.find(layer2_host);
+    if (l2 != sh.m.end() && l2->second.lazy_readers > 0) l2->second.lazy_readers--;
+    return 0;
+  }
   return 1;
 }
 int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
@@ -1956,9 +2012,10 @@ int lives_gpu_layer_sync(lives_gpu_layer_t *layer) {
     Dev b;
     if (plane_is_lazy(l.pd[p]) && !lazy_materialise(l.pd[p])) return LGPU_E_HIP;        // a pending program runs now
     {
-      std::lock_guard<SpinLock> lk(g_res_mu);
-      auto it = g_res.find(l.pd[p]);
-      if (it != g_res.end() && it->second.bytes >= n) { b = it->second; note_use(it->second, false); }
+      ResShard &sh = shard_of(l.pd[p]);
+      std::lock_guard<SpinLock> lk(sh.mu);
+      auto it = sh.m.find(l.pd[p]);
+      if (it != sh.m.end() && it->second.bytes >= n) { b = it->second; note_use(it->second, false); }
     }
     if (!b.d) continue;                                 // this plane's host bytes are current
     await(b, false);                                    // behind the work of whichever thread wrote it last
@@ -2021,9 +2078,10 @@ void *lives_gpu_resident_lookup(const void *host_plane, size_t min_bytes) {
   if (plane_is_lazy(host_plane) && !lazy_materialise(host_plane)) return nullptr;
   lazy_run_readers_of(host_plane);                    // the caller may write the plane
   {
-    std::lock_guard<SpinLock> lk(g_res_mu);
-    auto it = g_res.find(host_plane);
-    if (it == g_res.end() || it->second.bytes < min_bytes) return nullptr;
+    ResShard &sh = shard_of(host_plane);
+    std::lock_guard<SpinLock> lk(sh.mu);
+    auto it = sh.m.find(host_plane);
+    if (it == sh.m.end() || it->second.bytes < min_bytes) return nullptr;
     b = it->second;
     it->second.stream = nullptr; it->second.nr = 0;
   }
