@@ -962,6 +962,9 @@ struct PbPairArgs {
   const uint32_t *pairs;               // device: [16 y phases][ny_eff][16 x phases][2 parities][4 nq]
   unsigned rnd;
   int tile_h, wpairs, win_h;
+  int gx, gy, per_xcd;                 // tiles per row / per column; per_xcd > 0: the grid is ONE-dimensional, 8 * per_xcd workgroups, and workgroup b works on tile
+                                       // (b & 7) * per_xcd + (b >> 3) of the row-major tile sequence -- every XCD (workgroups reach them round robin) a contiguous run of
+                                       // tiles, so that the window rows two vertically neighbouring tiles share are found in that XCD's L2
 };
 
 // NPC: pairs per tap row when there are at most four (compile time: no work on the padding of the weight row), 0: any count, four at a time.
@@ -979,7 +982,13 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   PB_FRAME_ARGS(PbPairArgs);
   extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
-  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * A.tile_h;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (A.per_xcd) {
+    const int t = (int)(blockIdx.x & 7u) * A.per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= A.gx * A.gy) return;                       // padding of the last XCD's run (before any barrier: the whole workgroup leaves)
+    by = t / A.gx; bx = t - by * A.gx;
+  }
+  const int j0 = bx * 64, i0 = by * A.tile_h;
   const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~3;          // the window starts on a source pixel that is a multiple of 4: aligned pairs, 16-byte loads
   const int ys0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;
   const int j = j0 + lane;
@@ -1988,7 +1997,13 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       if ((size_t)pa.wpairs * wh * 16 <= lds_cap) { pa.tile_h = th; pa.win_h = wh; break; }
     }
     if (pa.tile_h) {
-      const dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h), (unsigned)n);
+      dim3 g(cdiv((unsigned)dw, 64), cdiv((unsigned)dh, (unsigned)pa.tile_h), (unsigned)n);
+      pa.gx = (int)g.x; pa.gy = (int)g.y; pa.per_xcd = 0;
+      // Tile order.  Counters on 4K -> 1706x960 (profiles/r06/fetch_size_calibration.md: FETCH_SIZE reports HALF of what is read for this kernel's 640-byte window
+      // segments exactly as for a full-wave stream -- 128-byte requests) put its L2 -> fabric reads at 2.0 x the source: with the tiles of a row dealt round robin to
+      // the XCDs, the window rows that vertically neighbouring tiles share (5 of 14) are fetched by another XCD's L2 again.  LGPU_PB_TILE_ORDER=1: every XCD a
+      // contiguous run of the row-major tile sequence.
+      if (tune(TUNE_PB_TILE_ORDER) != 0 && g.x * g.y >= 64) { pa.per_xcd = (int)cdiv(g.x * g.y, 8u); g = dim3(8u * (unsigned)pa.per_xcd, 1, (unsigned)n); }
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
 #define PB_PRE(CHN, NP_, NY_, OQ) { if (pa.tile_h <= 4) hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 1, OQ>), g, block, lds, st, pa, F); else hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 0, OQ>), g, block, lds, st, pa, F); }
