@@ -417,6 +417,10 @@ int lgpu_chain(const lgpu_chain_params *params, const lgpu_chain_track *tracks, 
    canvas-sized (irow2 / orow are their strides).  One launch on the pixbuf arithmetic for the exact aligned 2:1 case with an even offs_x; staged otherwise. */
 typedef struct { int nwidth, nheight, offs_x, offs_y; } lgpu_canvas;
 int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream);
+/* lgpu_chain / lgpu_chain_canvas (canvas may be NULL) on the gdk-pixbuf arithmetic with a blend amount PER TRACK (amounts[ntracks], 0..255; params->bf and
+   params->param_block_d are not used): the tracks of a tick share geometry and gamma table, not necessarily their transition amount -- still one launch.  What
+   lives_gpu_layers_flush() emits for the recorded plan steps of a tick (lives_gpu_layer.h). */
+int lgpu_chain_amounts(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, const uint8_t *amounts, void *stream);
 
 /* ---- timing helper: HIP events on `stream` around `reps` launches of the last-configured chain; used by
    bench.py to measure the kernel's average launch duration on the stream it is launched on. */

@@ -616,6 +616,20 @@ weed_error_t livesgpu_fx_process_batch(weed_plant_t **insts, int n, weed_timecod
   }
   psize = psize_of(pal);
   if (!psize || w <= 0 || h <= 0) return WEED_ERROR_FILTER_INVALID;
+  if (bc.op == LGPU_FX_BLEND_CHROMA) {
+    /* in-place chroma blends on planes that are still pending programs of the layer seam join those programs (as in fx_run); what cannot join runs below / instance by instance */
+    weed_plant_t *rest[LGPU_FX_MAX_FRAMES];
+    int nrec = 0, nrest = 0;
+    for (i = 0; i < n; i++) {
+      weed_plant_t *oc = (weed_plant_t *)g_ptr(insts[i], WEED_LEAF_OUT_CHANNELS, 0);
+      const void *od = g_ptr(oc, WEED_LEAF_PIXEL_DATA, 0), *i0 = g_ptr((weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_CHANNELS, 0), WEED_LEAF_PIXEL_DATA, 0),
+                 *i1 = g_ptr((weed_plant_t *)g_ptr(insts[i], WEED_LEAF_IN_CHANNELS, 1), WEED_LEAF_PIXEL_DATA, 0);
+      if (od == i0 && lives_gpu_deferred_blend_chroma(od, orow, w, h, pal, i1, irow[1], (int)amounts[i])) nrec++;
+      else rest[nrest++] = insts[i];
+    }
+    if (nrec == n) return WEED_SUCCESS;
+    if (nrec) return batch_fallback(rest, nrest, tc);
+  }
   if (bc.op != LGPU_FX_TRANSITION && (pal == WEED_PALETTE_ARGB32 || (bc.op == LGPU_FX_BLEND_MULTI && psize != 3))) return batch_fallback(insts, n, tc);   /* as k_simple / k_multi serve them */
   if (lgpu_init(0) != LGPU_OK) { fprintf(stderr, "livesgpu_fx: %s\n", lgpu_last_error()); return WEED_ERROR_PLUGIN_INVALID; }
   memset(fr, 0, sizeof fr); memset(rel, 0, sizeof rel);

@@ -620,7 +620,7 @@ void lazy_discard(Lazy *z) {
 bool lazy_same_shape(const Lazy *a, const Lazy *b) {
   return a->sw == b->sw && a->sh == b->sh && a->srs == b->srs && a->swap == b->swap && a->scale == b->scale && a->dw == b->dw && a->dh == b->dh &&
          a->interp == b->interp && a->canvas == b->canvas && a->nw == b->nw && a->nh == b->nh && a->ox == b->ox && a->oy == b->oy && a->blend == b->blend &&
-         a->bf == b->bf && a->l2rs == b->l2rs && a->lut == b->lut && (!a->lut || !memcmp(a->lut8, b->lut8, 256)) && a->w == b->w && a->h == b->h && a->rs == b->rs;
+         a->l2rs == b->l2rs &&          /* (not the blend amount: every track of a launch has its own, lgpu_chain_amounts) */ a->lut == b->lut && (!a->lut || !memcmp(a->lut8, b->lut8, 256)) && a->w == b->w && a->h == b->h && a->rs == b->rs;
 }
 // one program, stage by stage through stream-ordered scratch frames, into out (the plane's rowstride)
 int lazy_run_staged(const Lazy *z, uint8_t *out) {
@@ -680,9 +680,10 @@ int lazy_run_group(Lazy *const *zs, const void *const *hs, int n) {
     if (z0->lut) memcpy(pr.lut8, z0->lut8, 256);
     std::vector<lgpu_chain_track> tr((size_t)n);
     for (int i = 0; i < n; i++) { tr[(size_t)i].src_d = (const uint8_t *)zs[i]->src.d; tr[(size_t)i].layer2_d = (const uint8_t *)zs[i]->l2.d; tr[(size_t)i].dst_d = (uint8_t *)outs[(size_t)i].d; }
-    int crc;
-    if (z0->canvas) { const lgpu_canvas cv = {z0->nw, z0->nh, z0->ox, z0->oy}; crc = lgpu_chain_canvas(&pr, &cv, tr.data(), n, S()); }
-    else crc = lgpu_chain(&pr, tr.data(), n, S());
+    std::vector<uint8_t> amounts((size_t)n);
+    for (int i = 0; i < n; i++) amounts[(size_t)i] = (uint8_t)zs[i]->bf;
+    const lgpu_canvas cv = {z0->nw, z0->nh, z0->ox, z0->oy};
+    const int crc = lgpu_chain_amounts(&pr, z0->canvas ? &cv : nullptr, tr.data(), n, amounts.data(), S());
     if (crc == LGPU_OK) { done = true; g_lz_chain_launches++; g_lz_chain_tracks += (unsigned long long)n; }
     else if (crc != LGPU_E_BADARG && crc != LGPU_E_UNSUPPORTED) rc = crc;          // a shape the fused kernel does not take runs stage by stage below
   }

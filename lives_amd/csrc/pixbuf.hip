@@ -217,11 +217,13 @@ struct PbHalfArgs {
   int bgroup;                    // order 2: neighbouring bands per XCD turn (PBH_GROUP)
   int row_major;                 // work order (PBH_ORDER): 0 bands fastest, 1 column groups fastest, 2 that with the bands dealt round robin to the XCDs
   int aligned;                   // host side: strips of 64 quads (k_pb_half<.., ALIGNED>)
+  int bf_tracks;                 // 1: the blend amount of track t is PbTracks.bf[t] (bf / bf_d unused)
 };
 struct PbTracks {
   const uint8_t *src[LGPU_CHAIN_MAX_TRACKS];
   const uint8_t *l2[LGPU_CHAIN_MAX_TRACKS];
   uint8_t *dst[LGPU_CHAIN_MAX_TRACKS];
+  uint8_t bf[LGPU_CHAIN_MAX_TRACKS];       // PbHalfArgs.bf_tracks: a blend amount per track (lgpu_chain_amounts: the tracks of a tick need not share one)
 };
 typedef unsigned short pb_us2 __attribute__((ext_vector_type(2)));
 typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
     if (track >= A.ntracks) return;                       // padding up to a multiple of 8
     uint32_t bf = A.bf;
     if (A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
+    if (A.bf_tracks) bf = T.bf[track];
     const uint32_t w_lo = bf | ((255u - bf) << 8);
     const int top = A.oy * A.cw, bottom = (A.ch - A.oy - A.dh) * A.cw, sw_ = A.cw - A.dw, total = top + bottom + A.dh * sw_;
 #pragma unroll
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const bool fastp = BLUR && y0 - 2 >= 1 && y0 + rows + 1 <= A.dh - 2;
   uint32_t bf = A.bf;
   if (CHAIN && A.bf_d) bf = (uint32_t)A.bf_d[0] & 0xFF;
+  if (CHAIN && A.bf_tracks) bf = T.bf[track];
   const uint32_t w_lo = bf | ((255u - bf) << 8);
 
   // descriptors: base pointers made provably uniform (readfirstlane of both halves), range = the whole frame
@@ -1672,7 +1676,7 @@ static unsigned pb_half_grid(const PbHalfArgs &a) { return a.row_major == 2 ? 8u
 
 // the fused chain on the pixbuf arithmetic (lgpu_chain with LGPU_INTERP_PIXBUF): convert -> gdk-pixbuf 2:1 scale -> chroma blend -> gamma LUT in one launch.
 // LGPU_E_UNSUPPORTED when the geometry is not the exact aligned 2:1 case (the caller then runs the stages one by one).
-int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st, const uint8_t *amounts = nullptr) {
   const int interp = pr->interp & 0xFF;
   if (interp != 2 && interp != 3) return LGPU_E_UNSUPPORTED;
   PbPin pin;
@@ -1693,6 +1697,7 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   if ((rc = get_kscale(&a.kscale))) return rc;
   a.sw = pr->sw; a.sh = pr->sh; a.irow = pr->irow; a.dw = pr->dw; a.dh = pr->dh; a.orow = pr->orow;
   a.swap_rb = pr->swap_rb ? 1 : 0; a.blend = 1; a.irow2 = pr->irow2; a.use_lut = pr->use_lut ? 1 : 0; a.bf = (uint32_t)pr->bf & 0xFF; a.bf_d = pr->param_block_d;
+  a.bf_tracks = amounts ? 1 : 0;
   a.nt_out = 1;
   // (non-temporal loads for a band's inner source rows were measured and dropped: a gain only on buffers the memory-side cache still holds, profiles/r04/nt_cold_ab.txt)
   // Work order (PBH_ORDER; profiles/r04/order_ab.txt, interleaved on cold buffers).  0: a column group's bands one after the other, an XCD owning a contiguous run (rounds 3 / 4);
@@ -1717,7 +1722,7 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   a.main_blocks = (int)pb_half_grid(a);
   a.bar_first = (a.bar_blocks * ntracks + 7) & ~7;
   PbTracks T;
-  for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; }
+  for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; T.bf[i] = amounts ? amounts[i] : 0; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
   const dim3 grid((unsigned)(a.main_blocks + a.bar_first));
   // Workgroups per CU (PBH_OCC): a launch of more than one generation runs FIVE workgroups per CU instead of the eight its registers allow -- unused dynamic LDS is what
@@ -1751,11 +1756,11 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
 // lgpu_chain / lgpu_chain_canvas.  One fused launch for the exact aligned 2:1 case on the pixbuf arithmetic (blur stage and letterbox canvas included); otherwise the
 // stages run one after the other through stream-ordered scratch frames: [bars] -> scale (into the canvas) -> [5x5 gaussian] -> [R <-> B] + chroma blend + gamma LUT.
 // The channel swap commutes with the scalers and the gaussian (all treat the three colour bytes alike), so it rides in the last kernel.
-int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st) {
+int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st, const uint8_t *amounts) {
   int rc;
   const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0;
   if (pixbuf && !(cv && pr->do_blur)) {
-    rc = pb_chain_half(pr, cv, tracks, ntracks, st);         // one launch
+    rc = pb_chain_half(pr, cv, tracks, ntracks, st, amounts);         // one launch
     if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: one-launch form rc %d (%s)\n", rc, rc ? lgpu_last_error() : "ok");
     if (rc != LGPU_E_UNSUPPORTED) return rc;
   }
@@ -1776,7 +1781,7 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
     if (!rc && pr->do_blur) { rc = lgpu_gauss5((const uint8_t *)sa, cw * 4, (uint8_t *)sb, cw * 4, cw, ch, 4, st); trk = (const uint8_t *)sb; }
     if (rc) break;
     hipLaunchKernelGGL(k_pb_epilogue, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4)), dim3(256), 0, st, trk, cw * 4, tracks[i].layer2_d, pr->irow2,
-                       tracks[i].dst_d, pr->orow, cw, ch, pr->swap_rb ? 1 : 0, (uint32_t)pr->bf & 0xFF, pr->param_block_d, pr->use_lut ? 1 : 0, l);
+                       tracks[i].dst_d, pr->orow, cw, ch, pr->swap_rb ? 1 : 0, amounts ? (uint32_t)amounts[i] : (uint32_t)pr->bf & 0xFF, amounts ? nullptr : pr->param_block_d, pr->use_lut ? 1 : 0, l);
     if (hipGetLastError() != hipSuccess) { set_error("k_pb_epilogue launch failed"); rc = LGPU_E_HIP; }
   }
   lgpu_free_ordered(sa, st);
@@ -2090,7 +2095,7 @@ extern "C" int lgpu_pixbuf_scale_batch(const uint8_t *const *src_d, uint8_t *con
 
 // resize -> letterbox -> blend (-> gamma) as one call: BASELINE config 3's chain.  letterbox_layer (src/colourspace.c:15343-15567) centres the scaled frame on an
 // opaque black canvas; here the canvas never exists on its own: the scaled frame is blended and stored at its place, the bars are blended black.
-extern "C" int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream) {
+static int chain_canvas_impl(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream, const uint8_t *amounts) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(params && canvas && tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
@@ -2104,5 +2109,20 @@ extern "C" int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_can
     LGPU_REQUIRE(tracks[i].src_d && tracks[i].layer2_d && tracks[i].dst_d, "null track pointer");
     LGPU_REQUIRE((((uintptr_t)tracks[i].src_d | (uintptr_t)tracks[i].layer2_d | (uintptr_t)tracks[i].dst_d) & 3) == 0, "frames must be 4-byte aligned");
   }
-  return pb_chain(params, canvas, tracks, ntracks, (hipStream_t)stream);
+  return pb_chain(params, canvas, tracks, ntracks, (hipStream_t)stream, amounts);
+}
+extern "C" int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream) {
+  return chain_canvas_impl(params, canvas, tracks, ntracks, stream, nullptr);
+}
+// lgpu_chain / lgpu_chain_canvas (canvas may be NULL) on the pixbuf arithmetic with a blend amount PER TRACK (amounts[ntracks], 0..255; params->bf and
+// params->param_block_d are not used): the tracks of a tick share geometry and gamma table, not necessarily their transition amount -- one launch all the same
+extern "C" int lgpu_chain_amounts(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, const uint8_t *amounts, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  LGPU_REQUIRE(params && amounts && (params->interp & LGPU_INTERP_PIXBUF), "lgpu_chain_amounts serves the gdk-pixbuf arithmetic (LGPU_INTERP_PIXBUF)");
+  lgpu_chain_params p0 = *params;
+  p0.param_block_d = nullptr;
+  if (canvas) return chain_canvas_impl(&p0, canvas, tracks, ntracks, stream, amounts);
+  if ((rc = lgpu_chain_check(&p0, tracks, ntracks))) return rc;
+  return pb_chain(&p0, nullptr, tracks, ntracks, (hipStream_t)stream, amounts);
 }

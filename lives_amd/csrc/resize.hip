@@ -2269,7 +2269,7 @@ extern "C" int lgpu_gauss5(const uint8_t *src_d, int irow, uint8_t *dst_d, int o
   return LGPU_OK;
 }
 
-namespace lgpu { int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st); }
+namespace lgpu { int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st, const uint8_t *amounts); }
 // every LGPU_E_BADARG lgpu_chain can answer, and nothing else: pure argument checks, no device work.  lgpu_chain_step runs them before it feeds or enqueues anything.
 extern "C" int lgpu_chain_check(const lgpu_chain_params *pr, const lgpu_chain_track *tracks, int ntracks) {
   LGPU_REQUIRE(pr && tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
@@ -2294,9 +2294,9 @@ static int chain_launch(const lgpu_chain_params *pr, const lgpu_chain_track *tra
   int rc;
   if ((rc = lgpu_chain_check(pr, tracks, ntracks))) return rc;
   if (pr->interp & LGPU_INTERP_PIXBUF) {                 // the resize stage on the reference's gdk-pixbuf arithmetic (pixbuf.hip)
-    return pb_chain(pr, nullptr, tracks, ntracks, st);
+    return pb_chain(pr, nullptr, tracks, ntracks, st, nullptr);
   }
-  const int kernel = kernel_for_interp(pr->interp, pr->dw > pr->sw || pr->dh > pr->sh);
+  const int kernel = kernel_for_interp(pr->interp & 0xFF, pr->dw > pr->sw || pr->dh > pr->sh);      // (flag bits such as LGPU_INTERP_OPAQUE mean nothing to the polyphase stage)
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
   const uint32_t sel = pr->swap_rb ? 0x03000102u : 0x03020100u;   // swap3postalpha: [in2 in1 in0 in3]
   const Bank *hb, *vb, *gh, *gv;

@@ -139,6 +139,7 @@ PROTOTYPES = {
     "lgpu_colorkey_batch": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double, ci, ci, ci, ci, vp],
     "lgpu_rgb_to_yuv_batch": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp],
     "lgpu_yuv_to_rgb_batch": [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp],
+    "lgpu_chain_amounts": [vp, vp, vp, ci, vp, vp],
     "lgpu_pixbuf_scale_check": [ci, ci, ci, ci, ci, ci, vp],
     "lgpu_pixbuf_scale_batch": [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "lgpu_fx_batch": [ctypes.POINTER(FxParams), ctypes.POINTER(FxFrame), ci, vp],

@@ -385,6 +385,13 @@ def chain_canvas(params, tracks, nwidth, nheight, offs_x, offs_y):
     lib.call("lgpu_chain_canvas", ctypes.byref(params), ctypes.byref(cv), tracks, len(tracks), stream_ptr())
 
 
+def chain_amounts(params, tracks, amounts, canvas=None):
+    """lgpu_chain_amounts: the chain with a blend amount per track; canvas = (nwidth, nheight, offs_x, offs_y) or None"""
+    am = (ctypes.c_uint8 * len(tracks))(*[int(a) & 0xFF for a in amounts])
+    cv = lib.Canvas(*canvas) if canvas is not None else None
+    lib.call("lgpu_chain_amounts", ctypes.byref(params), ctypes.byref(cv) if cv is not None else None, tracks, len(tracks), am, stream_ptr())
+
+
 def stream_probe(params, tracks, reps):
     """lgpu_debug_stream_probe: the chain's algorithmic bytes as a bare stream on the same frames, ms for `reps` launches (destinations left dirty)"""
     ms = ctypes.c_float()

@@ -163,7 +163,7 @@ def test_the_tracks_of_a_tick_share_one_launch(seam, orc, deferred):
 
     def track(i):
         try:
-            plan_step(L, wh, H, lays[i], l2l[i], dw, dh, None, 128 if i < n else 77, 2)       # the last track blends with another amount: another shape
+            plan_step(L, wh, H, lays[i], l2l[i], dw, dh, None, 100 + 9 * i, 2 if i < n else None)     # every track its own blend amount (still one shape); the last has no gamma step: another shape
         except Exception as e:         # noqa: BLE001
             errs.append(e)
     ths = [threading.Thread(target=track, args=(i,)) for i in range(n + 1)]
@@ -179,7 +179,7 @@ def test_the_tracks_of_a_tick_share_one_launch(seam, orc, deferred):
     lut = srgb_to(orc, 2)
     for i in range(n + 1):
         assert L.lives_gpu_layer_sync(lays[i]) == 0
-        want = oracle_step(orc, srcs[i], sw, sh, l2s[i], dw, dh, None, 128 if i < n else 77, lut, True)
+        want = oracle_step(orc, srcs[i], sw, sh, l2s[i], dw, dh, None, 100 + 9 * i, lut if i < n else None, True)
         assert (view(wh, lays[i])[:, :dw * 4] == want).all(), i
     for a in lays + l2l:
         assert L.lives_gpu_layer_unpin(a) == 0
@@ -292,3 +292,38 @@ def test_frames_that_already_are_in_hbm(seam, orc, deferred, gpu):
     L.lives_gpu_transfer_stats(ctypes.byref(h2d1), None)
     assert h2d1.value == h2d0.value, "nothing was uploaded"
     assert (host(d_src) == src).all() and (host(d_l2) == l2a).all(), "the caller's buffers are as they were"
+
+
+def test_the_plugins_batch_hook_records_too(seam, orc, deferred):
+    """livesgpu_fx_process_batch(n chroma blend instances) on planes that are pending programs: every blend joins its program (nothing is launched), and the flush
+    that follows is one launch of the chain for all of them"""
+    L, wh, H = seam
+    rng = np.random.default_rng(0xDEFB)
+    sw, sh, dw, dh, n = 256, 144, 128, 72, 5
+    srcs = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(n)]
+    l2s = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(n)]
+    lays = [wh.new_layer(BGRA32, sw, sh, [s], gamma=1) for s in srcs]
+    l2l = [wh.new_layer(RGBA32, dw, dh, [s], gamma=1) for s in l2s]
+    for a in lays + l2l:
+        assert L.lives_gpu_layer_pin(a) == 0
+    for lay in lays:
+        assert L.lives_gpu_convert_layer_palette(lay, RGBA32, 0) == 1 and L.lives_gpu_resize_layer(lay, dw, dh, 3, RGBA32, 0) == 1
+    vs, v2 = [view(wh, a) for a in lays], [view(wh, a) for a in l2l]
+    amounts = [40 + 30 * i for i in range(n)]
+    s0 = dstats(L)
+    H.run_batch(OURS, "chroma blend", RGBA32, dw, dh, vs, v2, vs, amounts, hook="livesgpu_fx_process_batch", int_param=True)
+    s1 = dstats(L)
+    assert s1[0] - s0[0] == n and s1[1:] == s0[1:], "five blends recorded, nothing launched"
+    for lay in lays:
+        assert L.lives_gpu_gamma_convert_layer(2, lay) == 1
+    arr = (ctypes.c_void_p * n)(*lays)
+    assert L.lives_gpu_layers_flush(arr, n) == 0
+    s2 = dstats(L)
+    assert (s2[1] - s1[1], s2[2] - s1[2], s2[3] - s1[3]) == (1, n, 0), "five blend amounts, ONE launch (lgpu_chain_amounts): the amount is per track"
+    lut = srgb_to(orc, 2)
+    for i in range(n):
+        assert L.lives_gpu_layer_sync(lays[i]) == 0
+        want = oracle_step(orc, srcs[i], sw, sh, l2s[i], dw, dh, None, amounts[i], lut, True)
+        assert (view(wh, lays[i])[:, :dw * 4] == want).all(), i
+    for a in lays + l2l:
+        assert L.lives_gpu_layer_unpin(a) == 0

@@ -87,3 +87,39 @@ def test_opaque_scaler_equals_the_general_kernels_and_the_oracle(gpu, orc, geom,
         want = np.zeros((dh, dw * 4), np.uint8)
         assert orc.orc_pixbuf_scale(P(srcs[0]), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, interp) == 0
         assert (outs[OPAQUE][0][:dh] == want).all()
+
+
+@pytest.mark.parametrize("case", [(256, 144, 128, 72, 0, 0, None), (256, 144, 128, 72, 1, 0, None), (256, 144, 128, 72, 1, OPAQUE, None), (200, 120, 133, 80, 0, 0, None),
+                                  (256, 144, 128, 72, 0, 0, (160, 100, 16, 14)), (200, 120, 133, 80, 0, 0, (150, 90, 9, 5))])
+def test_a_blend_amount_per_track(gpu, orc, case):
+    """lgpu_chain_amounts: one launch, every track blended by its own amount -- each track's bytes are those of lgpu_chain[_canvas] on that track alone with
+    params->bf = its amount (and, without a canvas, the oracle's chain)"""
+    sw, sh, dw, dh, blur, flag, canvas = case
+    rng = np.random.default_rng(0x0FC0 + sw + dw + blur)
+    n = 5
+    amounts = [0, 255, 17, 128, 201]
+    cw, ch = (canvas[0], canvas[1]) if canvas else (dw, dh)
+    srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(n)]
+    if flag:
+        for s in srcs:
+            s[:, 3::4] = 255
+    l2s = [rng.integers(0, 256, (ch, cw * 4), dtype=np.uint8) for _ in range(n)]
+    lut = rng.permutation(256).astype(np.uint8)
+    d_s, d_l = [dev(a) for a in srcs], [dev(a) for a in l2s]
+    d_o = [dev(np.zeros((ch, cw * 4), np.uint8)) for _ in range(n)]
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, cw * 4, cw * 4, swap_rb=1, interp=3 | PIXBUF | flag, do_blur=blur, bf=99, lut=lut)
+    gpu.chain_amounts(prm, gpu.chain_tracks(d_s, d_l, d_o), amounts, canvas)
+    got = [host(t) for t in d_o]
+    for i in range(n):
+        one = dev(np.zeros((ch, cw * 4), np.uint8))
+        p1 = gpu.chain_params(sw, sh, sw * 4, dw, dh, cw * 4, cw * 4, swap_rb=1, interp=3 | PIXBUF | flag, do_blur=blur, bf=amounts[i], lut=lut)
+        tr = gpu.chain_tracks([d_s[i]], [d_l[i]], [one])
+        if canvas:
+            gpu.chain_canvas(p1, tr, *canvas)
+        else:
+            gpu.chain(p1, tr)
+        assert (got[i] == host(one)).all(), "track %d (amount %d)" % (i, amounts[i])
+        if not canvas:
+            want = np.zeros((dh, dw * 4), np.uint8)
+            assert orc.orc_chain(P(srcs[i]), sw * 4, sw, sh, P(l2s[i]), dw * 4, P(want), dw * 4, dw, dh, 1, 3 | PIXBUF, blur, amounts[i], P(lut)) == 0
+            assert (got[i] == want).all(), i
