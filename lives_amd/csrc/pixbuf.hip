@@ -996,18 +996,30 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   const int wx0 = ((int)(((long long)j0 * A.x_step + A.xoff) >> 16) + A.tx0) & ~3;          // the window starts on a source pixel that is a multiple of 4: aligned pairs, 16-byte loads
   const int ys0 = (int)(((long long)i0 * A.y_step + A.yoff) >> 16) + A.ty0;
   const int j = j0 + lane;
-  const long long x = (long long)j * A.x_step + A.xoff;
+  const bool live = j < A.dw;                          // lanes past the row's end compute its last pixel and store nothing: every lane stays active for the bpermutes below
+  const long long x = (long long)(live ? j : A.dw - 1) * A.x_step + A.xoff;
   const int xs = (int)(x >> 16), xph = (int)(x >> 12) & 15;
   const bool edge = xs < 0 || xs + A.n_x > A.sw;
   const int pos = xs + A.tx0, par = pos & 1, pidx = (pos - par - wx0) >> 1;
   const pb_u4 *pairs4 = reinterpret_cast<const pb_u4 *>(A.pairs);      // uniform base, 32-bit per-lane index: scalar-base addressing
+  // The weight vectors (rows of one vector, NPC > 0).  A (y phase, tap row) block holds one 16-byte vector per (x phase, parity): 32 vectors, 512 bytes.  Fetched per
+  // lane -- lane -> vector xph * 2 + par -- that is a gather whose neighbouring lanes sit in different cache lines: the texture unit looks up 64 tags per
+  // instruction (profiles/r06/pb_strip_diary.md).  Lane l requests vector l & 31 instead -- one contiguous 512-byte read -- and every lane takes its own vector from the lane
+  // that holds it (ds_bpermute_b32, one per pair).
+  const int lwsrc = (xph * 2 + par) * 4;
+  auto take = [&](const pb_u4 w, uint32_t *o) {
+    const uint32_t wq[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < (NPC ? NPC : 1); k++) o[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(lwsrc, (int)wq[k]);
+  };
   // tap rows known at compile time: the weight vectors of the wave's first destination row are requested BEFORE the window (they land while it is staged: the
   // in-order vector-memory counter makes the window's wait cover them), the following rows' during the taps of the row before -- no exposed load per tap row
   pb_u4 wv[(NPC && NY) ? NY : 1];
   if (NPC && NY) {
     const int i = min(i0 + wave, A.dh - 1), jc = min(j, A.dw - 1);
     const long long xc = (long long)jc * A.x_step + A.xoff;
-    const uint32_t wi0 = (uint32_t)(((int)(((long long)i * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + ((int)(xc >> 12) & 15) * 2 + (((int)(xc >> 16) + A.tx0) & 1));
+    const uint32_t wi0 = (uint32_t)(((int)(((long long)i * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + (lane & 31));
+    (void)xc;
 #pragma unroll
     for (int ty = 0; ty < NY; ty++) wv[ty] = pairs4[wi0 + 32 * ty];
   }
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   auto emit = [&](int i, unsigned r, unsigned g, unsigned b, unsigned a) {
     const uint32_t px = OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<CH>(r, g, b, a, edge, A.rnd);
     uint8_t *drow = A.dst + (size_t)i * A.orow;
-    if (CH == 4) reinterpret_cast<uint32_t *>(drow)[j] = px;
+    if (CH == 4) { if (live) reinterpret_cast<uint32_t *>(drow)[j] = px; }
     else if (quads3 && (j | 3) < A.dw) {
       // four lanes' 3-byte pixels = three dwords: every lane reads its quad's four values (DPP quad_perm broadcasts), packs them, and lanes 0..2 of the quad
       // store one dword each -- coalesced dword stores instead of three byte stores per pixel
@@ -1078,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
       pack3(q, w0, w1, w2);
       const int l = lane & 3;
       if (l < 3) reinterpret_cast<uint32_t *>(drow)[3 * (j >> 2) + l] = l == 0 ? w0 : l == 1 ? w1 : w2;
-    } else { uint8_t *d = drow + 3 * (size_t)j; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
+    } else if (live) { uint8_t *d = drow + 3 * (size_t)j; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
   };
   if (NPC && NY) {
     // tap rows known at compile time: this row's weight vectors are in `cur` (requested before the window was staged, or during the previous row's taps); the next
@@ -1090,14 +1102,15 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
       const int ys = (int)(y >> 16);
       const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
       if (!ONE && r_ + 4 < A.tile_h && i + 4 < A.dh) {
-        const uint32_t win = (uint32_t)(((int)(((long long)(i + 4) * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + xph * 2 + par);
+        const uint32_t win = (uint32_t)(((int)(((long long)(i + 4) * A.y_step + A.yoff) >> 12) & 15) * NY * 32 + (lane & 31));
 #pragma unroll
         for (int ty = 0; ty < NY; ty++) nxt[ty] = pairs4[win + 32 * ty];
       }
       unsigned r = 0, g = 0, b = 0, a = 0;
 #pragma unroll
       for (int ty = 0; ty < NY; ty++) {
-        const uint32_t wq[4] = {cur[ty].x, cur[ty].y, cur[ty].z, cur[ty].w};
+        uint32_t wq[4];
+        take(cur[ty], wq);
 #pragma unroll
         for (int k = 0; k < NPC; k++) {
           const pb_u4 dd = wp[ty * A.wpairs + k];
@@ -1110,28 +1123,25 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
       }
       emit(i, r, g, b, a);
     };
-    if (j < A.dw) {
-      for (int r_ = wave; r_ < A.tile_h && i0 + r_ < A.dh; r_ += 8) {
-        do_row(r_, wv, wn);
-        if (ONE || r_ + 4 >= A.tile_h || i0 + r_ + 4 >= A.dh) break;
-        do_row(r_ + 4, wn, wv);
-      }
+    for (int r_ = wave; r_ < A.tile_h && i0 + r_ < A.dh; r_ += 8) {
+      do_row(r_, wv, wn);
+      if (ONE || r_ + 4 >= A.tile_h || i0 + r_ + 4 >= A.dh) break;
+      do_row(r_ + 4, wn, wv);
     }
     return;
   }
   for (int r_ = wave; r_ < A.tile_h; r_ += 4) {
     const int i = i0 + r_;
     if (i >= A.dh) break;
-    if (j >= A.dw) continue;
     const long long y = (long long)i * A.y_step + A.yoff;
     const int ys = (int)(y >> 16), yph = (int)(y >> 12) & 15;
     const pb_u4 *wp = winp + (ys + A.ty0 - ys0) * A.wpairs + pidx;
-    const uint32_t wi = (uint32_t)(yph * A.ny_eff * 32 + xph * 2 + par);       // [y phase][tap row][x phase][parity]: a wave's 64 vectors of one tap row lie within 512 nq bytes
+    const uint32_t wi = (uint32_t)(yph * A.ny_eff * 32 + (NPC ? (lane & 31) : xph * 2 + par));       // [y phase][tap row][x phase][parity]; NPC: the vector this lane REQUESTS (see take())
     unsigned r = 0, g = 0, b = 0, a = 0;
     for (int ty = 0; ty < A.ny_eff; ty++, wp += A.wpairs) {
       if (NPC) {
-        const pb_u4 w = pairs4[wi + 32 * ty];
-        const uint32_t wq[4] = {w.x, w.y, w.z, w.w};
+        uint32_t wq[4];
+        take(pairs4[wi + 32 * ty], wq);
 #pragma unroll
         for (int k = 0; k < (NPC ? NPC : 1); k++) {
           const pb_u4 dd = wp[k];
@@ -1240,7 +1250,9 @@ struct PbUpArgs {
   int tx0, ty0, rb;                    // rb: destination rows per band
 };
 
-template <int NP, int NY>
+// OPQ (lgpu_pixbuf_scale with LGPU_INTERP_OPAQUE: the caller states that every source pixel has alpha 255): the window holds the colour bytes as 16-bit pairs (one
+// v_perm per pair and channel, no alpha product), three dot products per pair, and the library's un-premultiply is T >> 16 (k_pb_pairs<.., OPQ>; pb_opaque_check)
+template <int NP, int NY, int OPQ = 0>
 __global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t *__restrict__ gp, const PbFrames F) {
   PB_FRAME_ARGS(PbUpArgs);
   constexpr int RL = 2, PW = NY * RL;                  // dwords per tap row / per phase of the pair table (rows of 2 dwords for NP <= 2)
@@ -1274,6 +1286,11 @@ __global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t
   auto premul = [&](const Raw &R, uint32_t *o) {
 #pragma unroll
     for (int k = 0; k < NP; k++) {
+      if (OPQ) {
+        o[4 * k] = __builtin_amdgcn_perm(R.q[2 * k + 1], R.q[2 * k], 0x0C040C00u); o[4 * k + 1] = __builtin_amdgcn_perm(R.q[2 * k + 1], R.q[2 * k], 0x0C050C01u);
+        o[4 * k + 2] = __builtin_amdgcn_perm(R.q[2 * k + 1], R.q[2 * k], 0x0C060C02u); o[4 * k + 3] = 0u;
+        continue;
+      }
       o[4 * k] = pb_premul_pair<0>(R.q[2 * k], R.q[2 * k + 1]); o[4 * k + 1] = pb_premul_pair<1>(R.q[2 * k], R.q[2 * k + 1]);
       o[4 * k + 2] = pb_premul_pair<2>(R.q[2 * k], R.q[2 * k + 1]); o[4 * k + 3] = __builtin_amdgcn_perm(R.q[2 * k + 1], R.q[2 * k], 0x0C070C03u);
     }
@@ -1316,9 +1333,10 @@ __global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         const uint32_t ww = wv[t * RL + k];
-        r = pb_dot2(win[t][4 * k], ww, r); g = pb_dot2(win[t][4 * k + 1], ww, g); b = pb_dot2(win[t][4 * k + 2], ww, b); a = pb_dot2(win[t][4 * k + 3], ww, a);
+        r = pb_dot2(win[t][4 * k], ww, r); g = pb_dot2(win[t][4 * k + 1], ww, g); b = pb_dot2(win[t][4 * k + 2], ww, b);
+        if (!OPQ) a = pb_dot2(win[t][4 * k + 3], ww, a);
       }
-    if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_finish_px<4>(r, g, b, a, false, 0u);
+    if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<4>(r, g, b, a, false, 0u);
   }
 }
 
@@ -1964,9 +1982,10 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       { const int v = tune(TUNE_PB_UP_RB); if (v >= 1 && v <= 4096) ua.rb = v; }      // tuning probe
       const dim3 gu(cdiv(cdiv((unsigned)dw, 64), 4), cdiv((unsigned)dh, (unsigned)ua.rb), (unsigned)n);
       const uint32_t *gp = t->gpairs_d;
-#define PB_UP(NP_, NY_) hipLaunchKernelGGL((k_pb_up<NP_, NY_>), gu, block, 0, st, ua, gp, F)
-      if (unp == 1) { if (uny == 1) PB_UP(1, 1); else if (uny == 2) PB_UP(1, 2); else if (uny == 3) PB_UP(1, 3); else PB_UP(1, 4); }
-      else { if (uny == 1) PB_UP(2, 1); else if (uny == 2) PB_UP(2, 2); else if (uny == 3) PB_UP(2, 3); else PB_UP(2, 4); }
+      if (opaque && (rc = pb_opaque_check())) return rc;
+#define PB_UP(NP_, NY_) { if (opaque) hipLaunchKernelGGL((k_pb_up<NP_, NY_, 1>), gu, block, 0, st, ua, gp, F); else hipLaunchKernelGGL((k_pb_up<NP_, NY_, 0>), gu, block, 0, st, ua, gp, F); }
+      if (unp == 1) { if (uny == 1) PB_UP(1, 1) else if (uny == 2) PB_UP(1, 2) else if (uny == 3) PB_UP(1, 3) else PB_UP(1, 4) }
+      else { if (uny == 1) PB_UP(2, 1) else if (uny == 2) PB_UP(2, 2) else if (uny == 3) PB_UP(2, 3) else PB_UP(2, 4) }
 #undef PB_UP
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
