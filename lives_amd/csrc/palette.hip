@@ -213,10 +213,32 @@ __global__ __launch_bounds__(kBlock) void k_rgb_to_yuv(PalArgs a, const FxFrames
 // chroma as 16-bit pairs; cells are numbered linearly over the frame, the first cell's pixels are requested before the tables (9 KB + the chroma-average table) are
 // staged, and a 512-thread workgroup stages them once for 2,048 cells.  k_rgb_to_yuv<.., 4>: one workgroup of 256 pixel pairs per chroma row, the second row of every
 // pair of rows read twice.
+// The nine rgb -> yuv tables as THREE tables of {Y, U, V} contributions per colour byte, 16 bytes an entry: three ds_read_b128 per pixel instead of six to nine
+// ds_read_b32 (the cell kernels are bound by their table gathers: 4:4:4 packed went from 0.19 to 0.60 of the roofline with this layout and vector stores,
+// profiles/r06/yuv444_s.txt).  Same sums, same clamps as R2Y.
+typedef int pal_i4 __attribute__((ext_vector_type(4)));
+struct R2Y3 {
+  const pal_i4 *p;            // LDS [3][256]
+  int min_y, max_y, min_uv, max_uv;
+  __device__ __forceinline__ void stage(pal_i4 *s_p, const int32_t *tables, int unclamped) {      // every thread of the workgroup; the caller puts a barrier behind it
+    for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+      const int c = i >> 8, e = i & 255;
+      s_p[i] = pal_i4{tables[c * 256 + e], tables[768 + c * 256 + e], tables[1536 + c * 256 + e], 0};
+    }
+    p = s_p;
+    if (unclamped) { min_y = min_uv = 0; max_y = max_uv = 255; } else { min_y = min_uv = 16; max_y = 235; max_uv = 240; }
+  }
+  __device__ __forceinline__ pal_i4 sums(int r, int g, int b) const { return p[r] + p[256 + g] + p[512 + b]; }
+  __device__ __forceinline__ int Y(const pal_i4 s) const { const int a = (short)(s.x >> 16); return a > max_y ? max_y : a < min_y ? min_y : a; }
+  __device__ __forceinline__ int Uraw(const pal_i4 s) const { return (short)(s.y >> 16); }
+  __device__ __forceinline__ int Vraw(const pal_i4 s) const { return (short)(s.z >> 16); }
+  __device__ __forceinline__ int cuv(int a) const { return a > max_uv ? max_uv : a < min_uv ? min_uv : a; }
+};
+
 template <int ORDER>
 __global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
   pal_frame(a, F);
-  __shared__ int32_t s_t[9 * 256];
+  __shared__ pal_i4 s_p[3 * 256];
   typedef unsigned pu4 __attribute__((ext_vector_type(4)));
   const int ngr = a.width >> 2, hc = a.height >> 1, nunits = hc + 1;      // unit 0: row 0 alone; unit u + 1: rows 2u + 1, 2u + 2 -> chroma row u
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,13 +251,10 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gma
   pu4 qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
   if (valid) qa = *reinterpret_cast<const pu4 *>(a.src[0] + (size_t)ra * a.irow[0] + 16 * (size_t)gx);
   if (has_b) qb = *reinterpret_cast<const pu4 *>(a.src[0] + (size_t)rb * a.irow[0] + 16 * (size_t)gx);
-  for (int i = threadIdx.x; i < 9 * 256; i += blockDim.x) s_t[i] = a.tables[i];
+  R2Y3 c;
+  c.stage(s_p, a.tables, a.unclamped);
   cavg_init();                                                               // ends with the workgroup barrier
   if (!valid) return;
-  R2Y c;
-  c.t = s_t;
-  if (a.unclamped) { c.min_y = c.min_uv = 0; c.max_y = c.max_uv = 255; }
-  else { c.min_y = c.min_uv = 16; c.max_y = 235; c.max_uv = 240; }
   auto rgb = [](uint32_t p, int &r, int &g, int &b) {
     const int c0 = p & 0xFF, c1 = (p >> 8) & 0xFF, c2 = (p >> 16) & 0xFF;
     if (ORDER == 1) { r = c2; g = c1; b = c0; } else { r = c0; g = c1; b = c2; }
@@ -248,8 +267,9 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gma
     for (int i = 0; i < 4; i++) {
       int r, g, b;
       rgb(px[i], r, g, b);
-      yy |= (uint32_t)c.Y(r, g, b) << (8 * i);
-      if (chroma) { if (i & 1) v[i >> 1] = c.cuv(c.Vraw(r, g, b)); else u[i >> 1] = c.cuv(c.Uraw(r, g, b)); }
+      const pal_i4 sm = c.sums(r, g, b);
+      yy |= (uint32_t)c.Y(sm) << (8 * i);
+      if (chroma) { if (i & 1) v[i >> 1] = c.cuv(c.Vraw(sm)); else u[i >> 1] = c.cuv(c.Uraw(sm)); }
     }
   };
   const int ylim = 2 * hc;                                                   // luma rows the reference writes (an odd last row is read for its chroma only)
@@ -274,7 +294,7 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv420_s(PalArgs a, uint32_t gma
 template <int ORDER, int FMT>
 __global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
   pal_frame(a, F);
-  __shared__ int32_t s_t[9 * 256];
+  __shared__ pal_i4 s_p[3 * 256];
   typedef unsigned pu4 __attribute__((ext_vector_type(4)));
   const int ngr = a.width >> 2;
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,22 +304,20 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gma
   const bool valid = y < (uint32_t)a.height;
   pu4 q = {0, 0, 0, 0};
   if (valid) q = *reinterpret_cast<const pu4 *>(a.src[0] + (size_t)y * a.irow[0] + 16 * (size_t)gx);
-  for (int i = threadIdx.x; i < 9 * 256; i += blockDim.x) s_t[i] = a.tables[i];
+  R2Y3 c;
+  c.stage(s_p, a.tables, a.unclamped);
   __syncthreads();
   if (!valid) return;
-  R2Y c;
-  c.t = s_t;
-  if (a.unclamped) { c.min_y = c.min_uv = 0; c.max_y = c.max_uv = 255; }
-  else { c.min_y = c.min_uv = 16; c.max_y = 235; c.max_uv = 240; }
   const uint32_t px[4] = {q.x, q.y, q.z, q.w};
   uint32_t yy[4], uu[2], vv[2];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int c0 = px[i] & 0xFF, c1 = (px[i] >> 8) & 0xFF, c2 = (px[i] >> 16) & 0xFF;
     const int r = ORDER == 1 ? c2 : c0, g = c1, b = ORDER == 1 ? c0 : c2;
-    yy[i] = (uint32_t)c.Y(r, g, b);
-    if (i & 1) { const int vr = c.Vraw(r, g, b); vv[i >> 1] = FMT == 3 ? ((uint32_t)(vr < c.min_uv ? c.min_uv : vr) & 0xFF) : (uint32_t)c.cuv(vr); }
-    else { const int ur = c.Uraw(r, g, b); uu[i >> 1] = FMT == 3 ? ((uint32_t)(ur < c.min_uv ? c.min_uv : ur) & 0xFF) : (uint32_t)c.cuv(ur); }
+    const pal_i4 sm = c.sums(r, g, b);
+    yy[i] = (uint32_t)c.Y(sm);
+    if (i & 1) { const int vr = c.Vraw(sm); vv[i >> 1] = FMT == 3 ? ((uint32_t)(vr < c.min_uv ? c.min_uv : vr) & 0xFF) : (uint32_t)c.cuv(vr); }
+    else { const int ur = c.Uraw(sm); uu[i >> 1] = FMT == 3 ? ((uint32_t)(ur < c.min_uv ? c.min_uv : ur) & 0xFF) : (uint32_t)c.cuv(ur); }
   }
   if (FMT == 5) {
     *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + 4 * (size_t)gx) = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
@@ -310,6 +328,56 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gma
     if (FMT == 2) { o.x = uu[0] | (yy[0] << 8) | (vv[0] << 16) | (yy[1] << 24); o.y = uu[1] | (yy[2] << 8) | (vv[1] << 16) | (yy[3] << 24); }
     else { o.x = yy[0] | (uu[0] << 8) | (yy[1] << 16) | (vv[0] << 24); o.y = yy[2] | (uu[1] << 8) | (yy[3] << 16) | (vv[1] << 24); }
     *reinterpret_cast<uint2 *>(a.dst[0] + (size_t)y * a.orow[0] + 8 * (size_t)gx) = o;
+  }
+}
+
+// RGB24 / BGR24 / RGBA32 / BGRA32 -> YUV888 / YUVA8888 (packed 4:4:4) on aligned frames: a lane owns four pixels -- one 12- or 16-byte load, one 12- or 16-byte
+// store (k_rgb_to_yuv<.., 0> stores six to eight single bytes per pixel pair: x16 1080p at 0.19 of the HBM roofline) -- and the nine tables sit in LDS as THREE
+// tables of {Y, U, V} contributions per colour byte, 16 bytes an entry: three ds_read_b128 per pixel instead of nine ds_read_b32 (the table gathers are what
+// the cell kernels above are bound by).  Same sums, same clamps as R2Y (rgb2yuv, :2119-2127).
+template <int ORDER, int IPS, int AOUT>
+__global__ __launch_bounds__(512) void k_rgb_to_yuv444_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
+  pal_frame(a, F);
+  typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+  typedef unsigned pu3 __attribute__((ext_vector_type(3)));
+  typedef int pi4 __attribute__((ext_vector_type(4)));
+  typedef pu3 pu3a __attribute__((aligned(4)));
+  __shared__ pi4 s_p[3 * 256];
+  const int ngr = a.width >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);                                        // floor magic: the quotient or one less
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  const bool valid = y < (uint32_t)a.height;
+  uint32_t px[4] = {0, 0, 0, 0};
+  if (valid) {
+    const uint8_t *sp = a.src[0] + (size_t)y * a.irow[0] + 4 * IPS * (size_t)gx;
+    if (IPS == 4) { const pu4 q = *reinterpret_cast<const pu4 *>(sp); px[0] = q.x; px[1] = q.y; px[2] = q.z; px[3] = q.w; }
+    else {
+      const pu3 q = *reinterpret_cast<const pu3a *>(sp);
+      px[0] = q.x | 0xFF000000u; px[1] = __builtin_amdgcn_alignbyte(q.y, q.x, 3) | 0xFF000000u; px[2] = __builtin_amdgcn_alignbyte(q.z, q.y, 2) | 0xFF000000u; px[3] = (q.z >> 8) | 0xFF000000u;
+    }
+  }
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+    const int c = i >> 8, e = i & 255;
+    s_p[i] = pi4{a.tables[c * 256 + e], a.tables[768 + c * 256 + e], a.tables[1536 + c * 256 + e], 0};
+  }
+  __syncthreads();
+  if (!valid) return;
+  const int min_y = a.unclamped ? 0 : 16, max_y = a.unclamped ? 255 : 235, min_uv = min_y, max_uv = a.unclamped ? 255 : 240;
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t c0 = px[i] & 0xFF, c1 = (px[i] >> 8) & 0xFF, c2 = (px[i] >> 16) & 0xFF;
+    const pi4 er = s_p[ORDER == 1 ? c2 : c0], eg = s_p[256 + c1], eb = s_p[512 + (ORDER == 1 ? c0 : c2)];
+    const int yr = (short)((er.x + eg.x + eb.x) >> 16), ur = (short)((er.y + eg.y + eb.y) >> 16), vr = (short)((er.z + eg.z + eb.z) >> 16);
+    const int Y = yr > max_y ? max_y : yr < min_y ? min_y : yr, U = ur > max_uv ? max_uv : ur < min_uv ? min_uv : ur, V = vr > max_uv ? max_uv : vr < min_uv ? min_uv : vr;
+    o[i] = (uint32_t)Y | ((uint32_t)U << 8) | ((uint32_t)V << 16) | (px[i] & 0xFF000000u);
+  }
+  if (AOUT) *reinterpret_cast<pu4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = pu4{o[0], o[1], o[2], o[3]};
+  else {
+    const pu3 v = {(o[0] & 0xFFFFFFu) | (o[1] << 24), ((o[1] >> 8) & 0xFFFFu) | (o[2] << 16), ((o[2] >> 16) & 0xFFu) | (o[3] << 8)};
+    *reinterpret_cast<pu3a *>(a.dst[0] + (size_t)y * a.orow[0] + 12 * (size_t)gx) = v;
   }
 }
 
@@ -410,6 +478,59 @@ __global__ __launch_bounds__(512) void k_uyvy_to_rgb_s(PalArgs a, uint32_t gmagi
   typedef unsigned pu4 __attribute__((ext_vector_type(4)));
   const pu4 o = {px[0], px[1], px[2], px[3]};
   *reinterpret_cast<pu4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = o;
+}
+
+// YUV888 / YUVA8888 -> 3- or 4-byte RGB on aligned frames: four pixels per lane (one 12- / 16-byte load, one 12- / 16-byte store; k_yuv_to_rgb<0, ..> moves single
+// bytes), the table layout of k_uyvy_to_rgb_s (one gather for Y, one 8-byte gather each for the two terms indexed by V and by U).  put_rgb()'s arithmetic.
+template <int ORDER, int IPS, int OPS>
+__global__ __launch_bounds__(512) void k_yuv444_to_rgb_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
+  static_assert(ORDER != 2 || OPS == 4, "ARGB32 has four bytes");
+  pal_frame(a, F);
+  typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+  typedef unsigned pu3 __attribute__((ext_vector_type(3)));
+  typedef pu3 pu3a __attribute__((aligned(4)));
+  __shared__ int32_t s_ty[256];
+  __shared__ uint2 s_rg[256], s_gb[256];
+  const int ngr = a.width >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);                    // floor magic: the quotient or one less
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  const bool valid = y < (uint32_t)a.height;
+  uint32_t in[4] = {0, 0, 0, 0};
+  if (valid) {
+    const uint8_t *sp = a.src[0] + (size_t)y * a.irow[0] + 4 * IPS * (size_t)gx;
+    if (IPS == 4) { const pu4 q = *reinterpret_cast<const pu4 *>(sp); in[0] = q.x; in[1] = q.y; in[2] = q.z; in[3] = q.w; }
+    else {
+      const pu3 q = *reinterpret_cast<const pu3a *>(sp);
+      in[0] = q.x | 0xFF000000u; in[1] = __builtin_amdgcn_alignbyte(q.y, q.x, 3) | 0xFF000000u; in[2] = __builtin_amdgcn_alignbyte(q.z, q.y, 2) | 0xFF000000u; in[3] = (q.z >> 8) | 0xFF000000u;
+    }
+  }
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    s_ty[e] = a.tables[e];
+    s_rg[e] = make_uint2((uint32_t)a.tables[256 + e], (uint32_t)a.tables[768 + e]);       // R_Cr, G_Cr (indexed by V)
+    s_gb[e] = make_uint2((uint32_t)a.tables[512 + e], (uint32_t)a.tables[1024 + e]);      // G_Cb, B_Cb (indexed by U)
+  }
+  __syncthreads();
+  if (!valid) return;
+  uint32_t px[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t w = in[i];
+    const int32_t yy = s_ty[w & 0xFF];
+    const uint2 gb = s_gb[(w >> 8) & 0xFF], rg = s_rg[(w >> 16) & 0xFF];
+    const uint32_t r = (uint32_t)clamp255((yy + (int32_t)rg.x) >> 16), g = (uint32_t)clamp255((yy + (int32_t)gb.x + (int32_t)rg.y) >> 16), b = (uint32_t)clamp255((yy + (int32_t)gb.y) >> 16);
+    const uint32_t al = (IPS == 4 && a.alpha_in) ? (w >> 24) : 255u;
+    // (byte permutes: see k_uyvy_to_rgb_s about v_ashr_pk_u8_i32)
+    const uint32_t lo = ORDER == 1 ? __builtin_amdgcn_perm(g, b, 0x0C0C0400u) : __builtin_amdgcn_perm(g, r, 0x0C0C0400u);      // c0 | c1 << 8
+    const uint32_t c2 = ORDER == 1 ? r : b;
+    px[i] = ORDER == 2 ? (al | (r << 8) | (g << 16) | (b << 24)) : (__builtin_amdgcn_perm(c2, lo, 0x0C040100u) | (al << 24));
+  }
+  if (OPS == 4) *reinterpret_cast<pu4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = pu4{px[0], px[1], px[2], px[3]};
+  else {
+    const pu3 v = {(px[0] & 0xFFFFFFu) | (px[1] << 24), ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16), ((px[2] >> 16) & 0xFFu) | (px[3] << 8)};
+    *reinterpret_cast<pu3a *>(a.dst[0] + (size_t)y * a.orow[0] + 12 * (size_t)gx) = v;
+  }
 }
 
 // ---- K4b: RGB -> YUV411 (src/colourspace.c:6499-6615, rgb2_411 :2322-2343) -----------------------------------------------------
@@ -1197,6 +1318,22 @@ static int rgb_to_yuv_impl_n(const uint8_t *const *srcs, int irow, int width, in
       return LGPU_OK;
     }
   }
+  // aligned rows -> packed 4:4:4: the four-pixel form
+  if (out_fmt == 0 && in_order <= 1 && !no_s420 && (width & 3) == 0 && (sbits & (ips == 4 ? 15 : 3)) == 0 && (d0bits & (out_alpha ? 15 : 3)) == 0) {
+    const int ngr = width >> 2;
+    const unsigned long long cells = (unsigned long long)ngr * height;
+    if (cells < (1ull << 31)) {
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+      const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
+#define K444_CASE(O, I, AO) case (O) * 4 + ((I) == 4 ? 2 : 0) + (AO): hipLaunchKernelGGL((k_rgb_to_yuv444_s<O, I, AO>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
+      switch (in_order * 4 + (ips == 4 ? 2 : 0) + (out_alpha ? 1 : 0)) {
+        K444_CASE(0, 3, 0) K444_CASE(0, 3, 1) K444_CASE(0, 4, 0) K444_CASE(0, 4, 1) K444_CASE(1, 3, 0) K444_CASE(1, 3, 1) K444_CASE(1, 4, 0) K444_CASE(1, 4, 1)
+      }
+#undef K444_CASE
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
   const int nrows = out_fmt == 4 ? height >> 1 : height;
   const dim3 grid(cdiv((unsigned)npairs, kBlock), (unsigned)(nrows < 2048 ? nrows : 2048), (unsigned)nfr);
 #define K4_CASE(O, FM) case (O) * 8 + (FM): hipLaunchKernelGGL((k_rgb_to_yuv<O, FM>), grid, dim3(kBlock), 0, (hipStream_t)stream, a, F); break;
@@ -1284,6 +1421,26 @@ static int yuv_to_rgb_n(const uint8_t *const (*srcs)[4], const int irow[4], int 
 #undef K3S_CASE
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
+    }
+  }
+  // packed 4:4:4 on aligned rows: the four-pixel form
+  {
+    const int ips = in_alpha ? 4 : 3;
+    if (in_fmt == 0 && !no_s && (width & 3) == 0 && (sbits & (ips == 4 ? 15 : 3)) == 0 && (dbits & (ops == 4 ? 15 : 3)) == 0) {
+      const int ngr = width >> 2;
+      const unsigned long long cells = (unsigned long long)ngr * height;
+      if (cells < (1ull << 31)) {
+        const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+        const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
+#define K444_CASE(O, I, OP) case (O) * 4 + ((I) == 4 ? 2 : 0) + ((OP) == 4 ? 1 : 0): hipLaunchKernelGGL((k_yuv444_to_rgb_s<O, I, OP>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
+        switch (out_order * 4 + (ips == 4 ? 2 : 0) + (ops == 4 ? 1 : 0)) {
+          K444_CASE(0, 3, 3) K444_CASE(0, 3, 4) K444_CASE(0, 4, 3) K444_CASE(0, 4, 4) K444_CASE(1, 3, 3) K444_CASE(1, 3, 4) K444_CASE(1, 4, 3) K444_CASE(1, 4, 4)
+          K444_CASE(2, 3, 4) K444_CASE(2, 4, 4)
+        }
+#undef K444_CASE
+        LGPU_CHECK_LAUNCH();
+        return LGPU_OK;
+      }
     }
   }
   const dim3 grid(cdiv((unsigned)((width + 1) >> 1), kBlock), (unsigned)(height < 2048 ? height : 2048), (unsigned)nfr);
