@@ -335,7 +335,8 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv422_s(PalArgs a, uint32_t gma
 // store (k_rgb_to_yuv<.., 0> stores six to eight single bytes per pixel pair: x16 1080p at 0.19 of the HBM roofline) -- and the nine tables sit in LDS as THREE
 // tables of {Y, U, V} contributions per colour byte, 16 bytes an entry: three ds_read_b128 per pixel instead of nine ds_read_b32 (the table gathers are what
 // the cell kernels above are bound by).  Same sums, same clamps as R2Y (rgb2yuv, :2119-2127).
-template <int ORDER, int IPS, int AOUT>
+// PLANAR: YUV444P / YUVA4444P -- the four pixels leave as one dword per plane
+template <int ORDER, int IPS, int AOUT, int PLANAR = 0>
 __global__ __launch_bounds__(512) void k_rgb_to_yuv444_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
   pal_frame(a, F);
   typedef unsigned pu4 __attribute__((ext_vector_type(4)));
@@ -374,7 +375,14 @@ __global__ __launch_bounds__(512) void k_rgb_to_yuv444_s(PalArgs a, uint32_t gma
     const int Y = yr > max_y ? max_y : yr < min_y ? min_y : yr, U = ur > max_uv ? max_uv : ur < min_uv ? min_uv : ur, V = vr > max_uv ? max_uv : vr < min_uv ? min_uv : vr;
     o[i] = (uint32_t)Y | ((uint32_t)U << 8) | ((uint32_t)V << 16) | (px[i] & 0xFF000000u);
   }
-  if (AOUT) *reinterpret_cast<pu4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = pu4{o[0], o[1], o[2], o[3]};
+  if (PLANAR) {
+    // byte k of every pixel -> plane k: selector bytes 0 / 4 of the pair, then of the pair of pairs
+    auto plane = [&](uint32_t s01, uint32_t s23) { return __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], s23), __builtin_amdgcn_perm(o[1], o[0], s01), 0x05040100u); };
+    *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.orow[0] + 4 * (size_t)gx) = plane(0x0C0C0400u, 0x0C0C0400u);
+    *reinterpret_cast<uint32_t *>(a.dst[1] + (size_t)y * a.orow[1] + 4 * (size_t)gx) = plane(0x0C0C0501u, 0x0C0C0501u);
+    *reinterpret_cast<uint32_t *>(a.dst[2] + (size_t)y * a.orow[2] + 4 * (size_t)gx) = plane(0x0C0C0602u, 0x0C0C0602u);
+    if (AOUT) *reinterpret_cast<uint32_t *>(a.dst[3] + (size_t)y * a.orow[3] + 4 * (size_t)gx) = plane(0x0C0C0703u, 0x0C0C0703u);
+  } else if (AOUT) *reinterpret_cast<pu4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = pu4{o[0], o[1], o[2], o[3]};
   else {
     const pu3 v = {(o[0] & 0xFFFFFFu) | (o[1] << 24), ((o[1] >> 8) & 0xFFFFu) | (o[2] << 16), ((o[2] >> 16) & 0xFFu) | (o[3] << 8)};
     *reinterpret_cast<pu3a *>(a.dst[0] + (size_t)y * a.orow[0] + 12 * (size_t)gx) = v;
@@ -482,7 +490,8 @@ __global__ __launch_bounds__(512) void k_uyvy_to_rgb_s(PalArgs a, uint32_t gmagi
 
 // YUV888 / YUVA8888 -> 3- or 4-byte RGB on aligned frames: four pixels per lane (one 12- / 16-byte load, one 12- / 16-byte store; k_yuv_to_rgb<0, ..> moves single
 // bytes), the table layout of k_uyvy_to_rgb_s (one gather for Y, one 8-byte gather each for the two terms indexed by V and by U).  put_rgb()'s arithmetic.
-template <int ORDER, int IPS, int OPS>
+// PLANAR: YUV444P / YUVA4444P -- one dword per plane in (IPS 4: with the alpha plane)
+template <int ORDER, int IPS, int OPS, int PLANAR = 0>
 __global__ __launch_bounds__(512) void k_yuv444_to_rgb_s(PalArgs a, uint32_t gmagic, const FxFrames F) {
   static_assert(ORDER != 2 || OPS == 4, "ARGB32 has four bytes");
   pal_frame(a, F);
@@ -498,7 +507,15 @@ __global__ __launch_bounds__(512) void k_yuv444_to_rgb_s(PalArgs a, uint32_t gma
   if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
   const bool valid = y < (uint32_t)a.height;
   uint32_t in[4] = {0, 0, 0, 0};
-  if (valid) {
+  if (valid && PLANAR) {
+    const uint32_t Y4 = *reinterpret_cast<const uint32_t *>(a.src[0] + (size_t)y * a.irow[0] + 4 * (size_t)gx), U4 = *reinterpret_cast<const uint32_t *>(a.src[1] + (size_t)y * a.irow[1] + 4 * (size_t)gx);
+    const uint32_t V4 = *reinterpret_cast<const uint32_t *>(a.src[2] + (size_t)y * a.irow[2] + 4 * (size_t)gx);
+    const uint32_t A4 = IPS == 4 ? *reinterpret_cast<const uint32_t *>(a.src[3] + (size_t)y * a.irow[3] + 4 * (size_t)gx) : 0xFFFFFFFFu;
+    const uint32_t yu01 = __builtin_amdgcn_perm(U4, Y4, 0x05010400u), yu23 = __builtin_amdgcn_perm(U4, Y4, 0x07030602u);      // Y0 U0 Y1 U1 / Y2 U2 Y3 U3
+    const uint32_t va01 = __builtin_amdgcn_perm(A4, V4, 0x05010400u), va23 = __builtin_amdgcn_perm(A4, V4, 0x07030602u);      // V0 A0 V1 A1 / V2 A2 V3 A3
+    in[0] = __builtin_amdgcn_perm(va01, yu01, 0x05040100u); in[1] = __builtin_amdgcn_perm(va01, yu01, 0x07060302u);
+    in[2] = __builtin_amdgcn_perm(va23, yu23, 0x05040100u); in[3] = __builtin_amdgcn_perm(va23, yu23, 0x07060302u);
+  } else if (valid) {
     const uint8_t *sp = a.src[0] + (size_t)y * a.irow[0] + 4 * IPS * (size_t)gx;
     if (IPS == 4) { const pu4 q = *reinterpret_cast<const pu4 *>(sp); in[0] = q.x; in[1] = q.y; in[2] = q.z; in[3] = q.w; }
     else {
@@ -854,25 +871,45 @@ __global__ __launch_bounds__(kBlock) void k_yuv411_repack(R411Args a) {
   }
 }
 // YUV411 -> 4:2:0, the odd row after the last even one: each of its 2 wm chroma samples is averaged INTO THE FIRST sample of chroma row 0, in order
-// (the destination pointer is not advanced on odd rows, :9071-9073, :9096-9098, :9113-9115, :9134-9136).  A serial fold by one lane per plane.
-__global__ void k_yuv411_420_fold(const uint8_t *src, int wm, int row, uint8_t *du, uint8_t *dv, int cl) {
-  cavg_init();
-  const int off = threadIdx.x ? 3 : 0;                     // lane 0: U, lane 1: V
-  uint8_t *d = threadIdx.x ? dv : du;
-  if (threadIdx.x > 1) return;
+// (the destination pointer is not advanced on odd rows, :9071-9073, :9096-9098, :9113-9115, :9134-9136): acc = cavg(acc, c[m]) for m = 0 .. 2 wm - 1, a serial
+// fold.  One lane per plane walking it took 251 us at 1080p (two dependent global loads and two table gathers per step).  The fold is a composition of byte ->
+// byte functions, and composition is associative: the 2 wm steps are cut into chunks, 256 lanes per chunk each fold ONE possible start value through the
+// chunk (the average in its table-free form, cavg_arith) -- the chunk's function as a 256-byte table -- and a second launch walks the start value through the tables.
+__global__ __launch_bounds__(512) void k_yuv411_420_fold_chunks(const uint8_t *src, int wm, int row, int cl, int per, uint8_t *tables) {
+  // blockIdx.x: chunk; threads 0..255: U, 256..511: V; tables[(plane * gridDim.x + chunk) * 256 + start value]
+  extern __shared__ uint8_t s_c[];                       // [2][per]: the chunk's samples c[m], both planes
+  const int plane = threadIdx.x >> 8, x = threadIdx.x & 255, m0 = blockIdx.x * per, n = min(per, 2 * wm - m0);
   const uint8_t *rp = src + (size_t)row * wm * 6;
-  int acc = d[0];
-  for (int m = 0; m < 2 * wm; m++) {
-    int c;
-    if (m == 0) c = rp[off];
-    else if (m == 2 * wm - 1) c = rp[(size_t)(wm - 1) * 6 + off];
-    else {
-      const int j = (m + 1) >> 1, k = (m + 1) & 1;
-      const int p = rp[(size_t)(j - 1) * 6 + off], q = rp[(size_t)j * 6 + off];
-      c = cavg(cl, cavg(cl, p, q), k ? q : p);
+  for (int e = threadIdx.x; e < 2 * per; e += blockDim.x) {
+    const int pl = e >= per, k_ = e - pl * per, m = m0 + k_, off = pl ? 3 : 0;
+    int c = 0;
+    if (k_ < n) {
+      if (m == 0) c = rp[off];
+      else if (m == 2 * wm - 1) c = rp[(size_t)(wm - 1) * 6 + off];
+      else {
+        const int j = (m + 1) >> 1, k = (m + 1) & 1;
+        const int p = rp[(size_t)(j - 1) * 6 + off], q = rp[(size_t)j * 6 + off];
+        c = cavg_arith(cl, cavg_arith(cl, p, q), k ? q : p);
+      }
     }
-    acc = cavg(cl, acc, c);
+    s_c[e] = (uint8_t)c;
   }
+  __syncthreads();
+  int acc = x;
+  const uint8_t *c = s_c + plane * per;
+  for (int k = 0; k < n; k++) acc = cavg_arith(cl, acc, c[k]);
+  tables[((size_t)plane * gridDim.x + blockIdx.x) * 256 + x] = (uint8_t)acc;
+}
+__global__ __launch_bounds__(256) void k_yuv411_420_fold_walk(const uint8_t *tables, int nchunks, uint8_t *du, uint8_t *dv) {
+  extern __shared__ uint8_t s_tab[];                     // both planes' tables: the walk is a chain of dependent lookups, through LDS instead of through L2
+  const uint32_t *t4 = reinterpret_cast<const uint32_t *>(tables);
+  for (int e = threadIdx.x; e < 2 * nchunks * 64; e += blockDim.x) reinterpret_cast<uint32_t *>(s_tab)[e] = t4[e];
+  __syncthreads();
+  if (threadIdx.x > 1) return;
+  uint8_t *d = threadIdx.x ? dv : du;
+  const uint8_t *t = s_tab + (size_t)threadIdx.x * nchunks * 256;
+  int acc = d[0];
+  for (int ch = 0; ch < nchunks; ch++) acc = t[ch * 256 + acc];
   d[0] = (uint8_t)acc;
 }
 
@@ -1318,14 +1355,18 @@ static int rgb_to_yuv_impl_n(const uint8_t *const *srcs, int irow, int width, in
       return LGPU_OK;
     }
   }
-  // aligned rows -> packed 4:4:4: the four-pixel form
-  if (out_fmt == 0 && in_order <= 1 && !no_s420 && (width & 3) == 0 && (sbits & (ips == 4 ? 15 : 3)) == 0 && (d0bits & (out_alpha ? 15 : 3)) == 0) {
+  // aligned rows -> packed / planar 4:4:4: the four-pixel form
+  uintptr_t pbits = d0bits | d12bits;
+  if (out_fmt == 1 && out_alpha) { pbits |= (uintptr_t)orow[3]; for (int f = 0; f < nfr; f++) pbits |= (uintptr_t)dsts[f][3]; }
+  if (((out_fmt == 0 && (d0bits & (out_alpha ? 15 : 3)) == 0) || (out_fmt == 1 && (pbits & 3) == 0)) &&
+      in_order <= 1 && !no_s420 && (width & 3) == 0 && (sbits & (ips == 4 ? 15 : 3)) == 0) {
     const int ngr = width >> 2;
     const unsigned long long cells = (unsigned long long)ngr * height;
     if (cells < (1ull << 31)) {
       const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
       const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
-#define K444_CASE(O, I, AO) case (O) * 4 + ((I) == 4 ? 2 : 0) + (AO): hipLaunchKernelGGL((k_rgb_to_yuv444_s<O, I, AO>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
+#define K444_CASE(O, I, AO) case (O) * 4 + ((I) == 4 ? 2 : 0) + (AO): if (out_fmt == 1) hipLaunchKernelGGL((k_rgb_to_yuv444_s<O, I, AO, 1>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); \
+        else hipLaunchKernelGGL((k_rgb_to_yuv444_s<O, I, AO, 0>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
       switch (in_order * 4 + (ips == 4 ? 2 : 0) + (out_alpha ? 1 : 0)) {
         K444_CASE(0, 3, 0) K444_CASE(0, 3, 1) K444_CASE(0, 4, 0) K444_CASE(0, 4, 1) K444_CASE(1, 3, 0) K444_CASE(1, 3, 1) K444_CASE(1, 4, 0) K444_CASE(1, 4, 1)
       }
@@ -1426,13 +1467,16 @@ static int yuv_to_rgb_n(const uint8_t *const (*srcs)[4], const int irow[4], int 
   // packed 4:4:4 on aligned rows: the four-pixel form
   {
     const int ips = in_alpha ? 4 : 3;
-    if (in_fmt == 0 && !no_s && (width & 3) == 0 && (sbits & (ips == 4 ? 15 : 3)) == 0 && (dbits & (ops == 4 ? 15 : 3)) == 0) {
+    uintptr_t pb = 0;
+    if (in_fmt == 1) for (int f = 0; f < nfr; f++) for (int i = 0; i < nplanes; i++) pb |= (uintptr_t)srcs[f][i] | (uintptr_t)irow[i];
+    if (((in_fmt == 0 && (sbits & (ips == 4 ? 15 : 3)) == 0) || (in_fmt == 1 && (pb & 3) == 0)) && !no_s && (width & 3) == 0 && (dbits & (ops == 4 ? 15 : 3)) == 0) {
       const int ngr = width >> 2;
       const unsigned long long cells = (unsigned long long)ngr * height;
       if (cells < (1ull << 31)) {
         const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
         const dim3 gs((unsigned)((cells + 511) / 512), 1, (unsigned)nfr);
-#define K444_CASE(O, I, OP) case (O) * 4 + ((I) == 4 ? 2 : 0) + ((OP) == 4 ? 1 : 0): hipLaunchKernelGGL((k_yuv444_to_rgb_s<O, I, OP>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
+#define K444_CASE(O, I, OP) case (O) * 4 + ((I) == 4 ? 2 : 0) + ((OP) == 4 ? 1 : 0): if (in_fmt == 1) hipLaunchKernelGGL((k_yuv444_to_rgb_s<O, I, OP, 1>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); \
+          else hipLaunchKernelGGL((k_yuv444_to_rgb_s<O, I, OP, 0>), gs, dim3(512), 0, (hipStream_t)stream, a, magic, F); break;
         switch (out_order * 4 + (ips == 4 ? 2 : 0) + (ops == 4 ? 1 : 0)) {
           K444_CASE(0, 3, 3) K444_CASE(0, 3, 4) K444_CASE(0, 4, 3) K444_CASE(0, 4, 4) K444_CASE(1, 3, 3) K444_CASE(1, 3, 4) K444_CASE(1, 4, 3) K444_CASE(1, 4, 4)
           K444_CASE(2, 3, 4) K444_CASE(2, 4, 4)
@@ -1625,8 +1669,14 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     if (out_pal == P_YV12) { uint8_t *t = r.dst[1]; r.dst[1] = r.dst[2]; r.dst[2] = t; }       // is_yvu (:9055-9061)
     const dim3 grid(cdiv((unsigned)(width >> 2), kBlock), (unsigned)(height < 2048 ? height : 2048));
     hipLaunchKernelGGL(lgpu::k_yuv411_repack, grid, dim3(kBlock), 0, st, r);
-    if (r.kind == lgpu::K411_TO_420 && height >= 2 && !(height & 1))
-      hipLaunchKernelGGL(lgpu::k_yuv411_420_fold, dim3(1), dim3(64), 0, st, r.src[0], width >> 2, height - 1, r.dst[1], r.dst[2], r.clamped);
+    if (r.kind == lgpu::K411_TO_420 && height >= 2 && !(height & 1)) {
+      const int wm = width >> 2, per = wm >= 2048 ? 128 : 32, nch = (2 * wm + per - 1) / per;      // (the walk's tables stay within 64 KB of LDS: width < 32768)
+      void *tab = nullptr;
+      if ((rc = lgpu_malloc_ordered(&tab, (size_t)2 * nch * 256, st))) return rc;
+      hipLaunchKernelGGL(lgpu::k_yuv411_420_fold_chunks, dim3((unsigned)nch), dim3(512), (size_t)2 * per, st, r.src[0], wm, height - 1, r.clamped, per, (uint8_t *)tab);
+      hipLaunchKernelGGL(lgpu::k_yuv411_420_fold_walk, dim3(1), dim3(256), (size_t)2 * nch * 256, st, (const uint8_t *)tab, nch, r.dst[1], r.dst[2]);
+      lgpu_free_ordered(tab, st);
+    }
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }

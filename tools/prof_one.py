@@ -30,6 +30,80 @@ def case(op):
     if op == "edge":
         src, dst = rnd(h, w * 4), rnd(h, w * 4)
         return (lambda i: ops.edge(src[i % NB], dst[i % NB], w, h, 3, 0)), w * h * 16
+    # ---- single-frame entry points without a batch form (1080p): s:<name>
+    if op.startswith("s:"):
+        k = op[2:]
+        if k == "gauss5":
+            src, dst = rnd(h, w * 4), rnd(h, w * 4)
+            return (lambda i: ops.gauss5(src[i % NB], dst[i % NB], w, h, 4)), w * h * 8
+        if k == "resize":                # the polyphase spec (lgpu_resize), 4K -> 1080p BICUBIC class
+            src, dst = rnd(2160, 3840 * 4), rnd(h, w * 4)
+            return (lambda i: ops.resize(src[i % NB], dst[i % NB], 3840, 2160, w, h, 4, 3)), 3840 * 2160 * 4 + w * h * 4
+        if k == "deint":
+            src, dst = rnd(h, w * 4), rnd(h, w * 4)
+            return (lambda i: ops.deinterlace(src[i % NB], dst[i % NB], w, h, 3)), w * h * 8
+        if k == "deint420":
+            src, dst = rnd(h, w), rnd(h, w)
+            return (lambda i: ops.deinterlace(src[i % NB], dst[i % NB], w, h, 512)), w * h * 2
+        if k in ("tsplit", "dissolve", "slide", "transition", "chroma", "luma", "multi", "colorkey"):
+            ps = 3 if k in ("tsplit", "multi", "colorkey") else 4
+            a_, b_, o = rnd(h, w * ps), rnd(h, w * ps), rnd(h, w * ps)
+            nbytes = w * h * ps * 3
+            if k == "tsplit":
+                return (lambda i: ops.triple_split(a_[i % NB], b_[i % NB], o[i % NB], w, h, 0, 0.3, True, 0.7, False, 0.02, (255, 0, 0))), nbytes
+            if k == "dissolve":
+                mask = torch.from_numpy(ops.dissolve_mask(1234, w, h)).cuda()
+                return (lambda i, keep=mask: ops.dissolve(a_[i % NB], b_[i % NB], o[i % NB], w, h, ps, mask, 0.5)), nbytes + w * h * 4
+            if k == "slide":
+                return (lambda i: ops.slide_over(a_[i % NB], b_[i % NB], o[i % NB], w, h, ps, 128, 1)), nbytes
+            if k == "transition":
+                return (lambda i: ops.transition(1, a_[i % NB], b_[i % NB], o[i % NB], w, h, ps, 0.5)), nbytes
+            if k == "chroma":
+                return (lambda i: ops.blend_chroma(a_[i % NB], b_[i % NB], o[i % NB], w, h, ps, 128)), nbytes
+            if k == "luma":
+                return (lambda i: ops.blend_luma(1, a_[i % NB], b_[i % NB], o[i % NB], w, h, ps, 0, 128)), nbytes
+            if k == "multi":
+                return (lambda i: ops.blend_multi(1, a_[i % NB], b_[i % NB], o[i % NB], w, h, 0, 128)), nbytes
+            return (lambda i: ops.colorkey(a_[i % NB], b_[i % NB], o[i % NB], w, h, 0, 0.3, 0.8, (128, 128, 128))), nbytes
+        if k.startswith("repack"):        # s:repack:<in palette>:<out palette>   (WEED_PALETTE numbers)
+            _, ip_, op_ = k.split(":")
+            ip_, op_ = int(ip_), int(op_)
+
+            def planes(pal):
+                if pal in (512, 513):
+                    return [rnd(h, w), rnd(h // 2, w // 2), rnd(h // 2, w // 2)], w * h * 3 // 2
+                if pal == 522:
+                    return [rnd(h, w), rnd(h, w // 2), rnd(h, w // 2)], w * h * 2
+                if pal == 544:
+                    return [rnd(h, w), rnd(h, w), rnd(h, w)], w * h * 3
+                if pal in (564, 565):
+                    return [rnd(h, w * 2)], w * h * 2
+                if pal == 588:
+                    return [rnd(h, w * 3)], w * h * 3
+                if pal == 589:
+                    return [rnd(h, w * 4)], w * h * 4
+                if pal == 595:
+                    return [rnd(h, (w >> 2) * 6)], w * h * 6 // 4
+                raise SystemExit("palette " + str(pal))
+            sp, sb = planes(ip_)
+            dp, db = planes(op_)
+            return (lambda i: ops.yuv_repack(ip_, op_, [pl[i % NB] for pl in sp], [pl[i % NB] for pl in dp], w, h)), sb + db
+        if k == "clamp":
+            ya = rnd(h, w * 2)
+            return (lambda i: ops.yuv_switch_clamping([ya[i % NB]], 564, h, 1)), w * h * 4
+        if k == "r2y411":
+            src, dst = rnd(h, w * 4), rnd(h, (w >> 2) * 6)
+            return (lambda i: ops.rgb_to_yuv411(src[i % NB], dst[i % NB], w, h, 0, 1, 0)), w * h * 4 + w * h * 6 // 4
+        if k == "r2y444p":
+            src, d0, d1, d2 = rnd(h, w * 4), rnd(h, w), rnd(h, w), rnd(h, w)
+            return (lambda i: ops.rgb_to_yuv(src[i % NB], [d0[i % NB], d1[i % NB], d2[i % NB]], w, h, 0, 1, 1, 0, 0)), w * h * 7
+        if k == "y444p2rgb":
+            s0, s1, s2, dst = rnd(h, w), rnd(h, w), rnd(h, w), rnd(h, w * 4)
+            return (lambda i: ops.yuv_to_rgb([s0[i % NB], s1[i % NB], s2[i % NB]], dst[i % NB], w, h, 1, 0, 0, 1, 0)), w * h * 7
+        if k == "lb":
+            src, dst = rnd(h, w * 4), rnd(1200, w * 4)
+            return (lambda i: ops.letterbox(src[i % NB], dst[i % NB], w, h, w, 1200, 4, (0, 0, 0, 255))), w * h * 4 + w * 1200 * 4
+        raise SystemExit("unknown single op " + op)
     if op == "softlight":
         pl = [[a, b, c] for a, b, c in zip(rnd(h, w), rnd(h // 2, w // 2), rnd(h // 2, w // 2))]
         dl = [[torch.zeros_like(t) for t in p] for p in pl]
