@@ -933,20 +933,60 @@ __device__ __forceinline__ uint32_t pb_chroma_rgba(uint32_t p1, uint32_t p2, uin
   return lo | hi | (p1 & 0xFF000000u);
 }
 
-// the rest of the chain behind a resize that was not fused: [R <-> B] -> chroma blend with layer 2 -> gamma LUT, one RGBA pixel per thread
-__global__ __launch_bounds__(256) void k_pb_epilogue(const uint8_t *trk, int irow, const uint8_t *l2, int irow2, uint8_t *dst, int orow, int width, int height,
-                                                     int swap_rb, uint32_t bf, const int32_t *bf_d, int use_lut, const Lut8 lut) {
+// The chain's last stages inside a scaler's store (lgpu_chain off the exact 2:1 case, no gaussian, no canvas): the destination pixel goes [R <-> B] -> chroma blend with
+// layer 2 -> gamma LUT before it is written -- no scratch frame, no second launch.  Kernels take it as their last argument: PbNoEpi (nothing) or PbEpi.
+#define PB_NOT_FUSED 0x7ff0
+struct PbNoEpi {};
+struct PbEpi {
+  const uint8_t *l2[LGPU_CHAIN_MAX_TRACKS];    // layer 2 of frame z (the grid's z index)
+  uint8_t bf[LGPU_CHAIN_MAX_TRACKS];           // bf_tracks: a blend amount per frame
+  const int32_t *bf_d;                         // else, when set: the amount's low byte read on the device
+  uint32_t bf0;
+  int irow2, swap_rb, use_lut, bf_tracks;
+  Lut8 lut;
+};
+template <typename EA> struct pb_has_epi { static constexpr bool value = true; };
+template <> struct pb_has_epi<PbNoEpi> { static constexpr bool value = false; };
+__device__ __forceinline__ void pb_epi_stage(uint8_t *, const PbNoEpi &) {}
+__device__ __forceinline__ void pb_epi_stage(uint8_t *s_lut, const PbEpi &E) { stage_lut(s_lut, E.lut); }      // the caller's next barrier covers it
+__device__ __forceinline__ uint32_t pb_epi_px(const PbNoEpi &, const uint8_t *, uint32_t px, int, int) { return px; }
+__device__ __forceinline__ uint32_t pb_epi_px(const PbEpi &E, const uint8_t *s_lut, uint32_t px, int i, int j) {
+  const int z = blockIdx.z;
+  const uint32_t bf = E.bf_tracks ? (uint32_t)E.bf[z] : E.bf_d ? ((uint32_t)E.bf_d[0] & 0xFF) : E.bf0;
+  if (E.swap_rb) px = __builtin_amdgcn_perm(px, px, 0x03000102u);
+  px = pb_chroma_rgba(px, reinterpret_cast<const uint32_t *>(E.l2[z] + (size_t)i * E.irow2)[j], bf, 255u - bf);
+  if (E.use_lut) px = lut3_rgba(s_lut, px);
+  return px;
+}
+
+// the bars of a letterbox canvas for the one-launch forms off 2:1: opaque black through the chain's last stages, every canvas pixel outside the inner rectangle
+// (groups of four pixels along a row; frame = grid z)
+__global__ __launch_bounds__(256) void k_pb_bars_epi(const PbTracks T, const PbEpi E, int orow, int cw, int ch, int ox, int oy, int iw, int ih) {
+  __shared__ uint8_t s_lut[256];
+  pb_epi_stage(s_lut, E);
+  __syncthreads();
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cw || y >= ch) return;
+  if (y >= oy && y < oy + ih && x >= ox && x < ox + iw) return;
+  reinterpret_cast<uint32_t *>(T.dst[blockIdx.z] + (size_t)y * orow)[x] = pb_epi_px(E, s_lut, 0xFF000000u, y, x);
+}
+
+// the rest of the chain behind a resize that was not fused: [R <-> B] -> chroma blend with layer 2 -> gamma LUT, one RGBA pixel per thread;
+// the tracks of one staged group: track = grid z, its scaled frame at scratch + z * per, layer 2 / destination / blend amount from the track table
+__global__ __launch_bounds__(256) void k_pb_epilogue_n(const uint8_t *scratch, size_t per, int irow, const PbTracks T, int bf_tracks, int irow2, int orow, int width, int height,
+                                                       int swap_rb, uint32_t bf, const int32_t *bf_d, int use_lut, const Lut8 lut) {
   __shared__ uint8_t s_lut[256];
   stage_lut(s_lut, lut);
   __syncthreads();
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
   if (x >= width || y >= height) return;
   if (bf_d) bf = (uint32_t)bf_d[0] & 0xFF;
-  uint32_t p = reinterpret_cast<const uint32_t *>(trk + (size_t)y * irow)[x];
+  if (bf_tracks) bf = T.bf[z];
+  uint32_t p = reinterpret_cast<const uint32_t *>(scratch + (size_t)z * per + (size_t)y * irow)[x];
   if (swap_rb) p = __builtin_amdgcn_perm(p, p, 0x03000102u);
-  p = pb_chroma_rgba(p, reinterpret_cast<const uint32_t *>(l2 + (size_t)y * irow2)[x], bf, 255u - bf);
+  p = pb_chroma_rgba(p, reinterpret_cast<const uint32_t *>(T.l2[z] + (size_t)y * irow2)[x], bf, 255u - bf);
   if (use_lut) p = lut3_rgba(s_lut, p);
-  reinterpret_cast<uint32_t *>(dst + (size_t)y * orow)[x] = p;
+  reinterpret_cast<uint32_t *>(T.dst[z] + (size_t)y * orow)[x] = p;
 }
 
 // =====================================================================================================================================================
@@ -980,13 +1020,16 @@ struct PbPairArgs {
 // OPQ (4-byte pixels; lgpu_pixbuf_scale with LGPU_INTERP_OPAQUE: the caller states that every source pixel has alpha 255): the window holds the colour BYTES as 16-bit
 // pairs (one v_perm per pair and channel, no alpha product), the alpha sums are not formed (three dot products per pair instead of four), and the library's
 // (uint8_t)((double)(255 T) * fl(1 / (255 * 65536))) is T >> 16 -- equal for every T < 2^24, checked on the device before the first such launch (pb_opaque_check)
-template <int CH, int NPC, int NY, int ONE = 0, int OPQ = 0>
-__global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbFrames F) {
+template <int CH, int NPC, int NY, int ONE = 0, int OPQ = 0, typename EA = PbNoEpi>
+__global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbFrames F, const EA E) {
   static_assert(!OPQ || CH == 4, "the all-opaque form is a form of the 4-byte kernel");
+  static_assert(!pb_has_epi<EA>::value || CH == 4, "the chain's stages ride on 4-byte pixels");
   PB_FRAME_ARGS(PbPairArgs);
   extern __shared__ pb_u4 winp[];                      // [win_h][wpairs]
+  __shared__ uint8_t s_lut[pb_has_epi<EA>::value ? 256 : 4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // uniform, and the compiler is told so: row arithmetic on the scalar unit
   int bx = blockIdx.x, by = blockIdx.y;
+  pb_epi_stage(s_lut, E);                              // (the barrier behind the window covers it)
   if (A.per_xcd) {
     const int t = (int)(blockIdx.x & 7u) * A.per_xcd + (int)(blockIdx.x >> 3);
     if (t >= A.gx * A.gy) return;                       // padding of the last XCD's run (before any barrier: the whole workgroup leaves)
@@ -1080,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_pb_pairs(const PbPairArgs A_, const PbF
   auto emit = [&](int i, unsigned r, unsigned g, unsigned b, unsigned a) {
     const uint32_t px = OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<CH>(r, g, b, a, edge, A.rnd);
     uint8_t *drow = A.dst + (size_t)i * A.orow;
-    if (CH == 4) { if (live) reinterpret_cast<uint32_t *>(drow)[j] = px; }
+    if (CH == 4) { if (live) reinterpret_cast<uint32_t *>(drow)[j] = pb_epi_px(E, s_lut, px, i, j); }
     else if (quads3 && (j | 3) < A.dw) {
       // four lanes' 3-byte pixels = three dwords: every lane reads its quad's four values (DPP quad_perm broadcasts), packs them, and lanes 0..2 of the quad
       // store one dword each -- coalesced dword stores instead of three byte stores per pixel
@@ -1184,9 +1227,11 @@ struct PbGatherArgs {
 typedef pb_u4 pb_u4a __attribute__((aligned(4)));
 typedef pb_u2 pb_u2a __attribute__((aligned(4)));
 
-template <int NP>
-__global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A_, const uint32_t *__restrict__ gp, const PbFrames F) {
+template <int NP, typename EA = PbNoEpi>
+__global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A_, const uint32_t *__restrict__ gp, const PbFrames F, const EA E) {
   PB_FRAME_ARGS(PbGatherArgs);
+  __shared__ uint8_t s_lut[pb_has_epi<EA>::value ? 256 : 4];
+  if (pb_has_epi<EA>::value) { pb_epi_stage(s_lut, E); __syncthreads(); }      // (the only barrier of this kernel, and only in the chain's form)
   constexpr int RL = NP <= 2 ? 2 : 4;                  // weight dwords per tap row
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = blockIdx.x * 64 + lane, i = blockIdx.y * 4 + wave;
@@ -1231,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A_, const 
     }
     cur = nxt;
   }
-  if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_finish_px<4>(r, g, b, a, false, 0u);
+  if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_epi_px(E, s_lut, pb_finish_px<4>(r, g, b, a, false, 0u), i, j);
 }
 
 // =====================================================================================================================================================
@@ -1252,9 +1297,11 @@ struct PbUpArgs {
 
 // OPQ (lgpu_pixbuf_scale with LGPU_INTERP_OPAQUE: the caller states that every source pixel has alpha 255): the window holds the colour bytes as 16-bit pairs (one
 // v_perm per pair and channel, no alpha product), three dot products per pair, and the library's un-premultiply is T >> 16 (k_pb_pairs<.., OPQ>; pb_opaque_check)
-template <int NP, int NY, int OPQ = 0>
-__global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t *__restrict__ gp, const PbFrames F) {
+template <int NP, int NY, int OPQ = 0, typename EA = PbNoEpi>
+__global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t *__restrict__ gp, const PbFrames F, const EA E) {
   PB_FRAME_ARGS(PbUpArgs);
+  __shared__ uint8_t s_lut[pb_has_epi<EA>::value ? 256 : 4];
+  pb_epi_stage(s_lut, E);                              // (the barrier behind the weight table covers it)
   constexpr int RL = 2, PW = NY * RL;                  // dwords per tap row / per phase of the pair table (rows of 2 dwords for NP <= 2)
   __shared__ __attribute__((aligned(16))) uint32_t s_w[256 * PW];
   for (int e = threadIdx.x; e < 256 * PW; e += 256) s_w[e] = gp[e];
@@ -1336,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_pb_up(const PbUpArgs A_, const uint32_t
         r = pb_dot2(win[t][4 * k], ww, r); g = pb_dot2(win[t][4 * k + 1], ww, g); b = pb_dot2(win[t][4 * k + 2], ww, b);
         if (!OPQ) a = pb_dot2(win[t][4 * k + 3], ww, a);
       }
-    if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<4>(r, g, b, a, false, 0u);
+    if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_epi_px(E, s_lut, OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<4>(r, g, b, a, false, 0u), i, j);
   }
 }
 
@@ -1774,6 +1821,7 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
 // lgpu_chain / lgpu_chain_canvas.  One fused launch for the exact aligned 2:1 case on the pixbuf arithmetic (blur stage and letterbox canvas included); otherwise the
 // stages run one after the other through stream-ordered scratch frames: [bars] -> scale (into the canvas) -> [5x5 gaussian] -> [R <-> B] + chroma blend + gamma LUT.
 // The channel swap commutes with the scalers and the gaussian (all treat the three colour bytes alike), so it rides in the last kernel.
+int pb_scale_fused(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int irow, int sw, int sh, int orow, int dw, int dh, int interp, hipStream_t st, const PbEpi *epi);
 int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st, const uint8_t *amounts) {
   int rc;
   const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0;
@@ -1782,25 +1830,66 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
     if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: one-launch form rc %d (%s)\n", rc, rc ? lgpu_last_error() : "ok");
     if (rc != LGPU_E_UNSUPPORTED) return rc;
   }
+  // any other ratio, no gaussian, no canvas: the scaler of that ratio with the chain's last stages in its store -- one launch as well
+  // (a letterbox canvas: the scaled frame lands at its place in the canvas, its layer-2 pixels are the canvas's there, and the bars are one more small launch)
+  if (pixbuf && !pr->do_blur && !tune_on(TUNE_PB_CHAIN_GROUP)) {
+    PbEpi e;
+    PbTracks T;
+    const uint8_t *srcs[LGPU_CHAIN_MAX_TRACKS];
+    uint8_t *dsts[LGPU_CHAIN_MAX_TRACKS];
+    const size_t doff = cv ? (size_t)cv->offs_y * pr->orow + 4 * (size_t)cv->offs_x : 0, loff = cv ? (size_t)cv->offs_y * pr->irow2 + 4 * (size_t)cv->offs_x : 0;
+    for (int i = 0; i < ntracks; i++) {
+      srcs[i] = tracks[i].src_d; dsts[i] = tracks[i].dst_d + doff; e.l2[i] = tracks[i].layer2_d + loff; e.bf[i] = amounts ? amounts[i] : 0;
+      T.src[i] = nullptr; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; T.bf[i] = e.bf[i];
+    }
+    e.bf_d = amounts ? nullptr : pr->param_block_d; e.bf0 = (uint32_t)pr->bf & 0xFF; e.irow2 = pr->irow2; e.swap_rb = pr->swap_rb ? 1 : 0; e.use_lut = pr->use_lut ? 1 : 0;
+    e.bf_tracks = amounts ? 1 : 0; e.lut = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
+    rc = pb_scale_fused(srcs, dsts, ntracks, pr->irow, pr->sw, pr->sh, pr->orow, pr->dw, pr->dh, (pr->interp & 0xFF) | (pr->interp & LGPU_INTERP_OPAQUE), st, &e);
+    if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: scaler with the chain's last stages rc %d\n", rc);
+    if (rc == LGPU_OK && cv && (cv->nwidth != pr->dw || cv->nheight != pr->dh)) {
+      for (int i = 0; i < ntracks; i++) e.l2[i] = tracks[i].layer2_d;      // the bars read layer 2 at canvas coordinates
+      hipLaunchKernelGGL(k_pb_bars_epi, dim3(cdiv((unsigned)cv->nwidth, 64), cdiv((unsigned)cv->nheight, 4), (unsigned)ntracks), dim3(256), 0, st, T, e, pr->orow,
+                         cv->nwidth, cv->nheight, cv->offs_x, cv->offs_y, pr->dw, pr->dh);
+      if (hipGetLastError() != hipSuccess) { set_error("k_pb_bars_epi launch failed"); return LGPU_E_HIP; }
+    }
+    if (rc != PB_NOT_FUSED) return rc;
+  }
   const int interp = pr->interp & 0xFF;
   const int cw = cv ? cv->nwidth : pr->dw, ch = cv ? cv->nheight : pr->dh, ox = cv ? cv->offs_x : 0, oy = cv ? cv->offs_y : 0;
   const size_t per = (size_t)cw * 4 * ch;
+  // The tracks go through the stages in GROUPS (as many as fit 256 MB of scratch frames): the scaler serves a group in one launch (lgpu_pixbuf_scale_batch: the
+  // weight table, the launch and the ramp of a generation are paid once; 16 x 1080p -> 720p: 114 us against 16 x 11), and so does the last kernel.
+  int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)ntracks, ((size_t)256 << 20) / per));
+  if (tune(TUNE_PB_CHAIN_GROUP) >= 1) group = std::min(group, tune(TUNE_PB_CHAIN_GROUP));      // measurement: LGPU_PB_CHAIN_GROUP=1 is the track-by-track walk
   void *sa = nullptr, *sb = nullptr;
-  if ((rc = lgpu_malloc_ordered(&sa, per, st))) return rc;
-  if (pr->do_blur && (rc = lgpu_malloc_ordered(&sb, per, st))) { lgpu_free_ordered(sa, st); return rc; }
+  if ((rc = lgpu_malloc_ordered(&sa, per * group, st))) return rc;
+  if (pr->do_blur && (rc = lgpu_malloc_ordered(&sb, per * group, st))) { lgpu_free_ordered(sa, st); return rc; }
   const Lut8 l = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
   const uint8_t black[4] = {0, 0, 0, 255};
-  for (int i = 0; i < ntracks && !rc; i++) {
-    uint8_t *inner = (uint8_t *)sa + (size_t)oy * cw * 4 + (size_t)ox * 4;
-    if (cv) rc = lgpu_letterbox_bars((uint8_t *)sa, cw * 4, cw, ch, 4, black, ox, oy, pr->dw, pr->dh, st);
-    if (!rc) rc = pixbuf ? lgpu_pixbuf_scale(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp | (pr->interp & LGPU_INTERP_OPAQUE), st)
-                         : lgpu_resize(tracks[i].src_d, pr->irow, pr->sw, pr->sh, inner, cw * 4, pr->dw, pr->dh, 4, interp, nullptr, st);
+  for (int g0 = 0; g0 < ntracks && !rc; g0 += group) {
+    const int n = std::min(group, ntracks - g0);
+    const uint8_t *srcs[LGPU_CHAIN_MAX_TRACKS];
+    uint8_t *inner[LGPU_CHAIN_MAX_TRACKS];
+    PbTracks T;
+    for (int i = 0; i < n; i++) {
+      uint8_t *frame = (uint8_t *)sa + (size_t)i * per;
+      srcs[i] = tracks[g0 + i].src_d; inner[i] = frame + (size_t)oy * cw * 4 + (size_t)ox * 4;
+      T.src[i] = nullptr; T.l2[i] = tracks[g0 + i].layer2_d; T.dst[i] = tracks[g0 + i].dst_d; T.bf[i] = amounts ? amounts[g0 + i] : 0;
+      if (cv && !rc) rc = lgpu_letterbox_bars(frame, cw * 4, cw, ch, 4, black, ox, oy, pr->dw, pr->dh, st);
+    }
+    if (!rc) {
+      if (pixbuf) rc = lgpu_pixbuf_scale_batch(srcs, inner, n, pr->irow, pr->sw, pr->sh, cw * 4, pr->dw, pr->dh, 4, interp | (pr->interp & LGPU_INTERP_OPAQUE), st);
+      else for (int i = 0; i < n && !rc; i++) rc = lgpu_resize(srcs[i], pr->irow, pr->sw, pr->sh, inner[i], cw * 4, pr->dw, pr->dh, 4, interp, nullptr, st);
+    }
     const uint8_t *trk = (const uint8_t *)sa;
-    if (!rc && pr->do_blur) { rc = lgpu_gauss5((const uint8_t *)sa, cw * 4, (uint8_t *)sb, cw * 4, cw, ch, 4, st); trk = (const uint8_t *)sb; }
+    if (!rc && pr->do_blur) {
+      for (int i = 0; i < n && !rc; i++) rc = lgpu_gauss5((const uint8_t *)sa + (size_t)i * per, cw * 4, (uint8_t *)sb + (size_t)i * per, cw * 4, cw, ch, 4, st);
+      trk = (const uint8_t *)sb;
+    }
     if (rc) break;
-    hipLaunchKernelGGL(k_pb_epilogue, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4)), dim3(256), 0, st, trk, cw * 4, tracks[i].layer2_d, pr->irow2,
-                       tracks[i].dst_d, pr->orow, cw, ch, pr->swap_rb ? 1 : 0, amounts ? (uint32_t)amounts[i] : (uint32_t)pr->bf & 0xFF, amounts ? nullptr : pr->param_block_d, pr->use_lut ? 1 : 0, l);
-    if (hipGetLastError() != hipSuccess) { set_error("k_pb_epilogue launch failed"); rc = LGPU_E_HIP; }
+    hipLaunchKernelGGL(k_pb_epilogue_n, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4), (unsigned)n), dim3(256), 0, st, trk, per, cw * 4, T, amounts ? 1 : 0, pr->irow2,
+                       pr->orow, cw, ch, pr->swap_rb ? 1 : 0, (uint32_t)pr->bf & 0xFF, amounts ? nullptr : pr->param_block_d, pr->use_lut ? 1 : 0, l);
+    if (hipGetLastError() != hipSuccess) { set_error("k_pb_epilogue_n launch failed"); rc = LGPU_E_HIP; }
   }
   lgpu_free_ordered(sa, st);
   if (sb) lgpu_free_ordered(sb, st);
@@ -1879,7 +1968,9 @@ extern "C" int lgpu_pixbuf_weights(int interp, int sw, int sh, int dw, int dh, i
 }
 
 // n frames of one geometry in one launch of whichever kernel the geometry selects (n == 1: lgpu_pixbuf_scale)
-static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int irow, int sw, int sh, int orow, int dw, int dh, int channels, int interp, void *stream) {
+// epi: the chain's last stages in the store (PbEpi) -- served by the pair, gather and enlargement kernels; PB_NOT_FUSED (nothing launched) where another kernel has the ratio
+static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int irow, int sw, int sh, int orow, int dw, int dh, int channels, int interp, void *stream,
+                      const PbEpi *epi = nullptr) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(srcs && dsts && n >= 1 && n <= LGPU_CHAIN_MAX_TRACKS, "1..64 frames");
@@ -1902,6 +1993,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
   LGPU_REQUIRE(sw < 32768 && sh < 32768 && dw < 32768 && dh < 32768, "frame sides must stay below 32768 (16.16 positions)");
   if (channels == 4) LGPU_REQUIRE(((sbits | dbits | (unsigned)irow | (unsigned)orow) & 3) == 0, "4-byte pixels must be 4-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (epi && (channels != 4 || interp == 0 || (dw == sw && dh == sh))) return PB_NOT_FUSED;
   if (dw == sw && dh == sh) {                           // gdk_pixbuf_scale_simple: a plain copy
     for (int i = 0; i < n && !rc; i++) rc = lgpu_copy_rows(dsts[i], orow, srcs[i], irow, sw * channels, sh, stream);
     return rc;
@@ -1923,7 +2015,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
     if (rc == LGPU_E_UNSUPPORTED) set_error("lgpu_pixbuf_scale: %dx%d -> %dx%d needs %d x %d taps; the library's two-step scaler is not covered", sw, sh, dw, dh, t->n_x, t->n_y);
     return rc;
   }
-  if (channels == 4 && dw == 2 * sw && dh == 2 * sh && (sw & 1) == 0 && ((sbits | (unsigned)irow) & 7) == 0 && ((dbits | (unsigned)orow) & 15) == 0 &&
+  if (!epi && channels == 4 && dw == 2 * sw && dh == 2 * sh && (sw & 1) == 0 && ((sbits | (unsigned)irow) & 7) == 0 && ((dbits | (unsigned)orow) & 15) == 0 &&
       pb_double_ok(t, x_step, y_step) && !tune_on(TUNE_PB_NO_DOUBLE)) {
     PbHalfArgs h;
     h.sw = sw; h.sh = sh; h.irow = irow; h.dw = dw; h.dh = dh; h.orow = orow;
@@ -1947,7 +2039,7 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       return LGPU_OK;
     }
   }
-  if (channels == 4) {
+  if (channels == 4 && !epi) {
     PbHalfArgs h;
     if ((long long)sh * irow < (1ll << 31) && (long long)dh * orow < (1ll << 31) &&        // 32-bit buffer offsets in k_pb_half (see pb_chain_half)
         pb_half_ok(t, interp, sw, sh, dw, dh, sbits | (uintptr_t)irow, dbits | (uintptr_t)orow, &h.hyper, &h.ashift)) {
@@ -1983,7 +2075,8 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       const dim3 gu(cdiv(cdiv((unsigned)dw, 64), 4), cdiv((unsigned)dh, (unsigned)ua.rb), (unsigned)n);
       const uint32_t *gp = t->gpairs_d;
       if (opaque && (rc = pb_opaque_check())) return rc;
-#define PB_UP(NP_, NY_) { if (opaque) hipLaunchKernelGGL((k_pb_up<NP_, NY_, 1>), gu, block, 0, st, ua, gp, F); else hipLaunchKernelGGL((k_pb_up<NP_, NY_, 0>), gu, block, 0, st, ua, gp, F); }
+#define PB_UP(NP_, NY_) { if (epi) { if (opaque) hipLaunchKernelGGL((k_pb_up<NP_, NY_, 1, PbEpi>), gu, block, 0, st, ua, gp, F, *epi); else hipLaunchKernelGGL((k_pb_up<NP_, NY_, 0, PbEpi>), gu, block, 0, st, ua, gp, F, *epi); } \
+                          else if (opaque) hipLaunchKernelGGL((k_pb_up<NP_, NY_, 1, PbNoEpi>), gu, block, 0, st, ua, gp, F, PbNoEpi{}); else hipLaunchKernelGGL((k_pb_up<NP_, NY_, 0, PbNoEpi>), gu, block, 0, st, ua, gp, F, PbNoEpi{}); }
       if (unp == 1) { if (uny == 1) PB_UP(1, 1) else if (uny == 2) PB_UP(1, 2) else if (uny == 3) PB_UP(1, 3) else PB_UP(1, 4) }
       else { if (uny == 1) PB_UP(2, 1) else if (uny == 2) PB_UP(2, 2) else if (uny == 3) PB_UP(2, 3) else PB_UP(2, 4) }
 #undef PB_UP
@@ -1998,10 +2091,9 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
     ga.x_step = x_step; ga.y_step = y_step; ga.xoff = t->xoff; ga.yoff = t->yoff; ga.tx0 = t->tx0; ga.ty0 = t->ty0; ga.ny_eff = t->ty1 - t->ty0;
     const int gnp = (t->tx1 - t->tx0 + 1) / 2;
     const uint32_t *gp = t->gpairs_d;
-    if (gnp == 1) hipLaunchKernelGGL(k_pb_gather<1>, grid, block, 0, st, ga, gp, F);
-    else if (gnp == 2) hipLaunchKernelGGL(k_pb_gather<2>, grid, block, 0, st, ga, gp, F);
-    else if (gnp == 3) hipLaunchKernelGGL(k_pb_gather<3>, grid, block, 0, st, ga, gp, F);
-    else hipLaunchKernelGGL(k_pb_gather<4>, grid, block, 0, st, ga, gp, F);
+#define PB_GATHER(NP_) { if (epi) hipLaunchKernelGGL((k_pb_gather<NP_, PbEpi>), grid, block, 0, st, ga, gp, F, *epi); else hipLaunchKernelGGL((k_pb_gather<NP_, PbNoEpi>), grid, block, 0, st, ga, gp, F, PbNoEpi{}); }
+    if (gnp == 1) PB_GATHER(1) else if (gnp == 2) PB_GATHER(2) else if (gnp == 3) PB_GATHER(3) else PB_GATHER(4)
+#undef PB_GATHER
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
   }
@@ -2030,28 +2122,31 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
       if (tune(TUNE_PB_TILE_ORDER) != 0 && g.x * g.y >= 64) { pa.per_xcd = (int)cdiv(g.x * g.y, 8u); g = dim3(8u * (unsigned)pa.per_xcd, 1, (unsigned)n); }
       const size_t lds = (size_t)pa.wpairs * pa.win_h * 16;
       const int np = (t->tx1 - t->tx0 + 2) / 2;
-#define PB_PRE(CHN, NP_, NY_, OQ) { if (pa.tile_h <= 4) hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 1, OQ>), g, block, lds, st, pa, F); else hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 0, OQ>), g, block, lds, st, pa, F); }
-#define PB_PAIRS(CHN, OQ)                                                                                                 \
+#define PB_PRE(CHN, NP_, NY_, OQ, EAT, EAV) { if (pa.tile_h <= 4) hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 1, OQ, EAT>), g, block, lds, st, pa, F, EAV); else hipLaunchKernelGGL((k_pb_pairs<CHN, NP_, NY_, 0, OQ, EAT>), g, block, lds, st, pa, F, EAV); }
+#define PB_PAIRS(CHN, OQ, EAT, EAV)                                                                                       \
       { const int ny = t->ty1 - t->ty0;                                                                                   \
         const bool pre = !tune_on(TUNE_PB_NO_PRE);                                                                          \
-        if (np == 2 && ny == 2) PB_PRE(CHN, 2, 2, OQ)                                                                        \
-        else if (np == 2 && ny == 3) PB_PRE(CHN, 2, 3, OQ)                                                                   \
-        else if (np == 3 && ny == 3) PB_PRE(CHN, 3, 3, OQ)                                                                   \
-        else if (pre && np == 3 && ny == 4) PB_PRE(CHN, 3, 4, OQ)                                                            \
-        else if (pre && np == 3 && ny == 5) PB_PRE(CHN, 3, 5, OQ)                                                            \
-        else if (pre && np == 4 && ny == 6) PB_PRE(CHN, 4, 6, OQ)                                                            \
-        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
-        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
-        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
-        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0, 0, OQ>), g, block, lds, st, pa, F);                      \
-        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0, 0, OQ>), g, block, lds, st, pa, F); }
-      if (channels == 4 && opaque) { if ((rc = pb_opaque_check())) return rc; PB_PAIRS(4, 1) } else if (channels == 4) { PB_PAIRS(4, 0) } else { PB_PAIRS(3, 0) }
+        if (np == 2 && ny == 2) PB_PRE(CHN, 2, 2, OQ, EAT, EAV)                                                              \
+        else if (np == 2 && ny == 3) PB_PRE(CHN, 2, 3, OQ, EAT, EAV)                                                         \
+        else if (np == 3 && ny == 3) PB_PRE(CHN, 3, 3, OQ, EAT, EAV)                                                         \
+        else if (pre && np == 3 && ny == 4) PB_PRE(CHN, 3, 4, OQ, EAT, EAV)                                                  \
+        else if (pre && np == 3 && ny == 5) PB_PRE(CHN, 3, 5, OQ, EAT, EAV)                                                  \
+        else if (pre && np == 4 && ny == 6) PB_PRE(CHN, 4, 6, OQ, EAT, EAV)                                                  \
+        else if (np == 1) hipLaunchKernelGGL((k_pb_pairs<CHN, 1, 0, 0, OQ, EAT>), g, block, lds, st, pa, F, EAV);            \
+        else if (np == 2) hipLaunchKernelGGL((k_pb_pairs<CHN, 2, 0, 0, OQ, EAT>), g, block, lds, st, pa, F, EAV);            \
+        else if (np == 3) hipLaunchKernelGGL((k_pb_pairs<CHN, 3, 0, 0, OQ, EAT>), g, block, lds, st, pa, F, EAV);            \
+        else if (np == 4) hipLaunchKernelGGL((k_pb_pairs<CHN, 4, 0, 0, OQ, EAT>), g, block, lds, st, pa, F, EAV);            \
+        else hipLaunchKernelGGL((k_pb_pairs<CHN, 0, 0, 0, OQ, EAT>), g, block, lds, st, pa, F, EAV); }
+      if (channels == 4 && opaque && (rc = pb_opaque_check())) return rc;
+      if (epi) { if (opaque) { PB_PAIRS(4, 1, PbEpi, *epi) } else { PB_PAIRS(4, 0, PbEpi, *epi) } }
+      else if (channels == 4 && opaque) { PB_PAIRS(4, 1, PbNoEpi, PbNoEpi{}) } else if (channels == 4) { PB_PAIRS(4, 0, PbNoEpi, PbNoEpi{}) } else { PB_PAIRS(3, 0, PbNoEpi, PbNoEpi{}) }
 #undef PB_PAIRS
 #undef PB_PRE
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
   }
+  if (epi) return PB_NOT_FUSED;
   PbArgs a;
   a.src = src_d; a.dst = dst_d; a.irow = irow; a.orow = orow; a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
   a.x_step = x_step; a.y_step = y_step; a.xoff = t->xoff; a.yoff = t->yoff; a.n_x = t->n_x; a.n_y = t->n_y; a.table = t->table_d;
@@ -2085,6 +2180,9 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
 // what lgpu_pixbuf_scale would answer for this geometry, without launching anything (the weight table is built and cached on the way, so the scale that follows
 // finds it): LGPU_OK, LGPU_E_BADARG, or LGPU_E_UNSUPPORTED for a reduction past the library's one-step range.  The layer seam asks before it records a scale
 // for later (deferred execution, layer_seam.cpp): a recorded call must not turn into a refusal.
+int lgpu::pb_scale_fused(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int irow, int sw, int sh, int orow, int dw, int dh, int interp, hipStream_t st, const PbEpi *epi) {
+  return pb_scale_n(srcs, dsts, n, irow, sw, sh, orow, dw, dh, 4, interp, (void *)st, epi);
+}
 extern "C" int lgpu_pixbuf_scale_check(int sw, int sh, int dw, int dh, int channels, int interp, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;

@@ -445,7 +445,11 @@ def test_chain_with_a_letterbox_canvas(gpu, orc):
     cases = [  # sw, sh, dw, dh, nw, nh, ox, oy, interp flags, swap, bf, use lut, tracks
         (256, 144, 128, 72, 128, 80, 0, 4, 0x103, 0, 128, 0, 1), (256, 144, 128, 72, 160, 100, 16, 14, 0x103, 1, 77, 1, 2), (512, 40, 256, 20, 300, 21, 44, 1, 0x102, 1, 200, 1, 1),
         (256, 144, 128, 72, 131, 75, 3, 2, 0x103, 1, 99, 1, 1),          # odd offs_x: staged
-        (300, 200, 128, 72, 160, 90, 16, 9, 0x103, 0, 128, 1, 1),         # not 2:1: staged
+        (300, 200, 128, 72, 160, 90, 16, 9, 0x103, 0, 128, 1, 1),         # not 2:1: the pair kernel with the chain's last stages in its store + the bars launch
+        (300, 200, 128, 72, 161, 91, 17, 10, 0x102, 1, 40, 1, 3),        # the same, BILINEAR, odd offsets, three tracks
+        (96, 54, 200, 112, 210, 120, 5, 4, 0x103, 1, 201, 1, 2),          # enlargement (k_pb_up) into a canvas
+        (384, 216, 128, 72, 128, 96, 0, 12, 0x103, 0, 128, 0, 2),         # 3:1 (k_pb_gather) into a canvas
+        (384, 216, 128, 72, 128, 72, 0, 0, 0x103, 1, 17, 1, 2),           # canvas == frame: no bars
         (256, 144, 128, 72, 160, 100, 16, 14, 3, 1, 77, 1, 2)]            # polyphase backend: staged
     for (sw, sh, dw, dh, nw, nh, ox, oy, itp, swap, bf, use_lut, ntr) in cases:
         srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(ntr)]
