@@ -391,6 +391,8 @@ int lgpu_mirror(int mode, const uint8_t *src_d, int irow, uint8_t *dst_d, int or
                                       lighter instantiations with the same bytes run: the gaussian chain (do_blur, exact 2:1; lgpu_chain) and the two-dimensional
                                       filters of every other ratio (lgpu_pixbuf_scale[_batch], channels 4: pass interp | LGPU_INTERP_OPAQUE); ignored elsewhere.
                                       A frame that is not opaque gets wrong colours: state it only when known. */
+#define LGPU_INTERP_NOBLEND 0x400  /* lgpu_chain_amounts only: the track has no layer 2 -- [R <-> B] -> scale [-> letterbox] -> gamma LUT, the plan steps of a track that is not
+                                      blended with anything (layer2_d, irow2 and amounts are not read).  One launch like the blended form. */
 typedef struct {
   const uint8_t *src_d;      /* sw x sh, 4 bytes / pixel */
   const uint8_t *layer2_d;   /* dw x dh, RGBA32 */

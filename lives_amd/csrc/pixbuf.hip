@@ -371,6 +371,8 @@ __device__ __forceinline__ void pb_half_colours(uint32_t v0, uint32_t v1, uint32
 // Memory operations are buffer loads / stores: one 128-bit descriptor per frame in SGPRs (built once per wave from uniform values), the row as the scalar offset,
 // the lane's place in the row as a constant 32-bit VGPR offset -- no address arithmetic on the vector unit at all; lanes that must not store carry an offset beyond
 // the descriptor's range and the hardware drops their store (no exec-mask branch per row).
+// CHAIN: 0 the scaler alone; 1 [R <-> B] -> scale -> chroma blend with layer 2 -> gamma LUT; 2 the same without a layer 2 (LGPU_INTERP_NOBLEND: a track that is
+// not blended with anything -- no layer-2 loads, no blend arithmetic)
 template <int CHAIN, int HYPER, int BLUR, int ALIGNED = 0, int SWAP = 0, int OPAQUE = 0>
 __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTracks T, const Lut8 lut) {
   // the gamma LUT and the blend's alpha scalers.  ONE copy per workgroup, but no workgroup barrier on the frame path: every wave writes the whole of both tables
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       if (p < top) { y = p / A.cw; x = p - y * A.cw; }
       else if (p < top + bottom) { p -= top; y = p / A.cw; x = p - y * A.cw; y += A.oy + A.dh; }
       else { p -= top + bottom; y = p / sw_; x = p - y * sw_; y += A.oy; if (x >= A.ox) x += A.dw; }
+      if (CHAIN == 2) { const uint32_t c = s_lut[0]; reinterpret_cast<uint32_t *>(T.dst[track] + (size_t)y * A.orow)[x] = c * 0x010101u | 0xFF000000u; continue; }
       const uint32_t q = reinterpret_cast<const uint32_t *>(T.l2[track] + (size_t)y * A.irow2)[x];
       const pb_u2 kk = s_k[q >> 24];
       const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   const int out_rows = A.cw ? A.ch : A.dh;
   const __amdgpu_buffer_rsrc_t r_src = srd(T.src[track], (uint32_t)A.sh * (uint32_t)A.irow);
   const __amdgpu_buffer_rsrc_t r_dst = srd(T.dst[track], (uint32_t)out_rows * (uint32_t)A.orow);
-  const __amdgpu_buffer_rsrc_t r_l2 = srd(CHAIN ? (const void *)T.l2[track] : (const void *)T.src[track], CHAIN ? (uint32_t)out_rows * (uint32_t)A.irow2 : 16u);
+  const __amdgpu_buffer_rsrc_t r_l2 = srd(CHAIN == 1 ? (const void *)T.l2[track] : (const void *)T.src[track], CHAIN == 1 ? (uint32_t)out_rows * (uint32_t)A.irow2 : 16u);
   const uint32_t lane_off = fastp ? (k < 0 ? 4u : k > kmax ? 16u * (uint32_t)(kmax + 1) + 12u : 16u * (uint32_t)(k + 1)) : 16u * (uint32_t)kc;
   const int row_adj = __builtin_amdgcn_readfirstlane(fastp ? -16 : 0);      // fastp: the lane offsets are written against 16 bytes before the row
   auto load_row = [&](int sy) -> pb_u4 {
@@ -511,15 +514,15 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   // s1 = (track colour * K1[alpha2]) >> 16 (the reference's float scaling of translucent pixels as integers, lgpu_alpha_scalers; alpha 255 = identity), then
   // (bf * s2 + (255 - bf) * s1) >> 8, then the gamma LUT (the identity table when the chain has none)
   auto finish = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t al, uint32_t q) -> uint32_t {
-    if (CHAIN) {
+    if (CHAIN == 1) {
       const pb_u2 kk = s_k[q >> 24];
       const uint32_t qa_ = __umul24(q & 0xFF, kk.x), qb_ = __umul24((q >> 8) & 0xFF, kk.x), qc_ = __umul24((q >> 16) & 0xFF, kk.x);
       const uint32_t pa = __umul24(c0, kk.y), pb = __umul24(c1, kk.y), pc = __umul24(c2, kk.y);
       c0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pa, qa_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
       c1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pb, qb_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
       c2 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(pc, qc_, 0x0C0C0602u), w_lo, 0u, false) >> 8;
-      c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2];
     }
+    if (CHAIN) { c0 = s_lut[c0]; c1 = s_lut[c1]; c2 = s_lut[c2]; }
     return c0 | (c1 << 8) | (c2 << 16) | al;
   };
   const uint32_t st_off = out_lane ? 8u * (uint32_t)k + 4u * (uint32_t)A.ox : 0xFFFFFFF0u;      // beyond the descriptor's range: the hardware drops the store
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
   uint32_t e0 = load_e(S0), e1 = load_e(S0 + d), ea = load_e(S0 + 2 * d), eb = load_e(S0 + 3 * d);
   pb_u2 l2;
   l2.x = 0; l2.y = 0;
-  if (CHAIN && !fastp) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
+  if (CHAIN == 1 && !fastp) l2 = load_l2(d > 0 ? y0 : y0 + rows - 1);
   if (CHAIN) {        // the two small tables, requested while the first source rows are in flight; first read an output row later
     reinterpret_cast<uint32_t *>(s_lut)[lane] = lut.w[lane];
 #pragma unroll
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       if (r + 1 < rows) {       // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
         xa = load_row(S0 + d * (2 * r + 4)); xb = load_row(S0 + d * (2 * r + 5));
         xea = load_e(S0 + d * (2 * r + 4)); xeb = load_e(S0 + d * (2 * r + 5));
-        if (CHAIN) xl2 = load_l2(yy + d);
+        if (CHAIN == 1) xl2 = load_l2(yy + d);
       }
       uint32_t cc[2][3], al[2];
       scale_row(ca, cb, cea, ceb, cc, al);
@@ -715,13 +718,13 @@ __global__ __launch_bounds__(256) void k_pb_half(const PbHalfArgs A, const PbTra
       if (yy != produced) {
         // the next scaled row's two new source rows and the layer-2 pixels of the next output row: in flight during this row's arithmetic
         const int r = d > 0 ? yy - ystart : ystart - yy;
-        if (CHAIN) nl2 = load_l2(vr - d);
+        if (CHAIN == 1) nl2 = load_l2(vr - d);
         scale_row(qa, qb, 0u, 0u, cc, al);
         qa = load_row(S0 + d * (2 * r + 4)); qb = load_row(S0 + d * (2 * r + 5));       // into the registers just read (these two bands per track are not where the time goes)
         produced = yy;
         hblur(cc, al, ring[u]);
       } else {          // a row beyond the frame's first / last: the border row again
-        if (CHAIN) nl2 = load_l2(vr - d);
+        if (CHAIN == 1) nl2 = load_l2(vr - d);
 #pragma unroll
         for (int i = 0; i < 4; i++) ring[u][i] = ring[(u + 4) % 5][i];
       }
@@ -942,7 +945,7 @@ struct PbEpi {
   uint8_t bf[LGPU_CHAIN_MAX_TRACKS];           // bf_tracks: a blend amount per frame
   const int32_t *bf_d;                         // else, when set: the amount's low byte read on the device
   uint32_t bf0;
-  int irow2, swap_rb, use_lut, bf_tracks;
+  int irow2, swap_rb, use_lut, bf_tracks, blend;        // blend 0: no layer 2 (LGPU_INTERP_NOBLEND)
   Lut8 lut;
 };
 template <typename EA> struct pb_has_epi { static constexpr bool value = true; };
@@ -954,7 +957,7 @@ __device__ __forceinline__ uint32_t pb_epi_px(const PbEpi &E, const uint8_t *s_l
   const int z = blockIdx.z;
   const uint32_t bf = E.bf_tracks ? (uint32_t)E.bf[z] : E.bf_d ? ((uint32_t)E.bf_d[0] & 0xFF) : E.bf0;
   if (E.swap_rb) px = __builtin_amdgcn_perm(px, px, 0x03000102u);
-  px = pb_chroma_rgba(px, reinterpret_cast<const uint32_t *>(E.l2[z] + (size_t)i * E.irow2)[j], bf, 255u - bf);
+  if (E.blend) px = pb_chroma_rgba(px, reinterpret_cast<const uint32_t *>(E.l2[z] + (size_t)i * E.irow2)[j], bf, 255u - bf);
   if (E.use_lut) px = lut3_rgba(s_lut, px);
   return px;
 }
@@ -981,10 +984,10 @@ __global__ __launch_bounds__(256) void k_pb_epilogue_n(const uint8_t *scratch, s
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
   if (x >= width || y >= height) return;
   if (bf_d) bf = (uint32_t)bf_d[0] & 0xFF;
-  if (bf_tracks) bf = T.bf[z];
+  if (bf_tracks & 1) bf = T.bf[z];
   uint32_t p = reinterpret_cast<const uint32_t *>(scratch + (size_t)z * per + (size_t)y * irow)[x];
   if (swap_rb) p = __builtin_amdgcn_perm(p, p, 0x03000102u);
-  p = pb_chroma_rgba(p, reinterpret_cast<const uint32_t *>(T.l2[z] + (size_t)y * irow2)[x], bf, 255u - bf);
+  if (!(bf_tracks & 2)) p = pb_chroma_rgba(p, reinterpret_cast<const uint32_t *>(T.l2[z] + (size_t)y * irow2)[x], bf, 255u - bf);      // (bit 1: no layer 2)
   if (use_lut) p = lut3_rgba(s_lut, p);
   reinterpret_cast<uint32_t *>(T.dst[z] + (size_t)y * orow)[x] = p;
 }
@@ -1796,8 +1799,10 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
   int occ = (!pr->do_blur && (long long)a.cgroups * a.bands * ntracks > (long long)device_cus() * 8) ? 5 : 0;
   if (tune(TUNE_PBH_OCC) >= 0) occ = tune(TUNE_PBH_OCC);
   const size_t occ_lds = occ > 0 && occ < 16 ? (size_t)(160 * 1024) / (size_t)occ - 3072 : 0;
-#define PBH_LAUNCH(HY, BL, AL, SW) hipLaunchKernelGGL((k_pb_half<1, HY, BL, AL, SW>), grid, dim3(256), occ_lds, st, a, T, l)
-#define PBH_SWAP(HY, BL, AL) do { if (a.swap_rb) PBH_LAUNCH(HY, BL, AL, 1); else PBH_LAUNCH(HY, BL, AL, 0); } while (0)
+  const bool noblend = (pr->interp & LGPU_INTERP_NOBLEND) != 0;        // (never with the gaussian: pb_chain keeps that pair staged)
+#define PBH_LAUNCH(HY, BL, AL, SW) { if (noblend && !(BL)) hipLaunchKernelGGL((k_pb_half<(BL) ? 1 : 2, HY, BL, AL, SW>), grid, dim3(256), occ_lds, st, a, T, l); \
+                                     else hipLaunchKernelGGL((k_pb_half<1, HY, BL, AL, SW>), grid, dim3(256), occ_lds, st, a, T, l); }
+#define PBH_SWAP(HY, BL, AL) do { if (a.swap_rb) PBH_LAUNCH(HY, BL, AL, 1) else PBH_LAUNCH(HY, BL, AL, 0) } while (0)
 #define PBH_OPAQUE(HY, SW) hipLaunchKernelGGL((k_pb_half<1, HY, 1, 0, SW, 1>), grid, dim3(256), occ_lds, st, a, T, l)
   if (pr->do_blur && (pr->interp & LGPU_INTERP_OPAQUE)) {
     // the caller's word that every source pixel is opaque: the vector-bound gaussian chain sheds a quarter of its instructions (pb_half_hrow)
@@ -1824,8 +1829,8 @@ int pb_chain_half(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu
 int pb_scale_fused(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int irow, int sw, int sh, int orow, int dw, int dh, int interp, hipStream_t st, const PbEpi *epi);
 int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st, const uint8_t *amounts) {
   int rc;
-  const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0;
-  if (pixbuf && !(cv && pr->do_blur)) {
+  const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0, noblend = (pr->interp & LGPU_INTERP_NOBLEND) != 0;
+  if (pixbuf && !(cv && pr->do_blur) && !(noblend && pr->do_blur)) {
     rc = pb_chain_half(pr, cv, tracks, ntracks, st, amounts);         // one launch
     if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: one-launch form rc %d (%s)\n", rc, rc ? lgpu_last_error() : "ok");
     if (rc != LGPU_E_UNSUPPORTED) return rc;
@@ -1843,7 +1848,7 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
       T.src[i] = nullptr; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; T.bf[i] = e.bf[i];
     }
     e.bf_d = amounts ? nullptr : pr->param_block_d; e.bf0 = (uint32_t)pr->bf & 0xFF; e.irow2 = pr->irow2; e.swap_rb = pr->swap_rb ? 1 : 0; e.use_lut = pr->use_lut ? 1 : 0;
-    e.bf_tracks = amounts ? 1 : 0; e.lut = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
+    e.bf_tracks = amounts ? 1 : 0; e.blend = noblend ? 0 : 1; e.lut = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
     rc = pb_scale_fused(srcs, dsts, ntracks, pr->irow, pr->sw, pr->sh, pr->orow, pr->dw, pr->dh, (pr->interp & 0xFF) | (pr->interp & LGPU_INTERP_OPAQUE), st, &e);
     if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: scaler with the chain's last stages rc %d\n", rc);
     if (rc == LGPU_OK && cv && (cv->nwidth != pr->dw || cv->nheight != pr->dh)) {
@@ -1887,7 +1892,7 @@ int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chai
       trk = (const uint8_t *)sb;
     }
     if (rc) break;
-    hipLaunchKernelGGL(k_pb_epilogue_n, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4), (unsigned)n), dim3(256), 0, st, trk, per, cw * 4, T, amounts ? 1 : 0, pr->irow2,
+    hipLaunchKernelGGL(k_pb_epilogue_n, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4), (unsigned)n), dim3(256), 0, st, trk, per, cw * 4, T, (amounts ? 1 : 0) | (noblend ? 2 : 0), pr->irow2,
                        pr->orow, cw, ch, pr->swap_rb ? 1 : 0, (uint32_t)pr->bf & 0xFF, amounts ? nullptr : pr->param_block_d, pr->use_lut ? 1 : 0, l);
     if (hipGetLastError() != hipSuccess) { set_error("k_pb_epilogue_n launch failed"); rc = LGPU_E_HIP; }
   }
@@ -2236,9 +2241,18 @@ extern "C" int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_can
 extern "C" int lgpu_chain_amounts(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, const uint8_t *amounts, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  LGPU_REQUIRE(params && amounts && (params->interp & LGPU_INTERP_PIXBUF), "lgpu_chain_amounts serves the gdk-pixbuf arithmetic (LGPU_INTERP_PIXBUF)");
+  LGPU_REQUIRE(params && (params->interp & LGPU_INTERP_PIXBUF), "lgpu_chain_amounts serves the gdk-pixbuf arithmetic (LGPU_INTERP_PIXBUF)");
+  const bool noblend = (params->interp & LGPU_INTERP_NOBLEND) != 0;
+  LGPU_REQUIRE(amounts || noblend, "null amounts");
   lgpu_chain_params p0 = *params;
   p0.param_block_d = nullptr;
+  lgpu_chain_track tr[LGPU_CHAIN_MAX_TRACKS];
+  if (noblend) {
+    // no layer 2: the checks below see the destination in its place (same alignment and geometry rules), the kernels never read it
+    LGPU_REQUIRE(tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
+    for (int i = 0; i < ntracks; i++) { tr[i] = tracks[i]; tr[i].layer2_d = tracks[i].dst_d; }
+    tracks = tr; p0.irow2 = p0.orow; amounts = nullptr;
+  }
   if (canvas) return chain_canvas_impl(&p0, canvas, tracks, ntracks, stream, amounts);
   if ((rc = lgpu_chain_check(&p0, tracks, ntracks))) return rc;
   return pb_chain(&p0, nullptr, tracks, ntracks, (hipStream_t)stream, amounts);

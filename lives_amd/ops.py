@@ -372,7 +372,7 @@ def chain_tracks(srcs, layer2s, dsts):
     n = len(srcs)
     arr = (lib.ChainTrack * n)()
     for i in range(n):
-        arr[i].src_d, arr[i].layer2_d, arr[i].dst_d = srcs[i].data_ptr(), layer2s[i].data_ptr(), dsts[i].data_ptr()
+        arr[i].src_d, arr[i].layer2_d, arr[i].dst_d = srcs[i].data_ptr(), (layer2s[i].data_ptr() if layer2s is not None else None), dsts[i].data_ptr()
     return arr
 
 
@@ -387,7 +387,7 @@ def chain_canvas(params, tracks, nwidth, nheight, offs_x, offs_y):
 
 def chain_amounts(params, tracks, amounts, canvas=None):
     """lgpu_chain_amounts: the chain with a blend amount per track; canvas = (nwidth, nheight, offs_x, offs_y) or None"""
-    am = (ctypes.c_uint8 * len(tracks))(*[int(a) & 0xFF for a in amounts])
+    am = (ctypes.c_uint8 * len(tracks))(*[int(a) & 0xFF for a in amounts]) if amounts is not None else None      # None: with LGPU_INTERP_NOBLEND (0x400) in params.interp
     cv = lib.Canvas(*canvas) if canvas is not None else None
     lib.call("lgpu_chain_amounts", ctypes.byref(params), ctypes.byref(cv) if cv is not None else None, tracks, len(tracks), am, stream_ptr())
 

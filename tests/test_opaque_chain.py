@@ -123,3 +123,44 @@ def test_a_blend_amount_per_track(gpu, orc, case):
             want = np.zeros((dh, dw * 4), np.uint8)
             assert orc.orc_chain(P(srcs[i]), sw * 4, sw, sh, P(l2s[i]), dw * 4, P(want), dw * 4, dw, dh, 1, 3 | PIXBUF, blur, amounts[i], P(lut)) == 0
             assert (got[i] == want).all(), i
+
+
+NOBLEND = 0x400
+
+
+@pytest.mark.parametrize("case", [(256, 144, 128, 72, None), (200, 120, 133, 80, None), (96, 54, 200, 112, None), (384, 216, 128, 72, None),
+                                  (256, 144, 128, 72, (160, 100, 16, 14)), (200, 120, 133, 80, (150, 90, 9, 5)), (96, 54, 200, 112, (210, 120, 5, 4))])
+@pytest.mark.parametrize("interp", [3, 2, 0])
+def test_a_track_without_a_layer_2(gpu, orc, case, interp):
+    """lgpu_chain_amounts with LGPU_INTERP_NOBLEND: [R <-> B] -> gdk-pixbuf scale [-> letterbox] -> gamma LUT in one launch (every ratio: the exact 2:1, the pair
+    kernel's, an enlargement, 3:1; NEAREST goes the staged way) == the oracle's stages one after the other"""
+    sw, sh, dw, dh, canvas = case
+    rng = np.random.default_rng(0x0FD0 + sw + dw + interp)
+    n = 3
+    cw, ch = (canvas[0], canvas[1]) if canvas else (dw, dh)
+    srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(n)]
+    lut = rng.permutation(256).astype(np.uint8)
+    d_s = [dev(a) for a in srcs]
+    for swap, use_lut in ((1, True), (0, False), (0, True)):
+        d_o = [dev(np.full((ch, cw * 4), 0x5A, np.uint8)) for _ in range(n)]
+        prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, cw * 4, cw * 4, swap_rb=swap, interp=interp | PIXBUF | NOBLEND, do_blur=0, bf=0, lut=lut if use_lut else None)
+        gpu.chain_amounts(prm, gpu.chain_tracks(d_s, None, d_o), None, canvas)
+        for i in range(n):
+            conv = np.zeros((sh, sw * 4), np.uint8)
+            if swap:
+                orc.orc_swizzle(po.OPS.index("swap3postalpha"), 0, P(srcs[i]), sw * 4, P(conv), sw * 4, sw, sh, None)
+            else:
+                conv[:] = srcs[i]
+            want = np.zeros((dh, dw * 4), np.uint8)
+            assert orc.orc_pixbuf_scale(P(conv), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, interp) == 0
+            if canvas:
+                big = np.zeros((ch, cw * 4), np.uint8)
+                inner = np.zeros((ch, cw * 4), np.uint8)
+                inner[:, 3::4] = 255                                            # opaque black bars
+                inner[canvas[3]:canvas[3] + dh, canvas[2] * 4:(canvas[2] + dw) * 4] = want
+                big[:] = inner
+                want = big
+            if use_lut:
+                orc.orc_gamma_apply(P(want), want.strides[0], want.shape[1] // 4, want.shape[0], 4, 0, P(lut))
+            got = host(d_o[i])
+            assert (got == want).all(), "track %d swap %d lut %s: %d bytes differ" % (i, swap, use_lut, int((got != want).sum()))

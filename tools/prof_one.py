@@ -146,7 +146,10 @@ def case(op):
         delta = float(os.environ.get("C4_DELTA", "0.3"))
         return (lambda i: ops.gauss5_colorkey(a[i % NB], b[i % NB], o[i % NB], W, H, ps, 0, delta, 0.8, (128, 128, 128))), W * H * ps * 3
     if op.startswith("chg"):           # chgN:SWxSH:DWxDH -- the chain (R <-> B, gdk-pixbuf HYPER scale, chroma blend, gamma LUT) on N tracks of any geometry: the staged form off 2:1
-        parts = op.split(":")            # chgN:SWxSH:DWxDH[:CWxCH]: with a letterbox canvas the scaled frame is centred on it
+        parts = op.split(":")            # chgN:SWxSH:DWxDH[:CWxCH][:nb]: with a letterbox canvas the scaled frame is centred on it; nb: no layer 2 (LGPU_INTERP_NOBLEND)
+        nbl = parts[-1] == "nb"
+        if nbl:
+            parts = parts[:-1]
         head, a_, b_ = parts[:3]
         n = int(head[3:])
         sw, sh = (int(v) for v in a_.split("x"))
@@ -154,13 +157,16 @@ def case(op):
         cw, ch = (int(v) for v in parts[3].split("x")) if len(parts) > 3 else (dw, dh)
         nb = 2 if not COLD else max(2, NB // n + 1)
         lut = np.arange(256, dtype=np.uint8)[::-1].copy()
-        prm = ops.chain_params(sw, sh, sw * 4, dw, dh, cw * 4, cw * 4, swap_rb=1, interp=3 | 0x100, do_blur=0, bf=128, lut=lut)
+        prm = ops.chain_params(sw, sh, sw * 4, dw, dh, cw * 4, cw * 4, swap_rb=1, interp=3 | 0x100 | (0x400 if nbl else 0), do_blur=0, bf=128, lut=lut)
         sets = []
         for _ in range(nb):
             srcs = [torch.randint(0, 256, (sh, sw * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
             l2s = [torch.randint(0, 256, (ch, cw * 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(n)]
             ds = [torch.zeros_like(t) for t in l2s]
             sets.append((ops.chain_tracks(srcs, l2s, ds), srcs, l2s, ds))
+        if nbl:
+            cvs = (cw, ch, (cw - dw + 1) >> 1, (ch - dh + 1) >> 1) if len(parts) > 3 else None
+            return (lambda i: ops.chain_amounts(prm, sets[i % nb][0], None, cvs)), n * (sw * sh * 4 + cw * ch * 4)
         if len(parts) > 3:
             return (lambda i: ops.chain_canvas(prm, sets[i % nb][0], cw, ch, (cw - dw + 1) >> 1, (ch - dh + 1) >> 1)), n * (sw * sh * 4 + 2 * cw * ch * 4)
         return (lambda i: ops.chain(prm, sets[i % nb][0])), n * (sw * sh * 4 + 2 * dw * dh * 4)
