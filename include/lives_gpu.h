@@ -421,7 +421,9 @@ typedef struct { int nwidth, nheight, offs_x, offs_y; } lgpu_canvas;
 int lgpu_chain_canvas(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream);
 /* lgpu_chain / lgpu_chain_canvas (canvas may be NULL) on the gdk-pixbuf arithmetic with a blend amount PER TRACK (amounts[ntracks], 0..255; params->bf and
    params->param_block_d are not used): the tracks of a tick share geometry and gamma table, not necessarily their transition amount -- still one launch.  What
-   lives_gpu_layers_flush() emits for the recorded plan steps of a tick (lives_gpu_layer.h). */
+   lives_gpu_layers_flush() emits for the recorded plan steps of a tick (lives_gpu_layer.h).  Two more shapes are served here only: interp | LGPU_INTERP_NOBLEND (no
+   layer 2; amounts may be NULL), and sw == dw && sh == dh -- no resize stage: [R <-> B] [-> letterbox] [-> blend] [-> gamma LUT] on frames that already have their
+   size (dst must not be src). */
 int lgpu_chain_amounts(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, const uint8_t *amounts, void *stream);
 
 /* ---- timing helper: HIP events on `stream` around `reps` launches of the last-configured chain; used by

@@ -672,11 +672,11 @@ int lazy_run_group(Lazy *const *zs, const void *const *hs, int n) {
     if (z0->rs != z0->w * 4) rc = rc ? rc : lgpu_fill(outs[(size_t)i].d, 0, bytes, S());      // the row padding of a fresh plane is zero (calloc in the eager path)
   }
   bool done = false;
-  if (!rc && z0->scale && !(z0->dw == z0->sw && z0->dh == z0->sh) && n <= LGPU_CHAIN_MAX_TRACKS) {      // (with or without a blend: LGPU_INTERP_NOBLEND)
+  if (!rc && n <= LGPU_CHAIN_MAX_TRACKS) {      // every shape: with or without a resize stage, with or without a blend (lgpu_chain_amounts)
     lgpu_chain_params pr;
     memset(&pr, 0, sizeof pr);
-    pr.sw = z0->sw; pr.sh = z0->sh; pr.irow = z0->srs; pr.dw = z0->dw; pr.dh = z0->dh; pr.irow2 = z0->l2rs; pr.orow = z0->rs;
-    pr.swap_rb = z0->swap ? 1 : 0; pr.interp = z0->interp | LGPU_INTERP_PIXBUF | (z0->blend ? 0 : LGPU_INTERP_NOBLEND); pr.do_blur = 0; pr.bf = z0->bf; pr.use_lut = z0->lut ? 1 : 0;
+    pr.sw = z0->sw; pr.sh = z0->sh; pr.irow = z0->srs; pr.dw = z0->scale ? z0->dw : z0->sw; pr.dh = z0->scale ? z0->dh : z0->sh; pr.irow2 = z0->l2rs; pr.orow = z0->rs;
+    pr.swap_rb = z0->swap ? 1 : 0; pr.interp = (z0->scale ? z0->interp : 0) | LGPU_INTERP_PIXBUF | (z0->blend ? 0 : LGPU_INTERP_NOBLEND); pr.do_blur = 0; pr.bf = z0->bf; pr.use_lut = z0->lut ? 1 : 0;
     if (!z0->blend) pr.irow2 = z0->rs;
     if (z0->lut) memcpy(pr.lut8, z0->lut8, 256);
     std::vector<lgpu_chain_track> tr((size_t)n);

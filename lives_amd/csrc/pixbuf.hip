@@ -974,6 +974,19 @@ __global__ __launch_bounds__(256) void k_pb_bars_epi(const PbTracks T, const PbE
   reinterpret_cast<uint32_t *>(T.dst[blockIdx.z] + (size_t)y * orow)[x] = pb_epi_px(E, s_lut, 0xFF000000u, y, x);
 }
 
+// the chain on frames that are NOT resized (lgpu_chain_amounts with sw == dw, sh == dh: the plan steps of a track that already has the canvas's size, or is only
+// letterboxed): canvas pixel <- source pixel (inside the inner rectangle) or opaque black, then the chain's last stages; frame = grid z
+__global__ __launch_bounds__(256) void k_pb_flat_n(const PbTracks T, const PbEpi E, int irow, int orow, int cw, int ch, int ox, int oy, int iw, int ih) {
+  __shared__ uint8_t s_lut[256];
+  pb_epi_stage(s_lut, E);
+  __syncthreads();
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cw || y >= ch) return;
+  const bool in = y >= oy && y < oy + ih && x >= ox && x < ox + iw;
+  const uint32_t p = in ? reinterpret_cast<const uint32_t *>(T.src[blockIdx.z] + (size_t)(y - oy) * irow)[x - ox] : 0xFF000000u;
+  reinterpret_cast<uint32_t *>(T.dst[blockIdx.z] + (size_t)y * orow)[x] = pb_epi_px(E, s_lut, p, y, x);
+}
+
 // the rest of the chain behind a resize that was not fused: [R <-> B] -> chroma blend with layer 2 -> gamma LUT, one RGBA pixel per thread;
 // the tracks of one staged group: track = grid z, its scaled frame at scratch + z * per, layer 2 / destination / blend amount from the track table
 __global__ __launch_bounds__(256) void k_pb_epilogue_n(const uint8_t *scratch, size_t per, int irow, const PbTracks T, int bf_tracks, int irow2, int orow, int width, int height,
@@ -1830,6 +1843,19 @@ int pb_scale_fused(const uint8_t *const *srcs, uint8_t *const *dsts, int n, int 
 int pb_chain(const lgpu_chain_params *pr, const lgpu_canvas *cv, const lgpu_chain_track *tracks, int ntracks, hipStream_t st, const uint8_t *amounts) {
   int rc;
   const bool pixbuf = (pr->interp & LGPU_INTERP_PIXBUF) != 0, noblend = (pr->interp & LGPU_INTERP_NOBLEND) != 0;
+  if (pr->sw == pr->dw && pr->sh == pr->dh) {             // no resize stage (lgpu_chain_amounts only; the gaussian is not offered here)
+    if (pr->do_blur) { set_error("lgpu_chain_amounts: the gaussian needs the resize stage"); return LGPU_E_UNSUPPORTED; }
+    PbEpi e;
+    PbTracks T;
+    for (int i = 0; i < ntracks; i++) { T.src[i] = tracks[i].src_d; T.l2[i] = tracks[i].layer2_d; T.dst[i] = tracks[i].dst_d; T.bf[i] = e.bf[i] = amounts ? amounts[i] : 0; e.l2[i] = tracks[i].layer2_d; }
+    e.bf_d = amounts ? nullptr : pr->param_block_d; e.bf0 = (uint32_t)pr->bf & 0xFF; e.irow2 = pr->irow2; e.swap_rb = pr->swap_rb ? 1 : 0; e.use_lut = pr->use_lut ? 1 : 0;
+    e.bf_tracks = amounts ? 1 : 0; e.blend = noblend ? 0 : 1; e.lut = pack_lut(pr->use_lut ? pr->lut8 : nullptr);
+    const int cw = cv ? cv->nwidth : pr->dw, ch = cv ? cv->nheight : pr->dh;
+    hipLaunchKernelGGL(k_pb_flat_n, dim3(cdiv((unsigned)cw, 64), cdiv((unsigned)ch, 4), (unsigned)ntracks), dim3(256), 0, st, T, e, pr->irow, pr->orow, cw, ch,
+                       cv ? cv->offs_x : 0, cv ? cv->offs_y : 0, pr->dw, pr->dh);
+    if (hipGetLastError() != hipSuccess) { set_error("k_pb_flat_n launch failed"); return LGPU_E_HIP; }
+    return LGPU_OK;
+  }
   if (pixbuf && !(cv && pr->do_blur) && !(noblend && pr->do_blur)) {
     rc = pb_chain_half(pr, cv, tracks, ntracks, st, amounts);         // one launch
     if (tune_on(TUNE_PLAN_DEBUG)) fprintf(stderr, "pb_chain: one-launch form rc %d (%s)\n", rc, rc ? lgpu_last_error() : "ok");
@@ -2217,7 +2243,7 @@ extern "C" int lgpu_pixbuf_scale_batch(const uint8_t *const *src_d, uint8_t *con
 
 // resize -> letterbox -> blend (-> gamma) as one call: BASELINE config 3's chain.  letterbox_layer (src/colourspace.c:15343-15567) centres the scaled frame on an
 // opaque black canvas; here the canvas never exists on its own: the scaled frame is blended and stored at its place, the bars are blended black.
-static int chain_canvas_impl(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream, const uint8_t *amounts) {
+static int chain_canvas_impl(const lgpu_chain_params *params, const lgpu_canvas *canvas, const lgpu_chain_track *tracks, int ntracks, void *stream, const uint8_t *amounts, bool flat_ok = false) {
   int rc = ensure_init();
   if (rc) return rc;
   LGPU_REQUIRE(params && canvas && tracks && ntracks > 0 && ntracks <= LGPU_CHAIN_MAX_TRACKS, "1..64 tracks");
@@ -2226,10 +2252,11 @@ static int chain_canvas_impl(const lgpu_chain_params *params, const lgpu_canvas 
                canvas->offs_x + params->dw <= canvas->nwidth && canvas->offs_y + params->dh <= canvas->nheight, "the scaled frame must lie inside the canvas");
   LGPU_REQUIRE(params->irow >= params->sw * 4 && params->orow >= canvas->nwidth * 4 && params->irow2 >= canvas->nwidth * 4, "rowstride smaller than a row");
   LGPU_REQUIRE(((params->irow | params->orow | params->irow2) & 3) == 0, "rowstrides must be multiples of 4");
-  LGPU_REQUIRE(!(params->sw == params->dw && params->sh == params->dh), "chain needs a resize stage");
+  LGPU_REQUIRE(flat_ok || !(params->sw == params->dw && params->sh == params->dh), "chain needs a resize stage");
   for (int i = 0; i < ntracks; i++) {
     LGPU_REQUIRE(tracks[i].src_d && tracks[i].layer2_d && tracks[i].dst_d, "null track pointer");
     LGPU_REQUIRE((((uintptr_t)tracks[i].src_d | (uintptr_t)tracks[i].layer2_d | (uintptr_t)tracks[i].dst_d) & 3) == 0, "frames must be 4-byte aligned");
+    LGPU_REQUIRE(tracks[i].src_d != tracks[i].dst_d, "the chain cannot run in place");
   }
   return pb_chain(params, canvas, tracks, ntracks, (hipStream_t)stream, amounts);
 }
@@ -2253,7 +2280,9 @@ extern "C" int lgpu_chain_amounts(const lgpu_chain_params *params, const lgpu_ca
     for (int i = 0; i < ntracks; i++) { tr[i] = tracks[i]; tr[i].layer2_d = tracks[i].dst_d; }
     tracks = tr; p0.irow2 = p0.orow; amounts = nullptr;
   }
-  if (canvas) return chain_canvas_impl(&p0, canvas, tracks, ntracks, stream, amounts);
+  const lgpu_canvas whole = {p0.dw, p0.dh, 0, 0};
+  if (!canvas && p0.sw == p0.dw && p0.sh == p0.dh) canvas = &whole;      // no resize stage: the canvas form's checks (lgpu_chain_check insists on a resize)
+  if (canvas) return chain_canvas_impl(&p0, canvas, tracks, ntracks, stream, amounts, true);
   if ((rc = lgpu_chain_check(&p0, tracks, ntracks))) return rc;
   return pb_chain(&p0, nullptr, tracks, ntracks, (hipStream_t)stream, amounts);
 }
