@@ -16,6 +16,9 @@ echo "== K2 (lgpu_yuv420p_to_rgb[_batch]) and the chain (lgpu_chain, 4K tracks)"
 python tools/bench_one.py --cold k2 k2b8 k2b16 chain1 chain8 chain16 c3 2>/dev/null
 echo "   (with config 5's gaussian; chainbluropN: sources whose alpha is 255 everywhere + LGPU_INTERP_OPAQUE)"
 python tools/bench_one.py --cold chainblur1 chainblur4 chainblur8 chainblur16 chainblurop1 chainblurop4 chainblurop8 chainblurop16 2>/dev/null
+echo "== the chain off the headline shape (lgpu_chain / lgpu_chain_canvas / lgpu_chain_amounts: one launch each): other ratios, a letterbox canvas, nb = no layer 2 (LGPU_INTERP_NOBLEND)"
+python tools/bench_one.py --cold chg1:1920x1080:1280x720 chg16:1920x1080:1280x720 chg16:1280x720:1920x1080 chg8:3840x2160:1706x960 chg16:3840x2160:1280x720 chg16:1920x1080:1280x540:1280x720 \
+       chg1:3840x2160:1920x1080:nb chg16:3840x2160:1920x1080:nb chg1:1920x1080:1280x720:nb chg16:1920x1080:1280x720:nb chg1:1920x1080:1280x720:1280x800:nb 2>/dev/null
 echo "== gdk-pixbuf scaler (lgpu_pixbuf_scale[_batch])"
 for r in 3840x2160:1920x1080 1920x1080:1280x720 1280x720:1920x1080 3840x2160:1706x960 1920x1080:2560x1440 1280x720:3840x2160; do python tools/bench_one.py --cold pb:$r:3 pb8:$r:3 pb16:$r:3 2>/dev/null; done
 echo "   (BILINEAR, and sources whose alpha is 255 everywhere with LGPU_INTERP_OPAQUE: 3o)"
