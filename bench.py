@@ -435,7 +435,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def seam_chain_leg(srcs, l2s, ops, value_fps, T, ticks=150, warm=30):
+def seam_chain_leg(srcs, l2s, ops, value_fps, T, ticks=600, warm=150):
     """the headline chain through the two seams by the reference's names, from C host threads (tools/libseam_host.so)"""
     import numpy as np
     import torch

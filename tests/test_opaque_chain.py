@@ -164,3 +164,28 @@ def test_a_track_without_a_layer_2(gpu, orc, case, interp):
                 orc.orc_gamma_apply(P(want), want.strides[0], want.shape[1] // 4, want.shape[0], 4, 0, P(lut))
             got = host(d_o[i])
             assert (got == want).all(), "track %d swap %d lut %s: %d bytes differ" % (i, swap, use_lut, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("case", [(200, 120, 133, 80, None, 0), (200, 120, 133, 80, (150, 90, 9, 5), 0), (200, 120, 133, 80, None, NOBLEND), (256, 144, 128, 72, (160, 100, 16, 14), NOBLEND)])
+def test_the_staged_groups_equal_the_one_launch_forms(gpu, tune, case):
+    """LGPU_PB_CHAIN_GROUP = g: the chain's stages apart, g tracks at a time through lgpu_pixbuf_scale_batch and the batched last kernel (what the gaussian and the
+    polyphase backend keep) -- the bytes of the one-launch forms, for groups that divide the tracks and groups that do not"""
+    sw, sh, dw, dh, canvas, flag = case
+    rng = np.random.default_rng(0x0FE0 + sw + dw + flag)
+    n = 5
+    amounts = [3, 250, 77, 128, 40]
+    cw, ch = (canvas[0], canvas[1]) if canvas else (dw, dh)
+    srcs = [rng.integers(0, 256, (sh, sw * 4), dtype=np.uint8) for _ in range(n)]
+    l2s = [rng.integers(0, 256, (ch, cw * 4), dtype=np.uint8) for _ in range(n)]
+    lut = rng.permutation(256).astype(np.uint8)
+    d_s, d_l = [dev(a) for a in srcs], [dev(a) for a in l2s]
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, cw * 4, cw * 4, swap_rb=1, interp=3 | PIXBUF | flag, do_blur=0, bf=99, lut=lut)
+    res = []
+    for group in (0, 1, 2, 64):
+        tune("PB_CHAIN_GROUP", group if group else -1)
+        d_o = [dev(np.full((ch, cw * 4), 0x33, np.uint8)) for _ in range(n)]
+        gpu.chain_amounts(prm, gpu.chain_tracks(d_s, None if flag else d_l, d_o), None if flag else amounts, canvas)
+        res.append([host(t) for t in d_o])
+    for g in range(1, len(res)):
+        for i in range(n):
+            assert (res[g][i] == res[0][i]).all(), "group setting %d, track %d" % (g, i)
