@@ -128,6 +128,55 @@ def test_c5_sixteen_track_4k_chain(gpu, orc, do_blur, interp):
         assert torch.equal(dst2[t], dst_d[perm[t]])
 
 
+@pytest.mark.parametrize("geom", [(3840, 2160, 1706, 960), (1920, 1080, 1280, 720), (1280, 720, 1920, 1080), (3840, 2160, 1280, 720)], ids=["4k_to_1706x960", "1080p_to_720p", "720p_to_1080p", "4k_to_720p"])
+def test_chain_off_2to1_at_size_in_one_launch(gpu, orc, geom):
+    """the chain on eight tracks at ratios other than 2:1 (the scaler of the ratio -- pair, enlargement, 3:1 gather kernel -- with the chain's last stages in its
+    store), a blend amount per track: tracks 0 / 1 against the oracle's chain, the rest against the track with the same input"""
+    import torch
+    sw, sh, dw, dh = geom
+    T = 8
+    rng = np.random.default_rng(4105 + dw)
+    lut = l2s_lut()
+    base = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(2)]
+    l2b = [frame(rng, dw, dh, 4, alpha_mix=True) for _ in range(2)]
+    src_d, l2_d = [dev(base[t & 1]) for t in range(T)], [dev(l2b[t & 1]) for t in range(T)]
+    dst_d = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    amounts = [107 if t < 2 or (t & 1) == 0 else 31 for t in range(T)]          # tracks 0, 1, 2, 4, 6: 107; 3, 5, 7: 31
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=5, lut=lut)
+    gpu.chain_amounts(prm, gpu.chain_tracks(src_d, l2_d, dst_d), amounts)
+    for i in range(2):
+        want = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_chain(P(base[i]), sw * 4, sw, sh, P(l2b[i]), dw * 4, P(want), dw * 4, dw, dh, 1, 3 | PIXBUF, 0, 107, P(lut)) == 0
+        assert_same(host(dst_d[i]), want, dw, dh, 4, "chain %s track %d" % (geom, i))
+    want31 = np.zeros((dh, dw * 4), np.uint8)
+    assert orc.orc_chain(P(base[1]), sw * 4, sw, sh, P(l2b[1]), dw * 4, P(want31), dw * 4, dw, dh, 1, 3 | PIXBUF, 0, 31, P(lut)) == 0
+    assert_same(host(dst_d[3]), want31, dw, dh, 4, "chain %s track 3 (its own amount)" % (geom,))
+    for t in range(2, T):
+        assert torch.equal(dst_d[t], dst_d[0] if (t & 1) == 0 else dst_d[3]), "track %d" % t
+
+
+def test_a_4k_track_without_a_layer_2_at_size(gpu, orc):
+    """LGPU_INTERP_NOBLEND at the headline geometry (k_pb_half<2, ..>): BGRA32 4K -> R <-> B -> 1920 x 1080 -> gamma LUT, four tracks in one launch"""
+    import torch
+    sw, sh, dw, dh, T = 3840, 2160, 1920, 1080, 4
+    rng = np.random.default_rng(4207)
+    lut = l2s_lut()
+    base = [frame(rng, sw, sh, 4, alpha_mix=True) for _ in range(2)]
+    src_d = [dev(base[t & 1]) for t in range(T)]
+    dst_d = [torch.zeros((dh, dw * 4), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    prm = gpu.chain_params(sw, sh, sw * 4, dw, dh, dw * 4, dw * 4, swap_rb=1, interp=3 | PIXBUF | 0x400, do_blur=0, bf=0, lut=lut)
+    gpu.chain_amounts(prm, gpu.chain_tracks(src_d, None, dst_d), None)
+    for i in range(2):
+        conv = np.zeros((sh, sw * 4), np.uint8)
+        orc.orc_swizzle(po.OPS.index("swap3postalpha"), 0, P(base[i]), sw * 4, P(conv), sw * 4, sw, sh, None)
+        want = np.zeros((dh, dw * 4), np.uint8)
+        assert orc.orc_pixbuf_scale(P(conv), sw * 4, sw, sh, P(want), dw * 4, dw, dh, 4, 3) == 0
+        orc.orc_gamma_apply(P(want), dw * 4, dw, dh, 4, 0, P(lut))
+        assert_same(host(dst_d[i]), want, dw, dh, 4, "no layer 2, track %d" % i)
+    for t in range(2, T):
+        assert torch.equal(dst_d[t], dst_d[t & 1])
+
+
 @pytest.mark.parametrize("shape", ["feeder_lanes", "th8", "xcd_runs", "bands_one_by_one", "groups_of_5", "eight_per_cu"])
 def test_c5_bench_launch_in_its_other_shapes(gpu, orc, tune, shape):
     """the same 16-track launch in the shapes that ship behind the launch-shape switches (strips with feeder lanes instead of 64 storing lanes, another band height, the
