@@ -140,6 +140,10 @@ int lives_gpu_layer_unpin(lives_gpu_layer_t *layer);    /* sync, release the dev
    valid until the layer's pixel_data has been replaced by a seam call or the layer is synchronised / unpinned / forgotten.  producer_stream: where their
    contents were produced (NULL = the null stream); producer_done != 0: that work is known to be complete, nobody has to wait for it. */
 int lives_gpu_layer_pin_device(lives_gpu_layer_t *layer, const void *const *planes_d, int nplanes, void *producer_stream, int producer_done);
+/* weed_layer_copy(NULL, slayer) (the deep copy, src/layers.c:755-846) copies host bytes, which are stale while slayer is pinned.  Called on its result: dlayer (same
+   palette, size, rowstrides; host planes of its own) becomes a pinned layer whose device planes are device-to-device copies of slayer's -- a pending program of slayer
+   runs first, nothing crosses PCIe.  slayer not pinned: LGPU_OK, nothing done.  (A shallow copy shares the host planes and with them the device copies.) */
+int lives_gpu_layer_copy(lives_gpu_layer_t *dlayer, lives_gpu_layer_t *slayer);
 /* ---- deferred execution on pinned layers (on by default).  The host bytes of a pinned layer are stale until lives_gpu_layer_sync(), so the seam calls of one
    track's plan step on an RGBA32 / BGRA32 frame -- convert_layer_palette (R <-> B), resize_layer[_full] (gdk-pixbuf body), letterbox_layer, livesgpu_fx.so's
    "chroma blend" in place, gamma_convert_layer -- are RECORDED on the plane (every leaf changes as in the eager call) and run as ONE launch of the fused chain

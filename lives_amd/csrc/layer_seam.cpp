@@ -1913,6 +1913,29 @@ int lives_gpu_layer_pin_device(lives_gpu_layer_t *layer, const void *const *plan
   set_int(layer, kLeafResident, 1);
   return LGPU_OK;
 }
+// weed_layer_copy(NULL, slayer) -- the deep copy (src/layers.c:755-846: a new layer, copy_pixel_data_slice) -- copies HOST bytes, which are stale while slayer is
+// pinned.  Called on its result, this gives the copy the pixels: dlayer (the same palette, size and rowstrides, host planes of its own) becomes a pinned layer whose
+// device planes are device-to-device copies of slayer's (a pending program of slayer runs first); no byte crosses PCIe.  slayer not pinned: nothing to do.
+int lives_gpu_layer_copy(lives_gpu_layer_t *dlayer, lives_gpu_layer_t *slayer) {
+  Layer s, d;
+  if (!ready() || !read_layer(slayer, &s) || !read_layer(dlayer, &d)) return LGPU_E_BADARG;
+  if (!has_leaf(slayer, kLeafResident)) return LGPU_OK;
+  if (has_leaf(dlayer, kLeafResident) || s.nplanes != d.nplanes || s.pal != d.pal || s.width != d.width || s.height != d.height) return LGPU_E_BADARG;
+  for (int p = 0; p < s.nplanes; p++)
+    if (s.rs[p] != d.rs[p] || plane_bytes(s, p) != plane_bytes(d, p) || s.pd[p] == d.pd[p]) return LGPU_E_BADARG;      // (a shallow copy shares the planes and their device copies already)
+  for (int p = 0; p < s.nplanes; p++) {
+    const size_t n = plane_bytes(s, p);
+    const uint8_t *src = acquire(s.pd[p], n, false);
+    Dev b;
+    if (!src || !pool_take(n, &b)) { for (int q = 0; q < p; q++) res_drop(d.pd[q]); return src ? LGPU_E_NOMEM : LGPU_E_BADARG; }
+    if (lgpu_copy(b.d, src, n, S()) != LGPU_OK) { pool_give(b); for (int q = 0; q < p; q++) res_drop(d.pd[q]); return LGPU_E_HIP; }
+    touch_done(s.pd[p], false);
+    b.stream = S();
+    res_put(d.pd[p], b);
+  }
+  set_int(dlayer, kLeafResident, 1);
+  return LGPU_OK;
+}
 // deferred execution (see "deferred execution on pinned layers" above): on (default) / off; returns the previous setting
 int lives_gpu_set_deferred(int on) { return g_deferred.exchange(on ? 1 : 0); }
 // counters since the library was loaded: [0] stages recorded, [1] fused chain launches made for pending programs, [2] tracks (programs) those launches carried,

@@ -329,3 +329,38 @@ def test_the_plugins_batch_hook_records_too(seam, orc, deferred):
         assert (view(wh, lays[i])[:, :dw * 4] == want).all(), i
     for a in lays + l2l:
         assert L.lives_gpu_layer_unpin(a) == 0
+
+
+def test_a_deep_copy_of_a_pinned_layer_gets_the_pixels_on_the_device(seam, orc, deferred):
+    """lives_gpu_layer_copy(dlayer, slayer) behind the host's weed_layer_copy(NULL, slayer): the copy becomes a pinned layer with device copies of the planes -- of what
+    the source's recorded calls make of it (they run first) -- and lives on when the source changes or goes"""
+    L, wh, H = seam
+    rng = np.random.default_rng(0xDEFC)
+    sw, sh, dw, dh = 256, 144, 128, 72
+    src = frame(rng, sw, sh, 4, alpha_mix=True)
+    lay = wh.new_layer(BGRA32, sw, sh, [src], gamma=1)
+    assert L.lives_gpu_layer_pin(lay) == 0
+    plan_step(L, wh, H, lay, None, dw, dh, None, 0, None)                       # convert + resize recorded, pending
+    rs = wh.planes_of(lay)[2][0]
+    cp = wh.new_layer(RGBA32, dw, dh, [np.zeros((dh, rs), np.uint8)], gamma=wh.geti(lay, "gamma_type"))      # what weed_layer_copy makes: same leaves, stale bytes
+    assert wh.planes_of(cp)[2][0] == rs
+    assert L.lives_gpu_layer_copy(cp, lay) == 0
+    assert L.lives_gpu_gamma_convert_layer(2, lay) == 1                        # the source moves on
+    assert L.lives_gpu_layer_sync(cp) == 0 and L.lives_gpu_layer_sync(lay) == 0
+    want = oracle_step(orc, src, sw, sh, None, dw, dh, None, 0, None, True)
+    assert (view(wh, cp)[:, :dw * 4] == want).all(), "the copy holds the frame as it was when it was copied"
+    want2 = oracle_step(orc, src, sw, sh, None, dw, dh, None, 0, srgb_to(orc, 2), True)
+    assert (view(wh, lay)[:, :dw * 4] == want2).all()
+    assert L.lives_gpu_layer_unpin(lay) == 0
+    assert L.lives_gpu_convert_layer_palette(cp, BGRA32, 0) == 1 and L.lives_gpu_layer_sync(cp) == 0      # the copy is an ordinary pinned layer
+    back = np.zeros((dh, dw * 4), np.uint8)
+    orc.orc_swizzle(po.OPS.index("swap3postalpha"), 0, P(want), dw * 4, P(back), dw * 4, dw, dh, None)
+    assert (view(wh, cp)[:, :dw * 4] == back).all()
+    assert L.lives_gpu_layer_unpin(cp) == 0
+    # an unpinned source: nothing to do; mismatched geometry: refused
+    a, b = wh.new_layer(RGBA32, 64, 32, [frame(rng, 64, 32, 4)], gamma=1), wh.new_layer(RGBA32, 64, 32, [frame(rng, 64, 32, 4)], gamma=1)
+    assert L.lives_gpu_layer_copy(b, a) == 0 and wh.geti(b, "host_gpu_resident") is None
+    assert L.lives_gpu_layer_pin(a) == 0
+    c = wh.new_layer(RGBA32, 32, 32, [frame(rng, 32, 32, 4)], gamma=1)
+    assert L.lives_gpu_layer_copy(c, a) != 0
+    assert L.lives_gpu_layer_unpin(a) == 0
