@@ -978,6 +978,7 @@ struct RepackArgs {
   int yuyv_in, yuyv_out;     // byte order of a packed 4:2:2 source / destination
   int clamped;               // which averaging table (init_average, :190-216)
   int copy_w;                // bytes per row of the plain plane copies: the width, or the whole rowstride where the reference memcpy()s the plane
+  int cshift;                // RK_420_TO_PK: chroma row of luma row y = y >> cshift (1: 4:2:0, 0: planar 4:2:2)
 };
 
 // 4:2:0 -> UYVY / YUYV on aligned frames (the playback plugin's packed 4:2:2 from a decoder's planes): a permutation, so the whole cost is the shape -- cells of four
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(512) void k_420_to_packed_s(RepackArgs a, uint32_t 
   if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
   if (y >= (uint32_t)a.height) return;
   const uint2 y8 = *reinterpret_cast<const uint2 *>(a.src[0] + (size_t)y * a.irow[0] + 8 * (size_t)gx);
-  const uint32_t u4 = *reinterpret_cast<const uint32_t *>(a.src[1] + (size_t)(y >> 1) * a.irow[1] + 4 * (size_t)gx), v4 = *reinterpret_cast<const uint32_t *>(a.src[2] + (size_t)(y >> 1) * a.irow[2] + 4 * (size_t)gx);
+  const uint32_t u4 = *reinterpret_cast<const uint32_t *>(a.src[1] + (size_t)(y >> a.cshift) * a.irow[1] + 4 * (size_t)gx), v4 = *reinterpret_cast<const uint32_t *>(a.src[2] + (size_t)(y >> a.cshift) * a.irow[2] + 4 * (size_t)gx);
   uint32_t mpx[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -1133,7 +1134,7 @@ __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
     }
     case RK_420_TO_PK: {
       const uint8_t *sy = a.src[0] + (size_t)y * a.irow[0] + x0;
-      const uint8_t u = a.src[1][(size_t)(y >> 1) * a.irow[1] + mx], v = a.src[2][(size_t)(y >> 1) * a.irow[2] + mx];
+      const uint8_t u = a.src[1][(size_t)(y >> a.cshift) * a.irow[1] + mx], v = a.src[2][(size_t)(y >> a.cshift) * a.irow[2] + mx];
       uint8_t *d = a.dst[0] + (size_t)y * (size_t)((a.orow[0] / 4) * 4) + 4 * (size_t)mx;
       const uint32_t y0_ = sy[0], y1_ = sy[1];
       const uint32_t mp = a.yuyv_out ? (y0_ | ((uint32_t)u << 8) | (y1_ << 16) | ((uint32_t)v << 24)) : ((uint32_t)u | (y0_ << 8) | ((uint32_t)v << 16) | (y1_ << 24));
@@ -1712,7 +1713,12 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
   } else if (in420 && outpk) {
     // convert_yuv420_to_uyvy_frame steps its chroma pointers back by the rowstride (:7143-7146): compact chroma planes only
     if (irow[1] != (width >> 1) || irow[2] != (width >> 1) || ((width | height) & 1)) return unsupported("4:2:0 -> packed 4:2:2 needs compact chroma planes and even dimensions (colourspace.c:7143)");
-    a.kind = lgpu::RK_420_TO_PK; nin = 3;
+    a.kind = lgpu::RK_420_TO_PK; a.cshift = 1; nin = 3;
+  } else if (in_pal == P_422 && outpk) {
+    // own specification (docs/SPECS.md, "evident intent"): convert_yuv422p_to_uyvy_frame / _yuyv_frame (:6442-6497) loop `width` macropixels per row and overrun;
+    // what they mean is the interleave of the 4:2:0 sibling with a chroma row per luma row
+    if (width & 1) return unsupported("packed 4:2:2 needs an even width");
+    a.kind = lgpu::RK_420_TO_PK; a.cshift = 0; nin = 3;
   } else if (in420 && out_pal == P_422) {
     if ((width | height) & 1) return unsupported("a 4:2:0 source has even width and height");
     a.kind = lgpu::RK_420_TO_422P; nin = 3; nout = 3;

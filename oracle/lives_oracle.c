@@ -1665,6 +1665,21 @@ int orc_yuv_repack(int in_pal, int out_pal, const uint8_t *const src[4], const i
   const int inpk422 = (in_pal == P_UYVY || in_pal == P_YUYV);
   if (width < 1 || height < 1) return -1;
 
+  /* OWN SPECIFICATION (docs/SPECS.md, "evident intent"), not a restatement: convert_yuv422p_to_uyvy_frame / _yuyv_frame (:6442-6497) walk `width` macropixels per
+     row -- twice the row -- and overrun every buffer, so there is no reference behaviour to follow.  What the function's own comments and its 4:2:0 sibling
+     (:7100-7160) say it means: macropixel k of row y = (U[y][k], Y[y][2k], V[y][k], Y[y][2k + 1]) (UYVY; YUYV: Y U Y V), every plane with its own rowstride. */
+  if (in_pal == P_422 && (out_pal == P_UYVY || out_pal == P_YUYV)) {
+    if (width & 1) return -1;
+    for (int y = 0; y < height; y++) {
+      uint8_t *d = dst[0] + (size_t)y * (size_t)((orow[0] / 4) * 4);
+      for (int k = 0; k < width / 2; k++) {
+        const uint8_t y0 = src[0][(size_t)y * irow[0] + 2 * k], y1 = src[0][(size_t)y * irow[0] + 2 * k + 1], u = src[1][(size_t)y * irow[1] + k], v = src[2][(size_t)y * irow[2] + k];
+        if (out_pal == P_UYVY) { d[4 * k] = u; d[4 * k + 1] = y0; d[4 * k + 2] = v; d[4 * k + 3] = y1; }
+        else { d[4 * k] = y0; d[4 * k + 1] = u; d[4 * k + 2] = y1; d[4 * k + 3] = v; }
+      }
+    }
+    return 0;
+  }
   /* convert_combineplanes_frame :7593-7641 -- both of its branches write the same bytes */
   if (in444 && (out_pal == P_888 || out_pal == P_8888)) {
     const int ops = out_pal == P_8888 ? 4 : 3;

@@ -369,7 +369,8 @@ YUV_REPACK_PAIRS = [(544, 588, 1), (544, 589, 1), (545, 588, 1), (545, 589, 1), 
                     (544, 512, 1), (545, 512, 1), (544, 564, 0), (544, 565, 0), (545, 564, 0), (564, 544, 1), (565, 544, 1),
                     (564, 545, 1), (564, 588, 1), (565, 588, 1), (564, 589, 1), (565, 589, 1), (564, 512, 0), (565, 512, 0),
                     (588, 512, 0), (589, 512, 0), (588, 522, 0), (589, 522, 0), (588, 564, 0), (588, 565, 0), (589, 564, 0), (589, 565, 0),
-                    (564, 522, 0), (565, 522, 0)]
+                    (564, 522, 0), (565, 522, 0),
+                    (522, 564, 1), (522, 565, 1)]       # (own specification: the reference's functions overrun, docs/SPECS.md "evident intent")
 # 4:2:0 / 4:2:2 planar -> packed 4:4:4 (convert_quad_chroma_packed / convert_double_chroma_packed, :10715-10873)
 CHROMA_UP_PAIRS = [(512, 588), (512, 589), (522, 588), (522, 589)]
 
