@@ -1066,6 +1066,86 @@ __global__ __launch_bounds__(512) void k_swab_s(RepackArgs a, uint32_t gmagic) {
   *reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * a.orow[0] + 16 * (size_t)gx) = v;
 }
 
+// UYVY / YUYV -> planar 4:2:0 / planar 4:4:4 / packed 4:4:4 on aligned frames (a capture card's frame on its way to an encoder or into the effects): a lane owns four
+// macropixels of a row (of two rows for 4:2:0: its chroma is the average of the pair, K5b's RK_PK_TO_420 arithmetic), one 16-byte load per row, dword / 8- / 16-byte
+// stores.  k_yuv_repack moves the same bytes one at a time (9-12 us for one 1080p frame).
+template <int KIND>
+__global__ __launch_bounds__(512) void k_pk_to_s(RepackArgs a, uint32_t gmagic) {
+  if (KIND == RK_PK_TO_420) cavg_init();
+  typedef unsigned rk_u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned rk_u3 __attribute__((ext_vector_type(3)));
+  typedef rk_u3 rk_u3a __attribute__((aligned(4)));
+  const int ngr = a.width >> 3, rows = KIND == RK_PK_TO_420 ? (a.height + 1) >> 1 : a.height;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)rows) return;
+  const size_t irm = (size_t)((a.irow[0] / 4) * 4);
+  const int r0 = KIND == RK_PK_TO_420 ? 2 * (int)y : (int)y;
+  const rk_u4 m = *reinterpret_cast<const rk_u4 *>(a.src[0] + (size_t)r0 * irm + 16 * (size_t)gx);
+  const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+  // bytes of a macropixel: UYVY u y0 v y1, YUYV y0 u y1 v
+  auto lum = [&](const uint32_t *w, uint32_t &lo, uint32_t &hi) {      // eight luma bytes
+    const uint32_t sel = a.yuyv_in ? 0x06040200u : 0x07050301u;
+    lo = __builtin_amdgcn_perm(w[1], w[0], sel); hi = __builtin_amdgcn_perm(w[3], w[2], sel);
+  };
+  auto chr = [&](const uint32_t *w, uint32_t &u4, uint32_t &v4) {      // four U, four V
+    const uint32_t su = a.yuyv_in ? 0x0C0C0501u : 0x0C0C0400u, sv = a.yuyv_in ? 0x0C0C0703u : 0x0C0C0602u;
+    u4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(w[3], w[2], su), __builtin_amdgcn_perm(w[1], w[0], su), 0x05040100u);
+    v4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(w[3], w[2], sv), __builtin_amdgcn_perm(w[1], w[0], sv), 0x05040100u);
+  };
+  uint32_t ylo, yhi, u4, v4;
+  lum(mw, ylo, yhi);
+  chr(mw, u4, v4);
+  if (KIND == RK_PK_TO_420) {
+    *reinterpret_cast<uint2 *>(a.dst[0] + (size_t)r0 * a.width + 8 * (size_t)gx) = make_uint2(ylo, yhi);
+    if (r0 + 1 < a.height) {
+      const rk_u4 n = *reinterpret_cast<const rk_u4 *>(a.src[0] + (size_t)(r0 + 1) * irm + 16 * (size_t)gx);
+      const uint32_t nw[4] = {n.x, n.y, n.z, n.w};
+      uint32_t l2, h2, nu, nv;
+      lum(nw, l2, h2);
+      chr(nw, nu, nv);
+      *reinterpret_cast<uint2 *>(a.dst[0] + (size_t)(r0 + 1) * a.width + 8 * (size_t)gx) = make_uint2(l2, h2);
+      uint32_t ou = 0, ov = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        ou |= (uint32_t)cavg(a.clamped, (u4 >> (8 * k)) & 0xFF, (nu >> (8 * k)) & 0xFF) << (8 * k);
+        ov |= (uint32_t)cavg(a.clamped, (v4 >> (8 * k)) & 0xFF, (nv >> (8 * k)) & 0xFF) << (8 * k);
+      }
+      u4 = ou; v4 = ov;
+    }
+    *reinterpret_cast<uint32_t *>(a.dst[1] + (size_t)y * (a.width >> 1) + 4 * (size_t)gx) = u4;
+    *reinterpret_cast<uint32_t *>(a.dst[2] + (size_t)y * (a.width >> 1) + 4 * (size_t)gx) = v4;
+  } else if (KIND == RK_PK_TO_444) {
+    // every chroma sample serves its two pixels
+    const uint32_t ul = __builtin_amdgcn_perm(0u, u4, 0x01010000u), uh = __builtin_amdgcn_perm(0u, u4, 0x03030202u);
+    const uint32_t vl = __builtin_amdgcn_perm(0u, v4, 0x01010000u), vh = __builtin_amdgcn_perm(0u, v4, 0x03030202u);
+    const size_t di = (size_t)y * a.orow[0] + 8 * (size_t)gx;
+    *reinterpret_cast<uint2 *>(a.dst[0] + di) = make_uint2(ylo, yhi);
+    *reinterpret_cast<uint2 *>(a.dst[1] + di) = make_uint2(ul, uh);
+    *reinterpret_cast<uint2 *>(a.dst[2] + di) = make_uint2(vl, vh);
+  } else {
+    uint32_t px[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t yy = ((k < 4 ? ylo : yhi) >> (8 * (k & 3))) & 0xFF, u = (u4 >> (8 * (k >> 1))) & 0xFF, v = (v4 >> (8 * (k >> 1))) & 0xFF;
+      px[k] = yy | (u << 8) | (v << 16) | 0xFF000000u;
+    }
+    if (a.out_alpha) {
+      rk_u4 *d = reinterpret_cast<rk_u4 *>(a.dst[0] + (size_t)y * a.orow[0] + 32 * (size_t)gx);
+      d[0] = rk_u4{px[0], px[1], px[2], px[3]}; d[1] = rk_u4{px[4], px[5], px[6], px[7]};
+    } else {
+      uint8_t *d = a.dst[0] + (size_t)y * a.orow[0] + 24 * (size_t)gx;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t *o = px + 4 * h;
+        *reinterpret_cast<rk_u3a *>(d + 12 * h) = rk_u3{(o[0] & 0xFFFFFFu) | (o[1] << 24), ((o[1] >> 8) & 0xFFFFu) | (o[2] << 16), ((o[2] >> 16) & 0xFFu) | (o[3] << 8)};
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
   // the chroma-average table costs a workgroup a round of LDS writes and a barrier: only the kinds that average build it (kernel-uniform)
   if (a.kind > RK_420_TO_PK) cavg_init();              // RK_COMBINE .. RK_420_TO_PK are permutations
@@ -1810,6 +1890,23 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
     hipLaunchKernelGGL(lgpu::k_swab_s, dim3((unsigned)(((unsigned long long)ngr * height + 511) / 512)), dim3(512), 0, st, a, magic);
     LGPU_CHECK_LAUNCH();
     return LGPU_OK;
+  }
+  if ((a.kind == lgpu::RK_PK_TO_420 || a.kind == lgpu::RK_PK_TO_444 || a.kind == lgpu::RK_PK_TO_888) && !no_s && (width & 7) == 0 &&
+      (((uintptr_t)src_d[0] | (uintptr_t)((irow[0] / 4) * 4)) & 15) == 0 && (unsigned long long)(width >> 3) * height < (1ull << 31)) {
+    bool ok;
+    if (a.kind == lgpu::RK_PK_TO_420) ok = (((uintptr_t)dst_d[0]) & 7) == 0 && (((uintptr_t)dst_d[1] | (uintptr_t)dst_d[2]) & 3) == 0;      // (compact destination: width a multiple of 8)
+    else if (a.kind == lgpu::RK_PK_TO_444) ok = (((uintptr_t)dst_d[0] | (uintptr_t)dst_d[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[0]) & 7) == 0;
+    else ok = (((uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & (a.out_alpha ? 15 : 3)) == 0;
+    if (ok) {
+      const int ngr = width >> 3, rows_ = a.kind == lgpu::RK_PK_TO_420 ? (height + 1) >> 1 : height;
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+      const dim3 gs((unsigned)(((unsigned long long)ngr * rows_ + 511) / 512));
+      if (a.kind == lgpu::RK_PK_TO_420) hipLaunchKernelGGL(lgpu::k_pk_to_s<lgpu::RK_PK_TO_420>, gs, dim3(512), 0, st, a, magic);
+      else if (a.kind == lgpu::RK_PK_TO_444) hipLaunchKernelGGL(lgpu::k_pk_to_s<lgpu::RK_PK_TO_444>, gs, dim3(512), 0, st, a, magic);
+      else hipLaunchKernelGGL(lgpu::k_pk_to_s<lgpu::RK_PK_TO_888>, gs, dim3(512), 0, st, a, magic);
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
   }
   const int rows = (a.kind == lgpu::RK_444_TO_420 || a.kind == lgpu::RK_PK_TO_420 || a.kind == lgpu::RK_888_TO_420) ? (height + 1) >> 1 : height;
   const int span = a.copy_w > width ? a.copy_w : width;
