@@ -1146,6 +1146,82 @@ __global__ __launch_bounds__(512) void k_pk_to_s(RepackArgs a, uint32_t gmagic) 
   }
 }
 
+// YUV888 / YUVA8888 -> planar 4:2:0 / planar 4:2:2 / UYVY / YUYV on aligned frames (RK_888_TO_420 / RK_888_TO_422: the chroma of a pixel pair is the table
+// average of its two samples, of the 2 x 2 block the average of the two rows' averages, :8035-8270) and planar 4:2:0 -> planar 4:2:2 (RK_420_TO_422P: odd rows take
+// the average of the chroma rows around them, :7163-7226): a lane owns four pixels (eight for the planar pair) of one row / row pair.
+template <int KIND>
+__global__ __launch_bounds__(512) void k_888_to_s(RepackArgs a, uint32_t gmagic) {
+  cavg_init();
+  typedef unsigned rk_u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned rk_u3 __attribute__((ext_vector_type(3)));
+  typedef rk_u3 rk_u3a __attribute__((aligned(4)));
+  const int ngr = a.width >> 2, rows = KIND == RK_888_TO_420 ? a.height >> 1 : a.height;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)rows) return;
+  const int ips = a.in_alpha ? 4 : 3, hw = a.width >> 1;
+  auto load4 = [&](int row, uint32_t *px) {                 // four pixels as Y | U << 8 | V << 16
+    const uint8_t *sp = a.src[0] + (size_t)row * a.irow[0] + 4 * (size_t)ips * gx;
+    if (ips == 4) { const rk_u4 q = *reinterpret_cast<const rk_u4 *>(sp); px[0] = q.x; px[1] = q.y; px[2] = q.z; px[3] = q.w; }
+    else {
+      const rk_u3 q = *reinterpret_cast<const rk_u3a *>(sp);
+      px[0] = q.x; px[1] = __builtin_amdgcn_alignbyte(q.y, q.x, 3); px[2] = __builtin_amdgcn_alignbyte(q.z, q.y, 2); px[3] = q.z >> 8;
+    }
+  };
+  auto pairavg = [&](const uint32_t *px, int p, int sh) -> int { return cavg(a.clamped, (px[2 * p] >> sh) & 0xFF, (px[2 * p + 1] >> sh) & 0xFF); };
+  uint32_t p0[4];
+  const int r0 = KIND == RK_888_TO_420 ? 2 * (int)y : (int)y;
+  load4(r0, p0);
+  const uint32_t y4 = (p0[0] & 0xFF) | ((p0[1] & 0xFF) << 8) | ((p0[2] & 0xFF) << 16) | ((p0[3] & 0xFF) << 24);
+  int u[2] = {pairavg(p0, 0, 8), pairavg(p0, 1, 8)}, v[2] = {pairavg(p0, 0, 16), pairavg(p0, 1, 16)};
+  if (KIND == RK_888_TO_420) {
+    uint32_t p1[4];
+    load4(r0 + 1, p1);
+    *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)r0 * a.width + 4 * (size_t)gx) = y4;
+    *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)(r0 + 1) * a.width + 4 * (size_t)gx) = (p1[0] & 0xFF) | ((p1[1] & 0xFF) << 8) | ((p1[2] & 0xFF) << 16) | ((p1[3] & 0xFF) << 24);
+#pragma unroll
+    for (int p = 0; p < 2; p++) { u[p] = cavg(a.clamped, u[p], pairavg(p1, p, 8)); v[p] = cavg(a.clamped, v[p], pairavg(p1, p, 16)); }
+    *reinterpret_cast<uint16_t *>(a.dst[1] + (size_t)y * hw + 2 * (size_t)gx) = (uint16_t)(u[0] | (u[1] << 8));
+    *reinterpret_cast<uint16_t *>(a.dst[2] + (size_t)y * hw + 2 * (size_t)gx) = (uint16_t)(v[0] | (v[1] << 8));
+  } else if (a.out_alpha) {                                  // planar 4:2:2 (compact)
+    *reinterpret_cast<uint32_t *>(a.dst[0] + (size_t)y * a.width + 4 * (size_t)gx) = y4;
+    *reinterpret_cast<uint16_t *>(a.dst[1] + (size_t)y * hw + 2 * (size_t)gx) = (uint16_t)(u[0] | (u[1] << 8));
+    *reinterpret_cast<uint16_t *>(a.dst[2] + (size_t)y * hw + 2 * (size_t)gx) = (uint16_t)(v[0] | (v[1] << 8));
+  } else {                                                   // UYVY / YUYV (compact)
+    uint2 o;
+    const uint32_t ya = y4 & 0xFF, yb = (y4 >> 8) & 0xFF, yc = (y4 >> 16) & 0xFF, yd = y4 >> 24;
+    if (a.yuyv_out) { o.x = ya | ((uint32_t)u[0] << 8) | (yb << 16) | ((uint32_t)v[0] << 24); o.y = yc | ((uint32_t)u[1] << 8) | (yd << 16) | ((uint32_t)v[1] << 24); }
+    else { o.x = (uint32_t)u[0] | (ya << 8) | ((uint32_t)v[0] << 16) | (yb << 24); o.y = (uint32_t)u[1] | (yc << 8) | ((uint32_t)v[1] << 16) | (yd << 24); }
+    *reinterpret_cast<uint2 *>(a.dst[0] + (size_t)y * a.width * 2 + 8 * (size_t)gx) = o;
+  }
+}
+__global__ __launch_bounds__(512) void k_420_to_422p_s(RepackArgs a, uint32_t gmagic) {
+  cavg_init();
+  const int ngr = a.width >> 3;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t y = __umulhi(idx, gmagic);
+  uint32_t gx = idx - y * (uint32_t)ngr;
+  if (gx >= (uint32_t)ngr) { gx -= ngr; y++; }
+  if (y >= (uint32_t)a.height) return;
+  *reinterpret_cast<uint2 *>(a.dst[0] + (size_t)y * a.orow[0] + 8 * (size_t)gx) = *reinterpret_cast<const uint2 *>(a.src[0] + (size_t)y * a.irow[0] + 8 * (size_t)gx);
+  const int ch2 = (a.height >> 1) * 2;
+  if ((int)y >= ch2) return;
+#pragma unroll
+  for (int p = 1; p < 3; p++) {
+    uint32_t c4 = *reinterpret_cast<const uint32_t *>(a.src[p] + (size_t)(y >> 1) * a.irow[p] + 4 * (size_t)gx);
+    if ((y & 1) && (int)y + 1 < ch2) {
+      const uint32_t n4 = *reinterpret_cast<const uint32_t *>(a.src[p] + (size_t)((y + 1) >> 1) * a.irow[p] + 4 * (size_t)gx);
+      uint32_t o = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) o |= (uint32_t)cavg(a.clamped, (c4 >> (8 * k)) & 0xFF, (n4 >> (8 * k)) & 0xFF) << (8 * k);
+      c4 = o;
+    }
+    *reinterpret_cast<uint32_t *>(a.dst[p] + (size_t)y * a.orow[p] + 4 * (size_t)gx) = c4;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_yuv_repack(RepackArgs a) {
   // the chroma-average table costs a workgroup a round of LDS writes and a barrier: only the kinds that average build it (kernel-uniform)
   if (a.kind > RK_420_TO_PK) cavg_init();              // RK_COMBINE .. RK_420_TO_PK are permutations
@@ -1907,6 +1983,30 @@ extern "C" int lgpu_yuv_repack(int in_pal, int out_pal, const uint8_t *const src
       LGPU_CHECK_LAUNCH();
       return LGPU_OK;
     }
+  }
+  if ((a.kind == lgpu::RK_888_TO_420 || a.kind == lgpu::RK_888_TO_422) && !no_s && (width & 3) == 0 && (((uintptr_t)src_d[0] | (uintptr_t)irow[0]) & (a.in_alpha ? 15 : 3)) == 0 &&
+      (unsigned long long)(width >> 2) * height < (1ull << 31)) {
+    // (the destinations of these kinds are compact: checked above)
+    const bool planar = a.kind == lgpu::RK_888_TO_420 || a.out_alpha;
+    const bool ok = planar ? ((((uintptr_t)dst_d[0]) & 3) == 0 && (((uintptr_t)dst_d[1] | (uintptr_t)dst_d[2]) & 1) == 0) : ((((uintptr_t)dst_d[0]) & 7) == 0);
+    if (ok) {
+      const int ngr = width >> 2, rows_ = a.kind == lgpu::RK_888_TO_420 ? height >> 1 : height;
+      const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+      const dim3 gs((unsigned)(((unsigned long long)ngr * rows_ + 511) / 512));
+      if (a.kind == lgpu::RK_888_TO_420) hipLaunchKernelGGL(lgpu::k_888_to_s<lgpu::RK_888_TO_420>, gs, dim3(512), 0, st, a, magic);
+      else hipLaunchKernelGGL(lgpu::k_888_to_s<lgpu::RK_888_TO_422>, gs, dim3(512), 0, st, a, magic);
+      LGPU_CHECK_LAUNCH();
+      return LGPU_OK;
+    }
+  }
+  if (a.kind == lgpu::RK_420_TO_422P && !no_s && (width & 7) == 0 && (unsigned long long)(width >> 3) * height < (1ull << 31) &&
+      (((uintptr_t)src_d[0] | (uintptr_t)irow[0] | (uintptr_t)dst_d[0] | (uintptr_t)orow[0]) & 7) == 0 &&
+      (((uintptr_t)src_d[1] | (uintptr_t)src_d[2] | (uintptr_t)irow[1] | (uintptr_t)irow[2] | (uintptr_t)dst_d[1] | (uintptr_t)dst_d[2] | (uintptr_t)orow[1] | (uintptr_t)orow[2]) & 3) == 0) {
+    const int ngr = width >> 3;
+    const uint32_t magic = (uint32_t)((1ull << 32) / (unsigned)ngr - (ngr == 1 ? 1 : 0));
+    hipLaunchKernelGGL(lgpu::k_420_to_422p_s, dim3((unsigned)(((unsigned long long)ngr * height + 511) / 512)), dim3(512), 0, st, a, magic);
+    LGPU_CHECK_LAUNCH();
+    return LGPU_OK;
   }
   const int rows = (a.kind == lgpu::RK_444_TO_420 || a.kind == lgpu::RK_PK_TO_420 || a.kind == lgpu::RK_888_TO_420) ? (height + 1) >> 1 : height;
   const int span = a.copy_w > width ? a.copy_w : width;

@@ -26,7 +26,7 @@ for r in 1920x1080:1280x720 1280x720:1920x1080 3840x2160:1706x960 1280x720:3840x
 echo "== single-frame entry points (1080p; a plain copy of one 1080p frame is copy4: what one launch of this size can reach)"
 python tools/bench_one.py --cold copy1 copy4 2>/dev/null
 for c in s:lb s:gauss5 s:resize s:deint s:tsplit s:dissolve s:slide s:transition s:chroma s:luma s:multi s:colorkey premult_yuva s:clamp s:r2y411 s:r2y444p s:y444p2rgb softlight yuv411 composite \
-         s:repack:512:564 s:repack:522:564 s:repack:564:512 s:repack:512:588 s:repack:512:522 s:repack:564:565 s:repack:564:588 s:repack:588:564 s:repack:544:588 s:repack:588:544 s:repack:595:512 s:repack:595:522; do
+         s:repack:512:564 s:repack:522:564 s:repack:564:512 s:repack:512:588 s:repack:512:522 s:repack:564:565 s:repack:564:588 s:repack:588:564 s:repack:588:512 s:repack:588:522 s:repack:564:544 s:repack:544:588 s:repack:588:544 s:repack:595:512 s:repack:595:522; do
   python tools/bench_one.py --cold $c 2>&1 | tail -1
 done
 echo '```'
