@@ -19,3 +19,14 @@ def test_fuzz_ops_finds_no_mismatch(seed):
     assert out.returncode == 0 and m, text[-3000:]
     assert int(m.group(2)) == 0, text[-3000:]
     assert "MISMATCH" not in text
+
+
+@pytest.mark.gpu
+def test_chain_forms_on_random_geometry(gpu):
+    """tools/fuzz_chain.py: lgpu_chain_amounts at random sizes, ratios, canvases, with and without a layer 2 / a resize, against the oracle's stages (600 cases)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_chain
+    ran, tracks, bad = fuzz_chain.run(600, 77)
+    assert ran > 400 and tracks > 800 and bad == 0
