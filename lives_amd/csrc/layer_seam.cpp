@@ -672,7 +672,8 @@ int lazy_run_group(Lazy *const *zs, const void *const *hs, int n) {
     if (z0->rs != z0->w * 4) rc = rc ? rc : lgpu_fill(outs[(size_t)i].d, 0, bytes, S());      // the row padding of a fresh plane is zero (calloc in the eager path)
   }
   bool done = false;
-  if (!rc && n <= LGPU_CHAIN_MAX_TRACKS) {      // every shape: with or without a resize stage, with or without a blend (lgpu_chain_amounts)
+  // every shape: with or without a resize stage, with or without a blend (lgpu_chain_amounts); LGPU_SEAM_STAGED / lgpu_tuning_set("SEAM_STAGED", 1): the fallback walk, for tests
+  if (!rc && n <= LGPU_CHAIN_MAX_TRACKS && lgpu_tuning_get("SEAM_STAGED") <= 0) {
     lgpu_chain_params pr;
     memset(&pr, 0, sizeof pr);
     pr.sw = z0->sw; pr.sh = z0->sh; pr.irow = z0->srs; pr.dw = z0->scale ? z0->dw : z0->sw; pr.dh = z0->scale ? z0->dh : z0->sh; pr.irow2 = z0->l2rs; pr.orow = z0->rs;

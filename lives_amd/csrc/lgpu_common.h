@@ -83,7 +83,7 @@ enum Tune {
   TUNE_PBH_ALIGNED, TUNE_PBH_TH, TUNE_PB_NO_DOUBLE, TUNE_PB_NO_HALF3, TUNE_PB_NO_PAIRS, TUNE_PB_NO_GATHER, TUNE_PB_NO_UP, TUNE_PB_UP_RB,
   TUNE_GCK_TH, TUNE_CHAIN_SPARE_WGS, TUNE_SEP2_LDS_KB, TUNE_NO_SEP2P, TUNE_NO_SEP2P_MFMA, TUNE_PLAN_DEBUG,
   TUNE_SEP2P_FORCE, TUNE_PB_CACHE_MAX, TUNE_K2_WGS, TUNE_SOFT_NO_S, TUNE_SOFT_RB, TUNE_EDGE_NO_S, TUNE_EDGE_TH, TUNE_PBH_ORDER, TUNE_PBH_OCC, TUNE_PBH_GROUP, TUNE_G5_MFMA, TUNE_RGB2YUV_NO_S, TUNE_UYVY_NO_S, TUNE_REPACK_NO_S, TUNE_DISABLE_HALF8, TUNE_NO_SEP2, TUNE_SEP2P_TH, TUNE_G5_CLASSIC,
-  TUNE_GAUSS5_NO_ROWS, TUNE_PB_NO_PRE, TUNE_PB_LDS_KB, TUNE_PHASE_PROFILE, TUNE_PB_TILE_ORDER, TUNE_PB_CHAIN_GROUP, TUNE_COUNT
+  TUNE_GAUSS5_NO_ROWS, TUNE_PB_NO_PRE, TUNE_PB_LDS_KB, TUNE_PHASE_PROFILE, TUNE_PB_TILE_ORDER, TUNE_PB_CHAIN_GROUP, TUNE_SEAM_STAGED, TUNE_COUNT
 };
 int tune(Tune t);                                  // the value, or -1 when the switch is unset
 static inline bool tune_on(Tune t) { return tune(t) > 0; }

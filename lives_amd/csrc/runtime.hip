@@ -108,7 +108,7 @@ int device_cus() {
 static const char *const kTuneNames[TUNE_COUNT] = {
   "PBH_ALIGNED", "PBH_TH", "PB_NO_DOUBLE", "PB_NO_HALF3", "PB_NO_PAIRS", "PB_NO_GATHER", "PB_NO_UP", "PB_UP_RB",
   "GCK_TH", "CHAIN_SPARE_WGS", "SEP2_LDS_KB", "NO_SEP2P", "NO_SEP2P_MFMA", "PLAN_DEBUG",
-  "SEP2P_FORCE", "PB_CACHE_MAX", "K2_WGS", "SOFT_NO_S", "SOFT_RB", "EDGE_NO_S", "EDGE_TH", "PBH_ORDER", "PBH_OCC", "PBH_GROUP", "G5_MFMA", "RGB2YUV_NO_S", "UYVY_NO_S", "REPACK_NO_S", "DISABLE_HALF8", "NO_SEP2", "SEP2P_TH", "G5_CLASSIC", "GAUSS5_NO_ROWS", "PB_NO_PRE", "PB_LDS_KB", "PHASE_PROFILE", "PB_TILE_ORDER", "PB_CHAIN_GROUP"};
+  "SEP2P_FORCE", "PB_CACHE_MAX", "K2_WGS", "SOFT_NO_S", "SOFT_RB", "EDGE_NO_S", "EDGE_TH", "PBH_ORDER", "PBH_OCC", "PBH_GROUP", "G5_MFMA", "RGB2YUV_NO_S", "UYVY_NO_S", "REPACK_NO_S", "DISABLE_HALF8", "NO_SEP2", "SEP2P_TH", "G5_CLASSIC", "GAUSS5_NO_ROWS", "PB_NO_PRE", "PB_LDS_KB", "PHASE_PROFILE", "PB_TILE_ORDER", "PB_CHAIN_GROUP", "SEAM_STAGED"};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 static void tune_init() {

@@ -112,6 +112,29 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[s[-1] for s in SHAPES])
+def test_the_stage_by_stage_fallback_gives_the_same_bytes(seam, orc, deferred, tune, shape):
+    """the walk that runs a recorded program stage by stage (what is left for launches the one-launch forms decline: more than 64 tracks of a shape, planes of 2 GiB),
+    forced with SEAM_STAGED: the oracle's bytes for every shape"""
+    L, wh, H = seam
+    sw, sh, dw, dh, canvas, with_l2, gamma, _ = shape
+    rng = np.random.default_rng(0xDEFD + sw + dw)
+    ow, oh = canvas if canvas else (dw, dh)
+    src, l2a = frame(rng, sw, sh, 4, alpha_mix=True), frame(rng, ow, oh, 4, alpha_mix=True)
+    tune("SEAM_STAGED", 1)
+    lay = wh.new_layer(BGRA32, sw, sh, [src], gamma=1)
+    l2 = wh.new_layer(RGBA32, ow, oh, [l2a], gamma=1) if with_l2 else None
+    assert L.lives_gpu_layer_pin(lay) == 0 and (l2 is None or L.lives_gpu_layer_pin(l2) == 0)
+    s0 = dstats(L)
+    plan_step(L, wh, H, lay, l2, dw, dh, canvas, 90, gamma)
+    assert L.lives_gpu_layer_sync(lay) == 0
+    s1 = dstats(L)
+    assert (s1[1] - s0[1], s1[3] - s0[3]) == (0, 1), "no chain launch, one program walked"
+    want = oracle_step(orc, src, sw, sh, l2a if with_l2 else None, dw, dh, canvas, 90, srgb_to(orc, gamma) if gamma is not None else None, True)
+    assert (view(wh, lay)[:, :ow * 4] == want).all()
+    assert L.lives_gpu_layer_unpin(lay) == 0 and (l2 is None or L.lives_gpu_layer_unpin(l2) == 0)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[-1] for s in SHAPES])
 @pytest.mark.parametrize("src_pal", [BGRA32, RGBA32])
 def test_deferred_equals_eager_equals_oracle(seam, orc, deferred, shape, src_pal):
     L, wh, H = seam
