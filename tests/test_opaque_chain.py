@@ -189,3 +189,23 @@ def test_the_staged_groups_equal_the_one_launch_forms(gpu, tune, case):
     for g in range(1, len(res)):
         for i in range(n):
             assert (res[g][i] == res[0][i]).all(), "group setting %d, track %d" % (g, i)
+
+
+def test_bad_arguments_are_refused(gpu):
+    """lgpu_chain_amounts: no amounts with a layer 2, a polyphase request, the gaussian without a resize stage, dst == src -- LGPU_E_BADARG / UNSUPPORTED, nothing launched"""
+    from lives_amd.lib import LgpuError
+    a, b, o = dev(np.zeros((72, 128 * 4), np.uint8)), dev(np.zeros((72, 128 * 4), np.uint8)), dev(np.zeros((72, 128 * 4), np.uint8))
+    big = dev(np.zeros((144, 256 * 4), np.uint8))
+    ok = gpu.chain_params(256, 144, 256 * 4, 128, 72, 128 * 4, 128 * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=9, lut=None)
+    with pytest.raises(LgpuError):
+        gpu.chain_amounts(ok, gpu.chain_tracks([big], [b], [o]), None)                       # a layer 2 but no amounts
+    poly = gpu.chain_params(256, 144, 256 * 4, 128, 72, 128 * 4, 128 * 4, swap_rb=1, interp=3, do_blur=0, bf=9, lut=None)
+    with pytest.raises(LgpuError):
+        gpu.chain_amounts(poly, gpu.chain_tracks([big], [b], [o]), [9])
+    flat_blur = gpu.chain_params(128, 72, 128 * 4, 128, 72, 128 * 4, 128 * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=1, bf=9, lut=None)
+    with pytest.raises(LgpuError):
+        gpu.chain_amounts(flat_blur, gpu.chain_tracks([a], [b], [o]), [9])
+    flat = gpu.chain_params(128, 72, 128 * 4, 128, 72, 128 * 4, 128 * 4, swap_rb=1, interp=3 | PIXBUF, do_blur=0, bf=9, lut=None)
+    with pytest.raises(LgpuError):
+        gpu.chain_amounts(flat, gpu.chain_tracks([a], [b], [a]), [9])                         # in place
+    gpu.chain_amounts(flat, gpu.chain_tracks([a], [b], [o]), [9])                             # ... and the same call with a destination of its own is fine
