@@ -858,6 +858,7 @@ __global__ __launch_bounds__(kBlock) void k_dissolve(const uint8_t *src1, int ir
     if (!two && inplace) continue;
     const uint8_t *s = two ? src2 + (size_t)i * irow2 + (size_t)x * PS : src1 + (size_t)i * irow1 + (size_t)x * PS;
     uint8_t *d = dst + (size_t)i * orow + (size_t)x * PS;
+    if (PS == 4 && (((uintptr_t)s | (uintptr_t)d) & 3) == 0) { *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(s); continue; }      // a 4-byte pixel: one load, one store
 #pragma unroll
     for (int k = 0; k < PS; k++) d[k] = s[k];
   }
