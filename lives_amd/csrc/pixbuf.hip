@@ -1243,7 +1243,8 @@ struct PbGatherArgs {
 typedef pb_u4 pb_u4a __attribute__((aligned(4)));
 typedef pb_u2 pb_u2a __attribute__((aligned(4)));
 
-template <int NP, typename EA = PbNoEpi>
+// OPQ (LGPU_INTERP_OPAQUE): the taps go in as byte pairs (one v_perm per pair and channel instead of two SDWA products), no alpha sums, T >> 16 (k_pb_pairs<.., OPQ>)
+template <int NP, typename EA = PbNoEpi, int OPQ = 0>
 __global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A_, const uint32_t *__restrict__ gp, const PbFrames F, const EA E) {
   PB_FRAME_ARGS(PbGatherArgs);
   __shared__ uint8_t s_lut[pb_has_epi<EA>::value ? 256 : 4];
@@ -1287,12 +1288,16 @@ __global__ __launch_bounds__(256) void k_pb_gather(const PbGatherArgs A_, const 
 #pragma unroll
     for (int k = 0; k < NP; k++) {
       const uint32_t q0 = cur.q[2 * k], q1 = cur.q[2 * k + 1], w = cur.w[k];
+      if (OPQ) {
+        r = pb_dot2(__builtin_amdgcn_perm(q1, q0, 0x0C040C00u), w, r); g = pb_dot2(__builtin_amdgcn_perm(q1, q0, 0x0C050C01u), w, g); b = pb_dot2(__builtin_amdgcn_perm(q1, q0, 0x0C060C02u), w, b);
+        continue;
+      }
       r = pb_dot2(pb_premul_pair<0>(q0, q1), w, r); g = pb_dot2(pb_premul_pair<1>(q0, q1), w, g); b = pb_dot2(pb_premul_pair<2>(q0, q1), w, b);
       a = pb_dot2(__builtin_amdgcn_perm(q1, q0, 0x0C070C03u), w, a);
     }
     cur = nxt;
   }
-  if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_epi_px(E, s_lut, pb_finish_px<4>(r, g, b, a, false, 0u), i, j);
+  if (live) reinterpret_cast<uint32_t *>(A.dst + (size_t)i * A.orow)[j] = pb_epi_px(E, s_lut, OPQ ? ((r >> 16) | ((g >> 16) << 8) | ((b >> 16) << 16) | 0xFF000000u) : pb_finish_px<4>(r, g, b, a, false, 0u), i, j);
 }
 
 // =====================================================================================================================================================
@@ -2122,7 +2127,9 @@ static int pb_scale_n(const uint8_t *const *srcs, uint8_t *const *dsts, int n, i
     ga.x_step = x_step; ga.y_step = y_step; ga.xoff = t->xoff; ga.yoff = t->yoff; ga.tx0 = t->tx0; ga.ty0 = t->ty0; ga.ny_eff = t->ty1 - t->ty0;
     const int gnp = (t->tx1 - t->tx0 + 1) / 2;
     const uint32_t *gp = t->gpairs_d;
-#define PB_GATHER(NP_) { if (epi) hipLaunchKernelGGL((k_pb_gather<NP_, PbEpi>), grid, block, 0, st, ga, gp, F, *epi); else hipLaunchKernelGGL((k_pb_gather<NP_, PbNoEpi>), grid, block, 0, st, ga, gp, F, PbNoEpi{}); }
+    if (opaque && (rc = pb_opaque_check())) return rc;
+#define PB_GATHER(NP_) { if (epi) { if (opaque) hipLaunchKernelGGL((k_pb_gather<NP_, PbEpi, 1>), grid, block, 0, st, ga, gp, F, *epi); else hipLaunchKernelGGL((k_pb_gather<NP_, PbEpi, 0>), grid, block, 0, st, ga, gp, F, *epi); } \
+                         else if (opaque) hipLaunchKernelGGL((k_pb_gather<NP_, PbNoEpi, 1>), grid, block, 0, st, ga, gp, F, PbNoEpi{}); else hipLaunchKernelGGL((k_pb_gather<NP_, PbNoEpi, 0>), grid, block, 0, st, ga, gp, F, PbNoEpi{}); }
     if (gnp == 1) PB_GATHER(1) else if (gnp == 2) PB_GATHER(2) else if (gnp == 3) PB_GATHER(3) else PB_GATHER(4)
 #undef PB_GATHER
     LGPU_CHECK_LAUNCH();

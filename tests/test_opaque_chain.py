@@ -61,7 +61,7 @@ def test_the_flag_changes_nothing_where_there_is_no_lighter_form(gpu):
 
 
 @pytest.mark.parametrize("interp", [3, 2])
-@pytest.mark.parametrize("geom", [(384, 216, 171, 96), (200, 120, 133, 80), (128, 72, 200, 112), (96, 54, 320, 180), (1920, 1080, 1280, 720), (300, 200, 100, 50), (131, 77, 64, 36)])
+@pytest.mark.parametrize("geom", [(384, 216, 171, 96), (200, 120, 133, 80), (128, 72, 200, 112), (96, 54, 320, 180), (1920, 1080, 1280, 720), (300, 200, 100, 50), (384, 216, 128, 72), (131, 77, 64, 36)])
 def test_opaque_scaler_equals_the_general_kernels_and_the_oracle(gpu, orc, geom, interp):
     """lgpu_pixbuf_scale[_batch] with interp | LGPU_INTERP_OPAQUE on frames whose alpha is 255 everywhere: the pair kernel's lighter form (and, where another kernel
     serves the ratio, the flag ignored) -- the bytes of the general path and of the oracle's gdk-pixbuf restatement, alpha 255 out"""
