@@ -144,6 +144,10 @@ int lives_gpu_layer_pin_device(lives_gpu_layer_t *layer, const void *const *plan
    palette, size, rowstrides; host planes of its own) becomes a pinned layer whose device planes are device-to-device copies of slayer's -- a pending program of slayer
    runs first, nothing crosses PCIe.  slayer not pinned: LGPU_OK, nothing done.  (A shallow copy shares the host planes and with them the device copies.) */
 int lives_gpu_layer_copy(lives_gpu_layer_t *dlayer, lives_gpu_layer_t *slayer);
+/* The host's word that every pixel of the layer's frame has alpha 255 (decoded video; a frame that was RGB24 or YUV before it became RGBA32): resize_layer[_full] /
+   letterbox_layer on it -- recorded or eager -- then run the scalers' all-opaque instantiations (LGPU_INTERP_OPAQUE: the same bytes on such a frame, enlargements
+   25-30 % faster).  The word stays on the layer (private leaf "host_gpu_opaque") until the host takes it back (on = 0); a frame that is not opaque gets wrong colours. */
+int lives_gpu_layer_set_opaque(lives_gpu_layer_t *layer, int on);
 /* ---- deferred execution on pinned layers (on by default).  The host bytes of a pinned layer are stale until lives_gpu_layer_sync(), so the seam calls of one
    track's plan step on an RGBA32 / BGRA32 frame -- convert_layer_palette (R <-> B), resize_layer[_full] (gdk-pixbuf body), letterbox_layer, livesgpu_fx.so's
    "chroma blend" in place, gamma_convert_layer -- are RECORDED on the plane (every leaf changes as in the eager call) and run as ONE launch of the fused chain

@@ -38,6 +38,7 @@ lives_gpu_prefs g_prefs = {1, 0, 2, 1.4, 0};
 
 constexpr const char *kLeafHostFlags = "host_flags";          // LIVES_LEAF_HOST_FLAGS (src/colourspace.h:37)
 constexpr const char *kLeafContiguous = "host_contiguous";    // LIVES_LEAF_PIXEL_DATA_CONTIGUOUS (:33)
+constexpr const char *kLeafOpaque = "host_gpu_opaque";        // the host's word that every pixel of the layer's frame has alpha 255 (lives_gpu_layer_set_opaque)
 constexpr const char *kLeafResident = "host_gpu_resident";    // this library's private leaf (host_* convention, src/effects-weed.h:80-119)
 
 bool bound() { return g_api.leaf_get && g_api.leaf_set && g_api.leaf_num_elements && g_api.leaf_delete; }
@@ -591,7 +592,7 @@ struct Lazy {
   int sw = 0, sh = 0, srs = 0;
   int stage = LZ_NONE;              // the last stage recorded
   bool swap = false;
-  bool scale = false; int dw = 0, dh = 0, interp = 0;
+  bool scale = false; int dw = 0, dh = 0, interp = 0; bool opaque = false;     // opaque: the layer carried the host's word when the scale was recorded
   bool canvas = false; int nw = 0, nh = 0, ox = 0, oy = 0;
   bool blend = false; int bf = 0; const void *l2h = nullptr; Dev l2; int l2rs = 0;
   bool lut = false; uint8_t lut8[256];
@@ -619,7 +620,7 @@ void lazy_discard(Lazy *z) {
 }
 bool lazy_same_shape(const Lazy *a, const Lazy *b) {
   return a->sw == b->sw && a->sh == b->sh && a->srs == b->srs && a->swap == b->swap && a->scale == b->scale && a->dw == b->dw && a->dh == b->dh &&
-         a->interp == b->interp && a->canvas == b->canvas && a->nw == b->nw && a->nh == b->nh && a->ox == b->ox && a->oy == b->oy && a->blend == b->blend &&
+         a->interp == b->interp && a->opaque == b->opaque && a->canvas == b->canvas && a->nw == b->nw && a->nh == b->nh && a->ox == b->ox && a->oy == b->oy && a->blend == b->blend &&
          a->l2rs == b->l2rs &&          /* (not the blend amount: every track of a launch has its own, lgpu_chain_amounts) */ a->lut == b->lut && (!a->lut || !memcmp(a->lut8, b->lut8, 256)) && a->w == b->w && a->h == b->h && a->rs == b->rs;
 }
 // one program, stage by stage through stream-ordered scratch frames, into out (the plane's rowstride)
@@ -644,7 +645,7 @@ int lazy_run_staged(const Lazy *z, uint8_t *out) {
     cur = dst; crs = drs;
   }
   if (!rc && z->scale) {
-    if (!(rc = target(LZ_SCALE, z->dw, z->dh, &dst, &drs))) rc = lgpu_pixbuf_scale(cur, crs, cw, ch, dst, drs, z->dw, z->dh, 4, z->interp, S());
+    if (!(rc = target(LZ_SCALE, z->dw, z->dh, &dst, &drs))) rc = lgpu_pixbuf_scale(cur, crs, cw, ch, dst, drs, z->dw, z->dh, 4, z->interp | (z->opaque ? LGPU_INTERP_OPAQUE : 0), S());
     cur = dst; crs = drs; cw = z->dw; ch = z->dh;
   }
   if (!rc && z->canvas) {
@@ -677,7 +678,7 @@ int lazy_run_group(Lazy *const *zs, const void *const *hs, int n) {
     lgpu_chain_params pr;
     memset(&pr, 0, sizeof pr);
     pr.sw = z0->sw; pr.sh = z0->sh; pr.irow = z0->srs; pr.dw = z0->scale ? z0->dw : z0->sw; pr.dh = z0->scale ? z0->dh : z0->sh; pr.irow2 = z0->l2rs; pr.orow = z0->rs;
-    pr.swap_rb = z0->swap ? 1 : 0; pr.interp = (z0->scale ? z0->interp : 0) | LGPU_INTERP_PIXBUF | (z0->blend ? 0 : LGPU_INTERP_NOBLEND); pr.do_blur = 0; pr.bf = z0->bf; pr.use_lut = z0->lut ? 1 : 0;
+    pr.swap_rb = z0->swap ? 1 : 0; pr.interp = (z0->scale ? z0->interp : 0) | LGPU_INTERP_PIXBUF | (z0->blend ? 0 : LGPU_INTERP_NOBLEND) | (z0->scale && z0->opaque ? LGPU_INTERP_OPAQUE : 0); pr.do_blur = 0; pr.bf = z0->bf; pr.use_lut = z0->lut ? 1 : 0;
     if (!z0->blend) pr.irow2 = z0->rs;
     if (z0->lut) memcpy(pr.lut8, z0->lut8, 256);
     std::vector<lgpu_chain_track> tr((size_t)n);
@@ -1574,8 +1575,8 @@ static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int in
     if (Lazy *z = lazy_detach(l, LZ_SCALE)) {
       if (scale_is_served(l.width, l.height, width, height, interp)) {
         const int prev = z->stage;
-        z->scale = true; z->dw = width; z->dh = height; z->interp = interp; z->stage = LZ_SCALE;
-        if (!lazy_commit(layer, l, z, l.pal, width, height, 4)) { z->scale = false; z->stage = prev; lazy_reattach(l.pd[0], z); return 0; }
+        z->scale = true; z->dw = width; z->dh = height; z->interp = interp; z->stage = LZ_SCALE; z->opaque = has_leaf(layer, kLeafOpaque);
+        if (!lazy_commit(layer, l, z, l.pal, width, height, 4)) { z->scale = false; z->opaque = false; z->stage = prev; lazy_reattach(l.pd[0], z); return 0; }
         if (l.gamma != WEED_GAMMA_SRGB) set_int(layer, WEED_LEAF_GAMMA_TYPE, WEED_GAMMA_SRGB);
         return 1;
       }
@@ -1587,7 +1588,7 @@ static int resize_pixbuf_body(weed_plant_t *layer, int width, int height, int in
   Work w;
   const uint8_t *d_in = w.in(l.pd[0], (size_t)l.rs[0] * l.height, 0);
   uint8_t *d_out = w.out(np.pd[0], (size_t)np.rs[0] * height, 3, np.rs[0] != width * ch);
-  const int rc = w.ok ? lgpu_pixbuf_scale(d_in, l.rs[0], l.width, l.height, d_out, np.rs[0], width, height, ch, interp, S()) : LGPU_E_HIP;
+  const int rc = w.ok ? lgpu_pixbuf_scale(d_in, l.rs[0], l.width, l.height, d_out, np.rs[0], width, height, ch, interp | ((ch == 4 && has_leaf(layer, kLeafOpaque)) ? LGPU_INTERP_OPAQUE : 0), S()) : LGPU_E_HIP;
   if (rc != LGPU_OK || !w.finish()) {
     drop_new_planes(np);
     return rc == LGPU_E_UNSUPPORTED ? decline(layer) : 0;      // reductions past the library's one-step range: the host's own body takes them
@@ -1935,6 +1936,16 @@ int lives_gpu_layer_copy(lives_gpu_layer_t *dlayer, lives_gpu_layer_t *slayer) {
     res_put(d.pd[p], b);
   }
   set_int(dlayer, kLeafResident, 1);
+  return LGPU_OK;
+}
+// The host's word that every pixel of the layer's frame has alpha 255 (decoded video, a frame that was RGB24 / YUV before): the scalers then run their all-opaque
+// instantiations (LGPU_INTERP_OPAQUE: same bytes on such frames, 25-30 % less time for enlargements).  The word is the host's to keep true: it stays on the layer
+// through the seam's own calls (a scale, letterbox, R <-> B, gamma or chroma blend of an opaque frame is opaque) until the host takes it back (on = 0) or hands
+// the layer a new frame.  A frame that is not opaque gets wrong colours.
+int lives_gpu_layer_set_opaque(lives_gpu_layer_t *layer, int on) {
+  if (!layer || !bound()) return LGPU_E_BADARG;
+  if (on) set_int(layer, kLeafOpaque, 1);
+  else if (has_leaf(layer, kLeafOpaque)) g_api.leaf_delete(layer, kLeafOpaque);
   return LGPU_OK;
 }
 // deferred execution (see "deferred execution on pinned layers" above): on (default) / off; returns the previous setting

@@ -387,3 +387,30 @@ def test_a_deep_copy_of_a_pinned_layer_gets_the_pixels_on_the_device(seam, orc, 
     c = wh.new_layer(RGBA32, 32, 32, [frame(rng, 32, 32, 4)], gamma=1)
     assert L.lives_gpu_layer_copy(c, a) != 0
     assert L.lives_gpu_layer_unpin(a) == 0
+
+
+@pytest.mark.parametrize("geom", [(128, 72, 200, 112, None), (128, 72, 200, 112, (220, 120)), (300, 170, 200, 112, None), (256, 144, 128, 72, None)])
+@pytest.mark.parametrize("mode", [1, 0], ids=["deferred", "eager"])
+def test_the_hosts_word_that_a_frame_is_opaque(seam, orc, deferred, geom, mode):
+    """lives_gpu_layer_set_opaque(layer, 1) on a frame whose alpha is 255 everywhere: the scalers' all-opaque instantiations run (enlargement, pair kernel; the 2:1
+    chain has none) -- the bytes are the oracle's, the word stays on the layer through the step and goes when the host takes it back"""
+    L, wh, H = seam
+    sw, sh, dw, dh, canvas = geom
+    rng = np.random.default_rng(0xDEFE + sw + dw)
+    ow, oh = canvas if canvas else (dw, dh)
+    src = frame(rng, sw, sh, 4)
+    src[:, 3::4] = 255
+    l2a = frame(rng, ow, oh, 4, alpha_mix=True)
+    L.lives_gpu_set_deferred(mode)
+    lay = wh.new_layer(BGRA32, sw, sh, [src], gamma=1)
+    l2 = wh.new_layer(RGBA32, ow, oh, [l2a], gamma=1)
+    assert L.lives_gpu_layer_pin(lay) == 0 and L.lives_gpu_layer_pin(l2) == 0
+    assert L.lives_gpu_layer_set_opaque(lay, 1) == 0 and wh.geti(lay, "host_gpu_opaque") == 1
+    plan_step(L, wh, H, lay, l2, dw, dh, canvas, 77, 2)
+    assert L.lives_gpu_layer_sync(lay) == 0
+    want = oracle_step(orc, src, sw, sh, l2a, dw, dh, canvas, 77, srgb_to(orc, 2), True)
+    assert (view(wh, lay)[:, :ow * 4] == want).all()
+    assert wh.geti(lay, "host_gpu_opaque") == 1
+    assert L.lives_gpu_layer_set_opaque(lay, 0) == 0 and wh.geti(lay, "host_gpu_opaque") is None
+    assert L.lives_gpu_layer_unpin(lay) == 0 and L.lives_gpu_layer_unpin(l2) == 0
+    L.lives_gpu_set_deferred(1)

@@ -60,7 +60,7 @@ def bind(L):
                        ("lives_gpu_transfer_stats", [vp, vp]), ("lives_gpu_convert_layer_palette_with_sampling", [vp, ci, ci]),
                        ("lives_gpu_gamma_convert_layer_variant", [ctypes.c_double, ci, vp]), ("lives_gpu_resize_layer_full", [vp, ci, ci, ci, ci, ci, ci, ci, ci]),
                        ("lives_gpu_unletterbox_layer", [vp, ci, ci, ci, ci, ci, ci]), ("lives_gpu_compact_rowstrides", [vp]),
-                       ("lives_gpu_weed_layer_clear_pixel_data", [vp]), ("lives_gpu_layer_copy", [vp, vp])):
+                       ("lives_gpu_weed_layer_clear_pixel_data", [vp]), ("lives_gpu_layer_copy", [vp, vp]), ("lives_gpu_layer_set_opaque", [vp, ci])):
         getattr(L, name).argtypes = args
     L.lives_gpu_calc_rowstrides.argtypes = [ci, ci, vp, vp]
     L.lives_gpu_calc_rowstrides.restype = ctypes.POINTER(ci)
